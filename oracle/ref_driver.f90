@@ -1,0 +1,414 @@
+! TEST INFRASTRUCTURE (oracle/_ref build only) -- not part of the product.
+!
+! Driver around the reference's UNMODIFIED hot-path Fortran (compiled from
+! /root/reference/src where it lies; see oracle/Makefile).  It reproduces the call
+! order of src/program.f90:63-222 restricted to the dynamical core:
+!
+!     tstep_update -> advection -> subgrid -> forces -> poisson ->
+!     tstep_integrate -> halos -> boundary
+!
+! (the IBM / NetCDF / statistics modules cannot be built here and are outside the
+! hot path, SURVEY.md section 8).  Set-up mirrors src/modstartup.f90:
+!   readnamelists (:105-172, subset of groups/variables, same names),
+!   init2decomp (:652-691), cold start of readinitfiles (:1088-1290),
+!   lscale.inp reading (:2051-2092), randomize_field (:2367-2396).
+! None of that set-up code is on the measured/validated path: it only builds the
+! inputs, which are dumped so that the device library starts from identical data.
+!
+! Modes (argv[2]):
+!   run      : nsub substeps, dump state after the substeps listed in dump_at
+!   kernels  : spin-up nspin substeps, then call each reference routine separately
+!              and dump inputs/outputs (per-kernel golden vectors)
+!   time     : nsub substeps timed with MPI_Wtime exactly like src/modmpi.f90:140-160
+program ref_driver
+  use mpi
+  use decomp_2d
+  use modmpi
+  use modglobal
+  use modfields
+  use modsubgriddata
+  use modsurfdata, only: thl_top, wttop, wsvtop, sv_top, thvs, thls
+  use modboundary, only: initboundary, boundary, halos
+  use modthermodynamics, only: initthermodynamics
+  use modsubgrid, only: initsubgrid, subgrid
+  use modpois, only: initpois, poisson, p
+  use modadvection, only: advection
+  use modtstep, only: tstep_update, tstep_integrate
+  use modforces, only: forces
+  implicit none
+
+  character(256) :: mode, outfile, arg
+  integer :: nsub = 3, nspin = 2
+  integer :: dump_at(16) = -1
+  logical :: lforces = .true.
+  integer :: isub, n, ierr, iu
+  real :: t0, t1
+  real :: scal_a = 1.0, scal_b = 0.0     ! scalar init: sv = scal_b + scal_a*z/zsize
+  ! src/modstartup.f90:42-44 (module variables of modstartup, which cannot be built here)
+  integer(KIND=selected_int_kind(6)) :: irandom = 43
+  integer :: krand = huge(0)
+  real :: randu = 0.01
+  namelist /ORACLE/ nsub, nspin, dump_at, lforces, scal_a, scal_b
+
+  call initmpi
+  if (command_argument_count() < 3) then
+    write (0, *) 'usage: udales_ref namoptions.NNN {run|kernels|time} out.bin'
+    stop 1
+  end if
+  call get_command_argument(1, fname_options)
+  call get_command_argument(2, mode)
+  call get_command_argument(3, outfile)
+
+  call read_namelists_subset
+  open (ifnamopt, file=fname_options, status='old')
+  read (ifnamopt, ORACLE, iostat=ierr)
+  close (ifnamopt)
+
+  call init_decomp_np1
+  call initglobal
+  call initfields
+  call initboundary
+  call initthermodynamics
+  call initsubgrid
+  call initpois
+  call cold_start
+  call boundary
+
+  iu = 71
+  if (trim(mode) /= 'time') then
+    open (iu, file=trim(outfile), access='stream', form='unformatted', status='replace')
+    call dump_meta
+  end if
+
+  select case (trim(mode))
+  case ('run')
+    call dump_state('s000')
+    do isub = 1, nsub
+      call one_substep
+      if (any(dump_at == isub)) call dump_state(tag4(isub))
+    end do
+  case ('kernels')
+    do isub = 1, nspin
+      call one_substep
+    end do
+    call kernel_vectors
+  case ('time')
+    t0 = MPI_Wtime()
+    do isub = 1, nsub
+      call one_substep
+    end do
+    t1 = MPI_Wtime()
+    write (6, '(a,i0,a,i0,a,i0,a,i0,a,es14.6,a,es14.6)') 'REF_TIMING cells=', itot*jtot*ktot, &
+      ' itot=', itot, ' jtot=', jtot, ' substeps=', nsub, ' seconds=', t1 - t0, &
+      ' cell_updates_per_s=', real(itot)*real(jtot)*real(ktot)*real(nsub)/(t1 - t0)
+  case default
+    write (0, *) 'unknown mode ', trim(mode)
+    stop 1
+  end select
+  if (trim(mode) /= 'time') close (iu)
+
+contains
+
+  character(4) function tag4(i)
+    integer, intent(in) :: i
+    write (tag4, '(a1,i3.3)') 's', i
+  end function tag4
+
+  ! ---- src/program.f90:132-222 restricted to the dynamical core
+  subroutine one_substep
+    call tstep_update
+    call advection
+    call subgrid
+    if (lforces) call forces
+    call poisson
+    call tstep_integrate
+    call halos
+    call boundary
+  end subroutine one_substep
+
+  ! ---- subset of src/modstartup.f90:105-172 (same group and variable names)
+  subroutine read_namelists_subset
+    use modfields, only: dpdx
+    integer :: ierr
+    namelist /RUN/ iexpnr, runtime, dtmax, trestart, ladaptive, irandom, randu, krand, courant, diffnr, &
+      libm, lles, lrandomize, nprocx, nprocy
+    namelist /DOMAIN/ itot, jtot, ktot, xlen, ylen
+    namelist /PHYSICS/ lmoist, lcoriol, lbuoyancy, ltempeq, lprofforc, dpdx
+    namelist /DYNAMICS/ ipoiss, iadv_mom, iadv_tke, iadv_thl, iadv_qt, iadv_sv
+    namelist /BC/ BCxm, BCym, BCtopm, BCtopT, BCtops, BCbotm, BCzp, wttop, thl_top
+    namelist /SCALARS/ nsv
+    open (ifnamopt, file=fname_options, status='old', iostat=ierr)
+    if (ierr /= 0) then
+      write (0, *) 'ERROR: cannot open ', trim(fname_options)
+      stop 1
+    end if
+    read (ifnamopt, RUN, iostat=ierr); call chk(ierr, 'RUN'); rewind (ifnamopt)
+    read (ifnamopt, DOMAIN, iostat=ierr); call chk(ierr, 'DOMAIN'); rewind (ifnamopt)
+    read (ifnamopt, PHYSICS, iostat=ierr); call chk(ierr, 'PHYSICS'); rewind (ifnamopt)
+    read (ifnamopt, DYNAMICS, iostat=ierr); call chk(ierr, 'DYNAMICS'); rewind (ifnamopt)
+    read (ifnamopt, BC, iostat=ierr); call chk(ierr, 'BC'); rewind (ifnamopt)
+    read (ifnamopt, SCALARS, iostat=ierr); call chk(ierr, 'SCALARS')
+    close (ifnamopt)
+    nprocx = 1; nprocy = 1          ! the oracle build is single-rank whatever the deck says
+    libm = .false.
+    allocate (wsvtop(1:max(nsv, 1))); wsvtop = 0.      ! src/modstartup.f90:518-519
+    allocate (sv_top(1:max(nsv, 1))); sv_top = 0.
+    write (cexpnr, '(i3.3)') iexpnr
+  end subroutine read_namelists_subset
+
+  subroutine chk(ierr, grp)
+    integer, intent(in) :: ierr
+    character(*), intent(in) :: grp
+    if (ierr > 0) then
+      write (0, *) 'ERROR: problem in namoptions group ', grp, ' iostat=', ierr
+      stop 1
+    end if
+  end subroutine chk
+
+  ! ---- src/modstartup.f90:652-691 for one rank
+  subroutine init_decomp_np1
+    logical :: periodic_bc(3)
+    periodic_bc = .false.
+    call decomp_2d_init(itot, jtot, ktot, 1, 1, periodic_bc)
+    comm3d = DECOMP_2D_COMM_CART_Z
+    myidx = 0; myidy = 0
+    write (cmyidx, '(i3.3)') myidx
+    write (cmyidy, '(i3.3)') myidy
+  end subroutine init_decomp_np1
+
+  ! ---- src/modstartup.f90:1088-1290 and :2051-2092 (cold start, neutral subset)
+  subroutine cold_start
+    use modfields, only: dpdx
+    real, allocatable :: height(:)
+    character(80) :: chmess
+    integer :: i, j, k, n
+    real :: zsize_
+    allocate (height(kb:ke + kh))
+    dt = dtmax/100.
+    timee = 0.
+    open (ifinput, file='prof.inp.'//cexpnr)
+    read (ifinput, '(a80)') chmess
+    read (ifinput, '(a80)') chmess
+    do k = kb, ke
+      read (ifinput, *) height(k), thlprof(k), qtprof(k), uprof(k), vprof(k), e12prof(k)
+    end do
+    close (ifinput)
+    do k = kb, ke
+      do j = jb - 1, je + 1
+        do i = ib - 1, ie + 1
+          thl0(i, j, k) = thlprof(k); thlm(i, j, k) = thlprof(k)
+          qt0(i, j, k) = qtprof(k); qtm(i, j, k) = qtprof(k)
+          u0(i, j, k) = uprof(k); um(i, j, k) = uprof(k)
+          v0(i, j, k) = vprof(k); vm(i, j, k) = vprof(k)
+          w0(i, j, k) = 0.0; wm(i, j, k) = 0.0
+          e120(i, j, k) = e12prof(k); e12m(i, j, k) = e12prof(k)
+          ekm(i, j, k) = numol
+          ekh(i, j, k) = numol
+        end do
+      end do
+    end do
+    do k = kb, ke
+      do j = jb - jhc, je + jhc
+        do i = ib - ihc, ie + ihc
+          thl0c(i, j, k) = thlprof(k)
+        end do
+      end do
+    end do
+    ekh(:, :, ke + 1) = ekh(:, :, ke)
+    do j = jb - jh, je + jh
+      do i = ib - ih, ie + ih
+        thl0(i, j, ke + 1) = thl0(i, j, ke)
+        thl0(i, j, kb - 1) = thl0(i, j, kb)
+      end do
+    end do
+    if (lrandomize) then
+      krand = min(krand, ke)
+      do k = kb, krand
+        call randomize_field_l(um, k, randu, irandom, ih, jh)
+      end do
+      do k = kb, krand
+        call randomize_field_l(vm, k, randu, irandom, ih, jh)
+      end do
+      do k = kb, krand
+        call randomize_field_l(wm, k, randu, irandom, ih, jh)
+      end do
+    end if
+    u0 = um; v0 = vm; w0 = wm
+    ! passive scalars (stand-in for scalar.inp, src/modstartup.f90:1541-1560): linear profile
+    zsize_ = zh(ke + 1)
+    do n = 1, nsv
+      do k = kb, ke
+        sv0(:, :, k, n) = scal_b + scal_a*real(n)*zf(k)/zsize_
+      end do
+      sv0(:, :, kb - 1, n) = sv0(:, :, kb, n)
+      sv0(:, :, kb - 2, n) = sv0(:, :, kb, n)
+      svm(:, :, :, n) = sv0(:, :, :, n)
+    end do
+    call halos
+    uinit = um; vinit = vm
+    if (.not. ladaptive) dt = dtmax
+
+    open (ifinput, file='lscale.inp.'//cexpnr)
+    read (ifinput, '(a80)') chmess
+    read (ifinput, '(a80)') chmess
+    do k = kb, ke
+      read (ifinput, *) height(k), ug(k), vg(k), pgx(k), pgy(k), wfls(k), &
+        dqtdxls(k), dqtdyls(k), dqtdtls(k), thlpcar(k)
+    end do
+    close (ifinput)
+    if (lprofforc) then
+      do k = kb, ke
+        dpdxl(k) = -pgx(k) - dpdx
+        dpdyl(k) = -pgy(k)
+      end do
+    else
+      do k = kb, ke
+        dpdxl(k) = om23_gs*vg(k) - pgx(k) - dpdx
+        dpdyl(k) = -om23_gs*ug(k) - pgy(k)
+      end do
+    end if
+    btime = timee
+    timeleft = runtime
+    dt_lim = timeleft
+    ntrun = 0
+    ntimee = nint(timee/dtmax)
+    deallocate (height)
+  end subroutine cold_start
+
+  ! ---- src/modstartup.f90:2367-2396 (deterministic LCG keyed on the global index)
+  subroutine randomize_field_l(field, klev, ampl, ir, ihl, jhl)
+    integer(KIND=selected_int_kind(6)) :: imm, ia, ic, ir
+    integer ihl, jhl, i, j, klev, iglob, jglob
+    integer(KIND=selected_int_kind(12)) :: linear_id, state
+    real ran, ampl
+    real field(ib - ihl:ie + ihl, jb - jhl:je + jhl, kb - kh:ke + kh)
+    parameter(imm=134456, ia=8121, ic=28411)
+    do j = jb, je
+      jglob = j + zstart(2) - 1
+      do i = ib, ie
+        iglob = i + zstart(1) - 1
+        linear_id = int(iglob, kind(linear_id)) &
+                    + int(itot, kind(linear_id))*int(jglob - 1, kind(linear_id)) &
+                    + int(itot, kind(linear_id))*int(jtot, kind(linear_id))*int(klev - 1, kind(linear_id))
+        state = mod(int(ir, kind(state)) + linear_id, int(imm, kind(state)))
+        state = mod(state*int(ia, kind(state)) + int(ic, kind(state)), int(imm, kind(state)))
+        ran = real(state)/real(imm)
+        field(i, j, klev) = field(i, j, klev) + (ran - 0.5)*2.0*ampl
+      end do
+    end do
+  end subroutine randomize_field_l
+
+  ! ------------------------------------------------------------ dump helpers
+  subroutine put3(name, a, lb)
+    character(*), intent(in) :: name
+    real, intent(in) :: a(:, :, :)
+    integer, intent(in) :: lb(3)
+    character(16) :: nm
+    integer(4) :: hdr(7)
+    nm = name
+    hdr(1) = 3
+    hdr(2:4) = lb
+    hdr(5:7) = lb + shape(a) - 1
+    write (iu) nm, hdr, a
+  end subroutine put3
+
+  subroutine put1(name, a, lb)
+    character(*), intent(in) :: name
+    real, intent(in) :: a(:)
+    integer, intent(in) :: lb
+    character(16) :: nm
+    integer(4) :: hdr(7)
+    nm = name
+    hdr = 0
+    hdr(1) = 1
+    hdr(2) = lb
+    hdr(5) = lb + size(a) - 1
+    write (iu) nm, hdr, a
+  end subroutine put1
+
+  subroutine dump_meta
+    real :: meta(24)
+    meta = 0.
+    meta(1) = itot; meta(2) = jtot; meta(3) = ktot
+    meta(4) = dx; meta(5) = dy; meta(6) = dtmax
+    meta(7) = ih; meta(8) = jh; meta(9) = kh
+    meta(10) = ihc; meta(11) = jhc; meta(12) = khc
+    meta(13) = nsv; meta(14) = numol; meta(15) = prandtlmoli
+    meta(16) = prandtli; meta(17) = c_vreman; meta(18) = csz(1, 1)
+    meta(19) = merge(1., 0., lsmagorinsky); meta(20) = merge(1., 0., lvreman)
+    meta(21) = BCtopm; meta(22) = merge(1., 0., lles)
+    call put1('meta', meta, 1)
+    call put1('dzf', dzf, kb - kh)
+    call put1('dzh', dzh, kb)
+    call put1('zf', zf, kb)
+    call put1('dpdxl', dpdxl, kb)
+    call put1('dpdyl', dpdyl, kb)
+    call put1('delta_k', delta(1, :), kb)
+  end subroutine dump_meta
+
+  subroutine dump_state(tag)
+    character(*), intent(in) :: tag
+    integer :: n
+    character(2) :: cn
+    call put3(tag//'.u0', u0, (/ib - ih, jb - jh, kb - kh/))
+    call put3(tag//'.v0', v0, (/ib - ih, jb - jh, kb - kh/))
+    call put3(tag//'.w0', w0, (/ib - ih, jb - jh, kb - kh/))
+    call put3(tag//'.um', um, (/ib - ih, jb - jh, kb - kh/))
+    call put3(tag//'.vm', vm, (/ib - ih, jb - jh, kb - kh/))
+    call put3(tag//'.wm', wm, (/ib - ih, jb - jh, kb - kh/))
+    call put3(tag//'.pres0', pres0, (/ib - ih, jb - jh, kb - kh/))
+    call put3(tag//'.ekm', ekm, (/ib - ih, jb - jh, kb - kh/))
+    call put3(tag//'.ekh', ekh, (/ib - ih, jb - jh, kb - kh/))
+    call put3(tag//'.p', p, (/ib - ih, jb - jh, kb - kh/))
+    do n = 1, nsv
+      write (cn, '(i2.2)') n
+      call put3(tag//'.sv0_'//cn, sv0(:, :, :, n), (/ib - ihc, jb - jhc, kb - khc/))
+      call put3(tag//'.svm_'//cn, svm(:, :, :, n), (/ib - ihc, jb - jhc, kb - khc/))
+    end do
+  end subroutine dump_state
+
+  subroutine dump_tend(tag)
+    character(*), intent(in) :: tag
+    integer :: n
+    character(2) :: cn
+    call put3(tag//'.up', up, (/ib - ih, jb - jh, kb/))
+    call put3(tag//'.vp', vp, (/ib - ih, jb - jh, kb/))
+    call put3(tag//'.wp', wp, (/ib - ih, jb - jh, kb/))
+    do n = 1, nsv
+      write (cn, '(i2.2)') n
+      call put3(tag//'.svp_'//cn, svp(:, :, :, n), (/ib - ihc, jb - jhc, kb/))
+    end do
+  end subroutine dump_tend
+
+  ! ---- per-routine golden vectors: each reference routine is called on a known
+  !      state (dumped as 'in.*') and its outputs are dumped right after.
+  subroutine kernel_vectors
+    call tstep_update                       ! advances rk3step (and dt bookkeeping)
+    call put1('rk3', (/real(rk3step), dt/), 1)
+    call dump_state('in')                   ! state every kernel below starts from
+    call dump_tend('in')                    ! (tendencies are zero here)
+    call advection                          ! src/modadvection.f90:36
+    call dump_tend('adv')
+    up = 0.; vp = 0.; wp = 0.; svp = 0.
+    call subgrid                            ! src/modsubgrid.f90:128 (closure+closurebc+diff*)
+    call put3('sub.ekm', ekm, (/ib - ih, jb - jh, kb - kh/))
+    call put3('sub.ekh', ekh, (/ib - ih, jb - jh, kb - kh/))
+    call put3('sub.u0', u0, (/ib - ih, jb - jh, kb - kh/))   ! top ghost row rewritten by closurebc
+    call dump_tend('sub')
+    ! full tendency = advection + subgrid + forces, as the driver would have it
+    up = 0.; vp = 0.; wp = 0.; svp = 0.
+    call advection
+    call subgrid
+    if (lforces) call forces
+    call dump_tend('pre')
+    call poisson                            ! src/modpois.f90:419
+    call put3('poi.p', p, (/ib - ih, jb - jh, kb - kh/))
+    call put3('poi.pres0', pres0, (/ib - ih, jb - jh, kb - kh/))
+    call dump_tend('poi')
+    call tstep_integrate                    ! src/modtstep.f90:171
+    call halos
+    call boundary
+    call dump_state('out')
+  end subroutine kernel_vectors
+
+end program ref_driver

@@ -1,0 +1,829 @@
+/* TEST INFRASTRUCTURE -- CPU oracle, NOT the product.  See udcore_oracle.h.
+ *
+ * Straight restatement, loop for loop, of the reference Fortran; expression
+ * order follows the cited lines so that differences against the reference's own
+ * compiled code stay at the few-ulp level (compiled with -ffp-contract=off).
+ */
+#include "udcore_oracle.h"
+#include "fft_ref.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846264338327950288
+#endif
+
+#define SX (g->nx + 2)
+#define SY (g->ny + 2)
+#define M(a, i, j, k) a[(size_t)(i) + (size_t)SX * ((size_t)(j) + (size_t)SY * (size_t)(k))]
+#define SXC (g->nx + 4)
+#define SYC (g->ny + 4)
+#define C(a, i, j, k) a[(size_t)((i) + 1) + (size_t)SXC * ((size_t)((j) + 1) + (size_t)SYC * (size_t)((k) + 1))]
+
+static size_t msize(const orc_grid *g) { return (size_t)(g->nx + 2) * (g->ny + 2) * (g->nz + 2); }
+static size_t csize(const orc_grid *g) { return (size_t)(g->nx + 4) * (g->ny + 4) * (g->nz + 4); }
+
+/* metrics exactly as src/modglobal.f90:812-838 derives them */
+typedef struct {
+  double dxi, dyi, dxiq, dyiq, dx2i, dy2i, dxi5, dyi5, dx2, dy2;
+  double *dzfi, *dzfi5, *dzfiq, *dzf2, *dzhi, *dzhiq, *dzh2i; /* indexed by Fortran k */
+} metrics;
+
+static void metrics_init(const orc_grid *g, metrics *m) {
+  int n = g->nz + 2;
+  m->dxi = 1. / g->dx; m->dyi = 1. / g->dy;
+  m->dx2 = g->dx * g->dx; m->dy2 = g->dy * g->dy;
+  m->dxiq = 0.25 * m->dxi; m->dyiq = 0.25 * m->dyi;
+  m->dx2i = m->dxi * m->dxi; m->dy2i = m->dyi * m->dyi;
+  m->dxi5 = 0.5 * m->dxi; m->dyi5 = 0.5 * m->dyi;
+  m->dzfi = (double *)calloc(7 * (size_t)n, sizeof(double));
+  m->dzfi5 = m->dzfi + n; m->dzfiq = m->dzfi5 + n; m->dzf2 = m->dzfiq + n;
+  m->dzhi = m->dzf2 + n; m->dzhiq = m->dzhi + n; m->dzh2i = m->dzhiq + n;
+  for (int k = 0; k < n; ++k) {
+    m->dzfi[k] = 1. / g->dzf[k];
+    m->dzfi5[k] = 0.5 * m->dzfi[k];
+    m->dzfiq[k] = 0.25 * m->dzfi[k];
+    m->dzf2[k] = g->dzf[k] * g->dzf[k];
+  }
+  for (int k = 1; k < n; ++k) {
+    m->dzhi[k] = 1. / g->dzh[k];
+    m->dzhiq[k] = 0.25 * m->dzhi[k];
+    m->dzh2i[k] = m->dzhi[k] * m->dzhi[k];
+  }
+}
+static void metrics_free(metrics *m) { free(m->dzfi); }
+
+/* ====================================================================== advection */
+
+/* src/modadvection.f90:158-212 */
+void orc_advecu_2nd(const orc_grid *g, const double *u0, const double *v0, const double *w0,
+                    const double *pres0, double *up) {
+  metrics m; metrics_init(g, &m);
+  const double *dzf = g->dzf;
+  for (int k = 1; k <= g->nz; ++k)
+    for (int j = 1; j <= g->ny; ++j)
+      for (int i = 1; i <= g->nx; ++i) {
+        int im = i - 1, ip = i + 1, jm = j - 1, jp = j + 1;
+        M(up, i, j, k) = M(up, i, j, k) - (
+            ((M(u0, i, j, k) + M(u0, ip, j, k)) * (M(u0, i, j, k) + M(u0, ip, j, k))
+           - (M(u0, i, j, k) + M(u0, im, j, k)) * (M(u0, i, j, k) + M(u0, im, j, k))) * m.dxiq
+          + ((M(u0, i, j, k) + M(u0, i, jp, k)) * (M(v0, i, jp, k) + M(v0, im, jp, k))
+           - (M(u0, i, j, k) + M(u0, i, jm, k)) * (M(v0, i, j, k) + M(v0, im, j, k))) * m.dyiq)
+          - ((M(pres0, i, j, k) - M(pres0, i - 1, j, k)) * m.dxi);
+      }
+  for (int j = 1; j <= g->ny; ++j)
+    for (int i = 1; i <= g->nx; ++i)
+      for (int k = 1; k <= g->nz; ++k) {
+        int im = i - 1, km = k - 1, kp = k + 1;
+        M(up, i, j, k) = M(up, i, j, k) - (
+            (M(u0, i, j, kp) * dzf[k] + M(u0, i, j, k) * dzf[kp]) * m.dzhi[kp]
+              * (M(w0, i, j, kp) + M(w0, im, j, kp))
+          - (M(u0, i, j, k) * dzf[km] + M(u0, i, j, km) * dzf[k]) * m.dzhi[k]
+              * (M(w0, i, j, k) + M(w0, im, j, k))) * 0.5 * m.dzfi5[k];
+      }
+  metrics_free(&m);
+}
+
+/* src/modadvection.f90:215-270 */
+void orc_advecv_2nd(const orc_grid *g, const double *u0, const double *v0, const double *w0,
+                    const double *pres0, double *vp) {
+  metrics m; metrics_init(g, &m);
+  const double *dzf = g->dzf;
+  for (int k = 1; k <= g->nz; ++k)
+    for (int j = 1; j <= g->ny; ++j)
+      for (int i = 1; i <= g->nx; ++i) {
+        int im = i - 1, ip = i + 1, jm = j - 1, jp = j + 1;
+        M(vp, i, j, k) = M(vp, i, j, k) - (
+            ((M(u0, ip, j, k) + M(u0, ip, jm, k)) * (M(v0, i, j, k) + M(v0, ip, j, k))
+           - (M(u0, i, j, k) + M(u0, i, jm, k)) * (M(v0, i, j, k) + M(v0, im, j, k))) * m.dxiq
+          + ((M(v0, i, jp, k) + M(v0, i, j, k)) * (M(v0, i, j, k) + M(v0, i, jp, k))
+           - (M(v0, i, jm, k) + M(v0, i, j, k)) * (M(v0, i, j, k) + M(v0, i, jm, k))) * m.dyiq)
+          - ((M(pres0, i, j, k) - M(pres0, i, jm, k)) * m.dyi);
+      }
+  for (int j = 1; j <= g->ny; ++j)
+    for (int i = 1; i <= g->nx; ++i)
+      for (int k = 1; k <= g->nz; ++k) {
+        int jm = j - 1, km = k - 1, kp = k + 1;
+        M(vp, i, j, k) = M(vp, i, j, k) - (
+            (M(w0, i, j, kp) + M(w0, i, jm, kp))
+              * (M(v0, i, j, kp) * dzf[k] + M(v0, i, j, k) * dzf[kp]) * m.dzhi[kp]
+          - (M(w0, i, j, k) + M(w0, i, jm, k))
+              * (M(v0, i, j, km) * dzf[k] + M(v0, i, j, k) * dzf[km]) * m.dzhi[k]) * 0.5 * m.dzfi5[k];
+      }
+  metrics_free(&m);
+}
+
+/* src/modadvection.f90:273-314 */
+void orc_advecw_2nd(const orc_grid *g, const double *u0, const double *v0, const double *w0,
+                    const double *pres0, double *wp) {
+  metrics m; metrics_init(g, &m);
+  const double *dzf = g->dzf;
+  for (int k = 2; k <= g->nz; ++k)
+    for (int j = 1; j <= g->ny; ++j)
+      for (int i = 1; i <= g->nx; ++i) {
+        int im = i - 1, ip = i + 1, jm = j - 1, jp = j + 1, km = k - 1, kp = k + 1;
+        M(wp, i, j, k) = M(wp, i, j, k) - (
+            ((M(w0, ip, j, k) + M(w0, i, j, k)) * (dzf[km] * M(u0, ip, j, k) + dzf[k] * M(u0, ip, j, km))
+           - (M(w0, i, j, k) + M(w0, im, j, k)) * (dzf[km] * M(u0, i, j, k) + dzf[k] * M(u0, i, j, km)))
+              * m.dxiq * m.dzhi[k]
+          + ((M(w0, i, jp, k) + M(w0, i, j, k)) * (dzf[km] * M(v0, i, jp, k) + dzf[k] * M(v0, i, jp, km))
+           - (M(w0, i, j, k) + M(w0, i, jm, k)) * (dzf[km] * M(v0, i, j, k) + dzf[k] * M(v0, i, j, km)))
+              * m.dyiq * m.dzhi[k]
+          + ((M(w0, i, j, k) + M(w0, i, j, kp)) * (M(w0, i, j, k) + M(w0, i, j, kp))
+           - (M(w0, i, j, k) + M(w0, i, j, km)) * (M(w0, i, j, k) + M(w0, i, j, km))) * m.dzhiq[k])
+          - ((M(pres0, i, j, k) - M(pres0, i, j, km)) * m.dzhi[k]);
+      }
+  metrics_free(&m);
+}
+
+/* src/modadvection.f90:410-421, eps1 = 1e-10 (src/modglobal.f90:318) */
+static double rlim(double d1, double d2) {
+  const double eps1 = 1.e-10;
+  double ri = (d2 + eps1) / (d1 + eps1);
+  double phir = fmax(0., fmin(2. * ri, fmin(1. / 3. + 2. / 3. * ri, 2.)));
+  return 0.5 * phir * d1;
+}
+
+/* src/modadvection.f90:316-407; kappa grids src/modglobal.f90:841-867.
+ * The reference accumulates each direction through two temporaries (dumu, duml)
+ * and adds `dumu + duml` to the tendency; the same order is kept here. */
+void orc_advecc_kappa(const orc_grid *g, const double *u0, const double *v0, const double *w0,
+                      const double *c, double *cp) {
+  const int nx = g->nx, ny = g->ny, nz = g->nz;
+  const double dyi = 1. / g->dy;
+  /* x grid as src/modglobal.f90:771-791 builds it (uniform, but via differences) */
+  double *xh = (double *)calloc((size_t)8 * (nx + 8), sizeof(double));
+  double *xf = xh + (nx + 8), *dxf = xf + (nx + 8), *dxh = dxf + (nx + 8);
+  double *dxfc = dxh + (nx + 8), *dxfci = dxfc + (nx + 8), *dxhci = dxfci + (nx + 8);
+  /* arrays indexed by Fortran i + 2 (range -1..nx+2) */
+#define X(a, i) a[(i) + 2]
+  for (int i = 1; i <= nx + 1; ++i) { X(xh, i) = (i - 1) * g->dx; X(xf, i) = X(xh, i) + g->dx / 2; }
+  for (int i = 1; i <= nx; ++i) X(dxf, i) = X(xh, i + 1) - X(xh, i);
+  X(dxf, nx + 1) = X(dxf, nx); X(dxf, 0) = X(dxf, 1);
+  X(dxh, 1) = 2 * X(xf, 1);
+  for (int i = 2; i <= nx + 1; ++i) X(dxh, i) = X(xf, i) - X(xf, i - 1);
+  for (int i = 0; i <= nx + 1; ++i) X(dxfc, i) = X(dxf, i);
+  X(dxfc, -1) = X(dxfc, 0); X(dxfc, nx + 2) = X(dxfc, nx + 1);
+  for (int i = 1; i <= nx + 1; ++i) X(dxhci, i) = 1. / X(dxh, i);
+  X(dxhci, 0) = X(dxhci, 1); X(dxhci, nx + 2) = X(dxhci, nx + 1);
+  for (int i = -1; i <= nx + 2; ++i) X(dxfci, i) = 1. / X(dxfc, i);
+  /* z grids, Fortran k + 2 (range -1..nz+2) */
+  double *dzfc = (double *)calloc((size_t)3 * (nz + 8), sizeof(double));
+  double *dzfci = dzfc + (nz + 8), *dzhci = dzfci + (nz + 8);
+  for (int k = 0; k <= nz + 1; ++k) X(dzfc, k) = g->dzf[k];
+  X(dzfc, -1) = X(dzfc, 0); X(dzfc, nz + 2) = X(dzfc, nz + 1);
+  for (int k = 1; k <= nz + 1; ++k) X(dzhci, k) = 1. / g->dzh[k];
+  X(dzhci, 0) = X(dzhci, 1); X(dzhci, nz + 2) = X(dzhci, nz + 1);
+  for (int k = -1; k <= nz + 2; ++k) X(dzfci, k) = 1. / X(dzfc, k);
+
+  size_t n = csize(g);
+  double *dumu = (double *)calloc(2 * n, sizeof(double));
+  double *duml = dumu + n;
+  double d1, d2, cf;
+  /* -d(uc)/dx */
+  for (int k = 1; k <= nz; ++k)
+    for (int j = 1; j <= ny; ++j)
+      for (int i = 1; i <= nx + 1; ++i) {
+        if (M(u0, i, j, k) > 0) {
+          d1 = (C(c, i - 1, j, k) - C(c, i - 2, j, k)) * X(dxhci, i - 1);
+          d2 = (C(c, i, j, k) - C(c, i - 1, j, k)) * X(dxhci, i);
+          cf = C(c, i - 1, j, k);
+        } else {
+          d1 = (C(c, i, j, k) - C(c, i + 1, j, k)) * X(dxhci, i + 1);
+          d2 = (C(c, i - 1, j, k) - C(c, i, j, k)) * X(dxhci, i);
+          cf = C(c, i, j, k);
+        }
+        cf = cf + X(dxfc, i) * rlim(d1, d2);
+        C(dumu, i - 1, j, k) = -cf * M(u0, i, j, k) * X(dxfci, i - 1);
+        C(duml, i, j, k) = cf * M(u0, i, j, k) * X(dxfci, i);
+      }
+  for (size_t q = 0; q < n; ++q) cp[q] = cp[q] + dumu[q] + duml[q];
+  memset(dumu, 0, 2 * n * sizeof(double));
+  /* -d(vc)/dy */
+  for (int k = 1; k <= nz; ++k)
+    for (int j = 1; j <= ny + 1; ++j)
+      for (int i = 1; i <= nx; ++i) {
+        if (M(v0, i, j, k) > 0) {
+          d1 = C(c, i, j - 1, k) - C(c, i, j - 2, k);
+          d2 = C(c, i, j, k) - C(c, i, j - 1, k);
+          cf = C(c, i, j - 1, k);
+        } else {
+          d1 = C(c, i, j, k) - C(c, i, j + 1, k);
+          d2 = C(c, i, j - 1, k) - C(c, i, j, k);
+          cf = C(c, i, j, k);
+        }
+        cf = cf + rlim(d1, d2);
+        C(duml, i, j, k) = cf * M(v0, i, j, k) * dyi;
+        C(dumu, i, j - 1, k) = -cf * M(v0, i, j, k) * dyi;
+      }
+  for (size_t q = 0; q < n; ++q) cp[q] = cp[q] + dumu[q] + duml[q];
+  memset(dumu, 0, 2 * n * sizeof(double));
+  /* -d(wc)/dz, faces kb+1..ke+1 */
+  for (int k = 2; k <= nz + 1; ++k)
+    for (int j = 1; j <= ny; ++j)
+      for (int i = 1; i <= nx; ++i) {
+        if (M(w0, i, j, k) > 0) {
+          d1 = (C(c, i, j, k - 1) - C(c, i, j, k - 2)) * X(dzhci, k - 1);
+          d2 = (C(c, i, j, k) - C(c, i, j, k - 1)) * X(dzhci, k);
+          cf = C(c, i, j, k - 1);
+        } else {
+          d1 = (C(c, i, j, k) - C(c, i, j, k + 1)) * X(dzhci, k + 1);
+          d2 = (C(c, i, j, k - 1) - C(c, i, j, k)) * X(dzhci, k);
+          cf = C(c, i, j, k);
+        }
+        cf = cf + X(dzfc, k) * rlim(d1, d2);
+        C(duml, i, j, k) = cf * M(w0, i, j, k) * X(dzfci, k);
+        C(dumu, i, j, k - 1) = -cf * M(w0, i, j, k) * X(dzfci, k - 1);
+      }
+  for (size_t q = 0; q < n; ++q) cp[q] = cp[q] + dumu[q] + duml[q];
+#undef X
+  free(dumu); free(dzfc); free(xh);
+}
+
+/* ====================================================================== subgrid */
+
+/* closure: src/modsubgrid.f90:159-412 (Smagorinsky :208-264, Vreman :269-360,
+ * DNS :401-404), followed by closurebc.  As in the reference the molecular
+ * viscosity is added to the WHOLE array (halos included) before closurebc
+ * rewrites the halos. */
+void orc_closure(const orc_grid *g, const double *u0, const double *v0, const double *w0,
+                 double *ekm, double *ekh) {
+  metrics m; metrics_init(g, &m);
+  const double *dzf = g->dzf;
+  const size_t n = msize(g);
+  const int nx = g->nx, ny = g->ny, nz = g->nz;
+  if (g->sgs == 1) {
+    for (int k = 1; k <= nz; ++k) {
+      int kp = k + 1, km = k - 1;
+      for (int i = 1; i <= nx; ++i) {
+        int ip = i + 1, im = i - 1;
+        /* delta(i,k) = (dxf(i)*dy*dzf(k))**(1/3)  src/modglobal.f90:793-797; dxf(i) = xh(i+1)-xh(i) */
+        double dxf_i = (double)i * g->dx - (double)(i - 1) * g->dx;
+        double delta = pow(dxf_i * g->dy * dzf[k], 1. / 3.);
+        double mlen = g->csz * delta;
+        for (int j = 1; j <= ny; ++j) {
+          int jp = j + 1, jm = j - 1;
+          double damp = 1.;
+          double t, strain2;
+          t = (M(u0, ip, j, k) - M(u0, i, j, k)) * m.dxi; strain2 = t * t;
+          t = (M(v0, i, jp, k) - M(v0, i, j, k)) * m.dyi; strain2 = strain2 + t * t;
+          t = (M(w0, i, j, kp) - M(w0, i, j, k)) * m.dzfi[k]; strain2 = strain2 + t * t;
+          double a1 = (M(w0, i, j, kp) - M(w0, im, j, kp)) * m.dxi + (M(u0, i, j, kp) - M(u0, i, j, k)) * m.dzhi[kp];
+          double a2 = (M(w0, i, j, k) - M(w0, im, j, k)) * m.dxi + (M(u0, i, j, k) - M(u0, i, j, km)) * m.dzhi[k];
+          double a3 = (M(w0, ip, j, k) - M(w0, i, j, k)) * m.dxi + (M(u0, ip, j, k) - M(u0, ip, j, km)) * m.dzhi[k];
+          double a4 = (M(w0, ip, j, kp) - M(w0, i, j, kp)) * m.dxi + (M(u0, ip, j, kp) - M(u0, ip, j, k)) * m.dzhi[kp];
+          strain2 = strain2 + 0.125 * (a1 * a1 + a2 * a2 + a3 * a3 + a4 * a4);
+          a1 = (M(u0, i, jp, k) - M(u0, i, j, k)) * m.dyi + (M(v0, i, jp, k) - M(v0, im, jp, k)) * m.dxi;
+          a2 = (M(u0, i, j, k) - M(u0, i, jm, k)) * m.dyi + (M(v0, i, j, k) - M(v0, im, j, k)) * m.dxi;
+          a3 = (M(u0, ip, j, k) - M(u0, ip, jm, k)) * m.dyi + (M(v0, ip, j, k) - M(v0, i, j, k)) * m.dxi;
+          a4 = (M(u0, ip, jp, k) - M(u0, ip, j, k)) * m.dyi + (M(v0, ip, jp, k) - M(v0, i, jp, k)) * m.dxi;
+          strain2 = strain2 + 0.125 * (a1 * a1 + a2 * a2 + a3 * a3 + a4 * a4);
+          a1 = (M(v0, i, j, kp) - M(v0, i, j, k)) * m.dzhi[kp] + (M(w0, i, j, kp) - M(w0, i, jm, kp)) * m.dyi;
+          a2 = (M(v0, i, j, k) - M(v0, i, j, km)) * m.dzhi[k] + (M(w0, i, j, k) - M(w0, i, jm, k)) * m.dyi;
+          a3 = (M(v0, i, jp, k) - M(v0, i, jp, km)) * m.dzhi[k] + (M(w0, i, jp, k) - M(w0, i, j, k)) * m.dyi;
+          a4 = (M(v0, i, jp, kp) - M(v0, i, jp, k)) * m.dzhi[kp] + (M(w0, i, jp, kp) - M(w0, i, j, kp)) * m.dyi;
+          strain2 = strain2 + 0.125 * (a1 * a1 + a2 * a2 + a3 * a3 + a4 * a4);
+          double md = mlen * damp;
+          M(ekm, i, j, k) = (md * md) * sqrt(2. * strain2);
+          M(ekh, i, j, k) = M(ekm, i, j, k) * g->prandtli;
+        }
+      }
+    }
+    for (size_t q = 0; q < n; ++q) ekm[q] = ekm[q] + g->numol;
+    for (size_t q = 0; q < n; ++q) ekh[q] = ekh[q] + g->numol * g->prandtlmoli;
+  } else if (g->sgs == 2) {
+    for (int k = 1; k <= nz; ++k) {
+      int kp = k + 1, km = k - 1;
+      for (int j = 1; j <= ny; ++j) {
+        int jp = j + 1, jm = j - 1;
+        for (int i = 1; i <= nx; ++i) {
+          int ip = i + 1, im = i - 1;
+          double a11 = (M(u0, ip, j, k) - M(u0, i, j, k)) * m.dxi;
+          double a12 = (M(v0, ip, jp, k) + M(v0, ip, j, k) - M(v0, im, jp, k) - M(v0, im, j, k)) * m.dxiq;
+          double a13 = (M(w0, ip, j, kp) + M(w0, ip, j, k) - M(w0, im, j, kp) - M(w0, im, j, k)) * m.dxiq;
+          double a21 = (M(u0, ip, jp, k) + M(u0, i, jp, k) - M(u0, ip, jm, k) - M(u0, i, jm, k)) * m.dyiq;
+          double a22 = (M(v0, i, jp, k) - M(v0, i, j, k)) * m.dyi;
+          double a23 = (M(w0, i, jp, kp) + M(w0, i, jp, k) - M(w0, i, jm, kp) - M(w0, i, jm, k)) * m.dyiq;
+          double a31 = (((M(u0, ip, j, kp) + M(u0, i, j, kp)) * dzf[k] + (M(u0, ip, j, k) + M(u0, i, j, k)) * dzf[kp]) * m.dzhi[kp]
+                      - ((M(u0, ip, j, k) + M(u0, i, j, k)) * dzf[km] + (M(u0, ip, j, km) + M(u0, i, j, km)) * dzf[k]) * m.dzhi[k])
+                       * m.dzfiq[k];
+          double a32 = (((M(v0, i, jp, kp) + M(v0, i, j, kp)) * dzf[k] + (M(v0, i, jp, k) + M(v0, i, j, k)) * dzf[kp]) * m.dzhi[kp]
+                      - ((M(v0, i, jp, k) + M(v0, i, j, k)) * dzf[km] + (M(v0, i, jp, km) + M(v0, i, j, km)) * dzf[k]) * m.dzhi[k])
+                       * m.dzfiq[k];
+          double a33 = (M(w0, i, j, kp) - M(w0, i, j, k)) * m.dzfi[k];
+          double aa = a11 * a11 + a21 * a21 + a31 * a31 + a12 * a12 + a22 * a22 + a32 * a32
+                    + a13 * a13 + a23 * a23 + a33 * a33;
+          double dz2 = m.dzf2[k];
+          double b11 = m.dx2 * a11 * a11 + m.dy2 * a21 * a21 + dz2 * a31 * a31;
+          double b22 = m.dx2 * a12 * a12 + m.dy2 * a22 * a22 + dz2 * a32 * a32;
+          double b12 = m.dx2 * a11 * a12 + m.dy2 * a21 * a22 + dz2 * a31 * a32;
+          double b33 = m.dx2 * a13 * a13 + m.dy2 * a23 * a23 + dz2 * a33 * a33;
+          double b13 = m.dx2 * a11 * a13 + m.dy2 * a21 * a23 + dz2 * a31 * a33;
+          double b23 = m.dx2 * a12 * a13 + m.dy2 * a22 * a23 + dz2 * a32 * a33;
+          double bb = b11 * b22 - b12 * b12 + b11 * b33 - b13 * b13 + b22 * b33 - b23 * b23;
+          if (bb < 1.e-8) M(ekm, i, j, k) = 0.;
+          else M(ekm, i, j, k) = g->c_vreman * sqrt(bb / aa);
+        }
+      }
+    }
+    for (size_t q = 0; q < n; ++q) ekh[q] = ekm[q] * g->prandtli;
+    for (size_t q = 0; q < n; ++q) ekm[q] = ekm[q] + g->numol;
+    for (size_t q = 0; q < n; ++q) ekh[q] = ekh[q] + g->numol * g->prandtlmoli;
+  } else {
+    for (size_t q = 0; q < n; ++q) { ekm[q] = g->numol; ekh[q] = g->numol * g->prandtlmoli; }
+  }
+  metrics_free(&m);
+  orc_closurebc(g, ekm, ekh);
+}
+
+/* src/modboundary.f90:434-505, single rank, periodic x and y.
+ * (reassure_fluxtop_boundary :392-431 is applied by the caller, orc_substep.) */
+void orc_closurebc(const orc_grid *g, double *ekm, double *ekh) {
+  const int nx = g->nx, ny = g->ny, nz = g->nz;
+  const double nm = g->numol, nh = g->numol * g->prandtlmoli;
+  for (int j = 0; j <= ny + 1; ++j)
+    for (int i = 0; i <= nx + 1; ++i) {
+      if (g->bctopm == 2) {
+        M(ekm, i, j, nz + 1) = 2. * nm - M(ekm, i, j, nz);
+        M(ekh, i, j, nz + 1) = (2. * nh) - M(ekh, i, j, nz);
+      } else {
+        M(ekm, i, j, nz + 1) = M(ekm, i, j, nz);
+        M(ekh, i, j, nz + 1) = M(ekh, i, j, nz);
+      }
+      M(ekm, i, j, 0) = 2. * nm - M(ekm, i, j, 1);
+      M(ekh, i, j, 0) = (2. * nh) - M(ekh, i, j, 1);
+    }
+  for (int k = 0; k <= nz + 1; ++k)
+    for (int j = 0; j <= ny + 1; ++j) {
+      M(ekm, 0, j, k) = M(ekm, nx, j, k); M(ekm, nx + 1, j, k) = M(ekm, 1, j, k);
+      M(ekh, 0, j, k) = M(ekh, nx, j, k); M(ekh, nx + 1, j, k) = M(ekh, 1, j, k);
+    }
+  for (int k = 0; k <= nz + 1; ++k)
+    for (int i = 0; i <= nx + 1; ++i) {
+      M(ekm, i, 0, k) = M(ekm, i, ny, k); M(ekm, i, ny + 1, k) = M(ekm, i, 1, k);
+      M(ekh, i, 0, k) = M(ekh, i, ny, k); M(ekh, i, ny + 1, k) = M(ekh, i, 1, k);
+    }
+}
+
+/* src/modsubgrid.f90:672-775 (LES :685-732, DNS :734-771) */
+void orc_diffu(const orc_grid *g, const double *u0, const double *v0, const double *w0,
+               const double *ekm, double *up) {
+  metrics m; metrics_init(g, &m);
+  const double *dzf = g->dzf;
+  const double nu = g->numol;
+  for (int k = 1; k <= g->nz; ++k)
+    for (int j = 1; j <= g->ny; ++j)
+      for (int i = 1; i <= g->nx; ++i) {
+        int kp = k + 1, km = k - 1, jp = j + 1, jm = j - 1;
+        if (g->sgs != 0) {
+          double emom = (dzf[km] * (M(ekm, i, j, k) + M(ekm, i - 1, j, k)) + dzf[k] * (M(ekm, i, j, km) + M(ekm, i - 1, j, km))) * m.dzhiq[k];
+          double emop = (dzf[kp] * (M(ekm, i, j, k) + M(ekm, i - 1, j, k)) + dzf[k] * (M(ekm, i, j, kp) + M(ekm, i - 1, j, kp))) * m.dzhiq[kp];
+          double empo = 0.25 * ((M(ekm, i, j, k) + M(ekm, i, jp, k)) + (M(ekm, i - 1, j, k) + M(ekm, i - 1, jp, k)));
+          double emmo = 0.25 * ((M(ekm, i, j, k) + M(ekm, i, jm, k)) + (M(ekm, i - 1, jm, k) + M(ekm, i - 1, j, k)));
+          M(up, i, j, k) = M(up, i, j, k)
+            + (M(ekm, i, j, k) * (M(u0, i + 1, j, k) - M(u0, i, j, k))
+             - M(ekm, i - 1, j, k) * (M(u0, i, j, k) - M(u0, i - 1, j, k))) * 2. * m.dx2i
+            + (empo * ((M(u0, i, jp, k) - M(u0, i, j, k)) * m.dyi + (M(v0, i, jp, k) - M(v0, i - 1, jp, k)) * m.dxi)
+             - emmo * ((M(u0, i, j, k) - M(u0, i, jm, k)) * m.dyi + (M(v0, i, j, k) - M(v0, i - 1, j, k)) * m.dxi)) * m.dyi
+            + (emop * ((M(u0, i, j, kp) - M(u0, i, j, k)) * m.dzhi[kp] + (M(w0, i, j, kp) - M(w0, i - 1, j, kp)) * m.dxi)
+             - emom * ((M(u0, i, j, k) - M(u0, i, j, km)) * m.dzhi[k] + (M(w0, i, j, k) - M(w0, i - 1, j, k)) * m.dxi)) * m.dzfi[k];
+        } else {
+          M(up, i, j, k) = M(up, i, j, k)
+            + (nu * (M(u0, i + 1, j, k) - M(u0, i, j, k)) * m.dxi
+             - nu * (M(u0, i, j, k) - M(u0, i - 1, j, k)) * m.dxi) * 2. * m.dxi
+            + (nu * ((M(u0, i, jp, k) - M(u0, i, j, k)) * m.dyi + (M(v0, i, jp, k) - M(v0, i - 1, jp, k)) * m.dxi)
+             - nu * ((M(u0, i, j, k) - M(u0, i, jm, k)) * m.dyi + (M(v0, i, j, k) - M(v0, i - 1, j, k)) * m.dxi)) * m.dyi
+            + (nu * ((M(u0, i, j, kp) - M(u0, i, j, k)) * m.dzhi[kp] + (M(w0, i, j, kp) - M(w0, i - 1, j, kp)) * m.dxi)
+             - nu * ((M(u0, i, j, k) - M(u0, i, j, km)) * m.dzhi[k] + (M(w0, i, j, k) - M(w0, i - 1, j, k)) * m.dxi)) * m.dzfi[k];
+        }
+      }
+  metrics_free(&m);
+}
+
+/* src/modsubgrid.f90:778-886 */
+void orc_diffv(const orc_grid *g, const double *u0, const double *v0, const double *w0,
+               const double *ekm, double *vp) {
+  metrics m; metrics_init(g, &m);
+  const double *dzf = g->dzf;
+  const double nu = g->numol;
+  for (int k = 1; k <= g->nz; ++k)
+    for (int j = 1; j <= g->ny; ++j)
+      for (int i = 1; i <= g->nx; ++i) {
+        int kp = k + 1, km = k - 1, jp = j + 1, jm = j - 1;
+        if (g->sgs != 0) {
+          double eomm = (dzf[km] * (M(ekm, i, j, k) + M(ekm, i, jm, k)) + dzf[k] * (M(ekm, i, j, km) + M(ekm, i, jm, km))) * m.dzhiq[k];
+          double eomp = (dzf[kp] * (M(ekm, i, j, k) + M(ekm, i, jm, k)) + dzf[k] * (M(ekm, i, j, kp) + M(ekm, i, jm, kp))) * m.dzhiq[kp];
+          double emmo = 0.25 * (M(ekm, i, j, k) + M(ekm, i, jm, k) + M(ekm, i - 1, jm, k) + M(ekm, i - 1, j, k));
+          double epmo = 0.25 * (M(ekm, i, j, k) + M(ekm, i, jm, k) + M(ekm, i + 1, jm, k) + M(ekm, i + 1, j, k));
+          M(vp, i, j, k) = M(vp, i, j, k)
+            + (epmo * ((M(v0, i + 1, j, k) - M(v0, i, j, k)) * m.dxi + (M(u0, i + 1, j, k) - M(u0, i + 1, jm, k)) * m.dyi)
+             - emmo * ((M(v0, i, j, k) - M(v0, i - 1, j, k)) * m.dxi + (M(u0, i, j, k) - M(u0, i, jm, k)) * m.dyi)) * m.dxi
+            + (M(ekm, i, j, k) * (M(v0, i, jp, k) - M(v0, i, j, k))
+             - M(ekm, i, jm, k) * (M(v0, i, j, k) - M(v0, i, jm, k))) * 2. * m.dy2i
+            + (eomp * ((M(v0, i, j, kp) - M(v0, i, j, k)) * m.dzhi[kp] + (M(w0, i, j, kp) - M(w0, i, jm, kp)) * m.dyi)
+             - eomm * ((M(v0, i, j, k) - M(v0, i, j, km)) * m.dzhi[k] + (M(w0, i, j, k) - M(w0, i, jm, k)) * m.dyi)) * m.dzfi[k];
+        } else {
+          M(vp, i, j, k) = M(vp, i, j, k)
+            + (nu * ((M(v0, i + 1, j, k) - M(v0, i, j, k)) * m.dxi + (M(u0, i + 1, j, k) - M(u0, i + 1, jm, k)) * m.dyi)
+             - nu * ((M(v0, i, j, k) - M(v0, i - 1, j, k)) * m.dxi + (M(u0, i, j, k) - M(u0, i, jm, k)) * m.dyi)) * m.dxi
+            + (nu * (M(v0, i, jp, k) - M(v0, i, j, k)) - nu * (M(v0, i, j, k) - M(v0, i, jm, k))) * 2. * m.dy2i
+            + (nu * ((M(v0, i, j, kp) - M(v0, i, j, k)) * m.dzhi[kp] + (M(w0, i, j, kp) - M(w0, i, jm, kp)) * m.dyi)
+             - nu * ((M(v0, i, j, k) - M(v0, i, j, km)) * m.dzhi[k] + (M(w0, i, j, k) - M(w0, i, jm, k)) * m.dyi)) * m.dzfi[k];
+        }
+      }
+  metrics_free(&m);
+}
+
+/* src/modsubgrid.f90:890-997 */
+void orc_diffw(const orc_grid *g, const double *u0, const double *v0, const double *w0,
+               const double *ekm, double *wp) {
+  metrics m; metrics_init(g, &m);
+  const double *dzf = g->dzf;
+  const double nu = g->numol;
+  for (int k = 2; k <= g->nz; ++k)
+    for (int j = 1; j <= g->ny; ++j)
+      for (int i = 1; i <= g->nx; ++i) {
+        int kp = k + 1, km = k - 1, jp = j + 1, jm = j - 1;
+        if (g->sgs != 0) {
+          double emom = (dzf[km] * (M(ekm, i, j, k) + M(ekm, i - 1, j, k)) + dzf[k] * (M(ekm, i, j, km) + M(ekm, i - 1, j, km))) * m.dzhiq[k];
+          double eomm = (dzf[km] * (M(ekm, i, j, k) + M(ekm, i, jm, k)) + dzf[k] * (M(ekm, i, j, km) + M(ekm, i, jm, km))) * m.dzhiq[k];
+          double eopm = (dzf[km] * (M(ekm, i, j, k) + M(ekm, i, jp, k)) + dzf[k] * (M(ekm, i, j, km) + M(ekm, i, jp, km))) * m.dzhiq[k];
+          double epom = (dzf[km] * (M(ekm, i, j, k) + M(ekm, i + 1, j, k)) + dzf[k] * (M(ekm, i, j, km) + M(ekm, i + 1, j, km))) * m.dzhiq[k];
+          M(wp, i, j, k) = M(wp, i, j, k)
+            + (epom * ((M(w0, i + 1, j, k) - M(w0, i, j, k)) * m.dxi + (M(u0, i + 1, j, k) - M(u0, i + 1, j, km)) * m.dzhi[k])
+             - emom * ((M(w0, i, j, k) - M(w0, i - 1, j, k)) * m.dxi + (M(u0, i, j, k) - M(u0, i, j, km)) * m.dzhi[k])) * m.dxi
+            + (eopm * ((M(w0, i, jp, k) - M(w0, i, j, k)) * m.dyi + (M(v0, i, jp, k) - M(v0, i, jp, km)) * m.dzhi[k])
+             - eomm * ((M(w0, i, j, k) - M(w0, i, jm, k)) * m.dyi + (M(v0, i, j, k) - M(v0, i, j, km)) * m.dzhi[k])) * m.dyi
+            + (M(ekm, i, j, k) * (M(w0, i, j, kp) - M(w0, i, j, k)) * m.dzfi[k]
+             - M(ekm, i, j, km) * (M(w0, i, j, k) - M(w0, i, j, km)) * m.dzfi[km]) * 2. * m.dzhi[k];
+        } else {
+          M(wp, i, j, k) = M(wp, i, j, k)
+            + (nu * ((M(w0, i + 1, j, k) - M(w0, i, j, k)) * m.dxi + (M(u0, i + 1, j, k) - M(u0, i + 1, j, km)) * m.dzhi[k])
+             - nu * ((M(w0, i, j, k) - M(w0, i - 1, j, k)) * m.dxi + (M(u0, i, j, k) - M(u0, i, j, km)) * m.dzhi[k])) * m.dxi
+            + (nu * ((M(w0, i, jp, k) - M(w0, i, j, k)) * m.dyi + (M(v0, i, jp, k) - M(v0, i, jp, km)) * m.dzhi[k])
+             - nu * ((M(w0, i, j, k) - M(w0, i, jm, k)) * m.dyi + (M(v0, i, j, k) - M(v0, i, j, km)) * m.dzhi[k])) * m.dyi
+            + (nu * (M(w0, i, j, kp) - M(w0, i, j, k)) * m.dzfi[k]
+             - nu * (M(w0, i, j, k) - M(w0, i, j, km)) * m.dzfi[km]) * 2. * m.dzhi[k];
+        }
+      }
+  metrics_free(&m);
+}
+
+/* src/modsubgrid.f90:540-623 for a halo-2 scalar (ekh is a halo-1 array) */
+void orc_diffc(const orc_grid *g, const double *c, const double *ekh, double *cp) {
+  metrics m; metrics_init(g, &m);
+  const double *dzf = g->dzf;
+  const double cekh = g->numol * g->prandtlmoli;
+  for (int k = 1; k <= g->nz; ++k)
+    for (int j = 1; j <= g->ny; ++j)
+      for (int i = 1; i <= g->nx; ++i) {
+        int kp = k + 1, km = k - 1, jp = j + 1, jm = j - 1, ip = i + 1, im = i - 1;
+        if (g->sgs != 0) {
+          C(cp, i, j, k) = C(cp, i, j, k) + 0.5 * (
+              ((M(ekh, ip, j, k) + M(ekh, i, j, k)) * (C(c, ip, j, k) - C(c, i, j, k))
+             - (M(ekh, i, j, k) + M(ekh, im, j, k)) * (C(c, i, j, k) - C(c, im, j, k))) * m.dx2i
+            + ((M(ekh, i, jp, k) + M(ekh, i, j, k)) * (C(c, i, jp, k) - C(c, i, j, k))
+             - (M(ekh, i, j, k) + M(ekh, i, jm, k)) * (C(c, i, j, k) - C(c, i, jm, k))) * m.dy2i
+            + ((dzf[kp] * M(ekh, i, j, k) + dzf[k] * M(ekh, i, j, kp)) * (C(c, i, j, kp) - C(c, i, j, k)) * m.dzh2i[kp]
+             - (dzf[km] * M(ekh, i, j, k) + dzf[k] * M(ekh, i, j, km)) * (C(c, i, j, k) - C(c, i, j, km)) * m.dzh2i[k]) * m.dzfi[k]);
+        } else {
+          C(cp, i, j, k) = C(cp, i, j, k) + (
+              (cekh * (C(c, ip, j, k) - C(c, i, j, k)) - cekh * (C(c, i, j, k) - C(c, im, j, k))) * m.dx2i
+            + (cekh * (C(c, i, jp, k) - C(c, i, j, k)) - cekh * (C(c, i, j, k) - C(c, i, jm, k))) * m.dy2i
+            + (cekh * (C(c, i, j, kp) - C(c, i, j, k)) * m.dzhi[kp]
+             - cekh * (C(c, i, j, k) - C(c, i, j, km)) * m.dzhi[k]) * m.dzfi[k]);
+        }
+      }
+  metrics_free(&m);
+}
+
+/* ====================================================================== forces */
+/* src/modforces.f90:84-127, lbuoyancy = .false. */
+void orc_forces(const orc_grid *g, const double *dpdxl, const double *dpdyl,
+                double *up, double *vp, double *wp) {
+  for (int k = 1; k <= g->nz; ++k)
+    for (int j = 1; j <= g->ny; ++j)
+      for (int i = 1; i <= g->nx; ++i) {
+        M(up, i, j, k) = M(up, i, j, k) - dpdxl[k];
+        M(vp, i, j, k) = M(vp, i, j, k) - dpdyl[k];
+      }
+  for (int j = 1; j <= g->ny; ++j)
+    for (int i = 1; i <= g->nx; ++i) M(wp, i, j, 1) = 0.0;
+}
+
+/* ====================================================================== pressure */
+
+/* fillps src/modpois.f90:911-998 + bcpup src/modboundary.f90:1191-1341
+ * (free-slip / no-slip top, periodic x and y on one rank) */
+void orc_fillps(const orc_grid *g, double rk3coef, const double *up, const double *vp,
+                const double *wp, const double *um, const double *vm, const double *wm,
+                double *pup, double *pvp, double *pwp, double *p) {
+  const int nx = g->nx, ny = g->ny, nz = g->nz;
+  const double rk3coefi = 1. / rk3coef;
+  const double dxi = 1. / g->dx, dyi = 1. / g->dy;
+  for (int k = 1; k <= nz; ++k)
+    for (int j = 1; j <= ny; ++j)
+      for (int i = 1; i <= nx; ++i) {
+        M(pup, i, j, k) = M(up, i, j, k) + M(um, i, j, k) * rk3coefi;
+        M(pvp, i, j, k) = M(vp, i, j, k) + M(vm, i, j, k) * rk3coefi;
+        M(pwp, i, j, k) = M(wp, i, j, k) + M(wm, i, j, k) * rk3coefi;
+      }
+  for (int j = 1; j <= ny; ++j)
+    for (int i = 1; i <= nx; ++i) { M(pwp, i, j, 1) = 0.; M(pwp, i, j, nz + 1) = 0.; }
+  for (int k = 1; k <= nz; ++k)
+    for (int j = 1; j <= ny; ++j) M(pup, nx + 1, j, k) = M(pup, 1, j, k);
+  for (int k = 1; k <= nz; ++k)
+    for (int i = 1; i <= nx; ++i) M(pvp, i, ny + 1, k) = M(pvp, i, 1, k);
+  for (int k = 1; k <= nz; ++k) {
+    double dzfi = 1. / g->dzf[k];
+    for (int j = 1; j <= ny; ++j)
+      for (int i = 1; i <= nx; ++i)
+        M(p, i, j, k) = (M(pup, i + 1, j, k) - M(pup, i, j, k)) * dxi
+                      + (M(pvp, i, j + 1, k) - M(pvp, i, j, k)) * dyi
+                      + (M(pwp, i, j, k + 1) - M(pwp, i, j, k)) * dzfi;
+  }
+}
+
+/* initpois (eigenvalues, tridiagonal coefficients) src/modpois.f90:99-220 and the
+ * POISS_FFT2D branch of poisson :440-712 with solmpj :1107-1166.
+ * Spectral coefficients stay in real arrays with half-complex ordering
+ * [Re0, Re1, Im1, ..., Re(N/2)], exactly like the reference. */
+void orc_poisson_solve(const orc_grid *g, double *p) {
+  const int nx = g->nx, ny = g->ny, nz = g->nz;
+  const double dxi = 1. / g->dx, dyi = 1. / g->dy;
+  /* all 1-based like the Fortran */
+  double *xrt = (double *)calloc((size_t)nx + 2, sizeof(double));
+  double *yrt = (double *)calloc((size_t)ny + 2, sizeof(double));
+  double *a = (double *)calloc(3 * ((size_t)nz + 2), sizeof(double));
+  double *b = a + nz + 2, *c = b + nz + 2;
+  double fac = 1. / (2. * nx);
+  for (int i = 3; i <= nx; i += 2) {
+    double s = sin((double)(i - 1) * M_PI * fac);
+    xrt[i - 1] = -4. * dxi * dxi * (s * s);
+    xrt[i] = xrt[i - 1];
+  }
+  xrt[1] = 0.; xrt[nx] = -4. * dxi * dxi;
+  fac = 1. / (2. * ny);
+  for (int j = 3; j <= ny; j += 2) {
+    double s = sin((double)(j - 1) * M_PI * fac);
+    yrt[j - 1] = -4. * dyi * dyi * (s * s);
+    yrt[j] = yrt[j - 1];
+  }
+  yrt[1] = 0.; yrt[ny] = -4. * dyi * dyi;
+  /* rhobf = rhobh = 1 (src/modfields.f90:571-572) */
+  for (int k = 1; k <= nz; ++k) {
+    a[k] = 1. / (g->dzf[k] * g->dzh[k]);
+    c[k] = 1. / (g->dzf[k] * g->dzh[k + 1]);
+    b[k] = -(a[k] + c[k]);
+  }
+  b[1] = b[1] + a[1];
+  double b_top_N = b[nz] + c[nz];
+  double b_top_D = b[nz] - c[nz];
+  b[nz] = b_top_N;
+  a[1] = 0.; c[nz] = 0.;
+
+  size_t nn = (size_t)nx * ny * nz;
+  double *w = (double *)malloc(sizeof(double) * 3 * nn);      /* w[i + nx*(j + ny*k)], 0-based */
+  double *bxyzrt = w + nn, *d = bxyzrt + nn;
+#define W(a_, i, j, k) a_[(size_t)((i) - 1) + (size_t)nx * ((size_t)((j) - 1) + (size_t)ny * (size_t)((k) - 1))]
+  for (int k = 1; k <= nz; ++k)
+    for (int j = 1; j <= ny; ++j)
+      for (int i = 1; i <= nx; ++i) {
+        W(w, i, j, k) = M(p, i, j, k);
+        double xyzrt = 1. * (xrt[i] + yrt[j] + 0.);
+        if (xyzrt == 0. && k == nz) W(bxyzrt, i, j, k) = b_top_D;
+        else W(bxyzrt, i, j, k) = b[k] + xyzrt;
+      }
+  /* forward x : src/modpois.f90:478-490 */
+  fft_ref_plan *px = fft_ref_plan_create(nx), *py = fft_ref_plan_create(ny);
+  int nmax = nx > ny ? nx : ny;
+  double *line = (double *)malloc(sizeof(double) * (3 * (size_t)nmax + 8));
+  double *spec = line + nmax;
+  fac = 1. / sqrt(nx * 1.);
+  for (int k = 1; k <= nz; ++k)
+    for (int j = 1; j <= ny; ++j) {
+      for (int i = 1; i <= nx; ++i) line[i - 1] = W(w, i, j, k);
+      fft_ref_r2c(px, line, spec);
+      W(w, 1, j, k) = spec[0];
+      for (int i = 1; i <= nx / 2 - 1; ++i) { W(w, 2 * i, j, k) = spec[2 * i]; W(w, 2 * i + 1, j, k) = spec[2 * i + 1]; }
+      W(w, nx, j, k) = spec[2 * (nx / 2)];
+      for (int i = 1; i <= nx; ++i) W(w, i, j, k) = W(w, i, j, k) * fac;
+    }
+  /* forward y : :522-534 */
+  fac = 1. / sqrt(ny * 1.);
+  for (int i = 1; i <= nx; ++i)
+    for (int k = 1; k <= nz; ++k) {
+      for (int j = 1; j <= ny; ++j) line[j - 1] = W(w, i, j, k);
+      fft_ref_r2c(py, line, spec);
+      W(w, i, 1, k) = spec[0];
+      for (int j = 1; j <= ny / 2 - 1; ++j) { W(w, i, 2 * j, k) = spec[2 * j]; W(w, i, 2 * j + 1, k) = spec[2 * j + 1]; }
+      W(w, i, ny, k) = spec[2 * (ny / 2)];
+      for (int j = 1; j <= ny; ++j) W(w, i, j, k) = W(w, i, j, k) * fac;
+    }
+  /* solmpj : :1107-1166 */
+  for (int j = 1; j <= ny; ++j)
+    for (int i = 1; i <= nx; ++i) {
+      double z = 1. / W(bxyzrt, i, j, 1);
+      W(d, i, j, 1) = c[1] * z;
+      W(w, i, j, 1) = W(w, i, j, 1) * z;
+    }
+  for (int k = 2; k <= nz - 1; ++k)
+    for (int j = 1; j <= ny; ++j)
+      for (int i = 1; i <= nx; ++i) {
+        double bbk = W(bxyzrt, i, j, k);
+        double z = 1. / (bbk - a[k] * W(d, i, j, k - 1));
+        W(d, i, j, k) = c[k] * z;
+        W(w, i, j, k) = (W(w, i, j, k) - a[k] * W(w, i, j, k - 1)) * z;
+      }
+  {
+    double ak = a[nz];
+    for (int j = 1; j <= ny; ++j)
+      for (int i = 1; i <= nx; ++i) {
+        double bbk = W(bxyzrt, i, j, nz);
+        double z = bbk - ak * W(d, i, j, nz - 1);
+        W(w, i, j, nz) = (W(w, i, j, nz) - ak * W(w, i, j, nz - 1)) / z;
+      }
+  }
+  for (int k = nz - 1; k >= 1; --k)
+    for (int j = 1; j <= ny; ++j)
+      for (int i = 1; i <= nx; ++i) W(w, i, j, k) = W(w, i, j, k) - W(d, i, j, k) * W(w, i, j, k + 1);
+  /* backward y : :615-625 */
+  fac = 1. / sqrt(ny * 1.);
+  for (int i = 1; i <= nx; ++i)
+    for (int k = 1; k <= nz; ++k) {
+      spec[0] = W(w, i, 1, k); spec[1] = 0.;
+      for (int j = 1; j <= ny / 2 - 1; ++j) { spec[2 * j] = W(w, i, 2 * j, k); spec[2 * j + 1] = W(w, i, 2 * j + 1, k); }
+      spec[2 * (ny / 2)] = W(w, i, ny, k); spec[2 * (ny / 2) + 1] = 0.;
+      fft_ref_c2r(py, spec, line);
+      for (int j = 1; j <= ny; ++j) W(w, i, j, k) = line[j - 1] * fac;
+    }
+  /* backward x : :669-679 */
+  fac = 1. / sqrt(nx * 1.);
+  for (int k = 1; k <= nz; ++k)
+    for (int j = 1; j <= ny; ++j) {
+      spec[0] = W(w, 1, j, k); spec[1] = 0.;
+      for (int i = 1; i <= nx / 2 - 1; ++i) { spec[2 * i] = W(w, 2 * i, j, k); spec[2 * i + 1] = W(w, 2 * i + 1, j, k); }
+      spec[2 * (nx / 2)] = W(w, nx, j, k); spec[2 * (nx / 2) + 1] = 0.;
+      fft_ref_c2r(px, spec, line);
+      for (int i = 1; i <= nx; ++i) W(w, i, j, k) = line[i - 1] * fac;
+    }
+  for (int k = 1; k <= nz; ++k)
+    for (int j = 1; j <= ny; ++j)
+      for (int i = 1; i <= nx; ++i) M(p, i, j, k) = W(w, i, j, k);
+#undef W
+  free(line); free(w);
+  fft_ref_plan_destroy(px); fft_ref_plan_destroy(py);
+  free(xrt); free(yrt); free(a);
+}
+
+/* tderive src/modpois.f90:1001-1105 + bcp src/modboundary.f90:1344-1430 */
+void orc_tderive(const orc_grid *g, double *p, double *up, double *vp, double *wp, double *pres0) {
+  const int nx = g->nx, ny = g->ny, nz = g->nz;
+  const double dxi = 1. / g->dx, dyi = 1. / g->dy;
+  for (int j = 1; j <= ny; ++j)
+    for (int k = 1; k <= nz; ++k) { M(p, 0, j, k) = M(p, nx, j, k); M(p, nx + 1, j, k) = M(p, 1, j, k); }
+  for (int i = 1; i <= nx; ++i)
+    for (int k = 1; k <= nz; ++k) { M(p, i, 0, k) = M(p, i, ny, k); M(p, i, ny + 1, k) = M(p, i, 1, k); }
+  for (int i = 1; i <= nx; ++i)
+    for (int j = 1; j <= ny; ++j) {
+      M(up, i, j, 1) = M(up, i, j, 1) - (M(p, i, j, 1) - M(p, i - 1, j, 1)) * dxi;
+      M(vp, i, j, 1) = M(vp, i, j, 1) - (M(p, i, j, 1) - M(p, i, j - 1, 1)) * dyi;
+      for (int k = 2; k <= nz; ++k) {
+        M(up, i, j, k) = M(up, i, j, k) - (M(p, i, j, k) - M(p, i - 1, j, k)) * dxi;
+        M(vp, i, j, k) = M(vp, i, j, k) - (M(p, i, j, k) - M(p, i, j - 1, k)) * dyi;
+        M(wp, i, j, k) = M(wp, i, j, k) - (M(p, i, j, k) - M(p, i, j, k - 1)) * (1. / g->dzh[k]);
+      }
+    }
+  for (int k = 0; k <= nz + 1; ++k)
+    for (int j = 0; j <= ny + 1; ++j)
+      for (int i = 0; i <= nx + 1; ++i) M(pres0, i, j, k) = M(pres0, i, j, k) + M(p, i, j, k);
+}
+
+/* ====================================================================== time step */
+/* src/modtstep.f90:191-338 (loneeqn, ltempeq, lmoist false) */
+void orc_tstep_integrate(const orc_grid *g, int rk3step, double dt, double *u0, double *v0,
+                         double *w0, double *um, double *vm, double *wm, double *up, double *vp,
+                         double *wp, double *sv0, double *svm, double *svp) {
+  const double rk3coef = dt / (4. - (double)rk3step);
+  const size_t n = msize(g), nc = csize(g);
+  for (int k = 1; k <= g->nz; ++k)
+    for (int j = 1; j <= g->ny; ++j)
+      for (int i = 1; i <= g->nx; ++i) {
+        M(u0, i, j, k) = M(um, i, j, k) + rk3coef * M(up, i, j, k);
+        M(v0, i, j, k) = M(vm, i, j, k) + rk3coef * M(vp, i, j, k);
+        M(w0, i, j, k) = M(wm, i, j, k) + rk3coef * M(wp, i, j, k);
+        for (int s = 0; s < g->nsv; ++s) {
+          const double *pm = svm + s * nc, *pp = svp + s * nc;
+          double *p0 = sv0 + s * nc;
+          C(p0, i, j, k) = C(pm, i, j, k) + rk3coef * C(pp, i, j, k);
+        }
+      }
+  memset(up, 0, n * sizeof(double));
+  memset(vp, 0, n * sizeof(double));
+  memset(wp, 0, n * sizeof(double));
+  if (g->nsv > 0) memset(svp, 0, (size_t)g->nsv * nc * sizeof(double));
+  if (rk3step == 3) {
+    memcpy(um, u0, n * sizeof(double));
+    memcpy(vm, v0, n * sizeof(double));
+    memcpy(wm, w0, n * sizeof(double));
+    if (g->nsv > 0) memcpy(svm, sv0, (size_t)g->nsv * nc * sizeof(double));
+  }
+}
+
+/* ====================================================================== halos, boundary */
+/* xm_periodic then ym_periodic: src/modboundary.f90:508-539, 596-627 (over ALL j / ALL i) */
+void orc_halos_m(const orc_grid *g, double *a) {
+  const int nx = g->nx, ny = g->ny, nz = g->nz;
+  for (int k = 0; k <= nz + 1; ++k)
+    for (int j = 0; j <= ny + 1; ++j) { M(a, 0, j, k) = M(a, nx, j, k); M(a, nx + 1, j, k) = M(a, 1, j, k); }
+  for (int k = 0; k <= nz + 1; ++k)
+    for (int i = 0; i <= nx + 1; ++i) { M(a, i, 0, k) = M(a, i, ny, k); M(a, i, ny + 1, k) = M(a, i, 1, k); }
+}
+/* xs_periodic, ys_periodic: :580-593, 670-685 (halo 2) */
+void orc_halos_c(const orc_grid *g, double *a) {
+  const int nx = g->nx, ny = g->ny, nz = g->nz;
+  for (int m = 1; m <= 2; ++m)
+    for (int k = -1; k <= nz + 2; ++k)
+      for (int j = -1; j <= ny + 2; ++j) {
+        C(a, 1 - m, j, k) = C(a, nx + 1 - m, j, k);
+        C(a, nx + m, j, k) = C(a, m, j, k);
+      }
+  for (int m = 1; m <= 2; ++m)
+    for (int k = -1; k <= nz + 2; ++k)
+      for (int i = -1; i <= nx + 2; ++i) {
+        C(a, i, 1 - m, k) = C(a, i, ny + 1 - m, k);
+        C(a, i, ny + m, k) = C(a, i, m, k);
+      }
+}
+
+static void top_row_m(const orc_grid *g, double *a, double val) {
+  /* fluxtop with zero flux (:1494-1507) or valuetop (:1509-1519), whole padded xy plane */
+  for (int j = 0; j <= g->ny + 1; ++j)
+    for (int i = 0; i <= g->nx + 1; ++i) {
+      if (g->bctopm == 2) M(a, i, j, g->nz + 1) = 2 * val - M(a, i, j, g->nz);
+      else M(a, i, j, g->nz + 1) = M(a, i, j, g->nz);
+    }
+}
+
+/* boundary: src/modboundary.f90:163-247 (w(kb)=0; top ghost rows; scalars zero-flux top
+ * :1521-1537 with flux = 0, which adds exactly 0.0) */
+void orc_boundary(const orc_grid *g, double *u0, double *v0, double *w0, double *um, double *vm,
+                  double *wm, double *sv0, double *svm) {
+  const int nx = g->nx, ny = g->ny, nz = g->nz;
+  const size_t nc = csize(g);
+  for (int j = 0; j <= ny + 1; ++j)
+    for (int i = 0; i <= nx + 1; ++i) { M(wm, i, j, 1) = 0.; M(w0, i, j, 1) = 0.; }
+  top_row_m(g, um, g->uinf); top_row_m(g, u0, g->uinf);
+  top_row_m(g, vm, g->vinf); top_row_m(g, v0, g->vinf);
+  for (int j = 0; j <= ny + 1; ++j)
+    for (int i = 0; i <= nx + 1; ++i) { M(w0, i, j, nz + 1) = 0.; M(wm, i, j, nz + 1) = 0.; }
+  for (int s = 0; s < g->nsv; ++s) {
+    double *p0 = sv0 + s * nc, *pm = svm + s * nc;
+    for (int mm = 1; mm <= 2; ++mm)
+      for (int j = 0; j <= ny + 1; ++j)      /* reference slices ib-ih:ie+ih, jb-jh:je+jh */
+        for (int i = 0; i <= nx + 1; ++i) {
+          C(p0, i, j, nz + mm) = C(p0, i, j, nz) + 0.0;
+          C(pm, i, j, nz + mm) = C(pm, i, j, nz) + 0.0;
+        }
+  }
+}
+
+/* ====================================================================== substep */
+/* src/program.f90:132-222: advection, subgrid, forces, poisson, tstep_integrate, halos, boundary */
+void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
+  const size_t nc = csize(g);
+  const double rk3coef = dt / (4. - (double)rk3step);
+  orc_advecu_2nd(g, s->u0, s->v0, s->w0, s->pres0, s->up);
+  orc_advecv_2nd(g, s->u0, s->v0, s->w0, s->pres0, s->vp);
+  orc_advecw_2nd(g, s->u0, s->v0, s->w0, s->pres0, s->wp);
+  for (int n = 0; n < g->nsv; ++n) orc_advecc_kappa(g, s->u0, s->v0, s->w0, s->sv0 + n * nc, s->svp + n * nc);
+  orc_closure(g, s->u0, s->v0, s->w0, s->ekm, s->ekh);
+  /* reassure_fluxtop_boundary src/modboundary.f90:392-431 (free-slip: re-impose top rows) */
+  if (g->bctopm != 2) {
+    top_row_m(g, s->um, 0.); top_row_m(g, s->u0, 0.); top_row_m(g, s->vm, 0.); top_row_m(g, s->v0, 0.);
+    for (int n = 0; n < g->nsv; ++n) {
+      double *p0 = s->sv0 + n * nc, *pm = s->svm + n * nc;
+      for (int mm = 1; mm <= 2; ++mm)
+        for (int j = 0; j <= g->ny + 1; ++j)
+          for (int i = 0; i <= g->nx + 1; ++i) {
+            C(p0, i, j, g->nz + mm) = C(p0, i, j, g->nz) + 0.0;
+            C(pm, i, j, g->nz + mm) = C(pm, i, j, g->nz) + 0.0;
+          }
+    }
+  }
+  orc_diffu(g, s->u0, s->v0, s->w0, s->ekm, s->up);
+  orc_diffv(g, s->u0, s->v0, s->w0, s->ekm, s->vp);
+  orc_diffw(g, s->u0, s->v0, s->w0, s->ekm, s->wp);
+  for (int n = 0; n < g->nsv; ++n) orc_diffc(g, s->sv0 + n * nc, s->ekh, s->svp + n * nc);
+  if (s->dpdxl) orc_forces(g, s->dpdxl, s->dpdyl, s->up, s->vp, s->wp);
+  orc_fillps(g, rk3coef, s->up, s->vp, s->wp, s->um, s->vm, s->wm, s->pup, s->pvp, s->pwp, s->p);
+  orc_poisson_solve(g, s->p);
+  orc_tderive(g, s->p, s->up, s->vp, s->wp, s->pres0);
+  orc_tstep_integrate(g, rk3step, dt, s->u0, s->v0, s->w0, s->um, s->vm, s->wm, s->up, s->vp, s->wp,
+                      s->sv0, s->svm, s->svp);
+  orc_halos_m(g, s->u0); orc_halos_m(g, s->v0); orc_halos_m(g, s->w0);
+  orc_halos_m(g, s->um); orc_halos_m(g, s->vm); orc_halos_m(g, s->wm);
+  for (int n = 0; n < g->nsv; ++n) { orc_halos_c(g, s->sv0 + n * nc); orc_halos_c(g, s->svm + n * nc); }
+  orc_boundary(g, s->u0, s->v0, s->w0, s->um, s->vm, s->wm, s->sv0, s->svm);
+}

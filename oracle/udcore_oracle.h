@@ -1,0 +1,94 @@
+/* TEST INFRASTRUCTURE -- CPU oracle, NOT the product.
+ *
+ * Plain-C restatement of the reference's per-substep dynamical core
+ * (uDALES: src/modadvection.f90, src/modsubgrid.f90, src/modpois.f90,
+ * src/modtstep.f90 and the modboundary.f90 routines they call), single rank,
+ * periodic x/y, used only by tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg to CHECK the HIP library.  Every function cites the
+ * reference lines it follows.  Pinned against per-routine and multi-substep
+ * vectors produced by the reference's own unmodified Fortran (oracle/_ref,
+ * fixtures in tests/golden/), see tests/test_oracle_vs_reference.py.
+ *
+ * Array conventions (identical to the reference's Fortran storage, i fastest):
+ *   "m-arrays"  (u0,v0,w0,um,vm,wm,pres0,ekm,ekh,p,up,vp,wp,pup,pvp,pwp):
+ *       extents (0:nx+1, 0:ny+1, 0:nz+1), halo 1, so Fortran index == C index:
+ *       a[i + (nx+2)*(j + (ny+2)*k)].  Tendencies use the same box (the k=0
+ *       plane, which the reference does not allocate, is simply unused).
+ *   "c-arrays"  (sv0, svm, svp: kappa-advected scalars): extents
+ *       (-1:nx+2, -1:ny+2, -1:nz+2), halo 2: a[(i+1) + (nx+4)*((j+1) + (ny+4)*(k+1))].
+ *   dzf[0..nz+1]  = dzf(kb-1:ke+1),  dzh[0..nz+1] with dzh[k] = dzh(k), k=1..nz+1.
+ */
+#ifndef UDC_ORACLE_H
+#define UDC_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+  int nx, ny, nz;           /* itot, jtot, ktot (single rank: imax=itot, ...) */
+  double dx, dy;            /* xlen/itot, ylen/jtot (src/modglobal.f90:710-711) */
+  const double *dzf;        /* [nz+2] */
+  const double *dzh;        /* [nz+2], entry 0 unused */
+  double numol;             /* 1.5e-5   src/modglobal.f90:300 */
+  double prandtlmoli;       /* 1/0.71   src/modglobal.f90:303 */
+  double prandtli;          /* 1/Prandtl src/modsubgrid.f90:117 */
+  double c_vreman;          /* 0.07     src/modsubgriddata.f90:61 */
+  double csz;               /* Smagorinsky constant src/modsubgrid.f90:73-77 */
+  int sgs;                  /* 0 = DNS (lles false), 1 = Smagorinsky, 2 = Vreman */
+  int bctopm;               /* 1 free-slip, 2 no-slip (src/modglobal.f90:150-153) */
+  double uinf, vinf;        /* only for no-slip top (valuetop) */
+  int nsv;                  /* passive scalars, kappa scheme (src/modglobal.f90:557-559) */
+} orc_grid;
+
+/* ---- advection: src/modadvection.f90 */
+void orc_advecu_2nd(const orc_grid *g, const double *u0, const double *v0, const double *w0,
+                    const double *pres0, double *up);
+void orc_advecv_2nd(const orc_grid *g, const double *u0, const double *v0, const double *w0,
+                    const double *pres0, double *vp);
+void orc_advecw_2nd(const orc_grid *g, const double *u0, const double *v0, const double *w0,
+                    const double *pres0, double *wp);
+void orc_advecc_kappa(const orc_grid *g, const double *u0, const double *v0, const double *w0,
+                      const double *c, double *cp);
+/* ---- subgrid: src/modsubgrid.f90 + closurebc (src/modboundary.f90:434-505) */
+void orc_closure(const orc_grid *g, const double *u0, const double *v0, const double *w0,
+                 double *ekm, double *ekh);
+void orc_closurebc(const orc_grid *g, double *ekm, double *ekh);
+void orc_diffu(const orc_grid *g, const double *u0, const double *v0, const double *w0,
+               const double *ekm, double *up);
+void orc_diffv(const orc_grid *g, const double *u0, const double *v0, const double *w0,
+               const double *ekm, double *vp);
+void orc_diffw(const orc_grid *g, const double *u0, const double *v0, const double *w0,
+               const double *ekm, double *wp);
+void orc_diffc(const orc_grid *g, const double *c, const double *ekh, double *cp);
+/* ---- forces (neutral branch): src/modforces.f90:46-133 */
+void orc_forces(const orc_grid *g, const double *dpdxl, const double *dpdyl,
+                double *up, double *vp, double *wp);
+/* ---- pressure: src/modpois.f90 (ipoiss = POISS_FFT2D, BCzp = 1, periodic x,y) */
+void orc_fillps(const orc_grid *g, double rk3coef, const double *up, const double *vp,
+                const double *wp, const double *um, const double *vm, const double *wm,
+                double *pup, double *pvp, double *pwp, double *p);
+void orc_poisson_solve(const orc_grid *g, double *p);   /* in: rhs in p interior; out: p interior */
+void orc_tderive(const orc_grid *g, double *p, double *up, double *vp, double *wp, double *pres0);
+/* ---- time stepping: src/modtstep.f90:171-340 */
+void orc_tstep_integrate(const orc_grid *g, int rk3step, double dt, double *u0, double *v0,
+                         double *w0, double *um, double *vm, double *wm, double *up, double *vp,
+                         double *wp, double *sv0, double *svm, double *svp);
+/* ---- halos + boundary (periodic / top / bottom subset): src/modboundary.f90:67-109,115-247 */
+void orc_halos_m(const orc_grid *g, double *a);          /* x then y periodic wrap, halo 1 */
+void orc_halos_c(const orc_grid *g, double *a);          /* halo 2 */
+void orc_boundary(const orc_grid *g, double *u0, double *v0, double *w0, double *um, double *vm,
+                  double *wm, double *sv0, double *svm);
+
+/* ---- whole substep, src/program.f90:132-222 restricted to the dynamical core */
+typedef struct {
+  double *u0, *v0, *w0, *um, *vm, *wm, *up, *vp, *wp, *pres0, *ekm, *ekh, *p, *pup, *pvp, *pwp;
+  double *sv0, *svm, *svp;                /* nsv consecutive c-arrays each */
+  const double *dpdxl, *dpdyl;            /* [nz+2] indexed by Fortran k, or NULL (no forces) */
+} orc_state;
+void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory.
+
+Runs oracle/_ref/udales_ref -- the reference's own UNMODIFIED Fortran for the hot path
+(src/modadvection.f90, modsubgrid.f90, modpois.f90, modtstep.f90, modboundary.f90, ...)
+compiled from /root/reference/src by oracle/Makefile against single-rank shims -- on the
+small decks defined below, and stores the inputs/outputs it dumps.  The fixtures are data
+only (fields in, fields out); no reference source text is stored.
+
+    python tests/golden/make_golden.py          # needs oracle/_ref/udales_ref (make -C oracle ref)
+
+Fixture format: the record stream of oracle/ref_driver.f90 (see tests/refdump.py), gzip'ed,
+plus the input deck files of each case under cases/<name>/ so that the same namoptions drive
+the device library.
+"""
+import gzip
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from refdump import read_dump, write_dump  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref", "udales_ref")
+
+
+def deck(iexpnr, nx, ny, nz, dx=0.5, dy=0.5, dtmax=0.25, sgs="vreman", nsv=0, bctopm=1,
+         oracle="", lles=True, randu=0.01):
+    sub = {"vreman": "lvreman = .true.\nlsmagorinsky = .false.",
+           "smag": "lsmagorinsky = .true.\nlvreman = .false.",
+           "dns": "lvreman = .false.\nlsmagorinsky = .false."}[sgs]
+    return f"""&RUN
+iexpnr = {iexpnr}
+runtime = 1000.
+dtmax = {dtmax}
+ladaptive = .false.
+irandom = 43
+randu = {randu}
+nprocx = 1
+nprocy = 1
+libm = .false.
+lles = {'.true.' if lles else '.false.'}
+/
+&DOMAIN
+itot = {nx}
+jtot = {ny}
+ktot = {nz}
+xlen = {nx * dx}
+ylen = {ny * dy}
+/
+&PHYSICS
+/
+&DYNAMICS
+ipoiss = 0
+/
+&BC
+BCtopm = {bctopm}
+/
+&SCALARS
+nsv = {nsv}
+/
+&NAMSUBGRID
+{sub}
+/
+&ORACLE
+{oracle}
+/
+"""
+
+
+def zlevels(nz, dz0=0.5, stretch=1.0):
+    zf, zh = [], 0.0
+    dz = dz0
+    for _ in range(nz):
+        zf.append(zh + 0.5 * dz)
+        zh += dz
+        dz *= stretch
+    return zf
+
+
+def write_case(d, iexpnr, text, zf, u=1.0, v=0.0, pgx=1e-4):
+    with open(os.path.join(d, f"namoptions.{iexpnr:03d}"), "w") as f:
+        f.write(text)
+    with open(os.path.join(d, f"prof.inp.{iexpnr:03d}"), "w") as f:
+        f.write("# golden\n# z thl qt u v tke\n")
+        for z in zf:
+            f.write(f"{z:.15f} 288.0 0.0 {u} {v} 0.0\n")
+    with open(os.path.join(d, f"lscale.inp.{iexpnr:03d}"), "w") as f:
+        f.write("# golden\n# z uq vq pqx pqy wfls dqtdxls dqtdyls dqtdtls dthlrad\n")
+        for z in zf:
+            f.write(f"{z:.15f} 0.0 0.0 {pgx} 0.0 0.0 0.0 0.0 0.0 0.0\n")
+
+
+KEEP_KERNELS = ("meta dzf dzh zf dpdxl dpdyl rk3 in.u0 in.v0 in.w0 in.um in.vm in.wm in.pres0 "
+                "in.ekm in.ekh adv.up adv.vp adv.wp sub.ekm sub.ekh sub.u0 sub.up sub.vp sub.wp "
+                "pre.up pre.vp pre.wp poi.p poi.pres0 poi.up poi.vp poi.wp out.u0 out.v0 out.w0 "
+                "out.um out.pres0").split()
+
+CASES = {
+    # name: (mode, iexpnr, nx, ny, nz, kwargs, stretch)
+    "k_vreman_12x8x6": ("kernels", 11, 12, 8, 6, dict(sgs="vreman", oracle="nspin = 2"), 1.0),
+    "k_smag_8x12x10s": ("kernels", 12, 8, 12, 10, dict(sgs="smag", oracle="nspin = 4"), 1.08),
+    "k_noslip_8x8x6": ("kernels", 13, 8, 8, 6, dict(sgs="vreman", bctopm=2, oracle="nspin = 3"), 1.0),
+    "k_scalar_8x8x8": ("kernels", 14, 8, 8, 8, dict(sgs="smag", nsv=2, oracle="nspin = 5"), 1.05),
+    "k_dns_8x8x6": ("kernels", 15, 8, 8, 6, dict(sgs="dns", lles=False, oracle="nspin = 2"), 1.0),
+    "run_16x16x8": ("run", 21, 16, 16, 8, dict(sgs="vreman", oracle="nsub = 9\ndump_at = 1, 3, 9"), 1.0),
+    "run_smag_scalar_16x8x12s": ("run", 22, 16, 8, 12,
+                                 dict(sgs="smag", nsv=1, oracle="nsub = 6\ndump_at = 3, 6"), 1.06),
+}
+
+
+def main():
+    if not os.path.exists(REF):
+        sys.exit(f"{REF} missing: run `make -C oracle ref` in the build container first")
+    for name, (mode, iexp, nx, ny, nz, kw, stretch) in CASES.items():
+        cdir = os.path.join(HERE, "cases", name)
+        os.makedirs(cdir, exist_ok=True)
+        write_case(cdir, iexp, deck(iexp, nx, ny, nz, **kw), zlevels(nz, 0.5, stretch))
+        with tempfile.TemporaryDirectory() as tmp:
+            for fn in os.listdir(cdir):
+                shutil.copy(os.path.join(cdir, fn), tmp)
+            out = os.path.join(tmp, "out.bin")
+            subprocess.check_call([REF, f"namoptions.{iexp:03d}", mode, out], cwd=tmp)
+            d = read_dump(out)
+        if mode == "kernels":
+            keep = {k: v for k, v in d.items()
+                    if k in KEEP_KERNELS or ".sv" in k}
+        else:
+            keep = {k: v for k, v in d.items()
+                    if k.count(".") == 0 or k.split(".")[1] in ("u0", "v0", "w0", "pres0", "um")
+                    or k.startswith("s000.") or ".sv0" in k}
+        tmpf = os.path.join(HERE, name + ".bin")
+        write_dump(tmpf, keep)
+        with open(tmpf, "rb") as f, gzip.GzipFile(tmpf + ".gz", "wb", mtime=0) as g:
+            g.write(f.read())
+        os.remove(tmpf)
+        print(f"{name}: {len(keep)} records, {os.path.getsize(tmpf + '.gz') / 1024:.0f} kB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,130 @@
+"""ctypes binding of the CPU oracle (oracle/_ref/liboracle.so) -- TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+Arrays are numpy float64, C-contiguous, shaped [k, j, i] (== Fortran (i, j, k) storage):
+m-arrays (nz+2, ny+2, nx+2), c-arrays (nz+4, ny+4, nx+4).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "oracle", "_ref", "liboracle.so")
+
+DP = C.POINTER(C.c_double)
+
+
+class OrcGrid(C.Structure):
+    _fields_ = [("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int),
+                ("dx", C.c_double), ("dy", C.c_double),
+                ("dzf", DP), ("dzh", DP),
+                ("numol", C.c_double), ("prandtlmoli", C.c_double), ("prandtli", C.c_double),
+                ("c_vreman", C.c_double), ("csz", C.c_double),
+                ("sgs", C.c_int), ("bctopm", C.c_int),
+                ("uinf", C.c_double), ("vinf", C.c_double), ("nsv", C.c_int)]
+
+
+class OrcState(C.Structure):
+    _fields_ = [(n, DP) for n in ("u0", "v0", "w0", "um", "vm", "wm", "up", "vp", "wp", "pres0",
+                                  "ekm", "ekh", "p", "pup", "pvp", "pwp", "sv0", "svm", "svp",
+                                  "dpdxl", "dpdyl")]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"],
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build()
+        _lib = C.CDLL(LIB)
+    return _lib
+
+
+def ptr(a):
+    if a is None:
+        return C.cast(None, DP)
+    assert a.dtype == np.float64 and a.flags.c_contiguous
+    return a.ctypes.data_as(DP)
+
+
+class Oracle:
+    """Grid + convenience wrappers around the orc_* functions."""
+
+    def __init__(self, nx, ny, nz, dx, dy, dzf, dzh, sgs=2, bctopm=1, nsv=0, numol=1.5e-5,
+                 prandtlmoli=1. / 0.71, prandtli=1. / 0.333, c_vreman=0.07, csz=None,
+                 uinf=0., vinf=0.):
+        self.nx, self.ny, self.nz, self.nsv = nx, ny, nz, nsv
+        self.dzf = np.ascontiguousarray(dzf, dtype=np.float64)
+        self.dzh = np.ascontiguousarray(dzh, dtype=np.float64)
+        assert self.dzf.shape == (nz + 2,) and self.dzh.shape == (nz + 2,)
+        if csz is None:
+            cf, alpha = 2.5, 1.5
+            cm = cf / (2. * np.pi) * (1.5 * alpha) ** (-1.5)
+            ceps = 2. * np.pi / cf * (1.5 * alpha) ** (-1.5)
+            csz = (cm ** 3 / ceps) ** 0.25
+        self.g = OrcGrid(nx, ny, nz, dx, dy, ptr(self.dzf), ptr(self.dzh), numol, prandtlmoli,
+                         prandtli, c_vreman, csz, sgs, bctopm, uinf, vinf, nsv)
+        self.L = lib()
+
+    def mshape(self):
+        return (self.nz + 2, self.ny + 2, self.nx + 2)
+
+    def cshape(self):
+        return (self.nz + 4, self.ny + 4, self.nx + 4)
+
+    def call(self, name, *args):
+        f = getattr(self.L, name)
+        f.restype = None
+        cargs = [C.byref(self.g)]
+        for a in args:
+            if isinstance(a, np.ndarray) or a is None:
+                cargs.append(ptr(a))
+            elif isinstance(a, float):
+                cargs.append(C.c_double(a))
+            elif isinstance(a, int):
+                cargs.append(C.c_int(a))
+            else:
+                cargs.append(a)
+        f(*cargs)
+
+    def substep(self, st: dict, rk3step: int, dt: float):
+        s = OrcState(*[ptr(st.get(n)) for n, _ in OrcState._fields_])
+        f = self.L.orc_substep
+        f.restype = None
+        f(C.byref(self.g), C.byref(s), C.c_int(rk3step), C.c_double(dt))
+
+
+def fft_r2c(x):
+    L = lib()
+    n = len(x)
+    L.fft_ref_plan_create.restype = C.c_void_p
+    p = C.c_void_p(L.fft_ref_plan_create(C.c_int(n)))
+    xin = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.zeros(2 * (n // 2 + 1))
+    L.fft_ref_r2c(p, ptr(xin), ptr(out))
+    L.fft_ref_plan_destroy(p)
+    return out[0::2] + 1j * out[1::2]
+
+
+def fft_c2r(X, n):
+    L = lib()
+    L.fft_ref_plan_create.restype = C.c_void_p
+    p = C.c_void_p(L.fft_ref_plan_create(C.c_int(n)))
+    xin = np.zeros(2 * (n // 2 + 1))
+    xin[0::2] = X.real
+    xin[1::2] = X.imag
+    out = np.zeros(n)
+    L.fft_ref_c2r(p, ptr(xin), ptr(out))
+    L.fft_ref_plan_destroy(p)
+    return out

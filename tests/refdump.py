@@ -1,0 +1,80 @@
+"""Reader/writer for the record stream written by oracle/ref_driver.f90 (put1/put3).
+
+Each record: 16-char name, 7 x int32 (rank, lb[3], ub[3]), then the real(8) payload in
+Fortran (column-major, i fastest) order.  Arrays come back as ``Field`` = ndarray indexed
+[k, j, i] (C order view of the Fortran layout) plus the Fortran lower bounds, so that
+``f.at(i, j, k)`` uses the reference's own index conventions.
+"""
+from __future__ import annotations
+
+import io
+import struct
+from dataclasses import dataclass
+
+import numpy as np
+
+
+@dataclass
+class Field:
+    data: np.ndarray      # 3-D: [k, j, i]; 1-D: [k]
+    lb: tuple             # Fortran lower bounds (i, j, k) or (k,)
+
+    def at(self, *idx):
+        if self.data.ndim == 1:
+            return self.data[idx[0] - self.lb[0]]
+        i, j, k = idx
+        return self.data[k - self.lb[2], j - self.lb[1], i - self.lb[0]]
+
+    def box(self, i0, i1, j0, j1, k0, k1):
+        """Inclusive Fortran index box -> ndarray [k, j, i]."""
+        li, lj, lk = self.lb
+        return self.data[k0 - lk:k1 - lk + 1, j0 - lj:j1 - lj + 1, i0 - li:i1 - li + 1]
+
+
+def read_dump(path_or_bytes) -> dict:
+    if isinstance(path_or_bytes, (bytes, bytearray)):
+        buf = bytes(path_or_bytes)
+    else:
+        with open(path_or_bytes, "rb") as f:
+            buf = f.read()
+    out = {}
+    pos = 0
+    n = len(buf)
+    while pos < n:
+        name = buf[pos:pos + 16].decode("ascii").strip()
+        pos += 16
+        hdr = struct.unpack_from("<7i", buf, pos)
+        pos += 28
+        rank = hdr[0]
+        if rank == 1:
+            lb, ub = hdr[1], hdr[4]
+            cnt = ub - lb + 1
+            a = np.frombuffer(buf, dtype="<f8", count=cnt, offset=pos).copy()
+            out[name] = Field(a, (lb,))
+        else:
+            lb = hdr[1:4]
+            ub = hdr[4:7]
+            shp = tuple(ub[d] - lb[d] + 1 for d in range(3))
+            cnt = shp[0] * shp[1] * shp[2]
+            a = np.frombuffer(buf, dtype="<f8", count=cnt, offset=pos).copy()
+            a = a.reshape(shp[2], shp[1], shp[0])   # [k, j, i]
+            out[name] = Field(a, tuple(lb))
+        pos += 8 * cnt
+    return out
+
+
+def write_dump(path, fields: dict):
+    """Inverse of read_dump (used to store trimmed golden fixtures)."""
+    bio = io.BytesIO()
+    for name, f in fields.items():
+        bio.write(name.encode("ascii").ljust(16))
+        if f.data.ndim == 1:
+            lb = f.lb[0]
+            hdr = (1, lb, 0, 0, lb + f.data.shape[0] - 1, 0, 0)
+        else:
+            nk, nj, ni = f.data.shape
+            hdr = (3, f.lb[0], f.lb[1], f.lb[2], f.lb[0] + ni - 1, f.lb[1] + nj - 1, f.lb[2] + nk - 1)
+        bio.write(struct.pack("<7i", *hdr))
+        bio.write(np.ascontiguousarray(f.data, dtype="<f8").tobytes())
+    with open(path, "wb") as fh:
+        fh.write(bio.getvalue())
