@@ -1,0 +1,130 @@
+/* udcore.h -- C ABI of libudcore.so, the MI355X-native dynamical core for uDALES.
+ *
+ * The reference has no FFI: its seam is four Fortran modules whose argument-less
+ * procedures work on module-global arrays.  Each entry point
+ * below replaces one of those procedures; the Fortran drop-in modules in
+ * u-dales_amd/fortran/ (same module and procedure names as the reference) are thin
+ * ISO_C_BINDING wrappers over these symbols -- see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; the message is
+ *     available from udc_last_error().  Nothing here calls exit().
+ *   - plain pointers and sizes only; host arrays are owned by the caller (Fortran's
+ *     modfields), device arrays by the library; no host pointer is retained.
+ *   - host 3-D arrays are Fortran-ordered (i fastest) real(8) with inclusive index
+ *     bounds lb[3]..ub[3] given in the reference's own (1-based interior) indexing,
+ *     e.g. u0(ib-ih:ie+ih, jb-jh:je+jh, kb-kh:ke+kh) -> lb={0,0,0}, ub={nx+1,ny+1,nz+1}.
+ *   - one handle per GPU / per rank; calls on a handle are serialised by the caller
+ *     (the reference is single-threaded per rank).  Entry points are asynchronous on the
+ *     handle's HIP stream unless stated; udc_field_download() and udc_sync() synchronise.
+ */
+#ifndef UDCORE_H
+#define UDCORE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct udc_handle udc_handle;
+
+/* Field identifiers (reference array it mirrors, src/modfields.f90:30-80,
+ * src/modsubgriddata.f90:64-73, src/modpois.f90:44-46) */
+enum {
+  UDC_U0 = 0, UDC_V0, UDC_W0,        /* velocities, current RK stage            */
+  UDC_UM, UDC_VM, UDC_WM,            /* velocities, start of time step          */
+  UDC_UP, UDC_VP, UDC_WP,            /* tendencies                              */
+  UDC_PRES0,                         /* modified pressure                       */
+  UDC_P,                             /* pressure correction (modpois: p)        */
+  UDC_EKM, UDC_EKH,                  /* eddy viscosity / diffusivity            */
+  UDC_SV0,                           /* passive scalar n: UDC_SV0 + 3*n  (sv0)  */
+  UDC_SVM,                           /*                   UDC_SVM + 3*n  (svm)  */
+  UDC_SVP,                           /*                   UDC_SVP + 3*n  (svp)  */
+  UDC_FIELD_MAX = UDC_SV0 + 3 * 16
+};
+
+/* SGS closure selector: &NAMSUBGRID lsmagorinsky / lvreman (src/modsubgriddata.f90:39-42),
+ * DNS = lles .false. (src/modglobal.f90:194) */
+enum { UDC_SGS_DNS = 0, UDC_SGS_SMAGORINSKY = 1, UDC_SGS_VREMAN = 2 };
+/* BCtopm (src/modglobal.f90:150-153) */
+enum { UDC_TOP_FREESLIP = 1, UDC_TOP_NOSLIP = 2 };
+
+/* Everything the reference's initglobal / initsubgrid / initpois derive the kernels'
+ * constants from (src/modglobal.f90:536-874, src/modsubgrid.f90:44-79, src/modpois.f90:66-220). */
+typedef struct udc_config {
+  int itot, jtot, ktot;     /* global grid (&DOMAIN)                                     */
+  int nranks, rank;         /* y-slab decomposition: nprocx = 1, nprocy = nranks          */
+  int device;               /* HIP device ordinal for this rank                           */
+  double dx, dy;            /* xlen/itot, ylen/jtot                                       */
+  const double *dzf;        /* [ktot+2] = dzf(kb-1:ke+1)   (copied)                       */
+  const double *dzh;        /* [ktot+2], entry k = dzh(k), k = 1..ktot+1 (entry 0 unused) */
+  double numol;             /* src/modglobal.f90:300                                      */
+  double prandtlmoli;       /* src/modglobal.f90:303                                      */
+  double prandtli;          /* 1/Prandtl, src/modsubgrid.f90:117                          */
+  double c_vreman;          /* src/modsubgriddata.f90:61                                  */
+  double csz;               /* Smagorinsky constant, src/modsubgrid.f90:73-77             */
+  int sgs;                  /* UDC_SGS_*                                                  */
+  int bctopm;               /* UDC_TOP_*                                                  */
+  double uinf, vinf;        /* no-slip top wall velocity (valuetop)                       */
+  int nsv;                  /* passive scalars (kappa scheme, src/modglobal.f90:557-559)  */
+} udc_config;
+
+/* ---- lifetime ------------------------------------------------------------------- */
+/* replaces initfields/initsubgrid/initpois allocations (src/program.f90:77-89) */
+int udc_create(const udc_config *cfg, udc_handle **out);
+/* replaces exitsubgrid/exitpois (src/modstartup.f90:2352-2353) */
+int udc_destroy(udc_handle *h);
+const char *udc_last_error(void);
+int udc_version(void);
+
+/* ---- multi-GPU (RCCL over xGMI replaces 2decomp-fft's MPI) --- */
+/* id must point to 128 bytes; rank 0 fills it and the host broadcasts it (MPI_Bcast in the
+ * Fortran driver, torch.distributed in bench.py), then every rank calls udc_comm_init. */
+int udc_comm_unique_id(unsigned char id[128]);
+int udc_comm_init(udc_handle *h, const unsigned char id[128]);
+
+/* ---- host <-> device residency --------------------------------------------------- */
+int udc_field_upload(udc_handle *h, int field, const double *host, const int lb[3], const int ub[3]);
+int udc_field_download(udc_handle *h, int field, double *host, const int lb[3], const int ub[3]);
+/* dpdxl(kb:ke), dpdyl(kb:ke) of modfields (src/modstartup.f90:2071-2081); n = ktot */
+int udc_set_forcing(udc_handle *h, const double *dpdxl, const double *dpdyl, int n);
+
+/* ---- the reference's call surface (src/program.f90:134-207) ----------------------- */
+/* advection   src/modadvection.f90:36   up,vp,wp (+svp) -= div(u phi) (+ grad pres0)     */
+int udc_advection(udc_handle *h);
+/* subgrid     src/modsubgrid.f90:128    closure+closurebc, then diffu/diffv/diffw/diffc  */
+int udc_subgrid(udc_handle *h);
+/* forces      src/modforces.f90:46      neutral branch: up -= dpdxl(k), vp -= dpdyl(k), wp(kb)=0 */
+int udc_forces(udc_handle *h);
+/* poisson     src/modpois.f90:419       fillps+bcpup, FFT(x,y)+tridiagonal(z), tderive+bcp */
+int udc_poisson(udc_handle *h, int rk3step, double dt);
+/* tstep_integrate src/modtstep.f90:171  u0 = um + rk3coef*up ..., zero tendencies, m <- 0 on stage 3 */
+int udc_tstep_integrate(udc_handle *h, int rk3step, double dt);
+/* halos       src/modboundary.f90:67    periodic x (index wrap) and y (slab exchange / wrap) ghosts */
+int udc_halos(udc_handle *h);
+/* boundary    src/modboundary.f90:115   w(kb)=0 and top ghost rows (periodic lateral subset) */
+int udc_boundary(udc_handle *h);
+/* tstep_update src/modtstep.f90:49      adaptive dt: returns max Courant and diffusion numbers
+ * (already max-reduced over ranks); the caller applies dt = min(dtmax, dt*courant/C, dt*diffnr/D). */
+int udc_tstep_maxima(udc_handle *h, double dt, double *courtot, double *diffnrtot);
+
+/* One whole RK3 substep = advection, subgrid, forces, poisson, tstep_integrate, halos,
+ * boundary in the reference's order, with kernels fused across routine boundaries. */
+int udc_substep(udc_handle *h, int rk3step, double dt, int with_forces);
+/* n substeps with fixed dt, rk3step cycling 1,2,3 starting from rk3step0 */
+int udc_run(udc_handle *h, int nsubsteps, int rk3step0, double dt, int with_forces);
+
+/* divergence of u0 as modchecksim's chkdiv (src/modchecksim.f90:161-203): max |div|, sum div */
+int udc_divergence(udc_handle *h, double *divmax, double *divtot);
+
+int udc_sync(udc_handle *h);
+
+/* ---- measurement: HIP-event timing of every kernel launch on the library's stream --- */
+int udc_profile_enable(udc_handle *h, int on);
+int udc_profile_reset(udc_handle *h);
+/* returns the number of distinct kernels; fills up to cap entries */
+int udc_profile_get(udc_handle *h, int cap, char names[][64], double *total_ms, int *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,309 @@
+"""GPU parity tests: libudcore (through the C ABI) against
+  (a) golden vectors produced by the reference's own Fortran (tests/golden),
+  (b) the CPU oracle on seeded inputs at sizes it finishes in seconds,
+  (c) size-independent properties at BASELINE.json's 256^3 (divergence-free projection,
+      periodic-shift equivariance).
+
+Floating-point tolerances (real(8) everywhere, stated as error / max|reference field|):
+  KERNEL_TOL 1e-11 : one routine; differences come from FMA contraction and, for the Poisson
+                     solve, from rocFFT vs the FFTW-convention DFT used on the CPU side.
+  RUN_TOL    1e-9  : a handful of chained substeps.
+The north star's acceptance bar is 1e-6 after 100 steps (tests/test_gpu_long.py).
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from common import (KERNEL_CASES, RUN_CASES, carr, deck_path, interior, load_fixture, marr, nocorner,
+                    relerr)
+from udcore import read_deck, sgs_from_deck, cold_start
+from udcore.grid import Grid
+from udcore import lib as L
+
+pytestmark = pytest.mark.gpu
+
+KERNEL_TOL = 1e-11
+RUN_TOL = 1e-9
+
+
+def core_from_deck(name, iexp):
+    import udcore
+    d = read_deck(deck_path(name, iexp))
+    return d, udcore.from_deck(d)
+
+
+def upload_inputs(core, fix, tag, g, nsv):
+    for k in ("u0", "v0", "w0", "um", "vm", "wm", "pres0"):
+        core.upload(k, marr(fix, f"{tag}.{k}", g.nz))
+    for k in ("ekm", "ekh"):
+        if f"{tag}.{k}" in fix:
+            core.upload(k, np.nan_to_num(marr(fix, f"{tag}.{k}", g.nz)))
+    for n in range(nsv):
+        c = carr(fix, f"{tag}.sv0_{n + 1:02d}", g.nz)
+        core.upload(L.scalar_field(L.SV0, n), c)
+        key = f"{tag}.svm_{n + 1:02d}"
+        core.upload(L.scalar_field(L.SVM, n), carr(fix, key, g.nz) if key in fix else c)
+
+
+@pytest.mark.parametrize("name,iexp", sorted(KERNEL_CASES.items()))
+def test_each_routine_matches_reference(name, iexp):
+    """udc_advection / udc_subgrid / udc_forces / udc_poisson / udc_tstep_integrate, one at a time,
+    on the inputs and outputs the reference's own routines produced."""
+    fix = load_fixture(name)
+    d, core = core_from_deck(name, iexp)
+    g, nsv, nz = core.g, core.nsv, core.g.nz
+    upload_inputs(core, fix, "in", g, nsv)
+    zero = np.zeros(g.mshape())
+
+    def zero_tend():
+        for k in ("up", "vp", "wp"):
+            core.upload(k, zero)
+        for n in range(nsv):
+            core.upload(L.scalar_field(L.SVP, n), np.zeros(g.cshape()))
+
+    zero_tend()
+    core.advection()
+    for k in ("up", "vp", "wp"):
+        assert relerr(interior(core.download(k)), interior(marr(fix, "adv." + k, nz))) <= KERNEL_TOL, k
+    for n in range(nsv):
+        got = core.download(L.scalar_field(L.SVP, n), halo=2)
+        assert relerr(interior(got, 2), interior(carr(fix, f"adv.svp_{n + 1:02d}", nz), 2)) <= KERNEL_TOL
+
+    zero_tend()
+    core.subgrid()
+    ekm, ekh = core.download("ekm"), core.download("ekh")
+    assert relerr(ekm, marr(fix, "sub.ekm", nz)) <= KERNEL_TOL          # ghosts included (closurebc)
+    assert relerr(ekh, marr(fix, "sub.ekh", nz)) <= KERNEL_TOL
+    assert relerr(core.download("u0"), marr(fix, "sub.u0", nz)) <= KERNEL_TOL   # reassure_fluxtop row
+    for k in ("up", "vp", "wp"):
+        assert relerr(interior(core.download(k)), interior(marr(fix, "sub." + k, nz))) <= KERNEL_TOL, k
+    for n in range(nsv):
+        got = core.download(L.scalar_field(L.SVP, n), halo=2)
+        assert relerr(interior(got, 2), interior(carr(fix, f"sub.svp_{n + 1:02d}", nz), 2)) <= KERNEL_TOL
+
+    # full tendency as the reference driver had it, then forces (already inside pre.*), poisson
+    zero_tend()
+    core.advection()
+    core.subgrid()
+    core.forces()
+    for k in ("up", "vp", "wp"):
+        assert relerr(interior(core.download(k)), interior(marr(fix, "pre." + k, nz))) <= KERNEL_TOL, k
+    core.rk3step, core.dt = int(fix["rk3"].data[0]), float(fix["rk3"].data[1])
+    core.poisson()
+    # p solves lap(p) = div(up + um/rk3coef): its round-off floor is set by the O(U/rk3coef) terms
+    # that cancel in the divergence, so errors are measured against the natural pressure scale
+    # U*dx/rk3coef (or |p| itself when that is larger), not against a possibly tiny |p|.
+    rk3coef = core.dt / (4. - core.rk3step)
+    pnat = 1e-2 * np.abs(marr(fix, "in.um", nz)).max() * g.dx / rk3coef
+    pscale = max(np.abs(marr(fix, "poi.p", nz)).max(), np.abs(marr(fix, "poi.pres0", nz)).max(), pnat)
+    assert relerr(interior(core.download("p")), interior(marr(fix, "poi.p", nz)), pscale) <= KERNEL_TOL
+    pres = core.download("pres0")
+    assert relerr(nocorner(pres[1:-1]), nocorner(marr(fix, "poi.pres0", nz)[1:-1]), pscale) <= KERNEL_TOL
+    for k in ("up", "vp", "wp"):
+        assert relerr(interior(core.download(k)), interior(marr(fix, "poi." + k, nz))) <= KERNEL_TOL, k
+    core.tstep_integrate()
+    core.halos()
+    core.boundary()
+    for k in ("u0", "v0", "w0", "um", "pres0"):
+        ref = marr(fix, "out." + k, nz)
+        sc = pscale if k == "pres0" else None
+        assert relerr(nocorner(core.download(k)[1:-1]), nocorner(ref[1:-1]), sc) <= KERNEL_TOL, k
+    core.close()
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("name,iexp", sorted(RUN_CASES.items()))
+def test_substeps_match_reference(name, iexp, fused):
+    """Chained substeps from the cold start, both through the fused udc_substep and through the
+    reference's routine-by-routine call order."""
+    fix = load_fixture(name)
+    d, core = core_from_deck(name, iexp)
+    g, nsv = core.g, core.nsv
+    st = cold_start(g, d, nsv=nsv)
+    core.load_state(st)
+    dt = float(d.get("RUN", "dtmax"))
+    dumps = sorted(int(k[1:4]) for k in fix if k.endswith(".u0") and k != "s000.u0")
+    for isub in range(1, max(dumps) + 1):
+        if fused:
+            rk = (isub - 1) % 3 + 1
+            core.substep(rk, dt, with_forces=True)
+        else:
+            core.tstep_update(dt)
+            core.advection(); core.subgrid(); core.forces(); core.poisson()
+            core.tstep_integrate(); core.halos(); core.boundary()
+        if isub in dumps:
+            tag = f"s{isub:03d}"
+            for k in ("u0", "v0", "w0", "pres0"):
+                ref = marr(fix, f"{tag}.{k}", g.nz)
+                assert relerr(nocorner(core.download(k)[1:-1]), nocorner(ref[1:-1])) <= RUN_TOL, (tag, k)
+            for n in range(nsv):
+                got = core.download(L.scalar_field(L.SV0, n), halo=2)
+                ref = carr(fix, f"{tag}.sv0_{n + 1:02d}", g.nz)
+                assert relerr(interior(got, 2), interior(ref, 2)) <= RUN_TOL
+    core.close()
+
+
+def random_state(g, seed, nsv=0, amp=0.05):
+    rng = np.random.default_rng(seed)
+    st = {}
+    for k, base in (("u0", 1.0), ("v0", 0.2), ("w0", 0.0)):
+        a = np.zeros(g.mshape())
+        a[1:-1, 1:-1, 1:-1] = base + amp * rng.standard_normal((g.nz, g.ny, g.nx))
+        st[k] = a
+    st["w0"][1] = 0.
+    for k in ("u0", "v0", "w0"):
+        a = st[k]
+        a[:, :, 0] = a[:, :, -2]; a[:, :, -1] = a[:, :, 1]
+        a[:, 0, :] = a[:, -2, :]; a[:, -1, :] = a[:, 1, :]
+    st["u0"][-1] = st["u0"][-2]; st["v0"][-1] = st["v0"][-2]; st["w0"][-1] = 0.
+    for k, m in (("u0", "um"), ("v0", "vm"), ("w0", "wm")):
+        st[m] = st[k].copy()
+    st["pres0"] = np.zeros(g.mshape())
+    for n in range(nsv):
+        c = np.zeros(g.cshape())
+        zz = (np.arange(g.nz) + 0.5) / g.nz
+        c[2:-2, :, :] = zz[:, None, None] * (n + 1) + 0.1 * rng.standard_normal((g.nz, 1, 1))
+        c[2:-2, 2:-2, 2:-2] += 0.05 * rng.standard_normal((g.nz, g.ny, g.nx))
+        for q in (c,):
+            q[:, :, 0:2] = q[:, :, -4:-2]; q[:, :, -2:] = q[:, :, 2:4]
+            q[:, 0:2, :] = q[:, -4:-2, :]; q[:, -2:, :] = q[:, 2:4, :]
+        c[0] = c[2]; c[1] = c[2]; c[-2] = c[-3]; c[-1] = c[-3]
+        st[f"sv0_{n}"] = c
+        st[f"svm_{n}"] = c.copy()
+    return st
+
+
+def oracle_state(st, g, nsv):
+    o = {k: v.copy() for k, v in st.items() if not k.startswith("sv")}
+    for k in ("up", "vp", "wp", "ekm", "ekh", "p", "pup", "pvp", "pwp"):
+        o[k] = np.zeros(g.mshape())
+    if nsv:
+        o["sv0"] = np.stack([st[f"sv0_{n}"] for n in range(nsv)])
+        o["svm"] = o["sv0"].copy()
+        o["svp"] = np.zeros_like(o["sv0"])
+    return o
+
+
+@pytest.mark.parametrize("shape,sgs,nsv,stretch", [
+    ((64, 48, 40), 2, 0, 1.03),      # Vreman, stretched z
+    ((48, 64, 24), 1, 1, 1.00),      # Smagorinsky + kappa scalar
+    ((20, 12, 10), 2, 0, 1.00),      # non power-of-two FFT lengths (radix 5, 3)
+    ((4, 4, 3), 0, 0, 1.00),         # smallest grid the library accepts, DNS
+    ((128, 8, 6), 1, 2, 1.10),       # ragged aspect, two scalars
+])
+def test_against_oracle_seeded(shape, sgs, nsv, stretch):
+    """Three substeps (one RK3 step) vs the CPU oracle on seeded random fields."""
+    nx, ny, nz = shape
+    dz = 0.5 * stretch ** np.arange(nz)
+    zf = np.cumsum(dz) - 0.5 * dz
+    g = Grid.from_levels(nx, ny, nz, nx * 0.5, ny * 0.4, zf)
+    from udcore.core import DynCore
+    core = DynCore(g, sgs=sgs, nsv=nsv)
+    o = ol.Oracle(nx, ny, nz, g.dx, g.dy, g.dzf, g.dzh, sgs=sgs, nsv=nsv, csz=0.21658244510412)
+    st = random_state(g, seed=nx * 1000 + ny, nsv=nsv)
+    dp = np.zeros(nz + 2); dp[1:nz + 1] = -1e-3
+    dq = np.zeros(nz + 2); dq[1:nz + 1] = 2e-4
+    core.load_state(st)
+    core.set_forcing(dp[1:nz + 1], dq[1:nz + 1])
+    ost = oracle_state(st, g, nsv)
+    ost["dpdxl"], ost["dpdyl"] = dp, dq
+    dt = 0.05
+    for rk in (1, 2, 3):
+        core.substep(rk, dt, with_forces=True)
+        o.substep(ost, rk, dt)
+    for k in ("u0", "v0", "w0", "pres0", "um"):
+        assert relerr(nocorner(core.download(k)[1:-1]), nocorner(ost[k][1:-1])) <= RUN_TOL, k
+    for n in range(nsv):
+        got = core.download(L.scalar_field(L.SV0, n), halo=2)
+        assert relerr(interior(got, 2), interior(ost["sv0"][n], 2)) <= RUN_TOL
+    divmax, _ = core.divergence()
+    assert divmax < 1e-11
+    core.close()
+
+
+def test_upload_download_roundtrip_and_x_ghosts():
+    g = Grid.uniform(16, 8, 6)
+    from udcore.core import DynCore
+    core = DynCore(g)
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal(g.mshape())
+    core.upload("u0", a)
+    b = core.download("u0")
+    np.testing.assert_array_equal(b[:, :, 1:-1], a[:, :, 1:-1])          # bit exact, y/z ghosts included
+    np.testing.assert_array_equal(b[:, :, 0], a[:, :, -2])               # x ghosts rebuilt as periodic images
+    np.testing.assert_array_equal(b[:, :, -1], a[:, :, 1])
+    c = rng.standard_normal(g.cshape())
+    core2 = DynCore(g, nsv=1)
+    core2.upload(L.scalar_field(L.SV0, 0), c)
+    d = core2.download(L.scalar_field(L.SV0, 0), halo=2)
+    np.testing.assert_array_equal(d[:, :, 2:-2], c[:, :, 2:-2])
+    core.close(); core2.close()
+
+
+def test_error_behaviour():
+    """Bad arguments return an error (never exit): odd itot, unknown field, wrong forcing length."""
+    from udcore.core import DynCore
+    with pytest.raises(L.UdcError, match="even"):
+        DynCore(Grid.uniform(9, 8, 6))
+    core = DynCore(Grid.uniform(8, 8, 6))
+    with pytest.raises(L.UdcError, match="field"):
+        core.upload(L.scalar_field(L.SV0, 0), np.zeros((10, 12, 12)))      # nsv = 0: not allocated
+    with pytest.raises(L.UdcError, match="levels"):
+        core.set_forcing(np.zeros(3), np.zeros(3))
+    core.close()
+
+
+def test_tstep_maxima_matches_numpy():
+    g = Grid.uniform(32, 16, 12)
+    from udcore.core import DynCore
+    core = DynCore(g)
+    st = random_state(g, 11)
+    core.load_state(st)
+    core.substep(1, 0.05, with_forces=False)     # produces ekm/ekh
+    um, vm, wm = (interior(core.download(k)) for k in ("um", "vm", "wm"))
+    ekm, ekh = interior(core.download("ekm")), interior(core.download("ekh"))
+    dt = 0.05
+    dzh = g.dzh[1:g.nz + 1][:, None, None]
+    cour = ((np.abs(um) / g.dx + np.abs(vm) / g.dy + np.abs(wm) / dzh) * dt).max()
+    f = (1. / dzh ** 2 + 1. / g.dx ** 2 + 1. / g.dy ** 2) * dt
+    dif = max(1e-5, (ekm * f).max(), (ekh * f).max())
+    core.dt = dt
+    import ctypes as C
+    c, d = C.c_double(), C.c_double()
+    assert core.lib.udc_tstep_maxima(core.h, C.c_double(dt), C.byref(c), C.byref(d)) == 0
+    assert abs(c.value - cour) <= 1e-12 * cour and abs(d.value - dif) <= 1e-12 * dif
+    core.close()
+
+
+def test_full_size_properties_256():
+    """BASELINE config 2 (256^3): projection leaves a divergence-free field, and a periodic shift
+    of the input by (sx, sy) cells shifts the output (checks FFT/halo wiring at full size)."""
+    from udcore.core import DynCore
+    n = 256
+    g = Grid.uniform(n, n, n)
+    core = DynCore(g, sgs=L.SGS_VREMAN)
+    st = random_state(g, 5, amp=0.02)
+    core.load_state(st)
+    for rk in (1, 2, 3):
+        core.substep(rk, 0.1, with_forces=False)
+    divmax, divtot = core.divergence()
+    assert divmax < 1e-10, divmax
+    u_ref = core.download("u0")
+    sx, sy = 37, 101
+    st2 = {}
+    for k, a in st.items():
+        inner = np.roll(a[:, 1:-1, 1:-1], (sy, sx), axis=(1, 2))
+        b = a.copy()
+        b[:, 1:-1, 1:-1] = inner
+        b[:, :, 0] = b[:, :, -2]; b[:, :, -1] = b[:, :, 1]
+        b[:, 0, :] = b[:, -2, :]; b[:, -1, :] = b[:, 1, :]
+        st2[k] = b
+    core.load_state(st2)
+    for k in ("up", "vp", "wp"):
+        core.upload(k, np.zeros(g.mshape()))
+    for rk in (1, 2, 3):
+        core.substep(rk, 0.1, with_forces=False)
+    u_sh = core.download("u0")
+    exp = np.roll(u_ref[1:-1, 1:-1, 1:-1], (sy, sx), axis=(1, 2))
+    assert relerr(u_sh[1:-1, 1:-1, 1:-1], exp) <= 1e-10
+    core.close()

@@ -1,0 +1,117 @@
+"""CPU tests of the host-side logic and of the C-ABI library's symbol table (no compute calls)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from common import RUN_CASES, KERNEL_CASES, carr, deck_path, load_fixture, marr
+from udcore import read_deck, sgs_from_deck, cold_start
+from udcore.grid import Grid, lcg_noise
+from udcore.namoptions import parse_namelists
+from udcore import lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_namelist_parser_reference_style_deck():
+    text = """&RUN
+iexpnr       = 999
+runtime      = 21.
+ladaptive    = .true.
+nprocx       = 4   ! comment
+/
+
+&DOMAIN
+itot = 128
+xlen = 64
+/
+&DYNAMICS
+iadv_sv = 7, 7
+/
+"""
+    n = parse_namelists(text)
+    assert n["RUN"]["iexpnr"] == 999 and n["RUN"]["ladaptive"] is True and n["RUN"]["nprocx"] == 4
+    assert n["DOMAIN"]["itot"] == 128 and n["DOMAIN"]["xlen"] == 64
+    assert n["DYNAMICS"]["iadv_sv"] == [7, 7]
+
+
+@pytest.mark.parametrize("name,iexp", sorted({**KERNEL_CASES, **RUN_CASES}.items()))
+def test_grid_metrics_match_reference(name, iexp):
+    """Grid.from_deck == initglobal (src/modglobal.f90:747-762) bit for bit."""
+    fix = load_fixture(name)
+    g = Grid.from_deck(read_deck(deck_path(name, iexp)))
+    np.testing.assert_array_equal(g.dzf, fix["dzf"].data)
+    np.testing.assert_array_equal(g.dzh[1:], fix["dzh"].data)
+    meta = fix["meta"].data
+    assert (g.nx, g.ny, g.nz) == tuple(int(x) for x in meta[:3])
+    assert g.dx == meta[3] and g.dy == meta[4]
+
+
+@pytest.mark.parametrize("name,iexp", sorted(KERNEL_CASES.items()))
+def test_sgs_constants_match_reference(name, iexp):
+    fix = load_fixture(name)
+    meta = fix["meta"].data
+    sgs, csz, c_vreman, prandtli = sgs_from_deck(read_deck(deck_path(name, iexp)))
+    assert prandtli == meta[15] and c_vreman == meta[16]
+    assert abs(csz - meta[17]) <= 1e-15
+    assert sgs == (1 if meta[18] else (2 if meta[19] else 0)) * int(meta[21])
+
+
+@pytest.mark.parametrize("name,iexp", sorted(RUN_CASES.items()))
+def test_cold_start_matches_reference(name, iexp):
+    """cold_start == readinitfiles cold start + randomize_field + halos + boundary (s000 dump)."""
+    fix = load_fixture(name)
+    d = read_deck(deck_path(name, iexp))
+    g = Grid.from_deck(d)
+    nsv = int(d.get("SCALARS", "nsv"))
+    st = cold_start(g, d, nsv=nsv)
+    for k in ("u0", "v0", "w0", "um", "vm", "wm"):
+        np.testing.assert_array_equal(st[k], marr(fix, f"s000.{k}", g.nz), err_msg=k)
+    for n in range(nsv):
+        ref = carr(fix, f"s000.sv0_{n + 1:02d}", g.nz)
+        np.testing.assert_array_equal(st[f"sv0_{n}"][:, 1:-1, 1:-1], ref[:, 1:-1, 1:-1])
+
+
+def test_cold_start_slab_equals_global_rows():
+    """The LCG noise is keyed on the global index, so a y-slab gets the same values."""
+    full = lcg_noise(16, 12, 0, 12, 3)
+    part = lcg_noise(16, 12, 4, 4, 3)
+    np.testing.assert_array_equal(full[4:8], part)
+
+
+def test_forcing_matches_reference():
+    import udcore
+    for name, iexp in RUN_CASES.items():
+        fix = load_fixture(name)
+        d = read_deck(deck_path(name, iexp))
+        nz = d.get("DOMAIN", "ktot")
+        dpdx = float(d.get("PHYSICS", "dpdx"))
+        dpdxl = [0.0 * vg - pg - dpdx for vg, pg in zip(d.vg, d.pgx)]
+        np.testing.assert_allclose(dpdxl, fix["dpdxl"].data[:nz], rtol=0, atol=0)
+
+
+def test_header_symbols_are_exported():
+    """libudcore.so loads and exports every entry point include/udcore.h declares."""
+    if not os.path.exists(L.LIBPATH):
+        import __graft_entry__ as ge
+        ge.build()
+    with open(os.path.join(ROOT, "include", "udcore.h")) as f:
+        hdr = f.read()
+    declared = set(re.findall(r"\b(udc_\w+)\s*\(", hdr))
+    assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
+    lib = ctypes.CDLL(L.LIBPATH)
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), sym
+    assert lib.udc_version() >= 100
+
+
+def test_no_device_fails_loudly():
+    """Without a GPU the product path must refuse to run (no CPU fallback)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from udcore.core import DynCore
+    with pytest.raises(L.UdcError):
+        DynCore(Grid.uniform(8, 8, 8))

@@ -1,0 +1,379 @@
+// libudcore: handle, residency, orchestration of the reference's call surface.
+#include "udc_internal.h"
+#include <cstdarg>
+#include <cstring>
+#include <cmath>
+
+static thread_local char g_err[512] = "";
+
+void udc_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char *udc_last_error(void) { return g_err; }
+extern "C" int udc_version(void) { return 100; }
+
+// ------------------------------------------------------------------------------ profiling
+ProfScope::ProfScope(udc_handle *h_, const char *name) : h(h_), id(-1) {
+  if (!h->prof) return;
+  auto it = h->prof_ids.find(name);
+  if (it == h->prof_ids.end()) {
+    id = (int)h->prof_names.size();
+    h->prof_names.push_back(name);
+    h->prof_ids[name] = id;
+  } else {
+    id = it->second;
+  }
+  hipEventCreate(&a);
+  hipEventCreate(&b);
+  hipEventRecord(a, h->stream);
+}
+ProfScope::~ProfScope() {
+  if (id < 0) return;
+  hipEventRecord(b, h->stream);
+  h->prof_events.push_back({a, b, id});
+}
+
+static void prof_drain(udc_handle *h) {
+  for (auto &e : h->prof_events) {
+    hipEventSynchronize(e.b);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e.a, e.b);
+    auto &acc = h->prof_acc[e.name];
+    acc.first += ms;
+    acc.second += 1;
+    hipEventDestroy(e.a);
+    hipEventDestroy(e.b);
+  }
+  h->prof_events.clear();
+}
+
+extern "C" int udc_profile_enable(udc_handle *h, int on) {
+  if (!h) return 1;
+  if (!on) prof_drain(h);
+  h->prof = on != 0;
+  return 0;
+}
+extern "C" int udc_profile_reset(udc_handle *h) {
+  prof_drain(h);
+  h->prof_acc.clear();
+  return 0;
+}
+extern "C" int udc_profile_get(udc_handle *h, int cap, char names[][64], double *total_ms, int *launches) {
+  prof_drain(h);
+  int n = 0;
+  for (auto &kv : h->prof_acc) {
+    if (n < cap) {
+      snprintf(names[n], 64, "%s", h->prof_names[kv.first].c_str());
+      total_ms[n] = kv.second.first;
+      launches[n] = kv.second.second;
+    }
+    ++n;
+  }
+  return n;
+}
+
+// ------------------------------------------------------------------------------ lifetime
+static int alloc_field(udc_handle *h, int id) {
+  if ((int)h->fields.size() <= id) h->fields.resize(id + 1, nullptr);
+  if (h->fields[id]) return 0;
+  double *p = nullptr;
+  HIP_OK(hipMalloc(&p, sizeof(double) * h->g.n));
+  HIP_OK(hipMemsetAsync(p, 0, sizeof(double) * h->g.n, h->stream));
+  h->fields[id] = p;
+  return 0;
+}
+
+extern "C" int udc_create(const udc_config *cfg, udc_handle **out) {
+  if (!cfg || !out) { udc_set_error("udc_create: null argument"); return 1; }
+  if (cfg->itot < 4 || cfg->jtot < 4 || cfg->ktot < 3) { udc_set_error("udc_create: grid too small"); return 1; }
+  if (cfg->itot % 2 || cfg->jtot % 2) { udc_set_error("udc_create: itot and jtot must be even (half-complex FFT, src/modpois.f90:482-487)"); return 1; }
+  if (cfg->nranks < 1 || cfg->rank < 0 || cfg->rank >= cfg->nranks) { udc_set_error("udc_create: bad rank/nranks"); return 1; }
+  if (cfg->jtot % cfg->nranks) { udc_set_error("udc_create: jtot must be divisible by nranks (src/modstartup.f90:730-760)"); return 1; }
+  if (cfg->nranks > 1) { udc_set_error("udc_create: multi-GPU slabs not enabled in this build"); return 1; }
+  if (cfg->nsv < 0 || cfg->nsv > 16) { udc_set_error("udc_create: nsv out of range"); return 1; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    udc_set_error("udc_create: no HIP device visible -- libudcore has no CPU fallback");
+    return 1;
+  }
+  udc_handle *h = new udc_handle();
+  h->cfg = *cfg;
+  h->device = cfg->device;
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipStreamCreate(&h->stream));
+  Geo &g = h->g;
+  g.nx = cfg->itot; g.ny = cfg->jtot / cfg->nranks; g.nz = cfg->ktot;
+  g.py = g.ny + 2 * HY; g.pz = g.nz + 2 * HZ;
+  g.sy = g.nx; g.sz = (long)g.nx * g.py; g.n = g.sz * g.pz;
+  h->p = Params{cfg->numol, cfg->prandtlmoli, cfg->prandtli, cfg->c_vreman, cfg->csz,
+                cfg->uinf, cfg->vinf, cfg->sgs, cfg->bctopm};
+
+  // metrics exactly as src/modglobal.f90:812-838
+  const int nk = g.nz + 2;
+  std::vector<double> hm(12 * nk, 0.0);
+  double *dzf = &hm[0], *dzfi = dzf + nk, *dzfi5 = dzfi + nk, *dzfiq = dzfi5 + nk, *dzf2 = dzfiq + nk;
+  double *dzhi = dzf2 + nk, *dzhiq = dzhi + nk, *dzh2i = dzhiq + nk, *dzh = dzh2i + nk;
+  for (int k = 0; k < nk; ++k) {
+    dzf[k] = cfg->dzf[k];
+    dzfi[k] = 1. / dzf[k]; dzfi5[k] = 0.5 * dzfi[k]; dzfiq[k] = 0.25 * dzfi[k]; dzf2[k] = dzf[k] * dzf[k];
+  }
+  for (int k = 1; k < nk; ++k) {
+    dzh[k] = cfg->dzh[k];
+    dzhi[k] = 1. / dzh[k]; dzhiq[k] = 0.25 * dzhi[k]; dzh2i[k] = dzhi[k] * dzhi[k];
+  }
+  double *mlen = &hm[11 * nk];
+  // delta(i,k) = (dxf(i)*dy*dzf(k))**(1/3), src/modglobal.f90:793-797 (uniform x)
+  for (int k = 0; k < nk; ++k) mlen[k] = cfg->csz * pow(cfg->dx * cfg->dy * dzf[k], 1. / 3.);
+  dzh[0] = dzh[1]; dzhi[0] = dzhi[1]; dzhiq[0] = dzhiq[1]; dzh2i[0] = dzh2i[1];
+  HIP_OK(hipMalloc(&h->metrics_dev, sizeof(double) * hm.size()));
+  HIP_OK(hipMemcpy(h->metrics_dev, hm.data(), sizeof(double) * hm.size(), hipMemcpyHostToDevice));
+  Metrics &m = h->m;
+  double *b = h->metrics_dev;
+  m.dzf = b; m.dzfi = b + nk; m.dzfi5 = b + 2 * nk; m.dzfiq = b + 3 * nk; m.dzf2 = b + 4 * nk;
+  m.dzhi = b + 5 * nk; m.dzhiq = b + 6 * nk; m.dzh2i = b + 7 * nk; m.dzh = b + 8 * nk;
+  m.dpdxl = b + 9 * nk; m.dpdyl = b + 10 * nk; m.mlen = b + 11 * nk;
+  m.dx = cfg->dx; m.dy = cfg->dy;
+  m.dxi = 1. / cfg->dx; m.dyi = 1. / cfg->dy;
+  m.dx2 = cfg->dx * cfg->dx; m.dy2 = cfg->dy * cfg->dy;
+  m.dxiq = 0.25 * m.dxi; m.dyiq = 0.25 * m.dyi;
+  m.dx2i = m.dxi * m.dxi; m.dy2i = m.dyi * m.dyi;
+  m.dxi5 = 0.5 * m.dxi; m.dyi5 = 0.5 * m.dyi;
+
+  for (int f = UDC_U0; f <= UDC_EKH; ++f)
+    if (alloc_field(h, f)) return 1;
+  for (int n = 0; n < cfg->nsv; ++n)
+    for (int q = 0; q < 3; ++q)
+      if (alloc_field(h, UDC_SV0 + 3 * n + q)) return 1;
+  HIP_OK(hipMalloc(&h->red, sizeof(double) * 4096));
+  HIP_OK(hipHostMalloc(&h->red_host, sizeof(double) * 4096));
+  if (pois_init(h)) return 1;
+  HIP_OK(hipStreamSynchronize(h->stream));
+  *out = h;
+  return 0;
+}
+
+extern "C" int udc_destroy(udc_handle *h) {
+  if (!h) return 0;
+  hipSetDevice(h->device);
+  hipStreamSynchronize(h->stream);
+  prof_drain(h);
+  pois_destroy(h);
+  for (double *p : h->fields) if (p) hipFree(p);
+  if (h->metrics_dev) hipFree(h->metrics_dev);
+  if (h->red) hipFree(h->red);
+  if (h->red_host) hipHostFree(h->red_host);
+  if (h->sendbuf) hipFree(h->sendbuf);
+  if (h->recvbuf) hipFree(h->recvbuf);
+  hipStreamDestroy(h->stream);
+  delete h;
+  return 0;
+}
+
+extern "C" int udc_comm_unique_id(unsigned char id[128]) {
+  memset(id, 0, 128);
+  return 0;
+}
+extern "C" int udc_comm_init(udc_handle *h, const unsigned char id[128]) {
+  (void)id;
+  if (h->cfg.nranks == 1) return 0;
+  udc_set_error("udc_comm_init: multi-GPU slabs not enabled in this build");
+  return 1;
+}
+
+extern "C" int udc_sync(udc_handle *h) {
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------ residency
+static int field_ptr(udc_handle *h, int field, double **p) {
+  if (field < 0 || field >= (int)h->fields.size() || !h->fields[field]) {
+    udc_set_error("unknown or unallocated field id %d", field);
+    return 1;
+  }
+  *p = h->fields[field];
+  return 0;
+}
+
+static int copy3d(udc_handle *h, int field, double *host, const int lb[3], const int ub[3], bool up) {
+  double *dev;
+  if (field_ptr(h, field, &dev)) return 1;
+  const Geo &g = h->g;
+  const int hnx = ub[0] - lb[0] + 1, hny = ub[1] - lb[1] + 1;
+  int i0 = lb[0] > 1 ? lb[0] : 1, i1 = ub[0] < g.nx ? ub[0] : g.nx;
+  int j0 = lb[1] > 1 - HY ? lb[1] : 1 - HY, j1 = ub[1] < g.ny + HY ? ub[1] : g.ny + HY;
+  int k0 = lb[2] > 1 - HZ ? lb[2] : 1 - HZ, k1 = ub[2] < g.nz + HZ ? ub[2] : g.nz + HZ;
+  if (i1 < i0 || j1 < j0 || k1 < k0) { udc_set_error("field %d: empty overlap with host bounds", field); return 1; }
+  hipMemcpy3DParms p;
+  memset(&p, 0, sizeof(p));
+  hipPitchedPtr hp = make_hipPitchedPtr((void *)host, (size_t)hnx * 8, (size_t)hnx * 8, (size_t)hny);
+  hipPitchedPtr dp = make_hipPitchedPtr((void *)dev, (size_t)g.nx * 8, (size_t)g.nx * 8, (size_t)g.py);
+  hipPos hpos = make_hipPos((size_t)(i0 - lb[0]) * 8, (size_t)(j0 - lb[1]), (size_t)(k0 - lb[2]));
+  hipPos dpos = make_hipPos((size_t)(i0 - 1) * 8, (size_t)(j0 - 1 + HY), (size_t)(k0 - 1 + HZ));
+  p.extent = make_hipExtent((size_t)(i1 - i0 + 1) * 8, (size_t)(j1 - j0 + 1), (size_t)(k1 - k0 + 1));
+  if (up) { p.srcPtr = hp; p.srcPos = hpos; p.dstPtr = dp; p.dstPos = dpos; p.kind = hipMemcpyHostToDevice; }
+  else    { p.srcPtr = dp; p.srcPos = dpos; p.dstPtr = hp; p.dstPos = hpos; p.kind = hipMemcpyDeviceToHost; }
+  HIP_OK(hipStreamSynchronize(h->stream));
+  HIP_OK(hipMemcpy3D(&p));
+  if (!up) {
+    // the reference's x ghost columns are periodic images (src/modboundary.f90:516-529):
+    // rebuild them on the host so that untouched host routines see what they expect
+    const long hsy = hnx, hsz = (long)hnx * hny;
+    for (int k = k0; k <= k1; ++k)
+      for (int j = j0; j <= j1; ++j) {
+        double *row = host + (long)(j - lb[1]) * hsy + (long)(k - lb[2]) * hsz - lb[0];
+        for (int i = lb[0]; i < 1; ++i) row[i] = row[i + g.nx];
+        for (int i = g.nx + 1; i <= ub[0]; ++i) row[i] = row[i - g.nx];
+      }
+  }
+  return 0;
+}
+
+extern "C" int udc_field_upload(udc_handle *h, int field, const double *host, const int lb[3], const int ub[3]) {
+  HIP_OK(hipSetDevice(h->device));
+  return copy3d(h, field, const_cast<double *>(host), lb, ub, true);
+}
+extern "C" int udc_field_download(udc_handle *h, int field, double *host, const int lb[3], const int ub[3]) {
+  HIP_OK(hipSetDevice(h->device));
+  return copy3d(h, field, host, lb, ub, false);
+}
+
+extern "C" int udc_set_forcing(udc_handle *h, const double *dpdxl, const double *dpdyl, int n) {
+  if (n != h->g.nz) { udc_set_error("udc_set_forcing: expected %d levels", h->g.nz); return 1; }
+  const int nk = h->g.nz + 2;
+  std::vector<double> t(2 * nk, 0.0);
+  for (int k = 1; k <= n; ++k) { t[k] = dpdxl[k - 1]; t[nk + k] = dpdyl[k - 1]; }
+  HIP_OK(hipMemcpyAsync(const_cast<double *>(h->m.dpdxl), t.data(), sizeof(double) * 2 * nk,
+                        hipMemcpyHostToDevice, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------ call surface
+static int vel_fields(udc_handle *h, int rk3step, int *f) {
+  int n = 0;
+  f[n++] = UDC_U0; f[n++] = UDC_V0; f[n++] = UDC_W0;
+  if (rk3step == 3) { f[n++] = UDC_UM; f[n++] = UDC_VM; f[n++] = UDC_WM; }
+  (void)h;
+  return n;
+}
+
+extern "C" int udc_advection(udc_handle *h) {
+  HIP_OK(hipSetDevice(h->device));
+  if (k_momentum(h, true, false, false)) return 1;
+  for (int n = 0; n < h->cfg.nsv; ++n)
+    if (k_scalar_adv(h, n)) return 1;
+  return 0;
+}
+
+extern "C" int udc_subgrid(udc_handle *h) {
+  HIP_OK(hipSetDevice(h->device));
+  if (k_closure(h)) return 1;
+  if (k_ek_ghosts(h)) return 1;
+  if (k_top_rows_after_closure(h)) return 1;
+  if (k_momentum(h, false, true, false)) return 1;
+  for (int n = 0; n < h->cfg.nsv; ++n)
+    if (k_scalar_diff(h, n)) return 1;
+  return 0;
+}
+
+extern "C" int udc_forces(udc_handle *h) {
+  HIP_OK(hipSetDevice(h->device));
+  return k_forces(h);
+}
+
+extern "C" int udc_poisson(udc_handle *h, int rk3step, double dt) {
+  HIP_OK(hipSetDevice(h->device));
+  const double rk3coef = rk3step == 0 ? 1. : dt / (4. - (double)rk3step);
+  const int fvp[1] = {UDC_VP};
+  if (k_halo_y(h, fvp, 1, 1)) return 1;            // pvp(je+1) = pvp(jb): bcpup
+  if (k_divergence_rhs(h, rk3coef)) return 1;       // fillps
+  if (k_poisson_solve(h)) return 1;
+  const int fp[1] = {UDC_P};
+  if (k_halo_y(h, fp, 1, 1)) return 1;              // bcp
+  if (k_project(h)) return 1;                       // tderive
+  const int fpr[1] = {UDC_PRES0};
+  if (k_halo_y(h, fpr, 1, 1)) return 1;
+  return 0;
+}
+
+extern "C" int udc_tstep_integrate(udc_handle *h, int rk3step, double dt) {
+  HIP_OK(hipSetDevice(h->device));
+  return k_integrate(h, rk3step, dt);
+}
+
+static int scalar_halo_list(udc_handle *h, int rk3step, std::vector<int> &f) {
+  for (int n = 0; n < h->cfg.nsv; ++n) {
+    f.push_back(UDC_SV0 + 3 * n);
+    if (rk3step == 3 || rk3step < 0) f.push_back(UDC_SVM + 3 * n);
+  }
+  return 0;
+}
+
+extern "C" int udc_halos(udc_handle *h) {
+  HIP_OK(hipSetDevice(h->device));
+  const int f[6] = {UDC_U0, UDC_V0, UDC_W0, UDC_UM, UDC_VM, UDC_WM};
+  if (k_halo_y(h, f, 6, 1)) return 1;
+  std::vector<int> s;
+  scalar_halo_list(h, -1, s);
+  if (!s.empty() && k_halo_y(h, s.data(), (int)s.size(), 2)) return 1;
+  return 0;
+}
+
+extern "C" int udc_boundary(udc_handle *h) {
+  HIP_OK(hipSetDevice(h->device));
+  return k_top_bottom(h);
+}
+
+extern "C" int udc_tstep_maxima(udc_handle *h, double dt, double *courtot, double *diffnrtot) {
+  HIP_OK(hipSetDevice(h->device));
+  return k_maxima(h, dt, courtot, diffnrtot);
+}
+
+extern "C" int udc_divergence(udc_handle *h, double *divmax, double *divtot) {
+  HIP_OK(hipSetDevice(h->device));
+  return k_divergence_check(h, divmax, divtot);
+}
+
+extern "C" int udc_substep(udc_handle *h, int rk3step, double dt, int with_forces) {
+  HIP_OK(hipSetDevice(h->device));
+  const double rk3coef = dt / (4. - (double)rk3step);
+  // closure first: it only needs u0,v0,w0, and the fused sweep below needs ekm
+  if (k_closure(h)) return 1;
+  if (k_ek_ghosts(h)) return 1;
+  if (k_momentum(h, true, true, with_forces != 0)) return 1;
+  for (int n = 0; n < h->cfg.nsv; ++n) {
+    if (k_scalar_adv(h, n)) return 1;
+    if (k_scalar_diff(h, n)) return 1;
+  }
+  const int fvp[1] = {UDC_VP};
+  if (k_halo_y(h, fvp, 1, 1)) return 1;
+  if (k_divergence_rhs(h, rk3coef)) return 1;
+  if (k_poisson_solve(h)) return 1;
+  const int fp[1] = {UDC_P};
+  if (k_halo_y(h, fp, 1, 1)) return 1;
+  if (k_project_integrate(h, rk3step, dt)) return 1;
+  int f[8];
+  int nf = vel_fields(h, rk3step, f);
+  f[nf++] = UDC_PRES0;
+  if (k_halo_y(h, f, nf, 1)) return 1;
+  std::vector<int> s;
+  scalar_halo_list(h, rk3step, s);
+  if (!s.empty() && k_halo_y(h, s.data(), (int)s.size(), 2)) return 1;
+  if (k_top_bottom(h)) return 1;
+  return 0;
+}
+
+extern "C" int udc_run(udc_handle *h, int nsubsteps, int rk3step0, double dt, int with_forces) {
+  int rk = rk3step0;
+  for (int s = 0; s < nsubsteps; ++s) {
+    if (udc_substep(h, rk, dt, with_forces)) return 1;
+    rk = rk % 3 + 1;
+  }
+  return 0;
+}

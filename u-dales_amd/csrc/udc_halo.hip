@@ -1,0 +1,105 @@
+// Ghost rows / planes: y-periodic wrap (single slab) and the top/bottom rows of `boundary`.
+// x has no ghosts on the device (index wrap in the kernels).
+#include "udc_internal.h"
+
+namespace {
+
+struct FieldList {
+  double *f[16];
+};
+
+// rows j = -w..-1 <- ny-w..ny-1 and rows ny..ny+w-1 <- 0..w-1, for every k plane (ghost
+// planes included, as the reference's ym_periodic does: src/modboundary.f90:596-627)
+__global__ void halo_y_wrap_kernel(Geo g, FieldList fl, int width) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= g.nx) return;
+  const int r = blockIdx.y % (2 * width);
+  const int fi = blockIdx.y / (2 * width);
+  const int k = (int)blockIdx.z - HZ;
+  int jdst, jsrc;
+  if (r < width) { jdst = -1 - r; jsrc = g.ny - 1 - r; }
+  else { jdst = g.ny + (r - width); jsrc = r - width; }
+  double *a = fl.f[fi];
+  a[g.idx(i, jdst, k)] = a[g.idx(i, jsrc, k)];
+}
+
+struct BoundaryArgs {
+  double *u0, *v0, *w0, *um, *vm, *wm;
+  double *sv[32];
+  int nscal;         // number of scalar arrays in sv (sv0 and svm of every scalar)
+};
+
+// boundary: src/modboundary.f90:163-247 (periodic lateral subset): w(kb) = 0; top ghost rows
+// by fluxtop with zero flux (:1494-1507) or valuetop (:1509-1519); w(ke+1) = 0; scalars
+// zero-flux top (:1521-1537).  Runs over the whole padded y extent after the y ghosts.
+__global__ void top_bottom_kernel(Geo g, Params pr, BoundaryArgs a, int uv_only) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = (int)blockIdx.y - HY;
+  if (i >= g.nx) return;
+  const long top = g.idx(i, j, g.nz - 1), ghost = top + g.sz;
+  if (pr.bctopm == UDC_TOP_NOSLIP) {
+    if (!uv_only) {
+      a.um[ghost] = 2 * pr.uinf - a.um[top]; a.u0[ghost] = 2 * pr.uinf - a.u0[top];
+      a.vm[ghost] = 2 * pr.vinf - a.vm[top]; a.v0[ghost] = 2 * pr.vinf - a.v0[top];
+    }
+  } else {
+    a.um[ghost] = a.um[top]; a.u0[ghost] = a.u0[top];
+    a.vm[ghost] = a.vm[top]; a.v0[ghost] = a.v0[top];
+  }
+  if (uv_only) return;
+  const long bot = g.idx(i, j, 0);
+  a.wm[bot] = 0.; a.w0[bot] = 0.;
+  a.w0[ghost] = 0.; a.wm[ghost] = 0.;
+  for (int s = 0; s < a.nscal; ++s) {
+    double *c = a.sv[s];
+    const double t = c[top];
+    c[ghost] = t;
+    c[ghost + g.sz] = t;
+  }
+}
+
+}  // namespace
+
+int k_halo_y(udc_handle *h, const int *fields, int nf, int width) {
+  const Geo &g = h->g;
+  if (nf > 16 || width > HY) { udc_set_error("k_halo_y: bad arguments"); return 1; }
+  FieldList fl;
+  for (int q = 0; q < nf; ++q) fl.f[q] = h->fields[fields[q]];
+  PROF(h, "halo_y");
+  hipLaunchKernelGGL(halo_y_wrap_kernel, dim3((g.nx + 63) / 64, 2 * width * nf, g.pz), dim3(64), 0, h->stream,
+                     g, fl, width);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+static BoundaryArgs boundary_args(udc_handle *h) {
+  BoundaryArgs a;
+  a.u0 = h->fields[UDC_U0]; a.v0 = h->fields[UDC_V0]; a.w0 = h->fields[UDC_W0];
+  a.um = h->fields[UDC_UM]; a.vm = h->fields[UDC_VM]; a.wm = h->fields[UDC_WM];
+  a.nscal = 0;
+  for (int n = 0; n < h->cfg.nsv; ++n) {
+    a.sv[a.nscal++] = h->fields[UDC_SV0 + 3 * n];
+    a.sv[a.nscal++] = h->fields[UDC_SVM + 3 * n];
+  }
+  return a;
+}
+
+int k_top_bottom(udc_handle *h) {
+  const Geo &g = h->g;
+  PROF(h, "top_bottom");
+  hipLaunchKernelGGL(top_bottom_kernel, dim3((g.nx + 63) / 64, g.py), dim3(64), 0, h->stream, g, h->p,
+                     boundary_args(h), 0);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// reassure_fluxtop_boundary, src/modboundary.f90:392-431 (free-slip: top rows of um,u0,vm,v0)
+int k_top_rows_after_closure(udc_handle *h) {
+  const Geo &g = h->g;
+  if (h->p.bctopm == UDC_TOP_NOSLIP) return 0;
+  PROF(h, "top_rows");
+  hipLaunchKernelGGL(top_bottom_kernel, dim3((g.nx + 63) / 64, g.py), dim3(64), 0, h->stream, g, h->p,
+                     boundary_args(h), 1);
+  HIP_OK(hipGetLastError());
+  return 0;
+}

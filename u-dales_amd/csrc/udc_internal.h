@@ -1,0 +1,138 @@
+// Internal declarations of libudcore (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rocfft/rocfft.h>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/udcore.h"
+
+// ---------------------------------------------------------------------------------------
+// Device layout of every 3-D field (one geometry for all of them, so that one offset
+// serves u0,v0,w0,pres0,ekm,up,... in a fused kernel):
+//
+//   a[ i + nx * ( (j + HY) + py * (k + HZ) ) ],  i = 0..nx-1, j = -HY..nyl-1+HY, k = -HZ..nz-1+HZ
+//
+// * no ghost columns in x: with the y-slab decomposition x is always whole and periodic on
+//   a rank, so the kernels wrap the i index instead (the reference's x ghosts are, at every
+//   point of use, periodic images: src/modboundary.f90:508-539, 1249-1255, 1365-1375);
+//   rows are therefore nx*8 bytes, contiguous and 128-byte aligned for nx % 16 == 0.
+// * HY = HZ = 2 ghost rows / planes (kappa scalars need 2, momentum 1).
+// Reference index (if, jf, kf) (1-based interior) <-> device (if-1, jf-1, kf-1).
+// ---------------------------------------------------------------------------------------
+constexpr int HY = 2;
+constexpr int HZ = 2;
+
+struct Geo {
+  int nx, ny, nz;      // local interior (ny = rows of this y-slab)
+  int py, pz;          // padded extents ny+2HY, nz+2HZ
+  int sy;              // row stride   (= nx)
+  long sz;             // plane stride (= nx*py)
+  long n;              // total elements
+  __host__ __device__ inline long idx(int i, int j, int k) const {
+    return (long)i + (long)sy * (j + HY) + sz * (long)(k + HZ);
+  }
+};
+
+// per-level metrics in constant-like global memory, indexed by the reference's k (0..nz+1)
+struct Metrics {
+  const double *dzf, *dzfi, *dzfi5, *dzfiq, *dzf2;   // 0..nz+1
+  const double *dzhi, *dzhiq, *dzh2i, *dzh;          // 1..nz+1 (entry 0 = copy of entry 1)
+  const double *dpdxl, *dpdyl;                       // 0..nz+1 (forcing, zero if unset)
+  const double *mlen;                                // 0..nz+1 csz*delta(k), src/modsubgrid.f90:215
+  double dxi, dyi, dxiq, dyiq, dx2i, dy2i, dxi5, dyi5, dx2, dy2, dx, dy;
+};
+
+struct Params {
+  double numol, prandtlmoli, prandtli, c_vreman, csz, uinf, vinf;
+  int sgs, bctopm;
+};
+
+struct ProfEntry { hipEvent_t a, b; int name; };
+
+struct udc_handle {
+  udc_config cfg;
+  Geo g;
+  Metrics m;
+  Params p;
+  int device;
+  hipStream_t stream;
+  std::vector<double *> fields;         // device arrays, UDC_FIELD ids
+  double *metrics_dev = nullptr;        // backing store for Metrics arrays
+  // Poisson
+  double *spec = nullptr;               // complex (nkx, ny, nz) spectral work array
+  double *dtab = nullptr;               // Thomas d(kx,ky,k) table
+  double *ev = nullptr;                 // eigenvalue xrt(kx)+yrt(ky)
+  double *tri = nullptr;                // a,b,c (3*(nz+2))
+  int nkx = 0;
+  double btopD = 0.;                    // Dirichlet top coefficient of the singular mode
+  rocfft_plan plan_fwd = nullptr, plan_bwd = nullptr;
+  rocfft_execution_info info_fwd = nullptr, info_bwd = nullptr;
+  void *fft_work = nullptr;
+  double *rbuf = nullptr;               // compact real (nx,ny,nz) staging, only if rocFFT rejects strides
+  bool fwd_compact = false, bwd_compact = false;
+  // reductions
+  double *red = nullptr;                // small device scratch
+  double *red_host = nullptr;           // pinned
+  // profiling
+  bool prof = false;
+  std::vector<ProfEntry> prof_events;
+  std::vector<std::string> prof_names;
+  std::map<std::string, int> prof_ids;
+  std::map<int, std::pair<double, int>> prof_acc;
+  // multi-GPU
+  void *nccl = nullptr;
+  double *sendbuf = nullptr, *recvbuf = nullptr;
+};
+
+void udc_set_error(const char *fmt, ...);
+
+#define HIP_OK(expr)                                                                  \
+  do {                                                                                \
+    hipError_t e_ = (expr);                                                           \
+    if (e_ != hipSuccess) {                                                           \
+      udc_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,  \
+                    __LINE__);                                                        \
+      return 1;                                                                       \
+    }                                                                                 \
+  } while (0)
+
+#define FFT_OK(expr)                                                                  \
+  do {                                                                                \
+    rocfft_status s_ = (expr);                                                        \
+    if (s_ != rocfft_status_success) {                                                \
+      udc_set_error("%s failed: rocfft status %d (%s:%d)", #expr, (int)s_, __FILE__,  \
+                    __LINE__);                                                        \
+      return 1;                                                                       \
+    }                                                                                 \
+  } while (0)
+
+// kernel-launch bracket used for the optional HIP-event profile
+struct ProfScope {
+  udc_handle *h; int id; hipEvent_t a, b;
+  ProfScope(udc_handle *h_, const char *name);
+  ~ProfScope();
+};
+#define PROF(h, name) ProfScope prof_scope_(h, name)
+
+// ---- kernels (udc_mom.hip, udc_pois.hip, udc_scalar.hip, udc_halo.hip)
+int k_closure(udc_handle *h);
+int k_ek_ghosts(udc_handle *h);
+int k_momentum(udc_handle *h, bool adv, bool diff, bool forces);
+int k_scalar_adv(udc_handle *h, int n);
+int k_scalar_diff(udc_handle *h, int n);
+int k_forces(udc_handle *h);
+int k_divergence_rhs(udc_handle *h, double rk3coef);
+int k_poisson_solve(udc_handle *h);
+int k_project(udc_handle *h);                       // tderive: up,vp,wp -= grad p ; pres0 += p
+int k_integrate(udc_handle *h, int rk3step, double dt);
+int k_project_integrate(udc_handle *h, int rk3step, double dt);   // fused tderive + tstep_integrate
+int k_halo_y(udc_handle *h, const int *fields, int nf, int width);
+int k_top_bottom(udc_handle *h);
+int k_top_rows_after_closure(udc_handle *h);
+int k_maxima(udc_handle *h, double dt, double *cour, double *diffn);
+int k_divergence_check(udc_handle *h, double *divmax, double *divtot);
+int pois_init(udc_handle *h);
+void pois_destroy(udc_handle *h);

@@ -1,0 +1,339 @@
+// Closure (Smagorinsky / Vreman / DNS) and the fused momentum advection + diffusion sweep.
+//
+// Arithmetic follows the reference expression by expression (uDALES src/modadvection.f90:158-314,
+// src/modsubgrid.f90:208-360, 672-997) so that results agree with the CPU path to round-off;
+// the data movement is redesigned: one sweep reads u0,v0,w0,pres0,ekm once and updates
+// up,vp,wp once (88 B/cell algorithmic) instead of the reference's ~12 sweeps.
+#include "udc_internal.h"
+
+namespace {
+
+struct MomArgs {
+  const double *u, *v, *w, *p, *ek;
+  double *up, *vp, *wp;
+};
+
+// x is periodic on a rank: wrap the index (no ghost columns are stored)
+__device__ __forceinline__ int wrapm(int i, int nx) { return i == 0 ? nx - 1 : i - 1; }
+__device__ __forceinline__ int wrapp(int i, int nx) { return i == nx - 1 ? 0 : i + 1; }
+
+// ---------------------------------------------------------------------------- momentum
+// One thread per cell, x fastest (coalesced 512-B wave rows); neighbours in y and z come
+// from L1/L2.  ADV: advecu/v/w_2nd incl. -grad(pres0).  DIFF: diffu/v/w (LES or DNS form).
+// FORCES: modforces.f90:84-127 neutral branch.  Order of accumulation into the tendency is
+// the reference's: xy advection, z advection, diffusion, forcing.
+template <bool ADV, bool DIFF, bool LES, bool FORCES>
+__global__ __launch_bounds__(256) void mom_kernel(Geo g, Metrics m, MomArgs a, double numol) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= g.nx || j >= g.ny) return;
+  const int kf = k + 1;   // reference level index for the metric tables
+  const int im = wrapm(i, g.nx), ip = wrapp(i, g.nx);
+  const long r0 = g.idx(0, j, k);
+  const long sy = g.sy, sz = g.sz;
+  const long c = r0 + i, xm = r0 + im, xp = r0 + ip;
+
+  const double *__restrict__ u = a.u;
+  const double *__restrict__ v = a.v;
+  const double *__restrict__ w = a.w;
+
+  const double u_c = u[c], u_xm = u[xm], u_xp = u[xp], u_ym = u[c - sy], u_yp = u[c + sy],
+               u_zm = u[c - sz], u_zp = u[c + sz], u_xp_ym = u[xp - sy], u_xp_zm = u[xp - sz];
+  const double v_c = v[c], v_xm = v[xm], v_xp = v[xp], v_ym = v[c - sy], v_yp = v[c + sy],
+               v_zm = v[c - sz], v_zp = v[c + sz], v_xm_yp = v[xm + sy], v_yp_zm = v[c + sy - sz];
+  const double w_c = w[c], w_xm = w[xm], w_xp = w[xp], w_ym = w[c - sy], w_yp = w[c + sy],
+               w_zm = w[c - sz], w_zp = w[c + sz], w_xm_zp = w[xm + sz], w_ym_zp = w[c - sy + sz];
+
+  const double dzf_k = m.dzf[kf], dzf_km = m.dzf[kf - 1], dzf_kp = m.dzf[kf + 1];
+  const double dzhi_k = m.dzhi[kf], dzhi_kp = m.dzhi[kf + 1];
+  const double dzfi_k = m.dzfi[kf];
+
+  double tu = a.up[c], tv = a.vp[c], tw = a.wp[c];
+
+  if (ADV) {
+    const double *__restrict__ p = a.p;
+    const double p_c = p[c], p_xm = p[xm], p_ym = p[c - sy], p_zm = p[c - sz];
+    const double dzfi5_k = m.dzfi5[kf];
+    // advecu_2nd, src/modadvection.f90:178-187 and :202-207
+    tu = tu - (((u_c + u_xp) * (u_c + u_xp) - (u_c + u_xm) * (u_c + u_xm)) * m.dxiq
+             + ((u_c + u_yp) * (v_yp + v_xm_yp) - (u_c + u_ym) * (v_c + v_xm)) * m.dyiq)
+            - ((p_c - p_xm) * m.dxi);
+    tu = tu - ((u_zp * dzf_k + u_c * dzf_kp) * dzhi_kp * (w_zp + w_xm_zp)
+             - (u_c * dzf_km + u_zm * dzf_k) * dzhi_k * (w_c + w_xm)) * 0.5 * dzfi5_k;
+    // advecv_2nd, :235-245 and :260-265
+    tv = tv - (((u_xp + u_xp_ym) * (v_c + v_xp) - (u_c + u_ym) * (v_c + v_xm)) * m.dxiq
+             + ((v_yp + v_c) * (v_c + v_yp) - (v_ym + v_c) * (v_c + v_ym)) * m.dyiq)
+            - ((p_c - p_ym) * m.dyi);
+    tv = tv - ((w_zp + w_ym_zp) * (v_zp * dzf_k + v_c * dzf_kp) * dzhi_kp
+             - (w_c + w_ym) * (v_zm * dzf_k + v_c * dzf_km) * dzhi_k) * 0.5 * dzfi5_k;
+    // advecw_2nd, :295-309 (k = kb+1..ke)
+    if (k >= 1) {
+      const double dzhiq_k = m.dzhiq[kf];
+      tw = tw - (((w_xp + w_c) * (dzf_km * u_xp + dzf_k * u_xp_zm)
+                - (w_c + w_xm) * (dzf_km * u_c + dzf_k * u_zm)) * m.dxiq * dzhi_k
+               + ((w_yp + w_c) * (dzf_km * v_yp + dzf_k * v_yp_zm)
+                - (w_c + w_ym) * (dzf_km * v_c + dzf_k * v_zm)) * m.dyiq * dzhi_k
+               + ((w_c + w_zp) * (w_c + w_zp) - (w_c + w_zm) * (w_c + w_zm)) * dzhiq_k)
+              - ((p_c - p_zm) * dzhi_k);
+    }
+  }
+
+  if (DIFF) {
+    if (LES) {
+      const double *__restrict__ e = a.ek;
+      const double e_c = e[c], e_xm = e[xm], e_xp = e[xp], e_ym = e[c - sy], e_yp = e[c + sy],
+                   e_zm = e[c - sz], e_zp = e[c + sz];
+      const double e_xm_yp = e[xm + sy], e_xm_ym = e[xm - sy], e_xm_zm = e[xm - sz], e_xm_zp = e[xm + sz];
+      const double e_ym_zm = e[c - sy - sz], e_ym_zp = e[c - sy + sz], e_xp_ym = e[xp - sy];
+      const double e_yp_zm = e[c + sy - sz], e_xp_zm = e[xp - sz];
+      const double dzhiq_k = m.dzhiq[kf], dzhiq_kp = m.dzhiq[kf + 1];
+      {  // diffu, src/modsubgrid.f90:695-729
+        const double emom = (dzf_km * (e_c + e_xm) + dzf_k * (e_zm + e_xm_zm)) * dzhiq_k;
+        const double emop = (dzf_kp * (e_c + e_xm) + dzf_k * (e_zp + e_xm_zp)) * dzhiq_kp;
+        const double empo = 0.25 * ((e_c + e_yp) + (e_xm + e_xm_yp));
+        const double emmo = 0.25 * ((e_c + e_ym) + (e_xm_ym + e_xm));
+        tu = tu + (e_c * (u_xp - u_c) - e_xm * (u_c - u_xm)) * 2. * m.dx2i
+                + (empo * ((u_yp - u_c) * m.dyi + (v_yp - v_xm_yp) * m.dxi)
+                 - emmo * ((u_c - u_ym) * m.dyi + (v_c - v_xm) * m.dxi)) * m.dyi
+                + (emop * ((u_zp - u_c) * dzhi_kp + (w_zp - w_xm_zp) * m.dxi)
+                 - emom * ((u_c - u_zm) * dzhi_k + (w_c - w_xm) * m.dxi)) * dzfi_k;
+      }
+      {  // diffv, :802-838
+        const double eomm = (dzf_km * (e_c + e_ym) + dzf_k * (e_zm + e_ym_zm)) * dzhiq_k;
+        const double eomp = (dzf_kp * (e_c + e_ym) + dzf_k * (e_zp + e_ym_zp)) * dzhiq_kp;
+        const double emmo = 0.25 * (e_c + e_ym + e_xm_ym + e_xm);
+        const double epmo = 0.25 * (e_c + e_ym + e_xp_ym + e_xp);
+        tv = tv + (epmo * ((v_xp - v_c) * m.dxi + (u_xp - u_xp_ym) * m.dyi)
+                 - emmo * ((v_c - v_xm) * m.dxi + (u_c - u_ym) * m.dyi)) * m.dxi
+                + (e_c * (v_yp - v_c) - e_ym * (v_c - v_ym)) * 2. * m.dy2i
+                + (eomp * ((v_zp - v_c) * dzhi_kp + (w_zp - w_ym_zp) * m.dyi)
+                 - eomm * ((v_c - v_zm) * dzhi_k + (w_c - w_ym) * m.dyi)) * dzfi_k;
+      }
+      if (k >= 1) {  // diffw, :913-951
+        const double dzfi_km = m.dzfi[kf - 1];
+        const double emom = (dzf_km * (e_c + e_xm) + dzf_k * (e_zm + e_xm_zm)) * dzhiq_k;
+        const double eomm = (dzf_km * (e_c + e_ym) + dzf_k * (e_zm + e_ym_zm)) * dzhiq_k;
+        const double eopm = (dzf_km * (e_c + e_yp) + dzf_k * (e_zm + e_yp_zm)) * dzhiq_k;
+        const double epom = (dzf_km * (e_c + e_xp) + dzf_k * (e_zm + e_xp_zm)) * dzhiq_k;
+        tw = tw + (epom * ((w_xp - w_c) * m.dxi + (u_xp - u_xp_zm) * dzhi_k)
+                 - emom * ((w_c - w_xm) * m.dxi + (u_c - u_zm) * dzhi_k)) * m.dxi
+                + (eopm * ((w_yp - w_c) * m.dyi + (v_yp - v_yp_zm) * dzhi_k)
+                 - eomm * ((w_c - w_ym) * m.dyi + (v_c - v_zm) * dzhi_k)) * m.dyi
+                + (e_c * (w_zp - w_c) * dzfi_k - e_zm * (w_c - w_zm) * dzfi_km) * 2. * dzhi_k;
+      }
+    } else {
+      const double nu = numol;
+      // DNS forms, src/modsubgrid.f90:745-768, 855-878, 967-990
+      tu = tu + (nu * (u_xp - u_c) * m.dxi - nu * (u_c - u_xm) * m.dxi) * 2. * m.dxi
+              + (nu * ((u_yp - u_c) * m.dyi + (v_yp - v_xm_yp) * m.dxi)
+               - nu * ((u_c - u_ym) * m.dyi + (v_c - v_xm) * m.dxi)) * m.dyi
+              + (nu * ((u_zp - u_c) * dzhi_kp + (w_zp - w_xm_zp) * m.dxi)
+               - nu * ((u_c - u_zm) * dzhi_k + (w_c - w_xm) * m.dxi)) * dzfi_k;
+      tv = tv + (nu * ((v_xp - v_c) * m.dxi + (u_xp - u_xp_ym) * m.dyi)
+               - nu * ((v_c - v_xm) * m.dxi + (u_c - u_ym) * m.dyi)) * m.dxi
+              + (nu * (v_yp - v_c) - nu * (v_c - v_ym)) * 2. * m.dy2i
+              + (nu * ((v_zp - v_c) * dzhi_kp + (w_zp - w_ym_zp) * m.dyi)
+               - nu * ((v_c - v_zm) * dzhi_k + (w_c - w_ym) * m.dyi)) * dzfi_k;
+      if (k >= 1) {
+        const double dzfi_km = m.dzfi[kf - 1];
+        tw = tw + (nu * ((w_xp - w_c) * m.dxi + (u_xp - u_xp_zm) * dzhi_k)
+                 - nu * ((w_c - w_xm) * m.dxi + (u_c - u_zm) * dzhi_k)) * m.dxi
+                + (nu * ((w_yp - w_c) * m.dyi + (v_yp - v_yp_zm) * dzhi_k)
+                 - nu * ((w_c - w_ym) * m.dyi + (v_c - v_zm) * dzhi_k)) * m.dyi
+                + (nu * (w_zp - w_c) * dzfi_k - nu * (w_c - w_zm) * dzfi_km) * 2. * dzhi_k;
+      }
+    }
+  }
+
+  if (FORCES) {
+    tu = tu - m.dpdxl[kf];
+    tv = tv - m.dpdyl[kf];
+    if (k == 0) tw = 0.0;
+  }
+
+  a.up[c] = tu;
+  a.vp[c] = tv;
+  a.wp[c] = tw;   // unchanged at k = 0 unless FORCES (the reference's w loops start at kb+1)
+}
+
+// ---------------------------------------------------------------------------- closure
+// SGS: 1 = Smagorinsky (src/modsubgrid.f90:208-264), 2 = Vreman (:269-360).  The molecular
+// part is added in the same statement order as the reference (ekh from ekm first, then +nu).
+template <int SGS>
+__global__ __launch_bounds__(256) void closure_kernel(Geo g, Metrics m, Params pr, const double *__restrict__ u,
+                                                       const double *__restrict__ v, const double *__restrict__ w,
+                                                       double *__restrict__ ekm, double *__restrict__ ekh) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= g.nx || j >= g.ny) return;
+  const int kf = k + 1;
+  const int im = wrapm(i, g.nx), ip = wrapp(i, g.nx);
+  const long r0 = g.idx(0, j, k);
+  const long sy = g.sy, sz = g.sz;
+  const long c = r0 + i, xm = r0 + im, xp = r0 + ip;
+  const double dxi = m.dxi, dyi = m.dyi;
+  const double dzhi_k = m.dzhi[kf], dzhi_kp = m.dzhi[kf + 1], dzfi_k = m.dzfi[kf];
+  double em, eh;
+  if (SGS == 1) {
+    double t, strain2;
+    t = (u[xp] - u[c]) * dxi; strain2 = t * t;
+    t = (v[c + sy] - v[c]) * dyi; strain2 = strain2 + t * t;
+    t = (w[c + sz] - w[c]) * dzfi_k; strain2 = strain2 + t * t;
+    double a1 = (w[c + sz] - w[xm + sz]) * dxi + (u[c + sz] - u[c]) * dzhi_kp;
+    double a2 = (w[c] - w[xm]) * dxi + (u[c] - u[c - sz]) * dzhi_k;
+    double a3 = (w[xp] - w[c]) * dxi + (u[xp] - u[xp - sz]) * dzhi_k;
+    double a4 = (w[xp + sz] - w[c + sz]) * dxi + (u[xp + sz] - u[xp]) * dzhi_kp;
+    strain2 = strain2 + 0.125 * (a1 * a1 + a2 * a2 + a3 * a3 + a4 * a4);
+    a1 = (u[c + sy] - u[c]) * dyi + (v[c + sy] - v[xm + sy]) * dxi;
+    a2 = (u[c] - u[c - sy]) * dyi + (v[c] - v[xm]) * dxi;
+    a3 = (u[xp] - u[xp - sy]) * dyi + (v[xp] - v[c]) * dxi;
+    a4 = (u[xp + sy] - u[xp]) * dyi + (v[xp + sy] - v[c + sy]) * dxi;
+    strain2 = strain2 + 0.125 * (a1 * a1 + a2 * a2 + a3 * a3 + a4 * a4);
+    a1 = (v[c + sz] - v[c]) * dzhi_kp + (w[c + sz] - w[c - sy + sz]) * dyi;
+    a2 = (v[c] - v[c - sz]) * dzhi_k + (w[c] - w[c - sy]) * dyi;
+    a3 = (v[c + sy] - v[c + sy - sz]) * dzhi_k + (w[c + sy] - w[c]) * dyi;
+    a4 = (v[c + sy + sz] - v[c + sy]) * dzhi_kp + (w[c + sy + sz] - w[c + sz]) * dyi;
+    strain2 = strain2 + 0.125 * (a1 * a1 + a2 * a2 + a3 * a3 + a4 * a4);
+    const double ml = m.mlen[kf];
+    em = (ml * ml) * sqrt(2. * strain2);
+    eh = em * pr.prandtli;
+    em = em + pr.numol;
+    eh = eh + pr.numol * pr.prandtlmoli;
+  } else {
+    const double dzf_k = m.dzf[kf], dzf_km = m.dzf[kf - 1], dzf_kp = m.dzf[kf + 1];
+    const double a11 = (u[xp] - u[c]) * dxi;
+    const double a12 = (v[xp + sy] + v[xp] - v[xm + sy] - v[xm]) * m.dxiq;
+    const double a13 = (w[xp + sz] + w[xp] - w[xm + sz] - w[xm]) * m.dxiq;
+    const double a21 = (u[xp + sy] + u[c + sy] - u[xp - sy] - u[c - sy]) * m.dyiq;
+    const double a22 = (v[c + sy] - v[c]) * dyi;
+    const double a23 = (w[c + sy + sz] + w[c + sy] - w[c - sy + sz] - w[c - sy]) * m.dyiq;
+    const double a31 = (((u[xp + sz] + u[c + sz]) * dzf_k + (u[xp] + u[c]) * dzf_kp) * dzhi_kp
+                      - ((u[xp] + u[c]) * dzf_km + (u[xp - sz] + u[c - sz]) * dzf_k) * dzhi_k) * m.dzfiq[kf];
+    const double a32 = (((v[c + sy + sz] + v[c + sz]) * dzf_k + (v[c + sy] + v[c]) * dzf_kp) * dzhi_kp
+                      - ((v[c + sy] + v[c]) * dzf_km + (v[c + sy - sz] + v[c - sz]) * dzf_k) * dzhi_k) * m.dzfiq[kf];
+    const double a33 = (w[c + sz] - w[c]) * dzfi_k;
+    const double aa = a11 * a11 + a21 * a21 + a31 * a31 + a12 * a12 + a22 * a22 + a32 * a32
+                    + a13 * a13 + a23 * a23 + a33 * a33;
+    const double dx2 = m.dx2, dy2 = m.dy2, dz2 = m.dzf2[kf];
+    const double b11 = dx2 * a11 * a11 + dy2 * a21 * a21 + dz2 * a31 * a31;
+    const double b22 = dx2 * a12 * a12 + dy2 * a22 * a22 + dz2 * a32 * a32;
+    const double b12 = dx2 * a11 * a12 + dy2 * a21 * a22 + dz2 * a31 * a32;
+    const double b33 = dx2 * a13 * a13 + dy2 * a23 * a23 + dz2 * a33 * a33;
+    const double b13 = dx2 * a11 * a13 + dy2 * a21 * a23 + dz2 * a31 * a33;
+    const double b23 = dx2 * a12 * a13 + dy2 * a22 * a23 + dz2 * a32 * a33;
+    const double bb = b11 * b22 - b12 * b12 + b11 * b33 - b13 * b13 + b22 * b33 - b23 * b23;
+    em = (bb < 1.e-8) ? 0. : pr.c_vreman * sqrt(bb / aa);
+    eh = em * pr.prandtli;
+    em = em + pr.numol;
+    eh = eh + pr.numol * pr.prandtlmoli;
+  }
+  ekm[c] = em;
+  ekh[c] = eh;
+}
+
+__global__ void fill_const_kernel(Geo g, double *__restrict__ a, double val, double *__restrict__ b, double valb) {
+  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < g.n) { a[q] = val; b[q] = valb; }
+}
+
+// closurebc top/bottom rows, src/modboundary.f90:447-465, applied after the y ghosts are in
+// place (equivalent to the reference's "top/bottom, x wrap, y wrap" order: see DESIGN.md).
+__global__ void ek_topbot_kernel(Geo g, Params pr, double *__restrict__ ekm, double *__restrict__ ekh) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = (int)blockIdx.y - 1;            // rows -1 .. ny
+  if (i >= g.nx) return;
+  const double nm = pr.numol, nh = pr.numol * pr.prandtlmoli;
+  const long top = g.idx(i, j, g.nz - 1), bot = g.idx(i, j, 0);
+  if (pr.bctopm == UDC_TOP_NOSLIP) {
+    ekm[top + g.sz] = 2. * nm - ekm[top];
+    ekh[top + g.sz] = (2. * nh) - ekh[top];
+  } else {
+    ekm[top + g.sz] = ekm[top];
+    ekh[top + g.sz] = ekh[top];
+  }
+  ekm[bot - g.sz] = 2. * nm - ekm[bot];
+  ekh[bot - g.sz] = (2. * nh) - ekh[bot];
+}
+
+__global__ __launch_bounds__(256) void forces_kernel(Geo g, Metrics m, double *__restrict__ up,
+                                                      double *__restrict__ vp, double *__restrict__ wp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= g.nx || j >= g.ny) return;
+  const long c = g.idx(i, j, k);
+  up[c] = up[c] - m.dpdxl[k + 1];
+  vp[c] = vp[c] - m.dpdyl[k + 1];
+  if (k == 0) wp[c] = 0.0;
+}
+
+inline dim3 cell_grid(const Geo &g, dim3 b) {
+  return dim3((g.nx + b.x - 1) / b.x, (g.ny + b.y - 1) / b.y, g.nz);
+}
+
+}  // namespace
+
+int k_momentum(udc_handle *h, bool adv, bool diff, bool forces) {
+  const Geo &g = h->g;
+  MomArgs a{h->fields[UDC_U0], h->fields[UDC_V0], h->fields[UDC_W0], h->fields[UDC_PRES0],
+            h->fields[UDC_EKM], h->fields[UDC_UP], h->fields[UDC_VP], h->fields[UDC_WP]};
+  dim3 b(64, 4, 1), gr = cell_grid(g, b);
+  const bool les = h->p.sgs != UDC_SGS_DNS;
+  const double nu = h->p.numol;
+#define LAUNCH(A, D, L, F)                                                                   \
+  do {                                                                                       \
+    PROF(h, "mom_" #A #D #L #F);                                                             \
+    hipLaunchKernelGGL((mom_kernel<A, D, L, F>), gr, b, 0, h->stream, g, h->m, a, nu);       \
+  } while (0)
+  if (adv && diff) {
+    if (les) { if (forces) LAUNCH(true, true, true, true); else LAUNCH(true, true, true, false); }
+    else     { if (forces) LAUNCH(true, true, false, true); else LAUNCH(true, true, false, false); }
+  } else if (adv) {
+    LAUNCH(true, false, true, false);
+  } else if (diff) {
+    if (les) LAUNCH(false, true, true, false); else LAUNCH(false, true, false, false);
+  }
+#undef LAUNCH
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int k_forces(udc_handle *h) {
+  const Geo &g = h->g;
+  dim3 b(64, 4, 1), gr = cell_grid(g, b);
+  PROF(h, "forces");
+  hipLaunchKernelGGL(forces_kernel, gr, b, 0, h->stream, g, h->m, h->fields[UDC_UP], h->fields[UDC_VP],
+                     h->fields[UDC_WP]);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int k_closure(udc_handle *h) {
+  const Geo &g = h->g;
+  dim3 b(64, 4, 1), gr = cell_grid(g, b);
+  double *u = h->fields[UDC_U0], *v = h->fields[UDC_V0], *w = h->fields[UDC_W0];
+  double *ekm = h->fields[UDC_EKM], *ekh = h->fields[UDC_EKH];
+  PROF(h, "closure");
+  if (h->p.sgs == UDC_SGS_SMAGORINSKY)
+    hipLaunchKernelGGL((closure_kernel<1>), gr, b, 0, h->stream, g, h->m, h->p, u, v, w, ekm, ekh);
+  else if (h->p.sgs == UDC_SGS_VREMAN)
+    hipLaunchKernelGGL((closure_kernel<2>), gr, b, 0, h->stream, g, h->m, h->p, u, v, w, ekm, ekh);
+  else
+    hipLaunchKernelGGL(fill_const_kernel, dim3((unsigned)((g.n + 255) / 256)), dim3(256), 0, h->stream, g, ekm,
+                       h->p.numol, ekh, h->p.numol * h->p.prandtlmoli);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int k_ek_ghosts(udc_handle *h) {
+  const Geo &g = h->g;
+  const int f[2] = {UDC_EKM, UDC_EKH};
+  if (k_halo_y(h, f, 2, 1)) return 1;
+  PROF(h, "ek_topbot");
+  hipLaunchKernelGGL(ek_topbot_kernel, dim3((g.nx + 63) / 64, g.ny + 2), dim3(64), 0, h->stream, g, h->p,
+                     h->fields[UDC_EKM], h->fields[UDC_EKH]);
+  HIP_OK(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,464 @@
+// Pressure correction: divergence RHS (fillps), rocFFT (x,y) + batched Thomas solve in z
+// (solmpj), projection (tderive), RK3 update (tstep_integrate), plus the two reductions
+// (adaptive-dt maxima, chkdiv).
+//
+// Spectral layout.  The reference keeps real "half-complex" lines and transforms x then y
+// with 8 pencil transposes (src/modpois.f90:459-702).  Here the x and y transforms are one
+// batched rocFFT 2-D real-to-complex transform per k-plane, read straight from the padded
+// p field (strides), producing complex modes (kx = 0..nx/2, ky = 0..ny-1); every mode is an
+// independent real tridiagonal system in z, so Re and Im are solved with the same
+// coefficients.  Mode (kx,ky) has eigenvalue xrt(kx)+yrt(min(ky,ny-ky)), the same values the
+// reference assigns to the half-complex slots (:100-107,124-131); the two 1/sqrt(n) scalings
+// per direction (:490,534,623,677) collapse into one factor 1/(nx*ny).
+#include "udc_internal.h"
+#include <cmath>
+
+namespace {
+
+__device__ __forceinline__ int wrapm(int i, int nx) { return i == 0 ? nx - 1 : i - 1; }
+__device__ __forceinline__ int wrapp(int i, int nx) { return i == nx - 1 ? 0 : i + 1; }
+
+inline dim3 cell_grid(const Geo &g, dim3 b) {
+  return dim3((g.nx + b.x - 1) / b.x, (g.ny + b.y - 1) / b.y, g.nz);
+}
+
+// fillps + bcpup, src/modpois.f90:939-973, src/modboundary.f90:1227-1255,1309-1315:
+// p = d(pup)/dx + d(pvp)/dy + d(pwp)/dz with pup = up + um/rk3coef (not materialised),
+// pwp(kb) = pwp(ke+1) = 0, x cyclic by index wrap, y cyclic through the vp/vm ghost row.
+__global__ __launch_bounds__(256) void div_rhs_kernel(Geo g, Metrics m, double r,
+    const double *__restrict__ up, const double *__restrict__ vp, const double *__restrict__ wp,
+    const double *__restrict__ um, const double *__restrict__ vm, const double *__restrict__ wm,
+    double *__restrict__ p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= g.nx || j >= g.ny) return;
+  const long r0 = g.idx(0, j, k);
+  const long c = r0 + i, xp = r0 + wrapp(i, g.nx);
+  const double pu_c = up[c] + um[c] * r, pu_p = up[xp] + um[xp] * r;
+  const double pv_c = vp[c] + vm[c] * r, pv_p = vp[c + g.sy] + vm[c + g.sy] * r;
+  const double pw_c = (k == 0) ? 0. : wp[c] + wm[c] * r;
+  const double pw_p = (k == g.nz - 1) ? 0. : wp[c + g.sz] + wm[c + g.sz] * r;
+  p[c] = (pu_p - pu_c) * m.dxi + (pv_p - pv_c) * m.dyi + (pw_p - pw_c) * m.dzfi[k + 1];
+}
+
+// ---- Thomas tables: d(m,k) of solmpj (src/modpois.f90:1120-1139) does not depend on the RHS
+__global__ void thomas_table_kernel(int nmodes, int nz, const double *__restrict__ ev,
+                                    const double *__restrict__ tri, double btopD, double *__restrict__ dtab) {
+  const int mo = blockIdx.x * blockDim.x + threadIdx.x;
+  if (mo >= nmodes) return;
+  const double *a = tri, *b = tri + (nz + 2), *c = tri + 2 * (nz + 2);
+  const double e = ev[mo];
+  double z = 1. / (b[1] + e);
+  double d = c[1] * z;
+  dtab[mo] = d;
+  for (int k = 2; k <= nz - 1; ++k) {
+    const double bbk = b[k] + e;
+    z = 1. / (bbk - a[k] * d);
+    d = c[k] * z;
+    dtab[(long)(k - 1) * nmodes + mo] = d;
+  }
+  (void)btopD;
+}
+
+// solmpj, src/modpois.f90:1107-1166, one thread per (kx,ky) mode, complex data.
+// scale = 1/(nx*ny) carries the reference's four 1/sqrt(n) factors.
+__global__ __launch_bounds__(64) void thomas_kernel(int nmodes, int nz, double scale,
+    const double *__restrict__ ev, const double *__restrict__ tri, double btopD,
+    const double *__restrict__ dtab, double2 *__restrict__ x) {
+  const int mo = blockIdx.x * blockDim.x + threadIdx.x;
+  if (mo >= nmodes) return;
+  const double *a = tri, *b = tri + (nz + 2), *c = tri + 2 * (nz + 2);
+  const double e = ev[mo];
+  double z = 1. / (b[1] + e);
+  double d = c[1] * z;
+  double2 xp = x[mo];
+  xp.x = (xp.x * scale) * z; xp.y = (xp.y * scale) * z;
+  x[mo] = xp;
+  for (int k = 2; k <= nz - 1; ++k) {
+    const double bbk = b[k] + e;
+    z = 1. / (bbk - a[k] * d);
+    d = c[k] * z;
+    double2 xc = x[(long)(k - 1) * nmodes + mo];
+    xc.x = (xc.x * scale - a[k] * xp.x) * z;
+    xc.y = (xc.y * scale - a[k] * xp.y) * z;
+    x[(long)(k - 1) * nmodes + mo] = xc;
+    xp = xc;
+  }
+  {
+    // the singular (0,0) mode gets a Dirichlet condition across the top cell (:209-220)
+    const double bbk = (e == 0.) ? btopD : b[nz] + e;
+    const double ak = a[nz];
+    z = bbk - ak * d;
+    double2 xc = x[(long)(nz - 1) * nmodes + mo];
+    xc.x = (xc.x * scale - ak * xp.x) / z;
+    xc.y = (xc.y * scale - ak * xp.y) / z;
+    x[(long)(nz - 1) * nmodes + mo] = xc;
+    xp = xc;
+  }
+  for (int k = nz - 1; k >= 1; --k) {
+    const double dk = dtab[(long)(k - 1) * nmodes + mo];
+    double2 xc = x[(long)(k - 1) * nmodes + mo];
+    xc.x = xc.x - dk * xp.x;
+    xc.y = xc.y - dk * xp.y;
+    x[(long)(k - 1) * nmodes + mo] = xc;
+    xp = xc;
+  }
+}
+
+// compact (nx,ny,nz) <-> padded field interior (only used when rocFFT rejects the padded layout)
+template <bool TO_FIELD>
+__global__ __launch_bounds__(256) void real_copy_kernel(Geo g, double *__restrict__ field, double *__restrict__ buf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= g.nx || j >= g.ny) return;
+  const long c = g.idx(i, j, k);
+  const long q = (long)i + (long)g.nx * (j + (long)g.ny * k);
+  if (TO_FIELD) field[c] = buf[q]; else buf[q] = field[c];
+}
+
+// tderive, src/modpois.f90:1046-1056,1096-1102 (p ghosts: x by wrap, y by ghost row)
+__global__ __launch_bounds__(256) void project_kernel(Geo g, Metrics m, const double *__restrict__ p,
+    double *__restrict__ up, double *__restrict__ vp, double *__restrict__ wp, double *__restrict__ pres0) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= g.nx || j >= g.ny) return;
+  const long r0 = g.idx(0, j, k);
+  const long c = r0 + i, xm = r0 + wrapm(i, g.nx);
+  const double pc = p[c];
+  up[c] = up[c] - (pc - p[xm]) * m.dxi;
+  vp[c] = vp[c] - (pc - p[c - g.sy]) * m.dyi;
+  if (k >= 1) wp[c] = wp[c] - (pc - p[c - g.sz]) * m.dzhi[k + 1];
+  pres0[c] = pres0[c] + pc;
+}
+
+struct IntArgs {
+  double *u0, *v0, *w0, *um, *vm, *wm, *up, *vp, *wp;
+  double *sv0[16], *svm[16], *svp[16];
+  int nsv;
+};
+
+// tstep_integrate, src/modtstep.f90:219-230,322-338; PROJECT fuses tderive in front of it.
+template <bool PROJECT>
+__global__ __launch_bounds__(256) void integrate_kernel(Geo g, Metrics m, IntArgs a, const double *__restrict__ p,
+                                                         double *__restrict__ pres0, double rk3coef, int last) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= g.nx || j >= g.ny) return;
+  const long r0 = g.idx(0, j, k);
+  const long c = r0 + i;
+  double tu = a.up[c], tv = a.vp[c], tw = a.wp[c];
+  if (PROJECT) {
+    const long xm = r0 + wrapm(i, g.nx);
+    const double pc = p[c];
+    tu = tu - (pc - p[xm]) * m.dxi;
+    tv = tv - (pc - p[c - g.sy]) * m.dyi;
+    if (k >= 1) tw = tw - (pc - p[c - g.sz]) * m.dzhi[k + 1];
+    pres0[c] = pres0[c] + pc;
+  }
+  const double u = a.um[c] + rk3coef * tu;
+  const double v = a.vm[c] + rk3coef * tv;
+  const double w = a.wm[c] + rk3coef * tw;
+  a.u0[c] = u; a.v0[c] = v; a.w0[c] = w;
+  a.up[c] = 0.; a.vp[c] = 0.; a.wp[c] = 0.;
+  if (last) { a.um[c] = u; a.vm[c] = v; a.wm[c] = w; }
+  for (int s = 0; s < a.nsv; ++s) {
+    const double sv = a.svm[s][c] + rk3coef * a.svp[s][c];
+    a.sv0[s][c] = sv;
+    a.svp[s][c] = 0.;
+    if (last) a.svm[s][c] = sv;
+  }
+}
+
+// ---- reductions ---------------------------------------------------------------------
+__device__ __forceinline__ double wave_max(double v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ void atomic_max_nonneg(double *addr, double v) {
+  atomicMax(reinterpret_cast<unsigned long long *>(addr), (unsigned long long)__double_as_longlong(v));
+}
+
+// tstep_update, src/modtstep.f90:113-128
+__global__ __launch_bounds__(256) void maxima_kernel(Geo g, Metrics m, double dt, const double *__restrict__ um,
+    const double *__restrict__ vm, const double *__restrict__ wm, const double *__restrict__ ekm,
+    const double *__restrict__ ekh, double *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  double cour = 0., dif = 0.;
+  if (i < g.nx && j < g.ny) {
+    const long c = g.idx(i, j, k);
+    cour = (fabs(um[c]) * m.dxi + fabs(vm[c]) * m.dyi + fabs(wm[c]) / m.dzh[k + 1]) * dt;
+    const double f = (m.dzh2i[k + 1] + m.dx2i + m.dy2i);
+    dif = fmax(ekm[c] * f * dt, ekh[c] * f * dt);
+  }
+  cour = wave_max(cour); dif = wave_max(dif);
+  if ((threadIdx.x & 63) == 0 && (threadIdx.y * blockDim.x + threadIdx.x) % 64 == 0) {
+    atomic_max_nonneg(out, cour);
+    atomic_max_nonneg(out + 1, dif);
+  }
+}
+
+// chkdiv, src/modchecksim.f90:179-191
+__global__ __launch_bounds__(256) void divcheck_kernel(Geo g, Metrics m, const double *__restrict__ u,
+    const double *__restrict__ v, const double *__restrict__ w, double *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  double dmax = 0., dsum = 0.;
+  if (i < g.nx && j < g.ny) {
+    const long r0 = g.idx(0, j, k);
+    const long c = r0 + i, xp = r0 + wrapp(i, g.nx);
+    const double div = (u[xp] - u[c]) * m.dxi + (v[c + g.sy] - v[c]) * m.dyi + (w[c + g.sz] - w[c]) * m.dzfi[k + 1];
+    dmax = fabs(div);
+    dsum = div * m.dx * m.dy * m.dzf[k + 1];
+  }
+  dmax = wave_max(dmax); dsum = wave_sum(dsum);
+  if ((threadIdx.y * blockDim.x + threadIdx.x) % 64 == 0) {
+    atomic_max_nonneg(out, dmax);
+    atomicAdd(out + 1, dsum);
+  }
+}
+
+}  // namespace
+
+// --------------------------------------------------------------------------------------
+int pois_init(udc_handle *h) {
+  const Geo &g = h->g;
+  const int nx = g.nx, ny = g.ny, nz = g.nz;
+  const int nkx = nx / 2 + 1;
+  h->nkx = nkx;
+  const long nmodes = (long)nkx * ny;
+  const double pi = 3.141592653589793116;   // src/modglobal.f90:270
+  const double dxi = h->m.dxi, dyi = h->m.dyi;
+  // eigenvalues, src/modpois.f90:100-107,124-131 (value of complex mode kx = slot 2kx)
+  std::vector<double> xrt(nkx), yrt(ny), ev(nmodes);
+  {
+    const double fac = 1. / (2. * nx);
+    for (int kx = 1; kx < nx / 2; ++kx) { double s = sin((double)(2 * kx) * pi * fac); xrt[kx] = -4. * dxi * dxi * (s * s); }
+    xrt[0] = 0.; xrt[nx / 2] = -4. * dxi * dxi;
+  }
+  {
+    const double fac = 1. / (2. * ny);
+    for (int ky = 0; ky < ny; ++ky) {
+      const int mm = ky <= ny / 2 ? ky : ny - ky;
+      if (mm == 0) yrt[ky] = 0.;
+      else if (mm == ny / 2) yrt[ky] = -4. * dyi * dyi;
+      else { double s = sin((double)(2 * mm) * pi * fac); yrt[ky] = -4. * dyi * dyi * (s * s); }
+    }
+  }
+  for (int ky = 0; ky < ny; ++ky)
+    for (int kx = 0; kx < nkx; ++kx) ev[(long)ky * nkx + kx] = 1. * (xrt[kx] + yrt[ky] + 0.);
+  // tridiagonal coefficients, :154-176 (rhobf = rhobh = 1)
+  std::vector<double> tri(3 * (nz + 2), 0.0);
+  double *a = &tri[0], *b = &tri[nz + 2], *c = &tri[2 * (nz + 2)];
+  for (int k = 1; k <= nz; ++k) {
+    a[k] = 1. / (h->cfg.dzf[k] * h->cfg.dzh[k]);
+    c[k] = 1. / (h->cfg.dzf[k] * h->cfg.dzh[k + 1]);
+    b[k] = -(a[k] + c[k]);
+  }
+  b[1] = b[1] + a[1];
+  const double b_top_N = b[nz] + c[nz];
+  const double b_top_D = b[nz] - c[nz];
+  b[nz] = b_top_N;
+  a[1] = 0.; c[nz] = 0.;
+  h->btopD = b_top_D;
+
+  HIP_OK(hipMalloc(&h->spec, sizeof(double) * 2 * nmodes * nz));
+  HIP_OK(hipMalloc(&h->dtab, sizeof(double) * nmodes * (nz > 1 ? nz - 1 : 1)));
+  HIP_OK(hipMalloc(&h->ev, sizeof(double) * nmodes));
+  HIP_OK(hipMalloc(&h->tri, sizeof(double) * tri.size()));
+  HIP_OK(hipMemcpy(h->ev, ev.data(), sizeof(double) * nmodes, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(h->tri, tri.data(), sizeof(double) * tri.size(), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(thomas_table_kernel, dim3((unsigned)((nmodes + 63) / 64)), dim3(64), 0, h->stream,
+                     (int)nmodes, nz, h->ev, h->tri, b_top_D, h->dtab);
+  HIP_OK(hipGetLastError());
+
+  // rocFFT: batched 2-D real <-> Hermitian-interleaved, reading/writing the padded p field
+  static bool setup_done = false;
+  if (!setup_done) { FFT_OK(rocfft_setup()); setup_done = true; }
+  size_t lengths[2] = {(size_t)nx, (size_t)ny};
+  size_t cstr[2] = {1, (size_t)nkx};
+  size_t off[1] = {0};
+  // rocFFT (ROCm 7.2) refuses some padded real layouts (e.g. 8x8, 16x16 inverse): fall back to a
+  // compact real staging buffer + one strided copy for those sizes only.
+  for (int dir = 0; dir < 2; ++dir) {
+    rocfft_plan *plan = dir == 0 ? &h->plan_fwd : &h->plan_bwd;
+    bool *compact = dir == 0 ? &h->fwd_compact : &h->bwd_compact;
+    for (int attempt = 0; attempt < 2 && !*plan; ++attempt) {
+      const bool cmp = attempt == 1;
+      size_t rstr[2] = {1, cmp ? (size_t)nx : (size_t)g.sy};
+      const size_t rdist = cmp ? (size_t)nx * ny : (size_t)g.sz;
+      rocfft_plan_description d = nullptr;
+      FFT_OK(rocfft_plan_description_create(&d));
+      if (dir == 0)
+        FFT_OK(rocfft_plan_description_set_data_layout(d, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved,
+                                                       off, off, 2, rstr, rdist, 2, cstr, (size_t)nmodes));
+      else
+        FFT_OK(rocfft_plan_description_set_data_layout(d, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real,
+                                                       off, off, 2, cstr, (size_t)nmodes, 2, rstr, rdist));
+      rocfft_status st = rocfft_plan_create(plan, rocfft_placement_notinplace,
+                                            dir == 0 ? rocfft_transform_type_real_forward : rocfft_transform_type_real_inverse,
+                                            rocfft_precision_double, 2, lengths, (size_t)nz, d);
+      rocfft_plan_description_destroy(d);
+      if (st != rocfft_status_success) *plan = nullptr;
+      else *compact = cmp;
+    }
+    if (!*plan) { udc_set_error("rocfft_plan_create failed for %dx%d (batch %d)", nx, ny, nz); return 1; }
+  }
+  if (h->fwd_compact || h->bwd_compact) HIP_OK(hipMalloc(&h->rbuf, sizeof(double) * (size_t)nx * ny * nz));
+  size_t wf = 0, wb = 0;
+  FFT_OK(rocfft_plan_get_work_buffer_size(h->plan_fwd, &wf));
+  FFT_OK(rocfft_plan_get_work_buffer_size(h->plan_bwd, &wb));
+  const size_t wmax = wf > wb ? wf : wb;
+  if (wmax) HIP_OK(hipMalloc(&h->fft_work, wmax));
+  FFT_OK(rocfft_execution_info_create(&h->info_fwd));
+  FFT_OK(rocfft_execution_info_create(&h->info_bwd));
+  FFT_OK(rocfft_execution_info_set_stream(h->info_fwd, h->stream));
+  FFT_OK(rocfft_execution_info_set_stream(h->info_bwd, h->stream));
+  if (wf) FFT_OK(rocfft_execution_info_set_work_buffer(h->info_fwd, h->fft_work, wf));
+  if (wb) FFT_OK(rocfft_execution_info_set_work_buffer(h->info_bwd, h->fft_work, wb));
+  return 0;
+}
+
+void pois_destroy(udc_handle *h) {
+  if (h->plan_fwd) rocfft_plan_destroy(h->plan_fwd);
+  if (h->plan_bwd) rocfft_plan_destroy(h->plan_bwd);
+  if (h->info_fwd) rocfft_execution_info_destroy(h->info_fwd);
+  if (h->info_bwd) rocfft_execution_info_destroy(h->info_bwd);
+  if (h->fft_work) hipFree(h->fft_work);
+  if (h->spec) hipFree(h->spec);
+  if (h->rbuf) hipFree(h->rbuf);
+  if (h->dtab) hipFree(h->dtab);
+  if (h->ev) hipFree(h->ev);
+  if (h->tri) hipFree(h->tri);
+}
+
+int k_divergence_rhs(udc_handle *h, double rk3coef) {
+  const Geo &g = h->g;
+  dim3 b(64, 4, 1), gr = cell_grid(g, b);
+  PROF(h, "div_rhs");
+  hipLaunchKernelGGL(div_rhs_kernel, gr, b, 0, h->stream, g, h->m, 1. / rk3coef, h->fields[UDC_UP],
+                     h->fields[UDC_VP], h->fields[UDC_WP], h->fields[UDC_UM], h->fields[UDC_VM],
+                     h->fields[UDC_WM], h->fields[UDC_P]);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int k_poisson_solve(udc_handle *h) {
+  const Geo &g = h->g;
+  const long nmodes = (long)h->nkx * g.ny;
+  double *pin = h->fields[UDC_P] + g.idx(0, 0, 0);
+  dim3 b(64, 4, 1), gr = cell_grid(g, b);
+  if (h->fwd_compact) {
+    PROF(h, "fft_pack");
+    hipLaunchKernelGGL((real_copy_kernel<false>), gr, b, 0, h->stream, g, h->fields[UDC_P], h->rbuf);
+  }
+  {
+    PROF(h, "fft_fwd");
+    void *in[1] = {h->fwd_compact ? h->rbuf : pin}, *out[1] = {h->spec};
+    FFT_OK(rocfft_execute(h->plan_fwd, in, out, h->info_fwd));
+  }
+  {
+    PROF(h, "thomas");
+    hipLaunchKernelGGL(thomas_kernel, dim3((unsigned)((nmodes + 63) / 64)), dim3(64), 0, h->stream, (int)nmodes,
+                       g.nz, 1. / ((double)g.nx * (double)g.ny), h->ev, h->tri, h->btopD, h->dtab,
+                       reinterpret_cast<double2 *>(h->spec));
+    HIP_OK(hipGetLastError());
+  }
+  {
+    PROF(h, "fft_bwd");
+    void *in[1] = {h->spec}, *out[1] = {h->bwd_compact ? h->rbuf : pin};
+    FFT_OK(rocfft_execute(h->plan_bwd, in, out, h->info_bwd));
+  }
+  if (h->bwd_compact) {
+    PROF(h, "fft_unpack");
+    hipLaunchKernelGGL((real_copy_kernel<true>), gr, b, 0, h->stream, g, h->fields[UDC_P], h->rbuf);
+  }
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int k_project(udc_handle *h) {
+  const Geo &g = h->g;
+  dim3 b(64, 4, 1), gr = cell_grid(g, b);
+  PROF(h, "project");
+  hipLaunchKernelGGL(project_kernel, gr, b, 0, h->stream, g, h->m, h->fields[UDC_P], h->fields[UDC_UP],
+                     h->fields[UDC_VP], h->fields[UDC_WP], h->fields[UDC_PRES0]);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+static IntArgs int_args(udc_handle *h) {
+  IntArgs a;
+  a.u0 = h->fields[UDC_U0]; a.v0 = h->fields[UDC_V0]; a.w0 = h->fields[UDC_W0];
+  a.um = h->fields[UDC_UM]; a.vm = h->fields[UDC_VM]; a.wm = h->fields[UDC_WM];
+  a.up = h->fields[UDC_UP]; a.vp = h->fields[UDC_VP]; a.wp = h->fields[UDC_WP];
+  a.nsv = h->cfg.nsv;
+  for (int n = 0; n < a.nsv; ++n) {
+    a.sv0[n] = h->fields[UDC_SV0 + 3 * n];
+    a.svm[n] = h->fields[UDC_SVM + 3 * n];
+    a.svp[n] = h->fields[UDC_SVP + 3 * n];
+  }
+  return a;
+}
+
+int k_integrate(udc_handle *h, int rk3step, double dt) {
+  const Geo &g = h->g;
+  dim3 b(64, 4, 1), gr = cell_grid(g, b);
+  const double rk3coef = dt / (4. - (double)rk3step);
+  PROF(h, "integrate");
+  hipLaunchKernelGGL((integrate_kernel<false>), gr, b, 0, h->stream, g, h->m, int_args(h),
+                     (const double *)nullptr, (double *)nullptr, rk3coef, rk3step == 3 ? 1 : 0);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int k_project_integrate(udc_handle *h, int rk3step, double dt) {
+  const Geo &g = h->g;
+  dim3 b(64, 4, 1), gr = cell_grid(g, b);
+  const double rk3coef = dt / (4. - (double)rk3step);
+  PROF(h, "project_integrate");
+  hipLaunchKernelGGL((integrate_kernel<true>), gr, b, 0, h->stream, g, h->m, int_args(h),
+                     (const double *)h->fields[UDC_P], h->fields[UDC_PRES0], rk3coef, rk3step == 3 ? 1 : 0);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int k_maxima(udc_handle *h, double dt, double *cour, double *diffn) {
+  const Geo &g = h->g;
+  dim3 b(64, 4, 1), gr = cell_grid(g, b);
+  h->red_host[0] = 0.; h->red_host[1] = 1e-5;   // diffnrtotl starts at 1e-5, src/modtstep.f90:115
+  HIP_OK(hipMemcpyAsync(h->red, h->red_host, 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(maxima_kernel, gr, b, 0, h->stream, g, h->m, dt, h->fields[UDC_UM], h->fields[UDC_VM],
+                     h->fields[UDC_WM], h->fields[UDC_EKM], h->fields[UDC_EKH], h->red);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipMemcpyAsync(h->red_host, h->red, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  *cour = h->red_host[0];
+  *diffn = h->red_host[1];
+  return 0;
+}
+
+int k_divergence_check(udc_handle *h, double *divmax, double *divtot) {
+  const Geo &g = h->g;
+  dim3 b(64, 4, 1), gr = cell_grid(g, b);
+  h->red_host[0] = 0.; h->red_host[1] = 0.;
+  HIP_OK(hipMemcpyAsync(h->red, h->red_host, 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(divcheck_kernel, gr, b, 0, h->stream, g, h->m, h->fields[UDC_U0], h->fields[UDC_V0],
+                     h->fields[UDC_W0], h->red);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipMemcpyAsync(h->red_host, h->red, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  *divmax = h->red_host[0];
+  *divtot = h->red_host[1];
+  return 0;
+}

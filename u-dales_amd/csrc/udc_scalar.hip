@@ -1,0 +1,126 @@
+// Passive scalars: kappa-scheme (flux-limited, kappa = 1/3) advection and eddy diffusion.
+// Reference: advecc_kappa + rlim (src/modadvection.f90:316-421), diffc (src/modsubgrid.f90:540-623).
+// The reference builds each direction's fluxes into two 3-D temporaries and adds them to the
+// tendency (6 zero-fills, 3 whole-array adds); here every cell evaluates its six face values
+// in registers and accumulates in the reference's order ((cp + upper) + lower per direction).
+#include "udc_internal.h"
+
+namespace {
+
+__device__ __forceinline__ int wrap(int i, int nx) { return i < 0 ? i + nx : (i >= nx ? i - nx : i); }
+
+// src/modadvection.f90:410-421, eps1 = 1e-10 (src/modglobal.f90:318)
+__device__ __forceinline__ double rlim(double d1, double d2) {
+  const double eps1 = 1.e-10;
+  const double ri = (d2 + eps1) / (d1 + eps1);
+  const double phir = fmax(0., fmin(2. * ri, fmin(1. / 3. + 2. / 3. * ri, 2.)));
+  return 0.5 * phir * d1;
+}
+
+// face value on the low side of cell "0" given velocity vel there:
+// cm2,cm1,c0,cp1 = c at -2,-1,0,+1 ; h* = inverse half-level spacings at -1, 0, +1 ; df = cell size factor
+__device__ __forceinline__ double face(double vel, double cm2, double cm1, double c0, double cp1,
+                                       double hm1, double h0, double hp1, double df) {
+  double d1, d2, cf;
+  if (vel > 0) { d1 = (cm1 - cm2) * hm1; d2 = (c0 - cm1) * h0; cf = cm1; }
+  else { d1 = (c0 - cp1) * hp1; d2 = (cm1 - c0) * h0; cf = c0; }
+  return cf + df * rlim(d1, d2);
+}
+
+template <bool ADV, bool DIFF, bool LES>
+__global__ __launch_bounds__(256) void scalar_kernel(Geo g, Metrics m, double cekh, const double *__restrict__ u,
+    const double *__restrict__ v, const double *__restrict__ w, const double *__restrict__ ekh,
+    const double *__restrict__ c, double *__restrict__ cp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= g.nx || j >= g.ny) return;
+  const int kf = k + 1;
+  const long r0 = g.idx(0, j, k);
+  const long sy = g.sy, sz = g.sz;
+  const long o = r0 + i;
+  const long xm1 = r0 + wrap(i - 1, g.nx), xm2 = r0 + wrap(i - 2, g.nx);
+  const long xp1 = r0 + wrap(i + 1, g.nx), xp2 = r0 + wrap(i + 2, g.nx);
+  const double c0 = c[o];
+  const double cxm1 = c[xm1], cxp1 = c[xp1], cym1 = c[o - sy], cyp1 = c[o + sy], czm1 = c[o - sz], czp1 = c[o + sz];
+  double t = cp[o];
+  if (ADV) {
+    const double cxm2 = c[xm2], cxp2 = c[xp2];
+    const double cym2 = c[o - 2 * sy], cyp2 = c[o + 2 * sy];
+    const double czm2 = c[o - 2 * sz], czp2 = c[o + 2 * sz];
+    const double dxi = m.dxi, dx = m.dx, dyi = m.dyi;
+    {  // x: faces i (low) and i+1 (high); dxhci = dxi, dxfc = dx, dxfci = dxi on the uniform grid
+      const double ul = u[o], uh = u[xp1];
+      const double fl = face(ul, cxm2, cxm1, c0, cxp1, dxi, dxi, dxi, dx);
+      const double fh = face(uh, cxm1, c0, cxp1, cxp2, dxi, dxi, dxi, dx);
+      t = (t + (-fh * uh * dxi)) + fl * ul * dxi;
+    }
+    {  // y (no stretching: d's are plain differences, df = 1)
+      const double vl = v[o], vh = v[o + sy];
+      const double fl = face(vl, cym2, cym1, c0, cyp1, 1., 1., 1., 1.);
+      const double fh = face(vh, cym1, c0, cyp1, cyp2, 1., 1., 1., 1.);
+      t = (t + (-fh * vh * dyi)) + fl * vl * dyi;
+    }
+    {  // z: faces kb+1..ke+1 only (no flux through the floor, src/modadvection.f90:385)
+      const int nzp1 = g.nz + 1;
+      const double hkm1 = m.dzhi[kf - 1 < 1 ? 1 : kf - 1], hk = m.dzhi[kf], hkp1 = m.dzhi[kf + 1];
+      const double hkp2 = m.dzhi[kf + 2 > nzp1 ? nzp1 : kf + 2];
+      const double wl = w[o], wh = w[o + sz];
+      const double dzfci = m.dzfi[kf];
+      const double fh = face(wh, czm1, c0, czp1, czp2, hk, hkp1, hkp2, m.dzf[kf + 1]);
+      const double upper = -fh * wh * dzfci;
+      double lower = 0.;
+      if (k >= 1) {
+        const double fl = face(wl, czm2, czm1, c0, czp1, hkm1, hk, hkp1, m.dzf[kf]);
+        lower = fl * wl * dzfci;
+      }
+      t = (t + upper) + lower;
+    }
+  }
+  if (DIFF) {
+    const double dzf_k = m.dzf[kf], dzf_km = m.dzf[kf - 1], dzf_kp = m.dzf[kf + 1];
+    if (LES) {
+      const double e0 = ekh[o], exm = ekh[xm1], exp_ = ekh[xp1], eym = ekh[o - sy], eyp = ekh[o + sy],
+                   ezm = ekh[o - sz], ezp = ekh[o + sz];
+      t = t + 0.5 * (((exp_ + e0) * (cxp1 - c0) - (e0 + exm) * (c0 - cxm1)) * m.dx2i
+                   + ((eyp + e0) * (cyp1 - c0) - (e0 + eym) * (c0 - cym1)) * m.dy2i
+                   + ((dzf_kp * e0 + dzf_k * ezp) * (czp1 - c0) * m.dzh2i[kf + 1]
+                    - (dzf_km * e0 + dzf_k * ezm) * (c0 - czm1) * m.dzh2i[kf]) * m.dzfi[kf]);
+    } else {
+      t = t + ((cekh * (cxp1 - c0) - cekh * (c0 - cxm1)) * m.dx2i
+             + (cekh * (cyp1 - c0) - cekh * (c0 - cym1)) * m.dy2i
+             + (cekh * (czp1 - c0) * m.dzhi[kf + 1] - cekh * (c0 - czm1) * m.dzhi[kf]) * m.dzfi[kf]);
+    }
+  }
+  cp[o] = t;
+}
+
+inline dim3 cell_grid(const Geo &g, dim3 b) {
+  return dim3((g.nx + b.x - 1) / b.x, (g.ny + b.y - 1) / b.y, g.nz);
+}
+
+}  // namespace
+
+static int launch_scalar(udc_handle *h, int n, bool adv, bool diff) {
+  const Geo &g = h->g;
+  dim3 b(64, 4, 1), gr = cell_grid(g, b);
+  const double cekh = h->p.numol * h->p.prandtlmoli;
+  const double *u = h->fields[UDC_U0], *v = h->fields[UDC_V0], *w = h->fields[UDC_W0];
+  const double *ekh = h->fields[UDC_EKH], *c = h->fields[UDC_SV0 + 3 * n];
+  double *cp = h->fields[UDC_SVP + 3 * n];
+  const bool les = h->p.sgs != UDC_SGS_DNS;
+#define LS(A, D, L)                                                                                     \
+  do {                                                                                                  \
+    PROF(h, "scalar_" #A #D #L);                                                                        \
+    hipLaunchKernelGGL((scalar_kernel<A, D, L>), gr, b, 0, h->stream, g, h->m, cekh, u, v, w, ekh, c, cp); \
+  } while (0)
+  if (adv && diff) { if (les) LS(true, true, true); else LS(true, true, false); }
+  else if (adv) LS(true, false, true);
+  else if (diff) { if (les) LS(false, true, true); else LS(false, true, false); }
+#undef LS
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int k_scalar_adv(udc_handle *h, int n) { return launch_scalar(h, n, true, false); }
+int k_scalar_diff(udc_handle *h, int n) { return launch_scalar(h, n, false, true); }

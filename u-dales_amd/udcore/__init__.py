@@ -1,0 +1,31 @@
+"""udcore: MI355X-native dynamical core for uDALES (host-side Python mirror of the call surface).
+
+The package directory is `u-dales_amd/` (not an importable name): add it to sys.path and
+`import udcore` (tests/conftest.py, bench.py and __graft_entry__.py do that).
+"""
+from .grid import Grid, cold_start, sgs_from_deck  # noqa: F401
+from .namoptions import read_deck, Deck  # noqa: F401
+
+
+def from_deck(deck, device=0, rank=0, nranks=1):
+    """Build a DynCore from a parsed deck (same namoptions the reference reads)."""
+    from .core import DynCore
+    g = Grid.from_deck(deck)
+    sgs, csz, c_vreman, prandtli = sgs_from_deck(deck)
+    core = DynCore(g, sgs=sgs, bctopm=int(deck.get("BC", "BCtopm")), nsv=int(deck.get("SCALARS", "nsv")),
+                   prandtli=prandtli, c_vreman=c_vreman, csz=csz, device=device, rank=rank, nranks=nranks)
+    import numpy as np
+    # dpdxl, dpdyl: src/modstartup.f90:2071-2081 (lcoriol false => om23_gs terms still present:
+    # dpdxl = om23_gs*vg - pgx - dpdx with om23_gs = 2*omega*sin(lat); ug = vg = 0 in our decks)
+    import math
+    phi = 52. * 3.141592653589793116 / 180.
+    om23_gs = 2. * 7.292e-5 * math.sin(phi)
+    dpdx = float(deck.get("PHYSICS", "dpdx"))
+    if deck.get("PHYSICS", "lprofforc"):
+        dpdxl = [-pg - dpdx for pg in deck.pgx]
+        dpdyl = [-pg for pg in deck.pgy]
+    else:
+        dpdxl = [om23_gs * vg - pg - dpdx for vg, pg in zip(deck.vg, deck.pgx)]
+        dpdyl = [-om23_gs * ug - pg for ug, pg in zip(deck.ug, deck.pgy)]
+    core.set_forcing(np.array(dpdxl), np.array(dpdyl))
+    return core

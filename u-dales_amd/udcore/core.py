@@ -1,0 +1,155 @@
+"""Host-side mirror of the reference's dynamical-core call surface, in Python.
+
+`DynCore` exposes the procedures program.f90 calls (src/program.f90:134-207) with the same
+names and order -- tstep_update, advection, subgrid, forces, poisson, tstep_integrate, halos,
+boundary -- each a thin call into the C ABI (include/udcore.h).  The Fortran drop-in modules
+in u-dales_amd/fortran/ do the same thing from the reference's own driver.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import lib as L
+from .grid import Grid
+
+
+class DynCore:
+    def __init__(self, g: Grid, sgs=L.SGS_VREMAN, bctopm=1, nsv=0, numol=1.5e-5, prandtlmol=0.71,
+                 prandtli=1. / 0.333, c_vreman=0.07, csz=0.21658244510412, uinf=0., vinf=0.,
+                 device=0, rank=0, nranks=1):
+        self.g = g
+        self.nsv = nsv
+        self.lib = L.load()
+        self._dzf = np.ascontiguousarray(g.dzf, dtype=np.float64)
+        self._dzh = np.ascontiguousarray(g.dzh, dtype=np.float64)
+        cfg = L.UdcConfig(g.nx, g.ny, g.nz, nranks, rank, device, g.dx, g.dy,
+                          self._dzf.ctypes.data_as(L.DP), self._dzh.ctypes.data_as(L.DP),
+                          numol, 1. / prandtlmol, prandtli, c_vreman, csz, sgs, bctopm, uinf, vinf, nsv)
+        self.h = C.c_void_p()
+        L._check(self.lib.udc_create(C.byref(cfg), C.byref(self.h)), "udc_create")
+        self.nyl = g.ny // nranks
+        self.rk3step = 0
+        self.dt = 0.
+        self.timee = 0.
+
+    # ---- lifetime
+    def close(self):
+        if self.h:
+            self.lib.udc_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- residency
+    def _bounds(self, arr):
+        nz, ny, nx = arr.shape
+        hx = (nx - self.g.nx) // 2
+        hy = (ny - self.nyl) // 2
+        hz = (nz - self.g.nz) // 2
+        lb = (C.c_int * 3)(1 - hx, 1 - hy, 1 - hz)
+        ub = (C.c_int * 3)(self.g.nx + hx, self.nyl + hy, self.g.nz + hz)
+        return lb, ub
+
+    def upload(self, field, arr):
+        """arr: [k, j, i] float64 with symmetric halos (any width) around the local interior."""
+        fid = L.FIELD_IDS[field] if isinstance(field, str) else field
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        lb, ub = self._bounds(a)
+        L._check(self.lib.udc_field_upload(self.h, fid, a.ctypes.data_as(L.DP), lb, ub), f"upload {field}")
+
+    def download(self, field, halo=1):
+        fid = L.FIELD_IDS[field] if isinstance(field, str) else field
+        a = np.zeros((self.g.nz + 2 * halo, self.nyl + 2 * halo, self.g.nx + 2 * halo))
+        lb, ub = self._bounds(a)
+        L._check(self.lib.udc_field_download(self.h, fid, a.ctypes.data_as(L.DP), lb, ub), f"download {field}")
+        return a
+
+    def set_forcing(self, dpdxl, dpdyl):
+        a = np.ascontiguousarray(dpdxl, dtype=np.float64)
+        b = np.ascontiguousarray(dpdyl, dtype=np.float64)
+        L._check(self.lib.udc_set_forcing(self.h, a.ctypes.data_as(L.DP), b.ctypes.data_as(L.DP), len(a)),
+                 "udc_set_forcing")
+
+    def load_state(self, st: dict):
+        """st: output of grid.cold_start() or any dict of named arrays."""
+        for name, arr in st.items():
+            if name in L.FIELD_IDS:
+                self.upload(name, arr)
+            elif name.startswith("sv0_"):
+                self.upload(L.scalar_field(L.SV0, int(name[4:])), arr)
+            elif name.startswith("svm_"):
+                self.upload(L.scalar_field(L.SVM, int(name[4:])), arr)
+            elif name.startswith("svp_"):
+                self.upload(L.scalar_field(L.SVP, int(name[4:])), arr)
+
+    # ---- the reference's call surface
+    def tstep_update(self, dtmax, ladaptive=False, courant=1.5, diffnr=0.25):
+        """src/modtstep.f90:49-154 (normal time loop branch)."""
+        self.rk3step = self.rk3step % 3 + 1
+        if self.rk3step == 1:
+            if ladaptive:
+                c, d = C.c_double(), C.c_double()
+                L._check(self.lib.udc_tstep_maxima(self.h, C.c_double(self.dt), C.byref(c), C.byref(d)),
+                         "udc_tstep_maxima")
+                self.dt = min(dtmax, self.dt * courant / c.value, self.dt * diffnr / d.value)
+            else:
+                self.dt = dtmax
+            self.timee += self.dt
+        return self.rk3step, self.dt
+
+    def advection(self):
+        L._check(self.lib.udc_advection(self.h), "udc_advection")
+
+    def subgrid(self):
+        L._check(self.lib.udc_subgrid(self.h), "udc_subgrid")
+
+    def forces(self):
+        L._check(self.lib.udc_forces(self.h), "udc_forces")
+
+    def poisson(self):
+        L._check(self.lib.udc_poisson(self.h, self.rk3step, C.c_double(self.dt)), "udc_poisson")
+
+    def tstep_integrate(self):
+        L._check(self.lib.udc_tstep_integrate(self.h, self.rk3step, C.c_double(self.dt)), "udc_tstep_integrate")
+
+    def halos(self):
+        L._check(self.lib.udc_halos(self.h), "udc_halos")
+
+    def boundary(self):
+        L._check(self.lib.udc_boundary(self.h), "udc_boundary")
+
+    # ---- fused fast path
+    def substep(self, rk3step, dt, with_forces=True):
+        L._check(self.lib.udc_substep(self.h, rk3step, C.c_double(dt), 1 if with_forces else 0), "udc_substep")
+
+    def run(self, nsub, dt, rk3step0=1, with_forces=True):
+        L._check(self.lib.udc_run(self.h, nsub, rk3step0, C.c_double(dt), 1 if with_forces else 0), "udc_run")
+
+    def divergence(self):
+        a, b = C.c_double(), C.c_double()
+        L._check(self.lib.udc_divergence(self.h, C.byref(a), C.byref(b)), "udc_divergence")
+        return a.value, b.value
+
+    def sync(self):
+        L._check(self.lib.udc_sync(self.h), "udc_sync")
+
+    # ---- measurement
+    def profile(self, on=True):
+        L._check(self.lib.udc_profile_enable(self.h, 1 if on else 0), "udc_profile_enable")
+
+    def profile_reset(self):
+        self.lib.udc_profile_reset(self.h)
+
+    def profile_get(self):
+        cap = 64
+        names = ((C.c_char * 64) * cap)()
+        ms = (C.c_double * cap)()
+        cnt = (C.c_int * cap)()
+        n = self.lib.udc_profile_get(self.h, cap, names, ms, cnt)
+        return {names[i].value.decode(): (ms[i], cnt[i]) for i in range(min(n, cap))}

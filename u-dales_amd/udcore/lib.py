@@ -1,0 +1,69 @@
+"""ctypes binding of libudcore.so (the C ABI declared in include/udcore.h).
+
+There is no CPU fallback: importing works anywhere (so the host logic can be tested on CPU),
+but creating a `DynCore` requires the built library and a visible MI355X; otherwise it raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIBPATH = os.path.join(os.path.dirname(HERE), "lib", "libudcore.so")
+
+DP = C.POINTER(C.c_double)
+
+# field ids (include/udcore.h)
+U0, V0, W0, UM, VM, WM, UP, VP, WP, PRES0, P, EKM, EKH, SV0, SVM, SVP = range(16)
+FIELD_IDS = dict(u0=U0, v0=V0, w0=W0, um=UM, vm=VM, wm=WM, up=UP, vp=VP, wp=WP, pres0=PRES0, p=P,
+                 ekm=EKM, ekh=EKH)
+SGS_DNS, SGS_SMAGORINSKY, SGS_VREMAN = 0, 1, 2
+
+EXPORTS = ["udc_create", "udc_destroy", "udc_last_error", "udc_version", "udc_comm_unique_id",
+           "udc_comm_init", "udc_field_upload", "udc_field_download", "udc_set_forcing",
+           "udc_advection", "udc_subgrid", "udc_forces", "udc_poisson", "udc_tstep_integrate",
+           "udc_halos", "udc_boundary", "udc_tstep_maxima", "udc_substep", "udc_run",
+           "udc_divergence", "udc_sync", "udc_profile_enable", "udc_profile_reset",
+           "udc_profile_get"]
+
+
+class UdcConfig(C.Structure):
+    _fields_ = [("itot", C.c_int), ("jtot", C.c_int), ("ktot", C.c_int),
+                ("nranks", C.c_int), ("rank", C.c_int), ("device", C.c_int),
+                ("dx", C.c_double), ("dy", C.c_double),
+                ("dzf", DP), ("dzh", DP),
+                ("numol", C.c_double), ("prandtlmoli", C.c_double), ("prandtli", C.c_double),
+                ("c_vreman", C.c_double), ("csz", C.c_double),
+                ("sgs", C.c_int), ("bctopm", C.c_int),
+                ("uinf", C.c_double), ("vinf", C.c_double), ("nsv", C.c_int)]
+
+
+class UdcError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libudcore.so; raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIBPATH):
+            raise UdcError(f"{LIBPATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+                           f"g.build()'` (hipcc, gfx950). There is no CPU fallback.")
+        _lib = C.CDLL(LIBPATH, mode=C.RTLD_GLOBAL)
+        _lib.udc_last_error.restype = C.c_char_p
+    return _lib
+
+
+def scalar_field(kind: int, n: int) -> int:
+    """Field id of scalar n: kind is SV0, SVM or SVP."""
+    return kind + 3 * n
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise UdcError(f"{what}: {load().udc_last_error().decode()}")

@@ -1,0 +1,167 @@
+"""Reader for uDALES input decks: namoptions.NNN (Fortran namelists), prof.inp.NNN, lscale.inp.NNN.
+
+Mirrors the subset of src/modstartup.f90:105-172 (readnamelists) that the dynamical core
+consumes, with the reference's defaults (src/modglobal.f90, src/modsubgriddata.f90:39-61),
+so that the *same* namoptions file drives the reference CPU path and this library.
+"""
+from __future__ import annotations
+
+import math
+import os
+import re
+from dataclasses import dataclass, field
+
+# group -> {name: default}; names and defaults as in the reference
+DEFAULTS = {
+    "RUN": dict(iexpnr=0, runtime=300., dtmax=20., ladaptive=False, irandom=43, randu=0.01,
+                krand=2 ** 31 - 1, courant=-1., diffnr=0.25, libm=True, lles=True, lrandomize=True,
+                nprocx=1, nprocy=1, lwarmstart=False, trestart=10000.),
+    "DOMAIN": dict(itot=96, jtot=96, ktot=96, xlen=-1., ylen=-1.),
+    "PHYSICS": dict(lmoist=False, lcoriol=False, lbuoyancy=False, ltempeq=False, lprofforc=False,
+                    dpdx=0., igrw_damp=0),
+    "DYNAMICS": dict(ipoiss=0, iadv_mom=2, iadv_tke=-1, iadv_thl=-1, iadv_qt=-1),
+    "BC": dict(BCxm=1, BCym=1, BCtopm=1, BCbotm=2, BCzp=1, z0=-1., z0h=-1.),
+    "SCALARS": dict(nsv=0),
+    "NAMSUBGRID": dict(lsmagorinsky=False, lvreman=True, loneeqn=False, c_vreman=0.07, cs=-1.,
+                       cf=2.5, cn=0.76, Rigc=0.25, Prandtl=0.333, ldelta=False, lbuoycorr=False),
+    "WALLS": dict(nfcts=-1, lbottom=False),
+    "ORACLE": dict(nsub=3, nspin=2, lforces=True, scal_a=1.0, scal_b=0.0),
+}
+
+
+def _value(tok: str):
+    t = tok.strip().rstrip(",")
+    tl = t.lower()
+    if tl in (".true.", "t", ".t."):
+        return True
+    if tl in (".false.", "f", ".f."):
+        return False
+    if (t.startswith("'") and t.endswith("'")) or (t.startswith('"') and t.endswith('"')):
+        return t[1:-1]
+    try:
+        return int(t)
+    except ValueError:
+        pass
+    try:
+        return float(tl.replace("d", "e"))
+    except ValueError:
+        return t
+
+
+def parse_namelists(text: str) -> dict:
+    """Returns {GROUP: {name: value-or-list}} for every &GROUP ... / block in the text.
+
+    Line oriented (one or more `name = values` per line, values may continue on the
+    following lines), which covers every deck under the reference's examples/ and tests/.
+    """
+    out = {}
+    grp = None
+    last = None
+    for raw in text.splitlines():
+        line = raw.split("!")[0].strip()
+        if not line:
+            continue
+        if line.startswith("&"):
+            grp = out.setdefault(line[1:].split()[0].upper(), {})
+            last = None
+            line = " ".join(line.split()[1:])
+            if not line:
+                continue
+        if grp is None:
+            continue
+        if line == "/" or line.lower() in ("&end", "$end"):
+            grp, last = None, None
+            continue
+        if line.endswith("/"):
+            line, close = line[:-1], True
+        else:
+            close = False
+        parts = re.split(r"(\w+)\s*(?:\([^)]*\))?\s*=", line)
+        # parts = [pre, name1, vals1, name2, vals2, ...]
+        pre = parts[0].strip()
+        if pre and last is not None:
+            grp[last] = _as_list(grp[last]) + [_value(v) for v in re.split(r"[,\s]+", pre) if v]
+        for q in range(1, len(parts), 2):
+            name, vals = parts[q], parts[q + 1]
+            vv = [_value(v) for v in re.split(r"[,\s]+", vals.strip()) if v]
+            grp[name] = vv[0] if len(vv) == 1 else vv
+            last = name
+        if close:
+            grp, last = None, None
+    return out
+
+
+def _as_list(v):
+    return v if isinstance(v, list) else [v]
+
+
+@dataclass
+class Deck:
+    """A parsed case: namelist values (with reference defaults) + profile files."""
+    path: str
+    nml: dict
+    zf: list = field(default_factory=list)
+    thl: list = field(default_factory=list)
+    qt: list = field(default_factory=list)
+    u: list = field(default_factory=list)
+    v: list = field(default_factory=list)
+    tke: list = field(default_factory=list)
+    pgx: list = field(default_factory=list)
+    pgy: list = field(default_factory=list)
+    ug: list = field(default_factory=list)
+    vg: list = field(default_factory=list)
+
+    def get(self, group, name):
+        g = self.nml.get(group, {})
+        # namelist variable names are case-insensitive in Fortran
+        for k, v in g.items():
+            if k.lower() == name.lower():
+                return v
+        return DEFAULTS[group][name]
+
+
+def _read_table(path, ncol, nrows):
+    rows = []
+    with open(path) as f:
+        lines = f.readlines()[2:]
+    for ln in lines:
+        p = ln.split()
+        if len(p) >= ncol:
+            rows.append([float(x) for x in p[:ncol]])
+        if len(rows) == nrows:
+            break
+    if len(rows) != nrows:
+        raise ValueError(f"{path}: expected {nrows} rows, found {len(rows)}")
+    return rows
+
+
+def read_deck(namoptions_path: str) -> Deck:
+    with open(namoptions_path) as f:
+        nml = parse_namelists(f.read())
+    d = Deck(path=namoptions_path, nml=nml)
+    exp = d.get("RUN", "iexpnr")
+    base = os.path.dirname(os.path.abspath(namoptions_path))
+    ktot = d.get("DOMAIN", "ktot")
+    prof = _read_table(os.path.join(base, f"prof.inp.{exp:03d}"), 6, ktot)
+    d.zf = [r[0] for r in prof]
+    d.thl = [r[1] for r in prof]
+    d.qt = [r[2] for r in prof]
+    d.u = [r[3] for r in prof]
+    d.v = [r[4] for r in prof]
+    d.tke = [r[5] for r in prof]
+    ls = _read_table(os.path.join(base, f"lscale.inp.{exp:03d}"), 10, ktot)
+    d.ug = [r[1] for r in ls]
+    d.vg = [r[2] for r in ls]
+    d.pgx = [r[3] for r in ls]
+    d.pgy = [r[4] for r in ls]
+    return d
+
+
+def smagorinsky_constant(cs, cf=2.5, alpha_kolm=1.5):
+    """csz of src/modsubgrid.f90:65-77."""
+    if cs != -1.:
+        return cs
+    pi = 3.141592653589793116
+    cm = cf / (2. * pi) * (1.5 * alpha_kolm) ** (-1.5)
+    ceps = 2. * pi / cf * (1.5 * alpha_kolm) ** (-1.5)
+    return (cm ** 3 / ceps) ** 0.25
