@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""bench.py -- cell-updates/s of the uDALES dynamical core (advect + diffuse + Poisson + RK3) on MI355X.
+
+A "step" is ONE RK3 substep of the hot path (src/program.f90:132-222 restricted to advection,
+subgrid, forces, poisson, tstep_integrate, halos, boundary) over the whole grid, i.e. one
+cell-update per cell.  Workload at N=1: BASELINE.json configs[1], the
+256^3 neutral empty-domain channel (2nd-order advection, Vreman SGS = the reference default,
+FFT Poisson), synthetic cold start (LCG noise of src/modstartup.f90:2367-2396), fields resident
+in HBM before the timed region.
+
+    python bench.py                                   # 1 GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, timed live with HIP events
+recorded on the library's own stream during the timed region; `cpu_baseline` times the reference's
+own Fortran (oracle/_ref/udales_ref, see oracle/Makefile) on a bounded sample on this box's host.
+"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "u-dales_amd"))
+
+# algorithmic bytes per cell-update, per kernel (SURVEY.md section 8d / DESIGN.md section 4)
+ALGO_BYTES = {
+    "closure": 40, "mom": 88, "div_rhs": 56, "fft_fwd": 32, "fft_bwd": 32, "thomas": 24,
+    "project_integrate": 120, "scalar": 56,
+}
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def algo_bytes(name):
+    for k, v in ALGO_BYTES.items():
+        if name.startswith(k):
+            return v
+    return None
+
+
+def write_deck(d, iexp, nx, ny, nz, nsub, dt=0.25, nprocy=1):
+    with open(os.path.join(d, f"namoptions.{iexp:03d}"), "w") as f:
+        f.write(f"""&RUN
+iexpnr = {iexp}
+runtime = 1000000.
+dtmax = {dt}
+ladaptive = .false.
+irandom = 43
+randu = 0.01
+nprocx = 1
+nprocy = {nprocy}
+libm = .false.
+/
+&DOMAIN
+itot = {nx}
+jtot = {ny}
+ktot = {nz}
+xlen = {nx * 0.5}
+ylen = {ny * 0.5}
+/
+&PHYSICS
+/
+&DYNAMICS
+ipoiss = 0
+/
+&BC
+/
+&SCALARS
+nsv = 0
+/
+&NAMSUBGRID
+lvreman = .true.
+/
+&ORACLE
+nsub = {nsub}
+/
+""")
+    with open(os.path.join(d, f"prof.inp.{iexp:03d}"), "w") as f:
+        f.write("# bench\n# z thl qt u v tke\n")
+        for k in range(nz):
+            f.write(f"{(k + 0.5) * 0.5:.15f} 288.0 0.0 1.0 0.0 0.0\n")
+    with open(os.path.join(d, f"lscale.inp.{iexp:03d}"), "w") as f:
+        f.write("# bench\n# z uq vq pqx pqy wfls dqtdxls dqtdyls dqtdtls dthlrad\n")
+        for k in range(nz):
+            f.write(f"{(k + 0.5) * 0.5:.15f} 0.0 0.0 0.0001 0.0 0.0 0.0 0.0 0.0 0.0\n")
+    return os.path.join(d, f"namoptions.{iexp:03d}")
+
+
+def cpu_baseline(nx, ny, nz, budget_s=25.0):
+    """Reference CPU path (its own Fortran, single rank) on a bounded number of substeps."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "udales_ref")
+    if not os.path.exists(ref):
+        return None
+    cells = nx * ny * nz
+    nsub = max(1, min(6, int(budget_s * 3.0e6 / cells)))     # ~3e6 cell-updates/s/core expected
+    with tempfile.TemporaryDirectory() as tmp:
+        write_deck(tmp, 900, nx, ny, nz, nsub)
+        try:
+            r = subprocess.run(f"ulimit -s unlimited; exec {ref} namoptions.900 time none.bin", shell=True,
+                               cwd=tmp, capture_output=True, text=True, timeout=600, executable="/bin/bash")
+        except subprocess.TimeoutExpired:
+            return None
+    m = re.search(r"cell_updates_per_s=\s*([0-9.Ee+-]+)", r.stdout)
+    if not m:
+        return None
+    return {"value": float(m.group(1)), "unit": "cell-updates/s", "cores": 1, "kind": "reference",
+            "sample": f"{nsub} RK3 substeps of the same {nx}x{ny}x{nz} channel, reference Fortran "
+                      f"(flang -O3, real(8)) single rank over repo-owned np=1 decomp/FFT shims, "
+                      f"timed with MPI_Wtime-style wall clock as src/modmpi.f90:140-160"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--size", type=str, default="", help="override grid, e.g. 256x256x256")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libudcore has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from udcore import read_deck, cold_start
+    from udcore.grid import Grid
+    import udcore
+
+    if args.size:
+        nx, ny, nz = (int(x) for x in args.size.lower().split("x"))
+    else:
+        nx, ny, nz = 256, 256 * world, 256      # weak scaling: one 256^3 slab of the channel per GPU
+    dt = 0.25
+    with tempfile.TemporaryDirectory() as tmp:
+        deck = read_deck(write_deck(tmp, 901, nx, ny, nz, 0, dt=dt, nprocy=world))
+    core = udcore.from_deck(deck, device=local_rank, rank=rank, nranks=world)
+    if world > 1:
+        idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            import ctypes
+            buf = (ctypes.c_ubyte * 128)()
+            core.lib.udc_comm_unique_id(buf)
+            idt = torch.tensor(list(buf), dtype=torch.uint8, device="cuda")
+        dist.broadcast(idt, 0)
+        core.comm_init(bytes(idt.cpu().tolist()))
+    g = core.g
+    nyl = ny // world
+    st = cold_start(g, deck, j0=rank * nyl, nyl=nyl)
+    core.load_state(st)
+    core.halos()
+    core.boundary()
+    del st
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        core.sync()
+
+    rk = 1
+    for _ in range(args.warmup):
+        core.substep(rk, dt, True)
+        rk = rk % 3 + 1
+    barrier()
+    core.profile(True)
+    core.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        core.substep(rk, dt, True)
+        rk = rk % 3 + 1
+    barrier()
+    t1 = time.perf_counter()
+    prof = core.profile_get()
+    core.profile(False)
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    divmax, _ = core.divergence()
+
+    cells = nx * ny * nz
+    cells_local = nx * nyl * nz
+    value = cells * args.steps / elapsed
+    kernels = {}
+    for name, (ms, cnt) in prof.items():
+        ab = algo_bytes(name)
+        avg_ms = ms / max(cnt, 1)
+        ent = {"avg_ms": round(avg_ms, 5), "launches": cnt, "share": round(ms / (elapsed * 1e3), 4)}
+        if ab:
+            gbs = ab * cells_local / (avg_ms * 1e-3) / 1e9
+            ent.update({"algo_bytes_per_cell": ab, "achieved_GBs": round(gbs, 1),
+                        "frac": round(gbs / HBM_PEAK_GBS, 4)})
+        kernels[name] = ent
+    dom = max((k for k in kernels if "frac" in kernels[k]), key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"])
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tfile):
+        try:
+            with open(tfile) as f:
+                tj = json.load(f)
+            if tj.get("workload") == f"{nx}x{nyl}x{nz}" and dom in tj.get("kernels", {}):
+                traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
+    roofline = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": kernels[dom]["frac"], "traffic": traffic,
+                "algo_bytes_per_launch": kernels[dom]["algo_bytes_per_cell"] * cells_local,
+                "avg_launch_ms": kernels[dom]["avg_ms"]}
+    out = {
+        "metric": "cell-updates/sec (advect+diffuse+Poisson step)", "value": value, "unit": "cell-updates/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{nx}x{ny}x{nz} neutral empty-domain channel, cd2 momentum advection + "
+                               f"Vreman SGS diffusion + FFT(x,y)/tridiagonal(z) Poisson + RK3 substep "
+                               f"(BASELINE.json configs[1])",
+                   "grid": [nx, ny, nz], "decomposition": f"y-slabs x{world}", "dt": dt,
+                   "step": "one RK3 substep = one cell-update per cell"},
+        "whole_substep_hbm_frac": round(392.0 * cells_local * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4),
+        "divmax_after_run": divmax,
+        "roofline": roofline,
+        "kernels": kernels,
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu:
+            cb = cpu_baseline(nx, ny, nz)
+            out["cpu_baseline"] = cb if cb else {"value": None, "unit": "cell-updates/s", "cores": 0,
+                                                 "kind": "reference", "sample": "oracle/_ref/udales_ref unavailable"}
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    core.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

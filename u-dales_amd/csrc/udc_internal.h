@@ -36,6 +36,32 @@ struct Geo {
   }
 };
 
+// ---------------------------------------------------------------------------------------
+// Cell kernels use 64x4-thread tiles (one wave per x-row segment).  They are launched as a 1-D
+// grid of tiles_per_plane * nz workgroups and decode (tile, k) themselves, XCD-aware: the
+// hardware deals workgroup b to XCD b % 8, so within a plane XCD c is given a contiguous band of
+// y-tiles (its private 4 MiB L2 then serves the j+-1 rows shared by neighbouring tiles), and the
+// same (x,y) tile of plane k+1 lands on the same XCD (k+-1 reuse).  Placement only affects speed.
+// ---------------------------------------------------------------------------------------
+constexpr int TX = 64, TY = 4;
+struct TileGrid { int gx, gy, tiles; };
+inline TileGrid tile_grid(const Geo &g) {
+  TileGrid t; t.gx = (g.nx + TX - 1) / TX; t.gy = (g.ny + TY - 1) / TY; t.tiles = t.gx * t.gy; return t;
+}
+#if defined(__HIPCC__)
+__device__ __forceinline__ bool tile_decode(const Geo &g, const TileGrid &t, int &i, int &j, int &k) {
+  const unsigned L = blockIdx.x;
+  k = L / t.tiles;
+  const unsigned lp = L - (unsigned)k * t.tiles;
+  unsigned tt = lp;
+  if ((t.tiles & 7) == 0) tt = (lp & 7u) * (t.tiles >> 3) + (lp >> 3);
+  const int by = tt / t.gx, bx = tt - by * t.gx;
+  i = bx * TX + threadIdx.x;
+  j = by * TY + threadIdx.y;
+  return i < g.nx && j < g.ny;
+}
+#endif
+
 // per-level metrics in constant-like global memory, indexed by the reference's k (0..nz+1)
 struct Metrics {
   const double *dzf, *dzfi, *dzfi5, *dzfiq, *dzf2;   // 0..nz+1

@@ -23,11 +23,10 @@ __device__ __forceinline__ int wrapp(int i, int nx) { return i == nx - 1 ? 0 : i
 // FORCES: modforces.f90:84-127 neutral branch.  Order of accumulation into the tendency is
 // the reference's: xy advection, z advection, diffusion, forcing.
 template <bool ADV, bool DIFF, bool LES, bool FORCES>
-__global__ __launch_bounds__(256) void mom_kernel(Geo g, Metrics m, MomArgs a, double numol) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int k = blockIdx.z;
-  if (i >= g.nx || j >= g.ny) return;
+__global__ __launch_bounds__(256) void mom_kernel(Geo g, TileGrid tg, Metrics m, MomArgs a, double numol) {
+  int i, j, k;
+  const bool inside_ = tile_decode(g, tg, i, j, k);
+  if (!inside_) return;
   const int kf = k + 1;   // reference level index for the metric tables
   const int im = wrapm(i, g.nx), ip = wrapp(i, g.nx);
   const long r0 = g.idx(0, j, k);
@@ -161,13 +160,12 @@ __global__ __launch_bounds__(256) void mom_kernel(Geo g, Metrics m, MomArgs a, d
 // SGS: 1 = Smagorinsky (src/modsubgrid.f90:208-264), 2 = Vreman (:269-360).  The molecular
 // part is added in the same statement order as the reference (ekh from ekm first, then +nu).
 template <int SGS>
-__global__ __launch_bounds__(256) void closure_kernel(Geo g, Metrics m, Params pr, const double *__restrict__ u,
+__global__ __launch_bounds__(256) void closure_kernel(Geo g, TileGrid tg, Metrics m, Params pr, const double *__restrict__ u,
                                                        const double *__restrict__ v, const double *__restrict__ w,
                                                        double *__restrict__ ekm, double *__restrict__ ekh) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int k = blockIdx.z;
-  if (i >= g.nx || j >= g.ny) return;
+  int i, j, k;
+  const bool inside_ = tile_decode(g, tg, i, j, k);
+  if (!inside_) return;
   const int kf = k + 1;
   const int im = wrapm(i, g.nx), ip = wrapp(i, g.nx);
   const long r0 = g.idx(0, j, k);
@@ -257,12 +255,11 @@ __global__ void ek_topbot_kernel(Geo g, Params pr, double *__restrict__ ekm, dou
   ekh[bot - g.sz] = (2. * nh) - ekh[bot];
 }
 
-__global__ __launch_bounds__(256) void forces_kernel(Geo g, Metrics m, double *__restrict__ up,
+__global__ __launch_bounds__(256) void forces_kernel(Geo g, TileGrid tg, Metrics m, double *__restrict__ up,
                                                       double *__restrict__ vp, double *__restrict__ wp) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int k = blockIdx.z;
-  if (i >= g.nx || j >= g.ny) return;
+  int i, j, k;
+  const bool inside_ = tile_decode(g, tg, i, j, k);
+  if (!inside_) return;
   const long c = g.idx(i, j, k);
   up[c] = up[c] - m.dpdxl[k + 1];
   vp[c] = vp[c] - m.dpdyl[k + 1];
@@ -270,7 +267,8 @@ __global__ __launch_bounds__(256) void forces_kernel(Geo g, Metrics m, double *_
 }
 
 inline dim3 cell_grid(const Geo &g, dim3 b) {
-  return dim3((g.nx + b.x - 1) / b.x, (g.ny + b.y - 1) / b.y, g.nz);
+  (void)b;
+  return dim3((unsigned)tile_grid(g).tiles * (unsigned)g.nz, 1, 1);
 }
 
 }  // namespace
@@ -285,7 +283,7 @@ int k_momentum(udc_handle *h, bool adv, bool diff, bool forces) {
 #define LAUNCH(A, D, L, F)                                                                   \
   do {                                                                                       \
     PROF(h, "mom_" #A #D #L #F);                                                             \
-    hipLaunchKernelGGL((mom_kernel<A, D, L, F>), gr, b, 0, h->stream, g, h->m, a, nu);       \
+    hipLaunchKernelGGL((mom_kernel<A, D, L, F>), gr, b, 0, h->stream, g, tile_grid(g), h->m, a, nu);       \
   } while (0)
   if (adv && diff) {
     if (les) { if (forces) LAUNCH(true, true, true, true); else LAUNCH(true, true, true, false); }
@@ -304,7 +302,7 @@ int k_forces(udc_handle *h) {
   const Geo &g = h->g;
   dim3 b(64, 4, 1), gr = cell_grid(g, b);
   PROF(h, "forces");
-  hipLaunchKernelGGL(forces_kernel, gr, b, 0, h->stream, g, h->m, h->fields[UDC_UP], h->fields[UDC_VP],
+  hipLaunchKernelGGL(forces_kernel, gr, b, 0, h->stream, g, tile_grid(g), h->m, h->fields[UDC_UP], h->fields[UDC_VP],
                      h->fields[UDC_WP]);
   HIP_OK(hipGetLastError());
   return 0;
@@ -317,9 +315,9 @@ int k_closure(udc_handle *h) {
   double *ekm = h->fields[UDC_EKM], *ekh = h->fields[UDC_EKH];
   PROF(h, "closure");
   if (h->p.sgs == UDC_SGS_SMAGORINSKY)
-    hipLaunchKernelGGL((closure_kernel<1>), gr, b, 0, h->stream, g, h->m, h->p, u, v, w, ekm, ekh);
+    hipLaunchKernelGGL((closure_kernel<1>), gr, b, 0, h->stream, g, tile_grid(g), h->m, h->p, u, v, w, ekm, ekh);
   else if (h->p.sgs == UDC_SGS_VREMAN)
-    hipLaunchKernelGGL((closure_kernel<2>), gr, b, 0, h->stream, g, h->m, h->p, u, v, w, ekm, ekh);
+    hipLaunchKernelGGL((closure_kernel<2>), gr, b, 0, h->stream, g, tile_grid(g), h->m, h->p, u, v, w, ekm, ekh);
   else
     hipLaunchKernelGGL(fill_const_kernel, dim3((unsigned)((g.n + 255) / 256)), dim3(256), 0, h->stream, g, ekm,
                        h->p.numol, ekh, h->p.numol * h->p.prandtlmoli);

@@ -19,20 +19,20 @@ __device__ __forceinline__ int wrapm(int i, int nx) { return i == 0 ? nx - 1 : i
 __device__ __forceinline__ int wrapp(int i, int nx) { return i == nx - 1 ? 0 : i + 1; }
 
 inline dim3 cell_grid(const Geo &g, dim3 b) {
-  return dim3((g.nx + b.x - 1) / b.x, (g.ny + b.y - 1) / b.y, g.nz);
+  (void)b;
+  return dim3((unsigned)tile_grid(g).tiles * (unsigned)g.nz, 1, 1);
 }
 
 // fillps + bcpup, src/modpois.f90:939-973, src/modboundary.f90:1227-1255,1309-1315:
 // p = d(pup)/dx + d(pvp)/dy + d(pwp)/dz with pup = up + um/rk3coef (not materialised),
 // pwp(kb) = pwp(ke+1) = 0, x cyclic by index wrap, y cyclic through the vp/vm ghost row.
-__global__ __launch_bounds__(256) void div_rhs_kernel(Geo g, Metrics m, double r,
+__global__ __launch_bounds__(256) void div_rhs_kernel(Geo g, TileGrid tg, Metrics m, double r,
     const double *__restrict__ up, const double *__restrict__ vp, const double *__restrict__ wp,
     const double *__restrict__ um, const double *__restrict__ vm, const double *__restrict__ wm,
     double *__restrict__ p) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int k = blockIdx.z;
-  if (i >= g.nx || j >= g.ny) return;
+  int i, j, k;
+  const bool inside_ = tile_decode(g, tg, i, j, k);
+  if (!inside_) return;
   const long r0 = g.idx(0, j, k);
   const long c = r0 + i, xp = r0 + wrapp(i, g.nx);
   const double pu_c = up[c] + um[c] * r, pu_p = up[xp] + um[xp] * r;
@@ -108,23 +108,21 @@ __global__ __launch_bounds__(64) void thomas_kernel(int nmodes, int nz, double s
 
 // compact (nx,ny,nz) <-> padded field interior (only used when rocFFT rejects the padded layout)
 template <bool TO_FIELD>
-__global__ __launch_bounds__(256) void real_copy_kernel(Geo g, double *__restrict__ field, double *__restrict__ buf) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int k = blockIdx.z;
-  if (i >= g.nx || j >= g.ny) return;
+__global__ __launch_bounds__(256) void real_copy_kernel(Geo g, TileGrid tg, double *__restrict__ field, double *__restrict__ buf) {
+  int i, j, k;
+  const bool inside_ = tile_decode(g, tg, i, j, k);
+  if (!inside_) return;
   const long c = g.idx(i, j, k);
   const long q = (long)i + (long)g.nx * (j + (long)g.ny * k);
   if (TO_FIELD) field[c] = buf[q]; else buf[q] = field[c];
 }
 
 // tderive, src/modpois.f90:1046-1056,1096-1102 (p ghosts: x by wrap, y by ghost row)
-__global__ __launch_bounds__(256) void project_kernel(Geo g, Metrics m, const double *__restrict__ p,
+__global__ __launch_bounds__(256) void project_kernel(Geo g, TileGrid tg, Metrics m, const double *__restrict__ p,
     double *__restrict__ up, double *__restrict__ vp, double *__restrict__ wp, double *__restrict__ pres0) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int k = blockIdx.z;
-  if (i >= g.nx || j >= g.ny) return;
+  int i, j, k;
+  const bool inside_ = tile_decode(g, tg, i, j, k);
+  if (!inside_) return;
   const long r0 = g.idx(0, j, k);
   const long c = r0 + i, xm = r0 + wrapm(i, g.nx);
   const double pc = p[c];
@@ -142,12 +140,11 @@ struct IntArgs {
 
 // tstep_integrate, src/modtstep.f90:219-230,322-338; PROJECT fuses tderive in front of it.
 template <bool PROJECT>
-__global__ __launch_bounds__(256) void integrate_kernel(Geo g, Metrics m, IntArgs a, const double *__restrict__ p,
+__global__ __launch_bounds__(256) void integrate_kernel(Geo g, TileGrid tg, Metrics m, IntArgs a, const double *__restrict__ p,
                                                          double *__restrict__ pres0, double rk3coef, int last) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int k = blockIdx.z;
-  if (i >= g.nx || j >= g.ny) return;
+  int i, j, k;
+  const bool inside_ = tile_decode(g, tg, i, j, k);
+  if (!inside_) return;
   const long r0 = g.idx(0, j, k);
   const long c = r0 + i;
   double tu = a.up[c], tv = a.vp[c], tw = a.wp[c];
@@ -187,14 +184,13 @@ __device__ __forceinline__ void atomic_max_nonneg(double *addr, double v) {
 }
 
 // tstep_update, src/modtstep.f90:113-128
-__global__ __launch_bounds__(256) void maxima_kernel(Geo g, Metrics m, double dt, const double *__restrict__ um,
+__global__ __launch_bounds__(256) void maxima_kernel(Geo g, TileGrid tg, Metrics m, double dt, const double *__restrict__ um,
     const double *__restrict__ vm, const double *__restrict__ wm, const double *__restrict__ ekm,
     const double *__restrict__ ekh, double *__restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int k = blockIdx.z;
+  int i, j, k;
+  const bool inside_ = tile_decode(g, tg, i, j, k);
   double cour = 0., dif = 0.;
-  if (i < g.nx && j < g.ny) {
+  if (inside_) {
     const long c = g.idx(i, j, k);
     cour = (fabs(um[c]) * m.dxi + fabs(vm[c]) * m.dyi + fabs(wm[c]) / m.dzh[k + 1]) * dt;
     const double f = (m.dzh2i[k + 1] + m.dx2i + m.dy2i);
@@ -208,13 +204,12 @@ __global__ __launch_bounds__(256) void maxima_kernel(Geo g, Metrics m, double dt
 }
 
 // chkdiv, src/modchecksim.f90:179-191
-__global__ __launch_bounds__(256) void divcheck_kernel(Geo g, Metrics m, const double *__restrict__ u,
+__global__ __launch_bounds__(256) void divcheck_kernel(Geo g, TileGrid tg, Metrics m, const double *__restrict__ u,
     const double *__restrict__ v, const double *__restrict__ w, double *__restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int k = blockIdx.z;
+  int i, j, k;
+  const bool inside_ = tile_decode(g, tg, i, j, k);
   double dmax = 0., dsum = 0.;
-  if (i < g.nx && j < g.ny) {
+  if (inside_) {
     const long r0 = g.idx(0, j, k);
     const long c = r0 + i, xp = r0 + wrapp(i, g.nx);
     const double div = (u[xp] - u[c]) * m.dxi + (v[c + g.sy] - v[c]) * m.dyi + (w[c + g.sz] - w[c]) * m.dzfi[k + 1];
@@ -346,7 +341,7 @@ int k_divergence_rhs(udc_handle *h, double rk3coef) {
   const Geo &g = h->g;
   dim3 b(64, 4, 1), gr = cell_grid(g, b);
   PROF(h, "div_rhs");
-  hipLaunchKernelGGL(div_rhs_kernel, gr, b, 0, h->stream, g, h->m, 1. / rk3coef, h->fields[UDC_UP],
+  hipLaunchKernelGGL(div_rhs_kernel, gr, b, 0, h->stream, g, tile_grid(g), h->m, 1. / rk3coef, h->fields[UDC_UP],
                      h->fields[UDC_VP], h->fields[UDC_WP], h->fields[UDC_UM], h->fields[UDC_VM],
                      h->fields[UDC_WM], h->fields[UDC_P]);
   HIP_OK(hipGetLastError());
@@ -360,7 +355,7 @@ int k_poisson_solve(udc_handle *h) {
   dim3 b(64, 4, 1), gr = cell_grid(g, b);
   if (h->fwd_compact) {
     PROF(h, "fft_pack");
-    hipLaunchKernelGGL((real_copy_kernel<false>), gr, b, 0, h->stream, g, h->fields[UDC_P], h->rbuf);
+    hipLaunchKernelGGL((real_copy_kernel<false>), gr, b, 0, h->stream, g, tile_grid(g), h->fields[UDC_P], h->rbuf);
   }
   {
     PROF(h, "fft_fwd");
@@ -381,7 +376,7 @@ int k_poisson_solve(udc_handle *h) {
   }
   if (h->bwd_compact) {
     PROF(h, "fft_unpack");
-    hipLaunchKernelGGL((real_copy_kernel<true>), gr, b, 0, h->stream, g, h->fields[UDC_P], h->rbuf);
+    hipLaunchKernelGGL((real_copy_kernel<true>), gr, b, 0, h->stream, g, tile_grid(g), h->fields[UDC_P], h->rbuf);
   }
   HIP_OK(hipGetLastError());
   return 0;
@@ -391,7 +386,7 @@ int k_project(udc_handle *h) {
   const Geo &g = h->g;
   dim3 b(64, 4, 1), gr = cell_grid(g, b);
   PROF(h, "project");
-  hipLaunchKernelGGL(project_kernel, gr, b, 0, h->stream, g, h->m, h->fields[UDC_P], h->fields[UDC_UP],
+  hipLaunchKernelGGL(project_kernel, gr, b, 0, h->stream, g, tile_grid(g), h->m, h->fields[UDC_P], h->fields[UDC_UP],
                      h->fields[UDC_VP], h->fields[UDC_WP], h->fields[UDC_PRES0]);
   HIP_OK(hipGetLastError());
   return 0;
@@ -416,7 +411,7 @@ int k_integrate(udc_handle *h, int rk3step, double dt) {
   dim3 b(64, 4, 1), gr = cell_grid(g, b);
   const double rk3coef = dt / (4. - (double)rk3step);
   PROF(h, "integrate");
-  hipLaunchKernelGGL((integrate_kernel<false>), gr, b, 0, h->stream, g, h->m, int_args(h),
+  hipLaunchKernelGGL((integrate_kernel<false>), gr, b, 0, h->stream, g, tile_grid(g), h->m, int_args(h),
                      (const double *)nullptr, (double *)nullptr, rk3coef, rk3step == 3 ? 1 : 0);
   HIP_OK(hipGetLastError());
   return 0;
@@ -427,7 +422,7 @@ int k_project_integrate(udc_handle *h, int rk3step, double dt) {
   dim3 b(64, 4, 1), gr = cell_grid(g, b);
   const double rk3coef = dt / (4. - (double)rk3step);
   PROF(h, "project_integrate");
-  hipLaunchKernelGGL((integrate_kernel<true>), gr, b, 0, h->stream, g, h->m, int_args(h),
+  hipLaunchKernelGGL((integrate_kernel<true>), gr, b, 0, h->stream, g, tile_grid(g), h->m, int_args(h),
                      (const double *)h->fields[UDC_P], h->fields[UDC_PRES0], rk3coef, rk3step == 3 ? 1 : 0);
   HIP_OK(hipGetLastError());
   return 0;
@@ -438,7 +433,7 @@ int k_maxima(udc_handle *h, double dt, double *cour, double *diffn) {
   dim3 b(64, 4, 1), gr = cell_grid(g, b);
   h->red_host[0] = 0.; h->red_host[1] = 1e-5;   // diffnrtotl starts at 1e-5, src/modtstep.f90:115
   HIP_OK(hipMemcpyAsync(h->red, h->red_host, 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(maxima_kernel, gr, b, 0, h->stream, g, h->m, dt, h->fields[UDC_UM], h->fields[UDC_VM],
+  hipLaunchKernelGGL(maxima_kernel, gr, b, 0, h->stream, g, tile_grid(g), h->m, dt, h->fields[UDC_UM], h->fields[UDC_VM],
                      h->fields[UDC_WM], h->fields[UDC_EKM], h->fields[UDC_EKH], h->red);
   HIP_OK(hipGetLastError());
   HIP_OK(hipMemcpyAsync(h->red_host, h->red, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -453,7 +448,7 @@ int k_divergence_check(udc_handle *h, double *divmax, double *divtot) {
   dim3 b(64, 4, 1), gr = cell_grid(g, b);
   h->red_host[0] = 0.; h->red_host[1] = 0.;
   HIP_OK(hipMemcpyAsync(h->red, h->red_host, 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(divcheck_kernel, gr, b, 0, h->stream, g, h->m, h->fields[UDC_U0], h->fields[UDC_V0],
+  hipLaunchKernelGGL(divcheck_kernel, gr, b, 0, h->stream, g, tile_grid(g), h->m, h->fields[UDC_U0], h->fields[UDC_V0],
                      h->fields[UDC_W0], h->red);
   HIP_OK(hipGetLastError());
   HIP_OK(hipMemcpyAsync(h->red_host, h->red, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -28,13 +28,12 @@ __device__ __forceinline__ double face(double vel, double cm2, double cm1, doubl
 }
 
 template <bool ADV, bool DIFF, bool LES>
-__global__ __launch_bounds__(256) void scalar_kernel(Geo g, Metrics m, double cekh, const double *__restrict__ u,
+__global__ __launch_bounds__(256) void scalar_kernel(Geo g, TileGrid tg, Metrics m, double cekh, const double *__restrict__ u,
     const double *__restrict__ v, const double *__restrict__ w, const double *__restrict__ ekh,
     const double *__restrict__ c, double *__restrict__ cp) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int k = blockIdx.z;
-  if (i >= g.nx || j >= g.ny) return;
+  int i, j, k;
+  const bool inside_ = tile_decode(g, tg, i, j, k);
+  if (!inside_) return;
   const int kf = k + 1;
   const long r0 = g.idx(0, j, k);
   const long sy = g.sy, sz = g.sz;
@@ -96,7 +95,8 @@ __global__ __launch_bounds__(256) void scalar_kernel(Geo g, Metrics m, double ce
 }
 
 inline dim3 cell_grid(const Geo &g, dim3 b) {
-  return dim3((g.nx + b.x - 1) / b.x, (g.ny + b.y - 1) / b.y, g.nz);
+  (void)b;
+  return dim3((unsigned)tile_grid(g).tiles * (unsigned)g.nz, 1, 1);
 }
 
 }  // namespace
@@ -112,7 +112,7 @@ static int launch_scalar(udc_handle *h, int n, bool adv, bool diff) {
 #define LS(A, D, L)                                                                                     \
   do {                                                                                                  \
     PROF(h, "scalar_" #A #D #L);                                                                        \
-    hipLaunchKernelGGL((scalar_kernel<A, D, L>), gr, b, 0, h->stream, g, h->m, cekh, u, v, w, ekh, c, cp); \
+    hipLaunchKernelGGL((scalar_kernel<A, D, L>), gr, b, 0, h->stream, g, tile_grid(g), h->m, cekh, u, v, w, ekh, c, cp); \
   } while (0)
   if (adv && diff) { if (les) LS(true, true, true); else LS(true, true, false); }
   else if (adv) LS(true, false, true);

@@ -46,6 +46,11 @@ class DynCore:
         except Exception:
             pass
 
+    def comm_init(self, unique_id: bytes):
+        """RCCL communicator over the y-slab ranks (id from udc_comm_unique_id on rank 0)."""
+        buf = (C.c_ubyte * 128)(*unique_id)
+        L._check(self.lib.udc_comm_init(self.h, buf), "udc_comm_init")
+
     # ---- residency
     def _bounds(self, arr):
         nz, ny, nx = arr.shape
