@@ -1,0 +1,63 @@
+"""The drop-in boundary, exercised from Fortran: the reference-shaped driver (oracle/ref_driver.f90,
+call order of src/program.f90) linked with u-dales_amd/fortran/{modadvection,modsubgrid,modpois,
+modtstep}.f90 -- same module and procedure names as the reference -- instead of the reference's own
+four modules.  Its dumps must match the golden dumps the all-reference build produced from the same
+namoptions (tests/golden).  Every other module in the binary (modboundary::halos/boundary,
+modforces::forces, modglobal, modfields ...) is the reference's unmodified code running on the host.
+"""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from common import GOLDEN, KERNEL_CASES, RUN_CASES, load_fixture, nocorner, relerr
+from refdump import read_dump
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "oracle", "_ref", "udales_dropin")
+
+
+def run_dropin(name, iexp, mode, tmp_path, residency):
+    if not os.path.exists(BIN):
+        pytest.skip("oracle/_ref/udales_dropin not built (needs the reference sources + flang)")
+    for fn in os.listdir(os.path.join(GOLDEN, "cases", name)):
+        shutil.copy(os.path.join(GOLDEN, "cases", name, fn), tmp_path)
+    env = dict(os.environ, UDC_RESIDENCY=str(residency))
+    r = subprocess.run(f"ulimit -s unlimited; exec {BIN} namoptions.{iexp:03d} {mode} out.bin", shell=True,
+                       cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300, executable="/bin/bash")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return read_dump(os.path.join(tmp_path, "out.bin"))
+
+
+@pytest.mark.parametrize("residency", [0, 1])
+@pytest.mark.parametrize("name,iexp", sorted(RUN_CASES.items()))
+def test_fortran_driver_with_dropin_modules(name, iexp, residency, tmp_path):
+    fix = load_fixture(name)
+    got = run_dropin(name, iexp, "run", tmp_path, residency)
+    checked = 0
+    for key, ref in fix.items():
+        if "." not in key or key.startswith("s000.") or key.split(".")[1] not in ("u0", "v0", "w0", "pres0"):
+            continue
+        a, b = got[key].data[1:-1], ref.data[1:-1]
+        assert relerr(nocorner(a), nocorner(b)) <= 1e-9, key
+        checked += 1
+    assert checked >= 8
+
+
+def test_fortran_kernel_sequence(tmp_path):
+    """advection / subgrid / forces / poisson / tstep_integrate called one by one from Fortran."""
+    name, iexp = "k_vreman_12x8x6", KERNEL_CASES["k_vreman_12x8x6"]
+    fix = load_fixture(name)
+    got = run_dropin(name, iexp, "kernels", tmp_path, 0)
+    for key in ("adv.up", "adv.vp", "adv.wp", "sub.up", "sub.vp", "sub.wp", "sub.ekm", "pre.up", "poi.up",
+                "poi.vp", "poi.wp", "out.u0", "out.v0", "out.w0"):
+        a, b = got[key].data, fix[key].data
+        if key.startswith("out.") or key == "sub.ekm":
+            a, b = a[1:-1], b[1:-1]
+            assert relerr(nocorner(a), nocorner(b)) <= 1e-10, key
+        else:
+            assert relerr(a[:-1, 1:-1, 1:-1], b[:-1, 1:-1, 1:-1]) <= 1e-10, key

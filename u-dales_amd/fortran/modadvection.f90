@@ -1,0 +1,39 @@
+!> Drop-in replacement for the reference's module modadvection (src/modadvection.f90).
+!! Same module name, same public procedure `advection` (called at src/program.f90:142);
+!! the body hands the work to libudcore (udc_advection: fused cd2 momentum advection incl.
+!! -grad(pres0), kappa-scheme scalars) instead of looping on the host.
+module modadvection
+  implicit none
+contains
+
+  subroutine advection
+    use iso_c_binding, only: c_int
+    use modglobal, only: iadv_mom, iadv_cd2, iadv_thl, iadv_kappa, ltempeq, lmoist
+    use modsubgriddata, only: loneeqn
+    use udc_iface
+    implicit none
+
+    ! the device library implements what every BASELINE configuration uses
+    ! (src/modadvection.f90:46-99 dispatches on the same switches)
+    if (iadv_mom /= iadv_cd2) then
+      write (0, *) 'ERROR: Unknown advection scheme'
+      stop 1
+    end if
+    if (loneeqn .or. ltempeq .or. lmoist) then
+      write (0, *) 'ERROR: libudcore advection: TKE / thl / qt equations are not on the device path'
+      stop 1
+    end if
+
+    call udc_ensure
+    select case (udc_residency)
+    case (0)
+      call udc_push_state
+      call udc_push_tend
+    case (1)
+      call udc_push_tend
+    end select
+    call udc_check(udc_advection(udc_h), 'udc_advection')
+    if (udc_residency <= 1) call udc_pull_tend
+  end subroutine advection
+
+end module modadvection

@@ -1,0 +1,280 @@
+!> ISO_C_BINDING interface to libudcore.so (include/udcore.h) plus the residency manager the
+!! four drop-in modules (modadvection, modsubgrid, modpois, modtstep) share.
+!!
+!! The reference's seam is "argument-less module procedures working on the module-global
+!! arrays of modfields" (SURVEY.md section 8b).  The device library owns device mirrors of
+!! those arrays; this module decides what crosses PCIe around each call:
+!!
+!!   UDC_RESIDENCY=0 (default, "strict")   every entry point uploads the host arrays it reads and
+!!                        downloads the ones it writes -- correct with ANY untouched host routine
+!!                        in between (IBM, EB, trees, statistics ...), PCIe-bound.
+!!   UDC_RESIDENCY=1 ("tendencies")        velocities/pressure stay resident; only up,vp,wp (the
+!!                        arrays the reference's add-on physics modify, docs/udales-architecture.md:104)
+!!                        are exchanged, and u0,v0,w0 are pulled after tstep_integrate.
+!!   UDC_RESIDENCY=2 ("device")            nothing moves until udc_pull_all(); for drivers whose
+!!                        host-side routines in the loop are no-ops (neutral empty channel).
+module udc_iface
+  use iso_c_binding
+  implicit none
+  public
+
+  ! field ids, include/udcore.h
+  integer(c_int), parameter :: UDC_U0 = 0, UDC_V0 = 1, UDC_W0 = 2, UDC_UM = 3, UDC_VM = 4, UDC_WM = 5, &
+                               UDC_UP = 6, UDC_VP = 7, UDC_WP = 8, UDC_PRES0 = 9, UDC_P = 10, &
+                               UDC_EKM = 11, UDC_EKH = 12, UDC_SV0 = 13, UDC_SVM = 14, UDC_SVP = 15
+
+  type, bind(C) :: udc_config
+    integer(c_int) :: itot, jtot, ktot
+    integer(c_int) :: nranks, rank, device
+    real(c_double) :: dx, dy
+    type(c_ptr)    :: dzf, dzh
+    real(c_double) :: numol, prandtlmoli, prandtli, c_vreman, csz
+    integer(c_int) :: sgs, bctopm
+    real(c_double) :: uinf, vinf
+    integer(c_int) :: nsv
+  end type udc_config
+
+  type(c_ptr), save :: udc_h = c_null_ptr
+  integer, save :: udc_residency = 0
+
+  interface
+    integer(c_int) function udc_create(cfg, h) bind(C, name='udc_create')
+      import :: c_int, c_ptr, udc_config
+      type(udc_config), intent(in) :: cfg
+      type(c_ptr), intent(out) :: h
+    end function
+    integer(c_int) function udc_destroy(h) bind(C, name='udc_destroy')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+    end function
+    type(c_ptr) function udc_last_error() bind(C, name='udc_last_error')
+      import :: c_ptr
+    end function
+    integer(c_int) function udc_field_upload(h, field, host, lb, ub) bind(C, name='udc_field_upload')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: field
+      real(c_double), intent(in) :: host(*)
+      integer(c_int), intent(in) :: lb(3), ub(3)
+    end function
+    integer(c_int) function udc_field_download(h, field, host, lb, ub) bind(C, name='udc_field_download')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: field
+      real(c_double), intent(inout) :: host(*)
+      integer(c_int), intent(in) :: lb(3), ub(3)
+    end function
+    integer(c_int) function udc_set_forcing(h, dpdxl, dpdyl, n) bind(C, name='udc_set_forcing')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(in) :: dpdxl(*), dpdyl(*)
+      integer(c_int), value :: n
+    end function
+    integer(c_int) function udc_advection(h) bind(C, name='udc_advection')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function udc_subgrid(h) bind(C, name='udc_subgrid')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function udc_forces(h) bind(C, name='udc_forces')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function udc_poisson(h, rk3step, dt) bind(C, name='udc_poisson')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: rk3step
+      real(c_double), value :: dt
+    end function
+    integer(c_int) function udc_tstep_integrate(h, rk3step, dt) bind(C, name='udc_tstep_integrate')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: rk3step
+      real(c_double), value :: dt
+    end function
+    integer(c_int) function udc_halos(h) bind(C, name='udc_halos')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function udc_boundary(h) bind(C, name='udc_boundary')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function udc_tstep_maxima(h, dt, courtot, diffnrtot) bind(C, name='udc_tstep_maxima')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      real(c_double), value :: dt
+      real(c_double), intent(out) :: courtot, diffnrtot
+    end function
+    integer(c_int) function udc_substep(h, rk3step, dt, with_forces) bind(C, name='udc_substep')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: rk3step, with_forces
+      real(c_double), value :: dt
+    end function
+    integer(c_int) function udc_divergence(h, divmax, divtot) bind(C, name='udc_divergence')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(out) :: divmax, divtot
+    end function
+    integer(c_int) function udc_sync(h) bind(C, name='udc_sync')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+    end function
+  end interface
+
+contains
+
+  !> The reference's error convention: message on unit 0, stop 1 (e.g. src/modadvection.f90:52-53).
+  subroutine udc_check(rc, what)
+    integer(c_int), intent(in) :: rc
+    character(*), intent(in) :: what
+    character(kind=c_char), pointer :: msg(:)
+    integer :: n
+    if (rc == 0) return
+    call c_f_pointer(udc_last_error(), msg, [512])
+    n = 1
+    do while (n < 512 .and. msg(n) /= c_null_char)
+      n = n + 1
+    end do
+    write (0, *) 'ERROR: libudcore ', what, ': ', msg(1:n - 1)
+    stop 1
+  end subroutine udc_check
+
+  !> Create the device mirror once all of initglobal/initfields/initsubgrid/initpois have run.
+  subroutine udc_ensure
+    use modglobal, only: itot, jtot, ktot, dx, dy, dzf, dzh, kb, ke, kh, numol, prandtlmoli, nsv, &
+                         BCtopm, Uinf, Vinf, lles
+    use modsubgriddata, only: lsmagorinsky, lvreman, prandtli, c_vreman, csz
+    use modfields, only: dpdxl, dpdyl
+    use modmpi, only: myid, nprocs
+    type(udc_config) :: cfg
+    real(c_double), allocatable, target, save :: zf_(:), zh_(:)
+    character(16) :: env
+    integer :: stat
+    if (c_associated(udc_h)) return
+    allocate (zf_(0:ktot + 1), zh_(0:ktot + 1))
+    zf_(0:ktot + 1) = dzf(kb - kh:ke + kh)
+    zh_(0) = 0.
+    zh_(1:ktot + 1) = dzh(kb:ke + kh)
+    cfg%itot = itot; cfg%jtot = jtot; cfg%ktot = ktot
+    cfg%nranks = nprocs; cfg%rank = myid; cfg%device = 0
+    cfg%dx = dx; cfg%dy = dy
+    cfg%dzf = c_loc(zf_); cfg%dzh = c_loc(zh_)
+    cfg%numol = numol; cfg%prandtlmoli = prandtlmoli; cfg%prandtli = prandtli
+    cfg%c_vreman = c_vreman; cfg%csz = csz(1, kb)
+    cfg%sgs = 0
+    if (lles) then
+      if (lsmagorinsky) then
+        cfg%sgs = 1
+      else if (lvreman) then
+        cfg%sgs = 2
+      end if
+    end if
+    cfg%bctopm = BCtopm
+    cfg%uinf = Uinf; cfg%vinf = Vinf
+    cfg%nsv = nsv
+    call udc_check(udc_create(cfg, udc_h), 'udc_create')
+    call udc_check(udc_set_forcing(udc_h, dpdxl(kb:ke), dpdyl(kb:ke), int(ktot, c_int)), 'udc_set_forcing')
+    call get_environment_variable('UDC_RESIDENCY', env, status=stat)
+    if (stat == 0) read (env, *, iostat=stat) udc_residency
+    call udc_push_state
+  end subroutine udc_ensure
+
+  subroutine udc_push3(field, a, lb)
+    integer(c_int), intent(in) :: field
+    real(c_double), intent(in) :: a(:, :, :)
+    integer, intent(in) :: lb(3)
+    integer(c_int) :: l(3), u(3)
+    l = lb; u = lb + shape(a) - 1
+    call udc_check(udc_field_upload(udc_h, field, a, l, u), 'upload')
+  end subroutine udc_push3
+
+  subroutine udc_pull3(field, a, lb)
+    integer(c_int), intent(in) :: field
+    real(c_double), intent(inout) :: a(:, :, :)
+    integer, intent(in) :: lb(3)
+    integer(c_int) :: l(3), u(3)
+    l = lb; u = lb + shape(a) - 1
+    call udc_check(udc_field_download(udc_h, field, a, l, u), 'download')
+  end subroutine udc_pull3
+
+  !> Everything the device needs from the host's prognostic state (bounds: src/modfields.f90:440-474)
+  subroutine udc_push_state
+    use modglobal, only: ib, jb, kb, ih, jh, kh, ihc, jhc, khc, nsv
+    use modfields, only: u0, v0, w0, um, vm, wm, pres0, sv0, svm
+    integer :: n
+    call udc_push3(UDC_U0, u0, (/ib - ih, jb - jh, kb - kh/))
+    call udc_push3(UDC_V0, v0, (/ib - ih, jb - jh, kb - kh/))
+    call udc_push3(UDC_W0, w0, (/ib - ih, jb - jh, kb - kh/))
+    call udc_push3(UDC_UM, um, (/ib - ih, jb - jh, kb - kh/))
+    call udc_push3(UDC_VM, vm, (/ib - ih, jb - jh, kb - kh/))
+    call udc_push3(UDC_WM, wm, (/ib - ih, jb - jh, kb - kh/))
+    call udc_push3(UDC_PRES0, pres0, (/ib - ih, jb - jh, kb - kh/))
+    do n = 1, nsv
+      call udc_push3(UDC_SV0 + 3*(n - 1), sv0(:, :, :, n), (/ib - ihc, jb - jhc, kb - khc/))
+      call udc_push3(UDC_SVM + 3*(n - 1), svm(:, :, :, n), (/ib - ihc, jb - jhc, kb - khc/))
+    end do
+  end subroutine udc_push_state
+
+  subroutine udc_push_tend
+    use modglobal, only: ib, jb, kb, ih, jh, ihc, jhc, nsv
+    use modfields, only: up, vp, wp, svp
+    integer :: n
+    call udc_push3(UDC_UP, up, (/ib - ih, jb - jh, kb/))
+    call udc_push3(UDC_VP, vp, (/ib - ih, jb - jh, kb/))
+    call udc_push3(UDC_WP, wp, (/ib - ih, jb - jh, kb/))
+    do n = 1, nsv
+      call udc_push3(UDC_SVP + 3*(n - 1), svp(:, :, :, n), (/ib - ihc, jb - jhc, kb/))
+    end do
+  end subroutine udc_push_tend
+
+  subroutine udc_pull_tend
+    use modglobal, only: ib, jb, kb, ih, jh, ihc, jhc, nsv
+    use modfields, only: up, vp, wp, svp
+    integer :: n
+    call udc_pull3(UDC_UP, up, (/ib - ih, jb - jh, kb/))
+    call udc_pull3(UDC_VP, vp, (/ib - ih, jb - jh, kb/))
+    call udc_pull3(UDC_WP, wp, (/ib - ih, jb - jh, kb/))
+    do n = 1, nsv
+      call udc_pull3(UDC_SVP + 3*(n - 1), svp(:, :, :, n), (/ib - ihc, jb - jhc, kb/))
+    end do
+  end subroutine udc_pull_tend
+
+  subroutine udc_pull_vel(with_m)
+    use modglobal, only: ib, jb, kb, ih, jh, kh, ihc, jhc, khc, nsv
+    use modfields, only: u0, v0, w0, um, vm, wm, sv0, svm
+    logical, intent(in) :: with_m
+    integer :: n
+    call udc_pull3(UDC_U0, u0, (/ib - ih, jb - jh, kb - kh/))
+    call udc_pull3(UDC_V0, v0, (/ib - ih, jb - jh, kb - kh/))
+    call udc_pull3(UDC_W0, w0, (/ib - ih, jb - jh, kb - kh/))
+    do n = 1, nsv
+      call udc_pull3(UDC_SV0 + 3*(n - 1), sv0(:, :, :, n), (/ib - ihc, jb - jhc, kb - khc/))
+    end do
+    if (with_m) then
+      call udc_pull3(UDC_UM, um, (/ib - ih, jb - jh, kb - kh/))
+      call udc_pull3(UDC_VM, vm, (/ib - ih, jb - jh, kb - kh/))
+      call udc_pull3(UDC_WM, wm, (/ib - ih, jb - jh, kb - kh/))
+      do n = 1, nsv
+        call udc_pull3(UDC_SVM + 3*(n - 1), svm(:, :, :, n), (/ib - ihc, jb - jhc, kb - khc/))
+      end do
+    end if
+  end subroutine udc_pull_vel
+
+  !> Bring every host array up to date (before output / restart / statistics in device mode).
+  subroutine udc_pull_all
+    use modglobal, only: ib, jb, kb, ih, jh, kh
+    use modfields, only: pres0
+    use modsubgriddata, only: ekm, ekh
+    if (.not. c_associated(udc_h)) return
+    call udc_pull_vel(.true.)
+    call udc_pull_tend
+    call udc_pull3(UDC_PRES0, pres0, (/ib - ih, jb - jh, kb - kh/))
+    call udc_pull3(UDC_EKM, ekm, (/ib - ih, jb - jh, kb - kh/))
+    call udc_pull3(UDC_EKH, ekh, (/ib - ih, jb - jh, kb - kh/))
+  end subroutine udc_pull_all
+
+end module udc_iface
