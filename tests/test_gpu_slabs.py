@@ -1,0 +1,113 @@
+"""Multi-slab (multi-GPU) code path, tested on ONE GPU.
+
+(1) UDC_FORCE_SLAB=1 drives a single rank through the distributed layout (1-D x transform, packed
+    all-to-all blocks, transposed spectral array, packed ghost-row exchange) -> must match the golden
+    reference dumps like the fast single-GPU path does.
+(2) P = 2 and 4 virtual ranks in one process (one host thread per rank, device-to-device copies
+    instead of RCCL, everything else identical) -> decomposition invariance against the P = 1 result,
+    the same property the reference pins with its processor_boundaries test
+    (tests/integration/processor_boundaries/test_processor_boundaries.py:28-34: 1e-9 / 2e-8).
+"""
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from common import RUN_CASES, deck_path, load_fixture, marr, nocorner, relerr
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_forced_slab_path_matches_reference():
+    code = r'''
+import sys, numpy as np
+sys.path[:0] = ["%s/tests", "%s/u-dales_amd"]
+from common import RUN_CASES, deck_path, load_fixture, marr, nocorner, relerr
+import udcore
+from udcore import read_deck, cold_start
+for name, iexp in RUN_CASES.items():
+    fix = load_fixture(name)
+    d = read_deck(deck_path(name, iexp))
+    core = udcore.from_deck(d)
+    core.load_state(cold_start(core.g, d, nsv=core.nsv))
+    dt = float(d.get("RUN", "dtmax"))
+    dumps = sorted(int(k[1:4]) for k in fix if k.endswith(".u0") and k != "s000.u0")
+    for isub in range(1, max(dumps) + 1):
+        core.substep((isub - 1) %% 3 + 1, dt, True)
+        if isub in dumps:
+            for k in ("u0", "v0", "w0", "pres0"):
+                ref = marr(fix, f"s{isub:03d}.{k}", core.g.nz)
+                e = relerr(nocorner(core.download(k)[1:-1]), nocorner(ref[1:-1]))
+                assert e <= 1e-9, (name, isub, k, e)
+    core.close()
+print("SLAB_OK")
+''' % (ROOT, ROOT)
+    env = dict(os.environ, UDC_FORCE_SLAB="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert "SLAB_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def run_virtual(P, g, deck_like, st_global, nsub, dt, sgs, nsv=0):
+    """Run nsub substeps on P virtual ranks; returns the stitched global u0, v0, w0, pres0."""
+    from udcore.core import DynCore
+    from udcore import lib as L
+    lib = L.load()
+    group = lib.udc_local_group_create(P) if P > 1 else 0
+    nyl = g.ny // P
+    cores, errs = [None] * P, []
+    out = {}
+
+    def worker(r):
+        try:
+            core = DynCore(g, sgs=sgs, nsv=nsv, rank=r, nranks=P)
+            cores[r] = core
+            if P > 1:
+                core.comm_init_local(group)
+            local = {}
+            for k, a in st_global.items():
+                h = (a.shape[1] - g.ny) // 2
+                local[k] = np.ascontiguousarray(a[:, r * nyl:r * nyl + nyl + 2 * h, :])
+            core.load_state(local)
+            core.halos()
+            core.boundary()
+            for isub in range(nsub):
+                core.substep(isub % 3 + 1, dt, False)
+            out[r] = {k: core.download(k) for k in ("u0", "v0", "w0", "pres0")}
+            out[r]["div"] = core.divergence()
+        except Exception as e:   # noqa: BLE001
+            errs.append((r, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(P)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errs, errs
+    res = {}
+    for k in ("u0", "v0", "w0", "pres0"):
+        res[k] = np.concatenate([out[r][k][:, 1:-1, :] for r in range(P)], axis=1)
+    res["div"] = out[0]["div"]
+    for c in cores:
+        c.close()
+    return res
+
+
+@pytest.mark.parametrize("shape,sgs", [((32, 16, 12), 2), ((24, 32, 10), 1)])
+def test_decomposition_invariance(shape, sgs):
+    from test_gpu_parity import random_state
+    from udcore.grid import Grid
+    nx, ny, nz = shape
+    g = Grid.uniform(nx, ny, nz)
+    st = random_state(g, seed=42)
+    ref = run_virtual(1, g, None, st, 6, 0.05, sgs)
+    assert ref["div"][0] < 1e-11
+    for P in (2, 4):
+        got = run_virtual(P, g, None, st, 6, 0.05, sgs)
+        for k in ("u0", "v0", "w0", "pres0"):
+            e = relerr(got[k][1:-1], ref[k][1:-1])
+            assert e <= 1e-10, (P, k, e)
+        assert abs(got["div"][0] - ref["div"][0]) < 1e-12      # all-reduced max agrees on every rank

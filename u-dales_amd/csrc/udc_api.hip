@@ -3,6 +3,7 @@
 #include <cstdarg>
 #include <cstring>
 #include <cmath>
+#include <cstdlib>
 
 static thread_local char g_err[512] = "";
 
@@ -93,7 +94,8 @@ extern "C" int udc_create(const udc_config *cfg, udc_handle **out) {
   if (cfg->itot % 2 || cfg->jtot % 2) { udc_set_error("udc_create: itot and jtot must be even (half-complex FFT, src/modpois.f90:482-487)"); return 1; }
   if (cfg->nranks < 1 || cfg->rank < 0 || cfg->rank >= cfg->nranks) { udc_set_error("udc_create: bad rank/nranks"); return 1; }
   if (cfg->jtot % cfg->nranks) { udc_set_error("udc_create: jtot must be divisible by nranks (src/modstartup.f90:730-760)"); return 1; }
-  if (cfg->nranks > 1) { udc_set_error("udc_create: multi-GPU slabs not enabled in this build"); return 1; }
+  if (cfg->nranks > 64) { udc_set_error("udc_create: at most 64 slabs"); return 1; }
+  if ((cfg->jtot / cfg->nranks) < 2 * HY) { udc_set_error("udc_create: slab thinner than the ghost width"); return 1; }
   if (cfg->nsv < 0 || cfg->nsv > 16) { udc_set_error("udc_create: nsv out of range"); return 1; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
@@ -107,6 +109,8 @@ extern "C" int udc_create(const udc_config *cfg, udc_handle **out) {
   HIP_OK(hipStreamCreate(&h->stream));
   Geo &g = h->g;
   g.nx = cfg->itot; g.ny = cfg->jtot / cfg->nranks; g.nz = cfg->ktot;
+  h->jtot = cfg->jtot;
+  h->slab = cfg->nranks > 1 || (getenv("UDC_FORCE_SLAB") && atoi(getenv("UDC_FORCE_SLAB")) != 0);
   g.py = g.ny + 2 * HY; g.pz = g.nz + 2 * HZ;
   g.sy = g.nx; g.sz = (long)g.nx * g.py; g.n = g.sz * g.pz;
   h->p = Params{cfg->numol, cfg->prandtlmoli, cfg->prandtli, cfg->c_vreman, cfg->csz,
@@ -150,7 +154,12 @@ extern "C" int udc_create(const udc_config *cfg, udc_handle **out) {
       if (alloc_field(h, UDC_SV0 + 3 * n + q)) return 1;
   HIP_OK(hipMalloc(&h->red, sizeof(double) * 4096));
   HIP_OK(hipHostMalloc(&h->red_host, sizeof(double) * 4096));
-  if (pois_init(h)) return 1;
+  if (h->slab) { if (pois_slab_init(h)) return 1; }
+  else if (pois_init(h)) return 1;
+  if (h->slab) {
+    h->halo_cap = (size_t)16 * HY * g.nx * g.pz;
+    for (int q = 0; q < 4; ++q) HIP_OK(hipMalloc(&h->halo_buf[q], sizeof(double) * h->halo_cap));
+  }
   HIP_OK(hipStreamSynchronize(h->stream));
   *out = h;
   return 0;
@@ -162,26 +171,15 @@ extern "C" int udc_destroy(udc_handle *h) {
   hipStreamSynchronize(h->stream);
   prof_drain(h);
   pois_destroy(h);
+  comm_destroy(h);
+  for (int q = 0; q < 4; ++q) if (h->halo_buf[q]) hipFree(h->halo_buf[q]);
   for (double *p : h->fields) if (p) hipFree(p);
   if (h->metrics_dev) hipFree(h->metrics_dev);
   if (h->red) hipFree(h->red);
   if (h->red_host) hipHostFree(h->red_host);
-  if (h->sendbuf) hipFree(h->sendbuf);
-  if (h->recvbuf) hipFree(h->recvbuf);
   hipStreamDestroy(h->stream);
   delete h;
   return 0;
-}
-
-extern "C" int udc_comm_unique_id(unsigned char id[128]) {
-  memset(id, 0, 128);
-  return 0;
-}
-extern "C" int udc_comm_init(udc_handle *h, const unsigned char id[128]) {
-  (void)id;
-  if (h->cfg.nranks == 1) return 0;
-  udc_set_error("udc_comm_init: multi-GPU slabs not enabled in this build");
-  return 1;
 }
 
 extern "C" int udc_sync(udc_handle *h) {

@@ -1,0 +1,176 @@
+// Inter-slab communication.  One process per GPU; the y-slab neighbours exchange ghost rows and
+// the Poisson solver does two all-to-alls (kx <-> y).  Two transports implement the same three
+// primitives (neighbour rows, all-to-all blocks, tiny all-reduce):
+//
+//   * RCCL over xGMI (ncclSend/ncclRecv groups, ncclAllReduce) -- the production path; replaces
+//     2decomp-fft's MPI halo exchange and alltoall transposes.
+//   * "local group": P handles inside ONE process on ONE device, one host thread per virtual
+//     rank, buffers exchanged with device-to-device copies behind a pthread barrier.  It exists so
+//     that the multi-rank code path (packing, index maps, transposed spectral layout) can be
+//     parity-tested on a single-GPU box; everything except the byte mover is shared.
+#include "udc_internal.h"
+#include <rccl/rccl.h>
+#include <pthread.h>
+#include <mutex>
+#include <cstring>
+
+struct LocalGroup {
+  int P;
+  pthread_barrier_t bar;
+  // published per rank: send pointers by tag (0 = to-prev rows, 1 = to-next rows, 2 = all-to-all base)
+  const double *send[64][3];
+  double red[64][8];
+};
+
+static std::mutex g_groups_mu;
+static std::vector<LocalGroup *> g_groups;
+
+#define NCCL_OK(expr)                                                                     \
+  do {                                                                                    \
+    ncclResult_t r_ = (expr);                                                             \
+    if (r_ != ncclSuccess) {                                                              \
+      udc_set_error("%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r_), __FILE__,     \
+                    __LINE__);                                                            \
+      return 1;                                                                           \
+    }                                                                                     \
+  } while (0)
+
+extern "C" int udc_comm_unique_id(unsigned char id[128]) {
+  ncclUniqueId u;
+  NCCL_OK(ncclGetUniqueId(&u));
+  static_assert(sizeof(u) == 128, "ncclUniqueId size");
+  memcpy(id, &u, 128);
+  return 0;
+}
+
+extern "C" int udc_comm_init(udc_handle *h, const unsigned char id[128]) {
+  if (h->cfg.nranks == 1) return 0;
+  HIP_OK(hipSetDevice(h->device));
+  ncclUniqueId u;
+  memcpy(&u, id, 128);
+  ncclComm_t c;
+  NCCL_OK(ncclCommInitRank(&c, h->cfg.nranks, u, h->cfg.rank));
+  h->nccl = (void *)c;
+  return 0;
+}
+
+extern "C" int udc_local_group_create(int nranks) {
+  if (nranks < 1 || nranks > 64) { udc_set_error("udc_local_group_create: 1..64 ranks"); return -1; }
+  LocalGroup *g = new LocalGroup();
+  g->P = nranks;
+  pthread_barrier_init(&g->bar, nullptr, (unsigned)nranks);
+  std::lock_guard<std::mutex> lk(g_groups_mu);
+  g_groups.push_back(g);
+  return (int)g_groups.size();   // ids start at 1
+}
+
+extern "C" int udc_comm_init_local(udc_handle *h, int group) {
+  std::lock_guard<std::mutex> lk(g_groups_mu);
+  if (group < 1 || group > (int)g_groups.size() || g_groups[group - 1]->P != h->cfg.nranks) {
+    udc_set_error("udc_comm_init_local: bad group");
+    return 1;
+  }
+  h->local_group = g_groups[group - 1];
+  return 0;
+}
+
+void comm_destroy(udc_handle *h) {
+  if (h->nccl) { ncclCommDestroy((ncclComm_t)h->nccl); h->nccl = nullptr; }
+}
+
+static int need_comm(udc_handle *h) {
+  if (h->nccl || h->local_group) return 0;
+  udc_set_error("multi-rank handle used before udc_comm_init / udc_comm_init_local");
+  return 1;
+}
+
+// neighbour rows: to_prev/to_next are packed send buffers of `count` doubles each;
+// from_next receives the next rank's to_prev, from_prev the previous rank's to_next.
+int comm_neighbours(udc_handle *h, const double *to_prev, const double *to_next, double *from_prev,
+                    double *from_next, size_t count) {
+  const int P = h->cfg.nranks, r = h->cfg.rank;
+  const int prev = (r + P - 1) % P, next = (r + 1) % P;
+  if (P == 1) {   // single slab driven through the slab code path (UDC_FORCE_SLAB): periodic wrap onto itself
+    HIP_OK(hipMemcpyAsync(from_next, to_prev, count * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HIP_OK(hipMemcpyAsync(from_prev, to_next, count * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    return 0;
+  }
+  if (need_comm(h)) return 1;
+  if (h->nccl) {
+    ncclComm_t c = (ncclComm_t)h->nccl;
+    // with P == 2 both neighbours are the same peer: sends and receives pair up in posting order,
+    // so post "to prev" first on the send side and "from next" first on the receive side.
+    NCCL_OK(ncclGroupStart());
+    NCCL_OK(ncclSend(to_prev, count, ncclDouble, prev, c, h->stream));
+    NCCL_OK(ncclSend(to_next, count, ncclDouble, next, c, h->stream));
+    NCCL_OK(ncclRecv(from_next, count, ncclDouble, next, c, h->stream));
+    NCCL_OK(ncclRecv(from_prev, count, ncclDouble, prev, c, h->stream));
+    NCCL_OK(ncclGroupEnd());
+    return 0;
+  }
+  LocalGroup *g = (LocalGroup *)h->local_group;
+  g->send[r][0] = to_prev; g->send[r][1] = to_next;
+  HIP_OK(hipStreamSynchronize(h->stream));
+  pthread_barrier_wait(&g->bar);
+  HIP_OK(hipMemcpyAsync(from_next, g->send[next][0], count * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  HIP_OK(hipMemcpyAsync(from_prev, g->send[prev][1], count * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  pthread_barrier_wait(&g->bar);
+  return 0;
+}
+
+// all-to-all of equal blocks: block d of `send` goes to rank d, arriving as block r of its `recv`
+int comm_alltoall(udc_handle *h, const double *send, double *recv, size_t block) {
+  const int P = h->cfg.nranks, r = h->cfg.rank;
+  if (P == 1) {
+    HIP_OK(hipMemcpyAsync(recv, send, block * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    return 0;
+  }
+  if (need_comm(h)) return 1;
+  if (h->nccl) {
+    ncclComm_t c = (ncclComm_t)h->nccl;
+    NCCL_OK(ncclGroupStart());
+    for (int d = 0; d < P; ++d) {
+      NCCL_OK(ncclSend(send + (size_t)d * block, block, ncclDouble, d, c, h->stream));
+      NCCL_OK(ncclRecv(recv + (size_t)d * block, block, ncclDouble, d, c, h->stream));
+    }
+    NCCL_OK(ncclGroupEnd());
+    return 0;
+  }
+  LocalGroup *g = (LocalGroup *)h->local_group;
+  g->send[r][2] = send;
+  HIP_OK(hipStreamSynchronize(h->stream));
+  pthread_barrier_wait(&g->bar);
+  for (int s = 0; s < P; ++s)
+    HIP_OK(hipMemcpyAsync(recv + (size_t)s * block, g->send[s][2] + (size_t)r * block, block * sizeof(double),
+                          hipMemcpyDeviceToDevice, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  pthread_barrier_wait(&g->bar);
+  return 0;
+}
+
+// in-place all-reduce of n (<= 8) doubles held in device memory `buf`; op 0 = max, 1 = sum
+int comm_allreduce(udc_handle *h, double *buf, int n, int op) {
+  if (h->cfg.nranks == 1) return 0;
+  if (need_comm(h)) return 1;
+  if (h->nccl) {
+    NCCL_OK(ncclAllReduce(buf, buf, (size_t)n, ncclDouble, op == 0 ? ncclMax : ncclSum, (ncclComm_t)h->nccl,
+                          h->stream));
+    return 0;
+  }
+  LocalGroup *g = (LocalGroup *)h->local_group;
+  const int P = h->cfg.nranks, r = h->cfg.rank;
+  HIP_OK(hipMemcpyAsync(g->red[r], buf, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  pthread_barrier_wait(&g->bar);
+  double out[8];
+  for (int q = 0; q < n; ++q) {
+    double v = g->red[0][q];
+    for (int s = 1; s < P; ++s) v = op == 0 ? (g->red[s][q] > v ? g->red[s][q] : v) : v + g->red[s][q];
+    out[q] = v;
+  }
+  pthread_barrier_wait(&g->bar);
+  HIP_OK(hipMemcpyAsync(buf, out, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  return 0;
+}

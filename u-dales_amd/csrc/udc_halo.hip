@@ -23,6 +23,30 @@ __global__ void halo_y_wrap_kernel(Geo g, FieldList fl, int width) {
   a[g.idx(i, jdst, k)] = a[g.idx(i, jsrc, k)];
 }
 
+// multi-slab: pack `width` boundary rows of every field into a contiguous buffer
+// buf[((f*width + r)*pz + kk)*nx + i]; low = rows 0..w-1 (to previous rank), high = rows ny-w..ny-1.
+__global__ void halo_pack_kernel(Geo g, FieldList fl, int width, double *__restrict__ to_prev, double *__restrict__ to_next) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= g.nx) return;
+  const int r = blockIdx.y % width, fi = blockIdx.y / width;
+  const int kk = blockIdx.z, k = kk - HZ;
+  const double *a = fl.f[fi];
+  const size_t o = (((size_t)fi * width + r) * g.pz + kk) * g.nx + i;
+  to_prev[o] = a[g.idx(i, r, k)];
+  to_next[o] = a[g.idx(i, g.ny - width + r, k)];
+}
+__global__ void halo_unpack_kernel(Geo g, FieldList fl, int width, const double *__restrict__ from_prev,
+                                   const double *__restrict__ from_next) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= g.nx) return;
+  const int r = blockIdx.y % width, fi = blockIdx.y / width;
+  const int kk = blockIdx.z, k = kk - HZ;
+  double *a = fl.f[fi];
+  const size_t o = (((size_t)fi * width + r) * g.pz + kk) * g.nx + i;
+  a[g.idx(i, -width + r, k)] = from_prev[o];
+  a[g.idx(i, g.ny + r, k)] = from_next[o];
+}
+
 struct BoundaryArgs {
   double *u0, *v0, *w0, *um, *vm, *wm;
   double *sv[32];
@@ -65,10 +89,32 @@ int k_halo_y(udc_handle *h, const int *fields, int nf, int width) {
   if (nf > 16 || width > HY) { udc_set_error("k_halo_y: bad arguments"); return 1; }
   FieldList fl;
   for (int q = 0; q < nf; ++q) fl.f[q] = h->fields[fields[q]];
-  PROF(h, "halo_y");
-  hipLaunchKernelGGL(halo_y_wrap_kernel, dim3((g.nx + 63) / 64, 2 * width * nf, g.pz), dim3(64), 0, h->stream,
-                     g, fl, width);
-  HIP_OK(hipGetLastError());
+  if (!h->slab) {
+    PROF(h, "halo_y");
+    hipLaunchKernelGGL(halo_y_wrap_kernel, dim3((g.nx + 63) / 64, 2 * width * nf, g.pz), dim3(64), 0, h->stream,
+                       g, fl, width);
+    HIP_OK(hipGetLastError());
+    return 0;
+  }
+  // y-slabs: rows travel to the neighbouring ranks (periodic), as 2decomp's exchange_halo_z did
+  const size_t count = (size_t)nf * width * g.pz * g.nx;
+  if (count > h->halo_cap) { udc_set_error("k_halo_y: pack buffer too small"); return 1; }
+  {
+    PROF(h, "halo_pack");
+    hipLaunchKernelGGL(halo_pack_kernel, dim3((g.nx + 63) / 64, width * nf, g.pz), dim3(64), 0, h->stream, g, fl,
+                       width, h->halo_buf[0], h->halo_buf[1]);
+    HIP_OK(hipGetLastError());
+  }
+  {
+    PROF(h, "halo_xchg");
+    if (comm_neighbours(h, h->halo_buf[0], h->halo_buf[1], h->halo_buf[2], h->halo_buf[3], count)) return 1;
+  }
+  {
+    PROF(h, "halo_unpack");
+    hipLaunchKernelGGL(halo_unpack_kernel, dim3((g.nx + 63) / 64, width * nf, g.pz), dim3(64), 0, h->stream, g, fl,
+                       width, h->halo_buf[2], h->halo_buf[3]);
+    HIP_OK(hipGetLastError());
+  }
   return 0;
 }
 

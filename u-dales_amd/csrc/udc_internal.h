@@ -108,9 +108,20 @@ struct udc_handle {
   std::vector<std::string> prof_names;
   std::map<std::string, int> prof_ids;
   std::map<int, std::pair<double, int>> prof_acc;
-  // multi-GPU
+  // multi-GPU (y-slabs): RCCL communicator or in-process local group (udc_comm.hip)
   void *nccl = nullptr;
-  double *sendbuf = nullptr, *recvbuf = nullptr;
+  void *local_group = nullptr;
+  bool slab = false;                    // distributed Poisson layout in use (nranks > 1 or UDC_FORCE_SLAB)
+  int jtot = 0;                         // global number of rows
+  double *halo_buf[4] = {nullptr, nullptr, nullptr, nullptr};   // to_prev, to_next, from_prev, from_next
+  size_t halo_cap = 0;
+  // slab Poisson: x-spectral rows (all kx, local rows), transposed block (local kx, all rows)
+  int cx = 0;                           // kx chunk per rank = ceil(nkx / nranks)
+  double *specA = nullptr, *specB = nullptr, *a2a_send = nullptr, *a2a_recv = nullptr;
+  double *ev_slab = nullptr, *dtab_slab = nullptr;
+  rocfft_plan plan_xf = nullptr, plan_xb = nullptr, plan_yf = nullptr, plan_yb = nullptr;
+  rocfft_execution_info info_x = nullptr, info_y = nullptr;
+  void *fft_work_slab = nullptr;
 };
 
 void udc_set_error(const char *fmt, ...);
@@ -161,4 +172,12 @@ int k_top_rows_after_closure(udc_handle *h);
 int k_maxima(udc_handle *h, double dt, double *cour, double *diffn);
 int k_divergence_check(udc_handle *h, double *divmax, double *divtot);
 int pois_init(udc_handle *h);
+int pois_slab_init(udc_handle *h);
+int k_poisson_solve_slab(udc_handle *h);
+// udc_comm.hip
+int comm_neighbours(udc_handle *h, const double *to_prev, const double *to_next, double *from_prev,
+                    double *from_next, size_t count);
+int comm_alltoall(udc_handle *h, const double *send, double *recv, size_t block);
+int comm_allreduce(udc_handle *h, double *buf, int n, int op);
+void comm_destroy(udc_handle *h);
 void pois_destroy(udc_handle *h);

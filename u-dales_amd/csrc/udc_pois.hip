@@ -117,6 +117,88 @@ __global__ __launch_bounds__(256) void real_copy_kernel(Geo g, TileGrid tg, doub
   if (TO_FIELD) field[c] = buf[q]; else buf[q] = field[c];
 }
 
+
+// ======================================================================= y-slab Poisson path
+// Layouts (complex = interleaved double2):
+//   specA[row][kx]            row = (j+HY) + py*k over the p field's padded rows, kx = 0..nkx-1
+//   a2a blocks [d][k][kxl][j] kxl = 0..cx-1 (kx = d*cx + kxl), j = local row   (j fastest)
+//   specB[k][kxl][y]          y = global row 0..jtot-1                          (y fastest)
+// The x transform needs no communication; one all-to-all makes y whole with kx split, where the
+// y transform AND the tridiagonal solve are local; one all-to-all goes back.  (The reference's
+// pencil scheme does 8 transposes per solve, src/modpois.f90:459-702.)
+
+// specA -> send blocks (transposes kx-fastest rows into j-fastest runs through an LDS tile)
+__global__ __launch_bounds__(256) void slab_pack_fwd_kernel(Geo g, int nkx, int cx, int P,
+    const double2 *__restrict__ specA, double2 *__restrict__ send) {
+  __shared__ double2 tile[16][17];
+  const int k = blockIdx.z;
+  const int kx0 = blockIdx.x * 16, j0 = blockIdx.y * 16;
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  {
+    const int kx = kx0 + tx, j = j0 + ty;
+    double2 v = make_double2(0., 0.);
+    if (kx < nkx && j < g.ny) v = specA[((size_t)(j + HY) + (size_t)g.py * k) * nkx + kx];
+    tile[ty][tx] = v;
+  }
+  __syncthreads();
+  {
+    const int kx = kx0 + ty, j = j0 + tx;
+    if (kx < cx * P && j < g.ny) {
+      const int d = kx / cx, kxl = kx - d * cx;
+      send[(((size_t)d * g.nz + k) * cx + kxl) * g.ny + j] = tile[tx][ty];
+    }
+  }
+}
+
+// received blocks -> specB (contiguous runs of ny_local)
+__global__ __launch_bounds__(256) void slab_unpack_fwd_kernel(Geo g, int cx, int P, int jtot,
+    const double2 *__restrict__ recv, double2 *__restrict__ specB) {
+  const size_t n = (size_t)P * g.nz * cx * g.ny;
+  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const int j = q % g.ny;
+  size_t t = q / g.ny;
+  const int kxl = t % cx; t /= cx;
+  const int k = t % g.nz;
+  const int s = t / g.nz;
+  specB[((size_t)k * cx + kxl) * jtot + (size_t)s * g.ny + j] = recv[q];
+}
+
+__global__ __launch_bounds__(256) void slab_pack_bwd_kernel(Geo g, int cx, int P, int jtot,
+    const double2 *__restrict__ specB, double2 *__restrict__ send) {
+  const size_t n = (size_t)P * g.nz * cx * g.ny;
+  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const int j = q % g.ny;
+  size_t t = q / g.ny;
+  const int kxl = t % cx; t /= cx;
+  const int k = t % g.nz;
+  const int d = t / g.nz;
+  send[q] = specB[((size_t)k * cx + kxl) * jtot + (size_t)d * g.ny + j];
+}
+
+__global__ __launch_bounds__(256) void slab_unpack_bwd_kernel(Geo g, int nkx, int cx, int P,
+    const double2 *__restrict__ recv, double2 *__restrict__ specA) {
+  __shared__ double2 tile[16][17];
+  const int k = blockIdx.z;
+  const int kx0 = blockIdx.x * 16, j0 = blockIdx.y * 16;
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  {
+    const int kx = kx0 + ty, j = j0 + tx;
+    double2 v = make_double2(0., 0.);
+    if (kx < cx * P && j < g.ny) {
+      const int s = kx / cx, kxl = kx - s * cx;
+      v = recv[(((size_t)s * g.nz + k) * cx + kxl) * g.ny + j];
+    }
+    tile[ty][tx] = v;
+  }
+  __syncthreads();
+  {
+    const int kx = kx0 + tx, j = j0 + ty;
+    if (kx < nkx && j < g.ny) specA[((size_t)(j + HY) + (size_t)g.py * k) * nkx + kx] = tile[tx][ty];
+  }
+}
+
 // tderive, src/modpois.f90:1046-1056,1096-1102 (p ghosts: x by wrap, y by ghost row)
 __global__ __launch_bounds__(256) void project_kernel(Geo g, TileGrid tg, Metrics m, const double *__restrict__ p,
     double *__restrict__ up, double *__restrict__ vp, double *__restrict__ wp, double *__restrict__ pres0) {
@@ -324,6 +406,171 @@ int pois_init(udc_handle *h) {
   return 0;
 }
 
+
+static void poisson_coefficients(udc_handle *h, std::vector<double> &xrt, std::vector<double> &yrt,
+                                 std::vector<double> &tri, double &b_top_D) {
+  const int nx = h->g.nx, ny = h->jtot, nz = h->g.nz, nkx = nx / 2 + 1;
+  const double pi = 3.141592653589793116;   // src/modglobal.f90:270
+  const double dxi = h->m.dxi, dyi = h->m.dyi;
+  xrt.assign(nkx, 0.); yrt.assign(ny, 0.);
+  {
+    const double fac = 1. / (2. * nx);
+    for (int kx = 1; kx < nx / 2; ++kx) { double s = sin((double)(2 * kx) * pi * fac); xrt[kx] = -4. * dxi * dxi * (s * s); }
+    xrt[0] = 0.; xrt[nx / 2] = -4. * dxi * dxi;
+  }
+  {
+    const double fac = 1. / (2. * ny);
+    for (int ky = 0; ky < ny; ++ky) {
+      const int mm = ky <= ny / 2 ? ky : ny - ky;
+      if (mm == 0) yrt[ky] = 0.;
+      else if (mm == ny / 2) yrt[ky] = -4. * dyi * dyi;
+      else { double s = sin((double)(2 * mm) * pi * fac); yrt[ky] = -4. * dyi * dyi * (s * s); }
+    }
+  }
+  tri.assign(3 * (nz + 2), 0.0);
+  double *a = &tri[0], *b = &tri[nz + 2], *c = &tri[2 * (nz + 2)];
+  for (int k = 1; k <= nz; ++k) {
+    a[k] = 1. / (h->cfg.dzf[k] * h->cfg.dzh[k]);
+    c[k] = 1. / (h->cfg.dzf[k] * h->cfg.dzh[k + 1]);
+    b[k] = -(a[k] + c[k]);
+  }
+  b[1] = b[1] + a[1];
+  const double b_top_N = b[nz] + c[nz];
+  b_top_D = b[nz] - c[nz];
+  b[nz] = b_top_N;
+  a[1] = 0.; c[nz] = 0.;
+}
+
+int pois_slab_init(udc_handle *h) {
+  const Geo &g = h->g;
+  const int nx = g.nx, nyl = g.ny, ny = h->jtot, nz = g.nz, P = h->cfg.nranks, r = h->cfg.rank;
+  const int nkx = nx / 2 + 1, cx = (nkx + P - 1) / P;
+  h->nkx = nkx; h->cx = cx;
+  std::vector<double> xrt, yrt, tri;
+  double btopD;
+  poisson_coefficients(h, xrt, yrt, tri, btopD);
+  h->btopD = btopD;
+  const size_t nmodes = (size_t)cx * ny;
+  std::vector<double> ev(nmodes);
+  for (int kxl = 0; kxl < cx; ++kxl) {
+    const int kx = r * cx + kxl;
+    for (int y = 0; y < ny; ++y)
+      ev[(size_t)kxl * ny + y] = kx < nkx ? 1. * (xrt[kx] + yrt[y] + 0.) : -1.0;   // padding modes carry zeros
+  }
+  const size_t rows = (size_t)g.py * nz;
+  HIP_OK(hipMalloc(&h->specA, sizeof(double) * 2 * nkx * rows));
+  HIP_OK(hipMemsetAsync(h->specA, 0, sizeof(double) * 2 * nkx * rows, h->stream));
+  HIP_OK(hipMalloc(&h->specB, sizeof(double) * 2 * nmodes * nz));
+  HIP_OK(hipMalloc(&h->a2a_send, sizeof(double) * 2 * nmodes * nz));
+  HIP_OK(hipMalloc(&h->a2a_recv, sizeof(double) * 2 * nmodes * nz));
+  HIP_OK(hipMalloc(&h->ev_slab, sizeof(double) * nmodes));
+  HIP_OK(hipMalloc(&h->dtab_slab, sizeof(double) * nmodes * (nz > 1 ? nz - 1 : 1)));
+  HIP_OK(hipMalloc(&h->tri, sizeof(double) * tri.size()));
+  HIP_OK(hipMemcpy(h->ev_slab, ev.data(), sizeof(double) * nmodes, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(h->tri, tri.data(), sizeof(double) * tri.size(), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(thomas_table_kernel, dim3((unsigned)((nmodes + 63) / 64)), dim3(64), 0, h->stream,
+                     (int)nmodes, nz, h->ev_slab, h->tri, btopD, h->dtab_slab);
+  HIP_OK(hipGetLastError());
+
+  static bool setup_done = false;
+  if (!setup_done) { FFT_OK(rocfft_setup()); setup_done = true; }
+  size_t off[1] = {0}, one[1] = {1};
+  size_t lx[1] = {(size_t)nx}, ly[1] = {(size_t)ny};
+  rocfft_plan_description d = nullptr;
+  FFT_OK(rocfft_plan_description_create(&d));
+  FFT_OK(rocfft_plan_description_set_data_layout(d, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved,
+                                                 off, off, 1, one, (size_t)nx, 1, one, (size_t)nkx));
+  FFT_OK(rocfft_plan_create(&h->plan_xf, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
+                            rocfft_precision_double, 1, lx, rows, d));
+  rocfft_plan_description_destroy(d);
+  FFT_OK(rocfft_plan_description_create(&d));
+  FFT_OK(rocfft_plan_description_set_data_layout(d, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real,
+                                                 off, off, 1, one, (size_t)nkx, 1, one, (size_t)nx));
+  FFT_OK(rocfft_plan_create(&h->plan_xb, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
+                            rocfft_precision_double, 1, lx, rows, d));
+  rocfft_plan_description_destroy(d);
+  FFT_OK(rocfft_plan_create(&h->plan_yf, rocfft_placement_inplace, rocfft_transform_type_complex_forward,
+                            rocfft_precision_double, 1, ly, (size_t)cx * nz, nullptr));
+  FFT_OK(rocfft_plan_create(&h->plan_yb, rocfft_placement_inplace, rocfft_transform_type_complex_inverse,
+                            rocfft_precision_double, 1, ly, (size_t)cx * nz, nullptr));
+  size_t w = 0, wmax = 0;
+  rocfft_plan plans[4] = {h->plan_xf, h->plan_xb, h->plan_yf, h->plan_yb};
+  for (auto pl : plans) { FFT_OK(rocfft_plan_get_work_buffer_size(pl, &w)); if (w > wmax) wmax = w; }
+  if (wmax) HIP_OK(hipMalloc(&h->fft_work_slab, wmax));
+  FFT_OK(rocfft_execution_info_create(&h->info_x));
+  FFT_OK(rocfft_execution_info_set_stream(h->info_x, h->stream));
+  if (wmax) FFT_OK(rocfft_execution_info_set_work_buffer(h->info_x, h->fft_work_slab, wmax));
+  (void)nyl;
+  return 0;
+}
+
+int k_poisson_solve_slab(udc_handle *h) {
+  const Geo &g = h->g;
+  const int P = h->cfg.nranks, cx = h->cx, nkx = h->nkx, ny = h->jtot;
+  const size_t nmodes = (size_t)cx * ny;
+  const size_t block = (size_t)2 * g.nz * cx * g.ny;          // doubles per all-to-all block
+  double *prow0 = h->fields[UDC_P] + g.idx(0, -HY, 0);         // first padded row of plane k = 0
+  double2 *specA = reinterpret_cast<double2 *>(h->specA), *specB = reinterpret_cast<double2 *>(h->specB);
+  double2 *snd = reinterpret_cast<double2 *>(h->a2a_send), *rcv = reinterpret_cast<double2 *>(h->a2a_recv);
+  const dim3 tb(16, 16), tg((cx * P + 15) / 16, (g.ny + 15) / 16, g.nz);
+  const unsigned lin = (unsigned)(((size_t)P * g.nz * cx * g.ny + 255) / 256);
+  {
+    PROF(h, "fftx_fwd");
+    void *in[1] = {prow0}, *out[1] = {h->specA};
+    FFT_OK(rocfft_execute(h->plan_xf, in, out, h->info_x));
+  }
+  {
+    PROF(h, "a2a_pack");
+    hipLaunchKernelGGL(slab_pack_fwd_kernel, tg, tb, 0, h->stream, g, nkx, cx, P, specA, snd);
+    HIP_OK(hipGetLastError());
+  }
+  {
+    PROF(h, "a2a_xchg");
+    if (comm_alltoall(h, h->a2a_send, h->a2a_recv, block)) return 1;
+  }
+  {
+    PROF(h, "a2a_unpack");
+    hipLaunchKernelGGL(slab_unpack_fwd_kernel, dim3(lin), dim3(256), 0, h->stream, g, cx, P, ny, rcv, specB);
+    HIP_OK(hipGetLastError());
+  }
+  {
+    PROF(h, "ffty_fwd");
+    void *io[1] = {h->specB};
+    FFT_OK(rocfft_execute(h->plan_yf, io, nullptr, h->info_x));
+  }
+  {
+    PROF(h, "thomas");
+    hipLaunchKernelGGL(thomas_kernel, dim3((unsigned)((nmodes + 63) / 64)), dim3(64), 0, h->stream, (int)nmodes,
+                       g.nz, 1. / ((double)g.nx * (double)ny), h->ev_slab, h->tri, h->btopD, h->dtab_slab, specB);
+    HIP_OK(hipGetLastError());
+  }
+  {
+    PROF(h, "ffty_bwd");
+    void *io[1] = {h->specB};
+    FFT_OK(rocfft_execute(h->plan_yb, io, nullptr, h->info_x));
+  }
+  {
+    PROF(h, "a2a_pack");
+    hipLaunchKernelGGL(slab_pack_bwd_kernel, dim3(lin), dim3(256), 0, h->stream, g, cx, P, ny, specB, snd);
+    HIP_OK(hipGetLastError());
+  }
+  {
+    PROF(h, "a2a_xchg");
+    if (comm_alltoall(h, h->a2a_send, h->a2a_recv, block)) return 1;
+  }
+  {
+    PROF(h, "a2a_unpack");
+    hipLaunchKernelGGL(slab_unpack_bwd_kernel, tg, tb, 0, h->stream, g, nkx, cx, P, rcv, specA);
+    HIP_OK(hipGetLastError());
+  }
+  {
+    PROF(h, "fftx_bwd");
+    void *in[1] = {h->specA}, *out[1] = {prow0};
+    FFT_OK(rocfft_execute(h->plan_xb, in, out, h->info_x));
+  }
+  return 0;
+}
+
 void pois_destroy(udc_handle *h) {
   if (h->plan_fwd) rocfft_plan_destroy(h->plan_fwd);
   if (h->plan_bwd) rocfft_plan_destroy(h->plan_bwd);
@@ -335,6 +582,11 @@ void pois_destroy(udc_handle *h) {
   if (h->dtab) hipFree(h->dtab);
   if (h->ev) hipFree(h->ev);
   if (h->tri) hipFree(h->tri);
+  rocfft_plan sp[4] = {h->plan_xf, h->plan_xb, h->plan_yf, h->plan_yb};
+  for (auto pl : sp) if (pl) rocfft_plan_destroy(pl);
+  if (h->info_x) rocfft_execution_info_destroy(h->info_x);
+  double *bufs[7] = {h->specA, h->specB, h->a2a_send, h->a2a_recv, h->ev_slab, h->dtab_slab, (double *)h->fft_work_slab};
+  for (auto b : bufs) if (b) hipFree(b);
 }
 
 int k_divergence_rhs(udc_handle *h, double rk3coef) {
@@ -349,6 +601,7 @@ int k_divergence_rhs(udc_handle *h, double rk3coef) {
 }
 
 int k_poisson_solve(udc_handle *h) {
+  if (h->slab) return k_poisson_solve_slab(h);
   const Geo &g = h->g;
   const long nmodes = (long)h->nkx * g.ny;
   double *pin = h->fields[UDC_P] + g.idx(0, 0, 0);
@@ -436,6 +689,7 @@ int k_maxima(udc_handle *h, double dt, double *cour, double *diffn) {
   hipLaunchKernelGGL(maxima_kernel, gr, b, 0, h->stream, g, tile_grid(g), h->m, dt, h->fields[UDC_UM], h->fields[UDC_VM],
                      h->fields[UDC_WM], h->fields[UDC_EKM], h->fields[UDC_EKH], h->red);
   HIP_OK(hipGetLastError());
+  if (comm_allreduce(h, h->red, 2, 0)) return 1;     // MPI_ALLREDUCE(MAX), src/modtstep.f90:131-132
   HIP_OK(hipMemcpyAsync(h->red_host, h->red, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
   *cour = h->red_host[0];
@@ -451,6 +705,8 @@ int k_divergence_check(udc_handle *h, double *divmax, double *divtot) {
   hipLaunchKernelGGL(divcheck_kernel, gr, b, 0, h->stream, g, tile_grid(g), h->m, h->fields[UDC_U0], h->fields[UDC_V0],
                      h->fields[UDC_W0], h->red);
   HIP_OK(hipGetLastError());
+  if (comm_allreduce(h, h->red, 1, 0)) return 1;         // divmax: MPI_MAX
+  if (comm_allreduce(h, h->red + 1, 1, 1)) return 1;     // divtot: MPI_SUM (src/modchecksim.f90:193-196)
   HIP_OK(hipMemcpyAsync(h->red_host, h->red, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
   *divmax = h->red_host[0];

@@ -51,6 +51,10 @@ class DynCore:
         buf = (C.c_ubyte * 128)(*unique_id)
         L._check(self.lib.udc_comm_init(self.h, buf), "udc_comm_init")
 
+    def comm_init_local(self, group: int):
+        """Attach to an in-process group of virtual ranks (udc_local_group_create); test transport."""
+        L._check(self.lib.udc_comm_init_local(self.h, group), "udc_comm_init_local")
+
     # ---- residency
     def _bounds(self, arr):
         nz, ny, nx = arr.shape
