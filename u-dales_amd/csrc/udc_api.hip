@@ -110,6 +110,7 @@ extern "C" int udc_create(const udc_config *cfg, udc_handle **out) {
   Geo &g = h->g;
   g.nx = cfg->itot; g.ny = cfg->jtot / cfg->nranks; g.nz = cfg->ktot;
   h->jtot = cfg->jtot;
+  h->mom_simple = getenv("UDC_MOM_SIMPLE") && atoi(getenv("UDC_MOM_SIMPLE")) != 0;
   h->slab = cfg->nranks > 1 || (getenv("UDC_FORCE_SLAB") && atoi(getenv("UDC_FORCE_SLAB")) != 0);
   g.py = g.ny + 2 * HY; g.pz = g.nz + 2 * HZ;
   g.sy = g.nx; g.sz = (long)g.nx * g.py; g.n = g.sz * g.pz;
@@ -263,7 +264,7 @@ static int vel_fields(udc_handle *h, int rk3step, int *f) {
 
 extern "C" int udc_advection(udc_handle *h) {
   HIP_OK(hipSetDevice(h->device));
-  if (k_momentum(h, true, false, false)) return 1;
+  if ((h->mom_simple ? k_momentum(h, true, false, false) : k_momentum_lds(h, true, false, false))) return 1;
   for (int n = 0; n < h->cfg.nsv; ++n)
     if (k_scalar_adv(h, n)) return 1;
   return 0;
@@ -274,7 +275,7 @@ extern "C" int udc_subgrid(udc_handle *h) {
   if (k_closure(h)) return 1;
   if (k_ek_ghosts(h)) return 1;
   if (k_top_rows_after_closure(h)) return 1;
-  if (k_momentum(h, false, true, false)) return 1;
+  if ((h->mom_simple ? k_momentum(h, false, true, false) : k_momentum_lds(h, false, true, false))) return 1;
   for (int n = 0; n < h->cfg.nsv; ++n)
     if (k_scalar_diff(h, n)) return 1;
   return 0;
@@ -344,7 +345,7 @@ extern "C" int udc_substep(udc_handle *h, int rk3step, double dt, int with_force
   // closure first: it only needs u0,v0,w0, and the fused sweep below needs ekm
   if (k_closure(h)) return 1;
   if (k_ek_ghosts(h)) return 1;
-  if (k_momentum(h, true, true, with_forces != 0)) return 1;
+  if ((h->mom_simple ? k_momentum(h, true, true, with_forces != 0) : k_momentum_lds(h, true, true, with_forces != 0))) return 1;
   for (int n = 0; n < h->cfg.nsv; ++n) {
     if (k_scalar_adv(h, n)) return 1;
     if (k_scalar_diff(h, n)) return 1;

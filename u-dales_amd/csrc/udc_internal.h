@@ -103,6 +103,7 @@ struct udc_handle {
   double *red = nullptr;                // small device scratch
   double *red_host = nullptr;           // pinned
   // profiling
+  bool mom_simple = false;              // UDC_MOM_SIMPLE=1: use the direct-load momentum kernel
   bool prof = false;
   std::vector<ProfEntry> prof_events;
   std::vector<std::string> prof_names;
@@ -157,7 +158,8 @@ struct ProfScope {
 // ---- kernels (udc_mom.hip, udc_pois.hip, udc_scalar.hip, udc_halo.hip)
 int k_closure(udc_handle *h);
 int k_ek_ghosts(udc_handle *h);
-int k_momentum(udc_handle *h, bool adv, bool diff, bool forces);
+int k_momentum(udc_handle *h, bool adv, bool diff, bool forces);       // direct-load version (UDC_MOM_SIMPLE=1)
+int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces);   // LDS-staged k-marching version (default)
 int k_scalar_adv(udc_handle *h, int n);
 int k_scalar_diff(udc_handle *h, int n);
 int k_forces(udc_handle *h);

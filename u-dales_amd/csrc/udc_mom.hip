@@ -5,6 +5,7 @@
 // the data movement is redesigned: one sweep reads u0,v0,w0,pres0,ekm once and updates
 // up,vp,wp once (88 B/cell algorithmic) instead of the reference's ~12 sweeps.
 #include "udc_internal.h"
+#include "udc_mom_arith.h"
 
 namespace {
 
@@ -27,130 +28,34 @@ __global__ __launch_bounds__(256) void mom_kernel(Geo g, TileGrid tg, Metrics m,
   int i, j, k;
   const bool inside_ = tile_decode(g, tg, i, j, k);
   if (!inside_) return;
-  const int kf = k + 1;   // reference level index for the metric tables
   const int im = wrapm(i, g.nx), ip = wrapp(i, g.nx);
   const long r0 = g.idx(0, j, k);
   const long sy = g.sy, sz = g.sz;
   const long c = r0 + i, xm = r0 + im, xp = r0 + ip;
-
   const double *__restrict__ u = a.u;
   const double *__restrict__ v = a.v;
   const double *__restrict__ w = a.w;
-
-  const double u_c = u[c], u_xm = u[xm], u_xp = u[xp], u_ym = u[c - sy], u_yp = u[c + sy],
-               u_zm = u[c - sz], u_zp = u[c + sz], u_xp_ym = u[xp - sy], u_xp_zm = u[xp - sz];
-  const double v_c = v[c], v_xm = v[xm], v_xp = v[xp], v_ym = v[c - sy], v_yp = v[c + sy],
-               v_zm = v[c - sz], v_zp = v[c + sz], v_xm_yp = v[xm + sy], v_yp_zm = v[c + sy - sz];
-  const double w_c = w[c], w_xm = w[xm], w_xp = w[xp], w_ym = w[c - sy], w_yp = w[c + sy],
-               w_zm = w[c - sz], w_zp = w[c + sz], w_xm_zp = w[xm + sz], w_ym_zp = w[c - sy + sz];
-
-  const double dzf_k = m.dzf[kf], dzf_km = m.dzf[kf - 1], dzf_kp = m.dzf[kf + 1];
-  const double dzhi_k = m.dzhi[kf], dzhi_kp = m.dzhi[kf + 1];
-  const double dzfi_k = m.dzfi[kf];
-
-  double tu = a.up[c], tv = a.vp[c], tw = a.wp[c];
-
+  MomVals q;
+  q.u_c = u[c]; q.u_xm = u[xm]; q.u_xp = u[xp]; q.u_ym = u[c - sy]; q.u_yp = u[c + sy];
+  q.u_zm = u[c - sz]; q.u_zp = u[c + sz]; q.u_xp_ym = u[xp - sy]; q.u_xp_zm = u[xp - sz];
+  q.v_c = v[c]; q.v_xm = v[xm]; q.v_xp = v[xp]; q.v_ym = v[c - sy]; q.v_yp = v[c + sy];
+  q.v_zm = v[c - sz]; q.v_zp = v[c + sz]; q.v_xm_yp = v[xm + sy]; q.v_yp_zm = v[c + sy - sz];
+  q.w_c = w[c]; q.w_xm = w[xm]; q.w_xp = w[xp]; q.w_ym = w[c - sy]; q.w_yp = w[c + sy];
+  q.w_zm = w[c - sz]; q.w_zp = w[c + sz]; q.w_xm_zp = w[xm + sz]; q.w_ym_zp = w[c - sy + sz];
   if (ADV) {
     const double *__restrict__ p = a.p;
-    const double p_c = p[c], p_xm = p[xm], p_ym = p[c - sy], p_zm = p[c - sz];
-    const double dzfi5_k = m.dzfi5[kf];
-    // advecu_2nd, src/modadvection.f90:178-187 and :202-207
-    tu = tu - (((u_c + u_xp) * (u_c + u_xp) - (u_c + u_xm) * (u_c + u_xm)) * m.dxiq
-             + ((u_c + u_yp) * (v_yp + v_xm_yp) - (u_c + u_ym) * (v_c + v_xm)) * m.dyiq)
-            - ((p_c - p_xm) * m.dxi);
-    tu = tu - ((u_zp * dzf_k + u_c * dzf_kp) * dzhi_kp * (w_zp + w_xm_zp)
-             - (u_c * dzf_km + u_zm * dzf_k) * dzhi_k * (w_c + w_xm)) * 0.5 * dzfi5_k;
-    // advecv_2nd, :235-245 and :260-265
-    tv = tv - (((u_xp + u_xp_ym) * (v_c + v_xp) - (u_c + u_ym) * (v_c + v_xm)) * m.dxiq
-             + ((v_yp + v_c) * (v_c + v_yp) - (v_ym + v_c) * (v_c + v_ym)) * m.dyiq)
-            - ((p_c - p_ym) * m.dyi);
-    tv = tv - ((w_zp + w_ym_zp) * (v_zp * dzf_k + v_c * dzf_kp) * dzhi_kp
-             - (w_c + w_ym) * (v_zm * dzf_k + v_c * dzf_km) * dzhi_k) * 0.5 * dzfi5_k;
-    // advecw_2nd, :295-309 (k = kb+1..ke)
-    if (k >= 1) {
-      const double dzhiq_k = m.dzhiq[kf];
-      tw = tw - (((w_xp + w_c) * (dzf_km * u_xp + dzf_k * u_xp_zm)
-                - (w_c + w_xm) * (dzf_km * u_c + dzf_k * u_zm)) * m.dxiq * dzhi_k
-               + ((w_yp + w_c) * (dzf_km * v_yp + dzf_k * v_yp_zm)
-                - (w_c + w_ym) * (dzf_km * v_c + dzf_k * v_zm)) * m.dyiq * dzhi_k
-               + ((w_c + w_zp) * (w_c + w_zp) - (w_c + w_zm) * (w_c + w_zm)) * dzhiq_k)
-              - ((p_c - p_zm) * dzhi_k);
-    }
+    q.p_c = p[c]; q.p_xm = p[xm]; q.p_ym = p[c - sy]; q.p_zm = p[c - sz];
   }
-
-  if (DIFF) {
-    if (LES) {
-      const double *__restrict__ e = a.ek;
-      const double e_c = e[c], e_xm = e[xm], e_xp = e[xp], e_ym = e[c - sy], e_yp = e[c + sy],
-                   e_zm = e[c - sz], e_zp = e[c + sz];
-      const double e_xm_yp = e[xm + sy], e_xm_ym = e[xm - sy], e_xm_zm = e[xm - sz], e_xm_zp = e[xm + sz];
-      const double e_ym_zm = e[c - sy - sz], e_ym_zp = e[c - sy + sz], e_xp_ym = e[xp - sy];
-      const double e_yp_zm = e[c + sy - sz], e_xp_zm = e[xp - sz];
-      const double dzhiq_k = m.dzhiq[kf], dzhiq_kp = m.dzhiq[kf + 1];
-      {  // diffu, src/modsubgrid.f90:695-729
-        const double emom = (dzf_km * (e_c + e_xm) + dzf_k * (e_zm + e_xm_zm)) * dzhiq_k;
-        const double emop = (dzf_kp * (e_c + e_xm) + dzf_k * (e_zp + e_xm_zp)) * dzhiq_kp;
-        const double empo = 0.25 * ((e_c + e_yp) + (e_xm + e_xm_yp));
-        const double emmo = 0.25 * ((e_c + e_ym) + (e_xm_ym + e_xm));
-        tu = tu + (e_c * (u_xp - u_c) - e_xm * (u_c - u_xm)) * 2. * m.dx2i
-                + (empo * ((u_yp - u_c) * m.dyi + (v_yp - v_xm_yp) * m.dxi)
-                 - emmo * ((u_c - u_ym) * m.dyi + (v_c - v_xm) * m.dxi)) * m.dyi
-                + (emop * ((u_zp - u_c) * dzhi_kp + (w_zp - w_xm_zp) * m.dxi)
-                 - emom * ((u_c - u_zm) * dzhi_k + (w_c - w_xm) * m.dxi)) * dzfi_k;
-      }
-      {  // diffv, :802-838
-        const double eomm = (dzf_km * (e_c + e_ym) + dzf_k * (e_zm + e_ym_zm)) * dzhiq_k;
-        const double eomp = (dzf_kp * (e_c + e_ym) + dzf_k * (e_zp + e_ym_zp)) * dzhiq_kp;
-        const double emmo = 0.25 * (e_c + e_ym + e_xm_ym + e_xm);
-        const double epmo = 0.25 * (e_c + e_ym + e_xp_ym + e_xp);
-        tv = tv + (epmo * ((v_xp - v_c) * m.dxi + (u_xp - u_xp_ym) * m.dyi)
-                 - emmo * ((v_c - v_xm) * m.dxi + (u_c - u_ym) * m.dyi)) * m.dxi
-                + (e_c * (v_yp - v_c) - e_ym * (v_c - v_ym)) * 2. * m.dy2i
-                + (eomp * ((v_zp - v_c) * dzhi_kp + (w_zp - w_ym_zp) * m.dyi)
-                 - eomm * ((v_c - v_zm) * dzhi_k + (w_c - w_ym) * m.dyi)) * dzfi_k;
-      }
-      if (k >= 1) {  // diffw, :913-951
-        const double dzfi_km = m.dzfi[kf - 1];
-        const double emom = (dzf_km * (e_c + e_xm) + dzf_k * (e_zm + e_xm_zm)) * dzhiq_k;
-        const double eomm = (dzf_km * (e_c + e_ym) + dzf_k * (e_zm + e_ym_zm)) * dzhiq_k;
-        const double eopm = (dzf_km * (e_c + e_yp) + dzf_k * (e_zm + e_yp_zm)) * dzhiq_k;
-        const double epom = (dzf_km * (e_c + e_xp) + dzf_k * (e_zm + e_xp_zm)) * dzhiq_k;
-        tw = tw + (epom * ((w_xp - w_c) * m.dxi + (u_xp - u_xp_zm) * dzhi_k)
-                 - emom * ((w_c - w_xm) * m.dxi + (u_c - u_zm) * dzhi_k)) * m.dxi
-                + (eopm * ((w_yp - w_c) * m.dyi + (v_yp - v_yp_zm) * dzhi_k)
-                 - eomm * ((w_c - w_ym) * m.dyi + (v_c - v_zm) * dzhi_k)) * m.dyi
-                + (e_c * (w_zp - w_c) * dzfi_k - e_zm * (w_c - w_zm) * dzfi_km) * 2. * dzhi_k;
-      }
-    } else {
-      const double nu = numol;
-      // DNS forms, src/modsubgrid.f90:745-768, 855-878, 967-990
-      tu = tu + (nu * (u_xp - u_c) * m.dxi - nu * (u_c - u_xm) * m.dxi) * 2. * m.dxi
-              + (nu * ((u_yp - u_c) * m.dyi + (v_yp - v_xm_yp) * m.dxi)
-               - nu * ((u_c - u_ym) * m.dyi + (v_c - v_xm) * m.dxi)) * m.dyi
-              + (nu * ((u_zp - u_c) * dzhi_kp + (w_zp - w_xm_zp) * m.dxi)
-               - nu * ((u_c - u_zm) * dzhi_k + (w_c - w_xm) * m.dxi)) * dzfi_k;
-      tv = tv + (nu * ((v_xp - v_c) * m.dxi + (u_xp - u_xp_ym) * m.dyi)
-               - nu * ((v_c - v_xm) * m.dxi + (u_c - u_ym) * m.dyi)) * m.dxi
-              + (nu * (v_yp - v_c) - nu * (v_c - v_ym)) * 2. * m.dy2i
-              + (nu * ((v_zp - v_c) * dzhi_kp + (w_zp - w_ym_zp) * m.dyi)
-               - nu * ((v_c - v_zm) * dzhi_k + (w_c - w_ym) * m.dyi)) * dzfi_k;
-      if (k >= 1) {
-        const double dzfi_km = m.dzfi[kf - 1];
-        tw = tw + (nu * ((w_xp - w_c) * m.dxi + (u_xp - u_xp_zm) * dzhi_k)
-                 - nu * ((w_c - w_xm) * m.dxi + (u_c - u_zm) * dzhi_k)) * m.dxi
-                + (nu * ((w_yp - w_c) * m.dyi + (v_yp - v_yp_zm) * dzhi_k)
-                 - nu * ((w_c - w_ym) * m.dyi + (v_c - v_zm) * dzhi_k)) * m.dyi
-                + (nu * (w_zp - w_c) * dzfi_k - nu * (w_c - w_zm) * dzfi_km) * 2. * dzhi_k;
-      }
-    }
+  if (DIFF && LES) {
+    const double *__restrict__ e = a.ek;
+    q.e_c = e[c]; q.e_xm = e[xm]; q.e_xp = e[xp]; q.e_ym = e[c - sy]; q.e_yp = e[c + sy];
+    q.e_zm = e[c - sz]; q.e_zp = e[c + sz];
+    q.e_xm_yp = e[xm + sy]; q.e_xm_ym = e[xm - sy]; q.e_xm_zm = e[xm - sz]; q.e_xm_zp = e[xm + sz];
+    q.e_ym_zm = e[c - sy - sz]; q.e_ym_zp = e[c - sy + sz]; q.e_xp_ym = e[xp - sy];
+    q.e_yp_zm = e[c + sy - sz]; q.e_xp_zm = e[xp - sz];
   }
-
-  if (FORCES) {
-    tu = tu - m.dpdxl[kf];
-    tv = tv - m.dpdyl[kf];
-    if (k == 0) tw = 0.0;
-  }
-
+  double tu = a.up[c], tv = a.vp[c], tw = a.wp[c];
+  mom_arith<ADV, DIFF, LES, FORCES>(q, m, k, numol, tu, tv, tw);
   a.up[c] = tu;
   a.vp[c] = tv;
   a.wp[c] = tw;   // unchanged at k = 0 unless FORCES (the reference's w loops start at kb+1)

@@ -1,0 +1,169 @@
+// Fused momentum sweep, LDS-staged and marching in k ("2.5-D blocking").
+//
+// A workgroup owns a 64(x) x 4(y) column of cells and walks KC levels upward.  For every level it
+// stages the (64+2) x (4+2) tile of u0, v0, w0 (and ekm) of plane k+1 into LDS, keeping planes
+// k-1, k, k+1 resident (3 rotating buffers), so each value is fetched from global memory once per
+// workgroup instead of once per neighbouring cell (the direct-load kernel issues ~50 global loads
+// per cell; this one ~8 + 4 for pres0 + 3 for the tendencies).  The next plane is loaded into
+// registers BEFORE the current level is computed and written to LDS after it (async-stage split),
+// so HBM latency hides behind the ~400 flops of the stencil.  pres0 needs only (c, i-1, j-1, k-1) and
+// is read directly.  x is periodic: tile column c holds global i = (i0 - 1 + c) mod nx.
+#include "udc_internal.h"
+#include "udc_mom_arith.h"
+
+namespace {
+
+constexpr int LX = TX + 2, LY = TY + 2, LN = LX * LY;   // 66 x 6 = 396 doubles per field-plane
+constexpr int NT = TX * TY;                               // 256 threads
+#ifndef MOM_WAVES
+#define MOM_WAVES 3
+#endif
+
+struct MomArgs {
+  const double *u, *v, *w, *p, *ek;
+  double *up, *vp, *wp;
+};
+
+template <int NF>
+struct Stage {            // values of one plane held in registers between "load" and "commit"
+  double c[NF];           // this thread's own cell
+  double h[NF];           // one halo element (threads 0..LN-NT-1)
+};
+
+// tile element e (0..LN-1) -> offset from the plane's row base; halo elements are e >= NT
+__device__ __forceinline__ void halo_coords(int e, int &lx, int &ly) {
+  // enumerate the 140 halo cells: rows 0 and LY-1 fully (2*66), then columns 0 and LX-1 of rows 1..LY-2 (2*4)
+  if (e < LX) { ly = 0; lx = e; }
+  else if (e < 2 * LX) { ly = LY - 1; lx = e - LX; }
+  else { const int r = e - 2 * LX; ly = 1 + (r >> 1); lx = (r & 1) ? LX - 1 : 0; }
+}
+
+template <bool ADV, bool DIFF, bool LES, bool FORCES>
+__global__ __launch_bounds__(NT, MOM_WAVES) void mom_lds_kernel(Geo g, TileGrid tg, Metrics m, MomArgs a, double numol, int kc) {
+  constexpr int NF = (DIFF && LES) ? 4 : 3;
+  __shared__ double s[3][NF][LN];
+
+  // workgroup -> (tile, k-chunk); XCD-aware like tile_decode but with chunks instead of planes
+  const unsigned L = blockIdx.x;
+  const int chunk = L / tg.tiles;
+  const unsigned lp = L - (unsigned)chunk * tg.tiles;
+  unsigned tt = lp;
+  if ((tg.tiles & 7) == 0) tt = (lp & 7u) * (tg.tiles >> 3) + (lp >> 3);
+  const int by = tt / tg.gx, bx = tt - by * tg.gx;
+  const int i0 = bx * TX, j0 = by * TY;
+  const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * TX + tx;
+  const int i = i0 + tx, j = j0 + ty;
+  const bool inside = i < g.nx && j < g.ny;
+  const int k0 = chunk * kc;
+  const int k1 = min(k0 + kc, g.nz);
+
+  const double *fld[4] = {a.u, a.v, a.w, a.ek};
+
+  // global column offsets (within a plane) of the two elements this thread stages
+  const int ic = i % g.nx;                               // partial tiles: columns beyond nx hold the periodic images
+  const int jc = min(j, g.ny + HY - 1);
+  const long own_off = (long)ic + (long)g.sy * (jc + HY);
+  int hlx = 0, hly = 0;
+  const bool has_halo = tid < LN - NT;
+  if (has_halo) halo_coords(tid, hlx, hly);
+  int hi = i0 - 1 + hlx;
+  hi %= g.nx; if (hi < 0) hi += g.nx;
+  const int hj = min(j0 - 1 + hly, g.ny + HY - 1);
+  const long halo_off = (long)hi + (long)g.sy * (hj + HY);
+  const int own_l = (ty + 1) * LX + (tx + 1);
+  const int halo_l = hly * LX + hlx;
+
+  auto load_plane = [&](int k, Stage<NF> &st) {
+    const long pb = g.sz * (long)(k + HZ);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      st.c[f] = fld[f][pb + own_off];
+      st.h[f] = has_halo ? fld[f][pb + halo_off] : 0.0;
+    }
+  };
+  auto commit_plane = [&](int buf, const Stage<NF> &st) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      s[buf][f][own_l] = st.c[f];
+      if (has_halo) s[buf][f][halo_l] = st.h[f];
+    }
+  };
+
+  // prologue: planes k0-1 and k0 into buffers 0 and 1, plane k0+1 into registers
+  Stage<NF> st;
+  load_plane(k0 - 1, st); commit_plane(0, st);
+  load_plane(k0, st);     commit_plane(1, st);
+  load_plane(k0 + 1, st);
+  int bm = 0, bc = 1, bp = 2;      // buffers holding planes k-1, k, k+1
+  const long cell0 = own_off;
+
+  for (int k = k0; k < k1; ++k) {
+    commit_plane(bp, st);                                  // plane k+1
+    __syncthreads();
+    if (k + 1 < k1) load_plane(k + 2, st);                 // prefetch for the next level (in flight during compute)
+    if (inside) {
+      const double *um_ = s[bm][0], *uc_ = s[bc][0], *up_ = s[bp][0];
+      const double *vm_ = s[bm][1], *vc_ = s[bc][1], *vp_ = s[bp][1];
+      const double *wm_ = s[bm][2], *wc_ = s[bc][2], *wp_ = s[bp][2];
+      const int o = own_l;
+      MomVals q;
+      q.u_c = uc_[o]; q.u_xm = uc_[o - 1]; q.u_xp = uc_[o + 1]; q.u_ym = uc_[o - LX]; q.u_yp = uc_[o + LX];
+      q.u_zm = um_[o]; q.u_zp = up_[o]; q.u_xp_ym = uc_[o + 1 - LX]; q.u_xp_zm = um_[o + 1];
+      q.v_c = vc_[o]; q.v_xm = vc_[o - 1]; q.v_xp = vc_[o + 1]; q.v_ym = vc_[o - LX]; q.v_yp = vc_[o + LX];
+      q.v_zm = vm_[o]; q.v_zp = vp_[o]; q.v_xm_yp = vc_[o - 1 + LX]; q.v_yp_zm = vm_[o + LX];
+      q.w_c = wc_[o]; q.w_xm = wc_[o - 1]; q.w_xp = wc_[o + 1]; q.w_ym = wc_[o - LX]; q.w_yp = wc_[o + LX];
+      q.w_zm = wm_[o]; q.w_zp = wp_[o]; q.w_xm_zp = wp_[o - 1]; q.w_ym_zp = wp_[o - LX];
+      const long c = g.sz * (long)(k + HZ) + cell0;
+      if (ADV) {
+        const double *__restrict__ p = a.p;
+        const long xm = c - i + (i == 0 ? g.nx - 1 : i - 1);
+        q.p_c = p[c]; q.p_xm = p[xm]; q.p_ym = p[c - g.sy]; q.p_zm = p[c - g.sz];
+      }
+      if (DIFF && LES) {
+        const double *em_ = s[bm][NF - 1], *ec_ = s[bc][NF - 1], *ep_ = s[bp][NF - 1];
+        q.e_c = ec_[o]; q.e_xm = ec_[o - 1]; q.e_xp = ec_[o + 1]; q.e_ym = ec_[o - LX]; q.e_yp = ec_[o + LX];
+        q.e_zm = em_[o]; q.e_zp = ep_[o];
+        q.e_xm_yp = ec_[o - 1 + LX]; q.e_xm_ym = ec_[o - 1 - LX]; q.e_xm_zm = em_[o - 1]; q.e_xm_zp = ep_[o - 1];
+        q.e_ym_zm = em_[o - LX]; q.e_ym_zp = ep_[o - LX]; q.e_xp_ym = ec_[o + 1 - LX];
+        q.e_yp_zm = em_[o + LX]; q.e_xp_zm = em_[o + 1];
+      }
+      double tu = a.up[c], tv = a.vp[c], tw = a.wp[c];
+      mom_arith<ADV, DIFF, LES, FORCES>(q, m, k, numol, tu, tv, tw);
+      a.up[c] = tu; a.vp[c] = tv; a.wp[c] = tw;
+    }
+    __syncthreads();                                       // everyone done with plane k-1 before it is overwritten
+    const int t = bm; bm = bc; bc = bp; bp = t;
+  }
+}
+
+}  // namespace
+
+int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces) {
+  const Geo &g = h->g;
+  MomArgs a{h->fields[UDC_U0], h->fields[UDC_V0], h->fields[UDC_W0], h->fields[UDC_PRES0],
+            h->fields[UDC_EKM], h->fields[UDC_UP], h->fields[UDC_VP], h->fields[UDC_WP]};
+  const TileGrid tg = tile_grid(g);
+  // k-chunk: long enough to amortise the 2-plane prologue, short enough to fill 256 CUs x 4 workgroups
+  int kc = 32;
+  while (kc > 4 && (long)tg.tiles * ((g.nz + kc - 1) / kc) < 2048) kc >>= 1;
+  const int chunks = (g.nz + kc - 1) / kc;
+  dim3 b(TX, TY, 1), gr((unsigned)tg.tiles * (unsigned)chunks, 1, 1);
+  const bool les = h->p.sgs != UDC_SGS_DNS;
+  const double nu = h->p.numol;
+#define LAUNCH(A, D, L, F)                                                                         \
+  do {                                                                                             \
+    PROF(h, "mom_" #A #D #L #F);                                                                   \
+    hipLaunchKernelGGL((mom_lds_kernel<A, D, L, F>), gr, b, 0, h->stream, g, tg, h->m, a, nu, kc); \
+  } while (0)
+  if (adv && diff) {
+    if (les) { if (forces) LAUNCH(true, true, true, true); else LAUNCH(true, true, true, false); }
+    else     { if (forces) LAUNCH(true, true, false, true); else LAUNCH(true, true, false, false); }
+  } else if (adv) {
+    LAUNCH(true, false, true, false);
+  } else if (diff) {
+    if (les) LAUNCH(false, true, true, false); else LAUNCH(false, true, false, false);
+  }
+#undef LAUNCH
+  HIP_OK(hipGetLastError());
+  return 0;
+}

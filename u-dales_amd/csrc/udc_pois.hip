@@ -63,6 +63,10 @@ __global__ void thomas_table_kernel(int nmodes, int nz, const double *__restrict
 
 // solmpj, src/modpois.f90:1107-1166, one thread per (kx,ky) mode, complex data.
 // scale = 1/(nx*ny) carries the reference's four 1/sqrt(n) factors.
+// The recurrence is sequential in k but its loads are not: each thread fetches TU levels ahead
+// (independent 16-B loads in flight) before running the dependent arithmetic on them, which is what
+// keeps HBM busy with only nmodes/64 waves on the chip.
+constexpr int TU = 8;
 __global__ __launch_bounds__(64) void thomas_kernel(int nmodes, int nz, double scale,
     const double *__restrict__ ev, const double *__restrict__ tri, double btopD,
     const double *__restrict__ dtab, double2 *__restrict__ x) {
@@ -70,39 +74,68 @@ __global__ __launch_bounds__(64) void thomas_kernel(int nmodes, int nz, double s
   if (mo >= nmodes) return;
   const double *a = tri, *b = tri + (nz + 2), *c = tri + 2 * (nz + 2);
   const double e = ev[mo];
+  const size_t st = (size_t)nmodes;
+  double2 *xm = x + mo;                 // xm[(k-1)*st] = level k
   double z = 1. / (b[1] + e);
   double d = c[1] * z;
-  double2 xp = x[mo];
+  double2 xp = xm[0];
   xp.x = (xp.x * scale) * z; xp.y = (xp.y * scale) * z;
-  x[mo] = xp;
-  for (int k = 2; k <= nz - 1; ++k) {
-    const double bbk = b[k] + e;
-    z = 1. / (bbk - a[k] * d);
-    d = c[k] * z;
-    double2 xc = x[(long)(k - 1) * nmodes + mo];
-    xc.x = (xc.x * scale - a[k] * xp.x) * z;
-    xc.y = (xc.y * scale - a[k] * xp.y) * z;
-    x[(long)(k - 1) * nmodes + mo] = xc;
-    xp = xc;
+  xm[0] = xp;
+  // forward elimination, levels 2 .. nz-1
+  for (int k0 = 2; k0 <= nz - 1; k0 += TU) {
+    double2 buf[TU];
+#pragma unroll
+    for (int u = 0; u < TU; ++u)
+      if (k0 + u <= nz - 1) buf[u] = xm[(size_t)(k0 + u - 1) * st];
+#pragma unroll
+    for (int u = 0; u < TU; ++u) {
+      const int k = k0 + u;
+      if (k <= nz - 1) {
+        const double bbk = b[k] + e;
+        z = 1. / (bbk - a[k] * d);
+        d = c[k] * z;
+        double2 xc = buf[u];
+        xc.x = (xc.x * scale - a[k] * xp.x) * z;
+        xc.y = (xc.y * scale - a[k] * xp.y) * z;
+        buf[u] = xc;
+        xp = xc;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < TU; ++u)
+      if (k0 + u <= nz - 1) xm[(size_t)(k0 + u - 1) * st] = buf[u];
   }
   {
     // the singular (0,0) mode gets a Dirichlet condition across the top cell (:209-220)
     const double bbk = (e == 0.) ? btopD : b[nz] + e;
     const double ak = a[nz];
     z = bbk - ak * d;
-    double2 xc = x[(long)(nz - 1) * nmodes + mo];
+    double2 xc = xm[(size_t)(nz - 1) * st];
     xc.x = (xc.x * scale - ak * xp.x) / z;
     xc.y = (xc.y * scale - ak * xp.y) / z;
-    x[(long)(nz - 1) * nmodes + mo] = xc;
+    xm[(size_t)(nz - 1) * st] = xc;
     xp = xc;
   }
-  for (int k = nz - 1; k >= 1; --k) {
-    const double dk = dtab[(long)(k - 1) * nmodes + mo];
-    double2 xc = x[(long)(k - 1) * nmodes + mo];
-    xc.x = xc.x - dk * xp.x;
-    xc.y = xc.y - dk * xp.y;
-    x[(long)(k - 1) * nmodes + mo] = xc;
-    xp = xc;
+  // back substitution, levels nz-1 .. 1
+  const double *dm = dtab + mo;
+  for (int k0 = nz - 1; k0 >= 1; k0 -= TU) {
+    double2 buf[TU];
+    double dk[TU];
+#pragma unroll
+    for (int u = 0; u < TU; ++u)
+      if (k0 - u >= 1) { buf[u] = xm[(size_t)(k0 - u - 1) * st]; dk[u] = dm[(size_t)(k0 - u - 1) * st]; }
+#pragma unroll
+    for (int u = 0; u < TU; ++u)
+      if (k0 - u >= 1) {
+        double2 xc = buf[u];
+        xc.x = xc.x - dk[u] * xp.x;
+        xc.y = xc.y - dk[u] * xp.y;
+        buf[u] = xc;
+        xp = xc;
+      }
+#pragma unroll
+    for (int u = 0; u < TU; ++u)
+      if (k0 - u >= 1) xm[(size_t)(k0 - u - 1) * st] = buf[u];
   }
 }
 
@@ -116,7 +149,6 @@ __global__ __launch_bounds__(256) void real_copy_kernel(Geo g, TileGrid tg, doub
   const long q = (long)i + (long)g.nx * (j + (long)g.ny * k);
   if (TO_FIELD) field[c] = buf[q]; else buf[q] = field[c];
 }
-
 
 // ======================================================================= y-slab Poisson path
 // Layouts (complex = interleaved double2):
