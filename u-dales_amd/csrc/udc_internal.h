@@ -157,6 +157,7 @@ struct ProfScope {
 
 // ---- kernels (udc_mom.hip, udc_pois.hip, udc_scalar.hip, udc_halo.hip)
 int k_closure(udc_handle *h);
+int k_closure_lds(udc_handle *h);
 int k_ek_ghosts(udc_handle *h);
 int k_momentum(udc_handle *h, bool adv, bool diff, bool forces);       // direct-load version (UDC_MOM_SIMPLE=1)
 int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces);   // LDS-staged k-marching version (default)

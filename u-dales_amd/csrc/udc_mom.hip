@@ -6,6 +6,7 @@
 // up,vp,wp once (88 B/cell algorithmic) instead of the reference's ~12 sweeps.
 #include "udc_internal.h"
 #include "udc_mom_arith.h"
+#include "udc_closure_arith.h"
 
 namespace {
 
@@ -64,6 +65,17 @@ __global__ __launch_bounds__(256) void mom_kernel(Geo g, TileGrid tg, Metrics m,
 // ---------------------------------------------------------------------------- closure
 // SGS: 1 = Smagorinsky (src/modsubgrid.f90:208-264), 2 = Vreman (:269-360).  The molecular
 // part is added in the same statement order as the reference (ekh from ekm first, then +nu).
+struct GlobalAcc {   // neighbour access straight from global memory (x periodic by index wrap)
+  const double *pu, *pv, *pw;
+  long c, xm, xp, sy, sz;
+  __device__ __forceinline__ long off(int di, int dj, int dk) const {
+    return (di == 0 ? c : (di < 0 ? xm : xp)) + dj * sy + dk * sz;
+  }
+  __device__ __forceinline__ double u(int di, int dj, int dk) const { return pu[off(di, dj, dk)]; }
+  __device__ __forceinline__ double v(int di, int dj, int dk) const { return pv[off(di, dj, dk)]; }
+  __device__ __forceinline__ double w(int di, int dj, int dk) const { return pw[off(di, dj, dk)]; }
+};
+
 template <int SGS>
 __global__ __launch_bounds__(256) void closure_kernel(Geo g, TileGrid tg, Metrics m, Params pr, const double *__restrict__ u,
                                                        const double *__restrict__ v, const double *__restrict__ w,
@@ -71,69 +83,12 @@ __global__ __launch_bounds__(256) void closure_kernel(Geo g, TileGrid tg, Metric
   int i, j, k;
   const bool inside_ = tile_decode(g, tg, i, j, k);
   if (!inside_) return;
-  const int kf = k + 1;
-  const int im = wrapm(i, g.nx), ip = wrapp(i, g.nx);
   const long r0 = g.idx(0, j, k);
-  const long sy = g.sy, sz = g.sz;
-  const long c = r0 + i, xm = r0 + im, xp = r0 + ip;
-  const double dxi = m.dxi, dyi = m.dyi;
-  const double dzhi_k = m.dzhi[kf], dzhi_kp = m.dzhi[kf + 1], dzfi_k = m.dzfi[kf];
+  GlobalAcc A{u, v, w, r0 + i, r0 + wrapm(i, g.nx), r0 + wrapp(i, g.nx), g.sy, g.sz};
   double em, eh;
-  if (SGS == 1) {
-    double t, strain2;
-    t = (u[xp] - u[c]) * dxi; strain2 = t * t;
-    t = (v[c + sy] - v[c]) * dyi; strain2 = strain2 + t * t;
-    t = (w[c + sz] - w[c]) * dzfi_k; strain2 = strain2 + t * t;
-    double a1 = (w[c + sz] - w[xm + sz]) * dxi + (u[c + sz] - u[c]) * dzhi_kp;
-    double a2 = (w[c] - w[xm]) * dxi + (u[c] - u[c - sz]) * dzhi_k;
-    double a3 = (w[xp] - w[c]) * dxi + (u[xp] - u[xp - sz]) * dzhi_k;
-    double a4 = (w[xp + sz] - w[c + sz]) * dxi + (u[xp + sz] - u[xp]) * dzhi_kp;
-    strain2 = strain2 + 0.125 * (a1 * a1 + a2 * a2 + a3 * a3 + a4 * a4);
-    a1 = (u[c + sy] - u[c]) * dyi + (v[c + sy] - v[xm + sy]) * dxi;
-    a2 = (u[c] - u[c - sy]) * dyi + (v[c] - v[xm]) * dxi;
-    a3 = (u[xp] - u[xp - sy]) * dyi + (v[xp] - v[c]) * dxi;
-    a4 = (u[xp + sy] - u[xp]) * dyi + (v[xp + sy] - v[c + sy]) * dxi;
-    strain2 = strain2 + 0.125 * (a1 * a1 + a2 * a2 + a3 * a3 + a4 * a4);
-    a1 = (v[c + sz] - v[c]) * dzhi_kp + (w[c + sz] - w[c - sy + sz]) * dyi;
-    a2 = (v[c] - v[c - sz]) * dzhi_k + (w[c] - w[c - sy]) * dyi;
-    a3 = (v[c + sy] - v[c + sy - sz]) * dzhi_k + (w[c + sy] - w[c]) * dyi;
-    a4 = (v[c + sy + sz] - v[c + sy]) * dzhi_kp + (w[c + sy + sz] - w[c + sz]) * dyi;
-    strain2 = strain2 + 0.125 * (a1 * a1 + a2 * a2 + a3 * a3 + a4 * a4);
-    const double ml = m.mlen[kf];
-    em = (ml * ml) * sqrt(2. * strain2);
-    eh = em * pr.prandtli;
-    em = em + pr.numol;
-    eh = eh + pr.numol * pr.prandtlmoli;
-  } else {
-    const double dzf_k = m.dzf[kf], dzf_km = m.dzf[kf - 1], dzf_kp = m.dzf[kf + 1];
-    const double a11 = (u[xp] - u[c]) * dxi;
-    const double a12 = (v[xp + sy] + v[xp] - v[xm + sy] - v[xm]) * m.dxiq;
-    const double a13 = (w[xp + sz] + w[xp] - w[xm + sz] - w[xm]) * m.dxiq;
-    const double a21 = (u[xp + sy] + u[c + sy] - u[xp - sy] - u[c - sy]) * m.dyiq;
-    const double a22 = (v[c + sy] - v[c]) * dyi;
-    const double a23 = (w[c + sy + sz] + w[c + sy] - w[c - sy + sz] - w[c - sy]) * m.dyiq;
-    const double a31 = (((u[xp + sz] + u[c + sz]) * dzf_k + (u[xp] + u[c]) * dzf_kp) * dzhi_kp
-                      - ((u[xp] + u[c]) * dzf_km + (u[xp - sz] + u[c - sz]) * dzf_k) * dzhi_k) * m.dzfiq[kf];
-    const double a32 = (((v[c + sy + sz] + v[c + sz]) * dzf_k + (v[c + sy] + v[c]) * dzf_kp) * dzhi_kp
-                      - ((v[c + sy] + v[c]) * dzf_km + (v[c + sy - sz] + v[c - sz]) * dzf_k) * dzhi_k) * m.dzfiq[kf];
-    const double a33 = (w[c + sz] - w[c]) * dzfi_k;
-    const double aa = a11 * a11 + a21 * a21 + a31 * a31 + a12 * a12 + a22 * a22 + a32 * a32
-                    + a13 * a13 + a23 * a23 + a33 * a33;
-    const double dx2 = m.dx2, dy2 = m.dy2, dz2 = m.dzf2[kf];
-    const double b11 = dx2 * a11 * a11 + dy2 * a21 * a21 + dz2 * a31 * a31;
-    const double b22 = dx2 * a12 * a12 + dy2 * a22 * a22 + dz2 * a32 * a32;
-    const double b12 = dx2 * a11 * a12 + dy2 * a21 * a22 + dz2 * a31 * a32;
-    const double b33 = dx2 * a13 * a13 + dy2 * a23 * a23 + dz2 * a33 * a33;
-    const double b13 = dx2 * a11 * a13 + dy2 * a21 * a23 + dz2 * a31 * a33;
-    const double b23 = dx2 * a12 * a13 + dy2 * a22 * a23 + dz2 * a32 * a33;
-    const double bb = b11 * b22 - b12 * b12 + b11 * b33 - b13 * b13 + b22 * b33 - b23 * b23;
-    em = (bb < 1.e-8) ? 0. : pr.c_vreman * sqrt(bb / aa);
-    eh = em * pr.prandtli;
-    em = em + pr.numol;
-    eh = eh + pr.numol * pr.prandtlmoli;
-  }
-  ekm[c] = em;
-  ekh[c] = eh;
+  closure_arith<SGS>(A, m, pr, k, em, eh);
+  ekm[A.c] = em;
+  ekh[A.c] = eh;
 }
 
 __global__ void fill_const_kernel(Geo g, double *__restrict__ a, double val, double *__restrict__ b, double valb) {
@@ -218,6 +173,7 @@ int k_closure(udc_handle *h) {
   dim3 b(64, 4, 1), gr = cell_grid(g, b);
   double *u = h->fields[UDC_U0], *v = h->fields[UDC_V0], *w = h->fields[UDC_W0];
   double *ekm = h->fields[UDC_EKM], *ekh = h->fields[UDC_EKH];
+  if (!h->mom_simple && h->p.sgs != UDC_SGS_DNS) return k_closure_lds(h);
   PROF(h, "closure");
   if (h->p.sgs == UDC_SGS_SMAGORINSKY)
     hipLaunchKernelGGL((closure_kernel<1>), gr, b, 0, h->stream, g, tile_grid(g), h->m, h->p, u, v, w, ekm, ekh);

@@ -10,6 +10,7 @@
 // is read directly.  x is periodic: tile column c holds global i = (i0 - 1 + c) mod nx.
 #include "udc_internal.h"
 #include "udc_mom_arith.h"
+#include "udc_closure_arith.h"
 
 namespace {
 
@@ -136,7 +137,110 @@ __global__ __launch_bounds__(NT, MOM_WAVES) void mom_lds_kernel(Geo g, TileGrid 
   }
 }
 
+// -------------------------------------------------------------------------------- closure
+struct LdsAcc {      // neighbour access from the three staged planes (pointers to the tile centre element)
+  const double *um, *uc, *up, *vm, *vc, *vp, *wm, *wc, *wp;
+  __device__ __forceinline__ double u(int di, int dj, int dk) const {
+    return (dk == 0 ? uc : (dk < 0 ? um : up))[dj * LX + di];
+  }
+  __device__ __forceinline__ double v(int di, int dj, int dk) const {
+    return (dk == 0 ? vc : (dk < 0 ? vm : vp))[dj * LX + di];
+  }
+  __device__ __forceinline__ double w(int di, int dj, int dk) const {
+    return (dk == 0 ? wc : (dk < 0 ? wm : wp))[dj * LX + di];
+  }
+};
+
+// Same marching/staging scheme as mom_lds_kernel for u0, v0, w0; writes ekm, ekh.
+template <int SGS>
+__global__ __launch_bounds__(NT) void closure_lds_kernel(Geo g, TileGrid tg, Metrics m, Params pr,
+    const double *__restrict__ gu, const double *__restrict__ gv, const double *__restrict__ gw,
+    double *__restrict__ ekm, double *__restrict__ ekh, int kc) {
+  constexpr int NF = 3;
+  __shared__ double s[3][NF][LN];
+  const unsigned L = blockIdx.x;
+  const int chunk = L / tg.tiles;
+  const unsigned lp = L - (unsigned)chunk * tg.tiles;
+  unsigned tt = lp;
+  if ((tg.tiles & 7) == 0) tt = (lp & 7u) * (tg.tiles >> 3) + (lp >> 3);
+  const int by = tt / tg.gx, bx = tt - by * tg.gx;
+  const int i0 = bx * TX, j0 = by * TY;
+  const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * TX + tx;
+  const int i = i0 + tx, j = j0 + ty;
+  const bool inside = i < g.nx && j < g.ny;
+  const int k0 = chunk * kc;
+  const int k1 = min(k0 + kc, g.nz);
+  const double *fld[3] = {gu, gv, gw};
+  const int ic = i % g.nx;
+  const int jc = min(j, g.ny + HY - 1);
+  const long own_off = (long)ic + (long)g.sy * (jc + HY);
+  int hlx = 0, hly = 0;
+  const bool has_halo = tid < LN - NT;
+  if (has_halo) halo_coords(tid, hlx, hly);
+  int hi = i0 - 1 + hlx;
+  hi %= g.nx; if (hi < 0) hi += g.nx;
+  const int hj = min(j0 - 1 + hly, g.ny + HY - 1);
+  const long halo_off = (long)hi + (long)g.sy * (hj + HY);
+  const int own_l = (ty + 1) * LX + (tx + 1);
+  const int halo_l = hly * LX + hlx;
+  auto load_plane = [&](int k, Stage<NF> &st) {
+    const long pb = g.sz * (long)(k + HZ);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      st.c[f] = fld[f][pb + own_off];
+      st.h[f] = has_halo ? fld[f][pb + halo_off] : 0.0;
+    }
+  };
+  auto commit_plane = [&](int buf, const Stage<NF> &st) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      s[buf][f][own_l] = st.c[f];
+      if (has_halo) s[buf][f][halo_l] = st.h[f];
+    }
+  };
+  Stage<NF> st;
+  load_plane(k0 - 1, st); commit_plane(0, st);
+  load_plane(k0, st);     commit_plane(1, st);
+  load_plane(k0 + 1, st);
+  int bm = 0, bc = 1, bp = 2;
+  for (int k = k0; k < k1; ++k) {
+    commit_plane(bp, st);
+    __syncthreads();
+    if (k + 1 < k1) load_plane(k + 2, st);
+    if (inside) {
+      const int o = own_l;
+      LdsAcc A{s[bm][0] + o, s[bc][0] + o, s[bp][0] + o, s[bm][1] + o, s[bc][1] + o, s[bp][1] + o,
+               s[bm][2] + o, s[bc][2] + o, s[bp][2] + o};
+      double em, eh;
+      closure_arith<SGS>(A, m, pr, k, em, eh);
+      const long c = g.sz * (long)(k + HZ) + own_off;
+      ekm[c] = em;
+      ekh[c] = eh;
+    }
+    __syncthreads();
+    const int t = bm; bm = bc; bc = bp; bp = t;
+  }
+}
+
 }  // namespace
+
+int k_closure_lds(udc_handle *h) {
+  const Geo &g = h->g;
+  const TileGrid tg = tile_grid(g);
+  int kc = 32;
+  while (kc > 4 && (long)tg.tiles * ((g.nz + kc - 1) / kc) < 2048) kc >>= 1;
+  const int chunks = (g.nz + kc - 1) / kc;
+  dim3 b(TX, TY, 1), gr((unsigned)tg.tiles * (unsigned)chunks, 1, 1);
+  double *u = h->fields[UDC_U0], *v = h->fields[UDC_V0], *w = h->fields[UDC_W0];
+  double *ekm = h->fields[UDC_EKM], *ekh = h->fields[UDC_EKH];
+  PROF(h, "closure");
+  if (h->p.sgs == UDC_SGS_SMAGORINSKY)
+    hipLaunchKernelGGL((closure_lds_kernel<1>), gr, b, 0, h->stream, g, tg, h->m, h->p, u, v, w, ekm, ekh, kc);
+  else
+    hipLaunchKernelGGL((closure_lds_kernel<2>), gr, b, 0, h->stream, g, tg, h->m, h->p, u, v, w, ekm, ekh, kc);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
 
 int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces) {
   const Geo &g = h->g;
