@@ -42,7 +42,7 @@ __device__ __forceinline__ void halo_coords(int e, int &lx, int &ly) {
 template <bool ADV, bool DIFF, bool LES, bool FORCES>
 __global__ __launch_bounds__(NT, MOM_WAVES) void mom_lds_kernel(Geo g, TileGrid tg, Metrics m, MomArgs a, double numol, int kc) {
   constexpr int NF = (DIFF && LES) ? 4 : 3;
-  __shared__ double s[3][NF][LN];
+  __shared__ double s[4][NF][LN];     // 4 rotating plane buffers: one barrier per level is enough
 
   // workgroup -> (tile, k-chunk); XCD-aware like tile_decode but with chunks instead of planes
   const unsigned L = blockIdx.x;
@@ -90,18 +90,31 @@ __global__ __launch_bounds__(NT, MOM_WAVES) void mom_lds_kernel(Geo g, TileGrid 
     }
   };
 
-  // prologue: planes k0-1 and k0 into buffers 0 and 1, plane k0+1 into registers
+  // prologue: planes k0-1, k0, k0+1 into buffers 0..2, plane k0+2 into registers
   Stage<NF> st;
   load_plane(k0 - 1, st); commit_plane(0, st);
   load_plane(k0, st);     commit_plane(1, st);
-  load_plane(k0 + 1, st);
-  int bm = 0, bc = 1, bp = 2;      // buffers holding planes k-1, k, k+1
+  load_plane(k0 + 1, st); commit_plane(2, st);
+  if (k0 + 1 < k1) load_plane(k0 + 2, st);
+  int bm = 0, bc = 1, bp = 2, bn = 3;      // buffers holding planes k-1, k, k+1 and the one being filled (k+2)
   const long cell0 = own_off;
 
+  const long xm_off = (long)(i == 0 ? g.nx - 1 : i - 1) - i;
   for (int k = k0; k < k1; ++k) {
-    commit_plane(bp, st);                                  // plane k+1
+    // this level's direct operands (tendencies, pres0) are requested before the barrier so that their
+    // latency overlaps the barrier wait and the LDS traffic
+    const long c = g.sz * (long)(k + HZ) + cell0;
+    double tu = 0., tv = 0., tw = 0., p_c = 0., p_xm = 0., p_ym = 0., p_zm = 0.;
+    if (inside) {
+      tu = a.up[c]; tv = a.vp[c]; tw = a.wp[c];
+      if (ADV) { p_c = a.p[c]; p_xm = a.p[c + xm_off]; p_ym = a.p[c - g.sy]; p_zm = a.p[c - g.sz]; }
+    }
+    // everyone has finished level k-1 (last readers of buffer bn) and committed plane k+1
     __syncthreads();
-    if (k + 1 < k1) load_plane(k + 2, st);                 // prefetch for the next level (in flight during compute)
+    if (k + 1 < k1) {
+      commit_plane(bn, st);                                // plane k+2, read from level k+1 on
+      if (k + 2 < k1) load_plane(k + 3, st);               // in flight while this level is computed
+    }
     if (inside) {
       const double *um_ = s[bm][0], *uc_ = s[bc][0], *up_ = s[bp][0];
       const double *vm_ = s[bm][1], *vc_ = s[bc][1], *vp_ = s[bp][1];
@@ -114,12 +127,7 @@ __global__ __launch_bounds__(NT, MOM_WAVES) void mom_lds_kernel(Geo g, TileGrid 
       q.v_zm = vm_[o]; q.v_zp = vp_[o]; q.v_xm_yp = vc_[o - 1 + LX]; q.v_yp_zm = vm_[o + LX];
       q.w_c = wc_[o]; q.w_xm = wc_[o - 1]; q.w_xp = wc_[o + 1]; q.w_ym = wc_[o - LX]; q.w_yp = wc_[o + LX];
       q.w_zm = wm_[o]; q.w_zp = wp_[o]; q.w_xm_zp = wp_[o - 1]; q.w_ym_zp = wp_[o - LX];
-      const long c = g.sz * (long)(k + HZ) + cell0;
-      if (ADV) {
-        const double *__restrict__ p = a.p;
-        const long xm = c - i + (i == 0 ? g.nx - 1 : i - 1);
-        q.p_c = p[c]; q.p_xm = p[xm]; q.p_ym = p[c - g.sy]; q.p_zm = p[c - g.sz];
-      }
+      if (ADV) { q.p_c = p_c; q.p_xm = p_xm; q.p_ym = p_ym; q.p_zm = p_zm; }
       if (DIFF && LES) {
         const double *em_ = s[bm][NF - 1], *ec_ = s[bc][NF - 1], *ep_ = s[bp][NF - 1];
         q.e_c = ec_[o]; q.e_xm = ec_[o - 1]; q.e_xp = ec_[o + 1]; q.e_ym = ec_[o - LX]; q.e_yp = ec_[o + LX];
@@ -128,12 +136,10 @@ __global__ __launch_bounds__(NT, MOM_WAVES) void mom_lds_kernel(Geo g, TileGrid 
         q.e_ym_zm = em_[o - LX]; q.e_ym_zp = ep_[o - LX]; q.e_xp_ym = ec_[o + 1 - LX];
         q.e_yp_zm = em_[o + LX]; q.e_xp_zm = em_[o + 1];
       }
-      double tu = a.up[c], tv = a.vp[c], tw = a.wp[c];
       mom_arith<ADV, DIFF, LES, FORCES>(q, m, k, numol, tu, tv, tw);
       a.up[c] = tu; a.vp[c] = tv; a.wp[c] = tw;
     }
-    __syncthreads();                                       // everyone done with plane k-1 before it is overwritten
-    const int t = bm; bm = bc; bc = bp; bp = t;
+    const int t = bm; bm = bc; bc = bp; bp = bn; bn = t;
   }
 }
 
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(NT) void closure_lds_kernel(Geo g, TileGrid tg, Met
     const double *__restrict__ gu, const double *__restrict__ gv, const double *__restrict__ gw,
     double *__restrict__ ekm, double *__restrict__ ekh, int kc) {
   constexpr int NF = 3;
-  __shared__ double s[3][NF][LN];
+  __shared__ double s[4][NF][LN];
   const unsigned L = blockIdx.x;
   const int chunk = L / tg.tiles;
   const unsigned lp = L - (unsigned)chunk * tg.tiles;
@@ -201,12 +207,15 @@ __global__ __launch_bounds__(NT) void closure_lds_kernel(Geo g, TileGrid tg, Met
   Stage<NF> st;
   load_plane(k0 - 1, st); commit_plane(0, st);
   load_plane(k0, st);     commit_plane(1, st);
-  load_plane(k0 + 1, st);
-  int bm = 0, bc = 1, bp = 2;
+  load_plane(k0 + 1, st); commit_plane(2, st);
+  if (k0 + 1 < k1) load_plane(k0 + 2, st);
+  int bm = 0, bc = 1, bp = 2, bn = 3;
   for (int k = k0; k < k1; ++k) {
-    commit_plane(bp, st);
     __syncthreads();
-    if (k + 1 < k1) load_plane(k + 2, st);
+    if (k + 1 < k1) {
+      commit_plane(bn, st);
+      if (k + 2 < k1) load_plane(k + 3, st);
+    }
     if (inside) {
       const int o = own_l;
       LdsAcc A{s[bm][0] + o, s[bc][0] + o, s[bp][0] + o, s[bm][1] + o, s[bc][1] + o, s[bp][1] + o,
@@ -217,8 +226,7 @@ __global__ __launch_bounds__(NT) void closure_lds_kernel(Geo g, TileGrid tg, Met
       ekm[c] = em;
       ekh[c] = eh;
     }
-    __syncthreads();
-    const int t = bm; bm = bc; bc = bp; bp = t;
+    const int t = bm; bm = bc; bc = bp; bp = bn; bn = t;
   }
 }
 
