@@ -199,9 +199,12 @@ static int field_ptr(udc_handle *h, int field, double **p) {
   return 0;
 }
 
+static int tend_clean(udc_handle *h);
+
 static int copy3d(udc_handle *h, int field, double *host, const int lb[3], const int ub[3], bool up) {
   double *dev;
   if (field_ptr(h, field, &dev)) return 1;
+  if (field >= UDC_UP && field <= UDC_WP && tend_clean(h)) return 1;
   const Geo &g = h->g;
   const int hnx = ub[0] - lb[0] + 1, hny = ub[1] - lb[1] + 1;
   int i0 = lb[0] > 1 ? lb[0] : 1, i1 = ub[0] < g.nx ? ub[0] : g.nx;
@@ -253,6 +256,17 @@ extern "C" int udc_set_forcing(udc_handle *h, const double *dpdxl, const double 
   return 0;
 }
 
+// The fused substep leaves up,vp,wp unwritten (its next sweep does not read them).  Anything that
+// observes the tendencies through the reference's semantics (zero after tstep_integrate) goes
+// through here first.
+static int tend_clean(udc_handle *h) {
+  if (!h->tend_scratch) return 0;
+  for (int f = UDC_UP; f <= UDC_WP; ++f)
+    HIP_OK(hipMemsetAsync(h->fields[f], 0, sizeof(double) * h->g.n, h->stream));
+  h->tend_scratch = false;
+  return 0;
+}
+
 // ------------------------------------------------------------------------------ call surface
 static int vel_fields(udc_handle *h, int rk3step, int *f) {
   int n = 0;
@@ -264,7 +278,8 @@ static int vel_fields(udc_handle *h, int rk3step, int *f) {
 
 extern "C" int udc_advection(udc_handle *h) {
   HIP_OK(hipSetDevice(h->device));
-  if ((h->mom_simple ? k_momentum(h, true, false, false) : k_momentum_lds(h, true, false, false))) return 1;
+  if (tend_clean(h)) return 1;
+  if ((h->mom_simple ? k_momentum(h, true, false, false) : k_momentum_lds(h, true, false, false, false))) return 1;
   for (int n = 0; n < h->cfg.nsv; ++n)
     if (k_scalar_adv(h, n)) return 1;
   return 0;
@@ -272,10 +287,11 @@ extern "C" int udc_advection(udc_handle *h) {
 
 extern "C" int udc_subgrid(udc_handle *h) {
   HIP_OK(hipSetDevice(h->device));
+  if (tend_clean(h)) return 1;
   if (k_closure(h)) return 1;
   if (k_ek_ghosts(h)) return 1;
   if (k_top_rows_after_closure(h)) return 1;
-  if ((h->mom_simple ? k_momentum(h, false, true, false) : k_momentum_lds(h, false, true, false))) return 1;
+  if ((h->mom_simple ? k_momentum(h, false, true, false) : k_momentum_lds(h, false, true, false, false))) return 1;
   for (int n = 0; n < h->cfg.nsv; ++n)
     if (k_scalar_diff(h, n)) return 1;
   return 0;
@@ -283,11 +299,13 @@ extern "C" int udc_subgrid(udc_handle *h) {
 
 extern "C" int udc_forces(udc_handle *h) {
   HIP_OK(hipSetDevice(h->device));
+  if (tend_clean(h)) return 1;
   return k_forces(h);
 }
 
 extern "C" int udc_poisson(udc_handle *h, int rk3step, double dt) {
   HIP_OK(hipSetDevice(h->device));
+  if (tend_clean(h)) return 1;
   const double rk3coef = rk3step == 0 ? 1. : dt / (4. - (double)rk3step);
   const int fvp[1] = {UDC_VP};
   if (k_halo_y(h, fvp, 1, 1)) return 1;            // pvp(je+1) = pvp(jb): bcpup
@@ -303,6 +321,7 @@ extern "C" int udc_poisson(udc_handle *h, int rk3step, double dt) {
 
 extern "C" int udc_tstep_integrate(udc_handle *h, int rk3step, double dt) {
   HIP_OK(hipSetDevice(h->device));
+  if (tend_clean(h)) return 1;
   return k_integrate(h, rk3step, dt);
 }
 
@@ -345,7 +364,7 @@ extern "C" int udc_substep(udc_handle *h, int rk3step, double dt, int with_force
   // closure first: it only needs u0,v0,w0, and the fused sweep below needs ekm
   if (k_closure(h)) return 1;
   if (k_ek_ghosts(h)) return 1;
-  if ((h->mom_simple ? k_momentum(h, true, true, with_forces != 0) : k_momentum_lds(h, true, true, with_forces != 0))) return 1;
+  if ((h->mom_simple ? k_momentum(h, true, true, with_forces != 0) : k_momentum_lds(h, true, true, with_forces != 0, true))) return 1;
   for (int n = 0; n < h->cfg.nsv; ++n) {
     if (k_scalar_adv(h, n)) return 1;
     if (k_scalar_diff(h, n)) return 1;
@@ -356,7 +375,8 @@ extern "C" int udc_substep(udc_handle *h, int rk3step, double dt, int with_force
   if (k_poisson_solve(h)) return 1;
   const int fp[1] = {UDC_P};
   if (k_halo_y(h, fp, 1, 1)) return 1;
-  if (k_project_integrate(h, rk3step, dt)) return 1;
+  if (k_project_integrate(h, rk3step, dt, h->mom_simple)) return 1;
+  h->tend_scratch = !h->mom_simple;
   int f[8];
   int nf = vel_fields(h, rk3step, f);
   f[nf++] = UDC_PRES0;

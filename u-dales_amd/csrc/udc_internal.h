@@ -92,7 +92,7 @@ struct udc_handle {
   double *dtab = nullptr;               // Thomas d(kx,ky,k) table
   double *ev = nullptr;                 // eigenvalue xrt(kx)+yrt(ky)
   double *tri = nullptr;                // a,b,c (3*(nz+2))
-  int nkx = 0;
+  int nkx = 0, nkxp = 0;                // r2c modes in x and the padded row pitch of `spec`
   double btopD = 0.;                    // Dirichlet top coefficient of the singular mode
   rocfft_plan plan_fwd = nullptr, plan_bwd = nullptr;
   rocfft_execution_info info_fwd = nullptr, info_bwd = nullptr;
@@ -103,6 +103,7 @@ struct udc_handle {
   double *red = nullptr;                // small device scratch
   double *red_host = nullptr;           // pinned
   // profiling
+  bool tend_scratch = false;            // up,vp,wp hold leftovers of a fused substep (logically zero)
   bool mom_simple = false;              // UDC_MOM_SIMPLE=1: use the direct-load momentum kernel
   bool prof = false;
   std::vector<ProfEntry> prof_events;
@@ -160,7 +161,7 @@ int k_closure(udc_handle *h);
 int k_closure_lds(udc_handle *h);
 int k_ek_ghosts(udc_handle *h);
 int k_momentum(udc_handle *h, bool adv, bool diff, bool forces);       // direct-load version (UDC_MOM_SIMPLE=1)
-int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces);   // LDS-staged k-marching version (default)
+int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh);   // LDS-staged k-marching version (default)
 int k_scalar_adv(udc_handle *h, int n);
 int k_scalar_diff(udc_handle *h, int n);
 int k_forces(udc_handle *h);
@@ -168,7 +169,7 @@ int k_divergence_rhs(udc_handle *h, double rk3coef);
 int k_poisson_solve(udc_handle *h);
 int k_project(udc_handle *h);                       // tderive: up,vp,wp -= grad p ; pres0 += p
 int k_integrate(udc_handle *h, int rk3step, double dt);
-int k_project_integrate(udc_handle *h, int rk3step, double dt);   // fused tderive + tstep_integrate
+int k_project_integrate(udc_handle *h, int rk3step, double dt, bool zero_tend);   // fused tderive + tstep_integrate
 int k_halo_y(udc_handle *h, const int *fields, int nf, int width);
 int k_top_bottom(udc_handle *h);
 int k_top_rows_after_closure(udc_handle *h);

@@ -39,7 +39,8 @@ __device__ __forceinline__ void halo_coords(int e, int &lx, int &ly) {
   else { const int r = e - 2 * LX; ly = 1 + (r >> 1); lx = (r & 1) ? LX - 1 : 0; }
 }
 
-template <bool ADV, bool DIFF, bool LES, bool FORCES>
+// FRESH: the tendencies are known to be zero on entry (fused substep) -> not read at all.
+template <bool ADV, bool DIFF, bool LES, bool FORCES, bool FRESH>
 __global__ __launch_bounds__(NT, MOM_WAVES) void mom_lds_kernel(Geo g, TileGrid tg, Metrics m, MomArgs a, double numol, int kc) {
   constexpr int NF = (DIFF && LES) ? 4 : 3;
   __shared__ double s[4][NF][LN];     // 4 rotating plane buffers: one barrier per level is enough
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(NT, MOM_WAVES) void mom_lds_kernel(Geo g, TileGrid 
     const long c = g.sz * (long)(k + HZ) + cell0;
     double tu = 0., tv = 0., tw = 0., p_c = 0., p_xm = 0., p_ym = 0., p_zm = 0.;
     if (inside) {
-      tu = a.up[c]; tv = a.vp[c]; tw = a.wp[c];
+      if (!FRESH) { tu = a.up[c]; tv = a.vp[c]; tw = a.wp[c]; }
       if (ADV) { p_c = a.p[c]; p_xm = a.p[c + xm_off]; p_ym = a.p[c - g.sy]; p_zm = a.p[c - g.sz]; }
     }
     // everyone has finished level k-1 (last readers of buffer bn) and committed plane k+1
@@ -250,7 +251,7 @@ int k_closure_lds(udc_handle *h) {
   return 0;
 }
 
-int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces) {
+int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh) {
   const Geo &g = h->g;
   MomArgs a{h->fields[UDC_U0], h->fields[UDC_V0], h->fields[UDC_W0], h->fields[UDC_PRES0],
             h->fields[UDC_EKM], h->fields[UDC_UP], h->fields[UDC_VP], h->fields[UDC_WP]};
@@ -265,7 +266,8 @@ int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces) {
 #define LAUNCH(A, D, L, F)                                                                         \
   do {                                                                                             \
     PROF(h, "mom_" #A #D #L #F);                                                                   \
-    hipLaunchKernelGGL((mom_lds_kernel<A, D, L, F>), gr, b, 0, h->stream, g, tg, h->m, a, nu, kc); \
+    if (fresh) hipLaunchKernelGGL((mom_lds_kernel<A, D, L, F, true>), gr, b, 0, h->stream, g, tg, h->m, a, nu, kc);  \
+    else hipLaunchKernelGGL((mom_lds_kernel<A, D, L, F, false>), gr, b, 0, h->stream, g, tg, h->m, a, nu, kc);       \
   } while (0)
   if (adv && diff) {
     if (les) { if (forces) LAUNCH(true, true, true, true); else LAUNCH(true, true, true, false); }

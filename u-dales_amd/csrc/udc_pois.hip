@@ -12,6 +12,7 @@
 // per direction (:490,534,623,677) collapse into one factor 1/(nx*ny).
 #include "udc_internal.h"
 #include <cmath>
+#include <cstdlib>
 
 namespace {
 
@@ -253,7 +254,9 @@ struct IntArgs {
 };
 
 // tstep_integrate, src/modtstep.f90:219-230,322-338; PROJECT fuses tderive in front of it.
-template <bool PROJECT>
+// ZERO: write zeros to the tendencies as the reference does; the fused substep skips that (its next
+// momentum sweep does not read them).
+template <bool PROJECT, bool ZERO>
 __global__ __launch_bounds__(256) void integrate_kernel(Geo g, TileGrid tg, Metrics m, IntArgs a, const double *__restrict__ p,
                                                          double *__restrict__ pres0, double rk3coef, int last) {
   int i, j, k;
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(256) void integrate_kernel(Geo g, TileGrid tg, Metr
   const double v = a.vm[c] + rk3coef * tv;
   const double w = a.wm[c] + rk3coef * tw;
   a.u0[c] = u; a.v0[c] = v; a.w0[c] = w;
-  a.up[c] = 0.; a.vp[c] = 0.; a.wp[c] = 0.;
+  if (ZERO) { a.up[c] = 0.; a.vp[c] = 0.; a.wp[c] = 0.; }
   if (last) { a.um[c] = u; a.vm[c] = v; a.wm[c] = w; }
   for (int s = 0; s < a.nsv; ++s) {
     const double sv = a.svm[s][c] + rk3coef * a.svp[s][c];
@@ -345,11 +348,17 @@ int pois_init(udc_handle *h) {
   const int nx = g.nx, ny = g.ny, nz = g.nz;
   const int nkx = nx / 2 + 1;
   h->nkx = nkx;
-  const long nmodes = (long)nkx * ny;
+  // row pitch of the spectral array (complex elements): nkx = nx/2+1 is odd; padding it lets
+  // rocFFT's strided y pass and the Thomas sweep run on aligned rows.  Padding modes hold zeros.
+  int pad = (8 - nkx % 8) % 8;
+  if (getenv("UDC_SPEC_PAD")) pad = atoi(getenv("UDC_SPEC_PAD"));
+  const int nkxp = nkx + pad;
+  h->nkxp = nkxp;
+  const long nmodes = (long)nkxp * ny;
   const double pi = 3.141592653589793116;   // src/modglobal.f90:270
   const double dxi = h->m.dxi, dyi = h->m.dyi;
   // eigenvalues, src/modpois.f90:100-107,124-131 (value of complex mode kx = slot 2kx)
-  std::vector<double> xrt(nkx), yrt(ny), ev(nmodes);
+  std::vector<double> xrt(nkx), yrt(ny), ev(nmodes, -1.0);
   {
     const double fac = 1. / (2. * nx);
     for (int kx = 1; kx < nx / 2; ++kx) { double s = sin((double)(2 * kx) * pi * fac); xrt[kx] = -4. * dxi * dxi * (s * s); }
@@ -365,7 +374,7 @@ int pois_init(udc_handle *h) {
     }
   }
   for (int ky = 0; ky < ny; ++ky)
-    for (int kx = 0; kx < nkx; ++kx) ev[(long)ky * nkx + kx] = 1. * (xrt[kx] + yrt[ky] + 0.);
+    for (int kx = 0; kx < nkx; ++kx) ev[(long)ky * nkxp + kx] = 1. * (xrt[kx] + yrt[ky] + 0.);
   // tridiagonal coefficients, :154-176 (rhobf = rhobh = 1)
   std::vector<double> tri(3 * (nz + 2), 0.0);
   double *a = &tri[0], *b = &tri[nz + 2], *c = &tri[2 * (nz + 2)];
@@ -382,6 +391,7 @@ int pois_init(udc_handle *h) {
   h->btopD = b_top_D;
 
   HIP_OK(hipMalloc(&h->spec, sizeof(double) * 2 * nmodes * nz));
+  HIP_OK(hipMemsetAsync(h->spec, 0, sizeof(double) * 2 * nmodes * nz, h->stream));
   HIP_OK(hipMalloc(&h->dtab, sizeof(double) * nmodes * (nz > 1 ? nz - 1 : 1)));
   HIP_OK(hipMalloc(&h->ev, sizeof(double) * nmodes));
   HIP_OK(hipMalloc(&h->tri, sizeof(double) * tri.size()));
@@ -395,7 +405,7 @@ int pois_init(udc_handle *h) {
   static bool setup_done = false;
   if (!setup_done) { FFT_OK(rocfft_setup()); setup_done = true; }
   size_t lengths[2] = {(size_t)nx, (size_t)ny};
-  size_t cstr[2] = {1, (size_t)nkx};
+  size_t cstr[2] = {1, (size_t)nkxp};
   size_t off[1] = {0};
   // rocFFT (ROCm 7.2) refuses some padded real layouts (e.g. 8x8, 16x16 inverse): fall back to a
   // compact real staging buffer + one strided copy for those sizes only.
@@ -635,7 +645,7 @@ int k_divergence_rhs(udc_handle *h, double rk3coef) {
 int k_poisson_solve(udc_handle *h) {
   if (h->slab) return k_poisson_solve_slab(h);
   const Geo &g = h->g;
-  const long nmodes = (long)h->nkx * g.ny;
+  const long nmodes = (long)h->nkxp * g.ny;
   double *pin = h->fields[UDC_P] + g.idx(0, 0, 0);
   dim3 b(64, 4, 1), gr = cell_grid(g, b);
   if (h->fwd_compact) {
@@ -696,19 +706,23 @@ int k_integrate(udc_handle *h, int rk3step, double dt) {
   dim3 b(64, 4, 1), gr = cell_grid(g, b);
   const double rk3coef = dt / (4. - (double)rk3step);
   PROF(h, "integrate");
-  hipLaunchKernelGGL((integrate_kernel<false>), gr, b, 0, h->stream, g, tile_grid(g), h->m, int_args(h),
+  hipLaunchKernelGGL((integrate_kernel<false, true>), gr, b, 0, h->stream, g, tile_grid(g), h->m, int_args(h),
                      (const double *)nullptr, (double *)nullptr, rk3coef, rk3step == 3 ? 1 : 0);
   HIP_OK(hipGetLastError());
   return 0;
 }
 
-int k_project_integrate(udc_handle *h, int rk3step, double dt) {
+int k_project_integrate(udc_handle *h, int rk3step, double dt, bool zero_tend) {
   const Geo &g = h->g;
   dim3 b(64, 4, 1), gr = cell_grid(g, b);
   const double rk3coef = dt / (4. - (double)rk3step);
   PROF(h, "project_integrate");
-  hipLaunchKernelGGL((integrate_kernel<true>), gr, b, 0, h->stream, g, tile_grid(g), h->m, int_args(h),
-                     (const double *)h->fields[UDC_P], h->fields[UDC_PRES0], rk3coef, rk3step == 3 ? 1 : 0);
+  if (zero_tend)
+    hipLaunchKernelGGL((integrate_kernel<true, true>), gr, b, 0, h->stream, g, tile_grid(g), h->m, int_args(h),
+                       (const double *)h->fields[UDC_P], h->fields[UDC_PRES0], rk3coef, rk3step == 3 ? 1 : 0);
+  else
+    hipLaunchKernelGGL((integrate_kernel<true, false>), gr, b, 0, h->stream, g, tile_grid(g), h->m, int_args(h),
+                       (const double *)h->fields[UDC_P], h->fields[UDC_PRES0], rk3coef, rk3step == 3 ? 1 : 0);
   HIP_OK(hipGetLastError());
   return 0;
 }
