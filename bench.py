@@ -43,7 +43,7 @@ def algo_bytes(name):
     return None
 
 
-def write_deck(d, iexp, nx, ny, nz, nsub, dt=0.25, nprocy=1):
+def write_deck(d, iexp, nx, ny, nz, nsub, dt=0.25, nprocy=1, nsv=0, sgs="vreman"):
     with open(os.path.join(d, f"namoptions.{iexp:03d}"), "w") as f:
         f.write(f"""&RUN
 iexpnr = {iexp}
@@ -71,10 +71,10 @@ ipoiss = 0
 &BC
 /
 &SCALARS
-nsv = 0
+nsv = {nsv}
 /
 &NAMSUBGRID
-lvreman = .true.
+{'lvreman = .true.' if sgs == 'vreman' else 'lsmagorinsky = .true.' + chr(10) + 'lvreman = .false.'}
 /
 &ORACLE
 nsub = {nsub}
@@ -121,6 +121,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--size", type=str, default="", help="override grid, e.g. 256x256x256")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--nsv", type=int, default=0, help="passive scalars (kappa scheme), BASELINE configs[2]")
+    ap.add_argument("--sgs", type=str, default="vreman", choices=["vreman", "smag"])
     args = ap.parse_args()
 
     import numpy as np
@@ -148,7 +150,7 @@ def main():
         nx, ny, nz = 256, 256 * world, 256      # weak scaling: one 256^3 slab of the channel per GPU
     dt = 0.25
     with tempfile.TemporaryDirectory() as tmp:
-        deck = read_deck(write_deck(tmp, 901, nx, ny, nz, 0, dt=dt, nprocy=world))
+        deck = read_deck(write_deck(tmp, 901, nx, ny, nz, 0, dt=dt, nprocy=world, nsv=args.nsv, sgs=args.sgs))
     core = udcore.from_deck(deck, device=local_rank, rank=rank, nranks=world)
     if world > 1:
         idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
@@ -161,7 +163,7 @@ def main():
         core.comm_init(bytes(idt.cpu().tolist()))
     g = core.g
     nyl = ny // world
-    st = cold_start(g, deck, j0=rank * nyl, nyl=nyl)
+    st = cold_start(g, deck, j0=rank * nyl, nyl=nyl, nsv=args.nsv)
     core.load_state(st)
     core.halos()
     core.boundary()

@@ -365,10 +365,8 @@ extern "C" int udc_substep(udc_handle *h, int rk3step, double dt, int with_force
   if (k_closure(h)) return 1;
   if (k_ek_ghosts(h)) return 1;
   if ((h->mom_simple ? k_momentum(h, true, true, with_forces != 0) : k_momentum_lds(h, true, true, with_forces != 0, true))) return 1;
-  for (int n = 0; n < h->cfg.nsv; ++n) {
-    if (k_scalar_adv(h, n)) return 1;
-    if (k_scalar_diff(h, n)) return 1;
-  }
+  for (int n = 0; n < h->cfg.nsv; ++n)
+    if (k_scalar_fused(h, n)) return 1;
   const int fvp[1] = {UDC_VP};
   if (k_halo_y(h, fvp, 1, 1)) return 1;
   if (k_divergence_rhs(h, rk3coef)) return 1;

@@ -129,10 +129,14 @@ int comm_alltoall(udc_handle *h, const double *send, double *recv, size_t block)
   if (need_comm(h)) return 1;
   if (h->nccl) {
     ncclComm_t c = (ncclComm_t)h->nccl;
+    // own block: plain device copy; the other P-1 blocks use every xGMI link at once
+    HIP_OK(hipMemcpyAsync(recv + (size_t)r * block, send + (size_t)r * block, block * sizeof(double),
+                          hipMemcpyDeviceToDevice, h->stream));
     NCCL_OK(ncclGroupStart());
-    for (int d = 0; d < P; ++d) {
-      NCCL_OK(ncclSend(send + (size_t)d * block, block, ncclDouble, d, c, h->stream));
-      NCCL_OK(ncclRecv(recv + (size_t)d * block, block, ncclDouble, d, c, h->stream));
+    for (int q = 1; q < P; ++q) {
+      const int to = (r + q) % P, from = (r + P - q) % P;     // staggered so that pairs differ per step
+      NCCL_OK(ncclSend(send + (size_t)to * block, block, ncclDouble, to, c, h->stream));
+      NCCL_OK(ncclRecv(recv + (size_t)from * block, block, ncclDouble, from, c, h->stream));
     }
     NCCL_OK(ncclGroupEnd());
     return 0;

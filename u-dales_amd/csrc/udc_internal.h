@@ -164,6 +164,7 @@ int k_momentum(udc_handle *h, bool adv, bool diff, bool forces);       // direct
 int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh);   // LDS-staged k-marching version (default)
 int k_scalar_adv(udc_handle *h, int n);
 int k_scalar_diff(udc_handle *h, int n);
+int k_scalar_fused(udc_handle *h, int n);          // advection + diffusion in one sweep (same accumulation order)
 int k_forces(udc_handle *h);
 int k_divergence_rhs(udc_handle *h, double rk3coef);
 int k_poisson_solve(udc_handle *h);

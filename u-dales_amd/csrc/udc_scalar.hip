@@ -124,3 +124,4 @@ static int launch_scalar(udc_handle *h, int n, bool adv, bool diff) {
 
 int k_scalar_adv(udc_handle *h, int n) { return launch_scalar(h, n, true, false); }
 int k_scalar_diff(udc_handle *h, int n) { return launch_scalar(h, n, false, true); }
+int k_scalar_fused(udc_handle *h, int n) { return launch_scalar(h, n, true, true); }
