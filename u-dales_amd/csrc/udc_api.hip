@@ -111,6 +111,7 @@ extern "C" int udc_create(const udc_config *cfg, udc_handle **out) {
   g.nx = cfg->itot; g.ny = cfg->jtot / cfg->nranks; g.nz = cfg->ktot;
   h->jtot = cfg->jtot;
   h->mom_simple = getenv("UDC_MOM_SIMPLE") && atoi(getenv("UDC_MOM_SIMPLE")) != 0;
+  h->no_pup = getenv("UDC_NO_PUP") && atoi(getenv("UDC_NO_PUP")) != 0;
   h->slab = cfg->nranks > 1 || (getenv("UDC_FORCE_SLAB") && atoi(getenv("UDC_FORCE_SLAB")) != 0);
   g.py = g.ny + 2 * HY; g.pz = g.nz + 2 * HZ;
   g.sy = g.nx; g.sz = (long)g.nx * g.py; g.n = g.sz * g.pz;
@@ -279,7 +280,7 @@ static int vel_fields(udc_handle *h, int rk3step, int *f) {
 extern "C" int udc_advection(udc_handle *h) {
   HIP_OK(hipSetDevice(h->device));
   if (tend_clean(h)) return 1;
-  if ((h->mom_simple ? k_momentum(h, true, false, false) : k_momentum_lds(h, true, false, false, false))) return 1;
+  if ((h->mom_simple ? k_momentum(h, true, false, false) : k_momentum_lds(h, true, false, false, false, 0.))) return 1;
   for (int n = 0; n < h->cfg.nsv; ++n)
     if (k_scalar_adv(h, n)) return 1;
   return 0;
@@ -291,7 +292,7 @@ extern "C" int udc_subgrid(udc_handle *h) {
   if (k_closure(h)) return 1;
   if (k_ek_ghosts(h)) return 1;
   if (k_top_rows_after_closure(h)) return 1;
-  if ((h->mom_simple ? k_momentum(h, false, true, false) : k_momentum_lds(h, false, true, false, false))) return 1;
+  if ((h->mom_simple ? k_momentum(h, false, true, false) : k_momentum_lds(h, false, true, false, false, 0.))) return 1;
   for (int n = 0; n < h->cfg.nsv; ++n)
     if (k_scalar_diff(h, n)) return 1;
   return 0;
@@ -309,7 +310,7 @@ extern "C" int udc_poisson(udc_handle *h, int rk3step, double dt) {
   const double rk3coef = rk3step == 0 ? 1. : dt / (4. - (double)rk3step);
   const int fvp[1] = {UDC_VP};
   if (k_halo_y(h, fvp, 1, 1)) return 1;            // pvp(je+1) = pvp(jb): bcpup
-  if (k_divergence_rhs(h, rk3coef)) return 1;       // fillps
+  if (k_divergence_rhs(h, rk3coef, false)) return 1;       // fillps
   if (k_poisson_solve(h)) return 1;
   const int fp[1] = {UDC_P};
   if (k_halo_y(h, fp, 1, 1)) return 1;              // bcp
@@ -361,19 +362,20 @@ extern "C" int udc_divergence(udc_handle *h, double *divmax, double *divtot) {
 extern "C" int udc_substep(udc_handle *h, int rk3step, double dt, int with_forces) {
   HIP_OK(hipSetDevice(h->device));
   const double rk3coef = dt / (4. - (double)rk3step);
+  const bool pup = !h->mom_simple && !h->no_pup;
   // closure first: it only needs u0,v0,w0, and the fused sweep below needs ekm
   if (k_closure(h)) return 1;
   if (k_ek_ghosts(h)) return 1;
-  if ((h->mom_simple ? k_momentum(h, true, true, with_forces != 0) : k_momentum_lds(h, true, true, with_forces != 0, true))) return 1;
+  if ((h->mom_simple ? k_momentum(h, true, true, with_forces != 0) : k_momentum_lds(h, true, true, with_forces != 0, true, pup ? 1. / rk3coef : 0.))) return 1;
   for (int n = 0; n < h->cfg.nsv; ++n)
     if (k_scalar_fused(h, n)) return 1;
   const int fvp[1] = {UDC_VP};
   if (k_halo_y(h, fvp, 1, 1)) return 1;
-  if (k_divergence_rhs(h, rk3coef)) return 1;
+  if (k_divergence_rhs(h, rk3coef, pup)) return 1;
   if (k_poisson_solve(h)) return 1;
   const int fp[1] = {UDC_P};
   if (k_halo_y(h, fp, 1, 1)) return 1;
-  if (k_project_integrate(h, rk3step, dt, h->mom_simple)) return 1;
+  if (k_project_integrate(h, rk3step, dt, h->mom_simple, pup)) return 1;
   h->tend_scratch = !h->mom_simple;
   int f[8];
   int nf = vel_fields(h, rk3step, f);

@@ -23,6 +23,8 @@ constexpr int NT = TX * TY;                               // 256 threads
 struct MomArgs {
   const double *u, *v, *w, *p, *ek;
   double *up, *vp, *wp;
+  const double *um, *vm, *wm;   // only read in PUP mode
+  double rk3coefi;
 };
 
 template <int NF>
@@ -40,7 +42,10 @@ __device__ __forceinline__ void halo_coords(int e, int &lx, int &ly) {
 }
 
 // FRESH: the tendencies are known to be zero on entry (fused substep) -> not read at all.
-template <bool ADV, bool DIFF, bool LES, bool FORCES, bool FRESH>
+// PUP:   store the predicted velocity pup = up + um/rk3coef (fillps, src/modpois.f90:942-944, with
+//        pwp(kb) = 0 of bcpup) instead of the bare tendency, so that the divergence and the projection
+//        read 3 arrays instead of 6 (um,vm,wm are read here once instead of twice downstream).
+template <bool ADV, bool DIFF, bool LES, bool FORCES, bool FRESH, bool PUP>
 __global__ __launch_bounds__(NT, MOM_WAVES) void mom_lds_kernel(Geo g, TileGrid tg, Metrics m, MomArgs a, double numol, int kc) {
   constexpr int NF = (DIFF && LES) ? 4 : 3;
   __shared__ double s[4][NF][LN];     // 4 rotating plane buffers: one barrier per level is enough
@@ -105,9 +110,10 @@ __global__ __launch_bounds__(NT, MOM_WAVES) void mom_lds_kernel(Geo g, TileGrid 
     // this level's direct operands (tendencies, pres0) are requested before the barrier so that their
     // latency overlaps the barrier wait and the LDS traffic
     const long c = g.sz * (long)(k + HZ) + cell0;
-    double tu = 0., tv = 0., tw = 0., p_c = 0., p_xm = 0., p_ym = 0., p_zm = 0.;
+    double tu = 0., tv = 0., tw = 0., p_c = 0., p_xm = 0., p_ym = 0., p_zm = 0., pum = 0., pvm = 0., pwm = 0.;
     if (inside) {
       if (!FRESH) { tu = a.up[c]; tv = a.vp[c]; tw = a.wp[c]; }
+      if (PUP) { pum = a.um[c]; pvm = a.vm[c]; pwm = a.wm[c]; }
       if (ADV) { p_c = a.p[c]; p_xm = a.p[c + xm_off]; p_ym = a.p[c - g.sy]; p_zm = a.p[c - g.sz]; }
     }
     // everyone has finished level k-1 (last readers of buffer bn) and committed plane k+1
@@ -138,6 +144,11 @@ __global__ __launch_bounds__(NT, MOM_WAVES) void mom_lds_kernel(Geo g, TileGrid 
         q.e_yp_zm = em_[o + LX]; q.e_xp_zm = em_[o + 1];
       }
       mom_arith<ADV, DIFF, LES, FORCES>(q, m, k, numol, tu, tv, tw);
+      if (PUP) {
+        tu = tu + pum * a.rk3coefi;
+        tv = tv + pvm * a.rk3coefi;
+        tw = (k == 0) ? 0. : tw + pwm * a.rk3coefi;
+      }
       a.up[c] = tu; a.vp[c] = tv; a.wp[c] = tw;
     }
     const int t = bm; bm = bc; bc = bp; bp = bn; bn = t;
@@ -251,10 +262,12 @@ int k_closure_lds(udc_handle *h) {
   return 0;
 }
 
-int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh) {
+int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, double rk3coefi) {
+  const bool pup = fresh && rk3coefi != 0.;
   const Geo &g = h->g;
   MomArgs a{h->fields[UDC_U0], h->fields[UDC_V0], h->fields[UDC_W0], h->fields[UDC_PRES0],
-            h->fields[UDC_EKM], h->fields[UDC_UP], h->fields[UDC_VP], h->fields[UDC_WP]};
+            h->fields[UDC_EKM], h->fields[UDC_UP], h->fields[UDC_VP], h->fields[UDC_WP],
+            h->fields[UDC_UM], h->fields[UDC_VM], h->fields[UDC_WM], rk3coefi};
   const TileGrid tg = tile_grid(g);
   // k-chunk: long enough to amortise the 2-plane prologue, short enough to fill 256 CUs x 4 workgroups
   int kc = 32;
@@ -266,8 +279,9 @@ int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh) 
 #define LAUNCH(A, D, L, F)                                                                         \
   do {                                                                                             \
     PROF(h, "mom_" #A #D #L #F);                                                                   \
-    if (fresh) hipLaunchKernelGGL((mom_lds_kernel<A, D, L, F, true>), gr, b, 0, h->stream, g, tg, h->m, a, nu, kc);  \
-    else hipLaunchKernelGGL((mom_lds_kernel<A, D, L, F, false>), gr, b, 0, h->stream, g, tg, h->m, a, nu, kc);       \
+    if (pup) hipLaunchKernelGGL((mom_lds_kernel<A, D, L, F, true, true>), gr, b, 0, h->stream, g, tg, h->m, a, nu, kc);         \
+    else if (fresh) hipLaunchKernelGGL((mom_lds_kernel<A, D, L, F, true, false>), gr, b, 0, h->stream, g, tg, h->m, a, nu, kc);  \
+    else hipLaunchKernelGGL((mom_lds_kernel<A, D, L, F, false, false>), gr, b, 0, h->stream, g, tg, h->m, a, nu, kc);            \
   } while (0)
   if (adv && diff) {
     if (les) { if (forces) LAUNCH(true, true, true, true); else LAUNCH(true, true, true, false); }

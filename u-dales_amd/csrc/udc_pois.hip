@@ -27,6 +27,7 @@ inline dim3 cell_grid(const Geo &g, dim3 b) {
 // fillps + bcpup, src/modpois.f90:939-973, src/modboundary.f90:1227-1255,1309-1315:
 // p = d(pup)/dx + d(pvp)/dy + d(pwp)/dz with pup = up + um/rk3coef (not materialised),
 // pwp(kb) = pwp(ke+1) = 0, x cyclic by index wrap, y cyclic through the vp/vm ghost row.
+template <bool PUP>
 __global__ __launch_bounds__(256) void div_rhs_kernel(Geo g, TileGrid tg, Metrics m, double r,
     const double *__restrict__ up, const double *__restrict__ vp, const double *__restrict__ wp,
     const double *__restrict__ um, const double *__restrict__ vm, const double *__restrict__ wm,
@@ -36,10 +37,18 @@ __global__ __launch_bounds__(256) void div_rhs_kernel(Geo g, TileGrid tg, Metric
   if (!inside_) return;
   const long r0 = g.idx(0, j, k);
   const long c = r0 + i, xp = r0 + wrapp(i, g.nx);
-  const double pu_c = up[c] + um[c] * r, pu_p = up[xp] + um[xp] * r;
-  const double pv_c = vp[c] + vm[c] * r, pv_p = vp[c + g.sy] + vm[c + g.sy] * r;
-  const double pw_c = (k == 0) ? 0. : wp[c] + wm[c] * r;
-  const double pw_p = (k == g.nz - 1) ? 0. : wp[c + g.sz] + wm[c + g.sz] * r;
+  double pu_c, pu_p, pv_c, pv_p, pw_c, pw_p;
+  if (PUP) {   // up,vp,wp already hold pup,pvp,pwp (momentum sweep in PUP mode)
+    pu_c = up[c]; pu_p = up[xp];
+    pv_c = vp[c]; pv_p = vp[c + g.sy];
+    pw_c = wp[c];
+    pw_p = (k == g.nz - 1) ? 0. : wp[c + g.sz];
+  } else {
+    pu_c = up[c] + um[c] * r; pu_p = up[xp] + um[xp] * r;
+    pv_c = vp[c] + vm[c] * r; pv_p = vp[c + g.sy] + vm[c + g.sy] * r;
+    pw_c = (k == 0) ? 0. : wp[c] + wm[c] * r;
+    pw_p = (k == g.nz - 1) ? 0. : wp[c + g.sz] + wm[c + g.sz] * r;
+  }
   p[c] = (pu_p - pu_c) * m.dxi + (pv_p - pv_c) * m.dyi + (pw_p - pw_c) * m.dzfi[k + 1];
 }
 
@@ -256,7 +265,9 @@ struct IntArgs {
 // tstep_integrate, src/modtstep.f90:219-230,322-338; PROJECT fuses tderive in front of it.
 // ZERO: write zeros to the tendencies as the reference does; the fused substep skips that (its next
 // momentum sweep does not read them).
-template <bool PROJECT, bool ZERO>
+// PUP:  up,vp,wp hold pup = up + um/rk3coef, so u0 = rk3coef*(pup - grad p) and um is not read
+//       (algebraically the reference's um + rk3coef*(up - grad p); differs by one rounding of um).
+template <bool PROJECT, bool ZERO, bool PUP>
 __global__ __launch_bounds__(256) void integrate_kernel(Geo g, TileGrid tg, Metrics m, IntArgs a, const double *__restrict__ p,
                                                          double *__restrict__ pres0, double rk3coef, int last) {
   int i, j, k;
@@ -273,9 +284,9 @@ __global__ __launch_bounds__(256) void integrate_kernel(Geo g, TileGrid tg, Metr
     if (k >= 1) tw = tw - (pc - p[c - g.sz]) * m.dzhi[k + 1];
     pres0[c] = pres0[c] + pc;
   }
-  const double u = a.um[c] + rk3coef * tu;
-  const double v = a.vm[c] + rk3coef * tv;
-  const double w = a.wm[c] + rk3coef * tw;
+  double u, v, w;
+  if (PUP) { u = rk3coef * tu; v = rk3coef * tv; w = rk3coef * tw; }
+  else { u = a.um[c] + rk3coef * tu; v = a.vm[c] + rk3coef * tv; w = a.wm[c] + rk3coef * tw; }
   a.u0[c] = u; a.v0[c] = v; a.w0[c] = w;
   if (ZERO) { a.up[c] = 0.; a.vp[c] = 0.; a.wp[c] = 0.; }
   if (last) { a.um[c] = u; a.vm[c] = v; a.wm[c] = w; }
@@ -631,13 +642,18 @@ void pois_destroy(udc_handle *h) {
   for (auto b : bufs) if (b) hipFree(b);
 }
 
-int k_divergence_rhs(udc_handle *h, double rk3coef) {
+int k_divergence_rhs(udc_handle *h, double rk3coef, bool pup) {
   const Geo &g = h->g;
   dim3 b(64, 4, 1), gr = cell_grid(g, b);
   PROF(h, "div_rhs");
-  hipLaunchKernelGGL(div_rhs_kernel, gr, b, 0, h->stream, g, tile_grid(g), h->m, 1. / rk3coef, h->fields[UDC_UP],
-                     h->fields[UDC_VP], h->fields[UDC_WP], h->fields[UDC_UM], h->fields[UDC_VM],
-                     h->fields[UDC_WM], h->fields[UDC_P]);
+  if (pup)
+    hipLaunchKernelGGL((div_rhs_kernel<true>), gr, b, 0, h->stream, g, tile_grid(g), h->m, 1. / rk3coef,
+                       h->fields[UDC_UP], h->fields[UDC_VP], h->fields[UDC_WP], h->fields[UDC_UM],
+                       h->fields[UDC_VM], h->fields[UDC_WM], h->fields[UDC_P]);
+  else
+    hipLaunchKernelGGL((div_rhs_kernel<false>), gr, b, 0, h->stream, g, tile_grid(g), h->m, 1. / rk3coef,
+                       h->fields[UDC_UP], h->fields[UDC_VP], h->fields[UDC_WP], h->fields[UDC_UM],
+                       h->fields[UDC_VM], h->fields[UDC_WM], h->fields[UDC_P]);
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -706,22 +722,25 @@ int k_integrate(udc_handle *h, int rk3step, double dt) {
   dim3 b(64, 4, 1), gr = cell_grid(g, b);
   const double rk3coef = dt / (4. - (double)rk3step);
   PROF(h, "integrate");
-  hipLaunchKernelGGL((integrate_kernel<false, true>), gr, b, 0, h->stream, g, tile_grid(g), h->m, int_args(h),
+  hipLaunchKernelGGL((integrate_kernel<false, true, false>), gr, b, 0, h->stream, g, tile_grid(g), h->m, int_args(h),
                      (const double *)nullptr, (double *)nullptr, rk3coef, rk3step == 3 ? 1 : 0);
   HIP_OK(hipGetLastError());
   return 0;
 }
 
-int k_project_integrate(udc_handle *h, int rk3step, double dt, bool zero_tend) {
+int k_project_integrate(udc_handle *h, int rk3step, double dt, bool zero_tend, bool pup) {
   const Geo &g = h->g;
   dim3 b(64, 4, 1), gr = cell_grid(g, b);
   const double rk3coef = dt / (4. - (double)rk3step);
   PROF(h, "project_integrate");
-  if (zero_tend)
-    hipLaunchKernelGGL((integrate_kernel<true, true>), gr, b, 0, h->stream, g, tile_grid(g), h->m, int_args(h),
+  if (pup)
+    hipLaunchKernelGGL((integrate_kernel<true, false, true>), gr, b, 0, h->stream, g, tile_grid(g), h->m, int_args(h),
+                       (const double *)h->fields[UDC_P], h->fields[UDC_PRES0], rk3coef, rk3step == 3 ? 1 : 0);
+  else if (zero_tend)
+    hipLaunchKernelGGL((integrate_kernel<true, true, false>), gr, b, 0, h->stream, g, tile_grid(g), h->m, int_args(h),
                        (const double *)h->fields[UDC_P], h->fields[UDC_PRES0], rk3coef, rk3step == 3 ? 1 : 0);
   else
-    hipLaunchKernelGGL((integrate_kernel<true, false>), gr, b, 0, h->stream, g, tile_grid(g), h->m, int_args(h),
+    hipLaunchKernelGGL((integrate_kernel<true, false, false>), gr, b, 0, h->stream, g, tile_grid(g), h->m, int_args(h),
                        (const double *)h->fields[UDC_P], h->fields[UDC_PRES0], rk3coef, rk3step == 3 ? 1 : 0);
   HIP_OK(hipGetLastError());
   return 0;
