@@ -112,6 +112,7 @@ extern "C" int udc_create(const udc_config *cfg, udc_handle **out) {
   h->jtot = cfg->jtot;
   h->mom_simple = getenv("UDC_MOM_SIMPLE") && atoi(getenv("UDC_MOM_SIMPLE")) != 0;
   h->no_pup = getenv("UDC_NO_PUP") && atoi(getenv("UDC_NO_PUP")) != 0;
+  h->no_fold = getenv("UDC_NO_FOLD") && atoi(getenv("UDC_NO_FOLD")) != 0;
   h->slab = cfg->nranks > 1 || (getenv("UDC_FORCE_SLAB") && atoi(getenv("UDC_FORCE_SLAB")) != 0);
   g.py = g.ny + 2 * HY; g.pz = g.nz + 2 * HZ;
   g.sy = g.nx; g.sz = (long)g.nx * g.py; g.n = g.sz * g.pz;
@@ -362,29 +363,44 @@ extern "C" int udc_divergence(udc_handle *h, double *divmax, double *divtot) {
 extern "C" int udc_substep(udc_handle *h, int rk3step, double dt, int with_forces) {
   HIP_OK(hipSetDevice(h->device));
   const double rk3coef = dt / (4. - (double)rk3step);
-  const bool pup = !h->mom_simple && !h->no_pup;
+  const bool lds = !h->mom_simple;
+  const bool pup = lds && !h->no_pup;
+  // single slab (whole y extent local): the ghost-row/plane updates of closurebc, bcpup, bcp, halos and
+  // boundary are written by the kernels that own the neighbouring cells -> 7 fewer launches per substep
+  const bool fold = lds && !h->slab && !h->no_fold;
   // closure first: it only needs u0,v0,w0, and the fused sweep below needs ekm
-  if (k_closure(h)) return 1;
-  if (k_ek_ghosts(h)) return 1;
-  if ((h->mom_simple ? k_momentum(h, true, true, with_forces != 0) : k_momentum_lds(h, true, true, with_forces != 0, true, pup ? 1. / rk3coef : 0.))) return 1;
+  if (fold && h->p.sgs != UDC_SGS_DNS) {
+    if (k_closure_lds(h, true)) return 1;
+  } else {
+    if (k_closure(h)) return 1;
+    if (k_ek_ghosts(h)) return 1;
+  }
+  if (lds ? k_momentum_lds(h, true, true, with_forces != 0, true, pup ? 1. / rk3coef : 0.)
+          : k_momentum(h, true, true, with_forces != 0)) return 1;
   for (int n = 0; n < h->cfg.nsv; ++n)
     if (k_scalar_fused(h, n)) return 1;
-  const int fvp[1] = {UDC_VP};
-  if (k_halo_y(h, fvp, 1, 1)) return 1;
+  if (!fold) {
+    const int fvp[1] = {UDC_VP};
+    if (k_halo_y(h, fvp, 1, 1)) return 1;
+  }
   if (k_divergence_rhs(h, rk3coef, pup)) return 1;
   if (k_poisson_solve(h)) return 1;
-  const int fp[1] = {UDC_P};
-  if (k_halo_y(h, fp, 1, 1)) return 1;
-  if (k_project_integrate(h, rk3step, dt, h->mom_simple, pup)) return 1;
-  h->tend_scratch = !h->mom_simple;
-  int f[8];
-  int nf = vel_fields(h, rk3step, f);
-  f[nf++] = UDC_PRES0;
-  if (k_halo_y(h, f, nf, 1)) return 1;
+  if (!fold) {
+    const int fp[1] = {UDC_P};
+    if (k_halo_y(h, fp, 1, 1)) return 1;
+  }
+  if (k_project_integrate(h, rk3step, dt, !lds, pup, fold)) return 1;
+  h->tend_scratch = lds;
+  if (!fold) {
+    int f[8];
+    int nf = vel_fields(h, rk3step, f);
+    f[nf++] = UDC_PRES0;
+    if (k_halo_y(h, f, nf, 1)) return 1;
+  }
   std::vector<int> s;
   scalar_halo_list(h, rk3step, s);
   if (!s.empty() && k_halo_y(h, s.data(), (int)s.size(), 2)) return 1;
-  if (k_top_bottom(h)) return 1;
+  if (!fold || h->cfg.nsv > 0) { if (k_top_bottom(h)) return 1; }
   return 0;
 }
 

@@ -104,6 +104,7 @@ struct udc_handle {
   double *red_host = nullptr;           // pinned
   // profiling
   bool tend_scratch = false;            // up,vp,wp hold leftovers of a fused substep (logically zero)
+  bool no_fold = false;                 // UDC_NO_FOLD=1: keep separate ghost-row kernels on a single slab (A/B switch)
   bool no_pup = false;                  // UDC_NO_PUP=1: keep bare tendencies in the fused substep (A/B switch)
   bool mom_simple = false;              // UDC_MOM_SIMPLE=1: use the direct-load momentum kernel
   bool prof = false;
@@ -159,7 +160,7 @@ struct ProfScope {
 
 // ---- kernels (udc_mom.hip, udc_pois.hip, udc_scalar.hip, udc_halo.hip)
 int k_closure(udc_handle *h);
-int k_closure_lds(udc_handle *h);
+int k_closure_lds(udc_handle *h, bool ghosts);   // ghosts: closurebc folded in (single slab)
 int k_ek_ghosts(udc_handle *h);
 int k_momentum(udc_handle *h, bool adv, bool diff, bool forces);       // direct-load version (UDC_MOM_SIMPLE=1)
 int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, double rk3coefi);  // rk3coefi != 0: PUP mode   // LDS-staged k-marching version (default)
@@ -171,7 +172,7 @@ int k_divergence_rhs(udc_handle *h, double rk3coef, bool pup);
 int k_poisson_solve(udc_handle *h);
 int k_project(udc_handle *h);                       // tderive: up,vp,wp -= grad p ; pres0 += p
 int k_integrate(udc_handle *h, int rk3step, double dt);
-int k_project_integrate(udc_handle *h, int rk3step, double dt, bool zero_tend, bool pup);   // fused tderive + tstep_integrate
+int k_project_integrate(udc_handle *h, int rk3step, double dt, bool zero_tend, bool pup, bool ghosts);   // fused tderive + tstep_integrate
 int k_halo_y(udc_handle *h, const int *fields, int nf, int width);
 int k_top_bottom(udc_handle *h);
 int k_top_rows_after_closure(udc_handle *h);

@@ -173,7 +173,7 @@ int k_closure(udc_handle *h) {
   dim3 b(64, 4, 1), gr = cell_grid(g, b);
   double *u = h->fields[UDC_U0], *v = h->fields[UDC_V0], *w = h->fields[UDC_W0];
   double *ekm = h->fields[UDC_EKM], *ekh = h->fields[UDC_EKH];
-  if (!h->mom_simple && h->p.sgs != UDC_SGS_DNS) return k_closure_lds(h);
+  if (!h->mom_simple && h->p.sgs != UDC_SGS_DNS) return k_closure_lds(h, false);
   PROF(h, "closure");
   if (h->p.sgs == UDC_SGS_SMAGORINSKY)
     hipLaunchKernelGGL((closure_kernel<1>), gr, b, 0, h->stream, g, tile_grid(g), h->m, h->p, u, v, w, ekm, ekh);

@@ -25,6 +25,7 @@ struct MomArgs {
   double *up, *vp, *wp;
   const double *um, *vm, *wm;   // only read in PUP mode
   double rk3coefi;
+  int wrap_vp;                  // single slab: also store row 0 of vp into ghost row ny (bcpup's cyclic pvp)
 };
 
 template <int NF>
@@ -150,6 +151,7 @@ __global__ __launch_bounds__(NT, MOM_WAVES) void mom_lds_kernel(Geo g, TileGrid 
         tw = (k == 0) ? 0. : tw + pwm * a.rk3coefi;
       }
       a.up[c] = tu; a.vp[c] = tv; a.wp[c] = tw;
+      if (a.wrap_vp && j == 0) a.vp[c + (long)g.sy * g.ny] = tv;
     }
     const int t = bm; bm = bc; bc = bp; bp = bn; bn = t;
   }
@@ -173,7 +175,7 @@ struct LdsAcc {      // neighbour access from the three staged planes (pointers 
 template <int SGS>
 __global__ __launch_bounds__(NT) void closure_lds_kernel(Geo g, TileGrid tg, Metrics m, Params pr,
     const double *__restrict__ gu, const double *__restrict__ gv, const double *__restrict__ gw,
-    double *__restrict__ ekm, double *__restrict__ ekh, int kc) {
+    double *__restrict__ ekm, double *__restrict__ ekh, int kc, int ghosts) {
   constexpr int NF = 3;
   __shared__ double s[4][NF][LN];
   const unsigned L = blockIdx.x;
@@ -237,6 +239,25 @@ __global__ __launch_bounds__(NT) void closure_lds_kernel(Geo g, TileGrid tg, Met
       const long c = g.sz * (long)(k + HZ) + own_off;
       ekm[c] = em;
       ekh[c] = eh;
+      if (ghosts) {
+        // closurebc (src/modboundary.f90:447-500) folded in when the slab is the whole domain in y:
+        // periodic ghost rows and the bottom/top ghost planes are written by the owning thread.
+        const long up_row = (long)g.sy * g.ny, dn_row = -(long)g.sy * g.ny;
+        const long wr = (j == 0) ? up_row : ((j == g.ny - 1) ? dn_row : 0);   // ny >= 4, so at most one
+        if (wr) { ekm[c + wr] = em; ekh[c + wr] = eh; }
+        const double nm = pr.numol, nh = pr.numol * pr.prandtlmoli;
+        if (k == 0) {
+          const double gm = 2. * nm - em, gh = (2. * nh) - eh;
+          ekm[c - g.sz] = gm; ekh[c - g.sz] = gh;
+          if (wr) { ekm[c - g.sz + wr] = gm; ekh[c - g.sz + wr] = gh; }
+        }
+        if (k == g.nz - 1) {
+          const double gm = pr.bctopm == UDC_TOP_NOSLIP ? 2. * nm - em : em;
+          const double gh = pr.bctopm == UDC_TOP_NOSLIP ? (2. * nh) - eh : eh;
+          ekm[c + g.sz] = gm; ekh[c + g.sz] = gh;
+          if (wr) { ekm[c + g.sz + wr] = gm; ekh[c + g.sz + wr] = gh; }
+        }
+      }
     }
     const int t = bm; bm = bc; bc = bp; bp = bn; bn = t;
   }
@@ -244,7 +265,7 @@ __global__ __launch_bounds__(NT) void closure_lds_kernel(Geo g, TileGrid tg, Met
 
 }  // namespace
 
-int k_closure_lds(udc_handle *h) {
+int k_closure_lds(udc_handle *h, bool ghosts) {
   const Geo &g = h->g;
   const TileGrid tg = tile_grid(g);
   int kc = 32;
@@ -255,9 +276,9 @@ int k_closure_lds(udc_handle *h) {
   double *ekm = h->fields[UDC_EKM], *ekh = h->fields[UDC_EKH];
   PROF(h, "closure");
   if (h->p.sgs == UDC_SGS_SMAGORINSKY)
-    hipLaunchKernelGGL((closure_lds_kernel<1>), gr, b, 0, h->stream, g, tg, h->m, h->p, u, v, w, ekm, ekh, kc);
+    hipLaunchKernelGGL((closure_lds_kernel<1>), gr, b, 0, h->stream, g, tg, h->m, h->p, u, v, w, ekm, ekh, kc, ghosts ? 1 : 0);
   else
-    hipLaunchKernelGGL((closure_lds_kernel<2>), gr, b, 0, h->stream, g, tg, h->m, h->p, u, v, w, ekm, ekh, kc);
+    hipLaunchKernelGGL((closure_lds_kernel<2>), gr, b, 0, h->stream, g, tg, h->m, h->p, u, v, w, ekm, ekh, kc, ghosts ? 1 : 0);
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -267,7 +288,7 @@ int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, 
   const Geo &g = h->g;
   MomArgs a{h->fields[UDC_U0], h->fields[UDC_V0], h->fields[UDC_W0], h->fields[UDC_PRES0],
             h->fields[UDC_EKM], h->fields[UDC_UP], h->fields[UDC_VP], h->fields[UDC_WP],
-            h->fields[UDC_UM], h->fields[UDC_VM], h->fields[UDC_WM], rk3coefi};
+            h->fields[UDC_UM], h->fields[UDC_VM], h->fields[UDC_WM], rk3coefi, (fresh && !h->slab) ? 1 : 0};
   const TileGrid tg = tile_grid(g);
   // k-chunk: long enough to amortise the 2-plane prologue, short enough to fill 256 CUs x 4 workgroups
   int kc = 32;

@@ -269,27 +269,54 @@ struct IntArgs {
 //       (algebraically the reference's um + rk3coef*(up - grad p); differs by one rounding of um).
 template <bool PROJECT, bool ZERO, bool PUP>
 __global__ __launch_bounds__(256) void integrate_kernel(Geo g, TileGrid tg, Metrics m, IntArgs a, const double *__restrict__ p,
-                                                         double *__restrict__ pres0, double rk3coef, int last) {
+                                                         double *__restrict__ pres0, double rk3coef, int last,
+                                                         int ghosts, Params pr) {
   int i, j, k;
   const bool inside_ = tile_decode(g, tg, i, j, k);
   if (!inside_) return;
   const long r0 = g.idx(0, j, k);
   const long c = r0 + i;
+  // ghosts != 0 (the slab is the whole domain in y): `halos` and `boundary` (src/modboundary.f90:67-109,
+  // 163-178) are folded in -- p(j-1) wraps by index, and the owning thread also writes the periodic
+  // ghost row and the top ghost plane of what it updates.
+  const long wr = !ghosts ? 0 : ((j == 0) ? (long)g.sy * g.ny : ((j == g.ny - 1) ? -(long)g.sy * g.ny : 0));
   double tu = a.up[c], tv = a.vp[c], tw = a.wp[c];
+  double pr0 = 0.;
   if (PROJECT) {
     const long xm = r0 + wrapm(i, g.nx);
+    const long ym = (ghosts && j == 0) ? c + (long)g.sy * (g.ny - 1) : c - g.sy;
     const double pc = p[c];
     tu = tu - (pc - p[xm]) * m.dxi;
-    tv = tv - (pc - p[c - g.sy]) * m.dyi;
+    tv = tv - (pc - p[ym]) * m.dyi;
     if (k >= 1) tw = tw - (pc - p[c - g.sz]) * m.dzhi[k + 1];
-    pres0[c] = pres0[c] + pc;
+    pr0 = pres0[c] + pc;
+    pres0[c] = pr0;
+    if (wr) pres0[c + wr] = pr0;
   }
   double u, v, w;
   if (PUP) { u = rk3coef * tu; v = rk3coef * tv; w = rk3coef * tw; }
   else { u = a.um[c] + rk3coef * tu; v = a.vm[c] + rk3coef * tv; w = a.wm[c] + rk3coef * tw; }
+  if (ghosts && k == 0) w = 0.;                     // boundary: w(kb) = 0
   a.u0[c] = u; a.v0[c] = v; a.w0[c] = w;
   if (ZERO) { a.up[c] = 0.; a.vp[c] = 0.; a.wp[c] = 0.; }
   if (last) { a.um[c] = u; a.vm[c] = v; a.wm[c] = w; }
+  if (ghosts) {
+    if (wr) {
+      a.u0[c + wr] = u; a.v0[c + wr] = v; a.w0[c + wr] = w;
+      if (last) { a.um[c + wr] = u; a.vm[c + wr] = v; a.wm[c + wr] = w; }
+    }
+    if (k == g.nz - 1) {
+      const bool ns = pr.bctopm == UDC_TOP_NOSLIP;
+      const double ut = ns ? 2 * pr.uinf - u : u, vt = ns ? 2 * pr.vinf - v : v;
+      const long t = c + g.sz;
+      a.u0[t] = ut; a.v0[t] = vt; a.w0[t] = 0.;
+      if (last) { a.um[t] = ut; a.vm[t] = vt; a.wm[t] = 0.; }
+      if (wr) {
+        a.u0[t + wr] = ut; a.v0[t + wr] = vt; a.w0[t + wr] = 0.;
+        if (last) { a.um[t + wr] = ut; a.vm[t + wr] = vt; a.wm[t + wr] = 0.; }
+      }
+    }
+  }
   for (int s = 0; s < a.nsv; ++s) {
     const double sv = a.svm[s][c] + rk3coef * a.svp[s][c];
     a.sv0[s][c] = sv;
@@ -723,25 +750,25 @@ int k_integrate(udc_handle *h, int rk3step, double dt) {
   const double rk3coef = dt / (4. - (double)rk3step);
   PROF(h, "integrate");
   hipLaunchKernelGGL((integrate_kernel<false, true, false>), gr, b, 0, h->stream, g, tile_grid(g), h->m, int_args(h),
-                     (const double *)nullptr, (double *)nullptr, rk3coef, rk3step == 3 ? 1 : 0);
+                     (const double *)nullptr, (double *)nullptr, rk3coef, rk3step == 3 ? 1 : 0, 0, h->p);
   HIP_OK(hipGetLastError());
   return 0;
 }
 
-int k_project_integrate(udc_handle *h, int rk3step, double dt, bool zero_tend, bool pup) {
+int k_project_integrate(udc_handle *h, int rk3step, double dt, bool zero_tend, bool pup, bool ghosts) {
   const Geo &g = h->g;
   dim3 b(64, 4, 1), gr = cell_grid(g, b);
   const double rk3coef = dt / (4. - (double)rk3step);
   PROF(h, "project_integrate");
   if (pup)
     hipLaunchKernelGGL((integrate_kernel<true, false, true>), gr, b, 0, h->stream, g, tile_grid(g), h->m, int_args(h),
-                       (const double *)h->fields[UDC_P], h->fields[UDC_PRES0], rk3coef, rk3step == 3 ? 1 : 0);
+                       (const double *)h->fields[UDC_P], h->fields[UDC_PRES0], rk3coef, rk3step == 3 ? 1 : 0, ghosts ? 1 : 0, h->p);
   else if (zero_tend)
     hipLaunchKernelGGL((integrate_kernel<true, true, false>), gr, b, 0, h->stream, g, tile_grid(g), h->m, int_args(h),
-                       (const double *)h->fields[UDC_P], h->fields[UDC_PRES0], rk3coef, rk3step == 3 ? 1 : 0);
+                       (const double *)h->fields[UDC_P], h->fields[UDC_PRES0], rk3coef, rk3step == 3 ? 1 : 0, ghosts ? 1 : 0, h->p);
   else
     hipLaunchKernelGGL((integrate_kernel<true, false, false>), gr, b, 0, h->stream, g, tile_grid(g), h->m, int_args(h),
-                       (const double *)h->fields[UDC_P], h->fields[UDC_PRES0], rk3coef, rk3step == 3 ? 1 : 0);
+                       (const double *)h->fields[UDC_P], h->fields[UDC_PRES0], rk3coef, rk3step == 3 ? 1 : 0, ghosts ? 1 : 0, h->p);
   HIP_OK(hipGetLastError());
   return 0;
 }
