@@ -96,8 +96,10 @@ def run_virtual(P, g, deck_like, st_global, nsub, dt, sgs, nsv=0):
     return res
 
 
-@pytest.mark.parametrize("shape,sgs", [((32, 16, 12), 2), ((24, 32, 10), 1)])
-def test_decomposition_invariance(shape, sgs):
+@pytest.mark.parametrize("shape,sgs,chunks", [((32, 16, 12), 2, 1), ((24, 32, 10), 1, 2), ((32, 16, 12), 2, 3)])
+def test_decomposition_invariance(shape, sgs, chunks, monkeypatch):
+    # chunks > 1: the k-chunked all-to-all pipeline (exchange on a second stream, overlapped with rocFFT)
+    monkeypatch.setenv("UDC_A2A_CHUNKS", str(chunks))
     from test_gpu_parity import random_state
     from udcore.grid import Grid
     nx, ny, nz = shape

@@ -120,10 +120,10 @@ int comm_neighbours(udc_handle *h, const double *to_prev, const double *to_next,
 }
 
 // all-to-all of equal blocks: block d of `send` goes to rank d, arriving as block r of its `recv`
-int comm_alltoall(udc_handle *h, const double *send, double *recv, size_t block) {
+int comm_alltoall(udc_handle *h, const double *send, double *recv, size_t block, hipStream_t st) {
   const int P = h->cfg.nranks, r = h->cfg.rank;
   if (P == 1) {
-    HIP_OK(hipMemcpyAsync(recv, send, block * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HIP_OK(hipMemcpyAsync(recv, send, block * sizeof(double), hipMemcpyDeviceToDevice, st));
     return 0;
   }
   if (need_comm(h)) return 1;
@@ -131,24 +131,24 @@ int comm_alltoall(udc_handle *h, const double *send, double *recv, size_t block)
     ncclComm_t c = (ncclComm_t)h->nccl;
     // own block: plain device copy; the other P-1 blocks use every xGMI link at once
     HIP_OK(hipMemcpyAsync(recv + (size_t)r * block, send + (size_t)r * block, block * sizeof(double),
-                          hipMemcpyDeviceToDevice, h->stream));
+                          hipMemcpyDeviceToDevice, st));
     NCCL_OK(ncclGroupStart());
     for (int q = 1; q < P; ++q) {
       const int to = (r + q) % P, from = (r + P - q) % P;     // staggered so that pairs differ per step
-      NCCL_OK(ncclSend(send + (size_t)to * block, block, ncclDouble, to, c, h->stream));
-      NCCL_OK(ncclRecv(recv + (size_t)from * block, block, ncclDouble, from, c, h->stream));
+      NCCL_OK(ncclSend(send + (size_t)to * block, block, ncclDouble, to, c, st));
+      NCCL_OK(ncclRecv(recv + (size_t)from * block, block, ncclDouble, from, c, st));
     }
     NCCL_OK(ncclGroupEnd());
     return 0;
   }
   LocalGroup *g = (LocalGroup *)h->local_group;
   g->send[r][2] = send;
-  HIP_OK(hipStreamSynchronize(h->stream));
+  HIP_OK(hipStreamSynchronize(st));
   pthread_barrier_wait(&g->bar);
   for (int s = 0; s < P; ++s)
     HIP_OK(hipMemcpyAsync(recv + (size_t)s * block, g->send[s][2] + (size_t)r * block, block * sizeof(double),
-                          hipMemcpyDeviceToDevice, h->stream));
-  HIP_OK(hipStreamSynchronize(h->stream));
+                          hipMemcpyDeviceToDevice, st));
+  HIP_OK(hipStreamSynchronize(st));
   pthread_barrier_wait(&g->bar);
   return 0;
 }

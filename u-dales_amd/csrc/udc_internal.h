@@ -121,6 +121,9 @@ struct udc_handle {
   size_t halo_cap = 0;
   // slab Poisson: x-spectral rows (all kx, local rows), transposed block (local kx, all rows)
   int cx = 0;                           // kx chunk per rank = ceil(nkx / nranks)
+  int nch = 1;                          // k-chunks of the all-to-all pipeline
+  hipStream_t comm_stream = nullptr;    // all-to-all exchanges run here, overlapped with rocFFT on `stream`
+  hipEvent_t ev_ready[16] = {}, ev_done[16] = {};
   double *specA = nullptr, *specB = nullptr, *a2a_send = nullptr, *a2a_recv = nullptr;
   double *ev_slab = nullptr, *dtab_slab = nullptr;
   rocfft_plan plan_xf = nullptr, plan_xb = nullptr, plan_yf = nullptr, plan_yb = nullptr;
@@ -184,7 +187,7 @@ int k_poisson_solve_slab(udc_handle *h);
 // udc_comm.hip
 int comm_neighbours(udc_handle *h, const double *to_prev, const double *to_next, double *from_prev,
                     double *from_next, size_t count);
-int comm_alltoall(udc_handle *h, const double *send, double *recv, size_t block);
+int comm_alltoall(udc_handle *h, const double *send, double *recv, size_t block, hipStream_t st);
 int comm_allreduce(udc_handle *h, double *buf, int n, int op);
 void comm_destroy(udc_handle *h);
 void pois_destroy(udc_handle *h);

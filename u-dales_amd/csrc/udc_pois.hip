@@ -170,10 +170,12 @@ __global__ __launch_bounds__(256) void real_copy_kernel(Geo g, TileGrid tg, doub
 // pencil scheme does 8 transposes per solve, src/modpois.f90:459-702.)
 
 // specA -> send blocks (transposes kx-fastest rows into j-fastest runs through an LDS tile)
-__global__ __launch_bounds__(256) void slab_pack_fwd_kernel(Geo g, int nkx, int cx, int P,
+// All four kernels work on one k-chunk [k0, k0+nzc): blocks are [d][k-k0][kxl][j] inside the chunk's
+// slice of the send/recv buffers, so that chunks can be exchanged while others are transformed.
+__global__ __launch_bounds__(256) void slab_pack_fwd_kernel(Geo g, int nkx, int cx, int P, int k0, int nzc,
     const double2 *__restrict__ specA, double2 *__restrict__ send) {
   __shared__ double2 tile[16][17];
-  const int k = blockIdx.z;
+  const int kc = blockIdx.z, k = k0 + kc;
   const int kx0 = blockIdx.x * 16, j0 = blockIdx.y * 16;
   const int tx = threadIdx.x, ty = threadIdx.y;
   {
@@ -187,42 +189,42 @@ __global__ __launch_bounds__(256) void slab_pack_fwd_kernel(Geo g, int nkx, int 
     const int kx = kx0 + ty, j = j0 + tx;
     if (kx < cx * P && j < g.ny) {
       const int d = kx / cx, kxl = kx - d * cx;
-      send[(((size_t)d * g.nz + k) * cx + kxl) * g.ny + j] = tile[tx][ty];
+      send[(((size_t)d * nzc + kc) * cx + kxl) * g.ny + j] = tile[tx][ty];
     }
   }
 }
 
 // received blocks -> specB (contiguous runs of ny_local)
-__global__ __launch_bounds__(256) void slab_unpack_fwd_kernel(Geo g, int cx, int P, int jtot,
+__global__ __launch_bounds__(256) void slab_unpack_fwd_kernel(Geo g, int cx, int P, int jtot, int k0, int nzc,
     const double2 *__restrict__ recv, double2 *__restrict__ specB) {
-  const size_t n = (size_t)P * g.nz * cx * g.ny;
+  const size_t n = (size_t)P * nzc * cx * g.ny;
   const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= n) return;
   const int j = q % g.ny;
   size_t t = q / g.ny;
   const int kxl = t % cx; t /= cx;
-  const int k = t % g.nz;
-  const int s = t / g.nz;
-  specB[((size_t)k * cx + kxl) * jtot + (size_t)s * g.ny + j] = recv[q];
+  const int kc = t % nzc;
+  const int s = t / nzc;
+  specB[((size_t)(k0 + kc) * cx + kxl) * jtot + (size_t)s * g.ny + j] = recv[q];
 }
 
-__global__ __launch_bounds__(256) void slab_pack_bwd_kernel(Geo g, int cx, int P, int jtot,
+__global__ __launch_bounds__(256) void slab_pack_bwd_kernel(Geo g, int cx, int P, int jtot, int k0, int nzc,
     const double2 *__restrict__ specB, double2 *__restrict__ send) {
-  const size_t n = (size_t)P * g.nz * cx * g.ny;
+  const size_t n = (size_t)P * nzc * cx * g.ny;
   const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= n) return;
   const int j = q % g.ny;
   size_t t = q / g.ny;
   const int kxl = t % cx; t /= cx;
-  const int k = t % g.nz;
-  const int d = t / g.nz;
-  send[q] = specB[((size_t)k * cx + kxl) * jtot + (size_t)d * g.ny + j];
+  const int kc = t % nzc;
+  const int d = t / nzc;
+  send[q] = specB[((size_t)(k0 + kc) * cx + kxl) * jtot + (size_t)d * g.ny + j];
 }
 
-__global__ __launch_bounds__(256) void slab_unpack_bwd_kernel(Geo g, int nkx, int cx, int P,
+__global__ __launch_bounds__(256) void slab_unpack_bwd_kernel(Geo g, int nkx, int cx, int P, int k0, int nzc,
     const double2 *__restrict__ recv, double2 *__restrict__ specA) {
   __shared__ double2 tile[16][17];
-  const int k = blockIdx.z;
+  const int kc = blockIdx.z, k = k0 + kc;
   const int kx0 = blockIdx.x * 16, j0 = blockIdx.y * 16;
   const int tx = threadIdx.x, ty = threadIdx.y;
   {
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(256) void slab_unpack_bwd_kernel(Geo g, int nkx, in
     double2 v = make_double2(0., 0.);
     if (kx < cx * P && j < g.ny) {
       const int s = kx / cx, kxl = kx - s * cx;
-      v = recv[(((size_t)s * g.nz + k) * cx + kxl) * g.ny + j];
+      v = recv[(((size_t)s * nzc + kc) * cx + kxl) * g.ny + j];
     }
     tile[ty][tx] = v;
   }
@@ -537,6 +539,12 @@ int pois_slab_init(udc_handle *h) {
     for (int y = 0; y < ny; ++y)
       ev[(size_t)kxl * ny + y] = kx < nkx ? 1. * (xrt[kx] + yrt[y] + 0.) : -1.0;   // padding modes carry zeros
   }
+  // k-chunks of the all-to-all pipeline (UDC_A2A_CHUNKS overrides; chunks must divide nz)
+  int nch = (P > 1 && nz % 4 == 0 && nz >= 16) ? 4 : 1;
+  if (getenv("UDC_A2A_CHUNKS")) nch = atoi(getenv("UDC_A2A_CHUNKS"));
+  if (nch < 1 || nch > 16 || nz % nch) nch = 1;
+  h->nch = nch;
+  const int nzc = nz / nch;
   const size_t rows = (size_t)g.py * nz;
   HIP_OK(hipMalloc(&h->specA, sizeof(double) * 2 * nkx * rows));
   HIP_OK(hipMemsetAsync(h->specA, 0, sizeof(double) * 2 * nkx * rows, h->stream));
@@ -561,18 +569,23 @@ int pois_slab_init(udc_handle *h) {
   FFT_OK(rocfft_plan_description_set_data_layout(d, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved,
                                                  off, off, 1, one, (size_t)nx, 1, one, (size_t)nkx));
   FFT_OK(rocfft_plan_create(&h->plan_xf, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
-                            rocfft_precision_double, 1, lx, rows, d));
+                            rocfft_precision_double, 1, lx, (size_t)g.py * nzc, d));
   rocfft_plan_description_destroy(d);
   FFT_OK(rocfft_plan_description_create(&d));
   FFT_OK(rocfft_plan_description_set_data_layout(d, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real,
                                                  off, off, 1, one, (size_t)nkx, 1, one, (size_t)nx));
   FFT_OK(rocfft_plan_create(&h->plan_xb, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
-                            rocfft_precision_double, 1, lx, rows, d));
+                            rocfft_precision_double, 1, lx, (size_t)g.py * nzc, d));
   rocfft_plan_description_destroy(d);
   FFT_OK(rocfft_plan_create(&h->plan_yf, rocfft_placement_inplace, rocfft_transform_type_complex_forward,
-                            rocfft_precision_double, 1, ly, (size_t)cx * nz, nullptr));
+                            rocfft_precision_double, 1, ly, (size_t)cx * nzc, nullptr));
   FFT_OK(rocfft_plan_create(&h->plan_yb, rocfft_placement_inplace, rocfft_transform_type_complex_inverse,
-                            rocfft_precision_double, 1, ly, (size_t)cx * nz, nullptr));
+                            rocfft_precision_double, 1, ly, (size_t)cx * nzc, nullptr));
+  HIP_OK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+  for (int c = 0; c < nch; ++c) {
+    HIP_OK(hipEventCreateWithFlags(&h->ev_ready[c], hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&h->ev_done[c], hipEventDisableTiming));
+  }
   size_t w = 0, wmax = 0;
   rocfft_plan plans[4] = {h->plan_xf, h->plan_xb, h->plan_yf, h->plan_yb};
   for (auto pl : plans) { FFT_OK(rocfft_plan_get_work_buffer_size(pl, &w)); if (w > wmax) wmax = w; }
@@ -586,67 +599,78 @@ int pois_slab_init(udc_handle *h) {
 
 int k_poisson_solve_slab(udc_handle *h) {
   const Geo &g = h->g;
-  const int P = h->cfg.nranks, cx = h->cx, nkx = h->nkx, ny = h->jtot;
+  const int P = h->cfg.nranks, cx = h->cx, nkx = h->nkx, ny = h->jtot, nch = h->nch, nzc = g.nz / nch;
   const size_t nmodes = (size_t)cx * ny;
-  const size_t block = (size_t)2 * g.nz * cx * g.ny;          // doubles per all-to-all block
+  const size_t block = (size_t)2 * nzc * cx * g.ny;            // doubles per all-to-all block of one chunk
+  const size_t chunk = block * P;                              // doubles per chunk in the send/recv buffers
   double *prow0 = h->fields[UDC_P] + g.idx(0, -HY, 0);         // first padded row of plane k = 0
-  double2 *specA = reinterpret_cast<double2 *>(h->specA), *specB = reinterpret_cast<double2 *>(h->specB);
-  double2 *snd = reinterpret_cast<double2 *>(h->a2a_send), *rcv = reinterpret_cast<double2 *>(h->a2a_recv);
-  const dim3 tb(16, 16), tg((cx * P + 15) / 16, (g.ny + 15) / 16, g.nz);
-  const unsigned lin = (unsigned)(((size_t)P * g.nz * cx * g.ny + 255) / 256);
+  const dim3 tb(16, 16), tg((cx * P + 15) / 16, (g.ny + 15) / 16, nzc);
+  const unsigned lin = (unsigned)(((size_t)P * nzc * cx * g.ny + 255) / 256);
+  auto specA_at = [&](int k0) { return h->specA + (size_t)2 * nkx * g.py * k0; };
+  auto specB_at = [&](int k0) { return h->specB + (size_t)2 * nmodes * k0; };
+  // the exchange of chunk c runs on the communication stream while the compute stream transforms and
+  // packs chunk c+1 (forward) / unpacks and transforms chunk c-1: xGMI transfers hide behind rocFFT
+  auto exchange = [&](int c) -> int {
+    HIP_OK(hipEventRecord(h->ev_ready[c], h->stream));
+    HIP_OK(hipStreamWaitEvent(h->comm_stream, h->ev_ready[c], 0));
+    if (comm_alltoall(h, h->a2a_send + chunk * c, h->a2a_recv + chunk * c, block, h->comm_stream)) return 1;
+    HIP_OK(hipEventRecord(h->ev_done[c], h->comm_stream));
+    return 0;
+  };
   {
-    PROF(h, "fftx_fwd");
-    void *in[1] = {prow0}, *out[1] = {h->specA};
-    FFT_OK(rocfft_execute(h->plan_xf, in, out, h->info_x));
-  }
-  {
-    PROF(h, "a2a_pack");
-    hipLaunchKernelGGL(slab_pack_fwd_kernel, tg, tb, 0, h->stream, g, nkx, cx, P, specA, snd);
+    PROF(h, "fftx_pack_fwd");
+    for (int c = 0; c < nch; ++c) {
+      const int k0 = c * nzc;
+      void *in[1] = {prow0 + g.sz * k0}, *out[1] = {specA_at(k0)};
+      FFT_OK(rocfft_execute(h->plan_xf, in, out, h->info_x));
+      hipLaunchKernelGGL(slab_pack_fwd_kernel, tg, tb, 0, h->stream, g, nkx, cx, P, k0, nzc,
+                         reinterpret_cast<const double2 *>(h->specA), reinterpret_cast<double2 *>(h->a2a_send + chunk * c));
+      if (exchange(c)) return 1;
+    }
     HIP_OK(hipGetLastError());
   }
   {
-    PROF(h, "a2a_xchg");
-    if (comm_alltoall(h, h->a2a_send, h->a2a_recv, block)) return 1;
-  }
-  {
-    PROF(h, "a2a_unpack");
-    hipLaunchKernelGGL(slab_unpack_fwd_kernel, dim3(lin), dim3(256), 0, h->stream, g, cx, P, ny, rcv, specB);
+    PROF(h, "unpack_ffty_fwd");
+    for (int c = 0; c < nch; ++c) {
+      const int k0 = c * nzc;
+      HIP_OK(hipStreamWaitEvent(h->stream, h->ev_done[c], 0));
+      hipLaunchKernelGGL(slab_unpack_fwd_kernel, dim3(lin), dim3(256), 0, h->stream, g, cx, P, ny, k0, nzc,
+                         reinterpret_cast<const double2 *>(h->a2a_recv + chunk * c), reinterpret_cast<double2 *>(h->specB));
+      void *io[1] = {specB_at(k0)};
+      FFT_OK(rocfft_execute(h->plan_yf, io, nullptr, h->info_x));
+    }
     HIP_OK(hipGetLastError());
-  }
-  {
-    PROF(h, "ffty_fwd");
-    void *io[1] = {h->specB};
-    FFT_OK(rocfft_execute(h->plan_yf, io, nullptr, h->info_x));
   }
   {
     PROF(h, "thomas");
     hipLaunchKernelGGL(thomas_kernel, dim3((unsigned)((nmodes + 63) / 64)), dim3(64), 0, h->stream, (int)nmodes,
-                       g.nz, 1. / ((double)g.nx * (double)ny), h->ev_slab, h->tri, h->btopD, h->dtab_slab, specB);
+                       g.nz, 1. / ((double)g.nx * (double)ny), h->ev_slab, h->tri, h->btopD, h->dtab_slab,
+                       reinterpret_cast<double2 *>(h->specB));
     HIP_OK(hipGetLastError());
   }
   {
-    PROF(h, "ffty_bwd");
-    void *io[1] = {h->specB};
-    FFT_OK(rocfft_execute(h->plan_yb, io, nullptr, h->info_x));
-  }
-  {
-    PROF(h, "a2a_pack");
-    hipLaunchKernelGGL(slab_pack_bwd_kernel, dim3(lin), dim3(256), 0, h->stream, g, cx, P, ny, specB, snd);
+    PROF(h, "ffty_pack_bwd");
+    for (int c = 0; c < nch; ++c) {
+      const int k0 = c * nzc;
+      void *io[1] = {specB_at(k0)};
+      FFT_OK(rocfft_execute(h->plan_yb, io, nullptr, h->info_x));
+      hipLaunchKernelGGL(slab_pack_bwd_kernel, dim3(lin), dim3(256), 0, h->stream, g, cx, P, ny, k0, nzc,
+                         reinterpret_cast<const double2 *>(h->specB), reinterpret_cast<double2 *>(h->a2a_send + chunk * c));
+      if (exchange(c)) return 1;
+    }
     HIP_OK(hipGetLastError());
   }
   {
-    PROF(h, "a2a_xchg");
-    if (comm_alltoall(h, h->a2a_send, h->a2a_recv, block)) return 1;
-  }
-  {
-    PROF(h, "a2a_unpack");
-    hipLaunchKernelGGL(slab_unpack_bwd_kernel, tg, tb, 0, h->stream, g, nkx, cx, P, rcv, specA);
+    PROF(h, "unpack_fftx_bwd");
+    for (int c = 0; c < nch; ++c) {
+      const int k0 = c * nzc;
+      HIP_OK(hipStreamWaitEvent(h->stream, h->ev_done[c], 0));
+      hipLaunchKernelGGL(slab_unpack_bwd_kernel, tg, tb, 0, h->stream, g, nkx, cx, P, k0, nzc,
+                         reinterpret_cast<const double2 *>(h->a2a_recv + chunk * c), reinterpret_cast<double2 *>(h->specA));
+      void *in[1] = {specA_at(k0)}, *out[1] = {prow0 + g.sz * k0};
+      FFT_OK(rocfft_execute(h->plan_xb, in, out, h->info_x));
+    }
     HIP_OK(hipGetLastError());
-  }
-  {
-    PROF(h, "fftx_bwd");
-    void *in[1] = {h->specA}, *out[1] = {prow0};
-    FFT_OK(rocfft_execute(h->plan_xb, in, out, h->info_x));
   }
   return 0;
 }
@@ -665,6 +689,8 @@ void pois_destroy(udc_handle *h) {
   rocfft_plan sp[4] = {h->plan_xf, h->plan_xb, h->plan_yf, h->plan_yb};
   for (auto pl : sp) if (pl) rocfft_plan_destroy(pl);
   if (h->info_x) rocfft_execution_info_destroy(h->info_x);
+  if (h->comm_stream) hipStreamDestroy(h->comm_stream);
+  for (int c = 0; c < 16; ++c) { if (h->ev_ready[c]) hipEventDestroy(h->ev_ready[c]); if (h->ev_done[c]) hipEventDestroy(h->ev_done[c]); }
   double *bufs[7] = {h->specA, h->specB, h->a2a_send, h->a2a_recv, h->ev_slab, h->dtab_slab, (double *)h->fft_work_slab};
   for (auto b : bufs) if (b) hipFree(b);
 }
