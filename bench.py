@@ -28,10 +28,21 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "u-dales_amd"))
 
-# algorithmic bytes per cell-update, per kernel (SURVEY.md section 8d / DESIGN.md section 4)
+# Algorithmic (compulsory) bytes per cell-update of each kernel AS BUILT.
+# SURVEY.md section 8d's model is closure 40 + momentum 88 + Poisson/integrate 264 = 392 B; the fused
+# substep moves less than that model (no pup/pvp/pwp or rhs arrays, tendencies neither re-read nor
+# zero-filled): 40 + 88 + 32 + 64 + 24 + 72 = 320 B.  `whole_substep_hbm_frac` keeps SURVEY's 392 B
+# definition so that it stays comparable across rounds.
 ALGO_BYTES = {
-    "closure": 40, "mom": 88, "div_rhs": 56, "fft_fwd": 32, "fft_bwd": 32, "thomas": 24,
-    "project_integrate": 120, "scalar": 56,
+    "closure": 40,              # read u0,v0,w0; write ekm,ekh
+    "mom": 88,                  # read u0,v0,w0,pres0,ekm (40) + um,vm,wm (24); write pup,pvp,pwp (24)
+    "div_rhs": 32,              # read pup,pvp,pwp; write p
+    "fft_fwd": 32, "fft_bwd": 32,   # 2 passes x (8 read + 8 write)
+    "thomas": 24,               # SURVEY's figure (this kernel's own compulsory traffic is 36 B)
+    "project_integrate": 72,    # read p (8), pup,pvp,pwp (24); RMW pres0 (16); write u0,v0,w0 (24)
+    "scalar": 56,
+    # slab (multi-GPU) Poisson stages
+    "fftx_pack_fwd": 32, "unpack_ffty_fwd": 32, "ffty_pack_bwd": 32, "unpack_fftx_bwd": 32,
 }
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 

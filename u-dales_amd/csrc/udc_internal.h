@@ -102,6 +102,8 @@ struct udc_handle {
   // reductions
   double *red = nullptr;                // small device scratch
   double *red_host = nullptr;           // pinned
+  double *partials = nullptr;           // per-workgroup partial results of the two-stage reductions
+  size_t partials_cap = 0;
   // profiling
   bool tend_scratch = false;            // up,vp,wp hold leftovers of a fused substep (logically zero)
   bool no_fold = false;                 // UDC_NO_FOLD=1: keep separate ghost-row kernels on a single slab (A/B switch)

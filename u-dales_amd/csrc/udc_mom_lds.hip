@@ -11,6 +11,7 @@
 #include "udc_internal.h"
 #include "udc_mom_arith.h"
 #include "udc_closure_arith.h"
+#include <cstdlib>
 
 namespace {
 
@@ -265,11 +266,26 @@ __global__ __launch_bounds__(NT) void closure_lds_kernel(Geo g, TileGrid tg, Met
 
 }  // namespace
 
+// k-chunk length: each workgroup pays a 3-plane prologue, and the chip runs `slots` workgroups at a
+// time (256 CUs x 3, register-limited), so pick the chunk that minimises rounds x (kc + 3).
+static int pick_kc(const Geo &g, const TileGrid &tg) {
+  if (getenv("UDC_MOM_KC")) { int v = atoi(getenv("UDC_MOM_KC")); if (v >= 1) return v < g.nz ? v : g.nz; }
+  const long slots = 256 * 3;
+  int best = g.nz < 4 ? g.nz : 4;
+  double best_cost = 1e300;
+  for (int kc = 4; kc <= g.nz; ++kc) {
+    const long blocks = (long)tg.tiles * ((g.nz + kc - 1) / kc);
+    const long rounds = (blocks + slots - 1) / slots;
+    const double cost = (double)rounds * (kc + 3);
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = kc; }
+  }
+  return best;
+}
+
 int k_closure_lds(udc_handle *h, bool ghosts) {
   const Geo &g = h->g;
   const TileGrid tg = tile_grid(g);
-  int kc = 32;
-  while (kc > 4 && (long)tg.tiles * ((g.nz + kc - 1) / kc) < 2048) kc >>= 1;
+  int kc = pick_kc(g, tg);
   const int chunks = (g.nz + kc - 1) / kc;
   dim3 b(TX, TY, 1), gr((unsigned)tg.tiles * (unsigned)chunks, 1, 1);
   double *u = h->fields[UDC_U0], *v = h->fields[UDC_V0], *w = h->fields[UDC_W0];
@@ -291,8 +307,7 @@ int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, 
             h->fields[UDC_UM], h->fields[UDC_VM], h->fields[UDC_WM], rk3coefi, (fresh && !h->slab) ? 1 : 0};
   const TileGrid tg = tile_grid(g);
   // k-chunk: long enough to amortise the 2-plane prologue, short enough to fill 256 CUs x 4 workgroups
-  int kc = 32;
-  while (kc > 4 && (long)tg.tiles * ((g.nz + kc - 1) / kc) < 2048) kc >>= 1;
+  int kc = pick_kc(g, tg);
   const int chunks = (g.nz + kc - 1) / kc;
   dim3 b(TX, TY, 1), gr((unsigned)tg.tiles * (unsigned)chunks, 1, 1);
   const bool les = h->p.sgs != UDC_SGS_DNS;

@@ -76,7 +76,10 @@ __global__ void thomas_table_kernel(int nmodes, int nz, const double *__restrict
 // The recurrence is sequential in k but its loads are not: each thread fetches TU levels ahead
 // (independent 16-B loads in flight) before running the dependent arithmetic on them, which is what
 // keeps HBM busy with only nmodes/64 waves on the chip.
-constexpr int TU = 8;
+#ifndef THOMAS_TU
+#define THOMAS_TU 8
+#endif
+constexpr int TU = THOMAS_TU;
 __global__ __launch_bounds__(64) void thomas_kernel(int nmodes, int nz, double scale,
     const double *__restrict__ ev, const double *__restrict__ tri, double btopD,
     const double *__restrict__ dtab, double2 *__restrict__ x) {
@@ -336,8 +339,32 @@ __device__ __forceinline__ double wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
-__device__ __forceinline__ void atomic_max_nonneg(double *addr, double v) {
-  atomicMax(reinterpret_cast<unsigned long long *>(addr), (unsigned long long)__double_as_longlong(v));
+// Two-stage, atomic-free reductions (deterministic order): every workgroup writes its two partial
+// results to part[2*block .. +1]; reduce_partials_kernel folds them.  OP 0 = max, 1 = sum.
+template <int OP> __device__ __forceinline__ double red_op(double a, double b) { return OP == 0 ? fmax(a, b) : a + b; }
+template <int OP> __device__ __forceinline__ double wave_red(double v) {
+  for (int o = 32; o > 0; o >>= 1) v = red_op<OP>(v, __shfl_xor(v, o, 64));
+  return v;
+}
+template <int OP0, int OP1>
+__device__ __forceinline__ void block_reduce2(double a, double b, double *__restrict__ part) {
+  __shared__ double sa[16], sb[16];
+  const int tid = threadIdx.y * blockDim.x + threadIdx.x, wv = tid >> 6, nw = (blockDim.x * blockDim.y + 63) >> 6;
+  a = wave_red<OP0>(a); b = wave_red<OP1>(b);
+  if ((tid & 63) == 0) { sa[wv] = a; sb[wv] = b; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int q = 1; q < nw; ++q) { a = red_op<OP0>(a, sa[q]); b = red_op<OP1>(b, sb[q]); }
+    part[2 * (size_t)blockIdx.x] = a;
+    part[2 * (size_t)blockIdx.x + 1] = b;
+  }
+}
+template <int OP0, int OP1>
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const double *__restrict__ part, long n, double init0,
+                                                                double init1, double *__restrict__ out) {
+  double a = init0, b = init1;
+  for (long q = threadIdx.x; q < n; q += blockDim.x) { a = red_op<OP0>(a, part[2 * q]); b = red_op<OP1>(b, part[2 * q + 1]); }
+  block_reduce2<OP0, OP1>(a, b, out);
 }
 
 // tstep_update, src/modtstep.f90:113-128
@@ -353,11 +380,7 @@ __global__ __launch_bounds__(256) void maxima_kernel(Geo g, TileGrid tg, Metrics
     const double f = (m.dzh2i[k + 1] + m.dx2i + m.dy2i);
     dif = fmax(ekm[c] * f * dt, ekh[c] * f * dt);
   }
-  cour = wave_max(cour); dif = wave_max(dif);
-  if ((threadIdx.x & 63) == 0 && (threadIdx.y * blockDim.x + threadIdx.x) % 64 == 0) {
-    atomic_max_nonneg(out, cour);
-    atomic_max_nonneg(out + 1, dif);
-  }
+  block_reduce2<0, 0>(cour, dif, out);
 }
 
 // chkdiv, src/modchecksim.f90:179-191
@@ -373,11 +396,7 @@ __global__ __launch_bounds__(256) void divcheck_kernel(Geo g, TileGrid tg, Metri
     dmax = fabs(div);
     dsum = div * m.dx * m.dy * m.dzf[k + 1];
   }
-  dmax = wave_max(dmax); dsum = wave_sum(dsum);
-  if ((threadIdx.y * blockDim.x + threadIdx.x) % 64 == 0) {
-    atomic_max_nonneg(out, dmax);
-    atomicAdd(out + 1, dsum);
-  }
+  block_reduce2<0, 1>(dmax, dsum, out);
 }
 
 }  // namespace
@@ -686,6 +705,7 @@ void pois_destroy(udc_handle *h) {
   if (h->dtab) hipFree(h->dtab);
   if (h->ev) hipFree(h->ev);
   if (h->tri) hipFree(h->tri);
+  if (h->partials) hipFree(h->partials);
   rocfft_plan sp[4] = {h->plan_xf, h->plan_xb, h->plan_yf, h->plan_yb};
   for (auto pl : sp) if (pl) rocfft_plan_destroy(pl);
   if (h->info_x) rocfft_execution_info_destroy(h->info_x);
@@ -799,13 +819,23 @@ int k_project_integrate(udc_handle *h, int rk3step, double dt, bool zero_tend, b
   return 0;
 }
 
+static int ensure_partials(udc_handle *h, size_t nblocks) {
+  if (h->partials_cap >= nblocks) return 0;
+  if (h->partials) HIP_OK(hipFree(h->partials));
+  HIP_OK(hipMalloc(&h->partials, sizeof(double) * 2 * nblocks));
+  h->partials_cap = nblocks;
+  return 0;
+}
+
 int k_maxima(udc_handle *h, double dt, double *cour, double *diffn) {
   const Geo &g = h->g;
   dim3 b(64, 4, 1), gr = cell_grid(g, b);
-  h->red_host[0] = 0.; h->red_host[1] = 1e-5;   // diffnrtotl starts at 1e-5, src/modtstep.f90:115
-  HIP_OK(hipMemcpyAsync(h->red, h->red_host, 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (ensure_partials(h, gr.x)) return 1;
   hipLaunchKernelGGL(maxima_kernel, gr, b, 0, h->stream, g, tile_grid(g), h->m, dt, h->fields[UDC_UM], h->fields[UDC_VM],
-                     h->fields[UDC_WM], h->fields[UDC_EKM], h->fields[UDC_EKH], h->red);
+                     h->fields[UDC_WM], h->fields[UDC_EKM], h->fields[UDC_EKH], h->partials);
+  // diffnrtotl starts at 1e-5, src/modtstep.f90:115
+  hipLaunchKernelGGL((reduce_partials_kernel<0, 0>), dim3(1), dim3(1024), 0, h->stream, h->partials, (long)gr.x, 0.,
+                     1e-5, h->red);
   HIP_OK(hipGetLastError());
   if (comm_allreduce(h, h->red, 2, 0)) return 1;     // MPI_ALLREDUCE(MAX), src/modtstep.f90:131-132
   HIP_OK(hipMemcpyAsync(h->red_host, h->red, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -818,10 +848,11 @@ int k_maxima(udc_handle *h, double dt, double *cour, double *diffn) {
 int k_divergence_check(udc_handle *h, double *divmax, double *divtot) {
   const Geo &g = h->g;
   dim3 b(64, 4, 1), gr = cell_grid(g, b);
-  h->red_host[0] = 0.; h->red_host[1] = 0.;
-  HIP_OK(hipMemcpyAsync(h->red, h->red_host, 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (ensure_partials(h, gr.x)) return 1;
   hipLaunchKernelGGL(divcheck_kernel, gr, b, 0, h->stream, g, tile_grid(g), h->m, h->fields[UDC_U0], h->fields[UDC_V0],
-                     h->fields[UDC_W0], h->red);
+                     h->fields[UDC_W0], h->partials);
+  hipLaunchKernelGGL((reduce_partials_kernel<0, 1>), dim3(1), dim3(1024), 0, h->stream, h->partials, (long)gr.x, 0.,
+                     0., h->red);
   HIP_OK(hipGetLastError());
   if (comm_allreduce(h, h->red, 1, 0)) return 1;         // divmax: MPI_MAX
   if (comm_allreduce(h, h->red + 1, 1, 1)) return 1;     // divtot: MPI_SUM (src/modchecksim.f90:193-196)
