@@ -119,6 +119,15 @@ module udc_iface
       type(c_ptr), value :: h
       real(c_double), intent(out) :: divmax, divtot
     end function
+    integer(c_int) function udc_comm_unique_id(id) bind(C, name='udc_comm_unique_id')
+      import :: c_int, c_signed_char
+      integer(c_signed_char), intent(out) :: id(128)
+    end function
+    integer(c_int) function udc_comm_init(h, id) bind(C, name='udc_comm_init')
+      import :: c_int, c_ptr, c_signed_char
+      type(c_ptr), value :: h
+      integer(c_signed_char), intent(in) :: id(128)
+    end function
     integer(c_int) function udc_sync(h) bind(C, name='udc_sync')
       import :: c_int, c_ptr
       type(c_ptr), value :: h
@@ -149,8 +158,11 @@ contains
                          BCtopm, Uinf, Vinf, lles
     use modsubgriddata, only: lsmagorinsky, lvreman, prandtli, c_vreman, csz
     use modfields, only: dpdxl, dpdyl
-    use modmpi, only: myid, nprocs
+    use modmpi, only: myid, nprocs, nprocx, comm3d, mpierr
+    use mpi, only: MPI_CHARACTER
     type(udc_config) :: cfg
+    integer(c_signed_char) :: nccl_id(128)
+    integer :: gpus_per_node
     real(c_double), allocatable, target, save :: zf_(:), zh_(:)
     character(16) :: env
     integer :: stat
@@ -160,7 +172,14 @@ contains
     zh_(0) = 0.
     zh_(1:ktot + 1) = dzh(kb:ke + kh)
     cfg%itot = itot; cfg%jtot = jtot; cfg%ktot = ktot
-    cfg%nranks = nprocs; cfg%rank = myid; cfg%device = 0
+    if (nprocx /= 1) then
+      write (0, *) 'ERROR: libudcore decomposes in y only: set nprocx = 1, nprocy = number of GPUs'
+      stop 1
+    end if
+    gpus_per_node = 8
+    call get_environment_variable('UDC_GPUS_PER_NODE', env, status=stat)
+    if (stat == 0) read (env, *, iostat=stat) gpus_per_node
+    cfg%nranks = nprocs; cfg%rank = myid; cfg%device = mod(myid, max(gpus_per_node, 1))
     cfg%dx = dx; cfg%dy = dy
     cfg%dzf = c_loc(zf_); cfg%dzh = c_loc(zh_)
     cfg%numol = numol; cfg%prandtlmoli = prandtlmoli; cfg%prandtli = prandtli
@@ -177,6 +196,13 @@ contains
     cfg%uinf = Uinf; cfg%vinf = Vinf
     cfg%nsv = nsv
     call udc_check(udc_create(cfg, udc_h), 'udc_create')
+    if (nprocs > 1) then
+      ! RCCL communicator over the y-slab ranks: rank 0 makes the id, MPI carries it (INTEGRATION.md section 4)
+      nccl_id = 0
+      if (myid == 0) call udc_check(udc_comm_unique_id(nccl_id), 'udc_comm_unique_id')
+      call MPI_BCAST(nccl_id, 128, MPI_CHARACTER, 0, comm3d, mpierr)
+      call udc_check(udc_comm_init(udc_h, nccl_id), 'udc_comm_init')
+    end if
     call udc_check(udc_set_forcing(udc_h, dpdxl(kb:ke), dpdyl(kb:ke), int(ktot, c_int)), 'udc_set_forcing')
     call get_environment_variable('UDC_RESIDENCY', env, status=stat)
     if (stat == 0) read (env, *, iostat=stat) udc_residency
