@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void real_copy_kernel(Geo g, TileGrid tg, doub
 // specA -> send blocks (transposes kx-fastest rows into j-fastest runs through an LDS tile)
 // All four kernels work on one k-chunk [k0, k0+nzc): blocks are [d][k-k0][kxl][j] inside the chunk's
 // slice of the send/recv buffers, so that chunks can be exchanged while others are transformed.
-__global__ __launch_bounds__(256) void slab_pack_fwd_kernel(Geo g, int nkx, int cx, int P, int k0, int nzc,
+__global__ __launch_bounds__(256) void slab_pack_fwd_kernel(Geo g, int nkx, int pitch, int cx, int P, int k0, int nzc,
     const double2 *__restrict__ specA, double2 *__restrict__ send) {
   __shared__ double2 tile[16][17];
   const int kc = blockIdx.z, k = k0 + kc;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void slab_pack_fwd_kernel(Geo g, int nkx, int 
   {
     const int kx = kx0 + tx, j = j0 + ty;
     double2 v = make_double2(0., 0.);
-    if (kx < nkx && j < g.ny) v = specA[((size_t)(j + HY) + (size_t)g.py * k) * nkx + kx];
+    if (kx < nkx && j < g.ny) v = specA[((size_t)(j + HY) + (size_t)g.py * k) * pitch + kx];
     tile[ty][tx] = v;
   }
   __syncthreads();
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void slab_pack_bwd_kernel(Geo g, int cx, int P
   send[q] = specB[((size_t)(k0 + kc) * cx + kxl) * jtot + (size_t)d * g.ny + j];
 }
 
-__global__ __launch_bounds__(256) void slab_unpack_bwd_kernel(Geo g, int nkx, int cx, int P, int k0, int nzc,
+__global__ __launch_bounds__(256) void slab_unpack_bwd_kernel(Geo g, int nkx, int pitch, int cx, int P, int k0, int nzc,
     const double2 *__restrict__ recv, double2 *__restrict__ specA) {
   __shared__ double2 tile[16][17];
   const int kc = blockIdx.z, k = k0 + kc;
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void slab_unpack_bwd_kernel(Geo g, int nkx, in
   __syncthreads();
   {
     const int kx = kx0 + tx, j = j0 + ty;
-    if (kx < nkx && j < g.ny) specA[((size_t)(j + HY) + (size_t)g.py * k) * nkx + kx] = tile[tx][ty];
+    if (kx < nkx && j < g.ny) specA[((size_t)(j + HY) + (size_t)g.py * k) * pitch + kx] = tile[tx][ty];
   }
 }
 
@@ -546,7 +546,8 @@ int pois_slab_init(udc_handle *h) {
   const Geo &g = h->g;
   const int nx = g.nx, nyl = g.ny, ny = h->jtot, nz = g.nz, P = h->cfg.nranks, r = h->cfg.rank;
   const int nkx = nx / 2 + 1, cx = (nkx + P - 1) / P;
-  h->nkx = nkx; h->cx = cx;
+  const int nkxp = nkx + (8 - nkx % 8) % 8;      // aligned row pitch of specA
+  h->nkx = nkx; h->cx = cx; h->nkxp = nkxp;
   std::vector<double> xrt, yrt, tri;
   double btopD;
   poisson_coefficients(h, xrt, yrt, tri, btopD);
@@ -565,8 +566,8 @@ int pois_slab_init(udc_handle *h) {
   h->nch = nch;
   const int nzc = nz / nch;
   const size_t rows = (size_t)g.py * nz;
-  HIP_OK(hipMalloc(&h->specA, sizeof(double) * 2 * nkx * rows));
-  HIP_OK(hipMemsetAsync(h->specA, 0, sizeof(double) * 2 * nkx * rows, h->stream));
+  HIP_OK(hipMalloc(&h->specA, sizeof(double) * 2 * nkxp * rows));
+  HIP_OK(hipMemsetAsync(h->specA, 0, sizeof(double) * 2 * nkxp * rows, h->stream));
   HIP_OK(hipMalloc(&h->specB, sizeof(double) * 2 * nmodes * nz));
   HIP_OK(hipMalloc(&h->a2a_send, sizeof(double) * 2 * nmodes * nz));
   HIP_OK(hipMalloc(&h->a2a_recv, sizeof(double) * 2 * nmodes * nz));
@@ -586,13 +587,13 @@ int pois_slab_init(udc_handle *h) {
   rocfft_plan_description d = nullptr;
   FFT_OK(rocfft_plan_description_create(&d));
   FFT_OK(rocfft_plan_description_set_data_layout(d, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved,
-                                                 off, off, 1, one, (size_t)nx, 1, one, (size_t)nkx));
+                                                 off, off, 1, one, (size_t)nx, 1, one, (size_t)nkxp));
   FFT_OK(rocfft_plan_create(&h->plan_xf, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
                             rocfft_precision_double, 1, lx, (size_t)g.py * nzc, d));
   rocfft_plan_description_destroy(d);
   FFT_OK(rocfft_plan_description_create(&d));
   FFT_OK(rocfft_plan_description_set_data_layout(d, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real,
-                                                 off, off, 1, one, (size_t)nkx, 1, one, (size_t)nx));
+                                                 off, off, 1, one, (size_t)nkxp, 1, one, (size_t)nx));
   FFT_OK(rocfft_plan_create(&h->plan_xb, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
                             rocfft_precision_double, 1, lx, (size_t)g.py * nzc, d));
   rocfft_plan_description_destroy(d);
@@ -625,7 +626,8 @@ int k_poisson_solve_slab(udc_handle *h) {
   double *prow0 = h->fields[UDC_P] + g.idx(0, -HY, 0);         // first padded row of plane k = 0
   const dim3 tb(16, 16), tg((cx * P + 15) / 16, (g.ny + 15) / 16, nzc);
   const unsigned lin = (unsigned)(((size_t)P * nzc * cx * g.ny + 255) / 256);
-  auto specA_at = [&](int k0) { return h->specA + (size_t)2 * nkx * g.py * k0; };
+  const int pitch = h->nkxp;
+  auto specA_at = [&](int k0) { return h->specA + (size_t)2 * pitch * g.py * k0; };
   auto specB_at = [&](int k0) { return h->specB + (size_t)2 * nmodes * k0; };
   // the exchange of chunk c runs on the communication stream while the compute stream transforms and
   // packs chunk c+1 (forward) / unpacks and transforms chunk c-1: xGMI transfers hide behind rocFFT
@@ -642,7 +644,7 @@ int k_poisson_solve_slab(udc_handle *h) {
       const int k0 = c * nzc;
       void *in[1] = {prow0 + g.sz * k0}, *out[1] = {specA_at(k0)};
       FFT_OK(rocfft_execute(h->plan_xf, in, out, h->info_x));
-      hipLaunchKernelGGL(slab_pack_fwd_kernel, tg, tb, 0, h->stream, g, nkx, cx, P, k0, nzc,
+      hipLaunchKernelGGL(slab_pack_fwd_kernel, tg, tb, 0, h->stream, g, nkx, pitch, cx, P, k0, nzc,
                          reinterpret_cast<const double2 *>(h->specA), reinterpret_cast<double2 *>(h->a2a_send + chunk * c));
       if (exchange(c)) return 1;
     }
@@ -684,7 +686,7 @@ int k_poisson_solve_slab(udc_handle *h) {
     for (int c = 0; c < nch; ++c) {
       const int k0 = c * nzc;
       HIP_OK(hipStreamWaitEvent(h->stream, h->ev_done[c], 0));
-      hipLaunchKernelGGL(slab_unpack_bwd_kernel, tg, tb, 0, h->stream, g, nkx, cx, P, k0, nzc,
+      hipLaunchKernelGGL(slab_unpack_bwd_kernel, tg, tb, 0, h->stream, g, nkx, pitch, cx, P, k0, nzc,
                          reinterpret_cast<const double2 *>(h->a2a_recv + chunk * c), reinterpret_cast<double2 *>(h->specA));
       void *in[1] = {specA_at(k0)}, *out[1] = {prow0 + g.sz * k0};
       FFT_OK(rocfft_execute(h->plan_xb, in, out, h->info_x));
