@@ -42,7 +42,7 @@ program ref_driver
   integer :: dump_at(16) = -1
   logical :: lforces = .true.
   integer :: isub, n, ierr, iu
-  real :: t0, t1
+  real :: t0, t1, chk_u2, chk_div
   real :: scal_a = 1.0, scal_b = 0.0     ! scalar init: sv = scal_b + scal_a*z/zsize
   ! src/modstartup.f90:42-44 (module variables of modstartup, which cannot be built here)
   integer(KIND=selected_int_kind(6)) :: irandom = 43
@@ -98,9 +98,12 @@ program ref_driver
       call one_substep
     end do
     t1 = MPI_Wtime()
-    write (6, '(a,i0,a,i0,a,i0,a,i0,a,es14.6,a,es14.6)') 'REF_TIMING cells=', itot*jtot*ktot, &
-      ' itot=', itot, ' jtot=', jtot, ' substeps=', nsub, ' seconds=', t1 - t0, &
-      ' cell_updates_per_s=', real(itot)*real(jtot)*real(ktot)*real(nsub)/(t1 - t0)
+    call global_checks(chk_u2, chk_div)
+    if (myid == 0) write (6, '(a,i0,a,i0,a,i0,a,i0,a,i0,a,es14.6,a,es14.6,a,es22.14,a,es10.2)') &
+      'REF_TIMING cells=', itot*jtot*ktot, &
+      ' itot=', itot, ' jtot=', jtot, ' ranks=', nprocs, ' substeps=', nsub, ' seconds=', t1 - t0, &
+      ' cell_updates_per_s=', real(itot)*real(jtot)*real(ktot)*real(nsub)/(t1 - t0), &
+      ' sum_u0sq=', chk_u2, ' divmax=', chk_div
   case default
     write (0, *) 'unknown mode ', trim(mode)
     stop 1
@@ -108,6 +111,27 @@ program ref_driver
   if (trim(mode) /= 'time') close (iu)
 
 contains
+
+  !> decomposition-independent diagnostics printed with the timing: sum(u0^2) and chkdiv's divmax
+  !! (src/modchecksim.f90:179-196) over the whole domain
+  subroutine global_checks(u2, dmax)
+    real, intent(out) :: u2, dmax
+    real :: u2l, dl, div
+    integer :: i, j, k, ierr
+    u2l = 0.; dl = 0.
+    do k = kb, ke
+      do j = jb, je
+        do i = ib, ie
+          u2l = u2l + u0(i, j, k)**2
+          div = (u0(i + 1, j, k) - u0(i, j, k))*dxi + (v0(i, j + 1, k) - v0(i, j, k))*dyi + &
+                (w0(i, j, k + 1) - w0(i, j, k))*dzfi(k)
+          dl = max(dl, abs(div))
+        end do
+      end do
+    end do
+    call MPI_ALLREDUCE(u2l, u2, 1, MY_REAL, MPI_SUM, comm3d, ierr)
+    call MPI_ALLREDUCE(dl, dmax, 1, MY_REAL, MPI_MAX, comm3d, ierr)
+  end subroutine global_checks
 
   character(4) function tag4(i)
     integer, intent(in) :: i
@@ -149,7 +173,7 @@ contains
     read (ifnamopt, BC, iostat=ierr); call chk(ierr, 'BC'); rewind (ifnamopt)
     read (ifnamopt, SCALARS, iostat=ierr); call chk(ierr, 'SCALARS')
     close (ifnamopt)
-    nprocx = 1; nprocy = 1          ! the oracle build is single-rank whatever the deck says
+    nprocx = 1; nprocy = nprocs     ! y-slabs over however many ranks were launched (1 in the np1 build)
     libm = .false.
     allocate (wsvtop(1:max(nsv, 1))); wsvtop = 0.      ! src/modstartup.f90:518-519
     allocate (sv_top(1:max(nsv, 1))); sv_top = 0.
@@ -165,13 +189,14 @@ contains
     end if
   end subroutine chk
 
-  ! ---- src/modstartup.f90:652-691 for one rank
+  ! ---- src/modstartup.f90:652-691 (nprocx = 1; nprocy = number of ranks)
   subroutine init_decomp_np1
     logical :: periodic_bc(3)
     periodic_bc = .false.
-    call decomp_2d_init(itot, jtot, ktot, 1, 1, periodic_bc)
+    periodic_bc(2) = (BCym == BCym_periodic) .and. (nprocy > 1)
+    call decomp_2d_init(itot, jtot, ktot, nprocx, nprocy, periodic_bc)
     comm3d = DECOMP_2D_COMM_CART_Z
-    myidx = 0; myidy = 0
+    myidx = 0; myidy = mycol
     write (cmyidx, '(i3.3)') myidx
     write (cmyidy, '(i3.3)') myidy
   end subroutine init_decomp_np1

@@ -1,0 +1,316 @@
+! TEST INFRASTRUCTURE (oracle/_ref MPI build only) -- not part of the product.
+!
+! Multi-rank stand-in for the un-vendored 2DECOMP&FFT library, restricted to what the CPU
+! baseline needs: p_row = nprocx = 1, p_col = nprocy = P (y split in the z-pencil, z split in the
+! y/x pencils).  With p_row = 1 the y<->x transposes are local copies, z<->y is one MPI_ALLTOALL of
+! equal blocks (jtot % P == 0 and ktot % P == 0, which the reference itself requires,
+! src/modstartup.f90:730-760), and exchange_halo_z moves whole padded rows to the two y neighbours
+! (periodic).  It moves data only.  Used to time the reference's numerics on all host cores
+! (BASELINE.md section 4); the caveat that this is NOT the upstream 2decomp binary is printed with
+! every number that comes from it.
+module decomp_2d
+  use mpi
+  implicit none
+  integer, parameter :: mytype = kind(0.d0)
+  integer, save :: nrank = 0, nproc = 1
+  integer, save :: nx_global, ny_global, nz_global
+  integer, save, dimension(3) :: xstart, xend, xsize
+  integer, save, dimension(3) :: ystart, yend, ysize
+  integer, save, dimension(3) :: zstart, zend, zsize
+  integer, save :: DECOMP_2D_COMM_CART_X = 0, DECOMP_2D_COMM_CART_Y = 0, DECOMP_2D_COMM_CART_Z = 0
+  integer, save :: pcol = 1, mycol = 0, nbr_prev = 0, nbr_next = 0
+  logical, save :: periodic_y = .false.
+
+  type DECOMP_INFO
+    integer, dimension(3) :: xst, xen, xsz
+    integer, dimension(3) :: yst, yen, ysz
+    integer, dimension(3) :: zst, zen, zsz
+    integer, dimension(3) :: xlevel = (/0, 0, 0/), ylevel = (/0, 0, 0/), zlevel = (/0, 0, 0/)
+  end type DECOMP_INFO
+  type(DECOMP_INFO), save :: decomp_main
+
+  interface alloc_x
+    module procedure alloc_x_real
+  end interface
+  interface alloc_y
+    module procedure alloc_y_real
+  end interface
+  interface alloc_z
+    module procedure alloc_z_real
+  end interface
+  interface transpose_x_to_y
+    module procedure copy_real, copy_complex
+  end interface
+  interface transpose_y_to_x
+    module procedure copy_real, copy_complex
+  end interface
+  interface transpose_z_to_y
+    module procedure z_to_y_real, unsupported_complex
+  end interface
+  interface transpose_y_to_z
+    module procedure y_to_z_real, unsupported_complex
+  end interface
+  interface exchange_halo_z
+    module procedure exchange_halo_z_real
+  end interface
+  interface exchange_halo_x
+    module procedure exchange_unsupported
+  end interface
+  interface exchange_halo_y
+    module procedure exchange_unsupported
+  end interface
+
+contains
+
+  subroutine decomp_2d_init(nx, ny, nz, p_row, p_col, periodic_bc)
+    integer, intent(in) :: nx, ny, nz, p_row, p_col
+    logical, dimension(3), intent(in), optional :: periodic_bc
+    integer :: ierr, dims(2), coords(2)
+    logical :: periods(2)
+    call MPI_COMM_RANK(MPI_COMM_WORLD, nrank, ierr)
+    call MPI_COMM_SIZE(MPI_COMM_WORLD, nproc, ierr)
+    if (p_row /= 1 .or. p_col /= nproc .or. mod(ny, p_col) /= 0 .or. mod(nz, p_col) /= 0) then
+      if (nrank == 0) write (0, *) 'ERROR: oracle MPI decomp needs nprocx = 1, nprocy = #ranks, jtot and ktot divisible'
+      call MPI_ABORT(MPI_COMM_WORLD, 1, ierr)
+    end if
+    nx_global = nx; ny_global = ny; nz_global = nz
+    pcol = p_col
+    dims = (/1, p_col/); periods = (/.true., .true./)
+    call MPI_CART_CREATE(MPI_COMM_WORLD, 2, dims, periods, .false., DECOMP_2D_COMM_CART_Z, ierr)
+    call MPI_CART_COORDS(DECOMP_2D_COMM_CART_Z, nrank, 2, coords, ierr)
+    mycol = coords(2)
+    call MPI_CART_SHIFT(DECOMP_2D_COMM_CART_Z, 1, 1, nbr_prev, nbr_next, ierr)
+    DECOMP_2D_COMM_CART_X = DECOMP_2D_COMM_CART_Z; DECOMP_2D_COMM_CART_Y = DECOMP_2D_COMM_CART_Z
+    periodic_y = .false.
+    if (present(periodic_bc)) periodic_y = periodic_bc(2)
+    call decomp_info_init(nx, ny, nz, decomp_main)
+    xstart = decomp_main%xst; xend = decomp_main%xen; xsize = decomp_main%xsz
+    ystart = decomp_main%yst; yend = decomp_main%yen; ysize = decomp_main%ysz
+    zstart = decomp_main%zst; zend = decomp_main%zen; zsize = decomp_main%zsz
+  end subroutine decomp_2d_init
+
+  subroutine decomp_2d_finalize
+  end subroutine decomp_2d_finalize
+
+  subroutine decomp_info_init(nx, ny, nz, info)
+    integer, intent(in) :: nx, ny, nz
+    type(DECOMP_INFO), intent(inout) :: info
+    integer :: nyl, nzl
+    nyl = ny/pcol; nzl = nz/pcol
+    ! z-pencil: (nx, ny/P, nz);  y- and x-pencils: (nx, ny, nz/P)
+    info%zst = (/1, mycol*nyl + 1, 1/); info%zsz = (/nx, nyl, nz/); info%zen = info%zst + info%zsz - 1
+    info%yst = (/1, 1, mycol*nzl + 1/); info%ysz = (/nx, ny, nzl/); info%yen = info%yst + info%ysz - 1
+    info%xst = info%yst; info%xsz = info%ysz; info%xen = info%yen
+  end subroutine decomp_info_init
+
+  subroutine alloc_any(var, sz, lev)
+    real(mytype), allocatable, dimension(:, :, :) :: var
+    integer, intent(in) :: sz(3), lev(3)
+    allocate (var(1 - lev(1):sz(1) + lev(1), 1 - lev(2):sz(2) + lev(2), 1 - lev(3):sz(3) + lev(3)))
+    var = 0.
+  end subroutine alloc_any
+
+  subroutine alloc_x_real(var, opt_decomp, opt_global, opt_xlevel)
+    real(mytype), allocatable, dimension(:, :, :) :: var
+    type(DECOMP_INFO), intent(in), optional :: opt_decomp
+    logical, intent(in), optional :: opt_global
+    integer, intent(in), optional :: opt_xlevel(3)
+    integer :: lev(3)
+    lev = decomp_main%xlevel; if (present(opt_xlevel)) lev = opt_xlevel
+    call alloc_any(var, decomp_main%xsz, lev)
+  end subroutine alloc_x_real
+
+  subroutine alloc_y_real(var, opt_decomp, opt_global, opt_ylevel)
+    real(mytype), allocatable, dimension(:, :, :) :: var
+    type(DECOMP_INFO), intent(in), optional :: opt_decomp
+    logical, intent(in), optional :: opt_global
+    integer, intent(in), optional :: opt_ylevel(3)
+    integer :: lev(3)
+    lev = decomp_main%ylevel; if (present(opt_ylevel)) lev = opt_ylevel
+    call alloc_any(var, decomp_main%ysz, lev)
+  end subroutine alloc_y_real
+
+  subroutine alloc_z_real(var, opt_decomp, opt_global, opt_zlevel)
+    real(mytype), allocatable, dimension(:, :, :) :: var
+    type(DECOMP_INFO), intent(in), optional :: opt_decomp
+    logical, intent(in), optional :: opt_global
+    integer, intent(in), optional :: opt_zlevel(3)
+    integer :: lev(3)
+    lev = decomp_main%zlevel; if (present(opt_zlevel)) lev = opt_zlevel
+    call alloc_any(var, decomp_main%zsz, lev)
+  end subroutine alloc_z_real
+
+  subroutine copy_real(src, dst, opt_decomp)
+    real(mytype), dimension(:, :, :), intent(in) :: src
+    real(mytype), dimension(:, :, :), intent(out) :: dst
+    type(DECOMP_INFO), intent(in), optional :: opt_decomp
+    dst = src
+  end subroutine copy_real
+
+  subroutine copy_complex(src, dst, opt_decomp)
+    complex(mytype), dimension(:, :, :), intent(in) :: src
+    complex(mytype), dimension(:, :, :), intent(out) :: dst
+    type(DECOMP_INFO), intent(in), optional :: opt_decomp
+    dst = src
+  end subroutine copy_complex
+
+  subroutine unsupported_complex(src, dst, opt_decomp)
+    complex(mytype), dimension(:, :, :), intent(in) :: src
+    complex(mytype), dimension(:, :, :), intent(out) :: dst
+    type(DECOMP_INFO), intent(in), optional :: opt_decomp
+    write (0, *) 'ERROR: complex z<->y transposes are not provided by the oracle MPI shim'
+    stop 1
+  end subroutine unsupported_complex
+
+  ! z-pencil (nx, ny/P, nz) -> y-pencil (nx, ny, nz/P): block d holds my rows, z-slab of rank d
+  subroutine z_to_y_real(src, dst, opt_decomp)
+    real(mytype), dimension(:, :, :), intent(in) :: src
+    real(mytype), dimension(:, :, :), intent(out) :: dst
+    type(DECOMP_INFO), intent(in), optional :: opt_decomp
+    real(mytype), allocatable :: sbuf(:), rbuf(:)
+    integer :: nx, nyl, nzl, d, k, j, blk, ierr, o
+    nx = nx_global; nyl = ny_global/pcol; nzl = nz_global/pcol
+    blk = nx*nyl*nzl
+    allocate (sbuf(blk*pcol), rbuf(blk*pcol))
+    do d = 0, pcol - 1
+      o = d*blk
+      do k = 1, nzl
+        do j = 1, nyl
+          sbuf(o + 1:o + nx) = src(:, j, d*nzl + k)
+          o = o + nx
+        end do
+      end do
+    end do
+    call MPI_ALLTOALL(sbuf, blk, MPI_DOUBLE_PRECISION, rbuf, blk, MPI_DOUBLE_PRECISION, DECOMP_2D_COMM_CART_Z, ierr)
+    do d = 0, pcol - 1
+      o = d*blk
+      do k = 1, nzl
+        do j = 1, nyl
+          dst(:, d*nyl + j, k) = rbuf(o + 1:o + nx)
+          o = o + nx
+        end do
+      end do
+    end do
+    deallocate (sbuf, rbuf)
+  end subroutine z_to_y_real
+
+  subroutine y_to_z_real(src, dst, opt_decomp)
+    real(mytype), dimension(:, :, :), intent(in) :: src
+    real(mytype), dimension(:, :, :), intent(out) :: dst
+    type(DECOMP_INFO), intent(in), optional :: opt_decomp
+    real(mytype), allocatable :: sbuf(:), rbuf(:)
+    integer :: nx, nyl, nzl, d, k, j, blk, ierr, o
+    nx = nx_global; nyl = ny_global/pcol; nzl = nz_global/pcol
+    blk = nx*nyl*nzl
+    allocate (sbuf(blk*pcol), rbuf(blk*pcol))
+    do d = 0, pcol - 1
+      o = d*blk
+      do k = 1, nzl
+        do j = 1, nyl
+          sbuf(o + 1:o + nx) = src(:, d*nyl + j, k)
+          o = o + nx
+        end do
+      end do
+    end do
+    call MPI_ALLTOALL(sbuf, blk, MPI_DOUBLE_PRECISION, rbuf, blk, MPI_DOUBLE_PRECISION, DECOMP_2D_COMM_CART_Z, ierr)
+    do d = 0, pcol - 1
+      o = d*blk
+      do k = 1, nzl
+        do j = 1, nyl
+          dst(:, j, d*nzl + k) = rbuf(o + 1:o + nx)
+          o = o + nx
+        end do
+      end do
+    end do
+    deallocate (sbuf, rbuf)
+  end subroutine y_to_z_real
+
+  ! in-place halo exchange of a z-pencil array allocated WITH halos (uDALES-fork convention); the
+  ! halo widths come from the array's own extents: (nx + 2hi, ny/P + 2hj, nz + hk_lo + hk_hi).
+  subroutine exchange_halo_z_real(var, opt_decomp, opt_xlevel, opt_ylevel, opt_zlevel)
+    real(mytype), dimension(:, :, :), intent(inout) :: var
+    type(DECOMP_INFO), intent(in), optional :: opt_decomp
+    integer, intent(in), optional :: opt_xlevel(3), opt_ylevel(3), opt_zlevel(3)
+    integer :: hj, n1, n2, n3, nyl, cnt, ierr, st(MPI_STATUS_SIZE)
+    real(mytype), allocatable :: s1(:, :, :), s2(:, :, :), r1(:, :, :), r2(:, :, :)
+    if (.not. periodic_y) return
+    n1 = size(var, 1); n2 = size(var, 2); n3 = size(var, 3)
+    nyl = ny_global/pcol
+    hj = (n2 - nyl)/2
+    if (hj < 1) return
+    allocate (s1(n1, hj, n3), s2(n1, hj, n3), r1(n1, hj, n3), r2(n1, hj, n3))
+    s1 = var(:, hj + 1:2*hj, :)                 ! my lowest interior rows  -> previous rank's upper ghosts
+    s2 = var(:, n2 - 2*hj + 1:n2 - hj, :)       ! my highest interior rows -> next rank's lower ghosts
+    cnt = n1*hj*n3
+    call MPI_SENDRECV(s1, cnt, MPI_DOUBLE_PRECISION, nbr_prev, 1, r2, cnt, MPI_DOUBLE_PRECISION, nbr_next, 1, &
+                      DECOMP_2D_COMM_CART_Z, st, ierr)
+    call MPI_SENDRECV(s2, cnt, MPI_DOUBLE_PRECISION, nbr_next, 2, r1, cnt, MPI_DOUBLE_PRECISION, nbr_prev, 2, &
+                      DECOMP_2D_COMM_CART_Z, st, ierr)
+    var(:, 1:hj, :) = r1
+    var(:, n2 - hj + 1:n2, :) = r2
+    deallocate (s1, s2, r1, r2)
+  end subroutine exchange_halo_z_real
+
+  subroutine exchange_unsupported(var, opt_decomp, opt_xlevel, opt_ylevel, opt_zlevel)
+    real(mytype), dimension(:, :, :), intent(inout) :: var
+    type(DECOMP_INFO), intent(in), optional :: opt_decomp
+    integer, intent(in), optional :: opt_xlevel(3), opt_ylevel(3), opt_zlevel(3)
+    write (0, *) 'ERROR: exchange_halo_x/y are not provided by the oracle MPI shim'
+    stop 1
+  end subroutine exchange_unsupported
+
+  subroutine update_halo(in, out, level, opt_decomp, opt_global)
+    real(mytype), dimension(:, :, :), intent(in) :: in
+    real(mytype), allocatable, dimension(:, :, :), intent(out) :: out
+    integer, intent(in) :: level
+    type(DECOMP_INFO), intent(in), optional :: opt_decomp
+    logical, intent(in), optional :: opt_global
+    write (0, *) 'ERROR: update_halo not provided by the oracle shim'
+    stop 1
+  end subroutine update_halo
+
+end module decomp_2d
+
+module decomp_2d_fft
+  use decomp_2d
+  implicit none
+  integer(8), save :: plan(-1:2, 3) = 0
+  interface decomp_2d_fft_3d
+    module procedure fft_3d_r2c, fft_3d_c2r
+  end interface
+contains
+  subroutine fft_unavailable
+    write (0, *) 'ERROR: decomp_2d_fft is not provided by the oracle shim (ipoiss must be 0)'
+    stop 1
+  end subroutine fft_unavailable
+  subroutine decomp_2d_fft_init(pencil)
+    integer, intent(in) :: pencil
+    call fft_unavailable
+  end subroutine decomp_2d_fft_init
+  subroutine r2c_1m_x(input, output)
+    real(mytype), dimension(:, :, :), intent(in) :: input
+    complex(mytype), dimension(:, :, :), intent(out) :: output
+    call fft_unavailable
+  end subroutine r2c_1m_x
+  subroutine c2r_1m_x(input, output)
+    complex(mytype), dimension(:, :, :), intent(in) :: input
+    real(mytype), dimension(:, :, :), intent(out) :: output
+    call fft_unavailable
+  end subroutine c2r_1m_x
+  subroutine c2c_1m_y(inout, isign, plan1)
+    complex(mytype), dimension(:, :, :), intent(inout) :: inout
+    integer, intent(in) :: isign
+    integer(8), intent(in) :: plan1
+    call fft_unavailable
+  end subroutine c2c_1m_y
+  subroutine fft_3d_r2c(in_r, out_c)
+    real(mytype), dimension(:, :, :), intent(in) :: in_r
+    complex(mytype), dimension(:, :, :), intent(out) :: out_c
+    call fft_unavailable
+  end subroutine fft_3d_r2c
+  subroutine fft_3d_c2r(in_c, out_r)
+    complex(mytype), dimension(:, :, :), intent(in) :: in_c
+    real(mytype), dimension(:, :, :), intent(out) :: out_r
+    call fft_unavailable
+  end subroutine fft_3d_c2r
+end module decomp_2d_fft

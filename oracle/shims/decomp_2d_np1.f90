@@ -23,6 +23,7 @@ module decomp_2d
   integer, save, dimension(3) :: ystart, yend, ysize
   integer, save, dimension(3) :: zstart, zend, zsize
   integer, save :: DECOMP_2D_COMM_CART_X = 0, DECOMP_2D_COMM_CART_Y = 0, DECOMP_2D_COMM_CART_Z = 0
+  integer, save :: mycol = 0          ! y coordinate of this rank (always 0 here)
 
   type DECOMP_INFO
     integer, dimension(3) :: xst, xen, xsz

@@ -19,6 +19,7 @@
 #include "../fft_ref.h"
 
 /* ---------------------------------------------------------------- MPI np=1 */
+#ifndef WITH_REAL_MPI   /* the MPI baseline build links MPICH's libmpifort instead */
 static size_t tsize(int handle) { return (size_t)(handle / 100); }
 
 void mpi_init_(int *ierr) { *ierr = 0; }
@@ -56,6 +57,8 @@ double mpi_wtime_(void) {
   clock_gettime(CLOCK_MONOTONIC, &ts);
   return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
+
+#endif /* WITH_REAL_MPI */
 
 /* ------------------------------------------------------------ FFTW legacy */
 enum { K_R2C = 1, K_C2R = 2, K_REDFT10 = 3, K_REDFT01 = 4 };
