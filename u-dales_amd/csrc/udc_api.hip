@@ -4,6 +4,7 @@
 #include <cstring>
 #include <cmath>
 #include <cstdlib>
+#include <utility>
 
 static thread_local char g_err[512] = "";
 
@@ -113,6 +114,7 @@ extern "C" int udc_create(const udc_config *cfg, udc_handle **out) {
   h->mom_simple = getenv("UDC_MOM_SIMPLE") && atoi(getenv("UDC_MOM_SIMPLE")) != 0;
   h->no_pup = getenv("UDC_NO_PUP") && atoi(getenv("UDC_NO_PUP")) != 0;
   h->no_fold = getenv("UDC_NO_FOLD") && atoi(getenv("UDC_NO_FOLD")) != 0;
+  h->no_alias = getenv("UDC_NO_ALIAS") && atoi(getenv("UDC_NO_ALIAS")) != 0;
   h->slab = cfg->nranks > 1 || (getenv("UDC_FORCE_SLAB") && atoi(getenv("UDC_FORCE_SLAB")) != 0);
   g.py = g.ny + 2 * HY; g.pz = g.nz + 2 * HZ;
   g.sy = g.nx; g.sz = (long)g.nx * g.py; g.n = g.sz * g.pz;
@@ -202,11 +204,13 @@ static int field_ptr(udc_handle *h, int field, double **p) {
 }
 
 static int tend_clean(udc_handle *h);
+static int um_materialise(udc_handle *h);
 
 static int copy3d(udc_handle *h, int field, double *host, const int lb[3], const int ub[3], bool up) {
   double *dev;
   if (field_ptr(h, field, &dev)) return 1;
   if (field >= UDC_UP && field <= UDC_WP && tend_clean(h)) return 1;
+  if (field >= UDC_UM && field <= UDC_WM && um_materialise(h)) return 1;
   const Geo &g = h->g;
   const int hnx = ub[0] - lb[0] + 1, hny = ub[1] - lb[1] + 1;
   int i0 = lb[0] > 1 ? lb[0] : 1, i1 = ub[0] < g.nx ? ub[0] : g.nx;
@@ -269,6 +273,17 @@ static int tend_clean(udc_handle *h) {
   return 0;
 }
 
+// After RK stage 3 the fused substep does not copy u0,v0,w0 into um,vm,wm: it marks them aliased and
+// rotates the buffers at the next stage 1.  Anything that needs real um,vm,wm arrays comes through here.
+static int um_materialise(udc_handle *h) {
+  if (!h->um_alias) return 0;
+  for (int q = 0; q < 3; ++q)
+    HIP_OK(hipMemcpyAsync(h->fields[UDC_UM + q], h->fields[UDC_U0 + q], sizeof(double) * h->g.n,
+                          hipMemcpyDeviceToDevice, h->stream));
+  h->um_alias = false;
+  return 0;
+}
+
 // ------------------------------------------------------------------------------ call surface
 static int vel_fields(udc_handle *h, int rk3step, int *f) {
   int n = 0;
@@ -280,7 +295,7 @@ static int vel_fields(udc_handle *h, int rk3step, int *f) {
 
 extern "C" int udc_advection(udc_handle *h) {
   HIP_OK(hipSetDevice(h->device));
-  if (tend_clean(h)) return 1;
+  if (tend_clean(h) || um_materialise(h)) return 1;
   if ((h->mom_simple ? k_momentum(h, true, false, false) : k_momentum_lds(h, true, false, false, false, 0.))) return 1;
   for (int n = 0; n < h->cfg.nsv; ++n)
     if (k_scalar_adv(h, n)) return 1;
@@ -289,7 +304,7 @@ extern "C" int udc_advection(udc_handle *h) {
 
 extern "C" int udc_subgrid(udc_handle *h) {
   HIP_OK(hipSetDevice(h->device));
-  if (tend_clean(h)) return 1;
+  if (tend_clean(h) || um_materialise(h)) return 1;
   if (k_closure(h)) return 1;
   if (k_ek_ghosts(h)) return 1;
   if (k_top_rows_after_closure(h)) return 1;
@@ -301,13 +316,13 @@ extern "C" int udc_subgrid(udc_handle *h) {
 
 extern "C" int udc_forces(udc_handle *h) {
   HIP_OK(hipSetDevice(h->device));
-  if (tend_clean(h)) return 1;
+  if (tend_clean(h) || um_materialise(h)) return 1;
   return k_forces(h);
 }
 
 extern "C" int udc_poisson(udc_handle *h, int rk3step, double dt) {
   HIP_OK(hipSetDevice(h->device));
-  if (tend_clean(h)) return 1;
+  if (tend_clean(h) || um_materialise(h)) return 1;
   const double rk3coef = rk3step == 0 ? 1. : dt / (4. - (double)rk3step);
   const int fvp[1] = {UDC_VP};
   if (k_halo_y(h, fvp, 1, 1)) return 1;            // pvp(je+1) = pvp(jb): bcpup
@@ -323,7 +338,7 @@ extern "C" int udc_poisson(udc_handle *h, int rk3step, double dt) {
 
 extern "C" int udc_tstep_integrate(udc_handle *h, int rk3step, double dt) {
   HIP_OK(hipSetDevice(h->device));
-  if (tend_clean(h)) return 1;
+  if (tend_clean(h) || um_materialise(h)) return 1;
   return k_integrate(h, rk3step, dt);
 }
 
@@ -337,6 +352,7 @@ static int scalar_halo_list(udc_handle *h, int rk3step, std::vector<int> &f) {
 
 extern "C" int udc_halos(udc_handle *h) {
   HIP_OK(hipSetDevice(h->device));
+  if (um_materialise(h)) return 1;
   const int f[6] = {UDC_U0, UDC_V0, UDC_W0, UDC_UM, UDC_VM, UDC_WM};
   if (k_halo_y(h, f, 6, 1)) return 1;
   std::vector<int> s;
@@ -347,6 +363,7 @@ extern "C" int udc_halos(udc_handle *h) {
 
 extern "C" int udc_boundary(udc_handle *h) {
   HIP_OK(hipSetDevice(h->device));
+  if (um_materialise(h)) return 1;
   return k_top_bottom(h);
 }
 
@@ -368,6 +385,11 @@ extern "C" int udc_substep(udc_handle *h, int rk3step, double dt, int with_force
   // single slab (whole y extent local): the ghost-row/plane updates of closurebc, bcpup, bcp, halos and
   // boundary are written by the kernels that own the neighbouring cells -> 7 fewer launches per substep
   const bool fold = lds && !h->slab && !h->no_fold;
+  // um aliasing: stage 3 leaves um,vm,wm unwritten (== u0,v0,w0); stage 1 reads u0 in their place and
+  // writes the new u0,v0,w0 into the stale um buffers, then swaps the buffer pointers.
+  const bool alias_ok = pup && !h->no_alias;
+  if (h->um_alias && !(alias_ok && rk3step == 1)) { if (um_materialise(h)) return 1; }
+  const bool rotate = h->um_alias;                    // only true here for an aliased stage 1
   // closure first: it only needs u0,v0,w0, and the fused sweep below needs ekm
   if (fold && h->p.sgs != UDC_SGS_DNS) {
     if (k_closure_lds(h, true)) return 1;
@@ -375,7 +397,7 @@ extern "C" int udc_substep(udc_handle *h, int rk3step, double dt, int with_force
     if (k_closure(h)) return 1;
     if (k_ek_ghosts(h)) return 1;
   }
-  if (lds ? k_momentum_lds(h, true, true, with_forces != 0, true, pup ? 1. / rk3coef : 0.)
+  if (lds ? k_momentum_lds(h, true, true, with_forces != 0, true, pup ? 1. / rk3coef : 0., rotate)
           : k_momentum(h, true, true, with_forces != 0)) return 1;
   for (int n = 0; n < h->cfg.nsv; ++n)
     if (k_scalar_fused(h, n)) return 1;
@@ -389,11 +411,17 @@ extern "C" int udc_substep(udc_handle *h, int rk3step, double dt, int with_force
     const int fp[1] = {UDC_P};
     if (k_halo_y(h, fp, 1, 1)) return 1;
   }
-  if (k_project_integrate(h, rk3step, dt, !lds, pup, fold)) return 1;
+  const bool skip_um = alias_ok && rk3step == 3;
+  if (k_project_integrate(h, rk3step, dt, !lds, pup, fold, !skip_um, rotate)) return 1;
+  if (rotate) {
+    for (int q = 0; q < 3; ++q) std::swap(h->fields[UDC_U0 + q], h->fields[UDC_UM + q]);
+    h->um_alias = false;
+  }
+  if (skip_um) h->um_alias = true;
   h->tend_scratch = lds;
   if (!fold) {
     int f[8];
-    int nf = vel_fields(h, rk3step, f);
+    int nf = vel_fields(h, skip_um ? 0 : rk3step, f);
     f[nf++] = UDC_PRES0;
     if (k_halo_y(h, f, nf, 1)) return 1;
   }

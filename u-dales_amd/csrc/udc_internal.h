@@ -105,6 +105,9 @@ struct udc_handle {
   double *partials = nullptr;           // per-workgroup partial results of the two-stage reductions
   size_t partials_cap = 0;
   // profiling
+  bool um_alias = false;                // um,vm,wm are logically equal to u0,v0,w0 (after RK stage 3 of a fused
+                                        // substep); the UM buffers are stale until stage 1 rotates the pointers
+  bool no_alias = false;                // UDC_NO_ALIAS=1: always copy (A/B switch)
   bool tend_scratch = false;            // up,vp,wp hold leftovers of a fused substep (logically zero)
   bool no_fold = false;                 // UDC_NO_FOLD=1: keep separate ghost-row kernels on a single slab (A/B switch)
   bool no_pup = false;                  // UDC_NO_PUP=1: keep bare tendencies in the fused substep (A/B switch)
@@ -168,7 +171,7 @@ int k_closure(udc_handle *h);
 int k_closure_lds(udc_handle *h, bool ghosts);   // ghosts: closurebc folded in (single slab)
 int k_ek_ghosts(udc_handle *h);
 int k_momentum(udc_handle *h, bool adv, bool diff, bool forces);       // direct-load version (UDC_MOM_SIMPLE=1)
-int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, double rk3coefi);  // rk3coefi != 0: PUP mode   // LDS-staged k-marching version (default)
+int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, double rk3coefi, bool um_is_u0 = false);  // rk3coefi != 0: PUP mode   // LDS-staged k-marching version (default)
 int k_scalar_adv(udc_handle *h, int n);
 int k_scalar_diff(udc_handle *h, int n);
 int k_scalar_fused(udc_handle *h, int n);          // advection + diffusion in one sweep (same accumulation order)
@@ -177,7 +180,8 @@ int k_divergence_rhs(udc_handle *h, double rk3coef, bool pup);
 int k_poisson_solve(udc_handle *h);
 int k_project(udc_handle *h);                       // tderive: up,vp,wp -= grad p ; pres0 += p
 int k_integrate(udc_handle *h, int rk3step, double dt);
-int k_project_integrate(udc_handle *h, int rk3step, double dt, bool zero_tend, bool pup, bool ghosts);   // fused tderive + tstep_integrate
+int k_project_integrate(udc_handle *h, int rk3step, double dt, bool zero_tend, bool pup, bool ghosts,
+                        bool write_um = true, bool out_to_um = false);   // fused tderive + tstep_integrate
 int k_halo_y(udc_handle *h, const int *fields, int nf, int width);
 int k_top_bottom(udc_handle *h);
 int k_top_rows_after_closure(udc_handle *h);

@@ -27,6 +27,7 @@ struct MomArgs {
   const double *um, *vm, *wm;   // only read in PUP mode
   double rk3coefi;
   int wrap_vp;                  // single slab: also store row 0 of vp into ghost row ny (bcpup's cyclic pvp)
+  int um_is_u0;                 // RK stage 1 after an aliased stage 3: um == u0, already staged in LDS
 };
 
 template <int NF>
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(NT, MOM_WAVES) void mom_lds_kernel(Geo g, TileGrid 
     double tu = 0., tv = 0., tw = 0., p_c = 0., p_xm = 0., p_ym = 0., p_zm = 0., pum = 0., pvm = 0., pwm = 0.;
     if (inside) {
       if (!FRESH) { tu = a.up[c]; tv = a.vp[c]; tw = a.wp[c]; }
-      if (PUP) { pum = a.um[c]; pvm = a.vm[c]; pwm = a.wm[c]; }
+      if (PUP && !a.um_is_u0) { pum = a.um[c]; pvm = a.vm[c]; pwm = a.wm[c]; }
       if (ADV) { p_c = a.p[c]; p_xm = a.p[c + xm_off]; p_ym = a.p[c - g.sy]; p_zm = a.p[c - g.sz]; }
     }
     // everyone has finished level k-1 (last readers of buffer bn) and committed plane k+1
@@ -147,6 +148,7 @@ __global__ __launch_bounds__(NT, MOM_WAVES) void mom_lds_kernel(Geo g, TileGrid 
       }
       mom_arith<ADV, DIFF, LES, FORCES>(q, m, k, numol, tu, tv, tw);
       if (PUP) {
+        if (a.um_is_u0) { pum = q.u_c; pvm = q.v_c; pwm = q.w_c; }
         tu = tu + pum * a.rk3coefi;
         tv = tv + pvm * a.rk3coefi;
         tw = (k == 0) ? 0. : tw + pwm * a.rk3coefi;
@@ -299,12 +301,12 @@ int k_closure_lds(udc_handle *h, bool ghosts) {
   return 0;
 }
 
-int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, double rk3coefi) {
+int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, double rk3coefi, bool um_is_u0) {
   const bool pup = fresh && rk3coefi != 0.;
   const Geo &g = h->g;
   MomArgs a{h->fields[UDC_U0], h->fields[UDC_V0], h->fields[UDC_W0], h->fields[UDC_PRES0],
             h->fields[UDC_EKM], h->fields[UDC_UP], h->fields[UDC_VP], h->fields[UDC_WP],
-            h->fields[UDC_UM], h->fields[UDC_VM], h->fields[UDC_WM], rk3coefi, (fresh && !h->slab) ? 1 : 0};
+            h->fields[UDC_UM], h->fields[UDC_VM], h->fields[UDC_WM], rk3coefi, (fresh && !h->slab) ? 1 : 0, um_is_u0 ? 1 : 0};
   const TileGrid tg = tile_grid(g);
   // k-chunk: long enough to amortise the 2-plane prologue, short enough to fill 256 CUs x 4 workgroups
   int kc = pick_kc(g, tg);

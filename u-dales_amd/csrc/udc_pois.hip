@@ -304,21 +304,22 @@ __global__ __launch_bounds__(256) void integrate_kernel(Geo g, TileGrid tg, Metr
   if (ghosts && k == 0) w = 0.;                     // boundary: w(kb) = 0
   a.u0[c] = u; a.v0[c] = v; a.w0[c] = w;
   if (ZERO) { a.up[c] = 0.; a.vp[c] = 0.; a.wp[c] = 0.; }
-  if (last) { a.um[c] = u; a.vm[c] = v; a.wm[c] = w; }
+  const bool last_m = (last & 1) != 0, last_s = (last & 2) != 0;   // write um.. / write svm..
+  if (last_m) { a.um[c] = u; a.vm[c] = v; a.wm[c] = w; }
   if (ghosts) {
     if (wr) {
       a.u0[c + wr] = u; a.v0[c + wr] = v; a.w0[c + wr] = w;
-      if (last) { a.um[c + wr] = u; a.vm[c + wr] = v; a.wm[c + wr] = w; }
+      if (last_m) { a.um[c + wr] = u; a.vm[c + wr] = v; a.wm[c + wr] = w; }
     }
     if (k == g.nz - 1) {
       const bool ns = pr.bctopm == UDC_TOP_NOSLIP;
       const double ut = ns ? 2 * pr.uinf - u : u, vt = ns ? 2 * pr.vinf - v : v;
       const long t = c + g.sz;
       a.u0[t] = ut; a.v0[t] = vt; a.w0[t] = 0.;
-      if (last) { a.um[t] = ut; a.vm[t] = vt; a.wm[t] = 0.; }
+      if (last_m) { a.um[t] = ut; a.vm[t] = vt; a.wm[t] = 0.; }
       if (wr) {
         a.u0[t + wr] = ut; a.v0[t + wr] = vt; a.w0[t + wr] = 0.;
-        if (last) { a.um[t + wr] = ut; a.vm[t + wr] = vt; a.wm[t + wr] = 0.; }
+        if (last_m) { a.um[t + wr] = ut; a.vm[t + wr] = vt; a.wm[t + wr] = 0.; }
       }
     }
   }
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(256) void integrate_kernel(Geo g, TileGrid tg, Metr
     const double sv = a.svm[s][c] + rk3coef * a.svp[s][c];
     a.sv0[s][c] = sv;
     a.svp[s][c] = 0.;
-    if (last) a.svm[s][c] = sv;
+    if (last_s) a.svm[s][c] = sv;
   }
 }
 
@@ -798,25 +799,29 @@ int k_integrate(udc_handle *h, int rk3step, double dt) {
   const double rk3coef = dt / (4. - (double)rk3step);
   PROF(h, "integrate");
   hipLaunchKernelGGL((integrate_kernel<false, true, false>), gr, b, 0, h->stream, g, tile_grid(g), h->m, int_args(h),
-                     (const double *)nullptr, (double *)nullptr, rk3coef, rk3step == 3 ? 1 : 0, 0, h->p);
+                     (const double *)nullptr, (double *)nullptr, rk3coef, rk3step == 3 ? 3 : 0, 0, h->p);
   HIP_OK(hipGetLastError());
   return 0;
 }
 
-int k_project_integrate(udc_handle *h, int rk3step, double dt, bool zero_tend, bool pup, bool ghosts) {
+int k_project_integrate(udc_handle *h, int rk3step, double dt, bool zero_tend, bool pup, bool ghosts,
+                        bool write_um, bool out_to_um) {
   const Geo &g = h->g;
   dim3 b(64, 4, 1), gr = cell_grid(g, b);
   const double rk3coef = dt / (4. - (double)rk3step);
   PROF(h, "project_integrate");
+  const int lastf = rk3step == 3 ? (write_um ? 3 : 2) : 0;
+  IntArgs ia = int_args(h);
+  if (out_to_um) { ia.u0 = ia.um; ia.v0 = ia.vm; ia.w0 = ia.wm; }   // pointer rotation at RK stage 1 (um_alias)
   if (pup)
-    hipLaunchKernelGGL((integrate_kernel<true, false, true>), gr, b, 0, h->stream, g, tile_grid(g), h->m, int_args(h),
-                       (const double *)h->fields[UDC_P], h->fields[UDC_PRES0], rk3coef, rk3step == 3 ? 1 : 0, ghosts ? 1 : 0, h->p);
+    hipLaunchKernelGGL((integrate_kernel<true, false, true>), gr, b, 0, h->stream, g, tile_grid(g), h->m, ia,
+                       (const double *)h->fields[UDC_P], h->fields[UDC_PRES0], rk3coef, lastf, ghosts ? 1 : 0, h->p);
   else if (zero_tend)
-    hipLaunchKernelGGL((integrate_kernel<true, true, false>), gr, b, 0, h->stream, g, tile_grid(g), h->m, int_args(h),
-                       (const double *)h->fields[UDC_P], h->fields[UDC_PRES0], rk3coef, rk3step == 3 ? 1 : 0, ghosts ? 1 : 0, h->p);
+    hipLaunchKernelGGL((integrate_kernel<true, true, false>), gr, b, 0, h->stream, g, tile_grid(g), h->m, ia,
+                       (const double *)h->fields[UDC_P], h->fields[UDC_PRES0], rk3coef, lastf, ghosts ? 1 : 0, h->p);
   else
-    hipLaunchKernelGGL((integrate_kernel<true, false, false>), gr, b, 0, h->stream, g, tile_grid(g), h->m, int_args(h),
-                       (const double *)h->fields[UDC_P], h->fields[UDC_PRES0], rk3coef, rk3step == 3 ? 1 : 0, ghosts ? 1 : 0, h->p);
+    hipLaunchKernelGGL((integrate_kernel<true, false, false>), gr, b, 0, h->stream, g, tile_grid(g), h->m, ia,
+                       (const double *)h->fields[UDC_P], h->fields[UDC_PRES0], rk3coef, lastf, ghosts ? 1 : 0, h->p);
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -833,8 +838,9 @@ int k_maxima(udc_handle *h, double dt, double *cour, double *diffn) {
   const Geo &g = h->g;
   dim3 b(64, 4, 1), gr = cell_grid(g, b);
   if (ensure_partials(h, gr.x)) return 1;
-  hipLaunchKernelGGL(maxima_kernel, gr, b, 0, h->stream, g, tile_grid(g), h->m, dt, h->fields[UDC_UM], h->fields[UDC_VM],
-                     h->fields[UDC_WM], h->fields[UDC_EKM], h->fields[UDC_EKH], h->partials);
+  const int mo = h->um_alias ? UDC_U0 : UDC_UM;      // aliased: um == u0
+  hipLaunchKernelGGL(maxima_kernel, gr, b, 0, h->stream, g, tile_grid(g), h->m, dt, h->fields[mo], h->fields[mo + 1],
+                     h->fields[mo + 2], h->fields[UDC_EKM], h->fields[UDC_EKH], h->partials);
   // diffnrtotl starts at 1e-5, src/modtstep.f90:115
   hipLaunchKernelGGL((reduce_partials_kernel<0, 0>), dim3(1), dim3(1024), 0, h->stream, h->partials, (long)gr.x, 0.,
                      1e-5, h->red);
