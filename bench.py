@@ -38,7 +38,7 @@ ALGO_BYTES = {
     "mom": 88,                  # read u0,v0,w0,pres0,ekm (40) + um,vm,wm (24); write pup,pvp,pwp (24)
     "div_rhs": 32,              # read pup,pvp,pwp; write p
     "fft_fwd": 32, "fft_bwd": 32,   # 2 passes x (8 read + 8 write)
-    "thomas": 24,               # SURVEY's figure (this kernel's own compulsory traffic is 36 B)
+    "thomas": 24,               # x read once, written once (LDS-resident columns) + pivot table read twice
     "project_integrate": 72,    # read p (8), pup,pvp,pwp (24); RMW pres0 (16); write u0,v0,w0 (24)
     "scalar": 56,
     # slab (multi-GPU) Poisson stages

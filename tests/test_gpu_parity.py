@@ -191,8 +191,11 @@ def oracle_state(st, g, nsv):
     ((4, 4, 3), 0, 0, 1.00),         # smallest grid the library accepts, DNS
     ((128, 8, 6), 1, 2, 1.10),       # ragged aspect, two scalars
 ])
-def test_against_oracle_seeded(shape, sgs, nsv, stretch):
-    """Three substeps (one RK3 step) vs the CPU oracle on seeded random fields."""
+@pytest.mark.parametrize("thomas", ["0", "3"], ids=["thomas-stream", "thomas-lds"])
+def test_against_oracle_seeded(shape, sgs, nsv, stretch, thomas, monkeypatch):
+    """Three substeps (one RK3 step) vs the CPU oracle on seeded random fields, with either variant of
+    the tridiagonal solve (UDC_THOMAS: 0 = streaming kernel, 3 = LDS-resident columns)."""
+    monkeypatch.setenv("UDC_THOMAS", thomas)
     nx, ny, nz = shape
     dz = 0.5 * stretch ** np.arange(nz)
     zf = np.cumsum(dz) - 0.5 * dz

@@ -89,7 +89,7 @@ struct udc_handle {
   double *metrics_dev = nullptr;        // backing store for Metrics arrays
   // Poisson
   double *spec = nullptr;               // complex (nkx, ny, nz) spectral work array
-  double *dtab = nullptr;               // Thomas d(kx,ky,k) table
+  double *ztab = nullptr;               // Thomas d(kx,ky,k) table
   double *ev = nullptr;                 // eigenvalue xrt(kx)+yrt(ky)
   double *tri = nullptr;                // a,b,c (3*(nz+2))
   int nkx = 0, nkxp = 0;                // r2c modes in x and the padded row pitch of `spec`
@@ -130,7 +130,7 @@ struct udc_handle {
   hipStream_t comm_stream = nullptr;    // all-to-all exchanges run here, overlapped with rocFFT on `stream`
   hipEvent_t ev_ready[16] = {}, ev_done[16] = {};
   double *specA = nullptr, *specB = nullptr, *a2a_send = nullptr, *a2a_recv = nullptr;
-  double *ev_slab = nullptr, *dtab_slab = nullptr;
+  double *ev_slab = nullptr, *ztab_slab = nullptr;
   rocfft_plan plan_xf = nullptr, plan_xb = nullptr, plan_yf = nullptr, plan_yb = nullptr;
   rocfft_execution_info info_x = nullptr, info_y = nullptr;
   void *fft_work_slab = nullptr;

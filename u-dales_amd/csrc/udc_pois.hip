@@ -52,21 +52,22 @@ __global__ __launch_bounds__(256) void div_rhs_kernel(Geo g, TileGrid tg, Metric
   p[c] = (pu_p - pu_c) * m.dxi + (pv_p - pv_c) * m.dyi + (pw_p - pw_c) * m.dzfi[k + 1];
 }
 
-// ---- Thomas tables: d(m,k) of solmpj (src/modpois.f90:1120-1139) does not depend on the RHS
+// ---- Thomas table: the pivots z(m,k) = 1/(b_k + e_m - a_k d_{k-1}) of solmpj (src/modpois.f90:1120-1139)
+// do not depend on the RHS; d(m,k) = c_k z(m,k) is rebuilt from it with the reference's own multiply.
 __global__ void thomas_table_kernel(int nmodes, int nz, const double *__restrict__ ev,
-                                    const double *__restrict__ tri, double btopD, double *__restrict__ dtab) {
+                                    const double *__restrict__ tri, double btopD, double *__restrict__ ztab) {
   const int mo = blockIdx.x * blockDim.x + threadIdx.x;
   if (mo >= nmodes) return;
   const double *a = tri, *b = tri + (nz + 2), *c = tri + 2 * (nz + 2);
   const double e = ev[mo];
   double z = 1. / (b[1] + e);
   double d = c[1] * z;
-  dtab[mo] = d;
+  ztab[mo] = z;
   for (int k = 2; k <= nz - 1; ++k) {
     const double bbk = b[k] + e;
     z = 1. / (bbk - a[k] * d);
     d = c[k] * z;
-    dtab[(long)(k - 1) * nmodes + mo] = d;
+    ztab[(long)(k - 1) * nmodes + mo] = z;
   }
   (void)btopD;
 }
@@ -82,7 +83,7 @@ __global__ void thomas_table_kernel(int nmodes, int nz, const double *__restrict
 constexpr int TU = THOMAS_TU;
 __global__ __launch_bounds__(64) void thomas_kernel(int nmodes, int nz, double scale,
     const double *__restrict__ ev, const double *__restrict__ tri, double btopD,
-    const double *__restrict__ dtab, double2 *__restrict__ x) {
+    const double *__restrict__ ztab, double2 *__restrict__ x) {
   const int mo = blockIdx.x * blockDim.x + threadIdx.x;
   if (mo >= nmodes) return;
   const double *a = tri, *b = tri + (nz + 2), *c = tri + 2 * (nz + 2);
@@ -108,8 +109,9 @@ __global__ __launch_bounds__(64) void thomas_kernel(int nmodes, int nz, double s
         z = 1. / (bbk - a[k] * d);
         d = c[k] * z;
         double2 xc = buf[u];
-        xc.x = (xc.x * scale - a[k] * xp.x) * z;
-        xc.y = (xc.y * scale - a[k] * xp.y) * z;
+        const double gz = -(a[k] * z);
+        xc.x = __builtin_fma(gz, xp.x, (xc.x * scale) * z);
+        xc.y = __builtin_fma(gz, xp.y, (xc.y * scale) * z);
         buf[u] = xc;
         xp = xc;
       }
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(64) void thomas_kernel(int nmodes, int nz, double s
     xp = xc;
   }
   // back substitution, levels nz-1 .. 1
-  const double *dm = dtab + mo;
+  const double *dm = ztab + mo;
   for (int k0 = nz - 1; k0 >= 1; k0 -= TU) {
     double2 buf[TU];
     double dk[TU];
@@ -141,8 +143,9 @@ __global__ __launch_bounds__(64) void thomas_kernel(int nmodes, int nz, double s
     for (int u = 0; u < TU; ++u)
       if (k0 - u >= 1) {
         double2 xc = buf[u];
-        xc.x = xc.x - dk[u] * xp.x;
-        xc.y = xc.y - dk[u] * xp.y;
+        const double dd = -(c[k0 - u] * dk[u]);
+        xc.x = __builtin_fma(dd, xp.x, xc.x);
+        xc.y = __builtin_fma(dd, xp.y, xc.y);
         buf[u] = xc;
         xp = xc;
       }
@@ -150,6 +153,210 @@ __global__ __launch_bounds__(64) void thomas_kernel(int nmodes, int nz, double s
     for (int u = 0; u < TU; ++u)
       if (k0 - u >= 1) xm[(size_t)(k0 - u - 1) * st] = buf[u];
   }
+}
+
+// LDS-resident variant of the same solve.  A workgroup owns M consecutive modes (2M independent real
+// systems: the matrix is real, so real and imaginary parts never mix) and keeps their whole column in LDS,
+// so x is read from HBM once and written once; the pivot table streams through twice (forward / back).
+// All 256 threads move data in k-chunks of KC levels: the next chunk's global loads are in flight while
+// lanes 0..2M-1 run the recurrence on the current one.  The movers also do every product that does not
+// involve the neighbouring level, so the serial part is one fma per level:
+//   forward  x_k = (x_k s - a_k x_{k-1}) z_k   as  fma(-(a_k z_k), x_{k-1}, (x_k s) z_k)
+//   back     x_k = x_k - (c_k z_k) x_{k+1}     as  fma(-(c_k z_k), x_{k+1}, x_k)
+// (thomas_kernel evaluates the same expressions, so the result does not depend on which variant runs).
+template <int M, int KC>
+__global__ __launch_bounds__(256) void thomas_lds_kernel(int nmodes, int nz, double scale,
+    const double *__restrict__ ev, const double *__restrict__ tri, double btopD,
+    const double *__restrict__ ztab, double2 *__restrict__ x) {
+  constexpr int C = 2 * M;                 // doubles per level
+  constexpr int R = KC * M / 256;          // staged elements per thread per chunk
+  constexpr int U = 8;                     // levels per register group in the recurrence
+  static_assert(KC * M % 256 == 0 && KC % U == 0, "chunk must tile the workgroup");
+  extern __shared__ double lds_[];
+  double *xs = lds_;                       // [nz][C]   (x_k s) z_k, then x'_k, then the solution
+  double *zb = lds_ + (size_t)nz * C;      // [2][KC][M] -(a_k z_k) forward, -(c_k z_k) back
+  double *zt = zb + 2 * KC * M;            // [KC][M]   -(c_k z_k) of the top chunk, written by the forward sweep
+  const int tid = threadIdx.x;
+  const int m0 = blockIdx.x * M;
+  const double *a = tri, *b = tri + (nz + 2), *c = tri + 2 * (nz + 2);
+  const size_t st = (size_t)nmodes;
+  const int nch = (nz + KC - 1) / KC;
+
+  double2 rx[R];
+  double rz[R], rg[R], rt[R];
+  // fwd: x, z, a (and c for the top chunk); back: z, c
+  auto issue = [&](int ch, bool fwd) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int idx = tid + 256 * r;
+      const int kk = idx / M, mm = idx % M;
+      const int lev = ch * KC + kk;        // 0-based level, k = lev + 1
+      const bool ok = lev < nz && m0 + mm < nmodes;
+      if (fwd) rx[r] = ok ? x[(size_t)lev * st + m0 + mm] : make_double2(0., 0.);
+      rz[r] = (ok && lev < nz - 1) ? ztab[(size_t)lev * st + m0 + mm] : 1.;
+      const int kc_ = min(lev + 1, nz);
+      rg[r] = fwd ? a[kc_] : c[kc_];
+      if (fwd && ch == nch - 1) rt[r] = c[kc_];
+    }
+  };
+  auto commit = [&](int ch, bool fwd) {
+    double *zc = zb + (ch & 1) * (KC * M);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int idx = tid + 256 * r;
+      const int kk = idx / M, mm = idx % M;
+      const int lev = ch * KC + kk;
+      if (fwd && lev < nz) {
+        double2 t = rx[r];
+        t.x = (t.x * scale) * rz[r];
+        t.y = (t.y * scale) * rz[r];
+        *reinterpret_cast<double2 *>(xs + (size_t)lev * C + 2 * mm) = t;
+      }
+      zc[kk * M + mm] = -(rg[r] * rz[r]);
+      if (fwd && ch == nch - 1) zt[kk * M + mm] = -(rt[r] * rz[r]);
+    }
+  };
+
+  // the last pivot of the forward sweep is needed again when the top level is closed
+  double zl = 0.;
+  if (tid < C && nz >= 2) zl = ztab[(size_t)(nz - 2) * st + min(m0 + (tid >> 1), nmodes - 1)];
+  issue(0, true);
+  commit(0, true);
+  __syncthreads();
+  double xp = 0.;
+  // forward elimination, levels 1 .. nz-1 (0-based 0 .. nz-2)
+  for (int ch = 0; ch < nch; ++ch) {
+    if (ch + 1 < nch) issue(ch + 1, true);
+    if (tid < C) {
+      const double *zc = zb + (ch & 1) * (KC * M) + (tid >> 1);
+      const int l0 = ch * KC;
+      const int l1 = min(l0 + KC, nz - 1);
+      // U levels at a time with two register sets: the next group's operands are requested before the
+      // dependent chain of the current group runs
+      const int nfull = (l1 - l0) / U;
+      double tA[U], gA[U], tB[U], gB[U];
+      auto ld = [&](int lb, double (&T)[U], double (&G)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          T[u] = xs[(size_t)(lb + u) * C + tid];
+          G[u] = zc[(lb + u - l0) * M];
+        }
+      };
+      auto run = [&](int lb, double (&T)[U], double (&G)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) { xp = __builtin_fma(G[u], xp, T[u]); T[u] = xp; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) xs[(size_t)(lb + u) * C + tid] = T[u];
+      };
+      if (nfull > 0) ld(l0, tA, gA);
+      for (int gi = 0; gi < nfull; gi += 2) {
+        const int lb = l0 + gi * U;
+        if (gi + 1 < nfull) ld(lb + U, tB, gB);
+        run(lb, tA, gA);
+        if (gi + 1 < nfull) {
+          if (gi + 2 < nfull) ld(lb + 2 * U, tA, gA);
+          run(lb + U, tB, gB);
+        }
+      }
+      for (int lev = l0 + nfull * U; lev < l1; ++lev) {
+        xp = __builtin_fma(zc[(lev - l0) * M], xp, xs[(size_t)lev * C + tid]);
+        xs[(size_t)lev * C + tid] = xp;
+      }
+    }
+    if (ch + 1 < nch) commit(ch + 1, true);
+    __syncthreads();
+  }
+  // close the forward sweep: the top level (stored as x_nz s, its "pivot" slot was 1)
+  if (tid < C) {
+    const int mo = min(m0 + (tid >> 1), nmodes - 1);
+    const double e = ev[mo];
+    // the singular (0,0) mode gets a Dirichlet condition across the top cell (:209-220)
+    const double bbk = (e == 0.) ? btopD : b[nz] + e;
+    const double ak = a[nz];
+    const double d = c[nz - 1] * zl;
+    const double z = bbk - ak * d;
+    const double xc = (xs[(size_t)(nz - 1) * C + tid] - ak * xp) / z;
+    xs[(size_t)(nz - 1) * C + tid] = xc;
+    xp = xc;
+  }
+  // back substitution, levels nz-1 .. 1, chunk by chunk from the top; finished chunks stream out
+  for (int ch = nch - 1; ch >= 0; --ch) {
+    if (ch > 0) issue(ch - 1, false);
+    if (tid < C) {
+      const double *zc = (ch == nch - 1 ? zt : zb + (ch & 1) * (KC * M)) + (tid >> 1);
+      const int l0 = ch * KC;
+      const int l1 = min(l0 + KC, nz - 1);
+      const int nfull = (l1 - l0) / U;
+      // the chunk's ragged top (levels above the last full group) first, then full groups, pipelined
+      for (int lev = l1 - 1; lev >= l0 + nfull * U; --lev) {
+        xp = __builtin_fma(zc[(lev - l0) * M], xp, xs[(size_t)lev * C + tid]);
+        xs[(size_t)lev * C + tid] = xp;
+      }
+      double tA[U], gA[U], tB[U], gB[U];
+      auto ld = [&](int lb, double (&T)[U], double (&G)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          T[u] = xs[(size_t)(lb + u) * C + tid];
+          G[u] = zc[(lb + u - l0) * M];
+        }
+      };
+      auto run = [&](int lb, double (&T)[U], double (&G)[U]) {
+#pragma unroll
+        for (int u = U - 1; u >= 0; --u) { xp = __builtin_fma(G[u], xp, T[u]); T[u] = xp; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) xs[(size_t)(lb + u) * C + tid] = T[u];
+      };
+      if (nfull > 0) ld(l0 + (nfull - 1) * U, tA, gA);
+      for (int gi = nfull - 1; gi >= 0; gi -= 2) {
+        const int lb = l0 + gi * U;
+        if (gi > 0) ld(lb - U, tB, gB);
+        run(lb, tA, gA);
+        if (gi > 0) {
+          if (gi > 1) ld(lb - 2 * U, tA, gA);
+          run(lb - U, tB, gB);
+        }
+      }
+    }
+    if (ch > 0) commit(ch - 1, false);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int idx = tid + 256 * r;
+      const int kk = idx / M, mm = idx % M;
+      const int lev = ch * KC + kk;
+      if (lev < nz && m0 + mm < nmodes)
+        x[(size_t)lev * st + m0 + mm] = *reinterpret_cast<const double2 *>(xs + (size_t)lev * C + 2 * mm);
+    }
+  }
+}
+
+// picks the LDS variant that fits (two workgroups per CU when possible), else the streaming kernel
+static int launch_thomas(udc_handle *h, long nmodes, int nz, double scale, const double *ev, const double *ztab, double2 *x) {
+  // UDC_THOMAS: 0 = streaming kernel, 3 = LDS kernel whenever it fits; default: the LDS kernel where the
+  // streaming one would put fewer than ~6 waves on a CU (it needs that many to cover HBM latency), measured
+  // cross-over on MI355X between 68K modes (LDS 15 % faster) and 135K modes (streaming 5 % faster)
+  const char *env = getenv("UDC_THOMAS");
+  const int mode = env ? atoi(env) : -1;
+  const size_t full = 160 * 1024 - 1024;
+  auto need = [&](int M, int KC) { return ((size_t)nz * 2 * M + 3 * (size_t)KC * M) * sizeof(double); };
+#define UDC_TL(M, KC)                                                                                        \
+  do {                                                                                                       \
+    static bool attr_done = false;                                                                           \
+    if (!attr_done) {                                                                                        \
+      if (hipFuncSetAttribute((const void *)thomas_lds_kernel<M, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)full) != hipSuccess) return 1;                                            \
+      attr_done = true;                                                                                      \
+    }                                                                                                        \
+    hipLaunchKernelGGL((thomas_lds_kernel<M, KC>), dim3((unsigned)((nmodes + M - 1) / M)), dim3(256), need(M, KC), \
+                       h->stream, (int)nmodes, nz, scale, ev, h->tri, h->btopD, ztab, x);                    \
+    return 0;                                                                                                \
+  } while (0)
+  const bool want_lds = mode == 3 || (mode < 0 && nmodes <= 98304);
+  if (want_lds && nz >= 2 && need(8, 32) <= full) UDC_TL(8, 32);   // 4 workgroups per CU at nz = 256, 2 at nz = 512
+#undef UDC_TL
+  hipLaunchKernelGGL(thomas_kernel, dim3((unsigned)((nmodes + 63) / 64)), dim3(64), 0, h->stream, (int)nmodes, nz, scale,
+                     ev, h->tri, h->btopD, ztab, x);
+  return 0;
 }
 
 // compact (nx,ny,nz) <-> padded field interior (only used when rocFFT rejects the padded layout)
@@ -452,13 +659,13 @@ int pois_init(udc_handle *h) {
 
   HIP_OK(hipMalloc(&h->spec, sizeof(double) * 2 * nmodes * nz));
   HIP_OK(hipMemsetAsync(h->spec, 0, sizeof(double) * 2 * nmodes * nz, h->stream));
-  HIP_OK(hipMalloc(&h->dtab, sizeof(double) * nmodes * (nz > 1 ? nz - 1 : 1)));
+  HIP_OK(hipMalloc(&h->ztab, sizeof(double) * nmodes * (nz > 1 ? nz - 1 : 1)));
   HIP_OK(hipMalloc(&h->ev, sizeof(double) * nmodes));
   HIP_OK(hipMalloc(&h->tri, sizeof(double) * tri.size()));
   HIP_OK(hipMemcpy(h->ev, ev.data(), sizeof(double) * nmodes, hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(h->tri, tri.data(), sizeof(double) * tri.size(), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(thomas_table_kernel, dim3((unsigned)((nmodes + 63) / 64)), dim3(64), 0, h->stream,
-                     (int)nmodes, nz, h->ev, h->tri, b_top_D, h->dtab);
+                     (int)nmodes, nz, h->ev, h->tri, b_top_D, h->ztab);
   HIP_OK(hipGetLastError());
 
   // rocFFT: batched 2-D real <-> Hermitian-interleaved, reading/writing the padded p field
@@ -573,12 +780,12 @@ int pois_slab_init(udc_handle *h) {
   HIP_OK(hipMalloc(&h->a2a_send, sizeof(double) * 2 * nmodes * nz));
   HIP_OK(hipMalloc(&h->a2a_recv, sizeof(double) * 2 * nmodes * nz));
   HIP_OK(hipMalloc(&h->ev_slab, sizeof(double) * nmodes));
-  HIP_OK(hipMalloc(&h->dtab_slab, sizeof(double) * nmodes * (nz > 1 ? nz - 1 : 1)));
+  HIP_OK(hipMalloc(&h->ztab_slab, sizeof(double) * nmodes * (nz > 1 ? nz - 1 : 1)));
   HIP_OK(hipMalloc(&h->tri, sizeof(double) * tri.size()));
   HIP_OK(hipMemcpy(h->ev_slab, ev.data(), sizeof(double) * nmodes, hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(h->tri, tri.data(), sizeof(double) * tri.size(), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(thomas_table_kernel, dim3((unsigned)((nmodes + 63) / 64)), dim3(64), 0, h->stream,
-                     (int)nmodes, nz, h->ev_slab, h->tri, btopD, h->dtab_slab);
+                     (int)nmodes, nz, h->ev_slab, h->tri, btopD, h->ztab_slab);
   HIP_OK(hipGetLastError());
 
   static bool setup_done = false;
@@ -665,9 +872,8 @@ int k_poisson_solve_slab(udc_handle *h) {
   }
   {
     PROF(h, "thomas");
-    hipLaunchKernelGGL(thomas_kernel, dim3((unsigned)((nmodes + 63) / 64)), dim3(64), 0, h->stream, (int)nmodes,
-                       g.nz, 1. / ((double)g.nx * (double)ny), h->ev_slab, h->tri, h->btopD, h->dtab_slab,
-                       reinterpret_cast<double2 *>(h->specB));
+    if (launch_thomas(h, nmodes, g.nz, 1. / ((double)g.nx * (double)ny), h->ev_slab, h->ztab_slab,
+                      reinterpret_cast<double2 *>(h->specB))) return 1;
     HIP_OK(hipGetLastError());
   }
   {
@@ -705,7 +911,7 @@ void pois_destroy(udc_handle *h) {
   if (h->fft_work) hipFree(h->fft_work);
   if (h->spec) hipFree(h->spec);
   if (h->rbuf) hipFree(h->rbuf);
-  if (h->dtab) hipFree(h->dtab);
+  if (h->ztab) hipFree(h->ztab);
   if (h->ev) hipFree(h->ev);
   if (h->tri) hipFree(h->tri);
   if (h->partials) hipFree(h->partials);
@@ -714,7 +920,7 @@ void pois_destroy(udc_handle *h) {
   if (h->info_x) rocfft_execution_info_destroy(h->info_x);
   if (h->comm_stream) hipStreamDestroy(h->comm_stream);
   for (int c = 0; c < 16; ++c) { if (h->ev_ready[c]) hipEventDestroy(h->ev_ready[c]); if (h->ev_done[c]) hipEventDestroy(h->ev_done[c]); }
-  double *bufs[7] = {h->specA, h->specB, h->a2a_send, h->a2a_recv, h->ev_slab, h->dtab_slab, (double *)h->fft_work_slab};
+  double *bufs[7] = {h->specA, h->specB, h->a2a_send, h->a2a_recv, h->ev_slab, h->ztab_slab, (double *)h->fft_work_slab};
   for (auto b : bufs) if (b) hipFree(b);
 }
 
@@ -751,9 +957,8 @@ int k_poisson_solve(udc_handle *h) {
   }
   {
     PROF(h, "thomas");
-    hipLaunchKernelGGL(thomas_kernel, dim3((unsigned)((nmodes + 63) / 64)), dim3(64), 0, h->stream, (int)nmodes,
-                       g.nz, 1. / ((double)g.nx * (double)g.ny), h->ev, h->tri, h->btopD, h->dtab,
-                       reinterpret_cast<double2 *>(h->spec));
+    if (launch_thomas(h, nmodes, g.nz, 1. / ((double)g.nx * (double)g.ny), h->ev, h->ztab,
+                      reinterpret_cast<double2 *>(h->spec))) return 1;
     HIP_OK(hipGetLastError());
   }
   {
