@@ -15,11 +15,22 @@
 
 namespace {
 
-constexpr int LX = TX + 2, LY = TY + 2, LN = LX * LY;   // 66 x 6 = 396 doubles per field-plane
-constexpr int NT = TX * TY;                               // 256 threads
+// Tile of the two stencil kernels: 32 x 8 rather than the 64 x 4 of the streaming kernels -- (34 x 10)/(32 x 8)
+// = 1.33 halo overhead instead of 1.55, and 19 field-planes of it fit three workgroups into a CU's 160 KB.
+#ifndef MOM_TX
+#define MOM_TX 32
+#define MOM_TY 8
+#endif
+constexpr int MX = MOM_TX, MY = MOM_TY;
+constexpr int LX = MX + 2, LY = MY + 2, LN = LX * LY;   // 34 x 10 = 340 doubles per field-plane
+constexpr int NT = MX * MY;                               // 256 threads
+static_assert(NT == 256 && LN - NT <= NT, "one own cell and at most one halo cell per thread");
 #ifndef MOM_WAVES
 #define MOM_WAVES 3
 #endif
+static TileGrid lds_tile_grid(const Geo &g) {
+  TileGrid t; t.gx = (g.nx + MX - 1) / MX; t.gy = (g.ny + MY - 1) / MY; t.tiles = t.gx * t.gy; return t;
+}
 
 struct MomArgs {
   const double *u, *v, *w, *p, *ek;
@@ -38,7 +49,7 @@ struct Stage {            // values of one plane held in registers between "load
 
 // tile element e (0..LN-1) -> offset from the plane's row base; halo elements are e >= NT
 __device__ __forceinline__ void halo_coords(int e, int &lx, int &ly) {
-  // enumerate the 140 halo cells: rows 0 and LY-1 fully (2*66), then columns 0 and LX-1 of rows 1..LY-2 (2*4)
+  // enumerate the halo cells: rows 0 and LY-1 fully (2*LX), then columns 0 and LX-1 of rows 1..LY-2 (2*MY)
   if (e < LX) { ly = 0; lx = e; }
   else if (e < 2 * LX) { ly = LY - 1; lx = e - LX; }
   else { const int r = e - 2 * LX; ly = 1 + (r >> 1); lx = (r & 1) ? LX - 1 : 0; }
@@ -52,6 +63,7 @@ template <bool ADV, bool DIFF, bool LES, bool FORCES, bool FRESH, bool PUP>
 __global__ __launch_bounds__(NT, MOM_WAVES) void mom_lds_kernel(Geo g, TileGrid tg, Metrics m, MomArgs a, double numol, int kc) {
   constexpr int NF = (DIFF && LES) ? 4 : 3;
   __shared__ double s[4][NF][LN];     // 4 rotating plane buffers: one barrier per level is enough
+  __shared__ double sp[ADV ? 3 : 1][ADV ? LN : 1];   // pres0: planes k-1, k and the one being filled (k+1)
 
   // workgroup -> (tile, k-chunk); XCD-aware like tile_decode but with chunks instead of planes
   const unsigned L = blockIdx.x;
@@ -60,8 +72,8 @@ __global__ __launch_bounds__(NT, MOM_WAVES) void mom_lds_kernel(Geo g, TileGrid 
   unsigned tt = lp;
   if ((tg.tiles & 7) == 0) tt = (lp & 7u) * (tg.tiles >> 3) + (lp >> 3);
   const int by = tt / tg.gx, bx = tt - by * tg.gx;
-  const int i0 = bx * TX, j0 = by * TY;
-  const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * TX + tx;
+  const int i0 = bx * MX, j0 = by * MY;
+  const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * MX + tx;
   const int i = i0 + tx, j = j0 + ty;
   const bool inside = i < g.nx && j < g.ny;
   const int k0 = chunk * kc;
@@ -98,32 +110,48 @@ __global__ __launch_bounds__(NT, MOM_WAVES) void mom_lds_kernel(Geo g, TileGrid 
       if (has_halo) s[buf][f][halo_l] = st.h[f];
     }
   };
+  // pres0 is only needed at (c, i-1, j-1, k-1): its planes run one level behind the velocity planes
+  double pst_c = 0., pst_h = 0.;
+  const bool p_halo = has_halo && (hlx == 0 || hly == 0);
+  auto load_p = [&](int k) {
+    const long pb = g.sz * (long)(k + HZ);
+    pst_c = a.p[pb + own_off];
+    pst_h = p_halo ? a.p[pb + halo_off] : 0.0;
+  };
+  auto commit_p = [&](int buf) {
+    sp[buf][own_l] = pst_c;
+    if (p_halo) sp[buf][halo_l] = pst_h;
+  };
 
   // prologue: planes k0-1, k0, k0+1 into buffers 0..2, plane k0+2 into registers
   Stage<NF> st;
   load_plane(k0 - 1, st); commit_plane(0, st);
   load_plane(k0, st);     commit_plane(1, st);
   load_plane(k0 + 1, st); commit_plane(2, st);
-  if (k0 + 1 < k1) load_plane(k0 + 2, st);
+  if (ADV) {
+    load_p(k0 - 1); commit_p(0);
+    load_p(k0);     commit_p(1);
+  }
+  if (k0 + 1 < k1) { load_plane(k0 + 2, st); if (ADV) load_p(k0 + 1); }
   int bm = 0, bc = 1, bp = 2, bn = 3;      // buffers holding planes k-1, k, k+1 and the one being filled (k+2)
+  int qm = 0, qc = 1, qn = 2;              // pres0 buffers: planes k-1, k and the one being filled (k+1)
   const long cell0 = own_off;
 
-  const long xm_off = (long)(i == 0 ? g.nx - 1 : i - 1) - i;
   for (int k = k0; k < k1; ++k) {
     // this level's direct operands (tendencies, pres0) are requested before the barrier so that their
     // latency overlaps the barrier wait and the LDS traffic
     const long c = g.sz * (long)(k + HZ) + cell0;
-    double tu = 0., tv = 0., tw = 0., p_c = 0., p_xm = 0., p_ym = 0., p_zm = 0., pum = 0., pvm = 0., pwm = 0.;
+    double tu = 0., tv = 0., tw = 0., pum = 0., pvm = 0., pwm = 0.;
     if (inside) {
       if (!FRESH) { tu = a.up[c]; tv = a.vp[c]; tw = a.wp[c]; }
       if (PUP && !a.um_is_u0) { pum = a.um[c]; pvm = a.vm[c]; pwm = a.wm[c]; }
-      if (ADV) { p_c = a.p[c]; p_xm = a.p[c + xm_off]; p_ym = a.p[c - g.sy]; p_zm = a.p[c - g.sz]; }
     }
     // everyone has finished level k-1 (last readers of buffer bn) and committed plane k+1
     __syncthreads();
     if (k + 1 < k1) {
       commit_plane(bn, st);                                // plane k+2, read from level k+1 on
-      if (k + 2 < k1) load_plane(k + 3, st);               // in flight while this level is computed
+      if (ADV) commit_p(qn);                               // pres0 plane k+1
+      if (k + 2 < k1) { load_plane(k + 3, st); if (ADV) load_p(k + 2); }   // in flight while this level is computed
     }
     if (inside) {
       const double *um_ = s[bm][0], *uc_ = s[bc][0], *up_ = s[bp][0];
@@ -137,7 +165,7 @@ __global__ __launch_bounds__(NT, MOM_WAVES) void mom_lds_kernel(Geo g, TileGrid 
       q.v_zm = vm_[o]; q.v_zp = vp_[o]; q.v_xm_yp = vc_[o - 1 + LX]; q.v_yp_zm = vm_[o + LX];
       q.w_c = wc_[o]; q.w_xm = wc_[o - 1]; q.w_xp = wc_[o + 1]; q.w_ym = wc_[o - LX]; q.w_yp = wc_[o + LX];
       q.w_zm = wm_[o]; q.w_zp = wp_[o]; q.w_xm_zp = wp_[o - 1]; q.w_ym_zp = wp_[o - LX];
-      if (ADV) { q.p_c = p_c; q.p_xm = p_xm; q.p_ym = p_ym; q.p_zm = p_zm; }
+      if (ADV) { q.p_c = sp[qc][o]; q.p_xm = sp[qc][o - 1]; q.p_ym = sp[qc][o - LX]; q.p_zm = sp[qm][o]; }
       if (DIFF && LES) {
         const double *em_ = s[bm][NF - 1], *ec_ = s[bc][NF - 1], *ep_ = s[bp][NF - 1];
         q.e_c = ec_[o]; q.e_xm = ec_[o - 1]; q.e_xp = ec_[o + 1]; q.e_ym = ec_[o - LX]; q.e_yp = ec_[o + LX];
@@ -157,6 +185,7 @@ __global__ __launch_bounds__(NT, MOM_WAVES) void mom_lds_kernel(Geo g, TileGrid 
       if (a.wrap_vp && j == 0) a.vp[c + (long)g.sy * g.ny] = tv;
     }
     const int t = bm; bm = bc; bc = bp; bp = bn; bn = t;
+    const int t2 = qm; qm = qc; qc = qn; qn = t2;
   }
 }
 
@@ -187,8 +216,8 @@ __global__ __launch_bounds__(NT) void closure_lds_kernel(Geo g, TileGrid tg, Met
   unsigned tt = lp;
   if ((tg.tiles & 7) == 0) tt = (lp & 7u) * (tg.tiles >> 3) + (lp >> 3);
   const int by = tt / tg.gx, bx = tt - by * tg.gx;
-  const int i0 = bx * TX, j0 = by * TY;
-  const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * TX + tx;
+  const int i0 = bx * MX, j0 = by * MY;
+  const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * MX + tx;
   const int i = i0 + tx, j = j0 + ty;
   const bool inside = i < g.nx && j < g.ny;
   const int k0 = chunk * kc;
@@ -286,10 +315,10 @@ static int pick_kc(const Geo &g, const TileGrid &tg) {
 
 int k_closure_lds(udc_handle *h, bool ghosts) {
   const Geo &g = h->g;
-  const TileGrid tg = tile_grid(g);
+  const TileGrid tg = lds_tile_grid(g);
   int kc = pick_kc(g, tg);
   const int chunks = (g.nz + kc - 1) / kc;
-  dim3 b(TX, TY, 1), gr((unsigned)tg.tiles * (unsigned)chunks, 1, 1);
+  dim3 b(MX, MY, 1), gr((unsigned)tg.tiles * (unsigned)chunks, 1, 1);
   double *u = h->fields[UDC_U0], *v = h->fields[UDC_V0], *w = h->fields[UDC_W0];
   double *ekm = h->fields[UDC_EKM], *ekh = h->fields[UDC_EKH];
   PROF(h, "closure");
@@ -307,11 +336,11 @@ int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, 
   MomArgs a{h->fields[UDC_U0], h->fields[UDC_V0], h->fields[UDC_W0], h->fields[UDC_PRES0],
             h->fields[UDC_EKM], h->fields[UDC_UP], h->fields[UDC_VP], h->fields[UDC_WP],
             h->fields[UDC_UM], h->fields[UDC_VM], h->fields[UDC_WM], rk3coefi, (fresh && !h->slab) ? 1 : 0, um_is_u0 ? 1 : 0};
-  const TileGrid tg = tile_grid(g);
+  const TileGrid tg = lds_tile_grid(g);
   // k-chunk: long enough to amortise the 2-plane prologue, short enough to fill 256 CUs x 4 workgroups
   int kc = pick_kc(g, tg);
   const int chunks = (g.nz + kc - 1) / kc;
-  dim3 b(TX, TY, 1), gr((unsigned)tg.tiles * (unsigned)chunks, 1, 1);
+  dim3 b(MX, MY, 1), gr((unsigned)tg.tiles * (unsigned)chunks, 1, 1);
   const bool les = h->p.sgs != UDC_SGS_DNS;
   const double nu = h->p.numol;
 #define LAUNCH(A, D, L, F)                                                                         \
