@@ -51,6 +51,46 @@ print("SLAB_OK")
     assert "SLAB_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
+def test_rccl_transport_single_rank():
+    """UDC_FORCE_COMM=1: a real RCCL communicator (one rank) carries the ghost rows, the two all-to-alls of the
+    Poisson solve and the all-reduces of the forced slab path; torch is imported first, as in bench.py, so the
+    library has to coexist with torch's own RCCL user.  Results must match the golden dumps."""
+    code = r'''
+import sys, ctypes, numpy as np
+import torch
+torch.cuda.set_device(0)
+sys.path[:0] = ["%s/tests", "%s/u-dales_amd"]
+from common import RUN_CASES, deck_path, load_fixture, marr, nocorner, relerr
+import udcore
+from udcore import read_deck, cold_start
+name, iexp = sorted(RUN_CASES.items())[0]
+fix = load_fixture(name)
+d = read_deck(deck_path(name, iexp))
+core = udcore.from_deck(d)
+buf = (ctypes.c_ubyte * 128)()
+assert core.lib.udc_comm_unique_id(buf) == 0
+core.comm_init(bytes(buf))
+core.load_state(cold_start(core.g, d, nsv=core.nsv))
+dt = float(d.get("RUN", "dtmax"))
+dumps = sorted(int(k[1:4]) for k in fix if k.endswith(".u0") and k != "s000.u0")
+for isub in range(1, max(dumps) + 1):
+    core.substep((isub - 1) %% 3 + 1, dt, True)
+    if isub in dumps:
+        for k in ("u0", "v0", "w0", "pres0"):
+            ref = marr(fix, f"s{isub:03d}.{k}", core.g.nz)
+            e = relerr(nocorner(core.download(k)[1:-1]), nocorner(ref[1:-1]))
+            assert e <= 1e-9, (name, isub, k, e)
+core.dt, core.rk3step = dt, 3
+m = core.tstep_update(dt, ladaptive=True)
+dv = core.divergence()
+core.close()
+print("RCCL_OK", m, dv)
+''' % (ROOT, ROOT)
+    env = dict(os.environ, UDC_FORCE_SLAB="1", UDC_FORCE_COMM="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert "RCCL_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 def run_virtual(P, g, deck_like, st_global, nsub, dt, sgs, nsv=0):
     """Run nsub substeps on P virtual ranks; returns the stitched global u0, v0, w0, pres0."""
     from udcore.core import DynCore

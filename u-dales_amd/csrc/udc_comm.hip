@@ -13,6 +13,7 @@
 #include <pthread.h>
 #include <mutex>
 #include <cstring>
+#include <cstdlib>
 
 struct LocalGroup {
   int P;
@@ -43,8 +44,13 @@ extern "C" int udc_comm_unique_id(unsigned char id[128]) {
   return 0;
 }
 
+// UDC_FORCE_COMM=1: build the RCCL communicator even for a single rank and send the "exchanges" of the forced
+// slab path (UDC_FORCE_SLAB=1) through ncclSend/ncclRecv to self -- a hardware test of the RCCL plumbing
+// (communicator, grouped point-to-point on the library's streams, all-reduce) on a one-GPU box.
+static bool force_comm() { const char *e = getenv("UDC_FORCE_COMM"); return e && atoi(e) != 0; }
+
 extern "C" int udc_comm_init(udc_handle *h, const unsigned char id[128]) {
-  if (h->cfg.nranks == 1) return 0;
+  if (h->cfg.nranks == 1 && !force_comm()) return 0;
   HIP_OK(hipSetDevice(h->device));
   ncclUniqueId u;
   memcpy(&u, id, 128);
@@ -90,7 +96,7 @@ int comm_neighbours(udc_handle *h, const double *to_prev, const double *to_next,
                     double *from_next, size_t count) {
   const int P = h->cfg.nranks, r = h->cfg.rank;
   const int prev = (r + P - 1) % P, next = (r + 1) % P;
-  if (P == 1) {   // single slab driven through the slab code path (UDC_FORCE_SLAB): periodic wrap onto itself
+  if (P == 1 && !h->nccl) {   // single slab driven through the slab code path (UDC_FORCE_SLAB): periodic wrap onto itself
     HIP_OK(hipMemcpyAsync(from_next, to_prev, count * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     HIP_OK(hipMemcpyAsync(from_prev, to_next, count * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     return 0;
@@ -122,7 +128,7 @@ int comm_neighbours(udc_handle *h, const double *to_prev, const double *to_next,
 // all-to-all of equal blocks: block d of `send` goes to rank d, arriving as block r of its `recv`
 int comm_alltoall(udc_handle *h, const double *send, double *recv, size_t block, hipStream_t st) {
   const int P = h->cfg.nranks, r = h->cfg.rank;
-  if (P == 1) {
+  if (P == 1 && !h->nccl) {
     HIP_OK(hipMemcpyAsync(recv, send, block * sizeof(double), hipMemcpyDeviceToDevice, st));
     return 0;
   }
@@ -130,10 +136,11 @@ int comm_alltoall(udc_handle *h, const double *send, double *recv, size_t block,
   if (h->nccl) {
     ncclComm_t c = (ncclComm_t)h->nccl;
     // own block: plain device copy; the other P-1 blocks use every xGMI link at once
-    HIP_OK(hipMemcpyAsync(recv + (size_t)r * block, send + (size_t)r * block, block * sizeof(double),
-                          hipMemcpyDeviceToDevice, st));
+    const int q0 = (P == 1) ? 0 : 1;    // P == 1 only under UDC_FORCE_COMM: the own block goes through RCCL too
+    if (q0) HIP_OK(hipMemcpyAsync(recv + (size_t)r * block, send + (size_t)r * block, block * sizeof(double),
+                                  hipMemcpyDeviceToDevice, st));
     NCCL_OK(ncclGroupStart());
-    for (int q = 1; q < P; ++q) {
+    for (int q = q0; q < P; ++q) {
       const int to = (r + q) % P, from = (r + P - q) % P;     // staggered so that pairs differ per step
       NCCL_OK(ncclSend(send + (size_t)to * block, block, ncclDouble, to, c, st));
       NCCL_OK(ncclRecv(recv + (size_t)from * block, block, ncclDouble, from, c, st));
@@ -155,7 +162,7 @@ int comm_alltoall(udc_handle *h, const double *send, double *recv, size_t block,
 
 // in-place all-reduce of n (<= 8) doubles held in device memory `buf`; op 0 = max, 1 = sum
 int comm_allreduce(udc_handle *h, double *buf, int n, int op) {
-  if (h->cfg.nranks == 1) return 0;
+  if (h->cfg.nranks == 1 && !h->nccl) return 0;
   if (need_comm(h)) return 1;
   if (h->nccl) {
     NCCL_OK(ncclAllReduce(buf, buf, (size_t)n, ncclDouble, op == 0 ? ncclMax : ncclSum, (ncclComm_t)h->nccl,
