@@ -298,10 +298,10 @@ __global__ __launch_bounds__(NT) void closure_lds_kernel(Geo g, TileGrid tg, Met
 }  // namespace
 
 // k-chunk length: each workgroup pays a 3-plane prologue, and the chip runs `slots` workgroups at a
-// time (256 CUs x 3, register-limited), so pick the chunk that minimises rounds x (kc + 3).
-static int pick_kc(const Geo &g, const TileGrid &tg) {
+// time (256 CUs x per_cu, register/LDS-limited), so pick the chunk that minimises rounds x (kc + 3).
+static int pick_kc(const Geo &g, const TileGrid &tg, int per_cu) {
   if (getenv("UDC_MOM_KC")) { int v = atoi(getenv("UDC_MOM_KC")); if (v >= 1) return v < g.nz ? v : g.nz; }
-  const long slots = 256 * 3;
+  const long slots = 256L * per_cu;
   int best = g.nz < 4 ? g.nz : 4;
   double best_cost = 1e300;
   for (int kc = 4; kc <= g.nz; ++kc) {
@@ -316,7 +316,7 @@ static int pick_kc(const Geo &g, const TileGrid &tg) {
 int k_closure_lds(udc_handle *h, bool ghosts) {
   const Geo &g = h->g;
   const TileGrid tg = lds_tile_grid(g);
-  int kc = pick_kc(g, tg);
+  int kc = pick_kc(g, tg, getenv("UDC_CLOSURE_PERCU") ? atoi(getenv("UDC_CLOSURE_PERCU")) : 4);     // 116 VGPRs, 32 KB LDS: four workgroups per CU
   const int chunks = (g.nz + kc - 1) / kc;
   dim3 b(MX, MY, 1), gr((unsigned)tg.tiles * (unsigned)chunks, 1, 1);
   double *u = h->fields[UDC_U0], *v = h->fields[UDC_V0], *w = h->fields[UDC_W0];
@@ -338,7 +338,7 @@ int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, 
             h->fields[UDC_UM], h->fields[UDC_VM], h->fields[UDC_WM], rk3coefi, (fresh && !h->slab) ? 1 : 0, um_is_u0 ? 1 : 0};
   const TileGrid tg = lds_tile_grid(g);
   // k-chunk: long enough to amortise the 2-plane prologue, short enough to fill 256 CUs x 4 workgroups
-  int kc = pick_kc(g, tg);
+  int kc = pick_kc(g, tg, MOM_WAVES);
   const int chunks = (g.nz + kc - 1) / kc;
   dim3 b(MX, MY, 1), gr((unsigned)tg.tiles * (unsigned)chunks, 1, 1);
   const bool les = h->p.sgs != UDC_SGS_DNS;
