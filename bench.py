@@ -54,7 +54,7 @@ def algo_bytes(name):
     return None
 
 
-def write_deck(d, iexp, nx, ny, nz, nsub, dt=0.25, nprocy=1, nsv=0, sgs="vreman"):
+def write_deck(d, iexp, nx, ny, nz, nsub, dt=0.25, nprocy=1, nsv=0, sgs="vreman", floor=True):
     with open(os.path.join(d, f"namoptions.{iexp:03d}"), "w") as f:
         f.write(f"""&RUN
 iexpnr = {iexp}
@@ -80,7 +80,9 @@ ylen = {ny * 0.5}
 ipoiss = 0
 /
 &BC
+{('BCbotm = 3' + chr(10) + 'z0 = 0.05') if floor else ''}
 /
+{('&WALLS' + chr(10) + 'nfcts = 0' + chr(10) + 'lbottom = .true.' + chr(10) + '/') if floor else ''}
 &SCALARS
 nsv = {nsv}
 /
@@ -160,6 +162,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--nsv", type=int, default=0, help="passive scalars (kappa scheme), BASELINE configs[2]")
     ap.add_argument("--sgs", type=str, default="vreman", choices=["vreman", "smag"])
+    ap.add_argument("--no-floor", action="store_true",
+                    help="free floor instead of the neutral log-law wall function (lbottom, BCbotm = 3) of SURVEY 8d")
     args = ap.parse_args()
 
     import numpy as np
@@ -187,7 +191,7 @@ def main():
         nx, ny, nz = 256, 256 * world, 256      # weak scaling: one 256^3 slab of the channel per GPU
     dt = 0.25
     with tempfile.TemporaryDirectory() as tmp:
-        deck = read_deck(write_deck(tmp, 901, nx, ny, nz, 0, dt=dt, nprocy=world, nsv=args.nsv, sgs=args.sgs))
+        deck = read_deck(write_deck(tmp, 901, nx, ny, nz, 0, dt=dt, nprocy=world, nsv=args.nsv, sgs=args.sgs, floor=not args.no_floor))
     core = udcore.from_deck(deck, device=local_rank, rank=rank, nranks=world)
     if world > 1:
         idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
@@ -270,6 +274,8 @@ def main():
         "config": {"workload": f"{nx}x{ny}x{nz} neutral empty-domain channel, cd2 momentum advection + "
                                f"Vreman SGS diffusion + FFT(x,y)/tridiagonal(z) Poisson + RK3 substep "
                                f"(BASELINE.json configs[1])",
+                   "floor": "free (no wall function)" if args.no_floor else
+                            "neutral log-law wall function (lbottom, BCbotm=3, z0=0.05)",
                    "grid": [nx, ny, nz], "decomposition": f"y-slabs x{world}", "dt": dt,
                    "step": "one RK3 substep = one cell-update per cell"},
         "whole_substep_hbm_frac": round(392.0 * cells_local * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4),

@@ -66,6 +66,8 @@ typedef struct udc_config {
   int bctopm;               /* UDC_TOP_*                                                  */
   double uinf, vinf;        /* no-slip top wall velocity (valuetop)                       */
   int nsv;                  /* passive scalars (kappa scheme, src/modglobal.f90:557-559)  */
+  int lbottom;              /* &WALLS lbottom (src/modibm.f90:49): floor wall function, BCbotm = 3, BCbots = 1 */
+  double z0;                /* &BC z0 roughness length (src/modsurfdata.f90:72); > 0 when lbottom          */
 } udc_config;
 
 /* ---- lifetime ------------------------------------------------------------------- */
@@ -99,6 +101,11 @@ int udc_set_forcing(udc_handle *h, const double *dpdxl, const double *dpdyl, int
 int udc_advection(udc_handle *h);
 /* subgrid     src/modsubgrid.f90:128    closure+closurebc, then diffu/diffv/diffw/diffc  */
 int udc_subgrid(udc_handle *h);
+/* bottom      src/modibm.f90:1998       floor (lbottom): wfmneutral (src/modwallfunctions.f90:263-350) replaces the
+ *             resolved viscous flux through the floor in up,vp(kb) by the neutral log-law stress; zero-flux floor
+ *             for the scalars (:2073-2090).  Called between subgrid and forces (src/program.f90:146-160).
+ *             No-op when cfg.lbottom == 0.  The tau_x/tau_y/momfluxb diagnostics are not kept. */
+int udc_bottom(udc_handle *h);
 /* forces      src/modforces.f90:46      neutral branch: up -= dpdxl(k), vp -= dpdyl(k), wp(kb)=0 */
 int udc_forces(udc_handle *h);
 /* poisson     src/modpois.f90:419       fillps+bcpup, FFT(x,y)+tridiagonal(z), tderive+bcp */

@@ -8,7 +8,11 @@
 !     tstep_integrate -> halos -> boundary
 !
 ! (the IBM / NetCDF / statistics modules cannot be built here and are outside the
-! hot path, SURVEY.md section 8).  Set-up mirrors src/modstartup.f90:
+! hot path, SURVEY.md section 8).  With &WALLS lbottom=.true. the floor wall function of
+! `bottom` (src/modibm.f90:1998-2100, a module that needs NetCDF and cannot be built) runs between
+! subgrid and forces as in src/program.f90:146-160: its arithmetic is the reference's own wfmneutral
+! (src/modwallfunctions.f90:263-350, compiled unmodified); only the dispatch lines :2021-2026 and the
+! zero-flux scalar floor :2073-2090 are restated in floor_bottom below.  Set-up mirrors src/modstartup.f90:
 !   readnamelists (:105-172, subset of groups/variables, same names),
 !   init2decomp (:652-691), cold start of readinitfiles (:1088-1290),
 !   lscale.inp reading (:2051-2092), randomize_field (:2367-2396).
@@ -27,7 +31,8 @@ program ref_driver
   use modglobal
   use modfields
   use modsubgriddata
-  use modsurfdata, only: thl_top, wttop, wsvtop, sv_top, thvs, thls
+  use modsurfdata, only: thl_top, wttop, wsvtop, sv_top, thvs, thls, z0
+  use modwallfunctions, only: wfmneutral
   use modboundary, only: initboundary, boundary, halos
   use modthermodynamics, only: initthermodynamics
   use modsubgrid, only: initsubgrid, subgrid
@@ -41,6 +46,7 @@ program ref_driver
   integer :: nsub = 3, nspin = 2
   integer :: dump_at(16) = -1
   logical :: lforces = .true.
+  logical :: lbottom = .false.           ! src/modibm.f90:49 (module variable of modibm)
   integer :: isub, n, ierr, iu
   real :: t0, t1, chk_u2, chk_div
   real :: scal_a = 1.0, scal_b = 0.0     ! scalar init: sv = scal_b + scal_a*z/zsize
@@ -143,12 +149,42 @@ contains
     call tstep_update
     call advection
     call subgrid
+    call floor_bottom
     if (lforces) call forces
     call poisson
     call tstep_integrate
     call halos
     call boundary
   end subroutine one_substep
+
+  ! ---- `bottom`, src/modibm.f90:2021-2026 (momentum, BCbotm = 3) and :2073-2090 (scalars, BCbots = 1)
+  subroutine floor_bottom
+    integer :: i, j, m
+    if (.not. lbottom) return
+    if (BCbotm /= 3) then
+      write (0, *) 'ERROR: oracle build supports the neutral floor wall function only (BCbotm = 3)'
+      stop 1
+    end if
+    call wfmneutral(ih, jh, kh, up, vp, momfluxb, u0, v0, z0, 91)
+    if (nsv > 0) then
+      if (BCbots /= 1) then
+        write (0, *) 'ERROR: bottom boundary type for scalars undefined'
+        stop 1
+      end if
+      do j = jb, je
+        do i = ib, ie
+          do m = 1, nsv
+            svp(i, j, kb, m) = svp(i, j, kb, m) + ( &
+                               0.5*(dzf(kb - 1)*ekh(i, j, kb) + dzf(kb)*ekh(i, j, kb - 1)) &
+                               *(sv0(i, j, kb, m) - sv0(i, j, kb - 1, m)) &
+                               *dzh2i(kb) &
+                               + 0. &
+                               )*dzfi(kb)
+          end do
+        end do
+      end do
+    end if
+  end subroutine floor_bottom
 
   ! ---- subset of src/modstartup.f90:105-172 (same group and variable names)
   subroutine read_namelists_subset
@@ -159,8 +195,9 @@ contains
     namelist /DOMAIN/ itot, jtot, ktot, xlen, ylen
     namelist /PHYSICS/ lmoist, lcoriol, lbuoyancy, ltempeq, lprofforc, dpdx
     namelist /DYNAMICS/ ipoiss, iadv_mom, iadv_tke, iadv_thl, iadv_qt, iadv_sv
-    namelist /BC/ BCxm, BCym, BCtopm, BCtopT, BCtops, BCbotm, BCzp, wttop, thl_top
+    namelist /BC/ BCxm, BCym, BCtopm, BCtopT, BCtops, BCbotm, BCbots, BCzp, wttop, thl_top, z0
     namelist /SCALARS/ nsv
+    namelist /WALLS/ nfcts, lbottom
     open (ifnamopt, file=fname_options, status='old', iostat=ierr)
     if (ierr /= 0) then
       write (0, *) 'ERROR: cannot open ', trim(fname_options)
@@ -171,7 +208,8 @@ contains
     read (ifnamopt, PHYSICS, iostat=ierr); call chk(ierr, 'PHYSICS'); rewind (ifnamopt)
     read (ifnamopt, DYNAMICS, iostat=ierr); call chk(ierr, 'DYNAMICS'); rewind (ifnamopt)
     read (ifnamopt, BC, iostat=ierr); call chk(ierr, 'BC'); rewind (ifnamopt)
-    read (ifnamopt, SCALARS, iostat=ierr); call chk(ierr, 'SCALARS')
+    read (ifnamopt, SCALARS, iostat=ierr); call chk(ierr, 'SCALARS'); rewind (ifnamopt)
+    read (ifnamopt, WALLS, iostat=ierr); call chk(ierr, 'WALLS')
     close (ifnamopt)
     nprocx = 1; nprocy = nprocs     ! y-slabs over however many ranks were launched (1 in the np1 build)
     libm = .false.
@@ -420,10 +458,15 @@ contains
     call put3('sub.ekh', ekh, (/ib - ih, jb - jh, kb - kh/))
     call put3('sub.u0', u0, (/ib - ih, jb - jh, kb - kh/))   ! top ghost row rewritten by closurebc
     call dump_tend('sub')
+    if (lbottom) then                       ! floor wall function on top of the subgrid tendencies
+      call floor_bottom
+      call dump_tend('bot')
+    end if
     ! full tendency = advection + subgrid + forces, as the driver would have it
     up = 0.; vp = 0.; wp = 0.; svp = 0.
     call advection
     call subgrid
+    call floor_bottom
     if (lforces) call forces
     call dump_tend('pre')
     call poisson                            ! src/modpois.f90:419

@@ -789,6 +789,70 @@ void orc_boundary(const orc_grid *g, double *u0, double *v0, double *w0, double 
   }
 }
 
+/* ====================================================================== floor wall function */
+/* `bottom` (src/modibm.f90:1998-2100), lbottom branch with BCbotm = 3 -> wfmneutral case 91
+ * (src/modwallfunctions.f90:263-350); scalars BCbots = 1 (src/modibm.f90:2073-2090).
+ * dxf/dxhi follow src/modglobal.f90:770-790 (equal to dx up to the rounding of (i-1)*dx). */
+void orc_bottom(const orc_grid *g, const double *u0, const double *v0, const double *ekm, const double *ekh,
+                const double *sv0, double *up, double *vp, double *svp, double *momfluxb) {
+  if (!g->lbottom) return;
+  metrics m;
+  metrics_init(g, &m);
+  const int nx = g->nx, ny = g->ny;
+  const double *dzf = g->dzf;
+  const double fkar = 0.41;                       /* src/modglobal.f90:317 */
+  const double fkar2 = fkar * fkar;
+  const double umin = 0.0001;                     /* src/modwallfunctions.f90:286 */
+  double *xh = (double *)calloc(4 * (size_t)(nx + 3), sizeof(double));   /* Fortran i = 0..nx+1 */
+  double *xf = xh + (nx + 3), *dxf = xf + (nx + 3), *dxhi = dxf + (nx + 3);
+  for (int i = 1; i <= nx + 1; ++i) { xh[i] = (double)(i - 1) * g->dx; xf[i] = xh[i] + g->dx / 2; }
+  for (int i = 1; i <= nx; ++i) dxf[i] = xh[i + 1] - xh[i];
+  dxf[nx + 1] = dxf[nx]; dxf[0] = dxf[1];
+  dxhi[1] = 1. / (2 * xf[1]);
+  for (int i = 2; i <= nx + 1; ++i) dxhi[i] = 1. / (xf[i] - xf[i - 1]);
+
+  const int k = 1, km = 0;
+  const double delta = 0.5 * dzf[k];
+  const double l_ = log(delta / g->z0);
+  const double logdz2 = l_ * l_;
+  for (int j = 1; j <= ny; ++j)        /* u component, :318-331 */
+    for (int i = 1; i <= nx; ++i) {
+      const double utang1Int = M(u0, i, j, k);
+      const double utang2Int = (M(v0, i, j, k) + M(v0, i - 1, j, k) + M(v0, i, j + 1, k) + M(v0, i - 1, j + 1, k)) * 0.25;
+      const double utangInt = fmax(umin, (utang1Int * utang1Int + utang2Int * utang2Int));
+      const double ctm = fkar2 / (logdz2);
+      const double dummy = fabs(utang1Int) * sqrt(utangInt) * ctm;
+      const double bcmomflux = copysign(dummy, utang1Int);
+      if (momfluxb) M(momfluxb, i, j, k) = M(momfluxb, i, j, k) + bcmomflux * m.dzfi[k];
+      const double emom = (dzf[km] * (M(ekm, i, j, k) * dxf[i - 1] + M(ekm, i - 1, j, k) * dxf[i]) +
+                           dzf[k] * (M(ekm, i, j, km) * dxf[i - 1] + M(ekm, i - 1, j, km) * dxf[i])) * dxhi[i] * m.dzhiq[k];
+      M(up, i, j, k) = M(up, i, j, k) + (M(u0, i, j, k) - M(u0, i, j, km)) * emom * m.dzhi[k] * m.dzfi[k] - bcmomflux * m.dzfi[k];
+    }
+  for (int j = 1; j <= ny; ++j)        /* v component, :333-346 */
+    for (int i = 1; i <= nx; ++i) {
+      const double utang1Int = (M(u0, i, j, k) + M(u0, i, j - 1, k) + M(u0, i + 1, j - 1, k) + M(u0, i + 1, j, k)) * 0.25;
+      const double utang2Int = M(v0, i, j, k);
+      const double utangInt = fmax(umin, (utang1Int * utang1Int + utang2Int * utang2Int));
+      const double ctm = fkar2 / (logdz2);
+      const double dummy = fabs(utang2Int) * sqrt(utangInt) * ctm;
+      const double bcmomflux = copysign(dummy, utang2Int);
+      if (momfluxb) M(momfluxb, i, j, k) = M(momfluxb, i, j, k) + bcmomflux * m.dzfi[k];
+      const double eomm = (dzf[km] * (M(ekm, i, j, k) + M(ekm, i, j - 1, k)) + dzf[k] * (M(ekm, i, j, km) + M(ekm, i, j - 1, km))) * m.dzhiq[k];
+      M(vp, i, j, k) = M(vp, i, j, k) + (M(v0, i, j, k) - M(v0, i, j, km)) * eomm * m.dzhi[k] * m.dzfi[k] - bcmomflux * m.dzfi[k];
+    }
+  const size_t nc = csize(g);          /* zero-flux floor for the scalars */
+  for (int n = 0; n < g->nsv; ++n) {
+    const double *c0 = sv0 + n * nc;
+    double *cp = svp + n * nc;
+    for (int j = 1; j <= ny; ++j)
+      for (int i = 1; i <= nx; ++i)
+        C(cp, i, j, 1) = C(cp, i, j, 1) + (0.5 * (dzf[0] * M(ekh, i, j, 1) + dzf[1] * M(ekh, i, j, 0))
+                                           * (C(c0, i, j, 1) - C(c0, i, j, 0)) * m.dzh2i[1] + 0.) * m.dzfi[1];
+  }
+  free(xh);
+  metrics_free(&m);
+}
+
 /* ====================================================================== substep */
 /* src/program.f90:132-222: advection, subgrid, forces, poisson, tstep_integrate, halos, boundary */
 void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
@@ -816,6 +880,7 @@ void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
   orc_diffv(g, s->u0, s->v0, s->w0, s->ekm, s->vp);
   orc_diffw(g, s->u0, s->v0, s->w0, s->ekm, s->wp);
   for (int n = 0; n < g->nsv; ++n) orc_diffc(g, s->sv0 + n * nc, s->ekh, s->svp + n * nc);
+  orc_bottom(g, s->u0, s->v0, s->ekm, s->ekh, s->sv0, s->up, s->vp, s->svp, NULL);   /* src/program.f90:152 */
   if (s->dpdxl) orc_forces(g, s->dpdxl, s->dpdyl, s->up, s->vp, s->wp);
   orc_fillps(g, rk3coef, s->up, s->vp, s->wp, s->um, s->vm, s->wm, s->pup, s->pvp, s->pwp, s->p);
   orc_poisson_solve(g, s->p);

@@ -39,6 +39,8 @@ typedef struct {
   int bctopm;               /* 1 free-slip, 2 no-slip (src/modglobal.f90:150-153) */
   double uinf, vinf;        /* only for no-slip top (valuetop) */
   int nsv;                  /* passive scalars, kappa scheme (src/modglobal.f90:557-559) */
+  int lbottom;              /* floor wall function (src/modibm.f90:49,2021), BCbotm = 3, BCbots = 1 */
+  double z0;                /* roughness length (src/modsurfdata.f90:72) */
 } orc_grid;
 
 /* ---- advection: src/modadvection.f90 */
@@ -64,6 +66,9 @@ void orc_diffc(const orc_grid *g, const double *c, const double *ekh, double *cp
 /* ---- forces (neutral branch): src/modforces.f90:46-133 */
 void orc_forces(const orc_grid *g, const double *dpdxl, const double *dpdyl,
                 double *up, double *vp, double *wp);
+/* ---- floor: `bottom` src/modibm.f90:1998-2100 -> wfmneutral src/modwallfunctions.f90:263-350; momfluxb may be NULL */
+void orc_bottom(const orc_grid *g, const double *u0, const double *v0, const double *ekm, const double *ekh,
+                const double *sv0, double *up, double *vp, double *svp, double *momfluxb);
 /* ---- pressure: src/modpois.f90 (ipoiss = POISS_FFT2D, BCzp = 1, periodic x,y) */
 void orc_fillps(const orc_grid *g, double rk3coef, const double *up, const double *vp,
                 const double *wp, const double *um, const double *vm, const double *wm,

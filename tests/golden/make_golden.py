@@ -29,7 +29,7 @@ REF = os.path.join(ROOT, "oracle", "_ref", "udales_ref")
 
 
 def deck(iexpnr, nx, ny, nz, dx=0.5, dy=0.5, dtmax=0.25, sgs="vreman", nsv=0, bctopm=1,
-         oracle="", lles=True, randu=0.01):
+         oracle="", lles=True, randu=0.01, floor=False, z0=0.05):
     sub = {"vreman": "lvreman = .true.\nlsmagorinsky = .false.",
            "smag": "lsmagorinsky = .true.\nlvreman = .false.",
            "dns": "lvreman = .false.\nlsmagorinsky = .false."}[sgs]
@@ -59,7 +59,9 @@ ipoiss = 0
 /
 &BC
 BCtopm = {bctopm}
+{('BCbotm = 3' + chr(10) + 'z0 = ' + repr(z0)) if floor else ''}
 /
+{('&WALLS' + chr(10) + 'nfcts = 0' + chr(10) + 'lbottom = .true.' + chr(10) + '/') if floor else ''}
 &SCALARS
 nsv = {nsv}
 /
@@ -96,7 +98,7 @@ def write_case(d, iexpnr, text, zf, u=1.0, v=0.0, pgx=1e-4):
 
 
 KEEP_KERNELS = ("meta dzf dzh zf dpdxl dpdyl rk3 in.u0 in.v0 in.w0 in.um in.vm in.wm in.pres0 "
-                "in.ekm in.ekh adv.up adv.vp adv.wp sub.ekm sub.ekh sub.u0 sub.up sub.vp sub.wp "
+                "in.ekm in.ekh adv.up adv.vp adv.wp sub.ekm sub.ekh sub.u0 sub.up sub.vp sub.wp bot.up bot.vp "
                 "pre.up pre.vp pre.wp poi.p poi.pres0 poi.up poi.vp poi.wp out.u0 out.v0 out.w0 "
                 "out.um out.pres0").split()
 
@@ -110,6 +112,10 @@ CASES = {
     "run_16x16x8": ("run", 21, 16, 16, 8, dict(sgs="vreman", oracle="nsub = 9\ndump_at = 1, 3, 9"), 1.0),
     "run_smag_scalar_16x8x12s": ("run", 22, 16, 8, 12,
                                  dict(sgs="smag", nsv=1, oracle="nsub = 6\ndump_at = 3, 6"), 1.06),
+    # floor wall function (lbottom, BCbotm = 3: `bottom` -> wfmneutral), the floor of BASELINE configs 1-3
+    "k_floor_12x8x6": ("kernels", 16, 12, 8, 6, dict(sgs="vreman", floor=True, oracle="nspin = 3"), 1.0),
+    "run_floor_scalar_16x8x12s": ("run", 23, 16, 8, 12,
+                                  dict(sgs="smag", nsv=1, floor=True, dx=0.3, oracle="nsub = 6\ndump_at = 3, 6"), 1.06),
 }
 
 
@@ -132,7 +138,8 @@ def main():
         else:
             keep = {k: v for k, v in d.items()
                     if k.count(".") == 0 or k.split(".")[1] in ("u0", "v0", "w0", "pres0", "um")
-                    or k.startswith("s000.") or ".sv0" in k}
+                    or (k.startswith("s000.") and not k.startswith("s000.ek")) or ".sv0" in k}
+            # (s000.ekm/ekh are dumped before the first closure call: uninitialised memory, not data)
         tmpf = os.path.join(HERE, name + ".bin")
         write_dump(tmpf, keep)
         with open(tmpf, "rb") as f, gzip.GzipFile(tmpf + ".gz", "wb", mtime=0) as g:

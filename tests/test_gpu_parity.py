@@ -80,11 +80,17 @@ def test_each_routine_matches_reference(name, iexp):
     for n in range(nsv):
         got = core.download(L.scalar_field(L.SVP, n), halo=2)
         assert relerr(interior(got, 2), interior(carr(fix, f"sub.svp_{n + 1:02d}", nz), 2)) <= KERNEL_TOL
+    if "bot.up" in fix:       # floor wall function on top of the subgrid tendencies (`bottom` -> wfmneutral)
+        core.bottom()
+        for k in ("up", "vp"):
+            assert relerr(interior(core.download(k)), interior(marr(fix, "bot." + k, nz))) <= KERNEL_TOL, k
+        assert relerr(interior(core.download("up")), interior(marr(fix, "sub.up", nz))) > 1e-6
 
     # full tendency as the reference driver had it, then forces (already inside pre.*), poisson
     zero_tend()
     core.advection()
     core.subgrid()
+    core.bottom()
     core.forces()
     for k in ("up", "vp", "wp"):
         assert relerr(interior(core.download(k)), interior(marr(fix, "pre." + k, nz))) <= KERNEL_TOL, k
@@ -129,7 +135,7 @@ def test_substeps_match_reference(name, iexp, fused):
             core.substep(rk, dt, with_forces=True)
         else:
             core.tstep_update(dt)
-            core.advection(); core.subgrid(); core.forces(); core.poisson()
+            core.advection(); core.subgrid(); core.bottom(); core.forces(); core.poisson()
             core.tstep_integrate(); core.halos(); core.boundary()
         if isub in dumps:
             tag = f"s{isub:03d}"
@@ -184,15 +190,17 @@ def oracle_state(st, g, nsv):
     return o
 
 
-@pytest.mark.parametrize("shape,sgs,nsv,stretch", [
-    ((64, 48, 40), 2, 0, 1.03),      # Vreman, stretched z
-    ((48, 64, 24), 1, 1, 1.00),      # Smagorinsky + kappa scalar
-    ((20, 12, 10), 2, 0, 1.00),      # non power-of-two FFT lengths (radix 5, 3)
-    ((4, 4, 3), 0, 0, 1.00),         # smallest grid the library accepts, DNS
-    ((128, 8, 6), 1, 2, 1.10),       # ragged aspect, two scalars
+@pytest.mark.parametrize("shape,sgs,nsv,stretch,floor", [
+    ((64, 48, 40), 2, 0, 1.03, False),      # Vreman, stretched z
+    ((48, 64, 24), 1, 1, 1.00, False),      # Smagorinsky + kappa scalar
+    ((20, 12, 10), 2, 0, 1.00, False),      # non power-of-two FFT lengths (radix 5, 3)
+    ((4, 4, 3), 0, 0, 1.00, False),         # smallest grid the library accepts, DNS
+    ((128, 8, 6), 1, 2, 1.10, False),       # ragged aspect, two scalars
+    ((40, 24, 16), 2, 1, 1.05, True),       # floor wall function (lbottom, BCbotm = 3) + scalar floor
+    ((12, 8, 6), 0, 0, 1.00, True),         # floor under DNS viscosity
 ])
 @pytest.mark.parametrize("thomas", ["0", "3"], ids=["thomas-stream", "thomas-lds"])
-def test_against_oracle_seeded(shape, sgs, nsv, stretch, thomas, monkeypatch):
+def test_against_oracle_seeded(shape, sgs, nsv, stretch, floor, thomas, monkeypatch):
     """Three substeps (one RK3 step) vs the CPU oracle on seeded random fields, with either variant of
     the tridiagonal solve (UDC_THOMAS: 0 = streaming kernel, 3 = LDS-resident columns)."""
     monkeypatch.setenv("UDC_THOMAS", thomas)
@@ -201,8 +209,8 @@ def test_against_oracle_seeded(shape, sgs, nsv, stretch, thomas, monkeypatch):
     zf = np.cumsum(dz) - 0.5 * dz
     g = Grid.from_levels(nx, ny, nz, nx * 0.5, ny * 0.4, zf)
     from udcore.core import DynCore
-    core = DynCore(g, sgs=sgs, nsv=nsv)
-    o = ol.Oracle(nx, ny, nz, g.dx, g.dy, g.dzf, g.dzh, sgs=sgs, nsv=nsv, csz=0.21658244510412)
+    core = DynCore(g, sgs=sgs, nsv=nsv, lbottom=floor, z0=0.03)
+    o = ol.Oracle(nx, ny, nz, g.dx, g.dy, g.dzf, g.dzh, sgs=sgs, nsv=nsv, csz=0.21658244510412, lbottom=floor, z0=0.03)
     st = random_state(g, seed=nx * 1000 + ny, nsv=nsv)
     dp = np.zeros(nz + 2); dp[1:nz + 1] = -1e-3
     dq = np.zeros(nz + 2); dq[1:nz + 1] = 2e-4

@@ -98,6 +98,7 @@ extern "C" int udc_create(const udc_config *cfg, udc_handle **out) {
   if (cfg->nranks > 64) { udc_set_error("udc_create: at most 64 slabs"); return 1; }
   if ((cfg->jtot / cfg->nranks) < 2 * HY) { udc_set_error("udc_create: slab thinner than the ghost width"); return 1; }
   if (cfg->nsv < 0 || cfg->nsv > 16) { udc_set_error("udc_create: nsv out of range"); return 1; }
+  if (cfg->lbottom && !(cfg->z0 > 0.)) { udc_set_error("udc_create: lbottom needs a roughness length z0 > 0 (src/modwallfunctions.f90:314)"); return 1; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
     udc_set_error("udc_create: no HIP device visible -- libudcore has no CPU fallback");
@@ -119,7 +120,7 @@ extern "C" int udc_create(const udc_config *cfg, udc_handle **out) {
   g.py = g.ny + 2 * HY; g.pz = g.nz + 2 * HZ;
   g.sy = g.nx; g.sz = (long)g.nx * g.py; g.n = g.sz * g.pz;
   h->p = Params{cfg->numol, cfg->prandtlmoli, cfg->prandtli, cfg->c_vreman, cfg->csz,
-                cfg->uinf, cfg->vinf, cfg->sgs, cfg->bctopm};
+                cfg->uinf, cfg->vinf, cfg->sgs, cfg->bctopm, cfg->lbottom ? 1 : 0, cfg->z0};
 
   // metrics exactly as src/modglobal.f90:812-838
   const int nk = g.nz + 2;
@@ -314,6 +315,13 @@ extern "C" int udc_subgrid(udc_handle *h) {
   return 0;
 }
 
+extern "C" int udc_bottom(udc_handle *h) {
+  HIP_OK(hipSetDevice(h->device));
+  if (!h->p.lbottom) return 0;
+  if (tend_clean(h) || um_materialise(h)) return 1;
+  return k_bottom(h, false);
+}
+
 extern "C" int udc_forces(udc_handle *h) {
   HIP_OK(hipSetDevice(h->device));
   if (tend_clean(h) || um_materialise(h)) return 1;
@@ -401,6 +409,8 @@ extern "C" int udc_substep(udc_handle *h, int rk3step, double dt, int with_force
           : k_momentum(h, true, true, with_forces != 0)) return 1;
   for (int n = 0; n < h->cfg.nsv; ++n)
     if (k_scalar_fused(h, n)) return 1;
+  // `bottom` (src/program.f90:152): additive on the k = kb tendencies, hence equally on pup = up + um/rk3coef
+  if (h->p.lbottom && k_bottom(h, fold)) return 1;
   if (!fold) {
     const int fvp[1] = {UDC_VP};
     if (k_halo_y(h, fvp, 1, 1)) return 1;

@@ -74,6 +74,8 @@ struct Metrics {
 struct Params {
   double numol, prandtlmoli, prandtli, c_vreman, csz, uinf, vinf;
   int sgs, bctopm;
+  int lbottom;     // floor wall function (src/modibm.f90:2021)
+  double z0;
 };
 
 struct ProfEntry { hipEvent_t a, b; int name; };
@@ -176,6 +178,7 @@ int k_scalar_adv(udc_handle *h, int n);
 int k_scalar_diff(udc_handle *h, int n);
 int k_scalar_fused(udc_handle *h, int n);          // advection + diffusion in one sweep (same accumulation order)
 int k_forces(udc_handle *h);
+int k_bottom(udc_handle *h, bool wrap_vp);       // floor wall function; wrap_vp: also refresh vp's ghost row ny (bcpup)
 int k_divergence_rhs(udc_handle *h, double rk3coef, bool pup);
 int k_poisson_solve(udc_handle *h);
 int k_project(udc_handle *h);                       // tderive: up,vp,wp -= grad p ; pres0 += p

@@ -126,12 +126,77 @@ __global__ __launch_bounds__(256) void forces_kernel(Geo g, TileGrid tg, Metrics
   if (k == 0) wp[c] = 0.0;
 }
 
+// `bottom` with lbottom (src/modibm.f90:2021-2026, :2073-2090): wfmneutral case 91
+// (src/modwallfunctions.f90:309-346) on the k = kb plane; one thread per (i, j).  The uniform grid has
+// dxf = dx and dxhi = 1/dx.  The momfluxb / tau_x / tau_y diagnostics are not kept.
+struct BottomArgs {
+  const double *u0, *v0, *ekm, *ekh;
+  double *up, *vp;
+  const double *sv0[16];
+  double *svp[16];
+  int nsv, wrap_vp;
+  double z0;
+};
+__global__ __launch_bounds__(256) void bottom_kernel(Geo g, Metrics m, BottomArgs a) {
+  const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+  if (i >= g.nx || j >= g.ny) return;
+  const long c = g.idx(i, j, 0);
+  const long cxm = c - i + (i == 0 ? g.nx - 1 : i - 1), cxp = c - i + (i == g.nx - 1 ? 0 : i + 1);
+  const long sy = g.sy, sz = g.sz;
+  const int k = 1, km = 0;                       // reference level indices of the metric tables
+  const double fkar2 = 0.41 * 0.41, umin = 0.0001;
+  const double delta = 0.5 * m.dzf[k];
+  const double l_ = log(delta / a.z0);
+  const double logdz2 = l_ * l_;
+  const double ctm = fkar2 / (logdz2);
+  const double dzfi = m.dzfi[k], dzhi = m.dzhi[k], dzhiq = m.dzhiq[k];
+  {  // u component, :318-331
+    const double utang1Int = a.u0[c];
+    const double utang2Int = (a.v0[c] + a.v0[cxm] + a.v0[c + sy] + a.v0[cxm + sy]) * 0.25;
+    const double utangInt = fmax(umin, (utang1Int * utang1Int + utang2Int * utang2Int));
+    const double dummy = fabs(utang1Int) * sqrt(utangInt) * ctm;
+    const double bcmomflux = copysign(dummy, utang1Int);
+    const double emom = (m.dzf[km] * (a.ekm[c] * m.dx + a.ekm[cxm] * m.dx) +
+                         m.dzf[k] * (a.ekm[c - sz] * m.dx + a.ekm[cxm - sz] * m.dx)) * m.dxi * dzhiq;
+    a.up[c] = a.up[c] + (a.u0[c] - a.u0[c - sz]) * emom * dzhi * dzfi - bcmomflux * dzfi;
+  }
+  {  // v component, :333-346
+    const double utang1Int = (a.u0[c] + a.u0[c - sy] + a.u0[cxp - sy] + a.u0[cxp]) * 0.25;
+    const double utang2Int = a.v0[c];
+    const double utangInt = fmax(umin, (utang1Int * utang1Int + utang2Int * utang2Int));
+    const double dummy = fabs(utang2Int) * sqrt(utangInt) * ctm;
+    const double bcmomflux = copysign(dummy, utang2Int);
+    const double eomm = (m.dzf[km] * (a.ekm[c] + a.ekm[c - sy]) + m.dzf[k] * (a.ekm[c - sz] + a.ekm[c - sy - sz])) * dzhiq;
+    const double t = a.vp[c] + (a.v0[c] - a.v0[c - sz]) * eomm * dzhi * dzfi - bcmomflux * dzfi;
+    a.vp[c] = t;
+    if (a.wrap_vp && j == 0) a.vp[c + sy * g.ny] = t;      // bcpup's cyclic pvp(je+1) = pvp(jb)
+  }
+  for (int n = 0; n < a.nsv; ++n) {   // zero-flux floor for the scalars, src/modibm.f90:2073-2090
+    const double *c0 = a.sv0[n];
+    a.svp[n][c] = a.svp[n][c] + (0.5 * (m.dzf[km] * a.ekh[c] + m.dzf[k] * a.ekh[c - sz]) * (c0[c] - c0[c - sz]) * m.dzh2i[k] + 0.) * dzfi;
+  }
+}
+
 inline dim3 cell_grid(const Geo &g, dim3 b) {
   (void)b;
   return dim3((unsigned)tile_grid(g).tiles * (unsigned)g.nz, 1, 1);
 }
 
 }  // namespace
+
+int k_bottom(udc_handle *h, bool wrap_vp) {
+  const Geo &g = h->g;
+  BottomArgs a{};
+  a.u0 = h->fields[UDC_U0]; a.v0 = h->fields[UDC_V0]; a.ekm = h->fields[UDC_EKM]; a.ekh = h->fields[UDC_EKH];
+  a.up = h->fields[UDC_UP]; a.vp = h->fields[UDC_VP];
+  a.nsv = h->cfg.nsv; a.wrap_vp = wrap_vp ? 1 : 0; a.z0 = h->p.z0;
+  for (int n = 0; n < a.nsv; ++n) { a.sv0[n] = h->fields[UDC_SV0 + 3 * n]; a.svp[n] = h->fields[UDC_SVP + 3 * n]; }
+  PROF(h, "bottom");
+  hipLaunchKernelGGL(bottom_kernel, dim3((unsigned)((g.nx + 63) / 64), (unsigned)((g.ny + 3) / 4)), dim3(64, 4), 0, h->stream,
+                     g, h->m, a);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
 
 int k_momentum(udc_handle *h, bool adv, bool diff, bool forces) {
   const Geo &g = h->g;

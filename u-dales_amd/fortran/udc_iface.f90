@@ -32,10 +32,16 @@ module udc_iface
     integer(c_int) :: sgs, bctopm
     real(c_double) :: uinf, vinf
     integer(c_int) :: nsv
+    integer(c_int) :: lbottom
+    real(c_double) :: z0
   end type udc_config
 
   type(c_ptr), save :: udc_h = c_null_ptr
   integer, save :: udc_residency = 0
+  ! floor wall function on the device (device-resident mode only: in the other modes the host's own `bottom`,
+  ! src/modibm.f90:1998, edits the pulled tendencies and must not be applied twice); set by udc_set_floor
+  logical, save :: udc_floor_on = .false.
+  real(c_double), save :: udc_floor_z0 = -1.
 
   interface
     integer(c_int) function udc_create(cfg, h) bind(C, name='udc_create')
@@ -75,6 +81,10 @@ module udc_iface
       type(c_ptr), value :: h
     end function
     integer(c_int) function udc_subgrid(h) bind(C, name='udc_subgrid')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function udc_bottom(h) bind(C, name='udc_bottom')
       import :: c_int, c_ptr
       type(c_ptr), value :: h
     end function
@@ -152,6 +162,20 @@ contains
     stop 1
   end subroutine udc_check
 
+  !> Binding for modibm (INTEGRATION.md section 3): `call udc_set_floor(lbottom .and. BCbotm == 3, z0)` from initibm,
+  !! before the first substep, lets a device-resident run apply `bottom`'s floor wall function on the GPU
+  !! (udc_bottom inside the fused substep).
+  subroutine udc_set_floor(on, z0)
+    logical, intent(in) :: on
+    real(c_double), intent(in) :: z0
+    if (c_associated(udc_h)) then
+      write (0, *) 'ERROR: udc_set_floor must be called before the first advection/subgrid call'
+      stop 1
+    end if
+    udc_floor_on = on
+    udc_floor_z0 = z0
+  end subroutine udc_set_floor
+
   !> Create the device mirror once all of initglobal/initfields/initsubgrid/initpois have run.
   subroutine udc_ensure
     use modglobal, only: itot, jtot, ktot, dx, dy, dzf, dzh, kb, ke, kh, numol, prandtlmoli, nsv, &
@@ -195,6 +219,8 @@ contains
     cfg%bctopm = BCtopm
     cfg%uinf = Uinf; cfg%vinf = Vinf
     cfg%nsv = nsv
+    cfg%lbottom = merge(1, 0, udc_floor_on)
+    cfg%z0 = udc_floor_z0
     call udc_check(udc_create(cfg, udc_h), 'udc_create')
     if (nprocs > 1) then
       ! RCCL communicator over the y-slab ranks: rank 0 makes the id, MPI carries it (INTEGRATION.md section 4)

@@ -12,8 +12,13 @@ def from_deck(deck, device=0, rank=0, nranks=1):
     from .core import DynCore
     g = Grid.from_deck(deck)
     sgs, csz, c_vreman, prandtli = sgs_from_deck(deck)
+    lbottom = bool(deck.get("WALLS", "lbottom"))
+    if lbottom and int(deck.get("BC", "BCbotm")) != 3:
+        # the reference's other floor (BCbotm = 2, wfuno) needs the temperature equation
+        raise ValueError("lbottom: only the neutral floor wall function BCbotm = 3 (wfmneutral) is built")
     core = DynCore(g, sgs=sgs, bctopm=int(deck.get("BC", "BCtopm")), nsv=int(deck.get("SCALARS", "nsv")),
-                   prandtli=prandtli, c_vreman=c_vreman, csz=csz, device=device, rank=rank, nranks=nranks)
+                   prandtli=prandtli, c_vreman=c_vreman, csz=csz, device=device, rank=rank, nranks=nranks,
+                   lbottom=lbottom, z0=float(deck.get("BC", "z0")))
     import numpy as np
     # dpdxl, dpdyl: src/modstartup.f90:2071-2081 (lcoriol false => om23_gs terms still present:
     # dpdxl = om23_gs*vg - pgx - dpdx with om23_gs = 2*omega*sin(lat); ug = vg = 0 in our decks)

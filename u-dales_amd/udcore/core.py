@@ -18,7 +18,7 @@ from .grid import Grid
 class DynCore:
     def __init__(self, g: Grid, sgs=L.SGS_VREMAN, bctopm=1, nsv=0, numol=1.5e-5, prandtlmol=0.71,
                  prandtli=1. / 0.333, c_vreman=0.07, csz=0.21658244510412, uinf=0., vinf=0.,
-                 device=0, rank=0, nranks=1):
+                 device=0, rank=0, nranks=1, lbottom=False, z0=-1.):
         self.g = g
         self.nsv = nsv
         self.lib = L.load()
@@ -26,7 +26,8 @@ class DynCore:
         self._dzh = np.ascontiguousarray(g.dzh, dtype=np.float64)
         cfg = L.UdcConfig(g.nx, g.ny, g.nz, nranks, rank, device, g.dx, g.dy,
                           self._dzf.ctypes.data_as(L.DP), self._dzh.ctypes.data_as(L.DP),
-                          numol, 1. / prandtlmol, prandtli, c_vreman, csz, sgs, bctopm, uinf, vinf, nsv)
+                          numol, 1. / prandtlmol, prandtli, c_vreman, csz, sgs, bctopm, uinf, vinf, nsv,
+                          int(bool(lbottom)), z0)
         self.h = C.c_void_p()
         L._check(self.lib.udc_create(C.byref(cfg), C.byref(self.h)), "udc_create")
         self.nyl = g.ny // nranks
@@ -117,6 +118,10 @@ class DynCore:
 
     def subgrid(self):
         L._check(self.lib.udc_subgrid(self.h), "udc_subgrid")
+
+    def bottom(self):
+        """`bottom` (src/modibm.f90:1998): floor wall function, between subgrid and forces."""
+        L._check(self.lib.udc_bottom(self.h), "udc_bottom")
 
     def forces(self):
         L._check(self.lib.udc_forces(self.h), "udc_forces")

@@ -23,7 +23,7 @@ SGS_DNS, SGS_SMAGORINSKY, SGS_VREMAN = 0, 1, 2
 
 EXPORTS = ["udc_create", "udc_destroy", "udc_last_error", "udc_version", "udc_comm_unique_id",
            "udc_comm_init", "udc_local_group_create", "udc_comm_init_local", "udc_field_upload", "udc_field_download", "udc_set_forcing",
-           "udc_advection", "udc_subgrid", "udc_forces", "udc_poisson", "udc_tstep_integrate",
+           "udc_advection", "udc_subgrid", "udc_bottom", "udc_forces", "udc_poisson", "udc_tstep_integrate",
            "udc_halos", "udc_boundary", "udc_tstep_maxima", "udc_substep", "udc_run",
            "udc_divergence", "udc_sync", "udc_profile_enable", "udc_profile_reset",
            "udc_profile_get"]
@@ -37,7 +37,8 @@ class UdcConfig(C.Structure):
                 ("numol", C.c_double), ("prandtlmoli", C.c_double), ("prandtli", C.c_double),
                 ("c_vreman", C.c_double), ("csz", C.c_double),
                 ("sgs", C.c_int), ("bctopm", C.c_int),
-                ("uinf", C.c_double), ("vinf", C.c_double), ("nsv", C.c_int)]
+                ("uinf", C.c_double), ("vinf", C.c_double), ("nsv", C.c_int),
+                ("lbottom", C.c_int), ("z0", C.c_double)]
 
 
 class UdcError(RuntimeError):
