@@ -108,6 +108,12 @@ int udc_subgrid(udc_handle *h);
 int udc_bottom(udc_handle *h);
 /* forces      src/modforces.f90:46      neutral branch: up -= dpdxl(k), vp -= dpdyl(k), wp(kb)=0 */
 int udc_forces(udc_handle *h);
+/* masscorr    src/modforces.f90:328     volume-flow branches: up += (uflowrate - <um + rk3coef up>)/rk3coef (luvolflowr,
+ *             :389-417) and the same for v (lvvolflowr, :467-494); <.> = volume average over the whole domain
+ *             (all-reduced over the slabs).  Called after forces (src/program.f90:169).  No-op unless enabled with
+ *             udc_set_masscorr (&PHYSICS luvolflowr/uflowrate, lvvolflowr/vflowrate). */
+int udc_set_masscorr(udc_handle *h, int luvolflowr, double uflowrate, int lvvolflowr, double vflowrate);
+int udc_masscorr(udc_handle *h, int rk3step, double dt);
 /* poisson     src/modpois.f90:419       fillps+bcpup, FFT(x,y)+tridiagonal(z), tderive+bcp */
 int udc_poisson(udc_handle *h, int rk3step, double dt);
 /* tstep_integrate src/modtstep.f90:171  u0 = um + rk3coef*up ..., zero tendencies, m <- 0 on stage 3 */

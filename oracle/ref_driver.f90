@@ -39,7 +39,7 @@ program ref_driver
   use modpois, only: initpois, poisson, p
   use modadvection, only: advection
   use modtstep, only: tstep_update, tstep_integrate
-  use modforces, only: forces
+  use modforces, only: forces, masscorr
   implicit none
 
   character(256) :: mode, outfile, arg
@@ -73,6 +73,8 @@ program ref_driver
   call init_decomp_np1
   call initglobal
   call initfields
+  ! createmasks without IBM, src/modibm.f90:2121-2135 (modibm cannot be built): slab cell counts of the masks
+  IIcs = nint(rslabs); IIus = nint(rslabs); IIvs = nint(rslabs); IIws = nint(rslabs)
   call initboundary
   call initthermodynamics
   call initsubgrid
@@ -151,6 +153,7 @@ contains
     call subgrid
     call floor_bottom
     if (lforces) call forces
+    call masscorr                           ! src/program.f90:169 (no-op unless luvolflowr / lvvolflowr)
     call poisson
     call tstep_integrate
     call halos
@@ -193,7 +196,8 @@ contains
     namelist /RUN/ iexpnr, runtime, dtmax, trestart, ladaptive, irandom, randu, krand, courant, diffnr, &
       libm, lles, lrandomize, nprocx, nprocy
     namelist /DOMAIN/ itot, jtot, ktot, xlen, ylen
-    namelist /PHYSICS/ lmoist, lcoriol, lbuoyancy, ltempeq, lprofforc, dpdx
+    namelist /PHYSICS/ lmoist, lcoriol, lbuoyancy, ltempeq, lprofforc, dpdx, luvolflowr, uflowrate, &
+      lvvolflowr, vflowrate
     namelist /DYNAMICS/ ipoiss, iadv_mom, iadv_tke, iadv_thl, iadv_qt, iadv_sv
     namelist /BC/ BCxm, BCym, BCtopm, BCtopT, BCtops, BCbotm, BCbots, BCzp, wttop, thl_top, z0
     namelist /SCALARS/ nsv
@@ -468,6 +472,8 @@ contains
     call subgrid
     call floor_bottom
     if (lforces) call forces
+    if (luvolflowr .or. lvvolflowr) call dump_tend('frc')   ! tendencies masscorr starts from
+    call masscorr
     call dump_tend('pre')
     call poisson                            ! src/modpois.f90:419
     call put3('poi.p', p, (/ib - ih, jb - jh, kb - kh/))

@@ -853,6 +853,42 @@ void orc_bottom(const orc_grid *g, const double *u0, const double *v0, const dou
   metrics_free(&m);
 }
 
+/* ====================================================================== masscorr */
+/* src/modforces.f90:328-497, volume-flow branches: luvolflowr (:389-417) and lvvolflowr (:467-494);
+ * avexy_ibm without IBM (src/modmpi.f90:623-664): slab sums divided by IIus(k) = itot*jtot. */
+static double volflow_def(const orc_grid *g, double rk3coef, const double *tp, const double *tm, double target) {
+  double zsize = 0.;
+  for (int k = 1; k <= g->nz; ++k) zsize += g->dzf[k];               /* zh(ke+1) */
+  const double cnt = (double)g->nx * (double)g->ny;
+  double svol = 0., svolold = 0.;
+  for (int k = 1; k <= g->nz; ++k) {
+    double a = 0., b = 0.;
+    for (int j = 1; j <= g->ny; ++j)
+      for (int i = 1; i <= g->nx; ++i) { a += M(tp, i, j, k); b += M(tm, i, j, k); }
+    svol += (a / cnt) * g->dzf[k];
+    svolold += (b / cnt) * g->dzf[k];
+  }
+  const double outflow = rk3coef * svol / zsize;
+  const double flowrateold = svolold / zsize;
+  return target - (outflow + flowrateold);
+}
+void orc_masscorr(const orc_grid *g, int rk3step, double dt, double *up, const double *um, double *vp, const double *vm) {
+  const double rk3coef = dt / (4. - (double)rk3step);
+  const double rk3coefi = 1 / rk3coef;
+  if (g->luvolflowr) {
+    const double udef = volflow_def(g, rk3coef, up, um, g->uflowrate);
+    for (int k = 1; k <= g->nz; ++k)
+      for (int j = 1; j <= g->ny; ++j)
+        for (int i = 1; i <= g->nx; ++i) M(up, i, j, k) = M(up, i, j, k) + udef * rk3coefi;
+  }
+  if (g->lvvolflowr) {
+    const double vdef = volflow_def(g, rk3coef, vp, vm, g->vflowrate);
+    for (int k = 1; k <= g->nz; ++k)
+      for (int j = 1; j <= g->ny; ++j)
+        for (int i = 1; i <= g->nx; ++i) M(vp, i, j, k) = M(vp, i, j, k) + vdef * rk3coefi;
+  }
+}
+
 /* ====================================================================== substep */
 /* src/program.f90:132-222: advection, subgrid, forces, poisson, tstep_integrate, halos, boundary */
 void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
@@ -882,6 +918,7 @@ void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
   for (int n = 0; n < g->nsv; ++n) orc_diffc(g, s->sv0 + n * nc, s->ekh, s->svp + n * nc);
   orc_bottom(g, s->u0, s->v0, s->ekm, s->ekh, s->sv0, s->up, s->vp, s->svp, NULL);   /* src/program.f90:152 */
   if (s->dpdxl) orc_forces(g, s->dpdxl, s->dpdyl, s->up, s->vp, s->wp);
+  orc_masscorr(g, rk3step, dt, s->up, s->um, s->vp, s->vm);                            /* src/program.f90:169 */
   orc_fillps(g, rk3coef, s->up, s->vp, s->wp, s->um, s->vm, s->wm, s->pup, s->pvp, s->pwp, s->p);
   orc_poisson_solve(g, s->p);
   orc_tderive(g, s->p, s->up, s->vp, s->wp, s->pres0);

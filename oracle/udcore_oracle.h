@@ -41,6 +41,8 @@ typedef struct {
   int nsv;                  /* passive scalars, kappa scheme (src/modglobal.f90:557-559) */
   int lbottom;              /* floor wall function (src/modibm.f90:49,2021), BCbotm = 3, BCbots = 1 */
   double z0;                /* roughness length (src/modsurfdata.f90:72) */
+  int luvolflowr, lvvolflowr;   /* masscorr volume-flow switches (src/modglobal.f90:231) */
+  double uflowrate, vflowrate;  /* prescribed volume-mean velocities (src/modglobal.f90:331) */
 } orc_grid;
 
 /* ---- advection: src/modadvection.f90 */
@@ -69,6 +71,8 @@ void orc_forces(const orc_grid *g, const double *dpdxl, const double *dpdyl,
 /* ---- floor: `bottom` src/modibm.f90:1998-2100 -> wfmneutral src/modwallfunctions.f90:263-350; momfluxb may be NULL */
 void orc_bottom(const orc_grid *g, const double *u0, const double *v0, const double *ekm, const double *ekh,
                 const double *sv0, double *up, double *vp, double *svp, double *momfluxb);
+/* ---- masscorr: src/modforces.f90:328-497 (volume-flow branches) */
+void orc_masscorr(const orc_grid *g, int rk3step, double dt, double *up, const double *um, double *vp, const double *vm);
 /* ---- pressure: src/modpois.f90 (ipoiss = POISS_FFT2D, BCzp = 1, periodic x,y) */
 void orc_fillps(const orc_grid *g, double rk3coef, const double *up, const double *vp,
                 const double *wp, const double *um, const double *vm, const double *wm,

@@ -29,7 +29,7 @@ REF = os.path.join(ROOT, "oracle", "_ref", "udales_ref")
 
 
 def deck(iexpnr, nx, ny, nz, dx=0.5, dy=0.5, dtmax=0.25, sgs="vreman", nsv=0, bctopm=1,
-         oracle="", lles=True, randu=0.01, floor=False, z0=0.05):
+         oracle="", lles=True, randu=0.01, floor=False, z0=0.05, physics=""):
     sub = {"vreman": "lvreman = .true.\nlsmagorinsky = .false.",
            "smag": "lsmagorinsky = .true.\nlvreman = .false.",
            "dns": "lvreman = .false.\nlsmagorinsky = .false."}[sgs]
@@ -53,6 +53,7 @@ xlen = {nx * dx}
 ylen = {ny * dy}
 /
 &PHYSICS
+{physics}
 /
 &DYNAMICS
 ipoiss = 0
@@ -98,7 +99,7 @@ def write_case(d, iexpnr, text, zf, u=1.0, v=0.0, pgx=1e-4):
 
 
 KEEP_KERNELS = ("meta dzf dzh zf dpdxl dpdyl rk3 in.u0 in.v0 in.w0 in.um in.vm in.wm in.pres0 "
-                "in.ekm in.ekh adv.up adv.vp adv.wp sub.ekm sub.ekh sub.u0 sub.up sub.vp sub.wp bot.up bot.vp "
+                "in.ekm in.ekh adv.up adv.vp adv.wp sub.ekm sub.ekh sub.u0 sub.up sub.vp sub.wp bot.up bot.vp frc.up frc.vp "
                 "pre.up pre.vp pre.wp poi.p poi.pres0 poi.up poi.vp poi.wp out.u0 out.v0 out.w0 "
                 "out.um out.pres0").split()
 
@@ -116,6 +117,14 @@ CASES = {
     "k_floor_12x8x6": ("kernels", 16, 12, 8, 6, dict(sgs="vreman", floor=True, oracle="nspin = 3"), 1.0),
     "run_floor_scalar_16x8x12s": ("run", 23, 16, 8, 12,
                                   dict(sgs="smag", nsv=1, floor=True, dx=0.3, oracle="nsub = 6\ndump_at = 3, 6"), 1.06),
+    # masscorr: prescribed volume-flow rate in u (and v), src/modforces.f90:328-497
+    "k_volflow_12x8x6": ("kernels", 17, 12, 8, 6,
+                         dict(sgs="vreman", floor=True, physics="luvolflowr = .true.\nuflowrate = 1.2",
+                              oracle="nspin = 3"), 1.04),
+    "run_volflow_uv_16x16x8": ("run", 24, 16, 16, 8,
+                               dict(sgs="vreman", physics="luvolflowr = .true.\nuflowrate = 1.1\n"
+                                    "lvvolflowr = .true.\nvflowrate = 0.05",
+                                    oracle="nsub = 6\ndump_at = 1, 3, 6"), 1.0),
 }
 
 

@@ -26,7 +26,8 @@ class OrcGrid(C.Structure):
                 ("c_vreman", C.c_double), ("csz", C.c_double),
                 ("sgs", C.c_int), ("bctopm", C.c_int),
                 ("uinf", C.c_double), ("vinf", C.c_double), ("nsv", C.c_int),
-                ("lbottom", C.c_int), ("z0", C.c_double)]
+                ("lbottom", C.c_int), ("z0", C.c_double),
+                ("luvolflowr", C.c_int), ("lvvolflowr", C.c_int), ("uflowrate", C.c_double), ("vflowrate", C.c_double)]
 
 
 class OrcState(C.Structure):
@@ -64,7 +65,8 @@ class Oracle:
 
     def __init__(self, nx, ny, nz, dx, dy, dzf, dzh, sgs=2, bctopm=1, nsv=0, numol=1.5e-5,
                  prandtlmoli=1. / 0.71, prandtli=1. / 0.333, c_vreman=0.07, csz=None,
-                 uinf=0., vinf=0., lbottom=False, z0=0.05):
+                 uinf=0., vinf=0., lbottom=False, z0=0.05, luvolflowr=False, uflowrate=0.,
+                 lvvolflowr=False, vflowrate=0.):
         self.nx, self.ny, self.nz, self.nsv = nx, ny, nz, nsv
         self.dzf = np.ascontiguousarray(dzf, dtype=np.float64)
         self.dzh = np.ascontiguousarray(dzh, dtype=np.float64)
@@ -75,7 +77,8 @@ class Oracle:
             ceps = 2. * np.pi / cf * (1.5 * alpha) ** (-1.5)
             csz = (cm ** 3 / ceps) ** 0.25
         self.g = OrcGrid(nx, ny, nz, dx, dy, ptr(self.dzf), ptr(self.dzh), numol, prandtlmoli,
-                         prandtli, c_vreman, csz, sgs, bctopm, uinf, vinf, nsv, int(bool(lbottom)), z0)
+                         prandtli, c_vreman, csz, sgs, bctopm, uinf, vinf, nsv, int(bool(lbottom)), z0,
+                         int(bool(luvolflowr)), int(bool(lvvolflowr)), uflowrate, vflowrate)
         self.L = lib()
 
     def mshape(self):

@@ -92,9 +92,13 @@ def test_each_routine_matches_reference(name, iexp):
     core.subgrid()
     core.bottom()
     core.forces()
+    core.rk3step, core.dt = int(fix["rk3"].data[0]), float(fix["rk3"].data[1])
+    if "frc.up" in fix:      # masscorr: tendencies before / after the volume-flow correction
+        for k in ("up", "vp"):
+            assert relerr(interior(core.download(k)), interior(marr(fix, "frc." + k, nz))) <= KERNEL_TOL, k
+    core.masscorr()
     for k in ("up", "vp", "wp"):
         assert relerr(interior(core.download(k)), interior(marr(fix, "pre." + k, nz))) <= KERNEL_TOL, k
-    core.rk3step, core.dt = int(fix["rk3"].data[0]), float(fix["rk3"].data[1])
     core.poisson()
     # p solves lap(p) = div(up + um/rk3coef): its round-off floor is set by the O(U/rk3coef) terms
     # that cancel in the divergence, so errors are measured against the natural pressure scale
@@ -135,7 +139,7 @@ def test_substeps_match_reference(name, iexp, fused):
             core.substep(rk, dt, with_forces=True)
         else:
             core.tstep_update(dt)
-            core.advection(); core.subgrid(); core.bottom(); core.forces(); core.poisson()
+            core.advection(); core.subgrid(); core.bottom(); core.forces(); core.masscorr(); core.poisson()
             core.tstep_integrate(); core.halos(); core.boundary()
         if isub in dumps:
             tag = f"s{isub:03d}"

@@ -91,7 +91,7 @@ print("RCCL_OK", m, dv)
     assert "RCCL_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
-def run_virtual(P, g, deck_like, st_global, nsub, dt, sgs, nsv=0):
+def run_virtual(P, g, deck_like, st_global, nsub, dt, sgs, nsv=0, extras=False):
     """Run nsub substeps on P virtual ranks; returns the stitched global u0, v0, w0, pres0."""
     from udcore.core import DynCore
     from udcore import lib as L
@@ -103,8 +103,10 @@ def run_virtual(P, g, deck_like, st_global, nsub, dt, sgs, nsv=0):
 
     def worker(r):
         try:
-            core = DynCore(g, sgs=sgs, nsv=nsv, rank=r, nranks=P)
+            core = DynCore(g, sgs=sgs, nsv=nsv, rank=r, nranks=P, lbottom=extras, z0=0.04)
             cores[r] = core
+            if extras:      # floor wall function + prescribed volume flow (all-reduced sums)
+                core.set_masscorr(True, 1.03, True, 0.02)
             if P > 1:
                 core.comm_init_local(group)
             local = {}
@@ -136,8 +138,9 @@ def run_virtual(P, g, deck_like, st_global, nsub, dt, sgs, nsv=0):
     return res
 
 
-@pytest.mark.parametrize("shape,sgs,chunks", [((32, 16, 12), 2, 1), ((24, 32, 10), 1, 2), ((32, 16, 12), 2, 3)])
-def test_decomposition_invariance(shape, sgs, chunks, monkeypatch):
+@pytest.mark.parametrize("shape,sgs,chunks,extras", [((32, 16, 12), 2, 1, False), ((24, 32, 10), 1, 2, False),
+                                                     ((32, 16, 12), 2, 3, False), ((32, 16, 12), 2, 1, True)])
+def test_decomposition_invariance(shape, sgs, chunks, extras, monkeypatch):
     # chunks > 1: the k-chunked all-to-all pipeline (exchange on a second stream, overlapped with rocFFT)
     monkeypatch.setenv("UDC_A2A_CHUNKS", str(chunks))
     from test_gpu_parity import random_state
@@ -145,10 +148,10 @@ def test_decomposition_invariance(shape, sgs, chunks, monkeypatch):
     nx, ny, nz = shape
     g = Grid.uniform(nx, ny, nz)
     st = random_state(g, seed=42)
-    ref = run_virtual(1, g, None, st, 6, 0.05, sgs)
+    ref = run_virtual(1, g, None, st, 6, 0.05, sgs, extras=extras)
     assert ref["div"][0] < 1e-11
     for P in (2, 4):
-        got = run_virtual(P, g, None, st, 6, 0.05, sgs)
+        got = run_virtual(P, g, None, st, 6, 0.05, sgs, extras=extras)
         for k in ("u0", "v0", "w0", "pres0"):
             e = relerr(got[k][1:-1], ref[k][1:-1])
             assert e <= 1e-10, (P, k, e)

@@ -135,6 +135,8 @@ extern "C" int udc_create(const udc_config *cfg, udc_handle **out) {
     dzh[k] = cfg->dzh[k];
     dzhi[k] = 1. / dzh[k]; dzhiq[k] = 0.25 * dzhi[k]; dzh2i[k] = dzhi[k] * dzhi[k];
   }
+  h->zsize = 0.;
+  for (int k = 1; k <= g.nz; ++k) h->zsize += dzf[k];      // zh(ke+1), src/modglobal.f90:747-750
   double *mlen = &hm[11 * nk];
   // delta(i,k) = (dxf(i)*dy*dzf(k))**(1/3), src/modglobal.f90:793-797 (uniform x)
   for (int k = 0; k < nk; ++k) mlen[k] = cfg->csz * pow(cfg->dx * cfg->dy * dzf[k], 1. / 3.);
@@ -322,6 +324,19 @@ extern "C" int udc_bottom(udc_handle *h) {
   return k_bottom(h, false);
 }
 
+extern "C" int udc_set_masscorr(udc_handle *h, int luvolflowr, double uflowrate, int lvvolflowr, double vflowrate) {
+  h->luvolflowr = luvolflowr ? 1 : 0; h->uflowrate = uflowrate;
+  h->lvvolflowr = lvvolflowr ? 1 : 0; h->vflowrate = vflowrate;
+  return 0;
+}
+
+extern "C" int udc_masscorr(udc_handle *h, int rk3step, double dt) {
+  HIP_OK(hipSetDevice(h->device));
+  if (!h->luvolflowr && !h->lvvolflowr) return 0;
+  if (tend_clean(h) || um_materialise(h)) return 1;
+  return k_masscorr(h, dt / (4. - (double)rk3step), false, false);
+}
+
 extern "C" int udc_forces(udc_handle *h) {
   HIP_OK(hipSetDevice(h->device));
   if (tend_clean(h) || um_materialise(h)) return 1;
@@ -411,6 +426,8 @@ extern "C" int udc_substep(udc_handle *h, int rk3step, double dt, int with_force
     if (k_scalar_fused(h, n)) return 1;
   // `bottom` (src/program.f90:152): additive on the k = kb tendencies, hence equally on pup = up + um/rk3coef
   if (h->p.lbottom && k_bottom(h, fold)) return 1;
+  // masscorr (src/program.f90:169); without pup the tendencies and um are summed separately
+  if (k_masscorr(h, rk3coef, pup, fold)) return 1;
   if (!fold) {
     const int fvp[1] = {UDC_VP};
     if (k_halo_y(h, fvp, 1, 1)) return 1;

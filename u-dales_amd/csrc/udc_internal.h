@@ -107,6 +107,9 @@ struct udc_handle {
   double *partials = nullptr;           // per-workgroup partial results of the two-stage reductions
   size_t partials_cap = 0;
   // profiling
+  // masscorr (src/modforces.f90:328): prescribed volume-flow rates
+  int luvolflowr = 0, lvvolflowr = 0;
+  double uflowrate = 0., vflowrate = 0., zsize = 0.;
   bool um_alias = false;                // um,vm,wm are logically equal to u0,v0,w0 (after RK stage 3 of a fused
                                         // substep); the UM buffers are stale until stage 1 rotates the pointers
   bool no_alias = false;                // UDC_NO_ALIAS=1: always copy (A/B switch)
@@ -178,6 +181,7 @@ int k_scalar_adv(udc_handle *h, int n);
 int k_scalar_diff(udc_handle *h, int n);
 int k_scalar_fused(udc_handle *h, int n);          // advection + diffusion in one sweep (same accumulation order)
 int k_forces(udc_handle *h);
+int k_masscorr(udc_handle *h, double rk3coef, bool pup_mode, bool wrap_vp);   // masscorr, volume-flow branches
 int k_bottom(udc_handle *h, bool wrap_vp);       // floor wall function; wrap_vp: also refresh vp's ghost row ny (bcpup)
 int k_divergence_rhs(udc_handle *h, double rk3coef, bool pup);
 int k_poisson_solve(udc_handle *h);

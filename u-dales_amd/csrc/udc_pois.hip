@@ -607,6 +607,41 @@ __global__ __launch_bounds__(256) void divcheck_kernel(Geo g, TileGrid tg, Metri
   block_reduce2<0, 1>(dmax, dsum, out);
 }
 
+
+// masscorr, src/modforces.f90:328-497, volume-flow branches (luvolflowr :389-417, lvvolflowr :467-494).
+// flowsum: S_a = sum(a dzf(k)), S_b = sum(b dzf(k)) over the slab interior (b may be null).
+__global__ __launch_bounds__(256) void flowsum_kernel(Geo g, TileGrid tg, Metrics m, const double *__restrict__ a,
+                                                      const double *__restrict__ b, double *__restrict__ out) {
+  int i, j, k;
+  const bool inside_ = tile_decode(g, tg, i, j, k);
+  double sa = 0., sb = 0.;
+  if (inside_) {
+    const long c = g.idx(i, j, k);
+    const double w = m.dzf[k + 1];
+    sa = a[c] * w;
+    if (b) sb = b[c] * w;
+  }
+  block_reduce2<1, 1>(sa, sb, out);
+}
+// field += (target - (ca S[0] + cb S[1])) rk3coefi for up to two components (null field = skip)
+struct FlowShift { double *f; const double *S; double target, ca, cb; };
+__global__ __launch_bounds__(256) void flowshift_kernel(Geo g, TileGrid tg, FlowShift u, FlowShift v, double rk3coefi, int wrap_vp) {
+  int i, j, k;
+  const bool inside_ = tile_decode(g, tg, i, j, k);
+  if (!inside_) return;
+  const long c = g.idx(i, j, k);
+  if (u.f) {
+    const double def = u.target - (u.ca * u.S[0] + u.cb * u.S[1]);
+    u.f[c] = u.f[c] + def * rk3coefi;
+  }
+  if (v.f) {
+    const double def = v.target - (v.ca * v.S[0] + v.cb * v.S[1]);
+    const double t = v.f[c] + def * rk3coefi;
+    v.f[c] = t;
+    if (wrap_vp && j == 0) v.f[c + (long)g.sy * g.ny] = t;
+  }
+}
+
 }  // namespace
 
 // --------------------------------------------------------------------------------------
@@ -1036,6 +1071,37 @@ static int ensure_partials(udc_handle *h, size_t nblocks) {
   if (h->partials) HIP_OK(hipFree(h->partials));
   HIP_OK(hipMalloc(&h->partials, sizeof(double) * 2 * nblocks));
   h->partials_cap = nblocks;
+  return 0;
+}
+
+// masscorr: pup_mode = the UP/VP arrays hold pup = up + um/rk3coef (fused substep), so rk3coef <pup> is the
+// predicted flow rate and um is not read.  Sums are per-slab, then all-reduced (avexy_ibm's MPI_ALLREDUCE).
+int k_masscorr(udc_handle *h, double rk3coef, bool pup_mode, bool wrap_vp) {
+  if (!h->luvolflowr && !h->lvvolflowr) return 0;
+  const Geo &g = h->g;
+  dim3 b(64, 4, 1), gr = cell_grid(g, b);
+  if (ensure_partials(h, gr.x)) return 1;
+  PROF(h, "masscorr");
+  const double vol = (double)g.nx * (double)h->cfg.jtot * h->zsize;     // IIus(k) = itot*jtot cells per level, zh(ke+1)
+  double *S = h->red + 16;
+  FlowShift fu{nullptr, S, 0., 0., 0.}, fv{nullptr, S + 2, 0., 0., 0.};
+  const int mo = h->um_alias ? UDC_U0 : UDC_UM;
+  for (int c = 0; c < 2; ++c) {
+    if (!(c == 0 ? h->luvolflowr : h->lvvolflowr)) continue;
+    const double *a = h->fields[UDC_UP + c], *bm = pup_mode ? nullptr : h->fields[mo + c];
+    hipLaunchKernelGGL(flowsum_kernel, gr, b, 0, h->stream, g, tile_grid(g), h->m, a, bm, h->partials);
+    hipLaunchKernelGGL((reduce_partials_kernel<1, 1>), dim3(1), dim3(1024), 0, h->stream, h->partials, (long)gr.x, 0., 0.,
+                       S + 2 * c);
+    FlowShift &f = c == 0 ? fu : fv;
+    f.f = h->fields[UDC_UP + c];
+    f.target = c == 0 ? h->uflowrate : h->vflowrate;
+    f.ca = rk3coef / vol;
+    f.cb = pup_mode ? 0. : 1. / vol;
+  }
+  HIP_OK(hipGetLastError());
+  if (comm_allreduce(h, S, 4, 1)) return 1;
+  hipLaunchKernelGGL(flowshift_kernel, gr, b, 0, h->stream, g, tile_grid(g), fu, fv, 1. / rk3coef, wrap_vp ? 1 : 0);
+  HIP_OK(hipGetLastError());
   return 0;
 }
 

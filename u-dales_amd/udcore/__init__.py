@@ -19,6 +19,8 @@ def from_deck(deck, device=0, rank=0, nranks=1):
     core = DynCore(g, sgs=sgs, bctopm=int(deck.get("BC", "BCtopm")), nsv=int(deck.get("SCALARS", "nsv")),
                    prandtli=prandtli, c_vreman=c_vreman, csz=csz, device=device, rank=rank, nranks=nranks,
                    lbottom=lbottom, z0=float(deck.get("BC", "z0")))
+    core.set_masscorr(bool(deck.get("PHYSICS", "luvolflowr")), float(deck.get("PHYSICS", "uflowrate")),
+                      bool(deck.get("PHYSICS", "lvvolflowr")), float(deck.get("PHYSICS", "vflowrate")))
     import numpy as np
     # dpdxl, dpdyl: src/modstartup.f90:2071-2081 (lcoriol false => om23_gs terms still present:
     # dpdxl = om23_gs*vg - pgx - dpdx with om23_gs = 2*omega*sin(lat); ug = vg = 0 in our decks)

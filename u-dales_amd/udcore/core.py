@@ -126,6 +126,15 @@ class DynCore:
     def forces(self):
         L._check(self.lib.udc_forces(self.h), "udc_forces")
 
+    def set_masscorr(self, luvolflowr=False, uflowrate=1., lvvolflowr=False, vflowrate=1.):
+        """&PHYSICS luvolflowr/uflowrate, lvvolflowr/vflowrate (src/modglobal.f90:231,331)."""
+        L._check(self.lib.udc_set_masscorr(self.h, int(bool(luvolflowr)), C.c_double(uflowrate),
+                                           int(bool(lvvolflowr)), C.c_double(vflowrate)), "udc_set_masscorr")
+
+    def masscorr(self):
+        """masscorr (src/modforces.f90:328), after forces."""
+        L._check(self.lib.udc_masscorr(self.h, self.rk3step, C.c_double(self.dt)), "udc_masscorr")
+
     def poisson(self):
         L._check(self.lib.udc_poisson(self.h, self.rk3step, C.c_double(self.dt)), "udc_poisson")
 
