@@ -24,6 +24,9 @@
 !   kernels  : spin-up nspin substeps, then call each reference routine separately
 !              and dump inputs/outputs (per-kernel golden vectors)
 !   time     : nsub substeps timed with MPI_Wtime exactly like src/modmpi.f90:140-160
+!   restart  : nsub substeps (a multiple of 3), then the reference's own writerestartfiles
+!              (src/modsave.f90:37-128) writes initd/inits files into the working directory; the state
+!              is also dumped as 'rst.*' records so that readers of the restart format can be checked
 program ref_driver
   use mpi
   use decomp_2d
@@ -40,6 +43,7 @@ program ref_driver
   use modadvection, only: advection
   use modtstep, only: tstep_update, tstep_integrate
   use modforces, only: forces, masscorr
+  use modsave, only: writerestartfiles
   implicit none
 
   character(256) :: mode, outfile, arg
@@ -100,6 +104,14 @@ program ref_driver
       call one_substep
     end do
     call kernel_vectors
+  case ('restart')
+    do isub = 1, nsub
+      call one_substep
+    end do
+    tnextrestart = 0.                      ! due now (src/modsave.f90:77)
+    call writerestartfiles
+    call dump_state('rst')
+    call put1('rsttime', (/timee, dt, real(ntrun)/), 1)
   case ('time')
     t0 = MPI_Wtime()
     do isub = 1, nsub

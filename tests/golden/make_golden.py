@@ -128,6 +128,50 @@ CASES = {
 }
 
 
+# restart files written by the reference's own writerestartfiles (src/modsave.f90:37-128): the files are the
+# fixture (data), plus the state dumped next to them
+RESTART_CASES = {
+    "restart_8x8x8": (31, 8, 8, 8, dict(sgs="smag", nsv=2, floor=True, oracle="nsub = 6"), 1.05),
+}
+
+
+def make_restart_cases():
+    for name, (iexp, nx, ny, nz, kw, stretch) in RESTART_CASES.items():
+        cdir = os.path.join(HERE, "cases", name)
+        os.makedirs(cdir, exist_ok=True)
+        write_case(cdir, iexp, deck(iexp, nx, ny, nz, **kw), zlevels(nz, 0.5, stretch))
+        odir = os.path.join(HERE, name)
+        os.makedirs(odir, exist_ok=True)
+        with tempfile.TemporaryDirectory() as tmp:
+            for fn in os.listdir(cdir):
+                shutil.copy(os.path.join(cdir, fn), tmp)
+            out = os.path.join(tmp, "out.bin")
+            subprocess.check_call([REF, f"namoptions.{iexp:03d}", "restart", out], cwd=tmp, stdout=subprocess.DEVNULL)
+            d = read_dump(out)
+            keep = {k: v for k, v in d.items() if k.count(".") == 0 or k.startswith("rst.")}
+            # the same deck run on without a restart: where a warm start from the files above has to arrive
+            with open(os.path.join(tmp, f"namoptions.{iexp:03d}")) as f:
+                txt = f.read().replace("nsub = 6", "nsub = 9\ndump_at = 9")
+            with open(os.path.join(tmp, f"namoptions.{iexp:03d}"), "w") as f:
+                f.write(txt)
+            out2 = os.path.join(tmp, "out2.bin")
+            subprocess.check_call([REF, f"namoptions.{iexp:03d}", "run", out2], cwd=tmp, stdout=subprocess.DEVNULL)
+            d2 = read_dump(out2)
+            keep.update({k: v for k, v in d2.items()
+                         if k.startswith("s009.") and k.split(".")[1] in ("u0", "v0", "w0", "pres0", "sv0_01", "sv0_02")})
+            tmpf = os.path.join(odir, "state.bin")
+            write_dump(tmpf, keep)
+            with open(tmpf, "rb") as f, gzip.GzipFile(tmpf + ".gz", "wb", mtime=0) as g:
+                g.write(f.read())
+            os.remove(tmpf)
+            for fn in sorted(os.listdir(tmp)):
+                if fn.startswith("initd") or fn.startswith("inits"):
+                    with open(os.path.join(tmp, fn), "rb") as f, \
+                            gzip.GzipFile(os.path.join(odir, fn + ".gz"), "wb", mtime=0) as g:
+                        g.write(f.read())
+        print(f"{name}: {sorted(os.listdir(odir))}")
+
+
 def main():
     if not os.path.exists(REF):
         sys.exit(f"{REF} missing: run `make -C oracle ref` in the build container first")
@@ -155,6 +199,7 @@ def main():
             g.write(f.read())
         os.remove(tmpf)
         print(f"{name}: {len(keep)} records, {os.path.getsize(tmpf + '.gz') / 1024:.0f} kB")
+    make_restart_cases()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,153 @@
+"""Restart files in the reference's own layout: lets a device run warm-start from, and hand
+back to, CPU uDALES.
+
+Layout (writerestartfiles, src/modsave.f90:80-121; read back by readrestartfiles, src/modstartup.f90:2194-2217):
+one Fortran *sequential unformatted* file per rank, `initd<ntrun:8>_<myidx:3>_<myidy:3>.<expnr:3>`, records
+
+    mindist(ib:ie, jb:je, kb:ke)                 real(8)
+    wall(ib:ie, jb:je, kb:ke, 1:5)               integer(4)
+    u0, v0, w0, pres0, thl0, e120, ekm, qt0, ql0, ql0h   each (ib-ih:ie+ih, jb-jh:je+jh, kb:ke+kh), real(8)
+    timee, dt                                    real(8)
+
+and, when nsv > 0, `inits...` with sv0(ib-ih:ie+ih, jb-jh:je+jh, kb:ke+kh, 1:nsv) and timee.  Every record is
+framed by 4-byte length markers (gfortran/flang convention).  With the y-slab decomposition (nprocx = 1) rank r
+writes myidx = 0, myidy = r.
+
+Arrays here are numpy [k, j, i] "m-arrays" with one ghost cell on every side (shape (nz+2, ny+2, nx+2)), the
+convention of udcore.grid / DynCore.download; the file holds their k = 1..nz+1 planes.
+"""
+from __future__ import annotations
+
+import os
+import struct
+
+import numpy as np
+
+M_FIELDS = ("u0", "v0", "w0", "pres0", "thl0", "e120", "ekm", "qt0", "ql0", "ql0h")
+
+
+def restart_name(ntrun: int, myidy: int, expnr: int, kind: str = "d", myidx: int = 0) -> str:
+    return f"init{kind}{ntrun:08d}_{myidx:03d}_{myidy:03d}.{expnr:03d}"
+
+
+def _put(f, payload: bytes):
+    n = struct.pack("<i", len(payload))
+    f.write(n); f.write(payload); f.write(n)
+
+
+def _get(f) -> bytes:
+    head = f.read(4)
+    if len(head) != 4:
+        raise EOFError("restart file: truncated record header")
+    (n,) = struct.unpack("<i", head)
+    payload = f.read(n)
+    (m,) = struct.unpack("<i", f.read(4))
+    if m != n or len(payload) != n:
+        raise ValueError("restart file: record markers do not match (not a sequential unformatted file?)")
+    return payload
+
+
+def write_initd(path, nx, ny, nz, fields: dict, timee: float, dt: float, mindist=None, wall=None, fill=None):
+    """fields: m-arrays for any of M_FIELDS; missing ones are filled with fill[name] (default 0; the neutral
+    cold start has thl0 = the prof.inp value and e120 = e12min)."""
+    fill = dict(fill or {})
+    shp = (nz + 2, ny + 2, nx + 2)
+    with open(path, "wb") as f:
+        md = np.zeros((nz, ny, nx)) if mindist is None else np.ascontiguousarray(mindist, dtype="<f8")
+        assert md.shape == (nz, ny, nx)
+        _put(f, md.tobytes())
+        wl = np.zeros((5, nz, ny, nx), dtype="<i4") if wall is None else np.ascontiguousarray(wall, dtype="<i4")
+        assert wl.shape == (5, nz, ny, nx)
+        _put(f, wl.tobytes())
+        for name in M_FIELDS:
+            a = fields.get(name)
+            if a is None:
+                a = np.full(shp, float(fill.get(name, 0.0)))
+            a = np.asarray(a, dtype="<f8")
+            assert a.shape == shp, (name, a.shape, shp)
+            _put(f, np.ascontiguousarray(a[1:]).tobytes())          # k = kb .. ke+kh
+        _put(f, struct.pack("<2d", timee, dt))
+
+
+def read_initd(path, nx, ny, nz) -> dict:
+    """Returns the ten m-arrays (ghost plane k = kb-1 zero-filled: the file does not hold it), mindist, wall,
+    timee, dt."""
+    out = {}
+    with open(path, "rb") as f:
+        out["mindist"] = np.frombuffer(_get(f), dtype="<f8").reshape(nz, ny, nx).copy()
+        out["wall"] = np.frombuffer(_get(f), dtype="<i4").reshape(5, nz, ny, nx).copy()
+        for name in M_FIELDS:
+            a = np.zeros((nz + 2, ny + 2, nx + 2))
+            a[1:] = np.frombuffer(_get(f), dtype="<f8").reshape(nz + 1, ny + 2, nx + 2)
+            out[name] = a
+        out["timee"], out["dt"] = struct.unpack("<2d", _get(f))
+    return out
+
+
+def write_inits(path, nx, ny, nz, sv0: list, timee: float):
+    """sv0: list of nsv arrays, either m-arrays (halo 1) or c-arrays (halo 2, shape (nz+4, ny+4, nx+4))."""
+    planes = []
+    for a in sv0:
+        a = np.asarray(a, dtype="<f8")
+        if a.shape == (nz + 4, ny + 4, nx + 4):
+            a = a[1:-1, 1:-1, 1:-1]
+        assert a.shape == (nz + 2, ny + 2, nx + 2), a.shape
+        planes.append(np.ascontiguousarray(a[1:]))
+    with open(path, "wb") as f:
+        _put(f, np.stack(planes).tobytes())
+        _put(f, struct.pack("<d", timee))
+
+
+def read_inits(path, nx, ny, nz, nsv) -> dict:
+    with open(path, "rb") as f:
+        raw = np.frombuffer(_get(f), dtype="<f8").reshape(nsv, nz + 1, ny + 2, nx + 2)
+        (timee,) = struct.unpack("<d", _get(f))
+    sv = []
+    for n in range(nsv):
+        a = np.zeros((nz + 2, ny + 2, nx + 2))
+        a[1:] = raw[n]
+        sv.append(a)
+    return {"sv0": sv, "timee": timee}
+
+
+# ---- device <-> restart files ---------------------------------------------------------------------------
+def save_restart(core, directory, expnr, ntrun, timee, dt, rank=0, fill=None):
+    """Download u0, v0, w0, pres0, ekm (+ scalars) of this rank's slab and write the reference's restart files.
+    Call after RK stage 3 (the reference only writes then, src/modsave.f90:61)."""
+    from . import lib as L
+    g = core.g
+    ny = core.nyl
+    fields = {k: core.download(k) for k in ("u0", "v0", "w0", "pres0", "ekm")}
+    path = os.path.join(directory, restart_name(ntrun, rank, expnr, "d"))
+    write_initd(path, g.nx, ny, g.nz, fields, timee, dt, fill=fill)
+    paths = [path]
+    if core.nsv:
+        sv = [core.download(L.scalar_field(L.SV0, n), halo=2) for n in range(core.nsv)]
+        ps = os.path.join(directory, restart_name(ntrun, rank, expnr, "s"))
+        write_inits(ps, g.nx, ny, g.nz, sv, timee)
+        paths.append(ps)
+    return paths
+
+
+def load_restart(core, directory, expnr, ntrun, rank=0):
+    """Warm start as readrestartfiles + readinitfiles do (src/modstartup.f90:1292-1340): u0.. from the file,
+    um = u0 (the file is written after stage 3, when the reference itself has um = u0), ghosts re-derived by
+    halos/boundary.  Returns (timee, dt)."""
+    from . import lib as L
+    g = core.g
+    ny = core.nyl
+    d = read_initd(os.path.join(directory, restart_name(ntrun, rank, expnr, "d")), g.nx, ny, g.nz)
+    for k in ("u0", "v0", "w0", "pres0", "ekm"):
+        core.upload(k, d[k])
+    for k0, km in (("u0", "um"), ("v0", "vm"), ("w0", "wm")):
+        core.upload(km, d[k0])
+    if core.nsv:
+        s = read_inits(os.path.join(directory, restart_name(ntrun, rank, expnr, "s")), g.nx, ny, g.nz, core.nsv)
+        for n, a in enumerate(s["sv0"]):
+            c = np.zeros((g.nz + 4, ny + 4, g.nx + 4))
+            c[1:-1, 1:-1, 1:-1] = a
+            core.upload(L.scalar_field(L.SV0, n), c)
+            core.upload(L.scalar_field(L.SVM, n), c)
+    core.halos()
+    core.boundary()
+    return d["timee"], d["dt"]
