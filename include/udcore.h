@@ -39,7 +39,9 @@ enum {
   UDC_SV0,                           /* passive scalar n: UDC_SV0 + 3*n  (sv0)  */
   UDC_SVM,                           /*                   UDC_SVM + 3*n  (svm)  */
   UDC_SVP,                           /*                   UDC_SVP + 3*n  (svp)  */
-  UDC_FIELD_MAX = UDC_SV0 + 3 * 16
+  UDC_FIELD_MAX = UDC_SV0 + 3 * 16,
+  /* temperature equation (ltempeq): thl0, thlm, thlp live in scalar slot 15 (so nsv <= 15 with ltempeq) */
+  UDC_THL0 = UDC_SV0 + 3 * 15, UDC_THLM = UDC_SVM + 3 * 15, UDC_THLP = UDC_SVP + 3 * 15
 };
 
 /* SGS closure selector: &NAMSUBGRID lsmagorinsky / lvreman (src/modsubgriddata.f90:39-42),
@@ -95,6 +97,16 @@ int udc_field_upload(udc_handle *h, int field, const double *host, const int lb[
 int udc_field_download(udc_handle *h, int field, double *host, const int lb[3], const int ub[3]);
 /* dpdxl(kb:ke), dpdyl(kb:ke) of modfields (src/modstartup.f90:2071-2081); n = ktot */
 int udc_set_forcing(udc_handle *h, const double *dpdxl, const double *dpdyl, int n);
+
+/* Temperature equation, &PHYSICS ltempeq (src/modglobal.f90:176): thl is advected (advection: iadv_thl = 2 ->
+ * advecc_2nd, src/modadvection.f90:103-155), diffused (subgrid: diffc with ekh), integrated and given its top
+ * (BCtopT 1 = flux wttop, 2 = value thl_top, src/modboundary.f90:207-220) and floor (lbottom, BCbotT 1 = flux wtsurf,
+ * src/modibm.f90:2035-2047) conditions like the passive scalars.  Passive only: the buoyancy term and the
+ * thermodynamics diagnostics (lbuoyancy, src/modforces.f90:73-84, src/modthermodynamics.f90) are not built.
+ * Call once after udc_create, before the first substep.  thlpcar (udc_set_thl_source, [ktot] = thlpcar(kb:ke), the
+ * radiative tendency of src/modforces.f90:104-110) is optional. */
+int udc_set_tempeq(udc_handle *h, int iadv_thl, int bctopt, double wttop, double thl_top, int bcbott, double wtsurf);
+int udc_set_thl_source(udc_handle *h, const double *thlpcar, int n);
 
 /* ---- the reference's call surface (src/program.f90:134-207) ----------------------- */
 /* advection   src/modadvection.f90:36   up,vp,wp (+svp) -= div(u phi) (+ grad pres0)     */

@@ -34,7 +34,7 @@ program ref_driver
   use modglobal
   use modfields
   use modsubgriddata
-  use modsurfdata, only: thl_top, wttop, wsvtop, sv_top, thvs, thls, z0
+  use modsurfdata, only: thl_top, wttop, wsvtop, sv_top, thvs, thls, z0, wtsurf
   use modwallfunctions, only: wfmneutral
   use modboundary, only: initboundary, boundary, halos
   use modthermodynamics, only: initthermodynamics
@@ -181,6 +181,23 @@ contains
       stop 1
     end if
     call wfmneutral(ih, jh, kh, up, vp, momfluxb, u0, v0, z0, 91)
+    if (ltempeq) then                      ! src/modibm.f90:2033-2047, BCbotT = 1 (flux)
+      if (BCbotT /= 1) then
+        write (0, *) 'ERROR: oracle build supports the flux floor for temperature only (BCbotT = 1)'
+        stop 1
+      end if
+      do j = jb, je
+        do i = ib, ie
+          thlp(i, j, kb) = thlp(i, j, kb) &
+                           + ( &
+                           0.5*(dzf(kb - 1)*ekh(i, j, kb) + dzf(kb)*ekh(i, j, kb - 1)) &
+                           *(thl0(i, j, kb) - thl0(i, j, kb - 1)) &
+                           *dzh2i(kb) &
+                           - wtsurf &
+                           )*dzfi(kb)
+        end do
+      end do
+    end if
     if (nsv > 0) then
       if (BCbots /= 1) then
         write (0, *) 'ERROR: bottom boundary type for scalars undefined'
@@ -211,7 +228,7 @@ contains
     namelist /PHYSICS/ lmoist, lcoriol, lbuoyancy, ltempeq, lprofforc, dpdx, luvolflowr, uflowrate, &
       lvvolflowr, vflowrate
     namelist /DYNAMICS/ ipoiss, iadv_mom, iadv_tke, iadv_thl, iadv_qt, iadv_sv
-    namelist /BC/ BCxm, BCym, BCtopm, BCtopT, BCtops, BCbotm, BCbots, BCzp, wttop, thl_top, z0
+    namelist /BC/ BCxm, BCym, BCtopm, BCtopT, BCtops, BCbotm, BCbots, BCbotT, BCzp, wttop, thl_top, z0, wtsurf
     namelist /SCALARS/ nsv
     namelist /WALLS/ nfcts, lbottom
     open (ifnamopt, file=fname_options, status='old', iostat=ierr)
@@ -439,6 +456,10 @@ contains
     call put3(tag//'.ekm', ekm, (/ib - ih, jb - jh, kb - kh/))
     call put3(tag//'.ekh', ekh, (/ib - ih, jb - jh, kb - kh/))
     call put3(tag//'.p', p, (/ib - ih, jb - jh, kb - kh/))
+    if (ltempeq) then
+      call put3(tag//'.thl0', thl0, (/ib - ih, jb - jh, kb - kh/))
+      call put3(tag//'.thlm', thlm, (/ib - ih, jb - jh, kb - kh/))
+    end if
     do n = 1, nsv
       write (cn, '(i2.2)') n
       call put3(tag//'.sv0_'//cn, sv0(:, :, :, n), (/ib - ihc, jb - jhc, kb - khc/))
@@ -453,6 +474,7 @@ contains
     call put3(tag//'.up', up, (/ib - ih, jb - jh, kb/))
     call put3(tag//'.vp', vp, (/ib - ih, jb - jh, kb/))
     call put3(tag//'.wp', wp, (/ib - ih, jb - jh, kb/))
+    if (ltempeq) call put3(tag//'.thlp', thlp, (/ib - ih, jb - jh, kb/))
     do n = 1, nsv
       write (cn, '(i2.2)') n
       call put3(tag//'.svp_'//cn, svp(:, :, :, n), (/ib - ihc, jb - jhc, kb/))
@@ -468,18 +490,19 @@ contains
     call dump_tend('in')                    ! (tendencies are zero here)
     call advection                          ! src/modadvection.f90:36
     call dump_tend('adv')
-    up = 0.; vp = 0.; wp = 0.; svp = 0.
+    up = 0.; vp = 0.; wp = 0.; svp = 0.; thlp = 0.
     call subgrid                            ! src/modsubgrid.f90:128 (closure+closurebc+diff*)
     call put3('sub.ekm', ekm, (/ib - ih, jb - jh, kb - kh/))
     call put3('sub.ekh', ekh, (/ib - ih, jb - jh, kb - kh/))
     call put3('sub.u0', u0, (/ib - ih, jb - jh, kb - kh/))   ! top ghost row rewritten by closurebc
+    if (ltempeq) call put3('sub.thl0', thl0, (/ib - ih, jb - jh, kb - kh/))
     call dump_tend('sub')
     if (lbottom) then                       ! floor wall function on top of the subgrid tendencies
       call floor_bottom
       call dump_tend('bot')
     end if
     ! full tendency = advection + subgrid + forces, as the driver would have it
-    up = 0.; vp = 0.; wp = 0.; svp = 0.
+    up = 0.; vp = 0.; wp = 0.; svp = 0.; thlp = 0.
     call advection
     call subgrid
     call floor_bottom

@@ -853,6 +853,80 @@ void orc_bottom(const orc_grid *g, const double *u0, const double *v0, const dou
   metrics_free(&m);
 }
 
+/* ====================================================================== temperature equation (passive) */
+/* advecc_2nd, src/modadvection.f90:103-155, on an m-array (halo 1: advecc_2nd(ih,jh,kh,thl0,thlp), :68) */
+void orc_advecc_2nd(const orc_grid *g, const double *u0, const double *v0, const double *w0, const double *c, double *cp) {
+  metrics m; metrics_init(g, &m);
+  const double *dzf = g->dzf;
+  for (int k = 1; k <= g->nz; ++k)
+    for (int j = 1; j <= g->ny; ++j)
+      for (int i = 1; i <= g->nx; ++i) {
+        int ip = i + 1, im = i - 1, jp = j + 1, jm = j - 1;
+        M(cp, i, j, k) = M(cp, i, j, k) - (
+            (M(u0, ip, j, k) * (M(c, ip, j, k) + M(c, i, j, k)) - M(u0, i, j, k) * (M(c, im, j, k) + M(c, i, j, k))) * m.dxi5
+          + (M(v0, i, jp, k) * (M(c, i, jp, k) + M(c, i, j, k)) - M(v0, i, j, k) * (M(c, i, jm, k) + M(c, i, j, k))) * m.dyi5);
+      }
+  for (int j = 1; j <= g->ny; ++j)
+    for (int i = 1; i <= g->nx; ++i)
+      for (int k = 1; k <= g->nz; ++k) {
+        int kp = k + 1, km = k - 1;
+        M(cp, i, j, k) = M(cp, i, j, k) - (
+            M(w0, i, j, kp) * (M(c, i, j, kp) * dzf[k] + M(c, i, j, k) * dzf[kp]) * m.dzhi[kp]
+          - M(w0, i, j, k) * (M(c, i, j, km) * dzf[k] + M(c, i, j, k) * dzf[km]) * m.dzhi[k]) * m.dzfi5[k];
+      }
+  metrics_free(&m);
+}
+/* diffc, src/modsubgrid.f90:540-623, on an m-array (diffc(ih,jh,kh,thl0,thlp), :146) */
+void orc_diffc_m(const orc_grid *g, const double *c, const double *ekh, double *cp) {
+  metrics m; metrics_init(g, &m);
+  const double *dzf = g->dzf;
+  const double cekh = g->numol * g->prandtlmoli;
+  for (int k = 1; k <= g->nz; ++k)
+    for (int j = 1; j <= g->ny; ++j)
+      for (int i = 1; i <= g->nx; ++i) {
+        int kp = k + 1, km = k - 1, jp = j + 1, jm = j - 1, ip = i + 1, im = i - 1;
+        if (g->sgs != 0) {
+          M(cp, i, j, k) = M(cp, i, j, k) + 0.5 * (
+              ((M(ekh, ip, j, k) + M(ekh, i, j, k)) * (M(c, ip, j, k) - M(c, i, j, k))
+             - (M(ekh, i, j, k) + M(ekh, im, j, k)) * (M(c, i, j, k) - M(c, im, j, k))) * m.dx2i
+            + ((M(ekh, i, jp, k) + M(ekh, i, j, k)) * (M(c, i, jp, k) - M(c, i, j, k))
+             - (M(ekh, i, j, k) + M(ekh, i, jm, k)) * (M(c, i, j, k) - M(c, i, jm, k))) * m.dy2i
+            + ((dzf[kp] * M(ekh, i, j, k) + dzf[k] * M(ekh, i, j, kp)) * (M(c, i, j, kp) - M(c, i, j, k)) * m.dzh2i[kp]
+             - (dzf[km] * M(ekh, i, j, k) + dzf[k] * M(ekh, i, j, km)) * (M(c, i, j, k) - M(c, i, j, km)) * m.dzh2i[k]) * m.dzfi[k]);
+        } else {
+          M(cp, i, j, k) = M(cp, i, j, k) + (
+              (cekh * (M(c, ip, j, k) - M(c, i, j, k)) - cekh * (M(c, i, j, k) - M(c, im, j, k))) * m.dx2i
+            + (cekh * (M(c, i, jp, k) - M(c, i, j, k)) - cekh * (M(c, i, j, k) - M(c, i, jm, k))) * m.dy2i
+            + (cekh * (M(c, i, j, kp) - M(c, i, j, k)) * m.dzhi[kp]
+             - cekh * (M(c, i, j, k) - M(c, i, j, km)) * m.dzhi[k]) * m.dzfi[k]);
+        }
+      }
+  metrics_free(&m);
+}
+/* top condition of thl: fluxtop (src/modboundary.f90:1494-1507) / valuetop (:1509-1519), BCtopT 1 / 2 */
+void orc_thl_top(const orc_grid *g, const double *ekh, double *a) {
+  const int ke = g->nz;
+  const double eps1 = 1e-10;                      /* src/modglobal.f90:318 */
+  for (int j = 0; j <= g->ny + 1; ++j)
+    for (int i = 0; i <= g->nx + 1; ++i) {
+      if (g->bctopt == 2) M(a, i, j, ke + 1) = 2 * g->thl_top - M(a, i, j, ke);
+      else if (fabs(g->wttop) <= eps1) M(a, i, j, ke + 1) = M(a, i, j, ke);
+      else M(a, i, j, ke + 1) = M(a, i, j, ke) + g->dzh[ke + 1] * g->wttop /
+               ((1. / g->dzh[ke + 1]) * (0.5 * (g->dzf[ke] * M(ekh, i, j, ke + 1) + g->dzf[ke + 1] * M(ekh, i, j, ke))));
+    }
+}
+/* floor of thl in `bottom`, BCbotT = 1: src/modibm.f90:2035-2047 */
+void orc_thl_floor(const orc_grid *g, const double *ekh, const double *thl0, double *thlp) {
+  if (!g->lbottom) return;
+  metrics m; metrics_init(g, &m);
+  const double *dzf = g->dzf;
+  for (int j = 1; j <= g->ny; ++j)
+    for (int i = 1; i <= g->nx; ++i)
+      M(thlp, i, j, 1) = M(thlp, i, j, 1) + (0.5 * (dzf[0] * M(ekh, i, j, 1) + dzf[1] * M(ekh, i, j, 0))
+                                             * (M(thl0, i, j, 1) - M(thl0, i, j, 0)) * m.dzh2i[1] - g->wtsurf) * m.dzfi[1];
+  metrics_free(&m);
+}
+
 /* ====================================================================== masscorr */
 /* src/modforces.f90:328-497, volume-flow branches: luvolflowr (:389-417) and lvvolflowr (:467-494);
  * avexy_ibm without IBM (src/modmpi.f90:623-664): slab sums divided by IIus(k) = itot*jtot. */
@@ -897,6 +971,7 @@ void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
   orc_advecu_2nd(g, s->u0, s->v0, s->w0, s->pres0, s->up);
   orc_advecv_2nd(g, s->u0, s->v0, s->w0, s->pres0, s->vp);
   orc_advecw_2nd(g, s->u0, s->v0, s->w0, s->pres0, s->wp);
+  if (g->ltempeq) orc_advecc_2nd(g, s->u0, s->v0, s->w0, s->thl0, s->thlp);              /* src/modadvection.f90:66-68 */
   for (int n = 0; n < g->nsv; ++n) orc_advecc_kappa(g, s->u0, s->v0, s->w0, s->sv0 + n * nc, s->svp + n * nc);
   orc_closure(g, s->u0, s->v0, s->w0, s->ekm, s->ekh);
   /* reassure_fluxtop_boundary src/modboundary.f90:392-431 (free-slip: re-impose top rows) */
@@ -912,20 +987,38 @@ void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
           }
     }
   }
+  if (g->ltempeq && g->bctopt != 2) { orc_thl_top(g, s->ekh, s->thlm); orc_thl_top(g, s->ekh, s->thl0); }   /* :417-420 */
   orc_diffu(g, s->u0, s->v0, s->w0, s->ekm, s->up);
   orc_diffv(g, s->u0, s->v0, s->w0, s->ekm, s->vp);
   orc_diffw(g, s->u0, s->v0, s->w0, s->ekm, s->wp);
+  if (g->ltempeq) orc_diffc_m(g, s->thl0, s->ekh, s->thlp);                              /* src/modsubgrid.f90:146 */
   for (int n = 0; n < g->nsv; ++n) orc_diffc(g, s->sv0 + n * nc, s->ekh, s->svp + n * nc);
   orc_bottom(g, s->u0, s->v0, s->ekm, s->ekh, s->sv0, s->up, s->vp, s->svp, NULL);   /* src/program.f90:152 */
+  if (g->ltempeq) orc_thl_floor(g, s->ekh, s->thl0, s->thlp);
   if (s->dpdxl) orc_forces(g, s->dpdxl, s->dpdyl, s->up, s->vp, s->wp);
+  if (g->ltempeq && s->dpdxl && s->thlpcar)                                             /* src/modforces.f90:104-110 */
+    for (int k = 1; k <= g->nz; ++k)
+      for (int j = 1; j <= g->ny; ++j)
+        for (int i = 1; i <= g->nx; ++i) M(s->thlp, i, j, k) = M(s->thlp, i, j, k) + s->thlpcar[k];
   orc_masscorr(g, rk3step, dt, s->up, s->um, s->vp, s->vm);                            /* src/program.f90:169 */
   orc_fillps(g, rk3coef, s->up, s->vp, s->wp, s->um, s->vm, s->wm, s->pup, s->pvp, s->pwp, s->p);
   orc_poisson_solve(g, s->p);
   orc_tderive(g, s->p, s->up, s->vp, s->wp, s->pres0);
   orc_tstep_integrate(g, rk3step, dt, s->u0, s->v0, s->w0, s->um, s->vm, s->wm, s->up, s->vp, s->wp,
                       s->sv0, s->svm, s->svp);
+  if (g->ltempeq) {                                                                      /* src/modtstep.f90:240-249,325,334 */
+    const size_t nm = msize(g);
+    const double rk3c = dt / (4. - (double)rk3step);
+    for (int k = 1; k <= g->nz; ++k)
+      for (int j = 1; j <= g->ny; ++j)
+        for (int i = 1; i <= g->nx; ++i) M(s->thl0, i, j, k) = M(s->thlm, i, j, k) + rk3c * M(s->thlp, i, j, k);
+    memset(s->thlp, 0, nm * sizeof(double));
+    if (rk3step == 3) memcpy(s->thlm, s->thl0, nm * sizeof(double));
+    orc_halos_m(g, s->thl0); orc_halos_m(g, s->thlm);
+  }
   orc_halos_m(g, s->u0); orc_halos_m(g, s->v0); orc_halos_m(g, s->w0);
   orc_halos_m(g, s->um); orc_halos_m(g, s->vm); orc_halos_m(g, s->wm);
   for (int n = 0; n < g->nsv; ++n) { orc_halos_c(g, s->sv0 + n * nc); orc_halos_c(g, s->svm + n * nc); }
   orc_boundary(g, s->u0, s->v0, s->w0, s->um, s->vm, s->wm, s->sv0, s->svm);
+  if (g->ltempeq) { orc_thl_top(g, s->ekh, s->thlm); orc_thl_top(g, s->ekh, s->thl0); }     /* src/modboundary.f90:207-217 */
 }

@@ -43,6 +43,9 @@ typedef struct {
   double z0;                /* roughness length (src/modsurfdata.f90:72) */
   int luvolflowr, lvvolflowr;   /* masscorr volume-flow switches (src/modglobal.f90:231) */
   double uflowrate, vflowrate;  /* prescribed volume-mean velocities (src/modglobal.f90:331) */
+  int ltempeq;              /* passive temperature equation, iadv_thl = 2 (src/modglobal.f90:176) */
+  int bctopt;               /* BCtopT: 1 flux wttop, 2 value thl_top (src/modglobal.f90:144-154) */
+  double wttop, thl_top, wtsurf;   /* src/modsurfdata.f90:62,80,81 */
 } orc_grid;
 
 /* ---- advection: src/modadvection.f90 */
@@ -71,6 +74,11 @@ void orc_forces(const orc_grid *g, const double *dpdxl, const double *dpdyl,
 /* ---- floor: `bottom` src/modibm.f90:1998-2100 -> wfmneutral src/modwallfunctions.f90:263-350; momfluxb may be NULL */
 void orc_bottom(const orc_grid *g, const double *u0, const double *v0, const double *ekm, const double *ekh,
                 const double *sv0, double *up, double *vp, double *svp, double *momfluxb);
+/* ---- temperature equation (passive): advecc_2nd src/modadvection.f90:103-155, diffc on an m-array, top / floor */
+void orc_advecc_2nd(const orc_grid *g, const double *u0, const double *v0, const double *w0, const double *c, double *cp);
+void orc_diffc_m(const orc_grid *g, const double *c, const double *ekh, double *cp);
+void orc_thl_top(const orc_grid *g, const double *ekh, double *a);
+void orc_thl_floor(const orc_grid *g, const double *ekh, const double *thl0, double *thlp);
 /* ---- masscorr: src/modforces.f90:328-497 (volume-flow branches) */
 void orc_masscorr(const orc_grid *g, int rk3step, double dt, double *up, const double *um, double *vp, const double *vm);
 /* ---- pressure: src/modpois.f90 (ipoiss = POISS_FFT2D, BCzp = 1, periodic x,y) */
@@ -94,6 +102,8 @@ typedef struct {
   double *u0, *v0, *w0, *um, *vm, *wm, *up, *vp, *wp, *pres0, *ekm, *ekh, *p, *pup, *pvp, *pwp;
   double *sv0, *svm, *svp;                /* nsv consecutive c-arrays each */
   const double *dpdxl, *dpdyl;            /* [nz+2] indexed by Fortran k, or NULL (no forces) */
+  double *thl0, *thlm, *thlp;             /* m-arrays, used when g->ltempeq */
+  const double *thlpcar;                  /* [nz+2] or NULL */
 } orc_state;
 void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt);
 

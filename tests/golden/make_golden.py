@@ -29,7 +29,7 @@ REF = os.path.join(ROOT, "oracle", "_ref", "udales_ref")
 
 
 def deck(iexpnr, nx, ny, nz, dx=0.5, dy=0.5, dtmax=0.25, sgs="vreman", nsv=0, bctopm=1,
-         oracle="", lles=True, randu=0.01, floor=False, z0=0.05, physics=""):
+         oracle="", lles=True, randu=0.01, floor=False, z0=0.05, physics="", bc=""):
     sub = {"vreman": "lvreman = .true.\nlsmagorinsky = .false.",
            "smag": "lsmagorinsky = .true.\nlvreman = .false.",
            "dns": "lvreman = .false.\nlsmagorinsky = .false."}[sgs]
@@ -61,6 +61,7 @@ ipoiss = 0
 &BC
 BCtopm = {bctopm}
 {('BCbotm = 3' + chr(10) + 'z0 = ' + repr(z0)) if floor else ''}
+{bc}
 /
 {('&WALLS' + chr(10) + 'nfcts = 0' + chr(10) + 'lbottom = .true.' + chr(10) + '/') if floor else ''}
 &SCALARS
@@ -85,21 +86,22 @@ def zlevels(nz, dz0=0.5, stretch=1.0):
     return zf
 
 
-def write_case(d, iexpnr, text, zf, u=1.0, v=0.0, pgx=1e-4):
+def write_case(d, iexpnr, text, zf, u=1.0, v=0.0, pgx=1e-4, dthl=0.0, dthlrad=0.0):
     with open(os.path.join(d, f"namoptions.{iexpnr:03d}"), "w") as f:
         f.write(text)
     with open(os.path.join(d, f"prof.inp.{iexpnr:03d}"), "w") as f:
         f.write("# golden\n# z thl qt u v tke\n")
         for z in zf:
-            f.write(f"{z:.15f} 288.0 0.0 {u} {v} 0.0\n")
+            f.write(f"{z:.15f} {288.0 + dthl * z!r} 0.0 {u} {v} 0.0\n")
     with open(os.path.join(d, f"lscale.inp.{iexpnr:03d}"), "w") as f:
         f.write("# golden\n# z uq vq pqx pqy wfls dqtdxls dqtdyls dqtdtls dthlrad\n")
         for z in zf:
-            f.write(f"{z:.15f} 0.0 0.0 {pgx} 0.0 0.0 0.0 0.0 0.0 0.0\n")
+            f.write(f"{z:.15f} 0.0 0.0 {pgx} 0.0 0.0 0.0 0.0 0.0 {dthlrad!r}\n")
 
 
 KEEP_KERNELS = ("meta dzf dzh zf dpdxl dpdyl rk3 in.u0 in.v0 in.w0 in.um in.vm in.wm in.pres0 "
                 "in.ekm in.ekh adv.up adv.vp adv.wp sub.ekm sub.ekh sub.u0 sub.up sub.vp sub.wp bot.up bot.vp frc.up frc.vp "
+                "in.thl0 in.thlm adv.thlp sub.thlp sub.thl0 bot.thlp pre.thlp out.thl0 out.thlm "
                 "pre.up pre.vp pre.wp poi.p poi.pres0 poi.up poi.vp poi.wp out.u0 out.v0 out.w0 "
                 "out.um out.pres0").split()
 
@@ -125,7 +127,17 @@ CASES = {
                                dict(sgs="vreman", physics="luvolflowr = .true.\nuflowrate = 1.1\n"
                                     "lvvolflowr = .true.\nvflowrate = 0.05",
                                     oracle="nsub = 6\ndump_at = 1, 3, 6"), 1.0),
+    # passive temperature equation (ltempeq, iadv_thl = cd2 -> advecc_2nd): stratified profile, radiative source,
+    # floor flux wtsurf, top flux wttop / top value thl_top
+    "k_thl_12x8x6": ("kernels", 18, 12, 8, 6,
+                     dict(sgs="vreman", floor=True, physics="ltempeq = .true.\nlbuoyancy = .false.",
+                          bc="BCtopT = 1\nwttop = -0.002\nBCbotT = 1\nwtsurf = 0.01", oracle="nspin = 3"), 1.04),
+    "run_thl_16x8x12s": ("run", 25, 16, 8, 12,
+                         dict(sgs="smag", nsv=1, floor=True, physics="ltempeq = .true.\nlbuoyancy = .false.",
+                              bc="BCtopT = 2\nthl_top = 290.5\nBCbotT = 1\nwtsurf = 0.02",
+                              oracle="nsub = 6\ndump_at = 3, 6"), 1.06),
 }
+THL_CASES = {"k_thl_12x8x6": dict(dthl=0.4, dthlrad=2e-3), "run_thl_16x8x12s": dict(dthl=0.25, dthlrad=-1e-3)}
 
 
 # restart files written by the reference's own writerestartfiles (src/modsave.f90:37-128): the files are the
@@ -178,7 +190,7 @@ def main():
     for name, (mode, iexp, nx, ny, nz, kw, stretch) in CASES.items():
         cdir = os.path.join(HERE, "cases", name)
         os.makedirs(cdir, exist_ok=True)
-        write_case(cdir, iexp, deck(iexp, nx, ny, nz, **kw), zlevels(nz, 0.5, stretch))
+        write_case(cdir, iexp, deck(iexp, nx, ny, nz, **kw), zlevels(nz, 0.5, stretch), **THL_CASES.get(name, {}))
         with tempfile.TemporaryDirectory() as tmp:
             for fn in os.listdir(cdir):
                 shutil.copy(os.path.join(cdir, fn), tmp)
@@ -190,7 +202,7 @@ def main():
                     if k in KEEP_KERNELS or ".sv" in k}
         else:
             keep = {k: v for k, v in d.items()
-                    if k.count(".") == 0 or k.split(".")[1] in ("u0", "v0", "w0", "pres0", "um")
+                    if k.count(".") == 0 or k.split(".")[1] in ("u0", "v0", "w0", "pres0", "um", "thl0", "thlm")
                     or (k.startswith("s000.") and not k.startswith("s000.ek")) or ".sv0" in k}
             # (s000.ekm/ekh are dumped before the first closure call: uninitialised memory, not data)
         tmpf = os.path.join(HERE, name + ".bin")

@@ -27,13 +27,15 @@ class OrcGrid(C.Structure):
                 ("sgs", C.c_int), ("bctopm", C.c_int),
                 ("uinf", C.c_double), ("vinf", C.c_double), ("nsv", C.c_int),
                 ("lbottom", C.c_int), ("z0", C.c_double),
-                ("luvolflowr", C.c_int), ("lvvolflowr", C.c_int), ("uflowrate", C.c_double), ("vflowrate", C.c_double)]
+                ("luvolflowr", C.c_int), ("lvvolflowr", C.c_int), ("uflowrate", C.c_double), ("vflowrate", C.c_double),
+                ("ltempeq", C.c_int), ("bctopt", C.c_int), ("wttop", C.c_double), ("thl_top", C.c_double),
+                ("wtsurf", C.c_double)]
 
 
 class OrcState(C.Structure):
     _fields_ = [(n, DP) for n in ("u0", "v0", "w0", "um", "vm", "wm", "up", "vp", "wp", "pres0",
                                   "ekm", "ekh", "p", "pup", "pvp", "pwp", "sv0", "svm", "svp",
-                                  "dpdxl", "dpdyl")]
+                                  "dpdxl", "dpdyl", "thl0", "thlm", "thlp", "thlpcar")]
 
 
 def build():
@@ -66,7 +68,7 @@ class Oracle:
     def __init__(self, nx, ny, nz, dx, dy, dzf, dzh, sgs=2, bctopm=1, nsv=0, numol=1.5e-5,
                  prandtlmoli=1. / 0.71, prandtli=1. / 0.333, c_vreman=0.07, csz=None,
                  uinf=0., vinf=0., lbottom=False, z0=0.05, luvolflowr=False, uflowrate=0.,
-                 lvvolflowr=False, vflowrate=0.):
+                 lvvolflowr=False, vflowrate=0., ltempeq=False, bctopt=1, wttop=0., thl_top=-1., wtsurf=-1.):
         self.nx, self.ny, self.nz, self.nsv = nx, ny, nz, nsv
         self.dzf = np.ascontiguousarray(dzf, dtype=np.float64)
         self.dzh = np.ascontiguousarray(dzh, dtype=np.float64)
@@ -78,7 +80,8 @@ class Oracle:
             csz = (cm ** 3 / ceps) ** 0.25
         self.g = OrcGrid(nx, ny, nz, dx, dy, ptr(self.dzf), ptr(self.dzh), numol, prandtlmoli,
                          prandtli, c_vreman, csz, sgs, bctopm, uinf, vinf, nsv, int(bool(lbottom)), z0,
-                         int(bool(luvolflowr)), int(bool(lvvolflowr)), uflowrate, vflowrate)
+                         int(bool(luvolflowr)), int(bool(lvvolflowr)), uflowrate, vflowrate,
+                         int(bool(ltempeq)), bctopt, wttop, thl_top, wtsurf)
         self.L = lib()
 
     def mshape(self):

@@ -43,6 +43,9 @@ def upload_inputs(core, fix, tag, g, nsv):
         core.upload(L.scalar_field(L.SV0, n), c)
         key = f"{tag}.svm_{n + 1:02d}"
         core.upload(L.scalar_field(L.SVM, n), carr(fix, key, g.nz) if key in fix else c)
+    if f"{tag}.thl0" in fix:
+        core.upload("thl0", marr(fix, f"{tag}.thl0", g.nz))
+        core.upload("thlm", marr(fix, f"{tag}.thlm", g.nz))
 
 
 @pytest.mark.parametrize("name,iexp", sorted(KERNEL_CASES.items()))
@@ -55,8 +58,10 @@ def test_each_routine_matches_reference(name, iexp):
     upload_inputs(core, fix, "in", g, nsv)
     zero = np.zeros(g.mshape())
 
+    thl = "in.thl0" in fix
+
     def zero_tend():
-        for k in ("up", "vp", "wp"):
+        for k in ("up", "vp", "wp") + (("thlp",) if thl else ()):
             core.upload(k, zero)
         for n in range(nsv):
             core.upload(L.scalar_field(L.SVP, n), np.zeros(g.cshape()))
@@ -69,8 +74,14 @@ def test_each_routine_matches_reference(name, iexp):
         got = core.download(L.scalar_field(L.SVP, n), halo=2)
         assert relerr(interior(got, 2), interior(carr(fix, f"adv.svp_{n + 1:02d}", nz), 2)) <= KERNEL_TOL
 
+    if thl:       # advecc_2nd
+        assert relerr(interior(core.download("thlp")), interior(marr(fix, "adv.thlp", nz))) <= KERNEL_TOL
+
     zero_tend()
     core.subgrid()
+    if thl:       # top row re-imposed with the new ekh (reassure_fluxtop_boundary), then diffc
+        assert relerr(core.download("thl0")[1:], marr(fix, "sub.thl0", nz)[1:], 1.0) <= KERNEL_TOL
+        assert relerr(interior(core.download("thlp")), interior(marr(fix, "sub.thlp", nz))) <= KERNEL_TOL
     ekm, ekh = core.download("ekm"), core.download("ekh")
     assert relerr(ekm, marr(fix, "sub.ekm", nz)) <= KERNEL_TOL          # ghosts included (closurebc)
     assert relerr(ekh, marr(fix, "sub.ekh", nz)) <= KERNEL_TOL
@@ -85,6 +96,8 @@ def test_each_routine_matches_reference(name, iexp):
         for k in ("up", "vp"):
             assert relerr(interior(core.download(k)), interior(marr(fix, "bot." + k, nz))) <= KERNEL_TOL, k
         assert relerr(interior(core.download("up")), interior(marr(fix, "sub.up", nz))) > 1e-6
+        if thl:   # floor flux wtsurf
+            assert relerr(interior(core.download("thlp")), interior(marr(fix, "bot.thlp", nz))) <= KERNEL_TOL
 
     # full tendency as the reference driver had it, then forces (already inside pre.*), poisson
     zero_tend()
@@ -97,7 +110,7 @@ def test_each_routine_matches_reference(name, iexp):
         for k in ("up", "vp"):
             assert relerr(interior(core.download(k)), interior(marr(fix, "frc." + k, nz))) <= KERNEL_TOL, k
     core.masscorr()
-    for k in ("up", "vp", "wp"):
+    for k in ("up", "vp", "wp") + (("thlp",) if thl else ()):
         assert relerr(interior(core.download(k)), interior(marr(fix, "pre." + k, nz))) <= KERNEL_TOL, k
     core.poisson()
     # p solves lap(p) = div(up + um/rk3coef): its round-off floor is set by the O(U/rk3coef) terms
@@ -114,9 +127,9 @@ def test_each_routine_matches_reference(name, iexp):
     core.tstep_integrate()
     core.halos()
     core.boundary()
-    for k in ("u0", "v0", "w0", "um", "pres0"):
+    for k in ("u0", "v0", "w0", "um", "pres0") + (("thl0", "thlm") if thl else ()):
         ref = marr(fix, "out." + k, nz)
-        sc = pscale if k == "pres0" else None
+        sc = pscale if k == "pres0" else (1.0 if k.startswith("thl") else None)
         assert relerr(nocorner(core.download(k)[1:-1]), nocorner(ref[1:-1]), sc) <= KERNEL_TOL, k
     core.close()
 
@@ -143,9 +156,10 @@ def test_substeps_match_reference(name, iexp, fused):
             core.tstep_integrate(); core.halos(); core.boundary()
         if isub in dumps:
             tag = f"s{isub:03d}"
-            for k in ("u0", "v0", "w0", "pres0"):
+            for k in ("u0", "v0", "w0", "pres0") + (("thl0",) if core.ltempeq else ()):
                 ref = marr(fix, f"{tag}.{k}", g.nz)
-                assert relerr(nocorner(core.download(k)[1:-1]), nocorner(ref[1:-1])) <= RUN_TOL, (tag, k)
+                sc = 1.0 if k == "thl0" else None        # temperature differences are O(1) K on a 288 K mean
+                assert relerr(nocorner(core.download(k)[1:-1]), nocorner(ref[1:-1]), sc) <= RUN_TOL, (tag, k)
             for n in range(nsv):
                 got = core.download(L.scalar_field(L.SV0, n), halo=2)
                 ref = carr(fix, f"{tag}.sv0_{n + 1:02d}", g.nz)

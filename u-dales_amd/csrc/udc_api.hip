@@ -157,9 +157,11 @@ extern "C" int udc_create(const udc_config *cfg, udc_handle **out) {
 
   for (int f = UDC_U0; f <= UDC_EKH; ++f)
     if (alloc_field(h, f)) return 1;
-  for (int n = 0; n < cfg->nsv; ++n)
+  for (int n = 0; n < cfg->nsv; ++n) {
     for (int q = 0; q < 3; ++q)
       if (alloc_field(h, UDC_SV0 + 3 * n + q)) return 1;
+    h->slots.push_back(n);
+  }
   HIP_OK(hipMalloc(&h->red, sizeof(double) * 4096));
   HIP_OK(hipHostMalloc(&h->red_host, sizeof(double) * 4096));
   if (h->slab) { if (pois_slab_init(h)) return 1; }
@@ -185,6 +187,7 @@ extern "C" int udc_destroy(udc_handle *h) {
   if (h->metrics_dev) hipFree(h->metrics_dev);
   if (h->red) hipFree(h->red);
   if (h->red_host) hipHostFree(h->red_host);
+  if (h->thlpcar) hipFree(h->thlpcar);
   hipStreamDestroy(h->stream);
   delete h;
   return 0;
@@ -300,7 +303,7 @@ extern "C" int udc_advection(udc_handle *h) {
   HIP_OK(hipSetDevice(h->device));
   if (tend_clean(h) || um_materialise(h)) return 1;
   if ((h->mom_simple ? k_momentum(h, true, false, false) : k_momentum_lds(h, true, false, false, false, 0.))) return 1;
-  for (int n = 0; n < h->cfg.nsv; ++n)
+  for (int n : h->slots)
     if (k_scalar_adv(h, n)) return 1;
   return 0;
 }
@@ -312,8 +315,44 @@ extern "C" int udc_subgrid(udc_handle *h) {
   if (k_ek_ghosts(h)) return 1;
   if (k_top_rows_after_closure(h)) return 1;
   if ((h->mom_simple ? k_momentum(h, false, true, false) : k_momentum_lds(h, false, true, false, false, 0.))) return 1;
-  for (int n = 0; n < h->cfg.nsv; ++n)
+  if (k_scalar_top_flux(h)) return 1;      // reassure_fluxtop_boundary for a non-zero thl top flux (uses the new ekh)
+  for (int n : h->slots)
     if (k_scalar_diff(h, n)) return 1;
+  return 0;
+}
+
+extern "C" int udc_set_tempeq(udc_handle *h, int iadv_thl, int bctopt, double wttop, double thl_top, int bcbott, double wtsurf) {
+  HIP_OK(hipSetDevice(h->device));
+  if (h->cfg.nsv > 15) { udc_set_error("udc_set_tempeq: thl uses scalar slot 15, nsv must be <= 15"); return 1; }
+  if (iadv_thl != 2) { udc_set_error("udc_set_tempeq: only iadv_thl = 2 (cd2, advecc_2nd) is built"); return 1; }
+  if (bctopt != 1 && bctopt != 2) { udc_set_error("udc_set_tempeq: BCtopT must be 1 (flux) or 2 (value)"); return 1; }
+  if (h->p.lbottom && bcbott != 1) { udc_set_error("udc_set_tempeq: with lbottom only BCbotT = 1 (flux) is built"); return 1; }
+  const bool have = (int)h->fields.size() > UDC_THL0 && h->fields[UDC_THL0];
+  if (!have) {
+    for (int q = 0; q < 3; ++q)
+      if (alloc_field(h, UDC_SV0 + 3 * 15 + q)) return 1;
+    h->slots.push_back(15);
+    if (h->slab) {      // more rows travel per exchange
+      const size_t need = (size_t)16 * HY * h->g.nx * h->g.pz;
+      if (need > h->halo_cap) { udc_set_error("udc_set_tempeq: halo buffers too small"); return 1; }
+    }
+  }
+  udc_handle::Slot &sl = h->slot[15];
+  sl.adv = 2;
+  sl.top = bctopt == 2 ? 2 : (wttop != 0. ? 1 : 0);
+  sl.topval = bctopt == 2 ? thl_top : wttop;
+  sl.floorflux = wtsurf;
+  return 0;
+}
+
+extern "C" int udc_set_thl_source(udc_handle *h, const double *thlpcar, int n) {
+  HIP_OK(hipSetDevice(h->device));
+  if (n != h->g.nz) { udc_set_error("udc_set_thl_source: expected %d levels", h->g.nz); return 1; }
+  if ((int)h->fields.size() <= UDC_THL0 || !h->fields[UDC_THL0]) { udc_set_error("udc_set_thl_source: call udc_set_tempeq first"); return 1; }
+  std::vector<double> t(h->g.nz + 2, 0.0);
+  for (int k = 1; k <= n; ++k) t[k] = thlpcar[k - 1];
+  if (!h->thlpcar) HIP_OK(hipMalloc(&h->thlpcar, sizeof(double) * t.size()));
+  HIP_OK(hipMemcpy(h->thlpcar, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -340,6 +379,7 @@ extern "C" int udc_masscorr(udc_handle *h, int rk3step, double dt) {
 extern "C" int udc_forces(udc_handle *h) {
   HIP_OK(hipSetDevice(h->device));
   if (tend_clean(h) || um_materialise(h)) return 1;
+  if (h->thlpcar && k_level_source(h, 15, h->thlpcar)) return 1;      // thlp += thlpcar(k), src/modforces.f90:104-110
   return k_forces(h);
 }
 
@@ -366,7 +406,7 @@ extern "C" int udc_tstep_integrate(udc_handle *h, int rk3step, double dt) {
 }
 
 static int scalar_halo_list(udc_handle *h, int rk3step, std::vector<int> &f) {
-  for (int n = 0; n < h->cfg.nsv; ++n) {
+  for (int n : h->slots) {
     f.push_back(UDC_SV0 + 3 * n);
     if (rk3step == 3 || rk3step < 0) f.push_back(UDC_SVM + 3 * n);
   }
@@ -422,8 +462,10 @@ extern "C" int udc_substep(udc_handle *h, int rk3step, double dt, int with_force
   }
   if (lds ? k_momentum_lds(h, true, true, with_forces != 0, true, pup ? 1. / rk3coef : 0., rotate)
           : k_momentum(h, true, true, with_forces != 0)) return 1;
-  for (int n = 0; n < h->cfg.nsv; ++n)
+  if (k_scalar_top_flux(h)) return 1;
+  for (int n : h->slots)
     if (k_scalar_fused(h, n)) return 1;
+  if (with_forces && h->thlpcar && k_level_source(h, 15, h->thlpcar)) return 1;
   // `bottom` (src/program.f90:152): additive on the k = kb tendencies, hence equally on pup = up + um/rk3coef
   if (h->p.lbottom && k_bottom(h, fold)) return 1;
   // masscorr (src/program.f90:169); without pup the tendencies and um are summed separately
@@ -455,7 +497,7 @@ extern "C" int udc_substep(udc_handle *h, int rk3step, double dt, int with_force
   std::vector<int> s;
   scalar_halo_list(h, rk3step, s);
   if (!s.empty() && k_halo_y(h, s.data(), (int)s.size(), 2)) return 1;
-  if (!fold || h->cfg.nsv > 0) { if (k_top_bottom(h)) return 1; }
+  if (!fold || !h->slots.empty()) { if (k_top_bottom(h)) return 1; }
   return 0;
 }
 

@@ -50,6 +50,8 @@ __global__ void halo_unpack_kernel(Geo g, FieldList fl, int width, const double 
 struct BoundaryArgs {
   double *u0, *v0, *w0, *um, *vm, *wm;
   double *sv[32];
+  int kind[32];      // top condition per array: 0 zero-flux copy, 1 fluxtop (done by top_flux_kernel), 2 valuetop
+  double val[32];
   int nscal;         // number of scalar arrays in sv (sv0 and svm of every scalar)
 };
 
@@ -76,7 +78,8 @@ __global__ void top_bottom_kernel(Geo g, Params pr, BoundaryArgs a, int uv_only)
   a.w0[ghost] = 0.; a.wm[ghost] = 0.;
   for (int s = 0; s < a.nscal; ++s) {
     double *c = a.sv[s];
-    const double t = c[top];
+    if (a.kind[s] == 1) continue;                     // non-zero flux: top_flux_kernel (needs ekh)
+    const double t = a.kind[s] == 2 ? 2 * a.val[s] - c[top] : c[top];     // valuetop, src/modboundary.f90:1516
     c[ghost] = t;
     c[ghost + g.sz] = t;
   }
@@ -123,20 +126,24 @@ static BoundaryArgs boundary_args(udc_handle *h) {
   a.u0 = h->fields[UDC_U0]; a.v0 = h->fields[UDC_V0]; a.w0 = h->fields[UDC_W0];
   a.um = h->fields[UDC_UM]; a.vm = h->fields[UDC_VM]; a.wm = h->fields[UDC_WM];
   a.nscal = 0;
-  for (int n = 0; n < h->cfg.nsv; ++n) {
-    a.sv[a.nscal++] = h->fields[UDC_SV0 + 3 * n];
-    a.sv[a.nscal++] = h->fields[UDC_SVM + 3 * n];
+  for (int n : h->slots) {
+    for (int q = 0; q < 2; ++q) {
+      a.kind[a.nscal] = h->slot[n].top; a.val[a.nscal] = h->slot[n].topval;
+      a.sv[a.nscal++] = h->fields[(q == 0 ? UDC_SV0 : UDC_SVM) + 3 * n];
+    }
   }
   return a;
 }
 
 int k_top_bottom(udc_handle *h) {
   const Geo &g = h->g;
-  PROF(h, "top_bottom");
-  hipLaunchKernelGGL(top_bottom_kernel, dim3((g.nx + 63) / 64, g.py), dim3(64), 0, h->stream, g, h->p,
-                     boundary_args(h), 0);
-  HIP_OK(hipGetLastError());
-  return 0;
+  {
+    PROF(h, "top_bottom");
+    hipLaunchKernelGGL(top_bottom_kernel, dim3((g.nx + 63) / 64, g.py), dim3(64), 0, h->stream, g, h->p,
+                       boundary_args(h), 0);
+    HIP_OK(hipGetLastError());
+  }
+  return k_scalar_top_flux(h);
 }
 
 // reassure_fluxtop_boundary, src/modboundary.f90:392-431 (free-slip: top rows of um,u0,vm,v0)

@@ -107,6 +107,17 @@ struct udc_handle {
   double *partials = nullptr;           // per-workgroup partial results of the two-stage reductions
   size_t partials_cap = 0;
   // profiling
+  // transported scalars: passive scalars occupy slots 0..nsv-1 (kappa scheme, zero-flux top and floor); the
+  // temperature equation (ltempeq, udc_set_tempeq) occupies slot 15.  `slots` lists the active ones.
+  struct Slot {
+    int adv = 1;          // 1 = kappa (advecc_kappa), 2 = cd2 (advecc_2nd)
+    int top = 0;          // 0 = zero-flux copy, 1 = fluxtop with topval = flux (src/modboundary.f90:1494), 2 = valuetop
+    double topval = 0.;
+    double floorflux = 0.;   // wtsurf in bottom's Neumann floor (src/modibm.f90:2035-2047); 0 for passive scalars
+  };
+  Slot slot[16];
+  std::vector<int> slots;
+  double *thlpcar = nullptr;   // [nz+2] radiative heating profile added by forces (src/modforces.f90:104-110), or null
   // masscorr (src/modforces.f90:328): prescribed volume-flow rates
   int luvolflowr = 0, lvvolflowr = 0;
   double uflowrate = 0., vflowrate = 0., zsize = 0.;
@@ -192,6 +203,8 @@ int k_project_integrate(udc_handle *h, int rk3step, double dt, bool zero_tend, b
 int k_halo_y(udc_handle *h, const int *fields, int nf, int width);
 int k_top_bottom(udc_handle *h);
 int k_top_rows_after_closure(udc_handle *h);
+int k_scalar_top_flux(udc_handle *h);              // fluxtop with a non-zero flux: re-imposed after closure (reassure_fluxtop_boundary)
+int k_level_source(udc_handle *h, int slot, const double *src);   // cp(i,j,k) += src(k)
 int k_maxima(udc_handle *h, double dt, double *cour, double *diffn);
 int k_divergence_check(udc_handle *h, double *divmax, double *divtot);
 int pois_init(udc_handle *h);

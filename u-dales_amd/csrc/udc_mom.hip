@@ -134,6 +134,7 @@ struct BottomArgs {
   double *up, *vp;
   const double *sv0[16];
   double *svp[16];
+  double flux[16];       // prescribed floor flux (0 for passive scalars, wtsurf for thl)
   int nsv, wrap_vp;
   double z0;
 };
@@ -171,9 +172,9 @@ __global__ __launch_bounds__(256) void bottom_kernel(Geo g, Metrics m, BottomArg
     a.vp[c] = t;
     if (a.wrap_vp && j == 0) a.vp[c + sy * g.ny] = t;      // bcpup's cyclic pvp(je+1) = pvp(jb)
   }
-  for (int n = 0; n < a.nsv; ++n) {   // zero-flux floor for the scalars, src/modibm.f90:2073-2090
+  for (int n = 0; n < a.nsv; ++n) {   // Neumann floor: scalars src/modibm.f90:2073-2090 (flux 0), thl :2035-2047 (wtsurf)
     const double *c0 = a.sv0[n];
-    a.svp[n][c] = a.svp[n][c] + (0.5 * (m.dzf[km] * a.ekh[c] + m.dzf[k] * a.ekh[c - sz]) * (c0[c] - c0[c - sz]) * m.dzh2i[k] + 0.) * dzfi;
+    a.svp[n][c] = a.svp[n][c] + (0.5 * (m.dzf[km] * a.ekh[c] + m.dzf[k] * a.ekh[c - sz]) * (c0[c] - c0[c - sz]) * m.dzh2i[k] - a.flux[n]) * dzfi;
   }
 }
 
@@ -189,8 +190,11 @@ int k_bottom(udc_handle *h, bool wrap_vp) {
   BottomArgs a{};
   a.u0 = h->fields[UDC_U0]; a.v0 = h->fields[UDC_V0]; a.ekm = h->fields[UDC_EKM]; a.ekh = h->fields[UDC_EKH];
   a.up = h->fields[UDC_UP]; a.vp = h->fields[UDC_VP];
-  a.nsv = h->cfg.nsv; a.wrap_vp = wrap_vp ? 1 : 0; a.z0 = h->p.z0;
-  for (int n = 0; n < a.nsv; ++n) { a.sv0[n] = h->fields[UDC_SV0 + 3 * n]; a.svp[n] = h->fields[UDC_SVP + 3 * n]; }
+  a.nsv = 0; a.wrap_vp = wrap_vp ? 1 : 0; a.z0 = h->p.z0;
+  for (int n : h->slots) {
+    a.sv0[a.nsv] = h->fields[UDC_SV0 + 3 * n]; a.svp[a.nsv] = h->fields[UDC_SVP + 3 * n];
+    a.flux[a.nsv] = h->slot[n].floorflux; ++a.nsv;
+  }
   PROF(h, "bottom");
   hipLaunchKernelGGL(bottom_kernel, dim3((unsigned)((g.nx + 63) / 64), (unsigned)((g.ny + 3) / 4)), dim3(64, 4), 0, h->stream,
                      g, h->m, a);

@@ -1024,11 +1024,12 @@ static IntArgs int_args(udc_handle *h) {
   a.u0 = h->fields[UDC_U0]; a.v0 = h->fields[UDC_V0]; a.w0 = h->fields[UDC_W0];
   a.um = h->fields[UDC_UM]; a.vm = h->fields[UDC_VM]; a.wm = h->fields[UDC_WM];
   a.up = h->fields[UDC_UP]; a.vp = h->fields[UDC_VP]; a.wp = h->fields[UDC_WP];
-  a.nsv = h->cfg.nsv;
-  for (int n = 0; n < a.nsv; ++n) {
-    a.sv0[n] = h->fields[UDC_SV0 + 3 * n];
-    a.svm[n] = h->fields[UDC_SVM + 3 * n];
-    a.svp[n] = h->fields[UDC_SVP + 3 * n];
+  a.nsv = 0;
+  for (int n : h->slots) {
+    a.sv0[a.nsv] = h->fields[UDC_SV0 + 3 * n];
+    a.svm[a.nsv] = h->fields[UDC_SVM + 3 * n];
+    a.svp[a.nsv] = h->fields[UDC_SVP + 3 * n];
+    ++a.nsv;
   }
   return a;
 }

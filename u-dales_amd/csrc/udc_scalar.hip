@@ -1,5 +1,5 @@
-// Passive scalars: kappa-scheme (flux-limited, kappa = 1/3) advection and eddy diffusion.
-// Reference: advecc_kappa + rlim (src/modadvection.f90:316-421), diffc (src/modsubgrid.f90:540-623).
+// Transported scalars: kappa-scheme (flux-limited, kappa = 1/3) or 2nd-order central advection and eddy diffusion.
+// Reference: advecc_kappa + rlim (src/modadvection.f90:316-421), advecc_2nd (:103-155), diffc (src/modsubgrid.f90:540-623).
 // The reference builds each direction's fluxes into two 3-D temporaries and adds them to the
 // tendency (6 zero-fills, 3 whole-array adds); here every cell evaluates its six face values
 // in registers and accumulates in the reference's order ((cp + upper) + lower per direction).
@@ -27,7 +27,8 @@ __device__ __forceinline__ double face(double vel, double cm2, double cm1, doubl
   return cf + df * rlim(d1, d2);
 }
 
-template <bool ADV, bool DIFF, bool LES>
+// ADV: 0 = none, 1 = kappa, 2 = cd2
+template <int ADV, bool DIFF, bool LES>
 __global__ __launch_bounds__(256) void scalar_kernel(Geo g, TileGrid tg, Metrics m, double cekh, const double *__restrict__ u,
     const double *__restrict__ v, const double *__restrict__ w, const double *__restrict__ ekh,
     const double *__restrict__ c, double *__restrict__ cp) {
@@ -43,7 +44,15 @@ __global__ __launch_bounds__(256) void scalar_kernel(Geo g, TileGrid tg, Metrics
   const double c0 = c[o];
   const double cxm1 = c[xm1], cxp1 = c[xp1], cym1 = c[o - sy], cyp1 = c[o + sy], czm1 = c[o - sz], czp1 = c[o + sz];
   double t = cp[o];
-  if (ADV) {
+  if (ADV == 2) {
+    // advecc_2nd, src/modadvection.f90:127-133 and :148-151 (two statements, same order)
+    const double kdzf = m.dzf[kf], kdzfm = m.dzf[kf - 1], kdzfp = m.dzf[kf + 1];
+    t = t - ((u[xp1] * (cxp1 + c0) - u[o] * (cxm1 + c0)) * m.dxi5
+           + (v[o + sy] * (cyp1 + c0) - v[o] * (cym1 + c0)) * m.dyi5);
+    t = t - (w[o + sz] * (czp1 * kdzf + c0 * kdzfp) * m.dzhi[kf + 1]
+           - w[o] * (czm1 * kdzf + c0 * kdzfm) * m.dzhi[kf]) * m.dzfi5[kf];
+  }
+  if (ADV == 1) {
     const double cxm2 = c[xm2], cxp2 = c[xp2];
     const double cym2 = c[o - 2 * sy], cyp2 = c[o + 2 * sy];
     const double czm2 = c[o - 2 * sz], czp2 = c[o + 2 * sz];
@@ -99,7 +108,49 @@ inline dim3 cell_grid(const Geo &g, dim3 b) {
   return dim3((unsigned)tile_grid(g).tiles * (unsigned)g.nz, 1, 1);
 }
 
+// cp(i,j,k) += src(k): thlpcar in forces, src/modforces.f90:104-110
+__global__ __launch_bounds__(256) void level_source_kernel(Geo g, TileGrid tg, const double *__restrict__ src, double *__restrict__ cp) {
+  int i, j, k;
+  if (!tile_decode(g, tg, i, j, k)) return;
+  const long c = g.idx(i, j, k);
+  cp[c] = cp[c] + src[k + 1];
+}
+
+// fluxtop with a non-zero flux (src/modboundary.f90:1494-1507) on c0 and cm over the padded y extent
+__global__ void top_flux_kernel(Geo g, Metrics m, const double *__restrict__ ekh, double *__restrict__ c0, double *__restrict__ cm,
+                                double flux) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = (int)blockIdx.y - HY;
+  if (i >= g.nx) return;
+  const long top = g.idx(i, j, g.nz - 1), ghost = top + g.sz;
+  const int ke = g.nz;
+  const double d = m.dzh[ke + 1] * flux / (m.dzhi[ke + 1] * (0.5 * (m.dzf[ke] * ekh[ghost] + m.dzf[ke + 1] * ekh[top])));
+  c0[ghost] = c0[top] + d;
+  cm[ghost] = cm[top] + d;
+}
+
 }  // namespace
+
+int k_level_source(udc_handle *h, int slot, const double *src) {
+  const Geo &g = h->g;
+  dim3 b(64, 4, 1), gr = cell_grid(g, b);
+  PROF(h, "level_source");
+  hipLaunchKernelGGL(level_source_kernel, gr, b, 0, h->stream, g, tile_grid(g), src, h->fields[UDC_SVP + 3 * slot]);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int k_scalar_top_flux(udc_handle *h) {
+  const Geo &g = h->g;
+  for (int n : h->slots) {
+    if (h->slot[n].top != 1) continue;
+    PROF(h, "top_flux");
+    hipLaunchKernelGGL(top_flux_kernel, dim3((g.nx + 63) / 64, g.py), dim3(64), 0, h->stream, g, h->m, h->fields[UDC_EKH],
+                       h->fields[UDC_SV0 + 3 * n], h->fields[UDC_SVM + 3 * n], h->slot[n].topval);
+    HIP_OK(hipGetLastError());
+  }
+  return 0;
+}
 
 static int launch_scalar(udc_handle *h, int n, bool adv, bool diff) {
   const Geo &g = h->g;
@@ -109,14 +160,17 @@ static int launch_scalar(udc_handle *h, int n, bool adv, bool diff) {
   const double *ekh = h->fields[UDC_EKH], *c = h->fields[UDC_SV0 + 3 * n];
   double *cp = h->fields[UDC_SVP + 3 * n];
   const bool les = h->p.sgs != UDC_SGS_DNS;
+  const bool cd2 = h->slot[n].adv == 2;
 #define LS(A, D, L)                                                                                     \
   do {                                                                                                  \
     PROF(h, "scalar_" #A #D #L);                                                                        \
     hipLaunchKernelGGL((scalar_kernel<A, D, L>), gr, b, 0, h->stream, g, tile_grid(g), h->m, cekh, u, v, w, ekh, c, cp); \
   } while (0)
-  if (adv && diff) { if (les) LS(true, true, true); else LS(true, true, false); }
-  else if (adv) LS(true, false, true);
-  else if (diff) { if (les) LS(false, true, true); else LS(false, true, false); }
+  if (adv && diff) {
+    if (cd2) { if (les) LS(2, true, true); else LS(2, true, false); }
+    else { if (les) LS(1, true, true); else LS(1, true, false); }
+  } else if (adv) { if (cd2) LS(2, false, true); else LS(1, false, true); }
+  else if (diff) { if (les) LS(0, true, true); else LS(0, true, false); }
 #undef LS
   HIP_OK(hipGetLastError());
   return 0;

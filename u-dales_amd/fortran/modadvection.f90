@@ -19,8 +19,12 @@ contains
       write (0, *) 'ERROR: Unknown advection scheme'
       stop 1
     end if
-    if (loneeqn .or. ltempeq .or. lmoist) then
-      write (0, *) 'ERROR: libudcore advection: TKE / thl / qt equations are not on the device path'
+    if (loneeqn .or. lmoist) then
+      write (0, *) 'ERROR: libudcore advection: TKE / qt equations are not on the device path'
+      stop 1
+    end if
+    if (ltempeq .and. iadv_thl /= iadv_cd2) then   ! thl: advecc_2nd only (src/modadvection.f90:66-68)
+      write (0, *) 'ERROR: libudcore advection: iadv_thl must be 2 (cd2)'
       stop 1
     end if
 

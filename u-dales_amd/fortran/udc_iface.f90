@@ -21,7 +21,8 @@ module udc_iface
   ! field ids, include/udcore.h
   integer(c_int), parameter :: UDC_U0 = 0, UDC_V0 = 1, UDC_W0 = 2, UDC_UM = 3, UDC_VM = 4, UDC_WM = 5, &
                                UDC_UP = 6, UDC_VP = 7, UDC_WP = 8, UDC_PRES0 = 9, UDC_P = 10, &
-                               UDC_EKM = 11, UDC_EKH = 12, UDC_SV0 = 13, UDC_SVM = 14, UDC_SVP = 15
+                               UDC_EKM = 11, UDC_EKH = 12, UDC_SV0 = 13, UDC_SVM = 14, UDC_SVP = 15, &
+                               UDC_THL0 = 13 + 45, UDC_THLM = 14 + 45, UDC_THLP = 15 + 45   ! scalar slot 15
 
   type, bind(C) :: udc_config
     integer(c_int) :: itot, jtot, ktot
@@ -83,6 +84,18 @@ module udc_iface
     integer(c_int) function udc_subgrid(h) bind(C, name='udc_subgrid')
       import :: c_int, c_ptr
       type(c_ptr), value :: h
+    end function
+    integer(c_int) function udc_set_tempeq(h, iadv_thl, bctopt, wttop, thl_top, bcbott, wtsurf) bind(C, name='udc_set_tempeq')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: iadv_thl, bctopt, bcbott
+      real(c_double), value :: wttop, thl_top, wtsurf
+    end function
+    integer(c_int) function udc_set_thl_source(h, thlpcar, n) bind(C, name='udc_set_thl_source')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(in) :: thlpcar(*)
+      integer(c_int), value :: n
     end function
     integer(c_int) function udc_bottom(h) bind(C, name='udc_bottom')
       import :: c_int, c_ptr
@@ -179,9 +192,10 @@ contains
   !> Create the device mirror once all of initglobal/initfields/initsubgrid/initpois have run.
   subroutine udc_ensure
     use modglobal, only: itot, jtot, ktot, dx, dy, dzf, dzh, kb, ke, kh, numol, prandtlmoli, nsv, &
-                         BCtopm, Uinf, Vinf, lles
+                         BCtopm, Uinf, Vinf, lles, ltempeq, lbuoyancy, lmoist, iadv_thl, BCtopT, BCbotT
+    use modsurfdata, only: wttop, thl_top, wtsurf
     use modsubgriddata, only: lsmagorinsky, lvreman, prandtli, c_vreman, csz
-    use modfields, only: dpdxl, dpdyl
+    use modfields, only: dpdxl, dpdyl, thlpcar
     use modmpi, only: myid, nprocs, nprocx, comm3d, mpierr
     use mpi, only: MPI_CHARACTER
     type(udc_config) :: cfg
@@ -230,6 +244,15 @@ contains
       call udc_check(udc_comm_init(udc_h, nccl_id), 'udc_comm_init')
     end if
     call udc_check(udc_set_forcing(udc_h, dpdxl(kb:ke), dpdyl(kb:ke), int(ktot, c_int)), 'udc_set_forcing')
+    if (ltempeq) then      ! passive temperature equation (the buoyancy term stays on the host side: not built)
+      if (lbuoyancy .or. lmoist) then
+        write (0, *) 'ERROR: libudcore transports thl as a passive field only: lbuoyancy and lmoist must be .false.'
+        stop 1
+      end if
+      call udc_check(udc_set_tempeq(udc_h, int(iadv_thl, c_int), int(BCtopT, c_int), real(wttop, c_double), &
+                                    real(thl_top, c_double), int(BCbotT, c_int), real(wtsurf, c_double)), 'udc_set_tempeq')
+      call udc_check(udc_set_thl_source(udc_h, thlpcar(kb:ke), int(ktot, c_int)), 'udc_set_thl_source')
+    end if
     call get_environment_variable('UDC_RESIDENCY', env, status=stat)
     if (stat == 0) read (env, *, iostat=stat) udc_residency
     call udc_push_state
@@ -255,8 +278,8 @@ contains
 
   !> Everything the device needs from the host's prognostic state (bounds: src/modfields.f90:440-474)
   subroutine udc_push_state
-    use modglobal, only: ib, jb, kb, ih, jh, kh, ihc, jhc, khc, nsv
-    use modfields, only: u0, v0, w0, um, vm, wm, pres0, sv0, svm
+    use modglobal, only: ib, jb, kb, ih, jh, kh, ihc, jhc, khc, nsv, ltempeq
+    use modfields, only: u0, v0, w0, um, vm, wm, pres0, sv0, svm, thl0, thlm
     integer :: n
     call udc_push3(UDC_U0, u0, (/ib - ih, jb - jh, kb - kh/))
     call udc_push3(UDC_V0, v0, (/ib - ih, jb - jh, kb - kh/))
@@ -265,6 +288,10 @@ contains
     call udc_push3(UDC_VM, vm, (/ib - ih, jb - jh, kb - kh/))
     call udc_push3(UDC_WM, wm, (/ib - ih, jb - jh, kb - kh/))
     call udc_push3(UDC_PRES0, pres0, (/ib - ih, jb - jh, kb - kh/))
+    if (ltempeq) then
+      call udc_push3(UDC_THL0, thl0, (/ib - ih, jb - jh, kb - kh/))
+      call udc_push3(UDC_THLM, thlm, (/ib - ih, jb - jh, kb - kh/))
+    end if
     do n = 1, nsv
       call udc_push3(UDC_SV0 + 3*(n - 1), sv0(:, :, :, n), (/ib - ihc, jb - jhc, kb - khc/))
       call udc_push3(UDC_SVM + 3*(n - 1), svm(:, :, :, n), (/ib - ihc, jb - jhc, kb - khc/))
@@ -272,37 +299,40 @@ contains
   end subroutine udc_push_state
 
   subroutine udc_push_tend
-    use modglobal, only: ib, jb, kb, ih, jh, ihc, jhc, nsv
-    use modfields, only: up, vp, wp, svp
+    use modglobal, only: ib, jb, kb, ih, jh, ihc, jhc, nsv, ltempeq
+    use modfields, only: up, vp, wp, svp, thlp
     integer :: n
     call udc_push3(UDC_UP, up, (/ib - ih, jb - jh, kb/))
     call udc_push3(UDC_VP, vp, (/ib - ih, jb - jh, kb/))
     call udc_push3(UDC_WP, wp, (/ib - ih, jb - jh, kb/))
+    if (ltempeq) call udc_push3(UDC_THLP, thlp, (/ib - ih, jb - jh, kb/))
     do n = 1, nsv
       call udc_push3(UDC_SVP + 3*(n - 1), svp(:, :, :, n), (/ib - ihc, jb - jhc, kb/))
     end do
   end subroutine udc_push_tend
 
   subroutine udc_pull_tend
-    use modglobal, only: ib, jb, kb, ih, jh, ihc, jhc, nsv
-    use modfields, only: up, vp, wp, svp
+    use modglobal, only: ib, jb, kb, ih, jh, ihc, jhc, nsv, ltempeq
+    use modfields, only: up, vp, wp, svp, thlp
     integer :: n
     call udc_pull3(UDC_UP, up, (/ib - ih, jb - jh, kb/))
     call udc_pull3(UDC_VP, vp, (/ib - ih, jb - jh, kb/))
     call udc_pull3(UDC_WP, wp, (/ib - ih, jb - jh, kb/))
+    if (ltempeq) call udc_pull3(UDC_THLP, thlp, (/ib - ih, jb - jh, kb/))
     do n = 1, nsv
       call udc_pull3(UDC_SVP + 3*(n - 1), svp(:, :, :, n), (/ib - ihc, jb - jhc, kb/))
     end do
   end subroutine udc_pull_tend
 
   subroutine udc_pull_vel(with_m)
-    use modglobal, only: ib, jb, kb, ih, jh, kh, ihc, jhc, khc, nsv
-    use modfields, only: u0, v0, w0, um, vm, wm, sv0, svm
+    use modglobal, only: ib, jb, kb, ih, jh, kh, ihc, jhc, khc, nsv, ltempeq
+    use modfields, only: u0, v0, w0, um, vm, wm, sv0, svm, thl0, thlm
     logical, intent(in) :: with_m
     integer :: n
     call udc_pull3(UDC_U0, u0, (/ib - ih, jb - jh, kb - kh/))
     call udc_pull3(UDC_V0, v0, (/ib - ih, jb - jh, kb - kh/))
     call udc_pull3(UDC_W0, w0, (/ib - ih, jb - jh, kb - kh/))
+    if (ltempeq) call udc_pull3(UDC_THL0, thl0, (/ib - ih, jb - jh, kb - kh/))
     do n = 1, nsv
       call udc_pull3(UDC_SV0 + 3*(n - 1), sv0(:, :, :, n), (/ib - ihc, jb - jhc, kb - khc/))
     end do
@@ -310,6 +340,7 @@ contains
       call udc_pull3(UDC_UM, um, (/ib - ih, jb - jh, kb - kh/))
       call udc_pull3(UDC_VM, vm, (/ib - ih, jb - jh, kb - kh/))
       call udc_pull3(UDC_WM, wm, (/ib - ih, jb - jh, kb - kh/))
+      if (ltempeq) call udc_pull3(UDC_THLM, thlm, (/ib - ih, jb - jh, kb - kh/))
       do n = 1, nsv
         call udc_pull3(UDC_SVM + 3*(n - 1), svm(:, :, :, n), (/ib - ihc, jb - jhc, kb - khc/))
       end do

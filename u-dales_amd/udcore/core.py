@@ -33,6 +33,7 @@ class DynCore:
         self.nyl = g.ny // nranks
         self.rk3step = 0
         self.dt = 0.
+        self.ltempeq = False
         self.timee = 0.
 
     # ---- lifetime
@@ -130,6 +131,15 @@ class DynCore:
         """&PHYSICS luvolflowr/uflowrate, lvvolflowr/vflowrate (src/modglobal.f90:231,331)."""
         L._check(self.lib.udc_set_masscorr(self.h, int(bool(luvolflowr)), C.c_double(uflowrate),
                                            int(bool(lvvolflowr)), C.c_double(vflowrate)), "udc_set_masscorr")
+
+    def set_tempeq(self, iadv_thl=2, bctopt=1, wttop=0., thl_top=-1., bcbott=1, wtsurf=0., thlpcar=None):
+        """&PHYSICS ltempeq: thl becomes a transported (passive) field, see include/udcore.h udc_set_tempeq."""
+        L._check(self.lib.udc_set_tempeq(self.h, int(iadv_thl), int(bctopt), C.c_double(wttop), C.c_double(thl_top),
+                                         int(bcbott), C.c_double(wtsurf)), "udc_set_tempeq")
+        self.ltempeq = True
+        if thlpcar is not None:
+            a = np.ascontiguousarray(thlpcar, dtype=np.float64)
+            L._check(self.lib.udc_set_thl_source(self.h, a.ctypes.data_as(L.DP), len(a)), "udc_set_thl_source")
 
     def masscorr(self):
         """masscorr (src/modforces.f90:328), after forces."""

@@ -145,4 +145,15 @@ def cold_start(g: Grid, d: Deck, j0=0, nyl=None, nsv=0, scal_a=1.0, scal_b=0.0):
         c[nz + 3] = c[nz + 1]
         out[f"sv0_{n}"] = c
         out[f"svm_{n}"] = c.copy()
+    if d.get("PHYSICS", "ltempeq"):
+        # thl0 = thlm = thlprof(k), ghosts as src/modstartup.f90:1156-1208, then boundary's top condition
+        t = np.zeros(shape)
+        for k in range(1, nz + 1):
+            t[k] = d.thl[k - 1]
+        t[0] = t[1]
+        if int(d.get("BC", "BCtopT")) == 2:
+            t[nz + 1] = 2 * float(d.get("BC", "thl_top")) - t[nz]
+        else:
+            t[nz + 1] = t[nz]          # non-zero wttop needs ekh: re-imposed on the device after the first closure
+        out["thl0"], out["thlm"] = t, t.copy()
     return out

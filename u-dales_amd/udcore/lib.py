@@ -17,13 +17,14 @@ DP = C.POINTER(C.c_double)
 
 # field ids (include/udcore.h)
 U0, V0, W0, UM, VM, WM, UP, VP, WP, PRES0, P, EKM, EKH, SV0, SVM, SVP = range(16)
+THL0, THLM, THLP = SV0 + 45, SVM + 45, SVP + 45      # temperature equation: scalar slot 15 (include/udcore.h)
 FIELD_IDS = dict(u0=U0, v0=V0, w0=W0, um=UM, vm=VM, wm=WM, up=UP, vp=VP, wp=WP, pres0=PRES0, p=P,
-                 ekm=EKM, ekh=EKH)
+                 ekm=EKM, ekh=EKH, thl0=THL0, thlm=THLM, thlp=THLP)
 SGS_DNS, SGS_SMAGORINSKY, SGS_VREMAN = 0, 1, 2
 
 EXPORTS = ["udc_create", "udc_destroy", "udc_last_error", "udc_version", "udc_comm_unique_id",
            "udc_comm_init", "udc_local_group_create", "udc_comm_init_local", "udc_field_upload", "udc_field_download", "udc_set_forcing",
-           "udc_advection", "udc_subgrid", "udc_bottom", "udc_forces", "udc_set_masscorr", "udc_masscorr", "udc_poisson", "udc_tstep_integrate",
+           "udc_advection", "udc_subgrid", "udc_bottom", "udc_forces", "udc_set_masscorr", "udc_masscorr", "udc_set_tempeq", "udc_set_thl_source", "udc_poisson", "udc_tstep_integrate",
            "udc_halos", "udc_boundary", "udc_tstep_maxima", "udc_substep", "udc_run",
            "udc_divergence", "udc_sync", "udc_profile_enable", "udc_profile_reset",
            "udc_profile_get"]
