@@ -101,12 +101,15 @@ int udc_set_forcing(udc_handle *h, const double *dpdxl, const double *dpdyl, int
 /* Temperature equation, &PHYSICS ltempeq (src/modglobal.f90:176): thl is advected (advection: iadv_thl = 2 ->
  * advecc_2nd, src/modadvection.f90:103-155), diffused (subgrid: diffc with ekh), integrated and given its top
  * (BCtopT 1 = flux wttop, 2 = value thl_top, src/modboundary.f90:207-220) and floor (lbottom, BCbotT 1 = flux wtsurf,
- * src/modibm.f90:2035-2047) conditions like the passive scalars.  Passive only: the buoyancy term and the
- * thermodynamics diagnostics (lbuoyancy, src/modforces.f90:73-84, src/modthermodynamics.f90) are not built.
+ * src/modibm.f90:2035-2047) conditions like the passive scalars.  udc_set_buoyancy switches on forces' buoyancy
+ * term for dry air (lbuoyancy, src/modforces.f90:73-84): wp += grav (thv0h - thvh)/thvh with thv0h = thl0h of
+ * calc_halflev and thvh its slab average (src/modthermodynamics.f90:76,208,518-524), applied by udc_forces and
+ * inside udc_substep.  Moisture (lmoist) is not built.
  * Call once after udc_create, before the first substep.  thlpcar (udc_set_thl_source, [ktot] = thlpcar(kb:ke), the
  * radiative tendency of src/modforces.f90:104-110) is optional. */
 int udc_set_tempeq(udc_handle *h, int iadv_thl, int bctopt, double wttop, double thl_top, int bcbott, double wtsurf);
 int udc_set_thl_source(udc_handle *h, const double *thlpcar, int n);
+int udc_set_buoyancy(udc_handle *h, int lbuoyancy, double grav);
 
 /* ---- the reference's call surface (src/program.f90:134-207) ----------------------- */
 /* advection   src/modadvection.f90:36   up,vp,wp (+svp) -= div(u phi) (+ grad pres0)     */

@@ -34,10 +34,10 @@ program ref_driver
   use modglobal
   use modfields
   use modsubgriddata
-  use modsurfdata, only: thl_top, wttop, wsvtop, sv_top, thvs, thls, z0, wtsurf
+  use modsurfdata, only: thl_top, wttop, wsvtop, sv_top, thvs, thls, z0, wtsurf, qts
   use modwallfunctions, only: wfmneutral
   use modboundary, only: initboundary, boundary, halos
-  use modthermodynamics, only: initthermodynamics
+  use modthermodynamics, only: initthermodynamics, thermodynamics
   use modsubgrid, only: initsubgrid, subgrid
   use modpois, only: initpois, poisson, p
   use modadvection, only: advection
@@ -85,6 +85,7 @@ program ref_driver
   call initpois
   call cold_start
   call boundary
+  if (ltempeq) call thermodynamics         ! src/program.f90:120 (thv0h, thvh for the buoyancy term)
 
   iu = 71
   if (trim(mode) /= 'time') then
@@ -170,6 +171,7 @@ contains
     call tstep_integrate
     call halos
     call boundary
+    if (ltempeq) call thermodynamics       ! src/program.f90:214
   end subroutine one_substep
 
   ! ---- `bottom`, src/modibm.f90:2021-2026 (momentum, BCbotm = 3) and :2073-2090 (scalars, BCbots = 1)
@@ -221,6 +223,7 @@ contains
   ! ---- subset of src/modstartup.f90:105-172 (same group and variable names)
   subroutine read_namelists_subset
     use modfields, only: dpdx
+    use modglobal, only: rv_g => rv, rd_g => rd
     integer :: ierr
     namelist /RUN/ iexpnr, runtime, dtmax, trestart, ladaptive, irandom, randu, krand, courant, diffnr, &
       libm, lles, lrandomize, nprocx, nprocy
@@ -228,7 +231,7 @@ contains
     namelist /PHYSICS/ lmoist, lcoriol, lbuoyancy, ltempeq, lprofforc, dpdx, luvolflowr, uflowrate, &
       lvvolflowr, vflowrate
     namelist /DYNAMICS/ ipoiss, iadv_mom, iadv_tke, iadv_thl, iadv_qt, iadv_sv
-    namelist /BC/ BCxm, BCym, BCtopm, BCtopT, BCtops, BCbotm, BCbots, BCbotT, BCzp, wttop, thl_top, z0, wtsurf
+    namelist /BC/ BCxm, BCym, BCtopm, BCtopT, BCtops, BCbotm, BCbots, BCbotT, BCzp, wttop, thl_top, z0, wtsurf, thls
     namelist /SCALARS/ nsv
     namelist /WALLS/ nfcts, lbottom
     open (ifnamopt, file=fname_options, status='old', iostat=ierr)
@@ -248,6 +251,7 @@ contains
     libm = .false.
     allocate (wsvtop(1:max(nsv, 1))); wsvtop = 0.      ! src/modstartup.f90:518-519
     allocate (sv_top(1:max(nsv, 1))); sv_top = 0.
+    thvs = thls*(1.+(rv_g/rd_g - 1.)*qts)                  ! src/modstartup.f90:522
     write (cexpnr, '(i3.3)') iexpnr
   end subroutine read_namelists_subset
 

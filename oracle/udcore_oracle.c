@@ -927,6 +927,27 @@ void orc_thl_floor(const orc_grid *g, const double *ekh, const double *thl0, dou
   metrics_free(&m);
 }
 
+/* buoyancy term of forces with lbuoyancy for dry air (src/modforces.f90:73-84): thv0h = thl0h (calthv,
+ * src/modthermodynamics.f90:208; calc_halflev :518-524), thvh = its slab average (:76, avexy_ibm) */
+void orc_buoyancy(const orc_grid *g, const double *thl0, double *wp) {
+  if (!g->lbuoyancy) return;
+  const double grav = 9.81;                        /* src/modglobal.f90:271 */
+  const double *dzf = g->dzf, *dzh = g->dzh;
+  const double cnt = (double)g->nx * (double)g->ny;
+  for (int k = 2; k <= g->nz; ++k) {
+    double s = 0.;
+    for (int j = 1; j <= g->ny; ++j)
+      for (int i = 1; i <= g->nx; ++i)
+        s += (M(thl0, i, j, k) * dzf[k - 1] + M(thl0, i, j, k - 1) * dzf[k]) / (2 * dzh[k]);
+    const double thvh = s / cnt;
+    for (int j = 1; j <= g->ny; ++j)
+      for (int i = 1; i <= g->nx; ++i) {
+        const double th = (M(thl0, i, j, k) * dzf[k - 1] + M(thl0, i, j, k - 1) * dzf[k]) / (2 * dzh[k]);
+        M(wp, i, j, k) = M(wp, i, j, k) + grav * (th - thvh) / thvh;
+      }
+  }
+}
+
 /* ====================================================================== masscorr */
 /* src/modforces.f90:328-497, volume-flow branches: luvolflowr (:389-417) and lvvolflowr (:467-494);
  * avexy_ibm without IBM (src/modmpi.f90:623-664): slab sums divided by IIus(k) = itot*jtot. */
@@ -996,6 +1017,7 @@ void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
   orc_bottom(g, s->u0, s->v0, s->ekm, s->ekh, s->sv0, s->up, s->vp, s->svp, NULL);   /* src/program.f90:152 */
   if (g->ltempeq) orc_thl_floor(g, s->ekh, s->thl0, s->thlp);
   if (s->dpdxl) orc_forces(g, s->dpdxl, s->dpdyl, s->up, s->vp, s->wp);
+  if (s->dpdxl && g->ltempeq) orc_buoyancy(g, s->thl0, s->wp);
   if (g->ltempeq && s->dpdxl && s->thlpcar)                                             /* src/modforces.f90:104-110 */
     for (int k = 1; k <= g->nz; ++k)
       for (int j = 1; j <= g->ny; ++j)

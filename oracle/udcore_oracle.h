@@ -46,6 +46,7 @@ typedef struct {
   int ltempeq;              /* passive temperature equation, iadv_thl = 2 (src/modglobal.f90:176) */
   int bctopt;               /* BCtopT: 1 flux wttop, 2 value thl_top (src/modglobal.f90:144-154) */
   double wttop, thl_top, wtsurf;   /* src/modsurfdata.f90:62,80,81 */
+  int lbuoyancy;            /* forces' buoyancy term, dry air (src/modforces.f90:73-84) */
 } orc_grid;
 
 /* ---- advection: src/modadvection.f90 */
@@ -78,6 +79,7 @@ void orc_bottom(const orc_grid *g, const double *u0, const double *v0, const dou
 void orc_advecc_2nd(const orc_grid *g, const double *u0, const double *v0, const double *w0, const double *c, double *cp);
 void orc_diffc_m(const orc_grid *g, const double *c, const double *ekh, double *cp);
 void orc_thl_top(const orc_grid *g, const double *ekh, double *a);
+void orc_buoyancy(const orc_grid *g, const double *thl0, double *wp);
 void orc_thl_floor(const orc_grid *g, const double *ekh, const double *thl0, double *thlp);
 /* ---- masscorr: src/modforces.f90:328-497 (volume-flow branches) */
 void orc_masscorr(const orc_grid *g, int rk3step, double dt, double *up, const double *um, double *vp, const double *vm);

@@ -137,7 +137,18 @@ CASES = {
                               bc="BCtopT = 2\nthl_top = 290.5\nBCbotT = 1\nwtsurf = 0.02",
                               oracle="nsub = 6\ndump_at = 3, 6"), 1.06),
 }
-THL_CASES = {"k_thl_12x8x6": dict(dthl=0.4, dthlrad=2e-3), "run_thl_16x8x12s": dict(dthl=0.25, dthlrad=-1e-3)}
+CASES.update({
+    # buoyancy (lbuoyancy, dry air): forces' wp += grav (thv0h - thvh)/thvh with the reference's thermodynamics
+    "k_buoy_12x8x6": ("kernels", 19, 12, 8, 6,
+                      dict(sgs="vreman", floor=True, physics="ltempeq = .true.\nlbuoyancy = .true.",
+                           bc="BCtopT = 1\nBCbotT = 1\nwtsurf = 0.05\nthls = 288.0", oracle="nspin = 3"), 1.04),
+    "run_buoy_16x8x12s": ("run", 26, 16, 8, 12,
+                          dict(sgs="smag", floor=True, physics="ltempeq = .true.\nlbuoyancy = .true.",
+                               bc="BCtopT = 2\nthl_top = 290.5\nBCbotT = 1\nwtsurf = 0.05\nthls = 288.0",
+                               oracle="nsub = 9\ndump_at = 3, 9"), 1.06),
+})
+THL_CASES = {"k_thl_12x8x6": dict(dthl=0.4, dthlrad=2e-3), "run_thl_16x8x12s": dict(dthl=0.25, dthlrad=-1e-3),
+             "k_buoy_12x8x6": dict(dthl=0.3), "run_buoy_16x8x12s": dict(dthl=0.2)}
 
 
 # restart files written by the reference's own writerestartfiles (src/modsave.f90:37-128): the files are the

@@ -29,7 +29,7 @@ class OrcGrid(C.Structure):
                 ("lbottom", C.c_int), ("z0", C.c_double),
                 ("luvolflowr", C.c_int), ("lvvolflowr", C.c_int), ("uflowrate", C.c_double), ("vflowrate", C.c_double),
                 ("ltempeq", C.c_int), ("bctopt", C.c_int), ("wttop", C.c_double), ("thl_top", C.c_double),
-                ("wtsurf", C.c_double)]
+                ("wtsurf", C.c_double), ("lbuoyancy", C.c_int)]
 
 
 class OrcState(C.Structure):
@@ -68,7 +68,8 @@ class Oracle:
     def __init__(self, nx, ny, nz, dx, dy, dzf, dzh, sgs=2, bctopm=1, nsv=0, numol=1.5e-5,
                  prandtlmoli=1. / 0.71, prandtli=1. / 0.333, c_vreman=0.07, csz=None,
                  uinf=0., vinf=0., lbottom=False, z0=0.05, luvolflowr=False, uflowrate=0.,
-                 lvvolflowr=False, vflowrate=0., ltempeq=False, bctopt=1, wttop=0., thl_top=-1., wtsurf=-1.):
+                 lvvolflowr=False, vflowrate=0., ltempeq=False, bctopt=1, wttop=0., thl_top=-1., wtsurf=-1.,
+                 lbuoyancy=False):
         self.nx, self.ny, self.nz, self.nsv = nx, ny, nz, nsv
         self.dzf = np.ascontiguousarray(dzf, dtype=np.float64)
         self.dzh = np.ascontiguousarray(dzh, dtype=np.float64)
@@ -81,7 +82,7 @@ class Oracle:
         self.g = OrcGrid(nx, ny, nz, dx, dy, ptr(self.dzf), ptr(self.dzh), numol, prandtlmoli,
                          prandtli, c_vreman, csz, sgs, bctopm, uinf, vinf, nsv, int(bool(lbottom)), z0,
                          int(bool(luvolflowr)), int(bool(lvvolflowr)), uflowrate, vflowrate,
-                         int(bool(ltempeq)), bctopt, wttop, thl_top, wtsurf)
+                         int(bool(ltempeq)), bctopt, wttop, thl_top, wtsurf, int(bool(lbuoyancy)))
         self.L = lib()
 
     def mshape(self):

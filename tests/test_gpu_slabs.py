@@ -105,8 +105,10 @@ def run_virtual(P, g, deck_like, st_global, nsub, dt, sgs, nsv=0, extras=False):
         try:
             core = DynCore(g, sgs=sgs, nsv=nsv, rank=r, nranks=P, lbottom=extras, z0=0.04)
             cores[r] = core
-            if extras:      # floor wall function + prescribed volume flow (all-reduced sums)
+            if extras:      # floor wall function + prescribed volume flow + buoyant temperature (all-reduced sums)
                 core.set_masscorr(True, 1.03, True, 0.02)
+                core.set_tempeq(bctopt=2, thl_top=291., wtsurf=0.03)
+                core.set_buoyancy(True)
             if P > 1:
                 core.comm_init_local(group)
             local = {}
@@ -118,7 +120,7 @@ def run_virtual(P, g, deck_like, st_global, nsub, dt, sgs, nsv=0, extras=False):
             core.boundary()
             for isub in range(nsub):
                 core.substep(isub % 3 + 1, dt, False)
-            out[r] = {k: core.download(k) for k in ("u0", "v0", "w0", "pres0")}
+            out[r] = {k: core.download(k) for k in ("u0", "v0", "w0", "pres0") + (("thl0",) if extras else ())}
             out[r]["div"] = core.divergence()
         except Exception as e:   # noqa: BLE001
             errs.append((r, repr(e)))
@@ -130,7 +132,7 @@ def run_virtual(P, g, deck_like, st_global, nsub, dt, sgs, nsv=0, extras=False):
         t.join(timeout=300)
     assert not errs, errs
     res = {}
-    for k in ("u0", "v0", "w0", "pres0"):
+    for k in ("u0", "v0", "w0", "pres0") + (("thl0",) if extras else ()):
         res[k] = np.concatenate([out[r][k][:, 1:-1, :] for r in range(P)], axis=1)
     res["div"] = out[0]["div"]
     for c in cores:
@@ -148,11 +150,19 @@ def test_decomposition_invariance(shape, sgs, chunks, extras, monkeypatch):
     nx, ny, nz = shape
     g = Grid.uniform(nx, ny, nz)
     st = random_state(g, seed=42)
+    if extras:
+        rng = np.random.default_rng(5)
+        t = np.zeros(g.mshape())
+        t[1:-1, 1:-1, 1:-1] = 288. + 0.2 * g.zf[1:nz + 1, None, None] + 0.05 * rng.standard_normal((nz, ny, nx))
+        t[:, 0, :] = t[:, ny, :]; t[:, ny + 1, :] = t[:, 1, :]
+        t[:, :, 0] = t[:, :, nx]; t[:, :, nx + 1] = t[:, :, 1]
+        t[0] = t[1]; t[nz + 1] = 2 * 291. - t[nz]
+        st["thl0"], st["thlm"] = t, t.copy()
     ref = run_virtual(1, g, None, st, 6, 0.05, sgs, extras=extras)
     assert ref["div"][0] < 1e-11
     for P in (2, 4):
         got = run_virtual(P, g, None, st, 6, 0.05, sgs, extras=extras)
-        for k in ("u0", "v0", "w0", "pres0"):
-            e = relerr(got[k][1:-1], ref[k][1:-1])
+        for k in ("u0", "v0", "w0", "pres0") + (("thl0",) if extras else ()):
+            e = relerr(got[k][1:-1], ref[k][1:-1], 1.0 if k == "thl0" else None)
             assert e <= 1e-10, (P, k, e)
         assert abs(got["div"][0] - ref["div"][0]) < 1e-12      # all-reduced max agrees on every rank

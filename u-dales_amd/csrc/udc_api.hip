@@ -188,6 +188,8 @@ extern "C" int udc_destroy(udc_handle *h) {
   if (h->red) hipFree(h->red);
   if (h->red_host) hipHostFree(h->red_host);
   if (h->thlpcar) hipFree(h->thlpcar);
+  if (h->lev_part) hipFree(h->lev_part);
+  if (h->lev_sum) hipFree(h->lev_sum);
   hipStreamDestroy(h->stream);
   delete h;
   return 0;
@@ -345,6 +347,16 @@ extern "C" int udc_set_tempeq(udc_handle *h, int iadv_thl, int bctopt, double wt
   return 0;
 }
 
+extern "C" int udc_set_buoyancy(udc_handle *h, int lbuoyancy, double grav) {
+  if (lbuoyancy && ((int)h->fields.size() <= UDC_THL0 || !h->fields[UDC_THL0])) {
+    udc_set_error("udc_set_buoyancy: call udc_set_tempeq first (thv0h comes from thl0)");
+    return 1;
+  }
+  h->lbuoyancy = lbuoyancy ? 1 : 0;
+  h->grav = grav;
+  return 0;
+}
+
 extern "C" int udc_set_thl_source(udc_handle *h, const double *thlpcar, int n) {
   HIP_OK(hipSetDevice(h->device));
   if (n != h->g.nz) { udc_set_error("udc_set_thl_source: expected %d levels", h->g.nz); return 1; }
@@ -380,7 +392,8 @@ extern "C" int udc_forces(udc_handle *h) {
   HIP_OK(hipSetDevice(h->device));
   if (tend_clean(h) || um_materialise(h)) return 1;
   if (h->thlpcar && k_level_source(h, 15, h->thlpcar)) return 1;      // thlp += thlpcar(k), src/modforces.f90:104-110
-  return k_forces(h);
+  if (k_forces(h)) return 1;
+  return k_buoyancy(h);
 }
 
 extern "C" int udc_poisson(udc_handle *h, int rk3step, double dt) {
@@ -466,6 +479,7 @@ extern "C" int udc_substep(udc_handle *h, int rk3step, double dt, int with_force
   for (int n : h->slots)
     if (k_scalar_fused(h, n)) return 1;
   if (with_forces && h->thlpcar && k_level_source(h, 15, h->thlpcar)) return 1;
+  if (with_forces && k_buoyancy(h)) return 1;        // additive on wp(kb+1..ke), hence on pwp
   // `bottom` (src/program.f90:152): additive on the k = kb tendencies, hence equally on pup = up + um/rk3coef
   if (h->p.lbottom && k_bottom(h, fold)) return 1;
   // masscorr (src/program.f90:169); without pup the tendencies and um are summed separately

@@ -13,6 +13,7 @@
 #include <pthread.h>
 #include <mutex>
 #include <cstring>
+#include <vector>
 #include <cstdlib>
 
 struct LocalGroup {
@@ -20,7 +21,7 @@ struct LocalGroup {
   pthread_barrier_t bar;
   // published per rank: send pointers by tag (0 = to-prev rows, 1 = to-next rows, 2 = all-to-all base)
   const double *send[64][3];
-  double red[64][8];
+  double red[64][2048];
 };
 
 static std::mutex g_groups_mu;
@@ -160,7 +161,7 @@ int comm_alltoall(udc_handle *h, const double *send, double *recv, size_t block,
   return 0;
 }
 
-// in-place all-reduce of n (<= 8) doubles held in device memory `buf`; op 0 = max, 1 = sum
+// in-place all-reduce of n (<= 2048) doubles held in device memory `buf`; op 0 = max, 1 = sum
 int comm_allreduce(udc_handle *h, double *buf, int n, int op) {
   if (h->cfg.nranks == 1 && !h->nccl) return 0;
   if (need_comm(h)) return 1;
@@ -171,17 +172,18 @@ int comm_allreduce(udc_handle *h, double *buf, int n, int op) {
   }
   LocalGroup *g = (LocalGroup *)h->local_group;
   const int P = h->cfg.nranks, r = h->cfg.rank;
+  if (n > 2048) { udc_set_error("comm_allreduce: at most 2048 values"); return 1; }
   HIP_OK(hipMemcpyAsync(g->red[r], buf, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
   pthread_barrier_wait(&g->bar);
-  double out[8];
+  std::vector<double> out(n);
   for (int q = 0; q < n; ++q) {
     double v = g->red[0][q];
     for (int s = 1; s < P; ++s) v = op == 0 ? (g->red[s][q] > v ? g->red[s][q] : v) : v + g->red[s][q];
     out[q] = v;
   }
   pthread_barrier_wait(&g->bar);
-  HIP_OK(hipMemcpyAsync(buf, out, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_OK(hipMemcpyAsync(buf, out.data(), n * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
   return 0;
 }

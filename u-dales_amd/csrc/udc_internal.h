@@ -117,6 +117,10 @@ struct udc_handle {
   };
   Slot slot[16];
   std::vector<int> slots;
+  int lbuoyancy = 0;           // forces' buoyancy term (dry air), needs the temperature equation
+  double grav = 9.81;
+  double *lev_part = nullptr, *lev_sum = nullptr;   // per-level slab sums (thvh)
+  size_t lev_cap = 0;
   double *thlpcar = nullptr;   // [nz+2] radiative heating profile added by forces (src/modforces.f90:104-110), or null
   // masscorr (src/modforces.f90:328): prescribed volume-flow rates
   int luvolflowr = 0, lvvolflowr = 0;
@@ -204,7 +208,8 @@ int k_halo_y(udc_handle *h, const int *fields, int nf, int width);
 int k_top_bottom(udc_handle *h);
 int k_top_rows_after_closure(udc_handle *h);
 int k_scalar_top_flux(udc_handle *h);              // fluxtop with a non-zero flux: re-imposed after closure (reassure_fluxtop_boundary)
-int k_level_source(udc_handle *h, int slot, const double *src);   // cp(i,j,k) += src(k)
+int k_level_source(udc_handle *h, int slot, const double *src);
+int k_buoyancy(udc_handle *h);                     // wp += grav (thv0h - thvh)/thvh, src/modforces.f90:73-84   // cp(i,j,k) += src(k)
 int k_maxima(udc_handle *h, double dt, double *cour, double *diffn);
 int k_divergence_check(udc_handle *h, double *divmax, double *divtot);
 int pois_init(udc_handle *h);

@@ -129,7 +129,72 @@ __global__ void top_flux_kernel(Geo g, Metrics m, const double *__restrict__ ekh
   cm[ghost] = cm[top] + d;
 }
 
+// Buoyancy (forces with lbuoyancy, src/modforces.f90:73-84; dry air: thv0h = thl0h, src/modthermodynamics.f90:208):
+//   wp(k) += grav (thl0h(i,j,k) - thvh(k)) / thvh(k),  k = kb+1..ke,
+//   thl0h(k) = (thl0(k) dzf(k-1) + thl0(k-1) dzf(k)) / (2 dzh(k))          (calc_halflev, :518-524)
+//   thvh(k)  = slab average of thl0h(k)                                     (thermodynamics :76, avexy_ibm)
+__device__ __forceinline__ double thl_half(const Geo &g, const Metrics &m, const double *__restrict__ t, long c, int k) {
+  const int kf = k + 1;
+  return (t[c] * m.dzf[kf - 1] + t[c - g.sz] * m.dzf[kf]) / (2 * m.dzh[kf]);
+}
+// stage 1: one workgroup per (xy tile, level) -> part[level * tiles + tile]; stage 2: one workgroup per level
+__global__ __launch_bounds__(256) void levelsum_kernel(Geo g, Metrics m, int gx, const double *__restrict__ thl, double *__restrict__ part) {
+  __shared__ double sw[4];
+  const int tile = blockIdx.x, k = blockIdx.y;
+  const int by = tile / gx, bx = tile - by * gx;
+  const int i = bx * 64 + threadIdx.x, j = by * 4 + threadIdx.y;
+  double v = 0.;
+  if (i < g.nx && j < g.ny && k >= 1) v = thl_half(g, m, thl, g.idx(i, j, k), k);
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if (threadIdx.x == 0) sw[threadIdx.y] = v;
+  __syncthreads();
+  if (threadIdx.x == 0 && threadIdx.y == 0) part[(size_t)k * gridDim.x + tile] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+}
+__global__ __launch_bounds__(256) void levelsum_final_kernel(int tiles, const double *__restrict__ part, double *__restrict__ S) {
+  __shared__ double sw[4];
+  const int k = blockIdx.x;
+  double v = 0.;
+  for (int q = threadIdx.x; q < tiles; q += 256) v += part[(size_t)k * tiles + q];
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) S[k] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+}
+__global__ __launch_bounds__(256) void buoyancy_kernel(Geo g, TileGrid tg, Metrics m, const double *__restrict__ thl,
+                                                        const double *__restrict__ S, double cnt, double grav, double *__restrict__ wp) {
+  int i, j, k;
+  if (!tile_decode(g, tg, i, j, k) || k < 1) return;
+  const long c = g.idx(i, j, k);
+  const double thvh = S[k] / cnt;
+  wp[c] = wp[c] + grav * (thl_half(g, m, thl, c, k) - thvh) / thvh;
+}
+
 }  // namespace
+
+int k_buoyancy(udc_handle *h) {
+  const Geo &g = h->g;
+  if (!h->lbuoyancy) return 0;
+  if ((int)h->fields.size() <= UDC_THL0 || !h->fields[UDC_THL0]) { udc_set_error("buoyancy needs the temperature equation (udc_set_tempeq)"); return 1; }
+  const TileGrid tg = tile_grid(g);
+  const size_t need = (size_t)tg.tiles * g.nz;
+  if (h->lev_cap < need) {
+    if (h->lev_part) HIP_OK(hipFree(h->lev_part));
+    HIP_OK(hipMalloc(&h->lev_part, sizeof(double) * need));
+    h->lev_cap = need;
+  }
+  if (!h->lev_sum) HIP_OK(hipMalloc(&h->lev_sum, sizeof(double) * (g.nz + 2)));
+  PROF(h, "buoyancy");
+  const double *thl = h->fields[UDC_THL0];
+  hipLaunchKernelGGL(levelsum_kernel, dim3((unsigned)tg.tiles, (unsigned)g.nz), dim3(64, 4), 0, h->stream, g, h->m, tg.gx, thl, h->lev_part);
+  hipLaunchKernelGGL(levelsum_final_kernel, dim3((unsigned)g.nz), dim3(256), 0, h->stream, tg.tiles, h->lev_part, h->lev_sum);
+  HIP_OK(hipGetLastError());
+  if (comm_allreduce(h, h->lev_sum, g.nz, 1)) return 1;       // avexy_ibm's MPI_ALLREDUCE over the slabs
+  dim3 b(64, 4, 1), gr = cell_grid(g, b);
+  hipLaunchKernelGGL(buoyancy_kernel, gr, b, 0, h->stream, g, tg, h->m, thl, h->lev_sum, (double)g.nx * (double)h->cfg.jtot,
+                     h->grav, h->fields[UDC_WP]);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
 
 int k_level_source(udc_handle *h, int slot, const double *src) {
   const Geo &g = h->g;

@@ -91,6 +91,12 @@ module udc_iface
       integer(c_int), value :: iadv_thl, bctopt, bcbott
       real(c_double), value :: wttop, thl_top, wtsurf
     end function
+    integer(c_int) function udc_set_buoyancy(h, lbuoyancy, grav) bind(C, name='udc_set_buoyancy')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: lbuoyancy
+      real(c_double), value :: grav
+    end function
     integer(c_int) function udc_set_thl_source(h, thlpcar, n) bind(C, name='udc_set_thl_source')
       import :: c_int, c_ptr, c_double
       type(c_ptr), value :: h
@@ -192,7 +198,7 @@ contains
   !> Create the device mirror once all of initglobal/initfields/initsubgrid/initpois have run.
   subroutine udc_ensure
     use modglobal, only: itot, jtot, ktot, dx, dy, dzf, dzh, kb, ke, kh, numol, prandtlmoli, nsv, &
-                         BCtopm, Uinf, Vinf, lles, ltempeq, lbuoyancy, lmoist, iadv_thl, BCtopT, BCbotT
+                         BCtopm, Uinf, Vinf, lles, ltempeq, lbuoyancy, lmoist, iadv_thl, BCtopT, BCbotT, grav
     use modsurfdata, only: wttop, thl_top, wtsurf
     use modsubgriddata, only: lsmagorinsky, lvreman, prandtli, c_vreman, csz
     use modfields, only: dpdxl, dpdyl, thlpcar
@@ -244,14 +250,15 @@ contains
       call udc_check(udc_comm_init(udc_h, nccl_id), 'udc_comm_init')
     end if
     call udc_check(udc_set_forcing(udc_h, dpdxl(kb:ke), dpdyl(kb:ke), int(ktot, c_int)), 'udc_set_forcing')
-    if (ltempeq) then      ! passive temperature equation (the buoyancy term stays on the host side: not built)
-      if (lbuoyancy .or. lmoist) then
-        write (0, *) 'ERROR: libudcore transports thl as a passive field only: lbuoyancy and lmoist must be .false.'
+    if (ltempeq) then      ! temperature equation; the dry buoyancy term is on the device for device-resident runs
+      if (lmoist) then    ! (in residency 0/1 the host's own forces adds it to the pulled tendencies)
+        write (0, *) 'ERROR: libudcore: the moisture equation / moist thermodynamics are not built (lmoist)'
         stop 1
       end if
       call udc_check(udc_set_tempeq(udc_h, int(iadv_thl, c_int), int(BCtopT, c_int), real(wttop, c_double), &
                                     real(thl_top, c_double), int(BCbotT, c_int), real(wtsurf, c_double)), 'udc_set_tempeq')
       call udc_check(udc_set_thl_source(udc_h, thlpcar(kb:ke), int(ktot, c_int)), 'udc_set_thl_source')
+      if (lbuoyancy) call udc_check(udc_set_buoyancy(udc_h, 1_c_int, real(grav, c_double)), 'udc_set_buoyancy')
     end if
     call get_environment_variable('UDC_RESIDENCY', env, status=stat)
     if (stat == 0) read (env, *, iostat=stat) udc_residency

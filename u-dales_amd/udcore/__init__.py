@@ -22,13 +22,15 @@ def from_deck(deck, device=0, rank=0, nranks=1):
     core.set_masscorr(bool(deck.get("PHYSICS", "luvolflowr")), float(deck.get("PHYSICS", "uflowrate")),
                       bool(deck.get("PHYSICS", "lvvolflowr")), float(deck.get("PHYSICS", "vflowrate")))
     if deck.get("PHYSICS", "ltempeq"):
-        if deck.get("PHYSICS", "lbuoyancy") or deck.get("PHYSICS", "lmoist"):
-            raise ValueError("ltempeq: the buoyancy term / moisture (thermodynamics) are not built; set lbuoyancy = .false.")
+        if deck.get("PHYSICS", "lmoist"):
+            raise ValueError("lmoist: the moisture equation / moist thermodynamics are not built")
         iadv = int(deck.get("DYNAMICS", "iadv_thl"))
         core.set_tempeq(iadv_thl=int(deck.get("DYNAMICS", "iadv_mom")) if iadv < 0 else iadv,
                         bctopt=int(deck.get("BC", "BCtopT")), wttop=float(deck.get("BC", "wttop")),
                         thl_top=float(deck.get("BC", "thl_top")), bcbott=int(deck.get("BC", "BCbotT")),
                         wtsurf=float(deck.get("BC", "wtsurf")), thlpcar=getattr(deck, "thlpcar", None))
+        if deck.get("PHYSICS", "lbuoyancy"):
+            core.set_buoyancy(True)
     import numpy as np
     # dpdxl, dpdyl: src/modstartup.f90:2071-2081 (lcoriol false => om23_gs terms still present:
     # dpdxl = om23_gs*vg - pgx - dpdx with om23_gs = 2*omega*sin(lat); ug = vg = 0 in our decks)

@@ -141,6 +141,10 @@ class DynCore:
             a = np.ascontiguousarray(thlpcar, dtype=np.float64)
             L._check(self.lib.udc_set_thl_source(self.h, a.ctypes.data_as(L.DP), len(a)), "udc_set_thl_source")
 
+    def set_buoyancy(self, on=True, grav=9.81):
+        """&PHYSICS lbuoyancy (dry air): forces adds grav (thv0h - thvh)/thvh to wp."""
+        L._check(self.lib.udc_set_buoyancy(self.h, int(bool(on)), C.c_double(grav)), "udc_set_buoyancy")
+
     def masscorr(self):
         """masscorr (src/modforces.f90:328), after forces."""
         L._check(self.lib.udc_masscorr(self.h, self.rk3step, C.c_double(self.dt)), "udc_masscorr")
