@@ -123,6 +123,11 @@ int udc_subgrid(udc_handle *h);
 int udc_bottom(udc_handle *h);
 /* forces      src/modforces.f90:46      neutral branch: up -= dpdxl(k), vp -= dpdyl(k), wp(kb)=0 */
 int udc_forces(udc_handle *h);
+/* coriolis    src/modforces.f90:600     mode 1 = lcoriol: Coriolis terms with om22 = 2 omega cos(lat), om23 = 2 omega sin(lat)
+ *             (src/modglobal.f90:666-673), wp(kb) = 0; mode 2 = lprofforc: up += om23 (ug(k) - u0); ug = ug(kb:ke).
+ *             Called between bottom and forces (src/program.f90:158); inside udc_substep when with_forces != 0. */
+int udc_set_coriolis(udc_handle *h, int mode, double om22, double om23, const double *ug, int n);
+int udc_coriolis(udc_handle *h);
 /* masscorr    src/modforces.f90:328     volume-flow branches: up += (uflowrate - <um + rk3coef up>)/rk3coef (luvolflowr,
  *             :389-417) and the same for v (lvvolflowr, :467-494); <.> = volume average over the whole domain
  *             (all-reduced over the slabs).  Called after forces (src/program.f90:169).  No-op unless enabled with

@@ -42,7 +42,7 @@ program ref_driver
   use modpois, only: initpois, poisson, p
   use modadvection, only: advection
   use modtstep, only: tstep_update, tstep_integrate
-  use modforces, only: forces, masscorr
+  use modforces, only: forces, masscorr, coriolis
   use modsave, only: writerestartfiles
   implicit none
 
@@ -165,6 +165,7 @@ contains
     call advection
     call subgrid
     call floor_bottom
+    if (lforces) call coriolis              ! src/program.f90:158 (no-op unless lcoriol / lprofforc)
     if (lforces) call forces
     call masscorr                           ! src/program.f90:169 (no-op unless luvolflowr / lvvolflowr)
     call poisson
@@ -510,6 +511,7 @@ contains
     call advection
     call subgrid
     call floor_bottom
+    if (lforces) call coriolis
     if (lforces) call forces
     if (luvolflowr .or. lvvolflowr) call dump_tend('frc')   ! tendencies masscorr starts from
     call masscorr

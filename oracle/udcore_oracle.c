@@ -948,6 +948,46 @@ void orc_buoyancy(const orc_grid *g, const double *thl0, double *wp) {
   }
 }
 
+/* ====================================================================== coriolis */
+/* src/modforces.f90:600-717: lcoriol (:627-676) or lprofforc (:682-710); ug[k] indexed by Fortran k */
+void orc_coriolis(const orc_grid *g, const double *u0, const double *v0, const double *w0, const double *ug,
+                  double *up, double *vp, double *wp) {
+  const double *dzf = g->dzf, *dzh = g->dzh;
+  const double om22 = g->om22, om23 = g->om23;
+  if (g->coriolis_mode == 1) {
+    for (int k = 2; k <= g->nz; ++k) {
+      int kp = k + 1, km = k - 1;
+      for (int j = 1; j <= g->ny; ++j) {
+        int jp = j + 1, jm = j - 1;
+        for (int i = 1; i <= g->nx; ++i) {
+          M(up, i, j, k) = M(up, i, j, k)
+              + ((M(v0, i, j, k) + M(v0, i, jp, k) + M(v0, i - 1, j, k) + M(v0, i - 1, jp, k)) * om23 * 0.25)
+              - ((M(w0, i, j, k) + M(w0, i, j, kp) + M(w0, i - 1, j, kp) + M(w0, i - 1, j, k)) * om22 * 0.25);
+          M(vp, i, j, k) = M(vp, i, j, k)
+              - ((M(u0, i, j, k) + M(u0, i, jm, k) + M(u0, i + 1, jm, k) + M(u0, i + 1, j, k)) * om23 * 0.25);
+          M(wp, i, j, k) = M(wp, i, j, k) + (((dzf[km] * (M(u0, i, j, k) + M(u0, i + 1, j, k))
+                         + dzf[k] * (M(u0, i, j, km) + M(u0, i + 1, j, km))) / dzh[k]) * om22 * 0.25);
+        }
+      }
+    }
+    for (int j = 1; j <= g->ny; ++j) {
+      int jp = j + 1, jm = j - 1;
+      for (int i = 1; i <= g->nx; ++i) {
+        M(up, i, j, 1) = M(up, i, j, 1)
+            + (M(v0, i, j, 1) + M(v0, i, jp, 1) + M(v0, i - 1, j, 1) + M(v0, i - 1, jp, 1)) * om23 * 0.25
+            - (M(w0, i, j, 1) + M(w0, i, j, 2) + M(w0, i - 1, j, 2) + M(w0, i - 1, j, 1)) * om22 * 0.25;
+        M(vp, i, j, 1) = M(vp, i, j, 1)
+            - (M(u0, i, j, 1) + M(u0, i, jm, 1) + M(u0, i + 1, jm, 1) + M(u0, i + 1, j, 1)) * om23 * 0.25;
+        M(wp, i, j, 1) = 0.0;
+      }
+    }
+  } else if (g->coriolis_mode == 2) {
+    for (int k = 1; k <= g->nz; ++k)
+      for (int j = 1; j <= g->ny; ++j)
+        for (int i = 1; i <= g->nx; ++i) M(up, i, j, k) = M(up, i, j, k) + om23 * (ug[k] - M(u0, i, j, k));
+  }
+}
+
 /* ====================================================================== masscorr */
 /* src/modforces.f90:328-497, volume-flow branches: luvolflowr (:389-417) and lvvolflowr (:467-494);
  * avexy_ibm without IBM (src/modmpi.f90:623-664): slab sums divided by IIus(k) = itot*jtot. */
@@ -1016,6 +1056,7 @@ void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
   for (int n = 0; n < g->nsv; ++n) orc_diffc(g, s->sv0 + n * nc, s->ekh, s->svp + n * nc);
   orc_bottom(g, s->u0, s->v0, s->ekm, s->ekh, s->sv0, s->up, s->vp, s->svp, NULL);   /* src/program.f90:152 */
   if (g->ltempeq) orc_thl_floor(g, s->ekh, s->thl0, s->thlp);
+  if (s->dpdxl && g->coriolis_mode) orc_coriolis(g, s->u0, s->v0, s->w0, s->ug, s->up, s->vp, s->wp);   /* src/program.f90:158 */
   if (s->dpdxl) orc_forces(g, s->dpdxl, s->dpdyl, s->up, s->vp, s->wp);
   if (s->dpdxl && g->ltempeq) orc_buoyancy(g, s->thl0, s->wp);
   if (g->ltempeq && s->dpdxl && s->thlpcar)                                             /* src/modforces.f90:104-110 */

@@ -47,6 +47,8 @@ typedef struct {
   int bctopt;               /* BCtopT: 1 flux wttop, 2 value thl_top (src/modglobal.f90:144-154) */
   double wttop, thl_top, wtsurf;   /* src/modsurfdata.f90:62,80,81 */
   int lbuoyancy;            /* forces' buoyancy term, dry air (src/modforces.f90:73-84) */
+  int coriolis_mode;        /* 0 off, 1 lcoriol, 2 lprofforc (src/modforces.f90:600-717) */
+  double om22, om23;        /* src/modglobal.f90:666-673 */
 } orc_grid;
 
 /* ---- advection: src/modadvection.f90 */
@@ -81,6 +83,9 @@ void orc_diffc_m(const orc_grid *g, const double *c, const double *ekh, double *
 void orc_thl_top(const orc_grid *g, const double *ekh, double *a);
 void orc_buoyancy(const orc_grid *g, const double *thl0, double *wp);
 void orc_thl_floor(const orc_grid *g, const double *ekh, const double *thl0, double *thlp);
+/* ---- coriolis: src/modforces.f90:600-717 */
+void orc_coriolis(const orc_grid *g, const double *u0, const double *v0, const double *w0, const double *ug,
+                  double *up, double *vp, double *wp);
 /* ---- masscorr: src/modforces.f90:328-497 (volume-flow branches) */
 void orc_masscorr(const orc_grid *g, int rk3step, double dt, double *up, const double *um, double *vp, const double *vm);
 /* ---- pressure: src/modpois.f90 (ipoiss = POISS_FFT2D, BCzp = 1, periodic x,y) */
@@ -106,6 +111,7 @@ typedef struct {
   const double *dpdxl, *dpdyl;            /* [nz+2] indexed by Fortran k, or NULL (no forces) */
   double *thl0, *thlm, *thlp;             /* m-arrays, used when g->ltempeq */
   const double *thlpcar;                  /* [nz+2] or NULL */
+  const double *ug;                       /* [nz+2] geostrophic wind (lprofforc) or NULL */
 } orc_state;
 void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt);
 

@@ -16,10 +16,12 @@ KERNEL_CASES = {
     "k_scalar_8x8x8": 14, "k_dns_8x8x6": 15, "k_floor_12x8x6": 16,
     "k_volflow_12x8x6": 17, "k_thl_12x8x6": 18,
     "k_buoy_12x8x6": 19,
+    "k_coriol_12x8x6": 20,
 }
 RUN_CASES = {"run_16x16x8": 21, "run_smag_scalar_16x8x12s": 22, "run_floor_scalar_16x8x12s": 23,
              "run_volflow_uv_16x16x8": 24, "run_thl_16x8x12s": 25,
-             "run_buoy_16x8x12s": 26}
+             "run_buoy_16x8x12s": 26,
+             "run_profforc_16x16x8": 27}
 
 
 def load_fixture(name):

@@ -86,7 +86,7 @@ def zlevels(nz, dz0=0.5, stretch=1.0):
     return zf
 
 
-def write_case(d, iexpnr, text, zf, u=1.0, v=0.0, pgx=1e-4, dthl=0.0, dthlrad=0.0):
+def write_case(d, iexpnr, text, zf, u=1.0, v=0.0, pgx=1e-4, dthl=0.0, dthlrad=0.0, ug=0.0):
     with open(os.path.join(d, f"namoptions.{iexpnr:03d}"), "w") as f:
         f.write(text)
     with open(os.path.join(d, f"prof.inp.{iexpnr:03d}"), "w") as f:
@@ -96,7 +96,7 @@ def write_case(d, iexpnr, text, zf, u=1.0, v=0.0, pgx=1e-4, dthl=0.0, dthlrad=0.
     with open(os.path.join(d, f"lscale.inp.{iexpnr:03d}"), "w") as f:
         f.write("# golden\n# z uq vq pqx pqy wfls dqtdxls dqtdyls dqtdtls dthlrad\n")
         for z in zf:
-            f.write(f"{z:.15f} 0.0 0.0 {pgx} 0.0 0.0 0.0 0.0 0.0 {dthlrad!r}\n")
+            f.write(f"{z:.15f} {ug!r} 0.0 {pgx} 0.0 0.0 0.0 0.0 0.0 {dthlrad!r}\n")
 
 
 KEEP_KERNELS = ("meta dzf dzh zf dpdxl dpdyl rk3 in.u0 in.v0 in.w0 in.um in.vm in.wm in.pres0 "
@@ -147,7 +147,14 @@ CASES.update({
                                bc="BCtopT = 2\nthl_top = 290.5\nBCbotT = 1\nwtsurf = 0.05\nthls = 288.0",
                                oracle="nsub = 9\ndump_at = 3, 9"), 1.06),
 })
-THL_CASES = {"k_thl_12x8x6": dict(dthl=0.4, dthlrad=2e-3), "run_thl_16x8x12s": dict(dthl=0.25, dthlrad=-1e-3),
+CASES.update({
+    # coriolis (lcoriol) and the relaxation towards a geostrophic profile (lprofforc, as examples/024)
+    "k_coriol_12x8x6": ("kernels", 20, 12, 8, 6,
+                        dict(sgs="vreman", floor=True, physics="lcoriol = .true.", oracle="nspin = 3"), 1.04),
+    "run_profforc_16x16x8": ("run", 27, 16, 16, 8,
+                             dict(sgs="vreman", physics="lprofforc = .true.", oracle="nsub = 6\ndump_at = 3, 6"), 1.0),
+})
+THL_CASES = {"k_coriol_12x8x6": dict(ug=1.1), "run_profforc_16x16x8": dict(ug=1.3), "k_thl_12x8x6": dict(dthl=0.4, dthlrad=2e-3), "run_thl_16x8x12s": dict(dthl=0.25, dthlrad=-1e-3),
              "k_buoy_12x8x6": dict(dthl=0.3), "run_buoy_16x8x12s": dict(dthl=0.2)}
 
 

@@ -29,13 +29,14 @@ class OrcGrid(C.Structure):
                 ("lbottom", C.c_int), ("z0", C.c_double),
                 ("luvolflowr", C.c_int), ("lvvolflowr", C.c_int), ("uflowrate", C.c_double), ("vflowrate", C.c_double),
                 ("ltempeq", C.c_int), ("bctopt", C.c_int), ("wttop", C.c_double), ("thl_top", C.c_double),
-                ("wtsurf", C.c_double), ("lbuoyancy", C.c_int)]
+                ("wtsurf", C.c_double), ("lbuoyancy", C.c_int),
+                ("coriolis_mode", C.c_int), ("om22", C.c_double), ("om23", C.c_double)]
 
 
 class OrcState(C.Structure):
     _fields_ = [(n, DP) for n in ("u0", "v0", "w0", "um", "vm", "wm", "up", "vp", "wp", "pres0",
                                   "ekm", "ekh", "p", "pup", "pvp", "pwp", "sv0", "svm", "svp",
-                                  "dpdxl", "dpdyl", "thl0", "thlm", "thlp", "thlpcar")]
+                                  "dpdxl", "dpdyl", "thl0", "thlm", "thlp", "thlpcar", "ug")]
 
 
 def build():
@@ -69,7 +70,7 @@ class Oracle:
                  prandtlmoli=1. / 0.71, prandtli=1. / 0.333, c_vreman=0.07, csz=None,
                  uinf=0., vinf=0., lbottom=False, z0=0.05, luvolflowr=False, uflowrate=0.,
                  lvvolflowr=False, vflowrate=0., ltempeq=False, bctopt=1, wttop=0., thl_top=-1., wtsurf=-1.,
-                 lbuoyancy=False):
+                 lbuoyancy=False, coriolis_mode=0, om22=0., om23=0.):
         self.nx, self.ny, self.nz, self.nsv = nx, ny, nz, nsv
         self.dzf = np.ascontiguousarray(dzf, dtype=np.float64)
         self.dzh = np.ascontiguousarray(dzh, dtype=np.float64)
@@ -82,7 +83,8 @@ class Oracle:
         self.g = OrcGrid(nx, ny, nz, dx, dy, ptr(self.dzf), ptr(self.dzh), numol, prandtlmoli,
                          prandtli, c_vreman, csz, sgs, bctopm, uinf, vinf, nsv, int(bool(lbottom)), z0,
                          int(bool(luvolflowr)), int(bool(lvvolflowr)), uflowrate, vflowrate,
-                         int(bool(ltempeq)), bctopt, wttop, thl_top, wtsurf, int(bool(lbuoyancy)))
+                         int(bool(ltempeq)), bctopt, wttop, thl_top, wtsurf, int(bool(lbuoyancy)),
+                         coriolis_mode, om22, om23)
         self.L = lib()
 
     def mshape(self):

@@ -104,6 +104,7 @@ def test_each_routine_matches_reference(name, iexp):
     core.advection()
     core.subgrid()
     core.bottom()
+    core.coriolis()
     core.forces()
     core.rk3step, core.dt = int(fix["rk3"].data[0]), float(fix["rk3"].data[1])
     if "frc.up" in fix:      # masscorr: tendencies before / after the volume-flow correction
@@ -152,7 +153,7 @@ def test_substeps_match_reference(name, iexp, fused):
             core.substep(rk, dt, with_forces=True)
         else:
             core.tstep_update(dt)
-            core.advection(); core.subgrid(); core.bottom(); core.forces(); core.masscorr(); core.poisson()
+            core.advection(); core.subgrid(); core.bottom(); core.coriolis(); core.forces(); core.masscorr(); core.poisson()
             core.tstep_integrate(); core.halos(); core.boundary()
         if isub in dumps:
             tag = f"s{isub:03d}"

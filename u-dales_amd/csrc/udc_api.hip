@@ -188,6 +188,7 @@ extern "C" int udc_destroy(udc_handle *h) {
   if (h->red) hipFree(h->red);
   if (h->red_host) hipHostFree(h->red_host);
   if (h->thlpcar) hipFree(h->thlpcar);
+  if (h->ug) hipFree(h->ug);
   if (h->lev_part) hipFree(h->lev_part);
   if (h->lev_sum) hipFree(h->lev_sum);
   hipStreamDestroy(h->stream);
@@ -375,6 +376,25 @@ extern "C" int udc_bottom(udc_handle *h) {
   return k_bottom(h, false);
 }
 
+extern "C" int udc_set_coriolis(udc_handle *h, int mode, double om22, double om23, const double *ug, int n) {
+  HIP_OK(hipSetDevice(h->device));
+  if (mode < 0 || mode > 2) { udc_set_error("udc_set_coriolis: mode 0 (off), 1 (lcoriol) or 2 (lprofforc)"); return 1; }
+  if (mode == 2 && (!ug || n != h->g.nz)) { udc_set_error("udc_set_coriolis: lprofforc needs ug(kb:ke)"); return 1; }
+  h->coriolis_mode = mode; h->om22 = om22; h->om23 = om23;
+  std::vector<double> t(h->g.nz + 2, 0.0);
+  if (ug) for (int k = 1; k <= n && k <= h->g.nz; ++k) t[k] = ug[k - 1];
+  if (!h->ug) HIP_OK(hipMalloc(&h->ug, sizeof(double) * t.size()));
+  HIP_OK(hipMemcpy(h->ug, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int udc_coriolis(udc_handle *h) {
+  HIP_OK(hipSetDevice(h->device));
+  if (!h->coriolis_mode) return 0;
+  if (tend_clean(h) || um_materialise(h)) return 1;
+  return k_coriolis(h, false);
+}
+
 extern "C" int udc_set_masscorr(udc_handle *h, int luvolflowr, double uflowrate, int lvvolflowr, double vflowrate) {
   h->luvolflowr = luvolflowr ? 1 : 0; h->uflowrate = uflowrate;
   h->lvvolflowr = lvvolflowr ? 1 : 0; h->vflowrate = vflowrate;
@@ -482,6 +502,7 @@ extern "C" int udc_substep(udc_handle *h, int rk3step, double dt, int with_force
   if (with_forces && k_buoyancy(h)) return 1;        // additive on wp(kb+1..ke), hence on pwp
   // `bottom` (src/program.f90:152): additive on the k = kb tendencies, hence equally on pup = up + um/rk3coef
   if (h->p.lbottom && k_bottom(h, fold)) return 1;
+  if (with_forces && k_coriolis(h, fold)) return 1;        // src/program.f90:158; wrap of vp's ghost row follows below
   // masscorr (src/program.f90:169); without pup the tendencies and um are summed separately
   if (k_masscorr(h, rk3coef, pup, fold)) return 1;
   if (!fold) {

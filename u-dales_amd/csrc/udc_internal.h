@@ -117,6 +117,9 @@ struct udc_handle {
   };
   Slot slot[16];
   std::vector<int> slots;
+  int coriolis_mode = 0;       // 0 off, 1 lcoriol, 2 lprofforc (src/modforces.f90:600-717)
+  double om22 = 0., om23 = 0.;
+  double *ug = nullptr;        // [nz+2] geostrophic wind profile (lprofforc)
   int lbuoyancy = 0;           // forces' buoyancy term (dry air), needs the temperature equation
   double grav = 9.81;
   double *lev_part = nullptr, *lev_sum = nullptr;   // per-level slab sums (thvh)
@@ -196,6 +199,7 @@ int k_scalar_adv(udc_handle *h, int n);
 int k_scalar_diff(udc_handle *h, int n);
 int k_scalar_fused(udc_handle *h, int n);          // advection + diffusion in one sweep (same accumulation order)
 int k_forces(udc_handle *h);
+int k_coriolis(udc_handle *h, bool wrap_vp);                     // coriolis: lcoriol / lprofforc
 int k_masscorr(udc_handle *h, double rk3coef, bool pup_mode, bool wrap_vp);   // masscorr, volume-flow branches
 int k_bottom(udc_handle *h, bool wrap_vp);       // floor wall function; wrap_vp: also refresh vp's ghost row ny (bcpup)
 int k_divergence_rhs(udc_handle *h, double rk3coef, bool pup);

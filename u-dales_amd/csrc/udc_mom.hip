@@ -178,12 +178,60 @@ __global__ __launch_bounds__(256) void bottom_kernel(Geo g, Metrics m, BottomArg
   }
 }
 
+// coriolis, src/modforces.f90:600-717.  MODE 1: lcoriol (:627-676); MODE 2: lprofforc (:682-710), relaxation of u
+// towards the geostrophic profile ug(k).
+template <int MODE>
+__global__ __launch_bounds__(256) void coriolis_kernel(Geo g, TileGrid tg, Metrics m, double om22, double om23,
+    const double *__restrict__ ug, const double *__restrict__ u0, const double *__restrict__ v0, const double *__restrict__ w0,
+    double *__restrict__ up, double *__restrict__ vp, double *__restrict__ wp, int wrap_vp) {
+  int i, j, k;
+  if (!tile_decode(g, tg, i, j, k)) return;
+  const long r0 = g.idx(0, j, k);
+  const long c = r0 + i;
+  if (MODE == 2) { up[c] = up[c] + om23 * (ug[k + 1] - u0[c]); return; }
+  const long xm = r0 + (i == 0 ? g.nx - 1 : i - 1), xp = r0 + (i == g.nx - 1 ? 0 : i + 1);
+  const long sy = g.sy, sz = g.sz;
+  if (k >= 1) {
+    const int kf = k + 1;
+    up[c] = up[c] + ((v0[c] + v0[c + sy] + v0[xm] + v0[xm + sy]) * om23 * 0.25)
+                  - ((w0[c] + w0[c + sz] + w0[xm + sz] + w0[xm]) * om22 * 0.25);
+    const double tv = vp[c] - ((u0[c] + u0[c - sy] + u0[xp - sy] + u0[xp]) * om23 * 0.25);
+    vp[c] = tv;
+    if (wrap_vp && j == 0) vp[c + sy * g.ny] = tv;       // bcpup's cyclic pvp(je+1) = pvp(jb)
+    wp[c] = wp[c] + (((m.dzf[kf - 1] * (u0[c] + u0[xp]) + m.dzf[kf] * (u0[c - sz] + u0[xp - sz])) / m.dzh[kf]) * om22 * 0.25);
+  } else {
+    up[c] = up[c] + (v0[c] + v0[c + sy] + v0[xm] + v0[xm + sy]) * om23 * 0.25
+                  - (w0[c] + w0[c + sz] + w0[xm + sz] + w0[xm]) * om22 * 0.25;
+    const double tv = vp[c] - (u0[c] + u0[c - sy] + u0[xp - sy] + u0[xp]) * om23 * 0.25;
+    vp[c] = tv;
+    if (wrap_vp && j == 0) vp[c + sy * g.ny] = tv;
+    wp[c] = 0.0;
+  }
+}
+
 inline dim3 cell_grid(const Geo &g, dim3 b) {
   (void)b;
   return dim3((unsigned)tile_grid(g).tiles * (unsigned)g.nz, 1, 1);
 }
 
 }  // namespace
+
+int k_coriolis(udc_handle *h, bool wrap_vp) {
+  if (!h->coriolis_mode) return 0;
+  const Geo &g = h->g;
+  dim3 b(64, 4, 1), gr = cell_grid(g, b);
+  PROF(h, "coriolis");
+  if (h->coriolis_mode == 1)
+    hipLaunchKernelGGL((coriolis_kernel<1>), gr, b, 0, h->stream, g, tile_grid(g), h->m, h->om22, h->om23, h->ug,
+                       h->fields[UDC_U0], h->fields[UDC_V0], h->fields[UDC_W0], h->fields[UDC_UP], h->fields[UDC_VP], h->fields[UDC_WP],
+                       wrap_vp ? 1 : 0);
+  else
+    hipLaunchKernelGGL((coriolis_kernel<2>), gr, b, 0, h->stream, g, tile_grid(g), h->m, h->om22, h->om23, h->ug,
+                       h->fields[UDC_U0], h->fields[UDC_V0], h->fields[UDC_W0], h->fields[UDC_UP], h->fields[UDC_VP], h->fields[UDC_WP],
+                       wrap_vp ? 1 : 0);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
 
 int k_bottom(udc_handle *h, bool wrap_vp) {
   const Geo &g = h->g;

@@ -35,8 +35,12 @@ def from_deck(deck, device=0, rank=0, nranks=1):
     # dpdxl, dpdyl: src/modstartup.f90:2071-2081 (lcoriol false => om23_gs terms still present:
     # dpdxl = om23_gs*vg - pgx - dpdx with om23_gs = 2*omega*sin(lat); ug = vg = 0 in our decks)
     import math
-    phi = 52. * 3.141592653589793116 / 180.
+    phi = float(deck.get("PHYSICS", "xlat") if deck.get("PHYSICS", "xlat") is not None else 52.) * 3.141592653589793116 / 180.
     om23_gs = 2. * 7.292e-5 * math.sin(phi)
+    # coriolis (src/modforces.f90:600-717): om22, om23 of src/modglobal.f90:666-673
+    mode = 1 if deck.get("PHYSICS", "lcoriol") else (2 if deck.get("PHYSICS", "lprofforc") else 0)
+    if mode:
+        core.set_coriolis(mode, 2. * 7.292e-5 * math.cos(phi), 2. * 7.292e-5 * math.sin(phi), np.array(deck.ug))
     dpdx = float(deck.get("PHYSICS", "dpdx"))
     if deck.get("PHYSICS", "lprofforc"):
         dpdxl = [-pg - dpdx for pg in deck.pgx]

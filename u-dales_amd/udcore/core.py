@@ -141,6 +141,16 @@ class DynCore:
             a = np.ascontiguousarray(thlpcar, dtype=np.float64)
             L._check(self.lib.udc_set_thl_source(self.h, a.ctypes.data_as(L.DP), len(a)), "udc_set_thl_source")
 
+    def set_coriolis(self, mode, om22, om23, ug=None):
+        """mode 1 = &PHYSICS lcoriol, 2 = lprofforc (relaxation towards ug(k)); src/modforces.f90:600-717."""
+        n = 0 if ug is None else len(ug)
+        a = None if ug is None else np.ascontiguousarray(ug, dtype=np.float64)
+        L._check(self.lib.udc_set_coriolis(self.h, int(mode), C.c_double(om22), C.c_double(om23),
+                                           None if a is None else a.ctypes.data_as(L.DP), n), "udc_set_coriolis")
+
+    def coriolis(self):
+        L._check(self.lib.udc_coriolis(self.h), "udc_coriolis")
+
     def set_buoyancy(self, on=True, grav=9.81):
         """&PHYSICS lbuoyancy (dry air): forces adds grav (thv0h - thvh)/thvh to wp."""
         L._check(self.lib.udc_set_buoyancy(self.h, int(bool(on)), C.c_double(grav)), "udc_set_buoyancy")
