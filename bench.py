@@ -40,7 +40,7 @@ ALGO_BYTES = {
     "fft_fwd": 32, "fft_bwd": 32,   # 2 passes x (8 read + 8 write)
     "thomas": 24,               # x read once, written once (LDS-resident columns) + pivot table read twice
     "project_integrate": 72,    # read p (8), pup,pvp,pwp (24); RMW pres0 (16); write u0,v0,w0 (24)
-    "scalar": 56,
+    "scalar": 48,               # read c, ekh, u0,v0,w0 (40); write cp (8) -- tendencies are not re-read in the fused substep
     # slab (multi-GPU) Poisson stages
     "fftx_pack_fwd": 32, "unpack_ffty_fwd": 32, "ffty_pack_bwd": 32, "unpack_fftx_bwd": 32,
 }

@@ -218,7 +218,7 @@ static int um_materialise(udc_handle *h);
 static int copy3d(udc_handle *h, int field, double *host, const int lb[3], const int ub[3], bool up) {
   double *dev;
   if (field_ptr(h, field, &dev)) return 1;
-  if (field >= UDC_UP && field <= UDC_WP && tend_clean(h)) return 1;
+  if (((field >= UDC_UP && field <= UDC_WP) || (field >= UDC_SV0 && (field - UDC_SV0) % 3 == 2)) && tend_clean(h)) return 1;
   if (field >= UDC_UM && field <= UDC_WM && um_materialise(h)) return 1;
   const Geo &g = h->g;
   const int hnx = ub[0] - lb[0] + 1, hny = ub[1] - lb[1] + 1;
@@ -278,6 +278,8 @@ static int tend_clean(udc_handle *h) {
   if (!h->tend_scratch) return 0;
   for (int f = UDC_UP; f <= UDC_WP; ++f)
     HIP_OK(hipMemsetAsync(h->fields[f], 0, sizeof(double) * h->g.n, h->stream));
+  for (int n : h->slots)
+    HIP_OK(hipMemsetAsync(h->fields[UDC_SVP + 3 * n], 0, sizeof(double) * h->g.n, h->stream));
   h->tend_scratch = false;
   return 0;
 }
@@ -497,7 +499,7 @@ extern "C" int udc_substep(udc_handle *h, int rk3step, double dt, int with_force
           : k_momentum(h, true, true, with_forces != 0)) return 1;
   if (k_scalar_top_flux(h)) return 1;
   for (int n : h->slots)
-    if (k_scalar_fused(h, n)) return 1;
+    if (k_scalar_fused(h, n, lds)) return 1;       // lds: the tendencies are scratch between fused substeps (tend_scratch)
   if (with_forces && h->thlpcar && k_level_source(h, 15, h->thlpcar)) return 1;
   if (with_forces && k_buoyancy(h)) return 1;        // additive on wp(kb+1..ke), hence on pwp
   // `bottom` (src/program.f90:152): additive on the k = kb tendencies, hence equally on pup = up + um/rk3coef

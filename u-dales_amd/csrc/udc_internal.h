@@ -197,7 +197,7 @@ int k_momentum(udc_handle *h, bool adv, bool diff, bool forces);       // direct
 int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, double rk3coefi, bool um_is_u0 = false);  // rk3coefi != 0: PUP mode   // LDS-staged k-marching version (default)
 int k_scalar_adv(udc_handle *h, int n);
 int k_scalar_diff(udc_handle *h, int n);
-int k_scalar_fused(udc_handle *h, int n);          // advection + diffusion in one sweep (same accumulation order)
+int k_scalar_fused(udc_handle *h, int n, bool fresh);          // advection + diffusion in one sweep (same accumulation order)
 int k_forces(udc_handle *h);
 int k_coriolis(udc_handle *h, bool wrap_vp);                     // coriolis: lcoriol / lprofforc
 int k_masscorr(udc_handle *h, double rk3coef, bool pup_mode, bool wrap_vp);   // masscorr, volume-flow branches

@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256) void integrate_kernel(Geo g, TileGrid tg, Metr
   for (int s = 0; s < a.nsv; ++s) {
     const double sv = a.svm[s][c] + rk3coef * a.svp[s][c];
     a.sv0[s][c] = sv;
-    a.svp[s][c] = 0.;
+    if (ZERO) a.svp[s][c] = 0.;        // the fused substep's scalar sweep does not read svp either
     if (last_s) a.svm[s][c] = sv;
   }
 }

@@ -27,8 +27,8 @@ __device__ __forceinline__ double face(double vel, double cm2, double cm1, doubl
   return cf + df * rlim(d1, d2);
 }
 
-// ADV: 0 = none, 1 = kappa, 2 = cd2
-template <int ADV, bool DIFF, bool LES>
+// ADV: 0 = none, 1 = kappa, 2 = cd2.  FRESH: the tendency is known to be zero on entry (fused substep) -> not read.
+template <int ADV, bool DIFF, bool LES, bool FRESH>
 __global__ __launch_bounds__(256) void scalar_kernel(Geo g, TileGrid tg, Metrics m, double cekh, const double *__restrict__ u,
     const double *__restrict__ v, const double *__restrict__ w, const double *__restrict__ ekh,
     const double *__restrict__ c, double *__restrict__ cp) {
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void scalar_kernel(Geo g, TileGrid tg, Metrics
   const long xp1 = r0 + wrap(i + 1, g.nx), xp2 = r0 + wrap(i + 2, g.nx);
   const double c0 = c[o];
   const double cxm1 = c[xm1], cxp1 = c[xp1], cym1 = c[o - sy], cyp1 = c[o + sy], czm1 = c[o - sz], czp1 = c[o + sz];
-  double t = cp[o];
+  double t = FRESH ? 0. : cp[o];
   if (ADV == 2) {
     // advecc_2nd, src/modadvection.f90:127-133 and :148-151 (two statements, same order)
     const double kdzf = m.dzf[kf], kdzfm = m.dzf[kf - 1], kdzfp = m.dzf[kf + 1];
@@ -217,7 +217,7 @@ int k_scalar_top_flux(udc_handle *h) {
   return 0;
 }
 
-static int launch_scalar(udc_handle *h, int n, bool adv, bool diff) {
+static int launch_scalar(udc_handle *h, int n, bool adv, bool diff, bool fresh = false) {
   const Geo &g = h->g;
   dim3 b(64, 4, 1), gr = cell_grid(g, b);
   const double cekh = h->p.numol * h->p.prandtlmoli;
@@ -229,7 +229,8 @@ static int launch_scalar(udc_handle *h, int n, bool adv, bool diff) {
 #define LS(A, D, L)                                                                                     \
   do {                                                                                                  \
     PROF(h, "scalar_" #A #D #L);                                                                        \
-    hipLaunchKernelGGL((scalar_kernel<A, D, L>), gr, b, 0, h->stream, g, tile_grid(g), h->m, cekh, u, v, w, ekh, c, cp); \
+    if (fresh) hipLaunchKernelGGL((scalar_kernel<A, D, L, true>), gr, b, 0, h->stream, g, tile_grid(g), h->m, cekh, u, v, w, ekh, c, cp); \
+    else hipLaunchKernelGGL((scalar_kernel<A, D, L, false>), gr, b, 0, h->stream, g, tile_grid(g), h->m, cekh, u, v, w, ekh, c, cp); \
   } while (0)
   if (adv && diff) {
     if (cd2) { if (les) LS(2, true, true); else LS(2, true, false); }
@@ -243,4 +244,4 @@ static int launch_scalar(udc_handle *h, int n, bool adv, bool diff) {
 
 int k_scalar_adv(udc_handle *h, int n) { return launch_scalar(h, n, true, false); }
 int k_scalar_diff(udc_handle *h, int n) { return launch_scalar(h, n, false, true); }
-int k_scalar_fused(udc_handle *h, int n) { return launch_scalar(h, n, true, true); }
+int k_scalar_fused(udc_handle *h, int n, bool fresh) { return launch_scalar(h, n, true, true, fresh); }
