@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIBPATH = os.path.join(os.path.dirname(HERE), "lib", "libudcore.so")
+LIBPATH = os.environ.get("UDC_LIBPATH", os.path.join(os.path.dirname(HERE), "lib", "libudcore.so"))   # override: A/B builds
 
 DP = C.POINTER(C.c_double)
 
