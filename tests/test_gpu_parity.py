@@ -251,6 +251,67 @@ def test_against_oracle_seeded(shape, sgs, nsv, stretch, floor, thomas, monkeypa
     core.close()
 
 
+@pytest.mark.parametrize("shape,sgs,nsv,cor", [
+    ((36, 20, 14), 2, 1, 1),     # radix-3/5 FFT lengths, Vreman, lcoriol
+    ((24, 16, 18), 1, 2, 2),     # Smagorinsky, two scalars, lprofforc
+    ((16, 12, 8), 0, 0, 1),      # DNS viscosity
+])
+def test_all_forcings_together_against_oracle(shape, sgs, nsv, cor):
+    """Six substeps with every optional term switched on at once -- floor wall function, Coriolis / geostrophic
+    relaxation, buoyant temperature with a radiative source, top value / floor flux, prescribed volume flow in u and
+    v, kappa scalars -- through the fused substep, against the CPU oracle on a stretched grid."""
+    nx, ny, nz = shape
+    dz = 0.4 * 1.06 ** np.arange(nz)
+    zf = np.cumsum(dz) - 0.5 * dz
+    g = Grid.from_levels(nx, ny, nz, nx * 0.45, ny * 0.5, zf)
+    from udcore.core import DynCore
+    om22, om23 = 2. * 7.292e-5 * np.cos(0.9), 2. * 7.292e-5 * np.sin(0.9)
+    kw = dict(lbottom=True, z0=0.02)
+    core = DynCore(g, sgs=sgs, nsv=nsv, **kw)
+    o = ol.Oracle(nx, ny, nz, g.dx, g.dy, g.dzf, g.dzh, sgs=sgs, nsv=nsv, csz=0.21658244510412,
+                  luvolflowr=True, uflowrate=1.02, lvvolflowr=True, vflowrate=-0.01,
+                  ltempeq=True, bctopt=2, wttop=0., thl_top=290.2, wtsurf=0.04, lbuoyancy=True,
+                  coriolis_mode=cor, om22=om22 * 50, om23=om23 * 50, **kw)
+    ug = np.zeros(nz + 2); ug[1:nz + 1] = 1.0 + 0.01 * np.arange(nz)
+    tc = np.zeros(nz + 2); tc[1:nz + 1] = 1e-3 * np.sin(np.arange(nz))
+    core.set_masscorr(True, 1.02, True, -0.01)
+    core.set_tempeq(bctopt=2, thl_top=290.2, wtsurf=0.04, thlpcar=tc[1:nz + 1])
+    core.set_buoyancy(True)
+    core.set_coriolis(cor, om22 * 50, om23 * 50, ug[1:nz + 1])      # x50: make the terms visible in six substeps
+    st = random_state(g, seed=7 * nx + ny, nsv=nsv)
+    rng = np.random.default_rng(11)
+    t = np.zeros(g.mshape())
+    t[1:-1, 1:-1, 1:-1] = 288. + 0.3 * g.zf[1:nz + 1, None, None] + 0.05 * rng.standard_normal((nz, ny, nx))
+    t[:, 0, :] = t[:, ny, :]; t[:, ny + 1, :] = t[:, 1, :]
+    t[:, :, 0] = t[:, :, nx]; t[:, :, nx + 1] = t[:, :, 1]
+    t[0] = t[1]; t[nz + 1] = 2 * 290.2 - t[nz]
+    st["thl0"], st["thlm"] = t, t.copy()
+    dp = np.zeros(nz + 2); dp[1:nz + 1] = -2e-3
+    dq = np.zeros(nz + 2); dq[1:nz + 1] = 1e-4
+    core.load_state(st)
+    core.set_forcing(dp[1:nz + 1], dq[1:nz + 1])
+    ost = oracle_state(st, g, nsv)
+    ost.update(dpdxl=dp, dpdyl=dq, thl0=t.copy(), thlm=t.copy(), thlp=np.zeros(g.mshape()), thlpcar=tc, ug=ug)
+    dt = 0.04
+    for isub in range(6):
+        rk = isub % 3 + 1
+        core.substep(rk, dt, with_forces=True)
+        o.substep(ost, rk, dt)
+    for k in ("u0", "v0", "w0", "pres0", "um", "thl0"):
+        sc = 1.0 if k == "thl0" else None
+        assert relerr(nocorner(core.download(k)[1:-1]), nocorner(ost[k][1:-1]), sc) <= RUN_TOL, k
+    for n in range(nsv):
+        got = core.download(L.scalar_field(L.SV0, n), halo=2)
+        assert relerr(interior(got, 2), interior(ost["sv0"][n], 2)) <= RUN_TOL
+    # the prescribed volume flow is met: <u> = uflowrate, <v> = vflowrate (dzf-weighted)
+    w = g.dzf[1:nz + 1, None, None] / g.dzf[1:nz + 1].sum()
+    assert abs((core.download("u0")[1:-1, 1:-1, 1:-1] * w).sum() / (nx * ny) - 1.02) < 1e-12
+    assert abs((core.download("v0")[1:-1, 1:-1, 1:-1] * w).sum() / (nx * ny) + 0.01) < 1e-12
+    divmax, _ = core.divergence()
+    assert divmax < 1e-11
+    core.close()
+
+
 def test_upload_download_roundtrip_and_x_ghosts():
     g = Grid.uniform(16, 8, 6)
     from udcore.core import DynCore
