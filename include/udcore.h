@@ -41,12 +41,14 @@ enum {
   UDC_SVP,                           /*                   UDC_SVP + 3*n  (svp)  */
   UDC_FIELD_MAX = UDC_SV0 + 3 * 16,
   /* temperature equation (ltempeq): thl0, thlm, thlp live in scalar slot 15 (so nsv <= 15 with ltempeq) */
-  UDC_THL0 = UDC_SV0 + 3 * 15, UDC_THLM = UDC_SVM + 3 * 15, UDC_THLP = UDC_SVP + 3 * 15
+  UDC_THL0 = UDC_SV0 + 3 * 15, UDC_THLM = UDC_SVM + 3 * 15, UDC_THLP = UDC_SVP + 3 * 15,
+  /* one-equation closure (loneeqn): e120, e12m, e12p live in scalar slot 14 (so nsv <= 14 with loneeqn) */
+  UDC_E120 = UDC_SV0 + 3 * 14, UDC_E12M = UDC_SVM + 3 * 14, UDC_E12P = UDC_SVP + 3 * 14
 };
 
 /* SGS closure selector: &NAMSUBGRID lsmagorinsky / lvreman (src/modsubgriddata.f90:39-42),
  * DNS = lles .false. (src/modglobal.f90:194) */
-enum { UDC_SGS_DNS = 0, UDC_SGS_SMAGORINSKY = 1, UDC_SGS_VREMAN = 2 };
+enum { UDC_SGS_DNS = 0, UDC_SGS_SMAGORINSKY = 1, UDC_SGS_VREMAN = 2, UDC_SGS_ONEEQN = 3 /* set by udc_set_tke */ };
 /* BCtopm (src/modglobal.f90:150-153) */
 enum { UDC_TOP_FREESLIP = 1, UDC_TOP_NOSLIP = 2 };
 
@@ -110,6 +112,17 @@ int udc_set_forcing(udc_handle *h, const double *dpdxl, const double *dpdyl, int
 int udc_set_tempeq(udc_handle *h, int iadv_thl, int bctopt, double wttop, double thl_top, int bcbott, double wtsurf);
 int udc_set_thl_source(udc_handle *h, const double *thlpcar, int n);
 int udc_set_buoyancy(udc_handle *h, int lbuoyancy, double grav);
+
+/* One-equation (TKE) closure, &NAMSUBGRID loneeqn (src/modsubgrid.f90:363-400): switches the closure to
+ * ekm = cm zlt e120 + numol, ekh = (ch1 + ch2 zlt/delta) ekm + numol/Pr_mol with the stability-limited length zlt
+ * (dthvdz from thl0 when the temperature equation is on, else neutral), and makes e120 a transported field:
+ * advecc_2nd (iadv_tke = 2), diffe (src/modsubgrid.f90:627-669), sources (shear, buoyancy, dissipation, :415-538),
+ * e120 = max(e12min, e12m + rk3coef e12p) (src/modtstep.f90:209-211), e120(kb-1) = e120(kb) in `bottom`
+ * (src/modibm.f90:2012-2013), e120(ke+1) = e12min in `boundary` (src/modboundary.f90:180-181).
+ * Constants as initsubgrid derives them (src/modsubgrid.f90:63-71).  Call once after udc_create (and after
+ * udc_set_tempeq if used), before the first substep. */
+int udc_set_tke(udc_handle *h, double cm, double cn, double ch1, double ch2, double ce1, double ce2, double e12min,
+                double grav, double thvs, int ldelta);
 
 /* ---- the reference's call surface (src/program.f90:134-207) ----------------------- */
 /* advection   src/modadvection.f90:36   up,vp,wp (+svp) -= div(u phi) (+ grad pres0)     */

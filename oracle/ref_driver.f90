@@ -85,7 +85,7 @@ program ref_driver
   call initpois
   call cold_start
   call boundary
-  if (ltempeq) call thermodynamics         ! src/program.f90:120 (thv0h, thvh for the buoyancy term)
+  if (ltempeq .or. loneeqn) call thermodynamics   ! src/program.f90:120 (thv0h, thvh for buoyancy; dthvdz for the TKE closure)
 
   iu = 71
   if (trim(mode) /= 'time') then
@@ -172,12 +172,14 @@ contains
     call tstep_integrate
     call halos
     call boundary
-    if (ltempeq) call thermodynamics       ! src/program.f90:214
+    if (ltempeq .or. loneeqn) call thermodynamics   ! src/program.f90:214
   end subroutine one_substep
 
   ! ---- `bottom`, src/modibm.f90:2021-2026 (momentum, BCbotm = 3) and :2073-2090 (scalars, BCbots = 1)
   subroutine floor_bottom
     integer :: i, j, m
+    e120(:, :, kb - 1) = e120(:, :, kb)     ! src/modibm.f90:2012-2013 (unconditional)
+    e12m(:, :, kb - 1) = e12m(:, :, kb)
     if (.not. lbottom) return
     if (BCbotm /= 3) then
       write (0, *) 'ERROR: oracle build supports the neutral floor wall function only (BCbotm = 3)'
@@ -232,7 +234,7 @@ contains
     namelist /PHYSICS/ lmoist, lcoriol, lbuoyancy, ltempeq, lprofforc, dpdx, luvolflowr, uflowrate, &
       lvvolflowr, vflowrate
     namelist /DYNAMICS/ ipoiss, iadv_mom, iadv_tke, iadv_thl, iadv_qt, iadv_sv
-    namelist /BC/ BCxm, BCym, BCtopm, BCtopT, BCtops, BCbotm, BCbots, BCbotT, BCzp, wttop, thl_top, z0, wtsurf, thls
+    namelist /BC/ BCxm, BCym, BCtopm, BCtopT, BCtops, BCbotm, BCbots, BCbotT, BCzp, wttop, thl_top, z0, wtsurf, thls, qts
     namelist /SCALARS/ nsv
     namelist /WALLS/ nfcts, lbottom
     open (ifnamopt, file=fname_options, status='old', iostat=ierr)
@@ -461,6 +463,10 @@ contains
     call put3(tag//'.ekm', ekm, (/ib - ih, jb - jh, kb - kh/))
     call put3(tag//'.ekh', ekh, (/ib - ih, jb - jh, kb - kh/))
     call put3(tag//'.p', p, (/ib - ih, jb - jh, kb - kh/))
+    if (loneeqn) then
+      call put3(tag//'.e120', e120, (/ib - ih, jb - jh, kb - kh/))
+      call put3(tag//'.e12m', e12m, (/ib - ih, jb - jh, kb - kh/))
+    end if
     if (ltempeq) then
       call put3(tag//'.thl0', thl0, (/ib - ih, jb - jh, kb - kh/))
       call put3(tag//'.thlm', thlm, (/ib - ih, jb - jh, kb - kh/))
@@ -480,6 +486,7 @@ contains
     call put3(tag//'.vp', vp, (/ib - ih, jb - jh, kb/))
     call put3(tag//'.wp', wp, (/ib - ih, jb - jh, kb/))
     if (ltempeq) call put3(tag//'.thlp', thlp, (/ib - ih, jb - jh, kb/))
+    if (loneeqn) call put3(tag//'.e12p', e12p, (/ib - ih, jb - jh, kb/))
     do n = 1, nsv
       write (cn, '(i2.2)') n
       call put3(tag//'.svp_'//cn, svp(:, :, :, n), (/ib - ihc, jb - jhc, kb/))
@@ -495,7 +502,7 @@ contains
     call dump_tend('in')                    ! (tendencies are zero here)
     call advection                          ! src/modadvection.f90:36
     call dump_tend('adv')
-    up = 0.; vp = 0.; wp = 0.; svp = 0.; thlp = 0.
+    up = 0.; vp = 0.; wp = 0.; svp = 0.; thlp = 0.; e12p = 0.
     call subgrid                            ! src/modsubgrid.f90:128 (closure+closurebc+diff*)
     call put3('sub.ekm', ekm, (/ib - ih, jb - jh, kb - kh/))
     call put3('sub.ekh', ekh, (/ib - ih, jb - jh, kb - kh/))
@@ -507,7 +514,7 @@ contains
       call dump_tend('bot')
     end if
     ! full tendency = advection + subgrid + forces, as the driver would have it
-    up = 0.; vp = 0.; wp = 0.; svp = 0.; thlp = 0.
+    up = 0.; vp = 0.; wp = 0.; svp = 0.; thlp = 0.; e12p = 0.
     call advection
     call subgrid
     call floor_bottom

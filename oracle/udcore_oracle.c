@@ -988,6 +988,95 @@ void orc_coriolis(const orc_grid *g, const double *u0, const double *v0, const d
   }
 }
 
+/* ====================================================================== one-equation (TKE) closure */
+/* dthvdz of calthv, dry air (src/modthermodynamics.f90:208-232); thl0 may be NULL (no temperature equation) */
+static double orc_dthvdz(const orc_grid *g, const double *thl0, int i, int j, int k) {
+  const double eps1 = 1e-10;
+  double d = 0.;
+  if (thl0 && k >= 2) d = (M(thl0, i, j, k + 1) - M(thl0, i, j, k - 1)) / (g->dzh[k + 1] + g->dzh[k]);
+  if (fabs(d) < eps1) d = copysign(eps1, d);
+  return d;
+}
+static double orc_delta(const orc_grid *g, int i, int k) {
+  double dxf_i = (double)i * g->dx - (double)(i - 1) * g->dx;    /* src/modglobal.f90:783,793-797 */
+  return pow(dxf_i * g->dy * g->dzf[k], 1. / 3.);
+}
+/* closure, loneeqn branch: src/modsubgrid.f90:363-400 (damp = 1); closurebc applied by the caller as for the others */
+void orc_closure_tke(const orc_grid *g, const double *e120, const double *thl0, double *ekm, double *ekh) {
+  for (int k = 1; k <= g->nz; ++k)
+    for (int j = 1; j <= g->ny; ++j)
+      for (int i = 1; i <= g->nx; ++i) {
+        const double delta = orc_delta(g, i, k), dth = orc_dthvdz(g, thl0, i, j, k), e = M(e120, i, j, k);
+        if (g->ldelta || dth <= 0) {
+          const double zlt = delta;
+          M(ekm, i, j, k) = g->cm * zlt * 1. * e;
+          M(ekh, i, j, k) = (g->ch1 + g->ch2) * M(ekm, i, j, k);
+        } else {
+          const double zlt = fmin(delta, g->cn * e / sqrt(9.81 / g->thvs * fabs(dth)));
+          M(ekm, i, j, k) = g->cm * zlt * 1. * e;
+          M(ekh, i, j, k) = (g->ch1 + g->ch2 * zlt / delta) * M(ekm, i, j, k);
+        }
+        M(ekm, i, j, k) = M(ekm, i, j, k) + g->numol;
+        M(ekh, i, j, k) = M(ekh, i, j, k) + g->numol * g->prandtlmoli;
+      }
+  orc_closurebc(g, ekm, ekh);
+}
+/* diffe, src/modsubgrid.f90:627-669 */
+void orc_diffe(const orc_grid *g, const double *e120, const double *ekm, double *e12p) {
+  metrics m; metrics_init(g, &m);
+  const double *dzf = g->dzf;
+  for (int k = 1; k <= g->nz; ++k)
+    for (int j = 1; j <= g->ny; ++j)
+      for (int i = 1; i <= g->nx; ++i) {
+        int kp = k + 1, km = k - 1, jp = j + 1, jm = j - 1, ip = i + 1, im = i - 1;
+        M(e12p, i, j, k) = M(e12p, i, j, k) + 1.0 * (
+            ((M(ekm, ip, j, k) + M(ekm, i, j, k)) * (M(e120, ip, j, k) - M(e120, i, j, k))
+           - (M(ekm, i, j, k) + M(ekm, im, j, k)) * (M(e120, i, j, k) - M(e120, im, j, k))) * m.dx2i
+          + ((M(ekm, i, jp, k) + M(ekm, i, j, k)) * (M(e120, i, jp, k) - M(e120, i, j, k))
+           - (M(ekm, i, j, k) + M(ekm, i, jm, k)) * (M(e120, i, j, k) - M(e120, i, jm, k))) * m.dy2i
+          + ((dzf[kp] * M(ekm, i, j, k) + dzf[k] * M(ekm, i, j, kp)) * (M(e120, i, j, kp) - M(e120, i, j, k)) * m.dzh2i[kp]
+           - (dzf[km] * M(ekm, i, j, k) + dzf[k] * M(ekm, i, j, km)) * (M(e120, i, j, k) - M(e120, i, j, km)) * m.dzh2i[k]) * m.dzfi[k]);
+      }
+  metrics_free(&m);
+}
+/* sources, src/modsubgrid.f90:415-538: k = kb+1..ke (sbshr, sbbuo, sbdiss stay unwritten at kb) */
+void orc_sources(const orc_grid *g, const double *u0, const double *v0, const double *w0, const double *e120,
+                 const double *thl0, const double *ekm, const double *ekh, double *e12p) {
+  metrics m; metrics_init(g, &m);
+  const double dxi = m.dxi, dyi = m.dyi;
+#define SQ(x) ((x) * (x))
+  for (int k = 2; k <= g->nz; ++k)
+    for (int j = 1; j <= g->ny; ++j)
+      for (int i = 1; i <= g->nx; ++i) {
+        int kp = k + 1, km = k - 1, jp = j + 1, jm = j - 1, ip = i + 1, im = i - 1;
+        double tdef2 = 2. * (SQ((M(u0, ip, j, k) - M(u0, i, j, k)) * dxi) + SQ((M(v0, i, jp, k) - M(v0, i, j, k)) * dyi)
+                           + SQ((M(w0, i, j, kp) - M(w0, i, j, k)) * m.dzfi[k]));
+        tdef2 = tdef2 + 0.25 * (
+            SQ((M(w0, i, j, kp) - M(w0, im, j, kp)) * dxi + (M(u0, i, j, kp) - M(u0, i, j, k)) * m.dzhi[kp])
+          + SQ((M(w0, i, j, k) - M(w0, im, j, k)) * dxi + (M(u0, i, j, k) - M(u0, i, j, km)) * m.dzhi[k])
+          + SQ((M(w0, ip, j, k) - M(w0, i, j, k)) * dxi + (M(u0, ip, j, k) - M(u0, ip, j, km)) * m.dzhi[k])
+          + SQ((M(w0, ip, j, kp) - M(w0, i, j, kp)) * dxi + (M(u0, ip, j, kp) - M(u0, ip, j, k)) * m.dzhi[kp]));
+        tdef2 = tdef2 + 0.25 * (
+            SQ((M(u0, i, jp, k) - M(u0, i, j, k)) * dyi + (M(v0, i, jp, k) - M(v0, im, jp, k)) * dxi)
+          + SQ((M(u0, i, j, k) - M(u0, i, jm, k)) * dyi + (M(v0, i, j, k) - M(v0, im, j, k)) * dxi)
+          + SQ((M(u0, ip, j, k) - M(u0, ip, jm, k)) * dyi + (M(v0, ip, j, k) - M(v0, i, j, k)) * dxi)
+          + SQ((M(u0, ip, jp, k) - M(u0, ip, j, k)) * dyi + (M(v0, ip, jp, k) - M(v0, i, jp, k)) * dxi));
+        tdef2 = tdef2 + 0.25 * (
+            SQ((M(v0, i, j, kp) - M(v0, i, j, k)) * m.dzhi[kp] + (M(w0, i, j, kp) - M(w0, i, jm, kp)) * dyi)
+          + SQ((M(v0, i, j, k) - M(v0, i, j, km)) * m.dzhi[k] + (M(w0, i, j, k) - M(w0, i, jm, k)) * dyi)
+          + SQ((M(v0, i, jp, k) - M(v0, i, jp, km)) * m.dzhi[k] + (M(w0, i, jp, k) - M(w0, i, j, k)) * dyi)
+          + SQ((M(v0, i, jp, kp) - M(v0, i, jp, k)) * m.dzhi[kp] + (M(w0, i, jp, kp) - M(w0, i, j, kp)) * dyi));
+        const double e = M(e120, i, j, k), delta = orc_delta(g, i, k), dth = orc_dthvdz(g, thl0, i, j, k);
+        const double zlt = (g->ldelta || dth <= 0) ? delta : fmin(delta, g->cn * e / sqrt(9.81 / g->thvs * fabs(dth)));
+        const double sbshr = (M(ekm, i, j, k) - g->numol) * tdef2 / (2 * e);
+        const double sbbuo = -(M(ekh, i, j, k) - g->numol * g->prandtlmoli) * 9.81 / g->thvs * dth / (2 * e);
+        const double sbdiss = -2. * (g->ce1 + g->ce2 * zlt / delta) * (e * e) / (2. * 1. * zlt);
+        M(e12p, i, j, k) = M(e12p, i, j, k) + sbshr + sbbuo + sbdiss;
+      }
+#undef SQ
+  metrics_free(&m);
+}
+
 /* ====================================================================== masscorr */
 /* src/modforces.f90:328-497, volume-flow branches: luvolflowr (:389-417) and lvvolflowr (:467-494);
  * avexy_ibm without IBM (src/modmpi.f90:623-664): slab sums divided by IIus(k) = itot*jtot. */
@@ -1032,9 +1121,11 @@ void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
   orc_advecu_2nd(g, s->u0, s->v0, s->w0, s->pres0, s->up);
   orc_advecv_2nd(g, s->u0, s->v0, s->w0, s->pres0, s->vp);
   orc_advecw_2nd(g, s->u0, s->v0, s->w0, s->pres0, s->wp);
+  if (g->sgs == 3) orc_advecc_2nd(g, s->u0, s->v0, s->w0, s->e120, s->e12p);              /* src/modadvection.f90:56-58 */
   if (g->ltempeq) orc_advecc_2nd(g, s->u0, s->v0, s->w0, s->thl0, s->thlp);              /* src/modadvection.f90:66-68 */
   for (int n = 0; n < g->nsv; ++n) orc_advecc_kappa(g, s->u0, s->v0, s->w0, s->sv0 + n * nc, s->svp + n * nc);
-  orc_closure(g, s->u0, s->v0, s->w0, s->ekm, s->ekh);
+  if (g->sgs == 3) orc_closure_tke(g, s->e120, g->ltempeq ? s->thl0 : NULL, s->ekm, s->ekh);
+  else orc_closure(g, s->u0, s->v0, s->w0, s->ekm, s->ekh);
   /* reassure_fluxtop_boundary src/modboundary.f90:392-431 (free-slip: re-impose top rows) */
   if (g->bctopm != 2) {
     top_row_m(g, s->um, 0.); top_row_m(g, s->u0, 0.); top_row_m(g, s->vm, 0.); top_row_m(g, s->v0, 0.);
@@ -1052,8 +1143,14 @@ void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
   orc_diffu(g, s->u0, s->v0, s->w0, s->ekm, s->up);
   orc_diffv(g, s->u0, s->v0, s->w0, s->ekm, s->vp);
   orc_diffw(g, s->u0, s->v0, s->w0, s->ekm, s->wp);
+  if (g->sgs == 3) orc_diffe(g, s->e120, s->ekm, s->e12p);                               /* src/modsubgrid.f90:144 */
   if (g->ltempeq) orc_diffc_m(g, s->thl0, s->ekh, s->thlp);                              /* src/modsubgrid.f90:146 */
   for (int n = 0; n < g->nsv; ++n) orc_diffc(g, s->sv0 + n * nc, s->ekh, s->svp + n * nc);
+  if (g->sgs == 3) {
+    orc_sources(g, s->u0, s->v0, s->w0, s->e120, g->ltempeq ? s->thl0 : NULL, s->ekm, s->ekh, s->e12p);   /* :151 */
+    for (int j = 0; j <= g->ny + 1; ++j)                      /* `bottom`, src/modibm.f90:2012-2013 */
+      for (int i = 0; i <= g->nx + 1; ++i) { M(s->e120, i, j, 0) = M(s->e120, i, j, 1); M(s->e12m, i, j, 0) = M(s->e12m, i, j, 1); }
+  }
   orc_bottom(g, s->u0, s->v0, s->ekm, s->ekh, s->sv0, s->up, s->vp, s->svp, NULL);   /* src/program.f90:152 */
   if (g->ltempeq) orc_thl_floor(g, s->ekh, s->thl0, s->thlp);
   if (s->dpdxl && g->coriolis_mode) orc_coriolis(g, s->u0, s->v0, s->w0, s->ug, s->up, s->vp, s->wp);   /* src/program.f90:158 */
@@ -1069,6 +1166,22 @@ void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
   orc_tderive(g, s->p, s->up, s->vp, s->wp, s->pres0);
   orc_tstep_integrate(g, rk3step, dt, s->u0, s->v0, s->w0, s->um, s->vm, s->wm, s->up, s->vp, s->wp,
                       s->sv0, s->svm, s->svp);
+  if (g->sgs == 3) {                                                                     /* src/modtstep.f90:209-211,327,335 */
+    const size_t nm = msize(g);
+    const double rk3c = dt / (4. - (double)rk3step), e12min = 5.e-5;
+    for (int k = 1; k <= g->nz; ++k)
+      for (int j = 1; j <= g->ny; ++j)
+        for (int i = 1; i <= g->nx; ++i) {
+          M(s->e120, i, j, k) = M(s->e12m, i, j, k) + rk3c * M(s->e12p, i, j, k);
+          M(s->e120, i, j, k) = fmax(e12min, M(s->e120, i, j, k));
+          M(s->e12m, i, j, k) = fmax(e12min, M(s->e12m, i, j, k));
+        }
+    memset(s->e12p, 0, nm * sizeof(double));
+    if (rk3step == 3) memcpy(s->e12m, s->e120, nm * sizeof(double));
+    orc_halos_m(g, s->e120); orc_halos_m(g, s->e12m);
+    for (int j = 0; j <= g->ny + 1; ++j)                      /* boundary, src/modboundary.f90:180-181 */
+      for (int i = 0; i <= g->nx + 1; ++i) { M(s->e120, i, j, g->nz + 1) = e12min; M(s->e12m, i, j, g->nz + 1) = e12min; }
+  }
   if (g->ltempeq) {                                                                      /* src/modtstep.f90:240-249,325,334 */
     const size_t nm = msize(g);
     const double rk3c = dt / (4. - (double)rk3step);

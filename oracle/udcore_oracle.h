@@ -35,7 +35,7 @@ typedef struct {
   double prandtli;          /* 1/Prandtl src/modsubgrid.f90:117 */
   double c_vreman;          /* 0.07     src/modsubgriddata.f90:61 */
   double csz;               /* Smagorinsky constant src/modsubgrid.f90:73-77 */
-  int sgs;                  /* 0 = DNS (lles false), 1 = Smagorinsky, 2 = Vreman */
+  int sgs;                  /* 0 = DNS (lles false), 1 = Smagorinsky, 2 = Vreman, 3 = one-equation TKE */
   int bctopm;               /* 1 free-slip, 2 no-slip (src/modglobal.f90:150-153) */
   double uinf, vinf;        /* only for no-slip top (valuetop) */
   int nsv;                  /* passive scalars, kappa scheme (src/modglobal.f90:557-559) */
@@ -49,6 +49,9 @@ typedef struct {
   int lbuoyancy;            /* forces' buoyancy term, dry air (src/modforces.f90:73-84) */
   int coriolis_mode;        /* 0 off, 1 lcoriol, 2 lprofforc (src/modforces.f90:600-717) */
   double om22, om23;        /* src/modglobal.f90:666-673 */
+  /* one-equation closure (sgs = 3, loneeqn): constants of initsubgrid src/modsubgrid.f90:63-71 */
+  double cm, cn, ch1, ch2, ce1, ce2, thvs;
+  int ldelta;
 } orc_grid;
 
 /* ---- advection: src/modadvection.f90 */
@@ -83,6 +86,11 @@ void orc_diffc_m(const orc_grid *g, const double *c, const double *ekh, double *
 void orc_thl_top(const orc_grid *g, const double *ekh, double *a);
 void orc_buoyancy(const orc_grid *g, const double *thl0, double *wp);
 void orc_thl_floor(const orc_grid *g, const double *ekh, const double *thl0, double *thlp);
+/* ---- one-equation closure: src/modsubgrid.f90:363-400 (closure), :627-669 (diffe), :415-538 (sources) */
+void orc_closure_tke(const orc_grid *g, const double *e120, const double *thl0, double *ekm, double *ekh);
+void orc_diffe(const orc_grid *g, const double *e120, const double *ekm, double *e12p);
+void orc_sources(const orc_grid *g, const double *u0, const double *v0, const double *w0, const double *e120,
+                 const double *thl0, const double *ekm, const double *ekh, double *e12p);
 /* ---- coriolis: src/modforces.f90:600-717 */
 void orc_coriolis(const orc_grid *g, const double *u0, const double *v0, const double *w0, const double *ug,
                   double *up, double *vp, double *wp);
@@ -112,6 +120,7 @@ typedef struct {
   double *thl0, *thlm, *thlp;             /* m-arrays, used when g->ltempeq */
   const double *thlpcar;                  /* [nz+2] or NULL */
   const double *ug;                       /* [nz+2] geostrophic wind (lprofforc) or NULL */
+  double *e120, *e12m, *e12p;             /* m-arrays, used when g->sgs == 3 */
 } orc_state;
 void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt);
 

@@ -17,6 +17,7 @@ KERNEL_CASES = {
     "k_volflow_12x8x6": 17, "k_thl_12x8x6": 18,
     "k_buoy_12x8x6": 19,
     "k_coriol_12x8x6": 20,
+    "k_tke_12x8x6": 21, "k_tke_thl_12x8x6": 28,
 }
 RUN_CASES = {"run_16x16x8": 21, "run_smag_scalar_16x8x12s": 22, "run_floor_scalar_16x8x12s": 23,
              "run_volflow_uv_16x16x8": 24, "run_thl_16x8x12s": 25,

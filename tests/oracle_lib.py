@@ -30,13 +30,15 @@ class OrcGrid(C.Structure):
                 ("luvolflowr", C.c_int), ("lvvolflowr", C.c_int), ("uflowrate", C.c_double), ("vflowrate", C.c_double),
                 ("ltempeq", C.c_int), ("bctopt", C.c_int), ("wttop", C.c_double), ("thl_top", C.c_double),
                 ("wtsurf", C.c_double), ("lbuoyancy", C.c_int),
-                ("coriolis_mode", C.c_int), ("om22", C.c_double), ("om23", C.c_double)]
+                ("coriolis_mode", C.c_int), ("om22", C.c_double), ("om23", C.c_double),
+                ("cm", C.c_double), ("cn", C.c_double), ("ch1", C.c_double), ("ch2", C.c_double),
+                ("ce1", C.c_double), ("ce2", C.c_double), ("thvs", C.c_double), ("ldelta", C.c_int)]
 
 
 class OrcState(C.Structure):
     _fields_ = [(n, DP) for n in ("u0", "v0", "w0", "um", "vm", "wm", "up", "vp", "wp", "pres0",
                                   "ekm", "ekh", "p", "pup", "pvp", "pwp", "sv0", "svm", "svp",
-                                  "dpdxl", "dpdyl", "thl0", "thlm", "thlp", "thlpcar", "ug")]
+                                  "dpdxl", "dpdyl", "thl0", "thlm", "thlp", "thlpcar", "ug", "e120", "e12m", "e12p")]
 
 
 def build():
@@ -70,7 +72,7 @@ class Oracle:
                  prandtlmoli=1. / 0.71, prandtli=1. / 0.333, c_vreman=0.07, csz=None,
                  uinf=0., vinf=0., lbottom=False, z0=0.05, luvolflowr=False, uflowrate=0.,
                  lvvolflowr=False, vflowrate=0., ltempeq=False, bctopt=1, wttop=0., thl_top=-1., wtsurf=-1.,
-                 lbuoyancy=False, coriolis_mode=0, om22=0., om23=0.):
+                 lbuoyancy=False, coriolis_mode=0, om22=0., om23=0., tke=None):
         self.nx, self.ny, self.nz, self.nsv = nx, ny, nz, nsv
         self.dzf = np.ascontiguousarray(dzf, dtype=np.float64)
         self.dzh = np.ascontiguousarray(dzh, dtype=np.float64)
@@ -84,7 +86,9 @@ class Oracle:
                          prandtli, c_vreman, csz, sgs, bctopm, uinf, vinf, nsv, int(bool(lbottom)), z0,
                          int(bool(luvolflowr)), int(bool(lvvolflowr)), uflowrate, vflowrate,
                          int(bool(ltempeq)), bctopt, wttop, thl_top, wtsurf, int(bool(lbuoyancy)),
-                         coriolis_mode, om22, om23)
+                         coriolis_mode, om22, om23,
+                         *((tke["cm"], tke["cn"], tke["ch1"], tke["ch2"], tke["ce1"], tke["ce2"], tke["thvs"],
+                            int(tke.get("ldelta", 0))) if tke else (0., 0., 0., 0., 0., 0., 1., 0)))
         self.L = lib()
 
     def mshape(self):

@@ -53,10 +53,13 @@ def test_grid_metrics_match_reference(name, iexp):
 def test_sgs_constants_match_reference(name, iexp):
     fix = load_fixture(name)
     meta = fix["meta"].data
-    sgs, csz, c_vreman, prandtli = sgs_from_deck(read_deck(deck_path(name, iexp)))
+    d = read_deck(deck_path(name, iexp))
+    sgs, csz, c_vreman, prandtli = sgs_from_deck(d)
     assert prandtli == meta[15] and c_vreman == meta[16]
     assert abs(csz - meta[17]) <= 1e-15
-    assert sgs == (1 if meta[18] else (2 if meta[19] else 0)) * int(meta[21])
+    # closure precedence of src/modsubgrid.f90:208,269,363: Smagorinsky, Vreman, one-equation, none
+    oneeqn = 3 if d.get("NAMSUBGRID", "loneeqn") else 0
+    assert sgs == (1 if meta[18] else (2 if meta[19] else oneeqn)) * int(meta[21])
 
 
 @pytest.mark.parametrize("name,iexp", sorted(RUN_CASES.items()))

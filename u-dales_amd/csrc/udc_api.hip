@@ -124,7 +124,7 @@ extern "C" int udc_create(const udc_config *cfg, udc_handle **out) {
 
   // metrics exactly as src/modglobal.f90:812-838
   const int nk = g.nz + 2;
-  std::vector<double> hm(12 * nk, 0.0);
+  std::vector<double> hm(13 * nk, 0.0);
   double *dzf = &hm[0], *dzfi = dzf + nk, *dzfi5 = dzfi + nk, *dzfiq = dzfi5 + nk, *dzf2 = dzfiq + nk;
   double *dzhi = dzf2 + nk, *dzhiq = dzhi + nk, *dzh2i = dzhiq + nk, *dzh = dzh2i + nk;
   for (int k = 0; k < nk; ++k) {
@@ -140,6 +140,7 @@ extern "C" int udc_create(const udc_config *cfg, udc_handle **out) {
   double *mlen = &hm[11 * nk];
   // delta(i,k) = (dxf(i)*dy*dzf(k))**(1/3), src/modglobal.f90:793-797 (uniform x)
   for (int k = 0; k < nk; ++k) mlen[k] = cfg->csz * pow(cfg->dx * cfg->dy * dzf[k], 1. / 3.);
+  for (int k = 0; k < nk; ++k) hm[12 * nk + k] = pow(cfg->dx * cfg->dy * dzf[k], 1. / 3.);
   dzh[0] = dzh[1]; dzhi[0] = dzhi[1]; dzhiq[0] = dzhiq[1]; dzh2i[0] = dzh2i[1];
   HIP_OK(hipMalloc(&h->metrics_dev, sizeof(double) * hm.size()));
   HIP_OK(hipMemcpy(h->metrics_dev, hm.data(), sizeof(double) * hm.size(), hipMemcpyHostToDevice));
@@ -147,7 +148,7 @@ extern "C" int udc_create(const udc_config *cfg, udc_handle **out) {
   double *b = h->metrics_dev;
   m.dzf = b; m.dzfi = b + nk; m.dzfi5 = b + 2 * nk; m.dzfiq = b + 3 * nk; m.dzf2 = b + 4 * nk;
   m.dzhi = b + 5 * nk; m.dzhiq = b + 6 * nk; m.dzh2i = b + 7 * nk; m.dzh = b + 8 * nk;
-  m.dpdxl = b + 9 * nk; m.dpdyl = b + 10 * nk; m.mlen = b + 11 * nk;
+  m.dpdxl = b + 9 * nk; m.dpdyl = b + 10 * nk; m.mlen = b + 11 * nk; m.delta = b + 12 * nk;
   m.dx = cfg->dx; m.dy = cfg->dy;
   m.dxi = 1. / cfg->dx; m.dyi = 1. / cfg->dy;
   m.dx2 = cfg->dx * cfg->dx; m.dy2 = cfg->dy * cfg->dy;
@@ -323,6 +324,7 @@ extern "C" int udc_subgrid(udc_handle *h) {
   if (k_scalar_top_flux(h)) return 1;      // reassure_fluxtop_boundary for a non-zero thl top flux (uses the new ekh)
   for (int n : h->slots)
     if (k_scalar_diff(h, n)) return 1;
+  if (h->p.sgs == UDC_SGS_ONEEQN && k_tke_sources(h)) return 1;
   return 0;
 }
 
@@ -350,6 +352,27 @@ extern "C" int udc_set_tempeq(udc_handle *h, int iadv_thl, int bctopt, double wt
   return 0;
 }
 
+extern "C" int udc_set_tke(udc_handle *h, double cm, double cn, double ch1, double ch2, double ce1, double ce2, double e12min,
+                           double grav, double thvs, int ldelta) {
+  HIP_OK(hipSetDevice(h->device));
+  if (h->cfg.nsv > 14) { udc_set_error("udc_set_tke: e12 uses scalar slot 14, nsv must be <= 14"); return 1; }
+  if (!(thvs > 0.) || !(e12min > 0.)) { udc_set_error("udc_set_tke: thvs and e12min must be positive"); return 1; }
+  const bool have = (int)h->fields.size() > UDC_E120 && h->fields[UDC_E120];
+  if (!have) {
+    for (int q = 0; q < 3; ++q)
+      if (alloc_field(h, UDC_SV0 + 3 * 14 + q)) return 1;
+    // keep the slot list ordered: passive scalars, e12 (14), thl (15)
+    auto it = h->slots.begin();
+    while (it != h->slots.end() && *it < 14) ++it;
+    h->slots.insert(it, 14);
+  }
+  udc_handle::Slot &sl = h->slot[14];
+  sl.adv = 2; sl.top = 3; sl.topval = e12min; sl.floorflux = 0.; sl.tke = true;
+  h->tke = udc_handle::Tke{cm, cn, ch1, ch2, ce1, ce2, e12min, grav, thvs, ldelta ? 1 : 0};
+  h->p.sgs = UDC_SGS_ONEEQN;
+  return 0;
+}
+
 extern "C" int udc_set_buoyancy(udc_handle *h, int lbuoyancy, double grav) {
   if (lbuoyancy && ((int)h->fields.size() <= UDC_THL0 || !h->fields[UDC_THL0])) {
     udc_set_error("udc_set_buoyancy: call udc_set_tempeq first (thv0h comes from thl0)");
@@ -373,6 +396,7 @@ extern "C" int udc_set_thl_source(udc_handle *h, const double *thlpcar, int n) {
 
 extern "C" int udc_bottom(udc_handle *h) {
   HIP_OK(hipSetDevice(h->device));
+  if (h->p.sgs == UDC_SGS_ONEEQN && k_tke_floor(h)) return 1;      // unconditional part of `bottom`
   if (!h->p.lbottom) return 0;
   if (tend_clean(h) || um_materialise(h)) return 1;
   return k_bottom(h, false);
@@ -489,7 +513,7 @@ extern "C" int udc_substep(udc_handle *h, int rk3step, double dt, int with_force
   if (h->um_alias && !(alias_ok && rk3step == 1)) { if (um_materialise(h)) return 1; }
   const bool rotate = h->um_alias;                    // only true here for an aliased stage 1
   // closure first: it only needs u0,v0,w0, and the fused sweep below needs ekm
-  if (fold && h->p.sgs != UDC_SGS_DNS) {
+  if (fold && h->p.sgs != UDC_SGS_DNS && h->p.sgs != UDC_SGS_ONEEQN) {
     if (k_closure_lds(h, true)) return 1;
   } else {
     if (k_closure(h)) return 1;
@@ -500,6 +524,10 @@ extern "C" int udc_substep(udc_handle *h, int rk3step, double dt, int with_force
   if (k_scalar_top_flux(h)) return 1;
   for (int n : h->slots)
     if (k_scalar_fused(h, n, lds)) return 1;       // lds: the tendencies are scratch between fused substeps (tend_scratch)
+  if (h->p.sgs == UDC_SGS_ONEEQN) {
+    if (k_tke_sources(h)) return 1;                // subgrid's `sources`, after the diffusion terms
+    if (k_tke_floor(h)) return 1;                  // first lines of `bottom` (src/program.f90:152)
+  }
   if (with_forces && h->thlpcar && k_level_source(h, 15, h->thlpcar)) return 1;
   if (with_forces && k_buoyancy(h)) return 1;        // additive on wp(kb+1..ke), hence on pwp
   // `bottom` (src/program.f90:152): additive on the k = kb tendencies, hence equally on pup = up + um/rk3coef

@@ -50,7 +50,7 @@ __global__ void halo_unpack_kernel(Geo g, FieldList fl, int width, const double 
 struct BoundaryArgs {
   double *u0, *v0, *w0, *um, *vm, *wm;
   double *sv[32];
-  int kind[32];      // top condition per array: 0 zero-flux copy, 1 fluxtop (done by top_flux_kernel), 2 valuetop
+  int kind[32];      // top condition per array: 0 zero-flux copy, 1 fluxtop (top_flux_kernel), 2 valuetop, 3 fixed ghost value
   double val[32];
   int nscal;         // number of scalar arrays in sv (sv0 and svm of every scalar)
 };
@@ -79,7 +79,8 @@ __global__ void top_bottom_kernel(Geo g, Params pr, BoundaryArgs a, int uv_only)
   for (int s = 0; s < a.nscal; ++s) {
     double *c = a.sv[s];
     if (a.kind[s] == 1) continue;                     // non-zero flux: top_flux_kernel (needs ekh)
-    const double t = a.kind[s] == 2 ? 2 * a.val[s] - c[top] : c[top];     // valuetop, src/modboundary.f90:1516
+    const double t = a.kind[s] == 2 ? 2 * a.val[s] - c[top]                // valuetop, src/modboundary.f90:1516
+                   : (a.kind[s] == 3 ? a.val[s] : c[top]);                 // e120(ke+1) = e12min, :180-181
     c[ghost] = t;
     c[ghost + g.sz] = t;
   }

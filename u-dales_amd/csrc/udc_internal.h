@@ -68,6 +68,7 @@ struct Metrics {
   const double *dzhi, *dzhiq, *dzh2i, *dzh;          // 1..nz+1 (entry 0 = copy of entry 1)
   const double *dpdxl, *dpdyl;                       // 0..nz+1 (forcing, zero if unset)
   const double *mlen;                                // 0..nz+1 csz*delta(k), src/modsubgrid.f90:215
+  const double *delta;                               // 0..nz+1 delta(k) = (dx dy dzf(k))^(1/3), src/modglobal.f90:793-797
   double dxi, dyi, dxiq, dyiq, dx2i, dy2i, dxi5, dyi5, dx2, dy2, dx, dy;
 };
 
@@ -114,9 +115,12 @@ struct udc_handle {
     int top = 0;          // 0 = zero-flux copy, 1 = fluxtop with topval = flux (src/modboundary.f90:1494), 2 = valuetop
     double topval = 0.;
     double floorflux = 0.;   // wtsurf in bottom's Neumann floor (src/modibm.f90:2035-2047); 0 for passive scalars
+    bool tke = false;        // e120: diffused with ekm (diffe), clipped at e12min, own floor/top ghosts, no floor flux
   };
   Slot slot[16];
   std::vector<int> slots;
+  // one-equation closure constants (udc_set_tke)
+  struct Tke { double cm = 0., cn = 0., ch1 = 0., ch2 = 0., ce1 = 0., ce2 = 0., e12min = 5e-5, grav = 9.81, thvs = 0.; int ldelta = 0; } tke;
   int coriolis_mode = 0;       // 0 off, 1 lcoriol, 2 lprofforc (src/modforces.f90:600-717)
   double om22 = 0., om23 = 0.;
   double *ug = nullptr;        // [nz+2] geostrophic wind profile (lprofforc)
@@ -213,7 +217,10 @@ int k_top_bottom(udc_handle *h);
 int k_top_rows_after_closure(udc_handle *h);
 int k_scalar_top_flux(udc_handle *h);              // fluxtop with a non-zero flux: re-imposed after closure (reassure_fluxtop_boundary)
 int k_level_source(udc_handle *h, int slot, const double *src);
-int k_buoyancy(udc_handle *h);                     // wp += grav (thv0h - thvh)/thvh, src/modforces.f90:73-84   // cp(i,j,k) += src(k)
+int k_buoyancy(udc_handle *h);
+int k_tke_closure(udc_handle *h);                  // closure, loneeqn branch
+int k_tke_sources(udc_handle *h);                  // sources: e12p += shear + buoyancy + dissipation
+int k_tke_floor(udc_handle *h);                    // e120(kb-1) = e120(kb), e12m likewise (`bottom`)                     // wp += grav (thv0h - thvh)/thvh, src/modforces.f90:73-84   // cp(i,j,k) += src(k)
 int k_maxima(udc_handle *h, double dt, double *cour, double *diffn);
 int k_divergence_check(udc_handle *h, double *divmax, double *divtot);
 int pois_init(udc_handle *h);

@@ -240,6 +240,7 @@ int k_bottom(udc_handle *h, bool wrap_vp) {
   a.up = h->fields[UDC_UP]; a.vp = h->fields[UDC_VP];
   a.nsv = 0; a.wrap_vp = wrap_vp ? 1 : 0; a.z0 = h->p.z0;
   for (int n : h->slots) {
+    if (h->slot[n].tke) continue;      // e12 has no floor-flux correction in `bottom`
     a.sv0[a.nsv] = h->fields[UDC_SV0 + 3 * n]; a.svp[a.nsv] = h->fields[UDC_SVP + 3 * n];
     a.flux[a.nsv] = h->slot[n].floorflux; ++a.nsv;
   }
@@ -290,6 +291,7 @@ int k_closure(udc_handle *h) {
   dim3 b(64, 4, 1), gr = cell_grid(g, b);
   double *u = h->fields[UDC_U0], *v = h->fields[UDC_V0], *w = h->fields[UDC_W0];
   double *ekm = h->fields[UDC_EKM], *ekh = h->fields[UDC_EKH];
+  if (h->p.sgs == UDC_SGS_ONEEQN) return k_tke_closure(h);
   if (!h->mom_simple && h->p.sgs != UDC_SGS_DNS) return k_closure_lds(h, false);
   PROF(h, "closure");
   if (h->p.sgs == UDC_SGS_SMAGORINSKY)

@@ -471,6 +471,7 @@ __global__ __launch_bounds__(256) void project_kernel(Geo g, TileGrid tg, Metric
 struct IntArgs {
   double *u0, *v0, *w0, *um, *vm, *wm, *up, *vp, *wp;
   double *sv0[16], *svm[16], *svp[16];
+  double clip[16];      // lower bound (e12min for the TKE slot, src/modtstep.f90:210-211) or a negative value = none
   int nsv;
 };
 
@@ -531,7 +532,11 @@ __global__ __launch_bounds__(256) void integrate_kernel(Geo g, TileGrid tg, Metr
     }
   }
   for (int s = 0; s < a.nsv; ++s) {
-    const double sv = a.svm[s][c] + rk3coef * a.svp[s][c];
+    double sv = a.svm[s][c] + rk3coef * a.svp[s][c];
+    if (a.clip[s] > 0.) {
+      sv = fmax(a.clip[s], sv);
+      if (!last_s) a.svm[s][c] = fmax(a.clip[s], a.svm[s][c]);
+    }
     a.sv0[s][c] = sv;
     if (ZERO) a.svp[s][c] = 0.;        // the fused substep's scalar sweep does not read svp either
     if (last_s) a.svm[s][c] = sv;
@@ -1029,6 +1034,7 @@ static IntArgs int_args(udc_handle *h) {
     a.sv0[a.nsv] = h->fields[UDC_SV0 + 3 * n];
     a.svm[a.nsv] = h->fields[UDC_SVM + 3 * n];
     a.svp[a.nsv] = h->fields[UDC_SVP + 3 * n];
+    a.clip[a.nsv] = h->slot[n].tke ? h->tke.e12min : -1.;
     ++a.nsv;
   }
   return a;

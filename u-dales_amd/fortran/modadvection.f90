@@ -19,8 +19,8 @@ contains
       write (0, *) 'ERROR: Unknown advection scheme'
       stop 1
     end if
-    if (loneeqn .or. lmoist) then
-      write (0, *) 'ERROR: libudcore advection: TKE / qt equations are not on the device path'
+    if (lmoist) then
+      write (0, *) 'ERROR: libudcore advection: the qt equation is not on the device path'
       stop 1
     end if
     if (ltempeq .and. iadv_thl /= iadv_cd2) then   ! thl: advecc_2nd only (src/modadvection.f90:66-68)

@@ -84,8 +84,8 @@ contains
     use modglobal, only: ib, jb, kb, ih, jh, kh, ltempeq, lmoist
     use udc_iface
     implicit none
-    if (loneeqn .or. lmoist) then
-      write (0, *) 'ERROR: libudcore subgrid: TKE / qt equations are not on the device path'
+    if (lmoist) then
+      write (0, *) 'ERROR: libudcore subgrid: the qt equation is not on the device path'
       stop 1
     end if
     call udc_ensure

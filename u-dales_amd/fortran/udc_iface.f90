@@ -22,7 +22,8 @@ module udc_iface
   integer(c_int), parameter :: UDC_U0 = 0, UDC_V0 = 1, UDC_W0 = 2, UDC_UM = 3, UDC_VM = 4, UDC_WM = 5, &
                                UDC_UP = 6, UDC_VP = 7, UDC_WP = 8, UDC_PRES0 = 9, UDC_P = 10, &
                                UDC_EKM = 11, UDC_EKH = 12, UDC_SV0 = 13, UDC_SVM = 14, UDC_SVP = 15, &
-                               UDC_THL0 = 13 + 45, UDC_THLM = 14 + 45, UDC_THLP = 15 + 45   ! scalar slot 15
+                               UDC_THL0 = 13 + 45, UDC_THLM = 14 + 45, UDC_THLP = 15 + 45, &   ! scalar slot 15
+                               UDC_E120 = 13 + 42, UDC_E12M = 14 + 42, UDC_E12P = 15 + 42      ! scalar slot 14
 
   type, bind(C) :: udc_config
     integer(c_int) :: itot, jtot, ktot
@@ -90,6 +91,12 @@ module udc_iface
       type(c_ptr), value :: h
       integer(c_int), value :: iadv_thl, bctopt, bcbott
       real(c_double), value :: wttop, thl_top, wtsurf
+    end function
+    integer(c_int) function udc_set_tke(h, cm, cn, ch1, ch2, ce1, ce2, e12min, grav, thvs, ldelta) bind(C, name='udc_set_tke')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      real(c_double), value :: cm, cn, ch1, ch2, ce1, ce2, e12min, grav, thvs
+      integer(c_int), value :: ldelta
     end function
     integer(c_int) function udc_set_buoyancy(h, lbuoyancy, grav) bind(C, name='udc_set_buoyancy')
       import :: c_int, c_ptr, c_double
@@ -198,9 +205,9 @@ contains
   !> Create the device mirror once all of initglobal/initfields/initsubgrid/initpois have run.
   subroutine udc_ensure
     use modglobal, only: itot, jtot, ktot, dx, dy, dzf, dzh, kb, ke, kh, numol, prandtlmoli, nsv, &
-                         BCtopm, Uinf, Vinf, lles, ltempeq, lbuoyancy, lmoist, iadv_thl, BCtopT, BCbotT, grav
-    use modsurfdata, only: wttop, thl_top, wtsurf
-    use modsubgriddata, only: lsmagorinsky, lvreman, prandtli, c_vreman, csz
+                         BCtopm, Uinf, Vinf, lles, ltempeq, lbuoyancy, lmoist, iadv_thl, BCtopT, BCbotT, grav, e12min
+    use modsurfdata, only: wttop, thl_top, wtsurf, thvs
+    use modsubgriddata, only: lsmagorinsky, lvreman, loneeqn, ldelta, prandtli, c_vreman, csz, cm, cn, ch1, ch2, ce1, ce2
     use modfields, only: dpdxl, dpdyl, thlpcar
     use modmpi, only: myid, nprocs, nprocx, comm3d, mpierr
     use mpi, only: MPI_CHARACTER
@@ -234,6 +241,8 @@ contains
         cfg%sgs = 1
       else if (lvreman) then
         cfg%sgs = 2
+      else if (loneeqn) then
+        cfg%sgs = 3          ! one-equation closure: constants follow with udc_set_tke below
       end if
     end if
     cfg%bctopm = BCtopm
@@ -259,6 +268,11 @@ contains
                                     real(thl_top, c_double), int(BCbotT, c_int), real(wtsurf, c_double)), 'udc_set_tempeq')
       call udc_check(udc_set_thl_source(udc_h, thlpcar(kb:ke), int(ktot, c_int)), 'udc_set_thl_source')
       if (lbuoyancy) call udc_check(udc_set_buoyancy(udc_h, 1_c_int, real(grav, c_double)), 'udc_set_buoyancy')
+    end if
+    if (cfg%sgs == 3) then   ! after udc_set_tempeq: the closure reads thl0 when the temperature equation is on
+      call udc_check(udc_set_tke(udc_h, real(cm, c_double), real(cn, c_double), real(ch1, c_double), real(ch2, c_double), &
+                                 real(ce1, c_double), real(ce2, c_double), real(e12min, c_double), real(grav, c_double), &
+                                 real(thvs, c_double), merge(1_c_int, 0_c_int, ldelta)), 'udc_set_tke')
     end if
     call get_environment_variable('UDC_RESIDENCY', env, status=stat)
     if (stat == 0) read (env, *, iostat=stat) udc_residency
@@ -286,7 +300,7 @@ contains
   !> Everything the device needs from the host's prognostic state (bounds: src/modfields.f90:440-474)
   subroutine udc_push_state
     use modglobal, only: ib, jb, kb, ih, jh, kh, ihc, jhc, khc, nsv, ltempeq
-    use modfields, only: u0, v0, w0, um, vm, wm, pres0, sv0, svm, thl0, thlm
+    use modfields, only: u0, v0, w0, um, vm, wm, pres0, sv0, svm, thl0, thlm, e120, e12m
     integer :: n
     call udc_push3(UDC_U0, u0, (/ib - ih, jb - jh, kb - kh/))
     call udc_push3(UDC_V0, v0, (/ib - ih, jb - jh, kb - kh/))
@@ -295,6 +309,10 @@ contains
     call udc_push3(UDC_VM, vm, (/ib - ih, jb - jh, kb - kh/))
     call udc_push3(UDC_WM, wm, (/ib - ih, jb - jh, kb - kh/))
     call udc_push3(UDC_PRES0, pres0, (/ib - ih, jb - jh, kb - kh/))
+    if (loneeqn_dev()) then
+      call udc_push3(UDC_E120, e120, (/ib - ih, jb - jh, kb - kh/))
+      call udc_push3(UDC_E12M, e12m, (/ib - ih, jb - jh, kb - kh/))
+    end if
     if (ltempeq) then
       call udc_push3(UDC_THL0, thl0, (/ib - ih, jb - jh, kb - kh/))
       call udc_push3(UDC_THLM, thlm, (/ib - ih, jb - jh, kb - kh/))
@@ -307,12 +325,13 @@ contains
 
   subroutine udc_push_tend
     use modglobal, only: ib, jb, kb, ih, jh, ihc, jhc, nsv, ltempeq
-    use modfields, only: up, vp, wp, svp, thlp
+    use modfields, only: up, vp, wp, svp, thlp, e12p
     integer :: n
     call udc_push3(UDC_UP, up, (/ib - ih, jb - jh, kb/))
     call udc_push3(UDC_VP, vp, (/ib - ih, jb - jh, kb/))
     call udc_push3(UDC_WP, wp, (/ib - ih, jb - jh, kb/))
     if (ltempeq) call udc_push3(UDC_THLP, thlp, (/ib - ih, jb - jh, kb/))
+    if (loneeqn_dev()) call udc_push3(UDC_E12P, e12p, (/ib - ih, jb - jh, kb/))
     do n = 1, nsv
       call udc_push3(UDC_SVP + 3*(n - 1), svp(:, :, :, n), (/ib - ihc, jb - jhc, kb/))
     end do
@@ -320,12 +339,13 @@ contains
 
   subroutine udc_pull_tend
     use modglobal, only: ib, jb, kb, ih, jh, ihc, jhc, nsv, ltempeq
-    use modfields, only: up, vp, wp, svp, thlp
+    use modfields, only: up, vp, wp, svp, thlp, e12p
     integer :: n
     call udc_pull3(UDC_UP, up, (/ib - ih, jb - jh, kb/))
     call udc_pull3(UDC_VP, vp, (/ib - ih, jb - jh, kb/))
     call udc_pull3(UDC_WP, wp, (/ib - ih, jb - jh, kb/))
     if (ltempeq) call udc_pull3(UDC_THLP, thlp, (/ib - ih, jb - jh, kb/))
+    if (loneeqn_dev()) call udc_pull3(UDC_E12P, e12p, (/ib - ih, jb - jh, kb/))
     do n = 1, nsv
       call udc_pull3(UDC_SVP + 3*(n - 1), svp(:, :, :, n), (/ib - ihc, jb - jhc, kb/))
     end do
@@ -333,13 +353,14 @@ contains
 
   subroutine udc_pull_vel(with_m)
     use modglobal, only: ib, jb, kb, ih, jh, kh, ihc, jhc, khc, nsv, ltempeq
-    use modfields, only: u0, v0, w0, um, vm, wm, sv0, svm, thl0, thlm
+    use modfields, only: u0, v0, w0, um, vm, wm, sv0, svm, thl0, thlm, e120, e12m
     logical, intent(in) :: with_m
     integer :: n
     call udc_pull3(UDC_U0, u0, (/ib - ih, jb - jh, kb - kh/))
     call udc_pull3(UDC_V0, v0, (/ib - ih, jb - jh, kb - kh/))
     call udc_pull3(UDC_W0, w0, (/ib - ih, jb - jh, kb - kh/))
     if (ltempeq) call udc_pull3(UDC_THL0, thl0, (/ib - ih, jb - jh, kb - kh/))
+    if (loneeqn_dev()) call udc_pull3(UDC_E120, e120, (/ib - ih, jb - jh, kb - kh/))
     do n = 1, nsv
       call udc_pull3(UDC_SV0 + 3*(n - 1), sv0(:, :, :, n), (/ib - ihc, jb - jhc, kb - khc/))
     end do
@@ -348,11 +369,19 @@ contains
       call udc_pull3(UDC_VM, vm, (/ib - ih, jb - jh, kb - kh/))
       call udc_pull3(UDC_WM, wm, (/ib - ih, jb - jh, kb - kh/))
       if (ltempeq) call udc_pull3(UDC_THLM, thlm, (/ib - ih, jb - jh, kb - kh/))
+      if (loneeqn_dev()) call udc_pull3(UDC_E12M, e12m, (/ib - ih, jb - jh, kb - kh/))
       do n = 1, nsv
         call udc_pull3(UDC_SVM + 3*(n - 1), svm(:, :, :, n), (/ib - ihc, jb - jhc, kb - khc/))
       end do
     end if
   end subroutine udc_pull_vel
+
+  !> one-equation closure active on the device (lles, not overridden by lsmagorinsky / lvreman)
+  logical function loneeqn_dev()
+    use modglobal, only: lles
+    use modsubgriddata, only: lsmagorinsky, lvreman, loneeqn
+    loneeqn_dev = lles .and. loneeqn .and. .not. (lsmagorinsky .or. lvreman)
+  end function loneeqn_dev
 
   !> Bring every host array up to date (before output / restart / statistics in device mode).
   subroutine udc_pull_all

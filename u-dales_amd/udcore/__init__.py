@@ -31,6 +31,11 @@ def from_deck(deck, device=0, rank=0, nranks=1):
                         wtsurf=float(deck.get("BC", "wtsurf")), thlpcar=getattr(deck, "thlpcar", None))
         if deck.get("PHYSICS", "lbuoyancy"):
             core.set_buoyancy(True)
+    if sgs == 3:      # after set_tempeq: the closure reads thl0 when the temperature equation is on
+        thls, qts = float(deck.get("BC", "thls")), float(deck.get("BC", "qts"))
+        core.set_tke(cf=float(deck.get("NAMSUBGRID", "cf")), cn=float(deck.get("NAMSUBGRID", "cn")),
+                     Rigc=float(deck.get("NAMSUBGRID", "Rigc")), Prandtl=float(deck.get("NAMSUBGRID", "Prandtl")),
+                     thvs=thls * (1. + (461.5 / 287.04 - 1.) * qts), ldelta=bool(deck.get("NAMSUBGRID", "ldelta")))
     import numpy as np
     # dpdxl, dpdyl: src/modstartup.f90:2071-2081 (lcoriol false => om23_gs terms still present:
     # dpdxl = om23_gs*vg - pgx - dpdx with om23_gs = 2*omega*sin(lat); ug = vg = 0 in our decks)

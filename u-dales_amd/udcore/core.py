@@ -15,6 +15,16 @@ from . import lib as L
 from .grid import Grid
 
 
+def tke_constants(cf=2.5, cn=0.76, Rigc=0.25, Prandtl=0.333, ch1=1., alpha_kolm=1.5):
+    """cm, ch2, ce1, ce2 of initsubgrid (src/modsubgrid.f90:63-71)."""
+    pi = 3.141592653589793116
+    cm = cf / (2. * pi) * (1.5 * alpha_kolm) ** (-1.5)
+    ch2 = Prandtl - ch1
+    ceps = 2. * pi / cf * (1.5 * alpha_kolm) ** (-1.5)
+    ce1 = (cn ** 2) * (cm / Rigc - ch1 * cm)
+    return dict(cm=cm, cn=cn, ch1=ch1, ch2=ch2, ce1=ce1, ce2=ceps - ce1)
+
+
 class DynCore:
     def __init__(self, g: Grid, sgs=L.SGS_VREMAN, bctopm=1, nsv=0, numol=1.5e-5, prandtlmol=0.71,
                  prandtli=1. / 0.333, c_vreman=0.07, csz=0.21658244510412, uinf=0., vinf=0.,
@@ -150,6 +160,14 @@ class DynCore:
 
     def coriolis(self):
         L._check(self.lib.udc_coriolis(self.h), "udc_coriolis")
+
+    def set_tke(self, cf=2.5, cn=0.76, Rigc=0.25, Prandtl=0.333, ch1=1., thvs=288., ldelta=False, e12min=5.e-5,
+                grav=9.81):
+        """&NAMSUBGRID loneeqn: constants as initsubgrid derives them (src/modsubgrid.f90:63-71)."""
+        k = tke_constants(cf, cn, Rigc, Prandtl, ch1)
+        L._check(self.lib.udc_set_tke(self.h, C.c_double(k["cm"]), C.c_double(cn), C.c_double(ch1), C.c_double(k["ch2"]),
+                                      C.c_double(k["ce1"]), C.c_double(k["ce2"]), C.c_double(e12min), C.c_double(grav),
+                                      C.c_double(thvs), int(bool(ldelta))), "udc_set_tke")
 
     def set_buoyancy(self, on=True, grav=9.81):
         """&PHYSICS lbuoyancy (dry air): forces adds grav (thv0h - thvh)/thvh to wp."""

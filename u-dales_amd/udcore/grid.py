@@ -85,9 +85,11 @@ def sgs_from_deck(d: Deck):
         sgs = 1
     elif lvre:
         sgs = 2
+    elif d.get("NAMSUBGRID", "loneeqn"):
+        sgs = 3                 # one-equation TKE closure, src/modsubgrid.f90:363 (needs DynCore.set_tke)
     else:
         sgs = 0
-    if (lsmag or lvre):
+    if (lsmag or lvre or sgs == 3):
         lles = True
     if not lles:
         sgs = 0
@@ -145,6 +147,13 @@ def cold_start(g: Grid, d: Deck, j0=0, nyl=None, nsv=0, scal_a=1.0, scal_b=0.0):
         c[nz + 3] = c[nz + 1]
         out[f"sv0_{n}"] = c
         out[f"svm_{n}"] = c.copy()
+    if d.get("NAMSUBGRID", "loneeqn") and not (d.get("NAMSUBGRID", "lsmagorinsky") or d.get("NAMSUBGRID", "lvreman")):
+        # e120 = e12m = max(e12prof(k), e12min), src/modstartup.f90:1140-1169; ghosts: zero below, e12min above (boundary)
+        e = np.zeros(shape)
+        for k in range(1, nz + 1):
+            e[k] = max(d.tke[k - 1], 5.e-5)
+        e[nz + 1] = 5.e-5
+        out["e120"], out["e12m"] = e, e.copy()
     if d.get("PHYSICS", "ltempeq"):
         # thl0 = thlm = thlprof(k), ghosts as src/modstartup.f90:1156-1208, then boundary's top condition
         t = np.zeros(shape)
