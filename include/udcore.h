@@ -141,6 +141,19 @@ int udc_forces(udc_handle *h);
  *             Called between bottom and forces (src/program.f90:158); inside udc_substep when with_forces != 0. */
 int udc_set_coriolis(udc_handle *h, int mode, double om22, double om23, const double *ug, int n);
 int udc_coriolis(udc_handle *h);
+/* Per-level forcings (lstend src/modforces.f90:719-822, nudge :824-860, grwdamp src/modboundary.f90:1447-1488):
+ * they all have the form  tendency(i,j,k) += A(k) + B(k) * field(i,j,k)  with A, B built from slab averages
+ * (u0av, v0av, thl0av, sv0av of diagfld, src/modthermodynamics.f90:262-279) and input profiles.  The library provides
+ * the two device halves; the per-level arithmetic stays with the host (udcore/forcings.py mirrors the reference lines).
+ * udc_slab_average: avg[k-1] = mean over the whole horizontal plane (all slabs) of `field` at level k = 1..n
+ *   (n <= ktot+1: level ktot+1 is the top ghost plane, as avexy_ibm averages it); synchronises.
+ * udc_set_level_forcing: registers (or with A == NULL removes) the forcing of tendency field `tend`; src < 0 = no B
+ *   term; A, B hold levels 1..ktot; when = 0: applied before masscorr (lstend, nudge: src/program.f90:162-164),
+ *   when = 1: after it (grwdamp, :191).  Registered forcings are applied by udc_level_forcings(h, when) and, when
+ *   with_forces != 0, inside udc_substep. */
+int udc_slab_average(udc_handle *h, int field, double *avg, int n);
+int udc_set_level_forcing(udc_handle *h, int tend, int src, const double *A, const double *B, int n, int when);
+int udc_level_forcings(udc_handle *h, int when);
 /* masscorr    src/modforces.f90:328     volume-flow branches: up += (uflowrate - <um + rk3coef up>)/rk3coef (luvolflowr,
  *             :389-417) and the same for v (lvvolflowr, :467-494); <.> = volume average over the whole domain
  *             (all-reduced over the slabs).  Called after forces (src/program.f90:169).  No-op unless enabled with

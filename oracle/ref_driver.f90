@@ -36,13 +36,13 @@ program ref_driver
   use modsubgriddata
   use modsurfdata, only: thl_top, wttop, wsvtop, sv_top, thvs, thls, z0, wtsurf, qts
   use modwallfunctions, only: wfmneutral
-  use modboundary, only: initboundary, boundary, halos
+  use modboundary, only: initboundary, boundary, halos, grwdamp
   use modthermodynamics, only: initthermodynamics, thermodynamics
   use modsubgrid, only: initsubgrid, subgrid
   use modpois, only: initpois, poisson, p
   use modadvection, only: advection
   use modtstep, only: tstep_update, tstep_integrate
-  use modforces, only: forces, masscorr, coriolis
+  use modforces, only: forces, masscorr, coriolis, lstend, nudge
   use modsave, only: writerestartfiles
   implicit none
 
@@ -51,6 +51,7 @@ program ref_driver
   integer :: dump_at(16) = -1
   logical :: lforces = .true.
   logical :: lbottom = .false.           ! src/modibm.f90:49 (module variable of modibm)
+  logical :: need_thermo = .false.
   integer :: isub, n, ierr, iu
   real :: t0, t1, chk_u2, chk_div
   real :: scal_a = 1.0, scal_b = 0.0     ! scalar init: sv = scal_b + scal_a*z/zsize
@@ -85,7 +86,8 @@ program ref_driver
   call initpois
   call cold_start
   call boundary
-  if (ltempeq .or. loneeqn) call thermodynamics   ! src/program.f90:120 (thv0h, thvh for buoyancy; dthvdz for the TKE closure)
+  need_thermo = ltempeq .or. loneeqn .or. lnudge .or. igrw_damp /= 0 .or. any(whls /= 0.)
+  if (need_thermo) call thermodynamics            ! src/program.f90:120 (thv0h, thvh; dthvdz; diagfld's slab averages)
 
   iu = 71
   if (trim(mode) /= 'time') then
@@ -167,12 +169,15 @@ contains
     call floor_bottom
     if (lforces) call coriolis              ! src/program.f90:158 (no-op unless lcoriol / lprofforc)
     if (lforces) call forces
-    call masscorr                           ! src/program.f90:169 (no-op unless luvolflowr / lvvolflowr)
+    if (lforces) call lstend                ! src/program.f90:162 (large-scale subsidence; needs diagfld's slab averages)
+    if (lforces) call nudge                 ! src/program.f90:164
+    call masscorr                           ! src/program.f90:169
+    if (lforces) call grwdamp               ! src/program.f90:191 (sponge layer) (no-op unless luvolflowr / lvvolflowr)
     call poisson
     call tstep_integrate
     call halos
     call boundary
-    if (ltempeq .or. loneeqn) call thermodynamics   ! src/program.f90:214
+    if (need_thermo) call thermodynamics            ! src/program.f90:214
   end subroutine one_substep
 
   ! ---- `bottom`, src/modibm.f90:2021-2026 (momentum, BCbotm = 3) and :2073-2090 (scalars, BCbots = 1)
@@ -232,7 +237,7 @@ contains
       libm, lles, lrandomize, nprocx, nprocy
     namelist /DOMAIN/ itot, jtot, ktot, xlen, ylen
     namelist /PHYSICS/ lmoist, lcoriol, lbuoyancy, ltempeq, lprofforc, dpdx, luvolflowr, uflowrate, &
-      lvvolflowr, vflowrate
+      lvvolflowr, vflowrate, igrw_damp, geodamptime, lnudge, lnudgevel, tnudge, nnudge
     namelist /DYNAMICS/ ipoiss, iadv_mom, iadv_tke, iadv_thl, iadv_qt, iadv_sv
     namelist /BC/ BCxm, BCym, BCtopm, BCtopT, BCtops, BCbotm, BCbots, BCbotT, BCzp, wttop, thl_top, z0, wtsurf, thls, qts
     namelist /SCALARS/ nsv
@@ -359,6 +364,11 @@ contains
         dqtdxls(k), dqtdyls(k), dqtdtls(k), thlpcar(k)
     end do
     close (ifinput)
+    whls(kb) = 0.0                          ! src/modstartup.f90:2125-2129
+    do k = kb + 1, ke
+      whls(k) = (wfls(k)*dzf(k - 1) + wfls(k - 1)*dzf(k))/(2*dzh(k))
+    end do
+    whls(ke + 1) = (wfls(ke) + dzf(ke)*(wfls(ke) - wfls(ke - 1))/dzh(ke))
     if (lprofforc) then
       do k = kb, ke
         dpdxl(k) = -pgx(k) - dpdx
@@ -520,6 +530,15 @@ contains
     call floor_bottom
     if (lforces) call coriolis
     if (lforces) call forces
+    if (lforces .and. (lnudge .or. igrw_damp /= 0 .or. any(whls /= 0.))) then
+      call dump_tend('frc0')                ! tendencies the per-level forcings start from
+      call lstend
+      call nudge
+      call grwdamp
+      call dump_tend('lsf')
+      call put1('u0av', u0av(kb:ke + kh), kb)
+      call put1('thl0av', thl0av(kb:ke + kh), kb)
+    end if
     if (luvolflowr .or. lvvolflowr) call dump_tend('frc')   ! tendencies masscorr starts from
     call masscorr
     call dump_tend('pre')

@@ -87,7 +87,7 @@ def zlevels(nz, dz0=0.5, stretch=1.0):
     return zf
 
 
-def write_case(d, iexpnr, text, zf, u=1.0, v=0.0, pgx=1e-4, dthl=0.0, dthlrad=0.0, ug=0.0, tke=0.0):
+def write_case(d, iexpnr, text, zf, u=1.0, v=0.0, pgx=1e-4, dthl=0.0, dthlrad=0.0, ug=0.0, tke=0.0, wtop=0.0):
     with open(os.path.join(d, f"namoptions.{iexpnr:03d}"), "w") as f:
         f.write(text)
     with open(os.path.join(d, f"prof.inp.{iexpnr:03d}"), "w") as f:
@@ -97,13 +97,15 @@ def write_case(d, iexpnr, text, zf, u=1.0, v=0.0, pgx=1e-4, dthl=0.0, dthlrad=0.
     with open(os.path.join(d, f"lscale.inp.{iexpnr:03d}"), "w") as f:
         f.write("# golden\n# z uq vq pqx pqy wfls dqtdxls dqtdyls dqtdtls dthlrad\n")
         for z in zf:
-            f.write(f"{z:.15f} {ug!r} 0.0 {pgx} 0.0 0.0 0.0 0.0 0.0 {dthlrad!r}\n")
+            wf = wtop * z / zf[-1] if wtop else 0.0
+            f.write(f"{z:.15f} {ug!r} 0.0 {pgx} 0.0 {wf!r} 0.0 0.0 0.0 {dthlrad!r}\n")
 
 
 KEEP_KERNELS = ("meta dzf dzh zf dpdxl dpdyl rk3 in.u0 in.v0 in.w0 in.um in.vm in.wm in.pres0 "
                 "in.ekm in.ekh adv.up adv.vp adv.wp sub.ekm sub.ekh sub.u0 sub.up sub.vp sub.wp bot.up bot.vp frc.up frc.vp "
                 "in.thl0 in.thlm adv.thlp sub.thlp sub.thl0 bot.thlp pre.thlp out.thl0 out.thlm "
                 "in.e120 in.e12m adv.e12p sub.e12p pre.e12p out.e120 out.e12m "
+                "frc0.up frc0.vp frc0.wp frc0.thlp lsf.up lsf.vp lsf.wp lsf.thlp u0av thl0av "
                 "pre.up pre.vp pre.wp poi.p poi.pres0 poi.up poi.vp poi.wp out.u0 out.v0 out.w0 "
                 "out.um out.pres0").split()
 
@@ -169,7 +171,18 @@ CASES.update({
                               bc="BCtopT = 2\nthl_top = 291.5\nBCbotT = 1\nwtsurf = 0.03\nthls = 288.0\nqts = 0.0",
                               oracle="nspin = 3"), 1.06),
 })
-THL_CASES = {"k_tke_12x8x6": dict(tke=0.05), "k_tke_thl_12x8x6": dict(tke=0.08, dthl=0.3), "k_coriol_12x8x6": dict(ug=1.1), "run_profforc_16x16x8": dict(ug=1.3), "k_thl_12x8x6": dict(dthl=0.4, dthlrad=2e-3), "run_thl_16x8x12s": dict(dthl=0.25, dthlrad=-1e-3),
+CASES.update({
+    # per-level forcings: large-scale subsidence (lstend, wfls), nudging, gravity-wave sponge (grwdamp)
+    "k_lsf_12x8x24": ("kernels", 29, 12, 8, 24,
+                      dict(sgs="vreman", physics="ltempeq = .true.\nlbuoyancy = .true.\nlnudge = .true.\ntnudge = 50.\n"
+                           "nnudge = 2\nigrw_damp = 2", bc="BCtopT = 2\nthl_top = 295.\nthls = 288.0\nqts = 0.0",
+                           oracle="nspin = 3"), 1.03),
+    "run_lsf_16x8x24s": ("run", 30, 16, 8, 24,
+                         dict(sgs="smag", physics="ltempeq = .true.\nlbuoyancy = .true.\nlnudge = .true.\ntnudge = 40.\n"
+                              "nnudge = 3\nigrw_damp = 1\nlcoriol = .true.",
+                              bc="BCtopT = 2\nthl_top = 295.\nthls = 288.0\nqts = 0.0", oracle="nsub = 6\ndump_at = 3, 6"), 1.04),
+})
+THL_CASES = {"k_lsf_12x8x24": dict(dthl=0.3, ug=1.05, wtop=0.02), "run_lsf_16x8x24s": dict(dthl=0.25, ug=0.95, wtop=-0.03), "k_tke_12x8x6": dict(tke=0.05), "k_tke_thl_12x8x6": dict(tke=0.08, dthl=0.3), "k_coriol_12x8x6": dict(ug=1.1), "run_profforc_16x16x8": dict(ug=1.3), "k_thl_12x8x6": dict(dthl=0.4, dthlrad=2e-3), "run_thl_16x8x12s": dict(dthl=0.25, dthlrad=-1e-3),
              "k_buoy_12x8x6": dict(dthl=0.3), "run_buoy_16x8x12s": dict(dthl=0.2)}
 
 

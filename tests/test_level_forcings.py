@@ -1,0 +1,110 @@
+"""Per-level forcings (lstend / nudge / grwdamp, udcore/forcings.py) against the reference's own routines.
+
+CPU: the table arithmetic on the inputs the reference had (fixture k_lsf_12x8x24: tendencies before and after its
+lstend + nudge + grwdamp calls, and diagfld's slab averages).  GPU: a six-substep run with all three on, through the
+fused substep, against the reference run (run_lsf_16x8x24s)."""
+import numpy as np
+import pytest
+
+from common import deck_path, interior, load_fixture, marr, nocorner, relerr
+from udcore import read_deck
+from udcore.forcings import LevelForcings
+from udcore.grid import Grid
+
+
+class _FakeCore:
+    def __init__(self, g):
+        self.g, self.nsv = g, 0
+
+
+def _avg(a, nz):
+    out = np.zeros(nz + 2)
+    out[1:nz + 2] = a[1:nz + 2, 1:-1, 1:-1].mean(axis=(1, 2))
+    return out
+
+
+def test_tables_match_reference_routines():
+    name, iexp = "k_lsf_12x8x24", 29
+    fix = load_fixture(name)
+    d = read_deck(deck_path(name, iexp))
+    g = Grid.from_deck(d)
+    nz = g.nz
+    ls = LevelForcings(_FakeCore(g), d)
+    assert ls.active and ls.subsidence and ls.lnudge and ls.igrw == 2
+    fields = {k: marr(fix, "sub." + k if k == "u0" else "in." + k, nz) for k in ("u0", "v0", "w0")}
+    fields["thl0"] = marr(fix, "sub.thl0", nz)      # top ghost row re-imposed by closurebc before the forcings run
+    av = {k: _avg(fields[k], nz) for k in ("u0", "v0", "thl0")}
+    # the averages are diagfld's (src/modthermodynamics.f90:262-279)
+    np.testing.assert_allclose(av["u0"][1:nz + 2], fix["u0av"].data, rtol=0, atol=2e-15)
+    np.testing.assert_allclose(av["thl0"][1:nz + 1], fix["thl0av"].data[:nz], rtol=0, atol=1e-12)
+    tabs = ls.tables(av)
+    assert {t for t, _ in tabs} == {"up", "vp", "wp", "thlp"}
+    for tend in ("up", "vp", "wp", "thlp"):
+        t = marr(fix, "frc0." + tend, nz).copy()
+        for when in (0, 1):
+            if (tend, when) not in tabs:
+                continue
+            src, A, B = tabs[(tend, when)]
+            for k in range(1, nz + 1):
+                t[k] = t[k] + A[k] + (B[k] * fields[src][k] if src else 0.)
+        sc = np.abs(marr(fix, "lsf." + tend, nz) - marr(fix, "frc0." + tend, nz)).max()
+        assert sc > 1e-6, tend                                    # the forcings did something
+        assert np.abs(interior(t) - interior(marr(fix, "lsf." + tend, nz))).max() <= 1e-12 * max(sc, 1.), tend
+
+
+@pytest.mark.gpu
+def test_device_applies_tables_like_reference():
+    """udc_slab_average + udc_set_level_forcing + udc_level_forcings on the reference's inputs."""
+    import udcore
+    name, iexp = "k_lsf_12x8x24", 29
+    fix = load_fixture(name)
+    d = read_deck(deck_path(name, iexp))
+    core = udcore.from_deck(d)
+    nz = core.g.nz
+    for k in ("u0", "v0", "w0", "um", "vm", "wm", "pres0"):
+        core.upload(k, marr(fix, ("sub." if k == "u0" else "in.") + k, nz))
+    core.upload("thl0", marr(fix, "sub.thl0", nz))
+    core.upload("thlm", marr(fix, "in.thlm", nz))
+    for k in ("up", "vp", "wp", "thlp"):
+        core.upload(k, marr(fix, "frc0." + k, nz))
+    # slab averages = diagfld's
+    np.testing.assert_allclose(core.slab_average("u0")[1:nz + 2], fix["u0av"].data, rtol=0, atol=5e-15)
+    ls = LevelForcings(core, d)
+    ls.update()
+    core.level_forcings(0)
+    core.level_forcings(1)
+    for k in ("up", "vp", "wp", "thlp"):
+        sc = np.abs(marr(fix, "lsf." + k, nz) - marr(fix, "frc0." + k, nz)).max()
+        assert np.abs(interior(core.download(k)) - interior(marr(fix, "lsf." + k, nz))).max() <= 1e-11 * max(sc, 1.), k
+    core.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [True, False])
+def test_run_with_level_forcings_matches_reference(fused):
+    import udcore
+    from udcore import cold_start
+    name, iexp = "run_lsf_16x8x24s", 30
+    fix = load_fixture(name)
+    d = read_deck(deck_path(name, iexp))
+    core = udcore.from_deck(d)
+    core.load_state(cold_start(core.g, d))
+    ls = LevelForcings(core, d)
+    assert ls.active and ls.igrw == 1 and ls.lcoriol
+    dt = float(d.get("RUN", "dtmax"))
+    dumps = sorted(int(k[1:4]) for k in fix if k.endswith(".u0") and k != "s000.u0")
+    for isub in range(1, max(dumps) + 1):
+        ls.update()                                  # diagfld's averages of the state the substep starts from
+        if fused:
+            core.substep((isub - 1) % 3 + 1, dt, with_forces=True)
+        else:
+            core.tstep_update(dt)
+            core.advection(); core.subgrid(); core.bottom(); core.coriolis(); core.forces()
+            core.level_forcings(0); core.masscorr(); core.level_forcings(1)
+            core.poisson(); core.tstep_integrate(); core.halos(); core.boundary()
+        if isub in dumps:
+            for k in ("u0", "v0", "w0", "pres0", "thl0"):
+                ref = marr(fix, f"s{isub:03d}.{k}", core.g.nz)
+                sc = 1.0 if k == "thl0" else None
+                assert relerr(nocorner(core.download(k)[1:-1]), nocorner(ref[1:-1]), sc) <= 1e-9, (isub, k)
+    core.close()

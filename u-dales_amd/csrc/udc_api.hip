@@ -184,6 +184,7 @@ extern "C" int udc_destroy(udc_handle *h) {
   pois_destroy(h);
   comm_destroy(h);
   for (int q = 0; q < 4; ++q) if (h->halo_buf[q]) hipFree(h->halo_buf[q]);
+  for (auto &f : h->level_forcings) { if (f.A) hipFree(f.A); if (f.B) hipFree(f.B); }
   for (double *p : h->fields) if (p) hipFree(p);
   if (h->metrics_dev) hipFree(h->metrics_dev);
   if (h->red) hipFree(h->red);
@@ -421,6 +422,48 @@ extern "C" int udc_coriolis(udc_handle *h) {
   return k_coriolis(h, false);
 }
 
+extern "C" int udc_slab_average(udc_handle *h, int field, double *avg, int n) {
+  HIP_OK(hipSetDevice(h->device));
+  if (field >= UDC_UM && field <= UDC_WM && um_materialise(h)) return 1;
+  return k_slab_average(h, field, avg, n);
+}
+
+extern "C" int udc_set_level_forcing(udc_handle *h, int tend, int src, const double *A, const double *B, int n, int when) {
+  HIP_OK(hipSetDevice(h->device));
+  if (tend < 0 || tend >= (int)h->fields.size() || !h->fields[tend]) { udc_set_error("udc_set_level_forcing: unknown tendency field %d", tend); return 1; }
+  if (src >= 0 && (src >= (int)h->fields.size() || !h->fields[src])) { udc_set_error("udc_set_level_forcing: unknown source field %d", src); return 1; }
+  auto it = h->level_forcings.begin();
+  when = when ? 1 : 0;
+  while (it != h->level_forcings.end() && !(it->tend == tend && it->when == when)) ++it;
+  if (!A) {                       // remove
+    if (it != h->level_forcings.end()) { hipFree(it->A); hipFree(it->B); h->level_forcings.erase(it); }
+    return 0;
+  }
+  if (n != h->g.nz) { udc_set_error("udc_set_level_forcing: expected %d levels", h->g.nz); return 1; }
+  if (it == h->level_forcings.end()) {
+    udc_handle::LevelForcing f;
+    f.tend = tend; f.when = when;
+    HIP_OK(hipMalloc(&f.A, sizeof(double) * (n + 2)));
+    HIP_OK(hipMalloc(&f.B, sizeof(double) * (n + 2)));
+    h->level_forcings.push_back(f);
+    it = h->level_forcings.end() - 1;
+  }
+  it->src = (src >= 0 && B) ? src : -1;
+  std::vector<double> t(2 * (n + 2), 0.0);
+  for (int k = 1; k <= n; ++k) { t[k] = A[k - 1]; if (B) t[n + 2 + k] = B[k - 1]; }
+  HIP_OK(hipMemcpyAsync(it->A, t.data(), sizeof(double) * (n + 2), hipMemcpyHostToDevice, h->stream));
+  HIP_OK(hipMemcpyAsync(it->B, t.data() + n + 2, sizeof(double) * (n + 2), hipMemcpyHostToDevice, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+extern "C" int udc_level_forcings(udc_handle *h, int when) {
+  HIP_OK(hipSetDevice(h->device));
+  if (h->level_forcings.empty()) return 0;
+  if (tend_clean(h) || um_materialise(h)) return 1;
+  return k_level_forcings(h, when ? 1 : 0, false);
+}
+
 extern "C" int udc_set_masscorr(udc_handle *h, int luvolflowr, double uflowrate, int lvvolflowr, double vflowrate) {
   h->luvolflowr = luvolflowr ? 1 : 0; h->uflowrate = uflowrate;
   h->lvvolflowr = lvvolflowr ? 1 : 0; h->vflowrate = vflowrate;
@@ -533,8 +576,10 @@ extern "C" int udc_substep(udc_handle *h, int rk3step, double dt, int with_force
   // `bottom` (src/program.f90:152): additive on the k = kb tendencies, hence equally on pup = up + um/rk3coef
   if (h->p.lbottom && k_bottom(h, fold)) return 1;
   if (with_forces && k_coriolis(h, fold)) return 1;        // src/program.f90:158; wrap of vp's ghost row follows below
+  if (with_forces && !h->level_forcings.empty() && k_level_forcings(h, 0, fold)) return 1;   // lstend, nudge tables
   // masscorr (src/program.f90:169); without pup the tendencies and um are summed separately
   if (k_masscorr(h, rk3coef, pup, fold)) return 1;
+  if (with_forces && !h->level_forcings.empty() && k_level_forcings(h, 1, fold)) return 1;   // grwdamp tables
   if (!fold) {
     const int fvp[1] = {UDC_VP};
     if (k_halo_y(h, fvp, 1, 1)) return 1;

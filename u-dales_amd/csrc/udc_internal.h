@@ -121,6 +121,8 @@ struct udc_handle {
   std::vector<int> slots;
   // one-equation closure constants (udc_set_tke)
   struct Tke { double cm = 0., cn = 0., ch1 = 0., ch2 = 0., ce1 = 0., ce2 = 0., e12min = 5e-5, grav = 9.81, thvs = 0.; int ldelta = 0; } tke;
+  struct LevelForcing { int tend = -1, src = -1, when = 0; double *A = nullptr, *B = nullptr; };   // udc_set_level_forcing
+  std::vector<LevelForcing> level_forcings;
   int coriolis_mode = 0;       // 0 off, 1 lcoriol, 2 lprofforc (src/modforces.f90:600-717)
   double om22 = 0., om23 = 0.;
   double *ug = nullptr;        // [nz+2] geostrophic wind profile (lprofforc)
@@ -218,6 +220,8 @@ int k_top_rows_after_closure(udc_handle *h);
 int k_scalar_top_flux(udc_handle *h);              // fluxtop with a non-zero flux: re-imposed after closure (reassure_fluxtop_boundary)
 int k_level_source(udc_handle *h, int slot, const double *src);
 int k_buoyancy(udc_handle *h);
+int k_slab_average(udc_handle *h, int field, double *avg_host, int n);
+int k_level_forcings(udc_handle *h, int when, bool wrap_vp);
 int k_tke_closure(udc_handle *h);                  // closure, loneeqn branch
 int k_tke_sources(udc_handle *h);                  // sources: e12p += shear + buoyancy + dissipation
 int k_tke_floor(udc_handle *h);                    // e120(kb-1) = e120(kb), e12m likewise (`bottom`)                     // wp += grav (thv0h - thvh)/thvh, src/modforces.f90:73-84   // cp(i,j,k) += src(k)

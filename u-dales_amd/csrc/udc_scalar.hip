@@ -249,7 +249,69 @@ __global__ void tke_floor_kernel(Geo g, double *__restrict__ e0, double *__restr
   em[c - g.sz] = em[c];
 }
 
+// plain per-level slab sums (stage 1; levelsum_final_kernel is stage 2): levels k = 0..nlev-1 (device), i.e. 1..nlev
+__global__ __launch_bounds__(256) void levelsum_plain_kernel(Geo g, int gx, const double *__restrict__ f, double *__restrict__ part) {
+  __shared__ double sw[4];
+  const int tile = blockIdx.x, k = blockIdx.y;
+  const int by = tile / gx, bx = tile - by * gx;
+  const int i = bx * 64 + threadIdx.x, j = by * 4 + threadIdx.y;
+  double v = 0.;
+  if (i < g.nx && j < g.ny) v = f[g.idx(i, j, k)];
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if (threadIdx.x == 0) sw[threadIdx.y] = v;
+  __syncthreads();
+  if (threadIdx.x == 0 && threadIdx.y == 0) part[(size_t)k * gridDim.x + tile] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+}
+// tend += A(k) + B(k) src   (A, B indexed by the reference's k)
+__global__ __launch_bounds__(256) void level_affine_kernel(Geo g, TileGrid tg, const double *__restrict__ A, const double *__restrict__ B,
+                                                            const double *__restrict__ src, double *__restrict__ tend, int wrap) {
+  int i, j, k;
+  if (!tile_decode(g, tg, i, j, k)) return;
+  const long c = g.idx(i, j, k);
+  double t = tend[c] + A[k + 1];
+  if (src) t = t + B[k + 1] * src[c];
+  tend[c] = t;
+  if (wrap && j == 0) tend[c + (long)g.sy * g.ny] = t;
+}
+
 }  // namespace
+
+int k_slab_average(udc_handle *h, int field, double *avg_host, int n) {
+  const Geo &g = h->g;
+  if (n < 1 || n > g.nz + 1) { udc_set_error("udc_slab_average: 1 <= n <= ktot+1"); return 1; }
+  if (field < 0 || field >= (int)h->fields.size() || !h->fields[field]) { udc_set_error("udc_slab_average: unknown field %d", field); return 1; }
+  const TileGrid tg = tile_grid(g);
+  const size_t need = (size_t)tg.tiles * (g.nz + 1);
+  if (h->lev_cap < need) {
+    if (h->lev_part) HIP_OK(hipFree(h->lev_part));
+    HIP_OK(hipMalloc(&h->lev_part, sizeof(double) * need));
+    h->lev_cap = need;
+  }
+  if (!h->lev_sum) HIP_OK(hipMalloc(&h->lev_sum, sizeof(double) * (g.nz + 2)));
+  hipLaunchKernelGGL(levelsum_plain_kernel, dim3((unsigned)tg.tiles, (unsigned)n), dim3(64, 4), 0, h->stream, g, tg.gx,
+                     (const double *)h->fields[field], h->lev_part);
+  hipLaunchKernelGGL(levelsum_final_kernel, dim3((unsigned)n), dim3(256), 0, h->stream, tg.tiles, h->lev_part, h->lev_sum);
+  HIP_OK(hipGetLastError());
+  if (comm_allreduce(h, h->lev_sum, n, 1)) return 1;
+  HIP_OK(hipMemcpyAsync(h->red_host, h->lev_sum, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  const double cnt = (double)g.nx * (double)h->cfg.jtot;
+  for (int k = 0; k < n; ++k) avg_host[k] = h->red_host[k] / cnt;
+  return 0;
+}
+
+int k_level_forcings(udc_handle *h, int when, bool wrap_vp) {
+  const Geo &g = h->g;
+  dim3 b(64, 4, 1), gr = cell_grid(g, b);
+  for (const auto &f : h->level_forcings) {
+    if (f.when != when) continue;
+    PROF(h, "level_forcing");
+    hipLaunchKernelGGL(level_affine_kernel, gr, b, 0, h->stream, g, tile_grid(g), (const double *)f.A, (const double *)f.B,
+                       f.src >= 0 ? (const double *)h->fields[f.src] : nullptr, h->fields[f.tend], (wrap_vp && f.tend == UDC_VP) ? 1 : 0);
+    HIP_OK(hipGetLastError());
+  }
+  return 0;
+}
 
 static TkeK tke_consts(udc_handle *h) {
   return TkeK{h->tke.cm, h->tke.cn, h->tke.ch1, h->tke.ch2, h->tke.ce1, h->tke.ce2, h->tke.grav / h->tke.thvs,

@@ -151,6 +151,30 @@ class DynCore:
             a = np.ascontiguousarray(thlpcar, dtype=np.float64)
             L._check(self.lib.udc_set_thl_source(self.h, a.ctypes.data_as(L.DP), len(a)), "udc_set_thl_source")
 
+    def slab_average(self, field):
+        """Horizontal mean of `field` per level, indexed by the reference's k: entries 1..nz+1 (entry 0 unused)."""
+        from .forcings import field_id
+        fid = field_id(field) if isinstance(field, str) else field
+        a = np.zeros(self.g.nz + 2)
+        L._check(self.lib.udc_slab_average(self.h, fid, a[1:].ctypes.data_as(L.DP), self.g.nz + 1), "udc_slab_average")
+        return a
+
+    def set_level_forcing(self, tend, src, A, B, when=0):
+        """tend(i,j,k) += A(k) + B(k) src(i,j,k) inside every following substep; A=None removes it."""
+        from .forcings import field_id
+        t = field_id(tend) if isinstance(tend, str) else tend
+        s_ = -1 if src is None else (field_id(src) if isinstance(src, str) else src)
+        if A is None:
+            L._check(self.lib.udc_set_level_forcing(self.h, t, s_, None, None, 0, int(when)), "udc_set_level_forcing")
+            return
+        a = np.ascontiguousarray(A, dtype=np.float64)
+        b = np.ascontiguousarray(B if B is not None else np.zeros_like(a), dtype=np.float64)
+        L._check(self.lib.udc_set_level_forcing(self.h, t, s_, a.ctypes.data_as(L.DP), b.ctypes.data_as(L.DP), len(a),
+                                                int(when)), "udc_set_level_forcing")
+
+    def level_forcings(self, when=0):
+        L._check(self.lib.udc_level_forcings(self.h, int(when)), "udc_level_forcings")
+
     def set_coriolis(self, mode, om22, om23, ug=None):
         """mode 1 = &PHYSICS lcoriol, 2 = lprofforc (relaxation towards ug(k)); src/modforces.f90:600-717."""
         n = 0 if ug is None else len(ug)

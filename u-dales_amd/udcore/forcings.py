@@ -1,0 +1,142 @@
+"""Per-level forcings on top of the device core: large-scale subsidence (lstend), nudging and the gravity-wave
+sponge (grwdamp).
+
+The reference computes them on the host from slab averages; they all have the form
+``tendency(i,j,k) += A(k) + B(k) * field(i,j,k)``.  The device supplies the averages (udc_slab_average) and applies
+registered (A, B) tables inside the fused substep (udc_set_level_forcing); the per-level arithmetic below follows
+
+  lstend   src/modforces.f90:719-822   (subsidence of thl and the scalars with whls; the large-scale gradients
+                                        d*dxls/d*dyls have no input in this snapshot and are zero; lmomsubs is
+                                        not a namelist variable, so momentum is untouched)
+  nudge    src/modforces.f90:824-860   (u, v towards uprof, vprof when lnudgevel; thl towards thlprof)
+  grwdamp  src/modboundary.f90:1447-1488 (igrw_damp 1, 2, 3; tsc and ksp of initboundary :45-59)
+  whls     src/modstartup.f90:2125-2129
+
+Usage: ``ls = LevelForcings(core, deck)``; call ``ls.update()`` before every substep (after the previous one's
+boundary, where the reference's diagfld takes its averages).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import lib as L
+
+
+class LevelForcings:
+    def __init__(self, core, deck):
+        self.core, g = core, core.g
+        nz = g.nz
+        self.nz = nz
+        ph = lambda n: deck.get("PHYSICS", n)   # noqa: E731
+        self.igrw = int(ph("igrw_damp"))
+        self.lnudge = bool(ph("lnudge"))
+        self.lnudgevel = bool(ph("lnudgevel"))
+        self.tnudge = float(ph("tnudge"))
+        self.nnudge = int(ph("nnudge"))
+        self.lcoriol = bool(ph("lcoriol"))
+        self.geodamptime = float(ph("geodamptime"))
+        self.ltempeq = bool(ph("ltempeq"))
+        # profiles indexed by the reference's k (entry 0 unused)
+        f = lambda a: np.concatenate(([0.], np.asarray(a, dtype=float)[:nz]))   # noqa: E731
+        self.uprof, self.vprof, self.thlprof = f(deck.u), f(deck.v), f(deck.thl)
+        self.ug, self.vg = f(deck.ug), f(deck.vg)
+        wfls = f(getattr(deck, "wfls", np.zeros(nz)))
+        dzf, dzh = g.dzf, g.dzh
+        whls = np.zeros(nz + 2)                      # src/modstartup.f90:2125-2129
+        for k in range(2, nz + 1):
+            whls[k] = (wfls[k] * dzf[k - 1] + wfls[k - 1] * dzf[k]) / (2 * dzh[k])
+        whls[nz + 1] = (wfls[nz] + dzf[nz] * (wfls[nz] - wfls[nz - 1]) / dzh[nz])
+        self.whls = whls
+        self.subsidence = bool(np.any(wfls != 0.))
+        # sponge: initboundary, src/modboundary.f90:45-59 (rnu0 = 2.75e-3)
+        kmax = nz
+        self.ksp = max(min(3 * kmax // 4, kmax - 15), 1)
+        tsc = np.zeros(nz + 2)
+        zspb, zspt = g.zf[self.ksp], g.zf[nz]
+        pi = 3.141592653589793116
+        for k in range(self.ksp, nz + 1):
+            tsc[k] = 2.75e-3 * math.sin(0.5 * pi * (g.zf[k] - zspb) / (zspt - zspb)) ** 2
+        self.tsc = tsc
+        self.active = self.subsidence or self.lnudge or self.igrw != 0
+
+    def tables(self, av):
+        """av: dict of slab averages indexed by the reference's k (entries 1..nz+1).  Returns {(tend, when): [src, A, B]}
+        with A, B indexed 1..nz; when = 0 for lstend and nudge (before masscorr), 1 for the sponge (after it)."""
+        nz, dzh, whls = self.nz, self.core.g.dzh, self.whls
+        out = {}
+
+        def acc(tend, src=None, when=0):
+            key = (tend, when)
+            if key not in out:
+                out[key] = [src, np.zeros(nz + 2), np.zeros(nz + 2)]
+            if src is not None:
+                out[key][0] = src
+            return out[key]
+
+        scal = [("thl0", "thlp")] if self.ltempeq else []
+        scal += [(f"sv0_{n}", f"svp_{n}") for n in range(self.core.nsv)]
+        if self.subsidence:                                      # lstend
+            for name, tend in scal:
+                a = av[name]
+                A = acc(tend)[1]
+                if whls[2] < 0:                                  # k = kb, src/modforces.f90:768-781
+                    A[1] -= whls[2] * (a[2] - a[1]) / dzh[2]
+                for k in range(2, nz + 1):                       # :790-821
+                    if whls[k + 1] < 0:
+                        A[k] -= whls[k + 1] * (a[k + 1] - a[k]) / dzh[k + 1]
+                    else:
+                        A[k] -= whls[k] * (a[k] - a[k - 1]) / dzh[k]
+        if self.lnudge:                                          # nudge
+            k0 = 1 + self.nnudge
+            if self.lnudgevel:
+                for name, tend, prof in (("u0", "up", self.uprof), ("v0", "vp", self.vprof)):
+                    A = acc(tend)[1]
+                    for k in range(k0, nz + 1):
+                        A[k] -= (av[name][k] - prof[k]) / self.tnudge
+            if self.ltempeq:
+                A = acc("thlp")[1]
+                for k in range(k0, nz + 1):
+                    A[k] -= (av["thl0"][k] - self.thlprof[k]) / self.tnudge
+        if self.igrw in (1, 2, 3):                               # grwdamp
+            tsc = self.tsc
+            for name, tend, geo in (("u0", "up", self.ug), ("v0", "vp", self.vg)):
+                _, A, B = acc(tend, name, 1)
+                for k in range(self.ksp, nz + 1):
+                    ref = geo[k] if self.igrw == 2 else av[name][k]
+                    A[k] += ref * tsc[k]
+                    B[k] -= tsc[k]
+                    if self.igrw == 1 and self.lcoriol:
+                        c = (1. / (self.geodamptime * 2.75e-3)) * tsc[k]
+                        A[k] += geo[k] * c
+                        B[k] -= c
+            _, A, B = acc("wp", "w0", 1)
+            for k in range(self.ksp, nz + 1):
+                B[k] -= tsc[k]
+            if self.ltempeq:
+                _, A, B = acc("thlp", "thl0", 1)
+                for k in range(self.ksp, nz + 1):
+                    A[k] += av["thl0"][k] * tsc[k]
+                    B[k] -= tsc[k]
+        return out
+
+    def averages(self):
+        names = ["u0", "v0"] + (["thl0"] if self.ltempeq else []) + [f"sv0_{n}" for n in range(self.core.nsv)]
+        return {n: self.core.slab_average(n) for n in names}
+
+    def update(self):
+        """Take the slab averages of the current state and register the tables for the next substep."""
+        if not self.active:
+            return {}
+        tabs = self.tables(self.averages())
+        for (tend, when), (src, A, B) in tabs.items():
+            self.core.set_level_forcing(tend, src, A[1:self.nz + 1], B[1:self.nz + 1], when)
+        return tabs
+
+
+def field_id(name: str) -> int:
+    if name in L.FIELD_IDS:
+        return L.FIELD_IDS[name]
+    kind, n = name.rsplit("_", 1)
+    return L.scalar_field({"sv0": L.SV0, "svm": L.SVM, "svp": L.SVP}[kind], int(n))
