@@ -1,0 +1,129 @@
+// One-equation (TKE) closure, &NAMSUBGRID loneeqn: closure branch src/modsubgrid.f90:363-400, sources :415-538,
+// the e120 floor ghost of `bottom` (src/modibm.f90:2012-2013).  e120 itself is transported as scalar slot 14
+// (advecc_2nd + diffe, udc_scalar.hip) and clipped in the integrate kernel (udc_pois.hip).
+#include "udc_internal.h"
+
+namespace {
+
+__device__ __forceinline__ int wrap(int i, int nx) { return i < 0 ? i + nx : (i >= nx ? i - nx : i); }
+
+inline dim3 cell_grid(const Geo &g, dim3 b) {
+  (void)b;
+  return dim3((unsigned)tile_grid(g).tiles * (unsigned)g.nz, 1, 1);
+}
+
+// ---- one-equation closure -------------------------------------------------------------------------
+struct TkeK { double cm, cn, ch1, ch2, ce1, ce2, grav_thvs, numol, prandtlmoli; int ldelta; };
+// dthvdz of calthv for dry air (src/modthermodynamics.f90:208-222, eps1 clamp :224-232): thl may be null (neutral)
+__device__ __forceinline__ double dthvdz_at(const Geo &g, const Metrics &m, const double *__restrict__ thl, long c, int k) {
+  const double eps1 = 1e-10;
+  double d = 0.;
+  if (thl && k >= 1) d = (thl[c + g.sz] - thl[c - g.sz]) / (m.dzh[k + 2] + m.dzh[k + 1]);
+  if (fabs(d) < eps1) d = copysign(eps1, d);
+  return d;
+}
+__device__ __forceinline__ double tke_zlt(const TkeK &t, double delta, double e, double dthvdz) {
+  if (t.ldelta || dthvdz <= 0) return delta;
+  return fmin(delta, t.cn * e / sqrt(t.grav_thvs * fabs(dthvdz)));
+}
+// closure, loneeqn branch: src/modsubgrid.f90:363-400 (damp = 1)
+__global__ __launch_bounds__(256) void tke_closure_kernel(Geo g, TileGrid tg, Metrics m, TkeK t, const double *__restrict__ e12,
+    const double *__restrict__ thl, double *__restrict__ ekm, double *__restrict__ ekh) {
+  int i, j, k;
+  if (!tile_decode(g, tg, i, j, k)) return;
+  const long c = g.idx(i, j, k);
+  const double delta = m.delta[k + 1];
+  const double e = e12[c];
+  const double dth = dthvdz_at(g, m, thl, c, k);
+  double em, eh;
+  if (t.ldelta || dth <= 0) {
+    em = t.cm * delta * 1. * e;
+    eh = (t.ch1 + t.ch2) * em;
+  } else {
+    const double zlt = fmin(delta, t.cn * e / sqrt(t.grav_thvs * fabs(dth)));
+    em = t.cm * zlt * 1. * e;
+    eh = (t.ch1 + t.ch2 * zlt / delta) * em;
+  }
+  ekm[c] = em + t.numol;
+  ekh[c] = eh + t.numol * t.prandtlmoli;
+}
+// sources, src/modsubgrid.f90:450-497: k = kb+1..ke (the lowest level gets no source: its sb* arrays are never
+// written in the reference)
+__global__ __launch_bounds__(256) void tke_sources_kernel(Geo g, TileGrid tg, Metrics m, TkeK t, const double *__restrict__ u0,
+    const double *__restrict__ v0, const double *__restrict__ w0, const double *__restrict__ e12, const double *__restrict__ thl,
+    const double *__restrict__ ekm, const double *__restrict__ ekh, double *__restrict__ e12p) {
+  int i, j, k;
+  if (!tile_decode(g, tg, i, j, k) || k < 1) return;
+  const long r0 = g.idx(0, j, k);
+  const long c = r0 + i, im = r0 + wrap(i - 1, g.nx), ip = r0 + wrap(i + 1, g.nx);
+  const long sy = g.sy, sz = g.sz;
+  const int kf = k + 1;
+  const double dxi = m.dxi, dyi = m.dyi, dzfi = m.dzfi[kf], hk = m.dzhi[kf], hkp = m.dzhi[kf + 1];
+  auto sq = [](double x) { return x * x; };
+  double tdef2 = 2. * (sq((u0[ip] - u0[c]) * dxi) + sq((v0[c + sy] - v0[c]) * dyi) + sq((w0[c + sz] - w0[c]) * dzfi));
+  tdef2 = tdef2 + 0.25 * (sq((w0[c + sz] - w0[im + sz]) * dxi + (u0[c + sz] - u0[c]) * hkp)
+                        + sq((w0[c] - w0[im]) * dxi + (u0[c] - u0[c - sz]) * hk)
+                        + sq((w0[ip] - w0[c]) * dxi + (u0[ip] - u0[ip - sz]) * hk)
+                        + sq((w0[ip + sz] - w0[c + sz]) * dxi + (u0[ip + sz] - u0[ip]) * hkp));
+  tdef2 = tdef2 + 0.25 * (sq((u0[c + sy] - u0[c]) * dyi + (v0[c + sy] - v0[im + sy]) * dxi)
+                        + sq((u0[c] - u0[c - sy]) * dyi + (v0[c] - v0[im]) * dxi)
+                        + sq((u0[ip] - u0[ip - sy]) * dyi + (v0[ip] - v0[c]) * dxi)
+                        + sq((u0[ip + sy] - u0[ip]) * dyi + (v0[ip + sy] - v0[c + sy]) * dxi));
+  tdef2 = tdef2 + 0.25 * (sq((v0[c + sz] - v0[c]) * hkp + (w0[c + sz] - w0[c - sy + sz]) * dyi)
+                        + sq((v0[c] - v0[c - sz]) * hk + (w0[c] - w0[c - sy]) * dyi)
+                        + sq((v0[c + sy] - v0[c + sy - sz]) * hk + (w0[c + sy] - w0[c]) * dyi)
+                        + sq((v0[c + sy + sz] - v0[c + sy]) * hkp + (w0[c + sy + sz] - w0[c + sz]) * dyi));
+  const double e = e12[c], delta = m.delta[kf];
+  const double dth = dthvdz_at(g, m, thl, c, k);
+  const double zlt = tke_zlt(t, delta, e, dth);
+  const double sbshr = (ekm[c] - t.numol) * tdef2 / (2 * e);
+  const double sbbuo = -(ekh[c] - t.numol * t.prandtlmoli) * t.grav_thvs * dth / (2 * e);
+  const double sbdiss = -2. * (t.ce1 + t.ce2 * zlt / delta) * (e * e) / (2. * 1. * zlt);
+  e12p[c] = e12p[c] + sbshr + sbbuo + sbdiss;
+}
+// `bottom`, src/modibm.f90:2012-2013: e120(kb-1) = e120(kb), e12m(kb-1) = e12m(kb), whole padded plane
+__global__ void tke_floor_kernel(Geo g, double *__restrict__ e0, double *__restrict__ em) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = (int)blockIdx.y - HY;
+  if (i >= g.nx) return;
+  const long c = g.idx(i, j, 0);
+  e0[c - g.sz] = e0[c];
+  em[c - g.sz] = em[c];
+}
+
+}  // namespace
+
+static TkeK tke_consts(udc_handle *h) {
+  return TkeK{h->tke.cm, h->tke.cn, h->tke.ch1, h->tke.ch2, h->tke.ce1, h->tke.ce2, h->tke.grav / h->tke.thvs,
+              h->p.numol, h->p.prandtlmoli, h->tke.ldelta};
+}
+static const double *thl_or_null(udc_handle *h) {
+  return ((int)h->fields.size() > UDC_THL0 && h->fields[UDC_THL0]) ? h->fields[UDC_THL0] : nullptr;
+}
+int k_tke_closure(udc_handle *h) {
+  const Geo &g = h->g;
+  dim3 b(64, 4, 1), gr = cell_grid(g, b);
+  PROF(h, "closure");
+  hipLaunchKernelGGL(tke_closure_kernel, gr, b, 0, h->stream, g, tile_grid(g), h->m, tke_consts(h), h->fields[UDC_E120],
+                     thl_or_null(h), h->fields[UDC_EKM], h->fields[UDC_EKH]);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+int k_tke_sources(udc_handle *h) {
+  const Geo &g = h->g;
+  dim3 b(64, 4, 1), gr = cell_grid(g, b);
+  PROF(h, "tke_sources");
+  hipLaunchKernelGGL(tke_sources_kernel, gr, b, 0, h->stream, g, tile_grid(g), h->m, tke_consts(h), h->fields[UDC_U0],
+                     h->fields[UDC_V0], h->fields[UDC_W0], h->fields[UDC_E120], thl_or_null(h), h->fields[UDC_EKM],
+                     h->fields[UDC_EKH], h->fields[UDC_E12P]);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+int k_tke_floor(udc_handle *h) {
+  const Geo &g = h->g;
+  PROF(h, "tke_floor");
+  hipLaunchKernelGGL(tke_floor_kernel, dim3((g.nx + 63) / 64, g.py), dim3(64), 0, h->stream, g, h->fields[UDC_E120], h->fields[UDC_E12M]);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
