@@ -79,7 +79,7 @@ struct Params {
   double z0;
 };
 
-struct ProfEntry { hipEvent_t a, b; int name; };
+struct ProfEntry { hipEvent_t a, b; int name; bool own_a; };
 
 struct udc_handle {
   udc_config cfg;
@@ -143,6 +143,8 @@ struct udc_handle {
   bool mom_simple = false;              // UDC_MOM_SIMPLE=1: use the direct-load momentum kernel
   bool prof = false;
   std::vector<ProfEntry> prof_events;
+  std::vector<hipEvent_t> prof_pool;
+  hipEvent_t prof_chain = nullptr;      // end marker of the previous profiled launch (start marker of the next)
   std::vector<std::string> prof_names;
   std::map<std::string, int> prof_ids;
   std::map<int, std::pair<double, int>> prof_acc;
@@ -188,8 +190,9 @@ void udc_set_error(const char *fmt, ...);
   } while (0)
 
 // kernel-launch bracket used for the optional HIP-event profile
+hipEvent_t prof_take(udc_handle *h);
 struct ProfScope {
-  udc_handle *h; int id; hipEvent_t a, b;
+  udc_handle *h; int id; hipEvent_t a, b; bool own_a = true;
   ProfScope(udc_handle *h_, const char *name);
   ~ProfScope();
 };

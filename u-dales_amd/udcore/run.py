@@ -1,0 +1,133 @@
+"""Command-line runner: the time loop of src/program.f90:126-222 over the device core.
+
+    python -m udcore.run namoptions.NNN [--steps N] [--restart-from NTRUN] [--device D] [--quiet]
+
+reads the deck (namoptions, prof.inp, lscale.inp) from the file's directory, cold-starts (or warm-starts from the
+reference's initd/inits restart files, &RUN lwarmstart / --restart-from), advances until `runtime` (or N full steps)
+with the reference's own time-step control (tstep_update, src/modtstep.f90:113-150: fixed dtmax, or adaptive with the
+Courant / diffusion numbers), and writes restart files in the reference's layout every `trestart` seconds of model
+time and at the end (src/modsave.f90:77-121).  Immersed boundaries (libm), moisture and non-periodic lateral
+boundaries are not available on the device path: such decks are refused with the reference's error convention.
+
+Multi-GPU: launch one process per GPU with torch.distributed.run; the y-slab decomposition follows WORLD_SIZE.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+
+def _refuse(msg):
+    sys.stderr.write(f" ERROR: {msg}\n")
+    raise SystemExit(1)
+
+
+def check_supported(deck):
+    g = deck.get
+    if g("RUN", "libm") and int(g("WALLS", "nfcts")) > 0:
+        _refuse("immersed boundaries (libm with facets) are not on the device path")
+    if g("PHYSICS", "lmoist"):
+        _refuse("the moisture equation (lmoist) is not on the device path")
+    if int(g("BC", "BCxm")) != 1 or int(g("BC", "BCym")) != 1:
+        _refuse("only periodic lateral boundaries (BCxm = BCym = 1) are on the device path")
+    if int(g("DYNAMICS", "ipoiss")) != 0 or int(g("BC", "BCzp")) != 1:
+        _refuse("only ipoiss = 0 (FFT in x, y) with BCzp = 1 is on the device path")
+    if int(g("RUN", "nprocx")) != 1:
+        _refuse("the device path decomposes in y only: set nprocx = 1")
+
+
+def courant_default(deck):
+    """src/modglobal.f90:563-577."""
+    c = float(deck.get("RUN", "courant"))
+    if c >= 0:
+        return c
+    c = 1.5
+    kappa_used = int(deck.get("SCALARS", "nsv")) > 0 or int(deck.get("DYNAMICS", "iadv_thl")) == 7
+    return min(c, 1.1) if kappa_used else c
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="python -m udcore.run", description=__doc__.split("\n\n")[0])
+    ap.add_argument("namoptions")
+    ap.add_argument("--steps", type=int, default=0, help="stop after this many full time steps (default: run to `runtime`)")
+    ap.add_argument("--restart-from", type=int, default=-1, metavar="NTRUN",
+                    help="warm start from initd<NTRUN>_000_<rank>.<expnr> in the deck's directory")
+    ap.add_argument("--device", type=int, default=None)
+    ap.add_argument("--quiet", action="store_true")
+    args = ap.parse_args(argv)
+
+    from . import cold_start, from_deck, read_deck
+    from . import restart as R
+    from .forcings import LevelForcings
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    device = args.device if args.device is not None else int(os.environ.get("LOCAL_RANK", "0"))
+    deck = read_deck(args.namoptions)
+    check_supported(deck)
+    wdir = os.path.dirname(os.path.abspath(args.namoptions))
+    core = from_deck(deck, device=device, rank=rank, nranks=world)
+    if world > 1:
+        import ctypes
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(device)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            buf = (ctypes.c_ubyte * 128)()
+            core.lib.udc_comm_unique_id(buf)
+            idt = torch.tensor(list(buf), dtype=torch.uint8, device="cuda")
+        dist.broadcast(idt, 0)
+        core.comm_init(bytes(idt.cpu().tolist()))
+    iexp = int(deck.get("RUN", "iexpnr"))
+    dtmax = float(deck.get("RUN", "dtmax"))
+    runtime = float(deck.get("RUN", "runtime"))
+    trestart = float(deck.get("RUN", "trestart"))
+    ladaptive = bool(deck.get("RUN", "ladaptive"))
+    courant, diffnr = courant_default(deck), float(deck.get("RUN", "diffnr"))
+    nyl = core.g.ny // world
+    if args.restart_from >= 0:
+        timee, dt = R.load_restart(core, wdir, iexp, args.restart_from, rank=rank)
+        ntrun = args.restart_from
+    else:
+        core.load_state(cold_start(core.g, deck, j0=rank * nyl, nyl=nyl, nsv=core.nsv))
+        core.halos()
+        core.boundary()
+        timee, ntrun = 0., 0
+        dt = dtmax if not ladaptive else dtmax / 100.          # src/modstartup.f90:1099, 2038
+    core.dt, core.timee, core.rk3step = dt, timee, 0
+    forcings = LevelForcings(core, deck)
+    tnext = timee + trestart
+    t_end = timee + runtime
+    say = (lambda *a: None) if (args.quiet or rank) else (lambda *a: print(*a, flush=True))
+    say(f"udcore.run: {core.g.nx}x{core.g.ny}x{core.g.nz} cells on {world} GPU(s), dtmax = {dtmax}, runtime = {runtime}")
+    t0, nsteps = time.perf_counter(), 0
+    while core.timee < t_end - 1e-12 and (args.steps <= 0 or nsteps < args.steps):
+        for _ in range(3):                                     # one full RK3 step
+            rk, dt = core.tstep_update(dtmax, ladaptive, courant, diffnr)
+            forcings.update()
+            core.substep(rk, dt, with_forces=True)
+        nsteps += 1
+        ntrun += 1
+        if core.timee >= tnext:                                # writerestartfiles, src/modsave.f90:77
+            tnext += trestart
+            R.save_restart(core, wdir, iexp, ntrun, core.timee, core.dt, rank=rank, fill={"thl0": deck.thl[0]})
+            say(f"  restart files written at ntrun = {ntrun}, timee = {core.timee:.6f}")
+        if nsteps % 50 == 0:
+            divmax, _ = core.divergence()
+            say(f"  step {nsteps}: timee = {core.timee:.4f} dt = {core.dt:.5f} divmax = {divmax:.2e}")
+    core.sync()
+    wall = time.perf_counter() - t0
+    divmax, _ = core.divergence()
+    paths = R.save_restart(core, wdir, iexp, ntrun, core.timee, core.dt, rank=rank, fill={"thl0": deck.thl[0]})
+    cells = core.g.nx * core.g.ny * core.g.nz
+    say(f"udcore.run: {nsteps} steps to timee = {core.timee:.6f} in {wall:.2f} s "
+        f"({cells * 3 * nsteps / max(wall, 1e-9):.3e} cell-updates/s), divmax = {divmax:.2e}; restart: {os.path.basename(paths[0])}")
+    core.close()
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())
