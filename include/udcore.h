@@ -43,7 +43,9 @@ enum {
   /* temperature equation (ltempeq): thl0, thlm, thlp live in scalar slot 15 (so nsv <= 15 with ltempeq) */
   UDC_THL0 = UDC_SV0 + 3 * 15, UDC_THLM = UDC_SVM + 3 * 15, UDC_THLP = UDC_SVP + 3 * 15,
   /* one-equation closure (loneeqn): e120, e12m, e12p live in scalar slot 14 (so nsv <= 14 with loneeqn) */
-  UDC_E120 = UDC_SV0 + 3 * 14, UDC_E12M = UDC_SVM + 3 * 14, UDC_E12P = UDC_SVP + 3 * 14
+  UDC_E120 = UDC_SV0 + 3 * 14, UDC_E12M = UDC_SVM + 3 * 14, UDC_E12P = UDC_SVP + 3 * 14,
+  /* moisture (lmoist): qt0, qtm, qtp live in scalar slot 13 (so nsv <= 13 with lmoist) */
+  UDC_QT0 = UDC_SV0 + 3 * 13, UDC_QTM = UDC_SVM + 3 * 13, UDC_QTP = UDC_SVP + 3 * 13
 };
 
 /* SGS closure selector: &NAMSUBGRID lsmagorinsky / lvreman (src/modsubgriddata.f90:39-42),
@@ -106,11 +108,18 @@ int udc_set_forcing(udc_handle *h, const double *dpdxl, const double *dpdyl, int
  * src/modibm.f90:2035-2047) conditions like the passive scalars.  udc_set_buoyancy switches on forces' buoyancy
  * term for dry air (lbuoyancy, src/modforces.f90:73-84): wp += grav (thv0h - thvh)/thvh with thv0h = thl0h of
  * calc_halflev and thvh its slab average (src/modthermodynamics.f90:76,208,518-524), applied by udc_forces and
- * inside udc_substep.  Moisture (lmoist) is not built.
+ * inside udc_substep.
  * Call once after udc_create, before the first substep.  thlpcar (udc_set_thl_source, [ktot] = thlpcar(kb:ke), the
  * radiative tendency of src/modforces.f90:104-110) is optional. */
 int udc_set_tempeq(udc_handle *h, int iadv_thl, int bctopt, double wttop, double thl_top, int bcbott, double wtsurf);
 int udc_set_thl_source(udc_handle *h, const double *thlpcar, int n);
+/* Total water, &PHYSICS lmoist (src/modglobal.f90:402): qt is advected (iadv_qt = 2 -> advecc_2nd,
+ * src/modadvection.f90:78-86), diffused (diffc with ekh, src/modsubgrid.f90:147), integrated
+ * (src/modtstep.f90:256) and given its top (BCtopq 1 = flux wqtop, 2 = value qt_top, src/modboundary.f90:222-231)
+ * and floor (lbottom, BCbotq 1 = flux, "+ wqsurf" as the reference has it, src/modibm.f90:2050-2066) conditions.
+ * The condensate and the moist buoyancy (thermo / diagfld of src/modthermodynamics.f90) are not built: with
+ * lmoist, udc_set_buoyancy(lbuoyancy = 1) is refused. */
+int udc_set_moisture(udc_handle *h, int iadv_qt, int bctopq, double wqtop, double qt_top, int bcbotq, double wqsurf);
 int udc_set_buoyancy(udc_handle *h, int lbuoyancy, double grav);
 
 /* One-equation (TKE) closure, &NAMSUBGRID loneeqn (src/modsubgrid.f90:363-400): switches the closure to

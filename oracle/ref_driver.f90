@@ -34,7 +34,7 @@ program ref_driver
   use modglobal
   use modfields
   use modsubgriddata
-  use modsurfdata, only: thl_top, wttop, wsvtop, sv_top, thvs, thls, z0, wtsurf, qts
+  use modsurfdata, only: thl_top, wttop, wsvtop, sv_top, thvs, thls, z0, wtsurf, qts, wqtop, qt_top, wqsurf, ps
   use modwallfunctions, only: wfmneutral
   use modboundary, only: initboundary, boundary, halos, grwdamp
   use modthermodynamics, only: initthermodynamics, thermodynamics
@@ -86,7 +86,7 @@ program ref_driver
   call initpois
   call cold_start
   call boundary
-  need_thermo = ltempeq .or. loneeqn .or. lnudge .or. igrw_damp /= 0 .or. any(whls /= 0.)
+  need_thermo = ltempeq .or. lmoist .or. loneeqn .or. lnudge .or. igrw_damp /= 0 .or. any(whls /= 0.)
   if (need_thermo) call thermodynamics            ! src/program.f90:120 (thv0h, thvh; dthvdz; diagfld's slab averages)
 
   iu = 71
@@ -208,6 +208,22 @@ contains
         end do
       end do
     end if
+    if (lmoist) then                       ! src/modibm.f90:2050-2066, BCbotq = 1 (flux)
+      if (BCbotq /= 1) then
+        write (0, *) 'ERROR: bottom boundary type for moisture undefined'
+        stop 1
+      end if
+      do j = jb, je
+        do i = ib, ie
+          qtp(i, j, kb) = qtp(i, j, kb) + ( &
+                          0.5*(dzf(kb - 1)*ekh(i, j, kb) + dzf(kb)*ekh(i, j, kb - 1)) &
+                          *(qt0(i, j, kb) - qt0(i, j, kb - 1)) &
+                          *dzh2i(kb) &
+                          + wqsurf &
+                          )*dzfi(kb)
+        end do
+      end do
+    end if
     if (nsv > 0) then
       if (BCbots /= 1) then
         write (0, *) 'ERROR: bottom boundary type for scalars undefined'
@@ -239,7 +255,8 @@ contains
     namelist /PHYSICS/ lmoist, lcoriol, lbuoyancy, ltempeq, lprofforc, dpdx, luvolflowr, uflowrate, &
       lvvolflowr, vflowrate, igrw_damp, geodamptime, lnudge, lnudgevel, tnudge, nnudge
     namelist /DYNAMICS/ ipoiss, iadv_mom, iadv_tke, iadv_thl, iadv_qt, iadv_sv
-    namelist /BC/ BCxm, BCym, BCtopm, BCtopT, BCtops, BCbotm, BCbots, BCbotT, BCzp, wttop, thl_top, z0, wtsurf, thls, qts
+    namelist /BC/ BCxm, BCym, BCtopm, BCtopT, BCtops, BCbotm, BCbots, BCbotT, BCzp, wttop, thl_top, z0, wtsurf, thls, qts, &
+      BCtopq, BCbotq, wqtop, qt_top, wqsurf, ps
     namelist /SCALARS/ nsv
     namelist /WALLS/ nfcts, lbottom
     open (ifnamopt, file=fname_options, status='old', iostat=ierr)
@@ -481,6 +498,10 @@ contains
       call put3(tag//'.thl0', thl0, (/ib - ih, jb - jh, kb - kh/))
       call put3(tag//'.thlm', thlm, (/ib - ih, jb - jh, kb - kh/))
     end if
+    if (lmoist) then
+      call put3(tag//'.qt0', qt0, (/ib - ih, jb - jh, kb - kh/))
+      call put3(tag//'.qtm', qtm, (/ib - ih, jb - jh, kb - kh/))
+    end if
     do n = 1, nsv
       write (cn, '(i2.2)') n
       call put3(tag//'.sv0_'//cn, sv0(:, :, :, n), (/ib - ihc, jb - jhc, kb - khc/))
@@ -497,6 +518,7 @@ contains
     call put3(tag//'.wp', wp, (/ib - ih, jb - jh, kb/))
     if (ltempeq) call put3(tag//'.thlp', thlp, (/ib - ih, jb - jh, kb/))
     if (loneeqn) call put3(tag//'.e12p', e12p, (/ib - ih, jb - jh, kb/))
+    if (lmoist) call put3(tag//'.qtp', qtp, (/ib - ih, jb - jh, kb/))
     do n = 1, nsv
       write (cn, '(i2.2)') n
       call put3(tag//'.svp_'//cn, svp(:, :, :, n), (/ib - ihc, jb - jhc, kb/))
@@ -512,19 +534,20 @@ contains
     call dump_tend('in')                    ! (tendencies are zero here)
     call advection                          ! src/modadvection.f90:36
     call dump_tend('adv')
-    up = 0.; vp = 0.; wp = 0.; svp = 0.; thlp = 0.; e12p = 0.
+    up = 0.; vp = 0.; wp = 0.; svp = 0.; thlp = 0.; e12p = 0.; qtp = 0.
     call subgrid                            ! src/modsubgrid.f90:128 (closure+closurebc+diff*)
     call put3('sub.ekm', ekm, (/ib - ih, jb - jh, kb - kh/))
     call put3('sub.ekh', ekh, (/ib - ih, jb - jh, kb - kh/))
     call put3('sub.u0', u0, (/ib - ih, jb - jh, kb - kh/))   ! top ghost row rewritten by closurebc
     if (ltempeq) call put3('sub.thl0', thl0, (/ib - ih, jb - jh, kb - kh/))
+    if (lmoist) call put3('sub.qt0', qt0, (/ib - ih, jb - jh, kb - kh/))
     call dump_tend('sub')
     if (lbottom) then                       ! floor wall function on top of the subgrid tendencies
       call floor_bottom
       call dump_tend('bot')
     end if
     ! full tendency = advection + subgrid + forces, as the driver would have it
-    up = 0.; vp = 0.; wp = 0.; svp = 0.; thlp = 0.; e12p = 0.
+    up = 0.; vp = 0.; wp = 0.; svp = 0.; thlp = 0.; e12p = 0.; qtp = 0.
     call advection
     call subgrid
     call floor_bottom
@@ -538,6 +561,7 @@ contains
       call dump_tend('lsf')
       call put1('u0av', u0av(kb:ke + kh), kb)
       call put1('thl0av', thl0av(kb:ke + kh), kb)
+      if (lmoist) call put1('qt0av', qt0av(kb:ke + kh), kb)
     end if
     if (luvolflowr .or. lvvolflowr) call dump_tend('frc')   ! tendencies masscorr starts from
     call masscorr

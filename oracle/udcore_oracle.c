@@ -903,17 +903,31 @@ void orc_diffc_m(const orc_grid *g, const double *c, const double *ekh, double *
       }
   metrics_free(&m);
 }
-/* top condition of thl: fluxtop (src/modboundary.f90:1494-1507) / valuetop (:1509-1519), BCtopT 1 / 2 */
-void orc_thl_top(const orc_grid *g, const double *ekh, double *a) {
+/* top condition of thl / qt: fluxtop (src/modboundary.f90:1494-1507) / valuetop (:1509-1519), BCtopT, BCtopq 1 / 2 */
+static void scalar_top(const orc_grid *g, const double *ekh, double *a, int bctop, double wtop, double top_value) {
   const int ke = g->nz;
   const double eps1 = 1e-10;                      /* src/modglobal.f90:318 */
   for (int j = 0; j <= g->ny + 1; ++j)
     for (int i = 0; i <= g->nx + 1; ++i) {
-      if (g->bctopt == 2) M(a, i, j, ke + 1) = 2 * g->thl_top - M(a, i, j, ke);
-      else if (fabs(g->wttop) <= eps1) M(a, i, j, ke + 1) = M(a, i, j, ke);
-      else M(a, i, j, ke + 1) = M(a, i, j, ke) + g->dzh[ke + 1] * g->wttop /
+      if (bctop == 2) M(a, i, j, ke + 1) = 2 * top_value - M(a, i, j, ke);
+      else if (fabs(wtop) <= eps1) M(a, i, j, ke + 1) = M(a, i, j, ke);
+      else M(a, i, j, ke + 1) = M(a, i, j, ke) + g->dzh[ke + 1] * wtop /
                ((1. / g->dzh[ke + 1]) * (0.5 * (g->dzf[ke] * M(ekh, i, j, ke + 1) + g->dzf[ke + 1] * M(ekh, i, j, ke))));
     }
+}
+void orc_thl_top(const orc_grid *g, const double *ekh, double *a) { scalar_top(g, ekh, a, g->bctopt, g->wttop, g->thl_top); }
+/* src/modboundary.f90:222-231 */
+void orc_qt_top(const orc_grid *g, const double *ekh, double *a) { scalar_top(g, ekh, a, g->bctopq, g->wqtop, g->qt_top); }
+/* floor of qt in `bottom`, BCbotq = 1: src/modibm.f90:2050-2061 (the flux enters with a plus sign there) */
+void orc_qt_floor(const orc_grid *g, const double *ekh, const double *qt0, double *qtp) {
+  if (!g->lbottom) return;
+  metrics m; metrics_init(g, &m);
+  const double *dzf = g->dzf;
+  for (int j = 1; j <= g->ny; ++j)
+    for (int i = 1; i <= g->nx; ++i)
+      M(qtp, i, j, 1) = M(qtp, i, j, 1) + (0.5 * (dzf[0] * M(ekh, i, j, 1) + dzf[1] * M(ekh, i, j, 0))
+                                           * (M(qt0, i, j, 1) - M(qt0, i, j, 0)) * m.dzh2i[1] + g->wqsurf) * m.dzfi[1];
+  metrics_free(&m);
 }
 /* floor of thl in `bottom`, BCbotT = 1: src/modibm.f90:2035-2047 */
 void orc_thl_floor(const orc_grid *g, const double *ekh, const double *thl0, double *thlp) {
@@ -1123,6 +1137,7 @@ void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
   orc_advecw_2nd(g, s->u0, s->v0, s->w0, s->pres0, s->wp);
   if (g->sgs == 3) orc_advecc_2nd(g, s->u0, s->v0, s->w0, s->e120, s->e12p);              /* src/modadvection.f90:56-58 */
   if (g->ltempeq) orc_advecc_2nd(g, s->u0, s->v0, s->w0, s->thl0, s->thlp);              /* src/modadvection.f90:66-68 */
+  if (g->lmoist) orc_advecc_2nd(g, s->u0, s->v0, s->w0, s->qt0, s->qtp);                 /* src/modadvection.f90:78-86 */
   for (int n = 0; n < g->nsv; ++n) orc_advecc_kappa(g, s->u0, s->v0, s->w0, s->sv0 + n * nc, s->svp + n * nc);
   if (g->sgs == 3) orc_closure_tke(g, s->e120, g->ltempeq ? s->thl0 : NULL, s->ekm, s->ekh);
   else orc_closure(g, s->u0, s->v0, s->w0, s->ekm, s->ekh);
@@ -1140,11 +1155,13 @@ void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
     }
   }
   if (g->ltempeq && g->bctopt != 2) { orc_thl_top(g, s->ekh, s->thlm); orc_thl_top(g, s->ekh, s->thl0); }   /* :417-420 */
+  if (g->lmoist && g->bctopq != 2) { orc_qt_top(g, s->ekh, s->qtm); orc_qt_top(g, s->ekh, s->qt0); }         /* :422-425 */
   orc_diffu(g, s->u0, s->v0, s->w0, s->ekm, s->up);
   orc_diffv(g, s->u0, s->v0, s->w0, s->ekm, s->vp);
   orc_diffw(g, s->u0, s->v0, s->w0, s->ekm, s->wp);
   if (g->sgs == 3) orc_diffe(g, s->e120, s->ekm, s->e12p);                               /* src/modsubgrid.f90:144 */
   if (g->ltempeq) orc_diffc_m(g, s->thl0, s->ekh, s->thlp);                              /* src/modsubgrid.f90:146 */
+  if (g->lmoist) orc_diffc_m(g, s->qt0, s->ekh, s->qtp);                                 /* src/modsubgrid.f90:147 */
   for (int n = 0; n < g->nsv; ++n) orc_diffc(g, s->sv0 + n * nc, s->ekh, s->svp + n * nc);
   if (g->sgs == 3) {
     orc_sources(g, s->u0, s->v0, s->w0, s->e120, g->ltempeq ? s->thl0 : NULL, s->ekm, s->ekh, s->e12p);   /* :151 */
@@ -1153,6 +1170,7 @@ void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
   }
   orc_bottom(g, s->u0, s->v0, s->ekm, s->ekh, s->sv0, s->up, s->vp, s->svp, NULL);   /* src/program.f90:152 */
   if (g->ltempeq) orc_thl_floor(g, s->ekh, s->thl0, s->thlp);
+  if (g->lmoist) orc_qt_floor(g, s->ekh, s->qt0, s->qtp);
   if (s->dpdxl && g->coriolis_mode) orc_coriolis(g, s->u0, s->v0, s->w0, s->ug, s->up, s->vp, s->wp);   /* src/program.f90:158 */
   if (s->dpdxl) orc_forces(g, s->dpdxl, s->dpdyl, s->up, s->vp, s->wp);
   if (s->dpdxl && g->ltempeq) orc_buoyancy(g, s->thl0, s->wp);
@@ -1192,9 +1210,20 @@ void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
     if (rk3step == 3) memcpy(s->thlm, s->thl0, nm * sizeof(double));
     orc_halos_m(g, s->thl0); orc_halos_m(g, s->thlm);
   }
+  if (g->lmoist) {                                                                       /* src/modtstep.f90:256,328,337 */
+    const size_t nm = msize(g);
+    const double rk3c = dt / (4. - (double)rk3step);
+    for (int k = 1; k <= g->nz; ++k)
+      for (int j = 1; j <= g->ny; ++j)
+        for (int i = 1; i <= g->nx; ++i) M(s->qt0, i, j, k) = M(s->qtm, i, j, k) + rk3c * M(s->qtp, i, j, k);
+    memset(s->qtp, 0, nm * sizeof(double));
+    if (rk3step == 3) memcpy(s->qtm, s->qt0, nm * sizeof(double));
+    orc_halos_m(g, s->qt0); orc_halos_m(g, s->qtm);
+  }
   orc_halos_m(g, s->u0); orc_halos_m(g, s->v0); orc_halos_m(g, s->w0);
   orc_halos_m(g, s->um); orc_halos_m(g, s->vm); orc_halos_m(g, s->wm);
   for (int n = 0; n < g->nsv; ++n) { orc_halos_c(g, s->sv0 + n * nc); orc_halos_c(g, s->svm + n * nc); }
   orc_boundary(g, s->u0, s->v0, s->w0, s->um, s->vm, s->wm, s->sv0, s->svm);
   if (g->ltempeq) { orc_thl_top(g, s->ekh, s->thlm); orc_thl_top(g, s->ekh, s->thl0); }     /* src/modboundary.f90:207-217 */
+  if (g->lmoist) { orc_qt_top(g, s->ekh, s->qtm); orc_qt_top(g, s->ekh, s->qt0); }          /* src/modboundary.f90:222-231 */
 }

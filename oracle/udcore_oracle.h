@@ -52,6 +52,9 @@ typedef struct {
   /* one-equation closure (sgs = 3, loneeqn): constants of initsubgrid src/modsubgrid.f90:63-71 */
   double cm, cn, ch1, ch2, ce1, ce2, thvs;
   int ldelta;
+  int lmoist;               /* total water transported, iadv_qt = 2 (src/modglobal.f90:402) */
+  int bctopq;               /* BCtopq: 1 flux wqtop, 2 value qt_top (src/modglobal.f90:147-155) */
+  double wqtop, qt_top, wqsurf;    /* src/modsurfdata.f90:65,83,84 */
 } orc_grid;
 
 /* ---- advection: src/modadvection.f90 */
@@ -84,6 +87,8 @@ void orc_bottom(const orc_grid *g, const double *u0, const double *v0, const dou
 void orc_advecc_2nd(const orc_grid *g, const double *u0, const double *v0, const double *w0, const double *c, double *cp);
 void orc_diffc_m(const orc_grid *g, const double *c, const double *ekh, double *cp);
 void orc_thl_top(const orc_grid *g, const double *ekh, double *a);
+void orc_qt_top(const orc_grid *g, const double *ekh, double *a);
+void orc_qt_floor(const orc_grid *g, const double *ekh, const double *qt0, double *qtp);
 void orc_buoyancy(const orc_grid *g, const double *thl0, double *wp);
 void orc_thl_floor(const orc_grid *g, const double *ekh, const double *thl0, double *thlp);
 /* ---- one-equation closure: src/modsubgrid.f90:363-400 (closure), :627-669 (diffe), :415-538 (sources) */
@@ -121,6 +126,7 @@ typedef struct {
   const double *thlpcar;                  /* [nz+2] or NULL */
   const double *ug;                       /* [nz+2] geostrophic wind (lprofforc) or NULL */
   double *e120, *e12m, *e12p;             /* m-arrays, used when g->sgs == 3 */
+  double *qt0, *qtm, *qtp;                /* m-arrays, used when g->lmoist */
 } orc_state;
 void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt);
 

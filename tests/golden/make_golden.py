@@ -87,25 +87,26 @@ def zlevels(nz, dz0=0.5, stretch=1.0):
     return zf
 
 
-def write_case(d, iexpnr, text, zf, u=1.0, v=0.0, pgx=1e-4, dthl=0.0, dthlrad=0.0, ug=0.0, tke=0.0, wtop=0.0):
+def write_case(d, iexpnr, text, zf, u=1.0, v=0.0, pgx=1e-4, dthl=0.0, dthlrad=0.0, ug=0.0, tke=0.0, wtop=0.0, qt=0.0, dqt=0.0, dqtdx=0.0, dqtdy=0.0, dqtdt=0.0):
     with open(os.path.join(d, f"namoptions.{iexpnr:03d}"), "w") as f:
         f.write(text)
     with open(os.path.join(d, f"prof.inp.{iexpnr:03d}"), "w") as f:
         f.write("# golden\n# z thl qt u v tke\n")
         for z in zf:
-            f.write(f"{z:.15f} {288.0 + dthl * z!r} 0.0 {u} {v} {tke!r}\n")
+            f.write(f"{z:.15f} {288.0 + dthl * z!r} {(qt + dqt * z) if (qt or dqt) else 0.0!r} {u} {v} {tke!r}\n")
     with open(os.path.join(d, f"lscale.inp.{iexpnr:03d}"), "w") as f:
         f.write("# golden\n# z uq vq pqx pqy wfls dqtdxls dqtdyls dqtdtls dthlrad\n")
         for z in zf:
             wf = wtop * z / zf[-1] if wtop else 0.0
-            f.write(f"{z:.15f} {ug!r} 0.0 {pgx} 0.0 {wf!r} 0.0 0.0 0.0 {dthlrad!r}\n")
+            f.write(f"{z:.15f} {ug!r} 0.0 {pgx} 0.0 {wf!r} {dqtdx!r} {dqtdy!r} {dqtdt!r} {dthlrad!r}\n")
 
 
 KEEP_KERNELS = ("meta dzf dzh zf dpdxl dpdyl rk3 in.u0 in.v0 in.w0 in.um in.vm in.wm in.pres0 "
                 "in.ekm in.ekh adv.up adv.vp adv.wp sub.ekm sub.ekh sub.u0 sub.up sub.vp sub.wp bot.up bot.vp frc.up frc.vp "
                 "in.thl0 in.thlm adv.thlp sub.thlp sub.thl0 bot.thlp pre.thlp out.thl0 out.thlm "
+                "in.qt0 in.qtm adv.qtp sub.qtp sub.qt0 bot.qtp pre.qtp out.qt0 out.qtm "
                 "in.e120 in.e12m adv.e12p sub.e12p pre.e12p out.e120 out.e12m "
-                "frc0.up frc0.vp frc0.wp frc0.thlp lsf.up lsf.vp lsf.wp lsf.thlp u0av thl0av "
+                "frc0.up frc0.vp frc0.wp frc0.thlp lsf.up lsf.vp lsf.wp lsf.thlp u0av thl0av frc0.qtp lsf.qtp qt0av "
                 "pre.up pre.vp pre.wp poi.p poi.pres0 poi.up poi.vp poi.wp out.u0 out.v0 out.w0 "
                 "out.um out.pres0").split()
 
@@ -182,7 +183,30 @@ CASES.update({
                               "nnudge = 3\nigrw_damp = 1\nlcoriol = .true.",
                               bc="BCtopT = 2\nthl_top = 295.\nthls = 288.0\nqts = 0.0", oracle="nsub = 6\ndump_at = 3, 6"), 1.04),
 })
-THL_CASES = {"k_lsf_12x8x24": dict(dthl=0.3, ug=1.05, wtop=0.02), "run_lsf_16x8x24s": dict(dthl=0.25, ug=0.95, wtop=-0.03), "k_tke_12x8x6": dict(tke=0.05), "k_tke_thl_12x8x6": dict(tke=0.08, dthl=0.3), "k_coriol_12x8x6": dict(ug=1.1), "run_profforc_16x16x8": dict(ug=1.3), "k_thl_12x8x6": dict(dthl=0.4, dthlrad=2e-3), "run_thl_16x8x12s": dict(dthl=0.25, dthlrad=-1e-3),
+CASES.update({
+    # total water (lmoist) as a transported field: advecc_2nd + diffc, floor flux wqsurf, top flux wqtop / top value qt_top
+    "k_qt_12x8x6": ("kernels", 32, 12, 8, 6,
+                    dict(sgs="vreman", floor=True, physics="lmoist = .true.\nltempeq = .true.\nlbuoyancy = .false.",
+                         bc="BCtopT = 1\nBCbotT = 1\nwtsurf = 0.01\nthls = 288.0\nqts = 0.008\n"
+                            "BCtopq = 1\nwqtop = -1.e-5\nBCbotq = 1\nwqsurf = 2.e-5", oracle="nspin = 3"), 1.04),
+    "run_qt_16x8x12s": ("run", 33, 16, 8, 12,
+                        dict(sgs="smag", nsv=1, floor=True, physics="lmoist = .true.\nltempeq = .true.\nlbuoyancy = .false.",
+                             bc="BCtopT = 2\nthl_top = 290.5\nBCbotT = 1\nwtsurf = 0.02\nthls = 288.0\nqts = 0.008\n"
+                                "BCtopq = 2\nqt_top = 0.004\nBCbotq = 1\nwqsurf = 3.e-5",
+                             oracle="nsub = 6\ndump_at = 3, 6"), 1.06),
+})
+CASES.update({
+    # lstend / nudge / grwdamp acting on total water, with large-scale moisture gradients and tendency
+    "k_lsfq_12x8x20": ("kernels", 34, 12, 8, 20,
+                       dict(sgs="vreman", physics="lmoist = .true.\nltempeq = .true.\nlbuoyancy = .false.\nlnudge = .true.\n"
+                            "tnudge = 45.\nnnudge = 1\nigrw_damp = 3",
+                            bc="BCtopT = 2\nthl_top = 295.\nthls = 288.0\nqts = 0.008\nBCtopq = 2\nqt_top = 0.002",
+                            oracle="nspin = 3"), 1.03),
+})
+LSF_ONLY = ("k_lsfq_12x8x20",)
+THL_CASES = {"k_lsfq_12x8x20": dict(dthl=0.3, ug=1.0, wtop=0.025, qt=0.008, dqt=-3e-4, dqtdx=2e-7, dqtdy=-1e-7, dqtdt=3e-8),
+             "k_qt_12x8x6": dict(dthl=0.3, qt=0.008, dqt=-4e-4), "run_qt_16x8x12s": dict(dthl=0.25, qt=0.007, dqt=-2e-4),
+             "k_lsf_12x8x24": dict(dthl=0.3, ug=1.05, wtop=0.02), "run_lsf_16x8x24s": dict(dthl=0.25, ug=0.95, wtop=-0.03), "k_tke_12x8x6": dict(tke=0.05), "k_tke_thl_12x8x6": dict(tke=0.08, dthl=0.3), "k_coriol_12x8x6": dict(ug=1.1), "run_profforc_16x16x8": dict(ug=1.3), "k_thl_12x8x6": dict(dthl=0.4, dthlrad=2e-3), "run_thl_16x8x12s": dict(dthl=0.25, dthlrad=-1e-3),
              "k_buoy_12x8x6": dict(dthl=0.3), "run_buoy_16x8x12s": dict(dthl=0.2)}
 
 
@@ -246,9 +270,13 @@ def main():
         if mode == "kernels":
             keep = {k: v for k, v in d.items()
                     if k in KEEP_KERNELS or ".sv" in k}
+            if name in LSF_ONLY:      # only what tests/test_level_forcings.py reads
+                keep = {k: v for k, v in keep.items() if k.count(".") == 0 or k.startswith(("frc0.", "lsf."))
+                        or k in ("in.v0", "in.w0", "in.um", "in.vm", "in.wm", "in.pres0", "sub.u0", "sub.thl0", "in.thlm",
+                                 "sub.qt0", "in.qtm")}
         else:
             keep = {k: v for k, v in d.items()
-                    if k.count(".") == 0 or k.split(".")[1] in ("u0", "v0", "w0", "pres0", "um", "thl0", "thlm", "e120", "e12m")
+                    if k.count(".") == 0 or k.split(".")[1] in ("u0", "v0", "w0", "pres0", "um", "thl0", "thlm", "e120", "e12m", "qt0", "qtm")
                     or (k.startswith("s000.") and not k.startswith("s000.ek")) or ".sv0" in k}
             # (s000.ekm/ekh are dumped before the first closure call: uninitialised memory, not data)
         tmpf = os.path.join(HERE, name + ".bin")

@@ -32,13 +32,16 @@ class OrcGrid(C.Structure):
                 ("wtsurf", C.c_double), ("lbuoyancy", C.c_int),
                 ("coriolis_mode", C.c_int), ("om22", C.c_double), ("om23", C.c_double),
                 ("cm", C.c_double), ("cn", C.c_double), ("ch1", C.c_double), ("ch2", C.c_double),
-                ("ce1", C.c_double), ("ce2", C.c_double), ("thvs", C.c_double), ("ldelta", C.c_int)]
+                ("ce1", C.c_double), ("ce2", C.c_double), ("thvs", C.c_double), ("ldelta", C.c_int),
+                ("lmoist", C.c_int), ("bctopq", C.c_int), ("wqtop", C.c_double), ("qt_top", C.c_double),
+                ("wqsurf", C.c_double)]
 
 
 class OrcState(C.Structure):
     _fields_ = [(n, DP) for n in ("u0", "v0", "w0", "um", "vm", "wm", "up", "vp", "wp", "pres0",
                                   "ekm", "ekh", "p", "pup", "pvp", "pwp", "sv0", "svm", "svp",
-                                  "dpdxl", "dpdyl", "thl0", "thlm", "thlp", "thlpcar", "ug", "e120", "e12m", "e12p")]
+                                  "dpdxl", "dpdyl", "thl0", "thlm", "thlp", "thlpcar", "ug", "e120", "e12m", "e12p",
+                                  "qt0", "qtm", "qtp")]
 
 
 def build():
@@ -72,7 +75,8 @@ class Oracle:
                  prandtlmoli=1. / 0.71, prandtli=1. / 0.333, c_vreman=0.07, csz=None,
                  uinf=0., vinf=0., lbottom=False, z0=0.05, luvolflowr=False, uflowrate=0.,
                  lvvolflowr=False, vflowrate=0., ltempeq=False, bctopt=1, wttop=0., thl_top=-1., wtsurf=-1.,
-                 lbuoyancy=False, coriolis_mode=0, om22=0., om23=0., tke=None):
+                 lbuoyancy=False, coriolis_mode=0, om22=0., om23=0., tke=None,
+                 lmoist=False, bctopq=1, wqtop=0., qt_top=-1., wqsurf=-1.):
         self.nx, self.ny, self.nz, self.nsv = nx, ny, nz, nsv
         self.dzf = np.ascontiguousarray(dzf, dtype=np.float64)
         self.dzh = np.ascontiguousarray(dzh, dtype=np.float64)
@@ -88,7 +92,8 @@ class Oracle:
                          int(bool(ltempeq)), bctopt, wttop, thl_top, wtsurf, int(bool(lbuoyancy)),
                          coriolis_mode, om22, om23,
                          *((tke["cm"], tke["cn"], tke["ch1"], tke["ch2"], tke["ce1"], tke["ce2"], tke["thvs"],
-                            int(tke.get("ldelta", 0))) if tke else (0., 0., 0., 0., 0., 0., 1., 0)))
+                            int(tke.get("ldelta", 0))) if tke else (0., 0., 0., 0., 0., 0., 1., 0)),
+                         int(bool(lmoist)), bctopq, wqtop, qt_top, wqsurf)
         self.L = lib()
 
     def mshape(self):

@@ -40,7 +40,7 @@ def test_fortran_driver_with_dropin_modules(name, iexp, residency, tmp_path):
     got = run_dropin(name, iexp, "run", tmp_path, residency)
     checked = 0
     for key, ref in fix.items():
-        if "." not in key or key.startswith("s000.") or key.split(".")[1] not in ("u0", "v0", "w0", "pres0", "thl0"):
+        if "." not in key or key.startswith("s000.") or key.split(".")[1] not in ("u0", "v0", "w0", "pres0", "thl0", "qt0"):
             continue
         a, b = got[key].data[1:-1], ref.data[1:-1]
         sc = 1.0 if key.endswith("thl0") else None          # O(1) K variations on a 288 K mean

@@ -46,6 +46,9 @@ def upload_inputs(core, fix, tag, g, nsv):
     if f"{tag}.thl0" in fix:
         core.upload("thl0", marr(fix, f"{tag}.thl0", g.nz))
         core.upload("thlm", marr(fix, f"{tag}.thlm", g.nz))
+    if f"{tag}.qt0" in fix:
+        core.upload("qt0", marr(fix, f"{tag}.qt0", g.nz))
+        core.upload("qtm", marr(fix, f"{tag}.qtm", g.nz))
     if f"{tag}.e120" in fix:
         core.upload("e120", marr(fix, f"{tag}.e120", g.nz))
         core.upload("e12m", marr(fix, f"{tag}.e12m", g.nz))
@@ -63,9 +66,10 @@ def test_each_routine_matches_reference(name, iexp):
 
     thl = "in.thl0" in fix
     tke = "in.e120" in fix
+    qt = "in.qt0" in fix
 
     def zero_tend():
-        for k in ("up", "vp", "wp") + (("thlp",) if thl else ()) + (("e12p",) if tke else ()):
+        for k in ("up", "vp", "wp") + (("thlp",) if thl else ()) + (("e12p",) if tke else ()) + (("qtp",) if qt else ()):
             core.upload(k, zero)
         for n in range(nsv):
             core.upload(L.scalar_field(L.SVP, n), np.zeros(g.cshape()))
@@ -80,6 +84,8 @@ def test_each_routine_matches_reference(name, iexp):
 
     if thl:       # advecc_2nd
         assert relerr(interior(core.download("thlp")), interior(marr(fix, "adv.thlp", nz))) <= KERNEL_TOL
+    if qt:
+        assert relerr(interior(core.download("qtp")), interior(marr(fix, "adv.qtp", nz))) <= KERNEL_TOL
     # e12: the reference's x ghost columns of e120 are stale (never refreshed, src/modboundary.f90:527-536) while the
     # device wraps the index, so the columns next to the x boundary are not comparable
     def inx(a):
@@ -92,6 +98,9 @@ def test_each_routine_matches_reference(name, iexp):
     if thl:       # top row re-imposed with the new ekh (reassure_fluxtop_boundary), then diffc
         assert relerr(core.download("thl0")[1:], marr(fix, "sub.thl0", nz)[1:], 1.0) <= KERNEL_TOL
         assert relerr(interior(core.download("thlp")), interior(marr(fix, "sub.thlp", nz))) <= KERNEL_TOL
+    if qt:
+        assert relerr(core.download("qt0")[1:], marr(fix, "sub.qt0", nz)[1:]) <= KERNEL_TOL
+        assert relerr(interior(core.download("qtp")), interior(marr(fix, "sub.qtp", nz))) <= KERNEL_TOL
     if tke:       # closure from e120, then diffe + sources
         assert relerr(inx(core.download("e12p")), inx(marr(fix, "sub.e12p", nz))) <= KERNEL_TOL
     ekm, ekh = core.download("ekm"), core.download("ekh")
@@ -110,6 +119,9 @@ def test_each_routine_matches_reference(name, iexp):
         assert relerr(interior(core.download("up")), interior(marr(fix, "sub.up", nz))) > 1e-6
         if thl:   # floor flux wtsurf
             assert relerr(interior(core.download("thlp")), interior(marr(fix, "bot.thlp", nz))) <= KERNEL_TOL
+        if qt:    # floor flux wqsurf
+            assert relerr(interior(core.download("qtp")), interior(marr(fix, "bot.qtp", nz))) <= KERNEL_TOL
+            assert relerr(interior(core.download("qtp")), interior(marr(fix, "sub.qtp", nz))) > 1e-6
 
     # full tendency as the reference driver had it, then forces (already inside pre.*), poisson
     zero_tend()
@@ -123,7 +135,7 @@ def test_each_routine_matches_reference(name, iexp):
         for k in ("up", "vp"):
             assert relerr(interior(core.download(k)), interior(marr(fix, "frc." + k, nz))) <= KERNEL_TOL, k
     core.masscorr()
-    for k in ("up", "vp", "wp") + (("thlp",) if thl else ()):
+    for k in ("up", "vp", "wp") + (("thlp",) if thl else ()) + (("qtp",) if qt else ()):
         assert relerr(interior(core.download(k)), interior(marr(fix, "pre." + k, nz))) <= KERNEL_TOL, k
     if tke:
         assert relerr(inx(core.download("e12p")), inx(marr(fix, "pre.e12p", nz))) <= KERNEL_TOL
@@ -142,7 +154,7 @@ def test_each_routine_matches_reference(name, iexp):
     core.tstep_integrate()
     core.halos()
     core.boundary()
-    for k in ("u0", "v0", "w0", "um", "pres0") + (("thl0", "thlm") if thl else ()):
+    for k in ("u0", "v0", "w0", "um", "pres0") + (("thl0", "thlm") if thl else ()) + (("qt0", "qtm") if qt else ()):
         ref = marr(fix, "out." + k, nz)
         sc = pscale if k == "pres0" else (1.0 if k.startswith("thl") else None)
         assert relerr(nocorner(core.download(k)[1:-1]), nocorner(ref[1:-1]), sc) <= KERNEL_TOL, k
@@ -174,7 +186,7 @@ def test_substeps_match_reference(name, iexp, fused):
             core.tstep_integrate(); core.halos(); core.boundary()
         if isub in dumps:
             tag = f"s{isub:03d}"
-            for k in ("u0", "v0", "w0", "pres0") + (("thl0",) if core.ltempeq else ()):
+            for k in ("u0", "v0", "w0", "pres0") + (("thl0",) if core.ltempeq else ()) + (("qt0",) if core.lmoist else ()):
                 ref = marr(fix, f"{tag}.{k}", g.nz)
                 sc = 1.0 if k == "thl0" else None        # temperature differences are O(1) K on a 288 K mean
                 assert relerr(nocorner(core.download(k)[1:-1]), nocorner(ref[1:-1]), sc) <= RUN_TOL, (tag, k)
@@ -326,6 +338,56 @@ def test_all_forcings_together_against_oracle(shape, sgs, nsv, cor):
     assert abs((core.download("v0")[1:-1, 1:-1, 1:-1] * w).sum() / (nx * ny) + 0.01) < 1e-12
     divmax, _ = core.divergence()
     assert divmax < 1e-11
+    core.close()
+
+
+@pytest.mark.parametrize("bctopq", [1, 2], ids=["fluxtop", "valuetop"])
+def test_moisture_against_oracle(bctopq):
+    """Total water (lmoist) through six fused substeps next to a passive temperature and two kappa scalars, floor
+    flux wqsurf and both top conditions, against the CPU oracle."""
+    nx, ny, nz = 48, 40, 20
+    dz = 0.4 * 1.05 ** np.arange(nz)
+    zf = np.cumsum(dz) - 0.5 * dz
+    g = Grid.from_levels(nx, ny, nz, nx * 0.45, ny * 0.5, zf)
+    from udcore.core import DynCore
+    kw = dict(lbottom=True, z0=0.03)
+    qkw = dict(bctopq=bctopq, wqtop=-2e-5, qt_top=0.003, wqsurf=4e-5)
+    core = DynCore(g, sgs=2, nsv=2, **kw)
+    o = ol.Oracle(nx, ny, nz, g.dx, g.dy, g.dzf, g.dzh, sgs=2, nsv=2, ltempeq=True, bctopt=1, wttop=0., wtsurf=0.03,
+                  lmoist=True, **qkw, **kw)
+    core.set_tempeq(bctopt=1, wttop=0., wtsurf=0.03)
+    core.set_moisture(**qkw)
+    st = random_state(g, seed=91, nsv=2)
+    rng = np.random.default_rng(5)
+
+    def field(mean, grad, amp, top):
+        a = np.zeros(g.mshape())
+        a[1:-1, 1:-1, 1:-1] = mean + grad * g.zf[1:nz + 1, None, None] + amp * rng.standard_normal((nz, ny, nx))
+        a[:, 0, :] = a[:, ny, :]; a[:, ny + 1, :] = a[:, 1, :]
+        a[:, :, 0] = a[:, :, nx]; a[:, :, nx + 1] = a[:, :, 1]
+        a[nz + 1] = top(a[nz])
+        return a
+    t = field(288., 0.3, 0.05, lambda r: r)
+    t[0] = t[1]
+    q = field(0.008, -2e-4, 2e-4, (lambda r: 2 * 0.003 - r) if bctopq == 2 else (lambda r: r))   # floor ghost stays zero
+    st.update(thl0=t, thlm=t.copy(), qt0=q, qtm=q.copy())
+    dp = np.zeros(nz + 2); dp[1:nz + 1] = -1e-3
+    core.load_state(st)
+    core.set_forcing(dp[1:nz + 1], np.zeros(nz))
+    ost = oracle_state(st, g, 2)
+    ost.update(dpdxl=dp, dpdyl=np.zeros(nz + 2), thl0=t.copy(), thlm=t.copy(), thlp=np.zeros(g.mshape()),
+               qt0=q.copy(), qtm=q.copy(), qtp=np.zeros(g.mshape()))
+    dt = 0.04
+    for isub in range(6):
+        core.substep(isub % 3 + 1, dt, with_forces=True)
+        o.substep(ost, isub % 3 + 1, dt)
+    assert np.abs(ost["qt0"][1:-1] - q[1:-1]).max() > 1e-5          # moisture moved
+    for k in ("u0", "v0", "w0", "pres0", "thl0", "qt0", "qtm"):
+        sc = 1.0 if k == "thl0" else None
+        assert relerr(nocorner(core.download(k)[1:-1]), nocorner(ost[k][1:-1]), sc) <= RUN_TOL, k
+    for n in range(2):
+        got = core.download(L.scalar_field(L.SV0, n), halo=2)
+        assert relerr(interior(got, 2), interior(ost["sv0"][n], 2)) <= RUN_TOL
     core.close()
 
 

@@ -72,6 +72,10 @@ def test_cold_start_matches_reference(name, iexp):
     st = cold_start(g, d, nsv=nsv)
     for k in ("u0", "v0", "w0", "um", "vm", "wm"):
         np.testing.assert_array_equal(st[k], marr(fix, f"s000.{k}", g.nz), err_msg=k)
+    for k in ("thl0", "thlm", "qt0", "qtm"):
+        if f"s000.{k}" in fix:
+            lo = 1 if k.endswith("m") else 0      # the floor ghost of thlm / qtm is never read
+            np.testing.assert_array_equal(st[k][lo:, 1:-1, 1:-1], marr(fix, f"s000.{k}", g.nz)[lo:, 1:-1, 1:-1], err_msg=k)
     for n in range(nsv):
         ref = carr(fix, f"s000.sv0_{n + 1:02d}", g.nz)
         np.testing.assert_array_equal(st[f"sv0_{n}"][:, 1:-1, 1:-1], ref[:, 1:-1, 1:-1])

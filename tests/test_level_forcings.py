@@ -23,23 +23,33 @@ def _avg(a, nz):
     return out
 
 
-def test_tables_match_reference_routines():
-    name, iexp = "k_lsf_12x8x24", 29
+LSF_KERNELS = [("k_lsf_12x8x24", 29, 2), ("k_lsfq_12x8x20", 34, 3)]      # (fixture, iexpnr, igrw_damp)
+
+
+@pytest.mark.parametrize("name,iexp,igrw", LSF_KERNELS)
+def test_tables_match_reference_routines(name, iexp, igrw):
     fix = load_fixture(name)
     d = read_deck(deck_path(name, iexp))
     g = Grid.from_deck(d)
     nz = g.nz
     ls = LevelForcings(_FakeCore(g), d)
-    assert ls.active and ls.subsidence and ls.lnudge and ls.igrw == 2
+    assert ls.active and ls.subsidence and ls.lnudge and ls.igrw == igrw
+    qt = ls.lmoist
+    assert qt == ("sub.qt0" in fix) and ls.qtls == qt
     fields = {k: marr(fix, "sub." + k if k == "u0" else "in." + k, nz) for k in ("u0", "v0", "w0")}
     fields["thl0"] = marr(fix, "sub.thl0", nz)      # top ghost row re-imposed by closurebc before the forcings run
-    av = {k: _avg(fields[k], nz) for k in ("u0", "v0", "thl0")}
+    if qt:
+        fields["qt0"] = marr(fix, "sub.qt0", nz)
+    av = {k: _avg(fields[k], nz) for k in fields if k != "w0"}
+    if qt:
+        np.testing.assert_allclose(av["qt0"][1:nz + 1], fix["qt0av"].data[:nz], rtol=0, atol=1e-17)
     # the averages are diagfld's (src/modthermodynamics.f90:262-279)
     np.testing.assert_allclose(av["u0"][1:nz + 2], fix["u0av"].data, rtol=0, atol=2e-15)
     np.testing.assert_allclose(av["thl0"][1:nz + 1], fix["thl0av"].data[:nz], rtol=0, atol=1e-12)
     tabs = ls.tables(av)
-    assert {t for t, _ in tabs} == {"up", "vp", "wp", "thlp"}
-    for tend in ("up", "vp", "wp", "thlp"):
+    tends = ("up", "vp", "wp", "thlp") + (("qtp",) if qt else ())
+    assert {t for t, _ in tabs} == set(tends)
+    for tend in tends:
         t = marr(fix, "frc0." + tend, nz).copy()
         for when in (0, 1):
             if (tend, when) not in tabs:
@@ -48,15 +58,16 @@ def test_tables_match_reference_routines():
             for k in range(1, nz + 1):
                 t[k] = t[k] + A[k] + (B[k] * fields[src][k] if src else 0.)
         sc = np.abs(marr(fix, "lsf." + tend, nz) - marr(fix, "frc0." + tend, nz)).max()
-        assert sc > 1e-6, tend                                    # the forcings did something
-        assert np.abs(interior(t) - interior(marr(fix, "lsf." + tend, nz))).max() <= 1e-12 * max(sc, 1.), tend
+        assert sc > (1e-9 if tend == "qtp" else 1e-6), tend       # the forcings did something
+        tol = 1e-12 * (sc if tend == "qtp" else max(sc, 1.))
+        assert np.abs(interior(t) - interior(marr(fix, "lsf." + tend, nz))).max() <= tol, tend
 
 
 @pytest.mark.gpu
-def test_device_applies_tables_like_reference():
+@pytest.mark.parametrize("name,iexp,igrw", LSF_KERNELS)
+def test_device_applies_tables_like_reference(name, iexp, igrw):
     """udc_slab_average + udc_set_level_forcing + udc_level_forcings on the reference's inputs."""
     import udcore
-    name, iexp = "k_lsf_12x8x24", 29
     fix = load_fixture(name)
     d = read_deck(deck_path(name, iexp))
     core = udcore.from_deck(d)
@@ -65,7 +76,11 @@ def test_device_applies_tables_like_reference():
         core.upload(k, marr(fix, ("sub." if k == "u0" else "in.") + k, nz))
     core.upload("thl0", marr(fix, "sub.thl0", nz))
     core.upload("thlm", marr(fix, "in.thlm", nz))
-    for k in ("up", "vp", "wp", "thlp"):
+    tends = ("up", "vp", "wp", "thlp") + (("qtp",) if core.lmoist else ())
+    if core.lmoist:
+        core.upload("qt0", marr(fix, "sub.qt0", nz))
+        core.upload("qtm", marr(fix, "in.qtm", nz))
+    for k in tends:
         core.upload(k, marr(fix, "frc0." + k, nz))
     # slab averages = diagfld's
     np.testing.assert_allclose(core.slab_average("u0")[1:nz + 2], fix["u0av"].data, rtol=0, atol=5e-15)
@@ -73,9 +88,10 @@ def test_device_applies_tables_like_reference():
     ls.update()
     core.level_forcings(0)
     core.level_forcings(1)
-    for k in ("up", "vp", "wp", "thlp"):
+    for k in tends:
         sc = np.abs(marr(fix, "lsf." + k, nz) - marr(fix, "frc0." + k, nz)).max()
-        assert np.abs(interior(core.download(k)) - interior(marr(fix, "lsf." + k, nz))).max() <= 1e-11 * max(sc, 1.), k
+        tol = 1e-11 * (sc if k == "qtp" else max(sc, 1.))
+        assert np.abs(interior(core.download(k)) - interior(marr(fix, "lsf." + k, nz))).max() <= tol, k
     core.close()
 
 

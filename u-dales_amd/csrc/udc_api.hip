@@ -375,11 +375,38 @@ extern "C" int udc_set_tempeq(udc_handle *h, int iadv_thl, int bctopt, double wt
   return 0;
 }
 
+extern "C" int udc_set_moisture(udc_handle *h, int iadv_qt, int bctopq, double wqtop, double qt_top, int bcbotq, double wqsurf) {
+  HIP_OK(hipSetDevice(h->device));
+  if (h->cfg.nsv > 13) { udc_set_error("udc_set_moisture: qt uses scalar slot 13, nsv must be <= 13"); return 1; }
+  if (iadv_qt != 2) { udc_set_error("udc_set_moisture: only iadv_qt = 2 (cd2, advecc_2nd) exists (src/modadvection.f90:79-85)"); return 1; }
+  if (bctopq != 1 && bctopq != 2) { udc_set_error("udc_set_moisture: BCtopq must be 1 (flux) or 2 (value)"); return 1; }
+  if (h->p.lbottom && bcbotq != 1) { udc_set_error("udc_set_moisture: BCbotq must be 1 (flux) (src/modibm.f90:2051,2062-2064)"); return 1; }
+  if (h->lbuoyancy) { udc_set_error("udc_set_moisture: the moist buoyancy (thermo, diagfld) is not built"); return 1; }
+  if (h->p.sgs == UDC_SGS_ONEEQN) { udc_set_error("udc_set_moisture: the moist dthvdz of the one-equation closure is not built"); return 1; }
+  const bool have = (int)h->fields.size() > UDC_QT0 && h->fields[UDC_QT0];
+  if (!have) {
+    for (int q = 0; q < 3; ++q)
+      if (alloc_field(h, UDC_SV0 + 3 * 13 + q)) return 1;
+    // keep the slot list ordered: passive scalars, qt (13), e12 (14), thl (15)
+    auto it = h->slots.begin();
+    while (it != h->slots.end() && *it < 13) ++it;
+    h->slots.insert(it, 13);
+  }
+  udc_handle::Slot &sl = h->slot[13];
+  sl.adv = 2;
+  sl.top = bctopq == 2 ? 2 : (wqtop != 0. ? 1 : 0);
+  sl.topval = bctopq == 2 ? qt_top : wqtop;
+  sl.floorflux = -wqsurf;      // the reference adds wqsurf where it subtracts wtsurf (src/modibm.f90:2058 vs :2043)
+  h->lmoist = true;
+  return 0;
+}
+
 extern "C" int udc_set_tke(udc_handle *h, double cm, double cn, double ch1, double ch2, double ce1, double ce2, double e12min,
                            double grav, double thvs, int ldelta) {
   HIP_OK(hipSetDevice(h->device));
   if (h->cfg.nsv > 14) { udc_set_error("udc_set_tke: e12 uses scalar slot 14, nsv must be <= 14"); return 1; }
   if (!(thvs > 0.) || !(e12min > 0.)) { udc_set_error("udc_set_tke: thvs and e12min must be positive"); return 1; }
+  if (h->lmoist) { udc_set_error("udc_set_tke: the moist dthvdz of the one-equation closure is not built"); return 1; }
   const bool have = (int)h->fields.size() > UDC_E120 && h->fields[UDC_E120];
   if (!have) {
     for (int q = 0; q < 3; ++q)
@@ -397,6 +424,7 @@ extern "C" int udc_set_tke(udc_handle *h, double cm, double cn, double ch1, doub
 }
 
 extern "C" int udc_set_buoyancy(udc_handle *h, int lbuoyancy, double grav) {
+  if (lbuoyancy && h->lmoist) { udc_set_error("udc_set_buoyancy: the moist buoyancy (thermo, diagfld) is not built"); return 1; }
   if (lbuoyancy && ((int)h->fields.size() <= UDC_THL0 || !h->fields[UDC_THL0])) {
     udc_set_error("udc_set_buoyancy: call udc_set_tempeq first (thv0h comes from thl0)");
     return 1;

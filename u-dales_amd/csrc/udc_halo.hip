@@ -90,7 +90,12 @@ __global__ void top_bottom_kernel(Geo g, Params pr, BoundaryArgs a, int uv_only)
 
 int k_halo_y(udc_handle *h, const int *fields, int nf, int width) {
   const Geo &g = h->g;
-  if (nf > 16 || width > HY) { udc_set_error("k_halo_y: bad arguments"); return 1; }
+  if (width > HY) { udc_set_error("k_halo_y: bad arguments"); return 1; }
+  if (nf > 16) {      // one launch (and one exchange buffer) carries 16 fields; more go in rounds
+    for (int q = 0; q < nf; q += 16)
+      if (k_halo_y(h, fields + q, nf - q < 16 ? nf - q : 16, width)) return 1;
+    return 0;
+  }
   FieldList fl;
   for (int q = 0; q < nf; ++q) fl.f[q] = h->fields[fields[q]];
   if (!h->slab) {

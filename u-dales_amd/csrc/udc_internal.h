@@ -126,6 +126,7 @@ struct udc_handle {
   int coriolis_mode = 0;       // 0 off, 1 lcoriol, 2 lprofforc (src/modforces.f90:600-717)
   double om22 = 0., om23 = 0.;
   double *ug = nullptr;        // [nz+2] geostrophic wind profile (lprofforc)
+  bool lmoist = false;         // qt transported in slot 13 (udc_set_moisture)
   int lbuoyancy = 0;           // forces' buoyancy term (dry air), needs the temperature equation
   double grav = 9.81;
   double *lev_part = nullptr, *lev_sum = nullptr;   // per-level slab sums (thvh)

@@ -8,7 +8,7 @@ contains
 
   subroutine advection
     use iso_c_binding, only: c_int
-    use modglobal, only: iadv_mom, iadv_cd2, iadv_thl, iadv_kappa, ltempeq, lmoist
+    use modglobal, only: iadv_mom, iadv_cd2, iadv_thl, iadv_qt, iadv_kappa, ltempeq, lmoist
     use modsubgriddata, only: loneeqn
     use udc_iface
     implicit none
@@ -19,8 +19,8 @@ contains
       write (0, *) 'ERROR: Unknown advection scheme'
       stop 1
     end if
-    if (lmoist) then
-      write (0, *) 'ERROR: libudcore advection: the qt equation is not on the device path'
+    if (lmoist .and. iadv_qt /= iadv_cd2) then     ! qt: advecc_2nd only (src/modadvection.f90:78-86)
+      write (0, *) 'ERROR: Unknown advection scheme'
       stop 1
     end if
     if (ltempeq .and. iadv_thl /= iadv_cd2) then   ! thl: advecc_2nd only (src/modadvection.f90:66-68)

@@ -84,10 +84,6 @@ contains
     use modglobal, only: ib, jb, kb, ih, jh, kh, ltempeq, lmoist
     use udc_iface
     implicit none
-    if (lmoist) then
-      write (0, *) 'ERROR: libudcore subgrid: the qt equation is not on the device path'
-      stop 1
-    end if
     call udc_ensure
     select case (udc_residency)
     case (0)

@@ -43,7 +43,7 @@ contains
     use udc_iface
     implicit none
 
-    if (lmoist .or. lchem .or. ifixuinf == 2) then
+    if (lchem .or. ifixuinf == 2) then
       write (0, *) 'ERROR: libudcore tstep_integrate: option not on the device path'
       stop 1
     end if

@@ -23,6 +23,7 @@ module udc_iface
                                UDC_UP = 6, UDC_VP = 7, UDC_WP = 8, UDC_PRES0 = 9, UDC_P = 10, &
                                UDC_EKM = 11, UDC_EKH = 12, UDC_SV0 = 13, UDC_SVM = 14, UDC_SVP = 15, &
                                UDC_THL0 = 13 + 45, UDC_THLM = 14 + 45, UDC_THLP = 15 + 45, &   ! scalar slot 15
+                               UDC_QT0 = 13 + 39, UDC_QTM = 14 + 39, UDC_QTP = 15 + 39, &      ! scalar slot 13
                                UDC_E120 = 13 + 42, UDC_E12M = 14 + 42, UDC_E12P = 15 + 42      ! scalar slot 14
 
   type, bind(C) :: udc_config
@@ -104,6 +105,12 @@ module udc_iface
       integer(c_int), value :: lbuoyancy
       real(c_double), value :: grav
     end function
+    integer(c_int) function udc_set_moisture(h, iadv_qt, bctopq, wqtop, qt_top, bcbotq, wqsurf) bind(C, name='udc_set_moisture')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: iadv_qt, bctopq, bcbotq
+      real(c_double), value :: wqtop, qt_top, wqsurf
+    end function udc_set_moisture
     integer(c_int) function udc_set_thl_source(h, thlpcar, n) bind(C, name='udc_set_thl_source')
       import :: c_int, c_ptr, c_double
       type(c_ptr), value :: h
@@ -205,8 +212,9 @@ contains
   !> Create the device mirror once all of initglobal/initfields/initsubgrid/initpois have run.
   subroutine udc_ensure
     use modglobal, only: itot, jtot, ktot, dx, dy, dzf, dzh, kb, ke, kh, numol, prandtlmoli, nsv, &
-                         BCtopm, Uinf, Vinf, lles, ltempeq, lbuoyancy, lmoist, iadv_thl, BCtopT, BCbotT, grav, e12min
-    use modsurfdata, only: wttop, thl_top, wtsurf, thvs
+                         BCtopm, Uinf, Vinf, lles, ltempeq, lbuoyancy, lmoist, iadv_thl, BCtopT, BCbotT, grav, e12min, &
+                         iadv_qt, BCtopq, BCbotq
+    use modsurfdata, only: wttop, thl_top, wtsurf, thvs, wqtop, qt_top, wqsurf
     use modsubgriddata, only: lsmagorinsky, lvreman, loneeqn, ldelta, prandtli, c_vreman, csz, cm, cn, ch1, ch2, ce1, ce2
     use modfields, only: dpdxl, dpdyl, thlpcar
     use modmpi, only: myid, nprocs, nprocx, comm3d, mpierr
@@ -260,14 +268,15 @@ contains
     end if
     call udc_check(udc_set_forcing(udc_h, dpdxl(kb:ke), dpdyl(kb:ke), int(ktot, c_int)), 'udc_set_forcing')
     if (ltempeq) then      ! temperature equation; the dry buoyancy term is on the device for device-resident runs
-      if (lmoist) then    ! (in residency 0/1 the host's own forces adds it to the pulled tendencies)
-        write (0, *) 'ERROR: libudcore: the moisture equation / moist thermodynamics are not built (lmoist)'
-        stop 1
-      end if
+      ! (in residency 0/1 the host's own forces adds it to the pulled tendencies)
       call udc_check(udc_set_tempeq(udc_h, int(iadv_thl, c_int), int(BCtopT, c_int), real(wttop, c_double), &
                                     real(thl_top, c_double), int(BCbotT, c_int), real(wtsurf, c_double)), 'udc_set_tempeq')
       call udc_check(udc_set_thl_source(udc_h, thlpcar(kb:ke), int(ktot, c_int)), 'udc_set_thl_source')
       if (lbuoyancy) call udc_check(udc_set_buoyancy(udc_h, 1_c_int, real(grav, c_double)), 'udc_set_buoyancy')
+    end if
+    if (lmoist) then       ! total water as a transported field; udc_set_buoyancy above refuses lmoist (moist thermo not built)
+      call udc_check(udc_set_moisture(udc_h, int(iadv_qt, c_int), int(BCtopq, c_int), real(wqtop, c_double), &
+                                      real(qt_top, c_double), int(BCbotq, c_int), real(wqsurf, c_double)), 'udc_set_moisture')
     end if
     if (cfg%sgs == 3) then   ! after udc_set_tempeq: the closure reads thl0 when the temperature equation is on
       call udc_check(udc_set_tke(udc_h, real(cm, c_double), real(cn, c_double), real(ch1, c_double), real(ch2, c_double), &
@@ -299,8 +308,8 @@ contains
 
   !> Everything the device needs from the host's prognostic state (bounds: src/modfields.f90:440-474)
   subroutine udc_push_state
-    use modglobal, only: ib, jb, kb, ih, jh, kh, ihc, jhc, khc, nsv, ltempeq
-    use modfields, only: u0, v0, w0, um, vm, wm, pres0, sv0, svm, thl0, thlm, e120, e12m
+    use modglobal, only: ib, jb, kb, ih, jh, kh, ihc, jhc, khc, nsv, ltempeq, lmoist
+    use modfields, only: u0, v0, w0, um, vm, wm, pres0, sv0, svm, thl0, thlm, e120, e12m, qt0, qtm
     integer :: n
     call udc_push3(UDC_U0, u0, (/ib - ih, jb - jh, kb - kh/))
     call udc_push3(UDC_V0, v0, (/ib - ih, jb - jh, kb - kh/))
@@ -317,6 +326,10 @@ contains
       call udc_push3(UDC_THL0, thl0, (/ib - ih, jb - jh, kb - kh/))
       call udc_push3(UDC_THLM, thlm, (/ib - ih, jb - jh, kb - kh/))
     end if
+    if (lmoist) then
+      call udc_push3(UDC_QT0, qt0, (/ib - ih, jb - jh, kb - kh/))
+      call udc_push3(UDC_QTM, qtm, (/ib - ih, jb - jh, kb - kh/))
+    end if
     do n = 1, nsv
       call udc_push3(UDC_SV0 + 3*(n - 1), sv0(:, :, :, n), (/ib - ihc, jb - jhc, kb - khc/))
       call udc_push3(UDC_SVM + 3*(n - 1), svm(:, :, :, n), (/ib - ihc, jb - jhc, kb - khc/))
@@ -324,13 +337,14 @@ contains
   end subroutine udc_push_state
 
   subroutine udc_push_tend
-    use modglobal, only: ib, jb, kb, ih, jh, ihc, jhc, nsv, ltempeq
-    use modfields, only: up, vp, wp, svp, thlp, e12p
+    use modglobal, only: ib, jb, kb, ih, jh, ihc, jhc, nsv, ltempeq, lmoist
+    use modfields, only: up, vp, wp, svp, thlp, e12p, qtp
     integer :: n
     call udc_push3(UDC_UP, up, (/ib - ih, jb - jh, kb/))
     call udc_push3(UDC_VP, vp, (/ib - ih, jb - jh, kb/))
     call udc_push3(UDC_WP, wp, (/ib - ih, jb - jh, kb/))
     if (ltempeq) call udc_push3(UDC_THLP, thlp, (/ib - ih, jb - jh, kb/))
+    if (lmoist) call udc_push3(UDC_QTP, qtp, (/ib - ih, jb - jh, kb/))
     if (loneeqn_dev()) call udc_push3(UDC_E12P, e12p, (/ib - ih, jb - jh, kb/))
     do n = 1, nsv
       call udc_push3(UDC_SVP + 3*(n - 1), svp(:, :, :, n), (/ib - ihc, jb - jhc, kb/))
@@ -338,13 +352,14 @@ contains
   end subroutine udc_push_tend
 
   subroutine udc_pull_tend
-    use modglobal, only: ib, jb, kb, ih, jh, ihc, jhc, nsv, ltempeq
-    use modfields, only: up, vp, wp, svp, thlp, e12p
+    use modglobal, only: ib, jb, kb, ih, jh, ihc, jhc, nsv, ltempeq, lmoist
+    use modfields, only: up, vp, wp, svp, thlp, e12p, qtp
     integer :: n
     call udc_pull3(UDC_UP, up, (/ib - ih, jb - jh, kb/))
     call udc_pull3(UDC_VP, vp, (/ib - ih, jb - jh, kb/))
     call udc_pull3(UDC_WP, wp, (/ib - ih, jb - jh, kb/))
     if (ltempeq) call udc_pull3(UDC_THLP, thlp, (/ib - ih, jb - jh, kb/))
+    if (lmoist) call udc_pull3(UDC_QTP, qtp, (/ib - ih, jb - jh, kb/))
     if (loneeqn_dev()) call udc_pull3(UDC_E12P, e12p, (/ib - ih, jb - jh, kb/))
     do n = 1, nsv
       call udc_pull3(UDC_SVP + 3*(n - 1), svp(:, :, :, n), (/ib - ihc, jb - jhc, kb/))
@@ -352,14 +367,15 @@ contains
   end subroutine udc_pull_tend
 
   subroutine udc_pull_vel(with_m)
-    use modglobal, only: ib, jb, kb, ih, jh, kh, ihc, jhc, khc, nsv, ltempeq
-    use modfields, only: u0, v0, w0, um, vm, wm, sv0, svm, thl0, thlm, e120, e12m
+    use modglobal, only: ib, jb, kb, ih, jh, kh, ihc, jhc, khc, nsv, ltempeq, lmoist
+    use modfields, only: u0, v0, w0, um, vm, wm, sv0, svm, thl0, thlm, e120, e12m, qt0, qtm
     logical, intent(in) :: with_m
     integer :: n
     call udc_pull3(UDC_U0, u0, (/ib - ih, jb - jh, kb - kh/))
     call udc_pull3(UDC_V0, v0, (/ib - ih, jb - jh, kb - kh/))
     call udc_pull3(UDC_W0, w0, (/ib - ih, jb - jh, kb - kh/))
     if (ltempeq) call udc_pull3(UDC_THL0, thl0, (/ib - ih, jb - jh, kb - kh/))
+    if (lmoist) call udc_pull3(UDC_QT0, qt0, (/ib - ih, jb - jh, kb - kh/))
     if (loneeqn_dev()) call udc_pull3(UDC_E120, e120, (/ib - ih, jb - jh, kb - kh/))
     do n = 1, nsv
       call udc_pull3(UDC_SV0 + 3*(n - 1), sv0(:, :, :, n), (/ib - ihc, jb - jhc, kb - khc/))
@@ -369,6 +385,7 @@ contains
       call udc_pull3(UDC_VM, vm, (/ib - ih, jb - jh, kb - kh/))
       call udc_pull3(UDC_WM, wm, (/ib - ih, jb - jh, kb - kh/))
       if (ltempeq) call udc_pull3(UDC_THLM, thlm, (/ib - ih, jb - jh, kb - kh/))
+      if (lmoist) call udc_pull3(UDC_QTM, qtm, (/ib - ih, jb - jh, kb - kh/))
       if (loneeqn_dev()) call udc_pull3(UDC_E12M, e12m, (/ib - ih, jb - jh, kb - kh/))
       do n = 1, nsv
         call udc_pull3(UDC_SVM + 3*(n - 1), svm(:, :, :, n), (/ib - ihc, jb - jhc, kb - khc/))

@@ -22,8 +22,6 @@ def from_deck(deck, device=0, rank=0, nranks=1):
     core.set_masscorr(bool(deck.get("PHYSICS", "luvolflowr")), float(deck.get("PHYSICS", "uflowrate")),
                       bool(deck.get("PHYSICS", "lvvolflowr")), float(deck.get("PHYSICS", "vflowrate")))
     if deck.get("PHYSICS", "ltempeq"):
-        if deck.get("PHYSICS", "lmoist"):
-            raise ValueError("lmoist: the moisture equation / moist thermodynamics are not built")
         iadv = int(deck.get("DYNAMICS", "iadv_thl"))
         core.set_tempeq(iadv_thl=int(deck.get("DYNAMICS", "iadv_mom")) if iadv < 0 else iadv,
                         bctopt=int(deck.get("BC", "BCtopT")), wttop=float(deck.get("BC", "wttop")),
@@ -31,6 +29,14 @@ def from_deck(deck, device=0, rank=0, nranks=1):
                         wtsurf=float(deck.get("BC", "wtsurf")), thlpcar=getattr(deck, "thlpcar", None))
         if deck.get("PHYSICS", "lbuoyancy"):
             core.set_buoyancy(True)
+    if deck.get("PHYSICS", "lmoist"):
+        if deck.get("PHYSICS", "lbuoyancy") or sgs == 3:
+            raise ValueError("lmoist with lbuoyancy or loneeqn: the moist thermodynamics (thermo, diagfld) are not built")
+        iadv = int(deck.get("DYNAMICS", "iadv_qt"))
+        core.set_moisture(iadv_qt=int(deck.get("DYNAMICS", "iadv_mom")) if iadv < 0 else iadv,
+                          bctopq=int(deck.get("BC", "BCtopq")), wqtop=float(deck.get("BC", "wqtop")),
+                          qt_top=float(deck.get("BC", "qt_top")), bcbotq=int(deck.get("BC", "BCbotq")),
+                          wqsurf=float(deck.get("BC", "wqsurf")))
     if sgs == 3:      # after set_tempeq: the closure reads thl0 when the temperature equation is on
         thls, qts = float(deck.get("BC", "thls")), float(deck.get("BC", "qts"))
         core.set_tke(cf=float(deck.get("NAMSUBGRID", "cf")), cn=float(deck.get("NAMSUBGRID", "cn")),

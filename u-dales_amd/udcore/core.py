@@ -44,6 +44,8 @@ class DynCore:
         self.rk3step = 0
         self.dt = 0.
         self.ltempeq = False
+        self.lmoist = False
+        self.loneeqn = False
         self.timee = 0.
 
     # ---- lifetime
@@ -151,6 +153,12 @@ class DynCore:
             a = np.ascontiguousarray(thlpcar, dtype=np.float64)
             L._check(self.lib.udc_set_thl_source(self.h, a.ctypes.data_as(L.DP), len(a)), "udc_set_thl_source")
 
+    def set_moisture(self, iadv_qt=2, bctopq=1, wqtop=0., qt_top=-1., bcbotq=1, wqsurf=0.):
+        """&PHYSICS lmoist: qt becomes a transported field, see include/udcore.h udc_set_moisture."""
+        L._check(self.lib.udc_set_moisture(self.h, int(iadv_qt), int(bctopq), C.c_double(wqtop), C.c_double(qt_top),
+                                           int(bcbotq), C.c_double(wqsurf)), "udc_set_moisture")
+        self.lmoist = True
+
     def slab_average(self, field):
         """Horizontal mean of `field` per level, indexed by the reference's k: entries 1..nz+1 (entry 0 unused)."""
         from .forcings import field_id
@@ -192,6 +200,7 @@ class DynCore:
         L._check(self.lib.udc_set_tke(self.h, C.c_double(k["cm"]), C.c_double(cn), C.c_double(ch1), C.c_double(k["ch2"]),
                                       C.c_double(k["ce1"]), C.c_double(k["ce2"]), C.c_double(e12min), C.c_double(grav),
                                       C.c_double(thvs), int(bool(ldelta))), "udc_set_tke")
+        self.loneeqn = True
 
     def set_buoyancy(self, on=True, grav=9.81):
         """&PHYSICS lbuoyancy (dry air): forces adds grav (thv0h - thvh)/thvh to wp."""

@@ -38,10 +38,15 @@ class LevelForcings:
         self.lcoriol = bool(ph("lcoriol"))
         self.geodamptime = float(ph("geodamptime"))
         self.ltempeq = bool(ph("ltempeq"))
+        self.lmoist = bool(ph("lmoist"))
         # profiles indexed by the reference's k (entry 0 unused)
         f = lambda a: np.concatenate(([0.], np.asarray(a, dtype=float)[:nz]))   # noqa: E731
         self.uprof, self.vprof, self.thlprof = f(deck.u), f(deck.v), f(deck.thl)
         self.ug, self.vg = f(deck.ug), f(deck.vg)
+        self.qtprof = f(deck.qt)
+        # large-scale moisture gradients / tendency (lscale.inp columns 7-9, src/modstartup.f90:2060-2097)
+        self.dqtdxls, self.dqtdyls, self.dqtdtls = (f(getattr(deck, n, np.zeros(nz))) for n in ("dqtdxls", "dqtdyls", "dqtdtls"))
+        self.qtls = self.lmoist and bool(np.any(self.dqtdxls) or np.any(self.dqtdyls) or np.any(self.dqtdtls))
         wfls = f(getattr(deck, "wfls", np.zeros(nz)))
         dzf, dzh = g.dzf, g.dzh
         whls = np.zeros(nz + 2)                      # src/modstartup.f90:2125-2129
@@ -59,7 +64,7 @@ class LevelForcings:
         for k in range(self.ksp, nz + 1):
             tsc[k] = 2.75e-3 * math.sin(0.5 * pi * (g.zf[k] - zspb) / (zspt - zspb)) ** 2
         self.tsc = tsc
-        self.active = self.subsidence or self.lnudge or self.igrw != 0
+        self.active = self.subsidence or self.lnudge or self.igrw != 0 or self.qtls
 
     def tables(self, av):
         """av: dict of slab averages indexed by the reference's k (entries 1..nz+1).  Returns {(tend, when): [src, A, B]}
@@ -76,6 +81,7 @@ class LevelForcings:
             return out[key]
 
         scal = [("thl0", "thlp")] if self.ltempeq else []
+        scal += [("qt0", "qtp")] if self.lmoist else []
         scal += [(f"sv0_{n}", f"svp_{n}") for n in range(self.core.nsv)]
         if self.subsidence:                                      # lstend
             for name, tend in scal:
@@ -88,6 +94,10 @@ class LevelForcings:
                         A[k] -= whls[k + 1] * (a[k + 1] - a[k]) / dzh[k + 1]
                     else:
                         A[k] -= whls[k] * (a[k] - a[k - 1]) / dzh[k]
+        if self.qtls:                                            # lstend, src/modforces.f90:783,818
+            A = acc("qtp")[1]
+            for k in range(1, nz + 1):
+                A[k] += -av["u0"][k] * self.dqtdxls[k] - av["v0"][k] * self.dqtdyls[k] + self.dqtdtls[k]
         if self.lnudge:                                          # nudge
             k0 = 1 + self.nnudge
             if self.lnudgevel:
@@ -99,6 +109,10 @@ class LevelForcings:
                 A = acc("thlp")[1]
                 for k in range(k0, nz + 1):
                     A[k] -= (av["thl0"][k] - self.thlprof[k]) / self.tnudge
+            if self.lmoist:
+                A = acc("qtp")[1]
+                for k in range(k0, nz + 1):
+                    A[k] -= (av["qt0"][k] - self.qtprof[k]) / self.tnudge
         if self.igrw in (1, 2, 3):                               # grwdamp
             tsc = self.tsc
             for name, tend, geo in (("u0", "up", self.ug), ("v0", "vp", self.vg)):
@@ -114,15 +128,16 @@ class LevelForcings:
             _, A, B = acc("wp", "w0", 1)
             for k in range(self.ksp, nz + 1):
                 B[k] -= tsc[k]
-            if self.ltempeq:
-                _, A, B = acc("thlp", "thl0", 1)
-                for k in range(self.ksp, nz + 1):
-                    A[k] += av["thl0"][k] * tsc[k]
-                    B[k] -= tsc[k]
+            for on, name, tend in ((self.ltempeq, "thl0", "thlp"), (self.lmoist, "qt0", "qtp")):
+                if on:
+                    _, A, B = acc(tend, name, 1)
+                    for k in range(self.ksp, nz + 1):
+                        A[k] += av[name][k] * tsc[k]
+                        B[k] -= tsc[k]
         return out
 
     def averages(self):
-        names = ["u0", "v0"] + (["thl0"] if self.ltempeq else []) + [f"sv0_{n}" for n in range(self.core.nsv)]
+        names = ["u0", "v0"] + (["thl0"] if self.ltempeq else []) + (["qt0"] if self.lmoist else []) + [f"sv0_{n}" for n in range(self.core.nsv)]
         return {n: self.core.slab_average(n) for n in names}
 
     def update(self):

@@ -165,4 +165,15 @@ def cold_start(g: Grid, d: Deck, j0=0, nyl=None, nsv=0, scal_a=1.0, scal_b=0.0):
         else:
             t[nz + 1] = t[nz]          # non-zero wttop needs ekh: re-imposed on the device after the first closure
         out["thl0"], out["thlm"] = t, t.copy()
+    if d.get("PHYSICS", "lmoist"):
+        # qt0 = qtm = qtprof(k) (src/modstartup.f90:1160-1161); the floor ghost stays zero (nothing ever writes it),
+        # the top ghost comes from boundary (src/modboundary.f90:222-231)
+        q = np.zeros(shape)
+        for k in range(1, nz + 1):
+            q[k] = d.qt[k - 1]
+        if int(d.get("BC", "BCtopq")) == 2:
+            q[nz + 1] = 2 * float(d.get("BC", "qt_top")) - q[nz]
+        else:
+            q[nz + 1] = q[nz]
+        out["qt0"], out["qtm"] = q, q.copy()
     return out

@@ -19,13 +19,15 @@ DP = C.POINTER(C.c_double)
 U0, V0, W0, UM, VM, WM, UP, VP, WP, PRES0, P, EKM, EKH, SV0, SVM, SVP = range(16)
 THL0, THLM, THLP = SV0 + 45, SVM + 45, SVP + 45      # temperature equation: scalar slot 15 (include/udcore.h)
 E120, E12M, E12P = SV0 + 42, SVM + 42, SVP + 42      # one-equation closure: scalar slot 14
+QT0, QTM, QTP = SV0 + 39, SVM + 39, SVP + 39         # moisture: scalar slot 13
 FIELD_IDS = dict(u0=U0, v0=V0, w0=W0, um=UM, vm=VM, wm=WM, up=UP, vp=VP, wp=WP, pres0=PRES0, p=P,
-                 ekm=EKM, ekh=EKH, thl0=THL0, thlm=THLM, thlp=THLP, e120=E120, e12m=E12M, e12p=E12P)
+                 ekm=EKM, ekh=EKH, thl0=THL0, thlm=THLM, thlp=THLP, e120=E120, e12m=E12M, e12p=E12P,
+                 qt0=QT0, qtm=QTM, qtp=QTP)
 SGS_DNS, SGS_SMAGORINSKY, SGS_VREMAN, SGS_ONEEQN = 0, 1, 2, 3
 
 EXPORTS = ["udc_create", "udc_destroy", "udc_last_error", "udc_version", "udc_comm_unique_id",
            "udc_comm_init", "udc_local_group_create", "udc_comm_init_local", "udc_field_upload", "udc_field_download", "udc_set_forcing",
-           "udc_advection", "udc_subgrid", "udc_bottom", "udc_forces", "udc_slab_average", "udc_set_level_forcing", "udc_level_forcings", "udc_set_coriolis", "udc_coriolis", "udc_set_masscorr", "udc_masscorr", "udc_set_tempeq", "udc_set_thl_source", "udc_set_buoyancy", "udc_set_tke", "udc_poisson", "udc_tstep_integrate",
+           "udc_advection", "udc_subgrid", "udc_bottom", "udc_forces", "udc_slab_average", "udc_set_level_forcing", "udc_level_forcings", "udc_set_coriolis", "udc_coriolis", "udc_set_masscorr", "udc_masscorr", "udc_set_tempeq", "udc_set_thl_source", "udc_set_moisture", "udc_set_buoyancy", "udc_set_tke", "udc_poisson", "udc_tstep_integrate",
            "udc_halos", "udc_boundary", "udc_tstep_maxima", "udc_substep", "udc_run",
            "udc_divergence", "udc_sync", "udc_profile_enable", "udc_profile_reset",
            "udc_profile_get"]

@@ -21,7 +21,8 @@ DEFAULTS = {
                     dpdx=0., igrw_damp=0, geodamptime=7200., lnudge=False, lnudgevel=True, tnudge=60., nnudge=0, xlat=52., luvolflowr=False, uflowrate=1., lvvolflowr=False, vflowrate=1.),
     "DYNAMICS": dict(ipoiss=0, iadv_mom=2, iadv_tke=-1, iadv_thl=-1, iadv_qt=-1),
     "BC": dict(BCxm=1, BCym=1, BCtopm=1, BCbotm=2, BCzp=1, z0=-1., z0h=-1., BCtopT=1, BCbotT=1, BCbots=1, BCtops=1,
-               wttop=0., thl_top=-1., wtsurf=-1., thls=-1., qts=-1.),
+               wttop=0., thl_top=-1., wtsurf=-1., thls=-1., qts=-1.,
+               BCtopq=1, BCbotq=1, wqtop=0., qt_top=-1., wqsurf=-1.),
     "SCALARS": dict(nsv=0),
     "NAMSUBGRID": dict(lsmagorinsky=False, lvreman=True, loneeqn=False, c_vreman=0.07, cs=-1.,
                        cf=2.5, cn=0.76, Rigc=0.25, Prandtl=0.333, ldelta=False, lbuoycorr=False),
@@ -156,6 +157,7 @@ def read_deck(namoptions_path: str) -> Deck:
     d.pgx = [r[3] for r in ls]
     d.pgy = [r[4] for r in ls]
     d.wfls = [r[5] for r in ls]         # large-scale vertical velocity -> whls, src/modstartup.f90:2125-2129
+    d.dqtdxls, d.dqtdyls, d.dqtdtls = [r[6] for r in ls], [r[7] for r in ls], [r[8] for r in ls]
     d.thlpcar = [r[9] for r in ls]      # dthlrad column -> thlpcar(k), src/modstartup.f90:2060-2097
     return d
 

@@ -117,7 +117,7 @@ def save_restart(core, directory, expnr, ntrun, timee, dt, rank=0, fill=None):
     from . import lib as L
     g = core.g
     ny = core.nyl
-    fields = {k: core.download(k) for k in ("u0", "v0", "w0", "pres0", "ekm")}
+    fields = {k: core.download(k) for k in _restart_fields(core)}
     path = os.path.join(directory, restart_name(ntrun, rank, expnr, "d"))
     write_initd(path, g.nx, ny, g.nz, fields, timee, dt, fill=fill)
     paths = [path]
@@ -129,6 +129,18 @@ def save_restart(core, directory, expnr, ntrun, timee, dt, rank=0, fill=None):
     return paths
 
 
+def _restart_fields(core):
+    """The initd records this configuration transports (the rest are written as `fill` / ignored on read)."""
+    names = ["u0", "v0", "w0", "pres0", "ekm"]
+    if getattr(core, "ltempeq", False):
+        names.append("thl0")
+    if getattr(core, "loneeqn", False):
+        names.append("e120")
+    if getattr(core, "lmoist", False):
+        names.append("qt0")
+    return names
+
+
 def load_restart(core, directory, expnr, ntrun, rank=0):
     """Warm start as readrestartfiles + readinitfiles do (src/modstartup.f90:1292-1340): u0.. from the file,
     um = u0 (the file is written after stage 3, when the reference itself has um = u0), ghosts re-derived by
@@ -137,10 +149,12 @@ def load_restart(core, directory, expnr, ntrun, rank=0):
     g = core.g
     ny = core.nyl
     d = read_initd(os.path.join(directory, restart_name(ntrun, rank, expnr, "d")), g.nx, ny, g.nz)
-    for k in ("u0", "v0", "w0", "pres0", "ekm"):
+    names = _restart_fields(core)
+    for k in names:
         core.upload(k, d[k])
-    for k0, km in (("u0", "um"), ("v0", "vm"), ("w0", "wm")):
-        core.upload(km, d[k0])
+    for k0 in names:
+        if k0 not in ("pres0", "ekm"):      # um = u0, thlm = thl0, ... (src/modstartup.f90:1675-1684)
+            core.upload(k0[:-1] + "m", d[k0])
     if core.nsv:
         s = read_inits(os.path.join(directory, restart_name(ntrun, rank, expnr, "s")), g.nx, ny, g.nz, core.nsv)
         for n, a in enumerate(s["sv0"]):
