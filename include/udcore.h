@@ -117,9 +117,22 @@ int udc_set_thl_source(udc_handle *h, const double *thlpcar, int n);
  * src/modadvection.f90:78-86), diffused (diffc with ekh, src/modsubgrid.f90:147), integrated
  * (src/modtstep.f90:256) and given its top (BCtopq 1 = flux wqtop, 2 = value qt_top, src/modboundary.f90:222-231)
  * and floor (lbottom, BCbotq 1 = flux, "+ wqsurf" as the reference has it, src/modibm.f90:2050-2066) conditions.
- * The condensate and the moist buoyancy (thermo / diagfld of src/modthermodynamics.f90) are not built: with
- * lmoist, udc_set_buoyancy(lbuoyancy = 1) is refused. */
+ * Without buoyancy qt is a passive field.  With lbuoyancy the moist thermodynamics below must be set up before
+ * udc_set_buoyancy; the one-equation closure with moisture (calthv's moist dthvdz) is not built. */
 int udc_set_moisture(udc_handle *h, int iadv_qt, int bctopq, double wqtop, double qt_top, int bcbotq, double wqsurf);
+/* Moist thermodynamics (src/modthermodynamics.f90:57-124, lmoist): thls, qts, ps of &BC / modsurfdata
+ * (src/modsurfdata.f90:41,58,64) and the level heights zf(kb:ke+kh), zh(kb:ke+kh) ([n = ktot+1] each,
+ * src/modglobal.f90:747-751).  udc_thermodynamics is the reference's `thermodynamics`: thermo (condensate, all-or-nothing,
+ * Tetens), diagfld (slab averages, hydrostatic pressures by fromztop, exner functions), calc_halflev, thermo on the
+ * half levels and calthv's thv0h with its slab average thvh -- what forces' buoyancy term then uses
+ * (wp += grav (thv0h - thvh)/thvh, src/modforces.f90:73-84).  Call it once before the first substep
+ * (src/program.f90:120); udc_substep calls it at its end (:214), a routine-by-routine caller does so itself after
+ * udc_boundary.  The reference's off-by-one-level ql0 slab average is reproduced.
+ * udc_thermo_state reads (set = 0) or writes (set = 1) what one call leaves for the next: nine tables of [n = ktot+1]
+ * (k = kb..ke+kh) in the order presf, presh, exnf, exnh, thvh, thl0av, qt0av, ql0av, th0av. */
+int udc_set_moist_thermo(udc_handle *h, double thls, double qts, double ps, const double *zf, const double *zh, int n);
+int udc_thermodynamics(udc_handle *h);
+int udc_thermo_state(udc_handle *h, double *tables, int n, int set);
 int udc_set_buoyancy(udc_handle *h, int lbuoyancy, double grav);
 
 /* One-equation (TKE) closure, &NAMSUBGRID loneeqn (src/modsubgrid.f90:363-400): switches the closure to

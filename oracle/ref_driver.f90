@@ -531,6 +531,7 @@ contains
     call tstep_update                       ! advances rk3step (and dt bookkeeping)
     call put1('rk3', (/real(rk3step), dt/), 1)
     call dump_state('in')                   ! state every kernel below starts from
+    if (lmoist .and. lbuoyancy) call dump_thermo('thm')
     call dump_tend('in')                    ! (tendencies are zero here)
     call advection                          ! src/modadvection.f90:36
     call dump_tend('adv')
@@ -574,6 +575,23 @@ contains
     call halos
     call boundary
     call dump_state('out')
+    if (lmoist .and. lbuoyancy) then       ! src/program.f90:214: the thermodynamics call that ends the substep
+      call thermodynamics
+      call dump_thermo('thn')
+    end if
   end subroutine kernel_vectors
+
+  ! moist thermodynamics: what one `thermodynamics` call leaves behind for the next forces / thermodynamics
+  subroutine dump_thermo(tag)
+    character(*), intent(in) :: tag
+    call put1(tag//'.presf', presf(kb:ke + kh), kb)
+    call put1(tag//'.presh', presh(kb:ke + kh), kb)
+    call put1(tag//'.exnf', exnf(kb:ke + kh), kb)
+    call put1(tag//'.exnh', exnh(kb:ke + kh), kb)
+    call put1(tag//'.thvh', thvh(kb:ke + kh), kb)
+    call put1(tag//'.ql0av', ql0av(kb:ke + kh), kb)
+    call put3(tag//'.ql0', ql0, (/ib - ih, jb - jh, kb - kh/))
+    call put3(tag//'.thv0h', thv0h, (/ib - ih, jb - jh, kb/))
+  end subroutine dump_thermo
 
 end program ref_driver

@@ -1003,6 +1003,117 @@ void orc_coriolis(const orc_grid *g, const double *u0, const double *v0, const d
 }
 
 /* ====================================================================== one-equation (TKE) closure */
+/* ---- moist thermodynamics, src/modthermodynamics.f90 ------------------------------------------------------------ */
+static const double TH_RD = 287.04, TH_RV = 461.5, TH_CP = 1004., TH_RLV = 2.26e6, TH_GRAV = 9.81, TH_PREF0 = 1.e5,
+                    TH_TMELT = 273.16, TH_ES0 = 610.78, TH_AT = 17.27, TH_BT = 35.86;   /* src/modglobal.f90:271-313 */
+/* thermo (:430-503, lqlnr false): "all-or-nothing" condensate of one point */
+static double th_ql(double thl, double qt, double pressure, double exner) {
+  double tl = thl * exner;
+  if (tl < 100.0) tl = 100.0;                                                         /* :483-485 */
+  const double es = TH_ES0 * exp(TH_AT * (tl - TH_TMELT) / (tl - TH_BT));
+  const double qsl = TH_RD / TH_RV * es / (pressure - (1 - TH_RD / TH_RV) * es);
+  const double b1 = TH_RLV * TH_RLV / (tl * tl * TH_CP * TH_RV);
+  const double qs = qsl * (1. + b1 * qt) / (1. + b1 * qsl);
+  return qt - qs > 0. ? qt - qs : 0.;                                                 /* dim(qt - qs, 0) */
+}
+#define TH(t) (s->thermo + (size_t)(t) * (g->nz + 2))
+/* fromztop, :366-422 */
+static void th_fromztop(const orc_grid *g, orc_state *s) {
+  const int ke1 = g->nz + 1;
+  const double rdocp = TH_RD / TH_CP;
+  const double *dzf = g->dzf, *dzh = g->dzh, *th0av = TH(ORC_TH_TH0AV), *qt0av = TH(ORC_TH_QT0AV), *ql0av = TH(ORC_TH_QL0AV);
+  double *presf = TH(ORC_TH_PRESF), *presh = TH(ORC_TH_PRESH);
+  const double thvs = g->thls * (1. + (TH_RV / TH_RD - 1.) * g->qts);                 /* src/modstartup.f90:522 */
+  double thvh = thvs;
+  presf[1] = pow(g->ps, rdocp) - TH_GRAV * pow(TH_PREF0, rdocp) * g->zf[1] / (TH_CP * thvh);
+  presf[1] = pow(presf[1], 1. / rdocp);
+  for (int k = 2; k <= ke1; ++k) {
+    const double thetah = (th0av[k] * dzf[k - 1] + th0av[k - 1] * dzf[k]) / (2 * dzh[k]);
+    const double qth = (qt0av[k] * dzf[k - 1] + qt0av[k - 1] * dzf[k]) / (2 * dzh[k]);
+    const double qlh = (ql0av[k] * dzf[k - 1] + ql0av[k - 1] * dzf[k]) / (2 * dzh[k]);
+    thvh = thetah * (1 + (TH_RV / TH_RD - 1) * qth - TH_RV / TH_RD * qlh);
+    presf[k] = pow(presf[k - 1], rdocp) - TH_GRAV * pow(TH_PREF0, rdocp) * dzh[k] / (TH_CP * thvh);
+    presf[k] = pow(presf[k], 1. / rdocp);
+  }
+  presh[1] = g->ps;
+  for (int k = 2; k <= ke1; ++k) {
+    const double thvf = th0av[k - 1] * (1 + (TH_RV / TH_RD - 1) * qt0av[k - 1] - TH_RV / TH_RD * ql0av[k - 1]);
+    presh[k] = pow(presh[k - 1], rdocp) - TH_GRAV * pow(TH_PREF0, rdocp) * dzf[k - 1] / (TH_CP * thvf);
+    presh[k] = pow(presh[k], 1. / rdocp);
+  }
+}
+/* diagfld, :241-350 (the parts the moist path needs: thl0av, qt0av, ql0av, pressures, exner functions) */
+static void th_diagfld(const orc_grid *g, orc_state *s) {
+  const int ke1 = g->nz + 1;
+  const double cnt = (double)g->nx * (double)g->ny;
+  double *thl0av = TH(ORC_TH_THL0AV), *qt0av = TH(ORC_TH_QT0AV), *ql0av = TH(ORC_TH_QL0AV), *th0av = TH(ORC_TH_TH0AV);
+  double *exnf = TH(ORC_TH_EXNF), *exnh = TH(ORC_TH_EXNH), *presf = TH(ORC_TH_PRESF), *presh = TH(ORC_TH_PRESH);
+  for (int k = 1; k <= ke1; ++k) {
+    double a = 0., b = 0., c = 0.;
+    for (int j = 1; j <= g->ny; ++j)
+      for (int i = 1; i <= g->nx; ++i) { a += M(s->thl0, i, j, k); b += M(s->qt0, i, j, k); c += M(s->ql0, i, j, k); }
+    thl0av[k] = a / cnt; qt0av[k] = b / cnt; ql0av[k] = c / cnt;
+  }
+  for (int k = 1; k <= ke1; ++k) {                                                    /* :290-292 */
+    exnf[k] = 1 - TH_GRAV * g->zf[k] / (TH_CP * g->thls);
+    exnh[k] = 1 - TH_GRAV * g->zh[k] / (TH_CP * g->thls);
+    th0av[k] = thl0av[k] + (TH_RLV / TH_CP) * ql0av[k] / exnf[k];
+  }
+  th_fromztop(g, s);                                                                  /* :311 */
+  for (int k = 1; k <= ke1; ++k) {
+    exnf[k] = pow(presf[k] / TH_PREF0, TH_RD / TH_CP);
+    th0av[k] = thl0av[k] + (TH_RLV / TH_CP) * ql0av[k] / exnf[k];
+  }
+  th_fromztop(g, s);                                                                  /* :318 */
+  exnh[1] = pow(g->ps / TH_PREF0, TH_RD / TH_CP);                                     /* :329-334 */
+  exnf[1] = pow(presf[1] / TH_PREF0, TH_RD / TH_CP);
+  for (int k = 2; k <= ke1; ++k) {
+    exnf[k] = pow(presf[k] / TH_PREF0, TH_RD / TH_CP);
+    exnh[k] = pow(presh[k] / TH_PREF0, TH_RD / TH_CP);
+  }
+}
+/* thl0h, qt0h of calc_halflev (:508-539) and thv0h of calthv (:142-152) at one half level point */
+static double th_thv0h(const orc_grid *g, const orc_state *s, int i, int j, int k) {
+  const double *dzf = g->dzf, *dzh = g->dzh;
+  double thl0h = (M(s->thl0, i, j, k) * dzf[k - 1] + M(s->thl0, i, j, k - 1) * dzf[k]) / (2 * dzh[k]);
+  double qt0h = (M(s->qt0, i, j, k) * dzf[k - 1] + M(s->qt0, i, j, k - 1) * dzf[k]) / (2 * dzh[k]);
+  if (k == 1) { thl0h = g->thls; qt0h = g->qts; }
+  const double exnh = s->thermo[(size_t)ORC_TH_EXNH * (g->nz + 2) + k];
+  const double ql0h = th_ql(thl0h, qt0h, s->thermo[(size_t)ORC_TH_PRESH * (g->nz + 2) + k], exnh);
+  return (thl0h + TH_RLV * ql0h / (TH_CP * exnh)) * (1 + (TH_RV / TH_RD - 1) * qt0h - TH_RV / TH_RD * ql0h);
+}
+void orc_thermodynamics(const orc_grid *g, orc_state *s) {
+  const int ke1 = g->nz + 1;
+  double *valid = s->thermo + (size_t)ORC_TH_N * (g->nz + 2);
+  if (*valid == 0.) { th_diagfld(g, s); *valid = 1.; }                                /* if (timee==0) call diagfld, :64 */
+  const double *presf = TH(ORC_TH_PRESF), *exnf = TH(ORC_TH_EXNF);
+  /* thermo(thl0,qt0,ql0,presf,exnf), :66.  thermo declares its result ql(..., kb:ke+kh) (:441) while ql0 is allocated
+   * from kb-kh (alloc_z, src/modfields.f90:505), so by sequence association the value of level k lands in ql0(k-1):
+   * the reference's ql0 -- and with it ql0av in diagfld -- is one level low, and ql0(ke+kh) is never written.  Kept. */
+  for (int k = 1; k <= ke1; ++k)
+    for (int j = 1; j <= g->ny; ++j)
+      for (int i = 1; i <= g->nx; ++i) M(s->ql0, i, j, k - 1) = th_ql(M(s->thl0, i, j, k), M(s->qt0, i, j, k), presf[k], exnf[k]);
+  th_diagfld(g, s);                                                                   /* :69 */
+  double *thvh = TH(ORC_TH_THVH);
+  const double cnt = (double)g->nx * (double)g->ny;
+  for (int k = 1; k <= ke1; ++k) {                                                    /* :70-76 */
+    double a = 0.;
+    for (int j = 1; j <= g->ny; ++j)
+      for (int i = 1; i <= g->nx; ++i) a += th_thv0h(g, s, i, j, k);
+    thvh[k] = a / cnt;
+  }
+  thvh[1] = TH(ORC_TH_TH0AV)[1] * (1 + (TH_RV / TH_RD - 1) * TH(ORC_TH_QT0AV)[1] - TH_RV / TH_RD * TH(ORC_TH_QL0AV)[1]);   /* :90 */
+}
+void orc_buoyancy_moist(const orc_grid *g, const orc_state *s, double *wp) {
+  if (!g->lbuoyancy) return;
+  const double *thvh = s->thermo + (size_t)ORC_TH_THVH * (g->nz + 2);
+  for (int k = 2; k <= g->nz; ++k)
+    for (int j = 1; j <= g->ny; ++j)
+      for (int i = 1; i <= g->nx; ++i)
+        M(wp, i, j, k) = M(wp, i, j, k) + TH_GRAV * (th_thv0h(g, s, i, j, k) - thvh[k]) / thvh[k];
+}
+#undef TH
+
 /* dthvdz of calthv, dry air (src/modthermodynamics.f90:208-232); thl0 may be NULL (no temperature equation) */
 static double orc_dthvdz(const orc_grid *g, const double *thl0, int i, int j, int k) {
   const double eps1 = 1e-10;
@@ -1173,7 +1284,8 @@ void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
   if (g->lmoist) orc_qt_floor(g, s->ekh, s->qt0, s->qtp);
   if (s->dpdxl && g->coriolis_mode) orc_coriolis(g, s->u0, s->v0, s->w0, s->ug, s->up, s->vp, s->wp);   /* src/program.f90:158 */
   if (s->dpdxl) orc_forces(g, s->dpdxl, s->dpdyl, s->up, s->vp, s->wp);
-  if (s->dpdxl && g->ltempeq) orc_buoyancy(g, s->thl0, s->wp);
+  if (s->dpdxl && g->ltempeq && !g->lmoist) orc_buoyancy(g, s->thl0, s->wp);
+  if (s->dpdxl && g->lmoist && s->thermo) orc_buoyancy_moist(g, s, s->wp);
   if (g->ltempeq && s->dpdxl && s->thlpcar)                                             /* src/modforces.f90:104-110 */
     for (int k = 1; k <= g->nz; ++k)
       for (int j = 1; j <= g->ny; ++j)
@@ -1226,4 +1338,5 @@ void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
   orc_boundary(g, s->u0, s->v0, s->w0, s->um, s->vm, s->wm, s->sv0, s->svm);
   if (g->ltempeq) { orc_thl_top(g, s->ekh, s->thlm); orc_thl_top(g, s->ekh, s->thl0); }     /* src/modboundary.f90:207-217 */
   if (g->lmoist) { orc_qt_top(g, s->ekh, s->qtm); orc_qt_top(g, s->ekh, s->qt0); }          /* src/modboundary.f90:222-231 */
+  if (g->lmoist && g->lbuoyancy && s->thermo) orc_thermodynamics(g, s);                     /* src/program.f90:214 */
 }

@@ -55,6 +55,10 @@ typedef struct {
   int lmoist;               /* total water transported, iadv_qt = 2 (src/modglobal.f90:402) */
   int bctopq;               /* BCtopq: 1 flux wqtop, 2 value qt_top (src/modglobal.f90:147-155) */
   double wqtop, qt_top, wqsurf;    /* src/modsurfdata.f90:65,83,84 */
+  /* moist thermodynamics (lmoist with lbuoyancy): surface values and pressure (src/modsurfdata.f90:41,58,64) and
+   * the level heights zf(kb:ke+kh), zh(kb:ke+kh) as [nz+2] tables indexed by k (src/modglobal.f90:747-751) */
+  double thls, qts, ps;
+  const double *zf, *zh;
 } orc_grid;
 
 /* ---- advection: src/modadvection.f90 */
@@ -127,7 +131,18 @@ typedef struct {
   const double *ug;                       /* [nz+2] geostrophic wind (lprofforc) or NULL */
   double *e120, *e12m, *e12p;             /* m-arrays, used when g->sgs == 3 */
   double *qt0, *qtm, *qtp;                /* m-arrays, used when g->lmoist */
+  /* moist thermodynamics state kept between calls: ORC_TH_N tables of [nz+2] indexed by k (presf, presh, exnf, exnh,
+   * thvh, thl0av, qt0av, ql0av, th0av) followed by one flag (0 = diagfld has not run yet); and ql0 (m-array) */
+  double *thermo, *ql0;
 } orc_state;
+enum { ORC_TH_PRESF, ORC_TH_PRESH, ORC_TH_EXNF, ORC_TH_EXNH, ORC_TH_THVH, ORC_TH_THL0AV, ORC_TH_QT0AV, ORC_TH_QL0AV,
+       ORC_TH_TH0AV, ORC_TH_N };
+/* thermodynamics, src/modthermodynamics.f90:57-124 (lmoist): thermo, diagfld (fromztop twice), calc_halflev, thermo on
+ * the half levels, calthv's thv0h and its slab average thvh.  Called once before the first substep
+ * (src/program.f90:120) and by orc_substep at its end (:214) when g->lmoist && g->lbuoyancy. */
+void orc_thermodynamics(const orc_grid *g, orc_state *s);
+/* forces' buoyancy term with the moist thv0h (src/modforces.f90:73-84, src/modthermodynamics.f90:142-152) */
+void orc_buoyancy_moist(const orc_grid *g, const orc_state *s, double *wp);
 void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt);
 
 #ifdef __cplusplus

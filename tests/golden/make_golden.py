@@ -104,6 +104,8 @@ def write_case(d, iexpnr, text, zf, u=1.0, v=0.0, pgx=1e-4, dthl=0.0, dthlrad=0.
 KEEP_KERNELS = ("meta dzf dzh zf dpdxl dpdyl rk3 in.u0 in.v0 in.w0 in.um in.vm in.wm in.pres0 "
                 "in.ekm in.ekh adv.up adv.vp adv.wp sub.ekm sub.ekh sub.u0 sub.up sub.vp sub.wp bot.up bot.vp frc.up frc.vp "
                 "in.thl0 in.thlm adv.thlp sub.thlp sub.thl0 bot.thlp pre.thlp out.thl0 out.thlm "
+                "thm.presf thm.presh thm.exnf thm.exnh thm.thvh thm.ql0av thm.ql0 thm.thv0h "
+                "thn.presf thn.presh thn.exnf thn.exnh thn.thvh thn.ql0av thn.ql0 thn.thv0h "
                 "in.qt0 in.qtm adv.qtp sub.qtp sub.qt0 bot.qtp pre.qtp out.qt0 out.qtm "
                 "in.e120 in.e12m adv.e12p sub.e12p pre.e12p out.e120 out.e12m "
                 "frc0.up frc0.vp frc0.wp frc0.thlp lsf.up lsf.vp lsf.wp lsf.thlp u0av thl0av frc0.qtp lsf.qtp qt0av "
@@ -203,8 +205,22 @@ CASES.update({
                             bc="BCtopT = 2\nthl_top = 295.\nthls = 288.0\nqts = 0.008\nBCtopq = 2\nqt_top = 0.002",
                             oracle="nspin = 3"), 1.03),
 })
+CASES.update({
+    # moist thermodynamics (lmoist with lbuoyancy): condensate from thermo, hydrostatic pressures / exner functions from
+    # diagfld + fromztop, moist thv0h in forces' buoyancy; a profile that is saturated near the floor and dry above
+    "k_moist_12x8x8": ("kernels", 35, 12, 8, 8,
+                       dict(sgs="vreman", floor=True, physics="lmoist = .true.\nltempeq = .true.\nlbuoyancy = .true.",
+                            bc="BCtopT = 1\nBCbotT = 1\nwtsurf = 0.03\nthls = 288.0\nqts = 0.0105\n"
+                               "BCtopq = 1\nBCbotq = 1\nwqsurf = 4.e-5", oracle="nspin = 4"), 1.05),
+    "run_moist_16x8x12s": ("run", 36, 16, 8, 12,
+                           dict(sgs="smag", floor=True, physics="lmoist = .true.\nltempeq = .true.\nlbuoyancy = .true.",
+                                bc="BCtopT = 2\nthl_top = 290.5\nBCbotT = 1\nwtsurf = 0.04\nthls = 288.0\nqts = 0.0105\n"
+                                   "BCtopq = 2\nqt_top = 0.0104\nBCbotq = 1\nwqsurf = 5.e-5",
+                                oracle="nsub = 9\ndump_at = 3, 9"), 1.06),
+})
 LSF_ONLY = ("k_lsfq_12x8x20",)
-THL_CASES = {"k_lsfq_12x8x20": dict(dthl=0.3, ug=1.0, wtop=0.025, qt=0.008, dqt=-3e-4, dqtdx=2e-7, dqtdy=-1e-7, dqtdt=3e-8),
+THL_CASES = {"k_moist_12x8x8": dict(dthl=0.25, qt=0.0118, dqt=-8e-5), "run_moist_16x8x12s": dict(dthl=0.25, qt=0.0119, dqt=-6e-5),
+             "k_lsfq_12x8x20": dict(dthl=0.3, ug=1.0, wtop=0.025, qt=0.008, dqt=-3e-4, dqtdx=2e-7, dqtdy=-1e-7, dqtdt=3e-8),
              "k_qt_12x8x6": dict(dthl=0.3, qt=0.008, dqt=-4e-4), "run_qt_16x8x12s": dict(dthl=0.25, qt=0.007, dqt=-2e-4),
              "k_lsf_12x8x24": dict(dthl=0.3, ug=1.05, wtop=0.02), "run_lsf_16x8x24s": dict(dthl=0.25, ug=0.95, wtop=-0.03), "k_tke_12x8x6": dict(tke=0.05), "k_tke_thl_12x8x6": dict(tke=0.08, dthl=0.3), "k_coriol_12x8x6": dict(ug=1.1), "run_profforc_16x16x8": dict(ug=1.3), "k_thl_12x8x6": dict(dthl=0.4, dthlrad=2e-3), "run_thl_16x8x12s": dict(dthl=0.25, dthlrad=-1e-3),
              "k_buoy_12x8x6": dict(dthl=0.3), "run_buoy_16x8x12s": dict(dthl=0.2)}

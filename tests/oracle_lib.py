@@ -34,14 +34,18 @@ class OrcGrid(C.Structure):
                 ("cm", C.c_double), ("cn", C.c_double), ("ch1", C.c_double), ("ch2", C.c_double),
                 ("ce1", C.c_double), ("ce2", C.c_double), ("thvs", C.c_double), ("ldelta", C.c_int),
                 ("lmoist", C.c_int), ("bctopq", C.c_int), ("wqtop", C.c_double), ("qt_top", C.c_double),
-                ("wqsurf", C.c_double)]
+                ("wqsurf", C.c_double), ("thls", C.c_double), ("qts", C.c_double), ("ps", C.c_double),
+                ("zf", DP), ("zh", DP)]
 
 
 class OrcState(C.Structure):
     _fields_ = [(n, DP) for n in ("u0", "v0", "w0", "um", "vm", "wm", "up", "vp", "wp", "pres0",
                                   "ekm", "ekh", "p", "pup", "pvp", "pwp", "sv0", "svm", "svp",
                                   "dpdxl", "dpdyl", "thl0", "thlm", "thlp", "thlpcar", "ug", "e120", "e12m", "e12p",
-                                  "qt0", "qtm", "qtp")]
+                                  "qt0", "qtm", "qtp", "thermo", "ql0")]
+
+
+TH_TABLES = ("presf", "presh", "exnf", "exnh", "thvh", "thl0av", "qt0av", "ql0av", "th0av")      # ORC_TH_* order
 
 
 def build():
@@ -76,7 +80,7 @@ class Oracle:
                  uinf=0., vinf=0., lbottom=False, z0=0.05, luvolflowr=False, uflowrate=0.,
                  lvvolflowr=False, vflowrate=0., ltempeq=False, bctopt=1, wttop=0., thl_top=-1., wtsurf=-1.,
                  lbuoyancy=False, coriolis_mode=0, om22=0., om23=0., tke=None,
-                 lmoist=False, bctopq=1, wqtop=0., qt_top=-1., wqsurf=-1.):
+                 lmoist=False, bctopq=1, wqtop=0., qt_top=-1., wqsurf=-1., thls=-1., qts=-1., ps=101325., zf=None, zh=None):
         self.nx, self.ny, self.nz, self.nsv = nx, ny, nz, nsv
         self.dzf = np.ascontiguousarray(dzf, dtype=np.float64)
         self.dzh = np.ascontiguousarray(dzh, dtype=np.float64)
@@ -86,6 +90,8 @@ class Oracle:
             cm = cf / (2. * np.pi) * (1.5 * alpha) ** (-1.5)
             ceps = 2. * np.pi / cf * (1.5 * alpha) ** (-1.5)
             csz = (cm ** 3 / ceps) ** 0.25
+        self.zf = None if zf is None else np.ascontiguousarray(zf, dtype=np.float64)
+        self.zh = None if zh is None else np.ascontiguousarray(zh, dtype=np.float64)
         self.g = OrcGrid(nx, ny, nz, dx, dy, ptr(self.dzf), ptr(self.dzh), numol, prandtlmoli,
                          prandtli, c_vreman, csz, sgs, bctopm, uinf, vinf, nsv, int(bool(lbottom)), z0,
                          int(bool(luvolflowr)), int(bool(lvvolflowr)), uflowrate, vflowrate,
@@ -93,7 +99,7 @@ class Oracle:
                          coriolis_mode, om22, om23,
                          *((tke["cm"], tke["cn"], tke["ch1"], tke["ch2"], tke["ce1"], tke["ce2"], tke["thvs"],
                             int(tke.get("ldelta", 0))) if tke else (0., 0., 0., 0., 0., 0., 1., 0)),
-                         int(bool(lmoist)), bctopq, wqtop, qt_top, wqsurf)
+                         int(bool(lmoist)), bctopq, wqtop, qt_top, wqsurf, thls, qts, ps, ptr(self.zf), ptr(self.zh))
         self.L = lib()
 
     def mshape(self):
@@ -117,8 +123,21 @@ class Oracle:
                 cargs.append(a)
         f(*cargs)
 
+    def thermo_tables(self):
+        """Zeroed state block of the moist thermodynamics: ORC_TH_N tables of [nz+2] and the 'diagfld has run' flag."""
+        return np.zeros(len(TH_TABLES) * (self.nz + 2) + 1)
+
+    def state(self, st: dict):
+        return OrcState(*[ptr(st.get(n)) for n, _ in OrcState._fields_])
+
+    def thermodynamics(self, st: dict):
+        f = self.L.orc_thermodynamics
+        f.restype = None
+        s = self.state(st)
+        f(C.byref(self.g), C.byref(s))
+
     def substep(self, st: dict, rk3step: int, dt: float):
-        s = OrcState(*[ptr(st.get(n)) for n, _ in OrcState._fields_])
+        s = self.state(st)
         f = self.L.orc_substep
         f.restype = None
         f(C.byref(self.g), C.byref(s), C.c_int(rk3step), C.c_double(dt))

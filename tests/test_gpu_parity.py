@@ -49,6 +49,9 @@ def upload_inputs(core, fix, tag, g, nsv):
     if f"{tag}.qt0" in fix:
         core.upload("qt0", marr(fix, f"{tag}.qt0", g.nz))
         core.upload("qtm", marr(fix, f"{tag}.qtm", g.nz))
+    if "thm.presf" in fix and tag == "in":      # what the reference's last thermodynamics call left behind
+        core.thermo_state({n: np.concatenate(([0.], fix["thm." + n].data)) if "thm." + n in fix else np.zeros(g.nz + 2)
+                           for n in core.TH_TABLES})
     if f"{tag}.e120" in fix:
         core.upload("e120", marr(fix, f"{tag}.e120", g.nz))
         core.upload("e12m", marr(fix, f"{tag}.e12m", g.nz))
@@ -161,6 +164,15 @@ def test_each_routine_matches_reference(name, iexp):
     if tke:       # interior only: the reference never refreshes e120's lateral ghosts (src/modboundary.f90:527-536)
         for k in ("e120", "e12m"):
             assert relerr(inx(core.download(k)), inx(marr(fix, "out." + k, nz))) <= KERNEL_TOL, k
+    if "thn.presf" in fix:      # the thermodynamics call that ends the substep (src/program.f90:214)
+        core.thermodynamics()
+        got = core.thermo_state()
+        for n in ("presf", "presh", "exnf", "exnh", "thvh", "ql0av"):
+            ref = fix["thn." + n].data
+            lo = 1 if n == "thvh" else 0          # thvh(kb) is a diagnostic override the device does not keep
+            hi = nz if n == "thvh" else nz + 1    # thvh(ke+kh) is never used (forces: k = kb+1..ke)
+            assert np.abs(got[n][1 + lo:hi + 1] - ref[lo:hi]).max() <= 1e-12 * max(np.abs(ref).max(), 1e-300), n
+        assert fix["thn.ql0av"].data.max() > 1e-4
     core.close()
 
 
@@ -184,6 +196,8 @@ def test_substeps_match_reference(name, iexp, fused):
             core.tstep_update(dt)
             core.advection(); core.subgrid(); core.bottom(); core.coriolis(); core.forces(); core.masscorr(); core.poisson()
             core.tstep_integrate(); core.halos(); core.boundary()
+            if core.moist_thermo:
+                core.thermodynamics()
         if isub in dumps:
             tag = f"s{isub:03d}"
             for k in ("u0", "v0", "w0", "pres0") + (("thl0",) if core.ltempeq else ()) + (("qt0",) if core.lmoist else ()):
@@ -338,6 +352,61 @@ def test_all_forcings_together_against_oracle(shape, sgs, nsv, cor):
     assert abs((core.download("v0")[1:-1, 1:-1, 1:-1] * w).sum() / (nx * ny) + 0.01) < 1e-12
     divmax, _ = core.divergence()
     assert divmax < 1e-11
+    core.close()
+
+
+def test_moist_buoyancy_against_oracle():
+    """Moist thermodynamics in the loop: a partly saturated layer (condensate from thermo, pressures from diagfld /
+    fromztop, moist thv0h in the buoyancy term) through six fused substeps against the CPU oracle."""
+    nx, ny, nz = 48, 40, 20
+    dz = 0.4 * 1.05 ** np.arange(nz)
+    zf = np.cumsum(dz) - 0.5 * dz
+    g = Grid.from_levels(nx, ny, nz, nx * 0.45, ny * 0.5, zf)
+    from udcore.core import DynCore
+    kw = dict(lbottom=True, z0=0.03)
+    qkw = dict(bctopq=2, wqtop=0., qt_top=0.0105, wqsurf=5e-5)
+    core = DynCore(g, sgs=2, **kw)
+    o = ol.Oracle(nx, ny, nz, g.dx, g.dy, g.dzf, g.dzh, sgs=2, ltempeq=True, bctopt=2, wttop=0., thl_top=291., wtsurf=0.04,
+                  lbuoyancy=True, lmoist=True, thls=288., qts=0.0105, zf=g.zf, zh=g.zh, **qkw, **kw)
+    core.set_tempeq(bctopt=2, thl_top=291., wtsurf=0.04)
+    core.set_moisture(**qkw)
+    core.set_moist_thermo(288., 0.0105)
+    core.set_buoyancy(True)
+    st = random_state(g, seed=17)
+    rng = np.random.default_rng(8)
+
+    def field(mean, grad, amp, top):
+        a = np.zeros(g.mshape())
+        a[1:-1, 1:-1, 1:-1] = mean + grad * g.zf[1:nz + 1, None, None] + amp * rng.standard_normal((nz, ny, nx))
+        a[:, 0, :] = a[:, ny, :]; a[:, ny + 1, :] = a[:, 1, :]
+        a[:, :, 0] = a[:, :, nx]; a[:, :, nx + 1] = a[:, :, 1]
+        a[nz + 1] = top(a[nz])
+        return a
+    t = field(288., 0.25, 0.05, lambda r: 2 * 291. - r)
+    t[0] = t[1]
+    q = field(0.0118, -8e-5, 2e-4, lambda r: 2 * 0.0105 - r)
+    st.update(thl0=t, thlm=t.copy(), qt0=q, qtm=q.copy())
+    dp = np.zeros(nz + 2); dp[1:nz + 1] = -1e-3
+    core.load_state(st)
+    core.set_forcing(dp[1:nz + 1], np.zeros(nz))
+    ost = oracle_state(st, g, 0)
+    ost.update(dpdxl=dp, dpdyl=np.zeros(nz + 2), thl0=t.copy(), thlm=t.copy(), thlp=np.zeros(g.mshape()),
+               qt0=q.copy(), qtm=q.copy(), qtp=np.zeros(g.mshape()), thermo=o.thermo_tables(), ql0=np.zeros(g.mshape()))
+    o.thermodynamics(ost)                              # src/program.f90:120; the device does the same on its first substep
+    dt = 0.04
+    for isub in range(6):
+        core.substep(isub % 3 + 1, dt, with_forces=True)
+        o.substep(ost, isub % 3 + 1, dt)
+    ql = ost["ql0"][0:nz + 1, 1:-1, 1:-1]
+    assert 0.05 < (ql > 0).mean() < 0.9                 # partly cloudy: both branches of thermo are exercised
+    got, ref = core.thermo_state(), ost["thermo"]
+    for q_, name in enumerate(core.TH_TABLES[:5]):
+        r = ref[q_ * (nz + 2):(q_ + 1) * (nz + 2)]
+        lo, hi = (2, nz) if name == "thvh" else (1, nz + 1)
+        assert np.abs(got[name][lo:hi + 1] - r[lo:hi + 1]).max() <= 1e-12 * np.abs(r).max(), name
+    for k in ("u0", "v0", "w0", "pres0", "thl0", "qt0"):
+        sc = 1.0 if k == "thl0" else None
+        assert relerr(nocorner(core.download(k)[1:-1]), nocorner(ost[k][1:-1]), sc) <= RUN_TOL, k
     core.close()
 
 

@@ -108,6 +108,9 @@ def run_virtual(P, g, deck_like, st_global, nsub, dt, sgs, nsv=0, extras=False):
             if extras:      # floor wall function + prescribed volume flow + buoyant temperature (all-reduced sums)
                 core.set_masscorr(True, 1.03, True, 0.02)
                 core.set_tempeq(bctopt=2, thl_top=291., wtsurf=0.03)
+                if extras == 2:      # moist thermodynamics: three more all-reduced slab sums per call + thvh
+                    core.set_moisture(bctopq=2, qt_top=0.0105, wqsurf=4e-5)
+                    core.set_moist_thermo(288., 0.0105)
                 core.set_buoyancy(True)
             if P > 1:
                 core.comm_init_local(group)
@@ -119,8 +122,8 @@ def run_virtual(P, g, deck_like, st_global, nsub, dt, sgs, nsv=0, extras=False):
             core.halos()
             core.boundary()
             for isub in range(nsub):
-                core.substep(isub % 3 + 1, dt, False)
-            out[r] = {k: core.download(k) for k in ("u0", "v0", "w0", "pres0") + (("thl0",) if extras else ())}
+                core.substep(isub % 3 + 1, dt, bool(extras))
+            out[r] = {k: core.download(k) for k in ("u0", "v0", "w0", "pres0") + (("thl0",) if extras else ()) + (("qt0",) if extras == 2 else ())}
             out[r]["div"] = core.divergence()
         except Exception as e:   # noqa: BLE001
             errs.append((r, repr(e)))
@@ -132,7 +135,7 @@ def run_virtual(P, g, deck_like, st_global, nsub, dt, sgs, nsv=0, extras=False):
         t.join(timeout=300)
     assert not errs, errs
     res = {}
-    for k in ("u0", "v0", "w0", "pres0") + (("thl0",) if extras else ()):
+    for k in ("u0", "v0", "w0", "pres0") + (("thl0",) if extras else ()) + (("qt0",) if extras == 2 else ()):
         res[k] = np.concatenate([out[r][k][:, 1:-1, :] for r in range(P)], axis=1)
     res["div"] = out[0]["div"]
     for c in cores:
@@ -141,7 +144,8 @@ def run_virtual(P, g, deck_like, st_global, nsub, dt, sgs, nsv=0, extras=False):
 
 
 @pytest.mark.parametrize("shape,sgs,chunks,extras", [((32, 16, 12), 2, 1, False), ((24, 32, 10), 1, 2, False),
-                                                     ((32, 16, 12), 2, 3, False), ((32, 16, 12), 2, 1, True)])
+                                                     ((32, 16, 12), 2, 3, False), ((32, 16, 12), 2, 1, 1),
+                                                     ((32, 16, 12), 2, 2, 2)])
 def test_decomposition_invariance(shape, sgs, chunks, extras, monkeypatch):
     # chunks > 1: the k-chunked all-to-all pipeline (exchange on a second stream, overlapped with rocFFT)
     monkeypatch.setenv("UDC_A2A_CHUNKS", str(chunks))
@@ -158,11 +162,18 @@ def test_decomposition_invariance(shape, sgs, chunks, extras, monkeypatch):
         t[:, :, 0] = t[:, :, nx]; t[:, :, nx + 1] = t[:, :, 1]
         t[0] = t[1]; t[nz + 1] = 2 * 291. - t[nz]
         st["thl0"], st["thlm"] = t, t.copy()
+    if extras == 2:
+        q = np.zeros(g.mshape())
+        q[1:-1, 1:-1, 1:-1] = 0.0118 - 8e-5 * g.zf[1:nz + 1, None, None] + 2e-4 * rng.standard_normal((nz, ny, nx))
+        q[:, 0, :] = q[:, ny, :]; q[:, ny + 1, :] = q[:, 1, :]
+        q[:, :, 0] = q[:, :, nx]; q[:, :, nx + 1] = q[:, :, 1]
+        q[nz + 1] = 2 * 0.0105 - q[nz]
+        st["qt0"], st["qtm"] = q, q.copy()
     ref = run_virtual(1, g, None, st, 6, 0.05, sgs, extras=extras)
     assert ref["div"][0] < 1e-11
     for P in (2, 4):
         got = run_virtual(P, g, None, st, 6, 0.05, sgs, extras=extras)
-        for k in ("u0", "v0", "w0", "pres0") + (("thl0",) if extras else ()):
+        for k in ("u0", "v0", "w0", "pres0") + (("thl0",) if extras else ()) + (("qt0",) if extras == 2 else ()):
             e = relerr(got[k][1:-1], ref[k][1:-1], 1.0 if k == "thl0" else None)
             assert e <= 1e-10, (P, k, e)
         assert abs(got["div"][0] - ref["div"][0]) < 1e-12      # all-reduced max agrees on every rank

@@ -211,6 +211,7 @@ extern "C" int udc_destroy(udc_handle *h) {
   if (h->red) hipFree(h->red);
   if (h->red_host) hipHostFree(h->red_host);
   if (h->thlpcar) hipFree(h->thlpcar);
+  if (h->mt) hipFree(h->mt);
   if (h->ug) hipFree(h->ug);
   if (h->lev_part) hipFree(h->lev_part);
   if (h->lev_sum) hipFree(h->lev_sum);
@@ -381,7 +382,7 @@ extern "C" int udc_set_moisture(udc_handle *h, int iadv_qt, int bctopq, double w
   if (iadv_qt != 2) { udc_set_error("udc_set_moisture: only iadv_qt = 2 (cd2, advecc_2nd) exists (src/modadvection.f90:79-85)"); return 1; }
   if (bctopq != 1 && bctopq != 2) { udc_set_error("udc_set_moisture: BCtopq must be 1 (flux) or 2 (value)"); return 1; }
   if (h->p.lbottom && bcbotq != 1) { udc_set_error("udc_set_moisture: BCbotq must be 1 (flux) (src/modibm.f90:2051,2062-2064)"); return 1; }
-  if (h->lbuoyancy) { udc_set_error("udc_set_moisture: the moist buoyancy (thermo, diagfld) is not built"); return 1; }
+  if (h->lbuoyancy) { udc_set_error("udc_set_moisture: call it before udc_set_buoyancy (and udc_set_moist_thermo in between)"); return 1; }
   if (h->p.sgs == UDC_SGS_ONEEQN) { udc_set_error("udc_set_moisture: the moist dthvdz of the one-equation closure is not built"); return 1; }
   const bool have = (int)h->fields.size() > UDC_QT0 && h->fields[UDC_QT0];
   if (!have) {
@@ -398,6 +399,50 @@ extern "C" int udc_set_moisture(udc_handle *h, int iadv_qt, int bctopq, double w
   sl.topval = bctopq == 2 ? qt_top : wqtop;
   sl.floorflux = -wqsurf;      // the reference adds wqsurf where it subtracts wtsurf (src/modibm.f90:2058 vs :2043)
   h->lmoist = true;
+  return 0;
+}
+
+extern "C" int udc_set_moist_thermo(udc_handle *h, double thls, double qts, double ps, const double *zf, const double *zh, int n) {
+  HIP_OK(hipSetDevice(h->device));
+  const int nz = h->g.nz, n2 = nz + 2;
+  if (!h->lmoist) { udc_set_error("udc_set_moist_thermo: call udc_set_moisture first"); return 1; }
+  if ((int)h->fields.size() <= UDC_THL0 || !h->fields[UDC_THL0]) { udc_set_error("udc_set_moist_thermo: call udc_set_tempeq first"); return 1; }
+  if (n != nz + 1) { udc_set_error("udc_set_moist_thermo: expected %d levels (zf, zh of kb..ke+kh)", nz + 1); return 1; }
+  if (nz + 2 > 2000) { udc_set_error("udc_set_moist_thermo: ktot <= 1998 (diagfld keeps four level tables in LDS)"); return 1; }
+  if (!(thls > 0.) || !(ps > 0.) || qts < 0.) { udc_set_error("udc_set_moist_thermo: thls and ps must be positive, qts >= 0"); return 1; }
+  std::vector<double> t((size_t)udc_handle::MT_N * n2, 0.0);
+  for (int k = 1; k <= nz + 1; ++k) { t[udc_handle::MT_ZF * n2 + k] = zf[k - 1]; t[udc_handle::MT_ZH * n2 + k] = zh[k - 1]; }
+  if (!h->mt) HIP_OK(hipMalloc(&h->mt, sizeof(double) * t.size()));
+  HIP_OK(hipMemcpy(h->mt, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
+  h->thls = thls; h->qts = qts; h->ps = ps;
+  h->mt_valid = false;
+  return 0;
+}
+
+extern "C" int udc_thermodynamics(udc_handle *h) {
+  HIP_OK(hipSetDevice(h->device));
+  return k_thermodynamics(h);
+}
+
+extern "C" int udc_thermo_state(udc_handle *h, double *tables, int n, int set) {
+  HIP_OK(hipSetDevice(h->device));
+  const int nz = h->g.nz, n2 = nz + 2;
+  if (!h->mt) { udc_set_error("udc_thermo_state: call udc_set_moist_thermo first"); return 1; }
+  if (n != nz + 1) { udc_set_error("udc_thermo_state: expected %d levels", nz + 1); return 1; }
+  std::vector<double> t((size_t)udc_handle::MT_STATE_N * n2, 0.0);
+  if (set) {
+    for (int q = 0; q < udc_handle::MT_STATE_N; ++q)
+      for (int k = 1; k <= nz + 1; ++k) t[(size_t)q * n2 + k] = tables[(size_t)q * n + k - 1];
+    HIP_OK(hipMemcpyAsync(h->mt, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    h->mt_valid = true;
+  } else {
+    if (!h->mt_valid) { udc_set_error("udc_thermo_state: no thermodynamics call has been made yet"); return 1; }
+    HIP_OK(hipMemcpyAsync(t.data(), h->mt, sizeof(double) * t.size(), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    for (int q = 0; q < udc_handle::MT_STATE_N; ++q)
+      for (int k = 1; k <= nz + 1; ++k) tables[(size_t)q * n + k - 1] = t[(size_t)q * n2 + k];
+  }
   return 0;
 }
 
@@ -424,7 +469,10 @@ extern "C" int udc_set_tke(udc_handle *h, double cm, double cn, double ch1, doub
 }
 
 extern "C" int udc_set_buoyancy(udc_handle *h, int lbuoyancy, double grav) {
-  if (lbuoyancy && h->lmoist) { udc_set_error("udc_set_buoyancy: the moist buoyancy (thermo, diagfld) is not built"); return 1; }
+  if (lbuoyancy && h->lmoist && !h->mt) {
+    udc_set_error("udc_set_buoyancy: with moisture, call udc_set_moist_thermo first (surface values, pressure, level heights)");
+    return 1;
+  }
   if (lbuoyancy && ((int)h->fields.size() <= UDC_THL0 || !h->fields[UDC_THL0])) {
     udc_set_error("udc_set_buoyancy: call udc_set_tempeq first (thv0h comes from thl0)");
     return 1;
@@ -658,6 +706,7 @@ extern "C" int udc_substep(udc_handle *h, int rk3step, double dt, int with_force
   scalar_halo_list(h, rk3step, s);
   if (!s.empty() && k_halo_y(h, s.data(), (int)s.size(), 2)) return 1;
   if (!fold || !h->slots.empty()) { if (k_top_bottom(h)) return 1; }
+  if (h->lmoist && h->lbuoyancy && k_thermodynamics(h)) return 1;      // src/program.f90:214
   return 0;
 }
 

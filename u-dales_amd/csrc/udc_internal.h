@@ -131,6 +131,13 @@ struct udc_handle {
   double grav = 9.81;
   double *lev_part = nullptr, *lev_sum = nullptr;   // per-level slab sums (thvh)
   size_t lev_cap = 0;
+  // moist thermodynamics (udc_set_moist_thermo): MT_N tables of [nz+2] indexed by the reference's k, kept between
+  // thermodynamics calls (presf/exnf feed the next call's `thermo`, presh/exnh/thvh the next forces)
+  enum { MT_PRESF, MT_PRESH, MT_EXNF, MT_EXNH, MT_THVH, MT_THL0AV, MT_QT0AV, MT_QL0AV, MT_TH0AV, MT_STATE_N,
+         MT_ZF = MT_STATE_N, MT_ZH, MT_SUMS, MT_N = MT_SUMS + 3 };
+  double *mt = nullptr;
+  bool mt_valid = false;       // diagfld has run at least once
+  double thls = 0., qts = 0., ps = 0.;
   double *thlpcar = nullptr;   // [nz+2] radiative heating profile added by forces (src/modforces.f90:104-110), or null
   // masscorr (src/modforces.f90:328): prescribed volume-flow rates
   int luvolflowr = 0, lvvolflowr = 0;
@@ -224,6 +231,7 @@ int k_top_rows_after_closure(udc_handle *h);
 int k_scalar_top_flux(udc_handle *h);              // fluxtop with a non-zero flux: re-imposed after closure (reassure_fluxtop_boundary)
 int k_level_source(udc_handle *h, int slot, const double *src);
 int k_buoyancy(udc_handle *h);
+int k_thermodynamics(udc_handle *h);
 int k_slab_average(udc_handle *h, int field, double *avg_host, int n);
 int k_level_forcings(udc_handle *h, int when, bool wrap_vp);
 int k_tke_closure(udc_handle *h);                  // closure, loneeqn branch

@@ -51,6 +51,171 @@ __global__ __launch_bounds__(256) void buoyancy_kernel(Geo g, TileGrid tg, Metri
   wp[c] = wp[c] + grav * (thl_half(g, m, thl, c, k) - thvh) / thvh;
 }
 
+// ---- moist thermodynamics, src/modthermodynamics.f90 (lmoist) ---------------------------------------------------------
+// constants of src/modglobal.f90:271-313
+constexpr double TH_RD = 287.04, TH_RV = 461.5, TH_CP = 1004., TH_RLV = 2.26e6, TH_PREF0 = 1.e5, TH_TMELT = 273.16,
+                 TH_ES0 = 610.78, TH_AT = 17.27, TH_BT = 35.86;
+// thermo (:430-503, lqlnr false): all-or-nothing condensate of one point
+__device__ __forceinline__ double th_ql(double thl, double qt, double pressure, double exner) {
+  double tl = thl * exner;
+  if (tl < 100.0) tl = 100.0;
+  const double es = TH_ES0 * exp(TH_AT * (tl - TH_TMELT) / (tl - TH_BT));
+  const double qsl = TH_RD / TH_RV * es / (pressure - (1 - TH_RD / TH_RV) * es);
+  const double b1 = TH_RLV * TH_RLV / (tl * tl * TH_CP * TH_RV);
+  const double qs = qsl * (1. + b1 * qt) / (1. + b1 * qsl);
+  return qt - qs > 0. ? qt - qs : 0.;
+}
+// thv0h of calthv (:142-152) from calc_halflev's thl0h, qt0h (:508-539; kf >= kb+1 here) and thermo on the half level
+__device__ __forceinline__ double thv_half(const Geo &g, const Metrics &m, const double *__restrict__ thl, const double *__restrict__ qt,
+                                           double presh, double exnh, long c, int k) {
+  const double thl0h = thl_half(g, m, thl, c, k), qt0h = thl_half(g, m, qt, c, k);
+  const double ql0h = th_ql(thl0h, qt0h, presh, exnh);
+  return (thl0h + TH_RLV * ql0h / (TH_CP * exnh)) * (1 + (TH_RV / TH_RD - 1) * qt0h - TH_RV / TH_RD * ql0h);
+}
+// rows of 64 cells one thread of the slab-sum kernels below walks: fewer, fatter workgroups keep more loads in flight
+constexpr int MS_ROWS = 8;
+// slab sums of thl0, qt0 and the condensate thermo(thl0, qt0, presf, exnf) gives, levels kf = 1..nz+1 (device k = kf-1)
+template <bool QL>
+__global__ __launch_bounds__(256) void moist_sums_kernel(Geo g, int gx, const double *__restrict__ thl, const double *__restrict__ qt,
+                                                          const double *__restrict__ presf, const double *__restrict__ exnf,
+                                                          double *__restrict__ part) {
+  __shared__ double sw[3][4];
+  const int tile = blockIdx.x, k = blockIdx.y, kf = k + 1;
+  const int by = tile / gx, bx = tile - by * gx;
+  const int i = bx * 64 + threadIdx.x;
+  double v[3] = {0., 0., 0.};
+  const double pf = QL ? presf[kf] : 0., ef = QL ? exnf[kf] : 0.;
+#pragma unroll
+  for (int r = 0; r < MS_ROWS; ++r) {
+    const int j = (by * MS_ROWS + r) * 4 + threadIdx.y;
+    if (i < g.nx && j < g.ny) {
+      const long c = g.idx(i, j, k);
+      const double a = thl[c], b = qt[c];
+      v[0] += a; v[1] += b;
+      if (QL) v[2] += th_ql(a, b, pf, ef);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    for (int o = 32; o > 0; o >>= 1) v[q] += __shfl_xor(v[q], o, 64);
+    if (threadIdx.x == 0) sw[q][threadIdx.y] = v[q];
+  }
+  __syncthreads();
+  if (threadIdx.x < 3 && threadIdx.y == 0) {
+    const int q = threadIdx.x;
+    part[((size_t)q * gridDim.y + k) * gridDim.x + tile] = (sw[q][0] + sw[q][1]) + (sw[q][2] + sw[q][3]);
+  }
+}
+__global__ __launch_bounds__(256) void thv_sums_kernel(Geo g, Metrics m, int gx, const double *__restrict__ thl, const double *__restrict__ qt,
+                                                        const double *__restrict__ presh, const double *__restrict__ exnh,
+                                                        double *__restrict__ part) {
+  __shared__ double sw[4];
+  const int tile = blockIdx.x, k = blockIdx.y;
+  const int by = tile / gx, bx = tile - by * gx;
+  const int i = bx * 64 + threadIdx.x;
+  double v = 0.;
+  if (k >= 1) {
+    const double ph = presh[k + 1], eh = exnh[k + 1];
+#pragma unroll
+    for (int r = 0; r < MS_ROWS; ++r) {
+      const int j = (by * MS_ROWS + r) * 4 + threadIdx.y;
+      if (i < g.nx && j < g.ny) v += thv_half(g, m, thl, qt, ph, eh, g.idx(i, j, k), k);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if (threadIdx.x == 0) sw[threadIdx.y] = v;
+  __syncthreads();
+  if (threadIdx.x == 0 && threadIdx.y == 0) part[(size_t)k * gridDim.x + tile] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+}
+__global__ void divide_kernel(double *a, int n, double d) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n) a[q] = a[q] / d;
+}
+__global__ __launch_bounds__(256) void buoyancy_moist_kernel(Geo g, TileGrid tg, Metrics m, const double *__restrict__ thl,
+                                                              const double *__restrict__ qt, const double *__restrict__ presh,
+                                                              const double *__restrict__ exnh, const double *__restrict__ thvh_tab,
+                                                              double grav, double *__restrict__ wp) {
+  int i, j, k;
+  if (!tile_decode(g, tg, i, j, k) || k < 1) return;
+  const long c = g.idx(i, j, k);
+  const double thvh = thvh_tab[k + 1];
+  wp[c] = wp[c] + grav * (thv_half(g, m, thl, qt, presh[k + 1], exnh[k + 1], c, k) - thvh) / thvh;
+}
+
+// diagfld (:241-350) after the slab sums, one workgroup.  mt: the handle's tables ([n2 = nz+2] each, index = reference k);
+// sums: thl0, qt0, ql0 slab sums of levels kf = 1..nz+1 at [q*(nz+1) + kf-1].  fromztop (:366-422) integrates
+// p^(rd/cp) downwards-up: the recurrence runs on p^(rd/cp) itself (two serial chains of nz additions, one per wave)
+// and the powers are taken in parallel; the reference raises to 1/rdocp and back at every level, a round trip that
+// moves the last bit only.
+struct DiagArgs { int nz; double cnt, thls, qts, ps, grav; };
+__device__ void fromztop_dev(const DiagArgs &a, double *mt, const double *__restrict__ dzf, const double *__restrict__ dzh, double *lds) {
+  const int n2 = a.nz + 2, ke1 = a.nz + 1;
+  const double rdocp = TH_RD / TH_CP, c0 = a.grav * pow(TH_PREF0, rdocp);
+  const double *th0av = mt + udc_handle::MT_TH0AV * n2, *qt0av = mt + udc_handle::MT_QT0AV * n2, *ql0av = mt + udc_handle::MT_QL0AV * n2;
+  const double *zf = mt + udc_handle::MT_ZF * n2;
+  double *presf = mt + udc_handle::MT_PRESF * n2, *presh = mt + udc_handle::MT_PRESH * n2;
+  // the two serial chains read their increments from and write their results to LDS (a chain through global memory
+  // pays an L2 round trip per level: the stores keep the compiler from hoisting the loads)
+  double *__restrict__ incf = lds, *__restrict__ inch = lds + n2, *__restrict__ pf = lds + 2 * n2, *__restrict__ ph = lds + 3 * n2;
+  for (int k = 2 + threadIdx.x; k <= ke1; k += blockDim.x) {
+    const double thetah = (th0av[k] * dzf[k - 1] + th0av[k - 1] * dzf[k]) / (2 * dzh[k]);
+    const double qth = (qt0av[k] * dzf[k - 1] + qt0av[k - 1] * dzf[k]) / (2 * dzh[k]);
+    const double qlh = (ql0av[k] * dzf[k - 1] + ql0av[k - 1] * dzf[k]) / (2 * dzh[k]);
+    const double thvh = thetah * (1 + (TH_RV / TH_RD - 1) * qth - TH_RV / TH_RD * qlh);
+    incf[k] = c0 * dzh[k] / (TH_CP * thvh);
+    const double thvf = th0av[k - 1] * (1 + (TH_RV / TH_RD - 1) * qt0av[k - 1] - TH_RV / TH_RD * ql0av[k - 1]);
+    inch[k] = c0 * dzf[k - 1] / (TH_CP * thvf);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double thvs = a.thls * (1. + (TH_RV / TH_RD - 1.) * a.qts);
+    double p = pow(a.ps, rdocp) - c0 * zf[1] / (TH_CP * thvs);
+    pf[1] = p;
+    for (int k = 2; k <= ke1; ++k) { p = p - incf[k]; pf[k] = p; }
+  } else if (threadIdx.x == 64) {
+    double p = pow(a.ps, rdocp);
+    ph[1] = p;
+    for (int k = 2; k <= ke1; ++k) { p = p - inch[k]; ph[k] = p; }
+  }
+  __syncthreads();
+  for (int k = 1 + threadIdx.x; k <= ke1; k += blockDim.x) {
+    presf[k] = pow(pf[k], 1. / rdocp);
+    presh[k] = k == 1 ? a.ps : pow(ph[k], 1. / rdocp);
+  }
+  __syncthreads();
+}
+__global__ __launch_bounds__(256) void diagfld_kernel(DiagArgs a, double *mt, const double *__restrict__ sums,
+                                                       const double *__restrict__ dzf, const double *__restrict__ dzh, int with_ql) {
+  extern __shared__ double lds[];      // 4 (nz+2) doubles
+  const int n2 = a.nz + 2, ke1 = a.nz + 1;
+  double *thl0av = mt + udc_handle::MT_THL0AV * n2, *qt0av = mt + udc_handle::MT_QT0AV * n2, *ql0av = mt + udc_handle::MT_QL0AV * n2;
+  double *th0av = mt + udc_handle::MT_TH0AV * n2, *exnf = mt + udc_handle::MT_EXNF * n2, *exnh = mt + udc_handle::MT_EXNH * n2;
+  const double *zf = mt + udc_handle::MT_ZF * n2, *zh = mt + udc_handle::MT_ZH * n2;
+  const double *presf = mt + udc_handle::MT_PRESF * n2, *presh = mt + udc_handle::MT_PRESH * n2;
+  for (int k = 1 + threadIdx.x; k <= ke1; k += blockDim.x) {
+    thl0av[k] = sums[k - 1] / a.cnt;
+    qt0av[k] = sums[ke1 + k - 1] / a.cnt;
+    // the reference's ql0 holds level k+1 at k and nothing at ke+kh (sequence association in `thermo`, see
+    // oracle/udcore_oracle.c orc_thermodynamics): its slab average is one level low
+    ql0av[k] = (with_ql && k <= a.nz) ? sums[2 * ke1 + k] / a.cnt : 0.;
+    exnf[k] = 1 - a.grav * zf[k] / (TH_CP * a.thls);
+    exnh[k] = 1 - a.grav * zh[k] / (TH_CP * a.thls);
+    th0av[k] = thl0av[k] + (TH_RLV / TH_CP) * ql0av[k] / exnf[k];
+  }
+  __syncthreads();
+  fromztop_dev(a, mt, dzf, dzh, lds);
+  for (int k = 1 + threadIdx.x; k <= ke1; k += blockDim.x) {
+    exnf[k] = pow(presf[k] / TH_PREF0, TH_RD / TH_CP);
+    th0av[k] = thl0av[k] + (TH_RLV / TH_CP) * ql0av[k] / exnf[k];
+  }
+  __syncthreads();
+  fromztop_dev(a, mt, dzf, dzh, lds);
+  for (int k = 1 + threadIdx.x; k <= ke1; k += blockDim.x) {
+    exnf[k] = pow(presf[k] / TH_PREF0, TH_RD / TH_CP);
+    exnh[k] = pow((k == 1 ? a.ps : presh[k]) / TH_PREF0, TH_RD / TH_CP);
+  }
+}
+
 // plain per-level slab sums (stage 1; levelsum_final_kernel is stage 2): levels k = 0..nlev-1 (device), i.e. 1..nlev
 __global__ __launch_bounds__(256) void levelsum_plain_kernel(Geo g, int gx, const double *__restrict__ f, double *__restrict__ part) {
   __shared__ double sw[4];
@@ -115,10 +280,76 @@ int k_level_forcings(udc_handle *h, int when, bool wrap_vp) {
   return 0;
 }
 
+static int lev_scratch(udc_handle *h, size_t need) {
+  if (h->lev_cap < need) {
+    if (h->lev_part) HIP_OK(hipFree(h->lev_part));
+    HIP_OK(hipMalloc(&h->lev_part, sizeof(double) * need));
+    h->lev_cap = need;
+  }
+  return 0;
+}
+
+// thermodynamics, src/modthermodynamics.f90:57-124 with lmoist: [diagfld when none has run yet, :64] thermo(thl0, qt0)
+// with the previous call's presf/exnf, diagfld (slab averages, fromztop twice, exner functions), calc_halflev + thermo
+// on the half levels + calthv's thv0h, summed to thvh.  thv0h itself is recomputed where forces needs it.
+int k_thermodynamics(udc_handle *h) {
+  const Geo &g = h->g;
+  if (!h->lmoist || !h->mt) { udc_set_error("udc_thermodynamics: moist thermodynamics are not set up (udc_set_moisture, udc_set_moist_thermo)"); return 1; }
+  if ((int)h->fields.size() <= UDC_THL0 || !h->fields[UDC_THL0]) { udc_set_error("udc_thermodynamics needs the temperature equation (udc_set_tempeq)"); return 1; }
+  const TileGrid tg = tile_grid(g);
+  const int n2 = g.nz + 2, ke1 = g.nz + 1;
+  const int gy = (g.ny + 4 * MS_ROWS - 1) / (4 * MS_ROWS), mtiles = tg.gx * gy;      // 64 x (4 MS_ROWS) cells per workgroup
+  if (lev_scratch(h, (size_t)mtiles * ke1 * 3)) return 1;
+  const double *thl = h->fields[UDC_THL0], *qt = h->fields[UDC_QT0];
+  double *mt = h->mt, *sums = mt + udc_handle::MT_SUMS * n2;
+  const double cnt = (double)g.nx * (double)h->cfg.jtot;
+  const DiagArgs da{g.nz, cnt, h->thls, h->qts, h->ps, h->grav};
+  PROF(h, "thermodynamics");
+  for (int pass = h->mt_valid ? 1 : 0; pass < 2; ++pass) {
+    const dim3 gr((unsigned)mtiles, (unsigned)ke1), b(64, 4);
+    if (pass) hipLaunchKernelGGL(moist_sums_kernel<true>, gr, b, 0, h->stream, g, tg.gx, thl, qt, (const double *)(mt + udc_handle::MT_PRESF * n2),
+                                 (const double *)(mt + udc_handle::MT_EXNF * n2), h->lev_part);
+    else hipLaunchKernelGGL(moist_sums_kernel<false>, gr, b, 0, h->stream, g, tg.gx, thl, qt, (const double *)nullptr, (const double *)nullptr, h->lev_part);
+    hipLaunchKernelGGL(levelsum_final_kernel, dim3((unsigned)(3 * ke1)), dim3(256), 0, h->stream, mtiles, h->lev_part, sums);
+    HIP_OK(hipGetLastError());
+    if (comm_allreduce(h, sums, 3 * ke1, 1)) return 1;       // avexy_ibm's MPI_ALLREDUCE over the slabs
+    hipLaunchKernelGGL(diagfld_kernel, dim3(1), dim3(256), sizeof(double) * 4 * n2, h->stream, da, mt, (const double *)sums, h->m.dzf, h->m.dzh, pass);
+    HIP_OK(hipGetLastError());
+    h->mt_valid = true;
+  }
+  double *thvh = mt + udc_handle::MT_THVH * n2;
+  hipLaunchKernelGGL(thv_sums_kernel, dim3((unsigned)mtiles, (unsigned)g.nz), dim3(64, 4), 0, h->stream, g, h->m, tg.gx, thl, qt,
+                     (const double *)(mt + udc_handle::MT_PRESH * n2), (const double *)(mt + udc_handle::MT_EXNH * n2), h->lev_part);
+  hipLaunchKernelGGL(levelsum_final_kernel, dim3((unsigned)g.nz), dim3(256), 0, h->stream, mtiles, h->lev_part, thvh + 1);
+  HIP_OK(hipGetLastError());
+  if (comm_allreduce(h, thvh + 1, g.nz, 1)) return 1;
+  hipLaunchKernelGGL(divide_kernel, dim3((g.nz + 255) / 256), dim3(256), 0, h->stream, thvh + 1, g.nz, cnt);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+static int k_buoyancy_moist(udc_handle *h) {
+  const Geo &g = h->g;
+  if (!h->mt || !h->mt_valid) {
+    udc_set_error("moist buoyancy: call udc_thermodynamics once before the first substep (src/program.f90:120)");
+    return 1;
+  }
+  const int n2 = g.nz + 2;
+  PROF(h, "buoyancy");
+  dim3 b(64, 4, 1), gr = cell_grid(g, b);
+  hipLaunchKernelGGL(buoyancy_moist_kernel, gr, b, 0, h->stream, g, tile_grid(g), h->m, (const double *)h->fields[UDC_THL0],
+                     (const double *)h->fields[UDC_QT0], (const double *)(h->mt + udc_handle::MT_PRESH * n2),
+                     (const double *)(h->mt + udc_handle::MT_EXNH * n2), (const double *)(h->mt + udc_handle::MT_THVH * n2), h->grav,
+                     h->fields[UDC_WP]);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
 int k_buoyancy(udc_handle *h) {
   const Geo &g = h->g;
   if (!h->lbuoyancy) return 0;
   if ((int)h->fields.size() <= UDC_THL0 || !h->fields[UDC_THL0]) { udc_set_error("buoyancy needs the temperature equation (udc_set_tempeq)"); return 1; }
+  if (h->lmoist) return k_buoyancy_moist(h);
   const TileGrid tg = tile_grid(g);
   const size_t need = (size_t)tg.tiles * g.nz;
   if (h->lev_cap < need) {

@@ -111,6 +111,17 @@ module udc_iface
       integer(c_int), value :: iadv_qt, bctopq, bcbotq
       real(c_double), value :: wqtop, qt_top, wqsurf
     end function udc_set_moisture
+    integer(c_int) function udc_set_moist_thermo(h, thls, qts, ps, zf, zh, n) bind(C, name='udc_set_moist_thermo')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), value :: thls, qts, ps
+      real(c_double), intent(in) :: zf(*), zh(*)
+      integer(c_int), value :: n
+    end function udc_set_moist_thermo
+    integer(c_int) function udc_thermodynamics(h) bind(C, name='udc_thermodynamics')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
+    end function udc_thermodynamics
     integer(c_int) function udc_set_thl_source(h, thlpcar, n) bind(C, name='udc_set_thl_source')
       import :: c_int, c_ptr, c_double
       type(c_ptr), value :: h
@@ -213,8 +224,8 @@ contains
   subroutine udc_ensure
     use modglobal, only: itot, jtot, ktot, dx, dy, dzf, dzh, kb, ke, kh, numol, prandtlmoli, nsv, &
                          BCtopm, Uinf, Vinf, lles, ltempeq, lbuoyancy, lmoist, iadv_thl, BCtopT, BCbotT, grav, e12min, &
-                         iadv_qt, BCtopq, BCbotq
-    use modsurfdata, only: wttop, thl_top, wtsurf, thvs, wqtop, qt_top, wqsurf
+                         iadv_qt, BCtopq, BCbotq, zf, zh
+    use modsurfdata, only: wttop, thl_top, wtsurf, thvs, wqtop, qt_top, wqsurf, thls, qts, ps
     use modsubgriddata, only: lsmagorinsky, lvreman, loneeqn, ldelta, prandtli, c_vreman, csz, cm, cn, ch1, ch2, ce1, ce2
     use modfields, only: dpdxl, dpdyl, thlpcar
     use modmpi, only: myid, nprocs, nprocx, comm3d, mpierr
@@ -272,12 +283,16 @@ contains
       call udc_check(udc_set_tempeq(udc_h, int(iadv_thl, c_int), int(BCtopT, c_int), real(wttop, c_double), &
                                     real(thl_top, c_double), int(BCbotT, c_int), real(wtsurf, c_double)), 'udc_set_tempeq')
       call udc_check(udc_set_thl_source(udc_h, thlpcar(kb:ke), int(ktot, c_int)), 'udc_set_thl_source')
-      if (lbuoyancy) call udc_check(udc_set_buoyancy(udc_h, 1_c_int, real(grav, c_double)), 'udc_set_buoyancy')
     end if
-    if (lmoist) then       ! total water as a transported field; udc_set_buoyancy above refuses lmoist (moist thermo not built)
+    if (lmoist) then       ! total water; with buoyancy the moist thermodynamics (thermo, diagfld, calthv) too
       call udc_check(udc_set_moisture(udc_h, int(iadv_qt, c_int), int(BCtopq, c_int), real(wqtop, c_double), &
                                       real(qt_top, c_double), int(BCbotq, c_int), real(wqsurf, c_double)), 'udc_set_moisture')
+      if (ltempeq .and. lbuoyancy) then
+        call udc_check(udc_set_moist_thermo(udc_h, real(thls, c_double), real(qts, c_double), real(ps, c_double), &
+                                            zf(kb:ke + kh), zh(kb:ke + kh), int(ktot + 1, c_int)), 'udc_set_moist_thermo')
+      end if
     end if
+    if (ltempeq .and. lbuoyancy) call udc_check(udc_set_buoyancy(udc_h, 1_c_int, real(grav, c_double)), 'udc_set_buoyancy')
     if (cfg%sgs == 3) then   ! after udc_set_tempeq: the closure reads thl0 when the temperature equation is on
       call udc_check(udc_set_tke(udc_h, real(cm, c_double), real(cn, c_double), real(ch1, c_double), real(ch2, c_double), &
                                  real(ce1, c_double), real(ce2, c_double), real(e12min, c_double), real(grav, c_double), &

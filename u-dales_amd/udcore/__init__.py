@@ -27,16 +27,20 @@ def from_deck(deck, device=0, rank=0, nranks=1):
                         bctopt=int(deck.get("BC", "BCtopT")), wttop=float(deck.get("BC", "wttop")),
                         thl_top=float(deck.get("BC", "thl_top")), bcbott=int(deck.get("BC", "BCbotT")),
                         wtsurf=float(deck.get("BC", "wtsurf")), thlpcar=getattr(deck, "thlpcar", None))
-        if deck.get("PHYSICS", "lbuoyancy"):
-            core.set_buoyancy(True)
     if deck.get("PHYSICS", "lmoist"):
-        if deck.get("PHYSICS", "lbuoyancy") or sgs == 3:
-            raise ValueError("lmoist with lbuoyancy or loneeqn: the moist thermodynamics (thermo, diagfld) are not built")
+        if sgs == 3:
+            raise ValueError("lmoist with loneeqn: calthv's moist dthvdz is not built")
         iadv = int(deck.get("DYNAMICS", "iadv_qt"))
         core.set_moisture(iadv_qt=int(deck.get("DYNAMICS", "iadv_mom")) if iadv < 0 else iadv,
                           bctopq=int(deck.get("BC", "BCtopq")), wqtop=float(deck.get("BC", "wqtop")),
                           qt_top=float(deck.get("BC", "qt_top")), bcbotq=int(deck.get("BC", "BCbotq")),
                           wqsurf=float(deck.get("BC", "wqsurf")))
+        if deck.get("PHYSICS", "lbuoyancy"):
+            if not deck.get("PHYSICS", "ltempeq"):
+                raise ValueError("lmoist with lbuoyancy needs ltempeq on the device path")
+            core.set_moist_thermo(float(deck.get("BC", "thls")), float(deck.get("BC", "qts")), float(deck.get("BC", "ps")))
+    if deck.get("PHYSICS", "ltempeq") and deck.get("PHYSICS", "lbuoyancy"):
+        core.set_buoyancy(True)
     if sgs == 3:      # after set_tempeq: the closure reads thl0 when the temperature equation is on
         thls, qts = float(deck.get("BC", "thls")), float(deck.get("BC", "qts"))
         core.set_tke(cf=float(deck.get("NAMSUBGRID", "cf")), cn=float(deck.get("NAMSUBGRID", "cn")),

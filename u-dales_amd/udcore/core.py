@@ -45,6 +45,7 @@ class DynCore:
         self.dt = 0.
         self.ltempeq = False
         self.lmoist = False
+        self.moist_thermo, self._thermo_started = False, False
         self.loneeqn = False
         self.timee = 0.
 
@@ -137,6 +138,7 @@ class DynCore:
         L._check(self.lib.udc_bottom(self.h), "udc_bottom")
 
     def forces(self):
+        self._ensure_thermo()
         L._check(self.lib.udc_forces(self.h), "udc_forces")
 
     def set_masscorr(self, luvolflowr=False, uflowrate=1., lvvolflowr=False, vflowrate=1.):
@@ -158,6 +160,40 @@ class DynCore:
         L._check(self.lib.udc_set_moisture(self.h, int(iadv_qt), int(bctopq), C.c_double(wqtop), C.c_double(qt_top),
                                            int(bcbotq), C.c_double(wqsurf)), "udc_set_moisture")
         self.lmoist = True
+
+    TH_TABLES = ("presf", "presh", "exnf", "exnh", "thvh", "thl0av", "qt0av", "ql0av", "th0av")
+
+    def set_moist_thermo(self, thls, qts, ps=101325.):
+        """Moist thermodynamics (needed by lmoist with lbuoyancy), see include/udcore.h udc_set_moist_thermo."""
+        zf = np.ascontiguousarray(self.g.zf[1:self.g.nz + 2], dtype=np.float64)
+        zh = np.ascontiguousarray(self.g.zh[1:self.g.nz + 2], dtype=np.float64)
+        L._check(self.lib.udc_set_moist_thermo(self.h, C.c_double(thls), C.c_double(qts), C.c_double(ps),
+                                               zf.ctypes.data_as(L.DP), zh.ctypes.data_as(L.DP), len(zf)), "udc_set_moist_thermo")
+        self.moist_thermo, self._thermo_started = True, False
+
+    def thermodynamics(self):
+        """The reference's `thermodynamics` (src/program.f90:120 before the loop, :214 at the end of every substep)."""
+        L._check(self.lib.udc_thermodynamics(self.h), "udc_thermodynamics")
+        self._thermo_started = True
+
+    def thermo_state(self, tables=None):
+        """Read (tables None) or write the per-level state of the moist thermodynamics: dict name -> [nz+2] arrays
+        indexed by the reference's k (entry 0 unused), names in TH_TABLES."""
+        n = self.g.nz + 1
+        a = np.zeros((len(self.TH_TABLES), n))
+        if tables is not None:
+            for q, name in enumerate(self.TH_TABLES):
+                a[q] = np.asarray(tables[name], dtype=np.float64)[1:n + 1]
+        L._check(self.lib.udc_thermo_state(self.h, a.ctypes.data_as(L.DP), n, 0 if tables is None else 1), "udc_thermo_state")
+        if tables is not None:
+            self._thermo_started = True
+            return None
+        return {name: np.concatenate(([0.], a[q])) for q, name in enumerate(self.TH_TABLES)}
+
+    def _ensure_thermo(self):
+        # program.f90:120: one thermodynamics call on the start state before the first forces
+        if getattr(self, "moist_thermo", False) and not self._thermo_started:
+            self.thermodynamics()
 
     def slab_average(self, field):
         """Horizontal mean of `field` per level, indexed by the reference's k: entries 1..nz+1 (entry 0 unused)."""
@@ -224,9 +260,11 @@ class DynCore:
 
     # ---- fused fast path
     def substep(self, rk3step, dt, with_forces=True):
+        self._ensure_thermo()
         L._check(self.lib.udc_substep(self.h, rk3step, C.c_double(dt), 1 if with_forces else 0), "udc_substep")
 
     def run(self, nsub, dt, rk3step0=1, with_forces=True):
+        self._ensure_thermo()
         L._check(self.lib.udc_run(self.h, nsub, rk3step0, C.c_double(dt), 1 if with_forces else 0), "udc_run")
 
     def divergence(self):
