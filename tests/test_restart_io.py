@@ -122,3 +122,33 @@ def test_device_warm_start_and_hand_back(tmp_path):
     divmax, _ = core.divergence()
     assert divmax < 1e-11
     core.close()
+
+
+@pytest.mark.gpu
+def test_restart_round_trip_with_temperature_and_moisture(tmp_path):
+    """thl0 and qt0 travel through the initd file: a device run stopped after RK stage 3, written out, read into a fresh
+    handle and continued arrives where the uninterrupted device run does (moist thermodynamics on)."""
+    import udcore
+    from common import RUN_CASES, deck_path, nocorner, relerr
+    from udcore import read_deck, cold_start
+    name = "run_moist_16x8x12s"
+    d = read_deck(deck_path(name, RUN_CASES[name]))
+    dt = float(d.get("RUN", "dtmax"))
+    a = udcore.from_deck(d)
+    a.load_state(cold_start(a.g, d))
+    for isub in range(9):
+        a.substep(isub % 3 + 1, dt, True)
+        if isub == 5:
+            paths = R.save_restart(a, str(tmp_path), 36, 2, 2 * dt, dt)
+            th = a.thermo_state()
+    rec = R.read_initd(paths[0], a.g.nx, a.g.ny, a.g.nz)
+    assert rec["thl0"][1:-1].min() > 280. and 0.005 < rec["qt0"][1:-1].max() < 0.02
+    b = udcore.from_deck(d)
+    R.load_restart(b, str(tmp_path), 36, 2)
+    b.thermo_state(th)          # presf/exnf of the previous call are not in the reference's restart format
+    for isub in range(6, 9):
+        b.substep(isub % 3 + 1, dt, True)
+    for k in ("u0", "v0", "w0", "pres0", "thl0", "qt0"):
+        sc = 1.0 if k == "thl0" else None
+        assert relerr(nocorner(b.download(k)[1:-1]), nocorner(a.download(k)[1:-1]), sc) <= 1e-9, k
+    a.close(); b.close()
