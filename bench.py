@@ -269,7 +269,7 @@ def main():
     out = {
         "metric": "cell-updates/sec (advect+diffuse+Poisson step)", "value": value, "unit": "cell-updates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if (args.size and world > 1) else "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{nx}x{ny}x{nz} neutral empty-domain channel, cd2 momentum advection + "
                                f"Vreman SGS diffusion + FFT(x,y)/tridiagonal(z) Poisson + RK3 substep "
