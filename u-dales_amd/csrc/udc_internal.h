@@ -92,7 +92,8 @@ struct udc_handle {
   double *metrics_dev = nullptr;        // backing store for Metrics arrays
   // Poisson
   double *spec = nullptr;               // complex (nkx, ny, nz) spectral work array
-  double *ztab = nullptr;               // Thomas d(kx,ky,k) table
+  double *ztab = nullptr;               // Thomas pivot table z(kx,ky,k)
+  bool thomas_lds = false, thomas_lds_slab = false;   // which kernel solves (and hence how its table is laid out)
   double *ev = nullptr;                 // eigenvalue xrt(kx)+yrt(ky)
   double *tri = nullptr;                // a,b,c (3*(nz+2))
   int nkx = 0, nkxp = 0;                // r2c modes in x and the padded row pitch of `spec`

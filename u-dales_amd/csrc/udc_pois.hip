@@ -54,20 +54,27 @@ __global__ __launch_bounds__(256) void div_rhs_kernel(Geo g, TileGrid tg, Metric
 
 // ---- Thomas table: the pivots z(m,k) = 1/(b_k + e_m - a_k d_{k-1}) of solmpj (src/modpois.f90:1120-1139)
 // do not depend on the RHS; d(m,k) = c_k z(m,k) is rebuilt from it with the reference's own multiply.
+// Two layouts: [level][mode] for the streaming kernel (a wave reads 64 consecutive modes of one level), and blocks of
+// ZB modes [mode / ZB][level][mode % ZB] for the LDS kernel, whose workgroup owns ZB modes and walks the levels: its
+// chunk of the table is then one contiguous run instead of 64-byte pieces of 128-byte lines shared with the neighbour.
+constexpr int ZB = 8;
+__host__ __device__ __forceinline__ size_t ztab_index(bool blocked, int nmodes, int nz, int lev, int mo) {
+  return blocked ? ((size_t)(mo / ZB) * (size_t)(nz - 1) + lev) * ZB + (mo % ZB) : (size_t)lev * nmodes + mo;
+}
 __global__ void thomas_table_kernel(int nmodes, int nz, const double *__restrict__ ev,
-                                    const double *__restrict__ tri, double btopD, double *__restrict__ ztab) {
+                                    const double *__restrict__ tri, double btopD, double *__restrict__ ztab, int blocked) {
   const int mo = blockIdx.x * blockDim.x + threadIdx.x;
   if (mo >= nmodes) return;
   const double *a = tri, *b = tri + (nz + 2), *c = tri + 2 * (nz + 2);
   const double e = ev[mo];
   double z = 1. / (b[1] + e);
   double d = c[1] * z;
-  ztab[mo] = z;
+  if (nz >= 2) ztab[ztab_index(blocked, nmodes, nz, 0, mo)] = z;
   for (int k = 2; k <= nz - 1; ++k) {
     const double bbk = b[k] + e;
     z = 1. / (bbk - a[k] * d);
     d = c[k] * z;
-    ztab[(long)(k - 1) * nmodes + mo] = z;
+    ztab[ztab_index(blocked, nmodes, nz, k - 1, mo)] = z;
   }
   (void)btopD;
 }
@@ -164,10 +171,19 @@ __global__ __launch_bounds__(64) void thomas_kernel(int nmodes, int nz, double s
 //   forward  x_k = (x_k s - a_k x_{k-1}) z_k   as  fma(-(a_k z_k), x_{k-1}, (x_k s) z_k)
 //   back     x_k = x_k - (c_k z_k) x_{k+1}     as  fma(-(c_k z_k), x_{k+1}, x_k)
 // (thomas_kernel evaluates the same expressions, so the result does not depend on which variant runs).
-template <int M, int KC>
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+template <int M, int KC, int D>
 __global__ __launch_bounds__(256) void thomas_lds_kernel(int nmodes, int nz, double scale,
     const double *__restrict__ ev, const double *__restrict__ tri, double btopD,
     const double *__restrict__ ztab, double2 *__restrict__ x) {
+  static_assert(M == ZB, "the blocked pivot table is laid out for ZB modes per workgroup");
   constexpr int C = 2 * M;                 // doubles per level
   constexpr int R = KC * M / 256;          // staged elements per thread per chunk
   constexpr int U = 8;                     // levels per register group in the recurrence
@@ -182,24 +198,28 @@ __global__ __launch_bounds__(256) void thomas_lds_kernel(int nmodes, int nz, dou
   const size_t st = (size_t)nmodes;
   const int nch = (nz + KC - 1) / KC;
 
-  double2 rx[R];
-  double rz[R], rg[R], rt[R];
+  // D chunks of loads are in flight per workgroup (register slots, statically indexed): one chunk ahead leaves
+  // every chunk waiting a full HBM round trip, because the recurrence on a chunk is much shorter than that
+  double2 rx[D][R];
+  double rz[D][R], rg[D][R], rt[D][R];
   // fwd: x, z, a (and c for the top chunk); back: z, c
-  auto issue = [&](int ch, bool fwd) {
+  auto issue = [&](int ch, bool fwd, auto S) {
+    constexpr int s = decltype(S)::value;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int idx = tid + 256 * r;
       const int kk = idx / M, mm = idx % M;
       const int lev = ch * KC + kk;        // 0-based level, k = lev + 1
       const bool ok = lev < nz && m0 + mm < nmodes;
-      if (fwd) rx[r] = ok ? x[(size_t)lev * st + m0 + mm] : make_double2(0., 0.);
-      rz[r] = (ok && lev < nz - 1) ? ztab[(size_t)lev * st + m0 + mm] : 1.;
+      if (fwd) rx[s][r] = ok ? x[(size_t)lev * st + m0 + mm] : make_double2(0., 0.);
+      rz[s][r] = (ok && lev < nz - 1) ? ztab[ztab_index(true, nmodes, nz, lev, m0 + mm)] : 1.;
       const int kc_ = min(lev + 1, nz);
-      rg[r] = fwd ? a[kc_] : c[kc_];
-      if (fwd && ch == nch - 1) rt[r] = c[kc_];
+      rg[s][r] = fwd ? a[kc_] : c[kc_];
+      if (fwd && ch == nch - 1) rt[s][r] = c[kc_];
     }
   };
-  auto commit = [&](int ch, bool fwd) {
+  auto commit = [&](int ch, bool fwd, auto S) {
+    constexpr int s = decltype(S)::value;
     double *zc = zb + (ch & 1) * (KC * M);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -207,26 +227,29 @@ __global__ __launch_bounds__(256) void thomas_lds_kernel(int nmodes, int nz, dou
       const int kk = idx / M, mm = idx % M;
       const int lev = ch * KC + kk;
       if (fwd && lev < nz) {
-        double2 t = rx[r];
-        t.x = (t.x * scale) * rz[r];
-        t.y = (t.y * scale) * rz[r];
+        double2 t = rx[s][r];
+        t.x = (t.x * scale) * rz[s][r];
+        t.y = (t.y * scale) * rz[s][r];
         *reinterpret_cast<double2 *>(xs + (size_t)lev * C + 2 * mm) = t;
       }
-      zc[kk * M + mm] = -(rg[r] * rz[r]);
-      if (fwd && ch == nch - 1) zt[kk * M + mm] = -(rt[r] * rz[r]);
+      zc[kk * M + mm] = -(rg[s][r] * rz[s][r]);
+      if (fwd && ch == nch - 1) zt[kk * M + mm] = -(rt[s][r] * rz[s][r]);
     }
   };
 
   // the last pivot of the forward sweep is needed again when the top level is closed
   double zl = 0.;
-  if (tid < C && nz >= 2) zl = ztab[(size_t)(nz - 2) * st + min(m0 + (tid >> 1), nmodes - 1)];
-  issue(0, true);
-  commit(0, true);
+  if (tid < C && nz >= 2) zl = ztab[ztab_index(true, nmodes, nz, nz - 2, min(m0 + (tid >> 1), nmodes - 1))];
+  static_for<D>([&](auto S) { if (decltype(S)::value < nch) issue(decltype(S)::value, true, S); });
+  commit(0, true, std::integral_constant<int, 0>{});
   __syncthreads();
   double xp = 0.;
-  // forward elimination, levels 1 .. nz-1 (0-based 0 .. nz-2)
-  for (int ch = 0; ch < nch; ++ch) {
-    if (ch + 1 < nch) issue(ch + 1, true);
+  // forward elimination, levels 1 .. nz-1 (0-based 0 .. nz-2); chunk ch lives in slot ch % D
+  for (int ch0 = 0; ch0 < nch; ch0 += D) static_for<D>([&](auto S) {
+    constexpr int d = decltype(S)::value;
+    const int ch = ch0 + d;
+    if (ch >= nch) return;
+    if (ch + D < nch) issue(ch + D, true, S);      // slot d was committed in the previous iteration
     if (tid < C) {
       const double *zc = zb + (ch & 1) * (KC * M) + (tid >> 1);
       const int l0 = ch * KC;
@@ -263,9 +286,9 @@ __global__ __launch_bounds__(256) void thomas_lds_kernel(int nmodes, int nz, dou
         xs[(size_t)lev * C + tid] = xp;
       }
     }
-    if (ch + 1 < nch) commit(ch + 1, true);
+    if (ch + 1 < nch) commit(ch + 1, true, std::integral_constant<int, (d + 1) % D>{});
     __syncthreads();
-  }
+  });
   // close the forward sweep: the top level (stored as x_nz s, its "pivot" slot was 1)
   if (tid < C) {
     const int mo = min(m0 + (tid >> 1), nmodes - 1);
@@ -279,9 +302,16 @@ __global__ __launch_bounds__(256) void thomas_lds_kernel(int nmodes, int nz, dou
     xs[(size_t)(nz - 1) * C + tid] = xc;
     xp = xc;
   }
-  // back substitution, levels nz-1 .. 1, chunk by chunk from the top; finished chunks stream out
-  for (int ch = nch - 1; ch >= 0; --ch) {
-    if (ch > 0) issue(ch - 1, false);
+  // back substitution, levels nz-1 .. 1, chunk by chunk from the top; finished chunks stream out.  The top chunk's
+  // coefficients are in zt already; chunk c <= nch-2 lives in slot (nch-2-c) % D
+  static_for<D>([&](auto S) { if (nch - 2 - decltype(S)::value >= 0) issue(nch - 2 - decltype(S)::value, false, S); });
+  for (int t0 = 0; t0 < nch; t0 += D) static_for<D>([&](auto S) {
+    constexpr int d = decltype(S)::value;
+    const int t = t0 + d;
+    if (t >= nch) return;
+    const int ch = nch - 1 - t;
+    if (t >= 1 && nch - 1 - t - D >= 0)            // the slot freed by the previous iteration's commit
+      issue(nch - 1 - t - D, false, std::integral_constant<int, (d + D - 1) % D>{});
     if (tid < C) {
       const double *zc = (ch == nch - 1 ? zt : zb + (ch & 1) * (KC * M)) + (tid >> 1);
       const int l0 = ch * KC;
@@ -317,7 +347,7 @@ __global__ __launch_bounds__(256) void thomas_lds_kernel(int nmodes, int nz, dou
         }
       }
     }
-    if (ch > 0) commit(ch - 1, false);
+    if (ch > 0) commit(ch - 1, false, S);
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -327,32 +357,44 @@ __global__ __launch_bounds__(256) void thomas_lds_kernel(int nmodes, int nz, dou
       if (lev < nz && m0 + mm < nmodes)
         x[(size_t)lev * st + m0 + mm] = *reinterpret_cast<const double2 *>(xs + (size_t)lev * C + 2 * mm);
     }
-  }
+  });
 }
 
-// picks the LDS variant that fits (two workgroups per CU when possible), else the streaming kernel
-static int launch_thomas(udc_handle *h, long nmodes, int nz, double scale, const double *ev, const double *ztab, double2 *x) {
-  // UDC_THOMAS: 0 = streaming kernel, 3 = LDS kernel whenever it fits; default: the LDS kernel where the
-  // streaming one would put fewer than ~6 waves on a CU (it needs that many to cover HBM latency), measured
-  // cross-over on MI355X between 68K modes (LDS 15 % faster) and 135K modes (streaming 5 % faster)
+// LDS variant or streaming kernel?  Decided once per table (the table's layout follows the kernel).
+// UDC_THOMAS: 0 = streaming kernel, 3 = LDS kernel whenever it fits; default: the LDS kernel where the
+// streaming one would put fewer than ~6 waves on a CU (it needs that many to cover HBM latency), measured
+// cross-over on MI355X between 68K modes (LDS 15 % faster) and 135K modes (streaming 5 % faster)
+static size_t thomas_lds_bytes(int nz, int M, int KC) { return ((size_t)nz * 2 * M + 3 * (size_t)KC * M) * sizeof(double); }
+static bool thomas_wants_lds(long nmodes, int nz) {
   const char *env = getenv("UDC_THOMAS");
   const int mode = env ? atoi(env) : -1;
+  const bool want = mode == 3 || (mode < 0 && nmodes <= 98304);
+  return want && nz >= 2 && thomas_lds_bytes(nz, 8, 32) <= 160 * 1024 - 1024;
+}
+static size_t ztab_doubles(long nmodes, int nz) { return (size_t)((nmodes + ZB - 1) / ZB) * ZB * (size_t)(nz > 1 ? nz - 1 : 1); }
+
+static int launch_thomas(udc_handle *h, bool lds, long nmodes, int nz, double scale, const double *ev, const double *ztab, double2 *x) {
   const size_t full = 160 * 1024 - 1024;
-  auto need = [&](int M, int KC) { return ((size_t)nz * 2 * M + 3 * (size_t)KC * M) * sizeof(double); };
-#define UDC_TL(M, KC)                                                                                        \
+  auto need = [&](int M, int KC) { return thomas_lds_bytes(nz, M, KC); };
+#define UDC_TL(M, KC, D)                                                                                     \
   do {                                                                                                       \
     static bool attr_done = false;                                                                           \
     if (!attr_done) {                                                                                        \
-      if (hipFuncSetAttribute((const void *)thomas_lds_kernel<M, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+      if (hipFuncSetAttribute((const void *)thomas_lds_kernel<M, KC, D>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               (int)full) != hipSuccess) return 1;                                            \
       attr_done = true;                                                                                      \
     }                                                                                                        \
-    hipLaunchKernelGGL((thomas_lds_kernel<M, KC>), dim3((unsigned)((nmodes + M - 1) / M)), dim3(256), need(M, KC), \
+    hipLaunchKernelGGL((thomas_lds_kernel<M, KC, D>), dim3((unsigned)((nmodes + M - 1) / M)), dim3(256), need(M, KC), \
                        h->stream, (int)nmodes, nz, scale, ev, h->tri, h->btopD, ztab, x);                    \
     return 0;                                                                                                \
   } while (0)
-  const bool want_lds = mode == 3 || (mode < 0 && nmodes <= 98304);
-  if (want_lds && nz >= 2 && need(8, 32) <= full) UDC_TL(8, 32);   // 4 workgroups per CU at nz = 256, 2 at nz = 512
+  // 4 workgroups per CU at nz = 256, 2 at nz = 512; UDC_THOMAS_DEPTH: chunks of loads in flight per workgroup
+  // (measured at 256^3: 1 -> 0.114 ms, 2 -> 0.113, 3 -> 0.117, 4 -> 0.135 (130 VGPRs, 3 waves/SIMD), 6 -> 0.140)
+  const int depth = getenv("UDC_THOMAS_DEPTH") ? atoi(getenv("UDC_THOMAS_DEPTH")) : 2;
+  if (lds) {
+    if (depth <= 1) UDC_TL(8, 32, 1);
+    UDC_TL(8, 32, 2);
+  }
 #undef UDC_TL
   hipLaunchKernelGGL(thomas_kernel, dim3((unsigned)((nmodes + 63) / 64)), dim3(64), 0, h->stream, (int)nmodes, nz, scale,
                      ev, h->tri, h->btopD, ztab, x);
@@ -699,13 +741,14 @@ int pois_init(udc_handle *h) {
 
   HIP_OK(hipMalloc(&h->spec, sizeof(double) * 2 * nmodes * nz));
   HIP_OK(hipMemsetAsync(h->spec, 0, sizeof(double) * 2 * nmodes * nz, h->stream));
-  HIP_OK(hipMalloc(&h->ztab, sizeof(double) * nmodes * (nz > 1 ? nz - 1 : 1)));
+  h->thomas_lds = thomas_wants_lds((long)nmodes, nz);
+  HIP_OK(hipMalloc(&h->ztab, sizeof(double) * ztab_doubles((long)nmodes, nz)));
   HIP_OK(hipMalloc(&h->ev, sizeof(double) * nmodes));
   HIP_OK(hipMalloc(&h->tri, sizeof(double) * tri.size()));
   HIP_OK(hipMemcpy(h->ev, ev.data(), sizeof(double) * nmodes, hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(h->tri, tri.data(), sizeof(double) * tri.size(), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(thomas_table_kernel, dim3((unsigned)((nmodes + 63) / 64)), dim3(64), 0, h->stream,
-                     (int)nmodes, nz, h->ev, h->tri, b_top_D, h->ztab);
+                     (int)nmodes, nz, h->ev, h->tri, b_top_D, h->ztab, h->thomas_lds ? 1 : 0);
   HIP_OK(hipGetLastError());
 
   // rocFFT: batched 2-D real <-> Hermitian-interleaved, reading/writing the padded p field
@@ -820,12 +863,13 @@ int pois_slab_init(udc_handle *h) {
   HIP_OK(hipMalloc(&h->a2a_send, sizeof(double) * 2 * nmodes * nz));
   HIP_OK(hipMalloc(&h->a2a_recv, sizeof(double) * 2 * nmodes * nz));
   HIP_OK(hipMalloc(&h->ev_slab, sizeof(double) * nmodes));
-  HIP_OK(hipMalloc(&h->ztab_slab, sizeof(double) * nmodes * (nz > 1 ? nz - 1 : 1)));
+  h->thomas_lds_slab = thomas_wants_lds((long)nmodes, nz);
+  HIP_OK(hipMalloc(&h->ztab_slab, sizeof(double) * ztab_doubles((long)nmodes, nz)));
   HIP_OK(hipMalloc(&h->tri, sizeof(double) * tri.size()));
   HIP_OK(hipMemcpy(h->ev_slab, ev.data(), sizeof(double) * nmodes, hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(h->tri, tri.data(), sizeof(double) * tri.size(), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(thomas_table_kernel, dim3((unsigned)((nmodes + 63) / 64)), dim3(64), 0, h->stream,
-                     (int)nmodes, nz, h->ev_slab, h->tri, btopD, h->ztab_slab);
+                     (int)nmodes, nz, h->ev_slab, h->tri, btopD, h->ztab_slab, h->thomas_lds_slab ? 1 : 0);
   HIP_OK(hipGetLastError());
 
   static bool setup_done = false;
@@ -912,7 +956,7 @@ int k_poisson_solve_slab(udc_handle *h) {
   }
   {
     PROF(h, "thomas");
-    if (launch_thomas(h, nmodes, g.nz, 1. / ((double)g.nx * (double)ny), h->ev_slab, h->ztab_slab,
+    if (launch_thomas(h, h->thomas_lds_slab, nmodes, g.nz, 1. / ((double)g.nx * (double)ny), h->ev_slab, h->ztab_slab,
                       reinterpret_cast<double2 *>(h->specB))) return 1;
     HIP_OK(hipGetLastError());
   }
@@ -997,7 +1041,7 @@ int k_poisson_solve(udc_handle *h) {
   }
   {
     PROF(h, "thomas");
-    if (launch_thomas(h, nmodes, g.nz, 1. / ((double)g.nx * (double)g.ny), h->ev, h->ztab,
+    if (launch_thomas(h, h->thomas_lds, nmodes, g.nz, 1. / ((double)g.nx * (double)g.ny), h->ev, h->ztab,
                       reinterpret_cast<double2 *>(h->spec))) return 1;
     HIP_OK(hipGetLastError());
   }
