@@ -113,6 +113,12 @@ int udc_set_forcing(udc_handle *h, const double *dpdxl, const double *dpdyl, int
  * radiative tendency of src/modforces.f90:104-110) is optional. */
 int udc_set_tempeq(udc_handle *h, int iadv_thl, int bctopt, double wttop, double thl_top, int bcbott, double wtsurf);
 int udc_set_thl_source(udc_handle *h, const double *thlpcar, int n);
+/* Floor (lbottom) with the stability-dependent wall function wfuno (Louis 1979 / Uno et al. 1995 over a rough wall,
+ * src/modwallfunctions.f90:24-261) as `bottom` selects it (src/modibm.f90:2021-2045): BCbotm = 2 -> momentum (case 91;
+ * 3 = the neutral wfmneutral of udc_config), BCbotT = 2 -> temperature against a wall at thls with roughness length
+ * z0h (case 92; 1 = the prescribed flux wtsurf of udc_set_tempeq).  prandtlturb: src/modglobal.f90:304 (= prandtlmol).
+ * Needs the temperature equation; call after udc_set_tempeq (which must then be given the same BCbotT). */
+int udc_set_floor_wf(udc_handle *h, int bcbotm, int bcbott, double thls, double z0h, double prandtlturb);
 /* Total water, &PHYSICS lmoist (src/modglobal.f90:402): qt is advected (iadv_qt = 2 -> advecc_2nd,
  * src/modadvection.f90:78-86), diffused (diffc with ekh, src/modsubgrid.f90:147), integrated
  * (src/modtstep.f90:256) and given its top (BCtopq 1 = flux wqtop, 2 = value qt_top, src/modboundary.f90:222-231)

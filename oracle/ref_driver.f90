@@ -34,8 +34,8 @@ program ref_driver
   use modglobal
   use modfields
   use modsubgriddata
-  use modsurfdata, only: thl_top, wttop, wsvtop, sv_top, thvs, thls, z0, wtsurf, qts, wqtop, qt_top, wqsurf, ps
-  use modwallfunctions, only: wfmneutral
+  use modsurfdata, only: thl_top, wttop, wsvtop, sv_top, thvs, thls, z0, z0h, wtsurf, qts, wqtop, qt_top, wqsurf, ps
+  use modwallfunctions, only: wfmneutral, wfuno
   use modboundary, only: initboundary, boundary, halos, grwdamp
   use modthermodynamics, only: initthermodynamics, thermodynamics
   use modsubgrid, only: initsubgrid, subgrid
@@ -52,6 +52,7 @@ program ref_driver
   logical :: lforces = .true.
   logical :: lbottom = .false.           ! src/modibm.f90:49 (module variable of modibm)
   logical :: need_thermo = .false.
+  real :: bcTfluxA = 0.                  ! src/modibmdata.f90 (module variable of modibm's callers)
   integer :: isub, n, ierr, iu
   real :: t0, t1, chk_u2, chk_div
   real :: scal_a = 1.0, scal_b = 0.0     ! scalar init: sv = scal_b + scal_a*z/zsize
@@ -186,14 +187,19 @@ contains
     e120(:, :, kb - 1) = e120(:, :, kb)     ! src/modibm.f90:2012-2013 (unconditional)
     e12m(:, :, kb - 1) = e12m(:, :, kb)
     if (.not. lbottom) return
-    if (BCbotm /= 3) then
-      write (0, *) 'ERROR: oracle build supports the neutral floor wall function only (BCbotm = 3)'
+    if (BCbotm == 2) then                  ! src/modibm.f90:2021-2024
+      call wfuno(ih, jh, kh, up, vp, thlp, momfluxb, tfluxb, bcTfluxA, u0, v0, thl0, thls, z0, z0h, 91)
+    else if (BCbotm == 3) then
+      call wfmneutral(ih, jh, kh, up, vp, momfluxb, u0, v0, z0, 91)
+    else
+      write (0, *) 'ERROR: bottom boundary type for momentum undefined'
       stop 1
     end if
-    call wfmneutral(ih, jh, kh, up, vp, momfluxb, u0, v0, z0, 91)
-    if (ltempeq) then                      ! src/modibm.f90:2033-2047, BCbotT = 1 (flux)
+    if (ltempeq .and. BCbotT == 2) then    ! src/modibm.f90:2044-2045
+      call wfuno(ih, jh, kh, up, vp, thlp, momfluxb, tfluxb, bcTfluxA, u0, v0, thl0, thls, z0, z0h, 92)
+    else if (ltempeq) then                 ! src/modibm.f90:2033-2047, BCbotT = 1 (flux)
       if (BCbotT /= 1) then
-        write (0, *) 'ERROR: oracle build supports the flux floor for temperature only (BCbotT = 1)'
+        write (0, *) 'ERROR: bottom boundary type for temperature undefined'
         stop 1
       end if
       do j = jb, je
@@ -256,7 +262,7 @@ contains
       lvvolflowr, vflowrate, igrw_damp, geodamptime, lnudge, lnudgevel, tnudge, nnudge
     namelist /DYNAMICS/ ipoiss, iadv_mom, iadv_tke, iadv_thl, iadv_qt, iadv_sv
     namelist /BC/ BCxm, BCym, BCtopm, BCtopT, BCtops, BCbotm, BCbots, BCbotT, BCzp, wttop, thl_top, z0, wtsurf, thls, qts, &
-      BCtopq, BCbotq, wqtop, qt_top, wqsurf, ps
+      BCtopq, BCbotq, wqtop, qt_top, wqsurf, ps, z0h
     namelist /SCALARS/ nsv
     namelist /WALLS/ nfcts, lbottom
     open (ifnamopt, file=fname_options, status='old', iostat=ierr)

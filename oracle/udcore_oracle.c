@@ -853,6 +853,97 @@ void orc_bottom(const orc_grid *g, const double *u0, const double *v0, const dou
   metrics_free(&m);
 }
 
+/* ---- wfuno, src/modwallfunctions.f90:24-170: Louis (1979) / Uno et al. (1995) transfer coefficients over a rough wall */
+static void uno_F(double logdz, double sqdz, double Ri, double fkar2, double *Fm, double *Fh) {
+  const double b1 = 9.4, b2 = 4.7, dm = 7.4, dh = 5.3;                                  /* :184-187 */
+  if (Ri > 0.) { *Fm = 1. / ((1. + b2 * Ri) * (1. + b2 * Ri)); *Fh = *Fm; }             /* Eq. 4, stable */
+  else {
+    const double cm = (dm * fkar2) / (logdz * logdz) * b1 * sqdz, ch = (dh * fkar2) / (logdz * logdz) * b1 * sqdz;   /* Eq. 5 */
+    *Fm = 1. - (b1 * Ri) / (1. + cm * sqrt(fabs(Ri)));                                   /* Eq. 3 */
+    *Fh = 1. - (b1 * Ri) / (1. + ch * sqrt(fabs(Ri)));
+  }
+}
+/* unom, :224-261 */
+static double uno_m(double prt, double logdz, double logzh, double sqdz, double Ribl0, double fkar2) {
+  double Fm, Fh;
+  uno_F(logdz, sqdz, Ribl0, fkar2, &Fm, &Fh);
+  const double Mm = prt * logdz * sqrt(Fm) / Fh;                                        /* Eq. 14 */
+  const double Ribl1 = Ribl0 - Ribl0 * prt * logzh / (prt * logzh + Mm);                 /* Eq. 17 */
+  uno_F(logdz, sqdz, Ribl1, fkar2, &Fm, &Fh);
+  return fkar2 / (logdz * logdz) * Fm;                                                   /* Eq. 7 */
+}
+/* unoh, :176-220: returns the heat flux otf */
+static double uno_h(double prt, double logdz, double logzh, double sqdz, double utangInt, double dT, double Ribl0, double fkar2) {
+  double Fm, Fh;
+  uno_F(logdz, sqdz, Ribl0, fkar2, &Fm, &Fh);
+  double Mm = prt * logdz * sqrt(Fm) / Fh;
+  const double Ribl1 = Ribl0 - Ribl0 * prt * logzh / (prt * logzh + Mm);
+  uno_F(logdz, sqdz, Ribl1, fkar2, &Fm, &Fh);
+  Mm = prt * logdz * sqrt(Fm) / Fh;
+  const double dTrough = dT * 1. / (prt * logzh / Mm + 1.);                              /* Eq. 13a */
+  const double octh = sqrt(utangInt) * fkar2 / (logdz * logdz) * Fh / prt;               /* Eq. 8 */
+  return octh * dTrough;
+}
+void orc_bottom_uno(const orc_grid *g, const double *u0, const double *v0, const double *thl0, const double *ekm, const double *ekh,
+                    double *up, double *vp, double *thlp) {
+  if (!g->lbottom) return;
+  metrics m;
+  metrics_init(g, &m);
+  const int nx = g->nx, ny = g->ny, k = 1, km = 0;
+  const double *dzf = g->dzf;
+  const double fkar2 = 0.41 * 0.41, umin = 0.0001, grav = 9.81, Twall = g->thls, prt = g->prandtlturb;
+  double *xh = (double *)calloc(4 * (size_t)(nx + 3), sizeof(double));   /* dxf, dxhi as src/modglobal.f90 builds them */
+  double *xf = xh + (nx + 3), *dxf = xf + (nx + 3), *dxhi = dxf + (nx + 3);
+  for (int i = 1; i <= nx + 1; ++i) { xh[i] = (double)(i - 1) * g->dx; xf[i] = xh[i] + g->dx / 2; }
+  for (int i = 1; i <= nx; ++i) dxf[i] = xh[i + 1] - xh[i];
+  dxf[nx + 1] = dxf[nx]; dxf[0] = dxf[1];
+  dxhi[1] = 1. / (2 * xf[1]);
+  for (int i = 2; i <= nx + 1; ++i) dxhi[i] = 1. / (xf[i] - xf[i - 1]);
+  const double delta = 0.5 * dzf[k];
+  const double logdz = log(delta / g->z0), logzh = log(g->z0 / g->z0h), sqdz = sqrt(delta / g->z0);
+  if (g->bcbotm == 2) {
+    for (int j = 1; j <= ny; ++j)        /* case 91, u component, :92-109 */
+      for (int i = 1; i <= nx; ++i) {
+        const double utang1Int = M(u0, i, j, k);
+        const double utang2Int = (M(v0, i, j, k) + M(v0, i - 1, j, k) + M(v0, i, j + 1, k) + M(v0, i - 1, j + 1, k)) * 0.25;
+        const double utangInt = fmax(umin, (utang1Int * utang1Int + utang2Int * utang2Int));
+        const double dT = ((M(thl0, i, j, k) + M(thl0, i - 1, j, k)) - (Twall + Twall)) * 0.5;
+        const double Ribl0 = grav * delta * dT * 2 / ((Twall + Twall) * utangInt);
+        const double ctm = uno_m(prt, logdz, logzh, sqdz, Ribl0, fkar2);
+        const double bcmomflux = copysign(fabs(utang1Int) * sqrt(utangInt) * ctm, utang1Int);
+        const double emom = (dzf[km] * (M(ekm, i, j, k) * dxf[i - 1] + M(ekm, i - 1, j, k) * dxf[i]) +
+                             dzf[k] * (M(ekm, i, j, km) * dxf[i - 1] + M(ekm, i - 1, j, km) * dxf[i])) * dxhi[i] * m.dzhiq[k];
+        M(up, i, j, k) = M(up, i, j, k) + (M(u0, i, j, k) - M(u0, i, j, km)) * emom * m.dzhi[k] * m.dzfi[k] - bcmomflux * m.dzfi[k];
+      }
+    for (int j = 1; j <= ny; ++j)        /* v component, :111-127 */
+      for (int i = 1; i <= nx; ++i) {
+        const double utang1Int = (M(u0, i, j, k) + M(u0, i, j - 1, k) + M(u0, i + 1, j - 1, k) + M(u0, i + 1, j, k)) * 0.25;
+        const double utang2Int = M(v0, i, j, k);
+        const double utangInt = fmax(umin, (utang1Int * utang1Int + utang2Int * utang2Int));
+        const double dT = ((M(thl0, i, j, k) + M(thl0, i, j - 1, k)) - (Twall + Twall)) * 0.5;
+        const double Ribl0 = grav * delta * dT * 2 / ((Twall + Twall) * utangInt);
+        const double ctm = uno_m(prt, logdz, logzh, sqdz, Ribl0, fkar2);
+        const double bcmomflux = copysign(fabs(utang2Int) * sqrt(utangInt) * ctm, utang2Int);
+        const double eomm = (dzf[km] * (M(ekm, i, j, k) + M(ekm, i, j - 1, k)) + dzf[k] * (M(ekm, i, j, km) + M(ekm, i, j - 1, km))) * m.dzhiq[k];
+        M(vp, i, j, k) = M(vp, i, j, k) + (M(v0, i, j, k) - M(v0, i, j, km)) * eomm * m.dzhi[k] * m.dzfi[k] - bcmomflux * m.dzfi[k];
+      }
+  }
+  if (g->bcbott == 2 && thlp)            /* case 92, :131-165 */
+    for (int j = 1; j <= ny; ++j)
+      for (int i = 1; i <= nx; ++i) {
+        const double utang1Int = (M(u0, i, j, k) + M(u0, i + 1, j, k)) * 0.5;
+        const double utang2Int = (M(v0, i, j, k) + M(v0, i, j + 1, k)) * 0.5;
+        const double utangInt = fmax(umin, (utang1Int * utang1Int + utang2Int * utang2Int));
+        const double dT = (M(thl0, i, j, k) - Twall);
+        const double Ribl0 = grav * delta * dT / (Twall * utangInt);
+        const double bcTflux = uno_h(prt, logdz, logzh, sqdz, utangInt, dT, Ribl0, fkar2);
+        M(thlp, i, j, k) = M(thlp, i, j, k) + 0.5 * (dzf[k - 1] * M(ekh, i, j, k) + dzf[k] * M(ekh, i, j, k - 1)) *
+                           (M(thl0, i, j, k) - M(thl0, i, j, k - 1)) * m.dzh2i[k] * m.dzfi[k] - bcTflux * m.dzfi[k];
+      }
+  free(xh);
+  metrics_free(&m);
+}
+
 /* ====================================================================== temperature equation (passive) */
 /* advecc_2nd, src/modadvection.f90:103-155, on an m-array (halo 1: advecc_2nd(ih,jh,kh,thl0,thlp), :68) */
 void orc_advecc_2nd(const orc_grid *g, const double *u0, const double *v0, const double *w0, const double *c, double *cp) {
@@ -1279,8 +1370,16 @@ void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
     for (int j = 0; j <= g->ny + 1; ++j)                      /* `bottom`, src/modibm.f90:2012-2013 */
       for (int i = 0; i <= g->nx + 1; ++i) { M(s->e120, i, j, 0) = M(s->e120, i, j, 1); M(s->e12m, i, j, 0) = M(s->e12m, i, j, 1); }
   }
-  orc_bottom(g, s->u0, s->v0, s->ekm, s->ekh, s->sv0, s->up, s->vp, s->svp, NULL);   /* src/program.f90:152 */
-  if (g->ltempeq) orc_thl_floor(g, s->ekh, s->thl0, s->thlp);
+  if (g->bcbotm == 2) {                                                                  /* wfuno for momentum; scalars as before */
+    double *zu = (double *)calloc(2 * msize(g), sizeof(double));
+    orc_bottom(g, s->u0, s->v0, s->ekm, s->ekh, s->sv0, zu, zu + msize(g), s->svp, NULL);
+    free(zu);
+    orc_bottom_uno(g, s->u0, s->v0, s->thl0, s->ekm, s->ekh, s->up, s->vp, g->bcbott == 2 ? s->thlp : NULL);
+  } else {
+    orc_bottom(g, s->u0, s->v0, s->ekm, s->ekh, s->sv0, s->up, s->vp, s->svp, NULL);   /* src/program.f90:152 */
+    if (g->bcbott == 2) orc_bottom_uno(g, s->u0, s->v0, s->thl0, s->ekm, s->ekh, s->up, s->vp, s->thlp);
+  }
+  if (g->ltempeq && g->bcbott != 2) orc_thl_floor(g, s->ekh, s->thl0, s->thlp);
   if (g->lmoist) orc_qt_floor(g, s->ekh, s->qt0, s->qtp);
   if (s->dpdxl && g->coriolis_mode) orc_coriolis(g, s->u0, s->v0, s->w0, s->ug, s->up, s->vp, s->wp);   /* src/program.f90:158 */
   if (s->dpdxl) orc_forces(g, s->dpdxl, s->dpdyl, s->up, s->vp, s->wp);

@@ -59,6 +59,11 @@ typedef struct {
    * the level heights zf(kb:ke+kh), zh(kb:ke+kh) as [nz+2] tables indexed by k (src/modglobal.f90:747-751) */
   double thls, qts, ps;
   const double *zf, *zh;
+  /* floor with the stability-dependent wall function of Uno et al. 1995 (wfuno, src/modwallfunctions.f90:24-170):
+   * BCbotm 2 (momentum, case 91) / 3 (neutral, wfmneutral), BCbotT 1 (flux wtsurf) / 2 (wall temperature thls, case 92);
+   * roughness length for heat z0h (src/modsurfdata.f90:73), prandtlturb (src/modglobal.f90:304) */
+  int bcbotm, bcbott;
+  double z0h, prandtlturb;
 } orc_grid;
 
 /* ---- advection: src/modadvection.f90 */
@@ -91,6 +96,9 @@ void orc_bottom(const orc_grid *g, const double *u0, const double *v0, const dou
 void orc_advecc_2nd(const orc_grid *g, const double *u0, const double *v0, const double *w0, const double *c, double *cp);
 void orc_diffc_m(const orc_grid *g, const double *c, const double *ekh, double *cp);
 void orc_thl_top(const orc_grid *g, const double *ekh, double *a);
+/* `bottom` with wfuno: momentum (case 91) into up, vp; temperature (case 92, when g->bcbott == 2) into thlp */
+void orc_bottom_uno(const orc_grid *g, const double *u0, const double *v0, const double *thl0, const double *ekm, const double *ekh,
+                    double *up, double *vp, double *thlp);
 void orc_qt_top(const orc_grid *g, const double *ekh, double *a);
 void orc_qt_floor(const orc_grid *g, const double *ekh, const double *qt0, double *qtp);
 void orc_buoyancy(const orc_grid *g, const double *thl0, double *wp);

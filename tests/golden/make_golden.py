@@ -29,7 +29,7 @@ REF = os.path.join(ROOT, "oracle", "_ref", "udales_ref")
 
 
 def deck(iexpnr, nx, ny, nz, dx=0.5, dy=0.5, dtmax=0.25, sgs="vreman", nsv=0, bctopm=1,
-         oracle="", lles=True, randu=0.01, floor=False, z0=0.05, physics="", bc=""):
+         oracle="", lles=True, randu=0.01, floor=False, z0=0.05, physics="", bc="", bcbotm=3):
     sub = {"oneeqn": "loneeqn = .true.\nlvreman = .false.\nlsmagorinsky = .false.",
            "vreman": "lvreman = .true.\nlsmagorinsky = .false.",
            "smag": "lsmagorinsky = .true.\nlvreman = .false.",
@@ -61,7 +61,7 @@ ipoiss = 0
 /
 &BC
 BCtopm = {bctopm}
-{('BCbotm = 3' + chr(10) + 'z0 = ' + repr(z0)) if floor else ''}
+{('BCbotm = ' + str(bcbotm) + chr(10) + 'z0 = ' + repr(z0)) if floor else ''}
 {bc}
 /
 {('&WALLS' + chr(10) + 'nfcts = 0' + chr(10) + 'lbottom = .true.' + chr(10) + '/') if floor else ''}
@@ -218,8 +218,20 @@ CASES.update({
                                    "BCtopq = 2\nqt_top = 0.0104\nBCbotq = 1\nwqsurf = 5.e-5",
                                 oracle="nsub = 9\ndump_at = 3, 9"), 1.06),
 })
+CASES.update({
+    # floor with the stability-dependent wall function (wfuno, Uno et al. 1995): BCbotm = 2 for momentum, BCbotT = 2 for
+    # temperature against a wall at thls; an unstable floor (thls above the air) and a stable one (below)
+    "k_uno_12x8x6": ("kernels", 37, 12, 8, 6,
+                     dict(sgs="vreman", floor=True, bcbotm=2, physics="ltempeq = .true.\nlbuoyancy = .true.",
+                          bc="BCtopT = 1\nBCbotT = 2\nthls = 291.0\nz0h = 0.0067\nqts = 0.0", oracle="nspin = 4"), 1.04),
+    "run_uno_16x8x12s": ("run", 38, 16, 8, 12,
+                         dict(sgs="smag", floor=True, bcbotm=2, physics="ltempeq = .true.\nlbuoyancy = .true.",
+                              bc="BCtopT = 2\nthl_top = 290.5\nBCbotT = 2\nthls = 286.5\nz0h = 0.005\nqts = 0.0",
+                              oracle="nsub = 9\ndump_at = 3, 9"), 1.06),
+})
 LSF_ONLY = ("k_lsfq_12x8x20",)
-THL_CASES = {"k_moist_12x8x8": dict(dthl=0.25, qt=0.0118, dqt=-8e-5), "run_moist_16x8x12s": dict(dthl=0.25, qt=0.0119, dqt=-6e-5),
+THL_CASES = {"k_uno_12x8x6": dict(dthl=0.2), "run_uno_16x8x12s": dict(dthl=0.25),
+             "k_moist_12x8x8": dict(dthl=0.25, qt=0.0118, dqt=-8e-5), "run_moist_16x8x12s": dict(dthl=0.25, qt=0.0119, dqt=-6e-5),
              "k_lsfq_12x8x20": dict(dthl=0.3, ug=1.0, wtop=0.025, qt=0.008, dqt=-3e-4, dqtdx=2e-7, dqtdy=-1e-7, dqtdt=3e-8),
              "k_qt_12x8x6": dict(dthl=0.3, qt=0.008, dqt=-4e-4), "run_qt_16x8x12s": dict(dthl=0.25, qt=0.007, dqt=-2e-4),
              "k_lsf_12x8x24": dict(dthl=0.3, ug=1.05, wtop=0.02), "run_lsf_16x8x24s": dict(dthl=0.25, ug=0.95, wtop=-0.03), "k_tke_12x8x6": dict(tke=0.05), "k_tke_thl_12x8x6": dict(tke=0.08, dthl=0.3), "k_coriol_12x8x6": dict(ug=1.1), "run_profforc_16x16x8": dict(ug=1.3), "k_thl_12x8x6": dict(dthl=0.4, dthlrad=2e-3), "run_thl_16x8x12s": dict(dthl=0.25, dthlrad=-1e-3),

@@ -355,6 +355,47 @@ def test_all_forcings_together_against_oracle(shape, sgs, nsv, cor):
     core.close()
 
 
+@pytest.mark.parametrize("thls,bcbotm,bcbott", [(288.6, 2, 2), (287.2, 2, 2), (288.1, 3, 2), (288.1, 2, 1)],
+                         ids=["unstable", "stable", "neutral-mom+uno-T", "uno-mom+flux-T"])
+def test_uno_floor_against_oracle(thls, bcbotm, bcbott):
+    """Floor with the stability-dependent wall function (wfuno): a noisy near-floor temperature puts cells on both sides
+    of Ri = 0, so both branches of the transfer functions run; six fused substeps against the CPU oracle."""
+    nx, ny, nz = 40, 24, 12
+    dz = 0.4 * 1.06 ** np.arange(nz)
+    zf = np.cumsum(dz) - 0.5 * dz
+    g = Grid.from_levels(nx, ny, nz, nx * 0.45, ny * 0.5, zf)
+    from udcore.core import DynCore
+    kw = dict(lbottom=True, z0=0.03)
+    core = DynCore(g, sgs=2, **kw)
+    o = ol.Oracle(nx, ny, nz, g.dx, g.dy, g.dzf, g.dzh, sgs=2, ltempeq=True, bctopt=2, wttop=0., thl_top=290., wtsurf=0.02,
+                  lbuoyancy=True, thls=thls, bcbotm=bcbotm, bcbott=bcbott, z0h=0.004, **kw)
+    core.set_tempeq(bctopt=2, thl_top=290., bcbott=bcbott, wtsurf=0.02)
+    core.set_floor_wf(bcbotm, bcbott, thls, 0.004)
+    core.set_buoyancy(True)
+    st = random_state(g, seed=23)
+    rng = np.random.default_rng(4)
+    t = np.zeros(g.mshape())
+    t[1:-1, 1:-1, 1:-1] = 288. + 0.2 * g.zf[1:nz + 1, None, None] + 0.3 * rng.standard_normal((nz, ny, nx))
+    t[:, 0, :] = t[:, ny, :]; t[:, ny + 1, :] = t[:, 1, :]
+    t[:, :, 0] = t[:, :, nx]; t[:, :, nx + 1] = t[:, :, 1]
+    t[0] = t[1]; t[nz + 1] = 2 * 290. - t[nz]
+    st.update(thl0=t, thlm=t.copy())
+    if bcbott == 2 and bcbotm == 2:
+        assert ((t[1, 1:-1, 1:-1] - thls) > 0).any() and ((t[1, 1:-1, 1:-1] - thls) < 0).any()
+    dp = np.zeros(nz + 2); dp[1:nz + 1] = -1e-3
+    core.load_state(st)
+    core.set_forcing(dp[1:nz + 1], np.zeros(nz))
+    ost = oracle_state(st, g, 0)
+    ost.update(dpdxl=dp, dpdyl=np.zeros(nz + 2), thl0=t.copy(), thlm=t.copy(), thlp=np.zeros(g.mshape()))
+    for isub in range(6):
+        core.substep(isub % 3 + 1, 0.04, with_forces=True)
+        o.substep(ost, isub % 3 + 1, 0.04)
+    for k in ("u0", "v0", "w0", "pres0", "thl0"):
+        sc = 1.0 if k == "thl0" else None
+        assert relerr(nocorner(core.download(k)[1:-1]), nocorner(ost[k][1:-1]), sc) <= RUN_TOL, k
+    core.close()
+
+
 def test_moist_buoyancy_against_oracle():
     """Moist thermodynamics in the loop: a partly saturated layer (condensate from thermo, pressures from diagfld /
     fromztop, moist thv0h in the buoyancy term) through six fused substeps against the CPU oracle."""

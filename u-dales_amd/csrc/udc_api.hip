@@ -357,7 +357,7 @@ extern "C" int udc_set_tempeq(udc_handle *h, int iadv_thl, int bctopt, double wt
   if (h->cfg.nsv > 15) { udc_set_error("udc_set_tempeq: thl uses scalar slot 15, nsv must be <= 15"); return 1; }
   if (iadv_thl != 2) { udc_set_error("udc_set_tempeq: only iadv_thl = 2 (cd2, advecc_2nd) is built"); return 1; }
   if (bctopt != 1 && bctopt != 2) { udc_set_error("udc_set_tempeq: BCtopT must be 1 (flux) or 2 (value)"); return 1; }
-  if (h->p.lbottom && bcbott != 1) { udc_set_error("udc_set_tempeq: with lbottom only BCbotT = 1 (flux) is built"); return 1; }
+  if (h->p.lbottom && bcbott != 1 && bcbott != 2) { udc_set_error("udc_set_tempeq: BCbotT must be 1 (flux) or 2 (wall function)"); return 1; }
   const bool have = (int)h->fields.size() > UDC_THL0 && h->fields[UDC_THL0];
   if (!have) {
     for (int q = 0; q < 3; ++q)
@@ -373,6 +373,19 @@ extern "C" int udc_set_tempeq(udc_handle *h, int iadv_thl, int bctopt, double wt
   sl.top = bctopt == 2 ? 2 : (wttop != 0. ? 1 : 0);
   sl.topval = bctopt == 2 ? thl_top : wttop;
   sl.floorflux = wtsurf;
+  return 0;
+}
+
+extern "C" int udc_set_floor_wf(udc_handle *h, int bcbotm, int bcbott, double thls, double z0h, double prandtlturb) {
+  if (!h->p.lbottom) { udc_set_error("udc_set_floor_wf: the floor is off (udc_config.lbottom)"); return 1; }
+  if (bcbotm != 2 && bcbotm != 3) { udc_set_error("udc_set_floor_wf: BCbotm must be 2 (wfuno) or 3 (wfmneutral)"); return 1; }
+  if (bcbott != 1 && bcbott != 2) { udc_set_error("udc_set_floor_wf: BCbotT must be 1 (flux) or 2 (wfuno)"); return 1; }
+  if (bcbotm == 2 || bcbott == 2) {
+    if ((int)h->fields.size() <= UDC_THL0 || !h->fields[UDC_THL0]) { udc_set_error("udc_set_floor_wf: wfuno needs the temperature equation (call udc_set_tempeq first)"); return 1; }
+    if (!(thls > 0.) || !(z0h > 0.) || !(prandtlturb > 0.)) { udc_set_error("udc_set_floor_wf: thls, z0h and prandtlturb must be positive"); return 1; }
+  }
+  h->floor_bcbotm = bcbotm; h->floor_bcbott = bcbott;
+  h->floor_thls = thls; h->floor_z0h = z0h; h->floor_prt = prandtlturb;
   return 0;
 }
 

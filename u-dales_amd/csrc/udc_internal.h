@@ -127,6 +127,9 @@ struct udc_handle {
   int coriolis_mode = 0;       // 0 off, 1 lcoriol, 2 lprofforc (src/modforces.f90:600-717)
   double om22 = 0., om23 = 0.;
   double *ug = nullptr;        // [nz+2] geostrophic wind profile (lprofforc)
+  // floor wall function choice (udc_set_floor_wf): BCbotm 3 neutral / 2 wfuno, BCbotT 1 flux / 2 wfuno
+  int floor_bcbotm = 3, floor_bcbott = 1;
+  double floor_thls = 0., floor_z0h = 0., floor_prt = 0.71;
   bool lmoist = false;         // qt transported in slot 13 (udc_set_moisture)
   int lbuoyancy = 0;           // forces' buoyancy term (dry air), needs the temperature equation
   double grav = 9.81;

@@ -137,7 +137,44 @@ struct BottomArgs {
   double flux[16];       // prescribed floor flux (0 for passive scalars, wtsurf for thl)
   int nsv, wrap_vp;
   double z0;
+  // wfuno (UNO kernels): wall temperature, roughness length for heat, turbulent Prandtl number, the temperature the
+  // stability is judged on, and which entry of sv0/svp is thl when its floor is the wall function too (BCbotT = 2), else -1
+  double thls, z0h, prt;
+  const double *thl0;
+  int thl_wf;
 };
+// wfuno's transfer coefficients (src/modwallfunctions.f90:176-261): Louis 1979 / Uno et al. 1995 over a rough wall
+__device__ __forceinline__ void uno_F(double logdz, double sqdz, double Ri, double fkar2, double &Fm, double &Fh) {
+  const double b1 = 9.4, b2 = 4.7, dm = 7.4, dh = 5.3;
+  if (Ri > 0.) { Fm = 1. / ((1. + b2 * Ri) * (1. + b2 * Ri)); Fh = Fm; }
+  else {
+    const double cm = (dm * fkar2) / (logdz * logdz) * b1 * sqdz, ch = (dh * fkar2) / (logdz * logdz) * b1 * sqdz;
+    Fm = 1. - (b1 * Ri) / (1. + cm * sqrt(fabs(Ri)));
+    Fh = 1. - (b1 * Ri) / (1. + ch * sqrt(fabs(Ri)));
+  }
+}
+__device__ __forceinline__ double uno_m(double prt, double logdz, double logzh, double sqdz, double Ribl0, double fkar2) {
+  double Fm, Fh;
+  uno_F(logdz, sqdz, Ribl0, fkar2, Fm, Fh);
+  const double Mm = prt * logdz * sqrt(Fm) / Fh;
+  const double Ribl1 = Ribl0 - Ribl0 * prt * logzh / (prt * logzh + Mm);
+  uno_F(logdz, sqdz, Ribl1, fkar2, Fm, Fh);
+  return fkar2 / (logdz * logdz) * Fm;
+}
+__device__ __forceinline__ double uno_h(double prt, double logdz, double logzh, double sqdz, double utangInt, double dT, double Ribl0,
+                                        double fkar2) {
+  double Fm, Fh;
+  uno_F(logdz, sqdz, Ribl0, fkar2, Fm, Fh);
+  double Mm = prt * logdz * sqrt(Fm) / Fh;
+  const double Ribl1 = Ribl0 - Ribl0 * prt * logzh / (prt * logzh + Mm);
+  uno_F(logdz, sqdz, Ribl1, fkar2, Fm, Fh);
+  Mm = prt * logdz * sqrt(Fm) / Fh;
+  const double dTrough = dT * 1. / (prt * logzh / Mm + 1.);
+  const double octh = sqrt(utangInt) * fkar2 / (logdz * logdz) * Fh / prt;
+  return octh * dTrough;
+}
+// UNO = false: wfmneutral (BCbotm = 3, src/modwallfunctions.f90:263-350); true: wfuno case 91 (BCbotm = 2, :72-127)
+template <bool UNO>
 __global__ __launch_bounds__(256) void bottom_kernel(Geo g, Metrics m, BottomArgs a) {
   const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
   if (i >= g.nx || j >= g.ny) return;
@@ -149,22 +186,32 @@ __global__ __launch_bounds__(256) void bottom_kernel(Geo g, Metrics m, BottomArg
   const double delta = 0.5 * m.dzf[k];
   const double l_ = log(delta / a.z0);
   const double logdz2 = l_ * l_;
-  const double ctm = fkar2 / (logdz2);
+  double ctm = fkar2 / (logdz2);
   const double dzfi = m.dzfi[k], dzhi = m.dzhi[k], dzhiq = m.dzhiq[k];
-  {  // u component, :318-331
+  const double grav = 9.81, Twall = a.thls;
+  const double logzh = (UNO || a.thl_wf >= 0) ? log(a.z0 / a.z0h) : 0., sqdz = (UNO || a.thl_wf >= 0) ? sqrt(delta / a.z0) : 0.;
+  {  // u component, :318-331 (neutral) / :92-109 (uno)
     const double utang1Int = a.u0[c];
     const double utang2Int = (a.v0[c] + a.v0[cxm] + a.v0[c + sy] + a.v0[cxm + sy]) * 0.25;
     const double utangInt = fmax(umin, (utang1Int * utang1Int + utang2Int * utang2Int));
+    if (UNO) {
+      const double dT = ((a.thl0[c] + a.thl0[cxm]) - (Twall + Twall)) * 0.5;
+      ctm = uno_m(a.prt, l_, logzh, sqdz, grav * delta * dT * 2 / ((Twall + Twall) * utangInt), fkar2);
+    }
     const double dummy = fabs(utang1Int) * sqrt(utangInt) * ctm;
     const double bcmomflux = copysign(dummy, utang1Int);
     const double emom = (m.dzf[km] * (a.ekm[c] * m.dx + a.ekm[cxm] * m.dx) +
                          m.dzf[k] * (a.ekm[c - sz] * m.dx + a.ekm[cxm - sz] * m.dx)) * m.dxi * dzhiq;
     a.up[c] = a.up[c] + (a.u0[c] - a.u0[c - sz]) * emom * dzhi * dzfi - bcmomflux * dzfi;
   }
-  {  // v component, :333-346
+  {  // v component, :333-346 / :111-127
     const double utang1Int = (a.u0[c] + a.u0[c - sy] + a.u0[cxp - sy] + a.u0[cxp]) * 0.25;
     const double utang2Int = a.v0[c];
     const double utangInt = fmax(umin, (utang1Int * utang1Int + utang2Int * utang2Int));
+    if (UNO) {
+      const double dT = ((a.thl0[c] + a.thl0[c - sy]) - (Twall + Twall)) * 0.5;
+      ctm = uno_m(a.prt, l_, logzh, sqdz, grav * delta * dT * 2 / ((Twall + Twall) * utangInt), fkar2);
+    }
     const double dummy = fabs(utang2Int) * sqrt(utangInt) * ctm;
     const double bcmomflux = copysign(dummy, utang2Int);
     const double eomm = (m.dzf[km] * (a.ekm[c] + a.ekm[c - sy]) + m.dzf[k] * (a.ekm[c - sz] + a.ekm[c - sy - sz])) * dzhiq;
@@ -174,6 +221,16 @@ __global__ __launch_bounds__(256) void bottom_kernel(Geo g, Metrics m, BottomArg
   }
   for (int n = 0; n < a.nsv; ++n) {   // Neumann floor: scalars src/modibm.f90:2073-2090 (flux 0), thl :2035-2047 (wtsurf)
     const double *c0 = a.sv0[n];
+    if (n == a.thl_wf) {              // wfuno case 92 (BCbotT = 2, src/modwallfunctions.f90:131-165): wall at thls
+      const double utang1Int = (a.u0[c] + a.u0[cxp]) * 0.5;
+      const double utang2Int = (a.v0[c] + a.v0[c + sy]) * 0.5;
+      const double utangInt = fmax(umin, (utang1Int * utang1Int + utang2Int * utang2Int));
+      const double dT = (c0[c] - Twall);
+      const double bcTflux = uno_h(a.prt, l_, logzh, sqdz, utangInt, dT, grav * delta * dT / (Twall * utangInt), fkar2);
+      a.svp[n][c] = a.svp[n][c] + 0.5 * (m.dzf[k - 1] * a.ekh[c] + m.dzf[k] * a.ekh[c - sz]) * (c0[c] - c0[c - sz]) * m.dzh2i[k] * dzfi
+                    - bcTflux * dzfi;
+      continue;
+    }
     a.svp[n][c] = a.svp[n][c] + (0.5 * (m.dzf[km] * a.ekh[c] + m.dzf[k] * a.ekh[c - sz]) * (c0[c] - c0[c - sz]) * m.dzh2i[k] - a.flux[n]) * dzfi;
   }
 }
@@ -239,14 +296,21 @@ int k_bottom(udc_handle *h, bool wrap_vp) {
   a.u0 = h->fields[UDC_U0]; a.v0 = h->fields[UDC_V0]; a.ekm = h->fields[UDC_EKM]; a.ekh = h->fields[UDC_EKH];
   a.up = h->fields[UDC_UP]; a.vp = h->fields[UDC_VP];
   a.nsv = 0; a.wrap_vp = wrap_vp ? 1 : 0; a.z0 = h->p.z0;
+  a.thls = h->floor_thls; a.z0h = h->floor_z0h; a.prt = h->floor_prt; a.thl_wf = -1;
+  const bool have_thl = (int)h->fields.size() > UDC_THL0 && h->fields[UDC_THL0];
+  a.thl0 = have_thl ? h->fields[UDC_THL0] : nullptr;
+  const bool uno = h->floor_bcbotm == 2;
+  if ((uno || h->floor_bcbott == 2) && !have_thl) { udc_set_error("bottom: the wfuno floor needs the temperature equation (udc_set_tempeq)"); return 1; }
   for (int n : h->slots) {
     if (h->slot[n].tke) continue;      // e12 has no floor-flux correction in `bottom`
+    if (n == 15 && h->floor_bcbott == 2) a.thl_wf = a.nsv;
     a.sv0[a.nsv] = h->fields[UDC_SV0 + 3 * n]; a.svp[a.nsv] = h->fields[UDC_SVP + 3 * n];
     a.flux[a.nsv] = h->slot[n].floorflux; ++a.nsv;
   }
   PROF(h, "bottom");
-  hipLaunchKernelGGL(bottom_kernel, dim3((unsigned)((g.nx + 63) / 64), (unsigned)((g.ny + 3) / 4)), dim3(64, 4), 0, h->stream,
-                     g, h->m, a);
+  const dim3 gr((unsigned)((g.nx + 63) / 64), (unsigned)((g.ny + 3) / 4)), bl(64, 4);
+  if (uno) hipLaunchKernelGGL(bottom_kernel<true>, gr, bl, 0, h->stream, g, h->m, a);
+  else hipLaunchKernelGGL(bottom_kernel<false>, gr, bl, 0, h->stream, g, h->m, a);
   HIP_OK(hipGetLastError());
   return 0;
 }

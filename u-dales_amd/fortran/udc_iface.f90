@@ -105,6 +105,12 @@ module udc_iface
       integer(c_int), value :: lbuoyancy
       real(c_double), value :: grav
     end function
+    integer(c_int) function udc_set_floor_wf(h, bcbotm, bcbott, thls, z0h, prandtlturb) bind(C, name='udc_set_floor_wf')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: bcbotm, bcbott
+      real(c_double), value :: thls, z0h, prandtlturb
+    end function udc_set_floor_wf
     integer(c_int) function udc_set_moisture(h, iadv_qt, bctopq, wqtop, qt_top, bcbotq, wqsurf) bind(C, name='udc_set_moisture')
       import :: c_ptr, c_int, c_double
       type(c_ptr), value :: h
@@ -206,7 +212,7 @@ contains
     stop 1
   end subroutine udc_check
 
-  !> Binding for modibm (INTEGRATION.md section 3): `call udc_set_floor(lbottom .and. BCbotm == 3, z0)` from initibm,
+  !> Binding for modibm (INTEGRATION.md section 3): `call udc_set_floor(lbottom, z0)` from initibm,
   !! before the first substep, lets a device-resident run apply `bottom`'s floor wall function on the GPU
   !! (udc_bottom inside the fused substep).
   subroutine udc_set_floor(on, z0)
@@ -224,8 +230,8 @@ contains
   subroutine udc_ensure
     use modglobal, only: itot, jtot, ktot, dx, dy, dzf, dzh, kb, ke, kh, numol, prandtlmoli, nsv, &
                          BCtopm, Uinf, Vinf, lles, ltempeq, lbuoyancy, lmoist, iadv_thl, BCtopT, BCbotT, grav, e12min, &
-                         iadv_qt, BCtopq, BCbotq, zf, zh
-    use modsurfdata, only: wttop, thl_top, wtsurf, thvs, wqtop, qt_top, wqsurf, thls, qts, ps
+                         iadv_qt, BCtopq, BCbotq, zf, zh, BCbotm, prandtlturb
+    use modsurfdata, only: wttop, thl_top, wtsurf, thvs, wqtop, qt_top, wqsurf, thls, qts, ps, z0h
     use modsubgriddata, only: lsmagorinsky, lvreman, loneeqn, ldelta, prandtli, c_vreman, csz, cm, cn, ch1, ch2, ce1, ce2
     use modfields, only: dpdxl, dpdyl, thlpcar
     use modmpi, only: myid, nprocs, nprocx, comm3d, mpierr
@@ -293,6 +299,10 @@ contains
       end if
     end if
     if (ltempeq .and. lbuoyancy) call udc_check(udc_set_buoyancy(udc_h, 1_c_int, real(grav, c_double)), 'udc_set_buoyancy')
+    if (udc_floor_on .and. (BCbotm == 2 .or. (ltempeq .and. BCbotT == 2))) then   ! wfuno floor (src/modibm.f90:2021-2045)
+      call udc_check(udc_set_floor_wf(udc_h, int(BCbotm, c_int), int(BCbotT, c_int), real(thls, c_double), real(z0h, c_double), &
+                                      real(prandtlturb, c_double)), 'udc_set_floor_wf')
+    end if
     if (cfg%sgs == 3) then   ! after udc_set_tempeq: the closure reads thl0 when the temperature equation is on
       call udc_check(udc_set_tke(udc_h, real(cm, c_double), real(cn, c_double), real(ch1, c_double), real(ch2, c_double), &
                                  real(ce1, c_double), real(ce2, c_double), real(e12min, c_double), real(grav, c_double), &

@@ -155,6 +155,11 @@ class DynCore:
             a = np.ascontiguousarray(thlpcar, dtype=np.float64)
             L._check(self.lib.udc_set_thl_source(self.h, a.ctypes.data_as(L.DP), len(a)), "udc_set_thl_source")
 
+    def set_floor_wf(self, bcbotm=3, bcbott=1, thls=-1., z0h=-1., prandtlturb=0.71):
+        """Floor wall function choice of `bottom` (BCbotm 2 / BCbotT 2 = wfuno), see include/udcore.h udc_set_floor_wf."""
+        L._check(self.lib.udc_set_floor_wf(self.h, int(bcbotm), int(bcbott), C.c_double(thls), C.c_double(z0h),
+                                           C.c_double(prandtlturb)), "udc_set_floor_wf")
+
     def set_moisture(self, iadv_qt=2, bctopq=1, wqtop=0., qt_top=-1., bcbotq=1, wqsurf=0.):
         """&PHYSICS lmoist: qt becomes a transported field, see include/udcore.h udc_set_moisture."""
         L._check(self.lib.udc_set_moisture(self.h, int(iadv_qt), int(bctopq), C.c_double(wqtop), C.c_double(qt_top),
