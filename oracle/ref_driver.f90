@@ -369,7 +369,8 @@ contains
     zsize_ = zh(ke + 1)
     do n = 1, nsv
       do k = kb, ke
-        sv0(:, :, k, n) = scal_b + scal_a*real(n)*zf(k)/zsize_
+        svprof(k, n) = scal_b + scal_a*real(n)*zf(k)/zsize_      ! nudge relaxes towards it (src/modforces.f90:840-844)
+        sv0(:, :, k, n) = svprof(k, n)                            ! src/modstartup.f90:1561-1570
       end do
       sv0(:, :, kb - 1, n) = sv0(:, :, kb, n)
       sv0(:, :, kb - 2, n) = sv0(:, :, kb, n)

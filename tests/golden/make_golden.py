@@ -200,7 +200,7 @@ CASES.update({
 CASES.update({
     # lstend / nudge / grwdamp acting on total water, with large-scale moisture gradients and tendency
     "k_lsfq_12x8x20": ("kernels", 34, 12, 8, 20,
-                       dict(sgs="vreman", physics="lmoist = .true.\nltempeq = .true.\nlbuoyancy = .false.\nlnudge = .true.\n"
+                       dict(sgs="vreman", nsv=1, physics="lmoist = .true.\nltempeq = .true.\nlbuoyancy = .false.\nlnudge = .true.\n"
                             "tnudge = 45.\nnnudge = 1\nigrw_damp = 3",
                             bc="BCtopT = 2\nthl_top = 295.\nthls = 288.0\nqts = 0.008\nBCtopq = 2\nqt_top = 0.002",
                             oracle="nspin = 3"), 1.03),
@@ -301,7 +301,7 @@ def main():
             if name in LSF_ONLY:      # only what tests/test_level_forcings.py reads
                 keep = {k: v for k, v in keep.items() if k.count(".") == 0 or k.startswith(("frc0.", "lsf."))
                         or k in ("in.v0", "in.w0", "in.um", "in.vm", "in.wm", "in.pres0", "sub.u0", "sub.thl0", "in.thlm",
-                                 "sub.qt0", "in.qtm")}
+                                 "sub.qt0", "in.qtm", "in.sv0_01")}
         else:
             keep = {k: v for k, v in d.items()
                     if k.count(".") == 0 or k.split(".")[1] in ("u0", "v0", "w0", "pres0", "um", "thl0", "thlm", "e120", "e12m", "qt0", "qtm")

@@ -6,15 +6,15 @@ fused substep, against the reference run (run_lsf_16x8x24s)."""
 import numpy as np
 import pytest
 
-from common import deck_path, interior, load_fixture, marr, nocorner, relerr
+from common import carr, deck_path, interior, load_fixture, marr, nocorner, relerr
 from udcore import read_deck
 from udcore.forcings import LevelForcings
 from udcore.grid import Grid
 
 
 class _FakeCore:
-    def __init__(self, g):
-        self.g, self.nsv = g, 0
+    def __init__(self, g, nsv=0):
+        self.g, self.nsv = g, nsv
 
 
 def _avg(a, nz):
@@ -32,7 +32,8 @@ def test_tables_match_reference_routines(name, iexp, igrw):
     d = read_deck(deck_path(name, iexp))
     g = Grid.from_deck(d)
     nz = g.nz
-    ls = LevelForcings(_FakeCore(g), d)
+    nsv = int(d.get("SCALARS", "nsv"))
+    ls = LevelForcings(_FakeCore(g, nsv), d)
     assert ls.active and ls.subsidence and ls.lnudge and ls.igrw == igrw
     qt = ls.lmoist
     assert qt == ("sub.qt0" in fix) and ls.qtls == qt
@@ -40,6 +41,8 @@ def test_tables_match_reference_routines(name, iexp, igrw):
     fields["thl0"] = marr(fix, "sub.thl0", nz)      # top ghost row re-imposed by closurebc before the forcings run
     if qt:
         fields["qt0"] = marr(fix, "sub.qt0", nz)
+    for n in range(nsv):       # kappa scalars: subsidence and nudging towards the initial profile
+        fields[f"sv0_{n}"] = carr(fix, f"in.sv0_{n + 1:02d}", nz)[1:-1, 1:-1, 1:-1]
     av = {k: _avg(fields[k], nz) for k in fields if k != "w0"}
     if qt:
         np.testing.assert_allclose(av["qt0"][1:nz + 1], fix["qt0av"].data[:nz], rtol=0, atol=1e-17)
@@ -47,9 +50,20 @@ def test_tables_match_reference_routines(name, iexp, igrw):
     np.testing.assert_allclose(av["u0"][1:nz + 2], fix["u0av"].data, rtol=0, atol=2e-15)
     np.testing.assert_allclose(av["thl0"][1:nz + 1], fix["thl0av"].data[:nz], rtol=0, atol=1e-12)
     tabs = ls.tables(av)
-    tends = ("up", "vp", "wp", "thlp") + (("qtp",) if qt else ())
+    tends = ("up", "vp", "wp", "thlp") + (("qtp",) if qt else ()) + tuple(f"svp_{n}" for n in range(nsv))
     assert {t for t, _ in tabs} == set(tends)
     for tend in tends:
+        if tend.startswith("svp_"):
+            key = f"svp_{int(tend[4:]) + 1:02d}"
+            t = carr(fix, "frc0." + key, nz)[1:-1, 1:-1, 1:-1].copy()
+            src, A, B = tabs[(tend, 0)]
+            assert src is None and (tend, 1) not in tabs
+            for k in range(1, nz + 1):
+                t[k] = t[k] + A[k]
+            ref = carr(fix, "lsf." + key, nz)[1:-1, 1:-1, 1:-1]
+            sc = np.abs(ref - carr(fix, "frc0." + key, nz)[1:-1, 1:-1, 1:-1]).max()
+            assert sc > 1e-4 and np.abs(interior(t) - interior(ref)).max() <= 1e-12 * sc, tend
+            continue
         t = marr(fix, "frc0." + tend, nz).copy()
         for when in (0, 1):
             if (tend, when) not in tabs:
@@ -77,6 +91,11 @@ def test_device_applies_tables_like_reference(name, iexp, igrw):
     core.upload("thl0", marr(fix, "sub.thl0", nz))
     core.upload("thlm", marr(fix, "in.thlm", nz))
     tends = ("up", "vp", "wp", "thlp") + (("qtp",) if core.lmoist else ())
+    from udcore import lib as L
+    for n in range(core.nsv):
+        core.upload(L.scalar_field(L.SV0, n), carr(fix, f"in.sv0_{n + 1:02d}", nz))
+        core.upload(L.scalar_field(L.SVM, n), carr(fix, f"in.sv0_{n + 1:02d}", nz))
+        core.upload(L.scalar_field(L.SVP, n), carr(fix, f"frc0.svp_{n + 1:02d}", nz))
     if core.lmoist:
         core.upload("qt0", marr(fix, "sub.qt0", nz))
         core.upload("qtm", marr(fix, "in.qtm", nz))
@@ -92,6 +111,11 @@ def test_device_applies_tables_like_reference(name, iexp, igrw):
         sc = np.abs(marr(fix, "lsf." + k, nz) - marr(fix, "frc0." + k, nz)).max()
         tol = 1e-11 * (sc if k == "qtp" else max(sc, 1.))
         assert np.abs(interior(core.download(k)) - interior(marr(fix, "lsf." + k, nz))).max() <= tol, k
+    for n in range(core.nsv):
+        got = core.download(L.scalar_field(L.SVP, n), halo=2)
+        ref = carr(fix, f"lsf.svp_{n + 1:02d}", nz)
+        sc = np.abs(ref - carr(fix, f"frc0.svp_{n + 1:02d}", nz)).max()
+        assert np.abs(interior(got, 2) - interior(ref, 2)).max() <= 1e-11 * sc
     core.close()
 
 

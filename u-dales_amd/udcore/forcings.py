@@ -44,6 +44,8 @@ class LevelForcings:
         self.uprof, self.vprof, self.thlprof = f(deck.u), f(deck.v), f(deck.thl)
         self.ug, self.vg = f(deck.ug), f(deck.vg)
         self.qtprof = f(deck.qt)
+        from .grid import scalar_profiles
+        self.svprof = scalar_profiles(g, deck, getattr(core, "nsv", 0))
         # large-scale moisture gradients / tendency (lscale.inp columns 7-9, src/modstartup.f90:2060-2097)
         self.dqtdxls, self.dqtdyls, self.dqtdtls = (f(getattr(deck, n, np.zeros(nz))) for n in ("dqtdxls", "dqtdyls", "dqtdtls"))
         self.qtls = self.lmoist and bool(np.any(self.dqtdxls) or np.any(self.dqtdyls) or np.any(self.dqtdtls))
@@ -113,6 +115,10 @@ class LevelForcings:
                 A = acc("qtp")[1]
                 for k in range(k0, nz + 1):
                     A[k] -= (av["qt0"][k] - self.qtprof[k]) / self.tnudge
+            for n in range(self.core.nsv):                       # src/modforces.f90:840-844
+                A = acc(f"svp_{n}")[1]
+                for k in range(k0, nz + 1):
+                    A[k] -= (av[f"sv0_{n}"][k] - self.svprof[n][k]) / self.tnudge
         if self.igrw in (1, 2, 3):                               # grwdamp
             tsc = self.tsc
             for name, tend, geo in (("u0", "up", self.ug), ("v0", "vp", self.vg)):

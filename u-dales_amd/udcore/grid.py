@@ -97,6 +97,23 @@ def sgs_from_deck(d: Deck):
     return sgs, csz, float(d.get("NAMSUBGRID", "c_vreman")), 1. / float(d.get("NAMSUBGRID", "Prandtl"))
 
 
+def scalar_profiles(g: Grid, d: Deck, nsv, scal_a=None, scal_b=None):
+    """svprof(k, n) as [nsv][nz+2] (index = reference k): the columns of scalar.inp.xxx when the case has one
+    (src/modstartup.f90:1539-1548), else the linear stand-in profile of the oracle driver (&ORACLE scal_a, scal_b)."""
+    nz = g.nz
+    out = []
+    sp = getattr(d, "svprof", None)
+    a = float(d.get("ORACLE", "scal_a")) if scal_a is None else scal_a
+    b = float(d.get("ORACLE", "scal_b")) if scal_b is None else scal_b
+    zsize = g.zh[nz + 1]
+    for n in range(nsv):
+        p = np.zeros(nz + 2)
+        for k in range(1, nz + 1):
+            p[k] = sp[n][k - 1] if sp else b + a * float(n + 1) * g.zf[k] / zsize
+        out.append(p)
+    return out
+
+
 def cold_start(g: Grid, d: Deck, j0=0, nyl=None, nsv=0, scal_a=1.0, scal_b=0.0):
     """Initial um, vm, wm (= u0, v0, w0), and scalars for rows j0+1..j0+nyl of the global grid.
 
@@ -136,13 +153,14 @@ def cold_start(g: Grid, d: Deck, j0=0, nyl=None, nsv=0, scal_a=1.0, scal_b=0.0):
         a[nz + 1] = a[nz] if bctopm != 2 else -a[nz]
     wm[nz + 1] = 0.
     out["u0"], out["v0"], out["w0"] = um.copy(), vm.copy(), wm.copy()
-    zsize = g.zh[nz + 1]
+    svprof = scalar_profiles(g, d, nsv, scal_a, scal_b)
     for n in range(nsv):
         c = np.zeros((nz + 4, nyl + 4, nx + 4))
         for k in range(1, nz + 1):
-            c[k + 1] = scal_b + scal_a * float(n + 1) * g.zf[k] / zsize
-        c[1] = c[2]
-        c[0] = c[2]
+            c[k + 1] = svprof[n][k]
+        if not getattr(d, "svprof", None):      # (the reference leaves the sub-floor planes of a scalar.inp start at zero)
+            c[1] = c[2]
+            c[0] = c[2]
         c[nz + 2] = c[nz + 1]
         c[nz + 3] = c[nz + 1]
         out[f"sv0_{n}"] = c

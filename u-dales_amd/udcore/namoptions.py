@@ -159,6 +159,12 @@ def read_deck(namoptions_path: str) -> Deck:
     d.wfls = [r[5] for r in ls]         # large-scale vertical velocity -> whls, src/modstartup.f90:2125-2129
     d.dqtdxls, d.dqtdyls, d.dqtdtls = [r[6] for r in ls], [r[7] for r in ls], [r[8] for r in ls]
     d.thlpcar = [r[9] for r in ls]      # dthlrad column -> thlpcar(k), src/modstartup.f90:2060-2097
+    nsv = int(d.get("SCALARS", "nsv"))
+    sc = os.path.join(base, f"scalar.inp.{exp:03d}")
+    d.svprof = None
+    if nsv > 0 and os.path.exists(sc):  # z sv(1) .. sv(nsv), src/modstartup.f90:1541-1548
+        rows = _read_table(sc, 1 + nsv, ktot)
+        d.svprof = [[r[1 + n] for r in rows] for n in range(nsv)]
     return d
 
 
