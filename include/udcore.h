@@ -113,6 +113,13 @@ int udc_set_forcing(udc_handle *h, const double *dpdxl, const double *dpdyl, int
  * radiative tendency of src/modforces.f90:104-110) is optional. */
 int udc_set_tempeq(udc_handle *h, int iadv_thl, int bctopt, double wttop, double thl_top, int bcbott, double wtsurf);
 int udc_set_thl_source(udc_handle *h, const double *thlpcar, int n);
+/* scalsource  src/modscalsource.f90:379-483 (src/program.f90:181): Gaussian point and line sources of the scalars.  They
+ * depend on neither time nor flow, so the host evaluates the reference's expressions once (udcore/sources.py; in Fortran
+ * one call of the reference's own scalsource on a zeroed svp) and registers the result per scalar n (0-based) as a dense
+ * box src[(k-lb[2]) nj ni + (j-lb[1]) ni + (i-lb[0])] over the local interior indices lb..ub (src = NULL removes it);
+ * udc_scalsource adds it to svp, as does udc_substep after masscorr. */
+int udc_set_scalar_source(udc_handle *h, int n, const double *src, const int lb[3], const int ub[3]);
+int udc_scalsource(udc_handle *h);
 /* Floor (lbottom) with the stability-dependent wall function wfuno (Louis 1979 / Uno et al. 1995 over a rough wall,
  * src/modwallfunctions.f90:24-261) as `bottom` selects it (src/modibm.f90:2021-2045): BCbotm = 2 -> momentum (case 91;
  * 3 = the neutral wfmneutral of udc_config), BCbotT = 2 -> temperature against a wall at thls with roughness length

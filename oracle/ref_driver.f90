@@ -44,6 +44,7 @@ program ref_driver
   use modtstep, only: tstep_update, tstep_integrate
   use modforces, only: forces, masscorr, coriolis, lstend, nudge
   use modsave, only: writerestartfiles
+  use modscalsource, only: createscals, scalsource
   implicit none
 
   character(256) :: mode, outfile, arg
@@ -86,6 +87,7 @@ program ref_driver
   call initsubgrid
   call initpois
   call cold_start
+  call createscals                          ! src/modstartup.f90 (scalarsourcep / scalarsourcel files; no-op without sources)
   call boundary
   need_thermo = ltempeq .or. lmoist .or. loneeqn .or. lnudge .or. igrw_damp /= 0 .or. any(whls /= 0.)
   if (need_thermo) call thermodynamics            ! src/program.f90:120 (thv0h, thvh; dthvdz; diagfld's slab averages)
@@ -173,6 +175,7 @@ contains
     if (lforces) call lstend                ! src/program.f90:162 (large-scale subsidence; needs diagfld's slab averages)
     if (lforces) call nudge                 ! src/program.f90:164
     call masscorr                           ! src/program.f90:169
+    call scalsource                         ! src/program.f90:181 (point / line sources of the scalars; no-op unless lscasrc / lscasrcl)
     if (lforces) call grwdamp               ! src/program.f90:191 (sponge layer) (no-op unless luvolflowr / lvvolflowr)
     call poisson
     call tstep_integrate
@@ -263,7 +266,7 @@ contains
     namelist /DYNAMICS/ ipoiss, iadv_mom, iadv_tke, iadv_thl, iadv_qt, iadv_sv
     namelist /BC/ BCxm, BCym, BCtopm, BCtopT, BCtops, BCbotm, BCbots, BCbotT, BCzp, wttop, thl_top, z0, wtsurf, thls, qts, &
       BCtopq, BCbotq, wqtop, qt_top, wqsurf, ps, z0h
-    namelist /SCALARS/ nsv
+    namelist /SCALARS/ nsv, lscasrc, nscasrc, lscasrcl, nscasrcl
     namelist /WALLS/ nfcts, lbottom
     open (ifnamopt, file=fname_options, status='old', iostat=ierr)
     if (ierr /= 0) then
@@ -573,6 +576,10 @@ contains
     end if
     if (luvolflowr .or. lvvolflowr) call dump_tend('frc')   ! tendencies masscorr starts from
     call masscorr
+    if (lscasrc .or. lscasrcl) then
+      call dump_tend('src0')                ! tendencies the scalar sources start from
+      call scalsource
+    end if
     call dump_tend('pre')
     call poisson                            ! src/modpois.f90:419
     call put3('poi.p', p, (/ib - ih, jb - jh, kb - kh/))

@@ -853,6 +853,47 @@ void orc_bottom(const orc_grid *g, const double *u0, const double *v0, const dou
   metrics_free(&m);
 }
 
+/* ====================================================================== scalar sources */
+void orc_scalsource(const orc_grid *g, int npoint, const double *points, int nline, const double *lines, double *cp) {
+  const double pi = 3.141592653589793116;                 /* src/modglobal.f90:270 */
+  const double dx = g->dx, dy = g->dy, dxi = 1. / dx, dyi = 1. / dy;
+  metrics m; metrics_init(g, &m);
+  for (int ns = 0; ns < npoint; ++ns) {                   /* :392-415 */
+    const double xS = points[5 * ns], yS = points[5 * ns + 1], zS = points[5 * ns + 2], SS = points[5 * ns + 3], sigS = points[5 * ns + 4];
+    for (int k = 1; k <= g->nz; ++k)
+      for (int j = 1; j <= g->ny; ++j)
+        for (int i = 1; i <= g->nx; ++i) {
+          const double ax = (i - 0.5) * dx - xS, ay = (j - 0.5) * dy - yS, az = g->zf[k] - zS;
+          const double ra2 = ax * ax + ay * ay + az * az;
+          if (ra2 <= 9 * (sigS * sigS))
+            C(cp, i, j, k) = C(cp, i, j, k) + dxi * dyi * m.dzfi[k] * SS * exp(-ra2 / (2 * (sigS * sigS)));
+        }
+  }
+  for (int ns = 0; ns < nline; ++ns) {                    /* :420-478 */
+    const double *r = lines + 8 * ns;
+    const double xSb = r[0], ySb = r[1], zSb = r[2], xSe = r[3], ySe = r[4], zSe = r[5], SS = r[6], sigS = r[7];
+    const double lsx = xSe - xSb, lsy = ySe - ySb, lsz = zSe - zSb;
+    for (int k = 1; k <= g->nz; ++k)
+      for (int j = 1; j <= g->ny; ++j)
+        for (int i = 1; i <= g->nx; ++i) {
+          const double px = (i - 0.5) * dx, py = (j - 0.5) * dy, pz = g->zf[k];
+          const double vx = px - xSb, vy = py - ySb, vz = pz - zSb;
+          const double dot = (vx * lsx + vy * lsy + vz * lsz) / (lsx * lsx + lsy * lsy + lsz * lsz);
+          double ra2;
+          if (dot < 0.0) ra2 = (px - xSb) * (px - xSb) + (py - ySb) * (py - ySb) + (pz - zSb) * (pz - zSb);
+          else if (dot > 1.0) ra2 = (px - xSe) * (px - xSe) + (py - ySe) * (py - ySe) + (pz - zSe) * (pz - zSe);
+          else {
+            const double qx = px - (xSb + dot * lsx), qy = py - (ySb + dot * lsy), qz = pz - (zSb + dot * lsz);
+            ra2 = qx * qx + qy * qy + qz * qz;
+          }
+          if (ra2 <= 9 * (sigS * sigS))
+            C(cp, i, j, k) = C(cp, i, j, k) + dxi * dyi * m.dzfi[k] *
+                             sqrt(2.0 * pi) * SS * sigS * exp(-ra2 / (2 * (sigS * sigS))) * erf(sqrt((9 * (sigS * sigS) - ra2) / (2 * (sigS * sigS))));
+        }
+  }
+  metrics_free(&m);
+}
+
 /* ---- wfuno, src/modwallfunctions.f90:24-170: Louis (1979) / Uno et al. (1995) transfer coefficients over a rough wall */
 static void uno_F(double logdz, double sqdz, double Ri, double fkar2, double *Fm, double *Fh) {
   const double b1 = 9.4, b2 = 4.7, dm = 7.4, dh = 5.3;                                  /* :184-187 */
@@ -1390,6 +1431,8 @@ void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
       for (int j = 1; j <= g->ny; ++j)
         for (int i = 1; i <= g->nx; ++i) M(s->thlp, i, j, k) = M(s->thlp, i, j, k) + s->thlpcar[k];
   orc_masscorr(g, rk3step, dt, s->up, s->um, s->vp, s->vm);                            /* src/program.f90:169 */
+  if (s->svsrc)                                                                          /* scalsource, src/program.f90:181 */
+    for (size_t q = 0; q < (size_t)g->nsv * nc; ++q) s->svp[q] = s->svp[q] + s->svsrc[q];
   orc_fillps(g, rk3coef, s->up, s->vp, s->wp, s->um, s->vm, s->wm, s->pup, s->pvp, s->pwp, s->p);
   orc_poisson_solve(g, s->p);
   orc_tderive(g, s->p, s->up, s->vp, s->wp, s->pres0);

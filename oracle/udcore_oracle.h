@@ -99,6 +99,9 @@ void orc_thl_top(const orc_grid *g, const double *ekh, double *a);
 /* `bottom` with wfuno: momentum (case 91) into up, vp; temperature (case 92, when g->bcbott == 2) into thlp */
 void orc_bottom_uno(const orc_grid *g, const double *u0, const double *v0, const double *thl0, const double *ekm, const double *ekh,
                     double *up, double *vp, double *thlp);
+/* scalsource, src/modscalsource.f90:379-483: Gaussian point sources (rows xS yS zS SS sigS) and line sources (rows xSb ySb
+ * zSb xSe ySe zSe SS sigS) added to the tendency cp (c-array) of one scalar; zf as in orc_grid ([nz+2] by k) */
+void orc_scalsource(const orc_grid *g, int npoint, const double *points, int nline, const double *lines, double *cp);
 void orc_qt_top(const orc_grid *g, const double *ekh, double *a);
 void orc_qt_floor(const orc_grid *g, const double *ekh, const double *qt0, double *qtp);
 void orc_buoyancy(const orc_grid *g, const double *thl0, double *wp);
@@ -142,6 +145,7 @@ typedef struct {
   /* moist thermodynamics state kept between calls: ORC_TH_N tables of [nz+2] indexed by k (presf, presh, exnf, exnh,
    * thvh, thl0av, qt0av, ql0av, th0av) followed by one flag (0 = diagfld has not run yet); and ql0 (m-array) */
   double *thermo, *ql0;
+  const double *svsrc;                    /* nsv consecutive c-arrays: constant scalar sources added to svp (scalsource), or NULL */
 } orc_state;
 enum { ORC_TH_PRESF, ORC_TH_PRESH, ORC_TH_EXNF, ORC_TH_EXNH, ORC_TH_THVH, ORC_TH_THL0AV, ORC_TH_QT0AV, ORC_TH_QL0AV,
        ORC_TH_TH0AV, ORC_TH_N };

@@ -29,7 +29,7 @@ REF = os.path.join(ROOT, "oracle", "_ref", "udales_ref")
 
 
 def deck(iexpnr, nx, ny, nz, dx=0.5, dy=0.5, dtmax=0.25, sgs="vreman", nsv=0, bctopm=1,
-         oracle="", lles=True, randu=0.01, floor=False, z0=0.05, physics="", bc="", bcbotm=3):
+         oracle="", lles=True, randu=0.01, floor=False, z0=0.05, physics="", bc="", bcbotm=3, scalars=""):
     sub = {"oneeqn": "loneeqn = .true.\nlvreman = .false.\nlsmagorinsky = .false.",
            "vreman": "lvreman = .true.\nlsmagorinsky = .false.",
            "smag": "lsmagorinsky = .true.\nlvreman = .false.",
@@ -66,7 +66,7 @@ BCtopm = {bctopm}
 /
 {('&WALLS' + chr(10) + 'nfcts = 0' + chr(10) + 'lbottom = .true.' + chr(10) + '/') if floor else ''}
 &SCALARS
-nsv = {nsv}
+nsv = {nsv}{(chr(10) + scalars) if scalars else ''}
 /
 &NAMSUBGRID
 {sub}
@@ -87,7 +87,8 @@ def zlevels(nz, dz0=0.5, stretch=1.0):
     return zf
 
 
-def write_case(d, iexpnr, text, zf, u=1.0, v=0.0, pgx=1e-4, dthl=0.0, dthlrad=0.0, ug=0.0, tke=0.0, wtop=0.0, qt=0.0, dqt=0.0, dqtdx=0.0, dqtdy=0.0, dqtdt=0.0):
+def write_case(d, iexpnr, text, zf, u=1.0, v=0.0, pgx=1e-4, dthl=0.0, dthlrad=0.0, ug=0.0, tke=0.0, wtop=0.0, qt=0.0, dqt=0.0, dqtdx=0.0, dqtdy=0.0, dqtdt=0.0,
+               psrc=None, lsrc=None):
     with open(os.path.join(d, f"namoptions.{iexpnr:03d}"), "w") as f:
         f.write(text)
     with open(os.path.join(d, f"prof.inp.{iexpnr:03d}"), "w") as f:
@@ -101,6 +102,15 @@ def write_case(d, iexpnr, text, zf, u=1.0, v=0.0, pgx=1e-4, dthl=0.0, dthlrad=0.
             f.write(f"{z:.15f} {ug!r} 0.0 {pgx} 0.0 {wf!r} {dqtdx!r} {dqtdy!r} {dqtdt!r} {dthlrad!r}\n")
 
 
+    # scalar point / line sources: one file per scalar (src/modscalsource.f90:292-375)
+    for kind, rows in (("p", psrc), ("l", lsrc)):
+        for n, r in enumerate(rows or []):
+            with open(os.path.join(d, f"scalarsource{kind}.inp.{n + 1}.{iexpnr:03d}"), "w") as f:
+                f.write("# golden\n# " + ("xS yS zS SS sigS" if kind == "p" else "xSb ySb zSb xSe ySe zSe SS sigS") + "\n")
+                for row in r:
+                    f.write(" ".join(repr(float(x)) for x in row) + "\n")
+
+
 KEEP_KERNELS = ("meta dzf dzh zf dpdxl dpdyl rk3 in.u0 in.v0 in.w0 in.um in.vm in.wm in.pres0 "
                 "in.ekm in.ekh adv.up adv.vp adv.wp sub.ekm sub.ekh sub.u0 sub.up sub.vp sub.wp bot.up bot.vp frc.up frc.vp "
                 "in.thl0 in.thlm adv.thlp sub.thlp sub.thl0 bot.thlp pre.thlp out.thl0 out.thlm "
@@ -109,6 +119,7 @@ KEEP_KERNELS = ("meta dzf dzh zf dpdxl dpdyl rk3 in.u0 in.v0 in.w0 in.um in.vm i
                 "in.qt0 in.qtm adv.qtp sub.qtp sub.qt0 bot.qtp pre.qtp out.qt0 out.qtm "
                 "in.e120 in.e12m adv.e12p sub.e12p pre.e12p out.e120 out.e12m "
                 "frc0.up frc0.vp frc0.wp frc0.thlp lsf.up lsf.vp lsf.wp lsf.thlp u0av thl0av frc0.qtp lsf.qtp qt0av "
+                "src0.up "
                 "pre.up pre.vp pre.wp poi.p poi.pres0 poi.up poi.vp poi.wp out.u0 out.v0 out.w0 "
                 "out.um out.pres0").split()
 
@@ -229,8 +240,21 @@ CASES.update({
                               bc="BCtopT = 2\nthl_top = 290.5\nBCbotT = 2\nthls = 286.5\nz0h = 0.005\nqts = 0.0",
                               oracle="nsub = 9\ndump_at = 3, 9"), 1.06),
 })
+CASES.update({
+    # Gaussian point and line sources of the scalars (scalsource)
+    "k_src_12x8x8": ("kernels", 39, 12, 8, 8,
+                     dict(sgs="vreman", nsv=2, floor=True, scalars="lscasrc = .true.\nnscasrc = 2\nlscasrcl = .true.\nnscasrcl = 1",
+                          oracle="nspin = 3"), 1.04),
+    "run_src_16x8x12s": ("run", 40, 16, 8, 12,
+                         dict(sgs="smag", nsv=1, floor=True, scalars="lscasrc = .true.\nnscasrc = 1\nlscasrcl = .true.\nnscasrcl = 2",
+                              oracle="nsub = 6\ndump_at = 3, 6"), 1.06),
+})
 LSF_ONLY = ("k_lsfq_12x8x20",)
-THL_CASES = {"k_uno_12x8x6": dict(dthl=0.2), "run_uno_16x8x12s": dict(dthl=0.25),
+THL_CASES = {"k_src_12x8x8": dict(psrc=[[(2.2, 1.3, 0.9, 0.5, 0.6), (4.9, 3.1, 2.2, 0.2, 0.4)], [(1.0, 2.0, 1.5, 1.0, 0.5), (5.5, 0.4, 0.3, 0.3, 0.7)]],
+                                  lsrc=[[(0.5, 0.5, 0.6, 5.0, 3.5, 1.4, 0.4, 0.5)], [(3.0, 0.2, 2.0, 3.0, 3.8, 2.0, 0.6, 0.45)]]),
+             "run_src_16x8x12s": dict(psrc=[[(3.1, 1.9, 1.2, 0.8, 0.7)]],
+                                      lsrc=[[(1.0, 0.6, 0.5, 6.5, 0.6, 0.5, 0.5, 0.5), (6.0, 3.5, 2.5, 2.0, 1.0, 3.5, 0.3, 0.6)]]),
+             "k_uno_12x8x6": dict(dthl=0.2), "run_uno_16x8x12s": dict(dthl=0.25),
              "k_moist_12x8x8": dict(dthl=0.25, qt=0.0118, dqt=-8e-5), "run_moist_16x8x12s": dict(dthl=0.25, qt=0.0119, dqt=-6e-5),
              "k_lsfq_12x8x20": dict(dthl=0.3, ug=1.0, wtop=0.025, qt=0.008, dqt=-3e-4, dqtdx=2e-7, dqtdy=-1e-7, dqtdt=3e-8),
              "k_qt_12x8x6": dict(dthl=0.3, qt=0.008, dqt=-4e-4), "run_qt_16x8x12s": dict(dthl=0.25, qt=0.007, dqt=-2e-4),

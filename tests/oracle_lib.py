@@ -43,7 +43,7 @@ class OrcState(C.Structure):
     _fields_ = [(n, DP) for n in ("u0", "v0", "w0", "um", "vm", "wm", "up", "vp", "wp", "pres0",
                                   "ekm", "ekh", "p", "pup", "pvp", "pwp", "sv0", "svm", "svp",
                                   "dpdxl", "dpdyl", "thl0", "thlm", "thlp", "thlpcar", "ug", "e120", "e12m", "e12p",
-                                  "qt0", "qtm", "qtp", "thermo", "ql0")]
+                                  "qt0", "qtm", "qtp", "thermo", "ql0", "svsrc")]
 
 
 TH_TABLES = ("presf", "presh", "exnf", "exnh", "thvh", "thl0av", "qt0av", "ql0av", "th0av")      # ORC_TH_* order

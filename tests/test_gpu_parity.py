@@ -138,6 +138,13 @@ def test_each_routine_matches_reference(name, iexp):
         for k in ("up", "vp"):
             assert relerr(interior(core.download(k)), interior(marr(fix, "frc." + k, nz))) <= KERNEL_TOL, k
     core.masscorr()
+    if "src0.svp_01" in fix:      # scalsource: Gaussian point / line sources evaluated by udcore/sources.py
+        core.scalsource()
+        for n in range(nsv):
+            got = core.download(L.scalar_field(L.SVP, n), halo=2)
+            ref = carr(fix, f"pre.svp_{n + 1:02d}", nz)
+            assert relerr(interior(got, 2), interior(ref, 2)) <= KERNEL_TOL
+            assert relerr(interior(ref, 2), interior(carr(fix, f"src0.svp_{n + 1:02d}", nz), 2)) > 1e-3
     for k in ("up", "vp", "wp") + (("thlp",) if thl else ()) + (("qtp",) if qt else ()):
         assert relerr(interior(core.download(k)), interior(marr(fix, "pre." + k, nz))) <= KERNEL_TOL, k
     if tke:
@@ -194,7 +201,8 @@ def test_substeps_match_reference(name, iexp, fused):
             core.substep(rk, dt, with_forces=True)
         else:
             core.tstep_update(dt)
-            core.advection(); core.subgrid(); core.bottom(); core.coriolis(); core.forces(); core.masscorr(); core.poisson()
+            core.advection(); core.subgrid(); core.bottom(); core.coriolis(); core.forces(); core.masscorr()
+            core.scalsource(); core.poisson()
             core.tstep_integrate(); core.halos(); core.boundary()
             if core.moist_thermo:
                 core.thermodynamics()

@@ -212,6 +212,7 @@ extern "C" int udc_destroy(udc_handle *h) {
   if (h->red_host) hipHostFree(h->red_host);
   if (h->thlpcar) hipFree(h->thlpcar);
   if (h->mt) hipFree(h->mt);
+  for (auto &s : h->svsrc) if (s.d) hipFree(s.d);
   if (h->ug) hipFree(h->ug);
   if (h->lev_part) hipFree(h->lev_part);
   if (h->lev_sum) hipFree(h->lev_sum);
@@ -374,6 +375,30 @@ extern "C" int udc_set_tempeq(udc_handle *h, int iadv_thl, int bctopt, double wt
   sl.topval = bctopt == 2 ? thl_top : wttop;
   sl.floorflux = wtsurf;
   return 0;
+}
+
+extern "C" int udc_set_scalar_source(udc_handle *h, int n, const double *src, const int lb[3], const int ub[3]) {
+  HIP_OK(hipSetDevice(h->device));
+  if (n < 0 || n >= h->cfg.nsv) { udc_set_error("udc_set_scalar_source: scalar %d of %d", n, h->cfg.nsv); return 1; }
+  udc_handle::ScalarSource &s = h->svsrc[n];
+  if (s.d) { HIP_OK(hipFree(s.d)); s.d = nullptr; }
+  if (!src) return 0;
+  const int ext[3] = {h->g.nx, h->g.ny, h->g.nz};
+  size_t cnt = 1;
+  for (int q = 0; q < 3; ++q) {
+    if (lb[q] < 1 || ub[q] > ext[q] || ub[q] < lb[q]) { udc_set_error("udc_set_scalar_source: box outside the interior (dimension %d: %d..%d of 1..%d)", q, lb[q], ub[q], ext[q]); return 1; }
+    s.lo[q] = lb[q] - 1; s.hi[q] = ub[q] - 1;
+    cnt *= (size_t)(ub[q] - lb[q] + 1);
+  }
+  HIP_OK(hipMalloc(&s.d, sizeof(double) * cnt));
+  HIP_OK(hipMemcpy(s.d, src, sizeof(double) * cnt, hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int udc_scalsource(udc_handle *h) {
+  HIP_OK(hipSetDevice(h->device));
+  if (tend_clean(h)) return 1;
+  return k_scalsource(h);
 }
 
 extern "C" int udc_set_floor_wf(udc_handle *h, int bcbotm, int bcbott, double thls, double z0h, double prandtlturb) {
@@ -690,6 +715,7 @@ extern "C" int udc_substep(udc_handle *h, int rk3step, double dt, int with_force
   if (with_forces && !h->level_forcings.empty() && k_level_forcings(h, 0, fold)) return 1;   // lstend, nudge tables
   // masscorr (src/program.f90:169); without pup the tendencies and um are summed separately
   if (k_masscorr(h, rk3coef, pup, fold)) return 1;
+  if (k_scalsource(h)) return 1;                                       // src/program.f90:181
   if (with_forces && !h->level_forcings.empty() && k_level_forcings(h, 1, fold)) return 1;   // grwdamp tables
   if (!fold) {
     const int fvp[1] = {UDC_VP};

@@ -183,3 +183,29 @@ static int launch_scalar(udc_handle *h, int n, bool adv, bool diff, bool fresh =
 int k_scalar_adv(udc_handle *h, int n) { return launch_scalar(h, n, true, false); }
 int k_scalar_diff(udc_handle *h, int n) { return launch_scalar(h, n, false, true); }
 int k_scalar_fused(udc_handle *h, int n, bool fresh) { return launch_scalar(h, n, true, true, fresh); }
+
+// scalsource (src/modscalsource.f90:379-483): the sources are constant in time, the host evaluated them once
+// (udcore/sources.py, udc_set_scalar_source); svp += source over the box that holds it
+namespace {
+__global__ __launch_bounds__(256) void box_add_kernel(Geo g, const double *__restrict__ src, int i0, int j0, int k0, int ni, int nj, int nk,
+                                                       double *__restrict__ svp) {
+  const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
+  if (i >= ni || j >= nj || k >= nk) return;
+  const long c = g.idx(i0 + i, j0 + j, k0 + k);
+  svp[c] = svp[c] + src[((size_t)k * nj + j) * ni + i];
+}
+}  // namespace
+
+int k_scalsource(udc_handle *h) {
+  const Geo &g = h->g;
+  for (int n = 0; n < h->cfg.nsv; ++n) {
+    const udc_handle::ScalarSource &s = h->svsrc[n];
+    if (!s.d) continue;
+    const int ni = s.hi[0] - s.lo[0] + 1, nj = s.hi[1] - s.lo[1] + 1, nk = s.hi[2] - s.lo[2] + 1;
+    PROF(h, "scalsource");
+    hipLaunchKernelGGL(box_add_kernel, dim3((unsigned)((ni + 63) / 64), (unsigned)((nj + 3) / 4), (unsigned)nk), dim3(64, 4), 0, h->stream,
+                       g, (const double *)s.d, s.lo[0], s.lo[1], s.lo[2], ni, nj, nk, h->fields[UDC_SVP + 3 * n]);
+    HIP_OK(hipGetLastError());
+  }
+  return 0;
+}

@@ -68,4 +68,7 @@ def from_deck(deck, device=0, rank=0, nranks=1):
         dpdxl = [om23_gs * vg - pg - dpdx for vg, pg in zip(deck.vg, deck.pgx)]
         dpdyl = [-om23_gs * ug - pg for ug, pg in zip(deck.ug, deck.pgy)]
     core.set_forcing(np.array(dpdxl), np.array(dpdyl))
+    if core.nsv and (deck.get("SCALARS", "lscasrc") or deck.get("SCALARS", "lscasrcl")):
+        from .sources import apply_sources
+        apply_sources(core, deck, j0=rank * core.nyl)
     return core

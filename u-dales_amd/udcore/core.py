@@ -155,6 +155,28 @@ class DynCore:
             a = np.ascontiguousarray(thlpcar, dtype=np.float64)
             L._check(self.lib.udc_set_thl_source(self.h, a.ctypes.data_as(L.DP), len(a)), "udc_set_thl_source")
 
+    def set_scalar_source(self, n, src):
+        """Constant source of scalar n (scalsource): src is [nz, nyl, nx] over the interior of this slab, or None to remove
+        it.  Only the smallest box holding its non-zeros is kept on the device."""
+        if src is None:
+            L._check(self.lib.udc_set_scalar_source(self.h, int(n), None, (C.c_int * 3)(1, 1, 1), (C.c_int * 3)(0, 0, 0)),
+                     "udc_set_scalar_source")
+            return
+        a = np.asarray(src, dtype=np.float64)
+        assert a.shape == (self.g.nz, self.nyl, self.g.nx), a.shape
+        nzr = np.nonzero(a)
+        if len(nzr[0]) == 0:
+            return self.set_scalar_source(n, None)
+        lo = [int(x.min()) for x in nzr]
+        hi = [int(x.max()) for x in nzr]
+        box = np.ascontiguousarray(a[lo[0]:hi[0] + 1, lo[1]:hi[1] + 1, lo[2]:hi[2] + 1])
+        lb = (C.c_int * 3)(lo[2] + 1, lo[1] + 1, lo[0] + 1)          # (i, j, k), the reference's local indices
+        ub = (C.c_int * 3)(hi[2] + 1, hi[1] + 1, hi[0] + 1)
+        L._check(self.lib.udc_set_scalar_source(self.h, int(n), box.ctypes.data_as(L.DP), lb, ub), "udc_set_scalar_source")
+
+    def scalsource(self):
+        L._check(self.lib.udc_scalsource(self.h), "udc_scalsource")
+
     def set_floor_wf(self, bcbotm=3, bcbott=1, thls=-1., z0h=-1., prandtlturb=0.71):
         """Floor wall function choice of `bottom` (BCbotm 2 / BCbotT 2 = wfuno), see include/udcore.h udc_set_floor_wf."""
         L._check(self.lib.udc_set_floor_wf(self.h, int(bcbotm), int(bcbott), C.c_double(thls), C.c_double(z0h),
