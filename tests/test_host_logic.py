@@ -122,3 +122,21 @@ def test_no_device_fails_loudly():
     from udcore.core import DynCore
     with pytest.raises(L.UdcError):
         DynCore(Grid.uniform(8, 8, 8))
+
+
+def test_scalar_sources_slab_equals_global_rows():
+    """udcore/sources.py evaluates the sources per y-slab from the global row offset: stitched slabs == the global field;
+    the box registered with the device is the tight bounding box."""
+    from udcore.sources import source_field
+    g = Grid.uniform(16, 12, 8)
+    pts = [(3.1, 2.2, 1.4, 0.8, 0.6)]
+    lns = [(1.0, 0.6, 0.5, 6.5, 4.6, 2.5, 0.5, 0.5)]
+    full = source_field(g, pts, lns)
+    assert full.shape == (8, 12, 16) and full.max() > 0 and (full == 0).any()
+    for P in (2, 3):
+        nyl = g.ny // P
+        parts = [source_field(g, pts, lns, j0=r * nyl, nyl=nyl) for r in range(P)]
+        np.testing.assert_array_equal(np.concatenate(parts, axis=1), full)
+    # a source outside a slab leaves that slab empty
+    far = source_field(g, [(3.0, 0.4, 1.0, 1.0, 0.1)], [], j0=8, nyl=4)
+    assert not far.any()
