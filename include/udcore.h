@@ -103,7 +103,8 @@ int udc_field_download(udc_handle *h, int field, double *host, const int lb[3], 
 int udc_set_forcing(udc_handle *h, const double *dpdxl, const double *dpdyl, int n);
 
 /* Temperature equation, &PHYSICS ltempeq (src/modglobal.f90:176): thl is advected (advection: iadv_thl = 2 ->
- * advecc_2nd, src/modadvection.f90:103-155), diffused (subgrid: diffc with ekh), integrated and given its top
+ * advecc_2nd, src/modadvection.f90:103-155; 7 -> advecc_kappa on the thl0c copy, :66-72, whose vertical ghost planes
+ * follow src/modboundary.f90:211-213), diffused (subgrid: diffc with ekh), integrated and given its top
  * (BCtopT 1 = flux wttop, 2 = value thl_top, src/modboundary.f90:207-220) and floor (lbottom, BCbotT 1 = flux wtsurf,
  * src/modibm.f90:2035-2047) conditions like the passive scalars.  udc_set_buoyancy switches on forces' buoyancy
  * term for dry air (lbuoyancy, src/modforces.f90:73-84): wp += grav (thv0h - thvh)/thvh with thv0h = thl0h of

@@ -1035,6 +1035,28 @@ void orc_diffc_m(const orc_grid *g, const double *c, const double *ekh, double *
       }
   metrics_free(&m);
 }
+void orc_thl0c_from(const orc_grid *g, const double *thl0, double *thl0c) {
+  memset(thl0c, 0, csize(g) * sizeof(double));
+  for (int k = 1; k <= g->nz; ++k)
+    for (int j = 1; j <= g->ny; ++j)
+      for (int i = 1; i <= g->nx; ++i) C(thl0c, i, j, k) = M(thl0, i, j, k);
+  orc_halos_c(g, thl0c);
+  if (g->bctopt != 2)
+    for (int n = 1; n <= 2; ++n)
+      for (int j = -1; j <= g->ny + 2; ++j)
+        for (int i = -1; i <= g->nx + 2; ++i) C(thl0c, i, j, g->nz + n) = C(thl0c, i, j, g->nz + n - 1);
+}
+void orc_advec_thl_kappa(const orc_grid *g, const double *u0, const double *v0, const double *w0, const double *thl0c, double *thlp) {
+  double *pc = (double *)calloc(csize(g), sizeof(double));
+  for (int k = 1; k <= g->nz; ++k)
+    for (int j = 1; j <= g->ny; ++j)
+      for (int i = 1; i <= g->nx; ++i) C(pc, i, j, k) = M(thlp, i, j, k);
+  orc_advecc_kappa(g, u0, v0, w0, thl0c, pc);
+  for (int k = 1; k <= g->nz; ++k)
+    for (int j = 1; j <= g->ny; ++j)
+      for (int i = 1; i <= g->nx; ++i) M(thlp, i, j, k) = C(pc, i, j, k);
+  free(pc);
+}
 /* top condition of thl / qt: fluxtop (src/modboundary.f90:1494-1507) / valuetop (:1509-1519), BCtopT, BCtopq 1 / 2 */
 static void scalar_top(const orc_grid *g, const double *ekh, double *a, int bctop, double wtop, double top_value) {
   const int ke = g->nz;
@@ -1379,7 +1401,8 @@ void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
   orc_advecv_2nd(g, s->u0, s->v0, s->w0, s->pres0, s->vp);
   orc_advecw_2nd(g, s->u0, s->v0, s->w0, s->pres0, s->wp);
   if (g->sgs == 3) orc_advecc_2nd(g, s->u0, s->v0, s->w0, s->e120, s->e12p);              /* src/modadvection.f90:56-58 */
-  if (g->ltempeq) orc_advecc_2nd(g, s->u0, s->v0, s->w0, s->thl0, s->thlp);              /* src/modadvection.f90:66-68 */
+  if (g->ltempeq && g->iadv_thl == 7) orc_advec_thl_kappa(g, s->u0, s->v0, s->w0, s->thl0c, s->thlp);   /* src/modadvection.f90:69-72 */
+  else if (g->ltempeq) orc_advecc_2nd(g, s->u0, s->v0, s->w0, s->thl0, s->thlp);         /* src/modadvection.f90:66-68 */
   if (g->lmoist) orc_advecc_2nd(g, s->u0, s->v0, s->w0, s->qt0, s->qtp);                 /* src/modadvection.f90:78-86 */
   for (int n = 0; n < g->nsv; ++n) orc_advecc_kappa(g, s->u0, s->v0, s->w0, s->sv0 + n * nc, s->svp + n * nc);
   if (g->sgs == 3) orc_closure_tke(g, s->e120, g->ltempeq ? s->thl0 : NULL, s->ekm, s->ekh);
@@ -1479,6 +1502,7 @@ void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
   for (int n = 0; n < g->nsv; ++n) { orc_halos_c(g, s->sv0 + n * nc); orc_halos_c(g, s->svm + n * nc); }
   orc_boundary(g, s->u0, s->v0, s->w0, s->um, s->vm, s->wm, s->sv0, s->svm);
   if (g->ltempeq) { orc_thl_top(g, s->ekh, s->thlm); orc_thl_top(g, s->ekh, s->thl0); }     /* src/modboundary.f90:207-217 */
+  if (g->ltempeq && g->iadv_thl == 7) orc_thl0c_from(g, s->thl0, s->thl0c);                 /* src/modtstep.f90:249 + halos + boundary */
   if (g->lmoist) { orc_qt_top(g, s->ekh, s->qtm); orc_qt_top(g, s->ekh, s->qt0); }          /* src/modboundary.f90:222-231 */
   if (g->lmoist && g->lbuoyancy && s->thermo) orc_thermodynamics(g, s);                     /* src/program.f90:214 */
 }

@@ -64,6 +64,7 @@ typedef struct {
    * roughness length for heat z0h (src/modsurfdata.f90:73), prandtlturb (src/modglobal.f90:304) */
   int bcbotm, bcbott;
   double z0h, prandtlturb;
+  int iadv_thl;             /* 2 = cd2 (advecc_2nd), 7 = kappa (advecc_kappa on thl0c), src/modadvection.f90:64-76 */
 } orc_grid;
 
 /* ---- advection: src/modadvection.f90 */
@@ -102,6 +103,12 @@ void orc_bottom_uno(const orc_grid *g, const double *u0, const double *v0, const
 /* scalsource, src/modscalsource.f90:379-483: Gaussian point sources (rows xS yS zS SS sigS) and line sources (rows xSb ySb
  * zSb xSe ySe zSe SS sigS) added to the tendency cp (c-array) of one scalar; zf as in orc_grid ([nz+2] by k) */
 void orc_scalsource(const orc_grid *g, int npoint, const double *points, int nline, const double *lines, double *cp);
+/* thl0c as the reference maintains it: interior = thl0 (src/modtstep.f90:249), periodic lateral ghosts two wide
+ * (src/modboundary.f90:87,556-557,645-646), the two planes below the floor never written (zero), the two above the top
+ * copies of level ke for a flux condition (:211-213) and never written (zero) for a value condition */
+void orc_thl0c_from(const orc_grid *g, const double *thl0, double *thl0c);
+/* advection of thl with iadv_thl = 7 (src/modadvection.f90:69-72): thlpc = thlp; advecc_kappa(thl0c, thlpc); thlp = thlpc */
+void orc_advec_thl_kappa(const orc_grid *g, const double *u0, const double *v0, const double *w0, const double *thl0c, double *thlp);
 void orc_qt_top(const orc_grid *g, const double *ekh, double *a);
 void orc_qt_floor(const orc_grid *g, const double *ekh, const double *qt0, double *qtp);
 void orc_buoyancy(const orc_grid *g, const double *thl0, double *wp);
@@ -145,6 +152,7 @@ typedef struct {
   /* moist thermodynamics state kept between calls: ORC_TH_N tables of [nz+2] indexed by k (presf, presh, exnf, exnh,
    * thvh, thl0av, qt0av, ql0av, th0av) followed by one flag (0 = diagfld has not run yet); and ql0 (m-array) */
   double *thermo, *ql0;
+  double *thl0c;                          /* c-array: the wide copy of thl0 kappa advection runs on (g->iadv_thl == 7) */
   const double *svsrc;                    /* nsv consecutive c-arrays: constant scalar sources added to svp (scalsource), or NULL */
 } orc_state;
 enum { ORC_TH_PRESF, ORC_TH_PRESH, ORC_TH_EXNF, ORC_TH_EXNH, ORC_TH_THVH, ORC_TH_THL0AV, ORC_TH_QT0AV, ORC_TH_QL0AV,

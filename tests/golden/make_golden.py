@@ -29,7 +29,7 @@ REF = os.path.join(ROOT, "oracle", "_ref", "udales_ref")
 
 
 def deck(iexpnr, nx, ny, nz, dx=0.5, dy=0.5, dtmax=0.25, sgs="vreman", nsv=0, bctopm=1,
-         oracle="", lles=True, randu=0.01, floor=False, z0=0.05, physics="", bc="", bcbotm=3, scalars=""):
+         oracle="", lles=True, randu=0.01, floor=False, z0=0.05, physics="", bc="", bcbotm=3, scalars="", dynamics=""):
     sub = {"oneeqn": "loneeqn = .true.\nlvreman = .false.\nlsmagorinsky = .false.",
            "vreman": "lvreman = .true.\nlsmagorinsky = .false.",
            "smag": "lsmagorinsky = .true.\nlvreman = .false.",
@@ -57,7 +57,7 @@ ylen = {ny * dy}
 {physics}
 /
 &DYNAMICS
-ipoiss = 0
+ipoiss = 0{(chr(10) + dynamics) if dynamics else ''}
 /
 &BC
 BCtopm = {bctopm}
@@ -249,8 +249,19 @@ CASES.update({
                          dict(sgs="smag", nsv=1, floor=True, scalars="lscasrc = .true.\nnscasrc = 1\nlscasrcl = .true.\nnscasrcl = 2",
                               oracle="nsub = 6\ndump_at = 3, 6"), 1.06),
 })
+CASES.update({
+    # kappa advection of the temperature (iadv_thl = 7: advecc_kappa on the wide copy thl0c), flux top and value top
+    "k_thlk_12x8x6": ("kernels", 41, 12, 8, 6,
+                      dict(sgs="vreman", floor=True, physics="ltempeq = .true.\nlbuoyancy = .true.", dynamics="iadv_thl = 7",
+                           bc="BCtopT = 1\nwttop = -0.002\nBCbotT = 1\nwtsurf = 0.02\nthls = 288.0\nqts = 0.0", oracle="nspin = 4"), 1.04),
+    "run_thlk_16x8x12s": ("run", 42, 16, 8, 12,
+                          dict(sgs="smag", nsv=1, floor=True, physics="ltempeq = .true.\nlbuoyancy = .true.", dynamics="iadv_thl = 7",
+                               bc="BCtopT = 2\nthl_top = 290.5\nBCbotT = 1\nwtsurf = 0.03\nthls = 288.0\nqts = 0.0",
+                               oracle="nsub = 6\ndump_at = 3, 6"), 1.06),
+})
 LSF_ONLY = ("k_lsfq_12x8x20",)
-THL_CASES = {"k_src_12x8x8": dict(psrc=[[(2.2, 1.3, 0.9, 0.5, 0.6), (4.9, 3.1, 2.2, 0.2, 0.4)], [(1.0, 2.0, 1.5, 1.0, 0.5), (5.5, 0.4, 0.3, 0.3, 0.7)]],
+THL_CASES = {"k_thlk_12x8x6": dict(dthl=0.3), "run_thlk_16x8x12s": dict(dthl=0.25),
+             "k_src_12x8x8": dict(psrc=[[(2.2, 1.3, 0.9, 0.5, 0.6), (4.9, 3.1, 2.2, 0.2, 0.4)], [(1.0, 2.0, 1.5, 1.0, 0.5), (5.5, 0.4, 0.3, 0.3, 0.7)]],
                                   lsrc=[[(0.5, 0.5, 0.6, 5.0, 3.5, 1.4, 0.4, 0.5)], [(3.0, 0.2, 2.0, 3.0, 3.8, 2.0, 0.6, 0.45)]]),
              "run_src_16x8x12s": dict(psrc=[[(3.1, 1.9, 1.2, 0.8, 0.7)]],
                                       lsrc=[[(1.0, 0.6, 0.5, 6.5, 0.6, 0.5, 0.5, 0.5), (6.0, 3.5, 2.5, 2.0, 1.0, 3.5, 0.3, 0.6)]]),

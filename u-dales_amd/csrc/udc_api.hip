@@ -356,7 +356,7 @@ extern "C" int udc_subgrid(udc_handle *h) {
 extern "C" int udc_set_tempeq(udc_handle *h, int iadv_thl, int bctopt, double wttop, double thl_top, int bcbott, double wtsurf) {
   HIP_OK(hipSetDevice(h->device));
   if (h->cfg.nsv > 15) { udc_set_error("udc_set_tempeq: thl uses scalar slot 15, nsv must be <= 15"); return 1; }
-  if (iadv_thl != 2) { udc_set_error("udc_set_tempeq: only iadv_thl = 2 (cd2, advecc_2nd) is built"); return 1; }
+  if (iadv_thl != 2 && iadv_thl != 7) { udc_set_error("udc_set_tempeq: iadv_thl must be 2 (cd2, advecc_2nd) or 7 (kappa, advecc_kappa)"); return 1; }
   if (bctopt != 1 && bctopt != 2) { udc_set_error("udc_set_tempeq: BCtopT must be 1 (flux) or 2 (value)"); return 1; }
   if (h->p.lbottom && bcbott != 1 && bcbott != 2) { udc_set_error("udc_set_tempeq: BCbotT must be 1 (flux) or 2 (wall function)"); return 1; }
   const bool have = (int)h->fields.size() > UDC_THL0 && h->fields[UDC_THL0];
@@ -370,7 +370,8 @@ extern "C" int udc_set_tempeq(udc_handle *h, int iadv_thl, int bctopt, double wt
     }
   }
   udc_handle::Slot &sl = h->slot[15];
-  sl.adv = 2;
+  sl.adv = iadv_thl == 7 ? 1 : 2;
+  sl.kappa_ghosts = iadv_thl == 7 ? (bctopt == 2 ? 2 : 1) : 0;
   sl.top = bctopt == 2 ? 2 : (wttop != 0. ? 1 : 0);
   sl.topval = bctopt == 2 ? thl_top : wttop;
   sl.floorflux = wtsurf;

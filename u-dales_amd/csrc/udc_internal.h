@@ -116,6 +116,7 @@ struct udc_handle {
     int top = 0;          // 0 = zero-flux copy, 1 = fluxtop with topval = flux (src/modboundary.f90:1494), 2 = valuetop
     double topval = 0.;
     double floorflux = 0.;   // wtsurf in bottom's Neumann floor (src/modibm.f90:2035-2047); 0 for passive scalars
+    int kappa_ghosts = 0;    // kappa on thl: vertical ghosts of the reference's thl0c copy (1 flux top, 2 value top), else 0
     bool tke = false;        // e120: diffused with ekm (diffe), clipped at e12min, own floor/top ghosts, no floor flux
   };
   Slot slot[16];

@@ -31,7 +31,7 @@ __device__ __forceinline__ double face(double vel, double cm2, double cm1, doubl
 template <int ADV, bool DIFF, bool LES, bool FRESH>
 __global__ __launch_bounds__(256) void scalar_kernel(Geo g, TileGrid tg, Metrics m, double cekh, double dfac, const double *__restrict__ u,
     const double *__restrict__ v, const double *__restrict__ w, const double *__restrict__ ekh,
-    const double *__restrict__ c, double *__restrict__ cp) {
+    const double *__restrict__ c, double *__restrict__ cp, int gh) {
   int i, j, k;
   const bool inside_ = tile_decode(g, tg, i, j, k);
   if (!inside_) return;
@@ -55,7 +55,18 @@ __global__ __launch_bounds__(256) void scalar_kernel(Geo g, TileGrid tg, Metrics
   if (ADV == 1) {
     const double cxm2 = c[xm2], cxp2 = c[xp2];
     const double cym2 = c[o - 2 * sy], cyp2 = c[o + 2 * sy];
-    const double czm2 = c[o - 2 * sz], czp2 = c[o + 2 * sz];
+    double czm2 = c[o - 2 * sz], czp2 = c[o + 2 * sz];
+    double czm1 = c[o - sz], czp1 = c[o + sz];      // (shadow the diffusion operands: those stay thl0's own ghosts)
+    if (gh) {
+      // kappa on thl (iadv_thl = 7) runs on the reference's separate copy thl0c, whose vertical ghost planes are not
+      // thl0's: nothing ever writes the two below the floor (zero), and at the top `boundary` copies level ke upwards
+      // for a flux condition (src/modboundary.f90:211-213) and leaves them untouched (zero) for a value condition
+      const double top = gh == 1 ? 1. : 0.;
+      if (k == 0) czm1 = 0.;
+      if (k <= 1) czm2 = 0.;
+      if (k == g.nz - 1) { czp1 = top * c0; czp2 = top * c0; }
+      if (k == g.nz - 2) czp2 = top * czp1;
+    }
     const double dxi = m.dxi, dx = m.dx, dyi = m.dyi;
     {  // x: faces i (low) and i+1 (high); dxhci = dxi, dxfc = dx, dxfci = dxi on the uniform grid
       const double ul = u[o], uh = u[xp1];
@@ -164,11 +175,12 @@ static int launch_scalar(udc_handle *h, int n, bool adv, bool diff, bool fresh =
   double *cp = h->fields[UDC_SVP + 3 * n];
   const bool les = h->p.sgs != UDC_SGS_DNS;
   const bool cd2 = h->slot[n].adv == 2;
+  const int gh = h->slot[n].kappa_ghosts;
 #define LS(A, D, L)                                                                                     \
   do {                                                                                                  \
     PROF(h, "scalar_" #A #D #L);                                                                        \
-    if (fresh) hipLaunchKernelGGL((scalar_kernel<A, D, L, true>), gr, b, 0, h->stream, g, tile_grid(g), h->m, cekh, dfac, u, v, w, ekh, c, cp); \
-    else hipLaunchKernelGGL((scalar_kernel<A, D, L, false>), gr, b, 0, h->stream, g, tile_grid(g), h->m, cekh, dfac, u, v, w, ekh, c, cp); \
+    if (fresh) hipLaunchKernelGGL((scalar_kernel<A, D, L, true>), gr, b, 0, h->stream, g, tile_grid(g), h->m, cekh, dfac, u, v, w, ekh, c, cp, gh); \
+    else hipLaunchKernelGGL((scalar_kernel<A, D, L, false>), gr, b, 0, h->stream, g, tile_grid(g), h->m, cekh, dfac, u, v, w, ekh, c, cp, gh); \
   } while (0)
   if (adv && diff) {
     if (cd2) { if (les) LS(2, true, true); else LS(2, true, false); }

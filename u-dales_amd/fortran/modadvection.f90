@@ -23,8 +23,8 @@ contains
       write (0, *) 'ERROR: Unknown advection scheme'
       stop 1
     end if
-    if (ltempeq .and. iadv_thl /= iadv_cd2) then   ! thl: advecc_2nd only (src/modadvection.f90:66-68)
-      write (0, *) 'ERROR: libudcore advection: iadv_thl must be 2 (cd2)'
+    if (ltempeq .and. iadv_thl /= iadv_cd2 .and. iadv_thl /= iadv_kappa) then   ! src/modadvection.f90:64-76
+      write (0, *) 'ERROR: Unknown advection scheme'
       stop 1
     end if
 

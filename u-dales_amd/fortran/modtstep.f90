@@ -36,8 +36,8 @@ contains
   end subroutine tstep_update
 
   subroutine tstep_integrate
-    use modglobal, only: rk3step, dt, timee, ifixuinf, lchem, ltempeq, lmoist, iinletgen, idriver
-    use modfields, only: up, vp, wp, svp, thlp, qtp, e12p
+    use modglobal, only: rk3step, dt, timee, ifixuinf, lchem, ltempeq, lmoist, iinletgen, idriver, ib, ie, jb, je, kb, ke
+    use modfields, only: up, vp, wp, svp, thlp, qtp, e12p, thl0, thl0c
     use modsubgriddata, only: loneeqn
     use modmpi, only: myid, cmyid
     use udc_iface
@@ -59,7 +59,10 @@ contains
     ! keep the device's own ghosts consistent with what the host's halos/boundary will produce
     call udc_check(udc_halos(udc_h), 'udc_halos')
     call udc_check(udc_boundary(udc_h), 'udc_boundary')
-    if (udc_residency <= 1) call udc_pull_vel(rk3step == 3)
+    if (udc_residency <= 1) then
+      call udc_pull_vel(rk3step == 3)
+      if (ltempeq) thl0c(ib:ie, jb:je, kb:ke) = thl0(ib:ie, jb:je, kb:ke)      ! src/modtstep.f90:249 (the host's halos / boundary fill its ghosts)
+    end if
 
     if ((myid == 0) .and. (rk3step == 3)) then
       open (unit=11, file='monitor'//cmyid//'.txt', position='append')

@@ -333,8 +333,8 @@ contains
 
   !> Everything the device needs from the host's prognostic state (bounds: src/modfields.f90:440-474)
   subroutine udc_push_state
-    use modglobal, only: ib, jb, kb, ih, jh, kh, ihc, jhc, khc, nsv, ltempeq, lmoist
-    use modfields, only: u0, v0, w0, um, vm, wm, pres0, sv0, svm, thl0, thlm, e120, e12m, qt0, qtm
+    use modglobal, only: ib, jb, kb, ih, jh, kh, ihc, jhc, khc, nsv, ltempeq, lmoist, iadv_thl, iadv_kappa
+    use modfields, only: u0, v0, w0, um, vm, wm, pres0, sv0, svm, thl0, thlm, e120, e12m, qt0, qtm, thl0c
     integer :: n
     call udc_push3(UDC_U0, u0, (/ib - ih, jb - jh, kb - kh/))
     call udc_push3(UDC_V0, v0, (/ib - ih, jb - jh, kb - kh/))
@@ -348,6 +348,9 @@ contains
       call udc_push3(UDC_E12M, e12m, (/ib - ih, jb - jh, kb - kh/))
     end if
     if (ltempeq) then
+      ! kappa on thl reads two lateral ghost cells: those come from the reference's wide copy thl0c (its vertical ghosts
+      ! are re-created on the device, udc_set_tempeq), the inner ring and the vertical ghost planes from thl0 itself
+      if (iadv_thl == iadv_kappa) call udc_push3(UDC_THL0, thl0c, (/ib - ihc, jb - jhc, kb - khc/))
       call udc_push3(UDC_THL0, thl0, (/ib - ih, jb - jh, kb - kh/))
       call udc_push3(UDC_THLM, thlm, (/ib - ih, jb - jh, kb - kh/))
     end if
