@@ -42,7 +42,7 @@ program ref_driver
   use modpois, only: initpois, poisson, p
   use modadvection, only: advection
   use modtstep, only: tstep_update, tstep_integrate
-  use modforces, only: forces, masscorr, coriolis, lstend, nudge
+  use modforces, only: forces, masscorr, coriolis, lstend, nudge, fixuinf1, fixuinf2
   use modsave, only: writerestartfiles
   use modscalsource, only: createscals, scalsource
   implicit none
@@ -89,7 +89,7 @@ program ref_driver
   call cold_start
   call createscals                          ! src/modstartup.f90 (scalarsourcep / scalarsourcel files; no-op without sources)
   call boundary
-  need_thermo = ltempeq .or. lmoist .or. loneeqn .or. lnudge .or. igrw_damp /= 0 .or. any(whls /= 0.)
+  need_thermo = ltempeq .or. lmoist .or. loneeqn .or. lnudge .or. igrw_damp /= 0 .or. any(whls /= 0.) .or. ifixuinf /= 0
   if (need_thermo) call thermodynamics            ! src/program.f90:120 (thv0h, thvh; dthvdz; diagfld's slab averages)
 
   iu = 71
@@ -176,6 +176,8 @@ contains
     if (lforces) call nudge                 ! src/program.f90:164
     call masscorr                           ! src/program.f90:169
     call scalsource                         ! src/program.f90:181 (point / line sources of the scalars; no-op unless lscasrc / lscasrcl)
+    call fixuinf2                           ! src/program.f90:186 (dgdt of the dp/dx ODE; no-op unless ifixuinf = 2)
+    call fixuinf1                           ! src/program.f90:188 (pulls the top-level mean back to Uinf; no-op unless ifixuinf = 1)
     if (lforces) call grwdamp               ! src/program.f90:191 (sponge layer) (no-op unless luvolflowr / lvvolflowr)
     call poisson
     call tstep_integrate
@@ -262,7 +264,8 @@ contains
       libm, lles, lrandomize, nprocx, nprocy
     namelist /DOMAIN/ itot, jtot, ktot, xlen, ylen
     namelist /PHYSICS/ lmoist, lcoriol, lbuoyancy, ltempeq, lprofforc, dpdx, luvolflowr, uflowrate, &
-      lvvolflowr, vflowrate, igrw_damp, geodamptime, lnudge, lnudgevel, tnudge, nnudge
+      lvvolflowr, vflowrate, igrw_damp, geodamptime, lnudge, lnudgevel, tnudge, nnudge, ifixuinf, lvinf, tscale
+    namelist /INLET/ Uinf, Vinf, inletav
     namelist /DYNAMICS/ ipoiss, iadv_mom, iadv_tke, iadv_thl, iadv_qt, iadv_sv
     namelist /BC/ BCxm, BCym, BCtopm, BCtopT, BCtops, BCbotm, BCbots, BCbotT, BCzp, wttop, thl_top, z0, wtsurf, thls, qts, &
       BCtopq, BCbotq, wqtop, qt_top, wqsurf, ps, z0h
@@ -279,6 +282,7 @@ contains
     read (ifnamopt, DYNAMICS, iostat=ierr); call chk(ierr, 'DYNAMICS'); rewind (ifnamopt)
     read (ifnamopt, BC, iostat=ierr); call chk(ierr, 'BC'); rewind (ifnamopt)
     read (ifnamopt, SCALARS, iostat=ierr); call chk(ierr, 'SCALARS'); rewind (ifnamopt)
+    read (ifnamopt, INLET, iostat=ierr); call chk(ierr, 'INLET'); rewind (ifnamopt)     ! (absent group: iostat < 0)
     read (ifnamopt, WALLS, iostat=ierr); call chk(ierr, 'WALLS')
     close (ifnamopt)
     nprocx = 1; nprocy = nprocs     ! y-slabs over however many ranks were launched (1 in the np1 build)
@@ -508,6 +512,7 @@ contains
       call put3(tag//'.thl0', thl0, (/ib - ih, jb - jh, kb - kh/))
       call put3(tag//'.thlm', thlm, (/ib - ih, jb - jh, kb - kh/))
     end if
+    if (ifixuinf == 2) call put1(tag//'.dpdxl', dpdxl(kb:ke), kb)
     if (lmoist) then
       call put3(tag//'.qt0', qt0, (/ib - ih, jb - jh, kb - kh/))
       call put3(tag//'.qtm', qtm, (/ib - ih, jb - jh, kb - kh/))
@@ -579,6 +584,10 @@ contains
     if (lscasrc .or. lscasrcl) then
       call dump_tend('src0')                ! tendencies the scalar sources start from
       call scalsource
+    end if
+    if (ifixuinf == 1) then                 ! (applies at rk3step = 3 only: choose nspin = 2 mod 3)
+      call dump_tend('fix0')
+      call fixuinf1
     end if
     call dump_tend('pre')
     call poisson                            ! src/modpois.f90:419

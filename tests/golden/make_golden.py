@@ -29,7 +29,7 @@ REF = os.path.join(ROOT, "oracle", "_ref", "udales_ref")
 
 
 def deck(iexpnr, nx, ny, nz, dx=0.5, dy=0.5, dtmax=0.25, sgs="vreman", nsv=0, bctopm=1,
-         oracle="", lles=True, randu=0.01, floor=False, z0=0.05, physics="", bc="", bcbotm=3, scalars="", dynamics=""):
+         oracle="", lles=True, randu=0.01, floor=False, z0=0.05, physics="", bc="", bcbotm=3, scalars="", dynamics="", inlet=""):
     sub = {"oneeqn": "loneeqn = .true.\nlvreman = .false.\nlsmagorinsky = .false.",
            "vreman": "lvreman = .true.\nlsmagorinsky = .false.",
            "smag": "lsmagorinsky = .true.\nlvreman = .false.",
@@ -70,7 +70,7 @@ nsv = {nsv}{(chr(10) + scalars) if scalars else ''}
 /
 &NAMSUBGRID
 {sub}
-/
+/{(chr(10) + '&INLET' + chr(10) + inlet + chr(10) + '/') if inlet else ''}
 &ORACLE
 {oracle}
 /
@@ -119,7 +119,7 @@ KEEP_KERNELS = ("meta dzf dzh zf dpdxl dpdyl rk3 in.u0 in.v0 in.w0 in.um in.vm i
                 "in.qt0 in.qtm adv.qtp sub.qtp sub.qt0 bot.qtp pre.qtp out.qt0 out.qtm "
                 "in.e120 in.e12m adv.e12p sub.e12p pre.e12p out.e120 out.e12m "
                 "frc0.up frc0.vp frc0.wp frc0.thlp lsf.up lsf.vp lsf.wp lsf.thlp u0av thl0av frc0.qtp lsf.qtp qt0av "
-                "src0.up "
+                "src0.up fix0.up fix0.vp "
                 "pre.up pre.vp pre.wp poi.p poi.pres0 poi.up poi.vp poi.wp out.u0 out.v0 out.w0 "
                 "out.um out.pres0").split()
 
@@ -259,7 +259,16 @@ CASES.update({
                                bc="BCtopT = 2\nthl_top = 290.5\nBCbotT = 1\nwtsurf = 0.03\nthls = 288.0\nqts = 0.0",
                                oracle="nsub = 6\ndump_at = 3, 6"), 1.06),
 })
-LSF_ONLY = ("k_lsfq_12x8x20",)
+CASES.update({
+    # fixuinf1 / fixuinf2: the top-level mean velocity pulled back to Uinf, directly or through the dp/dx ODE
+    "k_fix1_12x8x6": ("kernels", 43, 12, 8, 6,
+                      dict(sgs="vreman", floor=True, physics="ifixuinf = 1\nlvinf = .true.", inlet="Uinf = 1.1\nVinf = 0.02",
+                           oracle="nspin = 5"), 1.04),
+    "run_fix2_16x8x12s": ("run", 44, 16, 8, 12,
+                          dict(sgs="smag", floor=True, physics="ifixuinf = 2\ntscale = 3.0", inlet="Uinf = 1.15\ninletav = 2.0",
+                               oracle="nsub = 9\ndump_at = 3, 6, 9"), 1.06),
+})
+LSF_ONLY = ("k_lsfq_12x8x20", "k_fix1_12x8x6")
 THL_CASES = {"k_thlk_12x8x6": dict(dthl=0.3), "run_thlk_16x8x12s": dict(dthl=0.25),
              "k_src_12x8x8": dict(psrc=[[(2.2, 1.3, 0.9, 0.5, 0.6), (4.9, 3.1, 2.2, 0.2, 0.4)], [(1.0, 2.0, 1.5, 1.0, 0.5), (5.5, 0.4, 0.3, 0.3, 0.7)]],
                                   lsrc=[[(0.5, 0.5, 0.6, 5.0, 3.5, 1.4, 0.4, 0.5)], [(3.0, 0.2, 2.0, 3.0, 3.8, 2.0, 0.6, 0.45)]]),
@@ -334,12 +343,12 @@ def main():
             keep = {k: v for k, v in d.items()
                     if k in KEEP_KERNELS or ".sv" in k}
             if name in LSF_ONLY:      # only what tests/test_level_forcings.py reads
-                keep = {k: v for k, v in keep.items() if k.count(".") == 0 or k.startswith(("frc0.", "lsf."))
+                keep = {k: v for k, v in keep.items() if k.count(".") == 0 or k.startswith(("frc0.", "lsf.") if "lsf" in name else ("fix0.", "pre.u", "pre.v"))
                         or k in ("in.v0", "in.w0", "in.um", "in.vm", "in.wm", "in.pres0", "sub.u0", "sub.thl0", "in.thlm",
                                  "sub.qt0", "in.qtm", "in.sv0_01")}
         else:
             keep = {k: v for k, v in d.items()
-                    if k.count(".") == 0 or k.split(".")[1] in ("u0", "v0", "w0", "pres0", "um", "thl0", "thlm", "e120", "e12m", "qt0", "qtm")
+                    if k.count(".") == 0 or k.split(".")[1] in ("u0", "v0", "w0", "pres0", "um", "thl0", "thlm", "e120", "e12m", "qt0", "qtm", "dpdxl")
                     or (k.startswith("s000.") and not k.startswith("s000.ek")) or ".sv0" in k}
             # (s000.ekm/ekh are dumped before the first closure call: uninitialised memory, not data)
         tmpf = os.path.join(HERE, name + ".bin")

@@ -148,3 +148,59 @@ def test_run_with_level_forcings_matches_reference(fused):
                 sc = 1.0 if k == "thl0" else None
                 assert relerr(nocorner(core.download(k)[1:-1]), nocorner(ref[1:-1]), sc) <= 1e-9, (isub, k)
     core.close()
+
+
+def test_fixuinf1_table_matches_reference_routine():
+    """ifixuinf = 1 (fixuinf1, src/modforces.f90:220-288): on RK stage 3 the top-level mean is pulled back to Uinf / Vinf."""
+    name, iexp = "k_fix1_12x8x6", 43
+    fix = load_fixture(name)
+    d = read_deck(deck_path(name, iexp))
+    g = Grid.from_deck(d)
+    nz = g.nz
+    ls = LevelForcings(_FakeCore(g), d)
+    assert ls.active and ls.ifixuinf == 1 and ls.lvinf and ls.Uinf == 1.1 and ls.Vinf == 0.02
+    rk3step, dt = int(fix["rk3"].data[0]), float(fix["rk3"].data[1])
+    assert rk3step == 3
+    av = {"u0": _avg(marr(fix, "sub.u0", nz), nz), "v0": _avg(marr(fix, "in.v0", nz), nz)}
+    tabs = ls.tables(av, rk3step, dt)
+    assert set(tabs) == {("up", 1), ("vp", 1)}
+    for tend in ("up", "vp"):
+        src, A, B = tabs[(tend, 1)]
+        assert src is None and not B.any()
+        t = marr(fix, "fix0." + tend, nz).copy()
+        for k in range(1, nz + 1):
+            t[k] = t[k] + A[k]
+        ref = marr(fix, "pre." + tend, nz)
+        sc = np.abs(ref - marr(fix, "fix0." + tend, nz)).max()
+        assert sc > 1e-7 and np.abs(interior(t) - interior(ref)).max() <= 1e-9 * sc, tend      # (earlier stage-3 substeps already pulled the mean close to Uinf)
+    # other RK stages: the same keys, zero tables (so that a stage-3 table never lingers on the device)
+    off = ls.tables(av, 1, dt)
+    assert set(off) == {("up", 1), ("vp", 1)} and not off[("up", 1)][1].any()
+
+
+@pytest.mark.gpu
+def test_run_with_fixuinf2_matches_reference():
+    """ifixuinf = 2: dp/dx follows the ODE d(dpdx)/dt = (freestreamav - Uinf)/tscale (fixuinf2 + tstep_integrate)."""
+    import udcore
+    from udcore import cold_start
+    name, iexp = "run_fix2_16x8x12s", 44
+    fix = load_fixture(name)
+    d = read_deck(deck_path(name, iexp))
+    core = udcore.from_deck(d)
+    core.load_state(cold_start(core.g, d))
+    ls = LevelForcings(core, d)
+    assert ls.active and ls.ifixuinf == 2
+    dt = float(d.get("RUN", "dtmax"))
+    nz = core.g.nz
+    for isub in range(1, 10):
+        rk = (isub - 1) % 3 + 1
+        ls.update(rk, dt)
+        core.substep(rk, dt, with_forces=True)
+        if isub in (3, 6, 9):
+            tag = f"s{isub:03d}"
+            np.testing.assert_allclose(core.dpdxl + ls._pending, fix[tag + ".dpdxl"].data[:nz], rtol=1e-11, atol=0)
+            for k in ("u0", "v0", "w0", "pres0"):
+                ref = marr(fix, f"{tag}.{k}", nz)
+                assert relerr(nocorner(core.download(k)[1:-1]), nocorner(ref[1:-1])) <= 1e-9, (isub, k)
+    assert abs(core.dpdxl[0] + ls._pending) > 0.3          # the ODE moved dp/dx a long way from its start value
+    core.close()

@@ -37,17 +37,21 @@ contains
 
   subroutine tstep_integrate
     use modglobal, only: rk3step, dt, timee, ifixuinf, lchem, ltempeq, lmoist, iinletgen, idriver, ib, ie, jb, je, kb, ke
-    use modfields, only: up, vp, wp, svp, thlp, qtp, e12p, thl0, thl0c
+    use modfields, only: up, vp, wp, svp, thlp, qtp, e12p, thl0, thl0c, dpdxl, dpdyl, dgdt
     use modsubgriddata, only: loneeqn
     use modmpi, only: myid, cmyid
     use udc_iface
     implicit none
 
-    if (lchem .or. ifixuinf == 2) then
+    if (lchem) then
       write (0, *) 'ERROR: libudcore tstep_integrate: option not on the device path'
       stop 1
     end if
     call udc_ensure
+    if (ifixuinf == 2) then      ! src/modtstep.f90:194-195: the dp/dx ODE (dgdt from the host's fixuinf2)
+      dpdxl(:) = dpdxl(:) + dgdt*(dt/(4. - real(rk3step)))
+      call udc_check(udc_set_forcing(udc_h, dpdxl(kb:ke), dpdyl(kb:ke), int(ke - kb + 1, c_int)), 'udc_set_forcing')
+    end if
     select case (udc_residency)
     case (0)
       call udc_push_state

@@ -20,7 +20,8 @@ def from_deck(deck, device=0, rank=0, nranks=1):
         raise ValueError("lbottom with BCbotm = 2 (wfuno) needs ltempeq on the device path; use BCbotm = 3 for a neutral floor")
     core = DynCore(g, sgs=sgs, bctopm=int(deck.get("BC", "BCtopm")), nsv=int(deck.get("SCALARS", "nsv")),
                    prandtli=prandtli, c_vreman=c_vreman, csz=csz, device=device, rank=rank, nranks=nranks,
-                   lbottom=lbottom, z0=float(deck.get("BC", "z0")))
+                   lbottom=lbottom, z0=float(deck.get("BC", "z0")),
+                   uinf=float(deck.get("INLET", "Uinf")), vinf=float(deck.get("INLET", "Vinf")))
     core.set_masscorr(bool(deck.get("PHYSICS", "luvolflowr")), float(deck.get("PHYSICS", "uflowrate")),
                       bool(deck.get("PHYSICS", "lvvolflowr")), float(deck.get("PHYSICS", "vflowrate")))
     if deck.get("PHYSICS", "ltempeq"):

@@ -97,6 +97,7 @@ class DynCore:
     def set_forcing(self, dpdxl, dpdyl):
         a = np.ascontiguousarray(dpdxl, dtype=np.float64)
         b = np.ascontiguousarray(dpdyl, dtype=np.float64)
+        self.dpdxl, self.dpdyl = a.copy(), b.copy()          # host copies (the dp/dx ODE of ifixuinf = 2 advances them)
         L._check(self.lib.udc_set_forcing(self.h, a.ctypes.data_as(L.DP), b.ctypes.data_as(L.DP), len(a)),
                  "udc_set_forcing")
 

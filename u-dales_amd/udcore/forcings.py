@@ -66,11 +66,18 @@ class LevelForcings:
         for k in range(self.ksp, nz + 1):
             tsc[k] = 2.75e-3 * math.sin(0.5 * pi * (g.zf[k] - zspb) / (zspt - zspb)) ** 2
         self.tsc = tsc
-        self.active = self.subsidence or self.lnudge or self.igrw != 0 or self.qtls
+        # fixuinf1 / fixuinf2 (src/modforces.f90:174-288; &PHYSICS ifixuinf, lvinf, tscale; &INLET Uinf, Vinf, inletav)
+        self.ifixuinf = int(ph("ifixuinf"))
+        self.lvinf = bool(ph("lvinf"))
+        self.tscale = float(ph("tscale"))
+        self.Uinf, self.Vinf, self.inletav = (float(deck.get("INLET", n)) for n in ("Uinf", "Vinf", "inletav"))
+        self.freestreamav, self.dgdt, self._pending = 0., 0., 0.      # src/modglobal.f90:261, src/modfields.f90:396
+        self.active = self.subsidence or self.lnudge or self.igrw != 0 or self.qtls or self.ifixuinf in (1, 2)
 
-    def tables(self, av):
+    def tables(self, av, rk3step=None, dt=None):
         """av: dict of slab averages indexed by the reference's k (entries 1..nz+1).  Returns {(tend, when): [src, A, B]}
-        with A, B indexed 1..nz; when = 0 for lstend and nudge (before masscorr), 1 for the sponge (after it)."""
+        with A, B indexed 1..nz; when = 0 for lstend and nudge (before masscorr), 1 for fixuinf1 and the sponge (after
+        it).  rk3step, dt: the substep about to run (fixuinf1 acts on RK stage 3 only)."""
         nz, dzh, whls = self.nz, self.core.g.dzh, self.whls
         out = {}
 
@@ -119,6 +126,17 @@ class LevelForcings:
                 A = acc(f"svp_{n}")[1]
                 for k in range(k0, nz + 1):
                     A[k] -= (av[f"sv0_{n}"][k] - self.svprof[n][k]) / self.tnudge
+        if self.ifixuinf == 1:                                   # fixuinf1, src/modforces.f90:220-288
+            if rk3step is None or dt is None:
+                raise ValueError("ifixuinf = 1: LevelForcings.update needs the substep's rk3step and dt")
+            on = 1. if rk3step == 3 else 0.
+            A = acc("up", None, 1)[1]
+            for k in range(1, nz + 1):
+                A[k] -= on * (1. / dt) * (av["u0"][nz] - self.Uinf)
+            if self.lvinf:
+                A = acc("vp", None, 1)[1]
+                for k in range(1, nz + 1):
+                    A[k] -= on * (1. / dt) * (av["v0"][nz] - self.Vinf)
         if self.igrw in (1, 2, 3):                               # grwdamp
             tsc = self.tsc
             for name, tend, geo in (("u0", "up", self.ug), ("v0", "vp", self.vg)):
@@ -146,11 +164,24 @@ class LevelForcings:
         names = ["u0", "v0"] + (["thl0"] if self.ltempeq else []) + (["qt0"] if self.lmoist else []) + [f"sv0_{n}" for n in range(self.core.nsv)]
         return {n: self.core.slab_average(n) for n in names}
 
-    def update(self):
-        """Take the slab averages of the current state and register the tables for the next substep."""
+    def update(self, rk3step=None, dt=None):
+        """Take the slab averages of the current state and register the tables for the next substep (rk3step, dt: that
+        substep's; needed by ifixuinf only)."""
         if not self.active:
             return {}
-        tabs = self.tables(self.averages())
+        av = self.averages()
+        if self.ifixuinf == 2:                                   # fixuinf2 (:174-218) + src/modtstep.f90:194-195
+            if rk3step is None or dt is None:
+                raise ValueError("ifixuinf = 2: LevelForcings.update needs the substep's rk3step and dt")
+            core = self.core
+            if self._pending != 0.:                              # dpdxl += dgdt rk3coef of the substep that just ran
+                core.set_forcing(core.dpdxl + self._pending, core.dpdyl)
+            if rk3step == 3:
+                freestream = av["v0" if self.lvinf else "u0"][self.nz]
+                self.freestreamav = freestream * dt / self.inletav + (1. - dt / self.inletav) * self.freestreamav
+                self.dgdt = (1. / self.tscale) * (self.freestreamav - self.Uinf)
+            self._pending = self.dgdt * (dt / (4. - rk3step))
+        tabs = self.tables(av, rk3step, dt)
         for (tend, when), (src, A, B) in tabs.items():
             self.core.set_level_forcing(tend, src, A[1:self.nz + 1], B[1:self.nz + 1], when)
         return tabs

@@ -107,7 +107,7 @@ def main(argv=None):
     while core.timee < t_end - 1e-12 and (args.steps <= 0 or nsteps < args.steps):
         for _ in range(3):                                     # one full RK3 step
             rk, dt = core.tstep_update(dtmax, ladaptive, courant, diffnr)
-            forcings.update()
+            forcings.update(rk, dt)
             core.substep(rk, dt, with_forces=True)
         nsteps += 1
         ntrun += 1
