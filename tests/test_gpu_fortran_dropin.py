@@ -62,3 +62,16 @@ def test_fortran_kernel_sequence(tmp_path):
             assert relerr(nocorner(a), nocorner(b)) <= 1e-10, key
         else:
             assert relerr(a[:-1, 1:-1, 1:-1], b[:-1, 1:-1, 1:-1]) <= 1e-10, key
+
+
+@pytest.mark.parametrize("residency", [0, 1])
+def test_fortran_driver_fixuinf2(residency, tmp_path):
+    """ifixuinf = 2 through the drop-in modtstep: the host's fixuinf2 sets dgdt, tstep_integrate advances dp/dx."""
+    name, iexp = "run_fix2_16x8x12s", 44
+    fix = load_fixture(name)
+    got = run_dropin(name, iexp, "run", tmp_path, residency)
+    for tag in ("s003", "s009"):
+        np.testing.assert_allclose(got[tag + ".dpdxl"].data, fix[tag + ".dpdxl"].data, rtol=1e-10, atol=0)
+        for k in ("u0", "v0", "w0", "pres0"):
+            a, b = got[f"{tag}.{k}"].data[1:-1], fix[f"{tag}.{k}"].data[1:-1]
+            assert relerr(nocorner(a), nocorner(b)) <= 1e-9, (tag, k)
