@@ -136,7 +136,8 @@ int udc_set_floor_wf(udc_handle *h, int bcbotm, int bcbott, double thls, double 
 int udc_set_moisture(udc_handle *h, int iadv_qt, int bctopq, double wqtop, double qt_top, int bcbotq, double wqsurf);
 /* Moist thermodynamics (src/modthermodynamics.f90:57-124, lmoist): thls, qts, ps of &BC / modsurfdata
  * (src/modsurfdata.f90:41,58,64) and the level heights zf(kb:ke+kh), zh(kb:ke+kh) ([n = ktot+1] each,
- * src/modglobal.f90:747-751).  udc_thermodynamics is the reference's `thermodynamics`: thermo (condensate, all-or-nothing,
+ * src/modglobal.f90:747-751); lqlnr (&DYNAMICS, src/modthermodynamics.f90:37) picks `thermo`'s Newton-Raphson branch
+ * (:448-473) instead of the one-step formula (:476-500).  udc_thermodynamics is the reference's `thermodynamics`: thermo (condensate, all-or-nothing,
  * Tetens), diagfld (slab averages, hydrostatic pressures by fromztop, exner functions), calc_halflev, thermo on the
  * half levels and calthv's thv0h with its slab average thvh -- what forces' buoyancy term then uses
  * (wp += grav (thv0h - thvh)/thvh, src/modforces.f90:73-84).  Call it once before the first substep
@@ -144,7 +145,7 @@ int udc_set_moisture(udc_handle *h, int iadv_qt, int bctopq, double wqtop, doubl
  * udc_boundary.  The reference's off-by-one-level ql0 slab average is reproduced.
  * udc_thermo_state reads (set = 0) or writes (set = 1) what one call leaves for the next: nine tables of [n = ktot+1]
  * (k = kb..ke+kh) in the order presf, presh, exnf, exnh, thvh, thl0av, qt0av, ql0av, th0av. */
-int udc_set_moist_thermo(udc_handle *h, double thls, double qts, double ps, const double *zf, const double *zh, int n);
+int udc_set_moist_thermo(udc_handle *h, double thls, double qts, double ps, const double *zf, const double *zh, int n, int lqlnr);
 int udc_thermodynamics(udc_handle *h);
 int udc_thermo_state(udc_handle *h, double *tables, int n, int set);
 int udc_set_buoyancy(udc_handle *h, int lbuoyancy, double grav);

@@ -37,7 +37,7 @@ program ref_driver
   use modsurfdata, only: thl_top, wttop, wsvtop, sv_top, thvs, thls, z0, z0h, wtsurf, qts, wqtop, qt_top, wqsurf, ps
   use modwallfunctions, only: wfmneutral, wfuno
   use modboundary, only: initboundary, boundary, halos, grwdamp
-  use modthermodynamics, only: initthermodynamics, thermodynamics
+  use modthermodynamics, only: initthermodynamics, thermodynamics, lqlnr
   use modsubgrid, only: initsubgrid, subgrid
   use modpois, only: initpois, poisson, p
   use modadvection, only: advection
@@ -266,7 +266,7 @@ contains
     namelist /PHYSICS/ lmoist, lcoriol, lbuoyancy, ltempeq, lprofforc, dpdx, luvolflowr, uflowrate, &
       lvvolflowr, vflowrate, igrw_damp, geodamptime, lnudge, lnudgevel, tnudge, nnudge, ifixuinf, lvinf, tscale
     namelist /INLET/ Uinf, Vinf, inletav
-    namelist /DYNAMICS/ ipoiss, iadv_mom, iadv_tke, iadv_thl, iadv_qt, iadv_sv
+    namelist /DYNAMICS/ lqlnr, ipoiss, iadv_mom, iadv_tke, iadv_thl, iadv_qt, iadv_sv
     namelist /BC/ BCxm, BCym, BCtopm, BCtopT, BCtops, BCbotm, BCbots, BCbotT, BCzp, wttop, thl_top, z0, wtsurf, thls, qts, &
       BCtopq, BCbotq, wqtop, qt_top, wqsurf, ps, z0h
     namelist /SCALARS/ nsv, lscasrc, nscasrc, lscasrcl, nscasrcl

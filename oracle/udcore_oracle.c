@@ -1160,6 +1160,18 @@ void orc_coriolis(const orc_grid *g, const double *u0, const double *v0, const d
 /* ---- moist thermodynamics, src/modthermodynamics.f90 ------------------------------------------------------------ */
 static const double TH_RD = 287.04, TH_RV = 461.5, TH_CP = 1004., TH_RLV = 2.26e6, TH_GRAV = 9.81, TH_PREF0 = 1.e5,
                     TH_TMELT = 273.16, TH_ES0 = 610.78, TH_AT = 17.27, TH_BT = 35.86;   /* src/modglobal.f90:271-313 */
+/* thermo with lqlnr (:448-473): Newton-Raphson on the temperature, first guess tl */
+static double th_ql_nr(double thl, double qt, double pressure, double exner) {
+  const double tl = thl * exner;
+  double Tnr = tl, Tnr_old = 0., qsatur = 0.;
+  while (fabs(Tnr - Tnr_old) / Tnr > 1e-5) {
+    Tnr_old = Tnr;
+    const double es = TH_ES0 * exp(TH_AT * (Tnr - TH_TMELT) / (Tnr - TH_BT));
+    qsatur = TH_RD / TH_RV * es / (pressure - (1 - TH_RD / TH_RV) * es);
+    Tnr = Tnr - (Tnr + (TH_RLV / TH_CP) * qsatur - tl - (TH_RLV / TH_CP) * qt) / (1 + (TH_RLV * TH_RLV * qsatur) / (TH_RV * TH_CP * (Tnr * Tnr)));
+  }
+  return qt - qsatur > 0. ? qt - qsatur : 0.;
+}
 /* thermo (:430-503, lqlnr false): "all-or-nothing" condensate of one point */
 static double th_ql(double thl, double qt, double pressure, double exner) {
   double tl = thl * exner;
@@ -1233,7 +1245,7 @@ static double th_thv0h(const orc_grid *g, const orc_state *s, int i, int j, int 
   double qt0h = (M(s->qt0, i, j, k) * dzf[k - 1] + M(s->qt0, i, j, k - 1) * dzf[k]) / (2 * dzh[k]);
   if (k == 1) { thl0h = g->thls; qt0h = g->qts; }
   const double exnh = s->thermo[(size_t)ORC_TH_EXNH * (g->nz + 2) + k];
-  const double ql0h = th_ql(thl0h, qt0h, s->thermo[(size_t)ORC_TH_PRESH * (g->nz + 2) + k], exnh);
+  const double ql0h = (g->lqlnr ? th_ql_nr : th_ql)(thl0h, qt0h, s->thermo[(size_t)ORC_TH_PRESH * (g->nz + 2) + k], exnh);
   return (thl0h + TH_RLV * ql0h / (TH_CP * exnh)) * (1 + (TH_RV / TH_RD - 1) * qt0h - TH_RV / TH_RD * ql0h);
 }
 void orc_thermodynamics(const orc_grid *g, orc_state *s) {
@@ -1246,7 +1258,7 @@ void orc_thermodynamics(const orc_grid *g, orc_state *s) {
    * the reference's ql0 -- and with it ql0av in diagfld -- is one level low, and ql0(ke+kh) is never written.  Kept. */
   for (int k = 1; k <= ke1; ++k)
     for (int j = 1; j <= g->ny; ++j)
-      for (int i = 1; i <= g->nx; ++i) M(s->ql0, i, j, k - 1) = th_ql(M(s->thl0, i, j, k), M(s->qt0, i, j, k), presf[k], exnf[k]);
+      for (int i = 1; i <= g->nx; ++i) M(s->ql0, i, j, k - 1) = (g->lqlnr ? th_ql_nr : th_ql)(M(s->thl0, i, j, k), M(s->qt0, i, j, k), presf[k], exnf[k]);
   th_diagfld(g, s);                                                                   /* :69 */
   double *thvh = TH(ORC_TH_THVH);
   const double cnt = (double)g->nx * (double)g->ny;

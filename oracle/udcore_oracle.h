@@ -64,6 +64,7 @@ typedef struct {
    * roughness length for heat z0h (src/modsurfdata.f90:73), prandtlturb (src/modglobal.f90:304) */
   int bcbotm, bcbott;
   double z0h, prandtlturb;
+  int lqlnr;                /* condensate by Newton-Raphson on T instead of the one-step formula (src/modthermodynamics.f90:37,448-473) */
   int iadv_thl;             /* 2 = cd2 (advecc_2nd), 7 = kappa (advecc_kappa on thl0c), src/modadvection.f90:64-76 */
 } orc_grid;
 

@@ -268,8 +268,17 @@ CASES.update({
                           dict(sgs="smag", floor=True, physics="ifixuinf = 2\ntscale = 3.0", inlet="Uinf = 1.15\ninletav = 2.0",
                                oracle="nsub = 9\ndump_at = 3, 6, 9"), 1.06),
 })
+CASES.update({
+    # the condensate by Newton-Raphson on the temperature (lqlnr) instead of the one-step formula
+    "run_moistnr_16x8x12s": ("run", 45, 16, 8, 12,
+                             dict(sgs="smag", floor=True, physics="lmoist = .true.\nltempeq = .true.\nlbuoyancy = .true.", dynamics="lqlnr = .true.",
+                                  bc="BCtopT = 2\nthl_top = 290.5\nBCbotT = 1\nwtsurf = 0.04\nthls = 288.0\nqts = 0.0105\n"
+                                     "BCtopq = 2\nqt_top = 0.0104\nBCbotq = 1\nwqsurf = 5.e-5",
+                                  oracle="nsub = 6\ndump_at = 3, 6"), 1.06),
+})
 LSF_ONLY = ("k_lsfq_12x8x20", "k_fix1_12x8x6")
-THL_CASES = {"k_thlk_12x8x6": dict(dthl=0.3), "run_thlk_16x8x12s": dict(dthl=0.25),
+THL_CASES = {"run_moistnr_16x8x12s": dict(dthl=0.25, qt=0.0119, dqt=-6e-5),
+             "k_thlk_12x8x6": dict(dthl=0.3), "run_thlk_16x8x12s": dict(dthl=0.25),
              "k_src_12x8x8": dict(psrc=[[(2.2, 1.3, 0.9, 0.5, 0.6), (4.9, 3.1, 2.2, 0.2, 0.4)], [(1.0, 2.0, 1.5, 1.0, 0.5), (5.5, 0.4, 0.3, 0.3, 0.7)]],
                                   lsrc=[[(0.5, 0.5, 0.6, 5.0, 3.5, 1.4, 0.4, 0.5)], [(3.0, 0.2, 2.0, 3.0, 3.8, 2.0, 0.6, 0.45)]]),
              "run_src_16x8x12s": dict(psrc=[[(3.1, 1.9, 1.2, 0.8, 0.7)]],

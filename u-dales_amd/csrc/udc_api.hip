@@ -441,7 +441,7 @@ extern "C" int udc_set_moisture(udc_handle *h, int iadv_qt, int bctopq, double w
   return 0;
 }
 
-extern "C" int udc_set_moist_thermo(udc_handle *h, double thls, double qts, double ps, const double *zf, const double *zh, int n) {
+extern "C" int udc_set_moist_thermo(udc_handle *h, double thls, double qts, double ps, const double *zf, const double *zh, int n, int lqlnr) {
   HIP_OK(hipSetDevice(h->device));
   const int nz = h->g.nz, n2 = nz + 2;
   if (!h->lmoist) { udc_set_error("udc_set_moist_thermo: call udc_set_moisture first"); return 1; }
@@ -453,7 +453,7 @@ extern "C" int udc_set_moist_thermo(udc_handle *h, double thls, double qts, doub
   for (int k = 1; k <= nz + 1; ++k) { t[udc_handle::MT_ZF * n2 + k] = zf[k - 1]; t[udc_handle::MT_ZH * n2 + k] = zh[k - 1]; }
   if (!h->mt) HIP_OK(hipMalloc(&h->mt, sizeof(double) * t.size()));
   HIP_OK(hipMemcpy(h->mt, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
-  h->thls = thls; h->qts = qts; h->ps = ps;
+  h->thls = thls; h->qts = qts; h->ps = ps; h->lqlnr = lqlnr ? 1 : 0;
   h->mt_valid = false;
   return 0;
 }

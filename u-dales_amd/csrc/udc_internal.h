@@ -146,6 +146,7 @@ struct udc_handle {
   double *mt = nullptr;
   bool mt_valid = false;       // diagfld has run at least once
   double thls = 0., qts = 0., ps = 0.;
+  int lqlnr = 0;               // condensate by Newton-Raphson (src/modthermodynamics.f90:37)
   double *thlpcar = nullptr;   // [nz+2] radiative heating profile added by forces (src/modforces.f90:104-110), or null
   // masscorr (src/modforces.f90:328): prescribed volume-flow rates
   int luvolflowr = 0, lvvolflowr = 0;

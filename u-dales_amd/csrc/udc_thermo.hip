@@ -65,11 +65,26 @@ __device__ __forceinline__ double th_ql(double thl, double qt, double pressure, 
   const double qs = qsl * (1. + b1 * qt) / (1. + b1 * qsl);
   return qt - qs > 0. ? qt - qs : 0.;
 }
+// thermo with lqlnr (:448-473): Newton-Raphson on the temperature from the first guess tl
+__device__ __forceinline__ double th_ql_nr(double thl, double qt, double pressure, double exner) {
+  const double tl = thl * exner;
+  double Tnr = tl, Tnr_old = 0., qsatur = 0.;
+  while (fabs(Tnr - Tnr_old) / Tnr > 1e-5) {
+    Tnr_old = Tnr;
+    const double es = TH_ES0 * exp(TH_AT * (Tnr - TH_TMELT) / (Tnr - TH_BT));
+    qsatur = TH_RD / TH_RV * es / (pressure - (1 - TH_RD / TH_RV) * es);
+    Tnr = Tnr - (Tnr + (TH_RLV / TH_CP) * qsatur - tl - (TH_RLV / TH_CP) * qt) / (1 + (TH_RLV * TH_RLV * qsatur) / (TH_RV * TH_CP * (Tnr * Tnr)));
+  }
+  return qt - qsatur > 0. ? qt - qsatur : 0.;
+}
+__device__ __forceinline__ double th_cond(int nr, double thl, double qt, double pressure, double exner) {
+  return nr ? th_ql_nr(thl, qt, pressure, exner) : th_ql(thl, qt, pressure, exner);
+}
 // thv0h of calthv (:142-152) from calc_halflev's thl0h, qt0h (:508-539; kf >= kb+1 here) and thermo on the half level
 __device__ __forceinline__ double thv_half(const Geo &g, const Metrics &m, const double *__restrict__ thl, const double *__restrict__ qt,
-                                           double presh, double exnh, long c, int k) {
+                                           double presh, double exnh, long c, int k, int nr) {
   const double thl0h = thl_half(g, m, thl, c, k), qt0h = thl_half(g, m, qt, c, k);
-  const double ql0h = th_ql(thl0h, qt0h, presh, exnh);
+  const double ql0h = th_cond(nr, thl0h, qt0h, presh, exnh);
   return (thl0h + TH_RLV * ql0h / (TH_CP * exnh)) * (1 + (TH_RV / TH_RD - 1) * qt0h - TH_RV / TH_RD * ql0h);
 }
 // rows of 64 cells one thread of the slab-sum kernels below walks: fewer, fatter workgroups keep more loads in flight
@@ -78,7 +93,7 @@ constexpr int MS_ROWS = 8;
 template <bool QL>
 __global__ __launch_bounds__(256) void moist_sums_kernel(Geo g, int gx, const double *__restrict__ thl, const double *__restrict__ qt,
                                                           const double *__restrict__ presf, const double *__restrict__ exnf,
-                                                          double *__restrict__ part) {
+                                                          double *__restrict__ part, int nr) {
   __shared__ double sw[3][4];
   const int tile = blockIdx.x, k = blockIdx.y, kf = k + 1;
   const int by = tile / gx, bx = tile - by * gx;
@@ -92,7 +107,7 @@ __global__ __launch_bounds__(256) void moist_sums_kernel(Geo g, int gx, const do
       const long c = g.idx(i, j, k);
       const double a = thl[c], b = qt[c];
       v[0] += a; v[1] += b;
-      if (QL) v[2] += th_ql(a, b, pf, ef);
+      if (QL) v[2] += th_cond(nr, a, b, pf, ef);
     }
   }
 #pragma unroll
@@ -108,7 +123,7 @@ __global__ __launch_bounds__(256) void moist_sums_kernel(Geo g, int gx, const do
 }
 __global__ __launch_bounds__(256) void thv_sums_kernel(Geo g, Metrics m, int gx, const double *__restrict__ thl, const double *__restrict__ qt,
                                                         const double *__restrict__ presh, const double *__restrict__ exnh,
-                                                        double *__restrict__ part) {
+                                                        double *__restrict__ part, int nr) {
   __shared__ double sw[4];
   const int tile = blockIdx.x, k = blockIdx.y;
   const int by = tile / gx, bx = tile - by * gx;
@@ -119,7 +134,7 @@ __global__ __launch_bounds__(256) void thv_sums_kernel(Geo g, Metrics m, int gx,
 #pragma unroll
     for (int r = 0; r < MS_ROWS; ++r) {
       const int j = (by * MS_ROWS + r) * 4 + threadIdx.y;
-      if (i < g.nx && j < g.ny) v += thv_half(g, m, thl, qt, ph, eh, g.idx(i, j, k), k);
+      if (i < g.nx && j < g.ny) v += thv_half(g, m, thl, qt, ph, eh, g.idx(i, j, k), k, nr);
     }
   }
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -134,12 +149,12 @@ __global__ void divide_kernel(double *a, int n, double d) {
 __global__ __launch_bounds__(256) void buoyancy_moist_kernel(Geo g, TileGrid tg, Metrics m, const double *__restrict__ thl,
                                                               const double *__restrict__ qt, const double *__restrict__ presh,
                                                               const double *__restrict__ exnh, const double *__restrict__ thvh_tab,
-                                                              double grav, double *__restrict__ wp) {
+                                                              double grav, double *__restrict__ wp, int nr) {
   int i, j, k;
   if (!tile_decode(g, tg, i, j, k) || k < 1) return;
   const long c = g.idx(i, j, k);
   const double thvh = thvh_tab[k + 1];
-  wp[c] = wp[c] + grav * (thv_half(g, m, thl, qt, presh[k + 1], exnh[k + 1], c, k) - thvh) / thvh;
+  wp[c] = wp[c] + grav * (thv_half(g, m, thl, qt, presh[k + 1], exnh[k + 1], c, k, nr) - thvh) / thvh;
 }
 
 // diagfld (:241-350) after the slab sums, one workgroup.  mt: the handle's tables ([n2 = nz+2] each, index = reference k);
@@ -308,8 +323,8 @@ int k_thermodynamics(udc_handle *h) {
   for (int pass = h->mt_valid ? 1 : 0; pass < 2; ++pass) {
     const dim3 gr((unsigned)mtiles, (unsigned)ke1), b(64, 4);
     if (pass) hipLaunchKernelGGL(moist_sums_kernel<true>, gr, b, 0, h->stream, g, tg.gx, thl, qt, (const double *)(mt + udc_handle::MT_PRESF * n2),
-                                 (const double *)(mt + udc_handle::MT_EXNF * n2), h->lev_part);
-    else hipLaunchKernelGGL(moist_sums_kernel<false>, gr, b, 0, h->stream, g, tg.gx, thl, qt, (const double *)nullptr, (const double *)nullptr, h->lev_part);
+                                 (const double *)(mt + udc_handle::MT_EXNF * n2), h->lev_part, h->lqlnr);
+    else hipLaunchKernelGGL(moist_sums_kernel<false>, gr, b, 0, h->stream, g, tg.gx, thl, qt, (const double *)nullptr, (const double *)nullptr, h->lev_part, 0);
     hipLaunchKernelGGL(levelsum_final_kernel, dim3((unsigned)(3 * ke1)), dim3(256), 0, h->stream, mtiles, h->lev_part, sums);
     HIP_OK(hipGetLastError());
     if (comm_allreduce(h, sums, 3 * ke1, 1)) return 1;       // avexy_ibm's MPI_ALLREDUCE over the slabs
@@ -319,7 +334,7 @@ int k_thermodynamics(udc_handle *h) {
   }
   double *thvh = mt + udc_handle::MT_THVH * n2;
   hipLaunchKernelGGL(thv_sums_kernel, dim3((unsigned)mtiles, (unsigned)g.nz), dim3(64, 4), 0, h->stream, g, h->m, tg.gx, thl, qt,
-                     (const double *)(mt + udc_handle::MT_PRESH * n2), (const double *)(mt + udc_handle::MT_EXNH * n2), h->lev_part);
+                     (const double *)(mt + udc_handle::MT_PRESH * n2), (const double *)(mt + udc_handle::MT_EXNH * n2), h->lev_part, h->lqlnr);
   hipLaunchKernelGGL(levelsum_final_kernel, dim3((unsigned)g.nz), dim3(256), 0, h->stream, mtiles, h->lev_part, thvh + 1);
   HIP_OK(hipGetLastError());
   if (comm_allreduce(h, thvh + 1, g.nz, 1)) return 1;
@@ -340,7 +355,7 @@ static int k_buoyancy_moist(udc_handle *h) {
   hipLaunchKernelGGL(buoyancy_moist_kernel, gr, b, 0, h->stream, g, tile_grid(g), h->m, (const double *)h->fields[UDC_THL0],
                      (const double *)h->fields[UDC_QT0], (const double *)(h->mt + udc_handle::MT_PRESH * n2),
                      (const double *)(h->mt + udc_handle::MT_EXNH * n2), (const double *)(h->mt + udc_handle::MT_THVH * n2), h->grav,
-                     h->fields[UDC_WP]);
+                     h->fields[UDC_WP], h->lqlnr);
   HIP_OK(hipGetLastError());
   return 0;
 }

@@ -117,12 +117,12 @@ module udc_iface
       integer(c_int), value :: iadv_qt, bctopq, bcbotq
       real(c_double), value :: wqtop, qt_top, wqsurf
     end function udc_set_moisture
-    integer(c_int) function udc_set_moist_thermo(h, thls, qts, ps, zf, zh, n) bind(C, name='udc_set_moist_thermo')
+    integer(c_int) function udc_set_moist_thermo(h, thls, qts, ps, zf, zh, n, lqlnr) bind(C, name='udc_set_moist_thermo')
       import :: c_ptr, c_int, c_double
       type(c_ptr), value :: h
       real(c_double), value :: thls, qts, ps
       real(c_double), intent(in) :: zf(*), zh(*)
-      integer(c_int), value :: n
+      integer(c_int), value :: n, lqlnr
     end function udc_set_moist_thermo
     integer(c_int) function udc_thermodynamics(h) bind(C, name='udc_thermodynamics')
       import :: c_ptr, c_int
@@ -232,6 +232,7 @@ contains
                          BCtopm, Uinf, Vinf, lles, ltempeq, lbuoyancy, lmoist, iadv_thl, BCtopT, BCbotT, grav, e12min, &
                          iadv_qt, BCtopq, BCbotq, zf, zh, BCbotm, prandtlturb
     use modsurfdata, only: wttop, thl_top, wtsurf, thvs, wqtop, qt_top, wqsurf, thls, qts, ps, z0h
+    use modthermodynamics, only: lqlnr
     use modsubgriddata, only: lsmagorinsky, lvreman, loneeqn, ldelta, prandtli, c_vreman, csz, cm, cn, ch1, ch2, ce1, ce2
     use modfields, only: dpdxl, dpdyl, thlpcar
     use modmpi, only: myid, nprocs, nprocx, comm3d, mpierr
@@ -295,7 +296,8 @@ contains
                                       real(qt_top, c_double), int(BCbotq, c_int), real(wqsurf, c_double)), 'udc_set_moisture')
       if (ltempeq .and. lbuoyancy) then
         call udc_check(udc_set_moist_thermo(udc_h, real(thls, c_double), real(qts, c_double), real(ps, c_double), &
-                                            zf(kb:ke + kh), zh(kb:ke + kh), int(ktot + 1, c_int)), 'udc_set_moist_thermo')
+                                            zf(kb:ke + kh), zh(kb:ke + kh), int(ktot + 1, c_int), &
+                                            merge(1_c_int, 0_c_int, lqlnr)), 'udc_set_moist_thermo')
       end if
     end if
     if (ltempeq .and. lbuoyancy) call udc_check(udc_set_buoyancy(udc_h, 1_c_int, real(grav, c_double)), 'udc_set_buoyancy')

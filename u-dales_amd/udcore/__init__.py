@@ -43,7 +43,8 @@ def from_deck(deck, device=0, rank=0, nranks=1):
         if deck.get("PHYSICS", "lbuoyancy"):
             if not deck.get("PHYSICS", "ltempeq"):
                 raise ValueError("lmoist with lbuoyancy needs ltempeq on the device path")
-            core.set_moist_thermo(float(deck.get("BC", "thls")), float(deck.get("BC", "qts")), float(deck.get("BC", "ps")))
+            core.set_moist_thermo(float(deck.get("BC", "thls")), float(deck.get("BC", "qts")), float(deck.get("BC", "ps")),
+                                  lqlnr=bool(deck.get("DYNAMICS", "lqlnr")))
     if deck.get("PHYSICS", "ltempeq") and deck.get("PHYSICS", "lbuoyancy"):
         core.set_buoyancy(True)
     if sgs == 3:      # after set_tempeq: the closure reads thl0 when the temperature equation is on

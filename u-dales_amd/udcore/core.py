@@ -191,12 +191,13 @@ class DynCore:
 
     TH_TABLES = ("presf", "presh", "exnf", "exnh", "thvh", "thl0av", "qt0av", "ql0av", "th0av")
 
-    def set_moist_thermo(self, thls, qts, ps=101325.):
+    def set_moist_thermo(self, thls, qts, ps=101325., lqlnr=False):
         """Moist thermodynamics (needed by lmoist with lbuoyancy), see include/udcore.h udc_set_moist_thermo."""
         zf = np.ascontiguousarray(self.g.zf[1:self.g.nz + 2], dtype=np.float64)
         zh = np.ascontiguousarray(self.g.zh[1:self.g.nz + 2], dtype=np.float64)
         L._check(self.lib.udc_set_moist_thermo(self.h, C.c_double(thls), C.c_double(qts), C.c_double(ps),
-                                               zf.ctypes.data_as(L.DP), zh.ctypes.data_as(L.DP), len(zf)), "udc_set_moist_thermo")
+                                               zf.ctypes.data_as(L.DP), zh.ctypes.data_as(L.DP), len(zf), int(bool(lqlnr))),
+                 "udc_set_moist_thermo")
         self.moist_thermo, self._thermo_started = True, False
 
     def thermodynamics(self):
