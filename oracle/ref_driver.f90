@@ -385,7 +385,8 @@ contains
     end do
     call halos
     uinit = um; vinit = vm
-    if (.not. ladaptive) dt = dtmax
+    dt = dtmax/100.                         ! src/modstartup.f90:1099
+    if (.not. ladaptive) dt = dtmax         ! src/modstartup.f90:2038
 
     open (ifinput, file='lscale.inp.'//cexpnr)
     read (ifinput, '(a80)') chmess
@@ -513,6 +514,7 @@ contains
       call put3(tag//'.thlm', thlm, (/ib - ih, jb - jh, kb - kh/))
     end if
     if (ifixuinf == 2) call put1(tag//'.dpdxl', dpdxl(kb:ke), kb)
+    if (ladaptive) call put1(tag//'.time', (/timee, dt/), 1)
     if (lmoist) then
       call put3(tag//'.qt0', qt0, (/ib - ih, jb - jh, kb - kh/))
       call put3(tag//'.qtm', qtm, (/ib - ih, jb - jh, kb - kh/))

@@ -29,7 +29,7 @@ REF = os.path.join(ROOT, "oracle", "_ref", "udales_ref")
 
 
 def deck(iexpnr, nx, ny, nz, dx=0.5, dy=0.5, dtmax=0.25, sgs="vreman", nsv=0, bctopm=1,
-         oracle="", lles=True, randu=0.01, floor=False, z0=0.05, physics="", bc="", bcbotm=3, scalars="", dynamics="", inlet=""):
+         oracle="", lles=True, randu=0.01, floor=False, z0=0.05, physics="", bc="", bcbotm=3, scalars="", dynamics="", inlet="", ladaptive=False):
     sub = {"oneeqn": "loneeqn = .true.\nlvreman = .false.\nlsmagorinsky = .false.",
            "vreman": "lvreman = .true.\nlsmagorinsky = .false.",
            "smag": "lsmagorinsky = .true.\nlvreman = .false.",
@@ -38,7 +38,7 @@ def deck(iexpnr, nx, ny, nz, dx=0.5, dy=0.5, dtmax=0.25, sgs="vreman", nsv=0, bc
 iexpnr = {iexpnr}
 runtime = 1000.
 dtmax = {dtmax}
-ladaptive = .false.
+ladaptive = {'.true.' if ladaptive else '.false.'}
 irandom = 43
 randu = {randu}
 nprocx = 1
@@ -276,6 +276,11 @@ CASES.update({
                                      "BCtopq = 2\nqt_top = 0.0104\nBCbotq = 1\nwqsurf = 5.e-5",
                                   oracle="nsub = 6\ndump_at = 3, 6"), 1.06),
 })
+CASES.update({
+    # adaptive time step (tstep_update: Courant / diffusion-number limits, dt = dtmax/100 at the cold start)
+    "run_adaptive_16x8x12s": ("run", 46, 16, 8, 12,
+                              dict(sgs="smag", nsv=1, floor=True, ladaptive=True, dtmax=2.0, oracle="nsub = 18\ndump_at = 3, 9, 18"), 1.06),
+})
 LSF_ONLY = ("k_lsfq_12x8x20", "k_fix1_12x8x6")
 THL_CASES = {"run_moistnr_16x8x12s": dict(dthl=0.25, qt=0.0119, dqt=-6e-5),
              "k_thlk_12x8x6": dict(dthl=0.3), "run_thlk_16x8x12s": dict(dthl=0.25),
@@ -357,7 +362,7 @@ def main():
                                  "sub.qt0", "in.qtm", "in.sv0_01")}
         else:
             keep = {k: v for k, v in d.items()
-                    if k.count(".") == 0 or k.split(".")[1] in ("u0", "v0", "w0", "pres0", "um", "thl0", "thlm", "e120", "e12m", "qt0", "qtm", "dpdxl")
+                    if k.count(".") == 0 or k.split(".")[1] in ("u0", "v0", "w0", "pres0", "um", "thl0", "thlm", "e120", "e12m", "qt0", "qtm", "dpdxl", "time")
                     or (k.startswith("s000.") and not k.startswith("s000.ek")) or ".sv0" in k}
             # (s000.ekm/ekh are dumped before the first closure call: uninitialised memory, not data)
         tmpf = os.path.join(HERE, name + ".bin")

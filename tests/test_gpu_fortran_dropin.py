@@ -75,3 +75,16 @@ def test_fortran_driver_fixuinf2(residency, tmp_path):
         for k in ("u0", "v0", "w0", "pres0"):
             a, b = got[f"{tag}.{k}"].data[1:-1], fix[f"{tag}.{k}"].data[1:-1]
             assert relerr(nocorner(a), nocorner(b)) <= 1e-9, (tag, k)
+
+
+@pytest.mark.parametrize("residency", [0, 1])
+def test_fortran_driver_adaptive_dt(residency, tmp_path):
+    """ladaptive through the drop-in modtstep::tstep_update (maxima on the device, src/modtstep.f90:49-154)."""
+    name, iexp = "run_adaptive_16x8x12s", 46
+    fix = load_fixture(name)
+    got = run_dropin(name, iexp, "run", tmp_path, residency)
+    for tag in ("s003", "s009", "s018"):
+        np.testing.assert_allclose(got[tag + ".time"].data, fix[tag + ".time"].data, rtol=1e-10, atol=0)
+        for k in ("u0", "v0", "w0", "pres0"):
+            a, b = got[f"{tag}.{k}"].data[1:-1], fix[f"{tag}.{k}"].data[1:-1]
+            assert relerr(nocorner(a), nocorner(b)) <= 1e-9, (tag, k)

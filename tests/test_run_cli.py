@@ -5,6 +5,7 @@ import shutil
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 from common import GOLDEN, RUN_CASES, deck_path, load_fixture, marr, nocorner, relerr
@@ -58,3 +59,37 @@ def test_cli_run_writes_the_reference_state(tmp_path):
     for k in ("u0", "v0", "w0", "pres0"):                  # 3 steps = 9 substeps = the fixture's last dump
         ref = marr(fix, f"s009.{k}", n[2])
         assert relerr(nocorner(got[k][1:-1]), nocorner(ref[1:-1])) <= 1e-9, k
+
+
+@pytest.mark.gpu
+def test_adaptive_time_step_matches_reference():
+    """tstep_update with ladaptive (src/modtstep.f90:49-154): dt = dtmax/100 at the cold start, then
+    min(dtmax, dt courant / C, dt diffnr / D) from the device's maxima -- the dt history and the fields of a reference run."""
+    import udcore
+    from common import carr, interior, load_fixture, marr, nocorner, relerr
+    from udcore import cold_start
+    from udcore import lib as L
+    name, iexp = "run_adaptive_16x8x12s", 46
+    fix = load_fixture(name)
+    d = read_deck(deck_path(name, iexp))
+    assert d.get("RUN", "ladaptive")
+    core = udcore.from_deck(d)
+    core.load_state(cold_start(core.g, d, nsv=core.nsv))
+    dtmax = float(d.get("RUN", "dtmax"))
+    courant, diffnr = courant_default(d), float(d.get("RUN", "diffnr"))
+    assert courant == 1.1
+    core.dt, core.timee, core.rk3step = dtmax / 100., 0., 0          # src/modstartup.f90:1099
+    np.testing.assert_allclose(fix["s000.time"].data, [0., dtmax / 100.])
+    nz = core.g.nz
+    for isub in range(1, 19):
+        rk, dt = core.tstep_update(dtmax, True, courant, diffnr)
+        core.substep(rk, dt, with_forces=True)
+        if isub in (3, 9, 18):
+            tag = f"s{isub:03d}"
+            np.testing.assert_allclose([core.timee, core.dt], fix[tag + ".time"].data, rtol=1e-10)
+            for k in ("u0", "v0", "w0", "pres0"):
+                assert relerr(nocorner(core.download(k)[1:-1]), nocorner(marr(fix, f"{tag}.{k}", nz)[1:-1])) <= 1e-9, (tag, k)
+            got = core.download(L.scalar_field(L.SV0, 0), halo=2)
+            assert relerr(interior(got, 2), interior(carr(fix, f"{tag}.sv0_01", nz), 2)) <= 1e-9
+    assert 0.3 < core.dt < dtmax            # the limiter, not dtmax, set the step
+    core.close()
