@@ -114,6 +114,10 @@ int udc_set_forcing(udc_handle *h, const double *dpdxl, const double *dpdyl, int
  * radiative tendency of src/modforces.f90:104-110) is optional. */
 int udc_set_tempeq(udc_handle *h, int iadv_thl, int bctopt, double wttop, double thl_top, int bcbott, double wtsurf);
 int udc_set_thl_source(udc_handle *h, const double *thlpcar, int n);
+/* Top condition of passive scalar n (0-based), src/modboundary.f90:236-247: BCtops 1 = flux wsvtop(n) (fluxtopscal,
+ * :1521-1537; the default with zero flux), 2 = value sv_top(n) (valuetopscal, :1539-1553; the reference sets
+ * sv_top = svprof(ke, n), src/modstartup.f90:1573-1574). */
+int udc_set_scalar_top(udc_handle *h, int n, int bctops, double value);
 /* scalsource  src/modscalsource.f90:379-483 (src/program.f90:181): Gaussian point and line sources of the scalars.  They
  * depend on neither time nor flow, so the host evaluates the reference's expressions once (udcore/sources.py; in Fortran
  * one call of the reference's own scalsource on a zeroed svp) and registers the result per scalar n (0-based) as a dense

@@ -34,7 +34,7 @@ program ref_driver
   use modglobal
   use modfields
   use modsubgriddata
-  use modsurfdata, only: thl_top, wttop, wsvtop, sv_top, thvs, thls, z0, z0h, wtsurf, qts, wqtop, qt_top, wqsurf, ps
+  use modsurfdata, only: thl_top, wttop, wsvtop, sv_top, wsvtopdum, thvs, thls, z0, z0h, wtsurf, qts, wqtop, qt_top, wqsurf, ps
   use modwallfunctions, only: wfmneutral, wfuno
   use modboundary, only: initboundary, boundary, halos, grwdamp
   use modthermodynamics, only: initthermodynamics, thermodynamics, lqlnr
@@ -268,7 +268,7 @@ contains
     namelist /INLET/ Uinf, Vinf, inletav
     namelist /DYNAMICS/ lqlnr, ipoiss, iadv_mom, iadv_tke, iadv_thl, iadv_qt, iadv_sv
     namelist /BC/ BCxm, BCym, BCtopm, BCtopT, BCtops, BCbotm, BCbots, BCbotT, BCzp, wttop, thl_top, z0, wtsurf, thls, qts, &
-      BCtopq, BCbotq, wqtop, qt_top, wqsurf, ps, z0h
+      BCtopq, BCbotq, wqtop, qt_top, wqsurf, ps, z0h, wsvtopdum
     namelist /SCALARS/ nsv, lscasrc, nscasrc, lscasrcl, nscasrcl
     namelist /WALLS/ nfcts, lbottom
     open (ifnamopt, file=fname_options, status='old', iostat=ierr)
@@ -288,6 +288,7 @@ contains
     nprocx = 1; nprocy = nprocs     ! y-slabs over however many ranks were launched (1 in the np1 build)
     libm = .false.
     allocate (wsvtop(1:max(nsv, 1))); wsvtop = 0.      ! src/modstartup.f90:518-519
+    if (nsv > 0) wsvtop(1:nsv) = wsvtopdum(1:nsv)
     allocate (sv_top(1:max(nsv, 1))); sv_top = 0.
     thvs = thls*(1.+(rv_g/rd_g - 1.)*qts)                  ! src/modstartup.f90:522
     write (cexpnr, '(i3.3)') iexpnr
@@ -383,6 +384,7 @@ contains
       sv0(:, :, kb - 2, n) = sv0(:, :, kb, n)
       svm(:, :, :, n) = sv0(:, :, :, n)
     end do
+    if (nsv > 0) sv_top(1:nsv) = svprof(ke, 1:nsv)        ! src/modstartup.f90:1573-1574
     call halos
     uinit = um; vinit = vm
     dt = dtmax/100.                         ! src/modstartup.f90:1099

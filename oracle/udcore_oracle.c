@@ -768,6 +768,32 @@ static void top_row_m(const orc_grid *g, double *a, double val) {
 
 /* boundary: src/modboundary.f90:163-247 (w(kb)=0; top ghost rows; scalars zero-flux top
  * :1521-1537 with flux = 0, which adds exactly 0.0) */
+/* anything other than the zero-flux copy orc_boundary already makes? */
+static int scalar_top_active(const orc_grid *g) {
+  if (g->bctops == 2) return 1;
+  for (int s = 0; s < g->nsv && s < 4; ++s) if (g->wsvtop[s] != 0.) return 1;
+  return 0;
+}
+void orc_scalar_tops(const orc_grid *g, const double *ekh, double *sv0, double *svm) {
+  const size_t nc = csize(g);
+  const int nz = g->nz;
+  for (int s = 0; s < g->nsv; ++s) {
+    double *p0 = sv0 + s * nc, *pm = svm + s * nc;
+    for (int mm = 1; mm <= 2; ++mm)
+      for (int j = 0; j <= g->ny + 1; ++j)
+        for (int i = 0; i <= g->nx + 1; ++i) {
+          if (g->bctops == 2) {
+            C(p0, i, j, nz + mm) = 2 * g->sv_top[s] - C(p0, i, j, nz);
+            C(pm, i, j, nz + mm) = 2 * g->sv_top[s] - C(pm, i, j, nz);
+          } else {
+            const double d = g->dzh[nz + 1] * g->wsvtop[s] /
+                             ((1. / g->dzh[nz + 1]) * (0.5 * (g->dzf[nz] * M(ekh, i, j, nz + 1) + g->dzf[nz + 1] * M(ekh, i, j, nz))));
+            C(p0, i, j, nz + mm) = C(p0, i, j, nz) + d;
+            C(pm, i, j, nz + mm) = C(pm, i, j, nz) + d;
+          }
+        }
+  }
+}
 void orc_boundary(const orc_grid *g, double *u0, double *v0, double *w0, double *um, double *vm,
                   double *wm, double *sv0, double *svm) {
   const int nx = g->nx, ny = g->ny, nz = g->nz;
@@ -1432,6 +1458,7 @@ void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
           }
     }
   }
+  if (g->nsv > 0 && g->bctops != 2 && scalar_top_active(g)) orc_scalar_tops(g, s->ekh, s->sv0, s->svm);      /* :427-430 */
   if (g->ltempeq && g->bctopt != 2) { orc_thl_top(g, s->ekh, s->thlm); orc_thl_top(g, s->ekh, s->thl0); }   /* :417-420 */
   if (g->lmoist && g->bctopq != 2) { orc_qt_top(g, s->ekh, s->qtm); orc_qt_top(g, s->ekh, s->qt0); }         /* :422-425 */
   orc_diffu(g, s->u0, s->v0, s->w0, s->ekm, s->up);
@@ -1513,6 +1540,7 @@ void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
   orc_halos_m(g, s->um); orc_halos_m(g, s->vm); orc_halos_m(g, s->wm);
   for (int n = 0; n < g->nsv; ++n) { orc_halos_c(g, s->sv0 + n * nc); orc_halos_c(g, s->svm + n * nc); }
   orc_boundary(g, s->u0, s->v0, s->w0, s->um, s->vm, s->wm, s->sv0, s->svm);
+  if (g->nsv > 0 && scalar_top_active(g)) orc_scalar_tops(g, s->ekh, s->sv0, s->svm);      /* src/modboundary.f90:236-247 */
   if (g->ltempeq) { orc_thl_top(g, s->ekh, s->thlm); orc_thl_top(g, s->ekh, s->thl0); }     /* src/modboundary.f90:207-217 */
   if (g->ltempeq && g->iadv_thl == 7) orc_thl0c_from(g, s->thl0, s->thl0c);                 /* src/modtstep.f90:249 + halos + boundary */
   if (g->lmoist) { orc_qt_top(g, s->ekh, s->qtm); orc_qt_top(g, s->ekh, s->qt0); }          /* src/modboundary.f90:222-231 */

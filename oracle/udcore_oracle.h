@@ -64,6 +64,10 @@ typedef struct {
    * roughness length for heat z0h (src/modsurfdata.f90:73), prandtlturb (src/modglobal.f90:304) */
   int bcbotm, bcbott;
   double z0h, prandtlturb;
+  /* top condition of the scalars (src/modboundary.f90:236-247): BCtops 1 = flux wsvtop(n) (fluxtopscal, :1521-1537),
+   * 2 = value sv_top(n) (valuetopscal, :1539-1553); up to 4 scalars here */
+  int bctops;
+  double wsvtop[4], sv_top[4];
   int lqlnr;                /* condensate by Newton-Raphson on T instead of the one-step formula (src/modthermodynamics.f90:37,448-473) */
   int iadv_thl;             /* 2 = cd2 (advecc_2nd), 7 = kappa (advecc_kappa on thl0c), src/modadvection.f90:64-76 */
 } orc_grid;
@@ -137,6 +141,8 @@ void orc_tstep_integrate(const orc_grid *g, int rk3step, double dt, double *u0, 
 /* ---- halos + boundary (periodic / top / bottom subset): src/modboundary.f90:67-109,115-247 */
 void orc_halos_m(const orc_grid *g, double *a);          /* x then y periodic wrap, halo 1 */
 void orc_halos_c(const orc_grid *g, double *a);          /* halo 2 */
+/* fluxtopscal / valuetopscal on sv0 and svm (both ghost planes get the same value); ekh: the current eddy diffusivity */
+void orc_scalar_tops(const orc_grid *g, const double *ekh, double *sv0, double *svm);
 void orc_boundary(const orc_grid *g, double *u0, double *v0, double *w0, double *um, double *vm,
                   double *wm, double *sv0, double *svm);
 

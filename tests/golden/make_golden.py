@@ -281,6 +281,13 @@ CASES.update({
     "run_adaptive_16x8x12s": ("run", 46, 16, 8, 12,
                               dict(sgs="smag", nsv=1, floor=True, ladaptive=True, dtmax=2.0, oracle="nsub = 18\ndump_at = 3, 9, 18"), 1.06),
 })
+CASES.update({
+    # top conditions of the scalars: a prescribed value (BCtops = 2, sv_top = svprof(ke)) and prescribed fluxes (wsvtopdum)
+    "k_svtop_8x8x8": ("kernels", 47, 8, 8, 8,
+                      dict(sgs="smag", nsv=2, bc="BCtops = 2", oracle="nspin = 4"), 1.05),
+    "run_svflux_16x8x12s": ("run", 48, 16, 8, 12,
+                            dict(sgs="smag", nsv=2, floor=True, bc="BCtops = 1\nwsvtopdum = -0.004, 0.006", oracle="nsub = 6\ndump_at = 3, 6"), 1.06),
+})
 LSF_ONLY = ("k_lsfq_12x8x20", "k_fix1_12x8x6")
 THL_CASES = {"run_moistnr_16x8x12s": dict(dthl=0.25, qt=0.0119, dqt=-6e-5),
              "k_thlk_12x8x6": dict(dthl=0.3), "run_thlk_16x8x12s": dict(dthl=0.25),

@@ -378,6 +378,14 @@ extern "C" int udc_set_tempeq(udc_handle *h, int iadv_thl, int bctopt, double wt
   return 0;
 }
 
+extern "C" int udc_set_scalar_top(udc_handle *h, int n, int bctops, double value) {
+  if (n < 0 || n >= h->cfg.nsv) { udc_set_error("udc_set_scalar_top: scalar %d of %d", n, h->cfg.nsv); return 1; }
+  if (bctops != 1 && bctops != 2) { udc_set_error("udc_set_scalar_top: BCtops must be 1 (flux) or 2 (value)"); return 1; }
+  h->slot[n].top = bctops == 2 ? 2 : (value != 0. ? 1 : 0);
+  h->slot[n].topval = value;
+  return 0;
+}
+
 extern "C" int udc_set_scalar_source(udc_handle *h, int n, const double *src, const int lb[3], const int ub[3]) {
   HIP_OK(hipSetDevice(h->device));
   if (n < 0 || n >= h->cfg.nsv) { udc_set_error("udc_set_scalar_source: scalar %d of %d", n, h->cfg.nsv); return 1; }

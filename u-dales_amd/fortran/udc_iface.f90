@@ -111,6 +111,12 @@ module udc_iface
       integer(c_int), value :: bcbotm, bcbott
       real(c_double), value :: thls, z0h, prandtlturb
     end function udc_set_floor_wf
+    integer(c_int) function udc_set_scalar_top(h, n, bctops, value) bind(C, name='udc_set_scalar_top')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: n, bctops
+      real(c_double), value :: value
+    end function udc_set_scalar_top
     integer(c_int) function udc_set_moisture(h, iadv_qt, bctopq, wqtop, qt_top, bcbotq, wqsurf) bind(C, name='udc_set_moisture')
       import :: c_ptr, c_int, c_double
       type(c_ptr), value :: h
@@ -230,8 +236,8 @@ contains
   subroutine udc_ensure
     use modglobal, only: itot, jtot, ktot, dx, dy, dzf, dzh, kb, ke, kh, numol, prandtlmoli, nsv, &
                          BCtopm, Uinf, Vinf, lles, ltempeq, lbuoyancy, lmoist, iadv_thl, BCtopT, BCbotT, grav, e12min, &
-                         iadv_qt, BCtopq, BCbotq, zf, zh, BCbotm, prandtlturb
-    use modsurfdata, only: wttop, thl_top, wtsurf, thvs, wqtop, qt_top, wqsurf, thls, qts, ps, z0h
+                         iadv_qt, BCtopq, BCbotq, zf, zh, BCbotm, prandtlturb, BCtops
+    use modsurfdata, only: wttop, thl_top, wtsurf, thvs, wqtop, qt_top, wqsurf, thls, qts, ps, z0h, wsvtop, sv_top
     use modthermodynamics, only: lqlnr
     use modsubgriddata, only: lsmagorinsky, lvreman, loneeqn, ldelta, prandtli, c_vreman, csz, cm, cn, ch1, ch2, ce1, ce2
     use modfields, only: dpdxl, dpdyl, thlpcar
@@ -239,7 +245,7 @@ contains
     use mpi, only: MPI_CHARACTER
     type(udc_config) :: cfg
     integer(c_signed_char) :: nccl_id(128)
-    integer :: gpus_per_node
+    integer :: gpus_per_node, n
     real(c_double), allocatable, target, save :: zf_(:), zh_(:)
     character(16) :: env
     integer :: stat
@@ -305,6 +311,10 @@ contains
       call udc_check(udc_set_floor_wf(udc_h, int(BCbotm, c_int), int(BCbotT, c_int), real(thls, c_double), real(z0h, c_double), &
                                       real(prandtlturb, c_double)), 'udc_set_floor_wf')
     end if
+    do n = 1, nsv          ! top condition of the scalars (src/modboundary.f90:236-247)
+      call udc_check(udc_set_scalar_top(udc_h, int(n - 1, c_int), int(BCtops, c_int), &
+                                        real(merge(sv_top(n), wsvtop(n), BCtops == 2), c_double)), 'udc_set_scalar_top')
+    end do
     if (cfg%sgs == 3) then   ! after udc_set_tempeq: the closure reads thl0 when the temperature equation is on
       call udc_check(udc_set_tke(udc_h, real(cm, c_double), real(cn, c_double), real(ch1, c_double), real(ch2, c_double), &
                                  real(ce1, c_double), real(ce2, c_double), real(e12min, c_double), real(grav, c_double), &

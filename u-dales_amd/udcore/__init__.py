@@ -70,6 +70,18 @@ def from_deck(deck, device=0, rank=0, nranks=1):
         dpdxl = [om23_gs * vg - pg - dpdx for vg, pg in zip(deck.vg, deck.pgx)]
         dpdyl = [-om23_gs * ug - pg for ug, pg in zip(deck.ug, deck.pgy)]
     core.set_forcing(np.array(dpdxl), np.array(dpdyl))
+    if core.nsv:      # top condition of the scalars (src/modboundary.f90:236-247; sv_top = svprof(ke), src/modstartup.f90:1574)
+        bctops = int(deck.get("BC", "BCtops"))
+        w = deck.get("BC", "wsvtopdum")
+        w = list(w) if isinstance(w, (list, tuple)) else [w]
+        if bctops == 2:
+            from .grid import scalar_profiles
+            prof = scalar_profiles(g, deck, core.nsv)
+            for n in range(core.nsv):
+                core.set_scalar_top(n, 2, prof[n][g.nz])
+        else:
+            for n in range(core.nsv):
+                core.set_scalar_top(n, 1, float(w[n]) if n < len(w) else 0.)
     if core.nsv and (deck.get("SCALARS", "lscasrc") or deck.get("SCALARS", "lscasrcl")):
         from .sources import apply_sources
         apply_sources(core, deck, j0=rank * core.nyl)

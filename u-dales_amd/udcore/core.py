@@ -156,6 +156,10 @@ class DynCore:
             a = np.ascontiguousarray(thlpcar, dtype=np.float64)
             L._check(self.lib.udc_set_thl_source(self.h, a.ctypes.data_as(L.DP), len(a)), "udc_set_thl_source")
 
+    def set_scalar_top(self, n, bctops=1, value=0.):
+        """&BC BCtops for scalar n: 1 = flux wsvtop(n), 2 = value sv_top(n) (include/udcore.h udc_set_scalar_top)."""
+        L._check(self.lib.udc_set_scalar_top(self.h, int(n), int(bctops), C.c_double(value)), "udc_set_scalar_top")
+
     def set_scalar_source(self, n, src):
         """Constant source of scalar n (scalsource): src is [nz, nyl, nx] over the interior of this slab, or None to remove
         it.  Only the smallest box holding its non-zeros is kept on the device."""

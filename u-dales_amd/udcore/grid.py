@@ -161,8 +161,14 @@ def cold_start(g: Grid, d: Deck, j0=0, nyl=None, nsv=0, scal_a=1.0, scal_b=0.0):
         if not getattr(d, "svprof", None):      # (the reference leaves the sub-floor planes of a scalar.inp start at zero)
             c[1] = c[2]
             c[0] = c[2]
-        c[nz + 2] = c[nz + 1]
-        c[nz + 3] = c[nz + 1]
+        if int(d.get("BC", "BCtops")) == 2:     # valuetopscal with sv_top = svprof(ke), as `boundary` leaves it
+            c[nz + 2] = 2 * svprof[n][nz] - c[nz + 1]
+        else:                                   # fluxtopscal with the start value ekh = numol (src/modboundary.f90:1532)
+            w = d.get("BC", "wsvtopdum")
+            w = list(w) if isinstance(w, (list, tuple)) else [w]
+            flux = float(w[n]) if n < len(w) else 0.
+            c[nz + 2] = c[nz + 1] + g.dzh[nz + 1] * flux / ((1. / g.dzh[nz + 1]) * (0.5 * (g.dzf[nz] * 1.5e-5 + g.dzf[nz + 1] * 1.5e-5)))
+        c[nz + 3] = c[nz + 2]
         out[f"sv0_{n}"] = c
         out[f"svm_{n}"] = c.copy()
     if d.get("NAMSUBGRID", "loneeqn") and not (d.get("NAMSUBGRID", "lsmagorinsky") or d.get("NAMSUBGRID", "lvreman")):
