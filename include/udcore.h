@@ -114,6 +114,13 @@ int udc_set_forcing(udc_handle *h, const double *dpdxl, const double *dpdyl, int
  * radiative tendency of src/modforces.f90:104-110) is optional. */
 int udc_set_tempeq(udc_handle *h, int iadv_thl, int bctopt, double wttop, double thl_top, int bcbott, double wtsurf);
 int udc_set_thl_source(udc_handle *h, const double *thlpcar, int n);
+/* shiftedPBCs  src/modforces.f90:953-980 (src/program.f90:144, &BC ds > 0): in the downstream half of the domain
+ * (global i > itot/2) the momentum tendencies get -vs (phi(j) - phi(j-1))/dy with vs = a u0av(k) sinx(i),
+ * a = 0.5 pi ds/(0.5 xlen), sinx(i) = sin(pi (xh(i) - xh(itot/2))/(0.5 xlen)) ([itot], zero where inactive).  u0av(kb:ke)
+ * is diagfld's slab average, refreshed by the host before every substep (udc_slab_average); udc_shifted_pbcs applies
+ * it, as does udc_substep.  a = 0 switches it off. */
+int udc_set_shifted_pbc(udc_handle *h, double a, const double *sinx, int nx, const double *u0av, int nz);
+int udc_shifted_pbcs(udc_handle *h);
 /* Top condition of passive scalar n (0-based), src/modboundary.f90:236-247: BCtops 1 = flux wsvtop(n) (fluxtopscal,
  * :1521-1537; the default with zero flux), 2 = value sv_top(n) (valuetopscal, :1539-1553; the reference sets
  * sv_top = svprof(ke, n), src/modstartup.f90:1573-1574). */

@@ -42,7 +42,7 @@ program ref_driver
   use modpois, only: initpois, poisson, p
   use modadvection, only: advection
   use modtstep, only: tstep_update, tstep_integrate
-  use modforces, only: forces, masscorr, coriolis, lstend, nudge, fixuinf1, fixuinf2
+  use modforces, only: forces, masscorr, coriolis, lstend, nudge, fixuinf1, fixuinf2, shiftedPBCs
   use modsave, only: writerestartfiles
   use modscalsource, only: createscals, scalsource
   implicit none
@@ -89,7 +89,7 @@ program ref_driver
   call cold_start
   call createscals                          ! src/modstartup.f90 (scalarsourcep / scalarsourcel files; no-op without sources)
   call boundary
-  need_thermo = ltempeq .or. lmoist .or. loneeqn .or. lnudge .or. igrw_damp /= 0 .or. any(whls /= 0.) .or. ifixuinf /= 0
+  need_thermo = ltempeq .or. lmoist .or. loneeqn .or. lnudge .or. igrw_damp /= 0 .or. any(whls /= 0.) .or. ifixuinf /= 0 .or. ds > 0
   if (need_thermo) call thermodynamics            ! src/program.f90:120 (thv0h, thvh; dthvdz; diagfld's slab averages)
 
   iu = 71
@@ -168,6 +168,7 @@ contains
   subroutine one_substep
     call tstep_update
     call advection
+    call shiftedPBCs                        ! src/program.f90:144 (no-op unless ds > 0)
     call subgrid
     call floor_bottom
     if (lforces) call coriolis              ! src/program.f90:158 (no-op unless lcoriol / lprofforc)
@@ -268,7 +269,7 @@ contains
     namelist /INLET/ Uinf, Vinf, inletav
     namelist /DYNAMICS/ lqlnr, ipoiss, iadv_mom, iadv_tke, iadv_thl, iadv_qt, iadv_sv
     namelist /BC/ BCxm, BCym, BCtopm, BCtopT, BCtops, BCbotm, BCbots, BCbotT, BCzp, wttop, thl_top, z0, wtsurf, thls, qts, &
-      BCtopq, BCbotq, wqtop, qt_top, wqsurf, ps, z0h, wsvtopdum
+      BCtopq, BCbotq, wqtop, qt_top, wqsurf, ps, z0h, wsvtopdum, ds
     namelist /SCALARS/ nsv, lscasrc, nscasrc, lscasrcl, nscasrcl
     namelist /WALLS/ nfcts, lbottom
     open (ifnamopt, file=fname_options, status='old', iostat=ierr)
@@ -569,6 +570,12 @@ contains
     ! full tendency = advection + subgrid + forces, as the driver would have it
     up = 0.; vp = 0.; wp = 0.; svp = 0.; thlp = 0.; e12p = 0.; qtp = 0.
     call advection
+    if (ds > 0) then
+      call dump_tend('shf0')
+      call shiftedPBCs
+      call dump_tend('shf')
+      call put1('u0av', u0av(kb:ke + kh), kb)
+    end if
     call subgrid
     call floor_bottom
     if (lforces) call coriolis

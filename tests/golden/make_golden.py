@@ -288,6 +288,11 @@ CASES.update({
     "run_svflux_16x8x12s": ("run", 48, 16, 8, 12,
                             dict(sgs="smag", nsv=2, floor=True, bc="BCtops = 1\nwsvtopdum = -0.004, 0.006", oracle="nsub = 6\ndump_at = 3, 6"), 1.06),
 })
+CASES.update({
+    # shifted periodic boundary conditions (&BC ds > 0, shiftedPBCs): a spanwise drift in the downstream half
+    "run_shift_16x8x12s": ("run", 49, 16, 8, 12,
+                           dict(sgs="smag", floor=True, bc="ds = 1.5", oracle="nsub = 6\ndump_at = 3, 6"), 1.06),
+})
 LSF_ONLY = ("k_lsfq_12x8x20", "k_fix1_12x8x6")
 THL_CASES = {"run_moistnr_16x8x12s": dict(dthl=0.25, qt=0.0119, dqt=-6e-5),
              "k_thlk_12x8x6": dict(dthl=0.3), "run_thlk_16x8x12s": dict(dthl=0.25),

@@ -88,3 +88,13 @@ def test_fortran_driver_adaptive_dt(residency, tmp_path):
         for k in ("u0", "v0", "w0", "pres0"):
             a, b = got[f"{tag}.{k}"].data[1:-1], fix[f"{tag}.{k}"].data[1:-1]
             assert relerr(nocorner(a), nocorner(b)) <= 1e-9, (tag, k)
+
+
+def test_fortran_driver_shifted_pbcs(tmp_path):
+    """&BC ds > 0: the host's shiftedPBCs edits the tendencies the drop-in advection pulled back."""
+    name, iexp = "run_shift_16x8x12s", 49
+    fix = load_fixture(name)
+    got = run_dropin(name, iexp, "run", tmp_path, 0)
+    for k in ("u0", "v0", "w0", "pres0"):
+        a, b = got[f"s006.{k}"].data[1:-1], fix[f"s006.{k}"].data[1:-1]
+        assert relerr(nocorner(a), nocorner(b)) <= 1e-9, k

@@ -212,6 +212,7 @@ extern "C" int udc_destroy(udc_handle *h) {
   if (h->red_host) hipHostFree(h->red_host);
   if (h->thlpcar) hipFree(h->thlpcar);
   if (h->mt) hipFree(h->mt);
+  if (h->shift_tab) hipFree(h->shift_tab);
   for (auto &s : h->svsrc) if (s.d) hipFree(s.d);
   if (h->ug) hipFree(h->ug);
   if (h->lev_part) hipFree(h->lev_part);
@@ -376,6 +377,24 @@ extern "C" int udc_set_tempeq(udc_handle *h, int iadv_thl, int bctopt, double wt
   sl.topval = bctopt == 2 ? thl_top : wttop;
   sl.floorflux = wtsurf;
   return 0;
+}
+
+extern "C" int udc_set_shifted_pbc(udc_handle *h, double a, const double *sinx, int nx, const double *u0av, int nz) {
+  HIP_OK(hipSetDevice(h->device));
+  h->shift_a = a;
+  if (a == 0.) return 0;
+  if (nx != h->g.nx || nz != h->g.nz) { udc_set_error("udc_set_shifted_pbc: expected sinx[%d], u0av[%d]", h->g.nx, h->g.nz); return 1; }
+  if (!h->shift_tab) HIP_OK(hipMalloc(&h->shift_tab, sizeof(double) * (size_t)(nx + nz)));
+  HIP_OK(hipMemcpyAsync(h->shift_tab, sinx, sizeof(double) * nx, hipMemcpyHostToDevice, h->stream));
+  HIP_OK(hipMemcpyAsync(h->shift_tab + nx, u0av, sizeof(double) * nz, hipMemcpyHostToDevice, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+extern "C" int udc_shifted_pbcs(udc_handle *h) {
+  HIP_OK(hipSetDevice(h->device));
+  if (tend_clean(h) || um_materialise(h)) return 1;
+  return k_shifted_pbcs(h, false);
 }
 
 extern "C" int udc_set_scalar_top(udc_handle *h, int n, int bctops, double value) {
@@ -721,6 +740,7 @@ extern "C" int udc_substep(udc_handle *h, int rk3step, double dt, int with_force
   // `bottom` (src/program.f90:152): additive on the k = kb tendencies, hence equally on pup = up + um/rk3coef
   if (h->p.lbottom && k_bottom(h, fold)) return 1;
   if (with_forces && k_coriolis(h, fold)) return 1;        // src/program.f90:158; wrap of vp's ghost row follows below
+  if (k_shifted_pbcs(h, fold)) return 1;                   // src/program.f90:144 (additive on the momentum tendencies)
   if (with_forces && !h->level_forcings.empty() && k_level_forcings(h, 0, fold)) return 1;   // lstend, nudge tables
   // masscorr (src/program.f90:169); without pup the tendencies and um are summed separately
   if (k_masscorr(h, rk3coef, pup, fold)) return 1;

@@ -131,6 +131,9 @@ struct udc_handle {
   // constant scalar sources (udc_set_scalar_source): a dense box per scalar, local device indices [lo, hi]
   struct ScalarSource { double *d = nullptr; int lo[3] = {0, 0, 0}, hi[3] = {-1, -1, -1}; };
   ScalarSource svsrc[16];
+  // shiftedPBCs (udc_set_shifted_pbc): a, sinx[nx], u0av[nz] on the device
+  double shift_a = 0.;
+  double *shift_tab = nullptr;
   // floor wall function choice (udc_set_floor_wf): BCbotm 3 neutral / 2 wfuno, BCbotT 1 flux / 2 wfuno
   int floor_bcbotm = 3, floor_bcbott = 1;
   double floor_thls = 0., floor_z0h = 0., floor_prt = 0.71;
@@ -241,6 +244,7 @@ int k_scalar_top_flux(udc_handle *h);              // fluxtop with a non-zero fl
 int k_level_source(udc_handle *h, int slot, const double *src);
 int k_buoyancy(udc_handle *h);
 int k_scalsource(udc_handle *h);
+int k_shifted_pbcs(udc_handle *h, bool wrap_vp);
 int k_thermodynamics(udc_handle *h);
 int k_slab_average(udc_handle *h, int field, double *avg_host, int n);
 int k_level_forcings(udc_handle *h, int when, bool wrap_vp);

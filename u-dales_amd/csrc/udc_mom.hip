@@ -266,6 +266,22 @@ __global__ __launch_bounds__(256) void coriolis_kernel(Geo g, TileGrid tg, Metri
   }
 }
 
+// shiftedPBCs, src/modforces.f90:953-980
+__global__ __launch_bounds__(256) void shifted_pbc_kernel(Geo g, TileGrid tg, double a, const double *__restrict__ sinx,
+    const double *__restrict__ u0av, double dyi, const double *__restrict__ u0, const double *__restrict__ v0, const double *__restrict__ w0,
+    double *__restrict__ up, double *__restrict__ vp, double *__restrict__ wp, int wrap_vp) {
+  int i, j, k;
+  if (!tile_decode(g, tg, i, j, k)) return;
+  if (i + 1 <= g.nx / 2) return;                       // ig > int(itot/2)
+  const long c = g.idx(i, j, k), sy = g.sy;
+  const double vs = a * u0av[k] * sinx[i];
+  up[c] = up[c] - vs * (u0[c] - u0[c - sy]) * dyi;
+  const double tv = vp[c] - vs * (v0[c] - v0[c - sy]) * dyi;
+  vp[c] = tv;
+  if (wrap_vp && j == 0) vp[c + sy * g.ny] = tv;       // bcpup's cyclic pvp(je+1) = pvp(jb)
+  wp[c] = wp[c] - vs * (w0[c] - w0[c - sy]) * dyi;
+}
+
 inline dim3 cell_grid(const Geo &g, dim3 b) {
   (void)b;
   return dim3((unsigned)tile_grid(g).tiles * (unsigned)g.nz, 1, 1);
@@ -311,6 +327,18 @@ int k_bottom(udc_handle *h, bool wrap_vp) {
   const dim3 gr((unsigned)((g.nx + 63) / 64), (unsigned)((g.ny + 3) / 4)), bl(64, 4);
   if (uno) hipLaunchKernelGGL(bottom_kernel<true>, gr, bl, 0, h->stream, g, h->m, a);
   else hipLaunchKernelGGL(bottom_kernel<false>, gr, bl, 0, h->stream, g, h->m, a);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int k_shifted_pbcs(udc_handle *h, bool wrap_vp) {
+  const Geo &g = h->g;
+  if (h->shift_a == 0. || !h->shift_tab) return 0;
+  PROF(h, "shifted_pbcs");
+  dim3 b(64, 4, 1), gr = cell_grid(g, b);
+  hipLaunchKernelGGL(shifted_pbc_kernel, gr, b, 0, h->stream, g, tile_grid(g), h->shift_a, (const double *)h->shift_tab,
+                     (const double *)(h->shift_tab + g.nx), h->m.dyi, (const double *)h->fields[UDC_U0], (const double *)h->fields[UDC_V0],
+                     (const double *)h->fields[UDC_W0], h->fields[UDC_UP], h->fields[UDC_VP], h->fields[UDC_WP], wrap_vp ? 1 : 0);
   HIP_OK(hipGetLastError());
   return 0;
 }

@@ -156,6 +156,16 @@ class DynCore:
             a = np.ascontiguousarray(thlpcar, dtype=np.float64)
             L._check(self.lib.udc_set_thl_source(self.h, a.ctypes.data_as(L.DP), len(a)), "udc_set_thl_source")
 
+    def set_shifted_pbc(self, a, sinx, u0av):
+        """shiftedPBCs (&BC ds): vs = a u0av(k) sinx(i), see include/udcore.h udc_set_shifted_pbc."""
+        sx = np.ascontiguousarray(sinx, dtype=np.float64)
+        ua = np.ascontiguousarray(u0av, dtype=np.float64)
+        L._check(self.lib.udc_set_shifted_pbc(self.h, C.c_double(a), sx.ctypes.data_as(L.DP), len(sx), ua.ctypes.data_as(L.DP), len(ua)),
+                 "udc_set_shifted_pbc")
+
+    def shifted_pbcs(self):
+        L._check(self.lib.udc_shifted_pbcs(self.h), "udc_shifted_pbcs")
+
     def set_scalar_top(self, n, bctops=1, value=0.):
         """&BC BCtops for scalar n: 1 = flux wsvtop(n), 2 = value sv_top(n) (include/udcore.h udc_set_scalar_top)."""
         L._check(self.lib.udc_set_scalar_top(self.h, int(n), int(bctops), C.c_double(value)), "udc_set_scalar_top")

@@ -72,7 +72,14 @@ class LevelForcings:
         self.tscale = float(ph("tscale"))
         self.Uinf, self.Vinf, self.inletav = (float(deck.get("INLET", n)) for n in ("Uinf", "Vinf", "inletav"))
         self.freestreamav, self.dgdt, self._pending = 0., 0., 0.      # src/modglobal.f90:261, src/modfields.f90:396
-        self.active = self.subsidence or self.lnudge or self.igrw != 0 or self.qtls or self.ifixuinf in (1, 2)
+        # shiftedPBCs (src/modforces.f90:953-980; &BC ds)
+        self.ds = float(deck.get("BC", "ds"))
+        xlen = g.nx * g.dx
+        self.shift_a = 0.5 * pi * self.ds / (0.5 * xlen)
+        half = g.nx // 2
+        xh = [(i - 1) * g.dx for i in range(0, g.nx + 2)]            # xh(i), src/modglobal.f90:770-776
+        self.shift_sinx = np.array([math.sin(pi * (xh[i] - xh[half]) / (0.5 * xlen)) if i > half else 0. for i in range(1, g.nx + 1)])
+        self.active = self.subsidence or self.lnudge or self.igrw != 0 or self.qtls or self.ifixuinf in (1, 2) or self.ds > 0
 
     def tables(self, av, rk3step=None, dt=None):
         """av: dict of slab averages indexed by the reference's k (entries 1..nz+1).  Returns {(tend, when): [src, A, B]}
@@ -181,6 +188,8 @@ class LevelForcings:
                 self.freestreamav = freestream * dt / self.inletav + (1. - dt / self.inletav) * self.freestreamav
                 self.dgdt = (1. / self.tscale) * (self.freestreamav - self.Uinf)
             self._pending = self.dgdt * (dt / (4. - rk3step))
+        if self.ds > 0:
+            self.core.set_shifted_pbc(self.shift_a, self.shift_sinx, av["u0"][1:self.nz + 1])
         tabs = self.tables(av, rk3step, dt)
         for (tend, when), (src, A, B) in tabs.items():
             self.core.set_level_forcing(tend, src, A[1:self.nz + 1], B[1:self.nz + 1], when)

@@ -24,7 +24,7 @@ DEFAULTS = {
     "DYNAMICS": dict(lqlnr=False, ipoiss=0, iadv_mom=2, iadv_tke=-1, iadv_thl=-1, iadv_qt=-1),
     "BC": dict(BCxm=1, BCym=1, BCtopm=1, BCbotm=2, BCzp=1, z0=-1., z0h=-1., BCtopT=1, BCbotT=1, BCbots=1, BCtops=1,
                wttop=0., thl_top=-1., wtsurf=-1., thls=-1., qts=-1.,
-               BCtopq=1, BCbotq=1, wqtop=0., qt_top=-1., wqsurf=-1., ps=101325., wsvtopdum=0.),
+               BCtopq=1, BCbotq=1, wqtop=0., qt_top=-1., wqsurf=-1., ps=101325., wsvtopdum=0., ds=0.),
     "SCALARS": dict(nsv=0, lscasrc=False, nscasrc=0, lscasrcl=False, nscasrcl=0),
     "NAMSUBGRID": dict(lsmagorinsky=False, lvreman=True, loneeqn=False, c_vreman=0.07, cs=-1.,
                        cf=2.5, cn=0.76, Rigc=0.25, Prandtl=0.333, ldelta=False, lbuoycorr=False),
