@@ -266,6 +266,22 @@ def main():
                 "unit": "GB/s", "frac": kernels[dom]["frac"], "traffic": traffic,
                 "algo_bytes_per_launch": kernels[dom]["algo_bytes_per_cell"] * cells_local,
                 "avg_launch_ms": kernels[dom]["avg_ms"]}
+    # measured copy ceiling of this GPU (BASELINE.md asks for the fraction against it next to the nominal 8 TB/s):
+    # a 1 GiB device-to-device copy, read + write bytes over the best of 10 repetitions, outside the timed region
+    try:
+        src = torch.empty(1 << 27, dtype=torch.float64, device="cuda")
+        dst = torch.empty_like(src)
+        best = float("inf")
+        for _ in range(12):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); dst.copy_(src); e1.record(); e1.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        ceiling = 2 * src.numel() * 8 / (best * 1e-3) / 1e9
+        roofline["copy_ceiling"] = round(ceiling, 1)
+        roofline["frac_of_copy_ceiling"] = round(kernels[dom]["achieved_GBs"] / ceiling, 4)
+        del src, dst
+    except Exception:      # noqa: BLE001 (the ceiling is a side measurement: never let it take the bench line down)
+        pass
     out = {
         "metric": "cell-updates/sec (advect+diffuse+Poisson step)", "value": value, "unit": "cell-updates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
