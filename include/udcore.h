@@ -39,7 +39,10 @@ enum {
   UDC_SV0,                           /* passive scalar n: UDC_SV0 + 3*n  (sv0)  */
   UDC_SVM,                           /*                   UDC_SVM + 3*n  (svm)  */
   UDC_SVP,                           /*                   UDC_SVP + 3*n  (svp)  */
-  UDC_FIELD_MAX = UDC_SV0 + 3 * 16,
+  /* ql0 as the reference's `thermo` leaves it (one level low); kept only for the one-equation
+   * closure with moisture (calthv's moist dthvdz reads it), written by udc_thermodynamics */
+  UDC_QL0 = UDC_SV0 + 3 * 16,
+  UDC_FIELD_MAX = UDC_QL0 + 1,
   /* temperature equation (ltempeq): thl0, thlm, thlp live in scalar slot 15 (so nsv <= 15 with ltempeq) */
   UDC_THL0 = UDC_SV0 + 3 * 15, UDC_THLM = UDC_SVM + 3 * 15, UDC_THLP = UDC_SVP + 3 * 15,
   /* one-equation closure (loneeqn): e120, e12m, e12p live in scalar slot 14 (so nsv <= 14 with loneeqn) */
@@ -143,7 +146,8 @@ int udc_set_floor_wf(udc_handle *h, int bcbotm, int bcbott, double thls, double 
  * (src/modtstep.f90:256) and given its top (BCtopq 1 = flux wqtop, 2 = value qt_top, src/modboundary.f90:222-231)
  * and floor (lbottom, BCbotq 1 = flux, "+ wqsurf" as the reference has it, src/modibm.f90:2050-2066) conditions.
  * Without buoyancy qt is a passive field.  With lbuoyancy the moist thermodynamics below must be set up before
- * udc_set_buoyancy; the one-equation closure with moisture (calthv's moist dthvdz) is not built. */
+ * udc_set_buoyancy.  With the one-equation closure the moist thermodynamics must be set up too: calthv's dthvdz takes
+ * its saturated branch where the (level-shifted) ql0 is positive (src/modthermodynamics.f90:154-205). */
 int udc_set_moisture(udc_handle *h, int iadv_qt, int bctopq, double wqtop, double qt_top, int bcbotq, double wqsurf);
 /* Moist thermodynamics (src/modthermodynamics.f90:57-124, lmoist): thls, qts, ps of &BC / modsurfdata
  * (src/modsurfdata.f90:41,58,64) and the level heights zf(kb:ke+kh), zh(kb:ke+kh) ([n = ktot+1] each,

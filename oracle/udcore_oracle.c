@@ -1307,10 +1307,36 @@ void orc_buoyancy_moist(const orc_grid *g, const orc_state *s, double *wp) {
 #undef TH
 
 /* dthvdz of calthv, dry air (src/modthermodynamics.f90:208-232); thl0 may be NULL (no temperature equation) */
+/* moist air (:154-205): set by orc_set_moist_context / orc_substep -- the state whose qt0, ql0 (level-shifted, as the
+ * reference has it) and thermodynamics tables calthv read.  NULL: dry */
+static const orc_state *moist_ctx = NULL;
+void orc_set_moist_context(const orc_state *s) { moist_ctx = s; }
 static double orc_dthvdz(const orc_grid *g, const double *thl0, int i, int j, int k) {
   const double eps1 = 1e-10;
   double d = 0.;
-  if (thl0 && k >= 2) d = (M(thl0, i, j, k + 1) - M(thl0, i, j, k - 1)) / (g->dzh[k + 1] + g->dzh[k]);
+  if (thl0 && k >= 2 && g->lmoist && moist_ctx && moist_ctx->ql0) {
+    const orc_state *s = moist_ctx;
+    const double chi_half = 0.5;                                    /* src/modthermodynamics.f90:39 */
+    const double epsilon = TH_RD / TH_RV, eps_I = 1 / epsilon - 1.;
+    const double qt = M(s->qt0, i, j, k), th = M(thl0, i, j, k), ql = M(s->ql0, i, j, k);
+    const double a_dry = 1. + eps_I * qt, b_dry = eps_I * th;
+    const double dth = M(thl0, i, j, k + 1) - M(thl0, i, j, k - 1), dq = M(s->qt0, i, j, k + 1) - M(s->qt0, i, j, k - 1);
+    const double del_thv_dry = a_dry * dth + b_dry * dq;
+    double dthv = del_thv_dry;
+    if (ql > 0) {
+      const double exnf = s->thermo[(size_t)ORC_TH_EXNF * (g->nz + 2) + k];
+      const double temp = th * exnf + (TH_RLV / TH_CP) * ql;
+      const double qs = qt - ql;
+      const double a_moist = (1. - qt + qs / epsilon * (1. + TH_RLV / (TH_RV * temp))) / (1. + TH_RLV * TH_RLV * qs / (TH_CP * TH_RV * (temp * temp)));
+      const double b_moist = a_moist * TH_RLV / TH_CP - temp;
+      const double c_liquid = a_dry * TH_RLV / TH_CP - th / epsilon;
+      const double del_thv_sat = a_moist * dth + b_moist * dq;
+      const double chi = 2 * chi_half * (g->zf[k] - g->zf[k - 1]) / (g->dzh[k] + g->dzh[k + 1]);
+      const double chi_sat = c_liquid * ql / (del_thv_dry - del_thv_sat);
+      if (chi < chi_sat) dthv = del_thv_sat;
+    }
+    d = dthv / (g->dzh[k + 1] + g->dzh[k]);
+  } else if (thl0 && k >= 2) d = (M(thl0, i, j, k + 1) - M(thl0, i, j, k - 1)) / (g->dzh[k + 1] + g->dzh[k]);
   if (fabs(d) < eps1) d = copysign(eps1, d);
   return d;
 }
@@ -1434,6 +1460,7 @@ void orc_masscorr(const orc_grid *g, int rk3step, double dt, double *up, const d
 /* src/program.f90:132-222: advection, subgrid, forces, poisson, tstep_integrate, halos, boundary */
 void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
   const size_t nc = csize(g);
+  moist_ctx = (g->lmoist && s->thermo && s->ql0) ? s : NULL;
   const double rk3coef = dt / (4. - (double)rk3step);
   orc_advecu_2nd(g, s->u0, s->v0, s->w0, s->pres0, s->up);
   orc_advecv_2nd(g, s->u0, s->v0, s->w0, s->pres0, s->vp);
@@ -1544,5 +1571,5 @@ void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
   if (g->ltempeq) { orc_thl_top(g, s->ekh, s->thlm); orc_thl_top(g, s->ekh, s->thl0); }     /* src/modboundary.f90:207-217 */
   if (g->ltempeq && g->iadv_thl == 7) orc_thl0c_from(g, s->thl0, s->thl0c);                 /* src/modtstep.f90:249 + halos + boundary */
   if (g->lmoist) { orc_qt_top(g, s->ekh, s->qtm); orc_qt_top(g, s->ekh, s->qt0); }          /* src/modboundary.f90:222-231 */
-  if (g->lmoist && g->lbuoyancy && s->thermo) orc_thermodynamics(g, s);                     /* src/program.f90:214 */
+  if (g->lmoist && s->thermo) orc_thermodynamics(g, s);                                     /* src/program.f90:214 */
 }

@@ -169,6 +169,8 @@ enum { ORC_TH_PRESF, ORC_TH_PRESH, ORC_TH_EXNF, ORC_TH_EXNH, ORC_TH_THVH, ORC_TH
  * (src/program.f90:120) and by orc_substep at its end (:214) when g->lmoist && g->lbuoyancy. */
 void orc_thermodynamics(const orc_grid *g, orc_state *s);
 /* forces' buoyancy term with the moist thv0h (src/modforces.f90:73-84, src/modthermodynamics.f90:142-152) */
+/* the state calthv's moist dthvdz (one-equation closure with lmoist) reads: qt0, ql0, the thermodynamics tables; NULL = dry */
+void orc_set_moist_context(const orc_state *s);
 void orc_buoyancy_moist(const orc_grid *g, const orc_state *s, double *wp);
 void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt);
 

@@ -17,7 +17,7 @@ KERNEL_CASES = {
     "k_volflow_12x8x6": 17, "k_thl_12x8x6": 18,
     "k_buoy_12x8x6": 19,
     "k_coriol_12x8x6": 20,
-    "k_tke_12x8x6": 21, "k_tke_thl_12x8x6": 28, "k_qt_12x8x6": 32, "k_moist_12x8x8": 35, "k_uno_12x8x6": 37, "k_src_12x8x8": 39, "k_thlk_12x8x6": 41, "k_svtop_8x8x8": 47,
+    "k_tke_12x8x6": 21, "k_tke_thl_12x8x6": 28, "k_qt_12x8x6": 32, "k_moist_12x8x8": 35, "k_uno_12x8x6": 37, "k_src_12x8x8": 39, "k_thlk_12x8x6": 41, "k_svtop_8x8x8": 47, "k_tke_moist_12x8x8": 50,
 }
 # per-level forcings (lstend, nudge, grwdamp): host-level routines, checked in tests/test_level_forcings.py
 LSF_CASES = {"k_lsf_12x8x24": 29, "run_lsf_16x8x24s": 30, "k_lsfq_12x8x20": 34}

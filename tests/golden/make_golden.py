@@ -293,8 +293,17 @@ CASES.update({
     "run_shift_16x8x12s": ("run", 49, 16, 8, 12,
                            dict(sgs="smag", floor=True, bc="ds = 1.5", oracle="nsub = 6\ndump_at = 3, 6"), 1.06),
 })
+CASES.update({
+    # one-equation closure in moist air: calthv's dthvdz takes its saturated branch inside the cloud
+    # (kernel vectors only, like the other loneeqn cases: the reference never refreshes e120's lateral ghosts)
+    "k_tke_moist_12x8x8": ("kernels", 50, 12, 8, 8,
+                           dict(sgs="oneeqn", floor=True, physics="lmoist = .true.\nltempeq = .true.\nlbuoyancy = .true.",
+                                bc="BCtopT = 1\nBCbotT = 1\nwtsurf = 0.03\nthls = 288.0\nqts = 0.0105\n"
+                                   "BCtopq = 1\nBCbotq = 1\nwqsurf = 4.e-5", oracle="nspin = 4"), 1.05),
+})
 LSF_ONLY = ("k_lsfq_12x8x20", "k_fix1_12x8x6")
-THL_CASES = {"run_moistnr_16x8x12s": dict(dthl=0.25, qt=0.0119, dqt=-6e-5),
+THL_CASES = {"k_tke_moist_12x8x8": dict(dthl=0.25, qt=0.0118, dqt=-8e-5, tke=0.06),
+             "run_moistnr_16x8x12s": dict(dthl=0.25, qt=0.0119, dqt=-6e-5),
              "k_thlk_12x8x6": dict(dthl=0.3), "run_thlk_16x8x12s": dict(dthl=0.25),
              "k_src_12x8x8": dict(psrc=[[(2.2, 1.3, 0.9, 0.5, 0.6), (4.9, 3.1, 2.2, 0.2, 0.4)], [(1.0, 2.0, 1.5, 1.0, 0.5), (5.5, 0.4, 0.3, 0.3, 0.7)]],
                                   lsrc=[[(0.5, 0.5, 0.6, 5.0, 3.5, 1.4, 0.4, 0.5)], [(3.0, 0.2, 2.0, 3.0, 3.8, 2.0, 0.6, 0.45)]]),

@@ -52,6 +52,8 @@ def upload_inputs(core, fix, tag, g, nsv):
     if "thm.presf" in fix and tag == "in":      # what the reference's last thermodynamics call left behind
         core.thermo_state({n: np.concatenate(([0.], fix["thm." + n].data)) if "thm." + n in fix else np.zeros(g.nz + 2)
                            for n in core.TH_TABLES})
+    if "thm.ql0" in fix and tag == "in" and f"{tag}.e120" in fix:      # moist dthvdz of the one-equation closure reads ql0
+        core.upload("ql0", marr(fix, "thm.ql0", g.nz))
     if f"{tag}.e120" in fix:
         core.upload("e120", marr(fix, f"{tag}.e120", g.nz))
         core.upload("e12m", marr(fix, f"{tag}.e12m", g.nz))
@@ -511,7 +513,7 @@ def test_moisture_against_oracle(bctopq):
     core.close()
 
 
-@pytest.mark.parametrize("strat", [False, True], ids=["neutral", "stratified"])
+@pytest.mark.parametrize("strat", [False, True, "moist"], ids=["neutral", "stratified", "moist"])
 def test_tke_closure_runs_against_oracle(strat):
     """One-equation closure (loneeqn) over six fused substeps against the CPU oracle (both with correct periodic
     e120 ghosts; the reference's own multi-substep loneeqn runs are not a target, see tests/golden/make_golden.py)."""
@@ -524,6 +526,10 @@ def test_tke_closure_runs_against_oracle(strat):
     tk.update(thvs=288., ldelta=0)
     core = DynCore(g, sgs=L.SGS_ONEEQN, lbottom=True, z0=0.03)
     kw = dict(ltempeq=True, bctopt=2, thl_top=291., wtsurf=0.02, lbuoyancy=True) if strat else {}
+    moist = strat == "moist"      # calthv's moist dthvdz: saturated branch inside a cloud layer near the floor
+    qkw = dict(bctopq=2, wqtop=0., qt_top=0.0105, wqsurf=4e-5)
+    if moist:
+        kw.update(lmoist=True, thls=288., qts=0.0105, zf=g.zf, zh=g.zh, **qkw)
     o = ol.Oracle(nx, ny, nz, g.dx, g.dy, g.dzf, g.dzh, sgs=3, tke=tk, lbottom=True, z0=0.03, **kw)
     st = random_state(g, seed=99)
     rng = np.random.default_rng(3)
@@ -541,6 +547,15 @@ def test_tke_closure_runs_against_oracle(strat):
         t[0] = t[1]; t[nz + 1] = 2 * 291. - t[nz]
         st["thl0"], st["thlm"] = t, t.copy()
         core.set_tempeq(bctopt=2, thl_top=291., wtsurf=0.02)
+        if moist:
+            q = np.zeros(g.mshape())
+            q[1:-1, 1:-1, 1:-1] = 0.0118 - 8e-5 * g.zf[1:nz + 1, None, None] + 2e-4 * rng.standard_normal((nz, ny, nx))
+            q[:, 0, :] = q[:, ny, :]; q[:, ny + 1, :] = q[:, 1, :]
+            q[:, :, 0] = q[:, :, nx]; q[:, :, nx + 1] = q[:, :, 1]
+            q[nz + 1] = 2 * 0.0105 - q[nz]
+            st["qt0"], st["qtm"] = q, q.copy()
+            core.set_moisture(**qkw)
+            core.set_moist_thermo(288., 0.0105)
         core.set_buoyancy(True)
     core.set_tke(thvs=288.)
     dp = np.zeros(nz + 2); dp[1:nz + 1] = -1e-3
@@ -551,11 +566,18 @@ def test_tke_closure_runs_against_oracle(strat):
     ost.update(dpdxl=dp, dpdyl=dq, e12p=np.zeros(g.mshape()))
     if strat:
         ost["thlp"] = np.zeros(g.mshape())
+    if moist:
+        ost.update(qt0=st["qt0"].copy(), qtm=st["qt0"].copy(), qtp=np.zeros(g.mshape()), thermo=o.thermo_tables(),
+                   ql0=np.zeros(g.mshape()))
+        o.thermodynamics(ost)
     for isub in range(6):
         rk = isub % 3 + 1
         core.substep(rk, 0.05, with_forces=True)
         o.substep(ost, rk, 0.05)
-    for k in ("u0", "v0", "w0", "pres0", "e120", "e12m") + (("thl0",) if strat else ()):
+    if moist:
+        cloud = ost["ql0"][1:nz + 1, 1:-1, 1:-1] > 0
+        assert 0.05 < cloud.mean() < 0.9
+    for k in ("u0", "v0", "w0", "pres0", "e120", "e12m") + (("thl0",) if strat else ()) + (("qt0",) if moist else ()):
         sc = 1.0 if k == "thl0" else None
         assert relerr(nocorner(core.download(k)[1:-1]), nocorner(ost[k][1:-1]), sc) <= RUN_TOL, k
     assert core.download("e120")[1:-1, 1:-1, 1:-1].min() >= 5e-5

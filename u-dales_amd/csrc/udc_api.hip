@@ -449,7 +449,6 @@ extern "C" int udc_set_moisture(udc_handle *h, int iadv_qt, int bctopq, double w
   if (bctopq != 1 && bctopq != 2) { udc_set_error("udc_set_moisture: BCtopq must be 1 (flux) or 2 (value)"); return 1; }
   if (h->p.lbottom && bcbotq != 1) { udc_set_error("udc_set_moisture: BCbotq must be 1 (flux) (src/modibm.f90:2051,2062-2064)"); return 1; }
   if (h->lbuoyancy) { udc_set_error("udc_set_moisture: call it before udc_set_buoyancy (and udc_set_moist_thermo in between)"); return 1; }
-  if (h->p.sgs == UDC_SGS_ONEEQN) { udc_set_error("udc_set_moisture: the moist dthvdz of the one-equation closure is not built"); return 1; }
   const bool have = (int)h->fields.size() > UDC_QT0 && h->fields[UDC_QT0];
   if (!have) {
     for (int q = 0; q < 3; ++q)
@@ -481,6 +480,7 @@ extern "C" int udc_set_moist_thermo(udc_handle *h, double thls, double qts, doub
   if (!h->mt) HIP_OK(hipMalloc(&h->mt, sizeof(double) * t.size()));
   HIP_OK(hipMemcpy(h->mt, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
   h->thls = thls; h->qts = qts; h->ps = ps; h->lqlnr = lqlnr ? 1 : 0;
+  if (h->p.sgs == UDC_SGS_ONEEQN && alloc_field(h, UDC_QL0)) return 1;
   h->mt_valid = false;
   return 0;
 }
@@ -517,7 +517,6 @@ extern "C" int udc_set_tke(udc_handle *h, double cm, double cn, double ch1, doub
   HIP_OK(hipSetDevice(h->device));
   if (h->cfg.nsv > 14) { udc_set_error("udc_set_tke: e12 uses scalar slot 14, nsv must be <= 14"); return 1; }
   if (!(thvs > 0.) || !(e12min > 0.)) { udc_set_error("udc_set_tke: thvs and e12min must be positive"); return 1; }
-  if (h->lmoist) { udc_set_error("udc_set_tke: the moist dthvdz of the one-equation closure is not built"); return 1; }
   const bool have = (int)h->fields.size() > UDC_E120 && h->fields[UDC_E120];
   if (!have) {
     for (int q = 0; q < 3; ++q)
@@ -531,6 +530,7 @@ extern "C" int udc_set_tke(udc_handle *h, double cm, double cn, double ch1, doub
   sl.adv = 2; sl.top = 3; sl.topval = e12min; sl.floorflux = 0.; sl.tke = true;
   h->tke = udc_handle::Tke{cm, cn, ch1, ch2, ce1, ce2, e12min, grav, thvs, ldelta ? 1 : 0};
   h->p.sgs = UDC_SGS_ONEEQN;
+  if (h->mt && alloc_field(h, UDC_QL0)) return 1;      // calthv's moist dthvdz reads ql0
   return 0;
 }
 
@@ -774,7 +774,7 @@ extern "C" int udc_substep(udc_handle *h, int rk3step, double dt, int with_force
   scalar_halo_list(h, rk3step, s);
   if (!s.empty() && k_halo_y(h, s.data(), (int)s.size(), 2)) return 1;
   if (!fold || !h->slots.empty()) { if (k_top_bottom(h)) return 1; }
-  if (h->lmoist && h->lbuoyancy && k_thermodynamics(h)) return 1;      // src/program.f90:214
+  if (h->lmoist && h->mt && k_thermodynamics(h)) return 1;             // src/program.f90:214
   return 0;
 }
 

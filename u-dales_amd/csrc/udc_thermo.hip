@@ -3,6 +3,7 @@
 // slab averages (:262-279) and the per-level forcings tend += A(k) + B(k) field of lstend / nudge / grwdamp
 // (src/modforces.f90:719-860, src/modboundary.f90:1447-1488; tables built on the host, udcore/forcings.py).
 #include "udc_internal.h"
+#include <algorithm>
 
 namespace {
 
@@ -93,7 +94,7 @@ constexpr int MS_ROWS = 8;
 template <bool QL>
 __global__ __launch_bounds__(256) void moist_sums_kernel(Geo g, int gx, const double *__restrict__ thl, const double *__restrict__ qt,
                                                           const double *__restrict__ presf, const double *__restrict__ exnf,
-                                                          double *__restrict__ part, int nr) {
+                                                          double *__restrict__ part, int nr, double *__restrict__ ql0) {
   __shared__ double sw[3][4];
   const int tile = blockIdx.x, k = blockIdx.y, kf = k + 1;
   const int by = tile / gx, bx = tile - by * gx;
@@ -107,7 +108,11 @@ __global__ __launch_bounds__(256) void moist_sums_kernel(Geo g, int gx, const do
       const long c = g.idx(i, j, k);
       const double a = thl[c], b = qt[c];
       v[0] += a; v[1] += b;
-      if (QL) v[2] += th_cond(nr, a, b, pf, ef);
+      if (QL) {
+        const double ql = th_cond(nr, a, b, pf, ef);
+        v[2] += ql;
+        if (ql0) ql0[c - g.sz] = ql;      // the reference's ql0 holds level k at k-1 (sequence association in `thermo`)
+      }
     }
   }
 #pragma unroll
@@ -319,12 +324,21 @@ int k_thermodynamics(udc_handle *h) {
   double *mt = h->mt, *sums = mt + udc_handle::MT_SUMS * n2;
   const double cnt = (double)g.nx * (double)h->cfg.jtot;
   const DiagArgs da{g.nz, cnt, h->thls, h->qts, h->ps, h->grav};
+  double *ql0 = nullptr;      // kept as a field only where something reads it: the one-equation closure's moist dthvdz
+  if (h->p.sgs == UDC_SGS_ONEEQN) {
+    if ((int)h->fields.size() <= UDC_QL0 || !h->fields[UDC_QL0]) {
+      h->fields.resize(std::max((size_t)UDC_QL0 + 1, h->fields.size()), nullptr);
+      HIP_OK(hipMalloc(&h->fields[UDC_QL0], sizeof(double) * g.n));
+      HIP_OK(hipMemsetAsync(h->fields[UDC_QL0], 0, sizeof(double) * g.n, h->stream));
+    }
+    ql0 = h->fields[UDC_QL0];
+  }
   PROF(h, "thermodynamics");
   for (int pass = h->mt_valid ? 1 : 0; pass < 2; ++pass) {
     const dim3 gr((unsigned)mtiles, (unsigned)ke1), b(64, 4);
     if (pass) hipLaunchKernelGGL(moist_sums_kernel<true>, gr, b, 0, h->stream, g, tg.gx, thl, qt, (const double *)(mt + udc_handle::MT_PRESF * n2),
-                                 (const double *)(mt + udc_handle::MT_EXNF * n2), h->lev_part, h->lqlnr);
-    else hipLaunchKernelGGL(moist_sums_kernel<false>, gr, b, 0, h->stream, g, tg.gx, thl, qt, (const double *)nullptr, (const double *)nullptr, h->lev_part, 0);
+                                 (const double *)(mt + udc_handle::MT_EXNF * n2), h->lev_part, h->lqlnr, ql0);
+    else hipLaunchKernelGGL(moist_sums_kernel<false>, gr, b, 0, h->stream, g, tg.gx, thl, qt, (const double *)nullptr, (const double *)nullptr, h->lev_part, 0, (double *)nullptr);
     hipLaunchKernelGGL(levelsum_final_kernel, dim3((unsigned)(3 * ke1)), dim3(256), 0, h->stream, mtiles, h->lev_part, sums);
     HIP_OK(hipGetLastError());
     if (comm_allreduce(h, sums, 3 * ke1, 1)) return 1;       // avexy_ibm's MPI_ALLREDUCE over the slabs

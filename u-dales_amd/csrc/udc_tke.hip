@@ -22,19 +22,52 @@ __device__ __forceinline__ double dthvdz_at(const Geo &g, const Metrics &m, cons
   if (fabs(d) < eps1) d = copysign(eps1, d);
   return d;
 }
+// the same for moist air (:154-205): the unsaturated jump, or the saturated one where the mixed parcel stays saturated.
+// ql0 is the reference's level-shifted field, exnf / zf the thermodynamics tables (index = reference k)
+struct MoistK { const double *qt, *ql0, *exnf, *zf; };
+__device__ __forceinline__ double dthvdz_moist_at(const Geo &g, const Metrics &m, const double *__restrict__ thl, const MoistK &q, long c, int k) {
+  const double eps1 = 1e-10, rd = 287.04, rv = 461.5, cp = 1004., rlv = 2.26e6, chi_half = 0.5;
+  double d = 0.;
+  if (k >= 1) {
+    const int kf = k + 1;
+    const double epsilon = rd / rv, eps_I = 1 / epsilon - 1.;
+    const double a_dry = 1. + eps_I * q.qt[c], b_dry = eps_I * thl[c];
+    const double dth = thl[c + g.sz] - thl[c - g.sz], dq = q.qt[c + g.sz] - q.qt[c - g.sz];
+    const double del_thv_dry = a_dry * dth + b_dry * dq;
+    double dthv = del_thv_dry;
+    const double ql = q.ql0[c];
+    if (ql > 0) {
+      const double temp = thl[c] * q.exnf[kf] + (rlv / cp) * ql;
+      const double qs = q.qt[c] - ql;
+      const double a_moist = (1. - q.qt[c] + qs / epsilon * (1. + rlv / (rv * temp))) / (1. + rlv * rlv * qs / (cp * rv * (temp * temp)));
+      const double b_moist = a_moist * rlv / cp - temp;
+      const double c_liquid = a_dry * rlv / cp - thl[c] / epsilon;
+      const double del_thv_sat = a_moist * dth + b_moist * dq;
+      const double chi = 2 * chi_half * (q.zf[kf] - q.zf[kf - 1]) / (m.dzh[kf] + m.dzh[kf + 1]);
+      const double chi_sat = c_liquid * ql / (del_thv_dry - del_thv_sat);
+      if (chi < chi_sat) dthv = del_thv_sat;
+    }
+    d = dthv / (m.dzh[kf + 1] + m.dzh[kf]);
+  }
+  if (fabs(d) < eps1) d = copysign(eps1, d);
+  return d;
+}
+__device__ __forceinline__ double dthvdz_any(const Geo &g, const Metrics &m, const double *__restrict__ thl, const MoistK &q, long c, int k) {
+  return q.ql0 ? dthvdz_moist_at(g, m, thl, q, c, k) : dthvdz_at(g, m, thl, c, k);
+}
 __device__ __forceinline__ double tke_zlt(const TkeK &t, double delta, double e, double dthvdz) {
   if (t.ldelta || dthvdz <= 0) return delta;
   return fmin(delta, t.cn * e / sqrt(t.grav_thvs * fabs(dthvdz)));
 }
 // closure, loneeqn branch: src/modsubgrid.f90:363-400 (damp = 1)
 __global__ __launch_bounds__(256) void tke_closure_kernel(Geo g, TileGrid tg, Metrics m, TkeK t, const double *__restrict__ e12,
-    const double *__restrict__ thl, double *__restrict__ ekm, double *__restrict__ ekh) {
+    const double *__restrict__ thl, MoistK mq, double *__restrict__ ekm, double *__restrict__ ekh) {
   int i, j, k;
   if (!tile_decode(g, tg, i, j, k)) return;
   const long c = g.idx(i, j, k);
   const double delta = m.delta[k + 1];
   const double e = e12[c];
-  const double dth = dthvdz_at(g, m, thl, c, k);
+  const double dth = dthvdz_any(g, m, thl, mq, c, k);
   double em, eh;
   if (t.ldelta || dth <= 0) {
     em = t.cm * delta * 1. * e;
@@ -51,7 +84,7 @@ __global__ __launch_bounds__(256) void tke_closure_kernel(Geo g, TileGrid tg, Me
 // written in the reference)
 __global__ __launch_bounds__(256) void tke_sources_kernel(Geo g, TileGrid tg, Metrics m, TkeK t, const double *__restrict__ u0,
     const double *__restrict__ v0, const double *__restrict__ w0, const double *__restrict__ e12, const double *__restrict__ thl,
-    const double *__restrict__ ekm, const double *__restrict__ ekh, double *__restrict__ e12p) {
+    const double *__restrict__ ekm, const double *__restrict__ ekh, double *__restrict__ e12p, MoistK mq) {
   int i, j, k;
   if (!tile_decode(g, tg, i, j, k) || k < 1) return;
   const long r0 = g.idx(0, j, k);
@@ -74,7 +107,7 @@ __global__ __launch_bounds__(256) void tke_sources_kernel(Geo g, TileGrid tg, Me
                         + sq((v0[c + sy] - v0[c + sy - sz]) * hk + (w0[c + sy] - w0[c]) * dyi)
                         + sq((v0[c + sy + sz] - v0[c + sy]) * hkp + (w0[c + sy + sz] - w0[c + sz]) * dyi));
   const double e = e12[c], delta = m.delta[kf];
-  const double dth = dthvdz_at(g, m, thl, c, k);
+  const double dth = dthvdz_any(g, m, thl, mq, c, k);
   const double zlt = tke_zlt(t, delta, e, dth);
   const double sbshr = (ekm[c] - t.numol) * tdef2 / (2 * e);
   const double sbbuo = -(ekh[c] - t.numol * t.prandtlmoli) * t.grav_thvs * dth / (2 * e);
@@ -100,22 +133,39 @@ static TkeK tke_consts(udc_handle *h) {
 static const double *thl_or_null(udc_handle *h) {
   return ((int)h->fields.size() > UDC_THL0 && h->fields[UDC_THL0]) ? h->fields[UDC_THL0] : nullptr;
 }
+// moist dthvdz inputs, or nulls for dry air; fails when the thermodynamics have not run yet (ql0, exnf undefined)
+static int moist_inputs(udc_handle *h, MoistK &q) {
+  q = MoistK{nullptr, nullptr, nullptr, nullptr};
+  if (!h->lmoist) return 0;
+  if (!h->mt || !h->mt_valid || (int)h->fields.size() <= UDC_QL0 || !h->fields[UDC_QL0]) {
+    udc_set_error("one-equation closure with moisture: set up udc_set_moist_thermo and call udc_thermodynamics before the first "
+                  "substep (calthv's dthvdz reads ql0 and exnf, src/modthermodynamics.f90:154-205)");
+    return 1;
+  }
+  const int n2 = h->g.nz + 2;
+  q = MoistK{h->fields[UDC_QT0], h->fields[UDC_QL0], h->mt + udc_handle::MT_EXNF * n2, h->mt + udc_handle::MT_ZF * n2};
+  return 0;
+}
 int k_tke_closure(udc_handle *h) {
   const Geo &g = h->g;
   dim3 b(64, 4, 1), gr = cell_grid(g, b);
+  MoistK mq;
+  if (moist_inputs(h, mq)) return 1;
   PROF(h, "closure");
   hipLaunchKernelGGL(tke_closure_kernel, gr, b, 0, h->stream, g, tile_grid(g), h->m, tke_consts(h), h->fields[UDC_E120],
-                     thl_or_null(h), h->fields[UDC_EKM], h->fields[UDC_EKH]);
+                     thl_or_null(h), mq, h->fields[UDC_EKM], h->fields[UDC_EKH]);
   HIP_OK(hipGetLastError());
   return 0;
 }
 int k_tke_sources(udc_handle *h) {
   const Geo &g = h->g;
   dim3 b(64, 4, 1), gr = cell_grid(g, b);
+  MoistK mq;
+  if (moist_inputs(h, mq)) return 1;
   PROF(h, "tke_sources");
   hipLaunchKernelGGL(tke_sources_kernel, gr, b, 0, h->stream, g, tile_grid(g), h->m, tke_consts(h), h->fields[UDC_U0],
                      h->fields[UDC_V0], h->fields[UDC_W0], h->fields[UDC_E120], thl_or_null(h), h->fields[UDC_EKM],
-                     h->fields[UDC_EKH], h->fields[UDC_E12P]);
+                     h->fields[UDC_EKH], h->fields[UDC_E12P], mq);
   HIP_OK(hipGetLastError());
   return 0;
 }

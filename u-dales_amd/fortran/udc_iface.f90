@@ -300,7 +300,7 @@ contains
     if (lmoist) then       ! total water; with buoyancy the moist thermodynamics (thermo, diagfld, calthv) too
       call udc_check(udc_set_moisture(udc_h, int(iadv_qt, c_int), int(BCtopq, c_int), real(wqtop, c_double), &
                                       real(qt_top, c_double), int(BCbotq, c_int), real(wqsurf, c_double)), 'udc_set_moisture')
-      if (ltempeq .and. lbuoyancy) then
+      if (ltempeq .and. (lbuoyancy .or. loneeqn_dev())) then      ! moist buoyancy / calthv's moist dthvdz
         call udc_check(udc_set_moist_thermo(udc_h, real(thls, c_double), real(qts, c_double), real(ps, c_double), &
                                             zf(kb:ke + kh), zh(kb:ke + kh), int(ktot + 1, c_int), &
                                             merge(1_c_int, 0_c_int, lqlnr)), 'udc_set_moist_thermo')

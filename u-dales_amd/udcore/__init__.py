@@ -33,16 +33,14 @@ def from_deck(deck, device=0, rank=0, nranks=1):
     if lbottom and (bcbotm == 2 or (bcbott == 2 and deck.get("PHYSICS", "ltempeq"))):
         core.set_floor_wf(bcbotm, bcbott, float(deck.get("BC", "thls")), float(deck.get("BC", "z0h")), 0.71)
     if deck.get("PHYSICS", "lmoist"):
-        if sgs == 3:
-            raise ValueError("lmoist with loneeqn: calthv's moist dthvdz is not built")
         iadv = int(deck.get("DYNAMICS", "iadv_qt"))
         core.set_moisture(iadv_qt=int(deck.get("DYNAMICS", "iadv_mom")) if iadv < 0 else iadv,
                           bctopq=int(deck.get("BC", "BCtopq")), wqtop=float(deck.get("BC", "wqtop")),
                           qt_top=float(deck.get("BC", "qt_top")), bcbotq=int(deck.get("BC", "BCbotq")),
                           wqsurf=float(deck.get("BC", "wqsurf")))
-        if deck.get("PHYSICS", "lbuoyancy"):
+        if deck.get("PHYSICS", "lbuoyancy") or sgs == 3:      # the moist thermodynamics feed the buoyancy and calthv's dthvdz
             if not deck.get("PHYSICS", "ltempeq"):
-                raise ValueError("lmoist with lbuoyancy needs ltempeq on the device path")
+                raise ValueError("lmoist with lbuoyancy or loneeqn needs ltempeq on the device path")
             core.set_moist_thermo(float(deck.get("BC", "thls")), float(deck.get("BC", "qts")), float(deck.get("BC", "ps")),
                                   lqlnr=bool(deck.get("DYNAMICS", "lqlnr")))
     if deck.get("PHYSICS", "ltempeq") and deck.get("PHYSICS", "lbuoyancy"):

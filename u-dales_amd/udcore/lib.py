@@ -22,7 +22,7 @@ E120, E12M, E12P = SV0 + 42, SVM + 42, SVP + 42      # one-equation closure: sca
 QT0, QTM, QTP = SV0 + 39, SVM + 39, SVP + 39         # moisture: scalar slot 13
 FIELD_IDS = dict(u0=U0, v0=V0, w0=W0, um=UM, vm=VM, wm=WM, up=UP, vp=VP, wp=WP, pres0=PRES0, p=P,
                  ekm=EKM, ekh=EKH, thl0=THL0, thlm=THLM, thlp=THLP, e120=E120, e12m=E12M, e12p=E12P,
-                 qt0=QT0, qtm=QTM, qtp=QTP)
+                 qt0=QT0, qtm=QTM, qtp=QTP, ql0=SV0 + 48)
 SGS_DNS, SGS_SMAGORINSKY, SGS_VREMAN, SGS_ONEEQN = 0, 1, 2, 3
 
 EXPORTS = ["udc_create", "udc_destroy", "udc_last_error", "udc_version", "udc_comm_unique_id",

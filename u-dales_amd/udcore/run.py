@@ -28,8 +28,6 @@ def check_supported(deck):
     g = deck.get
     if g("RUN", "libm") and int(g("WALLS", "nfcts")) > 0:
         _refuse("immersed boundaries (libm with facets) are not on the device path")
-    if g("PHYSICS", "lmoist") and g("NAMSUBGRID", "loneeqn") and not (g("NAMSUBGRID", "lsmagorinsky") or g("NAMSUBGRID", "lvreman")):
-        _refuse("lmoist with the one-equation closure (moist dthvdz) is not on the device path")
     if int(g("BC", "BCxm")) != 1 or int(g("BC", "BCym")) != 1:
         _refuse("only periodic lateral boundaries (BCxm = BCym = 1) are on the device path")
     if int(g("DYNAMICS", "ipoiss")) != 0 or int(g("BC", "BCzp")) != 1:
