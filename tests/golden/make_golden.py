@@ -301,7 +301,7 @@ CASES.update({
                                 bc="BCtopT = 1\nBCbotT = 1\nwtsurf = 0.03\nthls = 288.0\nqts = 0.0105\n"
                                    "BCtopq = 1\nBCbotq = 1\nwqsurf = 4.e-5", oracle="nspin = 4"), 1.05),
 })
-LSF_ONLY = ("k_lsfq_12x8x20", "k_fix1_12x8x6")
+LSF_ONLY = ("k_lsf_12x8x24", "k_lsfq_12x8x20", "k_fix1_12x8x6")
 THL_CASES = {"k_tke_moist_12x8x8": dict(dthl=0.25, qt=0.0118, dqt=-8e-5, tke=0.06),
              "run_moistnr_16x8x12s": dict(dthl=0.25, qt=0.0119, dqt=-6e-5),
              "k_thlk_12x8x6": dict(dthl=0.3), "run_thlk_16x8x12s": dict(dthl=0.25),
