@@ -204,6 +204,8 @@ int udc_coriolis(udc_handle *h);
  *   when = 1: after it (grwdamp, :191).  Registered forcings are applied by udc_level_forcings(h, when) and, when
  *   with_forces != 0, inside udc_substep. */
 int udc_slab_average(udc_handle *h, int field, double *avg, int n);
+/* the same for nf <= 16 fields at once (avg[q n + k]): one reduction, one copy back, one synchronisation */
+int udc_slab_averages(udc_handle *h, const int *fields, int nf, double *avg, int n);
 int udc_set_level_forcing(udc_handle *h, int tend, int src, const double *A, const double *B, int n, int when);
 int udc_level_forcings(udc_handle *h, int when);
 /* masscorr    src/modforces.f90:328     volume-flow branches: up += (uflowrate - <um + rk3coef up>)/rk3coef (luvolflowr,

@@ -217,6 +217,7 @@ extern "C" int udc_destroy(udc_handle *h) {
   if (h->ug) hipFree(h->ug);
   if (h->lev_part) hipFree(h->lev_part);
   if (h->lev_sum) hipFree(h->lev_sum);
+  if (h->lev_sum16) hipFree(h->lev_sum16);
   hipStreamDestroy(h->stream);
   delete h;
   return 0;
@@ -590,6 +591,12 @@ extern "C" int udc_slab_average(udc_handle *h, int field, double *avg, int n) {
   HIP_OK(hipSetDevice(h->device));
   if (field >= UDC_UM && field <= UDC_WM && um_materialise(h)) return 1;
   return k_slab_average(h, field, avg, n);
+}
+
+extern "C" int udc_slab_averages(udc_handle *h, const int *fields, int nf, double *avg, int n) {
+  HIP_OK(hipSetDevice(h->device));
+  if (um_materialise(h)) return 1;
+  return k_slab_averages(h, fields, nf, avg, n);
 }
 
 extern "C" int udc_set_level_forcing(udc_handle *h, int tend, int src, const double *A, const double *B, int n, int when) {

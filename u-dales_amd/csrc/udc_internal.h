@@ -141,6 +141,7 @@ struct udc_handle {
   int lbuoyancy = 0;           // forces' buoyancy term (dry air), needs the temperature equation
   double grav = 9.81;
   double *lev_part = nullptr, *lev_sum = nullptr;   // per-level slab sums (thvh)
+  double *lev_sum16 = nullptr;                      // udc_slab_averages: up to 16 fields x (nz+2)
   size_t lev_cap = 0;
   // moist thermodynamics (udc_set_moist_thermo): MT_N tables of [nz+2] indexed by the reference's k, kept between
   // thermodynamics calls (presf/exnf feed the next call's `thermo`, presh/exnh/thvh the next forces)
@@ -247,6 +248,7 @@ int k_scalsource(udc_handle *h);
 int k_shifted_pbcs(udc_handle *h, bool wrap_vp);
 int k_thermodynamics(udc_handle *h);
 int k_slab_average(udc_handle *h, int field, double *avg_host, int n);
+int k_slab_averages(udc_handle *h, const int *fields, int nf, double *avg_host, int n);
 int k_level_forcings(udc_handle *h, int when, bool wrap_vp);
 int k_tke_closure(udc_handle *h);                  // closure, loneeqn branch
 int k_tke_sources(udc_handle *h);                  // sources: e12p += shear + buoyancy + dissipation

@@ -263,29 +263,34 @@ __global__ __launch_bounds__(256) void level_affine_kernel(Geo g, TileGrid tg, c
 
 }  // namespace
 
-int k_slab_average(udc_handle *h, int field, double *avg_host, int n) {
+// slab averages of nf fields in one go: one all-reduce, one copy back, one synchronisation
+int k_slab_averages(udc_handle *h, const int *fields, int nf, double *avg_host, int n) {
   const Geo &g = h->g;
   if (n < 1 || n > g.nz + 1) { udc_set_error("udc_slab_average: 1 <= n <= ktot+1"); return 1; }
-  if (field < 0 || field >= (int)h->fields.size() || !h->fields[field]) { udc_set_error("udc_slab_average: unknown field %d", field); return 1; }
+  if (nf < 1 || nf > 16 || (size_t)nf * n > 4096) { udc_set_error("udc_slab_averages: at most 16 fields and 4096 values per call"); return 1; }
+  for (int q = 0; q < nf; ++q)
+    if (fields[q] < 0 || fields[q] >= (int)h->fields.size() || !h->fields[fields[q]]) { udc_set_error("udc_slab_average: unknown field %d", fields[q]); return 1; }
   const TileGrid tg = tile_grid(g);
-  const size_t need = (size_t)tg.tiles * (g.nz + 1);
+  const size_t need = (size_t)tg.tiles * n * nf;
   if (h->lev_cap < need) {
     if (h->lev_part) HIP_OK(hipFree(h->lev_part));
     HIP_OK(hipMalloc(&h->lev_part, sizeof(double) * need));
     h->lev_cap = need;
   }
-  if (!h->lev_sum) HIP_OK(hipMalloc(&h->lev_sum, sizeof(double) * (g.nz + 2)));
-  hipLaunchKernelGGL(levelsum_plain_kernel, dim3((unsigned)tg.tiles, (unsigned)n), dim3(64, 4), 0, h->stream, g, tg.gx,
-                     (const double *)h->fields[field], h->lev_part);
-  hipLaunchKernelGGL(levelsum_final_kernel, dim3((unsigned)n), dim3(256), 0, h->stream, tg.tiles, h->lev_part, h->lev_sum);
+  if (!h->lev_sum16) HIP_OK(hipMalloc(&h->lev_sum16, sizeof(double) * 16 * (g.nz + 2)));
+  for (int q = 0; q < nf; ++q)
+    hipLaunchKernelGGL(levelsum_plain_kernel, dim3((unsigned)tg.tiles, (unsigned)n), dim3(64, 4), 0, h->stream, g, tg.gx,
+                       (const double *)h->fields[fields[q]], h->lev_part + (size_t)q * n * tg.tiles);
+  hipLaunchKernelGGL(levelsum_final_kernel, dim3((unsigned)(n * nf)), dim3(256), 0, h->stream, tg.tiles, h->lev_part, h->lev_sum16);
   HIP_OK(hipGetLastError());
-  if (comm_allreduce(h, h->lev_sum, n, 1)) return 1;
-  HIP_OK(hipMemcpyAsync(h->red_host, h->lev_sum, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+  if (comm_allreduce(h, h->lev_sum16, n * nf, 1)) return 1;
+  HIP_OK(hipMemcpyAsync(h->red_host, h->lev_sum16, sizeof(double) * n * nf, hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
   const double cnt = (double)g.nx * (double)h->cfg.jtot;
-  for (int k = 0; k < n; ++k) avg_host[k] = h->red_host[k] / cnt;
+  for (int k = 0; k < n * nf; ++k) avg_host[k] = h->red_host[k] / cnt;
   return 0;
 }
+int k_slab_average(udc_handle *h, int field, double *avg_host, int n) { return k_slab_averages(h, &field, 1, avg_host, n); }
 
 int k_level_forcings(udc_handle *h, int when, bool wrap_vp) {
   const Geo &g = h->g;

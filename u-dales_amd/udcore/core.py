@@ -246,6 +246,15 @@ class DynCore:
         L._check(self.lib.udc_slab_average(self.h, fid, a[1:].ctypes.data_as(L.DP), self.g.nz + 1), "udc_slab_average")
         return a
 
+    def slab_averages(self, fields):
+        """Horizontal means of several fields per level in one device round trip: {name: [nz+2] by the reference's k}."""
+        from .forcings import field_id
+        ids = (C.c_int * len(fields))(*[field_id(f) if isinstance(f, str) else f for f in fields])
+        n = self.g.nz + 1
+        a = np.zeros((len(fields), n))
+        L._check(self.lib.udc_slab_averages(self.h, ids, len(fields), a.ctypes.data_as(L.DP), n), "udc_slab_averages")
+        return {f: np.concatenate(([0.], a[q])) for q, f in enumerate(fields)}
+
     def set_level_forcing(self, tend, src, A, B, when=0):
         """tend(i,j,k) += A(k) + B(k) src(i,j,k) inside every following substep; A=None removes it."""
         from .forcings import field_id

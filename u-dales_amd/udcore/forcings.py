@@ -169,6 +169,8 @@ class LevelForcings:
 
     def averages(self):
         names = ["u0", "v0"] + (["thl0"] if self.ltempeq else []) + (["qt0"] if self.lmoist else []) + [f"sv0_{n}" for n in range(self.core.nsv)]
+        if hasattr(self.core, "slab_averages"):
+            return self.core.slab_averages(names)
         return {n: self.core.slab_average(n) for n in names}
 
     def update(self, rk3step=None, dt=None):
