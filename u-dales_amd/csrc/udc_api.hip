@@ -205,7 +205,7 @@ extern "C" int udc_destroy(udc_handle *h) {
   pois_destroy(h);
   comm_destroy(h);
   for (int q = 0; q < 4; ++q) if (h->halo_buf[q]) hipFree(h->halo_buf[q]);
-  for (auto &f : h->level_forcings) { if (f.A) hipFree(f.A); if (f.B) hipFree(f.B); }
+  for (auto &f : h->level_forcings) { if (f.A) hipFree(f.A); if (f.stage) hipHostFree(f.stage); if (f.copied) hipEventDestroy(f.copied); }
   for (double *p : h->fields) if (p) hipFree(p);
   if (h->metrics_dev) hipFree(h->metrics_dev);
   if (h->red) hipFree(h->red);
@@ -607,24 +607,33 @@ extern "C" int udc_set_level_forcing(udc_handle *h, int tend, int src, const dou
   when = when ? 1 : 0;
   while (it != h->level_forcings.end() && !(it->tend == tend && it->when == when)) ++it;
   if (!A) {                       // remove
-    if (it != h->level_forcings.end()) { hipFree(it->A); hipFree(it->B); h->level_forcings.erase(it); }
+    if (it != h->level_forcings.end()) {
+      HIP_OK(hipStreamSynchronize(h->stream));
+      hipFree(it->A); hipHostFree(it->stage); hipEventDestroy(it->copied);
+      h->level_forcings.erase(it);
+    }
     return 0;
   }
   if (n != h->g.nz) { udc_set_error("udc_set_level_forcing: expected %d levels", h->g.nz); return 1; }
   if (it == h->level_forcings.end()) {
     udc_handle::LevelForcing f;
     f.tend = tend; f.when = when;
-    HIP_OK(hipMalloc(&f.A, sizeof(double) * (n + 2)));
-    HIP_OK(hipMalloc(&f.B, sizeof(double) * (n + 2)));
+    HIP_OK(hipMalloc(&f.A, sizeof(double) * 2 * (n + 2)));
+    f.B = f.A + (n + 2);
+    HIP_OK(hipHostMalloc(&f.stage, sizeof(double) * 2 * (n + 2)));
+    HIP_OK(hipEventCreateWithFlags(&f.copied, hipEventDisableTiming));
+    HIP_OK(hipEventRecord(f.copied, h->stream));
     h->level_forcings.push_back(f);
     it = h->level_forcings.end() - 1;
   }
   it->src = (src >= 0 && B) ? src : -1;
-  std::vector<double> t(2 * (n + 2), 0.0);
+  // one asynchronous upload from the entry's pinned block (waiting first for the previous upload of the same entry)
+  HIP_OK(hipEventSynchronize(it->copied));
+  double *t = it->stage;
+  for (int k = 0; k < 2 * (n + 2); ++k) t[k] = 0.0;
   for (int k = 1; k <= n; ++k) { t[k] = A[k - 1]; if (B) t[n + 2 + k] = B[k - 1]; }
-  HIP_OK(hipMemcpyAsync(it->A, t.data(), sizeof(double) * (n + 2), hipMemcpyHostToDevice, h->stream));
-  HIP_OK(hipMemcpyAsync(it->B, t.data() + n + 2, sizeof(double) * (n + 2), hipMemcpyHostToDevice, h->stream));
-  HIP_OK(hipStreamSynchronize(h->stream));
+  HIP_OK(hipMemcpyAsync(it->A, t, sizeof(double) * 2 * (n + 2), hipMemcpyHostToDevice, h->stream));
+  HIP_OK(hipEventRecord(it->copied, h->stream));
   return 0;
 }
 

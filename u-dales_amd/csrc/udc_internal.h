@@ -123,7 +123,8 @@ struct udc_handle {
   std::vector<int> slots;
   // one-equation closure constants (udc_set_tke)
   struct Tke { double cm = 0., cn = 0., ch1 = 0., ch2 = 0., ce1 = 0., ce2 = 0., e12min = 5e-5, grav = 9.81, thvs = 0.; int ldelta = 0; } tke;
-  struct LevelForcing { int tend = -1, src = -1, when = 0; double *A = nullptr, *B = nullptr; };   // udc_set_level_forcing
+  // udc_set_level_forcing: A and B share one device block; `stage` is its pinned host copy and `copied` marks the last upload done
+  struct LevelForcing { int tend = -1, src = -1, when = 0; double *A = nullptr, *B = nullptr, *stage = nullptr; hipEvent_t copied = nullptr; };
   std::vector<LevelForcing> level_forcings;
   int coriolis_mode = 0;       // 0 off, 1 lcoriol, 2 lprofforc (src/modforces.f90:600-717)
   double om22 = 0., om23 = 0.;

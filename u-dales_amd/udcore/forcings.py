@@ -99,72 +99,62 @@ class LevelForcings:
         scal = [("thl0", "thlp")] if self.ltempeq else []
         scal += [("qt0", "qtp")] if self.lmoist else []
         scal += [(f"sv0_{n}", f"svp_{n}") for n in range(self.core.nsv)]
+        # (numpy slices over k: the same elementwise arithmetic as a loop over the levels, without the Python overhead)
+        K = slice(2, nz + 1)                                     # k = kb+1 .. ke
+        Kp, Km = slice(3, nz + 2), slice(1, nz)                  # k+1, k-1
         if self.subsidence:                                      # lstend
+            down = whls[Kp] < 0
             for name, tend in scal:
-                a = av[name]
+                a = np.asarray(av[name])
                 A = acc(tend)[1]
                 if whls[2] < 0:                                  # k = kb, src/modforces.f90:768-781
                     A[1] -= whls[2] * (a[2] - a[1]) / dzh[2]
-                for k in range(2, nz + 1):                       # :790-821
-                    if whls[k + 1] < 0:
-                        A[k] -= whls[k + 1] * (a[k + 1] - a[k]) / dzh[k + 1]
-                    else:
-                        A[k] -= whls[k] * (a[k] - a[k - 1]) / dzh[k]
+                A[K] -= np.where(down, whls[Kp] * (a[Kp] - a[K]) / dzh[Kp], whls[K] * (a[K] - a[Km]) / dzh[K])   # :790-821
+        Ka = slice(1, nz + 1)
         if self.qtls:                                            # lstend, src/modforces.f90:783,818
             A = acc("qtp")[1]
-            for k in range(1, nz + 1):
-                A[k] += -av["u0"][k] * self.dqtdxls[k] - av["v0"][k] * self.dqtdyls[k] + self.dqtdtls[k]
+            A[Ka] += -np.asarray(av["u0"])[Ka] * self.dqtdxls[Ka] - np.asarray(av["v0"])[Ka] * self.dqtdyls[Ka] + self.dqtdtls[Ka]
         if self.lnudge:                                          # nudge
-            k0 = 1 + self.nnudge
+            Kn = slice(1 + self.nnudge, nz + 1)
+            pairs = []
             if self.lnudgevel:
-                for name, tend, prof in (("u0", "up", self.uprof), ("v0", "vp", self.vprof)):
-                    A = acc(tend)[1]
-                    for k in range(k0, nz + 1):
-                        A[k] -= (av[name][k] - prof[k]) / self.tnudge
+                pairs += [("u0", "up", self.uprof), ("v0", "vp", self.vprof)]
             if self.ltempeq:
-                A = acc("thlp")[1]
-                for k in range(k0, nz + 1):
-                    A[k] -= (av["thl0"][k] - self.thlprof[k]) / self.tnudge
+                pairs.append(("thl0", "thlp", self.thlprof))
             if self.lmoist:
-                A = acc("qtp")[1]
-                for k in range(k0, nz + 1):
-                    A[k] -= (av["qt0"][k] - self.qtprof[k]) / self.tnudge
-            for n in range(self.core.nsv):                       # src/modforces.f90:840-844
-                A = acc(f"svp_{n}")[1]
-                for k in range(k0, nz + 1):
-                    A[k] -= (av[f"sv0_{n}"][k] - self.svprof[n][k]) / self.tnudge
+                pairs.append(("qt0", "qtp", self.qtprof))
+            pairs += [(f"sv0_{n}", f"svp_{n}", self.svprof[n]) for n in range(self.core.nsv)]      # src/modforces.f90:840-844
+            for name, tend, prof in pairs:
+                A = acc(tend)[1]
+                A[Kn] -= (np.asarray(av[name])[Kn] - np.asarray(prof)[Kn]) / self.tnudge
         if self.ifixuinf == 1:                                   # fixuinf1, src/modforces.f90:220-288
             if rk3step is None or dt is None:
                 raise ValueError("ifixuinf = 1: LevelForcings.update needs the substep's rk3step and dt")
             on = 1. if rk3step == 3 else 0.
             A = acc("up", None, 1)[1]
-            for k in range(1, nz + 1):
-                A[k] -= on * (1. / dt) * (av["u0"][nz] - self.Uinf)
+            A[Ka] -= on * (1. / dt) * (av["u0"][nz] - self.Uinf)
             if self.lvinf:
                 A = acc("vp", None, 1)[1]
-                for k in range(1, nz + 1):
-                    A[k] -= on * (1. / dt) * (av["v0"][nz] - self.Vinf)
+                A[Ka] -= on * (1. / dt) * (av["v0"][nz] - self.Vinf)
         if self.igrw in (1, 2, 3):                               # grwdamp
             tsc = self.tsc
+            Ks = slice(self.ksp, nz + 1)
             for name, tend, geo in (("u0", "up", self.ug), ("v0", "vp", self.vg)):
                 _, A, B = acc(tend, name, 1)
-                for k in range(self.ksp, nz + 1):
-                    ref = geo[k] if self.igrw == 2 else av[name][k]
-                    A[k] += ref * tsc[k]
-                    B[k] -= tsc[k]
-                    if self.igrw == 1 and self.lcoriol:
-                        c = (1. / (self.geodamptime * 2.75e-3)) * tsc[k]
-                        A[k] += geo[k] * c
-                        B[k] -= c
+                ref = np.asarray(geo)[Ks] if self.igrw == 2 else np.asarray(av[name])[Ks]
+                A[Ks] += ref * tsc[Ks]
+                B[Ks] -= tsc[Ks]
+                if self.igrw == 1 and self.lcoriol:
+                    c = (1. / (self.geodamptime * 2.75e-3)) * tsc[Ks]
+                    A[Ks] += np.asarray(geo)[Ks] * c
+                    B[Ks] -= c
             _, A, B = acc("wp", "w0", 1)
-            for k in range(self.ksp, nz + 1):
-                B[k] -= tsc[k]
+            B[Ks] -= tsc[Ks]
             for on, name, tend in ((self.ltempeq, "thl0", "thlp"), (self.lmoist, "qt0", "qtp")):
                 if on:
                     _, A, B = acc(tend, name, 1)
-                    for k in range(self.ksp, nz + 1):
-                        A[k] += av[name][k] * tsc[k]
-                        B[k] -= tsc[k]
+                    A[Ks] += np.asarray(av[name])[Ks] * tsc[Ks]
+                    B[Ks] -= tsc[Ks]
         return out
 
     def averages(self):
