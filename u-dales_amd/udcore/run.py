@@ -6,7 +6,7 @@ reads the deck (namoptions, prof.inp, lscale.inp) from the file's directory, col
 reference's initd/inits restart files, &RUN lwarmstart / --restart-from), advances until `runtime` (or N full steps)
 with the reference's own time-step control (tstep_update, src/modtstep.f90:113-150: fixed dtmax, or adaptive with the
 Courant / diffusion numbers), and writes restart files in the reference's layout every `trestart` seconds of model
-time and at the end (src/modsave.f90:77-121).  Immersed boundaries (libm), moisture and non-periodic lateral
+time and at the end (src/modsave.f90:77-121).  Immersed boundaries (libm) and non-periodic lateral
 boundaries are not available on the device path: such decks are refused with the reference's error convention.
 
 Multi-GPU: launch one process per GPU with torch.distributed.run; the y-slab decomposition follows WORLD_SIZE.
