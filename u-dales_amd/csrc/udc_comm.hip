@@ -21,7 +21,7 @@ struct LocalGroup {
   pthread_barrier_t bar;
   // published per rank: send pointers by tag (0 = to-prev rows, 1 = to-next rows, 2 = all-to-all base)
   const double *send[64][3];
-  double red[64][2048];
+  double red[64][4096];
 };
 
 static std::mutex g_groups_mu;
@@ -161,7 +161,7 @@ int comm_alltoall(udc_handle *h, const double *send, double *recv, size_t block,
   return 0;
 }
 
-// in-place all-reduce of n (<= 2048) doubles held in device memory `buf`; op 0 = max, 1 = sum
+// in-place all-reduce of n (<= 4096 over the test transport) doubles held in device memory `buf`; op 0 = max, 1 = sum
 int comm_allreduce(udc_handle *h, double *buf, int n, int op) {
   if (h->cfg.nranks == 1 && !h->nccl) return 0;
   if (need_comm(h)) return 1;
@@ -172,7 +172,7 @@ int comm_allreduce(udc_handle *h, double *buf, int n, int op) {
   }
   LocalGroup *g = (LocalGroup *)h->local_group;
   const int P = h->cfg.nranks, r = h->cfg.rank;
-  if (n > 2048) { udc_set_error("comm_allreduce: at most 2048 values"); return 1; }
+  if (n > 4096) { udc_set_error("comm_allreduce: at most 4096 values"); return 1; }
   HIP_OK(hipMemcpyAsync(g->red[r], buf, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
   pthread_barrier_wait(&g->bar);
