@@ -449,28 +449,21 @@ __global__ __launch_bounds__(256) void slab_pack_fwd_kernel(Geo g, int nkx, int 
 // received blocks -> specB (contiguous runs of ny_local)
 __global__ __launch_bounds__(256) void slab_unpack_fwd_kernel(Geo g, int cx, int P, int jtot, int k0, int nzc,
     const double2 *__restrict__ recv, double2 *__restrict__ specB) {
-  const size_t n = (size_t)P * nzc * cx * g.ny;
-  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= n) return;
-  const int j = q % g.ny;
-  size_t t = q / g.ny;
-  const int kxl = t % cx; t /= cx;
-  const int kc = t % nzc;
-  const int s = t / nzc;
-  specB[((size_t)(k0 + kc) * cx + kxl) * jtot + (size_t)s * g.ny + j] = recv[q];
+  // grid (ceil(ny/256), cx, P*nzc): the run index comes from the block coordinates, no per-element 64-bit divisions
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= g.ny) return;
+  const int kxl = blockIdx.y, s = blockIdx.z / nzc, kc = blockIdx.z - s * nzc;
+  (void)P;
+  specB[((size_t)(k0 + kc) * cx + kxl) * jtot + (size_t)s * g.ny + j] = recv[(((size_t)s * nzc + kc) * cx + kxl) * g.ny + j];
 }
 
 __global__ __launch_bounds__(256) void slab_pack_bwd_kernel(Geo g, int cx, int P, int jtot, int k0, int nzc,
     const double2 *__restrict__ specB, double2 *__restrict__ send) {
-  const size_t n = (size_t)P * nzc * cx * g.ny;
-  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= n) return;
-  const int j = q % g.ny;
-  size_t t = q / g.ny;
-  const int kxl = t % cx; t /= cx;
-  const int kc = t % nzc;
-  const int d = t / nzc;
-  send[q] = specB[((size_t)(k0 + kc) * cx + kxl) * jtot + (size_t)d * g.ny + j];
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= g.ny) return;
+  const int kxl = blockIdx.y, d = blockIdx.z / nzc, kc = blockIdx.z - d * nzc;
+  (void)P;
+  send[(((size_t)d * nzc + kc) * cx + kxl) * g.ny + j] = specB[((size_t)(k0 + kc) * cx + kxl) * jtot + (size_t)d * g.ny + j];
 }
 
 __global__ __launch_bounds__(256) void slab_unpack_bwd_kernel(Geo g, int nkx, int pitch, int cx, int P, int k0, int nzc,
@@ -917,7 +910,8 @@ int k_poisson_solve_slab(udc_handle *h) {
   const size_t chunk = block * P;                              // doubles per chunk in the send/recv buffers
   double *prow0 = h->fields[UDC_P] + g.idx(0, -HY, 0);         // first padded row of plane k = 0
   const dim3 tb(16, 16), tg((cx * P + 15) / 16, (g.ny + 15) / 16, nzc);
-  const unsigned lin = (unsigned)(((size_t)P * nzc * cx * g.ny + 255) / 256);
+  const unsigned lb = g.ny >= 256 ? 256 : (g.ny >= 128 ? 128 : 64);      // threads along a run of ny_local
+  const dim3 lin3((unsigned)((g.ny + lb - 1) / lb), (unsigned)cx, (unsigned)(P * nzc));
   const int pitch = h->nkxp;
   auto specA_at = [&](int k0) { return h->specA + (size_t)2 * pitch * g.py * k0; };
   auto specB_at = [&](int k0) { return h->specB + (size_t)2 * nmodes * k0; };
@@ -947,7 +941,7 @@ int k_poisson_solve_slab(udc_handle *h) {
     for (int c = 0; c < nch; ++c) {
       const int k0 = c * nzc;
       HIP_OK(hipStreamWaitEvent(h->stream, h->ev_done[c], 0));
-      hipLaunchKernelGGL(slab_unpack_fwd_kernel, dim3(lin), dim3(256), 0, h->stream, g, cx, P, ny, k0, nzc,
+      hipLaunchKernelGGL(slab_unpack_fwd_kernel, lin3, dim3(lb), 0, h->stream, g, cx, P, ny, k0, nzc,
                          reinterpret_cast<const double2 *>(h->a2a_recv + chunk * c), reinterpret_cast<double2 *>(h->specB));
       void *io[1] = {specB_at(k0)};
       FFT_OK(rocfft_execute(h->plan_yf, io, nullptr, h->info_x));
@@ -966,7 +960,7 @@ int k_poisson_solve_slab(udc_handle *h) {
       const int k0 = c * nzc;
       void *io[1] = {specB_at(k0)};
       FFT_OK(rocfft_execute(h->plan_yb, io, nullptr, h->info_x));
-      hipLaunchKernelGGL(slab_pack_bwd_kernel, dim3(lin), dim3(256), 0, h->stream, g, cx, P, ny, k0, nzc,
+      hipLaunchKernelGGL(slab_pack_bwd_kernel, lin3, dim3(lb), 0, h->stream, g, cx, P, ny, k0, nzc,
                          reinterpret_cast<const double2 *>(h->specB), reinterpret_cast<double2 *>(h->a2a_send + chunk * c));
       if (exchange(c)) return 1;
     }
