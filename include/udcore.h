@@ -117,6 +117,10 @@ int udc_set_forcing(udc_handle *h, const double *dpdxl, const double *dpdyl, int
  * radiative tendency of src/modforces.f90:104-110) is optional. */
 int udc_set_tempeq(udc_handle *h, int iadv_thl, int bctopt, double wttop, double thl_top, int bcbott, double wtsurf);
 int udc_set_thl_source(udc_handle *h, const double *thlpcar, int n);
+/* chem  src/modchem.f90:27-73 (&CHEMISTRY lchem, k1, JNO2; called by tstep_integrate on RK stage 3, src/modtstep.f90:236-238):
+ * NO + O3 <-> NO2 on scalars 1-3 [ug/m3], fully implicit backward Euler over dt.  Needs nsv >= 3; applied inside
+ * udc_tstep_integrate / udc_substep. */
+int udc_set_chem(udc_handle *h, int lchem, double k1, double jno2);
 /* shiftedPBCs  src/modforces.f90:953-980 (src/program.f90:144, &BC ds > 0): in the downstream half of the domain
  * (global i > itot/2) the momentum tendencies get -vs (phi(j) - phi(j-1))/dy with vs = a u0av(k) sinx(i),
  * a = 0.5 pi ds/(0.5 xlen), sinx(i) = sin(pi (xh(i) - xh(itot/2))/(0.5 xlen)) ([itot], zero where inactive).  u0av(kb:ke)

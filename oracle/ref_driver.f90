@@ -267,6 +267,7 @@ contains
     namelist /PHYSICS/ lmoist, lcoriol, lbuoyancy, ltempeq, lprofforc, dpdx, luvolflowr, uflowrate, &
       lvvolflowr, vflowrate, igrw_damp, geodamptime, lnudge, lnudgevel, tnudge, nnudge, ifixuinf, lvinf, tscale
     namelist /INLET/ Uinf, Vinf, inletav
+    namelist /CHEMISTRY/ lchem, k1, JNO2
     namelist /DYNAMICS/ lqlnr, ipoiss, iadv_mom, iadv_tke, iadv_thl, iadv_qt, iadv_sv
     namelist /BC/ BCxm, BCym, BCtopm, BCtopT, BCtops, BCbotm, BCbots, BCbotT, BCzp, wttop, thl_top, z0, wtsurf, thls, qts, &
       BCtopq, BCbotq, wqtop, qt_top, wqsurf, ps, z0h, wsvtopdum, ds
@@ -284,6 +285,7 @@ contains
     read (ifnamopt, BC, iostat=ierr); call chk(ierr, 'BC'); rewind (ifnamopt)
     read (ifnamopt, SCALARS, iostat=ierr); call chk(ierr, 'SCALARS'); rewind (ifnamopt)
     read (ifnamopt, INLET, iostat=ierr); call chk(ierr, 'INLET'); rewind (ifnamopt)     ! (absent group: iostat < 0)
+    read (ifnamopt, CHEMISTRY, iostat=ierr); call chk(ierr, 'CHEMISTRY'); rewind (ifnamopt)
     read (ifnamopt, WALLS, iostat=ierr); call chk(ierr, 'WALLS')
     close (ifnamopt)
     nprocx = 1; nprocy = nprocs     ! y-slabs over however many ranks were launched (1 in the np1 build)

@@ -723,6 +723,7 @@ void orc_tstep_integrate(const orc_grid *g, int rk3step, double dt, double *u0, 
   memset(vp, 0, n * sizeof(double));
   memset(wp, 0, n * sizeof(double));
   if (g->nsv > 0) memset(svp, 0, (size_t)g->nsv * nc * sizeof(double));
+  if (g->lchem && g->nsv >= 3 && rk3step == 3) orc_chem(g, dt, sv0);      /* src/modtstep.f90:236-238 */
   if (rk3step == 3) {
     memcpy(um, u0, n * sizeof(double));
     memcpy(vm, v0, n * sizeof(double));
@@ -877,6 +878,22 @@ void orc_bottom(const orc_grid *g, const double *u0, const double *v0, const dou
   }
   free(xh);
   metrics_free(&m);
+}
+
+/* ====================================================================== chemistry */
+void orc_chem(const orc_grid *g, double dt, double *sv0) {
+  const size_t nc = csize(g);
+  double *a = sv0, *b = sv0 + nc, *c = sv0 + 2 * nc;
+  const double k1 = g->k1, J = g->JNO2;
+  for (int k = 1; k <= g->nz + 2; ++k)
+    for (int j = -1; j <= g->ny + 2; ++j)
+      for (int i = -1; i <= g->nx + 2; ++i) {
+        const double dNO = 1 * C(a, i, j, k) / 30.006, dNO2 = 1 * C(b, i, j, k) / 46.005, dO3 = 1 * C(c, i, j, k) / 47.997;
+        const double r = (dt * (-k1 * dNO * dO3 + J * dNO2)) / (1. + ((dNO + dO3) * k1 + J) * dt);
+        C(a, i, j, k) = 30.006 * ((C(a, i, j, k) / 30.006) + r);
+        C(b, i, j, k) = 46.005 * ((C(b, i, j, k) / 46.005) - r);
+        C(c, i, j, k) = 47.997 * ((C(c, i, j, k) / 47.997) + r);
+      }
 }
 
 /* ====================================================================== scalar sources */

@@ -68,6 +68,9 @@ typedef struct {
    * 2 = value sv_top(n) (valuetopscal, :1539-1553); up to 4 scalars here */
   int bctops;
   double wsvtop[4], sv_top[4];
+  /* NO - NO2 - O3 chemistry on scalars 1-3 (lchem, src/modchem.f90:27-73): rate constant, photolysis rate */
+  int lchem;
+  double k1, JNO2;
   int lqlnr;                /* condensate by Newton-Raphson on T instead of the one-step formula (src/modthermodynamics.f90:37,448-473) */
   int iadv_thl;             /* 2 = cd2 (advecc_2nd), 7 = kappa (advecc_kappa on thl0c), src/modadvection.f90:64-76 */
 } orc_grid;
@@ -114,6 +117,8 @@ void orc_scalsource(const orc_grid *g, int npoint, const double *points, int nli
 void orc_thl0c_from(const orc_grid *g, const double *thl0, double *thl0c);
 /* advection of thl with iadv_thl = 7 (src/modadvection.f90:69-72): thlpc = thlp; advecc_kappa(thl0c, thlpc); thlp = thlpc */
 void orc_advec_thl_kappa(const orc_grid *g, const double *u0, const double *v0, const double *w0, const double *thl0c, double *thlp);
+/* chem, src/modchem.f90:27-73 (IBM-free: IIc = 1): fully implicit backward Euler of NO + O3 <-> NO2 on sv0(:,:,kb:ke+khc,1:3) */
+void orc_chem(const orc_grid *g, double dt, double *sv0);
 void orc_qt_top(const orc_grid *g, const double *ekh, double *a);
 void orc_qt_floor(const orc_grid *g, const double *ekh, const double *qt0, double *qtp);
 void orc_buoyancy(const orc_grid *g, const double *thl0, double *wp);

@@ -29,7 +29,7 @@ REF = os.path.join(ROOT, "oracle", "_ref", "udales_ref")
 
 
 def deck(iexpnr, nx, ny, nz, dx=0.5, dy=0.5, dtmax=0.25, sgs="vreman", nsv=0, bctopm=1,
-         oracle="", lles=True, randu=0.01, floor=False, z0=0.05, physics="", bc="", bcbotm=3, scalars="", dynamics="", inlet="", ladaptive=False):
+         oracle="", lles=True, randu=0.01, floor=False, z0=0.05, physics="", bc="", bcbotm=3, scalars="", dynamics="", inlet="", ladaptive=False, chemistry=""):
     sub = {"oneeqn": "loneeqn = .true.\nlvreman = .false.\nlsmagorinsky = .false.",
            "vreman": "lvreman = .true.\nlsmagorinsky = .false.",
            "smag": "lsmagorinsky = .true.\nlvreman = .false.",
@@ -70,7 +70,7 @@ nsv = {nsv}{(chr(10) + scalars) if scalars else ''}
 /
 &NAMSUBGRID
 {sub}
-/{(chr(10) + '&INLET' + chr(10) + inlet + chr(10) + '/') if inlet else ''}
+/{(chr(10) + '&INLET' + chr(10) + inlet + chr(10) + '/') if inlet else ''}{(chr(10) + '&CHEMISTRY' + chr(10) + chemistry + chr(10) + '/') if chemistry else ''}
 &ORACLE
 {oracle}
 /
@@ -300,6 +300,12 @@ CASES.update({
                            dict(sgs="oneeqn", floor=True, physics="lmoist = .true.\nltempeq = .true.\nlbuoyancy = .true.",
                                 bc="BCtopT = 1\nBCbotT = 1\nwtsurf = 0.03\nthls = 288.0\nqts = 0.0105\n"
                                    "BCtopq = 1\nBCbotq = 1\nwqsurf = 4.e-5", oracle="nspin = 4"), 1.05),
+})
+CASES.update({
+    # NO - NO2 - O3 chemistry on scalars 1-3 (lchem): fully implicit step on RK stage 3
+    "run_chem_16x8x12s": ("run", 51, 16, 8, 12,
+                          dict(sgs="smag", nsv=3, floor=True, chemistry="lchem = .true.\nk1 = 0.4\nJNO2 = 0.008",
+                               oracle="nsub = 6\ndump_at = 3, 6\nscal_a = 30.\nscal_b = 20."), 1.06),
 })
 LSF_ONLY = ("k_lsf_12x8x24", "k_lsfq_12x8x20", "k_fix1_12x8x6")
 THL_CASES = {"k_tke_moist_12x8x8": dict(dthl=0.25, qt=0.0118, dqt=-8e-5, tke=0.06),

@@ -380,6 +380,12 @@ extern "C" int udc_set_tempeq(udc_handle *h, int iadv_thl, int bctopt, double wt
   return 0;
 }
 
+extern "C" int udc_set_chem(udc_handle *h, int lchem, double k1, double jno2) {
+  if (lchem && h->cfg.nsv < 3) { udc_set_error("udc_set_chem: the NO, NO2, O3 chemistry needs nsv >= 3 (src/modchem.f90:50-52)"); return 1; }
+  h->lchem = lchem ? 1 : 0; h->chem_k1 = k1; h->chem_jno2 = jno2;
+  return 0;
+}
+
 extern "C" int udc_set_shifted_pbc(udc_handle *h, double a, const double *sinx, int nx, const double *u0av, int nz) {
   HIP_OK(hipSetDevice(h->device));
   h->shift_a = a;
@@ -684,7 +690,9 @@ extern "C" int udc_poisson(udc_handle *h, int rk3step, double dt) {
 extern "C" int udc_tstep_integrate(udc_handle *h, int rk3step, double dt) {
   HIP_OK(hipSetDevice(h->device));
   if (tend_clean(h) || um_materialise(h)) return 1;
-  return k_integrate(h, rk3step, dt);
+  if (k_integrate(h, rk3step, dt)) return 1;
+  if (rk3step == 3 && k_chem(h, dt)) return 1;      // src/modtstep.f90:236-238
+  return 0;
 }
 
 static int scalar_halo_list(udc_handle *h, int rk3step, std::vector<int> &f) {
@@ -774,6 +782,7 @@ extern "C" int udc_substep(udc_handle *h, int rk3step, double dt, int with_force
   }
   const bool skip_um = alias_ok && rk3step == 3;
   if (k_project_integrate(h, rk3step, dt, !lds, pup, fold, !skip_um, rotate)) return 1;
+  if (rk3step == 3 && k_chem(h, dt)) return 1;      // src/modtstep.f90:236-238 (before the ghosts are refreshed)
   if (rotate) {
     for (int q = 0; q < 3; ++q) std::swap(h->fields[UDC_U0 + q], h->fields[UDC_UM + q]);
     h->um_alias = false;

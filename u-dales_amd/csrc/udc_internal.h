@@ -132,6 +132,8 @@ struct udc_handle {
   // constant scalar sources (udc_set_scalar_source): a dense box per scalar, local device indices [lo, hi]
   struct ScalarSource { double *d = nullptr; int lo[3] = {0, 0, 0}, hi[3] = {-1, -1, -1}; };
   ScalarSource svsrc[16];
+  int lchem = 0;               // udc_set_chem
+  double chem_k1 = 0., chem_jno2 = 0.;
   // shiftedPBCs (udc_set_shifted_pbc): a, sinx[nx], u0av[nz] on the device
   double shift_a = 0.;
   double *shift_tab = nullptr;
@@ -246,6 +248,7 @@ int k_scalar_top_flux(udc_handle *h);              // fluxtop with a non-zero fl
 int k_level_source(udc_handle *h, int slot, const double *src);
 int k_buoyancy(udc_handle *h);
 int k_scalsource(udc_handle *h);
+int k_chem(udc_handle *h, double dt);
 int k_shifted_pbcs(udc_handle *h, bool wrap_vp);
 int k_thermodynamics(udc_handle *h);
 int k_slab_average(udc_handle *h, int field, double *avg_host, int n);

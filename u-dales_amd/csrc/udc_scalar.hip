@@ -221,3 +221,31 @@ int k_scalsource(udc_handle *h) {
   }
   return 0;
 }
+
+
+// chem, src/modchem.f90:27-73 (IIc = 1 without obstacles): on RK stage 3, after sv0 = svm + rk3coef svp and before
+// svm = sv0 -- here both have been written already, so both get the new value
+namespace {
+__global__ __launch_bounds__(256) void chem_kernel(Geo g, TileGrid tg, double k1, double J, double dt, double *__restrict__ a0,
+    double *__restrict__ b0, double *__restrict__ c0, double *__restrict__ am, double *__restrict__ bm, double *__restrict__ cm) {
+  int i, j, k;
+  if (!tile_decode(g, tg, i, j, k)) return;
+  const long c = g.idx(i, j, k);
+  const double dNO = 1 * a0[c] / 30.006, dNO2 = 1 * b0[c] / 46.005, dO3 = 1 * c0[c] / 47.997;
+  const double r = (dt * (-k1 * dNO * dO3 + J * dNO2)) / (1. + ((dNO + dO3) * k1 + J) * dt);
+  const double na = 30.006 * ((a0[c] / 30.006) + r), nb = 46.005 * ((b0[c] / 46.005) - r), nc = 47.997 * ((c0[c] / 47.997) + r);
+  a0[c] = na; b0[c] = nb; c0[c] = nc;
+  am[c] = na; bm[c] = nb; cm[c] = nc;
+}
+}  // namespace
+
+int k_chem(udc_handle *h, double dt) {
+  const Geo &g = h->g;
+  if (!h->lchem) return 0;
+  PROF(h, "chem");
+  hipLaunchKernelGGL(chem_kernel, dim3((unsigned)tile_grid(g).tiles * (unsigned)g.nz), dim3(64, 4), 0, h->stream, g, tile_grid(g),
+                     h->chem_k1, h->chem_jno2, dt, h->fields[UDC_SV0], h->fields[UDC_SV0 + 3], h->fields[UDC_SV0 + 6],
+                     h->fields[UDC_SVM], h->fields[UDC_SVM + 3], h->fields[UDC_SVM + 6]);
+  HIP_OK(hipGetLastError());
+  return 0;
+}

@@ -43,10 +43,6 @@ contains
     use udc_iface
     implicit none
 
-    if (lchem) then
-      write (0, *) 'ERROR: libudcore tstep_integrate: option not on the device path'
-      stop 1
-    end if
     call udc_ensure
     if (ifixuinf == 2) then      ! src/modtstep.f90:194-195: the dp/dx ODE (dgdt from the host's fixuinf2)
       dpdxl(:) = dpdxl(:) + dgdt*(dt/(4. - real(rk3step)))

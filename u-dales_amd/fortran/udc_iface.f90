@@ -111,6 +111,12 @@ module udc_iface
       integer(c_int), value :: bcbotm, bcbott
       real(c_double), value :: thls, z0h, prandtlturb
     end function udc_set_floor_wf
+    integer(c_int) function udc_set_chem(h, lchem, k1, jno2) bind(C, name='udc_set_chem')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: lchem
+      real(c_double), value :: k1, jno2
+    end function udc_set_chem
     integer(c_int) function udc_set_scalar_top(h, n, bctops, value) bind(C, name='udc_set_scalar_top')
       import :: c_ptr, c_int, c_double
       type(c_ptr), value :: h
@@ -236,7 +242,7 @@ contains
   subroutine udc_ensure
     use modglobal, only: itot, jtot, ktot, dx, dy, dzf, dzh, kb, ke, kh, numol, prandtlmoli, nsv, &
                          BCtopm, Uinf, Vinf, lles, ltempeq, lbuoyancy, lmoist, iadv_thl, BCtopT, BCbotT, grav, e12min, &
-                         iadv_qt, BCtopq, BCbotq, zf, zh, BCbotm, prandtlturb, BCtops
+                         iadv_qt, BCtopq, BCbotq, zf, zh, BCbotm, prandtlturb, BCtops, lchem, k1, JNO2
     use modsurfdata, only: wttop, thl_top, wtsurf, thvs, wqtop, qt_top, wqsurf, thls, qts, ps, z0h, wsvtop, sv_top
     use modthermodynamics, only: lqlnr
     use modsubgriddata, only: lsmagorinsky, lvreman, loneeqn, ldelta, prandtli, c_vreman, csz, cm, cn, ch1, ch2, ce1, ce2
@@ -311,6 +317,7 @@ contains
       call udc_check(udc_set_floor_wf(udc_h, int(BCbotm, c_int), int(BCbotT, c_int), real(thls, c_double), real(z0h, c_double), &
                                       real(prandtlturb, c_double)), 'udc_set_floor_wf')
     end if
+    if (lchem) call udc_check(udc_set_chem(udc_h, 1_c_int, real(k1, c_double), real(JNO2, c_double)), 'udc_set_chem')
     do n = 1, nsv          ! top condition of the scalars (src/modboundary.f90:236-247)
       call udc_check(udc_set_scalar_top(udc_h, int(n - 1, c_int), int(BCtops, c_int), &
                                         real(merge(sv_top(n), wsvtop(n), BCtops == 2), c_double)), 'udc_set_scalar_top')

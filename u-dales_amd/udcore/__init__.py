@@ -68,6 +68,8 @@ def from_deck(deck, device=0, rank=0, nranks=1):
         dpdxl = [om23_gs * vg - pg - dpdx for vg, pg in zip(deck.vg, deck.pgx)]
         dpdyl = [-om23_gs * ug - pg for ug, pg in zip(deck.ug, deck.pgy)]
     core.set_forcing(np.array(dpdxl), np.array(dpdyl))
+    if deck.get("CHEMISTRY", "lchem"):
+        core.set_chem(True, float(deck.get("CHEMISTRY", "k1")), float(deck.get("CHEMISTRY", "JNO2")))
     if core.nsv:      # top condition of the scalars (src/modboundary.f90:236-247; sv_top = svprof(ke), src/modstartup.f90:1574)
         bctops = int(deck.get("BC", "BCtops"))
         w = deck.get("BC", "wsvtopdum")

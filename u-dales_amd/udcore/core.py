@@ -156,6 +156,10 @@ class DynCore:
             a = np.ascontiguousarray(thlpcar, dtype=np.float64)
             L._check(self.lib.udc_set_thl_source(self.h, a.ctypes.data_as(L.DP), len(a)), "udc_set_thl_source")
 
+    def set_chem(self, lchem=True, k1=0., jno2=0.):
+        """&CHEMISTRY lchem, k1, JNO2: NO - NO2 - O3 chemistry on scalars 1-3 (include/udcore.h udc_set_chem)."""
+        L._check(self.lib.udc_set_chem(self.h, int(bool(lchem)), C.c_double(k1), C.c_double(jno2)), "udc_set_chem")
+
     def set_shifted_pbc(self, a, sinx, u0av):
         """shiftedPBCs (&BC ds): vs = a u0av(k) sinx(i), see include/udcore.h udc_set_shifted_pbc."""
         sx = np.ascontiguousarray(sinx, dtype=np.float64)

@@ -114,7 +114,7 @@ def scalar_profiles(g: Grid, d: Deck, nsv, scal_a=None, scal_b=None):
     return out
 
 
-def cold_start(g: Grid, d: Deck, j0=0, nyl=None, nsv=0, scal_a=1.0, scal_b=0.0):
+def cold_start(g: Grid, d: Deck, j0=0, nyl=None, nsv=0, scal_a=None, scal_b=None):
     """Initial um, vm, wm (= u0, v0, w0), and scalars for rows j0+1..j0+nyl of the global grid.
 
     Returns dict of arrays with halos; x ghosts periodic, y ghosts periodic when the slab is

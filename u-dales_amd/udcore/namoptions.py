@@ -20,6 +20,7 @@ DEFAULTS = {
     "PHYSICS": dict(lmoist=False, lcoriol=False, lbuoyancy=False, ltempeq=False, lprofforc=False,
                     dpdx=0., igrw_damp=0, geodamptime=7200., lnudge=False, lnudgevel=True, tnudge=60., nnudge=0, xlat=52., luvolflowr=False, uflowrate=1., lvvolflowr=False, vflowrate=1.,
                     ifixuinf=0, lvinf=False, tscale=0.),
+    "CHEMISTRY": dict(lchem=False, k1=0., JNO2=0.),
     "INLET": dict(Uinf=0., Vinf=0., inletav=0.),
     "DYNAMICS": dict(lqlnr=False, ipoiss=0, iadv_mom=2, iadv_tke=-1, iadv_thl=-1, iadv_qt=-1),
     "BC": dict(BCxm=1, BCym=1, BCtopm=1, BCbotm=2, BCzp=1, z0=-1., z0h=-1., BCtopT=1, BCbotT=1, BCbots=1, BCtops=1,
