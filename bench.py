@@ -54,7 +54,7 @@ def algo_bytes(name):
     return None
 
 
-def write_deck(d, iexp, nx, ny, nz, nsub, dt=0.25, nprocy=1, nsv=0, sgs="vreman", floor=True):
+def write_deck(d, iexp, nx, ny, nz, nsub, dt=0.25, nprocy=1, nsv=0, sgs="vreman", floor=True, nwarm=0):
     with open(os.path.join(d, f"namoptions.{iexp:03d}"), "w") as f:
         f.write(f"""&RUN
 iexpnr = {iexp}
@@ -91,6 +91,7 @@ nsv = {nsv}
 /
 &ORACLE
 nsub = {nsub}
+nwarm = {nwarm}
 /
 """)
     with open(os.path.join(d, f"prof.inp.{iexp:03d}"), "w") as f:
@@ -104,14 +105,41 @@ nsub = {nsub}
     return os.path.join(d, f"namoptions.{iexp:03d}")
 
 
-def _run_ref(cmd, cwd):
+def _run_ref(cmd, cwd, env=None, raw=False):
     try:
         r = subprocess.run(f"ulimit -s unlimited; exec {cmd}", shell=True, cwd=cwd, capture_output=True,
-                           text=True, timeout=900, executable="/bin/bash")
+                           text=True, timeout=900, executable="/bin/bash", env=env)
     except subprocess.TimeoutExpired:
         return None
     m = re.search(r"cell_updates_per_s=\s*([0-9.Ee+-]+)", r.stdout)
+    if raw:
+        return (float(m.group(1)) if m else None), r.stdout
     return float(m.group(1)) if m else None
+
+
+def dropin_leg(nx, ny, nz, nsv, sgs, floor, value, nsub=150, nwarm=15):
+    """The same workload through the drop-in boundary: the reference-shaped Fortran driver (call order of
+    src/program.f90:132-222) linked with the drop-in modules of u-dales_amd/fortran/ over the C ABI, device resident
+    (UDC_RESIDENCY=2).  Wall clock around the Fortran time loop (MPI_Wtime + a final device synchronisation)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "udales_dropin")
+    if not os.path.exists(exe):
+        return None
+    with tempfile.TemporaryDirectory() as tmp:
+        write_deck(tmp, 902, nx, ny, nz, nsub, nsv=nsv, sgs=sgs, floor=floor, nwarm=nwarm)
+        env = dict(os.environ, UDC_RESIDENCY="2")
+        res = _run_ref(f"{exe} namoptions.902 time none.bin", tmp, env=env, raw=True)
+    if not res or not res[0]:
+        return {"value": None, "note": "udales_dropin failed"}
+    v, out = res
+    m = re.search(r"fused_substeps=(\d+) unfused=(\d+)", out)
+    dm = re.search(r"divmax=\s*([0-9.Ee+-]+)", out)
+    return {"value": v, "unit": "cell-updates/s", "frac_of_direct": round(v / value, 4), "substeps": nsub, "warmup": nwarm,
+            "ms_per_step": round(nx * ny * nz / v * 1e3, 5),
+            "fused_substeps": int(m.group(1)) if m else None, "unfused_substeps": int(m.group(2)) if m else None,
+            "divmax_after_run": float(dm.group(1)) if dm else None,
+            "surface": "Fortran driver (oracle/ref_driver.f90: tstep_update, advection, shiftedPBCs, subgrid, bottom, coriolis, "
+                       "forces, lstend, nudge, masscorr, scalsource, fixuinf2, fixuinf1, grwdamp, poisson, tstep_integrate, halos, "
+                       "boundary per substep) -> drop-in modules -> C ABI, UDC_RESIDENCY=2"}
 
 
 def cpu_baseline(nx, ny, nz, budget_s=25.0):
@@ -160,6 +188,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--size", type=str, default="", help="override grid, e.g. 256x256x256")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the Fortran drop-in leg")
     ap.add_argument("--nsv", type=int, default=0, help="passive scalars (kappa scheme), BASELINE configs[2]")
     ap.add_argument("--sgs", type=str, default="vreman", choices=["vreman", "smag"])
     ap.add_argument("--no-floor", action="store_true",
@@ -306,8 +335,13 @@ def main():
                                                  "kind": "reference", "sample": "oracle/_ref/udales_ref unavailable"}
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not args.no_dropin:
+            core.close()
+            core = None
+            out["dropin"] = dropin_leg(nx, ny, nz, args.nsv, args.sgs, not args.no_floor, value)
         print(json.dumps(out))
-    core.close()
+    if core is not None:
+        core.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -236,6 +236,20 @@ int udc_substep(udc_handle *h, int rk3step, double dt, int with_forces);
 /* n substeps with fixed dt, rk3step cycling 1,2,3 starting from rk3step0 */
 int udc_run(udc_handle *h, int nsubsteps, int rk3step0, double dt, int with_forces);
 
+/* Deferred execution -- how an UNTOUCHED driver (src/program.f90:132-222) gets the fused substep.  With it on, the
+ * tendency routines (udc_advection, udc_shifted_pbcs, udc_subgrid, udc_bottom, udc_coriolis, udc_forces,
+ * udc_level_forcings, udc_masscorr, udc_scalsource, udc_poisson) only record that they were called.  udc_tstep_integrate
+ * then runs the record: as ONE fused substep (the kernels of udc_substep, which also does halos, boundary and
+ * thermodynamics -- the driver's own calls of those right after find nothing left to do) when the record is the
+ * reference's sequence -- each routine at most once, in program.f90's order, advection + subgrid + poisson present --
+ * and routine by routine in call order otherwise.  Every other entry point (uploads, downloads, reductions, set-up
+ * calls other than udc_set_level_forcing / udc_set_shifted_pbc, whose tables only the recorded routines read) first
+ * runs what is recorded, so host-visible results never depend on the mode.  udc_deferred_stats counts the substeps
+ * that ran fused / routine by routine. */
+int udc_set_deferred(udc_handle *h, int on);
+int udc_flush(udc_handle *h);
+int udc_deferred_stats(udc_handle *h, long *fused, long *unfused);
+
 /* divergence of u0 as modchecksim's chkdiv (src/modchecksim.f90:161-203): max |div|, sum div */
 int udc_divergence(udc_handle *h, double *divmax, double *divtot);
 

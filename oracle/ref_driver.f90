@@ -23,7 +23,7 @@
 !   run      : nsub substeps, dump state after the substeps listed in dump_at
 !   kernels  : spin-up nspin substeps, then call each reference routine separately
 !              and dump inputs/outputs (per-kernel golden vectors)
-!   time     : nsub substeps timed with MPI_Wtime exactly like src/modmpi.f90:140-160
+!   time     : nsub substeps (after nwarm untimed ones) timed with MPI_Wtime exactly like src/modmpi.f90:140-160
 !   restart  : nsub substeps (a multiple of 3), then the reference's own writerestartfiles
 !              (src/modsave.f90:37-128) writes initd/inits files into the working directory; the state
 !              is also dumped as 'rst.*' records so that readers of the restart format can be checked
@@ -45,13 +45,23 @@ program ref_driver
   use modforces, only: forces, masscorr, coriolis, lstend, nudge, fixuinf1, fixuinf2, shiftedPBCs
   use modsave, only: writerestartfiles
   use modscalsource, only: createscals, scalsource
+#ifdef UDC_DROPIN
+  ! drop-in build: the floor (`bottom`), the masks and lbottom come from the drop-in modibm, as in src/program.f90:38
+  use modibm, only: initibm, createmasks, bottom, lbottom
+  use udc_iface, only: udc_residency, udc_pull_all, udc_h, udc_sync, udc_check, udc_deferred_stats
+  use iso_c_binding, only: c_long
+#endif
   implicit none
 
   character(256) :: mode, outfile, arg
-  integer :: nsub = 3, nspin = 2
+  integer :: nsub = 3, nspin = 2, nwarm = 0
   integer :: dump_at(16) = -1
   logical :: lforces = .true.
+#ifndef UDC_DROPIN
   logical :: lbottom = .false.           ! src/modibm.f90:49 (module variable of modibm)
+#else
+  integer(c_long) :: nfused, nunfused
+#endif
   logical :: need_thermo = .false.
   real :: bcTfluxA = 0.                  ! src/modibmdata.f90 (module variable of modibm's callers)
   integer :: isub, n, ierr, iu
@@ -61,7 +71,7 @@ program ref_driver
   integer(KIND=selected_int_kind(6)) :: irandom = 43
   integer :: krand = huge(0)
   real :: randu = 0.01
-  namelist /ORACLE/ nsub, nspin, dump_at, lforces, scal_a, scal_b
+  namelist /ORACLE/ nsub, nspin, nwarm, dump_at, lforces, scal_a, scal_b
 
   call initmpi
   if (command_argument_count() < 3) then
@@ -80,12 +90,18 @@ program ref_driver
   call init_decomp_np1
   call initglobal
   call initfields
+#ifndef UDC_DROPIN
   ! createmasks without IBM, src/modibm.f90:2121-2135 (modibm cannot be built): slab cell counts of the masks
   IIcs = nint(rslabs); IIus = nint(rslabs); IIvs = nint(rslabs); IIws = nint(rslabs)
+#endif
   call initboundary
   call initthermodynamics
   call initsubgrid
   call initpois
+#ifdef UDC_DROPIN
+  call initibm                              ! src/program.f90:93-95
+  call createmasks
+#endif
   call cold_start
   call createscals                          ! src/modstartup.f90 (scalarsourcep / scalarsourcel files; no-op without sources)
   call boundary
@@ -103,7 +119,10 @@ program ref_driver
     call dump_state('s000')
     do isub = 1, nsub
       call one_substep
-      if (any(dump_at == isub)) call dump_state(tag4(isub))
+      if (any(dump_at == isub)) then
+        call host_refresh
+        call dump_state(tag4(isub))
+      end if
     end do
   case ('kernels')
     do isub = 1, nspin
@@ -115,16 +134,31 @@ program ref_driver
       call one_substep
     end do
     tnextrestart = 0.                      ! due now (src/modsave.f90:77)
+    call host_refresh
     call writerestartfiles
     call dump_state('rst')
     call put1('rsttime', (/timee, dt, real(ntrun)/), 1)
   case ('time')
+    do isub = 1, nwarm                     ! untimed warm-up substeps (device set-up, first touches)
+      call one_substep
+    end do
+#ifdef UDC_DROPIN
+    if (nwarm > 0) call udc_check(udc_sync(udc_h), 'udc_sync')
+#endif
     t0 = MPI_Wtime()
     do isub = 1, nsub
       call one_substep
     end do
+#ifdef UDC_DROPIN
+    call udc_check(udc_sync(udc_h), 'udc_sync')      ! the device has finished what the loop enqueued
+#endif
     t1 = MPI_Wtime()
+    call host_refresh
     call global_checks(chk_u2, chk_div)
+#ifdef UDC_DROPIN
+    if (udc_deferred_stats(udc_h, nfused, nunfused) == 0 .and. myid == 0) &
+      write (6, '(a,i0,a,i0,a,i0)') 'DROPIN residency=', udc_residency, ' fused_substeps=', nfused, ' unfused=', nunfused
+#endif
     if (myid == 0) write (6, '(a,i0,a,i0,a,i0,a,i0,a,i0,a,es14.6,a,es14.6,a,es22.14,a,es10.2)') &
       'REF_TIMING cells=', itot*jtot*ktot, &
       ' itot=', itot, ' jtot=', jtot, ' ranks=', nprocs, ' substeps=', nsub, ' seconds=', t1 - t0, &
@@ -137,6 +171,14 @@ program ref_driver
   if (trim(mode) /= 'time') close (iu)
 
 contains
+
+  !> device-resident drop-in runs (UDC_RESIDENCY=2): bring the host arrays up to date before this driver reads them
+  !! (in src/program.f90 the drop-in halos / thermodynamics do that when output or a restart file is due)
+  subroutine host_refresh
+#ifdef UDC_DROPIN
+    if (udc_residency == 2) call udc_pull_all
+#endif
+  end subroutine host_refresh
 
   !> decomposition-independent diagnostics printed with the timing: sum(u0^2) and chkdiv's divmax
   !! (src/modchecksim.f90:179-196) over the whole domain
@@ -170,7 +212,7 @@ contains
     call advection
     call shiftedPBCs                        ! src/program.f90:144 (no-op unless ds > 0)
     call subgrid
-    call floor_bottom
+    call floor_bottom                       ! src/program.f90:152
     if (lforces) call coriolis              ! src/program.f90:158 (no-op unless lcoriol / lprofforc)
     if (lforces) call forces
     if (lforces) call lstend                ! src/program.f90:162 (large-scale subsidence; needs diagfld's slab averages)
@@ -190,6 +232,10 @@ contains
   ! ---- `bottom`, src/modibm.f90:2021-2026 (momentum, BCbotm = 3) and :2073-2090 (scalars, BCbots = 1)
   subroutine floor_bottom
     integer :: i, j, m
+#ifdef UDC_DROPIN
+    call bottom
+    return
+#endif
     e120(:, :, kb - 1) = e120(:, :, kb)     ! src/modibm.f90:2012-2013 (unconditional)
     e12m(:, :, kb - 1) = e12m(:, :, kb)
     if (.not. lbottom) return

@@ -1,9 +1,11 @@
 """The drop-in boundary, exercised from Fortran: the reference-shaped driver (oracle/ref_driver.f90,
 call order of src/program.f90) linked with u-dales_amd/fortran/{modadvection,modsubgrid,modpois,
-modtstep}.f90 -- same module and procedure names as the reference -- instead of the reference's own
-four modules.  Its dumps must match the golden dumps the all-reference build produced from the same
-namoptions (tests/golden).  Every other module in the binary (modboundary::halos/boundary,
-modforces::forces, modglobal, modfields ...) is the reference's unmodified code running on the host.
+modtstep,modforces,modboundary,modthermodynamics,modibm}.f90 -- same module and procedure names as the
+reference -- instead of the reference's own modules.  Its dumps must match the golden dumps the
+all-reference build produced from the same namoptions (tests/golden).  The state modules (modglobal,
+modfields, modsurfdata ...), modsave and modscalsource in the binary are the reference's unmodified
+code.  Residency 0 / 1: every routine carries the state / the tendencies over PCIe; residency 2: device
+resident, the routines record and tstep_integrate launches the fused substep.
 """
 import os
 import shutil
@@ -33,7 +35,7 @@ def run_dropin(name, iexp, mode, tmp_path, residency):
     return read_dump(os.path.join(tmp_path, "out.bin"))
 
 
-@pytest.mark.parametrize("residency", [0, 1])
+@pytest.mark.parametrize("residency", [0, 1, 2])
 @pytest.mark.parametrize("name,iexp", sorted(RUN_CASES.items()))
 def test_fortran_driver_with_dropin_modules(name, iexp, residency, tmp_path):
     fix = load_fixture(name)
@@ -64,7 +66,7 @@ def test_fortran_kernel_sequence(tmp_path):
             assert relerr(a[:-1, 1:-1, 1:-1], b[:-1, 1:-1, 1:-1]) <= 1e-10, key
 
 
-@pytest.mark.parametrize("residency", [0, 1])
+@pytest.mark.parametrize("residency", [0, 1, 2])
 def test_fortran_driver_fixuinf2(residency, tmp_path):
     """ifixuinf = 2 through the drop-in modtstep: the host's fixuinf2 sets dgdt, tstep_integrate advances dp/dx."""
     name, iexp = "run_fix2_16x8x12s", 44
@@ -77,7 +79,7 @@ def test_fortran_driver_fixuinf2(residency, tmp_path):
             assert relerr(nocorner(a), nocorner(b)) <= 1e-9, (tag, k)
 
 
-@pytest.mark.parametrize("residency", [0, 1])
+@pytest.mark.parametrize("residency", [0, 1, 2])
 def test_fortran_driver_adaptive_dt(residency, tmp_path):
     """ladaptive through the drop-in modtstep::tstep_update (maxima on the device, src/modtstep.f90:49-154)."""
     name, iexp = "run_adaptive_16x8x12s", 46
@@ -90,11 +92,46 @@ def test_fortran_driver_adaptive_dt(residency, tmp_path):
             assert relerr(nocorner(a), nocorner(b)) <= 1e-9, (tag, k)
 
 
-def test_fortran_driver_shifted_pbcs(tmp_path):
-    """&BC ds > 0: the host's shiftedPBCs edits the tendencies the drop-in advection pulled back."""
+@pytest.mark.parametrize("residency", [0, 2])
+def test_fortran_driver_shifted_pbcs(residency, tmp_path):
+    """&BC ds > 0 through the drop-in modforces::shiftedPBCs."""
     name, iexp = "run_shift_16x8x12s", 49
     fix = load_fixture(name)
-    got = run_dropin(name, iexp, "run", tmp_path, 0)
+    got = run_dropin(name, iexp, "run", tmp_path, residency)
     for k in ("u0", "v0", "w0", "pres0"):
         a, b = got[f"s006.{k}"].data[1:-1], fix[f"s006.{k}"].data[1:-1]
         assert relerr(nocorner(a), nocorner(b)) <= 1e-9, k
+
+
+@pytest.mark.parametrize("residency", [0, 2])
+def test_fortran_driver_level_forcings(residency, tmp_path):
+    """lstend, nudge, grwdamp through the drop-in modforces / modboundary (tables built in Fortran from the slab
+    averages the drop-in thermodynamics fetched)."""
+    name, iexp = "run_lsf_16x8x24s", 30
+    fix = load_fixture(name)
+    got = run_dropin(name, iexp, "run", tmp_path, residency)
+    tags = sorted({k.split(".")[0] for k in fix if k.endswith(".u0") and not k.startswith("s000")})
+    assert tags
+    for tag in tags:
+        for k in ("u0", "v0", "w0", "pres0", "thl0"):
+            if f"{tag}.{k}" not in fix:
+                continue
+            a, b = got[f"{tag}.{k}"].data[1:-1], fix[f"{tag}.{k}"].data[1:-1]
+            assert relerr(nocorner(a), nocorner(b), 1.0 if k == "thl0" else None) <= 1e-9, (tag, k)
+
+
+def test_fortran_device_mode_takes_the_fused_path(tmp_path):
+    """UDC_RESIDENCY=2: every substep of the untouched loop runs as the fused substep (none routine by routine)."""
+    name, iexp = "run_16x16x8", RUN_CASES["run_16x16x8"]
+    if not os.path.exists(BIN):
+        pytest.skip("oracle/_ref/udales_dropin not built")
+    for fn in os.listdir(os.path.join(GOLDEN, "cases", name)):
+        shutil.copy(os.path.join(GOLDEN, "cases", name, fn), tmp_path)
+    env = dict(os.environ, UDC_RESIDENCY="2")
+    r = subprocess.run(f"ulimit -s unlimited; exec {BIN} namoptions.{iexp:03d} time none.bin", shell=True,
+                       cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300, executable="/bin/bash")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    import re
+    m = re.search(r"DROPIN residency=2 fused_substeps=(\d+) unfused=(\d+)", r.stdout)
+    assert m, r.stdout[-1000:]
+    assert int(m.group(1)) > 0 and int(m.group(2)) == 0

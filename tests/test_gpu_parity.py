@@ -187,11 +187,12 @@ def test_each_routine_matches_reference(name, iexp):
     core.close()
 
 
-@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("fused", [True, False, "deferred"])
 @pytest.mark.parametrize("name,iexp", sorted(RUN_CASES.items()))
 def test_substeps_match_reference(name, iexp, fused):
-    """Chained substeps from the cold start, both through the fused udc_substep and through the
-    reference's routine-by-routine call order."""
+    """Chained substeps from the cold start: through the fused udc_substep, through the reference's
+    routine-by-routine call order, and through that same call order with deferred execution on (udc_set_deferred:
+    the routines record, tstep_integrate launches the fused substep -- how an untouched driver gets it)."""
     fix = load_fixture(name)
     d, core = core_from_deck(name, iexp)
     g, nsv = core.g, core.nsv
@@ -199,8 +200,11 @@ def test_substeps_match_reference(name, iexp, fused):
     core.load_state(st)
     dt = float(d.get("RUN", "dtmax"))
     dumps = sorted(int(k[1:4]) for k in fix if k.endswith(".u0") and k != "s000.u0")
+    if fused == "deferred":
+        core._ensure_thermo()
+        core.set_deferred(True)
     for isub in range(1, max(dumps) + 1):
-        if fused:
+        if fused is True:
             rk = (isub - 1) % 3 + 1
             core.substep(rk, dt, with_forces=True)
         else:
@@ -220,7 +224,33 @@ def test_substeps_match_reference(name, iexp, fused):
                 got = core.download(L.scalar_field(L.SV0, n), halo=2)
                 ref = carr(fix, f"{tag}.sv0_{n + 1:02d}", g.nz)
                 assert relerr(interior(got, 2), interior(ref, 2)) <= RUN_TOL
+    if fused == "deferred":
+        assert core.deferred_stats() == (max(dumps), 0)      # every substep took the fused path
     core.close()
+
+
+def test_deferred_out_of_order_runs_routine_by_routine():
+    """Deferred execution with a call order that is not the reference's (subgrid before advection, poisson missing
+    from one substep): the record runs routine by routine and gives what immediate execution gives."""
+    name, iexp = "run_16x16x8", RUN_CASES["run_16x16x8"]
+    out = []
+    for deferred in (False, True):
+        d, core = core_from_deck(name, iexp)
+        core.load_state(cold_start(core.g, d, nsv=core.nsv))
+        dt = float(d.get("RUN", "dtmax"))
+        core.set_deferred(deferred)
+        for isub in range(3):
+            core.tstep_update(dt)
+            core.subgrid(); core.advection(); core.forces()
+            if isub != 1:
+                core.poisson()
+            core.tstep_integrate(); core.halos(); core.boundary()
+        if deferred:
+            assert core.deferred_stats() == (0, 3)
+        out.append([core.download(k) for k in ("u0", "v0", "w0", "pres0")])
+        core.close()
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
 
 
 def random_state(g, seed, nsv=0, amp=0.05):

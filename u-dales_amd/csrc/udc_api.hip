@@ -15,6 +15,18 @@ void udc_set_error(const char *fmt, ...) {
   va_end(ap);
 }
 
+int udc_flush_pending(udc_handle *h);
+#define ENTRY(h)                                        \
+  do {                                                  \
+    if (!(h)) { udc_set_error("null handle"); return 1; } \
+    HIP_OK(hipSetDevice((h)->device));                  \
+  } while (0)
+#define ENTRY_FLUSH(h)                                  \
+  do {                                                  \
+    ENTRY(h);                                           \
+    if (udc_flush_pending(h)) return 1;                 \
+  } while (0)
+
 extern "C" const char *udc_last_error(void) { return g_err; }
 extern "C" int udc_version(void) { return 100; }
 
@@ -199,6 +211,7 @@ extern "C" int udc_create(const udc_config *cfg, udc_handle **out) {
 extern "C" int udc_destroy(udc_handle *h) {
   if (!h) return 0;
   hipSetDevice(h->device);
+  h->pend.clear();
   hipStreamSynchronize(h->stream);
   prof_drain(h);
   for (hipEvent_t e : h->prof_pool) hipEventDestroy(e);
@@ -224,7 +237,7 @@ extern "C" int udc_destroy(udc_handle *h) {
 }
 
 extern "C" int udc_sync(udc_handle *h) {
-  HIP_OK(hipSetDevice(h->device));
+  ENTRY_FLUSH(h);
   HIP_OK(hipStreamSynchronize(h->stream));
   h->prof_chain = nullptr;
   return 0;
@@ -248,6 +261,7 @@ static int copy3d(udc_handle *h, int field, double *host, const int lb[3], const
   if (field_ptr(h, field, &dev)) return 1;
   if (((field >= UDC_UP && field <= UDC_WP) || (field >= UDC_SV0 && (field - UDC_SV0) % 3 == 2)) && tend_clean(h)) return 1;
   if (field >= UDC_UM && field <= UDC_WM && um_materialise(h)) return 1;
+  if (up) h->halos_fresh = h->boundary_fresh = h->thermo_fresh = false;
   const Geo &g = h->g;
   const int hnx = ub[0] - lb[0] + 1, hny = ub[1] - lb[1] + 1;
   int i0 = lb[0] > 1 ? lb[0] : 1, i1 = ub[0] < g.nx ? ub[0] : g.nx;
@@ -280,15 +294,16 @@ static int copy3d(udc_handle *h, int field, double *host, const int lb[3], const
 }
 
 extern "C" int udc_field_upload(udc_handle *h, int field, const double *host, const int lb[3], const int ub[3]) {
-  HIP_OK(hipSetDevice(h->device));
+  ENTRY_FLUSH(h);
   return copy3d(h, field, const_cast<double *>(host), lb, ub, true);
 }
 extern "C" int udc_field_download(udc_handle *h, int field, double *host, const int lb[3], const int ub[3]) {
-  HIP_OK(hipSetDevice(h->device));
+  ENTRY_FLUSH(h);
   return copy3d(h, field, host, lb, ub, false);
 }
 
 extern "C" int udc_set_forcing(udc_handle *h, const double *dpdxl, const double *dpdyl, int n) {
+  ENTRY_FLUSH(h);
   if (n != h->g.nz) { udc_set_error("udc_set_forcing: expected %d levels", h->g.nz); return 1; }
   const int nk = h->g.nz + 2;
   std::vector<double> t(2 * nk, 0.0);
@@ -332,8 +347,7 @@ static int vel_fields(udc_handle *h, int rk3step, int *f) {
   return n;
 }
 
-extern "C" int udc_advection(udc_handle *h) {
-  HIP_OK(hipSetDevice(h->device));
+static int now_advection(udc_handle *h) {
   if (tend_clean(h) || um_materialise(h)) return 1;
   if ((h->mom_simple ? k_momentum(h, true, false, false) : k_momentum_lds(h, true, false, false, false, 0.))) return 1;
   for (int n : h->slots)
@@ -341,8 +355,7 @@ extern "C" int udc_advection(udc_handle *h) {
   return 0;
 }
 
-extern "C" int udc_subgrid(udc_handle *h) {
-  HIP_OK(hipSetDevice(h->device));
+static int now_subgrid(udc_handle *h) {
   if (tend_clean(h) || um_materialise(h)) return 1;
   if (k_closure(h)) return 1;
   if (k_ek_ghosts(h)) return 1;
@@ -356,7 +369,7 @@ extern "C" int udc_subgrid(udc_handle *h) {
 }
 
 extern "C" int udc_set_tempeq(udc_handle *h, int iadv_thl, int bctopt, double wttop, double thl_top, int bcbott, double wtsurf) {
-  HIP_OK(hipSetDevice(h->device));
+  ENTRY_FLUSH(h);
   if (h->cfg.nsv > 15) { udc_set_error("udc_set_tempeq: thl uses scalar slot 15, nsv must be <= 15"); return 1; }
   if (iadv_thl != 2 && iadv_thl != 7) { udc_set_error("udc_set_tempeq: iadv_thl must be 2 (cd2, advecc_2nd) or 7 (kappa, advecc_kappa)"); return 1; }
   if (bctopt != 1 && bctopt != 2) { udc_set_error("udc_set_tempeq: BCtopT must be 1 (flux) or 2 (value)"); return 1; }
@@ -381,6 +394,7 @@ extern "C" int udc_set_tempeq(udc_handle *h, int iadv_thl, int bctopt, double wt
 }
 
 extern "C" int udc_set_chem(udc_handle *h, int lchem, double k1, double jno2) {
+  ENTRY_FLUSH(h);
   if (lchem && h->cfg.nsv < 3) { udc_set_error("udc_set_chem: the NO, NO2, O3 chemistry needs nsv >= 3 (src/modchem.f90:50-52)"); return 1; }
   h->lchem = lchem ? 1 : 0; h->chem_k1 = k1; h->chem_jno2 = jno2;
   return 0;
@@ -398,13 +412,13 @@ extern "C" int udc_set_shifted_pbc(udc_handle *h, double a, const double *sinx, 
   return 0;
 }
 
-extern "C" int udc_shifted_pbcs(udc_handle *h) {
-  HIP_OK(hipSetDevice(h->device));
+static int now_shifted_pbcs(udc_handle *h) {
   if (tend_clean(h) || um_materialise(h)) return 1;
   return k_shifted_pbcs(h, false);
 }
 
 extern "C" int udc_set_scalar_top(udc_handle *h, int n, int bctops, double value) {
+  ENTRY_FLUSH(h);
   if (n < 0 || n >= h->cfg.nsv) { udc_set_error("udc_set_scalar_top: scalar %d of %d", n, h->cfg.nsv); return 1; }
   if (bctops != 1 && bctops != 2) { udc_set_error("udc_set_scalar_top: BCtops must be 1 (flux) or 2 (value)"); return 1; }
   h->slot[n].top = bctops == 2 ? 2 : (value != 0. ? 1 : 0);
@@ -413,7 +427,7 @@ extern "C" int udc_set_scalar_top(udc_handle *h, int n, int bctops, double value
 }
 
 extern "C" int udc_set_scalar_source(udc_handle *h, int n, const double *src, const int lb[3], const int ub[3]) {
-  HIP_OK(hipSetDevice(h->device));
+  ENTRY_FLUSH(h);
   if (n < 0 || n >= h->cfg.nsv) { udc_set_error("udc_set_scalar_source: scalar %d of %d", n, h->cfg.nsv); return 1; }
   udc_handle::ScalarSource &s = h->svsrc[n];
   if (s.d) { HIP_OK(hipFree(s.d)); s.d = nullptr; }
@@ -430,13 +444,13 @@ extern "C" int udc_set_scalar_source(udc_handle *h, int n, const double *src, co
   return 0;
 }
 
-extern "C" int udc_scalsource(udc_handle *h) {
-  HIP_OK(hipSetDevice(h->device));
+static int now_scalsource(udc_handle *h) {
   if (tend_clean(h)) return 1;
   return k_scalsource(h);
 }
 
 extern "C" int udc_set_floor_wf(udc_handle *h, int bcbotm, int bcbott, double thls, double z0h, double prandtlturb) {
+  ENTRY_FLUSH(h);
   if (!h->p.lbottom) { udc_set_error("udc_set_floor_wf: the floor is off (udc_config.lbottom)"); return 1; }
   if (bcbotm != 2 && bcbotm != 3) { udc_set_error("udc_set_floor_wf: BCbotm must be 2 (wfuno) or 3 (wfmneutral)"); return 1; }
   if (bcbott != 1 && bcbott != 2) { udc_set_error("udc_set_floor_wf: BCbotT must be 1 (flux) or 2 (wfuno)"); return 1; }
@@ -450,7 +464,7 @@ extern "C" int udc_set_floor_wf(udc_handle *h, int bcbotm, int bcbott, double th
 }
 
 extern "C" int udc_set_moisture(udc_handle *h, int iadv_qt, int bctopq, double wqtop, double qt_top, int bcbotq, double wqsurf) {
-  HIP_OK(hipSetDevice(h->device));
+  ENTRY_FLUSH(h);
   if (h->cfg.nsv > 13) { udc_set_error("udc_set_moisture: qt uses scalar slot 13, nsv must be <= 13"); return 1; }
   if (iadv_qt != 2) { udc_set_error("udc_set_moisture: only iadv_qt = 2 (cd2, advecc_2nd) exists (src/modadvection.f90:79-85)"); return 1; }
   if (bctopq != 1 && bctopq != 2) { udc_set_error("udc_set_moisture: BCtopq must be 1 (flux) or 2 (value)"); return 1; }
@@ -475,7 +489,7 @@ extern "C" int udc_set_moisture(udc_handle *h, int iadv_qt, int bctopq, double w
 }
 
 extern "C" int udc_set_moist_thermo(udc_handle *h, double thls, double qts, double ps, const double *zf, const double *zh, int n, int lqlnr) {
-  HIP_OK(hipSetDevice(h->device));
+  ENTRY_FLUSH(h);
   const int nz = h->g.nz, n2 = nz + 2;
   if (!h->lmoist) { udc_set_error("udc_set_moist_thermo: call udc_set_moisture first"); return 1; }
   if ((int)h->fields.size() <= UDC_THL0 || !h->fields[UDC_THL0]) { udc_set_error("udc_set_moist_thermo: call udc_set_tempeq first"); return 1; }
@@ -493,12 +507,15 @@ extern "C" int udc_set_moist_thermo(udc_handle *h, double thls, double qts, doub
 }
 
 extern "C" int udc_thermodynamics(udc_handle *h) {
-  HIP_OK(hipSetDevice(h->device));
-  return k_thermodynamics(h);
+  ENTRY_FLUSH(h);
+  if (h->thermo_fresh) return 0;      // the fused substep ended with it (src/program.f90:214) and nothing changed since
+  if (k_thermodynamics(h)) return 1;
+  h->thermo_fresh = true;
+  return 0;
 }
 
 extern "C" int udc_thermo_state(udc_handle *h, double *tables, int n, int set) {
-  HIP_OK(hipSetDevice(h->device));
+  ENTRY_FLUSH(h);
   const int nz = h->g.nz, n2 = nz + 2;
   if (!h->mt) { udc_set_error("udc_thermo_state: call udc_set_moist_thermo first"); return 1; }
   if (n != nz + 1) { udc_set_error("udc_thermo_state: expected %d levels", nz + 1); return 1; }
@@ -509,6 +526,7 @@ extern "C" int udc_thermo_state(udc_handle *h, double *tables, int n, int set) {
     HIP_OK(hipMemcpyAsync(h->mt, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream));
     h->mt_valid = true;
+    h->thermo_fresh = false;
   } else {
     if (!h->mt_valid) { udc_set_error("udc_thermo_state: no thermodynamics call has been made yet"); return 1; }
     HIP_OK(hipMemcpyAsync(t.data(), h->mt, sizeof(double) * t.size(), hipMemcpyDeviceToHost, h->stream));
@@ -521,7 +539,7 @@ extern "C" int udc_thermo_state(udc_handle *h, double *tables, int n, int set) {
 
 extern "C" int udc_set_tke(udc_handle *h, double cm, double cn, double ch1, double ch2, double ce1, double ce2, double e12min,
                            double grav, double thvs, int ldelta) {
-  HIP_OK(hipSetDevice(h->device));
+  ENTRY_FLUSH(h);
   if (h->cfg.nsv > 14) { udc_set_error("udc_set_tke: e12 uses scalar slot 14, nsv must be <= 14"); return 1; }
   if (!(thvs > 0.) || !(e12min > 0.)) { udc_set_error("udc_set_tke: thvs and e12min must be positive"); return 1; }
   const bool have = (int)h->fields.size() > UDC_E120 && h->fields[UDC_E120];
@@ -542,6 +560,7 @@ extern "C" int udc_set_tke(udc_handle *h, double cm, double cn, double ch1, doub
 }
 
 extern "C" int udc_set_buoyancy(udc_handle *h, int lbuoyancy, double grav) {
+  ENTRY_FLUSH(h);
   if (lbuoyancy && h->lmoist && !h->mt) {
     udc_set_error("udc_set_buoyancy: with moisture, call udc_set_moist_thermo first (surface values, pressure, level heights)");
     return 1;
@@ -556,7 +575,7 @@ extern "C" int udc_set_buoyancy(udc_handle *h, int lbuoyancy, double grav) {
 }
 
 extern "C" int udc_set_thl_source(udc_handle *h, const double *thlpcar, int n) {
-  HIP_OK(hipSetDevice(h->device));
+  ENTRY_FLUSH(h);
   if (n != h->g.nz) { udc_set_error("udc_set_thl_source: expected %d levels", h->g.nz); return 1; }
   if ((int)h->fields.size() <= UDC_THL0 || !h->fields[UDC_THL0]) { udc_set_error("udc_set_thl_source: call udc_set_tempeq first"); return 1; }
   std::vector<double> t(h->g.nz + 2, 0.0);
@@ -566,8 +585,7 @@ extern "C" int udc_set_thl_source(udc_handle *h, const double *thlpcar, int n) {
   return 0;
 }
 
-extern "C" int udc_bottom(udc_handle *h) {
-  HIP_OK(hipSetDevice(h->device));
+static int now_bottom(udc_handle *h) {
   if (h->p.sgs == UDC_SGS_ONEEQN && k_tke_floor(h)) return 1;      // unconditional part of `bottom`
   if (!h->p.lbottom) return 0;
   if (tend_clean(h) || um_materialise(h)) return 1;
@@ -575,7 +593,7 @@ extern "C" int udc_bottom(udc_handle *h) {
 }
 
 extern "C" int udc_set_coriolis(udc_handle *h, int mode, double om22, double om23, const double *ug, int n) {
-  HIP_OK(hipSetDevice(h->device));
+  ENTRY_FLUSH(h);
   if (mode < 0 || mode > 2) { udc_set_error("udc_set_coriolis: mode 0 (off), 1 (lcoriol) or 2 (lprofforc)"); return 1; }
   if (mode == 2 && (!ug || n != h->g.nz)) { udc_set_error("udc_set_coriolis: lprofforc needs ug(kb:ke)"); return 1; }
   h->coriolis_mode = mode; h->om22 = om22; h->om23 = om23;
@@ -586,21 +604,20 @@ extern "C" int udc_set_coriolis(udc_handle *h, int mode, double om22, double om2
   return 0;
 }
 
-extern "C" int udc_coriolis(udc_handle *h) {
-  HIP_OK(hipSetDevice(h->device));
+static int now_coriolis(udc_handle *h) {
   if (!h->coriolis_mode) return 0;
   if (tend_clean(h) || um_materialise(h)) return 1;
   return k_coriolis(h, false);
 }
 
 extern "C" int udc_slab_average(udc_handle *h, int field, double *avg, int n) {
-  HIP_OK(hipSetDevice(h->device));
+  ENTRY_FLUSH(h);
   if (field >= UDC_UM && field <= UDC_WM && um_materialise(h)) return 1;
   return k_slab_average(h, field, avg, n);
 }
 
 extern "C" int udc_slab_averages(udc_handle *h, const int *fields, int nf, double *avg, int n) {
-  HIP_OK(hipSetDevice(h->device));
+  ENTRY_FLUSH(h);
   if (um_materialise(h)) return 1;
   return k_slab_averages(h, fields, nf, avg, n);
 }
@@ -643,36 +660,33 @@ extern "C" int udc_set_level_forcing(udc_handle *h, int tend, int src, const dou
   return 0;
 }
 
-extern "C" int udc_level_forcings(udc_handle *h, int when) {
-  HIP_OK(hipSetDevice(h->device));
+static int now_level_forcings(udc_handle *h, int when) {
   if (h->level_forcings.empty()) return 0;
   if (tend_clean(h) || um_materialise(h)) return 1;
   return k_level_forcings(h, when ? 1 : 0, false);
 }
 
 extern "C" int udc_set_masscorr(udc_handle *h, int luvolflowr, double uflowrate, int lvvolflowr, double vflowrate) {
+  ENTRY_FLUSH(h);
   h->luvolflowr = luvolflowr ? 1 : 0; h->uflowrate = uflowrate;
   h->lvvolflowr = lvvolflowr ? 1 : 0; h->vflowrate = vflowrate;
   return 0;
 }
 
-extern "C" int udc_masscorr(udc_handle *h, int rk3step, double dt) {
-  HIP_OK(hipSetDevice(h->device));
+static int now_masscorr(udc_handle *h, int rk3step, double dt) {
   if (!h->luvolflowr && !h->lvvolflowr) return 0;
   if (tend_clean(h) || um_materialise(h)) return 1;
   return k_masscorr(h, dt / (4. - (double)rk3step), false, false);
 }
 
-extern "C" int udc_forces(udc_handle *h) {
-  HIP_OK(hipSetDevice(h->device));
+static int now_forces(udc_handle *h) {
   if (tend_clean(h) || um_materialise(h)) return 1;
   if (h->thlpcar && k_level_source(h, 15, h->thlpcar)) return 1;      // thlp += thlpcar(k), src/modforces.f90:104-110
   if (k_forces(h)) return 1;
   return k_buoyancy(h);
 }
 
-extern "C" int udc_poisson(udc_handle *h, int rk3step, double dt) {
-  HIP_OK(hipSetDevice(h->device));
+static int now_poisson(udc_handle *h, int rk3step, double dt) {
   if (tend_clean(h) || um_materialise(h)) return 1;
   const double rk3coef = rk3step == 0 ? 1. : dt / (4. - (double)rk3step);
   const int fvp[1] = {UDC_VP};
@@ -687,9 +701,9 @@ extern "C" int udc_poisson(udc_handle *h, int rk3step, double dt) {
   return 0;
 }
 
-extern "C" int udc_tstep_integrate(udc_handle *h, int rk3step, double dt) {
-  HIP_OK(hipSetDevice(h->device));
+static int now_tstep_integrate(udc_handle *h, int rk3step, double dt) {
   if (tend_clean(h) || um_materialise(h)) return 1;
+  h->halos_fresh = h->boundary_fresh = h->thermo_fresh = false;
   if (k_integrate(h, rk3step, dt)) return 1;
   if (rk3step == 3 && k_chem(h, dt)) return 1;      // src/modtstep.f90:236-238
   return 0;
@@ -704,37 +718,55 @@ static int scalar_halo_list(udc_handle *h, int rk3step, std::vector<int> &f) {
 }
 
 extern "C" int udc_halos(udc_handle *h) {
-  HIP_OK(hipSetDevice(h->device));
+  ENTRY_FLUSH(h);
+  if (h->halos_fresh) return 0;       // the fused substep already exchanged them and nothing changed since
   if (um_materialise(h)) return 1;
   const int f[6] = {UDC_U0, UDC_V0, UDC_W0, UDC_UM, UDC_VM, UDC_WM};
   if (k_halo_y(h, f, 6, 1)) return 1;
   std::vector<int> s;
   scalar_halo_list(h, -1, s);
   if (!s.empty() && k_halo_y(h, s.data(), (int)s.size(), 2)) return 1;
+  h->halos_fresh = true;
+  h->boundary_fresh = false;
   return 0;
 }
 
 extern "C" int udc_boundary(udc_handle *h) {
-  HIP_OK(hipSetDevice(h->device));
+  ENTRY_FLUSH(h);
+  if (h->boundary_fresh) return 0;
   if (um_materialise(h)) return 1;
-  return k_top_bottom(h);
+  if (k_top_bottom(h)) return 1;
+  h->boundary_fresh = h->halos_fresh;      // (boundary before halos leaves the ghost rows of the top planes stale)
+  return 0;
 }
 
 extern "C" int udc_tstep_maxima(udc_handle *h, double dt, double *courtot, double *diffnrtot) {
-  HIP_OK(hipSetDevice(h->device));
+  ENTRY_FLUSH(h);
   return k_maxima(h, dt, courtot, diffnrtot);
 }
 
 extern "C" int udc_divergence(udc_handle *h, double *divmax, double *divtot) {
-  HIP_OK(hipSetDevice(h->device));
+  ENTRY_FLUSH(h);
   return k_divergence_check(h, divmax, divtot);
 }
 
-extern "C" int udc_substep(udc_handle *h, int rk3step, double dt, int with_forces) {
-  HIP_OK(hipSetDevice(h->device));
+
+// ------------------------------------------------------------------------------ whole substep
+// The tendency routines of one RK3 substep, as bits (in the reference's call order, src/program.f90:142-193)
+enum : unsigned {
+  OP_ADV = 1u << 0, OP_SHIFT = 1u << 1, OP_SUBGRID = 1u << 2, OP_BOTTOM = 1u << 3, OP_CORIOLIS = 1u << 4,
+  OP_FORCES = 1u << 5, OP_LEV0 = 1u << 6, OP_MASSCORR = 1u << 7, OP_SCALSRC = 1u << 8, OP_LEV1 = 1u << 9,
+  OP_POISSON = 1u << 10
+};
+
+// advection, subgrid, poisson, tstep_integrate, halos, boundary, thermodynamics and the routines of `ops`, with kernels
+// fused across routine boundaries.  The additive terms are applied in a fixed order of their own (the momentum sweep
+// first); masscorr sees every momentum term the reference's masscorr sees.
+static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   const double rk3coef = dt / (4. - (double)rk3step);
   const bool lds = !h->mom_simple;
   const bool pup = lds && !h->no_pup;
+  const bool forces = (ops & OP_FORCES) != 0;
   // single slab (whole y extent local): the ghost-row/plane updates of closurebc, bcpup, bcp, halos and
   // boundary are written by the kernels that own the neighbouring cells -> 7 fewer launches per substep
   const bool fold = lds && !h->slab && !h->no_fold;
@@ -743,6 +775,7 @@ extern "C" int udc_substep(udc_handle *h, int rk3step, double dt, int with_force
   const bool alias_ok = pup && !h->no_alias;
   if (h->um_alias && !(alias_ok && rk3step == 1)) { if (um_materialise(h)) return 1; }
   const bool rotate = h->um_alias;                    // only true here for an aliased stage 1
+  h->halos_fresh = h->boundary_fresh = h->thermo_fresh = false;
   // closure first: it only needs u0,v0,w0, and the fused sweep below needs ekm
   if (fold && h->p.sgs != UDC_SGS_DNS && h->p.sgs != UDC_SGS_ONEEQN) {
     if (k_closure_lds(h, true)) return 1;
@@ -750,26 +783,26 @@ extern "C" int udc_substep(udc_handle *h, int rk3step, double dt, int with_force
     if (k_closure(h)) return 1;
     if (k_ek_ghosts(h)) return 1;
   }
-  if (lds ? k_momentum_lds(h, true, true, with_forces != 0, true, pup ? 1. / rk3coef : 0., rotate)
-          : k_momentum(h, true, true, with_forces != 0)) return 1;
+  if (lds ? k_momentum_lds(h, true, true, forces, true, pup ? 1. / rk3coef : 0., rotate)
+          : k_momentum(h, true, true, forces)) return 1;
   if (k_scalar_top_flux(h)) return 1;
   for (int n : h->slots)
     if (k_scalar_fused(h, n, lds)) return 1;       // lds: the tendencies are scratch between fused substeps (tend_scratch)
   if (h->p.sgs == UDC_SGS_ONEEQN) {
     if (k_tke_sources(h)) return 1;                // subgrid's `sources`, after the diffusion terms
-    if (k_tke_floor(h)) return 1;                  // first lines of `bottom` (src/program.f90:152)
+    if ((ops & OP_BOTTOM) && k_tke_floor(h)) return 1;   // first lines of `bottom` (src/program.f90:152)
   }
-  if (with_forces && h->thlpcar && k_level_source(h, 15, h->thlpcar)) return 1;
-  if (with_forces && k_buoyancy(h)) return 1;        // additive on wp(kb+1..ke), hence on pwp
+  if (forces && h->thlpcar && k_level_source(h, 15, h->thlpcar)) return 1;
+  if (forces && k_buoyancy(h)) return 1;        // additive on wp(kb+1..ke), hence on pwp
   // `bottom` (src/program.f90:152): additive on the k = kb tendencies, hence equally on pup = up + um/rk3coef
-  if (h->p.lbottom && k_bottom(h, fold)) return 1;
-  if (with_forces && k_coriolis(h, fold)) return 1;        // src/program.f90:158; wrap of vp's ghost row follows below
-  if (k_shifted_pbcs(h, fold)) return 1;                   // src/program.f90:144 (additive on the momentum tendencies)
-  if (with_forces && !h->level_forcings.empty() && k_level_forcings(h, 0, fold)) return 1;   // lstend, nudge tables
+  if ((ops & OP_BOTTOM) && h->p.lbottom && k_bottom(h, fold)) return 1;
+  if ((ops & OP_CORIOLIS) && k_coriolis(h, fold)) return 1;        // src/program.f90:158; wrap of vp's ghost row follows below
+  if ((ops & OP_SHIFT) && k_shifted_pbcs(h, fold)) return 1;       // src/program.f90:144 (additive on the momentum tendencies)
+  if ((ops & OP_LEV0) && !h->level_forcings.empty() && k_level_forcings(h, 0, fold)) return 1;   // lstend, nudge tables
   // masscorr (src/program.f90:169); without pup the tendencies and um are summed separately
-  if (k_masscorr(h, rk3coef, pup, fold)) return 1;
-  if (k_scalsource(h)) return 1;                                       // src/program.f90:181
-  if (with_forces && !h->level_forcings.empty() && k_level_forcings(h, 1, fold)) return 1;   // grwdamp tables
+  if ((ops & OP_MASSCORR) && k_masscorr(h, rk3coef, pup, fold)) return 1;
+  if ((ops & OP_SCALSRC) && k_scalsource(h)) return 1;                                       // src/program.f90:181
+  if ((ops & OP_LEV1) && !h->level_forcings.empty() && k_level_forcings(h, 1, fold)) return 1;   // fixuinf1, grwdamp tables
   if (!fold) {
     const int fvp[1] = {UDC_VP};
     if (k_halo_y(h, fvp, 1, 1)) return 1;
@@ -799,8 +832,121 @@ extern "C" int udc_substep(udc_handle *h, int rk3step, double dt, int with_force
   scalar_halo_list(h, rk3step, s);
   if (!s.empty() && k_halo_y(h, s.data(), (int)s.size(), 2)) return 1;
   if (!fold || !h->slots.empty()) { if (k_top_bottom(h)) return 1; }
-  if (h->lmoist && h->mt && k_thermodynamics(h)) return 1;             // src/program.f90:214
+  h->halos_fresh = h->boundary_fresh = true;
+  if (h->lmoist && h->mt) {                                             // src/program.f90:214
+    if (k_thermodynamics(h)) return 1;
+    h->thermo_fresh = true;
+  }
   return 0;
+}
+
+// ------------------------------------------------------------------------------ deferred execution
+static int run_op(udc_handle *h, unsigned op) {
+  switch (op) {
+    case OP_ADV: return now_advection(h);
+    case OP_SHIFT: return now_shifted_pbcs(h);
+    case OP_SUBGRID: return now_subgrid(h);
+    case OP_BOTTOM: return now_bottom(h);
+    case OP_CORIOLIS: return now_coriolis(h);
+    case OP_FORCES: return now_forces(h);
+    case OP_LEV0: return now_level_forcings(h, 0);
+    case OP_MASSCORR: return now_masscorr(h, h->pend_rk, h->pend_dt);
+    case OP_SCALSRC: return now_scalsource(h);
+    case OP_LEV1: return now_level_forcings(h, 1);
+    case OP_POISSON: return now_poisson(h, h->pend_rk, h->pend_dt);
+  }
+  udc_set_error("deferred execution: unknown routine bit %u", op);
+  return 1;
+}
+
+// Run whatever is recorded, routine by routine, in call order.
+int udc_flush_pending(udc_handle *h) {
+  if (h->pend.empty()) return 0;
+  std::vector<unsigned> ops;
+  ops.swap(h->pend);
+  for (unsigned op : ops)
+    if (run_op(h, op)) return 1;
+  h->pend_rk = 0;
+  ++h->n_unfused;
+  return 0;
+}
+
+static int defer(udc_handle *h, unsigned op, int rk3step = 0, double dt = 0.) {
+  if (rk3step) {
+    if (h->pend_rk && (h->pend_rk != rk3step || h->pend_dt != dt)) { if (udc_flush_pending(h)) return 1; }
+    h->pend_rk = rk3step; h->pend_dt = dt;
+  }
+  h->pend.push_back(op);
+  return 0;
+}
+
+
+extern "C" int udc_set_deferred(udc_handle *h, int on) {
+  ENTRY_FLUSH(h);
+  h->deferred = on != 0;
+  return 0;
+}
+extern "C" int udc_flush(udc_handle *h) { ENTRY_FLUSH(h); return 0; }
+extern "C" int udc_deferred_stats(udc_handle *h, long *fused, long *unfused) {
+  if (!h) return 1;
+  if (fused) *fused = h->n_fused;
+  if (unfused) *unfused = h->n_unfused;
+  return 0;
+}
+
+extern "C" int udc_advection(udc_handle *h) { ENTRY(h); return h->deferred ? defer(h, OP_ADV) : now_advection(h); }
+extern "C" int udc_shifted_pbcs(udc_handle *h) { ENTRY(h); return h->deferred ? defer(h, OP_SHIFT) : now_shifted_pbcs(h); }
+extern "C" int udc_subgrid(udc_handle *h) { ENTRY(h); return h->deferred ? defer(h, OP_SUBGRID) : now_subgrid(h); }
+extern "C" int udc_bottom(udc_handle *h) { ENTRY(h); return h->deferred ? defer(h, OP_BOTTOM) : now_bottom(h); }
+extern "C" int udc_coriolis(udc_handle *h) { ENTRY(h); return h->deferred ? defer(h, OP_CORIOLIS) : now_coriolis(h); }
+extern "C" int udc_forces(udc_handle *h) { ENTRY(h); return h->deferred ? defer(h, OP_FORCES) : now_forces(h); }
+extern "C" int udc_level_forcings(udc_handle *h, int when) {
+  ENTRY(h);
+  return h->deferred ? defer(h, when ? OP_LEV1 : OP_LEV0) : now_level_forcings(h, when);
+}
+extern "C" int udc_masscorr(udc_handle *h, int rk3step, double dt) {
+  ENTRY(h);
+  if (rk3step < 1 || rk3step > 3) { udc_set_error("udc_masscorr: rk3step %d", rk3step); return 1; }
+  return h->deferred ? defer(h, OP_MASSCORR, rk3step, dt) : now_masscorr(h, rk3step, dt);
+}
+extern "C" int udc_scalsource(udc_handle *h) { ENTRY(h); return h->deferred ? defer(h, OP_SCALSRC) : now_scalsource(h); }
+extern "C" int udc_poisson(udc_handle *h, int rk3step, double dt) {
+  ENTRY(h);
+  // (rk3step 0 = "rk3coef 1", a bare projection: never part of a substep, runs at once)
+  if (h->deferred && rk3step >= 1 && rk3step <= 3) return defer(h, OP_POISSON, rk3step, dt);
+  if (udc_flush_pending(h)) return 1;
+  return now_poisson(h, rk3step, dt);
+}
+
+extern "C" int udc_tstep_integrate(udc_handle *h, int rk3step, double dt) {
+  ENTRY(h);
+  if (!h->pend.empty()) {
+    // the reference's own sequence (each routine at most once, in program.f90's order, advection + subgrid + poisson
+    // present, masscorr/poisson recorded with this substep's rk3step and dt) runs as the fused substep
+    unsigned mask = 0, last = 0;
+    bool canon = true;
+    for (unsigned op : h->pend) {
+      if (op <= last) canon = false;
+      last = op; mask |= op;
+    }
+    const unsigned need = OP_ADV | OP_SUBGRID | OP_POISSON;
+    if ((mask & need) != need || h->pend_rk != rk3step || h->pend_dt != dt) canon = false;
+    if (canon) {
+      h->pend.clear();
+      h->pend_rk = 0;
+      ++h->n_fused;
+      return substep_fused(h, rk3step, dt, mask);
+    }
+    if (udc_flush_pending(h)) return 1;
+  }
+  return now_tstep_integrate(h, rk3step, dt);
+}
+
+extern "C" int udc_substep(udc_handle *h, int rk3step, double dt, int with_forces) {
+  ENTRY_FLUSH(h);
+  unsigned ops = OP_ADV | OP_SHIFT | OP_SUBGRID | OP_BOTTOM | OP_MASSCORR | OP_SCALSRC | OP_POISSON;
+  if (with_forces) ops |= OP_CORIOLIS | OP_FORCES | OP_LEV0 | OP_LEV1;
+  return substep_fused(h, rk3step, dt, ops);
 }
 
 extern "C" int udc_run(udc_handle *h, int nsubsteps, int rk3step0, double dt, int with_forces) {

@@ -165,6 +165,18 @@ struct udc_handle {
   bool no_fold = false;                 // UDC_NO_FOLD=1: keep separate ghost-row kernels on a single slab (A/B switch)
   bool no_pup = false;                  // UDC_NO_PUP=1: keep bare tendencies in the fused substep (A/B switch)
   bool mom_simple = false;              // UDC_MOM_SIMPLE=1: use the direct-load momentum kernel
+  // deferred execution (udc_set_deferred): the tendency routines of one RK3 substep are recorded instead of launched;
+  // udc_tstep_integrate then runs the recorded sequence -- as the fused substep when it is the reference's own
+  // (src/program.f90:142-197), routine by routine otherwise.  pend holds OP_* bits in call order.
+  bool deferred = false;
+  std::vector<unsigned> pend;
+  int pend_rk = 0;                      // rk3step / dt handed to the recorded masscorr / poisson (0 = none recorded)
+  double pend_dt = 0.;
+  // what the last whole substep (or udc_halos / udc_boundary / udc_thermodynamics) left valid; any change of the
+  // prognostic fields clears them, so that a driver's own halos / boundary / thermodynamics calls after a fused substep
+  // (which already did them) cost nothing
+  bool halos_fresh = false, boundary_fresh = false, thermo_fresh = false;
+  long n_fused = 0, n_unfused = 0;      // deferred substeps that ran fused / routine by routine (udc_deferred_stats)
   bool prof = false;
   std::vector<ProfEntry> prof_events;
   std::vector<hipEvent_t> prof_pool;

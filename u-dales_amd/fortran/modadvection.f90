@@ -28,16 +28,9 @@ contains
       stop 1
     end if
 
-    call udc_ensure
-    select case (udc_residency)
-    case (0)
-      call udc_push_state
-      call udc_push_tend
-    case (1)
-      call udc_push_tend
-    end select
+    call udc_begin(.true.)
     call udc_check(udc_advection(udc_h), 'udc_advection')
-    if (udc_residency <= 1) call udc_pull_tend
+    if (udc_mode() <= 1) call udc_pull_tend
   end subroutine advection
 
 end module modadvection

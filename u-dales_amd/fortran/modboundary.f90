@@ -1,0 +1,184 @@
+!> Drop-in replacement for the reference's module modboundary (src/modboundary.f90).
+!! Same module name and public list (src/modboundary.f90:29-30).  halos (:67) and boundary (:115) run on the device
+!! (udc_halos, udc_boundary; after a fused substep, which already did both, they find nothing left to do); grwdamp (:1447)
+!! builds its per-level tables here and the device adds them.  The library implements the periodic lateral conditions
+!! with a free-slip / no-slip top and flux / value tops for the scalars -- what `boundary` does for BCxm = BCym = 1;
+!! inflow-outflow decks are refused by initboundary.
+!!
+!! bcp, bcpup and closurebc (called only from modpois and modsubgrid, both replaced) and the x*/y*_periodic helpers are
+!! part of the device kernels; the names stay public so that `use modboundary, only: ...` keeps compiling, and stop
+!! with the reference's error convention if something calls them.
+module modboundary
+  use iso_c_binding, only: c_int, c_double
+  implicit none
+  save
+  private
+  public :: initboundary, boundary, grwdamp, ksp, tqaver, halos, bcp, bcpup, closurebc, &
+            xm_periodic, xT_periodic, xq_periodic, xs_periodic, ym_periodic, yT_periodic, yq_periodic, ys_periodic
+  integer :: ksp = -1                 !< lowest level of the sponge layer (&DOMAIN ksp; -1 = default)
+  real, allocatable :: tsc(:)         !< damping coefficients of grwdamp
+  real :: rnu0 = 2.75e-3
+
+contains
+
+  !> sponge layer coefficients (src/modboundary.f90:38-65)
+  subroutine initboundary
+    use modglobal, only: ib, kb, ke, kh, kmax, pi, zf, iplane, BCxm, BCym, BCtopm, BCtopm_pressure
+    use modinletdata, only: irecy
+    real :: zspb, zspt
+    integer :: k
+    if (BCxm /= 1 .or. BCym /= 1 .or. BCtopm == BCtopm_pressure) then
+      write (0, *) 'ERROR: libudcore boundary: only periodic x/y with a free-slip or no-slip top'
+      stop 1
+    end if
+    allocate (tsc(kb:ke + kh))
+    if (ksp == -1) ksp = (kb - 1) + max(min(3*kmax/4, kmax - 15), 1)
+    zspb = zf(ksp); zspt = zf(ke)
+    tsc = 0.
+    do k = ksp, ke
+      tsc(k) = rnu0*sin(0.5*pi*(zf(k) - zspb)/(zspt - zspb))**2
+    end do
+    tsc(ke + 1) = tsc(ke)
+    irecy = ib + iplane
+  end subroutine initboundary
+
+  !> periodic ghost cells of the prognostic fields (src/modboundary.f90:67-109)
+  subroutine halos
+    use modglobal, only: rk3step, timeleft, ntrun
+    use udc_iface
+    call udc_begin(.false.)
+    call udc_check(udc_halos(udc_h), 'udc_halos')
+    if (udc_mode() <= 1) then
+      call udc_pull_vel(.true.)
+    else if (rk3step == 3) then
+      ! device mode: checksim, fielddump and statsdump come next (src/program.f90:199-205) and read the host arrays
+      if (timeleft <= 0) then
+        call udc_pull_all
+      else if (udc_pull_every > 0) then
+        if (mod(ntrun, udc_pull_every) == 0) call udc_pull_all
+      end if
+    end if
+  end subroutine halos
+
+  !> w(kb) = 0 and the top ghost planes (src/modboundary.f90:115-247, periodic lateral subset)
+  subroutine boundary
+    use udc_iface
+    call udc_begin(.false.)
+    call udc_check(udc_boundary(udc_h), 'udc_boundary')
+    if (udc_mode() <= 1) call udc_pull_vel(.true.)
+  end subroutine boundary
+
+  !> gravity-wave damping in the sponge layer (src/modboundary.f90:1447-1492): tend -= (field - ref(k)) tsc(k).
+  !! Applied after masscorr together with fixuinf1's table; the constant scalar sources registered for a device-mode
+  !! run (udc_set_scalar_source) are added here as well, grwdamp being the first drop-in routine after the
+  !! reference's scalsource (src/program.f90:181-191).
+  subroutine grwdamp
+    use modglobal, only: kb, ke, lcoriol, igrw_damp, geodamptime, ltempeq, lmoist
+    use modfields, only: ug, vg, thl0av, qt0av, u0av, v0av
+    use udc_iface
+    integer :: k
+    real :: c
+    if (udc_scalsrc_on .and. udc_mode() == 2) call udc_check(udc_scalsource(udc_h), 'udc_scalsource')
+    select case (igrw_damp)
+    case (0)
+    case (1, 2, 3)
+      call udc_tab_start(1)
+      do k = ksp, ke
+        if (igrw_damp == 2) then
+          call damp(k, ROW_UP, ug(k), tsc(k))
+          call damp(k, ROW_VP, vg(k), tsc(k))
+        else
+          call damp(k, ROW_UP, u0av(k), tsc(k))
+          call damp(k, ROW_VP, v0av(k), tsc(k))
+        end if
+        call damp(k, ROW_WP, 0., tsc(k))
+        if (ltempeq) call damp(k, ROW_THLP, thl0av(k), tsc(k))
+        if (lmoist) call damp(k, ROW_QTP, qt0av(k), tsc(k))
+        if (igrw_damp == 1 .and. lcoriol) then
+          c = (1./(geodamptime*rnu0))*tsc(k)
+          call damp(k, ROW_UP, ug(k), c)
+          call damp(k, ROW_VP, vg(k), c)
+        end if
+      end do
+    case default
+      write (0, *) "ERROR: no gravity wave damping option selected"
+      stop 1
+    end select
+    call udc_tab_apply(1)
+  contains
+    subroutine damp(k, row, ref, coef)
+      integer, intent(in) :: k, row
+      real, intent(in) :: ref, coef
+      udc_tabA(k, row, 1) = udc_tabA(k, row, 1) + ref*coef
+      udc_tabB(k, row, 1) = udc_tabB(k, row, 1) - coef
+    end subroutine damp
+  end subroutine grwdamp
+
+  !> thl, qt and sv at level ke set to their slab averages (src/modboundary.f90:1556-1599; called by readinitfiles
+  !! on a warm start): host arithmetic on the host arrays, before the time loop
+  subroutine tqaver
+    use mpi
+    use modmpi, only: comm3d, mpierr, my_real
+    use modglobal, only: ib, ie, jb, je, ke, nsv, rslabs
+    use modfields, only: thl0, qt0, sv0
+    real :: loc(2 + max(nsv, 1)), tot(2 + max(nsv, 1))
+    integer :: n
+    loc(1) = sum(thl0(ib:ie, jb:je, ke)); loc(2) = sum(qt0(ib:ie, jb:je, ke))
+    do n = 1, nsv
+      loc(2 + n) = sum(sv0(ib:ie, jb:je, ke, n))
+    end do
+    call MPI_ALLREDUCE(loc, tot, 2 + nsv, MY_REAL, MPI_SUM, comm3d, mpierr)
+    tot = tot/rslabs
+    thl0(ib:ie, jb:je, ke) = tot(1); qt0(ib:ie, jb:je, ke) = tot(2)
+    do n = 1, nsv
+      sv0(ib:ie, jb:je, ke, n) = tot(2 + n)
+    end do
+  end subroutine tqaver
+
+  subroutine inside(what)
+    character(*), intent(in) :: what
+    write (0, *) 'ERROR: libudcore modboundary: ', what, ' is part of the device kernels and cannot be called on its own'
+    stop 1
+  end subroutine inside
+
+  subroutine bcp(p)
+    real, intent(inout) :: p(:, :, :)
+    call inside('bcp')
+  end subroutine bcp
+
+  subroutine bcpup(pup, pvp, pwp, rk3coef)
+    real, intent(inout) :: pup(:, :, :), pvp(:, :, :), pwp(:, :, :)
+    real, intent(in) :: rk3coef
+    call inside('bcpup')
+  end subroutine bcpup
+
+  subroutine closurebc
+    call inside('closurebc')
+  end subroutine closurebc
+
+  subroutine xm_periodic
+    call inside('xm_periodic')
+  end subroutine xm_periodic
+  subroutine xT_periodic
+    call inside('xT_periodic')
+  end subroutine xT_periodic
+  subroutine xq_periodic
+    call inside('xq_periodic')
+  end subroutine xq_periodic
+  subroutine xs_periodic
+    call inside('xs_periodic')
+  end subroutine xs_periodic
+  subroutine ym_periodic
+    call inside('ym_periodic')
+  end subroutine ym_periodic
+  subroutine yT_periodic
+    call inside('yT_periodic')
+  end subroutine yT_periodic
+  subroutine yq_periodic
+    call inside('yq_periodic')
+  end subroutine yq_periodic
+  subroutine ys_periodic
+    call inside('ys_periodic')
+  end subroutine ys_periodic
+
+end module modboundary

@@ -45,16 +45,9 @@ contains
     use modfields, only: pres0
     use udc_iface
     implicit none
-    call udc_ensure
-    select case (udc_residency)
-    case (0)
-      call udc_push_state
-      call udc_push_tend
-    case (1)
-      call udc_push_tend
-    end select
+    call udc_begin(.true.)
     call udc_check(udc_poisson(udc_h, int(rk3step, c_int), real(dt, c_double)), 'udc_poisson')
-    if (udc_residency <= 1) then
+    if (udc_mode() <= 1) then
       call udc_pull_tend
       call udc_pull3(UDC_P, p, (/ib - ih, jb - jh, kb - kh/))
       call udc_pull3(UDC_PRES0, pres0, (/ib - ih, jb - jh, kb - kh/))

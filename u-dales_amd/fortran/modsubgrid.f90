@@ -84,22 +84,15 @@ contains
     use modglobal, only: ib, jb, kb, ih, jh, kh, ltempeq, lmoist
     use udc_iface
     implicit none
-    call udc_ensure
-    select case (udc_residency)
-    case (0)
-      call udc_push_state
-      call udc_push_tend
-    case (1)
-      call udc_push_tend
-    end select
+    call udc_begin(.true.)
     call udc_check(udc_subgrid(udc_h), 'udc_subgrid')
-    if (udc_residency <= 1) then
+    if (udc_mode() <= 1) then
       call udc_pull_tend
       ! ekm/ekh are read by the host (statistics, tstep_update, IBM wall functions)
       call udc_pull3(UDC_EKM, ekm, (/ib - ih, jb - jh, kb - kh/))
       call udc_pull3(UDC_EKH, ekh, (/ib - ih, jb - jh, kb - kh/))
     end if
-    if (udc_residency == 0) call udc_pull_vel(.true.)   ! top ghost rows re-imposed by closurebc
+    if (udc_mode() == 0) call udc_pull_vel(.true.)   ! top ghost rows re-imposed by closurebc
   end subroutine subgrid
 
   subroutine exitsubgrid

@@ -11,8 +11,13 @@
 !!   UDC_RESIDENCY=1 ("tendencies")        velocities/pressure stay resident; only up,vp,wp (the
 !!                        arrays the reference's add-on physics modify, docs/udales-architecture.md:104)
 !!                        are exchanged, and u0,v0,w0 are pulled after tstep_integrate.
-!!   UDC_RESIDENCY=2 ("device")            nothing moves until udc_pull_all(); for drivers whose
-!!                        host-side routines in the loop are no-ops (neutral empty channel).
+!!   UDC_RESIDENCY=2 ("device")            inside the time loop nothing moves: the drop-in routines only record their call
+!!                        (udc_set_deferred) and tstep_integrate launches the fused substep.  The host arrays are
+!!                        refreshed (udc_pull_all) at the end of the run, when a restart file is due and every
+!!                        UDC_PULL_EVERY time steps (default: never) -- see the drop-in `halos` / `thermodynamics`.
+!!                        For decks whose remaining host routines in the loop are no-ops.
+!! Before the first tstep_update (start-up: readinitfiles calls halos / boundary / thermodynamics on host arrays that
+!! it is still filling) every mode behaves like 0.
 module udc_iface
   use iso_c_binding
   implicit none
@@ -45,6 +50,19 @@ module udc_iface
   ! src/modibm.f90:1998, edits the pulled tendencies and must not be applied twice); set by udc_set_floor
   logical, save :: udc_floor_on = .false.
   real(c_double), save :: udc_floor_z0 = -1.
+  logical, save :: udc_in_loop = .false.      !< set by the first tstep_update
+  logical, save :: udc_lqlnr = .false.        !< &DYNAMICS lqlnr (owned by modthermodynamics; copied by initthermodynamics)
+  logical, save :: udc_need_avg = .false.     !< some host routine reads diagfld's slab averages (lstend, nudge, grwdamp, fixuinf, shiftedPBCs)
+  logical, save :: udc_host_fresh = .true.    !< the host arrays hold the current state
+  !> per-level tables tend(i,j,k) += A(k) + B(k) field(i,j,k) under construction on the host (udc_tab_start/apply):
+  !! (level, row, when) with when = 0: applied before masscorr (lstend, nudge), 1: after it (fixuinf1, grwdamp)
+  integer, parameter :: ROW_UP = 1, ROW_VP = 2, ROW_WP = 3, ROW_THLP = 4, ROW_QTP = 5, ROW_SVP = 5
+  real(c_double), allocatable, save :: udc_tabA(:, :, :), udc_tabB(:, :, :)
+  logical, save :: udc_tab_open(0:1) = .false.
+  logical, save :: udc_tab_registered(0:1) = .false.
+  logical, save :: udc_row_registered(ROW_SVP + 16, 0:1) = .false.
+  logical, save :: udc_scalsrc_on = .false.   !< constant scalar sources are registered with the device (device mode)
+  integer, save :: udc_pull_every = 0         !< UDC_PULL_EVERY: refresh the host arrays every n-th time step in device mode
 
   interface
     integer(c_int) function udc_create(cfg, h) bind(C, name='udc_create')
@@ -200,6 +218,89 @@ module udc_iface
       type(c_ptr), value :: h
       integer(c_signed_char), intent(in) :: id(128)
     end function
+    integer(c_int) function udc_set_coriolis(h, mode, om22, om23, ug, n) bind(C, name='udc_set_coriolis')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: mode, n
+      real(c_double), value :: om22, om23
+      real(c_double), intent(in) :: ug(*)
+    end function
+    integer(c_int) function udc_coriolis(h) bind(C, name='udc_coriolis')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function udc_set_masscorr(h, lu, uflow, lv, vflow) bind(C, name='udc_set_masscorr')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: lu, lv
+      real(c_double), value :: uflow, vflow
+    end function
+    integer(c_int) function udc_masscorr(h, rk3step, dt) bind(C, name='udc_masscorr')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: rk3step
+      real(c_double), value :: dt
+    end function
+    integer(c_int) function udc_set_level_forcing(h, tend, src, A, B, n, when) bind(C, name='udc_set_level_forcing')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: tend, src, n, when
+      real(c_double), intent(in) :: A(*), B(*)
+    end function
+    integer(c_int) function udc_level_forcings(h, when) bind(C, name='udc_level_forcings')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+      integer(c_int), value :: when
+    end function
+    integer(c_int) function udc_slab_averages(h, fields, nf, avg, n) bind(C, name='udc_slab_averages')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      integer(c_int), intent(in) :: fields(*)
+      integer(c_int), value :: nf, n
+      real(c_double), intent(out) :: avg(*)
+    end function
+    integer(c_int) function udc_set_shifted_pbc(h, a, sinx, nx, u0av, nz) bind(C, name='udc_set_shifted_pbc')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      real(c_double), value :: a
+      real(c_double), intent(in) :: sinx(*), u0av(*)
+      integer(c_int), value :: nx, nz
+    end function
+    integer(c_int) function udc_shifted_pbcs(h) bind(C, name='udc_shifted_pbcs')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function udc_set_scalar_source(h, n, src, lb, ub) bind(C, name='udc_set_scalar_source')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: n
+      real(c_double), intent(in) :: src(*)
+      integer(c_int), intent(in) :: lb(3), ub(3)
+    end function
+    integer(c_int) function udc_scalsource(h) bind(C, name='udc_scalsource')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function udc_thermo_state(h, tables, n, set) bind(C, name='udc_thermo_state')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(inout) :: tables(*)
+      integer(c_int), value :: n, set
+    end function
+    integer(c_int) function udc_set_deferred(h, on) bind(C, name='udc_set_deferred')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+      integer(c_int), value :: on
+    end function
+    integer(c_int) function udc_flush(h) bind(C, name='udc_flush')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function udc_deferred_stats(h, fused, unfused) bind(C, name='udc_deferred_stats')
+      import :: c_int, c_ptr, c_long
+      type(c_ptr), value :: h
+      integer(c_long), intent(out) :: fused, unfused
+    end function
     integer(c_int) function udc_sync(h) bind(C, name='udc_sync')
       import :: c_int, c_ptr
       type(c_ptr), value :: h
@@ -242,11 +343,13 @@ contains
   subroutine udc_ensure
     use modglobal, only: itot, jtot, ktot, dx, dy, dzf, dzh, kb, ke, kh, numol, prandtlmoli, nsv, &
                          BCtopm, Uinf, Vinf, lles, ltempeq, lbuoyancy, lmoist, iadv_thl, BCtopT, BCbotT, grav, e12min, &
-                         iadv_qt, BCtopq, BCbotq, zf, zh, BCbotm, prandtlturb, BCtops, lchem, k1, JNO2
+                         iadv_qt, BCtopq, BCbotq, zf, zh, BCbotm, prandtlturb, BCtops, lchem, k1, JNO2, &
+                         lcoriol, lprofforc, om22, om23, luvolflowr, lvvolflowr, uflowrate, vflowrate, &
+                         lnudge, igrw_damp, ifixuinf, ds
     use modsurfdata, only: wttop, thl_top, wtsurf, thvs, wqtop, qt_top, wqsurf, thls, qts, ps, z0h, wsvtop, sv_top
-    use modthermodynamics, only: lqlnr
     use modsubgriddata, only: lsmagorinsky, lvreman, loneeqn, ldelta, prandtli, c_vreman, csz, cm, cn, ch1, ch2, ce1, ce2
-    use modfields, only: dpdxl, dpdyl, thlpcar
+    use modfields, only: dpdxl, dpdyl, thlpcar, ug, whls, dthldxls, dthldyls, dqtdxls, dqtdyls, dqtdtls, &
+                         dudxls, dudyls, dvdxls, dvdyls
     use modmpi, only: myid, nprocs, nprocx, comm3d, mpierr
     use mpi, only: MPI_CHARACTER
     type(udc_config) :: cfg
@@ -296,12 +399,10 @@ contains
       call MPI_BCAST(nccl_id, 128, MPI_CHARACTER, 0, comm3d, mpierr)
       call udc_check(udc_comm_init(udc_h, nccl_id), 'udc_comm_init')
     end if
-    call udc_check(udc_set_forcing(udc_h, dpdxl(kb:ke), dpdyl(kb:ke), int(ktot, c_int)), 'udc_set_forcing')
     if (ltempeq) then      ! temperature equation; the dry buoyancy term is on the device for device-resident runs
       ! (in residency 0/1 the host's own forces adds it to the pulled tendencies)
       call udc_check(udc_set_tempeq(udc_h, int(iadv_thl, c_int), int(BCtopT, c_int), real(wttop, c_double), &
                                     real(thl_top, c_double), int(BCbotT, c_int), real(wtsurf, c_double)), 'udc_set_tempeq')
-      call udc_check(udc_set_thl_source(udc_h, thlpcar(kb:ke), int(ktot, c_int)), 'udc_set_thl_source')
     end if
     if (lmoist) then       ! total water; with buoyancy the moist thermodynamics (thermo, diagfld, calthv) too
       call udc_check(udc_set_moisture(udc_h, int(iadv_qt, c_int), int(BCtopq, c_int), real(wqtop, c_double), &
@@ -309,7 +410,7 @@ contains
       if (ltempeq .and. (lbuoyancy .or. loneeqn_dev())) then      ! moist buoyancy / calthv's moist dthvdz
         call udc_check(udc_set_moist_thermo(udc_h, real(thls, c_double), real(qts, c_double), real(ps, c_double), &
                                             zf(kb:ke + kh), zh(kb:ke + kh), int(ktot + 1, c_int), &
-                                            merge(1_c_int, 0_c_int, lqlnr)), 'udc_set_moist_thermo')
+                                            merge(1_c_int, 0_c_int, udc_lqlnr)), 'udc_set_moist_thermo')
       end if
     end if
     if (ltempeq .and. lbuoyancy) call udc_check(udc_set_buoyancy(udc_h, 1_c_int, real(grav, c_double)), 'udc_set_buoyancy')
@@ -318,10 +419,6 @@ contains
                                       real(prandtlturb, c_double)), 'udc_set_floor_wf')
     end if
     if (lchem) call udc_check(udc_set_chem(udc_h, 1_c_int, real(k1, c_double), real(JNO2, c_double)), 'udc_set_chem')
-    do n = 1, nsv          ! top condition of the scalars (src/modboundary.f90:236-247)
-      call udc_check(udc_set_scalar_top(udc_h, int(n - 1, c_int), int(BCtops, c_int), &
-                                        real(merge(sv_top(n), wsvtop(n), BCtops == 2), c_double)), 'udc_set_scalar_top')
-    end do
     if (cfg%sgs == 3) then   ! after udc_set_tempeq: the closure reads thl0 when the temperature equation is on
       call udc_check(udc_set_tke(udc_h, real(cm, c_double), real(cn, c_double), real(ch1, c_double), real(ch2, c_double), &
                                  real(ce1, c_double), real(ce2, c_double), real(e12min, c_double), real(grav, c_double), &
@@ -329,8 +426,176 @@ contains
     end if
     call get_environment_variable('UDC_RESIDENCY', env, status=stat)
     if (stat == 0) read (env, *, iostat=stat) udc_residency
+    call get_environment_variable('UDC_PULL_EVERY', env, status=stat)
+    if (stat == 0) read (env, *, iostat=stat) udc_pull_every
+    call udc_late_setup
     call udc_push_state
   end subroutine udc_ensure
+
+  !> What depends on the input files readinitfiles reads (lscale.inp, scalar.inp: dpdxl, dpdyl, thlpcar, ug, whls, the
+  !! large-scale gradients, sv_top).  The handle may exist before they are in (readinitfiles itself calls halos /
+  !! boundary / thermodynamics), so this runs with every start-up call and a last time when the time loop starts.
+  subroutine udc_late_setup
+    use modglobal, only: ktot, kb, ke, nsv, ltempeq, BCtops, lcoriol, lprofforc, om22, om23, luvolflowr, lvvolflowr, &
+                         uflowrate, vflowrate, lnudge, igrw_damp, ifixuinf, ds
+    use modsurfdata, only: wsvtop, sv_top
+    use modfields, only: dpdxl, dpdyl, thlpcar, ug, whls, dthldxls, dthldyls, dqtdxls, dqtdyls, dqtdtls, &
+                         dudxls, dudyls, dvdxls, dvdyls
+    integer :: n
+    call udc_check(udc_set_forcing(udc_h, dpdxl(kb:ke), dpdyl(kb:ke), int(ktot, c_int)), 'udc_set_forcing')
+    if (ltempeq) then
+      call udc_check(udc_set_thl_source(udc_h, thlpcar(kb:ke), int(ktot, c_int)), 'udc_set_thl_source')
+    end if
+    do n = 1, nsv          ! top condition of the scalars (src/modboundary.f90:236-247)
+      call udc_check(udc_set_scalar_top(udc_h, int(n - 1, c_int), int(BCtops, c_int), &
+                                        real(merge(sv_top(n), wsvtop(n), BCtops == 2), c_double)), 'udc_set_scalar_top')
+    end do
+    ! coriolis (src/modforces.f90:600-717): lcoriol -> mode 1, lprofforc -> mode 2 (relaxation to ug)
+    if (lcoriol) then
+      call udc_check(udc_set_coriolis(udc_h, 1_c_int, real(om22, c_double), real(om23, c_double), ug(kb:ke), int(ktot, c_int)), &
+                     'udc_set_coriolis')
+    else if (lprofforc) then
+      call udc_check(udc_set_coriolis(udc_h, 2_c_int, real(om22, c_double), real(om23, c_double), ug(kb:ke), int(ktot, c_int)), &
+                     'udc_set_coriolis')
+    end if
+    ! masscorr, volume-flow branches (src/modforces.f90:389-417, 467-494)
+    call udc_check(udc_set_masscorr(udc_h, merge(1_c_int, 0_c_int, luvolflowr), real(uflowrate, c_double), &
+                                    merge(1_c_int, 0_c_int, lvvolflowr), real(vflowrate, c_double)), 'udc_set_masscorr')
+    ! does any host routine of the loop read diagfld's slab averages?
+    udc_need_avg = lnudge .or. igrw_damp /= 0 .or. ifixuinf /= 0 .or. ds > 0 .or. any(whls /= 0.) .or. &
+                   any(dthldxls /= 0.) .or. any(dthldyls /= 0.) .or. any(dqtdxls /= 0.) .or. any(dqtdyls /= 0.) .or. &
+                   any(dqtdtls /= 0.) .or. any(dudxls /= 0.) .or. any(dudyls /= 0.) .or. any(dvdxls /= 0.) .or. any(dvdyls /= 0.)
+  end subroutine udc_late_setup
+
+  !> Effective residency: start-up code (before the first tstep_update) works on the host arrays, so every call
+  !! there carries the state both ways.
+  integer function udc_mode()
+    udc_mode = merge(udc_residency, 0, udc_in_loop)
+  end function udc_mode
+
+  !> What a drop-in routine does before its device call ...
+  subroutine udc_begin(tend)
+    logical, intent(in) :: tend      !< the routine reads or edits the tendencies
+    call udc_ensure
+    if (.not. udc_in_loop) call udc_late_setup
+    select case (udc_mode())
+    case (0)
+      call udc_push_state
+      if (tend) call udc_push_tend
+    case (1)
+      if (tend) call udc_push_tend
+    end select
+  end subroutine udc_begin
+
+  !> ... and after it (routines that only edit tendencies)
+  subroutine udc_end_tend
+    if (udc_mode() <= 1) call udc_pull_tend
+  end subroutine udc_end_tend
+
+  !> First tstep_update: the time loop starts.  In device mode the state goes up once and the routines start recording.
+  subroutine udc_enter_loop
+    if (udc_in_loop) return
+    call udc_ensure
+    call udc_late_setup
+    udc_in_loop = .true.
+    if (udc_residency == 2) then
+      call udc_push_state
+      call udc_push_tend
+      call udc_check(udc_set_deferred(udc_h, 1_c_int), 'udc_set_deferred')
+      udc_host_fresh = .false.
+    end if
+  end subroutine udc_enter_loop
+
+  subroutine udc_tab_start(when)
+    use modglobal, only: kb, ke, nsv
+    integer, intent(in) :: when
+    if (.not. allocated(udc_tabA)) then
+      allocate (udc_tabA(kb:ke, ROW_SVP + max(nsv, 1), 0:1), udc_tabB(kb:ke, ROW_SVP + max(nsv, 1), 0:1))
+    end if
+    if (.not. udc_tab_open(when)) then
+      udc_tabA(:, :, when) = 0.; udc_tabB(:, :, when) = 0.
+    end if
+    udc_tab_open(when) = .true.
+  end subroutine udc_tab_start
+
+  !> Register the tables built since udc_tab_start(when) and let the device add them to the tendencies.  A substep that
+  !! builds none still has to overwrite what an earlier one registered (fixuinf1 acts on RK stage 3 only).
+  subroutine udc_tab_apply(when)
+    use modglobal, only: kb, ke, nsv, ltempeq, lmoist
+    integer, intent(in) :: when
+    integer :: n, nlev
+    if (.not. udc_tab_open(when)) then
+      if (.not. udc_tab_registered(when)) return
+      call udc_tab_start(when)          ! all-zero tables
+    end if
+    udc_tab_open(when) = .false.
+    udc_tab_registered(when) = .true.
+    nlev = ke - kb + 1
+    call udc_begin(.true.)
+    call reg(UDC_UP, UDC_U0, ROW_UP)
+    call reg(UDC_VP, UDC_V0, ROW_VP)
+    call reg(UDC_WP, UDC_W0, ROW_WP)
+    if (ltempeq) call reg(UDC_THLP, UDC_THL0, ROW_THLP)
+    if (lmoist) call reg(UDC_QTP, UDC_QT0, ROW_QTP)
+    do n = 1, nsv
+      call reg(UDC_SVP + 3*(n - 1), UDC_SV0 + 3*(n - 1), ROW_SVP + n)
+    end do
+    call udc_check(udc_level_forcings(udc_h, int(when, c_int)), 'udc_level_forcings')
+    call udc_end_tend
+  contains
+    subroutine reg(tend, src, row)
+      integer(c_int), intent(in) :: tend, src
+      integer, intent(in) :: row
+      integer(c_int) :: s
+      ! rows that are and always were zero cost nothing; a row once registered is overwritten from then on
+      if (.not. (udc_row_registered(row, when) .or. any(udc_tabA(:, row, when) /= 0.) .or. any(udc_tabB(:, row, when) /= 0.))) return
+      udc_row_registered(row, when) = .true.
+      s = -1
+      if (any(udc_tabB(:, row, when) /= 0.)) s = src
+      call udc_check(udc_set_level_forcing(udc_h, tend, s, udc_tabA(:, row, when), udc_tabB(:, row, when), &
+                                           int(nlev, c_int), int(when, c_int)), 'udc_set_level_forcing')
+    end subroutine reg
+  end subroutine udc_tab_apply
+
+  !> diagfld's slab averages (src/modthermodynamics.f90:262-290) from the device: u0av, v0av, thl0av, qt0av, sv0av.
+  subroutine udc_refresh_averages
+    use modglobal, only: kb, ke, kh, nsv, ltempeq, lmoist
+    use modfields, only: u0av, v0av, thl0av, qt0av, sv0av
+    integer(c_int) :: ids(16)
+    integer :: nf, n, n0, nb, q, nlev
+    real(c_double), allocatable :: avg(:, :)
+    nlev = ke + kh - kb + 1
+    nf = 2; ids(1) = UDC_U0; ids(2) = UDC_V0
+    if (ltempeq) then
+      nf = nf + 1; ids(nf) = UDC_THL0
+    end if
+    if (lmoist) then
+      nf = nf + 1; ids(nf) = UDC_QT0
+    end if
+    allocate (avg(nlev, 16))
+    call udc_check(udc_slab_averages(udc_h, ids, int(nf, c_int), avg, int(nlev, c_int)), 'udc_slab_averages')
+    u0av(kb:ke + kh) = avg(:, 1); v0av(kb:ke + kh) = avg(:, 2)
+    q = 2
+    if (ltempeq) then
+      q = q + 1; thl0av(kb:ke + kh) = avg(:, q)
+    end if
+    if (lmoist) then
+      q = q + 1; qt0av(kb:ke + kh) = avg(:, q)
+    end if
+    n0 = 1
+    do while (n0 <= nsv)                ! the scalars in batches of at most 16 fields (and 4096 values) per reduction
+      nb = min(nsv - n0 + 1, 16, max(4096/nlev, 1))
+      do n = 1, nb
+        ids(n) = UDC_SV0 + 3*(n0 + n - 2)
+      end do
+      call udc_check(udc_slab_averages(udc_h, ids, int(nb, c_int), avg, int(nlev, c_int)), 'udc_slab_averages')
+      do n = 1, nb
+        sv0av(kb:ke + kh, n0 + n - 1) = avg(:, n)
+      end do
+      n0 = n0 + nb
+    end do
+    deallocate (avg)
+  end subroutine udc_refresh_averages
 
   subroutine udc_push3(field, a, lb)
     integer(c_int), intent(in) :: field
@@ -414,14 +679,15 @@ contains
   end subroutine udc_pull_tend
 
   subroutine udc_pull_vel(with_m)
-    use modglobal, only: ib, jb, kb, ih, jh, kh, ihc, jhc, khc, nsv, ltempeq, lmoist
-    use modfields, only: u0, v0, w0, um, vm, wm, sv0, svm, thl0, thlm, e120, e12m, qt0, qtm
+    use modglobal, only: ib, jb, kb, ih, jh, kh, ihc, jhc, khc, nsv, ltempeq, lmoist, iadv_thl, iadv_kappa
+    use modfields, only: u0, v0, w0, um, vm, wm, sv0, svm, thl0, thlm, e120, e12m, qt0, qtm, thl0c
     logical, intent(in) :: with_m
     integer :: n
     call udc_pull3(UDC_U0, u0, (/ib - ih, jb - jh, kb - kh/))
     call udc_pull3(UDC_V0, v0, (/ib - ih, jb - jh, kb - kh/))
     call udc_pull3(UDC_W0, w0, (/ib - ih, jb - jh, kb - kh/))
     if (ltempeq) call udc_pull3(UDC_THL0, thl0, (/ib - ih, jb - jh, kb - kh/))
+    if (ltempeq .and. iadv_thl == iadv_kappa) call udc_pull3(UDC_THL0, thl0c, (/ib - ihc, jb - jhc, kb - khc/))   ! the wide copy (src/modboundary.f90:87)
     if (lmoist) call udc_pull3(UDC_QT0, qt0, (/ib - ih, jb - jh, kb - kh/))
     if (loneeqn_dev()) call udc_pull3(UDC_E120, e120, (/ib - ih, jb - jh, kb - kh/))
     do n = 1, nsv
@@ -453,6 +719,7 @@ contains
     use modfields, only: pres0
     use modsubgriddata, only: ekm, ekh
     if (.not. c_associated(udc_h)) return
+    udc_host_fresh = .true.
     call udc_pull_vel(.true.)
     call udc_pull_tend
     call udc_pull3(UDC_PRES0, pres0, (/ib - ih, jb - jh, kb - kh/))

@@ -323,6 +323,19 @@ class DynCore:
         self._ensure_thermo()
         L._check(self.lib.udc_run(self.h, nsub, rk3step0, C.c_double(dt), 1 if with_forces else 0), "udc_run")
 
+    # ---- deferred execution: the routine-by-routine surface runs as the fused substep (include/udcore.h)
+    def set_deferred(self, on=True):
+        L._check(self.lib.udc_set_deferred(self.h, 1 if on else 0), "udc_set_deferred")
+
+    def flush(self):
+        L._check(self.lib.udc_flush(self.h), "udc_flush")
+
+    def deferred_stats(self):
+        """(substeps that ran fused, substeps that ran routine by routine) since the handle was created."""
+        a, b = C.c_long(), C.c_long()
+        L._check(self.lib.udc_deferred_stats(self.h, C.byref(a), C.byref(b)), "udc_deferred_stats")
+        return a.value, b.value
+
     def divergence(self):
         a, b = C.c_double(), C.c_double()
         L._check(self.lib.udc_divergence(self.h, C.byref(a), C.byref(b)), "udc_divergence")
