@@ -168,6 +168,11 @@ int udc_set_moist_thermo(udc_handle *h, double thls, double qts, double ps, cons
 int udc_thermodynamics(udc_handle *h);
 int udc_thermo_state(udc_handle *h, double *tables, int n, int set);
 int udc_set_buoyancy(udc_handle *h, int lbuoyancy, double grav);
+/* Vreman buoyancy correction, &NAMSUBGRID lbuoycorr with lbuoyancy (src/modsubgrid.f90:330-353, Huusko et al. 2025):
+ * ekm *= sqrt(1 - min(max(Rig, 0), Rigc)/Rigc) before ekh = ekm/Pr and the molecular parts are added, with the gradient
+ * Richardson number Rig = (grav/thl0) dthvdz / (du0dz^2 + dv0dz^2 + 1e-10) and calthv's dthvdz (dry or moist).  Vreman
+ * closure only; call after udc_set_buoyancy.  Part of udc_subgrid / udc_substep. */
+int udc_set_buoycorr(udc_handle *h, int lbuoycorr, double rigc);
 
 /* One-equation (TKE) closure, &NAMSUBGRID loneeqn (src/modsubgrid.f90:363-400): switches the closure to
  * ekm = cm zlt e120 + numol, ekh = (ch1 + ch2 zlt/delta) ekm + numol/Pr_mol with the stability-limited length zlt

@@ -247,6 +247,10 @@ void orc_advecc_kappa(const orc_grid *g, const double *u0, const double *v0, con
  * DNS :401-404), followed by closurebc.  As in the reference the molecular
  * viscosity is added to the WHOLE array (halos included) before closurebc
  * rewrites the halos. */
+static double orc_dthvdz(const orc_grid *g, const double *thl0, int i, int j, int k);
+/* thl0 of the state the closure works on, for the Vreman buoyancy correction (orc_substep sets it; NULL: no correction) */
+static const double *closure_thl0 = NULL;
+void orc_set_closure_thl(const double *thl0) { closure_thl0 = thl0; }
 void orc_closure(const orc_grid *g, const double *u0, const double *v0, const double *w0,
                  double *ekm, double *ekh) {
   metrics m; metrics_init(g, &m);
@@ -324,6 +328,23 @@ void orc_closure(const orc_grid *g, const double *u0, const double *v0, const do
           double bb = b11 * b22 - b12 * b12 + b11 * b33 - b13 * b13 + b22 * b33 - b23 * b23;
           if (bb < 1.e-8) M(ekm, i, j, k) = 0.;
           else M(ekm, i, j, k) = g->c_vreman * sqrt(bb / aa);
+        }
+      }
+    }
+    /* buoyancy correction for stable stratification, src/modsubgrid.f90:330-353 (dthvdz: calthv's, from the same thl0) */
+    if (g->lbuoyancy && g->lbuoycorr && closure_thl0) {
+      const double *thl0 = closure_thl0;
+      for (int k = 1; k <= nz; ++k) {
+        int kp = k + 1, km = k - 1;
+        for (int j = 1; j <= ny; ++j) {
+          int jp = j + 1;
+          for (int i = 1; i <= nx; ++i) {
+            int ip = i + 1;
+            double du0dz = 0.5 * ((M(u0, i, j, kp) + M(u0, ip, j, kp)) - (M(u0, i, j, km) + M(u0, ip, j, km))) / (g->dzh[kp] + g->dzh[k]);
+            double dv0dz = 0.5 * ((M(v0, i, j, kp) + M(v0, i, jp, kp)) - (M(v0, i, j, km) + M(v0, i, jp, km))) / (g->dzh[kp] + g->dzh[k]);
+            double Rig = ((9.81 / M(thl0, i, j, k)) * orc_dthvdz(g, thl0, i, j, k)) / (du0dz * du0dz + dv0dz * dv0dz + 1.e-10);
+            M(ekm, i, j, k) = M(ekm, i, j, k) * sqrt(1.0 - fmin(fmax(Rig, 0.0), g->Rigc) / g->Rigc);
+          }
         }
       }
     }
@@ -1488,7 +1509,7 @@ void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
   if (g->lmoist) orc_advecc_2nd(g, s->u0, s->v0, s->w0, s->qt0, s->qtp);                 /* src/modadvection.f90:78-86 */
   for (int n = 0; n < g->nsv; ++n) orc_advecc_kappa(g, s->u0, s->v0, s->w0, s->sv0 + n * nc, s->svp + n * nc);
   if (g->sgs == 3) orc_closure_tke(g, s->e120, g->ltempeq ? s->thl0 : NULL, s->ekm, s->ekh);
-  else orc_closure(g, s->u0, s->v0, s->w0, s->ekm, s->ekh);
+  else { closure_thl0 = g->ltempeq ? s->thl0 : NULL; orc_closure(g, s->u0, s->v0, s->w0, s->ekm, s->ekh); }
   /* reassure_fluxtop_boundary src/modboundary.f90:392-431 (free-slip: re-impose top rows) */
   if (g->bctopm != 2) {
     top_row_m(g, s->um, 0.); top_row_m(g, s->u0, 0.); top_row_m(g, s->vm, 0.); top_row_m(g, s->v0, 0.);

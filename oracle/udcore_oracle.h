@@ -73,6 +73,8 @@ typedef struct {
   double k1, JNO2;
   int lqlnr;                /* condensate by Newton-Raphson on T instead of the one-step formula (src/modthermodynamics.f90:37,448-473) */
   int iadv_thl;             /* 2 = cd2 (advecc_2nd), 7 = kappa (advecc_kappa on thl0c), src/modadvection.f90:64-76 */
+  int lbuoycorr;            /* Vreman buoyancy correction (src/modsubgriddata.f90:41, src/modsubgrid.f90:330-353) */
+  double Rigc;              /* critical Richardson number (src/modsubgriddata.f90:44) */
 } orc_grid;
 
 /* ---- advection: src/modadvection.f90 */
@@ -87,6 +89,7 @@ void orc_advecc_kappa(const orc_grid *g, const double *u0, const double *v0, con
 /* ---- subgrid: src/modsubgrid.f90 + closurebc (src/modboundary.f90:434-505) */
 void orc_closure(const orc_grid *g, const double *u0, const double *v0, const double *w0,
                  double *ekm, double *ekh);
+void orc_set_closure_thl(const double *thl0);   /* thl0 for the Vreman buoyancy correction inside orc_closure */
 void orc_closurebc(const orc_grid *g, double *ekm, double *ekh);
 void orc_diffu(const orc_grid *g, const double *u0, const double *v0, const double *w0,
                const double *ekm, double *up);

@@ -17,14 +17,14 @@ KERNEL_CASES = {
     "k_volflow_12x8x6": 17, "k_thl_12x8x6": 18,
     "k_buoy_12x8x6": 19,
     "k_coriol_12x8x6": 20,
-    "k_tke_12x8x6": 21, "k_tke_thl_12x8x6": 28, "k_qt_12x8x6": 32, "k_moist_12x8x8": 35, "k_uno_12x8x6": 37, "k_src_12x8x8": 39, "k_thlk_12x8x6": 41, "k_svtop_8x8x8": 47, "k_tke_moist_12x8x8": 50,
+    "k_tke_12x8x6": 21, "k_tke_thl_12x8x6": 28, "k_qt_12x8x6": 32, "k_moist_12x8x8": 35, "k_uno_12x8x6": 37, "k_src_12x8x8": 39, "k_thlk_12x8x6": 41, "k_svtop_8x8x8": 47, "k_tke_moist_12x8x8": 50, "k_vreman_buoycorr_12x8x10": 52,
 }
 # per-level forcings (lstend, nudge, grwdamp): host-level routines, checked in tests/test_level_forcings.py
 LSF_CASES = {"k_lsf_12x8x24": 29, "run_lsf_16x8x24s": 30, "k_lsfq_12x8x20": 34}
 RUN_CASES = {"run_16x16x8": 21, "run_smag_scalar_16x8x12s": 22, "run_floor_scalar_16x8x12s": 23,
              "run_volflow_uv_16x16x8": 24, "run_thl_16x8x12s": 25, "run_qt_16x8x12s": 33, "run_moist_16x8x12s": 36, "run_uno_16x8x12s": 38, "run_src_16x8x12s": 40, "run_thlk_16x8x12s": 42, "run_moistnr_16x8x12s": 45, "run_svflux_16x8x12s": 48, "run_chem_16x8x12s": 51,
              "run_buoy_16x8x12s": 26,
-             "run_profforc_16x16x8": 27}
+             "run_profforc_16x16x8": 27, "run_vreman_buoycorr_16x8x12s": 53}
 
 
 def load_fixture(name):

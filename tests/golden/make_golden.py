@@ -7,7 +7,7 @@ compiled from /root/reference/src by oracle/Makefile against single-rank shims -
 small decks defined below, and stores the inputs/outputs it dumps.  The fixtures are data
 only (fields in, fields out); no reference source text is stored.
 
-    python tests/golden/make_golden.py          # needs oracle/_ref/udales_ref (make -C oracle ref)
+    python tests/golden/make_golden.py [case ...]   # needs oracle/_ref/udales_ref (make -C oracle ref)
 
 Fixture format: the record stream of oracle/ref_driver.f90 (see tests/refdump.py), gzip'ed,
 plus the input deck files of each case under cases/<name>/ so that the same namoptions drive
@@ -32,6 +32,7 @@ def deck(iexpnr, nx, ny, nz, dx=0.5, dy=0.5, dtmax=0.25, sgs="vreman", nsv=0, bc
          oracle="", lles=True, randu=0.01, floor=False, z0=0.05, physics="", bc="", bcbotm=3, scalars="", dynamics="", inlet="", ladaptive=False, chemistry=""):
     sub = {"oneeqn": "loneeqn = .true.\nlvreman = .false.\nlsmagorinsky = .false.",
            "vreman": "lvreman = .true.\nlsmagorinsky = .false.",
+           "vreman_bc": "lvreman = .true.\nlsmagorinsky = .false.\nlbuoycorr = .true.",
            "smag": "lsmagorinsky = .true.\nlvreman = .false.",
            "dns": "lvreman = .false.\nlsmagorinsky = .false."}[sgs]
     return f"""&RUN
@@ -307,6 +308,17 @@ CASES.update({
                           dict(sgs="smag", nsv=3, floor=True, chemistry="lchem = .true.\nk1 = 0.4\nJNO2 = 0.008",
                                oracle="nsub = 6\ndump_at = 3, 6\nscal_a = 30.\nscal_b = 20."), 1.06),
 })
+CASES.update({
+    # Vreman closure with the buoyancy correction for stable stratification (lbuoycorr with lbuoyancy): a weakly stable
+    # layer, so that Rig <= 0 (no correction), 0 < Rig < Rigc (damped) and Rig >= Rigc (ekm = molecular) all occur
+    "k_vreman_buoycorr_12x8x10": ("kernels", 52, 12, 8, 10,
+                                  dict(sgs="vreman_bc", floor=True, randu=0.05, physics="ltempeq = .true.\nlbuoyancy = .true.",
+                                       bc="BCtopT = 1\nBCbotT = 1\nwtsurf = -0.002\nthls = 288.0", oracle="nspin = 3"), 1.04),
+    "run_vreman_buoycorr_16x8x12s": ("run", 53, 16, 8, 12,
+                                     dict(sgs="vreman_bc", floor=True, randu=0.05, physics="ltempeq = .true.\nlbuoyancy = .true.",
+                                          bc="BCtopT = 2\nthl_top = 288.03\nBCbotT = 1\nwtsurf = -0.002\nthls = 288.0",
+                                          oracle="nsub = 9\ndump_at = 3, 9"), 1.06),
+})
 LSF_ONLY = ("k_lsf_12x8x24", "k_lsfq_12x8x20", "k_fix1_12x8x6")
 THL_CASES = {"k_tke_moist_12x8x8": dict(dthl=0.25, qt=0.0118, dqt=-8e-5, tke=0.06),
              "run_moistnr_16x8x12s": dict(dthl=0.25, qt=0.0119, dqt=-6e-5),
@@ -320,7 +332,8 @@ THL_CASES = {"k_tke_moist_12x8x8": dict(dthl=0.25, qt=0.0118, dqt=-8e-5, tke=0.0
              "k_lsfq_12x8x20": dict(dthl=0.3, ug=1.0, wtop=0.025, qt=0.008, dqt=-3e-4, dqtdx=2e-7, dqtdy=-1e-7, dqtdt=3e-8),
              "k_qt_12x8x6": dict(dthl=0.3, qt=0.008, dqt=-4e-4), "run_qt_16x8x12s": dict(dthl=0.25, qt=0.007, dqt=-2e-4),
              "k_lsf_12x8x24": dict(dthl=0.3, ug=1.05, wtop=0.02), "run_lsf_16x8x24s": dict(dthl=0.25, ug=0.95, wtop=-0.03), "k_tke_12x8x6": dict(tke=0.05), "k_tke_thl_12x8x6": dict(tke=0.08, dthl=0.3), "k_coriol_12x8x6": dict(ug=1.1), "run_profforc_16x16x8": dict(ug=1.3), "k_thl_12x8x6": dict(dthl=0.4, dthlrad=2e-3), "run_thl_16x8x12s": dict(dthl=0.25, dthlrad=-1e-3),
-             "k_buoy_12x8x6": dict(dthl=0.3), "run_buoy_16x8x12s": dict(dthl=0.2)}
+             "k_buoy_12x8x6": dict(dthl=0.3), "run_buoy_16x8x12s": dict(dthl=0.2),
+             "k_vreman_buoycorr_12x8x10": dict(dthl=0.004), "run_vreman_buoycorr_16x8x12s": dict(dthl=0.004)}
 
 
 # restart files written by the reference's own writerestartfiles (src/modsave.f90:37-128): the files are the
@@ -370,7 +383,10 @@ def make_restart_cases():
 def main():
     if not os.path.exists(REF):
         sys.exit(f"{REF} missing: run `make -C oracle ref` in the build container first")
+    only = set(sys.argv[1:])          # optional: regenerate only the named cases
     for name, (mode, iexp, nx, ny, nz, kw, stretch) in CASES.items():
+        if only and name not in only:
+            continue
         cdir = os.path.join(HERE, "cases", name)
         os.makedirs(cdir, exist_ok=True)
         write_case(cdir, iexp, deck(iexp, nx, ny, nz, **kw), zlevels(nz, 0.5, stretch), **THL_CASES.get(name, {}))

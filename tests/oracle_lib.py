@@ -37,7 +37,8 @@ class OrcGrid(C.Structure):
                 ("wqsurf", C.c_double), ("thls", C.c_double), ("qts", C.c_double), ("ps", C.c_double),
                 ("zf", DP), ("zh", DP), ("bcbotm", C.c_int), ("bcbott", C.c_int), ("z0h", C.c_double),
                 ("prandtlturb", C.c_double), ("bctops", C.c_int), ("wsvtop", C.c_double * 4), ("sv_top", C.c_double * 4),
-                ("lchem", C.c_int), ("k1", C.c_double), ("JNO2", C.c_double), ("lqlnr", C.c_int), ("iadv_thl", C.c_int)]
+                ("lchem", C.c_int), ("k1", C.c_double), ("JNO2", C.c_double), ("lqlnr", C.c_int), ("iadv_thl", C.c_int),
+                ("lbuoycorr", C.c_int), ("Rigc", C.c_double)]
 
 
 class OrcState(C.Structure):
@@ -84,7 +85,7 @@ class Oracle:
                  lbuoyancy=False, coriolis_mode=0, om22=0., om23=0., tke=None,
                  lmoist=False, bctopq=1, wqtop=0., qt_top=-1., wqsurf=-1., thls=-1., qts=-1., ps=101325., zf=None, zh=None,
                  bcbotm=3, bcbott=1, z0h=-1., prandtlturb=0.71, iadv_thl=2, lqlnr=False, bctops=1, wsvtop=(), sv_top=(),
-                 lchem=False, k1=0., JNO2=0.):
+                 lchem=False, k1=0., JNO2=0., lbuoycorr=False, Rigc=0.25):
         self.nx, self.ny, self.nz, self.nsv = nx, ny, nz, nsv
         self.dzf = np.ascontiguousarray(dzf, dtype=np.float64)
         self.dzh = np.ascontiguousarray(dzh, dtype=np.float64)
@@ -106,7 +107,7 @@ class Oracle:
                          int(bool(lmoist)), bctopq, wqtop, qt_top, wqsurf, thls, qts, ps, ptr(self.zf), ptr(self.zh),
                          bcbotm, bcbott, z0h, prandtlturb, bctops,
                          (C.c_double * 4)(*(list(wsvtop) + [0.] * 4)[:4]), (C.c_double * 4)(*(list(sv_top) + [0.] * 4)[:4]),
-                         int(bool(lchem)), k1, JNO2, int(bool(lqlnr)), iadv_thl)
+                         int(bool(lchem)), k1, JNO2, int(bool(lqlnr)), iadv_thl, int(bool(lbuoycorr)), Rigc)
         self.L = lib()
 
     def mshape(self):

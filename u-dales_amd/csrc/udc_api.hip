@@ -358,6 +358,7 @@ static int now_advection(udc_handle *h) {
 static int now_subgrid(udc_handle *h) {
   if (tend_clean(h) || um_materialise(h)) return 1;
   if (k_closure(h)) return 1;
+  if (h->lbuoycorr && k_vreman_buoycorr(h)) return 1;
   if (k_ek_ghosts(h)) return 1;
   if (k_top_rows_after_closure(h)) return 1;
   if ((h->mom_simple ? k_momentum(h, false, true, false) : k_momentum_lds(h, false, true, false, false, 0.))) return 1;
@@ -574,6 +575,16 @@ extern "C" int udc_set_buoyancy(udc_handle *h, int lbuoyancy, double grav) {
   return 0;
 }
 
+extern "C" int udc_set_buoycorr(udc_handle *h, int lbuoycorr, double rigc) {
+  ENTRY_FLUSH(h);
+  if (!lbuoycorr) { h->lbuoycorr = 0; h->p.bare = 0; return 0; }
+  if (h->p.sgs != UDC_SGS_VREMAN) { udc_set_error("udc_set_buoycorr: the correction belongs to the Vreman closure (src/modsubgrid.f90:269-353)"); return 1; }
+  if (!h->lbuoyancy) { udc_set_error("udc_set_buoycorr: call udc_set_buoyancy first (the reference applies it only with lbuoyancy)"); return 1; }
+  if (!(rigc > 0.)) { udc_set_error("udc_set_buoycorr: Rigc must be positive"); return 1; }
+  h->lbuoycorr = 1; h->rigc = rigc; h->p.bare = 1;
+  return 0;
+}
+
 extern "C" int udc_set_thl_source(udc_handle *h, const double *thlpcar, int n) {
   ENTRY_FLUSH(h);
   if (n != h->g.nz) { udc_set_error("udc_set_thl_source: expected %d levels", h->g.nz); return 1; }
@@ -777,10 +788,11 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   const bool rotate = h->um_alias;                    // only true here for an aliased stage 1
   h->halos_fresh = h->boundary_fresh = h->thermo_fresh = false;
   // closure first: it only needs u0,v0,w0, and the fused sweep below needs ekm
-  if (fold && h->p.sgs != UDC_SGS_DNS && h->p.sgs != UDC_SGS_ONEEQN) {
+  if (fold && h->p.sgs != UDC_SGS_DNS && h->p.sgs != UDC_SGS_ONEEQN && !h->lbuoycorr) {
     if (k_closure_lds(h, true)) return 1;
   } else {
     if (k_closure(h)) return 1;
+    if (h->lbuoycorr && k_vreman_buoycorr(h)) return 1;      // before closurebc, as in the reference
     if (k_ek_ghosts(h)) return 1;
   }
   if (lds ? k_momentum_lds(h, true, true, forces, true, pup ? 1. / rk3coef : 0., rotate)

@@ -33,6 +33,7 @@ __device__ __forceinline__ void closure_arith(const Acc &A, const Metrics &m, co
     strain2 = strain2 + 0.125 * (a1 * a1 + a2 * a2 + a3 * a3 + a4 * a4);
     const double ml = m.mlen[kf];
     em = (ml * ml) * sqrt(2. * strain2);
+    if (pr.bare) { eh = 0.; return; }
     eh = em * pr.prandtli;
     em = em + pr.numol;
     eh = eh + pr.numol * pr.prandtlmoli;
@@ -60,6 +61,7 @@ __device__ __forceinline__ void closure_arith(const Acc &A, const Metrics &m, co
     const double b23 = dx2 * a12 * a13 + dy2 * a22 * a23 + dz2 * a32 * a33;
     const double bb = b11 * b22 - b12 * b12 + b11 * b33 - b13 * b13 + b22 * b33 - b23 * b23;
     em = (bb < 1.e-8) ? 0. : pr.c_vreman * sqrt(bb / aa);
+    if (pr.bare) { eh = 0.; return; }      // the buoyancy correction comes first (src/modsubgrid.f90:330-357)
     eh = em * pr.prandtli;
     em = em + pr.numol;
     eh = eh + pr.numol * pr.prandtlmoli;

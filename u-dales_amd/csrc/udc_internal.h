@@ -77,6 +77,8 @@ struct Params {
   int sgs, bctopm;
   int lbottom;     // floor wall function (src/modibm.f90:2021)
   double z0;
+  int bare = 0;    // closure kernels leave the turbulent part of ekm only (ekh unwritten): the Vreman buoyancy correction
+                   // (k_vreman_buoycorr) scales it, derives ekh and adds the molecular parts in the reference's order
 };
 
 struct ProfEntry { hipEvent_t a, b; int name; bool own_a; };
@@ -142,6 +144,8 @@ struct udc_handle {
   double floor_thls = 0., floor_z0h = 0., floor_prt = 0.71;
   bool lmoist = false;         // qt transported in slot 13 (udc_set_moisture)
   int lbuoyancy = 0;           // forces' buoyancy term (dry air), needs the temperature equation
+  int lbuoycorr = 0;           // Vreman buoyancy correction (udc_set_buoycorr)
+  double rigc = 0.25;
   double grav = 9.81;
   double *lev_part = nullptr, *lev_sum = nullptr;   // per-level slab sums (thvh)
   double *lev_sum16 = nullptr;                      // udc_slab_averages: up to 16 fields x (nz+2)
@@ -268,6 +272,7 @@ int k_slab_averages(udc_handle *h, const int *fields, int nf, double *avg_host, 
 int k_level_forcings(udc_handle *h, int when, bool wrap_vp);
 int k_tke_closure(udc_handle *h);                  // closure, loneeqn branch
 int k_tke_sources(udc_handle *h);                  // sources: e12p += shear + buoyancy + dissipation
+int k_vreman_buoycorr(udc_handle *h);            // ekm *= sqrt(1 - min(max(Rig,0),Rigc)/Rigc), then ekh and the molecular parts
 int k_tke_floor(udc_handle *h);                    // e120(kb-1) = e120(kb), e12m likewise (`bottom`)                     // wp += grav (thv0h - thvh)/thvh, src/modforces.f90:73-84   // cp(i,j,k) += src(k)
 int k_maxima(udc_handle *h, double dt, double *cour, double *diffn);
 int k_divergence_check(udc_handle *h, double *divmax, double *divtot);

@@ -330,7 +330,7 @@ int k_thermodynamics(udc_handle *h) {
   const double cnt = (double)g.nx * (double)h->cfg.jtot;
   const DiagArgs da{g.nz, cnt, h->thls, h->qts, h->ps, h->grav};
   double *ql0 = nullptr;      // kept as a field only where something reads it: the one-equation closure's moist dthvdz
-  if (h->p.sgs == UDC_SGS_ONEEQN) {
+  if (h->p.sgs == UDC_SGS_ONEEQN || h->lbuoycorr) {      // (and the Vreman buoyancy correction's)
     if ((int)h->fields.size() <= UDC_QL0 || !h->fields[UDC_QL0]) {
       h->fields.resize(std::max((size_t)UDC_QL0 + 1, h->fields.size()), nullptr);
       HIP_OK(hipMalloc(&h->fields[UDC_QL0], sizeof(double) * g.n));

@@ -133,12 +133,35 @@ static TkeK tke_consts(udc_handle *h) {
 static const double *thl_or_null(udc_handle *h) {
   return ((int)h->fields.size() > UDC_THL0 && h->fields[UDC_THL0]) ? h->fields[UDC_THL0] : nullptr;
 }
+// Vreman buoyancy correction for stable stratification (lbuoycorr, src/modsubgrid.f90:330-353): the closure kernel left
+// the turbulent ekm; scale it with the gradient Richardson number (dthvdz: calthv's, from the same thl0), then ekh and
+// the molecular parts in the reference's statement order (:355-359)
+__global__ __launch_bounds__(256) void vreman_buoycorr_kernel(Geo g, TileGrid tg, Metrics m, Params pr, double grav, double rigc,
+                                                              const double *__restrict__ u0, const double *__restrict__ v0,
+                                                              const double *__restrict__ thl, MoistK mq,
+                                                              double *__restrict__ ekm, double *__restrict__ ekh) {
+  int i, j, k;
+  if (!tile_decode(g, tg, i, j, k)) return;
+  const long c = g.idx(i, j, k), cip = g.idx(wrap(i + 1, g.nx), j, k);
+  const int kf = k + 1;
+  const double dz2 = m.dzh[kf + 1] + m.dzh[kf];
+  const double du0dz = 0.5 * ((u0[c + g.sz] + u0[cip + g.sz]) - (u0[c - g.sz] + u0[cip - g.sz])) / dz2;
+  const double dv0dz = 0.5 * ((v0[c + g.sz] + v0[c + g.sy + g.sz]) - (v0[c - g.sz] + v0[c + g.sy - g.sz])) / dz2;
+  const double rig = ((grav / thl[c]) * dthvdz_any(g, m, thl, mq, c, k)) / (du0dz * du0dz + dv0dz * dv0dz + 1.e-10);
+  double em = ekm[c] * sqrt(1.0 - fmin(fmax(rig, 0.0), rigc) / rigc);
+  double eh = em * pr.prandtli;
+  em = em + pr.numol;
+  eh = eh + pr.numol * pr.prandtlmoli;
+  ekm[c] = em;
+  ekh[c] = eh;
+}
+
 // moist dthvdz inputs, or nulls for dry air; fails when the thermodynamics have not run yet (ql0, exnf undefined)
 static int moist_inputs(udc_handle *h, MoistK &q) {
   q = MoistK{nullptr, nullptr, nullptr, nullptr};
   if (!h->lmoist) return 0;
   if (!h->mt || !h->mt_valid || (int)h->fields.size() <= UDC_QL0 || !h->fields[UDC_QL0]) {
-    udc_set_error("one-equation closure with moisture: set up udc_set_moist_thermo and call udc_thermodynamics before the first "
+    udc_set_error("one-equation closure / Vreman buoyancy correction with moisture: set up udc_set_moist_thermo and call udc_thermodynamics before the first "
                   "substep (calthv's dthvdz reads ql0 and exnf, src/modthermodynamics.f90:154-205)");
     return 1;
   }
@@ -154,6 +177,18 @@ int k_tke_closure(udc_handle *h) {
   PROF(h, "closure");
   hipLaunchKernelGGL(tke_closure_kernel, gr, b, 0, h->stream, g, tile_grid(g), h->m, tke_consts(h), h->fields[UDC_E120],
                      thl_or_null(h), mq, h->fields[UDC_EKM], h->fields[UDC_EKH]);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+int k_vreman_buoycorr(udc_handle *h) {
+  const Geo &g = h->g;
+  dim3 b(64, 4, 1), gr = cell_grid(g, b);
+  MoistK mq;
+  if (moist_inputs(h, mq)) return 1;
+  PROF(h, "vreman_buoycorr");
+  hipLaunchKernelGGL(vreman_buoycorr_kernel, gr, b, 0, h->stream, g, tile_grid(g), h->m, h->p, h->grav, h->rigc,
+                     (const double *)h->fields[UDC_U0], (const double *)h->fields[UDC_V0], (const double *)h->fields[UDC_THL0], mq,
+                     h->fields[UDC_EKM], h->fields[UDC_EKH]);
   HIP_OK(hipGetLastError());
   return 0;
 }

@@ -123,6 +123,12 @@ module udc_iface
       integer(c_int), value :: lbuoyancy
       real(c_double), value :: grav
     end function
+    integer(c_int) function udc_set_buoycorr(h, lbuoycorr, rigc) bind(C, name='udc_set_buoycorr')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: lbuoycorr
+      real(c_double), value :: rigc
+    end function
     integer(c_int) function udc_set_floor_wf(h, bcbotm, bcbott, thls, z0h, prandtlturb) bind(C, name='udc_set_floor_wf')
       import :: c_ptr, c_int, c_double
       type(c_ptr), value :: h
@@ -347,7 +353,7 @@ contains
                          lcoriol, lprofforc, om22, om23, luvolflowr, lvvolflowr, uflowrate, vflowrate, &
                          lnudge, igrw_damp, ifixuinf, ds
     use modsurfdata, only: wttop, thl_top, wtsurf, thvs, wqtop, qt_top, wqsurf, thls, qts, ps, z0h, wsvtop, sv_top
-    use modsubgriddata, only: lsmagorinsky, lvreman, loneeqn, ldelta, prandtli, c_vreman, csz, cm, cn, ch1, ch2, ce1, ce2
+    use modsubgriddata, only: lsmagorinsky, lvreman, loneeqn, ldelta, prandtli, c_vreman, csz, cm, cn, ch1, ch2, ce1, ce2, lbuoycorr, Rigc
     use modfields, only: dpdxl, dpdyl, thlpcar, ug, whls, dthldxls, dthldyls, dqtdxls, dqtdyls, dqtdtls, &
                          dudxls, dudyls, dvdxls, dvdyls
     use modmpi, only: myid, nprocs, nprocx, comm3d, mpierr
@@ -414,6 +420,13 @@ contains
       end if
     end if
     if (ltempeq .and. lbuoyancy) call udc_check(udc_set_buoyancy(udc_h, 1_c_int, real(grav, c_double)), 'udc_set_buoyancy')
+    if (cfg%sgs == 2 .and. lbuoyancy .and. lbuoycorr) then      ! Vreman buoyancy correction (src/modsubgrid.f90:332)
+      if (.not. ltempeq) then
+        write (0, *) 'ERROR: libudcore: lbuoycorr needs the temperature equation (ltempeq)'
+        stop 1
+      end if
+      call udc_check(udc_set_buoycorr(udc_h, 1_c_int, real(Rigc, c_double)), 'udc_set_buoycorr')
+    end if
     if (udc_floor_on .and. (BCbotm == 2 .or. (ltempeq .and. BCbotT == 2))) then   ! wfuno floor (src/modibm.f90:2021-2045)
       call udc_check(udc_set_floor_wf(udc_h, int(BCbotm, c_int), int(BCbotT, c_int), real(thls, c_double), real(z0h, c_double), &
                                       real(prandtlturb, c_double)), 'udc_set_floor_wf')

@@ -45,6 +45,8 @@ def from_deck(deck, device=0, rank=0, nranks=1):
                                   lqlnr=bool(deck.get("DYNAMICS", "lqlnr")))
     if deck.get("PHYSICS", "ltempeq") and deck.get("PHYSICS", "lbuoyancy"):
         core.set_buoyancy(True)
+        if sgs == 2 and deck.get("NAMSUBGRID", "lbuoycorr"):      # src/modsubgrid.f90:332
+            core.set_buoycorr(True, float(deck.get("NAMSUBGRID", "Rigc")))
     if sgs == 3:      # after set_tempeq: the closure reads thl0 when the temperature equation is on
         thls, qts = float(deck.get("BC", "thls")), float(deck.get("BC", "qts"))
         core.set_tke(cf=float(deck.get("NAMSUBGRID", "cf")), cn=float(deck.get("NAMSUBGRID", "cn")),

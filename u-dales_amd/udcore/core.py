@@ -298,6 +298,10 @@ class DynCore:
         """&PHYSICS lbuoyancy (dry air): forces adds grav (thv0h - thvh)/thvh to wp."""
         L._check(self.lib.udc_set_buoyancy(self.h, int(bool(on)), C.c_double(grav)), "udc_set_buoyancy")
 
+    def set_buoycorr(self, on=True, rigc=0.25):
+        """&NAMSUBGRID lbuoycorr (Vreman closure with lbuoyancy): stable-stratification correction of ekm."""
+        L._check(self.lib.udc_set_buoycorr(self.h, int(bool(on)), C.c_double(rigc)), "udc_set_buoycorr")
+
     def masscorr(self):
         """masscorr (src/modforces.f90:328), after forces."""
         L._check(self.lib.udc_masscorr(self.h, self.rk3step, C.c_double(self.dt)), "udc_masscorr")
