@@ -6,7 +6,11 @@ subgrid, forces, poisson, tstep_integrate, halos, boundary) over the whole grid,
 cell-update per cell.  Workload at N=1: BASELINE.json configs[1], the
 256^3 neutral empty-domain channel (2nd-order advection, Vreman SGS = the reference default,
 FFT Poisson), synthetic cold start (LCG noise of src/modstartup.f90:2367-2396), fields resident
-in HBM before the timed region.
+in HBM before the timed region.  Workload at N>1: BASELINE.json configs[3], the 1024x512x512 channel
+split into N y-slabs (STRONG scaling: the same grid at every N; --size 1024x512x512 gives the N=1 point,
+and every N>1 line also carries rank 0's own one-GPU run of that grid, `single_gpu_same_workload`);
+--weak switches to one 256^3 slab per GPU.  `poisson_only_ms` times the reference's `poisson` routine
+alone (fillps + solve + tderive), the subject of the >= 6x strong-scaling target.
 
     python bench.py                                   # 1 GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -33,6 +37,7 @@ sys.path.insert(0, os.path.join(ROOT, "u-dales_amd"))
 # substep moves less than that model (no pup/pvp/pwp or rhs arrays, tendencies neither re-read nor
 # zero-filled): 40 + 88 + 32 + 64 + 24 + 72 = 320 B.  `whole_substep_hbm_frac` keeps SURVEY's 392 B
 # definition so that it stays comparable across rounds.
+SCALAR_INTEGRATE_BYTES = 24      # per transported scalar in project_integrate: read svp, svm; write sv0
 ALGO_BYTES = {
     "closure": 40,              # read u0,v0,w0; write ekm,ekh
     "mom": 88,                  # read u0,v0,w0,pres0,ekm (40) + um,vm,wm (24); write pup,pvp,pwp (24)
@@ -47,11 +52,35 @@ ALGO_BYTES = {
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 
-def algo_bytes(name):
+def algo_bytes(name, nscal=0):
     for k, v in ALGO_BYTES.items():
         if name.startswith(k):
-            return v
+            return v + (SCALAR_INTEGRATE_BYTES * nscal if k == "project_integrate" else 0)
     return None
+
+
+def workload_name(nx, ny, nz, sgs, nsv, floor):
+    """What actually runs, and the BASELINE.json configuration it is -- only when it is one."""
+    w = (f"{nx}x{ny}x{nz} neutral empty-domain channel, cd2 momentum advection + "
+         f"{'Vreman' if sgs == 'vreman' else 'Smagorinsky'} SGS diffusion"
+         f"{' + ' + str(nsv) + ' kappa-advected scalar' + ('s' if nsv > 1 else '') if nsv else ''}"
+         f" + FFT(x,y)/tridiagonal(z) Poisson + RK3 substep")
+    if (nx, ny, nz, sgs, nsv) == (256, 256, 256, "vreman", 0):
+        w += " (BASELINE.json configs[1])"
+    elif (nx, ny, nz, sgs, nsv) == (512, 512, 256, "smag", 1):
+        w += " (BASELINE.json configs[2])"
+    elif (nx, ny, nz, sgs, nsv) == (1024, 512, 512, "vreman", 0):
+        w += " (BASELINE.json configs[3])"
+    return w
+
+
+def time_loop(core, fn, n, barrier):
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    barrier()
+    return (time.perf_counter() - t0) / n * 1e3
 
 
 def write_deck(d, iexp, nx, ny, nz, nsub, dt=0.25, nprocy=1, nsv=0, sgs="vreman", floor=True, nwarm=0):
@@ -187,6 +216,8 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--size", type=str, default="", help="override grid, e.g. 256x256x256")
+    ap.add_argument("--weak", action="store_true", help="N>1: one 256^3 slab per GPU (weak scaling) instead of 1024x512x512 split N ways")
+    ap.add_argument("--no-single", action="store_true", help="N>1: skip rank 0's one-GPU run of the same grid")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-dropin", action="store_true", help="skip the Fortran drop-in leg")
     ap.add_argument("--nsv", type=int, default=0, help="passive scalars (kappa scheme), BASELINE configs[2]")
@@ -216,8 +247,13 @@ def main():
 
     if args.size:
         nx, ny, nz = (int(x) for x in args.size.lower().split("x"))
-    else:
+    elif world == 1:
+        nx, ny, nz = 256, 256, 256              # BASELINE.json configs[1]
+    elif args.weak:
         nx, ny, nz = 256, 256 * world, 256      # weak scaling: one 256^3 slab of the channel per GPU
+    else:
+        nx, ny, nz = 1024, 512, 512             # BASELINE.json configs[3]: strong scaling, the same grid at every N
+    scaling = "weak" if (args.weak and not args.size) else "strong"
     dt = 0.25
     with tempfile.TemporaryDirectory() as tmp:
         deck = read_deck(write_deck(tmp, 901, nx, ny, nz, 0, dt=dt, nprocy=world, nsv=args.nsv, sgs=args.sgs, floor=not args.no_floor))
@@ -261,18 +297,29 @@ def main():
     prof = core.profile_get()
     core.profile(False)
     elapsed = t1 - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+
+    def allmax(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
+
+    elapsed = allmax(elapsed)
     divmax, _ = core.divergence()
+    # the reference's `poisson` routine alone (src/modpois.f90:419: fillps + bcpup, FFTs / transposes, solmpj, tderive + bcp)
+    core.rk3step, core.dt = 1, dt
+    for _ in range(3):
+        core.poisson()
+    poisson_ms = allmax(time_loop(core, core.poisson, 20, barrier))
 
     cells = nx * ny * nz
     cells_local = nx * nyl * nz
     value = cells * args.steps / elapsed
     kernels = {}
+    nscal = args.nsv                      # transported scalars the integrate kernel also advances (the bench deck has no thl, qt)
     for name, (ms, cnt) in prof.items():
-        ab = algo_bytes(name)
+        ab = algo_bytes(name, nscal)
         avg_ms = ms / max(cnt, 1)
         ent = {"avg_ms": round(avg_ms, 5), "launches": cnt, "share": round(ms / (elapsed * 1e3), 4)}
         if ab:
@@ -281,18 +328,23 @@ def main():
                         "frac": round(gbs / HBM_PEAK_GBS, 4)})
         kernels[name] = ent
     dom = max((k for k in kernels if "frac" in kernels[k]), key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"])
-    traffic = None
+    # HBM traffic of the dominant kernel from the committed PMC collection (profiles/pmc_traffic.json, written by
+    # profiles/tools/collect.sh from separate rocprofv3 --pmc passes: counters cannot be read inside a timed run);
+    # entries are keyed by workload (grid per GPU, SGS, scalars) and by kernel, so a stale or foreign entry never matches
+    traffic, traffic_src = None, None
     tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tfile):
         try:
             with open(tfile) as f:
                 tj = json.load(f)
-            if tj.get("workload") == f"{nx}x{nyl}x{nz}" and dom in tj.get("kernels", {}):
-                traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
+            key = f"{nx}x{nyl}x{nz}/{args.sgs}/nsv{args.nsv}"
+            ent = tj.get("workloads", {}).get(key, {}).get(dom)
+            if ent:
+                traffic, traffic_src = ent["hbm_bytes_per_launch"], ent.get("source")
         except Exception:
             traffic = None
     roofline = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": kernels[dom]["frac"], "traffic": traffic,
+                "unit": "GB/s", "frac": kernels[dom]["frac"], "traffic": traffic, "traffic_source": traffic_src,
                 "algo_bytes_per_launch": kernels[dom]["algo_bytes_per_cell"] * cells_local,
                 "avg_launch_ms": kernels[dom]["avg_ms"]}
     # measured copy ceiling of this GPU (BASELINE.md asks for the fraction against it next to the nominal 8 TB/s):
@@ -314,20 +366,54 @@ def main():
     out = {
         "metric": "cell-updates/sec (advect+diffuse+Poisson step)", "value": value, "unit": "cell-updates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if (args.size and world > 1) else "weak",
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{nx}x{ny}x{nz} neutral empty-domain channel, cd2 momentum advection + "
-                               f"Vreman SGS diffusion + FFT(x,y)/tridiagonal(z) Poisson + RK3 substep "
-                               f"(BASELINE.json configs[1])",
+        "config": {"workload": workload_name(nx, ny, nz, args.sgs, args.nsv, not args.no_floor),
                    "floor": "free (no wall function)" if args.no_floor else
                             "neutral log-law wall function (lbottom, BCbotm=3, z0=0.05)",
                    "grid": [nx, ny, nz], "decomposition": f"y-slabs x{world}", "dt": dt,
                    "step": "one RK3 substep = one cell-update per cell"},
         "whole_substep_hbm_frac": round(392.0 * cells_local * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4),
         "divmax_after_run": divmax,
+        "poisson_only_ms": round(poisson_ms, 5),
         "roofline": roofline,
         "kernels": kernels,
     }
+    if world > 1 and not args.no_single:
+        # rank 0's own one-GPU run of the SAME grid (single-slab code path), so that every N>1 line carries its strong-scaling
+        # reference; the other ranks wait at the barrier below.  Cheap start state (uniform flow + noise): timing only.
+        single = None
+        if rank == 0:
+            with tempfile.TemporaryDirectory() as tmp:
+                deck1 = read_deck(write_deck(tmp, 903, nx, ny, nz, 0, dt=dt, nprocy=1, nsv=args.nsv, sgs=args.sgs, floor=not args.no_floor))
+            c1 = udcore.from_deck(deck1, device=local_rank, rank=0, nranks=1)
+            rng = np.random.default_rng(43)
+            noise = 0.02 * (rng.random(c1.g.mshape()) - 0.5)
+            for k, base in (("u0", 1.0), ("v0", 0.0), ("w0", 0.0)):
+                a = noise + base
+                c1.upload(k, a); c1.upload(k.replace("0", "m"), a)
+            del noise, a
+            c1.halos(); c1.boundary()
+            sync1 = lambda: (torch.cuda.synchronize(), c1.sync())      # noqa: E731
+            rk1 = [1]
+
+            def step1():
+                c1.substep(rk1[0], dt, True)
+                rk1[0] = rk1[0] % 3 + 1
+            for _ in range(6):
+                step1()
+            n1 = max(6, min(args.steps, 30))
+            ms1 = time_loop(c1, step1, n1, sync1)
+            c1.rk3step, c1.dt = 1, dt
+            for _ in range(3):
+                c1.poisson()
+            p1 = time_loop(c1, c1.poisson, 10, sync1)
+            c1.close()
+            single = {"ms_per_step": round(ms1, 5), "poisson_only_ms": round(p1, 5), "steps": n1,
+                      "speedup_substep": round(ms1 / (elapsed / args.steps * 1e3), 3),
+                      "speedup_poisson": round(p1 / poisson_ms, 3)}
+        dist.barrier()
+        out["single_gpu_same_workload"] = single
     if rank == 0:
         if world == 1 and not args.no_cpu:
             cb = cpu_baseline(nx, ny, nz)

@@ -36,7 +36,7 @@ program ref_driver
   use modsubgriddata
   use modsurfdata, only: thl_top, wttop, wsvtop, sv_top, wsvtopdum, thvs, thls, z0, z0h, wtsurf, qts, wqtop, qt_top, wqsurf, ps
   use modwallfunctions, only: wfmneutral, wfuno
-  use modboundary, only: initboundary, boundary, halos, grwdamp
+  use modboundary, only: initboundary, boundary, halos, grwdamp, ksp
   use modthermodynamics, only: initthermodynamics, thermodynamics, lqlnr
   use modsubgrid, only: initsubgrid, subgrid
   use modpois, only: initpois, poisson, p
@@ -309,14 +309,14 @@ contains
     integer :: ierr
     namelist /RUN/ iexpnr, runtime, dtmax, trestart, ladaptive, irandom, randu, krand, courant, diffnr, &
       libm, lles, lrandomize, nprocx, nprocy
-    namelist /DOMAIN/ itot, jtot, ktot, xlen, ylen
-    namelist /PHYSICS/ lmoist, lcoriol, lbuoyancy, ltempeq, lprofforc, dpdx, luvolflowr, uflowrate, &
+    namelist /DOMAIN/ itot, jtot, ktot, xlen, ylen, xlat, ksp
+    namelist /PHYSICS/ ps, lmoist, lcoriol, lbuoyancy, ltempeq, lprofforc, dpdx, luvolflowr, uflowrate, &
       lvvolflowr, vflowrate, igrw_damp, geodamptime, lnudge, lnudgevel, tnudge, nnudge, ifixuinf, lvinf, tscale
     namelist /INLET/ Uinf, Vinf, inletav
     namelist /CHEMISTRY/ lchem, k1, JNO2
     namelist /DYNAMICS/ lqlnr, ipoiss, iadv_mom, iadv_tke, iadv_thl, iadv_qt, iadv_sv
     namelist /BC/ BCxm, BCym, BCtopm, BCtopT, BCtops, BCbotm, BCbots, BCbotT, BCzp, wttop, thl_top, z0, wtsurf, thls, qts, &
-      BCtopq, BCbotq, wqtop, qt_top, wqsurf, ps, z0h, wsvtopdum, ds
+      BCtopq, BCbotq, wqtop, qt_top, wqsurf, z0h, wsvtopdum, ds
     namelist /SCALARS/ nsv, lscasrc, nscasrc, lscasrcl, nscasrcl
     namelist /WALLS/ nfcts, lbottom
     open (ifnamopt, file=fname_options, status='old', iostat=ierr)

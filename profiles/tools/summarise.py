@@ -63,24 +63,27 @@ with open(os.path.join(out, "pmc_summary.json"), "w") as fh:
     json.dump(summary, fh, indent=1, sort_keys=True)
 print("kernels:", len(summary), "stats rows:", len(rows))
 
-# ---- bench.py's traffic file (profiles/pmc_traffic.json): dominant kernels keyed by bench.py's profile names
-ALGO = {"closure": 40, "mom_truetruetruetrue": 88, "div_rhs": 32, "thomas": 24, "project_integrate": 72}
+# ---- bench.py's traffic file (profiles/pmc_traffic.json): kernels keyed by workload and by bench.py's profile names.
+# WORKLOAD_KEY = "<nx>x<nyl>x<nz>/<sgs>/nsv<n>" (bench.py's key), CELLS = cells per GPU; both set by collect.sh
+ALGO = {"closure": 40, "mom_truetruetruetrue": 88, "div_rhs": 32, "thomas": 24, "project_integrate": 72, "scalar": 48}
 MAP = [("closure_lds_kernel", "closure"), ("mom_lds_kernel", "mom_truetruetruetrue"), ("div_rhs_kernel", "div_rhs"),
-       ("thomas_lds_kernel", "thomas"), ("thomas_kernel", "thomas"), ("integrate_kernel", "project_integrate")]
-cells = 256 ** 3
-traffic = {"workload": "256x256x256",
-           "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), "
-                   "`python bench.py --no-cpu --steps 12 --warmup 3` via profiles/tools/collect.sh; raw values in KiB; "
+       ("thomas_lds_kernel", "thomas"), ("thomas_kernel", "thomas"), ("integrate_kernel", "project_integrate"),
+       ("scalar_kernel", "scalar")]
+key = os.environ.get("WORKLOAD_KEY", "256x256x256/vreman/nsv0")
+cells = int(os.environ.get("CELLS", str(256 ** 3)))
+nsv = int(key.rsplit("nsv", 1)[1])
+traffic = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) of `python bench.py "
+                   "--no-cpu --no-dropin --steps 12 --warmup 3 [workload flags]` via profiles/tools/collect.sh; raw values in KiB; "
                    "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (FETCH_SIZE doubled per MI355X_MICROARCH.md: "
                    "gfx950 tallies 128-B read requests as 64 B)",
-           "kernels": {}}
+           "workloads": {key: {}}}
 for k, ent in summary.items():
     for pat, name in MAP:
-        if k.startswith(pat) and "FETCH_SIZE" in ent and "WRITE_SIZE" in ent and name not in traffic["kernels"]:
+        if k.startswith(pat) and "FETCH_SIZE" in ent and "WRITE_SIZE" in ent and name not in traffic["workloads"][key]:
             hb = ent["hbm_read_bytes"] + ent["hbm_write_bytes"]
-            traffic["kernels"][name] = {"FETCH_SIZE_KiB": ent["FETCH_SIZE"], "WRITE_SIZE_KiB": ent["WRITE_SIZE"],
-                                        "hbm_bytes_per_launch": int(hb),
-                                        "algorithmic_bytes_per_launch": ALGO[name] * cells,
-                                        "ratio": round(hb / (ALGO[name] * cells), 3)}
+            ab = (ALGO[name] + (24 * nsv if name == "project_integrate" else 0)) * cells
+            traffic["workloads"][key][name] = {"FETCH_SIZE_KiB": ent["FETCH_SIZE"], "WRITE_SIZE_KiB": ent["WRITE_SIZE"],
+                                               "hbm_bytes_per_launch": int(hb), "algorithmic_bytes_per_launch": ab,
+                                               "ratio": round(hb / ab, 3), "source": os.environ.get("TRAFFIC_SOURCE", "")}
 with open(os.path.join(out, "pmc_traffic.json"), "w") as fh:
     json.dump(traffic, fh, indent=1)

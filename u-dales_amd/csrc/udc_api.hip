@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <utility>
+#include <algorithm>
 
 static thread_local char g_err[512] = "";
 
@@ -195,8 +196,9 @@ extern "C" int udc_create(const udc_config *cfg, udc_handle **out) {
       if (alloc_field(h, UDC_SV0 + 3 * n + q)) return 1;
     h->slots.push_back(n);
   }
-  HIP_OK(hipMalloc(&h->red, sizeof(double) * 4096));
-  HIP_OK(hipHostMalloc(&h->red_host, sizeof(double) * 4096));
+  h->red_cap = std::max((size_t)4096, (size_t)16 * (g.nz + 2));      // udc_slab_averages: 16 fields x (ktot + 1) levels
+  HIP_OK(hipMalloc(&h->red, sizeof(double) * h->red_cap));
+  HIP_OK(hipHostMalloc(&h->red_host, sizeof(double) * h->red_cap));
   if (h->slab) { if (pois_slab_init(h)) return 1; }
   else if (pois_init(h)) return 1;
   if (h->slab) {

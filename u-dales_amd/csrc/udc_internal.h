@@ -108,6 +108,7 @@ struct udc_handle {
   // reductions
   double *red = nullptr;                // small device scratch
   double *red_host = nullptr;           // pinned
+  size_t red_cap = 0;                   // doubles in red / red_host
   double *partials = nullptr;           // per-workgroup partial results of the two-stage reductions
   size_t partials_cap = 0;
   // profiling

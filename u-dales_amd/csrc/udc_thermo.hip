@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void level_affine_kernel(Geo g, TileGrid tg, c
 int k_slab_averages(udc_handle *h, const int *fields, int nf, double *avg_host, int n) {
   const Geo &g = h->g;
   if (n < 1 || n > g.nz + 1) { udc_set_error("udc_slab_average: 1 <= n <= ktot+1"); return 1; }
-  if (nf < 1 || nf > 16 || (size_t)nf * n > 4096) { udc_set_error("udc_slab_averages: at most 16 fields and 4096 values per call"); return 1; }
+  if (nf < 1 || nf > 16) { udc_set_error("udc_slab_averages: at most 16 fields per call"); return 1; }
   for (int q = 0; q < nf; ++q)
     if (fields[q] < 0 || fields[q] >= (int)h->fields.size() || !h->fields[fields[q]]) { udc_set_error("udc_slab_average: unknown field %d", fields[q]); return 1; }
   const TileGrid tg = tile_grid(g);

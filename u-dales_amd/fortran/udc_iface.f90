@@ -596,8 +596,8 @@ contains
       q = q + 1; qt0av(kb:ke + kh) = avg(:, q)
     end if
     n0 = 1
-    do while (n0 <= nsv)                ! the scalars in batches of at most 16 fields (and 4096 values) per reduction
-      nb = min(nsv - n0 + 1, 16, max(4096/nlev, 1))
+    do while (n0 <= nsv)                ! the scalars in batches of at most 16 fields per reduction
+      nb = min(nsv - n0 + 1, 16)
       do n = 1, nb
         ids(n) = UDC_SV0 + 3*(n0 + n - 2)
       end do

@@ -41,7 +41,7 @@ def from_deck(deck, device=0, rank=0, nranks=1):
         if deck.get("PHYSICS", "lbuoyancy") or sgs == 3:      # the moist thermodynamics feed the buoyancy and calthv's dthvdz
             if not deck.get("PHYSICS", "ltempeq"):
                 raise ValueError("lmoist with lbuoyancy or loneeqn needs ltempeq on the device path")
-            core.set_moist_thermo(float(deck.get("BC", "thls")), float(deck.get("BC", "qts")), float(deck.get("BC", "ps")),
+            core.set_moist_thermo(float(deck.get("BC", "thls")), float(deck.get("BC", "qts")), float(deck.get("PHYSICS", "ps")),
                                   lqlnr=bool(deck.get("DYNAMICS", "lqlnr")))
     if deck.get("PHYSICS", "ltempeq") and deck.get("PHYSICS", "lbuoyancy"):
         core.set_buoyancy(True)
@@ -56,7 +56,7 @@ def from_deck(deck, device=0, rank=0, nranks=1):
     # dpdxl, dpdyl: src/modstartup.f90:2071-2081 (lcoriol false => om23_gs terms still present:
     # dpdxl = om23_gs*vg - pgx - dpdx with om23_gs = 2*omega*sin(lat); ug = vg = 0 in our decks)
     import math
-    phi = float(deck.get("PHYSICS", "xlat") if deck.get("PHYSICS", "xlat") is not None else 52.) * 3.141592653589793116 / 180.
+    phi = float(deck.get("DOMAIN", "xlat")) * 3.141592653589793116 / 180.      # src/modglobal.f90:660-675
     om23_gs = 2. * 7.292e-5 * math.sin(phi)
     # coriolis (src/modforces.f90:600-717): om22, om23 of src/modglobal.f90:666-673
     mode = 1 if deck.get("PHYSICS", "lcoriol") else (2 if deck.get("PHYSICS", "lprofforc") else 0)

@@ -253,10 +253,13 @@ class DynCore:
     def slab_averages(self, fields):
         """Horizontal means of several fields per level in one device round trip: {name: [nz+2] by the reference's k}."""
         from .forcings import field_id
-        ids = (C.c_int * len(fields))(*[field_id(f) if isinstance(f, str) else f for f in fields])
         n = self.g.nz + 1
         a = np.zeros((len(fields), n))
-        L._check(self.lib.udc_slab_averages(self.h, ids, len(fields), a.ctypes.data_as(L.DP), n), "udc_slab_averages")
+        batch = 16                              # one reduction takes at most 16 fields
+        for q0 in range(0, len(fields), batch):
+            part = fields[q0:q0 + batch]
+            ids = (C.c_int * len(part))(*[field_id(f) if isinstance(f, str) else f for f in part])
+            L._check(self.lib.udc_slab_averages(self.h, ids, len(part), a[q0:q0 + len(part)].ctypes.data_as(L.DP), n), "udc_slab_averages")
         return {f: np.concatenate(([0.], a[q])) for q, f in enumerate(fields)}
 
     def set_level_forcing(self, tend, src, A, B, when=0):

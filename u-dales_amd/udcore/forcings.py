@@ -36,7 +36,8 @@ class LevelForcings:
         self.tnudge = float(ph("tnudge"))
         self.nnudge = int(ph("nnudge"))
         self.lcoriol = bool(ph("lcoriol"))
-        self.geodamptime = float(ph("geodamptime"))
+        from .namoptions import GEODAMPTIME
+        self.geodamptime = GEODAMPTIME
         self.ltempeq = bool(ph("ltempeq"))
         self.lmoist = bool(ph("lmoist"))
         # profiles indexed by the reference's k (entry 0 unused)
@@ -59,7 +60,10 @@ class LevelForcings:
         self.subsidence = bool(np.any(wfls != 0.))
         # sponge: initboundary, src/modboundary.f90:45-59 (rnu0 = 2.75e-3)
         kmax = nz
-        self.ksp = max(min(3 * kmax // 4, kmax - 15), 1)
+        ksp = int(deck.get("DOMAIN", "ksp"))                # &DOMAIN ksp (src/modstartup.f90:118); -1: the default below
+        self.ksp = ksp if ksp != -1 else max(min(3 * kmax // 4, kmax - 15), 1)
+        if not 1 <= self.ksp < nz:
+            raise ValueError(f"&DOMAIN ksp = {self.ksp} outside 1..{nz - 1}")
         tsc = np.zeros(nz + 2)
         zspb, zspt = g.zf[self.ksp], g.zf[nz]
         pi = 3.141592653589793116
@@ -158,7 +162,9 @@ class LevelForcings:
         return out
 
     def averages(self):
-        names = ["u0", "v0"] + (["thl0"] if self.ltempeq else []) + (["qt0"] if self.lmoist else []) + [f"sv0_{n}" for n in range(self.core.nsv)]
+        names = ["u0", "v0"] + (["thl0"] if self.ltempeq else []) + (["qt0"] if self.lmoist else [])
+        if self.subsidence or self.lnudge:      # the only two users of the scalars' slab means
+            names += [f"sv0_{n}" for n in range(self.core.nsv)]
         if hasattr(self.core, "slab_averages"):
             return self.core.slab_averages(names)
         return {n: self.core.slab_average(n) for n in names}

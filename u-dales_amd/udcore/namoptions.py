@@ -16,22 +16,78 @@ DEFAULTS = {
     "RUN": dict(iexpnr=0, runtime=300., dtmax=20., ladaptive=False, irandom=43, randu=0.01,
                 krand=2 ** 31 - 1, courant=-1., diffnr=0.25, libm=True, lles=True, lrandomize=True,
                 nprocx=1, nprocy=1, lwarmstart=False, trestart=10000.),
-    "DOMAIN": dict(itot=96, jtot=96, ktot=96, xlen=-1., ylen=-1.),
-    "PHYSICS": dict(lmoist=False, lcoriol=False, lbuoyancy=False, ltempeq=False, lprofforc=False,
-                    dpdx=0., igrw_damp=0, geodamptime=7200., lnudge=False, lnudgevel=True, tnudge=60., nnudge=0, xlat=52., luvolflowr=False, uflowrate=1., lvvolflowr=False, vflowrate=1.,
+    "DOMAIN": dict(itot=96, jtot=96, ktot=96, xlen=-1., ylen=-1., xlat=52., ksp=-1),
+    "PHYSICS": dict(lmoist=False, lcoriol=False, lbuoyancy=False, ltempeq=False, lprofforc=False, ps=101325.,
+                    dpdx=0., igrw_damp=0, lnudge=False, lnudgevel=True, tnudge=60., nnudge=0, luvolflowr=False, uflowrate=1., lvvolflowr=False, vflowrate=1.,
                     ifixuinf=0, lvinf=False, tscale=0.),
     "CHEMISTRY": dict(lchem=False, k1=0., JNO2=0.),
     "INLET": dict(Uinf=0., Vinf=0., inletav=0.),
     "DYNAMICS": dict(lqlnr=False, ipoiss=0, iadv_mom=2, iadv_tke=-1, iadv_thl=-1, iadv_qt=-1),
     "BC": dict(BCxm=1, BCym=1, BCtopm=1, BCbotm=2, BCzp=1, z0=-1., z0h=-1., BCtopT=1, BCbotT=1, BCbots=1, BCtops=1,
                wttop=0., thl_top=-1., wtsurf=-1., thls=-1., qts=-1.,
-               BCtopq=1, BCbotq=1, wqtop=0., qt_top=-1., wqsurf=-1., ps=101325., wsvtopdum=0., ds=0.),
+               BCtopq=1, BCbotq=1, wqtop=0., qt_top=-1., wqsurf=-1., wsvtopdum=0., ds=0.),
     "SCALARS": dict(nsv=0, lscasrc=False, nscasrc=0, lscasrcl=False, nscasrcl=0),
     "NAMSUBGRID": dict(lsmagorinsky=False, lvreman=True, loneeqn=False, c_vreman=0.07, cs=-1.,
                        cf=2.5, cn=0.76, Rigc=0.25, Prandtl=0.333, ldelta=False, lbuoycorr=False),
     "WALLS": dict(nfcts=-1, lbottom=False),
     "ORACLE": dict(nsub=3, nspin=2, lforces=True, scal_a=1.0, scal_b=0.0),
 }
+GEODAMPTIME = 7200.      # src/modglobal.f90 (not a namelist variable)
+
+# Every variable the reference's readnamelists accepts, per group (src/modstartup.f90:105-172, src/modsubgrid.f90:89-90).
+# A deck that sets a name outside its group's list would stop the reference ("Problem in namoptions"): read_deck does
+# the same.  wqtop (&BC) is an extension of the repo's test driver (oracle/ref_driver.f90); &ORACLE is that driver's own.
+KNOWN = {
+    "RUN": "iexpnr lwarmstart lstratstart startfile runmode runtime dtmax trestart ladaptive irandom randu randthl randqt krand "
+           "courant diffnr author libm lles lper2inout lwalldist lreadmean nprocx nprocy lrandomize",
+    "DOMAIN": "itot jtot ktot xlen ylen xlat xlon xday xtime ksp",
+    "PHYSICS": "ps igrw_damp lmoist lcoriol lbuoyancy ltempeq lprofforc ifixuinf lvinf tscale dpdx luoutflowr lvoutflowr "
+               "luvolflowr lvvolflowr uflowrate vflowrate lnudge lnudgevel tnudge nnudge ltimedepsurf ntimedepsurf "
+               "ltimedepnudge ntimedepnudge ltimedeplw ntimedeplw ltimedepsw ntimedepsw lconservativeibm",
+    "DYNAMICS": "lqlnr ipoiss iadv_mom iadv_tke iadv_thl iadv_qt iadv_sv",
+    "BC": "BCxm BCxT BCxq BCxs BCym BCyT BCyq BCys BCtopm BCtopT BCtopq BCtops BCbotm BCbotT BCbotq BCbots bctfxm bctfxp "
+          "bctfym bctfyp bctfz bcqfxm bcqfxp bcqfym bcqfyp bcqfz wttop thl_top qt_top qts wsvsurfdum wsvtopdum wtsurf "
+          "wqsurf thls z0 z0h BCzp ds wqtop",
+    "INLET": "Uinf Vinf di dti inletav linletRA lstoreplane lreadminl lfixinlet lfixutauin lwallfunc",
+    "DRIVER": "idriver tdriverstart driverjobnr dtdriver driverstore iplane iangledeg lchunkread chunkread_size",
+    "WALLS": "nfcts iwallmom iwalltemp iwallmoist iwallscal nsolpts_u nsolpts_v nsolpts_w nsolpts_c nbndpts_u nbndpts_v "
+             "nbndpts_w nbndpts_c nfctsecs_u nfctsecs_v nfctsecs_w nfctsecs_c lbottom lnorec prandtlturb fkar lwritefac dtfac",
+    "ENERGYBALANCE": "lEB lwriteEBfiles lperiodicEBcorr sinkbase lconstW dtEB bldT flrT wsoil wgrmax wwilt wfc skyLW GRLAI "
+                     "rsmin nfaclyrs lfacTlyrs lvfsparse nnz fraction",
+    "SCALARS": "lreadscal lscasrc lscasrcl lscasrcr nsv nscasrc nscasrcl",
+    "CHEMISTRY": "lchem k1 JNO2",
+    "OUTPUT": "lfielddump tfielddump fieldvars ltdump lydump lytdump lxydump lxytdump lmintdump lkslicedump kslice "
+              "lislicedump islice ljslicedump jslice ltkedump tstatsdump tsample tstatstart",
+    "TREES": "ltrees ntrees cd dec ud lad Qstar dQdt lsize r_s ltreedump itree_mode",
+    "PURIFS": "lpurif npurif Qpu epu",
+    "HEATPUMP": "lheatpump lfan_hp nhppoints Q_dot_hp QH_dot_hp",
+    "NAMSUBGRID": "ldelta lmason cf cn Rigc Prandtl lsmagorinsky lvreman loneeqn c_vreman cs nmason lbuoycorr",
+    "ORACLE": "nsub nspin nwarm dump_at lforces scal_a scal_b",
+}
+KNOWN = {g: {n.lower() for n in v.split()} for g, v in KNOWN.items()}
+# Switches of features that have no device implementation: a deck that turns one on is refused (udcore.run,
+# check_supported) instead of silently running different physics.  (group, name, value that means "off")
+UNSUPPORTED = [("RUN", "lstratstart", False), ("RUN", "lper2inout", False), ("RUN", "lreadmean", False),
+               ("PHYSICS", "ltimedepsurf", False), ("PHYSICS", "ltimedepnudge", False), ("PHYSICS", "ltimedeplw", False),
+               ("PHYSICS", "ltimedepsw", False), ("PHYSICS", "luoutflowr", False), ("PHYSICS", "lvoutflowr", False),
+               ("DRIVER", "idriver", 0), ("INLET", "linletRA", False), ("INLET", "lstoreplane", False),
+               ("INLET", "lreadminl", False), ("INLET", "lfixinlet", False), ("INLET", "lfixutauin", False),
+               ("ENERGYBALANCE", "lEB", False), ("ENERGYBALANCE", "lperiodicEBcorr", False),
+               ("SCALARS", "lreadscal", False), ("SCALARS", "lscasrcr", False),
+               ("TREES", "ltrees", False), ("PURIFS", "lpurif", False), ("HEATPUMP", "lheatpump", False),
+               ("NAMSUBGRID", "lmason", False)]
+
+
+def _expand(tokens):
+    """Fortran repeat counts: `3*0.` -> three values."""
+    out = []
+    for t in tokens:
+        m = re.fullmatch(r"(\d+)\*(.*)", t)
+        if m:
+            out += [m.group(2)] * int(m.group(1))
+        else:
+            out.append(t)
+    return out
 
 
 def _value(tok: str):
@@ -85,10 +141,10 @@ def parse_namelists(text: str) -> dict:
         # parts = [pre, name1, vals1, name2, vals2, ...]
         pre = parts[0].strip()
         if pre and last is not None:
-            grp[last] = _as_list(grp[last]) + [_value(v) for v in re.split(r"[,\s]+", pre) if v]
+            grp[last] = _as_list(grp[last]) + [_value(v) for v in _expand([v for v in re.split(r"[,\s]+", pre) if v])]
         for q in range(1, len(parts), 2):
             name, vals = parts[q], parts[q + 1]
-            vv = [_value(v) for v in re.split(r"[,\s]+", vals.strip()) if v]
+            vv = [_value(v) for v in _expand([v for v in re.split(r"[,\s]+", vals.strip()) if v])]
             grp[name] = vv[0] if len(vv) == 1 else vv
             last = name
         if close:
@@ -124,6 +180,20 @@ class Deck:
                 return v
         return DEFAULTS[group][name]
 
+    def is_set(self, group, name):
+        return any(k.lower() == name.lower() for k in self.nml.get(group, {}))
+
+    def validate(self):
+        """A name the reference's namelist of that group does not hold stops the reference; so it does here."""
+        for grp, vals in self.nml.items():
+            if grp not in KNOWN:
+                raise ValueError(f"{self.path}: unknown namelist group &{grp}")
+            for k in vals:
+                if k.lower() not in KNOWN[grp]:
+                    where = [g for g, names in KNOWN.items() if k.lower() in names]
+                    hint = f" (it belongs to &{where[0]})" if where else ""
+                    raise ValueError(f"{self.path}: &{grp} has no variable '{k}'{hint} -- Problem in namoptions {grp}")
+
 
 def _read_table(path, ncol, nrows):
     rows = []
@@ -144,6 +214,7 @@ def read_deck(namoptions_path: str) -> Deck:
     with open(namoptions_path) as f:
         nml = parse_namelists(f.read())
     d = Deck(path=namoptions_path, nml=nml)
+    d.validate()
     exp = d.get("RUN", "iexpnr")
     base = os.path.dirname(os.path.abspath(namoptions_path))
     ktot = d.get("DOMAIN", "ktot")

@@ -3,7 +3,7 @@
     python -m udcore.run namoptions.NNN [--steps N] [--restart-from NTRUN] [--device D] [--quiet]
 
 reads the deck (namoptions, prof.inp, lscale.inp) from the file's directory, cold-starts (or warm-starts from the
-reference's initd/inits restart files, &RUN lwarmstart / --restart-from), advances until `runtime` (or N full steps)
+reference's initd/inits restart files with --restart-from NTRUN; a deck with &RUN lwarmstart is refused), advances until `runtime` (or N full steps)
 with the reference's own time-step control (tstep_update, src/modtstep.f90:113-150: fixed dtmax, or adaptive with the
 Courant / diffusion numbers), and writes restart files in the reference's layout every `trestart` seconds of model
 time and at the end (src/modsave.f90:77-121).  Immersed boundaries (libm) and non-periodic lateral
@@ -25,7 +25,19 @@ def _refuse(msg):
 
 
 def check_supported(deck):
+    from .namoptions import UNSUPPORTED
     g = deck.get
+    for grp, name, off in UNSUPPORTED:                       # features without a device implementation
+        if deck.is_set(grp, name) and deck.nml[grp][[k for k in deck.nml[grp] if k.lower() == name.lower()][0]] != off:
+            _refuse(f"&{grp} {name} is not available on the device path")
+    if int(g("DYNAMICS", "iadv_mom")) != 2:
+        _refuse("Unknown advection scheme: only iadv_mom = 2 (cd2) is on the device path")      # src/modadvection.f90:52
+    for grp, names in (("BC", ("BCxT", "BCxq", "BCxs", "BCyT", "BCyq", "BCys")),):
+        for n in names:
+            if deck.is_set(grp, n) and int(deck.nml[grp][[k for k in deck.nml[grp] if k.lower() == n.lower()][0]]) != 1:
+                _refuse(f"only periodic lateral boundaries are on the device path (&BC {n})")
+    if bool(g("RUN", "lwarmstart")):
+        _refuse("&RUN lwarmstart: warm starts go through --restart-from NTRUN (the runner does not read startfile)")
     if g("RUN", "libm") and int(g("WALLS", "nfcts")) > 0:
         _refuse("immersed boundaries (libm with facets) are not on the device path")
     if int(g("BC", "BCxm")) != 1 or int(g("BC", "BCym")) != 1:
@@ -41,9 +53,16 @@ def courant_default(deck):
     c = float(deck.get("RUN", "courant"))
     if c >= 0:
         return c
-    c = 1.5
-    kappa_used = int(deck.get("SCALARS", "nsv")) > 0 or int(deck.get("DYNAMICS", "iadv_thl")) == 7
-    return min(c, 1.1) if kappa_used else c
+    iadv_mom = int(deck.get("DYNAMICS", "iadv_mom"))
+    c = 1.5 if iadv_mom == 2 else 1.4
+    # scalars always use the kappa scheme (:557-559); thl, qt, tke inherit the momentum scheme when < 0 (:549-551)
+    adv = [iadv_mom if int(deck.get("DYNAMICS", n)) < 0 else int(deck.get("DYNAMICS", n)) for n in ("iadv_thl", "iadv_qt", "iadv_tke")]
+    sv = [7] * int(deck.get("SCALARS", "nsv"))
+    if 7 in sv + adv or 1 in sv + adv:
+        c = min(c, 1.1)
+    elif 2 in sv + adv:
+        c = min(c, 1.5)
+    return c
 
 
 def main(argv=None):
@@ -97,6 +116,9 @@ def main(argv=None):
         dt = dtmax if not ladaptive else dtmax / 100.          # src/modstartup.f90:1099, 2038
     core.dt, core.timee, core.rk3step = dt, timee, 0
     forcings = LevelForcings(core, deck)
+    # (the reference restarts the restart clock and the step counter on a warm start: tnextrestart = trestart,
+    # ntrun = 0, src/modglobal.f90:869; this runner keeps counting from the file it started from, so that the files
+    # of a continued run do not overwrite those of the first leg)
     tnext = timee + trestart
     t_end = timee + runtime
     say = (lambda *a: None) if (args.quiet or rank) else (lambda *a: print(*a, flush=True))
