@@ -217,6 +217,21 @@ int udc_slab_average(udc_handle *h, int field, double *avg, int n);
 int udc_slab_averages(udc_handle *h, const int *fields, int nf, double *avg, int n);
 int udc_set_level_forcing(udc_handle *h, int tend, int src, const double *A, const double *B, int n, int when);
 int udc_level_forcings(udc_handle *h, int when);
+/* Immersed boundary, the sparse corrections (src/modibm.f90).  The point lists are the reference's input files
+ * solid_{u,v,w,c}.txt and fluid_boundary_{u,v,w,c}.txt: n rows of GLOBAL 1-based (i, j, k), here as int[n][3]; grid 0 = u,
+ * 1 = v, 2 = w, 3 = c (needed when scalars are transported).  udc_ibm_commit builds what initibm derives from them (the masks
+ * of :150-186, evaluated at the listed points; lateral neighbours wrap periodically) and keeps this slab's points.
+ *   udc_ibmwallfun  ibmwallfun (:1167) without facet wall functions (iwallmom = 1): diffu_corr (:990), diffv_corr (:1033),
+ *                   diffw_corr (:1075), diffc_corr (:1120) per scalar -- called after nudge (src/program.f90:166)
+ *   udc_ibmnorm     ibmnorm (:697): solid (:748) -- um, vm, wm and their tendencies zeroed at the solid points, svm / svp set
+ *                   to the mean of their fluid neighbours -- called after masscorr (src/program.f90:171)
+ * Both are part of udc_substep once committed.  Not available yet: the facet wall functions (wallfunmom :1286, wallfunheat
+ * :1436; hence thl / qt with immersed boundaries) and the masked slab averages (avexy_ibm) of masscorr and diagfld. */
+enum { UDC_IBM_U = 0, UDC_IBM_V = 1, UDC_IBM_W = 2, UDC_IBM_C = 3 };
+int udc_set_ibm_points(udc_handle *h, int grid, const int *solid, int nsolid, const int *bound, int nbound);
+int udc_ibm_commit(udc_handle *h);
+int udc_ibmwallfun(udc_handle *h);
+int udc_ibmnorm(udc_handle *h);
 /* masscorr    src/modforces.f90:328     volume-flow branches: up += (uflowrate - <um + rk3coef up>)/rk3coef (luvolflowr,
  *             :389-417) and the same for v (lvvolflowr, :467-494); <.> = volume average over the whole domain
  *             (all-reduced over the slabs).  Called after forces (src/program.f90:169).  No-op unless enabled with

@@ -7,12 +7,13 @@
 !     tstep_update -> advection -> subgrid -> forces -> poisson ->
 !     tstep_integrate -> halos -> boundary
 !
-! (the IBM / NetCDF / statistics modules cannot be built here and are outside the
-! hot path, SURVEY.md section 8).  With &WALLS lbottom=.true. the floor wall function of
-! `bottom` (src/modibm.f90:1998-2100, a module that needs NetCDF and cannot be built) runs between
-! subgrid and forces as in src/program.f90:146-160: its arithmetic is the reference's own wfmneutral
-! (src/modwallfunctions.f90:263-350, compiled unmodified); only the dispatch lines :2021-2026 and the
-! zero-flux scalar floor :2073-2090 are restated in floor_bottom below.  Set-up mirrors src/modstartup.f90:
+! (the NetCDF / statistics modules cannot be built here and are outside the hot path, SURVEY.md section 8).
+! src/modibm.f90 as a whole needs NetCDF (initfac, modstat_nc); its NetCDF-free routines -- bottom, createmasks, ibmnorm,
+! solid, advecc2nd_corr_*, diffu/v/w/c_corr, initibmnorm -- are compiled from the reference file where it lies
+! (oracle/extract_modibm.sh assembles them into a `module modibm` inside the build directory).  What is restated here of
+! that module: initibm's mask set-up (:150-163) and reading of the fluid-boundary point lists (:302-306) in ibm_setup,
+! and ibmwallfun's call sequence without the wall functions (:1216-1218, :1262-1264) in ibmwallfun below.
+! Set-up mirrors src/modstartup.f90:
 !   readnamelists (:105-172, subset of groups/variables, same names),
 !   init2decomp (:652-691), cold start of readinitfiles (:1088-1290),
 !   lscale.inp reading (:2051-2092), randomize_field (:2367-2396).
@@ -35,7 +36,6 @@ program ref_driver
   use modfields
   use modsubgriddata
   use modsurfdata, only: thl_top, wttop, wsvtop, sv_top, wsvtopdum, thvs, thls, z0, z0h, wtsurf, qts, wqtop, qt_top, wqsurf, ps
-  use modwallfunctions, only: wfmneutral, wfuno
   use modboundary, only: initboundary, boundary, halos, grwdamp, ksp
   use modthermodynamics, only: initthermodynamics, thermodynamics, lqlnr
   use modsubgrid, only: initsubgrid, subgrid
@@ -46,10 +46,19 @@ program ref_driver
   use modsave, only: writerestartfiles
   use modscalsource, only: createscals, scalsource
 #ifdef UDC_DROPIN
-  ! drop-in build: the floor (`bottom`), the masks and lbottom come from the drop-in modibm, as in src/program.f90:38
-  use modibm, only: initibm, createmasks, bottom, lbottom
+  ! drop-in build: the floor (`bottom`), the immersed boundary, the masks and lbottom come from the drop-in modibm, as in
+  ! src/program.f90:38
+  use modibm, only: initibm, createmasks, bottom, lbottom, ibmwallfun, ibmnorm, nsolpts_u, nsolpts_v, nsolpts_w, nsolpts_c, &
+                    nbndpts_u, nbndpts_v, nbndpts_w, nbndpts_c
   use udc_iface, only: udc_residency, udc_pull_all, udc_h, udc_sync, udc_check, udc_deferred_stats
   use iso_c_binding, only: c_long
+#else
+  ! reference build: the reference's own routines (assembled by oracle/extract_modibm.sh)
+  use modibm, only: createmasks, bottom, lbottom, ibmnorm, solid, diffu_corr, diffv_corr, diffw_corr, diffc_corr, &
+                    initibmnorm, solid_info_u, solid_info_v, solid_info_w, solid_info_c, bound_info_u, bound_info_v, &
+                    bound_info_w, bound_info_c, mask_u, mask_v, mask_w, mask_c, nsolpts_u, nsolpts_v, nsolpts_w, nsolpts_c, &
+                    nbndpts_u, nbndpts_v, nbndpts_w, nbndpts_c
+  use readinput, only: read_sparse_ijk
 #endif
   implicit none
 
@@ -57,13 +66,10 @@ program ref_driver
   integer :: nsub = 3, nspin = 2, nwarm = 0
   integer :: dump_at(16) = -1
   logical :: lforces = .true.
-#ifndef UDC_DROPIN
-  logical :: lbottom = .false.           ! src/modibm.f90:49 (module variable of modibm)
-#else
+#ifdef UDC_DROPIN
   integer(c_long) :: nfused, nunfused
 #endif
   logical :: need_thermo = .false.
-  real :: bcTfluxA = 0.                  ! src/modibmdata.f90 (module variable of modibm's callers)
   integer :: isub, n, ierr, iu
   real :: t0, t1, chk_u2, chk_div
   real :: scal_a = 1.0, scal_b = 0.0     ! scalar init: sv = scal_b + scal_a*z/zsize
@@ -90,18 +96,16 @@ program ref_driver
   call init_decomp_np1
   call initglobal
   call initfields
-#ifndef UDC_DROPIN
-  ! createmasks without IBM, src/modibm.f90:2121-2135 (modibm cannot be built): slab cell counts of the masks
-  IIcs = nint(rslabs); IIus = nint(rslabs); IIvs = nint(rslabs); IIws = nint(rslabs)
-#endif
   call initboundary
   call initthermodynamics
   call initsubgrid
   call initpois
 #ifdef UDC_DROPIN
   call initibm                              ! src/program.f90:93-95
-  call createmasks
+#else
+  call ibm_setup
 #endif
+  call createmasks
   call cold_start
   call createscals                          ! src/modstartup.f90 (scalarsourcep / scalarsourcel files; no-op without sources)
   call boundary
@@ -217,7 +221,9 @@ contains
     if (lforces) call forces
     if (lforces) call lstend                ! src/program.f90:162 (large-scale subsidence; needs diagfld's slab averages)
     if (lforces) call nudge                 ! src/program.f90:164
+    call ibmwallfun                         ! src/program.f90:166 (no-op unless libm)
     call masscorr                           ! src/program.f90:169
+    call ibmnorm                            ! src/program.f90:171 (no-op unless libm)
     call scalsource                         ! src/program.f90:181 (point / line sources of the scalars; no-op unless lscasrc / lscasrcl)
     call fixuinf2                           ! src/program.f90:186 (dgdt of the dp/dx ODE; no-op unless ifixuinf = 2)
     call fixuinf1                           ! src/program.f90:188 (pulls the top-level mean back to Uinf; no-op unless ifixuinf = 1)
@@ -229,78 +235,64 @@ contains
     if (need_thermo) call thermodynamics            ! src/program.f90:214
   end subroutine one_substep
 
-  ! ---- `bottom`, src/modibm.f90:2021-2026 (momentum, BCbotm = 3) and :2073-2090 (scalars, BCbots = 1)
-  subroutine floor_bottom
-    integer :: i, j, m
-#ifdef UDC_DROPIN
+  subroutine floor_bottom                   ! src/program.f90:152
     call bottom
-    return
-#endif
-    e120(:, :, kb - 1) = e120(:, :, kb)     ! src/modibm.f90:2012-2013 (unconditional)
-    e12m(:, :, kb - 1) = e12m(:, :, kb)
-    if (.not. lbottom) return
-    if (BCbotm == 2) then                  ! src/modibm.f90:2021-2024
-      call wfuno(ih, jh, kh, up, vp, thlp, momfluxb, tfluxb, bcTfluxA, u0, v0, thl0, thls, z0, z0h, 91)
-    else if (BCbotm == 3) then
-      call wfmneutral(ih, jh, kh, up, vp, momfluxb, u0, v0, z0, 91)
-    else
-      write (0, *) 'ERROR: bottom boundary type for momentum undefined'
+  end subroutine floor_bottom
+
+#ifndef UDC_DROPIN
+  ! ---- initibm without the facet wall functions (src/modibm.f90:131-193): solid point lists (initibmnorm, the reference's),
+  !      masks (:150-167), fluid-boundary point lists (read as initibmwallfun reads them, :302-306)
+  subroutine ibm_setup
+    real, allocatable :: rhs(:, :, :)
+    integer, allocatable :: ids(:)
+    if (.not. libm) return
+    if (ltempeq .or. lmoist) then
+      write (0, *) 'ERROR: ref_driver: libm with ltempeq / lmoist needs wallfunheat (src/modibm.f90:1436), which cannot be built here'
       stop 1
     end if
-    if (ltempeq .and. BCbotT == 2) then    ! src/modibm.f90:2044-2045
-      call wfuno(ih, jh, kh, up, vp, thlp, momfluxb, tfluxb, bcTfluxA, u0, v0, thl0, thls, z0, z0h, 92)
-    else if (ltempeq) then                 ! src/modibm.f90:2033-2047, BCbotT = 1 (flux)
-      if (BCbotT /= 1) then
-        write (0, *) 'ERROR: bottom boundary type for temperature undefined'
-        stop 1
-      end if
-      do j = jb, je
-        do i = ib, ie
-          thlp(i, j, kb) = thlp(i, j, kb) &
-                           + ( &
-                           0.5*(dzf(kb - 1)*ekh(i, j, kb) + dzf(kb)*ekh(i, j, kb - 1)) &
-                           *(thl0(i, j, kb) - thl0(i, j, kb - 1)) &
-                           *dzh2i(kb) &
-                           - wtsurf &
-                           )*dzfi(kb)
-        end do
-      end do
-    end if
-    if (lmoist) then                       ! src/modibm.f90:2050-2066, BCbotq = 1 (flux)
-      if (BCbotq /= 1) then
-        write (0, *) 'ERROR: bottom boundary type for moisture undefined'
-        stop 1
-      end if
-      do j = jb, je
-        do i = ib, ie
-          qtp(i, j, kb) = qtp(i, j, kb) + ( &
-                          0.5*(dzf(kb - 1)*ekh(i, j, kb) + dzf(kb)*ekh(i, j, kb - 1)) &
-                          *(qt0(i, j, kb) - qt0(i, j, kb - 1)) &
-                          *dzh2i(kb) &
-                          + wqsurf &
-                          )*dzfi(kb)
-        end do
-      end do
-    end if
+    solid_info_u%nsolpts = nsolpts_u; solid_info_v%nsolpts = nsolpts_v; solid_info_w%nsolpts = nsolpts_w
+    call initibmnorm('solid_u.txt', solid_info_u)
+    call initibmnorm('solid_v.txt', solid_info_v)
+    call initibmnorm('solid_w.txt', solid_info_w)
+    allocate (mask_u(ib - ih:ie + ih, jb - jh:je + jh, kb - kh:ke + kh)); mask_u = 1.
+    allocate (mask_v(ib - ih:ie + ih, jb - jh:je + jh, kb - kh:ke + kh)); mask_v = 1.
+    allocate (mask_w(ib - ih:ie + ih, jb - jh:je + jh, kb - kh:ke + kh)); mask_w = 1.
+    mask_w(:, :, kb) = 0.
+    mask_u(:, :, kb - kh) = 0.; mask_v(:, :, kb - kh) = 0.; mask_w(:, :, kb - kh) = 0.
+    allocate (rhs(ib - ih:ie + ih, jb - jh:je + jh, kb:ke + kh))
+    call solid(solid_info_u, mask_u, rhs, 0., ih, jh, kh)
+    call solid(solid_info_v, mask_v, rhs, 0., ih, jh, kh)
+    call solid(solid_info_w, mask_w, rhs, 0., ih, jh, kh)
+    call exchange_halo_z(mask_u); call exchange_halo_z(mask_v); call exchange_halo_z(mask_w)
+    bound_info_u%nbndpts = nbndpts_u; bound_info_v%nbndpts = nbndpts_v; bound_info_w%nbndpts = nbndpts_w
+    call read_sparse_ijk('fluid_boundary_u.txt', nbndpts_u, bound_info_u%nbndptsrank, ids, bound_info_u%bndpts_loc, nskip=1)
+    call read_sparse_ijk('fluid_boundary_v.txt', nbndpts_v, bound_info_v%nbndptsrank, ids, bound_info_v%bndpts_loc, nskip=1)
+    call read_sparse_ijk('fluid_boundary_w.txt', nbndpts_w, bound_info_w%nbndptsrank, ids, bound_info_w%bndpts_loc, nskip=1)
     if (nsv > 0) then
-      if (BCbots /= 1) then
-        write (0, *) 'ERROR: bottom boundary type for scalars undefined'
-        stop 1
-      end if
-      do j = jb, je
-        do i = ib, ie
-          do m = 1, nsv
-            svp(i, j, kb, m) = svp(i, j, kb, m) + ( &
-                               0.5*(dzf(kb - 1)*ekh(i, j, kb) + dzf(kb)*ekh(i, j, kb - 1)) &
-                               *(sv0(i, j, kb, m) - sv0(i, j, kb - 1, m)) &
-                               *dzh2i(kb) &
-                               + 0. &
-                               )*dzfi(kb)
-          end do
-        end do
-      end do
+      solid_info_c%nsolpts = nsolpts_c
+      call initibmnorm('solid_c.txt', solid_info_c)
+      bound_info_c%nbndpts = nbndpts_c
+      call read_sparse_ijk('fluid_boundary_c.txt', nbndpts_c, bound_info_c%nbndptsrank, ids, bound_info_c%bndpts_loc, nskip=1)
+      allocate (mask_c(ib - ih:ie + ih, jb - jh:je + jh, kb - kh:ke + kh)); mask_c = 1.
+      mask_c(:, :, kb - kh) = 0.
+      call solid(solid_info_c, mask_c, rhs, 0., ih, jh, kh)
+      call exchange_halo_z(mask_c)
     end if
-  end subroutine floor_bottom
+    deallocate (rhs)
+  end subroutine ibm_setup
+
+  ! ---- ibmwallfun without wall functions (iwallmom = 1; src/modibm.f90:1216-1218, 1262-1264)
+  subroutine ibmwallfun
+    integer :: n
+    if (.not. libm) return
+    call diffu_corr
+    call diffv_corr
+    call diffw_corr
+    do n = 1, nsv
+      call diffc_corr(sv0(:, :, :, n), svp(:, :, :, n), ihc, jhc, khc)
+    end do
+  end subroutine ibmwallfun
+#endif
 
   ! ---- subset of src/modstartup.f90:105-172 (same group and variable names)
   subroutine read_namelists_subset
@@ -318,7 +310,8 @@ contains
     namelist /BC/ BCxm, BCym, BCtopm, BCtopT, BCtops, BCbotm, BCbots, BCbotT, BCzp, wttop, thl_top, z0, wtsurf, thls, qts, &
       BCtopq, BCbotq, wqtop, qt_top, wqsurf, z0h, wsvtopdum, ds
     namelist /SCALARS/ nsv, lscasrc, nscasrc, lscasrcl, nscasrcl
-    namelist /WALLS/ nfcts, lbottom
+    namelist /WALLS/ nfcts, lbottom, iwallmom, iwalltemp, nsolpts_u, nsolpts_v, nsolpts_w, nsolpts_c, &
+      nbndpts_u, nbndpts_v, nbndpts_w, nbndpts_c
     open (ifnamopt, file=fname_options, status='old', iostat=ierr)
     if (ierr /= 0) then
       write (0, *) 'ERROR: cannot open ', trim(fname_options)
@@ -335,7 +328,10 @@ contains
     read (ifnamopt, WALLS, iostat=ierr); call chk(ierr, 'WALLS')
     close (ifnamopt)
     nprocx = 1; nprocy = nprocs     ! y-slabs over however many ranks were launched (1 in the np1 build)
-    libm = .false.
+    if (libm .and. iwallmom /= 1) then
+      write (0, *) 'ERROR: ref_driver: the facet wall functions (iwallmom > 1, src/modibm.f90:1286) need initfac / NetCDF'
+      stop 1
+    end if
     allocate (wsvtop(1:max(nsv, 1))); wsvtop = 0.      ! src/modstartup.f90:518-519
     if (nsv > 0) wsvtop(1:nsv) = wsvtopdum(1:nsv)
     allocate (sv_top(1:max(nsv, 1))); sv_top = 0.
@@ -638,8 +634,19 @@ contains
       call put1('thl0av', thl0av(kb:ke + kh), kb)
       if (lmoist) call put1('qt0av', qt0av(kb:ke + kh), kb)
     end if
+    if (libm) then                          ! src/program.f90:166: diffu/v/w/c_corr at the fluid-boundary points
+      call dump_tend('ibw0')
+      call ibmwallfun
+      call dump_tend('ibw')
+    end if
     if (luvolflowr .or. lvvolflowr) call dump_tend('frc')   ! tendencies masscorr starts from
     call masscorr
+    if (libm) then                          ! src/program.f90:171: solid
+      call dump_tend('ibn0')
+      call ibmnorm
+      call dump_tend('ibn')
+      call dump_state('ibn')                ! um, vm, wm, svm after solid
+    end if
     if (lscasrc .or. lscasrcl) then
       call dump_tend('src0')                ! tendencies the scalar sources start from
       call scalsource

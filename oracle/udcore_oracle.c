@@ -1495,6 +1495,164 @@ void orc_masscorr(const orc_grid *g, int rk3step, double dt, double *up, const d
 }
 
 /* ====================================================================== substep */
+/* ------------------------------------------------------------------------------------------------------------------
+ * Immersed boundary, sparse corrections: src/modibm.f90.  Point lists as the reference reads them (solid_*.txt,
+ * fluid_boundary_*.txt): pts[3*n + 0..2] = (i, j, k), 1-based; single rank.  Masks are m-arrays holding 1 (fluid) / 0.
+ * orc_ibm_mask restates initibm's mask set-up (:150-167): ones, zero at k = kb-1, mask_w also zero at kb, zero at the
+ * solid points; the lateral halos are the periodic images (what exchange_halo_z gives on more than one rank). */
+void orc_ibm_mask(const orc_grid *g, int is_w, const int *solid, int nsolid, double *mask) {
+  const size_t n = msize(g);
+  for (size_t q = 0; q < n; ++q) mask[q] = 1.;
+  for (int j = 0; j <= g->ny + 1; ++j)
+    for (int i = 0; i <= g->nx + 1; ++i) { M(mask, i, j, 0) = 0.; if (is_w) M(mask, i, j, 1) = 0.; }
+  for (int q = 0; q < nsolid; ++q) M(mask, solid[3 * q], solid[3 * q + 1], solid[3 * q + 2]) = 0.;
+  orc_halos_m(g, mask);
+}
+/* diffu_corr :990-1030 */
+void orc_ibm_diffu_corr(const orc_grid *g, const int *bnd, int nbnd, const double *mask_u, const double *u0, const double *ekm, double *up) {
+  metrics m; metrics_init(g, &m);
+  const double *dzf = g->dzf;
+  for (int n = 0; n < nbnd; ++n) {
+    const int i = bnd[3 * n], j = bnd[3 * n + 1], k = bnd[3 * n + 2];
+    if (fabs(M(mask_u, i, j + 1, k)) < 1e-10) {
+      double empo = 0.25 * ((M(ekm, i, j, k) + M(ekm, i, j + 1, k)) + (M(ekm, i - 1, j, k) + M(ekm, i - 1, j + 1, k)));
+      M(up, i, j, k) = M(up, i, j, k) - empo * (M(u0, i, j + 1, k) - M(u0, i, j, k)) * m.dy2i;
+    }
+    if (fabs(M(mask_u, i, j - 1, k)) < 1e-10) {
+      double emmo = 0.25 * ((M(ekm, i, j, k) + M(ekm, i, j - 1, k)) + (M(ekm, i - 1, j - 1, k) + M(ekm, i - 1, j, k)));
+      M(up, i, j, k) = M(up, i, j, k) + emmo * (M(u0, i, j, k) - M(u0, i, j - 1, k)) * m.dy2i;
+    }
+    if (fabs(M(mask_u, i, j, k + 1)) < 1e-10) {
+      double emop = (dzf[k + 1] * (M(ekm, i, j, k) + M(ekm, i - 1, j, k)) + dzf[k] * (M(ekm, i, j, k + 1) + M(ekm, i - 1, j, k + 1))) * m.dzhiq[k + 1];
+      M(up, i, j, k) = M(up, i, j, k) - emop * (M(u0, i, j, k + 1) - M(u0, i, j, k)) * m.dzhi[k + 1] * m.dzfi[k];
+    }
+    if (fabs(M(mask_u, i, j, k - 1)) < 1e-10) {
+      double emom = (dzf[k - 1] * (M(ekm, i, j, k) + M(ekm, i - 1, j, k)) + dzf[k] * (M(ekm, i, j, k - 1) + M(ekm, i - 1, j, k - 1))) * m.dzhiq[k];
+      M(up, i, j, k) = M(up, i, j, k) + emom * (M(u0, i, j, k) - M(u0, i, j, k - 1)) * m.dzhi[k] * m.dzfi[k];
+    }
+  }
+  metrics_free(&m);
+}
+/* diffv_corr :1033-1072 */
+void orc_ibm_diffv_corr(const orc_grid *g, const int *bnd, int nbnd, const double *mask_v, const double *v0, const double *ekm, double *vp) {
+  metrics m; metrics_init(g, &m);
+  const double *dzf = g->dzf;
+  for (int n = 0; n < nbnd; ++n) {
+    const int i = bnd[3 * n], j = bnd[3 * n + 1], k = bnd[3 * n + 2];
+    if (fabs(M(mask_v, i + 1, j, k)) < 1e-10) {
+      double epmo = 0.25 * (M(ekm, i, j, k) + M(ekm, i, j - 1, k) + M(ekm, i + 1, j - 1, k) + M(ekm, i + 1, j, k));
+      M(vp, i, j, k) = M(vp, i, j, k) - epmo * (M(v0, i + 1, j, k) - M(v0, i, j, k)) * m.dx2i;
+    }
+    if (fabs(M(mask_v, i - 1, j, k)) < 1e-10) {
+      double emmo = 0.25 * (M(ekm, i, j, k) + M(ekm, i, j - 1, k) + M(ekm, i - 1, j - 1, k) + M(ekm, i - 1, j, k));
+      M(vp, i, j, k) = M(vp, i, j, k) + emmo * (M(v0, i, j, k) - M(v0, i - 1, j, k)) * m.dx2i;
+    }
+    if (fabs(M(mask_v, i, j, k + 1)) < 1e-10) {
+      double eomp = (dzf[k + 1] * (M(ekm, i, j, k) + M(ekm, i, j - 1, k)) + dzf[k] * (M(ekm, i, j, k + 1) + M(ekm, i, j - 1, k + 1))) * m.dzhiq[k + 1];
+      M(vp, i, j, k) = M(vp, i, j, k) - eomp * (M(v0, i, j, k + 1) - M(v0, i, j, k)) * m.dzhi[k + 1] * m.dzfi[k];
+    }
+    if (fabs(M(mask_v, i, j, k - 1)) < 1e-10) {
+      double eomm = (dzf[k - 1] * (M(ekm, i, j, k) + M(ekm, i, j - 1, k)) + dzf[k] * (M(ekm, i, j, k - 1) + M(ekm, i, j - 1, k - 1))) * m.dzhiq[k];
+      M(vp, i, j, k) = M(vp, i, j, k) + eomm * (M(v0, i, j, k) - M(v0, i, j, k - 1)) * m.dzhi[k] * m.dzfi[k];
+    }
+  }
+  metrics_free(&m);
+}
+/* diffw_corr :1075-1117 */
+void orc_ibm_diffw_corr(const orc_grid *g, const int *bnd, int nbnd, const double *mask_w, const double *w0, const double *ekm, double *wp) {
+  metrics m; metrics_init(g, &m);
+  const double *dzf = g->dzf;
+  for (int n = 0; n < nbnd; ++n) {
+    const int i = bnd[3 * n], j = bnd[3 * n + 1], k = bnd[3 * n + 2];
+    if (fabs(M(mask_w, i + 1, j, k)) < 1e-10) {
+      double epom = (dzf[k - 1] * (M(ekm, i, j, k) + M(ekm, i + 1, j, k)) + dzf[k] * (M(ekm, i, j, k - 1) + M(ekm, i + 1, j, k - 1))) * m.dzhiq[k];
+      M(wp, i, j, k) = M(wp, i, j, k) - epom * (M(w0, i + 1, j, k) - M(w0, i, j, k)) * m.dx2i;
+    }
+    if (fabs(M(mask_w, i - 1, j, k)) < 1e-10) {
+      double emom = (dzf[k - 1] * (M(ekm, i, j, k) + M(ekm, i - 1, j, k)) + dzf[k] * (M(ekm, i, j, k - 1) + M(ekm, i - 1, j, k - 1))) * m.dzhiq[k];
+      M(wp, i, j, k) = M(wp, i, j, k) + emom * (M(w0, i, j, k) - M(w0, i - 1, j, k)) * m.dx2i;
+    }
+    if (fabs(M(mask_w, i, j + 1, k)) < 1e-10) {
+      double eopm = (dzf[k - 1] * (M(ekm, i, j, k) + M(ekm, i, j + 1, k)) + dzf[k] * (M(ekm, i, j, k - 1) + M(ekm, i, j + 1, k - 1))) * m.dzhiq[k];
+      M(wp, i, j, k) = M(wp, i, j, k) - eopm * (M(w0, i, j + 1, k) - M(w0, i, j, k)) * m.dy2i;
+    }
+    if (fabs(M(mask_w, i, j - 1, k)) < 1e-10) {
+      double eomm = (dzf[k - 1] * (M(ekm, i, j, k) + M(ekm, i, j - 1, k)) + dzf[k] * (M(ekm, i, j, k - 1) + M(ekm, i, j - 1, k - 1))) * m.dzhiq[k];
+      M(wp, i, j, k) = M(wp, i, j, k) + eomm * (M(w0, i, j, k) - M(w0, i, j - 1, k)) * m.dy2i;
+    }
+  }
+  metrics_free(&m);
+}
+/* diffc_corr :1120-1164 for a kappa-advected scalar (c-arrays, as ibmwallfun passes sv0 / svp with the wide halo :1262-1264) */
+void orc_ibm_diffc_corr(const orc_grid *g, const int *bnd, int nbnd, const double *mask_c, const double *var, const double *ekh, double *rhs) {
+  metrics m; metrics_init(g, &m);
+  const double *dzf = g->dzf;
+  for (int n = 0; n < nbnd; ++n) {
+    const int i = bnd[3 * n], j = bnd[3 * n + 1], k = bnd[3 * n + 2];
+    if (fabs(M(mask_c, i + 1, j, k)) < 1e-10)
+      C(rhs, i, j, k) = C(rhs, i, j, k) - 0.5 * (M(ekh, i + 1, j, k) + M(ekh, i, j, k)) * (C(var, i + 1, j, k) - C(var, i, j, k)) * m.dx2i;
+    if (fabs(M(mask_c, i - 1, j, k)) < 1e-10)
+      C(rhs, i, j, k) = C(rhs, i, j, k) + 0.5 * (M(ekh, i, j, k) + M(ekh, i - 1, j, k)) * (C(var, i, j, k) - C(var, i - 1, j, k)) * m.dx2i;
+    if (fabs(M(mask_c, i, j + 1, k)) < 1e-10)
+      C(rhs, i, j, k) = C(rhs, i, j, k) - 0.5 * (M(ekh, i, j + 1, k) + M(ekh, i, j, k)) * (C(var, i, j + 1, k) - C(var, i, j, k)) * m.dy2i;
+    if (fabs(M(mask_c, i, j - 1, k)) < 1e-10)
+      C(rhs, i, j, k) = C(rhs, i, j, k) + 0.5 * (M(ekh, i, j, k) + M(ekh, i, j - 1, k)) * (C(var, i, j, k) - C(var, i, j - 1, k)) * m.dy2i;
+    if (fabs(M(mask_c, i, j, k + 1)) < 1e-10)
+      C(rhs, i, j, k) = C(rhs, i, j, k) - 0.5 * (dzf[k + 1] * M(ekh, i, j, k) + dzf[k] * M(ekh, i, j, k + 1))
+                                              * (C(var, i, j, k + 1) - C(var, i, j, k)) * m.dzh2i[k + 1] * m.dzfi[k];
+    if (fabs(M(mask_c, i, j, k - 1)) < 1e-10)
+      C(rhs, i, j, k) = C(rhs, i, j, k) + 0.5 * (dzf[k - 1] * M(ekh, i, j, k) + dzf[k] * M(ekh, i, j, k - 1))
+                                              * (C(var, i, j, k) - C(var, i, j, k - 1)) * m.dzh2i[k] * m.dzfi[k];
+  }
+  metrics_free(&m);
+}
+/* solid :748-826 without a mask, m-arrays (ibmnorm :706-708: um / up ... with val = 0) */
+void orc_ibm_solid_m(const orc_grid *g, const int *pts, int n, double *var, double *rhs, double val) {
+  for (int q = 0; q < n; ++q) {
+    const int i = pts[3 * q], j = pts[3 * q + 1], k = pts[3 * q + 2];
+    M(var, i, j, k) = val;
+    M(rhs, i, j, k) = 0.;
+  }
+}
+/* solid with the c mask on a c-array pair (ibmnorm :733-734: svm / svp): mean over the fluid neighbours */
+void orc_ibm_solid_c(const orc_grid *g, const int *pts, int n, const double *mask, double *var, double *rhs, double val) {
+  const int di[6] = {0, 0, 0, 0, 1, -1}, dj[6] = {1, -1, 0, 0, 0, 0}, dk[6] = {0, 0, 1, -1, 0, 0};      /* the reference's order */
+  for (int q = 0; q < n; ++q) {
+    const int i = pts[3 * q], j = pts[3 * q + 1], k = pts[3 * q + 2];
+    double count = 0.;
+    C(var, i, j, k) = val;
+    C(rhs, i, j, k) = 0.;
+    for (int b = 0; b < 6; ++b)
+      if (fabs(M(mask, i + di[b], j + dj[b], k + dk[b]) - 1.) < 1e-10) {
+        count = count + 1;
+        C(var, i, j, k) = C(var, i, j, k) + C(var, i + di[b], j + dj[b], k + dk[b]);
+        C(rhs, i, j, k) = C(rhs, i, j, k) + C(rhs, i + di[b], j + dj[b], k + dk[b]);
+      }
+    if (count > 0) {
+      C(var, i, j, k) = (C(var, i, j, k) - val) / count;
+      C(rhs, i, j, k) = C(rhs, i, j, k) / count;
+    }
+  }
+}
+/* what the substep does with an immersed boundary: ibmwallfun without facet wall functions (src/program.f90:166) and
+ * ibmnorm (:171).  Set with orc_set_ibm (NULL: none). */
+static const orc_ibm *ibm_ctx = NULL;
+void orc_set_ibm(const orc_ibm *b) { ibm_ctx = b; }
+void orc_ibmwallfun(const orc_grid *g, const orc_ibm *b, orc_state *s) {
+  const size_t nc = csize(g);
+  orc_ibm_diffu_corr(g, b->bnd[0], b->nbnd[0], b->mask[0], s->u0, s->ekm, s->up);
+  orc_ibm_diffv_corr(g, b->bnd[1], b->nbnd[1], b->mask[1], s->v0, s->ekm, s->vp);
+  orc_ibm_diffw_corr(g, b->bnd[2], b->nbnd[2], b->mask[2], s->w0, s->ekm, s->wp);
+  for (int n = 0; n < g->nsv; ++n) orc_ibm_diffc_corr(g, b->bnd[3], b->nbnd[3], b->mask[3], s->sv0 + n * nc, s->ekh, s->svp + n * nc);
+}
+void orc_ibmnorm(const orc_grid *g, const orc_ibm *b, orc_state *s) {
+  const size_t nc = csize(g);
+  orc_ibm_solid_m(g, b->sol[0], b->nsol[0], s->um, s->up, 0.);
+  orc_ibm_solid_m(g, b->sol[1], b->nsol[1], s->vm, s->vp, 0.);
+  orc_ibm_solid_m(g, b->sol[2], b->nsol[2], s->wm, s->wp, 0.);
+  for (int n = 0; n < g->nsv; ++n) orc_ibm_solid_c(g, b->sol[3], b->nsol[3], b->mask[3], s->svm + n * nc, s->svp + n * nc, 0.);
+}
+
 /* src/program.f90:132-222: advection, subgrid, forces, poisson, tstep_integrate, halos, boundary */
 void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
   const size_t nc = csize(g);
@@ -1557,7 +1715,9 @@ void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
     for (int k = 1; k <= g->nz; ++k)
       for (int j = 1; j <= g->ny; ++j)
         for (int i = 1; i <= g->nx; ++i) M(s->thlp, i, j, k) = M(s->thlp, i, j, k) + s->thlpcar[k];
+  if (ibm_ctx) orc_ibmwallfun(g, ibm_ctx, s);                                          /* src/program.f90:166 */
   orc_masscorr(g, rk3step, dt, s->up, s->um, s->vp, s->vm);                            /* src/program.f90:169 */
+  if (ibm_ctx) orc_ibmnorm(g, ibm_ctx, s);                                             /* src/program.f90:171 */
   if (s->svsrc)                                                                          /* scalsource, src/program.f90:181 */
     for (size_t q = 0; q < (size_t)g->nsv * nc; ++q) s->svp[q] = s->svp[q] + s->svsrc[q];
   orc_fillps(g, rk3coef, s->up, s->vp, s->wp, s->um, s->vm, s->wm, s->pup, s->pvp, s->pwp, s->p);

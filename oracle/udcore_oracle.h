@@ -89,6 +89,21 @@ void orc_advecc_kappa(const orc_grid *g, const double *u0, const double *v0, con
 /* ---- subgrid: src/modsubgrid.f90 + closurebc (src/modboundary.f90:434-505) */
 void orc_closure(const orc_grid *g, const double *u0, const double *v0, const double *w0,
                  double *ekm, double *ekh);
+/* immersed boundary (src/modibm.f90): per grid 0 u, 1 v, 2 w, 3 c the solid and fluid-boundary point lists ([n][3], 1-based
+ * i j k as in solid_*.txt / fluid_boundary_*.txt) and the mask (m-array, 1 fluid / 0 solid, orc_ibm_mask) */
+typedef struct {
+  const int *sol[4]; int nsol[4];
+  const int *bnd[4]; int nbnd[4];
+  const double *mask[4];
+} orc_ibm;
+void orc_ibm_mask(const orc_grid *g, int is_w, const int *solid, int nsolid, double *mask);
+void orc_ibm_diffu_corr(const orc_grid *g, const int *bnd, int nbnd, const double *mask_u, const double *u0, const double *ekm, double *up);
+void orc_ibm_diffv_corr(const orc_grid *g, const int *bnd, int nbnd, const double *mask_v, const double *v0, const double *ekm, double *vp);
+void orc_ibm_diffw_corr(const orc_grid *g, const int *bnd, int nbnd, const double *mask_w, const double *w0, const double *ekm, double *wp);
+void orc_ibm_diffc_corr(const orc_grid *g, const int *bnd, int nbnd, const double *mask_c, const double *var, const double *ekh, double *rhs);
+void orc_ibm_solid_m(const orc_grid *g, const int *pts, int n, double *var, double *rhs, double val);
+void orc_ibm_solid_c(const orc_grid *g, const int *pts, int n, const double *mask, double *var, double *rhs, double val);
+void orc_set_ibm(const orc_ibm *b);      /* orc_substep then runs ibmwallfun / ibmnorm (src/program.f90:166, 171) */
 void orc_set_closure_thl(const double *thl0);   /* thl0 for the Vreman buoyancy correction inside orc_closure */
 void orc_closurebc(const orc_grid *g, double *ekm, double *ekh);
 void orc_diffu(const orc_grid *g, const double *u0, const double *v0, const double *w0,

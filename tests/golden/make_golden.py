@@ -29,7 +29,8 @@ REF = os.path.join(ROOT, "oracle", "_ref", "udales_ref")
 
 
 def deck(iexpnr, nx, ny, nz, dx=0.5, dy=0.5, dtmax=0.25, sgs="vreman", nsv=0, bctopm=1,
-         oracle="", lles=True, randu=0.01, floor=False, z0=0.05, physics="", bc="", bcbotm=3, scalars="", dynamics="", inlet="", ladaptive=False, chemistry=""):
+         oracle="", lles=True, randu=0.01, floor=False, z0=0.05, physics="", bc="", bcbotm=3, scalars="", dynamics="", inlet="", ladaptive=False, chemistry="",
+         ibm=None):
     sub = {"oneeqn": "loneeqn = .true.\nlvreman = .false.\nlsmagorinsky = .false.",
            "vreman": "lvreman = .true.\nlsmagorinsky = .false.",
            "vreman_bc": "lvreman = .true.\nlsmagorinsky = .false.\nlbuoycorr = .true.",
@@ -44,7 +45,7 @@ irandom = 43
 randu = {randu}
 nprocx = 1
 nprocy = 1
-libm = .false.
+libm = {'.true.' if ibm else '.false.'}
 lles = {'.true.' if lles else '.false.'}
 /
 &DOMAIN
@@ -65,7 +66,7 @@ BCtopm = {bctopm}
 {('BCbotm = ' + str(bcbotm) + chr(10) + 'z0 = ' + repr(z0)) if floor else ''}
 {bc}
 /
-{('&WALLS' + chr(10) + 'nfcts = 0' + chr(10) + 'lbottom = .true.' + chr(10) + '/') if floor else ''}
+{('&WALLS' + chr(10) + 'nfcts = 0' + chr(10) + ('lbottom = .true.' + chr(10) if floor else '') + (ibm_walls(ibm, nx, ny, nz) if ibm else '') + '/') if (floor or ibm) else ''}
 &SCALARS
 nsv = {nsv}{(chr(10) + scalars) if scalars else ''}
 /
@@ -76,6 +77,46 @@ nsv = {nsv}{(chr(10) + scalars) if scalars else ''}
 {oracle}
 /
 """
+
+
+def ibm_lists(blocks, nx, ny, nz):
+    """Point lists of the reference's IBM input files for axis-aligned blocks [(i0, i1, j0, j1, k1), ...] of solid cells
+    (1-based, inclusive; blocks stand on the floor).  A u point is solid when the face between cells i-1 and i touches a
+    solid cell (likewise v, w); fluid-boundary points are the fluid points with a solid point of their own grid among
+    their six neighbours (x, y periodic).  Rows in k, j, i order."""
+    import numpy as np
+    c = np.zeros((nz + 2, ny, nx), dtype=bool)
+    for (i0, i1, j0, j1, k1) in blocks:
+        c[1:k1 + 1, j0 - 1:j1, i0 - 1:i1] = True
+    u = c | np.roll(c, 1, axis=2)
+    v = c | np.roll(c, 1, axis=1)
+    w = c.copy(); w[1:] |= c[:-1]
+    out = {}
+    for name, sol in (("u", u), ("v", v), ("w", w), ("c", c)):
+        nb = np.zeros_like(sol)
+        for ax, sh in ((2, 1), (2, -1), (1, 1), (1, -1)):
+            nb |= np.roll(sol, sh, axis=ax)
+        nb[1:] |= sol[:-1]; nb[:-1] |= sol[1:]
+        bnd = nb & ~sol
+        lo = 2 if name == "w" else 1
+        pts = lambda m: [(i + 1, j + 1, k) for k in range(lo, nz + 1) for j in range(ny) for i in range(nx) if m[k, j, i]]   # noqa: E731
+        out[name] = (pts(sol) if name != "w" else [(i + 1, j + 1, k) for k in range(1, nz + 1) for j in range(ny) for i in range(nx) if sol[k, j, i]],
+                     pts(bnd))
+    return out
+
+
+def ibm_walls(blocks, nx, ny, nz):
+    L = ibm_lists(blocks, nx, ny, nz)
+    return "iwallmom = 1\n" + "".join(f"nsolpts_{g} = {len(L[g][0])}\nnbndpts_{g} = {len(L[g][1])}\n" for g in "uvwc")
+
+
+def write_ibm_files(d, blocks, nx, ny, nz):
+    for g, (sol, bnd) in ibm_lists(blocks, nx, ny, nz).items():
+        for fn, pts in ((f"solid_{g}.txt", sol), (f"fluid_boundary_{g}.txt", bnd)):
+            with open(os.path.join(d, fn), "w") as f:
+                f.write("# position (i,j,k)\n")
+                for p in pts:
+                    f.write("%5d %5d %5d\n" % p)
 
 
 def zlevels(nz, dz0=0.5, stretch=1.0):
@@ -121,6 +162,7 @@ KEEP_KERNELS = ("meta dzf dzh zf dpdxl dpdyl rk3 in.u0 in.v0 in.w0 in.um in.vm i
                 "in.e120 in.e12m adv.e12p sub.e12p pre.e12p out.e120 out.e12m "
                 "frc0.up frc0.vp frc0.wp frc0.thlp lsf.up lsf.vp lsf.wp lsf.thlp u0av thl0av frc0.qtp lsf.qtp qt0av "
                 "src0.up fix0.up fix0.vp "
+                "ibw0.up ibw0.vp ibw0.wp ibw.up ibw.vp ibw.wp ibn0.up ibn0.vp ibn0.wp ibn.up ibn.vp ibn.wp ibn.um ibn.vm ibn.wm "
                 "pre.up pre.vp pre.wp poi.p poi.pres0 poi.up poi.vp poi.wp out.u0 out.v0 out.w0 "
                 "out.um out.pres0").split()
 
@@ -319,6 +361,15 @@ CASES.update({
                                           bc="BCtopT = 2\nthl_top = 288.03\nBCbotT = 1\nwtsurf = -0.002\nthls = 288.0",
                                           oracle="nsub = 9\ndump_at = 3, 9"), 1.06),
 })
+IBM_BLOCKS = {"k_ibm_16x12x10": [(5, 8, 4, 7, 4), (11, 13, 8, 10, 2)], "run_ibm_16x12x10": [(5, 8, 4, 7, 4), (11, 13, 8, 10, 2)]}
+CASES.update({
+    # immersed boundary, sparse corrections (libm, iwallmom = 1: no facet wall functions): two blocks on the floor, one
+    # kappa-advected scalar.  Per-routine dumps around ibmwallfun (diff*_corr) and ibmnorm (solid), and a 9-substep run.
+    "k_ibm_16x12x10": ("kernels", 54, 16, 12, 10, dict(sgs="smag", nsv=1, floor=True, randu=0.05, ibm=IBM_BLOCKS["k_ibm_16x12x10"],
+                                                       oracle="nspin = 4"), 1.04),
+    "run_ibm_16x12x10": ("run", 55, 16, 12, 10, dict(sgs="vreman", nsv=1, floor=True, randu=0.05, ibm=IBM_BLOCKS["run_ibm_16x12x10"],
+                                                     oracle="nsub = 9\ndump_at = 3, 9"), 1.04),
+})
 LSF_ONLY = ("k_lsf_12x8x24", "k_lsfq_12x8x20", "k_fix1_12x8x6")
 THL_CASES = {"k_tke_moist_12x8x8": dict(dthl=0.25, qt=0.0118, dqt=-8e-5, tke=0.06),
              "run_moistnr_16x8x12s": dict(dthl=0.25, qt=0.0119, dqt=-6e-5),
@@ -390,6 +441,8 @@ def main():
         cdir = os.path.join(HERE, "cases", name)
         os.makedirs(cdir, exist_ok=True)
         write_case(cdir, iexp, deck(iexp, nx, ny, nz, **kw), zlevels(nz, 0.5, stretch), **THL_CASES.get(name, {}))
+        if name in IBM_BLOCKS:
+            write_ibm_files(cdir, IBM_BLOCKS[name], nx, ny, nz)
         with tempfile.TemporaryDirectory() as tmp:
             for fn in os.listdir(cdir):
                 shutil.copy(os.path.join(cdir, fn), tmp)

@@ -41,6 +41,11 @@ class OrcGrid(C.Structure):
                 ("lbuoycorr", C.c_int), ("Rigc", C.c_double)]
 
 
+class OrcIbm(C.Structure):
+    _fields_ = [("sol", C.POINTER(C.c_int) * 4), ("nsol", C.c_int * 4), ("bnd", C.POINTER(C.c_int) * 4), ("nbnd", C.c_int * 4),
+                ("mask", DP * 4)]
+
+
 class OrcState(C.Structure):
     _fields_ = [(n, DP) for n in ("u0", "v0", "w0", "um", "vm", "wm", "up", "vp", "wp", "pres0",
                                   "ekm", "ekh", "p", "pup", "pvp", "pwp", "sv0", "svm", "svp",
@@ -143,6 +148,30 @@ class Oracle:
         f.restype = None
         s = self.state(st)
         f(C.byref(self.g), C.byref(s))
+
+    # ---- immersed boundary: lists = {grid letter: (solid[n,3], boundary[n,3])} as udcore.ibm.read_ibm returns them
+    def set_ibm(self, lists):
+        """Build the masks (orc_ibm_mask) and make orc_substep run ibmwallfun / ibmnorm; None switches it off."""
+        if lists is None:
+            self.L.orc_set_ibm(None)
+            self._ibm = None
+            return None
+        ip = C.POINTER(C.c_int)
+        keep, b = [], OrcIbm()
+        for q, gname in enumerate("uvwc"):
+            sol, bnd = lists.get(gname, (np.zeros((0, 3), np.int32), np.zeros((0, 3), np.int32)))
+            sol, bnd = np.ascontiguousarray(sol, dtype=np.int32), np.ascontiguousarray(bnd, dtype=np.int32)
+            mask = np.zeros(self.mshape())
+            f = self.L.orc_ibm_mask
+            f.restype = None
+            f(C.byref(self.g), C.c_int(1 if gname == "w" else 0), sol.ctypes.data_as(ip), C.c_int(len(sol)), ptr(mask))
+            keep += [sol, bnd, mask]
+            b.sol[q], b.nsol[q] = sol.ctypes.data_as(ip), len(sol)
+            b.bnd[q], b.nbnd[q] = bnd.ctypes.data_as(ip), len(bnd)
+            b.mask[q] = ptr(mask)
+        self._ibm = (b, keep)
+        self.L.orc_set_ibm(C.byref(b))
+        return {g: keep[3 * q + 2] for q, g in enumerate("uvwc")}
 
     def substep(self, st: dict, rk3step: int, dt: float):
         s = self.state(st)

@@ -209,8 +209,8 @@ def test_substeps_match_reference(name, iexp, fused):
             core.substep(rk, dt, with_forces=True)
         else:
             core.tstep_update(dt)
-            core.advection(); core.subgrid(); core.bottom(); core.coriolis(); core.forces(); core.masscorr()
-            core.scalsource(); core.poisson()
+            core.advection(); core.subgrid(); core.bottom(); core.coriolis(); core.forces(); core.ibmwallfun(); core.masscorr()
+            core.ibmnorm(); core.scalsource(); core.poisson()
             core.tstep_integrate(); core.halos(); core.boundary()
             if core.moist_thermo:
                 core.thermodynamics()

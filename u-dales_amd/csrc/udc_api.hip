@@ -219,6 +219,7 @@ extern "C" int udc_destroy(udc_handle *h) {
   for (hipEvent_t e : h->prof_pool) hipEventDestroy(e);
   pois_destroy(h);
   comm_destroy(h);
+  ibm_destroy(h);
   for (int q = 0; q < 4; ++q) if (h->halo_buf[q]) hipFree(h->halo_buf[q]);
   for (auto &f : h->level_forcings) { if (f.A) hipFree(f.A); if (f.stage) hipHostFree(f.stage); if (f.copied) hipEventDestroy(f.copied); }
   for (double *p : h->fields) if (p) hipFree(p);
@@ -692,6 +693,17 @@ static int now_masscorr(udc_handle *h, int rk3step, double dt) {
   return k_masscorr(h, dt / (4. - (double)rk3step), false, false);
 }
 
+static int now_ibmwallfun(udc_handle *h) {
+  if (!h->ibm_on) return 0;
+  if (tend_clean(h) || um_materialise(h)) return 1;
+  return k_ibm_wallfun(h);
+}
+static int now_ibmnorm(udc_handle *h) {
+  if (!h->ibm_on) return 0;
+  if (tend_clean(h) || um_materialise(h)) return 1;
+  return k_ibm_norm(h);
+}
+
 static int now_forces(udc_handle *h) {
   if (tend_clean(h) || um_materialise(h)) return 1;
   if (h->thlpcar && k_level_source(h, 15, h->thlpcar)) return 1;      // thlp += thlpcar(k), src/modforces.f90:104-110
@@ -768,8 +780,8 @@ extern "C" int udc_divergence(udc_handle *h, double *divmax, double *divtot) {
 // The tendency routines of one RK3 substep, as bits (in the reference's call order, src/program.f90:142-193)
 enum : unsigned {
   OP_ADV = 1u << 0, OP_SHIFT = 1u << 1, OP_SUBGRID = 1u << 2, OP_BOTTOM = 1u << 3, OP_CORIOLIS = 1u << 4,
-  OP_FORCES = 1u << 5, OP_LEV0 = 1u << 6, OP_MASSCORR = 1u << 7, OP_SCALSRC = 1u << 8, OP_LEV1 = 1u << 9,
-  OP_POISSON = 1u << 10
+  OP_FORCES = 1u << 5, OP_LEV0 = 1u << 6, OP_IBMWALL = 1u << 7, OP_MASSCORR = 1u << 8, OP_IBMNORM = 1u << 9,
+  OP_SCALSRC = 1u << 10, OP_LEV1 = 1u << 11, OP_POISSON = 1u << 12
 };
 
 // advection, subgrid, poisson, tstep_integrate, halos, boundary, thermodynamics and the routines of `ops`, with kernels
@@ -785,7 +797,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   const bool fold = lds && !h->slab && !h->no_fold;
   // um aliasing: stage 3 leaves um,vm,wm unwritten (== u0,v0,w0); stage 1 reads u0 in their place and
   // writes the new u0,v0,w0 into the stale um buffers, then swaps the buffer pointers.
-  const bool alias_ok = pup && !h->no_alias;
+  const bool alias_ok = pup && !h->no_alias && !h->ibm_on;      // (ibmnorm edits um)
   if (h->um_alias && !(alias_ok && rk3step == 1)) { if (um_materialise(h)) return 1; }
   const bool rotate = h->um_alias;                    // only true here for an aliased stage 1
   h->halos_fresh = h->boundary_fresh = h->thermo_fresh = false;
@@ -813,8 +825,10 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   if ((ops & OP_CORIOLIS) && k_coriolis(h, fold)) return 1;        // src/program.f90:158; wrap of vp's ghost row follows below
   if ((ops & OP_SHIFT) && k_shifted_pbcs(h, fold)) return 1;       // src/program.f90:144 (additive on the momentum tendencies)
   if ((ops & OP_LEV0) && !h->level_forcings.empty() && k_level_forcings(h, 0, fold)) return 1;   // lstend, nudge tables
+  if ((ops & OP_IBMWALL) && k_ibm_wallfun(h)) return 1;                                      // src/program.f90:166
   // masscorr (src/program.f90:169); without pup the tendencies and um are summed separately
   if ((ops & OP_MASSCORR) && k_masscorr(h, rk3coef, pup, fold)) return 1;
+  if ((ops & OP_IBMNORM) && k_ibm_norm(h)) return 1;                                         // src/program.f90:171
   if ((ops & OP_SCALSRC) && k_scalsource(h)) return 1;                                       // src/program.f90:181
   if ((ops & OP_LEV1) && !h->level_forcings.empty() && k_level_forcings(h, 1, fold)) return 1;   // fixuinf1, grwdamp tables
   if (!fold) {
@@ -864,6 +878,8 @@ static int run_op(udc_handle *h, unsigned op) {
     case OP_CORIOLIS: return now_coriolis(h);
     case OP_FORCES: return now_forces(h);
     case OP_LEV0: return now_level_forcings(h, 0);
+    case OP_IBMWALL: return now_ibmwallfun(h);
+    case OP_IBMNORM: return now_ibmnorm(h);
     case OP_MASSCORR: return now_masscorr(h, h->pend_rk, h->pend_dt);
     case OP_SCALSRC: return now_scalsource(h);
     case OP_LEV1: return now_level_forcings(h, 1);
@@ -923,6 +939,8 @@ extern "C" int udc_masscorr(udc_handle *h, int rk3step, double dt) {
   if (rk3step < 1 || rk3step > 3) { udc_set_error("udc_masscorr: rk3step %d", rk3step); return 1; }
   return h->deferred ? defer(h, OP_MASSCORR, rk3step, dt) : now_masscorr(h, rk3step, dt);
 }
+extern "C" int udc_ibmwallfun(udc_handle *h) { ENTRY(h); return h->deferred ? defer(h, OP_IBMWALL) : now_ibmwallfun(h); }
+extern "C" int udc_ibmnorm(udc_handle *h) { ENTRY(h); return h->deferred ? defer(h, OP_IBMNORM) : now_ibmnorm(h); }
 extern "C" int udc_scalsource(udc_handle *h) { ENTRY(h); return h->deferred ? defer(h, OP_SCALSRC) : now_scalsource(h); }
 extern "C" int udc_poisson(udc_handle *h, int rk3step, double dt) {
   ENTRY(h);
@@ -958,7 +976,7 @@ extern "C" int udc_tstep_integrate(udc_handle *h, int rk3step, double dt) {
 
 extern "C" int udc_substep(udc_handle *h, int rk3step, double dt, int with_forces) {
   ENTRY_FLUSH(h);
-  unsigned ops = OP_ADV | OP_SHIFT | OP_SUBGRID | OP_BOTTOM | OP_MASSCORR | OP_SCALSRC | OP_POISSON;
+  unsigned ops = OP_ADV | OP_SHIFT | OP_SUBGRID | OP_BOTTOM | OP_IBMWALL | OP_MASSCORR | OP_IBMNORM | OP_SCALSRC | OP_POISSON;
   if (with_forces) ops |= OP_CORIOLIS | OP_FORCES | OP_LEV0 | OP_LEV1;
   return substep_fused(h, rk3step, dt, ops);
 }

@@ -1,0 +1,304 @@
+// Immersed boundary, sparse corrections (src/modibm.f90): the solid / fluid-boundary point lists of the u, v, w and c
+// grids (solid_*.txt, fluid_boundary_*.txt), the masks initibm derives from them (:150-186), and
+//   ibmwallfun without facet wall functions (:1216-1218, 1262-1264): diffu_corr (:990-1030), diffv_corr (:1033-1072),
+//       diffw_corr (:1075-1117), diffc_corr (:1120-1164) -- the subgrid fluxes through solid faces are taken back out
+//   ibmnorm (:697-745): solid (:748-826) -- velocities and tendencies zeroed inside the solid, scalars set to the mean of
+//       their fluid neighbours (zero-flux condition)
+// One thread per listed point.  The masks are only ever read at the listed points, so commit() evaluates them on the
+// host into a few flag bits per point and the device never holds a mask array.
+#include "udc_internal.h"
+#include <cstring>
+
+namespace {
+
+// flags of a fluid-boundary point: which neighbours (of the same grid) are solid
+//   u grid: 0 j+1, 1 j-1, 2 k+1, 3 k-1      v grid: 0 i+1, 1 i-1, 2 k+1, 3 k-1      w grid: 0 i+1, 1 i-1, 2 j+1, 3 j-1
+//   c grid: 0 i+1, 1 i-1, 2 j+1, 3 j-1, 4 k+1, 5 k-1
+// flags of a solid c point: which neighbours are fluid, in the reference's summation order 0 j+1, 1 j-1, 2 k+1, 3 k-1, 4 i+1, 5 i-1
+__device__ __forceinline__ int wrapx(int i, int nx) { return i < 0 ? i + nx : (i >= nx ? i - nx : i); }
+
+__global__ void ibm_diffu_corr_kernel(Geo g, Metrics m, int n, const int *__restrict__ pt, const unsigned char *__restrict__ fl,
+                                      const double *__restrict__ u0, const double *__restrict__ ekm, double *__restrict__ up) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const int i = pt[3 * q], j = pt[3 * q + 1], k = pt[3 * q + 2], kf = k + 1;
+  const int im = wrapx(i - 1, g.nx);
+  const long c = g.idx(i, j, k), cm = g.idx(im, j, k), sy = g.sy, sz = g.sz;
+  const unsigned f = fl[q];
+  double t = up[c];
+  if (f & 1u) {
+    const double empo = 0.25 * ((ekm[c] + ekm[c + sy]) + (ekm[cm] + ekm[cm + sy]));
+    t = t - empo * (u0[c + sy] - u0[c]) * m.dy2i;
+  }
+  if (f & 2u) {
+    const double emmo = 0.25 * ((ekm[c] + ekm[c - sy]) + (ekm[cm - sy] + ekm[cm]));
+    t = t + emmo * (u0[c] - u0[c - sy]) * m.dy2i;
+  }
+  if (f & 4u) {
+    const double emop = (m.dzf[kf + 1] * (ekm[c] + ekm[cm]) + m.dzf[kf] * (ekm[c + sz] + ekm[cm + sz])) * m.dzhiq[kf + 1];
+    t = t - emop * (u0[c + sz] - u0[c]) * m.dzhi[kf + 1] * m.dzfi[kf];
+  }
+  if (f & 8u) {
+    const double emom = (m.dzf[kf - 1] * (ekm[c] + ekm[cm]) + m.dzf[kf] * (ekm[c - sz] + ekm[cm - sz])) * m.dzhiq[kf];
+    t = t + emom * (u0[c] - u0[c - sz]) * m.dzhi[kf] * m.dzfi[kf];
+  }
+  up[c] = t;
+}
+
+__global__ void ibm_diffv_corr_kernel(Geo g, Metrics m, int n, const int *__restrict__ pt, const unsigned char *__restrict__ fl,
+                                      const double *__restrict__ v0, const double *__restrict__ ekm, double *__restrict__ vp) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const int i = pt[3 * q], j = pt[3 * q + 1], k = pt[3 * q + 2], kf = k + 1;
+  const long c = g.idx(i, j, k), cp = g.idx(wrapx(i + 1, g.nx), j, k), cm = g.idx(wrapx(i - 1, g.nx), j, k), sy = g.sy, sz = g.sz;
+  const unsigned f = fl[q];
+  double t = vp[c];
+  if (f & 1u) {
+    const double epmo = 0.25 * (ekm[c] + ekm[c - sy] + ekm[cp - sy] + ekm[cp]);
+    t = t - epmo * (v0[cp] - v0[c]) * m.dx2i;
+  }
+  if (f & 2u) {
+    const double emmo = 0.25 * (ekm[c] + ekm[c - sy] + ekm[cm - sy] + ekm[cm]);
+    t = t + emmo * (v0[c] - v0[cm]) * m.dx2i;
+  }
+  if (f & 4u) {
+    const double eomp = (m.dzf[kf + 1] * (ekm[c] + ekm[c - sy]) + m.dzf[kf] * (ekm[c + sz] + ekm[c - sy + sz])) * m.dzhiq[kf + 1];
+    t = t - eomp * (v0[c + sz] - v0[c]) * m.dzhi[kf + 1] * m.dzfi[kf];
+  }
+  if (f & 8u) {
+    const double eomm = (m.dzf[kf - 1] * (ekm[c] + ekm[c - sy]) + m.dzf[kf] * (ekm[c - sz] + ekm[c - sy - sz])) * m.dzhiq[kf];
+    t = t + eomm * (v0[c] - v0[c - sz]) * m.dzhi[kf] * m.dzfi[kf];
+  }
+  vp[c] = t;
+}
+
+__global__ void ibm_diffw_corr_kernel(Geo g, Metrics m, int n, const int *__restrict__ pt, const unsigned char *__restrict__ fl,
+                                      const double *__restrict__ w0, const double *__restrict__ ekm, double *__restrict__ wp) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const int i = pt[3 * q], j = pt[3 * q + 1], k = pt[3 * q + 2], kf = k + 1;
+  const long c = g.idx(i, j, k), cp = g.idx(wrapx(i + 1, g.nx), j, k), cm = g.idx(wrapx(i - 1, g.nx), j, k), sy = g.sy, sz = g.sz;
+  const unsigned f = fl[q];
+  const double dzf_m = m.dzf[kf - 1], dzf_k = m.dzf[kf], q4 = m.dzhiq[kf];
+  double t = wp[c];
+  if (f & 1u) {
+    const double epom = (dzf_m * (ekm[c] + ekm[cp]) + dzf_k * (ekm[c - sz] + ekm[cp - sz])) * q4;
+    t = t - epom * (w0[cp] - w0[c]) * m.dx2i;
+  }
+  if (f & 2u) {
+    const double emom = (dzf_m * (ekm[c] + ekm[cm]) + dzf_k * (ekm[c - sz] + ekm[cm - sz])) * q4;
+    t = t + emom * (w0[c] - w0[cm]) * m.dx2i;
+  }
+  if (f & 4u) {
+    const double eopm = (dzf_m * (ekm[c] + ekm[c + sy]) + dzf_k * (ekm[c - sz] + ekm[c + sy - sz])) * q4;
+    t = t - eopm * (w0[c + sy] - w0[c]) * m.dy2i;
+  }
+  if (f & 8u) {
+    const double eomm = (dzf_m * (ekm[c] + ekm[c - sy]) + dzf_k * (ekm[c - sz] + ekm[c - sy - sz])) * q4;
+    t = t + eomm * (w0[c] - w0[c - sy]) * m.dy2i;
+  }
+  wp[c] = t;
+}
+
+__global__ void ibm_diffc_corr_kernel(Geo g, Metrics m, int n, const int *__restrict__ pt, const unsigned char *__restrict__ fl,
+                                      const double *__restrict__ var, const double *__restrict__ ekh, double *__restrict__ rhs) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const int i = pt[3 * q], j = pt[3 * q + 1], k = pt[3 * q + 2], kf = k + 1;
+  const long c = g.idx(i, j, k), cp = g.idx(wrapx(i + 1, g.nx), j, k), cm = g.idx(wrapx(i - 1, g.nx), j, k), sy = g.sy, sz = g.sz;
+  const unsigned f = fl[q];
+  double t = rhs[c];
+  if (f & 1u) t = t - 0.5 * (ekh[cp] + ekh[c]) * (var[cp] - var[c]) * m.dx2i;
+  if (f & 2u) t = t + 0.5 * (ekh[c] + ekh[cm]) * (var[c] - var[cm]) * m.dx2i;
+  if (f & 4u) t = t - 0.5 * (ekh[c + sy] + ekh[c]) * (var[c + sy] - var[c]) * m.dy2i;
+  if (f & 8u) t = t + 0.5 * (ekh[c] + ekh[c - sy]) * (var[c] - var[c - sy]) * m.dy2i;
+  if (f & 16u) t = t - 0.5 * (m.dzf[kf + 1] * ekh[c] + m.dzf[kf] * ekh[c + sz]) * (var[c + sz] - var[c]) * m.dzh2i[kf + 1] * m.dzfi[kf];
+  if (f & 32u) t = t + 0.5 * (m.dzf[kf - 1] * ekh[c] + m.dzf[kf] * ekh[c - sz]) * (var[c] - var[c - sz]) * m.dzh2i[kf] * m.dzfi[kf];
+  rhs[c] = t;
+}
+
+// solid without a mask: var = 0, rhs = 0 at the listed points (velocities)
+__global__ void ibm_solid_zero_kernel(Geo g, int n, const int *__restrict__ pt, double *__restrict__ var, double *__restrict__ rhs) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const long c = g.idx(pt[3 * q], pt[3 * q + 1], pt[3 * q + 2]);
+  var[c] = 0.;
+  rhs[c] = 0.;
+}
+
+// solid with the c mask: value and tendency become the mean over the fluid neighbours (or val / 0 without any)
+__global__ void ibm_solid_mean_kernel(Geo g, int n, const int *__restrict__ pt, const unsigned char *__restrict__ fl, double val,
+                                      double *__restrict__ var, double *__restrict__ rhs) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const int i = pt[3 * q], j = pt[3 * q + 1], k = pt[3 * q + 2];
+  const long c = g.idx(i, j, k), sy = g.sy, sz = g.sz;
+  const long nb[6] = {c + sy, c - sy, c + sz, c - sz, g.idx(wrapx(i + 1, g.nx), j, k), g.idx(wrapx(i - 1, g.nx), j, k)};
+  const unsigned f = fl[q];
+  double v = val, r = 0., count = 0.;
+#pragma unroll
+  for (int b = 0; b < 6; ++b)
+    if (f & (1u << b)) { count += 1.; v = v + var[nb[b]]; r = r + rhs[nb[b]]; }
+  if (count > 0.) { v = (v - val) / count; r = r / count; }
+  var[c] = v;
+  rhs[c] = r;
+}
+
+inline unsigned blocks(int n) { return (unsigned)((n + 127) / 128); }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ host side
+extern "C" int udc_set_ibm_points(udc_handle *h, int grid, const int *solid, int nsolid, const int *bound, int nbound) {
+  if (!h) { udc_set_error("null handle"); return 1; }
+  if (grid < 0 || grid > 3) { udc_set_error("udc_set_ibm_points: grid 0 (u), 1 (v), 2 (w) or 3 (c)"); return 1; }
+  if (nsolid < 0 || nbound < 0 || (nsolid && !solid) || (nbound && !bound)) { udc_set_error("udc_set_ibm_points: bad list"); return 1; }
+  const int ext[3] = {h->g.nx, h->jtot, h->g.nz};
+  for (int pass = 0; pass < 2; ++pass) {
+    const int *p = pass ? bound : solid;
+    const int n = pass ? nbound : nsolid;
+    for (int q = 0; q < n; ++q)
+      for (int d = 0; d < 3; ++d)
+        if (p[3 * q + d] < 1 || p[3 * q + d] > ext[d]) {
+          udc_set_error("udc_set_ibm_points: %s point %d of grid %d outside the domain (%d %d %d)", pass ? "boundary" : "solid", q + 1,
+                        grid, p[3 * q], p[3 * q + 1], p[3 * q + 2]);
+          return 1;
+        }
+  }
+  udc_handle::IbmGrid &G = h->ibm[grid];
+  G.solid_g.assign(solid, solid + (size_t)3 * nsolid);
+  G.bound_g.assign(bound, bound + (size_t)3 * nbound);
+  G.given = true;
+  h->ibm_on = false;      // until udc_ibm_commit
+  return 0;
+}
+
+static int upload_points(udc_handle *h, const std::vector<int> &pts, const std::vector<unsigned char> &fl, int **dpt, unsigned char **dfl) {
+  if (*dpt) { HIP_OK(hipFree(*dpt)); *dpt = nullptr; }
+  if (*dfl) { HIP_OK(hipFree(*dfl)); *dfl = nullptr; }
+  if (pts.empty()) return 0;
+  HIP_OK(hipMalloc(dpt, sizeof(int) * pts.size()));
+  HIP_OK(hipMemcpy(*dpt, pts.data(), sizeof(int) * pts.size(), hipMemcpyHostToDevice));
+  HIP_OK(hipMalloc(dfl, fl.size()));
+  HIP_OK(hipMemcpy(*dfl, fl.data(), fl.size(), hipMemcpyHostToDevice));
+  (void)h;
+  return 0;
+}
+
+extern "C" int udc_ibm_commit(udc_handle *h) {
+  if (!h) { udc_set_error("null handle"); return 1; }
+  HIP_OK(hipSetDevice(h->device));
+  if (udc_flush_pending(h)) return 1;
+  for (int gq = 0; gq < 3; ++gq)
+    if (!h->ibm[gq].given) { udc_set_error("udc_ibm_commit: the u, v and w point lists are needed (udc_set_ibm_points)"); return 1; }
+  const bool have_c = h->ibm[3].given;
+  if (!h->slots.empty() && !have_c) { udc_set_error("udc_ibm_commit: transported scalars need the c point lists"); return 1; }
+  for (int n : h->slots)
+    if (n >= 13) { udc_set_error("udc_ibm_commit: thl, qt and e12 with immersed boundaries need the facet wall functions (wallfunheat), which this build does not have"); return 1; }
+  const int nx = h->g.nx, ny = h->jtot, nz = h->g.nz, j0 = h->cfg.rank * h->g.ny, nyl = h->g.ny;
+  // masks as initibm builds them (src/modibm.f90:150-186): 1 = fluid; planes k = 0 (kb-1) .. nz+1; lateral neighbours
+  // wrap periodically (what exchange_halo_z gives the reference on more than one rank)
+  const size_t plane = (size_t)nx * ny, msz = plane * (nz + 2);
+  std::vector<std::vector<unsigned char>> mask(4);
+  for (int gq = 0; gq < 4; ++gq) {
+    if (gq == 3 && !have_c) break;
+    mask[gq].assign(msz, 1);
+    std::memset(mask[gq].data(), 0, plane);                                  // k = kb-1
+    if (gq == 2) std::memset(mask[gq].data() + plane, 0, plane);             // mask_w(:,:,kb) = 0
+    const std::vector<int> &s = h->ibm[gq].solid_g;
+    for (size_t q = 0; q < s.size() / 3; ++q)
+      mask[gq][(size_t)(s[3 * q] - 1) + (size_t)nx * (s[3 * q + 1] - 1) + plane * s[3 * q + 2]] = 0;
+  }
+  auto at = [&](int gq, int i, int j, int k) -> unsigned char {      // 1-based i, j with wrap; k = 0..nz+1
+    i = (i - 1 + nx) % nx; j = (j - 1 + ny) % ny;
+    return mask[gq][(size_t)i + (size_t)nx * j + plane * k];
+  };
+  for (int gq = 0; gq < 4; ++gq) {
+    udc_handle::IbmGrid &G = h->ibm[gq];
+    if (gq == 3 && !have_c) { G.nsolid = G.nbound = 0; continue; }
+    std::vector<int> sp, bp;
+    std::vector<unsigned char> sf, bf;
+    for (size_t q = 0; q < G.solid_g.size() / 3; ++q) {
+      const int i = G.solid_g[3 * q], j = G.solid_g[3 * q + 1], k = G.solid_g[3 * q + 2];
+      if (j <= j0 || j > j0 + nyl) continue;
+      sp.push_back(i - 1); sp.push_back(j - 1 - j0); sp.push_back(k - 1);
+      unsigned f = 0;
+      if (gq == 3) {
+        const int ni[6] = {i, i, i, i, i + 1, i - 1}, nj[6] = {j + 1, j - 1, j, j, j, j}, nk[6] = {k, k, k + 1, k - 1, k, k};
+        for (int b = 0; b < 6; ++b)
+          if (at(3, ni[b], nj[b], nk[b]) == 1) f |= 1u << b;
+      }
+      sf.push_back((unsigned char)f);
+    }
+    for (size_t q = 0; q < G.bound_g.size() / 3; ++q) {
+      const int i = G.bound_g[3 * q], j = G.bound_g[3 * q + 1], k = G.bound_g[3 * q + 2];
+      if (j <= j0 || j > j0 + nyl) continue;
+      bp.push_back(i - 1); bp.push_back(j - 1 - j0); bp.push_back(k - 1);
+      unsigned f = 0;
+      int ni[6], nj[6], nk[6], nb = 4;
+      for (int b = 0; b < 6; ++b) { ni[b] = i; nj[b] = j; nk[b] = k; }
+      if (gq == 0) { nj[0] = j + 1; nj[1] = j - 1; nk[2] = k + 1; nk[3] = k - 1; }
+      else if (gq == 1) { ni[0] = i + 1; ni[1] = i - 1; nk[2] = k + 1; nk[3] = k - 1; }
+      else if (gq == 2) { ni[0] = i + 1; ni[1] = i - 1; nj[2] = j + 1; nj[3] = j - 1; }
+      else { ni[0] = i + 1; ni[1] = i - 1; nj[2] = j + 1; nj[3] = j - 1; nk[4] = k + 1; nk[5] = k - 1; nb = 6; }
+      for (int b = 0; b < nb; ++b)
+        if (at(gq, ni[b], nj[b], nk[b]) == 0) f |= 1u << b;
+      bf.push_back((unsigned char)f);
+    }
+    G.nsolid = (int)(sp.size() / 3); G.nbound = (int)(bp.size() / 3);
+    if (upload_points(h, sp, sf, &G.solid, &G.solid_fl)) return 1;
+    if (upload_points(h, bp, bf, &G.bound, &G.bound_fl)) return 1;
+  }
+  h->ibm_on = true;
+  return 0;
+}
+
+void ibm_destroy(udc_handle *h) {
+  for (auto &G : h->ibm) {
+    if (G.solid) hipFree(G.solid);
+    if (G.solid_fl) hipFree(G.solid_fl);
+    if (G.bound) hipFree(G.bound);
+    if (G.bound_fl) hipFree(G.bound_fl);
+  }
+}
+
+// ibmwallfun without facet wall functions: the diffusion corrections (additive, so equally valid on pup = up + um/rk3coef)
+int k_ibm_wallfun(udc_handle *h) {
+  if (!h->ibm_on) return 0;
+  const Geo &g = h->g;
+  PROF(h, "ibm_wallfun");
+  const udc_handle::IbmGrid &U = h->ibm[0], &V = h->ibm[1], &W = h->ibm[2], &C = h->ibm[3];
+  const double *ekm = h->fields[UDC_EKM], *ekh = h->fields[UDC_EKH];
+  if (U.nbound) hipLaunchKernelGGL(ibm_diffu_corr_kernel, dim3(blocks(U.nbound)), dim3(128), 0, h->stream, g, h->m, U.nbound, U.bound, U.bound_fl,
+                                   (const double *)h->fields[UDC_U0], ekm, h->fields[UDC_UP]);
+  if (V.nbound) hipLaunchKernelGGL(ibm_diffv_corr_kernel, dim3(blocks(V.nbound)), dim3(128), 0, h->stream, g, h->m, V.nbound, V.bound, V.bound_fl,
+                                   (const double *)h->fields[UDC_V0], ekm, h->fields[UDC_VP]);
+  if (W.nbound) hipLaunchKernelGGL(ibm_diffw_corr_kernel, dim3(blocks(W.nbound)), dim3(128), 0, h->stream, g, h->m, W.nbound, W.bound, W.bound_fl,
+                                   (const double *)h->fields[UDC_W0], ekm, h->fields[UDC_WP]);
+  if (C.nbound)
+    for (int n : h->slots)
+      hipLaunchKernelGGL(ibm_diffc_corr_kernel, dim3(blocks(C.nbound)), dim3(128), 0, h->stream, g, h->m, C.nbound, C.bound, C.bound_fl,
+                         (const double *)h->fields[UDC_SV0 + 3 * n], ekh, h->fields[UDC_SVP + 3 * n]);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// ibmnorm: solid velocities (um, and the tendency -- or pup, which must vanish with both) to zero; scalars to the mean
+// of their fluid neighbours
+int k_ibm_norm(udc_handle *h) {
+  if (!h->ibm_on) return 0;
+  const Geo &g = h->g;
+  PROF(h, "ibm_norm");
+  for (int q = 0; q < 3; ++q) {
+    const udc_handle::IbmGrid &G = h->ibm[q];
+    if (G.nsolid) hipLaunchKernelGGL(ibm_solid_zero_kernel, dim3(blocks(G.nsolid)), dim3(128), 0, h->stream, g, G.nsolid, G.solid,
+                                     h->fields[UDC_UM + q], h->fields[UDC_UP + q]);
+  }
+  const udc_handle::IbmGrid &C = h->ibm[3];
+  if (C.nsolid)
+    for (int n : h->slots)
+      hipLaunchKernelGGL(ibm_solid_mean_kernel, dim3(blocks(C.nsolid)), dim3(128), 0, h->stream, g, C.nsolid, C.solid, C.solid_fl, 0.,
+                         h->fields[UDC_SVM + 3 * n], h->fields[UDC_SVP + 3 * n]);
+  HIP_OK(hipGetLastError());
+  return 0;
+}

@@ -170,6 +170,17 @@ struct udc_handle {
   bool no_fold = false;                 // UDC_NO_FOLD=1: keep separate ghost-row kernels on a single slab (A/B switch)
   bool no_pup = false;                  // UDC_NO_PUP=1: keep bare tendencies in the fused substep (A/B switch)
   bool mom_simple = false;              // UDC_MOM_SIMPLE=1: use the direct-load momentum kernel
+  // immersed boundary (udc_ibm.hip): per grid (u, v, w, c) the global point lists as given, and this slab's points
+  // (local 0-based i, j, k triplets) with their neighbour flags on the device
+  struct IbmGrid {
+    std::vector<int> solid_g, bound_g;
+    bool given = false;
+    int nsolid = 0, nbound = 0;
+    int *solid = nullptr, *bound = nullptr;
+    unsigned char *solid_fl = nullptr, *bound_fl = nullptr;
+  };
+  IbmGrid ibm[4];
+  bool ibm_on = false;
   // deferred execution (udc_set_deferred): the tendency routines of one RK3 substep are recorded instead of launched;
   // udc_tstep_integrate then runs the recorded sequence -- as the fused substep when it is the reference's own
   // (src/program.f90:142-197), routine by routine otherwise.  pend holds OP_* bits in call order.
@@ -274,6 +285,10 @@ int k_level_forcings(udc_handle *h, int when, bool wrap_vp);
 int k_tke_closure(udc_handle *h);                  // closure, loneeqn branch
 int k_tke_sources(udc_handle *h);                  // sources: e12p += shear + buoyancy + dissipation
 int k_vreman_buoycorr(udc_handle *h);            // ekm *= sqrt(1 - min(max(Rig,0),Rigc)/Rigc), then ekh and the molecular parts
+int k_ibm_wallfun(udc_handle *h);                // diffu/v/w/c_corr at the fluid-boundary points
+int k_ibm_norm(udc_handle *h);                   // solid: velocities zeroed, scalars to the mean of their fluid neighbours
+void ibm_destroy(udc_handle *h);
+int udc_flush_pending(udc_handle *h);
 int k_tke_floor(udc_handle *h);                    // e120(kb-1) = e120(kb), e12m likewise (`bottom`)                     // wp += grav (thv0h - thvh)/thvh, src/modforces.f90:73-84   // cp(i,j,k) += src(k)
 int k_maxima(udc_handle *h, double dt, double *cour, double *diffn);
 int k_divergence_check(udc_handle *h, double *divmax, double *divtot);

@@ -1,12 +1,18 @@
-!> Drop-in replacement for the reference's module modibm (src/modibm.f90), floor part.
+!> Drop-in replacement for the reference's module modibm (src/modibm.f90).
 !! Same module name; public procedures initibm, createmasks, bottom, ibmwallfun, ibmnorm and the namelist variables
-!! of src/modibm.f90:30-62.  `bottom` (:1998-2100: floor wall function wfmneutral / wfuno for momentum and temperature,
-!! flux floors for thl, qt and the scalars, the e120 floor ghost) runs on the device (udc_bottom).  The immersed
-!! boundary itself (libm: ibmnorm, ibmwallfun and the *_corr routines they drive) is not taken over yet: a deck with
-!! libm = .true. stops in initibm with the reference's error convention.  Without IBM, createmasks (:2103-2135)
-!! fills the masks with ones and the slab counts with the cells per slab.
-!! The tau_x / tau_y / tau_z / thl_flux diagnostics of `bottom` (:2015-2018, 2094-2097: the tendency increments of the
-!! floor, read by the statistics) are not produced.
+!! of src/modibm.f90:30-62.
+!!   bottom (:1998-2100: floor wall function wfmneutral / wfuno for momentum and temperature, flux floors for thl, qt and
+!!       the scalars, the e120 floor ghost)                                        -> udc_bottom
+!!   initibm (:131): reads solid_{u,v,w,c}.txt and fluid_boundary_{u,v,w,c}.txt with the reference's own read_sparse_ijk
+!!       (src/readinput.f90) and hands the global lists to the device (udc_set_ibm_points, udc_ibm_commit); builds the
+!!       real masks mask_u .. mask_c as :150-186 does (modfielddump reads them)
+!!   ibmwallfun (:1167) without facet wall functions: diffu/v/w/c_corr             -> udc_ibmwallfun
+!!   ibmnorm (:697): solid                                                         -> udc_ibmnorm
+!!   createmasks (:2103): the integer masks II* and their slab / column counts, on the host as in the reference
+!! Not taken over yet (refused in initibm with the reference's error convention): the facet wall functions (iwallmom > 1:
+!! wallfunmom :1286, wallfunheat :1436 -- hence ltempeq / lmoist with libm), facet output (lwritefac).
+!! The tau_x / tau_y / tau_z / thl_flux diagnostics of `bottom` and `ibmwallfun` (the tendency increments, read by the
+!! statistics) are not produced.
 module modibm
   use iso_c_binding, only: c_int, c_double
   use modibmdata
@@ -24,17 +30,24 @@ module modibm
              nbndpts_u = 0, nbndpts_v = 0, nbndpts_w = 0, nbndpts_c = 0, &
              nfctsecs_u = 0, nfctsecs_v = 0, nfctsecs_w = 0, nfctsecs_c = 0
   real, allocatable, target, dimension(:, :, :) :: mask_u, mask_v, mask_w, mask_c
+  ! this rank's solid points (local indices), kept for createmasks
+  integer, allocatable :: sol_u(:, :), sol_v(:, :), sol_w(:, :), sol_c(:, :)
+
+  type ibm_lists
+    integer(c_int), allocatable :: sol(:, :), bnd(:, :)      ! (3, n): global i, j, k as in the input files
+    logical :: given = .false.
+  end type ibm_lists
+  type(ibm_lists) :: lists(0:3)
+  logical :: ibm_pending = .false.
 
 contains
 
   subroutine initibm
-    use modglobal, only: libm, ib, ie, ih, jb, je, jh, kb, ke, kh, ltempeq, lmoist, nsv, BCbotm, BCbotT, BCbotq, BCbots
+    use modglobal, only: libm, ib, ie, ih, jb, je, jh, kb, ke, kh, ltempeq, lmoist, nsv, BCbotm, BCbotT, BCbotq, BCbots, &
+                         iwallmom, lwritefac
     use modsurfdata, only: z0
     use udc_iface, only: udc_set_floor
-    if (libm) then
-      write (0, *) 'ERROR: libudcore modibm: immersed boundaries (libm) are not available in this build'
-      stop 1
-    end if
+    logical :: need_c
     if (lbottom) then      ! what `bottom` would stop on at its first call (src/modibm.f90:2027-2090)
       if (BCbotm /= 2 .and. BCbotm /= 3) then
         write (0, *) 'ERROR: bottom boundary type for momentum undefined'
@@ -53,31 +66,169 @@ contains
         stop 1
       end if
     end if
+    call udc_set_floor(lbottom, real(z0, c_double))
     allocate (mask_u(ib - ih:ie + ih, jb - jh:je + jh, kb - kh:ke + kh)); mask_u = 1.
     allocate (mask_v(ib - ih:ie + ih, jb - jh:je + jh, kb - kh:ke + kh)); mask_v = 1.
     allocate (mask_w(ib - ih:ie + ih, jb - jh:je + jh, kb - kh:ke + kh)); mask_w = 1.
     allocate (mask_c(ib - ih:ie + ih, jb - jh:je + jh, kb - kh:ke + kh)); mask_c = 1.
-    call udc_set_floor(lbottom, real(z0, c_double))
-  end subroutine initibm
-
-  !> masks and slab cell counts without blocks (src/modibm.f90:2121-2141)
-  subroutine createmasks
-    use modglobal, only: libm, jtot, rslabs
-    use modfields, only: IIc, IIu, IIv, IIw, IIuw, IIvw, IIuv, IIcs, IIus, IIvs, IIws, IIuws, IIvws, IIuvs, &
-                         IIct, IIut, IIvt, IIwt, IIuwt
-    if (libm) then
-      write (0, *) 'ERROR: libudcore modibm: immersed boundaries (libm) are not available in this build'
+    if (.not. libm) return
+    if (iwallmom > 1) then
+      write (0, *) 'ERROR: libudcore modibm: the facet wall functions (iwallmom > 1) are not available; set iwallmom = 1'
       stop 1
     end if
+    if (ltempeq .or. lmoist .or. lwritefac) then
+      write (0, *) 'ERROR: libudcore modibm: ltempeq / lmoist / lwritefac with libm need the facet wall functions (wallfunheat)'
+      stop 1
+    end if
+    need_c = nsv > 0
+    mask_w(:, :, kb) = 0.                     ! src/modibm.f90:154-157
+    mask_u(:, :, kb - kh) = 0.; mask_v(:, :, kb - kh) = 0.; mask_w(:, :, kb - kh) = 0.; mask_c(:, :, kb - kh) = 0.
+    call grid_lists(0, 'solid_u.txt', nsolpts_u, 'fluid_boundary_u.txt', nbndpts_u, mask_u, sol_u)
+    call grid_lists(1, 'solid_v.txt', nsolpts_v, 'fluid_boundary_v.txt', nbndpts_v, mask_v, sol_v)
+    call grid_lists(2, 'solid_w.txt', nsolpts_w, 'fluid_boundary_w.txt', nbndpts_w, mask_w, sol_w)
+    if (need_c) call grid_lists(3, 'solid_c.txt', nsolpts_c, 'fluid_boundary_c.txt', nbndpts_c, mask_c, sol_c)
+    ibm_pending = .true.
+  end subroutine initibm
+
+  !> one grid: read both lists (read_sparse_ijk: this rank's points with local indices + the global list), zero the real
+  !! mask at this rank's solid points, keep the global lists for the device (udc_ensure runs after all init* routines)
+  subroutine grid_lists(grid, fsol, nsol, fbnd, nbnd, mask, sol_loc)
+    use readinput, only: read_sparse_ijk
+    integer, intent(in) :: grid, nsol, nbnd
+    character(*), intent(in) :: fsol, fbnd
+    real, intent(inout) :: mask(:, :, :)
+    integer, allocatable, intent(out) :: sol_loc(:, :)
+    integer, allocatable :: ids(:), loc(:, :), glob(:, :)
+    integer :: n, nloc, lb(3)
+    call read_sparse_ijk(fsol, nsol, nloc, ids, sol_loc, nskip=1, pts_glob_out=glob)
+    lb = lbound_of_mask()
+    do n = 1, nloc
+      mask(sol_loc(n, 1) - lb(1) + 1, sol_loc(n, 2) - lb(2) + 1, sol_loc(n, 3) - lb(3) + 1) = 0.
+    end do
+    allocate (lists(grid)%sol(3, nsol))
+    lists(grid)%sol = transpose(glob)
+    deallocate (glob, ids)
+    call read_sparse_ijk(fbnd, nbnd, nloc, ids, loc, nskip=1, pts_glob_out=glob)
+    allocate (lists(grid)%bnd(3, nbnd))
+    lists(grid)%bnd = transpose(glob)
+    lists(grid)%given = .true.
+  contains
+    function lbound_of_mask() result(l)
+      use modglobal, only: ib, ih, jb, jh, kb, kh
+      integer :: l(3)
+      l = (/ib - ih, jb - jh, kb - kh/)
+    end function lbound_of_mask
+  end subroutine grid_lists
+
+  !> hand the lists to the device once its handle exists (first call of ibmwallfun / ibmnorm, or of anything else)
+  subroutine ibm_to_device
+    use udc_iface
+    integer :: q
+    integer(c_int) :: none(3)
+    if (.not. ibm_pending) return
+    call udc_ensure
+    none = 0
+    do q = 0, 3
+      if (lists(q)%given) then
+        call udc_check(udc_set_ibm_points(udc_h, int(q, c_int), lists(q)%sol, int(size(lists(q)%sol, 2), c_int), &
+                                          lists(q)%bnd, int(size(lists(q)%bnd, 2), c_int)), 'udc_set_ibm_points')
+      end if
+    end do
+    call udc_check(udc_ibm_commit(udc_h), 'udc_ibm_commit')
+    ibm_pending = .false.
+  end subroutine ibm_to_device
+
+  !> integer masks and their counts (src/modibm.f90:2103-2234)
+  subroutine createmasks
+    use mpi
+    use modglobal, only: libm, ib, ie, jb, je, kb, ke, khc, jtot, rslabs
+    use modfields, only: IIc, IIu, IIv, IIw, IIuw, IIvw, IIuv, IIcs, IIus, IIvs, IIws, IIuws, IIvws, IIuvs, &
+                         IIct, IIut, IIvt, IIwt, IIuwt
+    use modmpi, only: comm3d, mpierr
+    integer :: i, j, k, n
+    integer, allocatable :: loc(:), tot(:), cl(:, :), ct(:, :)
     IIc = 1; IIu = 1; IIv = 1; IIw = 1; IIuw = 1; IIvw = 1; IIuv = 1
-    IIcs = nint(rslabs); IIus = nint(rslabs); IIvs = nint(rslabs); IIws = nint(rslabs)
-    IIuws = nint(rslabs); IIvws = nint(rslabs); IIuvs = nint(rslabs)
-    IIct = jtot; IIut = jtot; IIvt = jtot; IIwt = jtot; IIuwt = jtot
+    if (.not. libm) then
+      IIcs = nint(rslabs); IIus = nint(rslabs); IIvs = nint(rslabs); IIws = nint(rslabs)
+      IIuws = nint(rslabs); IIvws = nint(rslabs); IIuvs = nint(rslabs)
+      IIct = jtot; IIut = jtot; IIvt = jtot; IIwt = jtot; IIuwt = jtot
+      return
+    end if
+    if (allocated(sol_u)) then
+      do n = 1, size(sol_u, 1)
+        IIu(sol_u(n, 1), sol_u(n, 2), sol_u(n, 3)) = 0
+      end do
+    end if
+    if (allocated(sol_v)) then
+      do n = 1, size(sol_v, 1)
+        IIv(sol_v(n, 1), sol_v(n, 2), sol_v(n, 3)) = 0
+      end do
+    end if
+    if (allocated(sol_w)) then
+      do n = 1, size(sol_w, 1)
+        IIw(sol_w(n, 1), sol_w(n, 2), sol_w(n, 3)) = 0
+      end do
+    end if
+    if (allocated(sol_c)) then
+      do n = 1, size(sol_c, 1)
+        IIc(sol_c(n, 1), sol_c(n, 2), sol_c(n, 3)) = 0
+      end do
+    end if
+    IIw(:, :, kb) = 0; IIuw(:, :, kb) = 0; IIvw(:, :, kb) = 0
+    do i = ib, ie      ! a stencil point counts as fluid only when every point of its stencil is (:2182-2192)
+      do j = jb, je
+        IIuv(i, j, kb) = IIu(i, j, kb)*IIu(i, j - 1, kb)*IIv(i, j, kb)*IIv(i - 1, j, kb)
+        do k = kb + 1, ke
+          IIuv(i, j, k) = IIu(i, j, k)*IIu(i, j - 1, k)*IIv(i, j, k)*IIv(i - 1, j, k)
+          IIuw(i, j, k) = IIu(i, j, k)*IIu(i, j, k - 1)*IIw(i, j, k)*IIw(i - 1, j, k)
+          IIvw(i, j, k) = IIv(i, j, k)*IIv(i, j, k - 1)*IIw(i, j, k)*IIw(i, j - 1, k)
+        end do
+      end do
+    end do
+    allocate (loc(kb:ke + khc), tot(kb:ke + khc))
+    call slabcount(IIc, IIcs); call slabcount(IIu, IIus); call slabcount(IIv, IIvs); call slabcount(IIw, IIws)
+    call slabcount(IIuw, IIuws); call slabcount(IIvw, IIvws); call slabcount(IIuv, IIuvs)
+    allocate (cl(ib:ie, kb:ke), ct(ib:ie, kb:ke))
+    call colcount(IIw, IIwt); call colcount(IIc, IIct); call colcount(IIuw, IIuwt); call colcount(IIu, IIut); call colcount(IIv, IIvt)
+  contains
+    subroutine slabcount(II, IIs)
+      integer, intent(in) :: II(:, :, :)
+      integer, intent(inout) :: IIs(kb:)
+      integer :: kk
+      ! (II arrays: (ib-ihc:ie+ihc, jb-jhc:je+jhc, kb-khc:ke+khc), src/modfields.f90)
+      do kk = kb, ke + khc
+        loc(kk) = sum(II(lbi():ubi(), lbj():ubj(), kk - kb + 1 + khc))
+      end do
+      call MPI_ALLREDUCE(loc, tot, ke + khc - kb + 1, MPI_INTEGER, MPI_SUM, comm3d, mpierr)
+      IIs(kb:ke + khc) = tot
+    end subroutine slabcount
+    subroutine colcount(II, IIt)
+      integer, intent(in) :: II(:, :, :)
+      integer, intent(inout) :: IIt(ib:, kb:)
+      cl = sum(II(lbi():ubi(), lbj():ubj(), 1 + khc:ke - kb + 1 + khc), DIM=2)
+      call MPI_ALLREDUCE(cl, ct, size(cl), MPI_INTEGER, MPI_SUM, comm3d, mpierr)
+      IIt(ib:ie, kb:ke) = ct
+    end subroutine colcount
+    integer function lbi()
+      use modglobal, only: ihc
+      lbi = 1 + ihc
+    end function lbi
+    integer function ubi()
+      use modglobal, only: ihc
+      ubi = ie - ib + 1 + ihc
+    end function ubi
+    integer function lbj()
+      use modglobal, only: jhc
+      lbj = 1 + jhc
+    end function lbj
+    integer function ubj()
+      use modglobal, only: jhc
+      ubj = je - jb + 1 + jhc
+    end function ubj
   end subroutine createmasks
 
   !> floor of the domain (src/modibm.f90:1998-2100)
   subroutine bottom
-    use modsubgriddata, only: loneeqn
     use udc_iface
     if (.not. (lbottom .or. loneeqn_dev())) return
     call udc_begin(.true.)
@@ -86,10 +237,27 @@ contains
     if (udc_mode() == 0 .and. loneeqn_dev()) call udc_pull_vel(.true.)     ! e120, e12m floor ghosts
   end subroutine bottom
 
-  subroutine ibmwallfun      ! no-ops without libm (src/modibm.f90:1167, 697)
+  !> immersed boundary forcing, shear part (src/modibm.f90:1167): the diffusion corrections at the fluid-boundary points
+  subroutine ibmwallfun
+    use modglobal, only: libm
+    use udc_iface
+    if (.not. libm) return
+    call ibm_to_device
+    call udc_begin(.true.)
+    call udc_check(udc_ibmwallfun(udc_h), 'udc_ibmwallfun')
+    call udc_end_tend
   end subroutine ibmwallfun
 
+  !> immersed boundary forcing, normal part (src/modibm.f90:697): solid points
   subroutine ibmnorm
+    use modglobal, only: libm
+    use udc_iface
+    if (.not. libm) return
+    call ibm_to_device
+    call udc_begin(.true.)
+    call udc_check(udc_ibmnorm(udc_h), 'udc_ibmnorm')
+    call udc_end_tend
+    if (udc_mode() <= 1) call udc_pull_vel(.true.)      ! um, vm, wm, svm were edited
   end subroutine ibmnorm
 
 end module modibm

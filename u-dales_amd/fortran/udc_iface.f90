@@ -129,6 +129,24 @@ module udc_iface
       integer(c_int), value :: lbuoycorr
       real(c_double), value :: rigc
     end function
+    integer(c_int) function udc_set_ibm_points(h, grid, solid, nsolid, bound, nbound) bind(C, name='udc_set_ibm_points')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+      integer(c_int), value :: grid, nsolid, nbound
+      integer(c_int), intent(in) :: solid(3, *), bound(3, *)
+    end function
+    integer(c_int) function udc_ibm_commit(h) bind(C, name='udc_ibm_commit')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function udc_ibmwallfun(h) bind(C, name='udc_ibmwallfun')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function udc_ibmnorm(h) bind(C, name='udc_ibmnorm')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+    end function
     integer(c_int) function udc_set_floor_wf(h, bcbotm, bcbott, thls, z0h, prandtlturb) bind(C, name='udc_set_floor_wf')
       import :: c_ptr, c_int, c_double
       type(c_ptr), value :: h

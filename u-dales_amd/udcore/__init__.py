@@ -84,6 +84,8 @@ def from_deck(deck, device=0, rank=0, nranks=1):
         else:
             for n in range(core.nsv):
                 core.set_scalar_top(n, 1, float(w[n]) if n < len(w) else 0.)
+    from .ibm import apply_ibm
+    apply_ibm(core, deck)
     if core.nsv and (deck.get("SCALARS", "lscasrc") or deck.get("SCALARS", "lscasrcl")):
         from .sources import apply_sources
         apply_sources(core, deck, j0=rank * core.nyl)

@@ -330,6 +330,25 @@ class DynCore:
         self._ensure_thermo()
         L._check(self.lib.udc_run(self.h, nsub, rk3step0, C.c_double(dt), 1 if with_forces else 0), "udc_run")
 
+    # ---- immersed boundary (sparse corrections, udcore/ibm.py reads the reference's input files)
+    def set_ibm_points(self, grid, solid, bound):
+        s = np.ascontiguousarray(solid, dtype=np.int32).reshape(-1, 3)
+        b = np.ascontiguousarray(bound, dtype=np.int32).reshape(-1, 3)
+        ip = C.POINTER(C.c_int)
+        L._check(self.lib.udc_set_ibm_points(self.h, int(grid), s.ctypes.data_as(ip), len(s), b.ctypes.data_as(ip), len(b)),
+                 "udc_set_ibm_points")
+
+    def ibm_commit(self):
+        L._check(self.lib.udc_ibm_commit(self.h), "udc_ibm_commit")
+
+    def ibmwallfun(self):
+        """ibmwallfun (src/modibm.f90:1167) without facet wall functions, after nudge."""
+        L._check(self.lib.udc_ibmwallfun(self.h), "udc_ibmwallfun")
+
+    def ibmnorm(self):
+        """ibmnorm (src/modibm.f90:697), after masscorr."""
+        L._check(self.lib.udc_ibmnorm(self.h), "udc_ibmnorm")
+
     # ---- deferred execution: the routine-by-routine surface runs as the fused substep (include/udcore.h)
     def set_deferred(self, on=True):
         L._check(self.lib.udc_set_deferred(self.h, 1 if on else 0), "udc_set_deferred")

@@ -1,0 +1,55 @@
+"""Immersed boundary, host side: the reference's sparse input files -> udc_set_ibm_points / udc_ibm_commit.
+
+The reference's preprocessing writes, per grid g in u, v, w, c, ``solid_g.txt`` and ``fluid_boundary_g.txt`` (one header line,
+then rows of global 1-based ``i j k``) and the counts into &WALLS (nsolpts_g, nbndpts_g); initibm reads them with
+read_sparse_ijk (src/modibm.f90:131-186, src/readinput.f90:31-130).  This slice has the corrections that need no facet
+data: iwallmom = 1 (no wall functions), no thl / qt.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+GRIDS = ("u", "v", "w", "c")
+
+
+def read_points(path, n):
+    """n rows of `i j k` after one header line (read_sparse_ijk)."""
+    if n == 0:
+        return np.zeros((0, 3), dtype=np.int32)
+    a = np.loadtxt(path, skiprows=1, dtype=np.int64, ndmin=2)
+    if a.shape[0] < n or a.shape[1] < 3:
+        raise ValueError(f"{path}: expected {n} rows of i j k")
+    return np.ascontiguousarray(a[:n, :3], dtype=np.int32)
+
+
+def read_ibm(deck):
+    """{grid: (solid[n,3], boundary[n,3])} from the deck's directory, counts from &WALLS."""
+    base = os.path.dirname(os.path.abspath(deck.path))
+    out = {}
+    need_c = int(deck.get("SCALARS", "nsv")) > 0 or bool(deck.get("PHYSICS", "ltempeq")) or bool(deck.get("PHYSICS", "lmoist"))
+    for g in GRIDS:
+        if g == "c" and not need_c:
+            continue
+        ns, nb = int(deck.get("WALLS", f"nsolpts_{g}")), int(deck.get("WALLS", f"nbndpts_{g}"))
+        out[g] = (read_points(os.path.join(base, f"solid_{g}.txt"), ns), read_points(os.path.join(base, f"fluid_boundary_{g}.txt"), nb))
+    return out
+
+
+def apply_ibm(core, deck):
+    """Register the deck's immersed boundary with the device core (no-op unless &RUN libm)."""
+    if not deck.get("RUN", "libm"):
+        return None
+    if int(deck.get("WALLS", "iwallmom")) != 1:
+        raise ValueError("libm: only iwallmom = 1 (no facet wall functions, src/modibm.f90:1286) is on the device path")
+    if deck.get("PHYSICS", "ltempeq") or deck.get("PHYSICS", "lmoist"):
+        raise ValueError("libm with ltempeq / lmoist needs the facet heat wall functions (wallfunheat), not on the device path")
+    if deck.get("PHYSICS", "luvolflowr") or deck.get("PHYSICS", "lvvolflowr"):
+        raise ValueError("libm with a prescribed volume flow needs the masked slab averages of masscorr, not on the device path")
+    lists = read_ibm(deck)
+    for q, g in enumerate(GRIDS):
+        if g in lists:
+            core.set_ibm_points(q, *lists[g])
+    core.ibm_commit()
+    return lists
