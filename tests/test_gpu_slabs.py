@@ -145,9 +145,12 @@ def run_virtual(P, g, deck_like, st_global, nsub, dt, sgs, nsv=0, extras=False):
 
 @pytest.mark.parametrize("shape,sgs,chunks,extras", [((32, 16, 12), 2, 1, False), ((24, 32, 10), 1, 2, False),
                                                      ((32, 16, 12), 2, 3, False), ((32, 16, 12), 2, 1, 1),
-                                                     ((32, 16, 12), 2, 2, 2)])
+                                                     ((32, 16, 12), 2, 2, 2),
+                                                     ((128, 64, 16), 2, 2, False), ((64, 32, 8), 1, 4, 1)])
 def test_decomposition_invariance(shape, sgs, chunks, extras, monkeypatch):
     # chunks > 1: the k-chunked all-to-all pipeline (exchange on a second stream, overlapped with rocFFT)
+    # power-of-two nx and ny: the slab ranks run the own line FFTs with fused packing (udc_fft.hip) against the single
+    # rank's 2-D rocFFT; (24, 32, 10) keeps the rocFFT + transpose kernels of the slab path covered
     monkeypatch.setenv("UDC_A2A_CHUNKS", str(chunks))
     from test_gpu_parity import random_state
     from udcore.grid import Grid

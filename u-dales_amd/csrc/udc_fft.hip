@@ -1,0 +1,346 @@
+// Line FFTs of the slab (multi-GPU) Poisson solve with the all-to-all packing fused in.
+//
+// The slab path (udc_pois.hip, k_poisson_solve_slab) transforms x on the y-slabs, exchanges blocks [d][k][kx_l][j]
+// with every rank, transforms y on the kx-slabs, and back.  With rocFFT each of the four transforms is followed /
+// preceded by a separate transpose kernel (4 extra passes over the spectral data).  Here a workgroup holds whole
+// lines in LDS -- L rows of x for the x transforms, C columns of y for the y transforms -- runs a Stockham autosort
+// FFT on them (radix 4, one radix-2 stage when log2 is odd) and reads / writes the exchange buffers directly:
+//
+//   fftx_fwd_pack    p rows (real, coalesced)          -> R2C  -> send[d][k][kx_l][j]   (runs of L in j)
+//   ffty_fwd_unpack  recv[s][k][kx_l][j] (runs of ny_l) -> C2C  -> specB[k][kx_l][y]     (what the Thomas kernel reads)
+//   ffty_bwd_pack    specB[k][kx_l][y]                  -> C2C^-1 -> send[d][k][kx_l][j]
+//   fftx_bwd_unpack  recv[s][k][kx_l][j] (runs of L)    -> C2R  -> p rows
+//
+// R2C / C2R of length N run as a complex transform of length M = N/2 on z[n] = x[2n] + i x[2n+1] with the usual
+// split / merge step.  All transforms are unnormalised, like rocFFT's and FFTW's (the Thomas kernel carries 1/(nx ny)).
+// Power-of-two lengths only (16 <= nx <= 2048, 8 <= ny <= 1024, power-of-two local rows >= 4); anything else keeps the
+// rocFFT path.
+#include "udc_internal.h"
+#include <cmath>
+#include <cstdlib>
+
+namespace {
+
+constexpr int FT = 256;      // threads per workgroup
+
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+  return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double2 cconj(double2 a) { return make_double2(a.x, -a.y); }
+
+// LDS index of element n of a line: one pad element per 16 so that the strided accesses of the radix-4 stages (stride 4
+// and 16 elements between neighbouring lanes) spread over the banks
+__device__ __forceinline__ int pad(int n) { return n + (n >> 4); }
+__host__ __device__ constexpr int padded(int n) { return n + (n >> 4) + 1; }
+
+// Stockham autosort FFT of 1 << LNL lines of M = 1 << LM complex each, held in LDS at a[line * MP + pad(n)]; b is the
+// other half of the ping-pong.  tw[n] = exp(-2 pi i n / M), n < M, in LDS; INV conjugates it.  Returns the buffer
+// holding the result.  All FT threads of the workgroup must call it.  Everything is a shift or a mask.
+template <bool INV, int LM>
+__device__ __forceinline__ double2 *fft_lines(double2 *a, double2 *b, const double2 *tw, int MP, int nl) {
+  constexpr int M = 1 << LM;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int lp = 0; lp < LM;) {
+    const bool r4 = LM - lp >= 2;
+    const int lR = r4 ? 2 : 1, lT = LM - lR, T = 1 << lT, p = 1 << lp, lstep = LM - lp - lR;
+    const int work = nl << lT;
+    for (int wi = tid; wi < work; wi += FT) {
+      const int line = wi >> lT, j = wi & (T - 1);
+      const int k = j & (p - 1);
+      const double2 *src = a + line * MP;
+      double2 *dst = b + line * MP;
+      const int o = ((j - k) << lR) + k;
+      if (r4) {
+        double2 u0 = src[pad(j)], u1 = src[pad(j + T)], u2 = src[pad(j + 2 * T)], u3 = src[pad(j + 3 * T)];
+        if (lp > 0) {
+          const int t1 = k << lstep;
+          double2 w1 = tw[t1], w2 = tw[2 * t1], w3 = tw[3 * t1];
+          if (INV) { w1.y = -w1.y; w2.y = -w2.y; w3.y = -w3.y; }
+          u1 = cmul(u1, w1); u2 = cmul(u2, w2); u3 = cmul(u3, w3);
+        }
+        const double2 t0 = cadd(u0, u2), t1_ = csub(u0, u2), t2 = cadd(u1, u3);
+        const double2 d = csub(u1, u3);
+        const double2 t3 = INV ? make_double2(-d.y, d.x) : make_double2(d.y, -d.x);      // (u1 - u3) * (-/+ i)
+        dst[pad(o)] = cadd(t0, t2);
+        dst[pad(o + p)] = cadd(t1_, t3);
+        dst[pad(o + 2 * p)] = csub(t0, t2);
+        dst[pad(o + 3 * p)] = csub(t1_, t3);
+      } else {
+        double2 u0 = src[pad(j)], u1 = src[pad(j + T)];
+        if (lp > 0) {
+          double2 w1 = tw[k << lstep];
+          if (INV) w1.y = -w1.y;
+          u1 = cmul(u1, w1);
+        }
+        dst[pad(o)] = cadd(u0, u1);
+        dst[pad(o + p)] = csub(u0, u1);
+      }
+    }
+    __syncthreads();
+    double2 *t = a; a = b; b = t;
+    lp += lR;
+  }
+  (void)M;
+  return a;
+}
+
+struct XArgs {
+  int nx, M, MP;            // real length, complex length nx/2, LDS pitch of a line
+  int nyl, py;              // local rows, padded rows per plane of the real field
+  long sz;                  // plane stride of the real field (doubles)
+  int nkx, cx, P;           // r2c modes nx/2+1, modes per rank, ranks
+  int k0, nzc;              // chunk
+  int lL;                   // log2 of the rows per workgroup
+};
+
+// LDS: two line buffers [L][MP], then the twiddles of the length-M transform [M], then the rank of every mode [cx*P]
+template <int LM>
+__device__ __forceinline__ void x_lds(const XArgs &q, double2 *lds, double2 *&a, double2 *&b, double2 *&tw, int *&dmap,
+                                      const double2 *__restrict__ twM) {
+  const int L = 1 << q.lL;
+  a = lds; b = lds + L * q.MP; tw = b + L * q.MP;
+  dmap = reinterpret_cast<int *>(tw + (1 << LM));
+  for (int n = threadIdx.x; n < (1 << LM); n += FT) tw[n] = twM[n];
+  for (int kx = threadIdx.x; kx < q.cx * q.P; kx += FT) dmap[kx] = kx / q.cx;
+}
+
+// x forward: rows j0..j0+L-1 of plane k0+kc -> send blocks
+template <int LM>
+__global__ __launch_bounds__(FT) void fftx_fwd_pack_kernel(XArgs q, const double *__restrict__ p, const double2 *__restrict__ twM,
+                                                           const double2 *__restrict__ twN, double2 *__restrict__ send) {
+  extern __shared__ double2 lds[];
+  constexpr int M = 1 << LM;
+  double2 *a, *b, *tw; int *dmap;
+  x_lds<LM>(q, lds, a, b, tw, dmap, twM);
+  const int tid = threadIdx.x, L = 1 << q.lL;
+  const int j0 = blockIdx.x << q.lL, kc = blockIdx.y, k = q.k0 + kc;
+  // load: row l holds M complex = nx reals, read as double2 (16-B aligned: nx even, rows nx*8 B apart, base 16-B aligned)
+  for (int wi = tid; wi < (M << q.lL); wi += FT) {
+    const int l = wi >> LM, n = wi & (M - 1);
+    const double2 *row = reinterpret_cast<const double2 *>(p + q.sz * (long)(k + HZ) + (long)q.nx * (j0 + l + HY));
+    a[l * q.MP + pad(n)] = row[n];
+  }
+  __syncthreads();
+  double2 *z = fft_lines<false, LM>(a, b, tw, q.MP, L);
+  // split: X[kx] = (Z[kx] + conj(Z[M-kx]))/2 - (i/2) e^{-2 pi i kx/N} (Z[kx] - conj(Z[M-kx])), kx = 0..M (Z[M] = Z[0]);
+  // written j-fastest: send[((d*nzc + kc)*cx + kxl)*nyl + j]; the padding modes kx >= nkx of the last rank are zero
+  const int nk = q.cx * q.P;
+  for (int wi = tid; wi < (nk << q.lL); wi += FT) {
+    const int kx = wi >> q.lL, l = wi & (L - 1);
+    double2 X = make_double2(0., 0.);
+    if (kx < q.nkx) {
+      const double2 *zl = z + l * q.MP;
+      const double2 zk = zl[pad(kx == M ? 0 : kx)], zc = cconj(zl[pad(kx == 0 ? 0 : M - kx)]);
+      const double2 s = cadd(zk, zc), d = csub(zk, zc);
+      const double2 w = twN[kx];                              // e^{-2 pi i kx / N}
+      const double2 wd = cmul(w, d);                          // -(i/2) w d = (wd.y, -wd.x)/2
+      X = make_double2(0.5 * (s.x + wd.y), 0.5 * (s.y - wd.x));
+    }
+    const int d_ = dmap[kx], kxl = kx - d_ * q.cx;
+    send[(((size_t)d_ * q.nzc + kc) * q.cx + kxl) * q.nyl + j0 + l] = X;
+  }
+}
+
+// x backward: recv blocks -> rows j0..j0+L-1 of plane k0+kc (unnormalised C2R)
+template <int LM>
+__global__ __launch_bounds__(FT) void fftx_bwd_unpack_kernel(XArgs q, const double2 *__restrict__ recv, const double2 *__restrict__ twM,
+                                                             const double2 *__restrict__ twN, double *__restrict__ p) {
+  extern __shared__ double2 lds[];
+  constexpr int M = 1 << LM;
+  double2 *a, *b, *tw; int *dmap;
+  x_lds<LM>(q, lds, a, b, tw, dmap, twM);
+  __syncthreads();
+  const int tid = threadIdx.x, L = 1 << q.lL;
+  const int j0 = blockIdx.x << q.lL, kc = blockIdx.y, k = q.k0 + kc;
+  for (int wi = tid; wi < (q.nkx << q.lL); wi += FT) {      // gather X[0..M] (the pitch holds M + 1 elements)
+    const int kx = wi >> q.lL, l = wi & (L - 1);
+    const int s_ = dmap[kx], kxl = kx - s_ * q.cx;
+    b[l * q.MP + pad(kx)] = recv[(((size_t)s_ * q.nzc + kc) * q.cx + kxl) * q.nyl + j0 + l];
+  }
+  __syncthreads();
+  // merge: Z[kx] = (X[kx] + conj(X[M-kx])) + i e^{+2 pi i kx/N} (X[kx] - conj(X[M-kx])), kx = 0..M-1
+  for (int wi = tid; wi < (M << q.lL); wi += FT) {
+    const int l = wi >> LM, kx = wi & (M - 1);
+    const double2 *xl = b + l * q.MP;
+    const double2 xk = xl[pad(kx)], xc = cconj(xl[pad(M - kx)]);
+    const double2 s = cadd(xk, xc), d = csub(xk, xc);
+    const double2 w = cconj(twN[kx]);
+    const double2 wd = cmul(w, d);                            // i w d = (-wd.y, wd.x)
+    a[l * q.MP + pad(kx)] = make_double2(s.x - wd.y, s.y + wd.x);
+  }
+  __syncthreads();
+  double2 *z = fft_lines<true, LM>(a, b, tw, q.MP, L);
+  for (int wi = tid; wi < (M << q.lL); wi += FT) {
+    const int l = wi >> LM, n = wi & (M - 1);
+    double2 *row = reinterpret_cast<double2 *>(p + q.sz * (long)(k + HZ) + (long)q.nx * (j0 + l + HY));
+    row[n] = z[l * q.MP + pad(n)];
+  }
+}
+
+struct YArgs {
+  int ny, MP;               // line length (global rows), LDS pitch
+  int nyl, lnyl, cx, P;     // local rows and their log2
+  int k0, nzc;
+  int C;                    // columns (kx_l) per workgroup
+};
+
+// y forward: recv[s][kc][kxl][j] -> C2C -> specB[k][kxl][y]
+template <int LM>
+__global__ __launch_bounds__(FT) void ffty_fwd_unpack_kernel(YArgs q, const double2 *__restrict__ recv, const double2 *__restrict__ twg,
+                                                             double2 *__restrict__ specB) {
+  extern __shared__ double2 lds[];
+  constexpr int M = 1 << LM;
+  double2 *a = lds, *b = lds + q.C * q.MP, *tw = b + q.C * q.MP;
+  const int tid = threadIdx.x;
+  for (int n = tid; n < M; n += FT) tw[n] = twg[n];
+  const int c0 = blockIdx.x * q.C, kc = blockIdx.y, k = q.k0 + kc;
+  const int ncol = min(q.C, q.cx - c0);
+  for (int wi = tid; wi < (ncol << LM); wi += FT) {
+    const int col = wi >> LM, y = wi & (M - 1);
+    const int s_ = y >> q.lnyl, j = y & (q.nyl - 1);
+    a[col * q.MP + pad(y)] = recv[(((size_t)s_ * q.nzc + kc) * q.cx + c0 + col) * q.nyl + j];
+  }
+  __syncthreads();
+  double2 *z = fft_lines<false, LM>(a, b, tw, q.MP, ncol);
+  for (int wi = tid; wi < (ncol << LM); wi += FT) {
+    const int col = wi >> LM, y = wi & (M - 1);
+    specB[((size_t)k * q.cx + c0 + col) * M + y] = z[col * q.MP + pad(y)];
+  }
+}
+
+// y backward: specB[k][kxl][y] -> C2C^-1 -> send[d][kc][kxl][j]
+template <int LM>
+__global__ __launch_bounds__(FT) void ffty_bwd_pack_kernel(YArgs q, const double2 *__restrict__ specB, const double2 *__restrict__ twg,
+                                                           double2 *__restrict__ send) {
+  extern __shared__ double2 lds[];
+  constexpr int M = 1 << LM;
+  double2 *a = lds, *b = lds + q.C * q.MP, *tw = b + q.C * q.MP;
+  const int tid = threadIdx.x;
+  for (int n = tid; n < M; n += FT) tw[n] = twg[n];
+  const int c0 = blockIdx.x * q.C, kc = blockIdx.y, k = q.k0 + kc;
+  const int ncol = min(q.C, q.cx - c0);
+  for (int wi = tid; wi < (ncol << LM); wi += FT) {
+    const int col = wi >> LM, y = wi & (M - 1);
+    a[col * q.MP + pad(y)] = specB[((size_t)k * q.cx + c0 + col) * M + y];
+  }
+  __syncthreads();
+  double2 *z = fft_lines<true, LM>(a, b, tw, q.MP, ncol);
+  for (int wi = tid; wi < (ncol << LM); wi += FT) {
+    const int col = wi >> LM, y = wi & (M - 1);
+    const int d_ = y >> q.lnyl, j = y & (q.nyl - 1);
+    send[(((size_t)d_ * q.nzc + kc) * q.cx + c0 + col) * q.nyl + j] = z[col * q.MP + pad(y)];
+  }
+}
+
+inline int ilog2(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
+inline bool pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ host side
+bool fft_fused_possible(const udc_handle *h) {
+  const int nx = h->g.nx, ny = h->jtot, nyl = h->g.ny;
+  return pow2(nx) && nx >= 16 && nx <= 2048 && pow2(ny) && ny >= 8 && ny <= 1024 && pow2(nyl) && nyl >= 4;
+}
+
+static size_t x_lds_bytes(const udc_handle *h, int L) {
+  const int M = h->g.nx / 2;
+  return (size_t)2 * L * padded(M + 1) * 16 + (size_t)M * 16 + (size_t)h->cx * h->cfg.nranks * 4;
+}
+static size_t y_lds_bytes(const udc_handle *h, int C) { return (size_t)2 * C * padded(h->jtot) * 16 + (size_t)h->jtot * 16; }
+
+#define FFT_DISPATCH(LMV, CALL)                                                        \
+  switch (LMV) {                                                                       \
+    case 3: { constexpr int LM = 3; CALL; } break;   case 4: { constexpr int LM = 4; CALL; } break;   \
+    case 5: { constexpr int LM = 5; CALL; } break;   case 6: { constexpr int LM = 6; CALL; } break;   \
+    case 7: { constexpr int LM = 7; CALL; } break;   case 8: { constexpr int LM = 8; CALL; } break;   \
+    case 9: { constexpr int LM = 9; CALL; } break;   case 10: { constexpr int LM = 10; CALL; } break; \
+    default: udc_set_error("fused FFT: unsupported length 2^%d", LMV); return 1;       \
+  }
+
+int fft_fused_init(udc_handle *h) {
+  const int nx = h->g.nx, ny = h->jtot, M = nx / 2;
+  const double pi = 3.141592653589793238462643383279502884;
+  std::vector<double> t;
+  t.reserve((size_t)2 * (M + (M + 1) + ny));
+  for (int n = 0; n < M; ++n) { t.push_back(cos(2. * pi * n / M)); t.push_back(-sin(2. * pi * n / M)); }          // twM
+  for (int n = 0; n <= M; ++n) { t.push_back(cos(2. * pi * n / nx)); t.push_back(-sin(2. * pi * n / nx)); }       // twN
+  for (int n = 0; n < ny; ++n) { t.push_back(cos(2. * pi * n / ny)); t.push_back(-sin(2. * pi * n / ny)); }       // twY
+  HIP_OK(hipMalloc(&h->fft_tw, sizeof(double) * t.size()));
+  HIP_OK(hipMemcpy(h->fft_tw, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
+  // rows per workgroup of the x kernels (= the run length of the packed writes): as long as four workgroups still fit
+  // a CU's 160 KB of LDS, at least 4; columns per workgroup of the y kernels likewise (UDC_FFT_L / UDC_FFT_C override)
+  int L = 16;
+  while (L > 4 && x_lds_bytes(h, L) > 40000) L >>= 1;
+  while (h->g.ny % L) L >>= 1;
+  int C = 8;
+  while (C > 1 && y_lds_bytes(h, C) > 40000) C >>= 1;
+  if (getenv("UDC_FFT_L")) { const int v = atoi(getenv("UDC_FFT_L")); if (pow2(v) && v >= 1 && h->g.ny % v == 0) L = v; }
+  if (getenv("UDC_FFT_C")) { const int v = atoi(getenv("UDC_FFT_C")); if (v >= 1) C = v; }
+  h->fft_L = L; h->fft_C = C;
+  const int ldsx = (int)x_lds_bytes(h, L), ldsy = (int)y_lds_bytes(h, C);
+  if (ldsx > 160 * 1024 || ldsy > 160 * 1024) { h->fft_fused = false; return 0; }
+  const int lmx = ilog2(M), lmy = ilog2(ny);
+  if (ldsx > 65536) {
+    FFT_DISPATCH(lmx, HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(fftx_fwd_pack_kernel<LM>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsx));
+                      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(fftx_bwd_unpack_kernel<LM>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsx)))
+  }
+  if (ldsy > 65536) {
+    FFT_DISPATCH(lmy, HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(ffty_fwd_unpack_kernel<LM>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsy));
+                      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(ffty_bwd_pack_kernel<LM>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsy)))
+  }
+  return 0;
+}
+
+static XArgs xargs(const udc_handle *h, int k0, int nzc) {
+  const Geo &g = h->g;
+  const int M = g.nx / 2;
+  return XArgs{g.nx, M, padded(M + 1), g.ny, g.py, g.sz, h->nkx, h->cx, h->cfg.nranks, k0, nzc, ilog2(h->fft_L)};
+}
+static YArgs yargs(const udc_handle *h, int k0, int nzc) {
+  return YArgs{h->jtot, padded(h->jtot), h->g.ny, ilog2(h->g.ny), h->cx, h->cfg.nranks, k0, nzc, h->fft_C};
+}
+
+int fft_x_fwd_pack(udc_handle *h, int k0, int nzc, double *send) {
+  const XArgs q = xargs(h, k0, nzc);
+  const double2 *tw = reinterpret_cast<const double2 *>(h->fft_tw);
+  const dim3 gr((unsigned)(q.nyl >> q.lL), (unsigned)nzc);
+  const size_t lds = x_lds_bytes(h, h->fft_L);
+  FFT_DISPATCH(ilog2(q.M), hipLaunchKernelGGL(fftx_fwd_pack_kernel<LM>, gr, dim3(FT), lds, h->stream, q, (const double *)h->fields[UDC_P], tw,
+                                              tw + q.M, reinterpret_cast<double2 *>(send)))
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+int fft_x_bwd_unpack(udc_handle *h, int k0, int nzc, const double *recv) {
+  const XArgs q = xargs(h, k0, nzc);
+  const double2 *tw = reinterpret_cast<const double2 *>(h->fft_tw);
+  const dim3 gr((unsigned)(q.nyl >> q.lL), (unsigned)nzc);
+  const size_t lds = x_lds_bytes(h, h->fft_L);
+  FFT_DISPATCH(ilog2(q.M), hipLaunchKernelGGL(fftx_bwd_unpack_kernel<LM>, gr, dim3(FT), lds, h->stream, q, reinterpret_cast<const double2 *>(recv),
+                                              tw, tw + q.M, h->fields[UDC_P]))
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+int fft_y_fwd_unpack(udc_handle *h, int k0, int nzc, const double *recv) {
+  const YArgs q = yargs(h, k0, nzc);
+  const double2 *tw = reinterpret_cast<const double2 *>(h->fft_tw) + (h->g.nx / 2) + (h->g.nx / 2 + 1);
+  const dim3 gr((unsigned)((q.cx + q.C - 1) / q.C), (unsigned)nzc);
+  const size_t lds = y_lds_bytes(h, q.C);
+  FFT_DISPATCH(ilog2(q.ny), hipLaunchKernelGGL(ffty_fwd_unpack_kernel<LM>, gr, dim3(FT), lds, h->stream, q, reinterpret_cast<const double2 *>(recv),
+                                               tw, reinterpret_cast<double2 *>(h->specB)))
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+int fft_y_bwd_pack(udc_handle *h, int k0, int nzc, double *send) {
+  const YArgs q = yargs(h, k0, nzc);
+  const double2 *tw = reinterpret_cast<const double2 *>(h->fft_tw) + (h->g.nx / 2) + (h->g.nx / 2 + 1);
+  const dim3 gr((unsigned)((q.cx + q.C - 1) / q.C), (unsigned)nzc);
+  const size_t lds = y_lds_bytes(h, q.C);
+  FFT_DISPATCH(ilog2(q.ny), hipLaunchKernelGGL(ffty_bwd_pack_kernel<LM>, gr, dim3(FT), lds, h->stream, q,
+                                               reinterpret_cast<const double2 *>(h->specB), tw, reinterpret_cast<double2 *>(send)))
+  HIP_OK(hipGetLastError());
+  return 0;
+}

@@ -217,6 +217,10 @@ struct udc_handle {
   rocfft_plan plan_xf = nullptr, plan_xb = nullptr, plan_yf = nullptr, plan_yb = nullptr;
   rocfft_execution_info info_x = nullptr, info_y = nullptr;
   void *fft_work_slab = nullptr;
+  // own line FFTs with the all-to-all packing fused in (udc_fft.hip; power-of-two nx, jtot), else rocFFT + transposes
+  bool fft_fused = false;
+  double *fft_tw = nullptr;             // twiddle tables
+  int fft_L = 0, fft_C = 0;             // x rows / y columns per workgroup
 };
 
 void udc_set_error(const char *fmt, ...);
@@ -295,6 +299,12 @@ int k_divergence_check(udc_handle *h, double *divmax, double *divtot);
 int pois_init(udc_handle *h);
 int pois_slab_init(udc_handle *h);
 int k_poisson_solve_slab(udc_handle *h);
+bool fft_fused_possible(const udc_handle *h);
+int fft_fused_init(udc_handle *h);
+int fft_x_fwd_pack(udc_handle *h, int k0, int nzc, double *send);
+int fft_x_bwd_unpack(udc_handle *h, int k0, int nzc, const double *recv);
+int fft_y_fwd_unpack(udc_handle *h, int k0, int nzc, const double *recv);
+int fft_y_bwd_pack(udc_handle *h, int k0, int nzc, double *send);
 // udc_comm.hip
 int comm_neighbours(udc_handle *h, const double *to_prev, const double *to_next, double *from_prev,
                     double *from_next, size_t count);

@@ -886,6 +886,8 @@ int pois_slab_init(udc_handle *h) {
                             rocfft_precision_double, 1, ly, (size_t)cx * nzc, nullptr));
   FFT_OK(rocfft_plan_create(&h->plan_yb, rocfft_placement_inplace, rocfft_transform_type_complex_inverse,
                             rocfft_precision_double, 1, ly, (size_t)cx * nzc, nullptr));
+  h->fft_fused = fft_fused_possible(h) && !(getenv("UDC_FFT_FUSED") && atoi(getenv("UDC_FFT_FUSED")) == 0);
+  if (h->fft_fused && fft_fused_init(h)) return 1;
   HIP_OK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
   for (int c = 0; c < nch; ++c) {
     HIP_OK(hipEventCreateWithFlags(&h->ev_ready[c], hipEventDisableTiming));
@@ -928,10 +930,14 @@ int k_poisson_solve_slab(udc_handle *h) {
     PROF(h, "fftx_pack_fwd");
     for (int c = 0; c < nch; ++c) {
       const int k0 = c * nzc;
-      void *in[1] = {prow0 + g.sz * k0}, *out[1] = {specA_at(k0)};
-      FFT_OK(rocfft_execute(h->plan_xf, in, out, h->info_x));
-      hipLaunchKernelGGL(slab_pack_fwd_kernel, tg, tb, 0, h->stream, g, nkx, pitch, cx, P, k0, nzc,
-                         reinterpret_cast<const double2 *>(h->specA), reinterpret_cast<double2 *>(h->a2a_send + chunk * c));
+      if (h->fft_fused) {
+        if (fft_x_fwd_pack(h, k0, nzc, h->a2a_send + chunk * c)) return 1;
+      } else {
+        void *in[1] = {prow0 + g.sz * k0}, *out[1] = {specA_at(k0)};
+        FFT_OK(rocfft_execute(h->plan_xf, in, out, h->info_x));
+        hipLaunchKernelGGL(slab_pack_fwd_kernel, tg, tb, 0, h->stream, g, nkx, pitch, cx, P, k0, nzc,
+                           reinterpret_cast<const double2 *>(h->specA), reinterpret_cast<double2 *>(h->a2a_send + chunk * c));
+      }
       if (exchange(c)) return 1;
     }
     HIP_OK(hipGetLastError());
@@ -941,6 +947,10 @@ int k_poisson_solve_slab(udc_handle *h) {
     for (int c = 0; c < nch; ++c) {
       const int k0 = c * nzc;
       HIP_OK(hipStreamWaitEvent(h->stream, h->ev_done[c], 0));
+      if (h->fft_fused) {
+        if (fft_y_fwd_unpack(h, k0, nzc, h->a2a_recv + chunk * c)) return 1;
+        continue;
+      }
       hipLaunchKernelGGL(slab_unpack_fwd_kernel, lin3, dim3(lb), 0, h->stream, g, cx, P, ny, k0, nzc,
                          reinterpret_cast<const double2 *>(h->a2a_recv + chunk * c), reinterpret_cast<double2 *>(h->specB));
       void *io[1] = {specB_at(k0)};
@@ -958,10 +968,14 @@ int k_poisson_solve_slab(udc_handle *h) {
     PROF(h, "ffty_pack_bwd");
     for (int c = 0; c < nch; ++c) {
       const int k0 = c * nzc;
-      void *io[1] = {specB_at(k0)};
-      FFT_OK(rocfft_execute(h->plan_yb, io, nullptr, h->info_x));
-      hipLaunchKernelGGL(slab_pack_bwd_kernel, lin3, dim3(lb), 0, h->stream, g, cx, P, ny, k0, nzc,
-                         reinterpret_cast<const double2 *>(h->specB), reinterpret_cast<double2 *>(h->a2a_send + chunk * c));
+      if (h->fft_fused) {
+        if (fft_y_bwd_pack(h, k0, nzc, h->a2a_send + chunk * c)) return 1;
+      } else {
+        void *io[1] = {specB_at(k0)};
+        FFT_OK(rocfft_execute(h->plan_yb, io, nullptr, h->info_x));
+        hipLaunchKernelGGL(slab_pack_bwd_kernel, lin3, dim3(lb), 0, h->stream, g, cx, P, ny, k0, nzc,
+                           reinterpret_cast<const double2 *>(h->specB), reinterpret_cast<double2 *>(h->a2a_send + chunk * c));
+      }
       if (exchange(c)) return 1;
     }
     HIP_OK(hipGetLastError());
@@ -971,6 +985,10 @@ int k_poisson_solve_slab(udc_handle *h) {
     for (int c = 0; c < nch; ++c) {
       const int k0 = c * nzc;
       HIP_OK(hipStreamWaitEvent(h->stream, h->ev_done[c], 0));
+      if (h->fft_fused) {
+        if (fft_x_bwd_unpack(h, k0, nzc, h->a2a_recv + chunk * c)) return 1;
+        continue;
+      }
       hipLaunchKernelGGL(slab_unpack_bwd_kernel, tg, tb, 0, h->stream, g, nkx, pitch, cx, P, k0, nzc,
                          reinterpret_cast<const double2 *>(h->a2a_recv + chunk * c), reinterpret_cast<double2 *>(h->specA));
       void *in[1] = {specA_at(k0)}, *out[1] = {prow0 + g.sz * k0};
@@ -998,6 +1016,7 @@ void pois_destroy(udc_handle *h) {
   if (h->info_x) rocfft_execution_info_destroy(h->info_x);
   if (h->comm_stream) hipStreamDestroy(h->comm_stream);
   for (int c = 0; c < 16; ++c) { if (h->ev_ready[c]) hipEventDestroy(h->ev_ready[c]); if (h->ev_done[c]) hipEventDestroy(h->ev_done[c]); }
+  if (h->fft_tw) hipFree(h->fft_tw);
   double *bufs[7] = {h->specA, h->specB, h->a2a_send, h->a2a_recv, h->ev_slab, h->ztab_slab, (double *)h->fft_work_slab};
   for (auto b : bufs) if (b) hipFree(b);
 }
