@@ -3,7 +3,8 @@
 
 The CPU side is the reference's own Fortran (oracle/_ref/udales_ref, built by oracle/Makefile from
 /root/reference/src; the binary travels to the GPU box).  Default size 64^3 (BASELINE configs[0]'s
-plumbing size, ~30 s of CPU); UDC_LONG_SIZE=128 or 256 runs the larger cases (minutes of CPU).
+plumbing size) is covered by the fixtures; the default here is 128^3 (~1 min of CPU), UDC_LONG_SIZE=256 runs BASELINE
+configs[1] itself (~10 min of CPU).
 """
 import os
 import subprocess
@@ -27,7 +28,7 @@ def test_100_steps_against_reference_cpu(tmp_path):
     from bench import write_deck
     import udcore
     from udcore import read_deck, cold_start
-    n = int(os.environ.get("UDC_LONG_SIZE", "64"))
+    n = int(os.environ.get("UDC_LONG_SIZE", "128"))
     nsub = 300
     path = write_deck(str(tmp_path), 77, n, n, n, nsub)
     with open(path) as f:
@@ -64,7 +65,7 @@ def test_100_steps_all_physics_against_reference_cpu(tmp_path):
     import udcore
     from udcore import read_deck, cold_start
     from udcore.forcings import LevelForcings
-    n = int(os.environ.get("UDC_LONG_SIZE", "64"))
+    n = int(os.environ.get("UDC_LONG_SIZE", "128"))
     nz = 48
     nsub = 300
     dz = 0.5

@@ -835,8 +835,11 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
     const int fvp[1] = {UDC_VP};
     if (k_halo_y(h, fvp, 1, 1)) return 1;
   }
-  if (k_divergence_rhs(h, rk3coef, pup)) return 1;
+  // slab path with the own line FFTs: fillps' divergence is evaluated inside the x forward transform (udc_fft.hip)
+  h->div_in_fft = pup && h->slab && h->fft_fused && !(getenv("UDC_DIV_IN_FFT") && atoi(getenv("UDC_DIV_IN_FFT")) == 0);
+  if (!h->div_in_fft && k_divergence_rhs(h, rk3coef, pup)) return 1;
   if (k_poisson_solve(h)) return 1;
+  h->div_in_fft = false;
   if (!fold) {
     const int fp[1] = {UDC_P};
     if (k_halo_y(h, fp, 1, 1)) return 1;

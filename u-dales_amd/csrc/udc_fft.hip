@@ -107,9 +107,13 @@ __device__ __forceinline__ void x_lds(const XArgs &q, double2 *lds, double2 *&a,
   for (int kx = threadIdx.x; kx < q.cx * q.P; kx += FT) dmap[kx] = kx / q.cx;
 }
 
+// fillps folded into the x forward transform (fused substep, PUP mode): the row is not read from p but evaluated as
+// the divergence of (pup, pvp, pwp) (src/modpois.f90:968-970; pwp(ke+1) = 0 of bcpup), which then never exists in memory
+struct DivArgs { const double *pu, *pv, *pw; const double *dzfi; double dxi, dyi; int nz; };
+
 // x forward: rows j0..j0+L-1 of plane k0+kc -> send blocks
-template <int LM>
-__global__ __launch_bounds__(FT) void fftx_fwd_pack_kernel(XArgs q, const double *__restrict__ p, const double2 *__restrict__ twM,
+template <int LM, bool DIV>
+__global__ __launch_bounds__(FT) void fftx_fwd_pack_kernel(XArgs q, const double *__restrict__ p, DivArgs dv, const double2 *__restrict__ twM,
                                                            const double2 *__restrict__ twN, double2 *__restrict__ send) {
   extern __shared__ double2 lds[];
   constexpr int M = 1 << LM;
@@ -120,8 +124,19 @@ __global__ __launch_bounds__(FT) void fftx_fwd_pack_kernel(XArgs q, const double
   // load: row l holds M complex = nx reals, read as double2 (16-B aligned: nx even, rows nx*8 B apart, base 16-B aligned)
   for (int wi = tid; wi < (M << q.lL); wi += FT) {
     const int l = wi >> LM, n = wi & (M - 1);
-    const double2 *row = reinterpret_cast<const double2 *>(p + q.sz * (long)(k + HZ) + (long)q.nx * (j0 + l + HY));
-    a[l * q.MP + pad(n)] = row[n];
+    const long ro = q.sz * (long)(k + HZ) + (long)q.nx * (j0 + l + HY);
+    if (DIV) {
+      const double2 *ru = reinterpret_cast<const double2 *>(dv.pu + ro), *rv = reinterpret_cast<const double2 *>(dv.pv + ro);
+      const double2 *rv1 = reinterpret_cast<const double2 *>(dv.pv + ro + q.nx), *rw = reinterpret_cast<const double2 *>(dv.pw + ro);
+      const double2 u = ru[n], un = ru[(n + 1) & (M - 1)], v = rv[n], v1 = rv1[n], w = rw[n];
+      double2 w1 = make_double2(0., 0.);
+      if (k < dv.nz - 1) w1 = reinterpret_cast<const double2 *>(dv.pw + ro + q.sz)[n];
+      const double dz = dv.dzfi[k + 1];
+      a[l * q.MP + pad(n)] = make_double2((u.y - u.x) * dv.dxi + (v1.x - v.x) * dv.dyi + (w1.x - w.x) * dz,
+                                          (un.x - u.y) * dv.dxi + (v1.y - v.y) * dv.dyi + (w1.y - w.y) * dz);
+    } else {
+      a[l * q.MP + pad(n)] = reinterpret_cast<const double2 *>(p + ro)[n];
+    }
   }
   __syncthreads();
   double2 *z = fft_lines<false, LM>(a, b, tw, q.MP, L);
@@ -285,7 +300,8 @@ int fft_fused_init(udc_handle *h) {
   if (ldsx > 160 * 1024 || ldsy > 160 * 1024) { h->fft_fused = false; return 0; }
   const int lmx = ilog2(M), lmy = ilog2(ny);
   if (ldsx > 65536) {
-    FFT_DISPATCH(lmx, HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(fftx_fwd_pack_kernel<LM>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsx));
+    FFT_DISPATCH(lmx, HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(fftx_fwd_pack_kernel<LM, false>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsx));
+                      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(fftx_fwd_pack_kernel<LM, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsx));
                       HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(fftx_bwd_unpack_kernel<LM>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsx)))
   }
   if (ldsy > 65536) {
@@ -309,8 +325,14 @@ int fft_x_fwd_pack(udc_handle *h, int k0, int nzc, double *send) {
   const double2 *tw = reinterpret_cast<const double2 *>(h->fft_tw);
   const dim3 gr((unsigned)(q.nyl >> q.lL), (unsigned)nzc);
   const size_t lds = x_lds_bytes(h, h->fft_L);
-  FFT_DISPATCH(ilog2(q.M), hipLaunchKernelGGL(fftx_fwd_pack_kernel<LM>, gr, dim3(FT), lds, h->stream, q, (const double *)h->fields[UDC_P], tw,
-                                              tw + q.M, reinterpret_cast<double2 *>(send)))
+  const DivArgs dv{h->fields[UDC_UP], h->fields[UDC_VP], h->fields[UDC_WP], h->m.dzfi, h->m.dxi, h->m.dyi, h->g.nz};
+  if (h->div_in_fft) {
+    FFT_DISPATCH(ilog2(q.M), hipLaunchKernelGGL((fftx_fwd_pack_kernel<LM, true>), gr, dim3(FT), lds, h->stream, q, (const double *)h->fields[UDC_P], dv,
+                                                tw, tw + q.M, reinterpret_cast<double2 *>(send)))
+  } else {
+    FFT_DISPATCH(ilog2(q.M), hipLaunchKernelGGL((fftx_fwd_pack_kernel<LM, false>), gr, dim3(FT), lds, h->stream, q, (const double *)h->fields[UDC_P], dv,
+                                                tw, tw + q.M, reinterpret_cast<double2 *>(send)))
+  }
   HIP_OK(hipGetLastError());
   return 0;
 }

@@ -221,6 +221,7 @@ struct udc_handle {
   bool fft_fused = false;
   double *fft_tw = nullptr;             // twiddle tables
   int fft_L = 0, fft_C = 0;             // x rows / y columns per workgroup
+  bool div_in_fft = false;              // this solve: the x forward transform evaluates fillps' divergence itself
 };
 
 void udc_set_error(const char *fmt, ...);

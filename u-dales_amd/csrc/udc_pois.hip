@@ -919,10 +919,15 @@ int k_poisson_solve_slab(udc_handle *h) {
   auto specB_at = [&](int k0) { return h->specB + (size_t)2 * nmodes * k0; };
   // the exchange of chunk c runs on the communication stream while the compute stream transforms and
   // packs chunk c+1 (forward) / unpacks and transforms chunk c-1: xGMI transfers hide behind rocFFT
+  // one rank without a communicator (UDC_FORCE_SLAB on a single GPU): the exchange is the identity, the "received"
+  // blocks are the packed ones
+  const bool self = P == 1 && !h->nccl && !h->local_group;
+  double *const rbuf = self ? h->a2a_send : h->a2a_recv;
   auto exchange = [&](int c) -> int {
+    if (self) return 0;
     HIP_OK(hipEventRecord(h->ev_ready[c], h->stream));
     HIP_OK(hipStreamWaitEvent(h->comm_stream, h->ev_ready[c], 0));
-    if (comm_alltoall(h, h->a2a_send + chunk * c, h->a2a_recv + chunk * c, block, h->comm_stream)) return 1;
+    if (comm_alltoall(h, h->a2a_send + chunk * c, rbuf + chunk * c, block, h->comm_stream)) return 1;
     HIP_OK(hipEventRecord(h->ev_done[c], h->comm_stream));
     return 0;
   };
@@ -946,13 +951,13 @@ int k_poisson_solve_slab(udc_handle *h) {
     PROF(h, "unpack_ffty_fwd");
     for (int c = 0; c < nch; ++c) {
       const int k0 = c * nzc;
-      HIP_OK(hipStreamWaitEvent(h->stream, h->ev_done[c], 0));
+      if (!self) HIP_OK(hipStreamWaitEvent(h->stream, h->ev_done[c], 0));
       if (h->fft_fused) {
-        if (fft_y_fwd_unpack(h, k0, nzc, h->a2a_recv + chunk * c)) return 1;
+        if (fft_y_fwd_unpack(h, k0, nzc, rbuf + chunk * c)) return 1;
         continue;
       }
       hipLaunchKernelGGL(slab_unpack_fwd_kernel, lin3, dim3(lb), 0, h->stream, g, cx, P, ny, k0, nzc,
-                         reinterpret_cast<const double2 *>(h->a2a_recv + chunk * c), reinterpret_cast<double2 *>(h->specB));
+                         reinterpret_cast<const double2 *>(rbuf + chunk * c), reinterpret_cast<double2 *>(h->specB));
       void *io[1] = {specB_at(k0)};
       FFT_OK(rocfft_execute(h->plan_yf, io, nullptr, h->info_x));
     }
@@ -984,13 +989,13 @@ int k_poisson_solve_slab(udc_handle *h) {
     PROF(h, "unpack_fftx_bwd");
     for (int c = 0; c < nch; ++c) {
       const int k0 = c * nzc;
-      HIP_OK(hipStreamWaitEvent(h->stream, h->ev_done[c], 0));
+      if (!self) HIP_OK(hipStreamWaitEvent(h->stream, h->ev_done[c], 0));
       if (h->fft_fused) {
-        if (fft_x_bwd_unpack(h, k0, nzc, h->a2a_recv + chunk * c)) return 1;
+        if (fft_x_bwd_unpack(h, k0, nzc, rbuf + chunk * c)) return 1;
         continue;
       }
       hipLaunchKernelGGL(slab_unpack_bwd_kernel, tg, tb, 0, h->stream, g, nkx, pitch, cx, P, k0, nzc,
-                         reinterpret_cast<const double2 *>(h->a2a_recv + chunk * c), reinterpret_cast<double2 *>(h->specA));
+                         reinterpret_cast<const double2 *>(rbuf + chunk * c), reinterpret_cast<double2 *>(h->specA));
       void *in[1] = {specA_at(k0)}, *out[1] = {prow0 + g.sz * k0};
       FFT_OK(rocfft_execute(h->plan_xb, in, out, h->info_x));
     }
