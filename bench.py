@@ -210,6 +210,52 @@ def cpu_baseline(nx, ny, nz, budget_s=25.0):
     return out
 
 
+
+def single_gpu_leg(nx, ny, nz, dt, args, device, ms_n, poisson_n, poisson_sub_n):
+    """One GPU, the same grid, the single-slab code path: cheap start state (uniform flow + noise), timing only."""
+    import numpy as np
+    import torch
+    import udcore
+    from udcore import read_deck
+    with tempfile.TemporaryDirectory() as tmp:
+        deck1 = read_deck(write_deck(tmp, 903, nx, ny, nz, 0, dt=dt, nprocy=1, nsv=args.nsv, sgs=args.sgs, floor=not args.no_floor))
+    c1 = udcore.from_deck(deck1, device=device, rank=0, nranks=1)
+    rng = np.random.default_rng(43)
+    noise = 0.02 * (rng.random(c1.g.mshape()) - 0.5)
+    for k, base in (("u0", 1.0), ("v0", 0.0), ("w0", 0.0)):
+        a = noise + base
+        c1.upload(k, a)
+        c1.upload(k.replace("0", "m"), a)
+    del noise, a
+    c1.halos()
+    c1.boundary()
+
+    def sync1():
+        torch.cuda.synchronize()
+        c1.sync()
+    rk1 = [1]
+
+    def step1():
+        c1.substep(rk1[0], dt, True)
+        rk1[0] = rk1[0] % 3 + 1
+    for _ in range(6):
+        step1()
+    n1 = max(6, min(args.steps, 30))
+    c1.profile(True)
+    c1.profile_reset()
+    ms1 = time_loop(c1, step1, n1, sync1)
+    prof1 = c1.profile_get()
+    c1.profile(False)
+    nonpois = sum(ms for name, (ms, cnt) in prof1.items() if name.startswith(("closure", "mom_", "bottom", "scalar"))) / n1
+    c1.rk3step, c1.dt = 1, dt
+    for _ in range(3):
+        c1.poisson()
+    p1 = time_loop(c1, c1.poisson, 10, sync1)
+    c1.close()
+    return {"ms_per_step": round(ms1, 5), "poisson_only_ms": round(p1, 5), "poisson_in_substep_ms": round(ms1 - nonpois, 5),
+            "steps": n1, "speedup_substep": round(ms1 / ms_n, 3), "speedup_poisson": round(p1 / poisson_n, 3),
+            "speedup_poisson_in_substep": round((ms1 - nonpois) / poisson_sub_n, 3)}
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,6 +264,7 @@ def main():
     ap.add_argument("--size", type=str, default="", help="override grid, e.g. 256x256x256")
     ap.add_argument("--weak", action="store_true", help="N>1: one 256^3 slab per GPU (weak scaling) instead of 1024x512x512 split N ways")
     ap.add_argument("--no-single", action="store_true", help="N>1: skip rank 0's one-GPU run of the same grid")
+    ap.add_argument("--with-single", action="store_true", help="N=1: run that leg anyway (exercises the code path on a one-GPU box)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-dropin", action="store_true", help="skip the Fortran drop-in leg")
     ap.add_argument("--nsv", type=int, default=0, help="passive scalars (kappa scheme), BASELINE configs[2]")
@@ -312,6 +359,10 @@ def main():
     for _ in range(3):
         core.poisson()
     poisson_ms = allmax(time_loop(core, core.poisson, 20, barrier))
+    # the same solve as the fused substep runs it (pup mode: the divergence of the stored predicted velocity, on the slab
+    # path inside the x transform; projection fused with the RK3 update): substep time minus its non-Poisson kernels
+    nonpois = sum(ms for name, (ms, cnt) in prof.items() if name.startswith(("closure", "mom_", "bottom", "scalar"))) / max(args.steps, 1)
+    poisson_in_substep_ms = elapsed / args.steps * 1e3 - nonpois
 
     cells = nx * ny * nz
     cells_local = nx * nyl * nz
@@ -376,43 +427,21 @@ def main():
         "whole_substep_hbm_frac": round(392.0 * cells_local * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4),
         "divmax_after_run": divmax,
         "poisson_only_ms": round(poisson_ms, 5),
+        "poisson_in_substep_ms": round(poisson_in_substep_ms, 5),
         "roofline": roofline,
         "kernels": kernels,
     }
-    if world > 1 and not args.no_single:
+    if (world > 1 and not args.no_single) or args.with_single:
         # rank 0's own one-GPU run of the SAME grid (single-slab code path), so that every N>1 line carries its strong-scaling
-        # reference; the other ranks wait at the barrier below.  Cheap start state (uniform flow + noise): timing only.
+        # reference; the other ranks wait at the barrier below
         single = None
         if rank == 0:
-            with tempfile.TemporaryDirectory() as tmp:
-                deck1 = read_deck(write_deck(tmp, 903, nx, ny, nz, 0, dt=dt, nprocy=1, nsv=args.nsv, sgs=args.sgs, floor=not args.no_floor))
-            c1 = udcore.from_deck(deck1, device=local_rank, rank=0, nranks=1)
-            rng = np.random.default_rng(43)
-            noise = 0.02 * (rng.random(c1.g.mshape()) - 0.5)
-            for k, base in (("u0", 1.0), ("v0", 0.0), ("w0", 0.0)):
-                a = noise + base
-                c1.upload(k, a); c1.upload(k.replace("0", "m"), a)
-            del noise, a
-            c1.halos(); c1.boundary()
-            sync1 = lambda: (torch.cuda.synchronize(), c1.sync())      # noqa: E731
-            rk1 = [1]
-
-            def step1():
-                c1.substep(rk1[0], dt, True)
-                rk1[0] = rk1[0] % 3 + 1
-            for _ in range(6):
-                step1()
-            n1 = max(6, min(args.steps, 30))
-            ms1 = time_loop(c1, step1, n1, sync1)
-            c1.rk3step, c1.dt = 1, dt
-            for _ in range(3):
-                c1.poisson()
-            p1 = time_loop(c1, c1.poisson, 10, sync1)
-            c1.close()
-            single = {"ms_per_step": round(ms1, 5), "poisson_only_ms": round(p1, 5), "steps": n1,
-                      "speedup_substep": round(ms1 / (elapsed / args.steps * 1e3), 3),
-                      "speedup_poisson": round(p1 / poisson_ms, 3)}
-        dist.barrier()
+            try:
+                single = single_gpu_leg(nx, ny, nz, dt, args, local_rank, elapsed / args.steps * 1e3, poisson_ms, poisson_in_substep_ms)
+            except Exception as e:      # noqa: BLE001 (a side measurement: never let it take the bench line down)
+                single = {"error": repr(e)[:300]}
+        if world > 1:
+            dist.barrier()
         out["single_gpu_same_workload"] = single
     if rank == 0:
         if world == 1 and not args.no_cpu:

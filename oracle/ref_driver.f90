@@ -25,6 +25,8 @@
 !   kernels  : spin-up nspin substeps, then call each reference routine separately
 !              and dump inputs/outputs (per-kernel golden vectors)
 !   time     : nsub substeps (after nwarm untimed ones) timed with MPI_Wtime exactly like src/modmpi.f90:140-160
+!   poisson1 : one analytic eigenmode (&ORACLE pmode) through the reference's whole `poisson`; dumps p, the exact p and the
+!              projected tendencies
 !   restart  : nsub substeps (a multiple of 3), then the reference's own writerestartfiles
 !              (src/modsave.f90:37-128) writes initd/inits files into the working directory; the state
 !              is also dumped as 'rst.*' records so that readers of the restart format can be checked
@@ -64,6 +66,7 @@ program ref_driver
 
   character(256) :: mode, outfile, arg
   integer :: nsub = 3, nspin = 2, nwarm = 0
+  integer :: pmode(3) = (/1, 0, 0/)      ! mode `poisson1`: wavenumbers (x, y, z) of the analytic pressure field
   integer :: dump_at(16) = -1
   logical :: lforces = .true.
 #ifdef UDC_DROPIN
@@ -77,7 +80,7 @@ program ref_driver
   integer(KIND=selected_int_kind(6)) :: irandom = 43
   integer :: krand = huge(0)
   real :: randu = 0.01
-  namelist /ORACLE/ nsub, nspin, nwarm, dump_at, lforces, scal_a, scal_b
+  namelist /ORACLE/ nsub, nspin, nwarm, dump_at, lforces, scal_a, scal_b, pmode
 
   call initmpi
   if (command_argument_count() < 3) then
@@ -133,6 +136,8 @@ program ref_driver
       call one_substep
     end do
     call kernel_vectors
+  case ('poisson1')
+    call analytic_poisson
   case ('restart')
     do isub = 1, nsub
       call one_substep
@@ -168,6 +173,7 @@ program ref_driver
       ' itot=', itot, ' jtot=', jtot, ' ranks=', nprocs, ' substeps=', nsub, ' seconds=', t1 - t0, &
       ' cell_updates_per_s=', real(itot)*real(jtot)*real(ktot)*real(nsub)/(t1 - t0), &
       ' sum_u0sq=', chk_u2, ' divmax=', chk_div
+    call more_checks
   case default
     write (0, *) 'unknown mode ', trim(mode)
     stop 1
@@ -204,6 +210,62 @@ contains
     call MPI_ALLREDUCE(u2l, u2, 1, MY_REAL, MPI_SUM, comm3d, ierr)
     call MPI_ALLREDUCE(dl, dmax, 1, MY_REAL, MPI_MAX, comm3d, ierr)
   end subroutine global_checks
+
+  !> One analytic mode through the reference's whole `poisson` (fillps, the FFTs with their half-complex packing and
+  !! normalisation, solmpj, tderive): on a uniform grid p*(i,j,k) = cos(2 pi m (i-1)/itot) cos(2 pi n (j-1)/jtot)
+  !! cos(pi l (k-1/2)/ktot) is an eigenvector of the discrete Laplacian the solver inverts (periodic x, y; Neumann floor
+  !! and top).  The tendencies are set to its discrete gradient (um = 0), so that fillps' right-hand side is L_h p* / 1
+  !! and the solve must return p* itself; tderive must then remove the whole tendency.  Dumps p, p* and the projected up.
+  subroutine analytic_poisson
+    real, allocatable :: pe(:, :, :)
+    integer :: i, j, k
+    allocate (pe(ib - ih:ie + ih, jb - jh:je + jh, kb - kh:ke + kh))
+    do k = kb - kh, ke + kh
+      do j = jb - jh, je + jh
+        do i = ib - ih, ie + ih
+          pe(i, j, k) = cos(2.*pi*pmode(1)*real(i - 1 + zstart(1) - 1)/real(itot))*cos(2.*pi*pmode(2)*real(j - 1 + zstart(2) - 1)/real(jtot)) &
+                        *cos(pi*pmode(3)*(real(k) - 0.5)/real(ktot))
+        end do
+      end do
+    end do
+    um = 0.; vm = 0.; wm = 0.; up = 0.; vp = 0.; wp = 0.; pres0 = 0.
+    do k = kb, ke
+      do j = jb, je
+        do i = ib, ie
+          up(i, j, k) = (pe(i, j, k) - pe(i - 1, j, k))*dxi
+          vp(i, j, k) = (pe(i, j, k) - pe(i, j - 1, k))*dyi
+          if (k > kb) wp(i, j, k) = (pe(i, j, k) - pe(i, j, k - 1))*dzhi(k)
+        end do
+      end do
+    end do
+    rk3step = 1; dt = dtmax
+    call put3('ana.upin', up, (/ib - ih, jb - jh, kb/))
+    call put3('ana.vpin', vp, (/ib - ih, jb - jh, kb/))
+    call put3('ana.wpin', wp, (/ib - ih, jb - jh, kb/))
+    call poisson
+    call put3('ana.p', p, (/ib - ih, jb - jh, kb - kh/))
+    call put3('ana.pexact', pe, (/ib - ih, jb - jh, kb - kh/))
+    call put3('ana.up', up, (/ib - ih, jb - jh, kb/))
+    call put3('ana.wp', wp, (/ib - ih, jb - jh, kb/))
+  end subroutine analytic_poisson
+
+  !> decomposition-independent sums of squares of every prognostic field (interior cells), for comparing the single-rank
+  !! build with the multi-rank one deck by deck (tests/test_oracle_mpi.py)
+  subroutine more_checks
+    real :: loc(6 + max(nsv, 1)), tot(6 + max(nsv, 1))
+    integer :: n, ierr
+    loc = 0.
+    loc(1) = sum(v0(ib:ie, jb:je, kb:ke)**2); loc(2) = sum(w0(ib:ie, jb:je, kb:ke)**2)
+    loc(3) = sum(pres0(ib:ie, jb:je, kb:ke)**2)
+    if (ltempeq) loc(4) = sum(thl0(ib:ie, jb:je, kb:ke)**2)
+    if (lmoist) loc(5) = sum(qt0(ib:ie, jb:je, kb:ke)**2)
+    if (loneeqn) loc(6) = sum(e120(ib:ie, jb:je, kb:ke)**2)
+    do n = 1, nsv
+      loc(6 + n) = sum(sv0(ib:ie, jb:je, kb:ke, n)**2)
+    end do
+    call MPI_ALLREDUCE(loc, tot, size(loc), MY_REAL, MPI_SUM, comm3d, ierr)
+    if (myid == 0) write (6, '(a,20es24.15)') 'REF_SUMSQ ', tot
+  end subroutine more_checks
 
   character(4) function tag4(i)
     integer, intent(in) :: i

@@ -732,3 +732,33 @@ def test_um_alias_and_mixed_api():
         a, b = mix.download(k)[1:-1], ref.download(k)[1:-1]
         assert relerr(nocorner(a), nocorner(b)) <= 1e-12, k
     ref.close(); mix.close()
+
+
+@pytest.mark.parametrize("shape,pmode", [((64, 32, 16), (5, 2, 1)), ((32, 48, 12), (16, 24, 0)), ((20, 12, 10), (3, 1, 7))])
+def test_poisson_returns_an_analytic_eigenmode(shape, pmode):
+    """p* = cos(2 pi m x) cos(2 pi n y) cos(pi l z) is an eigenvector of the discrete operator `poisson` inverts (uniform
+    grid, periodic x / y, Neumann floor and top): fed its discrete gradient as tendencies (um = 0), udc_poisson must
+    return p* and project the tendencies to zero -- an answer that involves no FFT (same check as on the reference's
+    own poisson, tests/test_oracle_vs_reference.py)."""
+    from udcore.core import DynCore
+    from udcore.grid import Grid
+    nx, ny, nz = shape
+    g = Grid.uniform(nx, ny, nz)
+    core = DynCore(g, sgs=L.SGS_VREMAN)
+    i = np.arange(-1, nx + 1)[None, None, :]
+    j = np.arange(-1, ny + 1)[None, :, None]
+    k = np.arange(0, nz + 2)[:, None, None]
+    pe = np.cos(2 * np.pi * pmode[0] * i / nx) * np.cos(2 * np.pi * pmode[1] * j / ny) * np.cos(np.pi * pmode[2] * (k - 0.5) / nz)
+    up, vp, wp = (np.zeros(g.mshape()) for _ in range(3))
+    up[1:-1, 1:-1, 1:-1] = (pe[1:-1, 1:-1, 1:-1] - pe[1:-1, 1:-1, :-2]) / g.dx
+    vp[1:-1, 1:-1, 1:-1] = (pe[1:-1, 1:-1, 1:-1] - pe[1:-1, :-2, 1:-1]) / g.dy
+    wp[2:-1, 1:-1, 1:-1] = (pe[2:-1, 1:-1, 1:-1] - pe[1:-2, 1:-1, 1:-1]) / g.dzh[2:nz + 1, None, None]
+    for name, a in (("up", up), ("vp", vp), ("wp", wp)):
+        core.upload(name, a)
+    core.rk3step, core.dt = 1, 0.3
+    core.poisson()
+    p = core.download("p")
+    assert np.abs(interior(p) - interior(pe)).max() <= 5e-13
+    for name in ("up", "vp", "wp"):
+        assert np.abs(interior(core.download(name))).max() <= 5e-12
+    core.close()

@@ -1,7 +1,10 @@
 """The all-cores CPU baseline (oracle/_ref/udales_ref_mpi: reference Fortran + MPICH + the y-slab
 decomposition shim oracle/shims/decomp_2d_mpi.f90) must be decomposition invariant, like the
 reference's own processor_boundaries test demands of 2decomp-fft
-(tests/integration/processor_boundaries/test_processor_boundaries.py:28-34)."""
+(tests/integration/processor_boundaries/test_processor_boundaries.py:28-34) -- and, deck by deck, give what the
+single-rank build (oracle/shims/decomp_2d_np1.f90, the one every golden fixture comes from) gives: the two stand-ins
+for the absent 2decomp-fft are written independently (copies vs MPI_ALLTOALL / MPI_SENDRECV), so their agreement on
+every run deck is a check of both."""
 import os
 import re
 import shutil
@@ -22,18 +25,50 @@ def run(cmd, cwd):
                        timeout=300, executable="/bin/bash")
     m = re.search(r"sum_u0sq=\s*([0-9.Ee+-]+)\s+divmax=\s*([0-9.Ee+-]+)", r.stdout)
     assert m, r.stdout[-1000:] + r.stderr[-1000:]
-    return float(m.group(1)), float(m.group(2))
+    s = re.search(r"REF_SUMSQ\s+(.*)", r.stdout)
+    sums = [float(x) for x in s.group(1).split()] if s else []
+    return float(m.group(1)), float(m.group(2)), sums
+
+
+def _have():
+    return os.path.exists(REF) and os.path.exists(REF_MPI) and os.path.exists(MPIEXEC)
 
 
 def test_mpi_baseline_is_decomposition_invariant(tmp_path):
-    if not (os.path.exists(REF) and os.path.exists(REF_MPI) and os.path.exists(MPIEXEC)):
+    if not _have():
         pytest.skip("reference CPU builds or MPICH not available here")
     name, iexp = "run_16x16x8", RUN_CASES["run_16x16x8"]
     for fn in os.listdir(os.path.join(GOLDEN, "cases", name)):
         shutil.copy(os.path.join(GOLDEN, "cases", name, fn), tmp_path)
     deck = f"namoptions.{iexp:03d}"
-    s1, d1 = run(f"{REF} {deck} time x.bin", tmp_path)
+    s1, d1, _ = run(f"{REF} {deck} time x.bin", tmp_path)
     for p in (2, 4, 8):
-        sp, dp = run(f"{MPIEXEC} -n {p} {REF_MPI} {deck} time x.bin", tmp_path)
+        sp, dp, _ = run(f"{MPIEXEC} -n {p} {REF_MPI} {deck} time x.bin", tmp_path)
         assert abs(sp - s1) <= 1e-11 * abs(s1), (p, sp, s1)
         assert dp < 1e-12
+
+
+@pytest.mark.parametrize("name,iexp", sorted(RUN_CASES.items()))
+def test_single_rank_and_multi_rank_shims_agree(name, iexp, tmp_path):
+    """Every run deck of the golden set on 1 rank (np1 shim) and on 2 / 4 ranks (MPI shim): sums of squares of u0, v0, w0,
+    pres0 and of every transported field agree to 1e-11."""
+    if not _have():
+        pytest.skip("reference CPU builds or MPICH not available here")
+    for fn in os.listdir(os.path.join(GOLDEN, "cases", name)):
+        shutil.copy(os.path.join(GOLDEN, "cases", name, fn), tmp_path)
+    deck = f"namoptions.{iexp:03d}"
+    with open(os.path.join(tmp_path, deck)) as f:
+        txt = f.read()
+    jtot, ktot = (int(re.search(rf"{v}\s*=\s*(\d+)", txt).group(1)) for v in ("jtot", "ktot"))
+    s1, d1, q1 = run(f"{REF} {deck} time x.bin", tmp_path)
+    assert q1 and q1[0] >= 0.
+    done = 0
+    for p in (2, 4):
+        if jtot % p or ktot % p or jtot // p < 2:
+            continue
+        sp, dp, qp = run(f"{MPIEXEC} -n {p} {REF_MPI} {deck} time x.bin", tmp_path)
+        assert abs(sp - s1) <= 1e-11 * abs(s1), (p, sp, s1)
+        for a, b in zip(qp, q1):
+            assert abs(a - b) <= 1e-11 * max(abs(b), 1e-300), (p, qp, q1)
+        done += 1
+    assert done >= 1
