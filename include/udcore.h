@@ -270,6 +270,29 @@ int udc_set_deferred(udc_handle *h, int on);
 int udc_flush(udc_handle *h);
 int udc_deferred_stats(udc_handle *h, long *fused, long *unfused);
 
+/* Statistics: the time-averaged 3-D set of tdump (src/modstatsdump.f90:1137-1213 accumulation, :1557-1645 output).
+ * udc_stats_sample(h, tsamplep, tstatsdumpp) takes one sample of the current um, vm, wm, pres0 (+ thlm, qtm, svm(1..4), ekh)
+ * into the running averages X <- (X (tstatsdumpp - tsamplep) + sample tsamplep)/tstatsdumpp, levels kb..ke+kh as the
+ * reference; the caller keeps the reference's two clocks and calls it on RK stage 3 when tsamplep >= tsample
+ * (:802-811; udcore/stats.py).  udc_stats_get downloads an accumulator like udc_field_download.  The output variables
+ * are means and <ab> - <a><b> of these (ut = UMT, upwpt = UWTIK - UTIK WTIK, tketc = ((UUTC - UTC^2) + ...)/2, ...). */
+enum {
+  UDC_ST_UMT = 0, UDC_ST_VMT, UDC_ST_WMT, UDC_ST_PT,          /* um, vm, wm, pres0                               */
+  UDC_ST_UTC, UDC_ST_VTC, UDC_ST_WTC,                         /* velocities at the cell centre                   */
+  UDC_ST_UUTC, UDC_ST_VVTC, UDC_ST_WWTC,                      /* their squares                                   */
+  UDC_ST_UWTIK, UDC_ST_VWTJK, UDC_ST_UVTIJ,                   /* products at the ik, jk, ij edges                */
+  UDC_ST_UTIK, UDC_ST_WTIK, UDC_ST_VTJK, UDC_ST_WTJK, UDC_ST_UTIJ, UDC_ST_VTIJ,   /* the edge interpolations    */
+  UDC_ST_MOM_N,
+  UDC_ST_THL = UDC_ST_MOM_N,      /* + 0 thlt, + 1 thltk (half level), + 2 wthltk, + 3 thlthlt                    */
+  UDC_ST_QT = UDC_ST_THL + 4,     /* + 0 qtt, + 1 qttk, + 2 wqttk, + 3 qtqtt                                      */
+  UDC_ST_SV = UDC_ST_QT + 4,      /* scalar n < 4: UDC_ST_SV + 5 n + (0 svt, 1 svtk, 2 wsvtk, 3 svsvt, 4 svsgst)  */
+  UDC_ST_SV_STRIDE = 5,
+  UDC_ST_MAX = UDC_ST_SV + 4 * UDC_ST_SV_STRIDE
+};
+int udc_stats_enable(udc_handle *h, int on);
+int udc_stats_sample(udc_handle *h, double tsamplep, double tstatsdumpp);
+int udc_stats_get(udc_handle *h, int id, double *host, const int lb[3], const int ub[3]);
+
 /* divergence of u0 as modchecksim's chkdiv (src/modchecksim.f90:161-203): max |div|, sum div */
 int udc_divergence(udc_handle *h, double *divmax, double *divtot);
 

@@ -93,3 +93,34 @@ def test_adaptive_time_step_matches_reference():
             assert relerr(interior(got, 2), interior(carr(fix, f"{tag}.sv0_01", nz), 2)) <= 1e-9
     assert 0.3 < core.dt < dtmax            # the limiter, not dtmax, set the step
     core.close()
+
+
+@pytest.mark.gpu
+def test_cli_run_writes_tdump_statistics(tmp_path):
+    """&OUTPUT ltdump through the runner: the device accumulates (udc_stats_sample), the runner keeps the reference's sample /
+    dump clocks and writes tdump.<expnr>.npz (and NetCDF-3 when scipy is there) with the reference's variable names."""
+    name, iexp = "run_smag_scalar_16x8x12s", RUN_CASES["run_smag_scalar_16x8x12s"]
+    for fn in os.listdir(os.path.join(GOLDEN, "cases", name)):
+        shutil.copy(os.path.join(GOLDEN, "cases", name, fn), tmp_path)
+    path = os.path.join(tmp_path, f"namoptions.{iexp:03d}")
+    d = read_deck(path)
+    dt = float(d.get("RUN", "dtmax"))
+    with open(path) as f:
+        txt = f.read()
+    with open(path, "w") as f:
+        f.write(txt.replace("&ORACLE", f"&OUTPUT\nltdump = .true.\ntsample = {dt}\ntstatsdump = {3 * dt}\n/\n&ORACLE"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "run_case.py"), f"namoptions.{iexp:03d}", "--steps", "7"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("tdump written") == 2
+    z = np.load(os.path.join(tmp_path, f"tdump.{iexp:03d}.npz"))
+    assert len(z["time"]) == 2 and abs(z["time"][0] - 3 * dt) < 1e-12
+    nx, ny, nz = (int(d.get("DOMAIN", k)) for k in ("itot", "jtot", "ktot"))
+    for k in ("ut", "vt", "wt", "pt", "upwpt", "tketc", "sca1t", "wpsca1pt", "sca1psca1pt", "sv1sgs"):
+        assert z[f"{k}.0"].shape == (nz, ny, nx), k
+    assert 0.8 < z["ut.1"].mean() < 1.2 and z["tketc.1"].min() > -1e-12 and z["tketc.1"].max() > 0.
+    if os.path.exists(os.path.join(tmp_path, f"tdump.{iexp:03d}.nc")):
+        from scipy.io import netcdf_file
+        with netcdf_file(os.path.join(tmp_path, f"tdump.{iexp:03d}.nc"), "r", mmap=False) as f:
+            assert f.variables["ut"].shape == (2, nz, ny, nx)
+            assert np.abs(f.variables["ut"][1] - z["ut.1"]).max() < 1e-6

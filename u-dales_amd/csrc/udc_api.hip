@@ -220,6 +220,7 @@ extern "C" int udc_destroy(udc_handle *h) {
   pois_destroy(h);
   comm_destroy(h);
   ibm_destroy(h);
+  stats_destroy(h);
   for (int q = 0; q < 4; ++q) if (h->halo_buf[q]) hipFree(h->halo_buf[q]);
   for (auto &f : h->level_forcings) { if (f.A) hipFree(f.A); if (f.stage) hipHostFree(f.stage); if (f.copied) hipEventDestroy(f.copied); }
   for (double *p : h->fields) if (p) hipFree(p);
@@ -259,12 +260,18 @@ static int field_ptr(udc_handle *h, int field, double **p) {
 static int tend_clean(udc_handle *h);
 static int um_materialise(udc_handle *h);
 
+static int copy3d_ptr(udc_handle *h, int field, double *dev, double *host, const int lb[3], const int ub[3], bool up);
 static int copy3d(udc_handle *h, int field, double *host, const int lb[3], const int ub[3], bool up) {
   double *dev;
   if (field_ptr(h, field, &dev)) return 1;
   if (((field >= UDC_UP && field <= UDC_WP) || (field >= UDC_SV0 && (field - UDC_SV0) % 3 == 2)) && tend_clean(h)) return 1;
   if (field >= UDC_UM && field <= UDC_WM && um_materialise(h)) return 1;
+  if (field >= UDC_UM && field <= UDC_WM && field_ptr(h, field, &dev)) return 1;
   if (up) h->halos_fresh = h->boundary_fresh = h->thermo_fresh = false;
+  return copy3d_ptr(h, field, dev, host, lb, ub, up);
+}
+
+static int copy3d_ptr(udc_handle *h, int field, double *dev, double *host, const int lb[3], const int ub[3], bool up) {
   const Geo &g = h->g;
   const int hnx = ub[0] - lb[0] + 1, hny = ub[1] - lb[1] + 1;
   int i0 = lb[0] > 1 ? lb[0] : 1, i1 = ub[0] < g.nx ? ub[0] : g.nx;
@@ -303,6 +310,14 @@ extern "C" int udc_field_upload(udc_handle *h, int field, const double *host, co
 extern "C" int udc_field_download(udc_handle *h, int field, double *host, const int lb[3], const int ub[3]) {
   ENTRY_FLUSH(h);
   return copy3d(h, field, host, lb, ub, false);
+}
+
+double *stats_ptr(udc_handle *h, int id);
+extern "C" int udc_stats_get(udc_handle *h, int id, double *host, const int lb[3], const int ub[3]) {
+  ENTRY_FLUSH(h);
+  double *dev = stats_ptr(h, id);
+  if (!dev) { udc_set_error("udc_stats_get: statistic %d is not being accumulated", id); return 1; }
+  return copy3d_ptr(h, -1, dev, host, lb, ub, false);
 }
 
 extern "C" int udc_set_forcing(udc_handle *h, const double *dpdxl, const double *dpdyl, int n) {

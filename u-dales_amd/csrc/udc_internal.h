@@ -181,6 +181,9 @@ struct udc_handle {
   };
   IbmGrid ibm[4];
   bool ibm_on = false;
+  // statistics accumulators (udc_stats.hip), UDC_ST_* ids
+  std::vector<double *> stats;
+  bool stats_on = false;
   // deferred execution (udc_set_deferred): the tendency routines of one RK3 substep are recorded instead of launched;
   // udc_tstep_integrate then runs the recorded sequence -- as the fused substep when it is the reference's own
   // (src/program.f90:142-197), routine by routine otherwise.  pend holds OP_* bits in call order.
@@ -293,6 +296,7 @@ int k_vreman_buoycorr(udc_handle *h);            // ekm *= sqrt(1 - min(max(Rig,
 int k_ibm_wallfun(udc_handle *h);                // diffu/v/w/c_corr at the fluid-boundary points
 int k_ibm_norm(udc_handle *h);                   // solid: velocities zeroed, scalars to the mean of their fluid neighbours
 void ibm_destroy(udc_handle *h);
+void stats_destroy(udc_handle *h);
 int udc_flush_pending(udc_handle *h);
 int k_tke_floor(udc_handle *h);                    // e120(kb-1) = e120(kb), e12m likewise (`bottom`)                     // wp += grav (thv0h - thvh)/thvh, src/modforces.f90:73-84   // cp(i,j,k) += src(k)
 int k_maxima(udc_handle *h, double dt, double *cour, double *diffn);

@@ -116,6 +116,11 @@ def main(argv=None):
         dt = dtmax if not ladaptive else dtmax / 100.          # src/modstartup.f90:1099, 2038
     core.dt, core.timee, core.rk3step = dt, timee, 0
     forcings = LevelForcings(core, deck)
+    tdump = None
+    if bool(deck.get("OUTPUT", "ltdump")):                  # time-averaged 3-D statistics (src/modstatsdump.f90, tdump)
+        from .stats import TDump
+        tdump = TDump(core, float(deck.get("OUTPUT", "tsample")), float(deck.get("OUTPUT", "tstatsdump")),
+                      float(deck.get("OUTPUT", "tstatstart")), wdir=wdir, expnr=iexp)
     # (the reference restarts the restart clock and the step counter on a warm start: tnextrestart = trestart,
     # ntrun = 0, src/modglobal.f90:869; this runner keeps counting from the file it started from, so that the files
     # of a continued run do not overwrite those of the first leg)
@@ -129,6 +134,8 @@ def main(argv=None):
             rk, dt = core.tstep_update(dtmax, ladaptive, courant, diffnr)
             forcings.update(rk, dt)
             core.substep(rk, dt, with_forces=True)
+            if tdump is not None and tdump.step(rk, dt, core.timee) == "dump":
+                say(f"  tdump written at timee = {core.timee:.6f} ({tdump.nsamples} samples so far)")
         nsteps += 1
         ntrun += 1
         if core.timee >= tnext:                                # writerestartfiles, src/modsave.f90:77
