@@ -1,5 +1,5 @@
-"""Index maps of the y-slab decomposition, shared by the host code and mirrored 1:1 by the HIP
-kernels in csrc/udc_pois.hip (slab_pack_*/slab_unpack_*) and csrc/udc_halo.hip (halo_pack/unpack).
+"""TEST SUPPORT (not part of the product package).  Index maps of the y-slab decomposition as the HIP kernels in
+u-dales_amd/csrc/udc_pois.hip (slab_pack_*/slab_unpack_*), udc_fft.hip and udc_halo.hip (halo_pack/unpack) use them.
 
 Also a small numpy + torch.distributed *model* of the two collective patterns (neighbour ghost rows,
 all-to-all spectral transpose).  The model is what the CPU (gloo, world_size 2) tests run: the

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _worker(rank, world, port, tmp):
     sys.path[:0] = [os.path.join(ROOT, "u-dales_amd"), os.path.join(ROOT, "tests")]
     import torch.distributed as dist
-    from udcore import slab
+    import slab_model as slab
     from udcore.grid import Grid, lcg_noise
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     nx, ny, nz = 16, 12, 6
@@ -66,7 +66,7 @@ def test_slab_exchange_patterns_gloo(world, tmp_path):
 
 def test_slab_index_maps_roundtrip():
     sys.path[:0] = [os.path.join(ROOT, "u-dales_amd")]
-    from udcore import slab
+    import slab_model as slab
     rng = np.random.default_rng(1)
     for P, nx, nyl, nz in ((1, 8, 4, 3), (2, 16, 6, 2), (4, 10, 2, 3), (8, 256, 4, 2)):
         nkx, cx = slab.kx_chunk(nx, P)
