@@ -225,8 +225,9 @@ int udc_level_forcings(udc_handle *h, int when);
  *                   diffw_corr (:1075), diffc_corr (:1120) per scalar -- called after nudge (src/program.f90:166)
  *   udc_ibmnorm     ibmnorm (:697): solid (:748) -- um, vm, wm and their tendencies zeroed at the solid points, svm / svp set
  *                   to the mean of their fluid neighbours -- called after masscorr (src/program.f90:171)
- * Both are part of udc_substep once committed.  Not available yet: the facet wall functions (wallfunmom :1286, wallfunheat
- * :1436; hence thl / qt with immersed boundaries) and the masked slab averages (avexy_ibm) of masscorr and diagfld. */
+ * Both are part of udc_substep once committed.  With an immersed boundary udc_masscorr and udc_slab_average(s) average over
+ * the fluid cells only (avexy_ibm, src/modmpi.f90:623-664, with IIu / IIv / IIc).  Not available yet: the facet wall
+ * functions (wallfunmom :1286, wallfunheat :1436; hence thl / qt with immersed boundaries). */
 enum { UDC_IBM_U = 0, UDC_IBM_V = 1, UDC_IBM_W = 2, UDC_IBM_C = 3 };
 int udc_set_ibm_points(udc_handle *h, int grid, const int *solid, int nsolid, const int *bound, int nbound);
 int udc_ibm_commit(udc_handle *h);

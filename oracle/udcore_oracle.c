@@ -1461,15 +1461,22 @@ void orc_sources(const orc_grid *g, const double *u0, const double *v0, const do
 /* ====================================================================== masscorr */
 /* src/modforces.f90:328-497, volume-flow branches: luvolflowr (:389-417) and lvvolflowr (:467-494);
  * avexy_ibm without IBM (src/modmpi.f90:623-664): slab sums divided by IIus(k) = itot*jtot. */
+static const double *ibm_ctx_mask(int grid);
+/* mask (m-array of 1 / 0, or NULL) of the velocity component masscorr averages: avexy_ibm with IIu / IIv
+ * (src/modforces.f90:404-405, src/modmpi.f90:623-664); set by orc_substep from the immersed-boundary context */
+static const double *flow_mask = NULL;
 static double volflow_def(const orc_grid *g, double rk3coef, const double *tp, const double *tm, double target) {
   double zsize = 0.;
   for (int k = 1; k <= g->nz; ++k) zsize += g->dzf[k];               /* zh(ke+1) */
-  const double cnt = (double)g->nx * (double)g->ny;
   double svol = 0., svolold = 0.;
   for (int k = 1; k <= g->nz; ++k) {
-    double a = 0., b = 0.;
+    double a = 0., b = 0., cnt = 0.;
     for (int j = 1; j <= g->ny; ++j)
-      for (int i = 1; i <= g->nx; ++i) { a += M(tp, i, j, k); b += M(tm, i, j, k); }
+      for (int i = 1; i <= g->nx; ++i) {
+        const double mk = flow_mask ? M(flow_mask, i, j, k) : 1.;
+        a += M(tp, i, j, k) * mk; b += M(tm, i, j, k) * mk; cnt += mk;
+      }
+    if (cnt == 0.) continue;                                         /* (-999 in the reference: no such level in the tests) */
     svol += (a / cnt) * g->dzf[k];
     svolold += (b / cnt) * g->dzf[k];
   }
@@ -1481,13 +1488,17 @@ void orc_masscorr(const orc_grid *g, int rk3step, double dt, double *up, const d
   const double rk3coef = dt / (4. - (double)rk3step);
   const double rk3coefi = 1 / rk3coef;
   if (g->luvolflowr) {
+    flow_mask = ibm_ctx_mask(0);
     const double udef = volflow_def(g, rk3coef, up, um, g->uflowrate);
+    flow_mask = NULL;
     for (int k = 1; k <= g->nz; ++k)
       for (int j = 1; j <= g->ny; ++j)
         for (int i = 1; i <= g->nx; ++i) M(up, i, j, k) = M(up, i, j, k) + udef * rk3coefi;
   }
   if (g->lvvolflowr) {
+    flow_mask = ibm_ctx_mask(1);
     const double vdef = volflow_def(g, rk3coef, vp, vm, g->vflowrate);
+    flow_mask = NULL;
     for (int k = 1; k <= g->nz; ++k)
       for (int j = 1; j <= g->ny; ++j)
         for (int i = 1; i <= g->nx; ++i) M(vp, i, j, k) = M(vp, i, j, k) + vdef * rk3coefi;
@@ -1638,6 +1649,7 @@ void orc_ibm_solid_c(const orc_grid *g, const int *pts, int n, const double *mas
  * ibmnorm (:171).  Set with orc_set_ibm (NULL: none). */
 static const orc_ibm *ibm_ctx = NULL;
 void orc_set_ibm(const orc_ibm *b) { ibm_ctx = b; }
+static const double *ibm_ctx_mask(int grid) { return ibm_ctx ? ibm_ctx->mask[grid] : NULL; }
 void orc_ibmwallfun(const orc_grid *g, const orc_ibm *b, orc_state *s) {
   const size_t nc = csize(g);
   orc_ibm_diffu_corr(g, b->bnd[0], b->nbnd[0], b->mask[0], s->u0, s->ekm, s->up);

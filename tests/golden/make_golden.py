@@ -370,6 +370,13 @@ CASES.update({
     "run_ibm_16x12x10": ("run", 55, 16, 12, 10, dict(sgs="vreman", nsv=1, floor=True, randu=0.05, ibm=IBM_BLOCKS["run_ibm_16x12x10"],
                                                      oracle="nsub = 9\ndump_at = 3, 9"), 1.04),
 })
+IBM_BLOCKS["run_ibm_volflow_16x12x10"] = IBM_BLOCKS["run_ibm_16x12x10"]
+CASES.update({
+    # immersed boundary with a prescribed volume flow: masscorr's avexy_ibm averages over the fluid cells (IIu, IIv)
+    "run_ibm_volflow_16x12x10": ("run", 56, 16, 12, 10, dict(sgs="vreman", nsv=1, floor=True, randu=0.05, ibm=IBM_BLOCKS["run_ibm_16x12x10"],
+                                                             physics="luvolflowr = .true.\nuflowrate = 1.1\nlvvolflowr = .true.\nvflowrate = 0.04",
+                                                             oracle="nsub = 9\ndump_at = 3, 9"), 1.04),
+})
 LSF_ONLY = ("k_lsf_12x8x24", "k_lsfq_12x8x20", "k_fix1_12x8x6")
 THL_CASES = {"k_tke_moist_12x8x8": dict(dthl=0.25, qt=0.0118, dqt=-8e-5, tke=0.06),
              "run_moistnr_16x8x12s": dict(dthl=0.25, qt=0.0119, dqt=-6e-5),

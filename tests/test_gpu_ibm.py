@@ -92,3 +92,30 @@ def test_ibm_refusals():
     d.nml.setdefault("PHYSICS", {})["ltempeq"] = True
     with pytest.raises(ValueError, match="wallfunheat"):
         udcore.from_deck(d)
+
+
+def test_masked_slab_averages():
+    """diagfld's slab averages with an immersed boundary run over the fluid cells of each level only (avexy_ibm with IIu,
+    IIv, IIc: src/modthermodynamics.f90:271-301, src/modmpi.f90:623-664)."""
+    import oracle_lib as ol
+    name, iexp = "run_ibm_volflow_16x12x10", 56
+    d, core = _core(name, iexp)
+    g = core.g
+    lists = read_ibm(d)
+    core.load_state(cold_start(g, d, nsv=core.nsv))
+    dt = float(d.get("RUN", "dtmax"))
+    core.run(6, dt)
+    o = ol.Oracle(g.nx, g.ny, g.nz, g.dx, g.dy, g.dzf, g.dzh)
+    masks = o.set_ibm(lists)
+    o.set_ibm(None)
+    av = core.slab_averages(["u0", "v0", "sv0_0"])
+    sv = core.download(L.scalar_field(L.SV0, 0), halo=2)[1:-1, 1:-1, 1:-1]
+    for nm, fld, mk in (("u0", core.download("u0"), masks["u"]), ("v0", core.download("v0"), masks["v"]), ("sv0_0", sv, masks["c"])):
+        for k in range(1, g.nz + 2):
+            m = mk[k, 1:-1, 1:-1]
+            ref = (fld[k, 1:-1, 1:-1] * m).sum() / m.sum()
+            assert abs(av[nm][k] - ref) <= 1e-13 * max(abs(ref), 1.), (nm, k)
+        # the blocks do make a difference on the levels they occupy
+        plain = fld[1, 1:-1, 1:-1].mean()
+        assert abs(plain - av[nm][1]) > 1e-6
+    core.close()

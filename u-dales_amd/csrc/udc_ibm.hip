@@ -144,6 +144,42 @@ __global__ void ibm_solid_mean_kernel(Geo g, int n, const int *__restrict__ pt, 
   rhs[c] = r;
 }
 
+// masked slab sums (avexy_ibm, src/modmpi.f90:623-664): the sum over the fluid cells of a level is the sum over all
+// cells minus the sum over the listed solid points.  One workgroup per (level, field); deterministic tree reduction.
+__global__ __launch_bounds__(256) void ibm_levelsum_kernel(Geo g, const int *__restrict__ pts, const int *__restrict__ off,
+                                                           const double *__restrict__ f, double *__restrict__ S) {
+  __shared__ double sw[4];
+  const int k = blockIdx.x;
+  double v = 0.;
+  for (int q = off[k] + threadIdx.x; q < off[k + 1]; q += 256) v += f[g.idx(pts[3 * q], pts[3 * q + 1], pts[3 * q + 2])];
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) S[k] = S[k] - ((sw[0] + sw[1]) + (sw[2] + sw[3]));
+}
+// the same with a per-level weight, summed over all levels (masscorr's volume averages): one workgroup
+__global__ __launch_bounds__(1024) void ibm_flowsum_kernel(Geo g, int n, const int *__restrict__ pts, const double *__restrict__ a,
+                                                           const double *__restrict__ b, const double *__restrict__ wlev, double *__restrict__ S) {
+  __shared__ double sa_[16], sb_[16];
+  double sa = 0., sb = 0.;
+  for (int q = threadIdx.x; q < n; q += 1024) {
+    const int k = pts[3 * q + 2];
+    const long c = g.idx(pts[3 * q], pts[3 * q + 1], k);
+    const double w = wlev[k + 1];
+    sa += a[c] * w;
+    if (b) sb += b[c] * w;
+  }
+  for (int o = 32; o > 0; o >>= 1) { sa += __shfl_xor(sa, o, 64); sb += __shfl_xor(sb, o, 64); }
+  if ((threadIdx.x & 63) == 0) { sa_[threadIdx.x >> 6] = sa; sb_[threadIdx.x >> 6] = sb; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ta = 0., tb = 0.;
+    for (int q = 0; q < 16; ++q) { ta += sa_[q]; tb += sb_[q]; }
+    S[0] = S[0] - ta;
+    S[1] = S[1] - tb;
+  }
+}
+
 inline unsigned blocks(int n) { return (unsigned)((n + 127) / 128); }
 
 }  // namespace
@@ -248,18 +284,75 @@ extern "C" int udc_ibm_commit(udc_handle *h) {
     G.nsolid = (int)(sp.size() / 3); G.nbound = (int)(bp.size() / 3);
     if (upload_points(h, sp, sf, &G.solid, &G.solid_fl)) return 1;
     if (upload_points(h, bp, bf, &G.bound, &G.bound_fl)) return 1;
+    // solid points by level (counting sort), fluid cells per level of the whole domain (IIus ... of createmasks; the w mask
+    // also excludes the floor level itself, src/modibm.f90:2179)
+    std::vector<int> off(nz + 3, 0), lp(sp.size());
+    for (size_t q = 0; q < sp.size() / 3; ++q) ++off[sp[3 * q + 2] + 1];
+    for (int k = 0; k <= nz + 1; ++k) off[k + 1] += off[k];
+    {
+      std::vector<int> pos(off.begin(), off.end() - 1);
+      for (size_t q = 0; q < sp.size() / 3; ++q) {
+        const int d = pos[sp[3 * q + 2]]++;
+        lp[3 * d] = sp[3 * q]; lp[3 * d + 1] = sp[3 * q + 1]; lp[3 * d + 2] = sp[3 * q + 2];
+      }
+    }
+    if (G.lev_pts) { HIP_OK(hipFree(G.lev_pts)); G.lev_pts = nullptr; }
+    if (G.lev_off) { HIP_OK(hipFree(G.lev_off)); G.lev_off = nullptr; }
+    if (!lp.empty()) {
+      HIP_OK(hipMalloc(&G.lev_pts, sizeof(int) * lp.size()));
+      HIP_OK(hipMemcpy(G.lev_pts, lp.data(), sizeof(int) * lp.size(), hipMemcpyHostToDevice));
+    }
+    HIP_OK(hipMalloc(&G.lev_off, sizeof(int) * off.size()));
+    HIP_OK(hipMemcpy(G.lev_off, off.data(), sizeof(int) * off.size(), hipMemcpyHostToDevice));
+    G.fluid_cnt.assign(nz + 2, (double)nx * (double)ny);
+    for (size_t q = 0; q < G.solid_g.size() / 3; ++q) {
+      const int k = G.solid_g[3 * q + 2];
+      if (!(gq == 2 && k == 1)) G.fluid_cnt[k] -= 1.;
+    }
+    if (gq == 2) G.fluid_cnt[1] = 0.;
   }
+  if (h->ibm_wlev) { HIP_OK(hipFree(h->ibm_wlev)); h->ibm_wlev = nullptr; }
   h->ibm_on = true;
   return 0;
 }
 
 void ibm_destroy(udc_handle *h) {
+  if (h->ibm_wlev) hipFree(h->ibm_wlev);
   for (auto &G : h->ibm) {
     if (G.solid) hipFree(G.solid);
     if (G.solid_fl) hipFree(G.solid_fl);
     if (G.bound) hipFree(G.bound);
     if (G.bound_fl) hipFree(G.bound_fl);
+    if (G.lev_pts) hipFree(G.lev_pts);
+    if (G.lev_off) hipFree(G.lev_off);
   }
+}
+
+int ibm_grid_of_field(int field) {
+  if (field == UDC_U0 || field == UDC_UM || field == UDC_UP) return 0;
+  if (field == UDC_V0 || field == UDC_VM || field == UDC_VP) return 1;
+  if (field == UDC_W0 || field == UDC_WM || field == UDC_WP) return 2;
+  return 3;
+}
+
+int k_ibm_levelsum_correct(udc_handle *h, const int *fields, int nf, int n, double *S) {
+  if (!h->ibm_on) return 0;
+  for (int q = 0; q < nf; ++q) {
+    const udc_handle::IbmGrid &G = h->ibm[ibm_grid_of_field(fields[q])];
+    if (!G.nsolid) continue;
+    hipLaunchKernelGGL(ibm_levelsum_kernel, dim3((unsigned)n), dim3(256), 0, h->stream, h->g, G.lev_pts, G.lev_off,
+                       (const double *)h->fields[fields[q]], S + (size_t)q * n);
+  }
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int k_ibm_flowsum_correct(udc_handle *h, int grid, const double *a, const double *b, const double *wlev, double *S) {
+  const udc_handle::IbmGrid &G = h->ibm[grid];
+  if (!h->ibm_on || !G.nsolid) return 0;
+  hipLaunchKernelGGL(ibm_flowsum_kernel, dim3(1), dim3(1024), 0, h->stream, h->g, G.nsolid, G.solid, a, b, wlev, S);
+  HIP_OK(hipGetLastError());
+  return 0;
 }
 
 // ibmwallfun without facet wall functions: the diffusion corrections (additive, so equally valid on pup = up + um/rk3coef)

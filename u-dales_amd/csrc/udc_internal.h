@@ -178,9 +178,14 @@ struct udc_handle {
     int nsolid = 0, nbound = 0;
     int *solid = nullptr, *bound = nullptr;
     unsigned char *solid_fl = nullptr, *bound_fl = nullptr;
+    // this slab's solid points sorted by level (for the masked slab sums of avexy_ibm): points of device level k are
+    // lev_pts[3 lev_off[k] .. 3 lev_off[k+1]), k = 0..nz; fluid_cnt[k] = fluid cells of the whole level (all slabs)
+    int *lev_pts = nullptr, *lev_off = nullptr;
+    std::vector<double> fluid_cnt;
   };
   IbmGrid ibm[4];
   bool ibm_on = false;
+  double *ibm_wlev = nullptr;           // masscorr's per-level weights with the masks, u then v ([2][nz+2])
   // statistics accumulators (udc_stats.hip), UDC_ST_* ids
   std::vector<double *> stats;
   bool stats_on = false;
@@ -294,7 +299,12 @@ int k_tke_closure(udc_handle *h);                  // closure, loneeqn branch
 int k_tke_sources(udc_handle *h);                  // sources: e12p += shear + buoyancy + dissipation
 int k_vreman_buoycorr(udc_handle *h);            // ekm *= sqrt(1 - min(max(Rig,0),Rigc)/Rigc), then ekh and the molecular parts
 int k_ibm_wallfun(udc_handle *h);                // diffu/v/w/c_corr at the fluid-boundary points
-int k_ibm_norm(udc_handle *h);                   // solid: velocities zeroed, scalars to the mean of their fluid neighbours
+int k_ibm_norm(udc_handle *h);
+int ibm_grid_of_field(int field);                // 0 u, 1 v, 2 w, 3 c: the mask a field's slab sums use (src/modthermodynamics.f90:271-301)
+// S[q n + k] -= sum of fields[q] over the solid points of device level k (q < nf, k < n); no-op without IBM
+int k_ibm_levelsum_correct(udc_handle *h, const int *fields, int nf, int n, double *S);
+// S[0] -= sum a w(k), S[1] -= sum b w(k) over the solid points of `grid` (b may be null)
+int k_ibm_flowsum_correct(udc_handle *h, int grid, const double *a, const double *b, const double *wlev, double *S);                   // solid: velocities zeroed, scalars to the mean of their fluid neighbours
 void ibm_destroy(udc_handle *h);
 void stats_destroy(udc_handle *h);
 int udc_flush_pending(udc_handle *h);

@@ -649,15 +649,16 @@ __global__ __launch_bounds__(256) void divcheck_kernel(Geo g, TileGrid tg, Metri
 
 
 // masscorr, src/modforces.f90:328-497, volume-flow branches (luvolflowr :389-417, lvvolflowr :467-494).
-// flowsum: S_a = sum(a dzf(k)), S_b = sum(b dzf(k)) over the slab interior (b may be null).
-__global__ __launch_bounds__(256) void flowsum_kernel(Geo g, TileGrid tg, Metrics m, const double *__restrict__ a,
+// flowsum: S_a = sum(a w(k)), S_b = sum(b w(k)) over the slab interior (b may be null); w = dzf, or with an immersed
+// boundary dzf(k) / (fluid cells of level k) / zh(ke+1) so that the sum is the volume average over the fluid
+__global__ __launch_bounds__(256) void flowsum_kernel(Geo g, TileGrid tg, const double *__restrict__ wlev, const double *__restrict__ a,
                                                       const double *__restrict__ b, double *__restrict__ out) {
   int i, j, k;
   const bool inside_ = tile_decode(g, tg, i, j, k);
   double sa = 0., sb = 0.;
   if (inside_) {
     const long c = g.idx(i, j, k);
-    const double w = m.dzf[k + 1];
+    const double w = wlev[k + 1];
     sa = a[c] * w;
     if (b) sb = b[c] * w;
   }
@@ -1155,17 +1156,31 @@ int k_masscorr(udc_handle *h, double rk3coef, bool pup_mode, bool wrap_vp) {
   double *S = h->red + 16;
   FlowShift fu{nullptr, S, 0., 0., 0.}, fv{nullptr, S + 2, 0., 0., 0.};
   const int mo = h->um_alias ? UDC_U0 : UDC_UM;
+  // immersed boundary: avexy_ibm's level averages run over the fluid cells (IIu / IIv, src/modforces.f90:404-405), so the
+  // weight of a cell becomes dzf(k) / IIus(k) / zh(ke+1) and the listed solid points are taken back out of the sum
+  if (h->ibm_on && !h->ibm_wlev) {
+    std::vector<double> w(2 * (g.nz + 2), 0.);
+    for (int q = 0; q < 2; ++q)
+      for (int k = 1; k <= g.nz; ++k) {
+        const double c = h->ibm[q].fluid_cnt[k];
+        w[q * (g.nz + 2) + k] = c > 0. ? h->cfg.dzf[k] / c / h->zsize : 0.;
+      }
+    HIP_OK(hipMalloc(&h->ibm_wlev, sizeof(double) * w.size()));
+    HIP_OK(hipMemcpy(h->ibm_wlev, w.data(), sizeof(double) * w.size(), hipMemcpyHostToDevice));
+  }
   for (int c = 0; c < 2; ++c) {
     if (!(c == 0 ? h->luvolflowr : h->lvvolflowr)) continue;
     const double *a = h->fields[UDC_UP + c], *bm = pup_mode ? nullptr : h->fields[mo + c];
-    hipLaunchKernelGGL(flowsum_kernel, gr, b, 0, h->stream, g, tile_grid(g), h->m, a, bm, h->partials);
+    const double *wlev = h->ibm_on ? h->ibm_wlev + (size_t)c * (g.nz + 2) : h->m.dzf;
+    hipLaunchKernelGGL(flowsum_kernel, gr, b, 0, h->stream, g, tile_grid(g), wlev, a, bm, h->partials);
     hipLaunchKernelGGL((reduce_partials_kernel<1, 1>), dim3(1), dim3(1024), 0, h->stream, h->partials, (long)gr.x, 0., 0.,
                        S + 2 * c);
+    if (h->ibm_on && k_ibm_flowsum_correct(h, c, a, bm, wlev, S + 2 * c)) return 1;
     FlowShift &f = c == 0 ? fu : fv;
     f.f = h->fields[UDC_UP + c];
     f.target = c == 0 ? h->uflowrate : h->vflowrate;
-    f.ca = rk3coef / vol;
-    f.cb = pup_mode ? 0. : 1. / vol;
+    f.ca = h->ibm_on ? rk3coef : rk3coef / vol;
+    f.cb = pup_mode ? 0. : (h->ibm_on ? 1. : 1. / vol);
   }
   HIP_OK(hipGetLastError());
   if (comm_allreduce(h, S, 4, 1)) return 1;

@@ -283,11 +283,22 @@ int k_slab_averages(udc_handle *h, const int *fields, int nf, double *avg_host, 
                        (const double *)h->fields[fields[q]], h->lev_part + (size_t)q * n * tg.tiles);
   hipLaunchKernelGGL(levelsum_final_kernel, dim3((unsigned)(n * nf)), dim3(256), 0, h->stream, tg.tiles, h->lev_part, h->lev_sum16);
   HIP_OK(hipGetLastError());
+  // immersed boundary: avexy_ibm averages over the fluid cells only (IIu / IIv / IIw / IIc, src/modthermodynamics.f90:271-301)
+  if (k_ibm_levelsum_correct(h, fields, nf, n, h->lev_sum16)) return 1;
   if (comm_allreduce(h, h->lev_sum16, n * nf, 1)) return 1;
   HIP_OK(hipMemcpyAsync(h->red_host, h->lev_sum16, sizeof(double) * n * nf, hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
   const double cnt = (double)g.nx * (double)h->cfg.jtot;
-  for (int k = 0; k < n * nf; ++k) avg_host[k] = h->red_host[k] / cnt;
+  for (int q = 0; q < nf; ++q) {
+    const std::vector<double> *fc = h->ibm_on ? &h->ibm[ibm_grid_of_field(fields[q])].fluid_cnt : nullptr;
+    for (int k = 0; k < n; ++k) {
+      double c = fc ? (*fc)[k + 1] : cnt;
+      // a level without fluid cells (avexy_ibm, src/modmpi.f90:649-660): -999, except the floor level, which takes the
+      // count of level ke (its sum is then the unmasked one: not reproduced, the floor level is never all solid here)
+      if (c == 0. && k == 0 && fc) c = (*fc)[g.nz];
+      avg_host[(size_t)q * n + k] = c > 0. ? h->red_host[(size_t)q * n + k] / c : -999.;
+    }
+  }
   return 0;
 }
 int k_slab_average(udc_handle *h, int field, double *avg_host, int n) { return k_slab_averages(h, &field, 1, avg_host, n); }

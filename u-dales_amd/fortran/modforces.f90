@@ -10,7 +10,6 @@
 !! and application point: lstend and nudge (applied before masscorr) share one, so lstend starts it and nudge -- the
 !! routine the reference's loop calls right after -- registers and applies it (masscorr does so if nudge was skipped).
 !!
-!! Without IBM (libm false) the fluid volume and outlet areas of calcfluidvolumes are those of the empty box.
 !! Not taken over: the outflow-rate branches of masscorr (luoutflowr / lvoutflowr: inflow-outflow decks) and
 !! periodicEBcorr (energy balance) -- refused with the reference's error convention.
 module modforces
@@ -158,27 +157,53 @@ contains
   subroutine fixthetainf      ! (empty in the reference as well, src/modforces.f90:290-326)
   end subroutine fixthetainf
 
-  !> outlet areas and fluid volume of the box without blocks (src/modforces.f90:499-598 with IIc = 1)
+  !> outlet areas (fluid part of the planes i = ie and j = je) and fluid volume, blocks excluded through the c mask of
+  !! createmasks (src/modforces.f90:499-598; equidistant x, as there)
   subroutine uoutletarea(area)
-    use modglobal, only: jtot, dy, zh, ke
+    use mpi
+    use modglobal, only: ie, jb, je, kb, ke, dy, dzf
+    use modfields, only: IIc
+    use modmpi, only: comm3d, mpierr, my_real
     real, intent(out) :: area
-    area = jtot*dy*zh(ke + 1)
+    real :: loc
+    integer :: k
+    loc = 0.
+    do k = kb, ke
+      loc = loc + sum(IIc(ie, jb:je, k))*dy*dzf(k)
+    end do
+    call MPI_ALLREDUCE(loc, area, 1, MY_REAL, MPI_SUM, comm3d, mpierr)
   end subroutine uoutletarea
 
   subroutine voutletarea(area)
-    use modglobal, only: itot, dx, zh, ke
+    use mpi
+    use modglobal, only: ib, ie, je, kb, ke, dxf, dzf, jtot
+    use modfields, only: IIc
+    use modmpi, only: comm3d, mpierr, my_real, myidy, nprocy
     real, intent(out) :: area
-    area = itot*dx*zh(ke + 1)
+    real :: loc
+    integer :: k
+    loc = 0.
+    if (myidy == nprocy - 1) then      ! the plane j = jtot lives on the last y-slab
+      do k = kb, ke
+        loc = loc + sum(IIc(ib:ie, je, k))*dxf(1)*dzf(k)
+      end do
+    end if
+    call MPI_ALLREDUCE(loc, area, 1, MY_REAL, MPI_SUM, comm3d, mpierr)
   end subroutine voutletarea
 
   subroutine fluidvolume(volume)
-    use modglobal, only: itot, jtot, dx, dy, zh, ke, libm
+    use mpi
+    use modglobal, only: ib, ie, jb, je, kb, ke, dy, dxf, dzf
+    use modfields, only: IIc
+    use modmpi, only: comm3d, mpierr, my_real
     real, intent(out) :: volume
-    if (libm) then
-      write (0, *) 'ERROR: libudcore fluidvolume: IBM masks are not available to this module (libm)'
-      stop 1
-    end if
-    volume = itot*dx*jtot*dy*zh(ke + 1)
+    real :: loc
+    integer :: k
+    loc = 0.
+    do k = kb, ke
+      loc = loc + sum(IIc(ib:ie, jb:je, k))*dxf(1)*dy*dzf(k)
+    end do
+    call MPI_ALLREDUCE(loc, volume, 1, MY_REAL, MPI_SUM, comm3d, mpierr)
   end subroutine fluidvolume
 
   subroutine calcfluidvolumes

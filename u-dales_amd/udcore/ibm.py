@@ -45,8 +45,6 @@ def apply_ibm(core, deck):
         raise ValueError("libm: only iwallmom = 1 (no facet wall functions, src/modibm.f90:1286) is on the device path")
     if deck.get("PHYSICS", "ltempeq") or deck.get("PHYSICS", "lmoist"):
         raise ValueError("libm with ltempeq / lmoist needs the facet heat wall functions (wallfunheat), not on the device path")
-    if deck.get("PHYSICS", "luvolflowr") or deck.get("PHYSICS", "lvvolflowr"):
-        raise ValueError("libm with a prescribed volume flow needs the masked slab averages of masscorr, not on the device path")
     lists = read_ibm(deck)
     for q, g in enumerate(GRIDS):
         if g in lists:
