@@ -68,7 +68,7 @@ def main():
         core.run(30, dt)
         core.sync()
         prof = {k: round(v[0] / 30, 4) for k, v in core.profile_get().items()}
-        keep = {k: v for k, v in prof.items() if k in ("scalars", "buoyancy", "thermodynamics", "mom", "closure", "integrate")}
+        keep = {k: v for k, v in prof.items() if k in ("buoyancy", "thermodynamics", "mom", "closure", "integrate") or k.startswith("scalar")}
         out = dict(config=label, n=n, ms_per_substep=round(ms, 4), cell_updates_per_s=float(f"{n ** 3 / ms * 1e3:.4g}"), kernels_ms=keep)
         if label.endswith("thermodynamics"):
             th = core.thermo_state()

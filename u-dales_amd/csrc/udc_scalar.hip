@@ -4,28 +4,23 @@
 // tendency (6 zero-fills, 3 whole-array adds); here every cell evaluates its six face values
 // in registers and accumulates in the reference's order ((cp + upper) + lower per direction).
 #include "udc_internal.h"
+#include "udc_scalar_arith.h"
 
 namespace {
 
 __device__ __forceinline__ int wrap(int i, int nx) { return i < 0 ? i + nx : (i >= nx ? i - nx : i); }
 
-// src/modadvection.f90:410-421, eps1 = 1e-10 (src/modglobal.f90:318)
-__device__ __forceinline__ double rlim(double d1, double d2) {
-  const double eps1 = 1.e-10;
-  const double ri = (d2 + eps1) / (d1 + eps1);
-  const double phir = fmax(0., fmin(2. * ri, fmin(1. / 3. + 2. / 3. * ri, 2.)));
-  return 0.5 * phir * d1;
-}
-
-// face value on the low side of cell "0" given velocity vel there:
-// cm2,cm1,c0,cp1 = c at -2,-1,0,+1 ; h* = inverse half-level spacings at -1, 0, +1 ; df = cell size factor
-__device__ __forceinline__ double face(double vel, double cm2, double cm1, double c0, double cp1,
-                                       double hm1, double h0, double hp1, double df) {
-  double d1, d2, cf;
-  if (vel > 0) { d1 = (cm1 - cm2) * hm1; d2 = (c0 - cm1) * h0; cf = cm1; }
-  else { d1 = (c0 - cp1) * hp1; d2 = (cm1 - c0) * h0; cf = c0; }
-  return cf + df * rlim(d1, d2);
-}
+// direct-load accessor: every operand straight from global memory (x wraps by index)
+struct GlobalAcc {
+  const double *c_, *e_;
+  long o, sy, sz, xm1, xm2, xp1, xp2;      // xm*/xp* are full offsets of the row's wrapped x neighbours
+  __device__ __forceinline__ long off(int di, int dj, int dk) const {
+    const long base = di == 0 ? o : (di == -1 ? xm1 : (di == 1 ? xp1 : (di == -2 ? xm2 : xp2)));
+    return base + dj * sy + dk * sz;
+  }
+  __device__ __forceinline__ double c(int di, int dj, int dk) const { return c_[off(di, dj, dk)]; }
+  __device__ __forceinline__ double e(int di, int dj, int dk) const { return e_[off(di, dj, dk)]; }
+};
 
 // ADV: 0 = none, 1 = kappa, 2 = cd2.  FRESH: the tendency is known to be zero on entry (fused substep) -> not read.
 template <int ADV, bool DIFF, bool LES, bool FRESH>
@@ -35,84 +30,12 @@ __global__ __launch_bounds__(256) void scalar_kernel(Geo g, TileGrid tg, Metrics
   int i, j, k;
   const bool inside_ = tile_decode(g, tg, i, j, k);
   if (!inside_) return;
-  const int kf = k + 1;
   const long r0 = g.idx(0, j, k);
-  const long sy = g.sy, sz = g.sz;
   const long o = r0 + i;
-  const long xm1 = r0 + wrap(i - 1, g.nx), xm2 = r0 + wrap(i - 2, g.nx);
-  const long xp1 = r0 + wrap(i + 1, g.nx), xp2 = r0 + wrap(i + 2, g.nx);
-  const double c0 = c[o];
-  const double cxm1 = c[xm1], cxp1 = c[xp1], cym1 = c[o - sy], cyp1 = c[o + sy], czm1 = c[o - sz], czp1 = c[o + sz];
-  double t = FRESH ? 0. : cp[o];
-  if (ADV == 2) {
-    // advecc_2nd, src/modadvection.f90:127-133 and :148-151 (two statements, same order)
-    const double kdzf = m.dzf[kf], kdzfm = m.dzf[kf - 1], kdzfp = m.dzf[kf + 1];
-    t = t - ((u[xp1] * (cxp1 + c0) - u[o] * (cxm1 + c0)) * m.dxi5
-           + (v[o + sy] * (cyp1 + c0) - v[o] * (cym1 + c0)) * m.dyi5);
-    t = t - (w[o + sz] * (czp1 * kdzf + c0 * kdzfp) * m.dzhi[kf + 1]
-           - w[o] * (czm1 * kdzf + c0 * kdzfm) * m.dzhi[kf]) * m.dzfi5[kf];
-  }
-  if (ADV == 1) {
-    const double cxm2 = c[xm2], cxp2 = c[xp2];
-    const double cym2 = c[o - 2 * sy], cyp2 = c[o + 2 * sy];
-    double czm2 = c[o - 2 * sz], czp2 = c[o + 2 * sz];
-    double czm1 = c[o - sz], czp1 = c[o + sz];      // (shadow the diffusion operands: those stay thl0's own ghosts)
-    if (gh) {
-      // kappa on thl (iadv_thl = 7) runs on the reference's separate copy thl0c, whose vertical ghost planes are not
-      // thl0's: nothing ever writes the two below the floor (zero), and at the top `boundary` copies level ke upwards
-      // for a flux condition (src/modboundary.f90:211-213) and leaves them untouched (zero) for a value condition
-      const double top = gh == 1 ? 1. : 0.;
-      if (k == 0) czm1 = 0.;
-      if (k <= 1) czm2 = 0.;
-      if (k == g.nz - 1) { czp1 = top * c0; czp2 = top * c0; }
-      if (k == g.nz - 2) czp2 = top * czp1;
-    }
-    const double dxi = m.dxi, dx = m.dx, dyi = m.dyi;
-    {  // x: faces i (low) and i+1 (high); dxhci = dxi, dxfc = dx, dxfci = dxi on the uniform grid
-      const double ul = u[o], uh = u[xp1];
-      const double fl = face(ul, cxm2, cxm1, c0, cxp1, dxi, dxi, dxi, dx);
-      const double fh = face(uh, cxm1, c0, cxp1, cxp2, dxi, dxi, dxi, dx);
-      t = (t + (-fh * uh * dxi)) + fl * ul * dxi;
-    }
-    {  // y (no stretching: d's are plain differences, df = 1)
-      const double vl = v[o], vh = v[o + sy];
-      const double fl = face(vl, cym2, cym1, c0, cyp1, 1., 1., 1., 1.);
-      const double fh = face(vh, cym1, c0, cyp1, cyp2, 1., 1., 1., 1.);
-      t = (t + (-fh * vh * dyi)) + fl * vl * dyi;
-    }
-    {  // z: faces kb+1..ke+1 only (no flux through the floor, src/modadvection.f90:385)
-      const int nzp1 = g.nz + 1;
-      const double hkm1 = m.dzhi[kf - 1 < 1 ? 1 : kf - 1], hk = m.dzhi[kf], hkp1 = m.dzhi[kf + 1];
-      const double hkp2 = m.dzhi[kf + 2 > nzp1 ? nzp1 : kf + 2];
-      const double wl = w[o], wh = w[o + sz];
-      const double dzfci = m.dzfi[kf];
-      const double fh = face(wh, czm1, c0, czp1, czp2, hk, hkp1, hkp2, m.dzf[kf + 1]);
-      const double upper = -fh * wh * dzfci;
-      double lower = 0.;
-      if (k >= 1) {
-        const double fl = face(wl, czm2, czm1, c0, czp1, hkm1, hk, hkp1, m.dzf[kf]);
-        lower = fl * wl * dzfci;
-      }
-      t = (t + upper) + lower;
-    }
-  }
-  if (DIFF) {
-    const double dzf_k = m.dzf[kf], dzf_km = m.dzf[kf - 1], dzf_kp = m.dzf[kf + 1];
-    if (LES) {
-      const double e0 = ekh[o], exm = ekh[xm1], exp_ = ekh[xp1], eym = ekh[o - sy], eyp = ekh[o + sy],
-                   ezm = ekh[o - sz], ezp = ekh[o + sz];
-      // dfac = 0.5 with ekh (diffc, src/modsubgrid.f90:569-584) or 1.0 with ekm (diffe, :649-663)
-      t = t + dfac * (((exp_ + e0) * (cxp1 - c0) - (e0 + exm) * (c0 - cxm1)) * m.dx2i
-                   + ((eyp + e0) * (cyp1 - c0) - (e0 + eym) * (c0 - cym1)) * m.dy2i
-                   + ((dzf_kp * e0 + dzf_k * ezp) * (czp1 - c0) * m.dzh2i[kf + 1]
-                    - (dzf_km * e0 + dzf_k * ezm) * (c0 - czm1) * m.dzh2i[kf]) * m.dzfi[kf]);
-    } else {
-      t = t + ((cekh * (cxp1 - c0) - cekh * (c0 - cxm1)) * m.dx2i
-             + (cekh * (cyp1 - c0) - cekh * (c0 - cym1)) * m.dy2i
-             + (cekh * (czp1 - c0) * m.dzhi[kf + 1] - cekh * (c0 - czm1) * m.dzhi[kf]) * m.dzfi[kf]);
-    }
-  }
-  cp[o] = t;
+  const GlobalAcc A{c, ekh, o, (long)g.sy, g.sz, r0 + wrap(i - 1, g.nx), r0 + wrap(i - 2, g.nx), r0 + wrap(i + 1, g.nx), r0 + wrap(i + 2, g.nx)};
+  double ul = 0., uh = 0., vl = 0., vh = 0., wl = 0., wh = 0.;
+  if (ADV) { ul = u[o]; uh = u[A.xp1]; vl = v[o]; vh = v[o + g.sy]; wl = w[o]; wh = w[o + g.sz]; }
+  cp[o] = scalar_tend<ADV, DIFF, LES>(A, m, k, g.nz, FRESH ? 0. : cp[o], ul, uh, vl, vh, wl, wh, cekh, dfac, gh);
 }
 
 inline dim3 cell_grid(const Geo &g, dim3 b) {
@@ -194,7 +117,12 @@ static int launch_scalar(udc_handle *h, int n, bool adv, bool diff, bool fresh =
 
 int k_scalar_adv(udc_handle *h, int n) { return launch_scalar(h, n, true, false); }
 int k_scalar_diff(udc_handle *h, int n) { return launch_scalar(h, n, false, true); }
-int k_scalar_fused(udc_handle *h, int n, bool fresh) { return launch_scalar(h, n, true, true, fresh); }
+bool k_scalar_fused_lds(udc_handle *h, int n, bool fresh, int *rc);      // udc_scalar_lds.hip
+int k_scalar_fused(udc_handle *h, int n, bool fresh) {
+  int rc = 0;
+  if (!h->mom_simple && k_scalar_fused_lds(h, n, fresh, &rc)) return rc;
+  return launch_scalar(h, n, true, true, fresh);
+}
 
 // scalsource (src/modscalsource.f90:379-483): the sources are constant in time, the host evaluated them once
 // (udcore/sources.py, udc_set_scalar_source); svp += source over the box that holds it
