@@ -269,6 +269,9 @@ def main():
     ap.add_argument("--no-dropin", action="store_true", help="skip the Fortran drop-in leg")
     ap.add_argument("--nsv", type=int, default=0, help="passive scalars (kappa scheme), BASELINE configs[2]")
     ap.add_argument("--sgs", type=str, default="vreman", choices=["vreman", "smag"])
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="testing only: let WORLD_SIZE exceed the node's GPUs (ranks share devices, rendezvous over gloo); "
+                         "RCCL refuses two ranks on one device, so the run stops cleanly at udc_comm_init")
     ap.add_argument("--no-floor", action="store_true",
                     help="free floor instead of the neutral log-law wall function (lbottom, BCbotm = 3) of SURVEY 8d")
     args = ap.parse_args()
@@ -284,9 +287,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libudcore has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    if world > ndev and not args.oversubscribe:
+        raise SystemExit(f"--gpus {world}: this node has {ndev} GPU(s); one rank per GPU (RCCL refuses two ranks on one device)")
+    dev = local_rank % ndev
+    torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.oversubscribe:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
 
     from udcore import read_deck, cold_start
     from udcore.grid import Grid
@@ -304,16 +314,24 @@ def main():
     dt = 0.25
     with tempfile.TemporaryDirectory() as tmp:
         deck = read_deck(write_deck(tmp, 901, nx, ny, nz, 0, dt=dt, nprocy=world, nsv=args.nsv, sgs=args.sgs, floor=not args.no_floor))
-    core = udcore.from_deck(deck, device=local_rank, rank=rank, nranks=world)
+    core = udcore.from_deck(deck, device=dev, rank=rank, nranks=world)
     if world > 1:
-        idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        iddev = "cpu" if args.oversubscribe else "cuda"
+        idt = torch.zeros(128, dtype=torch.uint8, device=iddev)
         if rank == 0:
             import ctypes
             buf = (ctypes.c_ubyte * 128)()
             core.lib.udc_comm_unique_id(buf)
-            idt = torch.tensor(list(buf), dtype=torch.uint8, device="cuda")
+            idt = torch.tensor(list(buf), dtype=torch.uint8, device=iddev)
         dist.broadcast(idt, 0)
-        core.comm_init(bytes(idt.cpu().tolist()))
+        try:
+            core.comm_init(bytes(idt.cpu().tolist()))
+        except RuntimeError as e:
+            # e.g. two ranks on one device: RCCL refuses, nothing has been exchanged yet -- leave without a collective
+            print(f"[bench rank {rank}] udc_comm_init refused: {e}", file=sys.stderr, flush=True)
+            core.close()
+            dist.destroy_process_group()
+            raise SystemExit(3)
     g = core.g
     nyl = ny // world
     st = cold_start(g, deck, j0=rank * nyl, nyl=nyl, nsv=args.nsv)

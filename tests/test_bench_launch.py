@@ -1,0 +1,63 @@
+"""bench.py under the driver's multi-GPU launch line (python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...): the rendezvous / RANK / LOCAL_RANK / WORLD_SIZE
+plumbing, the unique-id broadcast and udc_comm_init.  A one-GPU box cannot run two RCCL ranks (RCCL refuses two ranks
+on one device), so what is asserted there is that every rank gets as far as udc_comm_init and leaves cleanly -- no
+hang, no collective left half-posted -- with the refusal in its message.  On a box without a GPU the launch must stop
+with bench.py's own message on every rank."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch(n, extra, timeout):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1",
+           "--no-cpu", "--no-dropin", "--no-single", "--size", "32x16x16"] + extra
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def have_gpu():
+    import torch
+    return torch.cuda.is_available()
+
+
+def test_launch_without_gpu_stops_on_every_rank():
+    if have_gpu():
+        pytest.skip("this box has a GPU")
+    r = launch(2, [], 300)
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs an MI355X") >= 2, r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_two_ranks_need_two_gpus():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("more than one GPU here")
+    r = launch(2, [], 300)
+    assert r.returncode != 0
+    assert r.stderr.count("one rank per GPU") >= 2, r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_oversubscribed_ranks_reach_comm_init_and_leave_cleanly():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("more than one GPU here: the real N = 2 run is the driver's scaling bench")
+    r = launch(2, ["--oversubscribe"], 600)
+    assert r.returncode != 0
+    assert r.stderr.count("udc_comm_init refused") >= 2, r.stderr[-3000:]
+    # the JSON line is only printed by a run that finished
+    assert '"metric"' not in r.stdout

@@ -69,12 +69,18 @@ __global__ void thomas_table_kernel(int nmodes, int nz, const double *__restrict
   const double e = ev[mo];
   double z = 1. / (b[1] + e);
   double d = c[1] * z;
-  if (nz >= 2) ztab[ztab_index(blocked, nmodes, nz, 0, mo)] = z;
+  // the blocked table is followed by a second one holding -(c_k z_k), the back substitution's only coefficient
+  double *cz = blocked ? ztab + (size_t)((nmodes + ZB - 1) / ZB) * ZB * (size_t)(nz > 1 ? nz - 1 : 1) : nullptr;
+  if (nz >= 2) {
+    ztab[ztab_index(blocked, nmodes, nz, 0, mo)] = z;
+    if (cz) cz[ztab_index(true, nmodes, nz, 0, mo)] = -(c[1] * z);
+  }
   for (int k = 2; k <= nz - 1; ++k) {
     const double bbk = b[k] + e;
     z = 1. / (bbk - a[k] * d);
     d = c[k] * z;
     ztab[ztab_index(blocked, nmodes, nz, k - 1, mo)] = z;
+    if (cz) cz[ztab_index(true, nmodes, nz, k - 1, mo)] = -(c[k] * z);
   }
   (void)btopD;
 }
@@ -179,7 +185,7 @@ __device__ __forceinline__ void static_for(F &&f) {
   }
 }
 
-template <int M, int KC, int D>
+template <int M, int KC, int D, int DB>
 __global__ __launch_bounds__(256) void thomas_lds_kernel(int nmodes, int nz, double scale,
     const double *__restrict__ ev, const double *__restrict__ tri, double btopD,
     const double *__restrict__ ztab, double2 *__restrict__ x) {
@@ -303,15 +309,39 @@ __global__ __launch_bounds__(256) void thomas_lds_kernel(int nmodes, int nz, dou
     xp = xc;
   }
   // back substitution, levels nz-1 .. 1, chunk by chunk from the top; finished chunks stream out.  The top chunk's
-  // coefficients are in zt already; chunk c <= nch-2 lives in slot (nch-2-c) % D
-  static_for<D>([&](auto S) { if (nch - 2 - decltype(S)::value >= 0) issue(nch - 2 - decltype(S)::value, false, S); });
-  for (int t0 = 0; t0 < nch; t0 += D) static_for<D>([&](auto S) {
+  // coefficients are in zt already; chunk c <= nch-2 lives in slot (nch-2-c) % DB.  Only the pivots (8 B per point)
+  // are loaded in this phase, so the ring is deeper than the forward one: with D chunks (2 KB each) in flight the
+  // phase is latency-bound
+  const double *ztabc = ztab + (size_t)((nmodes + ZB - 1) / ZB) * ZB * (size_t)(nz > 1 ? nz - 1 : 1);
+  double bz[DB][R];
+  auto issue_b = [&](int ch, auto S) {
+    constexpr int s = decltype(S)::value;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int idx = tid + 256 * r;
+      const int kk = idx / M, mm = idx % M;
+      const int lev = ch * KC + kk;
+      const bool ok = lev < nz && m0 + mm < nmodes;
+      bz[s][r] = (ok && lev < nz - 1) ? ztabc[ztab_index(true, nmodes, nz, lev, m0 + mm)] : 0.;
+    }
+  };
+  auto commit_b = [&](int ch, auto S) {
+    constexpr int s = decltype(S)::value;
+    double *zc = zb + (ch & 1) * (KC * M);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int idx = tid + 256 * r;
+      zc[idx] = bz[s][r];
+    }
+  };
+  static_for<DB>([&](auto S) { if (nch - 2 - decltype(S)::value >= 0) issue_b(nch - 2 - decltype(S)::value, S); });
+  for (int t0 = 0; t0 < nch; t0 += DB) static_for<DB>([&](auto S) {
     constexpr int d = decltype(S)::value;
     const int t = t0 + d;
     if (t >= nch) return;
     const int ch = nch - 1 - t;
-    if (t >= 1 && nch - 1 - t - D >= 0)            // the slot freed by the previous iteration's commit
-      issue(nch - 1 - t - D, false, std::integral_constant<int, (d + D - 1) % D>{});
+    if (t >= 1 && nch - 1 - t - DB >= 0)           // the slot freed by the previous iteration's commit
+      issue_b(nch - 1 - t - DB, std::integral_constant<int, (d + DB - 1) % DB>{});
     if (tid < C) {
       const double *zc = (ch == nch - 1 ? zt : zb + (ch & 1) * (KC * M)) + (tid >> 1);
       const int l0 = ch * KC;
@@ -347,7 +377,7 @@ __global__ __launch_bounds__(256) void thomas_lds_kernel(int nmodes, int nz, dou
         }
       }
     }
-    if (ch > 0) commit(ch - 1, false, S);
+    if (ch > 0) commit_b(ch - 1, S);
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -361,39 +391,45 @@ __global__ __launch_bounds__(256) void thomas_lds_kernel(int nmodes, int nz, dou
 }
 
 // LDS variant or streaming kernel?  Decided once per table (the table's layout follows the kernel).
-// UDC_THOMAS: 0 = streaming kernel, 3 = LDS kernel whenever it fits; default: the LDS kernel where the
-// streaming one would put fewer than ~6 waves on a CU (it needs that many to cover HBM latency), measured
-// cross-over on MI355X between 68K modes (LDS 15 % faster) and 135K modes (streaming 5 % faster)
+// UDC_THOMAS: 0 = streaming kernel, 3 = LDS kernel whenever it fits; default: the LDS kernel while two workgroups
+// fit on a CU (nz <= ~590).  Measured on MI355X: 512x512x256 (132K modes) 0.389 ms against 0.509 ms streaming,
+// 1024x512x512 (263K modes, 2 workgroups per CU) 2.12 against 2.17 ms.
 static size_t thomas_lds_bytes(int nz, int M, int KC) { return ((size_t)nz * 2 * M + 3 * (size_t)KC * M) * sizeof(double); }
 static bool thomas_wants_lds(long nmodes, int nz) {
+  (void)nmodes;
   const char *env = getenv("UDC_THOMAS");
   const int mode = env ? atoi(env) : -1;
-  const bool want = mode == 3 || (mode < 0 && nmodes <= 98304);
-  return want && nz >= 2 && thomas_lds_bytes(nz, 8, 32) <= 160 * 1024 - 1024;
+  if (nz < 2 || mode == 0) return false;
+  const size_t need = thomas_lds_bytes(nz, 8, 32);
+  return mode == 3 ? need <= 160 * 1024 - 1024 : need <= 80 * 1024 - 512;
 }
 static size_t ztab_doubles(long nmodes, int nz) { return (size_t)((nmodes + ZB - 1) / ZB) * ZB * (size_t)(nz > 1 ? nz - 1 : 1); }
 
 static int launch_thomas(udc_handle *h, bool lds, long nmodes, int nz, double scale, const double *ev, const double *ztab, double2 *x) {
   const size_t full = 160 * 1024 - 1024;
   auto need = [&](int M, int KC) { return thomas_lds_bytes(nz, M, KC); };
-#define UDC_TL(M, KC, D)                                                                                     \
+#define UDC_TL(M, KC, D, DB)                                                                                    \
   do {                                                                                                       \
     static bool attr_done = false;                                                                           \
     if (!attr_done) {                                                                                        \
-      if (hipFuncSetAttribute((const void *)thomas_lds_kernel<M, KC, D>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+      if (hipFuncSetAttribute((const void *)thomas_lds_kernel<M, KC, D, DB>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               (int)full) != hipSuccess) return 1;                                            \
       attr_done = true;                                                                                      \
     }                                                                                                        \
-    hipLaunchKernelGGL((thomas_lds_kernel<M, KC, D>), dim3((unsigned)((nmodes + M - 1) / M)), dim3(256), need(M, KC), \
+    hipLaunchKernelGGL((thomas_lds_kernel<M, KC, D, DB>), dim3((unsigned)((nmodes + M - 1) / M)), dim3(256), need(M, KC), \
                        h->stream, (int)nmodes, nz, scale, ev, h->tri, h->btopD, ztab, x);                    \
     return 0;                                                                                                \
   } while (0)
-  // 4 workgroups per CU at nz = 256, 2 at nz = 512; UDC_THOMAS_DEPTH: chunks of loads in flight per workgroup
-  // (measured at 256^3: 1 -> 0.114 ms, 2 -> 0.113, 3 -> 0.117, 4 -> 0.135 (130 VGPRs, 3 waves/SIMD), 6 -> 0.140)
+  // 4 workgroups per CU at nz = 256, 2 at nz = 512.  D = chunks of x / pivot loads in flight per workgroup in the forward
+  // sweep (measured at 256^3: 1 -> 0.114 ms, 2 -> 0.113, 3 -> 0.117, 4 -> 0.135 (130 VGPRs, 3 waves/SIMD); at
+  // 1024x512x512: 2 -> 2.24, 3 -> 2.22, 4 -> 2.36), DB = chunks of -(c z) in flight in the back substitution (same box:
+  // 2 -> 0.431 / 2.365 ms at 512x512x256 / 1024x512x512, 4 -> 0.415 / 2.32, 8 -> 0.401 / 2.25)
   const int depth = getenv("UDC_THOMAS_DEPTH") ? atoi(getenv("UDC_THOMAS_DEPTH")) : 2;
   if (lds) {
-    if (depth <= 1) UDC_TL(8, 32, 1);
-    UDC_TL(8, 32, 2);
+    const int db = getenv("UDC_THOMAS_DB") ? atoi(getenv("UDC_THOMAS_DB")) : 8;
+    if (depth <= 1) UDC_TL(8, 32, 1, 8);
+    if (db <= 2) UDC_TL(8, 32, 2, 2);
+    UDC_TL(8, 32, 2, 8);
   }
 #undef UDC_TL
   hipLaunchKernelGGL(thomas_kernel, dim3((unsigned)((nmodes + 63) / 64)), dim3(64), 0, h->stream, (int)nmodes, nz, scale,
@@ -736,7 +772,7 @@ int pois_init(udc_handle *h) {
   HIP_OK(hipMalloc(&h->spec, sizeof(double) * 2 * nmodes * nz));
   HIP_OK(hipMemsetAsync(h->spec, 0, sizeof(double) * 2 * nmodes * nz, h->stream));
   h->thomas_lds = thomas_wants_lds((long)nmodes, nz);
-  HIP_OK(hipMalloc(&h->ztab, sizeof(double) * ztab_doubles((long)nmodes, nz)));
+  HIP_OK(hipMalloc(&h->ztab, sizeof(double) * ztab_doubles((long)nmodes, nz) * (h->thomas_lds ? 2 : 1)));
   HIP_OK(hipMalloc(&h->ev, sizeof(double) * nmodes));
   HIP_OK(hipMalloc(&h->tri, sizeof(double) * tri.size()));
   HIP_OK(hipMemcpy(h->ev, ev.data(), sizeof(double) * nmodes, hipMemcpyHostToDevice));
@@ -858,7 +894,7 @@ int pois_slab_init(udc_handle *h) {
   HIP_OK(hipMalloc(&h->a2a_recv, sizeof(double) * 2 * nmodes * nz));
   HIP_OK(hipMalloc(&h->ev_slab, sizeof(double) * nmodes));
   h->thomas_lds_slab = thomas_wants_lds((long)nmodes, nz);
-  HIP_OK(hipMalloc(&h->ztab_slab, sizeof(double) * ztab_doubles((long)nmodes, nz)));
+  HIP_OK(hipMalloc(&h->ztab_slab, sizeof(double) * ztab_doubles((long)nmodes, nz) * (h->thomas_lds_slab ? 2 : 1)));
   HIP_OK(hipMalloc(&h->tri, sizeof(double) * tri.size()));
   HIP_OK(hipMemcpy(h->ev_slab, ev.data(), sizeof(double) * nmodes, hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(h->tri, tri.data(), sizeof(double) * tri.size(), hipMemcpyHostToDevice));
