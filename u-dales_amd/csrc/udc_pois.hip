@@ -185,7 +185,7 @@ __device__ __forceinline__ void static_for(F &&f) {
   }
 }
 
-template <int M, int KC, int D, int DB>
+template <int M, int KC, int D, int DB, bool PART>
 __global__ __launch_bounds__(256) void thomas_lds_kernel(int nmodes, int nz, double scale,
     const double *__restrict__ ev, const double *__restrict__ tri, double btopD,
     const double *__restrict__ ztab, double2 *__restrict__ x) {
@@ -198,6 +198,7 @@ __global__ __launch_bounds__(256) void thomas_lds_kernel(int nmodes, int nz, dou
   double *xs = lds_;                       // [nz][C]   (x_k s) z_k, then x'_k, then the solution
   double *zb = lds_ + (size_t)nz * C;      // [2][KC][M] -(a_k z_k) forward, -(c_k z_k) back
   double *zt = zb + 2 * KC * M;            // [KC][M]   -(c_k z_k) of the top chunk, written by the forward sweep
+  double *sx = zt + KC * M;                // [4][C][2] segment summaries of the partitioned sweeps
   const int tid = threadIdx.x;
   const int m0 = blockIdx.x * M;
   const double *a = tri, *b = tri + (nz + 2), *c = tri + 2 * (nz + 2);
@@ -243,9 +244,67 @@ __global__ __launch_bounds__(256) void thomas_lds_kernel(int nmodes, int nz, dou
     }
   };
 
+
+  // Partitioned sweep (PART): both sweeps are first-order linear recurrences  v_l = g_l v_prev + t_l.  Run strictly
+  // in sequence, 16 lanes of one wave (one per real column) spend ~45 cycles per level on a dependent fma and its LDS
+  // operands, which at nz = 512 (two workgroups per CU) is a third of the kernel.  Instead all 64 lanes of the wave take
+  // a quarter of the chunk's KC levels each: with zero inflow  y_j = g_j y_{j-1} + t_j  and the running product
+  // P_j = g_j P_{j-1}, then the four segments are chained through (P_last, y_last) -- 4 dependent fmas, every lane
+  // redoing them -- and  v_j = P_j v_in + y_j.  Same equations as solmpj (src/modpois.f90:1120-1166); the rounding
+  // differs from the sequential order in the last bits (tests compare both kernels with the oracle).
+  // `down`: the chunk is walked from its top level downwards (back substitution).  Levels >= l1 pass through.
+  auto part_sweep_impl = [&](const double *zc, int l0, int l1, bool down, double &carry, auto FULL_) {
+    constexpr bool FULL = decltype(FULL_)::value;      // every level of the chunk takes part (all chunks but a ragged last one)
+    constexpr int SL = KC / 4;
+    static_assert(C == 16 && KC % 4 == 0, "four segments of one wave");
+    const int col = tid & (C - 1), seg = tid >> 4;
+    // lane's levels: lev_j = base + j * step
+    const int base = down ? l0 + KC - 1 - seg * SL : l0 + seg * SL;
+    const int step = down ? -1 : 1;
+    const double *xb = xs + (size_t)base * C + col;
+    const double *zq = zc + (base - l0) * M;
+    double y[SL], P[SL];
+#pragma unroll
+    for (int j = 0; j < SL; ++j) {
+      const bool ok = FULL || base + j * step < l1;
+      y[j] = ok ? xb[j * step * C] : 0.;
+      P[j] = ok ? zq[j * step * M] : 1.;
+    }
+#pragma unroll
+    for (int j = 1; j < SL; ++j) {
+      y[j] = __builtin_fma(P[j], y[j - 1], y[j]);
+      P[j] = P[j] * P[j - 1];
+    }
+    *reinterpret_cast<double2 *>(sx + (size_t)(seg * C + col) * 2) = make_double2(P[SL - 1], y[SL - 1]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double2 sm[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sm[q] = *reinterpret_cast<const double2 *>(sx + (size_t)(q * C + col) * 2);
+    double in = carry, mine = carry;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      in = __builtin_fma(sm[q].x, in, sm[q].y);
+      if (seg == q + 1) mine = in;
+    }
+    carry = in;
+    double *xw = xs + (size_t)base * C + col;
+#pragma unroll
+    for (int j = 0; j < SL; ++j)
+      if (FULL || base + j * step < l1) xw[j * step * C] = __builtin_fma(P[j], mine, y[j]);
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto part_sweep = [&](const double *zc, int l0, int l1, bool down, double &carry) {
+    if (l1 - l0 == KC) part_sweep_impl(zc, l0, l1, down, carry, std::true_type{});
+    else part_sweep_impl(zc, l0, l1, down, carry, std::false_type{});
+  };
+
   // the last pivot of the forward sweep is needed again when the top level is closed
   double zl = 0.;
-  if (tid < C && nz >= 2) zl = ztab[ztab_index(true, nmodes, nz, nz - 2, min(m0 + (tid >> 1), nmodes - 1))];
+  const int rl = PART ? 64 : C;            // lanes that carry the recurrence (PART: every lane of wave 0, column tid % C)
+  const int colr = tid & (C - 1);
+  if (tid < rl && nz >= 2) zl = ztab[ztab_index(true, nmodes, nz, nz - 2, min(m0 + (colr >> 1), nmodes - 1))];
   static_for<D>([&](auto S) { if (decltype(S)::value < nch) issue(decltype(S)::value, true, S); });
   commit(0, true, std::integral_constant<int, 0>{});
   __syncthreads();
@@ -256,7 +315,9 @@ __global__ __launch_bounds__(256) void thomas_lds_kernel(int nmodes, int nz, dou
     const int ch = ch0 + d;
     if (ch >= nch) return;
     if (ch + D < nch) issue(ch + D, true, S);      // slot d was committed in the previous iteration
-    if (tid < C) {
+    if (PART) {
+      if (tid < 64) part_sweep(zb + (ch & 1) * (KC * M) + ((tid & (C - 1)) >> 1), ch * KC, min(ch * KC + KC, nz - 1), false, xp);
+    } else if (tid < C) {
       const double *zc = zb + (ch & 1) * (KC * M) + (tid >> 1);
       const int l0 = ch * KC;
       const int l1 = min(l0 + KC, nz - 1);
@@ -296,16 +357,17 @@ __global__ __launch_bounds__(256) void thomas_lds_kernel(int nmodes, int nz, dou
     __syncthreads();
   });
   // close the forward sweep: the top level (stored as x_nz s, its "pivot" slot was 1)
-  if (tid < C) {
-    const int mo = min(m0 + (tid >> 1), nmodes - 1);
+  if (tid < rl) {
+    const int mo = min(m0 + (colr >> 1), nmodes - 1);
     const double e = ev[mo];
     // the singular (0,0) mode gets a Dirichlet condition across the top cell (:209-220)
     const double bbk = (e == 0.) ? btopD : b[nz] + e;
     const double ak = a[nz];
     const double d = c[nz - 1] * zl;
     const double z = bbk - ak * d;
-    const double xc = (xs[(size_t)(nz - 1) * C + tid] - ak * xp) / z;
-    xs[(size_t)(nz - 1) * C + tid] = xc;
+    const double xc = (xs[(size_t)(nz - 1) * C + colr] - ak * xp) / z;
+    __builtin_amdgcn_wave_barrier();         // (PART: every segment's lane has read the level before one of them rewrites it)
+    if (tid < C) xs[(size_t)(nz - 1) * C + colr] = xc;
     xp = xc;
   }
   // back substitution, levels nz-1 .. 1, chunk by chunk from the top; finished chunks stream out.  The top chunk's
@@ -342,7 +404,9 @@ __global__ __launch_bounds__(256) void thomas_lds_kernel(int nmodes, int nz, dou
     const int ch = nch - 1 - t;
     if (t >= 1 && nch - 1 - t - DB >= 0)           // the slot freed by the previous iteration's commit
       issue_b(nch - 1 - t - DB, std::integral_constant<int, (d + DB - 1) % DB>{});
-    if (tid < C) {
+    if (PART) {
+      if (tid < 64) part_sweep((ch == nch - 1 ? zt : zb + (ch & 1) * (KC * M)) + ((tid & (C - 1)) >> 1), ch * KC, min(ch * KC + KC, nz - 1), true, xp);
+    } else if (tid < C) {
       const double *zc = (ch == nch - 1 ? zt : zb + (ch & 1) * (KC * M)) + (tid >> 1);
       const int l0 = ch * KC;
       const int l1 = min(l0 + KC, nz - 1);
@@ -390,11 +454,237 @@ __global__ __launch_bounds__(256) void thomas_lds_kernel(int nmodes, int nz, dou
   });
 }
 
+// Wave-specialised LDS-resident solve.  Same data flow as thomas_lds_kernel (columns of M modes resident in LDS, x read
+// and written once, pivots read in the forward sweep, -(c z) in the back substitution) but the five waves of a workgroup
+// have fixed jobs, because a wave that mixes "issue loads two chunks ahead" with "wait for the chunk that is due" gets
+// s_waitcnt vmcnt(0) from the compiler at every wait (the number of younger loads is not static across its branches),
+// which drains the loads it has just issued: the ring never holds more than the chunk being waited for, and the
+// kernel's time is the sum of its load latency, its recurrence and its stores (measured: 1.03 + 0.56 + 0.23 ms on top
+// of a 0.53 ms skeleton at 1024x512x512).  Here
+//   wave 0      runs the recurrences (partitioned sweeps over all 64 lanes, see part_sweep) and never touches memory;
+//   waves 1..4  each own every fourth chunk of KC levels: load it (4 elements per lane), and when it is due wait for
+//               everything they have in flight -- which is only their own, four periods old -- scale it into LDS, and
+//               issue their next chunk; in the back substitution the owner of a finished chunk also streams it out.
+// Four (forward) or eight (back) chunks per workgroup are in flight whatever the compiler does with the waits.
+template <int M, int KC>
+__global__ __launch_bounds__(320) void thomas_ws_kernel(int nmodes, int nz, double scale,
+    const double *__restrict__ ev, const double *__restrict__ tri, double btopD,
+    const double *__restrict__ ztab, double2 *__restrict__ x) {
+  static_assert(M == ZB, "the blocked pivot table is laid out for ZB modes per workgroup");
+  constexpr int C = 2 * M;                 // real columns
+  constexpr int NMV = 4;                   // mover waves
+  constexpr int R = KC * M / 64;           // elements per mover lane and chunk
+  constexpr int SL = KC / 4;               // levels per segment of the partitioned sweep
+  static_assert(C == 16 && KC * M % 64 == 0 && KC % 4 == 0, "layout");
+  extern __shared__ double lds_[];
+  double *xs = lds_;                       // [nz][C]
+  double *zb = lds_ + (size_t)nz * C;      // [2][KC][M]
+  double *zt = zb + 2 * KC * M;            // [KC][M]
+  double *sx = zt + KC * M;                // [4][C][2]
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int m0 = blockIdx.x * M;
+  const double *a = tri, *b = tri + (nz + 2), *c = tri + 2 * (nz + 2);
+  const size_t st = (size_t)nmodes;
+  const int nch = (nz + KC - 1) / KC;
+  const double *ztabc = ztab + (size_t)((nmodes + ZB - 1) / ZB) * ZB * (size_t)(nz > 1 ? nz - 1 : 1);
+
+  if (wv == 0) {
+    // ---- the recurrence wave
+    const int col = lane & (C - 1), seg = lane >> 4;
+    auto sweep = [&](const double *zc, int l0, int l1, bool down, double &carry, auto FULL_) {
+      constexpr bool FULL = decltype(FULL_)::value;
+      const int base = down ? l0 + KC - 1 - seg * SL : l0 + seg * SL;
+      const int step = down ? -1 : 1;
+      double *xb = xs + (size_t)base * C + col;
+      const double *zq = zc + (base - l0) * M;
+      double y[SL], P[SL];
+#pragma unroll
+      for (int j = 0; j < SL; ++j) {
+        const bool ok = FULL || base + j * step < l1;
+        y[j] = ok ? xb[j * step * C] : 0.;
+        P[j] = ok ? zq[j * step * M] : 1.;
+      }
+#pragma unroll
+      for (int j = 1; j < SL; ++j) {
+        y[j] = __builtin_fma(P[j], y[j - 1], y[j]);
+        P[j] = P[j] * P[j - 1];
+      }
+      *reinterpret_cast<double2 *>(sx + (size_t)(seg * C + col) * 2) = make_double2(P[SL - 1], y[SL - 1]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      double2 sm[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sm[q] = *reinterpret_cast<const double2 *>(sx + (size_t)(q * C + col) * 2);
+      double in = carry, mine = carry;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        in = __builtin_fma(sm[q].x, in, sm[q].y);
+        if (seg == q + 1) mine = in;
+      }
+      carry = in;
+#pragma unroll
+      for (int j = 0; j < SL; ++j)
+        if (FULL || base + j * step < l1) xb[j * step * C] = __builtin_fma(P[j], mine, y[j]);
+      __builtin_amdgcn_wave_barrier();
+    };
+    auto sweep_chunk = [&](const double *zc, int ch, bool down, double &carry) {
+      const int l0 = ch * KC, l1 = min(l0 + KC, nz - 1);
+      if (l1 - l0 == KC) sweep(zc, l0, l1, down, carry, std::true_type{});
+      else sweep(zc, l0, l1, down, carry, std::false_type{});
+    };
+    const int mo = min(m0 + (col >> 1), nmodes - 1);
+    const double zl = nz >= 2 ? ztab[ztab_index(true, nmodes, nz, nz - 2, mo)] : 0.;
+    const double e = ev[mo];
+    double xp = 0.;
+    __syncthreads();                                         // chunk 0 is in LDS
+    for (int ch = 0; ch < nch; ++ch) {
+      sweep_chunk(zb + (ch & 1) * (KC * M) + (col >> 1), ch, false, xp);
+      __syncthreads();
+    }
+    {
+      // close the forward sweep: the top level; the singular (0,0) mode gets a Dirichlet condition across the top
+      // cell (src/modpois.f90:209-220)
+      const double bbk = (e == 0.) ? btopD : b[nz] + e;
+      const double ak = a[nz];
+      const double d = c[nz - 1] * zl;
+      const double z = bbk - ak * d;
+      const double xc = (xs[(size_t)(nz - 1) * C + col] - ak * xp) / z;
+      __builtin_amdgcn_wave_barrier();
+      if (lane < C) xs[(size_t)(nz - 1) * C + col] = xc;
+      __builtin_amdgcn_wave_barrier();
+      xp = xc;
+    }
+    for (int t = 0; t < nch; ++t) {
+      const int ch = nch - 1 - t;
+      sweep_chunk((ch == nch - 1 ? zt : zb + (ch & 1) * (KC * M)) + (col >> 1), ch, true, xp);
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ---- the movers
+  // Element r of a lane is (level kk0 + 8 r of the chunk, mode mm): the lane's part of every address is fixed, the rest
+  // is uniform (scalar registers).  A mover runs alone on its SIMD for its turn, so every vector instruction it spends
+  // on 64-bit index arithmetic is exposed latency: the full-chunk paths below do none.
+  static_assert(M == 8, "lane -> (level, mode) mapping");
+  const int w = wv - 1;
+  const int kk0 = lane >> 3, mm = lane & 7;
+  const bool modes_full = m0 + M <= nmodes;
+  const unsigned xoff = (unsigned)((size_t)kk0 * st + m0 + mm);       // < 8 nmodes
+  const size_t zrow = (size_t)blockIdx.x * (size_t)(nz - 1) * M;      // this workgroup's run of the blocked tables
+  double2 rx[R];
+  double rz[R], rg[R], rt[R];
+  auto issue_f = [&](int ch) {
+    if (modes_full && ch < nch - 1) {
+      const double *zq = ztab + zrow + (size_t)ch * KC * M;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        rx[r] = (x + (size_t)(ch * KC + 8 * r) * st)[xoff];
+        rz[r] = zq[lane + 64 * r];
+        rg[r] = (a + ch * KC + 1 + 8 * r)[kk0];
+      }
+      return;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int lev = ch * KC + kk0 + 8 * r;
+      const bool ok = lev < nz && m0 + mm < nmodes;
+      rx[r] = ok ? x[(size_t)lev * st + m0 + mm] : make_double2(0., 0.);
+      rz[r] = (ok && lev < nz - 1) ? ztab[ztab_index(true, nmodes, nz, lev, m0 + mm)] : 1.;
+      const int kc_ = min(lev + 1, nz);
+      rg[r] = a[kc_];
+      rt[r] = c[kc_];
+    }
+  };
+  auto commit_f = [&](int ch) {
+    double *zc = zb + (ch & 1) * (KC * M);
+    double *xc = xs + (size_t)ch * KC * C;
+    const bool top = ch == nch - 1;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int idx = lane + 64 * r;
+      if (!top || ch * KC + kk0 + 8 * r < nz) {
+        double2 t = rx[r];
+        t.x = (t.x * scale) * rz[r];
+        t.y = (t.y * scale) * rz[r];
+        *reinterpret_cast<double2 *>(xc + 2 * idx) = t;
+      }
+      zc[idx] = -(rg[r] * rz[r]);
+      if (top) zt[idx] = -(rt[r] * rz[r]);
+    }
+  };
+  if (w < nch) issue_f(w);
+  if (w == 0) commit_f(0);
+  __syncthreads();
+  if (w == 0 && NMV < nch) issue_f(NMV);
+  for (int ch = 0; ch < nch; ++ch) {
+    const int cn = ch + 1;
+    const bool mine = cn < nch && (cn & (NMV - 1)) == w;
+    if (mine) commit_f(cn);
+    __syncthreads();
+    // (after the barrier: when the memory pipeline is backed up the issue itself stalls, and nobody should wait for it)
+    if (mine && cn + NMV < nch) issue_f(cn + NMV);
+  }
+  // back substitution: two slots of -(c z) per mover (chunks cb and cb - 4 of its own), the finished chunk streams out
+  double bzA[R], bzB[R];
+  auto issue_b = [&](int ch, double (&bz)[R]) {        // ch <= nch - 2: every level of the chunk is below the top
+    if (modes_full) {
+      const double *zq = ztabc + zrow + (size_t)ch * KC * M;
+#pragma unroll
+      for (int r = 0; r < R; ++r) bz[r] = zq[lane + 64 * r];
+      return;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int lev = ch * KC + kk0 + 8 * r;
+      bz[r] = m0 + mm < nmodes ? ztabc[ztab_index(true, nmodes, nz, lev, m0 + mm)] : 0.;
+    }
+  };
+  auto commit_b = [&](int ch, const double (&bz)[R]) {
+    double *zc = zb + (ch & 1) * (KC * M);
+#pragma unroll
+    for (int r = 0; r < R; ++r) zc[lane + 64 * r] = bz[r];
+  };
+  // own chunks <= nch-2, from the top: c0 = the largest one, then c0 - 4, ...; slot A holds the even-numbered turns
+  int c0 = nch - 2;
+  while (c0 >= 0 && (c0 & (NMV - 1)) != w) --c0;
+  if (c0 >= 0) issue_b(c0, bzA);
+  if (c0 - NMV >= 0) issue_b(c0 - NMV, bzB);
+  bool useA = true;
+  for (int t = 0; t < nch; ++t) {
+    const int ch = nch - 1 - t;
+    const int cn = ch - 1;                                   // coefficients the next period needs
+    const bool mine = cn >= 0 && (cn & (NMV - 1)) == w;
+    if (mine) { if (useA) commit_b(cn, bzA); else commit_b(cn, bzB); }
+    __syncthreads();
+    if ((ch & (NMV - 1)) == w) {
+      const double *xc = xs + (size_t)ch * KC * C;
+      if (modes_full && ch * KC + KC <= nz) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          (x + (size_t)(ch * KC + 8 * r) * st)[xoff] = *reinterpret_cast<const double2 *>(xc + 2 * (lane + 64 * r));
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int lev = ch * KC + kk0 + 8 * r;
+          if (lev < nz && m0 + mm < nmodes)
+            x[(size_t)lev * st + m0 + mm] = *reinterpret_cast<const double2 *>(xc + 2 * (lane + 64 * r));
+        }
+      }
+    }
+    if (mine) {
+      if (cn - 2 * NMV >= 0) { if (useA) issue_b(cn - 2 * NMV, bzA); else issue_b(cn - 2 * NMV, bzB); }
+      useA = !useA;
+    }
+  }
+}
+
 // LDS variant or streaming kernel?  Decided once per table (the table's layout follows the kernel).
 // UDC_THOMAS: 0 = streaming kernel, 3 = LDS kernel whenever it fits; default: the LDS kernel while two workgroups
 // fit on a CU (nz <= ~590).  Measured on MI355X: 512x512x256 (132K modes) 0.389 ms against 0.509 ms streaming,
 // 1024x512x512 (263K modes, 2 workgroups per CU) 2.12 against 2.17 ms.
-static size_t thomas_lds_bytes(int nz, int M, int KC) { return ((size_t)nz * 2 * M + 3 * (size_t)KC * M) * sizeof(double); }
+static size_t thomas_lds_bytes(int nz, int M, int KC) { return ((size_t)nz * 2 * M + 3 * (size_t)KC * M + 4 * 2 * M * 2) * sizeof(double); }
 static bool thomas_wants_lds(long nmodes, int nz) {
   (void)nmodes;
   const char *env = getenv("UDC_THOMAS");
@@ -408,28 +698,39 @@ static size_t ztab_doubles(long nmodes, int nz) { return (size_t)((nmodes + ZB -
 static int launch_thomas(udc_handle *h, bool lds, long nmodes, int nz, double scale, const double *ev, const double *ztab, double2 *x) {
   const size_t full = 160 * 1024 - 1024;
   auto need = [&](int M, int KC) { return thomas_lds_bytes(nz, M, KC); };
-#define UDC_TL(M, KC, D, DB)                                                                                    \
+#define UDC_TL(M, KC, D, DB, PART)                                                                               \
   do {                                                                                                       \
     static bool attr_done = false;                                                                           \
     if (!attr_done) {                                                                                        \
-      if (hipFuncSetAttribute((const void *)thomas_lds_kernel<M, KC, D, DB>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+      if (hipFuncSetAttribute((const void *)thomas_lds_kernel<M, KC, D, DB, PART>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               (int)full) != hipSuccess) return 1;                                            \
       attr_done = true;                                                                                      \
     }                                                                                                        \
-    hipLaunchKernelGGL((thomas_lds_kernel<M, KC, D, DB>), dim3((unsigned)((nmodes + M - 1) / M)), dim3(256), need(M, KC), \
+    hipLaunchKernelGGL((thomas_lds_kernel<M, KC, D, DB, PART>), dim3((unsigned)((nmodes + M - 1) / M)), dim3(256), need(M, KC), \
                        h->stream, (int)nmodes, nz, scale, ev, h->tri, h->btopD, ztab, x);                    \
     return 0;                                                                                                \
   } while (0)
-  // 4 workgroups per CU at nz = 256, 2 at nz = 512.  D = chunks of x / pivot loads in flight per workgroup in the forward
-  // sweep (measured at 256^3: 1 -> 0.114 ms, 2 -> 0.113, 3 -> 0.117, 4 -> 0.135 (130 VGPRs, 3 waves/SIMD); at
-  // 1024x512x512: 2 -> 2.24, 3 -> 2.22, 4 -> 2.36), DB = chunks of -(c z) in flight in the back substitution (same box:
-  // 2 -> 0.431 / 2.365 ms at 512x512x256 / 1024x512x512, 4 -> 0.415 / 2.32, 8 -> 0.401 / 2.25)
-  const int depth = getenv("UDC_THOMAS_DEPTH") ? atoi(getenv("UDC_THOMAS_DEPTH")) : 2;
+  // Which LDS kernel: with four workgroups on a CU (nz <= 256) the plain one hides its own stalls (256^3 0.107 ms
+  // against 0.123 wave-specialised, 512x512x256 0.393 against 0.441); with two (256 < nz <= ~590) the wave-specialised
+  // one wins (1024x512x512: 1.65-1.72 ms against 2.18-2.25).  UDC_THOMAS_WS=0/1 forces the choice.
+  // thomas_lds_kernel: D = chunks of x / pivot loads per workgroup in the forward sweep, DB = chunks of -(c z) in the
+  // back substitution (same box, 512x512x256 / 1024x512x512: DB 2 -> 0.431 / 2.365 ms, 4 -> 0.415 / 2.32,
+  // 8 -> 0.401 / 2.25; D 2 -> 3 -> 4: 2.24 / 2.22 / 2.36); the partitioned sweeps (PART) 0.123 -> 0.104 ms at 256^3.
   if (lds) {
-    const int db = getenv("UDC_THOMAS_DB") ? atoi(getenv("UDC_THOMAS_DB")) : 8;
-    if (depth <= 1) UDC_TL(8, 32, 1, 8);
-    if (db <= 2) UDC_TL(8, 32, 2, 2);
-    UDC_TL(8, 32, 2, 8);
+    const char *wse = getenv("UDC_THOMAS_WS");
+    const bool ws = wse ? atoi(wse) != 0 : need(8, 32) * 4 > full;
+    if (ws) {
+      static bool ws_attr = false;
+      if (!ws_attr) {
+        if (hipFuncSetAttribute((const void *)thomas_ws_kernel<8, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)full) != hipSuccess) return 1;
+        ws_attr = true;
+      }
+      hipLaunchKernelGGL((thomas_ws_kernel<8, 32>), dim3((unsigned)((nmodes + 7) / 8)), dim3(320), need(8, 32), h->stream, (int)nmodes, nz,
+                         scale, ev, h->tri, h->btopD, ztab, x);
+      return 0;
+    }
+    if (getenv("UDC_THOMAS_PART") && atoi(getenv("UDC_THOMAS_PART")) == 0) UDC_TL(8, 32, 2, 8, false);
+    UDC_TL(8, 32, 2, 8, true);
   }
 #undef UDC_TL
   hipLaunchKernelGGL(thomas_kernel, dim3((unsigned)((nmodes + 63) / 64)), dim3(64), 0, h->stream, (int)nmodes, nz, scale,
