@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void mom_kernel(Geo g, TileGrid tg, Metrics m,
     q.e_yp_zm = e[c + sy - sz]; q.e_xp_zm = e[xp - sz];
   }
   double tu = a.up[c], tv = a.vp[c], tw = a.wp[c];
-  mom_arith<ADV, DIFF, LES, FORCES>(q, m, k, numol, tu, tv, tw);
+  mom_arith<ADV, DIFF, LES, FORCES>(q, m, levmet_global(m, k + 1), k, numol, tu, tv, tw);
   a.up[c] = tu;
   a.vp[c] = tv;
   a.wp[c] = tw;   // unchanged at k = 0 unless FORCES (the reference's w loops start at kb+1)

@@ -70,6 +70,7 @@ __global__ __launch_bounds__(NT / CPT, CPT == 1 ? MOM_WAVES : 2) void mom_lds_ke
   static_assert(LN - NT <= NTH, "one halo cell per thread");
   __shared__ double s[4][NF][LN];     // 4 rotating plane buffers: one barrier per level is enough
   __shared__ double sp[ADV ? 3 : 1][ADV ? LN : 1];   // pres0: planes k-1, k and the one being filled (k+1)
+  __shared__ double smet[2][NLEVMET + 4];            // LevelMet of levels k and k+1 (see udc_mom_arith.h)
 
   // workgroup -> (tile, k-chunk); XCD-aware like tile_decode but with chunks instead of planes
   const unsigned L = blockIdx.x;
@@ -139,6 +140,14 @@ __global__ __launch_bounds__(NT / CPT, CPT == 1 ? MOM_WAVES : 2) void mom_lds_ke
     if (p_halo) sp[buf][halo_l] = pst_h;
   };
 
+  // level metrics: thread t < NLEVMET stages entry t, one level ahead of its use, riding on the plane prefetch's wait
+  const bool met_thread = tid < NLEVMET;
+  const double *mp = levmet_src(m, met_thread ? tid : 0) + 1;      // entry of level k = mp[k]
+  double mreg = 0.;
+  if (met_thread) {
+    smet[k0 & 1][tid] = mp[k0];
+    if (k0 + 1 < k1) mreg = mp[k0 + 1];
+  }
   // prologue: planes k0-1, k0, k0+1 into buffers 0..2, plane k0+2 into registers
   Stage<NF, CPT> st;
   load_plane(k0 - 1, st); commit_plane(0, st);
@@ -171,8 +180,13 @@ __global__ __launch_bounds__(NT / CPT, CPT == 1 ? MOM_WAVES : 2) void mom_lds_ke
     if (k + 1 < k1) {
       commit_plane(bn, st);                                // plane k+2, read from level k+1 on
       if (ADV) commit_p(qn);                               // pres0 plane k+1
-      if (k + 2 < k1) { load_plane(k + 3, st); if (ADV) load_p(k + 2); }   // in flight while this level is computed
+      if (met_thread) smet[(k + 1) & 1][tid] = mreg;       // metrics of level k+1 (visible after the next barrier)
+      if (k + 2 < k1) {
+        if (met_thread) mreg = mp[k + 2];
+        load_plane(k + 3, st); if (ADV) load_p(k + 2);     // in flight while this level is computed
+      }
     }
+    const LevelMetLds lm{smet[k & 1]};
     const double *um_ = s[bm][0], *uc_ = s[bc][0], *up_ = s[bp][0];
     const double *vm_ = s[bm][1], *vc_ = s[bc][1], *vp_ = s[bp][1];
     const double *wm_ = s[bm][2], *wc_ = s[bc][2], *wp_ = s[bp][2];
@@ -196,7 +210,7 @@ __global__ __launch_bounds__(NT / CPT, CPT == 1 ? MOM_WAVES : 2) void mom_lds_ke
         qq.e_ym_zm = em_[o - LX]; qq.e_ym_zp = ep_[o - LX]; qq.e_xp_ym = ec_[o + 1 - LX];
         qq.e_yp_zm = em_[o + LX]; qq.e_xp_zm = em_[o + 1];
       }
-      mom_arith<ADV, DIFF, LES, FORCES>(qq, m, k, numol, tu[c], tv[c], tw[c]);
+      mom_arith<ADV, DIFF, LES, FORCES>(qq, m, lm, k, numol, tu[c], tv[c], tw[c]);
       if (PUP) {
         if (a.um_is_u0) { pum[c] = qq.u_c; pvm[c] = qq.v_c; pwm[c] = qq.w_c; }
         tu[c] = tu[c] + pum[c] * a.rk3coefi;
