@@ -5,12 +5,43 @@
 #pragma once
 #include "udc_internal.h"
 
-template <int SGS, class Acc>
-__device__ __forceinline__ void closure_arith(const Acc &A, const Metrics &m, const Params &pr, int k,
+// The level entries of the metric tables the closure reads (kf = k + 1), as for the momentum sweep (udc_mom_arith.h):
+// from the tables themselves (ClosMetGlobal) or from a block the marching kernel stages in LDS a level ahead (ClosMetLds).
+constexpr int NCLOSMET = 9;      // dzhi(kf), dzhi(kf+1), dzfi(kf), mlen(kf), dzf(kf-1), dzf(kf), dzf(kf+1), dzfiq(kf), dzf2(kf)
+__device__ __forceinline__ const double *closmet_src(const Metrics &m, int t) {
+  switch (t) {
+    case 0: return m.dzhi;
+    case 1: return m.dzhi + 1;
+    case 2: return m.dzfi;
+    case 3: return m.mlen;
+    case 4: return m.dzf - 1;
+    case 5: return m.dzf;
+    case 6: return m.dzf + 1;
+    case 7: return m.dzfiq;
+    default: return m.dzf2;
+  }
+}
+struct ClosMetGlobal {
+  const Metrics &m;
+  int kf;
+  __device__ __forceinline__ double get(int t) const { return closmet_src(m, t)[kf]; }
+};
+struct ClosMetLds {
+  const double *p;
+  __device__ __forceinline__ double get(int t) const {      // uniform: scalar registers
+    union { double d; int i[2]; } u;
+    u.d = p[t];
+    u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]);
+    u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
+    return u.d;
+  }
+};
+
+template <int SGS, class Acc, class LM>
+__device__ __forceinline__ void closure_arith(const Acc &A, const Metrics &m, const LM &lm, const Params &pr, int k,
                                               double &em, double &eh) {
-  const int kf = k + 1;
   const double dxi = m.dxi, dyi = m.dyi;
-  const double dzhi_k = m.dzhi[kf], dzhi_kp = m.dzhi[kf + 1], dzfi_k = m.dzfi[kf];
+  const double dzhi_k = lm.get(0), dzhi_kp = lm.get(1), dzfi_k = lm.get(2);
   if (SGS == 1) {
     double t, strain2;
     t = (A.u(1, 0, 0) - A.u(0, 0, 0)) * dxi; strain2 = t * t;
@@ -31,14 +62,14 @@ __device__ __forceinline__ void closure_arith(const Acc &A, const Metrics &m, co
     a3 = (A.v(0, 1, 0) - A.v(0, 1, -1)) * dzhi_k + (A.w(0, 1, 0) - A.w(0, 0, 0)) * dyi;
     a4 = (A.v(0, 1, 1) - A.v(0, 1, 0)) * dzhi_kp + (A.w(0, 1, 1) - A.w(0, 0, 1)) * dyi;
     strain2 = strain2 + 0.125 * (a1 * a1 + a2 * a2 + a3 * a3 + a4 * a4);
-    const double ml = m.mlen[kf];
+    const double ml = lm.get(3);
     em = (ml * ml) * sqrt(2. * strain2);
     if (pr.bare) { eh = 0.; return; }
     eh = em * pr.prandtli;
     em = em + pr.numol;
     eh = eh + pr.numol * pr.prandtlmoli;
   } else {
-    const double dzf_k = m.dzf[kf], dzf_km = m.dzf[kf - 1], dzf_kp = m.dzf[kf + 1];
+    const double dzf_k = lm.get(5), dzf_km = lm.get(4), dzf_kp = lm.get(6);
     const double a11 = (A.u(1, 0, 0) - A.u(0, 0, 0)) * dxi;
     const double a12 = (A.v(1, 1, 0) + A.v(1, 0, 0) - A.v(-1, 1, 0) - A.v(-1, 0, 0)) * m.dxiq;
     const double a13 = (A.w(1, 0, 1) + A.w(1, 0, 0) - A.w(-1, 0, 1) - A.w(-1, 0, 0)) * m.dxiq;
@@ -46,13 +77,13 @@ __device__ __forceinline__ void closure_arith(const Acc &A, const Metrics &m, co
     const double a22 = (A.v(0, 1, 0) - A.v(0, 0, 0)) * dyi;
     const double a23 = (A.w(0, 1, 1) + A.w(0, 1, 0) - A.w(0, -1, 1) - A.w(0, -1, 0)) * m.dyiq;
     const double a31 = (((A.u(1, 0, 1) + A.u(0, 0, 1)) * dzf_k + (A.u(1, 0, 0) + A.u(0, 0, 0)) * dzf_kp) * dzhi_kp
-                      - ((A.u(1, 0, 0) + A.u(0, 0, 0)) * dzf_km + (A.u(1, 0, -1) + A.u(0, 0, -1)) * dzf_k) * dzhi_k) * m.dzfiq[kf];
+                      - ((A.u(1, 0, 0) + A.u(0, 0, 0)) * dzf_km + (A.u(1, 0, -1) + A.u(0, 0, -1)) * dzf_k) * dzhi_k) * lm.get(7);
     const double a32 = (((A.v(0, 1, 1) + A.v(0, 0, 1)) * dzf_k + (A.v(0, 1, 0) + A.v(0, 0, 0)) * dzf_kp) * dzhi_kp
-                      - ((A.v(0, 1, 0) + A.v(0, 0, 0)) * dzf_km + (A.v(0, 1, -1) + A.v(0, 0, -1)) * dzf_k) * dzhi_k) * m.dzfiq[kf];
+                      - ((A.v(0, 1, 0) + A.v(0, 0, 0)) * dzf_km + (A.v(0, 1, -1) + A.v(0, 0, -1)) * dzf_k) * dzhi_k) * lm.get(7);
     const double a33 = (A.w(0, 0, 1) - A.w(0, 0, 0)) * dzfi_k;
     const double aa = a11 * a11 + a21 * a21 + a31 * a31 + a12 * a12 + a22 * a22 + a32 * a32
                     + a13 * a13 + a23 * a23 + a33 * a33;
-    const double dx2 = m.dx2, dy2 = m.dy2, dz2 = m.dzf2[kf];
+    const double dx2 = m.dx2, dy2 = m.dy2, dz2 = lm.get(8);
     const double b11 = dx2 * a11 * a11 + dy2 * a21 * a21 + dz2 * a31 * a31;
     const double b22 = dx2 * a12 * a12 + dy2 * a22 * a22 + dz2 * a32 * a32;
     const double b12 = dx2 * a11 * a12 + dy2 * a21 * a22 + dz2 * a31 * a32;

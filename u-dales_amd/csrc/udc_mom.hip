@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void closure_kernel(Geo g, TileGrid tg, Metric
   const long r0 = g.idx(0, j, k);
   GlobalAcc A{u, v, w, r0 + i, r0 + wrapm(i, g.nx), r0 + wrapp(i, g.nx), g.sy, g.sz};
   double em, eh;
-  closure_arith<SGS>(A, m, pr, k, em, eh);
+  closure_arith<SGS>(A, m, ClosMetGlobal{m, k + 1}, pr, k, em, eh);
   ekm[A.c] = em;
   ekh[A.c] = eh;
 }

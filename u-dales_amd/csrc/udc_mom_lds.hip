@@ -246,6 +246,7 @@ __global__ __launch_bounds__(NT) void closure_lds_kernel(Geo g, TileGrid tg, Met
     double *__restrict__ ekm, double *__restrict__ ekh, int kc, int ghosts) {
   constexpr int NF = 3;
   __shared__ double s[4][NF][LN];
+  __shared__ double smet[2][NCLOSMET + 3];       // level metrics of levels k and k+1, staged like the planes
   const unsigned L = blockIdx.x;
   const int chunk = L / tg.tiles;
   const unsigned lp = L - (unsigned)chunk * tg.tiles;
@@ -286,6 +287,13 @@ __global__ __launch_bounds__(NT) void closure_lds_kernel(Geo g, TileGrid tg, Met
       if (has_halo) s[buf][f][halo_l] = st.h[f];
     }
   };
+  const bool met_thread = tid < NCLOSMET;
+  const double *mp = closmet_src(m, met_thread ? tid : 0) + 1;     // entry of level k = mp[k]
+  double mreg = 0.;
+  if (met_thread) {
+    smet[k0 & 1][tid] = mp[k0];
+    if (k0 + 1 < k1) mreg = mp[k0 + 1];
+  }
   Stage<NF> st;
   load_plane(k0 - 1, st); commit_plane(0, st);
   load_plane(k0, st);     commit_plane(1, st);
@@ -296,14 +304,19 @@ __global__ __launch_bounds__(NT) void closure_lds_kernel(Geo g, TileGrid tg, Met
     __syncthreads();
     if (k + 1 < k1) {
       commit_plane(bn, st);
-      if (k + 2 < k1) load_plane(k + 3, st);
+      if (met_thread) smet[(k + 1) & 1][tid] = mreg;
+      if (k + 2 < k1) {
+        if (met_thread) mreg = mp[k + 2];
+        load_plane(k + 3, st);
+      }
     }
+    __builtin_amdgcn_sched_barrier(0);      // the prefetch is issued here, not wherever it shortens live ranges
     if (inside) {
       const int o = own_l;
       LdsAcc A{s[bm][0] + o, s[bc][0] + o, s[bp][0] + o, s[bm][1] + o, s[bc][1] + o, s[bp][1] + o,
                s[bm][2] + o, s[bc][2] + o, s[bp][2] + o};
       double em, eh;
-      closure_arith<SGS>(A, m, pr, k, em, eh);
+      closure_arith<SGS>(A, m, ClosMetLds{smet[k & 1]}, pr, k, em, eh);
       const long c = g.sz * (long)(k + HZ) + own_off;
       ekm[c] = em;
       ekh[c] = eh;

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void scalar_kernel(Geo g, TileGrid tg, Metrics
   const GlobalAcc A{c, ekh, o, (long)g.sy, g.sz, r0 + wrap(i - 1, g.nx), r0 + wrap(i - 2, g.nx), r0 + wrap(i + 1, g.nx), r0 + wrap(i + 2, g.nx)};
   double ul = 0., uh = 0., vl = 0., vh = 0., wl = 0., wh = 0.;
   if (ADV) { ul = u[o]; uh = u[A.xp1]; vl = v[o]; vh = v[o + g.sy]; wl = w[o]; wh = w[o + g.sz]; }
-  cp[o] = scalar_tend<ADV, DIFF, LES>(A, m, k, g.nz, FRESH ? 0. : cp[o], ul, uh, vl, vh, wl, wh, cekh, dfac, gh);
+  cp[o] = scalar_tend<ADV, DIFF, LES>(A, m, ScalMetGlobal{m, k + 1, g.nz}, k, g.nz, FRESH ? 0. : cp[o], ul, uh, vl, vh, wl, wh, cekh, dfac, gh);
 }
 
 inline dim3 cell_grid(const Geo &g, dim3 b) {

@@ -23,21 +23,56 @@ __device__ __forceinline__ double face(double vel, double cm2, double cm1, doubl
   return cf + df * rlim(d1, d2);
 }
 
+// Level entries of the metric tables (kf = k + 1), read from the tables (ScalMetGlobal) or from a block the marching
+// kernels stage in LDS a level ahead (ScalMetLds; see udc_mom_arith.h for why).  Entry t:
+//   0..2 dzf(kf-1), dzf(kf), dzf(kf+1);  3..6 dzhi(max(kf-1,1)), dzhi(kf), dzhi(kf+1), dzhi(min(kf+2,nz+1));
+//   7 dzfi(kf);  8 dzfi5(kf);  9, 10 dzh2i(kf), dzh2i(kf+1)
+constexpr int NSCALMET = 11;
+__device__ __forceinline__ double scalmet_load(const Metrics &m, int t, int kf, int nz) {
+  switch (t) {
+    case 0: return m.dzf[kf - 1];
+    case 1: return m.dzf[kf];
+    case 2: return m.dzf[kf + 1];
+    case 3: return m.dzhi[kf - 1 < 1 ? 1 : kf - 1];
+    case 4: return m.dzhi[kf];
+    case 5: return m.dzhi[kf + 1];
+    case 6: return m.dzhi[kf + 2 > nz + 1 ? nz + 1 : kf + 2];
+    case 7: return m.dzfi[kf];
+    case 8: return m.dzfi5[kf];
+    case 9: return m.dzh2i[kf];
+    default: return m.dzh2i[kf + 1];
+  }
+}
+struct ScalMetGlobal {
+  const Metrics &m;
+  int kf, nz;
+  __device__ __forceinline__ double get(int t) const { return scalmet_load(m, t, kf, nz); }
+};
+struct ScalMetLds {
+  const double *p;
+  __device__ __forceinline__ double get(int t) const {      // uniform: scalar registers
+    union { double d; int i[2]; } u;
+    u.d = p[t];
+    u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]);
+    u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
+    return u.d;
+  }
+};
+
 // ADV: 0 = none, 1 = kappa, 2 = cd2.  t = the tendency so far (0 when it is known to be zero).  ul/uh, vl/vh, wl/wh: the
 // velocities on the low / high faces of the cell; k = device level, nz = levels; gh = kappa_ghosts rule of thl0c.
-template <int ADV, bool DIFF, bool LES, class Acc>
-__device__ __forceinline__ double scalar_tend(const Acc &A, const Metrics &m, int k, int nz, double t, double ul, double uh,
+template <int ADV, bool DIFF, bool LES, class Acc, class LM>
+__device__ __forceinline__ double scalar_tend(const Acc &A, const Metrics &m, const LM &lm, int k, int nz, double t, double ul, double uh,
                                               double vl, double vh, double wl, double wh, double cekh, double dfac, int gh) {
-  const int kf = k + 1;
   const double c0 = A.c(0, 0, 0);
   const double cxm1 = A.c(-1, 0, 0), cxp1 = A.c(1, 0, 0), cym1 = A.c(0, -1, 0), cyp1 = A.c(0, 1, 0), czm1 = A.c(0, 0, -1), czp1 = A.c(0, 0, 1);
   if (ADV == 2) {
     // advecc_2nd, src/modadvection.f90:127-133 and :148-151 (two statements, same order)
-    const double kdzf = m.dzf[kf], kdzfm = m.dzf[kf - 1], kdzfp = m.dzf[kf + 1];
+    const double kdzf = lm.get(1), kdzfm = lm.get(0), kdzfp = lm.get(2);
     t = t - ((uh * (cxp1 + c0) - ul * (cxm1 + c0)) * m.dxi5
            + (vh * (cyp1 + c0) - vl * (cym1 + c0)) * m.dyi5);
-    t = t - (wh * (czp1 * kdzf + c0 * kdzfp) * m.dzhi[kf + 1]
-           - wl * (czm1 * kdzf + c0 * kdzfm) * m.dzhi[kf]) * m.dzfi5[kf];
+    t = t - (wh * (czp1 * kdzf + c0 * kdzfp) * lm.get(5)
+           - wl * (czm1 * kdzf + c0 * kdzfm) * lm.get(4)) * lm.get(8);
   }
   if (ADV == 1) {
     const double cxm2 = A.c(-2, 0, 0), cxp2 = A.c(2, 0, 0);
@@ -66,34 +101,33 @@ __device__ __forceinline__ double scalar_tend(const Acc &A, const Metrics &m, in
       t = (t + (-fh * vh * dyi)) + fl * vl * dyi;
     }
     {  // z: faces kb+1..ke+1 only (no flux through the floor, src/modadvection.f90:385)
-      const int nzp1 = nz + 1;
-      const double hkm1 = m.dzhi[kf - 1 < 1 ? 1 : kf - 1], hk = m.dzhi[kf], hkp1 = m.dzhi[kf + 1];
-      const double hkp2 = m.dzhi[kf + 2 > nzp1 ? nzp1 : kf + 2];
-      const double dzfci = m.dzfi[kf];
-      const double fh = face(wh, kzm1, c0, kzp1, kzp2, hk, hkp1, hkp2, m.dzf[kf + 1]);
+      const double hkm1 = lm.get(3), hk = lm.get(4), hkp1 = lm.get(5);
+      const double hkp2 = lm.get(6);
+      const double dzfci = lm.get(7);
+      const double fh = face(wh, kzm1, c0, kzp1, kzp2, hk, hkp1, hkp2, lm.get(2));
       const double upper = -fh * wh * dzfci;
       double lower = 0.;
       if (k >= 1) {
-        const double fl = face(wl, kzm2, kzm1, c0, kzp1, hkm1, hk, hkp1, m.dzf[kf]);
+        const double fl = face(wl, kzm2, kzm1, c0, kzp1, hkm1, hk, hkp1, lm.get(1));
         lower = fl * wl * dzfci;
       }
       t = (t + upper) + lower;
     }
   }
   if (DIFF) {
-    const double dzf_k = m.dzf[kf], dzf_km = m.dzf[kf - 1], dzf_kp = m.dzf[kf + 1];
+    const double dzf_k = lm.get(1), dzf_km = lm.get(0), dzf_kp = lm.get(2);
     if (LES) {
       const double e0 = A.e(0, 0, 0), exm = A.e(-1, 0, 0), exp_ = A.e(1, 0, 0), eym = A.e(0, -1, 0), eyp = A.e(0, 1, 0),
                    ezm = A.e(0, 0, -1), ezp = A.e(0, 0, 1);
       // dfac = 0.5 with ekh (diffc, src/modsubgrid.f90:569-584) or 1.0 with ekm (diffe, :649-663)
       t = t + dfac * (((exp_ + e0) * (cxp1 - c0) - (e0 + exm) * (c0 - cxm1)) * m.dx2i
                    + ((eyp + e0) * (cyp1 - c0) - (e0 + eym) * (c0 - cym1)) * m.dy2i
-                   + ((dzf_kp * e0 + dzf_k * ezp) * (czp1 - c0) * m.dzh2i[kf + 1]
-                    - (dzf_km * e0 + dzf_k * ezm) * (c0 - czm1) * m.dzh2i[kf]) * m.dzfi[kf]);
+                   + ((dzf_kp * e0 + dzf_k * ezp) * (czp1 - c0) * lm.get(10)
+                    - (dzf_km * e0 + dzf_k * ezm) * (c0 - czm1) * lm.get(9)) * lm.get(7));
     } else {
       t = t + ((cekh * (cxp1 - c0) - cekh * (c0 - cxm1)) * m.dx2i
              + (cekh * (cyp1 - c0) - cekh * (c0 - cym1)) * m.dy2i
-             + (cekh * (czp1 - c0) * m.dzhi[kf + 1] - cekh * (c0 - czm1) * m.dzhi[kf]) * m.dzfi[kf]);
+             + (cekh * (czp1 - c0) * lm.get(5) - cekh * (c0 - czm1) * lm.get(4)) * lm.get(7));
     }
   }
   return t;

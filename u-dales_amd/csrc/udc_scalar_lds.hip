@@ -36,6 +36,7 @@ __global__ __launch_bounds__(NT, 3) void scalar_lds_kernel(Geo g, int gx, int ti
     const double *__restrict__ c, double *__restrict__ cp, int gh, int kc) {
   __shared__ double sc[NCB][CN];
   __shared__ double se[LES ? NEB : 1][LES ? EN : 1];
+  __shared__ double smet[2][NSCALMET + 1];       // level metrics of levels k and k+1 (udc_scalar_arith.h)
   const unsigned Lb = blockIdx.x;
   const int chunk = Lb / tiles;
   const unsigned lp = Lb - (unsigned)chunk * tiles;
@@ -47,6 +48,12 @@ __global__ __launch_bounds__(NT, 3) void scalar_lds_kernel(Geo g, int gx, int ti
   const int i = i0 + tx, j = j0 + ty;
   const bool inside = i < g.nx && j < g.ny;
   const int k0 = chunk * kc, k1 = min(k0 + kc, g.nz);
+  const bool met_thread = tid < NSCALMET;
+  double mreg = 0.;
+  if (met_thread) {
+    smet[k0 & 1][tid] = scalmet_load(m, tid, k0 + 1, g.nz);
+    if (k0 + 1 < k1) mreg = scalmet_load(m, tid, k0 + 2, g.nz);
+  }
 
   // the (up to) two elements of each tile this thread stages: element e -> (lx, ly) row-major in the tile
   long coff[2], eoff[2];
@@ -108,8 +115,14 @@ __global__ __launch_bounds__(NT, 3) void scalar_lds_kernel(Geo g, int gx, int ti
     if (k + 1 < k1) {
       commit_c((cb0 + 5) % NCB);
       commit_e((eb0 + 3) % NEB);
-      if (k + 2 < k1) { load_c(k + 4); load_e(k + 3); }
+      if (met_thread) smet[(k + 1) & 1][tid] = mreg;
+      if (k + 2 < k1) {
+        if (met_thread) mreg = scalmet_load(m, tid, k + 3, g.nz);
+        load_c(k + 4); load_e(k + 3);
+      }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    const ScalMetLds lm{smet[k & 1]};
     if (inside) {
       const long pb = g.sz * (long)(k + HZ);
       LdsAcc A;
@@ -120,7 +133,7 @@ __global__ __launch_bounds__(NT, 3) void scalar_lds_kernel(Geo g, int gx, int ti
       const double ul = u[pb + own], uh = u[pb + xp1], vl = v[pb + own], vh = v[pb + own + g.sy];
       const double wh = w[pb + own + g.sz];
       const double t0 = FRESH ? 0. : cp[pb + own];
-      cp[pb + own] = scalar_tend<ADV, true, LES>(A, m, k, g.nz, t0, ul, uh, vl, vh, wl, wh, cekh, dfac, gh);
+      cp[pb + own] = scalar_tend<ADV, true, LES>(A, m, lm, k, g.nz, t0, ul, uh, vl, vh, wl, wh, cekh, dfac, gh);
       wl = wh;
     }
     cb0 = (cb0 + 1) % NCB;
@@ -144,6 +157,7 @@ __global__ __launch_bounds__(NT, 4) void scalar_kappa_faces_kernel(Geo g, int gx
   __shared__ double se[LES ? NEB : 1][LES ? EN : 1];
   __shared__ double sfx[2][MY][MX + 1];
   __shared__ double sfy[2][MY + 1][MX];
+  __shared__ double smet[2][NSCALMET + 1];       // level metrics of levels k and k+1
   const unsigned Lb = blockIdx.x;
   const int chunk = Lb / tiles;
   const unsigned lp = Lb - (unsigned)chunk * tiles;
@@ -156,6 +170,12 @@ __global__ __launch_bounds__(NT, 4) void scalar_kappa_faces_kernel(Geo g, int gx
   const bool inside = i < g.nx && j < g.ny;
   const int k0 = chunk * kc, k1 = min(k0 + kc, g.nz);
   const int jmax = g.ny + HY - 1;
+  const bool met_thread = tid < NSCALMET;
+  double mreg = 0.;
+  if (met_thread) {
+    smet[k0 & 1][tid] = scalmet_load(m, tid, k0 + 1, g.nz);
+    if (k0 + 1 < k1) mreg = scalmet_load(m, tid, k0 + 2, g.nz);
+  }
 
   long coff[2], eoff[2];
   bool chas[2], ehas[2];
@@ -230,7 +250,6 @@ __global__ __launch_bounds__(NT, 4) void scalar_kappa_faces_kernel(Geo g, int gx
   const long xr_g = (long)((i0 + MX) % g.nx) + (long)g.sy * (min(j0 + lane, jmax) + HY);
   const long yr_g = (long)((i0 + lane) % g.nx) + (long)g.sy * (min(j0 + MY, jmax) + HY);
   const double dxi = m.dxi, dx = m.dx, dyi = m.dyi;
-  const int nzp1 = g.nz + 1;
   const double top = gh == 1 ? 1. : 0.;
 
   __syncthreads();
@@ -257,14 +276,20 @@ __global__ __launch_bounds__(NT, 4) void scalar_kappa_faces_kernel(Geo g, int gx
   };
   load_vel(k0);
   for (int k = k0; k < k1; ++k) {
-    const int fb = k & 1, kf = k + 1;
+    const int fb = k & 1;
     const double ul = nu, vl = nv, wh = nw, ux = nx_, vy = ny_;
     if (k + 1 < k1) {
       commit_co(co[5]);
       commit_eo(eo[3]);
-      if (k + 2 < k1) { load_c(k + 4); load_e(k + 3); }
+      if (met_thread) smet[(k + 1) & 1][tid] = mreg;
+      if (k + 2 < k1) {
+        if (met_thread) mreg = scalmet_load(m, tid, k + 3, g.nz);
+        load_c(k + 4); load_e(k + 3);
+      }
       load_vel(k + 1);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    const ScalMetLds lm{smet[k & 1]};
     const long pb = g.sz * (long)(k + HZ);
     LdsAcc A;
 #pragma unroll
@@ -287,15 +312,15 @@ __global__ __launch_bounds__(NT, 4) void scalar_kappa_faces_kernel(Geo g, int gx
       if (k == g.nz - 1) { kzp1 = top * c0; kzp2 = top * c0; }
       if (k == g.nz - 2) kzp2 = top * kzp1;
     }
-    const double pzh = face(wh, kzm1, c0, kzp1, kzp2, m.dzhi[kf], m.dzhi[kf + 1], m.dzhi[kf + 2 > nzp1 ? nzp1 : kf + 2], m.dzf[kf + 1]) * wh;
-    const double dif = scalar_tend<0, true, LES>(A, m, k, g.nz, 0., 0., 0., 0., 0., 0., 0., cekh, dfac, 0);
+    const double pzh = face(wh, kzm1, c0, kzp1, kzp2, lm.get(4), lm.get(5), lm.get(6), lm.get(2)) * wh;
+    const double dif = scalar_tend<0, true, LES>(A, m, lm, k, g.nz, 0., 0., 0., 0., 0., 0., 0., cekh, dfac, 0);
     __syncthreads();
     const double pxh = sfx[fb][ty][tx + 1], pyh = sfy[fb][ty + 1][tx];
     double t = t0;
     t = (t + (-pxh * dxi)) + pxl * dxi;
     t = (t + (-pyh * dyi)) + pyl * dyi;
     {
-      const double dzfci = m.dzfi[kf];
+      const double dzfci = lm.get(7);
       const double upper = -pzh * dzfci;
       const double lower = k >= 1 ? pzl * dzfci : 0.;
       t = (t + upper) + lower;
