@@ -151,7 +151,13 @@ extern "C" int udc_create(const udc_config *cfg, udc_handle **out) {
   h->no_alias = getenv("UDC_NO_ALIAS") && atoi(getenv("UDC_NO_ALIAS")) != 0;
   h->slab = cfg->nranks > 1 || (getenv("UDC_FORCE_SLAB") && atoi(getenv("UDC_FORCE_SLAB")) != 0);
   g.py = g.ny + 2 * HY; g.pz = g.nz + 2 * HZ;
-  g.sy = g.nx; g.sz = (long)g.nx * g.py; g.n = g.sz * g.pz;
+  // row stride: rows of a power-of-two nx put every row of a tile column on the same few L2 channels and sets, and the
+  // stencil kernels' halo lines evict each other (closure at 1024x512x512: 2.2 x its algorithmic reads, 3.2 -> 2.55 ms with
+  // the padding; no effect at nx = 256).  16 doubles (one 128-B line) of padding after the nx cells of a row for
+  // nx >= 512 and a multiple of 256; never read (x is periodic by index wrap).  UDC_XPAD overrides (0 = none).
+  int xpad = (g.nx >= 512 && g.nx % 256 == 0) ? 16 : 0;
+  if (getenv("UDC_XPAD")) xpad = atoi(getenv("UDC_XPAD")) > 0 ? atoi(getenv("UDC_XPAD")) : 0;
+  g.sy = g.nx + xpad; g.sz = (long)g.sy * g.py; g.n = g.sz * g.pz;
   h->p = Params{cfg->numol, cfg->prandtlmoli, cfg->prandtli, cfg->c_vreman, cfg->csz,
                 cfg->uinf, cfg->vinf, cfg->sgs, cfg->bctopm, cfg->lbottom ? 1 : 0, cfg->z0};
 
@@ -281,7 +287,7 @@ static int copy3d_ptr(udc_handle *h, int field, double *dev, double *host, const
   hipMemcpy3DParms p;
   memset(&p, 0, sizeof(p));
   hipPitchedPtr hp = make_hipPitchedPtr((void *)host, (size_t)hnx * 8, (size_t)hnx * 8, (size_t)hny);
-  hipPitchedPtr dp = make_hipPitchedPtr((void *)dev, (size_t)g.nx * 8, (size_t)g.nx * 8, (size_t)g.py);
+  hipPitchedPtr dp = make_hipPitchedPtr((void *)dev, (size_t)g.sy * 8, (size_t)g.sy * 8, (size_t)g.py);
   hipPos hpos = make_hipPos((size_t)(i0 - lb[0]) * 8, (size_t)(j0 - lb[1]), (size_t)(k0 - lb[2]));
   hipPos dpos = make_hipPos((size_t)(i0 - 1) * 8, (size_t)(j0 - 1 + HY), (size_t)(k0 - 1 + HZ));
   p.extent = make_hipExtent((size_t)(i1 - i0 + 1) * 8, (size_t)(j1 - j0 + 1), (size_t)(k1 - k0 + 1));

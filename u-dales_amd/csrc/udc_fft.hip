@@ -90,6 +90,7 @@ __device__ __forceinline__ double2 *fft_lines(double2 *a, double2 *b, const doub
 struct XArgs {
   int nx, M, MP;            // real length, complex length nx/2, LDS pitch of a line
   int nyl, py;              // local rows, padded rows per plane of the real field
+  int sy;                   // row stride of the real field (doubles)
   long sz;                  // plane stride of the real field (doubles)
   int nkx, cx, P;           // r2c modes nx/2+1, modes per rank, ranks
   int k0, nzc;              // chunk
@@ -124,10 +125,10 @@ __global__ __launch_bounds__(FT) void fftx_fwd_pack_kernel(XArgs q, const double
   // load: row l holds M complex = nx reals, read as double2 (16-B aligned: nx even, rows nx*8 B apart, base 16-B aligned)
   for (int wi = tid; wi < (M << q.lL); wi += FT) {
     const int l = wi >> LM, n = wi & (M - 1);
-    const long ro = q.sz * (long)(k + HZ) + (long)q.nx * (j0 + l + HY);
+    const long ro = q.sz * (long)(k + HZ) + (long)q.sy * (j0 + l + HY);
     if (DIV) {
       const double2 *ru = reinterpret_cast<const double2 *>(dv.pu + ro), *rv = reinterpret_cast<const double2 *>(dv.pv + ro);
-      const double2 *rv1 = reinterpret_cast<const double2 *>(dv.pv + ro + q.nx), *rw = reinterpret_cast<const double2 *>(dv.pw + ro);
+      const double2 *rv1 = reinterpret_cast<const double2 *>(dv.pv + ro + q.sy), *rw = reinterpret_cast<const double2 *>(dv.pw + ro);
       const double2 u = ru[n], un = ru[(n + 1) & (M - 1)], v = rv[n], v1 = rv1[n], w = rw[n];
       double2 w1 = make_double2(0., 0.);
       if (k < dv.nz - 1) w1 = reinterpret_cast<const double2 *>(dv.pw + ro + q.sz)[n];
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(FT) void fftx_bwd_unpack_kernel(XArgs q, const doub
   double2 *z = fft_lines<true, LM>(a, b, tw, q.MP, L);
   for (int wi = tid; wi < (M << q.lL); wi += FT) {
     const int l = wi >> LM, n = wi & (M - 1);
-    double2 *row = reinterpret_cast<double2 *>(p + q.sz * (long)(k + HZ) + (long)q.nx * (j0 + l + HY));
+    double2 *row = reinterpret_cast<double2 *>(p + q.sz * (long)(k + HZ) + (long)q.sy * (j0 + l + HY));
     row[n] = z[l * q.MP + pad(n)];
   }
 }
@@ -314,7 +315,7 @@ int fft_fused_init(udc_handle *h) {
 static XArgs xargs(const udc_handle *h, int k0, int nzc) {
   const Geo &g = h->g;
   const int M = g.nx / 2;
-  return XArgs{g.nx, M, padded(M + 1), g.ny, g.py, g.sz, h->nkx, h->cx, h->cfg.nranks, k0, nzc, ilog2(h->fft_L)};
+  return XArgs{g.nx, M, padded(M + 1), g.ny, g.py, g.sy, g.sz, h->nkx, h->cx, h->cfg.nranks, k0, nzc, ilog2(h->fft_L)};
 }
 static YArgs yargs(const udc_handle *h, int k0, int nzc) {
   return YArgs{h->jtot, padded(h->jtot), h->g.ny, ilog2(h->g.ny), h->cx, h->cfg.nranks, k0, nzc, h->fft_C};

@@ -28,8 +28,8 @@ constexpr int HZ = 2;
 struct Geo {
   int nx, ny, nz;      // local interior (ny = rows of this y-slab)
   int py, pz;          // padded extents ny+2HY, nz+2HZ
-  int sy;              // row stride   (= nx)
-  long sz;             // plane stride (= nx*py)
+  int sy;              // row stride   (nx, or nx + 16 for large power-of-two rows: udc_create)
+  long sz;             // plane stride (= sy*py)
   long n;              // total elements
   __host__ __device__ inline long idx(int i, int j, int k) const {
     return (long)i + (long)sy * (j + HY) + sz * (long)(k + HZ);

@@ -1210,13 +1210,13 @@ int pois_slab_init(udc_handle *h) {
   rocfft_plan_description d = nullptr;
   FFT_OK(rocfft_plan_description_create(&d));
   FFT_OK(rocfft_plan_description_set_data_layout(d, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved,
-                                                 off, off, 1, one, (size_t)nx, 1, one, (size_t)nkxp));
+                                                 off, off, 1, one, (size_t)g.sy, 1, one, (size_t)nkxp));
   FFT_OK(rocfft_plan_create(&h->plan_xf, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
                             rocfft_precision_double, 1, lx, (size_t)g.py * nzc, d));
   rocfft_plan_description_destroy(d);
   FFT_OK(rocfft_plan_description_create(&d));
   FFT_OK(rocfft_plan_description_set_data_layout(d, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real,
-                                                 off, off, 1, one, (size_t)nkxp, 1, one, (size_t)nx));
+                                                 off, off, 1, one, (size_t)nkxp, 1, one, (size_t)g.sy));
   FFT_OK(rocfft_plan_create(&h->plan_xb, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
                             rocfft_precision_double, 1, lx, (size_t)g.py * nzc, d));
   rocfft_plan_description_destroy(d);
