@@ -352,12 +352,32 @@ def main():
         torch.cuda.synchronize()
         core.sync()
 
+    # Warm-up doubles as the per-kernel survey: after a few unmarked substeps every launch is bracketed by HIP events
+    # (one chained event per launch boundary; each costs ~6 us on the GPU timeline, ~4 % of a 256^3 substep) -> the kernel
+    # table and the dominant kernel.  The timed region then carries events around that kernel only (two per substep), so
+    # `value` is not taxed by the survey and roofline.achieved is still measured live inside the timed region.
     rk = 1
-    for _ in range(args.warmup):
+    skip = min(3, args.warmup)
+    for _ in range(skip):
         core.substep(rk, dt, True)
         rk = rk % 3 + 1
+    table, n_tab, tab_stage1 = {}, args.warmup - skip, 0
+    if n_tab > 0:
+        core.sync()
+        core.profile(True)
+        core.profile_reset()
+        for _ in range(n_tab):
+            core.substep(rk, dt, True)
+            tab_stage1 += rk == 1
+            rk = rk % 3 + 1
+        core.sync()
+        table = core.profile_get()
+        core.profile(False)
+    nscal = args.nsv                      # transported scalars the integrate kernel also advances (the bench deck has no thl, qt)
+    cand = [k for k in table if algo_bytes(k, nscal)]
+    dom = max(cand, key=lambda k: table[k][0]) if cand else None
     barrier()
-    core.profile(True)
+    core.profile(True, focus=dom)
     core.profile_reset()
     stage1 = 0
     t0 = time.perf_counter()
@@ -387,24 +407,33 @@ def main():
     poisson_ms = allmax(time_loop(core, core.poisson, 20, barrier))
     # the same solve as the fused substep runs it (pup mode: the divergence of the stored predicted velocity, on the slab
     # path inside the x transform; projection fused with the RK3 update): substep time minus its non-Poisson kernels
-    nonpois = sum(ms for name, (ms, cnt) in prof.items() if name.startswith(("closure", "mom_", "bottom", "scalar"))) / max(args.steps, 1)
+    survey = table if table else prof          # (no warm-up: the timed region carried every marker)
+    n_survey = n_tab if table else args.steps
+    nonpois = sum(ms for name, (ms, cnt) in survey.items() if name.startswith(("closure", "mom_", "bottom", "scalar"))) / max(n_survey, 1)
     poisson_in_substep_ms = elapsed / args.steps * 1e3 - nonpois
 
     cells = nx * ny * nz
     cells_local = nx * nyl * nz
     value = cells * args.steps / elapsed
     kernels = {}
-    nscal = args.nsv                      # transported scalars the integrate kernel also advances (the bench deck has no thl, qt)
-    for name, (ms, cnt) in prof.items():
-        ab = algo_bytes(name, nscal, stage1 / max(args.steps, 1))
+    ms_per = elapsed / args.steps * 1e3
+    for name, (ms, cnt) in survey.items():
+        live = table and name in prof          # the dominant kernel: measured inside the timed region
+        if live:
+            ms, cnt = prof[name]
+        s1 = (stage1 / max(args.steps, 1)) if (live or not table) else (tab_stage1 / max(n_tab, 1))
+        ab = algo_bytes(name, nscal, s1)
         avg_ms = ms / max(cnt, 1)
-        ent = {"avg_ms": round(avg_ms, 5), "launches": cnt, "share": round(ms / (elapsed * 1e3), 4)}
+        per_substep = cnt / max(args.steps if (live or not table) else n_tab, 1)
+        ent = {"avg_ms": round(avg_ms, 5), "launches": cnt, "share": round(avg_ms * per_substep / ms_per, 4),
+               "measured": "timed region" if (live or not table) else f"survey over {n_tab} warm-up substeps, every launch marked"}
         if ab:
             gbs = ab * cells_local / (avg_ms * 1e-3) / 1e9
             ent.update({"algo_bytes_per_cell": round(ab, 2), "achieved_GBs": round(gbs, 1),
                         "frac": round(gbs / HBM_PEAK_GBS, 4)})
         kernels[name] = ent
-    dom = max((k for k in kernels if "frac" in kernels[k]), key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"])
+    if dom is None or dom not in kernels:
+        dom = max((k for k in kernels if "frac" in kernels[k]), key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"])
     # HBM traffic of the dominant kernel from the committed PMC collection (profiles/pmc_traffic.json, written by
     # profiles/tools/collect.sh from separate rocprofv3 --pmc passes: counters cannot be read inside a timed run);
     # entries are keyed by workload (grid per GPU, SGS, scalars) and by kernel, so a stale or foreign entry never matches

@@ -34,6 +34,7 @@ extern "C" int udc_version(void) { return 100; }
 // ------------------------------------------------------------------------------ profiling
 ProfScope::ProfScope(udc_handle *h_, const char *name) : h(h_), id(-1) {
   if (!h->prof) return;
+  if (h->prof_focus_on && strncmp(name, h->prof_focus.c_str(), h->prof_focus.size()) != 0) return;
   auto it = h->prof_ids.find(name);
   if (it == h->prof_ids.end()) {
     id = (int)h->prof_names.size();
@@ -59,7 +60,7 @@ ProfScope::~ProfScope() {
   b = prof_take(h);
   hipEventRecord(b, h->stream);
   h->prof_events.push_back({a, b, id, own_a});
-  h->prof_chain = b;
+  h->prof_chain = h->prof_focus_on ? nullptr : b;      // focus mode: the next timed launch is not adjacent
 }
 
 hipEvent_t prof_take(udc_handle *h) {
@@ -88,8 +89,15 @@ static void prof_drain(udc_handle *h) {
 
 extern "C" int udc_profile_enable(udc_handle *h, int on) {
   if (!h) return 1;
-  if (!on) prof_drain(h);
+  prof_drain(h);
+  if (on == 2 && h->prof_focus.empty()) { udc_set_error("udc_profile_enable(2): call udc_profile_focus first"); return 1; }
   h->prof = on != 0;
+  h->prof_focus_on = on == 2;
+  return 0;
+}
+extern "C" int udc_profile_focus(udc_handle *h, const char *name_prefix) {
+  if (!h || !name_prefix) { udc_set_error("udc_profile_focus: null argument"); return 1; }
+  h->prof_focus = name_prefix;
   return 0;
 }
 extern "C" int udc_profile_reset(udc_handle *h) {

@@ -202,6 +202,8 @@ struct udc_handle {
   bool halos_fresh = false, boundary_fresh = false, thermo_fresh = false;
   long n_fused = 0, n_unfused = 0;      // deferred substeps that ran fused / routine by routine (udc_deferred_stats)
   bool prof = false;
+  bool prof_focus_on = false;           // only launches whose name starts with prof_focus are timed
+  std::string prof_focus;
   std::vector<ProfEntry> prof_events;
   std::vector<hipEvent_t> prof_pool;
   hipEvent_t prof_chain = nullptr;      // end marker of the previous profiled launch (start marker of the next)

@@ -371,8 +371,14 @@ class DynCore:
         L._check(self.lib.udc_sync(self.h), "udc_sync")
 
     # ---- measurement
-    def profile(self, on=True):
-        L._check(self.lib.udc_profile_enable(self.h, 1 if on else 0), "udc_profile_enable")
+    def profile(self, on=True, focus=None):
+        """HIP-event timing of the launches: every one (on=True), or only those whose name starts with `focus`
+        (two events per such launch and none elsewhere: affordable inside a timed region)."""
+        if on and focus:
+            L._check(self.lib.udc_profile_focus(self.h, focus.encode()), "udc_profile_focus")
+            L._check(self.lib.udc_profile_enable(self.h, 2), "udc_profile_enable")
+        else:
+            L._check(self.lib.udc_profile_enable(self.h, 1 if on else 0), "udc_profile_enable")
 
     def profile_reset(self):
         self.lib.udc_profile_reset(self.h)
