@@ -860,7 +860,10 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   if ((ops & OP_IBMNORM) && k_ibm_norm(h)) return 1;                                         // src/program.f90:171
   if ((ops & OP_SCALSRC) && k_scalsource(h)) return 1;                                       // src/program.f90:181
   if ((ops & OP_LEV1) && !h->level_forcings.empty() && k_level_forcings(h, 1, fold)) return 1;   // fixuinf1, grwdamp tables
-  if (!fold) {
+  // the ghost row of vp that fillps' divergence reads: folded into the kernels above when the slab is the whole domain --
+  // except for the immersed-boundary routines, which edit listed points only (a solid v point in the first row of the
+  // domain has its periodic image in the ghost row)
+  if (!fold || (h->ibm_on && (ops & (OP_IBMWALL | OP_IBMNORM)))) {
     const int fvp[1] = {UDC_VP};
     if (k_halo_y(h, fvp, 1, 1)) return 1;
   }
