@@ -220,7 +220,11 @@ int udc_level_forcings(udc_handle *h, int when);
 /* Immersed boundary, the sparse corrections (src/modibm.f90).  The point lists are the reference's input files
  * solid_{u,v,w,c}.txt and fluid_boundary_{u,v,w,c}.txt: n rows of GLOBAL 1-based (i, j, k), here as int[n][3]; grid 0 = u,
  * 1 = v, 2 = w, 3 = c (needed when scalars are transported).  udc_ibm_commit builds what initibm derives from them (the masks
- * of :150-186, evaluated at the listed points; lateral neighbours wrap periodically) and keeps this slab's points.
+ * of :150-186, evaluated at the listed points) and keeps this slab's points.  Across the lateral boundaries of the domain a
+ * neighbour is looked up in the periodic image by default; udc_set_ibm_mask_wrap(h, wrapx, wrapy) reproduces what the
+ * reference's masks hold there for a given decomposition: initibm fills their ghost cells with exchange_halo_z only, which
+ * wraps a direction only when it is split over more than one rank (periodic_bc, src/modstartup.f90:662-672) -- with
+ * nprocx = 1 (nprocy = 1) the masks' ghost columns (rows) stay "fluid".  Call it before udc_ibm_commit.
  *   udc_ibmwallfun  ibmwallfun (:1167) without facet wall functions (iwallmom = 1): diffu_corr (:990), diffv_corr (:1033),
  *                   diffw_corr (:1075), diffc_corr (:1120) per scalar -- called after nudge (src/program.f90:166)
  *   udc_ibmnorm     ibmnorm (:697): solid (:748) -- um, vm, wm and their tendencies zeroed at the solid points, svm / svp set
@@ -230,6 +234,7 @@ int udc_level_forcings(udc_handle *h, int when);
  * functions (wallfunmom :1286, wallfunheat :1436; hence thl / qt with immersed boundaries). */
 enum { UDC_IBM_U = 0, UDC_IBM_V = 1, UDC_IBM_W = 2, UDC_IBM_C = 3 };
 int udc_set_ibm_points(udc_handle *h, int grid, const int *solid, int nsolid, const int *bound, int nbound);
+int udc_set_ibm_mask_wrap(udc_handle *h, int wrapx, int wrapy);
 int udc_ibm_commit(udc_handle *h);
 int udc_ibmwallfun(udc_handle *h);
 int udc_ibmnorm(udc_handle *h);

@@ -1510,14 +1510,22 @@ void orc_masscorr(const orc_grid *g, int rk3step, double dt, double *up, const d
  * Immersed boundary, sparse corrections: src/modibm.f90.  Point lists as the reference reads them (solid_*.txt,
  * fluid_boundary_*.txt): pts[3*n + 0..2] = (i, j, k), 1-based; single rank.  Masks are m-arrays holding 1 (fluid) / 0.
  * orc_ibm_mask restates initibm's mask set-up (:150-167): ones, zero at k = kb-1, mask_w also zero at kb, zero at the
- * solid points; the lateral halos are the periodic images (what exchange_halo_z gives on more than one rank). */
-void orc_ibm_mask(const orc_grid *g, int is_w, const int *solid, int nsolid, double *mask) {
+ * solid points.  The lateral ghost cells come from exchange_halo_z alone (:163-165), which wraps a direction only when the
+ * run splits it over more than one rank (periodic_bc, src/modstartup.f90:662-672): wrapx / wrapy say which; without it
+ * the ghost cells keep the initial 1 ("fluid"), which is what the single-rank reference build has. */
+void orc_ibm_mask(const orc_grid *g, int is_w, const int *solid, int nsolid, double *mask, int wrapx, int wrapy) {
   const size_t n = msize(g);
+  const int nx = g->nx, ny = g->ny, nz = g->nz;
   for (size_t q = 0; q < n; ++q) mask[q] = 1.;
-  for (int j = 0; j <= g->ny + 1; ++j)
-    for (int i = 0; i <= g->nx + 1; ++i) { M(mask, i, j, 0) = 0.; if (is_w) M(mask, i, j, 1) = 0.; }
+  for (int j = 0; j <= ny + 1; ++j)
+    for (int i = 0; i <= nx + 1; ++i) { M(mask, i, j, 0) = 0.; if (is_w) M(mask, i, j, 1) = 0.; }
   for (int q = 0; q < nsolid; ++q) M(mask, solid[3 * q], solid[3 * q + 1], solid[3 * q + 2]) = 0.;
-  orc_halos_m(g, mask);
+  if (wrapx)
+    for (int k = 0; k <= nz + 1; ++k)
+      for (int j = 0; j <= ny + 1; ++j) { M(mask, 0, j, k) = M(mask, nx, j, k); M(mask, nx + 1, j, k) = M(mask, 1, j, k); }
+  if (wrapy)
+    for (int k = 0; k <= nz + 1; ++k)
+      for (int i = 0; i <= nx + 1; ++i) { M(mask, i, 0, k) = M(mask, i, ny, k); M(mask, i, ny + 1, k) = M(mask, i, 1, k); }
 }
 /* diffu_corr :990-1030 */
 void orc_ibm_diffu_corr(const orc_grid *g, const int *bnd, int nbnd, const double *mask_u, const double *u0, const double *ekm, double *up) {

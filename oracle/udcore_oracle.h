@@ -96,7 +96,7 @@ typedef struct {
   const int *bnd[4]; int nbnd[4];
   const double *mask[4];
 } orc_ibm;
-void orc_ibm_mask(const orc_grid *g, int is_w, const int *solid, int nsolid, double *mask);
+void orc_ibm_mask(const orc_grid *g, int is_w, const int *solid, int nsolid, double *mask, int wrapx, int wrapy);
 void orc_ibm_diffu_corr(const orc_grid *g, const int *bnd, int nbnd, const double *mask_u, const double *u0, const double *ekm, double *up);
 void orc_ibm_diffv_corr(const orc_grid *g, const int *bnd, int nbnd, const double *mask_v, const double *v0, const double *ekm, double *vp);
 void orc_ibm_diffw_corr(const orc_grid *g, const int *bnd, int nbnd, const double *mask_w, const double *w0, const double *ekm, double *wp);

@@ -377,6 +377,13 @@ CASES.update({
                                                              physics="luvolflowr = .true.\nuflowrate = 1.1\nlvvolflowr = .true.\nvflowrate = 0.04",
                                                              oracle="nsub = 9\ndump_at = 3, 9"), 1.04),
 })
+# immersed boundary against the periodic boundaries: one block in the first rows of y (its solid v points include j = 1,
+# whose periodic image is the ghost row fillps' divergence reads), one in the last rows of y and the last columns of x
+IBM_BLOCKS["run_ibm_edge_16x12x10"] = [(4, 7, 1, 3, 4), (14, 16, 10, 12, 3)]
+CASES.update({
+    "run_ibm_edge_16x12x10": ("run", 57, 16, 12, 10, dict(sgs="vreman", nsv=0, floor=True, randu=0.05, ibm=IBM_BLOCKS["run_ibm_edge_16x12x10"],
+                                                          oracle="nsub = 9\ndump_at = 3, 9"), 1.04),
+})
 LSF_ONLY = ("k_lsf_12x8x24", "k_lsfq_12x8x20", "k_fix1_12x8x6")
 THL_CASES = {"k_tke_moist_12x8x8": dict(dthl=0.25, qt=0.0118, dqt=-8e-5, tke=0.06),
              "run_moistnr_16x8x12s": dict(dthl=0.25, qt=0.0119, dqt=-6e-5),

@@ -150,8 +150,10 @@ class Oracle:
         f(C.byref(self.g), C.byref(s))
 
     # ---- immersed boundary: lists = {grid letter: (solid[n,3], boundary[n,3])} as udcore.ibm.read_ibm returns them
-    def set_ibm(self, lists):
-        """Build the masks (orc_ibm_mask) and make orc_substep run ibmwallfun / ibmnorm; None switches it off."""
+    def set_ibm(self, lists, wrapx=False, wrapy=False):
+        """Build the masks (orc_ibm_mask) and make orc_substep run ibmwallfun / ibmnorm; None switches it off.
+        wrapx / wrapy: the masks' lateral ghost cells are periodic images (a reference run that splits the direction
+        over ranks) or stay "fluid" (one rank: the fixtures' build)."""
         if lists is None:
             self.L.orc_set_ibm(None)
             self._ibm = None
@@ -164,7 +166,8 @@ class Oracle:
             mask = np.zeros(self.mshape())
             f = self.L.orc_ibm_mask
             f.restype = None
-            f(C.byref(self.g), C.c_int(1 if gname == "w" else 0), sol.ctypes.data_as(ip), C.c_int(len(sol)), ptr(mask))
+            f(C.byref(self.g), C.c_int(1 if gname == "w" else 0), sol.ctypes.data_as(ip), C.c_int(len(sol)), ptr(mask),
+              C.c_int(int(wrapx)), C.c_int(int(wrapy)))
             keep += [sol, bnd, mask]
             b.sol[q], b.nsol[q] = sol.ctypes.data_as(ip), len(sol)
             b.bnd[q], b.nbnd[q] = bnd.ctypes.data_as(ip), len(bnd)

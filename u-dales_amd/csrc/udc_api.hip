@@ -743,8 +743,10 @@ static int now_forces(udc_handle *h) {
 static int now_poisson(udc_handle *h, int rk3step, double dt) {
   if (tend_clean(h) || um_materialise(h)) return 1;
   const double rk3coef = rk3step == 0 ? 1. : dt / (4. - (double)rk3step);
-  const int fvp[1] = {UDC_VP};
-  if (k_halo_y(h, fvp, 1, 1)) return 1;            // pvp(je+1) = pvp(jb): bcpup
+  // pvp(je+1) = pvp(jb) of bcpup: pvp = vp + vm / rk3coef is formed on the fly from the two, so both ghost rows count
+  // (ibmnorm edits vm at the listed points after `halos` has run)
+  const int fvp[2] = {UDC_VP, UDC_VM};
+  if (k_halo_y(h, fvp, h->ibm_on ? 2 : 1, 1)) return 1;
   if (k_divergence_rhs(h, rk3coef, false)) return 1;       // fillps
   if (k_poisson_solve(h)) return 1;
   const int fp[1] = {UDC_P};

@@ -221,6 +221,13 @@ static int upload_points(udc_handle *h, const std::vector<int> &pts, const std::
   return 0;
 }
 
+extern "C" int udc_set_ibm_mask_wrap(udc_handle *h, int wrapx, int wrapy) {
+  if (!h) { udc_set_error("null handle"); return 1; }
+  h->ibm_wrap_x = wrapx != 0;
+  h->ibm_wrap_y = wrapy != 0;
+  return 0;
+}
+
 extern "C" int udc_ibm_commit(udc_handle *h) {
   if (!h) { udc_set_error("null handle"); return 1; }
   HIP_OK(hipSetDevice(h->device));
@@ -232,8 +239,9 @@ extern "C" int udc_ibm_commit(udc_handle *h) {
   for (int n : h->slots)
     if (n >= 13) { udc_set_error("udc_ibm_commit: thl, qt and e12 with immersed boundaries need the facet wall functions (wallfunheat), which this build does not have"); return 1; }
   const int nx = h->g.nx, ny = h->jtot, nz = h->g.nz, j0 = h->cfg.rank * h->g.ny, nyl = h->g.ny;
-  // masks as initibm builds them (src/modibm.f90:150-186): 1 = fluid; planes k = 0 (kb-1) .. nz+1; lateral neighbours
-  // wrap periodically (what exchange_halo_z gives the reference on more than one rank)
+  // masks as initibm builds them (src/modibm.f90:150-186): 1 = fluid; planes k = 0 (kb-1) .. nz+1.  Beyond a lateral
+  // boundary of the domain: the periodic image, or "fluid" where the reference's exchange_halo_z would not have wrapped
+  // (a direction held by one rank; udc_set_ibm_mask_wrap)
   const size_t plane = (size_t)nx * ny, msz = plane * (nz + 2);
   std::vector<std::vector<unsigned char>> mask(4);
   for (int gq = 0; gq < 4; ++gq) {
@@ -245,7 +253,10 @@ extern "C" int udc_ibm_commit(udc_handle *h) {
     for (size_t q = 0; q < s.size() / 3; ++q)
       mask[gq][(size_t)(s[3 * q] - 1) + (size_t)nx * (s[3 * q + 1] - 1) + plane * s[3 * q + 2]] = 0;
   }
-  auto at = [&](int gq, int i, int j, int k) -> unsigned char {      // 1-based i, j with wrap; k = 0..nz+1
+  const bool wrapx = h->ibm_wrap_x, wrapy = h->ibm_wrap_y;
+  auto at = [&](int gq, int i, int j, int k) -> unsigned char {      // 1-based i, j; k = 0..nz+1
+    if ((i < 1 || i > nx) && !wrapx) return 1;
+    if ((j < 1 || j > ny) && !wrapy) return 1;
     i = (i - 1 + nx) % nx; j = (j - 1 + ny) % ny;
     return mask[gq][(size_t)i + (size_t)nx * j + plane * k];
   };

@@ -185,6 +185,7 @@ struct udc_handle {
   };
   IbmGrid ibm[4];
   bool ibm_on = false;
+  bool ibm_wrap_x = true, ibm_wrap_y = true;     // mask look-ups across the domain's lateral boundaries (udc_set_ibm_mask_wrap)
   double *ibm_wlev = nullptr;           // masscorr's per-level weights with the masks, u then v ([2][nz+2])
   // statistics accumulators (udc_stats.hip), UDC_ST_* ids
   std::vector<double *> stats;

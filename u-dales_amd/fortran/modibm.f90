@@ -123,11 +123,16 @@ contains
   !> hand the lists to the device once its handle exists (first call of ibmwallfun / ibmnorm, or of anything else)
   subroutine ibm_to_device
     use udc_iface
+    use modmpi, only : nprocx, nprocy
     integer :: q
     integer(c_int) :: none(3)
     if (.not. ibm_pending) return
     call udc_ensure
     none = 0
+    ! initibm's masks get their ghost cells from exchange_halo_z alone, which wraps a direction only when this run splits
+    ! it over ranks (periodic_bc, src/modstartup.f90:662-672): the device looks neighbours up the same way
+    call udc_check(udc_set_ibm_mask_wrap(udc_h, merge(1_c_int, 0_c_int, nprocx > 1), merge(1_c_int, 0_c_int, nprocy > 1)), &
+                   'udc_set_ibm_mask_wrap')
     do q = 0, 3
       if (lists(q)%given) then
         call udc_check(udc_set_ibm_points(udc_h, int(q, c_int), lists(q)%sol, int(size(lists(q)%sol, 2), c_int), &

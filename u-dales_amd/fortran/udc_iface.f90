@@ -139,6 +139,11 @@ module udc_iface
       import :: c_int, c_ptr
       type(c_ptr), value :: h
     end function
+    integer(c_int) function udc_set_ibm_mask_wrap(h, wrapx, wrapy) bind(C, name='udc_set_ibm_mask_wrap')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+      integer(c_int), value :: wrapx, wrapy
+    end function
     integer(c_int) function udc_ibmwallfun(h) bind(C, name='udc_ibmwallfun')
       import :: c_int, c_ptr
       type(c_ptr), value :: h

@@ -338,6 +338,11 @@ class DynCore:
         L._check(self.lib.udc_set_ibm_points(self.h, int(grid), s.ctypes.data_as(ip), len(s), b.ctypes.data_as(ip), len(b)),
                  "udc_set_ibm_points")
 
+    def set_ibm_mask_wrap(self, wrapx, wrapy):
+        """Mask look-ups across the domain's lateral boundaries: periodic image (True) or "fluid" (False) -- the
+        reference's masks hold the latter in a direction its run keeps on one rank (udcore.h)."""
+        L._check(self.lib.udc_set_ibm_mask_wrap(self.h, int(bool(wrapx)), int(bool(wrapy))), "udc_set_ibm_mask_wrap")
+
     def ibm_commit(self):
         L._check(self.lib.udc_ibm_commit(self.h), "udc_ibm_commit")
 

@@ -46,6 +46,8 @@ def apply_ibm(core, deck):
     if deck.get("PHYSICS", "ltempeq") or deck.get("PHYSICS", "lmoist"):
         raise ValueError("libm with ltempeq / lmoist needs the facet heat wall functions (wallfunheat), not on the device path")
     lists = read_ibm(deck)
+    # the masks' ghost cells as the reference run of this deck has them: wrapped only in a direction it splits over ranks
+    core.set_ibm_mask_wrap(int(deck.get("RUN", "nprocx")) > 1, int(deck.get("RUN", "nprocy")) > 1)
     for q, g in enumerate(GRIDS):
         if g in lists:
             core.set_ibm_points(q, *lists[g])
