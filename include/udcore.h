@@ -193,8 +193,12 @@ int udc_subgrid(udc_handle *h);
 /* bottom      src/modibm.f90:1998       floor (lbottom): wfmneutral (src/modwallfunctions.f90:263-350) replaces the
  *             resolved viscous flux through the floor in up,vp(kb) by the neutral log-law stress; zero-flux floor
  *             for the scalars (:2073-2090).  Called between subgrid and forces (src/program.f90:146-160).
- *             No-op when cfg.lbottom == 0.  The tau_x/tau_y/momfluxb diagnostics are not kept. */
+ *             No-op when cfg.lbottom == 0.  tau_x, tau_y, thl_flux (what bottom added to up, vp, thlp: :2015-2018, 2094-2097;
+ *             nonzero on the k = kb plane only, the reference's fielddump variables) are kept on request:
+ *             udc_bottom_diagnostics(h, 1), then udc_bottom_diag_get(h, 0 | 1 | 2, out[ny_l * nx]) after a substep. */
 int udc_bottom(udc_handle *h);
+int udc_bottom_diagnostics(udc_handle *h, int on);
+int udc_bottom_diag_get(udc_handle *h, int which, double *out);      /* 0 tau_x, 1 tau_y, 2 thl_flux */
 /* forces      src/modforces.f90:46      neutral branch: up -= dpdxl(k), vp -= dpdyl(k), wp(kb)=0 */
 int udc_forces(udc_handle *h);
 /* coriolis    src/modforces.f90:600     mode 1 = lcoriol: Coriolis terms with om22 = 2 omega cos(lat), om23 = 2 omega sin(lat)

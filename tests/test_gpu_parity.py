@@ -120,9 +120,17 @@ def test_each_routine_matches_reference(name, iexp):
         got = core.download(L.scalar_field(L.SVP, n), halo=2)
         assert relerr(interior(got, 2), interior(carr(fix, f"sub.svp_{n + 1:02d}", nz), 2)) <= KERNEL_TOL
     if "bot.up" in fix:       # floor wall function on top of the subgrid tendencies (`bottom` -> wfmneutral)
+        core.bottom_diagnostics(True)
         core.bottom()
         for k in ("up", "vp"):
             assert relerr(interior(core.download(k)), interior(marr(fix, "bot." + k, nz))) <= KERNEL_TOL, k
+        # tau_x, tau_y, thl_flux: what `bottom` added (src/modibm.f90:2094-2097: `up - up_before`, same subtraction here),
+        # from the reference's own before / after dumps; nonzero on the k = kb plane only
+        for nm, k in (("tau_x", "up"), ("tau_y", "vp")) + ((("thl_flux", "thlp"),) if thl else ()):
+            inc = interior(marr(fix, "bot." + k, nz))[0] - interior(marr(fix, "sub." + k, nz))[0]
+            got = core.bottom_diag(nm)
+            assert np.abs(inc).max() > 0 and np.abs(got - inc).max() <= 1e-12 * np.abs(inc).max(), nm
+            assert np.all(interior(marr(fix, "bot." + k, nz))[1:] == interior(marr(fix, "sub." + k, nz))[1:])
         assert relerr(interior(core.download("up")), interior(marr(fix, "sub.up", nz))) > 1e-6
         if thl:   # floor flux wtsurf
             assert relerr(interior(core.download("thlp")), interior(marr(fix, "bot.thlp", nz))) <= KERNEL_TOL

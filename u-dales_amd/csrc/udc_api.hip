@@ -239,6 +239,7 @@ extern "C" int udc_destroy(udc_handle *h) {
   for (auto &f : h->level_forcings) { if (f.A) hipFree(f.A); if (f.stage) hipHostFree(f.stage); if (f.copied) hipEventDestroy(f.copied); }
   for (double *p : h->fields) if (p) hipFree(p);
   if (h->metrics_dev) hipFree(h->metrics_dev);
+  for (int q = 0; q < 3; ++q) if (h->bottom_diag[q]) hipFree(h->bottom_diag[q]);
   if (h->red) hipFree(h->red);
   if (h->red_host) hipHostFree(h->red_host);
   if (h->thlpcar) hipFree(h->thlpcar);
@@ -770,6 +771,34 @@ static int scalar_halo_list(udc_handle *h, int rk3step, std::vector<int> &f) {
     f.push_back(UDC_SV0 + 3 * n);
     if (rk3step == 3 || rk3step < 0) f.push_back(UDC_SVM + 3 * n);
   }
+  return 0;
+}
+
+// tau_x, tau_y, thl_flux of `bottom` (src/modibm.f90:2015-2018, 2094-2097)
+extern "C" int udc_bottom_diagnostics(udc_handle *h, int on) {
+  if (!h) { udc_set_error("null handle"); return 1; }
+  HIP_OK(hipSetDevice(h->device));
+  if (udc_flush_pending(h)) return 1;
+  const size_t n = (size_t)h->g.nx * h->g.ny;
+  for (int q = 0; q < 3; ++q) {
+    if (on && !h->bottom_diag[q]) {
+      HIP_OK(hipMalloc(&h->bottom_diag[q], sizeof(double) * n));
+      HIP_OK(hipMemsetAsync(h->bottom_diag[q], 0, sizeof(double) * n, h->stream));
+    } else if (!on && h->bottom_diag[q]) {
+      HIP_OK(hipStreamSynchronize(h->stream));
+      HIP_OK(hipFree(h->bottom_diag[q]));
+      h->bottom_diag[q] = nullptr;
+    }
+  }
+  return 0;
+}
+extern "C" int udc_bottom_diag_get(udc_handle *h, int which, double *out) {
+  if (!h || !out) { udc_set_error("udc_bottom_diag_get: null argument"); return 1; }
+  if (which < 0 || which > 2 || !h->bottom_diag[which]) { udc_set_error("udc_bottom_diag_get: enable with udc_bottom_diagnostics first"); return 1; }
+  HIP_OK(hipSetDevice(h->device));
+  if (udc_flush_pending(h)) return 1;
+  HIP_OK(hipMemcpyAsync(out, h->bottom_diag[which], sizeof(double) * (size_t)h->g.nx * h->g.ny, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
   return 0;
 }
 

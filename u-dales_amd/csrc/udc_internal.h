@@ -184,6 +184,7 @@ struct udc_handle {
     std::vector<double> fluid_cnt;
   };
   IbmGrid ibm[4];
+  double *bottom_diag[3] = {nullptr, nullptr, nullptr};      // tau_x, tau_y, thl_flux planes [ny_l][nx] (udc_bottom_diagnostics)
   bool ibm_on = false;
   bool ibm_wrap_x = true, ibm_wrap_y = true;     // mask look-ups across the domain's lateral boundaries (udc_set_ibm_mask_wrap)
   double *ibm_wlev = nullptr;           // masscorr's per-level weights with the masks, u then v ([2][nz+2])

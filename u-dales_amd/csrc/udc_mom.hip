@@ -128,7 +128,8 @@ __global__ __launch_bounds__(256) void forces_kernel(Geo g, TileGrid tg, Metrics
 
 // `bottom` with lbottom (src/modibm.f90:2021-2026, :2073-2090): wfmneutral case 91
 // (src/modwallfunctions.f90:309-346) on the k = kb plane; one thread per (i, j).  The uniform grid has
-// dxf = dx and dxhi = 1/dx.  The momfluxb / tau_x / tau_y diagnostics are not kept.
+// dxf = dx and dxhi = 1/dx.  tau_x, tau_y, thl_flux (src/modibm.f90:2015-2018, 2094-2097: what `bottom` added to up, vp,
+// thlp, nonzero on the k = kb plane only) are kept as planes when asked for (udc_bottom_diagnostics).
 struct BottomArgs {
   const double *u0, *v0, *ekm, *ekh;
   double *up, *vp;
@@ -142,6 +143,8 @@ struct BottomArgs {
   double thls, z0h, prt;
   const double *thl0;
   int thl_wf;
+  double *tau_x, *tau_y, *thl_flux;      // [ny_l][nx] planes or nullptr
+  int thl_slot;                          // entry of sv0/svp that is thl (for thl_flux), else -1
 };
 // wfuno's transfer coefficients (src/modwallfunctions.f90:176-261): Louis 1979 / Uno et al. 1995 over a rough wall
 __device__ __forceinline__ void uno_F(double logdz, double sqdz, double Ri, double fkar2, double &Fm, double &Fh) {
@@ -202,7 +205,10 @@ __global__ __launch_bounds__(256) void bottom_kernel(Geo g, Metrics m, BottomArg
     const double bcmomflux = copysign(dummy, utang1Int);
     const double emom = (m.dzf[km] * (a.ekm[c] * m.dx + a.ekm[cxm] * m.dx) +
                          m.dzf[k] * (a.ekm[c - sz] * m.dx + a.ekm[cxm - sz] * m.dx)) * m.dxi * dzhiq;
-    a.up[c] = a.up[c] + (a.u0[c] - a.u0[c - sz]) * emom * dzhi * dzfi - bcmomflux * dzfi;
+    const double old = a.up[c];
+    const double t = old + (a.u0[c] - a.u0[c - sz]) * emom * dzhi * dzfi - bcmomflux * dzfi;
+    a.up[c] = t;
+    if (a.tau_x) a.tau_x[(size_t)j * g.nx + i] = t - old;      // tau_x = up - (up before), :2094
   }
   {  // v component, :333-346 / :111-127
     const double utang1Int = (a.u0[c] + a.u0[c - sy] + a.u0[cxp - sy] + a.u0[cxp]) * 0.25;
@@ -215,8 +221,10 @@ __global__ __launch_bounds__(256) void bottom_kernel(Geo g, Metrics m, BottomArg
     const double dummy = fabs(utang2Int) * sqrt(utangInt) * ctm;
     const double bcmomflux = copysign(dummy, utang2Int);
     const double eomm = (m.dzf[km] * (a.ekm[c] + a.ekm[c - sy]) + m.dzf[k] * (a.ekm[c - sz] + a.ekm[c - sy - sz])) * dzhiq;
-    const double t = a.vp[c] + (a.v0[c] - a.v0[c - sz]) * eomm * dzhi * dzfi - bcmomflux * dzfi;
+    const double old = a.vp[c];
+    const double t = old + (a.v0[c] - a.v0[c - sz]) * eomm * dzhi * dzfi - bcmomflux * dzfi;
     a.vp[c] = t;
+    if (a.tau_y) a.tau_y[(size_t)j * g.nx + i] = t - old;
     if (a.wrap_vp && j == 0) a.vp[c + sy * g.ny] = t;      // bcpup's cyclic pvp(je+1) = pvp(jb)
   }
   for (int n = 0; n < a.nsv; ++n) {   // Neumann floor: scalars src/modibm.f90:2073-2090 (flux 0), thl :2035-2047 (wtsurf)
@@ -227,11 +235,17 @@ __global__ __launch_bounds__(256) void bottom_kernel(Geo g, Metrics m, BottomArg
       const double utangInt = fmax(umin, (utang1Int * utang1Int + utang2Int * utang2Int));
       const double dT = (c0[c] - Twall);
       const double bcTflux = uno_h(a.prt, l_, logzh, sqdz, utangInt, dT, grav * delta * dT / (Twall * utangInt), fkar2);
-      a.svp[n][c] = a.svp[n][c] + 0.5 * (m.dzf[k - 1] * a.ekh[c] + m.dzf[k] * a.ekh[c - sz]) * (c0[c] - c0[c - sz]) * m.dzh2i[k] * dzfi
-                    - bcTflux * dzfi;
+      const double old = a.svp[n][c];
+      const double t = old + 0.5 * (m.dzf[k - 1] * a.ekh[c] + m.dzf[k] * a.ekh[c - sz]) * (c0[c] - c0[c - sz]) * m.dzh2i[k] * dzfi
+                       - bcTflux * dzfi;
+      a.svp[n][c] = t;
+      if (a.thl_flux && n == a.thl_slot) a.thl_flux[(size_t)j * g.nx + i] = t - old;
       continue;
     }
-    a.svp[n][c] = a.svp[n][c] + (0.5 * (m.dzf[km] * a.ekh[c] + m.dzf[k] * a.ekh[c - sz]) * (c0[c] - c0[c - sz]) * m.dzh2i[k] - a.flux[n]) * dzfi;
+    const double old = a.svp[n][c];
+    const double t = old + (0.5 * (m.dzf[km] * a.ekh[c] + m.dzf[k] * a.ekh[c - sz]) * (c0[c] - c0[c - sz]) * m.dzh2i[k] - a.flux[n]) * dzfi;
+    a.svp[n][c] = t;
+    if (a.thl_flux && n == a.thl_slot) a.thl_flux[(size_t)j * g.nx + i] = t - old;
   }
 }
 
@@ -312,7 +326,8 @@ int k_bottom(udc_handle *h, bool wrap_vp) {
   a.u0 = h->fields[UDC_U0]; a.v0 = h->fields[UDC_V0]; a.ekm = h->fields[UDC_EKM]; a.ekh = h->fields[UDC_EKH];
   a.up = h->fields[UDC_UP]; a.vp = h->fields[UDC_VP];
   a.nsv = 0; a.wrap_vp = wrap_vp ? 1 : 0; a.z0 = h->p.z0;
-  a.thls = h->floor_thls; a.z0h = h->floor_z0h; a.prt = h->floor_prt; a.thl_wf = -1;
+  a.thls = h->floor_thls; a.z0h = h->floor_z0h; a.prt = h->floor_prt; a.thl_wf = -1; a.thl_slot = -1;
+  a.tau_x = h->bottom_diag[0]; a.tau_y = h->bottom_diag[1]; a.thl_flux = h->bottom_diag[2];
   const bool have_thl = (int)h->fields.size() > UDC_THL0 && h->fields[UDC_THL0];
   a.thl0 = have_thl ? h->fields[UDC_THL0] : nullptr;
   const bool uno = h->floor_bcbotm == 2;
@@ -320,6 +335,7 @@ int k_bottom(udc_handle *h, bool wrap_vp) {
   for (int n : h->slots) {
     if (h->slot[n].tke) continue;      // e12 has no floor-flux correction in `bottom`
     if (n == 15 && h->floor_bcbott == 2) a.thl_wf = a.nsv;
+    if (n == 15) a.thl_slot = a.nsv;
     a.sv0[a.nsv] = h->fields[UDC_SV0 + 3 * n]; a.svp[a.nsv] = h->fields[UDC_SVP + 3 * n];
     a.flux[a.nsv] = h->slot[n].floorflux; ++a.nsv;
   }

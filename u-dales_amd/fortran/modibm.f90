@@ -237,6 +237,10 @@ contains
     use udc_iface
     if (.not. (lbottom .or. loneeqn_dev())) return
     call udc_begin(.true.)
+    if (lbottom .and. .not. udc_bottom_diag_on) then      ! tau_x, tau_y, thl_flux: kept on the device, pulled with the fields
+      call udc_check(udc_bottom_diagnostics(udc_h, 1_c_int), 'udc_bottom_diagnostics')
+      udc_bottom_diag_on = .true.
+    end if
     call udc_check(udc_bottom(udc_h), 'udc_bottom')
     call udc_end_tend
     if (udc_mode() == 0 .and. loneeqn_dev()) call udc_pull_vel(.true.)     ! e120, e12m floor ghosts

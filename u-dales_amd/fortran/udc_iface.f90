@@ -54,6 +54,7 @@ module udc_iface
   logical, save :: udc_lqlnr = .false.        !< &DYNAMICS lqlnr (owned by modthermodynamics; copied by initthermodynamics)
   logical, save :: udc_need_avg = .false.     !< some host routine reads diagfld's slab averages (lstend, nudge, grwdamp, fixuinf, shiftedPBCs)
   logical, save :: udc_host_fresh = .true.    !< the host arrays hold the current state
+  logical, save :: udc_bottom_diag_on = .false.   !< the device keeps bottom's tau_x / tau_y / thl_flux planes
   !> per-level tables tend(i,j,k) += A(k) + B(k) field(i,j,k) under construction on the host (udc_tab_start/apply):
   !! (level, row, when) with when = 0: applied before masscorr (lstend, nudge), 1: after it (fixuinf1, grwdamp)
   integer, parameter :: ROW_UP = 1, ROW_VP = 2, ROW_WP = 3, ROW_THLP = 4, ROW_QTP = 5, ROW_SVP = 5
@@ -138,6 +139,17 @@ module udc_iface
     integer(c_int) function udc_ibm_commit(h) bind(C, name='udc_ibm_commit')
       import :: c_int, c_ptr
       type(c_ptr), value :: h
+    end function
+    integer(c_int) function udc_bottom_diagnostics(h, on) bind(C, name='udc_bottom_diagnostics')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+      integer(c_int), value :: on
+    end function
+    integer(c_int) function udc_bottom_diag_get(h, which, out) bind(C, name='udc_bottom_diag_get')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: which
+      real(c_double), intent(out) :: out(*)
     end function
     integer(c_int) function udc_set_ibm_mask_wrap(h, wrapx, wrapy) bind(C, name='udc_set_ibm_mask_wrap')
       import :: c_int, c_ptr
@@ -761,6 +773,28 @@ contains
     call udc_pull3(UDC_PRES0, pres0, (/ib - ih, jb - jh, kb - kh/))
     call udc_pull3(UDC_EKM, ekm, (/ib - ih, jb - jh, kb - kh/))
     call udc_pull3(UDC_EKH, ekh, (/ib - ih, jb - jh, kb - kh/))
+    call udc_pull_bottom_diag
   end subroutine udc_pull_all
+
+  !> tau_x, tau_y, tau_z, thl_flux (modfields; the fielddump variables `bottom` leaves behind, src/modibm.f90:2015-2018,
+  !! 2094-2097): what the floor added to up, vp, thlp -- nonzero on the k = kb plane only
+  subroutine udc_pull_bottom_diag
+    use modglobal, only: ib, ie, jb, je, kb, ltempeq
+    use modfields, only: tau_x, tau_y, tau_z, thl_flux
+    real(c_double), allocatable :: plane(:, :)
+    if (.not. udc_bottom_diag_on) return
+    if (.not. allocated(tau_x)) return
+    allocate (plane(ib:ie, jb:je))
+    tau_x = 0.; tau_y = 0.; tau_z = 0.; thl_flux = 0.
+    call udc_check(udc_bottom_diag_get(udc_h, 0_c_int, plane), 'udc_bottom_diag_get')
+    tau_x(ib:ie, jb:je, kb) = plane
+    call udc_check(udc_bottom_diag_get(udc_h, 1_c_int, plane), 'udc_bottom_diag_get')
+    tau_y(ib:ie, jb:je, kb) = plane
+    if (ltempeq) then
+      call udc_check(udc_bottom_diag_get(udc_h, 2_c_int, plane), 'udc_bottom_diag_get')
+      thl_flux(ib:ie, jb:je, kb) = plane
+    end if
+    deallocate (plane)
+  end subroutine udc_pull_bottom_diag
 
 end module udc_iface

@@ -338,6 +338,17 @@ class DynCore:
         L._check(self.lib.udc_set_ibm_points(self.h, int(grid), s.ctypes.data_as(ip), len(s), b.ctypes.data_as(ip), len(b)),
                  "udc_set_ibm_points")
 
+    def bottom_diagnostics(self, on=True):
+        """Keep tau_x, tau_y, thl_flux of `bottom` (what it adds to up, vp, thlp on the k = kb plane)."""
+        L._check(self.lib.udc_bottom_diagnostics(self.h, 1 if on else 0), "udc_bottom_diagnostics")
+
+    def bottom_diag(self, which):
+        """which: "tau_x" | "tau_y" | "thl_flux" -> [ny_l, nx]."""
+        out = np.empty((self.nyl, self.g.nx))
+        L._check(self.lib.udc_bottom_diag_get(self.h, {"tau_x": 0, "tau_y": 1, "thl_flux": 2}[which],
+                                              out.ctypes.data_as(C.POINTER(C.c_double))), "udc_bottom_diag_get")
+        return out
+
     def set_ibm_mask_wrap(self, wrapx, wrapy):
         """Mask look-ups across the domain's lateral boundaries: periodic image (True) or "fluid" (False) -- the
         reference's masks hold the latter in a direction its run keeps on one rank (udcore.h)."""
