@@ -26,6 +26,16 @@ struct ClosMetGlobal {
   int kf;
   __device__ __forceinline__ double get(int t) const { return closmet_src(m, t)[kf]; }
 };
+struct ClosMetLane {       // entry t sits in lane t of a vector register of every wave (loaded a level ahead): no LDS at all
+  double v;
+  __device__ __forceinline__ double get(int t) const {
+    union { double d; int i[2]; } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], t);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], t);
+    return u.d;
+  }
+};
 struct ClosMetLds {
   const double *p;
   __device__ __forceinline__ double get(int t) const {      // uniform: scalar registers

@@ -246,7 +246,6 @@ __global__ __launch_bounds__(NT) void closure_lds_kernel(Geo g, TileGrid tg, Met
     double *__restrict__ ekm, double *__restrict__ ekh, int kc, int ghosts) {
   constexpr int NF = 3;
   __shared__ double s[4][NF][LN];
-  __shared__ double smet[2][NCLOSMET + 3];       // level metrics of levels k and k+1, staged like the planes
   const unsigned L = blockIdx.x;
   const int chunk = L / tg.tiles;
   const unsigned lp = L - (unsigned)chunk * tg.tiles;
@@ -287,13 +286,14 @@ __global__ __launch_bounds__(NT) void closure_lds_kernel(Geo g, TileGrid tg, Met
       if (has_halo) s[buf][f][halo_l] = st.h[f];
     }
   };
-  const bool met_thread = tid < NCLOSMET;
-  const double *mp = closmet_src(m, met_thread ? tid : 0) + 1;     // entry of level k = mp[k]
-  double mreg = 0.;
-  if (met_thread) {
-    smet[k0 & 1][tid] = mp[k0];
-    if (k0 + 1 < k1) mreg = mp[k0 + 1];
-  }
+  // level metrics: lane t < NCLOSMET of every wave holds entry t, loaded one level ahead together with the plane
+  // prefetch (its wait is the commit's); the stencil reads them with v_readlane into scalar registers.  No LDS: the
+  // four plane buffers alone are 32 640 B, so five workgroups fit a CU
+  const int lane = tid & 63;
+  const bool met_thread = lane < NCLOSMET;
+  const double *mp = closmet_src(m, met_thread ? lane : 0) + 1;    // entry of level k = mp[k]
+  double mcur = met_thread ? mp[k0] : 0.;
+  double mnext = (met_thread && k0 + 1 < k1) ? mp[k0 + 1] : 0.;
   Stage<NF> st;
   load_plane(k0 - 1, st); commit_plane(0, st);
   load_plane(k0, st);     commit_plane(1, st);
@@ -304,19 +304,18 @@ __global__ __launch_bounds__(NT) void closure_lds_kernel(Geo g, TileGrid tg, Met
     __syncthreads();
     if (k + 1 < k1) {
       commit_plane(bn, st);
-      if (met_thread) smet[(k + 1) & 1][tid] = mreg;
-      if (k + 2 < k1) {
-        if (met_thread) mreg = mp[k + 2];
-        load_plane(k + 3, st);
-      }
+      if (k + 2 < k1) load_plane(k + 3, st);
     }
+    const ClosMetLane lm{mcur};
+    mcur = mnext;                                            // (arrived: the commit above waited for it)
+    if (met_thread && k + 2 < k1) mnext = mp[k + 2];
     __builtin_amdgcn_sched_barrier(0);      // the prefetch is issued here, not wherever it shortens live ranges
     if (inside) {
       const int o = own_l;
       LdsAcc A{s[bm][0] + o, s[bc][0] + o, s[bp][0] + o, s[bm][1] + o, s[bc][1] + o, s[bp][1] + o,
                s[bm][2] + o, s[bc][2] + o, s[bp][2] + o};
       double em, eh;
-      closure_arith<SGS>(A, m, ClosMetLds{smet[k & 1]}, pr, k, em, eh);
+      closure_arith<SGS>(A, m, lm, pr, k, em, eh);
       const long c = g.sz * (long)(k + HZ) + own_off;
       ekm[c] = em;
       ekh[c] = eh;
@@ -365,7 +364,10 @@ static int pick_kc(const Geo &g, const TileGrid &tg, int per_cu) {
 int k_closure_lds(udc_handle *h, bool ghosts) {
   const Geo &g = h->g;
   const TileGrid tg = lds_tile_grid(g);
-  int kc = pick_kc(g, tg, getenv("UDC_CLOSURE_PERCU") ? atoi(getenv("UDC_CLOSURE_PERCU")) : 4);     // 116 VGPRs, 32 KB LDS: four workgroups per CU
+  // 90 VGPRs, 32 640 B LDS: five workgroups fit a CU.  Measured: 512x512x256 0.634 -> 0.592 ms, 1024x512x512 2.60 -> 2.38 ms
+  // when the chunking fills them; at 256^3 (256 tiles) five shorter chunks per tile lose to four (0.19 against 0.172 ms)
+  const int per_cu = getenv("UDC_CLOSURE_PERCU") ? atoi(getenv("UDC_CLOSURE_PERCU")) : (tg.tiles >= 1024 ? 5 : 4);
+  int kc = pick_kc(g, tg, per_cu);
   const int chunks = (g.nz + kc - 1) / kc;
   dim3 b(MX, MY, 1), gr((unsigned)tg.tiles * (unsigned)chunks, 1, 1);
   double *u = h->fields[UDC_U0], *v = h->fields[UDC_V0], *w = h->fields[UDC_W0];
