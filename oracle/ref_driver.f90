@@ -16,7 +16,7 @@
 ! Set-up mirrors src/modstartup.f90:
 !   readnamelists (:105-172, subset of groups/variables, same names),
 !   init2decomp (:652-691), cold start of readinitfiles (:1088-1290),
-!   lscale.inp reading (:2051-2092), randomize_field (:2367-2396).
+!   lscale.inp reading (:2051-2092); randomize_field (:2367-2396) is the reference's own routine (extract_startup.sh).
 ! None of that set-up code is on the measured/validated path: it only builds the
 ! inputs, which are dumped so that the device library starts from identical data.
 !
@@ -62,6 +62,7 @@ program ref_driver
                     nbndpts_u, nbndpts_v, nbndpts_w, nbndpts_c
   use readinput, only: read_sparse_ijk
 #endif
+  use modstartup_rand, only: randomize_field        ! src/modstartup.f90:2367-2396, compiled from the reference (extract_startup.sh)
   implicit none
 
   character(256) :: mode, outfile, arg
@@ -470,13 +471,13 @@ contains
     if (lrandomize) then
       krand = min(krand, ke)
       do k = kb, krand
-        call randomize_field_l(um, k, randu, irandom, ih, jh)
+        call randomize_field(um, k, randu, irandom, ih, jh)
       end do
       do k = kb, krand
-        call randomize_field_l(vm, k, randu, irandom, ih, jh)
+        call randomize_field(vm, k, randu, irandom, ih, jh)
       end do
       do k = kb, krand
-        call randomize_field_l(wm, k, randu, irandom, ih, jh)
+        call randomize_field(wm, k, randu, irandom, ih, jh)
       end do
     end if
     u0 = um; v0 = vm; w0 = wm
@@ -530,28 +531,6 @@ contains
   end subroutine cold_start
 
   ! ---- src/modstartup.f90:2367-2396 (deterministic LCG keyed on the global index)
-  subroutine randomize_field_l(field, klev, ampl, ir, ihl, jhl)
-    integer(KIND=selected_int_kind(6)) :: imm, ia, ic, ir
-    integer ihl, jhl, i, j, klev, iglob, jglob
-    integer(KIND=selected_int_kind(12)) :: linear_id, state
-    real ran, ampl
-    real field(ib - ihl:ie + ihl, jb - jhl:je + jhl, kb - kh:ke + kh)
-    parameter(imm=134456, ia=8121, ic=28411)
-    do j = jb, je
-      jglob = j + zstart(2) - 1
-      do i = ib, ie
-        iglob = i + zstart(1) - 1
-        linear_id = int(iglob, kind(linear_id)) &
-                    + int(itot, kind(linear_id))*int(jglob - 1, kind(linear_id)) &
-                    + int(itot, kind(linear_id))*int(jtot, kind(linear_id))*int(klev - 1, kind(linear_id))
-        state = mod(int(ir, kind(state)) + linear_id, int(imm, kind(state)))
-        state = mod(state*int(ia, kind(state)) + int(ic, kind(state)), int(imm, kind(state)))
-        ran = real(state)/real(imm)
-        field(i, j, klev) = field(i, j, klev) + (ran - 0.5)*2.0*ampl
-      end do
-    end do
-  end subroutine randomize_field_l
-
   ! ------------------------------------------------------------ dump helpers
   subroutine put3(name, a, lb)
     character(*), intent(in) :: name
