@@ -146,7 +146,11 @@ def run_virtual(P, g, deck_like, st_global, nsub, dt, sgs, nsv=0, extras=False):
 @pytest.mark.parametrize("shape,sgs,chunks,extras", [((32, 16, 12), 2, 1, False), ((24, 32, 10), 1, 2, False),
                                                      ((32, 16, 12), 2, 3, False), ((32, 16, 12), 2, 1, 1),
                                                      ((32, 16, 12), 2, 2, 2),
-                                                     ((128, 64, 16), 2, 2, False), ((64, 32, 8), 1, 4, 1)])
+                                                     ((128, 64, 16), 2, 2, False), ((64, 32, 8), 1, 4, 1),
+                                                     # rows of 512 cells carry a line of padding (Geo.sy = nx + 16): halo packs, own line
+                                                     # FFTs and the exchange buffers across slabs; 272 levels: the wave-specialised Thomas
+                                                     # kernel (two-workgroup occupancy) on the slabs' share of the modes
+                                                     ((512, 32, 8), 2, 2, False), ((32, 32, 272), 2, 1, False)])
 def test_decomposition_invariance(shape, sgs, chunks, extras, monkeypatch):
     # chunks > 1: the k-chunked all-to-all pipeline (exchange on a second stream, overlapped with rocFFT)
     # power-of-two nx and ny: the slab ranks run the own line FFTs with fused packing (udc_fft.hip) against the single
