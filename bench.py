@@ -469,6 +469,11 @@ def main():
         del src, dst
     except Exception:      # noqa: BLE001 (the ceiling is a side measurement: never let it take the bench line down)
         pass
+    ab_sum = sum(k["algo_bytes_per_cell"] * k["share"] * ms_per / k["avg_ms"] for k in kernels.values() if "algo_bytes_per_cell" in k)
+    as_built = {"bytes_per_cell_update": round(ab_sum, 1),
+                "frac_of_hbm_peak": round(ab_sum * cells_local * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4)}
+    if "copy_ceiling" in roofline:
+        as_built["frac_of_copy_ceiling"] = round(ab_sum * cells_local * args.steps / elapsed / 1e9 / roofline["copy_ceiling"], 4)
     out = {
         "metric": "cell-updates/sec (advect+diffuse+Poisson step)", "value": value, "unit": "cell-updates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -480,6 +485,9 @@ def main():
                    "grid": [nx, ny, nz], "decomposition": f"y-slabs x{world}", "dt": dt,
                    "step": "one RK3 substep = one cell-update per cell"},
         "whole_substep_hbm_frac": round(392.0 * cells_local * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4),
+        # the same on the bytes the kernels as built must move (sum of the per-kernel algorithmic bytes, launches per
+        # substep as surveyed), against the 8 TB/s peak and against this box's measured copy rate
+        "whole_substep_as_built": as_built,
         "divmax_after_run": divmax,
         "poisson_only_ms": round(poisson_ms, 5),
         "poisson_in_substep_ms": round(poisson_in_substep_ms, 5),
