@@ -306,11 +306,16 @@ contains
   ! ---- initibm without the facet wall functions (src/modibm.f90:131-193): solid point lists (initibmnorm, the reference's),
   !      masks (:150-167), fluid-boundary point lists (read as initibmwallfun reads them, :302-306)
   subroutine ibm_setup
+    use modibmdata, only: bctfxm, bctfxp, bctfym, bctfyp, bctfz, bcqfxm, bcqfxp, bcqfym, bcqfyp, bcqfz
     real, allocatable :: rhs(:, :, :)
     integer, allocatable :: ids(:)
     if (.not. libm) return
-    if (ltempeq .or. lmoist) then
-      write (0, *) 'ERROR: ref_driver: libm with ltempeq / lmoist needs wallfunheat (src/modibm.f90:1436), which cannot be built here'
+    ! temperature / moisture: wallfunheat (src/modibm.f90:1436) cannot be built here (initfac, NetCDF).  With prescribed wall
+    ! fluxes (iwalltemp = 1, iwallmoist = 1) that are all zero it adds exactly nothing to thlp / qtp (`- flux * area / vol`,
+    ! :1535, :1584), so adiabatic, impermeable walls run on the reference's remaining routines alone.
+    if ((ltempeq .and. (iwalltemp /= 1 .or. any((/bctfxm, bctfxp, bctfym, bctfyp, bctfz/) /= 0.))) .or. &
+        (lmoist .and. (iwallmoist /= 1 .or. any((/bcqfxm, bcqfxp, bcqfym, bcqfyp, bcqfz/) /= 0.)))) then
+      write (0, *) 'ERROR: ref_driver: wall heat / moisture fluxes need wallfunheat (src/modibm.f90:1436), which cannot be built here'
       stop 1
     end if
     solid_info_u%nsolpts = nsolpts_u; solid_info_v%nsolpts = nsolpts_v; solid_info_w%nsolpts = nsolpts_w
@@ -331,7 +336,7 @@ contains
     call read_sparse_ijk('fluid_boundary_u.txt', nbndpts_u, bound_info_u%nbndptsrank, ids, bound_info_u%bndpts_loc, nskip=1)
     call read_sparse_ijk('fluid_boundary_v.txt', nbndpts_v, bound_info_v%nbndptsrank, ids, bound_info_v%bndpts_loc, nskip=1)
     call read_sparse_ijk('fluid_boundary_w.txt', nbndpts_w, bound_info_w%nbndptsrank, ids, bound_info_w%bndpts_loc, nskip=1)
-    if (nsv > 0) then
+    if (nsv > 0 .or. ltempeq .or. lmoist) then           ! :180
       solid_info_c%nsolpts = nsolpts_c
       call initibmnorm('solid_c.txt', solid_info_c)
       bound_info_c%nbndpts = nbndpts_c
@@ -351,6 +356,9 @@ contains
     call diffu_corr
     call diffv_corr
     call diffw_corr
+    ! (:1227-1231: wallfunheat here -- a no-op for the zero prescribed fluxes ibm_setup insists on)
+    if (ltempeq) call diffc_corr(thl0, thlp, ih, jh, kh)      ! :1232
+    if (lmoist) call diffc_corr(qt0, qtp, ih, jh, kh)         ! :1233
     do n = 1, nsv
       call diffc_corr(sv0(:, :, :, n), svp(:, :, :, n), ihc, jhc, khc)
     end do
@@ -361,19 +369,21 @@ contains
   subroutine read_namelists_subset
     use modfields, only: dpdx
     use modglobal, only: rv_g => rv, rd_g => rd
+    use modibmdata, only: bctfxm, bctfxp, bctfym, bctfyp, bctfz, bcqfxm, bcqfxp, bcqfym, bcqfyp, bcqfz
     integer :: ierr
     namelist /RUN/ iexpnr, runtime, dtmax, trestart, ladaptive, irandom, randu, krand, courant, diffnr, &
       libm, lles, lrandomize, nprocx, nprocy
     namelist /DOMAIN/ itot, jtot, ktot, xlen, ylen, xlat, ksp
     namelist /PHYSICS/ ps, lmoist, lcoriol, lbuoyancy, ltempeq, lprofforc, dpdx, luvolflowr, uflowrate, &
-      lvvolflowr, vflowrate, igrw_damp, geodamptime, lnudge, lnudgevel, tnudge, nnudge, ifixuinf, lvinf, tscale
+      lvvolflowr, vflowrate, igrw_damp, geodamptime, lnudge, lnudgevel, tnudge, nnudge, ifixuinf, lvinf, tscale, lconservativeibm
     namelist /INLET/ Uinf, Vinf, inletav
     namelist /CHEMISTRY/ lchem, k1, JNO2
     namelist /DYNAMICS/ lqlnr, ipoiss, iadv_mom, iadv_tke, iadv_thl, iadv_qt, iadv_sv
     namelist /BC/ BCxm, BCym, BCtopm, BCtopT, BCtops, BCbotm, BCbots, BCbotT, BCzp, wttop, thl_top, z0, wtsurf, thls, qts, &
-      BCtopq, BCbotq, wqtop, qt_top, wqsurf, z0h, wsvtopdum, ds
+      BCtopq, BCbotq, wqtop, qt_top, wqsurf, z0h, wsvtopdum, ds, bctfxm, bctfxp, bctfym, bctfyp, bctfz, &
+      bcqfxm, bcqfxp, bcqfym, bcqfyp, bcqfz
     namelist /SCALARS/ nsv, lscasrc, nscasrc, lscasrcl, nscasrcl
-    namelist /WALLS/ nfcts, lbottom, iwallmom, iwalltemp, nsolpts_u, nsolpts_v, nsolpts_w, nsolpts_c, &
+    namelist /WALLS/ nfcts, lbottom, iwallmom, iwalltemp, iwallmoist, nsolpts_u, nsolpts_v, nsolpts_w, nsolpts_c, &
       nbndpts_u, nbndpts_v, nbndpts_w, nbndpts_c
     open (ifnamopt, file=fname_options, status='old', iostat=ierr)
     if (ierr /= 0) then
@@ -637,6 +647,10 @@ contains
     call put1('rk3', (/real(rk3step), dt/), 1)
     call dump_state('in')                   ! state every kernel below starts from
     if (lmoist .and. lbuoyancy) call dump_thermo('thm')
+    if (libm .and. ltempeq) then            ! the slab averages over the fluid cells that forces / ibmnorm will use
+      call put1('ibm.thvh', thvh(kb:ke + kh), kb)
+      call put1('ibm.thl0av', thl0av(kb:ke + kh), kb)
+    end if
     call dump_tend('in')                    ! (tendencies are zero here)
     call advection                          ! src/modadvection.f90:36
     call dump_tend('adv')

@@ -1159,18 +1159,22 @@ void orc_thl_floor(const orc_grid *g, const double *ekh, const double *thl0, dou
   metrics_free(&m);
 }
 
+static const double *ibm_ctx_mask(int grid);
 /* buoyancy term of forces with lbuoyancy for dry air (src/modforces.f90:73-84): thv0h = thl0h (calthv,
  * src/modthermodynamics.f90:208; calc_halflev :518-524), thvh = its slab average (:76, avexy_ibm) */
 void orc_buoyancy(const orc_grid *g, const double *thl0, double *wp) {
   if (!g->lbuoyancy) return;
   const double grav = 9.81;                        /* src/modglobal.f90:271 */
   const double *dzf = g->dzf, *dzh = g->dzh;
-  const double cnt = (double)g->nx * (double)g->ny;
+  const double *mask_w = ibm_ctx_mask(2);          /* avexy_ibm with IIw, IIws: the fluid w points of the level only */
   for (int k = 2; k <= g->nz; ++k) {
-    double s = 0.;
+    double s = 0., cnt = 0.;
     for (int j = 1; j <= g->ny; ++j)
       for (int i = 1; i <= g->nx; ++i)
-        s += (M(thl0, i, j, k) * dzf[k - 1] + M(thl0, i, j, k - 1) * dzf[k]) / (2 * dzh[k]);
+        if (!mask_w || M(mask_w, i, j, k) > 0.5) {
+          s += (M(thl0, i, j, k) * dzf[k - 1] + M(thl0, i, j, k - 1) * dzf[k]) / (2 * dzh[k]);
+          cnt += 1.;
+        }
     const double thvh = s / cnt;
     for (int j = 1; j <= g->ny; ++j)
       for (int i = 1; i <= g->nx; ++i) {
@@ -1653,6 +1657,103 @@ void orc_ibm_solid_c(const orc_grid *g, const int *pts, int n, const double *mas
     }
   }
 }
+/* ---- thl / qt with an immersed boundary: the same routines on m-arrays (halo 1) */
+/* diffc_corr :1120-1164 as ibmwallfun calls it for thl0 / thlp and qt0 / qtp (:1232-1233) */
+void orc_ibm_diffc_corr_m(const orc_grid *g, const int *bnd, int nbnd, const double *mask_c, const double *var, const double *ekh, double *rhs) {
+  metrics m; metrics_init(g, &m);
+  const double *dzf = g->dzf;
+  for (int n = 0; n < nbnd; ++n) {
+    const int i = bnd[3 * n], j = bnd[3 * n + 1], k = bnd[3 * n + 2];
+    if (fabs(M(mask_c, i + 1, j, k)) < 1e-10)
+      M(rhs, i, j, k) = M(rhs, i, j, k) - 0.5 * (M(ekh, i + 1, j, k) + M(ekh, i, j, k)) * (M(var, i + 1, j, k) - M(var, i, j, k)) * m.dx2i;
+    if (fabs(M(mask_c, i - 1, j, k)) < 1e-10)
+      M(rhs, i, j, k) = M(rhs, i, j, k) + 0.5 * (M(ekh, i, j, k) + M(ekh, i - 1, j, k)) * (M(var, i, j, k) - M(var, i - 1, j, k)) * m.dx2i;
+    if (fabs(M(mask_c, i, j + 1, k)) < 1e-10)
+      M(rhs, i, j, k) = M(rhs, i, j, k) - 0.5 * (M(ekh, i, j + 1, k) + M(ekh, i, j, k)) * (M(var, i, j + 1, k) - M(var, i, j, k)) * m.dy2i;
+    if (fabs(M(mask_c, i, j - 1, k)) < 1e-10)
+      M(rhs, i, j, k) = M(rhs, i, j, k) + 0.5 * (M(ekh, i, j, k) + M(ekh, i, j - 1, k)) * (M(var, i, j, k) - M(var, i, j - 1, k)) * m.dy2i;
+    if (fabs(M(mask_c, i, j, k + 1)) < 1e-10)
+      M(rhs, i, j, k) = M(rhs, i, j, k) - 0.5 * (dzf[k + 1] * M(ekh, i, j, k) + dzf[k] * M(ekh, i, j, k + 1))
+                                              * (M(var, i, j, k + 1) - M(var, i, j, k)) * m.dzh2i[k + 1] * m.dzfi[k];
+    if (fabs(M(mask_c, i, j, k - 1)) < 1e-10)
+      M(rhs, i, j, k) = M(rhs, i, j, k) + 0.5 * (dzf[k - 1] * M(ekh, i, j, k) + dzf[k] * M(ekh, i, j, k - 1))
+                                              * (M(var, i, j, k) - M(var, i, j, k - 1)) * m.dzh2i[k] * m.dzfi[k];
+  }
+  metrics_free(&m);
+}
+/* solid :748-826 with the c mask on m-arrays (ibmnorm :715 thlm / thlp with the volume mean of thl0av, :726 qtm / qtp with 0) */
+void orc_ibm_solid_cm(const orc_grid *g, const int *pts, int n, const double *mask, double *var, double *rhs, double val) {
+  const int di[6] = {0, 0, 0, 0, 1, -1}, dj[6] = {1, -1, 0, 0, 0, 0}, dk[6] = {0, 0, 1, -1, 0, 0};      /* the reference's order */
+  for (int q = 0; q < n; ++q) {
+    const int i = pts[3 * q], j = pts[3 * q + 1], k = pts[3 * q + 2];
+    double count = 0.;
+    M(var, i, j, k) = val;
+    M(rhs, i, j, k) = 0.;
+    for (int b = 0; b < 6; ++b)
+      if (fabs(M(mask, i + di[b], j + dj[b], k + dk[b]) - 1.) < 1e-10) {
+        count = count + 1;
+        M(var, i, j, k) = M(var, i, j, k) + M(var, i + di[b], j + dj[b], k + dk[b]);
+        M(rhs, i, j, k) = M(rhs, i, j, k) + M(rhs, i + di[b], j + dj[b], k + dk[b]);
+      }
+    if (count > 0) {
+      M(var, i, j, k) = (M(var, i, j, k) - val) / count;
+      M(rhs, i, j, k) = M(rhs, i, j, k) / count;
+    }
+  }
+}
+/* advecc2nd_corr_conservative :889-933 / advecc2nd_corr_liberal :936-987 at the fluid-boundary points of the c grid */
+void orc_ibm_advecc2nd_corr_m(const orc_grid *g, int conservative, const int *bnd, int nbnd, const double *mask_u, const double *mask_v,
+                              const double *mask_w, const double *mask_c, const double *u0, const double *v0, const double *w0,
+                              const double *var, double *rhs) {
+  metrics m; metrics_init(g, &m);
+  const double *dzf = g->dzf, eps1 = 1e-10;
+  for (int n = 0; n < nbnd; ++n) {
+    const int i = bnd[3 * n], j = bnd[3 * n + 1], k = bnd[3 * n + 2];
+    const double v0c = M(var, i, j, k);
+    if (conservative) {
+      if (fabs(M(mask_u, i + 1, j, k)) < eps1 || fabs(M(mask_c, i + 1, j, k)) < eps1)
+        M(rhs, i, j, k) = M(rhs, i, j, k) + M(u0, i + 1, j, k) * (M(var, i + 1, j, k) + v0c) * m.dxi5;
+      if (fabs(M(mask_u, i, j, k)) < eps1 || fabs(M(mask_c, i - 1, j, k)) < eps1)
+        M(rhs, i, j, k) = M(rhs, i, j, k) - M(u0, i, j, k) * (M(var, i - 1, j, k) + v0c) * m.dxi5;
+      if (fabs(M(mask_v, i, j + 1, k)) < eps1 || fabs(M(mask_c, i, j + 1, k)) < eps1)
+        M(rhs, i, j, k) = M(rhs, i, j, k) + M(v0, i, j + 1, k) * (M(var, i, j + 1, k) + v0c) * m.dyi5;
+      if (fabs(M(mask_v, i, j, k)) < eps1 || fabs(M(mask_c, i, j - 1, k)) < eps1)
+        M(rhs, i, j, k) = M(rhs, i, j, k) - M(v0, i, j, k) * (M(var, i, j - 1, k) + v0c) * m.dyi5;
+      if (fabs(M(mask_w, i, j, k + 1)) < eps1 || fabs(M(mask_c, i, j, k + 1)) < eps1)
+        M(rhs, i, j, k) = M(rhs, i, j, k) + M(w0, i, j, k + 1) * (M(var, i, j, k + 1) * dzf[k] + v0c * dzf[k + 1]) * m.dzhi[k + 1] * m.dzfi5[k];
+      if (fabs(M(mask_w, i, j, k)) < eps1 || fabs(M(mask_c, i, j, k - 1)) < eps1)
+        M(rhs, i, j, k) = M(rhs, i, j, k) - M(w0, i, j, k) * (M(var, i, j, k - 1) * dzf[k] + v0c * dzf[k - 1]) * m.dzhi[k] * m.dzfi5[k];
+    } else {
+      if (fabs(M(mask_c, i + 1, j, k)) < eps1)
+        M(rhs, i, j, k) = M(rhs, i, j, k) + M(u0, i + 1, j, k) * (M(var, i + 1, j, k) + v0c) * m.dxi5
+                                          - M(u0, i + 1, j, k) * (v0c + v0c) * m.dxi5;
+      if (fabs(M(mask_c, i - 1, j, k)) < eps1)
+        M(rhs, i, j, k) = M(rhs, i, j, k) - M(u0, i, j, k) * (M(var, i - 1, j, k) + v0c) * m.dxi5
+                                          + M(u0, i, j, k) * (v0c + v0c) * m.dxi5;
+      if (fabs(M(mask_c, i, j + 1, k)) < eps1)
+        M(rhs, i, j, k) = M(rhs, i, j, k) + M(v0, i, j + 1, k) * (M(var, i, j + 1, k) + v0c) * m.dyi5
+                                          - M(v0, i, j + 1, k) * (v0c + v0c) * m.dyi5;
+      if (fabs(M(mask_c, i, j - 1, k)) < eps1)
+        M(rhs, i, j, k) = M(rhs, i, j, k) - M(v0, i, j, k) * (M(var, i, j - 1, k) + v0c) * m.dyi5
+                                          + M(v0, i, j, k) * (v0c + v0c) * m.dyi5;
+      if (fabs(M(mask_c, i, j, k + 1)) < eps1)
+        M(rhs, i, j, k) = M(rhs, i, j, k) + M(w0, i, j, k + 1) * (M(var, i, j, k + 1) * dzf[k] + v0c * dzf[k + 1]) * m.dzhi[k + 1] * m.dzfi5[k]
+                                          - M(w0, i, j, k + 1) * (v0c * dzf[k] + v0c * dzf[k + 1]) * m.dzhi[k + 1] * m.dzfi5[k];
+      if (fabs(M(mask_c, i, j, k - 1)) < eps1)
+        M(rhs, i, j, k) = M(rhs, i, j, k) - M(w0, i, j, k) * (M(var, i, j, k - 1) * dzf[k] + v0c * dzf[k - 1]) * m.dzhi[k] * m.dzfi5[k]
+                                          + M(w0, i, j, k) * (v0c * dzf[k] + v0c * dzf[k - 1]) * m.dzhi[k] * m.dzfi5[k];
+    }
+  }
+  metrics_free(&m);
+}
+/* avexy_ibm (src/modmpi.f90:623-664): the mean of f over the fluid cells of level k */
+double orc_ibm_level_mean_m(const orc_grid *g, const double *f, const double *mask, int k) {
+  double s = 0., c = 0.;
+  for (int j = 1; j <= g->ny; ++j)
+    for (int i = 1; i <= g->nx; ++i)
+      if (M(mask, i, j, k) > 0.5) { s += M(f, i, j, k); c += 1.; }
+  return c > 0. ? s / c : -999.;
+}
 /* what the substep does with an immersed boundary: ibmwallfun without facet wall functions (src/program.f90:166) and
  * ibmnorm (:171).  Set with orc_set_ibm (NULL: none). */
 static const orc_ibm *ibm_ctx = NULL;
@@ -1663,6 +1764,9 @@ void orc_ibmwallfun(const orc_grid *g, const orc_ibm *b, orc_state *s) {
   orc_ibm_diffu_corr(g, b->bnd[0], b->nbnd[0], b->mask[0], s->u0, s->ekm, s->up);
   orc_ibm_diffv_corr(g, b->bnd[1], b->nbnd[1], b->mask[1], s->v0, s->ekm, s->vp);
   orc_ibm_diffw_corr(g, b->bnd[2], b->nbnd[2], b->mask[2], s->w0, s->ekm, s->wp);
+  /* (:1227-1231 wallfunheat: not restated -- with prescribed zero wall fluxes it adds nothing) */
+  if (g->ltempeq) orc_ibm_diffc_corr_m(g, b->bnd[3], b->nbnd[3], b->mask[3], s->thl0, s->ekh, s->thlp);      /* :1232 */
+  if (g->lmoist) orc_ibm_diffc_corr_m(g, b->bnd[3], b->nbnd[3], b->mask[3], s->qt0, s->ekh, s->qtp);         /* :1233 */
   for (int n = 0; n < g->nsv; ++n) orc_ibm_diffc_corr(g, b->bnd[3], b->nbnd[3], b->mask[3], s->sv0 + n * nc, s->ekh, s->svp + n * nc);
 }
 void orc_ibmnorm(const orc_grid *g, const orc_ibm *b, orc_state *s) {
@@ -1670,6 +1774,21 @@ void orc_ibmnorm(const orc_grid *g, const orc_ibm *b, orc_state *s) {
   orc_ibm_solid_m(g, b->sol[0], b->nsol[0], s->um, s->up, 0.);
   orc_ibm_solid_m(g, b->sol[1], b->nsol[1], s->vm, s->vp, 0.);
   orc_ibm_solid_m(g, b->sol[2], b->nsol[2], s->wm, s->wp, 0.);
+  if (g->ltempeq) {                                                                     /* :714-722 */
+    /* thl0av of the last thermodynamics call (diagfld :277, fluid cells only): thl0 has not changed since */
+    double val = 0., zh_top = 0.;
+    for (int k = 1; k <= g->nz; ++k) { val += orc_ibm_level_mean_m(g, s->thl0, b->mask[3], k) * g->dzf[k]; zh_top += g->dzf[k]; }
+    val = val / zh_top;
+    orc_ibm_solid_cm(g, b->sol[3], b->nsol[3], b->mask[3], s->thlm, s->thlp, val);
+    if (g->iadv_thl != 7)
+      orc_ibm_advecc2nd_corr_m(g, b->conservative, b->bnd[3], b->nbnd[3], b->mask[0], b->mask[1], b->mask[2], b->mask[3],
+                               s->u0, s->v0, s->w0, s->thl0, s->thlp);
+  }
+  if (g->lmoist) {                                                                      /* :725-731 */
+    orc_ibm_solid_cm(g, b->sol[3], b->nsol[3], b->mask[3], s->qtm, s->qtp, 0.);
+    orc_ibm_advecc2nd_corr_m(g, b->conservative, b->bnd[3], b->nbnd[3], b->mask[0], b->mask[1], b->mask[2], b->mask[3],
+                             s->u0, s->v0, s->w0, s->qt0, s->qtp);
+  }
   for (int n = 0; n < g->nsv; ++n) orc_ibm_solid_c(g, b->sol[3], b->nsol[3], b->mask[3], s->svm + n * nc, s->svp + n * nc, 0.);
 }
 

@@ -95,6 +95,7 @@ typedef struct {
   const int *sol[4]; int nsol[4];
   const int *bnd[4]; int nbnd[4];
   const double *mask[4];
+  int conservative;          /* lconservativeibm (src/modglobal.f90:192): which advecc2nd_corr ibmnorm applies to thl / qt */
 } orc_ibm;
 void orc_ibm_mask(const orc_grid *g, int is_w, const int *solid, int nsolid, double *mask, int wrapx, int wrapy);
 void orc_ibm_diffu_corr(const orc_grid *g, const int *bnd, int nbnd, const double *mask_u, const double *u0, const double *ekm, double *up);
@@ -103,6 +104,14 @@ void orc_ibm_diffw_corr(const orc_grid *g, const int *bnd, int nbnd, const doubl
 void orc_ibm_diffc_corr(const orc_grid *g, const int *bnd, int nbnd, const double *mask_c, const double *var, const double *ekh, double *rhs);
 void orc_ibm_solid_m(const orc_grid *g, const int *pts, int n, double *var, double *rhs, double val);
 void orc_ibm_solid_c(const orc_grid *g, const int *pts, int n, const double *mask, double *var, double *rhs, double val);
+/* thl / qt with an immersed boundary (m-arrays): diffc_corr :1120, solid with the c mask :748, advecc2nd_corr_conservative :889 /
+ * _liberal :936; the slab average over the fluid cells of a level (avexy_ibm, src/modmpi.f90:623-664) */
+void orc_ibm_diffc_corr_m(const orc_grid *g, const int *bnd, int nbnd, const double *mask_c, const double *var, const double *ekh, double *rhs);
+void orc_ibm_solid_cm(const orc_grid *g, const int *pts, int n, const double *mask, double *var, double *rhs, double val);
+void orc_ibm_advecc2nd_corr_m(const orc_grid *g, int conservative, const int *bnd, int nbnd, const double *mask_u, const double *mask_v,
+                              const double *mask_w, const double *mask_c, const double *u0, const double *v0, const double *w0,
+                              const double *var, double *rhs);
+double orc_ibm_level_mean_m(const orc_grid *g, const double *f, const double *mask, int k);
 void orc_set_ibm(const orc_ibm *b);      /* orc_substep then runs ibmwallfun / ibmnorm (src/program.f90:166, 171) */
 void orc_set_closure_thl(const double *thl0);   /* thl0 for the Vreman buoyancy correction inside orc_closure */
 void orc_closurebc(const orc_grid *g, double *ekm, double *ekh);

@@ -163,6 +163,7 @@ KEEP_KERNELS = ("meta dzf dzh zf dpdxl dpdyl rk3 in.u0 in.v0 in.w0 in.um in.vm i
                 "frc0.up frc0.vp frc0.wp frc0.thlp lsf.up lsf.vp lsf.wp lsf.thlp u0av thl0av frc0.qtp lsf.qtp qt0av "
                 "src0.up fix0.up fix0.vp "
                 "ibw0.up ibw0.vp ibw0.wp ibw.up ibw.vp ibw.wp ibn0.up ibn0.vp ibn0.wp ibn.up ibn.vp ibn.wp ibn.um ibn.vm ibn.wm "
+                "ibw0.thlp ibw.thlp ibn0.thlp ibn.thlp ibn.thlm ibn.thl0 ibm.thvh ibm.thl0av "
                 "pre.up pre.vp pre.wp poi.p poi.pres0 poi.up poi.vp poi.wp out.u0 out.v0 out.w0 "
                 "out.um out.pres0").split()
 
@@ -384,6 +385,30 @@ CASES.update({
     "run_ibm_edge_16x12x10": ("run", 57, 16, 12, 10, dict(sgs="vreman", nsv=0, floor=True, randu=0.05, ibm=IBM_BLOCKS["run_ibm_edge_16x12x10"],
                                                           oracle="nsub = 9\ndump_at = 3, 9"), 1.04),
 })
+# immersed boundary with temperature (buoyant), a kappa-advected scalar, and moisture: ibmnorm's `solid`
+# on thl with the volume-mean value, advecc2nd_corr (liberal, and conservative with lconservativeibm), diffc_corr on thl / qt,
+# the masked slab averages of thermodynamics (IIw for thvh).  Adiabatic, impermeable walls (iwalltemp = iwallmoist = 1 with
+# zero prescribed fluxes): wallfunheat, which cannot be built here, then adds exactly nothing.
+IBM_BLOCKS["k_ibm_thl_16x12x10"] = IBM_BLOCKS["run_ibm_16x12x10"]
+IBM_BLOCKS["run_ibm_thl_16x12x10"] = IBM_BLOCKS["run_ibm_16x12x10"]
+IBM_BLOCKS["run_ibm_thlcons_16x12x10"] = IBM_BLOCKS["run_ibm_16x12x10"]
+IBM_BLOCKS["run_ibm_qt_16x12x10"] = IBM_BLOCKS["run_ibm_16x12x10"]
+_IBM_THL_BC = "BCtopT = 1\nwttop = 0.\nBCbotT = 1\nwtsurf = 0.02\nthls = 288.0"
+CASES.update({
+    "k_ibm_thl_16x12x10": ("kernels", 58, 16, 12, 10, dict(sgs="smag", nsv=1, floor=True, randu=0.05, ibm=IBM_BLOCKS["run_ibm_16x12x10"],
+                                                           physics="ltempeq = .true.\nlbuoyancy = .true.", bc=_IBM_THL_BC,
+                                                           oracle="nspin = 4"), 1.04),
+    "run_ibm_thl_16x12x10": ("run", 59, 16, 12, 10, dict(sgs="vreman", nsv=1, floor=True, randu=0.05, ibm=IBM_BLOCKS["run_ibm_16x12x10"],
+                                                         physics="ltempeq = .true.\nlbuoyancy = .true.", bc=_IBM_THL_BC,
+                                                         oracle="nsub = 9\ndump_at = 3, 9"), 1.04),
+    "run_ibm_thlcons_16x12x10": ("run", 60, 16, 12, 10, dict(sgs="vreman", nsv=1, floor=True, randu=0.05, ibm=IBM_BLOCKS["run_ibm_16x12x10"],
+                                                             physics="ltempeq = .true.\nlbuoyancy = .true.\nlconservativeibm = .true.",
+                                                             bc=_IBM_THL_BC, oracle="nsub = 9\ndump_at = 3, 9"), 1.04),
+    "run_ibm_qt_16x12x10": ("run", 61, 16, 12, 10, dict(sgs="smag", nsv=1, floor=True, randu=0.05, ibm=IBM_BLOCKS["run_ibm_16x12x10"],
+                                                        physics="lmoist = .true.\nltempeq = .true.\nlbuoyancy = .false.",
+                                                        bc=_IBM_THL_BC + "\nqts = 0.008\nBCtopq = 1\nwqtop = 0.\nBCbotq = 1\nwqsurf = 2.e-5",
+                                                        oracle="nsub = 9\ndump_at = 3, 9"), 1.04),
+})
 LSF_ONLY = ("k_lsf_12x8x24", "k_lsfq_12x8x20", "k_fix1_12x8x6")
 THL_CASES = {"k_tke_moist_12x8x8": dict(dthl=0.25, qt=0.0118, dqt=-8e-5, tke=0.06),
              "run_moistnr_16x8x12s": dict(dthl=0.25, qt=0.0119, dqt=-6e-5),
@@ -398,6 +423,8 @@ THL_CASES = {"k_tke_moist_12x8x8": dict(dthl=0.25, qt=0.0118, dqt=-8e-5, tke=0.0
              "k_qt_12x8x6": dict(dthl=0.3, qt=0.008, dqt=-4e-4), "run_qt_16x8x12s": dict(dthl=0.25, qt=0.007, dqt=-2e-4),
              "k_lsf_12x8x24": dict(dthl=0.3, ug=1.05, wtop=0.02), "run_lsf_16x8x24s": dict(dthl=0.25, ug=0.95, wtop=-0.03), "k_tke_12x8x6": dict(tke=0.05), "k_tke_thl_12x8x6": dict(tke=0.08, dthl=0.3), "k_coriol_12x8x6": dict(ug=1.1), "run_profforc_16x16x8": dict(ug=1.3), "k_thl_12x8x6": dict(dthl=0.4, dthlrad=2e-3), "run_thl_16x8x12s": dict(dthl=0.25, dthlrad=-1e-3),
              "k_buoy_12x8x6": dict(dthl=0.3), "run_buoy_16x8x12s": dict(dthl=0.2),
+             "k_ibm_thl_16x12x10": dict(dthl=0.3), "run_ibm_thl_16x12x10": dict(dthl=0.25), "run_ibm_thlcons_16x12x10": dict(dthl=0.25),
+             "run_ibm_qt_16x12x10": dict(dthl=0.25, qt=0.007, dqt=-2e-4),
              "k_vreman_buoycorr_12x8x10": dict(dthl=0.004), "run_vreman_buoycorr_16x8x12s": dict(dthl=0.004)}
 
 

@@ -43,7 +43,7 @@ class OrcGrid(C.Structure):
 
 class OrcIbm(C.Structure):
     _fields_ = [("sol", C.POINTER(C.c_int) * 4), ("nsol", C.c_int * 4), ("bnd", C.POINTER(C.c_int) * 4), ("nbnd", C.c_int * 4),
-                ("mask", DP * 4)]
+                ("mask", DP * 4), ("conservative", C.c_int)]
 
 
 class OrcState(C.Structure):
@@ -150,7 +150,7 @@ class Oracle:
         f(C.byref(self.g), C.byref(s))
 
     # ---- immersed boundary: lists = {grid letter: (solid[n,3], boundary[n,3])} as udcore.ibm.read_ibm returns them
-    def set_ibm(self, lists, wrapx=False, wrapy=False):
+    def set_ibm(self, lists, wrapx=False, wrapy=False, conservative=False):
         """Build the masks (orc_ibm_mask) and make orc_substep run ibmwallfun / ibmnorm; None switches it off.
         wrapx / wrapy: the masks' lateral ghost cells are periodic images (a reference run that splits the direction
         over ranks) or stay "fluid" (one rank: the fixtures' build)."""
@@ -172,6 +172,7 @@ class Oracle:
             b.sol[q], b.nsol[q] = sol.ctypes.data_as(ip), len(sol)
             b.bnd[q], b.nbnd[q] = bnd.ctypes.data_as(ip), len(bnd)
             b.mask[q] = ptr(mask)
+        b.conservative = int(bool(conservative))      # lconservativeibm: advecc2nd_corr_conservative instead of _liberal
         self._ibm = (b, keep)
         self.L.orc_set_ibm(C.byref(b))
         return {g: keep[3 * q + 2] for q, g in enumerate("uvwc")}

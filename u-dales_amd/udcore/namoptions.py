@@ -19,18 +19,19 @@ DEFAULTS = {
     "DOMAIN": dict(itot=96, jtot=96, ktot=96, xlen=-1., ylen=-1., xlat=52., ksp=-1),
     "PHYSICS": dict(lmoist=False, lcoriol=False, lbuoyancy=False, ltempeq=False, lprofforc=False, ps=101325.,
                     dpdx=0., igrw_damp=0, lnudge=False, lnudgevel=True, tnudge=60., nnudge=0, luvolflowr=False, uflowrate=1., lvvolflowr=False, vflowrate=1.,
-                    ifixuinf=0, lvinf=False, tscale=0.),
+                    ifixuinf=0, lvinf=False, tscale=0., lconservativeibm=False),
     "CHEMISTRY": dict(lchem=False, k1=0., JNO2=0.),
     "INLET": dict(Uinf=0., Vinf=0., inletav=0.),
     "DYNAMICS": dict(lqlnr=False, ipoiss=0, iadv_mom=2, iadv_tke=-1, iadv_thl=-1, iadv_qt=-1),
     "BC": dict(BCxm=1, BCym=1, BCtopm=1, BCbotm=2, BCzp=1, z0=-1., z0h=-1., BCtopT=1, BCbotT=1, BCbots=1, BCtops=1,
                wttop=0., thl_top=-1., wtsurf=-1., thls=-1., qts=-1.,
-               BCtopq=1, BCbotq=1, wqtop=0., qt_top=-1., wqsurf=-1., wsvtopdum=0., ds=0.),
+               BCtopq=1, BCbotq=1, wqtop=0., qt_top=-1., wqsurf=-1., wsvtopdum=0., ds=0.,
+               bctfxm=0., bctfxp=0., bctfym=0., bctfyp=0., bctfz=0., bcqfxm=0., bcqfxp=0., bcqfym=0., bcqfyp=0., bcqfz=0.),
     "SCALARS": dict(nsv=0, lscasrc=False, nscasrc=0, lscasrcl=False, nscasrcl=0),
     "NAMSUBGRID": dict(lsmagorinsky=False, lvreman=True, loneeqn=False, c_vreman=0.07, cs=-1.,
                        cf=2.5, cn=0.76, Rigc=0.25, Prandtl=0.333, ldelta=False, lbuoycorr=False),
     "OUTPUT": dict(ltdump=False, tstatsdump=10000., tsample=5., tstatstart=0.),
-    "WALLS": dict(nfcts=-1, lbottom=False, iwallmom=2, iwalltemp=1, nsolpts_u=0, nsolpts_v=0, nsolpts_w=0, nsolpts_c=0,
+    "WALLS": dict(nfcts=-1, lbottom=False, iwallmom=2, iwalltemp=1, iwallmoist=1, nsolpts_u=0, nsolpts_v=0, nsolpts_w=0, nsolpts_c=0,
                   nbndpts_u=0, nbndpts_v=0, nbndpts_w=0, nbndpts_c=0),
     "ORACLE": dict(nsub=3, nspin=2, lforces=True, scal_a=1.0, scal_b=0.0),
 }
