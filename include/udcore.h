@@ -239,6 +239,13 @@ int udc_level_forcings(udc_handle *h, int when);
 enum { UDC_IBM_U = 0, UDC_IBM_V = 1, UDC_IBM_W = 2, UDC_IBM_C = 3 };
 int udc_set_ibm_points(udc_handle *h, int grid, const int *solid, int nsolid, const int *bound, int nbound);
 int udc_set_ibm_mask_wrap(udc_handle *h, int wrapx, int wrapy);
+/* temperature (udc_set_tempeq) and total water (udc_set_moisture) with an immersed boundary: ibmnorm's solid on thlm / qtm (thl:
+ * the volume mean of the fluid-cell slab averages where an obstacle cell has no fluid neighbour, :715) and advecc2nd_corr --
+ * _liberal (:936) or, with lconservativeibm (&PHYSICS), _conservative (:889) --, ibmwallfun's diffc_corr, and the buoyancy
+ * term's thvh over the fluid w points.  The walls are adiabatic and impermeable: wallfunheat (:1436) is not on the device,
+ * which is exact for prescribed zero wall fluxes (iwalltemp = iwallmoist = 1, bctf* = bcqf* = 0; anything else is refused
+ * by the host side). */
+int udc_set_ibm_conservative(udc_handle *h, int lconservativeibm);
 int udc_ibm_commit(udc_handle *h);
 int udc_ibmwallfun(udc_handle *h);
 int udc_ibmnorm(udc_handle *h);

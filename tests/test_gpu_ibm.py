@@ -19,8 +19,10 @@ def _core(name, iexp):
     return d, udcore.from_deck(d)
 
 
-def test_ibm_routines_match_reference():
-    name, iexp = "k_ibm_16x12x10", 54
+@pytest.mark.parametrize("name,iexp", [("k_ibm_16x12x10", 54), ("k_ibm_thl_16x12x10", 58)])
+def test_ibm_routines_match_reference(name, iexp):
+    """The second deck adds temperature with buoyancy: diffc_corr and solid (volume-mean value) on thl, advecc2nd_corr_liberal,
+    and the slab averages over the fluid cells (thl0av; thvh through the buoyancy term of the run fixtures)."""
     fix = load_fixture(name)
     d, core = _core(name, iexp)
     nz, nsv = core.g.nz, core.nsv
@@ -30,6 +32,13 @@ def test_ibm_routines_match_reference():
     for n in range(nsv):
         core.upload(L.scalar_field(L.SV0, n), carr(fix, f"in.sv0_{n + 1:02d}", nz))
         core.upload(L.scalar_field(L.SVM, n), carr(fix, f"in.svm_{n + 1:02d}", nz))
+    thl = "ibw.thlp" in fix
+    if thl:
+        core.upload("thl0", marr(fix, "sub.thl0", nz)); core.upload("thlm", marr(fix, "in.thlm", nz))
+        # diagfld's thl0av over the fluid cells (what ibmnorm's solid value and the host forcings are built from)
+        av = core.slab_averages(["thl0"])["thl0"]
+        assert np.abs(av[1:nz + 1] - fix["ibm.thl0av"].data[:nz]).max() <= 1e-12 * 288.
+        core.upload("thlp", marr(fix, "ibw0.thlp", nz))
     # --- ibmwallfun: tendencies as the reference had them before the call
     for t in ("up", "vp", "wp"):
         core.upload(t, marr(fix, f"ibw0.{t}", nz))
@@ -43,6 +52,11 @@ def test_ibm_routines_match_reference():
     for n in range(nsv):
         got = core.download(L.scalar_field(L.SVP, n), halo=2)
         assert relerr(interior(got, 2), interior(carr(fix, f"ibw.svp_{n + 1:02d}", nz), 2)) <= 1e-12
+    if thl:
+        ref, before = marr(fix, "ibw.thlp", nz), marr(fix, "ibw0.thlp", nz)
+        assert np.abs(ref - before).max() > 1e-9
+        assert relerr(interior(core.download("thlp")), interior(ref)) <= 1e-12
+        core.upload("thlp", marr(fix, "ibn0.thlp", nz))
     # --- ibmnorm
     for t in ("up", "vp", "wp"):
         core.upload(t, marr(fix, f"ibn0.{t}", nz))
@@ -57,6 +71,11 @@ def test_ibm_routines_match_reference():
         assert relerr(interior(got, 2), interior(carr(fix, f"ibn.svp_{n + 1:02d}", nz), 2)) <= 1e-13
         got = core.download(L.scalar_field(L.SVM, n), halo=2)
         assert relerr(interior(got, 2), interior(carr(fix, f"ibn.svm_{n + 1:02d}", nz), 2)) <= 1e-13
+    if thl:       # solid with the volume mean of thl0av, then advecc2nd_corr_liberal
+        assert relerr(interior(core.download("thlm")), interior(marr(fix, "ibn.thlm", nz))) <= 1e-13
+        ref, before = marr(fix, "ibn.thlp", nz), marr(fix, "ibn0.thlp", nz)
+        assert np.abs(interior(ref) - interior(before)).max() > 1e-9
+        assert relerr(interior(core.download("thlp")), interior(ref)) <= 1e-12
     core.close()
 
 
@@ -90,6 +109,11 @@ def test_ibm_refusals():
         udcore.from_deck(d)
     d.nml["WALLS"]["iwallmom"] = 1
     d.nml.setdefault("PHYSICS", {})["ltempeq"] = True
+    d.nml["WALLS"]["iwalltemp"] = 2                      # wall temperatures: needs the heat wall function
+    with pytest.raises(ValueError, match="wallfunheat"):
+        udcore.from_deck(d)
+    d.nml["WALLS"]["iwalltemp"] = 1
+    d.nml.setdefault("BC", {})["bctfz"] = 0.01           # a prescribed wall flux: likewise (adiabatic walls only)
     with pytest.raises(ValueError, match="wallfunheat"):
         udcore.from_deck(d)
 

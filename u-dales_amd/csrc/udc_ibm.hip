@@ -127,10 +127,11 @@ __global__ void ibm_solid_zero_kernel(Geo g, int n, const int *__restrict__ pt, 
 }
 
 // solid with the c mask: value and tendency become the mean over the fluid neighbours (or val / 0 without any)
-__global__ void ibm_solid_mean_kernel(Geo g, int n, const int *__restrict__ pt, const unsigned char *__restrict__ fl, double val,
+__global__ void ibm_solid_mean_kernel(Geo g, int n, const int *__restrict__ pt, const unsigned char *__restrict__ fl, const double *__restrict__ valp,
                                       double *__restrict__ var, double *__restrict__ rhs) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= n) return;
+  const double val = valp ? *valp : 0.;
   const int i = pt[3 * q], j = pt[3 * q + 1], k = pt[3 * q + 2];
   const long c = g.idx(i, j, k), sy = g.sy, sz = g.sz;
   const long nb[6] = {c + sy, c - sy, c + sz, c - sz, g.idx(wrapx(i + 1, g.nx), j, k), g.idx(wrapx(i - 1, g.nx), j, k)};
@@ -142,6 +143,50 @@ __global__ void ibm_solid_mean_kernel(Geo g, int n, const int *__restrict__ pt, 
   if (count > 0.) { v = (v - val) / count; r = r / count; }
   var[c] = v;
   rhs[c] = r;
+}
+
+// the value `solid` gives thl where an obstacle cell has no fluid neighbour (ibmnorm, src/modibm.f90:715):
+// sum(thl0av(kb:ke) dzf(kb:ke)) / zh(ke+1) with thl0av the slab average over the fluid cells; S = masked level sums
+__global__ void ibm_thl_val_kernel(int nz, const double *__restrict__ S, const double *__restrict__ cnt, const double *__restrict__ dzf,
+                                   double zsize, double *__restrict__ out) {
+  double v = 0.;
+  for (int k = 1; k <= nz; ++k) v += S[k - 1] / cnt[k] * dzf[k];
+  *out = v / zsize;
+}
+
+// advecc2nd_corr_conservative (src/modibm.f90:889-933) / advecc2nd_corr_liberal (:936-987) at the fluid-boundary points of
+// the c grid, for a field advected by advecc_2nd (thl, qt).  fl bit b: mask_c of neighbour b (i+1, i-1, j+1, j-1, k+1,
+// k-1) is solid; fl2 bit b: the momentum mask on the face towards neighbour b is solid (mask_u(i+1), mask_u(i),
+// mask_v(j+1), mask_v(j), mask_w(k+1), mask_w(k)).
+template <bool CONS>
+__global__ void ibm_advecc_corr_kernel(Geo g, Metrics m, int n, const int *__restrict__ pt, const unsigned char *__restrict__ fl,
+                                       const unsigned char *__restrict__ fl2, const double *__restrict__ u0, const double *__restrict__ v0,
+                                       const double *__restrict__ w0, const double *__restrict__ var, double *__restrict__ rhs) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const int i = pt[3 * q], j = pt[3 * q + 1], k = pt[3 * q + 2], kf = k + 1;
+  const long c = g.idx(i, j, k), cp = g.idx(wrapx(i + 1, g.nx), j, k), cm = g.idx(wrapx(i - 1, g.nx), j, k), sy = g.sy, sz = g.sz;
+  const unsigned f = CONS ? (unsigned)(fl[q] | fl2[q]) : (unsigned)fl[q];
+  const double vc = var[c];
+  double t = rhs[c];
+  if (CONS) {
+    if (f & 1u)  t = t + u0[cp] * (var[cp] + vc) * m.dxi5;
+    if (f & 2u)  t = t - u0[c] * (var[cm] + vc) * m.dxi5;
+    if (f & 4u)  t = t + v0[c + sy] * (var[c + sy] + vc) * m.dyi5;
+    if (f & 8u)  t = t - v0[c] * (var[c - sy] + vc) * m.dyi5;
+    if (f & 16u) t = t + w0[c + sz] * (var[c + sz] * m.dzf[kf] + vc * m.dzf[kf + 1]) * m.dzhi[kf + 1] * m.dzfi5[kf];
+    if (f & 32u) t = t - w0[c] * (var[c - sz] * m.dzf[kf] + vc * m.dzf[kf - 1]) * m.dzhi[kf] * m.dzfi5[kf];
+  } else {
+    if (f & 1u)  t = t + u0[cp] * (var[cp] + vc) * m.dxi5 - u0[cp] * (vc + vc) * m.dxi5;
+    if (f & 2u)  t = t - u0[c] * (var[cm] + vc) * m.dxi5 + u0[c] * (vc + vc) * m.dxi5;
+    if (f & 4u)  t = t + v0[c + sy] * (var[c + sy] + vc) * m.dyi5 - v0[c + sy] * (vc + vc) * m.dyi5;
+    if (f & 8u)  t = t - v0[c] * (var[c - sy] + vc) * m.dyi5 + v0[c] * (vc + vc) * m.dyi5;
+    if (f & 16u) t = t + w0[c + sz] * (var[c + sz] * m.dzf[kf] + vc * m.dzf[kf + 1]) * m.dzhi[kf + 1] * m.dzfi5[kf]
+                       - w0[c + sz] * (vc * m.dzf[kf] + vc * m.dzf[kf + 1]) * m.dzhi[kf + 1] * m.dzfi5[kf];
+    if (f & 32u) t = t - w0[c] * (var[c - sz] * m.dzf[kf] + vc * m.dzf[kf - 1]) * m.dzhi[kf] * m.dzfi5[kf]
+                       + w0[c] * (vc * m.dzf[kf] + vc * m.dzf[kf - 1]) * m.dzhi[kf] * m.dzfi5[kf];
+  }
+  rhs[c] = t;
 }
 
 // masked slab sums (avexy_ibm, src/modmpi.f90:623-664): the sum over the fluid cells of a level is the sum over all
@@ -236,8 +281,13 @@ extern "C" int udc_ibm_commit(udc_handle *h) {
     if (!h->ibm[gq].given) { udc_set_error("udc_ibm_commit: the u, v and w point lists are needed (udc_set_ibm_points)"); return 1; }
   const bool have_c = h->ibm[3].given;
   if (!h->slots.empty() && !have_c) { udc_set_error("udc_ibm_commit: transported scalars need the c point lists"); return 1; }
+  // thl (slot 15) and qt (13): ibmnorm / diffc_corr as for the scalars plus advecc2nd_corr; the walls are adiabatic and
+  // impermeable (wallfunheat, src/modibm.f90:1436, is not on the device: with prescribed zero fluxes it adds nothing --
+  // the host side refuses decks that ask for anything else).  Not built: the one-equation closure's e12 next to obstacles,
+  // and the moist thermodynamics' slab averages over the fluid cells.
   for (int n : h->slots)
-    if (n >= 13) { udc_set_error("udc_ibm_commit: thl, qt and e12 with immersed boundaries need the facet wall functions (wallfunheat), which this build does not have"); return 1; }
+    if (n == 14) { udc_set_error("udc_ibm_commit: the one-equation closure (e12) is not available with immersed boundaries"); return 1; }
+  if (h->lmoist && h->mt) { udc_set_error("udc_ibm_commit: the moist thermodynamics (lmoist with lbuoyancy) are not available with immersed boundaries"); return 1; }
   const int nx = h->g.nx, ny = h->jtot, nz = h->g.nz, j0 = h->cfg.rank * h->g.ny, nyl = h->g.ny;
   // masks as initibm builds them (src/modibm.f90:150-186): 1 = fluid; planes k = 0 (kb-1) .. nz+1.  Beyond a lateral
   // boundary of the domain: the periodic image, or "fluid" where the reference's exchange_halo_z would not have wrapped
@@ -264,7 +314,7 @@ extern "C" int udc_ibm_commit(udc_handle *h) {
     udc_handle::IbmGrid &G = h->ibm[gq];
     if (gq == 3 && !have_c) { G.nsolid = G.nbound = 0; continue; }
     std::vector<int> sp, bp;
-    std::vector<unsigned char> sf, bf;
+    std::vector<unsigned char> sf, bf, bf2;
     for (size_t q = 0; q < G.solid_g.size() / 3; ++q) {
       const int i = G.solid_g[3 * q], j = G.solid_g[3 * q + 1], k = G.solid_g[3 * q + 2];
       if (j <= j0 || j > j0 + nyl) continue;
@@ -291,10 +341,25 @@ extern "C" int udc_ibm_commit(udc_handle *h) {
       for (int b = 0; b < nb; ++b)
         if (at(gq, ni[b], nj[b], nk[b]) == 0) f |= 1u << b;
       bf.push_back((unsigned char)f);
+      if (gq == 3) {      // advecc2nd_corr_conservative: mask_u(i+1), mask_u(i), mask_v(j+1), mask_v(j), mask_w(k+1), mask_w(k)
+        unsigned f2 = 0;
+        if (at(0, i + 1, j, k) == 0) f2 |= 1u;
+        if (at(0, i, j, k) == 0) f2 |= 2u;
+        if (at(1, i, j + 1, k) == 0) f2 |= 4u;
+        if (at(1, i, j, k) == 0) f2 |= 8u;
+        if (at(2, i, j, k + 1) == 0) f2 |= 16u;
+        if (at(2, i, j, k) == 0) f2 |= 32u;
+        bf2.push_back((unsigned char)f2);
+      }
     }
     G.nsolid = (int)(sp.size() / 3); G.nbound = (int)(bp.size() / 3);
     if (upload_points(h, sp, sf, &G.solid, &G.solid_fl)) return 1;
     if (upload_points(h, bp, bf, &G.bound, &G.bound_fl)) return 1;
+    if (G.bound_fl2) { HIP_OK(hipFree(G.bound_fl2)); G.bound_fl2 = nullptr; }
+    if (gq == 3 && !bf2.empty()) {
+      HIP_OK(hipMalloc(&G.bound_fl2, bf2.size()));
+      HIP_OK(hipMemcpy(G.bound_fl2, bf2.data(), bf2.size(), hipMemcpyHostToDevice));
+    }
     // solid points by level (counting sort), fluid cells per level of the whole domain (IIus ... of createmasks; the w mask
     // also excludes the floor level itself, src/modibm.f90:2179)
     std::vector<int> off(nz + 3, 0), lp(sp.size());
@@ -321,7 +386,11 @@ extern "C" int udc_ibm_commit(udc_handle *h) {
       if (!(gq == 2 && k == 1)) G.fluid_cnt[k] -= 1.;
     }
     if (gq == 2) G.fluid_cnt[1] = 0.;
+    if (G.cnt_dev) { HIP_OK(hipFree(G.cnt_dev)); G.cnt_dev = nullptr; }
+    HIP_OK(hipMalloc(&G.cnt_dev, sizeof(double) * (nz + 2)));
+    HIP_OK(hipMemcpy(G.cnt_dev, G.fluid_cnt.data(), sizeof(double) * (nz + 2), hipMemcpyHostToDevice));
   }
+  if (!h->ibm_val) HIP_OK(hipMalloc(&h->ibm_val, sizeof(double)));
   if (h->ibm_wlev) { HIP_OK(hipFree(h->ibm_wlev)); h->ibm_wlev = nullptr; }
   h->ibm_on = true;
   return 0;
@@ -336,7 +405,10 @@ void ibm_destroy(udc_handle *h) {
     if (G.bound_fl) hipFree(G.bound_fl);
     if (G.lev_pts) hipFree(G.lev_pts);
     if (G.lev_off) hipFree(G.lev_off);
+    if (G.cnt_dev) hipFree(G.cnt_dev);
+    if (G.bound_fl2) hipFree(G.bound_fl2);
   }
+  if (h->ibm_val) hipFree(h->ibm_val);
 }
 
 int ibm_grid_of_field(int field) {
@@ -399,10 +471,36 @@ int k_ibm_norm(udc_handle *h) {
                                      h->fields[UDC_UM + q], h->fields[UDC_UP + q]);
   }
   const udc_handle::IbmGrid &C = h->ibm[3];
-  if (C.nsolid)
-    for (int n : h->slots)
-      hipLaunchKernelGGL(ibm_solid_mean_kernel, dim3(blocks(C.nsolid)), dim3(128), 0, h->stream, g, C.nsolid, C.solid, C.solid_fl, 0.,
+  for (int n : h->slots) {
+    const double *valp = nullptr;
+    if (n == 15) {
+      // thl: the volume mean of thl0av (slab averages over the fluid cells, as the last `thermodynamics` left them: thl0
+      // has not changed since) -- level sums with the solid points taken out, all-reduced over the slabs, on the device
+      if (k_level_sums_dev(h, UDC_THL0, g.nz)) return 1;
+      hipLaunchKernelGGL(ibm_thl_val_kernel, dim3(1), dim3(1), 0, h->stream, g.nz, (const double *)h->lev_sum16, (const double *)C.cnt_dev,
+                         h->m.dzf, h->zsize, h->ibm_val);
+      valp = h->ibm_val;
+    }
+    if (C.nsolid)
+      hipLaunchKernelGGL(ibm_solid_mean_kernel, dim3(blocks(C.nsolid)), dim3(128), 0, h->stream, g, C.nsolid, C.solid, C.solid_fl, valp,
                          h->fields[UDC_SVM + 3 * n], h->fields[UDC_SVP + 3 * n]);
+    // fields advected by advecc_2nd (thl unless iadv_thl = 7, qt): src/modibm.f90:716-722, 727-731
+    if (C.nbound && n >= 13 && h->slot[n].adv == 2) {
+      const double *u0 = h->fields[UDC_U0], *v0 = h->fields[UDC_V0], *w0 = h->fields[UDC_W0];
+      if (h->ibm_conservative)
+        hipLaunchKernelGGL(ibm_advecc_corr_kernel<true>, dim3(blocks(C.nbound)), dim3(128), 0, h->stream, g, h->m, C.nbound, C.bound, C.bound_fl,
+                           C.bound_fl2, u0, v0, w0, (const double *)h->fields[UDC_SV0 + 3 * n], h->fields[UDC_SVP + 3 * n]);
+      else
+        hipLaunchKernelGGL(ibm_advecc_corr_kernel<false>, dim3(blocks(C.nbound)), dim3(128), 0, h->stream, g, h->m, C.nbound, C.bound, C.bound_fl,
+                           C.bound_fl2, u0, v0, w0, (const double *)h->fields[UDC_SV0 + 3 * n], h->fields[UDC_SVP + 3 * n]);
+    }
+  }
   HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int udc_set_ibm_conservative(udc_handle *h, int lconservativeibm) {
+  if (!h) { udc_set_error("null handle"); return 1; }
+  h->ibm_conservative = lconservativeibm != 0;
   return 0;
 }

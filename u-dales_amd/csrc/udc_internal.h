@@ -182,10 +182,14 @@ struct udc_handle {
     // lev_pts[3 lev_off[k] .. 3 lev_off[k+1]), k = 0..nz; fluid_cnt[k] = fluid cells of the whole level (all slabs)
     int *lev_pts = nullptr, *lev_off = nullptr;
     std::vector<double> fluid_cnt;
+    double *cnt_dev = nullptr;          // fluid_cnt on the device ([nz+2], indexed by the reference's k)
+    unsigned char *bound_fl2 = nullptr; // c grid: the momentum masks on the faces of a fluid-boundary cell (advecc2nd_corr_conservative)
   };
   IbmGrid ibm[4];
   double *bottom_diag[3] = {nullptr, nullptr, nullptr};      // tau_x, tau_y, thl_flux planes [ny_l][nx] (udc_bottom_diagnostics)
   bool ibm_on = false;
+  bool ibm_conservative = false;        // lconservativeibm: which advecc2nd_corr ibmnorm applies to thl, qt
+  double *ibm_val = nullptr;            // device scalar: the value solid() gives thl inside obstacles (volume mean of thl0av)
   bool ibm_wrap_x = true, ibm_wrap_y = true;     // mask look-ups across the domain's lateral boundaries (udc_set_ibm_mask_wrap)
   double *ibm_wlev = nullptr;           // masscorr's per-level weights with the masks, u then v ([2][nz+2])
   // statistics accumulators (udc_stats.hip), UDC_ST_* ids
@@ -273,6 +277,7 @@ int k_closure_lds(udc_handle *h, bool ghosts);   // ghosts: closurebc folded in 
 int k_ek_ghosts(udc_handle *h);
 int k_momentum(udc_handle *h, bool adv, bool diff, bool forces);       // direct-load version (UDC_MOM_SIMPLE=1)
 int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, double rk3coefi, bool um_is_u0 = false);  // rk3coefi != 0: PUP mode   // LDS-staged k-marching version (default)
+int k_level_sums_dev(udc_handle *h, int field, int n);      // udc_thermo.hip: masked, all-reduced level sums left on the device
 int k_scalar_adv(udc_handle *h, int n);
 int k_scalar_diff(udc_handle *h, int n);
 int k_scalar_fused(udc_handle *h, int n, bool fresh);          // advection + diffusion in one sweep (same accumulation order)

@@ -43,12 +43,28 @@ __global__ __launch_bounds__(256) void levelsum_final_kernel(int tiles, const do
   __syncthreads();
   if (threadIdx.x == 0) S[k] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
 }
+// immersed boundary: thvh is the average over the fluid w points of the level (avexy_ibm with IIw, IIws,
+// src/modthermodynamics.f90:76): take the listed solid w points back out of the level sums.  One workgroup per level.
+__global__ __launch_bounds__(256) void ibm_thvh_correct_kernel(Geo g, Metrics m, const int *__restrict__ pts, const int *__restrict__ off,
+                                                                const double *__restrict__ thl, double *__restrict__ S) {
+  __shared__ double sw[4];
+  const int k = blockIdx.x;
+  double v = 0.;
+  if (k >= 1)
+    for (int q = off[k] + threadIdx.x; q < off[k + 1]; q += 256) v += thl_half(g, m, thl, g.idx(pts[3 * q], pts[3 * q + 1], k), k);
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) S[k] = S[k] - ((sw[0] + sw[1]) + (sw[2] + sw[3]));
+}
+// cntk: fluid w points per level (indexed by the reference's k) with an immersed boundary, else nullptr and cnt applies
 __global__ __launch_bounds__(256) void buoyancy_kernel(Geo g, TileGrid tg, Metrics m, const double *__restrict__ thl,
-                                                        const double *__restrict__ S, double cnt, double grav, double *__restrict__ wp) {
+                                                        const double *__restrict__ S, double cnt, const double *__restrict__ cntk,
+                                                        double grav, double *__restrict__ wp) {
   int i, j, k;
   if (!tile_decode(g, tg, i, j, k) || k < 1) return;
   const long c = g.idx(i, j, k);
-  const double thvh = S[k] / cnt;
+  const double thvh = S[k] / (cntk ? cntk[k + 1] : cnt);
   wp[c] = wp[c] + grav * (thl_half(g, m, thl, c, k) - thvh) / thvh;
 }
 
@@ -303,6 +319,26 @@ int k_slab_averages(udc_handle *h, const int *fields, int nf, double *avg_host, 
 }
 int k_slab_average(udc_handle *h, int field, double *avg_host, int n) { return k_slab_averages(h, &field, 1, avg_host, n); }
 
+// level sums of one field over levels 1..n with the immersed boundary's solid points taken out, all-reduced over the
+// slabs, left in h->lev_sum16[0..n) on the device (no host round trip: for kernels that consume them)
+int k_level_sums_dev(udc_handle *h, int field, int n) {
+  const Geo &g = h->g;
+  const TileGrid tg = tile_grid(g);
+  const size_t need = (size_t)tg.tiles * n;
+  if (h->lev_cap < need) {
+    if (h->lev_part) HIP_OK(hipFree(h->lev_part));
+    HIP_OK(hipMalloc(&h->lev_part, sizeof(double) * need));
+    h->lev_cap = need;
+  }
+  if (!h->lev_sum16) HIP_OK(hipMalloc(&h->lev_sum16, sizeof(double) * 16 * (g.nz + 2)));
+  hipLaunchKernelGGL(levelsum_plain_kernel, dim3((unsigned)tg.tiles, (unsigned)n), dim3(64, 4), 0, h->stream, g, tg.gx,
+                     (const double *)h->fields[field], h->lev_part);
+  hipLaunchKernelGGL(levelsum_final_kernel, dim3((unsigned)n), dim3(256), 0, h->stream, tg.tiles, h->lev_part, h->lev_sum16);
+  HIP_OK(hipGetLastError());
+  if (k_ibm_levelsum_correct(h, &field, 1, n, h->lev_sum16)) return 1;
+  return comm_allreduce(h, h->lev_sum16, n, 1);
+}
+
 int k_level_forcings(udc_handle *h, int when, bool wrap_vp) {
   const Geo &g = h->g;
   dim3 b(64, 4, 1), gr = cell_grid(g, b);
@@ -408,9 +444,17 @@ int k_buoyancy(udc_handle *h) {
   hipLaunchKernelGGL(levelsum_kernel, dim3((unsigned)tg.tiles, (unsigned)g.nz), dim3(64, 4), 0, h->stream, g, h->m, tg.gx, thl, h->lev_part);
   hipLaunchKernelGGL(levelsum_final_kernel, dim3((unsigned)g.nz), dim3(256), 0, h->stream, tg.tiles, h->lev_part, h->lev_sum);
   HIP_OK(hipGetLastError());
+  const double *cntk = nullptr;
+  if (h->ibm_on) {
+    const udc_handle::IbmGrid &W = h->ibm[2];
+    if (W.nsolid)
+      hipLaunchKernelGGL(ibm_thvh_correct_kernel, dim3((unsigned)g.nz), dim3(256), 0, h->stream, g, h->m, (const int *)W.lev_pts,
+                         (const int *)W.lev_off, thl, h->lev_sum);
+    cntk = W.cnt_dev;
+  }
   if (comm_allreduce(h, h->lev_sum, g.nz, 1)) return 1;       // avexy_ibm's MPI_ALLREDUCE over the slabs
   dim3 b(64, 4, 1), gr = cell_grid(g, b);
-  hipLaunchKernelGGL(buoyancy_kernel, gr, b, 0, h->stream, g, tg, h->m, thl, h->lev_sum, (double)g.nx * (double)h->cfg.jtot,
+  hipLaunchKernelGGL(buoyancy_kernel, gr, b, 0, h->stream, g, tg, h->m, thl, h->lev_sum, (double)g.nx * (double)h->cfg.jtot, cntk,
                      h->grav, h->fields[UDC_WP]);
   HIP_OK(hipGetLastError());
   return 0;

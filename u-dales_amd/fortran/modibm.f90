@@ -43,8 +43,9 @@ module modibm
 contains
 
   subroutine initibm
-    use modglobal, only: libm, ib, ie, ih, jb, je, jh, kb, ke, kh, ltempeq, lmoist, nsv, BCbotm, BCbotT, BCbotq, BCbots, &
-                         iwallmom, lwritefac
+    use modglobal, only: libm, ib, ie, ih, jb, je, jh, kb, ke, kh, ltempeq, lmoist, lbuoyancy, nsv, BCbotm, BCbotT, BCbotq, BCbots, &
+                         iwallmom, iwalltemp, iwallmoist, lwritefac
+    use modibmdata, only: bctfxm, bctfxp, bctfym, bctfyp, bctfz, bcqfxm, bcqfxp, bcqfym, bcqfyp, bcqfz
     use modsurfdata, only: z0
     use udc_iface, only: udc_set_floor
     logical :: need_c
@@ -76,11 +77,19 @@ contains
       write (0, *) 'ERROR: libudcore modibm: the facet wall functions (iwallmom > 1) are not available; set iwallmom = 1'
       stop 1
     end if
-    if (ltempeq .or. lmoist .or. lwritefac) then
-      write (0, *) 'ERROR: libudcore modibm: ltempeq / lmoist / lwritefac with libm need the facet wall functions (wallfunheat)'
+    ! temperature / moisture: wallfunheat (src/modibm.f90:1436) is not available; it adds exactly nothing when the wall fluxes
+    ! are prescribed (iwalltemp / iwallmoist = 1) and zero -- adiabatic, impermeable walls -- and only such decks run
+    if (lwritefac .or. (ltempeq .and. (iwalltemp /= 1 .or. any((/bctfxm, bctfxp, bctfym, bctfyp, bctfz/) /= 0.))) .or. &
+        (lmoist .and. (iwallmoist /= 1 .or. any((/bcqfxm, bcqfxp, bcqfym, bcqfyp, bcqfz/) /= 0.)))) then
+      write (0, *) 'ERROR: libudcore modibm: wall heat / moisture fluxes and lwritefac need the facet wall functions (wallfunheat);'
+      write (0, *) '       only iwalltemp = iwallmoist = 1 with bctf* = bcqf* = 0 (adiabatic, impermeable walls) is available'
       stop 1
     end if
-    need_c = nsv > 0
+    if (lmoist .and. lbuoyancy) then
+      write (0, *) 'ERROR: libudcore modibm: the moist thermodynamics (lmoist with lbuoyancy) are not available with libm'
+      stop 1
+    end if
+    need_c = nsv > 0 .or. ltempeq .or. lmoist          ! src/modibm.f90:180
     mask_w(:, :, kb) = 0.                     ! src/modibm.f90:154-157
     mask_u(:, :, kb - kh) = 0.; mask_v(:, :, kb - kh) = 0.; mask_w(:, :, kb - kh) = 0.; mask_c(:, :, kb - kh) = 0.
     call grid_lists(0, 'solid_u.txt', nsolpts_u, 'fluid_boundary_u.txt', nbndpts_u, mask_u, sol_u)
@@ -124,6 +133,7 @@ contains
   subroutine ibm_to_device
     use udc_iface
     use modmpi, only : nprocx, nprocy
+    use modglobal, only : lconservativeibm
     integer :: q
     integer(c_int) :: none(3)
     if (.not. ibm_pending) return
@@ -133,6 +143,7 @@ contains
     ! it over ranks (periodic_bc, src/modstartup.f90:662-672): the device looks neighbours up the same way
     call udc_check(udc_set_ibm_mask_wrap(udc_h, merge(1_c_int, 0_c_int, nprocx > 1), merge(1_c_int, 0_c_int, nprocy > 1)), &
                    'udc_set_ibm_mask_wrap')
+    call udc_check(udc_set_ibm_conservative(udc_h, merge(1_c_int, 0_c_int, lconservativeibm)), 'udc_set_ibm_conservative')
     do q = 0, 3
       if (lists(q)%given) then
         call udc_check(udc_set_ibm_points(udc_h, int(q, c_int), lists(q)%sol, int(size(lists(q)%sol, 2), c_int), &

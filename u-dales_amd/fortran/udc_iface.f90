@@ -151,6 +151,11 @@ module udc_iface
       integer(c_int), value :: which
       real(c_double), intent(out) :: out(*)
     end function
+    integer(c_int) function udc_set_ibm_conservative(h, on) bind(C, name='udc_set_ibm_conservative')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+      integer(c_int), value :: on
+    end function
     integer(c_int) function udc_set_ibm_mask_wrap(h, wrapx, wrapy) bind(C, name='udc_set_ibm_mask_wrap')
       import :: c_int, c_ptr
       type(c_ptr), value :: h

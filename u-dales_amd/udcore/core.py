@@ -354,6 +354,10 @@ class DynCore:
         reference's masks hold the latter in a direction its run keeps on one rank (udcore.h)."""
         L._check(self.lib.udc_set_ibm_mask_wrap(self.h, int(bool(wrapx)), int(bool(wrapy))), "udc_set_ibm_mask_wrap")
 
+    def set_ibm_conservative(self, on):
+        """lconservativeibm: advecc2nd_corr_conservative instead of _liberal for thl / qt next to obstacles."""
+        L._check(self.lib.udc_set_ibm_conservative(self.h, int(bool(on))), "udc_set_ibm_conservative")
+
     def ibm_commit(self):
         L._check(self.lib.udc_ibm_commit(self.h), "udc_ibm_commit")
 

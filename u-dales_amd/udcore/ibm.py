@@ -43,8 +43,17 @@ def apply_ibm(core, deck):
         return None
     if int(deck.get("WALLS", "iwallmom")) != 1:
         raise ValueError("libm: only iwallmom = 1 (no facet wall functions, src/modibm.f90:1286) is on the device path")
-    if deck.get("PHYSICS", "ltempeq") or deck.get("PHYSICS", "lmoist"):
-        raise ValueError("libm with ltempeq / lmoist needs the facet heat wall functions (wallfunheat), not on the device path")
+    # temperature / moisture: wallfunheat (src/modibm.f90:1436) is not on the device path; it adds exactly nothing when the
+    # wall fluxes are prescribed (iwalltemp / iwallmoist = 1) and zero -- adiabatic, impermeable walls -- and only then
+    bc = lambda n: float(deck.get("BC", n))      # noqa: E731
+    if deck.get("PHYSICS", "ltempeq") and (int(deck.get("WALLS", "iwalltemp")) != 1 or any(bc(n) != 0. for n in ("bctfxm", "bctfxp", "bctfym", "bctfyp", "bctfz"))):
+        raise ValueError("libm with ltempeq: wall heat fluxes need the facet heat wall functions (wallfunheat), not on the device path; "
+                         "only iwalltemp = 1 with bctf* = 0 (adiabatic walls) is")
+    if deck.get("PHYSICS", "lmoist") and (int(deck.get("WALLS", "iwallmoist")) != 1 or any(bc(n) != 0. for n in ("bcqfxm", "bcqfxp", "bcqfym", "bcqfyp", "bcqfz"))):
+        raise ValueError("libm with lmoist: wall moisture fluxes need wallfunheat, not on the device path; only iwallmoist = 1 with bcqf* = 0 is")
+    if deck.get("PHYSICS", "lmoist") and deck.get("PHYSICS", "lbuoyancy"):
+        raise ValueError("libm with lmoist and lbuoyancy: the moist thermodynamics' slab averages over the fluid cells are not on the device path")
+    core.set_ibm_conservative(bool(deck.get("PHYSICS", "lconservativeibm")))
     lists = read_ibm(deck)
     # the masks' ghost cells as the reference run of this deck has them: wrapped only in a direction it splits over ranks
     core.set_ibm_mask_wrap(int(deck.get("RUN", "nprocx")) > 1, int(deck.get("RUN", "nprocy")) > 1)

@@ -32,7 +32,7 @@ EXPORTS = ["udc_create", "udc_destroy", "udc_last_error", "udc_version", "udc_co
            "udc_set_deferred", "udc_flush", "udc_deferred_stats",
            "udc_stats_enable", "udc_stats_sample", "udc_stats_get", "udc_set_ibm_points", "udc_ibm_commit", "udc_ibmwallfun", "udc_ibmnorm",
            "udc_divergence", "udc_sync", "udc_profile_enable", "udc_profile_reset",
-           "udc_profile_get", "udc_profile_focus", "udc_set_ibm_mask_wrap", "udc_bottom_diagnostics", "udc_bottom_diag_get"]
+           "udc_profile_get", "udc_profile_focus", "udc_set_ibm_mask_wrap", "udc_bottom_diagnostics", "udc_bottom_diag_get", "udc_set_ibm_conservative"]
 
 
 class UdcConfig(C.Structure):
