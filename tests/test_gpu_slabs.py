@@ -91,6 +91,30 @@ print("RCCL_OK", m, dv)
     assert "RCCL_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
+def ibm_block_lists(nx, ny, nz):
+    """Solid / fluid-boundary point lists (u, v, w, c) of two blocks on the floor, the rule of tests/golden/make_golden.py."""
+    c = np.zeros((nz + 2, ny, nx), dtype=bool)
+    c[1:5, ny // 2 - 3:ny // 2 + 3, 4:10] = True          # straddles the middle of the domain in y (a slab boundary for even P)
+    c[1:3, 2:5, nx - 9:nx - 4] = True
+    u = c | np.roll(c, 1, axis=2)
+    v = c | np.roll(c, 1, axis=1)
+    w = c.copy(); w[1:] |= c[:-1]
+    out = []
+    for name, sol in (("u", u), ("v", v), ("w", w), ("c", c)):
+        nb = np.zeros_like(sol)
+        for ax, sh in ((2, 1), (2, -1), (1, 1), (1, -1)):
+            nb |= np.roll(sol, sh, axis=ax)
+        nb[1:] |= sol[:-1]; nb[:-1] |= sol[1:]
+        bnd = nb & ~sol
+
+        def pts(m, lo):
+            m = m.copy(); m[:lo] = False; m[nz + 1:] = False
+            kji = np.argwhere(m)
+            return np.ascontiguousarray(np.stack([kji[:, 2] + 1, kji[:, 1] + 1, kji[:, 0]], axis=1), dtype=np.int32)
+        out.append((pts(sol, 1), pts(bnd, 2 if name == "w" else 1)))
+    return out
+
+
 def run_virtual(P, g, deck_like, st_global, nsub, dt, sgs, nsv=0, extras=False):
     """Run nsub substeps on P virtual ranks; returns the stitched global u0, v0, w0, pres0."""
     from udcore.core import DynCore
@@ -112,6 +136,13 @@ def run_virtual(P, g, deck_like, st_global, nsub, dt, sgs, nsv=0, extras=False):
                     core.set_moisture(bctopq=2, qt_top=0.0105, wqsurf=4e-5)
                     core.set_moist_thermo(288., 0.0105)
                 core.set_buoyancy(True)
+            if extras == 3:      # immersed boundary: two blocks, one across the slab boundaries, with temperature (adiabatic walls):
+                # per-slab point lists, level sums with the solid points taken out all-reduced over the slabs
+                for q, (sol, bnd) in enumerate(ibm_block_lists(g.nx, g.ny, g.nz)):
+                    if q < 3:
+                        core.set_ibm_points(q, sol, bnd)
+                core.set_ibm_points(3, *ibm_block_lists(g.nx, g.ny, g.nz)[3])
+                core.ibm_commit()
             if P > 1:
                 core.comm_init_local(group)
             local = {}
@@ -150,7 +181,8 @@ def run_virtual(P, g, deck_like, st_global, nsub, dt, sgs, nsv=0, extras=False):
                                                      # rows of 512 cells carry a line of padding (Geo.sy = nx + 16): halo packs, own line
                                                      # FFTs and the exchange buffers across slabs; 272 levels: the wave-specialised Thomas
                                                      # kernel (two-workgroup occupancy) on the slabs' share of the modes
-                                                     ((512, 32, 8), 2, 2, False), ((32, 32, 272), 2, 1, False)])
+                                                     ((512, 32, 8), 2, 2, False), ((32, 32, 272), 2, 1, False),
+                                                     ((32, 32, 12), 2, 1, 3)])      # immersed boundary + temperature
 def test_decomposition_invariance(shape, sgs, chunks, extras, monkeypatch):
     # chunks > 1: the k-chunked all-to-all pipeline (exchange on a second stream, overlapped with rocFFT)
     # power-of-two nx and ny: the slab ranks run the own line FFTs with fused packing (udc_fft.hip) against the single
