@@ -357,7 +357,7 @@ def main():
     # table and the dominant kernel.  The timed region then carries events around that kernel only (two per substep), so
     # `value` is not taxed by the survey and roofline.achieved is still measured live inside the timed region.
     rk = 1
-    skip = min(3, args.warmup)
+    skip = max(0, min(3, args.warmup - 1))      # (at least one surveyed substep whenever there is a warm-up at all)
     for _ in range(skip):
         core.substep(rk, dt, True)
         rk = rk % 3 + 1
