@@ -11,6 +11,8 @@
 // reference assigns to the half-complex slots (:100-107,124-131); the two 1/sqrt(n) scalings
 // per direction (:490,534,623,677) collapse into one factor 1/(nx*ny).
 #include "udc_internal.h"
+#include <atomic>
+#include <mutex>
 #include <cmath>
 #include <cstdlib>
 
@@ -700,7 +702,7 @@ static int launch_thomas(udc_handle *h, bool lds, long nmodes, int nz, double sc
   auto need = [&](int M, int KC) { return thomas_lds_bytes(nz, M, KC); };
 #define UDC_TL(M, KC, D, DB, PART)                                                                               \
   do {                                                                                                       \
-    static bool attr_done = false;                                                                           \
+    static std::atomic<bool> attr_done{false};                                                                       \
     if (!attr_done) {                                                                                        \
       if (hipFuncSetAttribute((const void *)thomas_lds_kernel<M, KC, D, DB, PART>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               (int)full) != hipSuccess) return 1;                                            \
@@ -720,7 +722,7 @@ static int launch_thomas(udc_handle *h, bool lds, long nmodes, int nz, double sc
     const char *wse = getenv("UDC_THOMAS_WS");
     const bool ws = wse ? atoi(wse) != 0 : need(8, 32) * 4 > full;
     if (ws) {
-      static bool ws_attr = false;
+      static std::atomic<bool> ws_attr{false};
       if (!ws_attr) {
         if (hipFuncSetAttribute((const void *)thomas_ws_kernel<8, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)full) != hipSuccess) return 1;
         ws_attr = true;
@@ -1023,6 +1025,16 @@ __global__ __launch_bounds__(256) void flowshift_kernel(Geo g, TileGrid tg, Flow
 }  // namespace
 
 // --------------------------------------------------------------------------------------
+// rocfft_setup exactly once per process, whichever handle (and host thread: the virtual ranks of the tests create theirs
+// concurrently) gets there first
+static int rocfft_setup_once() {
+  static std::once_flag once;
+  static rocfft_status st = rocfft_status_success;
+  std::call_once(once, [] { st = rocfft_setup(); });
+  if (st != rocfft_status_success) { udc_set_error("rocfft_setup failed: rocfft status %d", (int)st); return 1; }
+  return 0;
+}
+
 int pois_init(udc_handle *h) {
   const Geo &g = h->g;
   const int nx = g.nx, ny = g.ny, nz = g.nz;
@@ -1083,8 +1095,7 @@ int pois_init(udc_handle *h) {
   HIP_OK(hipGetLastError());
 
   // rocFFT: batched 2-D real <-> Hermitian-interleaved, reading/writing the padded p field
-  static bool setup_done = false;
-  if (!setup_done) { FFT_OK(rocfft_setup()); setup_done = true; }
+  if (rocfft_setup_once()) return 1;
   size_t lengths[2] = {(size_t)nx, (size_t)ny};
   size_t cstr[2] = {1, (size_t)nkxp};
   size_t off[1] = {0};
@@ -1203,8 +1214,7 @@ int pois_slab_init(udc_handle *h) {
                      (int)nmodes, nz, h->ev_slab, h->tri, btopD, h->ztab_slab, h->thomas_lds_slab ? 1 : 0);
   HIP_OK(hipGetLastError());
 
-  static bool setup_done = false;
-  if (!setup_done) { FFT_OK(rocfft_setup()); setup_done = true; }
+  if (rocfft_setup_once()) return 1;
   size_t off[1] = {0}, one[1] = {1};
   size_t lx[1] = {(size_t)nx}, ly[1] = {(size_t)ny};
   rocfft_plan_description d = nullptr;
