@@ -62,6 +62,7 @@ program ref_driver
                     nbndpts_u, nbndpts_v, nbndpts_w, nbndpts_c
   use readinput, only: read_sparse_ijk
 #endif
+  use modstatsdump, only: initstatsdump, statsdump  ! src/modstatsdump.f90: the sampling half, compiled from the reference (extract_statsdump.sh)
   use modstartup_rand, only: randomize_field        ! src/modstartup.f90:2367-2396, compiled from the reference (extract_startup.sh)
   implicit none
 
@@ -73,7 +74,7 @@ program ref_driver
 #ifdef UDC_DROPIN
   integer(c_long) :: nfused, nunfused
 #endif
-  logical :: need_thermo = .false.
+  logical :: need_thermo = .false., lstats = .false.
   integer :: isub, n, ierr, iu
   real :: t0, t1, chk_u2, chk_div
   real :: scal_a = 1.0, scal_b = 0.0     ! scalar init: sv = scal_b + scal_a*z/zsize
@@ -110,6 +111,8 @@ program ref_driver
   call ibm_setup
 #endif
   call createmasks
+  lstats = ltdump .or. lxytdump
+  if (lstats) call initstatsdump            ! src/program.f90:110 (here: its last two statements, the clocks)
   call cold_start
   call createscals                          ! src/modstartup.f90 (scalarsourcep / scalarsourcel files; no-op without sources)
   call boundary
@@ -132,6 +135,7 @@ program ref_driver
         call dump_state(tag4(isub))
       end if
     end do
+    if (lstats) call dump_stats
   case ('kernels')
     do isub = 1, nspin
       call one_substep
@@ -294,6 +298,10 @@ contains
     call poisson
     call tstep_integrate
     call halos
+    if (lstats) then                        ! src/program.f90:205
+      if (rk3step == 3) call host_refresh
+      call statsdump
+    end if
     call boundary
     if (need_thermo) call thermodynamics            ! src/program.f90:214
   end subroutine one_substep
@@ -383,6 +391,7 @@ contains
       BCtopq, BCbotq, wqtop, qt_top, wqsurf, z0h, wsvtopdum, ds, bctfxm, bctfxp, bctfym, bctfyp, bctfz, &
       bcqfxm, bcqfxp, bcqfym, bcqfyp, bcqfz
     namelist /SCALARS/ nsv, lscasrc, nscasrc, lscasrcl, nscasrcl
+    namelist /OUTPUT/ ltdump, lxytdump, tsample, tstatsdump, tstatstart
     namelist /WALLS/ nfcts, lbottom, iwallmom, iwalltemp, iwallmoist, nsolpts_u, nsolpts_v, nsolpts_w, nsolpts_c, &
       nbndpts_u, nbndpts_v, nbndpts_w, nbndpts_c
     open (ifnamopt, file=fname_options, status='old', iostat=ierr)
@@ -398,7 +407,8 @@ contains
     read (ifnamopt, SCALARS, iostat=ierr); call chk(ierr, 'SCALARS'); rewind (ifnamopt)
     read (ifnamopt, INLET, iostat=ierr); call chk(ierr, 'INLET'); rewind (ifnamopt)     ! (absent group: iostat < 0)
     read (ifnamopt, CHEMISTRY, iostat=ierr); call chk(ierr, 'CHEMISTRY'); rewind (ifnamopt)
-    read (ifnamopt, WALLS, iostat=ierr); call chk(ierr, 'WALLS')
+    read (ifnamopt, WALLS, iostat=ierr); call chk(ierr, 'WALLS'); rewind (ifnamopt)
+    read (ifnamopt, OUTPUT, iostat=ierr); call chk(ierr, 'OUTPUT')
     close (ifnamopt)
     nprocx = 1; nprocy = nprocs     ! y-slabs over however many ranks were launched (1 in the np1 build)
     if (libm .and. iwallmom /= 1) then
@@ -623,6 +633,76 @@ contains
       call put3(tag//'.svm_'//cn, svm(:, :, :, n), (/ib - ihc, jb - jhc, kb - khc/))
     end do
   end subroutine dump_state
+
+  !> the running averages statsdump keeps in modfields (src/modstatsdump.f90:1086-1213), and xytdump's table of slab
+  !! averages (:1404-1431, 1437-1460: local to statsdump there, so taken here with the reference's avexy_ibm from the same
+  !! accumulators and in the same expressions)
+  subroutine dump_stats
+    use modmpi, only: avexy_ibm
+    real :: prof(kb:ke + kh)
+    integer :: lb(3)
+    lb = (/ib, jb, kb/)
+    call put3('st.umt', umt, lb); call put3('st.vmt', vmt, lb); call put3('st.wmt', wmt, lb); call put3('st.pt', pt, lb)
+    call put3('st.utc', utc, lb); call put3('st.vtc', vtc, lb); call put3('st.wtc', wtc, lb)
+    call put3('st.uutc', uutc, lb); call put3('st.vvtc', vvtc, lb); call put3('st.wwtc', wwtc, lb)
+    call put3('st.uwtik', uwtik, lb); call put3('st.vwtjk', vwtjk, lb); call put3('st.uvtij', uvtij, lb)
+    call put3('st.utik', utik, lb); call put3('st.wtik', wtik, lb); call put3('st.vtjk', vtjk, lb)
+    call put3('st.wtjk', wtjk, lb); call put3('st.utij', utij, lb); call put3('st.vtij', vtij, lb)
+    if (ltempeq) then
+      call put3('st.thlt', thlt, lb); call put3('st.thltk', thltk, lb)
+      call put3('st.wthltk', wthltk, lb); call put3('st.thlthlt', thlthlt, lb)
+    end if
+    if (lmoist) then
+      call put3('st.qtt', qtt, lb); call put3('st.qttk', qttk, lb)
+      call put3('st.wqttk', wqttk, lb); call put3('st.qtqtt', qtqtt, lb)
+    end if
+    if (nsv > 0) then
+      call put3('st.sv1t', sv1t, lb); call put3('st.sv1tk', sv1tk, lb); call put3('st.wsv1tk', wsv1tk, lb)
+      call put3('st.sv1sv1t', sv1sv1t, lb); call put3('st.sv1sgst', sv1sgst, lb)
+    end if
+    if (nsv > 1) then
+      call put3('st.sv2t', sv2t, lb); call put3('st.sv2tk', sv2tk, lb); call put3('st.wsv2tk', wsv2tk, lb)
+      call put3('st.sv2sv2t', sv2sv2t, lb); call put3('st.sv2sgst', sv2sgst, lb)
+    end if
+    if (.not. lxytdump) return
+    call put1('xyt.uxyt', uxyt, kb); call put1('xyt.vxyt', vxyt, kb); call put1('xyt.wxyt', wxyt, kb)
+    call put1('xyt.pxyt', pxyt, kb); call put1('xyt.usgsxyt', usgsxyt, kb); call put1('xyt.vsgsxyt', vsgsxyt, kb)
+    if (ltempeq) then
+      call put1('xyt.thlxyt', thlxyt, kb); call put1('xyt.thlsgsxyt', thlsgsxyt, kb)
+    end if
+    if (lmoist) call put1('xyt.qtxyt', qtxyt, kb)
+    prof = 0.; call avexy_ibm(prof, utik*wtik, ib, ie, jb, je, kb, ke, kh, IIuw(ib:ie, jb:je, kb:ke + kh), IIuws(kb:ke + kh), .false.)
+    call put1('xyt.uwtxyik', prof, kb)
+    prof = 0.; call avexy_ibm(prof, vtjk*wtjk, ib, ie, jb, je, kb, ke, kh, IIvw(ib:ie, jb:je, kb:ke + kh), IIvws(kb:ke + kh), .false.)
+    call put1('xyt.vwtxyjk', prof, kb)
+    prof = 0.; call avexy_ibm(prof, wmt*wmt, ib, ie, jb, je, kb, ke, kh, IIw(ib:ie, jb:je, kb:ke + kh), IIws(kb:ke + kh), .false.)
+    call put1('xyt.wwtxyk', prof, kb)
+    prof = 0.; call avexy_ibm(prof, utij*vtij, ib, ie, jb, je, kb, ke, kh, IIuv(ib:ie, jb:je, kb:ke + kh), IIuvs(kb:ke + kh), .false.)
+    call put1('xyt.uvtxyij', prof, kb)
+    prof = 0.; call avexy_ibm(prof, uwtik - utik*wtik, ib, ie, jb, je, kb, ke, kh, IIuw(ib:ie, jb:je, kb:ke + kh), IIuws(kb:ke + kh), .false.)
+    call put1('xyt.upwptxyik', prof, kb)
+    prof = 0.; call avexy_ibm(prof, vwtjk - vtjk*wtjk, ib, ie, jb, je, kb, ke, kh, IIvw(ib:ie, jb:je, kb:ke + kh), IIvws(kb:ke + kh), .false.)
+    call put1('xyt.vpwptxyjk', prof, kb)
+    prof = 0.; call avexy_ibm(prof, uvtij - utij*vtij, ib, ie, jb, je, kb, ke, kh, IIuv(ib:ie, jb:je, kb:ke + kh), IIuvs(kb:ke + kh), .false.)
+    call put1('xyt.upvptxyij', prof, kb)
+    prof = 0.; call avexy_ibm(prof, uutc - utc*utc, ib, ie, jb, je, kb, ke, kh, IIc(ib:ie, jb:je, kb:ke + kh), IIcs(kb:ke + kh), .false.)
+    call put1('xyt.upuptxyc', prof, kb)
+    prof = 0.; call avexy_ibm(prof, vvtc - vtc*vtc, ib, ie, jb, je, kb, ke, kh, IIc(ib:ie, jb:je, kb:ke + kh), IIcs(kb:ke + kh), .false.)
+    call put1('xyt.vpvptxyc', prof, kb)
+    prof = 0.; call avexy_ibm(prof, wwtc - wtc*wtc, ib, ie, jb, je, kb, ke, kh, IIc(ib:ie, jb:je, kb:ke + kh), IIcs(kb:ke + kh), .false.)
+    call put1('xyt.wpwptxyc', prof, kb)
+    prof = 0.; call avexy_ibm(prof, 0.5*((wwtc - wtc*wtc) + (vvtc - vtc*vtc) + (uutc - utc*utc)), ib, ie, jb, je, kb, ke, kh, &
+                              IIc(ib:ie, jb:je, kb:ke + kh), IIcs(kb:ke + kh), .false.)
+    call put1('xyt.tketxyc', prof, kb)
+    if (ltempeq) then
+      prof = 0.; call avexy_ibm(prof, wmt*thltk, ib, ie, jb, je, kb, ke, kh, IIw(ib:ie, jb:je, kb:ke + kh), IIws(kb:ke + kh), .false.)
+      call put1('xyt.wthltxyk', prof, kb)
+      prof = 0.; call avexy_ibm(prof, wthltk - wmt*thltk, ib, ie, jb, je, kb, ke, kh, IIw(ib:ie, jb:je, kb:ke + kh), IIws(kb:ke + kh), .false.)
+      call put1('xyt.wpthlptxyk', prof, kb)
+      prof = 0.; call avexy_ibm(prof, thlthlt - thlt*thlt, ib, ie, jb, je, kb, ke, kh, IIc(ib:ie, jb:je, kb:ke + kh), IIcs(kb:ke + kh), .false.)
+      call put1('xyt.thlpthlptxy', prof, kb)
+    end if
+  end subroutine dump_stats
 
   subroutine dump_tend(tag)
     character(*), intent(in) :: tag

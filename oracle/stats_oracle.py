@@ -1,9 +1,13 @@
-"""TEST INFRASTRUCTURE -- numpy restatement of the tdump statistics of the reference, NOT the product.
+"""TEST INFRASTRUCTURE -- numpy restatement of the tdump / xytdump statistics of the reference, NOT the product.
 
-PARITY UNPINNED: src/modstatsdump.f90 cannot be compiled here (it writes NetCDF and its arithmetic is interleaved with
-those calls), and the reference holds no golden vectors for it, so this restatement is checked only against the lines it
-follows and against properties (tests/test_gpu_stats.py).  Lines followed: sampling :812-832, :858-927; running
-averages :1137-1213; output variables :1557-1645.
+Pinned on the reference's own compiled lines: the sampling half of statsdump (src/modstatsdump.f90:514-1235) and xytdump's
+final slab averages (:1404-1431) are assembled from the reference file at build time (oracle/extract_statsdump.sh; the
+NetCDF output half cannot be compiled here) and run inside oracle/_ref/udales_ref; the running averages they leave in
+modfields are the `st.*` / `xyt.*` records of the fixtures run_stats_16x8x12s and run_stats_ibm_16x12x10, which
+tests/test_oracle_vs_reference.py::test_statistics_match_reference holds this restatement against.  Lines followed:
+sampling :812-857 (interpolations, SGS fluxes), :858-927 (scalars); slab averages :1037-1056 with avexy_ibm
+(src/modmpi.f90:623-664) over createmasks' masks (src/modibm.f90:2141-2190); running averages :1086-1101, :1137-1213;
+output variables :1404-1460 (xytdump), :1557-1645 (tdump).
 
 Arrays are m-arrays [nz+2, ny+2, nx+2] (index == the reference's i, j, k with ghosts) for velocities / pres0 / ekh / thl /
 qt, c-arrays [nz+4, ny+4, nx+4] for the passive scalars.  Results are [nz+1, ny, nx]: levels kb..ke+kh, interior i, j.
@@ -19,10 +23,62 @@ def _m(a, di=0, dj=0, dk=0, nzp=None):
     return a[ks][:, 1 + dj:1 + dj + ny, 1 + di:1 + di + nx]
 
 
+MASKS = ("u", "v", "w", "c", "uw", "vw", "uv")
+
+
+def createmasks(nx, ny, nz, lists=None, wrapx=False, wrapy=False):
+    """IIu, IIv, IIw, IIc, IIuw, IIvw, IIuv on levels kb..ke+kh [nz+1, ny, nx] and their level counts II*s
+    (src/modibm.f90:2120-2206).  `lists`: {grid: (solid[n,3], ...)} global 1-based i, j, k, or None without libm.
+    Ghost cells of the point masks are fluid unless the direction wraps (a direction the reference run splits over ranks)."""
+    one = np.ones((nz + 1, ny, nx), dtype=np.int64)
+    if lists is None:
+        return {m: one.copy() for m in MASKS}, {m: np.full(nz + 1, nx * ny, dtype=np.int64) for m in MASKS}
+    pt = {}
+    for q in "uvwc":
+        a = np.ones((nz + 2, ny + 2, nx + 2), dtype=np.int64)          # index == i, j, k of the reference (ghost ring 0 / n+1)
+        if q in lists:
+            for i, j, k in lists[q][0]:
+                a[k, j, i] = 0
+        if wrapx:
+            a[:, :, 0], a[:, :, -1] = a[:, :, -2], a[:, :, 1]
+        if wrapy:
+            a[:, 0], a[:, -1] = a[:, -2], a[:, 1]
+        pt[q] = a
+    pt["w"][1] = 0                                                      # IIw(:, :, kb) = 0
+    I = lambda a, di=0, dj=0, dk=0: a[1 + dk:nz + 2 + dk, 1 + dj:ny + 1 + dj, 1 + di:nx + 1 + di]     # noqa: E731
+    II = {q: I(pt[q]).copy() for q in "uvwc"}
+    II["uv"], II["uw"], II["vw"] = one.copy(), one.copy(), one.copy()
+    II["uv"][:nz] = (I(pt["u"]) * I(pt["u"], dj=-1) * I(pt["v"]) * I(pt["v"], di=-1))[:nz]
+    II["uw"][1:nz] = (I(pt["u"]) * I(pt["u"], dk=-1) * I(pt["w"]) * I(pt["w"], di=-1))[1:nz]
+    II["vw"][1:nz] = (I(pt["v"]) * I(pt["v"], dk=-1) * I(pt["w"]) * I(pt["w"], dj=-1))[1:nz]
+    II["uw"][0] = 0
+    II["vw"][0] = 0
+    return II, {m: II[m].sum(axis=(1, 2)) for m in MASKS}
+
+
+def avexy_ibm(var, II, IIs, lnan=False):
+    """src/modmpi.f90:623-664: masked slab average; a level without fluid points gives -999, except the first one when
+    lnan is false, which takes the unmasked sum over the count of the last level."""
+    s = (var * II).sum(axis=(1, 2))
+    cnt = IIs.copy()
+    if not lnan and cnt[0] == 0:
+        s[0] = var[0].sum()
+        cnt[0] = cnt[-2]                                                # IId(kb) = IId(ke)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.where(cnt == 0, -999., s / np.where(cnt == 0, 1, cnt))
+
+
 class TDumpOracle:
-    def __init__(self, g, nsv=0, ltempeq=False, lmoist=False):
+    def __init__(self, g, nsv=0, ltempeq=False, lmoist=False, lists=None, wrapx=False, wrapy=False):
         self.g, self.nsv, self.ltempeq, self.lmoist = g, nsv, ltempeq, lmoist
         self.acc = {}
+        self.II, self.IIs = createmasks(g.nx, g.ny, g.nz, lists, wrapx, wrapy)
+        self.prof = {}
+
+    def _updp(self, name, var, mask, ts, T):
+        xy = avexy_ibm(var, self.II[mask], self.IIs[mask])
+        old = self.prof.get(name, np.zeros_like(xy))
+        self.prof[name] = (old * (T - ts) + xy * ts) * (1. / T)
 
     def _upd(self, name, sample, ts, T):
         old = self.acc.get(name, np.zeros_like(sample))
@@ -55,6 +111,23 @@ class TDumpOracle:
             self._upd(name, s, ts, T)
         ekh = st["ekh"]
         dzh2i = (1. / dzh[k] ** 2)[:, None, None]
+        # SGS momentum fluxes at the uw / vw edges (:834-846) and the slab averages of xytdump (:1041-1054, 1088-1099)
+        if "ekm" in st:
+            ekm, dyi, dzhiq = st["ekm"], 1. / g.dy, 0.25 * dzhi
+            emom = (dzf_km * (_m(ekm) * dx + _m(ekm, di=-1) * dx) + dzf_k * (_m(ekm, dk=-1) * dx + _m(ekm, di=-1, dk=-1) * dx)) * dxi * dzhiq
+            usgs = emom * ((u - _m(um, dk=-1)) * dzhi + (w - _m(wm, di=-1)) * dxi)
+            emom = (dzf_km * (_m(ekm) + _m(ekm, dj=-1)) + dzf_k * (_m(ekm, dk=-1) + _m(ekm, dj=-1, dk=-1))) * dzhiq
+            vsgs = emom * ((v - _m(vm, dk=-1)) * dzhi + (w - _m(wm, dj=-1)) * dyi)
+            self._updp("uxyt", u, "u", ts, T); self._updp("vxyt", v, "v", ts, T); self._updp("wxyt", w, "w", ts, T)
+            self._updp("pxyt", _m(st["pres0"]), "c", ts, T)
+            self._updp("usgsxyt", usgs, "uw", ts, T); self._updp("vsgsxyt", vsgs, "vw", ts, T)
+            if self.ltempeq:
+                th, thm = _m(st["thlm"]), _m(st["thlm"], dk=-1)
+                thlsgs = 0.5 * (dzf_km * _m(ekh) + dzf_k * _m(ekh, dk=-1)) * (th - thm) * dzh2i
+                thlsgs[-1] = 0.                              # ke+kh: never set in the reference
+                self._updp("thlxyt", th, "c", ts, T); self._updp("thlsgsxyt", thlsgs, "w", ts, T)
+            if self.lmoist:
+                self._updp("qtxyt", _m(st["qtm"]), "c", ts, T)
 
         def scalar(tag, a, with_sgs):
             p0, pm = _m(a), _m(a, dk=-1)
@@ -93,4 +166,21 @@ class TDumpOracle:
             o[f"wpsca{n}pt"] = a[f"wsv{n}tk"] - a["wmt"] * a[f"sv{n}tk"]
             o[f"sca{n}psca{n}pt"] = a[f"sv{n}sv{n}t"] - a[f"sv{n}t"] * a[f"sv{n}t"]
             o[f"sv{n}sgs"] = a[f"sv{n}sgst"]
+        return {k: v[:-1] for k, v in o.items()}
+
+    def xyt(self):
+        """xytdump's table (:1404-1460) on levels kb..ke."""
+        a, p = self.acc, self.prof
+        av = lambda v, m: avexy_ibm(v, self.II[m], self.IIs[m])      # noqa: E731
+        up2, vp2, wp2 = a["uutc"] - a["utc"] * a["utc"], a["vvtc"] - a["vtc"] * a["vtc"], a["wwtc"] - a["wtc"] * a["wtc"]
+        o = {"uxyt": p["uxyt"], "vxyt": p["vxyt"], "wxyt": p["wxyt"], "pxyt": p["pxyt"], "usgsxyt": p["usgsxyt"], "vsgsxyt": p["vsgsxyt"],
+             "uwtxyik": av(a["utik"] * a["wtik"], "uw"), "vwtxyjk": av(a["vtjk"] * a["wtjk"], "vw"), "wwtxyk": av(a["wmt"] * a["wmt"], "w"),
+             "uvtxyij": av(a["utij"] * a["vtij"], "uv"), "upwptxyik": av(a["uwtik"] - a["utik"] * a["wtik"], "uw"),
+             "vpwptxyjk": av(a["vwtjk"] - a["vtjk"] * a["wtjk"], "vw"), "upvptxyij": av(a["uvtij"] - a["utij"] * a["vtij"], "uv"),
+             "upuptxyc": av(up2, "c"), "vpvptxyc": av(vp2, "c"), "wpwptxyc": av(wp2, "c"), "tketxyc": av(0.5 * (wp2 + vp2 + up2), "c")}
+        if self.ltempeq:
+            o.update({"thlxyt": p["thlxyt"], "thlsgsxyt": p["thlsgsxyt"], "wthltxyk": av(a["wmt"] * a["thltk"], "w"),
+                      "wpthlptxyk": av(a["wthltk"] - a["wmt"] * a["thltk"], "w"), "thlpthlptxy": av(a["thlthlt"] - a["thlt"] * a["thlt"], "c")})
+        if self.lmoist:
+            o["qtxyt"] = p["qtxyt"]
         return {k: v[:-1] for k, v in o.items()}

@@ -25,7 +25,8 @@ RUN_CASES = {"run_16x16x8": 21, "run_smag_scalar_16x8x12s": 22, "run_floor_scala
              "run_volflow_uv_16x16x8": 24, "run_thl_16x8x12s": 25, "run_qt_16x8x12s": 33, "run_moist_16x8x12s": 36, "run_uno_16x8x12s": 38, "run_src_16x8x12s": 40, "run_thlk_16x8x12s": 42, "run_moistnr_16x8x12s": 45, "run_svflux_16x8x12s": 48, "run_chem_16x8x12s": 51,
              "run_buoy_16x8x12s": 26,
              "run_profforc_16x16x8": 27, "run_vreman_buoycorr_16x8x12s": 53, "run_ibm_16x12x10": 55, "run_ibm_volflow_16x12x10": 56, "run_ibm_edge_16x12x10": 57,
-             "run_ibm_thl_16x12x10": 59, "run_ibm_thlcons_16x12x10": 60, "run_ibm_qt_16x12x10": 61}
+             "run_ibm_thl_16x12x10": 59, "run_ibm_thlcons_16x12x10": 60, "run_ibm_qt_16x12x10": 61,
+             "run_stats_16x8x12s": 62, "run_stats_ibm_16x12x10": 63}
 
 
 def load_fixture(name):

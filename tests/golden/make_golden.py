@@ -30,7 +30,7 @@ REF = os.path.join(ROOT, "oracle", "_ref", "udales_ref")
 
 def deck(iexpnr, nx, ny, nz, dx=0.5, dy=0.5, dtmax=0.25, sgs="vreman", nsv=0, bctopm=1,
          oracle="", lles=True, randu=0.01, floor=False, z0=0.05, physics="", bc="", bcbotm=3, scalars="", dynamics="", inlet="", ladaptive=False, chemistry="",
-         ibm=None):
+         ibm=None, output=""):
     sub = {"oneeqn": "loneeqn = .true.\nlvreman = .false.\nlsmagorinsky = .false.",
            "vreman": "lvreman = .true.\nlsmagorinsky = .false.",
            "vreman_bc": "lvreman = .true.\nlsmagorinsky = .false.\nlbuoycorr = .true.",
@@ -72,7 +72,7 @@ nsv = {nsv}{(chr(10) + scalars) if scalars else ''}
 /
 &NAMSUBGRID
 {sub}
-/{(chr(10) + '&INLET' + chr(10) + inlet + chr(10) + '/') if inlet else ''}{(chr(10) + '&CHEMISTRY' + chr(10) + chemistry + chr(10) + '/') if chemistry else ''}
+/{(chr(10) + '&OUTPUT' + chr(10) + output + chr(10) + '/') if output else ''}{(chr(10) + '&INLET' + chr(10) + inlet + chr(10) + '/') if inlet else ''}{(chr(10) + '&CHEMISTRY' + chr(10) + chemistry + chr(10) + '/') if chemistry else ''}
 &ORACLE
 {oracle}
 /
@@ -409,6 +409,23 @@ CASES.update({
                                                         bc=_IBM_THL_BC + "\nqts = 0.008\nBCtopq = 1\nwqtop = 0.\nBCbotq = 1\nwqsurf = 2.e-5",
                                                         oracle="nsub = 9\ndump_at = 3, 9"), 1.04),
 })
+# statistics (src/modstatsdump.f90 statsdump, its sampling half compiled from the reference: oracle/extract_statsdump.sh):
+# the running time averages of tdump / xytdump after 8 steps.  First deck: a sample every second step, a dump (clock
+# restart) after the sixth; second deck: obstacles (masked slab averages, -999 on levels without fluid), buoyancy, a sample
+# every step (tsample <= dt, :802-803)
+IBM_BLOCKS["run_stats_ibm_16x12x10"] = IBM_BLOCKS["run_ibm_16x12x10"]
+CASES.update({
+    "run_stats_16x8x12s": ("run", 62, 16, 8, 12,
+                           dict(sgs="smag", nsv=2, floor=True, randu=0.05, physics="ltempeq = .true.\nlbuoyancy = .false.",
+                                bc="BCtopT = 2\nthl_top = 290.5\nBCbotT = 1\nwtsurf = 0.02",
+                                output="ltdump = .true.\nlxytdump = .true.\ntsample = 0.5\ntstatsdump = 1.5",
+                                oracle="nsub = 24\ndump_at = 24"), 1.06),
+    "run_stats_ibm_16x12x10": ("run", 63, 16, 12, 10,
+                               dict(sgs="vreman", nsv=1, floor=True, randu=0.05, ibm=IBM_BLOCKS["run_ibm_16x12x10"],
+                                    physics="ltempeq = .true.\nlbuoyancy = .true.", bc=_IBM_THL_BC,
+                                    output="ltdump = .true.\nlxytdump = .true.\ntsample = 0.1\ntstatsdump = 1000.",
+                                    oracle="nsub = 15\ndump_at = 15"), 1.04),
+})
 LSF_ONLY = ("k_lsf_12x8x24", "k_lsfq_12x8x20", "k_fix1_12x8x6")
 THL_CASES = {"k_tke_moist_12x8x8": dict(dthl=0.25, qt=0.0118, dqt=-8e-5, tke=0.06),
              "run_moistnr_16x8x12s": dict(dthl=0.25, qt=0.0119, dqt=-6e-5),
@@ -425,6 +442,7 @@ THL_CASES = {"k_tke_moist_12x8x8": dict(dthl=0.25, qt=0.0118, dqt=-8e-5, tke=0.0
              "k_buoy_12x8x6": dict(dthl=0.3), "run_buoy_16x8x12s": dict(dthl=0.2),
              "k_ibm_thl_16x12x10": dict(dthl=0.3), "run_ibm_thl_16x12x10": dict(dthl=0.25), "run_ibm_thlcons_16x12x10": dict(dthl=0.25),
              "run_ibm_qt_16x12x10": dict(dthl=0.25, qt=0.007, dqt=-2e-4),
+             "run_stats_16x8x12s": dict(dthl=0.25), "run_stats_ibm_16x12x10": dict(dthl=0.25),
              "k_vreman_buoycorr_12x8x10": dict(dthl=0.004), "run_vreman_buoycorr_16x8x12s": dict(dthl=0.004)}
 
 
@@ -500,7 +518,7 @@ def main():
         else:
             keep = {k: v for k, v in d.items()
                     if k.count(".") == 0 or k.split(".")[1] in ("u0", "v0", "w0", "pres0", "um", "thl0", "thlm", "e120", "e12m", "qt0", "qtm", "dpdxl", "time")
-                    or (k.startswith("s000.") and not k.startswith("s000.ek")) or ".sv0" in k}
+                    or (k.startswith("s000.") and not k.startswith("s000.ek")) or ".sv0" in k or k.startswith(("st.", "xyt."))}
             # (s000.ekm/ekh are dumped before the first closure call: uninitialised memory, not data)
         tmpf = os.path.join(HERE, name + ".bin")
         write_dump(tmpf, keep)
