@@ -306,9 +306,29 @@ enum {
   UDC_ST_SV_STRIDE = 5,
   UDC_ST_MAX = UDC_ST_SV + 4 * UDC_ST_SV_STRIDE
 };
-int udc_stats_enable(udc_handle *h, int on);
+int udc_stats_enable(udc_handle *h, int on);      /* 0 off; 1 the 3-D accumulators; 3 also xytdump's running profiles */
 int udc_stats_sample(udc_handle *h, double tsamplep, double tstatsdumpp);
 int udc_stats_get(udc_handle *h, int id, double *host, const int lb[3], const int ub[3]);
+
+/* xytdump (src/modstatsdump.f90:1037-1056 slab averages of a sample, :1086-1101 their running time averages, :1404-1460
+ * the table written every tstatsdump): x-, y- and time-averaged profiles on levels kb..ke.  The slab averages are
+ * avexy_ibm's (src/modmpi.f90:623-664, lnan = .false.): over the fluid points of createmasks' masks (src/modibm.f90:2141-2190)
+ * IIu, IIv, IIw, IIc, IIuw, IIvw, IIuv.  udc_stats_set_masks hands those over as one byte per cell of this rank's slab
+ * [ktot][jmax][itot] (bit 0 IIu ... bit 6 IIuv in that order; NULL = no obstacles) and the global fluid counts per level
+ * [7][ktot]; the caller applies avexy_ibm's rule for a first level without fluid points (all bits of that level set, count
+ * of level ke) before the call (udcore/stats.py: xyt_masks).  udc_stats_sample then also updates the nine running profiles;
+ * udc_stats_xyt forms the remaining slab averages from the 3-D accumulators and returns the table [UDC_XYT_N][ktot], rows in
+ * the order of the reference's output variables (-999 on levels without fluid points). */
+enum {
+  UDC_XYT_U = 0, UDC_XYT_V, UDC_XYT_W, UDC_XYT_THL, UDC_XYT_QT, UDC_XYT_P,          /* uxyt vxyt wxyt thlxyt qtxyt pxyt      */
+  UDC_XYT_UPWP, UDC_XYT_WPTHLP, UDC_XYT_VPWP, UDC_XYT_UPVP,                         /* upwpxyt wpthlpxyt vpwpxyt upvpxyt     */
+  UDC_XYT_UW, UDC_XYT_WTHL, UDC_XYT_UV, UDC_XYT_VW, UDC_XYT_WW,                     /* uwxyt wthlxyt uvxyt vwxyt wwxyt       */
+  UDC_XYT_USGS, UDC_XYT_THLSGS, UDC_XYT_VSGS,                                       /* usgsxyt thlsgsxyt vsgsxyt             */
+  UDC_XYT_THLPTHLP, UDC_XYT_UPUP, UDC_XYT_VPVP, UDC_XYT_WPWP, UDC_XYT_TKE,          /* thlpthlpt upuptxyc vpvptxyc wpwptxyc tketxyc */
+  UDC_XYT_N
+};
+int udc_stats_set_masks(udc_handle *h, const unsigned char *bits, const int *counts);
+int udc_stats_xyt(udc_handle *h, double *table);
 
 /* divergence of u0 as modchecksim's chkdiv (src/modchecksim.f90:161-203): max |div|, sum div */
 int udc_divergence(udc_handle *h, double *divmax, double *divtot);

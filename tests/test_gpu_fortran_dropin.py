@@ -48,6 +48,17 @@ def test_fortran_driver_with_dropin_modules(name, iexp, residency, tmp_path):
         sc = 1.0 if key.endswith("thl0") else None          # O(1) K variations on a 288 K mean
         assert relerr(nocorner(a), nocorner(b), sc) <= 1e-9, key
         checked += 1
+    # decks with statistics: the reference's own statsdump (its sampling half, oracle/extract_statsdump.sh) runs untouched on
+    # the host arrays the drop-in modules keep / refresh -- its running averages against those of the all-reference run
+    nz = int(fix["meta"].data[2])
+    u2 = np.abs(fix["st.uutc"].data).max() if "st.uutc" in fix else 0.
+    for key, ref in fix.items():
+        if not key.startswith(("st.", "xyt.")):
+            continue
+        a, b = got[key].data[:nz], ref.data[:nz]
+        sc = max(np.abs(b).max(), 1e-3 * u2, 1e-6 * np.abs(fix["st.thlthlt"].data).max() if "thlp" in key else 0.)
+        assert np.abs(a - b).max() <= 2e-9 * sc, key
+        checked += 1
     assert checked >= 8
 
 

@@ -152,9 +152,19 @@ def run_virtual(P, g, deck_like, st_global, nsub, dt, sgs, nsv=0, extras=False):
             core.load_state(local)
             core.halos()
             core.boundary()
+            td = None
+            if extras == 3:      # xytdump over the slabs: per-slab mask bits, level sums all-reduced, one sample per step
+                from udcore.stats import TDump
+                core.ltempeq = True
+                td = TDump(core, tsample=dt, tstatsdump=1e9, xyt=True, ibm_lists=dict(zip("uvwc", ibm_block_lists(g.nx, g.ny, g.nz))),
+                           jtot=g.ny, j0=r * nyl, nyl=nyl)
             for isub in range(nsub):
                 core.substep(isub % 3 + 1, dt, bool(extras))
-            out[r] = {k: core.download(k) for k in ("u0", "v0", "w0", "pres0") + (("thl0",) if extras else ()) + (("qt0",) if extras == 2 else ())}
+                if td is not None:
+                    td.step(isub % 3 + 1, dt, dt * (isub // 3 + 1))
+            if td is not None:
+                out.setdefault(r, {})["xyt"] = td.xyt()
+            out.setdefault(r, {}).update({k: core.download(k) for k in ("u0", "v0", "w0", "pres0") + (("thl0",) if extras else ()) + (("qt0",) if extras == 2 else ())})
             out[r]["div"] = core.divergence()
         except Exception as e:   # noqa: BLE001
             errs.append((r, repr(e)))
@@ -169,6 +179,11 @@ def run_virtual(P, g, deck_like, st_global, nsub, dt, sgs, nsv=0, extras=False):
     for k in ("u0", "v0", "w0", "pres0") + (("thl0",) if extras else ()) + (("qt0",) if extras == 2 else ()):
         res[k] = np.concatenate([out[r][k][:, 1:-1, :] for r in range(P)], axis=1)
     res["div"] = out[0]["div"]
+    if "xyt" in out[0]:
+        for r in range(1, P):      # the table is the same on every rank
+            for k, v in out[0]["xyt"].items():
+                assert np.array_equal(v, out[r]["xyt"][k]), (r, k)
+        res["xyt"] = out[0]["xyt"]
     for c in cores:
         c.close()
     return res
@@ -216,3 +231,8 @@ def test_decomposition_invariance(shape, sgs, chunks, extras, monkeypatch):
             e = relerr(got[k][1:-1], ref[k][1:-1], 1.0 if k == "thl0" else None)
             assert e <= 1e-10, (P, k, e)
         assert abs(got["div"][0] - ref["div"][0]) < 1e-12      # all-reduced max agrees on every rank
+        if "xyt" in ref:
+            for k, v in ref["xyt"].items():
+                sc = max(np.abs(v).max(), 1e-3 if k != "thlpthlptxy" else 1e-1)
+                assert np.abs(got["xyt"][k] - v).max() <= 1e-10 * sc, (P, k)
+            assert np.abs(ref["xyt"]["uxyt"]).max() > 0.1 and ref["xyt"]["tketxyc"].min() > 0.

@@ -1,16 +1,17 @@
-"""Statistics accumulation on the device (udc_stats.hip, udcore/stats.py: the time-averaged 3-D set of tdump,
-src/modstatsdump.f90) against the numpy restatement oracle/stats_oracle.py on the states the device itself produced, plus
-properties that hold whatever the restatement says: with one sample the mean is the sample; the running average of N
-equally weighted samples is their arithmetic mean; variances are non-negative up to round-off; the clocks sample every
-tsample and dump every tstatsdump seconds.  (The reference's modstatsdump needs NetCDF and cannot be compiled here:
-parity for this routine is unpinned, see the oracle's header.)"""
+"""Statistics accumulation on the device (udc_stats.hip, udcore/stats.py: the time-averaged 3-D set of tdump and the
+x-, y- and time-averaged profiles of xytdump, src/modstatsdump.f90) against the running averages the reference's own
+statsdump lines leave behind (fixtures run_stats_*: oracle/extract_statsdump.sh compiles the sampling half of the
+reference routine where it lies), against the numpy restatement oracle/stats_oracle.py on the states the device itself
+produced, plus properties that hold whatever the restatement says: with one sample the mean is the sample; the running
+average of N equally weighted samples is their arithmetic mean; variances are non-negative up to round-off; the clocks
+sample every tsample and dump every tstatsdump seconds."""
 import os
 import sys
 
 import numpy as np
 import pytest
 
-from common import deck_path, interior
+from common import deck_path, interior, load_fixture
 from udcore import cold_start, read_deck
 from udcore import lib as L
 
@@ -67,6 +68,62 @@ def test_tdump_accumulation_matches_restatement(name, iexp):
                 assert got[k].min() >= -1e-12
     # clocks: tsample = 2 dt -> a sample every second step; tstatsdump = 6 dt -> dumps at steps 6 (and the clock restarts)
     assert events.count("dump") >= 1 and td.nsamples >= 3
+    core.close()
+
+
+XYT_FIX = {"uwtxyik": "uwxyt", "vwtxyjk": "vwxyt", "wwtxyk": "wwxyt", "uvtxyij": "uvxyt", "upwptxyik": "upwpxyt", "vpwptxyjk": "vpwpxyt",
+           "upvptxyij": "upvpxyt", "wthltxyk": "wthlxyt", "wpthlptxyk": "wpthlpxyt"}
+
+
+@pytest.mark.parametrize("slabs", [1, 2])
+@pytest.mark.parametrize("name,iexp", [("run_stats_16x8x12s", 62), ("run_stats_ibm_16x12x10", 63)])
+def test_statistics_match_reference(name, iexp, slabs):
+    """tdump's 3-D running averages and xytdump's table after the deck's run, against what the reference's own statsdump
+    (its sampling half, compiled from src/modstatsdump.f90) left in modfields: with and without obstacles (masked slab
+    averages, the floor level of the w-point masks without fluid points), one sample per step and one every second step
+    with a dump in between; on one slab and through the forced-slab (multi-rank) path."""
+    import udcore
+    from udcore.ibm import read_ibm
+    from udcore.stats import TDump
+    fix = load_fixture(name)
+    d = read_deck(deck_path(name, iexp))
+    os.environ["UDC_FORCE_SLAB"] = "1" if slabs == 2 else "0"
+    try:
+        core = udcore.from_deck(d)
+    finally:
+        os.environ.pop("UDC_FORCE_SLAB")
+    core.load_state(cold_start(core.g, d, nsv=core.nsv))
+    dt = float(d.get("RUN", "dtmax"))
+    lists = read_ibm(d) if d.get("RUN", "libm") else None
+    td = TDump(core, float(d.get("OUTPUT", "tsample")), float(d.get("OUTPUT", "tstatsdump")), xyt=True, ibm_lists=lists)
+    nsub = max(int(k[1:4]) for k in fix if k.endswith(".u0"))
+    timee = 0.
+    for isub in range(1, nsub + 1):
+        rk = (isub - 1) % 3 + 1
+        core.substep(rk, dt, True)
+        if rk == 3:
+            timee += dt
+        td.step(rk, dt, timee)
+    assert td.nsamples >= 3
+    nz = core.g.nz
+    acc, xyt = td.accumulators(), td.xyt()
+    u2 = np.abs(fix["st.uutc"].data).max()
+    checked = 0
+    for k, rec in fix.items():
+        if k.startswith("st."):
+            got, ref = acc[k[3:]][:nz], rec.data[:nz]
+        elif k.startswith("xyt."):
+            got, ref = xyt[XYT_FIX.get(k[4:], k[4:])], rec.data[:nz]
+        else:
+            continue
+        scale = max(np.abs(ref).max(), 1e-30)
+        if k.startswith("xyt.") or k[3:] in ("uwtik", "vwtjk", "uvtij", "wtik", "wtjk", "wmt", "wtc", "wwtc", "vvtc"):
+            scale = max(scale, 1e-3 * u2)
+        if "thlp" in k:
+            scale = max(scale, 1e-6 * np.abs(fix["st.thlthlt"].data).max())
+        assert np.abs(got - ref).max() <= 2e-9 * scale, (k, np.abs(got - ref).max(), scale)      # RUN_TOL of the state parity tests
+        checked += 1
+    assert checked >= 50
     core.close()
 
 

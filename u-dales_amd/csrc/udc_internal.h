@@ -195,6 +195,12 @@ struct udc_handle {
   // statistics accumulators (udc_stats.hip), UDC_ST_* ids
   std::vector<double *> stats;
   bool stats_on = false;
+  // xytdump (udc_stats.hip): fluid masks of createmasks as bits per cell [nz][ny][nx] (nullptr = no obstacles), the
+  // counts avexy_ibm divides by [7][nz], the nine running slab-average profiles [9][nz], scratch for the level sums
+  bool xyt_on = false;
+  unsigned char *st_mask = nullptr;
+  double *st_cnt = nullptr, *st_prof = nullptr, *st_part = nullptr, *st_sum = nullptr, *st_table = nullptr;
+  size_t st_part_cap = 0;
   // deferred execution (udc_set_deferred): the tendency routines of one RK3 substep are recorded instead of launched;
   // udc_tstep_integrate then runs the recorded sequence -- as the fused substep when it is the reference's own
   // (src/program.f90:142-197), routine by routine otherwise.  pend holds OP_* bits in call order.

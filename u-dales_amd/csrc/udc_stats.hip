@@ -89,7 +89,158 @@ __global__ __launch_bounds__(256) void stats_scalar_kernel(Geo g, TileGrid tg, M
   }
 }
 
+// ---- xytdump: slab averages over the fluid points (avexy_ibm, src/modmpi.f90:623-664, lnan = .false.)
+//
+// Mask bits per cell (udc_stats_set_masks): 0 IIu, 1 IIv, 2 IIw, 3 IIc, 4 IIuw, 5 IIvw, 6 IIuv, levels kb..ke.  The host
+// has already applied avexy_ibm's rule for a first level without fluid points (unmasked sum over the count of level ke) to
+// the bits and counts it hands over, so the device only forms sum(var * bit) / count, or -999 where the count is zero.
+enum { MB_U = 0, MB_V, MB_W, MB_C, MB_UW, MB_VW, MB_UV };
+enum { XS_U = 0, XS_V, XS_W, XS_THL, XS_QT, XS_P, XS_USGS, XS_VSGS, XS_THLSGS, XS_N };      // the running profiles
+enum { XF_UPWP = 0, XF_WPTHLP, XF_VPWP, XF_UPVP, XF_UW, XF_WTHL, XF_UV, XF_VW, XF_WW, XF_THLPTHLP, XF_UPUP, XF_VPVP, XF_WPWP, XF_TKE, XF_N };
+__constant__ int xs_mask[XS_N] = {MB_U, MB_V, MB_W, MB_C, MB_C, MB_C, MB_UW, MB_VW, MB_W};
+__constant__ int xf_mask[XF_N] = {MB_UW, MB_W, MB_VW, MB_UV, MB_UW, MB_W, MB_UV, MB_VW, MB_W, MB_C, MB_C, MB_C, MB_C, MB_C};
+
+template <int NP>
+__device__ __forceinline__ void block_level_sums(double (&v)[NP], double *__restrict__ part, int tile, int tiles, int k, int nlev) {
+  __shared__ double sw[NP][4];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    double x = v[p];
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    if (threadIdx.x == 0) sw[p][threadIdx.y] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && threadIdx.y == 0)
+    for (int p = 0; p < NP; ++p) part[((size_t)p * nlev + k) * tiles + tile] = (sw[p][0] + sw[p][1]) + (sw[p][2] + sw[p][3]);
+}
+
+__device__ __forceinline__ double bit(unsigned mb, int b) { return (double)((mb >> b) & 1u); }
+
+// one sample (:816-846, 858-873, 1041-1054): um, vm, wm, thlm, qtm, pres0 and the SGS fluxes usgs, vsgs, thlsgs, masked,
+// summed per tile and level
+__global__ __launch_bounds__(256) void xyt_sample_kernel(Geo g, int gx, Metrics m, const double *__restrict__ um, const double *__restrict__ vm,
+                                                         const double *__restrict__ wm, const double *__restrict__ thl, const double *__restrict__ qt,
+                                                         const double *__restrict__ pres0, const double *__restrict__ ekm,
+                                                         const double *__restrict__ ekh, const unsigned char *__restrict__ mask,
+                                                         double *__restrict__ part) {
+  const int tile = blockIdx.x, k = blockIdx.y, kf = k + 1;
+  const int by = tile / gx, bx = tile - by * gx;
+  const int i = bx * 64 + threadIdx.x, j = by * 4 + threadIdx.y;
+  double v[XS_N];
+#pragma unroll
+  for (int p = 0; p < XS_N; ++p) v[p] = 0.;
+  if (i < g.nx && j < g.ny) {
+    const long c = g.idx(i, j, k), cm = g.idx(wrapx(i - 1, g.nx), j, k), sy = g.sy, sz = g.sz;
+    const unsigned mb = mask ? mask[((size_t)k * g.ny + j) * g.nx + i] : 0x7fu;
+    const double dzf_k = m.dzf[kf], dzf_km = m.dzf[kf - 1], dzhi = m.dzhi[kf], dzhiq = m.dzhiq[kf];
+    const double u = um[c], vv = vm[c], w = wm[c];
+    double emom = (dzf_km * (ekm[c] * m.dx + ekm[cm] * m.dx) + dzf_k * (ekm[c - sz] * m.dx + ekm[cm - sz] * m.dx)) * m.dxi * dzhiq;
+    const double usgs = emom * ((u - um[c - sz]) * dzhi + (w - wm[cm]) * m.dxi);
+    emom = (dzf_km * (ekm[c] + ekm[c - sy]) + dzf_k * (ekm[c - sz] + ekm[c - sy - sz])) * dzhiq;
+    const double vsgs = emom * ((vv - vm[c - sz]) * dzhi + (w - wm[c - sy]) * m.dyi);
+    v[XS_U] = u * bit(mb, MB_U);
+    v[XS_V] = vv * bit(mb, MB_V);
+    v[XS_W] = w * bit(mb, MB_W);
+    v[XS_P] = pres0[c] * bit(mb, MB_C);
+    v[XS_USGS] = usgs * bit(mb, MB_UW);
+    v[XS_VSGS] = vsgs * bit(mb, MB_VW);
+    if (thl) {
+      const double t0 = thl[c], tm = thl[c - sz];
+      v[XS_THL] = t0 * bit(mb, MB_C);
+      v[XS_THLSGS] = 0.5 * (dzf_km * ekh[c] + dzf_k * ekh[c - sz]) * (t0 - tm) * m.dzh2i[kf] * bit(mb, MB_W);
+    }
+    if (qt) v[XS_QT] = qt[c] * bit(mb, MB_C);
+  }
+  block_level_sums<XS_N>(v, part, tile, gridDim.x, k, gridDim.y);
+}
+
+struct XytAcc { const double *a[UDC_ST_MOM_N]; const double *thlt, *thltk, *wthltk, *thlthlt; };
+
+// the table's second half (:1407-1431): slab averages of products and (co)variances of the time-averaged 3-D fields
+__global__ __launch_bounds__(256) void xyt_final_kernel(Geo g, int gx, XytAcc s, const unsigned char *__restrict__ mask, double *__restrict__ part) {
+  const int tile = blockIdx.x, k = blockIdx.y;
+  const int by = tile / gx, bx = tile - by * gx;
+  const int i = bx * 64 + threadIdx.x, j = by * 4 + threadIdx.y;
+  double v[XF_N];
+#pragma unroll
+  for (int p = 0; p < XF_N; ++p) v[p] = 0.;
+  if (i < g.nx && j < g.ny) {
+    const long c = g.idx(i, j, k);
+    const unsigned mb = mask ? mask[((size_t)k * g.ny + j) * g.nx + i] : 0x7fu;
+    const double utik = s.a[UDC_ST_UTIK][c], wtik = s.a[UDC_ST_WTIK][c], vtjk = s.a[UDC_ST_VTJK][c], wtjk = s.a[UDC_ST_WTJK][c];
+    const double utij = s.a[UDC_ST_UTIJ][c], vtij = s.a[UDC_ST_VTIJ][c], wmt = s.a[UDC_ST_WMT][c];
+    const double utc = s.a[UDC_ST_UTC][c], vtc = s.a[UDC_ST_VTC][c], wtc = s.a[UDC_ST_WTC][c];
+    const double up2 = s.a[UDC_ST_UUTC][c] - utc * utc, vp2 = s.a[UDC_ST_VVTC][c] - vtc * vtc, wp2 = s.a[UDC_ST_WWTC][c] - wtc * wtc;
+    v[XF_UW] = utik * wtik * bit(mb, MB_UW);
+    v[XF_VW] = vtjk * wtjk * bit(mb, MB_VW);
+    v[XF_WW] = wmt * wmt * bit(mb, MB_W);
+    v[XF_UV] = utij * vtij * bit(mb, MB_UV);
+    v[XF_UPWP] = (s.a[UDC_ST_UWTIK][c] - utik * wtik) * bit(mb, MB_UW);
+    v[XF_VPWP] = (s.a[UDC_ST_VWTJK][c] - vtjk * wtjk) * bit(mb, MB_VW);
+    v[XF_UPVP] = (s.a[UDC_ST_UVTIJ][c] - utij * vtij) * bit(mb, MB_UV);
+    v[XF_UPUP] = up2 * bit(mb, MB_C);
+    v[XF_VPVP] = vp2 * bit(mb, MB_C);
+    v[XF_WPWP] = wp2 * bit(mb, MB_C);
+    v[XF_TKE] = 0.5 * ((wp2 + vp2) + up2) * bit(mb, MB_C);
+    if (s.thlt) {
+      const double thltk = s.thltk[c], thlt = s.thlt[c];
+      v[XF_WTHL] = wmt * thltk * bit(mb, MB_W);
+      v[XF_WPTHLP] = (s.wthltk[c] - wmt * thltk) * bit(mb, MB_W);
+      v[XF_THLPTHLP] = (s.thlthlt[c] - thlt * thlt) * bit(mb, MB_C);
+    }
+  }
+  block_level_sums<XF_N>(v, part, tile, gridDim.x, k, gridDim.y);
+}
+
+// stage 2: sum the tiles' partial sums; one workgroup per (quantity, level)
+__global__ __launch_bounds__(256) void xyt_tiles_kernel(int tiles, const double *__restrict__ part, double *__restrict__ S) {
+  __shared__ double sw[4];
+  const int q = blockIdx.x;
+  double v = 0.;
+  for (int t = threadIdx.x; t < tiles; t += 256) v += part[(size_t)q * tiles + t];
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) S[q] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+}
+
+// sums -> masked averages -> running time averages of the nine profiles (:1088-1099)
+__global__ void xyt_running_kernel(int nz, const double *__restrict__ S, const double *__restrict__ cnt, double ts, double T, double *__restrict__ prof) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= XS_N * nz) return;
+  const int p = q / nz, k = q - p * nz;
+  const double n = cnt[xs_mask[p] * nz + k];
+  const double xy = n > 0. ? S[q] / n : -999.;
+  prof[q] = (prof[q] * (T - ts) + xy * ts) * (1. / T);
+}
+
+// the table in the order of varsxyt (:1437-1460), levels kb..ke
+__global__ void xyt_table_kernel(int nz, const double *__restrict__ S, const double *__restrict__ cnt, const double *__restrict__ prof,
+                                 double *__restrict__ table) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= UDC_XYT_N * nz) return;
+  const int row = q / nz, k = q - row * nz;
+  // rows 0-5, 15-17: running profiles; the others: final slab averages
+  const int from_prof[UDC_XYT_N] = {XS_U, XS_V, XS_W, XS_THL, XS_QT, XS_P, -1, -1, -1, -1, -1, -1, -1, -1, -1, XS_USGS, XS_THLSGS, XS_VSGS, -1, -1, -1, -1, -1};
+  const int from_fin[UDC_XYT_N] = {-1, -1, -1, -1, -1, -1, XF_UPWP, XF_WPTHLP, XF_VPWP, XF_UPVP, XF_UW, XF_WTHL, XF_UV, XF_VW, XF_WW, -1, -1, -1,
+                                   XF_THLPTHLP, XF_UPUP, XF_VPVP, XF_WPWP, XF_TKE};
+  if (from_prof[row] >= 0) { table[q] = prof[from_prof[row] * nz + k]; return; }
+  const int f = from_fin[row];
+  const double n = cnt[xf_mask[f] * nz + k];
+  table[q] = n > 0. ? S[f * nz + k] / n : -999.;
+}
+
 }  // namespace
+
+static int xyt_scratch(udc_handle *h, int nq) {
+  const size_t need = (size_t)tile_grid(h->g).tiles * h->g.nz * nq;
+  if (h->st_part_cap < need) {
+    if (h->st_part) HIP_OK(hipFree(h->st_part));
+    HIP_OK(hipMalloc(&h->st_part, sizeof(double) * need));
+    h->st_part_cap = need;
+  }
+  return 0;
+}
 
 static int stat_alloc(udc_handle *h, int id) {
   if ((int)h->stats.size() <= id) h->stats.resize(id + 1, nullptr);
@@ -107,10 +258,22 @@ extern "C" int udc_stats_enable(udc_handle *h, int on) {
   if (udc_flush_pending(h)) return 1;
   if (!on) {
     HIP_OK(hipStreamSynchronize(h->stream));
-    for (double *p : h->stats) if (p) hipFree(p);
-    h->stats.clear();
+    stats_destroy(h);
     h->stats_on = false;
     return 0;
+  }
+  if (on & 2) {        // xytdump: the nine running profiles; masks default to "no obstacles" until udc_stats_set_masks
+    const int nz = h->g.nz;
+    if (!h->st_prof) {
+      HIP_OK(hipMalloc(&h->st_prof, sizeof(double) * XS_N * nz));
+      HIP_OK(hipMalloc(&h->st_sum, sizeof(double) * XF_N * nz));
+      HIP_OK(hipMalloc(&h->st_table, sizeof(double) * UDC_XYT_N * nz));
+      HIP_OK(hipMalloc(&h->st_cnt, sizeof(double) * 7 * nz));
+      std::vector<double> c((size_t)7 * nz, (double)h->g.nx * (double)h->cfg.jtot);
+      HIP_OK(hipMemcpy(h->st_cnt, c.data(), sizeof(double) * c.size(), hipMemcpyHostToDevice));
+    }
+    HIP_OK(hipMemsetAsync(h->st_prof, 0, sizeof(double) * XS_N * nz, h->stream));
+    h->xyt_on = true;
   }
   for (int q = 0; q < UDC_ST_MOM_N; ++q)
     if (stat_alloc(h, q)) return 1;
@@ -154,12 +317,89 @@ extern "C" int udc_stats_sample(udc_handle *h, double tsamplep, double tstatsdum
                        (const double *)h->fields[UDC_SVM + 3 * n], (const double *)h->fields[UDC_EKH], ss);
   }
   HIP_OK(hipGetLastError());
+  if (h->xyt_on) {
+    const int nz = g.nz;
+    if (xyt_scratch(h, XS_N)) return 1;
+    int thl = -1, qt = -1;
+    for (int n : h->slots) { if (n == 15) thl = UDC_SVM + 3 * n; if (n == 13) qt = UDC_SVM + 3 * n; }
+    PROF(h, "stats_xyt");
+    hipLaunchKernelGGL(xyt_sample_kernel, dim3((unsigned)tg.tiles, (unsigned)nz), dim3(64, 4), 0, h->stream, g, tg.gx, h->m, um, vm, wm,
+                       thl >= 0 ? (const double *)h->fields[thl] : nullptr, qt >= 0 ? (const double *)h->fields[qt] : nullptr,
+                       (const double *)h->fields[UDC_PRES0], (const double *)h->fields[UDC_EKM], (const double *)h->fields[UDC_EKH],
+                       (const unsigned char *)h->st_mask, h->st_part);
+    hipLaunchKernelGGL(xyt_tiles_kernel, dim3((unsigned)(XS_N * nz)), dim3(256), 0, h->stream, tg.tiles, (const double *)h->st_part, h->st_sum);
+    HIP_OK(hipGetLastError());
+    if (comm_allreduce(h, h->st_sum, XS_N * nz, 1)) return 1;
+    hipLaunchKernelGGL(xyt_running_kernel, dim3((unsigned)((XS_N * nz + 255) / 256)), dim3(256), 0, h->stream, nz, (const double *)h->st_sum,
+                       (const double *)h->st_cnt, tsamplep, tstatsdumpp, h->st_prof);
+    HIP_OK(hipGetLastError());
+  }
+  return 0;
+}
+
+extern "C" int udc_stats_set_masks(udc_handle *h, const unsigned char *bits, const int *counts) {
+  if (!h) { udc_set_error("null handle"); return 1; }
+  HIP_OK(hipSetDevice(h->device));
+  if (udc_flush_pending(h)) return 1;
+  if (!h->xyt_on) { udc_set_error("udc_stats_set_masks: enable the xyt statistics first (udc_stats_enable with bit 2)"); return 1; }
+  if (!counts) { udc_set_error("udc_stats_set_masks: counts missing"); return 1; }
+  const Geo &g = h->g;
+  const size_t n = (size_t)g.nz * g.ny * g.nx;
+  HIP_OK(hipStreamSynchronize(h->stream));
+  if (bits) {
+    if (!h->st_mask) HIP_OK(hipMalloc(&h->st_mask, n));
+    HIP_OK(hipMemcpy(h->st_mask, bits, n, hipMemcpyHostToDevice));
+  } else if (h->st_mask) {
+    HIP_OK(hipFree(h->st_mask));
+    h->st_mask = nullptr;
+  }
+  std::vector<double> c((size_t)7 * g.nz);
+  for (size_t q = 0; q < c.size(); ++q) {
+    if (counts[q] < 0) { udc_set_error("udc_stats_set_masks: negative count"); return 1; }
+    c[q] = (double)counts[q];
+  }
+  HIP_OK(hipMemcpy(h->st_cnt, c.data(), sizeof(double) * c.size(), hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int udc_stats_xyt(udc_handle *h, double *table) {
+  if (!h) { udc_set_error("null handle"); return 1; }
+  HIP_OK(hipSetDevice(h->device));
+  if (udc_flush_pending(h)) return 1;
+  if (!h->xyt_on || !h->stats_on) { udc_set_error("udc_stats_xyt: enable the xyt statistics first (udc_stats_enable with bit 2)"); return 1; }
+  if (!table) { udc_set_error("udc_stats_xyt: null table"); return 1; }
+  const Geo &g = h->g;
+  const TileGrid tg = tile_grid(g);
+  const int nz = g.nz;
+  if (xyt_scratch(h, XF_N)) return 1;
+  XytAcc s;
+  for (int q = 0; q < UDC_ST_MOM_N; ++q) s.a[q] = h->stats[q];
+  const bool thl = (int)h->stats.size() > UDC_ST_THL + 3 && h->stats[UDC_ST_THL];
+  s.thlt = thl ? h->stats[UDC_ST_THL] : nullptr;
+  s.thltk = thl ? h->stats[UDC_ST_THL + 1] : nullptr;
+  s.wthltk = thl ? h->stats[UDC_ST_THL + 2] : nullptr;
+  s.thlthlt = thl ? h->stats[UDC_ST_THL + 3] : nullptr;
+  hipLaunchKernelGGL(xyt_final_kernel, dim3((unsigned)tg.tiles, (unsigned)nz), dim3(64, 4), 0, h->stream, g, tg.gx, s,
+                     (const unsigned char *)h->st_mask, h->st_part);
+  hipLaunchKernelGGL(xyt_tiles_kernel, dim3((unsigned)(XF_N * nz)), dim3(256), 0, h->stream, tg.tiles, (const double *)h->st_part, h->st_sum);
+  HIP_OK(hipGetLastError());
+  if (comm_allreduce(h, h->st_sum, XF_N * nz, 1)) return 1;
+  hipLaunchKernelGGL(xyt_table_kernel, dim3((unsigned)((UDC_XYT_N * nz + 255) / 256)), dim3(256), 0, h->stream, nz, (const double *)h->st_sum,
+                     (const double *)h->st_cnt, (const double *)h->st_prof, h->st_table);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipMemcpyAsync(table, h->st_table, sizeof(double) * UDC_XYT_N * nz, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
   return 0;
 }
 
 void stats_destroy(udc_handle *h) {
   for (double *p : h->stats) if (p) hipFree(p);
   h->stats.clear();
+  for (double **p : {&h->st_cnt, &h->st_prof, &h->st_part, &h->st_sum, &h->st_table})
+    if (*p) { hipFree(*p); *p = nullptr; }
+  if (h->st_mask) { hipFree(h->st_mask); h->st_mask = nullptr; }
+  h->st_part_cap = 0;
+  h->xyt_on = false;
 }
 
 double *stats_ptr(udc_handle *h, int id) {

@@ -30,7 +30,7 @@ DEFAULTS = {
     "SCALARS": dict(nsv=0, lscasrc=False, nscasrc=0, lscasrcl=False, nscasrcl=0),
     "NAMSUBGRID": dict(lsmagorinsky=False, lvreman=True, loneeqn=False, c_vreman=0.07, cs=-1.,
                        cf=2.5, cn=0.76, Rigc=0.25, Prandtl=0.333, ldelta=False, lbuoycorr=False),
-    "OUTPUT": dict(ltdump=False, tstatsdump=10000., tsample=5., tstatstart=0.),
+    "OUTPUT": dict(ltdump=False, lxytdump=False, tstatsdump=10000., tsample=5., tstatstart=0.),
     "WALLS": dict(nfcts=-1, lbottom=False, iwallmom=2, iwalltemp=1, iwallmoist=1, nsolpts_u=0, nsolpts_v=0, nsolpts_w=0, nsolpts_c=0,
                   nbndpts_u=0, nbndpts_v=0, nbndpts_w=0, nbndpts_c=0),
     "ORACLE": dict(nsub=3, nspin=2, lforces=True, scal_a=1.0, scal_b=0.0),

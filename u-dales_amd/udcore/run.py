@@ -117,10 +117,16 @@ def main(argv=None):
     core.dt, core.timee, core.rk3step = dt, timee, 0
     forcings = LevelForcings(core, deck)
     tdump = None
-    if bool(deck.get("OUTPUT", "ltdump")):                  # time-averaged 3-D statistics (src/modstatsdump.f90, tdump)
+    if bool(deck.get("OUTPUT", "ltdump")) or bool(deck.get("OUTPUT", "lxytdump")):      # src/modstatsdump.f90: tdump, xytdump
         from .stats import TDump
+        lists = None
+        if deck.get("RUN", "libm"):
+            from .ibm import read_ibm
+            lists = read_ibm(deck)
         tdump = TDump(core, float(deck.get("OUTPUT", "tsample")), float(deck.get("OUTPUT", "tstatsdump")),
-                      float(deck.get("OUTPUT", "tstatstart")), wdir=wdir, expnr=iexp)
+                      float(deck.get("OUTPUT", "tstatstart")), wdir=wdir, expnr=iexp, xyt=bool(deck.get("OUTPUT", "lxytdump")),
+                      ibm_lists=lists, wrap=(int(deck.get("RUN", "nprocx")) > 1, int(deck.get("RUN", "nprocy")) > 1),
+                      jtot=int(deck.get("DOMAIN", "jtot")), j0=rank * nyl, nyl=nyl)
     # (the reference restarts the restart clock and the step counter on a warm start: tnextrestart = trestart,
     # ntrun = 0, src/modglobal.f90:869; this runner keeps counting from the file it started from, so that the files
     # of a continued run do not overwrite those of the first leg)

@@ -1,4 +1,5 @@
-"""Statistics on top of the device core: the time-averaged 3-D output of tdump (src/modstatsdump.f90, &OUTPUT ltdump).
+"""Statistics on top of the device core: the time-averaged 3-D output of tdump and the x-, y- and time-averaged profiles
+of xytdump (src/modstatsdump.f90, &OUTPUT ltdump / lxytdump).
 
 The device accumulates (udc_stats_sample); this class keeps the reference's two clocks -- tsamplep since the last sample,
 tstatsdumpp since the last dump (:802-811, 1393-1399, 1723-1729) -- and turns the accumulators into the reference's
@@ -22,13 +23,76 @@ MOM = ["umt", "vmt", "wmt", "pt", "utc", "vtc", "wtc", "uutc", "vvtc", "wwtc", "
 ST_THL, ST_QT, ST_SV, ST_SV_STRIDE = len(MOM), len(MOM) + 4, len(MOM) + 8, 5
 
 
+# rows of udc_stats_xyt, the reference's output variables (initstatsdump, src/modstatsdump.f90:249-271)
+XYT = ["uxyt", "vxyt", "wxyt", "thlxyt", "qtxyt", "pxyt", "upwpxyt", "wpthlpxyt", "vpwpxyt", "upvpxyt", "uwxyt", "wthlxyt", "uvxyt",
+       "vwxyt", "wwxyt", "usgsxyt", "thlsgsxyt", "vsgsxyt", "thlpthlptxy", "upuptxyc", "vpvptxyc", "wpwptxyc", "tketxyc"]
+
+
+def xyt_masks(nx, ny, nz, lists, wrapx=False, wrapy=False, j0=0, nyl=None):
+    """createmasks' fluid masks (src/modibm.f90:2141-2190) for udc_stats_set_masks: (bits[nz, nyl, nx] uint8, counts[7, nz])
+    from the solid point lists {grid: (solid[n, 3], ...)} (global 1-based i, j, k).  Bit order IIu, IIv, IIw, IIc, IIuw,
+    IIvw, IIuv.  The point masks' ghost cells are fluid unless the direction wraps (one the reference run splits over
+    ranks, as for udc_set_ibm_mask_wrap).  avexy_ibm's rule for a first level without fluid points (src/modmpi.f90:646-649,
+    lnan = .false.: the unmasked sum over the count of level ke) is applied here: such a level gets all its bits set and the
+    count of the last level.  j0, nyl: this rank's rows of the bits (the counts are global)."""
+    pt = {}
+    for q in "uvwc":
+        a = np.ones((nz + 2, ny + 2, nx + 2), dtype=np.uint8)
+        if q in lists and len(lists[q][0]):
+            i, j, k = np.asarray(lists[q][0]).T
+            a[k, j, i] = 0
+        if wrapx:
+            a[:, :, 0], a[:, :, -1] = a[:, :, -2], a[:, :, 1]
+        if wrapy:
+            a[:, 0], a[:, -1] = a[:, -2], a[:, 1]
+        pt[q] = a
+    pt["w"][1] = 0                                             # IIw(:, :, kb) = 0
+
+    def at(a, di=0, dj=0, dk=0):
+        return a[1 + dk:nz + 1 + dk, 1 + dj:ny + 1 + dj, 1 + di:nx + 1 + di]
+    II = [at(pt["u"]).copy(), at(pt["v"]).copy(), at(pt["w"]).copy(), at(pt["c"]).copy()]
+    uw = at(pt["u"]) * at(pt["u"], dk=-1) * at(pt["w"]) * at(pt["w"], di=-1)
+    vw = at(pt["v"]) * at(pt["v"], dk=-1) * at(pt["w"]) * at(pt["w"], dj=-1)
+    uw[0], vw[0] = 0, 0                                        # IIuw(:, :, kb) = IIvw(:, :, kb) = 0
+    II += [uw, vw, at(pt["u"]) * at(pt["u"], dj=-1) * at(pt["v"]) * at(pt["v"], di=-1)]
+    counts = np.array([m.sum(axis=(1, 2)) for m in II], dtype=np.int32)
+    for q, m in enumerate(II):
+        if counts[q, 0] == 0:
+            m[0] = 1
+            counts[q, 0] = counts[q, nz - 1]
+    bits = np.zeros((nz, ny, nx), dtype=np.uint8)
+    for q, m in enumerate(II):
+        bits |= (m.astype(np.uint8) << q)
+    nyl = ny if nyl is None else nyl
+    return np.ascontiguousarray(bits[:, j0:j0 + nyl]), np.ascontiguousarray(counts)
+
+
 class TDump:
-    def __init__(self, core, tsample, tstatsdump, tstatstart=0., wdir=None, expnr=0):
+    def __init__(self, core, tsample, tstatsdump, tstatstart=0., wdir=None, expnr=0, xyt=False, ibm_lists=None, wrap=(False, False),
+                 jtot=None, j0=0, nyl=None):
+        """xyt: also xytdump's profiles; ibm_lists (udcore.ibm.read_ibm) when the deck has obstacles, wrap = the directions
+        the reference run of the deck splits over ranks, jtot / j0 / nyl = global rows / this rank's first row / its row count for y-slab runs."""
         self.core, self.tsample, self.tstatsdump, self.tstatstart = core, float(tsample), float(tstatsdump), float(tstatstart)
         self.tsamplep, self.tstatsdumpp = 0., 0.
         self.wdir, self.expnr = wdir, expnr
-        self.nsamples, self.dumps = 0, []
-        L._check(core.lib.udc_stats_enable(core.h, 1), "udc_stats_enable")
+        self.nsamples, self.dumps, self.xyt_on, self.xyt_dumps = 0, [], bool(xyt), []
+        L._check(core.lib.udc_stats_enable(core.h, 3 if xyt else 1), "udc_stats_enable")
+        if xyt and ibm_lists is not None:
+            g = core.g
+            bits, counts = xyt_masks(g.nx, jtot or g.ny, g.nz, ibm_lists, wrap[0], wrap[1], j0=j0, nyl=nyl or g.ny)
+            L._check(core.lib.udc_stats_set_masks(core.h, bits.ctypes.data_as(C.POINTER(C.c_ubyte)), counts.ctypes.data_as(C.POINTER(C.c_int))),
+                     "udc_stats_set_masks")
+
+    def xyt(self):
+        """xytdump's table {name: profile[ktot]} (src/modstatsdump.f90:1437-1460); rows the deck does not have (thl, qt) left out."""
+        t = np.zeros((len(XYT), self.core.g.nz))
+        L._check(self.core.lib.udc_stats_xyt(self.core.h, t.ctypes.data_as(L.DP)), "udc_stats_xyt")
+        skip = set()
+        if not getattr(self.core, "ltempeq", False):
+            skip |= {"thlxyt", "wpthlpxyt", "wthlxyt", "thlsgsxyt", "thlpthlptxy"}
+        if not getattr(self.core, "lmoist", False):
+            skip.add("qtxyt")
+        return {n: t[q] for q, n in enumerate(XYT) if n not in skip}
 
     # ---- device accumulators
     def get(self, sid):
@@ -92,6 +156,8 @@ class TDump:
             self.tsamplep += dt
         if self.tstatsdumpp >= self.tstatsdump:
             self.dumps.append((timee, self.output()))
+            if self.xyt_on:
+                self.xyt_dumps.append((timee, self.xyt()))
             if self.wdir:
                 self.write()
             self.tstatsdumpp = dt
@@ -101,6 +167,9 @@ class TDump:
         return what
 
     def write(self):
+        if self.xyt_on:
+            np.savez(os.path.join(self.wdir, f"xytdump.{self.expnr:03d}.npz"), time=np.array([t for t, _ in self.xyt_dumps]),
+                     **{k: np.array([o[k] for _, o in self.xyt_dumps]) for k in self.xyt_dumps[0][1]})
         base = os.path.join(self.wdir, f"tdump.{self.expnr:03d}")
         flat = {"time": np.array([t for t, _ in self.dumps])}
         for q, (_, o) in enumerate(self.dumps):
