@@ -127,6 +127,37 @@ def test_statistics_match_reference(name, iexp, slabs):
     core.close()
 
 
+@pytest.mark.parametrize("fused", [True, False])
+def test_stage3_assignment_carries_the_planes_below_the_floor(fused):
+    """`thlm = thl0`, `svm = sv0`, `um = u0` at RK stage 3 are whole-array assignments in the reference
+    (src/modtstep.f90:331-339): the planes below the floor, which no boundary routine owns, go along.  A driver that starts
+    with thlm's still at zero (the reference's own cold start sets thl0(kb-1) only, src/modstartup.f90:1208) must find
+    thl0's there after the first step -- statsdump's thlk(kb) reads it (src/modstatsdump.f90:861)."""
+    import udcore
+    name, iexp = "run_stats_16x8x12s", 62
+    d = read_deck(deck_path(name, iexp))
+    core = udcore.from_deck(d)
+    st = cold_start(core.g, d, nsv=core.nsv)
+    floor = st["thl0"][0].copy()
+    assert floor[1:-1, 1:-1].min() > 280.
+    st["thlm"][0] = 0.
+    core.load_state(st)
+    dt = float(d.get("RUN", "dtmax"))
+    for rk in (1, 2, 3):
+        if rk == 3:
+            assert np.all(core.download("thlm")[0, 1:-1, 1:-1] == 0.)
+        if fused:
+            core.substep(rk, dt, True)
+        else:
+            core.tstep_update(dt)
+            core.advection(); core.subgrid(); core.bottom(); core.coriolis(); core.forces(); core.masscorr(); core.scalsource()
+            core.poisson(); core.tstep_integrate(); core.halos(); core.boundary()
+    assert np.array_equal(core.download("thlm")[0, 1:-1, 1:-1], floor[1:-1, 1:-1])
+    assert np.array_equal(core.download("thl0")[0, 1:-1, 1:-1], floor[1:-1, 1:-1])
+    assert np.all(core.download("um")[0, 1:-1, 1:-1] == 0.)
+    core.close()
+
+
 def test_running_average_is_the_arithmetic_mean():
     import udcore
     from udcore.stats import TDump

@@ -1450,6 +1450,20 @@ static IntArgs int_args(udc_handle *h) {
   return a;
 }
 
+// RK stage 3: the reference's `um = u0`, `thlm = thl0`, `svm = sv0` ... are whole-array assignments (src/modtstep.f90:331-339),
+// ghost planes included; the kernels above update the cells (and, folded, the lateral / top ghosts `halos` and `boundary` own).
+// The planes below the floor belong to no boundary routine -- they keep what the start-up put there -- so the m-fields take
+// them from the 0-fields here (statsdump reads thlm(kb-1), src/modstatsdump.f90:861).
+static int copy_floor_planes(udc_handle *h, bool vel) {
+  const size_t bytes = sizeof(double) * (size_t)HZ * (size_t)h->g.sz;
+  if (vel)
+    for (int q = 0; q < 3; ++q)
+      HIP_OK(hipMemcpyAsync(h->fields[UDC_UM + q], h->fields[UDC_U0 + q], bytes, hipMemcpyDeviceToDevice, h->stream));
+  for (int n : h->slots)
+    HIP_OK(hipMemcpyAsync(h->fields[UDC_SVM + 3 * n], h->fields[UDC_SV0 + 3 * n], bytes, hipMemcpyDeviceToDevice, h->stream));
+  return 0;
+}
+
 int k_integrate(udc_handle *h, int rk3step, double dt) {
   const Geo &g = h->g;
   dim3 b(64, 4, 1), gr = cell_grid(g, b);
@@ -1458,6 +1472,7 @@ int k_integrate(udc_handle *h, int rk3step, double dt) {
   hipLaunchKernelGGL((integrate_kernel<false, true, false>), gr, b, 0, h->stream, g, tile_grid(g), h->m, int_args(h),
                      (const double *)nullptr, (double *)nullptr, rk3coef, rk3step == 3 ? 3 : 0, 0, h->p);
   HIP_OK(hipGetLastError());
+  if (rk3step == 3 && copy_floor_planes(h, true)) return 1;
   return 0;
 }
 
@@ -1480,6 +1495,7 @@ int k_project_integrate(udc_handle *h, int rk3step, double dt, bool zero_tend, b
     hipLaunchKernelGGL((integrate_kernel<true, false, false>), gr, b, 0, h->stream, g, tile_grid(g), h->m, ia,
                        (const double *)h->fields[UDC_P], h->fields[UDC_PRES0], rk3coef, lastf, ghosts ? 1 : 0, h->p);
   HIP_OK(hipGetLastError());
+  if (rk3step == 3 && copy_floor_planes(h, write_um)) return 1;
   return 0;
 }
 

@@ -211,9 +211,9 @@ contains
       integer, intent(in) :: II(:, :, :)
       integer, intent(inout) :: IIs(kb:)
       integer :: kk
-      ! (II arrays: (ib-ihc:ie+ihc, jb-jhc:je+jhc, kb-khc:ke+khc), src/modfields.f90)
+      ! (II arrays: (ib-ihc:ie+ihc, jb-jhc:je+jhc, kb:ke+khc), src/modfields.f90:574-580)
       do kk = kb, ke + khc
-        loc(kk) = sum(II(lbi():ubi(), lbj():ubj(), kk - kb + 1 + khc))
+        loc(kk) = sum(II(lbi():ubi(), lbj():ubj(), kk - kb + 1))
       end do
       call MPI_ALLREDUCE(loc, tot, ke + khc - kb + 1, MPI_INTEGER, MPI_SUM, comm3d, mpierr)
       IIs(kb:ke + khc) = tot
@@ -221,7 +221,7 @@ contains
     subroutine colcount(II, IIt)
       integer, intent(in) :: II(:, :, :)
       integer, intent(inout) :: IIt(ib:, kb:)
-      cl = sum(II(lbi():ubi(), lbj():ubj(), 1 + khc:ke - kb + 1 + khc), DIM=2)
+      cl = sum(II(lbi():ubi(), lbj():ubj(), 1:ke - kb + 1), DIM=2)
       call MPI_ALLREDUCE(cl, ct, size(cl), MPI_INTEGER, MPI_SUM, comm3d, mpierr)
       IIt(ib:ie, kb:ke) = ct
     end subroutine colcount
