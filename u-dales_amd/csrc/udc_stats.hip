@@ -95,6 +95,16 @@ __global__ __launch_bounds__(256) void stats_scalar_kernel(Geo g, TileGrid tg, M
 // has already applied avexy_ibm's rule for a first level without fluid points (unmasked sum over the count of level ke) to
 // the bits and counts it hands over, so the device only forms sum(var * bit) / count, or -999 where the count is zero.
 enum { MB_U = 0, MB_V, MB_W, MB_C, MB_UW, MB_VW, MB_UV };
+// one workgroup of 64 x 4 threads sums 64 x (4 XR) cells of a level before it reduces: XR = 1 spent more time in the nine
+// cross-lane reductions than in the loads (256^3: 0.33 ms a sample; with 8 row groups per thread 0.1)
+constexpr int XR = 8;
+struct XytTiles { int gx, tiles; };
+static inline XytTiles xyt_tiles(const Geo &g) {
+  XytTiles t;
+  t.gx = (g.nx + 63) / 64;
+  t.tiles = t.gx * ((g.ny + 4 * XR - 1) / (4 * XR));
+  return t;
+}
 enum { XS_U = 0, XS_V, XS_W, XS_THL, XS_QT, XS_P, XS_USGS, XS_VSGS, XS_THLSGS, XS_N };      // the running profiles
 enum { XF_UPWP = 0, XF_WPTHLP, XF_VPWP, XF_UPVP, XF_UW, XF_WTHL, XF_UV, XF_VW, XF_WW, XF_THLPTHLP, XF_UPUP, XF_VPVP, XF_WPWP, XF_TKE, XF_N };
 __constant__ int xs_mask[XS_N] = {MB_U, MB_V, MB_W, MB_C, MB_C, MB_C, MB_UW, MB_VW, MB_W};
@@ -125,11 +135,13 @@ __global__ __launch_bounds__(256) void xyt_sample_kernel(Geo g, int gx, Metrics 
                                                          double *__restrict__ part) {
   const int tile = blockIdx.x, k = blockIdx.y, kf = k + 1;
   const int by = tile / gx, bx = tile - by * gx;
-  const int i = bx * 64 + threadIdx.x, j = by * 4 + threadIdx.y;
+  const int i = bx * 64 + threadIdx.x;
   double v[XS_N];
 #pragma unroll
   for (int p = 0; p < XS_N; ++p) v[p] = 0.;
-  if (i < g.nx && j < g.ny) {
+  for (int r = 0; r < XR; ++r) {
+    const int j = (by * XR + r) * 4 + threadIdx.y;
+    if (i >= g.nx || j >= g.ny) continue;
     const long c = g.idx(i, j, k), cm = g.idx(wrapx(i - 1, g.nx), j, k), sy = g.sy, sz = g.sz;
     const unsigned mb = mask ? mask[((size_t)k * g.ny + j) * g.nx + i] : 0x7fu;
     const double dzf_k = m.dzf[kf], dzf_km = m.dzf[kf - 1], dzhi = m.dzhi[kf], dzhiq = m.dzhiq[kf];
@@ -138,18 +150,18 @@ __global__ __launch_bounds__(256) void xyt_sample_kernel(Geo g, int gx, Metrics 
     const double usgs = emom * ((u - um[c - sz]) * dzhi + (w - wm[cm]) * m.dxi);
     emom = (dzf_km * (ekm[c] + ekm[c - sy]) + dzf_k * (ekm[c - sz] + ekm[c - sy - sz])) * dzhiq;
     const double vsgs = emom * ((vv - vm[c - sz]) * dzhi + (w - wm[c - sy]) * m.dyi);
-    v[XS_U] = u * bit(mb, MB_U);
-    v[XS_V] = vv * bit(mb, MB_V);
-    v[XS_W] = w * bit(mb, MB_W);
-    v[XS_P] = pres0[c] * bit(mb, MB_C);
-    v[XS_USGS] = usgs * bit(mb, MB_UW);
-    v[XS_VSGS] = vsgs * bit(mb, MB_VW);
+    v[XS_U] += u * bit(mb, MB_U);
+    v[XS_V] += vv * bit(mb, MB_V);
+    v[XS_W] += w * bit(mb, MB_W);
+    v[XS_P] += pres0[c] * bit(mb, MB_C);
+    v[XS_USGS] += usgs * bit(mb, MB_UW);
+    v[XS_VSGS] += vsgs * bit(mb, MB_VW);
     if (thl) {
       const double t0 = thl[c], tm = thl[c - sz];
-      v[XS_THL] = t0 * bit(mb, MB_C);
-      v[XS_THLSGS] = 0.5 * (dzf_km * ekh[c] + dzf_k * ekh[c - sz]) * (t0 - tm) * m.dzh2i[kf] * bit(mb, MB_W);
+      v[XS_THL] += t0 * bit(mb, MB_C);
+      v[XS_THLSGS] += 0.5 * (dzf_km * ekh[c] + dzf_k * ekh[c - sz]) * (t0 - tm) * m.dzh2i[kf] * bit(mb, MB_W);
     }
-    if (qt) v[XS_QT] = qt[c] * bit(mb, MB_C);
+    if (qt) v[XS_QT] += qt[c] * bit(mb, MB_C);
   }
   block_level_sums<XS_N>(v, part, tile, gridDim.x, k, gridDim.y);
 }
@@ -160,33 +172,35 @@ struct XytAcc { const double *a[UDC_ST_MOM_N]; const double *thlt, *thltk, *wthl
 __global__ __launch_bounds__(256) void xyt_final_kernel(Geo g, int gx, XytAcc s, const unsigned char *__restrict__ mask, double *__restrict__ part) {
   const int tile = blockIdx.x, k = blockIdx.y;
   const int by = tile / gx, bx = tile - by * gx;
-  const int i = bx * 64 + threadIdx.x, j = by * 4 + threadIdx.y;
+  const int i = bx * 64 + threadIdx.x;
   double v[XF_N];
 #pragma unroll
   for (int p = 0; p < XF_N; ++p) v[p] = 0.;
-  if (i < g.nx && j < g.ny) {
+  for (int r = 0; r < XR; ++r) {
+    const int j = (by * XR + r) * 4 + threadIdx.y;
+    if (i >= g.nx || j >= g.ny) continue;
     const long c = g.idx(i, j, k);
     const unsigned mb = mask ? mask[((size_t)k * g.ny + j) * g.nx + i] : 0x7fu;
     const double utik = s.a[UDC_ST_UTIK][c], wtik = s.a[UDC_ST_WTIK][c], vtjk = s.a[UDC_ST_VTJK][c], wtjk = s.a[UDC_ST_WTJK][c];
     const double utij = s.a[UDC_ST_UTIJ][c], vtij = s.a[UDC_ST_VTIJ][c], wmt = s.a[UDC_ST_WMT][c];
     const double utc = s.a[UDC_ST_UTC][c], vtc = s.a[UDC_ST_VTC][c], wtc = s.a[UDC_ST_WTC][c];
     const double up2 = s.a[UDC_ST_UUTC][c] - utc * utc, vp2 = s.a[UDC_ST_VVTC][c] - vtc * vtc, wp2 = s.a[UDC_ST_WWTC][c] - wtc * wtc;
-    v[XF_UW] = utik * wtik * bit(mb, MB_UW);
-    v[XF_VW] = vtjk * wtjk * bit(mb, MB_VW);
-    v[XF_WW] = wmt * wmt * bit(mb, MB_W);
-    v[XF_UV] = utij * vtij * bit(mb, MB_UV);
-    v[XF_UPWP] = (s.a[UDC_ST_UWTIK][c] - utik * wtik) * bit(mb, MB_UW);
-    v[XF_VPWP] = (s.a[UDC_ST_VWTJK][c] - vtjk * wtjk) * bit(mb, MB_VW);
-    v[XF_UPVP] = (s.a[UDC_ST_UVTIJ][c] - utij * vtij) * bit(mb, MB_UV);
-    v[XF_UPUP] = up2 * bit(mb, MB_C);
-    v[XF_VPVP] = vp2 * bit(mb, MB_C);
-    v[XF_WPWP] = wp2 * bit(mb, MB_C);
-    v[XF_TKE] = 0.5 * ((wp2 + vp2) + up2) * bit(mb, MB_C);
+    v[XF_UW] += utik * wtik * bit(mb, MB_UW);
+    v[XF_VW] += vtjk * wtjk * bit(mb, MB_VW);
+    v[XF_WW] += wmt * wmt * bit(mb, MB_W);
+    v[XF_UV] += utij * vtij * bit(mb, MB_UV);
+    v[XF_UPWP] += (s.a[UDC_ST_UWTIK][c] - utik * wtik) * bit(mb, MB_UW);
+    v[XF_VPWP] += (s.a[UDC_ST_VWTJK][c] - vtjk * wtjk) * bit(mb, MB_VW);
+    v[XF_UPVP] += (s.a[UDC_ST_UVTIJ][c] - utij * vtij) * bit(mb, MB_UV);
+    v[XF_UPUP] += up2 * bit(mb, MB_C);
+    v[XF_VPVP] += vp2 * bit(mb, MB_C);
+    v[XF_WPWP] += wp2 * bit(mb, MB_C);
+    v[XF_TKE] += 0.5 * ((wp2 + vp2) + up2) * bit(mb, MB_C);
     if (s.thlt) {
       const double thltk = s.thltk[c], thlt = s.thlt[c];
-      v[XF_WTHL] = wmt * thltk * bit(mb, MB_W);
-      v[XF_WPTHLP] = (s.wthltk[c] - wmt * thltk) * bit(mb, MB_W);
-      v[XF_THLPTHLP] = (s.thlthlt[c] - thlt * thlt) * bit(mb, MB_C);
+      v[XF_WTHL] += wmt * thltk * bit(mb, MB_W);
+      v[XF_WPTHLP] += (s.wthltk[c] - wmt * thltk) * bit(mb, MB_W);
+      v[XF_THLPTHLP] += (s.thlthlt[c] - thlt * thlt) * bit(mb, MB_C);
     }
   }
   block_level_sums<XF_N>(v, part, tile, gridDim.x, k, gridDim.y);
@@ -233,7 +247,7 @@ __global__ void xyt_table_kernel(int nz, const double *__restrict__ S, const dou
 }  // namespace
 
 static int xyt_scratch(udc_handle *h, int nq) {
-  const size_t need = (size_t)tile_grid(h->g).tiles * h->g.nz * nq;
+  const size_t need = (size_t)xyt_tiles(h->g).tiles * h->g.nz * nq;
   if (h->st_part_cap < need) {
     if (h->st_part) HIP_OK(hipFree(h->st_part));
     HIP_OK(hipMalloc(&h->st_part, sizeof(double) * need));
@@ -323,11 +337,12 @@ extern "C" int udc_stats_sample(udc_handle *h, double tsamplep, double tstatsdum
     int thl = -1, qt = -1;
     for (int n : h->slots) { if (n == 15) thl = UDC_SVM + 3 * n; if (n == 13) qt = UDC_SVM + 3 * n; }
     PROF(h, "stats_xyt");
-    hipLaunchKernelGGL(xyt_sample_kernel, dim3((unsigned)tg.tiles, (unsigned)nz), dim3(64, 4), 0, h->stream, g, tg.gx, h->m, um, vm, wm,
+    const XytTiles xt = xyt_tiles(g);
+    hipLaunchKernelGGL(xyt_sample_kernel, dim3((unsigned)xt.tiles, (unsigned)nz), dim3(64, 4), 0, h->stream, g, xt.gx, h->m, um, vm, wm,
                        thl >= 0 ? (const double *)h->fields[thl] : nullptr, qt >= 0 ? (const double *)h->fields[qt] : nullptr,
                        (const double *)h->fields[UDC_PRES0], (const double *)h->fields[UDC_EKM], (const double *)h->fields[UDC_EKH],
                        (const unsigned char *)h->st_mask, h->st_part);
-    hipLaunchKernelGGL(xyt_tiles_kernel, dim3((unsigned)(XS_N * nz)), dim3(256), 0, h->stream, tg.tiles, (const double *)h->st_part, h->st_sum);
+    hipLaunchKernelGGL(xyt_tiles_kernel, dim3((unsigned)(XS_N * nz)), dim3(256), 0, h->stream, xt.tiles, (const double *)h->st_part, h->st_sum);
     HIP_OK(hipGetLastError());
     if (comm_allreduce(h, h->st_sum, XS_N * nz, 1)) return 1;
     hipLaunchKernelGGL(xyt_running_kernel, dim3((unsigned)((XS_N * nz + 255) / 256)), dim3(256), 0, h->stream, nz, (const double *)h->st_sum,
@@ -369,7 +384,7 @@ extern "C" int udc_stats_xyt(udc_handle *h, double *table) {
   if (!h->xyt_on || !h->stats_on) { udc_set_error("udc_stats_xyt: enable the xyt statistics first (udc_stats_enable with bit 2)"); return 1; }
   if (!table) { udc_set_error("udc_stats_xyt: null table"); return 1; }
   const Geo &g = h->g;
-  const TileGrid tg = tile_grid(g);
+  const XytTiles tg = xyt_tiles(g);
   const int nz = g.nz;
   if (xyt_scratch(h, XF_N)) return 1;
   XytAcc s;
