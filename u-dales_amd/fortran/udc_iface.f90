@@ -342,6 +342,35 @@ module udc_iface
       import :: c_int, c_ptr
       type(c_ptr), value :: h
     end function
+    ! statistics on the device (include/udcore.h: tdump accumulators, xytdump profiles)
+    integer(c_int) function udc_stats_enable(h, on) bind(C, name='udc_stats_enable')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
+      integer(c_int), value :: on
+    end function udc_stats_enable
+    integer(c_int) function udc_stats_sample(h, tsamplep, tstatsdumpp) bind(C, name='udc_stats_sample')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), value :: tsamplep, tstatsdumpp
+    end function udc_stats_sample
+    integer(c_int) function udc_stats_get(h, id, host, lb, ub) bind(C, name='udc_stats_get')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: id
+      real(c_double), intent(inout) :: host(*)
+      integer(c_int), intent(in) :: lb(3), ub(3)
+    end function udc_stats_get
+    integer(c_int) function udc_stats_set_masks(h, bits, counts) bind(C, name='udc_stats_set_masks')
+      import :: c_ptr, c_int, c_signed_char
+      type(c_ptr), value :: h
+      integer(c_signed_char), intent(in) :: bits(*)
+      integer(c_int), intent(in) :: counts(*)
+    end function udc_stats_set_masks
+    integer(c_int) function udc_stats_xyt(h, table) bind(C, name='udc_stats_xyt')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(inout) :: table(*)
+    end function udc_stats_xyt
     integer(c_int) function udc_deferred_stats(h, fused, unfused) bind(C, name='udc_deferred_stats')
       import :: c_int, c_ptr, c_long
       type(c_ptr), value :: h
