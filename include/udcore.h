@@ -144,6 +144,11 @@ int udc_scalsource(udc_handle *h);
  * 3 = the neutral wfmneutral of udc_config), BCbotT = 2 -> temperature against a wall at thls with roughness length
  * z0h (case 92; 1 = the prescribed flux wtsurf of udc_set_tempeq).  prandtlturb: src/modglobal.f90:304 (= prandtlmol).
  * Needs the temperature equation; call after udc_set_tempeq (which must then be given the same BCbotT). */
+/* Temperature equation off (ltempeq = .false.) with the wfuno floor (BCbotm = 2, the reference's default): the reference's
+ * thl0 is allocated regardless, keeps the values of prof.inp for ever (src/modtstep.f90:240 integrates it under ltempeq
+ * only; src/modstartup.f90 does not perturb it) and wfuno judges the stability on its first level (src/modibm.f90:2022,
+ * src/modwallfunctions.f90:92-127).  thl_kb = thlprof(kb); call before the first `bottom`. */
+int udc_set_floor_air_temperature(udc_handle *h, double thl_kb);
 int udc_set_floor_wf(udc_handle *h, int bcbotm, int bcbott, double thls, double z0h, double prandtlturb);
 /* Total water, &PHYSICS lmoist (src/modglobal.f90:402): qt is advected (iadv_qt = 2 -> advecc_2nd,
  * src/modadvection.f90:78-86), diffused (diffc with ekh, src/modsubgrid.f90:147), integrated

@@ -136,6 +136,7 @@ program ref_driver
       end if
     end do
     if (lstats) call dump_stats
+    if (ladaptive) call put1('end.time', (/timee, dt/), 1)
   case ('kernels')
     do isub = 1, nspin
       call one_substep
@@ -391,7 +392,7 @@ contains
       BCtopq, BCbotq, wqtop, qt_top, wqsurf, z0h, wsvtopdum, ds, bctfxm, bctfxp, bctfym, bctfyp, bctfz, &
       bcqfxm, bcqfxp, bcqfym, bcqfyp, bcqfz
     namelist /SCALARS/ nsv, lscasrc, nscasrc, lscasrcl, nscasrcl
-    namelist /OUTPUT/ ltdump, lxytdump, tsample, tstatsdump, tstatstart
+    namelist /OUTPUT/ ltdump, lxytdump, tsample, tstatsdump, tstatstart, lfielddump, tfielddump, fieldvars      ! (the field dump itself is not run here)
     namelist /WALLS/ nfcts, lbottom, iwallmom, iwalltemp, iwallmoist, nsolpts_u, nsolpts_v, nsolpts_w, nsolpts_c, &
       nbndpts_u, nbndpts_v, nbndpts_w, nbndpts_c
     open (ifnamopt, file=fname_options, status='old', iostat=ierr)

@@ -17,7 +17,7 @@ KERNEL_CASES = {
     "k_volflow_12x8x6": 17, "k_thl_12x8x6": 18,
     "k_buoy_12x8x6": 19,
     "k_coriol_12x8x6": 20,
-    "k_tke_12x8x6": 21, "k_tke_thl_12x8x6": 28, "k_qt_12x8x6": 32, "k_moist_12x8x8": 35, "k_uno_12x8x6": 37, "k_src_12x8x8": 39, "k_thlk_12x8x6": 41, "k_svtop_8x8x8": 47, "k_tke_moist_12x8x8": 50, "k_vreman_buoycorr_12x8x10": 52,
+    "k_tke_12x8x6": 21, "k_tke_thl_12x8x6": 28, "k_qt_12x8x6": 32, "k_moist_12x8x8": 35, "k_uno_12x8x6": 37, "k_src_12x8x8": 39, "k_thlk_12x8x6": 41, "k_svtop_8x8x8": 47, "k_tke_moist_12x8x8": 50, "k_vreman_buoycorr_12x8x10": 52, "k_floor_uno_nothl_12x8x6": 64,
 }
 # per-level forcings (lstend, nudge, grwdamp): host-level routines, checked in tests/test_level_forcings.py
 LSF_CASES = {"k_lsf_12x8x24": 29, "run_lsf_16x8x24s": 30, "k_lsfq_12x8x20": 34}
@@ -26,7 +26,8 @@ RUN_CASES = {"run_16x16x8": 21, "run_smag_scalar_16x8x12s": 22, "run_floor_scala
              "run_buoy_16x8x12s": 26,
              "run_profforc_16x16x8": 27, "run_vreman_buoycorr_16x8x12s": 53, "run_ibm_16x12x10": 55, "run_ibm_volflow_16x12x10": 56, "run_ibm_edge_16x12x10": 57,
              "run_ibm_thl_16x12x10": 59, "run_ibm_thlcons_16x12x10": 60, "run_ibm_qt_16x12x10": 61,
-             "run_stats_16x8x12s": 62, "run_stats_ibm_16x12x10": 63}
+             "run_stats_16x8x12s": 62, "run_stats_ibm_16x12x10": 63,
+             "run_floor_uno_nothl_16x8x12s": 65}
 
 
 def load_fixture(name):

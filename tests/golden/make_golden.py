@@ -426,6 +426,13 @@ CASES.update({
                                     output="ltdump = .true.\nlxytdump = .true.\ntsample = 0.1\ntstatsdump = 1000.",
                                     oracle="nsub = 15\ndump_at = 15"), 1.04),
 })
+# the reference's defaults for a flat floor: lbottom with BCbotm = 2 (wfuno) and no temperature equation -- thl0 stays at
+# prof.inp's profile, thls at its default of -1 (examples/999 of the reference is such a deck)
+CASES.update({
+    "k_floor_uno_nothl_12x8x6": ("kernels", 64, 12, 8, 6, dict(sgs="vreman", floor=True, bcbotm=2, bc="z0h = 0.005", oracle="nspin = 3"), 1.04),
+    "run_floor_uno_nothl_16x8x12s": ("run", 65, 16, 8, 12, dict(sgs="smag", nsv=1, floor=True, bcbotm=2, bc="z0h = 0.005",
+                                                                oracle="nsub = 6\ndump_at = 3, 6"), 1.06),
+})
 LSF_ONLY = ("k_lsf_12x8x24", "k_lsfq_12x8x20", "k_fix1_12x8x6")
 THL_CASES = {"k_tke_moist_12x8x8": dict(dthl=0.25, qt=0.0118, dqt=-8e-5, tke=0.06),
              "run_moistnr_16x8x12s": dict(dthl=0.25, qt=0.0119, dqt=-6e-5),
@@ -490,6 +497,41 @@ def make_restart_cases():
         print(f"{name}: {sorted(os.listdir(odir))}")
 
 
+# A deck of the reference's own examples, run as it is (data files copied from the reference's examples directory: deck,
+# prof.inp, lscale.inp): examples/999, the flat neutral channel at 128^3 with the floor wall function at its defaults
+# (BCbotm = 2 without temperature equation), the adaptive time step and tdump / xytdump / fielddump output.  The golden holds
+# xytdump's table and the clock after `nsub` substeps of the reference binary (the 3-D fields would be 17 MB each).
+EXAMPLES = {"example_999": ("999", 999, 75)}
+
+
+def make_example_cases(only):
+    for name, (exdir, iexp, nsub) in EXAMPLES.items():
+        if only and name not in only:
+            continue
+        src = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(REF))), "..", "reference", "examples", exdir)
+        src = os.path.join("/root/reference/examples", exdir)
+        cdir = os.path.join(HERE, "cases", name)
+        os.makedirs(cdir, exist_ok=True)
+        for fn in (f"namoptions.{iexp:03d}", f"prof.inp.{iexp:03d}", f"lscale.inp.{iexp:03d}"):
+            shutil.copy(os.path.join(src, fn), cdir)
+        with tempfile.TemporaryDirectory() as tmp:
+            for fn in os.listdir(cdir):
+                shutil.copy(os.path.join(cdir, fn), tmp)
+            with open(os.path.join(tmp, f"namoptions.{iexp:03d}"), "a") as f:      # the driver's own group; the deck is otherwise untouched
+                f.write(f"\n&ORACLE\nnsub = {nsub}\n/\n")
+            out = os.path.join(tmp, "out.bin")
+            # (128^3: the reference's array-valued expressions in statsdump need more than the default 8 MB of stack)
+            subprocess.check_call(["bash", "-c", f"ulimit -s unlimited; exec {REF} namoptions.{iexp:03d} run {out}"], cwd=tmp)
+            d = read_dump(out)
+        keep = {k: v for k, v in d.items() if k.count(".") == 0 or k.startswith(("xyt.", "end."))}
+        tmpf = os.path.join(HERE, name + ".bin")
+        write_dump(tmpf, keep)
+        with open(tmpf, "rb") as f, gzip.GzipFile(tmpf + ".gz", "wb", mtime=0) as g:
+            g.write(f.read())
+        os.remove(tmpf)
+        print(f"{name}: {len(keep)} records, {os.path.getsize(tmpf + '.gz') / 1024:.0f} kB")
+
+
 def main():
     if not os.path.exists(REF):
         sys.exit(f"{REF} missing: run `make -C oracle ref` in the build container first")
@@ -527,6 +569,7 @@ def main():
         os.remove(tmpf)
         print(f"{name}: {len(keep)} records, {os.path.getsize(tmpf + '.gz') / 1024:.0f} kB")
     make_restart_cases()
+    make_example_cases(only)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,55 @@
+"""A deck of the reference's own examples, unmodified, through the device runner (`python -m udcore.run`): examples/999, the
+flat neutral channel at 128^3 -- floor wall function at the reference's defaults (BCbotm = 2 with the temperature equation
+off and thls at its default of -1), adaptive time step, &OUTPUT tdump + xytdump + fielddump, a CPU layout of 4 x 2 ranks in
+&RUN, a pre-processing group (&INP) the Fortran never reads.  Golden: xytdump's table and the clock after 25 steps of the
+reference binary on the same files (tests/golden/make_golden.py, EXAMPLES)."""
+import os
+import shutil
+import sys
+
+import numpy as np
+import pytest
+
+from common import GOLDEN, load_fixture
+
+pytestmark = pytest.mark.gpu
+XYT_FIX = {"uwtxyik": "uwxyt", "vwtxyjk": "vwxyt", "wwtxyk": "wwxyt", "uvtxyij": "uvxyt", "upwptxyik": "upwpxyt", "vpwptxyjk": "vpwpxyt",
+           "upvptxyij": "upvpxyt"}
+
+
+def test_reference_example_999_runs_unmodified(tmp_path):
+    from udcore import run
+    fix = load_fixture("example_999")
+    for fn in os.listdir(os.path.join(GOLDEN, "cases", "example_999")):
+        shutil.copy(os.path.join(GOLDEN, "cases", "example_999", fn), tmp_path)
+    got = {}
+
+    def at_end(core, tdump):
+        got["xyt"] = tdump.xyt()
+        got["time"] = (core.timee, core.dt)
+        got["div"] = core.divergence()[0]
+        got["nsamples"] = tdump.nsamples
+
+    assert run.main([str(tmp_path / "namoptions.999"), "--steps", "25", "--quiet"], at_end=at_end) == 0
+    # the clock: the adaptive time step followed the reference's through 75 substeps
+    tref, dtref = fix["end.time"].data
+    assert abs(got["time"][0] - tref) <= 1e-9 * tref and abs(got["time"][1] - dtref) <= 1e-8 * dtref
+    assert got["div"] < 1e-10 and got["nsamples"] >= 10
+    nz = 128
+    u2 = 1.0
+    for k, rec in fix.items():
+        if not k.startswith("xyt."):
+            continue
+        ref = rec.data[:nz]
+        g = got["xyt"][XYT_FIX.get(k[4:], k[4:])]
+        # profiles of O(1e-7 .. 1) quantities of a flow with |u| = 1: absolute agreement on the scale of u^2
+        assert np.abs(g - ref).max() <= 1e-9 * max(np.abs(ref).max(), 1e-3 * u2), (k, np.abs(g - ref).max())
+    # the floor at the reference's defaults is a strong sink: the first level has lost nearly all its momentum
+    assert got["xyt"]["uxyt"][0] < 0.05 and got["xyt"]["uxyt"][5] > 0.9
+    # output files of the deck's &OUTPUT
+    files = os.listdir(tmp_path)
+    assert "tdump.999.npz" in files and "xytdump.999.npz" in files and "fielddump.000.999.npz" in files
+    fd = np.load(tmp_path / "fielddump.000.999.npz")
+    assert fd["u0"].shape[1:] == (128, 128, 128) and len(fd["time"]) >= 3 and fd["u0"].dtype == np.float32
+    xd = np.load(tmp_path / "xytdump.999.npz")
+    assert xd["uxyt"].shape[1] == 128 and len(xd["time"]) >= 1

@@ -483,14 +483,24 @@ static int now_scalsource(udc_handle *h) {
   return k_scalsource(h);
 }
 
+extern "C" int udc_set_floor_air_temperature(udc_handle *h, double thl_kb) {
+  ENTRY_FLUSH(h);
+  h->floor_thl_air_on = true;
+  h->floor_thl_air = thl_kb;
+  return 0;
+}
+
 extern "C" int udc_set_floor_wf(udc_handle *h, int bcbotm, int bcbott, double thls, double z0h, double prandtlturb) {
   ENTRY_FLUSH(h);
   if (!h->p.lbottom) { udc_set_error("udc_set_floor_wf: the floor is off (udc_config.lbottom)"); return 1; }
   if (bcbotm != 2 && bcbotm != 3) { udc_set_error("udc_set_floor_wf: BCbotm must be 2 (wfuno) or 3 (wfmneutral)"); return 1; }
   if (bcbott != 1 && bcbott != 2) { udc_set_error("udc_set_floor_wf: BCbotT must be 1 (flux) or 2 (wfuno)"); return 1; }
   if (bcbotm == 2 || bcbott == 2) {
-    if ((int)h->fields.size() <= UDC_THL0 || !h->fields[UDC_THL0]) { udc_set_error("udc_set_floor_wf: wfuno needs the temperature equation (call udc_set_tempeq first)"); return 1; }
-    if (!(thls > 0.) || !(z0h > 0.) || !(prandtlturb > 0.)) { udc_set_error("udc_set_floor_wf: thls, z0h and prandtlturb must be positive"); return 1; }
+    const bool have_thl = (int)h->fields.size() > UDC_THL0 && h->fields[UDC_THL0];
+    if (bcbott == 2 && !have_thl) { udc_set_error("udc_set_floor_wf: BCbotT = 2 needs the temperature equation (call udc_set_tempeq first)"); return 1; }
+    // (BCbotm = 2 without the temperature equation: udc_set_floor_air_temperature, checked when `bottom` runs)
+    // (thls: the reference's default is -1 and it runs with it -- only a wall temperature of exactly zero has no meaning, :99)
+    if (thls == 0. || !(z0h > 0.) || !(prandtlturb > 0.)) { udc_set_error("udc_set_floor_wf: thls must not be zero, z0h and prandtlturb must be positive"); return 1; }
   }
   h->floor_bcbotm = bcbotm; h->floor_bcbott = bcbott;
   h->floor_thls = thls; h->floor_z0h = z0h; h->floor_prt = prandtlturb;

@@ -142,6 +142,7 @@ struct BottomArgs {
   // stability is judged on, and which entry of sv0/svp is thl when its floor is the wall function too (BCbotT = 2), else -1
   double thls, z0h, prt;
   const double *thl0;
+  double thl_air;        // thl0 == nullptr (temperature equation off): the uniform, frozen temperature of the first level
   int thl_wf;
   double *tau_x, *tau_y, *thl_flux;      // [ny_l][nx] planes or nullptr
   int thl_slot;                          // entry of sv0/svp that is thl (for thl_flux), else -1
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(256) void bottom_kernel(Geo g, Metrics m, BottomArg
     const double utang2Int = (a.v0[c] + a.v0[cxm] + a.v0[c + sy] + a.v0[cxm + sy]) * 0.25;
     const double utangInt = fmax(umin, (utang1Int * utang1Int + utang2Int * utang2Int));
     if (UNO) {
-      const double dT = ((a.thl0[c] + a.thl0[cxm]) - (Twall + Twall)) * 0.5;
+      const double dT = (a.thl0 ? ((a.thl0[c] + a.thl0[cxm]) - (Twall + Twall)) : ((a.thl_air + a.thl_air) - (Twall + Twall))) * 0.5;
       ctm = uno_m(a.prt, l_, logzh, sqdz, grav * delta * dT * 2 / ((Twall + Twall) * utangInt), fkar2);
     }
     const double dummy = fabs(utang1Int) * sqrt(utangInt) * ctm;
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(256) void bottom_kernel(Geo g, Metrics m, BottomArg
     const double utang2Int = a.v0[c];
     const double utangInt = fmax(umin, (utang1Int * utang1Int + utang2Int * utang2Int));
     if (UNO) {
-      const double dT = ((a.thl0[c] + a.thl0[c - sy]) - (Twall + Twall)) * 0.5;
+      const double dT = (a.thl0 ? ((a.thl0[c] + a.thl0[c - sy]) - (Twall + Twall)) : ((a.thl_air + a.thl_air) - (Twall + Twall))) * 0.5;
       ctm = uno_m(a.prt, l_, logzh, sqdz, grav * delta * dT * 2 / ((Twall + Twall) * utangInt), fkar2);
     }
     const double dummy = fabs(utang2Int) * sqrt(utangInt) * ctm;
@@ -330,8 +331,9 @@ int k_bottom(udc_handle *h, bool wrap_vp) {
   a.tau_x = h->bottom_diag[0]; a.tau_y = h->bottom_diag[1]; a.thl_flux = h->bottom_diag[2];
   const bool have_thl = (int)h->fields.size() > UDC_THL0 && h->fields[UDC_THL0];
   a.thl0 = have_thl ? h->fields[UDC_THL0] : nullptr;
+  a.thl_air = h->floor_thl_air;
   const bool uno = h->floor_bcbotm == 2;
-  if ((uno || h->floor_bcbott == 2) && !have_thl) { udc_set_error("bottom: the wfuno floor needs the temperature equation (udc_set_tempeq)"); return 1; }
+  if (((uno && !h->floor_thl_air_on) || h->floor_bcbott == 2) && !have_thl) { udc_set_error("bottom: the wfuno floor reads the temperature of the first level: udc_set_tempeq, or udc_set_floor_air_temperature when the temperature equation is off"); return 1; }
   for (int n : h->slots) {
     if (h->slot[n].tke) continue;      // e12 has no floor-flux correction in `bottom`
     if (n == 15 && h->floor_bcbott == 2) a.thl_wf = a.nsv;

@@ -246,8 +246,16 @@ contains
   !> floor of the domain (src/modibm.f90:1998-2100)
   subroutine bottom
     use udc_iface
+    use modglobal, only: ltempeq, BCbotm, ib, jb, kb
+    use modfields, only: thl0
+    logical, save :: air_set = .false.
     if (.not. (lbottom .or. loneeqn_dev())) return
     call udc_begin(.true.)
+    if (lbottom .and. BCbotm == 2 .and. .not. ltempeq .and. .not. air_set) then
+      ! temperature equation off: thl0 keeps its start-up profile for ever and wfuno still reads its first level (:2022)
+      call udc_check(udc_set_floor_air_temperature(udc_h, real(thl0(ib, jb, kb), c_double)), 'udc_set_floor_air_temperature')
+      air_set = .true.
+    end if
     if (lbottom .and. .not. udc_bottom_diag_on) then      ! tau_x, tau_y, thl_flux: kept on the device, pulled with the fields
       call udc_check(udc_bottom_diagnostics(udc_h, 1_c_int), 'udc_bottom_diagnostics')
       udc_bottom_diag_on = .true.

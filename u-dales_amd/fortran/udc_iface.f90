@@ -169,6 +169,11 @@ module udc_iface
       import :: c_int, c_ptr
       type(c_ptr), value :: h
     end function
+    integer(c_int) function udc_set_floor_air_temperature(h, thl_kb) bind(C, name='udc_set_floor_air_temperature')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), value :: thl_kb
+    end function udc_set_floor_air_temperature
     integer(c_int) function udc_set_floor_wf(h, bcbotm, bcbott, thls, z0h, prandtlturb) bind(C, name='udc_set_floor_wf')
       import :: c_ptr, c_int, c_double
       type(c_ptr), value :: h

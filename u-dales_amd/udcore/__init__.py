@@ -16,8 +16,6 @@ def from_deck(deck, device=0, rank=0, nranks=1):
     bcbotm, bcbott = int(deck.get("BC", "BCbotm")), int(deck.get("BC", "BCbotT"))
     if lbottom and bcbotm not in (2, 3):
         raise ValueError("lbottom: BCbotm must be 2 (wfuno) or 3 (wfmneutral), src/modibm.f90:2021-2029")
-    if lbottom and bcbotm == 2 and not deck.get("PHYSICS", "ltempeq"):
-        raise ValueError("lbottom with BCbotm = 2 (wfuno) needs ltempeq on the device path; use BCbotm = 3 for a neutral floor")
     core = DynCore(g, sgs=sgs, bctopm=int(deck.get("BC", "BCtopm")), nsv=int(deck.get("SCALARS", "nsv")),
                    prandtli=prandtli, c_vreman=c_vreman, csz=csz, device=device, rank=rank, nranks=nranks,
                    lbottom=lbottom, z0=float(deck.get("BC", "z0")),
@@ -30,6 +28,9 @@ def from_deck(deck, device=0, rank=0, nranks=1):
                         bctopt=int(deck.get("BC", "BCtopT")), wttop=float(deck.get("BC", "wttop")),
                         thl_top=float(deck.get("BC", "thl_top")), bcbott=int(deck.get("BC", "BCbotT")),
                         wtsurf=float(deck.get("BC", "wtsurf")), thlpcar=getattr(deck, "thlpcar", None))
+    if lbottom and bcbotm == 2 and not deck.get("PHYSICS", "ltempeq"):
+        # the reference's thl0 stays at prof.inp's profile when the temperature equation is off; wfuno reads its first level
+        core.set_floor_air_temperature(float(deck.thl[0]))
     if lbottom and (bcbotm == 2 or (bcbott == 2 and deck.get("PHYSICS", "ltempeq"))):
         core.set_floor_wf(bcbotm, bcbott, float(deck.get("BC", "thls")), float(deck.get("BC", "z0h")), 0.71)
     if deck.get("PHYSICS", "lmoist"):

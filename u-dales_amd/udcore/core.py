@@ -196,6 +196,10 @@ class DynCore:
     def scalsource(self):
         L._check(self.lib.udc_scalsource(self.h), "udc_scalsource")
 
+    def set_floor_air_temperature(self, thl_kb):
+        """ltempeq off + wfuno floor: the frozen temperature of the first level (include/udcore.h)."""
+        L._check(self.lib.udc_set_floor_air_temperature(self.h, C.c_double(thl_kb)), "udc_set_floor_air_temperature")
+
     def set_floor_wf(self, bcbotm=3, bcbott=1, thls=-1., z0h=-1., prandtlturb=0.71):
         """Floor wall function choice of `bottom` (BCbotm 2 / BCbotT 2 = wfuno), see include/udcore.h udc_set_floor_wf."""
         L._check(self.lib.udc_set_floor_wf(self.h, int(bcbotm), int(bcbott), C.c_double(thls), C.c_double(z0h),

@@ -30,7 +30,9 @@ DEFAULTS = {
     "SCALARS": dict(nsv=0, lscasrc=False, nscasrc=0, lscasrcl=False, nscasrcl=0),
     "NAMSUBGRID": dict(lsmagorinsky=False, lvreman=True, loneeqn=False, c_vreman=0.07, cs=-1.,
                        cf=2.5, cn=0.76, Rigc=0.25, Prandtl=0.333, ldelta=False, lbuoycorr=False),
-    "OUTPUT": dict(ltdump=False, lxytdump=False, tstatsdump=10000., tsample=5., tstatstart=0.),
+    "OUTPUT": dict(ltdump=False, lxytdump=False, lmintdump=False, tstatsdump=10000., tsample=5., tstatstart=0.,
+                   lfielddump=False, tfielddump=10000., fieldvars="", lydump=False, lytdump=False, lxydump=False, ltkedump=False,
+                   lkslicedump=False, lislicedump=False, ljslicedump=False),
     "WALLS": dict(nfcts=-1, lbottom=False, iwallmom=2, iwalltemp=1, iwallmoist=1, nsolpts_u=0, nsolpts_v=0, nsolpts_w=0, nsolpts_c=0,
                   nbndpts_u=0, nbndpts_v=0, nbndpts_w=0, nbndpts_c=0),
     "ORACLE": dict(nsub=3, nspin=2, lforces=True, scal_a=1.0, scal_b=0.0),
@@ -112,6 +114,12 @@ def _value(tok: str):
         return t
 
 
+def _split_values(s: str):
+    """Value tokens of a namelist line: separated by commas / blanks, except inside a quoted string
+    (fieldvars = 'u0,v0,w0' is one value)."""
+    return [m.group(0) for m in re.finditer(r"'[^']*'|\"[^\"]*\"|[^,\s]+", s)]
+
+
 def parse_namelists(text: str) -> dict:
     """Returns {GROUP: {name: value-or-list}} for every &GROUP ... / block in the text.
 
@@ -144,10 +152,10 @@ def parse_namelists(text: str) -> dict:
         # parts = [pre, name1, vals1, name2, vals2, ...]
         pre = parts[0].strip()
         if pre and last is not None:
-            grp[last] = _as_list(grp[last]) + [_value(v) for v in _expand([v for v in re.split(r"[,\s]+", pre) if v])]
+            grp[last] = _as_list(grp[last]) + [_value(v) for v in _expand(_split_values(pre))]
         for q in range(1, len(parts), 2):
             name, vals = parts[q], parts[q + 1]
-            vv = [_value(v) for v in _expand([v for v in re.split(r"[,\s]+", vals.strip()) if v])]
+            vv = [_value(v) for v in _expand(_split_values(vals.strip()))]
             grp[name] = vv[0] if len(vv) == 1 else vv
             last = name
         if close:
@@ -190,7 +198,9 @@ class Deck:
         """A name the reference's namelist of that group does not hold stops the reference; so it does here."""
         for grp, vals in self.nml.items():
             if grp not in KNOWN:
-                raise ValueError(f"{self.path}: unknown namelist group &{grp}")
+                # a Fortran namelist read looks for the group it names and skips every other one: groups only the
+                # reference's pre-processing reads (&INP, &INPS of tools/) or that no routine reads any more pass unseen
+                continue
             for k in vals:
                 if k.lower() not in KNOWN[grp]:
                     where = [g for g, names in KNOWN.items() if k.lower() in names]

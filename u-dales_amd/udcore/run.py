@@ -44,8 +44,10 @@ def check_supported(deck):
         _refuse("only periodic lateral boundaries (BCxm = BCym = 1) are on the device path")
     if int(g("DYNAMICS", "ipoiss")) != 0 or int(g("BC", "BCzp")) != 1:
         _refuse("only ipoiss = 0 (FFT in x, y) with BCzp = 1 is on the device path")
-    if int(g("RUN", "nprocx")) != 1:
-        _refuse("the device path decomposes in y only: set nprocx = 1")
+    # &RUN nprocx / nprocy describe the CPU run's pencil layout; the device path splits y over however many GPUs it is
+    # launched on and the fields do not depend on it.  (One thing in the reference does: the immersed boundary's point masks
+    # wrap periodically only in a direction that is split over ranks -- udcore.ibm hands the deck's values to
+    # udc_set_ibm_mask_wrap so that the run reproduces the reference run of this deck.)
 
 
 def courant_default(deck):
@@ -65,7 +67,41 @@ def courant_default(deck):
     return c
 
 
-def main(argv=None):
+class FieldDump:
+    """Instantaneous 3-D fields every tfielddump seconds (src/modfielddump.f90: &OUTPUT lfielddump, tfielddump, fieldvars).
+    The reference writes NetCDF-4 `fielddump.xxx.xxx.expnr.nc` per rank; here `fielddump.<rank>.<expnr>.npz`, one array per
+    variable and record (float32 like the reference's output), variables named as in fieldvars: u0, v0, w0, th (thl0),
+    ql / qt (qt0), p0 (pres0), s1.. (scalars).  Interior cells kb..ke."""
+    NAMES = {"u0": "u0", "v0": "v0", "w0": "w0", "th": "thl0", "qt": "qt0", "p0": "pres0"}
+
+    def __init__(self, core, tfielddump, fieldvars, wdir, expnr, rank=0):
+        from . import lib as L
+        self.core, self.dt, self.wdir, self.expnr, self.rank = core, float(tfielddump), wdir, expnr, rank
+        self.vars = [v.strip() for v in str(fieldvars).split(",") if v.strip()]
+        for v in self.vars:
+            if v not in self.NAMES and not (v[0] == "s" and v[1:].isdigit() and 1 <= int(v[1:]) <= core.nsv):
+                _refuse(f"&OUTPUT fieldvars: '{v}' is not available on the device path (u0 v0 w0 th qt p0 s1..)")
+        self.L, self.tnext, self.times, self.rec = L, self.dt, [], {v: [] for v in self.vars}
+
+    def step(self, timee):
+        if timee < self.tnext:                                  # src/modfielddump.f90: tnextfielddump
+            return False
+        self.tnext += self.dt
+        import numpy as np
+        for v in self.vars:
+            if v in self.NAMES:
+                a = self.core.download(self.NAMES[v])[1:-1, 1:-1, 1:-1]
+            else:
+                a = self.core.download(self.L.scalar_field(self.L.SV0, int(v[1:]) - 1), halo=2)[2:-2, 2:-2, 2:-2]
+            self.rec[v].append(a.astype(np.float32))
+        self.times.append(timee)
+        np.savez(os.path.join(self.wdir, f"fielddump.{self.rank:03d}.{self.expnr:03d}.npz"), time=np.array(self.times),
+                 **{v: np.array(r) for v, r in self.rec.items()})
+        return True
+
+
+def main(argv=None, at_end=None):
+    """at_end(core, tdump): called before the core is closed (tests look at the state and the statistics there)."""
     ap = argparse.ArgumentParser(prog="python -m udcore.run", description=__doc__.split("\n\n")[0])
     ap.add_argument("namoptions")
     ap.add_argument("--steps", type=int, default=0, help="stop after this many full time steps (default: run to `runtime`)")
@@ -117,7 +153,13 @@ def main(argv=None):
     core.dt, core.timee, core.rk3step = dt, timee, 0
     forcings = LevelForcings(core, deck)
     tdump = None
-    if bool(deck.get("OUTPUT", "ltdump")) or bool(deck.get("OUTPUT", "lxytdump")):      # src/modstatsdump.f90: tdump, xytdump
+    for sw in ("lydump", "lytdump", "lxydump", "ltkedump", "lkslicedump", "lislicedump", "ljslicedump"):
+        if deck.is_set("OUTPUT", sw) and deck.get("OUTPUT", sw):
+            sys.stderr.write(f" WARNING: &OUTPUT {sw}: this dump is not written by the device runner (tdump, xytdump, mintdump, fielddump are)\n")
+    fdump = None
+    if bool(deck.get("OUTPUT", "lfielddump")):
+        fdump = FieldDump(core, deck.get("OUTPUT", "tfielddump"), deck.get("OUTPUT", "fieldvars"), wdir, iexp, rank)
+    if bool(deck.get("OUTPUT", "ltdump")) or bool(deck.get("OUTPUT", "lxytdump")) or bool(deck.get("OUTPUT", "lmintdump")):      # src/modstatsdump.f90
         from .stats import TDump
         lists = None
         if deck.get("RUN", "libm"):
@@ -127,6 +169,7 @@ def main(argv=None):
                       float(deck.get("OUTPUT", "tstatstart")), wdir=wdir, expnr=iexp, xyt=bool(deck.get("OUTPUT", "lxytdump")),
                       ibm_lists=lists, wrap=(int(deck.get("RUN", "nprocx")) > 1, int(deck.get("RUN", "nprocy")) > 1),
                       jtot=int(deck.get("DOMAIN", "jtot")), j0=rank * nyl, nyl=nyl)
+        tdump.mint = bool(deck.get("OUTPUT", "lmintdump"))
     # (the reference restarts the restart clock and the step counter on a warm start: tnextrestart = trestart,
     # ntrun = 0, src/modglobal.f90:869; this runner keeps counting from the file it started from, so that the files
     # of a continued run do not overwrite those of the first leg)
@@ -144,6 +187,8 @@ def main(argv=None):
                 say(f"  tdump written at timee = {core.timee:.6f} ({tdump.nsamples} samples so far)")
         nsteps += 1
         ntrun += 1
+        if fdump is not None and fdump.step(core.timee):
+            say(f"  fielddump written at timee = {core.timee:.6f}")
         if core.timee >= tnext:                                # writerestartfiles, src/modsave.f90:77
             tnext += trestart
             R.save_restart(core, wdir, iexp, ntrun, core.timee, core.dt, rank=rank, fill={"thl0": deck.thl[0]})
@@ -158,6 +203,8 @@ def main(argv=None):
     cells = core.g.nx * core.g.ny * core.g.nz
     say(f"udcore.run: {nsteps} steps to timee = {core.timee:.6f} in {wall:.2f} s "
         f"({cells * 3 * nsteps / max(wall, 1e-9):.3e} cell-updates/s), divmax = {divmax:.2e}; restart: {os.path.basename(paths[0])}")
+    if at_end is not None:
+        at_end(core, tdump)
     core.close()
     return 0
 

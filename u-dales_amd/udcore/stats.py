@@ -76,6 +76,7 @@ class TDump:
         self.tsamplep, self.tstatsdumpp = 0., 0.
         self.wdir, self.expnr = wdir, expnr
         self.nsamples, self.dumps, self.xyt_on, self.xyt_dumps = 0, [], bool(xyt), []
+        self.mint = False             # mintdump (src/modstatsdump.f90:1670-1684): ut, vt, wt, thlt, qtt, pt of the same accumulators
         L._check(core.lib.udc_stats_enable(core.h, 3 if xyt else 1), "udc_stats_enable")
         if xyt and ibm_lists is not None:
             g = core.g
@@ -167,6 +168,10 @@ class TDump:
         return what
 
     def write(self):
+        if self.mint:
+            keep = [k for k in ("ut", "vt", "wt", "thlt", "qtt", "pt") if k in self.dumps[0][1]]
+            np.savez(os.path.join(self.wdir, f"mintdump.{self.expnr:03d}.npz"), time=np.array([t for t, _ in self.dumps]),
+                     **{k: np.array([o[k] for _, o in self.dumps]).astype(np.float32) for k in keep})
         if self.xyt_on:
             np.savez(os.path.join(self.wdir, f"xytdump.{self.expnr:03d}.npz"), time=np.array([t for t, _ in self.xyt_dumps]),
                      **{k: np.array([o[k] for _, o in self.xyt_dumps]) for k in self.xyt_dumps[0][1]})
