@@ -59,7 +59,9 @@ program ref_driver
   use modibm, only: createmasks, bottom, lbottom, ibmnorm, solid, diffu_corr, diffv_corr, diffw_corr, diffc_corr, &
                     initibmnorm, solid_info_u, solid_info_v, solid_info_w, solid_info_c, bound_info_u, bound_info_v, &
                     bound_info_w, bound_info_c, mask_u, mask_v, mask_w, mask_c, nsolpts_u, nsolpts_v, nsolpts_w, nsolpts_c, &
-                    nbndpts_u, nbndpts_v, nbndpts_w, nbndpts_c
+                    nbndpts_u, nbndpts_v, nbndpts_w, nbndpts_c, nfctsecs_u, nfctsecs_v, nfctsecs_w, nfctsecs_c, &
+                    lnorec, initibm, ref_ibmwallfun => ibmwallfun      ! the facet wall functions: the reference's own set-up and loop
+  use initfac, only: readfacetfiles
   use readinput, only: read_sparse_ijk
 #endif
   use modstatsdump, only: initstatsdump, statsdump  ! src/modstatsdump.f90: the sampling half, compiled from the reference (extract_statsdump.sh)
@@ -108,7 +110,12 @@ program ref_driver
 #ifdef UDC_DROPIN
   call initibm                              ! src/program.f90:93-95
 #else
-  call ibm_setup
+  if (libm .and. iwallmom > 1) then         ! src/program.f90:91-93
+    call readfacetfiles
+    call initibm
+  else
+    call ibm_setup
+  end if
 #endif
   call createmasks
   lstats = ltdump .or. lxytdump
@@ -358,10 +365,15 @@ contains
     deallocate (rhs)
   end subroutine ibm_setup
 
-  ! ---- ibmwallfun without wall functions (iwallmom = 1; src/modibm.f90:1216-1218, 1262-1264)
+  ! ---- ibmwallfun: with facet wall functions (iwallmom > 1) the reference's own routine; without them (iwallmom = 1) its
+  !      dispatch restated (src/modibm.f90:1216-1218, 1262-1264)
   subroutine ibmwallfun
     integer :: n
     if (.not. libm) return
+    if (iwallmom > 1) then
+      call ref_ibmwallfun
+      return
+    end if
     call diffu_corr
     call diffv_corr
     call diffw_corr
@@ -393,8 +405,13 @@ contains
       bcqfxm, bcqfxp, bcqfym, bcqfyp, bcqfz
     namelist /SCALARS/ nsv, lscasrc, nscasrc, lscasrcl, nscasrcl
     namelist /OUTPUT/ ltdump, lxytdump, tsample, tstatsdump, tstatstart, lfielddump, tfielddump, fieldvars      ! (the field dump itself is not run here)
+#ifdef UDC_DROPIN
     namelist /WALLS/ nfcts, lbottom, iwallmom, iwalltemp, iwallmoist, nsolpts_u, nsolpts_v, nsolpts_w, nsolpts_c, &
       nbndpts_u, nbndpts_v, nbndpts_w, nbndpts_c
+#else
+    namelist /WALLS/ nfcts, lbottom, iwallmom, iwalltemp, iwallmoist, nsolpts_u, nsolpts_v, nsolpts_w, nsolpts_c, &
+      nbndpts_u, nbndpts_v, nbndpts_w, nbndpts_c, nfctsecs_u, nfctsecs_v, nfctsecs_w, nfctsecs_c, lnorec
+#endif
     open (ifnamopt, file=fname_options, status='old', iostat=ierr)
     if (ierr /= 0) then
       write (0, *) 'ERROR: cannot open ', trim(fname_options)
@@ -412,10 +429,12 @@ contains
     read (ifnamopt, OUTPUT, iostat=ierr); call chk(ierr, 'OUTPUT')
     close (ifnamopt)
     nprocx = 1; nprocy = nprocs     ! y-slabs over however many ranks were launched (1 in the np1 build)
+#ifdef UDC_DROPIN
     if (libm .and. iwallmom /= 1) then
-      write (0, *) 'ERROR: ref_driver: the facet wall functions (iwallmom > 1, src/modibm.f90:1286) need initfac / NetCDF'
+      write (0, *) 'ERROR: ref_driver: the drop-in modibm has no facet wall functions (iwallmom > 1, src/modibm.f90:1286)'
       stop 1
     end if
+#endif
     allocate (wsvtop(1:max(nsv, 1))); wsvtop = 0.      ! src/modstartup.f90:518-519
     if (nsv > 0) wsvtop(1:nsv) = wsvtopdum(1:nsv)
     allocate (sv_top(1:max(nsv, 1))); sv_top = 0.
