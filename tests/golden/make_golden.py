@@ -30,7 +30,7 @@ REF = os.path.join(ROOT, "oracle", "_ref", "udales_ref")
 
 def deck(iexpnr, nx, ny, nz, dx=0.5, dy=0.5, dtmax=0.25, sgs="vreman", nsv=0, bctopm=1,
          oracle="", lles=True, randu=0.01, floor=False, z0=0.05, physics="", bc="", bcbotm=3, scalars="", dynamics="", inlet="", ladaptive=False, chemistry="",
-         ibm=None, output=""):
+         ibm=None, output="", iwallmom=1):
     sub = {"oneeqn": "loneeqn = .true.\nlvreman = .false.\nlsmagorinsky = .false.",
            "vreman": "lvreman = .true.\nlsmagorinsky = .false.",
            "vreman_bc": "lvreman = .true.\nlsmagorinsky = .false.\nlbuoycorr = .true.",
@@ -66,7 +66,7 @@ BCtopm = {bctopm}
 {('BCbotm = ' + str(bcbotm) + chr(10) + 'z0 = ' + repr(z0)) if floor else ''}
 {bc}
 /
-{('&WALLS' + chr(10) + 'nfcts = 0' + chr(10) + ('lbottom = .true.' + chr(10) if floor else '') + (ibm_walls(ibm, nx, ny, nz) if ibm else '') + '/') if (floor or ibm) else ''}
+{('&WALLS' + chr(10) + 'nfcts = 0' + chr(10) + ('lbottom = .true.' + chr(10) if floor else '') + ((ibm_walls(ibm, nx, ny, nz) if iwallmom == 1 else ibm_walls_wf(ibm, nx, ny, nz, dx, dy, 0.5, iwallmom)) if ibm else '') + '/') if (floor or ibm) else ''}
 &SCALARS
 nsv = {nsv}{(chr(10) + scalars) if scalars else ''}
 /
@@ -117,6 +117,80 @@ def write_ibm_files(d, blocks, nx, ny, nz):
                 f.write("# position (i,j,k)\n")
                 for p in pts:
                     f.write("%5d %5d %5d\n" % p)
+
+
+# ---- facets of the blocks for the reference's wall functions (iwallmom = 2, 3): facets.inp, factypes.inp, Tfacinit.inp and the
+#      facet_sections_<grid>.txt lists (facet, area, boundary point, distance) the pre-processing would write.  The geometry is
+#      that of the blocks -- one facet per block face; a section wherever a fluid-boundary point has a solid neighbour -- bent
+#      on purpose in two places so that every branch of initibmwallfun / wallfunmom runs: the second block's east face carries
+#      an oblique normal (rotation of the stress, a reconstruction line that leaves the cell sideways) and the second facet
+#      type is so rough that the log law is ill-defined at half a cell (reconstruction points, trilinear interpolation).
+FACET_TYPES = [(1, 0.01, 0.001), (2, 0.12, 0.0035)]      # id, z0, z0h
+
+
+def facet_files(blocks, nx, ny, nz, dx, dy, dz):
+    """-> (files {name: text}, counts {grid: nfctsecs}, nfcts)."""
+    import numpy as np
+    L = ibm_lists(blocks, nx, ny, nz)
+    owner = np.zeros((nz + 2, ny, nx), dtype=int)          # block number (1-based) of a solid c cell
+    for b, (i0, i1, j0, j1, k1) in enumerate(blocks):
+        owner[1:k1 + 1, j0 - 1:j1, i0 - 1:i1] = b + 1
+    # a solid u / v / w point belongs to the block of one of the cells it touches
+    own = {"c": owner,
+           "u": np.maximum(owner, np.roll(owner, 1, axis=2)), "v": np.maximum(owner, np.roll(owner, 1, axis=1))}
+    ow = owner.copy(); ow[1:] = np.maximum(owner[1:], owner[:-1]); own["w"] = ow
+    faces = ["top", "west", "east", "south", "north"]      # facet number = 5 (block - 1) + 1 + index
+    normal = {"top": (0., 0., 1.), "west": (-1., 0., 0.), "east": (1., 0., 0.), "south": (0., -1., 0.), "north": (0., 1., 0.)}
+    facets = []
+    for b in range(len(blocks)):
+        for f in faces:
+            n = normal[f]
+            if b == 1 and f == "east":
+                n = (0.8, 0.6, 0.)
+            facets.append((2 if (b == 1 and f in ("top", "north")) else 1, n))
+    nfcts = len(facets)
+    files = {"facets": "# type, normal\n" + "".join("%d %.4f %.4f %.4f\n" % ((t,) + n) for t, n in facets),
+             "factypes": "# walltype\n# -\n# wallid lGR z0 z0h al em d1 d2 d3 C1 C2 C3 l1 l2 l3 k1 k2 k3 k4\n" +
+                         "".join("%d 0 %.4f %.5f 0.5 0.85 0.1 0.2 0.2 1875000 1875000 1875000 0.75 0.75 0.75 4e-7 4e-7 4e-7 4e-7\n" % t for t in FACET_TYPES),
+             "Tfacinit": "# initial facet temperatures\n" + "".join("%.2f\n" % (289.5 + 0.25 * (q % 4)) for q in range(nfcts))}
+    counts = {}
+    # direction to the solid neighbour -> the face of that neighbour's block the point looks at
+    dirs = [((1, 0, 0), "west", dy * dz, dx), ((-1, 0, 0), "east", dy * dz, dx), ((0, 1, 0), "south", dx * dz, dy),
+            ((0, -1, 0), "north", dx * dz, dy), ((0, 0, -1), "top", dx * dy, dz)]
+    for g in "uvwc":
+        sol = own[g]
+        rows = []
+        for q, (i, j, k) in enumerate(L[g][1]):
+            for (di, dj, dk), face, area, h in dirs:
+                ii, jj, kk = (i - 1 + di) % nx, (j - 1 + dj) % ny, k + dk
+                if kk < 1 or kk > nz:
+                    continue
+                b = sol[kk, jj, ii]
+                if g == "w" and kk == 1 and b == 0:
+                    continue
+                if b:
+                    # half a cell from the face, a whole one along the grid's own staggering direction
+                    stag = {"u": (1, 0, 0), "v": (0, 1, 0), "w": (0, 0, 1)}.get(g, (0, 0, 0))
+                    dist = h if (abs(di), abs(dj), abs(dk)) == stag else 0.5 * h
+                    rows.append((5 * (b - 1) + 1 + faces.index(face), area, q + 1, dist))
+        counts[g] = len(rows)
+        files[f"sections_{g}"] = " # facet      area flux point distance\n" + "".join("%8d %9.4f %10d %8.4f\n" % r for r in rows)
+    return files, counts, nfcts
+
+
+def ibm_walls_wf(blocks, nx, ny, nz, dx, dy, dz, iwallmom):
+    L = ibm_lists(blocks, nx, ny, nz)
+    _, counts, nfcts = facet_files(blocks, nx, ny, nz, dx, dy, dz)
+    return (f"iwallmom = {iwallmom}\nnfcts = {nfcts}\n" + "".join(f"nsolpts_{g} = {len(L[g][0])}\nnbndpts_{g} = {len(L[g][1])}\n" for g in "uvwc")
+            + "".join(f"nfctsecs_{g} = {counts[g]}\n" for g in "uvwc"))
+
+
+def write_facet_files(d, iexp, blocks, nx, ny, nz, dx, dy, dz):
+    files, _, _ = facet_files(blocks, nx, ny, nz, dx, dy, dz)
+    for name, text in files.items():
+        fn = f"facet_{name}.txt" if name.startswith("sections_") else f"{name}.inp.{iexp:03d}"
+        with open(os.path.join(d, fn), "w") as f:
+            f.write(text)
 
 
 def zlevels(nz, dz0=0.5, stretch=1.0):
@@ -433,6 +507,21 @@ CASES.update({
     "run_floor_uno_nothl_16x8x12s": ("run", 65, 16, 8, 12, dict(sgs="smag", nsv=1, floor=True, bcbotm=2, bc="z0h = 0.005",
                                                                 oracle="nsub = 6\ndump_at = 3, 6"), 1.06),
 })
+# facet wall functions on the blocks (src/modibm.f90:1286 wallfunmom; the reference's default iwallmom = 2 with the
+# stability functions on the facet temperatures, iwallmom = 3 neutral): uniform z (the reference's reconstruction assumes it)
+for _n in ("k_ibm_wf3_16x12x10", "k_ibm_wf2_16x12x10", "run_ibm_wf2_16x12x10"):
+    IBM_BLOCKS[_n] = IBM_BLOCKS["run_ibm_16x12x10"]
+WF_CASES = {"k_ibm_wf3_16x12x10": 3, "k_ibm_wf2_16x12x10": 2, "run_ibm_wf2_16x12x10": 2}
+CASES.update({
+    "k_ibm_wf3_16x12x10": ("kernels", 66, 16, 12, 10, dict(sgs="smag", nsv=1, floor=True, randu=0.05, ibm=IBM_BLOCKS["run_ibm_16x12x10"],
+                                                           iwallmom=3, oracle="nspin = 4"), 1.0),
+    "k_ibm_wf2_16x12x10": ("kernels", 67, 16, 12, 10, dict(sgs="vreman", nsv=1, floor=True, randu=0.05, ibm=IBM_BLOCKS["run_ibm_16x12x10"],
+                                                           iwallmom=2, physics="ltempeq = .true.\nlbuoyancy = .true.", bc=_IBM_THL_BC,
+                                                           oracle="nspin = 4"), 1.0),
+    "run_ibm_wf2_16x12x10": ("run", 68, 16, 12, 10, dict(sgs="vreman", nsv=1, floor=True, randu=0.05, ibm=IBM_BLOCKS["run_ibm_16x12x10"],
+                                                         iwallmom=2, physics="ltempeq = .true.\nlbuoyancy = .true.", bc=_IBM_THL_BC,
+                                                         oracle="nsub = 9\ndump_at = 3, 9"), 1.0),
+})
 LSF_ONLY = ("k_lsf_12x8x24", "k_lsfq_12x8x20", "k_fix1_12x8x6")
 THL_CASES = {"k_tke_moist_12x8x8": dict(dthl=0.25, qt=0.0118, dqt=-8e-5, tke=0.06),
              "run_moistnr_16x8x12s": dict(dthl=0.25, qt=0.0119, dqt=-6e-5),
@@ -450,6 +539,7 @@ THL_CASES = {"k_tke_moist_12x8x8": dict(dthl=0.25, qt=0.0118, dqt=-8e-5, tke=0.0
              "k_ibm_thl_16x12x10": dict(dthl=0.3), "run_ibm_thl_16x12x10": dict(dthl=0.25), "run_ibm_thlcons_16x12x10": dict(dthl=0.25),
              "run_ibm_qt_16x12x10": dict(dthl=0.25, qt=0.007, dqt=-2e-4),
              "run_stats_16x8x12s": dict(dthl=0.25), "run_stats_ibm_16x12x10": dict(dthl=0.25),
+             "k_ibm_wf2_16x12x10": dict(dthl=0.3), "run_ibm_wf2_16x12x10": dict(dthl=0.25),
              "k_vreman_buoycorr_12x8x10": dict(dthl=0.004), "run_vreman_buoycorr_16x8x12s": dict(dthl=0.004)}
 
 
@@ -544,6 +634,8 @@ def main():
         write_case(cdir, iexp, deck(iexp, nx, ny, nz, **kw), zlevels(nz, 0.5, stretch), **THL_CASES.get(name, {}))
         if name in IBM_BLOCKS:
             write_ibm_files(cdir, IBM_BLOCKS[name], nx, ny, nz)
+        if name in WF_CASES:
+            write_facet_files(cdir, iexp, IBM_BLOCKS[name], nx, ny, nz, kw.get("dx", 0.5), kw.get("dy", 0.5), 0.5)
         with tempfile.TemporaryDirectory() as tmp:
             for fn in os.listdir(cdir):
                 shutil.copy(os.path.join(cdir, fn), tmp)
