@@ -239,8 +239,8 @@ int udc_level_forcings(udc_handle *h, int when);
  *   udc_ibmnorm     ibmnorm (:697): solid (:748) -- um, vm, wm and their tendencies zeroed at the solid points, svm / svp set
  *                   to the mean of their fluid neighbours -- called after masscorr (src/program.f90:171)
  * Both are part of udc_substep once committed.  With an immersed boundary udc_masscorr and udc_slab_average(s) average over
- * the fluid cells only (avexy_ibm, src/modmpi.f90:623-664, with IIu / IIv / IIc).  Not available yet: the facet wall
- * functions (wallfunmom :1286, wallfunheat :1436; hence thl / qt with immersed boundaries). */
+ * the fluid cells only (avexy_ibm, src/modmpi.f90:623-664, with IIu / IIv / IIc).  Not available: the facet heat / moisture wall
+ * functions (wallfunheat :1436) -- adiabatic, impermeable walls only. */
 enum { UDC_IBM_U = 0, UDC_IBM_V = 1, UDC_IBM_W = 2, UDC_IBM_C = 3 };
 int udc_set_ibm_points(udc_handle *h, int grid, const int *solid, int nsolid, const int *bound, int nbound);
 int udc_set_ibm_mask_wrap(udc_handle *h, int wrapx, int wrapy);
@@ -251,6 +251,22 @@ int udc_set_ibm_mask_wrap(udc_handle *h, int wrapx, int wrapy);
  * which is exact for prescribed zero wall fluxes (iwalltemp = iwallmoist = 1, bctf* = bcqf* = 0; anything else is refused
  * by the host side). */
 int udc_set_ibm_conservative(udc_handle *h, int lconservativeibm);
+/* Facet wall functions for momentum (wallfunmom, src/modibm.f90:1286-1433; &WALLS iwallmom: 2 = with the Uno et al. stability
+ * functions on the facet temperatures, the reference's default; 3 = neutral log law; 1 = none).  udc_set_ibm_wallfun: the
+ * choice, prandtlturb and the level coordinates zf(1:ktot+1), zh(1:ktot+1) the reconstruction interpolates on.
+ * udc_set_ibm_sections: the facet sections of one velocity grid as initibmwallfun (:273-644) leaves them, skipped sections
+ * left out, in the order of facet_sections_<grid>.txt -- per section the fluid-boundary cell (global 1-based i, j, k), the
+ * section's area, the wall distance of the cell, the facet's unit normal, roughness lengths z0 / z0h and surface temperature
+ * (facT(:,1); read for iwallmom = 2 only), whether the velocity is taken at the cell itself (comprec = 1) or at the
+ * reconstruction point recpt (x, y, z) inside the cells recids[4][3] (lower corners on the u, v, w, c grids, global 1-based),
+ * and the c-grid fluid masks of the two cells interp_temperature_* averages (tmask[2]: the cell, its lower neighbour along the
+ * grid's direction).  The host side that builds these from the reference's input files: udcore/facets.py.  Every slab
+ * passes all sections; each keeps the ones of its rows.  udc_ibmwallfun then applies the wall stress before the diffusion
+ * corrections, as the reference does. */
+int udc_set_ibm_wallfun(udc_handle *h, int iwallmom, double prandtlturb, const double *zf, const double *zh);
+int udc_set_ibm_sections(udc_handle *h, int grid, int n, const int *cell, const double *area, const double *dist, const double *norm,
+                         const double *z0, const double *z0h, const double *tsurf, const int *comprec, const double *recpt,
+                         const int *recids, const double *tmask);
 int udc_ibm_commit(udc_handle *h);
 int udc_ibmwallfun(udc_handle *h);
 int udc_ibmnorm(udc_handle *h);

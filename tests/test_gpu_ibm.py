@@ -19,9 +19,11 @@ def _core(name, iexp):
     return d, udcore.from_deck(d)
 
 
-@pytest.mark.parametrize("name,iexp", [("k_ibm_16x12x10", 54), ("k_ibm_thl_16x12x10", 58)])
+@pytest.mark.parametrize("name,iexp", [("k_ibm_16x12x10", 54), ("k_ibm_thl_16x12x10", 58), ("k_ibm_wf3_16x12x10", 66), ("k_ibm_wf2_16x12x10", 67)])
 def test_ibm_routines_match_reference(name, iexp):
-    """The second deck adds temperature with buoyancy: diffc_corr and solid (volume-mean value) on thl, advecc2nd_corr_liberal,
+    """The wf decks: the facet wall functions for momentum (wallfunmom, neutral and with the stability functions on the facet
+    temperatures; sections with reconstruction points and an oblique facet normal) ahead of the diffusion corrections.
+    The second deck adds temperature with buoyancy: diffc_corr and solid (volume-mean value) on thl, advecc2nd_corr_liberal,
     and the slab averages over the fluid cells (thl0av; thvh through the buoyancy term of the run fixtures)."""
     fix = load_fixture(name)
     d, core = _core(name, iexp)

@@ -235,6 +235,7 @@ extern "C" int udc_destroy(udc_handle *h) {
   comm_destroy(h);
   ibm_destroy(h);
   stats_destroy(h);
+  ibm_wf_destroy(h);
   for (int q = 0; q < 4; ++q) if (h->halo_buf[q]) hipFree(h->halo_buf[q]);
   for (auto &f : h->level_forcings) { if (f.A) hipFree(f.A); if (f.stage) hipHostFree(f.stage); if (f.copied) hipEventDestroy(f.copied); }
   for (double *p : h->fields) if (p) hipFree(p);

@@ -445,6 +445,7 @@ int k_ibm_wallfun(udc_handle *h) {
   PROF(h, "ibm_wallfun");
   const udc_handle::IbmGrid &U = h->ibm[0], &V = h->ibm[1], &W = h->ibm[2], &C = h->ibm[3];
   const double *ekm = h->fields[UDC_EKM], *ekh = h->fields[UDC_EKH];
+  if (k_ibm_wallfunmom(h)) return 1;      // iwallmom > 1: the facet wall functions first (src/modibm.f90:1183-1194)
   if (U.nbound) hipLaunchKernelGGL(ibm_diffu_corr_kernel, dim3(blocks(U.nbound)), dim3(128), 0, h->stream, g, h->m, U.nbound, U.bound, U.bound_fl,
                                    (const double *)h->fields[UDC_U0], ekm, h->fields[UDC_UP]);
   if (V.nbound) hipLaunchKernelGGL(ibm_diffv_corr_kernel, dim3(blocks(V.nbound)), dim3(128), 0, h->stream, g, h->m, V.nbound, V.bound, V.bound_fl,

@@ -189,6 +189,16 @@ struct udc_handle {
     unsigned char *bound_fl2 = nullptr; // c grid: the momentum masks on the faces of a fluid-boundary cell (advecc2nd_corr_conservative)
   };
   IbmGrid ibm[4];
+  // facet sections of the wall functions (udc_ibm_wf.hip): this slab's sections grouped by boundary cell in file order
+  struct IbmSections {
+    int ncell = 0, nsec = 0;
+    int *cell = nullptr, *off = nullptr, *comprec = nullptr, *recids = nullptr;     // cell: global 1-based i, j, k per row
+    double *area = nullptr, *dist = nullptr, *norm = nullptr, *z0 = nullptr, *z0h = nullptr, *tsurf = nullptr, *recpt = nullptr, *tmask = nullptr;
+  };
+  IbmSections ibm_sec[3];
+  int ibm_iwallmom = 1;                 // 1: no wall functions; 2: Uno et al. stability functions; 3: neutral log law
+  double ibm_prt = 0.71;
+  double *ibm_zgrid = nullptr;          // zf(1 : nz+1), zh(1 : nz+1)
   double *bottom_diag[3] = {nullptr, nullptr, nullptr};      // tau_x, tau_y, thl_flux planes [ny_l][nx] (udc_bottom_diagnostics)
   bool ibm_on = false;
   bool ibm_conservative = false;        // lconservativeibm: which advecc2nd_corr ibmnorm applies to thl, qt
@@ -325,6 +335,8 @@ int k_ibm_levelsum_correct(udc_handle *h, const int *fields, int nf, int n, doub
 int k_ibm_flowsum_correct(udc_handle *h, int grid, const double *a, const double *b, const double *wlev, double *S);                   // solid: velocities zeroed, scalars to the mean of their fluid neighbours
 void ibm_destroy(udc_handle *h);
 void stats_destroy(udc_handle *h);
+int k_ibm_wallfunmom(udc_handle *h);
+void ibm_wf_destroy(udc_handle *h);
 int udc_flush_pending(udc_handle *h);
 int k_tke_floor(udc_handle *h);                    // e120(kb-1) = e120(kb), e12m likewise (`bottom`)                     // wp += grav (thv0h - thvh)/thvh, src/modforces.f90:73-84   // cp(i,j,k) += src(k)
 int k_maxima(udc_handle *h, double dt, double *cour, double *diffn);

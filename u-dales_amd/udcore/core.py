@@ -196,6 +196,25 @@ class DynCore:
     def scalsource(self):
         L._check(self.lib.udc_scalsource(self.h), "udc_scalsource")
 
+    def set_ibm_wallfun(self, iwallmom, prandtlturb, zf, zh):
+        """Facet wall functions for momentum (include/udcore.h): zf, zh = levels 1..ktot+1."""
+        zf, zh = np.ascontiguousarray(zf, dtype=np.float64), np.ascontiguousarray(zh, dtype=np.float64)
+        L._check(self.lib.udc_set_ibm_wallfun(self.h, int(iwallmom), C.c_double(prandtlturb), zf.ctypes.data_as(L.DP), zh.ctypes.data_as(L.DP)),
+                 "udc_set_ibm_wallfun")
+
+    def set_ibm_sections(self, grid, S, facets, tmask):
+        """S: udcore.facets.wall_sections table; facets: read_facets; tmask[n, 2]."""
+        ip = C.POINTER(C.c_int)
+        f = S["fac"] - 1
+        a = lambda x, t: np.ascontiguousarray(x, dtype=t)      # noqa: E731
+        cell, comp, rid = a(S["cell"], np.int32), a(S["comprec"], np.int32), a(S["recids"], np.int32)
+        area, dist, recpt, tm = a(S["area"], np.float64), a(S["dist"], np.float64), a(S["recpt"], np.float64), a(tmask, np.float64)
+        norm, z0, z0h, ts = a(facets["norm"][f], np.float64), a(facets["z0"][f], np.float64), a(facets["z0h"][f], np.float64), a(facets["tsurf"][f], np.float64)
+        L._check(self.lib.udc_set_ibm_sections(self.h, int(grid), int(S["n"]), cell.ctypes.data_as(ip), area.ctypes.data_as(L.DP),
+                                               dist.ctypes.data_as(L.DP), norm.ctypes.data_as(L.DP), z0.ctypes.data_as(L.DP),
+                                               z0h.ctypes.data_as(L.DP), ts.ctypes.data_as(L.DP), comp.ctypes.data_as(ip),
+                                               recpt.ctypes.data_as(L.DP), rid.ctypes.data_as(ip), tm.ctypes.data_as(L.DP)), "udc_set_ibm_sections")
+
     def set_floor_air_temperature(self, thl_kb):
         """ltempeq off + wfuno floor: the frozen temperature of the first level (include/udcore.h)."""
         L._check(self.lib.udc_set_floor_air_temperature(self.h, C.c_double(thl_kb)), "udc_set_floor_air_temperature")

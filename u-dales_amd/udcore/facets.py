@@ -123,3 +123,29 @@ def wall_sections(deck, g, grid, bnd_pts, facets, lnorec=False):
     return {"n": n, "cell": np.array(T["cell"], dtype=np.int32).reshape(n, 3), "area": np.array(T["area"]), "dist": np.array(T["dist"]),
             "fac": np.array(T["fac"], dtype=np.int32), "comprec": np.array(T["comprec"], dtype=np.int32),
             "recpt": np.array(T["recpt"]).reshape(n, 3), "recids": np.array(T["recids"], dtype=np.int32).reshape(n, 4, 3)}
+
+
+def c_mask(nx, ny, nz, solid_c, wrapx=False, wrapy=False):
+    """mask_c of initibm (src/modibm.f90:188-191): 1 fluid / 0 solid on the c grid, [nz+2, ny+2, nx+2] with the ghost ring
+    (index == the reference's k, j, i); the plane below the floor is 0; ghost cells are fluid unless the direction wraps."""
+    m = np.ones((nz + 2, ny + 2, nx + 2))
+    m[0] = 0.
+    if len(solid_c):
+        i, j, k = np.asarray(solid_c).T
+        m[k, j, i] = 0.
+    if wrapx:
+        m[:, :, 0], m[:, :, -1] = m[:, :, -2], m[:, :, 1]
+    if wrapy:
+        m[:, 0], m[:, -1] = m[:, -2], m[:, 1]
+    return m
+
+
+def temperature_masks(grid, S, mask_c):
+    """The two c-grid masks interp_temperature_<grid> (:1794-1830) reads per section: the boundary cell and its lower neighbour
+    along the grid's direction."""
+    di, dj, dk = {"u": (1, 0, 0), "v": (0, 1, 0), "w": (0, 0, 1)}[grid]
+    out = np.ones((S["n"], 2))
+    for s in range(S["n"]):
+        i, j, k = (int(c) for c in S["cell"][s])
+        out[s] = (mask_c[k, j, i], mask_c[k - dk, j - dj, i - di])
+    return out

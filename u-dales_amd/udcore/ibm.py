@@ -41,8 +41,11 @@ def apply_ibm(core, deck):
     """Register the deck's immersed boundary with the device core (no-op unless &RUN libm)."""
     if not deck.get("RUN", "libm"):
         return None
-    if int(deck.get("WALLS", "iwallmom")) != 1:
-        raise ValueError("libm: only iwallmom = 1 (no facet wall functions, src/modibm.f90:1286) is on the device path")
+    iwallmom = int(deck.get("WALLS", "iwallmom"))
+    if iwallmom not in (1, 2, 3):
+        raise ValueError("&WALLS iwallmom must be 1 (no wall functions), 2 (stability functions) or 3 (neutral)")
+    if iwallmom == 2 and not deck.get("PHYSICS", "ltempeq"):
+        raise ValueError("libm with iwallmom = 2: the stability functions read the air temperature (ltempeq); use iwallmom = 3 for neutral walls")
     # temperature / moisture: wallfunheat (src/modibm.f90:1436) is not on the device path; it adds exactly nothing when the
     # wall fluxes are prescribed (iwalltemp / iwallmoist = 1) and zero -- adiabatic, impermeable walls -- and only then
     bc = lambda n: float(deck.get("BC", n))      # noqa: E731
@@ -61,4 +64,16 @@ def apply_ibm(core, deck):
         if g in lists:
             core.set_ibm_points(q, *lists[g])
     core.ibm_commit()
+    if iwallmom > 1:      # facet wall functions for momentum (wallfunmom): facets and section tables to the device
+        from .facets import c_mask, read_facets, temperature_masks, wall_sections
+        g = core.g
+        facets = read_facets(deck)
+        wrapx, wrapy = int(deck.get("RUN", "nprocx")) > 1, int(deck.get("RUN", "nprocy")) > 1
+        jtot = int(deck.get("DOMAIN", "jtot"))
+        gg = g if g.ny == jtot else type(g).from_deck(deck)
+        mask = c_mask(gg.nx, gg.ny, gg.nz, lists["c"][0] if "c" in lists else [], wrapx, wrapy)
+        core.set_ibm_wallfun(iwallmom, 0.71, gg.zf[1:gg.nz + 2], gg.zh[1:gg.nz + 2])
+        for q, gr in enumerate("uvw"):
+            S = wall_sections(deck, gg, gr, lists[gr][1], facets)
+            core.set_ibm_sections(q, S, facets, temperature_masks(gr, S, mask))
     return lists
