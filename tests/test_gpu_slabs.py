@@ -115,6 +115,31 @@ def ibm_block_lists(nx, ny, nz):
     return out
 
 
+def synthetic_sections(g, grid, bnd):
+    """Facet sections for the wall functions on every fluid-boundary point of a grid: one oblique facet; two thirds of the
+    sections take the velocity at the cell, the others at a reconstruction point inside the neighbouring cells (udcore.facets'
+    table layout)."""
+    from udcore.facets import _findloc
+    nx, ny, nz, dx, dy = g.nx, g.ny, g.nz, g.dx, g.dy
+    xh, xf = np.arange(nx + 1) * dx, (np.arange(nx + 1) + 0.5) * dx
+    yh, yf = np.arange(ny + 1) * dy, (np.arange(ny + 1) + 0.5) * dy
+    zf, zh = g.zf[1:nz + 2], g.zh[1:nz + 2]
+    xg, yg, zg = {"u": (xh, yf, zf), "v": (xf, yh, zf), "w": (xf, yf, zh)}[grid]
+    n = len(bnd)
+    S = {"n": n, "cell": np.asarray(bnd, dtype=np.int32).reshape(n, 3), "area": np.full(n, 0.1), "dist": np.full(n, 0.25),
+         "fac": np.ones(n, dtype=np.int32), "comprec": np.ones(n, dtype=np.int32), "recpt": np.zeros((n, 3)),
+         "recids": np.ones((n, 4, 3), dtype=np.int32)}
+    for q, (i, j, k) in enumerate(S["cell"]):
+        if q % 3 or k >= nz - 1:
+            continue
+        p = np.array([xg[i - 1] + 0.3 * dx, yg[j - 1] + 0.2 * dy, zg[k - 1] + 0.3 * (zf[1] - zf[0])])
+        ids = np.array([[_findloc(p[0], a), _findloc(p[1], b), _findloc(p[2], c)] for a, b, c in ((xh, yf, zf), (xf, yh, zf), (xf, yf, zh), (xf, yf, zf))])
+        if ids.min() < 1 or ids[:, 0].max() > nx or ids[:, 1].max() > ny or ids[:, 2].max() > nz:
+            continue
+        S["comprec"][q], S["recpt"][q], S["recids"][q] = 0, p, ids
+    return S
+
+
 def run_virtual(P, g, deck_like, st_global, nsub, dt, sgs, nsv=0, extras=False):
     """Run nsub substeps on P virtual ranks; returns the stitched global u0, v0, w0, pres0."""
     from udcore.core import DynCore
@@ -143,6 +168,14 @@ def run_virtual(P, g, deck_like, st_global, nsub, dt, sgs, nsv=0, extras=False):
                         core.set_ibm_points(q, sol, bnd)
                 core.set_ibm_points(3, *ibm_block_lists(g.nx, g.ny, g.nz)[3])
                 core.ibm_commit()
+                # facet wall functions (iwallmom = 2) on every boundary point: every slab is handed all sections and keeps its
+                # rows'; reconstruction cells reach into the neighbouring slab's ghost rows
+                facets = {"norm": np.array([[0.6, 0., 0.8]]), "z0": np.array([0.01]), "z0h": np.array([0.001]), "tsurf": np.array([289.])}
+                core.set_ibm_wallfun(2, 0.71, g.zf[1:g.nz + 2], g.zh[1:g.nz + 2])
+                for q, gr in enumerate("uvw"):
+                    S = synthetic_sections(g, gr, ibm_block_lists(g.nx, g.ny, g.nz)[q][1])
+                    assert (S["comprec"] == 0).sum() > 10
+                    core.set_ibm_sections(q, S, facets, np.ones((S["n"], 2)))
             if P > 1:
                 core.comm_init_local(group)
             local = {}
