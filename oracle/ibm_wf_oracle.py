@@ -100,3 +100,63 @@ def wallfunmom(grid, g, S, facets, iwallmom, u0, v0, w0, rhs, thl0=None, mask_c=
         rhs[k, j, i] = rhs[k, j, i] - stress_dir * S["area"][s] / (dx * dy * g.dzf[k])
         acted += 1
     return acted
+
+
+def _heat_flux(utan, dist, z0, z0h, tair, tsurf, prt):
+    """heat_transfer_coef_flux, src/modibm.f90:1920-1986 -> flux."""
+    b1, b2, dm, dh = 9.4, 4.7, 7.4, 5.3
+    dT = tair - tsurf
+    ri0 = GRAV * dist * dT / (tsurf * utan ** 2)
+    logdz, logzh, sqdz, fkar2 = np.log(dist / z0), np.log(z0 / z0h), np.sqrt(dist / z0), FKAR ** 2
+
+    def F(ri):
+        if ri > 0.:
+            fm = 1. / (1. + b2 * ri) ** 2
+            return fm, fm
+        cm = (dm * fkar2) / (logdz ** 2) * b1 * sqdz
+        ch = (dh * fkar2) / (logdz ** 2) * b1 * sqdz
+        return 1. - (b1 * ri) / (1. + cm * np.sqrt(abs(ri))), 1. - (b1 * ri) / (1. + ch * np.sqrt(abs(ri)))
+    fm, fh = F(ri0)
+    M = prt * logdz * np.sqrt(fm) / fh
+    ri1 = ri0 - ri0 * prt * logzh / (prt * logzh + M)
+    fm, fh = F(ri1)
+    M = prt * logdz * np.sqrt(fm) / fh
+    dTrough = dT * 1. / (prt * logzh / M + 1.)
+    cth = fkar2 / (logdz * logdz) * fh / prt
+    return abs(utan) * cth * dTrough
+
+
+def wallfunheat(g, S, facets, u0, v0, w0, thl0, thlp, prt=0.71, lnorec=False):
+    """wallfunheat's sensible part with iwalltemp = 2 (src/modibm.f90:1436-1540): thlp (m-array) updated in place."""
+    nx, ny, nz, dx, dy = g.nx, g.ny, g.nz, g.dx, g.dy
+    xh, xf = np.arange(nx + 1) * dx, (np.arange(nx + 1) + 0.5) * dx
+    yh, yf = np.arange(ny + 1) * dy, (np.arange(ny + 1) + 0.5) * dy
+    zf, zh = g.zf[1:nz + 2], g.zh[1:nz + 2]
+    acted = 0
+    for s in range(S["n"]):
+        i, j, k = (int(c) for c in S["cell"][s])
+        fac = int(S["fac"][s]) - 1
+        norm, z0, z0h = facets["norm"][fac], facets["z0"][fac], facets["z0h"][fac]
+        if S["comprec"][s] or lnorec:
+            uvec = np.array([0.5 * (u0[k, j, i] + u0[k, j, i + 1]), 0.5 * (v0[k, j, i] + v0[k, j + 1, i]), 0.5 * (w0[k, j, i] + w0[k + 1, j, i])])
+            tair = thl0[k, j, i]
+            dist = S["dist"][s]
+        else:
+            p, r = S["recpt"][s], S["recids"][s]
+            uvec = np.array([_trilinear(u0, r[0], xh, yf, zf, p), _trilinear(v0, r[1], xf, yh, zf, p), _trilinear(w0, r[2], xf, yf, zh, p)])
+            tair = _trilinear(thl0, r[3], xf, yf, zf, p)
+            dist = S["dist"][s] + np.linalg.norm(np.array([p[0] - xf[i - 1], p[1] - yf[j - 1], p[2] - zf[k - 1]]))
+        if np.log(dist / z0) <= 1.:
+            continue
+        if np.all(np.abs(uvec) < EPS1):
+            continue
+        span = np.cross(norm, uvec)
+        if np.all(np.abs(span) < EPS1):
+            continue
+        span = span / np.linalg.norm(span)
+        strm = np.cross(span, norm)
+        utan = float(np.dot(uvec, strm))
+        flux = _heat_flux(utan, dist, z0, z0h, tair, facets["tsurf"][fac], prt)
+        thlp[k, j, i] = thlp[k, j, i] - flux * S["area"][s] / (dx * dy * g.dzh[k])
+        acted += 1
+    return acted

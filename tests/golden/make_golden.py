@@ -30,7 +30,7 @@ REF = os.path.join(ROOT, "oracle", "_ref", "udales_ref")
 
 def deck(iexpnr, nx, ny, nz, dx=0.5, dy=0.5, dtmax=0.25, sgs="vreman", nsv=0, bctopm=1,
          oracle="", lles=True, randu=0.01, floor=False, z0=0.05, physics="", bc="", bcbotm=3, scalars="", dynamics="", inlet="", ladaptive=False, chemistry="",
-         ibm=None, output="", iwallmom=1):
+         ibm=None, output="", iwallmom=1, walls=""):
     sub = {"oneeqn": "loneeqn = .true.\nlvreman = .false.\nlsmagorinsky = .false.",
            "vreman": "lvreman = .true.\nlsmagorinsky = .false.",
            "vreman_bc": "lvreman = .true.\nlsmagorinsky = .false.\nlbuoycorr = .true.",
@@ -66,7 +66,7 @@ BCtopm = {bctopm}
 {('BCbotm = ' + str(bcbotm) + chr(10) + 'z0 = ' + repr(z0)) if floor else ''}
 {bc}
 /
-{('&WALLS' + chr(10) + 'nfcts = 0' + chr(10) + ('lbottom = .true.' + chr(10) if floor else '') + ((ibm_walls(ibm, nx, ny, nz) if iwallmom == 1 else ibm_walls_wf(ibm, nx, ny, nz, dx, dy, 0.5, iwallmom)) if ibm else '') + '/') if (floor or ibm) else ''}
+{('&WALLS' + chr(10) + 'nfcts = 0' + chr(10) + ('lbottom = .true.' + chr(10) if floor else '') + ((ibm_walls(ibm, nx, ny, nz) if iwallmom == 1 else ibm_walls_wf(ibm, nx, ny, nz, dx, dy, 0.5, iwallmom)) + (walls + chr(10) if walls else '') if ibm else '') + '/') if (floor or ibm) else ''}
 &SCALARS
 nsv = {nsv}{(chr(10) + scalars) if scalars else ''}
 /
@@ -511,7 +511,18 @@ CASES.update({
 # stability functions on the facet temperatures, iwallmom = 3 neutral): uniform z (the reference's reconstruction assumes it)
 for _n in ("k_ibm_wf3_16x12x10", "k_ibm_wf2_16x12x10", "run_ibm_wf2_16x12x10"):
     IBM_BLOCKS[_n] = IBM_BLOCKS["run_ibm_16x12x10"]
-WF_CASES = {"k_ibm_wf3_16x12x10": 3, "k_ibm_wf2_16x12x10": 2, "run_ibm_wf2_16x12x10": 2}
+for _n in ("k_ibm_wh2_16x12x10", "run_ibm_wh2_16x12x10"):
+    IBM_BLOCKS[_n] = IBM_BLOCKS["run_ibm_16x12x10"]
+WF_CASES = {"k_ibm_wf3_16x12x10": 3, "k_ibm_wf2_16x12x10": 2, "run_ibm_wf2_16x12x10": 2, "k_ibm_wh2_16x12x10": 2, "run_ibm_wh2_16x12x10": 2}
+# + the heat wall function on the facet temperatures (wallfunheat with iwalltemp = 2, src/modibm.f90:1436)
+CASES.update({
+    "k_ibm_wh2_16x12x10": ("kernels", 69, 16, 12, 10, dict(sgs="vreman", nsv=1, floor=True, randu=0.05, ibm=IBM_BLOCKS["run_ibm_16x12x10"],
+                                                           iwallmom=2, walls="iwalltemp = 2", physics="ltempeq = .true.\nlbuoyancy = .true.",
+                                                           bc=_IBM_THL_BC, oracle="nspin = 4"), 1.0),
+    "run_ibm_wh2_16x12x10": ("run", 70, 16, 12, 10, dict(sgs="vreman", nsv=1, floor=True, randu=0.05, ibm=IBM_BLOCKS["run_ibm_16x12x10"],
+                                                         iwallmom=2, walls="iwalltemp = 2", physics="ltempeq = .true.\nlbuoyancy = .true.",
+                                                         bc=_IBM_THL_BC, oracle="nsub = 9\ndump_at = 3, 9"), 1.0),
+})
 CASES.update({
     "k_ibm_wf3_16x12x10": ("kernels", 66, 16, 12, 10, dict(sgs="smag", nsv=1, floor=True, randu=0.05, ibm=IBM_BLOCKS["run_ibm_16x12x10"],
                                                            iwallmom=3, oracle="nspin = 4"), 1.0),
@@ -540,6 +551,7 @@ THL_CASES = {"k_tke_moist_12x8x8": dict(dthl=0.25, qt=0.0118, dqt=-8e-5, tke=0.0
              "run_ibm_qt_16x12x10": dict(dthl=0.25, qt=0.007, dqt=-2e-4),
              "run_stats_16x8x12s": dict(dthl=0.25), "run_stats_ibm_16x12x10": dict(dthl=0.25),
              "k_ibm_wf2_16x12x10": dict(dthl=0.3), "run_ibm_wf2_16x12x10": dict(dthl=0.25),
+             "k_ibm_wh2_16x12x10": dict(dthl=0.3), "run_ibm_wh2_16x12x10": dict(dthl=0.25),
              "k_vreman_buoycorr_12x8x10": dict(dthl=0.004), "run_vreman_buoycorr_16x8x12s": dict(dthl=0.004)}
 
 

@@ -19,10 +19,12 @@ def _core(name, iexp):
     return d, udcore.from_deck(d)
 
 
-@pytest.mark.parametrize("name,iexp", [("k_ibm_16x12x10", 54), ("k_ibm_thl_16x12x10", 58), ("k_ibm_wf3_16x12x10", 66), ("k_ibm_wf2_16x12x10", 67)])
+@pytest.mark.parametrize("name,iexp", [("k_ibm_16x12x10", 54), ("k_ibm_thl_16x12x10", 58), ("k_ibm_wf3_16x12x10", 66), ("k_ibm_wf2_16x12x10", 67),
+                                       ("k_ibm_wh2_16x12x10", 69)])
 def test_ibm_routines_match_reference(name, iexp):
     """The wf decks: the facet wall functions for momentum (wallfunmom, neutral and with the stability functions on the facet
     temperatures; sections with reconstruction points and an oblique facet normal) ahead of the diffusion corrections.
+    wh2: also the heat wall function on the facet temperatures (wallfunheat with iwalltemp = 2) ahead of diffc_corr on thl.
     The second deck adds temperature with buoyancy: diffc_corr and solid (volume-mean value) on thl, advecc2nd_corr_liberal,
     and the slab averages over the fluid cells (thl0av; thvh through the buoyancy term of the run fixtures)."""
     fix = load_fixture(name)
@@ -106,17 +108,20 @@ def test_ibm_refusals():
     import udcore
     name, iexp = "run_ibm_16x12x10", 55
     d = read_deck(deck_path(name, iexp))
-    d.nml["WALLS"]["iwallmom"] = 2
-    with pytest.raises(ValueError, match="iwallmom"):
+    d.nml["WALLS"]["iwallmom"] = 2                       # stability functions without an air temperature
+    with pytest.raises(ValueError, match="iwallmom = 2"):
+        udcore.from_deck(d)
+    d.nml["WALLS"]["iwallmom"] = 3                       # wall functions without the facets of the pre-processing
+    with pytest.raises(ValueError, match="nfcts"):
         udcore.from_deck(d)
     d.nml["WALLS"]["iwallmom"] = 1
     d.nml.setdefault("PHYSICS", {})["ltempeq"] = True
-    d.nml["WALLS"]["iwalltemp"] = 2                      # wall temperatures: needs the heat wall function
-    with pytest.raises(ValueError, match="wallfunheat"):
+    d.nml["WALLS"]["iwalltemp"] = 2                      # wall temperatures: the heat wall function needs the facets too
+    with pytest.raises(ValueError, match="nfcts"):
         udcore.from_deck(d)
     d.nml["WALLS"]["iwalltemp"] = 1
-    d.nml.setdefault("BC", {})["bctfz"] = 0.01           # a prescribed wall flux: likewise (adiabatic walls only)
-    with pytest.raises(ValueError, match="wallfunheat"):
+    d.nml.setdefault("BC", {})["bctfz"] = 0.01           # a prescribed, non-zero wall flux: not on the device
+    with pytest.raises(ValueError, match="iwalltemp = 1"):
         udcore.from_deck(d)
 
 

@@ -452,6 +452,7 @@ int k_ibm_wallfun(udc_handle *h) {
                                    (const double *)h->fields[UDC_V0], ekm, h->fields[UDC_VP]);
   if (W.nbound) hipLaunchKernelGGL(ibm_diffw_corr_kernel, dim3(blocks(W.nbound)), dim3(128), 0, h->stream, g, h->m, W.nbound, W.bound, W.bound_fl,
                                    (const double *)h->fields[UDC_W0], ekm, h->fields[UDC_WP]);
+  if (k_ibm_wallfunheat(h)) return 1;     // iwalltemp = 2: the heat wall function on thlp (:1220-1231), then diffc_corr
   if (C.nbound)
     for (int n : h->slots)
       hipLaunchKernelGGL(ibm_diffc_corr_kernel, dim3(blocks(C.nbound)), dim3(128), 0, h->stream, g, h->m, C.nbound, C.bound, C.bound_fl,

@@ -135,6 +135,76 @@ __global__ void ibm_wallfunmom_kernel(Geo g, Metrics m, WfArgs a) {
   a.rhs[c] = t;
 }
 
+// heat_transfer_coef_flux, :1920-1986 -> flux [K m/s]
+__device__ __forceinline__ double heat_flux(double utan, double dist, double z0, double z0h, double Tair, double Tsurf, double prt) {
+  const double b1 = 9.4, b2 = 4.7, dm = 7.4, dh = 5.3, grav = 9.81, fkar = 0.41;
+  const double dT = Tair - Tsurf;
+  const double Ribl0 = grav * dist * dT / (Tsurf * (utan * utan));
+  const double logdz = log(dist / z0), logzh = log(z0 / z0h), sqdz = sqrt(dist / z0), fkar2 = fkar * fkar;
+  double Fm, Fh;
+  auto F = [&](double Ri) {
+    if (Ri > 0.) {
+      Fm = 1. / ((1. + b2 * Ri) * (1. + b2 * Ri));
+      Fh = Fm;
+    } else {
+      const double cm = (dm * fkar2) / (logdz * logdz) * b1 * sqdz, ch = (dh * fkar2) / (logdz * logdz) * b1 * sqdz;
+      Fm = 1. - (b1 * Ri) / (1. + cm * sqrt(fabs(Ri)));
+      Fh = 1. - (b1 * Ri) / (1. + ch * sqrt(fabs(Ri)));
+    }
+  };
+  F(Ribl0);
+  double M = prt * logdz * sqrt(Fm) / Fh;
+  const double Ribl1 = Ribl0 - Ribl0 * prt * logzh / (prt * logzh + M);
+  F(Ribl1);
+  M = prt * logdz * sqrt(Fm) / Fh;
+  const double dTrough = dT * 1. / (prt * logzh / M + 1.);
+  const double cth = fkar2 / (logdz * logdz) * Fh / prt;
+  return fabs(utan) * cth * dTrough;
+}
+
+// wallfunheat, sensible part with the facet temperatures (iwalltemp = 2, :1436-1540): the c-grid sections
+__global__ void ibm_wallfunheat_kernel(Geo g, Metrics m, WfArgs a) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= a.ncell) return;
+  const int i = a.cell[3 * q], j = a.cell[3 * q + 1], k = a.cell[3 * q + 2], j0 = a.j0;
+  const long c = g.idx(i - 1, j - 1 - j0, k - 1);
+  const double eps1 = 1.e-10;
+  const double vol = m.dx * m.dy * m.dzh[k];
+  double t = a.rhs[c];
+  for (int s = a.off[q]; s < a.off[q + 1]; ++s) {
+    const double nrm[3] = {a.norm[3 * s], a.norm[3 * s + 1], a.norm[3 * s + 2]};
+    const double z0 = a.z0[s];
+    double uv[3], Tair, dist;
+    if (a.comprec[s]) {      // interp_velocity_c, :1780-1791
+      uv[0] = 0.5 * (at(g, a.u0, j0, i, j, k) + at(g, a.u0, j0, i + 1, j, k));
+      uv[1] = 0.5 * (at(g, a.v0, j0, i, j, k) + at(g, a.v0, j0, i, j + 1, k));
+      uv[2] = 0.5 * (at(g, a.w0, j0, i, j, k) + at(g, a.w0, j0, i, j, k + 1));
+      Tair = at(g, a.thl0, j0, i, j, k);
+      dist = a.dist[s];
+    } else {
+      const double *p = a.recpt + 3 * s;
+      const int *r = a.recids + 12 * s;
+      uv[0] = trilinear(g, m, a.u0, j0, r, 1, 0, a.zf, p);
+      uv[1] = trilinear(g, m, a.v0, j0, r + 3, 0, 1, a.zf, p);
+      uv[2] = trilinear(g, m, a.w0, j0, r + 6, 0, 0, a.zh, p);
+      Tair = trilinear(g, m, a.thl0, j0, r + 9, 0, 0, a.zf, p);
+      const double ex = p[0] - (i - 0.5) * m.dx, ey = p[1] - (j - 0.5) * m.dy, ez = p[2] - a.zf[k - 1];
+      dist = a.dist[s] + sqrt(ex * ex + ey * ey + ez * ez);
+    }
+    if (log(dist / z0) <= 1.) continue;
+    if (fabs(uv[0]) < eps1 && fabs(uv[1]) < eps1 && fabs(uv[2]) < eps1) continue;
+    double sp[3] = {nrm[1] * uv[2] - nrm[2] * uv[1], nrm[2] * uv[0] - nrm[0] * uv[2], nrm[0] * uv[1] - nrm[1] * uv[0]};
+    if (fabs(sp[0]) < eps1 && fabs(sp[1]) < eps1 && fabs(sp[2]) < eps1) continue;
+    const double sn = sqrt(sp[0] * sp[0] + sp[1] * sp[1] + sp[2] * sp[2]);
+    sp[0] /= sn; sp[1] /= sn; sp[2] /= sn;
+    const double st[3] = {sp[1] * nrm[2] - sp[2] * nrm[1], sp[2] * nrm[0] - sp[0] * nrm[2], sp[0] * nrm[1] - sp[1] * nrm[0]};
+    const double utan = uv[0] * st[0] + uv[1] * st[1] + uv[2] * st[2];
+    const double flux = heat_flux(utan, dist, z0, a.z0h[s], Tair, a.tsurf[s], a.prt);
+    t = t - flux * a.area[s] / vol;
+  }
+  a.rhs[c] = t;
+}
+
 template <class T>
 int upload(T **dst, const std::vector<T> &v) {
   if (*dst) { hipFree(*dst); *dst = nullptr; }
@@ -151,14 +221,14 @@ extern "C" int udc_set_ibm_wallfun(udc_handle *h, int iwallmom, double prandtltu
   HIP_OK(hipSetDevice(h->device));
   if (udc_flush_pending(h)) return 1;
   if (iwallmom < 1 || iwallmom > 3) { udc_set_error("udc_set_ibm_wallfun: iwallmom must be 1 (none), 2 (stability functions) or 3 (neutral)"); return 1; }
-  if (iwallmom > 1 && (!zf || !zh || !(prandtlturb > 0.))) { udc_set_error("udc_set_ibm_wallfun: zf, zh (levels 1..ktot+1) and prandtlturb > 0 are needed"); return 1; }
+  if (!zf || !zh || !(prandtlturb > 0.)) { udc_set_error("udc_set_ibm_wallfun: zf, zh (levels 1..ktot+1) and prandtlturb > 0 are needed"); return 1; }
   if (iwallmom == 2 && ((int)h->fields.size() <= UDC_THL0 || !h->fields[UDC_THL0])) {
     udc_set_error("udc_set_ibm_wallfun: iwallmom = 2 judges the stability on the air temperature: call udc_set_tempeq first (or use iwallmom = 3)");
     return 1;
   }
   h->ibm_iwallmom = iwallmom;
   h->ibm_prt = prandtlturb;
-  if (iwallmom > 1) {
+  {
     const int n = h->g.nz + 1;
     std::vector<double> z(zf, zf + n);
     z.insert(z.end(), zh, zh + n);
@@ -174,7 +244,7 @@ extern "C" int udc_set_ibm_sections(udc_handle *h, int grid, int n, const int *c
   if (!h) { udc_set_error("null handle"); return 1; }
   HIP_OK(hipSetDevice(h->device));
   if (udc_flush_pending(h)) return 1;
-  if (grid < 0 || grid > 2) { udc_set_error("udc_set_ibm_sections: grid 0 (u), 1 (v) or 2 (w)"); return 1; }
+  if (grid < 0 || grid > 3) { udc_set_error("udc_set_ibm_sections: grid 0 (u), 1 (v), 2 (w) or 3 (c, for the heat wall function)"); return 1; }
   if (n < 0 || (n && (!cell || !area || !dist || !norm || !z0 || !z0h || !tsurf || !comprec || !recpt || !recids || !tmask))) {
     udc_set_error("udc_set_ibm_sections: null array"); return 1;
   }
@@ -245,6 +315,36 @@ int k_ibm_wallfunmom(udc_handle *h) {
     a.prt = h->ibm_prt;
     hipLaunchKernelGGL(ibm_wallfunmom_kernel, dim3((unsigned)((S.ncell + 127) / 128)), dim3(128), 0, h->stream, g, h->m, a);
   }
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int udc_set_ibm_wallheat(udc_handle *h, int iwalltemp) {
+  if (!h) { udc_set_error("null handle"); return 1; }
+  HIP_OK(hipSetDevice(h->device));
+  if (udc_flush_pending(h)) return 1;
+  if (iwalltemp != 1 && iwalltemp != 2) { udc_set_error("udc_set_ibm_wallheat: iwalltemp must be 1 (prescribed fluxes; only zero is on the device) or 2 (facet temperatures)"); return 1; }
+  if (iwalltemp == 2 && ((int)h->fields.size() <= UDC_THL0 || !h->fields[UDC_THL0])) { udc_set_error("udc_set_ibm_wallheat: call udc_set_tempeq first"); return 1; }
+  if (iwalltemp == 2 && !h->ibm_zgrid) { udc_set_error("udc_set_ibm_wallheat: call udc_set_ibm_wallfun first (level coordinates, prandtlturb)"); return 1; }
+  h->ibm_iwalltemp = iwalltemp;
+  return 0;
+}
+
+// wallfunheat on thlp (ibmwallfun, src/modibm.f90:1220-1231), after the momentum corrections and before diffc_corr
+int k_ibm_wallfunheat(udc_handle *h) {
+  if (h->ibm_iwalltemp != 2) return 0;
+  const udc_handle::IbmSections &S = h->ibm_sec[3];
+  if (!S.ncell) return 0;
+  const Geo &g = h->g;
+  WfArgs a;
+  a.ncell = S.ncell; a.grid = 3; a.iwallmom = 2; a.j0 = h->cfg.rank * g.ny;
+  a.cell = S.cell; a.off = S.off; a.comprec = S.comprec; a.recids = S.recids;
+  a.area = S.area; a.dist = S.dist; a.norm = S.norm; a.z0 = S.z0; a.z0h = S.z0h; a.tsurf = S.tsurf; a.recpt = S.recpt; a.tmask = S.tmask;
+  a.u0 = h->fields[UDC_U0]; a.v0 = h->fields[UDC_V0]; a.w0 = h->fields[UDC_W0]; a.thl0 = h->fields[UDC_THL0];
+  a.zf = h->ibm_zgrid; a.zh = h->ibm_zgrid + (g.nz + 1);
+  a.rhs = h->fields[UDC_THLP];
+  a.prt = h->ibm_prt;
+  hipLaunchKernelGGL(ibm_wallfunheat_kernel, dim3((unsigned)((S.ncell + 127) / 128)), dim3(128), 0, h->stream, g, h->m, a);
   HIP_OK(hipGetLastError());
   return 0;
 }

@@ -195,8 +195,9 @@ struct udc_handle {
     int *cell = nullptr, *off = nullptr, *comprec = nullptr, *recids = nullptr;     // cell: global 1-based i, j, k per row
     double *area = nullptr, *dist = nullptr, *norm = nullptr, *z0 = nullptr, *z0h = nullptr, *tsurf = nullptr, *recpt = nullptr, *tmask = nullptr;
   };
-  IbmSections ibm_sec[3];
+  IbmSections ibm_sec[4];               // u, v, w (wallfunmom), c (wallfunheat)
   int ibm_iwallmom = 1;                 // 1: no wall functions; 2: Uno et al. stability functions; 3: neutral log law
+  int ibm_iwalltemp = 1;                // 1: prescribed wall heat fluxes (zero: adiabatic); 2: from the facet temperatures
   double ibm_prt = 0.71;
   double *ibm_zgrid = nullptr;          // zf(1 : nz+1), zh(1 : nz+1)
   double *bottom_diag[3] = {nullptr, nullptr, nullptr};      // tau_x, tau_y, thl_flux planes [ny_l][nx] (udc_bottom_diagnostics)
@@ -336,6 +337,7 @@ int k_ibm_flowsum_correct(udc_handle *h, int grid, const double *a, const double
 void ibm_destroy(udc_handle *h);
 void stats_destroy(udc_handle *h);
 int k_ibm_wallfunmom(udc_handle *h);
+int k_ibm_wallfunheat(udc_handle *h);
 void ibm_wf_destroy(udc_handle *h);
 int udc_flush_pending(udc_handle *h);
 int k_tke_floor(udc_handle *h);                    // e120(kb-1) = e120(kb), e12m likewise (`bottom`)                     // wp += grav (thv0h - thvh)/thvh, src/modforces.f90:73-84   // cp(i,j,k) += src(k)

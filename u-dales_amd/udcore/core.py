@@ -202,6 +202,9 @@ class DynCore:
         L._check(self.lib.udc_set_ibm_wallfun(self.h, int(iwallmom), C.c_double(prandtlturb), zf.ctypes.data_as(L.DP), zh.ctypes.data_as(L.DP)),
                  "udc_set_ibm_wallfun")
 
+    def set_ibm_wallheat(self, iwalltemp):
+        L._check(self.lib.udc_set_ibm_wallheat(self.h, int(iwalltemp)), "udc_set_ibm_wallheat")
+
     def set_ibm_sections(self, grid, S, facets, tmask):
         """S: udcore.facets.wall_sections table; facets: read_facets; tmask[n, 2]."""
         ip = C.POINTER(C.c_int)

@@ -39,7 +39,7 @@ def read_facets(deck):
     ftype = fac[:, 0].astype(int)
     out = {"norm": np.ascontiguousarray(fac[:, 1:4]), "z0": np.array([z0[t] for t in ftype]), "z0h": np.array([z0h[t] for t in ftype]),
            "tsurf": np.zeros(nfcts)}
-    if int(deck.get("WALLS", "iwallmom")) == 2:
+    if int(deck.get("WALLS", "iwallmom")) == 2 or int(deck.get("WALLS", "iwalltemp")) == 2:      # src/initfac.f90:299
         out["tsurf"] = _rows(os.path.join(base, f"Tfacinit.inp.{iexp:03d}"), 1, nfcts, 1)[:, 0].copy()
     return out
 
@@ -69,7 +69,7 @@ def _findloc(x, grid):
 
 
 def wall_sections(deck, g, grid, bnd_pts, facets, lnorec=False):
-    """The section table of one velocity grid ('u', 'v', 'w') in the file's order, skipped sections left out.
+    """The section table of one grid ('u', 'v', 'w'; 'c' for the heat wall function) in the file's order, skipped sections left out.
     bnd_pts: fluid_boundary_<grid>.txt rows (global 1-based i, j, k)."""
     base = os.path.dirname(os.path.abspath(deck.path))
     nsec = int(deck.get("WALLS", f"nfctsecs_{grid}"))
@@ -80,15 +80,15 @@ def wall_sections(deck, g, grid, bnd_pts, facets, lnorec=False):
     yh, yf = np.arange(ny + 1) * dy, (np.arange(ny + 1) + 0.5) * dy
     zf, zh = g.zf[1:nz + 2].copy(), g.zh[1:nz + 2].copy()
     dz1 = g.dzf[1]
-    dir_align = {"u": 1, "v": 2, "w": 3}[grid]
-    xg, yg, zg = {"u": (xh, yf, zf), "v": (xf, yh, zf), "w": (xf, yf, zh)}[grid]
+    dir_align = {"u": 1, "v": 2, "w": 3, "c": 0}[grid]
+    xg, yg, zg = {"u": (xh, yf, zf), "v": (xf, yh, zf), "w": (xf, yf, zh), "c": (xf, yf, zf)}[grid]
     xhat, yhat, zhat = np.eye(3)
     T = {k: [] for k in ("cell", "area", "dist", "fac", "comprec", "recpt", "recids")}
     for fac, area, bid, dst in rows:
         fac, bid = int(fac), int(bid)
         norm = facets["norm"][fac - 1]
         z0 = facets["z0"][fac - 1]
-        if (dir_align == alignment(norm)) or z0 < EPS1:            # :366-373
+        if (dir_align != 0 and dir_align == alignment(norm)) or z0 < EPS1:            # :366-373
             continue
         i, j, k = (int(v) for v in bnd_pts[bid - 1])
         comprec, recpt, recids = True, np.zeros(3), np.zeros((4, 3), dtype=np.int32)

@@ -46,12 +46,14 @@ def apply_ibm(core, deck):
         raise ValueError("&WALLS iwallmom must be 1 (no wall functions), 2 (stability functions) or 3 (neutral)")
     if iwallmom == 2 and not deck.get("PHYSICS", "ltempeq"):
         raise ValueError("libm with iwallmom = 2: the stability functions read the air temperature (ltempeq); use iwallmom = 3 for neutral walls")
-    # temperature / moisture: wallfunheat (src/modibm.f90:1436) is not on the device path; it adds exactly nothing when the
-    # wall fluxes are prescribed (iwalltemp / iwallmoist = 1) and zero -- adiabatic, impermeable walls -- and only then
+    # temperature: wallfunheat (src/modibm.f90:1436) from the facet temperatures (iwalltemp = 2) is on the device; with
+    # prescribed fluxes (iwalltemp = 1) only zero ones, where it adds exactly nothing (adiabatic walls).  Moisture: impermeable
+    # walls only (iwallmoist = 1, zero fluxes).
     bc = lambda n: float(deck.get("BC", n))      # noqa: E731
-    if deck.get("PHYSICS", "ltempeq") and (int(deck.get("WALLS", "iwalltemp")) != 1 or any(bc(n) != 0. for n in ("bctfxm", "bctfxp", "bctfym", "bctfyp", "bctfz"))):
-        raise ValueError("libm with ltempeq: wall heat fluxes need the facet heat wall functions (wallfunheat), not on the device path; "
-                         "only iwalltemp = 1 with bctf* = 0 (adiabatic walls) is")
+    iwalltemp = int(deck.get("WALLS", "iwalltemp"))
+    if deck.get("PHYSICS", "ltempeq") and (iwalltemp not in (1, 2) or (iwalltemp == 1 and any(bc(n) != 0. for n in ("bctfxm", "bctfxp", "bctfym", "bctfyp", "bctfz")))):
+        raise ValueError("libm with ltempeq: prescribed wall heat fluxes (iwalltemp = 1) are on the device path only when they are zero "
+                         "(adiabatic walls); iwalltemp = 2 takes them from the facet temperatures")
     if deck.get("PHYSICS", "lmoist") and (int(deck.get("WALLS", "iwallmoist")) != 1 or any(bc(n) != 0. for n in ("bcqfxm", "bcqfxp", "bcqfym", "bcqfyp", "bcqfz"))):
         raise ValueError("libm with lmoist: wall moisture fluxes need wallfunheat, not on the device path; only iwallmoist = 1 with bcqf* = 0 is")
     if deck.get("PHYSICS", "lmoist") and deck.get("PHYSICS", "lbuoyancy"):
@@ -64,7 +66,8 @@ def apply_ibm(core, deck):
         if g in lists:
             core.set_ibm_points(q, *lists[g])
     core.ibm_commit()
-    if iwallmom > 1:      # facet wall functions for momentum (wallfunmom): facets and section tables to the device
+    heat = bool(deck.get("PHYSICS", "ltempeq")) and iwalltemp == 2
+    if iwallmom > 1 or heat:      # facet wall functions (wallfunmom, wallfunheat): facets and section tables to the device
         from .facets import c_mask, read_facets, temperature_masks, wall_sections
         g = core.g
         facets = read_facets(deck)
@@ -73,7 +76,12 @@ def apply_ibm(core, deck):
         gg = g if g.ny == jtot else type(g).from_deck(deck)
         mask = c_mask(gg.nx, gg.ny, gg.nz, lists["c"][0] if "c" in lists else [], wrapx, wrapy)
         core.set_ibm_wallfun(iwallmom, 0.71, gg.zf[1:gg.nz + 2], gg.zh[1:gg.nz + 2])
-        for q, gr in enumerate("uvw"):
-            S = wall_sections(deck, gg, gr, lists[gr][1], facets)
-            core.set_ibm_sections(q, S, facets, temperature_masks(gr, S, mask))
+        if iwallmom > 1:
+            for q, gr in enumerate("uvw"):
+                S = wall_sections(deck, gg, gr, lists[gr][1], facets)
+                core.set_ibm_sections(q, S, facets, temperature_masks(gr, S, mask))
+        if heat:
+            S = wall_sections(deck, gg, "c", lists["c"][1], facets)
+            core.set_ibm_sections(3, S, facets, np.ones((S["n"], 2)))
+            core.set_ibm_wallheat(2)
     return lists
