@@ -51,7 +51,7 @@ program ref_driver
   ! drop-in build: the floor (`bottom`), the immersed boundary, the masks and lbottom come from the drop-in modibm, as in
   ! src/program.f90:38
   use modibm, only: initibm, createmasks, bottom, lbottom, ibmwallfun, ibmnorm, nsolpts_u, nsolpts_v, nsolpts_w, nsolpts_c, &
-                    nbndpts_u, nbndpts_v, nbndpts_w, nbndpts_c
+                    nbndpts_u, nbndpts_v, nbndpts_w, nbndpts_c, nfctsecs_u, nfctsecs_v, nfctsecs_w, nfctsecs_c, lnorec
   use udc_iface, only: udc_residency, udc_pull_all, udc_h, udc_sync, udc_check, udc_deferred_stats
   use iso_c_binding, only: c_long
 #else
@@ -61,9 +61,9 @@ program ref_driver
                     bound_info_w, bound_info_c, mask_u, mask_v, mask_w, mask_c, nsolpts_u, nsolpts_v, nsolpts_w, nsolpts_c, &
                     nbndpts_u, nbndpts_v, nbndpts_w, nbndpts_c, nfctsecs_u, nfctsecs_v, nfctsecs_w, nfctsecs_c, &
                     lnorec, initibm, ref_ibmwallfun => ibmwallfun      ! the facet wall functions: the reference's own set-up and loop
-  use initfac, only: readfacetfiles
   use readinput, only: read_sparse_ijk
 #endif
+  use initfac, only: readfacetfiles
   use modstatsdump, only: initstatsdump, statsdump  ! src/modstatsdump.f90: the sampling half, compiled from the reference (extract_statsdump.sh)
   use modstartup_rand, only: randomize_field        ! src/modstartup.f90:2367-2396, compiled from the reference (extract_startup.sh)
   implicit none
@@ -108,6 +108,7 @@ program ref_driver
   call initsubgrid
   call initpois
 #ifdef UDC_DROPIN
+  call readfacetfiles                       ! src/program.f90:91 (the reference's own initfac; returns unless nfcts > 0)
   call initibm                              ! src/program.f90:93-95
 #else
   if (libm .and. iwallmom > 1) then         ! src/program.f90:91-93
@@ -405,13 +406,8 @@ contains
       bcqfxm, bcqfxp, bcqfym, bcqfyp, bcqfz
     namelist /SCALARS/ nsv, lscasrc, nscasrc, lscasrcl, nscasrcl
     namelist /OUTPUT/ ltdump, lxytdump, tsample, tstatsdump, tstatstart, lfielddump, tfielddump, fieldvars      ! (the field dump itself is not run here)
-#ifdef UDC_DROPIN
-    namelist /WALLS/ nfcts, lbottom, iwallmom, iwalltemp, iwallmoist, nsolpts_u, nsolpts_v, nsolpts_w, nsolpts_c, &
-      nbndpts_u, nbndpts_v, nbndpts_w, nbndpts_c
-#else
     namelist /WALLS/ nfcts, lbottom, iwallmom, iwalltemp, iwallmoist, nsolpts_u, nsolpts_v, nsolpts_w, nsolpts_c, &
       nbndpts_u, nbndpts_v, nbndpts_w, nbndpts_c, nfctsecs_u, nfctsecs_v, nfctsecs_w, nfctsecs_c, lnorec
-#endif
     open (ifnamopt, file=fname_options, status='old', iostat=ierr)
     if (ierr /= 0) then
       write (0, *) 'ERROR: cannot open ', trim(fname_options)
@@ -429,12 +425,6 @@ contains
     read (ifnamopt, OUTPUT, iostat=ierr); call chk(ierr, 'OUTPUT')
     close (ifnamopt)
     nprocx = 1; nprocy = nprocs     ! y-slabs over however many ranks were launched (1 in the np1 build)
-#ifdef UDC_DROPIN
-    if (libm .and. iwallmom /= 1) then
-      write (0, *) 'ERROR: ref_driver: the drop-in modibm has no facet wall functions (iwallmom > 1, src/modibm.f90:1286)'
-      stop 1
-    end if
-#endif
     allocate (wsvtop(1:max(nsv, 1))); wsvtop = 0.      ! src/modstartup.f90:518-519
     if (nsv > 0) wsvtop(1:nsv) = wsvtopdum(1:nsv)
     allocate (sv_top(1:max(nsv, 1))); sv_top = 0.

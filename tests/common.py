@@ -29,7 +29,7 @@ RUN_CASES = {"run_16x16x8": 21, "run_smag_scalar_16x8x12s": 22, "run_floor_scala
              "run_stats_16x8x12s": 62, "run_stats_ibm_16x12x10": 63,
              "run_floor_uno_nothl_16x8x12s": 65, "run_ibm_wf2_16x12x10": 68, "run_ibm_wh2_16x12x10": 70}
 # decks with the facet wall functions (iwallmom > 1): on the device path and in the reference build; not in the C oracle's
-# whole-substep driver (the numpy restatement covers the routine) nor in the Fortran drop-in modibm
+# whole-substep driver (the numpy restatement covers the routine); the Fortran drop-in modibm builds the section tables itself
 WF_RUN_CASES = {"run_ibm_wf2_16x12x10", "run_ibm_wh2_16x12x10"}
 
 

@@ -38,9 +38,6 @@ def run_dropin(name, iexp, mode, tmp_path, residency):
 @pytest.mark.parametrize("residency", [0, 1, 2])
 @pytest.mark.parametrize("name,iexp", sorted(RUN_CASES.items()))
 def test_fortran_driver_with_dropin_modules(name, iexp, residency, tmp_path):
-    from common import WF_RUN_CASES
-    if name in WF_RUN_CASES:
-        pytest.skip("the drop-in modibm has no facet wall functions yet (the C ABI does: udc_set_ibm_sections)")
     fix = load_fixture(name)
     got = run_dropin(name, iexp, "run", tmp_path, residency)
     checked = 0

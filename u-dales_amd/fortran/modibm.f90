@@ -9,8 +9,11 @@
 !!   ibmwallfun (:1167) without facet wall functions: diffu/v/w/c_corr             -> udc_ibmwallfun
 !!   ibmnorm (:697): solid                                                         -> udc_ibmnorm
 !!   createmasks (:2103): the integer masks II* and their slab / column counts, on the host as in the reference
-!! Not taken over yet (refused in initibm with the reference's error convention): the facet wall functions (iwallmom > 1:
-!! wallfunmom :1286, wallfunheat :1436 -- hence ltempeq / lmoist with libm), facet output (lwritefac).
+!!   facet wall functions (iwallmom = 2, 3: wallfunmom :1286; iwalltemp = 2: wallfunheat :1436, sensible part): the section
+!!       tables of initibmwallfun (:273-644) are built here from facet_sections_*.txt and the reference's own initfac data
+!!       (readfacetfiles stays the driver's call) and handed to the device once (udc_set_ibm_sections)
+!! Not taken over (refused in initibm with the reference's error convention): prescribed non-zero wall heat fluxes, wall
+!! moisture fluxes, facet output (lwritefac).
 !! The tau_x / tau_y / tau_z / thl_flux diagnostics of `bottom` and `ibmwallfun` (the tendency increments, read by the
 !! statistics) are not produced.
 module modibm
@@ -73,16 +76,17 @@ contains
     allocate (mask_w(ib - ih:ie + ih, jb - jh:je + jh, kb - kh:ke + kh)); mask_w = 1.
     allocate (mask_c(ib - ih:ie + ih, jb - jh:je + jh, kb - kh:ke + kh)); mask_c = 1.
     if (.not. libm) return
-    if (iwallmom > 1) then
-      write (0, *) 'ERROR: libudcore modibm: the facet wall functions (iwallmom > 1) are not available; set iwallmom = 1'
+    if (iwallmom < 1 .or. iwallmom > 3 .or. (iwallmom == 2 .and. .not. ltempeq)) then
+      write (0, *) 'ERROR: libudcore modibm: iwallmom must be 1, 2 (with ltempeq: the stability functions read the air temperature) or 3'
       stop 1
     end if
-    ! temperature / moisture: wallfunheat (src/modibm.f90:1436) is not available; it adds exactly nothing when the wall fluxes
-    ! are prescribed (iwalltemp / iwallmoist = 1) and zero -- adiabatic, impermeable walls -- and only such decks run
-    if (lwritefac .or. (ltempeq .and. (iwalltemp /= 1 .or. any((/bctfxm, bctfxp, bctfym, bctfyp, bctfz/) /= 0.))) .or. &
+    ! temperature: wallfunheat (src/modibm.f90:1436) from the facet temperatures (iwalltemp = 2) is available; prescribed fluxes
+    ! (iwalltemp = 1) only when they are zero, where it adds exactly nothing.  Moisture: impermeable walls only.
+    if (lwritefac .or. (ltempeq .and. ((iwalltemp /= 1 .and. iwalltemp /= 2) .or. &
+                                       (iwalltemp == 1 .and. any((/bctfxm, bctfxp, bctfym, bctfyp, bctfz/) /= 0.)))) .or. &
         (lmoist .and. (iwallmoist /= 1 .or. any((/bcqfxm, bcqfxp, bcqfym, bcqfyp, bcqfz/) /= 0.)))) then
-      write (0, *) 'ERROR: libudcore modibm: wall heat / moisture fluxes and lwritefac need the facet wall functions (wallfunheat);'
-      write (0, *) '       only iwalltemp = iwallmoist = 1 with bctf* = bcqf* = 0 (adiabatic, impermeable walls) is available'
+      write (0, *) 'ERROR: libudcore modibm: not available: lwritefac, prescribed non-zero wall heat fluxes (iwalltemp = 1),'
+      write (0, *) '       wall moisture fluxes (only iwallmoist = 1 with bcqf* = 0)'
       stop 1
     end if
     if (lmoist .and. lbuoyancy) then
@@ -151,8 +155,166 @@ contains
       end if
     end do
     call udc_check(udc_ibm_commit(udc_h), 'udc_ibm_commit')
+    call sections_to_device
     ibm_pending = .false.
   end subroutine ibm_to_device
+
+  !> facet wall functions (wallfunmom :1286, wallfunheat :1436): level coordinates and the facet sections of each grid
+  subroutine sections_to_device
+    use udc_iface
+    use modglobal, only: iwallmom, iwalltemp, ltempeq, prandtlturb, zf, zh, kb, ke, kh
+    logical :: heat
+    heat = ltempeq .and. iwalltemp == 2
+    if (iwallmom <= 1 .and. .not. heat) return
+    call udc_check(udc_set_ibm_wallfun(udc_h, int(iwallmom, c_int), real(prandtlturb, c_double), real(zf(kb:ke + kh), c_double), &
+                                       real(zh(kb:ke + kh), c_double)), 'udc_set_ibm_wallfun')
+    if (iwallmom > 1) then
+      call grid_sections(0, 'facet_sections_u.txt', nfctsecs_u)
+      call grid_sections(1, 'facet_sections_v.txt', nfctsecs_v)
+      call grid_sections(2, 'facet_sections_w.txt', nfctsecs_w)
+    end if
+    if (heat) then
+      call grid_sections(3, 'facet_sections_c.txt', nfctsecs_c)
+      call udc_check(udc_set_ibm_wallheat(udc_h, 2_c_int), 'udc_set_ibm_wallheat')
+    end if
+  end subroutine sections_to_device
+
+  !> One grid's section table as initibmwallfun (src/modibm.f90:273-644) leaves it: which sections act (:366-373), where the
+  !! velocity is taken -- the boundary cell, or a reconstruction point along the facet normal when log(dist / z0) <= 1
+  !! (:375-424) -- and the cells around that point on the four grids (:426-482).  Facet data from the reference's initfac.
+  subroutine grid_sections(grid, fname, nsec)
+    use udc_iface
+    use modglobal, only: ifinput, ib, itot, ih, jb, jtot, jh, kb, ke, kh, xf, xh, yf, yh, zf, zh, dx, dy, dzf, eps1
+    use initfac, only: facnorm, facz0, facz0h, facT
+    use decomp_2d, only: zstart, zend
+    integer, intent(in) :: grid, nsec
+    character(*), intent(in) :: fname
+    integer(c_int), allocatable :: cell(:, :), comprec(:), recids(:, :, :)
+    real(c_double), allocatable :: area(:), dist(:), norm(:, :), z0(:), z0h(:), ts(:), recpt(:, :), tmask(:, :)
+    integer :: n, m, fac, bid, dalign, q, pos, i, j, k, di, dj, dk, li, lj
+    real :: a, dst, xc, yc, zc, p0(3), p1(3), nrm(3), inter(6, 3), idist(6), planes(6, 3), pn(6, 3)
+    integer :: chk(6)
+    logical :: skip
+    character(80) :: chmess
+    allocate (cell(3, nsec), comprec(nsec), recids(3, 4, nsec), area(nsec), dist(nsec), norm(3, nsec), z0(nsec), z0h(nsec), ts(nsec), &
+              recpt(3, nsec), tmask(2, nsec))
+    recids = 1; recpt = 0.; tmask = 1.
+    dalign = merge(0, grid + 1, grid == 3)
+    di = merge(1, 0, grid == 0); dj = merge(1, 0, grid == 1); dk = merge(1, 0, grid == 2)
+    m = 0
+    if (nsec > 0) then
+      open (ifinput, file=fname)
+      read (ifinput, '(a80)') chmess
+      do n = 1, nsec
+        read (ifinput, *) fac, a, bid, dst
+        nrm = facnorm(fac, :)
+        if ((dalign /= 0 .and. dalign == alignment(nrm)) .or. facz0(fac) < eps1) cycle          ! :366-373
+        i = lists(grid)%bnd(1, bid); j = lists(grid)%bnd(2, bid); k = lists(grid)%bnd(3, bid)
+        m = m + 1
+        cell(:, m) = (/i, j, k/); area(m) = a; dist(m) = dst; norm(:, m) = nrm
+        z0(m) = facz0(fac); z0h(m) = facz0h(fac)
+        ts(m) = 0.
+        if (allocated(facT)) ts(m) = facT(fac, 1)
+        comprec(m) = 1
+        if (.not. (log(dst/facz0(fac)) > 1. .or. lnorec)) then                                       ! :375-378
+          comprec(m) = 0
+          select case (grid)
+          case (0); xc = xh(i); yc = yf(j); zc = zf(k)
+          case (1); xc = xf(i); yc = yh(j); zc = zf(k)
+          case (2); xc = xf(i); yc = yf(j); zc = zh(k)
+          case default; xc = xf(i); yc = yf(j); zc = zf(k)
+          end select
+          p0 = (/xc, yc, zc/)
+          p1 = p0 + nrm*sqrt(3.)*(dx*dy*dzf(1))**(1./3.)
+          pn = 0.; pn(1:2, 1) = 1.; pn(3:4, 2) = 1.; pn(5:6, 3) = 1.
+          planes(1, :) = (/xc - dx/2., yc, zc/); planes(2, :) = (/xc + dx/2., yc, zc/)
+          planes(3, :) = (/xc, yc - dy/2., zc/); planes(4, :) = (/xc, yc + dy/2., zc/)
+          planes(5, :) = (/xc, yc, zc - dzf(1)/2./); planes(6, :) = (/xc, yc, zc + dzf(1)/2./)
+          pos = 0
+          do q = 1, 6
+            call plane_line(pn(q, :), planes(q, :), p0, p1, inter(q, :), chk(q), idist(q))
+            if (chk(q) == 1) then
+              if (pos == 0) then
+                pos = q
+              else if (idist(q) < idist(pos)) then
+                pos = q
+              end if
+            end if
+          end do
+          if (pos == 0) then
+            write (0, *) 'ERROR: no intersection found'
+            stop 1
+          end if
+          recpt(:, m) = inter(pos, :)
+          recids(1, 1, m) = lastle(xh, recpt(1, m)); recids(2, 1, m) = lastle(yf, recpt(2, m)); recids(3, 1, m) = lastle(zf, recpt(3, m))
+          recids(1, 2, m) = lastle(xf, recpt(1, m)); recids(2, 2, m) = lastle(yh, recpt(2, m)); recids(3, 2, m) = lastle(zf, recpt(3, m))
+          recids(1, 3, m) = lastle(xf, recpt(1, m)); recids(2, 3, m) = lastle(yf, recpt(2, m)); recids(3, 3, m) = lastle(zh, recpt(3, m))
+          recids(1, 4, m) = lastle(xf, recpt(1, m)); recids(2, 4, m) = lastle(yf, recpt(2, m)); recids(3, 4, m) = lastle(zf, recpt(3, m))
+          skip = .false.
+          do q = 1, 4                                                                                  ! :447-482
+            if (recids(1, q, m) < ib .or. recids(1, q, m) + 1 > itot + ih .or. recids(2, q, m) < jb .or. recids(2, q, m) + 1 > jtot + jh .or. &
+                recids(3, q, m) < kb .or. recids(3, q, m) + 1 > ke + kh) skip = .true.
+          end do
+          if (skip) then
+            m = m - 1
+            cycle
+          end if
+        end if
+        ! interp_temperature_* (:1794-1830) reads mask_c at the cell and its lower neighbour along the grid's direction
+        if (grid < 3 .and. allocated(mask_c) .and. i >= zstart(1) .and. i <= zend(1) .and. j >= zstart(2) .and. j <= zend(2)) then
+          li = i - zstart(1) + 1; lj = j - zstart(2) + 1
+          tmask(1, m) = mask_c(li, lj, k); tmask(2, m) = mask_c(li - di, lj - dj, k - dk)
+        end if
+      end do
+      close (ifinput)
+    end if
+    call udc_check(udc_set_ibm_sections(udc_h, int(grid, c_int), int(m, c_int), cell, area, dist, norm, z0, z0h, ts, comprec, recpt, recids, &
+                                        tmask), 'udc_set_ibm_sections')
+  contains
+    !> findloc(x >= g, .true., 1, back = .true.): the last index of g (from ib, jb or kb on) with g <= x, 0 when there is none
+    integer function lastle(g, x)
+      real, intent(in) :: g(:), x
+      integer :: t
+      lastle = 0
+      do t = 1, size(g)
+        if (x >= g(t)) lastle = t
+      end do
+    end function lastle
+  end subroutine grid_sections
+
+  !> src/modibm.f90:1683-1706
+  integer function alignment(n)
+    use modglobal, only: eps1
+    real, intent(in) :: n(3)
+    integer :: d
+    real :: e(3)
+    alignment = 0
+    do d = 1, 3
+      e = 0.; e(d) = 1.
+      if (all(abs(n - e) < eps1)) alignment = d
+      if (all(abs(n + e) < eps1)) alignment = -d
+    end do
+  end function alignment
+
+  !> src/modibm.f90:647-694
+  subroutine plane_line(norm, V0, P0, P1, I, check, dist)
+    use modglobal, only: eps1
+    real, intent(in) :: norm(3), V0(3), P0(3), P1(3)
+    real, intent(out) :: I(3), dist
+    integer, intent(out) :: check
+    real :: u(3), w(3), D, N, sI
+    I = 0.; dist = 0.
+    w = P0 - V0; u = P1 - P0
+    D = dot_product(norm, u); N = -dot_product(norm, w)
+    if (abs(D) < eps1) then
+      check = merge(2, 0, abs(N) < eps1)
+      return
+    end if
+    sI = N/D
+    I = P0 + sI*u
+    dist = norm2(I - P0)
+    check = merge(3, 1, (sI < 0.) .or. (sI > 1.))
+  end subroutine plane_line
 
   !> integer masks and their counts (src/modibm.f90:2103-2234)
   subroutine createmasks

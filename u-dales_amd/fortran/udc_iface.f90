@@ -169,6 +169,26 @@ module udc_iface
       import :: c_int, c_ptr
       type(c_ptr), value :: h
     end function
+    integer(c_int) function udc_set_ibm_wallfun(h, iwallmom, prandtlturb, zf, zh) bind(C, name='udc_set_ibm_wallfun')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: iwallmom
+      real(c_double), value :: prandtlturb
+      real(c_double), intent(in) :: zf(*), zh(*)
+    end function udc_set_ibm_wallfun
+    integer(c_int) function udc_set_ibm_wallheat(h, iwalltemp) bind(C, name='udc_set_ibm_wallheat')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
+      integer(c_int), value :: iwalltemp
+    end function udc_set_ibm_wallheat
+    integer(c_int) function udc_set_ibm_sections(h, grid, n, cell, area, dist, norm, z0, z0h, tsurf, comprec, recpt, recids, tmask) &
+        bind(C, name='udc_set_ibm_sections')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: grid, n
+      integer(c_int), intent(in) :: cell(*), comprec(*), recids(*)
+      real(c_double), intent(in) :: area(*), dist(*), norm(*), z0(*), z0h(*), tsurf(*), recpt(*), tmask(*)
+    end function udc_set_ibm_sections
     integer(c_int) function udc_set_floor_air_temperature(h, thl_kb) bind(C, name='udc_set_floor_air_temperature')
       import :: c_ptr, c_int, c_double
       type(c_ptr), value :: h
