@@ -266,8 +266,10 @@ int udc_set_ibm_conservative(udc_handle *h, int lconservativeibm);
 int udc_set_ibm_wallfun(udc_handle *h, int iwallmom, double prandtlturb, const double *zf, const double *zh);
 /* Heat wall function (wallfunheat, src/modibm.f90:1436-1540, sensible part): iwalltemp = 2 takes the wall heat flux from the
  * facet temperatures with heat_transfer_coef_flux (:1920-1986) on the c-grid sections (udc_set_ibm_sections with grid 3) and
- * takes flux * area / (dx dy dzh(k)) out of thlp, before diffc_corr; iwalltemp = 1 (prescribed fluxes) is on the device for zero
- * fluxes only, where it adds nothing.  After udc_set_tempeq and udc_set_ibm_wallfun. */
+ * takes flux * area / (dx dy dzh(k)) out of thlp, before diffc_corr; iwalltemp = 1: the prescribed flux of the facet's direction
+ * (bctfxm ... bctfz, :1508-1524) is handed over per section in the slot of the facet temperature (tsurf), the same sections act
+ * (log-law and velocity checks included, as in the reference); 0 (the default): off, adiabatic walls.  After udc_set_tempeq and
+ * udc_set_ibm_wallfun. */
 int udc_set_ibm_wallheat(udc_handle *h, int iwalltemp);
 int udc_set_ibm_sections(udc_handle *h, int grid, int n, const int *cell, const double *area, const double *dist, const double *norm,
                          const double *z0, const double *z0h, const double *tsurf, const int *comprec, const double *recpt,

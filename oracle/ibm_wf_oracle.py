@@ -126,8 +126,10 @@ def _heat_flux(utan, dist, z0, z0h, tair, tsurf, prt):
     return abs(utan) * cth * dTrough
 
 
-def wallfunheat(g, S, facets, u0, v0, w0, thl0, thlp, prt=0.71, lnorec=False):
-    """wallfunheat's sensible part with iwalltemp = 2 (src/modibm.f90:1436-1540): thlp (m-array) updated in place."""
+def wallfunheat(g, S, facets, u0, v0, w0, thl0, thlp, prt=0.71, lnorec=False, prescribed=None):
+    """wallfunheat's sensible part (src/modibm.f90:1436-1540): thlp (m-array) updated in place.  iwalltemp = 2 unless
+    `prescribed` holds iwalltemp = 1's fluxes {alignment of the facet normal: flux} (:1508-1524)."""
+    from udcore.facets import alignment
     nx, ny, nz, dx, dy = g.nx, g.ny, g.nz, g.dx, g.dy
     xh, xf = np.arange(nx + 1) * dx, (np.arange(nx + 1) + 0.5) * dx
     yh, yf = np.arange(ny + 1) * dy, (np.arange(ny + 1) + 0.5) * dy
@@ -156,7 +158,7 @@ def wallfunheat(g, S, facets, u0, v0, w0, thl0, thlp, prt=0.71, lnorec=False):
         span = span / np.linalg.norm(span)
         strm = np.cross(span, norm)
         utan = float(np.dot(uvec, strm))
-        flux = _heat_flux(utan, dist, z0, z0h, tair, facets["tsurf"][fac], prt)
+        flux = prescribed[alignment(norm)] if prescribed is not None else _heat_flux(utan, dist, z0, z0h, tair, facets["tsurf"][fac], prt)
         thlp[k, j, i] = thlp[k, j, i] - flux * S["area"][s] / (dx * dy * g.dzh[k])
         acted += 1
     return acted

@@ -128,7 +128,10 @@ def write_ibm_files(d, blocks, nx, ny, nz):
 FACET_TYPES = [(1, 0.01, 0.001), (2, 0.12, 0.0035)]      # id, z0, z0h
 
 
-def facet_files(blocks, nx, ny, nz, dx, dy, dz):
+WF_NO_OBLIQUE = set()      # cases whose facets are all grid-aligned (prescribed wall heat fluxes are defined for those only)
+
+
+def facet_files(blocks, nx, ny, nz, dx, dy, dz, oblique=True):
     """-> (files {name: text}, counts {grid: nfctsecs}, nfcts)."""
     import numpy as np
     L = ibm_lists(blocks, nx, ny, nz)
@@ -145,7 +148,7 @@ def facet_files(blocks, nx, ny, nz, dx, dy, dz):
     for b in range(len(blocks)):
         for f in faces:
             n = normal[f]
-            if b == 1 and f == "east":
+            if b == 1 and f == "east" and oblique:
                 n = (0.8, 0.6, 0.)
             facets.append((2 if (b == 1 and f in ("top", "north")) else 1, n))
     nfcts = len(facets)
@@ -180,13 +183,13 @@ def facet_files(blocks, nx, ny, nz, dx, dy, dz):
 
 def ibm_walls_wf(blocks, nx, ny, nz, dx, dy, dz, iwallmom):
     L = ibm_lists(blocks, nx, ny, nz)
-    _, counts, nfcts = facet_files(blocks, nx, ny, nz, dx, dy, dz)
+    _, counts, nfcts = facet_files(blocks, nx, ny, nz, dx, dy, dz)      # (the counts do not depend on the oblique normal)
     return (f"iwallmom = {iwallmom}\nnfcts = {nfcts}\n" + "".join(f"nsolpts_{g} = {len(L[g][0])}\nnbndpts_{g} = {len(L[g][1])}\n" for g in "uvwc")
             + "".join(f"nfctsecs_{g} = {counts[g]}\n" for g in "uvwc"))
 
 
-def write_facet_files(d, iexp, blocks, nx, ny, nz, dx, dy, dz):
-    files, _, _ = facet_files(blocks, nx, ny, nz, dx, dy, dz)
+def write_facet_files(d, iexp, blocks, nx, ny, nz, dx, dy, dz, oblique=True):
+    files, _, _ = facet_files(blocks, nx, ny, nz, dx, dy, dz, oblique)
     for name, text in files.items():
         fn = f"facet_{name}.txt" if name.startswith("sections_") else f"{name}.inp.{iexp:03d}"
         with open(os.path.join(d, fn), "w") as f:
@@ -513,7 +516,22 @@ for _n in ("k_ibm_wf3_16x12x10", "k_ibm_wf2_16x12x10", "run_ibm_wf2_16x12x10"):
     IBM_BLOCKS[_n] = IBM_BLOCKS["run_ibm_16x12x10"]
 for _n in ("k_ibm_wh2_16x12x10", "run_ibm_wh2_16x12x10"):
     IBM_BLOCKS[_n] = IBM_BLOCKS["run_ibm_16x12x10"]
-WF_CASES = {"k_ibm_wf3_16x12x10": 3, "k_ibm_wf2_16x12x10": 2, "run_ibm_wf2_16x12x10": 2, "k_ibm_wh2_16x12x10": 2, "run_ibm_wh2_16x12x10": 2}
+WF_CASES = {"k_ibm_wf3_16x12x10": 3, "k_ibm_wf2_16x12x10": 2, "run_ibm_wf2_16x12x10": 2, "k_ibm_wh2_16x12x10": 2, "run_ibm_wh2_16x12x10": 2,
+            "k_ibm_wh1_16x12x10": 2, "run_ibm_wh1_16x12x10": 2}
+# + prescribed wall heat fluxes (wallfunheat with iwalltemp = 1 and non-zero bctf*: one flux per facet direction, :1510-1524;
+#   grid-aligned facets only -- the reference leaves the flux of any other normal undefined)
+for _n in ("k_ibm_wh1_16x12x10", "run_ibm_wh1_16x12x10"):
+    IBM_BLOCKS[_n] = IBM_BLOCKS["run_ibm_16x12x10"]
+    WF_NO_OBLIQUE.add(_n)
+_WH1_BC = _IBM_THL_BC + "\nbctfxm = 0.012\nbctfxp = -0.008\nbctfym = 0.02\nbctfyp = 0.005\nbctfz = 0.015"
+CASES.update({
+    "k_ibm_wh1_16x12x10": ("kernels", 71, 16, 12, 10, dict(sgs="vreman", nsv=1, floor=True, randu=0.05, ibm=IBM_BLOCKS["run_ibm_16x12x10"],
+                                                           iwallmom=2, walls="iwalltemp = 1", physics="ltempeq = .true.\nlbuoyancy = .true.",
+                                                           bc=_WH1_BC, oracle="nspin = 4"), 1.0),
+    "run_ibm_wh1_16x12x10": ("run", 72, 16, 12, 10, dict(sgs="vreman", nsv=1, floor=True, randu=0.05, ibm=IBM_BLOCKS["run_ibm_16x12x10"],
+                                                         iwallmom=2, walls="iwalltemp = 1", physics="ltempeq = .true.\nlbuoyancy = .true.",
+                                                         bc=_WH1_BC, oracle="nsub = 9\ndump_at = 3, 9"), 1.0),
+})
 # + the heat wall function on the facet temperatures (wallfunheat with iwalltemp = 2, src/modibm.f90:1436)
 CASES.update({
     "k_ibm_wh2_16x12x10": ("kernels", 69, 16, 12, 10, dict(sgs="vreman", nsv=1, floor=True, randu=0.05, ibm=IBM_BLOCKS["run_ibm_16x12x10"],
@@ -552,6 +570,7 @@ THL_CASES = {"k_tke_moist_12x8x8": dict(dthl=0.25, qt=0.0118, dqt=-8e-5, tke=0.0
              "run_stats_16x8x12s": dict(dthl=0.25), "run_stats_ibm_16x12x10": dict(dthl=0.25),
              "k_ibm_wf2_16x12x10": dict(dthl=0.3), "run_ibm_wf2_16x12x10": dict(dthl=0.25),
              "k_ibm_wh2_16x12x10": dict(dthl=0.3), "run_ibm_wh2_16x12x10": dict(dthl=0.25),
+             "k_ibm_wh1_16x12x10": dict(dthl=0.3), "run_ibm_wh1_16x12x10": dict(dthl=0.25),
              "k_vreman_buoycorr_12x8x10": dict(dthl=0.004), "run_vreman_buoycorr_16x8x12s": dict(dthl=0.004)}
 
 
@@ -647,7 +666,7 @@ def main():
         if name in IBM_BLOCKS:
             write_ibm_files(cdir, IBM_BLOCKS[name], nx, ny, nz)
         if name in WF_CASES:
-            write_facet_files(cdir, iexp, IBM_BLOCKS[name], nx, ny, nz, kw.get("dx", 0.5), kw.get("dy", 0.5), 0.5)
+            write_facet_files(cdir, iexp, IBM_BLOCKS[name], nx, ny, nz, kw.get("dx", 0.5), kw.get("dy", 0.5), 0.5, name not in WF_NO_OBLIQUE)
         with tempfile.TemporaryDirectory() as tmp:
             for fn in os.listdir(cdir):
                 shutil.copy(os.path.join(cdir, fn), tmp)

@@ -20,7 +20,7 @@ def _core(name, iexp):
 
 
 @pytest.mark.parametrize("name,iexp", [("k_ibm_16x12x10", 54), ("k_ibm_thl_16x12x10", 58), ("k_ibm_wf3_16x12x10", 66), ("k_ibm_wf2_16x12x10", 67),
-                                       ("k_ibm_wh2_16x12x10", 69)])
+                                       ("k_ibm_wh2_16x12x10", 69), ("k_ibm_wh1_16x12x10", 71)])
 def test_ibm_routines_match_reference(name, iexp):
     """The wf decks: the facet wall functions for momentum (wallfunmom, neutral and with the stability functions on the facet
     temperatures; sections with reconstruction points and an oblique facet normal) ahead of the diffusion corrections.
@@ -120,8 +120,8 @@ def test_ibm_refusals():
     with pytest.raises(ValueError, match="nfcts"):
         udcore.from_deck(d)
     d.nml["WALLS"]["iwalltemp"] = 1
-    d.nml.setdefault("BC", {})["bctfz"] = 0.01           # a prescribed, non-zero wall flux: not on the device
-    with pytest.raises(ValueError, match="iwalltemp = 1"):
+    d.nml.setdefault("BC", {})["bctfz"] = 0.01           # a prescribed wall flux acts on the facet sections: facets needed
+    with pytest.raises(ValueError, match="nfcts"):
         udcore.from_deck(d)
 
 

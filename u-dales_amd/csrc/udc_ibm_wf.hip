@@ -199,7 +199,8 @@ __global__ void ibm_wallfunheat_kernel(Geo g, Metrics m, WfArgs a) {
     sp[0] /= sn; sp[1] /= sn; sp[2] /= sn;
     const double st[3] = {sp[1] * nrm[2] - sp[2] * nrm[1], sp[2] * nrm[0] - sp[0] * nrm[2], sp[0] * nrm[1] - sp[1] * nrm[0]};
     const double utan = uv[0] * st[0] + uv[1] * st[1] + uv[2] * st[2];
-    const double flux = heat_flux(utan, dist, z0, a.z0h[s], Tair, a.tsurf[s], a.prt);
+    // iwalltemp = 1: the prescribed flux of the facet's direction rides in the slot of the facet temperature
+    const double flux = a.iwallmom == 1 ? a.tsurf[s] : heat_flux(utan, dist, z0, a.z0h[s], Tair, a.tsurf[s], a.prt);
     t = t - flux * a.area[s] / vol;
   }
   a.rhs[c] = t;
@@ -323,21 +324,21 @@ extern "C" int udc_set_ibm_wallheat(udc_handle *h, int iwalltemp) {
   if (!h) { udc_set_error("null handle"); return 1; }
   HIP_OK(hipSetDevice(h->device));
   if (udc_flush_pending(h)) return 1;
-  if (iwalltemp != 1 && iwalltemp != 2) { udc_set_error("udc_set_ibm_wallheat: iwalltemp must be 1 (prescribed fluxes; only zero is on the device) or 2 (facet temperatures)"); return 1; }
-  if (iwalltemp == 2 && ((int)h->fields.size() <= UDC_THL0 || !h->fields[UDC_THL0])) { udc_set_error("udc_set_ibm_wallheat: call udc_set_tempeq first"); return 1; }
-  if (iwalltemp == 2 && !h->ibm_zgrid) { udc_set_error("udc_set_ibm_wallheat: call udc_set_ibm_wallfun first (level coordinates, prandtlturb)"); return 1; }
+  if (iwalltemp < 0 || iwalltemp > 2) { udc_set_error("udc_set_ibm_wallheat: 0 (off: adiabatic walls), 1 (prescribed fluxes in the sections' tsurf) or 2 (facet temperatures)"); return 1; }
+  if (iwalltemp && ((int)h->fields.size() <= UDC_THL0 || !h->fields[UDC_THL0])) { udc_set_error("udc_set_ibm_wallheat: call udc_set_tempeq first"); return 1; }
+  if (iwalltemp && !h->ibm_zgrid) { udc_set_error("udc_set_ibm_wallheat: call udc_set_ibm_wallfun first (level coordinates, prandtlturb)"); return 1; }
   h->ibm_iwalltemp = iwalltemp;
   return 0;
 }
 
 // wallfunheat on thlp (ibmwallfun, src/modibm.f90:1220-1231), after the momentum corrections and before diffc_corr
 int k_ibm_wallfunheat(udc_handle *h) {
-  if (h->ibm_iwalltemp != 2) return 0;
+  if (h->ibm_iwalltemp < 1) return 0;
   const udc_handle::IbmSections &S = h->ibm_sec[3];
   if (!S.ncell) return 0;
   const Geo &g = h->g;
   WfArgs a;
-  a.ncell = S.ncell; a.grid = 3; a.iwallmom = 2; a.j0 = h->cfg.rank * g.ny;
+  a.ncell = S.ncell; a.grid = 3; a.iwallmom = h->ibm_iwalltemp; a.j0 = h->cfg.rank * g.ny;      // (iwallmom carries iwalltemp here)
   a.cell = S.cell; a.off = S.off; a.comprec = S.comprec; a.recids = S.recids;
   a.area = S.area; a.dist = S.dist; a.norm = S.norm; a.z0 = S.z0; a.z0h = S.z0h; a.tsurf = S.tsurf; a.recpt = S.recpt; a.tmask = S.tmask;
   a.u0 = h->fields[UDC_U0]; a.v0 = h->fields[UDC_V0]; a.w0 = h->fields[UDC_W0]; a.thl0 = h->fields[UDC_THL0];

@@ -197,7 +197,7 @@ struct udc_handle {
   };
   IbmSections ibm_sec[4];               // u, v, w (wallfunmom), c (wallfunheat)
   int ibm_iwallmom = 1;                 // 1: no wall functions; 2: Uno et al. stability functions; 3: neutral log law
-  int ibm_iwalltemp = 1;                // 1: prescribed wall heat fluxes (zero: adiabatic); 2: from the facet temperatures
+  int ibm_iwalltemp = 0;                // wallfunheat: 0 off (adiabatic walls); 1 prescribed fluxes per section; 2 from the facet temperatures
   double ibm_prt = 0.71;
   double *ibm_zgrid = nullptr;          // zf(1 : nz+1), zh(1 : nz+1)
   double *bottom_diag[3] = {nullptr, nullptr, nullptr};      // tau_x, tau_y, thl_flux planes [ny_l][nx] (udc_bottom_diagnostics)

@@ -80,13 +80,11 @@ contains
       write (0, *) 'ERROR: libudcore modibm: iwallmom must be 1, 2 (with ltempeq: the stability functions read the air temperature) or 3'
       stop 1
     end if
-    ! temperature: wallfunheat (src/modibm.f90:1436) from the facet temperatures (iwalltemp = 2) is available; prescribed fluxes
-    ! (iwalltemp = 1) only when they are zero, where it adds exactly nothing.  Moisture: impermeable walls only.
-    if (lwritefac .or. (ltempeq .and. ((iwalltemp /= 1 .and. iwalltemp /= 2) .or. &
-                                       (iwalltemp == 1 .and. any((/bctfxm, bctfxp, bctfym, bctfyp, bctfz/) /= 0.)))) .or. &
+    ! temperature: wallfunheat (src/modibm.f90:1436) with prescribed fluxes (iwalltemp = 1) or from the facet temperatures (2).
+    ! Moisture: impermeable walls only.
+    if (lwritefac .or. (ltempeq .and. iwalltemp /= 1 .and. iwalltemp /= 2) .or. &
         (lmoist .and. (iwallmoist /= 1 .or. any((/bcqfxm, bcqfxp, bcqfym, bcqfyp, bcqfz/) /= 0.)))) then
-      write (0, *) 'ERROR: libudcore modibm: not available: lwritefac, prescribed non-zero wall heat fluxes (iwalltemp = 1),'
-      write (0, *) '       wall moisture fluxes (only iwallmoist = 1 with bcqf* = 0)'
+      write (0, *) 'ERROR: libudcore modibm: not available: lwritefac, wall moisture fluxes (only iwallmoist = 1 with bcqf* = 0)'
       stop 1
     end if
     if (lmoist .and. lbuoyancy) then
@@ -163,8 +161,9 @@ contains
   subroutine sections_to_device
     use udc_iface
     use modglobal, only: iwallmom, iwalltemp, ltempeq, prandtlturb, zf, zh, kb, ke, kh
+    use modibmdata, only: bctfxm, bctfxp, bctfym, bctfyp, bctfz
     logical :: heat
-    heat = ltempeq .and. iwalltemp == 2
+    heat = ltempeq .and. (iwalltemp == 2 .or. (iwalltemp == 1 .and. any((/bctfxm, bctfxp, bctfym, bctfyp, bctfz/) /= 0.)))
     if (iwallmom <= 1 .and. .not. heat) return
     call udc_check(udc_set_ibm_wallfun(udc_h, int(iwallmom, c_int), real(prandtlturb, c_double), real(zf(kb:ke + kh), c_double), &
                                        real(zh(kb:ke + kh), c_double)), 'udc_set_ibm_wallfun')
@@ -175,7 +174,7 @@ contains
     end if
     if (heat) then
       call grid_sections(3, 'facet_sections_c.txt', nfctsecs_c)
-      call udc_check(udc_set_ibm_wallheat(udc_h, 2_c_int), 'udc_set_ibm_wallheat')
+      call udc_check(udc_set_ibm_wallheat(udc_h, int(iwalltemp, c_int)), 'udc_set_ibm_wallheat')
     end if
   end subroutine sections_to_device
 
@@ -184,7 +183,8 @@ contains
   !! (:375-424) -- and the cells around that point on the four grids (:426-482).  Facet data from the reference's initfac.
   subroutine grid_sections(grid, fname, nsec)
     use udc_iface
-    use modglobal, only: ifinput, ib, itot, ih, jb, jtot, jh, kb, ke, kh, xf, xh, yf, yh, zf, zh, dx, dy, dzf, eps1
+    use modglobal, only: ifinput, ib, itot, ih, jb, jtot, jh, kb, ke, kh, xf, xh, yf, yh, zf, zh, dx, dy, dzf, eps1, iwalltemp
+    use modibmdata, only: bctfxm, bctfxp, bctfyp, bctfz
     use initfac, only: facnorm, facz0, facz0h, facT
     use decomp_2d, only: zstart, zend
     integer, intent(in) :: grid, nsec
@@ -215,6 +215,18 @@ contains
         z0(m) = facz0(fac); z0h(m) = facz0h(fac)
         ts(m) = 0.
         if (allocated(facT)) ts(m) = facT(fac, 1)
+        if (grid == 3 .and. iwalltemp == 1) then      ! the prescribed flux of the facet's direction (:1508-1524) rides in this slot
+          select case (alignment(nrm))
+          case (1); ts(m) = bctfxp
+          case (-1); ts(m) = bctfxm
+          case (2); ts(m) = bctfyp
+          case (-2); ts(m) = bctfxm      ! (the reference's own assignment, :1518)
+          case (3); ts(m) = bctfz
+          case default
+            write (0, *) 'ERROR: libudcore modibm: iwalltemp = 1: the reference defines the wall heat flux for facets facing +-x, +-y, +z only'
+            stop 1
+          end select
+        end if
         comprec(m) = 1
         if (.not. (log(dst/facz0(fac)) > 1. .or. lnorec)) then                                       ! :375-378
           comprec(m) = 0

@@ -149,3 +149,18 @@ def temperature_masks(grid, S, mask_c):
         i, j, k = (int(c) for c in S["cell"][s])
         out[s] = (mask_c[k, j, i], mask_c[k - dk, j - dj, i - di])
     return out
+
+
+def prescribed_fluxes(deck, S, facets):
+    """wallfunheat with iwalltemp = 1 (src/modibm.f90:1508-1524): one wall heat flux per facet direction -- +x bctfxp, -x bctfxm,
+    +y bctfyp, -y bctfxm (the reference's own assignment), +z bctfz.  Any other normal keeps whatever `flux` held before in the
+    reference (undefined): refused.  -> flux per section."""
+    bc = lambda n: float(deck.get("BC", n))      # noqa: E731
+    table = {1: bc("bctfxp"), -1: bc("bctfxm"), 2: bc("bctfyp"), -2: bc("bctfxm"), 3: bc("bctfz")}
+    out = np.zeros(S["n"])
+    for s in range(S["n"]):
+        a = alignment(facets["norm"][int(S["fac"][s]) - 1])
+        if a not in table:
+            raise ValueError("iwalltemp = 1 with non-zero wall heat fluxes: the reference defines the flux for facets facing +-x, +-y, +z only")
+        out[s] = table[a]
+    return out

@@ -51,9 +51,9 @@ def apply_ibm(core, deck):
     # walls only (iwallmoist = 1, zero fluxes).
     bc = lambda n: float(deck.get("BC", n))      # noqa: E731
     iwalltemp = int(deck.get("WALLS", "iwalltemp"))
-    if deck.get("PHYSICS", "ltempeq") and (iwalltemp not in (1, 2) or (iwalltemp == 1 and any(bc(n) != 0. for n in ("bctfxm", "bctfxp", "bctfym", "bctfyp", "bctfz")))):
-        raise ValueError("libm with ltempeq: prescribed wall heat fluxes (iwalltemp = 1) are on the device path only when they are zero "
-                         "(adiabatic walls); iwalltemp = 2 takes them from the facet temperatures")
+    if deck.get("PHYSICS", "ltempeq") and iwalltemp not in (1, 2):
+        raise ValueError("libm with ltempeq: iwalltemp must be 1 (prescribed wall heat fluxes bctf*) or 2 (from the facet temperatures)")
+    fluxes = iwalltemp == 1 and any(bc(n) != 0. for n in ("bctfxm", "bctfxp", "bctfym", "bctfyp", "bctfz"))
     if deck.get("PHYSICS", "lmoist") and (int(deck.get("WALLS", "iwallmoist")) != 1 or any(bc(n) != 0. for n in ("bcqfxm", "bcqfxp", "bcqfym", "bcqfyp", "bcqfz"))):
         raise ValueError("libm with lmoist: wall moisture fluxes need wallfunheat, not on the device path; only iwallmoist = 1 with bcqf* = 0 is")
     if deck.get("PHYSICS", "lmoist") and deck.get("PHYSICS", "lbuoyancy"):
@@ -66,7 +66,7 @@ def apply_ibm(core, deck):
         if g in lists:
             core.set_ibm_points(q, *lists[g])
     core.ibm_commit()
-    heat = bool(deck.get("PHYSICS", "ltempeq")) and iwalltemp == 2
+    heat = bool(deck.get("PHYSICS", "ltempeq")) and (iwalltemp == 2 or fluxes)
     if iwallmom > 1 or heat:      # facet wall functions (wallfunmom, wallfunheat): facets and section tables to the device
         from .facets import c_mask, read_facets, temperature_masks, wall_sections
         g = core.g
@@ -82,6 +82,12 @@ def apply_ibm(core, deck):
                 core.set_ibm_sections(q, S, facets, temperature_masks(gr, S, mask))
         if heat:
             S = wall_sections(deck, gg, "c", lists["c"][1], facets)
+            if iwalltemp == 1:      # prescribed fluxes ride in the slot of the facet temperature
+                from .facets import prescribed_fluxes
+                nf = np.asarray(S["fac"]) - 1
+                facets = {"norm": facets["norm"][nf], "z0": facets["z0"][nf], "z0h": facets["z0h"][nf],
+                          "tsurf": prescribed_fluxes(deck, S, facets)}      # one entry per section
+                S = dict(S, fac=np.arange(1, S["n"] + 1, dtype=np.int32))
             core.set_ibm_sections(3, S, facets, np.ones((S["n"], 2)))
-            core.set_ibm_wallheat(2)
+            core.set_ibm_wallheat(iwalltemp)
     return lists
