@@ -65,7 +65,69 @@ def algo_bytes(name, nscal=0, stage1_frac=0.0):
     return None
 
 
-def workload_name(nx, ny, nz, sgs, nsv, floor):
+def cube_array_ibm(core, nx, ny, nz, j0=0, edge=32, pitch=128, iwallmom=3, heat=False):
+    """A staggered array of cubes (edge cells every pitch cells, the layout of BASELINE configs[4]) handed to the core: solid and
+    fluid-boundary point lists of the four grids and one facet section per boundary point for the wall functions (an oblique
+    facet normal, so that nothing is skipped and the stress is rotated; every third section takes the velocity at a
+    reconstruction point).  Global lists: every slab keeps its rows.  -> counts."""
+    import numpy as np
+    g = core.g
+    c = np.zeros((nz + 2, ny, nx), dtype=bool)
+    for jb, jj in enumerate(range(pitch // 4, ny - edge, pitch)):
+        for ii in range(pitch // 4 + (pitch // 2 if jb % 2 else 0), nx - edge, pitch):
+            c[1:edge + 1, jj:jj + edge, ii:ii + edge] = True
+    u = c | np.roll(c, 1, axis=2)
+    v = c | np.roll(c, 1, axis=1)
+    w = c.copy(); w[1:] |= c[:-1]
+    lists = {}
+    for name, sol in (("u", u), ("v", v), ("w", w), ("c", c)):
+        nb = np.zeros_like(sol)
+        for ax, sh in ((2, 1), (2, -1), (1, 1), (1, -1)):
+            nb |= np.roll(sol, sh, axis=ax)
+        nb[1:] |= sol[:-1]; nb[:-1] |= sol[1:]
+        bnd = nb & ~sol
+
+        def pts(m, lo):
+            m = m.copy(); m[:lo] = False; m[nz + 1:] = False
+            kji = np.argwhere(m)
+            return np.ascontiguousarray(np.stack([kji[:, 2] + 1, kji[:, 1] + 1, kji[:, 0]], axis=1), dtype=np.int32)
+        lists[name] = (pts(sol, 1), pts(bnd, 2 if name == "w" else 1))
+    for q, name in enumerate("uvwc"):
+        if name == "c" and not (core.nsv or getattr(core, "ltempeq", False)):
+            continue
+        core.set_ibm_points(q, *lists[name])
+    core.ibm_commit()
+    dx, dy = g.dx, g.dy
+    xh, xf = np.arange(nx + 1) * dx, (np.arange(nx + 1) + 0.5) * dx
+    yh, yf = np.arange(ny + 1) * dy, (np.arange(ny + 1) + 0.5) * dy
+    zf, zh = g.zf[1:nz + 2], g.zh[1:nz + 2]
+    facets = {"norm": np.array([[0.6, 0., 0.8]]), "z0": np.array([0.01]), "z0h": np.array([0.001]), "tsurf": np.array([289.])}
+    core.set_ibm_wallfun(iwallmom, 0.71, zf, zh)
+    counts = {"solid_c_cells": int(c.sum()), "sections": {}}
+    for q, name in enumerate("uvwc" if heat else "uvw"):
+        bnd = lists[name][1]
+        n = len(bnd)
+        xg, yg, zg = {"u": (xh, yf, zf), "v": (xf, yh, zf), "w": (xf, yf, zh), "c": (xf, yf, zf)}[name]
+        i, j, k = bnd[:, 0], bnd[:, 1], bnd[:, 2]
+        p = np.stack([xg[i - 1] + 0.3 * dx, yg[j - 1] + 0.2 * dy, zg[k - 1] + 0.3 * (zf[1] - zf[0])], axis=1)
+        ids = np.zeros((n, 4, 3), dtype=np.int32)
+        for t, (a, b, cc) in enumerate(((xh, yf, zf), (xf, yh, zf), (xf, yf, zh), (xf, yf, zf))):
+            ids[:, t, 0] = np.searchsorted(a, p[:, 0], side="right")
+            ids[:, t, 1] = np.searchsorted(b, p[:, 1], side="right")
+            ids[:, t, 2] = np.searchsorted(cc, p[:, 2], side="right")
+        ok = (ids.min(axis=(1, 2)) >= 1) & (ids[:, :, 0].max(axis=1) <= nx) & (ids[:, :, 1].max(axis=1) <= ny) & (ids[:, :, 2].max(axis=1) <= nz)
+        rec = ok & (np.arange(n) % 3 == 0)
+        S = {"n": n, "cell": bnd, "area": np.full(n, 0.1), "dist": np.full(n, 0.25), "fac": np.ones(n, dtype=np.int32),
+             "comprec": np.where(rec, 0, 1).astype(np.int32), "recpt": p, "recids": np.where(rec[:, None, None], ids, 1).astype(np.int32)}
+        core.set_ibm_sections(q, S, facets, np.ones((n, 2)))
+        counts["sections"][name] = {"sections": int(n), "with_reconstruction": int(rec.sum())}
+    if heat:
+        core.set_ibm_wallheat(2)
+    counts["points"] = {n: {"solid": int(len(lists[n][0])), "boundary": int(len(lists[n][1]))} for n in "uvwc"}
+    return counts
+
+
+def workload_name(nx, ny, nz, sgs, nsv, floor, ibm=False):
     """What actually runs, and the BASELINE.json configuration it is -- only when it is one."""
     w = (f"{nx}x{ny}x{nz} neutral empty-domain channel, cd2 momentum advection + "
          f"{'Vreman' if sgs == 'vreman' else 'Smagorinsky'} SGS diffusion"
@@ -77,6 +139,12 @@ def workload_name(nx, ny, nz, sgs, nsv, floor):
         w += " (BASELINE.json configs[2])"
     elif (nx, ny, nz, sgs, nsv) == (1024, 512, 512, "vreman", 0):
         w += " (BASELINE.json configs[3])"
+    if ibm:
+        w = w.replace("neutral empty-domain channel", "channel over a staggered array of 32-cell cubes every 128 cells (immersed boundary: "
+                      "masked stencils, sparse corrections, neutral facet wall functions on every boundary point)")
+        w = w.replace(" (BASELINE.json configs[1])", "").replace(" (BASELINE.json configs[2])", "").replace(" (BASELINE.json configs[3])", "")
+        if (nx, ny, nz) == (512, 512, 512):
+            w += " (the grid and obstacle layout of BASELINE.json configs[4])"
     return w
 
 
@@ -278,6 +346,8 @@ def main():
     ap.add_argument("--oversubscribe", action="store_true",
                     help="testing only: let WORLD_SIZE exceed the node's GPUs (ranks share devices, rendezvous over gloo); "
                          "RCCL refuses two ranks on one device, so the run stops cleanly at udc_comm_init")
+    ap.add_argument("--ibm", action="store_true",
+                    help="a staggered cube array with the immersed boundary and neutral facet wall functions (BASELINE configs[4]'s layout)")
     ap.add_argument("--no-floor", action="store_true",
                     help="free floor instead of the neutral log-law wall function (lbottom, BCbotm = 3) of SURVEY 8d")
     args = ap.parse_args()
@@ -340,6 +410,7 @@ def main():
             raise SystemExit(3)
     g = core.g
     nyl = ny // world
+    ibm_counts = cube_array_ibm(core, nx, ny, nz) if args.ibm else None
     st = cold_start(g, deck, j0=rank * nyl, nyl=nyl, nsv=args.nsv)
     core.load_state(st)
     core.halos()
@@ -479,7 +550,8 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": workload_name(nx, ny, nz, args.sgs, args.nsv, not args.no_floor),
+        "config": {"workload": workload_name(nx, ny, nz, args.sgs, args.nsv, not args.no_floor, args.ibm),
+                   **({"immersed_boundary": ibm_counts} if args.ibm else {}),
                    "floor": "free (no wall function)" if args.no_floor else
                             "neutral log-law wall function (lbottom, BCbotm=3, z0=0.05)",
                    "grid": [nx, ny, nz], "decomposition": f"y-slabs x{world}", "dt": dt,

@@ -28,54 +28,7 @@ def main():
     deck.nml.setdefault("RUN", {})["libm"] = False      # the lists are handed over below, not read from files
     core = udcore.from_deck(deck)
     g = core.g
-    c = np.zeros((nz + 2, ny, nx), dtype=bool)
-    for jb, j0 in enumerate(range(pitch // 4, ny - edge, pitch)):
-        for i0 in range(pitch // 4 + (pitch // 2 if jb % 2 else 0), nx - edge, pitch):
-            c[1:edge + 1, j0:j0 + edge, i0:i0 + edge] = True
-    u = c | np.roll(c, 1, axis=2)
-    v = c | np.roll(c, 1, axis=1)
-    w = c.copy(); w[1:] |= c[:-1]
-    lists = {}
-    for name, sol in (("u", u), ("v", v), ("w", w), ("c", c)):
-        nb = np.zeros_like(sol)
-        for ax, sh in ((2, 1), (2, -1), (1, 1), (1, -1)):
-            nb |= np.roll(sol, sh, axis=ax)
-        nb[1:] |= sol[:-1]; nb[:-1] |= sol[1:]
-        bnd = nb & ~sol
-
-        def pts(m, lo):
-            m = m.copy(); m[:lo] = False; m[nz + 1:] = False
-            kji = np.argwhere(m)
-            return np.ascontiguousarray(np.stack([kji[:, 2] + 1, kji[:, 1] + 1, kji[:, 0]], axis=1), dtype=np.int32)
-        lists[name] = (pts(sol, 1), pts(bnd, 2 if name == "w" else 1))
-    for q, name in enumerate("uvwc"):
-        core.set_ibm_points(q, *lists[name])
-    core.ibm_commit()
-    dx, dy = g.dx, g.dy
-    xh, xf = np.arange(nx + 1) * dx, (np.arange(nx + 1) + 0.5) * dx
-    yh, yf = np.arange(ny + 1) * dy, (np.arange(ny + 1) + 0.5) * dy
-    zf, zh = g.zf[1:nz + 2], g.zh[1:nz + 2]
-    facets = {"norm": np.array([[0.6, 0., 0.8]]), "z0": np.array([0.01]), "z0h": np.array([0.001]), "tsurf": np.array([289.])}
-    core.set_ibm_wallfun(2, 0.71, zf, zh)
-    nsec = {}
-    for q, name in enumerate("uvwc"):
-        bnd = lists[name][1]
-        n = len(bnd)
-        xg, yg, zg = {"u": (xh, yf, zf), "v": (xf, yh, zf), "w": (xf, yf, zh), "c": (xf, yf, zf)}[name]
-        i, j, k = bnd[:, 0], bnd[:, 1], bnd[:, 2]
-        p = np.stack([xg[i - 1] + 0.3 * dx, yg[j - 1] + 0.2 * dy, zg[k - 1] + 0.3 * (zf[1] - zf[0])], axis=1)
-        ids = np.zeros((n, 4, 3), dtype=np.int32)
-        for t, (a, b, cc) in enumerate(((xh, yf, zf), (xf, yh, zf), (xf, yf, zh), (xf, yf, zf))):
-            ids[:, t, 0] = np.searchsorted(a, p[:, 0], side="right")
-            ids[:, t, 1] = np.searchsorted(b, p[:, 1], side="right")
-            ids[:, t, 2] = np.searchsorted(cc, p[:, 2], side="right")
-        ok = (ids.min(axis=(1, 2)) >= 1) & (ids[:, :, 0].max(axis=1) <= nx) & (ids[:, :, 1].max(axis=1) <= ny) & (ids[:, :, 2].max(axis=1) <= nz)
-        rec = ok & (np.arange(n) % 3 == 0)
-        S = {"n": n, "cell": bnd, "area": np.full(n, 0.1), "dist": np.full(n, 0.25), "fac": np.ones(n, dtype=np.int32),
-             "comprec": np.where(rec, 0, 1).astype(np.int32), "recpt": p, "recids": np.where(rec[:, None, None], ids, 1).astype(np.int32)}
-        core.set_ibm_sections(q, S, facets, np.ones((n, 2)))
-        nsec[name] = {"sections": int(n), "with_reconstruction": int(rec.sum())}
-    core.set_ibm_wallheat(2)
+    counts = bench.cube_array_ibm(core, nx, ny, nz, iwallmom=2, heat=True)
     core.load_state(cold_start(g, deck, nsv=0))
     core.halos(); core.boundary()
     dt = 0.05
@@ -91,8 +44,8 @@ def main():
     prof = core.profile_get()
     core.profile(False)
     total = sum(ms for ms, _ in prof.values()) / nsub
-    out = {"grid": size, "cubes": {"edge": edge, "pitch": pitch, "solid_c_cells": int(c.sum())},
-           "points": {n: {"solid": int(len(lists[n][0])), "boundary": int(len(lists[n][1]))} for n in "uvwc"}, "sections": nsec,
+    out = {"grid": size, "cubes": {"edge": edge, "pitch": pitch, "solid_c_cells": counts["solid_c_cells"]},
+           "points": counts["points"], "sections": counts["sections"],
            "substep_ms_marked": round(total, 4), "kernels": {}}
     for name, (ms, cnt) in sorted(prof.items()):
         if name.startswith("ibm"):
