@@ -79,12 +79,19 @@ nsv = {nsv}{(chr(10) + scalars) if scalars else ''}
 """
 
 
+GROUND_CASES = set()      # blocks == "ground": no obstacles, the floor itself is the immersed boundary (the reference's examples/001)
+
+
 def ibm_lists(blocks, nx, ny, nz):
     """Point lists of the reference's IBM input files for axis-aligned blocks [(i0, i1, j0, j1, k1), ...] of solid cells
     (1-based, inclusive; blocks stand on the floor).  A u point is solid when the face between cells i-1 and i touches a
     solid cell (likewise v, w); fluid-boundary points are the fluid points with a solid point of their own grid among
     their six neighbours (x, y periodic).  Rows in k, j, i order."""
     import numpy as np
+    if blocks == "ground":      # the floor as facets: the w points of the first level are solid, the first cells of u, v, c (and
+        # the second level of w) look at it -- the lists of the reference's examples/001
+        full = [(i + 1, j + 1, 1) for j in range(ny) for i in range(nx)]
+        return {"u": ([], full), "v": ([], full), "c": ([], full), "w": (full, [(i, j, 2) for (i, j, _) in full])}
     c = np.zeros((nz + 2, ny, nx), dtype=bool)
     for (i0, i1, j0, j1, k1) in blocks:
         c[1:k1 + 1, j0 - 1:j1, i0 - 1:i1] = True
@@ -135,6 +142,19 @@ def facet_files(blocks, nx, ny, nz, dx, dy, dz, oblique=True):
     """-> (files {name: text}, counts {grid: nfctsecs}, nfcts)."""
     import numpy as np
     L = ibm_lists(blocks, nx, ny, nz)
+    if blocks == "ground":      # one facet per column pair, normal +z, half a cell below the u, v, c points and a cell below w(2)
+        nf = 4
+        files = {"facets": "# type, normal\n" + "".join("%d 0.0000 0.0000 1.0000\n" % (1 + q % 2) for q in range(nf)),
+                 "factypes": "# walltype\n# -\n# wallid lGR z0 z0h al em d1 d2 d3 C1 C2 C3 l1 l2 l3 k1 k2 k3 k4\n" +
+                             "".join("%d 0 %.4f %.5f 0.5 0.85 0.1 0.2 0.2 1875000 1875000 1875000 0.75 0.75 0.75 4e-7 4e-7 4e-7 4e-7\n" % t
+                                     for t in ((1, 0.05, 0.00035), (2, 0.02, 0.0002))),
+                 "Tfacinit": "# initial facet temperatures\n" + "".join("%.2f\n" % (288.5 + 0.5 * q) for q in range(nf))}
+        counts = {}
+        for g in "uvwc":
+            rows = [(1 + (i + j) % nf, dx * dy, q + 1, dz if g == "w" else 0.5 * dz) for q, (i, j, k) in enumerate(L[g][1])]
+            counts[g] = len(rows)
+            files[f"sections_{g}"] = " # facet      area flux point distance\n" + "".join("%8d %9.4f %10d %8.4f\n" % r for r in rows)
+        return files, counts, nf
     owner = np.zeros((nz + 2, ny, nx), dtype=int)          # block number (1-based) of a solid c cell
     for b, (i0, i1, j0, j1, k1) in enumerate(blocks):
         owner[1:k1 + 1, j0 - 1:j1, i0 - 1:i1] = b + 1
@@ -517,7 +537,18 @@ for _n in ("k_ibm_wf3_16x12x10", "k_ibm_wf2_16x12x10", "run_ibm_wf2_16x12x10"):
 for _n in ("k_ibm_wh2_16x12x10", "run_ibm_wh2_16x12x10"):
     IBM_BLOCKS[_n] = IBM_BLOCKS["run_ibm_16x12x10"]
 WF_CASES = {"k_ibm_wf3_16x12x10": 3, "k_ibm_wf2_16x12x10": 2, "run_ibm_wf2_16x12x10": 2, "k_ibm_wh2_16x12x10": 2, "run_ibm_wh2_16x12x10": 2,
-            "k_ibm_wh1_16x12x10": 2, "run_ibm_wh1_16x12x10": 2}
+            "k_ibm_wh1_16x12x10": 2, "run_ibm_wh1_16x12x10": 2, "run_ground_wf3_16x8x12": 3, "run_ground_wh2_16x8x12": 2}
+# the floor as facets instead of lbottom (the reference's examples/001: a flat channel whose ground is the immersed boundary, wall
+# functions on every first-level cell), neutral and with the stability functions + heat wall function
+for _n in ("run_ground_wf3_16x8x12", "run_ground_wh2_16x8x12"):
+    IBM_BLOCKS[_n] = "ground"
+CASES.update({
+    "run_ground_wf3_16x8x12": ("run", 73, 16, 8, 12, dict(sgs="vreman", nsv=1, randu=0.05, ibm="ground", iwallmom=3,
+                                                          oracle="nsub = 9\ndump_at = 3, 9"), 1.0),
+    "run_ground_wh2_16x8x12": ("run", 74, 16, 8, 12, dict(sgs="smag", nsv=1, randu=0.05, ibm="ground", iwallmom=2, walls="iwalltemp = 2",
+                                                          physics="ltempeq = .true.\nlbuoyancy = .true.",
+                                                          bc="BCtopT = 1\nwttop = 0.\nthls = 288.0", oracle="nsub = 9\ndump_at = 3, 9"), 1.0),
+})
 # + prescribed wall heat fluxes (wallfunheat with iwalltemp = 1 and non-zero bctf*: one flux per facet direction, :1510-1524;
 #   grid-aligned facets only -- the reference leaves the flux of any other normal undefined)
 for _n in ("k_ibm_wh1_16x12x10", "run_ibm_wh1_16x12x10"):
@@ -570,7 +601,7 @@ THL_CASES = {"k_tke_moist_12x8x8": dict(dthl=0.25, qt=0.0118, dqt=-8e-5, tke=0.0
              "run_stats_16x8x12s": dict(dthl=0.25), "run_stats_ibm_16x12x10": dict(dthl=0.25),
              "k_ibm_wf2_16x12x10": dict(dthl=0.3), "run_ibm_wf2_16x12x10": dict(dthl=0.25),
              "k_ibm_wh2_16x12x10": dict(dthl=0.3), "run_ibm_wh2_16x12x10": dict(dthl=0.25),
-             "k_ibm_wh1_16x12x10": dict(dthl=0.3), "run_ibm_wh1_16x12x10": dict(dthl=0.25),
+             "k_ibm_wh1_16x12x10": dict(dthl=0.3), "run_ibm_wh1_16x12x10": dict(dthl=0.25), "run_ground_wh2_16x8x12": dict(dthl=0.25),
              "k_vreman_buoycorr_12x8x10": dict(dthl=0.004), "run_vreman_buoycorr_16x8x12s": dict(dthl=0.004)}
 
 
