@@ -653,7 +653,15 @@ def make_restart_cases():
 # prof.inp, lscale.inp): examples/999, the flat neutral channel at 128^3 with the floor wall function at its defaults
 # (BCbotm = 2 without temperature equation), the adaptive time step and tdump / xytdump / fielddump output.  The golden holds
 # xytdump's table and the clock after `nsub` substeps of the reference binary (the 3-D fields would be 17 MB each).
-EXAMPLES = {"example_999": ("999", 999, 75)}
+EXAMPLES = {"example_999": ("999", 999, 75), "example_001": ("001", 1, 75)}
+# examples/001: the same channel with the ground as an immersed boundary (128 facets, 16384 boundary points per grid, ~17800
+# facet sections on u and v: the output of the reference's pre-processing).  The shipped deck leaves iwallmom at its default
+# of 2, which needs a Tfacinit.inp the example does not ship (the reference stops in readfacetfiles) and reads mask_c
+# unallocated; the fixture's deck selects the neutral wall function (one line added to &WALLS), everything else is the example's.
+EXAMPLE_FILES = {"example_001": ["facets.inp.001", "factypes.inp.001", "facet_sections_u.txt", "facet_sections_v.txt", "facet_sections_w.txt",
+                                 "facet_sections_c.txt", "fluid_boundary_u.txt", "fluid_boundary_v.txt", "fluid_boundary_w.txt",
+                                 "fluid_boundary_c.txt", "solid_u.txt", "solid_v.txt", "solid_w.txt", "solid_c.txt"]}
+EXAMPLE_PATCH = {"example_001": ("&WALLS\n", "&WALLS\niwallmom = 3\n")}
 
 
 def make_example_cases(only):
@@ -666,9 +674,23 @@ def make_example_cases(only):
         os.makedirs(cdir, exist_ok=True)
         for fn in (f"namoptions.{iexp:03d}", f"prof.inp.{iexp:03d}", f"lscale.inp.{iexp:03d}"):
             shutil.copy(os.path.join(src, fn), cdir)
+        if name in EXAMPLE_PATCH:
+            old, new = EXAMPLE_PATCH[name]
+            with open(os.path.join(cdir, f"namoptions.{iexp:03d}")) as f:
+                text = f.read()
+            assert text.count(old) == 1
+            with open(os.path.join(cdir, f"namoptions.{iexp:03d}"), "w") as f:
+                f.write(text.replace(old, new))
+        for fn in EXAMPLE_FILES.get(name, []):      # the pre-processing's lists, kept compressed (1.4 MB of text)
+            with open(os.path.join(src, fn), "rb") as f, gzip.GzipFile(os.path.join(cdir, fn + ".gz"), "wb", mtime=0) as gz:
+                gz.write(f.read())
         with tempfile.TemporaryDirectory() as tmp:
             for fn in os.listdir(cdir):
-                shutil.copy(os.path.join(cdir, fn), tmp)
+                if fn.endswith(".gz"):
+                    with gzip.open(os.path.join(cdir, fn), "rb") as f, open(os.path.join(tmp, fn[:-3]), "wb") as o:
+                        o.write(f.read())
+                else:
+                    shutil.copy(os.path.join(cdir, fn), tmp)
             with open(os.path.join(tmp, f"namoptions.{iexp:03d}"), "a") as f:      # the driver's own group; the deck is otherwise untouched
                 f.write(f"\n&ORACLE\nnsub = {nsub}\n/\n")
             out = os.path.join(tmp, "out.bin")

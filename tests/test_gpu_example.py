@@ -3,6 +3,7 @@ flat neutral channel at 128^3 -- floor wall function at the reference's defaults
 off and thls at its default of -1), adaptive time step, &OUTPUT tdump + xytdump + fielddump, a CPU layout of 4 x 2 ranks in
 &RUN, a pre-processing group (&INP) the Fortran never reads.  Golden: xytdump's table and the clock after 25 steps of the
 reference binary on the same files (tests/golden/make_golden.py, EXAMPLES)."""
+import gzip
 import os
 import shutil
 import sys
@@ -17,11 +18,45 @@ XYT_FIX = {"uwtxyik": "uwxyt", "vwtxyjk": "vwxyt", "wwtxyk": "wwxyt", "uvtxyij":
            "upvptxyij": "upvpxyt"}
 
 
+def _unpack(case, tmp_path):
+    src = os.path.join(GOLDEN, "cases", case)
+    for fn in os.listdir(src):
+        if fn.endswith(".gz"):
+            with gzip.open(os.path.join(src, fn), "rb") as f, open(tmp_path / fn[:-3], "wb") as o:
+                o.write(f.read())
+        else:
+            shutil.copy(os.path.join(src, fn), tmp_path)
+
+
+def test_reference_example_001_with_the_ground_as_facets(tmp_path):
+    """examples/001 of the reference: the same 128^3 channel with the ground as an immersed boundary -- the lists and the ~53000
+    facet sections are the output of the reference's own pre-processing (multiple sections per boundary point, facets from an
+    STL), read by udcore/facets.py.  One line is added to the shipped deck (iwallmom = 3: its default of 2 needs a facet
+    temperature file the example does not ship).  25 adaptive steps against the reference binary on the same files."""
+    from udcore import run
+    fix = load_fixture("example_001")
+    _unpack("example_001", tmp_path)
+    got = {}
+
+    def at_end(core, tdump):
+        got["xyt"], got["time"], got["div"] = tdump.xyt(), (core.timee, core.dt), core.divergence()[0]
+
+    assert run.main([str(tmp_path / "namoptions.001"), "--steps", "25", "--quiet"], at_end=at_end) == 0
+    tref, dtref = fix["end.time"].data
+    assert abs(got["time"][0] - tref) <= 1e-9 * tref and abs(got["time"][1] - dtref) <= 1e-8 * dtref
+    assert got["div"] < 1e-10
+    for k, rec in fix.items():
+        if k.startswith("xyt."):
+            ref = rec.data[:128]
+            g = got["xyt"][XYT_FIX.get(k[4:], k[4:])]
+            assert np.abs(g - ref).max() <= 1e-9 * max(np.abs(ref).max(), 1e-3), (k, np.abs(g - ref).max())
+    assert 0.2 < got["xyt"]["uxyt"][0] < 0.5 and got["xyt"]["uxyt"][5] > 0.9      # the wall functions slowed the first level down
+
+
 def test_reference_example_999_runs_unmodified(tmp_path):
     from udcore import run
     fix = load_fixture("example_999")
-    for fn in os.listdir(os.path.join(GOLDEN, "cases", "example_999")):
-        shutil.copy(os.path.join(GOLDEN, "cases", "example_999", fn), tmp_path)
+    _unpack("example_999", tmp_path)
     got = {}
 
     def at_end(core, tdump):

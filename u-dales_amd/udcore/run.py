@@ -38,8 +38,9 @@ def check_supported(deck):
                 _refuse(f"only periodic lateral boundaries are on the device path (&BC {n})")
     if bool(g("RUN", "lwarmstart")):
         _refuse("&RUN lwarmstart: warm starts go through --restart-from NTRUN (the runner does not read startfile)")
-    if g("RUN", "libm") and int(g("WALLS", "iwallmom")) != 1:
-        _refuse("immersed boundaries: only iwallmom = 1 (no facet wall functions) is on the device path")
+    if g("RUN", "libm") and int(g("WALLS", "iwallmom")) == 2 and not g("PHYSICS", "ltempeq"):
+        # (the reference reads mask_c unallocated in this combination, src/modibm.f90:180, 1794-1830)
+        _refuse("immersed boundaries with iwallmom = 2 (stability functions) read the air temperature: needs ltempeq; iwallmom = 3 is the neutral wall function")
     if int(g("BC", "BCxm")) != 1 or int(g("BC", "BCym")) != 1:
         _refuse("only periodic lateral boundaries (BCxm = BCym = 1) are on the device path")
     if int(g("DYNAMICS", "ipoiss")) != 0 or int(g("BC", "BCzp")) != 1:
