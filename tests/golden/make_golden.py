@@ -653,7 +653,7 @@ def make_restart_cases():
 # prof.inp, lscale.inp): examples/999, the flat neutral channel at 128^3 with the floor wall function at its defaults
 # (BCbotm = 2 without temperature equation), the adaptive time step and tdump / xytdump / fielddump output.  The golden holds
 # xytdump's table and the clock after `nsub` substeps of the reference binary (the 3-D fields would be 17 MB each).
-EXAMPLES = {"example_999": ("999", 999, 75), "example_001": ("001", 1, 75)}
+EXAMPLES = {"example_999": ("999", 999, 75), "example_001": ("001", 1, 75), "example_002": ("002", 2, 75)}
 # examples/001: the same channel with the ground as an immersed boundary (128 facets, 16384 boundary points per grid, ~17800
 # facet sections on u and v: the output of the reference's pre-processing).  The shipped deck leaves iwallmom at its default
 # of 2, which needs a Tfacinit.inp the example does not ship (the reference stops in readfacetfiles) and reads mask_c
@@ -661,7 +661,8 @@ EXAMPLES = {"example_999": ("999", 999, 75), "example_001": ("001", 1, 75)}
 EXAMPLE_FILES = {"example_001": ["facets.inp.001", "factypes.inp.001", "facet_sections_u.txt", "facet_sections_v.txt", "facet_sections_w.txt",
                                  "facet_sections_c.txt", "fluid_boundary_u.txt", "fluid_boundary_v.txt", "fluid_boundary_w.txt",
                                  "fluid_boundary_c.txt", "solid_u.txt", "solid_v.txt", "solid_w.txt", "solid_c.txt"]}
-EXAMPLE_PATCH = {"example_001": ("&WALLS\n", "&WALLS\niwallmom = 3\n")}
+EXAMPLE_FILES["example_002"] = [f.replace(".001", ".002") for f in EXAMPLE_FILES["example_001"]]      # 64^3, an array of cubes: 1024 facets
+EXAMPLE_PATCH = {"example_001": ("&WALLS\n", "&WALLS\niwallmom = 3\n"), "example_002": ("&WALLS\n", "&WALLS\niwallmom = 3\n")}
 
 
 def make_example_cases(only):

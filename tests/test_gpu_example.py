@@ -53,6 +53,29 @@ def test_reference_example_001_with_the_ground_as_facets(tmp_path):
     assert 0.2 < got["xyt"]["uxyt"][0] < 0.5 and got["xyt"]["uxyt"][5] > 0.9      # the wall functions slowed the first level down
 
 
+def test_reference_example_002_cube_array_with_facets(tmp_path):
+    """examples/002: 64^3, a regular array of cubes from an STL -- 1024 facets, ~8500 boundary points per grid and ~10800 facet
+    sections per velocity grid from the reference's pre-processing, the deck's CPU layout of 2 x 2 ranks, xytdump with masked
+    slab averages; as for 001 the deck gets `iwallmom = 3`.  25 adaptive steps against the reference binary."""
+    from udcore import run
+    fix = load_fixture("example_002")
+    _unpack("example_002", tmp_path)
+    got = {}
+
+    def at_end(core, tdump):
+        got["xyt"], got["time"], got["div"] = tdump.xyt(), (core.timee, core.dt), core.divergence()[0]
+
+    assert run.main([str(tmp_path / "namoptions.002"), "--steps", "25", "--quiet"], at_end=at_end) == 0
+    tref, dtref = fix["end.time"].data
+    assert abs(got["time"][0] - tref) <= 1e-9 * tref and abs(got["time"][1] - dtref) <= 1e-8 * dtref
+    assert got["div"] < 1e-10
+    for k, rec in fix.items():
+        if k.startswith("xyt."):
+            ref = rec.data[:64]
+            g = got["xyt"][XYT_FIX.get(k[4:], k[4:])]
+            assert np.abs(g - ref).max() <= 1e-9 * max(np.abs(ref).max(), 1e-3 * 2.25), (k, np.abs(g - ref).max())
+
+
 def test_reference_example_999_runs_unmodified(tmp_path):
     from udcore import run
     fix = load_fixture("example_999")
