@@ -358,6 +358,16 @@ enum {
 int udc_stats_set_masks(udc_handle *h, const unsigned char *bits, const int *counts);
 int udc_stats_xyt(udc_handle *h, double *table);
 
+/* Passive scalars with an inflow and an outflow in x while the flow stays periodic (&BC BCxs = 2, the reference's dispersion
+ * examples): inlet ghost cells mirrored about the inflow profile (xsi_profile, src/modboundary.f90:844-861), a convective outlet
+ * ghost updated at every `boundary` (xso_convective, :983-996, with uouttot = ubulk of a prescribed volume flow, :159), no
+ * periodic refresh of the scalars' x ghosts (:99).  svprof[nsv][ktot+2] is indexed by the reference's k; the east ghost columns
+ * are taken from any upload of sv0 whose host array carries them (lb[0] <= itot+1, ub[0] >= itot+2).  advecc_kappa and diffc
+ * then see those ghosts in the two cell columns next to either end; a download of sv0 into such an array fills them back in
+ * (the inlet ones by xsi_profile's rule).  Not covered: obstacles touching the x ends of the domain; svm's ghost columns (no
+ * routine reads them). */
+int udc_set_scalar_bcx(udc_handle *h, int bcxs, const double *svprof, double uouttot);
+
 /* divergence of u0 as modchecksim's chkdiv (src/modchecksim.f90:161-203): max |div|, sum div */
 int udc_divergence(udc_handle *h, double *divmax, double *divtot);
 

@@ -401,7 +401,7 @@ contains
     namelist /INLET/ Uinf, Vinf, inletav
     namelist /CHEMISTRY/ lchem, k1, JNO2
     namelist /DYNAMICS/ lqlnr, ipoiss, iadv_mom, iadv_tke, iadv_thl, iadv_qt, iadv_sv
-    namelist /BC/ BCxm, BCym, BCtopm, BCtopT, BCtops, BCbotm, BCbots, BCbotT, BCzp, wttop, thl_top, z0, wtsurf, thls, qts, &
+    namelist /BC/ BCxs, BCxm, BCym, BCtopm, BCtopT, BCtops, BCbotm, BCbots, BCbotT, BCzp, wttop, thl_top, z0, wtsurf, thls, qts, &
       BCtopq, BCbotq, wqtop, qt_top, wqsurf, z0h, wsvtopdum, ds, bctfxm, bctfxp, bctfym, bctfyp, bctfz, &
       bcqfxm, bcqfxp, bcqfym, bcqfyp, bcqfz
     namelist /SCALARS/ nsv, lscasrc, nscasrc, lscasrcl, nscasrcl
@@ -511,6 +511,10 @@ contains
       end do
     end if
     u0 = um; v0 = vm; w0 = wm
+    block      ! src/modstartup.f90:1336-1341: the outflow speed of the convective outlet under luvolflowr (src/modboundary.f90:159)
+      use modinletdata, only: ubulk
+      ubulk = sum(uprof(kb:ke)*dzf(kb:ke))/(zh(ke + 1) - zh(kb))
+    end block
     ! passive scalars (stand-in for scalar.inp, src/modstartup.f90:1541-1560): linear profile
     zsize_ = zh(ke + 1)
     do n = 1, nsv

@@ -17,7 +17,7 @@ KERNEL_CASES = {
     "k_volflow_12x8x6": 17, "k_thl_12x8x6": 18,
     "k_buoy_12x8x6": 19,
     "k_coriol_12x8x6": 20,
-    "k_tke_12x8x6": 21, "k_tke_thl_12x8x6": 28, "k_qt_12x8x6": 32, "k_moist_12x8x8": 35, "k_uno_12x8x6": 37, "k_src_12x8x8": 39, "k_thlk_12x8x6": 41, "k_svtop_8x8x8": 47, "k_tke_moist_12x8x8": 50, "k_vreman_buoycorr_12x8x10": 52, "k_floor_uno_nothl_12x8x6": 64,
+    "k_tke_12x8x6": 21, "k_tke_thl_12x8x6": 28, "k_qt_12x8x6": 32, "k_moist_12x8x8": 35, "k_uno_12x8x6": 37, "k_src_12x8x8": 39, "k_thlk_12x8x6": 41, "k_svtop_8x8x8": 47, "k_tke_moist_12x8x8": 50, "k_vreman_buoycorr_12x8x10": 52, "k_floor_uno_nothl_12x8x6": 64, "k_bcxs_16x8x12": 75,
 }
 # per-level forcings (lstend, nudge, grwdamp): host-level routines, checked in tests/test_level_forcings.py
 LSF_CASES = {"k_lsf_12x8x24": 29, "run_lsf_16x8x24s": 30, "k_lsfq_12x8x20": 34}
@@ -28,10 +28,11 @@ RUN_CASES = {"run_16x16x8": 21, "run_smag_scalar_16x8x12s": 22, "run_floor_scala
              "run_ibm_thl_16x12x10": 59, "run_ibm_thlcons_16x12x10": 60, "run_ibm_qt_16x12x10": 61,
              "run_stats_16x8x12s": 62, "run_stats_ibm_16x12x10": 63,
              "run_floor_uno_nothl_16x8x12s": 65, "run_ibm_wf2_16x12x10": 68, "run_ibm_wh2_16x12x10": 70, "run_ibm_wh1_16x12x10": 72,
-             "run_ground_wf3_16x8x12": 73, "run_ground_wh2_16x8x12": 74}
+             "run_ground_wf3_16x8x12": 73, "run_ground_wh2_16x8x12": 74, "run_bcxs_16x8x12s": 76}
 # decks with the facet wall functions (iwallmom > 1): on the device path and in the reference build; not in the C oracle's
 # whole-substep driver (the numpy restatement covers the routine); the Fortran drop-in modibm builds the section tables itself
-WF_RUN_CASES = {"run_ibm_wf2_16x12x10", "run_ibm_wh2_16x12x10", "run_ibm_wh1_16x12x10", "run_ground_wf3_16x8x12", "run_ground_wh2_16x8x12"}
+# (also: BCxs = 2, the scalars' inflow / outflow -- pinned device against reference fixture, not restated in the C oracle)
+WF_RUN_CASES = {"run_bcxs_16x8x12s", "run_ibm_wf2_16x12x10", "run_ibm_wh2_16x12x10", "run_ibm_wh1_16x12x10", "run_ground_wf3_16x8x12", "run_ground_wh2_16x8x12"}
 
 
 def load_fixture(name):

@@ -582,6 +582,15 @@ CASES.update({
                                                          iwallmom=2, physics="ltempeq = .true.\nlbuoyancy = .true.", bc=_IBM_THL_BC,
                                                          oracle="nsub = 9\ndump_at = 3, 9"), 1.0),
 })
+# scalars with an inflow / outflow in x while the flow stays periodic (BCxs = 2, the reference's dispersion examples 101 / 102):
+# inlet ghosts mirrored about the inflow profile (xsi_profile, src/modboundary.f90:844), a convective outlet ghost (xso_convective
+# :983, outflow speed ubulk under luvolflowr), no periodic refresh of the scalars' x ghosts
+CASES.update({
+    "k_bcxs_16x8x12": ("kernels", 75, 16, 8, 12, dict(sgs="smag", nsv=2, floor=True, randu=0.05, physics="luvolflowr = .true.\nuflowrate = 1.1",
+                                                      bc="BCxs = 2", oracle="nspin = 5\nscal_b = 0.2"), 1.05),
+    "run_bcxs_16x8x12s": ("run", 76, 16, 8, 12, dict(sgs="vreman", nsv=1, floor=True, randu=0.05, physics="luvolflowr = .true.\nuflowrate = 1.1",
+                                                     bc="BCxs = 2", oracle="nsub = 9\ndump_at = 3, 9\nscal_b = 0.2"), 1.06),
+})
 LSF_ONLY = ("k_lsf_12x8x24", "k_lsfq_12x8x20", "k_fix1_12x8x6")
 THL_CASES = {"k_tke_moist_12x8x8": dict(dthl=0.25, qt=0.0118, dqt=-8e-5, tke=0.06),
              "run_moistnr_16x8x12s": dict(dthl=0.25, qt=0.0119, dqt=-6e-5),

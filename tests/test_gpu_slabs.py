@@ -26,9 +26,10 @@ def test_forced_slab_path_matches_reference():
     code = r'''
 import sys, numpy as np
 sys.path[:0] = ["%s/tests", "%s/u-dales_amd"]
-from common import RUN_CASES, deck_path, load_fixture, marr, nocorner, relerr
+from common import RUN_CASES, carr, deck_path, interior, load_fixture, marr, nocorner, relerr
 import udcore
 from udcore import read_deck, cold_start
+from udcore import lib as L
 for name, iexp in RUN_CASES.items():
     fix = load_fixture(name)
     d = read_deck(deck_path(name, iexp))
@@ -43,6 +44,9 @@ for name, iexp in RUN_CASES.items():
                 ref = marr(fix, f"s{isub:03d}.{k}", core.g.nz)
                 e = relerr(nocorner(core.download(k)[1:-1]), nocorner(ref[1:-1]))
                 assert e <= 1e-9, (name, isub, k, e)
+            for n in range(core.nsv):      # (the scalars' inflow / outflow of the BCxs deck lives here)
+                e = relerr(interior(core.download(L.scalar_field(L.SV0, n), halo=2), 2), interior(carr(fix, f"s{isub:03d}.sv0_{n + 1:02d}", core.g.nz), 2))
+                assert e <= 1e-9, (name, isub, "sv0", n, e)
     core.close()
 print("SLAB_OK")
 ''' % (ROOT, ROOT)

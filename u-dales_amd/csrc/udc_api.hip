@@ -236,6 +236,8 @@ extern "C" int udc_destroy(udc_handle *h) {
   ibm_destroy(h);
   stats_destroy(h);
   ibm_wf_destroy(h);
+  for (double *&p : h->bcx_east) if (p) { hipFree(p); p = nullptr; }
+  if (h->bcx_prof) { hipFree(h->bcx_prof); h->bcx_prof = nullptr; }
   for (int q = 0; q < 4; ++q) if (h->halo_buf[q]) hipFree(h->halo_buf[q]);
   for (auto &f : h->level_forcings) { if (f.A) hipFree(f.A); if (f.stage) hipHostFree(f.stage); if (f.copied) hipEventDestroy(f.copied); }
   for (double *p : h->fields) if (p) hipFree(p);
@@ -321,11 +323,40 @@ static int copy3d_ptr(udc_handle *h, int field, double *dev, double *host, const
 
 extern "C" int udc_field_upload(udc_handle *h, int field, const double *host, const int lb[3], const int ub[3]) {
   ENTRY_FLUSH(h);
-  return copy3d(h, field, const_cast<double *>(host), lb, ub, true);
+  if (copy3d(h, field, const_cast<double *>(host), lb, ub, true)) return 1;
+  if (h->scal_bcx == 2 && field >= UDC_SV0 && (field - UDC_SV0) % 3 == 0)      // sv0 with its east ghost columns (BCxs = 2)
+    return k_scalar_bcx_capture(h, (field - UDC_SV0) / 3, host, lb, ub);
+  return 0;
+}
+
+extern "C" int udc_set_scalar_bcx(udc_handle *h, int bcxs, const double *svprof, double uouttot) {
+  ENTRY_FLUSH(h);
+  if (bcxs != 1 && bcxs != 2) { udc_set_error("udc_set_scalar_bcx: BCxs must be 1 (periodic) or 2 (inflow profile, convective outflow)"); return 1; }
+  const Geo &g = h->g;
+  h->scal_bcx = bcxs;
+  if (bcxs == 1) return 0;
+  if (!svprof) { udc_set_error("udc_set_scalar_bcx: the inflow profiles svprof[nsv][ktot+2] are needed"); return 1; }
+  if (h->cfg.nsv < 1) { udc_set_error("udc_set_scalar_bcx: no passive scalars"); return 1; }
+  if (g.nx < 8) { udc_set_error("udc_set_scalar_bcx: itot >= 8"); return 1; }
+  h->bcx_uout = uouttot;
+  const size_t np = (size_t)h->cfg.nsv * (g.nz + 2);
+  HIP_OK(hipStreamSynchronize(h->stream));
+  if (!h->bcx_prof) HIP_OK(hipMalloc(&h->bcx_prof, sizeof(double) * np));
+  HIP_OK(hipMemcpy(h->bcx_prof, svprof, sizeof(double) * np, hipMemcpyHostToDevice));
+  h->bcx_prof_host.assign(svprof, svprof + np);
+  for (int n = 0; n < h->cfg.nsv && n < 13; ++n)
+    if (!h->bcx_east[n]) {
+      HIP_OK(hipMalloc(&h->bcx_east[n], sizeof(double) * 2 * g.pz * g.py));
+      HIP_OK(hipMemset(h->bcx_east[n], 0, sizeof(double) * 2 * g.pz * g.py));
+    }
+  return 0;
 }
 extern "C" int udc_field_download(udc_handle *h, int field, double *host, const int lb[3], const int ub[3]) {
   ENTRY_FLUSH(h);
-  return copy3d(h, field, host, lb, ub, false);
+  if (copy3d(h, field, host, lb, ub, false)) return 1;
+  if (h->scal_bcx == 2 && field >= UDC_SV0 && (field - UDC_SV0) % 3 == 0)      // sv0: its x ghost columns under BCxs = 2
+    return k_scalar_bcx_fill_host(h, (field - UDC_SV0) / 3, host, lb, ub);
+  return 0;
 }
 
 double *stats_ptr(udc_handle *h, int id);
@@ -771,6 +802,7 @@ static int now_poisson(udc_handle *h, int rk3step, double dt) {
 
 static int now_tstep_integrate(udc_handle *h, int rk3step, double dt) {
   if (tend_clean(h) || um_materialise(h)) return 1;
+  h->bcx_rk3coef = dt / (4. - (double)rk3step);
   h->halos_fresh = h->boundary_fresh = h->thermo_fresh = false;
   if (k_integrate(h, rk3step, dt)) return 1;
   if (rk3step == 3 && k_chem(h, dt)) return 1;      // src/modtstep.f90:236-238
@@ -832,6 +864,7 @@ extern "C" int udc_boundary(udc_handle *h) {
   if (h->boundary_fresh) return 0;
   if (um_materialise(h)) return 1;
   if (k_top_bottom(h)) return 1;
+  if (k_scalar_bcx_outlet(h)) return 1;    // BCxs = 2: xso_convective with the rk3coef of the substep just integrated
   h->boundary_fresh = h->halos_fresh;      // (boundary before halos leaves the ghost rows of the top planes stale)
   return 0;
 }
@@ -860,6 +893,7 @@ enum : unsigned {
 // first); masscorr sees every momentum term the reference's masscorr sees.
 static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   const double rk3coef = dt / (4. - (double)rk3step);
+  h->bcx_rk3coef = rk3coef;
   const bool lds = !h->mom_simple;
   const bool pup = lds && !h->no_pup;
   const bool forces = (ops & OP_FORCES) != 0;
@@ -937,6 +971,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   scalar_halo_list(h, rk3step, s);
   if (!s.empty() && k_halo_y(h, s.data(), (int)s.size(), 2)) return 1;
   if (!fold || !h->slots.empty()) { if (k_top_bottom(h)) return 1; }
+  if (k_scalar_bcx_outlet(h)) return 1;
   h->halos_fresh = h->boundary_fresh = true;
   if (h->lmoist && h->mt) {                                             // src/program.f90:214
     if (k_thermodynamics(h)) return 1;

@@ -124,6 +124,13 @@ struct udc_handle {
   };
   Slot slot[16];
   std::vector<int> slots;
+  // passive scalars with an inflow / outflow in x (BCxs = 2; udc_set_scalar_bcx): the fields stay ghost-free and periodic by
+  // index; the two east ghost columns sv0(ie+1), sv0(ie+2) live here as planes [pz][py] per scalar, the inflow profile per level
+  int scal_bcx = 1;
+  double bcx_uout = 0., bcx_rk3coef = 0.;
+  double *bcx_east[13] = {nullptr};      // [2][pz][py] per passive scalar: ie+1, ie+2
+  double *bcx_prof = nullptr;            // [nsv][nz+2], indexed by the reference's k
+  std::vector<double> bcx_prof_host;
   // one-equation closure constants (udc_set_tke)
   struct Tke { double cm = 0., cn = 0., ch1 = 0., ch2 = 0., ce1 = 0., ce2 = 0., e12min = 5e-5, grav = 9.81, thvs = 0.; int ldelta = 0; } tke;
   // udc_set_level_forcing: A and B share one device block; `stage` is its pinned host copy and `copied` marks the last upload done
@@ -299,6 +306,9 @@ int k_momentum(udc_handle *h, bool adv, bool diff, bool forces);       // direct
 int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, double rk3coefi, bool um_is_u0 = false);  // rk3coefi != 0: PUP mode   // LDS-staged k-marching version (default)
 int k_level_sums_dev(udc_handle *h, int field, int n);      // udc_thermo.hip: masked, all-reduced level sums left on the device
 int k_scalar_adv(udc_handle *h, int n);
+int k_scalar_bcx_outlet(udc_handle *h);
+int k_scalar_bcx_capture(udc_handle *h, int n, const double *host, const int lb[3], const int ub[3]);
+int k_scalar_bcx_fill_host(udc_handle *h, int n, double *host, const int lb[3], const int ub[3]);
 int k_scalar_diff(udc_handle *h, int n);
 int k_scalar_fused(udc_handle *h, int n, bool fresh);          // advection + diffusion in one sweep (same accumulation order)
 int k_forces(udc_handle *h);

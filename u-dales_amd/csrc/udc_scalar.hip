@@ -4,6 +4,7 @@
 // tendency (6 zero-fills, 3 whole-array adds); here every cell evaluates its six face values
 // in registers and accumulates in the reference's order ((cp + upper) + lower per direction).
 #include "udc_internal.h"
+#include <algorithm>
 #include "udc_scalar_arith.h"
 
 namespace {
@@ -36,6 +37,58 @@ __global__ __launch_bounds__(256) void scalar_kernel(Geo g, TileGrid tg, Metrics
   double ul = 0., uh = 0., vl = 0., vh = 0., wl = 0., wh = 0.;
   if (ADV) { ul = u[o]; uh = u[A.xp1]; vl = v[o]; vh = v[o + g.sy]; wl = w[o]; wh = w[o + g.sz]; }
   cp[o] = scalar_tend<ADV, DIFF, LES>(A, m, ScalMetGlobal{m, k + 1, g.nz}, k, g.nz, FRESH ? 0. : cp[o], ul, uh, vl, vh, wl, wh, cekh, dfac, gh);
+}
+
+// ---- BCxs = 2: the scalars see an inlet at the low-x and a convective outlet at the high-x side of the domain while the flow
+// stays periodic (src/modboundary.f90:844-861 xsi_profile, :983-996 xso_convective; `halos` then leaves their x ghosts alone,
+// :99).  The fields keep the periodic, ghost-free layout; after the periodic sweep the two columns at either end get the
+// difference between the tendency with the true ghost values and the one with the wrapped ones.
+//   west ghosts (xsi_profile, m = 1, 2):  c(ib-1) = 2 prof(k) - c(ib),   c(ib-2) = 2 prof(k) - c(ib-1) = c(ib)
+//   east ghosts:  c(ie+1) evolves by the convective condition at every `boundary`, c(ie+2) keeps what the start gave it
+struct BcxAcc {
+  const double *c_, *e_, *east, *prof;      // east: [2][pz][py]
+  Geo g;
+  int i, j, k;
+  __device__ __forceinline__ double c(int di, int dj, int dk) const {
+    const int ii = i + di, jj = j + dj, kk = k + dk;
+    if (ii >= 0 && ii < g.nx) return c_[g.idx(ii, jj, kk)];
+    if (ii == -1) return 2. * prof[kk + 1] - c_[g.idx(0, jj, kk)];
+    if (ii == -2) return c_[g.idx(0, jj, kk)];
+    const long q = (long)(kk + HZ) * g.py + (jj + HY);
+    return ii == g.nx ? east[q] : east[(long)g.pz * g.py + q];
+  }
+  __device__ __forceinline__ double e(int di, int dj, int dk) const {      // ekh: periodic in x as before
+    const int ii = i + di;
+    return e_[g.idx(ii < 0 ? ii + g.nx : (ii >= g.nx ? ii - g.nx : ii), j + dj, k + dk)];
+  }
+};
+
+template <int ADV, bool DIFF, bool LES>
+__global__ __launch_bounds__(64) void scalar_bcx_edge_kernel(Geo g, Metrics m, double cekh, double dfac, const double *__restrict__ u,
+    const double *__restrict__ v, const double *__restrict__ w, const double *__restrict__ ekh, const double *__restrict__ c,
+    const double *__restrict__ east, const double *__restrict__ prof, double *__restrict__ cp, int gh) {
+  const int col = blockIdx.x & 3, j = (blockIdx.x >> 2) * 64 + threadIdx.x, k = blockIdx.y;
+  if (j >= g.ny) return;
+  const int i = col < 2 ? col : g.nx - 4 + col;      // 0, 1, nx-2, nx-1
+  if (g.nx < 4 || i < 0) return;
+  const long r0 = g.idx(0, j, k), o = r0 + i;
+  const GlobalAcc A{c, ekh, o, (long)g.sy, g.sz, r0 + wrap(i - 1, g.nx), r0 + wrap(i - 2, g.nx), r0 + wrap(i + 1, g.nx), r0 + wrap(i + 2, g.nx)};
+  const BcxAcc B{c, ekh, east, prof, g, i, j, k};
+  double ul = 0., uh = 0., vl = 0., vh = 0., wl = 0., wh = 0.;
+  if (ADV) { ul = u[o]; uh = u[A.xp1]; vl = v[o]; vh = v[o + g.sy]; wl = w[o]; wh = w[o + g.sz]; }
+  const ScalMetGlobal lm{m, k + 1, g.nz};
+  const double periodic = scalar_tend<ADV, DIFF, LES>(A, m, lm, k, g.nz, 0., ul, uh, vl, vh, wl, wh, cekh, dfac, gh);
+  const double bounded = scalar_tend<ADV, DIFF, LES>(B, m, lm, k, g.nz, 0., ul, uh, vl, vh, wl, wh, cekh, dfac, gh);
+  cp[o] = cp[o] + (bounded - periodic);
+}
+
+// xso_convective: c(ie+1) <- c(ie+1) - (c(ie+1) - c(ie)) dxi rk3coef uouttot, on every row and level the plane holds
+__global__ void scalar_bcx_outlet_kernel(Geo g, double fac, const double *__restrict__ c, double *__restrict__ east) {
+  const int jj = blockIdx.x * blockDim.x + threadIdx.x, kk = blockIdx.y;      // padded indices
+  if (jj >= g.py) return;
+  const long q = (long)kk * g.py + jj;
+  const double e1 = east[q];
+  east[q] = e1 - (e1 - c[g.idx(g.nx - 1, jj - HY, kk - HZ)]) * fac;
 }
 
 inline dim3 cell_grid(const Geo &g, dim3 b) {
@@ -115,13 +168,87 @@ static int launch_scalar(udc_handle *h, int n, bool adv, bool diff, bool fresh =
   return 0;
 }
 
-int k_scalar_adv(udc_handle *h, int n) { return launch_scalar(h, n, true, false); }
-int k_scalar_diff(udc_handle *h, int n) { return launch_scalar(h, n, false, true); }
+// the end columns of a passive scalar under BCxs = 2 (after any periodic sweep, LDS or plain)
+int k_scalar_bcx_edges(udc_handle *h, int n, bool adv, bool diff) {
+  if (h->scal_bcx != 2 || n >= 13 || !h->bcx_east[n]) return 0;
+  const Geo &g = h->g;
+  const double cekh = h->p.numol * h->p.prandtlmoli;
+  const double *u = h->fields[UDC_U0], *v = h->fields[UDC_V0], *w = h->fields[UDC_W0];
+  const double *ekh = h->fields[UDC_EKH], *c = h->fields[UDC_SV0 + 3 * n];
+  double *cp = h->fields[UDC_SVP + 3 * n];
+  const bool les = h->p.sgs != UDC_SGS_DNS;
+  const double *prof = h->bcx_prof + (size_t)n * (g.nz + 2);
+  const dim3 gr((unsigned)(4 * ((g.ny + 63) / 64)), (unsigned)g.nz), b(64);
+  PROF(h, "scalar_bcx_edges");
+#define LE(A, D, L) hipLaunchKernelGGL((scalar_bcx_edge_kernel<A, D, L>), gr, b, 0, h->stream, g, h->m, cekh, 0.5, u, v, w, ekh, c, \
+                                       (const double *)h->bcx_east[n], prof, cp, 0)
+  if (adv && diff) { if (les) LE(1, true, true); else LE(1, true, false); }
+  else if (adv) LE(1, false, true);
+  else if (diff) { if (les) LE(0, true, true); else LE(0, true, false); }
+#undef LE
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int k_scalar_bcx_outlet(udc_handle *h) {
+  if (h->scal_bcx != 2) return 0;
+  const Geo &g = h->g;
+  const double fac = h->m.dxi * h->bcx_rk3coef * h->bcx_uout;
+  for (int n : h->slots) {
+    if (n >= 13 || !h->bcx_east[n]) continue;
+    hipLaunchKernelGGL(scalar_bcx_outlet_kernel, dim3((unsigned)((g.py + 63) / 64), (unsigned)g.pz), dim3(64), 0, h->stream, g, fac,
+                       (const double *)h->fields[UDC_SV0 + 3 * n], h->bcx_east[n]);
+  }
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// an upload of sv0 whose host array carries the x ghost columns (the reference's c-arrays do): keep the two east ones
+int k_scalar_bcx_capture(udc_handle *h, int n, const double *host, const int lb[3], const int ub[3]) {
+  if (h->scal_bcx != 2 || n >= 13 || !h->bcx_east[n]) return 0;
+  const Geo &g = h->g;
+  if (lb[0] > g.nx + 1 || ub[0] < g.nx + 2) return 0;      // no east ghost columns in this array
+  const long hnx = ub[0] - lb[0] + 1, hny = ub[1] - lb[1] + 1;
+  std::vector<double> e((size_t)2 * g.pz * g.py);
+  HIP_OK(hipMemcpy(e.data(), h->bcx_east[n], sizeof(double) * e.size(), hipMemcpyDeviceToHost));
+  for (int k = std::max(lb[2], 1 - HZ); k <= std::min(ub[2], g.nz + HZ); ++k)
+    for (int j = std::max(lb[1], 1 - HY); j <= std::min(ub[1], g.ny + HY); ++j)
+      for (int q = 0; q < 2; ++q)
+        e[(size_t)q * g.pz * g.py + (size_t)(k - 1 + HZ) * g.py + (j - 1 + HY)] =
+            host[(long)(g.nx + 1 + q - lb[0]) + hnx * ((long)(j - lb[1]) + hny * (long)(k - lb[2]))];
+  HIP_OK(hipMemcpy(h->bcx_east[n], e.data(), sizeof(double) * e.size(), hipMemcpyHostToDevice));
+  return 0;
+}
+
+// ... and a download of sv0 into such an array gets them back: the east columns from the stored planes, the inlet ghosts by
+// xsi_profile's rule on levels kb .. ke+1 (elsewhere the periodic images udc_field_download put there stay)
+int k_scalar_bcx_fill_host(udc_handle *h, int n, double *host, const int lb[3], const int ub[3]) {
+  if (h->scal_bcx != 2 || n >= 13 || !h->bcx_east[n]) return 0;
+  const Geo &g = h->g;
+  const long hnx = ub[0] - lb[0] + 1, hny = ub[1] - lb[1] + 1;
+  std::vector<double> e((size_t)2 * g.pz * g.py);
+  HIP_OK(hipMemcpy(e.data(), h->bcx_east[n], sizeof(double) * e.size(), hipMemcpyDeviceToHost));
+  const double *prof = h->bcx_prof_host.data() + (size_t)n * (g.nz + 2);
+  for (int k = std::max(lb[2], 1 - HZ); k <= std::min(ub[2], g.nz + HZ); ++k)
+    for (int j = std::max(lb[1], 1 - HY); j <= std::min(ub[1], g.ny + HY); ++j) {
+      double *row = host + hnx * ((long)(j - lb[1]) + hny * (long)(k - lb[2])) - lb[0];      // row[i], i = the reference's index
+      for (int q = 0; q < 2; ++q)
+        if (g.nx + 1 + q <= ub[0]) row[g.nx + 1 + q] = e[(size_t)q * g.pz * g.py + (size_t)(k - 1 + HZ) * g.py + (j - 1 + HY)];
+      if (k >= 1 && k <= g.nz + 1 && j >= 1 && j <= g.ny) {
+        if (lb[0] <= 0) row[0] = 2. * prof[k] - row[1];
+        if (lb[0] <= -1) row[-1] = 2. * prof[k] - row[0];
+      }
+    }
+  return 0;
+}
+
+int k_scalar_adv(udc_handle *h, int n) { return launch_scalar(h, n, true, false) || k_scalar_bcx_edges(h, n, true, false); }
+int k_scalar_diff(udc_handle *h, int n) { return launch_scalar(h, n, false, true) || k_scalar_bcx_edges(h, n, false, true); }
 bool k_scalar_fused_lds(udc_handle *h, int n, bool fresh, int *rc);      // udc_scalar_lds.hip
 int k_scalar_fused(udc_handle *h, int n, bool fresh) {
   int rc = 0;
-  if (!h->mom_simple && k_scalar_fused_lds(h, n, fresh, &rc)) return rc;
-  return launch_scalar(h, n, true, true, fresh);
+  if (!h->mom_simple && k_scalar_fused_lds(h, n, fresh, &rc)) return rc || k_scalar_bcx_edges(h, n, true, true);
+  return launch_scalar(h, n, true, true, fresh) || k_scalar_bcx_edges(h, n, true, true);
 }
 
 // scalsource (src/modscalsource.f90:379-483): the sources are constant in time, the host evaluated them once

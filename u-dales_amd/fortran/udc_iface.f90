@@ -189,6 +189,13 @@ module udc_iface
       integer(c_int), intent(in) :: cell(*), comprec(*), recids(*)
       real(c_double), intent(in) :: area(*), dist(*), norm(*), z0(*), z0h(*), tsurf(*), recpt(*), tmask(*)
     end function udc_set_ibm_sections
+    integer(c_int) function udc_set_scalar_bcx(h, bcxs, svprof, uouttot) bind(C, name='udc_set_scalar_bcx')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: bcxs
+      real(c_double), intent(in) :: svprof(*)
+      real(c_double), value :: uouttot
+    end function udc_set_scalar_bcx
     integer(c_int) function udc_set_floor_air_temperature(h, thl_kb) bind(C, name='udc_set_floor_air_temperature')
       import :: c_ptr, c_int, c_double
       type(c_ptr), value :: h
@@ -544,7 +551,7 @@ contains
   !! boundary / thermodynamics), so this runs with every start-up call and a last time when the time loop starts.
   subroutine udc_late_setup
     use modglobal, only: ktot, kb, ke, nsv, ltempeq, BCtops, lcoriol, lprofforc, om22, om23, luvolflowr, lvvolflowr, &
-                         uflowrate, vflowrate, lnudge, igrw_damp, ifixuinf, ds
+                         uflowrate, vflowrate, lnudge, igrw_damp, ifixuinf, ds, BCxs
     use modsurfdata, only: wsvtop, sv_top
     use modfields, only: dpdxl, dpdyl, thlpcar, ug, whls, dthldxls, dthldyls, dqtdxls, dqtdyls, dqtdtls, &
                          dudxls, dudyls, dvdxls, dvdyls
@@ -565,6 +572,8 @@ contains
       call udc_check(udc_set_coriolis(udc_h, 2_c_int, real(om22, c_double), real(om23, c_double), ug(kb:ke), int(ktot, c_int)), &
                      'udc_set_coriolis')
     end if
+    ! scalars with an inflow / outflow in x (BCxs = 2: xsi_profile, xso_convective; src/modboundary.f90:844, 983)
+    if (nsv > 0 .and. BCxs /= 1) call scalar_bcx_setup
     ! masscorr, volume-flow branches (src/modforces.f90:389-417, 467-494)
     call udc_check(udc_set_masscorr(udc_h, merge(1_c_int, 0_c_int, luvolflowr), real(uflowrate, c_double), &
                                     merge(1_c_int, 0_c_int, lvvolflowr), real(vflowrate, c_double)), 'udc_set_masscorr')
@@ -573,6 +582,21 @@ contains
                    any(dthldxls /= 0.) .or. any(dthldyls /= 0.) .or. any(dqtdxls /= 0.) .or. any(dqtdyls /= 0.) .or. &
                    any(dqtdtls /= 0.) .or. any(dudxls /= 0.) .or. any(dudyls /= 0.) .or. any(dvdxls /= 0.) .or. any(dvdyls /= 0.)
   end subroutine udc_late_setup
+
+  subroutine scalar_bcx_setup
+    use modglobal, only: ktot, kb, ke, nsv, BCxs, luvolflowr
+    use modfields, only: svprof
+    use modinletdata, only: ubulk
+    real(c_double), allocatable :: t(:, :)
+    if (BCxs /= 2 .or. .not. luvolflowr) then
+      write (0, *) 'ERROR: libudcore: BCxs must be 1 (periodic) or 2 (inflow profile, convective outflow) with luvolflowr'
+      stop 1
+    end if
+    allocate (t(0:ktot + 1, nsv))
+    t = 0.
+    t(1:ktot + 1, :) = svprof(kb:ke + 1, 1:nsv)
+    call udc_check(udc_set_scalar_bcx(udc_h, 2_c_int, t, real(ubulk, c_double)), 'udc_set_scalar_bcx')
+  end subroutine scalar_bcx_setup
 
   !> Effective residency: start-up code (before the first tstep_update) works on the host arrays, so every call
   !! there carries the state both ways.

@@ -196,6 +196,11 @@ class DynCore:
     def scalsource(self):
         L._check(self.lib.udc_scalsource(self.h), "udc_scalsource")
 
+    def set_scalar_bcx(self, bcxs, svprof, uouttot):
+        """&BC BCxs (include/udcore.h): svprof[nsv, ktot+2] indexed by the reference's k."""
+        p = np.ascontiguousarray(svprof, dtype=np.float64)
+        L._check(self.lib.udc_set_scalar_bcx(self.h, int(bcxs), p.ctypes.data_as(L.DP), C.c_double(uouttot)), "udc_set_scalar_bcx")
+
     def set_ibm_wallfun(self, iwallmom, prandtlturb, zf, zh):
         """Facet wall functions for momentum (include/udcore.h): zf, zh = levels 1..ktot+1."""
         zf, zh = np.ascontiguousarray(zf, dtype=np.float64), np.ascontiguousarray(zh, dtype=np.float64)

@@ -161,6 +161,9 @@ def cold_start(g: Grid, d: Deck, j0=0, nyl=None, nsv=0, scal_a=None, scal_b=None
         if not getattr(d, "svprof", None):      # (the reference leaves the sub-floor planes of a scalar.inp start at zero)
             c[1] = c[2]
             c[0] = c[2]
+        else:      # ... and fills ib-1 : ie+1, jb-1 : je+1 only (src/modstartup.f90:1561-1570): the outermost ghost columns stay zero,
+            # which is what a convective outlet (BCxs = 2) keeps in its second ghost cell for ever
+            c[:, :, 0] = 0.; c[:, :, -1] = 0.; c[:, 0, :] = 0.; c[:, -1, :] = 0.
         if int(d.get("BC", "BCtops")) == 2:     # valuetopscal with sv_top = svprof(ke), as `boundary` leaves it
             c[nz + 2] = 2 * svprof[n][nz] - c[nz + 1]
         else:                                   # fluxtopscal with the start value ekh = numol (src/modboundary.f90:1532)
@@ -169,6 +172,10 @@ def cold_start(g: Grid, d: Deck, j0=0, nyl=None, nsv=0, scal_a=None, scal_b=None
             flux = float(w[n]) if n < len(w) else 0.
             c[nz + 2] = c[nz + 1] + g.dzh[nz + 1] * flux / ((1. / g.dzh[nz + 1]) * (0.5 * (g.dzf[nz] * 1.5e-5 + g.dzf[nz + 1] * 1.5e-5)))
         c[nz + 3] = c[nz + 2]
+        if int(d.get("BC", "BCxs")) == 2:       # the start-up call of `boundary`: xsi_profile (src/modboundary.f90:844-861) also runs on
+            # level ke+1, where svprof is zero -- the inlet ghosts of the top ghost level mirror about 0 (no stencil reads them)
+            c[nz + 2, 2:-2, 1] = -c[nz + 2, 2:-2, 2]
+            c[nz + 2, 2:-2, 0] = -c[nz + 2, 2:-2, 1]
         out[f"sv0_{n}"] = c
         out[f"svm_{n}"] = c.copy()
     if d.get("NAMSUBGRID", "loneeqn") and not (d.get("NAMSUBGRID", "lsmagorinsky") or d.get("NAMSUBGRID", "lvreman")):

@@ -32,7 +32,9 @@ def check_supported(deck):
             _refuse(f"&{grp} {name} is not available on the device path")
     if int(g("DYNAMICS", "iadv_mom")) != 2:
         _refuse("Unknown advection scheme: only iadv_mom = 2 (cd2) is on the device path")      # src/modadvection.f90:52
-    for grp, names in (("BC", ("BCxT", "BCxq", "BCxs", "BCyT", "BCyq", "BCys")),):
+    if deck.is_set("BC", "BCxs") and int(g("BC", "BCxs")) not in (1, 2):
+        _refuse("&BC BCxs: only 1 (periodic) and 2 (inflow profile, convective outflow) are on the device path")
+    for grp, names in (("BC", ("BCxT", "BCxq", "BCyT", "BCyq", "BCys")),):
         for n in names:
             if deck.is_set(grp, n) and int(deck.nml[grp][[k for k in deck.nml[grp] if k.lower() == n.lower()][0]]) != 1:
                 _refuse(f"only periodic lateral boundaries are on the device path (&BC {n})")
