@@ -84,6 +84,7 @@ program ref_driver
   integer(KIND=selected_int_kind(6)) :: irandom = 43
   integer :: krand = huge(0)
   real :: randu = 0.01
+  real :: randthl = 0., randqt = 0.       ! (read and ignored by the reference too: its perturbation of thl / qt is commented out, :1532)
   namelist /ORACLE/ nsub, nspin, nwarm, dump_at, lforces, scal_a, scal_b, pmode
 
   call initmpi
@@ -145,6 +146,7 @@ program ref_driver
     end do
     if (lstats) call dump_stats
     if (ladaptive) call put1('end.time', (/timee, dt/), 1)
+    if (nsv > 0) call dump_scalar_profiles
   case ('kernels')
     do isub = 1, nspin
       call one_substep
@@ -393,7 +395,7 @@ contains
     use modglobal, only: rv_g => rv, rd_g => rd
     use modibmdata, only: bctfxm, bctfxp, bctfym, bctfyp, bctfz, bcqfxm, bcqfxp, bcqfym, bcqfyp, bcqfz
     integer :: ierr
-    namelist /RUN/ iexpnr, runtime, dtmax, trestart, ladaptive, irandom, randu, krand, courant, diffnr, &
+    namelist /RUN/ iexpnr, runtime, dtmax, trestart, ladaptive, irandom, randu, randthl, randqt, krand, courant, diffnr, &
       libm, lles, lrandomize, nprocx, nprocy
     namelist /DOMAIN/ itot, jtot, ktot, xlen, ylen, xlat, ksp
     namelist /PHYSICS/ ps, lmoist, lcoriol, lbuoyancy, ltempeq, lprofforc, dpdx, luvolflowr, uflowrate, &
@@ -647,6 +649,25 @@ contains
       call put3(tag//'.svm_'//cn, svm(:, :, :, n), (/ib - ihc, jb - jhc, kb - khc/))
     end do
   end subroutine dump_state
+
+  !> small observables of the first scalar at the end of a run (for decks whose fields are too large to keep): its mean over
+  !! the fluid cells of every level and its mean over y and z along x
+  subroutine dump_scalar_profiles
+    use modmpi, only: avexy_ibm
+    real :: prof(kb:ke + kh), tmp(ib:ie, jb:je, kb:ke + kh), alongx(ib:ie)
+    integer :: i
+    tmp = sv0(ib:ie, jb:je, kb:ke + kh, 1)
+    prof = 0.; call avexy_ibm(prof, tmp, ib, ie, jb, je, kb, ke, kh, IIc(ib:ie, jb:je, kb:ke + kh), IIcs(kb:ke + kh), .false.)
+    call put1('end.sv1xy', prof(kb:ke), kb)
+    do i = ib, ie
+      alongx(i) = sum(sv0(i, jb:je, kb:ke, 1))/real((je - jb + 1)*(ke - kb + 1))
+    end do
+    call put1('end.sv1x', alongx, ib)
+    if (ltempeq) then      ! the first level and the plane below the floor of what statsdump's thlsgs(kb) is made of
+      call put3('end.thlm_k01', thlm(:, :, kb - 1:kb), (/ib - ih, jb - jh, kb - 1/))
+      call put3('end.ekh_k01', ekh(:, :, kb - 1:kb), (/ib - ih, jb - jh, kb - 1/))
+    end if
+  end subroutine dump_scalar_profiles
 
   !> the running averages statsdump keeps in modfields (src/modstatsdump.f90:1086-1213), and xytdump's table of slab
   !! averages (:1404-1431, 1437-1460: local to statsdump there, so taken here with the reference's avexy_ibm from the same

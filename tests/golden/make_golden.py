@@ -662,7 +662,7 @@ def make_restart_cases():
 # prof.inp, lscale.inp): examples/999, the flat neutral channel at 128^3 with the floor wall function at its defaults
 # (BCbotm = 2 without temperature equation), the adaptive time step and tdump / xytdump / fielddump output.  The golden holds
 # xytdump's table and the clock after `nsub` substeps of the reference binary (the 3-D fields would be 17 MB each).
-EXAMPLES = {"example_999": ("999", 999, 75), "example_001": ("001", 1, 75), "example_002": ("002", 2, 75)}
+EXAMPLES = {"example_999": ("999", 999, 75), "example_001": ("001", 1, 75), "example_002": ("002", 2, 75), "example_101": ("101", 101, 75)}
 # examples/001: the same channel with the ground as an immersed boundary (128 facets, 16384 boundary points per grid, ~17800
 # facet sections on u and v: the output of the reference's pre-processing).  The shipped deck leaves iwallmom at its default
 # of 2, which needs a Tfacinit.inp the example does not ship (the reference stops in readfacetfiles) and reads mask_c
@@ -671,6 +671,11 @@ EXAMPLE_FILES = {"example_001": ["facets.inp.001", "factypes.inp.001", "facet_se
                                  "facet_sections_c.txt", "fluid_boundary_u.txt", "fluid_boundary_v.txt", "fluid_boundary_w.txt",
                                  "fluid_boundary_c.txt", "solid_u.txt", "solid_v.txt", "solid_w.txt", "solid_c.txt"]}
 EXAMPLE_FILES["example_002"] = [f.replace(".001", ".002") for f in EXAMPLE_FILES["example_001"]]      # 64^3, an array of cubes: 1024 facets
+# examples/101: street canyons with heated walls -- temperature with buoyancy, wall functions with the stability functions
+# (iwallmom = 2, the default) and the heat wall function on the facet temperatures (iwalltemp = 2), a prescribed volume flow, a
+# scalar line source whose plume enters clean (BCxs = 2: inflow profile, convective outflow).  The deck as shipped.
+EXAMPLE_FILES["example_101"] = [f.replace(".001", ".101") for f in EXAMPLE_FILES["example_001"]] + ["Tfacinit.inp.101", "scalar.inp.101",
+                                                                                                    "scalarsourcel.inp.1.101"]
 EXAMPLE_PATCH = {"example_001": ("&WALLS\n", "&WALLS\niwallmom = 3\n"), "example_002": ("&WALLS\n", "&WALLS\niwallmom = 3\n")}
 
 
@@ -702,7 +707,7 @@ def make_example_cases(only):
                 else:
                     shutil.copy(os.path.join(cdir, fn), tmp)
             with open(os.path.join(tmp, f"namoptions.{iexp:03d}"), "a") as f:      # the driver's own group; the deck is otherwise untouched
-                f.write(f"\n&ORACLE\nnsub = {nsub}\n/\n")
+                f.write(f"\n&ORACLE\nnsub = {nsub}\nscal_a = 0.\nscal_b = 0.\n/\n")      # (scalar.inp of the examples is zero; the driver has a stand-in for it)
             out = os.path.join(tmp, "out.bin")
             # (128^3: the reference's array-valued expressions in statsdump need more than the default 8 MB of stack)
             subprocess.check_call(["bash", "-c", f"ulimit -s unlimited; exec {REF} namoptions.{iexp:03d} run {out}"], cwd=tmp)

@@ -110,6 +110,10 @@ def main(argv=None, at_end=None):
     ap.add_argument("--steps", type=int, default=0, help="stop after this many full time steps (default: run to `runtime`)")
     ap.add_argument("--restart-from", type=int, default=-1, metavar="NTRUN",
                     help="warm start from initd<NTRUN>_000_<rank>.<expnr> in the deck's directory")
+    ap.add_argument("--ibm-mask-wrap", choices=("deck", "none", "both"), default="deck",
+                    help="immersed boundary: the reference's point masks wrap periodically only in a direction its run splits over ranks "
+                         "(&RUN nprocx, nprocy), which decides what an obstacle cell on the edge of the domain averages over; "
+                         "'deck' reproduces the reference run with the deck's layout, 'none' its single-rank run, 'both' a fully split one")
     ap.add_argument("--device", type=int, default=None)
     ap.add_argument("--quiet", action="store_true")
     args = ap.parse_args(argv)
@@ -121,6 +125,8 @@ def main(argv=None, at_end=None):
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     device = args.device if args.device is not None else int(os.environ.get("LOCAL_RANK", "0"))
     deck = read_deck(args.namoptions)
+    if args.ibm_mask_wrap != "deck":      # (in memory only: the device's own decomposition does not come from these)
+        deck.nml.setdefault("RUN", {}).update(nprocx=1 if args.ibm_mask_wrap == "none" else 2, nprocy=1 if args.ibm_mask_wrap == "none" else 2)
     check_supported(deck)
     wdir = os.path.dirname(os.path.abspath(args.namoptions))
     core = from_deck(deck, device=device, rank=rank, nranks=world)
