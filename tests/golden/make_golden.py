@@ -687,18 +687,16 @@ def make_example_cases(only):
         src = os.path.join("/root/reference/examples", exdir)
         cdir = os.path.join(HERE, "cases", name)
         os.makedirs(cdir, exist_ok=True)
-        for fn in (f"namoptions.{iexp:03d}", f"prof.inp.{iexp:03d}", f"lscale.inp.{iexp:03d}"):
-            shutil.copy(os.path.join(src, fn), cdir)
-        if name in EXAMPLE_PATCH:
-            old, new = EXAMPLE_PATCH[name]
-            with open(os.path.join(cdir, f"namoptions.{iexp:03d}")) as f:
-                text = f.read()
-            assert text.count(old) == 1
-            with open(os.path.join(cdir, f"namoptions.{iexp:03d}"), "w") as f:
-                f.write(text.replace(old, new))
-        for fn in EXAMPLE_FILES.get(name, []):      # the pre-processing's lists, kept compressed (1.4 MB of text)
-            with open(os.path.join(src, fn), "rb") as f, gzip.GzipFile(os.path.join(cdir, fn + ".gz"), "wb", mtime=0) as gz:
-                gz.write(f.read())
+        # the example's input data, kept compressed: the deck, the profiles, the pre-processing's lists (1.4 MB of text for 001)
+        for fn in [f"namoptions.{iexp:03d}", f"prof.inp.{iexp:03d}", f"lscale.inp.{iexp:03d}"] + EXAMPLE_FILES.get(name, []):
+            with open(os.path.join(src, fn), "rb") as f:
+                data = f.read()
+            if fn.startswith("namoptions") and name in EXAMPLE_PATCH:
+                old, new = EXAMPLE_PATCH[name]
+                assert data.decode().count(old) == 1
+                data = data.decode().replace(old, new).encode()
+            with gzip.GzipFile(os.path.join(cdir, fn + ".gz"), "wb", mtime=0) as gz:
+                gz.write(data)
         with tempfile.TemporaryDirectory() as tmp:
             for fn in os.listdir(cdir):
                 if fn.endswith(".gz"):
