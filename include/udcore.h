@@ -367,6 +367,10 @@ int udc_stats_xyt(udc_handle *h, double *table);
  * (the inlet ones by xsi_profile's rule).  Not covered: obstacles touching the x ends of the domain; svm's ghost columns (no
  * routine reads them). */
 int udc_set_scalar_bcx(udc_handle *h, int bcxs, const double *svprof, double uouttot);
+/* Without a prescribed volume flow the reference takes the outlet's speed from diagfld's slab averages of the previous substep's end
+ * (src/modboundary.f90:143-156): uouttot = sum_k wlev(k) u0av(k), wlev(k) = dzf(k) / (zh(ke+1) - zh(kb+1)), u0av over the fluid u
+ * points.  wlev[ktot]; evaluated on the device at the start of every substep.  NULL: back to the constant of udc_set_scalar_bcx. */
+int udc_set_scalar_bcx_outflow(udc_handle *h, const double *wlev);
 
 /* divergence of u0 as modchecksim's chkdiv (src/modchecksim.f90:161-203): max |div|, sum div */
 int udc_divergence(udc_handle *h, double *divmax, double *divtot);

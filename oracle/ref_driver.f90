@@ -125,7 +125,8 @@ program ref_driver
   call cold_start
   call createscals                          ! src/modstartup.f90 (scalarsourcep / scalarsourcel files; no-op without sources)
   call boundary
-  need_thermo = ltempeq .or. lmoist .or. loneeqn .or. lnudge .or. igrw_damp /= 0 .or. any(whls /= 0.) .or. ifixuinf /= 0 .or. ds > 0
+  need_thermo = ltempeq .or. lmoist .or. loneeqn .or. lnudge .or. igrw_damp /= 0 .or. any(whls /= 0.) .or. ifixuinf /= 0 .or. ds > 0 &
+                .or. (BCxs /= 1 .and. .not. luvolflowr)      ! the convective outlet's speed comes from diagfld's u0av (src/modboundary.f90:143-156)
   if (need_thermo) call thermodynamics            ! src/program.f90:120 (thv0h, thvh; dthvdz; diagfld's slab averages)
 
   iu = 71

@@ -588,6 +588,9 @@ CASES.update({
 CASES.update({
     "k_bcxs_16x8x12": ("kernels", 75, 16, 8, 12, dict(sgs="smag", nsv=2, floor=True, randu=0.05, physics="luvolflowr = .true.\nuflowrate = 1.1",
                                                       bc="BCxs = 2", oracle="nspin = 5\nscal_b = 0.2"), 1.05),
+    # ... and without a prescribed volume flow: the outlet convects with the mean of diagfld's slab averages (:143-156)
+    "run_bcxs_avg_16x8x12s": ("run", 77, 16, 8, 12, dict(sgs="smag", nsv=1, floor=True, randu=0.05, bc="BCxs = 2",
+                                                         oracle="nsub = 9\ndump_at = 3, 9\nscal_b = 0.2"), 1.06),
     "run_bcxs_16x8x12s": ("run", 76, 16, 8, 12, dict(sgs="vreman", nsv=1, floor=True, randu=0.05, physics="luvolflowr = .true.\nuflowrate = 1.1",
                                                      bc="BCxs = 2", oracle="nsub = 9\ndump_at = 3, 9\nscal_b = 0.2"), 1.06),
 })

@@ -238,6 +238,8 @@ extern "C" int udc_destroy(udc_handle *h) {
   ibm_wf_destroy(h);
   for (double *&p : h->bcx_east) if (p) { hipFree(p); p = nullptr; }
   if (h->bcx_prof) { hipFree(h->bcx_prof); h->bcx_prof = nullptr; }
+  if (h->bcx_uout_dev) { hipFree(h->bcx_uout_dev); h->bcx_uout_dev = nullptr; }
+  if (h->bcx_wlev) { hipFree(h->bcx_wlev); h->bcx_wlev = nullptr; }
   for (int q = 0; q < 4; ++q) if (h->halo_buf[q]) hipFree(h->halo_buf[q]);
   for (auto &f : h->level_forcings) { if (f.A) hipFree(f.A); if (f.stage) hipHostFree(f.stage); if (f.copied) hipEventDestroy(f.copied); }
   for (double *p : h->fields) if (p) hipFree(p);
@@ -329,6 +331,17 @@ extern "C" int udc_field_upload(udc_handle *h, int field, const double *host, co
   return 0;
 }
 
+extern "C" int udc_set_scalar_bcx_outflow(udc_handle *h, const double *wlev) {
+  ENTRY_FLUSH(h);
+  if (h->scal_bcx != 2 || !h->bcx_uout_dev) { udc_set_error("udc_set_scalar_bcx_outflow: call udc_set_scalar_bcx(h, 2, ...) first"); return 1; }
+  if (!wlev) { h->bcx_uout_avg = false; return 0; }
+  HIP_OK(hipStreamSynchronize(h->stream));
+  if (!h->bcx_wlev) HIP_OK(hipMalloc(&h->bcx_wlev, sizeof(double) * h->g.nz));
+  HIP_OK(hipMemcpy(h->bcx_wlev, wlev, sizeof(double) * h->g.nz, hipMemcpyHostToDevice));
+  h->bcx_uout_avg = true;
+  return 0;
+}
+
 extern "C" int udc_set_scalar_bcx(udc_handle *h, int bcxs, const double *svprof, double uouttot) {
   ENTRY_FLUSH(h);
   if (bcxs != 1 && bcxs != 2) { udc_set_error("udc_set_scalar_bcx: BCxs must be 1 (periodic) or 2 (inflow profile, convective outflow)"); return 1; }
@@ -344,6 +357,9 @@ extern "C" int udc_set_scalar_bcx(udc_handle *h, int bcxs, const double *svprof,
   if (!h->bcx_prof) HIP_OK(hipMalloc(&h->bcx_prof, sizeof(double) * np));
   HIP_OK(hipMemcpy(h->bcx_prof, svprof, sizeof(double) * np, hipMemcpyHostToDevice));
   h->bcx_prof_host.assign(svprof, svprof + np);
+  if (!h->bcx_uout_dev) HIP_OK(hipMalloc(&h->bcx_uout_dev, sizeof(double)));
+  HIP_OK(hipMemcpy(h->bcx_uout_dev, &uouttot, sizeof(double), hipMemcpyHostToDevice));
+  h->bcx_uout_avg = false;
   for (int n = 0; n < h->cfg.nsv && n < 13; ++n)
     if (!h->bcx_east[n]) {
       HIP_OK(hipMalloc(&h->bcx_east[n], sizeof(double) * 2 * g.pz * g.py));
@@ -803,6 +819,7 @@ static int now_poisson(udc_handle *h, int rk3step, double dt) {
 static int now_tstep_integrate(udc_handle *h, int rk3step, double dt) {
   if (tend_clean(h) || um_materialise(h)) return 1;
   h->bcx_rk3coef = dt / (4. - (double)rk3step);
+  if (k_scalar_bcx_uout(h)) return 1;
   h->halos_fresh = h->boundary_fresh = h->thermo_fresh = false;
   if (k_integrate(h, rk3step, dt)) return 1;
   if (rk3step == 3 && k_chem(h, dt)) return 1;      // src/modtstep.f90:236-238
@@ -894,6 +911,7 @@ enum : unsigned {
 static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   const double rk3coef = dt / (4. - (double)rk3step);
   h->bcx_rk3coef = rk3coef;
+  if (k_scalar_bcx_uout(h)) return 1;      // BCxs = 2 without a prescribed volume flow: the outlet's speed from the state the substep starts from
   const bool lds = !h->mom_simple;
   const bool pup = lds && !h->no_pup;
   const bool forces = (ops & OP_FORCES) != 0;

@@ -128,6 +128,9 @@ struct udc_handle {
   // index; the two east ghost columns sv0(ie+1), sv0(ie+2) live here as planes [pz][py] per scalar, the inflow profile per level
   int scal_bcx = 1;
   double bcx_uout = 0., bcx_rk3coef = 0.;
+  double *bcx_uout_dev = nullptr;        // the outlet's convection speed uouttot (device scalar)
+  double *bcx_wlev = nullptr;            // without a prescribed volume flow: uouttot = sum_k wlev(k) u0av(k) of the previous substep's end
+  bool bcx_uout_avg = false;
   double *bcx_east[13] = {nullptr};      // [2][pz][py] per passive scalar: ie+1, ie+2
   double *bcx_prof = nullptr;            // [nsv][nz+2], indexed by the reference's k
   std::vector<double> bcx_prof_host;
@@ -307,6 +310,7 @@ int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, 
 int k_level_sums_dev(udc_handle *h, int field, int n);      // udc_thermo.hip: masked, all-reduced level sums left on the device
 int k_scalar_adv(udc_handle *h, int n);
 int k_scalar_bcx_outlet(udc_handle *h);
+int k_scalar_bcx_uout(udc_handle *h);
 int k_scalar_bcx_capture(udc_handle *h, int n, const double *host, const int lb[3], const int ub[3]);
 int k_scalar_bcx_fill_host(udc_handle *h, int n, double *host, const int lb[3], const int ub[3]);
 int k_scalar_diff(udc_handle *h, int n);

@@ -83,12 +83,24 @@ __global__ __launch_bounds__(64) void scalar_bcx_edge_kernel(Geo g, Metrics m, d
 }
 
 // xso_convective: c(ie+1) <- c(ie+1) - (c(ie+1) - c(ie)) dxi rk3coef uouttot, on every row and level the plane holds
-__global__ void scalar_bcx_outlet_kernel(Geo g, double fac, const double *__restrict__ c, double *__restrict__ east) {
+__global__ void scalar_bcx_outlet_kernel(Geo g, double fac0, const double *__restrict__ uout, const double *__restrict__ c,
+                                         double *__restrict__ east) {
   const int jj = blockIdx.x * blockDim.x + threadIdx.x, kk = blockIdx.y;      // padded indices
   if (jj >= g.py) return;
   const long q = (long)kk * g.py + jj;
+  const double fac = fac0 * uout[0];
   const double e1 = east[q];
   east[q] = e1 - (e1 - c[g.idx(g.nx - 1, jj - HY, kk - HZ)]) * fac;
+}
+
+// uouttot without a prescribed volume flow (src/modboundary.f90:143-156): sum_k u0av(k) dzf(k) / (zh(ke+1) - zh(kb+1)) with
+// diagfld's slab averages over the fluid u points; S = level sums (solid points taken out), cnt = fluid counts or nullptr
+__global__ void scalar_bcx_uout_kernel(int nz, const double *__restrict__ S, const double *__restrict__ cnt, double ncell,
+                                       const double *__restrict__ wlev, double *__restrict__ out) {
+  if (threadIdx.x || blockIdx.x) return;
+  double u = 0.;
+  for (int k = 0; k < nz; ++k) u = u + (S[k] / (cnt ? cnt[k + 1] : ncell)) * wlev[k];      // (the reference's order: sum over k of u0av dzf, then the division)
+  out[0] = u;
 }
 
 inline dim3 cell_grid(const Geo &g, dim3 b) {
@@ -193,12 +205,24 @@ int k_scalar_bcx_edges(udc_handle *h, int n, bool adv, bool diff) {
 int k_scalar_bcx_outlet(udc_handle *h) {
   if (h->scal_bcx != 2) return 0;
   const Geo &g = h->g;
-  const double fac = h->m.dxi * h->bcx_rk3coef * h->bcx_uout;
+  const double fac = h->m.dxi * h->bcx_rk3coef;
   for (int n : h->slots) {
     if (n >= 13 || !h->bcx_east[n]) continue;
     hipLaunchKernelGGL(scalar_bcx_outlet_kernel, dim3((unsigned)((g.py + 63) / 64), (unsigned)g.pz), dim3(64), 0, h->stream, g, fac,
-                       (const double *)h->fields[UDC_SV0 + 3 * n], h->bcx_east[n]);
+                       (const double *)h->bcx_uout_dev, (const double *)h->fields[UDC_SV0 + 3 * n], h->bcx_east[n]);
   }
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// the outlet's speed from the state the substep starts from (= what diagfld left at the end of the previous one)
+int k_scalar_bcx_uout(udc_handle *h) {
+  if (h->scal_bcx != 2 || !h->bcx_uout_avg) return 0;
+  const Geo &g = h->g;
+  if (k_level_sums_dev(h, UDC_U0, g.nz)) return 1;
+  const double *cnt = h->ibm_on ? h->ibm[0].cnt_dev : nullptr;
+  hipLaunchKernelGGL(scalar_bcx_uout_kernel, dim3(1), dim3(64), 0, h->stream, g.nz, (const double *)h->lev_sum16, cnt,
+                     (double)g.nx * (double)h->jtot, (const double *)h->bcx_wlev, h->bcx_uout_dev);
   HIP_OK(hipGetLastError());
   return 0;
 }

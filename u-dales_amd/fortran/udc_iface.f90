@@ -196,6 +196,11 @@ module udc_iface
       real(c_double), intent(in) :: svprof(*)
       real(c_double), value :: uouttot
     end function udc_set_scalar_bcx
+    integer(c_int) function udc_set_scalar_bcx_outflow(h, wlev) bind(C, name='udc_set_scalar_bcx_outflow')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(in) :: wlev(*)
+    end function udc_set_scalar_bcx_outflow
     integer(c_int) function udc_set_floor_air_temperature(h, thl_kb) bind(C, name='udc_set_floor_air_temperature')
       import :: c_ptr, c_int, c_double
       type(c_ptr), value :: h
@@ -584,18 +589,20 @@ contains
   end subroutine udc_late_setup
 
   subroutine scalar_bcx_setup
-    use modglobal, only: ktot, kb, ke, nsv, BCxs, luvolflowr
+    use modglobal, only: ktot, kb, ke, nsv, BCxs, luvolflowr, luoutflowr, dzf, zh
     use modfields, only: svprof
     use modinletdata, only: ubulk
     real(c_double), allocatable :: t(:, :)
-    if (BCxs /= 2 .or. .not. luvolflowr) then
-      write (0, *) 'ERROR: libudcore: BCxs must be 1 (periodic) or 2 (inflow profile, convective outflow) with luvolflowr'
+    if (BCxs /= 2 .or. luoutflowr) then
+      write (0, *) 'ERROR: libudcore: BCxs must be 1 (periodic) or 2 (inflow profile, convective outflow; not with luoutflowr)'
       stop 1
     end if
     allocate (t(0:ktot + 1, nsv))
     t = 0.
     t(1:ktot + 1, :) = svprof(kb:ke + 1, 1:nsv)
     call udc_check(udc_set_scalar_bcx(udc_h, 2_c_int, t, real(ubulk, c_double)), 'udc_set_scalar_bcx')
+    if (.not. luvolflowr) &      ! the outlet's speed from diagfld's slab averages (src/modboundary.f90:143-156)
+      call udc_check(udc_set_scalar_bcx_outflow(udc_h, real(dzf(kb:ke)/(zh(ke + 1) - zh(kb + 1)), c_double)), 'udc_set_scalar_bcx_outflow')
   end subroutine scalar_bcx_setup
 
   !> Effective residency: start-up code (before the first tstep_update) works on the host arrays, so every call

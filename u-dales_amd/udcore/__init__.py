@@ -89,12 +89,13 @@ def from_deck(deck, device=0, rank=0, nranks=1):
     if bcxs not in (1, 2):
         raise ValueError("&BC BCxs: 1 (periodic) or 2 (inflow profile, convective outflow) are on the device path")
     if core.nsv and bcxs == 2:      # scalars enter at the low-x side with svprof and leave at the high-x side (src/modboundary.f90:844, 983)
-        if not deck.get("PHYSICS", "luvolflowr"):
-            raise ValueError("BCxs = 2 is on the device path with a prescribed volume flow (luvolflowr: the outlet convects with ubulk, "
-                             "src/modboundary.f90:159); without it the reference takes the speed from the slab averages of every substep")
+        if deck.is_set("PHYSICS", "luoutflowr") and deck.nml["PHYSICS"][[k for k in deck.nml["PHYSICS"] if k.lower() == "luoutflowr"][0]]:
+            raise ValueError("BCxs = 2 with luoutflowr is not on the device path")
         from .grid import scalar_profiles
         ubulk = float(np.sum(np.asarray(deck.u) * g.dzf[1:g.nz + 1]) / (g.zh[g.nz + 1] - g.zh[1]))      # src/modstartup.f90:1336-1341
-        core.set_scalar_bcx(2, np.array(scalar_profiles(g, deck, core.nsv)), ubulk)
+        core.set_scalar_bcx(2, np.array(scalar_profiles(g, deck, core.nsv)), ubulk)      # luvolflowr: the outlet convects with ubulk (:159)
+        if not deck.get("PHYSICS", "luvolflowr"):      # else with the mean of diagfld's slab averages (:143-156)
+            core.set_scalar_bcx_outflow(g.dzf[1:g.nz + 1] / (g.zh[g.nz + 1] - g.zh[2]))
     from .ibm import apply_ibm
     apply_ibm(core, deck)
     if core.nsv and (deck.get("SCALARS", "lscasrc") or deck.get("SCALARS", "lscasrcl")):

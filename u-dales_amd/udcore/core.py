@@ -201,6 +201,10 @@ class DynCore:
         p = np.ascontiguousarray(svprof, dtype=np.float64)
         L._check(self.lib.udc_set_scalar_bcx(self.h, int(bcxs), p.ctypes.data_as(L.DP), C.c_double(uouttot)), "udc_set_scalar_bcx")
 
+    def set_scalar_bcx_outflow(self, wlev):
+        w = np.ascontiguousarray(wlev, dtype=np.float64)
+        L._check(self.lib.udc_set_scalar_bcx_outflow(self.h, w.ctypes.data_as(L.DP)), "udc_set_scalar_bcx_outflow")
+
     def set_ibm_wallfun(self, iwallmom, prandtlturb, zf, zh):
         """Facet wall functions for momentum (include/udcore.h): zf, zh = levels 1..ktot+1."""
         zf, zh = np.ascontiguousarray(zf, dtype=np.float64), np.ascontiguousarray(zh, dtype=np.float64)
