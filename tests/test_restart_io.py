@@ -48,6 +48,33 @@ def test_read_reference_restart(tmp_path):
         np.testing.assert_array_equal(s["sv0"][n][1:], ref[1:])
 
 
+@pytest.mark.parametrize("px,py", [(2, 2), (1, 4), (4, 1)])
+def test_restart_set_of_any_pencil_layout_is_assembled(px, py, tmp_path):
+    """A run of the reference on nprocx x nprocy ranks leaves one file per pencil, each with its block and a ghost cell around it
+    (src/modsave.f90:80-121: ib-ih:ie+ih, jb-jh:je+jh).  The reference-written single-rank file, cut into such blocks (ghost cells
+    from the neighbouring block, as the reference's halo exchange leaves them), comes back as the whole domain."""
+    st = _state()
+    timee, dt, ntrun = st["rsttime"].data
+    ntrun = int(ntrun)
+    d = R.read_initd(_unzip(R.restart_name(ntrun, 0, IEXP), tmp_path), N, N, N)
+    s = R.read_inits(_unzip(R.restart_name(ntrun, 0, IEXP, "s"), tmp_path), N, N, N, 2)
+    out = tmp_path / "split"
+    out.mkdir()
+    lx, ly = N // px, N // py
+    for ix in range(px):
+        for iy in range(py):
+            cut = lambda a: np.ascontiguousarray(a[:, iy * ly:iy * ly + ly + 2, ix * lx:ix * lx + lx + 2])      # noqa: E731
+            R.write_initd(str(out / R.restart_name(ntrun, iy, IEXP, "d", myidx=ix)), lx, ly, N, {k: cut(d[k]) for k in R.M_FIELDS}, timee, dt)
+            R.write_inits(str(out / R.restart_name(ntrun, iy, IEXP, "s", myidx=ix)), lx, ly, N, [cut(a) for a in s["sv0"]], timee)
+    assert R.find_layout(str(out), IEXP, ntrun) == (px, py)
+    f, sv, t2, dt2 = R.read_global(str(out), IEXP, ntrun, N, N, N, nsv=2)
+    assert (t2, dt2) == (timee, dt)
+    for k in R.M_FIELDS:
+        np.testing.assert_array_equal(f[k][1:], d[k][1:], err_msg=k)
+    for n in range(2):
+        np.testing.assert_array_equal(sv[n][1:], s["sv0"][n][1:])
+
+
 def test_write_is_byte_identical(tmp_path):
     """What read_initd returns, written back, is the reference's file byte for byte."""
     st = _state()
@@ -78,6 +105,58 @@ def test_truncated_file_is_rejected(tmp_path):
         g.write(f.read()[:5000])
     with pytest.raises((EOFError, ValueError, Exception)):
         R.read_initd(bad, N, N, N)
+
+
+@pytest.mark.gpu
+def test_runner_warm_starts_from_the_deck(tmp_path):
+    """&RUN lwarmstart / startfile as the reference reads them (src/modstartup.f90:784, 2194-2229), the restart set cut into the
+    files of a 2 x 2 CPU layout: the runner picks ntrun from the file name, assembles the set, reads the scalars under lreadscal,
+    and continues from the file's clock with the file's fields."""
+    import shutil
+    from common import nocorner, relerr
+    from udcore import lib as L
+    from udcore import run
+    st = _state()
+    timee, dt, ntrun = st["rsttime"].data
+    ntrun = int(ntrun)
+    d = R.read_initd(_unzip(R.restart_name(ntrun, 0, IEXP), tmp_path), N, N, N)
+    s = R.read_inits(_unzip(R.restart_name(ntrun, 0, IEXP, "s"), tmp_path), N, N, N, 2)
+    work = tmp_path / "case"
+    work.mkdir()
+    for fn in os.listdir(os.path.join(GOLDEN, "cases", NAME)):
+        shutil.copy(os.path.join(GOLDEN, "cases", NAME, fn), work)
+    for ix in range(2):
+        for iy in range(2):
+            cut = lambda a: np.ascontiguousarray(a[:, iy * 4:iy * 4 + 6, ix * 4:ix * 4 + 6])      # noqa: E731
+            R.write_initd(str(work / R.restart_name(ntrun, iy, IEXP, "d", myidx=ix)), 4, 4, N, {k: cut(d[k]) for k in R.M_FIELDS}, timee, dt)
+            R.write_inits(str(work / R.restart_name(ntrun, iy, IEXP, "s", myidx=ix)), 4, 4, N, [cut(a) for a in s["sv0"]], timee)
+    deck = work / f"namoptions.{IEXP:03d}"
+    text = deck.read_text()
+    text = text.replace("&RUN\n", f"&RUN\nlwarmstart = .true.\nstartfile = 'initd{ntrun:08d}_xxx_xxx.{IEXP:03d}'\n", 1)
+    text = text.replace("&SCALARS\n", "&SCALARS\nlreadscal = .true.\n", 1)
+    deck.write_text(text)
+    got = {}
+
+    def at_end(core, tdump):
+        got["time"] = core.timee
+        got["u0"] = core.download("u0")
+        got["sv"] = core.download(L.scalar_field(L.SV0, 0), halo=2)
+
+    # zero steps: the state the time loop would start from
+    assert run.main([str(deck), "--steps", "1", "--quiet"], at_end=at_end) == 0
+    assert abs(got["time"] - (timee + dt)) < 1e-12      # one step on from the file's clock
+    # the same through the single-file reader, one step
+    import udcore
+    from udcore import read_deck
+    core = udcore.from_deck(read_deck(os.path.join(GOLDEN, "cases", NAME, f"namoptions.{IEXP:03d}")))
+    for kind in "ds":
+        _unzip(R.restart_name(ntrun, 0, IEXP, kind), tmp_path)
+    t0, dt0 = R.load_restart(core, str(tmp_path), IEXP, ntrun)
+    for rk in (1, 2, 3):
+        core.substep(rk, dt0, True)
+    assert relerr(nocorner(got["u0"][1:-1]), nocorner(core.download("u0")[1:-1])) <= 1e-12
+    assert relerr(got["sv"][2:-2, 2:-2, 2:-2], core.download(L.scalar_field(L.SV0, 0), halo=2)[2:-2, 2:-2, 2:-2]) <= 1e-12
+    core.close()
 
 
 @pytest.mark.gpu

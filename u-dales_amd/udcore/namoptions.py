@@ -15,7 +15,7 @@ from dataclasses import dataclass, field
 DEFAULTS = {
     "RUN": dict(iexpnr=0, runtime=300., dtmax=20., ladaptive=False, irandom=43, randu=0.01,
                 krand=2 ** 31 - 1, courant=-1., diffnr=0.25, libm=True, lles=True, lrandomize=True,
-                nprocx=1, nprocy=1, lwarmstart=False, trestart=10000.),
+                nprocx=1, nprocy=1, lwarmstart=False, startfile="", trestart=10000.),
     "DOMAIN": dict(itot=96, jtot=96, ktot=96, xlen=-1., ylen=-1., xlat=52., ksp=-1),
     "PHYSICS": dict(lmoist=False, lcoriol=False, lbuoyancy=False, ltempeq=False, lprofforc=False, ps=101325.,
                     dpdx=0., igrw_damp=0, lnudge=False, lnudgevel=True, tnudge=60., nnudge=0, luvolflowr=False, uflowrate=1., lvvolflowr=False, vflowrate=1.,
@@ -27,7 +27,7 @@ DEFAULTS = {
                wttop=0., thl_top=-1., wtsurf=-1., thls=-1., qts=-1.,
                BCtopq=1, BCbotq=1, wqtop=0., qt_top=-1., wqsurf=-1., wsvtopdum=0., ds=0.,
                bctfxm=0., bctfxp=0., bctfym=0., bctfyp=0., bctfz=0., bcqfxm=0., bcqfxp=0., bcqfym=0., bcqfyp=0., bcqfz=0.),
-    "SCALARS": dict(nsv=0, lscasrc=False, nscasrc=0, lscasrcl=False, nscasrcl=0),
+    "SCALARS": dict(nsv=0, lreadscal=False, lscasrc=False, nscasrc=0, lscasrcl=False, nscasrcl=0),
     "NAMSUBGRID": dict(lsmagorinsky=False, lvreman=True, loneeqn=False, c_vreman=0.07, cs=-1.,
                        cf=2.5, cn=0.76, Rigc=0.25, Prandtl=0.333, ldelta=False, lbuoycorr=False),
     "OUTPUT": dict(ltdump=False, lxytdump=False, lmintdump=False, tstatsdump=10000., tsample=5., tstatstart=0.,
@@ -78,7 +78,7 @@ UNSUPPORTED = [("RUN", "lstratstart", False), ("RUN", "lper2inout", False), ("RU
                ("DRIVER", "idriver", 0), ("INLET", "linletRA", False), ("INLET", "lstoreplane", False),
                ("INLET", "lreadminl", False), ("INLET", "lfixinlet", False), ("INLET", "lfixutauin", False),
                ("ENERGYBALANCE", "lEB", False), ("ENERGYBALANCE", "lperiodicEBcorr", False),
-               ("SCALARS", "lreadscal", False), ("SCALARS", "lscasrcr", False),
+               ("SCALARS", "lscasrcr", False),
                ("TREES", "ltrees", False), ("PURIFS", "lpurif", False), ("HEATPUMP", "lheatpump", False),
                ("NAMSUBGRID", "lmason", False)]
 

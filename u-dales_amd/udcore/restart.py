@@ -141,6 +141,75 @@ def _restart_fields(core):
     return names
 
 
+def find_layout(directory, expnr, ntrun, kind="d"):
+    """(nprocx, nprocy) of the restart set init<kind><ntrun>_<myidx>_<myidy>.<expnr> in a directory, from its file names."""
+    import glob
+    import re
+    pat = re.compile(rf"init{kind}{ntrun:08d}_(\d{{3}})_(\d{{3}})\.{expnr:03d}$")
+    ids = [tuple(int(v) for v in pat.search(os.path.basename(f)).groups())
+           for f in glob.glob(os.path.join(directory, f"init{kind}{ntrun:08d}_*_*.{expnr:03d}")) if pat.search(os.path.basename(f))]
+    if not ids:
+        raise FileNotFoundError(f"no init{kind}{ntrun:08d}_*_*.{expnr:03d} in {directory}")
+    px, py = max(i for i, _ in ids) + 1, max(j for _, j in ids) + 1
+    if len(set(ids)) != px * py:
+        raise ValueError(f"restart set {ntrun} in {directory}: files of a {px} x {py} layout expected, {len(set(ids))} found")
+    return px, py
+
+
+def read_global(directory, expnr, ntrun, nx, ny, nz, nsv=0):
+    """The whole domain from a restart set written on any pencil layout of the reference (nprocx x nprocy files, each holding
+    its block with one ghost cell around it): -> (fields {name: m-array [nz+2, ny+2, nx+2]}, sv0 list of such arrays, timee, dt).
+    Interior cells come from the rank that owns them; the outer ghost ring from the blocks on the domain's edge."""
+    px, py = find_layout(directory, expnr, ntrun)
+    if nx % px or ny % py:
+        raise ValueError(f"restart set on {px} x {py} ranks does not divide a {nx} x {ny} domain")
+    lx, ly = nx // px, ny // py
+    out, sv, timee, dt = {}, [np.zeros((nz + 2, ny + 2, nx + 2)) for _ in range(nsv)], 0., 0.
+    have_s = nsv > 0 and os.path.exists(os.path.join(directory, restart_name(ntrun, 0, expnr, "s")))
+    for ix in range(px):
+        for iy in range(py):
+            d = read_initd(os.path.join(directory, restart_name(ntrun, iy, expnr, "d", myidx=ix)), lx, ly, nz)
+            timee, dt = d["timee"], d["dt"]
+            # destination ranges in the global array (with its ghost ring) and the matching ranges of the block
+            gi0, gi1 = ix * lx + (0 if ix == 0 else 1), (ix + 1) * lx + (2 if ix == px - 1 else 1)
+            gj0, gj1 = iy * ly + (0 if iy == 0 else 1), (iy + 1) * ly + (2 if iy == py - 1 else 1)
+            bi0, bj0 = gi0 - ix * lx, gj0 - iy * ly
+            blocks = [(k, v) for k, v in d.items() if isinstance(v, np.ndarray) and v.ndim == 3 and v.shape == (nz + 2, ly + 2, lx + 2)]
+            for k, v in blocks:
+                out.setdefault(k, np.zeros((nz + 2, ny + 2, nx + 2)))[:, gj0:gj1, gi0:gi1] = v[:, bj0:bj0 + gj1 - gj0, bi0:bi0 + gi1 - gi0]
+            if have_s:
+                s = read_inits(os.path.join(directory, restart_name(ntrun, iy, expnr, "s", myidx=ix)), lx, ly, nz, nsv)
+                for n, a in enumerate(s["sv0"]):
+                    sv[n][:, gj0:gj1, gi0:gi1] = a[:, bj0:bj0 + gj1 - gj0, bi0:bi0 + gi1 - gi0]
+    return out, (sv if have_s else None), timee, dt
+
+
+def load_restart_global(core, directory, expnr, ntrun, rank=0, nranks=1, read_scalars=True):
+    """Warm start from a restart set of any CPU layout: this rank's y-slab of the assembled fields (see load_restart)."""
+    from . import lib as L
+    g = core.g
+    nyl = core.nyl
+    ny = nyl * nranks
+    d, sv, timee, dt = read_global(directory, expnr, ntrun, g.nx, ny, g.nz, core.nsv)
+    j0 = rank * nyl
+    cut = lambda a: np.ascontiguousarray(a[:, j0:j0 + nyl + 2, :])      # noqa: E731
+    names = _restart_fields(core)
+    for k in names:
+        core.upload(k, cut(d[k]))
+    for k0 in names:
+        if k0 not in ("pres0", "ekm"):
+            core.upload(k0[:-1] + "m", cut(d[k0]))
+    if core.nsv and sv is not None and read_scalars:
+        for n, a in enumerate(sv):
+            c = np.zeros((g.nz + 4, nyl + 4, g.nx + 4))
+            c[1:-1, 1:-1, 1:-1] = cut(a)
+            core.upload(L.scalar_field(L.SV0, n), c)
+            core.upload(L.scalar_field(L.SVM, n), c)
+    core.halos()
+    core.boundary()
+    return timee, dt
+
+
 def load_restart(core, directory, expnr, ntrun, rank=0):
     """Warm start as readrestartfiles + readinitfiles do (src/modstartup.f90:1292-1340): u0.. from the file,
     um = u0 (the file is written after stage 3, when the reference itself has um = u0), ghosts re-derived by

@@ -38,8 +38,6 @@ def check_supported(deck):
         for n in names:
             if deck.is_set(grp, n) and int(deck.nml[grp][[k for k in deck.nml[grp] if k.lower() == n.lower()][0]]) != 1:
                 _refuse(f"only periodic lateral boundaries are on the device path (&BC {n})")
-    if bool(g("RUN", "lwarmstart")):
-        _refuse("&RUN lwarmstart: warm starts go through --restart-from NTRUN (the runner does not read startfile)")
     if g("RUN", "libm") and int(g("WALLS", "iwallmom")) == 2 and not g("PHYSICS", "ltempeq"):
         # (the reference reads mask_c unallocated in this combination, src/modibm.f90:180, 1794-1830)
         _refuse("immersed boundaries with iwallmom = 2 (stability functions) read the air temperature: needs ltempeq; iwallmom = 3 is the neutral wall function")
@@ -150,9 +148,25 @@ def main(argv=None, at_end=None):
     ladaptive = bool(deck.get("RUN", "ladaptive"))
     courant, diffnr = courant_default(deck), float(deck.get("RUN", "diffnr"))
     nyl = core.g.ny // world
-    if args.restart_from >= 0:
-        timee, dt = R.load_restart(core, wdir, iexp, args.restart_from, rank=rank)
-        ntrun = args.restart_from
+    warm = args.restart_from
+    if warm < 0 and bool(deck.get("RUN", "lwarmstart")):      # &RUN lwarmstart / startfile = 'initdNNNNNNNN_xxx_xxx.EEE' (src/modstartup.f90:784, 2194)
+        import re
+        m = re.search(r"initd(\d{8})_", str(deck.get("RUN", "startfile")))
+        if not m:
+            _refuse("&RUN lwarmstart: startfile must be named initd<ntrun>_xxx_xxx.<expnr>")
+        warm = int(m.group(1))
+    if warm >= 0:
+        # the restart set may come from any CPU pencil layout (nprocx x nprocy files); scalars are read when the deck says so
+        # (lreadscal, :2212) or when the warm start was asked for on the command line
+        rs = bool(deck.get("SCALARS", "lreadscal")) or args.restart_from >= 0
+        timee, dt = R.load_restart_global(core, wdir, iexp, warm, rank=rank, nranks=world, read_scalars=rs)
+        if core.nsv and not rs:      # scalars start from their profile (:2220-2229)
+            stc = cold_start(core.g, deck, j0=rank * nyl, nyl=nyl, nsv=core.nsv)
+            from . import lib as L
+            for n in range(core.nsv):
+                core.upload(L.scalar_field(L.SV0, n), stc[f"sv0_{n}"]); core.upload(L.scalar_field(L.SVM, n), stc[f"svm_{n}"])
+            core.halos(); core.boundary()
+        ntrun = warm
     else:
         core.load_state(cold_start(core.g, deck, j0=rank * nyl, nyl=nyl, nsv=core.nsv))
         core.halos()
