@@ -120,7 +120,7 @@ program ref_driver
   end if
 #endif
   call createmasks
-  lstats = ltdump .or. lxytdump
+  lstats = ltdump .or. lxytdump .or. lytdump
   if (lstats) call initstatsdump            ! src/program.f90:110 (here: its last two statements, the clocks)
   call cold_start
   call createscals                          ! src/modstartup.f90 (scalarsourcep / scalarsourcel files; no-op without sources)
@@ -408,7 +408,7 @@ contains
       BCtopq, BCbotq, wqtop, qt_top, wqsurf, z0h, wsvtopdum, ds, bctfxm, bctfxp, bctfym, bctfyp, bctfz, &
       bcqfxm, bcqfxp, bcqfym, bcqfyp, bcqfz
     namelist /SCALARS/ nsv, lscasrc, nscasrc, lscasrcl, nscasrcl
-    namelist /OUTPUT/ ltdump, lxytdump, tsample, tstatsdump, tstatstart, lfielddump, tfielddump, fieldvars      ! (the field dump itself is not run here)
+    namelist /OUTPUT/ lytdump, ltdump, lxytdump, tsample, tstatsdump, tstatstart, lfielddump, tfielddump, fieldvars      ! (the field dump itself is not run here)
     namelist /WALLS/ nfcts, lbottom, iwallmom, iwalltemp, iwallmoist, nsolpts_u, nsolpts_v, nsolpts_w, nsolpts_c, &
       nbndpts_u, nbndpts_v, nbndpts_w, nbndpts_c, nfctsecs_u, nfctsecs_v, nfctsecs_w, nfctsecs_c, lnorec
     open (ifnamopt, file=fname_options, status='old', iostat=ierr)
@@ -651,6 +651,59 @@ contains
     end do
   end subroutine dump_state
 
+  !> ytdump: the running y-averages statsdump keeps in modfields (src/modstatsdump.f90:1104-1132) and the table's y-averages of
+  !! the time-averaged 3-D fields (:1471-1507: local to statsdump there, taken here with the reference's avey_ibm, same expressions)
+  subroutine dump_ytstats
+    use modmpi, only: avey_ibm
+    real :: a(ib:ie, kb:ke)
+    call puty('yt.uyt', uyt); call puty('yt.vyt', vyt); call puty('yt.wyt', wyt)
+    call puty('yt.usgsyt', usgsyt); call puty('yt.wsgsyt', wsgsyt)
+    if (ltempeq) then
+      call puty('yt.thlyt', thlyt); call puty('yt.thlsgsyt', thlsgsyt)
+    end if
+    if (lmoist) then
+      call puty('yt.qtyt', qtyt); call puty('yt.qtsgsyt', qtsgsyt)
+    end if
+    if (nsv > 0) then
+      call puty('yt.sca1yt', sca1yt); call puty('yt.sv1sgsyt', sv1sgsyt)
+    end if
+    if (nsv > 1) then
+      call puty('yt.sca2yt', sca2yt); call puty('yt.sv2sgsyt', sv2sgsyt)
+    end if
+    call avey_ibm(a, uwtik(ib:ie, jb:je, kb:ke) - utik(ib:ie, jb:je, kb:ke)*wtik(ib:ie, jb:je, kb:ke), ib, ie, jb, je, kb, ke, &
+                  IIuw(ib:ie, jb:je, kb:ke), IIuwt(ib:ie, kb:ke)); call puty('yt.upwptyik', a)
+    call avey_ibm(a, utik(ib:ie, jb:je, kb:ke)*wtik(ib:ie, jb:je, kb:ke), ib, ie, jb, je, kb, ke, IIuw(ib:ie, jb:je, kb:ke), IIuwt(ib:ie, kb:ke))
+    call puty('yt.uwtyik', a)
+    call avey_ibm(a, uutc(ib:ie, jb:je, kb:ke) - utc(ib:ie, jb:je, kb:ke)*utc(ib:ie, jb:je, kb:ke), ib, ie, jb, je, kb, ke, &
+                  IIc(ib:ie, jb:je, kb:ke), IIct(ib:ie, kb:ke)); call puty('yt.upuptyc', a)
+    call avey_ibm(a, wwtc(ib:ie, jb:je, kb:ke) - wtc(ib:ie, jb:je, kb:ke)*wtc(ib:ie, jb:je, kb:ke), ib, ie, jb, je, kb, ke, &
+                  IIc(ib:ie, jb:je, kb:ke), IIct(ib:ie, kb:ke)); call puty('yt.wpwptyc', a)
+    if (ltempeq) then
+      call avey_ibm(a, wthltk(ib:ie, jb:je, kb:ke) - wmt(ib:ie, jb:je, kb:ke)*thltk(ib:ie, jb:je, kb:ke), ib, ie, jb, je, kb, ke, &
+                    IIw(ib:ie, jb:je, kb:ke), IIwt(ib:ie, kb:ke)); call puty('yt.wpthlptyk', a)
+      call avey_ibm(a, wmt(ib:ie, jb:je, kb:ke)*thltk(ib:ie, jb:je, kb:ke), ib, ie, jb, je, kb, ke, IIw(ib:ie, jb:je, kb:ke), IIwt(ib:ie, kb:ke))
+      call puty('yt.wthltyk', a)
+      call avey_ibm(a, thlthlt(ib:ie, jb:je, kb:ke) - thlt(ib:ie, jb:je, kb:ke)*thlt(ib:ie, jb:je, kb:ke), ib, ie, jb, je, kb, ke, &
+                    IIc(ib:ie, jb:je, kb:ke), IIct(ib:ie, kb:ke)); call puty('yt.thlpthlpty', a)
+    end if
+    if (nsv > 0) then
+      call avey_ibm(a, wsv1tk(ib:ie, jb:je, kb:ke) - wmt(ib:ie, jb:je, kb:ke)*sv1tk(ib:ie, jb:je, kb:ke), ib, ie, jb, je, kb, ke, &
+                    IIw(ib:ie, jb:je, kb:ke), IIwt(ib:ie, kb:ke)); call puty('yt.wpsv1ptyk', a)
+      call avey_ibm(a, wmt(ib:ie, jb:je, kb:ke)*sv1tk(ib:ie, jb:je, kb:ke), ib, ie, jb, je, kb, ke, IIw(ib:ie, jb:je, kb:ke), IIwt(ib:ie, kb:ke))
+      call puty('yt.wsv1tyk', a)
+      call avey_ibm(a, sv1sv1t(ib:ie, jb:je, kb:ke) - sv1t(ib:ie, jb:je, kb:ke)*sv1t(ib:ie, jb:je, kb:ke), ib, ie, jb, je, kb, ke, &
+                    IIc(ib:ie, jb:je, kb:ke), IIct(ib:ie, kb:ke)); call puty('yt.sv1psv1pty', a)
+    end if
+  end subroutine dump_ytstats
+
+  subroutine puty(name, a)      ! an (ib:ie, kb:ke) plane as a record with one row
+    character(*), intent(in) :: name
+    real, intent(in) :: a(ib:ie, kb:ke)
+    real :: b(ib:ie, 1, kb:ke)
+    b(:, 1, :) = a
+    call put3(name, b, (/ib, 1, kb/))
+  end subroutine puty
+
   !> small observables of the first scalar at the end of a run (for decks whose fields are too large to keep): its mean over
   !! the fluid cells of every level and its mean over y and z along x
   subroutine dump_scalar_profiles
@@ -700,6 +753,7 @@ contains
       call put3('st.sv2t', sv2t, lb); call put3('st.sv2tk', sv2tk, lb); call put3('st.wsv2tk', wsv2tk, lb)
       call put3('st.sv2sv2t', sv2sv2t, lb); call put3('st.sv2sgst', sv2sgst, lb)
     end if
+    if (lytdump) call dump_ytstats
     if (.not. lxytdump) return
     call put1('xyt.uxyt', uxyt, kb); call put1('xyt.vxyt', vxyt, kb); call put1('xyt.wxyt', wxyt, kb)
     call put1('xyt.pxyt', pxyt, kb); call put1('xyt.usgsxyt', usgsxyt, kb); call put1('xyt.vsgsxyt', vsgsxyt, kb)

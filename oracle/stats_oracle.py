@@ -74,6 +74,24 @@ class TDumpOracle:
         self.acc = {}
         self.II, self.IIs = createmasks(g.nx, g.ny, g.nz, lists, wrapx, wrapy)
         self.prof = {}
+        self.yprof = {}
+
+    def _updy(self, name, var, mask, ts, T):
+        """avey_ibm (src/modmpi.f90: masked sum over y / column count, -999 where a column has no fluid point) + running average"""
+        nz = self.g.nz
+        II = self.II[mask][:nz]
+        cnt = II.sum(axis=1)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ya = np.where(cnt == 0, -999., (var[:nz] * II).sum(axis=1) / np.where(cnt == 0, 1, cnt))
+        old = self.yprof.get(name, np.zeros_like(ya))
+        self.yprof[name] = (old * (T - ts) + ya * ts) * (1. / T)
+
+    def _avey(self, var, mask):
+        nz = self.g.nz
+        II = self.II[mask][:nz]
+        cnt = II.sum(axis=1)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return np.where(cnt == 0, -999., (var[:nz] * II).sum(axis=1) / np.where(cnt == 0, 1, cnt))
 
     def _updp(self, name, var, mask, ts, T):
         xy = avexy_ibm(var, self.II[mask], self.IIs[mask])
@@ -118,6 +136,21 @@ class TDumpOracle:
             usgs = emom * ((u - _m(um, dk=-1)) * dzhi + (w - _m(wm, di=-1)) * dxi)
             emom = (dzf_km * (_m(ekm) + _m(ekm, dj=-1)) + dzf_k * (_m(ekm, dk=-1) + _m(ekm, dj=-1, dk=-1))) * dzhiq
             vsgs = emom * ((v - _m(vm, dk=-1)) * dzhi + (w - _m(wm, dj=-1)) * dyi)
+            # ytdump's sample (:964-999): y-averages of the same quantities (+ wsgs, :851-855), levels kb..ke
+            dzfi = (1. / dzf[np.minimum(k, nz + 1)])[:, None, None]
+            dzfi_m = (1. / dzf[k - 1])[:, None, None]
+            wsgs = (_m(ekm) * (_m(wm, dk=1) - w) * dzfi - _m(ekm, dk=-1) * (w - _m(wm, dk=-1)) * dzfi_m) * 2. * dzhi
+            self._updy("uyt", u, "u", ts, T); self._updy("vyt", v, "v", ts, T); self._updy("wyt", w, "w", ts, T)
+            self._updy("usgsyt", usgs, "uw", ts, T); self._updy("wsgsyt", wsgs, "w", ts, T)
+            if self.ltempeq:
+                th_, thm_ = _m(st["thlm"]), _m(st["thlm"], dk=-1)
+                self._updy("thlyt", th_, "c", ts, T)
+                self._updy("thlsgsyt", 0.5 * (dzf_km * _m(ekh) + dzf_k * _m(ekh, dk=-1)) * (th_ - thm_) * dzh2i, "w", ts, T)
+            for n in range(min(self.nsv, 3)):
+                a = st[f"svm_{n}"][1:-1, 1:-1, 1:-1]
+                p0, pm = _m(a), _m(a, dk=-1)
+                self._updy(f"sca{n + 1}yt", p0, "c", ts, T)
+                self._updy(f"sv{n + 1}sgsyt", 0.5 * (dzf_km * _m(ekh) + dzf_k * _m(ekh, dk=-1)) * (p0 - pm) * dzh2i, "w", ts, T)
             self._updp("uxyt", u, "u", ts, T); self._updp("vxyt", v, "v", ts, T); self._updp("wxyt", w, "w", ts, T)
             self._updp("pxyt", _m(st["pres0"]), "c", ts, T)
             self._updp("usgsxyt", usgs, "uw", ts, T); self._updp("vsgsxyt", vsgs, "vw", ts, T)
@@ -184,3 +217,17 @@ class TDumpOracle:
         if self.lmoist:
             o["qtxyt"] = p["qtxyt"]
         return {k: v[:-1] for k, v in o.items()}
+
+    def yt(self):
+        """ytdump's table (:1104-1132 running y-averages, :1471-1507 y-averages of the time-averaged fields), [nz, nx]."""
+        a = self.acc
+        o = dict(self.yprof)
+        o.update({"upwptyik": self._avey(a["uwtik"] - a["utik"] * a["wtik"], "uw"), "uwtyik": self._avey(a["utik"] * a["wtik"], "uw"),
+                  "upuptyc": self._avey(a["uutc"] - a["utc"] * a["utc"], "c"), "wpwptyc": self._avey(a["wwtc"] - a["wtc"] * a["wtc"], "c")})
+        if self.ltempeq:
+            o.update({"wpthlptyk": self._avey(a["wthltk"] - a["wmt"] * a["thltk"], "w"), "wthltyk": self._avey(a["wmt"] * a["thltk"], "w"),
+                      "thlpthlpty": self._avey(a["thlthlt"] - a["thlt"] * a["thlt"], "c")})
+        for n in range(1, min(self.nsv, 3) + 1):
+            o.update({f"wpsv{n}ptyk": self._avey(a[f"wsv{n}tk"] - a["wmt"] * a[f"sv{n}tk"], "w"), f"wsv{n}tyk": self._avey(a["wmt"] * a[f"sv{n}tk"], "w"),
+                      f"sv{n}psv{n}pty": self._avey(a[f"sv{n}sv{n}t"] - a[f"sv{n}t"] * a[f"sv{n}t"], "c")})
+        return o

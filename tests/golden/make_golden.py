@@ -511,12 +511,19 @@ CASES.update({
 # restart) after the sixth; second deck: obstacles (masked slab averages, -999 on levels without fluid), buoyancy, a sample
 # every step (tsample <= dt, :802-803)
 IBM_BLOCKS["run_stats_ibm_16x12x10"] = IBM_BLOCKS["run_ibm_16x12x10"]
+IBM_BLOCKS["run_ytstats_ibm_16x12x10"] = IBM_BLOCKS["run_ibm_16x12x10"]
 CASES.update({
     "run_stats_16x8x12s": ("run", 62, 16, 8, 12,
                            dict(sgs="smag", nsv=2, floor=True, randu=0.05, physics="ltempeq = .true.\nlbuoyancy = .false.",
                                 bc="BCtopT = 2\nthl_top = 290.5\nBCbotT = 1\nwtsurf = 0.02",
                                 output="ltdump = .true.\nlxytdump = .true.\ntsample = 0.5\ntstatsdump = 1.5",
                                 oracle="nsub = 24\ndump_at = 24"), 1.06),
+    # ytdump (y- and time-averaged x-z fields, :964-999, 1104-1132, 1466-1507) on the same obstacle deck
+    "run_ytstats_ibm_16x12x10": ("run", 78, 16, 12, 10,
+                                 dict(sgs="vreman", nsv=1, floor=True, randu=0.05, ibm=IBM_BLOCKS["run_ibm_16x12x10"],
+                                      physics="ltempeq = .true.\nlbuoyancy = .true.", bc=_IBM_THL_BC,
+                                      output="lytdump = .true.\ntsample = 0.1\ntstatsdump = 1000.",
+                                      oracle="nsub = 15\ndump_at = 15"), 1.04),
     "run_stats_ibm_16x12x10": ("run", 63, 16, 12, 10,
                                dict(sgs="vreman", nsv=1, floor=True, randu=0.05, ibm=IBM_BLOCKS["run_ibm_16x12x10"],
                                     physics="ltempeq = .true.\nlbuoyancy = .true.", bc=_IBM_THL_BC,
@@ -610,7 +617,7 @@ THL_CASES = {"k_tke_moist_12x8x8": dict(dthl=0.25, qt=0.0118, dqt=-8e-5, tke=0.0
              "k_buoy_12x8x6": dict(dthl=0.3), "run_buoy_16x8x12s": dict(dthl=0.2),
              "k_ibm_thl_16x12x10": dict(dthl=0.3), "run_ibm_thl_16x12x10": dict(dthl=0.25), "run_ibm_thlcons_16x12x10": dict(dthl=0.25),
              "run_ibm_qt_16x12x10": dict(dthl=0.25, qt=0.007, dqt=-2e-4),
-             "run_stats_16x8x12s": dict(dthl=0.25), "run_stats_ibm_16x12x10": dict(dthl=0.25),
+             "run_stats_16x8x12s": dict(dthl=0.25), "run_stats_ibm_16x12x10": dict(dthl=0.25), "run_ytstats_ibm_16x12x10": dict(dthl=0.25),
              "k_ibm_wf2_16x12x10": dict(dthl=0.3), "run_ibm_wf2_16x12x10": dict(dthl=0.25),
              "k_ibm_wh2_16x12x10": dict(dthl=0.3), "run_ibm_wh2_16x12x10": dict(dthl=0.25),
              "k_ibm_wh1_16x12x10": dict(dthl=0.3), "run_ibm_wh1_16x12x10": dict(dthl=0.25), "run_ground_wh2_16x8x12": dict(dthl=0.25),
@@ -752,7 +759,7 @@ def main():
         else:
             keep = {k: v for k, v in d.items()
                     if k.count(".") == 0 or k.split(".")[1] in ("u0", "v0", "w0", "pres0", "um", "thl0", "thlm", "e120", "e12m", "qt0", "qtm", "dpdxl", "time")
-                    or (k.startswith("s000.") and not k.startswith("s000.ek")) or ".sv0" in k or k.startswith(("st.", "xyt."))}
+                    or (k.startswith("s000.") and not k.startswith("s000.ek")) or ".sv0" in k or k.startswith(("st.", "xyt.", "yt."))}
             # (s000.ekm/ekh are dumped before the first closure call: uninitialised memory, not data)
         tmpf = os.path.join(HERE, name + ".bin")
         write_dump(tmpf, keep)
