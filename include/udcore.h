@@ -334,7 +334,7 @@ enum {
   UDC_ST_SV_STRIDE = 5,
   UDC_ST_MAX = UDC_ST_SV + 4 * UDC_ST_SV_STRIDE
 };
-int udc_stats_enable(udc_handle *h, int on);      /* 0 off; 1 the 3-D accumulators; 3 also xytdump's running profiles */
+int udc_stats_enable(udc_handle *h, int on);      /* 0 off; 1 the 3-D accumulators; +2 xytdump's running profiles; +4 ytdump's running y-averages */
 int udc_stats_sample(udc_handle *h, double tsamplep, double tstatsdumpp);
 int udc_stats_get(udc_handle *h, int id, double *host, const int lb[3], const int ub[3]);
 
@@ -357,6 +357,17 @@ enum {
 };
 int udc_stats_set_masks(udc_handle *h, const unsigned char *bits, const int *counts);
 int udc_stats_xyt(udc_handle *h, double *table);
+/* ytdump (src/modstatsdump.f90:964-999 y-averages of a sample with avey_ibm, :1104-1132 their running time averages, :1466-1551
+ * the table): y- and time-averaged x-z fields on levels kb..ke, udc_stats_enable with bit 4 (on = 5, or 7 with xytdump).  The masks
+ * are those of udc_stats_set_masks; avey_ibm has no rule for a level without fluid points, so the caller names the masks whose
+ * first level it filled for avexy_ibm's rule (udc_stats_set_forced, forced[7] in the masks' bit order) and the device empties
+ * those again; the column counts IIut ... IIuwt are formed on the device.  udc_stats_yt returns the table
+ * [UDC_YT_N][ktot][itot] in the order of the reference's output variables (uyt vyt wyt thlyt qtyt sca1-3yt, upwpyt wpthlpyt
+ * wpqtpyt wpsca1-3pyt, uwyt wthlyt wqtyt wsca1-3yt, upupyt wpwpyt thlpthlpyt qtpqtpyt sca1-3psca1-3pyt, usgsyt wsgsyt thlsgsyt
+ * qtsgsyt sca1-3sgsyt); -999 in columns without fluid points. */
+enum { UDC_YT_N = 34 };
+int udc_stats_set_forced(udc_handle *h, const int *forced);
+int udc_stats_yt(udc_handle *h, double *table);
 
 /* Passive scalars with an inflow and an outflow in x while the flow stays periodic (&BC BCxs = 2, the reference's dispersion
  * examples): inlet ghost cells mirrored about the inflow profile (xsi_profile, src/modboundary.f90:844-861), a convective outlet

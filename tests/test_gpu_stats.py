@@ -127,6 +127,54 @@ def test_statistics_match_reference(name, iexp, slabs):
     core.close()
 
 
+YT_FIX = {"upwptyik": "upwpyt", "uwtyik": "uwyt", "upuptyc": "upupyt", "wpwptyc": "wpwpyt", "wpthlptyk": "wpthlpyt", "wthltyk": "wthlyt",
+          "thlpthlpty": "thlpthlpyt", "wpsv1ptyk": "wpsca1tpyt", "wsv1tyk": "wsca1yt", "sv1psv1pty": "sca1tpsca1pyt", "sv1sgsyt": "sca1sgsyt"}
+
+
+@pytest.mark.parametrize("slabs", [1, 2])
+def test_ytdump_matches_reference(slabs):
+    """ytdump (y- and time-averaged x-z fields) after the deck's run against what the reference's own statsdump left in modfields
+    and its avey_ibm gives for the table: obstacles (columns without fluid points are -999), temperature, one scalar; on one slab
+    and through the forced-slab path."""
+    import udcore
+    from udcore.ibm import read_ibm
+    from udcore.stats import TDump
+    name, iexp = "run_ytstats_ibm_16x12x10", 78
+    fix = load_fixture(name)
+    d = read_deck(deck_path(name, iexp))
+    os.environ["UDC_FORCE_SLAB"] = "1" if slabs == 2 else "0"
+    try:
+        core = udcore.from_deck(d)
+    finally:
+        os.environ.pop("UDC_FORCE_SLAB")
+    core.load_state(cold_start(core.g, d, nsv=core.nsv))
+    dt = float(d.get("RUN", "dtmax"))
+    td = TDump(core, float(d.get("OUTPUT", "tsample")), float(d.get("OUTPUT", "tstatsdump")), yt=True, ibm_lists=read_ibm(d))
+    nsub = max(int(k[1:4]) for k in fix if k.endswith(".u0"))
+    timee = 0.
+    for isub in range(1, nsub + 1):
+        rk = (isub - 1) % 3 + 1
+        core.substep(rk, dt, True)
+        if rk == 3:
+            timee += dt
+        td.step(rk, dt, timee)
+    yt = td.yt()
+    u2 = np.abs(fix["st.uutc"].data).max()
+    checked = 0
+    for k, rec in fix.items():
+        if not k.startswith("yt."):
+            continue
+        ref = rec.data[:, 0, :]
+        got = yt[YT_FIX.get(k[3:], k[3:])]
+        assert np.array_equal(got == -999., ref == -999.), k
+        ok = ref != -999.
+        scale = max(np.abs(ref[ok]).max(), 1e-3 * u2, 1e-6 * np.abs(fix["st.thlthlt"].data).max() if "thlp" in k else 0.)
+        assert np.abs(got[ok] - ref[ok]).max() <= 2e-9 * scale, (k, np.abs(got[ok] - ref[ok]).max(), scale)
+        checked += 1
+    assert checked >= 18 and (yt["wyt"] == -999.).any()
+    core.close()
+
+
 @pytest.mark.parametrize("fused", [True, False])
 def test_stage3_assignment_carries_the_planes_below_the_floor(fused):
     """`thlm = thl0`, `svm = sv0`, `um = u0` at RK stage 3 are whole-array assignments in the reference

@@ -225,6 +225,10 @@ struct udc_handle {
   unsigned char *st_mask = nullptr;
   double *st_cnt = nullptr, *st_prof = nullptr, *st_part = nullptr, *st_sum = nullptr, *st_table = nullptr;
   size_t st_part_cap = 0;
+  // ytdump: running y-averages [15][nz][nx], column counts of the masks IIu, IIv, IIw, IIc, IIuw [5][nz][nx], scratch, table
+  bool yt_on = false;
+  double *yt_prof = nullptr, *yt_cnt = nullptr, *yt_sum = nullptr, *yt_table = nullptr;
+  int yt_forced[7] = {0, 0, 0, 0, 0, 0, 0};      // masks whose first level udc_stats_set_masks' caller filled for avexy_ibm's rule
   // deferred execution (udc_set_deferred): the tendency routines of one RK3 substep are recorded instead of launched;
   // udc_tstep_integrate then runs the recorded sequence -- as the fused substep when it is the reference's own
   // (src/program.f90:142-197), routine by routine otherwise.  pend holds OP_* bits in call order.

@@ -244,7 +244,153 @@ __global__ void xyt_table_kernel(int nz, const double *__restrict__ S, const dou
   table[q] = n > 0. ? S[f * nz + k] / n : -999.;
 }
 
+// ---- ytdump: averages over y (avey_ibm, src/modmpi.f90: masked sum over y / the column's fluid count, -999 where it is zero)
+enum { YS_U = 0, YS_V, YS_W, YS_THL, YS_QT, YS_SV1, YS_SV2, YS_SV3, YS_USGS, YS_WSGS, YS_THLSGS, YS_QTSGS, YS_SV1SGS, YS_SV2SGS, YS_SV3SGS, YS_N };
+enum { YF_UPWP = 0, YF_WPTHLP, YF_WPQTP, YF_WPSV1P, YF_WPSV2P, YF_WPSV3P, YF_UW, YF_WTHL, YF_WQT, YF_WSV1, YF_WSV2, YF_WSV3, YF_UPUP, YF_WPWP,
+       YF_THLPTHLP, YF_QTPQTP, YF_SV1P, YF_SV2P, YF_SV3P, YF_N };
+__constant__ int ys_mask[YS_N] = {MB_U, MB_V, MB_W, MB_C, MB_C, MB_C, MB_C, MB_C, MB_UW, MB_W, MB_W, MB_W, MB_W, MB_W, MB_W};
+__constant__ int yf_mask[YF_N] = {MB_UW, MB_W, MB_W, MB_W, MB_W, MB_W, MB_UW, MB_W, MB_W, MB_W, MB_W, MB_W, MB_C, MB_C, MB_C, MB_C, MB_C, MB_C, MB_C};
+
+struct YForced { int f[7]; };
+// mask bits of a cell with the levels the caller filled for avexy_ibm's rule emptied again (avey_ibm has no such rule)
+__device__ __forceinline__ unsigned ybits(const unsigned char *mask, const Geo &g, const YForced &F, int i, int j, int k) {
+  unsigned mb = mask ? mask[((size_t)k * g.ny + j) * g.nx + i] : 0x7fu;
+  if (k == 0 && mask)
+    for (int q = 0; q < 7; ++q) if (F.f[q]) mb &= ~(1u << q);
+  return mb;
+}
+
+template <int NP>
+__device__ __forceinline__ void ysum_store(double (&v)[NP], double *__restrict__ S, int i, int k, int nx, int nz, bool in) {
+  __shared__ double sw[NP][4][64];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) sw[p][threadIdx.y][threadIdx.x] = v[p];
+  __syncthreads();
+  if (threadIdx.y == 0 && in)
+    for (int p = 0; p < NP; ++p)
+      S[((size_t)p * nz + k) * nx + i] = (sw[p][0][threadIdx.x] + sw[p][1][threadIdx.x]) + (sw[p][2][threadIdx.x] + sw[p][3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void yt_count_kernel(Geo g, const unsigned char *__restrict__ mask, YForced F, double *__restrict__ S) {
+  const int i = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y;
+  double v[5] = {0., 0., 0., 0., 0.};
+  const bool in = i < g.nx;
+  if (in)
+    for (int j = threadIdx.y; j < g.ny; j += 4) {
+      const unsigned mb = ybits(mask, g, F, i, j, k);
+      for (int q = 0; q < 5; ++q) v[q] += bit(mb, q);
+    }
+  ysum_store<5>(v, S, i, k, g.nx, g.nz, in);
+}
+
+struct YtFields { const double *um, *vm, *wm, *thl, *qt, *sv[3], *ekm, *ekh; };
+
+__global__ __launch_bounds__(256) void yt_sample_kernel(Geo g, Metrics m, YtFields f, const unsigned char *__restrict__ mask, YForced F,
+                                                        double *__restrict__ S) {
+  const int i = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y, kf = k + 1;
+  double v[YS_N];
+#pragma unroll
+  for (int p = 0; p < YS_N; ++p) v[p] = 0.;
+  const bool in = i < g.nx;
+  if (in) {
+    const double dzf_k = m.dzf[kf], dzf_km = m.dzf[kf - 1], dzhi = m.dzhi[kf], dzhiq = m.dzhiq[kf], dzh2i = m.dzh2i[kf];
+    const double dzfi = m.dzfi[kf], dzfi_m = m.dzfi[kf - 1];
+    const int im = wrapx(i - 1, g.nx);
+    for (int j = threadIdx.y; j < g.ny; j += 4) {
+      const long c = g.idx(i, j, k), cm = g.idx(im, j, k), sz = g.sz;
+      const unsigned mb = ybits(mask, g, F, i, j, k);
+      const double u = f.um[c], w = f.wm[c];
+      const double emom = (dzf_km * (f.ekm[c] * m.dx + f.ekm[cm] * m.dx) + dzf_k * (f.ekm[c - sz] * m.dx + f.ekm[cm - sz] * m.dx)) * m.dxi * dzhiq;
+      const double usgs = emom * ((u - f.um[c - sz]) * dzhi + (w - f.wm[cm]) * m.dxi);
+      const double wsgs = (f.ekm[c] * (f.wm[c + sz] - w) * dzfi - f.ekm[c - sz] * (w - f.wm[c - sz]) * dzfi_m) * 2. * dzhi;
+      const double eh = 0.5 * (dzf_km * f.ekh[c] + dzf_k * f.ekh[c - sz]);
+      v[YS_U] += u * bit(mb, MB_U);
+      v[YS_V] += f.vm[c] * bit(mb, MB_V);
+      v[YS_W] += w * bit(mb, MB_W);
+      v[YS_USGS] += usgs * bit(mb, MB_UW);
+      v[YS_WSGS] += wsgs * bit(mb, MB_W);
+      if (f.thl) { const double t0 = f.thl[c]; v[YS_THL] += t0 * bit(mb, MB_C); v[YS_THLSGS] += eh * (t0 - f.thl[c - sz]) * dzh2i * bit(mb, MB_W); }
+      if (f.qt) { const double q0 = f.qt[c]; v[YS_QT] += q0 * bit(mb, MB_C); v[YS_QTSGS] += eh * (q0 - f.qt[c - sz]) * dzh2i * bit(mb, MB_W); }
+#pragma unroll
+      for (int n = 0; n < 3; ++n)
+        if (f.sv[n]) { const double s0 = f.sv[n][c]; v[YS_SV1 + n] += s0 * bit(mb, MB_C); v[YS_SV1SGS + n] += eh * (s0 - f.sv[n][c - sz]) * dzh2i * bit(mb, MB_W); }
+    }
+  }
+  ysum_store<YS_N>(v, S, i, k, g.nx, g.nz, in);
+}
+
+struct YtAcc { const double *a[UDC_ST_MOM_N]; const double *thl[4], *qt[4], *sv[3][4]; };
+
+__global__ __launch_bounds__(256) void yt_final_kernel(Geo g, YtAcc s, const unsigned char *__restrict__ mask, YForced F, double *__restrict__ S) {
+  const int i = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y;
+  double v[YF_N];
+#pragma unroll
+  for (int p = 0; p < YF_N; ++p) v[p] = 0.;
+  const bool in = i < g.nx;
+  if (in)
+    for (int j = threadIdx.y; j < g.ny; j += 4) {
+      const long c = g.idx(i, j, k);
+      const unsigned mb = ybits(mask, g, F, i, j, k);
+      const double utik = s.a[UDC_ST_UTIK][c], wtik = s.a[UDC_ST_WTIK][c], wmt = s.a[UDC_ST_WMT][c];
+      const double utc = s.a[UDC_ST_UTC][c], wtc = s.a[UDC_ST_WTC][c];
+      v[YF_UPWP] += (s.a[UDC_ST_UWTIK][c] - utik * wtik) * bit(mb, MB_UW);
+      v[YF_UW] += utik * wtik * bit(mb, MB_UW);
+      v[YF_UPUP] += (s.a[UDC_ST_UUTC][c] - utc * utc) * bit(mb, MB_C);
+      v[YF_WPWP] += (s.a[UDC_ST_WWTC][c] - wtc * wtc) * bit(mb, MB_C);
+      // scalar-like fields: [0] t, [1] tk, [2] wtk, [3] sq
+      if (s.thl[0]) {
+        v[YF_WPTHLP] += (s.thl[2][c] - wmt * s.thl[1][c]) * bit(mb, MB_W); v[YF_WTHL] += wmt * s.thl[1][c] * bit(mb, MB_W);
+        v[YF_THLPTHLP] += (s.thl[3][c] - s.thl[0][c] * s.thl[0][c]) * bit(mb, MB_C);
+      }
+      if (s.qt[0]) {
+        v[YF_WPQTP] += (s.qt[2][c] - wmt * s.qt[1][c]) * bit(mb, MB_W); v[YF_WQT] += wmt * s.qt[1][c] * bit(mb, MB_W);
+        v[YF_QTPQTP] += (s.qt[3][c] - s.qt[0][c] * s.qt[0][c]) * bit(mb, MB_C);
+      }
+#pragma unroll
+      for (int n = 0; n < 3; ++n)
+        if (s.sv[n][0]) {
+          v[YF_WPSV1P + n] += (s.sv[n][2][c] - wmt * s.sv[n][1][c]) * bit(mb, MB_W); v[YF_WSV1 + n] += wmt * s.sv[n][1][c] * bit(mb, MB_W);
+          v[YF_SV1P + n] += (s.sv[n][3][c] - s.sv[n][0][c] * s.sv[n][0][c]) * bit(mb, MB_C);
+        }
+    }
+  ysum_store<YF_N>(v, S, i, k, g.nx, g.nz, in);
+}
+
+__global__ void yt_running_kernel(int n, const double *__restrict__ S, const double *__restrict__ cnt, double ts, double T, double *__restrict__ prof) {
+  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= (long)YS_N * n) return;
+  const int p = (int)(q / n);
+  const long r = q - (long)p * n;
+  const double c = cnt[(long)ys_mask[p] * n + r];
+  const double ya = c > 0. ? S[q] / c : -999.;
+  prof[q] = (prof[q] * (T - ts) + ya * ts) * (1. / T);
+}
+
+// the table in the order of varsyt (:1513-1551)
+__global__ void yt_table_kernel(int n, const double *__restrict__ S, const double *__restrict__ cnt, const double *__restrict__ prof,
+                                double *__restrict__ table) {
+  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= (long)UDC_YT_N * n) return;
+  const int row = (int)(q / n);
+  const long r = q - (long)row * n;
+  if (row < 8) { table[q] = prof[(long)row * n + r]; return; }                          // uyt .. sca3yt
+  if (row >= 27) { table[q] = prof[(long)(YS_USGS + row - 27) * n + r]; return; }         // usgsyt .. sca3sgsyt
+  const int f = row - 8;                                                                  // upwpyt .. sca3psca3pyt
+  const double c = cnt[(long)yf_mask[f] * n + r];
+  table[q] = c > 0. ? S[(long)f * n + r] / c : -999.;
+}
+
 }  // namespace
+
+static int yt_counts(udc_handle *h) {
+  const Geo &g = h->g;
+  YForced F;
+  for (int q = 0; q < 7; ++q) F.f[q] = h->yt_forced[q];
+  hipLaunchKernelGGL(yt_count_kernel, dim3((unsigned)((g.nx + 63) / 64), (unsigned)g.nz), dim3(64, 4), 0, h->stream, g,
+                     (const unsigned char *)h->st_mask, F, h->yt_cnt);
+  HIP_OK(hipGetLastError());
+  return comm_allreduce(h, h->yt_cnt, 5 * g.nz * g.nx, 1);
+}
 
 static int xyt_scratch(udc_handle *h, int nq) {
   const size_t need = (size_t)xyt_tiles(h->g).tiles * h->g.nz * nq;
@@ -288,6 +434,18 @@ extern "C" int udc_stats_enable(udc_handle *h, int on) {
     }
     HIP_OK(hipMemsetAsync(h->st_prof, 0, sizeof(double) * XS_N * nz, h->stream));
     h->xyt_on = true;
+  }
+  if (on & 4) {        // ytdump: running y-averages and the column counts of the masks
+    const size_t n = (size_t)h->g.nz * h->g.nx;
+    if (!h->yt_prof) {
+      HIP_OK(hipMalloc(&h->yt_prof, sizeof(double) * YS_N * n));
+      HIP_OK(hipMalloc(&h->yt_cnt, sizeof(double) * 5 * n));
+      HIP_OK(hipMalloc(&h->yt_sum, sizeof(double) * YF_N * n));
+      HIP_OK(hipMalloc(&h->yt_table, sizeof(double) * UDC_YT_N * n));
+    }
+    HIP_OK(hipMemsetAsync(h->yt_prof, 0, sizeof(double) * YS_N * n, h->stream));
+    h->yt_on = true;
+    if (yt_counts(h)) return 1;
   }
   for (int q = 0; q < UDC_ST_MOM_N; ++q)
     if (stat_alloc(h, q)) return 1;
@@ -349,6 +507,63 @@ extern "C" int udc_stats_sample(udc_handle *h, double tsamplep, double tstatsdum
                        (const double *)h->st_cnt, tsamplep, tstatsdumpp, h->st_prof);
     HIP_OK(hipGetLastError());
   }
+  if (h->yt_on) {
+    const size_t n = (size_t)g.nz * g.nx;
+    YtFields f{um, vm, wm, nullptr, nullptr, {nullptr, nullptr, nullptr}, (const double *)h->fields[UDC_EKM], (const double *)h->fields[UDC_EKH]};
+    for (int s : h->slots) {
+      if (s == 15) f.thl = h->fields[UDC_SVM + 3 * s];
+      if (s == 13) f.qt = h->fields[UDC_SVM + 3 * s];
+      if (s < 3) f.sv[s] = h->fields[UDC_SVM + 3 * s];
+    }
+    YForced F;
+    for (int q = 0; q < 7; ++q) F.f[q] = h->yt_forced[q];
+    PROF(h, "stats_yt");
+    hipLaunchKernelGGL(yt_sample_kernel, dim3((unsigned)((g.nx + 63) / 64), (unsigned)g.nz), dim3(64, 4), 0, h->stream, g, h->m, f,
+                       (const unsigned char *)h->st_mask, F, h->yt_sum);
+    HIP_OK(hipGetLastError());
+    if (comm_allreduce(h, h->yt_sum, (int)(YS_N * n), 1)) return 1;
+    hipLaunchKernelGGL(yt_running_kernel, dim3((unsigned)((YS_N * n + 255) / 256)), dim3(256), 0, h->stream, (int)n, (const double *)h->yt_sum,
+                       (const double *)h->yt_cnt, tsamplep, tstatsdumpp, h->yt_prof);
+    HIP_OK(hipGetLastError());
+  }
+  return 0;
+}
+
+extern "C" int udc_stats_set_forced(udc_handle *h, const int *forced) {
+  if (!h) { udc_set_error("null handle"); return 1; }
+  HIP_OK(hipSetDevice(h->device));
+  if (udc_flush_pending(h)) return 1;
+  for (int q = 0; q < 7; ++q) h->yt_forced[q] = forced && forced[q] ? 1 : 0;
+  if (h->yt_on && yt_counts(h)) return 1;
+  return 0;
+}
+
+extern "C" int udc_stats_yt(udc_handle *h, double *table) {
+  if (!h) { udc_set_error("null handle"); return 1; }
+  HIP_OK(hipSetDevice(h->device));
+  if (udc_flush_pending(h)) return 1;
+  if (!h->yt_on || !h->stats_on) { udc_set_error("udc_stats_yt: enable the yt statistics first (udc_stats_enable with bit 4)"); return 1; }
+  if (!table) { udc_set_error("udc_stats_yt: null table"); return 1; }
+  const Geo &g = h->g;
+  const size_t n = (size_t)g.nz * g.nx;
+  auto st = [&](int id) -> const double * { return id < (int)h->stats.size() ? h->stats[id] : nullptr; };
+  YtAcc s;
+  for (int q = 0; q < UDC_ST_MOM_N; ++q) s.a[q] = h->stats[q];
+  for (int q = 0; q < 4; ++q) {
+    s.thl[q] = st(UDC_ST_THL + q); s.qt[q] = st(UDC_ST_QT + q);
+    for (int m = 0; m < 3; ++m) s.sv[m][q] = st(UDC_ST_SV + UDC_ST_SV_STRIDE * m + q);
+  }
+  YForced F;
+  for (int q = 0; q < 7; ++q) F.f[q] = h->yt_forced[q];
+  hipLaunchKernelGGL(yt_final_kernel, dim3((unsigned)((g.nx + 63) / 64), (unsigned)g.nz), dim3(64, 4), 0, h->stream, g, s,
+                     (const unsigned char *)h->st_mask, F, h->yt_sum);
+  HIP_OK(hipGetLastError());
+  if (comm_allreduce(h, h->yt_sum, (int)(YF_N * n), 1)) return 1;
+  hipLaunchKernelGGL(yt_table_kernel, dim3((unsigned)((UDC_YT_N * n + 255) / 256)), dim3(256), 0, h->stream, (int)n, (const double *)h->yt_sum,
+                     (const double *)h->yt_cnt, (const double *)h->yt_prof, h->yt_table);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipMemcpyAsync(table, h->yt_table, sizeof(double) * UDC_YT_N * n, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
   return 0;
 }
 
@@ -356,7 +571,7 @@ extern "C" int udc_stats_set_masks(udc_handle *h, const unsigned char *bits, con
   if (!h) { udc_set_error("null handle"); return 1; }
   HIP_OK(hipSetDevice(h->device));
   if (udc_flush_pending(h)) return 1;
-  if (!h->xyt_on) { udc_set_error("udc_stats_set_masks: enable the xyt statistics first (udc_stats_enable with bit 2)"); return 1; }
+  if (!h->xyt_on && !h->yt_on) { udc_set_error("udc_stats_set_masks: enable the xyt or yt statistics first (udc_stats_enable with bit 2 or 4)"); return 1; }
   if (!counts) { udc_set_error("udc_stats_set_masks: counts missing"); return 1; }
   const Geo &g = h->g;
   const size_t n = (size_t)g.nz * g.ny * g.nx;
@@ -373,7 +588,8 @@ extern "C" int udc_stats_set_masks(udc_handle *h, const unsigned char *bits, con
     if (counts[q] < 0) { udc_set_error("udc_stats_set_masks: negative count"); return 1; }
     c[q] = (double)counts[q];
   }
-  HIP_OK(hipMemcpy(h->st_cnt, c.data(), sizeof(double) * c.size(), hipMemcpyHostToDevice));
+  if (h->st_cnt) HIP_OK(hipMemcpy(h->st_cnt, c.data(), sizeof(double) * c.size(), hipMemcpyHostToDevice));
+  if (h->yt_on && yt_counts(h)) return 1;
   return 0;
 }
 
@@ -410,11 +626,12 @@ extern "C" int udc_stats_xyt(udc_handle *h, double *table) {
 void stats_destroy(udc_handle *h) {
   for (double *p : h->stats) if (p) hipFree(p);
   h->stats.clear();
-  for (double **p : {&h->st_cnt, &h->st_prof, &h->st_part, &h->st_sum, &h->st_table})
+  for (double **p : {&h->st_cnt, &h->st_prof, &h->st_part, &h->st_sum, &h->st_table, &h->yt_prof, &h->yt_cnt, &h->yt_sum, &h->yt_table})
     if (*p) { hipFree(*p); *p = nullptr; }
   if (h->st_mask) { hipFree(h->st_mask); h->st_mask = nullptr; }
   h->st_part_cap = 0;
   h->xyt_on = false;
+  h->yt_on = false;
 }
 
 double *stats_ptr(udc_handle *h, int id) {

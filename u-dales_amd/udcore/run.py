@@ -176,13 +176,13 @@ def main(argv=None, at_end=None):
     core.dt, core.timee, core.rk3step = dt, timee, 0
     forcings = LevelForcings(core, deck)
     tdump = None
-    for sw in ("lydump", "lytdump", "lxydump", "ltkedump", "lkslicedump", "lislicedump", "ljslicedump"):
+    for sw in ("lydump", "lxydump", "ltkedump", "lkslicedump", "lislicedump", "ljslicedump"):
         if deck.is_set("OUTPUT", sw) and deck.get("OUTPUT", sw):
             sys.stderr.write(f" WARNING: &OUTPUT {sw}: this dump is not written by the device runner (tdump, xytdump, mintdump, fielddump are)\n")
     fdump = None
     if bool(deck.get("OUTPUT", "lfielddump")):
         fdump = FieldDump(core, deck.get("OUTPUT", "tfielddump"), deck.get("OUTPUT", "fieldvars"), wdir, iexp, rank)
-    if bool(deck.get("OUTPUT", "ltdump")) or bool(deck.get("OUTPUT", "lxytdump")) or bool(deck.get("OUTPUT", "lmintdump")):      # src/modstatsdump.f90
+    if any(bool(deck.get("OUTPUT", sw)) for sw in ("ltdump", "lxytdump", "lmintdump", "lytdump")):      # src/modstatsdump.f90
         from .stats import TDump
         lists = None
         if deck.get("RUN", "libm"):
@@ -191,7 +191,7 @@ def main(argv=None, at_end=None):
         tdump = TDump(core, float(deck.get("OUTPUT", "tsample")), float(deck.get("OUTPUT", "tstatsdump")),
                       float(deck.get("OUTPUT", "tstatstart")), wdir=wdir, expnr=iexp, xyt=bool(deck.get("OUTPUT", "lxytdump")),
                       ibm_lists=lists, wrap=(int(deck.get("RUN", "nprocx")) > 1, int(deck.get("RUN", "nprocy")) > 1),
-                      jtot=int(deck.get("DOMAIN", "jtot")), j0=rank * nyl, nyl=nyl)
+                      jtot=int(deck.get("DOMAIN", "jtot")), j0=rank * nyl, nyl=nyl, yt=bool(deck.get("OUTPUT", "lytdump")))
         tdump.mint = bool(deck.get("OUTPUT", "lmintdump"))
     # (the reference restarts the restart clock and the step counter on a warm start: tnextrestart = trestart,
     # ntrun = 0, src/modglobal.f90:869; this runner keeps counting from the file it started from, so that the files

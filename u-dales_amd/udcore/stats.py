@@ -28,8 +28,14 @@ XYT = ["uxyt", "vxyt", "wxyt", "thlxyt", "qtxyt", "pxyt", "upwpxyt", "wpthlpxyt"
        "vwxyt", "wwxyt", "usgsxyt", "thlsgsxyt", "vsgsxyt", "thlpthlptxy", "upuptxyc", "vpvptxyc", "wpwptxyc", "tketxyc"]
 
 
+# rows of udc_stats_yt (initstatsdump, src/modstatsdump.f90:165-199)
+YT = ["uyt", "vyt", "wyt", "thlyt", "qtyt", "sca1yt", "sca2yt", "sca3yt", "upwpyt", "wpthlpyt", "wpqtpyt", "wpsca1tpyt", "wpsca2tpyt",
+      "wpsca3tpyt", "uwyt", "wthlyt", "wqtyt", "wsca1yt", "wsca2yt", "wsca3yt", "upupyt", "wpwpyt", "thlpthlpyt", "qtpqtpyt",
+      "sca1tpsca1pyt", "sca2tpsca2pyt", "sca3tpsca3pyt", "usgsyt", "wsgsyt", "thlsgsyt", "qtsgsyt", "sca1sgsyt", "sca2sgsyt", "sca3sgsyt"]
+
+
 def xyt_masks(nx, ny, nz, lists, wrapx=False, wrapy=False, j0=0, nyl=None):
-    """createmasks' fluid masks (src/modibm.f90:2141-2190) for udc_stats_set_masks: (bits[nz, nyl, nx] uint8, counts[7, nz])
+    """createmasks' fluid masks (src/modibm.f90:2141-2190) for udc_stats_set_masks: (bits[nz, nyl, nx] uint8, counts[7, nz], forced[7])
     from the solid point lists {grid: (solid[n, 3], ...)} (global 1-based i, j, k).  Bit order IIu, IIv, IIw, IIc, IIuw,
     IIvw, IIuv.  The point masks' ghost cells are fluid unless the direction wraps (one the reference run splits over
     ranks, as for udc_set_ibm_mask_wrap).  avexy_ibm's rule for a first level without fluid points (src/modmpi.f90:646-649,
@@ -56,33 +62,47 @@ def xyt_masks(nx, ny, nz, lists, wrapx=False, wrapy=False, j0=0, nyl=None):
     uw[0], vw[0] = 0, 0                                        # IIuw(:, :, kb) = IIvw(:, :, kb) = 0
     II += [uw, vw, at(pt["u"]) * at(pt["u"], dj=-1) * at(pt["v"]) * at(pt["v"], di=-1)]
     counts = np.array([m.sum(axis=(1, 2)) for m in II], dtype=np.int32)
+    forced = np.zeros(7, dtype=np.int32)
     for q, m in enumerate(II):
         if counts[q, 0] == 0:
             m[0] = 1
             counts[q, 0] = counts[q, nz - 1]
+            forced[q] = 1
     bits = np.zeros((nz, ny, nx), dtype=np.uint8)
     for q, m in enumerate(II):
         bits |= (m.astype(np.uint8) << q)
     nyl = ny if nyl is None else nyl
-    return np.ascontiguousarray(bits[:, j0:j0 + nyl]), np.ascontiguousarray(counts)
+    return np.ascontiguousarray(bits[:, j0:j0 + nyl]), np.ascontiguousarray(counts), forced
 
 
 class TDump:
     def __init__(self, core, tsample, tstatsdump, tstatstart=0., wdir=None, expnr=0, xyt=False, ibm_lists=None, wrap=(False, False),
-                 jtot=None, j0=0, nyl=None):
+                 jtot=None, j0=0, nyl=None, yt=False):
         """xyt: also xytdump's profiles; ibm_lists (udcore.ibm.read_ibm) when the deck has obstacles, wrap = the directions
         the reference run of the deck splits over ranks, jtot / j0 / nyl = global rows / this rank's first row / its row count for y-slab runs."""
         self.core, self.tsample, self.tstatsdump, self.tstatstart = core, float(tsample), float(tstatsdump), float(tstatstart)
         self.tsamplep, self.tstatsdumpp = 0., 0.
         self.wdir, self.expnr = wdir, expnr
         self.nsamples, self.dumps, self.xyt_on, self.xyt_dumps = 0, [], bool(xyt), []
+        self.yt_on, self.yt_dumps = bool(yt), []
         self.mint = False             # mintdump (src/modstatsdump.f90:1670-1684): ut, vt, wt, thlt, qtt, pt of the same accumulators
-        L._check(core.lib.udc_stats_enable(core.h, 3 if xyt else 1), "udc_stats_enable")
-        if xyt and ibm_lists is not None:
+        L._check(core.lib.udc_stats_enable(core.h, 1 + (2 if xyt else 0) + (4 if yt else 0)), "udc_stats_enable")
+        if (xyt or yt) and ibm_lists is not None:
             g = core.g
-            bits, counts = xyt_masks(g.nx, jtot or g.ny, g.nz, ibm_lists, wrap[0], wrap[1], j0=j0, nyl=nyl or g.ny)
+            bits, counts, forced = xyt_masks(g.nx, jtot or g.ny, g.nz, ibm_lists, wrap[0], wrap[1], j0=j0, nyl=nyl or g.ny)
             L._check(core.lib.udc_stats_set_masks(core.h, bits.ctypes.data_as(C.POINTER(C.c_ubyte)), counts.ctypes.data_as(C.POINTER(C.c_int))),
                      "udc_stats_set_masks")
+            L._check(core.lib.udc_stats_set_forced(core.h, forced.ctypes.data_as(C.POINTER(C.c_int))), "udc_stats_set_forced")
+
+    def yt(self):
+        """ytdump's table {name: field[ktot, itot]} (src/modstatsdump.f90:1513-1551); -999 in columns without fluid points."""
+        g = self.core.g
+        t = np.zeros((len(YT), g.nz, g.nx))
+        L._check(self.core.lib.udc_stats_yt(self.core.h, t.ctypes.data_as(L.DP)), "udc_stats_yt")
+        c = self.core
+        have = lambda n: (("thl" not in n) or getattr(c, "ltempeq", False)) and (("qt" not in n) or getattr(c, "lmoist", False)) and \
+            not any(f"sca{q}" in n and c.nsv < q for q in (1, 2, 3))      # noqa: E731
+        return {n: t[q] for q, n in enumerate(YT) if have(n)}
 
     def xyt(self):
         """xytdump's table {name: profile[ktot]} (src/modstatsdump.f90:1437-1460); rows the deck does not have (thl, qt) left out."""
@@ -159,6 +179,8 @@ class TDump:
             self.dumps.append((timee, self.output()))
             if self.xyt_on:
                 self.xyt_dumps.append((timee, self.xyt()))
+            if self.yt_on:
+                self.yt_dumps.append((timee, self.yt()))
             if self.wdir:
                 self.write()
             self.tstatsdumpp = dt
@@ -168,6 +190,9 @@ class TDump:
         return what
 
     def write(self):
+        if self.yt_on:
+            np.savez(os.path.join(self.wdir, f"ytdump.{self.expnr:03d}.npz"), time=np.array([t for t, _ in self.yt_dumps]),
+                     **{k: np.array([o[k] for _, o in self.yt_dumps]) for k in self.yt_dumps[0][1]})
         if self.mint:
             keep = [k for k in ("ut", "vt", "wt", "thlt", "qtt", "pt") if k in self.dumps[0][1]]
             np.savez(os.path.join(self.wdir, f"mintdump.{self.expnr:03d}.npz"), time=np.array([t for t, _ in self.dumps]),
