@@ -161,7 +161,7 @@ int comm_alltoall(udc_handle *h, const double *send, double *recv, size_t block,
   return 0;
 }
 
-// in-place all-reduce of n (<= 4096 over the test transport) doubles held in device memory `buf`; op 0 = max, 1 = sum
+// in-place all-reduce of n doubles held in device memory `buf`; op 0 = max, 1 = sum
 int comm_allreduce(udc_handle *h, double *buf, int n, int op) {
   if (h->cfg.nranks == 1 && !h->nccl) return 0;
   if (need_comm(h)) return 1;
@@ -172,18 +172,20 @@ int comm_allreduce(udc_handle *h, double *buf, int n, int op) {
   }
   LocalGroup *g = (LocalGroup *)h->local_group;
   const int P = h->cfg.nranks, r = h->cfg.rank;
-  if (n > 4096) { udc_set_error("comm_allreduce: at most 4096 values"); return 1; }
-  HIP_OK(hipMemcpyAsync(g->red[r], buf, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_OK(hipStreamSynchronize(h->stream));
-  pthread_barrier_wait(&g->bar);
-  std::vector<double> out(n);
-  for (int q = 0; q < n; ++q) {
-    double v = g->red[0][q];
-    for (int s = 1; s < P; ++s) v = op == 0 ? (g->red[s][q] > v ? g->red[s][q] : v) : v + g->red[s][q];
-    out[q] = v;
+  std::vector<double> out(4096);
+  for (int o = 0; o < n; o += 4096) {          // the test transport's staging rows hold 4096 values: go in chunks
+    const int m = n - o < 4096 ? n - o : 4096;
+    HIP_OK(hipMemcpyAsync(g->red[r], buf + o, m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    pthread_barrier_wait(&g->bar);
+    for (int q = 0; q < m; ++q) {
+      double v = g->red[0][q];
+      for (int s = 1; s < P; ++s) v = op == 0 ? (g->red[s][q] > v ? g->red[s][q] : v) : v + g->red[s][q];
+      out[q] = v;
+    }
+    pthread_barrier_wait(&g->bar);
+    HIP_OK(hipMemcpyAsync(buf + o, out.data(), m * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
   }
-  pthread_barrier_wait(&g->bar);
-  HIP_OK(hipMemcpyAsync(buf, out.data(), n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIP_OK(hipStreamSynchronize(h->stream));
   return 0;
 }
