@@ -79,8 +79,8 @@ UNSUPPORTED = [("RUN", "lstratstart", False), ("RUN", "lper2inout", False), ("RU
                ("INLET", "lreadminl", False), ("INLET", "lfixinlet", False), ("INLET", "lfixutauin", False),
                ("ENERGYBALANCE", "lEB", False), ("ENERGYBALANCE", "lperiodicEBcorr", False),
                ("SCALARS", "lscasrcr", False),
-               ("TREES", "ltrees", False), ("PURIFS", "lpurif", False), ("HEATPUMP", "lheatpump", False),
-               ("NAMSUBGRID", "lmason", False)]
+               ("TREES", "ltrees", False), ("PURIFS", "lpurif", False), ("HEATPUMP", "lheatpump", False)]
+# &NAMSUBGRID lmason / nmason are read and broadcast by the reference (src/modsubgrid.f90:90-106) and used nowhere: accepted, no effect
 
 
 def _expand(tokens):
