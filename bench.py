@@ -205,6 +205,11 @@ nwarm = {nwarm}
         f.write("# bench\n# z uq vq pqx pqy wfls dqtdxls dqtdyls dqtdtls dthlrad\n")
         for k in range(nz):
             f.write(f"{(k + 0.5) * 0.5:.15f} 0.0 0.0 0.0001 0.0 0.0 0.0 0.0 0.0 0.0\n")
+    if nsv > 0:      # scalar.inp (src/modstartup.f90:1541-1548): scalar n = n z / zsize, so that the kappa limiter has work
+        with open(os.path.join(d, f"scalar.inp.{iexp:03d}"), "w") as f:
+            f.write("# bench\n# z sv(1..nsv)\n")
+            for k in range(nz):
+                f.write(f"{(k + 0.5) * 0.5:.15f} " + " ".join(repr((n + 1) * (k + 0.5) / nz) for n in range(nsv)) + "\n")
     return os.path.join(d, f"namoptions.{iexp:03d}")
 
 
@@ -240,9 +245,9 @@ def dropin_leg(nx, ny, nz, nsv, sgs, floor, value, nsub=150, nwarm=15):
             "ms_per_step": round(nx * ny * nz / v * 1e3, 5),
             "fused_substeps": int(m.group(1)) if m else None, "unfused_substeps": int(m.group(2)) if m else None,
             "divmax_after_run": float(dm.group(1)) if dm else None,
-            "surface": "Fortran driver (oracle/ref_driver.f90: tstep_update, advection, shiftedPBCs, subgrid, bottom, coriolis, "
-                       "forces, lstend, nudge, masscorr, scalsource, fixuinf2, fixuinf1, grwdamp, poisson, tstep_integrate, halos, "
-                       "boundary per substep) -> drop-in modules -> C ABI, UDC_RESIDENCY=2"}
+            "surface": "the reference's whole src/ tree minus the eight drop-in modules (modstartup's start-up, every call of "
+                       "src/program.f90:132-222 per substep incl. checksim, statsdump, thermodynamics; main program oracle/ref_driver.f90 "
+                       "for the timer around the loop) -> drop-in modules -> C ABI, UDC_RESIDENCY=2"}
 
 
 def cpu_baseline(nx, ny, nz, budget_s=25.0):

@@ -1,26 +1,21 @@
-! TEST INFRASTRUCTURE (oracle/_ref build only) -- not part of the product.
+! TEST INFRASTRUCTURE (oracle/_ref builds only) -- not part of the product.
 !
-! Driver around the reference's UNMODIFIED hot-path Fortran (compiled from
-! /root/reference/src where it lies; see oracle/Makefile).  It reproduces the call
-! order of src/program.f90:63-222 restricted to the dynamical core:
+! A second main program around the reference's UNMODIFIED src/ tree (every file compiled where it lies, oracle/Makefile), in place
+! of src/program.f90 -- same modules, same start-up, same loop -- for what the reference's own executable cannot do: dump the state
+! between routines (per-routine golden vectors), after chosen substeps, and time the loop alone.
 !
-!     tstep_update -> advection -> subgrid -> forces -> poisson ->
-!     tstep_integrate -> halos -> boundary
+! What is the reference's own code here: EVERYTHING that computes or decides.  Start-up is src/program.f90:63-124 call for call --
+! modstartup's readnamelists (all groups, all defaults), init2decomp, checkinitvalues (incl. the rules that re-route wall
+! functions, :811-816), initglobal, initfields ... readinitfiles (cold / warm start, prof.inp, lscale.inp, scalar.inp, the random
+! perturbation), createscals, the statistics / output initialisers, boundary -- and one pass of the loop is the call sequence of
+! src/program.f90:132-222.  What is written here: that list of calls (it is the contract, SURVEY.md section 3), the dump records, and
+! the namelist group &ORACLE (substep counts, where to dump), which the reference's reader never looks at.
+! `run` mode is pinned on the reference's executable itself: oracle/_ref/udales_full (program.f90 and all) on the same deck writes a
+! restart file that must equal this driver's state bit for bit (tests/test_full_reference.py).
 !
-! (the NetCDF / statistics modules cannot be built here and are outside the hot path, SURVEY.md section 8).
-! src/modibm.f90 as a whole needs NetCDF (initfac, modstat_nc); its NetCDF-free routines -- bottom, createmasks, ibmnorm,
-! solid, advecc2nd_corr_*, diffu/v/w/c_corr, initibmnorm -- are compiled from the reference file where it lies
-! (oracle/extract_modibm.sh assembles them into a `module modibm` inside the build directory).  What is restated here of
-! that module: initibm's mask set-up (:150-163) and reading of the fluid-boundary point lists (:302-306) in ibm_setup,
-! and ibmwallfun's call sequence without the wall functions (:1216-1218, :1262-1264) in ibmwallfun below.
-! Set-up mirrors src/modstartup.f90:
-!   readnamelists (:105-172, subset of groups/variables, same names),
-!   init2decomp (:652-691), cold start of readinitfiles (:1088-1290),
-!   lscale.inp reading (:2051-2092); randomize_field (:2367-2396) is the reference's own routine (extract_startup.sh).
-! None of that set-up code is on the measured/validated path: it only builds the
-! inputs, which are dumped so that the device library starts from identical data.
+! The absent third-party layers are the stand-ins of oracle/shims (MPI, 2DECOMP&FFT, FFTW through fft_ref.c, a recording NetCDF).
 !
-! Modes (argv[2]):
+! Modes (argv[2]; argv[1] is the deck, as for the reference's executable, src/modstartup.f90:175-177):
 !   run      : nsub substeps, dump state after the substeps listed in dump_at
 !   kernels  : spin-up nspin substeps, then call each reference routine separately
 !              and dump inputs/outputs (per-kernel golden vectors)
@@ -38,37 +33,36 @@ program ref_driver
   use modfields
   use modsubgriddata
   use modsurfdata, only: thl_top, wttop, wsvtop, sv_top, wsvtopdum, thvs, thls, z0, z0h, wtsurf, qts, wqtop, qt_top, wqsurf, ps
-  use modboundary, only: initboundary, boundary, halos, grwdamp, ksp
-  use modthermodynamics, only: initthermodynamics, thermodynamics, lqlnr
+  ! src/program.f90:30-57
+  use modstartup, only: readnamelists, init2decomp, checkinitvalues, readinitfiles
+  use modsave, only: writerestartfiles
+  use modboundary, only: initboundary, boundary, grwdamp, halos
+  use modthermodynamics, only: initthermodynamics, thermodynamics
   use modsubgrid, only: initsubgrid, subgrid
+  use modforces, only: calcfluidvolumes, forces, coriolis, lstend, fixuinf1, fixuinf2, nudge, masscorr, shiftedPBCs, periodicEBcorr
   use modpois, only: initpois, poisson, p
+  use modibm, only: initibm, createmasks, ibmwallfun, ibmnorm, bottom, lbottom
+  use vegetation, only: init_vegetation, vegetation_forcing
+  use modpurifiers, only: createpurifiers, purifiers
+  use modheatpump, only: init_heatpump, heatpump
+  use initfac, only: readfacetfiles
+  use modEB, only: initEB, EB
+  use moddriver, only: initdriver
   use modadvection, only: advection
   use modtstep, only: tstep_update, tstep_integrate
-  use modforces, only: forces, masscorr, coriolis, lstend, nudge, fixuinf1, fixuinf2, shiftedPBCs
-  use modsave, only: writerestartfiles
   use modscalsource, only: createscals, scalsource
+  use modchecksim, only: initchecksim, checksim
+  use modstat_nc, only: initstat_nc
+  use modfielddump, only: initfielddump, fielddump
+  use modstatsdump, only: initstatsdump, statsdump
+  use modtimedep, only: inittimedep, timedep
 #ifdef UDC_DROPIN
-  ! drop-in build: the floor (`bottom`), the immersed boundary, the masks and lbottom come from the drop-in modibm, as in
-  ! src/program.f90:38
-  use modibm, only: initibm, createmasks, bottom, lbottom, ibmwallfun, ibmnorm, nsolpts_u, nsolpts_v, nsolpts_w, nsolpts_c, &
-                    nbndpts_u, nbndpts_v, nbndpts_w, nbndpts_c, nfctsecs_u, nfctsecs_v, nfctsecs_w, nfctsecs_c, lnorec
   use udc_iface, only: udc_residency, udc_pull_all, udc_h, udc_sync, udc_check, udc_deferred_stats
   use iso_c_binding, only: c_long
-#else
-  ! reference build: the reference's own routines (assembled by oracle/extract_modibm.sh)
-  use modibm, only: createmasks, bottom, lbottom, ibmnorm, solid, diffu_corr, diffv_corr, diffw_corr, diffc_corr, &
-                    initibmnorm, solid_info_u, solid_info_v, solid_info_w, solid_info_c, bound_info_u, bound_info_v, &
-                    bound_info_w, bound_info_c, mask_u, mask_v, mask_w, mask_c, nsolpts_u, nsolpts_v, nsolpts_w, nsolpts_c, &
-                    nbndpts_u, nbndpts_v, nbndpts_w, nbndpts_c, nfctsecs_u, nfctsecs_v, nfctsecs_w, nfctsecs_c, &
-                    lnorec, initibm, ref_ibmwallfun => ibmwallfun      ! the facet wall functions: the reference's own set-up and loop
-  use readinput, only: read_sparse_ijk
 #endif
-  use initfac, only: readfacetfiles
-  use modstatsdump, only: initstatsdump, statsdump  ! src/modstatsdump.f90: the sampling half, compiled from the reference (extract_statsdump.sh)
-  use modstartup_rand, only: randomize_field        ! src/modstartup.f90:2367-2396, compiled from the reference (extract_startup.sh)
   implicit none
 
-  character(256) :: mode, outfile, arg
+  character(256) :: mode, outfile, deckfile
   integer :: nsub = 3, nspin = 2, nwarm = 0
   integer :: pmode(3) = (/1, 0, 0/)      ! mode `poisson1`: wavenumbers (x, y, z) of the analytic pressure field
   integer :: dump_at(16) = -1
@@ -76,58 +70,52 @@ program ref_driver
 #ifdef UDC_DROPIN
   integer(c_long) :: nfused, nunfused
 #endif
-  logical :: need_thermo = .false., lstats = .false.
-  integer :: isub, n, ierr, iu
+  logical :: lstats = .false.
+  integer :: isub, ierr, iu
   real :: t0, t1, chk_u2, chk_div
-  real :: scal_a = 1.0, scal_b = 0.0     ! scalar init: sv = scal_b + scal_a*z/zsize
-  ! src/modstartup.f90:42-44 (module variables of modstartup, which cannot be built here)
-  integer(KIND=selected_int_kind(6)) :: irandom = 43
-  integer :: krand = huge(0)
-  real :: randu = 0.01
-  real :: randthl = 0., randqt = 0.       ! (read and ignored by the reference too: its perturbation of thl / qt is commented out, :1532)
-  namelist /ORACLE/ nsub, nspin, nwarm, dump_at, lforces, scal_a, scal_b, pmode
+  namelist /ORACLE/ nsub, nspin, nwarm, dump_at, lforces, pmode
 
-  call initmpi
   if (command_argument_count() < 3) then
-    write (0, *) 'usage: udales_ref namoptions.NNN {run|kernels|time} out.bin'
+    write (0, *) 'usage: udales_ref namoptions.NNN {run|kernels|time|poisson1|restart} out.bin'
     stop 1
   end if
-  call get_command_argument(1, fname_options)
+  call get_command_argument(1, deckfile)
   call get_command_argument(2, mode)
   call get_command_argument(3, outfile)
 
-  call read_namelists_subset
-  open (ifnamopt, file=fname_options, status='old')
-  read (ifnamopt, ORACLE, iostat=ierr)
-  close (ifnamopt)
-
-  call init_decomp_np1
+  ! ---- src/program.f90:63-124, call for call (execute_runmode_actions, :73, dispatches the in-solver tests: see udales_full)
+  call initmpi
+  call readnamelists
+  call init2decomp
+  call checkinitvalues
   call initglobal
   call initfields
   call initboundary
   call initthermodynamics
   call initsubgrid
+  call initdriver
   call initpois
-#ifdef UDC_DROPIN
-  call readfacetfiles                       ! src/program.f90:91 (the reference's own initfac; returns unless nfcts > 0)
-  call initibm                              ! src/program.f90:93-95
-#else
-  if (libm .and. iwallmom > 1) then         ! src/program.f90:91-93
-    call readfacetfiles
-    call initibm
-  else
-    call ibm_setup
-  end if
-#endif
+  call readfacetfiles
+  call initibm
   call createmasks
-  lstats = ltdump .or. lxytdump .or. lytdump
-  if (lstats) call initstatsdump            ! src/program.f90:110 (here: its last two statements, the clocks)
-  call cold_start
-  call createscals                          ! src/modstartup.f90 (scalarsourcep / scalarsourcel files; no-op without sources)
+  call calcfluidvolumes
+  call readinitfiles
+  call createscals
+  call initchecksim
+  call initstat_nc
+  call initstatsdump
+  call initEB
+  call inittimedep
+  call initfielddump
   call boundary
-  need_thermo = ltempeq .or. lmoist .or. loneeqn .or. lnudge .or. igrw_damp /= 0 .or. any(whls /= 0.) .or. ifixuinf /= 0 .or. ds > 0 &
-                .or. (BCxs /= 1 .and. .not. luvolflowr)      ! the convective outlet's speed comes from diagfld's u0av (src/modboundary.f90:143-156)
-  if (need_thermo) call thermodynamics            ! src/program.f90:120 (thv0h, thvh; dthvdz; diagfld's slab averages)
+  call init_vegetation
+  call createpurifiers
+  call init_heatpump
+
+  open (ifnamopt, file=trim(deckfile), status='old')      ! the driver's own group (every rank reads it)
+  read (ifnamopt, ORACLE, iostat=ierr)
+  close (ifnamopt)
+  lstats = ltdump .or. lxytdump .or. lytdump
 
   iu = 71
   if (trim(mode) /= 'time') then
@@ -289,285 +277,46 @@ contains
     write (tag4, '(a1,i3.3)') 's', i
   end function tag4
 
-  ! ---- src/program.f90:132-222 restricted to the dynamical core
+  ! ---- one pass of src/program.f90:132-222, call for call
   subroutine one_substep
     call tstep_update
+    call timedep
     call advection
-    call shiftedPBCs                        ! src/program.f90:144 (no-op unless ds > 0)
+    call shiftedPBCs
     call subgrid
-    call floor_bottom                       ! src/program.f90:152
-    if (lforces) call coriolis              ! src/program.f90:158 (no-op unless lcoriol / lprofforc)
+    call bottom
+    if (lforces) call coriolis
     if (lforces) call forces
-    if (lforces) call lstend                ! src/program.f90:162 (large-scale subsidence; needs diagfld's slab averages)
-    if (lforces) call nudge                 ! src/program.f90:164
-    call ibmwallfun                         ! src/program.f90:166 (no-op unless libm)
-    call masscorr                           ! src/program.f90:169
-    call ibmnorm                            ! src/program.f90:171 (no-op unless libm)
-    call scalsource                         ! src/program.f90:181 (point / line sources of the scalars; no-op unless lscasrc / lscasrcl)
-    call fixuinf2                           ! src/program.f90:186 (dgdt of the dp/dx ODE; no-op unless ifixuinf = 2)
-    call fixuinf1                           ! src/program.f90:188 (pulls the top-level mean back to Uinf; no-op unless ifixuinf = 1)
-    if (lforces) call grwdamp               ! src/program.f90:191 (sponge layer) (no-op unless luvolflowr / lvvolflowr)
+    if (lforces) call lstend
+    if (lforces) call nudge
+    call ibmwallfun
+    call periodicEBcorr
+    call masscorr
+    call ibmnorm
+    call EB
+    call vegetation_forcing
+    call heatpump
+    call scalsource
+    call fixuinf2
+    call fixuinf1
+    if (lforces) call grwdamp
     call poisson
+    call purifiers
     call tstep_integrate
     call halos
-    if (lstats) then                        ! src/program.f90:205
-      if (rk3step == 3) call host_refresh
-      call statsdump
-    end if
+    call checksim
+    call fielddump
+    if (lstats .and. rk3step == 3) call host_refresh      ! (drop-in build, device resident: statsdump samples host arrays)
+    call statsdump
     call boundary
-    if (need_thermo) call thermodynamics            ! src/program.f90:214
+    call thermodynamics
+    call writerestartfiles
   end subroutine one_substep
 
   subroutine floor_bottom                   ! src/program.f90:152
     call bottom
   end subroutine floor_bottom
 
-#ifndef UDC_DROPIN
-  ! ---- initibm without the facet wall functions (src/modibm.f90:131-193): solid point lists (initibmnorm, the reference's),
-  !      masks (:150-167), fluid-boundary point lists (read as initibmwallfun reads them, :302-306)
-  subroutine ibm_setup
-    use modibmdata, only: bctfxm, bctfxp, bctfym, bctfyp, bctfz, bcqfxm, bcqfxp, bcqfym, bcqfyp, bcqfz
-    real, allocatable :: rhs(:, :, :)
-    integer, allocatable :: ids(:)
-    if (.not. libm) return
-    ! temperature / moisture: wallfunheat (src/modibm.f90:1436) cannot be built here (initfac, NetCDF).  With prescribed wall
-    ! fluxes (iwalltemp = 1, iwallmoist = 1) that are all zero it adds exactly nothing to thlp / qtp (`- flux * area / vol`,
-    ! :1535, :1584), so adiabatic, impermeable walls run on the reference's remaining routines alone.
-    if ((ltempeq .and. (iwalltemp /= 1 .or. any((/bctfxm, bctfxp, bctfym, bctfyp, bctfz/) /= 0.))) .or. &
-        (lmoist .and. (iwallmoist /= 1 .or. any((/bcqfxm, bcqfxp, bcqfym, bcqfyp, bcqfz/) /= 0.)))) then
-      write (0, *) 'ERROR: ref_driver: wall heat / moisture fluxes need wallfunheat (src/modibm.f90:1436), which cannot be built here'
-      stop 1
-    end if
-    solid_info_u%nsolpts = nsolpts_u; solid_info_v%nsolpts = nsolpts_v; solid_info_w%nsolpts = nsolpts_w
-    call initibmnorm('solid_u.txt', solid_info_u)
-    call initibmnorm('solid_v.txt', solid_info_v)
-    call initibmnorm('solid_w.txt', solid_info_w)
-    allocate (mask_u(ib - ih:ie + ih, jb - jh:je + jh, kb - kh:ke + kh)); mask_u = 1.
-    allocate (mask_v(ib - ih:ie + ih, jb - jh:je + jh, kb - kh:ke + kh)); mask_v = 1.
-    allocate (mask_w(ib - ih:ie + ih, jb - jh:je + jh, kb - kh:ke + kh)); mask_w = 1.
-    mask_w(:, :, kb) = 0.
-    mask_u(:, :, kb - kh) = 0.; mask_v(:, :, kb - kh) = 0.; mask_w(:, :, kb - kh) = 0.
-    allocate (rhs(ib - ih:ie + ih, jb - jh:je + jh, kb:ke + kh))
-    call solid(solid_info_u, mask_u, rhs, 0., ih, jh, kh)
-    call solid(solid_info_v, mask_v, rhs, 0., ih, jh, kh)
-    call solid(solid_info_w, mask_w, rhs, 0., ih, jh, kh)
-    call exchange_halo_z(mask_u); call exchange_halo_z(mask_v); call exchange_halo_z(mask_w)
-    bound_info_u%nbndpts = nbndpts_u; bound_info_v%nbndpts = nbndpts_v; bound_info_w%nbndpts = nbndpts_w
-    call read_sparse_ijk('fluid_boundary_u.txt', nbndpts_u, bound_info_u%nbndptsrank, ids, bound_info_u%bndpts_loc, nskip=1)
-    call read_sparse_ijk('fluid_boundary_v.txt', nbndpts_v, bound_info_v%nbndptsrank, ids, bound_info_v%bndpts_loc, nskip=1)
-    call read_sparse_ijk('fluid_boundary_w.txt', nbndpts_w, bound_info_w%nbndptsrank, ids, bound_info_w%bndpts_loc, nskip=1)
-    if (nsv > 0 .or. ltempeq .or. lmoist) then           ! :180
-      solid_info_c%nsolpts = nsolpts_c
-      call initibmnorm('solid_c.txt', solid_info_c)
-      bound_info_c%nbndpts = nbndpts_c
-      call read_sparse_ijk('fluid_boundary_c.txt', nbndpts_c, bound_info_c%nbndptsrank, ids, bound_info_c%bndpts_loc, nskip=1)
-      allocate (mask_c(ib - ih:ie + ih, jb - jh:je + jh, kb - kh:ke + kh)); mask_c = 1.
-      mask_c(:, :, kb - kh) = 0.
-      call solid(solid_info_c, mask_c, rhs, 0., ih, jh, kh)
-      call exchange_halo_z(mask_c)
-    end if
-    deallocate (rhs)
-  end subroutine ibm_setup
-
-  ! ---- ibmwallfun: with facet wall functions (iwallmom > 1) the reference's own routine; without them (iwallmom = 1) its
-  !      dispatch restated (src/modibm.f90:1216-1218, 1262-1264)
-  subroutine ibmwallfun
-    integer :: n
-    if (.not. libm) return
-    if (iwallmom > 1) then
-      call ref_ibmwallfun
-      return
-    end if
-    call diffu_corr
-    call diffv_corr
-    call diffw_corr
-    ! (:1227-1231: wallfunheat here -- a no-op for the zero prescribed fluxes ibm_setup insists on)
-    if (ltempeq) call diffc_corr(thl0, thlp, ih, jh, kh)      ! :1232
-    if (lmoist) call diffc_corr(qt0, qtp, ih, jh, kh)         ! :1233
-    do n = 1, nsv
-      call diffc_corr(sv0(:, :, :, n), svp(:, :, :, n), ihc, jhc, khc)
-    end do
-  end subroutine ibmwallfun
-#endif
-
-  ! ---- subset of src/modstartup.f90:105-172 (same group and variable names)
-  subroutine read_namelists_subset
-    use modfields, only: dpdx
-    use modglobal, only: rv_g => rv, rd_g => rd
-    use modibmdata, only: bctfxm, bctfxp, bctfym, bctfyp, bctfz, bcqfxm, bcqfxp, bcqfym, bcqfyp, bcqfz
-    integer :: ierr
-    namelist /RUN/ iexpnr, runtime, dtmax, trestart, ladaptive, irandom, randu, randthl, randqt, krand, courant, diffnr, &
-      libm, lles, lrandomize, nprocx, nprocy
-    namelist /DOMAIN/ itot, jtot, ktot, xlen, ylen, xlat, ksp
-    namelist /PHYSICS/ ps, lmoist, lcoriol, lbuoyancy, ltempeq, lprofforc, dpdx, luvolflowr, uflowrate, &
-      lvvolflowr, vflowrate, igrw_damp, geodamptime, lnudge, lnudgevel, tnudge, nnudge, ifixuinf, lvinf, tscale, lconservativeibm
-    namelist /INLET/ Uinf, Vinf, inletav
-    namelist /CHEMISTRY/ lchem, k1, JNO2
-    namelist /DYNAMICS/ lqlnr, ipoiss, iadv_mom, iadv_tke, iadv_thl, iadv_qt, iadv_sv
-    namelist /BC/ BCxs, BCxm, BCym, BCtopm, BCtopT, BCtops, BCbotm, BCbots, BCbotT, BCzp, wttop, thl_top, z0, wtsurf, thls, qts, &
-      BCtopq, BCbotq, wqtop, qt_top, wqsurf, z0h, wsvtopdum, ds, bctfxm, bctfxp, bctfym, bctfyp, bctfz, &
-      bcqfxm, bcqfxp, bcqfym, bcqfyp, bcqfz
-    namelist /SCALARS/ nsv, lscasrc, nscasrc, lscasrcl, nscasrcl
-    namelist /OUTPUT/ lytdump, ltdump, lxytdump, tsample, tstatsdump, tstatstart, lfielddump, tfielddump, fieldvars      ! (the field dump itself is not run here)
-    namelist /WALLS/ nfcts, lbottom, iwallmom, iwalltemp, iwallmoist, nsolpts_u, nsolpts_v, nsolpts_w, nsolpts_c, &
-      nbndpts_u, nbndpts_v, nbndpts_w, nbndpts_c, nfctsecs_u, nfctsecs_v, nfctsecs_w, nfctsecs_c, lnorec
-    open (ifnamopt, file=fname_options, status='old', iostat=ierr)
-    if (ierr /= 0) then
-      write (0, *) 'ERROR: cannot open ', trim(fname_options)
-      stop 1
-    end if
-    read (ifnamopt, RUN, iostat=ierr); call chk(ierr, 'RUN'); rewind (ifnamopt)
-    read (ifnamopt, DOMAIN, iostat=ierr); call chk(ierr, 'DOMAIN'); rewind (ifnamopt)
-    read (ifnamopt, PHYSICS, iostat=ierr); call chk(ierr, 'PHYSICS'); rewind (ifnamopt)
-    read (ifnamopt, DYNAMICS, iostat=ierr); call chk(ierr, 'DYNAMICS'); rewind (ifnamopt)
-    read (ifnamopt, BC, iostat=ierr); call chk(ierr, 'BC'); rewind (ifnamopt)
-    read (ifnamopt, SCALARS, iostat=ierr); call chk(ierr, 'SCALARS'); rewind (ifnamopt)
-    read (ifnamopt, INLET, iostat=ierr); call chk(ierr, 'INLET'); rewind (ifnamopt)     ! (absent group: iostat < 0)
-    read (ifnamopt, CHEMISTRY, iostat=ierr); call chk(ierr, 'CHEMISTRY'); rewind (ifnamopt)
-    read (ifnamopt, WALLS, iostat=ierr); call chk(ierr, 'WALLS'); rewind (ifnamopt)
-    read (ifnamopt, OUTPUT, iostat=ierr); call chk(ierr, 'OUTPUT')
-    close (ifnamopt)
-    nprocx = 1; nprocy = nprocs     ! y-slabs over however many ranks were launched (1 in the np1 build)
-    allocate (wsvtop(1:max(nsv, 1))); wsvtop = 0.      ! src/modstartup.f90:518-519
-    if (nsv > 0) wsvtop(1:nsv) = wsvtopdum(1:nsv)
-    allocate (sv_top(1:max(nsv, 1))); sv_top = 0.
-    thvs = thls*(1.+(rv_g/rd_g - 1.)*qts)                  ! src/modstartup.f90:522
-    write (cexpnr, '(i3.3)') iexpnr
-  end subroutine read_namelists_subset
-
-  subroutine chk(ierr, grp)
-    integer, intent(in) :: ierr
-    character(*), intent(in) :: grp
-    if (ierr > 0) then
-      write (0, *) 'ERROR: problem in namoptions group ', grp, ' iostat=', ierr
-      stop 1
-    end if
-  end subroutine chk
-
-  ! ---- src/modstartup.f90:652-691 (nprocx = 1; nprocy = number of ranks)
-  subroutine init_decomp_np1
-    logical :: periodic_bc(3)
-    periodic_bc = .false.
-    periodic_bc(2) = (BCym == BCym_periodic) .and. (nprocy > 1)
-    call decomp_2d_init(itot, jtot, ktot, nprocx, nprocy, periodic_bc)
-    comm3d = DECOMP_2D_COMM_CART_Z
-    myidx = 0; myidy = mycol
-    write (cmyidx, '(i3.3)') myidx
-    write (cmyidy, '(i3.3)') myidy
-  end subroutine init_decomp_np1
-
-  ! ---- src/modstartup.f90:1088-1290 and :2051-2092 (cold start, neutral subset)
-  subroutine cold_start
-    use modfields, only: dpdx
-    real, allocatable :: height(:)
-    character(80) :: chmess
-    integer :: i, j, k, n
-    real :: zsize_
-    allocate (height(kb:ke + kh))
-    dt = dtmax/100.
-    timee = 0.
-    open (ifinput, file='prof.inp.'//cexpnr)
-    read (ifinput, '(a80)') chmess
-    read (ifinput, '(a80)') chmess
-    do k = kb, ke
-      read (ifinput, *) height(k), thlprof(k), qtprof(k), uprof(k), vprof(k), e12prof(k)
-    end do
-    close (ifinput)
-    do k = kb, ke
-      do j = jb - 1, je + 1
-        do i = ib - 1, ie + 1
-          thl0(i, j, k) = thlprof(k); thlm(i, j, k) = thlprof(k)
-          qt0(i, j, k) = qtprof(k); qtm(i, j, k) = qtprof(k)
-          u0(i, j, k) = uprof(k); um(i, j, k) = uprof(k)
-          v0(i, j, k) = vprof(k); vm(i, j, k) = vprof(k)
-          w0(i, j, k) = 0.0; wm(i, j, k) = 0.0
-          e120(i, j, k) = e12prof(k); e12m(i, j, k) = e12prof(k)
-          ekm(i, j, k) = numol
-          ekh(i, j, k) = numol
-        end do
-      end do
-    end do
-    do k = kb, ke
-      do j = jb - jhc, je + jhc
-        do i = ib - ihc, ie + ihc
-          thl0c(i, j, k) = thlprof(k)
-        end do
-      end do
-    end do
-    ekh(:, :, ke + 1) = ekh(:, :, ke)
-    do j = jb - jh, je + jh
-      do i = ib - ih, ie + ih
-        thl0(i, j, ke + 1) = thl0(i, j, ke)
-        thl0(i, j, kb - 1) = thl0(i, j, kb)
-      end do
-    end do
-    if (lrandomize) then
-      krand = min(krand, ke)
-      do k = kb, krand
-        call randomize_field(um, k, randu, irandom, ih, jh)
-      end do
-      do k = kb, krand
-        call randomize_field(vm, k, randu, irandom, ih, jh)
-      end do
-      do k = kb, krand
-        call randomize_field(wm, k, randu, irandom, ih, jh)
-      end do
-    end if
-    u0 = um; v0 = vm; w0 = wm
-    block      ! src/modstartup.f90:1336-1341: the outflow speed of the convective outlet under luvolflowr (src/modboundary.f90:159)
-      use modinletdata, only: ubulk
-      ubulk = sum(uprof(kb:ke)*dzf(kb:ke))/(zh(ke + 1) - zh(kb))
-    end block
-    ! passive scalars (stand-in for scalar.inp, src/modstartup.f90:1541-1560): linear profile
-    zsize_ = zh(ke + 1)
-    do n = 1, nsv
-      do k = kb, ke
-        svprof(k, n) = scal_b + scal_a*real(n)*zf(k)/zsize_      ! nudge relaxes towards it (src/modforces.f90:840-844)
-        sv0(:, :, k, n) = svprof(k, n)                            ! src/modstartup.f90:1561-1570
-      end do
-      sv0(:, :, kb - 1, n) = sv0(:, :, kb, n)
-      sv0(:, :, kb - 2, n) = sv0(:, :, kb, n)
-      svm(:, :, :, n) = sv0(:, :, :, n)
-    end do
-    if (nsv > 0) sv_top(1:nsv) = svprof(ke, 1:nsv)        ! src/modstartup.f90:1573-1574
-    call halos
-    uinit = um; vinit = vm
-    dt = dtmax/100.                         ! src/modstartup.f90:1099
-    if (.not. ladaptive) dt = dtmax         ! src/modstartup.f90:2038
-
-    open (ifinput, file='lscale.inp.'//cexpnr)
-    read (ifinput, '(a80)') chmess
-    read (ifinput, '(a80)') chmess
-    do k = kb, ke
-      read (ifinput, *) height(k), ug(k), vg(k), pgx(k), pgy(k), wfls(k), &
-        dqtdxls(k), dqtdyls(k), dqtdtls(k), thlpcar(k)
-    end do
-    close (ifinput)
-    whls(kb) = 0.0                          ! src/modstartup.f90:2125-2129
-    do k = kb + 1, ke
-      whls(k) = (wfls(k)*dzf(k - 1) + wfls(k - 1)*dzf(k))/(2*dzh(k))
-    end do
-    whls(ke + 1) = (wfls(ke) + dzf(ke)*(wfls(ke) - wfls(ke - 1))/dzh(ke))
-    if (lprofforc) then
-      do k = kb, ke
-        dpdxl(k) = -pgx(k) - dpdx
-        dpdyl(k) = -pgy(k)
-      end do
-    else
-      do k = kb, ke
-        dpdxl(k) = om23_gs*vg(k) - pgx(k) - dpdx
-        dpdyl(k) = -om23_gs*ug(k) - pgy(k)
-      end do
-    end if
-    btime = timee
-    timeleft = runtime
-    dt_lim = timeleft
-    ntrun = 0
-    ntimee = nint(timee/dtmax)
-    deallocate (height)
-  end subroutine cold_start
-
-  ! ---- src/modstartup.f90:2367-2396 (deterministic LCG keyed on the global index)
   ! ------------------------------------------------------------ dump helpers
   subroutine put3(name, a, lb)
     character(*), intent(in) :: name

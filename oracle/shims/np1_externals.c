@@ -52,6 +52,17 @@ void mpi_send_(void) { p2p_unavailable("MPI_SEND"); }
 void mpi_recv_(void) { p2p_unavailable("MPI_RECV"); }
 void mpi_sendrecv_(void) { p2p_unavailable("MPI_SENDRECV"); }
 void mpi_wait_(void) { p2p_unavailable("MPI_WAIT"); }
+/* the whole-tree build: src/modstartup.f90:681-688 asks for this rank's coordinates and neighbours in the (1 x 1) grid; with one
+   rank in a direction 2DECOMP's grid is not periodic there (:662-672), so both neighbours are MPI_PROC_NULL (-2, mpi_np1.f90) */
+void mpi_cart_coords_(int *comm, int *rank, int *maxdims, int *coords, int *ierr) {
+  (void)comm; (void)rank;
+  for (int i = 0; i < *maxdims; i++) coords[i] = 0;
+  *ierr = 0;
+}
+void mpi_cart_shift_(int *comm, int *dir, int *disp, int *src, int *dst, int *ierr) {
+  (void)comm; (void)dir; (void)disp;
+  *src = -2; *dst = -2; *ierr = 0;
+}
 double mpi_wtime_(void) {
   struct timespec ts;
   clock_gettime(CLOCK_MONOTONIC, &ts);

@@ -78,3 +78,41 @@ def write_dump(path, fields: dict):
         bio.write(np.ascontiguousarray(f.data, dtype="<f8").tobytes())
     with open(path, "wb") as fh:
         fh.write(bio.getvalue())
+
+
+def read_ncrec(path, want=None) -> dict:
+    """Reader for what the reference's output modules leave behind when they are linked against the NetCDF stand-in of the
+    oracle builds (oracle/shims/netcdf_rec_io.c): {variable name: list of (start, array)} in the order written; arrays come
+    back [..., j, i]-ordered (the Fortran shape reversed).  `want`: only these variable names (the 3-D dumps are large)."""
+    out, names = {}, {}
+    with open(path, "rb") as f:
+        buf = f.read()
+    pos, n = 0, len(buf)
+    while pos < n:
+        assert buf[pos:pos + 4] == b"UDNC", pos
+        kind, = struct.unpack_from("<i", buf, pos + 4)
+        pos += 8
+        if kind == 1:
+            _, _, ln = struct.unpack_from("<3i", buf, pos)
+            pos += 12 + ln
+        elif kind == 2:
+            vid, _, nd = struct.unpack_from("<3i", buf, pos)
+            pos += 12 + 4 * nd
+            ln, = struct.unpack_from("<i", buf, pos)
+            names[vid] = buf[pos + 4:pos + 4 + ln].decode()
+            pos += 4 + ln
+        else:
+            vid, ns = struct.unpack_from("<2i", buf, pos)
+            pos += 8
+            start = struct.unpack_from(f"<{ns}i", buf, pos)
+            pos += 4 * ns
+            rank, = struct.unpack_from("<i", buf, pos)
+            pos += 4
+            shp = struct.unpack_from(f"<{rank}i", buf, pos)
+            pos += 4 * rank
+            cnt = int(np.prod(shp)) if rank else 1
+            if want is None or names[vid] in want:
+                a = np.frombuffer(buf, dtype="<f8", count=cnt, offset=pos).reshape(tuple(reversed(shp)))
+                out.setdefault(names[vid], []).append((start, a.copy()))
+            pos += 8 * cnt
+    return out

@@ -1,0 +1,105 @@
+"""The drop-in boundary under the reference's REAL program.
+
+oracle/_ref/udales_full_dropin is what INTEGRATION.md section 1 prescribes, carried out: every file of the reference's src/ --
+program.f90, modstartup.f90, tests.f90, the statistics / output modules, unmodified, compiled where they lie -- except the eight
+modules u-dales_amd/fortran/ replaces, linked against libudcore (u-dales_amd/fortran/Makefile).  Same command line as the
+reference's executable: `udales_full_dropin namoptions.NNN`.  Its counterpart oracle/_ref/udales_full is the same build with the
+reference's own eight modules; the fixtures come from that one (tests/test_full_reference.py pins them on it bit for bit).
+
+Here: every run deck of the golden set and the reference's examples/999 through the real program on the device, device resident
+(UDC_RESIDENCY=2: the routines record, tstep_integrate launches the fused substep) and with every call carrying its fields
+(UDC_RESIDENCY=0), compared through what the program itself writes -- the restart files of the reference's writerestartfiles, the
+monitor file, xytdump as handed to NetCDF."""
+import gzip
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from common import GOLDEN, RUN_CASES, STARTUP_TRANSIENT_TOL, load_fixture, nocorner, relerr
+from refdump import read_ncrec
+from test_full_reference import run_full
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DROPIN = os.path.join(ROOT, "oracle", "_ref", "udales_full_dropin")
+
+
+@pytest.mark.parametrize("residency", [2, 0])
+@pytest.mark.parametrize("name,iexp", sorted(RUN_CASES.items()))
+def test_run_decks_through_the_reference_program(name, iexp, residency, tmp_path):
+    if not os.path.exists(DROPIN):
+        pytest.skip("oracle/_ref/udales_full_dropin not built (needs the reference sources + flang)")
+    if residency == 0 and name not in ("run_16x16x8", "run_ibm_wf2_16x12x10", "run_moist_16x8x12s", "run_stats_16x8x12s", "run_bcxs_16x8x12s"):
+        pytest.skip("strict residency: a selection of decks")
+    env = dict(os.environ, UDC_RESIDENCY=str(residency), UDC_PULL_EVERY="1")
+    fix, last, rs, _ = run_full(name, iexp, tmp_path, exe=DROPIN, env=env)
+    nz = int(fix["meta"].data[2])
+    tol = STARTUP_TRANSIENT_TOL.get(name, 1e-9)
+    if last + ".time" in fix:
+        np.testing.assert_allclose((rs["timee"], rs["dt"]), fix[last + ".time"].data, rtol=1e-10)
+    checked = 0
+    for k in ("u0", "v0", "w0", "pres0", "thl0", "qt0"):
+        key = f"{last}.{k}"
+        if key not in fix:
+            continue
+        a, b = rs[k][1:nz + 1], fix[key].data[1:nz + 1]
+        assert relerr(nocorner(a), nocorner(b), 1.0 if k == "thl0" else None) <= tol, key
+        checked += 1
+    for n in range(int(fix["meta"].data[12])):
+        b = fix[f"{last}.sv0_{n + 1:02d}"].data[2:nz + 2, 2:-2, 2:-2]
+        assert relerr(rs["sv0"][n][1:nz + 1, 1:-1, 1:-1], b) <= tol, n
+        checked += 1
+    assert checked >= 4
+
+
+def test_example_999_through_the_reference_program(tmp_path):
+    """examples/999 of the reference (128^3, adaptive time step, tdump + xytdump + fielddump) as a user runs it -- the deck, prof.inp,
+    lscale.inp, one rank -- under the untouched program.f90 with the drop-in modules, device resident.  Golden: the same through the
+    all-reference executable (tests/golden/make_golden.py, make_full_example): the clock after each of the 15 steps, the first
+    xytdump record, the restart file (slab means, rms and every 8th point of u0, v0, w0, pres0)."""
+    from udcore import restart
+    if not os.path.exists(DROPIN):
+        pytest.skip("oracle/_ref/udales_full_dropin not built")
+    fix = load_fixture("full_example_999")
+    cdir = os.path.join(GOLDEN, "cases", "example_999")
+    for fn in os.listdir(cdir):
+        with gzip.open(os.path.join(cdir, fn), "rb") as f, open(tmp_path / fn[:-3], "wb") as o:
+            o.write(f.read())
+    deck = tmp_path / "namoptions.999"
+    txt = deck.read_text()
+    txt = re.sub(r"nprocx\s*=\s*\d+", "nprocx = 1", re.sub(r"nprocy\s*=\s*\d+", "nprocy = 1", txt))
+    txt = re.sub(r"runtime\s*=\s*[0-9.]+", "runtime = 11.", re.sub(r"trestart\s*=\s*[0-9.]+", "trestart = 10.9", txt))
+    deck.write_text(txt)
+    env = dict(os.environ, UDC_RESIDENCY="2", UDC_PULL_EVERY="1")
+    r = subprocess.run(f"ulimit -s unlimited; exec {DROPIN} namoptions.999", shell=True, cwd=tmp_path, capture_output=True, text=True,
+                       timeout=1500, executable="/bin/bash", env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    mon = np.loadtxt(tmp_path / "monitor000.txt")
+    ref = fix["monitor"].data
+    assert len(mon) == len(ref) == 15
+    np.testing.assert_allclose(mon, ref, rtol=2e-6)            # (the monitor file holds six digits)
+    rec = read_ncrec(str(tmp_path / "xytdump.999.nc"))
+    checked = 0
+    for k, f in fix.items():
+        if not k.startswith("xyt.") or k == "xyt.time":
+            continue
+        name = [n for n in rec if n[:11] == k[4:]]
+        assert len(name) == 1, k
+        got = rec[name[0]][0][1]
+        sc = max(np.abs(f.data).max(), 1e-3 if "p" in k[4:8] else 1e-6)
+        assert np.abs(got - f.data).max() <= 1e-8 * sc, (k, np.abs(got - f.data).max(), sc)
+        checked += 1
+    assert checked >= 20
+    rst = [f for f in os.listdir(tmp_path) if f.startswith("initd")]
+    assert len(rst) == 1 and float(rst[0][5:13]) == fix["rst.time"].data[2]
+    rs = restart.read_initd(str(tmp_path / rst[0]), 128, 128, 128)
+    np.testing.assert_allclose((rs["timee"], rs["dt"]), fix["rst.time"].data[:2], rtol=1e-9)
+    for k in ("u0", "v0", "w0", "pres0"):
+        a = rs[k][1:129, 1:129, 1:129]
+        sc = np.abs(fix[f"rst.{k}.pts"].data).max()
+        assert np.abs(a[::8, ::8, ::8] - fix[f"rst.{k}.pts"].data).max() <= 1e-8 * sc, k
+        assert np.abs(a.mean(axis=(1, 2)) - fix[f"rst.{k}.mean"].data).max() <= 1e-9 * sc, k
+        assert np.abs(np.sqrt((a ** 2).mean(axis=(1, 2))) - fix[f"rst.{k}.rms"].data).max() <= 1e-9 * sc, k

@@ -49,9 +49,12 @@ def test_ibm_routines_match_reference(name, iexp):
     for n in range(nsv):
         core.upload(L.scalar_field(L.SVP, n), carr(fix, f"ibw0.svp_{n + 1:02d}", nz))
     core.ibmwallfun()
+    wf = int(d.get("WALLS", "iwallmom")) > 1
     for t in ("up", "vp", "wp"):
         ref, before = marr(fix, f"ibw.{t}", nz), marr(fix, f"ibw0.{t}", nz)
-        assert np.abs(ref - before).max() > 1e-9
+        # without wall functions (iwallmom = 1) the reference never reads the velocity grids' fluid-boundary points
+        # (src/modibm.f90:166-179): diffu/v/w_corr change nothing, here as there
+        assert (np.abs(ref - before).max() > 1e-9) == wf
         assert relerr(interior(core.download(t)), interior(ref)) <= 1e-12, t
     for n in range(nsv):
         got = core.download(L.scalar_field(L.SVP, n), halo=2)

@@ -21,13 +21,23 @@ MPIEXEC = "/opt/conda/bin/mpiexec"
 
 
 def run(cmd, cwd):
-    r = subprocess.run(f"ulimit -s unlimited; exec {cmd}", shell=True, cwd=cwd, capture_output=True, text=True,
+    # (output files of an earlier run in the directory: the NetCDF stand-in of these builds cannot append to them)
+    r = subprocess.run(f"ulimit -s unlimited; rm -f *.nc; exec {cmd}", shell=True, cwd=cwd, capture_output=True, text=True,
                        timeout=300, executable="/bin/bash")
     m = re.search(r"sum_u0sq=\s*([0-9.Ee+-]+)\s+divmax=\s*([0-9.Ee+-]+)", r.stdout)
     assert m, r.stdout[-1000:] + r.stderr[-1000:]
     s = re.search(r"REF_SUMSQ\s+(.*)", r.stdout)
     sums = [float(x) for x in s.group(1).split()] if s else []
     return float(m.group(1)), float(m.group(2)), sums
+
+
+def set_ranks(deck_path, p):
+    """the reference reads its process grid from the deck (&RUN nprocx, nprocy, src/modstartup.f90:105-117): y-slabs over p ranks"""
+    with open(deck_path) as f:
+        txt = f.read()
+    txt = re.sub(r"nprocy\s*=\s*\d+", f"nprocy = {p}", txt)
+    with open(deck_path, "w") as f:
+        f.write(txt)
 
 
 def _have():
@@ -43,6 +53,7 @@ def test_mpi_baseline_is_decomposition_invariant(tmp_path):
     deck = f"namoptions.{iexp:03d}"
     s1, d1, _ = run(f"{REF} {deck} time x.bin", tmp_path)
     for p in (2, 4, 8):
+        set_ranks(os.path.join(tmp_path, deck), p)
         sp, dp, _ = run(f"{MPIEXEC} -n {p} {REF_MPI} {deck} time x.bin", tmp_path)
         assert abs(sp - s1) <= 1e-11 * abs(s1), (p, sp, s1)
         assert dp < 1e-12
@@ -71,6 +82,7 @@ def test_single_rank_and_multi_rank_shims_agree(name, iexp, tmp_path):
     for p in (2, 4):
         if jtot % p or ktot % p or jtot // p < 2:
             continue
+        set_ranks(os.path.join(tmp_path, deck), p)
         sp, dp, qp = run(f"{MPIEXEC} -n {p} {REF_MPI} {deck} time x.bin", tmp_path)
         assert abs(sp - s1) <= 1e-11 * abs(s1), (p, sp, s1)
         for a, b in zip(qp, q1):

@@ -36,6 +36,26 @@ module modibm
   ! this rank's solid points (local indices), kept for createmasks
   integer, allocatable :: sol_u(:, :), sol_v(:, :), sol_w(:, :), sol_c(:, :)
 
+  ! The reference's modibm has no `private` (src/modibm.f90:24-34), and its in-solver self test reads the point tables of
+  ! initibm through these two types (src/tests.f90:50-54, 139, 177: this rank's count, file indices and local i, j, k).  Kept
+  ! with the reference's component names for the parts that exist here; the device holds the working copies.
+  type solid_info_type
+    integer :: nsolpts = 0
+    integer, allocatable :: solpts(:, :)          ! (nsolpts, 3): global i, j, k as read
+    integer, allocatable :: solptsrank(:)         ! file indices of the points on this rank
+    integer :: nsolptsrank = 0
+    integer, allocatable :: solpts_loc(:, :)      ! (nsolptsrank, 3): local i, j, k
+  end type solid_info_type
+  type bound_info_type
+    integer :: nbndpts = 0
+    integer, allocatable :: bndpts(:, :)
+    integer, allocatable :: bndptsrank(:)
+    integer :: nbndptsrank = 0
+    integer, allocatable :: bndpts_loc(:, :)
+  end type bound_info_type
+  type(solid_info_type) :: solid_info_u, solid_info_v, solid_info_w, solid_info_c
+  type(bound_info_type) :: bound_info_u, bound_info_v, bound_info_w, bound_info_c
+
   type ibm_lists
     integer(c_int), allocatable :: sol(:, :), bnd(:, :)      ! (3, n): global i, j, k as in the input files
     logical :: given = .false.
@@ -94,21 +114,23 @@ contains
     need_c = nsv > 0 .or. ltempeq .or. lmoist          ! src/modibm.f90:180
     mask_w(:, :, kb) = 0.                     ! src/modibm.f90:154-157
     mask_u(:, :, kb - kh) = 0.; mask_v(:, :, kb - kh) = 0.; mask_w(:, :, kb - kh) = 0.; mask_c(:, :, kb - kh) = 0.
-    call grid_lists(0, 'solid_u.txt', nsolpts_u, 'fluid_boundary_u.txt', nbndpts_u, mask_u, sol_u)
-    call grid_lists(1, 'solid_v.txt', nsolpts_v, 'fluid_boundary_v.txt', nbndpts_v, mask_v, sol_v)
-    call grid_lists(2, 'solid_w.txt', nsolpts_w, 'fluid_boundary_w.txt', nbndpts_w, mask_w, sol_w)
-    if (need_c) call grid_lists(3, 'solid_c.txt', nsolpts_c, 'fluid_boundary_c.txt', nbndpts_c, mask_c, sol_c)
+    call grid_lists(0, 'solid_u.txt', nsolpts_u, 'fluid_boundary_u.txt', nbndpts_u, mask_u, sol_u, solid_info_u, bound_info_u)
+    call grid_lists(1, 'solid_v.txt', nsolpts_v, 'fluid_boundary_v.txt', nbndpts_v, mask_v, sol_v, solid_info_v, bound_info_v)
+    call grid_lists(2, 'solid_w.txt', nsolpts_w, 'fluid_boundary_w.txt', nbndpts_w, mask_w, sol_w, solid_info_w, bound_info_w)
+    if (need_c) call grid_lists(3, 'solid_c.txt', nsolpts_c, 'fluid_boundary_c.txt', nbndpts_c, mask_c, sol_c, solid_info_c, bound_info_c)
     ibm_pending = .true.
   end subroutine initibm
 
   !> one grid: read both lists (read_sparse_ijk: this rank's points with local indices + the global list), zero the real
   !! mask at this rank's solid points, keep the global lists for the device (udc_ensure runs after all init* routines)
-  subroutine grid_lists(grid, fsol, nsol, fbnd, nbnd, mask, sol_loc)
+  subroutine grid_lists(grid, fsol, nsol, fbnd, nbnd, mask, sol_loc, sinfo, binfo)
     use readinput, only: read_sparse_ijk
     integer, intent(in) :: grid, nsol, nbnd
     character(*), intent(in) :: fsol, fbnd
     real, intent(inout) :: mask(:, :, :)
     integer, allocatable, intent(out) :: sol_loc(:, :)
+    type(solid_info_type), intent(out) :: sinfo
+    type(bound_info_type), intent(out) :: binfo
     integer, allocatable :: ids(:), loc(:, :), glob(:, :)
     integer :: n, nloc, lb(3)
     call read_sparse_ijk(fsol, nsol, nloc, ids, sol_loc, nskip=1, pts_glob_out=glob)
@@ -118,11 +140,15 @@ contains
     end do
     allocate (lists(grid)%sol(3, nsol))
     lists(grid)%sol = transpose(glob)
+    sinfo%nsolpts = nsol; sinfo%nsolptsrank = nloc
+    sinfo%solpts = glob; sinfo%solptsrank = ids; sinfo%solpts_loc = sol_loc
     deallocate (glob, ids)
     call read_sparse_ijk(fbnd, nbnd, nloc, ids, loc, nskip=1, pts_glob_out=glob)
     allocate (lists(grid)%bnd(3, nbnd))
     lists(grid)%bnd = transpose(glob)
     lists(grid)%given = .true.
+    binfo%nbndpts = nbnd; binfo%nbndptsrank = nloc
+    binfo%bndpts = glob; binfo%bndptsrank = ids; binfo%bndpts_loc = loc
   contains
     function lbound_of_mask() result(l)
       use modglobal, only: ib, ih, jb, jh, kb, kh
@@ -135,8 +161,8 @@ contains
   subroutine ibm_to_device
     use udc_iface
     use modmpi, only : nprocx, nprocy
-    use modglobal, only : lconservativeibm
-    integer :: q
+    use modglobal, only : lconservativeibm, iwallmom
+    integer :: q, nbnd
     integer(c_int) :: none(3)
     if (.not. ibm_pending) return
     call udc_ensure
@@ -148,8 +174,12 @@ contains
     call udc_check(udc_set_ibm_conservative(udc_h, merge(1_c_int, 0_c_int, lconservativeibm)), 'udc_set_ibm_conservative')
     do q = 0, 3
       if (lists(q)%given) then
+        ! without wall functions the reference never reads the fluid-boundary points of the velocity grids (initibmwallfun for
+        ! u, v, w sits under `iwallmom > 1`, src/modibm.f90:166-179): diffu/v/w_corr then loop over no points
+        nbnd = size(lists(q)%bnd, 2)
+        if (iwallmom == 1 .and. q < 3) nbnd = 0
         call udc_check(udc_set_ibm_points(udc_h, int(q, c_int), lists(q)%sol, int(size(lists(q)%sol, 2), c_int), &
-                                          lists(q)%bnd, int(size(lists(q)%bnd, 2), c_int)), 'udc_set_ibm_points')
+                                          lists(q)%bnd, int(nbnd, c_int)), 'udc_set_ibm_points')
       end if
     end do
     call udc_check(udc_ibm_commit(udc_h), 'udc_ibm_commit')

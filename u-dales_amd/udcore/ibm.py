@@ -3,7 +3,7 @@
 The reference's preprocessing writes, per grid g in u, v, w, c, ``solid_g.txt`` and ``fluid_boundary_g.txt`` (one header line,
 then rows of global 1-based ``i j k``) and the counts into &WALLS (nsolpts_g, nbndpts_g); initibm reads them with
 read_sparse_ijk (src/modibm.f90:131-186, src/readinput.f90:31-130).  This slice has the corrections that need no facet
-data: iwallmom = 1 (no wall functions), no thl / qt.
+data, and the hand-over of the facet section tables (udcore/facets.py) for the wall functions.
 """
 from __future__ import annotations
 
@@ -29,10 +29,16 @@ def read_ibm(deck):
     base = os.path.dirname(os.path.abspath(deck.path))
     out = {}
     need_c = int(deck.get("SCALARS", "nsv")) > 0 or bool(deck.get("PHYSICS", "ltempeq")) or bool(deck.get("PHYSICS", "lmoist"))
+    iwallmom = int(deck.get("WALLS", "iwallmom"))
     for g in GRIDS:
         if g == "c" and not need_c:
             continue
         ns, nb = int(deck.get("WALLS", f"nsolpts_{g}")), int(deck.get("WALLS", f"nbndpts_{g}"))
+        if g != "c" and iwallmom == 1:
+            # without wall functions initibm never reads the fluid-boundary points of the velocity grids (src/modibm.f90:166-179:
+            # initibmwallfun for u, v, w sits under `iwallmom > 1`), so ibmwallfun's diffu/v/w_corr loop over no points: the
+            # subgrid fluxes through solid faces stay in the momentum tendencies.  The c grid's list is read whatever iwallmom (:180-186).
+            nb = 0
         out[g] = (read_points(os.path.join(base, f"solid_{g}.txt"), ns), read_points(os.path.join(base, f"fluid_boundary_{g}.txt"), nb))
     return out
 

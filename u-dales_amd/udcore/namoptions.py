@@ -35,13 +35,14 @@ DEFAULTS = {
                    lkslicedump=False, lislicedump=False, ljslicedump=False),
     "WALLS": dict(nfcts=-1, lbottom=False, iwallmom=2, iwalltemp=1, iwallmoist=1, nsolpts_u=0, nsolpts_v=0, nsolpts_w=0, nsolpts_c=0,
                   nbndpts_u=0, nbndpts_v=0, nbndpts_w=0, nbndpts_c=0),
-    "ORACLE": dict(nsub=3, nspin=2, lforces=True, scal_a=1.0, scal_b=0.0),
+    "ORACLE": dict(nsub=3, nspin=2, lforces=True, scal_a=1.0, scal_b=0.0),      # (scal_a, scal_b: the linear stand-in profile of decks without a scalar.inp)
 }
 GEODAMPTIME = 7200.      # src/modglobal.f90 (not a namelist variable)
 
 # Every variable the reference's readnamelists accepts, per group (src/modstartup.f90:105-172, src/modsubgrid.f90:89-90).
 # A deck that sets a name outside its group's list would stop the reference ("Problem in namoptions"): read_deck does
-# the same.  wqtop (&BC) is an extension of the repo's test driver (oracle/ref_driver.f90); &ORACLE is that driver's own.
+# the same.  (wqtop, the top moisture flux, is in no namelist of the reference: it stays at its default.)  &ORACLE is the test
+# driver's own group (oracle/ref_driver.f90); the reference's reader never looks at it.
 KNOWN = {
     "RUN": "iexpnr lwarmstart lstratstart startfile runmode runtime dtmax trestart ladaptive irandom randu randthl randqt krand "
            "courant diffnr author libm lles lper2inout lwalldist lreadmean nprocx nprocy lrandomize",
@@ -52,7 +53,7 @@ KNOWN = {
     "DYNAMICS": "lqlnr ipoiss iadv_mom iadv_tke iadv_thl iadv_qt iadv_sv",
     "BC": "BCxm BCxT BCxq BCxs BCym BCyT BCyq BCys BCtopm BCtopT BCtopq BCtops BCbotm BCbotT BCbotq BCbots bctfxm bctfxp "
           "bctfym bctfyp bctfz bcqfxm bcqfxp bcqfym bcqfyp bcqfz wttop thl_top qt_top qts wsvsurfdum wsvtopdum wtsurf "
-          "wqsurf thls z0 z0h BCzp ds wqtop",
+          "wqsurf thls z0 z0h BCzp ds",
     "INLET": "Uinf Vinf di dti inletav linletRA lstoreplane lreadminl lfixinlet lfixutauin lwallfunc",
     "DRIVER": "idriver tdriverstart driverjobnr dtdriver driverstore iplane iangledeg lchunkread chunkread_size",
     "WALLS": "nfcts iwallmom iwalltemp iwallmoist iwallscal nsolpts_u nsolpts_v nsolpts_w nsolpts_c nbndpts_u nbndpts_v "
@@ -194,6 +195,23 @@ class Deck:
     def is_set(self, group, name):
         return any(k.lower() == name.lower() for k in self.nml.get(group, {}))
 
+    def set(self, group, name, value):
+        """Overrides a value whatever the case its name was written in (Deck.get returns the first case-insensitive match)."""
+        g = self.nml.setdefault(group, {})
+        for k in list(g):
+            if k.lower() == name.lower():
+                del g[k]
+        g[name] = value
+
+    def apply_checkinitvalues(self):
+        """The values checkinitvalues re-routes before anything is initialised (src/modstartup.f90:811-816): without the
+        temperature equation, or with prescribed wall heat fluxes (iwalltemp = 1, the default), the stability-dependent wall
+        function (iwallmom = 2, the default) becomes the neutral one -- on the facets AND on the floor (BCbotm = 3), whatever the
+        deck says about BCbotm."""
+        if (not self.get("PHYSICS", "ltempeq") or int(self.get("WALLS", "iwalltemp")) == 1) and int(self.get("WALLS", "iwallmom")) == 2:
+            self.set("WALLS", "iwallmom", 3)
+            self.set("BC", "BCbotm", 3)
+
     def validate(self):
         """A name the reference's namelist of that group does not hold stops the reference; so it does here."""
         for grp, vals in self.nml.items():
@@ -228,6 +246,7 @@ def read_deck(namoptions_path: str) -> Deck:
         nml = parse_namelists(f.read())
     d = Deck(path=namoptions_path, nml=nml)
     d.validate()
+    d.apply_checkinitvalues()
     exp = d.get("RUN", "iexpnr")
     base = os.path.dirname(os.path.abspath(namoptions_path))
     ktot = d.get("DOMAIN", "ktot")

@@ -38,9 +38,8 @@ def check_supported(deck):
         for n in names:
             if deck.is_set(grp, n) and int(deck.nml[grp][[k for k in deck.nml[grp] if k.lower() == n.lower()][0]]) != 1:
                 _refuse(f"only periodic lateral boundaries are on the device path (&BC {n})")
-    if g("RUN", "libm") and int(g("WALLS", "iwallmom")) == 2 and not g("PHYSICS", "ltempeq"):
-        # (the reference reads mask_c unallocated in this combination, src/modibm.f90:180, 1794-1830)
-        _refuse("immersed boundaries with iwallmom = 2 (stability functions) read the air temperature: needs ltempeq; iwallmom = 3 is the neutral wall function")
+    # (iwallmom = 2 without the temperature equation never reaches initibm: checkinitvalues has made it 3 by then,
+    #  src/modstartup.f90:811-816 -- Deck.apply_checkinitvalues)
     if int(g("BC", "BCxm")) != 1 or int(g("BC", "BCym")) != 1:
         _refuse("only periodic lateral boundaries (BCxm = BCym = 1) are on the device path")
     if int(g("DYNAMICS", "ipoiss")) != 0 or int(g("BC", "BCzp")) != 1:
@@ -124,7 +123,8 @@ def main(argv=None, at_end=None):
     device = args.device if args.device is not None else int(os.environ.get("LOCAL_RANK", "0"))
     deck = read_deck(args.namoptions)
     if args.ibm_mask_wrap != "deck":      # (in memory only: the device's own decomposition does not come from these)
-        deck.nml.setdefault("RUN", {}).update(nprocx=1 if args.ibm_mask_wrap == "none" else 2, nprocy=1 if args.ibm_mask_wrap == "none" else 2)
+        for key in ("nprocx", "nprocy"):
+            deck.set("RUN", key, 1 if args.ibm_mask_wrap == "none" else 2)
     check_supported(deck)
     wdir = os.path.dirname(os.path.abspath(args.namoptions))
     core = from_deck(deck, device=device, rank=rank, nranks=world)
