@@ -157,6 +157,9 @@ extern "C" int udc_create(const udc_config *cfg, udc_handle **out) {
   h->no_pup = getenv("UDC_NO_PUP") && atoi(getenv("UDC_NO_PUP")) != 0;
   h->no_fold = getenv("UDC_NO_FOLD") && atoi(getenv("UDC_NO_FOLD")) != 0;
   h->no_alias = getenv("UDC_NO_ALIAS") && atoi(getenv("UDC_NO_ALIAS")) != 0;
+  h->ek_always = getenv("UDC_EK_ALWAYS") && atoi(getenv("UDC_EK_ALWAYS")) != 0;
+  h->no_fused_closure = getenv("UDC_NO_FUSED_CLOSURE") && atoi(getenv("UDC_NO_FUSED_CLOSURE")) != 0;
+  h->no_div_in_fft = getenv("UDC_DIV_IN_FFT") && atoi(getenv("UDC_DIV_IN_FFT")) == 0;
   h->slab = cfg->nranks > 1 || (getenv("UDC_FORCE_SLAB") && atoi(getenv("UDC_FORCE_SLAB")) != 0);
   g.py = g.ny + 2 * HY; g.pz = g.nz + 2 * HZ;
   // row stride: rows of a power-of-two nx put every row of a tile column on the same few L2 channels and sets, and the
@@ -326,6 +329,7 @@ static int copy3d_ptr(udc_handle *h, int field, double *dev, double *host, const
 extern "C" int udc_field_upload(udc_handle *h, int field, const double *host, const int lb[3], const int ub[3]) {
   ENTRY_FLUSH(h);
   if (copy3d(h, field, const_cast<double *>(host), lb, ub, true)) return 1;
+  if (field == UDC_EKM || field == UDC_EKH) h->ek_stale = false;
   if (h->scal_bcx == 2 && field >= UDC_SV0 && (field - UDC_SV0) % 3 == 0)      // sv0 with its east ghost columns (BCxs = 2)
     return k_scalar_bcx_capture(h, (field - UDC_SV0) / 3, host, lb, ub);
   return 0;
@@ -367,8 +371,19 @@ extern "C" int udc_set_scalar_bcx(udc_handle *h, int bcxs, const double *svprof,
     }
   return 0;
 }
+// ekm / ekh in memory are those of the last substep that wrote them: RK stages 1 and 2 of a substep whose closure ran inside
+// the momentum sweep keep them in LDS only (udc_mom_fused.hip).  Nothing of the reference's loop looks at them there; a caller
+// that does is told so instead of being handed an older substep's values.
+static int ek_current(udc_handle *h, const char *who) {
+  if (!h->ek_stale) return 0;
+  udc_set_error("%s: ekm / ekh were not written by the last substep (RK stage 1 or 2 with the closure evaluated inside the "
+                "momentum sweep); set UDC_EK_ALWAYS=1 before udc_create to have every substep write them", who);
+  return 1;
+}
+
 extern "C" int udc_field_download(udc_handle *h, int field, double *host, const int lb[3], const int ub[3]) {
   ENTRY_FLUSH(h);
+  if ((field == UDC_EKM || field == UDC_EKH) && ek_current(h, "udc_field_download")) return 1;
   if (copy3d(h, field, host, lb, ub, false)) return 1;
   if (h->scal_bcx == 2 && field >= UDC_SV0 && (field - UDC_SV0) % 3 == 0)      // sv0: its x ghost columns under BCxs = 2
     return k_scalar_bcx_fill_host(h, (field - UDC_SV0) / 3, host, lb, ub);
@@ -441,6 +456,7 @@ static int now_subgrid(udc_handle *h) {
   if (k_closure(h)) return 1;
   if (h->lbuoycorr && k_vreman_buoycorr(h)) return 1;
   if (k_ek_ghosts(h)) return 1;
+  h->ek_stale = false;
   if (k_top_rows_after_closure(h)) return 1;
   if ((h->mom_simple ? k_momentum(h, false, true, false) : k_momentum_lds(h, false, true, false, false, 0.))) return 1;
   if (k_scalar_top_flux(h)) return 1;      // reassure_fluxtop_boundary for a non-zero thl top flux (uses the new ekh)
@@ -888,6 +904,7 @@ extern "C" int udc_boundary(udc_handle *h) {
 
 extern "C" int udc_tstep_maxima(udc_handle *h, double dt, double *courtot, double *diffnrtot) {
   ENTRY_FLUSH(h);
+  if (ek_current(h, "udc_tstep_maxima")) return 1;
   return k_maxima(h, dt, courtot, diffnrtot);
 }
 
@@ -924,16 +941,26 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   if (h->um_alias && !(alias_ok && rk3step == 1)) { if (um_materialise(h)) return 1; }
   const bool rotate = h->um_alias;                    // only true here for an aliased stage 1
   h->halos_fresh = h->boundary_fresh = h->thermo_fresh = false;
-  // closure first: it only needs u0,v0,w0, and the fused sweep below needs ekm
-  if (fold && h->p.sgs != UDC_SGS_DNS && h->p.sgs != UDC_SGS_ONEEQN && !h->lbuoycorr) {
-    if (k_closure_lds(h, true)) return 1;
+  // closure + momentum.  Single slab, Smagorinsky / Vreman: ONE sweep that evaluates ekm in LDS (udc_mom_fused.hip); ekm / ekh
+  // reach memory only when something else reads them -- the scalar sweeps, the immersed boundary and the statistics of this
+  // substep, or (RK stage 3) whatever looks at them between time steps: tstep_update's maxima, restart files, downloads.
+  if (fold && pup && fused_closure_possible(h)) {
+    const bool emit = h->ek_always || rk3step == 3 || !h->slots.empty() || h->ibm_on || h->stats_on || h->xyt_on || h->yt_on;
+    if (k_momentum_closure(h, forces, 1. / rk3coef, rotate, emit)) return 1;
+    h->ek_stale = !emit;
   } else {
-    if (k_closure(h)) return 1;
-    if (h->lbuoycorr && k_vreman_buoycorr(h)) return 1;      // before closurebc, as in the reference
-    if (k_ek_ghosts(h)) return 1;
+    // closure first: it only needs u0,v0,w0, and the momentum sweep below needs ekm
+    if (fold && h->p.sgs != UDC_SGS_DNS && h->p.sgs != UDC_SGS_ONEEQN && !h->lbuoycorr) {
+      if (k_closure_lds(h, true)) return 1;
+    } else {
+      if (k_closure(h)) return 1;
+      if (h->lbuoycorr && k_vreman_buoycorr(h)) return 1;      // before closurebc, as in the reference
+      if (k_ek_ghosts(h)) return 1;
+    }
+    h->ek_stale = false;
+    if (lds ? k_momentum_lds(h, true, true, forces, true, pup ? 1. / rk3coef : 0., rotate)
+            : k_momentum(h, true, true, forces)) return 1;
   }
-  if (lds ? k_momentum_lds(h, true, true, forces, true, pup ? 1. / rk3coef : 0., rotate)
-          : k_momentum(h, true, true, forces)) return 1;
   if (k_scalar_top_flux(h)) return 1;
   for (int n : h->slots)
     if (k_scalar_fused(h, n, lds)) return 1;       // lds: the tendencies are scratch between fused substeps (tend_scratch)
@@ -962,7 +989,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
     if (k_halo_y(h, fvp, 1, 1)) return 1;
   }
   // slab path with the own line FFTs: fillps' divergence is evaluated inside the x forward transform (udc_fft.hip)
-  h->div_in_fft = pup && h->slab && h->fft_fused && !(getenv("UDC_DIV_IN_FFT") && atoi(getenv("UDC_DIV_IN_FFT")) == 0);
+  h->div_in_fft = pup && h->slab && h->fft_fused && !h->no_div_in_fft;
   if (!h->div_in_fft && k_divergence_rhs(h, rk3coef, pup)) return 1;
   if (k_poisson_solve(h)) return 1;
   h->div_in_fft = false;

@@ -183,6 +183,10 @@ struct udc_handle {
   bool no_fold = false;                 // UDC_NO_FOLD=1: keep separate ghost-row kernels on a single slab (A/B switch)
   bool no_pup = false;                  // UDC_NO_PUP=1: keep bare tendencies in the fused substep (A/B switch)
   bool mom_simple = false;              // UDC_MOM_SIMPLE=1: use the direct-load momentum kernel
+  bool ek_stale = false;                // the last fused substep kept ekm / ekh in LDS only: the arrays hold an older substep's values
+  bool ek_always = false;               // UDC_EK_ALWAYS=1: every substep writes ekm / ekh
+  bool no_fused_closure = false;        // UDC_NO_FUSED_CLOSURE=1: closure and momentum sweep as two kernels (A/B switch)
+  bool no_div_in_fft = false;           // UDC_DIV_IN_FFT=0: slab path with a separate divergence kernel (A/B switch)
   // immersed boundary (udc_ibm.hip): per grid (u, v, w, c) the global point lists as given, and this slab's points
   // (local 0-based i, j, k triplets) with their neighbour flags on the device
   struct IbmGrid {
@@ -311,6 +315,8 @@ int k_closure_lds(udc_handle *h, bool ghosts);   // ghosts: closurebc folded in 
 int k_ek_ghosts(udc_handle *h);
 int k_momentum(udc_handle *h, bool adv, bool diff, bool forces);       // direct-load version (UDC_MOM_SIMPLE=1)
 int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, double rk3coefi, bool um_is_u0 = false);  // rk3coefi != 0: PUP mode   // LDS-staged k-marching version (default)
+bool fused_closure_possible(const udc_handle *h);                      // udc_mom_fused.hip: closure inside the momentum sweep
+int k_momentum_closure(udc_handle *h, bool forces, double rk3coefi, bool um_is_u0, bool emit);   // emit: ekm, ekh also written (with closurebc's ghosts)
 int k_level_sums_dev(udc_handle *h, int field, int n);      // udc_thermo.hip: masked, all-reduced level sums left on the device
 int k_scalar_adv(udc_handle *h, int n);
 int k_scalar_bcx_outlet(udc_handle *h);

@@ -615,7 +615,11 @@ contains
   subroutine udc_begin(tend)
     logical, intent(in) :: tend      !< the routine reads or edits the tendencies
     call udc_ensure
-    if (.not. udc_in_loop) call udc_late_setup
+    if (.not. udc_in_loop) then
+      call udc_late_setup
+      call udc_push_ek      ! start-up: the cold start's ekm = ekh = numol (src/modstartup.f90:1164-1165, 1190) is what the
+                            ! flux tops of `boundary` divide by before the first closure has run (src/modboundary.f90:1532)
+    end if
     select case (udc_mode())
     case (0)
       call udc_push_state
@@ -639,6 +643,7 @@ contains
     if (udc_residency == 2) then
       call udc_push_state
       call udc_push_tend
+      call udc_push_ek
       call udc_check(udc_set_deferred(udc_h, 1_c_int), 'udc_set_deferred')
       udc_host_fresh = .false.
     end if
@@ -785,6 +790,14 @@ contains
       call udc_push3(UDC_SVM + 3*(n - 1), svm(:, :, :, n), (/ib - ihc, jb - jhc, kb - khc/))
     end do
   end subroutine udc_push_state
+
+  !> the eddy diffusivities as the host has them (start-up values, or a restart file's ekm)
+  subroutine udc_push_ek
+    use modglobal, only: ib, jb, kb, ih, jh, kh
+    use modsubgriddata, only: ekm, ekh
+    call udc_push3(UDC_EKM, ekm, (/ib - ih, jb - jh, kb - kh/))
+    call udc_push3(UDC_EKH, ekh, (/ib - ih, jb - jh, kb - kh/))
+  end subroutine udc_push_ek
 
   subroutine udc_push_tend
     use modglobal, only: ib, jb, kb, ih, jh, ihc, jhc, nsv, ltempeq, lmoist
