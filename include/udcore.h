@@ -171,6 +171,15 @@ int udc_set_moisture(udc_handle *h, int iadv_qt, int bctopq, double wqtop, doubl
  * (k = kb..ke+kh) in the order presf, presh, exnf, exnh, thvh, thl0av, qt0av, ql0av, th0av. */
 int udc_set_moist_thermo(udc_handle *h, double thls, double qts, double ps, const double *zf, const double *zh, int n, int lqlnr);
 int udc_thermodynamics(udc_handle *h);
+/* calthv's dthvdz (src/modthermodynamics.f90:154-232) is state in the reference: computed whenever `thermodynamics` runs and read by
+ * the closure of the NEXT substep (Vreman's buoyancy correction src/modsubgrid.f90:330-353, the one-equation closure :363-400).  The
+ * library evaluates it from thl0 / qt0 inside those kernels, which is the same thing because nothing changes the fields in between
+ * -- except at a start-up, where the reference's thermodynamics runs before `boundary` has set the top ghost plane
+ * (src/modstartup.f90:1601, src/program.f90:118-120).  udc_calthv records the top ghost planes of thl0 / qt0 as they are at the
+ * call; the closures read level ke's dthvdz from them until the next time integration.  Call it where the reference calls
+ * `thermodynamics` at start-up: after the fields are set, before udc_boundary (udc_thermodynamics does so itself; dry decks call
+ * this).  Without the call the first closure after a cold start sees the top condition's ghost value one substep early. */
+int udc_calthv(udc_handle *h);
 int udc_thermo_state(udc_handle *h, double *tables, int n, int set);
 int udc_set_buoyancy(udc_handle *h, int lbuoyancy, double grav);
 /* Vreman buoyancy correction, &NAMSUBGRID lbuoycorr with lbuoyancy (src/modsubgrid.f90:330-353, Huusko et al. 2025):

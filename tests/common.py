@@ -35,11 +35,12 @@ RUN_CASES = {"run_16x16x8": 21, "run_smag_scalar_16x8x12s": 22, "run_floor_scala
 WF_RUN_CASES = {"run_bcxs_16x8x12s", "run_bcxs_avg_16x8x12s", "run_ibm_wf2_16x12x10", "run_ibm_wh2_16x12x10", "run_ibm_wh1_16x12x10", "run_ground_wf3_16x8x12", "run_ground_wh2_16x8x12"}
 
 
-# A start-up transient of the reference that the library does not mimic: readinitfiles calls `thermodynamics`
-# BEFORE program.f90:118's `boundary` has set the top ghost plane of thl0 (src/modstartup.f90:1601 vs src/program.f90:118), so the
-# dthvdz that the FIRST closure after a cold start reads has, at level ke, `thl0(ke+1) = thl0(ke)` where every later substep sees the
-# top condition's ghost value.  Only a deck with a value top for thl (BCtopT = 2) and a closure that reads dthvdz (lbuoycorr) notices:
-# the eddy viscosity of the top level in one substep, 1e-6 .. 3e-5 of the fields afterwards.  Run-level tolerance for these decks:
+# A start-up transient of the reference: readinitfiles calls `thermodynamics` BEFORE program.f90:118's `boundary` has set the top
+# ghost plane of thl0 (src/modstartup.f90:1601 vs src/program.f90:118), so the dthvdz that the FIRST closure after a cold start reads
+# has, at level ke, `thl0(ke+1) = thl0(ke)` where every later substep sees the top condition's ghost value.  Only a deck with a value
+# top for thl (BCtopT = 2) and a closure that reads dthvdz (lbuoycorr) notices: the eddy viscosity of the top level in one substep,
+# 1e-6 .. 3e-5 of the fields afterwards.  The library reproduces it (udc_calthv, DynCore.start_up); the C oracle's whole-substep driver
+# (tests only) starts from the dumped state s000 and does not -- its run-level tolerance for these decks:
 STARTUP_TRANSIENT_TOL = {"run_vreman_buoycorr_16x8x12s": 1e-4}
 
 

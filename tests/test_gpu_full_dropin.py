@@ -18,7 +18,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from common import GOLDEN, RUN_CASES, STARTUP_TRANSIENT_TOL, load_fixture, nocorner, relerr
+from common import GOLDEN, RUN_CASES, load_fixture, nocorner, relerr
 from refdump import read_ncrec
 from test_full_reference import run_full
 
@@ -37,7 +37,7 @@ def test_run_decks_through_the_reference_program(name, iexp, residency, tmp_path
     env = dict(os.environ, UDC_RESIDENCY=str(residency), UDC_PULL_EVERY="1")
     fix, last, rs, _ = run_full(name, iexp, tmp_path, exe=DROPIN, env=env)
     nz = int(fix["meta"].data[2])
-    tol = STARTUP_TRANSIENT_TOL.get(name, 1e-9)
+    tol = 1e-9
     if last + ".time" in fix:
         np.testing.assert_allclose((rs["timee"], rs["dt"]), fix[last + ".time"].data, rtol=1e-10)
     checked = 0

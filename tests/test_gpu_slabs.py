@@ -34,7 +34,8 @@ for name, iexp in RUN_CASES.items():
     fix = load_fixture(name)
     d = read_deck(deck_path(name, iexp))
     core = udcore.from_deck(d)
-    core.load_state(cold_start(core.g, d, nsv=core.nsv))
+    core.load_state(cold_start(core.g, d, nsv=core.nsv, pre_boundary=True))
+    core.start_up()
     dt = float(d.get("RUN", "dtmax"))
     dumps = sorted(int(k[1:4]) for k in fix if k.endswith(".u0") and k != "s000.u0")
     for isub in range(1, max(dumps) + 1):

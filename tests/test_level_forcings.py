@@ -128,8 +128,9 @@ def test_run_with_level_forcings_matches_reference(fused):
     fix = load_fixture(name)
     d = read_deck(deck_path(name, iexp))
     core = udcore.from_deck(d)
-    core.load_state(cold_start(core.g, d))
+    core.load_state(cold_start(core.g, d, pre_boundary=True))      # the fields as readinitfiles leaves them
     ls = LevelForcings(core, d)
+    core.start_up(before_boundary=ls.capture_startup)             # thermodynamics (diagfld's averages), then boundary
     assert ls.active and ls.igrw == 1 and ls.lcoriol
     dt = float(d.get("RUN", "dtmax"))
     dumps = sorted(int(k[1:4]) for k in fix if k.endswith(".u0") and k != "s000.u0")
@@ -187,8 +188,9 @@ def test_run_with_fixuinf2_matches_reference():
     fix = load_fixture(name)
     d = read_deck(deck_path(name, iexp))
     core = udcore.from_deck(d)
-    core.load_state(cold_start(core.g, d))
+    core.load_state(cold_start(core.g, d, pre_boundary=True))      # the fields as readinitfiles leaves them
     ls = LevelForcings(core, d)
+    core.start_up(before_boundary=ls.capture_startup)             # thermodynamics (diagfld's averages), then boundary
     assert ls.active and ls.ifixuinf == 2
     dt = float(d.get("RUN", "dtmax"))
     nz = core.g.nz
@@ -216,8 +218,9 @@ def test_run_with_shifted_pbcs_matches_reference(fused):
     fix = load_fixture(name)
     d = read_deck(deck_path(name, iexp))
     core = udcore.from_deck(d)
-    core.load_state(cold_start(core.g, d))
+    core.load_state(cold_start(core.g, d, pre_boundary=True))      # the fields as readinitfiles leaves them
     ls = LevelForcings(core, d)
+    core.start_up(before_boundary=ls.capture_startup)             # thermodynamics (diagfld's averages), then boundary
     assert ls.active and ls.ds == 1.5 and ls.shift_sinx[:8].max() == 0. and ls.shift_sinx[8:].max() > 0.9
     dt = float(d.get("RUN", "dtmax"))
     for isub in range(1, 7):

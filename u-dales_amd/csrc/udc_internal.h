@@ -160,6 +160,8 @@ struct udc_handle {
   int lbuoyancy = 0;           // forces' buoyancy term (dry air), needs the temperature equation
   int lbuoycorr = 0;           // Vreman buoyancy correction (udc_set_buoycorr)
   double rigc = 0.25;
+  double *dthv_top = nullptr;  // udc_calthv: the top ghost planes of thl0, qt0 as the last explicit thermodynamics call saw them
+  bool dthv_top_on = false;    // ... in force until the next time integration (the closures' dthvdz at level ke)
   double grav = 9.81;
   double *lev_part = nullptr, *lev_sum = nullptr;   // per-level slab sums (thvh)
   double *lev_sum16 = nullptr;                      // udc_slab_averages: up to 16 fields x (nz+2)
@@ -185,7 +187,7 @@ struct udc_handle {
   bool mom_simple = false;              // UDC_MOM_SIMPLE=1: use the direct-load momentum kernel
   bool ek_stale = false;                // the last fused substep kept ekm / ekh in LDS only: the arrays hold an older substep's values
   bool ek_always = false;               // UDC_EK_ALWAYS=1: every substep writes ekm / ekh
-  bool no_fused_closure = false;        // UDC_NO_FUSED_CLOSURE=1: closure and momentum sweep as two kernels (A/B switch)
+  bool no_fused_closure = true;         // UDC_FUSED_CLOSURE=1 turns the one-kernel closure + momentum sweep on (A/B switch; slower as measured)
   bool no_div_in_fft = false;           // UDC_DIV_IN_FFT=0: slab path with a separate divergence kernel (A/B switch)
   // immersed boundary (udc_ibm.hip): per grid (u, v, w, c) the global point lists as given, and this slab's points
   // (local 0-based i, j, k triplets) with their neighbour flags on the device
@@ -350,6 +352,7 @@ int k_slab_averages(udc_handle *h, const int *fields, int nf, double *avg_host, 
 int k_level_forcings(udc_handle *h, int when, bool wrap_vp);
 int k_tke_closure(udc_handle *h);                  // closure, loneeqn branch
 int k_tke_sources(udc_handle *h);                  // sources: e12p += shear + buoyancy + dissipation
+int k_calthv_capture(udc_handle *h);
 int k_vreman_buoycorr(udc_handle *h);            // ekm *= sqrt(1 - min(max(Rig,0),Rigc)/Rigc), then ekh and the molecular parts
 int k_ibm_wallfun(udc_handle *h);                // diffu/v/w/c_corr at the fluid-boundary points
 int k_ibm_norm(udc_handle *h);

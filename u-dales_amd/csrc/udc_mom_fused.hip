@@ -35,6 +35,7 @@ struct FusedArgs {
   double *ekm, *ekh;            // written when emit
   double rk3coefi;
   int wrap_vp, um_is_u0, emit;
+  int dbg;                      // timing experiments only (UDC_FUSED_DBG bits: 1 no halo evaluations, 2 no closure at all, 4 no second barrier, 8 no stores)
 };
 
 // velocity-tile halo element e (0 .. NVH-1) -> tile coordinates
@@ -229,20 +230,20 @@ __global__ __launch_bounds__(NT, 2) void mom_closure_kernel(Geo g, TileGrid tg, 
     // ---- ekm(k+1) on the 34 x 10 tile
     {
       double em, eh;
-      if (k + 1 < g.nz) {
+      if (k + 1 < g.nz && !(a.dbg & 2)) {
         const FusedClosMetLds lmc{smet[k & 1]};
         eval(own_v, vc_, vp_, vq_, k + 1, lmc, em, eh);
         if (k + 1 < k1) emit_own(k + 1, em, eh);
         em_own = em; eh_own = eh;
         E[ep_][own_t] = em;
-        if (has_th) { eval(th_v, vc_, vp_, vq_, k + 1, lmc, em, eh); em_halo = em; E[ep_][th_t] = em; }
+        if (has_th && !(a.dbg & 1)) { eval(th_v, vc_, vp_, vq_, k + 1, lmc, em, eh); em_halo = em; E[ep_][th_t] = em; }
       } else {      // above the top: zero gradient, or the mirror value under a no-slip lid (src/modboundary.f90:455-465)
         const bool ns = pr.bctopm == UDC_TOP_NOSLIP;
         E[ep_][own_t] = ns ? 2. * nm - em_own : em_own;
         if (has_th) E[ep_][th_t] = ns ? 2. * nm - em_halo : em_halo;
       }
     }
-    __syncthreads();                                           // B2: ekm(k+1) is complete
+    if (!(a.dbg & 4)) __syncthreads();                         // B2: ekm(k+1) is complete
     // ---- momentum stencil of level k
     if (inside) {
       const FusedMetLds lm{smet[k & 1]};
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(NT, 2) void mom_closure_kernel(Geo g, TileGrid tg, 
       tu = tu + pum * a.rk3coefi;
       tv = tv + pvm * a.rk3coefi;
       tw = (k == 0) ? 0. : tw + pwm * a.rk3coefi;
-      a.up[cc] = tu; a.vp[cc] = tv; a.wp[cc] = tw;
+      if (!(a.dbg & 8) || tu == 1.2345e300) { a.up[cc] = tu; a.vp[cc] = tv; a.wp[cc] = tw; }
       if (a.wrap_vp && j == 0) a.vp[cc + (long)g.sy * g.ny] = tv;
     }
     { const int t = vf_; vf_ = vm_; vm_ = vc_; vc_ = vp_; vp_ = vq_; vq_ = t; }
@@ -308,7 +309,7 @@ int k_momentum_closure(udc_handle *h, bool forces, double rk3coefi, bool um_is_u
   FusedArgs a{h->fields[UDC_U0], h->fields[UDC_V0], h->fields[UDC_W0], h->fields[UDC_PRES0],
               h->fields[UDC_UP], h->fields[UDC_VP], h->fields[UDC_WP],
               h->fields[UDC_UM], h->fields[UDC_VM], h->fields[UDC_WM], h->fields[UDC_EKM], h->fields[UDC_EKH],
-              rk3coefi, 1, um_is_u0 ? 1 : 0, emit ? 1 : 0};
+              rk3coefi, 1, um_is_u0 ? 1 : 0, emit ? 1 : 0, getenv("UDC_FUSED_DBG") ? atoi(getenv("UDC_FUSED_DBG")) : 0};
   static bool attr_set = false;
   if (!attr_set) {
     HIP_OK(hipFuncSetAttribute((const void *)mom_closure_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS));

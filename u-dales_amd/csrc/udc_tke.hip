@@ -15,24 +15,32 @@ inline dim3 cell_grid(const Geo &g, dim3 b) {
 // ---- one-equation closure -------------------------------------------------------------------------
 struct TkeK { double cm, cn, ch1, ch2, ce1, ce2, grav_thvs, numol, prandtlmoli; int ldelta; };
 // dthvdz of calthv for dry air (src/modthermodynamics.f90:208-222, eps1 clamp :224-232): thl may be null (neutral)
-__device__ __forceinline__ double dthvdz_at(const Geo &g, const Metrics &m, const double *__restrict__ thl, long c, int k) {
+// dthvdz is STATE in the reference: calthv computes it when `thermodynamics` runs (end of every substep, after `boundary`) and the
+// closure of the next substep reads it.  Nothing changes thl0 / qt0 in between, so evaluating it here from the fields is the same
+// thing -- except right after a start-up, where the reference's thermodynamics runs BEFORE `boundary` has set the top ghost plane
+// (src/modstartup.f90:1601 against src/program.f90:118).  TopGhost then holds that plane as calthv saw it (udc_calthv).
+struct TopGhost { const double *thl, *qt; };
+__device__ __forceinline__ double above(const Geo &g, const double *__restrict__ f, const double *__restrict__ top, long c, int k) {
+  return (top && k == g.nz - 1) ? top[c - g.sz * (long)(k + HZ)] : f[c + g.sz];
+}
+__device__ __forceinline__ double dthvdz_at(const Geo &g, const Metrics &m, const double *__restrict__ thl, const TopGhost &tg, long c, int k) {
   const double eps1 = 1e-10;
   double d = 0.;
-  if (thl && k >= 1) d = (thl[c + g.sz] - thl[c - g.sz]) / (m.dzh[k + 2] + m.dzh[k + 1]);
+  if (thl && k >= 1) d = (above(g, thl, tg.thl, c, k) - thl[c - g.sz]) / (m.dzh[k + 2] + m.dzh[k + 1]);
   if (fabs(d) < eps1) d = copysign(eps1, d);
   return d;
 }
 // the same for moist air (:154-205): the unsaturated jump, or the saturated one where the mixed parcel stays saturated.
 // ql0 is the reference's level-shifted field, exnf / zf the thermodynamics tables (index = reference k)
-struct MoistK { const double *qt, *ql0, *exnf, *zf; };
-__device__ __forceinline__ double dthvdz_moist_at(const Geo &g, const Metrics &m, const double *__restrict__ thl, const MoistK &q, long c, int k) {
+struct MoistK { const double *qt, *ql0, *exnf, *zf; TopGhost top; };
+__device__ __forceinline__ double dthvdz_moist_at(const Geo &g, const Metrics &m, const double *__restrict__ thl, const MoistK &q, const TopGhost &tg, long c, int k) {
   const double eps1 = 1e-10, rd = 287.04, rv = 461.5, cp = 1004., rlv = 2.26e6, chi_half = 0.5;
   double d = 0.;
   if (k >= 1) {
     const int kf = k + 1;
     const double epsilon = rd / rv, eps_I = 1 / epsilon - 1.;
     const double a_dry = 1. + eps_I * q.qt[c], b_dry = eps_I * thl[c];
-    const double dth = thl[c + g.sz] - thl[c - g.sz], dq = q.qt[c + g.sz] - q.qt[c - g.sz];
+    const double dth = above(g, thl, tg.thl, c, k) - thl[c - g.sz], dq = above(g, q.qt, tg.qt, c, k) - q.qt[c - g.sz];
     const double del_thv_dry = a_dry * dth + b_dry * dq;
     double dthv = del_thv_dry;
     const double ql = q.ql0[c];
@@ -52,8 +60,8 @@ __device__ __forceinline__ double dthvdz_moist_at(const Geo &g, const Metrics &m
   if (fabs(d) < eps1) d = copysign(eps1, d);
   return d;
 }
-__device__ __forceinline__ double dthvdz_any(const Geo &g, const Metrics &m, const double *__restrict__ thl, const MoistK &q, long c, int k) {
-  return q.ql0 ? dthvdz_moist_at(g, m, thl, q, c, k) : dthvdz_at(g, m, thl, c, k);
+__device__ __forceinline__ double dthvdz_any(const Geo &g, const Metrics &m, const double *__restrict__ thl, const MoistK &q, const TopGhost &tg, long c, int k) {
+  return q.ql0 ? dthvdz_moist_at(g, m, thl, q, tg, c, k) : dthvdz_at(g, m, thl, tg, c, k);
 }
 __device__ __forceinline__ double tke_zlt(const TkeK &t, double delta, double e, double dthvdz) {
   if (t.ldelta || dthvdz <= 0) return delta;
@@ -67,7 +75,7 @@ __global__ __launch_bounds__(256) void tke_closure_kernel(Geo g, TileGrid tg, Me
   const long c = g.idx(i, j, k);
   const double delta = m.delta[k + 1];
   const double e = e12[c];
-  const double dth = dthvdz_any(g, m, thl, mq, c, k);
+  const double dth = dthvdz_any(g, m, thl, mq, mq.top, c, k);
   double em, eh;
   if (t.ldelta || dth <= 0) {
     em = t.cm * delta * 1. * e;
@@ -107,7 +115,7 @@ __global__ __launch_bounds__(256) void tke_sources_kernel(Geo g, TileGrid tg, Me
                         + sq((v0[c + sy] - v0[c + sy - sz]) * hk + (w0[c + sy] - w0[c]) * dyi)
                         + sq((v0[c + sy + sz] - v0[c + sy]) * hkp + (w0[c + sy + sz] - w0[c + sz]) * dyi));
   const double e = e12[c], delta = m.delta[kf];
-  const double dth = dthvdz_any(g, m, thl, mq, c, k);
+  const double dth = dthvdz_any(g, m, thl, mq, mq.top, c, k);
   const double zlt = tke_zlt(t, delta, e, dth);
   const double sbshr = (ekm[c] - t.numol) * tdef2 / (2 * e);
   const double sbbuo = -(ekh[c] - t.numol * t.prandtlmoli) * t.grav_thvs * dth / (2 * e);
@@ -147,7 +155,7 @@ __global__ __launch_bounds__(256) void vreman_buoycorr_kernel(Geo g, TileGrid tg
   const double dz2 = m.dzh[kf + 1] + m.dzh[kf];
   const double du0dz = 0.5 * ((u0[c + g.sz] + u0[cip + g.sz]) - (u0[c - g.sz] + u0[cip - g.sz])) / dz2;
   const double dv0dz = 0.5 * ((v0[c + g.sz] + v0[c + g.sy + g.sz]) - (v0[c - g.sz] + v0[c + g.sy - g.sz])) / dz2;
-  const double rig = ((grav / thl[c]) * dthvdz_any(g, m, thl, mq, c, k)) / (du0dz * du0dz + dv0dz * dv0dz + 1.e-10);
+  const double rig = ((grav / thl[c]) * dthvdz_any(g, m, thl, mq, mq.top, c, k)) / (du0dz * du0dz + dv0dz * dv0dz + 1.e-10);
   double em = ekm[c] * sqrt(1.0 - fmin(fmax(rig, 0.0), rigc) / rigc);
   double eh = em * pr.prandtli;
   em = em + pr.numol;
@@ -158,7 +166,8 @@ __global__ __launch_bounds__(256) void vreman_buoycorr_kernel(Geo g, TileGrid tg
 
 // moist dthvdz inputs, or nulls for dry air; fails when the thermodynamics have not run yet (ql0, exnf undefined)
 static int moist_inputs(udc_handle *h, MoistK &q) {
-  q = MoistK{nullptr, nullptr, nullptr, nullptr};
+  const TopGhost top{h->dthv_top_on ? h->dthv_top : nullptr, (h->dthv_top_on && h->lmoist) ? h->dthv_top + (size_t)h->g.sy * h->g.py : nullptr};
+  q = MoistK{nullptr, nullptr, nullptr, nullptr, top};
   if (!h->lmoist) return 0;
   if (!h->mt || !h->mt_valid || (int)h->fields.size() <= UDC_QL0 || !h->fields[UDC_QL0]) {
     udc_set_error("one-equation closure / Vreman buoyancy correction with moisture: set up udc_set_moist_thermo and call udc_thermodynamics before the first "
@@ -166,7 +175,20 @@ static int moist_inputs(udc_handle *h, MoistK &q) {
     return 1;
   }
   const int n2 = h->g.nz + 2;
-  q = MoistK{h->fields[UDC_QT0], h->fields[UDC_QL0], h->mt + udc_handle::MT_EXNF * n2, h->mt + udc_handle::MT_ZF * n2};
+  q = MoistK{h->fields[UDC_QT0], h->fields[UDC_QL0], h->mt + udc_handle::MT_EXNF * n2, h->mt + udc_handle::MT_ZF * n2, top};
+  return 0;
+}
+// udc_calthv: keep the top ghost planes of thl0 (and qt0) as they are now -- what the reference's calthv, running at this point,
+// builds the top level's dthvdz from; the closures read them until the next time integration
+int k_calthv_capture(udc_handle *h) {
+  if ((int)h->fields.size() <= UDC_THL0 || !h->fields[UDC_THL0]) return 0;      // no temperature equation: dthvdz = 0
+  const Geo &g = h->g;
+  const size_t plane = (size_t)g.sy * g.py;
+  if (!h->dthv_top) HIP_OK(hipMalloc(&h->dthv_top, sizeof(double) * 2 * plane));
+  HIP_OK(hipMemcpyAsync(h->dthv_top, h->fields[UDC_THL0] + g.sz * (long)(g.nz + HZ), sizeof(double) * plane, hipMemcpyDeviceToDevice, h->stream));
+  if (h->lmoist)
+    HIP_OK(hipMemcpyAsync(h->dthv_top + plane, h->fields[UDC_QT0] + g.sz * (long)(g.nz + HZ), sizeof(double) * plane, hipMemcpyDeviceToDevice, h->stream));
+  h->dthv_top_on = true;
   return 0;
 }
 int k_tke_closure(udc_handle *h) {

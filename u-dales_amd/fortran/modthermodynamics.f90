@@ -37,6 +37,9 @@ contains
     logical :: moist_dev
     call udc_begin(.false.)
     moist_dev = lmoist .and. ltempeq .and. (lbuoyancy .or. loneeqn_dev())      ! udc_set_moist_thermo was called
+    ! start-up (src/modstartup.f90:1601: before program.f90:118's `boundary`): calthv's dthvdz at the top level is built from the
+    ! ghost plane as it is NOW; the device keeps that plane for the first closure (udc_calthv; udc_thermodynamics does it itself)
+    if (.not. udc_in_loop .and. ltempeq .and. .not. moist_dev) call udc_check(udc_calthv(udc_h), 'udc_calthv')
     if (moist_dev) then
       call udc_check(udc_thermodynamics(udc_h), 'udc_thermodynamics')
       if (udc_mode() <= 1 .or. udc_need_avg) then

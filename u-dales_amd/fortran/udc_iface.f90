@@ -241,6 +241,10 @@ module udc_iface
       import :: c_ptr, c_int
       type(c_ptr), value :: h
     end function udc_thermodynamics
+    integer(c_int) function udc_calthv(h) bind(C, name='udc_calthv')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+    end function udc_calthv
     integer(c_int) function udc_set_thl_source(h, thlpcar, n) bind(C, name='udc_set_thl_source')
       import :: c_int, c_ptr, c_double
       type(c_ptr), value :: h

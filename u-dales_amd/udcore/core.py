@@ -253,6 +253,22 @@ class DynCore:
                  "udc_set_moist_thermo")
         self.moist_thermo, self._thermo_started = True, False
 
+    def calthv(self):
+        """Record the top ghost planes of thl0 / qt0 as calthv would see them now (include/udcore.h udc_calthv)."""
+        L._check(self.lib.udc_calthv(self.h), "udc_calthv")
+
+    def start_up(self, before_boundary=None):
+        """What the reference does between filling the fields and entering the loop (src/modstartup.f90:1601, src/program.f90:118):
+        `thermodynamics` on the state as readinitfiles left it -- grid.cold_start(..., pre_boundary=True) --, then `boundary`.
+        `before_boundary`: a callable run in between (the host's level forcings take diagfld's slab averages there)."""
+        if getattr(self, "moist_thermo", False):
+            self.thermodynamics()
+        else:
+            self.calthv()
+        if before_boundary is not None:
+            before_boundary()
+        self.boundary()
+
     def thermodynamics(self):
         """The reference's `thermodynamics` (src/program.f90:120 before the loop, :214 at the end of every substep)."""
         L._check(self.lib.udc_thermodynamics(self.h), "udc_thermodynamics")

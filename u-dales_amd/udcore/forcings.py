@@ -169,12 +169,20 @@ class LevelForcings:
             return self.core.slab_averages(names)
         return {n: self.core.slab_average(n) for n in names}
 
+    def capture_startup(self):
+        """diagfld's slab averages as the start-up `thermodynamics` takes them (src/modstartup.f90:1601): of the state BEFORE
+        program.f90:118's `boundary` has set the planes above level ke, which lstend's upward differences read.  The first
+        update() uses them (DynCore.start_up(before_boundary=forcings.capture_startup))."""
+        if self.active:
+            self._startup_av = self.averages()
+
     def update(self, rk3step=None, dt=None):
         """Take the slab averages of the current state and register the tables for the next substep (rk3step, dt: that
         substep's; needed by ifixuinf only)."""
         if not self.active:
             return {}
-        av = self.averages()
+        av = getattr(self, "_startup_av", None) or self.averages()
+        self._startup_av = None
         if self.ifixuinf == 2:                                   # fixuinf2 (:174-218) + src/modtstep.f90:194-195
             if rk3step is None or dt is None:
                 raise ValueError("ifixuinf = 2: LevelForcings.update needs the substep's rk3step and dt")

@@ -114,11 +114,14 @@ def scalar_profiles(g: Grid, d: Deck, nsv, scal_a=None, scal_b=None):
     return out
 
 
-def cold_start(g: Grid, d: Deck, j0=0, nyl=None, nsv=0, scal_a=None, scal_b=None):
+def cold_start(g: Grid, d: Deck, j0=0, nyl=None, nsv=0, scal_a=None, scal_b=None, pre_boundary=False):
     """Initial um, vm, wm (= u0, v0, w0), and scalars for rows j0+1..j0+nyl of the global grid.
 
     Returns dict of arrays with halos; x ghosts periodic, y ghosts periodic when the slab is
-    the whole domain (otherwise left for the halo exchange), k ghost rows as `boundary` sets them.
+    the whole domain (otherwise left for the halo exchange), k ghost rows as `boundary` sets them --
+    or, with pre_boundary, as readinitfiles leaves them (src/modstartup.f90:1150-1210: nothing above level ke but a copy of
+    thl0's last level): the state the reference's start-up `thermodynamics` sees (:1601) BEFORE program.f90:118 calls
+    `boundary`; DynCore.start_up() then does those two calls in that order.
     """
     nx, ny, nz = g.nx, g.ny, g.nz
     nyl = ny if nyl is None else nyl
@@ -140,6 +143,13 @@ def cold_start(g: Grid, d: Deck, j0=0, nyl=None, nsv=0, scal_a=None, scal_b=None
             vm[k, 1:nyl + 1, 1:nx + 1] += pert
             wm[k, 1:nyl + 1, 1:nx + 1] += pert
     out = {"um": um, "vm": vm, "wm": wm}
+    if pre_boundary:      # ekm = ekh = numol on the levels, ekh(ke+1) = ekh(ke) (src/modstartup.f90:1164-1165, 1190): what the flux tops of
+        # the start-up `boundary` divide by
+        ek = np.zeros(shape)
+        ek[1:nz + 1] = 1.5e-5
+        out["ekm"] = ek
+        out["ekh"] = ek.copy()
+        out["ekh"][nz + 1] = 1.5e-5
     for a in (um, vm, wm):
         a[:, :, 0] = a[:, :, nx]
         a[:, :, nx + 1] = a[:, :, 1]
@@ -149,8 +159,9 @@ def cold_start(g: Grid, d: Deck, j0=0, nyl=None, nsv=0, scal_a=None, scal_b=None
     # boundary(): w(kb) = 0, free-slip top rows (src/modboundary.f90:165-178)
     wm[1, :, :] = 0.
     bctopm = int(d.get("BC", "BCtopm"))
-    for a in (um, vm):
-        a[nz + 1] = a[nz] if bctopm != 2 else -a[nz]
+    if not pre_boundary:
+        for a in (um, vm):
+            a[nz + 1] = a[nz] if bctopm != 2 else -a[nz]
     wm[nz + 1] = 0.
     out["u0"], out["v0"], out["w0"] = um.copy(), vm.copy(), wm.copy()
     svprof = scalar_profiles(g, d, nsv, scal_a, scal_b)
@@ -164,7 +175,9 @@ def cold_start(g: Grid, d: Deck, j0=0, nyl=None, nsv=0, scal_a=None, scal_b=None
         else:      # ... and fills ib-1 : ie+1, jb-1 : je+1 only (src/modstartup.f90:1561-1570): the outermost ghost columns stay zero,
             # which is what a convective outlet (BCxs = 2) keeps in its second ghost cell for ever
             c[:, :, 0] = 0.; c[:, :, -1] = 0.; c[:, 0, :] = 0.; c[:, -1, :] = 0.
-        if int(d.get("BC", "BCtops")) == 2:     # valuetopscal with sv_top = svprof(ke), as `boundary` leaves it
+        if pre_boundary:
+            pass
+        elif int(d.get("BC", "BCtops")) == 2:     # valuetopscal with sv_top = svprof(ke), as `boundary` leaves it
             c[nz + 2] = 2 * svprof[n][nz] - c[nz + 1]
         else:                                   # fluxtopscal with the start value ekh = numol (src/modboundary.f90:1532)
             w = d.get("BC", "wsvtopdum")
@@ -172,7 +185,7 @@ def cold_start(g: Grid, d: Deck, j0=0, nyl=None, nsv=0, scal_a=None, scal_b=None
             flux = float(w[n]) if n < len(w) else 0.
             c[nz + 2] = c[nz + 1] + g.dzh[nz + 1] * flux / ((1. / g.dzh[nz + 1]) * (0.5 * (g.dzf[nz] * 1.5e-5 + g.dzf[nz + 1] * 1.5e-5)))
         c[nz + 3] = c[nz + 2]
-        if int(d.get("BC", "BCxs")) == 2:       # the start-up call of `boundary`: xsi_profile (src/modboundary.f90:844-861) also runs on
+        if int(d.get("BC", "BCxs")) == 2 and not pre_boundary:       # the start-up call of `boundary`: xsi_profile (src/modboundary.f90:844-861) also runs on
             # level ke+1, where svprof is zero -- the inlet ghosts of the top ghost level mirror about 0 (no stencil reads them)
             c[nz + 2, 2:-2, 1] = -c[nz + 2, 2:-2, 2]
             c[nz + 2, 2:-2, 0] = -c[nz + 2, 2:-2, 1]
@@ -183,7 +196,8 @@ def cold_start(g: Grid, d: Deck, j0=0, nyl=None, nsv=0, scal_a=None, scal_b=None
         e = np.zeros(shape)
         for k in range(1, nz + 1):
             e[k] = max(d.tke[k - 1], 5.e-5)
-        e[nz + 1] = 5.e-5
+        if not pre_boundary:
+            e[nz + 1] = 5.e-5
         out["e120"], out["e12m"] = e, e.copy()
     if d.get("PHYSICS", "ltempeq"):
         # thl0 = thlm = thlprof(k), ghosts as src/modstartup.f90:1156-1208, then boundary's top condition
@@ -191,7 +205,7 @@ def cold_start(g: Grid, d: Deck, j0=0, nyl=None, nsv=0, scal_a=None, scal_b=None
         for k in range(1, nz + 1):
             t[k] = d.thl[k - 1]
         t[0] = t[1]
-        if int(d.get("BC", "BCtopT")) == 2:
+        if int(d.get("BC", "BCtopT")) == 2 and not pre_boundary:
             t[nz + 1] = 2 * float(d.get("BC", "thl_top")) - t[nz]
         else:
             t[nz + 1] = t[nz]          # non-zero wttop needs ekh: re-imposed on the device after the first closure
@@ -202,7 +216,9 @@ def cold_start(g: Grid, d: Deck, j0=0, nyl=None, nsv=0, scal_a=None, scal_b=None
         q = np.zeros(shape)
         for k in range(1, nz + 1):
             q[k] = d.qt[k - 1]
-        if int(d.get("BC", "BCtopq")) == 2:
+        if pre_boundary:
+            pass
+        elif int(d.get("BC", "BCtopq")) == 2:
             q[nz + 1] = 2 * float(d.get("BC", "qt_top")) - q[nz]
         else:
             q[nz + 1] = q[nz]

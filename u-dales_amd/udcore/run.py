@@ -168,13 +168,14 @@ def main(argv=None, at_end=None):
             core.halos(); core.boundary()
         ntrun = warm
     else:
-        core.load_state(cold_start(core.g, deck, j0=rank * nyl, nyl=nyl, nsv=core.nsv))
+        core.load_state(cold_start(core.g, deck, j0=rank * nyl, nyl=nyl, nsv=core.nsv, pre_boundary=True))
         core.halos()
-        core.boundary()
         timee, ntrun = 0., 0
         dt = dtmax if not ladaptive else dtmax / 100.          # src/modstartup.f90:1099, 2038
     core.dt, core.timee, core.rk3step = dt, timee, 0
     forcings = LevelForcings(core, deck)
+    if warm < 0:      # the reference's order at a cold start: thermodynamics on the fields as read (src/modstartup.f90:1601), then boundary
+        core.start_up(before_boundary=forcings.capture_startup)
     tdump = None
     for sw in ("lydump", "lxydump", "ltkedump", "lkslicedump", "lislicedump", "ljslicedump"):
         if deck.is_set("OUTPUT", sw) and deck.get("OUTPUT", sw):
