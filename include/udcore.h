@@ -92,12 +92,14 @@ int udc_version(void);
  * Fortran driver, torch.distributed in bench.py), then every rank calls udc_comm_init. */
 int udc_comm_unique_id(unsigned char id[128]);
 int udc_comm_init(udc_handle *h, const unsigned char id[128]);
-/* Test transport: P handles (cfg.nranks = P, rank = 0..P-1) inside ONE process on ONE device, each
- * driven by its own host thread; ghost rows and all-to-all blocks move by device-to-device copies
- * behind a barrier.  Lets the multi-slab code path be parity-tested on a single-GPU box.
- * udc_local_group_create returns a group id > 0 (or -1). */
+#ifdef UDC_TEST_TRANSPORT
+/* Test transport, NOT part of libudcore.so: libudcore_test.so (same sources + -DUDC_TEST_TRANSPORT) adds it for the virtual-rank
+ * tests.  P handles (cfg.nranks = P, rank = 0..P-1) inside ONE process on ONE device, each driven by its own host thread; ghost
+ * rows and all-to-all blocks move by device-to-device copies behind a barrier.  Lets the multi-slab code path be parity-tested
+ * on a single-GPU box.  udc_local_group_create returns a group id > 0 (or -1). */
 int udc_local_group_create(int nranks);
 int udc_comm_init_local(udc_handle *h, int group);
+#endif
 
 /* ---- host <-> device residency --------------------------------------------------- */
 int udc_field_upload(udc_handle *h, int field, const double *host, const int lb[3], const int ub[3]);

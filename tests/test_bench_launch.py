@@ -38,7 +38,8 @@ def test_launch_without_gpu_stops_on_every_rank():
         pytest.skip("this box has a GPU")
     r = launch(2, [], 300)
     assert r.returncode != 0
-    assert r.stderr.count("bench.py needs an MI355X") >= 2, r.stderr[-2000:]
+    # (torchrun tears the group down as soon as the first rank has left: the other may not get to print)
+    assert r.stderr.count("bench.py needs an MI355X") >= 1, r.stderr[-2000:]
 
 
 @pytest.mark.gpu

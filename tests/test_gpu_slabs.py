@@ -145,7 +145,15 @@ def synthetic_sections(g, grid, bnd):
     return S
 
 
-def run_virtual(P, g, deck_like, st_global, nsub, dt, sgs, nsv=0, extras=False):
+def run_virtual(*args, **kw):
+    """Virtual ranks need the in-process `local group` transport, which only libudcore_test.so has (the product library is built
+    without it): the whole run, handles included, lives inside lib.test_transport()."""
+    from udcore import lib as L
+    with L.test_transport():
+        return _run_virtual(*args, **kw)
+
+
+def _run_virtual(P, g, deck_like, st_global, nsub, dt, sgs, nsv=0, extras=False):
     """Run nsub substeps on P virtual ranks; returns the stitched global u0, v0, w0, pres0."""
     from udcore.core import DynCore
     from udcore import lib as L

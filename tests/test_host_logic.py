@@ -106,12 +106,22 @@ def test_header_symbols_are_exported():
         ge.build()
     with open(os.path.join(ROOT, "include", "udcore.h")) as f:
         hdr = f.read()
-    declared = set(re.findall(r"\b(udc_\w+)\s*\(", hdr))
+    # (the block under UDC_TEST_TRANSPORT declares the virtual-rank tests' transport, which only libudcore_test.so contains)
+    test_part = re.search(r"#ifdef UDC_TEST_TRANSPORT(.*?)#endif", hdr, re.S).group(1)
+    test_only = set(re.findall(r"\b(udc_\w+)\s*\(", test_part))
+    declared = set(re.findall(r"\b(udc_\w+)\s*\(", hdr)) - test_only
+    assert test_only == set(L.TEST_EXPORTS)
     assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
     lib = ctypes.CDLL(L.LIBPATH)
     for sym in sorted(declared):
         assert hasattr(lib, sym), sym
+    for sym in test_only:      # the shipped library does not carry test scaffolding
+        assert not hasattr(lib, sym), sym
     assert lib.udc_version() >= 100
+    if os.path.exists(L.TESTLIBPATH):
+        tl = ctypes.CDLL(L.TESTLIBPATH, mode=ctypes.RTLD_LOCAL)
+        for sym in sorted(declared | test_only):
+            assert hasattr(tl, sym), sym
 
 
 def test_no_device_fails_loudly():

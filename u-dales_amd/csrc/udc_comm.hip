@@ -4,7 +4,8 @@
 //
 //   * RCCL over xGMI (ncclSend/ncclRecv groups, ncclAllReduce) -- the production path; replaces
 //     2decomp-fft's MPI halo exchange and alltoall transposes.
-//   * "local group": P handles inside ONE process on ONE device, one host thread per virtual
+//   * "local group" (ONLY in libudcore_test.so, built with -DUDC_TEST_TRANSPORT; the product library does not
+//     contain it): P handles inside ONE process on ONE device, one host thread per virtual
 //     rank, buffers exchanged with device-to-device copies behind a pthread barrier.  It exists so
 //     that the multi-rank code path (packing, index maps, transposed spectral layout) can be
 //     parity-tested on a single-GPU box; everything except the byte mover is shared.
@@ -16,6 +17,7 @@
 #include <vector>
 #include <cstdlib>
 
+#ifdef UDC_TEST_TRANSPORT
 struct LocalGroup {
   int P;
   pthread_barrier_t bar;
@@ -26,6 +28,7 @@ struct LocalGroup {
 
 static std::mutex g_groups_mu;
 static std::vector<LocalGroup *> g_groups;
+#endif
 
 #define NCCL_OK(expr)                                                                     \
   do {                                                                                    \
@@ -61,6 +64,7 @@ extern "C" int udc_comm_init(udc_handle *h, const unsigned char id[128]) {
   return 0;
 }
 
+#ifdef UDC_TEST_TRANSPORT
 extern "C" int udc_local_group_create(int nranks) {
   if (nranks < 1 || nranks > 64) { udc_set_error("udc_local_group_create: 1..64 ranks"); return -1; }
   LocalGroup *g = new LocalGroup();
@@ -80,14 +84,15 @@ extern "C" int udc_comm_init_local(udc_handle *h, int group) {
   h->local_group = g_groups[group - 1];
   return 0;
 }
+#endif
 
 void comm_destroy(udc_handle *h) {
   if (h->nccl) { ncclCommDestroy((ncclComm_t)h->nccl); h->nccl = nullptr; }
 }
 
 static int need_comm(udc_handle *h) {
-  if (h->nccl || h->local_group) return 0;
-  udc_set_error("multi-rank handle used before udc_comm_init / udc_comm_init_local");
+  if (h->nccl || h->local_group) return 0;      // (local_group is only ever set by the test build)
+  udc_set_error("multi-rank handle used before udc_comm_init");
   return 1;
 }
 
@@ -115,6 +120,7 @@ int comm_neighbours(udc_handle *h, const double *to_prev, const double *to_next,
     NCCL_OK(ncclGroupEnd());
     return 0;
   }
+#ifdef UDC_TEST_TRANSPORT
   LocalGroup *g = (LocalGroup *)h->local_group;
   g->send[r][0] = to_prev; g->send[r][1] = to_next;
   HIP_OK(hipStreamSynchronize(h->stream));
@@ -124,6 +130,10 @@ int comm_neighbours(udc_handle *h, const double *to_prev, const double *to_next,
   HIP_OK(hipStreamSynchronize(h->stream));
   pthread_barrier_wait(&g->bar);
   return 0;
+#else
+  (void)prev; (void)next;
+  return need_comm(h) ? 1 : 1;
+#endif
 }
 
 // all-to-all of equal blocks: block d of `send` goes to rank d, arriving as block r of its `recv`
@@ -149,6 +159,7 @@ int comm_alltoall(udc_handle *h, const double *send, double *recv, size_t block,
     NCCL_OK(ncclGroupEnd());
     return 0;
   }
+#ifdef UDC_TEST_TRANSPORT
   LocalGroup *g = (LocalGroup *)h->local_group;
   g->send[r][2] = send;
   HIP_OK(hipStreamSynchronize(st));
@@ -159,6 +170,9 @@ int comm_alltoall(udc_handle *h, const double *send, double *recv, size_t block,
   HIP_OK(hipStreamSynchronize(st));
   pthread_barrier_wait(&g->bar);
   return 0;
+#else
+  return 1;
+#endif
 }
 
 // in-place all-reduce of n doubles held in device memory `buf`; op 0 = max, 1 = sum
@@ -170,6 +184,7 @@ int comm_allreduce(udc_handle *h, double *buf, int n, int op) {
                           h->stream));
     return 0;
   }
+#ifdef UDC_TEST_TRANSPORT
   LocalGroup *g = (LocalGroup *)h->local_group;
   const int P = h->cfg.nranks, r = h->cfg.rank;
   std::vector<double> out(4096);
@@ -188,4 +203,7 @@ int comm_allreduce(udc_handle *h, double *buf, int n, int op) {
     HIP_OK(hipStreamSynchronize(h->stream));
   }
   return 0;
+#else
+  return 1;
+#endif
 }
