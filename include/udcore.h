@@ -152,6 +152,9 @@ int udc_scalsource(udc_handle *h);
  * src/modwallfunctions.f90:92-127).  thl_kb = thlprof(kb); call before the first `bottom`. */
 int udc_set_floor_air_temperature(udc_handle *h, double thl_kb);
 int udc_set_floor_wf(udc_handle *h, int bcbotm, int bcbott, double thls, double z0h, double prandtlturb);
+/* The von Karman constant of every wall function -- the floor's (wfuno, wfmneutral: src/modwallfunctions.f90:72, 307) and the
+ * facets' (src/modibm.f90:1878, 1915, 1942): &WALLS fkar (src/modstartup.f90:152-153), default 0.41 (src/modglobal.f90:317). */
+int udc_set_fkar(udc_handle *h, double fkar);
 /* Total water, &PHYSICS lmoist (src/modglobal.f90:402): qt is advected (iadv_qt = 2 -> advecc_2nd,
  * src/modadvection.f90:78-86), diffused (diffc with ekh, src/modsubgrid.f90:147), integrated
  * (src/modtstep.f90:256) and given its top (BCtopq 1 = flux wqtop, 2 = value qt_top, src/modboundary.f90:222-231)

@@ -616,6 +616,13 @@ extern "C" int udc_set_moist_thermo(udc_handle *h, double thls, double qts, doub
   return 0;
 }
 
+extern "C" int udc_set_fkar(udc_handle *h, double fkar) {
+  ENTRY_FLUSH(h);
+  if (!(fkar > 0.)) { udc_set_error("udc_set_fkar: the von Karman constant must be positive"); return 1; }
+  h->fkar = fkar;
+  return 0;
+}
+
 extern "C" int udc_calthv(udc_handle *h) {
   ENTRY_FLUSH(h);
   return k_calthv_capture(h);

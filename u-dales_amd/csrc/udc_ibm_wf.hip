@@ -19,7 +19,7 @@ struct WfArgs {
   const double *area, *dist, *norm, *z0, *z0h, *tsurf, *recpt, *tmask;
   const double *u0, *v0, *w0, *thl0, *zf, *zh;      // zf, zh: entry 0 = reference index 1
   double *rhs;
-  double prt;
+  double prt, fkar;      // &WALLS prandtlturb, fkar (src/modglobal.f90:304, 317)
 };
 
 __device__ __forceinline__ int wx(int i, int nx) { return i < 0 ? i + nx : (i >= nx ? i - nx : i); }
@@ -45,8 +45,8 @@ __device__ __forceinline__ double trilinear(const Geo &g, const Metrics &m, cons
 }
 
 // mom_transfer_coef_stability, :1856-1904
-__device__ __forceinline__ double ctm_stability(double utan, double dist, double z0, double z0h, double Tair, double Tsurf, double prt) {
-  const double b1 = 9.4, b2 = 4.7, dm = 7.4, dh = 5.3, grav = 9.81, fkar = 0.41;
+__device__ __forceinline__ double ctm_stability(double utan, double dist, double z0, double z0h, double Tair, double Tsurf, double prt, double fkar) {
+  const double b1 = 9.4, b2 = 4.7, dm = 7.4, dh = 5.3, grav = 9.81;
   const double dT = Tair - Tsurf;
   const double Ribl0 = grav * dist * dT / (Tsurf * (utan * utan));
   const double logdz = log(dist / z0), logzh = log(z0 / z0h), sqdz = sqrt(dist / z0), fkar2 = fkar * fkar;
@@ -75,7 +75,7 @@ __global__ void ibm_wallfunmom_kernel(Geo g, Metrics m, WfArgs a) {
   if (q >= a.ncell) return;
   const int i = a.cell[3 * q], j = a.cell[3 * q + 1], k = a.cell[3 * q + 2], j0 = a.j0;
   const long c = g.idx(i - 1, j - 1 - j0, k - 1);
-  const double eps1 = 1.e-10, fkar = 0.41;
+  const double eps1 = 1.e-10, fkar = a.fkar;
   const double vol = m.dx * m.dy * m.dzf[k];
   double t = a.rhs[c];
   for (int s = a.off[q]; s < a.off[q + 1]; ++s) {
@@ -119,7 +119,7 @@ __global__ void ibm_wallfunmom_kernel(Geo g, Metrics m, WfArgs a) {
     const double st[3] = {sp[1] * nrm[2] - sp[2] * nrm[1], sp[2] * nrm[0] - sp[0] * nrm[2], sp[0] * nrm[1] - sp[1] * nrm[0]};
     const double utan = uv[0] * st[0] + uv[1] * st[1] + uv[2] * st[2];
     double ctm;
-    if (a.iwallmom == 2) ctm = ctm_stability(utan, dist, z0, a.z0h[s], Tair, a.tsurf[s], a.prt);
+    if (a.iwallmom == 2) ctm = ctm_stability(utan, dist, z0, a.z0h[s], Tair, a.tsurf[s], a.prt, a.fkar);
     else { const double l = fkar / log(dist / z0); ctm = l * l; }
     const double stress = ctm * (utan * utan);
     const double a_is = st[a.grid];                       // dot(dir, strm)
@@ -136,8 +136,8 @@ __global__ void ibm_wallfunmom_kernel(Geo g, Metrics m, WfArgs a) {
 }
 
 // heat_transfer_coef_flux, :1920-1986 -> flux [K m/s]
-__device__ __forceinline__ double heat_flux(double utan, double dist, double z0, double z0h, double Tair, double Tsurf, double prt) {
-  const double b1 = 9.4, b2 = 4.7, dm = 7.4, dh = 5.3, grav = 9.81, fkar = 0.41;
+__device__ __forceinline__ double heat_flux(double utan, double dist, double z0, double z0h, double Tair, double Tsurf, double prt, double fkar) {
+  const double b1 = 9.4, b2 = 4.7, dm = 7.4, dh = 5.3, grav = 9.81;
   const double dT = Tair - Tsurf;
   const double Ribl0 = grav * dist * dT / (Tsurf * (utan * utan));
   const double logdz = log(dist / z0), logzh = log(z0 / z0h), sqdz = sqrt(dist / z0), fkar2 = fkar * fkar;
@@ -200,7 +200,7 @@ __global__ void ibm_wallfunheat_kernel(Geo g, Metrics m, WfArgs a) {
     const double st[3] = {sp[1] * nrm[2] - sp[2] * nrm[1], sp[2] * nrm[0] - sp[0] * nrm[2], sp[0] * nrm[1] - sp[1] * nrm[0]};
     const double utan = uv[0] * st[0] + uv[1] * st[1] + uv[2] * st[2];
     // iwalltemp = 1: the prescribed flux of the facet's direction rides in the slot of the facet temperature
-    const double flux = a.iwallmom == 1 ? a.tsurf[s] : heat_flux(utan, dist, z0, a.z0h[s], Tair, a.tsurf[s], a.prt);
+    const double flux = a.iwallmom == 1 ? a.tsurf[s] : heat_flux(utan, dist, z0, a.z0h[s], Tair, a.tsurf[s], a.prt, a.fkar);
     t = t - flux * a.area[s] / vol;
   }
   a.rhs[c] = t;
@@ -313,7 +313,7 @@ int k_ibm_wallfunmom(udc_handle *h) {
     a.thl0 = h->ibm_iwallmom == 2 ? h->fields[UDC_THL0] : nullptr;
     a.zf = h->ibm_zgrid; a.zh = h->ibm_zgrid + (g.nz + 1);
     a.rhs = h->fields[UDC_UP + q];
-    a.prt = h->ibm_prt;
+    a.prt = h->ibm_prt; a.fkar = h->fkar;
     hipLaunchKernelGGL(ibm_wallfunmom_kernel, dim3((unsigned)((S.ncell + 127) / 128)), dim3(128), 0, h->stream, g, h->m, a);
   }
   HIP_OK(hipGetLastError());
@@ -344,7 +344,7 @@ int k_ibm_wallfunheat(udc_handle *h) {
   a.u0 = h->fields[UDC_U0]; a.v0 = h->fields[UDC_V0]; a.w0 = h->fields[UDC_W0]; a.thl0 = h->fields[UDC_THL0];
   a.zf = h->ibm_zgrid; a.zh = h->ibm_zgrid + (g.nz + 1);
   a.rhs = h->fields[UDC_THLP];
-  a.prt = h->ibm_prt;
+  a.prt = h->ibm_prt; a.fkar = h->fkar;
   hipLaunchKernelGGL(ibm_wallfunheat_kernel, dim3((unsigned)((S.ncell + 127) / 128)), dim3(128), 0, h->stream, g, h->m, a);
   HIP_OK(hipGetLastError());
   return 0;

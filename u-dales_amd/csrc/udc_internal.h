@@ -153,6 +153,7 @@ struct udc_handle {
   // floor wall function choice (udc_set_floor_wf): BCbotm 3 neutral / 2 wfuno, BCbotT 1 flux / 2 wfuno
   int floor_bcbotm = 3, floor_bcbott = 1;
   double floor_thls = 0., floor_z0h = 0., floor_prt = 0.71;
+  double fkar = 0.41;          // von Karman constant of every wall function (udc_set_fkar; &WALLS fkar, src/modglobal.f90:317)
   // temperature equation off: the reference's thl0 keeps prof.inp's values for ever and wfuno still reads its first level
   bool floor_thl_air_on = false;
   double floor_thl_air = 0.;

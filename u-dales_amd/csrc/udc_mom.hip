@@ -137,7 +137,7 @@ struct BottomArgs {
   double *svp[16];
   double flux[16];       // prescribed floor flux (0 for passive scalars, wtsurf for thl)
   int nsv, wrap_vp;
-  double z0;
+  double z0, fkar;      // fkar: von Karman constant (&WALLS fkar, src/modglobal.f90:317)
   // wfuno (UNO kernels): wall temperature, roughness length for heat, turbulent Prandtl number, the temperature the
   // stability is judged on, and which entry of sv0/svp is thl when its floor is the wall function too (BCbotT = 2), else -1
   double thls, z0h, prt;
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void bottom_kernel(Geo g, Metrics m, BottomArg
   const long cxm = c - i + (i == 0 ? g.nx - 1 : i - 1), cxp = c - i + (i == g.nx - 1 ? 0 : i + 1);
   const long sy = g.sy, sz = g.sz;
   const int k = 1, km = 0;                       // reference level indices of the metric tables
-  const double fkar2 = 0.41 * 0.41, umin = 0.0001;
+  const double fkar2 = a.fkar * a.fkar, umin = 0.0001;
   const double delta = 0.5 * m.dzf[k];
   const double l_ = log(delta / a.z0);
   const double logdz2 = l_ * l_;
@@ -327,7 +327,7 @@ int k_bottom(udc_handle *h, bool wrap_vp) {
   a.u0 = h->fields[UDC_U0]; a.v0 = h->fields[UDC_V0]; a.ekm = h->fields[UDC_EKM]; a.ekh = h->fields[UDC_EKH];
   a.up = h->fields[UDC_UP]; a.vp = h->fields[UDC_VP];
   a.nsv = 0; a.wrap_vp = wrap_vp ? 1 : 0; a.z0 = h->p.z0;
-  a.thls = h->floor_thls; a.z0h = h->floor_z0h; a.prt = h->floor_prt; a.thl_wf = -1; a.thl_slot = -1;
+  a.thls = h->floor_thls; a.z0h = h->floor_z0h; a.prt = h->floor_prt; a.fkar = h->fkar; a.thl_wf = -1; a.thl_slot = -1;
   a.tau_x = h->bottom_diag[0]; a.tau_y = h->bottom_diag[1]; a.thl_flux = h->bottom_diag[2];
   const bool have_thl = (int)h->fields.size() > UDC_THL0 && h->fields[UDC_THL0];
   a.thl0 = have_thl ? h->fields[UDC_THL0] : nullptr;

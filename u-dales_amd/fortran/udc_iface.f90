@@ -206,6 +206,11 @@ module udc_iface
       type(c_ptr), value :: h
       real(c_double), value :: thl_kb
     end function udc_set_floor_air_temperature
+    integer(c_int) function udc_set_fkar(h, fkar) bind(C, name='udc_set_fkar')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      real(c_double), value :: fkar
+    end function
     integer(c_int) function udc_set_floor_wf(h, bcbotm, bcbott, thls, z0h, prandtlturb) bind(C, name='udc_set_floor_wf')
       import :: c_ptr, c_int, c_double
       type(c_ptr), value :: h
@@ -459,7 +464,7 @@ contains
   subroutine udc_ensure
     use modglobal, only: itot, jtot, ktot, dx, dy, dzf, dzh, kb, ke, kh, numol, prandtlmoli, nsv, &
                          BCtopm, Uinf, Vinf, lles, ltempeq, lbuoyancy, lmoist, iadv_thl, BCtopT, BCbotT, grav, e12min, &
-                         iadv_qt, BCtopq, BCbotq, zf, zh, BCbotm, prandtlturb, BCtops, lchem, k1, JNO2, &
+                         iadv_qt, BCtopq, BCbotq, zf, zh, BCbotm, prandtlturb, fkar, BCtops, lchem, k1, JNO2, &
                          lcoriol, lprofforc, om22, om23, luvolflowr, lvvolflowr, uflowrate, vflowrate, &
                          lnudge, igrw_damp, ifixuinf, ds
     use modsurfdata, only: wttop, thl_top, wtsurf, thvs, wqtop, qt_top, wqsurf, thls, qts, ps, z0h, wsvtop, sv_top
@@ -537,6 +542,7 @@ contains
       end if
       call udc_check(udc_set_buoycorr(udc_h, 1_c_int, real(Rigc, c_double)), 'udc_set_buoycorr')
     end if
+    call udc_check(udc_set_fkar(udc_h, real(fkar, c_double)), 'udc_set_fkar')      ! &WALLS fkar: every wall function's von Karman constant
     if (udc_floor_on .and. (BCbotm == 2 .or. (ltempeq .and. BCbotT == 2))) then   ! wfuno floor (src/modibm.f90:2021-2045)
       call udc_check(udc_set_floor_wf(udc_h, int(BCbotm, c_int), int(BCbotT, c_int), real(thls, c_double), real(z0h, c_double), &
                                       real(prandtlturb, c_double)), 'udc_set_floor_wf')

@@ -31,8 +31,11 @@ def from_deck(deck, device=0, rank=0, nranks=1):
     if lbottom and bcbotm == 2 and not deck.get("PHYSICS", "ltempeq"):
         # the reference's thl0 stays at prof.inp's profile when the temperature equation is off; wfuno reads its first level
         core.set_floor_air_temperature(float(deck.thl[0]))
+    prt = float(deck.get("WALLS", "prandtlturb"))      # &WALLS prandtlturb, fkar (src/modstartup.f90:152-153; defaults prandtlmol, 0.41)
+    if deck.is_set("WALLS", "fkar"):
+        core.set_fkar(float(deck.get("WALLS", "fkar")))
     if lbottom and (bcbotm == 2 or (bcbott == 2 and deck.get("PHYSICS", "ltempeq"))):
-        core.set_floor_wf(bcbotm, bcbott, float(deck.get("BC", "thls")), float(deck.get("BC", "z0h")), 0.71)
+        core.set_floor_wf(bcbotm, bcbott, float(deck.get("BC", "thls")), float(deck.get("BC", "z0h")), prt)
     if deck.get("PHYSICS", "lmoist"):
         iadv = int(deck.get("DYNAMICS", "iadv_qt"))
         core.set_moisture(iadv_qt=int(deck.get("DYNAMICS", "iadv_mom")) if iadv < 0 else iadv,

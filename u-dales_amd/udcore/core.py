@@ -41,6 +41,7 @@ class DynCore:
         self.h = C.c_void_p()
         L._check(self.lib.udc_create(C.byref(cfg), C.byref(self.h)), "udc_create")
         self.nyl = g.ny // nranks
+        self.rank, self.nranks = rank, nranks
         self.rk3step = 0
         self.dt = 0.
         self.ltempeq = False
@@ -230,6 +231,10 @@ class DynCore:
     def set_floor_air_temperature(self, thl_kb):
         """ltempeq off + wfuno floor: the frozen temperature of the first level (include/udcore.h)."""
         L._check(self.lib.udc_set_floor_air_temperature(self.h, C.c_double(thl_kb)), "udc_set_floor_air_temperature")
+
+    def set_fkar(self, fkar):
+        """&WALLS fkar: the von Karman constant of the floor and facet wall functions (include/udcore.h udc_set_fkar)."""
+        L._check(self.lib.udc_set_fkar(self.h, C.c_double(fkar)), "udc_set_fkar")
 
     def set_floor_wf(self, bcbotm=3, bcbott=1, thls=-1., z0h=-1., prandtlturb=0.71):
         """Floor wall function choice of `bottom` (BCbotm 2 / BCbotT 2 = wfuno), see include/udcore.h udc_set_floor_wf."""

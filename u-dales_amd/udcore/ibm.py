@@ -81,13 +81,14 @@ def apply_ibm(core, deck):
         jtot = int(deck.get("DOMAIN", "jtot"))
         gg = g if g.ny == jtot else type(g).from_deck(deck)
         mask = c_mask(gg.nx, gg.ny, gg.nz, lists["c"][0] if "c" in lists else [], wrapx, wrapy)
-        core.set_ibm_wallfun(iwallmom, 0.71, gg.zf[1:gg.nz + 2], gg.zh[1:gg.nz + 2])
+        lnorec = bool(deck.get("WALLS", "lnorec"))      # &WALLS lnorec: no reconstruction points (src/modibm.f90:380, 1345, 1481)
+        core.set_ibm_wallfun(iwallmom, float(deck.get("WALLS", "prandtlturb")), gg.zf[1:gg.nz + 2], gg.zh[1:gg.nz + 2])
         if iwallmom > 1:
             for q, gr in enumerate("uvw"):
-                S = wall_sections(deck, gg, gr, lists[gr][1], facets)
+                S = wall_sections(deck, gg, gr, lists[gr][1], facets, lnorec)
                 core.set_ibm_sections(q, S, facets, temperature_masks(gr, S, mask))
         if heat:
-            S = wall_sections(deck, gg, "c", lists["c"][1], facets)
+            S = wall_sections(deck, gg, "c", lists["c"][1], facets, lnorec)
             if iwalltemp == 1:      # prescribed fluxes ride in the slot of the facet temperature
                 from .facets import prescribed_fluxes
                 nf = np.asarray(S["fac"]) - 1

@@ -34,7 +34,8 @@ DEFAULTS = {
                    lfielddump=False, tfielddump=10000., fieldvars="", lydump=False, lytdump=False, lxydump=False, ltkedump=False,
                    lkslicedump=False, lislicedump=False, ljslicedump=False),
     "WALLS": dict(nfcts=-1, lbottom=False, iwallmom=2, iwalltemp=1, iwallmoist=1, nsolpts_u=0, nsolpts_v=0, nsolpts_w=0, nsolpts_c=0,
-                  nbndpts_u=0, nbndpts_v=0, nbndpts_w=0, nbndpts_c=0),
+                  nbndpts_u=0, nbndpts_v=0, nbndpts_w=0, nbndpts_c=0, nfctsecs_u=0, nfctsecs_v=0, nfctsecs_w=0, nfctsecs_c=0,
+                  lnorec=False, prandtlturb=0.71, fkar=0.41, lwritefac=False),      # src/modglobal.f90:304 (= prandtlmol), 317; src/modibm.f90:50
     "ORACLE": dict(nsub=3, nspin=2, lforces=True, scal_a=1.0, scal_b=0.0),      # (scal_a, scal_b: the linear stand-in profile of decks without a scalar.inp)
 }
 GEODAMPTIME = 7200.      # src/modglobal.f90 (not a namelist variable)
@@ -73,7 +74,8 @@ KNOWN = {
 KNOWN = {g: {n.lower() for n in v.split()} for g, v in KNOWN.items()}
 # Switches of features that have no device implementation: a deck that turns one on is refused (udcore.run,
 # check_supported) instead of silently running different physics.  (group, name, value that means "off")
-UNSUPPORTED = [("RUN", "lstratstart", False), ("RUN", "lper2inout", False), ("RUN", "lreadmean", False),
+UNSUPPORTED = [("WALLS", "lwritefac", False),      # facet statistics (fac.NNN.nc): host code of the reference, not on the device path
+               ("RUN", "lstratstart", False), ("RUN", "lper2inout", False), ("RUN", "lreadmean", False),
                ("PHYSICS", "ltimedepsurf", False), ("PHYSICS", "ltimedepnudge", False), ("PHYSICS", "ltimedeplw", False),
                ("PHYSICS", "ltimedepsw", False), ("PHYSICS", "luoutflowr", False), ("PHYSICS", "lvoutflowr", False),
                ("DRIVER", "idriver", 0), ("INLET", "linletRA", False), ("INLET", "lstoreplane", False),

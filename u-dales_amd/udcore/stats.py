@@ -190,17 +190,22 @@ class TDump:
         return what
 
     def write(self):
-        if self.yt_on:
+        """The reference's naming (src/modstatsdump.f90:320-365): the 3-D sets are per rank -- tdump.<myidx>.<myidy>.<expnr>, each rank
+        its own slab --, the tables of global reductions (xytdump, ytdump) are written once, by rank 0.  A single-rank run keeps the
+        short names tdump.<expnr> / mintdump.<expnr>."""
+        rank, nranks = getattr(self.core, "rank", 0), getattr(self.core, "nranks", 1)
+        tag = f"000.{rank:03d}." if nranks > 1 else ""
+        if self.yt_on and rank == 0:
             np.savez(os.path.join(self.wdir, f"ytdump.{self.expnr:03d}.npz"), time=np.array([t for t, _ in self.yt_dumps]),
                      **{k: np.array([o[k] for _, o in self.yt_dumps]) for k in self.yt_dumps[0][1]})
         if self.mint:
             keep = [k for k in ("ut", "vt", "wt", "thlt", "qtt", "pt") if k in self.dumps[0][1]]
-            np.savez(os.path.join(self.wdir, f"mintdump.{self.expnr:03d}.npz"), time=np.array([t for t, _ in self.dumps]),
+            np.savez(os.path.join(self.wdir, f"mintdump.{tag}{self.expnr:03d}.npz"), time=np.array([t for t, _ in self.dumps]),
                      **{k: np.array([o[k] for _, o in self.dumps]).astype(np.float32) for k in keep})
-        if self.xyt_on:
+        if self.xyt_on and rank == 0:
             np.savez(os.path.join(self.wdir, f"xytdump.{self.expnr:03d}.npz"), time=np.array([t for t, _ in self.xyt_dumps]),
                      **{k: np.array([o[k] for _, o in self.xyt_dumps]) for k in self.xyt_dumps[0][1]})
-        base = os.path.join(self.wdir, f"tdump.{self.expnr:03d}")
+        base = os.path.join(self.wdir, f"tdump.{tag}{self.expnr:03d}")
         flat = {"time": np.array([t for t, _ in self.dumps])}
         for q, (_, o) in enumerate(self.dumps):
             for k, v in o.items():
