@@ -397,6 +397,10 @@ int udc_set_scalar_bcx(udc_handle *h, int bcxs, const double *svprof, double uou
  * points.  wlev[ktot]; evaluated on the device at the start of every substep.  NULL: back to the constant of udc_set_scalar_bcx. */
 int udc_set_scalar_bcx_outflow(udc_handle *h, const double *wlev);
 
+/* checksim's diagnostics (src/modchecksim.f90:76-203) of the state on the device: out[0] = calccourant's number -- the maximum of the
+ * SIGNED sum (um dxhi + vm dyi + wm dzhi) dtmn, :111-117 --, out[1] = calcdiffnr's (:142-149), out[2], out[3] = chkdiv's divmax and
+ * divtot of u0, v0, w0 (:179-196); dtmn: the mean time step since the last report (:83, :86). */
+int udc_checksim(udc_handle *h, double dtmn, double out[4]);
 /* divergence of u0 as modchecksim's chkdiv (src/modchecksim.f90:161-203): max |div|, sum div */
 int udc_divergence(udc_handle *h, double *divmax, double *divtot);
 

@@ -34,7 +34,7 @@ def test_run_decks_through_the_reference_program(name, iexp, residency, tmp_path
         pytest.skip("oracle/_ref/udales_full_dropin not built (needs the reference sources + flang)")
     if residency == 0 and name not in ("run_16x16x8", "run_ibm_wf2_16x12x10", "run_moist_16x8x12s", "run_stats_16x8x12s", "run_bcxs_16x8x12s"):
         pytest.skip("strict residency: a selection of decks")
-    env = dict(os.environ, UDC_RESIDENCY=str(residency), UDC_PULL_EVERY="1")
+    env = dict(os.environ, UDC_RESIDENCY=str(residency))
     fix, last, rs, _ = run_full(name, iexp, tmp_path, exe=DROPIN, env=env)
     nz = int(fix["meta"].data[2])
     tol = 1e-9
@@ -73,7 +73,8 @@ def test_example_999_through_the_reference_program(tmp_path):
     txt = re.sub(r"nprocx\s*=\s*\d+", "nprocx = 1", re.sub(r"nprocy\s*=\s*\d+", "nprocy = 1", txt))
     txt = re.sub(r"runtime\s*=\s*[0-9.]+", "runtime = 11.", re.sub(r"trestart\s*=\s*[0-9.]+", "trestart = 10.9", txt))
     deck.write_text(txt)
-    env = dict(os.environ, UDC_RESIDENCY="2", UDC_PULL_EVERY="1")
+    # (device resident; the host arrays are refreshed on the steps on which the untouched statsdump / fielddump look at them)
+    env = dict(os.environ, UDC_RESIDENCY="2")
     r = subprocess.run(f"ulimit -s unlimited; exec {DROPIN} namoptions.999", shell=True, cwd=tmp_path, capture_output=True, text=True,
                        timeout=1500, executable="/bin/bash", env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -41,7 +41,8 @@ def test_100_steps_against_reference_cpu(tmp_path):
     ref = read_dump(os.path.join(tmp_path, "ref.bin"))
     d = read_deck(path)
     core = udcore.from_deck(d)
-    core.load_state(cold_start(core.g, d))
+    core.load_state(cold_start(core.g, d, pre_boundary=True))
+    core.start_up()
     core.run(nsub, float(d.get("RUN", "dtmax")), 1, True)
     worst = {}
     for k in ("u0", "v0", "w0", "pres0"):
@@ -57,7 +58,8 @@ def test_100_steps_against_reference_cpu(tmp_path):
 
 def test_100_steps_all_physics_against_reference_cpu(tmp_path):
     """The same acceptance with every built physics option switched on at once: temperature and total water with the
-    moist thermodynamics (a cloud layer near the floor), buoyancy, the stability-dependent floor wall function, Coriolis,
+    moist thermodynamics (a cloud layer near the floor), buoyancy, the stability-dependent floor wall function (&WALLS iwalltemp = 2:
+    with the default of 1 checkinitvalues makes the floor neutral, src/modstartup.f90:811-816), Coriolis,
     large-scale subsidence, nudging, the gravity-wave sponge, a kappa scalar -- 300 RK3 substeps against the
     reference's own Fortran on identical namoptions."""
     if not os.path.exists(REF):
@@ -116,6 +118,7 @@ wqsurf = 3.e-5
 &WALLS
 nfcts = 0
 lbottom = .true.
+iwalltemp = 2
 /
 &SCALARS
 nsv = 1
@@ -133,6 +136,10 @@ dump_at = {nsub}
         for k in range(nz):
             z = (k + 0.5) * dz
             f.write(f"{z:.15f} {288.0 + 0.05 * z!r} {0.0116 - 4e-5 * z!r} 1.0 0.0 0.0\n")
+    with open(tmp_path / "scalar.inp.078", "w") as f:
+        f.write("# all physics\n# z sv1\n")
+        for k in range(nz):
+            f.write(f"{(k + 0.5) * dz:.15f} {(k + 0.5) / nz!r}\n")
     with open(tmp_path / "lscale.inp.078", "w") as f:
         f.write("# all physics\n# z uq vq pqx pqy wfls dqtdxls dqtdyls dqtdtls dthlrad\n")
         for k in range(nz):
@@ -144,8 +151,9 @@ dump_at = {nsub}
     ref = read_dump(os.path.join(tmp_path, "ref.bin"))
     d = read_deck(str(tmp_path / "namoptions.078"))
     core = udcore.from_deck(d)
-    core.load_state(cold_start(core.g, d, nsv=1))
+    core.load_state(cold_start(core.g, d, nsv=1, pre_boundary=True))      # the reference's start-up order: the fields as read,
     ls = LevelForcings(core, d)
+    core.start_up(before_boundary=ls.capture_startup)                       # thermodynamics (and diagfld's averages), then boundary
     assert ls.active and ls.subsidence and core.moist_thermo
     dt = float(d.get("RUN", "dtmax"))
     for isub in range(nsub):

@@ -332,6 +332,7 @@ extern "C" int udc_field_upload(udc_handle *h, int field, const double *host, co
   ENTRY_FLUSH(h);
   if (copy3d(h, field, const_cast<double *>(host), lb, ub, true)) return 1;
   if (field == UDC_EKM || field == UDC_EKH) h->ek_stale = false;
+  if (field == UDC_EKH) h->ekh_stale = false;
   if (h->scal_bcx == 2 && field >= UDC_SV0 && (field - UDC_SV0) % 3 == 0)      // sv0 with its east ghost columns (BCxs = 2)
     return k_scalar_bcx_capture(h, (field - UDC_SV0) / 3, host, lb, ub);
   return 0;
@@ -376,16 +377,16 @@ extern "C" int udc_set_scalar_bcx(udc_handle *h, int bcxs, const double *svprof,
 // ekm / ekh in memory are those of the last substep that wrote them: RK stages 1 and 2 of a substep whose closure ran inside
 // the momentum sweep keep them in LDS only (udc_mom_fused.hip).  Nothing of the reference's loop looks at them there; a caller
 // that does is told so instead of being handed an older substep's values.
-static int ek_current(udc_handle *h, const char *who) {
-  if (!h->ek_stale) return 0;
-  udc_set_error("%s: ekm / ekh were not written by the last substep (RK stage 1 or 2 with the closure evaluated inside the "
-                "momentum sweep); set UDC_EK_ALWAYS=1 before udc_create to have every substep write them", who);
+static int ek_current(udc_handle *h, const char *who, bool ekh_only = false) {
+  if (!h->ek_stale && !(h->ekh_stale && ekh_only)) return 0;
+  udc_set_error("%s: ekm / ekh were not (both) written by the last substep -- an RK stage 1 or 2 in which nothing of the reference's "
+                "loop reads them; set UDC_EK_ALWAYS=1 before udc_create to have every substep write them", who);
   return 1;
 }
 
 extern "C" int udc_field_download(udc_handle *h, int field, double *host, const int lb[3], const int ub[3]) {
   ENTRY_FLUSH(h);
-  if ((field == UDC_EKM || field == UDC_EKH) && ek_current(h, "udc_field_download")) return 1;
+  if ((field == UDC_EKM || field == UDC_EKH) && ek_current(h, "udc_field_download", field == UDC_EKH)) return 1;
   if (copy3d(h, field, host, lb, ub, false)) return 1;
   if (h->scal_bcx == 2 && field >= UDC_SV0 && (field - UDC_SV0) % 3 == 0)      // sv0: its x ghost columns under BCxs = 2
     return k_scalar_bcx_fill_host(h, (field - UDC_SV0) / 3, host, lb, ub);
@@ -458,7 +459,7 @@ static int now_subgrid(udc_handle *h) {
   if (k_closure(h)) return 1;
   if (h->lbuoycorr && k_vreman_buoycorr(h)) return 1;
   if (k_ek_ghosts(h)) return 1;
-  h->ek_stale = false;
+  h->ek_stale = h->ekh_stale = false;
   if (k_top_rows_after_closure(h)) return 1;
   if ((h->mom_simple ? k_momentum(h, false, true, false) : k_momentum_lds(h, false, true, false, false, 0.))) return 1;
   if (k_scalar_top_flux(h)) return 1;      // reassure_fluxtop_boundary for a non-zero thl top flux (uses the new ekh)
@@ -920,8 +921,15 @@ extern "C" int udc_boundary(udc_handle *h) {
 
 extern "C" int udc_tstep_maxima(udc_handle *h, double dt, double *courtot, double *diffnrtot) {
   ENTRY_FLUSH(h);
-  if (ek_current(h, "udc_tstep_maxima")) return 1;
+  if (ek_current(h, "udc_tstep_maxima", true)) return 1;
   return k_maxima(h, dt, courtot, diffnrtot);
+}
+
+extern "C" int udc_checksim(udc_handle *h, double dtmn, double out[4]) {
+  ENTRY_FLUSH(h);
+  if (ek_current(h, "udc_checksim", true)) return 1;
+  if (k_maxima(h, dtmn, &out[0], &out[1], true)) return 1;
+  return k_divergence_check(h, &out[2], &out[3]);
 }
 
 extern "C" int udc_divergence(udc_handle *h, double *divmax, double *divtot) {
@@ -963,11 +971,15 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   if (fold && pup && fused_closure_possible(h)) {
     const bool emit = h->ek_always || rk3step == 3 || !h->slots.empty() || h->ibm_on || h->stats_on || h->xyt_on || h->yt_on;
     if (k_momentum_closure(h, forces, 1. / rk3coef, rotate, emit)) return 1;
-    h->ek_stale = !emit;
+    h->ek_stale = !emit; h->ekh_stale = !emit;
   } else {
     // closure first: it only needs u0,v0,w0, and the momentum sweep below needs ekm
+    h->ekh_stale = false;
     if (fold && h->p.sgs != UDC_SGS_DNS && h->p.sgs != UDC_SGS_ONEEQN && !h->lbuoycorr) {
-      if (k_closure_lds(h, true)) return 1;
+      // ekh has readers only where a scalar is transported, or between time steps (maxima, statistics, restart files: RK stage 3)
+      const bool need_ekh = h->ek_always || rk3step == 3 || !h->slots.empty() || h->stats_on || h->xyt_on || h->yt_on;
+      if (k_closure_lds(h, true, need_ekh)) return 1;
+      h->ekh_stale = !need_ekh;
     } else {
       if (k_closure(h)) return 1;
       if (h->lbuoycorr && k_vreman_buoycorr(h)) return 1;      // before closurebc, as in the reference

@@ -186,6 +186,7 @@ struct udc_handle {
   bool no_fold = false;                 // UDC_NO_FOLD=1: keep separate ghost-row kernels on a single slab (A/B switch)
   bool no_pup = false;                  // UDC_NO_PUP=1: keep bare tendencies in the fused substep (A/B switch)
   bool mom_simple = false;              // UDC_MOM_SIMPLE=1: use the direct-load momentum kernel
+  bool ekh_stale = false;               // the last closure wrote ekm only (no reader of ekh in that substep)
   bool ek_stale = false;                // the last fused substep kept ekm / ekh in LDS only: the arrays hold an older substep's values
   bool ek_always = false;               // UDC_EK_ALWAYS=1: every substep writes ekm / ekh
   bool no_fused_closure = true;         // UDC_FUSED_CLOSURE=1 turns the one-kernel closure + momentum sweep on (A/B switch; slower as measured)
@@ -314,7 +315,7 @@ struct ProfScope {
 
 // ---- kernels (udc_mom.hip, udc_pois.hip, udc_scalar.hip, udc_halo.hip)
 int k_closure(udc_handle *h);
-int k_closure_lds(udc_handle *h, bool ghosts);   // ghosts: closurebc folded in (single slab)
+int k_closure_lds(udc_handle *h, bool ghosts, bool write_ekh = true);   // ghosts: closurebc folded in (single slab); write_ekh false: ekm only
 int k_ek_ghosts(udc_handle *h);
 int k_momentum(udc_handle *h, bool adv, bool diff, bool forces);       // direct-load version (UDC_MOM_SIMPLE=1)
 int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, double rk3coefi, bool um_is_u0 = false);  // rk3coefi != 0: PUP mode   // LDS-staged k-marching version (default)
@@ -369,7 +370,7 @@ int k_ibm_wallfunheat(udc_handle *h);
 void ibm_wf_destroy(udc_handle *h);
 int udc_flush_pending(udc_handle *h);
 int k_tke_floor(udc_handle *h);                    // e120(kb-1) = e120(kb), e12m likewise (`bottom`)                     // wp += grav (thv0h - thvh)/thvh, src/modforces.f90:73-84   // cp(i,j,k) += src(k)
-int k_maxima(udc_handle *h, double dt, double *cour, double *diffn);
+int k_maxima(udc_handle *h, double dt, double *cour, double *diffn, bool checksim = false);
 int k_divergence_check(udc_handle *h, double *divmax, double *divtot);
 int pois_init(udc_handle *h);
 int pois_slab_init(udc_handle *h);

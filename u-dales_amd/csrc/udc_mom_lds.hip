@@ -240,7 +240,9 @@ struct LdsAcc {      // neighbour access from the three staged planes (pointers 
 };
 
 // Same marching/staging scheme as mom_lds_kernel for u0, v0, w0; writes ekm, ekh.
-template <int SGS>
+// EKH = false: ekh is not written (nothing reads it in this substep: no transported scalar, not the stage whose fields the
+// time-step maxima / statistics / restart files see) -- 8 of the kernel's 40 B per cell.
+template <int SGS, bool EKH>
 __global__ __launch_bounds__(NT) void closure_lds_kernel(Geo g, TileGrid tg, Metrics m, Params pr,
     const double *__restrict__ gu, const double *__restrict__ gv, const double *__restrict__ gw,
     double *__restrict__ ekm, double *__restrict__ ekh, int kc, int ghosts) {
@@ -318,24 +320,24 @@ __global__ __launch_bounds__(NT) void closure_lds_kernel(Geo g, TileGrid tg, Met
       closure_arith<SGS>(A, m, lm, pr, k, em, eh);
       const long c = g.sz * (long)(k + HZ) + own_off;
       ekm[c] = em;
-      ekh[c] = eh;
+      if (EKH) ekh[c] = eh;
       if (ghosts) {
         // closurebc (src/modboundary.f90:447-500) folded in when the slab is the whole domain in y:
         // periodic ghost rows and the bottom/top ghost planes are written by the owning thread.
         const long up_row = (long)g.sy * g.ny, dn_row = -(long)g.sy * g.ny;
         const long wr = (j == 0) ? up_row : ((j == g.ny - 1) ? dn_row : 0);   // ny >= 4, so at most one
-        if (wr) { ekm[c + wr] = em; ekh[c + wr] = eh; }
+        if (wr) { ekm[c + wr] = em; if (EKH) ekh[c + wr] = eh; }
         const double nm = pr.numol, nh = pr.numol * pr.prandtlmoli;
         if (k == 0) {
           const double gm = 2. * nm - em, gh = (2. * nh) - eh;
-          ekm[c - g.sz] = gm; ekh[c - g.sz] = gh;
-          if (wr) { ekm[c - g.sz + wr] = gm; ekh[c - g.sz + wr] = gh; }
+          ekm[c - g.sz] = gm; if (EKH) ekh[c - g.sz] = gh;
+          if (wr) { ekm[c - g.sz + wr] = gm; if (EKH) ekh[c - g.sz + wr] = gh; }
         }
         if (k == g.nz - 1) {
           const double gm = pr.bctopm == UDC_TOP_NOSLIP ? 2. * nm - em : em;
           const double gh = pr.bctopm == UDC_TOP_NOSLIP ? (2. * nh) - eh : eh;
-          ekm[c + g.sz] = gm; ekh[c + g.sz] = gh;
-          if (wr) { ekm[c + g.sz + wr] = gm; ekh[c + g.sz + wr] = gh; }
+          ekm[c + g.sz] = gm; if (EKH) ekh[c + g.sz] = gh;
+          if (wr) { ekm[c + g.sz + wr] = gm; if (EKH) ekh[c + g.sz + wr] = gh; }
         }
       }
     }
@@ -361,7 +363,7 @@ static int pick_kc(const Geo &g, const TileGrid &tg, int per_cu) {
   return best;
 }
 
-int k_closure_lds(udc_handle *h, bool ghosts) {
+int k_closure_lds(udc_handle *h, bool ghosts, bool write_ekh) {
   const Geo &g = h->g;
   const TileGrid tg = lds_tile_grid(g);
   // 90 VGPRs, 32 640 B LDS: five workgroups fit a CU.  Measured: 512x512x256 0.634 -> 0.592 ms, 1024x512x512 2.60 -> 2.38 ms
@@ -373,10 +375,14 @@ int k_closure_lds(udc_handle *h, bool ghosts) {
   double *u = h->fields[UDC_U0], *v = h->fields[UDC_V0], *w = h->fields[UDC_W0];
   double *ekm = h->fields[UDC_EKM], *ekh = h->fields[UDC_EKH];
   PROF(h, "closure");
-  if (h->p.sgs == UDC_SGS_SMAGORINSKY)
-    hipLaunchKernelGGL((closure_lds_kernel<1>), gr, b, 0, h->stream, g, tg, h->m, h->p, u, v, w, ekm, ekh, kc, ghosts ? 1 : 0);
-  else
-    hipLaunchKernelGGL((closure_lds_kernel<2>), gr, b, 0, h->stream, g, tg, h->m, h->p, u, v, w, ekm, ekh, kc, ghosts ? 1 : 0);
+  const int gh = ghosts ? 1 : 0;
+  if (h->p.sgs == UDC_SGS_SMAGORINSKY) {
+    if (write_ekh) hipLaunchKernelGGL((closure_lds_kernel<1, true>), gr, b, 0, h->stream, g, tg, h->m, h->p, u, v, w, ekm, ekh, kc, gh);
+    else hipLaunchKernelGGL((closure_lds_kernel<1, false>), gr, b, 0, h->stream, g, tg, h->m, h->p, u, v, w, ekm, ekh, kc, gh);
+  } else {
+    if (write_ekh) hipLaunchKernelGGL((closure_lds_kernel<2, true>), gr, b, 0, h->stream, g, tg, h->m, h->p, u, v, w, ekm, ekh, kc, gh);
+    else hipLaunchKernelGGL((closure_lds_kernel<2, false>), gr, b, 0, h->stream, g, tg, h->m, h->p, u, v, w, ekm, ekh, kc, gh);
+  }
   HIP_OK(hipGetLastError());
   return 0;
 }

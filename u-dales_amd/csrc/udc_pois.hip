@@ -954,7 +954,9 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const double *__r
   block_reduce2<OP0, OP1>(a, b, out);
 }
 
-// tstep_update, src/modtstep.f90:113-128
+// tstep_update, src/modtstep.f90:113-128; CHECKSIM: the diagnostics of checksim instead (calccourant, src/modchecksim.f90:102-127: the
+// SIGNED sum um dxhi + vm dyi + wm dzhi; calcdiffnr, :130-157: 1 / dzh(k)**2 formed on the spot)
+template <bool CHECKSIM>
 __global__ __launch_bounds__(256) void maxima_kernel(Geo g, TileGrid tg, Metrics m, double dt, const double *__restrict__ um,
     const double *__restrict__ vm, const double *__restrict__ wm, const double *__restrict__ ekm,
     const double *__restrict__ ekh, double *__restrict__ out) {
@@ -963,9 +965,16 @@ __global__ __launch_bounds__(256) void maxima_kernel(Geo g, TileGrid tg, Metrics
   double cour = 0., dif = 0.;
   if (inside_) {
     const long c = g.idx(i, j, k);
-    cour = (fabs(um[c]) * m.dxi + fabs(vm[c]) * m.dyi + fabs(wm[c]) / m.dzh[k + 1]) * dt;
-    const double f = (m.dzh2i[k + 1] + m.dx2i + m.dy2i);
-    dif = fmax(ekm[c] * f * dt, ekh[c] * f * dt);
+    if (CHECKSIM) {
+      cour = (um[c] * m.dxi + vm[c] * m.dyi + wm[c] * m.dzhi[k + 1]) * dt;
+      const double dzh = m.dzh[k + 1];
+      const double f = (1 / (dzh * dzh) + m.dx2i + m.dy2i);
+      dif = fmax(ekm[c] * f * dt, ekh[c] * f * dt);
+    } else {
+      cour = (fabs(um[c]) * m.dxi + fabs(vm[c]) * m.dyi + fabs(wm[c]) / m.dzh[k + 1]) * dt;
+      const double f = (m.dzh2i[k + 1] + m.dx2i + m.dy2i);
+      dif = fmax(ekm[c] * f * dt, ekh[c] * f * dt);
+    }
   }
   block_reduce2<0, 0>(cour, dif, out);
 }
@@ -1552,16 +1561,20 @@ int k_masscorr(udc_handle *h, double rk3coef, bool pup_mode, bool wrap_vp) {
   return 0;
 }
 
-int k_maxima(udc_handle *h, double dt, double *cour, double *diffn) {
+int k_maxima(udc_handle *h, double dt, double *cour, double *diffn, bool checksim) {
   const Geo &g = h->g;
   dim3 b(64, 4, 1), gr = cell_grid(g, b);
   if (ensure_partials(h, gr.x)) return 1;
   const int mo = h->um_alias ? UDC_U0 : UDC_UM;      // aliased: um == u0
-  hipLaunchKernelGGL(maxima_kernel, gr, b, 0, h->stream, g, tile_grid(g), h->m, dt, h->fields[mo], h->fields[mo + 1],
-                     h->fields[mo + 2], h->fields[UDC_EKM], h->fields[UDC_EKH], h->partials);
-  // diffnrtotl starts at 1e-5, src/modtstep.f90:115
+  if (checksim)
+    hipLaunchKernelGGL(maxima_kernel<true>, gr, b, 0, h->stream, g, tile_grid(g), h->m, dt, h->fields[mo], h->fields[mo + 1],
+                       h->fields[mo + 2], h->fields[UDC_EKM], h->fields[UDC_EKH], h->partials);
+  else
+    hipLaunchKernelGGL(maxima_kernel<false>, gr, b, 0, h->stream, g, tile_grid(g), h->m, dt, h->fields[mo], h->fields[mo + 1],
+                       h->fields[mo + 2], h->fields[UDC_EKM], h->fields[UDC_EKH], h->partials);
+  // diffnrtotl starts at 1e-5, src/modtstep.f90:115 (checksim's at 0, src/modchecksim.f90:141)
   hipLaunchKernelGGL((reduce_partials_kernel<0, 0>), dim3(1), dim3(1024), 0, h->stream, h->partials, (long)gr.x, 0.,
-                     1e-5, h->red);
+                     checksim ? 0. : 1e-5, h->red);
   HIP_OK(hipGetLastError());
   if (comm_allreduce(h, h->red, 2, 0)) return 1;     // MPI_ALLREDUCE(MAX), src/modtstep.f90:131-132
   HIP_OK(hipMemcpyAsync(h->red_host, h->red, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -16,6 +16,7 @@ module modboundary
   public :: initboundary, boundary, grwdamp, ksp, tqaver, halos, bcp, bcpup, closurebc, &
             xm_periodic, xT_periodic, xq_periodic, xs_periodic, ym_periodic, yT_periodic, yq_periodic, ys_periodic
   integer :: ksp = -1                 !< lowest level of the sponge layer (&DOMAIN ksp; -1 = default)
+  real :: stat_clock = 0.             !< mirror of statsdump's sampling clock tsamplep (private to modstatsdump, src/modstatsdump.f90:65)
   real, allocatable :: tsc(:)         !< damping coefficients of grwdamp
   real :: rnu0 = 2.75e-3
 
@@ -44,21 +45,45 @@ contains
 
   !> periodic ghost cells of the prognostic fields (src/modboundary.f90:67-109)
   subroutine halos
-    use modglobal, only: rk3step, timeleft, ntrun
+    use modglobal, only: rk3step, timeleft, ntrun, timee, lfielddump, tnextfielddump
     use udc_iface
+    logical :: due
     call udc_begin(.false.)
     call udc_check(udc_halos(udc_h), 'udc_halos')
     if (udc_mode() <= 1) then
       call udc_pull_vel(.true.)
     else if (rk3step == 3) then
-      ! device mode: checksim, fielddump and statsdump come next (src/program.f90:199-205) and read the host arrays
-      if (timeleft <= 0) then
+      ! device mode: checksim, fielddump and statsdump come next (src/program.f90:199-205) and read the host arrays.  They are
+      ! refreshed when the run ends, every UDC_PULL_EVERY steps, and -- so that the untouched statsdump samples the state it
+      ! would sample in an all-host run -- on exactly the steps on which it takes a sample
+      due = stats_sample_due()
+      if (lfielddump .and. timee >= tnextfielddump) due = .true.      ! fielddump's own condition (src/modfielddump.f90:392-396)
+      if (timeleft <= 0 .or. due) then
         call udc_pull_all
       else if (udc_pull_every > 0) then
         if (mod(ntrun, udc_pull_every) == 0) call udc_pull_all
       end if
     end if
   end subroutine halos
+
+  !> statsdump's sampling clock (src/modstatsdump.f90:738-741, 797-805, 1394-1397), kept in step here because the module keeps
+  !! its own private: true on the steps on which the statsdump call that follows `halos` takes a sample.  Called once per RK
+  !! stage 3, like the lines it mirrors.
+  logical function stats_sample_due()
+    use modglobal, only: timee, dt, tsample, tstatstart, lydump, lytdump, lxydump, lxytdump, ltdump, lmintdump, &
+                         lkslicedump, lislicedump, ljslicedump, ltreedump
+    stats_sample_due = .false.
+    if (timee < tstatstart) return
+    if (.not. (lydump .or. lytdump .or. lxydump .or. lxytdump .or. ltdump .or. lmintdump &
+               .or. lkslicedump .or. lislicedump .or. ljslicedump .or. ltreedump)) return
+    if (stat_clock == 0. .and. tsample <= dt) stat_clock = dt
+    if (stat_clock >= tsample) then
+      stats_sample_due = .true.
+      stat_clock = dt
+    else
+      stat_clock = stat_clock + dt
+    end if
+  end function stats_sample_due
 
   !> w(kb) = 0 and the top ghost planes (src/modboundary.f90:115-247, periodic lateral subset)
   subroutine boundary

@@ -301,6 +301,12 @@ module udc_iface
       type(c_ptr), value :: h
       real(c_double), intent(out) :: divmax, divtot
     end function
+    integer(c_int) function udc_checksim(h, dtmn, d) bind(C, name='udc_checksim')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      real(c_double), value :: dtmn
+      real(c_double), intent(out) :: d(4)
+    end function
     integer(c_int) function udc_comm_unique_id(id) bind(C, name='udc_comm_unique_id')
       import :: c_int, c_signed_char
       integer(c_signed_char), intent(out) :: id(128)
