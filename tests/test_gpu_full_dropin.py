@@ -1,10 +1,10 @@
 """The drop-in boundary under the reference's REAL program.
 
 oracle/_ref/udales_full_dropin is what INTEGRATION.md section 1 prescribes, carried out: every file of the reference's src/ --
-program.f90, modstartup.f90, tests.f90, the statistics / output modules, unmodified, compiled where they lie -- except the eight
+program.f90, modstartup.f90, tests.f90, the statistics / output modules, unmodified, compiled where they lie -- except the nine
 modules u-dales_amd/fortran/ replaces, linked against libudcore (u-dales_amd/fortran/Makefile).  Same command line as the
 reference's executable: `udales_full_dropin namoptions.NNN`.  Its counterpart oracle/_ref/udales_full is the same build with the
-reference's own eight modules; the fixtures come from that one (tests/test_full_reference.py pins them on it bit for bit).
+reference's own nine modules; the fixtures come from that one (tests/test_full_reference.py pins them on it bit for bit).
 
 Here: every run deck of the golden set and the reference's examples/999 through the real program on the device, device resident
 (UDC_RESIDENCY=2: the routines record, tstep_integrate launches the fused substep) and with every call carrying its fields

@@ -149,8 +149,14 @@ __global__ void ibm_solid_mean_kernel(Geo g, int n, const int *__restrict__ pt, 
 // sum(thl0av(kb:ke) dzf(kb:ke)) / zh(ke+1) with thl0av the slab average over the fluid cells; S = masked level sums
 __global__ void ibm_thl_val_kernel(int nz, const double *__restrict__ S, const double *__restrict__ cnt, const double *__restrict__ dzf,
                                    double zsize, double *__restrict__ out) {
+  // a level without fluid cells: avexy_ibm's rule (src/modmpi.f90:646-660, as k_slab_averages applies it on the host): -999,
+  // except the floor level, which takes the count of level ke
   double v = 0.;
-  for (int k = 1; k <= nz; ++k) v += S[k - 1] / cnt[k] * dzf[k];
+  for (int k = 1; k <= nz; ++k) {
+    double c = cnt[k];
+    if (c == 0. && k == 1) c = cnt[nz];
+    v += (c > 0. ? S[k - 1] / c : -999.) * dzf[k];
+  }
   *out = v / zsize;
 }
 

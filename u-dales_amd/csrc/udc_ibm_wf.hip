@@ -253,6 +253,7 @@ extern "C" int udc_set_ibm_sections(udc_handle *h, int grid, int n, const int *c
   const int j0 = h->cfg.rank * g.ny;
   // this slab's sections, grouped by cell, the file's order kept inside a cell and between first appearances of cells
   std::vector<int> mine;
+  std::vector<char> fallback(n, 0);
   for (int s = 0; s < n; ++s) {
     const int i = cell[3 * s], j = cell[3 * s + 1], k = cell[3 * s + 2];
     if (i < 1 || i > g.nx || j < 1 || j > h->jtot || k < 1 || k > g.nz) { udc_set_error("udc_set_ibm_sections: section %d: cell (%d %d %d) outside the domain", s + 1, i, j, k); return 1; }
@@ -261,11 +262,13 @@ extern "C" int udc_set_ibm_sections(udc_handle *h, int grid, int n, const int *c
     if (!comprec[s] && is_mine)
       for (int q = 0; q < 4; ++q) {
         const int *r = recids + 12 * s + 3 * q;
-        if (r[0] < 0 || r[0] > g.nx || r[1] < j0 || r[1] > j0 + g.ny || r[2] < 1 || r[2] > g.nz) {
-          // (the reference falls back to the boundary point when the cell is out of a rank's reach, :606-622)
-          udc_set_error("udc_set_ibm_sections: section %d: reconstruction cell (%d %d %d) outside this slab's reach", s + 1, r[0], r[1], r[2]);
+        if (r[2] < 1 || r[2] > g.nz) {
+          udc_set_error("udc_set_ibm_sections: section %d: reconstruction cell (%d %d %d) outside the levels of the domain", s + 1, r[0], r[1], r[2]);
           return 1;
         }
+        // a reconstruction cell beyond the rows this slab can read (its own and one ghost row either side): the reference then
+        // falls back to the boundary point itself -- lcomprec_loc = .true., src/modibm.f90:606-622 -- and so does this slab
+        if (r[0] < 0 || r[0] > g.nx || r[1] < j0 || r[1] > j0 + g.ny) fallback[s] = 1;
       }
     if (is_mine) mine.push_back(s);
   }
@@ -279,7 +282,7 @@ extern "C" int udc_set_ibm_sections(udc_handle *h, int grid, int n, const int *c
       off.push_back((int)q);
       cells.insert(cells.end(), cell + 3 * s, cell + 3 * s + 3);
     }
-    comp.push_back(comprec[s]);
+    comp.push_back(fallback[s] ? 1 : comprec[s]);
     rid.insert(rid.end(), recids + 12 * s, recids + 12 * s + 12);
     ar.push_back(area[s]); di.push_back(dist[s]); zz.push_back(z0[s]); zh_.push_back(z0h[s]); ts.push_back(tsurf[s]);
     nr.insert(nr.end(), norm + 3 * s, norm + 3 * s + 3);

@@ -99,7 +99,11 @@ __global__ void scalar_bcx_uout_kernel(int nz, const double *__restrict__ S, con
                                        const double *__restrict__ wlev, double *__restrict__ out) {
   if (threadIdx.x || blockIdx.x) return;
   double u = 0.;
-  for (int k = 0; k < nz; ++k) u = u + (S[k] / (cnt ? cnt[k + 1] : ncell)) * wlev[k];      // (the reference's order: sum over k of u0av dzf, then the division)
+  for (int k = 0; k < nz; ++k) {      // (the reference's order: sum over k of u0av dzf, then the division)
+    double c = cnt ? cnt[k + 1] : ncell;
+    if (c == 0. && k == 0) c = cnt[nz];      // avexy_ibm's rule for a level without fluid cells (src/modmpi.f90:646-660)
+    u = u + (c > 0. ? S[k] / c : -999.) * wlev[k];
+  }
   out[0] = u;
 }
 
