@@ -28,7 +28,9 @@ def run_dropin(name, iexp, mode, tmp_path, residency):
         pytest.skip("oracle/_ref/udales_dropin not built (needs the reference sources + flang)")
     for fn in os.listdir(os.path.join(GOLDEN, "cases", name)):
         shutil.copy(os.path.join(GOLDEN, "cases", name, fn), tmp_path)
-    env = dict(os.environ, UDC_RESIDENCY=str(residency))
+    # (UDC_EK_ALWAYS: this test driver also dumps ekm / ekh after RK stages 1 and 2, where nothing of the reference's own loop looks
+    # at them and a deck without scalars does not write ekh; the real program -- tests/test_gpu_full_dropin.py -- runs without it)
+    env = dict(os.environ, UDC_RESIDENCY=str(residency), UDC_EK_ALWAYS="1")
     r = subprocess.run(f"ulimit -s unlimited; exec {BIN} namoptions.{iexp:03d} {mode} out.bin", shell=True,
                        cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300, executable="/bin/bash")
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -171,8 +171,10 @@ __global__ __launch_bounds__(NT / CPT, CPT == 1 ? MOM_WAVES : 2) void mom_lds_ke
       cc[c] = g.sz * (long)(k + HZ) + own_off[c];
       tu[c] = tv[c] = tw[c] = pum[c] = pvm[c] = pwm[c] = 0.;
       if (inside[c]) {
-        if (!FRESH) { tu[c] = a.up[cc[c]]; tv[c] = a.vp[cc[c]]; tw[c] = a.wp[cc[c]]; }
-        if (PUP && !a.um_is_u0) { pum[c] = a.um[cc[c]]; pvm[c] = a.vm[cc[c]]; pwm[c] = a.wm[cc[c]]; }
+        // read-once operands: nontemporal, so that they do not push the tile halos of u0, v0, w0, ekm (re-read by the neighbouring
+        // workgroups) out of the XCD's L2
+        if (!FRESH) { tu[c] = NT_LOAD(&a.up[cc[c]]); tv[c] = NT_LOAD(&a.vp[cc[c]]); tw[c] = NT_LOAD(&a.wp[cc[c]]); }
+        if (PUP && !a.um_is_u0) { pum[c] = NT_LOAD(&a.um[cc[c]]); pvm[c] = NT_LOAD(&a.vm[cc[c]]); pwm[c] = NT_LOAD(&a.wm[cc[c]]); }
       }
     }
     // everyone has finished level k-1 (last readers of buffer bn) and committed plane k+1
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(NT / CPT, CPT == 1 ? MOM_WAVES : 2) void mom_lds_ke
         tv[c] = tv[c] + pvm[c] * a.rk3coefi;
         tw[c] = (k == 0) ? 0. : tw[c] + pwm[c] * a.rk3coefi;
       }
-      a.up[cc[c]] = tu[c]; a.vp[cc[c]] = tv[c]; a.wp[cc[c]] = tw[c];
+      NT_STORE(tu[c], &a.up[cc[c]]); NT_STORE(tv[c], &a.vp[cc[c]]); NT_STORE(tw[c], &a.wp[cc[c]]);
       if (a.wrap_vp && jj[c] == 0) a.vp[cc[c] + (long)g.sy * g.ny] = tv[c];
     }
     const int t = bm; bm = bc; bc = bp; bp = bn; bn = t;
@@ -319,8 +321,8 @@ __global__ __launch_bounds__(NT) void closure_lds_kernel(Geo g, TileGrid tg, Met
       double em, eh;
       closure_arith<SGS>(A, m, lm, pr, k, em, eh);
       const long c = g.sz * (long)(k + HZ) + own_off;
-      ekm[c] = em;
-      if (EKH) ekh[c] = eh;
+      ekm[c] = em;                      // (re-read by the momentum sweep that follows: kept cacheable)
+      if (EKH) NT_STORE(eh, &ekh[c]);
       if (ghosts) {
         // closurebc (src/modboundary.f90:447-500) folded in when the slab is the whole domain in y:
         // periodic ghost rows and the bottom/top ghost planes are written by the owning thread.

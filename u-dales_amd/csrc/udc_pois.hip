@@ -867,7 +867,7 @@ __global__ __launch_bounds__(256) void integrate_kernel(Geo g, TileGrid tg, Metr
   // 163-178) are folded in -- p(j-1) wraps by index, and the owning thread also writes the periodic
   // ghost row and the top ghost plane of what it updates.
   const long wr = !ghosts ? 0 : ((j == 0) ? (long)g.sy * g.ny : ((j == g.ny - 1) ? -(long)g.sy * g.ny : 0));
-  double tu = a.up[c], tv = a.vp[c], tw = a.wp[c];
+  double tu = NT_LOAD(&a.up[c]), tv = NT_LOAD(&a.vp[c]), tw = NT_LOAD(&a.wp[c]);
   double pr0 = 0.;
   if (PROJECT) {
     const long xm = r0 + wrapm(i, g.nx);
@@ -876,18 +876,18 @@ __global__ __launch_bounds__(256) void integrate_kernel(Geo g, TileGrid tg, Metr
     tu = tu - (pc - p[xm]) * m.dxi;
     tv = tv - (pc - p[ym]) * m.dyi;
     if (k >= 1) tw = tw - (pc - p[c - g.sz]) * m.dzhi[k + 1];
-    pr0 = pres0[c] + pc;
-    pres0[c] = pr0;
+    pr0 = NT_LOAD(&pres0[c]) + pc;
+    NT_STORE(pr0, &pres0[c]);
     if (wr) pres0[c + wr] = pr0;
   }
   double u, v, w;
   if (PUP) { u = rk3coef * tu; v = rk3coef * tv; w = rk3coef * tw; }
   else { u = a.um[c] + rk3coef * tu; v = a.vm[c] + rk3coef * tv; w = a.wm[c] + rk3coef * tw; }
   if (ghosts && k == 0) w = 0.;                     // boundary: w(kb) = 0
-  a.u0[c] = u; a.v0[c] = v; a.w0[c] = w;
+  NT_STORE(u, &a.u0[c]); NT_STORE(v, &a.v0[c]); NT_STORE(w, &a.w0[c]);
   if (ZERO) { a.up[c] = 0.; a.vp[c] = 0.; a.wp[c] = 0.; }
   const bool last_m = (last & 1) != 0, last_s = (last & 2) != 0;   // write um.. / write svm..
-  if (last_m) { a.um[c] = u; a.vm[c] = v; a.wm[c] = w; }
+  if (last_m) { NT_STORE(u, &a.um[c]); NT_STORE(v, &a.vm[c]); NT_STORE(w, &a.wm[c]); }
   if (ghosts) {
     if (wr) {
       a.u0[c + wr] = u; a.v0[c + wr] = v; a.w0[c + wr] = w;
