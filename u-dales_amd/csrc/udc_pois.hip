@@ -906,12 +906,12 @@ __global__ __launch_bounds__(256) void integrate_kernel(Geo g, TileGrid tg, Metr
     }
   }
   for (int s = 0; s < a.nsv; ++s) {
-    double sv = a.svm[s][c] + rk3coef * a.svp[s][c];
+    double sv = NT_LOAD(&a.svm[s][c]) + rk3coef * NT_LOAD(&a.svp[s][c]);
     if (a.clip[s] > 0.) {
       sv = fmax(a.clip[s], sv);
       if (!last_s) a.svm[s][c] = fmax(a.clip[s], a.svm[s][c]);
     }
-    a.sv0[s][c] = sv;
+    NT_STORE(sv, &a.sv0[s][c]);
     if (ZERO) a.svp[s][c] = 0.;        // the fused substep's scalar sweep does not read svp either
     if (last_s) a.svm[s][c] = sv;
   }

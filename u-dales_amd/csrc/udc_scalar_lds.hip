@@ -133,7 +133,7 @@ __global__ __launch_bounds__(NT, 3) void scalar_lds_kernel(Geo g, int gx, int ti
       const double ul = u[pb + own], uh = u[pb + xp1], vl = v[pb + own], vh = v[pb + own + g.sy];
       const double wh = w[pb + own + g.sz];
       const double t0 = FRESH ? 0. : cp[pb + own];
-      cp[pb + own] = scalar_tend<ADV, true, LES>(A, m, lm, k, g.nz, t0, ul, uh, vl, vh, wl, wh, cekh, dfac, gh);
+      NT_STORE((scalar_tend<ADV, true, LES>(A, m, lm, k, g.nz, t0, ul, uh, vl, vh, wl, wh, cekh, dfac, gh)), &cp[pb + own]);
       wl = wh;
     }
     cb0 = (cb0 + 1) % NCB;
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(NT, 4) void scalar_kappa_faces_kernel(Geo g, int gx
       t = (t + upper) + lower;
     }
     t = t + dif;
-    if (inside) cp[pb + own] = t;
+    if (inside) NT_STORE(t, &cp[pb + own]);      // written once, read by the integration from memory
     pzl = pzh;
     {
       const int c0_ = co[0];

@@ -14,8 +14,11 @@
 !!       (readfacetfiles stays the driver's call) and handed to the device once (udc_set_ibm_sections)
 !! Not taken over (refused in initibm with the reference's error convention): prescribed non-zero wall heat fluxes, wall
 !! moisture fluxes, facet output (lwritefac).
-!! The tau_x / tau_y / tau_z / thl_flux diagnostics of `bottom` and `ibmwallfun` (the tendency increments, read by the
-!! statistics) are not produced.
+!! The tau_x / tau_y / thl_flux planes `bottom` leaves behind (src/modibm.f90:2015-2018, 2094-2097: what the floor added to the
+!! tendencies) are filled from the device whenever the host fields are refreshed (udc_iface: udc_bottom_diagnostics); the facet
+!! averages of ibmwallfun's stresses (lwritefac, :1246-1282) are not produced.
+!! Without wall functions (iwallmom = 1) the fluid-boundary points of the velocity grids are not handed over: the reference never
+!! reads them then (:166-179) and diffu/v/w_corr act on no points.
 module modibm
   use iso_c_binding, only: c_int, c_double
   use modibmdata
