@@ -48,7 +48,9 @@ ALGO_BYTES = {
     "project_integrate": 72,    # read p (8), pup,pvp,pwp (24); RMW pres0 (16); write u0,v0,w0 (24)
     "scalar": 48,               # read c, ekh, u0,v0,w0 (40); write cp (8) -- tendencies are not re-read in the fused substep
     # slab (multi-GPU) Poisson stages
-    # (own line FFTs reading / writing the exchange buffers directly: one real field in, one out per stage)
+    # (own line FFTs reading / writing the exchange buffers directly: one real field in, one out per stage, DESIGN.md section 6;
+    #  the x forward stage of the fused substep evaluates the divergence itself -- reads pup, pvp, pwp instead of p: 24 + 8 = 32,
+    #  charged below when the substep launched no div_rhs)
     "fftx_pack_fwd": 16, "unpack_ffty_fwd": 16, "ffty_pack_bwd": 16, "unpack_fftx_bwd": 16,
 }
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
@@ -532,6 +534,8 @@ def main():
             ms, cnt = prof[name]
         s1 = (stage1 / max(args.steps, 1)) if (live or not table) else (tab_stage1 / max(n_tab, 1))
         ab = algo_bytes(name, nscal, s1)
+        if name == "fftx_pack_fwd" and "div_rhs" not in survey:
+            ab += 16                           # the divergence is folded into this stage (ALGO_BYTES)
         avg_ms = ms / max(cnt, 1)
         per_substep = cnt / max(args.steps if (live or not table) else n_tab, 1)
         net = avg_ms if (live or not table) else max(avg_ms - marker_ms, 0.)

@@ -21,7 +21,15 @@
 
 namespace {
 
-constexpr int FT = 256;      // threads per workgroup
+constexpr int FT = 256;      // threads per workgroup of the y kernels; the x kernels take theirs from the line length (xthreads)
+// Measured at 1024 x 512 x 512 (x lines of 512 complex, four per workgroup; profiles/r03/fft_threads_scan.txt): 256 / 512 / 1024
+// threads: x forward 2.39 / 2.08 / 1.79 ms, x backward 2.07 / 1.41 / 1.23 ms -- the five stages of a line are separated by
+// barriers and only a fat workgroup keeps enough of them in flight; the y kernels (lines of 512, eight per workgroup) go the
+// other way, 1.00 / 1.10 / 1.65 ms.
+#ifndef UDC_XT_LM8
+#define UDC_XT_LM8 512
+#endif
+__host__ __device__ constexpr int xthreads(int LM) { return LM >= 9 ? 1024 : (LM == 8 ? UDC_XT_LM8 : 256); }
 
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
   return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
@@ -37,8 +45,8 @@ __host__ __device__ constexpr int padded(int n) { return n + (n >> 4) + 1; }
 
 // Stockham autosort FFT of 1 << LNL lines of M = 1 << LM complex each, held in LDS at a[line * MP + pad(n)]; b is the
 // other half of the ping-pong.  tw[n] = exp(-2 pi i n / M), n < M, in LDS; INV conjugates it.  Returns the buffer
-// holding the result.  All FT threads of the workgroup must call it.  Everything is a shift or a mask.
-template <bool INV, int LM>
+// holding the result.  All NTH threads of the workgroup must call it.  Everything is a shift or a mask.
+template <bool INV, int LM, int NTH = FT>
 __device__ __forceinline__ double2 *fft_lines(double2 *a, double2 *b, const double2 *tw, int MP, int nl) {
   constexpr int M = 1 << LM;
   const int tid = threadIdx.x;
@@ -47,7 +55,7 @@ __device__ __forceinline__ double2 *fft_lines(double2 *a, double2 *b, const doub
     const bool r4 = LM - lp >= 2;
     const int lR = r4 ? 2 : 1, lT = LM - lR, T = 1 << lT, p = 1 << lp, lstep = LM - lp - lR;
     const int work = nl << lT;
-    for (int wi = tid; wi < work; wi += FT) {
+    for (int wi = tid; wi < work; wi += NTH) {
       const int line = wi >> lT, j = wi & (T - 1);
       const int k = j & (p - 1);
       const double2 *src = a + line * MP;
@@ -104,8 +112,9 @@ __device__ __forceinline__ void x_lds(const XArgs &q, double2 *lds, double2 *&a,
   const int L = 1 << q.lL;
   a = lds; b = lds + L * q.MP; tw = b + L * q.MP;
   dmap = reinterpret_cast<int *>(tw + (1 << LM));
-  for (int n = threadIdx.x; n < (1 << LM); n += FT) tw[n] = twM[n];
-  for (int kx = threadIdx.x; kx < q.cx * q.P; kx += FT) dmap[kx] = kx / q.cx;
+  constexpr int NTH = xthreads(LM);
+  for (int n = threadIdx.x; n < (1 << LM); n += NTH) tw[n] = twM[n];
+  for (int kx = threadIdx.x; kx < q.cx * q.P; kx += NTH) dmap[kx] = kx / q.cx;
 }
 
 // fillps folded into the x forward transform (fused substep, PUP mode): the row is not read from p but evaluated as
@@ -114,16 +123,16 @@ struct DivArgs { const double *pu, *pv, *pw; const double *dzfi; double dxi, dyi
 
 // x forward: rows j0..j0+L-1 of plane k0+kc -> send blocks
 template <int LM, bool DIV>
-__global__ __launch_bounds__(FT) void fftx_fwd_pack_kernel(XArgs q, const double *__restrict__ p, DivArgs dv, const double2 *__restrict__ twM,
+__global__ __launch_bounds__(xthreads(LM)) void fftx_fwd_pack_kernel(XArgs q, const double *__restrict__ p, DivArgs dv, const double2 *__restrict__ twM,
                                                            const double2 *__restrict__ twN, double2 *__restrict__ send) {
   extern __shared__ double2 lds[];
-  constexpr int M = 1 << LM;
+  constexpr int M = 1 << LM, NTH = xthreads(LM);
   double2 *a, *b, *tw; int *dmap;
   x_lds<LM>(q, lds, a, b, tw, dmap, twM);
   const int tid = threadIdx.x, L = 1 << q.lL;
   const int j0 = blockIdx.x << q.lL, kc = blockIdx.y, k = q.k0 + kc;
   // load: row l holds M complex = nx reals, read as double2 (16-B aligned: nx even, rows nx*8 B apart, base 16-B aligned)
-  for (int wi = tid; wi < (M << q.lL); wi += FT) {
+  for (int wi = tid; wi < (M << q.lL); wi += NTH) {
     const int l = wi >> LM, n = wi & (M - 1);
     const long ro = q.sz * (long)(k + HZ) + (long)q.sy * (j0 + l + HY);
     if (DIV) {
@@ -140,11 +149,11 @@ __global__ __launch_bounds__(FT) void fftx_fwd_pack_kernel(XArgs q, const double
     }
   }
   __syncthreads();
-  double2 *z = fft_lines<false, LM>(a, b, tw, q.MP, L);
+  double2 *z = fft_lines<false, LM, NTH>(a, b, tw, q.MP, L);
   // split: X[kx] = (Z[kx] + conj(Z[M-kx]))/2 - (i/2) e^{-2 pi i kx/N} (Z[kx] - conj(Z[M-kx])), kx = 0..M (Z[M] = Z[0]);
   // written j-fastest: send[((d*nzc + kc)*cx + kxl)*nyl + j]; the padding modes kx >= nkx of the last rank are zero
   const int nk = q.cx * q.P;
-  for (int wi = tid; wi < (nk << q.lL); wi += FT) {
+  for (int wi = tid; wi < (nk << q.lL); wi += NTH) {
     const int kx = wi >> q.lL, l = wi & (L - 1);
     double2 X = make_double2(0., 0.);
     if (kx < q.nkx) {
@@ -162,23 +171,23 @@ __global__ __launch_bounds__(FT) void fftx_fwd_pack_kernel(XArgs q, const double
 
 // x backward: recv blocks -> rows j0..j0+L-1 of plane k0+kc (unnormalised C2R)
 template <int LM>
-__global__ __launch_bounds__(FT) void fftx_bwd_unpack_kernel(XArgs q, const double2 *__restrict__ recv, const double2 *__restrict__ twM,
+__global__ __launch_bounds__(xthreads(LM)) void fftx_bwd_unpack_kernel(XArgs q, const double2 *__restrict__ recv, const double2 *__restrict__ twM,
                                                              const double2 *__restrict__ twN, double *__restrict__ p) {
   extern __shared__ double2 lds[];
-  constexpr int M = 1 << LM;
+  constexpr int M = 1 << LM, NTH = xthreads(LM);
   double2 *a, *b, *tw; int *dmap;
   x_lds<LM>(q, lds, a, b, tw, dmap, twM);
   __syncthreads();
   const int tid = threadIdx.x, L = 1 << q.lL;
   const int j0 = blockIdx.x << q.lL, kc = blockIdx.y, k = q.k0 + kc;
-  for (int wi = tid; wi < (q.nkx << q.lL); wi += FT) {      // gather X[0..M] (the pitch holds M + 1 elements)
+  for (int wi = tid; wi < (q.nkx << q.lL); wi += NTH) {      // gather X[0..M] (the pitch holds M + 1 elements)
     const int kx = wi >> q.lL, l = wi & (L - 1);
     const int s_ = dmap[kx], kxl = kx - s_ * q.cx;
     b[l * q.MP + pad(kx)] = recv[(((size_t)s_ * q.nzc + kc) * q.cx + kxl) * q.nyl + j0 + l];
   }
   __syncthreads();
   // merge: Z[kx] = (X[kx] + conj(X[M-kx])) + i e^{+2 pi i kx/N} (X[kx] - conj(X[M-kx])), kx = 0..M-1
-  for (int wi = tid; wi < (M << q.lL); wi += FT) {
+  for (int wi = tid; wi < (M << q.lL); wi += NTH) {
     const int l = wi >> LM, kx = wi & (M - 1);
     const double2 *xl = b + l * q.MP;
     const double2 xk = xl[pad(kx)], xc = cconj(xl[pad(M - kx)]);
@@ -188,8 +197,8 @@ __global__ __launch_bounds__(FT) void fftx_bwd_unpack_kernel(XArgs q, const doub
     a[l * q.MP + pad(kx)] = make_double2(s.x - wd.y, s.y + wd.x);
   }
   __syncthreads();
-  double2 *z = fft_lines<true, LM>(a, b, tw, q.MP, L);
-  for (int wi = tid; wi < (M << q.lL); wi += FT) {
+  double2 *z = fft_lines<true, LM, NTH>(a, b, tw, q.MP, L);
+  for (int wi = tid; wi < (M << q.lL); wi += NTH) {
     const int l = wi >> LM, n = wi & (M - 1);
     double2 *row = reinterpret_cast<double2 *>(p + q.sz * (long)(k + HZ) + (long)q.sy * (j0 + l + HY));
     row[n] = z[l * q.MP + pad(n)];
@@ -328,10 +337,10 @@ int fft_x_fwd_pack(udc_handle *h, int k0, int nzc, double *send) {
   const size_t lds = x_lds_bytes(h, h->fft_L);
   const DivArgs dv{h->fields[UDC_UP], h->fields[UDC_VP], h->fields[UDC_WP], h->m.dzfi, h->m.dxi, h->m.dyi, h->g.nz};
   if (h->div_in_fft) {
-    FFT_DISPATCH(ilog2(q.M), hipLaunchKernelGGL((fftx_fwd_pack_kernel<LM, true>), gr, dim3(FT), lds, h->stream, q, (const double *)h->fields[UDC_P], dv,
+    FFT_DISPATCH(ilog2(q.M), hipLaunchKernelGGL((fftx_fwd_pack_kernel<LM, true>), gr, dim3(xthreads(LM)), lds, h->stream, q, (const double *)h->fields[UDC_P], dv,
                                                 tw, tw + q.M, reinterpret_cast<double2 *>(send)))
   } else {
-    FFT_DISPATCH(ilog2(q.M), hipLaunchKernelGGL((fftx_fwd_pack_kernel<LM, false>), gr, dim3(FT), lds, h->stream, q, (const double *)h->fields[UDC_P], dv,
+    FFT_DISPATCH(ilog2(q.M), hipLaunchKernelGGL((fftx_fwd_pack_kernel<LM, false>), gr, dim3(xthreads(LM)), lds, h->stream, q, (const double *)h->fields[UDC_P], dv,
                                                 tw, tw + q.M, reinterpret_cast<double2 *>(send)))
   }
   HIP_OK(hipGetLastError());
@@ -342,7 +351,7 @@ int fft_x_bwd_unpack(udc_handle *h, int k0, int nzc, const double *recv) {
   const double2 *tw = reinterpret_cast<const double2 *>(h->fft_tw);
   const dim3 gr((unsigned)(q.nyl >> q.lL), (unsigned)nzc);
   const size_t lds = x_lds_bytes(h, h->fft_L);
-  FFT_DISPATCH(ilog2(q.M), hipLaunchKernelGGL(fftx_bwd_unpack_kernel<LM>, gr, dim3(FT), lds, h->stream, q, reinterpret_cast<const double2 *>(recv),
+  FFT_DISPATCH(ilog2(q.M), hipLaunchKernelGGL(fftx_bwd_unpack_kernel<LM>, gr, dim3(xthreads(LM)), lds, h->stream, q, reinterpret_cast<const double2 *>(recv),
                                               tw, tw + q.M, h->fields[UDC_P]))
   HIP_OK(hipGetLastError());
   return 0;
