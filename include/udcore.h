@@ -253,17 +253,17 @@ int udc_level_forcings(udc_handle *h, int when);
  *   udc_ibmnorm     ibmnorm (:697): solid (:748) -- um, vm, wm and their tendencies zeroed at the solid points, svm / svp set
  *                   to the mean of their fluid neighbours -- called after masscorr (src/program.f90:171)
  * Both are part of udc_substep once committed.  With an immersed boundary udc_masscorr and udc_slab_average(s) average over
- * the fluid cells only (avexy_ibm, src/modmpi.f90:623-664, with IIu / IIv / IIc).  Not available: the facet heat / moisture wall
- * functions (wallfunheat :1436) -- adiabatic, impermeable walls only. */
+ * the fluid cells only (avexy_ibm, src/modmpi.f90:623-664, with IIu / IIv / IIc), and so do the moist thermodynamics' slab averages
+ * (udc_thermodynamics: diagfld's thl0av, qt0av, ql0av over IIc, thvh over IIw; src/modthermodynamics.f90:76,262-279).  Wall
+ * fluxes of heat and moisture: udc_set_ibm_wallheat / udc_set_ibm_wallmoist below; without them adiabatic, impermeable walls. */
 enum { UDC_IBM_U = 0, UDC_IBM_V = 1, UDC_IBM_W = 2, UDC_IBM_C = 3 };
 int udc_set_ibm_points(udc_handle *h, int grid, const int *solid, int nsolid, const int *bound, int nbound);
 int udc_set_ibm_mask_wrap(udc_handle *h, int wrapx, int wrapy);
 /* temperature (udc_set_tempeq) and total water (udc_set_moisture) with an immersed boundary: ibmnorm's solid on thlm / qtm (thl:
  * the volume mean of the fluid-cell slab averages where an obstacle cell has no fluid neighbour, :715) and advecc2nd_corr --
  * _liberal (:936) or, with lconservativeibm (&PHYSICS), _conservative (:889) --, ibmwallfun's diffc_corr, and the buoyancy
- * term's thvh over the fluid w points.  The walls are adiabatic and impermeable: wallfunheat (:1436) is not on the device,
- * which is exact for prescribed zero wall fluxes (iwalltemp = iwallmoist = 1, bctf* = bcqf* = 0; anything else is refused
- * by the host side). */
+ * term's thvh over the fluid w points.  The walls are adiabatic and impermeable unless udc_set_ibm_wallheat /
+ * udc_set_ibm_wallmoist say otherwise. */
 int udc_set_ibm_conservative(udc_handle *h, int lconservativeibm);
 /* Facet wall functions for momentum (wallfunmom, src/modibm.f90:1286-1433; &WALLS iwallmom: 2 = with the Uno et al. stability
  * functions on the facet temperatures, the reference's default; 3 = neutral log law; 1 = none).  udc_set_ibm_wallfun: the
@@ -285,6 +285,17 @@ int udc_set_ibm_wallfun(udc_handle *h, int iwallmom, double prandtlturb, const d
  * (log-law and velocity checks included, as in the reference); 0 (the default): off, adiabatic walls.  After udc_set_tempeq and
  * udc_set_ibm_wallfun. */
 int udc_set_ibm_wallheat(udc_handle *h, int iwalltemp);
+/* Latent part of wallfunheat (src/modibm.f90:1556-1600; lmoist, vegetated facets only -- faclGR): per c-grid section, n and the
+ * order as given to udc_set_ibm_sections(grid 3): lgr (1 = the section's facet is vegetated), and
+ *   iwallmoist = 1: qwall = the prescribed moisture flux of the facet's direction (bcqfxm ... bcqfz, :1558-1568);
+ *   iwallmoist = 2: qwall = facqsat (saturation humidity at the facet temperature), hurel = fachurel, resc / ress = the canopy /
+ *                   soil resistances facf(:, 4) / facf(:, 5): flux = moist_flux (:1989) with the aerodynamic resistance
+ *                   1 / (htc |utan|) of the sensible part's heat transfer coefficient -- needs iwalltemp = 2;
+ *   0 (the default): off, impermeable walls.
+ * flux * area / (dx dy dzh(k)) comes out of qtp in the same sweep as the sensible part.  After udc_set_moisture,
+ * udc_set_ibm_sections(3, ...) and udc_set_ibm_wallheat. */
+int udc_set_ibm_wallmoist(udc_handle *h, int iwallmoist, int n, const int *lgr, const double *qwall, const double *hurel,
+                          const double *resc, const double *ress);
 int udc_set_ibm_sections(udc_handle *h, int grid, int n, const int *cell, const double *area, const double *dist, const double *norm,
                          const double *z0, const double *z0h, const double *tsurf, const int *comprec, const double *recpt,
                          const int *recids, const double *tmask);

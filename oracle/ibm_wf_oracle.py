@@ -102,7 +102,7 @@ def wallfunmom(grid, g, S, facets, iwallmom, u0, v0, w0, rhs, thl0=None, mask_c=
     return acted
 
 
-def _heat_flux(utan, dist, z0, z0h, tair, tsurf, prt):
+def _heat_flux(utan, dist, z0, z0h, tair, tsurf, prt, htc_out=None):
     """heat_transfer_coef_flux, src/modibm.f90:1920-1986 -> flux."""
     b1, b2, dm, dh = 9.4, 4.7, 7.4, 5.3
     dT = tair - tsurf
@@ -123,12 +123,18 @@ def _heat_flux(utan, dist, z0, z0h, tair, tsurf, prt):
     M = prt * logdz * np.sqrt(fm) / fh
     dTrough = dT * 1. / (prt * logzh / M + 1.)
     cth = fkar2 / (logdz * logdz) * fh / prt
-    return abs(utan) * cth * dTrough
+    flux = abs(utan) * cth * dTrough
+    if htc_out is not None:      # :1975-1979
+        htc_out[0] = flux / (abs(utan) * dT) if abs(abs(utan) * dT) > 0. else 0.
+    return flux
 
 
-def wallfunheat(g, S, facets, u0, v0, w0, thl0, thlp, prt=0.71, lnorec=False, prescribed=None):
-    """wallfunheat's sensible part (src/modibm.f90:1436-1540): thlp (m-array) updated in place.  iwalltemp = 2 unless
-    `prescribed` holds iwalltemp = 1's fluxes {alignment of the facet normal: flux} (:1508-1524)."""
+def wallfunheat(g, S, facets, u0, v0, w0, thl0, thlp, prt=0.71, lnorec=False, prescribed=None, moist=None):
+    """wallfunheat (src/modibm.f90:1436-1607): thlp (m-array) updated in place.  Sensible part: iwalltemp = 2 unless
+    `prescribed` holds iwalltemp = 1's fluxes {alignment of the facet normal: flux} (:1508-1524).  Latent part (:1556-1600) when
+    `moist` = dict(qt0=, qtp= (updated in place), iwallmoist=, prescribed= {alignment: flux} for iwallmoist = 1): on the vegetated
+    facets (facets["lgr"]), moist_flux (:1989) of the air's humidity against facets["qsat"] / ["hurel"] through the aerodynamic
+    resistance 1 / (htc |utan|) and facets["resc"] / ["ress"]."""
     from udcore.facets import alignment
     nx, ny, nz, dx, dy = g.nx, g.ny, g.nz, g.dx, g.dy
     xh, xf = np.arange(nx + 1) * dx, (np.arange(nx + 1) + 0.5) * dx
@@ -142,11 +148,13 @@ def wallfunheat(g, S, facets, u0, v0, w0, thl0, thlp, prt=0.71, lnorec=False, pr
         if S["comprec"][s] or lnorec:
             uvec = np.array([0.5 * (u0[k, j, i] + u0[k, j, i + 1]), 0.5 * (v0[k, j, i] + v0[k, j + 1, i]), 0.5 * (w0[k, j, i] + w0[k + 1, j, i])])
             tair = thl0[k, j, i]
+            qtair = moist["qt0"][k, j, i] if moist else 0.
             dist = S["dist"][s]
         else:
             p, r = S["recpt"][s], S["recids"][s]
             uvec = np.array([_trilinear(u0, r[0], xh, yf, zf, p), _trilinear(v0, r[1], xf, yh, zf, p), _trilinear(w0, r[2], xf, yf, zh, p)])
             tair = _trilinear(thl0, r[3], xf, yf, zf, p)
+            qtair = _trilinear(moist["qt0"], r[3], xf, yf, zf, p) if moist else 0.
             dist = S["dist"][s] + np.linalg.norm(np.array([p[0] - xf[i - 1], p[1] - yf[j - 1], p[2] - zf[k - 1]]))
         if np.log(dist / z0) <= 1.:
             continue
@@ -158,7 +166,15 @@ def wallfunheat(g, S, facets, u0, v0, w0, thl0, thlp, prt=0.71, lnorec=False, pr
         span = span / np.linalg.norm(span)
         strm = np.cross(span, norm)
         utan = float(np.dot(uvec, strm))
-        flux = prescribed[alignment(norm)] if prescribed is not None else _heat_flux(utan, dist, z0, z0h, tair, facets["tsurf"][fac], prt)
+        htc = [0.]
+        flux = prescribed[alignment(norm)] if prescribed is not None else _heat_flux(utan, dist, z0, z0h, tair, facets["tsurf"][fac], prt, htc)
         thlp[k, j, i] = thlp[k, j, i] - flux * S["area"][s] / (dx * dy * g.dzh[k])
+        if moist and facets["lgr"][fac]:
+            if moist["iwallmoist"] == 1:
+                flux = moist["prescribed"][alignment(norm)]
+            elif abs(htc[0] * abs(utan)) > 0.:      # (else `flux` keeps the sensible one, as in the reference)
+                resa, cveg, qw = 1. / (htc[0] * abs(utan)), 0.8, facets["qsat"][fac]
+                flux = min(0., cveg * (qtair - qw) / (resa + facets["resc"][fac]) + (1 - cveg) * (qtair - qw * facets["hurel"][fac]) / (resa + facets["ress"][fac]))
+            moist["qtp"][k, j, i] = moist["qtp"][k, j, i] - flux * S["area"][s] / (dx * dy * g.dzh[k])
         acted += 1
     return acted

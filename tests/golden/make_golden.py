@@ -30,7 +30,7 @@ REF = os.path.join(ROOT, "oracle", "_ref", "udales_ref")
 
 def deck(iexpnr, nx, ny, nz, dx=0.5, dy=0.5, dtmax=0.25, sgs="vreman", nsv=0, bctopm=1,
          oracle="", lles=True, randu=0.01, floor=False, z0=0.05, physics="", bc="", bcbotm=3, scalars="", dynamics="", inlet="", ladaptive=False, chemistry="",
-         ibm=None, output="", iwallmom=1, walls=""):
+         ibm=None, output="", iwallmom=1, walls="", extra=""):
     sub = {"oneeqn": "loneeqn = .true.\nlvreman = .false.\nlsmagorinsky = .false.",
            "vreman": "lvreman = .true.\nlsmagorinsky = .false.",
            "vreman_bc": "lvreman = .true.\nlsmagorinsky = .false.\nlbuoycorr = .true.",
@@ -73,7 +73,7 @@ nsv = {nsv}{(chr(10) + scalars) if scalars else ''}
 &NAMSUBGRID
 {sub}
 /{(chr(10) + '&OUTPUT' + chr(10) + output + chr(10) + '/') if output else ''}{(chr(10) + '&INLET' + chr(10) + inlet + chr(10) + '/') if inlet else ''}{(chr(10) + '&CHEMISTRY' + chr(10) + chemistry + chr(10) + '/') if chemistry else ''}
-&ORACLE
+{(extra + chr(10)) if extra else ''}&ORACLE
 {oracle}
 /
 """
@@ -141,8 +141,8 @@ FACET_TYPES = [(1, 0.01, 0.001), (2, 0.12, 0.0035)]      # id, z0, z0h
 WF_NO_OBLIQUE = set()      # cases whose facets are all grid-aligned (prescribed wall heat fluxes are defined for those only)
 
 
-def facet_files(blocks, nx, ny, nz, dx, dy, dz, oblique=True):
-    """-> (files {name: text}, counts {grid: nfctsecs}, nfcts)."""
+def facet_files(blocks, nx, ny, nz, dx, dy, dz, oblique=True, green=False):
+    """-> (files {name: text}, counts {grid: nfctsecs}, nfcts).  green: the second facet type is vegetated (lGR)."""
     import numpy as np
     L = ibm_lists(blocks, nx, ny, nz)
     if blocks == "ground":      # one facet per column pair, normal +z, half a cell below the u, v, c points and a cell below w(2)
@@ -177,8 +177,9 @@ def facet_files(blocks, nx, ny, nz, dx, dy, dz, oblique=True):
     nfcts = len(facets)
     files = {"facets": "# type, normal\n" + "".join("%d %.4f %.4f %.4f\n" % ((t,) + n) for t, n in facets),
              "factypes": "# walltype\n# -\n# wallid lGR z0 z0h al em d1 d2 d3 C1 C2 C3 l1 l2 l3 k1 k2 k3 k4\n" +
-                         "".join("%d 0 %.4f %.5f 0.5 0.85 0.1 0.2 0.2 1875000 1875000 1875000 0.75 0.75 0.75 4e-7 4e-7 4e-7 4e-7\n" % t for t in FACET_TYPES),
-             "Tfacinit": "# initial facet temperatures\n" + "".join("%.2f\n" % (289.5 + 0.25 * (q % 4)) for q in range(nfcts))}
+                         "".join("%d %d %.4f %.5f 0.5 0.85 0.1 0.2 0.2 1875000 1875000 1875000 0.75 0.75 0.75 4e-7 4e-7 4e-7 4e-7\n"
+                                 % (t[0], 1 if (green and t[0] == 2) else 0, t[1], t[2]) for t in FACET_TYPES),
+             "Tfacinit": "# initial facet temperatures\n" + "".join("%.2f\n" % ((292.0 if green else 289.5) + 0.25 * (q % 4)) for q in range(nfcts))}
     counts = {}
     # direction to the solid neighbour -> the face of that neighbour's block the point looks at
     dirs = [((1, 0, 0), "west", dy * dz, dx), ((-1, 0, 0), "east", dy * dz, dx), ((0, 1, 0), "south", dx * dz, dy),
@@ -211,8 +212,8 @@ def ibm_walls_wf(blocks, nx, ny, nz, dx, dy, dz, iwallmom):
             + "".join(f"nfctsecs_{g} = {counts[g]}\n" for g in "uvwc"))
 
 
-def write_facet_files(d, iexp, blocks, nx, ny, nz, dx, dy, dz, oblique=True):
-    files, _, _ = facet_files(blocks, nx, ny, nz, dx, dy, dz, oblique)
+def write_facet_files(d, iexp, blocks, nx, ny, nz, dx, dy, dz, oblique=True, green=False):
+    files, _, _ = facet_files(blocks, nx, ny, nz, dx, dy, dz, oblique, green)
     for name, text in files.items():
         fn = f"facet_{name}.txt" if name.startswith("sections_") else f"{name}.inp.{iexp:03d}"
         with open(os.path.join(d, fn), "w") as f:
@@ -272,7 +273,7 @@ KEEP_KERNELS = ("meta dzf dzh zf dpdxl dpdyl rk3 in.u0 in.v0 in.w0 in.um in.vm i
                 "frc0.up frc0.vp frc0.wp frc0.thlp lsf.up lsf.vp lsf.wp lsf.thlp u0av thl0av frc0.qtp lsf.qtp qt0av "
                 "src0.up fix0.up fix0.vp "
                 "ibw0.up ibw0.vp ibw0.wp ibw.up ibw.vp ibw.wp ibn0.up ibn0.vp ibn0.wp ibn.up ibn.vp ibn.wp ibn.um ibn.vm ibn.wm "
-                "ibw0.thlp ibw.thlp ibn0.thlp ibn.thlp ibn.thlm ibn.thl0 ibm.thvh ibm.thl0av "
+                "ibw0.thlp ibw.thlp ibn0.thlp ibn.thlp ibn.thlm ibn.thl0 ibm.thvh ibm.thl0av ibw0.qtp ibw.qtp ibn0.qtp ibn.qtp ibn.qtm "
                 "pre.up pre.vp pre.wp poi.p poi.pres0 poi.up poi.vp poi.wp out.u0 out.v0 out.w0 "
                 "out.um out.pres0").split()
 
@@ -604,6 +605,23 @@ CASES.update({
                                                          iwallmom=2, physics="ltempeq = .true.\nlbuoyancy = .true.", bc=_IBM_THL_BC,
                                                          oracle="nsub = 9\ndump_at = 3, 9"), 1.0),
 })
+# moisture next to obstacles: the moist thermodynamics' slab averages over the fluid cells only (diagfld's avexy_ibm on thl0, qt0, ql0
+# with IIc / IIcs and thvh with IIw / IIws, src/modthermodynamics.f90:76,262-279), first with impermeable walls, then with the latent
+# wall flux of vegetated facets (iwallmoist = 2: wallfunheat's moist_flux, src/modibm.f90:1556-1600,1989; the second facet type green)
+GREEN_CASES = {"run_ibm_moistwq_16x12x10", "k_ibm_wq2_16x12x10"}
+_IBM_MOIST = dict(sgs="vreman", nsv=1, floor=True, randu=0.05, ibm=IBM_BLOCKS["run_ibm_16x12x10"], iwallmom=2,
+                  physics="lmoist = .true.\nltempeq = .true.\nlbuoyancy = .true.",
+                  bc=_IBM_THL_BC + "\nqts = 0.0105\nBCtopq = 1\nBCbotq = 1\nwqsurf = 2.e-5")
+for _n in ("run_ibm_moist_16x12x10", "run_ibm_moistwq_16x12x10", "k_ibm_wq2_16x12x10"):
+    IBM_BLOCKS[_n] = IBM_BLOCKS["run_ibm_16x12x10"]
+    WF_CASES[_n] = 2
+CASES.update({
+    "run_ibm_moist_16x12x10": ("run", 79, 16, 12, 10, dict(_IBM_MOIST, walls="iwalltemp = 2", oracle="nsub = 9\ndump_at = 3, 9"), 1.0),
+    "run_ibm_moistwq_16x12x10": ("run", 80, 16, 12, 10, dict(_IBM_MOIST, walls="iwalltemp = 2\niwallmoist = 2",
+                                                             extra="&ENERGYBALANCE\nwsoil = 300.\nwfc = 313.\n/", oracle="nsub = 9\ndump_at = 3, 9"), 1.0),
+    "k_ibm_wq2_16x12x10": ("kernels", 81, 16, 12, 10, dict(_IBM_MOIST, walls="iwalltemp = 2\niwallmoist = 2",
+                                                           extra="&ENERGYBALANCE\nwsoil = 300.\nwfc = 313.\n/", oracle="nspin = 4"), 1.0),
+})
 # scalars with an inflow / outflow in x while the flow stays periodic (BCxs = 2, the reference's dispersion examples 101 / 102):
 # inlet ghosts mirrored about the inflow profile (xsi_profile, src/modboundary.f90:844), a convective outlet ghost (xso_convective
 # :983, outflow speed ubulk under luvolflowr), no periodic refresh of the scalars' x ghosts
@@ -636,6 +654,8 @@ THL_CASES = {"k_tke_moist_12x8x8": dict(dthl=0.25, qt=0.0118, dqt=-8e-5, tke=0.0
              "k_ibm_wf2_16x12x10": dict(dthl=0.3), "run_ibm_wf2_16x12x10": dict(dthl=0.25),
              "k_ibm_wh2_16x12x10": dict(dthl=0.3), "run_ibm_wh2_16x12x10": dict(dthl=0.25),
              "k_ibm_wh1_16x12x10": dict(dthl=0.3), "run_ibm_wh1_16x12x10": dict(dthl=0.25), "run_ground_wh2_16x8x12": dict(dthl=0.25),
+             "run_ibm_moist_16x12x10": dict(dthl=0.25, qt=0.0119, dqt=-6e-5), "run_ibm_moistwq_16x12x10": dict(dthl=0.25, qt=0.0119, dqt=-6e-5),
+             "k_ibm_wq2_16x12x10": dict(dthl=0.3, qt=0.0118, dqt=-8e-5),
              "k_vreman_buoycorr_12x8x10": dict(dthl=0.004), "run_vreman_buoycorr_16x8x12s": dict(dthl=0.004)}
 
 
@@ -823,7 +843,7 @@ def main():
         if name in IBM_BLOCKS:
             write_ibm_files(cdir, IBM_BLOCKS[name], nx, ny, nz)
         if name in WF_CASES:
-            write_facet_files(cdir, iexp, IBM_BLOCKS[name], nx, ny, nz, kw.get("dx", 0.5), kw.get("dy", 0.5), 0.5, name not in WF_NO_OBLIQUE)
+            write_facet_files(cdir, iexp, IBM_BLOCKS[name], nx, ny, nz, kw.get("dx", 0.5), kw.get("dy", 0.5), 0.5, name not in WF_NO_OBLIQUE, name in GREEN_CASES)
         with tempfile.TemporaryDirectory() as tmp:
             for fn in os.listdir(cdir):
                 shutil.copy(os.path.join(cdir, fn), tmp)

@@ -20,11 +20,12 @@ def _core(name, iexp):
 
 
 @pytest.mark.parametrize("name,iexp", [("k_ibm_16x12x10", 54), ("k_ibm_thl_16x12x10", 58), ("k_ibm_wf3_16x12x10", 66), ("k_ibm_wf2_16x12x10", 67),
-                                       ("k_ibm_wh2_16x12x10", 69), ("k_ibm_wh1_16x12x10", 71)])
+                                       ("k_ibm_wh2_16x12x10", 69), ("k_ibm_wh1_16x12x10", 71), ("k_ibm_wq2_16x12x10", 81)])
 def test_ibm_routines_match_reference(name, iexp):
     """The wf decks: the facet wall functions for momentum (wallfunmom, neutral and with the stability functions on the facet
     temperatures; sections with reconstruction points and an oblique facet normal) ahead of the diffusion corrections.
     wh2: also the heat wall function on the facet temperatures (wallfunheat with iwalltemp = 2) ahead of diffc_corr on thl.
+    wq2: also its latent part on the vegetated facets (iwallmoist = 2: moist_flux against the facets' humidity) on qtp.
     The second deck adds temperature with buoyancy: diffc_corr and solid (volume-mean value) on thl, advecc2nd_corr_liberal,
     and the slab averages over the fluid cells (thl0av; thvh through the buoyancy term of the run fixtures)."""
     fix = load_fixture(name)
@@ -43,6 +44,10 @@ def test_ibm_routines_match_reference(name, iexp):
         av = core.slab_averages(["thl0"])["thl0"]
         assert np.abs(av[1:nz + 1] - fix["ibm.thl0av"].data[:nz]).max() <= 1e-12 * 288.
         core.upload("thlp", marr(fix, "ibw0.thlp", nz))
+    qt = "ibw.qtp" in fix
+    if qt:
+        core.upload("qt0", marr(fix, "sub.qt0", nz)); core.upload("qtm", marr(fix, "in.qtm", nz))
+        core.upload("qtp", marr(fix, "ibw0.qtp", nz))
     # --- ibmwallfun: tendencies as the reference had them before the call
     for t in ("up", "vp", "wp"):
         core.upload(t, marr(fix, f"ibw0.{t}", nz))
@@ -64,6 +69,11 @@ def test_ibm_routines_match_reference(name, iexp):
         assert np.abs(ref - before).max() > 1e-9
         assert relerr(interior(core.download("thlp")), interior(ref)) <= 1e-12
         core.upload("thlp", marr(fix, "ibn0.thlp", nz))
+    if qt:
+        ref, before = marr(fix, "ibw.qtp", nz), marr(fix, "ibw0.qtp", nz)
+        assert np.abs(ref - before).max() > 1e-6
+        assert relerr(interior(core.download("qtp")), interior(ref)) <= 1e-11
+        core.upload("qtp", marr(fix, "ibn0.qtp", nz))
     # --- ibmnorm
     for t in ("up", "vp", "wp"):
         core.upload(t, marr(fix, f"ibn0.{t}", nz))
@@ -83,6 +93,9 @@ def test_ibm_routines_match_reference(name, iexp):
         ref, before = marr(fix, "ibn.thlp", nz), marr(fix, "ibn0.thlp", nz)
         assert np.abs(interior(ref) - interior(before)).max() > 1e-9
         assert relerr(interior(core.download("thlp")), interior(ref)) <= 1e-12
+    if qt:        # solid (mean of the fluid neighbours) and advecc2nd_corr on qt
+        assert relerr(interior(core.download("qtm")), interior(marr(fix, "ibn.qtm", nz))) <= 1e-13
+        assert relerr(interior(core.download("qtp")), interior(marr(fix, "ibn.qtp", nz))) <= 1e-11
     core.close()
 
 

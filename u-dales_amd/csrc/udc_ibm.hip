@@ -287,13 +287,12 @@ extern "C" int udc_ibm_commit(udc_handle *h) {
     if (!h->ibm[gq].given) { udc_set_error("udc_ibm_commit: the u, v and w point lists are needed (udc_set_ibm_points)"); return 1; }
   const bool have_c = h->ibm[3].given;
   if (!h->slots.empty() && !have_c) { udc_set_error("udc_ibm_commit: transported scalars need the c point lists"); return 1; }
-  // thl (slot 15) and qt (13): ibmnorm / diffc_corr as for the scalars plus advecc2nd_corr; the walls are adiabatic and
-  // impermeable (wallfunheat, src/modibm.f90:1436, is not on the device: with prescribed zero fluxes it adds nothing --
-  // the host side refuses decks that ask for anything else).  Not built: the one-equation closure's e12 next to obstacles,
-  // and the moist thermodynamics' slab averages over the fluid cells.
+  // thl (slot 15) and qt (13): ibmnorm / diffc_corr as for the scalars plus advecc2nd_corr; wall fluxes of heat and moisture:
+  // wallfunheat (udc_ibm_wf.hip; udc_set_ibm_wallheat / udc_set_ibm_wallmoist), else adiabatic / impermeable walls.  The moist
+  // thermodynamics' slab averages run over the fluid cells (udc_thermo.hip).  Not built: the one-equation closure's e12 next to obstacles.
   for (int n : h->slots)
     if (n == 14) { udc_set_error("udc_ibm_commit: the one-equation closure (e12) is not available with immersed boundaries"); return 1; }
-  if (h->lmoist && h->mt) { udc_set_error("udc_ibm_commit: the moist thermodynamics (lmoist with lbuoyancy) are not available with immersed boundaries"); return 1; }
+  if (h->lmoist && h->mt && !have_c) { udc_set_error("udc_ibm_commit: the moist thermodynamics average over the fluid cells: the c point lists are needed"); return 1; }
   const int nx = h->g.nx, ny = h->jtot, nz = h->g.nz, j0 = h->cfg.rank * h->g.ny, nyl = h->g.ny;
   // masks as initibm builds them (src/modibm.f90:150-186): 1 = fluid; planes k = 0 (kb-1) .. nz+1.  Beyond a lateral
   // boundary of the domain: the periodic image, or "fluid" where the reference's exchange_halo_z would not have wrapped

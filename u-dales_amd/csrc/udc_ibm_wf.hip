@@ -20,6 +20,11 @@ struct WfArgs {
   const double *u0, *v0, *w0, *thl0, *zf, *zh;      // zf, zh: entry 0 = reference index 1
   double *rhs;
   double prt, fkar;      // &WALLS prandtlturb, fkar (src/modglobal.f90:304, 317)
+  // latent part of wallfunheat (c grid, lmoist): 0 off, 1 prescribed flux per section (in qwall), 2 moist_flux on the facets' humidity
+  int iwallmoist;
+  const int *lgr;
+  const double *qwall, *hurel, *resc, *ress, *qt0;
+  double *rhsq;
 };
 
 __device__ __forceinline__ int wx(int i, int nx) { return i < 0 ? i + nx : (i >= nx ? i - nx : i); }
@@ -135,8 +140,8 @@ __global__ void ibm_wallfunmom_kernel(Geo g, Metrics m, WfArgs a) {
   a.rhs[c] = t;
 }
 
-// heat_transfer_coef_flux, :1920-1986 -> flux [K m/s]
-__device__ __forceinline__ double heat_flux(double utan, double dist, double z0, double z0h, double Tair, double Tsurf, double prt, double fkar) {
+// heat_transfer_coef_flux, :1920-1986 -> flux [K m/s]; htc = flux / (|utan| dT) where that is defined, else 0 (:1975-1979)
+__device__ __forceinline__ double heat_flux(double utan, double dist, double z0, double z0h, double Tair, double Tsurf, double prt, double fkar, double &htc) {
   const double b1 = 9.4, b2 = 4.7, dm = 7.4, dh = 5.3, grav = 9.81;
   const double dT = Tair - Tsurf;
   const double Ribl0 = grav * dist * dT / (Tsurf * (utan * utan));
@@ -159,10 +164,14 @@ __device__ __forceinline__ double heat_flux(double utan, double dist, double z0,
   M = prt * logdz * sqrt(Fm) / Fh;
   const double dTrough = dT * 1. / (prt * logzh / M + 1.);
   const double cth = fkar2 / (logdz * logdz) * Fh / prt;
-  return fabs(utan) * cth * dTrough;
+  const double flux = fabs(utan) * cth * dTrough;
+  htc = fabs(fabs(utan) * dT) > 0. ? flux / (fabs(utan) * dT) : 0.;
+  return flux;
 }
 
-// wallfunheat, sensible part with the facet temperatures (iwalltemp = 2, :1436-1540): the c-grid sections
+// wallfunheat (:1436-1607): the c-grid sections.  Sensible part from the facet temperatures (iwalltemp = 2) or prescribed
+// (iwalltemp = 1); latent part on the vegetated facets (faclGR, :1556-1600): prescribed (iwallmoist = 1) or moist_flux (:1989) of the
+// air's humidity against the facet's saturation humidity through the aerodynamic + canopy / soil resistances (iwallmoist = 2)
 __global__ void ibm_wallfunheat_kernel(Geo g, Metrics m, WfArgs a) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= a.ncell) return;
@@ -171,15 +180,18 @@ __global__ void ibm_wallfunheat_kernel(Geo g, Metrics m, WfArgs a) {
   const double eps1 = 1.e-10;
   const double vol = m.dx * m.dy * m.dzh[k];
   double t = a.rhs[c];
+  const bool moist = a.iwallmoist > 0;
+  double tq = moist ? a.rhsq[c] : 0.;
   for (int s = a.off[q]; s < a.off[q + 1]; ++s) {
     const double nrm[3] = {a.norm[3 * s], a.norm[3 * s + 1], a.norm[3 * s + 2]};
     const double z0 = a.z0[s];
-    double uv[3], Tair, dist;
+    double uv[3], Tair, dist, qtair = 0.;
     if (a.comprec[s]) {      // interp_velocity_c, :1780-1791
       uv[0] = 0.5 * (at(g, a.u0, j0, i, j, k) + at(g, a.u0, j0, i + 1, j, k));
       uv[1] = 0.5 * (at(g, a.v0, j0, i, j, k) + at(g, a.v0, j0, i, j + 1, k));
       uv[2] = 0.5 * (at(g, a.w0, j0, i, j, k) + at(g, a.w0, j0, i, j, k + 1));
       Tair = at(g, a.thl0, j0, i, j, k);
+      if (moist) qtair = at(g, a.qt0, j0, i, j, k);
       dist = a.dist[s];
     } else {
       const double *p = a.recpt + 3 * s;
@@ -188,6 +200,7 @@ __global__ void ibm_wallfunheat_kernel(Geo g, Metrics m, WfArgs a) {
       uv[1] = trilinear(g, m, a.v0, j0, r + 3, 0, 1, a.zf, p);
       uv[2] = trilinear(g, m, a.w0, j0, r + 6, 0, 0, a.zh, p);
       Tair = trilinear(g, m, a.thl0, j0, r + 9, 0, 0, a.zf, p);
+      if (moist) qtair = trilinear(g, m, a.qt0, j0, r + 9, 0, 0, a.zf, p);
       const double ex = p[0] - (i - 0.5) * m.dx, ey = p[1] - (j - 0.5) * m.dy, ez = p[2] - a.zf[k - 1];
       dist = a.dist[s] + sqrt(ex * ex + ey * ey + ez * ez);
     }
@@ -200,10 +213,21 @@ __global__ void ibm_wallfunheat_kernel(Geo g, Metrics m, WfArgs a) {
     const double st[3] = {sp[1] * nrm[2] - sp[2] * nrm[1], sp[2] * nrm[0] - sp[0] * nrm[2], sp[0] * nrm[1] - sp[1] * nrm[0]};
     const double utan = uv[0] * st[0] + uv[1] * st[1] + uv[2] * st[2];
     // iwalltemp = 1: the prescribed flux of the facet's direction rides in the slot of the facet temperature
-    const double flux = a.iwallmom == 1 ? a.tsurf[s] : heat_flux(utan, dist, z0, a.z0h[s], Tair, a.tsurf[s], a.prt, a.fkar);
+    double htc = 0.;
+    double flux = a.iwallmom == 1 ? a.tsurf[s] : heat_flux(utan, dist, z0, a.z0h[s], Tair, a.tsurf[s], a.prt, a.fkar, htc);
     t = t - flux * a.area[s] / vol;
+    if (moist && a.lgr[s]) {
+      if (a.iwallmoist == 1) flux = a.qwall[s];
+      else if (fabs(htc * fabs(utan)) > 0.) {      // (else the reference's `flux` still holds the sensible one, which is then zero)
+        const double resa = 1. / (htc * fabs(utan)), cveg = 0.8;
+        const double qw = a.qwall[s];
+        flux = fmin(0., cveg * (qtair - qw) / (resa + a.resc[s]) + (1 - cveg) * (qtair - qw * a.hurel[s]) / (resa + a.ress[s]));
+      }
+      tq = tq - flux * a.area[s] / vol;
+    }
   }
   a.rhs[c] = t;
+  if (moist) a.rhsq[c] = tq;
 }
 
 template <class T>
@@ -294,6 +318,7 @@ extern "C" int udc_set_ibm_sections(udc_handle *h, int grid, int n, const int *c
   HIP_OK(hipStreamSynchronize(h->stream));
   S.ncell = (int)cells.size() / 3;
   S.nsec = (int)mine.size();
+  S.order = mine; S.nglobal = n;
   if (upload(&S.cell, cells) || upload(&S.off, off) || upload(&S.comprec, comp) || upload(&S.recids, rid) || upload(&S.area, ar) ||
       upload(&S.dist, di) || upload(&S.norm, nr) || upload(&S.z0, zz) || upload(&S.z0h, zh_) || upload(&S.tsurf, ts) || upload(&S.recpt, rp) ||
       upload(&S.tmask, tm))
@@ -316,7 +341,7 @@ int k_ibm_wallfunmom(udc_handle *h) {
     a.thl0 = h->ibm_iwallmom == 2 ? h->fields[UDC_THL0] : nullptr;
     a.zf = h->ibm_zgrid; a.zh = h->ibm_zgrid + (g.nz + 1);
     a.rhs = h->fields[UDC_UP + q];
-    a.prt = h->ibm_prt; a.fkar = h->fkar;
+    a.prt = h->ibm_prt; a.fkar = h->fkar; a.iwallmoist = 0;
     hipLaunchKernelGGL(ibm_wallfunmom_kernel, dim3((unsigned)((S.ncell + 127) / 128)), dim3(128), 0, h->stream, g, h->m, a);
   }
   HIP_OK(hipGetLastError());
@@ -334,6 +359,37 @@ extern "C" int udc_set_ibm_wallheat(udc_handle *h, int iwalltemp) {
   return 0;
 }
 
+// Latent part of wallfunheat (src/modibm.f90:1556-1600): per c-grid section, in the order udc_set_ibm_sections(grid 3) was given them:
+// lgr -- the facet is vegetated (faclGR; only those exchange moisture); iwallmoist = 1: qwall = the prescribed flux of the facet's
+// direction (bcqfxm ...); iwallmoist = 2: qwall = facqsat, hurel = fachurel, resc / ress = facf(:, 4) / facf(:, 5)
+extern "C" int udc_set_ibm_wallmoist(udc_handle *h, int iwallmoist, int n, const int *lgr, const double *qwall, const double *hurel,
+                                     const double *resc, const double *ress) {
+  if (!h) { udc_set_error("null handle"); return 1; }
+  HIP_OK(hipSetDevice(h->device));
+  if (udc_flush_pending(h)) return 1;
+  if (iwallmoist < 0 || iwallmoist > 2) { udc_set_error("udc_set_ibm_wallmoist: 0 (off: impermeable walls), 1 (prescribed fluxes) or 2 (moist_flux on the facets' humidity)"); return 1; }
+  udc_handle::IbmSections &S = h->ibm_sec[3];
+  if (!iwallmoist) { h->ibm_iwallmoist = 0; return 0; }
+  if (!h->lmoist) { udc_set_error("udc_set_ibm_wallmoist: call udc_set_moisture first"); return 1; }
+  if (iwallmoist == 2 && h->ibm_iwalltemp != 2) {
+    udc_set_error("udc_set_ibm_wallmoist: iwallmoist = 2 takes its aerodynamic resistance from the heat transfer coefficient of iwalltemp = 2 "
+                  "(undefined in the reference otherwise, src/modibm.f90:1571-1574): call udc_set_ibm_wallheat(2) first");
+    return 1;
+  }
+  if (h->ibm_iwalltemp < 1) { udc_set_error("udc_set_ibm_wallmoist: the latent flux is part of wallfunheat: call udc_set_ibm_wallheat first"); return 1; }
+  if (n != S.nglobal) { udc_set_error("udc_set_ibm_wallmoist: %d sections, udc_set_ibm_sections(grid 3) was given %d", n, S.nglobal); return 1; }
+  if (n && (!lgr || !qwall || (iwallmoist == 2 && (!hurel || !resc || !ress)))) { udc_set_error("udc_set_ibm_wallmoist: null array"); return 1; }
+  std::vector<int> lg; std::vector<double> qw, hu, rc, rs;
+  for (int s : S.order) {
+    lg.push_back(lgr[s]); qw.push_back(qwall[s]);
+    hu.push_back(iwallmoist == 2 ? hurel[s] : 0.); rc.push_back(iwallmoist == 2 ? resc[s] : 0.); rs.push_back(iwallmoist == 2 ? ress[s] : 0.);
+  }
+  HIP_OK(hipStreamSynchronize(h->stream));
+  if (upload(&S.lgr, lg) || upload(&S.qwall, qw) || upload(&S.hurel, hu) || upload(&S.resc, rc) || upload(&S.ress, rs)) return 1;
+  h->ibm_iwallmoist = iwallmoist;
+  return 0;
+}
+
 // wallfunheat on thlp (ibmwallfun, src/modibm.f90:1220-1231), after the momentum corrections and before diffc_corr
 int k_ibm_wallfunheat(udc_handle *h) {
   if (h->ibm_iwalltemp < 1) return 0;
@@ -348,6 +404,9 @@ int k_ibm_wallfunheat(udc_handle *h) {
   a.zf = h->ibm_zgrid; a.zh = h->ibm_zgrid + (g.nz + 1);
   a.rhs = h->fields[UDC_THLP];
   a.prt = h->ibm_prt; a.fkar = h->fkar;
+  a.iwallmoist = (h->ibm_iwallmoist && S.lgr) ? h->ibm_iwallmoist : 0;
+  a.lgr = S.lgr; a.qwall = S.qwall; a.hurel = S.hurel; a.resc = S.resc; a.ress = S.ress;
+  a.qt0 = a.iwallmoist ? h->fields[UDC_QT0] : nullptr; a.rhsq = a.iwallmoist ? h->fields[UDC_QTP] : nullptr;
   hipLaunchKernelGGL(ibm_wallfunheat_kernel, dim3((unsigned)((S.ncell + 127) / 128)), dim3(128), 0, h->stream, g, h->m, a);
   HIP_OK(hipGetLastError());
   return 0;
@@ -355,8 +414,8 @@ int k_ibm_wallfunheat(udc_handle *h) {
 
 void ibm_wf_destroy(udc_handle *h) {
   for (auto &S : h->ibm_sec) {
-    for (int **p : {&S.cell, &S.off, &S.comprec, &S.recids}) if (*p) { hipFree(*p); *p = nullptr; }
-    for (double **p : {&S.area, &S.dist, &S.norm, &S.z0, &S.z0h, &S.tsurf, &S.recpt, &S.tmask}) if (*p) { hipFree(*p); *p = nullptr; }
+    for (int **p : {&S.cell, &S.off, &S.comprec, &S.recids, &S.lgr}) if (*p) { hipFree(*p); *p = nullptr; }
+    for (double **p : {&S.area, &S.dist, &S.norm, &S.z0, &S.z0h, &S.tsurf, &S.recpt, &S.tmask, &S.qwall, &S.hurel, &S.resc, &S.ress}) if (*p) { hipFree(*p); *p = nullptr; }
     S.ncell = S.nsec = 0;
   }
   if (h->ibm_zgrid) { hipFree(h->ibm_zgrid); h->ibm_zgrid = nullptr; }

@@ -236,9 +236,14 @@ struct udc_handle {
     int ncell = 0, nsec = 0;
     int *cell = nullptr, *off = nullptr, *comprec = nullptr, *recids = nullptr;     // cell: global 1-based i, j, k per row
     double *area = nullptr, *dist = nullptr, *norm = nullptr, *z0 = nullptr, *z0h = nullptr, *tsurf = nullptr, *recpt = nullptr, *tmask = nullptr;
+    std::vector<int> order;             // position in the caller's list of each kept section (later per-section tables follow it)
+    int nglobal = 0;                    // sections the caller listed (all slabs)
+    int *lgr = nullptr;                 // c grid, latent wall flux (udc_set_ibm_wallmoist): vegetated facet; saturation humidity /
+    double *qwall = nullptr, *hurel = nullptr, *resc = nullptr, *ress = nullptr;      // prescribed flux, humidity, resistances
   };
   IbmSections ibm_sec[4];               // u, v, w (wallfunmom), c (wallfunheat)
   int ibm_iwallmom = 1;                 // 1: no wall functions; 2: Uno et al. stability functions; 3: neutral log law
+  int ibm_iwallmoist = 0;               // wallfunheat's latent part: 0 off (impermeable walls); 1 prescribed per section; 2 moist_flux
   int ibm_iwalltemp = 0;                // wallfunheat: 0 off (adiabatic walls); 1 prescribed fluxes per section; 2 from the facet temperatures
   double ibm_prt = 0.71;
   double *ibm_zgrid = nullptr;          // zf(1 : nz+1), zh(1 : nz+1)

@@ -163,9 +163,60 @@ __global__ __launch_bounds__(256) void thv_sums_kernel(Geo g, Metrics m, int gx,
   __syncthreads();
   if (threadIdx.x == 0 && threadIdx.y == 0) part[(size_t)k * gridDim.x + tile] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
 }
-__global__ void divide_kernel(double *a, int n, double d) {
+// cntk: fluid points per level with an immersed boundary (entry q of a <-> cntk[q]), else null and d applies
+__global__ void divide_kernel(double *a, int n, double d, const double *__restrict__ cntk) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q < n) a[q] = a[q] / d;
+  if (q < n) {
+    const double c = cntk ? cntk[q] : d;
+    a[q] = c > 0. ? a[q] / c : -999.;      // (a level without fluid points: avexy_ibm's -999, src/modmpi.f90:655-659)
+  }
+}
+// Immersed boundary: diagfld's slab averages run over the fluid c cells only (avexy_ibm with IIc / IIcs, :262-279), so the listed
+// solid c points come back out of the level sums of moist_sums_kernel.  One workgroup per level k = 0..nz.  The reference's ql0
+// holds level k+1 at k (see moist_sums_kernel), so in ql0av the mask of level k meets the condensate of level k+1.
+template <bool QL>
+__global__ __launch_bounds__(256) void ibm_moist_sums_correct_kernel(Geo g, int ke1, const int *__restrict__ pts, const int *__restrict__ off,
+                                                                      const double *__restrict__ thl, const double *__restrict__ qt,
+                                                                      const double *__restrict__ presf, const double *__restrict__ exnf,
+                                                                      double *__restrict__ sums, int nr) {
+  __shared__ double sw[3][4];
+  const int k = blockIdx.x;
+  const bool qlok = QL && k + 1 <= g.nz;
+  const double pf = qlok ? presf[k + 2] : 0., ef = qlok ? exnf[k + 2] : 0.;
+  double v[3] = {0., 0., 0.};
+  for (int q = off[k] + threadIdx.x; q < off[k + 1]; q += 256) {
+    const long c = g.idx(pts[3 * q], pts[3 * q + 1], k);
+    v[0] += thl[c]; v[1] += qt[c];
+    if (qlok) v[2] += th_cond(nr, thl[c + g.sz], qt[c + g.sz], pf, ef);
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    for (int o = 32; o > 0; o >>= 1) v[q] += __shfl_xor(v[q], o, 64);
+    if ((threadIdx.x & 63) == 0) sw[q][threadIdx.x >> 6] = v[q];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    sums[k] = sums[k] - ((sw[0][0] + sw[0][1]) + (sw[0][2] + sw[0][3]));
+    sums[ke1 + k] = sums[ke1 + k] - ((sw[1][0] + sw[1][1]) + (sw[1][2] + sw[1][3]));
+    if (qlok) sums[2 * ke1 + k + 1] = sums[2 * ke1 + k + 1] - ((sw[2][0] + sw[2][1]) + (sw[2][2] + sw[2][3]));
+  }
+}
+// ... and thvh over the fluid w points (avexy_ibm with IIw / IIws, :76): S[k] = level sum of thv0h at device level k
+__global__ __launch_bounds__(256) void ibm_thv_correct_kernel(Geo g, Metrics m, const int *__restrict__ pts, const int *__restrict__ off,
+                                                               const double *__restrict__ thl, const double *__restrict__ qt,
+                                                               const double *__restrict__ presh, const double *__restrict__ exnh,
+                                                               double *__restrict__ S, int nr) {
+  __shared__ double sw[4];
+  const int k = blockIdx.x;
+  double v = 0.;
+  if (k >= 1) {
+    const double ph = presh[k + 1], eh = exnh[k + 1];
+    for (int q = off[k] + threadIdx.x; q < off[k + 1]; q += 256) v += thv_half(g, m, thl, qt, ph, eh, g.idx(pts[3 * q], pts[3 * q + 1], k), k, nr);
+  }
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) S[k] = S[k] - ((sw[0] + sw[1]) + (sw[2] + sw[3]));
 }
 __global__ __launch_bounds__(256) void buoyancy_moist_kernel(Geo g, TileGrid tg, Metrics m, const double *__restrict__ thl,
                                                               const double *__restrict__ qt, const double *__restrict__ presh,
@@ -220,8 +271,10 @@ __device__ void fromztop_dev(const DiagArgs &a, double *mt, const double *__rest
   }
   __syncthreads();
 }
+// cntc: fluid c cells per level (reference index) with an immersed boundary, else null and a.cnt applies
 __global__ __launch_bounds__(256) void diagfld_kernel(DiagArgs a, double *mt, const double *__restrict__ sums,
-                                                       const double *__restrict__ dzf, const double *__restrict__ dzh, int with_ql) {
+                                                       const double *__restrict__ dzf, const double *__restrict__ dzh, int with_ql,
+                                                       const double *__restrict__ cntc) {
   extern __shared__ double lds[];      // 4 (nz+2) doubles
   const int n2 = a.nz + 2, ke1 = a.nz + 1;
   double *thl0av = mt + udc_handle::MT_THL0AV * n2, *qt0av = mt + udc_handle::MT_QT0AV * n2, *ql0av = mt + udc_handle::MT_QL0AV * n2;
@@ -229,11 +282,12 @@ __global__ __launch_bounds__(256) void diagfld_kernel(DiagArgs a, double *mt, co
   const double *zf = mt + udc_handle::MT_ZF * n2, *zh = mt + udc_handle::MT_ZH * n2;
   const double *presf = mt + udc_handle::MT_PRESF * n2, *presh = mt + udc_handle::MT_PRESH * n2;
   for (int k = 1 + threadIdx.x; k <= ke1; k += blockDim.x) {
-    thl0av[k] = sums[k - 1] / a.cnt;
-    qt0av[k] = sums[ke1 + k - 1] / a.cnt;
+    const double cnt = cntc ? cntc[k] : a.cnt;
+    thl0av[k] = sums[k - 1] / cnt;
+    qt0av[k] = sums[ke1 + k - 1] / cnt;
     // the reference's ql0 holds level k+1 at k and nothing at ke+kh (sequence association in `thermo`, see
     // oracle/udcore_oracle.c orc_thermodynamics): its slab average is one level low
-    ql0av[k] = (with_ql && k <= a.nz) ? sums[2 * ke1 + k] / a.cnt : 0.;
+    ql0av[k] = (with_ql && k <= a.nz) ? sums[2 * ke1 + k] / cnt : 0.;
     exnf[k] = 1 - a.grav * zf[k] / (TH_CP * a.thls);
     exnh[k] = 1 - a.grav * zh[k] / (TH_CP * a.thls);
     th0av[k] = thl0av[k] + (TH_RLV / TH_CP) * ql0av[k] / exnf[k];
@@ -385,6 +439,9 @@ int k_thermodynamics(udc_handle *h) {
     }
     ql0 = h->fields[UDC_QL0];
   }
+  // immersed boundary: the averages run over the fluid cells (c grid) / fluid w points only
+  const udc_handle::IbmGrid *Cg = h->ibm_on ? &h->ibm[3] : nullptr, *Wg = h->ibm_on ? &h->ibm[2] : nullptr;
+  if (Cg && !Cg->given) { udc_set_error("udc_thermodynamics with an immersed boundary: the c-grid point lists are needed (udc_set_ibm_points, grid 3)"); return 1; }
   PROF(h, "thermodynamics");
   for (int pass = h->mt_valid ? 1 : 0; pass < 2; ++pass) {
     const dim3 gr((unsigned)mtiles, (unsigned)ke1), b(64, 4);
@@ -392,9 +449,17 @@ int k_thermodynamics(udc_handle *h) {
                                  (const double *)(mt + udc_handle::MT_EXNF * n2), h->lev_part, h->lqlnr, ql0);
     else hipLaunchKernelGGL(moist_sums_kernel<false>, gr, b, 0, h->stream, g, tg.gx, thl, qt, (const double *)nullptr, (const double *)nullptr, h->lev_part, 0, (double *)nullptr);
     hipLaunchKernelGGL(levelsum_final_kernel, dim3((unsigned)(3 * ke1)), dim3(256), 0, h->stream, mtiles, h->lev_part, sums);
+    if (Cg && Cg->nsolid) {
+      if (pass) hipLaunchKernelGGL(ibm_moist_sums_correct_kernel<true>, dim3((unsigned)ke1), dim3(256), 0, h->stream, g, ke1, (const int *)Cg->lev_pts,
+                                   (const int *)Cg->lev_off, thl, qt, (const double *)(mt + udc_handle::MT_PRESF * n2),
+                                   (const double *)(mt + udc_handle::MT_EXNF * n2), sums, h->lqlnr);
+      else hipLaunchKernelGGL(ibm_moist_sums_correct_kernel<false>, dim3((unsigned)ke1), dim3(256), 0, h->stream, g, ke1, (const int *)Cg->lev_pts,
+                              (const int *)Cg->lev_off, thl, qt, (const double *)nullptr, (const double *)nullptr, sums, 0);
+    }
     HIP_OK(hipGetLastError());
     if (comm_allreduce(h, sums, 3 * ke1, 1)) return 1;       // avexy_ibm's MPI_ALLREDUCE over the slabs
-    hipLaunchKernelGGL(diagfld_kernel, dim3(1), dim3(256), sizeof(double) * 4 * n2, h->stream, da, mt, (const double *)sums, h->m.dzf, h->m.dzh, pass);
+    hipLaunchKernelGGL(diagfld_kernel, dim3(1), dim3(256), sizeof(double) * 4 * n2, h->stream, da, mt, (const double *)sums, h->m.dzf, h->m.dzh, pass,
+                       (const double *)(Cg ? Cg->cnt_dev : nullptr));
     HIP_OK(hipGetLastError());
     h->mt_valid = true;
   }
@@ -402,9 +467,13 @@ int k_thermodynamics(udc_handle *h) {
   hipLaunchKernelGGL(thv_sums_kernel, dim3((unsigned)mtiles, (unsigned)g.nz), dim3(64, 4), 0, h->stream, g, h->m, tg.gx, thl, qt,
                      (const double *)(mt + udc_handle::MT_PRESH * n2), (const double *)(mt + udc_handle::MT_EXNH * n2), h->lev_part, h->lqlnr);
   hipLaunchKernelGGL(levelsum_final_kernel, dim3((unsigned)g.nz), dim3(256), 0, h->stream, mtiles, h->lev_part, thvh + 1);
+  if (Wg && Wg->nsolid)
+    hipLaunchKernelGGL(ibm_thv_correct_kernel, dim3((unsigned)g.nz), dim3(256), 0, h->stream, g, h->m, (const int *)Wg->lev_pts, (const int *)Wg->lev_off,
+                       thl, qt, (const double *)(mt + udc_handle::MT_PRESH * n2), (const double *)(mt + udc_handle::MT_EXNH * n2), thvh + 1, h->lqlnr);
   HIP_OK(hipGetLastError());
   if (comm_allreduce(h, thvh + 1, g.nz, 1)) return 1;
-  hipLaunchKernelGGL(divide_kernel, dim3((g.nz + 255) / 256), dim3(256), 0, h->stream, thvh + 1, g.nz, cnt);
+  // (entry q of thvh + 1 is the reference's level q + 1; level kb itself is never read: forces starts at kb + 1)
+  hipLaunchKernelGGL(divide_kernel, dim3((g.nz + 255) / 256), dim3(256), 0, h->stream, thvh + 1, g.nz, cnt, (const double *)(Wg ? Wg->cnt_dev + 1 : nullptr));
   HIP_OK(hipGetLastError());
   return 0;
 }

@@ -65,6 +65,10 @@ module modibm
   end type ibm_lists
   type(ibm_lists) :: lists(0:3)
   logical :: ibm_pending = .false.
+  ! latent part of wallfunheat: per kept c-grid section, between grid_sections(3) and udc_set_ibm_wallmoist
+  logical :: latent = .false.
+  integer(c_int), allocatable :: wm_lgr(:)
+  real(c_double), allocatable :: wm_q(:), wm_hurel(:), wm_resc(:), wm_ress(:)
 
 contains
 
@@ -103,15 +107,18 @@ contains
       write (0, *) 'ERROR: libudcore modibm: iwallmom must be 1, 2 (with ltempeq: the stability functions read the air temperature) or 3'
       stop 1
     end if
-    ! temperature: wallfunheat (src/modibm.f90:1436) with prescribed fluxes (iwalltemp = 1) or from the facet temperatures (2).
-    ! Moisture: impermeable walls only.
-    if (lwritefac .or. (ltempeq .and. iwalltemp /= 1 .and. iwalltemp /= 2) .or. &
-        (lmoist .and. (iwallmoist /= 1 .or. any((/bcqfxm, bcqfxp, bcqfym, bcqfyp, bcqfz/) /= 0.)))) then
-      write (0, *) 'ERROR: libudcore modibm: not available: lwritefac, wall moisture fluxes (only iwallmoist = 1 with bcqf* = 0)'
+    ! wallfunheat (src/modibm.f90:1436): sensible part prescribed (iwalltemp = 1) or from the facet temperatures (2); latent part on
+    ! the vegetated facets prescribed (iwallmoist = 1) or from the facets' humidity (2, with the heat transfer coefficient of iwalltemp = 2)
+    if (lwritefac .or. (ltempeq .and. iwalltemp /= 1 .and. iwalltemp /= 2) .or. (lmoist .and. iwallmoist /= 1 .and. iwallmoist /= 2)) then
+      write (0, *) 'ERROR: libudcore modibm: not available: lwritefac; iwalltemp / iwallmoist must be 1 or 2'
       stop 1
     end if
-    if (lmoist .and. lbuoyancy) then
-      write (0, *) 'ERROR: libudcore modibm: the moist thermodynamics (lmoist with lbuoyancy) are not available with libm'
+    if (lmoist .and. iwallmoist == 2 .and. .not. (ltempeq .and. iwalltemp == 2)) then
+      write (0, *) 'ERROR: libudcore modibm: iwallmoist = 2 takes its aerodynamic resistance from the heat transfer coefficient of iwalltemp = 2'
+      stop 1
+    end if
+    if (lmoist .and. .not. ltempeq .and. any((/bcqfxm, bcqfxp, bcqfym, bcqfyp, bcqfz/) /= 0.)) then
+      write (0, *) 'ERROR: libudcore modibm: wall moisture fluxes: wallfunheat runs with the temperature equation (ltempeq)'
       stop 1
     end if
     need_c = nsv > 0 .or. ltempeq .or. lmoist          ! src/modibm.f90:180
@@ -193,10 +200,11 @@ contains
   !> facet wall functions (wallfunmom :1286, wallfunheat :1436): level coordinates and the facet sections of each grid
   subroutine sections_to_device
     use udc_iface
-    use modglobal, only: iwallmom, iwalltemp, ltempeq, prandtlturb, zf, zh, kb, ke, kh
-    use modibmdata, only: bctfxm, bctfxp, bctfym, bctfyp, bctfz
+    use modglobal, only: iwallmom, iwalltemp, iwallmoist, ltempeq, lmoist, prandtlturb, zf, zh, kb, ke, kh
+    use modibmdata, only: bctfxm, bctfxp, bctfym, bctfyp, bctfz, bcqfxm, bcqfxp, bcqfym, bcqfyp, bcqfz
     logical :: heat
-    heat = ltempeq .and. (iwalltemp == 2 .or. (iwalltemp == 1 .and. any((/bctfxm, bctfxp, bctfym, bctfyp, bctfz/) /= 0.)))
+    latent = lmoist .and. (iwallmoist == 2 .or. (iwallmoist == 1 .and. any((/bcqfxm, bcqfxp, bcqfym, bcqfyp, bcqfz/) /= 0.)))
+    heat = ltempeq .and. (iwalltemp == 2 .or. (iwalltemp == 1 .and. any((/bctfxm, bctfxp, bctfym, bctfyp, bctfz/) /= 0.)) .or. latent)
     if (iwallmom <= 1 .and. .not. heat) return
     call udc_check(udc_set_ibm_wallfun(udc_h, int(iwallmom, c_int), real(prandtlturb, c_double), real(zf(kb:ke + kh), c_double), &
                                        real(zh(kb:ke + kh), c_double)), 'udc_set_ibm_wallfun')
@@ -208,6 +216,11 @@ contains
     if (heat) then
       call grid_sections(3, 'facet_sections_c.txt', nfctsecs_c)
       call udc_check(udc_set_ibm_wallheat(udc_h, int(iwalltemp, c_int)), 'udc_set_ibm_wallheat')
+      if (latent) then      ! the tables grid_sections(3) left: vegetated?, prescribed flux / saturation humidity, humidity, resistances
+        call udc_check(udc_set_ibm_wallmoist(udc_h, int(iwallmoist, c_int), int(size(wm_lgr), c_int), wm_lgr, wm_q, wm_hurel, wm_resc, wm_ress), &
+                       'udc_set_ibm_wallmoist')
+        deallocate (wm_lgr, wm_q, wm_hurel, wm_resc, wm_ress)
+      end if
     end if
   end subroutine sections_to_device
 
@@ -216,14 +229,14 @@ contains
   !! (:375-424) -- and the cells around that point on the four grids (:426-482).  Facet data from the reference's initfac.
   subroutine grid_sections(grid, fname, nsec)
     use udc_iface
-    use modglobal, only: ifinput, ib, itot, ih, jb, jtot, jh, kb, ke, kh, xf, xh, yf, yh, zf, zh, dx, dy, dzf, eps1, iwalltemp
-    use modibmdata, only: bctfxm, bctfxp, bctfyp, bctfz
-    use initfac, only: facnorm, facz0, facz0h, facT
+    use modglobal, only: ifinput, ib, itot, ih, jb, jtot, jh, kb, ke, kh, xf, xh, yf, yh, zf, zh, dx, dy, dzf, eps1, iwalltemp, iwallmoist
+    use modibmdata, only: bctfxm, bctfxp, bctfyp, bctfz, bcqfxm, bcqfxp, bcqfym, bcqfyp, bcqfz
+    use initfac, only: facnorm, facz0, facz0h, facT, faclGR, facqsat, fachurel, facf
     use decomp_2d, only: zstart, zend
     integer, intent(in) :: grid, nsec
     character(*), intent(in) :: fname
-    integer(c_int), allocatable :: cell(:, :), comprec(:), recids(:, :, :)
-    real(c_double), allocatable :: area(:), dist(:), norm(:, :), z0(:), z0h(:), ts(:), recpt(:, :), tmask(:, :)
+    integer(c_int), allocatable :: cell(:, :), comprec(:), recids(:, :, :), t_lgr(:)
+    real(c_double), allocatable :: area(:), dist(:), norm(:, :), z0(:), z0h(:), ts(:), recpt(:, :), tmask(:, :), t_q(:), t_hurel(:), t_resc(:), t_ress(:)
     integer :: n, m, fac, bid, dalign, q, pos, i, j, k, di, dj, dk, li, lj
     real :: a, dst, xc, yc, zc, p0(3), p1(3), nrm(3), inter(6, 3), idist(6), planes(6, 3), pn(6, 3)
     integer :: chk(6)
@@ -232,6 +245,10 @@ contains
     allocate (cell(3, nsec), comprec(nsec), recids(3, 4, nsec), area(nsec), dist(nsec), norm(3, nsec), z0(nsec), z0h(nsec), ts(nsec), &
               recpt(3, nsec), tmask(2, nsec))
     recids = 1; recpt = 0.; tmask = 1.
+    if (grid == 3 .and. latent) then
+      allocate (t_lgr(nsec), t_q(nsec), t_hurel(nsec), t_resc(nsec), t_ress(nsec))
+      t_lgr = 0; t_q = 0.; t_hurel = 0.; t_resc = 0.; t_ress = 0.
+    end if
     dalign = merge(0, grid + 1, grid == 3)
     di = merge(1, 0, grid == 0); dj = merge(1, 0, grid == 1); dk = merge(1, 0, grid == 2)
     m = 0
@@ -259,6 +276,23 @@ contains
             write (0, *) 'ERROR: libudcore modibm: iwalltemp = 1: the reference defines the wall heat flux for facets facing +-x, +-y, +z only'
             stop 1
           end select
+        end if
+        if (grid == 3 .and. latent) then      ! latent part (:1556-1600): the vegetated facets only
+          t_lgr(m) = merge(1, 0, faclGR(fac)); t_q(m) = 0.; t_hurel(m) = 0.; t_resc(m) = 0.; t_ress(m) = 0.
+          if (faclGR(fac) .and. iwallmoist == 1) then
+            select case (alignment(nrm))
+            case (1); t_q(m) = bcqfxp
+            case (-1); t_q(m) = bcqfxm
+            case (2); t_q(m) = bcqfyp
+            case (-2); t_q(m) = bcqfym
+            case (3); t_q(m) = bcqfz
+            case default
+              write (0, *) 'ERROR: libudcore modibm: iwallmoist = 1: the reference defines the wall moisture flux for facets facing +-x, +-y, +z only'
+              stop 1
+            end select
+          else if (iwallmoist == 2) then
+            t_q(m) = facqsat(fac); t_hurel(m) = fachurel(fac); t_resc(m) = facf(fac, 4); t_ress(m) = facf(fac, 5)
+          end if
         end if
         comprec(m) = 1
         if (.not. (log(dst/facz0(fac)) > 1. .or. lnorec)) then                                       ! :375-378
@@ -315,6 +349,10 @@ contains
     end if
     call udc_check(udc_set_ibm_sections(udc_h, int(grid, c_int), int(m, c_int), cell, area, dist, norm, z0, z0h, ts, comprec, recpt, recids, &
                                         tmask), 'udc_set_ibm_sections')
+    if (grid == 3 .and. latent) then
+      allocate (wm_lgr(m), wm_q(m), wm_hurel(m), wm_resc(m), wm_ress(m))
+      wm_lgr = t_lgr(1:m); wm_q = t_q(1:m); wm_hurel = t_hurel(1:m); wm_resc = t_resc(1:m); wm_ress = t_ress(1:m)
+    end if
   contains
     !> findloc(x >= g, .true., 1, back = .true.): the last index of g (from ib, jb or kb on) with g <= x, 0 when there is none
     integer function lastle(g, x)

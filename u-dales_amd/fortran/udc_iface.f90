@@ -181,6 +181,13 @@ module udc_iface
       type(c_ptr), value :: h
       integer(c_int), value :: iwalltemp
     end function udc_set_ibm_wallheat
+    integer(c_int) function udc_set_ibm_wallmoist(h, iwallmoist, n, lgr, qwall, hurel, resc, ress) bind(C, name='udc_set_ibm_wallmoist')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: iwallmoist, n
+      integer(c_int), intent(in) :: lgr(*)
+      real(c_double), intent(in) :: qwall(*), hurel(*), resc(*), ress(*)
+    end function udc_set_ibm_wallmoist
     integer(c_int) function udc_set_ibm_sections(h, grid, n, cell, area, dist, norm, z0, z0h, tsurf, comprec, recpt, recids, tmask) &
         bind(C, name='udc_set_ibm_sections')
       import :: c_ptr, c_int, c_double

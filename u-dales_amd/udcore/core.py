@@ -228,6 +228,13 @@ class DynCore:
                                                z0h.ctypes.data_as(L.DP), ts.ctypes.data_as(L.DP), comp.ctypes.data_as(ip),
                                                recpt.ctypes.data_as(L.DP), rid.ctypes.data_as(ip), tm.ctypes.data_as(L.DP)), "udc_set_ibm_sections")
 
+    def set_ibm_wallmoist(self, iwallmoist, lgr, qwall, hurel=None, resc=None, ress=None):
+        """Latent part of wallfunheat per c-grid section (include/udcore.h udc_set_ibm_wallmoist)."""
+        lg = np.ascontiguousarray(lgr, dtype=np.int32)
+        arr = [None if x is None else np.ascontiguousarray(x, dtype=np.float64) for x in (qwall, hurel, resc, ress)]
+        ptr = [None if x is None else x.ctypes.data_as(L.DP) for x in arr]
+        L._check(self.lib.udc_set_ibm_wallmoist(self.h, int(iwallmoist), int(lg.size), lg.ctypes.data_as(C.POINTER(C.c_int)), *ptr), "udc_set_ibm_wallmoist")
+
     def set_floor_air_temperature(self, thl_kb):
         """ltempeq off + wfuno floor: the frozen temperature of the first level (include/udcore.h)."""
         L._check(self.lib.udc_set_floor_air_temperature(self.h, C.c_double(thl_kb)), "udc_set_floor_air_temperature")

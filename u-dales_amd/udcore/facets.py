@@ -24,8 +24,16 @@ def _rows(path, nskip, n, ncol):
     return a
 
 
+def qsat(T):
+    """src/initfac.f90:406-412 (Bolton 1980; Murphy & Koop 2005 at 1000 hPa)."""
+    gres = 611.00 * np.exp(17.27 * (T - 273.15) / (T - 35.85))
+    return 0.62198 * 0.01 * gres / (1000 - 0.01 * gres)
+
+
 def read_facets(deck):
-    """facnorm[nfcts, 3], z0[nfcts], z0h[nfcts], tsurf[nfcts] (facT(:, 1); zeros unless iwallmom = 2)."""
+    """facnorm[nfcts, 3], z0[nfcts], z0h[nfcts], tsurf[nfcts] (facT(:, 1); zeros unless iwallmom = 2 / iwalltemp = 2 / iwallmoist = 2),
+    lgr[nfcts] (vegetated: factypes' lGR column, src/initfac.f90:216) and, with iwallmoist = 2, the facets' humidity as initfac leaves
+    it without an energy balance (:353-356): qsat at the facet temperature, fachurel of the vegetated ones from &ENERGYBALANCE wsoil, wfc."""
     base = os.path.dirname(os.path.abspath(deck.path))
     iexp = int(deck.get("RUN", "iexpnr"))
     nfcts = int(deck.get("WALLS", "nfcts"))
@@ -36,11 +44,18 @@ def read_facets(deck):
         types = [ln.split() for ln in f.readlines()[3:] if ln.strip()]
     z0 = {int(float(t[0])): float(t[2]) for t in types}
     z0h = {int(float(t[0])): float(t[3]) for t in types}
+    lgr = {int(float(t[0])): abs(float(t[1]) - 1.00) < 1.0e-5 for t in types}
     ftype = fac[:, 0].astype(int)
     out = {"norm": np.ascontiguousarray(fac[:, 1:4]), "z0": np.array([z0[t] for t in ftype]), "z0h": np.array([z0h[t] for t in ftype]),
-           "tsurf": np.zeros(nfcts)}
-    if int(deck.get("WALLS", "iwallmom")) == 2 or int(deck.get("WALLS", "iwalltemp")) == 2:      # src/initfac.f90:299
+           "tsurf": np.zeros(nfcts), "lgr": np.array([lgr[t] for t in ftype])}
+    moist2 = int(deck.get("WALLS", "iwallmoist")) == 2
+    if int(deck.get("WALLS", "iwallmom")) == 2 or int(deck.get("WALLS", "iwalltemp")) == 2 or moist2:      # src/initfac.f90:299
         out["tsurf"] = _rows(os.path.join(base, f"Tfacinit.inp.{iexp:03d}"), 1, nfcts, 1)[:, 0].copy()
+    if moist2:
+        wsoil, wfc = float(deck.get("ENERGYBALANCE", "wsoil")), float(deck.get("ENERGYBALANCE", "wfc"))
+        out["qsat"] = qsat(out["tsurf"])
+        out["hurel"] = np.where(out["lgr"], 0.5 * (1. - np.cos(3.14159 * wsoil / wfc)), 0.)
+        out["resc"], out["ress"] = np.full(nfcts, 200.), np.full(nfcts, 50.)      # facf(:, 4), facf(:, 5): src/initfac.f90:134
     return out
 
 
@@ -148,6 +163,23 @@ def temperature_masks(grid, S, mask_c):
     for s in range(S["n"]):
         i, j, k = (int(c) for c in S["cell"][s])
         out[s] = (mask_c[k, j, i], mask_c[k - dk, j - dj, i - di])
+    return out
+
+
+def prescribed_moisture_fluxes(deck, S, facets):
+    """wallfunheat's latent part with iwallmoist = 1 (src/modibm.f90:1557-1568): +x bcqfxp, -x bcqfxm, +y bcqfyp, -y bcqfym, +z bcqfz on
+    the vegetated facets; any other normal is undefined in the reference: refused.  -> flux per section (0 where not vegetated)."""
+    bc = lambda n: float(deck.get("BC", n))      # noqa: E731
+    table = {1: bc("bcqfxp"), -1: bc("bcqfxm"), 2: bc("bcqfyp"), -2: bc("bcqfym"), 3: bc("bcqfz")}
+    out = np.zeros(S["n"])
+    for s in range(S["n"]):
+        f = int(S["fac"][s]) - 1
+        if not facets["lgr"][f]:
+            continue
+        a = alignment(facets["norm"][f])
+        if a not in table:
+            raise ValueError("iwallmoist = 1 with non-zero wall moisture fluxes: the reference defines the flux for facets facing +-x, +-y, +z only")
+        out[s] = table[a]
     return out
 
 

@@ -52,18 +52,24 @@ def apply_ibm(core, deck):
         raise ValueError("&WALLS iwallmom must be 1 (no wall functions), 2 (stability functions) or 3 (neutral)")
     if iwallmom == 2 and not deck.get("PHYSICS", "ltempeq"):
         raise ValueError("libm with iwallmom = 2: the stability functions read the air temperature (ltempeq); use iwallmom = 3 for neutral walls")
-    # temperature: wallfunheat (src/modibm.f90:1436) from the facet temperatures (iwalltemp = 2) is on the device; with
-    # prescribed fluxes (iwalltemp = 1) only zero ones, where it adds exactly nothing (adiabatic walls).  Moisture: impermeable
-    # walls only (iwallmoist = 1, zero fluxes).
+    # wallfunheat (src/modibm.f90:1436): the sensible part from the facet temperatures (iwalltemp = 2) or prescribed (1; all-zero fluxes
+    # add exactly nothing: adiabatic walls, no tables needed); the latent part on the vegetated facets prescribed (iwallmoist = 1; zero:
+    # impermeable walls) or from the facets' humidity (2: needs the heat transfer coefficient of iwalltemp = 2).
     bc = lambda n: float(deck.get("BC", n))      # noqa: E731
     iwalltemp = int(deck.get("WALLS", "iwalltemp"))
     if deck.get("PHYSICS", "ltempeq") and iwalltemp not in (1, 2):
         raise ValueError("libm with ltempeq: iwalltemp must be 1 (prescribed wall heat fluxes bctf*) or 2 (from the facet temperatures)")
     fluxes = iwalltemp == 1 and any(bc(n) != 0. for n in ("bctfxm", "bctfxp", "bctfym", "bctfyp", "bctfz"))
-    if deck.get("PHYSICS", "lmoist") and (int(deck.get("WALLS", "iwallmoist")) != 1 or any(bc(n) != 0. for n in ("bcqfxm", "bcqfxp", "bcqfym", "bcqfyp", "bcqfz"))):
-        raise ValueError("libm with lmoist: wall moisture fluxes need wallfunheat, not on the device path; only iwallmoist = 1 with bcqf* = 0 is")
-    if deck.get("PHYSICS", "lmoist") and deck.get("PHYSICS", "lbuoyancy"):
-        raise ValueError("libm with lmoist and lbuoyancy: the moist thermodynamics' slab averages over the fluid cells are not on the device path")
+    lmoist = bool(deck.get("PHYSICS", "lmoist"))
+    iwallmoist = int(deck.get("WALLS", "iwallmoist")) if lmoist else 0
+    if lmoist and iwallmoist not in (1, 2):
+        raise ValueError("libm with lmoist: iwallmoist must be 1 (prescribed wall moisture fluxes bcqf*) or 2 (from the facets' humidity)")
+    qfluxes = iwallmoist == 1 and any(bc(n) != 0. for n in ("bcqfxm", "bcqfxp", "bcqfym", "bcqfyp", "bcqfz"))
+    if iwallmoist == 2 and not (deck.get("PHYSICS", "ltempeq") and iwalltemp == 2):
+        raise ValueError("libm with iwallmoist = 2: the aerodynamic resistance comes from the heat transfer coefficient of iwalltemp = 2 "
+                         "(undefined in the reference otherwise, src/modibm.f90:1571-1574)")
+    if qfluxes and not deck.get("PHYSICS", "ltempeq"):
+        raise ValueError("libm with wall moisture fluxes: wallfunheat runs with the temperature equation (ltempeq)")
     core.set_ibm_conservative(bool(deck.get("PHYSICS", "lconservativeibm")))
     lists = read_ibm(deck)
     # the masks' ghost cells as the reference run of this deck has them: wrapped only in a direction it splits over ranks
@@ -72,7 +78,8 @@ def apply_ibm(core, deck):
         if g in lists:
             core.set_ibm_points(q, *lists[g])
     core.ibm_commit()
-    heat = bool(deck.get("PHYSICS", "ltempeq")) and (iwalltemp == 2 or fluxes)
+    latent = iwallmoist == 2 or qfluxes
+    heat = bool(deck.get("PHYSICS", "ltempeq")) and (iwalltemp == 2 or fluxes or latent)
     if iwallmom > 1 or heat:      # facet wall functions (wallfunmom, wallfunheat): facets and section tables to the device
         from .facets import c_mask, read_facets, temperature_masks, wall_sections
         g = core.g
@@ -89,12 +96,20 @@ def apply_ibm(core, deck):
                 core.set_ibm_sections(q, S, facets, temperature_masks(gr, S, mask))
         if heat:
             S = wall_sections(deck, gg, "c", lists["c"][1], facets, lnorec)
+            nf = np.asarray(S["fac"]) - 1
+            if latent:      # per section: vegetated?, then the prescribed flux or the facet's humidity and resistances
+                from .facets import prescribed_moisture_fluxes
+                if iwallmoist == 1:
+                    wm = (facets["lgr"][nf], prescribed_moisture_fluxes(deck, S, facets), None, None, None)
+                else:
+                    wm = (facets["lgr"][nf], facets["qsat"][nf], facets["hurel"][nf], facets["resc"][nf], facets["ress"][nf])
             if iwalltemp == 1:      # prescribed fluxes ride in the slot of the facet temperature
                 from .facets import prescribed_fluxes
-                nf = np.asarray(S["fac"]) - 1
                 facets = {"norm": facets["norm"][nf], "z0": facets["z0"][nf], "z0h": facets["z0h"][nf],
                           "tsurf": prescribed_fluxes(deck, S, facets)}      # one entry per section
                 S = dict(S, fac=np.arange(1, S["n"] + 1, dtype=np.int32))
             core.set_ibm_sections(3, S, facets, np.ones((S["n"], 2)))
             core.set_ibm_wallheat(iwalltemp)
+            if latent:
+                core.set_ibm_wallmoist(iwallmoist, *wm)
     return lists

@@ -36,6 +36,7 @@ DEFAULTS = {
     "WALLS": dict(nfcts=-1, lbottom=False, iwallmom=2, iwalltemp=1, iwallmoist=1, nsolpts_u=0, nsolpts_v=0, nsolpts_w=0, nsolpts_c=0,
                   nbndpts_u=0, nbndpts_v=0, nbndpts_w=0, nbndpts_c=0, nfctsecs_u=0, nfctsecs_v=0, nfctsecs_w=0, nfctsecs_c=0,
                   lnorec=False, prandtlturb=0.71, fkar=0.41, lwritefac=False),      # src/modglobal.f90:304 (= prandtlmol), 317; src/modibm.f90:50
+    "ENERGYBALANCE": dict(wsoil=0., wfc=313.),      # src/modglobal.f90:286, 292 (read for the vegetated facets' humidity, src/initfac.f90:355)
     "ORACLE": dict(nsub=3, nspin=2, lforces=True, scal_a=1.0, scal_b=0.0),      # (scal_a, scal_b: the linear stand-in profile of decks without a scalar.inp)
 }
 GEODAMPTIME = 7200.      # src/modglobal.f90 (not a namelist variable)
