@@ -307,6 +307,12 @@ int udc_ibmnorm(udc_handle *h);
  *             (all-reduced over the slabs).  Called after forces (src/program.f90:169).  No-op unless enabled with
  *             udc_set_masscorr (&PHYSICS luvolflowr/uflowrate, lvvolflowr/vflowrate). */
 int udc_set_masscorr(udc_handle *h, int luvolflowr, double uflowrate, int lvvolflowr, double vflowrate);
+/* masscorr's outflow-rate branch for u (&PHYSICS luoutflowr, src/modforces.f90:352-387; it takes precedence over luvolflowr): the
+ * mean of um + rk3coef up over the fluid u points of the outlet plane i = itot -- integrated with dy dzf(k), divided by the area of
+ * that plane's fluid c cells (uoutletarea :499-522) -- is brought to uflowrate by a uniform shift of up.  Call it after
+ * udc_set_masscorr.  The v counterpart (lvoutflowr :424-465) is not offered: the reference hands a (kb:ke) array to a dummy of
+ * shape (ib:ie, kb:ke) there and overruns it. */
+int udc_set_masscorr_outflow(udc_handle *h, int luoutflowr, double uflowrate);
 int udc_masscorr(udc_handle *h, int rk3step, double dt);
 /* poisson     src/modpois.f90:419       fillps+bcpup, FFT(x,y)+tridiagonal(z), tderive+bcp */
 int udc_poisson(udc_handle *h, int rk3step, double dt);

@@ -29,12 +29,12 @@ RUN_CASES = {"run_16x16x8": 21, "run_smag_scalar_16x8x12s": 22, "run_floor_scala
              "run_stats_16x8x12s": 62, "run_stats_ibm_16x12x10": 63,
              "run_floor_uno_nothl_16x8x12s": 65, "run_ibm_wf2_16x12x10": 68, "run_ibm_wh2_16x12x10": 70, "run_ibm_wh1_16x12x10": 72,
              "run_ground_wf3_16x8x12": 73, "run_ground_wh2_16x8x12": 74, "run_bcxs_16x8x12s": 76, "run_bcxs_avg_16x8x12s": 77, "run_ytstats_ibm_16x12x10": 78,
-             "run_ibm_moist_16x12x10": 79, "run_ibm_moistwq_16x12x10": 80}
+             "run_ibm_moist_16x12x10": 79, "run_ibm_moistwq_16x12x10": 80, "run_uoutflow_16x16x8": 82, "run_ibm_uoutflow_16x12x10": 83}
 # decks with the facet wall functions (iwallmom > 1): on the device path and in the reference build; not in the C oracle's
 # whole-substep driver (the numpy restatement covers the routine); the Fortran drop-in modibm builds the section tables itself
 # (also: BCxs = 2, the scalars' inflow / outflow -- pinned device against reference fixture, not restated in the C oracle)
 WF_RUN_CASES = {"run_bcxs_16x8x12s", "run_bcxs_avg_16x8x12s", "run_ibm_wf2_16x12x10", "run_ibm_wh2_16x12x10", "run_ibm_wh1_16x12x10", "run_ground_wf3_16x8x12", "run_ground_wh2_16x8x12",
-                "run_ibm_moist_16x12x10", "run_ibm_moistwq_16x12x10"}
+                "run_ibm_moist_16x12x10", "run_ibm_moistwq_16x12x10", "run_uoutflow_16x16x8", "run_ibm_uoutflow_16x12x10"}
 
 
 # A start-up transient of the reference: readinitfiles calls `thermodynamics` BEFORE program.f90:118's `boundary` has set the top

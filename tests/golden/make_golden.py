@@ -495,6 +495,17 @@ CASES.update({
     "run_ibm_edge_16x12x10": ("run", 57, 16, 12, 10, dict(sgs="vreman", nsv=0, floor=True, randu=0.05, ibm=IBM_BLOCKS["run_ibm_edge_16x12x10"],
                                                           oracle="nsub = 9\ndump_at = 3, 9"), 1.04),
 })
+# masscorr's outflow-rate branch (luoutflowr, src/modforces.f90:352-387): u is corrected so that the flow through the plane i = ie
+# (over its fluid u points, per area of its fluid c cells -- uoutletarea :499) stays at uflowrate; plain channel, and with a block
+# standing in that plane.  (The v counterpart, lvoutflowr :424-465, hands a (kb:ke) array to sumy_ibm's (ib:ie, kb:ke) dummy -- it
+# overruns: not a usable branch of the reference.)
+IBM_BLOCKS["run_ibm_uoutflow_16x12x10"] = IBM_BLOCKS["run_ibm_edge_16x12x10"]
+CASES.update({
+    "run_uoutflow_16x16x8": ("run", 82, 16, 16, 8, dict(sgs="vreman", floor=True, randu=0.05, physics="luoutflowr = .true.\nuflowrate = 1.1",
+                                                        oracle="nsub = 9\ndump_at = 3, 9"), 1.04),
+    "run_ibm_uoutflow_16x12x10": ("run", 83, 16, 12, 10, dict(sgs="vreman", nsv=1, floor=True, randu=0.05, ibm=IBM_BLOCKS["run_ibm_edge_16x12x10"],
+                                                              physics="luoutflowr = .true.\nuflowrate = 1.05", oracle="nsub = 9\ndump_at = 3, 9"), 1.04),
+})
 # immersed boundary with temperature (buoyant), a kappa-advected scalar, and moisture: ibmnorm's `solid`
 # on thl with the volume-mean value, advecc2nd_corr (liberal, and conservative with lconservativeibm), diffc_corr on thl / qt,
 # the masked slab averages of thermodynamics (IIw for thvh).  Adiabatic, impermeable walls (iwalltemp = iwallmoist = 1 with

@@ -807,6 +807,13 @@ extern "C" int udc_set_masscorr(udc_handle *h, int luvolflowr, double uflowrate,
   return 0;
 }
 
+extern "C" int udc_set_masscorr_outflow(udc_handle *h, int luoutflowr, double uflowrate) {
+  ENTRY_FLUSH(h);
+  if (luoutflowr) { h->luvolflowr = 2; h->uflowrate = uflowrate; }      // (takes precedence over luvolflowr, src/modforces.f90:352,389)
+  else if (h->luvolflowr == 2) h->luvolflowr = 0;
+  return 0;
+}
+
 static int now_masscorr(udc_handle *h, int rk3step, double dt) {
   if (!h->luvolflowr && !h->lvvolflowr) return 0;
   if (tend_clean(h) || um_materialise(h)) return 1;

@@ -7,6 +7,7 @@
 // One thread per listed point.  The masks are only ever read at the listed points, so commit() evaluates them on the
 // host into a few flag bits per point and the device never holds a mask array.
 #include "udc_internal.h"
+#include "udc_scalar_arith.h"
 #include <cstring>
 
 namespace {
@@ -126,9 +127,17 @@ __global__ void ibm_solid_zero_kernel(Geo g, int n, const int *__restrict__ pt, 
   rhs[c] = 0.;
 }
 
-// solid with the c mask: value and tendency become the mean over the fluid neighbours (or val / 0 without any)
+// solid with the c mask: value and tendency become the mean over the fluid neighbours (or val / 0 without any).  A neighbour
+// beyond a lateral edge of the domain (flagged "fluid" where the reference's masks are not wrapped: udc_set_ibm_mask_wrap) is a
+// ghost cell there: its value is the periodic image; its tendency (src/modibm.f90:748-826 reads rhs(i+-1, j+-1) all the same, and
+// tendency ghosts are not exchanged) is whatever this substep's routines left there -- nothing (zero), except under the kappa
+// scheme, whose face loops run to ie + 1 / je + 1 and credit each face's flux to both cells it borders (src/modadvection.f90:335-377):
+// the ghost cell beyond the high edge holds + (flux through the domain's edge face) / dx, the one beyond the low edge - that.
+// kc / u0 / v0: the kappa-advected field and the velocities (null: no such term).  j0 / jtot: this slab's first global row / the
+// domain's rows.
 __global__ void ibm_solid_mean_kernel(Geo g, int n, const int *__restrict__ pt, const unsigned char *__restrict__ fl, const double *__restrict__ valp,
-                                      double *__restrict__ var, double *__restrict__ rhs) {
+                                      double *__restrict__ var, double *__restrict__ rhs, int j0, int jtot, const double *__restrict__ kc,
+                                      const double *__restrict__ u0, const double *__restrict__ v0, double dx, double dxi, double dyi) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= n) return;
   const double val = valp ? *valp : 0.;
@@ -136,10 +145,27 @@ __global__ void ibm_solid_mean_kernel(Geo g, int n, const int *__restrict__ pt, 
   const long c = g.idx(i, j, k), sy = g.sy, sz = g.sz;
   const long nb[6] = {c + sy, c - sy, c + sz, c - sz, g.idx(wrapx(i + 1, g.nx), j, k), g.idx(wrapx(i - 1, g.nx), j, k)};
   const unsigned f = fl[q];
+  const bool ghost[6] = {j0 + j + 1 >= jtot, j0 + j - 1 < 0, false, false, i + 1 >= g.nx, i - 1 < 0};
   double v = val, r = 0., count = 0.;
 #pragma unroll
   for (int b = 0; b < 6; ++b)
-    if (f & (1u << b)) { count += 1.; v = v + var[nb[b]]; r = r + rhs[nb[b]]; }
+    if (f & (1u << b)) {
+      count += 1.; v = v + var[nb[b]];
+      if (!ghost[b]) r = r + rhs[nb[b]];
+      else if (kc) {
+        if (b >= 4) {      // the edge face in x: between columns nx-1 and 0
+          const long r0 = g.idx(0, j, k);
+          const double vel = u0[r0];
+          const double fx = face(vel, kc[r0 + g.nx - 2], kc[r0 + g.nx - 1], kc[r0], kc[r0 + 1], dxi, dxi, dxi, dx) * vel;
+          r = r + (b == 4 ? fx * dxi : -fx * dxi);
+        } else {           // the edge face in y: the low face of row jj = ny (b = 0: its ghost copy) or 0 (b = 1)
+          const long r0 = g.idx(i, b == 0 ? j + 1 : j, k);
+          const double vel = v0[r0];
+          const double fy = face(vel, kc[r0 - 2 * sy], kc[r0 - sy], kc[r0], kc[r0 + sy], 1., 1., 1., 1.) * vel;
+          r = r + (b == 0 ? fy * dyi : -fy * dyi);
+        }
+      }
+    }
   if (count > 0.) { v = (v - val) / count; r = r / count; }
   var[c] = v;
   rhs[c] = r;
@@ -210,10 +236,12 @@ __global__ __launch_bounds__(256) void ibm_levelsum_kernel(Geo g, const int *__r
 }
 // the same with a per-level weight, summed over all levels (masscorr's volume averages): one workgroup
 __global__ __launch_bounds__(1024) void ibm_flowsum_kernel(Geo g, int n, const int *__restrict__ pts, const double *__restrict__ a,
-                                                           const double *__restrict__ b, const double *__restrict__ wlev, double *__restrict__ S) {
+                                                           const double *__restrict__ b, const double *__restrict__ wlev, double *__restrict__ S,
+                                                           int only_i) {
   __shared__ double sa_[16], sb_[16];
   double sa = 0., sb = 0.;
   for (int q = threadIdx.x; q < n; q += 1024) {
+    if (only_i >= 0 && pts[3 * q] != only_i) continue;
     const int k = pts[3 * q + 2];
     const long c = g.idx(pts[3 * q], pts[3 * q + 1], k);
     const double w = wlev[k + 1];
@@ -435,10 +463,10 @@ int k_ibm_levelsum_correct(udc_handle *h, const int *fields, int nf, int n, doub
   return 0;
 }
 
-int k_ibm_flowsum_correct(udc_handle *h, int grid, const double *a, const double *b, const double *wlev, double *S) {
+int k_ibm_flowsum_correct(udc_handle *h, int grid, const double *a, const double *b, const double *wlev, double *S, int only_i) {
   const udc_handle::IbmGrid &G = h->ibm[grid];
   if (!h->ibm_on || !G.nsolid) return 0;
-  hipLaunchKernelGGL(ibm_flowsum_kernel, dim3(1), dim3(1024), 0, h->stream, h->g, G.nsolid, G.solid, a, b, wlev, S);
+  hipLaunchKernelGGL(ibm_flowsum_kernel, dim3(1), dim3(1024), 0, h->stream, h->g, G.nsolid, G.solid, a, b, wlev, S, only_i);
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -490,7 +518,9 @@ int k_ibm_norm(udc_handle *h) {
     }
     if (C.nsolid)
       hipLaunchKernelGGL(ibm_solid_mean_kernel, dim3(blocks(C.nsolid)), dim3(128), 0, h->stream, g, C.nsolid, C.solid, C.solid_fl, valp,
-                         h->fields[UDC_SVM + 3 * n], h->fields[UDC_SVP + 3 * n]);
+                         h->fields[UDC_SVM + 3 * n], h->fields[UDC_SVP + 3 * n], h->cfg.rank * g.ny, h->jtot,
+                         (const double *)(h->slot[n].adv == 2 ? nullptr : h->fields[UDC_SV0 + 3 * n]), (const double *)h->fields[UDC_U0],
+                         (const double *)h->fields[UDC_V0], h->m.dx, h->m.dxi, h->m.dyi);
     // fields advected by advecc_2nd (thl unless iadv_thl = 7, qt): src/modibm.f90:716-722, 727-731
     if (C.nbound && n >= 13 && h->slot[n].adv == 2) {
       const double *u0 = h->fields[UDC_U0], *v0 = h->fields[UDC_V0], *w0 = h->fields[UDC_W0];

@@ -201,7 +201,8 @@ struct udc_handle {
   int lqlnr = 0;               // condensate by Newton-Raphson (src/modthermodynamics.f90:37)
   double *thlpcar = nullptr;   // [nz+2] radiative heating profile added by forces (src/modforces.f90:104-110), or null
   // masscorr (src/modforces.f90:328): prescribed volume-flow rates
-  int luvolflowr = 0, lvvolflowr = 0;
+  int luvolflowr = 0, lvvolflowr = 0;     // luvolflowr: 1 = volume flow (luvolflowr), 2 = flow through the outlet plane (luoutflowr)
+  double *outlet_w = nullptr;             // luoutflowr: dy dzf(k) / outlet area, [nz+2] indexed by the reference's k
   double uflowrate = 0., vflowrate = 0., zsize = 0.;
   bool um_alias = false;                // um,vm,wm are logically equal to u0,v0,w0 (after RK stage 3 of a fused
                                         // substep); the UM buffers are stale until stage 1 rotates the pointers
@@ -391,7 +392,7 @@ int ibm_grid_of_field(int field);                // 0 u, 1 v, 2 w, 3 c: the mask
 // S[q n + k] -= sum of fields[q] over the solid points of device level k (q < nf, k < n); no-op without IBM
 int k_ibm_levelsum_correct(udc_handle *h, const int *fields, int nf, int n, double *S);
 // S[0] -= sum a w(k), S[1] -= sum b w(k) over the solid points of `grid` (b may be null)
-int k_ibm_flowsum_correct(udc_handle *h, int grid, const double *a, const double *b, const double *wlev, double *S);                   // solid: velocities zeroed, scalars to the mean of their fluid neighbours
+int k_ibm_flowsum_correct(udc_handle *h, int grid, const double *a, const double *b, const double *wlev, double *S, int only_i = -1);                   // solid: velocities zeroed, scalars to the mean of their fluid neighbours
 void ibm_destroy(udc_handle *h);
 void stats_destroy(udc_handle *h);
 int k_ibm_wallfunmom(udc_handle *h);

@@ -996,15 +996,17 @@ __global__ __launch_bounds__(256) void divcheck_kernel(Geo g, TileGrid tg, Metri
 }
 
 
-// masscorr, src/modforces.f90:328-497, volume-flow branches (luvolflowr :389-417, lvvolflowr :467-494).
+// masscorr, src/modforces.f90:328-497: volume-flow branches (luvolflowr :389-417, lvvolflowr :467-494) and the u outflow-rate
+// branch (luoutflowr :352-387).
 // flowsum: S_a = sum(a w(k)), S_b = sum(b w(k)) over the slab interior (b may be null); w = dzf, or with an immersed
-// boundary dzf(k) / (fluid cells of level k) / zh(ke+1) so that the sum is the volume average over the fluid
+// boundary dzf(k) / (fluid cells of level k) / zh(ke+1) so that the sum is the volume average over the fluid.  only_i >= 0: the
+// plane i = only_i alone (the outlet plane i = ie; w = dy dzf(k) / outlet area).
 __global__ __launch_bounds__(256) void flowsum_kernel(Geo g, TileGrid tg, const double *__restrict__ wlev, const double *__restrict__ a,
-                                                      const double *__restrict__ b, double *__restrict__ out) {
+                                                      const double *__restrict__ b, double *__restrict__ out, int only_i) {
   int i, j, k;
   const bool inside_ = tile_decode(g, tg, i, j, k);
   double sa = 0., sb = 0.;
-  if (inside_) {
+  if (inside_ && (only_i < 0 || i == only_i)) {
     const long c = g.idx(i, j, k);
     const double w = wlev[k + 1];
     sa = a[c] * w;
@@ -1370,6 +1372,7 @@ void pois_destroy(udc_handle *h) {
   if (h->spec) hipFree(h->spec);
   if (h->rbuf) hipFree(h->rbuf);
   if (h->ztab) hipFree(h->ztab);
+  if (h->outlet_w) hipFree(h->outlet_w);
   if (h->ev) hipFree(h->ev);
   if (h->tri) hipFree(h->tri);
   if (h->partials) hipFree(h->partials);
@@ -1521,6 +1524,21 @@ static int ensure_partials(udc_handle *h, size_t nblocks) {
 int k_masscorr(udc_handle *h, double rk3coef, bool pup_mode, bool wrap_vp) {
   if (!h->luvolflowr && !h->lvvolflowr) return 0;
   const Geo &g = h->g;
+  // luoutflowr (h->luvolflowr == 2): the flow through the outlet plane i = ie over its fluid u points, per area of its fluid c cells
+  // (uoutletarea, src/modforces.f90:499-522: sum of IIc(ie, j, k) dy dzf(k); all cells count when no c-grid lists were read)
+  const bool outlet = h->luvolflowr == 2;
+  if (outlet && !h->outlet_w) {
+    std::vector<double> cnt(g.nz + 2, (double)h->cfg.jtot), w(g.nz + 2, 0.);
+    if (h->ibm_on && h->ibm[3].given)
+      for (size_t q = 0; q < h->ibm[3].solid_g.size() / 3; ++q)
+        if (h->ibm[3].solid_g[3 * q] == g.nx) cnt[h->ibm[3].solid_g[3 * q + 2]] -= 1.;
+    double area = 0.;
+    for (int k = 1; k <= g.nz; ++k) area += cnt[k] * h->cfg.dy * h->cfg.dzf[k];
+    if (!(area > 0.)) { udc_set_error("masscorr (luoutflowr): the outlet plane i = itot has no fluid cell"); return 1; }
+    for (int k = 1; k <= g.nz; ++k) w[k] = h->cfg.dy * h->cfg.dzf[k] / area;
+    HIP_OK(hipMalloc(&h->outlet_w, sizeof(double) * w.size()));
+    HIP_OK(hipMemcpy(h->outlet_w, w.data(), sizeof(double) * w.size(), hipMemcpyHostToDevice));
+  }
   dim3 b(64, 4, 1), gr = cell_grid(g, b);
   if (ensure_partials(h, gr.x)) return 1;
   PROF(h, "masscorr");
@@ -1543,16 +1561,19 @@ int k_masscorr(udc_handle *h, double rk3coef, bool pup_mode, bool wrap_vp) {
   for (int c = 0; c < 2; ++c) {
     if (!(c == 0 ? h->luvolflowr : h->lvvolflowr)) continue;
     const double *a = h->fields[UDC_UP + c], *bm = pup_mode ? nullptr : h->fields[mo + c];
-    const double *wlev = h->ibm_on ? h->ibm_wlev + (size_t)c * (g.nz + 2) : h->m.dzf;
-    hipLaunchKernelGGL(flowsum_kernel, gr, b, 0, h->stream, g, tile_grid(g), wlev, a, bm, h->partials);
+    const bool out_c = outlet && c == 0;
+    const double *wlev = out_c ? h->outlet_w : (h->ibm_on ? h->ibm_wlev + (size_t)c * (g.nz + 2) : h->m.dzf);
+    const int only_i = out_c ? g.nx - 1 : -1;
+    hipLaunchKernelGGL(flowsum_kernel, gr, b, 0, h->stream, g, tile_grid(g), wlev, a, bm, h->partials, only_i);
     hipLaunchKernelGGL((reduce_partials_kernel<1, 1>), dim3(1), dim3(1024), 0, h->stream, h->partials, (long)gr.x, 0., 0.,
                        S + 2 * c);
-    if (h->ibm_on && k_ibm_flowsum_correct(h, c, a, bm, wlev, S + 2 * c)) return 1;
+    if (h->ibm_on && k_ibm_flowsum_correct(h, c, a, bm, wlev, S + 2 * c, only_i)) return 1;
     FlowShift &f = c == 0 ? fu : fv;
     f.f = h->fields[UDC_UP + c];
     f.target = c == 0 ? h->uflowrate : h->vflowrate;
-    f.ca = h->ibm_on ? rk3coef : rk3coef / vol;
-    f.cb = pup_mode ? 0. : (h->ibm_on ? 1. : 1. / vol);
+    const bool weighted = h->ibm_on || out_c;      // the weights already carry the normalisation
+    f.ca = weighted ? rk3coef : rk3coef / vol;
+    f.cb = pup_mode ? 0. : (weighted ? 1. : 1. / vol);
   }
   HIP_OK(hipGetLastError());
   if (comm_allreduce(h, S, 4, 1)) return 1;

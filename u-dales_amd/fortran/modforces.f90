@@ -10,8 +10,9 @@
 !! and application point: lstend and nudge (applied before masscorr) share one, so lstend starts it and nudge -- the
 !! routine the reference's loop calls right after -- registers and applies it (masscorr does so if nudge was skipped).
 !!
-!! Not taken over: the outflow-rate branches of masscorr (luoutflowr / lvoutflowr: inflow-outflow decks) and
-!! periodicEBcorr (energy balance) -- refused with the reference's error convention.
+!! masscorr: the volume-flow branches and the u outflow-rate branch (luoutflowr) on the device.  Not taken over: lvoutflowr (the
+!! reference's own call overruns its array there, src/modforces.f90:441-442) and periodicEBcorr (energy balance) -- refused with
+!! the reference's error convention.
 module modforces
   use iso_c_binding, only: c_int, c_double
   implicit none
@@ -98,17 +99,18 @@ contains
     call udc_tab_apply(0)
   end subroutine nudge
 
-  !> prescribed volume flow: up += (uflowrate - <um + rk3coef up>)/rk3coef, same for v (src/modforces.f90:389-417, 467-494)
+  !> prescribed volume flow: up += (uflowrate - <um + rk3coef up>)/rk3coef, same for v (src/modforces.f90:389-417, 467-494);
+  !! luoutflowr: <.> over the outlet plane i = ie instead (:352-387)
   subroutine masscorr
     use modglobal, only: rk3step, dt, linoutflow, luoutflowr, lvoutflowr, luvolflowr, lvvolflowr
     use udc_iface
     if (udc_tab_open(0)) call udc_tab_apply(0)      ! (lstend's table if the driver skipped nudge)
     if (linoutflow) return
-    if (luoutflowr .or. lvoutflowr) then
-      write (0, *) 'ERROR: libudcore masscorr: the outflow-rate branches (luoutflowr, lvoutflowr) are not available'
+    if (lvoutflowr) then
+      write (0, *) 'ERROR: libudcore masscorr: lvoutflowr is not available (src/modforces.f90:441 hands sumy_ibm an array it overruns)'
       stop 1
     end if
-    if (.not. (luvolflowr .or. lvvolflowr)) return
+    if (.not. (luvolflowr .or. lvvolflowr .or. luoutflowr)) return
     call udc_begin(.true.)
     call udc_check(udc_masscorr(udc_h, int(rk3step, c_int), real(dt, c_double)), 'udc_masscorr')
     call udc_end_tend

@@ -334,6 +334,12 @@ module udc_iface
       import :: c_int, c_ptr
       type(c_ptr), value :: h
     end function
+    integer(c_int) function udc_set_masscorr_outflow(h, lu, uflow) bind(C, name='udc_set_masscorr_outflow')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: lu
+      real(c_double), value :: uflow
+    end function udc_set_masscorr_outflow
     integer(c_int) function udc_set_masscorr(h, lu, uflow, lv, vflow) bind(C, name='udc_set_masscorr')
       import :: c_int, c_ptr, c_double
       type(c_ptr), value :: h
@@ -578,7 +584,7 @@ contains
   !! large-scale gradients, sv_top).  The handle may exist before they are in (readinitfiles itself calls halos /
   !! boundary / thermodynamics), so this runs with every start-up call and a last time when the time loop starts.
   subroutine udc_late_setup
-    use modglobal, only: ktot, kb, ke, nsv, ltempeq, BCtops, lcoriol, lprofforc, om22, om23, luvolflowr, lvvolflowr, &
+    use modglobal, only: ktot, kb, ke, nsv, ltempeq, BCtops, lcoriol, lprofforc, om22, om23, luvolflowr, lvvolflowr, luoutflowr, &
                          uflowrate, vflowrate, lnudge, igrw_damp, ifixuinf, ds, BCxs
     use modsurfdata, only: wsvtop, sv_top
     use modfields, only: dpdxl, dpdyl, thlpcar, ug, whls, dthldxls, dthldyls, dqtdxls, dqtdyls, dqtdtls, &
@@ -605,6 +611,8 @@ contains
     ! masscorr, volume-flow branches (src/modforces.f90:389-417, 467-494)
     call udc_check(udc_set_masscorr(udc_h, merge(1_c_int, 0_c_int, luvolflowr), real(uflowrate, c_double), &
                                     merge(1_c_int, 0_c_int, lvvolflowr), real(vflowrate, c_double)), 'udc_set_masscorr')
+    ! ... and the u outflow-rate branch (:352-387; it wins over luvolflowr)
+    if (luoutflowr) call udc_check(udc_set_masscorr_outflow(udc_h, 1_c_int, real(uflowrate, c_double)), 'udc_set_masscorr_outflow')
     ! does any host routine of the loop read diagfld's slab averages?
     udc_need_avg = lnudge .or. igrw_damp /= 0 .or. ifixuinf /= 0 .or. ds > 0 .or. any(whls /= 0.) .or. &
                    any(dthldxls /= 0.) .or. any(dthldyls /= 0.) .or. any(dqtdxls /= 0.) .or. any(dqtdyls /= 0.) .or. &

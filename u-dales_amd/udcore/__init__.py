@@ -22,6 +22,8 @@ def from_deck(deck, device=0, rank=0, nranks=1):
                    uinf=float(deck.get("INLET", "Uinf")), vinf=float(deck.get("INLET", "Vinf")))
     core.set_masscorr(bool(deck.get("PHYSICS", "luvolflowr")), float(deck.get("PHYSICS", "uflowrate")),
                       bool(deck.get("PHYSICS", "lvvolflowr")), float(deck.get("PHYSICS", "vflowrate")))
+    if deck.get("PHYSICS", "luoutflowr"):      # masscorr's outflow-rate branch for u (src/modforces.f90:352-387)
+        core.set_masscorr_outflow(True, float(deck.get("PHYSICS", "uflowrate")))
     if deck.get("PHYSICS", "ltempeq"):
         iadv = int(deck.get("DYNAMICS", "iadv_thl"))
         core.set_tempeq(iadv_thl=int(deck.get("DYNAMICS", "iadv_mom")) if iadv < 0 else iadv,

@@ -143,6 +143,10 @@ class DynCore:
         self._ensure_thermo()
         L._check(self.lib.udc_forces(self.h), "udc_forces")
 
+    def set_masscorr_outflow(self, luoutflowr=True, uflowrate=1.):
+        """&PHYSICS luoutflowr: include/udcore.h udc_set_masscorr_outflow."""
+        L._check(self.lib.udc_set_masscorr_outflow(self.h, int(bool(luoutflowr)), C.c_double(uflowrate)), "udc_set_masscorr_outflow")
+
     def set_masscorr(self, luvolflowr=False, uflowrate=1., lvvolflowr=False, vflowrate=1.):
         """&PHYSICS luvolflowr/uflowrate, lvvolflowr/vflowrate (src/modglobal.f90:231,331)."""
         L._check(self.lib.udc_set_masscorr(self.h, int(bool(luvolflowr)), C.c_double(uflowrate),

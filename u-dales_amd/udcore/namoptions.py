@@ -18,7 +18,7 @@ DEFAULTS = {
                 nprocx=1, nprocy=1, lwarmstart=False, startfile="", trestart=10000.),
     "DOMAIN": dict(itot=96, jtot=96, ktot=96, xlen=-1., ylen=-1., xlat=52., ksp=-1),
     "PHYSICS": dict(lmoist=False, lcoriol=False, lbuoyancy=False, ltempeq=False, lprofforc=False, ps=101325.,
-                    dpdx=0., igrw_damp=0, lnudge=False, lnudgevel=True, tnudge=60., nnudge=0, luvolflowr=False, uflowrate=1., lvvolflowr=False, vflowrate=1.,
+                    dpdx=0., igrw_damp=0, lnudge=False, lnudgevel=True, tnudge=60., nnudge=0, luvolflowr=False, uflowrate=1., lvvolflowr=False, vflowrate=1., luoutflowr=False, lvoutflowr=False,
                     ifixuinf=0, lvinf=False, tscale=0., lconservativeibm=False),
     "CHEMISTRY": dict(lchem=False, k1=0., JNO2=0.),
     "INLET": dict(Uinf=0., Vinf=0., inletav=0.),
@@ -78,7 +78,8 @@ KNOWN = {g: {n.lower() for n in v.split()} for g, v in KNOWN.items()}
 UNSUPPORTED = [("WALLS", "lwritefac", False),      # facet statistics (fac.NNN.nc): host code of the reference, not on the device path
                ("RUN", "lstratstart", False), ("RUN", "lper2inout", False), ("RUN", "lreadmean", False),
                ("PHYSICS", "ltimedepsurf", False), ("PHYSICS", "ltimedepnudge", False), ("PHYSICS", "ltimedeplw", False),
-               ("PHYSICS", "ltimedepsw", False), ("PHYSICS", "luoutflowr", False), ("PHYSICS", "lvoutflowr", False),
+               ("PHYSICS", "ltimedepsw", False),
+               ("PHYSICS", "lvoutflowr", False),      # (the reference's own call overruns its array there, src/modforces.f90:441-442)
                ("DRIVER", "idriver", 0), ("INLET", "linletRA", False), ("INLET", "lstoreplane", False),
                ("INLET", "lreadminl", False), ("INLET", "lfixinlet", False), ("INLET", "lfixutauin", False),
                ("ENERGYBALANCE", "lEB", False), ("ENERGYBALANCE", "lperiodicEBcorr", False),
