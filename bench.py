@@ -39,7 +39,8 @@ sys.path.insert(0, os.path.join(ROOT, "u-dales_amd"))
 # definition so that it stays comparable across rounds.
 SCALAR_INTEGRATE_BYTES = 24      # per transported scalar in project_integrate: read svp, svm; write sv0
 ALGO_BYTES = {
-    "closure": 40,              # read u0,v0,w0; write ekm,ekh
+    "closure": 40,              # read u0,v0,w0; write ekm,ekh -- ekh only where something reads it: with no transported scalar and no
+                                # statistics that is RK stage 3 alone (the time-step limit of tstep_update): 32 + 8/3, charged below
     "mom": 88,                  # read u0,v0,w0,pres0,ekm (40) + um,vm,wm (24); write pup,pvp,pwp (24); on RK stage 1 um is u0
                                 # (buffer rotation, already staged): 64 -- the timed launches are charged their own mix
     "div_rhs": 32,              # read pup,pvp,pwp; write p
@@ -64,6 +65,8 @@ def algo_bytes(name, nscal=0, stage1_frac=0.0):
         if name.startswith(k):
             if k == "mom":
                 return v - MOM_STAGE1_SAVING * stage1_frac
+            if k == "closure" and nscal == 0 and os.environ.get("UDC_EK_ALWAYS", "0") in ("", "0"):
+                return v - 8 * 2.0 / 3.0
             return v + (SCALAR_INTEGRATE_BYTES * nscal if k == "project_integrate" else 0)
     return None
 
