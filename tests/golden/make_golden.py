@@ -784,8 +784,13 @@ def make_example_cases(only):
 FULL = os.path.join(ROOT, "oracle", "_ref", "udales_full")
 
 
-def make_full_example():
-    """examples/999 through the reference's own EXECUTABLE (oracle/_ref/udales_full: program.f90 and all), command line and files
+FULL_EXAMPLES = {"999": 128, "002": 64, "101": 64}      # example -> grid size (cubic)
+
+
+def make_full_example(ex="999"):
+    """(examples/002 -- an array of cubes -- and examples/101 -- heated street canyons with wall functions for momentum and heat, a
+    prescribed volume flow and a scalar line source with BCxs = 2 -- the same way, 64^3 each.)
+    examples/999 through the reference's own EXECUTABLE (oracle/_ref/udales_full: program.f90 and all), command line and files
     as a user has them -- one change to the deck: one rank (the stand-in decomposition of this build), and a shorter run: 11 s, past
     the first xytdump, with a restart file at the end.  Kept: the clock after every step (monitor file), xytdump's first record as
     handed to NetCDF, and of the restart file the clock, the slab means and rms of u0, v0, w0, pres0 and every 8th point of them."""
@@ -794,37 +799,40 @@ def make_full_example():
     from refdump import Field, read_ncrec
     sys.path.insert(0, os.path.join(ROOT, "u-dales_amd"))
     from udcore import restart
-    cdir = os.path.join(HERE, "cases", "example_999")
+    n = FULL_EXAMPLES[ex]
+    cdir = os.path.join(HERE, "cases", f"example_{ex}")
     with tempfile.TemporaryDirectory() as tmp:
         for fn in os.listdir(cdir):
             with gzip.open(os.path.join(cdir, fn), "rb") as f, open(os.path.join(tmp, fn[:-3]), "wb") as o:
                 o.write(f.read())
-        with open(os.path.join(tmp, "namoptions.999")) as f:
+        with open(os.path.join(tmp, f"namoptions.{ex}")) as f:
             txt = f.read()
         txt = re.sub(r"nprocx\s*=\s*\d+", "nprocx = 1", re.sub(r"nprocy\s*=\s*\d+", "nprocy = 1", txt))
         txt = re.sub(r"runtime\s*=\s*[0-9.]+", "runtime = 11.", re.sub(r"trestart\s*=\s*[0-9.]+", "trestart = 10.9", txt))
-        with open(os.path.join(tmp, "namoptions.999"), "w") as f:
+        with open(os.path.join(tmp, f"namoptions.{ex}"), "w") as f:
             f.write(txt)
-        subprocess.check_call(["bash", "-c", f"ulimit -s unlimited; exec {FULL} namoptions.999"], cwd=tmp, stdout=subprocess.DEVNULL)
+        subprocess.check_call(["bash", "-c", f"ulimit -s unlimited; exec {FULL} namoptions.{ex}"], cwd=tmp, stdout=subprocess.DEVNULL)
         keep = {"monitor": Field(np.loadtxt(os.path.join(tmp, "monitor000.txt")), (1,))}
-        for k, v in read_ncrec(os.path.join(tmp, "xytdump.999.nc")).items():
+        for k, v in read_ncrec(os.path.join(tmp, f"xytdump.{ex}.nc")).items():
             if k.endswith(("xyt", "txyc", "txy")) or k == "time":
                 keep["xyt." + k[:11]] = Field(np.atleast_1d(v[0][1]).astype(float), (1,))
         rst = [f for f in os.listdir(tmp) if f.startswith("initd")]
         assert len(rst) == 1
-        r = restart.read_initd(os.path.join(tmp, rst[0]), 128, 128, 128)
+        r = restart.read_initd(os.path.join(tmp, rst[0]), n, n, n)
         keep["rst.time"] = Field(np.array([r["timee"], r["dt"], float(rst[0][5:13])]), (1,))
-        for k in ("u0", "v0", "w0", "pres0"):
-            a = r[k][1:129, 1:129, 1:129]
+        for k in ("u0", "v0", "w0", "pres0", "thl0"):
+            if k == "thl0" and "ltempeq" not in txt:
+                continue
+            a = r[k][1:n + 1, 1:n + 1, 1:n + 1]
             keep[f"rst.{k}.mean"] = Field(a.mean(axis=(1, 2)), (1,))
             keep[f"rst.{k}.rms"] = Field(np.sqrt((a ** 2).mean(axis=(1, 2))), (1,))
             keep[f"rst.{k}.pts"] = Field(np.ascontiguousarray(a[::8, ::8, ::8]), (1, 1, 1))
-    tmpf = os.path.join(HERE, "full_example_999.bin")
+    tmpf = os.path.join(HERE, f"full_example_{ex}.bin")
     write_dump(tmpf, keep)
     with open(tmpf, "rb") as f, gzip.GzipFile(tmpf + ".gz", "wb", mtime=0) as g:
         g.write(f.read())
     os.remove(tmpf)
-    print(f"full_example_999: {len(keep)} records, {os.path.getsize(tmpf + '.gz') / 1024:.0f} kB")
+    print(f"full_example_{ex}: {len(keep)} records, {os.path.getsize(tmpf + '.gz') / 1024:.0f} kB")
 
 
 def split_scal(kw):
@@ -881,8 +889,9 @@ def main():
         print(f"{name}: {len(keep)} records, {os.path.getsize(tmpf + '.gz') / 1024:.0f} kB")
     make_restart_cases()
     make_example_cases(only)
-    if not only or "full_example_999" in only:
-        make_full_example()
+    for ex in FULL_EXAMPLES:
+        if not only or f"full_example_{ex}" in only:
+            make_full_example(ex)
 
 
 if __name__ == "__main__":

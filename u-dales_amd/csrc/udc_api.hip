@@ -869,7 +869,9 @@ static int now_tstep_integrate(udc_handle *h, int rk3step, double dt) {
 static int scalar_halo_list(udc_handle *h, int rk3step, std::vector<int> &f) {
   for (int n : h->slots) {
     f.push_back(UDC_SV0 + 3 * n);
-    if (rk3step == 3 || rk3step < 0) f.push_back(UDC_SVM + 3 * n);
+    // (the m-fields change on RK stage 3 only -- except under an immersed boundary, whose `solid` rewrites them at the solid cells on
+    //  every substep and reads, for a solid cell in the first / last row, the ghost row the last `halos` left: src/modibm.f90:748-826)
+    if (rk3step == 3 || rk3step < 0 || (h->ibm_on && h->ibm[3].given)) f.push_back(UDC_SVM + 3 * n);
   }
   return 0;
 }
