@@ -733,6 +733,7 @@ EXAMPLE_FILES["example_002"] = [f.replace(".001", ".002") for f in EXAMPLE_FILES
 # scalar line source whose plume enters clean (BCxs = 2: inflow profile, convective outflow).  The deck as shipped.
 EXAMPLE_FILES["example_101"] = [f.replace(".001", ".101") for f in EXAMPLE_FILES["example_001"]] + ["Tfacinit.inp.101", "scalar.inp.101",
                                                                                                     "scalarsourcel.inp.1.101"]
+# (examples/102 is a warm start from the restart files of a 2 x 2 rank run: not runnable on the one rank of this build)
 EXAMPLE_PATCH = {}      # (the decks as shipped: checkinitvalues picks the neutral wall function for 001 / 002 itself)
 
 
@@ -784,7 +785,7 @@ def make_example_cases(only):
 FULL = os.path.join(ROOT, "oracle", "_ref", "udales_full")
 
 
-FULL_EXAMPLES = {"999": 128, "002": 64, "101": 64}      # example -> grid size (cubic)
+FULL_EXAMPLES = {"999": 128, "002": 64, "101": 64, "001": 128}      # example -> grid size (cubic)
 
 
 def make_full_example(ex="999"):

@@ -55,7 +55,7 @@ def test_run_decks_through_the_reference_program(name, iexp, residency, tmp_path
     assert checked >= 4
 
 
-@pytest.mark.parametrize("ex,n", [("999", 128), ("002", 64), ("101", 64)])
+@pytest.mark.parametrize("ex,n", [("999", 128), ("002", 64), ("101", 64), ("001", 128)])
 def test_examples_through_the_reference_program(ex, n, tmp_path):
     """examples/999 of the reference (128^3, adaptive time step, tdump + xytdump + fielddump) as a user runs it -- the deck, prof.inp,
     lscale.inp, one rank -- under the untouched program.f90 with the drop-in modules, device resident.  Golden: the same through the
@@ -64,7 +64,9 @@ def test_examples_through_the_reference_program(ex, n, tmp_path):
     examples/002 (64^3, an array of cubes: immersed boundary, the deck's iwallmom = 2 turned into the neutral wall function by the
     reference's own checkinitvalues, masked xytdump) and examples/101 (64^3 street canyons: temperature with buoyancy, wall functions
     for momentum and heat on the facet temperatures, a prescribed volume flow, a kappa-advected scalar from a line source entering /
-    leaving through BCxs = 2, fielddump) the same way, decks untouched but for the rank count and the run length."""
+    leaving through BCxs = 2, fielddump) the same way, decks untouched but for the rank count and the run length; and examples/001
+    (128^3, the ground as 128 facets with wall functions on every first-level cell).  (examples/102 is a warm start from the restart
+    files of a 2 x 2 rank run: not runnable on one rank.)"""
     from udcore import restart
     if not os.path.exists(DROPIN):
         pytest.skip("oracle/_ref/udales_full_dropin not built")
