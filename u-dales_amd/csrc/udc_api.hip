@@ -999,8 +999,17 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
             : k_momentum(h, true, true, forces)) return 1;
   }
   if (k_scalar_top_flux(h)) return 1;
-  for (int n : h->slots)
+  // thl (slot 15) and qt (13) share velocities and diffusivity: one sweep for both where their schemes agree
+  bool paired = false;
+  if (lds && std::find(h->slots.begin(), h->slots.end(), 15) != h->slots.end() && std::find(h->slots.begin(), h->slots.end(), 13) != h->slots.end()) {
+    const int r = k_scalar_fused_pair(h, 15, 13, lds);
+    if (r > 0) return 1;
+    paired = r == 0;
+  }
+  for (int n : h->slots) {
+    if (paired && (n == 15 || n == 13)) continue;
     if (k_scalar_fused(h, n, lds)) return 1;       // lds: the tendencies are scratch between fused substeps (tend_scratch)
+  }
   if (h->p.sgs == UDC_SGS_ONEEQN) {
     if (k_tke_sources(h)) return 1;                // subgrid's `sources`, after the diffusion terms
     if ((ops & OP_BOTTOM) && k_tke_floor(h)) return 1;   // first lines of `bottom` (src/program.f90:152)

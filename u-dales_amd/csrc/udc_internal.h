@@ -358,7 +358,8 @@ int k_scalar_bcx_uout(udc_handle *h);
 int k_scalar_bcx_capture(udc_handle *h, int n, const double *host, const int lb[3], const int ub[3]);
 int k_scalar_bcx_fill_host(udc_handle *h, int n, double *host, const int lb[3], const int ub[3]);
 int k_scalar_diff(udc_handle *h, int n);
-int k_scalar_fused(udc_handle *h, int n, bool fresh);          // advection + diffusion in one sweep (same accumulation order)
+int k_scalar_fused(udc_handle *h, int n, bool fresh);
+int k_scalar_fused_pair(udc_handle *h, int na, int nb, bool fresh);      // 0 done, -1 not applicable, 1 error          // advection + diffusion in one sweep (same accumulation order)
 int k_forces(udc_handle *h);
 int k_coriolis(udc_handle *h, bool wrap_vp);                     // coriolis: lcoriol / lprofforc
 int k_masscorr(udc_handle *h, double rk3coef, bool pup_mode, bool wrap_vp);   // masscorr, volume-flow branches

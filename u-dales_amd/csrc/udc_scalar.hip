@@ -279,6 +279,15 @@ int k_scalar_fused(udc_handle *h, int n, bool fresh) {
   return launch_scalar(h, n, true, true, fresh) || k_scalar_bcx_edges(h, n, true, true);
 }
 
+// two slots in one sweep where that applies (udc_scalar_lds.hip, k_scalar_pair_lds): 0 done, -1 not applicable, 1 error
+bool k_scalar_pair_lds(udc_handle *h, int na, int nb, bool fresh, int *rc);
+int k_scalar_fused_pair(udc_handle *h, int na, int nb, bool fresh) {
+  int rc = 0;
+  if (h->mom_simple || !k_scalar_pair_lds(h, na, nb, fresh, &rc)) return -1;
+  if (rc || k_scalar_bcx_edges(h, na, true, true) || k_scalar_bcx_edges(h, nb, true, true)) return 1;
+  return 0;
+}
+
 // scalsource (src/modscalsource.f90:379-483): the sources are constant in time, the host evaluated them once
 // (udcore/sources.py, udc_set_scalar_source); svp += source over the box that holds it
 namespace {

@@ -10,7 +10,8 @@
 // registers one level ahead.  Two kernels: scalar_lds_kernel (2nd-order central advection: thl, qt) takes the six face
 // velocities from global memory; scalar_kappa_faces_kernel (kappa scheme) in addition evaluates every face once and
 // shares it between the two cells it borders.  Measured (MI355X): cd2 0.229 -> 0.215 ms at 256^3, kappa 1.135 ->
-// 0.925 ms at 512x512x256 (0.355 -> 0.435 of the roofline).  UDC_SCALAR_LDS=0 selects the direct-load kernel.
+// 0.925 ms at 512x512x256 (0.355 -> 0.435 of the roofline).  UDC_SCALAR_LDS=0 selects the direct-load kernel.  thl and qt (both
+// advecc_2nd, both diffused with ekh) share one launch of scalar_lds_kernel (NS = 2; UDC_SCALAR_PAIR=0: one by one).
 #include "udc_internal.h"
 #include "udc_scalar_arith.h"
 #include <cstdlib>
@@ -30,13 +31,17 @@ struct LdsAcc {
   __device__ __forceinline__ double e(int di, int dj, int dk) const { return eb[dk + 1][dj * EX + di]; }
 };
 
-template <int ADV, bool LES, bool FRESH>
+// NS: scalars per launch.  Two fields that share the advecting velocities and the diffusivity (thl and qt, both advecc_2nd + diffc
+// with ekh) go through one sweep: u0, v0, w0 and ekh are fetched once for both, 64 B per cell instead of 2 x 48.
+template <int ADV, bool LES, bool FRESH, int NS>
 __global__ __launch_bounds__(NT, 3) void scalar_lds_kernel(Geo g, int gx, int tiles, Metrics m, double cekh, double dfac,
     const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ w, const double *__restrict__ ekh,
-    const double *__restrict__ c, double *__restrict__ cp, int gh, int kc) {
-  __shared__ double sc[NCB][CN];
+    const double *__restrict__ c_a, double *__restrict__ cp_a, const double *__restrict__ c_b, double *__restrict__ cp_b, int gh, int kc) {
+  __shared__ double sc[NS][NCB][CN];
   __shared__ double se[LES ? NEB : 1][LES ? EN : 1];
   __shared__ double smet[2][NSCALMET + 1];       // level metrics of levels k and k+1 (udc_scalar_arith.h)
+  const double *const cs[2] = {c_a, c_b};
+  double *const cps[2] = {cp_a, cp_b};
   const unsigned Lb = blockIdx.x;
   const int chunk = Lb / tiles;
   const unsigned lp = Lb - (unsigned)chunk * tiles;
@@ -80,15 +85,19 @@ __global__ __launch_bounds__(NT, 3) void scalar_lds_kernel(Geo g, int gx, int ti
     }
   }
   // planes below -HZ / above nz-1+HZ do not exist: c is read at k-2 >= -2 and k+2 <= nz+1, both inside the padding
-  double rc[2], re[2];
+  double rc[NS][2], re[2];
   auto load_c = [&](int k) {
     const long pb = g.sz * (long)(k + HZ);
 #pragma unroll
-    for (int q = 0; q < 2; ++q) rc[q] = chas[q] ? c[pb + coff[q]] : 0.;
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) rc[s][q] = chas[q] ? cs[s][pb + coff[q]] : 0.;
   };
   auto commit_c = [&](int buf) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) if (chas[q]) sc[buf][cl[q]] = rc[q];
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) if (chas[q]) sc[s][buf][cl[q]] = rc[s][q];
   };
   auto load_e = [&](int k) {
     if (!LES) return;
@@ -125,15 +134,18 @@ __global__ __launch_bounds__(NT, 3) void scalar_lds_kernel(Geo g, int gx, int ti
     const ScalMetLds lm{smet[k & 1]};
     if (inside) {
       const long pb = g.sz * (long)(k + HZ);
-      LdsAcc A;
-#pragma unroll
-      for (int d = 0; d < 5; ++d) A.cb[d] = sc[(cb0 + d) % NCB] + own_c;
-#pragma unroll
-      for (int d = 0; d < 3; ++d) A.eb[d] = LES ? se[(eb0 + d) % NEB] + own_e : nullptr;
       const double ul = u[pb + own], uh = u[pb + xp1], vl = v[pb + own], vh = v[pb + own + g.sy];
       const double wh = w[pb + own + g.sz];
-      const double t0 = FRESH ? 0. : cp[pb + own];
-      NT_STORE((scalar_tend<ADV, true, LES>(A, m, lm, k, g.nz, t0, ul, uh, vl, vh, wl, wh, cekh, dfac, gh)), &cp[pb + own]);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        LdsAcc A;
+#pragma unroll
+        for (int d = 0; d < 5; ++d) A.cb[d] = sc[s][(cb0 + d) % NCB] + own_c;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) A.eb[d] = LES ? se[(eb0 + d) % NEB] + own_e : nullptr;
+        const double t0 = FRESH ? 0. : cps[s][pb + own];
+        NT_STORE((scalar_tend<ADV, true, LES>(A, m, lm, k, g.nz, t0, ul, uh, vl, vh, wl, wh, cekh, dfac, gh)), &cps[s][pb + own]);
+      }
       wl = wh;
     }
     cb0 = (cb0 + 1) % NCB;
@@ -373,7 +385,7 @@ bool k_scalar_fused_lds(udc_handle *h, int n, bool fresh, int *rc) {
   const bool les = h->p.sgs != UDC_SGS_DNS, cd2 = h->slot[n].adv == 2;
   const int gh = h->slot[n].kappa_ghosts;
 #define LF(L, F) hipLaunchKernelGGL((scalar_kappa_faces_kernel<L, F>), gr, b, 0, h->stream, g, gx, tiles, h->m, cekh, dfac, u, v, w, ekh, c, cp, gh, kc)
-#define LS(A, L, F) hipLaunchKernelGGL((scalar_lds_kernel<A, L, F>), gr, b, 0, h->stream, g, gx, tiles, h->m, cekh, dfac, u, v, w, ekh, c, cp, gh, kc)
+#define LS(A, L, F) hipLaunchKernelGGL((scalar_lds_kernel<A, L, F, 1>), gr, b, 0, h->stream, g, gx, tiles, h->m, cekh, dfac, u, v, w, ekh, c, cp, c, cp, gh, kc)
   {
     PROF(h, cd2 ? "scalar_lds_cd2" : "scalar_kappa_faces");
     if (cd2) { if (les) { if (fresh) LS(2, true, true); else LS(2, true, false); } else { if (fresh) LS(2, false, true); else LS(2, false, false); } }
@@ -384,3 +396,44 @@ bool k_scalar_fused_lds(udc_handle *h, int n, bool fresh, int *rc) {
   if (hipGetLastError() != hipSuccess) { udc_set_error("scalar_lds_kernel launch failed"); *rc = 1; }
   return true;
 }
+
+// advection + diffusion of TWO scalar slots in one sweep (see scalar_lds_kernel's NS): both advected by advecc_2nd, both diffused
+// with ekh, same vertical ghost rule -- thl and qt.  false when that does not apply (the caller launches them one by one).
+bool k_scalar_pair_lds(udc_handle *h, int na, int nb, bool fresh, int *rc) {
+  *rc = 0;
+  if (getenv("UDC_SCALAR_LDS") && atoi(getenv("UDC_SCALAR_LDS")) == 0) return false;
+  if (getenv("UDC_SCALAR_PAIR") && atoi(getenv("UDC_SCALAR_PAIR")) == 0) return false;
+  const Geo &g = h->g;
+  if (g.nx < MX || g.ny < 4) return false;
+  const udc_handle::Slot &A = h->slot[na], &B = h->slot[nb];
+  if (A.adv != 2 || B.adv != 2 || A.tke || B.tke || A.kappa_ghosts != B.kappa_ghosts) return false;
+  const int gx = (g.nx + MX - 1) / MX, gy = (g.ny + MY - 1) / MY, tiles = gx * gy;
+  int kc = g.nz < 8 ? g.nz : 8;
+  {
+    const long slots = 256L * 3;      // 52 KB of LDS: three workgroups per CU
+    double best = 1e300;
+    for (int q = 8; q <= g.nz; ++q) {
+      const long blocks = (long)tiles * ((g.nz + q - 1) / q);
+      const double cost = (double)((blocks + slots - 1) / slots) * (q + 5);
+      if (cost < best - 1e-9) { best = cost; kc = q; }
+    }
+    if (getenv("UDC_SCALAR_KC")) { const int v = atoi(getenv("UDC_SCALAR_KC")); if (v >= 1) kc = v < g.nz ? v : g.nz; }
+  }
+  const int chunks = (g.nz + kc - 1) / kc;
+  const dim3 b(MX, MY, 1), gr((unsigned)tiles * (unsigned)chunks, 1, 1);
+  const double cekh = h->p.numol * h->p.prandtlmoli, dfac = 0.5;
+  const double *u = h->fields[UDC_U0], *v = h->fields[UDC_V0], *w = h->fields[UDC_W0], *ekh = h->fields[UDC_EKH];
+  const double *ca = h->fields[UDC_SV0 + 3 * na], *cb = h->fields[UDC_SV0 + 3 * nb];
+  double *cpa = h->fields[UDC_SVP + 3 * na], *cpb = h->fields[UDC_SVP + 3 * nb];
+  const bool les = h->p.sgs != UDC_SGS_DNS;
+  const int gh = A.kappa_ghosts;
+#define LP(L, F) hipLaunchKernelGGL((scalar_lds_kernel<2, L, F, 2>), gr, b, 0, h->stream, g, gx, tiles, h->m, cekh, dfac, u, v, w, ekh, ca, cpa, cb, cpb, gh, kc)
+  {
+    PROF(h, "scalar_lds_cd2_pair");
+    if (les) { if (fresh) LP(true, true); else LP(true, false); } else { if (fresh) LP(false, true); else LP(false, false); }
+  }
+#undef LP
+  if (hipGetLastError() != hipSuccess) { udc_set_error("scalar_lds_kernel (pair) launch failed"); *rc = 1; }
+  return true;
+}
+
