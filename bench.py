@@ -248,7 +248,7 @@ def dropin_leg(nx, ny, nz, nsv, sgs, floor, value, nsub=150, nwarm=15):
     m = re.search(r"fused_substeps=(\d+) unfused=(\d+)", out)
     dm = re.search(r"divmax=\s*([0-9.Ee+-]+)", out)
     # ... and through the reference's OWN main program (oracle/_ref/udales_full_dropin: src/program.f90 untouched, every other file of
-    # the reference's src/ but the nine drop-in modules), timed by the reference's own clock around its loop (`TOTAL CPU time by
+    # the reference's src/ but the ten drop-in modules), timed by the reference's own clock around its loop (`TOTAL CPU time by
     # main time loop`, src/modmpi.f90:140-160) -- which, unlike the figure above, includes the first substep's upload of the state
     # and the last one's download for the restart / output code
     real = None
@@ -266,7 +266,7 @@ def dropin_leg(nx, ny, nz, nsv, sgs, floor, value, nsub=150, nwarm=15):
                     real = {"value": nx * ny * nz * 3 * nstep / sec, "unit": "cell-updates/s", "steps": nstep, "loop_seconds": round(sec, 4),
                             "frac_of_direct": round(nx * ny * nz * 3 * nstep / sec / value, 4),
                             "surface": "oracle/_ref/udales_full_dropin namoptions.NNN: the reference's program.f90, modstartup.f90 and every "
-                                       "other file of its src/ unmodified, minus the nine drop-in modules; its own timer around its loop "
+                                       "other file of its src/ unmodified, minus the ten drop-in modules; its own timer around its loop "
                                        "(incl. the one-time upload / final download of the state)"}
             except subprocess.TimeoutExpired:
                 real = None
@@ -274,7 +274,7 @@ def dropin_leg(nx, ny, nz, nsv, sgs, floor, value, nsub=150, nwarm=15):
             "ms_per_step": round(nx * ny * nz / v * 1e3, 5),
             "fused_substeps": int(m.group(1)) if m else None, "unfused_substeps": int(m.group(2)) if m else None,
             "divmax_after_run": float(dm.group(1)) if dm else None,
-            "surface": "the reference's whole src/ tree minus the nine drop-in modules (modstartup's start-up, every call of "
+            "surface": "the reference's whole src/ tree minus the ten drop-in modules (modstartup's start-up, every call of "
                        "src/program.f90:132-222 per substep incl. checksim, statsdump, thermodynamics; main program oracle/ref_driver.f90 "
                        "for the timer around the loop) -> drop-in modules -> C ABI, UDC_RESIDENCY=2"}
 

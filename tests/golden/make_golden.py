@@ -817,6 +817,16 @@ def make_full_example(ex="999"):
         for k, v in read_ncrec(os.path.join(tmp, f"xytdump.{ex}.nc")).items():
             if k.endswith(("xyt", "txyc", "txy")) or k == "time":
                 keep["xyt." + k[:11]] = Field(np.atleast_1d(v[0][1]).astype(float), (1,))
+        tfile = os.path.join(tmp, f"tdump.000.000.{ex}.nc")      # tdump's first record: every 16th point and the level means of each variable
+        if os.path.exists(tfile):
+            for k, v in read_ncrec(tfile).items():
+                if k == "time":
+                    continue
+                a = np.squeeze(np.asarray(v[0][1], dtype=float))
+                if a.ndim != 3:      # (the coordinate variables)
+                    continue
+                keep["tp." + k[:12]] = Field(np.ascontiguousarray(a[::16, ::16, ::16]), (1, 1, 1))
+                keep["tm." + k[:12]] = Field(a.mean(axis=(1, 2)), (1,))
         rst = [f for f in os.listdir(tmp) if f.startswith("initd")]
         assert len(rst) == 1
         r = restart.read_initd(os.path.join(tmp, rst[0]), n, n, n)

@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FULL = os.path.join(ROOT, "oracle", "_ref", "udales_full")
 
 
-def run_full(name, iexp, tmp_path, exe=FULL, env=None):
+def run_full(name, iexp, tmp_path, exe=FULL, env=None, deck_text=None):
     """-> (fixture, tag of its last dump, restart dict of the real program stopped at that time, working directory)"""
     from udcore import restart
     fix = load_fixture(name)
@@ -41,6 +41,8 @@ def run_full(name, iexp, tmp_path, exe=FULL, env=None):
     deck = os.path.join(tmp_path, f"namoptions.{iexp:03d}")
     with open(deck) as f:
         txt = f.read()
+    if deck_text is not None:      # (a variant of the case's deck)
+        txt = deck_text
     dtmax = float(re.search(r"dtmax\s*=\s*([0-9.eE+-]+)", txt).group(1))
     tend = fix[last + ".time"].data[0] if last + ".time" in fix else dtmax * nsub / 3
     runtime = tend * (1. - 1e-9)       # the loop runs while timeleft > 0 (src/program.f90:132): stops after the step that reaches tend

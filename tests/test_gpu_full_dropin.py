@@ -1,10 +1,10 @@
 """The drop-in boundary under the reference's REAL program.
 
 oracle/_ref/udales_full_dropin is what INTEGRATION.md section 1 prescribes, carried out: every file of the reference's src/ --
-program.f90, modstartup.f90, tests.f90, the statistics / output modules, unmodified, compiled where they lie -- except the nine
+program.f90, modstartup.f90, tests.f90, the statistics / output modules, unmodified, compiled where they lie -- except the ten
 modules u-dales_amd/fortran/ replaces, linked against libudcore (u-dales_amd/fortran/Makefile).  Same command line as the
 reference's executable: `udales_full_dropin namoptions.NNN`.  Its counterpart oracle/_ref/udales_full is the same build with the
-reference's own nine modules; the fixtures come from that one (tests/test_full_reference.py pins them on it bit for bit).
+reference's own ten modules; the fixtures come from that one (tests/test_full_reference.py pins them on it bit for bit).
 
 Here: every run deck of the golden set and the reference's examples/999 through the real program on the device, device resident
 (UDC_RESIDENCY=2: the routines record, tstep_integrate launches the fused substep) and with every call carrying its fields
@@ -55,6 +55,48 @@ def test_run_decks_through_the_reference_program(name, iexp, residency, tmp_path
     assert checked >= 4
 
 
+@pytest.mark.parametrize("name", ["run_stats_16x8x12s", "run_stats_ibm_16x12x10", "run_ytstats_ibm_16x12x10"])
+def test_statistics_files_of_the_dropin_statsdump(name, tmp_path):
+    """The drop-in modstatsdump (time-averaged statistics accumulated on the device, u-dales_amd/fortran/modstatsdump.f90) against
+    the reference's: the same deck through oracle/_ref/udales_full (all reference; it travels with the snapshot) and through
+    udales_full_dropin, + lmintdump; every record either hands to NetCDF -- tdump's 32 variables, mintdump, xytdump's 23
+    profiles, ytdump's 34 x-z fields, the record times -- compared one by one (obstacles: -999 where a level / column has no fluid)."""
+    from test_full_reference import FULL
+    if not (os.path.exists(DROPIN) and os.path.exists(FULL)):
+        pytest.skip("oracle/_ref/udales_full(_dropin) not built")
+    iexp = RUN_CASES[name]
+    nsv = int(load_fixture(name)["meta"].data[12])
+    out = {}
+    for tag, exe in (("ref", FULL), ("dev", DROPIN)):
+        d = tmp_path / tag
+        d.mkdir()
+        deck = os.path.join(GOLDEN, "cases", name, f"namoptions.{iexp:03d}")
+        txt = open(deck).read().replace("&OUTPUT", "&OUTPUT\nlmintdump = .true.")
+        txt = re.sub(r"tstatsdump\s*=\s*1000\.", "tstatsdump = 1.0", txt)      # (the two obstacle decks: a record every fourth step)
+        assert "lmintdump" in txt
+        run_full(name, iexp, d, exe=exe, env=dict(os.environ, UDC_RESIDENCY="2"), deck_text=txt)
+        out[tag] = {fn: read_ncrec(str(d / fn)) for fn in sorted(os.listdir(d)) if fn.endswith(".nc") and "dump" in fn and "field" not in fn}
+    assert set(out["ref"]) == set(out["dev"]) and len(out["ref"]) >= 2, (sorted(out["ref"]), sorted(out["dev"]))
+    checked = 0
+    for fn, ref in out["ref"].items():
+        dev = out["dev"][fn]
+        assert list(ref) == list(dev), fn                      # the same variables in the same order
+        for var, recs in ref.items():
+            assert len(recs) == len(dev[var]) >= 1, (fn, var)
+            # ytdump's rows of fields the deck does not carry: the reference never assigns them (src/modstatsdump.f90:1483-1505 sit
+            # under lmoist / nsv > n) and writes what the arrays happen to hold; the drop-in writes zeros
+            if fn.startswith("ytdump") and (("qt" in var and "lmoist" not in txt) or any(f"sca{q}" in var and nsv < q for q in (1, 2, 3))):
+                continue
+            for (s0, a), (s1, b) in zip(recs, dev[var]):
+                assert s0 == s1 and a.shape == b.shape, (fn, var)
+                hole = a < -900.
+                assert np.array_equal(hole, b < -900.), (fn, var)
+                sc = max(np.abs(a[~hole]).max() if (~hole).any() else 0., 1e-3 if var.startswith("p") else 1e-6)      # (slab means of w, v: round-off zeros)
+                assert np.abs(a - b)[~hole].max(initial=0.) <= 1e-8 * sc, (fn, var, np.abs(a - b)[~hole].max(), sc)
+                checked += 1
+    assert checked >= 30
+
+
 @pytest.mark.parametrize("ex,n", [("999", 128), ("002", 64), ("101", 64), ("001", 128)])
 def test_examples_through_the_reference_program(ex, n, tmp_path):
     """examples/999 of the reference (128^3, adaptive time step, tdump + xytdump + fielddump) as a user runs it -- the deck, prof.inp,
@@ -103,6 +145,21 @@ def test_examples_through_the_reference_program(ex, n, tmp_path):
         assert np.abs(got - f.data)[lev].max() <= 1e-8 * sc, (k, np.abs(got - f.data)[lev].max(), sc)
         checked += 1
     assert checked >= 20
+    # tdump's first record (the 32 time-averaged 3-D variables; written by the drop-in modstatsdump from the device's accumulators)
+    tkeys = [k for k in fix if k.startswith("tp.")]
+    if tkeys:
+        trec = read_ncrec(str(tmp_path / f"tdump.000.000.{ex}.nc"))
+        tchecked = 0
+        for k in tkeys:
+            name = [q for q in trec if q[:12] == k[3:]]
+            assert len(name) == 1, k
+            got = np.squeeze(trec[name[0]][0][1])
+            ref = fix[k].data
+            sc = max(np.abs(ref).max(), 1e-3 if k[3:] == "pt" else 1e-9)      # (p: see xytdump above)
+            assert np.abs(got[::16, ::16, ::16] - ref).max() <= 1e-7 * sc, (k, np.abs(got[::16, ::16, ::16] - ref).max(), sc)
+            assert np.abs(got.mean(axis=(1, 2)) - fix["tm." + k[3:]].data).max() <= 1e-7 * sc, k
+            tchecked += 1
+        assert tchecked == 32
     rst = [f for f in os.listdir(tmp_path) if f.startswith("initd")]
     assert len(rst) == 1 and float(rst[0][5:13]) == fix["rst.time"].data[2]
     rs = restart.read_initd(str(tmp_path / rst[0]), n, n, n)

@@ -1,5 +1,5 @@
 """The Fortran / MPI route into the library, as far as one box allows: the reference's real program with the drop-in modules over a
-real MPI (oracle/_ref/udales_full_dropin_mpi: every file of the reference's src/ but the nine replaced ones, MPICH, the y-slab
+real MPI (oracle/_ref/udales_full_dropin_mpi: every file of the reference's src/ but the ten replaced ones, MPICH, the y-slab
 decomposition stand-in), launched as a user launches the reference: `mpiexec -n 2 <exe> namoptions.NNN` with nprocx = 1, nprocy = 2.
 
 Each rank reads the deck (rank 0 reads, MPI_BCAST of every value: src/modstartup.f90:175-520), sets up its slab, creates its library

@@ -466,7 +466,9 @@ extern "C" int udc_stats_sample(udc_handle *h, double tsamplep, double tstatsdum
   HIP_OK(hipSetDevice(h->device));
   if (udc_flush_pending(h)) return 1;
   if (!h->stats_on) { udc_set_error("udc_stats_sample: call udc_stats_enable first"); return 1; }
-  if (!(tstatsdumpp > 0.) || tsamplep < 0. || tsamplep > tstatsdumpp) { udc_set_error("udc_stats_sample: need 0 <= tsamplep <= tstatsdumpp, tstatsdumpp > 0"); return 1; }
+  // (tsamplep may exceed tstatsdumpp: the reference's clocks allow it -- a sample interval that straddles a dump, with an adaptive
+  //  time step -- and its running average then weighs the old value negatively, src/modstatsdump.f90:1137-1213; same formula here)
+  if (!(tstatsdumpp > 0.) || tsamplep < 0.) { udc_set_error("udc_stats_sample: need tsamplep >= 0, tstatsdumpp > 0"); return 1; }
   const Geo &g = h->g;
   const TileGrid tg = tile_grid(g);
   const dim3 b(64, 4, 1), gr((unsigned)tg.tiles * (unsigned)(g.nz + 1), 1, 1);      // levels kb .. ke+kh

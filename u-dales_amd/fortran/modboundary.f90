@@ -56,7 +56,8 @@ contains
       ! device mode: checksim, fielddump and statsdump come next (src/program.f90:199-205) and read the host arrays.  They are
       ! refreshed when the run ends, every UDC_PULL_EVERY steps, and -- so that the untouched statsdump samples the state it
       ! would sample in an all-host run -- on exactly the steps on which it takes a sample
-      due = stats_sample_due()
+      due = .false.
+      if (.not. udc_stats_on_device) due = stats_sample_due()      ! (the drop-in statsdump samples on the device)
       if (lfielddump .and. timee >= tnextfielddump) due = .true.      ! fielddump's own condition (src/modfielddump.f90:392-396)
       if (timeleft <= 0 .or. due) then
         call udc_pull_all

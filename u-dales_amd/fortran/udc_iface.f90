@@ -63,6 +63,8 @@ module udc_iface
   logical, save :: udc_tab_registered(0:1) = .false.
   logical, save :: udc_row_registered(ROW_SVP + 16, 0:1) = .false.
   logical, save :: udc_scalsrc_on = .false.   !< constant scalar sources are registered with the device (device mode)
+  logical, save :: udc_stats_on_device = .false.      !< the drop-in modstatsdump is linked and has something to do: the reference's
+                                                      !! statsdump is not there to read the host arrays
   integer, save :: udc_pull_every = 0         !< UDC_PULL_EVERY: refresh the host arrays every n-th time step in device mode
 
   interface
