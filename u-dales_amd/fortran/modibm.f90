@@ -436,16 +436,15 @@ contains
       end do
     end if
     IIw(:, :, kb) = 0; IIuw(:, :, kb) = 0; IIvw(:, :, kb) = 0
-    do i = ib, ie      ! a stencil point counts as fluid only when every point of its stencil is (:2182-2192)
-      do j = jb, je
-        IIuv(i, j, kb) = IIu(i, j, kb)*IIu(i, j - 1, kb)*IIv(i, j, kb)*IIv(i - 1, j, kb)
-        do k = kb + 1, ke
-          IIuv(i, j, k) = IIu(i, j, k)*IIu(i, j - 1, k)*IIv(i, j, k)*IIv(i - 1, j, k)
-          IIuw(i, j, k) = IIu(i, j, k)*IIu(i, j, k - 1)*IIw(i, j, k)*IIw(i - 1, j, k)
-          IIvw(i, j, k) = IIv(i, j, k)*IIv(i, j, k - 1)*IIw(i, j, k)*IIw(i, j - 1, k)
-        end do
-      end do
-    end do
+    ! edge masks: an edge point counts as fluid only when the four staggered points around it do (src/modibm.f90:2182-2192) -- the
+    ! two points of each component that meet at the edge.  uv edges exist on every level, uw / vw edges from kb + 1 up (below them
+    ! lies the floor, set solid above).  Whole-array products over this rank's interior:
+    IIuv(ib:ie, jb:je, kb:ke) = min(IIu(ib:ie, jb:je, kb:ke), IIu(ib:ie, jb - 1:je - 1, kb:ke), &
+                                    IIv(ib:ie, jb:je, kb:ke), IIv(ib - 1:ie - 1, jb:je, kb:ke))
+    IIuw(ib:ie, jb:je, kb + 1:ke) = min(IIu(ib:ie, jb:je, kb + 1:ke), IIu(ib:ie, jb:je, kb:ke - 1), &
+                                        IIw(ib:ie, jb:je, kb + 1:ke), IIw(ib - 1:ie - 1, jb:je, kb + 1:ke))
+    IIvw(ib:ie, jb:je, kb + 1:ke) = min(IIv(ib:ie, jb:je, kb + 1:ke), IIv(ib:ie, jb:je, kb:ke - 1), &
+                                        IIw(ib:ie, jb:je, kb + 1:ke), IIw(ib:ie, jb - 1:je - 1, kb + 1:ke))
     allocate (loc(kb:ke + khc), tot(kb:ke + khc))
     call slabcount(IIc, IIcs); call slabcount(IIu, IIus); call slabcount(IIv, IIvs); call slabcount(IIw, IIws)
     call slabcount(IIuw, IIuws); call slabcount(IIvw, IIvws); call slabcount(IIuv, IIuvs)
