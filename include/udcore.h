@@ -365,7 +365,8 @@ enum {
   UDC_ST_SV_STRIDE = 5,
   UDC_ST_MAX = UDC_ST_SV + 4 * UDC_ST_SV_STRIDE
 };
-int udc_stats_enable(udc_handle *h, int on);      /* 0 off; 1 the 3-D accumulators; +2 xytdump's running profiles; +4 ytdump's running y-averages */
+int udc_stats_enable(udc_handle *h, int on);      /* 0 off; 1 the 3-D accumulators; +2 xytdump's running profiles; +4 ytdump's running y-averages;
+                                                   * +8 xydump's and +16 ydump's instantaneous tables of every sample (udc_stats_xy / udc_stats_y) */
 int udc_stats_sample(udc_handle *h, double tsamplep, double tstatsdumpp);
 int udc_stats_get(udc_handle *h, int id, double *host, const int lb[3], const int ub[3]);
 
@@ -399,6 +400,16 @@ int udc_stats_xyt(udc_handle *h, double *table);
 enum { UDC_YT_N = 34 };
 int udc_stats_set_forced(udc_handle *h, const int *forced);
 int udc_stats_yt(udc_handle *h, double *table);
+/* xydump and ydump (src/modstatsdump.f90:1002-1081 the averages of one sample, :1294-1349 the records written every tsample): the
+ * instantaneous counterparts of the two tables above -- the x-y (x-z) averages of the LAST sample udc_stats_sample took, no time
+ * averaging.  udc_stats_xy: [UDC_XY_N][ktot] in the order of the reference's record (uxy vxy wxy thlxy qtxy pxy upwpxyik wpthlpxyk
+ * vpwpxyjk usgsxy thlsgsxy vsgsxy uwxyik wthlxyk vwxyjk; the products of the edge interpolations are averaged with avexy_ibm's lnan =
+ * .true.: -999 on a level without fluid points, the first level included -- the flux rows then carry the reference's arithmetic on
+ * those -999).  udc_stats_y: [UDC_Y_N][ktot][itot] (uy vy wy thly qty sca1-3y upwpyik wpthlpyk usgsy thlsgsy uwyik wthlyk), -999 in
+ * columns without fluid points.  udc_stats_enable with bit 8 / 16. */
+enum { UDC_XY_N = 15, UDC_Y_N = 14 };
+int udc_stats_xy(udc_handle *h, double *table);
+int udc_stats_y(udc_handle *h, double *table);
 
 /* Passive scalars with an inflow and an outflow in x while the flow stays periodic (&BC BCxs = 2, the reference's dispersion
  * examples): inlet ghost cells mirrored about the inflow profile (xsi_profile, src/modboundary.f90:844-861), a convective outlet

@@ -59,7 +59,7 @@ def test_run_decks_through_the_reference_program(name, iexp, residency, tmp_path
 def test_statistics_files_of_the_dropin_statsdump(name, tmp_path):
     """The drop-in modstatsdump (time-averaged statistics accumulated on the device, u-dales_amd/fortran/modstatsdump.f90) against
     the reference's: the same deck through oracle/_ref/udales_full (all reference; it travels with the snapshot) and through
-    udales_full_dropin, + lmintdump and the three slice dumps; every record either hands to NetCDF -- tdump's 32 variables, mintdump,
+    udales_full_dropin, + lmintdump, the instantaneous xydump / ydump and the three slice dumps; every record either hands to NetCDF -- tdump's 32 variables, mintdump,
     xytdump's 23 profiles, ytdump's 34 x-z fields, the slices (planes downloaded on their own), the record times -- compared one by
     one (obstacles: -999 where a level / column has no fluid)."""
     from test_full_reference import FULL
@@ -72,13 +72,13 @@ def test_statistics_files_of_the_dropin_statsdump(name, tmp_path):
         d = tmp_path / tag
         d.mkdir()
         deck = os.path.join(GOLDEN, "cases", name, f"namoptions.{iexp:03d}")
-        txt = open(deck).read().replace("&OUTPUT", "&OUTPUT\nlmintdump = .true.\nlkslicedump = .true.\nkslice = 3\nlislicedump = .true.\nislice = 5\n"
+        txt = open(deck).read().replace("&OUTPUT", "&OUTPUT\nlmintdump = .true.\nlxydump = .true.\nlydump = .true.\nlkslicedump = .true.\nkslice = 3\nlislicedump = .true.\nislice = 5\n"
                                                            "ljslicedump = .true.\njslice = 4")
         txt = re.sub(r"tstatsdump\s*=\s*1000\.", "tstatsdump = 1.0", txt)      # (the two obstacle decks: a record every fourth step)
         assert "lmintdump" in txt
         run_full(name, iexp, d, exe=exe, env=dict(os.environ, UDC_RESIDENCY="2"), deck_text=txt)
         out[tag] = {fn: read_ncrec(str(d / fn)) for fn in sorted(os.listdir(d)) if fn.endswith(".nc") and "dump" in fn and "field" not in fn}
-    assert set(out["ref"]) == set(out["dev"]) and len(out["ref"]) >= 5, (sorted(out["ref"]), sorted(out["dev"]))
+    assert set(out["ref"]) == set(out["dev"]) and len(out["ref"]) >= 7, (sorted(out["ref"]), sorted(out["dev"]))
     checked = 0
     for fn, ref in out["ref"].items():
         dev = out["dev"][fn]

@@ -262,6 +262,8 @@ struct udc_handle {
   bool xyt_on = false;
   unsigned char *st_mask = nullptr;
   double *st_cnt = nullptr, *st_prof = nullptr, *st_part = nullptr, *st_sum = nullptr, *st_table = nullptr;
+  double *xy_table = nullptr, *xy_sum = nullptr, *y_table = nullptr, *y_sum = nullptr;      // xydump / ydump: the last sample's own tables
+  bool xy_on = false, y_on = false;
   size_t st_part_cap = 0;
   // ytdump: running y-averages [15][nz][nx], column counts of the masks IIu, IIv, IIw, IIc, IIuw [5][nz][nx], scratch, table
   bool yt_on = false;

@@ -380,6 +380,109 @@ __global__ void yt_table_kernel(int n, const double *__restrict__ S, const doubl
   table[q] = c > 0. ? S[(long)f * n + r] / c : -999.;
 }
 
+// ---- xydump / ydump: the instantaneous slab / column averages of ONE sample, written every tsample (src/modstatsdump.f90:1002-1081,
+// 1294-1349).  Next to the averages the running profiles are built from (xyt_sample_kernel / yt_sample_kernel above) they hold the
+// products of the edge interpolations of that sample: uik wik, vjk wjk, wm thlk and the factors on their own.
+enum { XI_UW = 0, XI_UIK, XI_WIK, XI_VW, XI_VJK, XI_WJK, XI_WTHL, XI_THLK, XI_N };
+__constant__ int xi_mask[XI_N] = {MB_UW, MB_UW, MB_UW, MB_VW, MB_VW, MB_VW, MB_W, MB_W};
+struct EdgeVals { double uik, wik, vjk, wjk, thlk, w; };
+__device__ __forceinline__ EdgeVals edge_vals(const Geo &g, const Metrics &m, const double *__restrict__ um, const double *__restrict__ vm,
+                                              const double *__restrict__ wm, const double *__restrict__ thl, int i, int j, int k) {
+  const int kf = k + 1;
+  const long c = g.idx(i, j, k), cm = g.idx(wrapx(i - 1, g.nx), j, k), sy = g.sy, sz = g.sz;
+  const double dzf_k = m.dzf[kf], dzf_km = m.dzf[kf - 1], dzhi = m.dzhi[kf];
+  const double w = wm[c];
+  EdgeVals e;      // :816-826, 862 (as stats_mom_kernel / stats_scalar_kernel)
+  e.uik = 0.5 * dzhi * (um[c] * dzf_km + um[c - sz] * dzf_k);
+  e.wik = 0.5 * m.dxi * (w * m.dx + wm[cm] * m.dx);
+  e.vjk = 0.5 * dzhi * (vm[c] * dzf_km + vm[c - sz] * dzf_k);
+  e.wjk = 0.5 * (w + wm[c - sy]);
+  e.thlk = thl ? 0.5 * dzhi * (thl[c] * dzf_km + thl[c - sz] * dzf_k) : 0.;
+  e.w = w;
+  return e;
+}
+__global__ __launch_bounds__(256) void xy_sample_kernel(Geo g, int gx, Metrics m, const double *__restrict__ um, const double *__restrict__ vm,
+                                                        const double *__restrict__ wm, const double *__restrict__ thl,
+                                                        const unsigned char *__restrict__ mask, double *__restrict__ part) {
+  const int tile = blockIdx.x, k = blockIdx.y;
+  const int by = tile / gx, bx = tile - by * gx;
+  const int i = bx * 64 + threadIdx.x;
+  double v[XI_N];
+#pragma unroll
+  for (int p = 0; p < XI_N; ++p) v[p] = 0.;
+  for (int r = 0; r < XR; ++r) {
+    const int j = (by * XR + r) * 4 + threadIdx.y;
+    if (i >= g.nx || j >= g.ny) continue;
+    const unsigned mb = mask ? mask[((size_t)k * g.ny + j) * g.nx + i] : 0x7fu;
+    const EdgeVals e = edge_vals(g, m, um, vm, wm, thl, i, j, k);
+    v[XI_UW] += e.uik * e.wik * bit(mb, MB_UW); v[XI_UIK] += e.uik * bit(mb, MB_UW); v[XI_WIK] += e.wik * bit(mb, MB_UW);
+    v[XI_VW] += e.vjk * e.wjk * bit(mb, MB_VW); v[XI_VJK] += e.vjk * bit(mb, MB_VW); v[XI_WJK] += e.wjk * bit(mb, MB_VW);
+    v[XI_WTHL] += e.w * e.thlk * bit(mb, MB_W); v[XI_THLK] += e.thlk * bit(mb, MB_W);
+  }
+  block_level_sums<XI_N>(v, part, tile, gridDim.x, k, gridDim.y);
+}
+// the 15 profiles of xydump in the order of varsxy (:1330-1344).  S9: the sample's nine masked level sums (XS_*, avexy_ibm with
+// lnan = .false.: the caller's first-level rule applies), SI: the eight above (lnan = .true.: a level without fluid points is -999,
+// first level included -- `forced` names the masks whose first level the caller filled).
+struct XyForced { int f[7]; };
+__global__ void xy_table_kernel(int nz, const double *__restrict__ S9, const double *__restrict__ SI, const double *__restrict__ cnt, XyForced F,
+                                double *__restrict__ table) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nz) return;
+  auto a9 = [&](int p) { const double n = cnt[xs_mask[p] * nz + k]; return n > 0. ? S9[p * nz + k] / n : -999.; };
+  auto ai = [&](int p) {
+    const int mk = xi_mask[p];
+    const double n = (k == 0 && F.f[mk]) ? 0. : cnt[mk * nz + k];
+    return n > 0. ? SI[p * nz + k] / n : -999.;
+  };
+  const double uw = ai(XI_UW), vw = ai(XI_VW), wthl = ai(XI_WTHL), wxy = a9(XS_W);
+  double *t = table + k;
+  t[0 * nz] = a9(XS_U); t[1 * nz] = a9(XS_V); t[2 * nz] = wxy; t[3 * nz] = a9(XS_THL); t[4 * nz] = a9(XS_QT); t[5 * nz] = a9(XS_P);
+  t[6 * nz] = uw - ai(XI_UIK) * ai(XI_WIK);
+  t[7 * nz] = wthl - wxy * ai(XI_THLK);
+  t[8 * nz] = vw - ai(XI_VJK) * ai(XI_WJK);
+  t[9 * nz] = a9(XS_USGS); t[10 * nz] = a9(XS_THLSGS); t[11 * nz] = a9(XS_VSGS);
+  t[12 * nz] = uw; t[13 * nz] = wthl; t[14 * nz] = vw;
+}
+
+enum { YI_UW = 0, YI_UIK, YI_WIK, YI_WTHL, YI_THLK, YI_N };
+__constant__ int yi_mask[YI_N] = {MB_UW, MB_UW, MB_UW, MB_W, MB_W};
+// column counts live in yt_cnt as [IIu, IIv, IIw, IIc, IIuw][nz][nx] (yt_count_kernel sums bits 0..4)
+__global__ __launch_bounds__(256) void y_sample_kernel(Geo g, Metrics m, const double *__restrict__ um, const double *__restrict__ vm,
+                                                       const double *__restrict__ wm, const double *__restrict__ thl,
+                                                       const unsigned char *__restrict__ mask, YForced F, double *__restrict__ S) {
+  const int i = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y;
+  double v[YI_N];
+#pragma unroll
+  for (int p = 0; p < YI_N; ++p) v[p] = 0.;
+  const bool in = i < g.nx;
+  if (in)
+    for (int j = threadIdx.y; j < g.ny; j += 4) {
+      const unsigned mb = ybits(mask, g, F, i, j, k);
+      const EdgeVals e = edge_vals(g, m, um, vm, wm, thl, i, j, k);
+      v[YI_UW] += e.uik * e.wik * bit(mb, MB_UW); v[YI_UIK] += e.uik * bit(mb, MB_UW); v[YI_WIK] += e.wik * bit(mb, MB_UW);
+      v[YI_WTHL] += e.w * e.thlk * bit(mb, MB_W); v[YI_THLK] += e.thlk * bit(mb, MB_W);
+    }
+  ysum_store<YI_N>(v, S, i, k, g.nx, g.nz, in);
+}
+// the 14 x-z fields of ydump in the order of varsy (:1303-1316); SY: the sample's YS_* column sums, SI: the five above
+__global__ void y_table_kernel(int n, const double *__restrict__ SY, const double *__restrict__ SI, const double *__restrict__ cnt,
+                               double *__restrict__ table) {
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  auto ay = [&](int p) { const double c = cnt[(long)ys_mask[p] * n + r]; return c > 0. ? SY[(long)p * n + r] / c : -999.; };
+  auto ai = [&](int p) { const double c = cnt[(long)yi_mask[p] * n + r]; return c > 0. ? SI[(long)p * n + r] / c : -999.; };
+  const double uw = ai(YI_UW), wthl = ai(YI_WTHL), wy = ay(YS_W);
+  const double cuw = cnt[(long)MB_UW * n + r], cw = cnt[(long)MB_W * n + r];
+  double *t = table + r;
+  t[0L * n] = ay(YS_U); t[1L * n] = ay(YS_V); t[2L * n] = wy; t[3L * n] = ay(YS_THL); t[4L * n] = ay(YS_QT);
+  t[5L * n] = ay(YS_SV1); t[6L * n] = ay(YS_SV2); t[7L * n] = ay(YS_SV3);
+  t[8L * n] = cuw > 0. ? uw - ai(YI_UIK) * ai(YI_WIK) : -999.;      // where (IIuwt == 0) upwpyik = -999 (:1026-1028)
+  t[9L * n] = cw > 0. ? wthl - wy * ai(YI_THLK) : -999.;            // where (IIwt == 0) wpthlpyk = -999 (:1020-1022)
+  t[10L * n] = ay(YS_USGS); t[11L * n] = ay(YS_THLSGS);
+  t[12L * n] = uw; t[13L * n] = wthl;
+}
+
 }  // namespace
 
 static int yt_counts(udc_handle *h) {
@@ -422,6 +525,8 @@ extern "C" int udc_stats_enable(udc_handle *h, int on) {
     h->stats_on = false;
     return 0;
   }
+  if (on & 8) on |= 2;      // xydump's profiles are built on xytdump's sample sums, ydump's on ytdump's
+  if (on & 16) on |= 4;
   if (on & 2) {        // xytdump: the nine running profiles; masks default to "no obstacles" until udc_stats_set_masks
     const int nz = h->g.nz;
     if (!h->st_prof) {
@@ -434,6 +539,12 @@ extern "C" int udc_stats_enable(udc_handle *h, int on) {
     }
     HIP_OK(hipMemsetAsync(h->st_prof, 0, sizeof(double) * XS_N * nz, h->stream));
     h->xyt_on = true;
+    if ((on & 8) && !h->xy_table) {
+      HIP_OK(hipMalloc(&h->xy_table, sizeof(double) * UDC_XY_N * nz));
+      HIP_OK(hipMalloc(&h->xy_sum, sizeof(double) * XI_N * nz));
+      HIP_OK(hipMemsetAsync(h->xy_table, 0, sizeof(double) * UDC_XY_N * nz, h->stream));
+    }
+    h->xy_on = (on & 8) != 0;
   }
   if (on & 4) {        // ytdump: running y-averages and the column counts of the masks
     const size_t n = (size_t)h->g.nz * h->g.nx;
@@ -445,6 +556,12 @@ extern "C" int udc_stats_enable(udc_handle *h, int on) {
     }
     HIP_OK(hipMemsetAsync(h->yt_prof, 0, sizeof(double) * YS_N * n, h->stream));
     h->yt_on = true;
+    if ((on & 16) && !h->y_table) {
+      HIP_OK(hipMalloc(&h->y_table, sizeof(double) * UDC_Y_N * n));
+      HIP_OK(hipMalloc(&h->y_sum, sizeof(double) * YI_N * n));
+      HIP_OK(hipMemsetAsync(h->y_table, 0, sizeof(double) * UDC_Y_N * n, h->stream));
+    }
+    h->y_on = (on & 16) != 0;
     if (yt_counts(h)) return 1;
   }
   for (int q = 0; q < UDC_ST_MOM_N; ++q)
@@ -508,6 +625,18 @@ extern "C" int udc_stats_sample(udc_handle *h, double tsamplep, double tstatsdum
     hipLaunchKernelGGL(xyt_running_kernel, dim3((unsigned)((XS_N * nz + 255) / 256)), dim3(256), 0, h->stream, nz, (const double *)h->st_sum,
                        (const double *)h->st_cnt, tsamplep, tstatsdumpp, h->st_prof);
     HIP_OK(hipGetLastError());
+    if (h->xy_on) {      // xydump: this sample's own profiles (st_sum still holds its nine level sums)
+      hipLaunchKernelGGL(xy_sample_kernel, dim3((unsigned)xt.tiles, (unsigned)nz), dim3(64, 4), 0, h->stream, g, xt.gx, h->m, um, vm, wm,
+                         thl >= 0 ? (const double *)h->fields[thl] : nullptr, (const unsigned char *)h->st_mask, h->st_part);
+      hipLaunchKernelGGL(xyt_tiles_kernel, dim3((unsigned)(XI_N * nz)), dim3(256), 0, h->stream, xt.tiles, (const double *)h->st_part, h->xy_sum);
+      HIP_OK(hipGetLastError());
+      if (comm_allreduce(h, h->xy_sum, XI_N * nz, 1)) return 1;
+      XyForced XF;
+      for (int q = 0; q < 7; ++q) XF.f[q] = h->st_mask ? h->yt_forced[q] : 0;
+      hipLaunchKernelGGL(xy_table_kernel, dim3((unsigned)((nz + 63) / 64)), dim3(64), 0, h->stream, nz, (const double *)h->st_sum,
+                         (const double *)h->xy_sum, (const double *)h->st_cnt, XF, h->xy_table);
+      HIP_OK(hipGetLastError());
+    }
   }
   if (h->yt_on) {
     const size_t n = (size_t)g.nz * g.nx;
@@ -527,6 +656,15 @@ extern "C" int udc_stats_sample(udc_handle *h, double tsamplep, double tstatsdum
     hipLaunchKernelGGL(yt_running_kernel, dim3((unsigned)((YS_N * n + 255) / 256)), dim3(256), 0, h->stream, (int)n, (const double *)h->yt_sum,
                        (const double *)h->yt_cnt, tsamplep, tstatsdumpp, h->yt_prof);
     HIP_OK(hipGetLastError());
+    if (h->y_on) {       // ydump: this sample's own x-z fields (yt_sum still holds its column sums)
+      hipLaunchKernelGGL(y_sample_kernel, dim3((unsigned)((g.nx + 63) / 64), (unsigned)g.nz), dim3(64, 4), 0, h->stream, g, h->m, um, vm, wm,
+                         f.thl, (const unsigned char *)h->st_mask, F, h->y_sum);
+      HIP_OK(hipGetLastError());
+      if (comm_allreduce(h, h->y_sum, (int)(YI_N * n), 1)) return 1;
+      hipLaunchKernelGGL(y_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (int)n, (const double *)h->yt_sum,
+                         (const double *)h->y_sum, (const double *)h->yt_cnt, h->y_table);
+      HIP_OK(hipGetLastError());
+    }
   }
   return 0;
 }
@@ -625,15 +763,39 @@ extern "C" int udc_stats_xyt(udc_handle *h, double *table) {
   return 0;
 }
 
+extern "C" int udc_stats_xy(udc_handle *h, double *table) {
+  if (!h) { udc_set_error("null handle"); return 1; }
+  HIP_OK(hipSetDevice(h->device));
+  if (udc_flush_pending(h)) return 1;
+  if (!h->xy_on || !h->stats_on) { udc_set_error("udc_stats_xy: enable xydump's profiles first (udc_stats_enable with bit 8)"); return 1; }
+  if (!table) { udc_set_error("udc_stats_xy: null table"); return 1; }
+  HIP_OK(hipMemcpyAsync(table, h->xy_table, sizeof(double) * UDC_XY_N * h->g.nz, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+extern "C" int udc_stats_y(udc_handle *h, double *table) {
+  if (!h) { udc_set_error("null handle"); return 1; }
+  HIP_OK(hipSetDevice(h->device));
+  if (udc_flush_pending(h)) return 1;
+  if (!h->y_on || !h->stats_on) { udc_set_error("udc_stats_y: enable ydump's fields first (udc_stats_enable with bit 16)"); return 1; }
+  if (!table) { udc_set_error("udc_stats_y: null table"); return 1; }
+  HIP_OK(hipMemcpyAsync(table, h->y_table, sizeof(double) * UDC_Y_N * (size_t)h->g.nz * h->g.nx, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
 void stats_destroy(udc_handle *h) {
   for (double *p : h->stats) if (p) hipFree(p);
   h->stats.clear();
-  for (double **p : {&h->st_cnt, &h->st_prof, &h->st_part, &h->st_sum, &h->st_table, &h->yt_prof, &h->yt_cnt, &h->yt_sum, &h->yt_table})
+  for (double **p : {&h->st_cnt, &h->st_prof, &h->st_part, &h->st_sum, &h->st_table, &h->yt_prof, &h->yt_cnt, &h->yt_sum, &h->yt_table,
+                     &h->xy_table, &h->xy_sum, &h->y_table, &h->y_sum})
     if (*p) { hipFree(*p); *p = nullptr; }
   if (h->st_mask) { hipFree(h->st_mask); h->st_mask = nullptr; }
   h->st_part_cap = 0;
   h->xyt_on = false;
   h->yt_on = false;
+  h->xy_on = h->y_on = false;
 }
 
 double *stats_ptr(udc_handle *h, int id) {

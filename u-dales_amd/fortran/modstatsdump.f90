@@ -5,12 +5,13 @@
 !! (tsamplep, tstatsdumpp: :797-811, 1393-1399, 1723-1729), same files, variables, attributes and record order, written through
 !! the reference's own modstat_nc.
 !!
-!! The slice dumps (kslicedump / islicedump / jslicedump, :418-502, 1352-1389: um, vm, wm, thlm, qtm on one plane every tsample)
-!! download that plane alone.
+!! The instantaneous tables written at every sample -- xydump (:215-245, 1326-1349), ydump (:131-158, 1294-1323) -- are the device's
+!! tables of the last sample (udc_stats_xy / udc_stats_y).  The slice dumps (kslicedump / islicedump / jslicedump, :418-502, 1352-1389:
+!! um, vm, wm, thlm, qtm on one plane every tsample) download that plane alone.
 !!
 !! Not taken over (stop 1, the reference's error convention; link the reference's own modstatsdump instead -- the drop-in
 !! modboundary then refreshes the host arrays on exactly the steps on which it samples, u-dales_amd/fortran/Makefile):
-!! the instantaneous dumps ydump / xydump, the TKE budget, the tree dump, and tdump's PSS defect with lchem.
+!! the TKE budget (whose sampling call the reference has commented out), the tree dump, and tdump's PSS defect with lchem.
 module modstatsdump
   use iso_c_binding, only: c_int, c_double, c_ptr
   implicit none
@@ -18,9 +19,10 @@ module modstatsdump
   public :: initstatsdump, statsdump, exitstatsdump
   save
 
-  integer, parameter :: nstatt = 32, nstatmint = 6, nstatxyt = 23, nstatyt = 34
-  integer :: ncidt = -1, ncidmint = -1, ncidxyt = -1, ncidyt = -1, ncidsl(3) = -1
-  integer :: nrect = 0, nrecmint = 0, nrecxyt = 0, nrecyt = 0, nrecsl(3) = 0
+  integer, parameter :: nstatt = 32, nstatmint = 6, nstatxyt = 23, nstatyt = 34, nstatxy = 15, nstaty = 14
+  integer :: ncidt = -1, ncidmint = -1, ncidxyt = -1, ncidyt = -1, ncidsl(3) = -1, ncidxy = -1, ncidy = -1
+  integer :: nrect = 0, nrecmint = 0, nrecxyt = 0, nrecyt = 0, nrecsl(3) = 0, nrecxy = 0, nrecy = 0
+  character(80) :: ncstatxy(nstatxy, 4), ncstaty(nstaty, 4)
   character(80) :: ncstatsl(5, 4, 3)
   logical :: slice_on(3) = .false., slices = .false.
   character(80) :: tvar(1, 4)
@@ -61,6 +63,17 @@ module modstatsdump
     'sca3tpsca3pyt|scalar. variance|M^2|t0tt', 'usgsyt|SGS mom. flux|m^2/s^2|m0mt', 'wsgsyt|SGS mom. flux|m^2/s^2|t0mt', &
     'thlsgsyt|SGS heat flux|K m/s|t0mt', 'qtsgsyt|SGS moisture flux|kg/kg m/s|t0mt', 'sca1sgsyt|SGS scalar flux|M m/s|t0mt', &
     'sca2sgsyt|SGS scalar flux|M m/s|t0mt', 'sca3sgsyt|SGS scalar flux|M m/s|t0mt']
+
+  character(*), parameter :: meta_xy(nstatxy) = [character(64) :: &
+    'uxy|Streamwise velocity|m/s|tt', 'vxy|Spanwise velocity|m/s|tt', 'wxy|Vertical velocity|m/s|mt', 'thlxy|Temperature|K|tt', &
+    'qtxy|Moisture|kg/kg|tt', 'pxy|Pressure|m^2/s^2|tt', 'upwpxy|Mom. flux|m^2/s^2|mt', 'wpthlpxy|Heat flux|Km/s|mt', 'vpwpxy|Mom. flux|Km/s|mt', &
+    'usgsxy|SGS mom. flux|m^2/s^2|mt', 'thlsgsxy|SGS heat flux|Km/s|mt', 'vsgsxy|SGS mom. flux|m^2/s^2|mt', &
+    'uwxyik|Advective mom. flux|m^2/s^2|mt', 'wthlxy|Advective heat flux|K m/s|mt', 'vwxy|Advective mom. flux|m^2/s^2|mt']
+  character(*), parameter :: meta_y(nstaty) = [character(64) :: &
+    'uy|Streamwise velocity|m/s|m0tt', 'vy|Spanwise velocity|m/s|t0tt', 'wy|Vertical velocity|m/s|t0mt', 'thly|Temperature|K|t0tt', &
+    'qty|Moisture|kg/kg|t0tt', 'sca1y|Scalar field 1|kg/m^3|t0tt', 'sca2y|Scalar field 2|kg/m^3|t0tt', 'sca3y|Scalar field 3|kg/m^3|t0tt', &
+    'upwpy|Turbulent mom. flux|m^2/s^2|m0mt', 'wpthlpy|Turbulent heat flux|K m/s|t0mt', 'usgsy|SGS mom. flux|m^2/s^2|m0mt', &
+    'thlsgsy|SGS heat flux|K m/s|t0mt', 'uwyik|Advective mom. flux|m^2/s^2|m0mt', 'wthlyk|Advective heat flux|K m/s|t0mt']
 
   ! slices: plane k = kslice (1), i = islice (2), j = jslice (3); the dimension string has a 0 where the plane cuts
   character(*), parameter :: slice_tag(3) = ['k', 'i', 'j']
@@ -115,6 +128,16 @@ module modstatsdump
       type(c_ptr), value :: h
       real(c_double), intent(out) :: table(*)
     end function udc_stats_yt
+    integer(c_int) function udc_stats_xy(h, table) bind(C, name='udc_stats_xy')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(out) :: table(*)
+    end function udc_stats_xy
+    integer(c_int) function udc_stats_y(h, table) bind(C, name='udc_stats_y')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(out) :: table(*)
+    end function udc_stats_y
   end interface
 
 contains
@@ -148,8 +171,8 @@ contains
     use udc_iface, only: udc_stats_on_device
     character(80) :: fname
     integer :: nk, q, n
-    if (lydump .or. lxydump .or. ltkedump .or. ltreedump) then
-      write (0, *) 'ERROR: libudcore statsdump: ydump, xydump, tkedump and treedump are not taken over by the device ', &
+    if (ltkedump .or. ltreedump) then
+      write (0, *) 'ERROR: libudcore statsdump: tkedump and treedump are not taken over by the device ', &
         'statistics; link the reference''s modstatsdump instead (u-dales_amd/fortran/Makefile)'
       stop 1
     end if
@@ -157,13 +180,27 @@ contains
       write (0, *) 'ERROR: libudcore statsdump: tdump''s PSS defect (lchem) is not accumulated on the device'
       stop 1
     end if
-    active = ltdump .or. lmintdump .or. lxytdump .or. lytdump
+    active = ltdump .or. lmintdump .or. lxytdump .or. lytdump .or. lxydump .or. lydump
     slices = lkslicedump .or. lislicedump .or. ljslicedump
     udc_stats_on_device = active .or. slices
     tsamplep = 0.; tstatsdumpp = 0.
     if (.not. (active .or. slices)) return
     nk = ke - kb + 1
     tvar(1, :) = [character(80) :: 'time', 'Time', 's', 'time']
+    if (lydump) then
+      call unpack_meta(meta_y, ncstaty)
+      if (myid == 0) then
+        fname = 'ydump.'//cexpnr//'.nc'
+        call start_file(fname, ncidy, nrecy, nstaty, ncstaty, n1=imax, n3=nk)
+      end if
+    end if
+    if (lxydump) then
+      call unpack_meta(meta_xy, ncstatxy)
+      if (myid == 0) then
+        fname = 'xydump.'//cexpnr//'.nc'
+        call start_file(fname, ncidxy, nrecxy, nstatxy, ncstatxy, n3=nk)
+      end if
+    end if
     if (lytdump) then
       call unpack_meta(meta_yt, ncstatyt)
       if (myid == 0) then
@@ -226,16 +263,17 @@ contains
 
   !> first call inside the loop (the handle exists by then): switch the device accumulators on and hand over createmasks' masks
   subroutine device_setup
-    use modglobal, only: ib, ie, jb, je, kb, ke, imax, jmax, lxytdump, lytdump, libm
+    use modglobal, only: ib, ie, jb, je, kb, ke, imax, jmax, lxytdump, lytdump, lxydump, lydump, libm
     use modfields, only: IIu, IIv, IIw, IIc, IIuw, IIvw, IIuv, IIus, IIvs, IIws, IIcs, IIuws, IIvws, IIuvs
     use udc_iface, only: udc_h, udc_check
     integer(1), allocatable :: bits(:, :, :)
     integer(c_int), allocatable :: counts(:, :)
     integer(c_int) :: forced(7)
     integer :: nk, q
-    call udc_check(udc_stats_enable(udc_h, int(1 + merge(2, 0, lxytdump) + merge(4, 0, lytdump), c_int)), 'udc_stats_enable')
+    call udc_check(udc_stats_enable(udc_h, int(1 + merge(2, 0, lxytdump) + merge(4, 0, lytdump) + merge(8, 0, lxydump) + merge(16, 0, lydump), &
+                                               c_int)), 'udc_stats_enable')
     device_ready = .true.
-    if (.not. (libm .and. (lxytdump .or. lytdump))) return
+    if (.not. (libm .and. (lxytdump .or. lytdump .or. lxydump .or. lydump))) return
     ! one byte per cell, bit order IIu, IIv, IIw, IIc, IIuw, IIvw, IIuv, levels kb..ke; the global fluid counts per level.
     ! avexy_ibm's rule for a first level without fluid points (src/modmpi.f90:646-649: the unmasked sum over the count of level
     ! ke) is applied here, as udc_stats_set_masks asks: that level gets its bit set everywhere and the count of the last level
@@ -269,7 +307,7 @@ contains
   !> the reference's two clocks (src/modstatsdump.f90:738-741, 797-811, 1393-1399, 1400, 1723-1729); a sample is one sweep on the
   !! device, a record is what crosses the bus
   subroutine statsdump
-    use modglobal, only: rk3step, timee, dt, tsample, tstatsdump, tstatstart, lxytdump, lytdump, ltdump, lmintdump
+    use modglobal, only: rk3step, timee, dt, tsample, tstatsdump, tstatstart, lxytdump, lytdump, ltdump, lmintdump, lxydump, lydump
     use udc_iface, only: udc_h, udc_check, udc_begin
     if (.not. (active .or. slices)) return
     if (timee < tstatstart) return
@@ -281,6 +319,8 @@ contains
       if (active) then
         if (.not. device_ready) call device_setup
         call udc_check(udc_stats_sample(udc_h, real(tsamplep, c_double), real(tstatsdumpp, c_double)), 'udc_stats_sample')
+        if (lydump) call write_y
+        if (lxydump) call write_xy
       end if
       if (slices) call write_slices
       tsamplep = dt
@@ -361,6 +401,33 @@ contains
       deallocate (v, a)
     end if
   end subroutine write_slices
+
+  !> the last sample's own profiles / x-z fields (every tsample, :1294-1349)
+  subroutine write_xy
+    use modglobal, only: kb, ke, timee
+    use modmpi, only: myid
+    use modstat_nc, only: writestat_nc, writestat_1D_nc
+    use udc_iface, only: udc_h, udc_check
+    real, allocatable :: tab(:, :)
+    allocate (tab(ke - kb + 1, nstatxy))
+    call udc_check(udc_stats_xy(udc_h, tab), 'udc_stats_xy')
+    if (myid /= 0) return
+    call writestat_nc(ncidxy, 1, tvar, (/timee/), nrecxy, .true.)
+    call writestat_1D_nc(ncidxy, nstatxy, ncstatxy, tab, nrecxy, ke - kb + 1)
+  end subroutine write_xy
+
+  subroutine write_y
+    use modglobal, only: kb, ke, imax, timee
+    use modmpi, only: myid
+    use modstat_nc, only: writestat_nc
+    use udc_iface, only: udc_h, udc_check
+    real, allocatable :: tab(:, :, :)
+    allocate (tab(imax, ke - kb + 1, nstaty))
+    call udc_check(udc_stats_y(udc_h, tab), 'udc_stats_y')
+    if (myid /= 0) return
+    call writestat_nc(ncidy, 1, tvar, (/timee/), nrecy, .true.)
+    call writestat_nc(ncidy, nstaty, ncstaty, tab, nrecy, imax, ke - kb + 1)
+  end subroutine write_y
 
   subroutine write_xyt
     use modglobal, only: kb, ke, timee
