@@ -202,7 +202,7 @@ def _run_virtual(P, g, deck_like, st_global, nsub, dt, sgs, nsv=0, extras=False)
             if extras == 3:      # xytdump over the slabs: per-slab mask bits, level sums all-reduced, one sample per step
                 from udcore.stats import TDump
                 core.ltempeq = True
-                td = TDump(core, tsample=dt, tstatsdump=1e9, xyt=True, yt=True, ibm_lists=dict(zip("uvwc", ibm_block_lists(g.nx, g.ny, g.nz))),
+                td = TDump(core, tsample=dt, tstatsdump=1e9, xyt=True, yt=True, xy=True, y=True, ibm_lists=dict(zip("uvwc", ibm_block_lists(g.nx, g.ny, g.nz))),
                            jtot=g.ny, j0=r * nyl, nyl=nyl)
             for isub in range(nsub):
                 core.substep(isub % 3 + 1, dt, bool(extras))
@@ -211,6 +211,8 @@ def _run_virtual(P, g, deck_like, st_global, nsub, dt, sgs, nsv=0, extras=False)
             if td is not None:
                 out.setdefault(r, {})["xyt"] = td.xyt()
                 out[r]["xyt"].update({"yt." + k: v for k, v in td.yt().items()})     # ytdump's y-averages: same table on every rank
+                out[r]["xyt"].update({"xy." + k: v for k, v in td.xy().items()})     # xydump / ydump: the last sample's own tables
+                out[r]["xyt"].update({"y." + k: v for k, v in td.y().items()})
             out.setdefault(r, {}).update({k: core.download(k) for k in ("u0", "v0", "w0", "pres0") + (("thl0",) if extras else ()) + (("qt0",) if extras == 2 else ())})
             out[r]["div"] = core.divergence()
         except Exception as e:   # noqa: BLE001
@@ -282,7 +284,7 @@ def test_decomposition_invariance(shape, sgs, chunks, extras, monkeypatch):
             for k, v in ref["xyt"].items():
                 fl = v != -999.                 # ytdump's marker of columns without fluid points: same places, exactly
                 assert np.array_equal(fl, got["xyt"][k] != -999.), (P, k)
-                sc = max(np.abs(v[fl]).max(), 1e-1 if "thlpthlp" in k or k in ("wpthlpyt", "yt.wpthlpyt") else 1e-3)
+                sc = max(np.abs(v[fl]).max(), 1e-1 if "thlpthlp" in k or "wpthlp" in k else 1e-3)
                 assert np.abs(got["xyt"][k] - v)[fl].max() <= 1e-10 * sc, (P, k)
             assert np.abs(ref["xyt"]["yt.upupyt"]).max() > 1e-4
             assert np.abs(ref["xyt"]["uxyt"]).max() > 0.1 and ref["xyt"]["tketxyc"].min() > 0.

@@ -34,6 +34,11 @@ YT = ["uyt", "vyt", "wyt", "thlyt", "qtyt", "sca1yt", "sca2yt", "sca3yt", "upwpy
       "sca1tpsca1pyt", "sca2tpsca2pyt", "sca3tpsca3pyt", "usgsyt", "wsgsyt", "thlsgsyt", "qtsgsyt", "sca1sgsyt", "sca2sgsyt", "sca3sgsyt"]
 
 
+# rows of udc_stats_xy / udc_stats_y: the instantaneous tables of xydump / ydump (initstatsdump, src/modstatsdump.f90:215-231, 131-148)
+XY = ["uxy", "vxy", "wxy", "thlxy", "qtxy", "pxy", "upwpxy", "wpthlpxy", "vpwpxy", "usgsxy", "thlsgsxy", "vsgsxy", "uwxyik", "wthlxy", "vwxy"]
+Y = ["uy", "vy", "wy", "thly", "qty", "sca1y", "sca2y", "sca3y", "upwpy", "wpthlpy", "usgsy", "thlsgsy", "uwyik", "wthlyk"]
+
+
 def xyt_masks(nx, ny, nz, lists, wrapx=False, wrapy=False, j0=0, nyl=None):
     """createmasks' fluid masks (src/modibm.f90:2141-2190) for udc_stats_set_masks: (bits[nz, nyl, nx] uint8, counts[7, nz], forced[7])
     from the solid point lists {grid: (solid[n, 3], ...)} (global 1-based i, j, k).  Bit order IIu, IIv, IIw, IIc, IIuw,
@@ -77,7 +82,7 @@ def xyt_masks(nx, ny, nz, lists, wrapx=False, wrapy=False, j0=0, nyl=None):
 
 class TDump:
     def __init__(self, core, tsample, tstatsdump, tstatstart=0., wdir=None, expnr=0, xyt=False, ibm_lists=None, wrap=(False, False),
-                 jtot=None, j0=0, nyl=None, yt=False):
+                 jtot=None, j0=0, nyl=None, yt=False, xy=False, y=False):
         """xyt: also xytdump's profiles; ibm_lists (udcore.ibm.read_ibm) when the deck has obstacles, wrap = the directions
         the reference run of the deck splits over ranks, jtot / j0 / nyl = global rows / this rank's first row / its row count for y-slab runs."""
         self.core, self.tsample, self.tstatsdump, self.tstatstart = core, float(tsample), float(tstatsdump), float(tstatstart)
@@ -86,8 +91,8 @@ class TDump:
         self.nsamples, self.dumps, self.xyt_on, self.xyt_dumps = 0, [], bool(xyt), []
         self.yt_on, self.yt_dumps = bool(yt), []
         self.mint = False             # mintdump (src/modstatsdump.f90:1670-1684): ut, vt, wt, thlt, qtt, pt of the same accumulators
-        L._check(core.lib.udc_stats_enable(core.h, 1 + (2 if xyt else 0) + (4 if yt else 0)), "udc_stats_enable")
-        if (xyt or yt) and ibm_lists is not None:
+        L._check(core.lib.udc_stats_enable(core.h, 1 + (2 if xyt else 0) + (4 if yt else 0) + (8 if xy else 0) + (16 if y else 0)), "udc_stats_enable")
+        if (xyt or yt or xy or y) and ibm_lists is not None:
             g = core.g
             bits, counts, forced = xyt_masks(g.nx, jtot or g.ny, g.nz, ibm_lists, wrap[0], wrap[1], j0=j0, nyl=nyl or g.ny)
             L._check(core.lib.udc_stats_set_masks(core.h, bits.ctypes.data_as(C.POINTER(C.c_ubyte)), counts.ctypes.data_as(C.POINTER(C.c_int))),
@@ -103,6 +108,19 @@ class TDump:
         have = lambda n: (("thl" not in n) or getattr(c, "ltempeq", False)) and (("qt" not in n) or getattr(c, "lmoist", False)) and \
             not any(f"sca{q}" in n and c.nsv < q for q in (1, 2, 3))      # noqa: E731
         return {n: t[q] for q, n in enumerate(YT) if have(n)}
+
+    def xy(self):
+        """xydump's table of the LAST sample {name: profile[ktot]} (src/modstatsdump.f90:1330-1344)."""
+        t = np.zeros((len(XY), self.core.g.nz))
+        L._check(self.core.lib.udc_stats_xy(self.core.h, t.ctypes.data_as(L.DP)), "udc_stats_xy")
+        return {n: t[q] for q, n in enumerate(XY)}
+
+    def y(self):
+        """ydump's table of the LAST sample {name: field[ktot, itot]} (src/modstatsdump.f90:1303-1316)."""
+        g = self.core.g
+        t = np.zeros((len(Y), g.nz, g.nx))
+        L._check(self.core.lib.udc_stats_y(self.core.h, t.ctypes.data_as(L.DP)), "udc_stats_y")
+        return {n: t[q] for q, n in enumerate(Y)}
 
     def xyt(self):
         """xytdump's table {name: profile[ktot]} (src/modstatsdump.f90:1437-1460); rows the deck does not have (thl, qt) left out."""
