@@ -73,6 +73,15 @@ def test_restart_set_of_any_pencil_layout_is_assembled(px, py, tmp_path):
         np.testing.assert_array_equal(f[k][1:], d[k][1:], err_msg=k)
     for n in range(2):
         np.testing.assert_array_equal(sv[n][1:], s["sv0"][n][1:])
+    # a y-slab of it (what one rank of a multi-GPU run reads: its rows + two ghost rows, only the files that hold them, only the
+    # fields it uploads)
+    for j0, nyl in ((0, N // 2), (N // 2, N // 2), (2, 3)):
+        fs, svs, t3, dt3 = R.read_global(str(out), IEXP, ntrun, N, N, N, nsv=2, rows=(j0, j0 + nyl + 2), fields={"u0", "pres0"})
+        assert (t3, dt3) == (timee, dt) and set(fs) == {"u0", "pres0"}
+        for k in fs:
+            np.testing.assert_array_equal(fs[k], f[k][:, j0:j0 + nyl + 2, :], err_msg=k)
+        for n in range(2):
+            np.testing.assert_array_equal(svs[n], sv[n][:, j0:j0 + nyl + 2, :])
 
 
 def test_write_is_byte_identical(tmp_path):

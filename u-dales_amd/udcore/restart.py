@@ -156,31 +156,43 @@ def find_layout(directory, expnr, ntrun, kind="d"):
     return px, py
 
 
-def read_global(directory, expnr, ntrun, nx, ny, nz, nsv=0):
+def read_global(directory, expnr, ntrun, nx, ny, nz, nsv=0, rows=None, fields=None):
     """The whole domain from a restart set written on any pencil layout of the reference (nprocx x nprocy files, each holding
     its block with one ghost cell around it): -> (fields {name: m-array [nz+2, ny+2, nx+2]}, sv0 list of such arrays, timee, dt).
-    Interior cells come from the rank that owns them; the outer ghost ring from the blocks on the domain's edge."""
+    Interior cells come from the rank that owns them; the outer ghost ring from the blocks on the domain's edge.
+    rows = (r0, r1): only rows r0 <= j < r1 of the ghosted global array (a y-slab with its ghost rows) -- the arrays come back
+    [nz+2, r1-r0, nx+2] and only the files whose rows overlap are opened; fields: only these names."""
     px, py = find_layout(directory, expnr, ntrun)
     if nx % px or ny % py:
         raise ValueError(f"restart set on {px} x {py} ranks does not divide a {nx} x {ny} domain")
     lx, ly = nx // px, ny // py
-    out, sv, timee, dt = {}, [np.zeros((nz + 2, ny + 2, nx + 2)) for _ in range(nsv)], 0., 0.
+    r0, r1 = rows if rows is not None else (0, ny + 2)
+    shape = (nz + 2, r1 - r0, nx + 2)
+    out, sv, timee, dt = {}, [np.zeros(shape) for _ in range(nsv)], 0., 0.
     have_s = nsv > 0 and os.path.exists(os.path.join(directory, restart_name(ntrun, 0, expnr, "s")))
-    for ix in range(px):
-        for iy in range(py):
+    for iy in range(py):
+        # destination rows in the global array (with its ghost ring) and the matching rows of the block
+        gj0, gj1 = iy * ly + (0 if iy == 0 else 1), (iy + 1) * ly + (2 if iy == py - 1 else 1)
+        lo, hi = max(gj0, r0), min(gj1, r1)
+        if lo >= hi:
+            if rows is None or (timee or dt):
+                continue
+        for ix in range(px):
             d = read_initd(os.path.join(directory, restart_name(ntrun, iy, expnr, "d", myidx=ix)), lx, ly, nz)
             timee, dt = d["timee"], d["dt"]
-            # destination ranges in the global array (with its ghost ring) and the matching ranges of the block
+            if lo >= hi:      # (only the clock was wanted from this file)
+                break
             gi0, gi1 = ix * lx + (0 if ix == 0 else 1), (ix + 1) * lx + (2 if ix == px - 1 else 1)
-            gj0, gj1 = iy * ly + (0 if iy == 0 else 1), (iy + 1) * ly + (2 if iy == py - 1 else 1)
-            bi0, bj0 = gi0 - ix * lx, gj0 - iy * ly
-            blocks = [(k, v) for k, v in d.items() if isinstance(v, np.ndarray) and v.ndim == 3 and v.shape == (nz + 2, ly + 2, lx + 2)]
+            bi0, bj0 = gi0 - ix * lx, lo - iy * ly
+            blocks = [(k, v) for k, v in d.items() if isinstance(v, np.ndarray) and v.ndim == 3 and v.shape == (nz + 2, ly + 2, lx + 2)
+                      and (fields is None or k in fields)]
             for k, v in blocks:
-                out.setdefault(k, np.zeros((nz + 2, ny + 2, nx + 2)))[:, gj0:gj1, gi0:gi1] = v[:, bj0:bj0 + gj1 - gj0, bi0:bi0 + gi1 - gi0]
+                out.setdefault(k, np.zeros(shape))[:, lo - r0:hi - r0, gi0:gi1] = v[:, bj0:bj0 + hi - lo, bi0:bi0 + gi1 - gi0]
+            del d
             if have_s:
                 s = read_inits(os.path.join(directory, restart_name(ntrun, iy, expnr, "s", myidx=ix)), lx, ly, nz, nsv)
                 for n, a in enumerate(s["sv0"]):
-                    sv[n][:, gj0:gj1, gi0:gi1] = a[:, bj0:bj0 + gj1 - gj0, bi0:bi0 + gi1 - gi0]
+                    sv[n][:, lo - r0:hi - r0, gi0:gi1] = a[:, bj0:bj0 + hi - lo, bi0:bi0 + gi1 - gi0]
     return out, (sv if have_s else None), timee, dt
 
 
@@ -190,10 +202,11 @@ def load_restart_global(core, directory, expnr, ntrun, rank=0, nranks=1, read_sc
     g = core.g
     nyl = core.nyl
     ny = nyl * nranks
-    d, sv, timee, dt = read_global(directory, expnr, ntrun, g.nx, ny, g.nz, core.nsv)
     j0 = rank * nyl
-    cut = lambda a: np.ascontiguousarray(a[:, j0:j0 + nyl + 2, :])      # noqa: E731
     names = _restart_fields(core)
+    # (only the files whose rows overlap this slab and its two ghost rows are read, and of those only the fields that are uploaded)
+    d, sv, timee, dt = read_global(directory, expnr, ntrun, g.nx, ny, g.nz, core.nsv if read_scalars else 0, rows=(j0, j0 + nyl + 2), fields=set(names))
+    cut = np.ascontiguousarray
     for k in names:
         core.upload(k, cut(d[k]))
     for k0 in names:

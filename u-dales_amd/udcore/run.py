@@ -3,7 +3,7 @@
     python -m udcore.run namoptions.NNN [--steps N] [--restart-from NTRUN] [--device D] [--quiet]
 
 reads the deck (namoptions, prof.inp, lscale.inp) from the file's directory, cold-starts (or warm-starts from the
-reference's initd/inits restart files with --restart-from NTRUN; a deck with &RUN lwarmstart is refused), advances until `runtime` (or N full steps)
+reference's initd/inits restart files with --restart-from NTRUN; or the deck's own &RUN lwarmstart / startfile), advances until `runtime` (or N full steps)
 with the reference's own time-step control (tstep_update, src/modtstep.f90:113-150: fixed dtmax, or adaptive with the
 Courant / diffusion numbers), and writes restart files in the reference's layout every `trestart` seconds of model
 time and at the end (src/modsave.f90:77-121).  Immersed boundaries (libm) and non-periodic lateral
