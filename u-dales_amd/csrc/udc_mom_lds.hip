@@ -24,7 +24,7 @@ namespace {
 constexpr int MX = MOM_TX, MY = MOM_TY;
 constexpr int LX = MX + 2, LY = MY + 2, LN = LX * LY;   // 34 x 10 = 340 doubles per field-plane
 constexpr int NT = MX * MY;                               // 256 threads
-static_assert(NT == 256 && LN - NT <= NT, "one own cell and at most one halo cell per thread");
+static_assert((NT == 256 || NT == 512) && LN - NT <= NT, "one own cell and at most one halo cell per thread");
 #ifndef MOM_WAVES
 #define MOM_WAVES 3
 #endif
