@@ -99,6 +99,10 @@ int udc_comm_init(udc_handle *h, const unsigned char id[128]);
  * on a single-GPU box.  udc_local_group_create returns a group id > 0 (or -1). */
 int udc_local_group_create(int nranks);
 int udc_comm_init_local(udc_handle *h, int group);
+/* ... and between P PROCESSES sharing one device (mpiexec -n P of the Fortran drop-in build on a one-GPU box, where RCCL refuses
+ * two ranks per device): outboxes in the POSIX shared-memory segment `name` ("/something", the same on every rank; rank 0 creates
+ * it), device <-> host copies around process-shared barriers.  For small grids only. */
+int udc_comm_init_shm(udc_handle *h, const char *name);
 #endif
 
 /* ---- host <-> device residency --------------------------------------------------- */

@@ -66,3 +66,122 @@ def test_two_mpi_ranks_on_one_gpu_reach_udc_comm_init(tmp_path):
     # both ranks got their handle and the id; RCCL itself refuses the second rank on the same device
     assert "ERROR: libudcore udc_comm_init" in out, out[-3000:]
     assert "udc_create" not in out, out[-3000:]
+
+
+# ---- two MPI ranks to the end, on one GPU: the test build of the same program (udales_full_dropin_mpi_test: udc_iface.f90 compiled
+# with -DUDC_TEST_TRANSPORT, linked against libudcore_test.so) exchanges through shared memory instead of RCCL (UDC_TEST_SHM)
+EXE_TEST = os.path.join(ROOT, "oracle", "_ref", "udales_full_dropin_mpi_test")
+
+
+def run_ranks(name, iexp, tmp_path, nranks, deck_edit=None):
+    """The deck through the test build on `nranks` MPI ranks sharing device 0, stopped at the fixture's last dump -> working directory"""
+    import numpy as np      # noqa: F401
+    from common import load_fixture
+    fix = load_fixture(name)
+    tags = sorted(set(k.split(".")[0] for k in fix if re.match(r"s\d\d\d\.", k)))
+    last = tags[-1]
+    nsub = int(last[1:])
+    for fn in os.listdir(os.path.join(GOLDEN, "cases", name)):
+        shutil.copy(os.path.join(GOLDEN, "cases", name, fn), tmp_path)
+    deck = os.path.join(tmp_path, f"namoptions.{iexp:03d}")
+    with open(deck) as f:
+        txt = f.read()
+    dtmax = float(re.search(r"dtmax\s*=\s*([0-9.eE+-]+)", txt).group(1))
+    tend = fix[last + ".time"].data[0] if last + ".time" in fix else dtmax * nsub / 3
+    runtime = tend * (1. - 1e-9)
+    txt = re.sub(r"runtime\s*=\s*[0-9.eE+-]+", f"runtime = {runtime!r}\ntrestart = {0.999 * runtime!r}", txt)
+    txt = re.sub(r"nprocy\s*=\s*\d+", f"nprocy = {nranks}", txt)
+    if deck_edit:
+        txt = deck_edit(txt)
+    with open(deck, "w") as f:
+        f.write(txt)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", UDC_RESIDENCY="2", UDC_GPUS_PER_NODE="1", UDC_TEST_SHM=f"/udc_test_{os.getpid()}_{nranks}")
+    r = subprocess.run(f"ulimit -s unlimited; exec {MPIEXEC} -n {nranks} {EXE_TEST} namoptions.{iexp:03d}", shell=True, cwd=tmp_path, env=env,
+                       capture_output=True, text=True, timeout=900, executable="/bin/bash")
+    assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-2500:]
+    return fix, last
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["run_16x16x8", "run_smag_scalar_16x8x12s", "run_moist_16x8x12s", "run_ibm_wf2_16x12x10", "run_ibm_moistwq_16x12x10"])
+def test_two_mpi_ranks_run_the_deck_to_the_end(name, tmp_path):
+    """mpiexec -n 2 of the reference's real program with the drop-in modules, nprocy = 2: MPI start-up and broadcasts, two library
+    handles with two slabs, the Fortran modules' slab logic (rows of the point lists and facet sections, masks, per-rank restart
+    files), ghost rows and the Poisson transposes through the library's multi-rank path -- against the one-rank fixture of the
+    all-reference executable, through the restart files both ranks write."""
+    import numpy as np
+    from common import nocorner, relerr
+    from udcore import restart
+    if not (os.path.exists(EXE_TEST) and os.path.exists(MPIEXEC)):
+        pytest.skip("oracle/_ref/udales_full_dropin_mpi_test or MPICH not available")
+    iexp = RUN_CASES[name]
+    fix, last = run_ranks(name, iexp, tmp_path, 2)
+    nx, ny, nz = (int(v) for v in fix["meta"].data[:3])
+    nyl = ny // 2
+    files = sorted(f for f in os.listdir(tmp_path) if f.startswith("initd"))
+    assert len(files) == 2 and files[0][14:21] == "000_000" and files[1][14:21] == "000_001", files
+    parts = [restart.read_initd(str(tmp_path / f), nx, nyl, nz) for f in files]
+    checked = 0
+    for k in ("u0", "v0", "w0", "pres0", "thl0", "qt0"):
+        key = f"{last}.{k}"
+        if key not in fix:
+            continue
+        ref = fix[key].data
+        got = np.concatenate([p[k][1:nz + 1, 1:nyl + 1, 1:nx + 1] for p in parts], axis=1)
+        assert relerr(got, ref[1:nz + 1, 1:ny + 1, 1:nx + 1], 1.0 if k == "thl0" else None) <= 1e-9, k
+        checked += 1
+    nsv = int(fix["meta"].data[12])
+    if nsv:
+        sv = [restart.read_inits(str(tmp_path / f.replace("initd", "inits")), nx, nyl, nz, nsv) for f in files]
+        for n in range(nsv):
+            got = np.concatenate([s["sv0"][n][1:nz + 1, 1:nyl + 1, 1:nx + 1] for s in sv], axis=1)
+            ref = fix[f"{last}.sv0_{n + 1:02d}"].data[2:nz + 2, 2:-2, 2:-2]
+            assert relerr(got, ref) <= 1e-9, n
+            checked += 1
+    assert checked >= 4
+    del nocorner
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["run_stats_ibm_16x12x10", "run_ytstats_ibm_16x12x10"])
+def test_statistics_tables_on_two_mpi_ranks(name, tmp_path):
+    """The drop-in statsdump on two ranks: xytdump / ytdump (rank 0 writes the all-reduced tables), xydump / ydump, and tdump (one
+    file per rank, its own rows) equal the one-rank run's."""
+    import numpy as np
+    from refdump import read_ncrec
+    if not (os.path.exists(EXE_TEST) and os.path.exists(MPIEXEC)):
+        pytest.skip("oracle/_ref/udales_full_dropin_mpi_test or MPICH not available")
+    iexp = RUN_CASES[name]
+    edit = lambda t: re.sub(r"tstatsdump\s*=\s*1000\.", "tstatsdump = 1.0", t.replace("&OUTPUT", "&OUTPUT\nlxydump = .true.\nlydump = .true."))      # noqa: E731
+    out = {}
+    for P in (1, 2):
+        d = tmp_path / f"p{P}"
+        d.mkdir()
+        run_ranks(name, iexp, d, P, edit)
+        out[P] = {fn: read_ncrec(str(d / fn)) for fn in sorted(os.listdir(d)) if fn.endswith(".nc") and "dump" in fn and "field" not in fn}
+    checked = 0
+    for fn, ref in out[1].items():
+        if fn.startswith("tdump"):      # per-rank files: stitch the rows
+            parts = [out[2][fn.replace("000.000", f"000.{r:03d}")] for r in range(2)]
+            for var, recs in ref.items():
+                if var == "time" or np.squeeze(recs[0][1]).ndim != 3:
+                    continue
+                for q, (_, a) in enumerate(recs):
+                    a = np.squeeze(a)
+                    b = np.concatenate([np.squeeze(p[var][q][1]) for p in parts], axis=1)
+                    sc = max(np.abs(a).max(), 1e-6)
+                    assert np.abs(a - b).max() <= 1e-8 * sc, (fn, var)
+                    checked += 1
+            continue
+        dev = out[2][fn]
+        assert list(ref) == list(dev), fn
+        for var, recs in ref.items():
+            if fn.startswith("ytdump") and ("qt" in var or "sca2" in var or "sca3" in var):
+                continue
+            for (_, a), (_, b) in zip(recs, dev[var]):
+                hole = a < -900.
+                assert np.array_equal(hole, b < -900.), (fn, var)
+                sc = max(np.abs(a[~hole]).max() if (~hole).any() else 0., 1e-3 if var.startswith("p") else 1e-6)
+                assert np.abs(a - b)[~hole].max(initial=0.) <= 1e-8 * sc, (fn, var)
+                checked += 1
+    assert checked >= 40

@@ -18,6 +18,23 @@
 #include <cstdlib>
 
 #ifdef UDC_TEST_TRANSPORT
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+// Second test transport, between PROCESSES on one device (mpiexec -n P of the Fortran drop-in build on a one-GPU box, where RCCL
+// refuses two ranks per device): every rank owns an outbox in a POSIX shared-memory segment; an exchange is "copy what I send into
+// my outbox, barrier, copy what is meant for me out of the others', barrier".  Slow and only for small grids -- the point is that
+// the multi-rank route through MPI start-up, the Fortran modules' slab logic, per-rank files and the library's packing runs at all.
+struct ShmGroup {
+  pthread_barrier_t bar;
+  int P, ready;
+  size_t cap;                 // bytes per outbox
+  // followed by P outboxes
+  unsigned char *box(int r) { return reinterpret_cast<unsigned char *>(this) + 4096 + (size_t)r * cap; }
+};
+constexpr size_t SHM_CAP = (size_t)48 << 20;
+
 struct LocalGroup {
   int P;
   pthread_barrier_t bar;
@@ -88,10 +105,63 @@ extern "C" int udc_comm_init_local(udc_handle *h, int group) {
 
 void comm_destroy(udc_handle *h) {
   if (h->nccl) { ncclCommDestroy((ncclComm_t)h->nccl); h->nccl = nullptr; }
+#ifdef UDC_TEST_TRANSPORT
+  if (h->shm_group) { munmap(h->shm_group, 4096 + (size_t)h->cfg.nranks * SHM_CAP); h->shm_group = nullptr; }
+#endif
 }
 
+#ifdef UDC_TEST_TRANSPORT
+extern "C" int udc_comm_init_shm(udc_handle *h, const char *name) {
+  if (!h || !name || name[0] != '/') { udc_set_error("udc_comm_init_shm: name must start with '/'"); return 1; }
+  const int P = h->cfg.nranks, r = h->cfg.rank;
+  const size_t bytes = 4096 + (size_t)P * SHM_CAP;
+  ShmGroup *g = nullptr;
+  if (r == 0) {
+    shm_unlink(name);
+    const int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) { udc_set_error("udc_comm_init_shm: cannot create %s", name); return 1; }
+    g = (ShmGroup *)mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (g == MAP_FAILED) { udc_set_error("udc_comm_init_shm: mmap failed"); return 1; }
+    pthread_barrierattr_t at;
+    pthread_barrierattr_init(&at);
+    pthread_barrierattr_setpshared(&at, PTHREAD_PROCESS_SHARED);
+    pthread_barrier_init(&g->bar, &at, (unsigned)P);
+    g->P = P; g->cap = SHM_CAP;
+    __atomic_store_n(&g->ready, 1, __ATOMIC_RELEASE);
+  } else {
+    int fd = -1;
+    for (int t = 0; t < 60000 && fd < 0; ++t) { fd = shm_open(name, O_RDWR, 0600); if (fd < 0) usleep(1000); }
+    struct stat sb;
+    for (int t = 0; t < 60000 && fd >= 0; ++t) { if (fstat(fd, &sb) == 0 && (size_t)sb.st_size >= bytes) break; usleep(1000); }
+    if (fd < 0) { udc_set_error("udc_comm_init_shm: %s never appeared", name); return 1; }
+    g = (ShmGroup *)mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (g == MAP_FAILED) { udc_set_error("udc_comm_init_shm: mmap failed"); return 1; }
+    for (int t = 0; t < 60000 && !__atomic_load_n(&g->ready, __ATOMIC_ACQUIRE); ++t) usleep(1000);
+    if (!g->ready || g->P != P) { udc_set_error("udc_comm_init_shm: segment of another run"); return 1; }
+  }
+  pthread_barrier_wait(&g->bar);
+  if (r == 0) shm_unlink(name);      // everyone is attached: the name can go
+  h->shm_group = g;
+  return 0;
+}
+// one exchange step: `put` bytes from device memory into this rank's outbox; after the barrier `get(g)` copies out of the others'
+template <class Get>
+static int shm_step(udc_handle *h, hipStream_t st, const void *src, size_t put, Get get) {
+  ShmGroup *g = (ShmGroup *)h->shm_group;
+  if (put > g->cap) { udc_set_error("test transport (shared memory): %zu bytes exceed the outbox", put); return 1; }
+  HIP_OK(hipStreamSynchronize(st));
+  if (put) HIP_OK(hipMemcpy(g->box(h->cfg.rank), src, put, hipMemcpyDeviceToHost));
+  pthread_barrier_wait(&g->bar);
+  if (get(g)) return 1;
+  pthread_barrier_wait(&g->bar);
+  return 0;
+}
+#endif
+
 static int need_comm(udc_handle *h) {
-  if (h->nccl || h->local_group) return 0;      // (local_group is only ever set by the test build)
+  if (h->nccl || h->local_group || h->shm_group) return 0;      // (the last two are only ever set by the test build)
   udc_set_error("multi-rank handle used before udc_comm_init");
   return 1;
 }
@@ -121,6 +191,19 @@ int comm_neighbours(udc_handle *h, const double *to_prev, const double *to_next,
     return 0;
   }
 #ifdef UDC_TEST_TRANSPORT
+  if (h->shm_group) {      // outbox = [to_prev | to_next]
+    const size_t nb = count * sizeof(double);
+    ShmGroup *sg = (ShmGroup *)h->shm_group;
+    if (2 * nb > sg->cap) { udc_set_error("test transport (shared memory): ghost rows exceed the outbox"); return 1; }
+    HIP_OK(hipStreamSynchronize(h->stream));
+    HIP_OK(hipMemcpy(sg->box(r), to_prev, nb, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(sg->box(r) + nb, to_next, nb, hipMemcpyDeviceToHost));
+    pthread_barrier_wait(&sg->bar);
+    HIP_OK(hipMemcpy(from_next, sg->box(next), nb, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(from_prev, sg->box(prev) + nb, nb, hipMemcpyHostToDevice));
+    pthread_barrier_wait(&sg->bar);
+    return 0;
+  }
   LocalGroup *g = (LocalGroup *)h->local_group;
   g->send[r][0] = to_prev; g->send[r][1] = to_next;
   HIP_OK(hipStreamSynchronize(h->stream));
@@ -160,6 +243,12 @@ int comm_alltoall(udc_handle *h, const double *send, double *recv, size_t block,
     return 0;
   }
 #ifdef UDC_TEST_TRANSPORT
+  if (h->shm_group)
+    return shm_step(h, st, send, (size_t)P * block * sizeof(double), [&](ShmGroup *sg) {
+      for (int s = 0; s < P; ++s)
+        HIP_OK(hipMemcpy(recv + (size_t)s * block, sg->box(s) + (size_t)r * block * sizeof(double), block * sizeof(double), hipMemcpyHostToDevice));
+      return 0;
+    });
   LocalGroup *g = (LocalGroup *)h->local_group;
   g->send[r][2] = send;
   HIP_OK(hipStreamSynchronize(st));
@@ -185,6 +274,20 @@ int comm_allreduce(udc_handle *h, double *buf, int n, int op) {
     return 0;
   }
 #ifdef UDC_TEST_TRANSPORT
+  if (h->shm_group)
+    return shm_step(h, h->stream, buf, (size_t)n * sizeof(double), [&](ShmGroup *sg) {
+      std::vector<double> acc(n);
+      for (int q = 0; q < n; ++q) {
+        double v = reinterpret_cast<const double *>(sg->box(0))[q];
+        for (int s = 1; s < sg->P; ++s) {
+          const double w = reinterpret_cast<const double *>(sg->box(s))[q];
+          v = op == 0 ? (w > v ? w : v) : v + w;
+        }
+        acc[q] = v;
+      }
+      HIP_OK(hipMemcpy(buf, acc.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+      return 0;
+    });
   LocalGroup *g = (LocalGroup *)h->local_group;
   const int P = h->cfg.nranks, r = h->cfg.rank;
   std::vector<double> out(4096);

@@ -293,6 +293,7 @@ struct udc_handle {
   // multi-GPU (y-slabs): RCCL communicator or in-process local group (udc_comm.hip)
   void *nccl = nullptr;
   void *local_group = nullptr;
+  void *shm_group = nullptr;            // test build only: the inter-process test transport (udc_comm_init_shm)
   bool slab = false;                    // distributed Poisson layout in use (nranks > 1 or UDC_FORCE_SLAB)
   int jtot = 0;                         // global number of rows
   double *halo_buf[4] = {nullptr, nullptr, nullptr, nullptr};   // to_prev, to_next, from_prev, from_next

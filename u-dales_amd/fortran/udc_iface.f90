@@ -336,6 +336,13 @@ module udc_iface
       import :: c_int, c_ptr
       type(c_ptr), value :: h
     end function
+#ifdef UDC_TEST_TRANSPORT
+    integer(c_int) function udc_comm_init_shm(h, name) bind(C, name='udc_comm_init_shm')
+      import :: c_ptr, c_int, c_char
+      type(c_ptr), value :: h
+      character(kind=c_char), intent(in) :: name(*)
+    end function udc_comm_init_shm
+#endif
     integer(c_int) function udc_set_masscorr_outflow(h, lu, uflow) bind(C, name='udc_set_masscorr_outflow')
       import :: c_ptr, c_int, c_double
       type(c_ptr), value :: h
@@ -500,6 +507,10 @@ contains
     real(c_double), allocatable, target, save :: zf_(:), zh_(:)
     character(16) :: env
     integer :: stat
+#ifdef UDC_TEST_TRANSPORT
+    character(64) :: shm_name
+    logical :: shm_on = .false.
+#endif
     if (c_associated(udc_h)) return
     allocate (zf_(0:ktot + 1), zh_(0:ktot + 1))
     zf_(0:ktot + 1) = dzf(kb - kh:ke + kh)
@@ -536,10 +547,23 @@ contains
     call udc_check(udc_create(cfg, udc_h), 'udc_create')
     if (nprocs > 1) then
       ! RCCL communicator over the y-slab ranks: rank 0 makes the id, MPI carries it (INTEGRATION.md section 4)
+#ifdef UDC_TEST_TRANSPORT
+      ! test build (udales_full_dropin_mpi_test, linked against libudcore_test.so): with UDC_TEST_SHM=/name the ranks exchange
+      ! through shared memory instead of RCCL, so that mpiexec -n P runs on a one-GPU box
+      call get_environment_variable('UDC_TEST_SHM', shm_name, status=stat)
+      if (stat == 0 .and. len_trim(shm_name) > 0) then
+        call udc_check(udc_comm_init_shm(udc_h, trim(shm_name)//c_null_char), 'udc_comm_init_shm')
+        shm_on = .true.
+      end if
+      if (.not. shm_on) then
+#endif
       nccl_id = 0
       if (myid == 0) call udc_check(udc_comm_unique_id(nccl_id), 'udc_comm_unique_id')
       call MPI_BCAST(nccl_id, 128, MPI_CHARACTER, 0, comm3d, mpierr)
       call udc_check(udc_comm_init(udc_h, nccl_id), 'udc_comm_init')
+#ifdef UDC_TEST_TRANSPORT
+      end if
+#endif
     end if
     if (ltempeq) then      ! temperature equation; the dry buoyancy term is on the device for device-resident runs
       ! (in residency 0/1 the host's own forces adds it to the pulled tendencies)

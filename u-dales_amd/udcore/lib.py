@@ -66,7 +66,7 @@ def load():
     return _lib
 
 
-TEST_EXPORTS = ["udc_local_group_create", "udc_comm_init_local"]      # libudcore_test.so only (the virtual-rank tests' transport)
+TEST_EXPORTS = ["udc_local_group_create", "udc_comm_init_local", "udc_comm_init_shm"]      # libudcore_test.so only (the virtual-rank tests' transport)
 TESTLIBPATH = os.path.join(os.path.dirname(LIBPATH), "libudcore_test.so")
 
 
