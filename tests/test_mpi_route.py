@@ -103,9 +103,10 @@ def run_ranks(name, iexp, tmp_path, nranks, deck_edit=None):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["run_16x16x8", "run_smag_scalar_16x8x12s", "run_moist_16x8x12s", "run_ibm_wf2_16x12x10", "run_ibm_moistwq_16x12x10"])
-def test_two_mpi_ranks_run_the_deck_to_the_end(name, tmp_path):
-    """mpiexec -n 2 of the reference's real program with the drop-in modules, nprocy = 2: MPI start-up and broadcasts, two library
+@pytest.mark.parametrize("name,P", [("run_16x16x8", 2), ("run_16x16x8", 4), ("run_smag_scalar_16x8x12s", 2),
+                                    ("run_moist_16x8x12s", 2), ("run_ibm_wf2_16x12x10", 2), ("run_ibm_moistwq_16x12x10", 2)])
+def test_two_mpi_ranks_run_the_deck_to_the_end(name, P, tmp_path):
+    """mpiexec -n P (2, 4) of the reference's real program with the drop-in modules, nprocy = P: MPI start-up and broadcasts, two library
     handles with two slabs, the Fortran modules' slab logic (rows of the point lists and facet sections, masks, per-rank restart
     files), ghost rows and the Poisson transposes through the library's multi-rank path -- against the one-rank fixture of the
     all-reference executable, through the restart files both ranks write."""
@@ -115,11 +116,11 @@ def test_two_mpi_ranks_run_the_deck_to_the_end(name, tmp_path):
     if not (os.path.exists(EXE_TEST) and os.path.exists(MPIEXEC)):
         pytest.skip("oracle/_ref/udales_full_dropin_mpi_test or MPICH not available")
     iexp = RUN_CASES[name]
-    fix, last = run_ranks(name, iexp, tmp_path, 2)
+    fix, last = run_ranks(name, iexp, tmp_path, P)
     nx, ny, nz = (int(v) for v in fix["meta"].data[:3])
-    nyl = ny // 2
+    nyl = ny // P
     files = sorted(f for f in os.listdir(tmp_path) if f.startswith("initd"))
-    assert len(files) == 2 and files[0][14:21] == "000_000" and files[1][14:21] == "000_001", files
+    assert len(files) == P and [f[14:21] for f in files] == [f"000_{r:03d}" for r in range(P)], files
     parts = [restart.read_initd(str(tmp_path / f), nx, nyl, nz) for f in files]
     checked = 0
     for k in ("u0", "v0", "w0", "pres0", "thl0", "qt0"):
