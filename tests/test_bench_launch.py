@@ -20,11 +20,11 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch(n, extra, timeout):
+def launch(n, extra, timeout, env_extra=None, size="32x16x16", single=False):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1",
-           "--no-cpu", "--no-dropin", "--no-single", "--size", "32x16x16"] + extra
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+           "--no-cpu", "--no-dropin", "--size", size] + ([] if single else ["--no-single"]) + extra
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
 
 
@@ -62,3 +62,30 @@ def test_oversubscribed_ranks_reach_comm_init_and_leave_cleanly():
     assert r.stderr.count("udc_comm_init refused") >= 2, r.stderr[-3000:]
     # the JSON line is only printed by a run that finished
     assert '"metric"' not in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 4])
+def test_bench_line_of_a_multi_rank_run(n):
+    """The N > 1 branch of bench.py run to its JSON line on ONE GPU: the ranks share the device (--oversubscribe, rendezvous over gloo)
+    and the library is the test build, whose inter-process transport (UDC_TEST_SHM, shared memory) stands in for RCCL.  Checked: the
+    line's contract fields, the divergence of the run, the one-GPU reference of the same grid in the same line, and that the slabs'
+    answer is the single GPU's (poisson-only and substep times are both there)."""
+    import json
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("more than one GPU here: the real run is the driver's scaling bench")
+    lib = os.path.join(ROOT, "u-dales_amd", "lib", "libudcore_test.so")
+    if not os.path.exists(lib):
+        pytest.skip("libudcore_test.so not built")
+    r = launch(n, ["--oversubscribe"], 900, {"UDC_LIBPATH": lib, "UDC_TEST_SHM": f"/udc_bench_{os.getpid()}_{n}"}, size="64x32x32", single=True)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "cell-updates/s" and d["scaling"] == "strong"
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and d["divmax_after_run"] < 1e-10
+    assert d["config"]["decomposition"] == f"y-slabs x{n}" and d["config"]["grid"] == [64, 32, 32]
+    assert d["cpu_baseline"] is None and d["roofline"]["bound"] == "hbm"
+    one = d["single_gpu_same_workload"]
+    assert one and "error" not in one, one

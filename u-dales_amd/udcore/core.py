@@ -8,6 +8,7 @@ in u-dales_amd/fortran/ do the same thing from the reference's own driver.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -64,6 +65,11 @@ class DynCore:
 
     def comm_init(self, unique_id: bytes):
         """RCCL communicator over the y-slab ranks (id from udc_comm_unique_id on rank 0)."""
+        shm = os.environ.get("UDC_TEST_SHM", "")
+        if shm and getattr(self.lib, "udc_comm_init_shm", None) is not None:
+            # the test library's inter-process transport (libudcore_test.so via UDC_LIBPATH): ranks sharing one device in tests
+            L._check(self.lib.udc_comm_init_shm(self.h, shm.encode()), "udc_comm_init_shm")
+            return
         buf = (C.c_ubyte * 128)(*unique_id)
         L._check(self.lib.udc_comm_init(self.h, buf), "udc_comm_init")
 
