@@ -544,7 +544,7 @@ def main():
         net = avg_ms if (live or not table) else max(avg_ms - marker_ms, 0.)
         ent = {"avg_ms": round(avg_ms, 5), "avg_ms_net": round(net, 5), "launches": cnt, "share": round(net * per_substep / ms_per, 4),
                "measured": "timed region" if (live or not table) else f"survey over {n_tab} untimed substeps, every launch marked"}
-        if ab:
+        if ab and net > 0.:      # (a launch shorter than the marker's cost nets to zero on tiny test grids: no rate for it)
             gbs = ab * cells_local / (net * 1e-3) / 1e9
             ent.update({"algo_bytes_per_cell": round(ab, 2), "achieved_GBs": round(gbs, 1),
                         "frac": round(gbs / HBM_PEAK_GBS, 4)})

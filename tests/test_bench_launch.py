@@ -79,6 +79,9 @@ def test_bench_line_of_a_multi_rank_run(n):
     if not os.path.exists(lib):
         pytest.skip("libudcore_test.so not built")
     r = launch(n, ["--oversubscribe"], 900, {"UDC_LIBPATH": lib, "UDC_TEST_SHM": f"/udc_bench_{os.getpid()}_{n}"}, size="64x32x32", single=True)
+    if r.returncode != 0 and os.environ.get("UDC_TEST_KEEP_LOGS"):
+        with open(os.path.join(os.environ["UDC_TEST_KEEP_LOGS"], f"bench_launch_{n}_{os.getpid()}.err"), "w") as f:
+            f.write(r.stdout + "\n=====\n" + r.stderr)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
     assert len(lines) == 1, r.stdout[-2000:]
