@@ -859,6 +859,26 @@ def split_scal(kw):
     return kw, sc
 
 
+def make_reference_test_cases():
+    """The inputs of the reference's OWN solver-facing tests, staged as data (tests/test_reference_own_tests.py):
+    tests/cases/100 of the reference (the Xie / Castro cube array, 128^3, immersed boundary: prof / lscale / facet / point-list
+    files; the STL the solver never reads is left out), and the decks its test drivers put on top of it --
+    tests/integration/processor_boundaries/namoptions.100.serial (one step, tdump) and
+    tests/integration/mpi_operators/namoptions.1005.{serial,ysplit} (runmode 1005: src/tests.f90's operator test).  No outputs are
+    kept: the all-reference executable (oracle/_ref/udales_full, which travels with the snapshot) produces them on the test box."""
+    src = "/root/reference/tests"
+    cdir = os.path.join(HERE, "cases", "case_100")
+    os.makedirs(cdir, exist_ok=True)
+    files = [os.path.join(src, "cases", "100", fn) for fn in sorted(os.listdir(os.path.join(src, "cases", "100"))) if not fn.endswith(".stl")]
+    files += [os.path.join(src, "integration", "processor_boundaries", "namoptions.100.serial"),
+              os.path.join(src, "integration", "mpi_operators", "namoptions.1005.serial"),
+              os.path.join(src, "integration", "mpi_operators", "namoptions.1005.ysplit")]
+    for fn in files:
+        with open(fn, "rb") as f, gzip.GzipFile(os.path.join(cdir, os.path.basename(fn) + ".gz"), "wb", mtime=0) as g:
+            g.write(f.read())
+    print(f"case_100: {len(files)} input files staged")
+
+
 def main():
     if not os.path.exists(REF):
         sys.exit(f"{REF} missing: run `make -C oracle ref` in the build container first")
@@ -900,6 +920,8 @@ def main():
         print(f"{name}: {len(keep)} records, {os.path.getsize(tmpf + '.gz') / 1024:.0f} kB")
     make_restart_cases()
     make_example_cases(only)
+    if not only or "case_100" in only:
+        make_reference_test_cases()
     for ex in FULL_EXAMPLES:
         if not only or f"full_example_{ex}" in only:
             make_full_example(ex)

@@ -1,0 +1,217 @@
+"""The reference's OWN tests of this path, run here (SURVEY.md section 4 lists them; there are no others that touch the solver).
+
+1. src/tests.f90's operator test -- `runmode = 1005` in &RUN (program.f90:238-274 dispatches it): avexy_ibm / avey_ibm / sumx_ibm /
+   sumy_ibm on analytic fields over the masks of tests/cases/100, against a brute-force MPI_ALLREDUCE, tolerance 1e-9
+   (src/tests.f90:188-431); driven by tests/integration/mpi_operators/run_test.sh with the decks namoptions.1005.{serial,xsplit,
+   ysplit,xysplit}.  Here: through oracle/_ref/udales_full (the reference's whole src/ tree, one rank) and udales_full_mpi (2 and 4
+   ranks over MPICH and the y-slab decomposition stand-in: `ysplit`; nprocx > 1 is not something the stand-in does) -- which puts
+   the MPI stand-ins under the reference's own test -- and, on a GPU box, through udales_full_dropin: the same unmodified
+   program.f90 / tests.f90 over the ten drop-in modules, i.e. the masks of the drop-in createmasks, its initibm, its start-up.
+   The device's own masked averages get the same treatment: the test's analytic fields and tolerance on udc_stats_xy / udc_stats_y.
+
+2. tests/integration/processor_boundaries/test_processor_boundaries.py -- "the only solver-numerics pin" of the reference: case 100
+   (128^3, the Xie / Castro cube array) run for one step (namoptions.100.serial) on 1 x 1, 2 x 1, 1 x 2, 2 x 2 ranks, `ut, vt, wt` of
+   tdump compared: <= 1e-9 on the bands next to the rank boundaries, <= 2e-8 everywhere (their files are float32).  Here the
+   candidates are the device runs -- the reference's program with the drop-in modules on one rank and on 2 / 4 MPI ranks (y split;
+   the ranks share the one GPU through the test library's transport) -- and the reference is the ALL-REFERENCE executable on the
+   box's host: <= 1e-9 EVERYWHERE for all three fields (the recording NetCDF stand-in keeps float64, so no float32 allowance is
+   needed), i.e. their decomposition-invariance test and a parity test against the reference in one.
+
+(runmode 1004, the sparse point-list reader, compares against rank-local golden files of a 2 x 2 decomposition,
+tests/integration/ibm_sparse_input/*_X_Y.txt: not runnable over a y-slab stand-in; runmode 1003 only prints pencil extents.)"""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from common import GOLDEN
+from refdump import read_ncrec
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFDIR = os.path.join(ROOT, "oracle", "_ref")
+FULL = os.path.join(REFDIR, "udales_full")
+FULL_MPI = os.path.join(REFDIR, "udales_full_mpi")
+DROPIN = os.path.join(REFDIR, "udales_full_dropin")
+DROPIN_MPI_TEST = os.path.join(REFDIR, "udales_full_dropin_mpi_test")
+MPIEXEC = "/opt/conda/bin/mpiexec"
+CASE = os.path.join(GOLDEN, "cases", "case_100")
+TOL = 1.0e-9            # ABS_TOL of test_processor_boundaries.py:28 and of src/tests.f90:389
+
+
+def stage(tmp, deck, nprocy=1, steps=None):
+    """tests/cases/100 + one of the test drivers' decks as namoptions.100 (what run_test.sh / _copy_namelist do)."""
+    os.makedirs(tmp, exist_ok=True)
+    for fn in os.listdir(CASE):
+        if fn.startswith("namoptions"):
+            continue
+        with gzip.open(os.path.join(CASE, fn), "rb") as f, open(os.path.join(tmp, fn[:-3]), "wb") as o:
+            o.write(f.read())
+    with gzip.open(os.path.join(CASE, deck + ".gz"), "rt") as f:
+        txt = f.read()
+    import re
+    txt = re.sub(r"nprocy\s*=\s*\d+", f"nprocy       = {nprocy}", txt)
+    assert re.search(r"nprocx\s*=\s*1\b", txt)
+    if steps is not None:      # a longer variant of the one-step deck: `steps` steps of dtmax, one tdump record at the end
+        dtmax = float(re.search(r"dtmax\s*=\s*([0-9.eE+-]+)", txt).group(1))
+        txt = re.sub(r"runtime\s*=\s*[0-9.eE+-]+", f"runtime      = {dtmax * (steps - 0.5)!r}", txt)
+        txt = re.sub(r"tstatsdump\s*=\s*[0-9.eE+-]+", f"tstatsdump   = {dtmax * steps!r}", txt)
+        txt = re.sub(r"tsample\s*=\s*[0-9.eE+-]+", f"tsample      = {dtmax!r}", txt)
+    with open(os.path.join(tmp, "namoptions.100"), "w") as f:
+        f.write(txt)
+
+
+def run(tmp, exe, nranks=1, env=None, timeout=1500):
+    cmd = f"{exe} namoptions.100" if nranks == 1 and "mpi" not in os.path.basename(exe) else f"{MPIEXEC} -n {nranks} {exe} namoptions.100"
+    r = subprocess.run(f"ulimit -s unlimited; exec {cmd}", shell=True, cwd=tmp, env=env, capture_output=True, text=True, timeout=timeout,
+                       executable="/bin/bash")
+    return r
+
+
+# ---- 1. runmode 1005 ------------------------------------------------------------------------------------------------------------
+
+def test_operator_test_of_the_reference_on_one_rank(tmp_path):
+    if not os.path.exists(FULL):
+        pytest.skip("oracle/_ref/udales_full not built")
+    stage(tmp_path, "namoptions.1005.serial")
+    r = run(tmp_path, FULL)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]          # program.f90:268-272: stop 1 on failure
+    assert "ALL TESTS PASSED: tests_mpi_operators" in r.stdout and "FAIL" not in r.stdout
+
+
+@pytest.mark.parametrize("P", [2, 4])
+def test_operator_test_of_the_reference_over_the_mpi_stand_in(P, tmp_path):
+    if not (os.path.exists(FULL_MPI) and os.path.exists(MPIEXEC)):
+        pytest.skip("oracle/_ref/udales_full_mpi or MPICH not available")
+    stage(tmp_path, "namoptions.1005.ysplit", nprocy=P)
+    r = run(tmp_path, FULL_MPI, P)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+    assert "ALL TESTS PASSED: tests_mpi_operators" in r.stdout and "FAIL" not in r.stdout
+
+
+@pytest.mark.gpu
+def test_operator_test_of_the_reference_over_the_dropin_modules(tmp_path):
+    if not os.path.exists(DROPIN):
+        pytest.skip("oracle/_ref/udales_full_dropin not built")
+    stage(tmp_path, "namoptions.1005.serial")
+    r = run(tmp_path, DROPIN, env=dict(os.environ, UDC_RESIDENCY="2"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+    assert "ALL TESTS PASSED: tests_mpi_operators" in r.stdout and "FAIL" not in r.stdout
+
+
+def analytic(loc_id, nx, ny, nz, c):
+    """var_clean of src/tests.f90:287 (xy) / :334 (y); i, j, k the Fortran indices ib.., jb.., kb.. = 1.."""
+    k, j, i = np.meshgrid(np.arange(1, nz + 1), np.arange(1, ny + 1), np.arange(1, nx + 1), indexing="ij")
+    return c[0] * loc_id + c[1] * i + c[2] * j + c[3] * k
+
+
+@pytest.mark.gpu
+def test_masked_averages_of_the_device_pass_the_operator_test():
+    """check_loc_xy / check_loc_y of src/tests.f90 put to the device's masked averages: the same analytic fields, one per grid
+    location (C = 1 on thl, U = 2, V = 3, W = 4), over case 100's masks, udc_stats_sample -> udc_stats_xy (avexy_ibm with IIu, IIv,
+    IIw, IIc) and udc_stats_y (avey_ibm), against the brute-force sums, 1e-9 absolute; -999 where a level / column has no fluid."""
+    import tempfile
+    import udcore
+    from udcore import read_deck
+    from udcore.ibm import read_ibm
+    from udcore.stats import TDump, xyt_masks
+    with tempfile.TemporaryDirectory() as tmp:
+        stage(tmp, "namoptions.100.serial")
+        with open(os.path.join(tmp, "namoptions.100")) as f:
+            txt = f.read()
+        with open(os.path.join(tmp, "namoptions.100"), "w") as f:      # thl carries the C-location field
+            f.write(txt + "\n&PHYSICS\nltempeq = .true.\n/\n")
+        d = read_deck(os.path.join(tmp, "namoptions.100"))
+        lists = read_ibm(d)
+        core = udcore.from_deck(d)
+    g = core.g
+    nx, ny, nz = g.nx, g.ny, g.nz
+    assert (nx, ny, nz) == (128, 128, 128)
+    cxy, cy = (0.25, 0.13, -0.07, 0.011), (0.5, 0.21, -0.03, 0.017)
+    bits, counts, forced = xyt_masks(nx, ny, nz, lists)
+    II = {q: ((bits >> b) & 1).astype(float) for b, q in enumerate("uvwc")}
+    for b, q in enumerate("uvwc"):
+        if forced[b]:
+            II[q][0] = 0.      # createmasks' own mask (IIw(:, :, kb) = 0); xyt_masks fills such a level for avexy_ibm's lnan = .false. rule
+    for coef, which in ((cxy, "xy"), (cy, "y")):
+        fld = {"u": analytic(2, nx, ny, nz, coef), "v": analytic(3, nx, ny, nz, coef), "w": analytic(4, nx, ny, nz, coef),
+               "c": analytic(1, nx, ny, nz, coef)}
+        for name, q in (("um", "u"), ("vm", "v"), ("wm", "w"), ("thlm", "c"), ("u0", "u"), ("v0", "v"), ("w0", "w"), ("thl0", "c")):
+            core.upload(name, np.pad(fld[q], 1, mode="edge"))
+        td = TDump(core, 1., 1e9, xyt=False, ibm_lists=lists, xy=(which == "xy"), y=(which == "y"))
+        td.step(3, 1., 1.)
+        assert td.nsamples == 1
+        if which == "xy":
+            got = td.xy()
+            for row, q, b in (("uxy", "u", 0), ("vxy", "v", 1), ("wxy", "w", 2), ("thlxy", "c", 3)):
+                s = (fld[q] * II[q]).sum(axis=(1, 2))
+                n = II[q].sum(axis=(1, 2))
+                exp = np.where(n > 0, s / np.maximum(n, 1), -999.)
+                lev = np.ones(nz, dtype=bool)
+                if forced[b]:
+                    lev[0] = False      # (avexy_ibm's lnan = .false. rule for a first level without fluid: not what tests.f90 checks)
+                assert np.abs(got[row] - exp)[lev].max() <= TOL, (row, np.abs(got[row] - exp)[lev].max())
+        else:
+            got = td.y()
+            for row, q in (("uy", "u"), ("vy", "v"), ("wy", "w"), ("thly", "c")):
+                s = (fld[q] * II[q]).sum(axis=1)
+                n = II[q].sum(axis=1)
+                exp = np.where(n > 0, s / np.maximum(n, 1), -999.)
+                assert np.abs(got[row] - exp).max() <= TOL, (row, np.abs(got[row] - exp).max())
+    core.close()
+
+
+# ---- 2. processor boundaries, case 100 ------------------------------------------------------------------------------------------
+
+def tdump_fields(tmp, nranks):
+    """ut, vt, wt of tdump.000.RRR.100.nc stitched over the ranks' rows -> {name: [k, j, i]} (the reference's _load_global_fields)."""
+    parts = []
+    for r in range(nranks):
+        rec = read_ncrec(os.path.join(tmp, f"tdump.000.{r:03d}.100.nc"), want=("ut", "vt", "wt"))
+        parts.append({k: np.squeeze(np.asarray(v[-1][1], dtype=float)) for k, v in rec.items()})
+    return {k: np.concatenate([p[k] for p in parts], axis=1) for k in ("ut", "vt", "wt")}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("steps", [None, 25])
+def test_processor_boundaries_case_100(steps, tmp_path):
+    """steps = None: the reference's deck as it is (one step).  25: the same deck run for 25 steps with a sample every step and the
+    one tdump record at the end (not a test the reference holds: the same comparison on a run long enough for the wall functions,
+    the immersed boundary and the pressure solver to have acted on each other's output)."""
+    if not (os.path.exists(FULL) and os.path.exists(DROPIN)):
+        pytest.skip("oracle/_ref/udales_full(_dropin) not built")
+    out = {}
+    stage(tmp_path / "ref", "namoptions.100.serial", steps=steps)
+    r = run(tmp_path / "ref", FULL)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    out["reference, serial"] = tdump_fields(tmp_path / "ref", 1)
+    stage(tmp_path / "dev1", "namoptions.100.serial", steps=steps)
+    r = run(tmp_path / "dev1", DROPIN, env=dict(os.environ, UDC_RESIDENCY="2"))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    out["device, serial"] = tdump_fields(tmp_path / "dev1", 1)
+    if os.path.exists(DROPIN_MPI_TEST) and os.path.exists(MPIEXEC):
+        for P in (2, 4):
+            d = tmp_path / f"dev{P}"
+            stage(d, "namoptions.100.serial", nprocy=P, steps=steps)
+            env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", UDC_RESIDENCY="2", UDC_GPUS_PER_NODE="1", UDC_TEST_SHM=f"/udc_c100_{os.getpid()}_{P}")
+            r = run(d, DROPIN_MPI_TEST, P, env=env)
+            assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+            out[f"device, y split over {P}"] = tdump_fields(d, P)
+    ref = out["reference, serial"]
+    assert ref["ut"].shape == (128, 128, 128) and np.abs(ref["ut"]).max() > 1.      # (u0 = 3 m/s + noise of amplitude randu = 1)
+    worst = {}
+    for label, cand in out.items():
+        for against in ("reference, serial", "device, serial"):
+            if label == against or (against == "device, serial" and label == "reference, serial"):
+                continue
+            for k in ("ut", "vt", "wt"):
+                worst[(label, against, k)] = float(np.abs(cand[k] - out[against][k]).max())
+    if os.environ.get("UDC_TEST_KEEP_LOGS"):
+        with open(os.path.join(os.environ["UDC_TEST_KEEP_LOGS"], f"processor_boundaries_case100_{steps or 1}steps.txt"), "w") as f:
+            f.write(f"max |candidate - against| of tdump's ut, vt, wt after {steps or 1} step(s) of namoptions.100.serial (tolerance 1e-9)\n")
+            for (label, against, k), v in worst.items():
+                f.write(f"{label:28s} vs {against:18s} {k}: {v:.3e}\n")
+    bad = {k: v for k, v in worst.items() if not v <= TOL}
+    assert not bad, bad
+    assert len(worst) >= 3
