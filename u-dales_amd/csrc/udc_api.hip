@@ -989,6 +989,14 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
       const bool need_ekh = h->ek_always || rk3step == 3 || !h->slots.empty() || h->stats_on || h->xyt_on || h->yt_on;
       if (k_closure_lds(h, true, need_ekh)) return 1;
       h->ekh_stale = !need_ekh;
+    } else if (lds && (h->p.sgs == UDC_SGS_SMAGORINSKY || h->p.sgs == UDC_SGS_VREMAN) && !h->lbuoycorr && halo_overlap(h, closure_lds_tile_rows(h->g))) {
+      // y-slabs: the tile rows next to the neighbouring ranks first; their ekm / ekh rows travel while the rows in between are swept
+      const int fek[2] = {UDC_EKM, UDC_EKH};
+      if (k_closure_lds(h, false, true, 1)) return 1;
+      if (k_halo_y_begin(h, fek, 2, 1)) return 1;
+      if (k_closure_lds(h, false, true, 2)) return 1;
+      if (k_halo_y_join(h)) return 1;
+      if (k_ek_ghosts(h, false)) return 1;
     } else {
       if (k_closure(h)) return 1;
       if (h->lbuoycorr && k_vreman_buoycorr(h)) return 1;      // before closurebc, as in the reference
@@ -1044,7 +1052,25 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
     if (k_halo_y(h, fp, 1, 1)) return 1;
   }
   const bool skip_um = alias_ok && rk3step == 3;
-  if (k_project_integrate(h, rk3step, dt, !lds, pup, fold, !skip_um, rotate)) return 1;
+  // y-slabs: the rows next to the neighbouring ranks first; the ghost rows of the new velocities and of pres0 travel while the rows
+  // in between are integrated (the exchange names the arrays as they will be known after the pointer rotation below)
+  const bool ov_int = !fold && halo_overlap(h, tile_grid(h->g).gy);
+  if (ov_int) {
+    if (k_project_integrate(h, rk3step, dt, !lds, pup, fold, !skip_um, rotate, 1)) return 1;
+    int f[8];
+    int nf = vel_fields(h, skip_um ? 0 : rk3step, f);
+    f[nf++] = UDC_PRES0;
+    double *ptr[8];
+    for (int q = 0; q < nf; ++q) {
+      int id = f[q];
+      if (rotate && id >= UDC_U0 && id < UDC_U0 + 3) id = UDC_UM + (id - UDC_U0);
+      else if (rotate && id >= UDC_UM && id < UDC_UM + 3) id = UDC_U0 + (id - UDC_UM);
+      ptr[q] = h->fields[id];
+    }
+    if (k_halo_y_begin(h, f, nf, 1, ptr)) return 1;
+    if (k_project_integrate(h, rk3step, dt, !lds, pup, fold, !skip_um, rotate, 2)) return 1;
+    if (k_halo_y_join(h)) return 1;
+  } else if (k_project_integrate(h, rk3step, dt, !lds, pup, fold, !skip_um, rotate)) return 1;
   h->dthv_top_on = false;
   if (rk3step == 3 && k_chem(h, dt)) return 1;      // src/modtstep.f90:236-238 (before the ghosts are refreshed)
   if (rotate) {
@@ -1053,7 +1079,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   }
   if (skip_um) h->um_alias = true;
   h->tend_scratch = lds;
-  if (!fold) {
+  if (!fold && !ov_int) {
     int f[8];
     int nf = vel_fields(h, skip_um ? 0 : rk3step, f);
     f[nf++] = UDC_PRES0;

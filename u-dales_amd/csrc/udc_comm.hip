@@ -169,12 +169,13 @@ static int need_comm(udc_handle *h) {
 // neighbour rows: to_prev/to_next are packed send buffers of `count` doubles each;
 // from_next receives the next rank's to_prev, from_prev the previous rank's to_next.
 int comm_neighbours(udc_handle *h, const double *to_prev, const double *to_next, double *from_prev,
-                    double *from_next, size_t count) {
+                    double *from_next, size_t count, hipStream_t st) {
+  if (!st) st = h->stream;
   const int P = h->cfg.nranks, r = h->cfg.rank;
   const int prev = (r + P - 1) % P, next = (r + 1) % P;
   if (P == 1 && !h->nccl) {   // single slab driven through the slab code path (UDC_FORCE_SLAB): periodic wrap onto itself
-    HIP_OK(hipMemcpyAsync(from_next, to_prev, count * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    HIP_OK(hipMemcpyAsync(from_prev, to_next, count * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HIP_OK(hipMemcpyAsync(from_next, to_prev, count * sizeof(double), hipMemcpyDeviceToDevice, st));
+    HIP_OK(hipMemcpyAsync(from_prev, to_next, count * sizeof(double), hipMemcpyDeviceToDevice, st));
     return 0;
   }
   if (need_comm(h)) return 1;
@@ -183,10 +184,10 @@ int comm_neighbours(udc_handle *h, const double *to_prev, const double *to_next,
     // with P == 2 both neighbours are the same peer: sends and receives pair up in posting order,
     // so post "to prev" first on the send side and "from next" first on the receive side.
     NCCL_OK(ncclGroupStart());
-    NCCL_OK(ncclSend(to_prev, count, ncclDouble, prev, c, h->stream));
-    NCCL_OK(ncclSend(to_next, count, ncclDouble, next, c, h->stream));
-    NCCL_OK(ncclRecv(from_next, count, ncclDouble, next, c, h->stream));
-    NCCL_OK(ncclRecv(from_prev, count, ncclDouble, prev, c, h->stream));
+    NCCL_OK(ncclSend(to_prev, count, ncclDouble, prev, c, st));
+    NCCL_OK(ncclSend(to_next, count, ncclDouble, next, c, st));
+    NCCL_OK(ncclRecv(from_next, count, ncclDouble, next, c, st));
+    NCCL_OK(ncclRecv(from_prev, count, ncclDouble, prev, c, st));
     NCCL_OK(ncclGroupEnd());
     return 0;
   }
@@ -195,7 +196,7 @@ int comm_neighbours(udc_handle *h, const double *to_prev, const double *to_next,
     const size_t nb = count * sizeof(double);
     ShmGroup *sg = (ShmGroup *)h->shm_group;
     if (2 * nb > sg->cap) { udc_set_error("test transport (shared memory): ghost rows exceed the outbox"); return 1; }
-    HIP_OK(hipStreamSynchronize(h->stream));
+    HIP_OK(hipStreamSynchronize(st));
     HIP_OK(hipMemcpy(sg->box(r), to_prev, nb, hipMemcpyDeviceToHost));
     HIP_OK(hipMemcpy(sg->box(r) + nb, to_next, nb, hipMemcpyDeviceToHost));
     pthread_barrier_wait(&sg->bar);
@@ -206,11 +207,11 @@ int comm_neighbours(udc_handle *h, const double *to_prev, const double *to_next,
   }
   LocalGroup *g = (LocalGroup *)h->local_group;
   g->send[r][0] = to_prev; g->send[r][1] = to_next;
-  HIP_OK(hipStreamSynchronize(h->stream));
+  HIP_OK(hipStreamSynchronize(st));
   pthread_barrier_wait(&g->bar);
-  HIP_OK(hipMemcpyAsync(from_next, g->send[next][0], count * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-  HIP_OK(hipMemcpyAsync(from_prev, g->send[prev][1], count * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-  HIP_OK(hipStreamSynchronize(h->stream));
+  HIP_OK(hipMemcpyAsync(from_next, g->send[next][0], count * sizeof(double), hipMemcpyDeviceToDevice, st));
+  HIP_OK(hipMemcpyAsync(from_prev, g->send[prev][1], count * sizeof(double), hipMemcpyDeviceToDevice, st));
+  HIP_OK(hipStreamSynchronize(st));
   pthread_barrier_wait(&g->bar);
   return 0;
 #else

@@ -127,6 +127,39 @@ int k_halo_y(udc_handle *h, const int *fields, int nf, int width) {
   return 0;
 }
 
+// ---- ghost-row exchange beside the compute stream (y-slabs)
+// The producer of the rows is launched twice: first over the tile rows next to the neighbouring ranks, then over the rows in
+// between; the exchange of what the first launch wrote -- pack, send / receive, unpack -- is queued in between on the communication
+// stream (highest priority: its few workgroups go ahead of the second launch's queue) and the compute stream waits for it after the
+// second launch.  The second launch touches no row the exchange reads or writes (its tiles lie >= one tile row inside).
+bool halo_overlap(const udc_handle *h, int tile_rows_y) {
+  return h->slab && h->comm_stream && !h->no_halo_overlap && tile_rows_y >= 3;
+}
+
+int k_halo_y_begin(udc_handle *h, const int *fields, int nf, int width, double *const *ptrs) {
+  const Geo &g = h->g;
+  if (width > HY || nf > 16 || !h->slab || !h->comm_stream) { udc_set_error("k_halo_y_begin: bad arguments"); return 1; }
+  FieldList fl;
+  for (int q = 0; q < nf; ++q) fl.f[q] = ptrs ? ptrs[q] : h->fields[fields[q]];
+  const size_t count = (size_t)nf * width * g.pz * g.nx;
+  if (count > h->halo_cap) { udc_set_error("k_halo_y_begin: pack buffer too small"); return 1; }
+  hipStream_t cs = h->comm_stream;
+  HIP_OK(hipEventRecord(h->ev_halo_ready, h->stream));
+  HIP_OK(hipStreamWaitEvent(cs, h->ev_halo_ready, 0));
+  hipLaunchKernelGGL(halo_pack_kernel, dim3((g.nx + 63) / 64, width * nf, g.pz), dim3(64), 0, cs, g, fl, width, h->halo_buf[0], h->halo_buf[1]);
+  HIP_OK(hipGetLastError());
+  if (comm_neighbours(h, h->halo_buf[0], h->halo_buf[1], h->halo_buf[2], h->halo_buf[3], count, cs)) return 1;
+  hipLaunchKernelGGL(halo_unpack_kernel, dim3((g.nx + 63) / 64, width * nf, g.pz), dim3(64), 0, cs, g, fl, width, h->halo_buf[2], h->halo_buf[3]);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipEventRecord(h->ev_halo_done, cs));
+  return 0;
+}
+
+int k_halo_y_join(udc_handle *h) {
+  HIP_OK(hipStreamWaitEvent(h->stream, h->ev_halo_done, 0));
+  return 0;
+}
+
 static BoundaryArgs boundary_args(udc_handle *h) {
   BoundaryArgs a;
   a.u0 = h->fields[UDC_U0]; a.v0 = h->fields[UDC_V0]; a.w0 = h->fields[UDC_W0];

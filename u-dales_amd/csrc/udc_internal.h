@@ -68,10 +68,22 @@ struct Geo {
 // same (x,y) tile of plane k+1 lands on the same XCD (k+-1 reuse).  Placement only affects speed.
 // ---------------------------------------------------------------------------------------
 constexpr int TX = 64, TY = 4;
-struct TileGrid { int gx, gy, tiles; };
+// A launch may cover a subset of the tile rows (y-slabs: the rows next to the neighbouring ranks first, their ghost-row exchange
+// then runs beside the launch over the interior rows, udc_halo.hip): gy / tiles count the rows of THIS launch, and local tile row
+// b stands for row  y0 + b + (b >= ysplit ? yjump : 0)  of the slab.
+struct TileGrid { int gx, gy, tiles; int y0 = 0, ysplit = 1 << 30, yjump = 0; };
 inline TileGrid tile_grid(const Geo &g) {
   TileGrid t; t.gx = (g.nx + TX - 1) / TX; t.gy = (g.ny + TY - 1) / TY; t.tiles = t.gx * t.gy; return t;
 }
+// rows of a split launch: edge = the first and last `e` tile rows of `full`, otherwise the rows in between (full.gy > 2 e)
+inline TileGrid tile_rows(const TileGrid &full, int e, bool edge) {
+  TileGrid t = full;
+  if (edge) { t.gy = 2 * e; t.y0 = 0; t.ysplit = e; t.yjump = full.gy - 2 * e; }
+  else { t.gy = full.gy - 2 * e; t.y0 = e; }
+  t.tiles = t.gx * t.gy;
+  return t;
+}
+__host__ __device__ __forceinline__ int tile_row(const TileGrid &t, int b) { return t.y0 + b + (b >= t.ysplit ? t.yjump : 0); }
 #if defined(__HIPCC__)
 __device__ __forceinline__ bool tile_decode(const Geo &g, const TileGrid &t, int &i, int &j, int &k) {
   const unsigned L = blockIdx.x;
@@ -79,7 +91,8 @@ __device__ __forceinline__ bool tile_decode(const Geo &g, const TileGrid &t, int
   const unsigned lp = L - (unsigned)k * t.tiles;
   unsigned tt = lp;
   if ((t.tiles & 7) == 0) tt = (lp & 7u) * (t.tiles >> 3) + (lp >> 3);
-  const int by = tt / t.gx, bx = tt - by * t.gx;
+  const int byl = tt / t.gx, bx = tt - byl * t.gx;
+  const int by = tile_row(t, byl);
   i = bx * TX + threadIdx.x;
   j = by * TY + threadIdx.y;
   return i < g.nx && j < g.ny;
@@ -303,6 +316,8 @@ struct udc_handle {
   int nch = 1;                          // k-chunks of the all-to-all pipeline
   hipStream_t comm_stream = nullptr;    // all-to-all exchanges run here, overlapped with rocFFT on `stream`
   hipEvent_t ev_ready[16] = {}, ev_done[16] = {};
+  hipEvent_t ev_halo_ready = nullptr, ev_halo_done = nullptr;      // k_halo_y_begin / _join
+  bool no_halo_overlap = false;         // UDC_HALO_OVERLAP=0: every ghost-row exchange in line on the compute stream
   double *specA = nullptr, *specB = nullptr, *a2a_send = nullptr, *a2a_recv = nullptr;
   double *ev_slab = nullptr, *ztab_slab = nullptr;
   rocfft_plan plan_xf = nullptr, plan_xb = nullptr, plan_yf = nullptr, plan_yb = nullptr;
@@ -348,8 +363,9 @@ struct ProfScope {
 
 // ---- kernels (udc_mom.hip, udc_pois.hip, udc_scalar.hip, udc_halo.hip)
 int k_closure(udc_handle *h);
-int k_closure_lds(udc_handle *h, bool ghosts, bool write_ekh = true);   // ghosts: closurebc folded in (single slab); write_ekh false: ekm only
-int k_ek_ghosts(udc_handle *h);
+int k_closure_lds(udc_handle *h, bool ghosts, bool write_ekh = true, int rows = 0);   // ghosts: closurebc folded in (single slab); write_ekh false: ekm only
+int k_ek_ghosts(udc_handle *h, bool exchange = true);
+int closure_lds_tile_rows(const Geo &g);      // tile rows of k_closure_lds over the slab
 int k_momentum(udc_handle *h, bool adv, bool diff, bool forces);       // direct-load version (UDC_MOM_SIMPLE=1)
 int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, double rk3coefi, bool um_is_u0 = false);  // rk3coefi != 0: PUP mode   // LDS-staged k-marching version (default)
 bool fused_closure_possible(const udc_handle *h);                      // udc_mom_fused.hip: closure inside the momentum sweep
@@ -372,8 +388,16 @@ int k_poisson_solve(udc_handle *h);
 int k_project(udc_handle *h);                       // tderive: up,vp,wp -= grad p ; pres0 += p
 int k_integrate(udc_handle *h, int rk3step, double dt);
 int k_project_integrate(udc_handle *h, int rk3step, double dt, bool zero_tend, bool pup, bool ghosts,
-                        bool write_um = true, bool out_to_um = false);   // fused tderive + tstep_integrate
+                        bool write_um = true, bool out_to_um = false, int rows = 0);   // fused tderive + tstep_integrate
+// rows (k_closure_lds, k_project_integrate): 0 all tile rows of the slab, 1 only the tile rows next to the neighbouring ranks,
+// 2 only the rows in between (see halo_overlap_rows)
 int k_halo_y(udc_handle *h, const int *fields, int nf, int width);
+// the same exchange beside the compute stream: _begin queues pack, exchange and unpack on the communication stream behind what
+// the compute stream holds so far; _join makes the compute stream wait for it.  `ptrs` (optional): the arrays, where the caller
+// knows better than h->fields (pointer rotation in flight)
+int k_halo_y_begin(udc_handle *h, const int *fields, int nf, int width, double *const *ptrs = nullptr);
+int k_halo_y_join(udc_handle *h);
+bool halo_overlap(const udc_handle *h, int tile_rows_y);      // y-slabs with enough tile rows for an edge / interior split
 int k_top_bottom(udc_handle *h);
 int k_top_rows_after_closure(udc_handle *h);
 int k_scalar_top_flux(udc_handle *h);              // fluxtop with a non-zero flux: re-imposed after closure (reassure_fluxtop_boundary)
@@ -417,7 +441,7 @@ int fft_y_fwd_unpack(udc_handle *h, int k0, int nzc, const double *recv);
 int fft_y_bwd_pack(udc_handle *h, int k0, int nzc, double *send);
 // udc_comm.hip
 int comm_neighbours(udc_handle *h, const double *to_prev, const double *to_next, double *from_prev,
-                    double *from_next, size_t count);
+                    double *from_next, size_t count, hipStream_t st = nullptr);      // st: the stream it runs on (default h->stream)
 int comm_alltoall(udc_handle *h, const double *send, double *recv, size_t block, hipStream_t st);
 int comm_allreduce(udc_handle *h, double *buf, int n, int op);
 void comm_destroy(udc_handle *h);

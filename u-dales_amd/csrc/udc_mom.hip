@@ -415,10 +415,10 @@ int k_closure(udc_handle *h) {
   return 0;
 }
 
-int k_ek_ghosts(udc_handle *h) {
+int k_ek_ghosts(udc_handle *h, bool exchange) {
   const Geo &g = h->g;
   const int f[2] = {UDC_EKM, UDC_EKH};
-  if (k_halo_y(h, f, 2, 1)) return 1;
+  if (exchange && k_halo_y(h, f, 2, 1)) return 1;      // (false: the caller has exchanged the rows beside the closure sweep)
   PROF(h, "ek_topbot");
   hipLaunchKernelGGL(ek_topbot_kernel, dim3((g.nx + 63) / 64, g.ny + 2), dim3(64), 0, h->stream, g, h->p,
                      h->fields[UDC_EKM], h->fields[UDC_EKH]);

@@ -78,7 +78,8 @@ __global__ __launch_bounds__(NT / CPT, CPT == 1 ? MOM_WAVES : 2) void mom_lds_ke
   const unsigned lp = L - (unsigned)chunk * tg.tiles;
   unsigned tt = lp;
   if ((tg.tiles & 7) == 0) tt = (lp & 7u) * (tg.tiles >> 3) + (lp >> 3);
-  const int by = tt / tg.gx, bx = tt - by * tg.gx;
+  const int byl = tt / tg.gx, bx = tt - byl * tg.gx;
+  const int by = tile_row(tg, byl);
   const int i0 = bx * MX, j0 = by * MY;
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * MX + tx;
   const int i = i0 + tx;
@@ -255,7 +256,8 @@ __global__ __launch_bounds__(NT) void closure_lds_kernel(Geo g, TileGrid tg, Met
   const unsigned lp = L - (unsigned)chunk * tg.tiles;
   unsigned tt = lp;
   if ((tg.tiles & 7) == 0) tt = (lp & 7u) * (tg.tiles >> 3) + (lp >> 3);
-  const int by = tt / tg.gx, bx = tt - by * tg.gx;
+  const int byl = tt / tg.gx, bx = tt - byl * tg.gx;
+  const int by = tile_row(tg, byl);
   const int i0 = bx * MX, j0 = by * MY;
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * MX + tx;
   const int i = i0 + tx, j = j0 + ty;
@@ -365,9 +367,12 @@ static int pick_kc(const Geo &g, const TileGrid &tg, int per_cu) {
   return best;
 }
 
-int k_closure_lds(udc_handle *h, bool ghosts, bool write_ekh) {
+int closure_lds_tile_rows(const Geo &g) { return lds_tile_grid(g).gy; }
+
+int k_closure_lds(udc_handle *h, bool ghosts, bool write_ekh, int rows) {
   const Geo &g = h->g;
-  const TileGrid tg = lds_tile_grid(g);
+  // rows 1 / 2: the tile rows next to the neighbouring ranks / the rows in between (k_ek_ghosts_overlapped exchanges in between)
+  const TileGrid tg = rows == 0 ? lds_tile_grid(g) : tile_rows(lds_tile_grid(g), 1, rows == 1);
   // 90 VGPRs, 32 640 B LDS: five workgroups fit a CU.  Measured: 512x512x256 0.634 -> 0.592 ms, 1024x512x512 2.60 -> 2.38 ms
   // when the chunking fills them; at 256^3 (256 tiles) five shorter chunks per tile lose to four (0.19 against 0.172 ms)
   const int per_cu = getenv("UDC_CLOSURE_PERCU") ? atoi(getenv("UDC_CLOSURE_PERCU")) : (tg.tiles >= 1024 ? 5 : 4);
@@ -376,7 +381,7 @@ int k_closure_lds(udc_handle *h, bool ghosts, bool write_ekh) {
   dim3 b(MX, MY, 1), gr((unsigned)tg.tiles * (unsigned)chunks, 1, 1);
   double *u = h->fields[UDC_U0], *v = h->fields[UDC_V0], *w = h->fields[UDC_W0];
   double *ekm = h->fields[UDC_EKM], *ekh = h->fields[UDC_EKH];
-  PROF(h, "closure");
+  PROF(h, rows == 1 ? "closure_edge" : "closure");
   const int gh = ghosts ? 1 : 0;
   if (h->p.sgs == UDC_SGS_SMAGORINSKY) {
     if (write_ekh) hipLaunchKernelGGL((closure_lds_kernel<1, true>), gr, b, 0, h->stream, g, tg, h->m, h->p, u, v, w, ekm, ekh, kc, gh);

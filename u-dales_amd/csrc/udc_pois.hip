@@ -1247,7 +1247,16 @@ int pois_slab_init(udc_handle *h) {
                             rocfft_precision_double, 1, ly, (size_t)cx * nzc, nullptr));
   h->fft_fused = fft_fused_possible(h) && !(getenv("UDC_FFT_FUSED") && atoi(getenv("UDC_FFT_FUSED")) == 0);
   if (h->fft_fused && fft_fused_init(h)) return 1;
-  HIP_OK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+  {
+    // exchanges run beside the transforms / the interior launches of the split kernels: highest priority, so that their few
+    // workgroups are dispatched ahead of the compute stream's queue instead of behind it
+    int lo = 0, hi = 0;
+    HIP_OK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIP_OK(hipStreamCreateWithPriority(&h->comm_stream, hipStreamNonBlocking, hi));
+    HIP_OK(hipEventCreateWithFlags(&h->ev_halo_ready, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&h->ev_halo_done, hipEventDisableTiming));
+    h->no_halo_overlap = getenv("UDC_HALO_OVERLAP") && atoi(getenv("UDC_HALO_OVERLAP")) == 0;
+  }
   for (int c = 0; c < nch; ++c) {
     HIP_OK(hipEventCreateWithFlags(&h->ev_ready[c], hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&h->ev_done[c], hipEventDisableTiming));
@@ -1380,6 +1389,8 @@ void pois_destroy(udc_handle *h) {
   for (auto pl : sp) if (pl) rocfft_plan_destroy(pl);
   if (h->info_x) rocfft_execution_info_destroy(h->info_x);
   if (h->comm_stream) hipStreamDestroy(h->comm_stream);
+  if (h->ev_halo_ready) hipEventDestroy(h->ev_halo_ready);
+  if (h->ev_halo_done) hipEventDestroy(h->ev_halo_done);
   for (int c = 0; c < 16; ++c) { if (h->ev_ready[c]) hipEventDestroy(h->ev_ready[c]); if (h->ev_done[c]) hipEventDestroy(h->ev_done[c]); }
   if (h->fft_tw) hipFree(h->fft_tw);
   double *bufs[7] = {h->specA, h->specB, h->a2a_send, h->a2a_recv, h->ev_slab, h->ztab_slab, (double *)h->fft_work_slab};
@@ -1489,25 +1500,28 @@ int k_integrate(udc_handle *h, int rk3step, double dt) {
 }
 
 int k_project_integrate(udc_handle *h, int rk3step, double dt, bool zero_tend, bool pup, bool ghosts,
-                        bool write_um, bool out_to_um) {
+                        bool write_um, bool out_to_um, int rows) {
   const Geo &g = h->g;
-  dim3 b(64, 4, 1), gr = cell_grid(g, b);
+  const dim3 b(64, 4, 1);
+  // rows 1 / 2: the tile rows next to the neighbouring ranks / the rows in between (the caller exchanges ghost rows in between)
+  const TileGrid tg = rows == 0 ? tile_grid(g) : tile_rows(tile_grid(g), 1, rows == 1);
+  const dim3 gr((unsigned)tg.tiles * (unsigned)g.nz, 1, 1);
   const double rk3coef = dt / (4. - (double)rk3step);
-  PROF(h, "project_integrate");
+  PROF(h, rows == 1 ? "project_integrate_edge" : "project_integrate");
   const int lastf = rk3step == 3 ? (write_um ? 3 : 2) : 0;
   IntArgs ia = int_args(h);
   if (out_to_um) { ia.u0 = ia.um; ia.v0 = ia.vm; ia.w0 = ia.wm; }   // pointer rotation at RK stage 1 (um_alias)
   if (pup)
-    hipLaunchKernelGGL((integrate_kernel<true, false, true>), gr, b, 0, h->stream, g, tile_grid(g), h->m, ia,
+    hipLaunchKernelGGL((integrate_kernel<true, false, true>), gr, b, 0, h->stream, g, tg, h->m, ia,
                        (const double *)h->fields[UDC_P], h->fields[UDC_PRES0], rk3coef, lastf, ghosts ? 1 : 0, h->p);
   else if (zero_tend)
-    hipLaunchKernelGGL((integrate_kernel<true, true, false>), gr, b, 0, h->stream, g, tile_grid(g), h->m, ia,
+    hipLaunchKernelGGL((integrate_kernel<true, true, false>), gr, b, 0, h->stream, g, tg, h->m, ia,
                        (const double *)h->fields[UDC_P], h->fields[UDC_PRES0], rk3coef, lastf, ghosts ? 1 : 0, h->p);
   else
-    hipLaunchKernelGGL((integrate_kernel<true, false, false>), gr, b, 0, h->stream, g, tile_grid(g), h->m, ia,
+    hipLaunchKernelGGL((integrate_kernel<true, false, false>), gr, b, 0, h->stream, g, tg, h->m, ia,
                        (const double *)h->fields[UDC_P], h->fields[UDC_PRES0], rk3coef, lastf, ghosts ? 1 : 0, h->p);
   HIP_OK(hipGetLastError());
-  if (rk3step == 3 && copy_floor_planes(h, write_um)) return 1;
+  if (rk3step == 3 && rows != 2 && copy_floor_planes(h, write_um)) return 1;      // (whole planes below the floor: once)
   return 0;
 }
 
