@@ -96,6 +96,56 @@ print("RCCL_OK", m, dv)
     assert "RCCL_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
+def test_rccl_carries_the_overlapped_exchanges(tmp_path):
+    """The ghost rows that travel beside the sweeps (closure edge / interior, project + integrate edge / interior: k_halo_y_begin /
+    _join on the communication stream) through a real one-rank RCCL communicator, on a grid with enough tile rows for both splits
+    (64 x 48 x 24: 6 and 12 tile rows), Vreman + floor wall function, nine substeps: the forced slab path with RCCL, with the overlap
+    on and off, against the single-slab path (2-D rocFFT, folded ghost rows)."""
+    code = r'''
+import sys, ctypes, os, numpy as np
+import torch
+torch.cuda.set_device(0)
+sys.path[:0] = ["%s/tests", "%s/u-dales_amd"]
+from udcore.core import DynCore
+from udcore.grid import Grid
+nx, ny, nz = 64, 48, 24
+g = Grid.uniform(nx, ny, nz)
+core = DynCore(g, sgs=2, nsv=0, lbottom=True, z0=0.05)
+if os.environ.get("UDC_FORCE_COMM") == "1":
+    buf = (ctypes.c_ubyte * 128)()
+    assert core.lib.udc_comm_unique_id(buf) == 0
+    core.comm_init(bytes(buf))
+core.set_forcing(np.full(nz, -1e-4), np.zeros(nz))
+rng = np.random.default_rng(11)
+for k, base in (("u0", 1.0), ("v0", 0.0), ("w0", 0.0)):
+    a = np.zeros(g.mshape())
+    a[1:-1, 1:-1, 1:-1] = base + 0.04 * (rng.random((nz, ny, nx)) - 0.5)
+    if k == "w0":
+        a[1] = 0.
+    core.upload(k, a); core.upload(k.replace("0", "m"), a)
+core.halos(); core.boundary()
+core.run(9, 0.25)
+out = {k: core.download(k) for k in ("u0", "v0", "w0", "pres0")}
+out["div"] = core.divergence()[0]
+core.close()
+np.save(sys.argv[1], out, allow_pickle=True)
+print("RUN_OK")
+''' % (ROOT, ROOT)
+    import numpy as np
+    res = {}
+    for tag, env in (("single", {}), ("rccl", {"UDC_FORCE_SLAB": "1", "UDC_FORCE_COMM": "1"}),
+                     ("rccl_inline", {"UDC_FORCE_SLAB": "1", "UDC_FORCE_COMM": "1", "UDC_HALO_OVERLAP": "0"})):
+        out = str(tmp_path / (tag + ".npy"))
+        r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert "RUN_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+        res[tag] = np.load(out, allow_pickle=True).item()
+    for tag in ("rccl", "rccl_inline"):
+        assert res[tag]["div"] < 1e-10
+        for k in ("u0", "v0", "w0", "pres0"):
+            a, b = res[tag][k][1:-1], res["single"][k][1:-1]          # ghost rows included
+            assert np.abs(a - b).max() <= 1e-10 * max(np.abs(b).max(), 1e-3), (tag, k, np.abs(a - b).max())
+
+
 def ibm_block_lists(nx, ny, nz):
     """Solid / fluid-boundary point lists (u, v, w, c) of two blocks on the floor, the rule of tests/golden/make_golden.py."""
     c = np.zeros((nz + 2, ny, nx), dtype=bool)
