@@ -156,13 +156,15 @@ __global__ __launch_bounds__(NT, 3) void scalar_lds_kernel(Geo g, int gx, int ti
 // kappa scheme with every face value evaluated once.  The limiter (two additions, a division and a min/max chain per
 // face, src/modadvection.f90:410-421) dominates this kernel, and the face between two cells is the same number for
 // both: face(vel, c-2, c-1, c0, c+1) on the low side of cell i is what cell i-1 needs on its high side.  Each thread
-// evaluates the low x- and low y-face of its own cell and leaves them in LDS; 8 lanes of one wave add the tile's 33rd
-// column of x-faces and 32 lanes of another its 9th row of y-faces; the high z-face is carried to the next level as
+// evaluates the low x- and low y-face of its own cell and leaves them in LDS; 40 lanes of one wave add the tile's 33rd
+// column of x-faces and its 9th row of y-faces in one pass; the high z-face is carried to the next level as
 // its low face.  3 (+1/4) limiter evaluations per cell instead of 6, bit-identical operands and operation order.
 // One barrier per level: faces of level k go to the flux buffers of parity k&1, planes are committed two levels
 // before they are first read, and the diffusion (which reads the diffusivity planes) is evaluated before the barrier.
-template <bool LES, bool FRESH>
-__global__ __launch_bounds__(NT, 4) void scalar_kappa_faces_kernel(Geo g, int gx, int tiles, Metrics m, double cekh, double dfac,
+// W5: a fifth wave owns the extra faces (and a share of the staging) instead of one of the four cell waves: the waves that meet at
+// the barrier then all carry three face evaluations; five waves per SIMD need <= 96 VGPRs
+template <bool LES, bool FRESH, bool W5>
+__global__ __launch_bounds__(W5 ? NT + 64 : NT, W5 ? 5 : 4) void scalar_kappa_faces_kernel(Geo g, int gx, int tiles, Metrics m, double cekh, double dfac,
     const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ w, const double *__restrict__ ekh,
     const double *__restrict__ c, double *__restrict__ cp, int gh, int kc) {
   __shared__ double sc[NCB][CN];
@@ -177,9 +179,11 @@ __global__ __launch_bounds__(NT, 4) void scalar_kappa_faces_kernel(Geo g, int gx
   if ((tiles & 7) == 0) tt = (lp & 7u) * (tiles >> 3) + (lp >> 3);      // XCD-aware, as tile_decode
   const int by = tt / gx, bx = tt - by * gx;
   const int i0 = bx * MX, j0 = by * MY;
+  constexpr int NTS = W5 ? NT + 64 : NT;          // threads that stage planes
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * MX + tx;
-  const int i = i0 + tx, j = j0 + ty;
-  const bool inside = i < g.nx && j < g.ny;
+  const bool own = !W5 || tid < NT;               // (wave-uniform) this thread has a cell of the tile
+  const int i = i0 + tx, j = j0 + (own ? ty : 0);
+  const bool inside = own && i < g.nx && j < g.ny;
   const int k0 = chunk * kc, k1 = min(k0 + kc, g.nz);
   const int jmax = g.ny + HY - 1;
   const bool met_thread = tid < NSCALMET;
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(NT, 4) void scalar_kappa_faces_kernel(Geo g, int gx
   bool chas[2], ehas[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
-    const int e = tid + q * NT;
+    const int e = tid + q * NTS;
     chas[q] = e < CN;
     {
       const int ly = e / CX, lx = e - ly * CX;
@@ -217,16 +221,16 @@ __global__ __launch_bounds__(NT, 4) void scalar_kappa_faces_kernel(Geo g, int gx
   };
   auto commit_c = [&](int buf) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) if (chas[q]) sc[buf][tid + q * NT] = rc[q];
+    for (int q = 0; q < 2; ++q) if (chas[q]) sc[buf][tid + q * NTS] = rc[q];
   };
   auto commit_co = [&](int off) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) if (chas[q]) scf_[off + tid + q * NT] = rc[q];
+    for (int q = 0; q < 2; ++q) if (chas[q]) scf_[off + tid + q * NTS] = rc[q];
   };
   auto commit_eo = [&](int off) {
     if (!LES) return;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) if (ehas[q]) sef_[off + tid + q * NT] = re[q];
+    for (int q = 0; q < 2; ++q) if (ehas[q]) sef_[off + tid + q * NTS] = re[q];
   };
   auto load_e = [&](int k) {
     if (!LES) return;
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(NT, 4) void scalar_kappa_faces_kernel(Geo g, int gx
   auto commit_e = [&](int buf) {
     if (!LES) return;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) if (ehas[q]) se[buf][tid + q * NT] = re[q];
+    for (int q = 0; q < 2; ++q) if (ehas[q]) se[buf][tid + q * NTS] = re[q];
   };
   for (int d = 0; d < 5; ++d) { load_c(k0 - 2 + d); commit_c(d); }
   for (int d = 0; d < 3; ++d) { load_e(k0 - 1 + d); commit_e(d); }
@@ -251,25 +255,30 @@ __global__ __launch_bounds__(NT, 4) void scalar_kappa_faces_kernel(Geo g, int gx
   for (int d = 0; d < NEB; ++d) eo[d] = d * EN;
   double *const scf = &sc[0][0];
   double *const sef = &se[0][0];
-  const int own_c = (ty + 2) * CX + (tx + 2), own_e = (ty + 1) * EX + (tx + 1);
-  const long own = (long)(i % g.nx) + (long)g.sy * (min(j, jmax) + HY);
+  const int oty = own ? ty : 0;
+  const int own_c = (oty + 2) * CX + (tx + 2), own_e = (oty + 1) * EX + (tx + 1);
+  const long owng = (long)(i % g.nx) + (long)g.sy * (min(j, jmax) + HY);
   // the extra faces: wave xw, lanes 0..MY-1 -> x-face MX of row lane; wave yw, lanes 0..MX-1 -> y-face MY of column lane
   // (the two waves rotate with the block so that no SIMD always hosts the longer ones)
+  // ONE wave per workgroup (rotating with the block) evaluates all 40 of them in a single pass: lanes 0..MX-1 the y-faces,
+  // lanes MX..MX+MY-1 the x-faces (two passes in two waves cost a whole wave's issue time each, for 8 and 32 lanes)
   const int wave = tid >> 6, lane = tid & 63;
-  const int xw = Lb & 3, yw = (Lb + 2) & 3;
-  const bool xrole = wave == xw && lane < MY, yrole = wave == yw && lane < MX;
-  const int xr_c = (lane + 2) * CX + (MX + 2), yr_c = (MY + 2) * CX + (lane + 2);
-  const long xr_g = (long)((i0 + MX) % g.nx) + (long)g.sy * (min(j0 + lane, jmax) + HY);
-  const long yr_g = (long)((i0 + lane) % g.nx) + (long)g.sy * (min(j0 + MY, jmax) + HY);
+  const bool erole = wave == (W5 ? 4 : (int)(Lb & 3)) && lane < MX + MY;
+  const bool ex = lane >= MX;                      // this lane's extra face is an x-face (row lane - MX), else a y-face (column lane)
+  const int el = ex ? lane - MX : lane;
+  const int er_c = ex ? (el + 2) * CX + (MX + 2) : (MY + 2) * CX + (el + 2);      // the cell on the high side of the face
+  const int er_s = ex ? 1 : CX;                                                    // stride towards the low side
+  const long er_g = ex ? (long)((i0 + MX) % g.nx) + (long)g.sy * (min(j0 + el, jmax) + HY)
+                       : (long)((i0 + el) % g.nx) + (long)g.sy * (min(j0 + MY, jmax) + HY);
   const double dxi = m.dxi, dx = m.dx, dyi = m.dyi;
   const double top = gh == 1 ? 1. : 0.;
 
   __syncthreads();
   // what crosses a face is (face value) x (face velocity): the product is shared, so each thread needs the velocities
   // on its own low faces only; those of the next level are fetched one level ahead like the staged planes
-  const double wl0 = w[g.sz * (long)(k0 + HZ) + own];
+  const double wl0 = own ? w[g.sz * (long)(k0 + HZ) + owng] : 0.;
   double pzl = 0.;      // face value x w on the low z side of the own cell at level k
-  if (k0 >= 1) {
+  if (own && k0 >= 1) {
     const int k = k0, kf = k + 1;
     double kzm2 = sc[0][own_c], kzm1 = sc[1][own_c], kzp1 = sc[3][own_c];
     const double c0 = sc[2][own_c];
@@ -279,17 +288,17 @@ __global__ __launch_bounds__(NT, 4) void scalar_kappa_faces_kernel(Geo g, int gx
     }
     pzl = face(wl0, kzm2, kzm1, c0, kzp1, m.dzhi[kf - 1 < 1 ? 1 : kf - 1], m.dzhi[kf], m.dzhi[kf + 1], m.dzf[kf]) * wl0;
   }
-  double nu, nv, nw, nx_ = 0., ny_ = 0.;
+  double nu = 0., nv = 0., nw = 0., ne_ = 0.;
+  const double *const evel = ex ? u : v;
   auto load_vel = [&](int k) {
     const long pb = g.sz * (long)(k + HZ);
-    nu = u[pb + own]; nv = v[pb + own]; nw = w[pb + own + g.sz];
-    if (xrole) nx_ = u[pb + xr_g];
-    if (yrole) ny_ = v[pb + yr_g];
+    if (own) { nu = u[pb + owng]; nv = v[pb + owng]; nw = w[pb + owng + g.sz]; }
+    if (erole) ne_ = evel[pb + er_g];
   };
   load_vel(k0);
   for (int k = k0; k < k1; ++k) {
     const int fb = k & 1;
-    const double ul = nu, vl = nv, wh = nw, ux = nx_, vy = ny_;
+    const double ul = nu, vl = nv, wh = nw, ve = ne_;
     if (k + 1 < k1) {
       commit_co(co[5]);
       commit_eo(eo[3]);
@@ -309,14 +318,22 @@ __global__ __launch_bounds__(NT, 4) void scalar_kappa_faces_kernel(Geo g, int gx
 #pragma unroll
     for (int d = 0; d < 3; ++d) A.eb[d] = LES ? sef + eo[d] + own_e : nullptr;
     const double *pl = scf + co[2];
-    const double t0 = (FRESH || !inside) ? 0. : cp[pb + own];
+    const double t0 = (FRESH || !inside) ? 0. : cp[pb + owng];
+    double pxl = 0., pyl = 0., pzh = 0., dif = 0.;
+    if (own) {
     const double c0 = pl[own_c];
-    const double pxl = face(ul, pl[own_c - 2], pl[own_c - 1], c0, pl[own_c + 1], dxi, dxi, dxi, dx) * ul;
-    const double pyl = face(vl, pl[own_c - 2 * CX], pl[own_c - CX], c0, pl[own_c + CX], 1., 1., 1., 1.) * vl;
+    pxl = face(ul, pl[own_c - 2], pl[own_c - 1], c0, pl[own_c + 1], dxi, dxi, dxi, dx) * ul;
+    pyl = face(vl, pl[own_c - 2 * CX], pl[own_c - CX], c0, pl[own_c + CX], 1., 1., 1., 1.) * vl;
     sfx[fb][ty][tx] = pxl;
     sfy[fb][ty][tx] = pyl;
-    if (xrole) sfx[fb][lane][MX] = face(ux, pl[xr_c - 2], pl[xr_c - 1], pl[xr_c], pl[xr_c + 1], dxi, dxi, dxi, dx) * ux;
-    if (yrole) sfy[fb][MY][lane] = face(vy, pl[yr_c - 2 * CX], pl[yr_c - CX], pl[yr_c], pl[yr_c + CX], 1., 1., 1., 1.) * vy;
+    }
+    if (erole) {
+      const double hh = ex ? dxi : 1., df = ex ? dx : 1.;
+      const double f = face(ve, pl[er_c - 2 * er_s], pl[er_c - er_s], pl[er_c], pl[er_c + er_s], hh, hh, hh, df) * ve;
+      if (ex) sfx[fb][el][MX] = f; else sfy[fb][MY][el] = f;
+    }
+    if (own) {
+    const double c0 = pl[own_c];
     // z: the high face (faces kb+1..ke+1; no flux through the floor, src/modadvection.f90:385); operands as scalar_tend
     double kzm1 = A.c(0, 0, -1), kzp1 = A.c(0, 0, 1), kzp2 = A.c(0, 0, 2);
     if (gh) {
@@ -324,9 +341,11 @@ __global__ __launch_bounds__(NT, 4) void scalar_kappa_faces_kernel(Geo g, int gx
       if (k == g.nz - 1) { kzp1 = top * c0; kzp2 = top * c0; }
       if (k == g.nz - 2) kzp2 = top * kzp1;
     }
-    const double pzh = face(wh, kzm1, c0, kzp1, kzp2, lm.get(4), lm.get(5), lm.get(6), lm.get(2)) * wh;
-    const double dif = scalar_tend<0, true, LES>(A, m, lm, k, g.nz, 0., 0., 0., 0., 0., 0., 0., cekh, dfac, 0);
+    pzh = face(wh, kzm1, c0, kzp1, kzp2, lm.get(4), lm.get(5), lm.get(6), lm.get(2)) * wh;
+    dif = scalar_tend<0, true, LES>(A, m, lm, k, g.nz, 0., 0., 0., 0., 0., 0., 0., cekh, dfac, 0);
+    }
     __syncthreads();
+    if (own) {
     const double pxh = sfx[fb][ty][tx + 1], pyh = sfy[fb][ty + 1][tx];
     double t = t0;
     t = (t + (-pxh * dxi)) + pxl * dxi;
@@ -338,7 +357,8 @@ __global__ __launch_bounds__(NT, 4) void scalar_kappa_faces_kernel(Geo g, int gx
       t = (t + upper) + lower;
     }
     t = t + dif;
-    if (inside) NT_STORE(t, &cp[pb + own]);      // written once, read by the integration from memory
+    if (inside) NT_STORE(t, &cp[pb + owng]);      // written once, read by the integration from memory
+    }
     pzl = pzh;
     {
       const int c0_ = co[0];
@@ -384,7 +404,10 @@ bool k_scalar_fused_lds(udc_handle *h, int n, bool fresh, int *rc) {
   double *cp = h->fields[UDC_SVP + 3 * n];
   const bool les = h->p.sgs != UDC_SGS_DNS, cd2 = h->slot[n].adv == 2;
   const int gh = h->slot[n].kappa_ghosts;
-#define LF(L, F) hipLaunchKernelGGL((scalar_kappa_faces_kernel<L, F>), gr, b, 0, h->stream, g, gx, tiles, h->m, cekh, dfac, u, v, w, ekh, c, cp, gh, kc)
+  static const bool w5 = getenv("UDC_KAPPA_W5") && atoi(getenv("UDC_KAPPA_W5")) != 0;
+  const dim3 b5(MX, MY + 2, 1);
+#define LF(L, F) do { if (w5) hipLaunchKernelGGL((scalar_kappa_faces_kernel<L, F, true>), gr, b5, 0, h->stream, g, gx, tiles, h->m, cekh, dfac, u, v, w, ekh, c, cp, gh, kc); \
+                      else hipLaunchKernelGGL((scalar_kappa_faces_kernel<L, F, false>), gr, b, 0, h->stream, g, gx, tiles, h->m, cekh, dfac, u, v, w, ekh, c, cp, gh, kc); } while (0)
 #define LS(A, L, F) hipLaunchKernelGGL((scalar_lds_kernel<A, L, F, 1>), gr, b, 0, h->stream, g, gx, tiles, h->m, cekh, dfac, u, v, w, ekh, c, cp, c, cp, gh, kc)
   {
     PROF(h, cd2 ? "scalar_lds_cd2" : "scalar_kappa_faces");
