@@ -405,9 +405,10 @@ bool k_scalar_fused_lds(udc_handle *h, int n, bool fresh, int *rc) {
   const bool les = h->p.sgs != UDC_SGS_DNS, cd2 = h->slot[n].adv == 2;
   const int gh = h->slot[n].kappa_ghosts;
   static const bool w5 = getenv("UDC_KAPPA_W5") && atoi(getenv("UDC_KAPPA_W5")) != 0;
+  static const int ldspad = getenv("UDC_KAPPA_LDSPAD") ? atoi(getenv("UDC_KAPPA_LDSPAD")) : 0;      // occupancy experiments: unused dynamic LDS
   const dim3 b5(MX, MY + 2, 1);
-#define LF(L, F) do { if (w5) hipLaunchKernelGGL((scalar_kappa_faces_kernel<L, F, true>), gr, b5, 0, h->stream, g, gx, tiles, h->m, cekh, dfac, u, v, w, ekh, c, cp, gh, kc); \
-                      else hipLaunchKernelGGL((scalar_kappa_faces_kernel<L, F, false>), gr, b, 0, h->stream, g, gx, tiles, h->m, cekh, dfac, u, v, w, ekh, c, cp, gh, kc); } while (0)
+#define LF(L, F) do { if (w5) hipLaunchKernelGGL((scalar_kappa_faces_kernel<L, F, true>), gr, b5, ldspad, h->stream, g, gx, tiles, h->m, cekh, dfac, u, v, w, ekh, c, cp, gh, kc); \
+                      else hipLaunchKernelGGL((scalar_kappa_faces_kernel<L, F, false>), gr, b, ldspad, h->stream, g, gx, tiles, h->m, cekh, dfac, u, v, w, ekh, c, cp, gh, kc); } while (0)
 #define LS(A, L, F) hipLaunchKernelGGL((scalar_lds_kernel<A, L, F, 1>), gr, b, 0, h->stream, g, gx, tiles, h->m, cekh, dfac, u, v, w, ekh, c, cp, c, cp, gh, kc)
   {
     PROF(h, cd2 ? "scalar_lds_cd2" : "scalar_kappa_faces");
