@@ -66,10 +66,10 @@ print("kernels:", len(summary), "stats rows:", len(rows))
 # ---- bench.py's traffic file (profiles/pmc_traffic.json): kernels keyed by workload and by bench.py's profile names.
 # WORKLOAD_KEY = "<nx>x<nyl>x<nz>/<sgs>/nsv<n>" (bench.py's key), CELLS = cells per GPU; both set by collect.sh
 # momentum: 88 B on RK stages 2 and 3, 64 B on stage 1 (um aliases u0 and is not read): 80 B averaged over whole RK3 steps
-ALGO = {"closure": 40, "mom_truetruetruetrue": 80, "div_rhs": 32, "thomas": 24, "project_integrate": 72, "scalar": 48}
+ALGO = {"closure": 40, "mom_truetruetruetrue": 80, "div_rhs": 32, "thomas": 24, "project_integrate": 72, "scalar": 48, "scalar_kappa_faces": 48, "scalar_lds_cd2": 48}
 MAP = [("closure_lds_kernel", "closure"), ("mom_lds_kernel", "mom_truetruetruetrue"), ("div_rhs_kernel", "div_rhs"),
        ("thomas_lds_kernel", "thomas"), ("thomas_kernel", "thomas"), ("integrate_kernel", "project_integrate"),
-       ("scalar_kernel", "scalar")]
+       ("scalar_kernel", "scalar"), ("scalar_kappa_faces_kernel", "scalar_kappa_faces"), ("scalar_lds_kernel", "scalar_lds_cd2")]
 key = os.environ.get("WORKLOAD_KEY", "256x256x256/vreman/nsv0")
 cells = int(os.environ.get("CELLS", str(256 ** 3)))
 nsv = int(key.rsplit("nsv", 1)[1])

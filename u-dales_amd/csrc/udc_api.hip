@@ -1055,6 +1055,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   // y-slabs: the rows next to the neighbouring ranks first; the ghost rows of the new velocities and of pres0 travel while the rows
   // in between are integrated (the exchange names the arrays as they will be known after the pointer rotation below)
   const bool ov_int = !fold && halo_overlap(h, tile_grid(h->g).gy);
+  bool ov_scal = false;
   if (ov_int) {
     if (k_project_integrate(h, rk3step, dt, !lds, pup, fold, !skip_um, rotate, 1)) return 1;
     int f[8];
@@ -1068,6 +1069,11 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
       ptr[q] = h->fields[id];
     }
     if (k_halo_y_begin(h, f, nf, 1, ptr)) return 1;
+    // the transported scalars' two ghost rows behind them on the same stream (not on a chemistry step: k_chem below edits them first)
+    std::vector<int> sc;
+    scalar_halo_list(h, rk3step, sc);
+    ov_scal = !sc.empty() && sc.size() <= 16 && !(h->lchem && rk3step == 3);
+    if (ov_scal && k_halo_y_begin(h, sc.data(), (int)sc.size(), 2)) return 1;
     if (k_project_integrate(h, rk3step, dt, !lds, pup, fold, !skip_um, rotate, 2)) return 1;
     if (k_halo_y_join(h)) return 1;
   } else if (k_project_integrate(h, rk3step, dt, !lds, pup, fold, !skip_um, rotate)) return 1;
@@ -1087,7 +1093,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   }
   std::vector<int> s;
   scalar_halo_list(h, rk3step, s);
-  if (!s.empty() && k_halo_y(h, s.data(), (int)s.size(), 2)) return 1;
+  if (!s.empty() && !ov_scal && k_halo_y(h, s.data(), (int)s.size(), 2)) return 1;
   if (!fold || !h->slots.empty()) { if (k_top_bottom(h)) return 1; }
   if (k_scalar_bcx_outlet(h)) return 1;
   h->halos_fresh = h->boundary_fresh = true;
