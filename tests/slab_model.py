@@ -120,3 +120,55 @@ def poisson_slab_model(rhs_local: np.ndarray, dx, dy, dzf, dzh, dist, rank: int,
     specB = np.fft.ifft(x, axis=2) * ny
     specA = unpack_bwd(alltoall(pack_bwd(specB, nranks), dist, nranks), nkx)
     return np.fft.irfft(specA, n=nx, axis=2) * nx
+
+
+# ---------------------------------------------------------------- split launches (udc_internal.h: TileGrid row subsets, udc_halo.hip)
+def tile_rows(gy_full: int, e: int, edge: bool):
+    """TileGrid of a split launch as (gy, y0, ysplit, yjump): edge = the first and last `e` tile rows, else the rows in between."""
+    if edge:
+        return 2 * e, 0, e, gy_full - 2 * e
+    return gy_full - 2 * e, e, 1 << 30, 0
+
+
+def tile_row(t, b: int) -> int:
+    """local tile row b of a launch -> tile row of the slab (tile_row in udc_internal.h)"""
+    gy, y0, ysplit, yjump = t
+    return y0 + b + (yjump if b >= ysplit else 0)
+
+
+def produce_and_exchange_split(a: np.ndarray, width: int, tile_h: int, dist, rank: int, nranks: int) -> np.ndarray:
+    """What k_closure_lds(rows = 1) -> k_halo_y_begin -> k_closure_lds(rows = 2) -> k_halo_y_join do, on a [k, j, i] array `a` with one
+    valid ghost row on each side: a 3-point y stencil b[j] = a[j-1] - 2 a[j] + a[j+1] evaluated over the edge tile rows first, the
+    ghost rows of b posted (not waited for), the interior tile rows evaluated, then the wait and the unpack.  -> b with `width` ghost
+    rows.  The interior evaluation must not touch a row the exchange reads or writes (asserted)."""
+    import torch
+    nz, nyg, nx = a.shape
+    nyl = nyg - 2
+    gy = (nyl + tile_h - 1) // tile_h
+    assert gy >= 3
+    b = np.full((nz, nyl + 2 * width, nx), np.nan)
+
+    def sweep(t):
+        rows = []
+        for bl in range(t[0]):
+            r = tile_row(t, bl)
+            for j in range(r * tile_h, min((r + 1) * tile_h, nyl)):
+                b[:, width + j, :] = a[:, j, :] - 2. * a[:, j + 1, :] + a[:, j + 2, :]
+                rows.append(j)
+        return rows
+    edge_rows = sweep(tile_rows(gy, 1, True))
+    prev, nxt = (rank - 1) % nranks, (rank + 1) % nranks
+    to_prev = torch.from_numpy(np.ascontiguousarray(b[:, width:2 * width, :]))
+    to_next = torch.from_numpy(np.ascontiguousarray(b[:, -2 * width:-width, :]))
+    assert not np.isnan(to_prev.numpy()).any() and not np.isnan(to_next.numpy()).any()      # the edge launch wrote what travels
+    from_prev, from_next = torch.empty_like(to_next), torch.empty_like(to_prev)
+    reqs = [dist.isend(to_prev, prev, tag=11), dist.isend(to_next, nxt, tag=12),
+            dist.irecv(from_next, nxt, tag=11), dist.irecv(from_prev, prev, tag=12)]
+    inner_rows = sweep(tile_rows(gy, 1, False))
+    assert sorted(edge_rows + inner_rows) == list(range(nyl))                                # every row exactly once
+    assert min(inner_rows) >= width and max(inner_rows) < nyl - width                        # the interior launch stays off the travelling rows
+    for r in reqs:
+        r.wait()
+    b[:, :width, :] = from_prev.numpy()
+    b[:, -width:, :] = from_next.numpy()
+    return b

@@ -30,6 +30,18 @@ def _worker(rank, world, port, tmp):
     slab.halo_exchange(a, 2, dist, rank, world)
     np.testing.assert_array_equal(a[:, :2, :], full[:, [(j0 - 2) % ny, (j0 - 1) % ny], :])
     np.testing.assert_array_equal(a[:, -2:, :], full[:, [j1 % ny, (j1 + 1) % ny], :])
+    # --- a producer launched edge rows first, its ghost rows travelling while the interior rows are swept (closure / integrate split)
+    nyw = 16 * world
+    fullw = rng.standard_normal((nz, nyw, nx))
+    jw0 = rank * 16
+    aw = np.zeros((nz, 16 + 2, nx))
+    aw[:, 1:-1, :] = fullw[:, jw0:jw0 + 16, :]
+    slab.halo_exchange(aw, 1, dist, rank, world)
+    bw = slab.produce_and_exchange_split(aw, 1, 4, dist, rank, world)
+    bfull = np.roll(fullw, 1, axis=1) - 2. * fullw + np.roll(fullw, -1, axis=1)
+    np.testing.assert_array_equal(bw[:, 1:-1, :], bfull[:, jw0:jw0 + 16, :])
+    np.testing.assert_array_equal(bw[:, 0, :], bfull[:, (jw0 - 1) % nyw, :])
+    np.testing.assert_array_equal(bw[:, -1, :], bfull[:, (jw0 + 16) % nyw, :])
     # --- cold-start noise is a function of the global index only
     np.testing.assert_array_equal(lcg_noise(nx, ny, j0, nyl, 3), lcg_noise(nx, ny, 0, ny, 3)[j0:j1])
     # --- distributed Poisson solve == single-rank oracle
@@ -62,6 +74,18 @@ def test_slab_exchange_patterns_gloo(world, tmp_path):
     got = np.concatenate([np.load(tmp_path / f"p_{r}.npy") for r in range(world)], axis=1)
     ref = p[1:-1, 1:-1, 1:-1]
     assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+def test_split_launch_rows_cover_the_slab_once():
+    """tile_rows / tile_row (udc_internal.h, mirrored in slab_model.py): the edge launch and the interior launch together visit
+    every tile row of the slab exactly once, for every split the library makes (e = 1)."""
+    sys.path[:0] = [os.path.join(ROOT, "tests")]
+    import slab_model as slab
+    for gy in range(3, 40):
+        edge, inner = slab.tile_rows(gy, 1, True), slab.tile_rows(gy, 1, False)
+        rows = [slab.tile_row(edge, b) for b in range(edge[0])] + [slab.tile_row(inner, b) for b in range(inner[0])]
+        assert sorted(rows) == list(range(gy)), gy
+        assert [slab.tile_row(edge, b) for b in range(edge[0])] == [0, gy - 1]
 
 
 def test_slab_index_maps_roundtrip():
