@@ -21,6 +21,7 @@
 tests/integration/ibm_sparse_input/*_X_Y.txt: not runnable over a y-slab stand-in; runmode 1003 only prints pencil extents.)"""
 import gzip
 import os
+import re
 import subprocess
 
 import numpy as np
@@ -50,7 +51,6 @@ def stage(tmp, deck, nprocy=1, steps=None):
             o.write(f.read())
     with gzip.open(os.path.join(CASE, deck + ".gz"), "rt") as f:
         txt = f.read()
-    import re
     txt = re.sub(r"nprocy\s*=\s*\d+", f"nprocy       = {nprocy}", txt)
     assert re.search(r"nprocx\s*=\s*1\b", txt)
     if steps is not None:      # a longer variant of the one-step deck: `steps` steps of dtmax, one tdump record at the end
