@@ -90,6 +90,29 @@ def test_operator_test_of_the_reference_over_the_mpi_stand_in(P, tmp_path):
     assert "ALL TESTS PASSED: tests_mpi_operators" in r.stdout and "FAIL" not in r.stdout
 
 
+@pytest.mark.parametrize("P", [1, 2])
+def test_pencil_extents_of_the_decomposition_stand_in(P, tmp_path):
+    """runmode 1003 (src/tests.f90:30-41, tests_2decomp_init_exit): the reference prints 2DECOMP's xstart .. zsize after its own
+    start-up.  Over the stand-in: one rank owns 1..128 in every direction; with nprocy = 2 every pencil of rank r holds rows
+    64 r + 1 .. 64 r + 64 (the stand-in keeps y-slabs in all three orientations)."""
+    exe = FULL if P == 1 else FULL_MPI
+    if not os.path.exists(exe) or (P > 1 and not os.path.exists(MPIEXEC)):
+        pytest.skip("oracle/_ref/udales_full(_mpi) or MPICH not available")
+    stage(tmp_path, "namoptions.1005.serial", nprocy=P)
+    deck = tmp_path / "namoptions.100"
+    deck.write_text(re.sub(r"runmode\s*=\s*1005", "runmode      = 1003", deck.read_text()))
+    r = run(tmp_path, exe, P)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+    rows = [tuple(int(v) for v in ln.split()) for ln in r.stdout.splitlines() if re.fullmatch(r"\s*\d+\s+\d+\s+\d+\s*", ln)]
+    assert len(rows) == 9 * P, r.stdout[-1500:]
+    if P == 1:
+        assert rows == [(1, 1, 1)] * 3 + [(128, 128, 128)] * 6
+    else:
+        starts = sorted(set(rows[q] for q in range(len(rows)) if rows[q][0] == 1 and rows[q][2] == 1 and rows[q][1] in (1, 65)))
+        assert starts == [(1, 1, 1), (1, 65, 1)], rows
+        assert (128, 64, 128) in rows and (128, 128, 128) in rows      # sizes and the upper rank's ends
+
+
 @pytest.mark.gpu
 def test_operator_test_of_the_reference_over_the_dropin_modules(tmp_path):
     if not os.path.exists(DROPIN):
