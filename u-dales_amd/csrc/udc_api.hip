@@ -1038,25 +1038,41 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   // the ghost row of vp that fillps' divergence reads: folded into the kernels above when the slab is the whole domain --
   // except for the immersed-boundary routines, which edit listed points only (a solid v point in the first row of the
   // domain has its periodic image in the ghost row)
-  if (!fold || (h->ibm_on && (ops & (OP_IBMWALL | OP_IBMNORM)))) {
-    const int fvp[1] = {UDC_VP};
-    if (k_halo_y(h, fvp, 1, 1)) return 1;
-  }
   // slab path with the own line FFTs: fillps' divergence is evaluated inside the x forward transform (udc_fft.hip)
   h->div_in_fft = pup && h->slab && h->fft_fused && !h->no_div_in_fft;
+  if (!fold || (h->ibm_on && (ops & (OP_IBMWALL | OP_IBMNORM)))) {
+    const int fvp[1] = {UDC_VP};
+    // y-slabs with the divergence inside the x transform: the row travels while all but the last row group of the first k-chunk
+    // are transformed (k_poisson_solve_slab joins)
+    if (h->div_in_fft && halo_overlap(h, 3) && fft_x_row_groups(h) >= 2) {
+      if (k_halo_y_begin(h, fvp, 1, 1)) return 1;
+      h->vp_halo_pending = true;
+    } else if (k_halo_y(h, fvp, 1, 1)) return 1;
+  }
   if (!h->div_in_fft && k_divergence_rhs(h, rk3coef, pup)) return 1;
   if (k_poisson_solve(h)) return 1;
   h->div_in_fft = false;
+  if (h->vp_halo_pending) { if (k_halo_y_join(h)) return 1; h->vp_halo_pending = false; }      // (no path leaves it pending)
+  const int gyI = tile_grid(h->g).gy;
+  // y-slabs: p's ghost row (the projection of the slab's first row reads it) travels while a first part of the interior rows is
+  // integrated; those rows need neither it nor anything the edge launch writes
+  const bool ov_p = !fold && halo_overlap(h, gyI) && gyI >= 4;
   if (!fold) {
     const int fp[1] = {UDC_P};
-    if (k_halo_y(h, fp, 1, 1)) return 1;
+    if (ov_p) { if (k_halo_y_begin(h, fp, 1, 1)) return 1; }
+    else if (k_halo_y(h, fp, 1, 1)) return 1;
   }
   const bool skip_um = alias_ok && rk3step == 3;
   // y-slabs: the rows next to the neighbouring ranks first; the ghost rows of the new velocities and of pres0 travel while the rows
   // in between are integrated (the exchange names the arrays as they will be known after the pointer rotation below)
-  const bool ov_int = !fold && halo_overlap(h, tile_grid(h->g).gy);
+  const bool ov_int = !fold && halo_overlap(h, gyI);
   bool ov_scal = false;
   if (ov_int) {
+    const int rb = ov_p ? 1 + std::max(1, (gyI - 2) / 4) : 1;      // interior tile rows [1, rb) first, [rb, gyI - 1) last
+    if (ov_p) {
+      if (k_project_integrate(h, rk3step, dt, !lds, pup, fold, !skip_um, rotate, 3, 1, rb)) return 1;
+      if (k_halo_y_join(h)) return 1;
+    }
     if (k_project_integrate(h, rk3step, dt, !lds, pup, fold, !skip_um, rotate, 1)) return 1;
     int f[8];
     int nf = vel_fields(h, skip_um ? 0 : rk3step, f);
@@ -1074,7 +1090,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
     scalar_halo_list(h, rk3step, sc);
     ov_scal = !sc.empty() && sc.size() <= 16 && !(h->lchem && rk3step == 3);
     if (ov_scal && k_halo_y_begin(h, sc.data(), (int)sc.size(), 2)) return 1;
-    if (k_project_integrate(h, rk3step, dt, !lds, pup, fold, !skip_um, rotate, 2)) return 1;
+    if (rb < gyI - 1 && k_project_integrate(h, rk3step, dt, !lds, pup, fold, !skip_um, rotate, 4, rb, gyI - 1)) return 1;
     if (k_halo_y_join(h)) return 1;
   } else if (k_project_integrate(h, rk3step, dt, !lds, pup, fold, !skip_um, rotate)) return 1;
   h->dthv_top_on = false;

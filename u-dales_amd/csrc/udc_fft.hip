@@ -103,6 +103,7 @@ struct XArgs {
   int nkx, cx, P;           // r2c modes nx/2+1, modes per rank, ranks
   int k0, nzc;              // chunk
   int lL;                   // log2 of the rows per workgroup
+  int jg0;                  // first row group of this launch (fftx_fwd_pack: the last group may follow vp's ghost row)
 };
 
 // LDS: two line buffers [L][MP], then the twiddles of the length-M transform [M], then the rank of every mode [cx*P]
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(xthreads(LM)) void fftx_fwd_pack_kernel(XArgs q, co
   double2 *a, *b, *tw; int *dmap;
   x_lds<LM>(q, lds, a, b, tw, dmap, twM);
   const int tid = threadIdx.x, L = 1 << q.lL;
-  const int j0 = blockIdx.x << q.lL, kc = blockIdx.y, k = q.k0 + kc;
+  const int j0 = (blockIdx.x + q.jg0) << q.lL, kc = blockIdx.y, k = q.k0 + kc;
   // load: row l holds M complex = nx reals, read as double2 (16-B aligned: nx even, rows nx*8 B apart, base 16-B aligned)
   for (int wi = tid; wi < (M << q.lL); wi += NTH) {
     const int l = wi >> LM, n = wi & (M - 1);
@@ -324,16 +325,21 @@ int fft_fused_init(udc_handle *h) {
 static XArgs xargs(const udc_handle *h, int k0, int nzc) {
   const Geo &g = h->g;
   const int M = g.nx / 2;
-  return XArgs{g.nx, M, padded(M + 1), g.ny, g.py, g.sy, g.sz, h->nkx, h->cx, h->cfg.nranks, k0, nzc, ilog2(h->fft_L)};
+  return XArgs{g.nx, M, padded(M + 1), g.ny, g.py, g.sy, g.sz, h->nkx, h->cx, h->cfg.nranks, k0, nzc, ilog2(h->fft_L), 0};
 }
 static YArgs yargs(const udc_handle *h, int k0, int nzc) {
   return YArgs{h->jtot, padded(h->jtot), h->g.ny, ilog2(h->g.ny), h->cx, h->cfg.nranks, k0, nzc, h->fft_C};
 }
 
-int fft_x_fwd_pack(udc_handle *h, int k0, int nzc, double *send) {
-  const XArgs q = xargs(h, k0, nzc);
+int fft_x_row_groups(const udc_handle *h) { return h->g.ny / h->fft_L; }
+
+// g0, g1: row groups [g0, g1) of the slab (fft_x_row_groups; g1 <= 0: all)
+int fft_x_fwd_pack(udc_handle *h, int k0, int nzc, double *send, int g0, int g1) {
+  XArgs q = xargs(h, k0, nzc);
   const double2 *tw = reinterpret_cast<const double2 *>(h->fft_tw);
-  const dim3 gr((unsigned)(q.nyl >> q.lL), (unsigned)nzc);
+  if (g1 <= 0) { g0 = 0; g1 = q.nyl >> q.lL; }
+  q.jg0 = g0;
+  const dim3 gr((unsigned)(g1 - g0), (unsigned)nzc);
   const size_t lds = x_lds_bytes(h, h->fft_L);
   const DivArgs dv{h->fields[UDC_UP], h->fields[UDC_VP], h->fields[UDC_WP], h->m.dzfi, h->m.dxi, h->m.dyi, h->g.nz};
   if (h->div_in_fft) {

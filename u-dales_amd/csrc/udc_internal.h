@@ -76,6 +76,11 @@ inline TileGrid tile_grid(const Geo &g) {
   TileGrid t; t.gx = (g.nx + TX - 1) / TX; t.gy = (g.ny + TY - 1) / TY; t.tiles = t.gx * t.gy; return t;
 }
 // rows of a split launch: edge = the first and last `e` tile rows of `full`, otherwise the rows in between (full.gy > 2 e)
+inline TileGrid tile_range(const TileGrid &full, int r0, int r1) {      // the tile rows [r0, r1)
+  TileGrid t = full;
+  t.gy = r1 - r0; t.y0 = r0; t.tiles = t.gx * t.gy;
+  return t;
+}
 inline TileGrid tile_rows(const TileGrid &full, int e, bool edge) {
   TileGrid t = full;
   if (edge) { t.gy = 2 * e; t.y0 = 0; t.ysplit = e; t.yjump = full.gy - 2 * e; }
@@ -317,6 +322,7 @@ struct udc_handle {
   hipStream_t comm_stream = nullptr;    // all-to-all exchanges run here, overlapped with rocFFT on `stream`
   hipEvent_t ev_ready[16] = {}, ev_done[16] = {};
   hipEvent_t ev_halo_ready = nullptr, ev_halo_done = nullptr;      // k_halo_y_begin / _join
+  bool vp_halo_pending = false;         // vp's ghost row is travelling (k_halo_y_begin): the x forward transform joins before its last row group
   bool no_halo_overlap = false;         // UDC_HALO_OVERLAP=0: every ghost-row exchange in line on the compute stream
   double *specA = nullptr, *specB = nullptr, *a2a_send = nullptr, *a2a_recv = nullptr;
   double *ev_slab = nullptr, *ztab_slab = nullptr;
@@ -388,9 +394,9 @@ int k_poisson_solve(udc_handle *h);
 int k_project(udc_handle *h);                       // tderive: up,vp,wp -= grad p ; pres0 += p
 int k_integrate(udc_handle *h, int rk3step, double dt);
 int k_project_integrate(udc_handle *h, int rk3step, double dt, bool zero_tend, bool pup, bool ghosts,
-                        bool write_um = true, bool out_to_um = false, int rows = 0);   // fused tderive + tstep_integrate
+                        bool write_um = true, bool out_to_um = false, int rows = 0, int r0 = 0, int r1 = 0);   // fused tderive + tstep_integrate
 // rows (k_closure_lds, k_project_integrate): 0 all tile rows of the slab, 1 only the tile rows next to the neighbouring ranks,
-// 2 only the rows in between (see halo_overlap_rows)
+// 2 only the rows in between; k_project_integrate also 3 / 4: the tile rows [r0, r1) (3: profiled with the edge launch)
 int k_halo_y(udc_handle *h, const int *fields, int nf, int width);
 // the same exchange beside the compute stream: _begin queues pack, exchange and unpack on the communication stream behind what
 // the compute stream holds so far; _join makes the compute stream wait for it.  `ptrs` (optional): the arrays, where the caller
@@ -435,7 +441,8 @@ int pois_slab_init(udc_handle *h);
 int k_poisson_solve_slab(udc_handle *h);
 bool fft_fused_possible(const udc_handle *h);
 int fft_fused_init(udc_handle *h);
-int fft_x_fwd_pack(udc_handle *h, int k0, int nzc, double *send);
+int fft_x_fwd_pack(udc_handle *h, int k0, int nzc, double *send, int g0 = 0, int g1 = 0);      // row groups [g0, g1); g1 <= 0: all
+int fft_x_row_groups(const udc_handle *h);
 int fft_x_bwd_unpack(udc_handle *h, int k0, int nzc, const double *recv);
 int fft_y_fwd_unpack(udc_handle *h, int k0, int nzc, const double *recv);
 int fft_y_bwd_pack(udc_handle *h, int k0, int nzc, double *send);

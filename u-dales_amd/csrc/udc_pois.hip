@@ -1304,8 +1304,19 @@ int k_poisson_solve_slab(udc_handle *h) {
     for (int c = 0; c < nch; ++c) {
       const int k0 = c * nzc;
       if (h->fft_fused) {
-        if (fft_x_fwd_pack(h, k0, nzc, h->a2a_send + chunk * c)) return 1;
+        const int G = fft_x_row_groups(h);
+        if (h->vp_halo_pending && G >= 2) {
+          // vp's ghost row (the divergence of the slab's last row reads it) is still travelling: every row group but the last first
+          if (fft_x_fwd_pack(h, k0, nzc, h->a2a_send + chunk * c, 0, G - 1)) return 1;
+          if (k_halo_y_join(h)) return 1;
+          h->vp_halo_pending = false;
+          if (fft_x_fwd_pack(h, k0, nzc, h->a2a_send + chunk * c, G - 1, G)) return 1;
+        } else {
+          if (h->vp_halo_pending) { if (k_halo_y_join(h)) return 1; h->vp_halo_pending = false; }
+          if (fft_x_fwd_pack(h, k0, nzc, h->a2a_send + chunk * c)) return 1;
+        }
       } else {
+        if (h->vp_halo_pending) { if (k_halo_y_join(h)) return 1; h->vp_halo_pending = false; }
         void *in[1] = {prow0 + g.sz * k0}, *out[1] = {specA_at(k0)};
         FFT_OK(rocfft_execute(h->plan_xf, in, out, h->info_x));
         hipLaunchKernelGGL(slab_pack_fwd_kernel, tg, tb, 0, h->stream, g, nkx, pitch, cx, P, k0, nzc,
@@ -1500,14 +1511,15 @@ int k_integrate(udc_handle *h, int rk3step, double dt) {
 }
 
 int k_project_integrate(udc_handle *h, int rk3step, double dt, bool zero_tend, bool pup, bool ghosts,
-                        bool write_um, bool out_to_um, int rows) {
+                        bool write_um, bool out_to_um, int rows, int r0, int r1) {
   const Geo &g = h->g;
   const dim3 b(64, 4, 1);
-  // rows 1 / 2: the tile rows next to the neighbouring ranks / the rows in between (the caller exchanges ghost rows in between)
-  const TileGrid tg = rows == 0 ? tile_grid(g) : tile_rows(tile_grid(g), 1, rows == 1);
+  // rows 1 / 2: the tile rows next to the neighbouring ranks / the rows in between (the caller exchanges ghost rows in between);
+  // 3 / 4: the tile rows [r0, r1)
+  const TileGrid tg = rows == 0 ? tile_grid(g) : (rows >= 3 ? tile_range(tile_grid(g), r0, r1) : tile_rows(tile_grid(g), 1, rows == 1));
   const dim3 gr((unsigned)tg.tiles * (unsigned)g.nz, 1, 1);
   const double rk3coef = dt / (4. - (double)rk3step);
-  PROF(h, rows == 1 ? "project_integrate_edge" : "project_integrate");
+  PROF(h, (rows == 1 || rows == 3) ? "project_integrate_edge" : "project_integrate");
   const int lastf = rk3step == 3 ? (write_um ? 3 : 2) : 0;
   IntArgs ia = int_args(h);
   if (out_to_um) { ia.u0 = ia.um; ia.v0 = ia.vm; ia.w0 = ia.wm; }   // pointer rotation at RK stage 1 (um_alias)
@@ -1521,7 +1533,7 @@ int k_project_integrate(udc_handle *h, int rk3step, double dt, bool zero_tend, b
     hipLaunchKernelGGL((integrate_kernel<true, false, false>), gr, b, 0, h->stream, g, tg, h->m, ia,
                        (const double *)h->fields[UDC_P], h->fields[UDC_PRES0], rk3coef, lastf, ghosts ? 1 : 0, h->p);
   HIP_OK(hipGetLastError());
-  if (rk3step == 3 && rows != 2 && copy_floor_planes(h, write_um)) return 1;      // (whole planes below the floor: once)
+  if (rk3step == 3 && (rows == 0 || rows == 1) && copy_floor_planes(h, write_um)) return 1;      // (whole planes below the floor: once)
   return 0;
 }
 
