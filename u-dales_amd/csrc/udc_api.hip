@@ -1003,9 +1003,29 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
       if (k_ek_ghosts(h)) return 1;
     }
     h->ek_stale = false;
-    if (lds ? k_momentum_lds(h, true, true, forces, true, pup ? 1. / rk3coef : 0., rotate)
-            : k_momentum(h, true, true, forces)) return 1;
+    // y-slabs, nothing between the sweep and the solve but the floor: the sweep is pipelined with the solve's k-chunks.  Tile row 0
+    // first over all levels (+ the floor on its rows): it holds the row of vp that the previous rank's divergence reads, which then
+    // travels; the other rows follow level range by level range from inside k_poisson_solve_slab, each ahead of the x forward
+    // transform of the same k-chunk -- so the forward all-to-all of chunk c runs under the sweep of the levels above it
+    const int gyM = momentum_lds_tile_rows(h->g);
+    const bool floor_on = (ops & OP_BOTTOM) && h->p.lbottom;
+    const bool pipe = h->slab && lds && pup && !h->no_mom_pipe && h->fft_fused && !h->no_div_in_fft && halo_overlap(h, gyM) &&
+                      h->slots.empty() && h->p.sgs != UDC_SGS_ONEEQN && !h->coriolis_mode && h->level_forcings.empty() &&
+                      !h->luvolflowr && !h->lvvolflowr && !h->ibm_on && h->shift_a == 0. && !h->thlpcar && !h->lbuoyancy &&
+                      fft_x_row_groups(h) >= 2 && h->g.nz / h->nch >= 4;
+    if (pipe) {
+      const MomPart row0{0, 1, 0, 0, true};
+      if (k_momentum_lds(h, true, true, forces, true, 1. / rk3coef, rotate, &row0)) return 1;
+      if (floor_on && k_bottom(h, false, 0, momentum_lds_tile_height())) return 1;
+      const int fvp[1] = {UDC_VP};
+      if (k_halo_y_begin(h, fvp, 1, 1)) return 1;
+      h->vp_halo_pending = true;
+      h->mom_pipe.active = true; h->mom_pipe.forces = forces; h->mom_pipe.um_is_u0 = rotate; h->mom_pipe.bottom = floor_on;
+      h->mom_pipe.rk3coefi = 1. / rk3coef;
+    } else if (lds ? k_momentum_lds(h, true, true, forces, true, pup ? 1. / rk3coef : 0., rotate)
+                   : k_momentum(h, true, true, forces)) return 1;
   }
+  const bool piped = h->mom_pipe.active;      // (then nothing below up to the solve has anything to do: see `pipe`)
   if (k_scalar_top_flux(h)) return 1;
   // thl (slot 15) and qt (13) share velocities and diffusivity: one sweep for both where their schemes agree
   bool paired = false;
@@ -1025,7 +1045,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   if (forces && h->thlpcar && k_level_source(h, 15, h->thlpcar)) return 1;
   if (forces && k_buoyancy(h)) return 1;        // additive on wp(kb+1..ke), hence on pwp
   // `bottom` (src/program.f90:152): additive on the k = kb tendencies, hence equally on pup = up + um/rk3coef
-  if ((ops & OP_BOTTOM) && h->p.lbottom && k_bottom(h, fold)) return 1;
+  if (!piped && (ops & OP_BOTTOM) && h->p.lbottom && k_bottom(h, fold)) return 1;
   if ((ops & OP_CORIOLIS) && k_coriolis(h, fold)) return 1;        // src/program.f90:158; wrap of vp's ghost row follows below
   if ((ops & OP_SHIFT) && k_shifted_pbcs(h, fold)) return 1;       // src/program.f90:144 (additive on the momentum tendencies)
   if ((ops & OP_LEV0) && !h->level_forcings.empty() && k_level_forcings(h, 0, fold)) return 1;   // lstend, nudge tables
@@ -1040,7 +1060,9 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   // domain has its periodic image in the ghost row)
   // slab path with the own line FFTs: fillps' divergence is evaluated inside the x forward transform (udc_fft.hip)
   h->div_in_fft = pup && h->slab && h->fft_fused && !h->no_div_in_fft;
-  if (!fold || (h->ibm_on && (ops & (OP_IBMWALL | OP_IBMNORM)))) {
+  if (piped) {
+    // (vp's row is already travelling)
+  } else if (!fold || (h->ibm_on && (ops & (OP_IBMWALL | OP_IBMNORM)))) {
     const int fvp[1] = {UDC_VP};
     // y-slabs with the divergence inside the x transform: the row travels while all but the last row group of the first k-chunk
     // are transformed (k_poisson_solve_slab joins)
@@ -1052,6 +1074,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   if (!h->div_in_fft && k_divergence_rhs(h, rk3coef, pup)) return 1;
   if (k_poisson_solve(h)) return 1;
   h->div_in_fft = false;
+  h->mom_pipe.active = false;
   if (h->vp_halo_pending) { if (k_halo_y_join(h)) return 1; h->vp_halo_pending = false; }      // (no path leaves it pending)
   const int gyI = tile_grid(h->g).gy;
   // y-slabs: p's ghost row (the projection of the slab's first row reads it) travels while a first part of the interior rows is
@@ -1117,6 +1140,19 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
     if (k_thermodynamics(h)) return 1;
     h->thermo_fresh = true;
   }
+  return 0;
+}
+
+// the momentum sweep's piece that feeds k-chunk c of the slab solve: tile rows 1 .. of levels [c nzc + 1, (c + 1) nzc + 1) (the x
+// forward transform of chunk c reads pwp one level up), from level 0 for c = 0 and to the top for the last; after the first piece the
+// floor on those rows (`bottom` acts on level kb only)
+int k_momentum_pipe_stage(udc_handle *h, int c) {
+  if (!h->mom_pipe.active) return 0;
+  const int nch = h->nch, nzc = h->g.nz / nch, gy = momentum_lds_tile_rows(h->g);
+  const int kbeg = c == 0 ? 0 : c * nzc + 1, kend = c == nch - 1 ? h->g.nz : (c + 1) * nzc + 1;
+  const MomPart part{1, gy, kbeg, kend, c != nch - 1};
+  if (k_momentum_lds(h, true, true, h->mom_pipe.forces, true, h->mom_pipe.rk3coefi, h->mom_pipe.um_is_u0, &part)) return 1;
+  if (c == 0 && h->mom_pipe.bottom && k_bottom(h, false, momentum_lds_tile_height(), -1)) return 1;
   return 0;
 }
 

@@ -322,6 +322,10 @@ struct udc_handle {
   hipStream_t comm_stream = nullptr;    // all-to-all exchanges run here, overlapped with rocFFT on `stream`
   hipEvent_t ev_ready[16] = {}, ev_done[16] = {};
   hipEvent_t ev_halo_ready = nullptr, ev_halo_done = nullptr;      // k_halo_y_begin / _join
+  // the momentum sweep pipelined with the slab solve (substep_fused, k_momentum_pipe_stage): tile row 0 is swept first over all
+  // levels, the other rows level range by level range ahead of the x forward transform of the same k-chunk
+  struct MomPipe { bool active = false, forces = false, um_is_u0 = false, bottom = false; double rk3coefi = 0.; } mom_pipe;
+  bool no_mom_pipe = false;             // UDC_MOM_PIPE=0
   bool vp_halo_pending = false;         // vp's ghost row is travelling (k_halo_y_begin): the x forward transform joins before its last row group
   bool no_halo_overlap = false;         // UDC_HALO_OVERLAP=0: every ghost-row exchange in line on the compute stream
   double *specA = nullptr, *specB = nullptr, *a2a_send = nullptr, *a2a_recv = nullptr;
@@ -373,7 +377,11 @@ int k_closure_lds(udc_handle *h, bool ghosts, bool write_ekh = true, int rows = 
 int k_ek_ghosts(udc_handle *h, bool exchange = true);
 int closure_lds_tile_rows(const Geo &g);      // tile rows of k_closure_lds over the slab
 int k_momentum(udc_handle *h, bool adv, bool diff, bool forces);       // direct-load version (UDC_MOM_SIMPLE=1)
-int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, double rk3coefi, bool um_is_u0 = false);  // rk3coefi != 0: PUP mode   // LDS-staged k-marching version (default)
+struct MomPart { int r0, r1, kbeg, kend; bool more; };      // a piece of the momentum sweep: tile rows [r0, r1), levels [kbeg, kend)
+int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, double rk3coefi, bool um_is_u0 = false, const MomPart *part = nullptr);
+int momentum_lds_tile_rows(const Geo &g);
+int momentum_lds_tile_height();
+int k_momentum_pipe_stage(udc_handle *h, int c);      // the sweep's level range that feeds k-chunk c of the slab solve (udc_api.hip)  // rk3coefi != 0: PUP mode   // LDS-staged k-marching version (default)
 bool fused_closure_possible(const udc_handle *h);                      // udc_mom_fused.hip: closure inside the momentum sweep
 int k_momentum_closure(udc_handle *h, bool forces, double rk3coefi, bool um_is_u0, bool emit);   // emit: ekm, ekh also written (with closurebc's ghosts)
 int k_level_sums_dev(udc_handle *h, int field, int n);      // udc_thermo.hip: masked, all-reduced level sums left on the device
@@ -388,7 +396,7 @@ int k_scalar_fused_pair(udc_handle *h, int na, int nb, bool fresh);      // 0 do
 int k_forces(udc_handle *h);
 int k_coriolis(udc_handle *h, bool wrap_vp);                     // coriolis: lcoriol / lprofforc
 int k_masscorr(udc_handle *h, double rk3coef, bool pup_mode, bool wrap_vp);   // masscorr, volume-flow branches
-int k_bottom(udc_handle *h, bool wrap_vp);       // floor wall function; wrap_vp: also refresh vp's ghost row ny (bcpup)
+int k_bottom(udc_handle *h, bool wrap_vp, int jbeg = 0, int jend = -1);      // rows [jbeg, jend) (jend < 0: all)       // floor wall function; wrap_vp: also refresh vp's ghost row ny (bcpup)
 int k_divergence_rhs(udc_handle *h, double rk3coef, bool pup);
 int k_poisson_solve(udc_handle *h);
 int k_project(udc_handle *h);                       // tderive: up,vp,wp -= grad p ; pres0 += p

@@ -146,6 +146,7 @@ struct BottomArgs {
   int thl_wf;
   double *tau_x, *tau_y, *thl_flux;      // [ny_l][nx] planes or nullptr
   int thl_slot;                          // entry of sv0/svp that is thl (for thl_flux), else -1
+  int jbeg, jend;                        // rows [jbeg, jend) of this launch
 };
 // wfuno's transfer coefficients (src/modwallfunctions.f90:176-261): Louis 1979 / Uno et al. 1995 over a rough wall
 __device__ __forceinline__ void uno_F(double logdz, double sqdz, double Ri, double fkar2, double &Fm, double &Fh) {
@@ -180,8 +181,8 @@ __device__ __forceinline__ double uno_h(double prt, double logdz, double logzh, 
 // UNO = false: wfmneutral (BCbotm = 3, src/modwallfunctions.f90:263-350); true: wfuno case 91 (BCbotm = 2, :72-127)
 template <bool UNO>
 __global__ __launch_bounds__(256) void bottom_kernel(Geo g, Metrics m, BottomArgs a) {
-  const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
-  if (i >= g.nx || j >= g.ny) return;
+  const int i = blockIdx.x * 64 + threadIdx.x, j = a.jbeg + blockIdx.y * 4 + threadIdx.y;
+  if (i >= g.nx || j >= a.jend) return;
   const long c = g.idx(i, j, 0);
   const long cxm = c - i + (i == 0 ? g.nx - 1 : i - 1), cxp = c - i + (i == g.nx - 1 ? 0 : i + 1);
   const long sy = g.sy, sz = g.sz;
@@ -321,9 +322,11 @@ int k_coriolis(udc_handle *h, bool wrap_vp) {
   return 0;
 }
 
-int k_bottom(udc_handle *h, bool wrap_vp) {
+int k_bottom(udc_handle *h, bool wrap_vp, int jbeg, int jend) {
   const Geo &g = h->g;
   BottomArgs a{};
+  a.jbeg = jbeg; a.jend = jend < 0 ? g.ny : (jend < g.ny ? jend : g.ny);
+  if (a.jend <= a.jbeg) return 0;
   a.u0 = h->fields[UDC_U0]; a.v0 = h->fields[UDC_V0]; a.ekm = h->fields[UDC_EKM]; a.ekh = h->fields[UDC_EKH];
   a.up = h->fields[UDC_UP]; a.vp = h->fields[UDC_VP];
   a.nsv = 0; a.wrap_vp = wrap_vp ? 1 : 0; a.z0 = h->p.z0;
@@ -342,7 +345,7 @@ int k_bottom(udc_handle *h, bool wrap_vp) {
     a.flux[a.nsv] = h->slot[n].floorflux; ++a.nsv;
   }
   PROF(h, "bottom");
-  const dim3 gr((unsigned)((g.nx + 63) / 64), (unsigned)((g.ny + 3) / 4)), bl(64, 4);
+  const dim3 gr((unsigned)((g.nx + 63) / 64), (unsigned)((a.jend - a.jbeg + 3) / 4)), bl(64, 4);
   if (uno) hipLaunchKernelGGL(bottom_kernel<true>, gr, bl, 0, h->stream, g, h->m, a);
   else hipLaunchKernelGGL(bottom_kernel<false>, gr, bl, 0, h->stream, g, h->m, a);
   HIP_OK(hipGetLastError());

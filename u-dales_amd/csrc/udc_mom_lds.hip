@@ -39,6 +39,7 @@ struct MomArgs {
   double rk3coefi;
   int wrap_vp;                  // single slab: also store row 0 of vp into ghost row ny (bcpup's cyclic pvp)
   int um_is_u0;                 // RK stage 1 after an aliased stage 3: um == u0, already staged in LDS
+  int kbeg, kend;               // levels [kbeg, kend) of this launch (the whole column unless the sweep is pipelined with the solve)
 };
 
 template <int NF, int CPT = 1>
@@ -83,8 +84,8 @@ __global__ __launch_bounds__(NT / CPT, CPT == 1 ? MOM_WAVES : 2) void mom_lds_ke
   const int i0 = bx * MX, j0 = by * MY;
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * MX + tx;
   const int i = i0 + tx;
-  const int k0 = chunk * kc;
-  const int k1 = min(k0 + kc, g.nz);
+  const int k0 = a.kbeg + chunk * kc;
+  const int k1 = min(k0 + kc, a.kend);
 
   const double *fld[4] = {a.u, a.v, a.w, a.ek};
 
@@ -394,22 +395,35 @@ int k_closure_lds(udc_handle *h, bool ghosts, bool write_ekh, int rows) {
   return 0;
 }
 
-int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, double rk3coefi, bool um_is_u0) {
+int momentum_lds_tile_rows(const Geo &g) { return lds_tile_grid(g).gy; }
+int momentum_lds_tile_height() { return MY; }
+
+// part: a piece of the sweep -- tile rows [r0, r1) (r1 <= 0: all), levels [kbeg, kend) (kend <= 0: all); `more`: not the last piece
+// of this substep (profiled under "<name>_edge", which bench.py folds into <name>)
+int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, double rk3coefi, bool um_is_u0, const MomPart *part) {
   const bool pup = fresh && rk3coefi != 0.;
   const Geo &g = h->g;
   MomArgs a{h->fields[UDC_U0], h->fields[UDC_V0], h->fields[UDC_W0], h->fields[UDC_PRES0],
             h->fields[UDC_EKM], h->fields[UDC_UP], h->fields[UDC_VP], h->fields[UDC_WP],
-            h->fields[UDC_UM], h->fields[UDC_VM], h->fields[UDC_WM], rk3coefi, (fresh && !h->slab) ? 1 : 0, um_is_u0 ? 1 : 0};
-  const TileGrid tg = lds_tile_grid(g);
+            h->fields[UDC_UM], h->fields[UDC_VM], h->fields[UDC_WM], rk3coefi, (fresh && !h->slab) ? 1 : 0, um_is_u0 ? 1 : 0, 0, g.nz};
+  TileGrid tg = lds_tile_grid(g);
+  bool more = false;
+  if (part) {
+    if (part->r1 > 0) tg = tile_range(tg, part->r0, part->r1);
+    if (part->kend > 0) { a.kbeg = part->kbeg; a.kend = part->kend; }
+    more = part->more;
+  }
   // k-chunk: long enough to amortise the 2-plane prologue, short enough to fill 256 CUs x 4 workgroups
-  int kc = pick_kc(g, tg, MOM_WAVES);
-  const int chunks = (g.nz + kc - 1) / kc;
+  Geo gl = g;
+  gl.nz = a.kend - a.kbeg;
+  int kc = pick_kc(gl, tg, MOM_WAVES);
+  const int chunks = (gl.nz + kc - 1) / kc;
   dim3 b(MX, MY, 1), gr((unsigned)tg.tiles * (unsigned)chunks, 1, 1);
   const bool les = h->p.sgs != UDC_SGS_DNS;
   const double nu = h->p.numol;
 #define LAUNCH(A, D, L, F)                                                                         \
   do {                                                                                             \
-    PROF(h, "mom_" #A #D #L #F);                                                                   \
+    PROF(h, more ? "mom_" #A #D #L #F "_edge" : "mom_" #A #D #L #F);                               \
     if (pup) hipLaunchKernelGGL((mom_lds_kernel<A, D, L, F, true, true, 1>), gr, b, 0, h->stream, g, tg, h->m, a, nu, kc);    \
     else if (fresh) hipLaunchKernelGGL((mom_lds_kernel<A, D, L, F, true, false, 1>), gr, b, 0, h->stream, g, tg, h->m, a, nu, kc);  \
     else hipLaunchKernelGGL((mom_lds_kernel<A, D, L, F, false, false, 1>), gr, b, 0, h->stream, g, tg, h->m, a, nu, kc);            \

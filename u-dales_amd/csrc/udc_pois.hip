@@ -1256,6 +1256,7 @@ int pois_slab_init(udc_handle *h) {
     HIP_OK(hipEventCreateWithFlags(&h->ev_halo_ready, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&h->ev_halo_done, hipEventDisableTiming));
     h->no_halo_overlap = getenv("UDC_HALO_OVERLAP") && atoi(getenv("UDC_HALO_OVERLAP")) == 0;
+    h->no_mom_pipe = getenv("UDC_MOM_PIPE") && atoi(getenv("UDC_MOM_PIPE")) == 0;
   }
   for (int c = 0; c < nch; ++c) {
     HIP_OK(hipEventCreateWithFlags(&h->ev_ready[c], hipEventDisableTiming));
@@ -1300,9 +1301,10 @@ int k_poisson_solve_slab(udc_handle *h) {
     return 0;
   };
   {
-    PROF(h, "fftx_pack_fwd");
     for (int c = 0; c < nch; ++c) {
       const int k0 = c * nzc;
+      if (k_momentum_pipe_stage(h, c)) return 1;      // (the momentum sweep's levels for this chunk, when it is pipelined with the solve)
+      PROF(h, "fftx_pack_fwd");
       if (h->fft_fused) {
         const int G = fft_x_row_groups(h);
         if (h->vp_halo_pending && G >= 2) {
