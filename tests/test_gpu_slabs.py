@@ -98,7 +98,7 @@ print("RCCL_OK", m, dv)
 
 def test_rccl_carries_the_overlapped_exchanges(tmp_path):
     """The ghost rows that travel beside the sweeps (closure edge / interior, project + integrate edge / interior: k_halo_y_begin /
-    _join on the communication stream) through a real one-rank RCCL communicator, on a grid with enough tile rows for both splits
+    _join on the communication stream; the momentum sweep pipelined with the solve's k-chunks) through a real one-rank RCCL communicator, on a grid with enough tile rows for the splits
     (64 x 48 x 24: 6 and 12 tile rows), Vreman + floor wall function, nine substeps: the forced slab path with RCCL, with the overlap
     on and off, against the single-slab path (2-D rocFFT, folded ghost rows)."""
     code = r'''
@@ -133,12 +133,15 @@ print("RUN_OK")
 ''' % (ROOT, ROOT)
     import numpy as np
     res = {}
-    for tag, env in (("single", {}), ("rccl", {"UDC_FORCE_SLAB": "1", "UDC_FORCE_COMM": "1"}),
-                     ("rccl_inline", {"UDC_FORCE_SLAB": "1", "UDC_FORCE_COMM": "1", "UDC_HALO_OVERLAP": "0"})):
+    for tag, env in (("single", {}), ("rccl", {"UDC_FORCE_SLAB": "1", "UDC_FORCE_COMM": "1", "UDC_A2A_CHUNKS": "4"}),
+                     ("rccl_inline", {"UDC_FORCE_SLAB": "1", "UDC_FORCE_COMM": "1", "UDC_A2A_CHUNKS": "4", "UDC_HALO_OVERLAP": "0", "UDC_MOM_PIPE": "0"})):
         out = str(tmp_path / (tag + ".npy"))
         r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert "RUN_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
         res[tag] = np.load(out, allow_pickle=True).item()
+    # the overlapped order (exchanges beside the sweeps, the momentum sweep cut along the solve's four k-chunks) changes no arithmetic
+    for k in ("u0", "v0", "w0", "pres0"):
+        assert np.array_equal(res["rccl"][k], res["rccl_inline"][k]), k
     for tag in ("rccl", "rccl_inline"):
         assert res[tag]["div"] < 1e-10
         for k in ("u0", "v0", "w0", "pres0"):
