@@ -150,3 +150,22 @@ def test_scalar_sources_slab_equals_global_rows():
     # a source outside a slab leaves that slab empty
     far = source_field(g, [(3.0, 0.4, 1.0, 1.0, 0.1)], [], j0=8, nyl=4)
     assert not far.any()
+
+
+def test_bench_kernel_table_folds_split_launches():
+    """bench.py: a kernel launched in pieces on the y-slab path (`<name>_edge` launches ahead of `<name>`) is one row of the kernel
+    table with the time of all pieces and the launch count of the last; algorithmic bytes are looked up under the folded name; a
+    surveyed launch shorter than the markers' cost carries no rate (no division by zero)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    tab = {"closure_edge": (0.3, 6), "closure": (0.9, 6), "mom_truetruetruetrue_edge": (2.0, 24), "mom_truetruetruetrue": (0.5, 6),
+           "project_integrate_edge": (0.4, 12), "project_integrate": (0.8, 6), "halo_pack": (0.01, 6), "only_edge": (0.2, 3)}
+    out = b.fold_edges(tab)
+    assert out["closure"] == (pytest.approx(1.2), 6) and out["mom_truetruetruetrue"] == (pytest.approx(2.5), 6)
+    assert out["project_integrate"] == (pytest.approx(1.2), 6) and out["halo_pack"] == (0.01, 6) and out["only"] == (0.2, 3)
+    assert not any(k.endswith("_edge") for k in out)
+    assert b.algo_bytes("mom_truetruetruetrue", 0, 1.0) == 64 and b.algo_bytes("mom_truetruetruetrue", 0, 0.0) == 88
+    assert b.algo_bytes("project_integrate", 2) == 72 + 48 and b.algo_bytes("halo_pack") is None
