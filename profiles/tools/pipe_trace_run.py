@@ -29,6 +29,12 @@ for k, base in (("u0", 1.0), ("v0", 0.0), ("w0", 0.0)):
         a[1] = 0.
     core.upload(k, a); core.upload(k.replace("0", "m"), a)
 core.halos(); core.boundary()
-core.run(9, 0.25)
-print("divmax", core.divergence()[0])
+import time
+core.run(3, 0.25)
+core.sync()
+nsub = int(os.environ.get("PIPE_TRACE_SUBSTEPS", "6"))
+t0 = time.perf_counter()
+core.run(nsub, 0.25)
+core.sync()
+print("ms_per_substep", (time.perf_counter() - t0) / nsub * 1e3, "divmax", core.divergence()[0])
 core.close()
