@@ -234,11 +234,17 @@ int comm_alltoall(udc_handle *h, const double *send, double *recv, size_t block,
     const int q0 = (P == 1) ? 0 : 1;    // P == 1 only under UDC_FORCE_COMM: the own block goes through RCCL too
     if (q0) HIP_OK(hipMemcpyAsync(recv + (size_t)r * block, send + (size_t)r * block, block * sizeof(double),
                                   hipMemcpyDeviceToDevice, st));
+    // one operation carries at most 2^26 doubles (512 MiB): measured on this RCCL, a single send / receive of more than 1 GiB (the
+    // 1024 x 512 x 512 transposes in one or two k-chunks on one rank) delivers garbage without an error; pieces go in the same group
+    const size_t piece = (size_t)1 << 26;
     NCCL_OK(ncclGroupStart());
     for (int q = q0; q < P; ++q) {
       const int to = (r + q) % P, from = (r + P - q) % P;     // staggered so that pairs differ per step
-      NCCL_OK(ncclSend(send + (size_t)to * block, block, ncclDouble, to, c, st));
-      NCCL_OK(ncclRecv(recv + (size_t)from * block, block, ncclDouble, from, c, st));
+      for (size_t o = 0; o < block; o += piece) {
+        const size_t n = block - o < piece ? block - o : piece;
+        NCCL_OK(ncclSend(send + (size_t)to * block + o, n, ncclDouble, to, c, st));
+        NCCL_OK(ncclRecv(recv + (size_t)from * block + o, n, ncclDouble, from, c, st));
+      }
     }
     NCCL_OK(ncclGroupEnd());
     return 0;
