@@ -183,11 +183,15 @@ int comm_neighbours(udc_handle *h, const double *to_prev, const double *to_next,
     ncclComm_t c = (ncclComm_t)h->nccl;
     // with P == 2 both neighbours are the same peer: sends and receives pair up in posting order,
     // so post "to prev" first on the send side and "from next" first on the receive side.
+    const size_t piece = (size_t)1 << 26;      // at most 512 MiB per operation (see comm_alltoall)
     NCCL_OK(ncclGroupStart());
-    NCCL_OK(ncclSend(to_prev, count, ncclDouble, prev, c, st));
-    NCCL_OK(ncclSend(to_next, count, ncclDouble, next, c, st));
-    NCCL_OK(ncclRecv(from_next, count, ncclDouble, next, c, st));
-    NCCL_OK(ncclRecv(from_prev, count, ncclDouble, prev, c, st));
+    for (size_t o = 0; o < count; o += piece) {
+      const size_t n = count - o < piece ? count - o : piece;
+      NCCL_OK(ncclSend(to_prev + o, n, ncclDouble, prev, c, st));
+      NCCL_OK(ncclSend(to_next + o, n, ncclDouble, next, c, st));
+      NCCL_OK(ncclRecv(from_next + o, n, ncclDouble, next, c, st));
+      NCCL_OK(ncclRecv(from_prev + o, n, ncclDouble, prev, c, st));
+    }
     NCCL_OK(ncclGroupEnd());
     return 0;
   }
