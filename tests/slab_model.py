@@ -172,3 +172,11 @@ def produce_and_exchange_split(a: np.ndarray, width: int, tile_h: int, dist, ran
     b[:, :width, :] = from_prev.numpy()
     b[:, -width:, :] = from_next.numpy()
     return b
+
+
+# ---------------------------------------------------------------- the momentum sweep pipelined with the solve (udc_api.hip)
+def momentum_pipe_ranges(nz: int, nch: int):
+    """Level ranges [kbeg, kend) of k_momentum_pipe_stage(c), c = 0 .. nch - 1 (tile rows 1 ..; tile row 0 is swept over all levels
+    before the first stage)."""
+    nzc = nz // nch
+    return [(0 if c == 0 else c * nzc + 1, nz if c == nch - 1 else (c + 1) * nzc + 1) for c in range(nch)]

@@ -88,6 +88,24 @@ def test_split_launch_rows_cover_the_slab_once():
         assert [slab.tile_row(edge, b) for b in range(edge[0])] == [0, gy - 1]
 
 
+def test_momentum_pipe_ranges_feed_their_chunk():
+    """k_momentum_pipe_stage's level ranges (mirrored in slab_model.py): together they cover every level once, in order, and when
+    stage c has run every level the x forward transform of k-chunk c reads is there -- its own levels and, for the divergence's
+    pwp(k + 1), the first level of the next chunk."""
+    sys.path[:0] = [os.path.join(ROOT, "tests")]
+    import slab_model as slab
+    for nz in (16, 24, 64, 256, 512):
+        for nch in (1, 2, 4, 8):
+            if nz % nch or nz // nch < 4:
+                continue
+            r = slab.momentum_pipe_ranges(nz, nch)
+            assert r[0][0] == 0 and r[-1][1] == nz and all(r[c][1] == r[c + 1][0] for c in range(nch - 1)), (nz, nch, r)
+            nzc = nz // nch
+            for c in range(nch):
+                need_top = min((c + 1) * nzc, nz - 1)          # highest level read: k + 1 for k = (c + 1) nzc - 1, none above the lid
+                assert r[c][1] > need_top and r[c][0] <= c * nzc + (0 if c == 0 else 1), (nz, nch, c, r)
+
+
 def test_slab_index_maps_roundtrip():
     sys.path[:0] = [os.path.join(ROOT, "u-dales_amd")]
     import slab_model as slab
