@@ -616,6 +616,9 @@ def main():
                    "floor": "free (no wall function)" if args.no_floor else
                             "neutral log-law wall function (lbottom, BCbotm=3, z0=0.05)",
                    "grid": [nx, ny, nz], "decomposition": f"y-slabs x{world}", "dt": dt,
+                   **({"slab_order": {"ghost_rows_beside_compute": os.environ.get("UDC_HALO_OVERLAP", "1") != "0",
+                                      "momentum_sweep_pipelined_with_solve": os.environ.get("UDC_MOM_PIPE", "1") != "0",
+                                      "transpose_k_chunks": int(os.environ.get("UDC_A2A_CHUNKS", "4"))}} if world > 1 else {}),
                    "step": "one RK3 substep = one cell-update per cell"},
         "whole_substep_hbm_frac": round(392.0 * cells_local * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4),
         # the same on the bytes the kernels as built must move (sum of the per-kernel algorithmic bytes, launches per
