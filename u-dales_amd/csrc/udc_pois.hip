@@ -1304,7 +1304,7 @@ int k_poisson_solve_slab(udc_handle *h) {
     for (int c = 0; c < nch; ++c) {
       const int k0 = c * nzc;
       if (k_momentum_pipe_stage(h, c)) return 1;      // (the momentum sweep's levels for this chunk, when it is pipelined with the solve)
-      PROF(h, "fftx_pack_fwd");
+      PROF(h, c == nch - 1 ? "fftx_pack_fwd" : "fftx_pack_fwd_edge");      // (one table row per substep: bench.py folds *_edge)
       if (h->fft_fused) {
         const int G = fft_x_row_groups(h);
         if (h->vp_halo_pending && G >= 2) {
