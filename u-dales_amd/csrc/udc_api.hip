@@ -157,6 +157,7 @@ extern "C" int udc_create(const udc_config *cfg, udc_handle **out) {
   h->no_pup = getenv("UDC_NO_PUP") && atoi(getenv("UDC_NO_PUP")) != 0;
   h->no_fold = getenv("UDC_NO_FOLD") && atoi(getenv("UDC_NO_FOLD")) != 0;
   h->no_alias = getenv("UDC_NO_ALIAS") && atoi(getenv("UDC_NO_ALIAS")) != 0;
+  h->closure_carry = getenv("UDC_CLOSURE_CARRY") && atoi(getenv("UDC_CLOSURE_CARRY")) != 0;
   h->ek_always = getenv("UDC_EK_ALWAYS") && atoi(getenv("UDC_EK_ALWAYS")) != 0;
   // closure inside the momentum sweep (udc_mom_fused.hip): correct, but slower than the two kernels as measured -> opt-in
   h->no_fused_closure = !(getenv("UDC_FUSED_CLOSURE") && atoi(getenv("UDC_FUSED_CLOSURE")) != 0);

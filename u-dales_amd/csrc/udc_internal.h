@@ -231,6 +231,7 @@ struct udc_handle {
   bool mom_simple = false;              // UDC_MOM_SIMPLE=1: use the direct-load momentum kernel
   bool ekh_stale = false;               // the last closure wrote ekm only (no reader of ekh in that substep)
   bool ek_stale = false;                // the last fused substep kept ekm / ekh in LDS only: the arrays hold an older substep's values
+  bool closure_carry = false;           // UDC_CLOSURE_CARRY=1: the closure sweep carries the re-used stencil values in registers (A/B switch)
   bool ek_always = false;               // UDC_EK_ALWAYS=1: every substep writes ekm / ekh
   bool no_fused_closure = true;         // UDC_FUSED_CLOSURE=1 turns the one-kernel closure + momentum sweep on (A/B switch; slower as measured)
   bool no_div_in_fft = false;           // UDC_DIV_IN_FFT=0: slab path with a separate divergence kernel (A/B switch)

@@ -243,10 +243,41 @@ struct LdsAcc {      // neighbour access from the three staged planes (pointers 
   }
 };
 
+// The same neighbours with everything a thread has already read on an earlier level carried in registers: of the 30 values of the
+// closure's stencil (both models read the same set) the 8 of plane k-1 / k in the thread's own u and v pairs and the 5 w values of
+// plane k were the "plane k / k+1" values one level ago.  Per level that leaves 9 reads of plane k+1 and 8 in-plane reads of plane k:
+// 17 LDS reads instead of 30 (the closure is bound by LDS issue + f64 VALU, not by its bytes); operands and operation order unchanged.
+struct CarryAcc {
+  const double *ucp, *vcp;      // plane k, tile centre element (in-plane neighbours that are not carried)
+  double ut[2], uc[2], ub[2];   // u(di, 0, +1 / 0 / -1), di = 0, 1
+  double vt[2], vc[2], vb[2];   // v(0, dj, +1 / 0 / -1), dj = 0, 1
+  double wt[5], wc[5];          // w at (0,0), (1,0), (-1,0), (0,1), (0,-1) of planes k+1 / k
+  static __device__ __forceinline__ constexpr int widx(int di, int dj) { return di == 1 ? 1 : (di == -1 ? 2 : (dj == 1 ? 3 : (dj == -1 ? 4 : 0))); }
+  __device__ __forceinline__ double u(int di, int dj, int dk) const {
+    if (dj == 0 && (di == 0 || di == 1)) return dk > 0 ? ut[di] : (dk < 0 ? ub[di] : uc[di]);
+    return ucp[dj * LX + di];
+  }
+  __device__ __forceinline__ double v(int di, int dj, int dk) const {
+    if (di == 0 && (dj == 0 || dj == 1)) return dk > 0 ? vt[dj] : (dk < 0 ? vb[dj] : vc[dj]);
+    return vcp[dj * LX + di];
+  }
+  __device__ __forceinline__ double w(int di, int dj, int dk) const { return dk > 0 ? wt[widx(di, dj)] : wc[widx(di, dj)]; }
+  __device__ __forceinline__ void read_top(const double *up, const double *vp, const double *wp) {
+    ut[0] = up[0]; ut[1] = up[1]; vt[0] = vp[0]; vt[1] = vp[LX];
+    wt[0] = wp[0]; wt[1] = wp[1]; wt[2] = wp[-1]; wt[3] = wp[LX]; wt[4] = wp[-LX];
+  }
+  __device__ __forceinline__ void shift() {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { ub[q] = uc[q]; uc[q] = ut[q]; vb[q] = vc[q]; vc[q] = vt[q]; }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) wc[q] = wt[q];
+  }
+};
+
 // Same marching/staging scheme as mom_lds_kernel for u0, v0, w0; writes ekm, ekh.
 // EKH = false: ekh is not written (nothing reads it in this substep: no transported scalar, not the stage whose fields the
 // time-step maxima / statistics / restart files see) -- 8 of the kernel's 40 B per cell.
-template <int SGS, bool EKH>
+template <int SGS, bool EKH, bool CARRY>
 __global__ __launch_bounds__(NT) void closure_lds_kernel(Geo g, TileGrid tg, Metrics m, Params pr,
     const double *__restrict__ gu, const double *__restrict__ gv, const double *__restrict__ gw,
     double *__restrict__ ekm, double *__restrict__ ekh, int kc, int ghosts) {
@@ -307,11 +338,18 @@ __global__ __launch_bounds__(NT) void closure_lds_kernel(Geo g, TileGrid tg, Met
   load_plane(k0 + 1, st); commit_plane(2, st);
   if (k0 + 1 < k1) load_plane(k0 + 2, st);
   int bm = 0, bc = 1, bp = 2, bn = 3;
+  CarryAcc C;
   for (int k = k0; k < k1; ++k) {
     __syncthreads();
     if (k + 1 < k1) {
       commit_plane(bn, st);
       if (k + 2 < k1) load_plane(k + 3, st);
+    }
+    if (CARRY && k == k0) {         // planes k0 - 1 and k0 as "bottom" and "centre" of the first level
+      C.read_top(s[bm][0] + own_l, s[bm][1] + own_l, s[bm][2] + own_l);
+      C.shift();
+      C.read_top(s[bc][0] + own_l, s[bc][1] + own_l, s[bc][2] + own_l);
+      C.shift();
     }
     const ClosMetLane lm{mcur};
     mcur = mnext;                                            // (arrived: the commit above waited for it)
@@ -322,7 +360,14 @@ __global__ __launch_bounds__(NT) void closure_lds_kernel(Geo g, TileGrid tg, Met
       LdsAcc A{s[bm][0] + o, s[bc][0] + o, s[bp][0] + o, s[bm][1] + o, s[bc][1] + o, s[bp][1] + o,
                s[bm][2] + o, s[bc][2] + o, s[bp][2] + o};
       double em, eh;
-      closure_arith<SGS>(A, m, lm, pr, k, em, eh);
+      if (CARRY) {
+        C.ucp = s[bc][0] + o; C.vcp = s[bc][1] + o;
+        C.read_top(s[bp][0] + o, s[bp][1] + o, s[bp][2] + o);
+        closure_arith<SGS>(C, m, lm, pr, k, em, eh);
+        C.shift();
+      } else {
+        closure_arith<SGS>(A, m, lm, pr, k, em, eh);
+      }
       const long c = g.sz * (long)(k + HZ) + own_off;
       ekm[c] = em;                      // (re-read by the momentum sweep that follows: kept cacheable)
       if (EKH) NT_STORE(eh, &ekh[c]);
@@ -384,13 +429,16 @@ int k_closure_lds(udc_handle *h, bool ghosts, bool write_ekh, int rows) {
   double *ekm = h->fields[UDC_EKM], *ekh = h->fields[UDC_EKH];
   PROF(h, rows == 1 ? "closure_edge" : "closure");
   const int gh = ghosts ? 1 : 0;
-  if (h->p.sgs == UDC_SGS_SMAGORINSKY) {
-    if (write_ekh) hipLaunchKernelGGL((closure_lds_kernel<1, true>), gr, b, 0, h->stream, g, tg, h->m, h->p, u, v, w, ekm, ekh, kc, gh);
-    else hipLaunchKernelGGL((closure_lds_kernel<1, false>), gr, b, 0, h->stream, g, tg, h->m, h->p, u, v, w, ekm, ekh, kc, gh);
+#define CLOSURE_LAUNCH(S, E, C) hipLaunchKernelGGL((closure_lds_kernel<S, E, C>), gr, b, 0, h->stream, g, tg, h->m, h->p, u, v, w, ekm, ekh, kc, gh)
+  const bool smag = h->p.sgs == UDC_SGS_SMAGORINSKY;
+  if (h->closure_carry) {
+    if (smag) { if (write_ekh) CLOSURE_LAUNCH(1, true, true); else CLOSURE_LAUNCH(1, false, true); }
+    else      { if (write_ekh) CLOSURE_LAUNCH(2, true, true); else CLOSURE_LAUNCH(2, false, true); }
   } else {
-    if (write_ekh) hipLaunchKernelGGL((closure_lds_kernel<2, true>), gr, b, 0, h->stream, g, tg, h->m, h->p, u, v, w, ekm, ekh, kc, gh);
-    else hipLaunchKernelGGL((closure_lds_kernel<2, false>), gr, b, 0, h->stream, g, tg, h->m, h->p, u, v, w, ekm, ekh, kc, gh);
+    if (smag) { if (write_ekh) CLOSURE_LAUNCH(1, true, false); else CLOSURE_LAUNCH(1, false, false); }
+    else      { if (write_ekh) CLOSURE_LAUNCH(2, true, false); else CLOSURE_LAUNCH(2, false, false); }
   }
+#undef CLOSURE_LAUNCH
   HIP_OK(hipGetLastError());
   return 0;
 }
