@@ -379,6 +379,56 @@ def single_gpu_leg(nx, ny, nz, dt, args, device, ms_n, poisson_n, poisson_sub_n)
             "steps": n1, "speedup_substep": round(ms1 / ms_n, 3), "speedup_poisson": round(p1 / poisson_n, 3),
             "speedup_poisson_in_substep": round((ms1 - nonpois) / poisson_sub_n, 3)}
 
+def live_traffic(args, dom, timeout_s=240):
+    """HBM bytes per launch of the dominant kernel, measured in THIS run: two child runs of this script (the same workload, 9 substeps,
+    no CPU / drop-in legs) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- one counter per pass and
+    kernel tracing only, as MI355X_MICROARCH.md prescribes (counters serialise the kernels, so they cannot sit in the timed region);
+    bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 with the guide's gfx950 correction of the fetch tally (profiles/tools/summarise.py
+    applies the same formula to the kept profiles).  None when rocprofv3 is absent, this process is itself being profiled, or a pass
+    fails: the caller then falls back to the committed collection and says so."""
+    import csv
+    import glob
+    import shutil
+    pats = {"closure": "closure_lds_kernel", "div_rhs": "div_rhs_kernel", "thomas": "thomas_", "project_integrate": "integrate_kernel",
+            "scalar_kappa_faces": "scalar_kappa_faces_kernel", "scalar_lds_cd2": "scalar_lds_kernel", "scalar": "scalar_kernel"}
+    pat = "mom_lds_kernel" if dom.startswith("mom_") else pats.get(dom)
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if pat is None or prof is None or any(k.startswith("ROCPROF") for k in os.environ):
+        return None
+    flags = ["--no-cpu", "--no-dropin", "--no-pmc", "--steps", "6", "--warmup", "3", "--sgs", args.sgs, "--nsv", str(args.nsv)]
+    if args.size:
+        flags += ["--size", args.size]
+    if args.ibm:
+        flags.append("--ibm")
+    if args.no_floor:
+        flags.append("--no-floor")
+    means, launches = {}, 0
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [prof, "--kernel-trace", "--output-format", "csv", "--pmc", counter, "-d", d, "-o", "pmc", "--",
+                   sys.executable, os.path.abspath(__file__)] + flags
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            except Exception:      # noqa: BLE001
+                return None
+            if r.returncode != 0:
+                return None
+            tot, n = 0.0, 0
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if row.get("Counter_Name") == counter and pat in row.get("Kernel_Name", ""):
+                            tot += float(row["Counter_Value"])
+                            n += 1
+            if n == 0:
+                return None
+            means[counter], launches = tot / n, n
+    return {"bytes": int((2.0 * means["FETCH_SIZE"] + means["WRITE_SIZE"]) * 1024), "launches": launches,
+            "FETCH_SIZE_KiB": round(means["FETCH_SIZE"], 1), "WRITE_SIZE_KiB": round(means["WRITE_SIZE"], 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -390,6 +440,7 @@ def main():
     ap.add_argument("--with-single", action="store_true", help="N=1: run that leg anyway (exercises the code path on a one-GPU box)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-dropin", action="store_true", help="skip the Fortran drop-in leg")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes behind roofline.traffic (N = 1)")
     ap.add_argument("--nsv", type=int, default=0, help="passive scalars (kappa scheme), BASELINE configs[2]")
     ap.add_argument("--sgs", type=str, default="vreman", choices=["vreman", "smag"])
     ap.add_argument("--oversubscribe", action="store_true",
@@ -581,6 +632,15 @@ def main():
                 traffic, traffic_src = ent["hbm_bytes_per_launch"], ent.get("source")
         except Exception:
             traffic = None
+    # ... unless this run can measure it itself (one GPU, rocprofv3 on the box): two short child passes after the timed region
+    if world == 1 and not args.no_pmc:
+        lt = live_traffic(args, dom)
+        if lt:
+            traffic = lt["bytes"]
+            traffic_src = (f"this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of the same workload, mean of "
+                           f"{lt['launches']} launches, (2 x {lt['FETCH_SIZE_KiB']} + {lt['WRITE_SIZE_KiB']}) KiB")
+        elif traffic is not None:
+            traffic_src = f"{traffic_src} (committed collection: no live counter pass in this run)"
     roofline = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": kernels[dom]["frac"], "traffic": traffic, "traffic_source": traffic_src,
                 "algo_bytes_per_launch": int(kernels[dom]["algo_bytes_per_cell"] * cells_local),

@@ -15,7 +15,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --no-cpu --no-dropin --steps 12 --warmup 3 $*"
+CMD="python $ROOT/bench.py --no-cpu --no-dropin --no-pmc --steps 12 --warmup 3 $*"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- $CMD > "$OUT/stats.log" 2>&1
 i=0

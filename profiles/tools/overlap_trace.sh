@@ -6,6 +6,6 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/overlap_trace
 mkdir -p $OUT
 cd /tmp
-UDC_FORCE_SLAB=1 UDC_A2A_CHUNKS=4 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT -o tr -- python $ROOT/bench.py --size 1024x512x512 --steps 3 --warmup 0 --no-cpu --no-dropin --no-single > $OUT/run.log 2>&1
+UDC_FORCE_SLAB=1 UDC_A2A_CHUNKS=4 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT -o tr -- python $ROOT/bench.py --size 1024x512x512 --steps 3 --warmup 0 --no-cpu --no-pmc --no-dropin --no-single > $OUT/run.log 2>&1
 cd $ROOT
 python profiles/tools/overlap_trace.py $OUT > gpurun_out/overlap_trace_summary.txt 2>&1

@@ -1,7 +1,7 @@
 # rocprofv3 kernel-trace statistics of the default bench workload over a run long enough for steady clocks (the 15-substep passes
 # of collect.sh catch the ramp: mom_lds_kernel 255 .. 356 us in one trace): 120 substeps after 30 of warm-up.
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/prof_r03_256_long; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python $ROOT/bench.py --no-cpu --no-dropin --steps 120 --warmup 30 > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python $ROOT/bench.py --no-cpu --no-pmc --no-dropin --steps 120 --warmup 30 > $OUT/stats.log 2>&1
 grep "^{\"metric\"" $OUT/stats.log | tail -1 > $OUT/bench_line.json
 cd $ROOT; python - <<PY
 import csv, json

@@ -23,7 +23,7 @@ def free_port():
 def launch(n, extra, timeout, env_extra=None, size="32x16x16", single=False):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1",
-           "--no-cpu", "--no-dropin", "--size", size] + ([] if single else ["--no-single"]) + extra
+           "--no-cpu", "--no-pmc", "--no-dropin", "--size", size] + ([] if single else ["--no-single"]) + extra
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
 
