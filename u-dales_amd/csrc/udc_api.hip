@@ -1060,7 +1060,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   // except for the immersed-boundary routines, which edit listed points only (a solid v point in the first row of the
   // domain has its periodic image in the ghost row)
   // slab path with the own line FFTs: fillps' divergence is evaluated inside the x forward transform (udc_fft.hip)
-  h->div_in_fft = pup && h->slab && h->fft_fused && !h->no_div_in_fft;
+  h->div_in_fft = pup && ((h->slab && h->fft_fused && !h->no_div_in_fft) || (!h->slab && h->own_fwd));
   if (piped) {
     // (vp's row is already travelling)
   } else if (!fold || (h->ibm_on && (ops & (OP_IBMWALL | OP_IBMNORM)))) {

@@ -261,6 +261,183 @@ __global__ __launch_bounds__(FT) void ffty_bwd_pack_kernel(YArgs q, const double
   }
 }
 
+// ------------------------------------------------------------------------------------------------ one GPU, natural layout
+// The single-slab solve keeps rocFFT's spectral layout spec[k][j][kx] (row pitch nkxp) for the Thomas sweep and the backward
+// 2-D transform; its forward half can run here instead: the x transform with fillps' divergence folded in (div_rhs and rocFFT's
+// x pass in one sweep: 32 B per cell instead of 32 + 16) followed by a y pass over columns of that layout, which rocFFT has no
+// single plan for (a strided transform inside two batch dimensions, kx and k).  UDC_OWN_FWD=1 (A/B switch).
+struct NatArgs {
+  int nx, M, MP;            // real length, complex length nx/2, LDS pitch of an x line
+  int ny, nkx, nkxp;        // rows, r2c modes, row pitch of spec (complex elements)
+  int sy; long sz;          // strides of the real fields (doubles)
+  int lL;                   // log2 of the rows per workgroup (x kernel)
+  int C, YP;                // columns per workgroup and LDS pitch of a column (y kernel)
+};
+
+template <int LM>
+__global__ __launch_bounds__(xthreads(LM)) void fftx_fwd_nat_kernel(NatArgs q, DivArgs dv, const double2 *__restrict__ twM,
+                                                                    const double2 *__restrict__ twN, double2 *__restrict__ spec) {
+  extern __shared__ double2 lds[];
+  constexpr int M = 1 << LM, NTH = xthreads(LM);
+  const int tid = threadIdx.x, L = 1 << q.lL;
+  double2 *a = lds, *b = lds + L * q.MP, *tw = b + L * q.MP;
+  for (int n = tid; n < M; n += NTH) tw[n] = twM[n];
+  const int j0 = blockIdx.x << q.lL, k = blockIdx.y;
+  for (int wi = tid; wi < (M << q.lL); wi += NTH) {
+    const int l = wi >> LM, n = wi & (M - 1);
+    const long ro = q.sz * (long)(k + HZ) + (long)q.sy * (j0 + l + HY);
+    const double2 *ru = reinterpret_cast<const double2 *>(dv.pu + ro), *rv = reinterpret_cast<const double2 *>(dv.pv + ro);
+    const double2 *rv1 = reinterpret_cast<const double2 *>(dv.pv + ro + q.sy), *rw = reinterpret_cast<const double2 *>(dv.pw + ro);
+    const double2 u = ru[n], un = ru[(n + 1) & (M - 1)], v = rv[n], v1 = rv1[n], w = rw[n];
+    double2 w1 = make_double2(0., 0.);
+    if (k < dv.nz - 1) w1 = reinterpret_cast<const double2 *>(dv.pw + ro + q.sz)[n];
+    const double dz = dv.dzfi[k + 1];
+    a[l * q.MP + pad(n)] = make_double2((u.y - u.x) * dv.dxi + (v1.x - v.x) * dv.dyi + (w1.x - w.x) * dz,
+                                        (un.x - u.y) * dv.dxi + (v1.y - v.y) * dv.dyi + (w1.y - w.y) * dz);
+  }
+  __syncthreads();
+  double2 *z = fft_lines<false, LM, NTH>(a, b, tw, q.MP, L);
+  // split (as in fftx_fwd_pack_kernel), stored kx-fastest: one row of spec per line; kx = M by the first L threads
+  for (int wi = tid; wi < (M << q.lL) + L; wi += NTH) {
+    const bool last = wi >= (M << q.lL);
+    const int l = last ? wi - (M << q.lL) : wi >> LM, kx = last ? M : (wi & (M - 1));
+    const double2 *zl = z + l * q.MP;
+    const double2 zk = zl[pad(kx == M ? 0 : kx)], zc = cconj(zl[pad(kx == 0 ? 0 : M - kx)]);
+    const double2 s_ = cadd(zk, zc), d = csub(zk, zc);
+    const double2 wd = cmul(twN[kx], d);
+    spec[((size_t)k * q.ny + j0 + l) * q.nkxp + kx] = make_double2(0.5 * (s_.x + wd.y), 0.5 * (s_.y - wd.x));
+  }
+}
+
+// y pass, in place: columns c0 .. c0+C-1 of plane k (C consecutive complex per row)
+template <int LM>
+__global__ __launch_bounds__(FT) void ffty_nat_kernel(NatArgs q, const double2 *__restrict__ twg, double2 *__restrict__ spec) {
+  extern __shared__ double2 lds[];
+  constexpr int M = 1 << LM;
+  double2 *a = lds, *b = lds + q.C * q.YP, *tw = b + q.C * q.YP;
+  const int tid = threadIdx.x;
+  for (int n = tid; n < M; n += FT) tw[n] = twg[n];
+  const int c0 = blockIdx.x * q.C, k = blockIdx.y;
+  const int ncol = min(q.C, q.nkxp - c0);
+  double2 *pl = spec + (size_t)k * q.ny * q.nkxp + c0;
+  for (int wi = tid; wi < M * q.C; wi += FT) {
+    const int y = wi / q.C, col = wi - y * q.C;
+    if (col < ncol) a[col * q.YP + pad(y)] = pl[(size_t)y * q.nkxp + col];
+  }
+  __syncthreads();
+  double2 *z = fft_lines<false, LM>(a, b, tw, q.YP, ncol);
+  for (int wi = tid; wi < M * q.C; wi += FT) {
+    const int y = wi / q.C, col = wi - y * q.C;
+    if (col < ncol) pl[(size_t)y * q.nkxp + col] = z[col * q.YP + pad(y)];
+  }
+}
+
+// y pass of 256 points with one trip through LDS: 256 = 16 x 16 (Cooley-Tukey, n = 16 n1 + n2, k = k1 + 16 k2).  Thread (col, n2)
+// loads its 16 rows n = 16 n1 + n2 straight from memory, transforms them in registers (two layers of radix 4), applies
+// W_256^(n2 k1) and leaves Y[k1] in LDS; after the barrier thread (col, k1) picks up its 16 values over n2, transforms them and
+// stores rows k = k1 + 16 k2.  C x 16 threads, C x 16 x 17 complex of LDS (rows of 17: the second step reads with stride 17).
+__device__ __forceinline__ double2 mulw16(double2 v, int e) {        // v * exp(-2 pi i e / 16); e is a constant after unrolling
+  constexpr double c1 = 0.92387953251128673848, s1 = 0.38268343236508978178, h = 0.70710678118654752440;
+  switch (e & 15) {
+    case 0: return v;
+    case 1: return make_double2(v.x * c1 + v.y * s1, v.y * c1 - v.x * s1);
+    case 2: return make_double2((v.x + v.y) * h, (v.y - v.x) * h);
+    case 3: return make_double2(v.x * s1 + v.y * c1, v.y * s1 - v.x * c1);
+    case 4: return make_double2(v.y, -v.x);
+    case 6: return make_double2((v.y - v.x) * h, -(v.x + v.y) * h);
+    case 9: return make_double2(-v.x * c1 - v.y * s1, v.x * s1 - v.y * c1);
+    default: return v;      // (not reached: the exponents are j q, j, q < 4)
+  }
+}
+__device__ __forceinline__ void r4fwd(double2 &a, double2 &b, double2 &c, double2 &d) {
+  const double2 t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), e = csub(b, d);
+  const double2 t3 = make_double2(e.y, -e.x);
+  a = cadd(t0, t2); b = cadd(t1, t3); c = csub(t0, t2); d = csub(t1, t3);
+}
+// forward transform of 16 values in registers; X[q + 4 r] ends up in x[4 q + r]
+__device__ __forceinline__ void fft16(double2 (&x)[16]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    r4fwd(x[j], x[j + 4], x[j + 8], x[j + 12]);
+#pragma unroll
+    for (int q = 1; q < 4; ++q) x[j + 4 * q] = mulw16(x[j + 4 * q], j * q);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) r4fwd(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+}
+
+// v * exp(-2 pi i e / 32), e a constant after unrolling
+__device__ __forceinline__ double2 mulw32(double2 v, int e) {
+  constexpr double C32[16] = {1.00000000000000000000, 0.98078528040323043058, 0.92387953251128673848, 0.83146961230254523567, 0.70710678118654757274, 0.55557023301960228867, 0.38268343236508983729, 0.19509032201612833135, 0.00000000000000006123, -0.19509032201612819257, -0.38268343236508972627, -0.55557023301960195560, -0.70710678118654746172, -0.83146961230254534669, -0.92387953251128673848, -0.98078528040323043058};
+  constexpr double S32[16] = {0.00000000000000000000, 0.19509032201612824808, 0.38268343236508978178, 0.55557023301960217765, 0.70710678118654746172, 0.83146961230254523567, 0.92387953251128673848, 0.98078528040323043058, 1.00000000000000000000, 0.98078528040323043058, 0.92387953251128673848, 0.83146961230254545772, 0.70710678118654757274, 0.55557023301960217765, 0.38268343236508989280, 0.19509032201612860891};
+  if (e == 0) return v;
+  if (e == 8) return make_double2(v.y, -v.x);
+  return make_double2(v.x * C32[e & 15] + v.y * S32[e & 15], v.y * C32[e & 15] - v.x * S32[e & 15]);
+}
+// forward transforms of 8 / 32 values in registers: one radix-2 layer (decimation in frequency) over two halves;
+// X[k] ends up in x[regpos<N>(k)]
+__device__ __forceinline__ void fft8(double2 (&x)[8]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const double2 a = cadd(x[j], x[j + 4]), b = csub(x[j], x[j + 4]);
+    x[j] = a; x[j + 4] = mulw32(b, 4 * j);
+  }
+  r4fwd(x[0], x[1], x[2], x[3]);
+  r4fwd(x[4], x[5], x[6], x[7]);
+}
+__device__ __forceinline__ void fft32(double2 (&x)[32]) {
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const double2 a = cadd(x[j], x[j + 16]), b = csub(x[j], x[j + 16]);
+    x[j] = a; x[j + 16] = mulw32(b, j);
+  }
+  double2 (&lo)[16] = *reinterpret_cast<double2 (*)[16]>(&x[0]);
+  double2 (&hi)[16] = *reinterpret_cast<double2 (*)[16]>(&x[16]);
+  fft16(lo);
+  fft16(hi);
+}
+__device__ __forceinline__ constexpr int regpos16(int k) { return 4 * (k & 3) + (k >> 2); }
+template <int N> __device__ __forceinline__ constexpr int regpos(int k) {
+  return N == 16 ? regpos16(k) : (N == 8 ? ((k & 1) ? 4 + (k >> 1) : (k >> 1)) : ((k & 1) ? 16 + regpos16(k >> 1) : regpos16(k >> 1)));
+}
+template <int N> __device__ __forceinline__ void fft_reg(double2 (&x)[N]);
+template <> __device__ __forceinline__ void fft_reg<8>(double2 (&x)[8]) { fft8(x); }
+template <> __device__ __forceinline__ void fft_reg<16>(double2 (&x)[16]) { fft16(x); }
+template <> __device__ __forceinline__ void fft_reg<32>(double2 (&x)[32]) { fft32(x); }
+
+// N = 16 x N2 (N2 = 8, 16, 32: ny = 128, 256, 512); max(16, N2) threads per column
+template <int LN2>
+__global__ __launch_bounds__(256) void ffty_natreg_kernel(NatArgs q, const double2 *__restrict__ twg, double2 *__restrict__ spec) {
+  extern __shared__ double2 lds[];
+  constexpr int N2 = 1 << LN2, LP = N2 + 1;
+  const int tid = threadIdx.x;
+  const int col = tid % q.C, t = tid / q.C;            // t = n2 in the first step, k1 in the second
+  const int c0 = blockIdx.x * q.C, k = blockIdx.y;
+  const bool on = c0 + col < q.nkxp;
+  double2 *pl = spec + (size_t)k * q.ny * q.nkxp + c0 + col;
+  double2 *mine = lds + col * (16 * LP);
+  if (on && t < N2) {
+    double2 x[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) x[n1] = pl[(size_t)(N2 * n1 + t) * q.nkxp];
+    double2 w[16];                                    // all fifteen twiddles in flight behind the rows, not one wait each
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) w[k1] = twg[t * k1];
+    fft16(x);
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) mine[k1 * LP + t] = k1 == 0 ? x[regpos16(k1)] : cmul(x[regpos16(k1)], w[k1]);
+  }
+  __syncthreads();
+  if (on && t < 16) {
+    double2 x[N2];
+#pragma unroll
+    for (int n2 = 0; n2 < N2; ++n2) x[n2] = mine[t * LP + n2];
+    fft_reg<N2>(x);
+#pragma unroll
+    for (int k2 = 0; k2 < N2; ++k2) pl[(size_t)(t + 16 * k2) * q.nkxp] = x[regpos<N2>(k2)];
+  }
+}
+
 inline int ilog2(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
 inline bool pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
@@ -380,5 +557,88 @@ int fft_y_bwd_pack(udc_handle *h, int k0, int nzc, double *send) {
   FFT_DISPATCH(ilog2(q.ny), hipLaunchKernelGGL(ffty_bwd_pack_kernel<LM>, gr, dim3(FT), lds, h->stream, q,
                                                reinterpret_cast<const double2 *>(h->specB), tw, reinterpret_cast<double2 *>(send)))
   HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// ---- one GPU: forward half in rocFFT's layout (UDC_OWN_FWD=1)
+static size_t nat_x_lds(int M, int L) { return (size_t)2 * L * padded(M + 1) * 16 + (size_t)M * 16; }
+static size_t nat_y_lds(int ny, int C) { return (size_t)2 * C * padded(ny) * 16 + (size_t)ny * 16; }
+
+int fft_nat_init(udc_handle *h) {
+  // default: on where the register y pass exists (ny = 128, 256, 512); UDC_OWN_FWD=0 keeps div_rhs + rocFFT's forward plan,
+  // UDC_OWN_FWD=1 also takes the other power-of-two sizes (Stockham y pass: slower than rocFFT's, for tests)
+  h->own_fwd = false;
+  const int want = getenv("UDC_OWN_FWD") ? atoi(getenv("UDC_OWN_FWD")) : -1;
+  if (want == 0) return 0;
+  const int nx = h->g.nx, ny = h->g.ny, M = nx / 2;
+  if (h->slab || h->fwd_compact || !pow2(nx) || nx < 16 || nx > 2048 || !pow2(ny) || ny < 8 || ny > 1024) return 0;
+  if (want < 0 && !(ny == 128 || ny == 256 || ny == 512)) return 0;
+  if (!h->fft_tw) {
+    const double pi = 3.141592653589793238462643383279502884;
+    std::vector<double> t;
+    for (int n = 0; n < M; ++n) { t.push_back(cos(2. * pi * n / M)); t.push_back(-sin(2. * pi * n / M)); }
+    for (int n = 0; n <= M; ++n) { t.push_back(cos(2. * pi * n / nx)); t.push_back(-sin(2. * pi * n / nx)); }
+    for (int n = 0; n < ny; ++n) { t.push_back(cos(2. * pi * n / ny)); t.push_back(-sin(2. * pi * n / ny)); }
+    HIP_OK(hipMalloc(&h->fft_tw, sizeof(double) * t.size()));
+    HIP_OK(hipMemcpy(h->fft_tw, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
+  }
+  // rows per workgroup of the x kernel: 4 (256^3: 0.085 ms against 0.088 with 2 and 0.097 with 8, profiles/r03/own_fwd_ab.json)
+  int L = 4;
+  while (ny % L) L >>= 1;
+  int C = 8;
+  if (getenv("UDC_NAT_L")) { const int v = atoi(getenv("UDC_NAT_L")); if (pow2(v) && ny % v == 0) L = v; }
+  if (getenv("UDC_NAT_C")) { const int v = atoi(getenv("UDC_NAT_C")); if (v >= 1 && v <= 32) C = v; }
+  h->nat_reg16 = (ny == 128 || ny == 256 || ny == 512) && !(getenv("UDC_NAT_REG") && atoi(getenv("UDC_NAT_REG")) == 0);
+  if (h->nat_reg16) {
+    const int n2 = ny / 16, tpc = n2 > 16 ? n2 : 16;
+    while (C > 1 && C * tpc > 256) C >>= 1;
+    const int ldsb = C * 16 * (n2 + 1) * 16;
+    if (ldsb > 65536) {
+      if (n2 == 32) HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(ffty_natreg_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
+      else if (n2 == 16) HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(ffty_natreg_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
+    }
+  }
+  h->nat_L = L; h->nat_C = C;
+  const int ldsx = (int)nat_x_lds(M, L), ldsy = (int)nat_y_lds(ny, C);
+  if (ldsx > 160 * 1024 || ldsy > 160 * 1024) return 0;
+  const int lmx = ilog2(M), lmy = ilog2(ny);
+  if (ldsx > 65536) {
+    FFT_DISPATCH(lmx, HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(fftx_fwd_nat_kernel<LM>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsx)))
+  }
+  if (ldsy > 65536) {
+    FFT_DISPATCH(lmy, HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(ffty_nat_kernel<LM>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsy)))
+  }
+  h->own_fwd = true;
+  return 0;
+}
+
+// divergence of (pup, pvp, pwp) -> x R2C -> y C2C, into h->spec
+int fft_nat_forward(udc_handle *h) {
+  const Geo &g = h->g;
+  const int M = g.nx / 2;
+  NatArgs q{g.nx, M, padded(M + 1), g.ny, h->nkx, h->nkxp, g.sy, g.sz, ilog2(h->nat_L), h->nat_C, padded(g.ny)};
+  const double2 *tw = reinterpret_cast<const double2 *>(h->fft_tw);
+  const DivArgs dv{h->fields[UDC_UP], h->fields[UDC_VP], h->fields[UDC_WP], h->m.dzfi, h->m.dxi, h->m.dyi, g.nz};
+  double2 *spec = reinterpret_cast<double2 *>(h->spec);
+  {
+    PROF(h, "fftx_pack_fwd");
+    const dim3 gr((unsigned)(g.ny >> q.lL), (unsigned)g.nz);
+    FFT_DISPATCH(ilog2(M), hipLaunchKernelGGL(fftx_fwd_nat_kernel<LM>, gr, dim3(xthreads(LM)), nat_x_lds(M, h->nat_L), h->stream, q, dv, tw, tw + M, spec))
+    HIP_OK(hipGetLastError());
+  }
+  {
+    PROF(h, "unpack_ffty_fwd");
+    const dim3 gr((unsigned)((h->nkxp + q.C - 1) / q.C), (unsigned)g.nz);
+    if (h->nat_reg16) {
+      const int n2 = g.ny / 16, tpc = n2 > 16 ? n2 : 16;
+      const size_t ldsb = (size_t)q.C * 16 * (n2 + 1) * 16;
+      if (n2 == 8) hipLaunchKernelGGL(ffty_natreg_kernel<3>, gr, dim3(tpc * q.C), ldsb, h->stream, q, tw + M + (M + 1), spec);
+      else if (n2 == 16) hipLaunchKernelGGL(ffty_natreg_kernel<4>, gr, dim3(tpc * q.C), ldsb, h->stream, q, tw + M + (M + 1), spec);
+      else hipLaunchKernelGGL(ffty_natreg_kernel<5>, gr, dim3(tpc * q.C), ldsb, h->stream, q, tw + M + (M + 1), spec);
+    } else {
+      FFT_DISPATCH(ilog2(g.ny), hipLaunchKernelGGL(ffty_nat_kernel<LM>, gr, dim3(FT), nat_y_lds(g.ny, q.C), h->stream, q, tw + M + (M + 1), spec))
+    }
+    HIP_OK(hipGetLastError());
+  }
   return 0;
 }

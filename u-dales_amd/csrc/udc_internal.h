@@ -338,6 +338,9 @@ struct udc_handle {
   bool fft_fused = false;
   double *fft_tw = nullptr;             // twiddle tables
   int fft_L = 0, fft_C = 0;             // x rows / y columns per workgroup
+  bool own_fwd = false;                 // UDC_OWN_FWD=1, one GPU: divergence + x transform + y pass of udc_fft.hip instead of div_rhs + rocFFT's forward plan
+  int nat_L = 0, nat_C = 0;
+  bool nat_reg16 = false;               // ny = 256: the y pass as 16 x 16 in registers (UDC_NAT_REG=0: the Stockham kernel)
   bool div_in_fft = false;              // this solve: the x forward transform evaluates fillps' divergence itself
 };
 
@@ -450,6 +453,8 @@ int pois_slab_init(udc_handle *h);
 int k_poisson_solve_slab(udc_handle *h);
 bool fft_fused_possible(const udc_handle *h);
 int fft_fused_init(udc_handle *h);
+int fft_nat_init(udc_handle *h);
+int fft_nat_forward(udc_handle *h);
 int fft_x_fwd_pack(udc_handle *h, int k0, int nzc, double *send, int g0 = 0, int g1 = 0);      // row groups [g0, g1); g1 <= 0: all
 int fft_x_row_groups(const udc_handle *h);
 int fft_x_bwd_unpack(udc_handle *h, int k0, int nzc, const double *recv);

@@ -1148,6 +1148,7 @@ int pois_init(udc_handle *h) {
   FFT_OK(rocfft_execution_info_set_stream(h->info_bwd, h->stream));
   if (wf) FFT_OK(rocfft_execution_info_set_work_buffer(h->info_fwd, h->fft_work, wf));
   if (wb) FFT_OK(rocfft_execution_info_set_work_buffer(h->info_bwd, h->fft_work, wb));
+  if (fft_nat_init(h)) return 1;
   return 0;
 }
 
@@ -1436,7 +1437,9 @@ int k_poisson_solve(udc_handle *h) {
     PROF(h, "fft_pack");
     hipLaunchKernelGGL((real_copy_kernel<false>), gr, b, 0, h->stream, g, tile_grid(g), h->fields[UDC_P], h->rbuf);
   }
-  {
+  if (h->div_in_fft) {
+    if (fft_nat_forward(h)) return 1;
+  } else {
     PROF(h, "fft_fwd");
     void *in[1] = {h->fwd_compact ? h->rbuf : pin}, *out[1] = {h->spec};
     FFT_OK(rocfft_execute(h->plan_fwd, in, out, h->info_fwd));
