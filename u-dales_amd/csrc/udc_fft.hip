@@ -438,6 +438,53 @@ __global__ __launch_bounds__(256) void ffty_natreg_kernel(NatArgs q, const doubl
   }
 }
 
+// The slab path's y transforms the same way (16 x N2 in registers, one trip through LDS), on its y-contiguous lines: lanes run
+// along y, so the loads are runs of N2 and the stores runs of 16 complex.  INV: conj(FFT(conj(x))), unnormalised.
+//   forward:  recv[s][kc][kxl][j]  -> specB[k][kxl][y]        backward:  specB[k][kxl][y] -> send[d][kc][kxl][j]
+template <int LN2, bool INV>
+__global__ __launch_bounds__(256) void ffty_slabreg_kernel(YArgs q, const double2 *__restrict__ in, const double2 *__restrict__ twg,
+                                                           double2 *__restrict__ out) {
+  extern __shared__ double2 lds[];
+  constexpr int N2 = 1 << LN2, LP = N2 + 1, T = N2 > 16 ? N2 : 16, M = 16 * N2;
+  const int tid = threadIdx.x;
+  const int t = tid % T, col = tid / T;               // t = n2 in the first step, k1 in the second
+  const int c0 = blockIdx.x * q.C, kc = blockIdx.y, k = q.k0 + kc;
+  const bool on = c0 + col < q.cx;
+  double2 *mine = lds + col * (16 * LP);
+  const size_t lineB = ((size_t)k * q.cx + c0 + col) * M;                       // specB line
+  auto xoff = [&](int y) {                                                      // exchange-buffer element of (this column, y)
+    const int s_ = y >> q.lnyl, j = y & (q.nyl - 1);
+    return (((size_t)s_ * q.nzc + kc) * q.cx + c0 + col) * q.nyl + j;
+  };
+  if (on && t < N2) {
+    double2 x[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+      const int y = N2 * n1 + t;
+      x[n1] = INV ? cconj(in[lineB + y]) : in[xoff(y)];
+    }
+    double2 w[16];
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) w[k1] = twg[t * k1];
+    fft16(x);
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) mine[k1 * LP + t] = k1 == 0 ? x[regpos16(k1)] : cmul(x[regpos16(k1)], w[k1]);
+  }
+  __syncthreads();
+  if (on && t < 16) {
+    double2 x[N2];
+#pragma unroll
+    for (int n2 = 0; n2 < N2; ++n2) x[n2] = mine[t * LP + n2];
+    fft_reg<N2>(x);
+#pragma unroll
+    for (int k2 = 0; k2 < N2; ++k2) {
+      const int y = t + 16 * k2;
+      if (INV) out[xoff(y)] = cconj(x[regpos<N2>(k2)]);
+      else out[lineB + y] = x[regpos<N2>(k2)];
+    }
+  }
+}
+
 inline int ilog2(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
 inline bool pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
@@ -464,6 +511,7 @@ static size_t y_lds_bytes(const udc_handle *h, int C) { return (size_t)2 * C * p
     default: udc_set_error("fused FFT: unsupported length 2^%d", LMV); return 1;       \
   }
 
+static int slab_yreg_cols(int ny);
 int fft_fused_init(udc_handle *h) {
   const int nx = h->g.nx, ny = h->jtot, M = nx / 2;
   const double pi = 3.141592653589793238462643383279502884;
@@ -484,6 +532,12 @@ int fft_fused_init(udc_handle *h) {
   if (getenv("UDC_FFT_L")) { const int v = atoi(getenv("UDC_FFT_L")); if (pow2(v) && v >= 1 && h->g.ny % v == 0) L = v; }
   if (getenv("UDC_FFT_C")) { const int v = atoi(getenv("UDC_FFT_C")); if (v >= 1) C = v; }
   h->fft_L = L; h->fft_C = C;
+  h->slab_yreg = (ny == 128 || ny == 256 || ny == 512) && !(getenv("UDC_SLAB_YREG") && atoi(getenv("UDC_SLAB_YREG")) == 0);
+  if (h->slab_yreg && ny == 512) {
+    const int ldsb = slab_yreg_cols(ny) * 16 * 33 * 16;
+    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(ffty_slabreg_kernel<5, false>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
+    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(ffty_slabreg_kernel<5, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
+  }
   const int ldsx = (int)x_lds_bytes(h, L), ldsy = (int)y_lds_bytes(h, C);
   if (ldsx > 160 * 1024 || ldsy > 160 * 1024) { h->fft_fused = false; return 0; }
   const int lmx = ilog2(M), lmy = ilog2(ny);
@@ -539,9 +593,25 @@ int fft_x_bwd_unpack(udc_handle *h, int k0, int nzc, const double *recv) {
   HIP_OK(hipGetLastError());
   return 0;
 }
+// register y pass of the slab path: ny = 128, 256, 512 (UDC_SLAB_YREG=0: the Stockham kernels)
+static int slab_yreg_cols(int ny) { const int n2 = ny / 16, tpc = n2 > 16 ? n2 : 16; int C = 8; while (C > 1 && C * tpc > 256) C >>= 1; return C; }
+template <bool INV>
+static int launch_slab_yreg(udc_handle *h, YArgs q, const double2 *in, const double2 *tw, double2 *out) {
+  const int n2 = q.ny / 16, tpc = n2 > 16 ? n2 : 16;
+  q.C = slab_yreg_cols(q.ny);
+  const size_t ldsb = (size_t)q.C * 16 * (n2 + 1) * 16;
+  const dim3 gr((unsigned)((q.cx + q.C - 1) / q.C), (unsigned)q.nzc), b((unsigned)(tpc * q.C));
+  if (n2 == 8) hipLaunchKernelGGL((ffty_slabreg_kernel<3, INV>), gr, b, ldsb, h->stream, q, in, tw, out);
+  else if (n2 == 16) hipLaunchKernelGGL((ffty_slabreg_kernel<4, INV>), gr, b, ldsb, h->stream, q, in, tw, out);
+  else hipLaunchKernelGGL((ffty_slabreg_kernel<5, INV>), gr, b, ldsb, h->stream, q, in, tw, out);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
 int fft_y_fwd_unpack(udc_handle *h, int k0, int nzc, const double *recv) {
   const YArgs q = yargs(h, k0, nzc);
   const double2 *tw = reinterpret_cast<const double2 *>(h->fft_tw) + (h->g.nx / 2) + (h->g.nx / 2 + 1);
+  if (h->slab_yreg) return launch_slab_yreg<false>(h, q, reinterpret_cast<const double2 *>(recv), tw, reinterpret_cast<double2 *>(h->specB));
   const dim3 gr((unsigned)((q.cx + q.C - 1) / q.C), (unsigned)nzc);
   const size_t lds = y_lds_bytes(h, q.C);
   FFT_DISPATCH(ilog2(q.ny), hipLaunchKernelGGL(ffty_fwd_unpack_kernel<LM>, gr, dim3(FT), lds, h->stream, q, reinterpret_cast<const double2 *>(recv),
@@ -552,6 +622,7 @@ int fft_y_fwd_unpack(udc_handle *h, int k0, int nzc, const double *recv) {
 int fft_y_bwd_pack(udc_handle *h, int k0, int nzc, double *send) {
   const YArgs q = yargs(h, k0, nzc);
   const double2 *tw = reinterpret_cast<const double2 *>(h->fft_tw) + (h->g.nx / 2) + (h->g.nx / 2 + 1);
+  if (h->slab_yreg) return launch_slab_yreg<true>(h, q, reinterpret_cast<const double2 *>(h->specB), tw, reinterpret_cast<double2 *>(send));
   const dim3 gr((unsigned)((q.cx + q.C - 1) / q.C), (unsigned)nzc);
   const size_t lds = y_lds_bytes(h, q.C);
   FFT_DISPATCH(ilog2(q.ny), hipLaunchKernelGGL(ffty_bwd_pack_kernel<LM>, gr, dim3(FT), lds, h->stream, q,
