@@ -405,6 +405,9 @@ template <> __device__ __forceinline__ void fft_reg<8>(double2 (&x)[8]) { fft8(x
 template <> __device__ __forceinline__ void fft_reg<16>(double2 (&x)[16]) { fft16(x); }
 template <> __device__ __forceinline__ void fft_reg<32>(double2 (&x)[32]) { fft32(x); }
 
+#ifndef NATREG_CPAD
+#define NATREG_CPAD 2
+#endif
 // N = 16 x N2 (N2 = 8, 16, 32: ny = 128, 256, 512); max(16, N2) threads per column
 template <int LN2>
 __global__ __launch_bounds__(256) void ffty_natreg_kernel(NatArgs q, const double2 *__restrict__ twg, double2 *__restrict__ spec) {
@@ -415,7 +418,7 @@ __global__ __launch_bounds__(256) void ffty_natreg_kernel(NatArgs q, const doubl
   const int c0 = blockIdx.x * q.C, k = blockIdx.y;
   const bool on = c0 + col < q.nkxp;
   double2 *pl = spec + (size_t)k * q.ny * q.nkxp + c0 + col;
-  double2 *mine = lds + col * (16 * LP);
+  double2 *mine = lds + col * (16 * LP + NATREG_CPAD);      // lanes run along the columns here: +2 keeps 8 columns x 2 rows on 16 different 16-B slots
   if (on && t < N2) {
     double2 x[16];
 #pragma unroll
@@ -511,9 +514,10 @@ static size_t y_lds_bytes(const udc_handle *h, int C) { return (size_t)2 * C * p
     default: udc_set_error("fused FFT: unsupported length 2^%d", LMV); return 1;       \
   }
 
-static int slab_yreg_cols(int ny);
-int fft_fused_init(udc_handle *h) {
-  const int nx = h->g.nx, ny = h->jtot, M = nx / 2;
+// twiddle tables of the line transforms: exp(-2 pi i n / M), n < M = nx/2 | exp(-2 pi i n / nx), n <= M | exp(-2 pi i n / ny), n < ny
+static int fft_twiddles(udc_handle *h, int nx, int ny) {
+  if (h->fft_tw) return 0;
+  const int M = nx / 2;
   const double pi = 3.141592653589793238462643383279502884;
   std::vector<double> t;
   t.reserve((size_t)2 * (M + (M + 1) + ny));
@@ -522,6 +526,13 @@ int fft_fused_init(udc_handle *h) {
   for (int n = 0; n < ny; ++n) { t.push_back(cos(2. * pi * n / ny)); t.push_back(-sin(2. * pi * n / ny)); }       // twY
   HIP_OK(hipMalloc(&h->fft_tw, sizeof(double) * t.size()));
   HIP_OK(hipMemcpy(h->fft_tw, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
+  return 0;
+}
+
+static int slab_yreg_cols(int ny);
+int fft_fused_init(udc_handle *h) {
+  const int nx = h->g.nx, ny = h->jtot, M = nx / 2;
+  if (fft_twiddles(h, nx, ny)) return 1;
   // rows per workgroup of the x kernels (= the run length of the packed writes): as long as four workgroups still fit
   // a CU's 160 KB of LDS, at least 4; columns per workgroup of the y kernels likewise (UDC_FFT_L / UDC_FFT_C override)
   int L = 16;
@@ -644,15 +655,7 @@ int fft_nat_init(udc_handle *h) {
   const int nx = h->g.nx, ny = h->g.ny, M = nx / 2;
   if (h->slab || h->fwd_compact || !pow2(nx) || nx < 16 || nx > 2048 || !pow2(ny) || ny < 8 || ny > 1024) return 0;
   if (want < 0 && !(ny == 128 || ny == 256 || ny == 512)) return 0;
-  if (!h->fft_tw) {
-    const double pi = 3.141592653589793238462643383279502884;
-    std::vector<double> t;
-    for (int n = 0; n < M; ++n) { t.push_back(cos(2. * pi * n / M)); t.push_back(-sin(2. * pi * n / M)); }
-    for (int n = 0; n <= M; ++n) { t.push_back(cos(2. * pi * n / nx)); t.push_back(-sin(2. * pi * n / nx)); }
-    for (int n = 0; n < ny; ++n) { t.push_back(cos(2. * pi * n / ny)); t.push_back(-sin(2. * pi * n / ny)); }
-    HIP_OK(hipMalloc(&h->fft_tw, sizeof(double) * t.size()));
-    HIP_OK(hipMemcpy(h->fft_tw, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
-  }
+  if (fft_twiddles(h, nx, ny)) return 1;
   // rows per workgroup of the x kernel: 4 (256^3: 0.085 ms against 0.088 with 2 and 0.097 with 8, profiles/r03/own_fwd_ab.json)
   int L = 4;
   while (ny % L) L >>= 1;
@@ -663,7 +666,7 @@ int fft_nat_init(udc_handle *h) {
   if (h->nat_reg16) {
     const int n2 = ny / 16, tpc = n2 > 16 ? n2 : 16;
     while (C > 1 && C * tpc > 256) C >>= 1;
-    const int ldsb = C * 16 * (n2 + 1) * 16;
+    const int ldsb = C * (16 * (n2 + 1) + NATREG_CPAD) * 16;
     if (ldsb > 65536) {
       if (n2 == 32) HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(ffty_natreg_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
       else if (n2 == 16) HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(ffty_natreg_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
@@ -702,7 +705,7 @@ int fft_nat_forward(udc_handle *h) {
     const dim3 gr((unsigned)((h->nkxp + q.C - 1) / q.C), (unsigned)g.nz);
     if (h->nat_reg16) {
       const int n2 = g.ny / 16, tpc = n2 > 16 ? n2 : 16;
-      const size_t ldsb = (size_t)q.C * 16 * (n2 + 1) * 16;
+      const size_t ldsb = (size_t)q.C * (16 * (n2 + 1) + NATREG_CPAD) * 16;
       if (n2 == 8) hipLaunchKernelGGL(ffty_natreg_kernel<3>, gr, dim3(tpc * q.C), ldsb, h->stream, q, tw + M + (M + 1), spec);
       else if (n2 == 16) hipLaunchKernelGGL(ffty_natreg_kernel<4>, gr, dim3(tpc * q.C), ldsb, h->stream, q, tw + M + (M + 1), spec);
       else hipLaunchKernelGGL(ffty_natreg_kernel<5>, gr, dim3(tpc * q.C), ldsb, h->stream, q, tw + M + (M + 1), spec);
