@@ -15,6 +15,11 @@
 // split / merge step.  All transforms are unnormalised, like rocFFT's and FFTW's (the Thomas kernel carries 1/(nx ny)).
 // Power-of-two lengths only (16 <= nx <= 2048, 8 <= ny <= 1024, power-of-two local rows >= 4); anything else keeps the
 // rocFFT path.
+//
+// One GPU (no exchange): the forward half of the solve also runs here, in rocFFT's own spectral layout spec[k][j][kx] --
+//   fftx_fwd_nat_kernel   divergence of (pup, pvp, pwp) -> R2C -> rows of spec            (div_rhs + rocFFT's x pass in one sweep)
+//   ffty_natreg_kernel    columns of spec, in place, 16 x N2 in registers with one trip through LDS   (ny = 128, 256, 512)
+// and the slab path's y transforms use the same register scheme on their y-contiguous lines (ffty_slabreg_kernel).
 #include "udc_internal.h"
 #include <cmath>
 #include <cstdlib>
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(FT) void ffty_bwd_pack_kernel(YArgs q, const double
 // The single-slab solve keeps rocFFT's spectral layout spec[k][j][kx] (row pitch nkxp) for the Thomas sweep and the backward
 // 2-D transform; its forward half can run here instead: the x transform with fillps' divergence folded in (div_rhs and rocFFT's
 // x pass in one sweep: 32 B per cell instead of 32 + 16) followed by a y pass over columns of that layout, which rocFFT has no
-// single plan for (a strided transform inside two batch dimensions, kx and k).  UDC_OWN_FWD=1 (A/B switch).
+// single plan for (a strided transform inside two batch dimensions, kx and k).  UDC_OWN_FWD=0 restores div_rhs + rocFFT (A/B switch).
 struct NatArgs {
   int nx, M, MP;            // real length, complex length nx/2, LDS pitch of an x line
   int ny, nkx, nkxp;        // rows, r2c modes, row pitch of spec (complex elements)
@@ -642,7 +647,7 @@ int fft_y_bwd_pack(udc_handle *h, int k0, int nzc, double *send) {
   return 0;
 }
 
-// ---- one GPU: forward half in rocFFT's layout (UDC_OWN_FWD=1)
+// ---- one GPU: forward half in rocFFT's layout (default where the register y pass exists; UDC_OWN_FWD=0 / 1)
 static size_t nat_x_lds(int M, int L) { return (size_t)2 * L * padded(M + 1) * 16 + (size_t)M * 16; }
 static size_t nat_y_lds(int ny, int C) { return (size_t)2 * C * padded(ny) * 16 + (size_t)ny * 16; }
 
