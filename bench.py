@@ -48,7 +48,8 @@ ALGO_BYTES = {
     "thomas": 24,               # x read once, written once (LDS-resident columns) + pivot table read twice
     "project_integrate": 72,    # read p (8), pup,pvp,pwp (24); RMW pres0 (16); write u0,v0,w0 (24)
     "scalar": 48,               # read c, ekh, u0,v0,w0 (40); write cp (8) -- tendencies are not re-read in the fused substep
-    # slab (multi-GPU) Poisson stages
+    # slab (multi-GPU) Poisson stages; on one GPU the forward half carries the first two names too (udc_fft.hip: divergence + x transform
+    # into rocFFT's spectral layout = "fftx_pack_fwd" at 32 B, the y pass over it = "unpack_ffty_fwd" at 16 B; 40 + 88 + 32 + 16 + 24 + 32 + 72 = 304 B)
     # (own line FFTs reading / writing the exchange buffers directly: one real field in, one out per stage, DESIGN.md section 6;
     #  the x forward stage of the fused substep evaluates the divergence itself -- reads pup, pvp, pwp instead of p: 24 + 8 = 32,
     #  charged below when the substep launched no div_rhs)
