@@ -661,7 +661,8 @@ int fft_nat_init(udc_handle *h) {
   if (h->slab || h->fwd_compact || !pow2(nx) || nx < 16 || nx > 2048 || !pow2(ny) || ny < 8 || ny > 1024) return 0;
   if (want < 0 && !(ny == 128 || ny == 256 || ny == 512)) return 0;
   if (fft_twiddles(h, nx, ny)) return 1;
-  // rows per workgroup of the x kernel: 4 (256^3: 0.085 ms against 0.088 with 2 and 0.097 with 8, profiles/r03/own_fwd_ab.json)
+  // rows per workgroup of the x kernel: 4 (256^3: 0.085 ms against 0.088 with 2 and 0.097 with 8, profiles/r03/own_fwd_ab.json;
+  // nx = 512: 0.387 against 0.417 / 0.424, nx = 1024: 1.64 against 1.67 / 2.24, profiles/r03/nat_l_scan.json)
   int L = 4;
   while (ny % L) L >>= 1;
   int C = 8;
