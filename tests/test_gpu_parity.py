@@ -312,15 +312,19 @@ def oracle_state(st, g, nsv):
     ((40, 24, 16), 2, 1, 1.05, True),       # floor wall function (lbottom, BCbotm = 3) + scalar floor
     ((12, 8, 6), 0, 0, 1.00, True),         # floor under DNS viscosity
 ])
-@pytest.mark.parametrize("thomas", ["0", "3", "3ws", "3seq"], ids=["thomas-stream", "thomas-lds", "thomas-lds-ws", "thomas-lds-seq"])
+@pytest.mark.parametrize("thomas", ["0", "3", "3ws", "3seq", "4", "4sl16"],
+                         ids=["thomas-stream", "thomas-lds", "thomas-lds-ws", "thomas-lds-seq", "thomas-reg", "thomas-reg-sl16"])
 def test_against_oracle_seeded(shape, sgs, nsv, stretch, floor, thomas, monkeypatch):
     """Three substeps (one RK3 step) vs the CPU oracle on seeded random fields, with every variant of the tridiagonal
     solve (UDC_THOMAS: 0 = streaming kernel, 3 = LDS-resident columns; of the latter the plain kernel with partitioned
-    or (UDC_THOMAS_PART=0) sequential sweeps, and the wave-specialised kernel (UDC_THOMAS_WS=1) that large nz selects)."""
+    or (UDC_THOMAS_PART=0) sequential sweeps, and the wave-specialised kernel (UDC_THOMAS_WS=1); 4 = register-resident segments, the
+    default, with 8 or (UDC_THOMAS_SL=16) 16 levels per thread)."""
     monkeypatch.setenv("UDC_THOMAS", thomas[0])
     monkeypatch.setenv("UDC_THOMAS_WS", "1" if thomas.endswith("ws") else "0")
     if thomas.endswith("seq"):
         monkeypatch.setenv("UDC_THOMAS_PART", "0")
+    if thomas.endswith("sl16"):
+        monkeypatch.setenv("UDC_THOMAS_SL", "16")
     nx, ny, nz = shape
     dz = 0.5 * stretch ** np.arange(nz)
     zf = np.cumsum(dz) - 0.5 * dz

@@ -130,6 +130,46 @@ static int alloc_field(udc_handle *h, int id) {
   return 0;
 }
 
+static int env_int(const char *name, int dflt) {
+  const char *e = getenv(name);
+  return (e && *e) ? atoi(e) : dflt;
+}
+// The one place the library reads its environment (include/udcore.h, "environment").
+void udc_read_switches(Switches &sw) {
+  sw.force_slab = env_int("UDC_FORCE_SLAB", 0) != 0;
+  sw.force_comm = env_int("UDC_FORCE_COMM", 0) != 0;
+  sw.halo_overlap = env_int("UDC_HALO_OVERLAP", 1) != 0;
+  sw.mom_pipe = env_int("UDC_MOM_PIPE", 1) != 0;
+  sw.int_pipe = env_int("UDC_INT_PIPE", 1) != 0;
+  sw.a2a_chunks = env_int("UDC_A2A_CHUNKS", 4);
+  sw.fft_fused = env_int("UDC_FFT_FUSED", 1) != 0;
+  sw.own_fwd = env_int("UDC_OWN_FWD", -1);
+  sw.div_in_fft = env_int("UDC_DIV_IN_FFT", 1) != 0;
+  sw.no_pup = env_int("UDC_NO_PUP", 0) != 0;
+  sw.no_fold = env_int("UDC_NO_FOLD", 0) != 0;
+  sw.no_alias = env_int("UDC_NO_ALIAS", 0) != 0;
+  sw.mom_simple = env_int("UDC_MOM_SIMPLE", 0) != 0;
+  sw.ek_always = env_int("UDC_EK_ALWAYS", 0) != 0;
+  sw.scalar_pair = env_int("UDC_SCALAR_PAIR", 1) != 0;
+  sw.thomas = env_int("UDC_THOMAS", -1);
+  sw.thomas_ws = env_int("UDC_THOMAS_WS", -1);
+  sw.thomas_part = env_int("UDC_THOMAS_PART", 1) != 0;
+  sw.thomas_sl = env_int("UDC_THOMAS_SL", 8);
+  sw.thomas_w = env_int("UDC_THOMAS_W", 3);
+  sw.thomas_pair = env_int("UDC_THOMAS_PAIR", 1) != 0;
+  sw.mom_kc = env_int("UDC_MOM_KC", 0);
+  sw.scalar_kc = env_int("UDC_SCALAR_KC", 0);
+  sw.closure_percu = env_int("UDC_CLOSURE_PERCU", 0);
+  sw.xpad = env_int("UDC_XPAD", -1);
+  sw.spec_pad = env_int("UDC_SPEC_PAD", -1);
+  sw.fft_l = env_int("UDC_FFT_L", 0);
+  sw.fft_c = env_int("UDC_FFT_C", 0);
+  sw.nat_l = env_int("UDC_NAT_L", 0);
+  sw.nat_c = env_int("UDC_NAT_C", 0);
+  sw.nat_reg = env_int("UDC_NAT_REG", 1) != 0;
+  sw.slab_yreg = env_int("UDC_SLAB_YREG", 1) != 0;
+}
+
 extern "C" int udc_create(const udc_config *cfg, udc_handle **out) {
   if (!cfg || !out) { udc_set_error("udc_create: null argument"); return 1; }
   if (cfg->itot < 4 || cfg->jtot < 4 || cfg->ktot < 3) { udc_set_error("udc_create: grid too small"); return 1; }
@@ -146,8 +186,15 @@ extern "C" int udc_create(const udc_config *cfg, udc_handle **out) {
     return 1;
   }
   udc_handle *h = new udc_handle();
+  udc_read_switches(h->sw);
   h->cfg = *cfg;
-  h->device = cfg->device;
+  // device < 0: the library deals the ranks round over the node's devices (one rank per GPU)
+  h->device = cfg->device >= 0 ? cfg->device : cfg->rank % ndev;
+  if (h->device >= ndev) {
+    udc_set_error("udc_create: device index beyond the visible HIP devices");
+    delete h;
+    return 1;
+  }
   HIP_OK(hipSetDevice(h->device));
   HIP_OK(hipStreamCreate(&h->stream));
   Geo &g = h->g;

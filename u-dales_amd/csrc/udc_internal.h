@@ -125,7 +125,38 @@ struct Params {
 
 struct ProfEntry { hipEvent_t a, b; int name; bool own_a; };
 
+// Every environment switch of the library.  Read ONCE, in udc_create (udc_read_switches, udc_api.hip); no launcher reads the
+// environment.  -1 / 0 = "not set: the library's own choice".  DESIGN.md section 9 lists what each one is for.
+struct Switches {
+  // order of a slab substep (A/B switches, each order is tested against the others)
+  int force_slab = 0;        // UDC_FORCE_SLAB=1: one rank through the slab layout
+  int force_comm = 0;        // UDC_FORCE_COMM=1: a real one-rank RCCL communicator under the forced slab path
+  int halo_overlap = 1;      // UDC_HALO_OVERLAP=0: every ghost-row exchange in line
+  int mom_pipe = 1;          // UDC_MOM_PIPE=0: momentum sweep not cut along the solve's k-chunks
+  int int_pipe = 1;          // UDC_INT_PIPE=0: project + integrate not cut along the backward k-chunks
+  int a2a_chunks = 4;        // UDC_A2A_CHUNKS: k-chunks of the transposes
+  int fft_fused = 1;         // UDC_FFT_FUSED=0: rocFFT + transpose kernels on the slab path
+  int own_fwd = -1;          // UDC_OWN_FWD=0/1: single-slab forward half in own kernels
+  int div_in_fft = 1;        // UDC_DIV_IN_FFT=0: separate divergence kernel on the slab path
+  int no_pup = 0, no_fold = 0, no_alias = 0;      // UDC_NO_PUP / UDC_NO_FOLD / UDC_NO_ALIAS = 1
+  int mom_simple = 0;        // UDC_MOM_SIMPLE=1: direct-load kernels (no LDS staging), the small-grid fallback everywhere
+  int ek_always = 0;         // UDC_EK_ALWAYS=1: every substep writes ekm / ekh
+  int scalar_pair = 1;       // UDC_SCALAR_PAIR=0: thl and qt swept one by one
+  // tridiagonal solve
+  int thomas = -1;           // UDC_THOMAS: 0 streaming, 3 LDS-resident columns, 4 register-resident segments
+  int thomas_ws = -1;        // UDC_THOMAS_WS (with 3): wave-specialised or plain
+  int thomas_part = 1;       // UDC_THOMAS_PART=0 (with 3): sequential sweeps
+  int thomas_sl = 8;         // UDC_THOMAS_SL: levels per thread of the register kernel (8 | 16)
+  int thomas_pair = 1;       // UDC_THOMAS_PAIR=0: one GPU: rows ky and ny - ky not solved together
+  int thomas_w = 3;          // UDC_THOMAS_W: waves per SIMD the register kernel is compiled for (2 | 3 | 4)
+  // tuning knobs (0 / -1 = the library's own choice)
+  int mom_kc = 0, scalar_kc = 0, closure_percu = 0, xpad = -1, spec_pad = -1;
+  int fft_l = 0, fft_c = 0, nat_l = 0, nat_c = 0, nat_reg = 1, slab_yreg = 1;
+};
+void udc_read_switches(Switches &sw);
+
 struct udc_handle {
+  Switches sw;
   udc_config cfg;
   Geo g;
   Metrics m;

@@ -682,22 +682,210 @@ __global__ __launch_bounds__(320) void thomas_ws_kernel(int nmodes, int nz, doub
   }
 }
 
-// LDS variant or streaming kernel?  Decided once per table (the table's layout follows the kernel).
-// UDC_THOMAS: 0 = streaming kernel, 3 = LDS kernel whenever it fits; default: the LDS kernel while two workgroups
-// fit on a CU (nz <= ~590).  Measured on MI355X: 512x512x256 (132K modes) 0.389 ms against 0.509 ms streaming,
-// 1024x512x512 (263K modes, 2 workgroups per CU) 2.12 against 2.17 ms.
+// Register-resident segments (round 4).  The LDS-resident kernels above keep a workgroup's columns in LDS and let one
+// wave walk them, 64 dependent chains per CU: they sit at half of the roofline whatever feeds them.  Here nothing is
+// resident anywhere but in registers: thread (mode mm of the workgroup's ZB modes, segment s) owns SL consecutive levels of
+// one complex column -- SL independent 16-B loads of x, SL pivots and SL back-substitution coefficients, all issued before
+// the first use -- and the two sweeps, first-order linear recurrences  v_l = g_l v_prev + t_l,  are solved by partition:
+//   1. zero-inflow recurrence over the own segment -> summary (P = prod g, y) -> LDS, one barrier;
+//   2. every thread chains the summaries of the segments before (forward) / above (back) its own: v_in;
+//   3. the own segment again, from v_in, in the reference's order (src/modpois.f90:1120-1166) -- so only the inflow
+//      value carries the partition's rounding (same class as the partitioned sweeps of the LDS kernels);
+//   the top level (Dirichlet row of the singular mode, :209-220) is closed by the thread that owns it between the sweeps.
+// A wave is 8 modes x 8 segments: every load instruction fetches eight full 128-B lines of x (64-B runs of the blocked
+// tables).  Two barriers per workgroup, no LDS traffic but the summaries; x and both tables cross the bus exactly once.
+// NP = 2 (one GPU, spectral layout spec[k][ky][kx]): the eigenvalue of mode (kx, ky) is xrt(kx) + yrt(ky) with yrt(ky) = yrt(ny - ky)
+// bit for bit (pois_init), so rows ky and ny - ky have the same matrix: the workgroup takes the same eight kx of both rows, and the
+// pivot tables -- a third of the solve's traffic -- are read for one of them only (48 -> 40 B per complex mode and level); rows 0
+// and ny / 2 are their own mirror images and run with the second system switched off.
+template <int SL, int NT, int W, int NP>
+__global__ __launch_bounds__(NT, W) void thomas_reg_kernel(int nmodes, int nz, double scale,
+    const double *__restrict__ ev, const double *__restrict__ tri, double btopD,
+    const double *__restrict__ ztab, double2 *__restrict__ x, int nkb, int ny) {
+  constexpr int M = ZB;                    // modes per workgroup and system = lanes per segment
+  constexpr int NS = NT / M;               // segment slots
+  __shared__ double sP[2][NS][M];
+  __shared__ double2 sY[2][NP][NS][M];
+  const int tid = threadIdx.x, mm = tid & (M - 1), seg = tid >> 3;
+  const int nseg = (nz + SL - 1) / SL;     // segments that hold a level (<= NS)
+  // block of eight modes of system 0 (whose tables are read) and of system 1
+  int blk0 = blockIdx.x, blk1 = blockIdx.x;
+  bool on1 = false;
+  if (NP == 2) {
+    const int kyh = blockIdx.x / nkb, kxb = blockIdx.x - kyh * nkb;
+    on1 = kyh != 0 && 2 * kyh != ny;
+    blk1 = on1 ? (ny - kyh) * nkb + kxb : blk0;
+  }
+  const int mo = blk0 * M + mm;
+  const bool mok = mo < nmodes;
+  const int moc = mok ? mo : nmodes - 1;
+  const double *a = tri, *b = tri + (nz + 2), *c = tri + 2 * (nz + 2);
+  const size_t st = (size_t)nmodes;
+  const int l0 = seg * SL;
+  const size_t ntab = (size_t)((nmodes + ZB - 1) / ZB) * ZB * (size_t)(nz > 1 ? nz - 1 : 1);
+  // addresses: a uniform 64-bit base per level offset j (scalar registers) + one 32-bit byte offset per lane, so that the loads in
+  // flight cost no address registers (the launcher sends arrays of 4 GiB and more to the streaming kernel)
+  const char *zb_ = reinterpret_cast<const char *>(ztab + (size_t)blk0 * (size_t)(nz - 1) * M);      // [lev][M] run of this workgroup
+  const char *cb_ = zb_ + ntab * sizeof(double);
+  char *xb_[NP];
+  xb_[0] = reinterpret_cast<char *>(x + (size_t)blk0 * M);
+  if (NP == 2) xb_[NP - 1] = reinterpret_cast<char *>(x + (size_t)blk1 * M);
+  const unsigned zoff = (unsigned)(((size_t)l0 * M + mm) * sizeof(double));
+  const unsigned xoff = (unsigned)(((size_t)l0 * st + (size_t)(moc - blk0 * M)) * sizeof(double2));
+  double2 t[NP][SL];
+  double g[SL], cz[SL], aj[SL];
+  double2 xt[NP];                          // (x s) of the top level, kept by its owner
+  const unsigned aoff = (unsigned)((l0 + 1) * sizeof(double));
+  // a wave whose eight segments all lie below the top level loads without a test (every load of the kernel is then issued
+  // before the first wait); the wave(s) around the top level test each level
+  const bool full = __all(l0 + SL <= nz - 1) != 0;
+  if (full) {
+#pragma unroll
+    for (int j = 0; j < SL; ++j) {
+#pragma unroll
+      for (int s = 0; s < NP; ++s) t[s][j] = *reinterpret_cast<const double2 *>(xb_[s] + (size_t)j * st * sizeof(double2) + xoff);
+      g[j] = *reinterpret_cast<const double *>(zb_ + (size_t)j * M * sizeof(double) + zoff);
+      cz[j] = *reinterpret_cast<const double *>(cb_ + (size_t)j * M * sizeof(double) + zoff);
+      aj[j] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(a) + j * sizeof(double) + aoff);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < SL; ++j) {
+      const int lev = l0 + j;
+#pragma unroll
+      for (int s = 0; s < NP; ++s)
+        t[s][j] = lev < nz ? *reinterpret_cast<const double2 *>(xb_[s] + (size_t)j * st * sizeof(double2) + xoff) : make_double2(0., 0.);
+      const bool rec = lev < nz - 1;       // levels 1 .. nz-1 of solmpj take part in the recurrences
+      g[j] = rec ? *reinterpret_cast<const double *>(zb_ + (size_t)j * M * sizeof(double) + zoff) : 1.;
+      cz[j] = rec ? *reinterpret_cast<const double *>(cb_ + (size_t)j * M * sizeof(double) + zoff) : 0.;
+      aj[j] = a[min(lev + 1, nz)];
+    }
+  }
+  const double *zt = ztab + (size_t)blk0 * (size_t)(nz - 1) * M + mm;
+  const bool own_top = l0 <= nz - 1 && nz - 1 < l0 + SL;
+  double zl = 0., etop = 0.;
+  if (own_top) { zl = zt[(size_t)(nz - 2) * M]; etop = ev[moc]; }
+  // forward: t = (x s) z, g = -(a z); levels >= nz-1 pass the carry through (g = 1, t = 0)
+  double P = 1.;
+  double2 y[NP];
+#pragma unroll
+  for (int s = 0; s < NP; ++s) { y[s] = make_double2(0., 0.); xt[s] = make_double2(0., 0.); }
+#pragma unroll
+  for (int j = 0; j < SL; ++j) {
+    const int lev = l0 + j;
+    const double zz = g[j];
+    const bool rec = lev < nz - 1;
+    g[j] = rec ? -(aj[j] * zz) : 1.;
+#pragma unroll
+    for (int s = 0; s < NP; ++s) {
+      double2 v = t[s][j];
+      v.x = (v.x * scale) * zz; v.y = (v.y * scale) * zz;
+      if (lev == nz - 1) xt[s] = v;
+      t[s][j] = rec ? v : make_double2(0., 0.);
+      y[s].x = __builtin_fma(g[j], y[s].x, t[s][j].x); y[s].y = __builtin_fma(g[j], y[s].y, t[s][j].y);
+    }
+    P *= g[j];
+  }
+  sP[0][seg][mm] = P;
+#pragma unroll
+  for (int s = 0; s < NP; ++s) sY[0][s][seg][mm] = y[s];
+  __syncthreads();
+  double2 v[NP];
+#pragma unroll
+  for (int s = 0; s < NP; ++s) v[s] = make_double2(0., 0.);
+  for (int q = 0; q < seg; ++q) {
+    const double Pq = sP[0][q][mm];
+#pragma unroll
+    for (int s = 0; s < NP; ++s) {
+      const double2 yq = sY[0][s][q][mm];
+      v[s].x = __builtin_fma(Pq, v[s].x, yq.x); v[s].y = __builtin_fma(Pq, v[s].y, yq.y);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < SL; ++j) {
+#pragma unroll
+    for (int s = 0; s < NP; ++s) {
+      v[s].x = __builtin_fma(g[j], v[s].x, t[s][j].x); v[s].y = __builtin_fma(g[j], v[s].y, t[s][j].y);
+      t[s][j] = v[s];
+    }
+  }
+  if (own_top) {
+    // v = x'_{nz-1} (the levels from nz-1 on passed it through); the singular (0,0) mode gets a Dirichlet condition
+    // across the top cell (:209-220)
+    const double bbk = (etop == 0.) ? btopD : b[nz] + etop;
+    const double ak = a[nz];
+    const double d = c[nz - 1] * zl;
+    const double z = bbk - ak * d;
+#pragma unroll
+    for (int s = 0; s < NP; ++s) {
+      const double2 xc = make_double2((xt[s].x - ak * v[s].x) / z, (xt[s].y - ak * v[s].y) / z);
+#pragma unroll
+      for (int j = 0; j < SL; ++j) if (l0 + j == nz - 1) t[s][j] = xc;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < SL; ++j)
+    if (l0 + j > nz - 1) {
+#pragma unroll
+      for (int s = 0; s < NP; ++s) t[s][j] = make_double2(0., 0.);
+    }
+  // back substitution  x_l = x'_l - (c z)_l x_{l+1}  downwards; the top level has coefficient 0 and x' = its solution
+  P = 1.;
+#pragma unroll
+  for (int s = 0; s < NP; ++s) y[s] = make_double2(0., 0.);
+#pragma unroll
+  for (int j = SL - 1; j >= 0; --j) {
+#pragma unroll
+    for (int s = 0; s < NP; ++s) { y[s].x = __builtin_fma(cz[j], y[s].x, t[s][j].x); y[s].y = __builtin_fma(cz[j], y[s].y, t[s][j].y); }
+    P *= cz[j];
+  }
+  sP[1][seg][mm] = P;
+#pragma unroll
+  for (int s = 0; s < NP; ++s) sY[1][s][seg][mm] = y[s];
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < NP; ++s) v[s] = make_double2(0., 0.);
+  for (int q = nseg - 1; q > seg; --q) {
+    const double Pq = sP[1][q][mm];
+#pragma unroll
+    for (int s = 0; s < NP; ++s) {
+      const double2 yq = sY[1][s][q][mm];
+      v[s].x = __builtin_fma(Pq, v[s].x, yq.x); v[s].y = __builtin_fma(Pq, v[s].y, yq.y);
+    }
+  }
+#pragma unroll
+  for (int j = SL - 1; j >= 0; --j) {
+#pragma unroll
+    for (int s = 0; s < NP; ++s) {
+      v[s].x = __builtin_fma(cz[j], v[s].x, t[s][j].x); v[s].y = __builtin_fma(cz[j], v[s].y, t[s][j].y);
+      if (mok && l0 + j < nz && (s == 0 || on1)) *reinterpret_cast<double2 *>(xb_[s] + (size_t)j * st * sizeof(double2) + xoff) = v[s];
+    }
+  }
+}
+
+// Which solve.  The table's layout follows the kernel, so the choice is made once per table (udc_create reads UDC_THOMAS
+// into the handle: -1 = default, 0 = streaming kernel, 3 = LDS-resident columns, 4 = register-resident segments).
+// Default: register-resident segments for nz <= 1024 (every deck there is), the streaming kernel above that.
 static size_t thomas_lds_bytes(int nz, int M, int KC) { return ((size_t)nz * 2 * M + 3 * (size_t)KC * M + 4 * 2 * M * 2) * sizeof(double); }
-static bool thomas_wants_lds(long nmodes, int nz) {
-  (void)nmodes;
-  const char *env = getenv("UDC_THOMAS");
-  const int mode = env ? atoi(env) : -1;
+static bool thomas_reg_fits(long nmodes, int nz) { return nz >= 3 && nz <= 1024 && (size_t)nmodes * (size_t)nz * 16 < ((size_t)1 << 32); }
+static bool thomas_lds_fits(int nz) { return thomas_lds_bytes(nz, 8, 32) <= 160 * 1024 - 1024; }
+static bool thomas_wants_lds(const udc_handle *h, long nmodes, int nz) {      // the blocked tables (both LDS and register kernels)
+  const int mode = h->sw.thomas;
   if (nz < 2 || mode == 0) return false;
-  const size_t need = thomas_lds_bytes(nz, 8, 32);
-  return mode == 3 ? need <= 160 * 1024 - 1024 : need <= 80 * 1024 - 512;
+  if (mode == 3) return thomas_lds_fits(nz) || thomas_reg_fits(nmodes, nz);
+  return thomas_reg_fits(nmodes, nz);
 }
 static size_t ztab_doubles(long nmodes, int nz) { return (size_t)((nmodes + ZB - 1) / ZB) * ZB * (size_t)(nz > 1 ? nz - 1 : 1); }
 
-static int launch_thomas(udc_handle *h, bool lds, long nmodes, int nz, double scale, const double *ev, const double *ztab, double2 *x) {
+template <int SL, int NT, int W, int NP>
+static void launch_thomas_reg(udc_handle *h, long nmodes, int nz, double scale, const double *ev, const double *ztab, double2 *x, int nkb, int ny) {
+  const unsigned blocks = NP == 2 ? (unsigned)((ny / 2 + 1) * nkb) : (unsigned)((nmodes + ZB - 1) / ZB);
+  hipLaunchKernelGGL((thomas_reg_kernel<SL, NT, (W > NT / 256 ? W : NT / 256), NP>), dim3(blocks), dim3(NT), 0, h->stream,
+                     (int)nmodes, nz, scale, ev, h->tri, h->btopD, ztab, x, nkb, ny);
+}
+
+static int launch_thomas(udc_handle *h, bool lds, long nmodes, int nz, double scale, const double *ev, const double *ztab, double2 *x,
+                         int nkb = 0, int pair_ny = 0) {
   const size_t full = 160 * 1024 - 1024;
   auto need = [&](int M, int KC) { return thomas_lds_bytes(nz, M, KC); };
 #define UDC_TL(M, KC, D, DB, PART)                                                                               \
@@ -712,15 +900,37 @@ static int launch_thomas(udc_handle *h, bool lds, long nmodes, int nz, double sc
                        h->stream, (int)nmodes, nz, scale, ev, h->tri, h->btopD, ztab, x);                    \
     return 0;                                                                                                \
   } while (0)
-  // Which LDS kernel: with four workgroups on a CU (nz <= 256) the plain one hides its own stalls (256^3 0.107 ms
-  // against 0.123 wave-specialised, 512x512x256 0.393 against 0.441); with two (256 < nz <= ~590) the wave-specialised
-  // one wins (1024x512x512: 1.65-1.72 ms against 2.18-2.25).  UDC_THOMAS_WS=0/1 forces the choice.
-  // thomas_lds_kernel: D = chunks of x / pivot loads per workgroup in the forward sweep, DB = chunks of -(c z) in the
-  // back substitution (same box, 512x512x256 / 1024x512x512: DB 2 -> 0.431 / 2.365 ms, 4 -> 0.415 / 2.32,
-  // 8 -> 0.401 / 2.25; D 2 -> 3 -> 4: 2.24 / 2.22 / 2.36); the partitioned sweeps (PART) 0.123 -> 0.104 ms at 256^3.
+  if (lds && !(h->sw.thomas == 3 && thomas_lds_fits(nz)) && thomas_reg_fits(nmodes, nz)) {
+    // levels per thread: 8 (up to 1024 threads per workgroup) unless asked for 4 (nz <= 512) or 16
+    int SL = 8;
+    if (h->sw.thomas_sl == 16) SL = 16;
+    if (h->sw.thomas_sl == 4 && nz <= 512) SL = 4;
+    const int nt = 8 * ((nz + SL - 1) / SL);
+#define UDC_TR(SLv, Wv, NPv)                                                                                      \
+    do {                                                                                                          \
+      if (nt <= 64) launch_thomas_reg<SLv, 64, Wv, NPv>(h, nmodes, nz, scale, ev, ztab, x, nkb, pair_ny);         \
+      else if (nt <= 128) launch_thomas_reg<SLv, 128, Wv, NPv>(h, nmodes, nz, scale, ev, ztab, x, nkb, pair_ny);  \
+      else if (nt <= 256) launch_thomas_reg<SLv, 256, Wv, NPv>(h, nmodes, nz, scale, ev, ztab, x, nkb, pair_ny);  \
+      else if (nt <= 512) launch_thomas_reg<SLv, 512, Wv, NPv>(h, nmodes, nz, scale, ev, ztab, x, nkb, pair_ny);  \
+      else launch_thomas_reg<SLv, 1024, Wv, NPv>(h, nmodes, nz, scale, ev, ztab, x, nkb, pair_ny);                \
+    } while (0)
+    // pair_ny > 0: the caller's modes are spec[k][ky][kx] rows of nkb blocks of eight, ky = 0 .. pair_ny - 1 (one GPU)
+    const bool pair = pair_ny > 0 && h->sw.thomas_pair;
+    const int W = h->sw.thomas_w;
+    if (pair) { if (SL == 4) UDC_TR(4, 4, 2); else UDC_TR(8, 2, 2); }
+    else if (SL == 16) UDC_TR(16, 2, 1);
+    else if (SL == 4) UDC_TR(4, 4, 1);
+    else if (W == 2) UDC_TR(8, 2, 1);
+    else if (W == 4) UDC_TR(8, 4, 1);
+    else UDC_TR(8, 3, 1);
+#undef UDC_TR
+    return 0;
+  }
+  // LDS-resident columns (UDC_THOMAS=3): with four workgroups on a CU (nz <= 256) the plain kernel hides its own stalls (256^3
+  // 0.107 ms against 0.123 wave-specialised, 512x512x256 0.393 against 0.441); with two (256 < nz <= ~590) the wave-specialised
+  // one wins (1024x512x512: 1.65-1.72 ms against 2.18-2.25).
   if (lds) {
-    const char *wse = getenv("UDC_THOMAS_WS");
-    const bool ws = wse ? atoi(wse) != 0 : need(8, 32) * 4 > full;
+    const bool ws = h->sw.thomas_ws >= 0 ? h->sw.thomas_ws != 0 : need(8, 32) * 4 > full;
     if (ws) {
       static std::atomic<bool> ws_attr{false};
       if (!ws_attr) {
@@ -731,7 +941,7 @@ static int launch_thomas(udc_handle *h, bool lds, long nmodes, int nz, double sc
                          scale, ev, h->tri, h->btopD, ztab, x);
       return 0;
     }
-    if (getenv("UDC_THOMAS_PART") && atoi(getenv("UDC_THOMAS_PART")) == 0) UDC_TL(8, 32, 2, 8, false);
+    if (h->sw.thomas_part == 0) UDC_TL(8, 32, 2, 8, false);
     UDC_TL(8, 32, 2, 8, true);
   }
 #undef UDC_TL
@@ -1095,7 +1305,7 @@ int pois_init(udc_handle *h) {
 
   HIP_OK(hipMalloc(&h->spec, sizeof(double) * 2 * nmodes * nz));
   HIP_OK(hipMemsetAsync(h->spec, 0, sizeof(double) * 2 * nmodes * nz, h->stream));
-  h->thomas_lds = thomas_wants_lds((long)nmodes, nz);
+  h->thomas_lds = thomas_wants_lds(h, (long)nmodes, nz);
   HIP_OK(hipMalloc(&h->ztab, sizeof(double) * ztab_doubles((long)nmodes, nz) * (h->thomas_lds ? 2 : 1)));
   HIP_OK(hipMalloc(&h->ev, sizeof(double) * nmodes));
   HIP_OK(hipMalloc(&h->tri, sizeof(double) * tri.size()));
@@ -1217,7 +1427,7 @@ int pois_slab_init(udc_handle *h) {
   HIP_OK(hipMalloc(&h->a2a_send, sizeof(double) * 2 * nmodes * nz));
   HIP_OK(hipMalloc(&h->a2a_recv, sizeof(double) * 2 * nmodes * nz));
   HIP_OK(hipMalloc(&h->ev_slab, sizeof(double) * nmodes));
-  h->thomas_lds_slab = thomas_wants_lds((long)nmodes, nz);
+  h->thomas_lds_slab = thomas_wants_lds(h, (long)nmodes, nz);
   HIP_OK(hipMalloc(&h->ztab_slab, sizeof(double) * ztab_doubles((long)nmodes, nz) * (h->thomas_lds_slab ? 2 : 1)));
   HIP_OK(hipMalloc(&h->tri, sizeof(double) * tri.size()));
   HIP_OK(hipMemcpy(h->ev_slab, ev.data(), sizeof(double) * nmodes, hipMemcpyHostToDevice));
@@ -1446,8 +1656,10 @@ int k_poisson_solve(udc_handle *h) {
   }
   {
     PROF(h, "thomas");
+    // (rows of nkxp complex with nkxp a multiple of eight: the mirrored rows ky, ny - ky are solved together)
+    const bool pairable = h->nkxp % ZB == 0 && g.ny % 2 == 0;
     if (launch_thomas(h, h->thomas_lds, nmodes, g.nz, 1. / ((double)g.nx * (double)g.ny), h->ev, h->ztab,
-                      reinterpret_cast<double2 *>(h->spec))) return 1;
+                      reinterpret_cast<double2 *>(h->spec), pairable ? h->nkxp / ZB : 0, pairable ? g.ny : 0)) return 1;
     HIP_OK(hipGetLastError());
   }
   {
