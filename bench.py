@@ -45,7 +45,8 @@ ALGO_BYTES = {
                                 # (buffer rotation, already staged): 64 -- the timed launches are charged their own mix
     "div_rhs": 32,              # read pup,pvp,pwp; write p
     "fft_fwd": 32, "fft_bwd": 32,   # 2 passes x (8 read + 8 write)
-    "thomas": 24,               # x read once, written once (LDS-resident columns) + pivot table read twice
+    "thomas": 24,               # x read once, written once + both pivot tables read once (SURVEY 8d's figure; one GPU: the mirrored
+                                # rows ky, ny - ky share their tables, 20 B as built)
     "project_integrate": 72,    # read p (8), pup,pvp,pwp (24); RMW pres0 (16); write u0,v0,w0 (24)
     "scalar": 48,               # read c, ekh, u0,v0,w0 (40); write cp (8) -- tendencies are not re-read in the fused substep
     # slab (multi-GPU) Poisson stages; on one GPU the forward half carries the first two names too (udc_fft.hip: divergence + x transform
@@ -55,7 +56,8 @@ ALGO_BYTES = {
     #  charged below when the substep launched no div_rhs)
     "fftx_pack_fwd": 16, "unpack_ffty_fwd": 16, "ffty_pack_bwd": 16, "unpack_fftx_bwd": 16,
 }
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_ACHIEVABLE_GBS = 6300.0    # ... and what the same guide gives as achievable
 
 
 MOM_STAGE1_SAVING = 24         # um, vm, wm are not read on RK stage 1 of the fused substep (um aliases u0)
@@ -306,10 +308,12 @@ def cpu_baseline(nx, ny, nz, budget_s=25.0):
     cells = nx * ny * nz
     nsub = max(1, min(6, int(budget_s * 3.0e6 / cells)))     # ~3e6 cell-updates/s/core expected
     caveat = ("reference Fortran (flang -O3, real(8)) over repo-owned stand-ins for the absent "
-              "2decomp-fft/FFTW layers, wall clock as src/modmpi.f90:140-160")
+              "2decomp-fft/FFTW layers (real line transforms as half-length complex FFT + split, no allocation per line: "
+              "FFT_REF_FAST=1), wall clock as src/modmpi.f90:140-160")
+    fenv = dict(os.environ, FFT_REF_FAST="1")
     with tempfile.TemporaryDirectory() as tmp:
         write_deck(tmp, 900, nx, ny, nz, nsub)
-        v1 = _run_ref(f"{ref} namoptions.900 time none.bin", tmp)
+        v1 = _run_ref(f"{ref} namoptions.900 time none.bin", tmp, env=fenv)
         out = None
         if v1:
             out = {"value": v1, "unit": "cell-updates/s", "cores": 1, "kind": "reference",
@@ -321,7 +325,7 @@ def cpu_baseline(nx, ny, nz, budget_s=25.0):
                 if p > max(ncpu // 2, 1) or ny % p or nz % p or ny // p < 4:
                     continue
                 write_deck(tmp, 900, nx, ny, nz, 2 * nsub, nprocy=p)
-                vp = _run_ref(f"{mpiexec} -n {p} {ref_mpi} namoptions.900 time none.bin", tmp)
+                vp = _run_ref(f"{mpiexec} -n {p} {ref_mpi} namoptions.900 time none.bin", tmp, env=fenv)
                 if vp:
                     scan[p] = vp
             if scan:
@@ -335,8 +339,15 @@ def cpu_baseline(nx, ny, nz, budget_s=25.0):
 
 
 
-def single_gpu_leg(nx, ny, nz, dt, args, device, ms_n, poisson_n, poisson_sub_n):
-    """One GPU, the same grid, the single-slab code path: cheap start state (uniform flow + noise), timing only."""
+INVARIANCE_TOL = 1.0e-9      # ABS_TOL of the reference's decomposition test (tests/integration/processor_boundaries/
+                             # test_processor_boundaries.py:28) on fields of order one; here relative to each field's maximum
+
+
+def single_gpu_leg(nx, ny, nz, dt, args, device, ms_n, poisson_n, poisson_sub_n, init=None, after=None, nsub_inv=0):
+    """One GPU, the same grid, the single-slab code path.  With `init` (global interior u0, v0, w0 of the run's cold start, torch
+    tensors on this device or numpy) the leg starts from the SAME state as the slab ranks did, runs `nsub_inv` substeps and
+    compares u0, v0, w0, pres0 with `after` (the slabs' fields after the same substeps, gathered): the decomposition-invariance
+    record of the line.  Then timing, from wherever the state is."""
     import numpy as np
     import torch
     import udcore
@@ -344,13 +355,23 @@ def single_gpu_leg(nx, ny, nz, dt, args, device, ms_n, poisson_n, poisson_sub_n)
     with tempfile.TemporaryDirectory() as tmp:
         deck1 = read_deck(write_deck(tmp, 903, nx, ny, nz, 0, dt=dt, nprocy=1, nsv=args.nsv, sgs=args.sgs, floor=not args.no_floor))
     c1 = udcore.from_deck(deck1, device=device, rank=0, nranks=1)
-    rng = np.random.default_rng(43)
-    noise = 0.02 * (rng.random(c1.g.mshape()) - 0.5)
-    for k, base in (("u0", 1.0), ("v0", 0.0), ("w0", 0.0)):
-        a = noise + base
-        c1.upload(k, a)
-        c1.upload(k.replace("0", "m"), a)
-    del noise, a
+    if args.ibm:
+        cube_array_ibm(c1, nx, ny, nz)
+    inv = None
+    if init is not None:
+        for k in ("u0", "v0", "w0"):
+            a = init[k].cpu().numpy() if hasattr(init[k], "cpu") else init[k]
+            c1.upload(k, a)
+            c1.upload(k.replace("0", "m"), a)
+            del a
+    else:
+        rng = np.random.default_rng(43)
+        noise = 0.02 * (rng.random(c1.g.mshape()) - 0.5)
+        for k, base in (("u0", 1.0), ("v0", 0.0), ("w0", 0.0)):
+            a = noise + base
+            c1.upload(k, a)
+            c1.upload(k.replace("0", "m"), a)
+        del noise, a
     c1.halos()
     c1.boundary()
 
@@ -362,6 +383,23 @@ def single_gpu_leg(nx, ny, nz, dt, args, device, ms_n, poisson_n, poisson_sub_n)
     def step1():
         c1.substep(rk1[0], dt, True)
         rk1[0] = rk1[0] % 3 + 1
+    if init is not None and after is not None and nsub_inv > 0:
+        for _ in range(nsub_inv):
+            step1()
+        sync1()
+        worst = {}
+        for k in ("u0", "v0", "w0", "pres0"):
+            ref = torch.from_numpy(c1.download(k)[1:-1, 1:-1, 1:-1])
+            got = after[k]
+            got = got if hasattr(got, "cpu") else torch.from_numpy(got)
+            ref = ref.to(got.device)
+            scale = max(float(ref.abs().max()), 1e-30)
+            worst[k] = float((got - ref).abs().max()) / scale
+            del ref, got
+        inv = {"substeps": nsub_inv, "max_rel_diff": {k: float(f"{v:.3e}") for k, v in worst.items()}, "tolerance": INVARIANCE_TOL,
+               "ok": bool(all(v <= INVARIANCE_TOL for v in worst.values())),
+               "against": "rank 0's one-GPU run (single-slab code path) of the same grid from the same cold start, u0 v0 w0 pres0 "
+                          "of every cell, max |slabs - one GPU| / max |one GPU|"}
     for _ in range(6):
         step1()
     n1 = max(6, min(args.steps, 30))
@@ -376,9 +414,137 @@ def single_gpu_leg(nx, ny, nz, dt, args, device, ms_n, poisson_n, poisson_sub_n)
         c1.poisson()
     p1 = time_loop(c1, c1.poisson, 10, sync1)
     c1.close()
-    return {"ms_per_step": round(ms1, 5), "poisson_only_ms": round(p1, 5), "poisson_in_substep_ms": round(ms1 - nonpois, 5),
-            "steps": n1, "speedup_substep": round(ms1 / ms_n, 3), "speedup_poisson": round(p1 / poisson_n, 3),
-            "speedup_poisson_in_substep": round((ms1 - nonpois) / poisson_sub_n, 3)}
+    out = {"ms_per_step": round(ms1, 5), "poisson_only_ms": round(p1, 5), "poisson_in_substep_ms": round(ms1 - nonpois, 5),
+           "steps": n1, "speedup_substep": round(ms1 / ms_n, 3), "speedup_poisson": round(p1 / poisson_n, 3),
+           "speedup_poisson_in_substep": round((ms1 - nonpois) / poisson_sub_n, 3)}
+    return out, inv
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# N > 1: every rank that torch.distributed.run starts is a SUPERVISOR.  It never touches a GPU; it starts the real bench (this file
+# with --worker) as a child with its own rendezvous port, watches the child's heartbeat file, and agrees with the other supervisors
+# (gloo over the launcher's own MASTER_ADDR / MASTER_PORT, one small all-reduce every half second) on what happened.  A child that
+# dies, or whose heartbeat stands still for --stall-timeout seconds (a hung collective), fails the attempt on EVERY rank: all
+# children of the attempt are killed and the next rung of the ladder is tried -- the same workload, the same timed region, with the
+# slab substep's overlap features taken back one group at a time.  The line says which rung produced the number.
+LADDER = [
+    ("defaults", {}),
+    ("ghost rows and sweeps in line", {"UDC_HALO_OVERLAP": "0", "UDC_MOM_PIPE": "0", "UDC_INT_PIPE": "0"}),
+    ("... and the transposes in one piece", {"UDC_HALO_OVERLAP": "0", "UDC_MOM_PIPE": "0", "UDC_INT_PIPE": "0", "UDC_A2A_CHUNKS": "1"}),
+    ("... and rocFFT + transpose kernels instead of the fused line transforms",
+     {"UDC_HALO_OVERLAP": "0", "UDC_MOM_PIPE": "0", "UDC_INT_PIPE": "0", "UDC_A2A_CHUNKS": "1", "UDC_FFT_FUSED": "0"}),
+    ("... and RCCL without peer-to-peer transport (through host memory: degraded links, a number of last resort)",
+     {"UDC_HALO_OVERLAP": "0", "UDC_MOM_PIPE": "0", "UDC_INT_PIPE": "0", "UDC_A2A_CHUNKS": "1", "UDC_FFT_FUSED": "0", "NCCL_P2P_DISABLE": "1"}),
+]
+
+
+def heartbeat(phase):
+    """Worker side: one line per phase into the file the supervisor watches (no file: not supervised)."""
+    fn = os.environ.get("UDC_BENCH_HEARTBEAT")
+    if fn:
+        with open(fn, "a") as f:
+            f.write(f"{time.time():.3f} {phase}\n")
+    inj = os.environ.get("UDC_BENCH_INJECT", "")      # tests only: "rung:phase:hang|exit[:rank]" makes that rung fail at that phase
+    if inj:
+        parts = inj.split(":")
+        if (int(parts[0]) == int(os.environ.get("UDC_BENCH_RUNG", "-1")) and parts[1] == phase
+                and (len(parts) < 4 or int(parts[3]) == int(os.environ.get("RANK", "0")))):
+            if parts[2] == "hang":
+                time.sleep(1e6)
+            raise SystemExit(7)
+
+
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def supervise(args, argv):
+    import signal
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    dist.init_process_group("gloo")
+    tmp = tempfile.mkdtemp(prefix=f"udc_bench_r{rank}_")
+    attempts, line, fallback_line = [], None, None
+    rungs = LADDER if not args.no_ladder else LADDER[:1]
+    for ri, (name, env_extra) in enumerate(rungs):
+        port = [free_port() if rank == 0 else 0]
+        dist.broadcast_object_list(port, src=0)
+        hb, fo, fe = (os.path.join(tmp, f"{x}{ri}") for x in ("hb", "out", "err"))
+        # (the launcher's agent store belongs to the supervisors: the children rendezvous by themselves on their own port)
+        env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+        env.update(MASTER_PORT=str(port[0]), UDC_BENCH_HEARTBEAT=hb, UDC_BENCH_RUNG=str(ri), **env_extra)
+        if env.get("UDC_TEST_SHM"):      # test transport: a segment name per attempt (a killed attempt leaves its segment behind)
+            env["UDC_TEST_SHM"] = f"{env['UDC_TEST_SHM']}_{ri}_{port[0]}"
+        open(hb, "w").close()
+        t0 = time.time()
+        with open(fo, "w") as so, open(fe, "w") as se:
+            child = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv + ["--worker"], env=env, stdout=so, stderr=se,
+                                     start_new_session=True, cwd=os.getcwd())
+        last_size, last_change, my, why = 0, time.time(), 0, ""      # my: 0 running, 1 finished well, 2 failed
+        while True:
+            if my == 0:
+                rc = child.poll()
+                sz = os.path.getsize(hb)
+                if sz != last_size:
+                    last_size, last_change = sz, time.time()
+                if rc is not None:
+                    my, why = (1, "") if rc in (0, 4) else (2, f"exit code {rc}")
+                    if rc == 4:
+                        why = "decomposition-invariance check failed"
+                elif time.time() - last_change > args.stall_timeout:
+                    my, why = 2, f"no progress for {args.stall_timeout:.0f} s after phase '{open(hb).read().strip().splitlines()[-1:] or ['start']}'"
+                elif time.time() - t0 > args.attempt_timeout:
+                    my, why = 2, f"attempt longer than {args.attempt_timeout:.0f} s"
+            t = torch.tensor([int(my == 0), int(my == 1), int(my == 2), int(my == 1 and child.returncode == 4)], dtype=torch.int64)
+            dist.all_reduce(t)
+            if int(t[2]) > 0 or int(t[1]) == world:
+                break
+            time.sleep(0.5)
+        failed, inv_failed = int(t[2]) > 0, int(t[3]) > 0
+        if child.poll() is None:      # somebody's child failed or hung: this attempt is over for everybody
+            try:
+                os.killpg(child.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            child.wait()
+        reasons = [None] * world
+        dist.all_gather_object(reasons, why)
+        att = {"rung": ri, "name": name, "env": env_extra, "seconds": round(time.time() - t0, 1),
+               "outcome": "failed" if failed else ("ran, decomposition-invariance check FAILED" if inv_failed else "ok"),
+               "reasons": sorted(set(r for r in reasons if r))}
+        attempts.append(att)
+        got = None
+        if rank == 0 and not failed:
+            got = next((ln for ln in open(fo).read().splitlines() if ln.startswith('{"metric"')), None)
+        if failed or (rank == 0 and got is None):
+            tail = open(fe).read()[-3000:]
+            print(f"[bench supervisor rank {rank}] rung {ri} ({name}) failed: {why or 'another rank failed'}\n{tail}", file=sys.stderr, flush=True)
+        ok = [bool(got) and not inv_failed]
+        dist.broadcast_object_list(ok, src=0)
+        if rank == 0 and got and fallback_line is None:
+            fallback_line = (ri, got)
+        if ok[0]:
+            line = (ri, got)
+            break
+    if rank == 0:
+        use = line or fallback_line
+        if use:
+            d = json.loads(use[1])
+            d["ladder"] = {"rung": use[0], "name": rungs[use[0]][0], "env": rungs[use[0]][1], "attempts": attempts,
+                           "outcome": "ok" if line else "NO rung passed the decomposition-invariance check: the number is of the first rung that ran to its end",
+                           "stall_timeout_s": args.stall_timeout, "attempt_timeout_s": args.attempt_timeout}
+            print(json.dumps(d), flush=True)
+        else:
+            print(f"[bench supervisor] no rung of the ladder ran to its end: {json.dumps(attempts)}", file=sys.stderr, flush=True)
+    good = [bool(line or fallback_line)]
+    dist.broadcast_object_list(good, src=0)
+    dist.destroy_process_group()
+    raise SystemExit(0 if good[0] else 5)
+
 
 def live_traffic(args, dom, timeout_s=240):
     """HBM bytes per launch of the dominant kernel, measured in THIS run: two child runs of this script (the same workload, 9 substeps,
@@ -451,7 +617,16 @@ def main():
                     help="a staggered cube array with the immersed boundary and neutral facet wall functions (BASELINE configs[4]'s layout)")
     ap.add_argument("--no-floor", action="store_true",
                     help="free floor instead of the neutral log-law wall function (lbottom, BCbotm = 3) of SURVEY 8d")
+    ap.add_argument("--no-invariance", action="store_true", help="N>1: skip the field comparison with the one-GPU run")
+    ap.add_argument("--invariance-substeps", type=int, default=6, help="substeps from the cold start after which the fields are compared")
+    ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)      # the supervised child of an N>1 run
+    ap.add_argument("--no-ladder", action="store_true", help="N>1: one attempt with the defaults, no fallback rungs")
+    ap.add_argument("--stall-timeout", type=float, default=240., help="N>1: seconds without a heartbeat before an attempt is killed")
+    ap.add_argument("--attempt-timeout", type=float, default=1500., help="N>1: seconds an attempt may take in all")
     args = ap.parse_args()
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not args.worker and int(os.environ.get("WORLD_SIZE", "1")) == args.gpus:
+        supervise(args, sys.argv[1:])
+    heartbeat("start")
 
     import numpy as np
     import torch
@@ -512,11 +687,28 @@ def main():
     g = core.g
     nyl = ny // world
     ibm_counts = cube_array_ibm(core, nx, ny, nz) if args.ibm else None
+    heartbeat("communicator")
     st = cold_start(g, deck, j0=rank * nyl, nyl=nyl, nsv=args.nsv)
     core.load_state(st)
     core.halos()
     core.boundary()
+    want_single = (world > 1 and not args.no_single) or args.with_single
+    want_inv = want_single and not args.no_invariance and args.invariance_substeps > 0
+    nsub_inv = 3 * ((args.invariance_substeps + 2) // 3)      # whole RK3 steps: the timed loop starts at stage 1 again
+    init_rows = {k: np.ascontiguousarray(st[k][1:-1, 1:-1, 1:-1]) for k in ("u0", "v0", "w0")} if want_inv else None
     del st
+    heartbeat("cold start loaded")
+    after_rows = None
+    if want_inv:
+        # decomposition invariance, first half: the slabs' fields after `nsub_inv` substeps from the cold start (the one-GPU run they
+        # are compared with follows after the timed region, on rank 0)
+        rk_ = 1
+        for _ in range(nsub_inv):
+            core.substep(rk_, dt, True)
+            rk_ = rk_ % 3 + 1
+        core.sync()
+        after_rows = {k: np.ascontiguousarray(core.download(k)[1:-1, 1:-1, 1:-1]) for k in ("u0", "v0", "w0", "pres0")}
+        heartbeat("invariance substeps")
 
     def barrier():
         if world > 1:
@@ -550,6 +742,7 @@ def main():
     nscal = args.nsv                      # transported scalars the integrate kernel also advances (the bench deck has no thl, qt)
     cand = [k for k in table if algo_bytes(k, nscal)]
     dom = max(cand, key=lambda k: table[k][0]) if cand else None
+    heartbeat("warm-up")
     barrier()
     core.profile(True, focus=dom)
     core.profile_reset()
@@ -572,6 +765,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    heartbeat("timed region")
     elapsed = allmax(elapsed)
     divmax, _ = core.divergence()
     # the reference's `poisson` routine alone (src/modpois.f90:419: fillps + bcpup, FFTs / transposes, solmpj, tderive + bcp)
@@ -579,6 +773,7 @@ def main():
     for _ in range(3):
         core.poisson()
     poisson_ms = allmax(time_loop(core, core.poisson, 20, barrier))
+    heartbeat("poisson alone")
     # the same solve as the fused substep runs it (pup mode: the divergence of the stored predicted velocity, on the slab
     # path inside the x transform; projection fused with the RK3 update): substep time minus its non-Poisson kernels
     survey = table if table else prof          # (no warm-up: the timed region carried every marker)
@@ -609,7 +804,8 @@ def main():
         avg_ms = ms / max(cnt, 1)
         per_substep = cnt / max(args.steps if (live or not table) else n_tab, 1)
         net = avg_ms if (live or not table) else max(avg_ms - marker_ms, 0.)
-        ent = {"avg_ms": round(avg_ms, 5), "avg_ms_net": round(net, 5), "launches": cnt, "share": round(net * per_substep / ms_per, 4),
+        ent = {"avg_ms": round(avg_ms, 5), "avg_ms_net": round(net, 5), "launches": cnt, "launches_per_substep": round(per_substep, 3),
+               "share": round(net * per_substep / ms_per, 4),
                "measured": "timed region" if (live or not table) else f"survey over {n_tab} untimed substeps, every launch marked"}
         if ab and net > 0.:      # (a launch shorter than the marker's cost nets to zero on tiny test grids: no rate for it)
             gbs = ab * cells_local / (net * 1e-3) / 1e9
@@ -645,7 +841,9 @@ def main():
     roofline = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": kernels[dom]["frac"], "traffic": traffic, "traffic_source": traffic_src,
                 "algo_bytes_per_launch": int(kernels[dom]["algo_bytes_per_cell"] * cells_local),
-                "avg_launch_ms": kernels[dom]["avg_ms"]}
+                "avg_launch_ms": kernels[dom]["avg_ms"],
+                # the rate MI355X_MICROARCH.md calls achievable for streaming kernels, next to the nominal peak
+                "achievable": HBM_ACHIEVABLE_GBS, "frac_of_achievable": round(kernels[dom]["achieved_GBs"] / HBM_ACHIEVABLE_GBS, 4)}
     # measured copy ceiling of this GPU (BASELINE.md asks for the fraction against it next to the nominal 8 TB/s):
     # a 1 GiB device-to-device copy, read + write bytes over the best of 10 repetitions, outside the timed region
     try:
@@ -659,12 +857,19 @@ def main():
         ceiling = 2 * src.numel() * 8 / (best * 1e-3) / 1e9
         roofline["copy_ceiling"] = round(ceiling, 1)
         roofline["frac_of_copy_ceiling"] = round(kernels[dom]["achieved_GBs"] / ceiling, 4)
+        roofline["copy_ceiling_note"] = "1 GiB device-to-device copy on this GPU, read + write bytes, best of 12"
         del src, dst
     except Exception:      # noqa: BLE001 (the ceiling is a side measurement: never let it take the bench line down)
         pass
-    ab_sum = sum(k["algo_bytes_per_cell"] * k["share"] * ms_per / k["avg_ms"] for k in kernels.values() if "algo_bytes_per_cell" in k)
+    # bytes the substep as built must move: every kernel's algorithmic bytes x the whole-grid passes it makes per substep -- its
+    # launches per substep on the single-slab path (one per transported scalar for the scalar sweeps); on the slab path the sweeps
+    # are cut into launches over parts of the slab (edge rows / interior, level ranges) that add up to one pass
+    slab_path = world > 1 or os.environ.get("UDC_FORCE_SLAB", "0") not in ("", "0")
+    ab_sum = sum(k["algo_bytes_per_cell"] * ((max(args.nsv, 1) if name.startswith("scalar") else 1) if slab_path else k["launches_per_substep"])
+                 for name, k in kernels.items() if "algo_bytes_per_cell" in k)
     as_built = {"bytes_per_cell_update": round(ab_sum, 1),
                 "frac_of_hbm_peak": round(ab_sum * cells_local * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4)}
+    as_built["frac_of_achievable"] = round(ab_sum * cells_local * args.steps / elapsed / 1e9 / HBM_ACHIEVABLE_GBS, 4)
     if "copy_ceiling" in roofline:
         as_built["frac_of_copy_ceiling"] = round(ab_sum * cells_local * args.steps / elapsed / 1e9 / roofline["copy_ceiling"], 4)
     out = {
@@ -679,6 +884,8 @@ def main():
                    "grid": [nx, ny, nz], "decomposition": f"y-slabs x{world}", "dt": dt,
                    **({"slab_order": {"ghost_rows_beside_compute": os.environ.get("UDC_HALO_OVERLAP", "1") != "0",
                                       "momentum_sweep_pipelined_with_solve": os.environ.get("UDC_MOM_PIPE", "1") != "0",
+                                      "project_integrate_pipelined_with_solve": os.environ.get("UDC_INT_PIPE", "1") != "0",
+                                      "fused_line_transforms": os.environ.get("UDC_FFT_FUSED", "1") != "0",
                                       "transpose_k_chunks": int(os.environ.get("UDC_A2A_CHUNKS", "4"))}} if world > 1 else {}),
                    "step": "one RK3 substep = one cell-update per cell"},
         "whole_substep_hbm_frac": round(392.0 * cells_local * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4),
@@ -693,18 +900,39 @@ def main():
         "kernels_note": {"marker_cost_ms_per_launch": round(marker_ms, 5), "surveyed_substeps": n_tab,
                          "sum_of_shares": round(sum(k["share"] for k in kernels.values()), 4)},
     }
-    if (world > 1 and not args.no_single) or args.with_single:
+    inv_ok = True
+    if want_single:
         # rank 0's own one-GPU run of the SAME grid (single-slab code path), so that every N>1 line carries its strong-scaling
-        # reference; the other ranks wait at the barrier below
-        single = None
+        # reference AND the field comparison behind it; the other ranks hand over their rows and wait at the barrier below
+        single, inv = None, None
+        init_g = after_g = None
+        if want_inv:
+            def gather_rows(a):      # [nz, nyl, nx] of every rank -> [nz, ny, nx] on rank 0 (device tensors under RCCL, host under gloo)
+                t = torch.from_numpy(a)
+                if world == 1:
+                    return t
+                t = t.cuda() if dist.get_backend() == "nccl" else t
+                parts = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+                dist.gather(t, parts, dst=0)
+                return torch.cat(parts, dim=1) if rank == 0 else None
+            init_g = {k: gather_rows(v) for k, v in init_rows.items()}
+            after_g = {k: gather_rows(v) for k, v in after_rows.items()}
+            del init_rows, after_rows
+            heartbeat("rows gathered")
         if rank == 0:
             try:
-                single = single_gpu_leg(nx, ny, nz, dt, args, local_rank, elapsed / args.steps * 1e3, poisson_ms, poisson_in_substep_ms)
+                single, inv = single_gpu_leg(nx, ny, nz, dt, args, dev, elapsed / args.steps * 1e3,
+                                             poisson_ms, poisson_in_substep_ms, init_g if want_inv else None, after_g, nsub_inv)
             except Exception as e:      # noqa: BLE001 (a side measurement: never let it take the bench line down)
                 single = {"error": repr(e)[:300]}
+        del init_g, after_g
         if world > 1:
             dist.barrier()
+        heartbeat("one-GPU leg")
         out["single_gpu_same_workload"] = single
+        if want_inv:
+            out["decomposition_invariance"] = inv if inv else {"ok": False, "error": "the one-GPU run did not finish", "tolerance": INVARIANCE_TOL}
+            inv_ok = bool(inv and inv["ok"])
     if rank == 0:
         if world == 1 and not args.no_cpu:
             cb = cpu_baseline(nx, ny, nz)
@@ -720,7 +948,13 @@ def main():
     if core is not None:
         core.close()
     if world > 1:
+        ok = [inv_ok]
+        dist.broadcast_object_list(ok, src=0)
+        inv_ok = ok[0]
         dist.destroy_process_group()
+    heartbeat("done")
+    if not inv_ok:
+        raise SystemExit(4)      # the line is printed, flagged; a supervised run goes on to the next rung
 
 
 if __name__ == "__main__":

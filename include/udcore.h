@@ -62,7 +62,7 @@ enum { UDC_TOP_FREESLIP = 1, UDC_TOP_NOSLIP = 2 };
 typedef struct udc_config {
   int itot, jtot, ktot;     /* global grid (&DOMAIN)                                     */
   int nranks, rank;         /* y-slab decomposition: nprocx = 1, nprocy = nranks          */
-  int device;               /* HIP device ordinal for this rank                           */
+  int device;               /* HIP device ordinal for this rank; < 0: rank % visible devices */
   double dx, dy;            /* xlen/itot, ylen/jtot                                       */
   const double *dzf;        /* [ktot+2] = dzf(kb-1:ke+1)   (copied)                       */
   const double *dzh;        /* [ktot+2], entry k = dzh(k), k = 1..ktot+1 (entry 0 unused) */

@@ -93,3 +93,32 @@ def nocorner(a, h=1):
     b = a.copy()
     b[:, :h, :h] = 0; b[:, :h, -h:] = 0; b[:, -h:, :h] = 0; b[:, -h:, -h:] = 0
     return b
+
+
+# ---- multi-rank launches: real RCCL wherever the box has a GPU per rank, the shared-memory test transport on a one-GPU box --------
+REFDIR = os.path.join(os.path.dirname(HERE), "oracle", "_ref")
+MPIEXEC = "/opt/conda/bin/mpiexec"
+
+
+def gpu_count():
+    try:
+        import torch
+        return torch.cuda.device_count() if torch.cuda.is_available() else 0
+    except Exception:      # noqa: BLE001
+        return 0
+
+
+def mpi_transport(nranks, tag):
+    """-> (executable, environment, label) for `mpiexec -n nranks` of the reference's program over the drop-in modules.
+
+    A box with at least `nranks` GPUs runs the PRODUCT: oracle/_ref/udales_full_dropin_mpi over libudcore.so, one rank per GPU,
+    ghost rows / transposes / reductions through RCCL (udc_comm_init).  A one-GPU box runs the test build
+    (udales_full_dropin_mpi_test over libudcore_test.so), every rank on device 0, the same exchanges through a shared-memory
+    segment (UDC_TEST_SHM) -- which validates the harness and everything but RCCL's byte mover."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", UDC_RESIDENCY="2")
+    if gpu_count() >= nranks:
+        env.pop("UDC_GPUS_PER_NODE", None)
+        env.pop("UDC_TEST_SHM", None)
+        return os.path.join(REFDIR, "udales_full_dropin_mpi"), env, "rccl"
+    env.update(UDC_GPUS_PER_NODE="1", UDC_TEST_SHM=f"/udc_{tag}_{os.getpid()}_{nranks}")
+    return os.path.join(REFDIR, "udales_full_dropin_mpi_test"), env, "shm"

@@ -312,19 +312,16 @@ def oracle_state(st, g, nsv):
     ((40, 24, 16), 2, 1, 1.05, True),       # floor wall function (lbottom, BCbotm = 3) + scalar floor
     ((12, 8, 6), 0, 0, 1.00, True),         # floor under DNS viscosity
 ])
-@pytest.mark.parametrize("thomas", ["0", "3", "3ws", "3seq", "4", "4sl16"],
-                         ids=["thomas-stream", "thomas-lds", "thomas-lds-ws", "thomas-lds-seq", "thomas-reg", "thomas-reg-sl16"])
+@pytest.mark.parametrize("thomas", ["stream", "reg", "reg-nopair"])
 def test_against_oracle_seeded(shape, sgs, nsv, stretch, floor, thomas, monkeypatch):
-    """Three substeps (one RK3 step) vs the CPU oracle on seeded random fields, with every variant of the tridiagonal
-    solve (UDC_THOMAS: 0 = streaming kernel, 3 = LDS-resident columns; of the latter the plain kernel with partitioned
-    or (UDC_THOMAS_PART=0) sequential sweeps, and the wave-specialised kernel (UDC_THOMAS_WS=1); 4 = register-resident segments, the
-    default, with 8 or (UDC_THOMAS_SL=16) 16 levels per thread)."""
-    monkeypatch.setenv("UDC_THOMAS", thomas[0])
-    monkeypatch.setenv("UDC_THOMAS_WS", "1" if thomas.endswith("ws") else "0")
-    if thomas.endswith("seq"):
-        monkeypatch.setenv("UDC_THOMAS_PART", "0")
-    if thomas.endswith("sl16"):
-        monkeypatch.setenv("UDC_THOMAS_SL", "16")
+    """Three substeps (one RK3 step) vs the CPU oracle on seeded random fields, with every variant of the tridiagonal solve:
+    the streaming kernel (UDC_THOMAS=0: one thread per mode, solmpj's own order), register-resident segments (the default:
+    partitioned recurrences, rows ky and ny - ky of the one-GPU layout solved together) and the same without the pairing
+    (UDC_THOMAS_PAIR=0: what the slab ranks run)."""
+    if thomas == "stream":
+        monkeypatch.setenv("UDC_THOMAS", "0")
+    if thomas == "reg-nopair":
+        monkeypatch.setenv("UDC_THOMAS_PAIR", "0")
     nx, ny, nz = shape
     dz = 0.5 * stretch ** np.arange(nz)
     zf = np.cumsum(dz) - 0.5 * dz

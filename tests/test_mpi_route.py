@@ -8,7 +8,8 @@ MPI_BCAST carries it over comm3d, every rank calls udc_comm_init -- joins the co
   * Without a GPU (here): both ranks must stop at udc_create with the library's refusal, not hang and not fall back.
   * On a one-GPU box: with both ranks mapped onto the one device (UDC_GPUS_PER_NODE=1) both must get through udc_create and the
     broadcast and into udc_comm_init, where RCCL refuses two ranks on one device; both leave with that error.
-The real two-GPU run is the driver's scaling bench."""
+  * On a box with a GPU per rank the decks below run over RCCL itself (common.mpi_transport picks the product executable there,
+    the shared-memory test transport on a one-GPU box): 2, 4 and 8 ranks against the one-rank fixtures."""
 import os
 import re
 import shutil
@@ -16,7 +17,7 @@ import subprocess
 
 import pytest
 
-from common import GOLDEN, RUN_CASES
+from common import GOLDEN, RUN_CASES, gpu_count, mpi_transport
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "oracle", "_ref", "udales_full_dropin_mpi")
@@ -59,7 +60,7 @@ def test_two_mpi_ranks_on_one_gpu_reach_udc_comm_init(tmp_path):
     if not (os.path.exists(EXE) and os.path.exists(MPIEXEC)):
         pytest.skip("oracle/_ref/udales_full_dropin_mpi or MPICH not available")
     if torch.cuda.device_count() >= 2:
-        pytest.skip("more than one GPU here: the real N = 2 run is the driver's scaling bench")
+        pytest.skip("a one-GPU behaviour (RCCL's refusal of two ranks per device); here test_mpi_ranks_run_the_deck_to_the_end runs over RCCL")
     r = launch(tmp_path, {"UDC_GPUS_PER_NODE": "1"})
     out = r.stdout + r.stderr
     assert r.returncode != 0, out[-2000:]
@@ -95,8 +96,10 @@ def run_ranks(name, iexp, tmp_path, nranks, deck_edit=None):
         txt = deck_edit(txt)
     with open(deck, "w") as f:
         f.write(txt)
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", UDC_RESIDENCY="2", UDC_GPUS_PER_NODE="1", UDC_TEST_SHM=f"/udc_test_{os.getpid()}_{nranks}")
-    r = subprocess.run(f"ulimit -s unlimited; exec {MPIEXEC} -n {nranks} {EXE_TEST} namoptions.{iexp:03d}", shell=True, cwd=tmp_path, env=env,
+    exe, env, _ = mpi_transport(nranks, "test")
+    if not (os.path.exists(exe) and os.path.exists(MPIEXEC)):
+        pytest.skip(f"{exe} or MPICH not available")
+    r = subprocess.run(f"ulimit -s unlimited; exec {MPIEXEC} -n {nranks} {exe} namoptions.{iexp:03d}", shell=True, cwd=tmp_path, env=env,
                        capture_output=True, text=True, timeout=900, executable="/bin/bash")
     assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-2500:]
     return fix, last
@@ -104,17 +107,19 @@ def run_ranks(name, iexp, tmp_path, nranks, deck_edit=None):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,P", [("run_16x16x8", 2), ("run_16x16x8", 4), ("run_smag_scalar_16x8x12s", 2),
-                                    ("run_moist_16x8x12s", 2), ("run_ibm_wf2_16x12x10", 2), ("run_ibm_moistwq_16x12x10", 2)])
-def test_two_mpi_ranks_run_the_deck_to_the_end(name, P, tmp_path):
-    """mpiexec -n P (2, 4) of the reference's real program with the drop-in modules, nprocy = P: MPI start-up and broadcasts, two library
-    handles with two slabs, the Fortran modules' slab logic (rows of the point lists and facet sections, masks, per-rank restart
+                                    ("run_moist_16x8x12s", 2), ("run_ibm_wf2_16x12x10", 2), ("run_ibm_wf2_16x12x10", 3),
+                                    ("run_ibm_moistwq_16x12x10", 2)])
+def test_mpi_ranks_run_the_deck_to_the_end(name, P, tmp_path):
+    """mpiexec -n P (2, 3, 4) of the reference's real program with the drop-in modules, nprocy = P: MPI start-up and broadcasts, P library
+    handles with P slabs, the Fortran modules' slab logic (rows of the point lists and facet sections, masks, per-rank restart
     files), ghost rows and the Poisson transposes through the library's multi-rank path -- against the one-rank fixture of the
-    all-reference executable, through the restart files both ranks write."""
+    all-reference executable, through the restart files the ranks write.  Transport: RCCL where the box has P GPUs (the product
+    executable), the shared-memory stand-in on a one-GPU box; a box with 2 <= GPUs < P skips the P-rank case."""
+    if 1 < gpu_count() < P:
+        pytest.skip(f"{P} ranks need {P} GPUs (or the one-GPU test transport)")
     import numpy as np
     from common import nocorner, relerr
     from udcore import restart
-    if not (os.path.exists(EXE_TEST) and os.path.exists(MPIEXEC)):
-        pytest.skip("oracle/_ref/udales_full_dropin_mpi_test or MPICH not available")
     iexp = RUN_CASES[name]
     fix, last = run_ranks(name, iexp, tmp_path, P)
     nx, ny, nz = (int(v) for v in fix["meta"].data[:3])
@@ -150,8 +155,6 @@ def test_statistics_tables_on_two_mpi_ranks(name, tmp_path):
     file per rank, its own rows) equal the one-rank run's."""
     import numpy as np
     from refdump import read_ncrec
-    if not (os.path.exists(EXE_TEST) and os.path.exists(MPIEXEC)):
-        pytest.skip("oracle/_ref/udales_full_dropin_mpi_test or MPICH not available")
     iexp = RUN_CASES[name]
     edit = lambda t: re.sub(r"tstatsdump\s*=\s*1000\.", "tstatsdump = 1.0", t.replace("&OUTPUT", "&OUTPUT\nlxydump = .true.\nlydump = .true."))      # noqa: E731
     out = {}

@@ -12,8 +12,8 @@
 2. tests/integration/processor_boundaries/test_processor_boundaries.py -- "the only solver-numerics pin" of the reference: case 100
    (128^3, the Xie / Castro cube array) run for one step (namoptions.100.serial) on 1 x 1, 2 x 1, 1 x 2, 2 x 2 ranks, `ut, vt, wt` of
    tdump compared: <= 1e-9 on the bands next to the rank boundaries, <= 2e-8 everywhere (their files are float32).  Here the
-   candidates are the device runs -- the reference's program with the drop-in modules on one rank and on 2 / 4 MPI ranks (y split;
-   the ranks share the one GPU through the test library's transport) -- and the reference is the ALL-REFERENCE executable on the
+   candidates are the device runs -- the reference's program with the drop-in modules on one rank and on 2 / 4 (/ 8) MPI ranks (y split;
+   over RCCL where the box has a GPU per rank, else sharing the one GPU through the test library's transport) -- and the reference is the ALL-REFERENCE executable on the
    box's host: <= 1e-9 EVERYWHERE for all three fields (the recording NetCDF stand-in keeps float64, so no float32 allowance is
    needed), i.e. their decomposition-invariance test and a parity test against the reference in one.
 
@@ -27,7 +27,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from common import GOLDEN
+from common import GOLDEN, gpu_count, mpi_transport
 from refdump import read_ncrec
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -213,14 +213,17 @@ def test_processor_boundaries_case_100(steps, tmp_path):
     r = run(tmp_path / "dev1", DROPIN, env=dict(os.environ, UDC_RESIDENCY="2"))
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     out["device, serial"] = tdump_fields(tmp_path / "dev1", 1)
-    if os.path.exists(DROPIN_MPI_TEST) and os.path.exists(MPIEXEC):
-        for P in (2, 4):
+    if os.path.exists(MPIEXEC):
+        # RCCL where the box has a GPU per rank (2, 4, 8 ranks of the product executable), the shared-memory test transport on one GPU
+        for P in ((2, 4) if gpu_count() < 2 else tuple(q for q in (2, 4, 8) if q <= gpu_count())):
+            exe, env, how = mpi_transport(P, "c100")
+            if not os.path.exists(exe):
+                continue
             d = tmp_path / f"dev{P}"
             stage(d, "namoptions.100.serial", nprocy=P, steps=steps)
-            env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", UDC_RESIDENCY="2", UDC_GPUS_PER_NODE="1", UDC_TEST_SHM=f"/udc_c100_{os.getpid()}_{P}")
-            r = run(d, DROPIN_MPI_TEST, P, env=env)
+            r = run(d, exe, P, env=env)
             assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
-            out[f"device, y split over {P}"] = tdump_fields(d, P)
+            out[f"device, y split over {P} ({how})"] = tdump_fields(d, P)
     ref = out["reference, serial"]
     assert ref["ut"].shape == (128, 128, 128) and np.abs(ref["ut"]).max() > 1.      # (u0 = 3 m/s + noise of amplitude randu = 1)
     worst = {}

@@ -152,10 +152,6 @@ void udc_read_switches(Switches &sw) {
   sw.ek_always = env_int("UDC_EK_ALWAYS", 0) != 0;
   sw.scalar_pair = env_int("UDC_SCALAR_PAIR", 1) != 0;
   sw.thomas = env_int("UDC_THOMAS", -1);
-  sw.thomas_ws = env_int("UDC_THOMAS_WS", -1);
-  sw.thomas_part = env_int("UDC_THOMAS_PART", 1) != 0;
-  sw.thomas_sl = env_int("UDC_THOMAS_SL", 8);
-  sw.thomas_w = env_int("UDC_THOMAS_W", 3);
   sw.thomas_pair = env_int("UDC_THOMAS_PAIR", 1) != 0;
   sw.mom_kc = env_int("UDC_MOM_KC", 0);
   sw.scalar_kc = env_int("UDC_SCALAR_KC", 0);
@@ -200,23 +196,20 @@ extern "C" int udc_create(const udc_config *cfg, udc_handle **out) {
   Geo &g = h->g;
   g.nx = cfg->itot; g.ny = cfg->jtot / cfg->nranks; g.nz = cfg->ktot;
   h->jtot = cfg->jtot;
-  h->mom_simple = getenv("UDC_MOM_SIMPLE") && atoi(getenv("UDC_MOM_SIMPLE")) != 0;
-  h->no_pup = getenv("UDC_NO_PUP") && atoi(getenv("UDC_NO_PUP")) != 0;
-  h->no_fold = getenv("UDC_NO_FOLD") && atoi(getenv("UDC_NO_FOLD")) != 0;
-  h->no_alias = getenv("UDC_NO_ALIAS") && atoi(getenv("UDC_NO_ALIAS")) != 0;
-  h->closure_carry = getenv("UDC_CLOSURE_CARRY") && atoi(getenv("UDC_CLOSURE_CARRY")) != 0;
-  h->ek_always = getenv("UDC_EK_ALWAYS") && atoi(getenv("UDC_EK_ALWAYS")) != 0;
-  // closure inside the momentum sweep (udc_mom_fused.hip): correct, but slower than the two kernels as measured -> opt-in
-  h->no_fused_closure = !(getenv("UDC_FUSED_CLOSURE") && atoi(getenv("UDC_FUSED_CLOSURE")) != 0);
-  h->no_div_in_fft = getenv("UDC_DIV_IN_FFT") && atoi(getenv("UDC_DIV_IN_FFT")) == 0;
-  h->slab = cfg->nranks > 1 || (getenv("UDC_FORCE_SLAB") && atoi(getenv("UDC_FORCE_SLAB")) != 0);
+  h->mom_simple = h->sw.mom_simple;
+  h->no_pup = h->sw.no_pup;
+  h->no_fold = h->sw.no_fold;
+  h->no_alias = h->sw.no_alias;
+  h->ek_always = h->sw.ek_always;
+  h->no_div_in_fft = !h->sw.div_in_fft;
+  h->slab = cfg->nranks > 1 || h->sw.force_slab;
   g.py = g.ny + 2 * HY; g.pz = g.nz + 2 * HZ;
   // row stride: rows of a power-of-two nx put every row of a tile column on the same few L2 channels and sets, and the
   // stencil kernels' halo lines evict each other (closure at 1024x512x512: 2.2 x its algorithmic reads, 3.2 -> 2.55 ms with
   // the padding; no effect at nx = 256).  16 doubles (one 128-B line) of padding after the nx cells of a row for
   // nx >= 512 and a multiple of 256; never read (x is periodic by index wrap).  UDC_XPAD overrides (0 = none).
   int xpad = (g.nx >= 512 && g.nx % 256 == 0) ? 16 : 0;
-  if (getenv("UDC_XPAD")) xpad = atoi(getenv("UDC_XPAD")) > 0 ? atoi(getenv("UDC_XPAD")) : 0;
+  if (h->sw.xpad >= 0) xpad = h->sw.xpad;
   g.sy = g.nx + xpad; g.sz = (long)g.sy * g.py; g.n = g.sz * g.pz;
   h->p = Params{cfg->numol, cfg->prandtlmoli, cfg->prandtli, cfg->c_vreman, cfg->csz,
                 cfg->uinf, cfg->vinf, cfg->sgs, cfg->bctopm, cfg->lbottom ? 1 : 0, cfg->z0};
@@ -1022,14 +1015,9 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   if (h->um_alias && !(alias_ok && rk3step == 1)) { if (um_materialise(h)) return 1; }
   const bool rotate = h->um_alias;                    // only true here for an aliased stage 1
   h->halos_fresh = h->boundary_fresh = h->thermo_fresh = false;
-  // closure + momentum.  Single slab, Smagorinsky / Vreman: ONE sweep that evaluates ekm in LDS (udc_mom_fused.hip); ekm / ekh
-  // reach memory only when something else reads them -- the scalar sweeps, the immersed boundary and the statistics of this
-  // substep, or (RK stage 3) whatever looks at them between time steps: tstep_update's maxima, restart files, downloads.
-  if (fold && pup && fused_closure_possible(h)) {
-    const bool emit = h->ek_always || rk3step == 3 || !h->slots.empty() || h->ibm_on || h->stats_on || h->xyt_on || h->yt_on;
-    if (k_momentum_closure(h, forces, 1. / rk3coef, rotate, emit)) return 1;
-    h->ek_stale = !emit; h->ekh_stale = !emit;
-  } else {
+  // closure + momentum.  (One sweep evaluating ekm in LDS was built and measured slower than the two kernels, DESIGN.md section 5:
+  // not kept.)
+  {
     // closure first: it only needs u0,v0,w0, and the momentum sweep below needs ekm
     h->ekh_stale = false;
     if (fold && h->p.sgs != UDC_SGS_DNS && h->p.sgs != UDC_SGS_ONEEQN && !h->lbuoycorr) {

@@ -68,10 +68,9 @@ extern "C" int udc_comm_unique_id(unsigned char id[128]) {
 // UDC_FORCE_COMM=1: build the RCCL communicator even for a single rank and send the "exchanges" of the forced
 // slab path (UDC_FORCE_SLAB=1) through ncclSend/ncclRecv to self -- a hardware test of the RCCL plumbing
 // (communicator, grouped point-to-point on the library's streams, all-reduce) on a one-GPU box.
-static bool force_comm() { const char *e = getenv("UDC_FORCE_COMM"); return e && atoi(e) != 0; }
 
 extern "C" int udc_comm_init(udc_handle *h, const unsigned char id[128]) {
-  if (h->cfg.nranks == 1 && !force_comm()) return 0;
+  if (h->cfg.nranks == 1 && !h->sw.force_comm) return 0;
   HIP_OK(hipSetDevice(h->device));
   ncclUniqueId u;
   memcpy(&u, id, 128);

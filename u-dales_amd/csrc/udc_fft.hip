@@ -545,10 +545,10 @@ int fft_fused_init(udc_handle *h) {
   while (h->g.ny % L) L >>= 1;
   int C = 8;
   while (C > 1 && y_lds_bytes(h, C) > 40000) C >>= 1;
-  if (getenv("UDC_FFT_L")) { const int v = atoi(getenv("UDC_FFT_L")); if (pow2(v) && v >= 1 && h->g.ny % v == 0) L = v; }
-  if (getenv("UDC_FFT_C")) { const int v = atoi(getenv("UDC_FFT_C")); if (v >= 1) C = v; }
+  if (h->sw.fft_l >= 1 && pow2(h->sw.fft_l) && h->g.ny % h->sw.fft_l == 0) L = h->sw.fft_l;
+  if (h->sw.fft_c >= 1) C = h->sw.fft_c;
   h->fft_L = L; h->fft_C = C;
-  h->slab_yreg = (ny == 128 || ny == 256 || ny == 512) && !(getenv("UDC_SLAB_YREG") && atoi(getenv("UDC_SLAB_YREG")) == 0);
+  h->slab_yreg = (ny == 128 || ny == 256 || ny == 512) && h->sw.slab_yreg;
   if (h->slab_yreg && ny == 512) {
     const int ldsb = slab_yreg_cols(ny) * 16 * 33 * 16;
     HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(ffty_slabreg_kernel<5, false>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
@@ -655,7 +655,7 @@ int fft_nat_init(udc_handle *h) {
   // default: on where the register y pass exists (ny = 128, 256, 512); UDC_OWN_FWD=0 keeps div_rhs + rocFFT's forward plan,
   // UDC_OWN_FWD=1 also takes the other power-of-two sizes (Stockham y pass: slower than rocFFT's, for tests)
   h->own_fwd = false;
-  const int want = getenv("UDC_OWN_FWD") ? atoi(getenv("UDC_OWN_FWD")) : -1;
+  const int want = h->sw.own_fwd;
   if (want == 0) return 0;
   const int nx = h->g.nx, ny = h->g.ny, M = nx / 2;
   if (h->slab || h->fwd_compact || !pow2(nx) || nx < 16 || nx > 2048 || !pow2(ny) || ny < 8 || ny > 1024) return 0;
@@ -666,9 +666,9 @@ int fft_nat_init(udc_handle *h) {
   int L = 4;
   while (ny % L) L >>= 1;
   int C = 8;
-  if (getenv("UDC_NAT_L")) { const int v = atoi(getenv("UDC_NAT_L")); if (pow2(v) && ny % v == 0) L = v; }
-  if (getenv("UDC_NAT_C")) { const int v = atoi(getenv("UDC_NAT_C")); if (v >= 1 && v <= 32) C = v; }
-  h->nat_reg16 = (ny == 128 || ny == 256 || ny == 512) && !(getenv("UDC_NAT_REG") && atoi(getenv("UDC_NAT_REG")) == 0);
+  if (h->sw.nat_l >= 1 && pow2(h->sw.nat_l) && ny % h->sw.nat_l == 0) L = h->sw.nat_l;
+  if (h->sw.nat_c >= 1 && h->sw.nat_c <= 32) C = h->sw.nat_c;
+  h->nat_reg16 = (ny == 128 || ny == 256 || ny == 512) && h->sw.nat_reg;
   if (h->nat_reg16) {
     const int n2 = ny / 16, tpc = n2 > 16 ? n2 : 16;
     while (C > 1 && C * tpc > 256) C >>= 1;

@@ -143,12 +143,8 @@ struct Switches {
   int ek_always = 0;         // UDC_EK_ALWAYS=1: every substep writes ekm / ekh
   int scalar_pair = 1;       // UDC_SCALAR_PAIR=0: thl and qt swept one by one
   // tridiagonal solve
-  int thomas = -1;           // UDC_THOMAS: 0 streaming, 3 LDS-resident columns, 4 register-resident segments
-  int thomas_ws = -1;        // UDC_THOMAS_WS (with 3): wave-specialised or plain
-  int thomas_part = 1;       // UDC_THOMAS_PART=0 (with 3): sequential sweeps
-  int thomas_sl = 8;         // UDC_THOMAS_SL: levels per thread of the register kernel (8 | 16)
+  int thomas = -1;           // UDC_THOMAS=0: the streaming kernel (one thread per mode) instead of register-resident segments
   int thomas_pair = 1;       // UDC_THOMAS_PAIR=0: one GPU: rows ky and ny - ky not solved together
-  int thomas_w = 3;          // UDC_THOMAS_W: waves per SIMD the register kernel is compiled for (2 | 3 | 4)
   // tuning knobs (0 / -1 = the library's own choice)
   int mom_kc = 0, scalar_kc = 0, closure_percu = 0, xpad = -1, spec_pad = -1;
   int fft_l = 0, fft_c = 0, nat_l = 0, nat_c = 0, nat_reg = 1, slab_yreg = 1;
@@ -262,9 +258,7 @@ struct udc_handle {
   bool mom_simple = false;              // UDC_MOM_SIMPLE=1: use the direct-load momentum kernel
   bool ekh_stale = false;               // the last closure wrote ekm only (no reader of ekh in that substep)
   bool ek_stale = false;                // the last fused substep kept ekm / ekh in LDS only: the arrays hold an older substep's values
-  bool closure_carry = false;           // UDC_CLOSURE_CARRY=1: the closure sweep carries the re-used stencil values in registers (A/B switch)
   bool ek_always = false;               // UDC_EK_ALWAYS=1: every substep writes ekm / ekh
-  bool no_fused_closure = true;         // UDC_FUSED_CLOSURE=1 turns the one-kernel closure + momentum sweep on (A/B switch; slower as measured)
   bool no_div_in_fft = false;           // UDC_DIV_IN_FFT=0: slab path with a separate divergence kernel (A/B switch)
   // immersed boundary (udc_ibm.hip): per grid (u, v, w, c) the global point lists as given, and this slab's points
   // (local 0-based i, j, k triplets) with their neighbour flags on the device
@@ -418,8 +412,6 @@ int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, 
 int momentum_lds_tile_rows(const Geo &g);
 int momentum_lds_tile_height();
 int k_momentum_pipe_stage(udc_handle *h, int c);      // the sweep's level range that feeds k-chunk c of the slab solve (udc_api.hip)  // rk3coefi != 0: PUP mode   // LDS-staged k-marching version (default)
-bool fused_closure_possible(const udc_handle *h);                      // udc_mom_fused.hip: closure inside the momentum sweep
-int k_momentum_closure(udc_handle *h, bool forces, double rk3coefi, bool um_is_u0, bool emit);   // emit: ekm, ekh also written (with closurebc's ghosts)
 int k_level_sums_dev(udc_handle *h, int field, int n);      // udc_thermo.hip: masked, all-reduced level sums left on the device
 int k_scalar_adv(udc_handle *h, int n);
 int k_scalar_bcx_outlet(udc_handle *h);

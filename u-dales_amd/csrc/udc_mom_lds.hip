@@ -243,41 +243,10 @@ struct LdsAcc {      // neighbour access from the three staged planes (pointers 
   }
 };
 
-// The same neighbours with everything a thread has already read on an earlier level carried in registers: of the 30 values of the
-// closure's stencil (both models read the same set) the 8 of plane k-1 / k in the thread's own u and v pairs and the 5 w values of
-// plane k were the "plane k / k+1" values one level ago.  Per level that leaves 9 reads of plane k+1 and 8 in-plane reads of plane k:
-// 17 LDS reads instead of 30 (the closure is bound by LDS issue + f64 VALU, not by its bytes); operands and operation order unchanged.
-struct CarryAcc {
-  const double *ucp, *vcp;      // plane k, tile centre element (in-plane neighbours that are not carried)
-  double ut[2], uc[2], ub[2];   // u(di, 0, +1 / 0 / -1), di = 0, 1
-  double vt[2], vc[2], vb[2];   // v(0, dj, +1 / 0 / -1), dj = 0, 1
-  double wt[5], wc[5];          // w at (0,0), (1,0), (-1,0), (0,1), (0,-1) of planes k+1 / k
-  static __device__ __forceinline__ constexpr int widx(int di, int dj) { return di == 1 ? 1 : (di == -1 ? 2 : (dj == 1 ? 3 : (dj == -1 ? 4 : 0))); }
-  __device__ __forceinline__ double u(int di, int dj, int dk) const {
-    if (dj == 0 && (di == 0 || di == 1)) return dk > 0 ? ut[di] : (dk < 0 ? ub[di] : uc[di]);
-    return ucp[dj * LX + di];
-  }
-  __device__ __forceinline__ double v(int di, int dj, int dk) const {
-    if (di == 0 && (dj == 0 || dj == 1)) return dk > 0 ? vt[dj] : (dk < 0 ? vb[dj] : vc[dj]);
-    return vcp[dj * LX + di];
-  }
-  __device__ __forceinline__ double w(int di, int dj, int dk) const { return dk > 0 ? wt[widx(di, dj)] : wc[widx(di, dj)]; }
-  __device__ __forceinline__ void read_top(const double *up, const double *vp, const double *wp) {
-    ut[0] = up[0]; ut[1] = up[1]; vt[0] = vp[0]; vt[1] = vp[LX];
-    wt[0] = wp[0]; wt[1] = wp[1]; wt[2] = wp[-1]; wt[3] = wp[LX]; wt[4] = wp[-LX];
-  }
-  __device__ __forceinline__ void shift() {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) { ub[q] = uc[q]; uc[q] = ut[q]; vb[q] = vc[q]; vc[q] = vt[q]; }
-#pragma unroll
-    for (int q = 0; q < 5; ++q) wc[q] = wt[q];
-  }
-};
-
 // Same marching/staging scheme as mom_lds_kernel for u0, v0, w0; writes ekm, ekh.
 // EKH = false: ekh is not written (nothing reads it in this substep: no transported scalar, not the stage whose fields the
 // time-step maxima / statistics / restart files see) -- 8 of the kernel's 40 B per cell.
-template <int SGS, bool EKH, bool CARRY>
+template <int SGS, bool EKH>
 __global__ __launch_bounds__(NT) void closure_lds_kernel(Geo g, TileGrid tg, Metrics m, Params pr,
     const double *__restrict__ gu, const double *__restrict__ gv, const double *__restrict__ gw,
     double *__restrict__ ekm, double *__restrict__ ekh, int kc, int ghosts) {
@@ -338,18 +307,11 @@ __global__ __launch_bounds__(NT) void closure_lds_kernel(Geo g, TileGrid tg, Met
   load_plane(k0 + 1, st); commit_plane(2, st);
   if (k0 + 1 < k1) load_plane(k0 + 2, st);
   int bm = 0, bc = 1, bp = 2, bn = 3;
-  CarryAcc C;
   for (int k = k0; k < k1; ++k) {
     __syncthreads();
     if (k + 1 < k1) {
       commit_plane(bn, st);
       if (k + 2 < k1) load_plane(k + 3, st);
-    }
-    if (CARRY && k == k0) {         // planes k0 - 1 and k0 as "bottom" and "centre" of the first level
-      C.read_top(s[bm][0] + own_l, s[bm][1] + own_l, s[bm][2] + own_l);
-      C.shift();
-      C.read_top(s[bc][0] + own_l, s[bc][1] + own_l, s[bc][2] + own_l);
-      C.shift();
     }
     const ClosMetLane lm{mcur};
     mcur = mnext;                                            // (arrived: the commit above waited for it)
@@ -360,14 +322,7 @@ __global__ __launch_bounds__(NT) void closure_lds_kernel(Geo g, TileGrid tg, Met
       LdsAcc A{s[bm][0] + o, s[bc][0] + o, s[bp][0] + o, s[bm][1] + o, s[bc][1] + o, s[bp][1] + o,
                s[bm][2] + o, s[bc][2] + o, s[bp][2] + o};
       double em, eh;
-      if (CARRY) {
-        C.ucp = s[bc][0] + o; C.vcp = s[bc][1] + o;
-        C.read_top(s[bp][0] + o, s[bp][1] + o, s[bp][2] + o);
-        closure_arith<SGS>(C, m, lm, pr, k, em, eh);
-        C.shift();
-      } else {
-        closure_arith<SGS>(A, m, lm, pr, k, em, eh);
-      }
+      closure_arith<SGS>(A, m, lm, pr, k, em, eh);
       const long c = g.sz * (long)(k + HZ) + own_off;
       ekm[c] = em;                      // (re-read by the momentum sweep that follows: kept cacheable)
       if (EKH) NT_STORE(eh, &ekh[c]);
@@ -399,8 +354,8 @@ __global__ __launch_bounds__(NT) void closure_lds_kernel(Geo g, TileGrid tg, Met
 
 // k-chunk length: each workgroup pays a 3-plane prologue, and the chip runs `slots` workgroups at a
 // time (256 CUs x per_cu, register/LDS-limited), so pick the chunk that minimises rounds x (kc + 3).
-static int pick_kc(const Geo &g, const TileGrid &tg, int per_cu) {
-  if (getenv("UDC_MOM_KC")) { int v = atoi(getenv("UDC_MOM_KC")); if (v >= 1) return v < g.nz ? v : g.nz; }
+static int pick_kc(const Geo &g, const TileGrid &tg, int per_cu, int forced) {
+  if (forced >= 1) return forced < g.nz ? forced : g.nz;
   const long slots = 256L * per_cu;
   int best = g.nz < 4 ? g.nz : 4;
   double best_cost = 1e300;
@@ -421,23 +376,18 @@ int k_closure_lds(udc_handle *h, bool ghosts, bool write_ekh, int rows) {
   const TileGrid tg = rows == 0 ? lds_tile_grid(g) : tile_rows(lds_tile_grid(g), 1, rows == 1);
   // 90 VGPRs, 32 640 B LDS: five workgroups fit a CU.  Measured: 512x512x256 0.634 -> 0.592 ms, 1024x512x512 2.60 -> 2.38 ms
   // when the chunking fills them; at 256^3 (256 tiles) five shorter chunks per tile lose to four (0.19 against 0.172 ms)
-  const int per_cu = getenv("UDC_CLOSURE_PERCU") ? atoi(getenv("UDC_CLOSURE_PERCU")) : (tg.tiles >= 1024 ? 5 : 4);
-  int kc = pick_kc(g, tg, per_cu);
+  const int per_cu = h->sw.closure_percu > 0 ? h->sw.closure_percu : (tg.tiles >= 1024 ? 5 : 4);
+  int kc = pick_kc(g, tg, per_cu, h->sw.mom_kc);
   const int chunks = (g.nz + kc - 1) / kc;
   dim3 b(MX, MY, 1), gr((unsigned)tg.tiles * (unsigned)chunks, 1, 1);
   double *u = h->fields[UDC_U0], *v = h->fields[UDC_V0], *w = h->fields[UDC_W0];
   double *ekm = h->fields[UDC_EKM], *ekh = h->fields[UDC_EKH];
   PROF(h, rows == 1 ? "closure_edge" : "closure");
   const int gh = ghosts ? 1 : 0;
-#define CLOSURE_LAUNCH(S, E, C) hipLaunchKernelGGL((closure_lds_kernel<S, E, C>), gr, b, 0, h->stream, g, tg, h->m, h->p, u, v, w, ekm, ekh, kc, gh)
+#define CLOSURE_LAUNCH(S, E) hipLaunchKernelGGL((closure_lds_kernel<S, E>), gr, b, 0, h->stream, g, tg, h->m, h->p, u, v, w, ekm, ekh, kc, gh)
   const bool smag = h->p.sgs == UDC_SGS_SMAGORINSKY;
-  if (h->closure_carry) {
-    if (smag) { if (write_ekh) CLOSURE_LAUNCH(1, true, true); else CLOSURE_LAUNCH(1, false, true); }
-    else      { if (write_ekh) CLOSURE_LAUNCH(2, true, true); else CLOSURE_LAUNCH(2, false, true); }
-  } else {
-    if (smag) { if (write_ekh) CLOSURE_LAUNCH(1, true, false); else CLOSURE_LAUNCH(1, false, false); }
-    else      { if (write_ekh) CLOSURE_LAUNCH(2, true, false); else CLOSURE_LAUNCH(2, false, false); }
-  }
+  if (smag) { if (write_ekh) CLOSURE_LAUNCH(1, true); else CLOSURE_LAUNCH(1, false); }
+  else      { if (write_ekh) CLOSURE_LAUNCH(2, true); else CLOSURE_LAUNCH(2, false); }
 #undef CLOSURE_LAUNCH
   HIP_OK(hipGetLastError());
   return 0;
@@ -464,7 +414,7 @@ int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, 
   // k-chunk: long enough to amortise the 2-plane prologue, short enough to fill 256 CUs x 4 workgroups
   Geo gl = g;
   gl.nz = a.kend - a.kbeg;
-  int kc = pick_kc(gl, tg, MOM_WAVES);
+  int kc = pick_kc(gl, tg, MOM_WAVES, h->sw.mom_kc);
   const int chunks = (gl.nz + kc - 1) / kc;
   dim3 b(MX, MY, 1), gr((unsigned)tg.tiles * (unsigned)chunks, 1, 1);
   const bool les = h->p.sgs != UDC_SGS_DNS;

@@ -170,527 +170,15 @@ __global__ __launch_bounds__(64) void thomas_kernel(int nmodes, int nz, double s
   }
 }
 
-// LDS-resident variant of the same solve.  A workgroup owns M consecutive modes (2M independent real
-// systems: the matrix is real, so real and imaginary parts never mix) and keeps their whole column in LDS,
-// so x is read from HBM once and written once; the pivot table streams through twice (forward / back).
-// All 256 threads move data in k-chunks of KC levels: the next chunk's global loads are in flight while
-// lanes 0..2M-1 run the recurrence on the current one.  The movers also do every product that does not
-// involve the neighbouring level, so the serial part is one fma per level:
-//   forward  x_k = (x_k s - a_k x_{k-1}) z_k   as  fma(-(a_k z_k), x_{k-1}, (x_k s) z_k)
-//   back     x_k = x_k - (c_k z_k) x_{k+1}     as  fma(-(c_k z_k), x_{k+1}, x_k)
-// (thomas_kernel evaluates the same expressions, so the result does not depend on which variant runs).
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F &&f) {
-  if constexpr (N > 0) {
-    static_for<N - 1>(f);
-    f(std::integral_constant<int, N - 1>{});
-  }
-}
-
-template <int M, int KC, int D, int DB, bool PART>
-__global__ __launch_bounds__(256) void thomas_lds_kernel(int nmodes, int nz, double scale,
-    const double *__restrict__ ev, const double *__restrict__ tri, double btopD,
-    const double *__restrict__ ztab, double2 *__restrict__ x) {
-  static_assert(M == ZB, "the blocked pivot table is laid out for ZB modes per workgroup");
-  constexpr int C = 2 * M;                 // doubles per level
-  constexpr int R = KC * M / 256;          // staged elements per thread per chunk
-  constexpr int U = 8;                     // levels per register group in the recurrence
-  static_assert(KC * M % 256 == 0 && KC % U == 0, "chunk must tile the workgroup");
-  extern __shared__ double lds_[];
-  double *xs = lds_;                       // [nz][C]   (x_k s) z_k, then x'_k, then the solution
-  double *zb = lds_ + (size_t)nz * C;      // [2][KC][M] -(a_k z_k) forward, -(c_k z_k) back
-  double *zt = zb + 2 * KC * M;            // [KC][M]   -(c_k z_k) of the top chunk, written by the forward sweep
-  double *sx = zt + KC * M;                // [4][C][2] segment summaries of the partitioned sweeps
-  const int tid = threadIdx.x;
-  const int m0 = blockIdx.x * M;
-  const double *a = tri, *b = tri + (nz + 2), *c = tri + 2 * (nz + 2);
-  const size_t st = (size_t)nmodes;
-  const int nch = (nz + KC - 1) / KC;
-
-  // D chunks of loads are in flight per workgroup (register slots, statically indexed): one chunk ahead leaves
-  // every chunk waiting a full HBM round trip, because the recurrence on a chunk is much shorter than that
-  double2 rx[D][R];
-  double rz[D][R], rg[D][R], rt[D][R];
-  // fwd: x, z, a (and c for the top chunk); back: z, c
-  auto issue = [&](int ch, bool fwd, auto S) {
-    constexpr int s = decltype(S)::value;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int idx = tid + 256 * r;
-      const int kk = idx / M, mm = idx % M;
-      const int lev = ch * KC + kk;        // 0-based level, k = lev + 1
-      const bool ok = lev < nz && m0 + mm < nmodes;
-      if (fwd) rx[s][r] = ok ? x[(size_t)lev * st + m0 + mm] : make_double2(0., 0.);
-      rz[s][r] = (ok && lev < nz - 1) ? ztab[ztab_index(true, nmodes, nz, lev, m0 + mm)] : 1.;
-      const int kc_ = min(lev + 1, nz);
-      rg[s][r] = fwd ? a[kc_] : c[kc_];
-      if (fwd && ch == nch - 1) rt[s][r] = c[kc_];
-    }
-  };
-  auto commit = [&](int ch, bool fwd, auto S) {
-    constexpr int s = decltype(S)::value;
-    double *zc = zb + (ch & 1) * (KC * M);
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int idx = tid + 256 * r;
-      const int kk = idx / M, mm = idx % M;
-      const int lev = ch * KC + kk;
-      if (fwd && lev < nz) {
-        double2 t = rx[s][r];
-        t.x = (t.x * scale) * rz[s][r];
-        t.y = (t.y * scale) * rz[s][r];
-        *reinterpret_cast<double2 *>(xs + (size_t)lev * C + 2 * mm) = t;
-      }
-      zc[kk * M + mm] = -(rg[s][r] * rz[s][r]);
-      if (fwd && ch == nch - 1) zt[kk * M + mm] = -(rt[s][r] * rz[s][r]);
-    }
-  };
-
-
-  // Partitioned sweep (PART): both sweeps are first-order linear recurrences  v_l = g_l v_prev + t_l.  Run strictly
-  // in sequence, 16 lanes of one wave (one per real column) spend ~45 cycles per level on a dependent fma and its LDS
-  // operands, which at nz = 512 (two workgroups per CU) is a third of the kernel.  Instead all 64 lanes of the wave take
-  // a quarter of the chunk's KC levels each: with zero inflow  y_j = g_j y_{j-1} + t_j  and the running product
-  // P_j = g_j P_{j-1}, then the four segments are chained through (P_last, y_last) -- 4 dependent fmas, every lane
-  // redoing them -- and  v_j = P_j v_in + y_j.  Same equations as solmpj (src/modpois.f90:1120-1166); the rounding
-  // differs from the sequential order in the last bits (tests compare both kernels with the oracle).
-  // `down`: the chunk is walked from its top level downwards (back substitution).  Levels >= l1 pass through.
-  auto part_sweep_impl = [&](const double *zc, int l0, int l1, bool down, double &carry, auto FULL_) {
-    constexpr bool FULL = decltype(FULL_)::value;      // every level of the chunk takes part (all chunks but a ragged last one)
-    constexpr int SL = KC / 4;
-    static_assert(C == 16 && KC % 4 == 0, "four segments of one wave");
-    const int col = tid & (C - 1), seg = tid >> 4;
-    // lane's levels: lev_j = base + j * step
-    const int base = down ? l0 + KC - 1 - seg * SL : l0 + seg * SL;
-    const int step = down ? -1 : 1;
-    const double *xb = xs + (size_t)base * C + col;
-    const double *zq = zc + (base - l0) * M;
-    double y[SL], P[SL];
-#pragma unroll
-    for (int j = 0; j < SL; ++j) {
-      const bool ok = FULL || base + j * step < l1;
-      y[j] = ok ? xb[j * step * C] : 0.;
-      P[j] = ok ? zq[j * step * M] : 1.;
-    }
-#pragma unroll
-    for (int j = 1; j < SL; ++j) {
-      y[j] = __builtin_fma(P[j], y[j - 1], y[j]);
-      P[j] = P[j] * P[j - 1];
-    }
-    *reinterpret_cast<double2 *>(sx + (size_t)(seg * C + col) * 2) = make_double2(P[SL - 1], y[SL - 1]);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    double2 sm[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) sm[q] = *reinterpret_cast<const double2 *>(sx + (size_t)(q * C + col) * 2);
-    double in = carry, mine = carry;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      in = __builtin_fma(sm[q].x, in, sm[q].y);
-      if (seg == q + 1) mine = in;
-    }
-    carry = in;
-    double *xw = xs + (size_t)base * C + col;
-#pragma unroll
-    for (int j = 0; j < SL; ++j)
-      if (FULL || base + j * step < l1) xw[j * step * C] = __builtin_fma(P[j], mine, y[j]);
-    __builtin_amdgcn_wave_barrier();
-  };
-  auto part_sweep = [&](const double *zc, int l0, int l1, bool down, double &carry) {
-    if (l1 - l0 == KC) part_sweep_impl(zc, l0, l1, down, carry, std::true_type{});
-    else part_sweep_impl(zc, l0, l1, down, carry, std::false_type{});
-  };
-
-  // the last pivot of the forward sweep is needed again when the top level is closed
-  double zl = 0.;
-  const int rl = PART ? 64 : C;            // lanes that carry the recurrence (PART: every lane of wave 0, column tid % C)
-  const int colr = tid & (C - 1);
-  if (tid < rl && nz >= 2) zl = ztab[ztab_index(true, nmodes, nz, nz - 2, min(m0 + (colr >> 1), nmodes - 1))];
-  static_for<D>([&](auto S) { if (decltype(S)::value < nch) issue(decltype(S)::value, true, S); });
-  commit(0, true, std::integral_constant<int, 0>{});
-  __syncthreads();
-  double xp = 0.;
-  // forward elimination, levels 1 .. nz-1 (0-based 0 .. nz-2); chunk ch lives in slot ch % D
-  for (int ch0 = 0; ch0 < nch; ch0 += D) static_for<D>([&](auto S) {
-    constexpr int d = decltype(S)::value;
-    const int ch = ch0 + d;
-    if (ch >= nch) return;
-    if (ch + D < nch) issue(ch + D, true, S);      // slot d was committed in the previous iteration
-    if (PART) {
-      if (tid < 64) part_sweep(zb + (ch & 1) * (KC * M) + ((tid & (C - 1)) >> 1), ch * KC, min(ch * KC + KC, nz - 1), false, xp);
-    } else if (tid < C) {
-      const double *zc = zb + (ch & 1) * (KC * M) + (tid >> 1);
-      const int l0 = ch * KC;
-      const int l1 = min(l0 + KC, nz - 1);
-      // U levels at a time with two register sets: the next group's operands are requested before the
-      // dependent chain of the current group runs
-      const int nfull = (l1 - l0) / U;
-      double tA[U], gA[U], tB[U], gB[U];
-      auto ld = [&](int lb, double (&T)[U], double (&G)[U]) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          T[u] = xs[(size_t)(lb + u) * C + tid];
-          G[u] = zc[(lb + u - l0) * M];
-        }
-      };
-      auto run = [&](int lb, double (&T)[U], double (&G)[U]) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) { xp = __builtin_fma(G[u], xp, T[u]); T[u] = xp; }
-#pragma unroll
-        for (int u = 0; u < U; ++u) xs[(size_t)(lb + u) * C + tid] = T[u];
-      };
-      if (nfull > 0) ld(l0, tA, gA);
-      for (int gi = 0; gi < nfull; gi += 2) {
-        const int lb = l0 + gi * U;
-        if (gi + 1 < nfull) ld(lb + U, tB, gB);
-        run(lb, tA, gA);
-        if (gi + 1 < nfull) {
-          if (gi + 2 < nfull) ld(lb + 2 * U, tA, gA);
-          run(lb + U, tB, gB);
-        }
-      }
-      for (int lev = l0 + nfull * U; lev < l1; ++lev) {
-        xp = __builtin_fma(zc[(lev - l0) * M], xp, xs[(size_t)lev * C + tid]);
-        xs[(size_t)lev * C + tid] = xp;
-      }
-    }
-    if (ch + 1 < nch) commit(ch + 1, true, std::integral_constant<int, (d + 1) % D>{});
-    __syncthreads();
-  });
-  // close the forward sweep: the top level (stored as x_nz s, its "pivot" slot was 1)
-  if (tid < rl) {
-    const int mo = min(m0 + (colr >> 1), nmodes - 1);
-    const double e = ev[mo];
-    // the singular (0,0) mode gets a Dirichlet condition across the top cell (:209-220)
-    const double bbk = (e == 0.) ? btopD : b[nz] + e;
-    const double ak = a[nz];
-    const double d = c[nz - 1] * zl;
-    const double z = bbk - ak * d;
-    const double xc = (xs[(size_t)(nz - 1) * C + colr] - ak * xp) / z;
-    __builtin_amdgcn_wave_barrier();         // (PART: every segment's lane has read the level before one of them rewrites it)
-    if (tid < C) xs[(size_t)(nz - 1) * C + colr] = xc;
-    xp = xc;
-  }
-  // back substitution, levels nz-1 .. 1, chunk by chunk from the top; finished chunks stream out.  The top chunk's
-  // coefficients are in zt already; chunk c <= nch-2 lives in slot (nch-2-c) % DB.  Only the pivots (8 B per point)
-  // are loaded in this phase, so the ring is deeper than the forward one: with D chunks (2 KB each) in flight the
-  // phase is latency-bound
-  const double *ztabc = ztab + (size_t)((nmodes + ZB - 1) / ZB) * ZB * (size_t)(nz > 1 ? nz - 1 : 1);
-  double bz[DB][R];
-  auto issue_b = [&](int ch, auto S) {
-    constexpr int s = decltype(S)::value;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int idx = tid + 256 * r;
-      const int kk = idx / M, mm = idx % M;
-      const int lev = ch * KC + kk;
-      const bool ok = lev < nz && m0 + mm < nmodes;
-      bz[s][r] = (ok && lev < nz - 1) ? ztabc[ztab_index(true, nmodes, nz, lev, m0 + mm)] : 0.;
-    }
-  };
-  auto commit_b = [&](int ch, auto S) {
-    constexpr int s = decltype(S)::value;
-    double *zc = zb + (ch & 1) * (KC * M);
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int idx = tid + 256 * r;
-      zc[idx] = bz[s][r];
-    }
-  };
-  static_for<DB>([&](auto S) { if (nch - 2 - decltype(S)::value >= 0) issue_b(nch - 2 - decltype(S)::value, S); });
-  for (int t0 = 0; t0 < nch; t0 += DB) static_for<DB>([&](auto S) {
-    constexpr int d = decltype(S)::value;
-    const int t = t0 + d;
-    if (t >= nch) return;
-    const int ch = nch - 1 - t;
-    if (t >= 1 && nch - 1 - t - DB >= 0)           // the slot freed by the previous iteration's commit
-      issue_b(nch - 1 - t - DB, std::integral_constant<int, (d + DB - 1) % DB>{});
-    if (PART) {
-      if (tid < 64) part_sweep((ch == nch - 1 ? zt : zb + (ch & 1) * (KC * M)) + ((tid & (C - 1)) >> 1), ch * KC, min(ch * KC + KC, nz - 1), true, xp);
-    } else if (tid < C) {
-      const double *zc = (ch == nch - 1 ? zt : zb + (ch & 1) * (KC * M)) + (tid >> 1);
-      const int l0 = ch * KC;
-      const int l1 = min(l0 + KC, nz - 1);
-      const int nfull = (l1 - l0) / U;
-      // the chunk's ragged top (levels above the last full group) first, then full groups, pipelined
-      for (int lev = l1 - 1; lev >= l0 + nfull * U; --lev) {
-        xp = __builtin_fma(zc[(lev - l0) * M], xp, xs[(size_t)lev * C + tid]);
-        xs[(size_t)lev * C + tid] = xp;
-      }
-      double tA[U], gA[U], tB[U], gB[U];
-      auto ld = [&](int lb, double (&T)[U], double (&G)[U]) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          T[u] = xs[(size_t)(lb + u) * C + tid];
-          G[u] = zc[(lb + u - l0) * M];
-        }
-      };
-      auto run = [&](int lb, double (&T)[U], double (&G)[U]) {
-#pragma unroll
-        for (int u = U - 1; u >= 0; --u) { xp = __builtin_fma(G[u], xp, T[u]); T[u] = xp; }
-#pragma unroll
-        for (int u = 0; u < U; ++u) xs[(size_t)(lb + u) * C + tid] = T[u];
-      };
-      if (nfull > 0) ld(l0 + (nfull - 1) * U, tA, gA);
-      for (int gi = nfull - 1; gi >= 0; gi -= 2) {
-        const int lb = l0 + gi * U;
-        if (gi > 0) ld(lb - U, tB, gB);
-        run(lb, tA, gA);
-        if (gi > 0) {
-          if (gi > 1) ld(lb - 2 * U, tA, gA);
-          run(lb - U, tB, gB);
-        }
-      }
-    }
-    if (ch > 0) commit_b(ch - 1, S);
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int idx = tid + 256 * r;
-      const int kk = idx / M, mm = idx % M;
-      const int lev = ch * KC + kk;
-      if (lev < nz && m0 + mm < nmodes)
-        x[(size_t)lev * st + m0 + mm] = *reinterpret_cast<const double2 *>(xs + (size_t)lev * C + 2 * mm);
-    }
-  });
-}
-
-// Wave-specialised LDS-resident solve.  Same data flow as thomas_lds_kernel (columns of M modes resident in LDS, x read
-// and written once, pivots read in the forward sweep, -(c z) in the back substitution) but the five waves of a workgroup
-// have fixed jobs, because a wave that mixes "issue loads two chunks ahead" with "wait for the chunk that is due" gets
-// s_waitcnt vmcnt(0) from the compiler at every wait (the number of younger loads is not static across its branches),
-// which drains the loads it has just issued: the ring never holds more than the chunk being waited for, and the
-// kernel's time is the sum of its load latency, its recurrence and its stores (measured: 1.03 + 0.56 + 0.23 ms on top
-// of a 0.53 ms skeleton at 1024x512x512).  Here
-//   wave 0      runs the recurrences (partitioned sweeps over all 64 lanes, see part_sweep) and never touches memory;
-//   waves 1..4  each own every fourth chunk of KC levels: load it (4 elements per lane), and when it is due wait for
-//               everything they have in flight -- which is only their own, four periods old -- scale it into LDS, and
-//               issue their next chunk; in the back substitution the owner of a finished chunk also streams it out.
-// Four (forward) or eight (back) chunks per workgroup are in flight whatever the compiler does with the waits.
-template <int M, int KC>
-__global__ __launch_bounds__(320) void thomas_ws_kernel(int nmodes, int nz, double scale,
-    const double *__restrict__ ev, const double *__restrict__ tri, double btopD,
-    const double *__restrict__ ztab, double2 *__restrict__ x) {
-  static_assert(M == ZB, "the blocked pivot table is laid out for ZB modes per workgroup");
-  constexpr int C = 2 * M;                 // real columns
-  constexpr int NMV = 4;                   // mover waves
-  constexpr int R = KC * M / 64;           // elements per mover lane and chunk
-  constexpr int SL = KC / 4;               // levels per segment of the partitioned sweep
-  static_assert(C == 16 && KC * M % 64 == 0 && KC % 4 == 0, "layout");
-  extern __shared__ double lds_[];
-  double *xs = lds_;                       // [nz][C]
-  double *zb = lds_ + (size_t)nz * C;      // [2][KC][M]
-  double *zt = zb + 2 * KC * M;            // [KC][M]
-  double *sx = zt + KC * M;                // [4][C][2]
-  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-  const int m0 = blockIdx.x * M;
-  const double *a = tri, *b = tri + (nz + 2), *c = tri + 2 * (nz + 2);
-  const size_t st = (size_t)nmodes;
-  const int nch = (nz + KC - 1) / KC;
-  const double *ztabc = ztab + (size_t)((nmodes + ZB - 1) / ZB) * ZB * (size_t)(nz > 1 ? nz - 1 : 1);
-
-  if (wv == 0) {
-    // ---- the recurrence wave
-    const int col = lane & (C - 1), seg = lane >> 4;
-    auto sweep = [&](const double *zc, int l0, int l1, bool down, double &carry, auto FULL_) {
-      constexpr bool FULL = decltype(FULL_)::value;
-      const int base = down ? l0 + KC - 1 - seg * SL : l0 + seg * SL;
-      const int step = down ? -1 : 1;
-      double *xb = xs + (size_t)base * C + col;
-      const double *zq = zc + (base - l0) * M;
-      double y[SL], P[SL];
-#pragma unroll
-      for (int j = 0; j < SL; ++j) {
-        const bool ok = FULL || base + j * step < l1;
-        y[j] = ok ? xb[j * step * C] : 0.;
-        P[j] = ok ? zq[j * step * M] : 1.;
-      }
-#pragma unroll
-      for (int j = 1; j < SL; ++j) {
-        y[j] = __builtin_fma(P[j], y[j - 1], y[j]);
-        P[j] = P[j] * P[j - 1];
-      }
-      *reinterpret_cast<double2 *>(sx + (size_t)(seg * C + col) * 2) = make_double2(P[SL - 1], y[SL - 1]);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      double2 sm[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) sm[q] = *reinterpret_cast<const double2 *>(sx + (size_t)(q * C + col) * 2);
-      double in = carry, mine = carry;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        in = __builtin_fma(sm[q].x, in, sm[q].y);
-        if (seg == q + 1) mine = in;
-      }
-      carry = in;
-#pragma unroll
-      for (int j = 0; j < SL; ++j)
-        if (FULL || base + j * step < l1) xb[j * step * C] = __builtin_fma(P[j], mine, y[j]);
-      __builtin_amdgcn_wave_barrier();
-    };
-    auto sweep_chunk = [&](const double *zc, int ch, bool down, double &carry) {
-      const int l0 = ch * KC, l1 = min(l0 + KC, nz - 1);
-      if (l1 - l0 == KC) sweep(zc, l0, l1, down, carry, std::true_type{});
-      else sweep(zc, l0, l1, down, carry, std::false_type{});
-    };
-    const int mo = min(m0 + (col >> 1), nmodes - 1);
-    const double zl = nz >= 2 ? ztab[ztab_index(true, nmodes, nz, nz - 2, mo)] : 0.;
-    const double e = ev[mo];
-    double xp = 0.;
-    __syncthreads();                                         // chunk 0 is in LDS
-    for (int ch = 0; ch < nch; ++ch) {
-      sweep_chunk(zb + (ch & 1) * (KC * M) + (col >> 1), ch, false, xp);
-      __syncthreads();
-    }
-    {
-      // close the forward sweep: the top level; the singular (0,0) mode gets a Dirichlet condition across the top
-      // cell (src/modpois.f90:209-220)
-      const double bbk = (e == 0.) ? btopD : b[nz] + e;
-      const double ak = a[nz];
-      const double d = c[nz - 1] * zl;
-      const double z = bbk - ak * d;
-      const double xc = (xs[(size_t)(nz - 1) * C + col] - ak * xp) / z;
-      __builtin_amdgcn_wave_barrier();
-      if (lane < C) xs[(size_t)(nz - 1) * C + col] = xc;
-      __builtin_amdgcn_wave_barrier();
-      xp = xc;
-    }
-    for (int t = 0; t < nch; ++t) {
-      const int ch = nch - 1 - t;
-      sweep_chunk((ch == nch - 1 ? zt : zb + (ch & 1) * (KC * M)) + (col >> 1), ch, true, xp);
-      __syncthreads();
-    }
-    return;
-  }
-
-  // ---- the movers
-  // Element r of a lane is (level kk0 + 8 r of the chunk, mode mm): the lane's part of every address is fixed, the rest
-  // is uniform (scalar registers).  A mover runs alone on its SIMD for its turn, so every vector instruction it spends
-  // on 64-bit index arithmetic is exposed latency: the full-chunk paths below do none.
-  static_assert(M == 8, "lane -> (level, mode) mapping");
-  const int w = wv - 1;
-  const int kk0 = lane >> 3, mm = lane & 7;
-  const bool modes_full = m0 + M <= nmodes;
-  const unsigned xoff = (unsigned)((size_t)kk0 * st + m0 + mm);       // < 8 nmodes
-  const size_t zrow = (size_t)blockIdx.x * (size_t)(nz - 1) * M;      // this workgroup's run of the blocked tables
-  double2 rx[R];
-  double rz[R], rg[R], rt[R];
-  auto issue_f = [&](int ch) {
-    if (modes_full && ch < nch - 1) {
-      const double *zq = ztab + zrow + (size_t)ch * KC * M;
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        rx[r] = (x + (size_t)(ch * KC + 8 * r) * st)[xoff];
-        rz[r] = zq[lane + 64 * r];
-        rg[r] = (a + ch * KC + 1 + 8 * r)[kk0];
-      }
-      return;
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int lev = ch * KC + kk0 + 8 * r;
-      const bool ok = lev < nz && m0 + mm < nmodes;
-      rx[r] = ok ? x[(size_t)lev * st + m0 + mm] : make_double2(0., 0.);
-      rz[r] = (ok && lev < nz - 1) ? ztab[ztab_index(true, nmodes, nz, lev, m0 + mm)] : 1.;
-      const int kc_ = min(lev + 1, nz);
-      rg[r] = a[kc_];
-      rt[r] = c[kc_];
-    }
-  };
-  auto commit_f = [&](int ch) {
-    double *zc = zb + (ch & 1) * (KC * M);
-    double *xc = xs + (size_t)ch * KC * C;
-    const bool top = ch == nch - 1;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int idx = lane + 64 * r;
-      if (!top || ch * KC + kk0 + 8 * r < nz) {
-        double2 t = rx[r];
-        t.x = (t.x * scale) * rz[r];
-        t.y = (t.y * scale) * rz[r];
-        *reinterpret_cast<double2 *>(xc + 2 * idx) = t;
-      }
-      zc[idx] = -(rg[r] * rz[r]);
-      if (top) zt[idx] = -(rt[r] * rz[r]);
-    }
-  };
-  if (w < nch) issue_f(w);
-  if (w == 0) commit_f(0);
-  __syncthreads();
-  if (w == 0 && NMV < nch) issue_f(NMV);
-  for (int ch = 0; ch < nch; ++ch) {
-    const int cn = ch + 1;
-    const bool mine = cn < nch && (cn & (NMV - 1)) == w;
-    if (mine) commit_f(cn);
-    __syncthreads();
-    // (after the barrier: when the memory pipeline is backed up the issue itself stalls, and nobody should wait for it)
-    if (mine && cn + NMV < nch) issue_f(cn + NMV);
-  }
-  // back substitution: two slots of -(c z) per mover (chunks cb and cb - 4 of its own), the finished chunk streams out
-  double bzA[R], bzB[R];
-  auto issue_b = [&](int ch, double (&bz)[R]) {        // ch <= nch - 2: every level of the chunk is below the top
-    if (modes_full) {
-      const double *zq = ztabc + zrow + (size_t)ch * KC * M;
-#pragma unroll
-      for (int r = 0; r < R; ++r) bz[r] = zq[lane + 64 * r];
-      return;
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int lev = ch * KC + kk0 + 8 * r;
-      bz[r] = m0 + mm < nmodes ? ztabc[ztab_index(true, nmodes, nz, lev, m0 + mm)] : 0.;
-    }
-  };
-  auto commit_b = [&](int ch, const double (&bz)[R]) {
-    double *zc = zb + (ch & 1) * (KC * M);
-#pragma unroll
-    for (int r = 0; r < R; ++r) zc[lane + 64 * r] = bz[r];
-  };
-  // own chunks <= nch-2, from the top: c0 = the largest one, then c0 - 4, ...; slot A holds the even-numbered turns
-  int c0 = nch - 2;
-  while (c0 >= 0 && (c0 & (NMV - 1)) != w) --c0;
-  if (c0 >= 0) issue_b(c0, bzA);
-  if (c0 - NMV >= 0) issue_b(c0 - NMV, bzB);
-  bool useA = true;
-  for (int t = 0; t < nch; ++t) {
-    const int ch = nch - 1 - t;
-    const int cn = ch - 1;                                   // coefficients the next period needs
-    const bool mine = cn >= 0 && (cn & (NMV - 1)) == w;
-    if (mine) { if (useA) commit_b(cn, bzA); else commit_b(cn, bzB); }
-    __syncthreads();
-    if ((ch & (NMV - 1)) == w) {
-      const double *xc = xs + (size_t)ch * KC * C;
-      if (modes_full && ch * KC + KC <= nz) {
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-          (x + (size_t)(ch * KC + 8 * r) * st)[xoff] = *reinterpret_cast<const double2 *>(xc + 2 * (lane + 64 * r));
-      } else {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const int lev = ch * KC + kk0 + 8 * r;
-          if (lev < nz && m0 + mm < nmodes)
-            x[(size_t)lev * st + m0 + mm] = *reinterpret_cast<const double2 *>(xc + 2 * (lane + 64 * r));
-        }
-      }
-    }
-    if (mine) {
-      if (cn - 2 * NMV >= 0) { if (useA) issue_b(cn - 2 * NMV, bzA); else issue_b(cn - 2 * NMV, bzB); }
-      useA = !useA;
-    }
-  }
-}
-
-// Register-resident segments (round 4).  The LDS-resident kernels above keep a workgroup's columns in LDS and let one
-// wave walk them, 64 dependent chains per CU: they sit at half of the roofline whatever feeds them.  Here nothing is
-// resident anywhere but in registers: thread (mode mm of the workgroup's ZB modes, segment s) owns SL consecutive levels of
+// Register-resident segments (round 4).  Rounds 2-3 kept a workgroup's columns in LDS and let one wave walk them (plain and
+// wave-specialised variants, 64 dependent chains per CU): half of the roofline whatever fed them (profiles/r04/thomas_variants_ab.txt;
+// removed).  Here nothing is resident anywhere but in registers: thread (mode mm of the workgroup's ZB modes, segment s) owns SL consecutive levels of
 // one complex column -- SL independent 16-B loads of x, SL pivots and SL back-substitution coefficients, all issued before
 // the first use -- and the two sweeps, first-order linear recurrences  v_l = g_l v_prev + t_l,  are solved by partition:
 //   1. zero-inflow recurrence over the own segment -> summary (P = prod g, y) -> LDS, one barrier;
 //   2. every thread chains the summaries of the segments before (forward) / above (back) its own: v_in;
 //   3. the own segment again, from v_in, in the reference's order (src/modpois.f90:1120-1166) -- so only the inflow
-//      value carries the partition's rounding (same class as the partitioned sweeps of the LDS kernels);
+//      value carries the partition's rounding;
 //   the top level (Dirichlet row of the singular mode, :209-220) is closed by the thread that owns it between the sweeps.
 // A wave is 8 modes x 8 segments: every load instruction fetches eight full 128-B lines of x (64-B runs of the blocked
 // tables).  Two barriers per workgroup, no LDS traffic but the summaries; x and both tables cross the bus exactly once.
@@ -863,88 +351,43 @@ __global__ __launch_bounds__(NT, W) void thomas_reg_kernel(int nmodes, int nz, d
   }
 }
 
-// Which solve.  The table's layout follows the kernel, so the choice is made once per table (udc_create reads UDC_THOMAS
-// into the handle: -1 = default, 0 = streaming kernel, 3 = LDS-resident columns, 4 = register-resident segments).
-// Default: register-resident segments for nz <= 1024 (every deck there is), the streaming kernel above that.
-static size_t thomas_lds_bytes(int nz, int M, int KC) { return ((size_t)nz * 2 * M + 3 * (size_t)KC * M + 4 * 2 * M * 2) * sizeof(double); }
+// Which solve.  The table's layout follows the kernel, so the choice is made once per table (udc_create reads UDC_THOMAS into the
+// handle: 0 = the streaming kernel everywhere).  Default: register-resident segments for nz <= 1024 and arrays below 4 GiB (every
+// deck there is), the streaming kernel otherwise.
 static bool thomas_reg_fits(long nmodes, int nz) { return nz >= 3 && nz <= 1024 && (size_t)nmodes * (size_t)nz * 16 < ((size_t)1 << 32); }
-static bool thomas_lds_fits(int nz) { return thomas_lds_bytes(nz, 8, 32) <= 160 * 1024 - 1024; }
-static bool thomas_wants_lds(const udc_handle *h, long nmodes, int nz) {      // the blocked tables (both LDS and register kernels)
-  const int mode = h->sw.thomas;
-  if (nz < 2 || mode == 0) return false;
-  if (mode == 3) return thomas_lds_fits(nz) || thomas_reg_fits(nmodes, nz);
-  return thomas_reg_fits(nmodes, nz);
+static bool thomas_wants_lds(const udc_handle *h, long nmodes, int nz) {      // -> the blocked tables of the register kernel
+  return h->sw.thomas != 0 && thomas_reg_fits(nmodes, nz);
 }
 static size_t ztab_doubles(long nmodes, int nz) { return (size_t)((nmodes + ZB - 1) / ZB) * ZB * (size_t)(nz > 1 ? nz - 1 : 1); }
 
-template <int SL, int NT, int W, int NP>
+template <int NT, int W, int NP>
 static void launch_thomas_reg(udc_handle *h, long nmodes, int nz, double scale, const double *ev, const double *ztab, double2 *x, int nkb, int ny) {
   const unsigned blocks = NP == 2 ? (unsigned)((ny / 2 + 1) * nkb) : (unsigned)((nmodes + ZB - 1) / ZB);
-  hipLaunchKernelGGL((thomas_reg_kernel<SL, NT, (W > NT / 256 ? W : NT / 256), NP>), dim3(blocks), dim3(NT), 0, h->stream,
+  hipLaunchKernelGGL((thomas_reg_kernel<8, NT, (W > NT / 256 ? W : NT / 256), NP>), dim3(blocks), dim3(NT), 0, h->stream,
                      (int)nmodes, nz, scale, ev, h->tri, h->btopD, ztab, x, nkb, ny);
 }
 
-static int launch_thomas(udc_handle *h, bool lds, long nmodes, int nz, double scale, const double *ev, const double *ztab, double2 *x,
+// nkb, pair_ny > 0: the caller's modes are spec[k][ky][kx] rows of nkb blocks of eight, ky = 0 .. pair_ny - 1 (one GPU): rows ky and
+// ny - ky are solved together (UDC_THOMAS_PAIR=0: not)
+static int launch_thomas(udc_handle *h, bool blocked, long nmodes, int nz, double scale, const double *ev, const double *ztab, double2 *x,
                          int nkb = 0, int pair_ny = 0) {
-  const size_t full = 160 * 1024 - 1024;
-  auto need = [&](int M, int KC) { return thomas_lds_bytes(nz, M, KC); };
-#define UDC_TL(M, KC, D, DB, PART)                                                                               \
-  do {                                                                                                       \
-    static std::atomic<bool> attr_done{false};                                                                       \
-    if (!attr_done) {                                                                                        \
-      if (hipFuncSetAttribute((const void *)thomas_lds_kernel<M, KC, D, DB, PART>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              (int)full) != hipSuccess) return 1;                                            \
-      attr_done = true;                                                                                      \
-    }                                                                                                        \
-    hipLaunchKernelGGL((thomas_lds_kernel<M, KC, D, DB, PART>), dim3((unsigned)((nmodes + M - 1) / M)), dim3(256), need(M, KC), \
-                       h->stream, (int)nmodes, nz, scale, ev, h->tri, h->btopD, ztab, x);                    \
-    return 0;                                                                                                \
-  } while (0)
-  if (lds && !(h->sw.thomas == 3 && thomas_lds_fits(nz)) && thomas_reg_fits(nmodes, nz)) {
-    // levels per thread: 8 (up to 1024 threads per workgroup) unless asked for 4 (nz <= 512) or 16
-    int SL = 8;
-    if (h->sw.thomas_sl == 16) SL = 16;
-    if (h->sw.thomas_sl == 4 && nz <= 512) SL = 4;
-    const int nt = 8 * ((nz + SL - 1) / SL);
-#define UDC_TR(SLv, Wv, NPv)                                                                                      \
-    do {                                                                                                          \
-      if (nt <= 64) launch_thomas_reg<SLv, 64, Wv, NPv>(h, nmodes, nz, scale, ev, ztab, x, nkb, pair_ny);         \
-      else if (nt <= 128) launch_thomas_reg<SLv, 128, Wv, NPv>(h, nmodes, nz, scale, ev, ztab, x, nkb, pair_ny);  \
-      else if (nt <= 256) launch_thomas_reg<SLv, 256, Wv, NPv>(h, nmodes, nz, scale, ev, ztab, x, nkb, pair_ny);  \
-      else if (nt <= 512) launch_thomas_reg<SLv, 512, Wv, NPv>(h, nmodes, nz, scale, ev, ztab, x, nkb, pair_ny);  \
-      else launch_thomas_reg<SLv, 1024, Wv, NPv>(h, nmodes, nz, scale, ev, ztab, x, nkb, pair_ny);                \
-    } while (0)
-    // pair_ny > 0: the caller's modes are spec[k][ky][kx] rows of nkb blocks of eight, ky = 0 .. pair_ny - 1 (one GPU)
+  if (blocked) {
+    // eight levels per thread; workgroups of 8 x ceil(nz / 8) threads.  Measured (profiles/r04/thomas_variants_ab.txt, thomas_pair_ab.txt):
+    // 16 levels per thread spill, 4 leave too little in flight per thread; compiled for 3 waves per SIMD (2 with two systems per thread)
+    const int nt = 8 * ((nz + 7) / 8);
     const bool pair = pair_ny > 0 && h->sw.thomas_pair;
-    const int W = h->sw.thomas_w;
-    if (pair) { if (SL == 4) UDC_TR(4, 4, 2); else UDC_TR(8, 2, 2); }
-    else if (SL == 16) UDC_TR(16, 2, 1);
-    else if (SL == 4) UDC_TR(4, 4, 1);
-    else if (W == 2) UDC_TR(8, 2, 1);
-    else if (W == 4) UDC_TR(8, 4, 1);
-    else UDC_TR(8, 3, 1);
+#define UDC_TR(Wv, NPv)                                                                                      \
+    do {                                                                                                     \
+      if (nt <= 64) launch_thomas_reg<64, Wv, NPv>(h, nmodes, nz, scale, ev, ztab, x, nkb, pair_ny);         \
+      else if (nt <= 128) launch_thomas_reg<128, Wv, NPv>(h, nmodes, nz, scale, ev, ztab, x, nkb, pair_ny);  \
+      else if (nt <= 256) launch_thomas_reg<256, Wv, NPv>(h, nmodes, nz, scale, ev, ztab, x, nkb, pair_ny);  \
+      else if (nt <= 512) launch_thomas_reg<512, Wv, NPv>(h, nmodes, nz, scale, ev, ztab, x, nkb, pair_ny);  \
+      else launch_thomas_reg<1024, Wv, NPv>(h, nmodes, nz, scale, ev, ztab, x, nkb, pair_ny);                \
+    } while (0)
+    if (pair) UDC_TR(2, 2); else UDC_TR(3, 1);
 #undef UDC_TR
     return 0;
   }
-  // LDS-resident columns (UDC_THOMAS=3): with four workgroups on a CU (nz <= 256) the plain kernel hides its own stalls (256^3
-  // 0.107 ms against 0.123 wave-specialised, 512x512x256 0.393 against 0.441); with two (256 < nz <= ~590) the wave-specialised
-  // one wins (1024x512x512: 1.65-1.72 ms against 2.18-2.25).
-  if (lds) {
-    const bool ws = h->sw.thomas_ws >= 0 ? h->sw.thomas_ws != 0 : need(8, 32) * 4 > full;
-    if (ws) {
-      static std::atomic<bool> ws_attr{false};
-      if (!ws_attr) {
-        if (hipFuncSetAttribute((const void *)thomas_ws_kernel<8, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)full) != hipSuccess) return 1;
-        ws_attr = true;
-      }
-      hipLaunchKernelGGL((thomas_ws_kernel<8, 32>), dim3((unsigned)((nmodes + 7) / 8)), dim3(320), need(8, 32), h->stream, (int)nmodes, nz,
-                         scale, ev, h->tri, h->btopD, ztab, x);
-      return 0;
-    }
-    if (h->sw.thomas_part == 0) UDC_TL(8, 32, 2, 8, false);
-    UDC_TL(8, 32, 2, 8, true);
-  }
-#undef UDC_TL
   hipLaunchKernelGGL(thomas_kernel, dim3((unsigned)((nmodes + 63) / 64)), dim3(64), 0, h->stream, (int)nmodes, nz, scale,
                      ev, h->tri, h->btopD, ztab, x);
   return 0;
@@ -1264,7 +707,7 @@ int pois_init(udc_handle *h) {
   // row pitch of the spectral array (complex elements): nkx = nx/2+1 is odd; padding it lets
   // rocFFT's strided y pass and the Thomas sweep run on aligned rows.  Padding modes hold zeros.
   int pad = (8 - nkx % 8) % 8;
-  if (getenv("UDC_SPEC_PAD")) pad = atoi(getenv("UDC_SPEC_PAD"));
+  if (h->sw.spec_pad >= 0) pad = h->sw.spec_pad;
   const int nkxp = nkx + pad;
   h->nkxp = nkxp;
   const long nmodes = (long)nkxp * ny;
@@ -1416,7 +859,7 @@ int pois_slab_init(udc_handle *h) {
   }
   // k-chunks of the all-to-all pipeline (UDC_A2A_CHUNKS overrides; chunks must divide nz)
   int nch = (P > 1 && nz % 4 == 0 && nz >= 16) ? 4 : 1;
-  if (getenv("UDC_A2A_CHUNKS")) nch = atoi(getenv("UDC_A2A_CHUNKS"));
+  nch = h->sw.a2a_chunks;
   if (nch < 1 || nch > 16 || nz % nch) nch = 1;
   h->nch = nch;
   const int nzc = nz / nch;
@@ -1456,7 +899,7 @@ int pois_slab_init(udc_handle *h) {
                             rocfft_precision_double, 1, ly, (size_t)cx * nzc, nullptr));
   FFT_OK(rocfft_plan_create(&h->plan_yb, rocfft_placement_inplace, rocfft_transform_type_complex_inverse,
                             rocfft_precision_double, 1, ly, (size_t)cx * nzc, nullptr));
-  h->fft_fused = fft_fused_possible(h) && !(getenv("UDC_FFT_FUSED") && atoi(getenv("UDC_FFT_FUSED")) == 0);
+  h->fft_fused = fft_fused_possible(h) && h->sw.fft_fused;
   if (h->fft_fused && fft_fused_init(h)) return 1;
   {
     // exchanges run beside the transforms / the interior launches of the split kernels: highest priority, so that their few
@@ -1466,8 +909,8 @@ int pois_slab_init(udc_handle *h) {
     HIP_OK(hipStreamCreateWithPriority(&h->comm_stream, hipStreamNonBlocking, hi));
     HIP_OK(hipEventCreateWithFlags(&h->ev_halo_ready, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&h->ev_halo_done, hipEventDisableTiming));
-    h->no_halo_overlap = getenv("UDC_HALO_OVERLAP") && atoi(getenv("UDC_HALO_OVERLAP")) == 0;
-    h->no_mom_pipe = getenv("UDC_MOM_PIPE") && atoi(getenv("UDC_MOM_PIPE")) == 0;
+    h->no_halo_overlap = !h->sw.halo_overlap;
+    h->no_mom_pipe = !h->sw.mom_pipe;
   }
   for (int c = 0; c < nch; ++c) {
     HIP_OK(hipEventCreateWithFlags(&h->ev_ready[c], hipEventDisableTiming));

@@ -161,10 +161,9 @@ __global__ __launch_bounds__(NT, 3) void scalar_lds_kernel(Geo g, int gx, int ti
 // its low face.  3 (+1/4) limiter evaluations per cell instead of 6, bit-identical operands and operation order.
 // One barrier per level: faces of level k go to the flux buffers of parity k&1, planes are committed two levels
 // before they are first read, and the diffusion (which reads the diffusivity planes) is evaluated before the barrier.
-// W5: a fifth wave owns the extra faces (and a share of the staging) instead of one of the four cell waves: the waves that meet at
-// the barrier then all carry three face evaluations; five waves per SIMD need <= 96 VGPRs
-template <bool LES, bool FRESH, bool W5>
-__global__ __launch_bounds__(W5 ? NT + 64 : NT, W5 ? 5 : 4) void scalar_kappa_faces_kernel(Geo g, int gx, int tiles, Metrics m, double cekh, double dfac,
+// (A fifth wave owning the extra faces was built and measured slower, profiles/r03/kappa_w5_ab.json: not kept.)
+template <bool LES, bool FRESH>
+__global__ __launch_bounds__(NT, 4) void scalar_kappa_faces_kernel(Geo g, int gx, int tiles, Metrics m, double cekh, double dfac,
     const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ w, const double *__restrict__ ekh,
     const double *__restrict__ c, double *__restrict__ cp, int gh, int kc) {
   __shared__ double sc[NCB][CN];
@@ -179,9 +178,9 @@ __global__ __launch_bounds__(W5 ? NT + 64 : NT, W5 ? 5 : 4) void scalar_kappa_fa
   if ((tiles & 7) == 0) tt = (lp & 7u) * (tiles >> 3) + (lp >> 3);      // XCD-aware, as tile_decode
   const int by = tt / gx, bx = tt - by * gx;
   const int i0 = bx * MX, j0 = by * MY;
-  constexpr int NTS = W5 ? NT + 64 : NT;          // threads that stage planes
+  constexpr int NTS = NT;                         // threads that stage planes
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * MX + tx;
-  const bool own = !W5 || tid < NT;               // (wave-uniform) this thread has a cell of the tile
+  constexpr bool own = true;                      // every thread has a cell of the tile
   const int i = i0 + tx, j = j0 + (own ? ty : 0);
   const bool inside = own && i < g.nx && j < g.ny;
   const int k0 = chunk * kc, k1 = min(k0 + kc, g.nz);
@@ -263,7 +262,7 @@ __global__ __launch_bounds__(W5 ? NT + 64 : NT, W5 ? 5 : 4) void scalar_kappa_fa
   // ONE wave per workgroup (rotating with the block) evaluates all 40 of them in a single pass: lanes 0..MX-1 the y-faces,
   // lanes MX..MX+MY-1 the x-faces (two passes in two waves cost a whole wave's issue time each, for 8 and 32 lanes)
   const int wave = tid >> 6, lane = tid & 63;
-  const bool erole = wave == (W5 ? 4 : (int)(Lb & 3)) && lane < MX + MY;
+  const bool erole = wave == (int)(Lb & 3) && lane < MX + MY;
   const bool ex = lane >= MX;                      // this lane's extra face is an x-face (row lane - MX), else a y-face (column lane)
   const int el = ex ? lane - MX : lane;
   const int er_c = ex ? (el + 2) * CX + (MX + 2) : (MY + 2) * CX + (el + 2);      // the cell on the high side of the face
@@ -378,7 +377,7 @@ __global__ __launch_bounds__(W5 ? NT + 64 : NT, W5 ? 5 : 4) void scalar_kappa_fa
 // fused advection + diffusion of scalar slot n; false when this kernel does not apply (the caller falls back)
 bool k_scalar_fused_lds(udc_handle *h, int n, bool fresh, int *rc) {
   *rc = 0;
-  if (getenv("UDC_SCALAR_LDS") && atoi(getenv("UDC_SCALAR_LDS")) == 0) return false;
+  if (h->sw.mom_simple) return false;
   const Geo &g = h->g;
   if (g.nx < MX || g.ny < 4) return false;
   const int gx = (g.nx + MX - 1) / MX, gy = (g.ny + MY - 1) / MY, tiles = gx * gy;
@@ -392,7 +391,7 @@ bool k_scalar_fused_lds(udc_handle *h, int n, bool fresh, int *rc) {
       const double cost = (double)((blocks + slots - 1) / slots) * (q + 5);
       if (cost < best - 1e-9) { best = cost; kc = q; }
     }
-    if (getenv("UDC_SCALAR_KC")) { const int v = atoi(getenv("UDC_SCALAR_KC")); if (v >= 1) kc = v < g.nz ? v : g.nz; }
+    if (h->sw.scalar_kc >= 1) kc = h->sw.scalar_kc < g.nz ? h->sw.scalar_kc : g.nz;
   }
   const int chunks = (g.nz + kc - 1) / kc;
   const dim3 b(MX, MY, 1), gr((unsigned)tiles * (unsigned)chunks, 1, 1);
@@ -404,11 +403,7 @@ bool k_scalar_fused_lds(udc_handle *h, int n, bool fresh, int *rc) {
   double *cp = h->fields[UDC_SVP + 3 * n];
   const bool les = h->p.sgs != UDC_SGS_DNS, cd2 = h->slot[n].adv == 2;
   const int gh = h->slot[n].kappa_ghosts;
-  static const bool w5 = getenv("UDC_KAPPA_W5") && atoi(getenv("UDC_KAPPA_W5")) != 0;
-  static const int ldspad = getenv("UDC_KAPPA_LDSPAD") ? atoi(getenv("UDC_KAPPA_LDSPAD")) : 0;      // occupancy experiments: unused dynamic LDS
-  const dim3 b5(MX, MY + 2, 1);
-#define LF(L, F) do { if (w5) hipLaunchKernelGGL((scalar_kappa_faces_kernel<L, F, true>), gr, b5, ldspad, h->stream, g, gx, tiles, h->m, cekh, dfac, u, v, w, ekh, c, cp, gh, kc); \
-                      else hipLaunchKernelGGL((scalar_kappa_faces_kernel<L, F, false>), gr, b, ldspad, h->stream, g, gx, tiles, h->m, cekh, dfac, u, v, w, ekh, c, cp, gh, kc); } while (0)
+#define LF(L, F) hipLaunchKernelGGL((scalar_kappa_faces_kernel<L, F>), gr, b, 0, h->stream, g, gx, tiles, h->m, cekh, dfac, u, v, w, ekh, c, cp, gh, kc)
 #define LS(A, L, F) hipLaunchKernelGGL((scalar_lds_kernel<A, L, F, 1>), gr, b, 0, h->stream, g, gx, tiles, h->m, cekh, dfac, u, v, w, ekh, c, cp, c, cp, gh, kc)
   {
     PROF(h, cd2 ? "scalar_lds_cd2" : "scalar_kappa_faces");
@@ -425,8 +420,8 @@ bool k_scalar_fused_lds(udc_handle *h, int n, bool fresh, int *rc) {
 // with ekh, same vertical ghost rule -- thl and qt.  false when that does not apply (the caller launches them one by one).
 bool k_scalar_pair_lds(udc_handle *h, int na, int nb, bool fresh, int *rc) {
   *rc = 0;
-  if (getenv("UDC_SCALAR_LDS") && atoi(getenv("UDC_SCALAR_LDS")) == 0) return false;
-  if (getenv("UDC_SCALAR_PAIR") && atoi(getenv("UDC_SCALAR_PAIR")) == 0) return false;
+  if (h->sw.mom_simple) return false;
+  if (!h->sw.scalar_pair) return false;
   const Geo &g = h->g;
   if (g.nx < MX || g.ny < 4) return false;
   const udc_handle::Slot &A = h->slot[na], &B = h->slot[nb];
@@ -441,7 +436,7 @@ bool k_scalar_pair_lds(udc_handle *h, int na, int nb, bool fresh, int *rc) {
       const double cost = (double)((blocks + slots - 1) / slots) * (q + 5);
       if (cost < best - 1e-9) { best = cost; kc = q; }
     }
-    if (getenv("UDC_SCALAR_KC")) { const int v = atoi(getenv("UDC_SCALAR_KC")); if (v >= 1) kc = v < g.nz ? v : g.nz; }
+    if (h->sw.scalar_kc >= 1) kc = h->sw.scalar_kc < g.nz ? h->sw.scalar_kc : g.nz;
   }
   const int chunks = (g.nz + kc - 1) / kc;
   const dim3 b(MX, MY, 1), gr((unsigned)tiles * (unsigned)chunks, 1, 1);

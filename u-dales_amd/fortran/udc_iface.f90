@@ -521,10 +521,14 @@ contains
       write (0, *) 'ERROR: libudcore decomposes in y only: set nprocx = 1, nprocy = number of GPUs'
       stop 1
     end if
-    gpus_per_node = 8
+    ! device: the library deals the ranks round over the node's visible devices (cfg%device = -1) unless UDC_GPUS_PER_NODE says
+    ! how many of them to use (1 = every rank on device 0: the one-GPU tests)
+    gpus_per_node = 0
     call get_environment_variable('UDC_GPUS_PER_NODE', env, status=stat)
     if (stat == 0) read (env, *, iostat=stat) gpus_per_node
-    cfg%nranks = nprocs; cfg%rank = myid; cfg%device = mod(myid, max(gpus_per_node, 1))
+    cfg%nranks = nprocs; cfg%rank = myid
+    cfg%device = -1
+    if (gpus_per_node > 0) cfg%device = mod(myid, gpus_per_node)
     cfg%dx = dx; cfg%dy = dy
     cfg%dzf = c_loc(zf_); cfg%dzh = c_loc(zh_)
     cfg%numol = numol; cfg%prandtlmoli = prandtlmoli; cfg%prandtli = prandtli
