@@ -277,12 +277,23 @@ def dropin_leg(nx, ny, nz, nsv, sgs, floor, value, nsub=150, nwarm=15):
             write_deck(tmp, 904, nx, ny, nz, 0, nsv=nsv, sgs=sgs, floor=floor, runtime=nstep * 0.25 - 1e-6)
             try:
                 r2 = subprocess.run(f"ulimit -s unlimited; exec {exe2} namoptions.904", shell=True, cwd=tmp, capture_output=True, text=True,
-                                    timeout=900, executable="/bin/bash", env=dict(os.environ, UDC_RESIDENCY="2"))
+                                    timeout=900, executable="/bin/bash", env=dict(os.environ, UDC_RESIDENCY="2", UDC_TIMERS="1"))
                 mt = re.search(r"TOTAL CPU time by main time loop =\s*([0-9.Ee+-]+)", r2.stdout)
                 if r2.returncode == 0 and mt:
                     sec = float(mt.group(1))
+                    # the drop-in modules' host-side phase clock (UDC_TIMERS=1): the one-time upload of the state when the loop starts and
+                    # its download for the output / restart code when it ends, and what the host spends inside the drop-in routines
+                    phases = {m_.group(1): {"calls": int(m_.group(2)), "seconds": float(m_.group(3))}
+                              for m_ in re.finditer(r"UDC_TIMER\s+(\w+)\s+calls=\s*(\d+)\s+seconds=\s*([0-9.Ee+-]+)", r2.stdout)}
+                    once = sum(phases.get(k, {}).get("seconds", 0.) for k in ("upload", "download"))
+                    steady = max(sec - once, 1e-9)
                     real = {"value": nx * ny * nz * 3 * nstep / sec, "unit": "cell-updates/s", "steps": nstep, "loop_seconds": round(sec, 4),
                             "frac_of_direct": round(nx * ny * nz * 3 * nstep / sec / value, 4),
+                            "host_phases": phases,
+                            "one_time_transfers_s": round(once, 4),
+                            "steady_state": {"value": nx * ny * nz * 3 * nstep / steady, "ms_per_substep": round(steady / (3 * nstep) * 1e3, 5),
+                                             "frac_of_direct": round(nx * ny * nz * 3 * nstep / steady / value, 4),
+                                             "note": "the loop's time minus the one-time upload / download of the state"},
                             "surface": "oracle/_ref/udales_full_dropin namoptions.NNN: the reference's program.f90, modstartup.f90 and every "
                                        "other file of its src/ unmodified, minus the ten drop-in modules; its own timer around its loop "
                                        "(incl. the one-time upload / final download of the state)"}

@@ -433,6 +433,11 @@ int udc_set_scalar_bcx_outflow(udc_handle *h, const double *wlev);
  * SIGNED sum (um dxhi + vm dyi + wm dzhi) dtmn, :111-117 --, out[1] = calcdiffnr's (:142-149), out[2], out[3] = chkdiv's divmax and
  * divtot of u0, v0, w0 (:179-196); dtmn: the mean time step since the last report (:83, :86). */
 int udc_checksim(udc_handle *h, double dtmn, double out[4]);
+/* The same in two halves: _begin queues the reductions and their copy to the host behind whatever the handle's stream holds and
+ * returns at once; _end waits for them and hands the four numbers over.  A driver that reports every time step (tcheck <= dt,
+ * src/modchecksim.f90:66) calls _end of the previous report just before the next _begin and so never waits on the device. */
+int udc_checksim_begin(udc_handle *h, double dtmn);
+int udc_checksim_end(udc_handle *h, double out[4]);
 /* divergence of u0 as modchecksim's chkdiv (src/modchecksim.f90:161-203): max |div|, sum div */
 int udc_divergence(udc_handle *h, double *divmax, double *divtot);
 

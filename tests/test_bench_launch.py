@@ -124,7 +124,7 @@ def test_fallback_ladder_of_a_multi_rank_run(mode):
     names the rung that produced the number and lists the failed attempt with its reason."""
     extra, env, how = transport_args(2, f"ladder{mode}")
     env = dict(env, UDC_BENCH_INJECT=f"0:warm-up:{mode}:1")
-    r = launch(2, extra + ["--stall-timeout", "25"], 1500, env, size="64x32x32", single=True)
+    r = launch(2, extra + ["--stall-timeout", "12"], 1500, env, size="64x32x32", single=True)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     d = bench_line(r)
     lad = d["ladder"]

@@ -3,8 +3,9 @@
 
 The CPU side is the reference's own Fortran (oracle/_ref/udales_ref, built by oracle/Makefile from
 /root/reference/src; the binary travels to the GPU box).  Default size 64^3 (BASELINE configs[0]'s
-plumbing size) is covered by the fixtures; the default here is 128^3 (~1 min of CPU), UDC_LONG_SIZE=256 runs BASELINE
-configs[1] itself (~10 min of CPU).
+plumbing size) is covered by the fixtures; the default here is 128 x 128 x 32 (~20 s of CPU: the suite has a time limit on the
+driver's box), UDC_LONG_SIZE=128 the cube, UDC_LONG_SIZE=256 BASELINE configs[1] itself (~10 min of CPU; the acceptance runs kept
+under profiles/).
 """
 import os
 import subprocess
@@ -29,8 +30,9 @@ def test_100_steps_against_reference_cpu(tmp_path):
     import udcore
     from udcore import read_deck, cold_start
     n = int(os.environ.get("UDC_LONG_SIZE", "128"))
+    nzl = n if "UDC_LONG_SIZE" in os.environ else 32
     nsub = 300
-    path = write_deck(str(tmp_path), 77, n, n, n, nsub)
+    path = write_deck(str(tmp_path), 77, n, n, nzl, nsub)
     with open(path) as f:
         txt = f.read().replace(f"nsub = {nsub}", f"nsub = {nsub}\ndump_at = {nsub}")
     with open(path, "w") as f:
@@ -67,7 +69,7 @@ def test_100_steps_all_physics_against_reference_cpu(tmp_path):
     import udcore
     from udcore import read_deck, cold_start
     from udcore.forcings import LevelForcings
-    n = int(os.environ.get("UDC_LONG_SIZE", "128"))
+    n = int(os.environ.get("UDC_LONG_SIZE", "64"))
     nz = 48
     nsub = 300
     dz = 0.5

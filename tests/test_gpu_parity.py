@@ -685,6 +685,45 @@ def test_tstep_maxima_matches_numpy():
     core.close()
 
 
+@pytest.mark.parametrize("stage", [3, 2], ids=["after-stage-3-um-is-u0", "after-stage-2-um-distinct"])
+def test_checksim_numbers_match_numpy(stage):
+    """udc_checksim (src/modchecksim.f90:102-203: calccourant's SIGNED maximum of um dxhi + vm dyi + wm dzhi, calcdiffnr, chkdiv's divmax
+    and divtot) against the same expressions in numpy -- after RK stage 3 of a fused substep (um is u0: the one-sweep kernel) and after
+    stage 2 (um distinct: the two kernels) -- and the two halves udc_checksim_begin / _end against the blocking call."""
+    import ctypes as C
+    g = Grid.from_levels(32, 16, 12, 16., 6.4, np.cumsum(0.5 * 1.04 ** np.arange(12)) - 0.25 * 1.04 ** np.arange(12))
+    from udcore.core import DynCore
+    core = DynCore(g)
+    core.load_state(random_state(g, 12))
+    for rk in ((1, 2, 3) if stage == 3 else (1, 2, 3, 1, 2)):
+        core.substep(rk, 0.05, with_forces=False)
+    dtmn = 0.04
+    out = (C.c_double * 4)()
+    assert core.lib.udc_checksim(core.h, C.c_double(dtmn), out) == 0
+    um, vm, wm = (interior(core.download(k)) for k in ("um", "vm", "wm"))
+    ekm, ekh = interior(core.download("ekm")), interior(core.download("ekh"))
+    dzh = g.dzh[1:g.nz + 1][:, None, None]
+    dzf = g.dzf[1:g.nz + 1][:, None, None]
+    cour = ((um / g.dx + vm / g.dy + wm / dzh) * dtmn).max()
+    f = (1. / dzh ** 2 + 1. / g.dx ** 2 + 1. / g.dy ** 2) * dtmn
+    dif = max((ekm * f).max(), (ekh * f).max())
+    u, v, w = (core.download(k) for k in ("u0", "v0", "w0"))
+    div = ((u[1:-1, 1:-1, 2:] - u[1:-1, 1:-1, 1:-1]) / g.dx + (v[1:-1, 2:, 1:-1] - v[1:-1, 1:-1, 1:-1]) / g.dy
+           + (w[2:, 1:-1, 1:-1] - w[1:-1, 1:-1, 1:-1]) / dzf)
+    assert abs(out[0] - cour) <= 1e-12 * abs(cour) and abs(out[1] - dif) <= 1e-12 * dif
+    # (the divergence of a projected field is rounding noise: compared on the scale of its terms, |u| / dx)
+    scale = np.abs(u).max() / g.dx
+    assert abs(out[2] - np.abs(div).max()) <= 1e-13 * scale
+    assert abs(out[3] - (div * g.dx * g.dy * dzf).sum()) <= 1e-13 * scale * (g.dx * g.dy * dzf).sum() * div.size / g.nz
+    out2 = (C.c_double * 4)()
+    assert core.lib.udc_checksim_begin(core.h, C.c_double(dtmn)) == 0
+    core.substep(3 if stage == 2 else 1, 0.05, with_forces=False)      # the report is picked up after more work has been queued
+    assert core.lib.udc_checksim_end(core.h, out2) == 0
+    assert list(out2) == list(out)
+    assert core.lib.udc_checksim_end(core.h, out2) != 0                    # nothing pending any more
+    core.close()
+
+
 def test_full_size_properties_256():
     """BASELINE config 2 (256^3): projection leaves a divergence-free field, and a periodic shift
     of the input by (sx, sy) cells shifts the output (checks FFT/halo wiring at full size)."""

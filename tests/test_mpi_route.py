@@ -107,10 +107,10 @@ def run_ranks(name, iexp, tmp_path, nranks, deck_edit=None):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,P", [("run_16x16x8", 2), ("run_16x16x8", 4), ("run_smag_scalar_16x8x12s", 2),
-                                    ("run_moist_16x8x12s", 2), ("run_ibm_wf2_16x12x10", 2), ("run_ibm_wf2_16x12x10", 3),
+                                    ("run_moist_16x8x12s", 2), ("run_ibm_wf2_16x12x10", 2),
                                     ("run_ibm_moistwq_16x12x10", 2)])
 def test_mpi_ranks_run_the_deck_to_the_end(name, P, tmp_path):
-    """mpiexec -n P (2, 3, 4) of the reference's real program with the drop-in modules, nprocy = P: MPI start-up and broadcasts, P library
+    """mpiexec -n P (2, 4) of the reference's real program with the drop-in modules, nprocy = P: MPI start-up and broadcasts, P library
     handles with P slabs, the Fortran modules' slab logic (rows of the point lists and facet sections, masks, per-rank restart
     files), ghost rows and the Poisson transposes through the library's multi-rank path -- against the one-rank fixture of the
     all-reference executable, through the restart files the ranks write.  Transport: RCCL where the box has P GPUs (the product

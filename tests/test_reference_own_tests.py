@@ -197,9 +197,9 @@ def tdump_fields(tmp, nranks):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("steps", [None, 25])
+@pytest.mark.parametrize("steps", [None, 10])
 def test_processor_boundaries_case_100(steps, tmp_path):
-    """steps = None: the reference's deck as it is (one step).  25: the same deck run for 25 steps with a sample every step and the
+    """steps = None: the reference's deck as it is (one step).  10: the same deck run for 10 steps with a sample every step and the
     one tdump record at the end (not a test the reference holds: the same comparison on a run long enough for the wall functions,
     the immersed boundary and the pressure solver to have acted on each other's output)."""
     if not (os.path.exists(FULL) and os.path.exists(DROPIN)):

@@ -292,6 +292,9 @@ extern "C" int udc_destroy(udc_handle *h) {
   for (int q = 0; q < 3; ++q) if (h->bottom_diag[q]) hipFree(h->bottom_diag[q]);
   if (h->red) hipFree(h->red);
   if (h->red_host) hipHostFree(h->red_host);
+  if (h->chk_host) hipHostFree(h->chk_host);
+  if (h->chk_dev) hipFree(h->chk_dev);
+  if (h->ev_chk) hipEventDestroy(h->ev_chk);
   if (h->thlpcar) hipFree(h->thlpcar);
   if (h->dthv_top) hipFree(h->dthv_top);
   if (h->mt) hipFree(h->mt);
@@ -975,11 +978,15 @@ extern "C" int udc_tstep_maxima(udc_handle *h, double dt, double *courtot, doubl
   return k_maxima(h, dt, courtot, diffnrtot);
 }
 
-extern "C" int udc_checksim(udc_handle *h, double dtmn, double out[4]) {
+extern "C" int udc_checksim_begin(udc_handle *h, double dtmn) {
   ENTRY_FLUSH(h);
   if (ek_current(h, "udc_checksim", true)) return 1;
-  if (k_maxima(h, dtmn, &out[0], &out[1], true)) return 1;
-  return k_divergence_check(h, &out[2], &out[3]);
+  return k_checksim_begin(h, dtmn);
+}
+extern "C" int udc_checksim_end(udc_handle *h, double out[4]) { return k_checksim_end(h, out); }
+extern "C" int udc_checksim(udc_handle *h, double dtmn, double out[4]) {
+  if (udc_checksim_begin(h, dtmn)) return 1;
+  return k_checksim_end(h, out);
 }
 
 extern "C" int udc_divergence(udc_handle *h, double *divmax, double *divtot) {

@@ -89,6 +89,15 @@ inline TileGrid tile_rows(const TileGrid &full, int e, bool edge) {
   return t;
 }
 __host__ __device__ __forceinline__ int tile_row(const TileGrid &t, int b) { return t.y0 + b + (b >= t.ysplit ? t.yjump : 0); }
+// Launch index within a plane / k-chunk (lp) -> local tile row and column.  The hardware deals workgroup b to XCD b % 8: XCD c is
+// given a contiguous run of tiles, row by row.  (Round 4 tried sub-blocks of 4 / 8 / 16 columns x all rows of the XCD's band instead,
+// so that the tile above / below a tile is a few dispatch slots away: the sweeps' traffic and time did not move,
+// profiles/r04/tile_order_ab.txt -- not kept.)
+__host__ __device__ __forceinline__ void xcd_tile(const TileGrid &t, unsigned lp, int &byl, int &bx) {
+  unsigned tt = lp;
+  if ((t.tiles & 7) == 0) tt = (lp & 7u) * (t.tiles >> 3) + (lp >> 3);
+  byl = tt / t.gx; bx = tt - byl * t.gx;
+}
 #if defined(__HIPCC__)
 __device__ __forceinline__ bool tile_decode(const Geo &g, const TileGrid &t, int &i, int &j, int &k) {
   const unsigned L = blockIdx.x;
@@ -180,6 +189,9 @@ struct udc_handle {
   size_t red_cap = 0;                   // doubles in red / red_host
   double *partials = nullptr;           // per-workgroup partial results of the two-stage reductions
   size_t partials_cap = 0;
+  double *chk_host = nullptr, *chk_dev = nullptr;      // checksim's four numbers (udc_checksim_begin / _end)
+  hipEvent_t ev_chk = nullptr;
+  bool chk_pending = false;
   // profiling
   // transported scalars: passive scalars occupy slots 0..nsv-1 (kappa scheme, zero-flux top and floor); the
   // temperature equation (ltempeq, udc_set_tempeq) occupies slot 15.  `slots` lists the active ones.
@@ -472,6 +484,8 @@ int udc_flush_pending(udc_handle *h);
 int k_tke_floor(udc_handle *h);                    // e120(kb-1) = e120(kb), e12m likewise (`bottom`)                     // wp += grav (thv0h - thvh)/thvh, src/modforces.f90:73-84   // cp(i,j,k) += src(k)
 int k_maxima(udc_handle *h, double dt, double *cour, double *diffn, bool checksim = false);
 int k_divergence_check(udc_handle *h, double *divmax, double *divtot);
+int k_checksim_begin(udc_handle *h, double dtmn);
+int k_checksim_end(udc_handle *h, double out[4]);
 int pois_init(udc_handle *h);
 int pois_slab_init(udc_handle *h);
 int k_poisson_solve_slab(udc_handle *h);

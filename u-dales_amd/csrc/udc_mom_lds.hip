@@ -77,9 +77,8 @@ __global__ __launch_bounds__(NT / CPT, CPT == 1 ? MOM_WAVES : 2) void mom_lds_ke
   const unsigned L = blockIdx.x;
   const int chunk = L / tg.tiles;
   const unsigned lp = L - (unsigned)chunk * tg.tiles;
-  unsigned tt = lp;
-  if ((tg.tiles & 7) == 0) tt = (lp & 7u) * (tg.tiles >> 3) + (lp >> 3);
-  const int byl = tt / tg.gx, bx = tt - byl * tg.gx;
+  int byl, bx;
+  xcd_tile(tg, lp, byl, bx);
   const int by = tile_row(tg, byl);
   const int i0 = bx * MX, j0 = by * MY;
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * MX + tx;
@@ -255,9 +254,8 @@ __global__ __launch_bounds__(NT) void closure_lds_kernel(Geo g, TileGrid tg, Met
   const unsigned L = blockIdx.x;
   const int chunk = L / tg.tiles;
   const unsigned lp = L - (unsigned)chunk * tg.tiles;
-  unsigned tt = lp;
-  if ((tg.tiles & 7) == 0) tt = (lp & 7u) * (tg.tiles >> 3) + (lp >> 3);
-  const int byl = tt / tg.gx, bx = tt - byl * tg.gx;
+  int byl, bx;
+  xcd_tile(tg, lp, byl, bx);
   const int by = tile_row(tg, byl);
   const int i0 = bx * MX, j0 = by * MY;
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * MX + tx;

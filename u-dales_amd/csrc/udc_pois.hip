@@ -649,6 +649,32 @@ __global__ __launch_bounds__(256) void divcheck_kernel(Geo g, TileGrid tg, Metri
 }
 
 
+// checksim's three routines in one sweep (the state is read once: 40 B per cell instead of 64) for the usual case that um is u0
+// (after RK stage 3 of an aliased fused substep): calccourant + calcdiffnr as maxima_kernel<true>, chkdiv as divcheck_kernel.
+// out: [2 nblocks] (courant, diffusion) maxima, then [2 nblocks] (divmax, divtot).
+__global__ __launch_bounds__(256) void checksim_kernel(Geo g, TileGrid tg, Metrics m, double dt, const double *__restrict__ u,
+    const double *__restrict__ v, const double *__restrict__ w, const double *__restrict__ ekm, const double *__restrict__ ekh,
+    double *__restrict__ out) {
+  int i, j, k;
+  const bool inside_ = tile_decode(g, tg, i, j, k);
+  double cour = 0., dif = 0., dmax = 0., dsum = 0.;
+  if (inside_) {
+    const long r0 = g.idx(0, j, k);
+    const long c = r0 + i, xp = r0 + wrapp(i, g.nx);
+    const double uc = u[c], vc = v[c], wc = w[c];
+    cour = (uc * m.dxi + vc * m.dyi + wc * m.dzhi[k + 1]) * dt;
+    const double dzh = m.dzh[k + 1];
+    const double f = (1 / (dzh * dzh) + m.dx2i + m.dy2i);
+    dif = fmax(ekm[c] * f * dt, ekh[c] * f * dt);
+    const double div = (u[xp] - uc) * m.dxi + (v[c + g.sy] - vc) * m.dyi + (w[c + g.sz] - wc) * m.dzfi[k + 1];
+    dmax = fabs(div);
+    dsum = div * m.dx * m.dy * m.dzf[k + 1];
+  }
+  block_reduce2<0, 0>(cour, dif, out);
+  __syncthreads();      // (block_reduce2's staging arrays are reused)
+  block_reduce2<0, 1>(dmax, dsum, out + 2 * (size_t)gridDim.x);
+}
+
 // masscorr, src/modforces.f90:328-497: volume-flow branches (luvolflowr :389-417, lvvolflowr :467-494) and the u outflow-rate
 // branch (luoutflowr :352-387).
 // flowsum: S_a = sum(a w(k)), S_b = sum(b w(k)) over the slab interior (b may be null); w = dzf, or with an immersed
@@ -1288,6 +1314,45 @@ int k_maxima(udc_handle *h, double dt, double *cour, double *diffn, bool checksi
   HIP_OK(hipStreamSynchronize(h->stream));
   *cour = h->red_host[0];
   *diffn = h->red_host[1];
+  return 0;
+}
+
+// checksim, asynchronous: the four numbers are computed and copied into pinned memory behind whatever the stream holds; the
+// caller picks them up later (k_checksim_end) -- so the time loop's only per-step wait disappears from runs that report every step
+int k_checksim_begin(udc_handle *h, double dtmn) {
+  const Geo &g = h->g;
+  dim3 b(64, 4, 1), gr = cell_grid(g, b);
+  if (ensure_partials(h, 2 * (size_t)gr.x)) return 1;
+  if (!h->chk_host) {
+    HIP_OK(hipHostMalloc(&h->chk_host, 4 * sizeof(double)));
+    HIP_OK(hipMalloc(&h->chk_dev, 4 * sizeof(double)));
+    HIP_OK(hipEventCreateWithFlags(&h->ev_chk, hipEventDisableTiming));
+  }
+  if (h->um_alias) {
+    hipLaunchKernelGGL(checksim_kernel, gr, b, 0, h->stream, g, tile_grid(g), h->m, dtmn, h->fields[UDC_U0], h->fields[UDC_V0],
+                       h->fields[UDC_W0], h->fields[UDC_EKM], h->fields[UDC_EKH], h->partials);
+  } else {
+    hipLaunchKernelGGL(maxima_kernel<true>, gr, b, 0, h->stream, g, tile_grid(g), h->m, dtmn, h->fields[UDC_UM], h->fields[UDC_VM],
+                       h->fields[UDC_WM], h->fields[UDC_EKM], h->fields[UDC_EKH], h->partials);
+    hipLaunchKernelGGL(divcheck_kernel, gr, b, 0, h->stream, g, tile_grid(g), h->m, h->fields[UDC_U0], h->fields[UDC_V0],
+                       h->fields[UDC_W0], h->partials + 2 * (size_t)gr.x);
+  }
+  hipLaunchKernelGGL((reduce_partials_kernel<0, 0>), dim3(1), dim3(1024), 0, h->stream, h->partials, (long)gr.x, 0., 0., h->chk_dev);
+  hipLaunchKernelGGL((reduce_partials_kernel<0, 1>), dim3(1), dim3(1024), 0, h->stream, h->partials + 2 * (size_t)gr.x, (long)gr.x, 0., 0.,
+                     h->chk_dev + 2);
+  HIP_OK(hipGetLastError());
+  if (comm_allreduce(h, h->chk_dev, 3, 0)) return 1;      // courant, diffusion number, divmax: MPI_MAX
+  if (comm_allreduce(h, h->chk_dev + 3, 1, 1)) return 1;  // divtot: MPI_SUM (src/modchecksim.f90:193-196)
+  HIP_OK(hipMemcpyAsync(h->chk_host, h->chk_dev, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipEventRecord(h->ev_chk, h->stream));
+  h->chk_pending = true;
+  return 0;
+}
+int k_checksim_end(udc_handle *h, double out[4]) {
+  if (!h->chk_pending) { udc_set_error("udc_checksim_end: no report pending"); return 1; }
+  HIP_OK(hipEventSynchronize(h->ev_chk));
+  for (int q = 0; q < 4; ++q) out[q] = h->chk_host[q];
+  h->chk_pending = false;
   return 0;
 }
 

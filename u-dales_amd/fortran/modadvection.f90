@@ -7,6 +7,13 @@ module modadvection
 contains
 
   subroutine advection
+    use udc_iface, only: udc_tic, udc_toc, UDC_T_RECORD
+    call udc_tic(UDC_T_RECORD)
+    call advection_timed
+    call udc_toc(UDC_T_RECORD)
+  end subroutine advection
+
+  subroutine advection_timed
     use iso_c_binding, only: c_int
     use modglobal, only: iadv_mom, iadv_cd2, iadv_thl, iadv_qt, iadv_kappa, ltempeq, lmoist
     use modsubgriddata, only: loneeqn
@@ -31,6 +38,6 @@ contains
     call udc_begin(.true.)
     call udc_check(udc_advection(udc_h), 'udc_advection')
     if (udc_mode() <= 1) call udc_pull_tend
-  end subroutine advection
+  end subroutine advection_timed
 
 end module modadvection

@@ -45,6 +45,13 @@ contains
 
   !> periodic ghost cells of the prognostic fields (src/modboundary.f90:67-109)
   subroutine halos
+    use udc_iface, only: udc_tic, udc_toc, UDC_T_HALOS
+    call udc_tic(UDC_T_HALOS)
+    call halos_timed
+    call udc_toc(UDC_T_HALOS)
+  end subroutine halos
+
+  subroutine halos_timed
     use modglobal, only: rk3step, timeleft, ntrun, timee, lfielddump, tnextfielddump
     use udc_iface
     logical :: due
@@ -65,7 +72,7 @@ contains
         if (mod(ntrun, udc_pull_every) == 0) call udc_pull_all
       end if
     end if
-  end subroutine halos
+  end subroutine halos_timed
 
   !> statsdump's sampling clock (src/modstatsdump.f90:738-741, 797-805, 1394-1397), kept in step here because the module keeps
   !! its own private: true on the steps on which the statsdump call that follows `halos` takes a sample.  Called once per RK

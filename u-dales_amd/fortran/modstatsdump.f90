@@ -307,6 +307,13 @@ contains
   !> the reference's two clocks (src/modstatsdump.f90:738-741, 797-811, 1393-1399, 1400, 1723-1729); a sample is one sweep on the
   !! device, a record is what crosses the bus
   subroutine statsdump
+    use udc_iface, only: udc_tic, udc_toc, UDC_T_STATS
+    call udc_tic(UDC_T_STATS)
+    call statsdump_timed
+    call udc_toc(UDC_T_STATS)
+  end subroutine statsdump
+
+  subroutine statsdump_timed
     use modglobal, only: rk3step, timee, dt, tsample, tstatsdump, tstatstart, lxytdump, lytdump, ltdump, lmintdump, lxydump, lydump
     use udc_iface, only: udc_h, udc_check, udc_begin
     if (.not. (active .or. slices)) return
@@ -340,7 +347,7 @@ contains
     else
       tstatsdumpp = tstatsdumpp + dt
     end if
-  end subroutine statsdump
+  end subroutine statsdump_timed
 
   !> um, vm, wm, thlm, qtm on the planes of the slice dumps (:1352-1389): only the planes come over (two where a velocity is
   !! brought to the cell centre across the plane); fields the deck does not carry are read from the host arrays, where they never change
@@ -514,6 +521,8 @@ contains
 
   !> (the reference's does nothing either: src/modstatsdump.f90:2148-2169)
   subroutine exitstatsdump
+    use udc_iface, only: udc_timers_report
+    call udc_timers_report      ! (UDC_TIMERS=1: the host-side phase clock of the run)
   end subroutine exitstatsdump
 
 end module modstatsdump

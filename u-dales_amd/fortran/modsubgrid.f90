@@ -81,6 +81,13 @@ contains
   end subroutine subgridnamelist
 
   subroutine subgrid
+    use udc_iface, only: udc_tic, udc_toc, UDC_T_RECORD
+    call udc_tic(UDC_T_RECORD)
+    call subgrid_timed
+    call udc_toc(UDC_T_RECORD)
+  end subroutine subgrid
+
+  subroutine subgrid_timed
     use modglobal, only: ib, jb, kb, ih, jh, kh, ltempeq, lmoist
     use udc_iface
     implicit none
@@ -93,7 +100,7 @@ contains
       call udc_pull3(UDC_EKH, ekh, (/ib - ih, jb - jh, kb - kh/))
     end if
     if (udc_mode() == 0) call udc_pull_vel(.true.)   ! top ghost rows re-imposed by closurebc
-  end subroutine subgrid
+  end subroutine subgrid_timed
 
   subroutine exitsubgrid
     implicit none

@@ -29,6 +29,13 @@ contains
   end subroutine initthermodynamics
 
   subroutine thermodynamics
+    use udc_iface, only: udc_tic, udc_toc, UDC_T_THERMO
+    call udc_tic(UDC_T_THERMO)
+    call thermodynamics_timed
+    call udc_toc(UDC_T_THERMO)
+  end subroutine thermodynamics
+
+  subroutine thermodynamics_timed
     use modglobal, only: kb, ke, kh, lmoist, ltempeq, lbuoyancy, rk3step, timee, tnextrestart, timeleft
     use modfields, only: presf, presh, exnf, exnh, thvh, thl0av, qt0av, ql0av
     use udc_iface
@@ -57,7 +64,7 @@ contains
     if (udc_mode() == 2 .and. rk3step == 3) then
       if (timee >= tnextrestart .or. timeleft <= 0) call udc_pull_all
     end if
-  end subroutine thermodynamics
+  end subroutine thermodynamics_timed
 
   !> thl0h, qt0h (src/modthermodynamics.f90:508-539) are read by `thermodynamics` alone, which computes them on the device
   subroutine calc_halflev

@@ -77,6 +77,13 @@ contains
   end subroutine register_scalar_sources
 
   subroutine tstep_integrate
+    use udc_iface, only: udc_tic, udc_toc, UDC_T_INTEGRATE
+    call udc_tic(UDC_T_INTEGRATE)
+    call tstep_integrate_timed
+    call udc_toc(UDC_T_INTEGRATE)
+  end subroutine tstep_integrate
+
+  subroutine tstep_integrate_timed
     use modglobal, only: rk3step, dt, timee, ifixuinf, lchem, ltempeq, lmoist, iinletgen, idriver, ib, ie, jb, je, kb, ke
     use modfields, only: up, vp, wp, svp, thlp, qtp, e12p, thl0, thl0c, dpdxl, dpdyl, dgdt
     use modsubgriddata, only: loneeqn
@@ -107,6 +114,6 @@ contains
     if (udc_mode() <= 1) then
       up = 0.; vp = 0.; wp = 0.; thlp = 0.; svp = 0.; e12p = 0.; qtp = 0.
     end if
-  end subroutine tstep_integrate
+  end subroutine tstep_integrate_timed
 
 end module modtstep

@@ -66,6 +66,16 @@ module udc_iface
   logical, save :: udc_stats_on_device = .false.      !< the drop-in modstatsdump is linked and has something to do: the reference's
                                                       !! statsdump is not there to read the host arrays
   integer, save :: udc_pull_every = 0         !< UDC_PULL_EVERY: refresh the host arrays every n-th time step in device mode
+  ! host-side phase clock (UDC_TIMERS=1): wall time the time loop spends in the transfers and in the drop-in routines, printed by
+  ! udc_timers_report (exitstatsdump calls it): what of the loop's time is the one-time upload / download, what the per-step
+  ! waits, what the host's own work
+  integer, parameter :: UDC_T_UPLOAD = 1, UDC_T_DOWNLOAD = 2, UDC_T_INTEGRATE = 3, UDC_T_CHECKSIM = 4, UDC_T_STATS = 5, UDC_T_RECORD = 6, &
+                        UDC_T_THERMO = 7, UDC_T_HALOS = 8, UDC_T_N = 8
+  character(10), parameter :: udc_t_name(UDC_T_N) = [character(10) :: 'upload', 'download', 'integrate', 'checksim', 'statsdump', &
+                                                     'record', 'thermo', 'halos']
+  logical, save :: udc_timers_on = .false.
+  real(8), save :: udc_t_sum(UDC_T_N) = 0.
+  integer(8), save :: udc_t_cnt(UDC_T_N) = 0, udc_t_start(UDC_T_N) = 0
 
   interface
     integer(c_int) function udc_create(cfg, h) bind(C, name='udc_create')
@@ -316,6 +326,16 @@ module udc_iface
       real(c_double), value :: dtmn
       real(c_double), intent(out) :: d(4)
     end function
+    integer(c_int) function udc_checksim_begin(h, dtmn) bind(C, name='udc_checksim_begin')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), value :: dtmn
+    end function udc_checksim_begin
+    integer(c_int) function udc_checksim_end(h, d) bind(C, name='udc_checksim_end')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double) :: d(4)
+    end function udc_checksim_end
     integer(c_int) function udc_comm_unique_id(id) bind(C, name='udc_comm_unique_id')
       import :: c_int, c_signed_char
       integer(c_signed_char), intent(out) :: id(128)
@@ -606,6 +626,8 @@ contains
     if (stat == 0) read (env, *, iostat=stat) udc_residency
     call get_environment_variable('UDC_PULL_EVERY', env, status=stat)
     if (stat == 0) read (env, *, iostat=stat) udc_pull_every
+    call get_environment_variable('UDC_TIMERS', env, status=stat)
+    if (stat == 0) udc_timers_on = (trim(env) /= '0')
     call udc_late_setup
     call udc_push_state
   end subroutine udc_ensure
@@ -673,6 +695,28 @@ contains
   end function udc_mode
 
   !> What a drop-in routine does before its device call ...
+  subroutine udc_tic(id)
+    integer, intent(in) :: id
+    if (udc_timers_on) call system_clock(udc_t_start(id))
+  end subroutine udc_tic
+  subroutine udc_toc(id)
+    integer, intent(in) :: id
+    integer(8) :: c, rate
+    if (.not. udc_timers_on) return
+    call system_clock(c, rate)
+    udc_t_sum(id) = udc_t_sum(id) + real(c - udc_t_start(id), 8)/real(rate, 8)
+    udc_t_cnt(id) = udc_t_cnt(id) + 1
+  end subroutine udc_toc
+  !> one line per phase: "UDC_TIMER <name> calls=<n> seconds=<s>"
+  subroutine udc_timers_report
+    use modmpi, only: myid
+    integer :: q
+    if (.not. udc_timers_on .or. myid /= 0) return
+    do q = 1, UDC_T_N
+      write (*, '(A,A10,A,I9,A,F12.6)') 'UDC_TIMER ', udc_t_name(q), ' calls=', udc_t_cnt(q), ' seconds=', udc_t_sum(q)
+    end do
+  end subroutine udc_timers_report
+
   subroutine udc_begin(tend)
     logical, intent(in) :: tend      !< the routine reads or edits the tendencies
     call udc_ensure
@@ -824,6 +868,7 @@ contains
     use modglobal, only: ib, jb, kb, ih, jh, kh, ihc, jhc, khc, nsv, ltempeq, lmoist, iadv_thl, iadv_kappa
     use modfields, only: u0, v0, w0, um, vm, wm, pres0, sv0, svm, thl0, thlm, e120, e12m, qt0, qtm, thl0c
     integer :: n
+    call udc_tic(UDC_T_UPLOAD)
     call udc_push3(UDC_U0, u0, (/ib - ih, jb - jh, kb - kh/))
     call udc_push3(UDC_V0, v0, (/ib - ih, jb - jh, kb - kh/))
     call udc_push3(UDC_W0, w0, (/ib - ih, jb - jh, kb - kh/))
@@ -850,20 +895,24 @@ contains
       call udc_push3(UDC_SV0 + 3*(n - 1), sv0(:, :, :, n), (/ib - ihc, jb - jhc, kb - khc/))
       call udc_push3(UDC_SVM + 3*(n - 1), svm(:, :, :, n), (/ib - ihc, jb - jhc, kb - khc/))
     end do
+    call udc_toc(UDC_T_UPLOAD)
   end subroutine udc_push_state
 
   !> the eddy diffusivities as the host has them (start-up values, or a restart file's ekm)
   subroutine udc_push_ek
     use modglobal, only: ib, jb, kb, ih, jh, kh
     use modsubgriddata, only: ekm, ekh
+    call udc_tic(UDC_T_UPLOAD)
     call udc_push3(UDC_EKM, ekm, (/ib - ih, jb - jh, kb - kh/))
     call udc_push3(UDC_EKH, ekh, (/ib - ih, jb - jh, kb - kh/))
+    call udc_toc(UDC_T_UPLOAD)
   end subroutine udc_push_ek
 
   subroutine udc_push_tend
     use modglobal, only: ib, jb, kb, ih, jh, ihc, jhc, nsv, ltempeq, lmoist
     use modfields, only: up, vp, wp, svp, thlp, e12p, qtp
     integer :: n
+    call udc_tic(UDC_T_UPLOAD)
     call udc_push3(UDC_UP, up, (/ib - ih, jb - jh, kb/))
     call udc_push3(UDC_VP, vp, (/ib - ih, jb - jh, kb/))
     call udc_push3(UDC_WP, wp, (/ib - ih, jb - jh, kb/))
@@ -873,6 +922,7 @@ contains
     do n = 1, nsv
       call udc_push3(UDC_SVP + 3*(n - 1), svp(:, :, :, n), (/ib - ihc, jb - jhc, kb/))
     end do
+    call udc_toc(UDC_T_UPLOAD)
   end subroutine udc_push_tend
 
   subroutine udc_pull_tend
@@ -931,6 +981,7 @@ contains
     use modfields, only: pres0
     use modsubgriddata, only: ekm, ekh
     if (.not. c_associated(udc_h)) return
+    call udc_tic(UDC_T_DOWNLOAD)
     udc_host_fresh = .true.
     call udc_pull_vel(.true.)
     call udc_pull_tend
@@ -938,6 +989,7 @@ contains
     call udc_pull3(UDC_EKM, ekm, (/ib - ih, jb - jh, kb - kh/))
     call udc_pull3(UDC_EKH, ekh, (/ib - ih, jb - jh, kb - kh/))
     call udc_pull_bottom_diag
+    call udc_toc(UDC_T_DOWNLOAD)
   end subroutine udc_pull_all
 
   !> tau_x, tau_y, tau_z, thl_flux (modfields; the fielddump variables `bottom` leaves behind, src/modibm.f90:2015-2018,
