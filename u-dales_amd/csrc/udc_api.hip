@@ -846,7 +846,9 @@ static int now_level_forcings(udc_handle *h, int when) {
 
 extern "C" int udc_set_masscorr(udc_handle *h, int luvolflowr, double uflowrate, int lvvolflowr, double vflowrate) {
   ENTRY_FLUSH(h);
-  h->luvolflowr = luvolflowr ? 1 : 0; h->uflowrate = uflowrate;
+  // (an outflow-rate correction set by udc_set_masscorr_outflow -- luvolflowr == 2 -- takes precedence and stays in force,
+  // src/modforces.f90:352,389, whatever order the two setters are called in)
+  if (h->luvolflowr != 2) { h->luvolflowr = luvolflowr ? 1 : 0; h->uflowrate = uflowrate; }
   h->lvvolflowr = lvvolflowr ? 1 : 0; h->vflowrate = vflowrate;
   return 0;
 }
@@ -1010,29 +1012,35 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   const double rk3coef = dt / (4. - (double)rk3step);
   h->bcx_rk3coef = rk3coef;
   if (k_scalar_bcx_uout(h)) return 1;      // BCxs = 2 without a prescribed volume flow: the outlet's speed from the state the substep starts from
-  const bool lds = !h->mom_simple;
-  const bool pup = lds && !h->no_pup;
+  // what runs, in which order, is decided in one place: plan_substep (udc_plan.h; DESIGN.md section 9 has the table, the CPU test
+  // tests/test_substep_plan.py enumerates it)
+  PlanIn pin{};
+  pin.mom_simple = h->mom_simple; pin.no_pup = h->no_pup; pin.no_fold = h->no_fold; pin.no_alias = h->no_alias;
+  pin.ek_always = h->ek_always; pin.halo_overlap = !h->no_halo_overlap; pin.mom_pipe = !h->no_mom_pipe; pin.div_in_fft = !h->no_div_in_fft;
+  pin.slab = h->slab; pin.comm_stream = h->comm_stream != nullptr; pin.sgs = h->p.sgs; pin.lbuoycorr = h->lbuoycorr;
+  pin.nslots = (int)h->slots.size(); pin.ibm_on = h->ibm_on; pin.stats_any = h->stats_on || h->xyt_on || h->yt_on;
+  pin.fft_fused = h->fft_fused; pin.own_fwd = h->own_fwd;
+  pin.between = h->coriolis_mode || !h->level_forcings.empty() || h->luvolflowr || h->lvvolflowr || h->ibm_on || h->shift_a != 0. ||
+                h->thlpcar || h->lbuoyancy;
+  pin.closure_tile_rows = closure_lds_tile_rows(h->g); pin.mom_tile_rows = momentum_lds_tile_rows(h->g); pin.int_tile_rows = tile_grid(h->g).gy;
+  pin.x_row_groups = (h->slab && h->fft_fused) ? fft_x_row_groups(h) : 0;
+  pin.levels_per_chunk = h->g.nz / (h->nch > 0 ? h->nch : 1);
+  pin.rk3step = rk3step; pin.um_alias = h->um_alias; pin.ibm_edits_now = (ops & (OP_IBMWALL | OP_IBMNORM)) != 0;
+  const Plan plan = plan_substep(pin);
+  const bool lds = plan.lds, pup = plan.pup, fold = plan.fold;
   const bool forces = (ops & OP_FORCES) != 0;
-  // single slab (whole y extent local): the ghost-row/plane updates of closurebc, bcpup, bcp, halos and
-  // boundary are written by the kernels that own the neighbouring cells -> 7 fewer launches per substep
-  const bool fold = lds && !h->slab && !h->no_fold;
-  // um aliasing: stage 3 leaves um,vm,wm unwritten (== u0,v0,w0); stage 1 reads u0 in their place and
-  // writes the new u0,v0,w0 into the stale um buffers, then swaps the buffer pointers.
-  const bool alias_ok = pup && !h->no_alias && !h->ibm_on;      // (ibmnorm edits um)
-  if (h->um_alias && !(alias_ok && rk3step == 1)) { if (um_materialise(h)) return 1; }
-  const bool rotate = h->um_alias;                    // only true here for an aliased stage 1
+  if (plan.materialise_um) { if (um_materialise(h)) return 1; }
+  const bool rotate = plan.rotate;
   h->halos_fresh = h->boundary_fresh = h->thermo_fresh = false;
   // closure + momentum.  (One sweep evaluating ekm in LDS was built and measured slower than the two kernels, DESIGN.md section 5:
   // not kept.)
   {
     // closure first: it only needs u0,v0,w0, and the momentum sweep below needs ekm
     h->ekh_stale = false;
-    if (fold && h->p.sgs != UDC_SGS_DNS && h->p.sgs != UDC_SGS_ONEEQN && !h->lbuoycorr) {
-      // ekh has readers only where a scalar is transported, or between time steps (maxima, statistics, restart files: RK stage 3)
-      const bool need_ekh = h->ek_always || rk3step == 3 || !h->slots.empty() || h->stats_on || h->xyt_on || h->yt_on;
-      if (k_closure_lds(h, true, need_ekh)) return 1;
-      h->ekh_stale = !need_ekh;
-    } else if (lds && (h->p.sgs == UDC_SGS_SMAGORINSKY || h->p.sgs == UDC_SGS_VREMAN) && !h->lbuoycorr && halo_overlap(h, closure_lds_tile_rows(h->g))) {
+    if (plan.closure == CLOSURE_FOLDED) {
+      if (k_closure_lds(h, true, plan.need_ekh)) return 1;
+      h->ekh_stale = !plan.need_ekh;
+    } else if (plan.closure == CLOSURE_OVERLAPPED) {
       // y-slabs: the tile rows next to the neighbouring ranks first; their ekm / ekh rows travel while the rows in between are swept
       const int fek[2] = {UDC_EKM, UDC_EKH};
       if (k_closure_lds(h, false, true, 1)) return 1;
@@ -1050,12 +1058,8 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
     // first over all levels (+ the floor on its rows): it holds the row of vp that the previous rank's divergence reads, which then
     // travels; the other rows follow level range by level range from inside k_poisson_solve_slab, each ahead of the x forward
     // transform of the same k-chunk -- so the forward all-to-all of chunk c runs under the sweep of the levels above it
-    const int gyM = momentum_lds_tile_rows(h->g);
     const bool floor_on = (ops & OP_BOTTOM) && h->p.lbottom;
-    const bool pipe = h->slab && lds && pup && !h->no_mom_pipe && h->fft_fused && !h->no_div_in_fft && halo_overlap(h, gyM) &&
-                      h->slots.empty() && h->p.sgs != UDC_SGS_ONEEQN && !h->coriolis_mode && h->level_forcings.empty() &&
-                      !h->luvolflowr && !h->lvvolflowr && !h->ibm_on && h->shift_a == 0. && !h->thlpcar && !h->lbuoyancy &&
-                      fft_x_row_groups(h) >= 2 && h->g.nz / h->nch >= 4;
+    const bool pipe = plan.mom_pipe;
     if (pipe) {
       const MomPart row0{0, 1, 0, 0, true};
       if (k_momentum_lds(h, true, true, forces, true, 1. / rk3coef, rotate, &row0)) return 1;
@@ -1102,18 +1106,17 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   // except for the immersed-boundary routines, which edit listed points only (a solid v point in the first row of the
   // domain has its periodic image in the ghost row)
   // slab path with the own line FFTs: fillps' divergence is evaluated inside the x forward transform (udc_fft.hip)
-  h->div_in_fft = pup && ((h->slab && h->fft_fused && !h->no_div_in_fft) || (!h->slab && h->own_fwd));
-  if (piped) {
-    // (vp's row is already travelling)
-  } else if (!fold || (h->ibm_on && (ops & (OP_IBMWALL | OP_IBMNORM)))) {
-    const int fvp[1] = {UDC_VP};
+  h->div_in_fft = plan.div_in_fft;
+  if (plan.vp_row == ROW_BESIDE) {
     // y-slabs with the divergence inside the x transform: the row travels while all but the last row group of the first k-chunk
     // are transformed (k_poisson_solve_slab joins)
-    if (h->div_in_fft && halo_overlap(h, 3) && fft_x_row_groups(h) >= 2) {
-      if (k_halo_y_begin(h, fvp, 1, 1)) return 1;
-      h->vp_halo_pending = true;
-    } else if (k_halo_y(h, fvp, 1, 1)) return 1;
-  }
+    const int fvp[1] = {UDC_VP};
+    if (k_halo_y_begin(h, fvp, 1, 1)) return 1;
+    h->vp_halo_pending = true;
+  } else if (plan.vp_row == ROW_INLINE) {
+    const int fvp[1] = {UDC_VP};
+    if (k_halo_y(h, fvp, 1, 1)) return 1;
+  }      // (ROW_PIPED: already travelling; ROW_FOLDED: written by the kernels above)
   if (!h->div_in_fft && k_divergence_rhs(h, rk3coef, pup)) return 1;
   if (k_poisson_solve(h)) return 1;
   h->div_in_fft = false;
@@ -1122,16 +1125,16 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   const int gyI = tile_grid(h->g).gy;
   // y-slabs: p's ghost row (the projection of the slab's first row reads it) travels while a first part of the interior rows is
   // integrated; those rows need neither it nor anything the edge launch writes
-  const bool ov_p = !fold && halo_overlap(h, gyI) && gyI >= 4;
-  if (!fold) {
+  const bool ov_p = plan.p_row == ROW_BESIDE;
+  if (plan.p_row != ROW_FOLDED) {
     const int fp[1] = {UDC_P};
     if (ov_p) { if (k_halo_y_begin(h, fp, 1, 1)) return 1; }
     else if (k_halo_y(h, fp, 1, 1)) return 1;
   }
-  const bool skip_um = alias_ok && rk3step == 3;
+  const bool skip_um = plan.skip_um;
   // y-slabs: the rows next to the neighbouring ranks first; the ghost rows of the new velocities and of pres0 travel while the rows
   // in between are integrated (the exchange names the arrays as they will be known after the pointer rotation below)
-  const bool ov_int = !fold && halo_overlap(h, gyI);
+  const bool ov_int = plan.integrate == INT_EDGES_FIRST;
   bool ov_scal = false;
   if (ov_int) {
     const int rb = ov_p ? 1 + std::max(1, (gyI - 2) / 4) : 1;      // interior tile rows [1, rb) first, [rb, gyI - 1) last

@@ -98,6 +98,8 @@ int k_halo_y(udc_handle *h, const int *fields, int nf, int width) {
   }
   FieldList fl;
   for (int q = 0; q < nf; ++q) fl.f[q] = h->fields[fields[q]];
+  // an exchange started beside the compute stream (k_halo_y_begin) uses the same pack buffers and events: it is joined first
+  if (h->halo_async_pending && k_halo_y_join(h)) return 1;
   if (!h->slab) {
     PROF(h, "halo_y");
     hipLaunchKernelGGL(halo_y_wrap_kernel, dim3((g.nx + 63) / 64, 2 * width * nf, g.pz), dim3(64), 0, h->stream,
@@ -152,11 +154,13 @@ int k_halo_y_begin(udc_handle *h, const int *fields, int nf, int width, double *
   hipLaunchKernelGGL(halo_unpack_kernel, dim3((g.nx + 63) / 64, width * nf, g.pz), dim3(64), 0, cs, g, fl, width, h->halo_buf[2], h->halo_buf[3]);
   HIP_OK(hipGetLastError());
   HIP_OK(hipEventRecord(h->ev_halo_done, cs));
+  h->halo_async_pending = true;      // (several begins in a row queue behind each other on the communication stream; one join covers them)
   return 0;
 }
 
 int k_halo_y_join(udc_handle *h) {
   HIP_OK(hipStreamWaitEvent(h->stream, h->ev_halo_done, 0));
+  h->halo_async_pending = false;
   return 0;
 }
 

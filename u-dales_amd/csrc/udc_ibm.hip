@@ -314,6 +314,8 @@ extern "C" int udc_ibm_commit(udc_handle *h) {
   for (int gq = 0; gq < 3; ++gq)
     if (!h->ibm[gq].given) { udc_set_error("udc_ibm_commit: the u, v and w point lists are needed (udc_set_ibm_points)"); return 1; }
   const bool have_c = h->ibm[3].given;
+  // tables built from the point lists are rebuilt on their next use: masscorr's outlet-area weights (luoutflowr) and level weights
+  if (h->outlet_w) { HIP_OK(hipStreamSynchronize(h->stream)); HIP_OK(hipFree(h->outlet_w)); h->outlet_w = nullptr; }
   if (!h->slots.empty() && !have_c) { udc_set_error("udc_ibm_commit: transported scalars need the c point lists"); return 1; }
   // thl (slot 15) and qt (13): ibmnorm / diffc_corr as for the scalars plus advecc2nd_corr; wall fluxes of heat and moisture:
   // wallfunheat (udc_ibm_wf.hip; udc_set_ibm_wallheat / udc_set_ibm_wallmoist), else adiabatic / impermeable walls.  The moist

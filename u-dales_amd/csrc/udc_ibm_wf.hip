@@ -296,6 +296,17 @@ extern "C" int udc_set_ibm_sections(udc_handle *h, int grid, int n, const int *c
       }
     if (is_mine) mine.push_back(s);
   }
+  {
+    // the reference's `p` counter and warning (src/modibm.f90:608-630).  Its bound is one row wider at the slab's upper end
+    // (zend + 1; the interpolation then reads row zend + 2): here a reconstruction cell must lie where the cell AND its +1
+    // neighbour are within the one ghost row the velocities exchange ("facet sections next to a slab boundary")
+    long nover = 0;
+    for (int s : mine) nover += fallback[s] ? 1 : 0;
+    if (nover > 0)
+      fprintf(stderr, " WARNING libudcore udc_set_ibm_sections: rank %d overrode %ld facet section(s) of grid %d to simple reconstruction "
+                      "because a reconstruction cell falls outside the rows this slab can read.\n", h->cfg.rank, nover, grid);
+    h->ibm_sec[grid].noverride = (int)nover;
+  }
   auto key = [&](int s) { return ((long)cell[3 * s + 2] * h->jtot + cell[3 * s + 1]) * g.nx + cell[3 * s]; };
   std::stable_sort(mine.begin(), mine.end(), [&](int x, int y) { return key(x) < key(y); });
   std::vector<int> cells, off, comp, rid;

@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 #include "../../include/udcore.h"
+#include "udc_plan.h"
 
 // ---------------------------------------------------------------------------------------
 // Device layout of every 3-D field (one geometry for all of them, so that one offset
@@ -295,6 +296,7 @@ struct udc_handle {
     double *area = nullptr, *dist = nullptr, *norm = nullptr, *z0 = nullptr, *z0h = nullptr, *tsurf = nullptr, *recpt = nullptr, *tmask = nullptr;
     std::vector<int> order;             // position in the caller's list of each kept section (later per-section tables follow it)
     int nglobal = 0;                    // sections the caller listed (all slabs)
+    int noverride = 0;                  // sections of this slab whose reconstruction cell is out of reach (simple reconstruction instead)
     int *lgr = nullptr;                 // c grid, latent wall flux (udc_set_ibm_wallmoist): vegetated facet; saturation humidity /
     double *qwall = nullptr, *hurel = nullptr, *resc = nullptr, *ress = nullptr;      // prescribed flux, humidity, resistances
   };
@@ -360,6 +362,7 @@ struct udc_handle {
   hipStream_t comm_stream = nullptr;    // all-to-all exchanges run here, overlapped with rocFFT on `stream`
   hipEvent_t ev_ready[16] = {}, ev_done[16] = {};
   hipEvent_t ev_halo_ready = nullptr, ev_halo_done = nullptr;      // k_halo_y_begin / _join
+  bool halo_async_pending = false;      // a k_halo_y_begin has not been joined yet (k_halo_y joins it before touching the shared buffers)
   // the momentum sweep pipelined with the slab solve (substep_fused, k_momentum_pipe_stage): tile row 0 is swept first over all
   // levels, the other rows level range by level range ahead of the x forward transform of the same k-chunk
   struct MomPipe { bool active = false, forces = false, um_is_u0 = false, bottom = false; double rk3coefi = 0.; } mom_pipe;

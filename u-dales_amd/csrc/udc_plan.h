@@ -1,0 +1,86 @@
+// The order of one fused RK3 substep as a pure function of what it depends on (no HIP, no handle): substep_fused (udc_api.hip)
+// asks plan_substep() and then only executes.  Host-only C++, also compiled by g++ into lib/libudcplan.so, which the CPU test
+// tests/test_substep_plan.py enumerates against the table of DESIGN.md section 9.
+#pragma once
+
+struct PlanIn {
+  // switches (Switches, udc_internal.h)
+  int mom_simple, no_pup, no_fold, no_alias, ek_always, halo_overlap, mom_pipe, div_in_fft;
+  // what the handle is
+  int slab;             // distributed layout in use (more than one rank, or UDC_FORCE_SLAB)
+  int comm_stream;      // the communication stream exists (slab layout set up)
+  int sgs;              // 0 DNS, 1 Smagorinsky, 2 Vreman, 3 one-equation
+  int lbuoycorr;
+  int nslots;           // transported scalars (thl, qt, tke, passive)
+  int ibm_on, stats_any;
+  int fft_fused;        // own line transforms on the slab path
+  int own_fwd;          // own forward half on the single-slab path
+  int between;          // something acts on the tendencies between the momentum sweep and the solve besides the floor: Coriolis,
+                        // level forcings, prescribed flow rates, immersed boundary, shifted boundaries, buoyancy / radiative source
+  int closure_tile_rows, mom_tile_rows, int_tile_rows;      // tile rows of the three sweeps on this slab
+  int x_row_groups;     // row groups of the x forward transform
+  int levels_per_chunk; // nz / k-chunks of the transposes
+  // this call
+  int rk3step;
+  int um_alias;         // um, vm, wm are logically u0, v0, w0 (the previous substep was an aliased stage 3)
+  int ibm_edits_now;    // this substep runs ibmwallfun / ibmnorm
+};
+
+enum PlanClosure { CLOSURE_FOLDED = 0, CLOSURE_OVERLAPPED = 1, CLOSURE_PLAIN = 2 };
+enum PlanRow { ROW_FOLDED = 0, ROW_BESIDE = 1, ROW_INLINE = 2, ROW_PIPED = 3 };
+enum PlanIntegrate { INT_ONE = 0, INT_EDGES_FIRST = 1 };
+
+struct Plan {
+  int lds, pup, fold, alias_ok;
+  int materialise_um;   // um is made a real copy again before anything else
+  int rotate;           // stage 1 after an aliased stage 3: reads u0 as um, writes into the stale um buffers, swaps the pointers
+  int skip_um;          // stage 3 leaves um unwritten (aliased from now on)
+  int closure;          // PlanClosure
+  int need_ekh;         // (CLOSURE_FOLDED) the closure writes ekh as well
+  int mom_pipe;         // momentum sweep cut along the solve's k-chunks, under the forward transposes
+  int div_in_fft;       // fillps' divergence inside the x forward transform
+  int vp_row;           // PlanRow: vp's ghost row
+  int p_row;            // PlanRow: p's ghost row (FOLDED / BESIDE the first interior rows / INLINE)
+  int integrate;        // PlanIntegrate
+};
+
+inline bool plan_halo_overlap(const PlanIn &in, int tile_rows) { return in.slab && in.comm_stream && in.halo_overlap && tile_rows >= 3; }
+
+inline Plan plan_substep(const PlanIn &in) {
+  Plan p{};
+  p.lds = !in.mom_simple;
+  p.pup = p.lds && !in.no_pup;
+  // single slab (whole y extent local): the ghost rows / planes of closurebc, bcpup, bcp, halos and boundary are written by the
+  // kernels that own the neighbouring cells
+  p.fold = p.lds && !in.slab && !in.no_fold;
+  // um aliasing: stage 3 leaves um unwritten (== u0); stage 1 reads u0 in its place (ibmnorm edits um: not with obstacles)
+  p.alias_ok = p.pup && !in.no_alias && !in.ibm_on;
+  p.materialise_um = in.um_alias && !(p.alias_ok && in.rk3step == 1);
+  p.rotate = in.um_alias && !p.materialise_um;
+  p.skip_um = p.alias_ok && in.rk3step == 3;
+  const bool smag_vreman = in.sgs == 1 || in.sgs == 2;
+  if (p.fold && smag_vreman && !in.lbuoycorr) {
+    p.closure = CLOSURE_FOLDED;
+    // ekh has readers only where a scalar is transported, or between time steps (maxima, statistics, restart files: RK stage 3)
+    p.need_ekh = in.ek_always || in.rk3step == 3 || in.nslots > 0 || in.stats_any;
+  } else if (p.lds && smag_vreman && !in.lbuoycorr && plan_halo_overlap(in, in.closure_tile_rows)) {
+    p.closure = CLOSURE_OVERLAPPED;
+    p.need_ekh = 1;
+  } else {
+    p.closure = CLOSURE_PLAIN;
+    p.need_ekh = 1;
+  }
+  p.mom_pipe = in.slab && p.lds && p.pup && in.mom_pipe && in.fft_fused && in.div_in_fft && plan_halo_overlap(in, in.mom_tile_rows) &&
+               in.nslots == 0 && in.sgs != 3 && !in.between && in.x_row_groups >= 2 && in.levels_per_chunk >= 4;
+  p.div_in_fft = p.pup && ((in.slab && in.fft_fused && in.div_in_fft) || (!in.slab && in.own_fwd));
+  if (p.mom_pipe) p.vp_row = ROW_PIPED;
+  else if (!p.fold || (in.ibm_on && in.ibm_edits_now))
+    p.vp_row = (p.div_in_fft && plan_halo_overlap(in, 3) && in.x_row_groups >= 2) ? ROW_BESIDE : ROW_INLINE;
+  else p.vp_row = ROW_FOLDED;
+  if (p.fold) { p.p_row = ROW_FOLDED; p.integrate = INT_ONE; }
+  else {
+    p.p_row = (plan_halo_overlap(in, in.int_tile_rows) && in.int_tile_rows >= 4) ? ROW_BESIDE : ROW_INLINE;
+    p.integrate = plan_halo_overlap(in, in.int_tile_rows) ? INT_EDGES_FIRST : INT_ONE;
+  }
+  return p;
+}

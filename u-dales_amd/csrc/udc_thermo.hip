@@ -283,11 +283,13 @@ __global__ __launch_bounds__(256) void diagfld_kernel(DiagArgs a, double *mt, co
   const double *presf = mt + udc_handle::MT_PRESF * n2, *presh = mt + udc_handle::MT_PRESH * n2;
   for (int k = 1 + threadIdx.x; k <= ke1; k += blockDim.x) {
     const double cnt = cntc ? cntc[k] : a.cnt;
-    thl0av[k] = sums[k - 1] / cnt;
-    qt0av[k] = sums[ke1 + k - 1] / cnt;
+    // avexy_ibm's rule for a level without fluid cells: -999 (src/modmpi.f90, as divide_kernel and ibm_thl_val_kernel have it)
+    const bool none = cntc && !(cnt > 0.);
+    thl0av[k] = none ? -999. : sums[k - 1] / cnt;
+    qt0av[k] = none ? -999. : sums[ke1 + k - 1] / cnt;
     // the reference's ql0 holds level k+1 at k and nothing at ke+kh (sequence association in `thermo`, see
     // oracle/udcore_oracle.c orc_thermodynamics): its slab average is one level low
-    ql0av[k] = (with_ql && k <= a.nz) ? sums[2 * ke1 + k] / cnt : 0.;
+    ql0av[k] = (with_ql && k <= a.nz) ? (none ? -999. : sums[2 * ke1 + k] / cnt) : 0.;
     exnf[k] = 1 - a.grav * zf[k] / (TH_CP * a.thls);
     exnh[k] = 1 - a.grav * zh[k] / (TH_CP * a.thls);
     th0av[k] = thl0av[k] + (TH_RLV / TH_CP) * ql0av[k] / exnf[k];
