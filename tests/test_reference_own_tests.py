@@ -56,7 +56,8 @@ def stage(tmp, deck, nprocy=1, steps=None):
     if steps is not None:      # a longer variant of the one-step deck: `steps` steps of dtmax, one tdump record at the end
         dtmax = float(re.search(r"dtmax\s*=\s*([0-9.eE+-]+)", txt).group(1))
         txt = re.sub(r"runtime\s*=\s*[0-9.eE+-]+", f"runtime      = {dtmax * (steps - 0.5)!r}", txt)
-        txt = re.sub(r"tstatsdump\s*=\s*[0-9.eE+-]+", f"tstatsdump   = {dtmax * steps!r}", txt)
+        # (half a step early: the dump clock is a running sum of dt, which may fall a rounding short of the product dtmax * steps)
+        txt = re.sub(r"tstatsdump\s*=\s*[0-9.eE+-]+", f"tstatsdump   = {dtmax * (steps - 0.5)!r}", txt)
         txt = re.sub(r"tsample\s*=\s*[0-9.eE+-]+", f"tsample      = {dtmax!r}", txt)
     with open(os.path.join(tmp, "namoptions.100"), "w") as f:
         f.write(txt)
