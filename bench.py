@@ -249,7 +249,7 @@ def _run_ref(cmd, cwd, env=None, raw=False):
     return float(m.group(1)) if m else None
 
 
-def dropin_leg(nx, ny, nz, nsv, sgs, floor, value, nsub=150, nwarm=15):
+def dropin_leg(nx, ny, nz, nsv, sgs, floor, value, nsub=450, nwarm=30):
     """The same workload through the drop-in boundary: the reference-shaped Fortran driver (call order of
     src/program.f90:132-222) linked with the drop-in modules of u-dales_amd/fortran/ over the C ABI, device resident
     (UDC_RESIDENCY=2).  Wall clock around the Fortran time loop (MPI_Wtime + a final device synchronisation)."""
