@@ -44,6 +44,20 @@ def test_launch_without_gpu_stops_on_every_rank():
     assert r.stderr.count("bench.py needs an MI355X") >= 1, r.stderr[-2000:]
 
 
+def test_ladder_without_gpu_walks_every_rung_and_gives_up():
+    """No GPU: every attempt dies at once (bench.py's own message), the supervisors agree on that rung by rung, walk the whole ladder and
+    leave with code 5 and no JSON line -- no hang, no rank left behind."""
+    if have_gpu():
+        pytest.skip("this box has a GPU")
+    r = launch(2, ["--stall-timeout", "60"], 600)
+    assert r.returncode != 0
+    assert '"metric"' not in r.stdout
+    for rung in range(5):
+        assert f"rung {rung} (" in r.stderr, r.stderr[-3000:]
+    assert "no rung of the ladder ran to its end" in r.stderr
+    assert r.stderr.count("bench.py needs an MI355X") >= 5
+
+
 @pytest.mark.gpu
 def test_two_ranks_need_two_gpus():
     import torch
