@@ -375,7 +375,7 @@ static int launch_thomas(udc_handle *h, bool blocked, long nmodes, int nz, doubl
     // eight levels per thread; workgroups of 8 x ceil(nz / 8) threads.  Measured (profiles/r04/thomas_variants_ab.txt, thomas_pair_ab.txt):
     // 16 levels per thread spill, 4 leave too little in flight per thread; compiled for 3 waves per SIMD (2 with two systems per thread)
     const int nt = 8 * ((nz + 7) / 8);
-    const bool pair = pair_ny > 0 && h->sw.thomas_pair;
+    const bool pair = pair_ny > 0 && h->sw.thomas_pair && nt <= 512;      // (two systems per thread do not fit 1024-thread workgroups' 128 VGPRs)
 #define UDC_TR(Wv, NPv)                                                                                      \
     do {                                                                                                     \
       if (nt <= 64) launch_thomas_reg<64, Wv, NPv>(h, nmodes, nz, scale, ev, ztab, x, nkb, pair_ny);         \
