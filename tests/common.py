@@ -100,6 +100,9 @@ REFDIR = os.path.join(os.path.dirname(HERE), "oracle", "_ref")
 MPIEXEC = "/opt/conda/bin/mpiexec"
 
 
+_SHM_SERIAL = [0]
+
+
 def gpu_count():
     try:
         import torch
@@ -120,5 +123,7 @@ def mpi_transport(nranks, tag):
         env.pop("UDC_GPUS_PER_NODE", None)
         env.pop("UDC_TEST_SHM", None)
         return os.path.join(REFDIR, "udales_full_dropin_mpi"), env, "rccl"
-    env.update(UDC_GPUS_PER_NODE="1", UDC_TEST_SHM=f"/udc_{tag}_{os.getpid()}_{nranks}")
+    # (a name per launch: a run that died before its ranks had all attached leaves its segment behind under its name)
+    _SHM_SERIAL[0] += 1
+    env.update(UDC_GPUS_PER_NODE="1", UDC_TEST_SHM=f"/udc_{tag}_{os.getpid()}_{nranks}_{_SHM_SERIAL[0]}")
     return os.path.join(REFDIR, "udales_full_dropin_mpi_test"), env, "shm"
