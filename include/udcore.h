@@ -9,6 +9,9 @@
  * Conventions
  *   - every function returns 0 on success, non-zero on failure; the message is
  *     available from udc_last_error().  Nothing here calls exit().
+ *   - Environment: the library reads its UDC_* switches exactly once, inside udc_create (A/B switches of the substep order, tuning
+ *     knobs; DESIGN.md section 9 lists them); no other entry point looks at the environment, and none changes results beyond
+ *     round-off.
  *   - plain pointers and sizes only; host arrays are owned by the caller (Fortran's
  *     modfields), device arrays by the library; no host pointer is retained.
  *   - host 3-D arrays are Fortran-ordered (i fastest) real(8) with inclusive index

@@ -134,7 +134,7 @@ static int env_int(const char *name, int dflt) {
   const char *e = getenv(name);
   return (e && *e) ? atoi(e) : dflt;
 }
-// The one place the library reads its environment (include/udcore.h, "environment").
+// The one place the library reads its environment (include/udcore.h, "Environment").
 void udc_read_switches(Switches &sw) {
   sw.force_slab = env_int("UDC_FORCE_SLAB", 0) != 0;
   sw.force_comm = env_int("UDC_FORCE_COMM", 0) != 0;
