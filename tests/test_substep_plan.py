@@ -56,7 +56,7 @@ def table(i):
     c_folded = fold & sv & ~b(i["lbuoycorr"])
     c_over = ~c_folded & lds & sv & ~b(i["lbuoycorr"]) & beside(i["closure_tile_rows"])
     closure = np.where(c_folded, FOLDED, np.where(c_over, OVERLAPPED, PLAIN))
-    need_ekh = np.where(c_folded, b(i["ek_always"]) | (i["rk3step"] == 3) | (i["nslots"] > 0) | b(i["stats_any"]), True)
+    need_ekh = np.where(c_folded | c_over, b(i["ek_always"]) | (i["rk3step"] == 3) | (i["nslots"] > 0) | b(i["stats_any"]), True)
     pipe = (b(i["slab"]) & lds & pup & b(i["mom_pipe"]) & b(i["fft_fused"]) & b(i["div_in_fft"]) & beside(i["mom_tile_rows"])
             & (i["nslots"] == 0) & (i["sgs"] != 3) & ~b(i["between"]) & (i["x_row_groups"] >= 2) & (i["levels_per_chunk"] >= 4))
     div = pup & ((b(i["slab"]) & b(i["fft_fused"]) & b(i["div_in_fft"])) | (~b(i["slab"]) & b(i["own_fwd"])))

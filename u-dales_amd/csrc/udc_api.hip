@@ -1042,12 +1042,14 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
       h->ekh_stale = !plan.need_ekh;
     } else if (plan.closure == CLOSURE_OVERLAPPED) {
       // y-slabs: the tile rows next to the neighbouring ranks first; their ekm / ekh rows travel while the rows in between are swept
+      // (ekh -- its array and its ghost row -- only where something reads it: a transported scalar, or between time steps)
       const int fek[2] = {UDC_EKM, UDC_EKH};
-      if (k_closure_lds(h, false, true, 1)) return 1;
-      if (k_halo_y_begin(h, fek, 2, 1)) return 1;
-      if (k_closure_lds(h, false, true, 2)) return 1;
+      if (k_closure_lds(h, false, plan.need_ekh, 1)) return 1;
+      if (k_halo_y_begin(h, fek, plan.need_ekh ? 2 : 1, 1)) return 1;
+      if (k_closure_lds(h, false, plan.need_ekh, 2)) return 1;
       if (k_halo_y_join(h)) return 1;
       if (k_ek_ghosts(h, false)) return 1;
+      h->ekh_stale = !plan.need_ekh;
     } else {
       if (k_closure(h)) return 1;
       if (h->lbuoycorr && k_vreman_buoycorr(h)) return 1;      // before closurebc, as in the reference

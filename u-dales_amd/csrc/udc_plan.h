@@ -36,7 +36,7 @@ struct Plan {
   int rotate;           // stage 1 after an aliased stage 3: reads u0 as um, writes into the stale um buffers, swaps the pointers
   int skip_um;          // stage 3 leaves um unwritten (aliased from now on)
   int closure;          // PlanClosure
-  int need_ekh;         // (CLOSURE_FOLDED) the closure writes ekh as well
+  int need_ekh;         // the closure writes (and, on y-slabs, exchanges) ekh as well: always with the plain kernel
   int mom_pipe;         // momentum sweep cut along the solve's k-chunks, under the forward transposes
   int div_in_fft;       // fillps' divergence inside the x forward transform
   int vp_row;           // PlanRow: vp's ghost row
@@ -65,7 +65,7 @@ inline Plan plan_substep(const PlanIn &in) {
     p.need_ekh = in.ek_always || in.rk3step == 3 || in.nslots > 0 || in.stats_any;
   } else if (p.lds && smag_vreman && !in.lbuoycorr && plan_halo_overlap(in, in.closure_tile_rows)) {
     p.closure = CLOSURE_OVERLAPPED;
-    p.need_ekh = 1;
+    p.need_ekh = in.ek_always || in.rk3step == 3 || in.nslots > 0 || in.stats_any;      // (as folded: one array and one ghost row less)
   } else {
     p.closure = CLOSURE_PLAIN;
     p.need_ekh = 1;
