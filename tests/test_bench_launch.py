@@ -131,6 +131,17 @@ def test_bench_line_of_a_multi_rank_run(n):
 
 
 @pytest.mark.gpu
+def test_bench_line_of_a_multi_rank_run_with_a_kappa_scalar():
+    """BASELINE configs[2]'s physics (Smagorinsky + a kappa scalar) on two ranks: the scalar's two ghost rows and ekh's travel too."""
+    extra, env, how = transport_args(2, "benchsv")
+    r = launch(2, extra + ["--nsv", "1", "--sgs", "smag"], 1500, env, size="64x32x32" if how == "shm" else "256x256x256", single=True)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    d = bench_line(r)
+    assert d["divmax_after_run"] < 1e-10 and d["decomposition_invariance"]["ok"], d["decomposition_invariance"]
+    assert any(k.startswith("scalar") for k in d["kernels"]) and d["ladder"]["rung"] == 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["hang", "exit"])
 def test_fallback_ladder_of_a_multi_rank_run(mode):
     """A first attempt that hangs (one rank stops answering in the warm-up: the others sit in a collective) or dies must not take the
