@@ -22,7 +22,19 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_forced_slab_path_matches_reference():
+@pytest.mark.parametrize("switches", [
+    {"UDC_FORCE_SLAB": "1"},                                # one rank through the slab layout: own line transforms, exchanges onto itself
+    {"UDC_FORCE_SLAB": "1", "UDC_FFT_FUSED": "0"},          # ... with rocFFT + transpose kernels (rung 3 of bench.py's ladder)
+    {"UDC_FORCE_SLAB": "1", "UDC_DIV_IN_FFT": "0"},         # ... with the separate divergence kernel
+    {"UDC_FORCE_SLAB": "1", "UDC_HALO_OVERLAP": "0", "UDC_MOM_PIPE": "0", "UDC_A2A_CHUNKS": "1"},      # rungs 1 and 2 of the ladder
+    {"UDC_NO_FOLD": "1"},                                   # single slab: separate ghost-row kernels
+    {"UDC_NO_ALIAS": "1"},                                  # ... um always a real copy
+    {"UDC_SCALAR_PAIR": "0"},                               # ... thl and qt swept one by one
+    {"UDC_THOMAS": "0"},                                    # ... the streaming tridiagonal kernel
+], ids=lambda d: " ".join(f"{k[4:]}={v}" for k, v in d.items()))
+def test_every_switch_setting_matches_reference(switches):
+    """Every run fixture (the reference's real program's restart files) through the fused substep under each of the library's order /
+    variant switches: none may change a result beyond round-off."""
     code = r'''
 import sys, numpy as np
 sys.path[:0] = ["%s/tests", "%s/u-dales_amd"]
@@ -51,7 +63,7 @@ for name, iexp in RUN_CASES.items():
     core.close()
 print("SLAB_OK")
 ''' % (ROOT, ROOT)
-    env = dict(os.environ, UDC_FORCE_SLAB="1")
+    env = dict(os.environ, **switches)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert "SLAB_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 

@@ -145,10 +145,8 @@ void udc_read_switches(Switches &sw) {
   sw.fft_fused = env_int("UDC_FFT_FUSED", 1) != 0;
   sw.own_fwd = env_int("UDC_OWN_FWD", -1);
   sw.div_in_fft = env_int("UDC_DIV_IN_FFT", 1) != 0;
-  sw.no_pup = env_int("UDC_NO_PUP", 0) != 0;
   sw.no_fold = env_int("UDC_NO_FOLD", 0) != 0;
   sw.no_alias = env_int("UDC_NO_ALIAS", 0) != 0;
-  sw.mom_simple = env_int("UDC_MOM_SIMPLE", 0) != 0;
   sw.ek_always = env_int("UDC_EK_ALWAYS", 0) != 0;
   sw.scalar_pair = env_int("UDC_SCALAR_PAIR", 1) != 0;
   sw.thomas = env_int("UDC_THOMAS", -1);
@@ -196,8 +194,6 @@ extern "C" int udc_create(const udc_config *cfg, udc_handle **out) {
   Geo &g = h->g;
   g.nx = cfg->itot; g.ny = cfg->jtot / cfg->nranks; g.nz = cfg->ktot;
   h->jtot = cfg->jtot;
-  h->mom_simple = h->sw.mom_simple;
-  h->no_pup = h->sw.no_pup;
   h->no_fold = h->sw.no_fold;
   h->no_alias = h->sw.no_alias;
   h->ek_always = h->sw.ek_always;
@@ -492,7 +488,7 @@ static int vel_fields(udc_handle *h, int rk3step, int *f) {
 
 static int now_advection(udc_handle *h) {
   if (tend_clean(h) || um_materialise(h)) return 1;
-  if ((h->mom_simple ? k_momentum(h, true, false, false) : k_momentum_lds(h, true, false, false, false, 0.))) return 1;
+  if (k_momentum_lds(h, true, false, false, false, 0.)) return 1;
   for (int n : h->slots)
     if (k_scalar_adv(h, n)) return 1;
   return 0;
@@ -505,7 +501,7 @@ static int now_subgrid(udc_handle *h) {
   if (k_ek_ghosts(h)) return 1;
   h->ek_stale = h->ekh_stale = false;
   if (k_top_rows_after_closure(h)) return 1;
-  if ((h->mom_simple ? k_momentum(h, false, true, false) : k_momentum_lds(h, false, true, false, false, 0.))) return 1;
+  if (k_momentum_lds(h, false, true, false, false, 0.)) return 1;
   if (k_scalar_top_flux(h)) return 1;      // reassure_fluxtop_boundary for a non-zero thl top flux (uses the new ekh)
   for (int n : h->slots)
     if (k_scalar_diff(h, n)) return 1;
@@ -1015,7 +1011,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   // what runs, in which order, is decided in one place: plan_substep (udc_plan.h; DESIGN.md section 9 has the table, the CPU test
   // tests/test_substep_plan.py enumerates it)
   PlanIn pin{};
-  pin.mom_simple = h->mom_simple; pin.no_pup = h->no_pup; pin.no_fold = h->no_fold; pin.no_alias = h->no_alias;
+  pin.no_fold = h->no_fold; pin.no_alias = h->no_alias;
   pin.ek_always = h->ek_always; pin.halo_overlap = !h->no_halo_overlap; pin.mom_pipe = !h->no_mom_pipe; pin.div_in_fft = !h->no_div_in_fft;
   pin.slab = h->slab; pin.comm_stream = h->comm_stream != nullptr; pin.sgs = h->p.sgs; pin.lbuoycorr = h->lbuoycorr;
   pin.nslots = (int)h->slots.size(); pin.ibm_on = h->ibm_on; pin.stats_any = h->stats_on || h->xyt_on || h->yt_on;
@@ -1027,7 +1023,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   pin.levels_per_chunk = h->g.nz / (h->nch > 0 ? h->nch : 1);
   pin.rk3step = rk3step; pin.um_alias = h->um_alias; pin.ibm_edits_now = (ops & (OP_IBMWALL | OP_IBMNORM)) != 0;
   const Plan plan = plan_substep(pin);
-  const bool lds = plan.lds, pup = plan.pup, fold = plan.fold;
+  const bool lds = true, pup = true, fold = plan.fold;      // (LDS-staged sweeps, tendencies as predicted velocity: always)
   const bool forces = (ops & OP_FORCES) != 0;
   if (plan.materialise_um) { if (um_materialise(h)) return 1; }
   const bool rotate = plan.rotate;
@@ -1071,8 +1067,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
       h->vp_halo_pending = true;
       h->mom_pipe.active = true; h->mom_pipe.forces = forces; h->mom_pipe.um_is_u0 = rotate; h->mom_pipe.bottom = floor_on;
       h->mom_pipe.rk3coefi = 1. / rk3coef;
-    } else if (lds ? k_momentum_lds(h, true, true, forces, true, pup ? 1. / rk3coef : 0., rotate)
-                   : k_momentum(h, true, true, forces)) return 1;
+    } else if (k_momentum_lds(h, true, true, forces, true, 1. / rk3coef, rotate)) return 1;
   }
   const bool piped = h->mom_pipe.active;      // (then nothing below up to the solve has anything to do: see `pipe`)
   if (k_scalar_top_flux(h)) return 1;

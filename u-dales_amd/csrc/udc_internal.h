@@ -148,8 +148,7 @@ struct Switches {
   int fft_fused = 1;         // UDC_FFT_FUSED=0: rocFFT + transpose kernels on the slab path
   int own_fwd = -1;          // UDC_OWN_FWD=0/1: single-slab forward half in own kernels
   int div_in_fft = 1;        // UDC_DIV_IN_FFT=0: separate divergence kernel on the slab path
-  int no_pup = 0, no_fold = 0, no_alias = 0;      // UDC_NO_PUP / UDC_NO_FOLD / UDC_NO_ALIAS = 1
-  int mom_simple = 0;        // UDC_MOM_SIMPLE=1: direct-load kernels (no LDS staging), the small-grid fallback everywhere
+  int no_fold = 0, no_alias = 0;      // UDC_NO_FOLD / UDC_NO_ALIAS = 1
   int ek_always = 0;         // UDC_EK_ALWAYS=1: every substep writes ekm / ekh
   int scalar_pair = 1;       // UDC_SCALAR_PAIR=0: thl and qt swept one by one
   // tridiagonal solve
@@ -267,8 +266,6 @@ struct udc_handle {
   bool no_alias = false;                // UDC_NO_ALIAS=1: always copy (A/B switch)
   bool tend_scratch = false;            // up,vp,wp hold leftovers of a fused substep (logically zero)
   bool no_fold = false;                 // UDC_NO_FOLD=1: keep separate ghost-row kernels on a single slab (A/B switch)
-  bool no_pup = false;                  // UDC_NO_PUP=1: keep bare tendencies in the fused substep (A/B switch)
-  bool mom_simple = false;              // UDC_MOM_SIMPLE=1: use the direct-load momentum kernel
   bool ekh_stale = false;               // the last closure wrote ekm only (no reader of ekh in that substep)
   bool ek_stale = false;                // the last fused substep kept ekm / ekh in LDS only: the arrays hold an older substep's values
   bool ek_always = false;               // UDC_EK_ALWAYS=1: every substep writes ekm / ekh
@@ -421,7 +418,6 @@ int k_closure(udc_handle *h);
 int k_closure_lds(udc_handle *h, bool ghosts, bool write_ekh = true, int rows = 0);   // ghosts: closurebc folded in (single slab); write_ekh false: ekm only
 int k_ek_ghosts(udc_handle *h, bool exchange = true);
 int closure_lds_tile_rows(const Geo &g);      // tile rows of k_closure_lds over the slab
-int k_momentum(udc_handle *h, bool adv, bool diff, bool forces);       // direct-load version (UDC_MOM_SIMPLE=1)
 struct MomPart { int r0, r1, kbeg, kend; bool more; };      // a piece of the momentum sweep: tile rows [r0, r1), levels [kbeg, kend)
 int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, double rk3coefi, bool um_is_u0 = false, const MomPart *part = nullptr);
 int momentum_lds_tile_rows(const Geo &g);

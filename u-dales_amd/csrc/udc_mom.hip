@@ -19,78 +19,8 @@ struct MomArgs {
 __device__ __forceinline__ int wrapm(int i, int nx) { return i == 0 ? nx - 1 : i - 1; }
 __device__ __forceinline__ int wrapp(int i, int nx) { return i == nx - 1 ? 0 : i + 1; }
 
-// ---------------------------------------------------------------------------- momentum
-// One thread per cell, x fastest (coalesced 512-B wave rows); neighbours in y and z come
-// from L1/L2.  ADV: advecu/v/w_2nd incl. -grad(pres0).  DIFF: diffu/v/w (LES or DNS form).
-// FORCES: modforces.f90:84-127 neutral branch.  Order of accumulation into the tendency is
-// the reference's: xy advection, z advection, diffusion, forcing.
-template <bool ADV, bool DIFF, bool LES, bool FORCES>
-__global__ __launch_bounds__(256) void mom_kernel(Geo g, TileGrid tg, Metrics m, MomArgs a, double numol) {
-  int i, j, k;
-  const bool inside_ = tile_decode(g, tg, i, j, k);
-  if (!inside_) return;
-  const int im = wrapm(i, g.nx), ip = wrapp(i, g.nx);
-  const long r0 = g.idx(0, j, k);
-  const long sy = g.sy, sz = g.sz;
-  const long c = r0 + i, xm = r0 + im, xp = r0 + ip;
-  const double *__restrict__ u = a.u;
-  const double *__restrict__ v = a.v;
-  const double *__restrict__ w = a.w;
-  MomVals q;
-  q.u_c = u[c]; q.u_xm = u[xm]; q.u_xp = u[xp]; q.u_ym = u[c - sy]; q.u_yp = u[c + sy];
-  q.u_zm = u[c - sz]; q.u_zp = u[c + sz]; q.u_xp_ym = u[xp - sy]; q.u_xp_zm = u[xp - sz];
-  q.v_c = v[c]; q.v_xm = v[xm]; q.v_xp = v[xp]; q.v_ym = v[c - sy]; q.v_yp = v[c + sy];
-  q.v_zm = v[c - sz]; q.v_zp = v[c + sz]; q.v_xm_yp = v[xm + sy]; q.v_yp_zm = v[c + sy - sz];
-  q.w_c = w[c]; q.w_xm = w[xm]; q.w_xp = w[xp]; q.w_ym = w[c - sy]; q.w_yp = w[c + sy];
-  q.w_zm = w[c - sz]; q.w_zp = w[c + sz]; q.w_xm_zp = w[xm + sz]; q.w_ym_zp = w[c - sy + sz];
-  if (ADV) {
-    const double *__restrict__ p = a.p;
-    q.p_c = p[c]; q.p_xm = p[xm]; q.p_ym = p[c - sy]; q.p_zm = p[c - sz];
-  }
-  if (DIFF && LES) {
-    const double *__restrict__ e = a.ek;
-    q.e_c = e[c]; q.e_xm = e[xm]; q.e_xp = e[xp]; q.e_ym = e[c - sy]; q.e_yp = e[c + sy];
-    q.e_zm = e[c - sz]; q.e_zp = e[c + sz];
-    q.e_xm_yp = e[xm + sy]; q.e_xm_ym = e[xm - sy]; q.e_xm_zm = e[xm - sz]; q.e_xm_zp = e[xm + sz];
-    q.e_ym_zm = e[c - sy - sz]; q.e_ym_zp = e[c - sy + sz]; q.e_xp_ym = e[xp - sy];
-    q.e_yp_zm = e[c + sy - sz]; q.e_xp_zm = e[xp - sz];
-  }
-  double tu = a.up[c], tv = a.vp[c], tw = a.wp[c];
-  mom_arith<ADV, DIFF, LES, FORCES>(q, m, levmet_global(m, k + 1), k, numol, tu, tv, tw);
-  a.up[c] = tu;
-  a.vp[c] = tv;
-  a.wp[c] = tw;   // unchanged at k = 0 unless FORCES (the reference's w loops start at kb+1)
-}
-
-// ---------------------------------------------------------------------------- closure
-// SGS: 1 = Smagorinsky (src/modsubgrid.f90:208-264), 2 = Vreman (:269-360).  The molecular
-// part is added in the same statement order as the reference (ekh from ekm first, then +nu).
-struct GlobalAcc {   // neighbour access straight from global memory (x periodic by index wrap)
-  const double *pu, *pv, *pw;
-  long c, xm, xp, sy, sz;
-  __device__ __forceinline__ long off(int di, int dj, int dk) const {
-    return (di == 0 ? c : (di < 0 ? xm : xp)) + dj * sy + dk * sz;
-  }
-  __device__ __forceinline__ double u(int di, int dj, int dk) const { return pu[off(di, dj, dk)]; }
-  __device__ __forceinline__ double v(int di, int dj, int dk) const { return pv[off(di, dj, dk)]; }
-  __device__ __forceinline__ double w(int di, int dj, int dk) const { return pw[off(di, dj, dk)]; }
-};
-
-template <int SGS>
-__global__ __launch_bounds__(256) void closure_kernel(Geo g, TileGrid tg, Metrics m, Params pr, const double *__restrict__ u,
-                                                       const double *__restrict__ v, const double *__restrict__ w,
-                                                       double *__restrict__ ekm, double *__restrict__ ekh) {
-  int i, j, k;
-  const bool inside_ = tile_decode(g, tg, i, j, k);
-  if (!inside_) return;
-  const long r0 = g.idx(0, j, k);
-  GlobalAcc A{u, v, w, r0 + i, r0 + wrapm(i, g.nx), r0 + wrapp(i, g.nx), g.sy, g.sz};
-  double em, eh;
-  closure_arith<SGS>(A, m, ClosMetGlobal{m, k + 1}, pr, k, em, eh);
-  ekm[A.c] = em;
-  ekh[A.c] = eh;
-}
-
+// (The direct-load momentum and closure kernels of round 1 -- one thread per cell, neighbours from L1 / L2 -- were A/B switches
+// until round 4 (UDC_MOM_SIMPLE); the LDS-staged sweeps of udc_mom_lds.hip run on every grid size, and the switch is gone.)
 __global__ void fill_const_kernel(Geo g, double *__restrict__ a, double val, double *__restrict__ b, double valb) {
   const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (q < g.n) { a[q] = val; b[q] = valb; }
@@ -364,31 +294,6 @@ int k_shifted_pbcs(udc_handle *h, bool wrap_vp) {
   return 0;
 }
 
-int k_momentum(udc_handle *h, bool adv, bool diff, bool forces) {
-  const Geo &g = h->g;
-  MomArgs a{h->fields[UDC_U0], h->fields[UDC_V0], h->fields[UDC_W0], h->fields[UDC_PRES0],
-            h->fields[UDC_EKM], h->fields[UDC_UP], h->fields[UDC_VP], h->fields[UDC_WP]};
-  dim3 b(64, 4, 1), gr = cell_grid(g, b);
-  const bool les = h->p.sgs != UDC_SGS_DNS;
-  const double nu = h->p.numol;
-#define LAUNCH(A, D, L, F)                                                                   \
-  do {                                                                                       \
-    PROF(h, "mom_" #A #D #L #F);                                                             \
-    hipLaunchKernelGGL((mom_kernel<A, D, L, F>), gr, b, 0, h->stream, g, tile_grid(g), h->m, a, nu);       \
-  } while (0)
-  if (adv && diff) {
-    if (les) { if (forces) LAUNCH(true, true, true, true); else LAUNCH(true, true, true, false); }
-    else     { if (forces) LAUNCH(true, true, false, true); else LAUNCH(true, true, false, false); }
-  } else if (adv) {
-    LAUNCH(true, false, true, false);
-  } else if (diff) {
-    if (les) LAUNCH(false, true, true, false); else LAUNCH(false, true, false, false);
-  }
-#undef LAUNCH
-  HIP_OK(hipGetLastError());
-  return 0;
-}
-
 int k_forces(udc_handle *h) {
   const Geo &g = h->g;
   dim3 b(64, 4, 1), gr = cell_grid(g, b);
@@ -401,19 +306,12 @@ int k_forces(udc_handle *h) {
 
 int k_closure(udc_handle *h) {
   const Geo &g = h->g;
-  dim3 b(64, 4, 1), gr = cell_grid(g, b);
-  double *u = h->fields[UDC_U0], *v = h->fields[UDC_V0], *w = h->fields[UDC_W0];
   double *ekm = h->fields[UDC_EKM], *ekh = h->fields[UDC_EKH];
   if (h->p.sgs == UDC_SGS_ONEEQN) return k_tke_closure(h);
-  if (!h->mom_simple && h->p.sgs != UDC_SGS_DNS) return k_closure_lds(h, false);
+  if (h->p.sgs != UDC_SGS_DNS) return k_closure_lds(h, false);
   PROF(h, "closure");
-  if (h->p.sgs == UDC_SGS_SMAGORINSKY)
-    hipLaunchKernelGGL((closure_kernel<1>), gr, b, 0, h->stream, g, tile_grid(g), h->m, h->p, u, v, w, ekm, ekh);
-  else if (h->p.sgs == UDC_SGS_VREMAN)
-    hipLaunchKernelGGL((closure_kernel<2>), gr, b, 0, h->stream, g, tile_grid(g), h->m, h->p, u, v, w, ekm, ekh);
-  else
-    hipLaunchKernelGGL(fill_const_kernel, dim3((unsigned)((g.n + 255) / 256)), dim3(256), 0, h->stream, g, ekm,
-                       h->p.numol, ekh, h->p.numol * h->p.prandtlmoli);
+  hipLaunchKernelGGL(fill_const_kernel, dim3((unsigned)((g.n + 255) / 256)), dim3(256), 0, h->stream, g, ekm,
+                     h->p.numol, ekh, h->p.numol * h->p.prandtlmoli);
   HIP_OK(hipGetLastError());
   return 0;
 }

@@ -5,7 +5,7 @@
 
 struct PlanIn {
   // switches (Switches, udc_internal.h)
-  int mom_simple, no_pup, no_fold, no_alias, ek_always, halo_overlap, mom_pipe, div_in_fft;
+  int no_fold, no_alias, ek_always, halo_overlap, mom_pipe, div_in_fft;
   // what the handle is
   int slab;             // distributed layout in use (more than one rank, or UDC_FORCE_SLAB)
   int comm_stream;      // the communication stream exists (slab layout set up)
@@ -48,8 +48,8 @@ inline bool plan_halo_overlap(const PlanIn &in, int tile_rows) { return in.slab 
 
 inline Plan plan_substep(const PlanIn &in) {
   Plan p{};
-  p.lds = !in.mom_simple;
-  p.pup = p.lds && !in.no_pup;
+  p.lds = 1;      // (the LDS-staged sweeps and the predicted-velocity form of the tendencies: always, since round 4)
+  p.pup = 1;
   // single slab (whole y extent local): the ghost rows / planes of closurebc, bcpup, bcp, halos and boundary are written by the
   // kernels that own the neighbouring cells
   p.fold = p.lds && !in.slab && !in.no_fold;

@@ -275,7 +275,7 @@ int k_scalar_diff(udc_handle *h, int n) { return launch_scalar(h, n, false, true
 bool k_scalar_fused_lds(udc_handle *h, int n, bool fresh, int *rc);      // udc_scalar_lds.hip
 int k_scalar_fused(udc_handle *h, int n, bool fresh) {
   int rc = 0;
-  if (!h->mom_simple && k_scalar_fused_lds(h, n, fresh, &rc)) return rc || k_scalar_bcx_edges(h, n, true, true);
+  if (k_scalar_fused_lds(h, n, fresh, &rc)) return rc || k_scalar_bcx_edges(h, n, true, true);
   return launch_scalar(h, n, true, true, fresh) || k_scalar_bcx_edges(h, n, true, true);
 }
 
@@ -283,7 +283,7 @@ int k_scalar_fused(udc_handle *h, int n, bool fresh) {
 bool k_scalar_pair_lds(udc_handle *h, int na, int nb, bool fresh, int *rc);
 int k_scalar_fused_pair(udc_handle *h, int na, int nb, bool fresh) {
   int rc = 0;
-  if (h->mom_simple || !k_scalar_pair_lds(h, na, nb, fresh, &rc)) return -1;
+  if (!k_scalar_pair_lds(h, na, nb, fresh, &rc)) return -1;
   if (rc || k_scalar_bcx_edges(h, na, true, true) || k_scalar_bcx_edges(h, nb, true, true)) return 1;
   return 0;
 }

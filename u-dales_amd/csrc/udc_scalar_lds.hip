@@ -377,7 +377,6 @@ __global__ __launch_bounds__(NT, 4) void scalar_kappa_faces_kernel(Geo g, int gx
 // fused advection + diffusion of scalar slot n; false when this kernel does not apply (the caller falls back)
 bool k_scalar_fused_lds(udc_handle *h, int n, bool fresh, int *rc) {
   *rc = 0;
-  if (h->sw.mom_simple) return false;
   const Geo &g = h->g;
   if (g.nx < MX || g.ny < 4) return false;
   const int gx = (g.nx + MX - 1) / MX, gy = (g.ny + MY - 1) / MY, tiles = gx * gy;
@@ -420,7 +419,6 @@ bool k_scalar_fused_lds(udc_handle *h, int n, bool fresh, int *rc) {
 // with ekh, same vertical ghost rule -- thl and qt.  false when that does not apply (the caller launches them one by one).
 bool k_scalar_pair_lds(udc_handle *h, int na, int nb, bool fresh, int *rc) {
   *rc = 0;
-  if (h->sw.mom_simple) return false;
   if (!h->sw.scalar_pair) return false;
   const Geo &g = h->g;
   if (g.nx < MX || g.ny < 4) return false;
