@@ -1063,7 +1063,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
       if (k_momentum_lds(h, true, true, forces, true, 1. / rk3coef, rotate, &row0)) return 1;
       if (floor_on && k_bottom(h, false, 0, momentum_lds_tile_height())) return 1;
       const int fvp[1] = {UDC_VP};
-      if (k_halo_y_begin(h, fvp, 1, 1)) return 1;
+      if (k_halo_y_begin(h, fvp, 1, 1, nullptr, HALO_TO_PREV)) return 1;      // (only the divergence of the slab's last row reads a ghost row of vp)
       h->vp_halo_pending = true;
       h->mom_pipe.active = true; h->mom_pipe.forces = forces; h->mom_pipe.um_is_u0 = rotate; h->mom_pipe.bottom = floor_on;
       h->mom_pipe.rk3coefi = 1. / rk3coef;
@@ -1108,11 +1108,11 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
     // y-slabs with the divergence inside the x transform: the row travels while all but the last row group of the first k-chunk
     // are transformed (k_poisson_solve_slab joins)
     const int fvp[1] = {UDC_VP};
-    if (k_halo_y_begin(h, fvp, 1, 1)) return 1;
+    if (k_halo_y_begin(h, fvp, 1, 1, nullptr, HALO_TO_PREV)) return 1;
     h->vp_halo_pending = true;
   } else if (plan.vp_row == ROW_INLINE) {
     const int fvp[1] = {UDC_VP};
-    if (k_halo_y(h, fvp, 1, 1)) return 1;
+    if (k_halo_y(h, fvp, 1, 1, HALO_TO_PREV)) return 1;
   }      // (ROW_PIPED: already travelling; ROW_FOLDED: written by the kernels above)
   if (!h->div_in_fft && k_divergence_rhs(h, rk3coef, pup)) return 1;
   if (k_poisson_solve(h)) return 1;
@@ -1125,8 +1125,9 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   const bool ov_p = plan.p_row == ROW_BESIDE;
   if (plan.p_row != ROW_FOLDED) {
     const int fp[1] = {UDC_P};
-    if (ov_p) { if (k_halo_y_begin(h, fp, 1, 1)) return 1; }
-    else if (k_halo_y(h, fp, 1, 1)) return 1;
+    // (only the projection of the slab's first row reads a ghost row of p: the previous rank's last row)
+    if (ov_p) { if (k_halo_y_begin(h, fp, 1, 1, nullptr, HALO_TO_NEXT)) return 1; }
+    else if (k_halo_y(h, fp, 1, 1, HALO_TO_NEXT)) return 1;
   }
   const bool skip_um = plan.skip_um;
   // y-slabs: the rows next to the neighbouring ranks first; the ghost rows of the new velocities and of pres0 travel while the rows

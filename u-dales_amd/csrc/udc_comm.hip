@@ -168,13 +168,14 @@ static int need_comm(udc_handle *h) {
 // neighbour rows: to_prev/to_next are packed send buffers of `count` doubles each;
 // from_next receives the next rank's to_prev, from_prev the previous rank's to_next.
 int comm_neighbours(udc_handle *h, const double *to_prev, const double *to_next, double *from_prev,
-                    double *from_next, size_t count, hipStream_t st) {
+                    double *from_next, size_t count, hipStream_t st, int dirs) {
   if (!st) st = h->stream;
   const int P = h->cfg.nranks, r = h->cfg.rank;
   const int prev = (r + P - 1) % P, next = (r + 1) % P;
+  const bool dp = (dirs & 1) != 0, dn = (dirs & 2) != 0;      // rows to the previous rank (and from the next) / to the next (from the previous)
   if (P == 1 && !h->nccl) {   // single slab driven through the slab code path (UDC_FORCE_SLAB): periodic wrap onto itself
-    HIP_OK(hipMemcpyAsync(from_next, to_prev, count * sizeof(double), hipMemcpyDeviceToDevice, st));
-    HIP_OK(hipMemcpyAsync(from_prev, to_next, count * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (dp) HIP_OK(hipMemcpyAsync(from_next, to_prev, count * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (dn) HIP_OK(hipMemcpyAsync(from_prev, to_next, count * sizeof(double), hipMemcpyDeviceToDevice, st));
     return 0;
   }
   if (need_comm(h)) return 1;
@@ -186,10 +187,10 @@ int comm_neighbours(udc_handle *h, const double *to_prev, const double *to_next,
     NCCL_OK(ncclGroupStart());
     for (size_t o = 0; o < count; o += piece) {
       const size_t n = count - o < piece ? count - o : piece;
-      NCCL_OK(ncclSend(to_prev + o, n, ncclDouble, prev, c, st));
-      NCCL_OK(ncclSend(to_next + o, n, ncclDouble, next, c, st));
-      NCCL_OK(ncclRecv(from_next + o, n, ncclDouble, next, c, st));
-      NCCL_OK(ncclRecv(from_prev + o, n, ncclDouble, prev, c, st));
+      if (dp) NCCL_OK(ncclSend(to_prev + o, n, ncclDouble, prev, c, st));
+      if (dn) NCCL_OK(ncclSend(to_next + o, n, ncclDouble, next, c, st));
+      if (dp) NCCL_OK(ncclRecv(from_next + o, n, ncclDouble, next, c, st));
+      if (dn) NCCL_OK(ncclRecv(from_prev + o, n, ncclDouble, prev, c, st));
     }
     NCCL_OK(ncclGroupEnd());
     return 0;
@@ -200,11 +201,11 @@ int comm_neighbours(udc_handle *h, const double *to_prev, const double *to_next,
     ShmGroup *sg = (ShmGroup *)h->shm_group;
     if (2 * nb > sg->cap) { udc_set_error("test transport (shared memory): ghost rows exceed the outbox"); return 1; }
     HIP_OK(hipStreamSynchronize(st));
-    HIP_OK(hipMemcpy(sg->box(r), to_prev, nb, hipMemcpyDeviceToHost));
-    HIP_OK(hipMemcpy(sg->box(r) + nb, to_next, nb, hipMemcpyDeviceToHost));
+    if (dp) HIP_OK(hipMemcpy(sg->box(r), to_prev, nb, hipMemcpyDeviceToHost));
+    if (dn) HIP_OK(hipMemcpy(sg->box(r) + nb, to_next, nb, hipMemcpyDeviceToHost));
     pthread_barrier_wait(&sg->bar);
-    HIP_OK(hipMemcpy(from_next, sg->box(next), nb, hipMemcpyHostToDevice));
-    HIP_OK(hipMemcpy(from_prev, sg->box(prev) + nb, nb, hipMemcpyHostToDevice));
+    if (dp) HIP_OK(hipMemcpy(from_next, sg->box(next), nb, hipMemcpyHostToDevice));
+    if (dn) HIP_OK(hipMemcpy(from_prev, sg->box(prev) + nb, nb, hipMemcpyHostToDevice));
     pthread_barrier_wait(&sg->bar);
     return 0;
   }
@@ -212,8 +213,8 @@ int comm_neighbours(udc_handle *h, const double *to_prev, const double *to_next,
   g->send[r][0] = to_prev; g->send[r][1] = to_next;
   HIP_OK(hipStreamSynchronize(st));
   pthread_barrier_wait(&g->bar);
-  HIP_OK(hipMemcpyAsync(from_next, g->send[next][0], count * sizeof(double), hipMemcpyDeviceToDevice, st));
-  HIP_OK(hipMemcpyAsync(from_prev, g->send[prev][1], count * sizeof(double), hipMemcpyDeviceToDevice, st));
+  if (dp) HIP_OK(hipMemcpyAsync(from_next, g->send[next][0], count * sizeof(double), hipMemcpyDeviceToDevice, st));
+  if (dn) HIP_OK(hipMemcpyAsync(from_prev, g->send[prev][1], count * sizeof(double), hipMemcpyDeviceToDevice, st));
   HIP_OK(hipStreamSynchronize(st));
   pthread_barrier_wait(&g->bar);
   return 0;

@@ -25,26 +25,27 @@ __global__ void halo_y_wrap_kernel(Geo g, FieldList fl, int width) {
 
 // multi-slab: pack `width` boundary rows of every field into a contiguous buffer
 // buf[((f*width + r)*pz + kk)*nx + i]; low = rows 0..w-1 (to previous rank), high = rows ny-w..ny-1.
-__global__ void halo_pack_kernel(Geo g, FieldList fl, int width, double *__restrict__ to_prev, double *__restrict__ to_next) {
+// dirs: bit 0 = the rows that go to the previous rank (and arrive from the next one), bit 1 = to the next (from the previous)
+__global__ void halo_pack_kernel(Geo g, FieldList fl, int width, double *__restrict__ to_prev, double *__restrict__ to_next, int dirs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= g.nx) return;
   const int r = blockIdx.y % width, fi = blockIdx.y / width;
   const int kk = blockIdx.z, k = kk - HZ;
   const double *a = fl.f[fi];
   const size_t o = (((size_t)fi * width + r) * g.pz + kk) * g.nx + i;
-  to_prev[o] = a[g.idx(i, r, k)];
-  to_next[o] = a[g.idx(i, g.ny - width + r, k)];
+  if (dirs & 1) to_prev[o] = a[g.idx(i, r, k)];
+  if (dirs & 2) to_next[o] = a[g.idx(i, g.ny - width + r, k)];
 }
 __global__ void halo_unpack_kernel(Geo g, FieldList fl, int width, const double *__restrict__ from_prev,
-                                   const double *__restrict__ from_next) {
+                                   const double *__restrict__ from_next, int dirs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= g.nx) return;
   const int r = blockIdx.y % width, fi = blockIdx.y / width;
   const int kk = blockIdx.z, k = kk - HZ;
   double *a = fl.f[fi];
   const size_t o = (((size_t)fi * width + r) * g.pz + kk) * g.nx + i;
-  a[g.idx(i, -width + r, k)] = from_prev[o];
-  a[g.idx(i, g.ny + r, k)] = from_next[o];
+  if (dirs & 2) a[g.idx(i, -width + r, k)] = from_prev[o];
+  if (dirs & 1) a[g.idx(i, g.ny + r, k)] = from_next[o];
 }
 
 struct BoundaryArgs {
@@ -88,12 +89,12 @@ __global__ void top_bottom_kernel(Geo g, Params pr, BoundaryArgs a, int uv_only)
 
 }  // namespace
 
-int k_halo_y(udc_handle *h, const int *fields, int nf, int width) {
+int k_halo_y(udc_handle *h, const int *fields, int nf, int width, int dirs) {
   const Geo &g = h->g;
   if (width > HY) { udc_set_error("k_halo_y: bad arguments"); return 1; }
   if (nf > 16) {      // one launch (and one exchange buffer) carries 16 fields; more go in rounds
     for (int q = 0; q < nf; q += 16)
-      if (k_halo_y(h, fields + q, nf - q < 16 ? nf - q : 16, width)) return 1;
+      if (k_halo_y(h, fields + q, nf - q < 16 ? nf - q : 16, width, dirs)) return 1;
     return 0;
   }
   FieldList fl;
@@ -113,17 +114,17 @@ int k_halo_y(udc_handle *h, const int *fields, int nf, int width) {
   {
     PROF(h, "halo_pack");
     hipLaunchKernelGGL(halo_pack_kernel, dim3((g.nx + 63) / 64, width * nf, g.pz), dim3(64), 0, h->stream, g, fl,
-                       width, h->halo_buf[0], h->halo_buf[1]);
+                       width, h->halo_buf[0], h->halo_buf[1], dirs);
     HIP_OK(hipGetLastError());
   }
   {
     PROF(h, "halo_xchg");
-    if (comm_neighbours(h, h->halo_buf[0], h->halo_buf[1], h->halo_buf[2], h->halo_buf[3], count)) return 1;
+    if (comm_neighbours(h, h->halo_buf[0], h->halo_buf[1], h->halo_buf[2], h->halo_buf[3], count, nullptr, dirs)) return 1;
   }
   {
     PROF(h, "halo_unpack");
     hipLaunchKernelGGL(halo_unpack_kernel, dim3((g.nx + 63) / 64, width * nf, g.pz), dim3(64), 0, h->stream, g, fl,
-                       width, h->halo_buf[2], h->halo_buf[3]);
+                       width, h->halo_buf[2], h->halo_buf[3], dirs);
     HIP_OK(hipGetLastError());
   }
   return 0;
@@ -138,7 +139,7 @@ bool halo_overlap(const udc_handle *h, int tile_rows_y) {
   return h->slab && h->comm_stream && !h->no_halo_overlap && tile_rows_y >= 3;
 }
 
-int k_halo_y_begin(udc_handle *h, const int *fields, int nf, int width, double *const *ptrs) {
+int k_halo_y_begin(udc_handle *h, const int *fields, int nf, int width, double *const *ptrs, int dirs) {
   const Geo &g = h->g;
   if (width > HY || nf > 16 || !h->slab || !h->comm_stream) { udc_set_error("k_halo_y_begin: bad arguments"); return 1; }
   FieldList fl;
@@ -148,10 +149,10 @@ int k_halo_y_begin(udc_handle *h, const int *fields, int nf, int width, double *
   hipStream_t cs = h->comm_stream;
   HIP_OK(hipEventRecord(h->ev_halo_ready, h->stream));
   HIP_OK(hipStreamWaitEvent(cs, h->ev_halo_ready, 0));
-  hipLaunchKernelGGL(halo_pack_kernel, dim3((g.nx + 63) / 64, width * nf, g.pz), dim3(64), 0, cs, g, fl, width, h->halo_buf[0], h->halo_buf[1]);
+  hipLaunchKernelGGL(halo_pack_kernel, dim3((g.nx + 63) / 64, width * nf, g.pz), dim3(64), 0, cs, g, fl, width, h->halo_buf[0], h->halo_buf[1], dirs);
   HIP_OK(hipGetLastError());
-  if (comm_neighbours(h, h->halo_buf[0], h->halo_buf[1], h->halo_buf[2], h->halo_buf[3], count, cs)) return 1;
-  hipLaunchKernelGGL(halo_unpack_kernel, dim3((g.nx + 63) / 64, width * nf, g.pz), dim3(64), 0, cs, g, fl, width, h->halo_buf[2], h->halo_buf[3]);
+  if (comm_neighbours(h, h->halo_buf[0], h->halo_buf[1], h->halo_buf[2], h->halo_buf[3], count, cs, dirs)) return 1;
+  hipLaunchKernelGGL(halo_unpack_kernel, dim3((g.nx + 63) / 64, width * nf, g.pz), dim3(64), 0, cs, g, fl, width, h->halo_buf[2], h->halo_buf[3], dirs);
   HIP_OK(hipGetLastError());
   HIP_OK(hipEventRecord(h->ev_halo_done, cs));
   h->halo_async_pending = true;      // (several begins in a row queue behind each other on the communication stream; one join covers them)

@@ -444,11 +444,14 @@ int k_project_integrate(udc_handle *h, int rk3step, double dt, bool zero_tend, b
                         bool write_um = true, bool out_to_um = false, int rows = 0, int r0 = 0, int r1 = 0);   // fused tderive + tstep_integrate
 // rows (k_closure_lds, k_project_integrate): 0 all tile rows of the slab, 1 only the tile rows next to the neighbouring ranks,
 // 2 only the rows in between; k_project_integrate also 3 / 4: the tile rows [r0, r1) (3: profiled with the edge launch)
-int k_halo_y(udc_handle *h, const int *fields, int nf, int width);
+// dirs: HALO_TO_PREV (this slab's first rows -> the previous rank's upper ghost rows; the upper ghost rows here arrive from the next
+// rank), HALO_TO_NEXT (the last rows -> the next rank's lower ghost rows), or both
+enum { HALO_TO_PREV = 1, HALO_TO_NEXT = 2, HALO_BOTH = 3 };
+int k_halo_y(udc_handle *h, const int *fields, int nf, int width, int dirs = HALO_BOTH);
 // the same exchange beside the compute stream: _begin queues pack, exchange and unpack on the communication stream behind what
 // the compute stream holds so far; _join makes the compute stream wait for it.  `ptrs` (optional): the arrays, where the caller
 // knows better than h->fields (pointer rotation in flight)
-int k_halo_y_begin(udc_handle *h, const int *fields, int nf, int width, double *const *ptrs = nullptr);
+int k_halo_y_begin(udc_handle *h, const int *fields, int nf, int width, double *const *ptrs = nullptr, int dirs = HALO_BOTH);
 int k_halo_y_join(udc_handle *h);
 bool halo_overlap(const udc_handle *h, int tile_rows_y);      // y-slabs with enough tile rows for an edge / interior split
 int k_top_bottom(udc_handle *h);
@@ -499,7 +502,7 @@ int fft_y_fwd_unpack(udc_handle *h, int k0, int nzc, const double *recv);
 int fft_y_bwd_pack(udc_handle *h, int k0, int nzc, double *send);
 // udc_comm.hip
 int comm_neighbours(udc_handle *h, const double *to_prev, const double *to_next, double *from_prev,
-                    double *from_next, size_t count, hipStream_t st = nullptr);      // st: the stream it runs on (default h->stream)
+                    double *from_next, size_t count, hipStream_t st = nullptr, int dirs = 3);      // st: the stream it runs on (default h->stream); dirs: HALO_*
 int comm_alltoall(udc_handle *h, const double *send, double *recv, size_t block, hipStream_t st);
 int comm_allreduce(udc_handle *h, double *buf, int n, int op);
 void comm_destroy(udc_handle *h);

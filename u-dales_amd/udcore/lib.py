@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -61,6 +62,15 @@ def load():
         if not os.path.exists(LIBPATH):
             raise UdcError(f"{LIBPATH} not found: build it with `python -c 'import __graft_entry__ as g; "
                            f"g.build()'` (hipcc, gfx950). There is no CPU fallback.")
+        # torch (bench.py, the tests, `python -m torch.distributed.run`) ships its own copies of the ROCm runtime libraries under
+        # the same sonames as the system's.  Whichever is loaded first serves both; torch-first works, libudcore-first makes the
+        # process abort at exit (glibc: "double free or corruption" in the runtimes' tear-down).  So where torch is installed it
+        # goes first (UDC_TORCH_FIRST=0: not).  The Fortran route never meets torch.
+        if "torch" not in sys.modules and os.environ.get("UDC_TORCH_FIRST", "1") != "0":
+            try:
+                import torch      # noqa: F401
+            except Exception:      # noqa: BLE001
+                pass
         _lib = C.CDLL(LIBPATH, mode=C.RTLD_GLOBAL)
         _lib.udc_last_error.restype = C.c_char_p
     return _lib
