@@ -98,3 +98,25 @@ def test_switch_is_visible_in_the_profile(monkeypatch):
         core.close()
     assert "fftx_pack_fwd" in names["own"] and "div_rhs" not in names["own"], names["own"]
     assert "div_rhs" in names["rocfft"] and "fftx_pack_fwd" not in names["rocfft"], names["rocfft"]
+
+
+@pytest.mark.parametrize("shape", [(16, 8, 4), (32, 16, 5), (64, 8, 4), (128, 16, 6), (256, 32, 4), (512, 16, 4), (1024, 8, 4), (2048, 8, 3)])
+def test_slab_line_transforms_of_every_length(shape, monkeypatch):
+    """The slab ranks' own x transforms at every line length they accept (nx = 16 .. 2048: the backward one as radix-8 butterflies in
+    registers, 2^c 8^a complex points for every c in 0, 1, 2 and a in 1 .. 3; mirrored Thomas pairs where a line has 16 rows) against the
+    single-slab path (2-D rocFFT) on the same state: src/modpois.f90:459-702."""
+    from udcore.grid import Grid
+    nx, ny, nz = shape
+    g = Grid.uniform(nx, ny, nz)
+    o, st = _state(g, 5)
+    dt = 0.1
+    monkeypatch.setenv("UDC_OWN_FWD", "0")
+    ref, div_ref = _run(g, st, 3, dt)
+    monkeypatch.setenv("UDC_FORCE_SLAB", "1")
+    monkeypatch.setenv("UDC_THOMAS_MIRROR_MIN", "16")
+    own, div_own = _run(g, st, 3, dt)
+    for k in ref:
+        scale = max(np.abs(ref[k]).max(), 1e-30)
+        err = np.abs(own[k][1:-1, 1:-1, 1:-1] - ref[k][1:-1, 1:-1, 1:-1]).max() / scale
+        assert err <= (1e-10 if k == "pres0" else 1e-11), (shape, k, err)
+    assert div_own < 1e-11 and div_ref < 1e-11, (div_own, div_ref)

@@ -312,16 +312,21 @@ def oracle_state(st, g, nsv):
     ((40, 24, 16), 2, 1, 1.05, True),       # floor wall function (lbottom, BCbotm = 3) + scalar floor
     ((12, 8, 6), 0, 0, 1.00, True),         # floor under DNS viscosity
 ])
-@pytest.mark.parametrize("thomas", ["stream", "reg", "reg-nopair"])
+@pytest.mark.parametrize("thomas", ["stream", "reg", "reg-nopair", "slab-mirror"])
 def test_against_oracle_seeded(shape, sgs, nsv, stretch, floor, thomas, monkeypatch):
     """Three substeps (one RK3 step) vs the CPU oracle on seeded random fields, with every variant of the tridiagonal solve:
     the streaming kernel (UDC_THOMAS=0: one thread per mode, solmpj's own order), register-resident segments (the default:
-    partitioned recurrences, rows ky and ny - ky of the one-GPU layout solved together) and the same without the pairing
-    (UDC_THOMAS_PAIR=0: what the slab ranks run)."""
+    partitioned recurrences, rows ky and ny - ky of the one-GPU layout solved together), the same without the pairing
+    (UDC_THOMAS_PAIR=0) and the slab ranks' layout with the mirrored runs of a line solved together (from lines of 256 by
+    default; here from 16: the shapes with 48 and 64 rows take it, the others the unpaired kernel of the slab path -- and every
+    shape the radix-8 x backward transform, lines of 2 to 64 complex)."""
     if thomas == "stream":
         monkeypatch.setenv("UDC_THOMAS", "0")
     if thomas == "reg-nopair":
         monkeypatch.setenv("UDC_THOMAS_PAIR", "0")
+    if thomas == "slab-mirror":
+        monkeypatch.setenv("UDC_FORCE_SLAB", "1")
+        monkeypatch.setenv("UDC_THOMAS_MIRROR_MIN", "16")
     nx, ny, nz = shape
     dz = 0.5 * stretch ** np.arange(nz)
     zf = np.cumsum(dz) - 0.5 * dz

@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("switches", [
     {"UDC_FORCE_SLAB": "1"},                                # one rank through the slab layout: own line transforms, exchanges onto itself
     {"UDC_FORCE_SLAB": "1", "UDC_FFT_FUSED": "0"},          # ... with rocFFT + transpose kernels (rung 3 of bench.py's ladder)
+    {"UDC_FORCE_SLAB": "1", "UDC_THOMAS_MIRROR_MIN": "16"},  # ... mirrored runs of a line solved together wherever a line has 16 rows
     {"UDC_FORCE_SLAB": "1", "UDC_DIV_IN_FFT": "0"},         # ... with the separate divergence kernel
     {"UDC_FORCE_SLAB": "1", "UDC_HALO_OVERLAP": "0", "UDC_MOM_PIPE": "0", "UDC_A2A_CHUNKS": "1"},      # rungs 1 and 2 of the ladder
     {"UDC_NO_FOLD": "1"},                                   # single slab: separate ghost-row kernels

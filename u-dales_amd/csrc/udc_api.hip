@@ -151,6 +151,7 @@ void udc_read_switches(Switches &sw) {
   sw.scalar_pair = env_int("UDC_SCALAR_PAIR", 1) != 0;
   sw.thomas = env_int("UDC_THOMAS", -1);
   sw.thomas_pair = env_int("UDC_THOMAS_PAIR", 1) != 0;
+  sw.thomas_mirror_min = env_int("UDC_THOMAS_MIRROR_MIN", 256);
   sw.mom_kc = env_int("UDC_MOM_KC", 0);
   sw.scalar_kc = env_int("UDC_SCALAR_KC", 0);
   sw.closure_percu = env_int("UDC_CLOSURE_PERCU", 0);

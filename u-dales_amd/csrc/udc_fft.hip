@@ -9,7 +9,7 @@
 //   fftx_fwd_pack    p rows (real, coalesced)          -> R2C  -> send[d][k][kx_l][j]   (runs of L in j)
 //   ffty_fwd_unpack  recv[s][k][kx_l][j] (runs of ny_l) -> C2C  -> specB[k][kx_l][y]     (what the Thomas kernel reads)
 //   ffty_bwd_pack    specB[k][kx_l][y]                  -> C2C^-1 -> send[d][k][kx_l][j]
-//   fftx_bwd_unpack  recv[s][k][kx_l][j] (runs of L)    -> C2R  -> p rows
+//   fftx_bwd_r8      recv[s][k][kx_l][j] (runs of L)    -> C2R  -> p rows      (radix-8 butterflies in registers, persistent)
 //
 // R2C / C2R of length N run as a complex transform of length M = N/2 on z[n] = x[2n] + i x[2n+1] with the usual
 // split / merge step.  All transforms are unnormalised, like rocFFT's and FFTW's (the Thomas kernel carries 1/(nx ny)).
@@ -21,6 +21,7 @@
 //   ffty_natreg_kernel    columns of spec, in place, 16 x N2 in registers with one trip through LDS   (ny = 128, 256, 512)
 // and the slab path's y transforms use the same register scheme on their y-contiguous lines (ffty_slabreg_kernel).
 #include "udc_internal.h"
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 
@@ -109,6 +110,7 @@ struct XArgs {
   int k0, nzc;              // chunk
   int lL;                   // log2 of the rows per workgroup
   int jg0;                  // first row group of this launch (fftx_fwd_pack: the last group may follow vp's ghost row)
+  unsigned cxmul;           // floor(2^32 / cx) + 1: kx / cx = __umulhi(kx, cxmul) for every mode index (r8 kernels)
 };
 
 // LDS: two line buffers [L][MP], then the twiddles of the length-M transform [M], then the rank of every mode [cx*P]
@@ -121,6 +123,17 @@ __device__ __forceinline__ void x_lds(const XArgs &q, double2 *lds, double2 *&a,
   constexpr int NTH = xthreads(LM);
   for (int n = threadIdx.x; n < (1 << LM); n += NTH) tw[n] = twM[n];
   for (int kx = threadIdx.x; kx < q.cx * q.P; kx += NTH) dmap[kx] = kx / q.cx;
+}
+
+// Workgroup -> (row group, level of the chunk).  Row groups 2m and 2m + 1 share every 128-B line of the exchange blocks when L = 4
+// (runs of L complex = 64 B in j): the hardware deals workgroup b to XCD b % 8, so with the launch order as it is the two halves of a
+// line are fetched by two different L2s (measured, profiles/r05: fftx_bwd_unpack read 2.0x its block).  XCD c is given a contiguous
+// run of (level, row group) pairs instead, as xcd_tile does for the stencil sweeps: the second half of a line then hits.
+__device__ __forceinline__ void x_block(int &jg, int &kc) {
+  const unsigned gx = gridDim.x, nwg = gx * gridDim.y;
+  unsigned v = blockIdx.x + gx * blockIdx.y;
+  if ((nwg & 7u) == 0) v = (v & 7u) * (nwg >> 3) + (v >> 3);
+  kc = (int)(v / gx); jg = (int)(v - (unsigned)kc * gx);
 }
 
 // fillps folded into the x forward transform (fused substep, PUP mode): the row is not read from p but evaluated as
@@ -136,7 +149,9 @@ __global__ __launch_bounds__(xthreads(LM)) void fftx_fwd_pack_kernel(XArgs q, co
   double2 *a, *b, *tw; int *dmap;
   x_lds<LM>(q, lds, a, b, tw, dmap, twM);
   const int tid = threadIdx.x, L = 1 << q.lL;
-  const int j0 = (blockIdx.x + q.jg0) << q.lL, kc = blockIdx.y, k = q.k0 + kc;
+  int jg, kc;
+  x_block(jg, kc);
+  const int j0 = (jg + q.jg0) << q.lL, k = q.k0 + kc;
   // load: row l holds M complex = nx reals, read as double2 (16-B aligned: nx even, rows nx*8 B apart, base 16-B aligned)
   for (int wi = tid; wi < (M << q.lL); wi += NTH) {
     const int l = wi >> LM, n = wi & (M - 1);
@@ -175,39 +190,166 @@ __global__ __launch_bounds__(xthreads(LM)) void fftx_fwd_pack_kernel(XArgs q, co
   }
 }
 
-// x backward: recv blocks -> rows j0..j0+L-1 of plane k0+kc (unnormalised C2R)
+// ------------------------------------------------------------------------------------------------ radix-8 line transforms (round 5)
+// The Stockham kernels above pass a line through LDS once per radix-4 stage (five round trips and seven barriers for 512 complex,
+// half of the 1024 threads idle in four of them): measured on the x backward transform of a rank's slab of 1024 x 64 x 512
+// (profiles/r05/xbwd_phase_ablation.txt) the stages, the gather and the store each cost about a third and nothing overlaps.  Here a
+// thread holds a radix-8 butterfly in registers: M = 2^c 8^a points are a pre-stage of radix 2^c (c = 1, 2; eight neighbouring
+// elements per thread) and `a` decimation-in-time stages of radix 8, in place in ONE line buffer (a stage reads and writes the same
+// eight slots of the same thread: one barrier between stages), input placed digit-reversed, so that the last stage holds
+// X[t + (M/8) q] in thread t: the stores to memory are coalesced straight from registers.  M/8 threads per line.
+// LDS slot of element p: p + p/8 + p/64 (the stride-1 stage reads eight neighbours per thread: one pad per eight keeps eight lanes
+// on eight different bank groups; the second term does the same for the digit-reversed placement, whose neighbouring inputs stand
+// M/8 slots apart), lines LP = M + M/8 + M/64 + 1 apart (an odd number of 16-B slots: the lines of a workgroup start on different banks).
+template <int LM> struct R8 {
+  static constexpr int M = 1 << LM, A = LM / 3, C = LM % 3, TPL = M / 8, LP = M + M / 8 + M / 64 + 1;
+  // slot (before padding) at which input element n has to stand: stage radices R_1 .. R_S = [2^C,] 8 x A, n = r_S + R_S (r_{S-1} + ...),
+  // slot = r_1 + R_1 (r_2 + R_2 (...))
+  __host__ __device__ static constexpr int place(int n) {
+    int p = 0, w = M;
+    for (int i = 0; i < A; ++i) { w >>= 3; p += (n & 7) * w; n >>= 3; }
+    return p + n;
+  }
+};
+__device__ __forceinline__ int pad8(int p) { return p + (p >> 3) + (p >> 6); }
+
+// eight-point transform in registers, natural order in and out; INV: e^{+2 pi i / 8}
+template <bool INV>
+__device__ __forceinline__ void dft8(double2 (&x)[8]) {
+  constexpr double h = 0.70710678118654752440;
+  auto rot = [](double2 v) { return INV ? make_double2(-v.y, v.x) : make_double2(v.y, -v.x); };      // v * (-/+ i)
+  const double2 e0 = cadd(x[0], x[4]), e1 = csub(x[0], x[4]), e2 = cadd(x[2], x[6]), e3 = rot(csub(x[2], x[6]));
+  const double2 o0 = cadd(x[1], x[5]), o1 = csub(x[1], x[5]), o2 = cadd(x[3], x[7]), o3 = rot(csub(x[3], x[7]));
+  const double2 E0 = cadd(e0, e2), E2 = csub(e0, e2), E1 = cadd(e1, e3), E3 = csub(e1, e3);
+  const double2 O0 = cadd(o0, o2), O2 = rot(csub(o0, o2));
+  const double2 q1 = cadd(o1, o3), q3 = csub(o1, o3);
+  // w O1, w^3 O3 with w = (1 -/+ i) / sqrt 2
+  const double2 O1 = INV ? make_double2((q1.x - q1.y) * h, (q1.x + q1.y) * h) : make_double2((q1.x + q1.y) * h, (q1.y - q1.x) * h);
+  const double2 O3 = INV ? make_double2(-(q3.x + q3.y) * h, (q3.x - q3.y) * h) : make_double2((q3.y - q3.x) * h, -(q3.x + q3.y) * h);
+  x[0] = cadd(E0, O0); x[4] = csub(E0, O0);
+  x[1] = cadd(E1, O1); x[5] = csub(E1, O1);
+  x[2] = cadd(E2, O2); x[6] = csub(E2, O2);
+  x[3] = cadd(E3, O3); x[7] = csub(E3, O3);
+}
+
+// the stages of one line held at `ln` (slots pad8(p)), thread t of the line's M/8; tw[n] = exp(-2 pi i n / M) in memory.  On return
+// x[q] = X[t + (M/8) q].  Every thread of the workgroup must call it (barriers).
+template <bool INV, int LM>
+__device__ __forceinline__ void r8_stages(double2 *ln, int t, const double2 *tw, double2 (&x)[8]) {
+  using G = R8<LM>;
+  if (G::C > 0) {                     // pre-stage: 8 / 2^C transforms of radix 2^C on this thread's eight neighbouring slots
+#pragma unroll
+    for (int r = 0; r < 8; ++r) x[r] = ln[pad8(8 * t) + r];
+    if (G::C == 1) {
+#pragma unroll
+      for (int m = 0; m < 8; m += 2) { const double2 a = x[m], b = x[m + 1]; x[m] = cadd(a, b); x[m + 1] = csub(a, b); }
+    } else {
+#pragma unroll
+      for (int m = 0; m < 8; m += 4) {
+        const double2 t0 = cadd(x[m], x[m + 2]), t1 = csub(x[m], x[m + 2]), t2 = cadd(x[m + 1], x[m + 3]), d = csub(x[m + 1], x[m + 3]);
+        const double2 t3 = INV ? make_double2(-d.y, d.x) : make_double2(d.y, -d.x);
+        x[m] = cadd(t0, t2); x[m + 1] = cadd(t1, t3); x[m + 2] = csub(t0, t2); x[m + 3] = csub(t1, t3);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) ln[pad8(8 * t) + r] = x[r];
+    __syncthreads();
+  }
+#pragma unroll
+  for (int st = 0; st < G::A; ++st) {
+    const int lB = G::C + 3 * st, B = 1 << lB;            // slots between the butterfly's elements
+    const int j = t & (B - 1), base = ((t >> lB) << (lB + 3)) + j;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) x[r] = ln[pad8(base + (r << lB))];
+    if (lB > 0) {
+      const int step = G::M >> (lB + 3);                  // W_{8B}^m = tw[m step]
+#pragma unroll
+      for (int r = 1; r < 8; ++r) {
+        double2 w = tw[r * j * step];
+        if (INV) w.y = -w.y;
+        x[r] = cmul(x[r], w);
+      }
+    }
+    dft8<INV>(x);
+    if (st + 1 < G::A) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) ln[pad8(base + (r << lB))] = x[r];
+      __syncthreads();
+    }
+  }
+}
+
+// x backward: recv blocks -> rows j0 .. j0+L-1 of plane k0+kc (unnormalised C2R); L M/8 threads.  The merge step of the C2R runs on
+// the way in: the thread that fetches X[kx] and X[M - kx] leaves both Z[kx] and Z[M - kx] -- every element of the blocks is read once.
+// Workgroups are persistent: the launch holds as many as are resident at once (LDS: four of 256 threads per CU) and each walks
+// items (row group, level) vb = blockIdx.x, + gridDim.x, ...; the loads of the next item are issued before the stages of the
+// current one.  (All workgroups of a launch start together, and with one item each they also gathered, transformed and stored
+// together: the three phases added up -- 0.056 + 0.037 + 0.026 ms of 0.152 at 1024 x 64 x 512, profiles/r05/xbwd_phase_ablation.txt.)
 template <int LM>
-__global__ __launch_bounds__(xthreads(LM)) void fftx_bwd_unpack_kernel(XArgs q, const double2 *__restrict__ recv, const double2 *__restrict__ twM,
-                                                             const double2 *__restrict__ twN, double *__restrict__ p) {
+__global__ __launch_bounds__(512) void fftx_bwd_r8_kernel(XArgs q, const double2 *__restrict__ recv, const double2 *__restrict__ twM,
+                                                          const double2 *__restrict__ twN, double *__restrict__ p) {
+  using G = R8<LM>;
+  constexpr int M = G::M, TPL = G::TPL, LP = G::LP;
   extern __shared__ double2 lds[];
-  constexpr int M = 1 << LM, NTH = xthreads(LM);
-  double2 *a, *b, *tw; int *dmap;
-  x_lds<LM>(q, lds, a, b, tw, dmap, twM);
-  __syncthreads();
   const int tid = threadIdx.x, L = 1 << q.lL;
-  const int j0 = blockIdx.x << q.lL, kc = blockIdx.y, k = q.k0 + kc;
-  for (int wi = tid; wi < (q.nkx << q.lL); wi += NTH) {      // gather X[0..M] (the pitch holds M + 1 elements)
-    const int kx = wi >> q.lL, l = wi & (L - 1);
-    const int s_ = dmap[kx], kxl = kx - s_ * q.cx;
-    b[l * q.MP + pad(kx)] = recv[(((size_t)s_ * q.nzc + kc) * q.cx + kxl) * q.nyl + j0 + l];
-  }
-  __syncthreads();
-  // merge: Z[kx] = (X[kx] + conj(X[M-kx])) + i e^{+2 pi i kx/N} (X[kx] - conj(X[M-kx])), kx = 0..M-1
-  for (int wi = tid; wi < (M << q.lL); wi += NTH) {
-    const int l = wi >> LM, kx = wi & (M - 1);
-    const double2 *xl = b + l * q.MP;
-    const double2 xk = xl[pad(kx)], xc = cconj(xl[pad(M - kx)]);
-    const double2 s = cadd(xk, xc), d = csub(xk, xc);
-    const double2 w = cconj(twN[kx]);
-    const double2 wd = cmul(w, d);                            // i w d = (-wd.y, wd.x)
-    a[l * q.MP + pad(kx)] = make_double2(s.x - wd.y, s.y + wd.x);
-  }
-  __syncthreads();
-  double2 *z = fft_lines<true, LM, NTH>(a, b, tw, q.MP, L);
-  for (int wi = tid; wi < (M << q.lL); wi += NTH) {
-    const int l = wi >> LM, n = wi & (M - 1);
-    double2 *row = reinterpret_cast<double2 *>(p + q.sz * (long)(k + HZ) + (long)q.sy * (j0 + l + HY));
-    row[n] = z[l * q.MP + pad(n)];
+  const unsigned gx = (unsigned)(q.nyl >> q.lL), nitems = gx * (unsigned)q.nzc, nwg = gridDim.x;
+  // item -> (row group, level of the chunk): XCD c (workgroups b % 8 == c) walks a contiguous run of (level, row group) pairs, so
+  // that row groups sharing 128-B lines of the blocks (L = 4: runs of 64 B) meet in one L2
+  auto decode = [&](unsigned vb, int &j0, int &kc) {
+    unsigned v = vb;
+    if ((nitems & 7u) == 0 && (nwg & 7u) == 0) v = (vb & 7u) * (nitems >> 3) + (vb >> 3);
+    kc = (int)(v / gx);
+    j0 = (int)(v - (unsigned)kc * gx) << q.lL;
+  };
+  auto src = [&](int kx, int l, int j0, int kc) {
+    const int s_ = (int)__umulhi((unsigned)kx, q.cxmul), kxl = kx - s_ * q.cx;
+    return recv[(((size_t)s_ * q.nzc + kc) * q.cx + kxl) * q.nyl + j0 + l];
+  };
+  // pairs (kx, M - kx), kx = 0 .. M/2 (kx = 0 pairs X[0] with X[M]; kx = M/2 with itself), l fastest: runs of L complex in the blocks
+  constexpr int IT = (M / 2) / TPL;      // = 4 passes of all threads, then the L pairs kx = M/2
+  const int lg = tid & (L - 1), pi0 = tid >> q.lL;      // gather: line and first pair of this thread
+  const int l = tid / TPL, t = tid - l * TPL;           // stages: line and thread of the line
+  // the stages' twiddles from LDS and the merge's in registers: a load from memory behind the prefetch below would wait for it
+  double2 *tws = lds + (LP << q.lL);
+  for (int n = tid; n < M; n += TPL << q.lL) tws[n] = twM[n];
+  double2 wn[IT];
+#pragma unroll
+  for (int it = 0; it < IT; ++it) wn[it] = cconj(twN[pi0 + it * TPL]);
+  double2 xa[IT], xb[IT], xh = make_double2(0., 0.);
+  auto fetch = [&](unsigned vb) {
+    int j0, kc;
+    decode(vb, j0, kc);
+#pragma unroll
+    for (int it = 0; it < IT; ++it) { const int kx = pi0 + it * TPL; xa[it] = src(kx, lg, j0, kc); xb[it] = src(M - kx, lg, j0, kc); }
+    if (tid < L) xh = src(M / 2, tid, j0, kc);
+  };
+  unsigned vb = blockIdx.x;
+  if (vb < nitems) fetch(vb);
+  for (; vb < nitems; vb += nwg) {
+    {
+      double2 *ln = lds + lg * LP;
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const int kx = pi0 + it * TPL;
+        // Z[kx] = (X[kx] + conj X[M-kx]) + i e^{+2 pi i kx/N} (X[kx] - conj X[M-kx]);  Z[M-kx]: s -> conj s, i w d -> -conj(i w d)
+        const double2 xc = cconj(xb[it]);
+        const double2 s_ = cadd(xa[it], xc), d = csub(xa[it], xc);
+        const double2 wd = cmul(wn[it], d);                                      // i w d = (-wd.y, wd.x)
+        ln[pad8(G::place(kx))] = make_double2(s_.x - wd.y, s_.y + wd.x);
+        if (kx > 0) ln[pad8(G::place(M - kx))] = make_double2(s_.x + wd.y, wd.x - s_.y);
+      }
+      if (tid < L) lds[tid * LP + pad8(G::place(M / 2))] = make_double2(2. * xh.x, -2. * xh.y);      // w = i: Z = 2 conj X
+    }
+    __syncthreads();
+    if (vb + nwg < nitems) fetch(vb + nwg);      // in flight while this item is transformed
+    int j0, kc;
+    decode(vb, j0, kc);
+    double2 x[8];
+    r8_stages<true, LM>(lds + l * LP, t, tws, x);
+    double2 *row = reinterpret_cast<double2 *>(p + q.sz * (long)(q.k0 + kc + HZ) + (long)q.sy * (j0 + l + HY));
+#pragma unroll
+    for (int r = 0; r < 8; ++r) row[t + r * TPL] = x[r];
+    __syncthreads();                             // the last stage's reads are done before the next item is placed
   }
 }
 
@@ -508,6 +650,7 @@ static size_t x_lds_bytes(const udc_handle *h, int L) {
   const int M = h->g.nx / 2;
   return (size_t)2 * L * padded(M + 1) * 16 + (size_t)M * 16 + (size_t)h->cx * h->cfg.nranks * 4;
 }
+static size_t r8_lds_bytes(int M, int L) { return ((size_t)L * (M + M / 8 + M / 64 + 1) + M) * 16; }      // lines + the stages' twiddles
 static size_t y_lds_bytes(const udc_handle *h, int C) { return (size_t)2 * C * padded(h->jtot) * 16 + (size_t)h->jtot * 16; }
 
 #define FFT_DISPATCH(LMV, CALL)                                                        \
@@ -556,11 +699,11 @@ int fft_fused_init(udc_handle *h) {
   }
   const int ldsx = (int)x_lds_bytes(h, L), ldsy = (int)y_lds_bytes(h, C);
   if (ldsx > 160 * 1024 || ldsy > 160 * 1024) { h->fft_fused = false; return 0; }
+  if (M == 1024) HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(fftx_bwd_r8_kernel<10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)r8_lds_bytes(M, 4)));
   const int lmx = ilog2(M), lmy = ilog2(ny);
   if (ldsx > 65536) {
     FFT_DISPATCH(lmx, HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(fftx_fwd_pack_kernel<LM, false>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsx));
-                      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(fftx_fwd_pack_kernel<LM, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsx));
-                      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(fftx_bwd_unpack_kernel<LM>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsx)))
+                      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(fftx_fwd_pack_kernel<LM, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsx)))
   }
   if (ldsy > 65536) {
     FFT_DISPATCH(lmy, HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(ffty_fwd_unpack_kernel<LM>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsy));
@@ -572,7 +715,8 @@ int fft_fused_init(udc_handle *h) {
 static XArgs xargs(const udc_handle *h, int k0, int nzc) {
   const Geo &g = h->g;
   const int M = g.nx / 2;
-  return XArgs{g.nx, M, padded(M + 1), g.ny, g.py, g.sy, g.sz, h->nkx, h->cx, h->cfg.nranks, k0, nzc, ilog2(h->fft_L), 0};
+  return XArgs{g.nx, M, padded(M + 1), g.ny, g.py, g.sy, g.sz, h->nkx, h->cx, h->cfg.nranks, k0, nzc, ilog2(h->fft_L), 0,
+               (unsigned)((1ULL << 32) / (unsigned long long)h->cx + 1ULL)};
 }
 static YArgs yargs(const udc_handle *h, int k0, int nzc) {
   return YArgs{h->jtot, padded(h->jtot), h->g.ny, ilog2(h->g.ny), h->cx, h->cfg.nranks, k0, nzc, h->fft_C};
@@ -599,12 +743,25 @@ int fft_x_fwd_pack(udc_handle *h, int k0, int nzc, double *send, int g0, int g1)
   HIP_OK(hipGetLastError());
   return 0;
 }
+// rows per workgroup of the radix-8 x kernel: as many as 256 threads hold (512 for lines of 1024 complex)
+static int r8_rows(const udc_handle *h) {
+  const int tpl = h->g.nx / 16, ntmax = tpl * 4 > 256 ? tpl * 4 : 256;
+  int L = ntmax / tpl;
+  if (L > 16) L = 16;
+  while (L > 1 && h->g.ny % L) L >>= 1;
+  return L;
+}
 int fft_x_bwd_unpack(udc_handle *h, int k0, int nzc, const double *recv) {
-  const XArgs q = xargs(h, k0, nzc);
+  XArgs q = xargs(h, k0, nzc);
   const double2 *tw = reinterpret_cast<const double2 *>(h->fft_tw);
-  const dim3 gr((unsigned)(q.nyl >> q.lL), (unsigned)nzc);
-  const size_t lds = x_lds_bytes(h, h->fft_L);
-  FFT_DISPATCH(ilog2(q.M), hipLaunchKernelGGL(fftx_bwd_unpack_kernel<LM>, gr, dim3(xthreads(LM)), lds, h->stream, q, reinterpret_cast<const double2 *>(recv),
+  const int L = r8_rows(h), tpl = q.M / 8;
+  q.lL = ilog2(L);
+  const size_t lds = r8_lds_bytes(q.M, L);
+  const unsigned items = (unsigned)(q.nyl >> q.lL) * (unsigned)nzc;
+  // persistent workgroups: as many as are resident at once (LDS, 2048 threads per CU)
+  const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(160 * 1024 / lds, 2048 / (size_t)(L * tpl)));
+  const dim3 gr(std::min(items, 256u * per_cu));
+  FFT_DISPATCH(ilog2(q.M), hipLaunchKernelGGL(fftx_bwd_r8_kernel<LM>, gr, dim3(L * tpl), lds, h->stream, q, reinterpret_cast<const double2 *>(recv),
                                               tw, tw + q.M, h->fields[UDC_P]))
   HIP_OK(hipGetLastError());
   return 0;

@@ -153,7 +153,8 @@ struct Switches {
   int scalar_pair = 1;       // UDC_SCALAR_PAIR=0: thl and qt swept one by one
   // tridiagonal solve
   int thomas = -1;           // UDC_THOMAS=0: the streaming kernel (one thread per mode) instead of register-resident segments
-  int thomas_pair = 1;       // UDC_THOMAS_PAIR=0: one GPU: rows ky and ny - ky not solved together
+  int thomas_pair = 1;       // UDC_THOMAS_PAIR=0: rows ky and ny - ky not solved together (one GPU: rows of spec; slab ranks: mirrored runs of a line)
+  int thomas_mirror_min = 256;      // slab ranks: shortest line solved in mirrored pairs (UDC_THOMAS_MIRROR_MIN; tests set 16)
   // tuning knobs (0 / -1 = the library's own choice)
   int mom_kc = 0, scalar_kc = 0, closure_percu = 0, xpad = -1, spec_pad = -1;
   int fft_l = 0, fft_c = 0, nat_l = 0, nat_c = 0, nat_reg = 1, slab_yreg = 1;

@@ -186,10 +186,18 @@ __global__ __launch_bounds__(64) void thomas_kernel(int nmodes, int nz, double s
 // bit for bit (pois_init), so rows ky and ny - ky have the same matrix: the workgroup takes the same eight kx of both rows, and the
 // pivot tables -- a third of the solve's traffic -- are read for one of them only (48 -> 40 B per complex mode and level); rows 0
 // and ny / 2 are their own mirror images and run with the second system switched off.
-template <int SL, int NT, int W, int NP>
+// MIR (NP = 2, the slab ranks' layout specB[k][kx_l][y], round 5): the mirror image of the run y = 8 b .. 8 b + 7 of a line is the
+// run ny - 8 b - 7 .. ny - 8 b -- contiguous, lane-reversed and one element off the 128-B alignment.  A workgroup takes block b of
+// line kx_l as system 0 and that run as system 1 (lane mm <-> y' = ny - y), so that here too the tables are read for one row of each
+// pair; blocks b = 0 .. ny/16 - 1 cover y < ny/2 and their images, lane 0 of block 0 (y = 0) has no partner, and the modes y = ny/2
+// of eight lines share one more workgroup (one system, every lane on its own line and table block).  The straddled 128-B line of a
+// mirrored run is shared with the neighbouring block of the same line: the workgroups are dealt to the XCDs in contiguous runs (as
+// xcd_tile does; the grid is padded to a multiple of eight for that), so that it is fetched once per L2.
+template <int SL, int NT, int W, int NP, bool MIR>
 __global__ __launch_bounds__(NT, W) void thomas_reg_kernel(int nmodes, int nz, double scale,
     const double *__restrict__ ev, const double *__restrict__ tri, double btopD,
     const double *__restrict__ ztab, double2 *__restrict__ x, int nkb, int ny) {
+  static_assert(!MIR || NP == 2, "the mirrored layout is a paired solve");
   constexpr int M = ZB;                    // modes per workgroup and system = lanes per segment
   constexpr int NS = NT / M;               // segment slots
   __shared__ double sP[2][NS][M];
@@ -198,15 +206,48 @@ __global__ __launch_bounds__(NT, W) void thomas_reg_kernel(int nmodes, int nz, d
   const int nseg = (nz + SL - 1) / SL;     // segments that hold a level (<= NS)
   // block of eight modes of system 0 (whose tables are read) and of system 1
   int blk0 = blockIdx.x, blk1 = blockIdx.x;
-  bool on1 = false;
-  if (NP == 2) {
+  bool on1 = false;                        // this lane solves a second system
+  int mo = 0;                              // this lane's mode of system 0
+  bool mok = true;
+  int tlane = mm;                          // lane's entry within its table block, and how many table blocks it lies beyond blk0
+  long tskip = 0, xskip = 0;               // (MIR, the workgroups of the modes y = ny/2: doubles / elements from blk0's)
+  long base1 = 0;                          // MIR: first element (level 0) of system 1's run
+  int lane1 = mm;                          // lane's element within system 1's run
+  if (NP == 2 && !MIR) {
     const int kyh = blockIdx.x / nkb, kxb = blockIdx.x - kyh * nkb;
     on1 = kyh != 0 && 2 * kyh != ny;
     blk1 = on1 ? (ny - kyh) * nkb + kxb : blk0;
   }
-  const int mo = blk0 * M + mm;
-  const bool mok = mo < nmodes;
-  const int moc = mok ? mo : nmodes - 1;
+  if (MIR) {
+    unsigned v = blockIdx.x;
+    v = (v & 7u) * (gridDim.x >> 3) + (v >> 3);                                         // (gridDim.x is a multiple of eight)
+    const int lines = nmodes / ny;
+    const unsigned npair = (unsigned)lines * (unsigned)nkb;                             // nkb = ny/16 paired blocks per line
+    if (v >= npair + (unsigned)((lines + 7) >> 3)) return;                              // padding
+    if (v < npair) {
+      const int kxl = (int)(v / (unsigned)nkb), b = (int)(v - (unsigned)kxl * nkb);
+      const int y = 8 * b + mm;
+      blk0 = kxl * (ny >> 3) + b;
+      mo = blk0 * M + mm;
+      xskip = mm;
+      on1 = y >= 1;
+      base1 = (long)kxl * ny + (ny - 8 * b - 7);
+      lane1 = 7 - (y >= 1 ? mm : 1);       // (y = 0: its neighbour's address, loaded and never stored)
+    } else {
+      const int l0_ = 8 * (int)(v - npair), kxl = min(l0_ + mm, lines - 1);
+      mok = l0_ + mm < lines;
+      blk0 = (int)(((long)l0_ * ny + (ny >> 1)) >> 3);
+      mo = kxl * ny + (ny >> 1);
+      tlane = 0;
+      tskip = (long)(kxl - l0_) * (ny >> 3) * (long)(nz - 1) * M;
+      xskip = (long)(kxl - l0_) * ny;
+    }
+  } else {
+    mo = blk0 * M + mm;
+    mok = mo < nmodes;
+    xskip = (mok ? mo : nmodes - 1) - blk0 * M;
+  }
+  const int moc = mok ? mo : (MIR ? mo : nmodes - 1);
   const double *a = tri, *b = tri + (nz + 2), *c = tri + 2 * (nz + 2);
   const size_t st = (size_t)nmodes;
   const int l0 = seg * SL;
@@ -217,9 +258,11 @@ __global__ __launch_bounds__(NT, W) void thomas_reg_kernel(int nmodes, int nz, d
   const char *cb_ = zb_ + ntab * sizeof(double);
   char *xb_[NP];
   xb_[0] = reinterpret_cast<char *>(x + (size_t)blk0 * M);
-  if (NP == 2) xb_[NP - 1] = reinterpret_cast<char *>(x + (size_t)blk1 * M);
-  const unsigned zoff = (unsigned)(((size_t)l0 * M + mm) * sizeof(double));
-  const unsigned xoff = (unsigned)(((size_t)l0 * st + (size_t)(moc - blk0 * M)) * sizeof(double2));
+  if (NP == 2) xb_[NP - 1] = reinterpret_cast<char *>(MIR ? x + base1 : x + (size_t)blk1 * M);
+  const unsigned zoff = (unsigned)(((size_t)l0 * M + (size_t)tlane + (size_t)tskip) * sizeof(double));
+  unsigned xo_[NP];                        // lane offsets: the same for both systems unless the second one is a mirrored run
+  xo_[0] = (unsigned)(((size_t)l0 * st + (size_t)xskip) * sizeof(double2));
+  if (NP == 2) xo_[NP - 1] = MIR ? (unsigned)(((size_t)l0 * st + (size_t)lane1) * sizeof(double2)) : xo_[0];
   double2 t[NP][SL];
   double g[SL], cz[SL], aj[SL];
   double2 xt[NP];                          // (x s) of the top level, kept by its owner
@@ -231,7 +274,7 @@ __global__ __launch_bounds__(NT, W) void thomas_reg_kernel(int nmodes, int nz, d
 #pragma unroll
     for (int j = 0; j < SL; ++j) {
 #pragma unroll
-      for (int s = 0; s < NP; ++s) t[s][j] = *reinterpret_cast<const double2 *>(xb_[s] + (size_t)j * st * sizeof(double2) + xoff);
+      for (int s = 0; s < NP; ++s) t[s][j] = *reinterpret_cast<const double2 *>(xb_[s] + (size_t)j * st * sizeof(double2) + xo_[s]);
       g[j] = *reinterpret_cast<const double *>(zb_ + (size_t)j * M * sizeof(double) + zoff);
       cz[j] = *reinterpret_cast<const double *>(cb_ + (size_t)j * M * sizeof(double) + zoff);
       aj[j] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(a) + j * sizeof(double) + aoff);
@@ -242,14 +285,14 @@ __global__ __launch_bounds__(NT, W) void thomas_reg_kernel(int nmodes, int nz, d
       const int lev = l0 + j;
 #pragma unroll
       for (int s = 0; s < NP; ++s)
-        t[s][j] = lev < nz ? *reinterpret_cast<const double2 *>(xb_[s] + (size_t)j * st * sizeof(double2) + xoff) : make_double2(0., 0.);
+        t[s][j] = lev < nz ? *reinterpret_cast<const double2 *>(xb_[s] + (size_t)j * st * sizeof(double2) + xo_[s]) : make_double2(0., 0.);
       const bool rec = lev < nz - 1;       // levels 1 .. nz-1 of solmpj take part in the recurrences
       g[j] = rec ? *reinterpret_cast<const double *>(zb_ + (size_t)j * M * sizeof(double) + zoff) : 1.;
       cz[j] = rec ? *reinterpret_cast<const double *>(cb_ + (size_t)j * M * sizeof(double) + zoff) : 0.;
       aj[j] = a[min(lev + 1, nz)];
     }
   }
-  const double *zt = ztab + (size_t)blk0 * (size_t)(nz - 1) * M + mm;
+  const double *zt = reinterpret_cast<const double *>(zb_ + zoff) - (size_t)l0 * M;      // this lane's column of the pivot table
   const bool own_top = l0 <= nz - 1 && nz - 1 < l0 + SL;
   double zl = 0., etop = 0.;
   if (own_top) { zl = zt[(size_t)(nz - 2) * M]; etop = ev[moc]; }
@@ -346,7 +389,7 @@ __global__ __launch_bounds__(NT, W) void thomas_reg_kernel(int nmodes, int nz, d
 #pragma unroll
     for (int s = 0; s < NP; ++s) {
       v[s].x = __builtin_fma(cz[j], v[s].x, t[s][j].x); v[s].y = __builtin_fma(cz[j], v[s].y, t[s][j].y);
-      if (mok && l0 + j < nz && (s == 0 || on1)) *reinterpret_cast<double2 *>(xb_[s] + (size_t)j * st * sizeof(double2) + xoff) = v[s];
+      if (l0 + j < nz && mok && (s == 0 || on1)) *reinterpret_cast<double2 *>(xb_[s] + (size_t)j * st * sizeof(double2) + xo_[s]) = v[s];
     }
   }
 }
@@ -360,31 +403,40 @@ static bool thomas_wants_lds(const udc_handle *h, long nmodes, int nz) {      //
 }
 static size_t ztab_doubles(long nmodes, int nz) { return (size_t)((nmodes + ZB - 1) / ZB) * ZB * (size_t)(nz > 1 ? nz - 1 : 1); }
 
-template <int NT, int W, int NP>
+template <int NT, int W, int NP, bool MIR>
 static void launch_thomas_reg(udc_handle *h, long nmodes, int nz, double scale, const double *ev, const double *ztab, double2 *x, int nkb, int ny) {
-  const unsigned blocks = NP == 2 ? (unsigned)((ny / 2 + 1) * nkb) : (unsigned)((nmodes + ZB - 1) / ZB);
-  hipLaunchKernelGGL((thomas_reg_kernel<8, NT, (W > NT / 256 ? W : NT / 256), NP>), dim3(blocks), dim3(NT), 0, h->stream,
+  const unsigned blocks = MIR ? (unsigned)(((nmodes / ny) * nkb + (nmodes / ny + 7) / 8 + 7) / 8 * 8) : (NP == 2 ? (unsigned)((ny / 2 + 1) * nkb) : (unsigned)((nmodes + ZB - 1) / ZB));
+  hipLaunchKernelGGL((thomas_reg_kernel<8, NT, (W > NT / 256 ? W : NT / 256), NP, MIR>), dim3(blocks), dim3(NT), 0, h->stream,
                      (int)nmodes, nz, scale, ev, h->tri, h->btopD, ztab, x, nkb, ny);
 }
 
 // nkb, pair_ny > 0: the caller's modes are spec[k][ky][kx] rows of nkb blocks of eight, ky = 0 .. pair_ny - 1 (one GPU): rows ky and
-// ny - ky are solved together (UDC_THOMAS_PAIR=0: not)
+// ny - ky are solved together (UDC_THOMAS_PAIR=0: not).  mirror_ny > 0: the caller's modes are lines specB[k][kx_l][y] of mirror_ny
+// elements (the slab ranks): y and ny - y of a line are solved together (thomas_reg_kernel, MIR).
 static int launch_thomas(udc_handle *h, bool blocked, long nmodes, int nz, double scale, const double *ev, const double *ztab, double2 *x,
-                         int nkb = 0, int pair_ny = 0) {
+                         int nkb = 0, int pair_ny = 0, int mirror_ny = 0) {
   if (blocked) {
     // eight levels per thread; workgroups of 8 x ceil(nz / 8) threads.  Measured (profiles/r04/thomas_variants_ab.txt, thomas_pair_ab.txt):
     // 16 levels per thread spill, 4 leave too little in flight per thread; compiled for 3 waves per SIMD (2 with two systems per thread)
     const int nt = 8 * ((nz + 7) / 8);
-    const bool pair = pair_ny > 0 && h->sw.thomas_pair && nt <= 512;      // (two systems per thread do not fit 1024-thread workgroups' 128 VGPRs)
-#define UDC_TR(Wv, NPv)                                                                                      \
-    do {                                                                                                     \
-      if (nt <= 64) launch_thomas_reg<64, Wv, NPv>(h, nmodes, nz, scale, ev, ztab, x, nkb, pair_ny);         \
-      else if (nt <= 128) launch_thomas_reg<128, Wv, NPv>(h, nmodes, nz, scale, ev, ztab, x, nkb, pair_ny);  \
-      else if (nt <= 256) launch_thomas_reg<256, Wv, NPv>(h, nmodes, nz, scale, ev, ztab, x, nkb, pair_ny);  \
-      else if (nt <= 512) launch_thomas_reg<512, Wv, NPv>(h, nmodes, nz, scale, ev, ztab, x, nkb, pair_ny);  \
-      else launch_thomas_reg<1024, Wv, NPv>(h, nmodes, nz, scale, ev, ztab, x, nkb, pair_ny);                \
+    const bool pairs_fit = h->sw.thomas_pair && nt <= 512;      // (two systems per thread do not fit 1024-thread workgroups' 128 VGPRs)
+    const bool pair = pair_ny > 0 && pairs_fit;
+    // measured (profiles/r05/thomas_mirror_ab.txt, one rank's spectral slab of 1024 x 512 x 512 on eight ranks): lines of 512 -> 210 us
+    // against 228 unpaired; lines of 64 (the forced-slab stand-in 1024 x 64 x 512) -> 251 against 206: the straddled lines of the
+    // mirrored runs are fetched twice there (PMC) -- paired from lines of 256 on
+    const bool mirror = mirror_ny >= h->sw.thomas_mirror_min && mirror_ny >= 16 && mirror_ny % 16 == 0 && nmodes % mirror_ny == 0 && pairs_fit;
+#define UDC_TR(Wv, NPv, MIRv)                                                                                      \
+    do {                                                                                                           \
+      if (nt <= 64) launch_thomas_reg<64, Wv, NPv, MIRv>(h, nmodes, nz, scale, ev, ztab, x, nkb, ny_);             \
+      else if (nt <= 128) launch_thomas_reg<128, Wv, NPv, MIRv>(h, nmodes, nz, scale, ev, ztab, x, nkb, ny_);      \
+      else if (nt <= 256) launch_thomas_reg<256, Wv, NPv, MIRv>(h, nmodes, nz, scale, ev, ztab, x, nkb, ny_);      \
+      else if (nt <= 512) launch_thomas_reg<512, Wv, NPv, MIRv>(h, nmodes, nz, scale, ev, ztab, x, nkb, ny_);      \
+      else launch_thomas_reg<1024, Wv, NPv, MIRv>(h, nmodes, nz, scale, ev, ztab, x, nkb, ny_);                    \
     } while (0)
-    if (pair) UDC_TR(2, 2); else UDC_TR(3, 1);
+    int ny_ = pair_ny;
+    if (mirror) { ny_ = mirror_ny; nkb = mirror_ny / 16; UDC_TR(2, 2, true); }
+    else if (pair) UDC_TR(2, 2, false);
+    else UDC_TR(3, 1, false);
 #undef UDC_TR
     return 0;
   }
@@ -1027,7 +1079,7 @@ int k_poisson_solve_slab(udc_handle *h) {
   {
     PROF(h, "thomas");
     if (launch_thomas(h, h->thomas_lds_slab, nmodes, g.nz, 1. / ((double)g.nx * (double)ny), h->ev_slab, h->ztab_slab,
-                      reinterpret_cast<double2 *>(h->specB))) return 1;
+                      reinterpret_cast<double2 *>(h->specB), 0, 0, ny)) return 1;
     HIP_OK(hipGetLastError());
   }
   {
