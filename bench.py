@@ -440,12 +440,12 @@ def single_gpu_leg(nx, ny, nz, dt, args, device, ms_n, poisson_n, poisson_sub_n,
 # slab substep's overlap features taken back one group at a time.  The line says which rung produced the number.
 LADDER = [
     ("defaults", {}),
-    ("ghost rows and sweeps in line", {"UDC_HALO_OVERLAP": "0", "UDC_MOM_PIPE": "0", "UDC_INT_PIPE": "0"}),
-    ("... and the transposes in one piece", {"UDC_HALO_OVERLAP": "0", "UDC_MOM_PIPE": "0", "UDC_INT_PIPE": "0", "UDC_A2A_CHUNKS": "1"}),
+    ("ghost rows and sweeps in line", {"UDC_HALO_OVERLAP": "0", "UDC_MOM_PIPE": "0"}),
+    ("... and the transposes in one piece", {"UDC_HALO_OVERLAP": "0", "UDC_MOM_PIPE": "0", "UDC_A2A_CHUNKS": "1"}),
     ("... and rocFFT + transpose kernels instead of the fused line transforms",
-     {"UDC_HALO_OVERLAP": "0", "UDC_MOM_PIPE": "0", "UDC_INT_PIPE": "0", "UDC_A2A_CHUNKS": "1", "UDC_FFT_FUSED": "0"}),
+     {"UDC_HALO_OVERLAP": "0", "UDC_MOM_PIPE": "0", "UDC_A2A_CHUNKS": "1", "UDC_FFT_FUSED": "0"}),
     ("... and RCCL without peer-to-peer transport (through host memory: degraded links, a number of last resort)",
-     {"UDC_HALO_OVERLAP": "0", "UDC_MOM_PIPE": "0", "UDC_INT_PIPE": "0", "UDC_A2A_CHUNKS": "1", "UDC_FFT_FUSED": "0", "NCCL_P2P_DISABLE": "1"}),
+     {"UDC_HALO_OVERLAP": "0", "UDC_MOM_PIPE": "0", "UDC_A2A_CHUNKS": "1", "UDC_FFT_FUSED": "0", "NCCL_P2P_DISABLE": "1"}),
 ]
 
 
@@ -785,6 +785,53 @@ def main():
         core.poisson()
     poisson_ms = allmax(time_loop(core, core.poisson, 20, barrier))
     heartbeat("poisson alone")
+    executed_plan = core.last_plan()
+    # What the exchanges did (slab layout only).  (i) the communicator's own account of itself; (ii) six more substeps with every
+    # exchange counted and timed by a pair of events on the stream it runs on: bytes per peer, and the rate one link saw during an
+    # all-to-all (every peer's block travels at once, so a block's bytes / the operation's time is the per-link rate); (iii) the same
+    # substeps with the exchanges switched off (udc_comm_dry_run: kernels only, results wrong -- this state is not used again):
+    # substep - that = the exchange time the overlap did NOT hide.
+    exchange = None
+    if executed_plan["slab_layout"]:
+        try:
+            nx_sub = 6
+            core.comm_stats(1)
+            for _ in range(nx_sub):
+                core.substep(rk, dt, True)
+                rk = rk % 3 + 1
+            barrier()
+            cs = core.comm_stats(2)
+            a2a_ms_op = cs["alltoall_ms"] / cs["alltoall_ops"] if cs["alltoall_ops"] else None
+            core.comm_dry_run(True)
+            for _ in range(3):
+                core.substep(rk, dt, True)
+                rk = rk % 3 + 1
+            n_dry = max(6, min(args.steps, 30))
+            barrier()
+            td0 = time.perf_counter()
+            for _ in range(n_dry):
+                core.substep(rk, dt, True)
+                rk = rk % 3 + 1
+            barrier()
+            dry_ms = allmax((time.perf_counter() - td0) / n_dry * 1e3)
+            core.comm_dry_run(False)
+            exchange = {
+                "alltoall_per_substep": cs["alltoall_ops"] / nx_sub, "alltoall_bytes_per_peer": int(cs["alltoall_bytes_per_peer"]),
+                "alltoall_bytes_sent_per_substep": int(cs["alltoall_bytes_sent"] / nx_sub),
+                "alltoall_ms_per_operation": round(a2a_ms_op, 5) if a2a_ms_op else None,
+                "alltoall_GBs_per_link": round(cs["alltoall_bytes_per_peer"] / (a2a_ms_op * 1e-3) / 1e9, 6) if a2a_ms_op else None,
+                "ghost_row_exchanges_per_substep": cs["ghost_row_exchanges"] / nx_sub,
+                "ghost_row_bytes_to_prev_per_substep": int(cs["ghost_row_bytes_to_prev"] / nx_sub),
+                "ghost_row_bytes_to_next_per_substep": int(cs["ghost_row_bytes_to_next"] / nx_sub),
+                "ghost_row_ms_per_substep": round(cs["ghost_row_ms"] / nx_sub, 5),
+                "allreduce_per_substep": cs["allreduce_ops"] / nx_sub,
+                "substep_ms_exchanges_off": round(dry_ms, 5),
+                "exposed_exchange_ms": round(elapsed / args.steps * 1e3 - dry_ms, 5),
+                "note": "rank 0's counters over 6 substeps after the timed region; times from event pairs on the exchange's own stream; "
+                        "exposed = timed substep - the same substep with every exchange a no-op (max over ranks)"}
+        except Exception as e:      # noqa: BLE001 (a side measurement)
+            exchange = {"error": repr(e)[:300]}
+        heartbeat("exchange account")
     # the same solve as the fused substep runs it (pup mode: the divergence of the stored predicted velocity, on the slab
     # path inside the x transform; projection fused with the RK3 update): substep time minus its non-Poisson kernels
     survey = table if table else prof          # (no warm-up: the timed region carried every marker)
@@ -893,11 +940,8 @@ def main():
                    "floor": "free (no wall function)" if args.no_floor else
                             "neutral log-law wall function (lbottom, BCbotm=3, z0=0.05)",
                    "grid": [nx, ny, nz], "decomposition": f"y-slabs x{world}", "dt": dt,
-                   **({"slab_order": {"ghost_rows_beside_compute": os.environ.get("UDC_HALO_OVERLAP", "1") != "0",
-                                      "momentum_sweep_pipelined_with_solve": os.environ.get("UDC_MOM_PIPE", "1") != "0",
-                                      "project_integrate_pipelined_with_solve": os.environ.get("UDC_INT_PIPE", "1") != "0",
-                                      "fused_line_transforms": os.environ.get("UDC_FFT_FUSED", "1") != "0",
-                                      "transpose_k_chunks": int(os.environ.get("UDC_A2A_CHUNKS", "4"))}} if world > 1 else {}),
+                   # the order the substeps ran in, as the library's planner decided it (udc_last_plan), not as the environment suggests
+                   "executed_plan": executed_plan,
                    "step": "one RK3 substep = one cell-update per cell"},
         "whole_substep_hbm_frac": round(392.0 * cells_local * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4),
         # the same on the bytes the kernels as built must move (sum of the per-kernel algorithmic bytes, launches per
@@ -911,6 +955,9 @@ def main():
         "kernels_note": {"marker_cost_ms_per_launch": round(marker_ms, 5), "surveyed_substeps": n_tab,
                          "sum_of_shares": round(sum(k["share"] for k in kernels.values()), 4)},
     }
+    if executed_plan["slab_layout"]:
+        out["rccl"] = core.comm_info()
+        out["exchange"] = exchange
     inv_ok = True
     if want_single:
         # rank 0's own one-GPU run of the SAME grid (single-slab code path), so that every N>1 line carries its strong-scaling

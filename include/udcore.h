@@ -95,6 +95,26 @@ int udc_version(void);
  * Fortran driver, torch.distributed in bench.py), then every rank calls udc_comm_init. */
 int udc_comm_unique_id(unsigned char id[128]);
 int udc_comm_init(udc_handle *h, const unsigned char id[128]);
+/* What the communicator says about itself (bench.py's N > 1 line echoes it): info[0] transport (0 none: one rank; 1 RCCL; 2, 3 the
+ * test transports of libudcore_test.so), [1] ncclCommCount, [2] ncclCommUserRank, [3] ncclCommCuDevice, [4] ncclGetVersion,
+ * [5] k-chunks of the two transposes, [6] ranks the handle was created for, [7] its rank.  Replaces nothing in the reference
+ * (2decomp-fft's decomp_2d_init prints its own layout, src/modstartup.f90:676). */
+int udc_comm_info(udc_handle *h, int info[8]);
+/* Exchange bookkeeping.  mode 1: reset the counters and time every exchange from now on with a pair of events on the stream it runs
+ * on; mode 0: read (waits for the device); mode 2: read and stop timing.  out[0] all-to-all operations, [1] bytes one of them sends
+ * to ONE peer, [2] bytes sent to other ranks by all of them, [3] their time on the communication stream (ms, sum); [4] ghost-row
+ * exchanges, [5] bytes sent to the previous rank, [6] to the next, [7] their time (ms, sum); [8] all-reduces, [9] doubles reduced. */
+int udc_comm_stats(udc_handle *h, int mode, double out[16]);
+/* on != 0: every exchange returns at once without moving anything -- the substep then costs what its kernels cost (results are wrong
+ * from there on: a timing device for bench.py's exposed-exchange figure, used on a state that is thrown away). */
+int udc_comm_dry_run(udc_handle *h, int on);
+/* The order the last fused substep ran in, as plan_substep decided it (udc_plan.h; DESIGN.md "order of a substep"): out[0] ghost rows
+ * folded into the kernels (single slab), [1] closure 0 folded / 1 edge rows first, rows travel beside the interior / 2 plain,
+ * [2] ekh written, [3] momentum sweep pipelined with the solve's k-chunks, [4] divergence inside the x transform, [5] vp's and
+ * [6] p's ghost row: 0 folded / 1 beside a sweep / 2 in line / 3 ahead of the pipelined sweep, [7] integration 0 one launch / 1 edge
+ * rows first, [8] um rotated, [9] um left aliased, [10] um materialised, [11] slab layout, [12] own line transforms on the slab path,
+ * [13] k-chunks of the transposes, [14] own forward half (one GPU), [15] own backward half (one GPU). */
+int udc_last_plan(udc_handle *h, int out[16]);
 #ifdef UDC_TEST_TRANSPORT
 /* Test transport, NOT part of libudcore.so: libudcore_test.so (same sources + -DUDC_TEST_TRANSPORT) adds it for the virtual-rank
  * tests.  P handles (cfg.nranks = P, rank = 0..P-1) inside ONE process on ONE device, each driven by its own host thread; ghost

@@ -128,6 +128,20 @@ def test_bench_line_of_a_multi_rank_run(n):
     assert inv["ok"] and inv["substeps"] == 6 and set(inv["max_rel_diff"]) == {"u0", "v0", "w0", "pres0"}, inv
     assert max(inv["max_rel_diff"].values()) <= 1e-9, inv
     assert d["ladder"]["rung"] == 0 and d["ladder"]["outcome"] == "ok" and len(d["ladder"]["attempts"]) == 1, d["ladder"]
+    # the line says what the communicator saw and what the exchanges cost (round 5): RCCL's own rank count where RCCL carried it
+    rc, ex, plan = d["rccl"], d["exchange"], d["config"]["executed_plan"]
+    assert rc["handle_nranks"] == n and rc["handle_rank"] == 0 and rc["transport"] == ("rccl" if how == "rccl" else "test: shared memory"), rc
+    if how == "rccl":
+        assert rc["nranks"] == n and rc["rank"] == 0 and rc["version"].count(".") == 2, rc
+    assert "error" not in ex, ex
+    nx_, ny_, nz_ = (int(v) for v in size.split("x"))
+    nch = rc["transpose_k_chunks"]
+    cx = -(-(nx_ // 2 + 1) // n)                      # modes per rank of the half spectrum
+    assert ex["alltoall_per_substep"] == 2 * nch and ex["alltoall_bytes_per_peer"] == 16 * (nz_ // nch) * cx * (ny_ // n), (ex, nch, cx)
+    assert ex["alltoall_bytes_sent_per_substep"] == 2 * nch * (n - 1) * ex["alltoall_bytes_per_peer"]
+    assert ex["ghost_row_exchanges_per_substep"] >= 4 and ex["ghost_row_bytes_to_prev_per_substep"] > 0 and ex["ghost_row_bytes_to_next_per_substep"] > 0
+    assert ex["alltoall_GBs_per_link"] > 0 and ex["substep_ms_exchanges_off"] > 0 and "exposed_exchange_ms" in ex
+    assert plan["slab_layout"] and plan["transpose_k_chunks"] == nch and plan["p_ghost_row"] != "folded", plan
 
 
 @pytest.mark.gpu

@@ -140,8 +140,7 @@ void udc_read_switches(Switches &sw) {
   sw.force_comm = env_int("UDC_FORCE_COMM", 0) != 0;
   sw.halo_overlap = env_int("UDC_HALO_OVERLAP", 1) != 0;
   sw.mom_pipe = env_int("UDC_MOM_PIPE", 1) != 0;
-  sw.int_pipe = env_int("UDC_INT_PIPE", 1) != 0;
-  sw.a2a_chunks = env_int("UDC_A2A_CHUNKS", 4);
+  sw.a2a_chunks = env_int("UDC_A2A_CHUNKS", 0);
   sw.fft_fused = env_int("UDC_FFT_FUSED", 1) != 0;
   sw.own_fwd = env_int("UDC_OWN_FWD", -1);
   sw.div_in_fft = env_int("UDC_DIV_IN_FFT", 1) != 0;
@@ -152,19 +151,11 @@ void udc_read_switches(Switches &sw) {
   sw.thomas = env_int("UDC_THOMAS", -1);
   sw.thomas_pair = env_int("UDC_THOMAS_PAIR", 1) != 0;
   sw.thomas_mirror_min = env_int("UDC_THOMAS_MIRROR_MIN", 256);
-  sw.mom_kc = env_int("UDC_MOM_KC", 0);
-  sw.scalar_kc = env_int("UDC_SCALAR_KC", 0);
-  sw.closure_percu = env_int("UDC_CLOSURE_PERCU", 0);
-  sw.xpad = env_int("UDC_XPAD", -1);
-  sw.spec_pad = env_int("UDC_SPEC_PAD", -1);
-  sw.fft_l = env_int("UDC_FFT_L", 0);
-  sw.fft_c = env_int("UDC_FFT_C", 0);
-  sw.nat_l = env_int("UDC_NAT_L", 0);
-  sw.nat_c = env_int("UDC_NAT_C", 0);
   sw.nat_reg = env_int("UDC_NAT_REG", 1) != 0;
   sw.slab_yreg = env_int("UDC_SLAB_YREG", 1) != 0;
 }
 
+static int create_on_device(const udc_config *cfg, udc_handle *h);
 extern "C" int udc_create(const udc_config *cfg, udc_handle **out) {
   if (!cfg || !out) { udc_set_error("udc_create: null argument"); return 1; }
   if (cfg->itot < 4 || cfg->jtot < 4 || cfg->ktot < 3) { udc_set_error("udc_create: grid too small"); return 1; }
@@ -180,16 +171,20 @@ extern "C" int udc_create(const udc_config *cfg, udc_handle **out) {
     udc_set_error("udc_create: no HIP device visible -- libudcore has no CPU fallback");
     return 1;
   }
+  // device < 0: the library deals the ranks round over the node's devices (one rank per GPU)
+  const int device = cfg->device >= 0 ? cfg->device : cfg->rank % ndev;
+  if (device >= ndev) { udc_set_error("udc_create: device index beyond the visible HIP devices"); return 1; }
   udc_handle *h = new udc_handle();
+  h->device = device;
+  // whatever fails from here on: the handle, its stream and what it has allocated so far go back (udc_destroy takes a half-built handle)
+  if (create_on_device(cfg, h)) { udc_destroy(h); return 1; }
+  *out = h;
+  return 0;
+}
+
+static int create_on_device(const udc_config *cfg, udc_handle *h) {
   udc_read_switches(h->sw);
   h->cfg = *cfg;
-  // device < 0: the library deals the ranks round over the node's devices (one rank per GPU)
-  h->device = cfg->device >= 0 ? cfg->device : cfg->rank % ndev;
-  if (h->device >= ndev) {
-    udc_set_error("udc_create: device index beyond the visible HIP devices");
-    delete h;
-    return 1;
-  }
   HIP_OK(hipSetDevice(h->device));
   HIP_OK(hipStreamCreate(&h->stream));
   Geo &g = h->g;
@@ -204,9 +199,8 @@ extern "C" int udc_create(const udc_config *cfg, udc_handle **out) {
   // row stride: rows of a power-of-two nx put every row of a tile column on the same few L2 channels and sets, and the
   // stencil kernels' halo lines evict each other (closure at 1024x512x512: 2.2 x its algorithmic reads, 3.2 -> 2.55 ms with
   // the padding; no effect at nx = 256).  16 doubles (one 128-B line) of padding after the nx cells of a row for
-  // nx >= 512 and a multiple of 256; never read (x is periodic by index wrap).  UDC_XPAD overrides (0 = none).
-  int xpad = (g.nx >= 512 && g.nx % 256 == 0) ? 16 : 0;
-  if (h->sw.xpad >= 0) xpad = h->sw.xpad;
+  // nx >= 512 and a multiple of 256 (udc_tuning.h); never read (x is periodic by index wrap).
+  const int xpad = tune::row_padding(g.nx);
   g.sy = g.nx + xpad; g.sz = (long)g.sy * g.py; g.n = g.sz * g.pz;
   h->p = Params{cfg->numol, cfg->prandtlmoli, cfg->prandtli, cfg->c_vreman, cfg->csz,
                 cfg->uinf, cfg->vinf, cfg->sgs, cfg->bctopm, cfg->lbottom ? 1 : 0, cfg->z0};
@@ -262,7 +256,6 @@ extern "C" int udc_create(const udc_config *cfg, udc_handle **out) {
     for (int q = 0; q < 4; ++q) HIP_OK(hipMalloc(&h->halo_buf[q], sizeof(double) * h->halo_cap));
   }
   HIP_OK(hipStreamSynchronize(h->stream));
-  *out = h;
   return 0;
 }
 
@@ -270,7 +263,7 @@ extern "C" int udc_destroy(udc_handle *h) {
   if (!h) return 0;
   hipSetDevice(h->device);
   h->pend.clear();
-  hipStreamSynchronize(h->stream);
+  if (h->stream) hipStreamSynchronize(h->stream);
   prof_drain(h);
   for (hipEvent_t e : h->prof_pool) hipEventDestroy(e);
   pois_destroy(h);
@@ -301,7 +294,7 @@ extern "C" int udc_destroy(udc_handle *h) {
   if (h->lev_part) hipFree(h->lev_part);
   if (h->lev_sum) hipFree(h->lev_sum);
   if (h->lev_sum16) hipFree(h->lev_sum16);
-  hipStreamDestroy(h->stream);
+  if (h->stream) hipStreamDestroy(h->stream);
   delete h;
   return 0;
 }
@@ -841,19 +834,25 @@ static int now_level_forcings(udc_handle *h, int when) {
   return k_level_forcings(h, when ? 1 : 0, false);
 }
 
+static void masscorr_effective(udc_handle *h) {
+  if (h->uout_req) { h->luvolflowr = 2; h->uflowrate = h->uout_rate; }
+  else { h->luvolflowr = h->uvol_req; h->uflowrate = h->uvol_rate; }
+}
+
 extern "C" int udc_set_masscorr(udc_handle *h, int luvolflowr, double uflowrate, int lvvolflowr, double vflowrate) {
   ENTRY_FLUSH(h);
-  // (an outflow-rate correction set by udc_set_masscorr_outflow -- luvolflowr == 2 -- takes precedence and stays in force,
-  // src/modforces.f90:352,389, whatever order the two setters are called in)
-  if (h->luvolflowr != 2) { h->luvolflowr = luvolflowr ? 1 : 0; h->uflowrate = uflowrate; }
+  // the two requests for u are kept side by side; an outflow-rate correction (udc_set_masscorr_outflow) takes precedence while it
+  // is on (src/modforces.f90:352,389), whatever order the two setters are called in and however often
+  h->uvol_req = luvolflowr ? 1 : 0; h->uvol_rate = uflowrate;
+  masscorr_effective(h);
   h->lvvolflowr = lvvolflowr ? 1 : 0; h->vflowrate = vflowrate;
   return 0;
 }
 
 extern "C" int udc_set_masscorr_outflow(udc_handle *h, int luoutflowr, double uflowrate) {
   ENTRY_FLUSH(h);
-  if (luoutflowr) { h->luvolflowr = 2; h->uflowrate = uflowrate; }      // (takes precedence over luvolflowr, src/modforces.f90:352,389)
-  else if (h->luvolflowr == 2) h->luvolflowr = 0;
+  h->uout_req = luoutflowr ? 1 : 0; h->uout_rate = uflowrate;
+  masscorr_effective(h);
   return 0;
 }
 
@@ -1024,6 +1023,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   pin.levels_per_chunk = h->g.nz / (h->nch > 0 ? h->nch : 1);
   pin.rk3step = rk3step; pin.um_alias = h->um_alias; pin.ibm_edits_now = (ops & (OP_IBMWALL | OP_IBMNORM)) != 0;
   const Plan plan = plan_substep(pin);
+  h->last_plan = plan; h->have_plan = true;
   const bool lds = true, pup = true, fold = plan.fold;      // (LDS-staged sweeps, tendencies as predicted velocity: always)
   const bool forces = (ops & OP_FORCES) != 0;
   if (plan.materialise_um) { if (um_materialise(h)) return 1; }
@@ -1185,6 +1185,16 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
     if (k_thermodynamics(h)) return 1;
     h->thermo_fresh = true;
   }
+  return 0;
+}
+
+extern "C" int udc_last_plan(udc_handle *h, int out[16]) {
+  if (!h || !out) { udc_set_error("udc_last_plan: null argument"); return 1; }
+  if (!h->have_plan) { udc_set_error("udc_last_plan: no fused substep has run on this handle"); return 1; }
+  const Plan &p = h->last_plan;
+  const int v[16] = {p.fold, p.closure, p.need_ekh, p.mom_pipe, p.div_in_fft, p.vp_row, p.p_row, p.integrate, p.rotate, p.skip_um,
+                     p.materialise_um, h->slab ? 1 : 0, h->fft_fused ? 1 : 0, h->nch, h->own_fwd ? 1 : 0, h->own_bwd ? 1 : 0};
+  for (int q = 0; q < 16; ++q) out[q] = v[q];
   return 0;
 }
 

@@ -103,6 +103,8 @@ extern "C" int udc_comm_init_local(udc_handle *h, int group) {
 #endif
 
 void comm_destroy(udc_handle *h) {
+  for (auto &t : h->ctimed) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
+  h->ctimed.clear();
   if (h->nccl) { ncclCommDestroy((ncclComm_t)h->nccl); h->nccl = nullptr; }
 #ifdef UDC_TEST_TRANSPORT
   if (h->shm_group) { munmap(h->shm_group, 4096 + (size_t)h->cfg.nranks * SHM_CAP); h->shm_group = nullptr; }
@@ -159,6 +161,72 @@ static int shm_step(udc_handle *h, hipStream_t st, const void *src, size_t put, 
 }
 #endif
 
+// bookkeeping around every exchange: counters always, a pair of timing events on the exchange's stream when asked for
+struct CommScope {
+  udc_handle *h; hipStream_t st; hipEvent_t b = nullptr;
+  CommScope(udc_handle *h_, hipStream_t st_, int kind) : h(h_), st(st_) {
+    if (!h->comm_timing) return;
+    hipEvent_t a = nullptr;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { b = nullptr; return; }
+    hipEventRecord(a, st);
+    h->ctimed.push_back({a, b, kind});
+  }
+  ~CommScope() { if (b) hipEventRecord(b, st); }
+};
+
+extern "C" int udc_comm_info(udc_handle *h, int info[8]) {
+  if (!h || !info) { udc_set_error("udc_comm_info: null argument"); return 1; }
+  for (int q = 0; q < 8; ++q) info[q] = 0;
+  info[0] = h->nccl ? 1 : (h->local_group ? 2 : (h->shm_group ? 3 : 0));
+  info[1] = info[2] = info[3] = -1;
+  if (h->nccl) {
+    ncclComm_t c = (ncclComm_t)h->nccl;
+    NCCL_OK(ncclCommCount(c, &info[1]));
+    NCCL_OK(ncclCommUserRank(c, &info[2]));
+    NCCL_OK(ncclCommCuDevice(c, &info[3]));
+  }
+  NCCL_OK(ncclGetVersion(&info[4]));
+  info[5] = h->nch; info[6] = h->cfg.nranks; info[7] = h->cfg.rank;
+  return 0;
+}
+
+extern "C" int udc_comm_stats(udc_handle *h, int mode, double out[16]) {
+  if (!h) { udc_set_error("udc_comm_stats: null handle"); return 1; }
+  HIP_OK(hipSetDevice(h->device));
+  if (mode == 1) {
+    HIP_OK(hipDeviceSynchronize());
+    for (auto &t : h->ctimed) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
+    h->ctimed.clear();
+    h->cstat = udc_handle::CommStats();
+    h->comm_timing = true;
+    return 0;
+  }
+  if (!out) { udc_set_error("udc_comm_stats: null output"); return 1; }
+  HIP_OK(hipDeviceSynchronize());
+  double ms[2] = {0., 0.};
+  for (auto &t : h->ctimed) {
+    float m = 0.f;
+    if (hipEventElapsedTime(&m, t.a, t.b) == hipSuccess) ms[t.kind] += m;
+  }
+  for (int q = 0; q < 16; ++q) out[q] = 0.;
+  const auto &s = h->cstat;
+  out[0] = s.a2a_ops; out[1] = s.a2a_block_bytes; out[2] = s.a2a_bytes; out[3] = ms[0];
+  out[4] = s.halo_ops; out[5] = s.halo_prev; out[6] = s.halo_next; out[7] = ms[1];
+  out[8] = s.red_ops; out[9] = s.red_doubles;
+  if (mode == 2) {
+    for (auto &t : h->ctimed) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
+    h->ctimed.clear();
+    h->comm_timing = false;
+  }
+  return 0;
+}
+
+extern "C" int udc_comm_dry_run(udc_handle *h, int on) {
+  if (!h) { udc_set_error("udc_comm_dry_run: null handle"); return 1; }
+  h->comm_dry = on != 0;
+  return 0;
+}
+
 static int need_comm(udc_handle *h) {
   if (h->nccl || h->local_group || h->shm_group) return 0;      // (the last two are only ever set by the test build)
   udc_set_error("multi-rank handle used before udc_comm_init");
@@ -173,6 +241,11 @@ int comm_neighbours(udc_handle *h, const double *to_prev, const double *to_next,
   const int P = h->cfg.nranks, r = h->cfg.rank;
   const int prev = (r + P - 1) % P, next = (r + 1) % P;
   const bool dp = (dirs & 1) != 0, dn = (dirs & 2) != 0;      // rows to the previous rank (and from the next) / to the next (from the previous)
+  h->cstat.halo_ops += 1;
+  if (dp) h->cstat.halo_prev += (double)(count * sizeof(double));
+  if (dn) h->cstat.halo_next += (double)(count * sizeof(double));
+  if (h->comm_dry) return 0;
+  CommScope scope(h, st, 1);
   if (P == 1 && !h->nccl) {   // single slab driven through the slab code path (UDC_FORCE_SLAB): periodic wrap onto itself
     if (dp) HIP_OK(hipMemcpyAsync(from_next, to_prev, count * sizeof(double), hipMemcpyDeviceToDevice, st));
     if (dn) HIP_OK(hipMemcpyAsync(from_prev, to_next, count * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -227,6 +300,11 @@ int comm_neighbours(udc_handle *h, const double *to_prev, const double *to_next,
 // all-to-all of equal blocks: block d of `send` goes to rank d, arriving as block r of its `recv`
 int comm_alltoall(udc_handle *h, const double *send, double *recv, size_t block, hipStream_t st) {
   const int P = h->cfg.nranks, r = h->cfg.rank;
+  h->cstat.a2a_ops += 1;
+  h->cstat.a2a_block_bytes = (double)(block * sizeof(double));
+  h->cstat.a2a_bytes += (double)(block * sizeof(double)) * (P > 1 ? P - 1 : 1);
+  if (h->comm_dry) return 0;
+  CommScope scope(h, st, 0);
   if (P == 1 && !h->nccl) {
     HIP_OK(hipMemcpyAsync(recv, send, block * sizeof(double), hipMemcpyDeviceToDevice, st));
     return 0;
@@ -278,6 +356,7 @@ int comm_alltoall(udc_handle *h, const double *send, double *recv, size_t block,
 // in-place all-reduce of n doubles held in device memory `buf`; op 0 = max, 1 = sum
 int comm_allreduce(udc_handle *h, double *buf, int n, int op) {
   if (h->cfg.nranks == 1 && !h->nccl) return 0;
+  h->cstat.red_ops += 1; h->cstat.red_doubles += n;
   if (need_comm(h)) return 1;
   if (h->nccl) {
     NCCL_OK(ncclAllReduce(buf, buf, (size_t)n, ncclDouble, op == 0 ? ncclMax : ncclSum, (ncclComm_t)h->nccl,

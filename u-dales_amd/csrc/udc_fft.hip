@@ -684,12 +684,10 @@ int fft_fused_init(udc_handle *h) {
   // rows per workgroup of the x kernels (= the run length of the packed writes): as long as four workgroups still fit
   // a CU's 160 KB of LDS, at least 4; columns per workgroup of the y kernels likewise (UDC_FFT_L / UDC_FFT_C override)
   int L = 16;
-  while (L > 4 && x_lds_bytes(h, L) > 40000) L >>= 1;
+  while (L > tune::FFT_X_MIN_ROWS && x_lds_bytes(h, L) > (size_t)tune::FFT_X_LDS_BUDGET) L >>= 1;
   while (h->g.ny % L) L >>= 1;
-  int C = 8;
-  while (C > 1 && y_lds_bytes(h, C) > 40000) C >>= 1;
-  if (h->sw.fft_l >= 1 && pow2(h->sw.fft_l) && h->g.ny % h->sw.fft_l == 0) L = h->sw.fft_l;
-  if (h->sw.fft_c >= 1) C = h->sw.fft_c;
+  int C = tune::FFT_Y_COLS;
+  while (C > 1 && y_lds_bytes(h, C) > (size_t)tune::FFT_X_LDS_BUDGET) C >>= 1;
   h->fft_L = L; h->fft_C = C;
   h->slab_yreg = (ny == 128 || ny == 256 || ny == 512) && h->sw.slab_yreg;
   if (h->slab_yreg && ny == 512) {
@@ -820,11 +818,9 @@ int fft_nat_init(udc_handle *h) {
   if (fft_twiddles(h, nx, ny)) return 1;
   // rows per workgroup of the x kernel: 4 (256^3: 0.085 ms against 0.088 with 2 and 0.097 with 8, profiles/r03/own_fwd_ab.json;
   // nx = 512: 0.387 against 0.417 / 0.424, nx = 1024: 1.64 against 1.67 / 2.24, profiles/r03/nat_l_scan.json)
-  int L = 4;
+  int L = tune::NAT_X_ROWS;
   while (ny % L) L >>= 1;
-  int C = 8;
-  if (h->sw.nat_l >= 1 && pow2(h->sw.nat_l) && ny % h->sw.nat_l == 0) L = h->sw.nat_l;
-  if (h->sw.nat_c >= 1 && h->sw.nat_c <= 32) C = h->sw.nat_c;
+  int C = tune::NAT_Y_COLS;
   h->nat_reg16 = (ny == 128 || ny == 256 || ny == 512) && h->sw.nat_reg;
   if (h->nat_reg16) {
     const int n2 = ny / 16, tpc = n2 > 16 ? n2 : 16;

@@ -9,6 +9,7 @@
 #include <vector>
 #include "../../include/udcore.h"
 #include "udc_plan.h"
+#include "udc_tuning.h"
 
 // ---------------------------------------------------------------------------------------
 // Device layout of every 3-D field (one geometry for all of them, so that one offset
@@ -143,8 +144,7 @@ struct Switches {
   int force_comm = 0;        // UDC_FORCE_COMM=1: a real one-rank RCCL communicator under the forced slab path
   int halo_overlap = 1;      // UDC_HALO_OVERLAP=0: every ghost-row exchange in line
   int mom_pipe = 1;          // UDC_MOM_PIPE=0: momentum sweep not cut along the solve's k-chunks
-  int int_pipe = 1;          // UDC_INT_PIPE=0: project + integrate not cut along the backward k-chunks
-  int a2a_chunks = 4;        // UDC_A2A_CHUNKS: k-chunks of the transposes
+  int a2a_chunks = 0;        // UDC_A2A_CHUNKS: k-chunks of the transposes (0: the library's choice, pois_slab_init)
   int fft_fused = 1;         // UDC_FFT_FUSED=0: rocFFT + transpose kernels on the slab path
   int own_fwd = -1;          // UDC_OWN_FWD=0/1: single-slab forward half in own kernels
   int div_in_fft = 1;        // UDC_DIV_IN_FFT=0: separate divergence kernel on the slab path
@@ -155,9 +155,8 @@ struct Switches {
   int thomas = -1;           // UDC_THOMAS=0: the streaming kernel (one thread per mode) instead of register-resident segments
   int thomas_pair = 1;       // UDC_THOMAS_PAIR=0: rows ky and ny - ky not solved together (one GPU: rows of spec; slab ranks: mirrored runs of a line)
   int thomas_mirror_min = 256;      // slab ranks: shortest line solved in mirrored pairs (UDC_THOMAS_MIRROR_MIN; tests set 16)
-  // tuning knobs (0 / -1 = the library's own choice)
-  int mom_kc = 0, scalar_kc = 0, closure_percu = 0, xpad = -1, spec_pad = -1;
-  int fft_l = 0, fft_c = 0, nat_l = 0, nat_c = 0, nat_reg = 1, slab_yreg = 1;
+  // variants of the line transforms (A/B switches; the launch shapes themselves are constants: udc_tuning.h)
+  int nat_reg = 1, slab_yreg = 1;      // UDC_NAT_REG / UDC_SLAB_YREG = 0: the Stockham y passes instead of 16 x N2 in registers
 };
 void udc_read_switches(Switches &sw);
 
@@ -168,7 +167,7 @@ struct udc_handle {
   Metrics m;
   Params p;
   int device;
-  hipStream_t stream;
+  hipStream_t stream = nullptr;
   std::vector<double *> fields;         // device arrays, UDC_FIELD ids
   double *metrics_dev = nullptr;        // backing store for Metrics arrays
   // Poisson
@@ -260,6 +259,8 @@ struct udc_handle {
   double *thlpcar = nullptr;   // [nz+2] radiative heating profile added by forces (src/modforces.f90:104-110), or null
   // masscorr (src/modforces.f90:328): prescribed volume-flow rates
   int luvolflowr = 0, lvvolflowr = 0;     // luvolflowr: 1 = volume flow (luvolflowr), 2 = flow through the outlet plane (luoutflowr)
+  int uvol_req = 0, uout_req = 0;         // what udc_set_masscorr / udc_set_masscorr_outflow asked for; luvolflowr is derived from both
+  double uvol_rate = 0., uout_rate = 0.;
   double *outlet_w = nullptr;             // luoutflowr: dy dzf(k) / outlet area, [nz+2] indexed by the reference's k
   double uflowrate = 0., vflowrate = 0., zsize = 0.;
   bool um_alias = false;                // um,vm,wm are logically equal to u0,v0,w0 (after RK stage 3 of a fused
@@ -348,6 +349,13 @@ struct udc_handle {
   std::map<int, std::pair<double, int>> prof_acc;
   // multi-GPU (y-slabs): RCCL communicator or in-process local group (udc_comm.hip)
   void *nccl = nullptr;
+  // exchange bookkeeping (udc_comm_stats) and the timing-only mode (udc_comm_dry_run)
+  struct CommStats { double a2a_ops = 0, a2a_block_bytes = 0, a2a_bytes = 0, halo_ops = 0, halo_prev = 0, halo_next = 0, red_ops = 0, red_doubles = 0; } cstat;
+  struct CommTimed { hipEvent_t a, b; int kind; };
+  std::vector<CommTimed> ctimed;
+  bool comm_timing = false, comm_dry = false;
+  Plan last_plan{};                     // the order the last fused substep ran in (udc_last_plan)
+  bool have_plan = false;
   void *local_group = nullptr;
   void *shm_group = nullptr;            // test build only: the inter-process test transport (udc_comm_init_shm)
   bool slab = false;                    // distributed Poisson layout in use (nranks > 1 or UDC_FORCE_SLAB)
@@ -377,6 +385,7 @@ struct udc_handle {
   double *fft_tw = nullptr;             // twiddle tables
   int fft_L = 0, fft_C = 0;             // x rows / y columns per workgroup
   bool slab_yreg = false;               // slab path: y transforms as 16 x N2 in registers (ny = 128, 256, 512)
+  bool own_bwd = false;                 // one GPU: own backward half (reserved; rocFFT's backward plan runs today)
   bool own_fwd = false;                 // UDC_OWN_FWD=1, one GPU: divergence + x transform + y pass of udc_fft.hip instead of div_rhs + rocFFT's forward plan
   int nat_L = 0, nat_C = 0;
   bool nat_reg16 = false;               // ny = 256: the y pass as 16 x 16 in registers (UDC_NAT_REG=0: the Stockham kernel)

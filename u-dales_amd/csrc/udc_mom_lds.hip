@@ -25,9 +25,7 @@ constexpr int MX = MOM_TX, MY = MOM_TY;
 constexpr int LX = MX + 2, LY = MY + 2, LN = LX * LY;   // 34 x 10 = 340 doubles per field-plane
 constexpr int NT = MX * MY;                               // 256 threads
 static_assert((NT == 256 || NT == 512) && LN - NT <= NT, "one own cell and at most one halo cell per thread");
-#ifndef MOM_WAVES
-#define MOM_WAVES 3
-#endif
+constexpr int MOM_WAVES = tune::MOM_PER_CU;
 static TileGrid lds_tile_grid(const Geo &g) {
   TileGrid t; t.gx = (g.nx + MX - 1) / MX; t.gy = (g.ny + MY - 1) / MY; t.tiles = t.gx * t.gy; return t;
 }
@@ -352,8 +350,7 @@ __global__ __launch_bounds__(NT) void closure_lds_kernel(Geo g, TileGrid tg, Met
 
 // k-chunk length: each workgroup pays a 3-plane prologue, and the chip runs `slots` workgroups at a
 // time (256 CUs x per_cu, register/LDS-limited), so pick the chunk that minimises rounds x (kc + 3).
-static int pick_kc(const Geo &g, const TileGrid &tg, int per_cu, int forced) {
-  if (forced >= 1) return forced < g.nz ? forced : g.nz;
+static int pick_kc(const Geo &g, const TileGrid &tg, int per_cu) {
   const long slots = 256L * per_cu;
   int best = g.nz < 4 ? g.nz : 4;
   double best_cost = 1e300;
@@ -374,8 +371,7 @@ int k_closure_lds(udc_handle *h, bool ghosts, bool write_ekh, int rows) {
   const TileGrid tg = rows == 0 ? lds_tile_grid(g) : tile_rows(lds_tile_grid(g), 1, rows == 1);
   // 90 VGPRs, 32 640 B LDS: five workgroups fit a CU.  Measured: 512x512x256 0.634 -> 0.592 ms, 1024x512x512 2.60 -> 2.38 ms
   // when the chunking fills them; at 256^3 (256 tiles) five shorter chunks per tile lose to four (0.19 against 0.172 ms)
-  const int per_cu = h->sw.closure_percu > 0 ? h->sw.closure_percu : (tg.tiles >= 1024 ? 5 : 4);
-  int kc = pick_kc(g, tg, per_cu, h->sw.mom_kc);
+  int kc = pick_kc(g, tg, tune::closure_per_cu(tg.tiles));
   const int chunks = (g.nz + kc - 1) / kc;
   dim3 b(MX, MY, 1), gr((unsigned)tg.tiles * (unsigned)chunks, 1, 1);
   double *u = h->fields[UDC_U0], *v = h->fields[UDC_V0], *w = h->fields[UDC_W0];
@@ -412,7 +408,7 @@ int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, 
   // k-chunk: long enough to amortise the 2-plane prologue, short enough to fill 256 CUs x 4 workgroups
   Geo gl = g;
   gl.nz = a.kend - a.kbeg;
-  int kc = pick_kc(gl, tg, MOM_WAVES, h->sw.mom_kc);
+  int kc = pick_kc(gl, tg, tune::MOM_PER_CU);
   const int chunks = (gl.nz + kc - 1) / kc;
   dim3 b(MX, MY, 1), gr((unsigned)tg.tiles * (unsigned)chunks, 1, 1);
   const bool les = h->p.sgs != UDC_SGS_DNS;

@@ -390,7 +390,6 @@ bool k_scalar_fused_lds(udc_handle *h, int n, bool fresh, int *rc) {
       const double cost = (double)((blocks + slots - 1) / slots) * (q + 5);
       if (cost < best - 1e-9) { best = cost; kc = q; }
     }
-    if (h->sw.scalar_kc >= 1) kc = h->sw.scalar_kc < g.nz ? h->sw.scalar_kc : g.nz;
   }
   const int chunks = (g.nz + kc - 1) / kc;
   const dim3 b(MX, MY, 1), gr((unsigned)tiles * (unsigned)chunks, 1, 1);
@@ -434,7 +433,6 @@ bool k_scalar_pair_lds(udc_handle *h, int na, int nb, bool fresh, int *rc) {
       const double cost = (double)((blocks + slots - 1) / slots) * (q + 5);
       if (cost < best - 1e-9) { best = cost; kc = q; }
     }
-    if (h->sw.scalar_kc >= 1) kc = h->sw.scalar_kc < g.nz ? h->sw.scalar_kc : g.nz;
   }
   const int chunks = (g.nz + kc - 1) / kc;
   const dim3 b(MX, MY, 1), gr((unsigned)tiles * (unsigned)chunks, 1, 1);

@@ -60,6 +60,8 @@ contains
     if (timee == 0.0) return
     if (rk3step /= 3) return
     dtmn = dtmn + dt; ndt = ndt + 1.
+    ! the last step of the run is not a report step: the report still waiting from the previous interval appears now, not never
+    if (timee < tnext .and. pending .and. timeleft <= 0) call report
     if (timee < tnext) return
     if (first) then
       first = .false.

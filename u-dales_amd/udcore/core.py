@@ -73,6 +73,42 @@ class DynCore:
         buf = (C.c_ubyte * 128)(*unique_id)
         L._check(self.lib.udc_comm_init(self.h, buf), "udc_comm_init")
 
+    def comm_info(self) -> dict:
+        """What the communicator says about itself (udc_comm_info): transport, RCCL's own rank count / rank / device / version."""
+        info = (C.c_int * 8)()
+        L._check(self.lib.udc_comm_info(self.h, info), "udc_comm_info")
+        v = info[4]
+        return {"transport": ("none", "rccl", "test: in-process group", "test: shared memory")[info[0]],
+                "nranks": info[1], "rank": info[2], "device": info[3],
+                "version": f"{v // 10000}.{v // 100 % 100}.{v % 100}", "transpose_k_chunks": info[5],
+                "handle_nranks": info[6], "handle_rank": info[7]}
+
+    def comm_stats(self, mode: int = 0):
+        """Exchange bookkeeping (udc_comm_stats): mode 1 resets and starts timing, 0 reads, 2 reads and stops."""
+        out = (C.c_double * 16)()
+        L._check(self.lib.udc_comm_stats(self.h, mode, out), "udc_comm_stats")
+        if mode == 1:
+            return None
+        keys = ("alltoall_ops", "alltoall_bytes_per_peer", "alltoall_bytes_sent", "alltoall_ms", "ghost_row_exchanges",
+                "ghost_row_bytes_to_prev", "ghost_row_bytes_to_next", "ghost_row_ms", "allreduce_ops", "allreduce_doubles")
+        return {k: out[i] for i, k in enumerate(keys)}
+
+    def comm_dry_run(self, on: bool):
+        """Exchanges skipped (timing only; the state is wrong from there on)."""
+        L._check(self.lib.udc_comm_dry_run(self.h, 1 if on else 0), "udc_comm_dry_run")
+
+    def last_plan(self) -> dict:
+        """The order the last fused substep ran in (udc_last_plan)."""
+        o = (C.c_int * 16)()
+        L._check(self.lib.udc_last_plan(self.h, o), "udc_last_plan")
+        row = ("folded", "beside a sweep", "in line", "ahead of the pipelined sweep")
+        return {"ghost_rows_folded": bool(o[0]), "closure": ("folded", "edge rows first, ekm rows beside the interior", "plain")[o[1]],
+                "ekh_written": bool(o[2]), "momentum_sweep_pipelined_with_solve": bool(o[3]), "divergence_in_x_transform": bool(o[4]),
+                "vp_ghost_row": row[o[5]], "p_ghost_row": row[o[6]],
+                "integration": ("one launch", "edge rows first, velocity rows beside the interior")[o[7]],
+                "slab_layout": bool(o[11]), "fused_line_transforms": bool(o[12]), "transpose_k_chunks": o[13],
+                "own_forward_half": bool(o[14])}
+
     def comm_init_local(self, group: int):
         """Attach to an in-process group of virtual ranks (udc_local_group_create); test transport."""
         L._check(self.lib.udc_comm_init_local(self.h, group), "udc_comm_init_local")

@@ -27,7 +27,7 @@ FIELD_IDS = dict(u0=U0, v0=V0, w0=W0, um=UM, vm=VM, wm=WM, up=UP, vp=VP, wp=WP, 
 SGS_DNS, SGS_SMAGORINSKY, SGS_VREMAN, SGS_ONEEQN = 0, 1, 2, 3
 
 EXPORTS = ["udc_create", "udc_destroy", "udc_last_error", "udc_version", "udc_comm_unique_id",
-           "udc_comm_init", "udc_field_upload", "udc_field_download", "udc_set_forcing",
+           "udc_comm_init", "udc_comm_info", "udc_comm_stats", "udc_comm_dry_run", "udc_last_plan", "udc_field_upload", "udc_field_download", "udc_set_forcing",
            "udc_advection", "udc_subgrid", "udc_bottom", "udc_forces", "udc_slab_average", "udc_slab_averages", "udc_set_level_forcing", "udc_level_forcings", "udc_set_coriolis", "udc_coriolis", "udc_set_masscorr", "udc_set_masscorr_outflow", "udc_masscorr", "udc_set_tempeq", "udc_set_thl_source", "udc_set_floor_wf", "udc_set_fkar", "udc_set_chem", "udc_set_shifted_pbc", "udc_shifted_pbcs", "udc_set_scalar_top", "udc_set_scalar_source", "udc_scalsource", "udc_set_moisture", "udc_set_moist_thermo", "udc_thermodynamics", "udc_calthv", "udc_thermo_state", "udc_set_buoyancy", "udc_set_buoycorr", "udc_set_tke", "udc_poisson", "udc_tstep_integrate",
            "udc_halos", "udc_boundary", "udc_tstep_maxima", "udc_substep", "udc_run",
            "udc_set_deferred", "udc_flush", "udc_deferred_stats",
