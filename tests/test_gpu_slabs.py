@@ -32,10 +32,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     {"UDC_NO_ALIAS": "1"},                                  # ... um always a real copy
     {"UDC_SCALAR_PAIR": "0"},                               # ... thl and qt swept one by one
     {"UDC_THOMAS": "0"},                                    # ... the streaming tridiagonal kernel
-    {"UDC_MOM_KC": "3", "UDC_SCALAR_KC": "5", "UDC_CLOSURE_PERCU": "3"},      # tuning knobs: short k-chunks of the sweeps
-    {"UDC_XPAD": "16", "UDC_SPEC_PAD": "3"},                # ... padded rows; spectral rows that are no multiple of eight (no mirrored pairs)
-    {"UDC_OWN_FWD": "1", "UDC_NAT_REG": "0", "UDC_NAT_L": "2", "UDC_NAT_C": "4"},      # ... own forward half through the Stockham y pass
-    {"UDC_FORCE_SLAB": "1", "UDC_FFT_L": "2", "UDC_FFT_C": "2", "UDC_SLAB_YREG": "0"},      # ... slab transforms: lines per workgroup, Stockham y pass
+    {"UDC_OWN_FWD": "1", "UDC_NAT_REG": "0"},               # ... own forward half through the Stockham y pass
+    {"UDC_FORCE_SLAB": "1", "UDC_SLAB_YREG": "0"},          # ... slab transforms through the Stockham y pass
 ], ids=lambda d: " ".join(f"{k[4:]}={v}" for k, v in d.items()))
 def test_every_switch_setting_matches_reference(switches, monkeypatch):
     """Every run fixture (the reference's real program's restart files) through the fused substep under each of the library's order /
