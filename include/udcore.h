@@ -10,7 +10,7 @@
  *   - every function returns 0 on success, non-zero on failure; the message is
  *     available from udc_last_error().  Nothing here calls exit().
  *   - Environment: the library reads its UDC_* switches exactly once, inside udc_create (A/B switches of the substep order, tuning
- *     knobs; DESIGN.md section 9 lists them); no other entry point looks at the environment, and none changes results beyond
+ *     knobs; DESIGN.md section 7 lists them); no other entry point looks at the environment, and none changes results beyond
  *     round-off.
  *   - plain pointers and sizes only; host arrays are owned by the caller (Fortran's
  *     modfields), device arrays by the library; no host pointer is retained.
@@ -42,7 +42,7 @@ enum {
   UDC_SV0,                           /* passive scalar n: UDC_SV0 + 3*n  (sv0)  */
   UDC_SVM,                           /*                   UDC_SVM + 3*n  (svm)  */
   UDC_SVP,                           /*                   UDC_SVP + 3*n  (svp)  */
-  /* ql0 as the reference's `thermo` leaves it (one level low); kept only for the one-equation
+  /* ql0 as the reference's `thermo` leaves it (one level low: profiles/HISTORY.md, section 8); kept only for the one-equation
    * closure with moisture (calthv's moist dthvdz reads it), written by udc_thermodynamics */
   UDC_QL0 = UDC_SV0 + 3 * 16,
   UDC_FIELD_MAX = UDC_QL0 + 1,
@@ -198,7 +198,7 @@ int udc_set_moisture(udc_handle *h, int iadv_qt, int bctopq, double wqtop, doubl
  * half levels and calthv's thv0h with its slab average thvh -- what forces' buoyancy term then uses
  * (wp += grav (thv0h - thvh)/thvh, src/modforces.f90:73-84).  Call it once before the first substep
  * (src/program.f90:120); udc_substep calls it at its end (:214), a routine-by-routine caller does so itself after
- * udc_boundary.  The reference's off-by-one-level ql0 slab average is reproduced.
+ * udc_boundary.  The reference's off-by-one-level ql0 slab average is reproduced (profiles/HISTORY.md, section 8).
  * udc_thermo_state reads (set = 0) or writes (set = 1) what one call leaves for the next: nine tables of [n = ktot+1]
  * (k = kb..ke+kh) in the order presf, presh, exnf, exnh, thvh, thl0av, qt0av, ql0av, th0av. */
 int udc_set_moist_thermo(udc_handle *h, double thls, double qts, double ps, const double *zf, const double *zh, int n, int lqlnr);

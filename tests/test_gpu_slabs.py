@@ -37,7 +37,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ], ids=lambda d: " ".join(f"{k[4:]}={v}" for k, v in d.items()))
 def test_every_switch_setting_matches_reference(switches, monkeypatch):
     """Every run fixture (the reference's real program's restart files) through the fused substep under each of the library's order /
-    variant switches (DESIGN.md section 9; udc_create reads them): none may change a result beyond round-off."""
+    variant switches (DESIGN.md section 7; udc_create reads them): none may change a result beyond round-off."""
     from common import RUN_CASES, carr, deck_path, interior, load_fixture, marr, nocorner, relerr
     import udcore
     from udcore import read_deck, cold_start

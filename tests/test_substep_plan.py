@@ -1,4 +1,4 @@
-"""The order of a fused substep as a table (DESIGN.md section 9), enumerated.
+"""The order of a fused substep as a table (DESIGN.md section 7), enumerated.
 
 substep_fused (u-dales_amd/csrc/udc_api.hip) no longer decides anything itself: it asks plan_substep (udc_plan.h, a pure function of the
 switches, of what the handle is and of the call) and executes the answer.  Here that function -- compiled by g++ into
@@ -42,7 +42,7 @@ def run(L, rows):
 
 
 def table(i):
-    """DESIGN.md section 9, restated: i = dict of input columns -> dict of expected output columns."""
+    """DESIGN.md section 7, restated: i = dict of input columns -> dict of expected output columns."""
     b = lambda x: x.astype(bool)      # noqa: E731
     lds = np.ones_like(i["slab"], dtype=bool)
     pup = lds
@@ -123,7 +123,7 @@ def test_every_combination_matches_the_table_and_is_safe():
 
 
 def test_named_configurations():
-    """The rows of DESIGN.md section 9's table for the BASELINE configurations, with the library's defaults."""
+    """The rows of DESIGN.md section 7's table for the BASELINE configurations, with the library's defaults."""
     L = lib()
     dflt = dict(no_fold=0, no_alias=0, ek_always=0, halo_overlap=1, mom_pipe=1, div_in_fft=1, lbuoycorr=0, stats_any=0,
                 ibm_edits_now=0, um_alias=0)

@@ -134,7 +134,7 @@ static int env_int(const char *name, int dflt) {
   const char *e = getenv(name);
   return (e && *e) ? atoi(e) : dflt;
 }
-// The one place the library reads its environment (include/udcore.h, "Environment"; DESIGN.md section 9).
+// The one place the library reads its environment (include/udcore.h, "Environment"; DESIGN.md section 7).
 void udc_read_switches(Switches &sw) {
   sw.force_slab = env_int("UDC_FORCE_SLAB", 0) != 0;
   sw.force_comm = env_int("UDC_FORCE_COMM", 0) != 0;
@@ -1008,7 +1008,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   const double rk3coef = dt / (4. - (double)rk3step);
   h->bcx_rk3coef = rk3coef;
   if (k_scalar_bcx_uout(h)) return 1;      // BCxs = 2 without a prescribed volume flow: the outlet's speed from the state the substep starts from
-  // what runs, in which order, is decided in one place: plan_substep (udc_plan.h; DESIGN.md section 9 has the table, the CPU test
+  // what runs, in which order, is decided in one place: plan_substep (udc_plan.h; DESIGN.md section 7 has the table, the CPU test
   // tests/test_substep_plan.py enumerates it)
   PlanIn pin{};
   pin.no_fold = h->no_fold; pin.no_alias = h->no_alias;
@@ -1029,7 +1029,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   if (plan.materialise_um) { if (um_materialise(h)) return 1; }
   const bool rotate = plan.rotate;
   h->halos_fresh = h->boundary_fresh = h->thermo_fresh = false;
-  // closure + momentum.  (One sweep evaluating ekm in LDS was built and measured slower than the two kernels, DESIGN.md section 5:
+  // closure + momentum.  (One sweep evaluating ekm in LDS was built and measured slower than the two kernels, profiles/HISTORY.md section 5:
   // not kept.)
   {
     // closure first: it only needs u0,v0,w0, and the momentum sweep below needs ekm

@@ -137,7 +137,7 @@ struct Params {
 struct ProfEntry { hipEvent_t a, b; int name; bool own_a; };
 
 // Every environment switch of the library.  Read ONCE, in udc_create (udc_read_switches, udc_api.hip); no launcher reads the
-// environment.  -1 / 0 = "not set: the library's own choice".  DESIGN.md section 9 lists what each one is for.
+// environment.  -1 / 0 = "not set: the library's own choice".  DESIGN.md section 7 lists what each one is for.
 struct Switches {
   // order of a slab substep (A/B switches, each order is tested against the others)
   int force_slab = 0;        // UDC_FORCE_SLAB=1: one rank through the slab layout

@@ -1,6 +1,6 @@
 // The order of one fused RK3 substep as a pure function of what it depends on (no HIP, no handle): substep_fused (udc_api.hip)
 // asks plan_substep() and then only executes.  Host-only C++, also compiled by g++ into lib/libudcplan.so, which the CPU test
-// tests/test_substep_plan.py enumerates against the table of DESIGN.md section 9.
+// tests/test_substep_plan.py enumerates against the table of DESIGN.md section 7.
 #pragma once
 
 struct PlanIn {
