@@ -488,6 +488,8 @@ def supervise(args, argv):
         # (the launcher's agent store belongs to the supervisors: the children rendezvous by themselves on their own port)
         env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
         env.update(MASTER_PORT=str(port[0]), UDC_BENCH_HEARTBEAT=hb, UDC_BENCH_RUNG=str(ri), **env_extra)
+        if ri > 0:      # a fallback rung runs the workload and the checks, not the side measurement of the exchanges
+            env["UDC_BENCH_NO_EXCHANGE_ACCOUNT"] = "1"
         if env.get("UDC_TEST_SHM"):      # test transport: a segment name per attempt (a killed attempt leaves its segment behind)
             env["UDC_TEST_SHM"] = f"{env['UDC_TEST_SHM']}_{ri}_{port[0]}"
         open(hb, "w").close()
@@ -792,7 +794,7 @@ def main():
     # substeps with the exchanges switched off (udc_comm_dry_run: kernels only, results wrong -- this state is not used again):
     # substep - that = the exchange time the overlap did NOT hide.
     exchange = None
-    if executed_plan["slab_layout"]:
+    if executed_plan["slab_layout"] and os.environ.get("UDC_BENCH_NO_EXCHANGE_ACCOUNT", "0") in ("", "0"):
         try:
             nx_sub = 6
             core.comm_stats(1)
