@@ -174,6 +174,23 @@ def test_cube_array_properties(tmp_path):
         assert e <= (1e-8 if k == "pres0" else 1e-10), (k, e)
 
 
+def test_configs4_grid_cube_array_512cube(tmp_path):
+    """BASELINE configs[4]'s own grid, 512^3, with the staggered cube array on ONE GPU (the 8-GPU decomposition is what no box here
+    can run): three substeps through the single-slab path and through the slab layout (own line transforms, exchanges onto itself),
+    immersed-boundary corrections on every listed point -- divergence at round-off, solid points at rest, the two paths equal."""
+    nx, ny, nz, cubes = 512, 512, 512, (32, 128)
+    res, ref = _run(tmp_path, nx, ny, nz, 2, 0, None, 3, False, "single512", cubes)
+    assert res["div"] < 1e-10 and 0.9 < res["umax"] < 5. and res["wmax"] > 1e-4, res
+    assert res["solid_u"] < 0.2 * res["umax"], res
+    res2, slab = _run(tmp_path, nx, ny, nz, 2, 0, None, 3, True, "slab512", cubes)
+    assert res2["div"] < 1e-10, res2
+    for k in ref:
+        if k == "div":
+            continue
+        e = np.abs(ref[k] - slab[k]).max() / max(np.abs(ref[k]).max(), 1e-300)
+        assert e <= (1e-8 if k == "pres0" else 1e-10), (k, e)
+
+
 def test_rccl_operations_above_one_gib(tmp_path):
     """The 1024 x 512 x 512 transposes through a REAL one-rank RCCL communicator in ONE k-chunk: 2.1 GB per all-to-all block.  Measured
     on this image's RCCL: a single ncclSend / ncclRecv of more than 1 GiB delivers garbage without an error (divmax 1e22 .. inf after
