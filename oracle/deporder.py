@@ -1,20 +1,22 @@
 """TEST INFRASTRUCTURE.  Compile order of a Fortran source set from its `use` statements.
 
-    deporder.py <reference src dir> [<drop-in dir>]
+    deporder.py <reference src dir> [<drop-in dir>] [--skip name.f90 ...]
 
 prints "path path ..." (module dependencies first).  With a second directory, every file there replaces the reference file of
-the same name and the rest (udc_iface.f90) is added -- the source set of INTEGRATION.md section 1."""
+the same name and the rest (udc_iface.f90, decomp_2d.f90) is added -- the source set of INTEGRATION.md section 1.  --skip leaves files
+out (the one-rank builds take their decomp_2d from oracle/shims instead of the MPI y-slab module)."""
 import glob
 import os
 import re
 import sys
 
 
-def order(dirs):
+def order(dirs, skip=()):
     files = {}
     for d in dirs:
         for f in sorted(glob.glob(os.path.join(d, "*.f90"))):
-            files[os.path.basename(f)] = f
+            if os.path.basename(f) not in skip:
+                files[os.path.basename(f)] = f
     prov, uses = {}, {}
     for f in files.values():
         t = open(f, errors="replace").read()
@@ -41,4 +43,9 @@ def order(dirs):
 
 
 if __name__ == "__main__":
-    print(" ".join(order(sys.argv[1:])))
+    args = sys.argv[1:]
+    skip = ()
+    if "--skip" in args:
+        q = args.index("--skip")
+        args, skip = args[:q], tuple(args[q + 1:])
+    print(" ".join(order(args, skip)))

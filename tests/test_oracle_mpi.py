@@ -1,5 +1,5 @@
 """The all-cores CPU baseline (oracle/_ref/udales_ref_mpi: reference Fortran + MPICH + the y-slab
-decomposition shim oracle/shims/decomp_2d_mpi.f90) must be decomposition invariant, like the
+y-slab decomp_2d of u-dales_amd/fortran/decomp_2d.f90) must be decomposition invariant, like the
 reference's own processor_boundaries test demands of 2decomp-fft
 (tests/integration/processor_boundaries/test_processor_boundaries.py:28-34) -- and, deck by deck, give what the
 single-rank build (oracle/shims/decomp_2d_np1.f90, the one every golden fixture comes from) gives: the two stand-ins
@@ -31,11 +31,12 @@ def run(cmd, cwd):
     return float(m.group(1)), float(m.group(2)), sums
 
 
-def set_ranks(deck_path, p):
-    """the reference reads its process grid from the deck (&RUN nprocx, nprocy, src/modstartup.f90:105-117): y-slabs over p ranks"""
+def set_ranks(deck_path, p, px=1):
+    """the reference reads its process grid from the deck (&RUN nprocx, nprocy, src/modstartup.f90:105-117): px x p pencils"""
     with open(deck_path) as f:
         txt = f.read()
     txt = re.sub(r"nprocy\s*=\s*\d+", f"nprocy = {p}", txt)
+    txt = re.sub(r"nprocx\s*=\s*\d+", f"nprocx = {px}", txt)
     with open(deck_path, "w") as f:
         f.write(txt)
 
@@ -57,6 +58,38 @@ def test_mpi_baseline_is_decomposition_invariant(tmp_path):
         sp, dp, _ = run(f"{MPIEXEC} -n {p} {REF_MPI} {deck} time x.bin", tmp_path)
         assert abs(sp - s1) <= 1e-11 * abs(s1), (p, sp, s1)
         assert dp < 1e-12
+
+
+@pytest.mark.parametrize("name", ["run_16x16x8", "run_smag_scalar_16x8x12s", "run_ibm_16x12x10", "run_adaptive_16x8x12s"])
+def test_x_split_decks_run_as_slabs(name, tmp_path):
+    """Decks that name an x-split process grid (nprocx = 2: 2 x 1 and 2 x 2 pencils, what 19 of the reference's 28 shipped decks
+    do) through the reference's own program over u-dales_amd/fortran/decomp_2d.f90, which hands the pencils out as 2 / 4 y-slabs:
+    the same sums as the one-rank build to 1e-11 -- the solver takes extents and edge flags from zsize / zstart
+    (src/modglobal.f90:622-662) and never asks how the ranks are arranged."""
+    if not _have():
+        pytest.skip("reference CPU builds or MPICH not available here")
+    if name not in RUN_CASES:
+        pytest.skip("deck not in the golden set")
+    iexp = RUN_CASES[name]
+    for fn in os.listdir(os.path.join(GOLDEN, "cases", name)):
+        shutil.copy(os.path.join(GOLDEN, "cases", name, fn), tmp_path)
+    deck = f"namoptions.{iexp:03d}"
+    with open(os.path.join(tmp_path, deck)) as f:
+        txt = f.read()
+    itot, jtot, ktot = (int(re.search(rf"{v}\s*=\s*(\d+)", txt).group(1)) for v in ("itot", "jtot", "ktot"))
+    s1, d1, q1 = run(f"{REF} {deck} time x.bin", tmp_path)
+    done = 0
+    for px, py in ((2, 1), (2, 2)):
+        p = px * py
+        if itot % px or jtot % p or ktot % p or jtot // p < 2 or ktot % py or jtot % py:
+            continue
+        set_ranks(os.path.join(tmp_path, deck), py, px)
+        sp, dp, qp = run(f"{MPIEXEC} -n {p} {REF_MPI} {deck} time x.bin", tmp_path)
+        assert abs(sp - s1) <= 1e-11 * abs(s1), (px, py, sp, s1)
+        for a, b in zip(qp, q1):
+            assert abs(a - b) <= 1e-11 * max(abs(b), 1e-300), (px, py, qp, q1)
+        done += 1
+    assert done >= 1
 
 
 @pytest.mark.parametrize("name,iexp", sorted(RUN_CASES.items()))

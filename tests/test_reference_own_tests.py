@@ -41,7 +41,7 @@ CASE = os.path.join(GOLDEN, "cases", "case_100")
 TOL = 1.0e-9            # ABS_TOL of test_processor_boundaries.py:28 and of src/tests.f90:389
 
 
-def stage(tmp, deck, nprocy=1, steps=None):
+def stage(tmp, deck, nprocy=1, steps=None, nprocx=1):
     """tests/cases/100 + one of the test drivers' decks as namoptions.100 (what run_test.sh / _copy_namelist do)."""
     os.makedirs(tmp, exist_ok=True)
     for fn in os.listdir(CASE):
@@ -53,6 +53,7 @@ def stage(tmp, deck, nprocy=1, steps=None):
         txt = f.read()
     txt = re.sub(r"nprocy\s*=\s*\d+", f"nprocy       = {nprocy}", txt)
     assert re.search(r"nprocx\s*=\s*1\b", txt)
+    txt = re.sub(r"nprocx\s*=\s*1\b", f"nprocx       = {nprocx}", txt)
     if steps is not None:      # a longer variant of the one-step deck: `steps` steps of dtmax, one tdump record at the end
         dtmax = float(re.search(r"dtmax\s*=\s*([0-9.eE+-]+)", txt).group(1))
         txt = re.sub(r"runtime\s*=\s*[0-9.eE+-]+", f"runtime      = {dtmax * (steps - 0.5)!r}", txt)
@@ -225,6 +226,21 @@ def test_processor_boundaries_case_100(steps, tmp_path):
             r = run(d, exe, P, env=env)
             assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
             out[f"device, y split over {P} ({how})"] = tdump_fields(d, P)
+        # the reference's own x-split and x-y-split variants (2 x 1 and 2 x 2 pencils, test_processor_boundaries.py:28-34): the decks
+        # run UNEDITED in their process grid -- u-dales_amd/fortran/decomp_2d.f90 hands the pencils out as 2 / 4 y-slabs
+        for px, py in ((2, 1), (2, 2)):
+            P = px * py
+            if 1 < gpu_count() < P:
+                continue
+            exe, env, how = mpi_transport(P, f"c100x{px}{py}")
+            if not os.path.exists(exe):
+                continue
+            d = tmp_path / f"dev{px}x{py}"
+            stage(d, "namoptions.100.serial", nprocy=py, steps=steps, nprocx=px)
+            r = run(d, exe, P, env=env)
+            assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+            assert f"the deck asks for {px} x {py} pencils" in r.stdout, r.stdout[-1500:]
+            out[f"device, deck {px} x {py} ({how})"] = tdump_fields(d, P)
     ref = out["reference, serial"]
     assert ref["ut"].shape == (128, 128, 128) and np.abs(ref["ut"]).max() > 1.      # (u0 = 3 m/s + noise of amplitude randu = 1)
     worst = {}

@@ -1,13 +1,20 @@
-! TEST INFRASTRUCTURE (oracle/_ref MPI build only) -- not part of the product.
+! decomp_2d / decomp_2d_fft -- the interface of the 2DECOMP&FFT library as the uDALES solver uses it (SURVEY.md section 2.4:
+! decomp_2d_init, decomp_info_init, alloc_x / _y / _z with halo levels, exchange_halo_z on arrays allocated WITH halos, the
+! transposes, zsize / zstart / zend ..., DECOMP_2D_COMM_CART_Z), provided for the device-resident run.  The reference's submodule
+! `2decomp-fft/` is empty and unpinned (`/root/reference/.gitmodules`), so whoever builds the driver has to supply these symbols; this
+! is the layout libudcore wants: **y-slabs only** -- x stays whole on a rank (one GPU), y is split over ALL ranks.
 !
-! Multi-rank stand-in for the un-vendored 2DECOMP&FFT library, restricted to what the CPU
-! baseline needs: p_row = nprocx = 1, p_col = nprocy = P (y split in the z-pencil, z split in the
-! y/x pencils).  With p_row = 1 the y<->x transposes are local copies, z<->y is one MPI_ALLTOALL of
-! equal blocks (jtot % P == 0 and ktot % P == 0, which the reference itself requires,
-! src/modstartup.f90:730-760), and exchange_halo_z moves whole padded rows to the two y neighbours
-! (periodic).  It moves data only.  Used to time the reference's numerics on all host cores
-! (BASELINE.md section 4); the caveat that this is NOT the upstream 2decomp binary is printed with
-! every number that comes from it.
+! A deck that asks for p_row x p_col pencils (`nprocx`, `nprocy` of &RUN, src/modstartup.f90:676) is run as p_row * p_col y-slabs:
+! the solver takes its local extents from zsize / zstart (src/modglobal.f90:622-662), decides "am I at a domain edge" from them
+! (:640-660) and wraps a direction itself where one rank holds both edges (src/modboundary.f90:95-107), so nothing of it has to know.
+! The 19 of the reference's 28 shipped decks that say nprocx > 1 therefore run unedited (jtot must divide by the number of ranks).
+! Host-side data movement only; the device path (libudcore) does its own exchanges over RCCL.
+!   exchange_halo_z : whole padded rows to the two y neighbours (periodic), after wrapping the x ghosts where the DECK split x
+!                     periodically (the solver then expects them from here);
+!   transposes      : z <-> y is one MPI_ALLTOALL of equal blocks (jtot and ktot divisible by the ranks), y <-> x a copy -- used by
+!                     the reference's own modpois only (the CPU baseline of oracle/Makefile; the drop-in modpois never calls them).
+! The all-reference MPI builds of oracle/Makefile (the CPU baseline) link this file too: the reference's own program then runs an
+! x-split deck as slabs as well (tests/test_oracle_mpi.py: 2 x 1 and 2 x 2 decks against the one-rank build); rank 0 says so in a line.
 module decomp_2d
   use mpi
   implicit none
@@ -19,7 +26,7 @@ module decomp_2d
   integer, save, dimension(3) :: zstart, zend, zsize
   integer, save :: DECOMP_2D_COMM_CART_X = 0, DECOMP_2D_COMM_CART_Y = 0, DECOMP_2D_COMM_CART_Z = 0
   integer, save :: pcol = 1, mycol = 0, nbr_prev = 0, nbr_next = 0
-  logical, save :: periodic_y = .false.
+  logical, save :: periodic_y = .false., wrap_x = .false.
 
   type DECOMP_INFO
     integer, dimension(3) :: xst, xen, xsz
@@ -69,20 +76,29 @@ contains
     logical :: periods(2)
     call MPI_COMM_RANK(MPI_COMM_WORLD, nrank, ierr)
     call MPI_COMM_SIZE(MPI_COMM_WORLD, nproc, ierr)
-    if (p_row /= 1 .or. p_col /= nproc .or. mod(ny, p_col) /= 0 .or. mod(nz, p_col) /= 0) then
-      if (nrank == 0) write (0, *) 'ERROR: oracle MPI decomp needs nprocx = 1, nprocy = #ranks, jtot and ktot divisible'
+    if (p_row*p_col /= nproc .or. mod(ny, nproc) /= 0) then
+      if (nrank == 0) write (0, *) 'ERROR: decomp_2d (y-slabs): nprocx * nprocy must be the number of ranks and divide jtot:', &
+        p_row, p_col, nproc, ny
       call MPI_ABORT(MPI_COMM_WORLD, 1, ierr)
     end if
+    if (p_row > 1 .and. nrank == 0) write (*, '(A,I0,A,I0,A,I0,A)') ' decomp_2d: the deck asks for ', p_row, ' x ', p_col, &
+      ' pencils; run as ', nproc, ' y-slabs (x stays whole on a rank)'
     nx_global = nx; ny_global = ny; nz_global = nz
-    pcol = p_col
-    dims = (/1, p_col/); periods = (/.true., .true./)
+    pcol = nproc
+    dims = (/1, nproc/); periods = (/.true., .true./)
     call MPI_CART_CREATE(MPI_COMM_WORLD, 2, dims, periods, .false., DECOMP_2D_COMM_CART_Z, ierr)
     call MPI_CART_COORDS(DECOMP_2D_COMM_CART_Z, nrank, 2, coords, ierr)
     mycol = coords(2)
     call MPI_CART_SHIFT(DECOMP_2D_COMM_CART_Z, 1, 1, nbr_prev, nbr_next, ierr)
     DECOMP_2D_COMM_CART_X = DECOMP_2D_COMM_CART_Z; DECOMP_2D_COMM_CART_Y = DECOMP_2D_COMM_CART_Z
-    periodic_y = .false.
-    if (present(periodic_bc)) periodic_y = periodic_bc(2)
+    periodic_y = .false.; wrap_x = .false.
+    if (present(periodic_bc)) then
+      ! (periodic_bc(d) is set by the solver only where the DECK splits direction d, src/modstartup.f90:662-672)
+      wrap_x = periodic_bc(1)                    ! the deck split x: the solver expects x's periodic ghosts from the exchange
+      ! y split here but not in the deck: the solver meant to wrap y itself if periodic and cannot any more -- taken as periodic
+      ! like x (every run of the device path has periodic lateral momentum boundaries: udc_iface refuses the others)
+      periodic_y = periodic_bc(2) .or. (p_col == 1 .and. p_row > 1 .and. periodic_bc(1))
+    end if
     call decomp_info_init(nx, ny, nz, decomp_main)
     xstart = decomp_main%xst; xend = decomp_main%xen; xsize = decomp_main%xsz
     ystart = decomp_main%yst; yend = decomp_main%yen; ysize = decomp_main%ysz
@@ -158,7 +174,7 @@ contains
     complex(mytype), dimension(:, :, :), intent(in) :: src
     complex(mytype), dimension(:, :, :), intent(out) :: dst
     type(DECOMP_INFO), intent(in), optional :: opt_decomp
-    write (0, *) 'ERROR: complex z<->y transposes are not provided by the oracle MPI shim'
+    write (0, *) 'ERROR: complex z<->y transposes are not provided by this y-slab decomp_2d'
     stop 1
   end subroutine unsupported_complex
 
@@ -170,6 +186,10 @@ contains
     real(mytype), allocatable :: sbuf(:), rbuf(:)
     integer :: nx, nyl, nzl, d, k, j, blk, ierr, o
     nx = nx_global; nyl = ny_global/pcol; nzl = nz_global/pcol
+    if (mod(nz_global, pcol) /= 0) then
+      write (0, *) 'ERROR: decomp_2d (y-slabs): the transposes need ktot divisible by the number of ranks'
+      call MPI_ABORT(MPI_COMM_WORLD, 1, ierr)
+    end if
     blk = nx*nyl*nzl
     allocate (sbuf(blk*pcol), rbuf(blk*pcol))
     do d = 0, pcol - 1
@@ -231,10 +251,17 @@ contains
     real(mytype), dimension(:, :, :), intent(inout) :: var
     type(DECOMP_INFO), intent(in), optional :: opt_decomp
     integer, intent(in), optional :: opt_xlevel(3), opt_ylevel(3), opt_zlevel(3)
-    integer :: hj, n1, n2, n3, nyl, cnt, ierr, st(MPI_STATUS_SIZE)
+    integer :: hi, hj, n1, n2, n3, nyl, cnt, ierr, st(MPI_STATUS_SIZE)
     real(mytype), allocatable :: s1(:, :, :), s2(:, :, :), r1(:, :, :), r2(:, :, :)
-    if (.not. periodic_y) return
     n1 = size(var, 1); n2 = size(var, 2); n3 = size(var, 3)
+    if (wrap_x) then        ! x ghosts first, over the interior rows; the rows then travel with their x ghosts (corners consistent)
+      hi = (n1 - nx_global)/2
+      if (hi >= 1) then
+        var(1:hi, :, :) = var(n1 - 2*hi + 1:n1 - hi, :, :)
+        var(n1 - hi + 1:n1, :, :) = var(hi + 1:2*hi, :, :)
+      end if
+    end if
+    if (.not. periodic_y) return
     nyl = ny_global/pcol
     hj = (n2 - nyl)/2
     if (hj < 1) return
@@ -255,7 +282,7 @@ contains
     real(mytype), dimension(:, :, :), intent(inout) :: var
     type(DECOMP_INFO), intent(in), optional :: opt_decomp
     integer, intent(in), optional :: opt_xlevel(3), opt_ylevel(3), opt_zlevel(3)
-    write (0, *) 'ERROR: exchange_halo_x/y are not provided by the oracle MPI shim'
+    write (0, *) 'ERROR: exchange_halo_x/y are not provided by this y-slab decomp_2d'
     stop 1
   end subroutine exchange_unsupported
 
@@ -265,7 +292,7 @@ contains
     integer, intent(in) :: level
     type(DECOMP_INFO), intent(in), optional :: opt_decomp
     logical, intent(in), optional :: opt_global
-    write (0, *) 'ERROR: update_halo not provided by the oracle shim'
+    write (0, *) 'ERROR: update_halo not provided by this y-slab decomp_2d'
     stop 1
   end subroutine update_halo
 
@@ -280,7 +307,7 @@ module decomp_2d_fft
   end interface
 contains
   subroutine fft_unavailable
-    write (0, *) 'ERROR: decomp_2d_fft is not provided by the oracle shim (ipoiss must be 0)'
+    write (0, *) 'ERROR: decomp_2d_fft is not provided by this y-slab decomp_2d (ipoiss must be 0)'
     stop 1
   end subroutine fft_unavailable
   subroutine decomp_2d_fft_init(pencil)

@@ -178,14 +178,14 @@ contains
 
   subroutine voutletarea(area)
     use mpi
-    use modglobal, only: ib, ie, je, kb, ke, dxf, dzf, jtot
+    use modglobal, only: ib, ie, je, kb, ke, dxf, dzf, jtot, jerank
     use modfields, only: IIc
-    use modmpi, only: comm3d, mpierr, my_real, myidy, nprocy
+    use modmpi, only: comm3d, mpierr, my_real
     real, intent(out) :: area
     real :: loc
     integer :: k
     loc = 0.
-    if (myidy == nprocy - 1) then      ! the plane j = jtot lives on the last y-slab
+    if (jerank) then      ! the plane j = jtot lives on the rank that holds the domain's last row (src/modglobal.f90:652-660)
       do k = kb, ke
         loc = loc + sum(IIc(ib:ie, je, k))*dxf(1)*dzf(k)
       end do

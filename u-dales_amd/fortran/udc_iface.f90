@@ -519,7 +519,8 @@ contains
     use modsubgriddata, only: lsmagorinsky, lvreman, loneeqn, ldelta, prandtli, c_vreman, csz, cm, cn, ch1, ch2, ce1, ce2, lbuoycorr, Rigc
     use modfields, only: dpdxl, dpdyl, thlpcar, ug, whls, dthldxls, dthldyls, dqtdxls, dqtdyls, dqtdtls, &
                          dudxls, dudyls, dvdxls, dvdyls
-    use modmpi, only: myid, nprocs, nprocx, comm3d, mpierr
+    use modmpi, only: myid, nprocs, comm3d, mpierr
+    use decomp_2d, only: zsize, zstart
     use mpi, only: MPI_CHARACTER
     type(udc_config) :: cfg
     integer(c_signed_char) :: nccl_id(128)
@@ -537,8 +538,12 @@ contains
     zh_(0) = 0.
     zh_(1:ktot + 1) = dzh(kb:ke + kh)
     cfg%itot = itot; cfg%jtot = jtot; cfg%ktot = ktot
-    if (nprocx /= 1) then
-      write (0, *) 'ERROR: libudcore decomposes in y only: set nprocx = 1, nprocy = number of GPUs'
+    ! the library's layout is y-slabs: x whole on a rank, every rank one slab of jtot / #ranks rows in rank order.  That is what the
+    ! decomp_2d of this directory hands out whatever nprocx x nprocy the deck names; with another decomposition library an x-split
+    ! deck is refused here (nprocx = 1, nprocy = number of GPUs is then the deck to write)
+    if (zsize(1) /= itot .or. zsize(2)*nprocs /= jtot .or. zstart(2) /= myid*zsize(2) + 1) then
+      write (0, *) 'ERROR: libudcore decomposes in y only (x whole on a rank, slabs in rank order): link u-dales_amd/fortran/decomp_2d.f90, ', &
+                   'or set nprocx = 1, nprocy = number of GPUs.  This rank holds i, j from', zstart(1:2), ' extents', zsize(1:2)
       stop 1
     end if
     ! device: the library deals the ranks round over the node's visible devices (cfg%device = -1) unless UDC_GPUS_PER_NODE says
