@@ -31,8 +31,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     {"UDC_NO_FOLD": "1"},                                   # single slab: separate ghost-row kernels
     {"UDC_NO_ALIAS": "1"},                                  # ... um always a real copy
     {"UDC_SCALAR_PAIR": "0"},                               # ... thl and qt swept one by one
-    {"UDC_FLOOR_IN_SWEEP": "0"},                            # ... the neutral floor wall function as its own launch
-    {"UDC_FORCE_SLAB": "1", "UDC_FLOOR_IN_SWEEP": "0"},     # ... likewise behind the pipelined sweep of the slab path
     {"UDC_THOMAS": "0"},                                    # ... the streaming tridiagonal kernel
     {"UDC_OWN_FWD": "1", "UDC_NAT_REG": "0"},               # ... own forward half through the Stockham y pass
     {"UDC_FORCE_SLAB": "1", "UDC_SLAB_YREG": "0"},          # ... slab transforms through the Stockham y pass

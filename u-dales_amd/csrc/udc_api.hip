@@ -148,7 +148,6 @@ void udc_read_switches(Switches &sw) {
   sw.no_alias = env_int("UDC_NO_ALIAS", 0) != 0;
   sw.ek_always = env_int("UDC_EK_ALWAYS", 0) != 0;
   sw.scalar_pair = env_int("UDC_SCALAR_PAIR", 1) != 0;
-  sw.floor_in_sweep = env_int("UDC_FLOOR_IN_SWEEP", 1) != 0;
   sw.thomas = env_int("UDC_THOMAS", -1);
   sw.thomas_pair = env_int("UDC_THOMAS_PAIR", 1) != 0;
   sw.thomas_mirror_min = env_int("UDC_THOMAS_MIRROR_MIN", 256);
@@ -1026,7 +1025,6 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   const Plan plan = plan_substep(pin);
   h->last_plan = plan; h->have_plan = true;
   const bool lds = true, pup = true, fold = plan.fold;      // (LDS-staged sweeps, tendencies as predicted velocity: always)
-  bool floor_in_sweep = false;      // `bottom`'s momentum part applied by the momentum sweep itself
   const bool forces = (ops & OP_FORCES) != 0;
   if (plan.materialise_um) { if (um_materialise(h)) return 1; }
   const bool rotate = plan.rotate;
@@ -1060,19 +1058,17 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
     // travels; the other rows follow level range by level range from inside k_poisson_solve_slab, each ahead of the x forward
     // transform of the same k-chunk -- so the forward all-to-all of chunk c runs under the sweep of the levels above it
     const bool floor_on = (ops & OP_BOTTOM) && h->p.lbottom;
-    floor_in_sweep = floor_on && h->sw.floor_in_sweep && momentum_lds_takes_floor(h);
     const bool pipe = plan.mom_pipe;
     if (pipe) {
       const MomPart row0{0, 1, 0, 0, true};
-      if (k_momentum_lds(h, true, true, forces, true, 1. / rk3coef, rotate, &row0, floor_in_sweep)) return 1;
-      if (floor_on && !floor_in_sweep && k_bottom(h, false, 0, momentum_lds_tile_height())) return 1;
+      if (k_momentum_lds(h, true, true, forces, true, 1. / rk3coef, rotate, &row0)) return 1;
+      if (floor_on && k_bottom(h, false, 0, momentum_lds_tile_height())) return 1;
       const int fvp[1] = {UDC_VP};
       if (k_halo_y_begin(h, fvp, 1, 1, nullptr, HALO_TO_PREV)) return 1;      // (only the divergence of the slab's last row reads a ghost row of vp)
       h->vp_halo_pending = true;
       h->mom_pipe.active = true; h->mom_pipe.forces = forces; h->mom_pipe.um_is_u0 = rotate; h->mom_pipe.bottom = floor_on;
-      h->mom_pipe.floor_in_sweep = floor_in_sweep;
       h->mom_pipe.rk3coefi = 1. / rk3coef;
-    } else if (k_momentum_lds(h, true, true, forces, true, 1. / rk3coef, rotate, nullptr, floor_in_sweep)) return 1;
+    } else if (k_momentum_lds(h, true, true, forces, true, 1. / rk3coef, rotate)) return 1;
   }
   const bool piped = h->mom_pipe.active;      // (then nothing below up to the solve has anything to do: see `pipe`)
   if (k_scalar_top_flux(h)) return 1;
@@ -1094,7 +1090,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   if (forces && h->thlpcar && k_level_source(h, 15, h->thlpcar)) return 1;
   if (forces && k_buoyancy(h)) return 1;        // additive on wp(kb+1..ke), hence on pwp
   // `bottom` (src/program.f90:152): additive on the k = kb tendencies, hence equally on pup = up + um/rk3coef
-  if (!piped && !floor_in_sweep && (ops & OP_BOTTOM) && h->p.lbottom && k_bottom(h, fold)) return 1;
+  if (!piped && (ops & OP_BOTTOM) && h->p.lbottom && k_bottom(h, fold)) return 1;
   if ((ops & OP_CORIOLIS) && k_coriolis(h, fold)) return 1;        // src/program.f90:158; wrap of vp's ghost row follows below
   if ((ops & OP_SHIFT) && k_shifted_pbcs(h, fold)) return 1;       // src/program.f90:144 (additive on the momentum tendencies)
   if ((ops & OP_LEV0) && !h->level_forcings.empty() && k_level_forcings(h, 0, fold)) return 1;   // lstend, nudge tables
@@ -1210,8 +1206,8 @@ int k_momentum_pipe_stage(udc_handle *h, int c) {
   const int nch = h->nch, nzc = h->g.nz / nch, gy = momentum_lds_tile_rows(h->g);
   const int kbeg = c == 0 ? 0 : c * nzc + 1, kend = c == nch - 1 ? h->g.nz : (c + 1) * nzc + 1;
   const MomPart part{1, gy, kbeg, kend, c != nch - 1};
-  if (k_momentum_lds(h, true, true, h->mom_pipe.forces, true, h->mom_pipe.rk3coefi, h->mom_pipe.um_is_u0, &part, h->mom_pipe.floor_in_sweep && kbeg == 0)) return 1;
-  if (c == 0 && h->mom_pipe.bottom && !h->mom_pipe.floor_in_sweep && k_bottom(h, false, momentum_lds_tile_height(), -1)) return 1;
+  if (k_momentum_lds(h, true, true, h->mom_pipe.forces, true, h->mom_pipe.rk3coefi, h->mom_pipe.um_is_u0, &part)) return 1;
+  if (c == 0 && h->mom_pipe.bottom && k_bottom(h, false, momentum_lds_tile_height(), -1)) return 1;
   return 0;
 }
 

@@ -125,17 +125,6 @@ __device__ __forceinline__ void x_lds(const XArgs &q, double2 *lds, double2 *&a,
   for (int kx = threadIdx.x; kx < q.cx * q.P; kx += NTH) dmap[kx] = kx / q.cx;
 }
 
-// Workgroup -> (row group, level of the chunk).  Row groups 2m and 2m + 1 share every 128-B line of the exchange blocks when L = 4
-// (runs of L complex = 64 B in j): the hardware deals workgroup b to XCD b % 8, so with the launch order as it is the two halves of a
-// line are fetched by two different L2s (measured, profiles/r05: fftx_bwd_unpack read 2.0x its block).  XCD c is given a contiguous
-// run of (level, row group) pairs instead, as xcd_tile does for the stencil sweeps: the second half of a line then hits.
-__device__ __forceinline__ void x_block(int &jg, int &kc) {
-  const unsigned gx = gridDim.x, nwg = gx * gridDim.y;
-  unsigned v = blockIdx.x + gx * blockIdx.y;
-  if ((nwg & 7u) == 0) v = (v & 7u) * (nwg >> 3) + (v >> 3);
-  kc = (int)(v / gx); jg = (int)(v - (unsigned)kc * gx);
-}
-
 // fillps folded into the x forward transform (fused substep, PUP mode): the row is not read from p but evaluated as
 // the divergence of (pup, pvp, pwp) (src/modpois.f90:968-970; pwp(ke+1) = 0 of bcpup), which then never exists in memory
 struct DivArgs { const double *pu, *pv, *pw; const double *dzfi; double dxi, dyi; int nz; };
@@ -149,9 +138,9 @@ __global__ __launch_bounds__(xthreads(LM)) void fftx_fwd_pack_kernel(XArgs q, co
   double2 *a, *b, *tw; int *dmap;
   x_lds<LM>(q, lds, a, b, tw, dmap, twM);
   const int tid = threadIdx.x, L = 1 << q.lL;
-  int jg, kc;
-  x_block(jg, kc);
-  const int j0 = (jg + q.jg0) << q.lL, k = q.k0 + kc;
+  // (the launch order as it is: dealing the XCDs contiguous runs, as the backward kernel does, halves this kernel's partial-line
+  // writes in the counters but costs it 5 % -- profiles/r05/same_box_ab_r04_r05.txt)
+  const int j0 = (blockIdx.x + q.jg0) << q.lL, kc = blockIdx.y, k = q.k0 + kc;
   // load: row l holds M complex = nx reals, read as double2 (16-B aligned: nx even, rows nx*8 B apart, base 16-B aligned)
   for (int wi = tid; wi < (M << q.lL); wi += NTH) {
     const int l = wi >> LM, n = wi & (M - 1);

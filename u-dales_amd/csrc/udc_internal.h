@@ -151,7 +151,6 @@ struct Switches {
   int no_fold = 0, no_alias = 0;      // UDC_NO_FOLD / UDC_NO_ALIAS = 1
   int ek_always = 0;         // UDC_EK_ALWAYS=1: every substep writes ekm / ekh
   int scalar_pair = 1;       // UDC_SCALAR_PAIR=0: thl and qt swept one by one
-  int floor_in_sweep = 1;    // UDC_FLOOR_IN_SWEEP=0: the neutral floor wall function as its own launch after the momentum sweep
   // tridiagonal solve
   int thomas = -1;           // UDC_THOMAS=0: the streaming kernel (one thread per mode) instead of register-resident segments
   int thomas_pair = 1;       // UDC_THOMAS_PAIR=0: rows ky and ny - ky not solved together (one GPU: rows of spec; slab ranks: mirrored runs of a line)
@@ -372,7 +371,7 @@ struct udc_handle {
   bool halo_async_pending = false;      // a k_halo_y_begin has not been joined yet (k_halo_y joins it before touching the shared buffers)
   // the momentum sweep pipelined with the slab solve (substep_fused, k_momentum_pipe_stage): tile row 0 is swept first over all
   // levels, the other rows level range by level range ahead of the x forward transform of the same k-chunk
-  struct MomPipe { bool active = false, forces = false, um_is_u0 = false, bottom = false, floor_in_sweep = false; double rk3coefi = 0.; } mom_pipe;
+  struct MomPipe { bool active = false, forces = false, um_is_u0 = false, bottom = false; double rk3coefi = 0.; } mom_pipe;
   bool no_mom_pipe = false;             // UDC_MOM_PIPE=0
   bool vp_halo_pending = false;         // vp's ghost row is travelling (k_halo_y_begin): the x forward transform joins before its last row group
   bool no_halo_overlap = false;         // UDC_HALO_OVERLAP=0: every ghost-row exchange in line on the compute stream
@@ -430,9 +429,7 @@ int k_closure_lds(udc_handle *h, bool ghosts, bool write_ekh = true, int rows = 
 int k_ek_ghosts(udc_handle *h, bool exchange = true);
 int closure_lds_tile_rows(const Geo &g);      // tile rows of k_closure_lds over the slab
 struct MomPart { int r0, r1, kbeg, kend; bool more; };      // a piece of the momentum sweep: tile rows [r0, r1), levels [kbeg, kend)
-int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, double rk3coefi, bool um_is_u0 = false, const MomPart *part = nullptr,
-                   bool floor = false);
-bool momentum_lds_takes_floor(const udc_handle *h);      // `bottom`'s momentum part inside the sweep (neutral wall function, nothing else on the floor)
+int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, double rk3coefi, bool um_is_u0 = false, const MomPart *part = nullptr);
 int momentum_lds_tile_rows(const Geo &g);
 int momentum_lds_tile_height();
 int k_momentum_pipe_stage(udc_handle *h, int c);      // the sweep's level range that feeds k-chunk c of the slab solve (udc_api.hip)  // rk3coefi != 0: PUP mode   // LDS-staged k-marching version (default)

@@ -125,8 +125,7 @@ __global__ __launch_bounds__(256) void bottom_kernel(Geo g, Metrics m, BottomArg
   const double dzfi = m.dzfi[k], dzhi = m.dzhi[k], dzhiq = m.dzhiq[k];
   const double grav = 9.81, Twall = a.thls;
   const double logzh = (UNO || a.thl_wf >= 0) ? log(a.z0 / a.z0h) : 0., sqdz = (UNO || a.thl_wf >= 0) ? sqrt(delta / a.z0) : 0.;
-  if (!UNO) floor_neutral_uv(g, m, a.u0, a.v0, a.ekm, a.up, a.vp, i, j, a.z0, a.fkar, a.wrap_vp, a.tau_x, a.tau_y);      // (udc_mom_arith.h)
-  if (UNO) {  // u component, src/modwallfunctions.f90:92-109
+  {  // u component, :318-331 (neutral) / :92-109 (uno)
     const double utang1Int = a.u0[c];
     const double utang2Int = (a.v0[c] + a.v0[cxm] + a.v0[c + sy] + a.v0[cxm + sy]) * 0.25;
     const double utangInt = fmax(umin, (utang1Int * utang1Int + utang2Int * utang2Int));
@@ -143,7 +142,7 @@ __global__ __launch_bounds__(256) void bottom_kernel(Geo g, Metrics m, BottomArg
     a.up[c] = t;
     if (a.tau_x) a.tau_x[(size_t)j * g.nx + i] = t - old;      // tau_x = up - (up before), :2094
   }
-  if (UNO) {  // v component, :111-127
+  {  // v component, :333-346 / :111-127
     const double utang1Int = (a.u0[c] + a.u0[c - sy] + a.u0[cxp - sy] + a.u0[cxp]) * 0.25;
     const double utang2Int = a.v0[c];
     const double utangInt = fmax(umin, (utang1Int * utang1Int + utang2Int * utang2Int));

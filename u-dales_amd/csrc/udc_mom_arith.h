@@ -3,51 +3,7 @@
 // advecu/v/w_2nd (src/modadvection.f90:158-314), diffu/v/w (src/modsubgrid.f90:672-997),
 // forces (src/modforces.f90:84-127); accumulation order: xy advection, z advection, diffusion, forcing.
 #pragma once
-// `bottom`'s momentum part with the neutral wall function (src/modibm.f90:2015-2097 -> wfmneutral, src/modwallfunctions.f90:263-350)
-// at cell (i, j) of level kb: one body for bottom_kernel<false> (udc_mom.hip) and for the momentum sweep that applies it itself
-// (mom_lds_kernel, udc_mom_lds.hip).  tau_x / tau_y: what the floor added (src/modibm.f90:2094-2097), or nullptr.
 #include "udc_internal.h"
-
-__device__ __forceinline__ void floor_neutral_uv(const Geo &g, const Metrics &m, const double *__restrict__ u0, const double *__restrict__ v0,
-                                                 const double *__restrict__ ekm, double *up, double *vp, int i, int j, double z0, double fkar,
-                                                 int wrap_vp, double *tau_x, double *tau_y) {
-  const long c = g.idx(i, j, 0);
-  const long cxm = c - i + (i == 0 ? g.nx - 1 : i - 1), cxp = c - i + (i == g.nx - 1 ? 0 : i + 1);
-  const long sy = g.sy, sz = g.sz;
-  const int k = 1, km = 0;                       // reference level indices of the metric tables
-  const double fkar2 = fkar * fkar, umin = 0.0001;
-  const double delta = 0.5 * m.dzf[k];
-  const double l_ = log(delta / z0);
-  const double logdz2 = l_ * l_;
-  const double ctm = fkar2 / (logdz2);
-  const double dzfi = m.dzfi[k], dzhi = m.dzhi[k], dzhiq = m.dzhiq[k];
-  {  // u component, src/modwallfunctions.f90:318-331
-    const double utang1Int = u0[c];
-    const double utang2Int = (v0[c] + v0[cxm] + v0[c + sy] + v0[cxm + sy]) * 0.25;
-    const double utangInt = fmax(umin, (utang1Int * utang1Int + utang2Int * utang2Int));
-    const double dummy = fabs(utang1Int) * sqrt(utangInt) * ctm;
-    const double bcmomflux = copysign(dummy, utang1Int);
-    const double emom = (m.dzf[km] * (ekm[c] * m.dx + ekm[cxm] * m.dx) +
-                         m.dzf[k] * (ekm[c - sz] * m.dx + ekm[cxm - sz] * m.dx)) * m.dxi * dzhiq;
-    const double old = up[c];
-    const double t = old + (u0[c] - u0[c - sz]) * emom * dzhi * dzfi - bcmomflux * dzfi;
-    up[c] = t;
-    if (tau_x) tau_x[(size_t)j * g.nx + i] = t - old;      // tau_x = up - (up before), src/modibm.f90:2094
-  }
-  {  // v component, :333-346
-    const double utang1Int = (u0[c] + u0[c - sy] + u0[cxp - sy] + u0[cxp]) * 0.25;
-    const double utang2Int = v0[c];
-    const double utangInt = fmax(umin, (utang1Int * utang1Int + utang2Int * utang2Int));
-    const double dummy = fabs(utang2Int) * sqrt(utangInt) * ctm;
-    const double bcmomflux = copysign(dummy, utang2Int);
-    const double eomm = (m.dzf[km] * (ekm[c] + ekm[c - sy]) + m.dzf[k] * (ekm[c - sz] + ekm[c - sy - sz])) * dzhiq;
-    const double old = vp[c];
-    const double t = old + (v0[c] - v0[c - sz]) * eomm * dzhi * dzfi - bcmomflux * dzfi;
-    vp[c] = t;
-    if (tau_y) tau_y[(size_t)j * g.nx + i] = t - old;
-    if (wrap_vp && j == 0) vp[c + sy * g.ny] = t;      // bcpup's cyclic pvp(je+1) = pvp(jb)
-  }
-}
 
 struct MomVals {
   double u_c, u_xm, u_xp, u_ym, u_yp, u_zm, u_zp, u_xp_ym, u_xp_zm;

@@ -38,10 +38,6 @@ struct MomArgs {
   int wrap_vp;                  // single slab: also store row 0 of vp into ghost row ny (bcpup's cyclic pvp)
   int um_is_u0;                 // RK stage 1 after an aliased stage 3: um == u0, already staged in LDS
   int kbeg, kend;               // levels [kbeg, kend) of this launch (the whole column unless the sweep is pipelined with the solve)
-  // the neutral floor wall function (`bottom`, src/modibm.f90:1998-2100 -> wfmneutral, src/modwallfunctions.f90:263-350) on level kb,
-  // applied to the finished tendencies exactly as bottom_kernel<false> does (udc_mom.hip): one launch (and its wait) less per substep
-  int floor;
-  double floor_z0, floor_fkar;
 };
 
 template <int NF, int CPT = 1>
@@ -228,13 +224,6 @@ __global__ __launch_bounds__(NT / CPT, CPT == 1 ? MOM_WAVES : 2) void mom_lds_ke
     const int t = bm; bm = bc; bc = bp; bp = bn; bn = t;
     const int t2 = qm; qm = qc; qc = qn; qn = t2;
   }
-  // the floor (level kb) once the column's first chunk is done: bottom_kernel's own arithmetic on what this thread has just stored --
-  // outside the march, so that it costs the loop no registers
-  if (a.floor && k0 == 0) {
-#pragma unroll
-    for (int c = 0; c < CPT; ++c)
-      if (inside[c]) floor_neutral_uv(g, m, a.u, a.v, a.ek, a.up, a.vp, i, jj[c], a.floor_z0, a.floor_fkar, a.wrap_vp, nullptr, nullptr);
-  }
 }
 
 // -------------------------------------------------------------------------------- closure
@@ -403,19 +392,12 @@ int momentum_lds_tile_height() { return MY; }
 
 // part: a piece of the sweep -- tile rows [r0, r1) (r1 <= 0: all), levels [kbeg, kend) (kend <= 0: all); `more`: not the last piece
 // of this substep (profiled under "<name>_edge", which bench.py folds into <name>)
-// the floor's momentum part can ride in the sweep: neutral wall function, LES viscosity staged, no scalar floor fluxes, no diagnostics
-bool momentum_lds_takes_floor(const udc_handle *h) {
-  return h->p.lbottom && h->floor_bcbotm != 2 && h->p.sgs != UDC_SGS_DNS && h->slots.empty() && !h->bottom_diag[0] && !h->bottom_diag[1];
-}
-
-int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, double rk3coefi, bool um_is_u0, const MomPart *part, bool floor) {
+int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, double rk3coefi, bool um_is_u0, const MomPart *part) {
   const bool pup = fresh && rk3coefi != 0.;
   const Geo &g = h->g;
   MomArgs a{h->fields[UDC_U0], h->fields[UDC_V0], h->fields[UDC_W0], h->fields[UDC_PRES0],
             h->fields[UDC_EKM], h->fields[UDC_UP], h->fields[UDC_VP], h->fields[UDC_WP],
-            h->fields[UDC_UM], h->fields[UDC_VM], h->fields[UDC_WM], rk3coefi, (fresh && !h->slab) ? 1 : 0, um_is_u0 ? 1 : 0, 0, g.nz,
-            (floor && pup && adv && diff) ? 1 : 0, h->p.z0, h->fkar};
-  if (floor && !a.floor) { udc_set_error("k_momentum_lds: the floor rides only in the fused advection + diffusion sweep"); return 1; }
+            h->fields[UDC_UM], h->fields[UDC_VM], h->fields[UDC_WM], rk3coefi, (fresh && !h->slab) ? 1 : 0, um_is_u0 ? 1 : 0, 0, g.nz};
   TileGrid tg = lds_tile_grid(g);
   bool more = false;
   if (part) {

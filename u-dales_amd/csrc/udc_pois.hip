@@ -245,7 +245,6 @@ __global__ __launch_bounds__(NT, W) void thomas_reg_kernel(int nmodes, int nz, d
   } else {
     mo = blk0 * M + mm;
     mok = mo < nmodes;
-    xskip = (mok ? mo : nmodes - 1) - blk0 * M;
   }
   const int moc = mok ? mo : (MIR ? mo : nmodes - 1);
   const double *a = tri, *b = tri + (nz + 2), *c = tri + 2 * (nz + 2);
@@ -259,9 +258,13 @@ __global__ __launch_bounds__(NT, W) void thomas_reg_kernel(int nmodes, int nz, d
   char *xb_[NP];
   xb_[0] = reinterpret_cast<char *>(x + (size_t)blk0 * M);
   if (NP == 2) xb_[NP - 1] = reinterpret_cast<char *>(MIR ? x + base1 : x + (size_t)blk1 * M);
-  const unsigned zoff = (unsigned)(((size_t)l0 * M + (size_t)tlane + (size_t)tskip) * sizeof(double));
+  // (the non-mirrored instantiations keep the plain forms: with them the compiler addresses every load as uniform base in scalar
+  // registers + 32-bit lane offset; the general forms cost a 64-bit address pair per stream and 6 % of the kernel at nz = 512)
+  const unsigned zoff = MIR ? (unsigned)(((size_t)l0 * M + (size_t)tlane + (size_t)tskip) * sizeof(double))
+                            : (unsigned)(((size_t)l0 * M + mm) * sizeof(double));
   unsigned xo_[NP];                        // lane offsets: the same for both systems unless the second one is a mirrored run
-  xo_[0] = (unsigned)(((size_t)l0 * st + (size_t)xskip) * sizeof(double2));
+  xo_[0] = MIR ? (unsigned)(((size_t)l0 * st + (size_t)xskip) * sizeof(double2))
+               : (unsigned)(((size_t)l0 * st + (size_t)(moc - blk0 * M)) * sizeof(double2));
   if (NP == 2) xo_[NP - 1] = MIR ? (unsigned)(((size_t)l0 * st + (size_t)lane1) * sizeof(double2)) : xo_[0];
   double2 t[NP][SL];
   double g[SL], cz[SL], aj[SL];
@@ -292,7 +295,8 @@ __global__ __launch_bounds__(NT, W) void thomas_reg_kernel(int nmodes, int nz, d
       aj[j] = a[min(lev + 1, nz)];
     }
   }
-  const double *zt = reinterpret_cast<const double *>(zb_ + zoff) - (size_t)l0 * M;      // this lane's column of the pivot table
+  const double *zt = MIR ? reinterpret_cast<const double *>(zb_ + zoff) - (size_t)l0 * M      // this lane's column of the pivot table
+                         : ztab + (size_t)blk0 * (size_t)(nz - 1) * M + mm;
   const bool own_top = l0 <= nz - 1 && nz - 1 < l0 + SL;
   double zl = 0., etop = 0.;
   if (own_top) { zl = zt[(size_t)(nz - 2) * M]; etop = ev[moc]; }
