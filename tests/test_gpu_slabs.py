@@ -98,6 +98,21 @@ for isub in range(1, max(dumps) + 1):
 core.dt, core.rk3step = dt, 3
 m = core.tstep_update(dt, ladaptive=True)
 dv = core.divergence()
+# what the communicator says about itself, and the exchange account with RCCL moving the buffers (bench.py's N > 1 fields)
+info = core.comm_info()
+assert info["transport"] == "rccl" and info["nranks"] == 1 and info["rank"] == 0 and info["version"].count(".") == 2, info
+core.comm_stats(1)
+for isub in range(3):
+    core.substep(isub + 1, dt, True)
+cs = core.comm_stats(2)
+nch = info["transpose_k_chunks"]
+assert cs["alltoall_ops"] == 3 * 2 * nch and cs["alltoall_ms"] > 0 and cs["ghost_row_exchanges"] >= 3 * 4 and cs["ghost_row_ms"] > 0, cs
+plan = core.last_plan()
+assert plan["slab_layout"] and plan["transpose_k_chunks"] == nch, plan
+core.comm_dry_run(True)
+core.substep(1, dt, True)      # (exchanges skipped: timing only, the state is discarded)
+core.comm_dry_run(False)
+core.sync()
 core.close()
 print("RCCL_OK", m, dv)
 ''' % (ROOT, ROOT)
