@@ -65,17 +65,25 @@ def _compare(name, out, tol):
     return worst
 
 
-def test_configs1_256cube_300_substeps_against_reference(tmp_path):
+@pytest.mark.parametrize("path", ["single slab", "slab layout"])
+def test_configs1_256cube_300_substeps_against_reference(path, tmp_path, monkeypatch):
     """256^3 neutral channel, Vreman, floor wall function: 100 full time steps = 300 RK3 substeps; u0, v0, w0, pres0 within the
-    north star's 1e-6 of the reference CPU path -- asserted at 1e-9 (measured 5e-13: profiles/r05/full_size_parity.txt)."""
+    north star's 1e-6 of the reference CPU path -- asserted at 1e-9 (measured 5e-13: profiles/r05/full_size_parity.txt).  Once on the
+    one-GPU path and once through the slab (multi-GPU) layout: own line transforms both ways, the momentum sweep pipelined with the
+    k-chunks, mirrored Thomas pairs on lines of 256, every exchange onto itself."""
+    if path == "slab layout":
+        monkeypatch.setenv("UDC_FORCE_SLAB", "1")
     out, divmax, _ = _run_case("c1", tmp_path)
     _compare("c1", out, 1e-9)
     assert divmax < 1e-10
 
 
-def test_configs2_512x512x256_kappa_smagorinsky_against_reference(tmp_path):
+@pytest.mark.parametrize("path", ["single slab", "slab layout"])
+def test_configs2_512x512x256_kappa_smagorinsky_against_reference(path, tmp_path, monkeypatch):
     """512 x 512 x 256, Smagorinsky + one kappa-advected scalar: three time steps = 9 substeps at 1e-9 (the reference's own
-    decomposition-invariance tolerance, tests/integration/processor_boundaries/test_processor_boundaries.py:28-34)."""
+    decomposition-invariance tolerance, tests/integration/processor_boundaries/test_processor_boundaries.py:28-34); both code paths."""
+    if path == "slab layout":
+        monkeypatch.setenv("UDC_FORCE_SLAB", "1")
     out, divmax, _ = _run_case("c2", tmp_path)
     _compare("c2", out, 1e-9)
     assert divmax < 1e-10
