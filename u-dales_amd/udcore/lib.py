@@ -66,11 +66,18 @@ def load():
         # the same sonames as the system's.  Whichever is loaded first serves both; torch-first works, libudcore-first makes the
         # process abort at exit (glibc: "double free or corruption" in the runtimes' tear-down).  So where torch is installed it
         # goes first (UDC_TORCH_FIRST=0: not).  The Fortran route never meets torch.
+        # (only where torch is installed at all -- found without importing it -- and said out loud under UDC_VERBOSE=1: an implicit
+        # import of this size should not be a secret)
         if "torch" not in sys.modules and os.environ.get("UDC_TORCH_FIRST", "1") != "0":
-            try:
-                import torch      # noqa: F401
-            except Exception:      # noqa: BLE001
-                pass
+            import importlib.util
+            if importlib.util.find_spec("torch") is not None:
+                try:
+                    import torch      # noqa: F401
+                    if os.environ.get("UDC_VERBOSE", "0") not in ("", "0"):
+                        print("udcore: imported torch ahead of libudcore.so (two ROCm runtimes under one soname; UDC_TORCH_FIRST=0 skips this)",
+                              file=sys.stderr)
+                except Exception as e:      # noqa: BLE001
+                    print(f"udcore: torch is installed but did not import ({e!r}); loading libudcore.so without it", file=sys.stderr)
         _lib = C.CDLL(LIBPATH, mode=C.RTLD_GLOBAL)
         _lib.udc_last_error.restype = C.c_char_p
     return _lib
