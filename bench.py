@@ -35,7 +35,7 @@ sys.path.insert(0, os.path.join(ROOT, "u-dales_amd"))
 # Algorithmic (compulsory) bytes per cell-update of each kernel AS BUILT.
 # SURVEY.md section 8d's model is closure 40 + momentum 88 + Poisson/integrate 264 = 392 B; the fused
 # substep moves less than that model (no pup/pvp/pwp or rhs arrays, tendencies neither re-read nor
-# zero-filled): 40 + 88 + 32 + 64 + 24 + 72 = 320 B.  `whole_substep_hbm_frac` keeps SURVEY's 392 B
+# zero-filled): 40 + 88 + 32 + 64 + 20 + 72 = 316 B.  `whole_substep_hbm_frac` keeps SURVEY's 392 B
 # definition so that it stays comparable across rounds.
 SCALAR_INTEGRATE_BYTES = 24      # per transported scalar in project_integrate: read svp, svm; write sv0
 ALGO_BYTES = {
@@ -45,12 +45,13 @@ ALGO_BYTES = {
                                 # (buffer rotation, already staged): 64 -- the timed launches are charged their own mix
     "div_rhs": 32,              # read pup,pvp,pwp; write p
     "fft_fwd": 32, "fft_bwd": 32,   # 2 passes x (8 read + 8 write)
-    "thomas": 24,               # x read once, written once + both pivot tables read once (SURVEY 8d's figure; one GPU: the mirrored
-                                # rows ky, ny - ky share their tables, 20 B as built)
+    "thomas": 20,               # x read once, written once (16) + the pivot table read once (4) -- as built since round 5 (SURVEY 8d's
+                                # model has a second table, 24 B; the back substitution's coefficient is now formed in the kernel);
+                                # one GPU: the mirrored rows ky, ny - ky share the table, 18 B
     "project_integrate": 72,    # read p (8), pup,pvp,pwp (24); RMW pres0 (16); write u0,v0,w0 (24)
     "scalar": 48,               # read c, ekh, u0,v0,w0 (40); write cp (8) -- tendencies are not re-read in the fused substep
     # slab (multi-GPU) Poisson stages; on one GPU the forward half carries the first two names too (udc_fft.hip: divergence + x transform
-    # into rocFFT's spectral layout = "fftx_pack_fwd" at 32 B, the y pass over it = "unpack_ffty_fwd" at 16 B; 40 + 88 + 32 + 16 + 24 + 32 + 72 = 304 B)
+    # into rocFFT's spectral layout = "fftx_pack_fwd" at 32 B, the y pass over it = "unpack_ffty_fwd" at 16 B; 40 + 88 + 32 + 16 + 20 + 32 + 72 = 300 B)
     # (own line FFTs reading / writing the exchange buffers directly: one real field in, one out per stage, DESIGN.md section 6;
     #  the x forward stage of the fused substep evaluates the divergence itself -- reads pup, pvp, pwp instead of p: 24 + 8 = 32,
     #  charged below when the substep launched no div_rhs)

@@ -71,18 +71,14 @@ __global__ void thomas_table_kernel(int nmodes, int nz, const double *__restrict
   const double e = ev[mo];
   double z = 1. / (b[1] + e);
   double d = c[1] * z;
-  // the blocked table is followed by a second one holding -(c_k z_k), the back substitution's only coefficient
-  double *cz = blocked ? ztab + (size_t)((nmodes + ZB - 1) / ZB) * ZB * (size_t)(nz > 1 ? nz - 1 : 1) : nullptr;
-  if (nz >= 2) {
-    ztab[ztab_index(blocked, nmodes, nz, 0, mo)] = z;
-    if (cz) cz[ztab_index(true, nmodes, nz, 0, mo)] = -(c[1] * z);
-  }
+  // (round 5: the blocked table used to be followed by a second one holding -(c_k z_k), the back substitution's coefficient -- a
+  // sixth of the solve's traffic; the register kernel now forms it from z and the level's c, the same multiply)
+  if (nz >= 2) ztab[ztab_index(blocked, nmodes, nz, 0, mo)] = z;
   for (int k = 2; k <= nz - 1; ++k) {
     const double bbk = b[k] + e;
     z = 1. / (bbk - a[k] * d);
     d = c[k] * z;
     ztab[ztab_index(blocked, nmodes, nz, k - 1, mo)] = z;
-    if (cz) cz[ztab_index(true, nmodes, nz, k - 1, mo)] = -(c[k] * z);
   }
   (void)btopD;
 }
@@ -173,18 +169,19 @@ __global__ __launch_bounds__(64) void thomas_kernel(int nmodes, int nz, double s
 // Register-resident segments (round 4).  Rounds 2-3 kept a workgroup's columns in LDS and let one wave walk them (plain and
 // wave-specialised variants, 64 dependent chains per CU): half of the roofline whatever fed them (profiles/r04/thomas_variants_ab.txt;
 // removed).  Here nothing is resident anywhere but in registers: thread (mode mm of the workgroup's ZB modes, segment s) owns SL consecutive levels of
-// one complex column -- SL independent 16-B loads of x, SL pivots and SL back-substitution coefficients, all issued before
-// the first use -- and the two sweeps, first-order linear recurrences  v_l = g_l v_prev + t_l,  are solved by partition:
+// one complex column -- SL independent 16-B loads of x and SL pivots, all issued before the first use (the coefficients -(a z) and
+// -(c z) are formed from the pivot and the level's a, c, which sit in LDS: round 5, the table of -(c z) was a sixth of the traffic)
+// -- and the two sweeps, first-order linear recurrences  v_l = g_l v_prev + t_l,  are solved by partition:
 //   1. zero-inflow recurrence over the own segment -> summary (P = prod g, y) -> LDS, one barrier;
-//   2. every thread chains the summaries of the segments before (forward) / above (back) its own: v_in;
+//   2. the summaries of the segments before (forward) / above (back) the own one, composed: v_in (thomas_scan_in);
 //   3. the own segment again, from v_in, in the reference's order (src/modpois.f90:1120-1166) -- so only the inflow
 //      value carries the partition's rounding;
 //   the top level (Dirichlet row of the singular mode, :209-220) is closed by the thread that owns it between the sweeps.
 // A wave is 8 modes x 8 segments: every load instruction fetches eight full 128-B lines of x (64-B runs of the blocked
-// tables).  Two barriers per workgroup, no LDS traffic but the summaries; x and both tables cross the bus exactly once.
+// table).  Three barriers per workgroup, no LDS traffic but a, c and the summaries; x and the table cross the bus exactly once.
 // NP = 2 (one GPU, spectral layout spec[k][ky][kx]): the eigenvalue of mode (kx, ky) is xrt(kx) + yrt(ky) with yrt(ky) = yrt(ny - ky)
 // bit for bit (pois_init), so rows ky and ny - ky have the same matrix: the workgroup takes the same eight kx of both rows, and the
-// pivot tables -- a third of the solve's traffic -- are read for one of them only (48 -> 40 B per complex mode and level); rows 0
+// pivot table -- a fifth of the solve's traffic -- is read for one of them only (40 -> 36 B per complex mode and level); rows 0
 // and ny / 2 are their own mirror images and run with the second system switched off.
 // MIR (NP = 2, the slab ranks' layout specB[k][kx_l][y], round 5): the mirror image of the run y = 8 b .. 8 b + 7 of a line is the
 // run ny - 8 b - 7 .. ny - 8 b -- contiguous, lane-reversed and one element off the 128-B alignment.  A workgroup takes block b of
@@ -193,17 +190,86 @@ __global__ __launch_bounds__(64) void thomas_kernel(int nmodes, int nz, double s
 // of eight lines share one more workgroup (one system, every lane on its own line and table block).  The straddled 128-B line of a
 // mirrored run is shared with the neighbouring block of the same line: the workgroups are dealt to the XCDs in contiguous runs (as
 // xcd_tile does; the grid is padded to a multiple of eight for that), so that it is fetched once per L2.
+// Step 2 of the partition: the value that enters a thread's segment, from the summaries (P, y) of the segments before it (FWD) or
+// above it (back substitution) -- each summary the affine map v -> P v + y, applied in the order of the sweep to v = 0.
+// Round 5, second session: every thread used to chain all of them out of LDS itself (seg iterations of two LDS reads and two
+// dependent FMAs: at nz = 512 up to 63, 32 on average -- 2.6 us of a workgroup's 10 during which nothing was in flight, and with
+// 512-thread workgroups only one fits a CU).  Now: an exclusive scan of the affine maps over the eight segments a wave holds (lanes
+// 8 apart; Kogge-Stone, three rounds of lane shuffles, compositions f o f_before = (P P', P y' + y)), the composition of a whole wave
+// through LDS (one barrier, as before), at most NW - 1 chained wave summaries, one FMA for the own prefix.  The association differs
+// from the chain's: the inflow value carries the partition's rounding, as it did.
+template <int NP, int NW, bool FWD>
+__device__ __forceinline__ void thomas_scan_in(double P, const double2 (&y)[NP], double2 (&v)[NP], double (*sP)[ZB], double2 (*sY)[NW][ZB], int tid) {
+  const int lane = tid & 63, w = tid >> 6, mm = tid & (ZB - 1), sl = lane >> 3;
+  auto from = [&](double a, int d) { return FWD ? __shfl_up(a, d, 64) : __shfl_down(a, d, 64); };
+  const int pos = FWD ? sl : 7 - sl;       // segments of this wave that come before this one in the sweep
+  // the map of the segment just before (exclusive scan: the first of the wave starts from the identity)
+  double Pe = from(P, 8);
+  double2 ye[NP];
+#pragma unroll
+  for (int s = 0; s < NP; ++s) { ye[s].x = from(y[s].x, 8); ye[s].y = from(y[s].y, 8); }
+  if (pos == 0) {
+    Pe = 1.;
+#pragma unroll
+    for (int s = 0; s < NP; ++s) ye[s] = make_double2(0., 0.);
+  }
+#pragma unroll
+  for (int d = 1; d < 8; d *= 2) {
+    const double Pp = from(Pe, 8 * d);
+    double2 yp[NP];
+#pragma unroll
+    for (int s = 0; s < NP; ++s) { yp[s].x = from(ye[s].x, 8 * d); yp[s].y = from(ye[s].y, 8 * d); }
+    if (pos >= d) {
+#pragma unroll
+      for (int s = 0; s < NP; ++s) { ye[s].x = __builtin_fma(Pe, yp[s].x, ye[s].x); ye[s].y = __builtin_fma(Pe, yp[s].y, ye[s].y); }
+      Pe *= Pp;
+    }
+  }
+  // the wave as a whole: the last segment of the sweep composes its own map with its prefix
+  if (pos == 7) {
+    sP[w][mm] = P * Pe;
+#pragma unroll
+    for (int s = 0; s < NP; ++s) sY[s][w][mm] = make_double2(__builtin_fma(P, ye[s].x, y[s].x), __builtin_fma(P, ye[s].y, y[s].y));
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < NP; ++s) v[s] = make_double2(0., 0.);
+  if (NW > 1) {
+    if (FWD) {
+      for (int q = 0; q < w; ++q) {
+        const double Pq = sP[q][mm];
+#pragma unroll
+        for (int s = 0; s < NP; ++s) {
+          const double2 yq = sY[s][q][mm];
+          v[s].x = __builtin_fma(Pq, v[s].x, yq.x); v[s].y = __builtin_fma(Pq, v[s].y, yq.y);
+        }
+      }
+    } else {
+      for (int q = NW - 1; q > w; --q) {
+        const double Pq = sP[q][mm];
+#pragma unroll
+        for (int s = 0; s < NP; ++s) {
+          const double2 yq = sY[s][q][mm];
+          v[s].x = __builtin_fma(Pq, v[s].x, yq.x); v[s].y = __builtin_fma(Pq, v[s].y, yq.y);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < NP; ++s) { v[s].x = __builtin_fma(Pe, v[s].x, ye[s].x); v[s].y = __builtin_fma(Pe, v[s].y, ye[s].y); }
+}
+
 template <int SL, int NT, int W, int NP, bool MIR>
 __global__ __launch_bounds__(NT, W) void thomas_reg_kernel(int nmodes, int nz, double scale,
     const double *__restrict__ ev, const double *__restrict__ tri, double btopD,
     const double *__restrict__ ztab, double2 *__restrict__ x, int nkb, int ny) {
   static_assert(!MIR || NP == 2, "the mirrored layout is a paired solve");
   constexpr int M = ZB;                    // modes per workgroup and system = lanes per segment
-  constexpr int NS = NT / M;               // segment slots
-  __shared__ double sP[2][NS][M];
-  __shared__ double2 sY[2][NP][NS][M];
+  constexpr int NW = NT / 64;              // waves: eight segments of the eight modes each
+  __shared__ double sP[2][NW][M];          // summaries of whole waves only (see scan_in below)
+  __shared__ double2 sY[2][NP][NW][M];
+  __shared__ double sA[NT + 1], sC[NT + 1];      // a_k, c_k of the levels (entry k = reference level k, 1 .. nz)
   const int tid = threadIdx.x, mm = tid & (M - 1), seg = tid >> 3;
-  const int nseg = (nz + SL - 1) / SL;     // segments that hold a level (<= NS)
   // block of eight modes of system 0 (whose tables are read) and of system 1
   int blk0 = blockIdx.x, blk1 = blockIdx.x;
   bool on1 = false;                        // this lane solves a second system
@@ -250,26 +316,37 @@ __global__ __launch_bounds__(NT, W) void thomas_reg_kernel(int nmodes, int nz, d
   const double *a = tri, *b = tri + (nz + 2), *c = tri + 2 * (nz + 2);
   const size_t st = (size_t)nmodes;
   const int l0 = seg * SL;
-  const size_t ntab = (size_t)((nmodes + ZB - 1) / ZB) * ZB * (size_t)(nz > 1 ? nz - 1 : 1);
-  // addresses: a uniform 64-bit base per level offset j (scalar registers) + one 32-bit byte offset per lane, so that the loads in
-  // flight cost no address registers (the launcher sends arrays of 4 GiB and more to the streaming kernel)
-  const char *zb_ = reinterpret_cast<const char *>(ztab + (size_t)blk0 * (size_t)(nz - 1) * M);      // [lev][M] run of this workgroup
-  const char *cb_ = zb_ + ntab * sizeof(double);
-  char *xb_[NP];
-  xb_[0] = reinterpret_cast<char *>(x + (size_t)blk0 * M);
-  if (NP == 2) xb_[NP - 1] = reinterpret_cast<char *>(MIR ? x + base1 : x + (size_t)blk1 * M);
-  // (the non-mirrored instantiations keep the plain forms: with them the compiler addresses every load as uniform base in scalar
-  // registers + 32-bit lane offset; the general forms cost a 64-bit address pair per stream and 6 % of the kernel at nz = 512)
-  const unsigned zoff = MIR ? (unsigned)(((size_t)l0 * M + (size_t)tlane + (size_t)tskip) * sizeof(double))
-                            : (unsigned)(((size_t)l0 * M + mm) * sizeof(double));
-  unsigned xo_[NP];                        // lane offsets: the same for both systems unless the second one is a mirrored run
-  xo_[0] = MIR ? (unsigned)(((size_t)l0 * st + (size_t)xskip) * sizeof(double2))
-               : (unsigned)(((size_t)l0 * st + (size_t)(moc - blk0 * M)) * sizeof(double2));
-  if (NP == 2) xo_[NP - 1] = MIR ? (unsigned)(((size_t)l0 * st + (size_t)lane1) * sizeof(double2)) : xo_[0];
+  // addresses: buffer descriptors over the whole of x and of the pivot table (kernel arguments: wave-uniform, so the compiler keeps them
+  // in scalar registers), one 32-bit byte offset per lane and stream, the level offset j in the instruction's scalar offset (x) or its
+  // immediate (table): the loads in flight cost no address registers.  (Round 5; the pointer forms cost a 64-bit pair per load in
+  // flight.  The launcher sends arrays of 4 GiB and more to the streaming kernel.)
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(x, 0, (int)(unsigned)((size_t)nmodes * (size_t)nz * sizeof(double2)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(ztab), 0,
+      (int)(unsigned)((size_t)((nmodes + ZB - 1) / ZB) * ZB * (size_t)(nz > 1 ? nz - 1 : 1) * sizeof(double)), 0x00020000);
+  const size_t zrun = (size_t)blk0 * (size_t)(nz - 1) * M;      // [lev][M] run of this workgroup in the table
+  const unsigned zoff = MIR ? (unsigned)((zrun + (size_t)l0 * M + (size_t)tlane + (size_t)tskip) * sizeof(double))
+                            : (unsigned)((zrun + (size_t)l0 * M + mm) * sizeof(double));
+  unsigned xo_[NP];                        // lane offsets of level l0 in the two systems
+  xo_[0] = MIR ? (unsigned)(((size_t)blk0 * M + (size_t)l0 * st + (size_t)xskip) * sizeof(double2))
+               : (unsigned)(((size_t)l0 * st + (size_t)moc) * sizeof(double2));
+  if (NP == 2) xo_[NP - 1] = MIR ? (unsigned)(((size_t)base1 + (size_t)l0 * st + (size_t)lane1) * sizeof(double2))
+                                 : (unsigned)(((size_t)blk1 * M + (size_t)l0 * st + (size_t)(moc - blk0 * M)) * sizeof(double2));
+  const unsigned xlev = (unsigned)(st * sizeof(double2));      // one level up in x
+  auto ldx = [&](int s, int j) {
+    const auto r = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)xo_[s], (int)(j * xlev), 0);
+    union { decltype(__builtin_amdgcn_raw_buffer_load_b128(rx, 0, 0, 0)) v; double2 d; } u;
+    u.v = r;
+    return u.d;
+  };
+  auto ldz = [&](int j) {
+    const auto r = __builtin_amdgcn_raw_buffer_load_b64(rz, (int)(zoff + (unsigned)(j * M * sizeof(double))), 0, 0);
+    union { decltype(__builtin_amdgcn_raw_buffer_load_b64(rz, 0, 0, 0)) v; double d; } u;
+    u.v = r;
+    return u.d;
+  };
   double2 t[NP][SL];
-  double g[SL], cz[SL], aj[SL];
+  double g[SL], cz[SL];      // cz: the pivots z until the back substitution turns them into -(c z)
   double2 xt[NP];                          // (x s) of the top level, kept by its owner
-  const unsigned aoff = (unsigned)((l0 + 1) * sizeof(double));
   // a wave whose eight segments all lie below the top level loads without a test (every load of the kernel is then issued
   // before the first wait); the wave(s) around the top level test each level
   const bool full = __all(l0 + SL <= nz - 1) != 0;
@@ -277,26 +354,29 @@ __global__ __launch_bounds__(NT, W) void thomas_reg_kernel(int nmodes, int nz, d
 #pragma unroll
     for (int j = 0; j < SL; ++j) {
 #pragma unroll
-      for (int s = 0; s < NP; ++s) t[s][j] = *reinterpret_cast<const double2 *>(xb_[s] + (size_t)j * st * sizeof(double2) + xo_[s]);
-      g[j] = *reinterpret_cast<const double *>(zb_ + (size_t)j * M * sizeof(double) + zoff);
-      cz[j] = *reinterpret_cast<const double *>(cb_ + (size_t)j * M * sizeof(double) + zoff);
-      aj[j] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(a) + j * sizeof(double) + aoff);
+      for (int s = 0; s < NP; ++s) t[s][j] = ldx(s, j);
+      cz[j] = ldz(j);
     }
   } else {
 #pragma unroll
     for (int j = 0; j < SL; ++j) {
       const int lev = l0 + j;
 #pragma unroll
-      for (int s = 0; s < NP; ++s)
-        t[s][j] = lev < nz ? *reinterpret_cast<const double2 *>(xb_[s] + (size_t)j * st * sizeof(double2) + xo_[s]) : make_double2(0., 0.);
-      const bool rec = lev < nz - 1;       // levels 1 .. nz-1 of solmpj take part in the recurrences
-      g[j] = rec ? *reinterpret_cast<const double *>(zb_ + (size_t)j * M * sizeof(double) + zoff) : 1.;
-      cz[j] = rec ? *reinterpret_cast<const double *>(cb_ + (size_t)j * M * sizeof(double) + zoff) : 0.;
-      aj[j] = a[min(lev + 1, nz)];
+      for (int s = 0; s < NP; ++s) t[s][j] = lev < nz ? ldx(s, j) : make_double2(0., 0.);
+      cz[j] = lev < nz - 1 ? ldz(j) : 1.;       // levels 1 .. nz-1 of solmpj take part in the recurrences
     }
   }
-  const double *zt = MIR ? reinterpret_cast<const double *>(zb_ + zoff) - (size_t)l0 * M      // this lane's column of the pivot table
-                         : ztab + (size_t)blk0 * (size_t)(nz - 1) * M + mm;
+  // the levels' a and c go through LDS (8 KB at nz = 512) instead of sitting in 32 registers per thread while x and the pivots
+  // travel; their loads (cache hits) behind the big ones, so that nothing waits before those are issued
+  // (entries from the top level on: a = -1, c = 0, which with z = 1 there make the coefficients g = 1 and -(c z) = -0 of the levels
+  // that only pass the carry through -- no test per level in the sweeps)
+  {
+    const int li_ = min(tid + 1, nz);
+    const double av = a[li_], cv = c[li_];
+    sA[tid + 1] = tid + 1 < nz ? av : -1.; sC[tid + 1] = tid + 1 < nz ? cv : 0.;
+  }
+  __syncthreads();
+  const double *zt = reinterpret_cast<const double *>(reinterpret_cast<const char *>(ztab) + zoff) - (size_t)l0 * M;      // this lane's column of the pivot table
   const bool own_top = l0 <= nz - 1 && nz - 1 < l0 + SL;
   double zl = 0., etop = 0.;
   if (own_top) { zl = zt[(size_t)(nz - 2) * M]; etop = ev[moc]; }
@@ -308,9 +388,9 @@ __global__ __launch_bounds__(NT, W) void thomas_reg_kernel(int nmodes, int nz, d
 #pragma unroll
   for (int j = 0; j < SL; ++j) {
     const int lev = l0 + j;
-    const double zz = g[j];
+    const double zz = cz[j];
     const bool rec = lev < nz - 1;
-    g[j] = rec ? -(aj[j] * zz) : 1.;
+    g[j] = -(sA[lev + 1] * zz);
 #pragma unroll
     for (int s = 0; s < NP; ++s) {
       double2 v = t[s][j];
@@ -321,21 +401,8 @@ __global__ __launch_bounds__(NT, W) void thomas_reg_kernel(int nmodes, int nz, d
     }
     P *= g[j];
   }
-  sP[0][seg][mm] = P;
-#pragma unroll
-  for (int s = 0; s < NP; ++s) sY[0][s][seg][mm] = y[s];
-  __syncthreads();
   double2 v[NP];
-#pragma unroll
-  for (int s = 0; s < NP; ++s) v[s] = make_double2(0., 0.);
-  for (int q = 0; q < seg; ++q) {
-    const double Pq = sP[0][q][mm];
-#pragma unroll
-    for (int s = 0; s < NP; ++s) {
-      const double2 yq = sY[0][s][q][mm];
-      v[s].x = __builtin_fma(Pq, v[s].x, yq.x); v[s].y = __builtin_fma(Pq, v[s].y, yq.y);
-    }
-  }
+  thomas_scan_in<NP, NW, true>(P, y, v, sP[0], sY[0], tid);
 #pragma unroll
   for (int j = 0; j < SL; ++j) {
 #pragma unroll
@@ -370,30 +437,22 @@ __global__ __launch_bounds__(NT, W) void thomas_reg_kernel(int nmodes, int nz, d
   for (int s = 0; s < NP; ++s) y[s] = make_double2(0., 0.);
 #pragma unroll
   for (int j = SL - 1; j >= 0; --j) {
+    cz[j] = -(sC[l0 + j + 1] * cz[j]);
 #pragma unroll
     for (int s = 0; s < NP; ++s) { y[s].x = __builtin_fma(cz[j], y[s].x, t[s][j].x); y[s].y = __builtin_fma(cz[j], y[s].y, t[s][j].y); }
     P *= cz[j];
   }
-  sP[1][seg][mm] = P;
-#pragma unroll
-  for (int s = 0; s < NP; ++s) sY[1][s][seg][mm] = y[s];
-  __syncthreads();
-#pragma unroll
-  for (int s = 0; s < NP; ++s) v[s] = make_double2(0., 0.);
-  for (int q = nseg - 1; q > seg; --q) {
-    const double Pq = sP[1][q][mm];
-#pragma unroll
-    for (int s = 0; s < NP; ++s) {
-      const double2 yq = sY[1][s][q][mm];
-      v[s].x = __builtin_fma(Pq, v[s].x, yq.x); v[s].y = __builtin_fma(Pq, v[s].y, yq.y);
-    }
-  }
+  thomas_scan_in<NP, NW, false>(P, y, v, sP[1], sY[1], tid);      // (segments above the top level are (P, y) = (0, 0): they start the chain at 0)
 #pragma unroll
   for (int j = SL - 1; j >= 0; --j) {
 #pragma unroll
     for (int s = 0; s < NP; ++s) {
       v[s].x = __builtin_fma(cz[j], v[s].x, t[s][j].x); v[s].y = __builtin_fma(cz[j], v[s].y, t[s][j].y);
-      if (l0 + j < nz && mok && (s == 0 || on1)) *reinterpret_cast<double2 *>(xb_[s] + (size_t)j * st * sizeof(double2) + xo_[s]) = v[s];
+      if (l0 + j < nz && mok && (s == 0 || on1)) {
+        union { decltype(__builtin_amdgcn_raw_buffer_load_b128(rx, 0, 0, 0)) q; double2 d; } u;
+        u.d = v[s];
+        __builtin_amdgcn_raw_buffer_store_b128(u.q, rx, (int)xo_[s], (int)(j * xlev), 0);
+      }
     }
   }
 }
@@ -401,7 +460,8 @@ __global__ __launch_bounds__(NT, W) void thomas_reg_kernel(int nmodes, int nz, d
 // Which solve.  The table's layout follows the kernel, so the choice is made once per table (udc_create reads UDC_THOMAS into the
 // handle: 0 = the streaming kernel everywhere).  Default: register-resident segments for nz <= 1024 and arrays below 4 GiB (every
 // deck there is), the streaming kernel otherwise.
-static bool thomas_reg_fits(long nmodes, int nz) { return nz >= 3 && nz <= 1024 && (size_t)nmodes * (size_t)nz * 16 < ((size_t)1 << 32); }
+// (32-bit byte offsets into x: the whole array, and eight levels from any element of it)
+static bool thomas_reg_fits(long nmodes, int nz) { return nz >= 3 && nz <= 1024 && (size_t)nmodes * (size_t)(nz > 8 ? nz : 8) * 16 < ((size_t)1 << 32); }
 static bool thomas_wants_lds(const udc_handle *h, long nmodes, int nz) {      // -> the blocked tables of the register kernel
   return h->sw.thomas != 0 && thomas_reg_fits(nmodes, nz);
 }
@@ -830,7 +890,7 @@ int pois_init(udc_handle *h) {
   HIP_OK(hipMalloc(&h->spec, sizeof(double) * 2 * nmodes * nz));
   HIP_OK(hipMemsetAsync(h->spec, 0, sizeof(double) * 2 * nmodes * nz, h->stream));
   h->thomas_lds = thomas_wants_lds(h, (long)nmodes, nz);
-  HIP_OK(hipMalloc(&h->ztab, sizeof(double) * ztab_doubles((long)nmodes, nz) * (h->thomas_lds ? 2 : 1)));
+  HIP_OK(hipMalloc(&h->ztab, sizeof(double) * ztab_doubles((long)nmodes, nz)));
   HIP_OK(hipMalloc(&h->ev, sizeof(double) * nmodes));
   HIP_OK(hipMalloc(&h->tri, sizeof(double) * tri.size()));
   HIP_OK(hipMemcpy(h->ev, ev.data(), sizeof(double) * nmodes, hipMemcpyHostToDevice));
@@ -954,7 +1014,7 @@ int pois_slab_init(udc_handle *h) {
   HIP_OK(hipMalloc(&h->a2a_recv, sizeof(double) * 2 * nmodes * nz));
   HIP_OK(hipMalloc(&h->ev_slab, sizeof(double) * nmodes));
   h->thomas_lds_slab = thomas_wants_lds(h, (long)nmodes, nz);
-  HIP_OK(hipMalloc(&h->ztab_slab, sizeof(double) * ztab_doubles((long)nmodes, nz) * (h->thomas_lds_slab ? 2 : 1)));
+  HIP_OK(hipMalloc(&h->ztab_slab, sizeof(double) * ztab_doubles((long)nmodes, nz)));
   HIP_OK(hipMalloc(&h->tri, sizeof(double) * tri.size()));
   HIP_OK(hipMemcpy(h->ev_slab, ev.data(), sizeof(double) * nmodes, hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(h->tri, tri.data(), sizeof(double) * tri.size(), hipMemcpyHostToDevice));
