@@ -311,6 +311,8 @@ def oracle_state(st, g, nsv):
     ((128, 8, 6), 1, 2, 1.10, False),       # ragged aspect, two scalars
     ((40, 24, 16), 2, 1, 1.05, True),       # floor wall function (lbottom, BCbotm = 3) + scalar floor
     ((12, 8, 6), 0, 0, 1.00, True),         # floor under DNS viscosity
+    ((16, 16, 300), 2, 0, 1.01, False),     # tall columns: 512-thread workgroups (eight levels per thread) / sixteen levels per thread unpaired
+    ((8, 8, 530), 1, 0, 1.005, True),       # ... above 512 levels: two systems per thread do not fit, sixteen levels per thread everywhere
 ])
 @pytest.mark.parametrize("thomas", ["stream", "reg", "reg-nopair", "slab-mirror"])
 def test_against_oracle_seeded(shape, sgs, nsv, stretch, floor, thomas, monkeypatch):

@@ -34,7 +34,7 @@ extern "C" int udc_version(void) { return 100; }
 // ------------------------------------------------------------------------------ profiling
 ProfScope::ProfScope(udc_handle *h_, const char *name) : h(h_), id(-1) {
   if (!h->prof) return;
-  if (h->prof_focus_on && strncmp(name, h->prof_focus.c_str(), h->prof_focus.size()) != 0) return;
+  if (h->prof_focus_on && (strncmp(name, h->prof_focus.c_str(), h->prof_focus.size()) != 0 || (h->substep_seq - h->prof_phase - 1) % h->prof_every != 0)) return;
   auto it = h->prof_ids.find(name);
   if (it == h->prof_ids.end()) {
     id = (int)h->prof_names.size();
@@ -98,6 +98,12 @@ extern "C" int udc_profile_enable(udc_handle *h, int on) {
 extern "C" int udc_profile_focus(udc_handle *h, const char *name_prefix) {
   if (!h || !name_prefix) { udc_set_error("udc_profile_focus: null argument"); return 1; }
   h->prof_focus = name_prefix;
+  return 0;
+}
+extern "C" int udc_profile_every(udc_handle *h, int n) {
+  if (!h || n < 1) { udc_set_error("udc_profile_every: null handle or n < 1"); return 1; }
+  h->prof_every = n;
+  h->prof_phase = h->substep_seq;       // the next fused substep is a timed one, then every n-th after it
   return 0;
 }
 extern "C" int udc_profile_reset(udc_handle *h) {
@@ -1007,6 +1013,7 @@ enum : unsigned {
 static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   const double rk3coef = dt / (4. - (double)rk3step);
   h->bcx_rk3coef = rk3coef;
+  ++h->substep_seq;
   if (k_scalar_bcx_uout(h)) return 1;      // BCxs = 2 without a prescribed volume flow: the outlet's speed from the state the substep starts from
   // what runs, in which order, is decided in one place: plan_substep (udc_plan.h; DESIGN.md section 7 has the table, the CPU test
   // tests/test_substep_plan.py enumerates it)

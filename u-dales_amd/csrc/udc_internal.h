@@ -341,6 +341,8 @@ struct udc_handle {
   bool prof = false;
   bool prof_focus_on = false;           // only launches whose name starts with prof_focus are timed
   std::string prof_focus;
+  int prof_every = 1;                   // focus mode: the launches of every prof_every-th fused substep only (udc_profile_every)
+  long substep_seq = 0, prof_phase = 0; // fused substeps run so far; ... when udc_profile_every was called
   std::vector<ProfEntry> prof_events;
   std::vector<hipEvent_t> prof_pool;
   hipEvent_t prof_chain = nullptr;      // end marker of the previous profiled launch (start marker of the next)

@@ -268,7 +268,8 @@ __global__ __launch_bounds__(NT, W) void thomas_reg_kernel(int nmodes, int nz, d
   constexpr int NW = NT / 64;              // waves: eight segments of the eight modes each
   __shared__ double sP[2][NW][M];          // summaries of whole waves only (see scan_in below)
   __shared__ double2 sY[2][NP][NW][M];
-  __shared__ double sA[NT + 1], sC[NT + 1];      // a_k, c_k of the levels (entry k = reference level k, 1 .. nz)
+  constexpr int NLEV = SL * (NT / M);      // levels the workgroup's segments cover (>= nz)
+  __shared__ double sA[NLEV + 1], sC[NLEV + 1];      // a_k, c_k of the levels (entry k = reference level k, 1 .. nz)
   const int tid = threadIdx.x, mm = tid & (M - 1), seg = tid >> 3;
   // block of eight modes of system 0 (whose tables are read) and of system 1
   int blk0 = blockIdx.x, blk1 = blockIdx.x;
@@ -370,10 +371,11 @@ __global__ __launch_bounds__(NT, W) void thomas_reg_kernel(int nmodes, int nz, d
   // travel; their loads (cache hits) behind the big ones, so that nothing waits before those are issued
   // (entries from the top level on: a = -1, c = 0, which with z = 1 there make the coefficients g = 1 and -(c z) = -0 of the levels
   // that only pass the carry through -- no test per level in the sweeps)
-  {
-    const int li_ = min(tid + 1, nz);
+#pragma unroll
+  for (int it = 0; it < NLEV / NT; ++it) {      // (NLEV = (SL / 8) NT: entries 1 .. NLEV, no test)
+    const int k = tid + 1 + it * NT, li_ = min(k, nz);
     const double av = a[li_], cv = c[li_];
-    sA[tid + 1] = tid + 1 < nz ? av : -1.; sC[tid + 1] = tid + 1 < nz ? cv : 0.;
+    sA[k] = k < nz ? av : -1.; sC[k] = k < nz ? cv : 0.;
   }
   __syncthreads();
   const double *zt = reinterpret_cast<const double *>(reinterpret_cast<const char *>(ztab) + zoff) - (size_t)l0 * M;      // this lane's column of the pivot table
@@ -467,10 +469,10 @@ static bool thomas_wants_lds(const udc_handle *h, long nmodes, int nz) {      //
 }
 static size_t ztab_doubles(long nmodes, int nz) { return (size_t)((nmodes + ZB - 1) / ZB) * ZB * (size_t)(nz > 1 ? nz - 1 : 1); }
 
-template <int NT, int W, int NP, bool MIR>
+template <int NT, int W, int NP, bool MIR, int SL = 8>
 static void launch_thomas_reg(udc_handle *h, long nmodes, int nz, double scale, const double *ev, const double *ztab, double2 *x, int nkb, int ny) {
   const unsigned blocks = MIR ? (unsigned)(((nmodes / ny) * nkb + (nmodes / ny + 7) / 8 + 7) / 8 * 8) : (NP == 2 ? (unsigned)((ny / 2 + 1) * nkb) : (unsigned)((nmodes + ZB - 1) / ZB));
-  hipLaunchKernelGGL((thomas_reg_kernel<8, NT, (W > NT / 256 ? W : NT / 256), NP, MIR>), dim3(blocks), dim3(NT), 0, h->stream,
+  hipLaunchKernelGGL((thomas_reg_kernel<SL, NT, (W > NT / 256 ? W : NT / 256), NP, MIR>), dim3(blocks), dim3(NT), 0, h->stream,
                      (int)nmodes, nz, scale, ev, h->tri, h->btopD, ztab, x, nkb, ny);
 }
 
@@ -500,6 +502,13 @@ static int launch_thomas(udc_handle *h, bool blocked, long nmodes, int nz, doubl
     int ny_ = pair_ny;
     if (mirror) { ny_ = mirror_ny; nkb = mirror_ny / 16; UDC_TR(2, 2, true); }
     else if (pair) UDC_TR(2, 2, false);
+    else if (nz > tune::THOMAS_SL16_ABOVE) {
+      // tall columns, one system per thread: sixteen levels per thread (t, z, g: 128 registers of 250) halve the workgroup -- at
+      // nz = 512 two of 256 threads share a CU and one loads while the other solves (with eight levels the one 512-thread
+      // workgroup a CU holds does the two in turn); above 512 levels no 1024-thread workgroup capped at 128 registers
+      if (nz <= 512) launch_thomas_reg<256, 2, 1, false, 16>(h, nmodes, nz, scale, ev, ztab, x, nkb, ny_);
+      else launch_thomas_reg<512, 2, 1, false, 16>(h, nmodes, nz, scale, ev, ztab, x, nkb, ny_);
+    }
     else UDC_TR(3, 1, false);
 #undef UDC_TR
     return 0;

@@ -25,4 +25,9 @@ inline int closure_per_cu(int tiles) { return tiles >= 1024 ? 5 : 4; }
 constexpr int FFT_X_LDS_BUDGET = 40000, FFT_X_MIN_ROWS = 4, FFT_Y_COLS = 8;
 constexpr int NAT_X_ROWS = 4, NAT_Y_COLS = 8;
 
+// Thomas solve with one system per thread (the slab ranks' lines shorter than 256, UDC_THOMAS_PAIR=0): sixteen levels per thread
+// instead of eight above this many levels (one rank's slab of eight of 1024 x 512 x 512: 150 -> 134 us; the same grid unpaired on one GPU
+// 1.27 -> 1.15 ms; no difference at 256 levels: profiles/r05/thomas_scan_ab.txt).
+constexpr int THOMAS_SL16_ABOVE = 256;
+
 }  // namespace tune

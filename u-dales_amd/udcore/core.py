@@ -500,11 +500,12 @@ class DynCore:
         L._check(self.lib.udc_sync(self.h), "udc_sync")
 
     # ---- measurement
-    def profile(self, on=True, focus=None):
+    def profile(self, on=True, focus=None, every=1):
         """HIP-event timing of the launches: every one (on=True), or only those whose name starts with `focus`
-        (two events per such launch and none elsewhere: affordable inside a timed region)."""
+        (two events per such launch and none elsewhere: affordable inside a timed region), in every `every`-th substep."""
         if on and focus:
             L._check(self.lib.udc_profile_focus(self.h, focus.encode()), "udc_profile_focus")
+            L._check(self.lib.udc_profile_every(self.h, int(every)), "udc_profile_every")
             L._check(self.lib.udc_profile_enable(self.h, 2), "udc_profile_enable")
         else:
             L._check(self.lib.udc_profile_enable(self.h, 1 if on else 0), "udc_profile_enable")

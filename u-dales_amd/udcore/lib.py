@@ -33,7 +33,7 @@ EXPORTS = ["udc_create", "udc_destroy", "udc_last_error", "udc_version", "udc_co
            "udc_set_deferred", "udc_flush", "udc_deferred_stats",
            "udc_stats_enable", "udc_stats_sample", "udc_stats_get", "udc_stats_set_masks", "udc_stats_xyt", "udc_stats_set_forced", "udc_stats_yt", "udc_stats_xy", "udc_stats_y", "udc_set_floor_air_temperature", "udc_set_ibm_wallfun", "udc_set_ibm_sections", "udc_set_ibm_wallheat", "udc_set_ibm_wallmoist", "udc_set_scalar_bcx", "udc_set_scalar_bcx_outflow", "udc_set_ibm_points", "udc_ibm_commit", "udc_ibmwallfun", "udc_ibmnorm",
            "udc_divergence", "udc_checksim", "udc_checksim_begin", "udc_checksim_end", "udc_sync", "udc_profile_enable", "udc_profile_reset",
-           "udc_profile_get", "udc_profile_focus", "udc_set_ibm_mask_wrap", "udc_bottom_diagnostics", "udc_bottom_diag_get", "udc_set_ibm_conservative"]
+           "udc_profile_get", "udc_profile_focus", "udc_profile_every", "udc_set_ibm_mask_wrap", "udc_bottom_diagnostics", "udc_bottom_diag_get", "udc_set_ibm_conservative"]
 
 
 class UdcConfig(C.Structure):
