@@ -6,6 +6,7 @@
   c1  256 x 256 x 256 neutral channel (bench.py's deck: Vreman, floor wall function, fixed dt = 0.25), 100 steps = 300 RK3 substeps
       (SURVEY.md section 8(d) "Parity run")
   c2  512 x 512 x 256, Smagorinsky + one kappa-advected scalar (linear profile), 3 steps = 9 substeps
+  c3s 1024 x 64 x 512 neutral channel, 3 steps = 9 substeps: one rank's slab of eight of configs[3] as a whole domain
 
 oracle/_ref/udales_ref (the reference's unmodified src/ under oracle/ref_driver.f90, see make_golden.py) runs the deck that
 bench.write_deck writes and dumps its state after the last substep; what is kept per field (u0, v0, w0, pres0[, sv0_01], interior cells):
@@ -31,6 +32,9 @@ REF = os.path.join(ROOT, "oracle", "_ref", "udales_ref")
 CASES = {      # name: (iexpnr, nx, ny, nz, nsub, write_deck keywords, sample strides (x, y, z), fields)
     "c1": (77, 256, 256, 256, 300, {}, (8, 8, 8), ("u0", "v0", "w0", "pres0")),
     "c2": (79, 512, 512, 256, 9, dict(nsv=1, sgs="smag"), (16, 16, 8), ("u0", "v0", "w0", "pres0", "sv0_01")),
+    # one rank's slab of eight of configs[3] (1024 x 512 x 512 on 8 GPUs) as a whole domain: the shapes the multi-GPU kernels work on
+    # (x lines of 1024, columns of 512 levels); configs[3]'s own grid does not fit this container's memory under the reference
+    "c3s": (81, 1024, 64, 512, 9, {}, (32, 4, 16), ("u0", "v0", "w0", "pres0")),
 }
 OFFSET = (3, 5, 1)
 
