@@ -2,8 +2,8 @@
 
 substep_fused (u-dales_amd/csrc/udc_api.hip) no longer decides anything itself: it asks plan_substep (udc_plan.h, a pure function of the
 switches, of what the handle is and of the call) and executes the answer.  Here that function -- compiled by g++ into
-u-dales_amd/lib/libudcplan.so, no GPU involved -- is run over EVERY combination of its inputs (all 2^6 switch settings x a lattice of
-configurations and calls: ~9 million rows) and compared with the table as DESIGN.md states it, written down a second time below in
+u-dales_amd/lib/libudcplan.so, no GPU involved -- is run over EVERY combination of its inputs (all 2^7 switch settings x a lattice of
+configurations and calls: ~19 million rows) and compared with the table as DESIGN.md states it, written down a second time below in
 numpy; and the invariants that make an order safe are checked on every row."""
 import ctypes
 import itertools
@@ -15,11 +15,11 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "u-dales_amd", "lib", "libudcplan.so")
 
-IN = ["no_fold", "no_alias", "ek_always", "halo_overlap", "mom_pipe", "div_in_fft",
-      "slab", "comm_stream", "sgs", "lbuoycorr", "nslots", "ibm_on", "stats_any", "fft_fused", "own_fwd", "between",
+IN = ["no_fold", "no_alias", "ek_always", "halo_overlap", "mom_pipe", "div_in_fft", "ptotal",
+      "slab", "comm_stream", "sgs", "lbuoycorr", "nslots", "ibm_on", "stats_any", "fft_fused", "own_fwd", "tend_plane", "between",
       "closure_tile_rows", "mom_tile_rows", "int_tile_rows", "x_row_groups", "levels_per_chunk", "rk3step", "um_alias", "ibm_edits_now"]
 OUT = ["lds", "pup", "fold", "alias_ok", "materialise_um", "rotate", "skip_um", "closure", "need_ekh", "mom_pipe", "div_in_fft",
-       "vp_row", "p_row", "integrate"]
+       "vp_row", "p_row", "integrate", "ptotal"]
 FOLDED, OVERLAPPED, PLAIN = 0, 1, 2
 ROW_FOLDED, ROW_BESIDE, ROW_INLINE, ROW_PIPED = 0, 1, 2, 3
 INT_ONE, INT_EDGES_FIRST = 0, 1
@@ -65,14 +65,15 @@ def table(i):
                                             ROW_FOLDED))
     prow = np.where(fold, ROW_FOLDED, np.where(beside(i["int_tile_rows"]) & (i["int_tile_rows"] >= 4), ROW_BESIDE, ROW_INLINE))
     integ = np.where(~fold & beside(i["int_tile_rows"]), INT_EDGES_FIRST, INT_ONE)
+    ptot = b(i["ptotal"]) & pup & ~b(i["ibm_on"]) & ~b(i["tend_plane"])
     return dict(lds=lds, pup=pup, fold=fold, alias_ok=alias_ok, materialise_um=mat, rotate=rotate, skip_um=skip, closure=closure,
-                need_ekh=need_ekh, mom_pipe=pipe, div_in_fft=div, vp_row=vp, p_row=prow, integrate=integ)
+                need_ekh=need_ekh, mom_pipe=pipe, div_in_fft=div, vp_row=vp, p_row=prow, integrate=integ, ptotal=ptot)
 
 
 def lattice():
     """every configuration / call for one setting of the eight switches"""
     axes = dict(slab=[0, 1], sgs=[0, 1, 2, 3], lbuoycorr=[0, 1], nslots=[0, 2], ibm_on=[0, 1], stats_any=[0, 1], fft_fused=[0, 1],
-                own_fwd=[0, 1], between=[0, 1], rows=[2, 3, 8], x_row_groups=[1, 4], levels_per_chunk=[2, 16], rk3step=[1, 2, 3],
+                own_fwd=[0, 1], tend_plane=[0, 1], between=[0, 1], rows=[2, 3, 8], x_row_groups=[1, 4], levels_per_chunk=[2, 16], rk3step=[1, 2, 3],
                 um_alias=[0, 1], ibm_edits_now=[0, 1])
     grids = np.meshgrid(*[np.array(v, dtype=np.int32) for v in axes.values()], indexing="ij")
     cols = {k: g.ravel() for k, g in zip(axes, grids)}
@@ -88,9 +89,9 @@ def test_every_combination_matches_the_table_and_is_safe():
     base = lattice()
     n = len(base["slab"])
     total = 0
-    for sw in itertools.product([0, 1], repeat=6):
+    for sw in itertools.product([0, 1], repeat=7):
         i = dict(base)
-        for name, v in zip(IN[:6], sw):
+        for name, v in zip(IN[:7], sw):
             i[name] = np.full(n, v, dtype=np.int32)
         rows = np.stack([i[k] for k in IN], axis=1)
         got = run(L, rows)
@@ -118,14 +119,18 @@ def test_every_combination_matches_the_table_and_is_safe():
         assert ((g["rotate"] + g["materialise_um"]) == i["um_alias"]).all()
         # the divergence inside a transform needs the predicted-velocity form of the tendencies
         assert not ((g["div_in_fft"] == 1) & (g["pup"] == 0)).any()
+        # the pressure-total form: never with obstacles (ibmnorm edits the tendencies point by point) nor where the tendencies are read
+        # on one plane (outflow-rate mass correction), only over the predicted-velocity form
+        pt = g["ptotal"] == 1
+        assert not (pt & ((i["ibm_on"] == 1) | (i["tend_plane"] == 1) | (g["pup"] == 0))).any()
         total += n
-    assert total == 64 * n and n > 100000
+    assert total == 128 * n and n > 100000
 
 
 def test_named_configurations():
     """The rows of DESIGN.md section 7's table for the BASELINE configurations, with the library's defaults."""
     L = lib()
-    dflt = dict(no_fold=0, no_alias=0, ek_always=0, halo_overlap=1, mom_pipe=1, div_in_fft=1, lbuoycorr=0, stats_any=0,
+    dflt = dict(no_fold=0, no_alias=0, ek_always=0, halo_overlap=1, mom_pipe=1, div_in_fft=1, ptotal=1, tend_plane=0, lbuoycorr=0, stats_any=0,
                 ibm_edits_now=0, um_alias=0)
 
     def one(**kw):

@@ -150,6 +150,7 @@ void udc_read_switches(Switches &sw) {
   sw.fft_fused = env_int("UDC_FFT_FUSED", 1) != 0;
   sw.own_fwd = env_int("UDC_OWN_FWD", -1);
   sw.div_in_fft = env_int("UDC_DIV_IN_FFT", 1) != 0;
+  sw.ptotal = env_int("UDC_PTOTAL", 1) != 0;
   sw.no_fold = env_int("UDC_NO_FOLD", 0) != 0;
   sw.no_alias = env_int("UDC_NO_ALIAS", 0) != 0;
   sw.ek_always = env_int("UDC_EK_ALWAYS", 0) != 0;
@@ -1019,10 +1020,11 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   // tests/test_substep_plan.py enumerates it)
   PlanIn pin{};
   pin.no_fold = h->no_fold; pin.no_alias = h->no_alias;
-  pin.ek_always = h->ek_always; pin.halo_overlap = !h->no_halo_overlap; pin.mom_pipe = !h->no_mom_pipe; pin.div_in_fft = !h->no_div_in_fft;
+  pin.ek_always = h->ek_always; pin.halo_overlap = !h->no_halo_overlap; pin.mom_pipe = !h->no_mom_pipe; pin.div_in_fft = !h->no_div_in_fft; pin.ptotal = h->sw.ptotal;
   pin.slab = h->slab; pin.comm_stream = h->comm_stream != nullptr; pin.sgs = h->p.sgs; pin.lbuoycorr = h->lbuoycorr;
   pin.nslots = (int)h->slots.size(); pin.ibm_on = h->ibm_on; pin.stats_any = h->stats_on || h->xyt_on || h->yt_on;
   pin.fft_fused = h->fft_fused; pin.own_fwd = h->own_fwd;
+  pin.tend_plane = h->luvolflowr == 2;
   pin.between = h->coriolis_mode || !h->level_forcings.empty() || h->luvolflowr || h->lvvolflowr || h->ibm_on || h->shift_a != 0. ||
                 h->thlpcar || h->lbuoyancy;
   pin.closure_tile_rows = closure_lds_tile_rows(h->g); pin.mom_tile_rows = momentum_lds_tile_rows(h->g); pin.int_tile_rows = tile_grid(h->g).gy;
@@ -1068,14 +1070,14 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
     const bool pipe = plan.mom_pipe;
     if (pipe) {
       const MomPart row0{0, 1, 0, 0, true};
-      if (k_momentum_lds(h, true, true, forces, true, 1. / rk3coef, rotate, &row0)) return 1;
+      if (k_momentum_lds(h, true, true, forces, true, 1. / rk3coef, rotate, &row0, !plan.ptotal)) return 1;
       if (floor_on && k_bottom(h, false, 0, momentum_lds_tile_height())) return 1;
       const int fvp[1] = {UDC_VP};
       if (k_halo_y_begin(h, fvp, 1, 1, nullptr, HALO_TO_PREV)) return 1;      // (only the divergence of the slab's last row reads a ghost row of vp)
       h->vp_halo_pending = true;
       h->mom_pipe.active = true; h->mom_pipe.forces = forces; h->mom_pipe.um_is_u0 = rotate; h->mom_pipe.bottom = floor_on;
-      h->mom_pipe.rk3coefi = 1. / rk3coef;
-    } else if (k_momentum_lds(h, true, true, forces, true, 1. / rk3coef, rotate)) return 1;
+      h->mom_pipe.rk3coefi = 1. / rk3coef; h->mom_pipe.pgrad = !plan.ptotal;
+    } else if (k_momentum_lds(h, true, true, forces, true, 1. / rk3coef, rotate, nullptr, !plan.ptotal)) return 1;
   }
   const bool piped = h->mom_pipe.active;      // (then nothing below up to the solve has anything to do: see `pipe`)
   if (k_scalar_top_flux(h)) return 1;
@@ -1133,25 +1135,28 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   const bool ov_p = plan.p_row == ROW_BESIDE;
   if (plan.p_row != ROW_FOLDED) {
     const int fp[1] = {UDC_P};
-    // (only the projection of the slab's first row reads a ghost row of p: the previous rank's last row)
-    if (ov_p) { if (k_halo_y_begin(h, fp, 1, 1, nullptr, HALO_TO_NEXT)) return 1; }
-    else if (k_halo_y(h, fp, 1, 1, HALO_TO_NEXT)) return 1;
+    // (only the projection of the slab's first row reads a ghost row of p: the previous rank's last row; in the pressure-total form
+    // p is the new pres0 and its other ghost row travels with it -- pres0 then leaves the exchange of the velocities' rows below)
+    const int pdirs = plan.ptotal ? HALO_BOTH : HALO_TO_NEXT;
+    if (ov_p) { if (k_halo_y_begin(h, fp, 1, 1, nullptr, pdirs)) return 1; }
+    else if (k_halo_y(h, fp, 1, 1, pdirs)) return 1;
   }
   const bool skip_um = plan.skip_um;
   // y-slabs: the rows next to the neighbouring ranks first; the ghost rows of the new velocities and of pres0 travel while the rows
   // in between are integrated (the exchange names the arrays as they will be known after the pointer rotation below)
   const bool ov_int = plan.integrate == INT_EDGES_FIRST;
   bool ov_scal = false;
+  const bool ptot = plan.ptotal != 0;
   if (ov_int) {
     const int rb = ov_p ? 1 + std::max(1, (gyI - 2) / 4) : 1;      // interior tile rows [1, rb) first, [rb, gyI - 1) last
     if (ov_p) {
-      if (k_project_integrate(h, rk3step, dt, !lds, pup, fold, !skip_um, rotate, 3, 1, rb)) return 1;
+      if (k_project_integrate(h, rk3step, dt, !lds, pup, fold, !skip_um, rotate, 3, 1, rb, ptot)) return 1;
       if (k_halo_y_join(h)) return 1;
     }
-    if (k_project_integrate(h, rk3step, dt, !lds, pup, fold, !skip_um, rotate, 1)) return 1;
+    if (k_project_integrate(h, rk3step, dt, !lds, pup, fold, !skip_um, rotate, 1, 0, 0, ptot)) return 1;
     int f[8];
     int nf = vel_fields(h, skip_um ? 0 : rk3step, f);
-    f[nf++] = UDC_PRES0;
+    if (!ptot) f[nf++] = UDC_PRES0;
     double *ptr[8];
     for (int q = 0; q < nf; ++q) {
       int id = f[q];
@@ -1165,9 +1170,10 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
     scalar_halo_list(h, rk3step, sc);
     ov_scal = !sc.empty() && sc.size() <= 16 && !(h->lchem && rk3step == 3);
     if (ov_scal && k_halo_y_begin(h, sc.data(), (int)sc.size(), 2)) return 1;
-    if (rb < gyI - 1 && k_project_integrate(h, rk3step, dt, !lds, pup, fold, !skip_um, rotate, 4, rb, gyI - 1)) return 1;
+    if (rb < gyI - 1 && k_project_integrate(h, rk3step, dt, !lds, pup, fold, !skip_um, rotate, 4, rb, gyI - 1, ptot)) return 1;
     if (k_halo_y_join(h)) return 1;
-  } else if (k_project_integrate(h, rk3step, dt, !lds, pup, fold, !skip_um, rotate)) return 1;
+  } else if (k_project_integrate(h, rk3step, dt, !lds, pup, fold, !skip_um, rotate, 0, 0, 0, ptot)) return 1;
+  if (ptot) std::swap(h->fields[UDC_P], h->fields[UDC_PRES0]);      // what the solve returned is pres0 now; the old pres0 array takes the next solve's output
   h->dthv_top_on = false;
   if (rk3step == 3 && k_chem(h, dt)) return 1;      // src/modtstep.f90:236-238 (before the ghosts are refreshed)
   if (rotate) {
@@ -1179,7 +1185,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   if (!fold && !ov_int) {
     int f[8];
     int nf = vel_fields(h, skip_um ? 0 : rk3step, f);
-    f[nf++] = UDC_PRES0;
+    if (!ptot) f[nf++] = UDC_PRES0;
     if (k_halo_y(h, f, nf, 1)) return 1;
   }
   std::vector<int> s;
@@ -1200,7 +1206,7 @@ extern "C" int udc_last_plan(udc_handle *h, int out[16]) {
   if (!h->have_plan) { udc_set_error("udc_last_plan: no fused substep has run on this handle"); return 1; }
   const Plan &p = h->last_plan;
   const int v[16] = {p.fold, p.closure, p.need_ekh, p.mom_pipe, p.div_in_fft, p.vp_row, p.p_row, p.integrate, p.rotate, p.skip_um,
-                     p.materialise_um, h->slab ? 1 : 0, h->fft_fused ? 1 : 0, h->nch, h->own_fwd ? 1 : 0, h->own_bwd ? 1 : 0};
+                     p.materialise_um, h->slab ? 1 : 0, h->fft_fused ? 1 : 0, h->nch, h->own_fwd ? 1 : 0, p.ptotal};
   for (int q = 0; q < 16; ++q) out[q] = v[q];
   return 0;
 }
@@ -1213,7 +1219,7 @@ int k_momentum_pipe_stage(udc_handle *h, int c) {
   const int nch = h->nch, nzc = h->g.nz / nch, gy = momentum_lds_tile_rows(h->g);
   const int kbeg = c == 0 ? 0 : c * nzc + 1, kend = c == nch - 1 ? h->g.nz : (c + 1) * nzc + 1;
   const MomPart part{1, gy, kbeg, kend, c != nch - 1};
-  if (k_momentum_lds(h, true, true, h->mom_pipe.forces, true, h->mom_pipe.rk3coefi, h->mom_pipe.um_is_u0, &part)) return 1;
+  if (k_momentum_lds(h, true, true, h->mom_pipe.forces, true, h->mom_pipe.rk3coefi, h->mom_pipe.um_is_u0, &part, h->mom_pipe.pgrad)) return 1;
   if (c == 0 && h->mom_pipe.bottom && k_bottom(h, false, momentum_lds_tile_height(), -1)) return 1;
   return 0;
 }

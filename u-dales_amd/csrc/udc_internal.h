@@ -148,6 +148,7 @@ struct Switches {
   int fft_fused = 1;         // UDC_FFT_FUSED=0: rocFFT + transpose kernels on the slab path
   int own_fwd = -1;          // UDC_OWN_FWD=0/1: single-slab forward half in own kernels
   int div_in_fft = 1;        // UDC_DIV_IN_FFT=0: separate divergence kernel on the slab path
+  int ptotal = 1;            // UDC_PTOTAL=0: the fused substep keeps pres0 and p apart like the reference (single slab: no pressure-total form)
   int no_fold = 0, no_alias = 0;      // UDC_NO_FOLD / UDC_NO_ALIAS = 1
   int ek_always = 0;         // UDC_EK_ALWAYS=1: every substep writes ekm / ekh
   int scalar_pair = 1;       // UDC_SCALAR_PAIR=0: thl and qt swept one by one
@@ -373,7 +374,7 @@ struct udc_handle {
   bool halo_async_pending = false;      // a k_halo_y_begin has not been joined yet (k_halo_y joins it before touching the shared buffers)
   // the momentum sweep pipelined with the slab solve (substep_fused, k_momentum_pipe_stage): tile row 0 is swept first over all
   // levels, the other rows level range by level range ahead of the x forward transform of the same k-chunk
-  struct MomPipe { bool active = false, forces = false, um_is_u0 = false, bottom = false; double rk3coefi = 0.; } mom_pipe;
+  struct MomPipe { bool active = false, forces = false, um_is_u0 = false, bottom = false, pgrad = true; double rk3coefi = 0.; } mom_pipe;
   bool no_mom_pipe = false;             // UDC_MOM_PIPE=0
   bool vp_halo_pending = false;         // vp's ghost row is travelling (k_halo_y_begin): the x forward transform joins before its last row group
   bool no_halo_overlap = false;         // UDC_HALO_OVERLAP=0: every ghost-row exchange in line on the compute stream
@@ -431,7 +432,8 @@ int k_closure_lds(udc_handle *h, bool ghosts, bool write_ekh = true, int rows = 
 int k_ek_ghosts(udc_handle *h, bool exchange = true);
 int closure_lds_tile_rows(const Geo &g);      // tile rows of k_closure_lds over the slab
 struct MomPart { int r0, r1, kbeg, kend; bool more; };      // a piece of the momentum sweep: tile rows [r0, r1), levels [kbeg, kend)
-int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, double rk3coefi, bool um_is_u0 = false, const MomPart *part = nullptr);
+int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, double rk3coefi, bool um_is_u0 = false, const MomPart *part = nullptr,
+                   bool pgrad = true);      // pgrad false: the pressure-total form (no gradient of pres0; fused substep only)
 int momentum_lds_tile_rows(const Geo &g);
 int momentum_lds_tile_height();
 int k_momentum_pipe_stage(udc_handle *h, int c);      // the sweep's level range that feeds k-chunk c of the slab solve (udc_api.hip)  // rk3coefi != 0: PUP mode   // LDS-staged k-marching version (default)
@@ -453,7 +455,7 @@ int k_poisson_solve(udc_handle *h);
 int k_project(udc_handle *h);                       // tderive: up,vp,wp -= grad p ; pres0 += p
 int k_integrate(udc_handle *h, int rk3step, double dt);
 int k_project_integrate(udc_handle *h, int rk3step, double dt, bool zero_tend, bool pup, bool ghosts,
-                        bool write_um = true, bool out_to_um = false, int rows = 0, int r0 = 0, int r1 = 0);   // fused tderive + tstep_integrate
+                        bool write_um = true, bool out_to_um = false, int rows = 0, int r0 = 0, int r1 = 0, bool ptotal = false);   // fused tderive + tstep_integrate
 // rows (k_closure_lds, k_project_integrate): 0 all tile rows of the slab, 1 only the tile rows next to the neighbouring ranks,
 // 2 only the rows in between; k_project_integrate also 3 / 4: the tile rows [r0, r1) (3: profiled with the edge launch)
 // dirs: HALO_TO_PREV (this slab's first rows -> the previous rank's upper ghost rows; the upper ghost rows here arrive from the next

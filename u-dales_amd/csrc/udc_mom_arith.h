@@ -59,7 +59,9 @@ __device__ __forceinline__ LevelMet levmet_global(const Metrics &m, int kf) {
                   m.dzfi5[kf], m.dzhiq[kf], m.dzhiq[kf + 1], m.dpdxl[kf], m.dpdyl[kf]};
 }
 
-template <bool ADV, bool DIFF, bool LES, bool FORCES, class LM>
+// PGRAD = false: the gradient of pres0 is left out (pressure-total form of the fused substep: the solve then returns pres0 + p and
+// the projection applies all of it, udc_plan.h ptotal)
+template <bool ADV, bool DIFF, bool LES, bool FORCES, bool PGRAD = true, class LM>
 __device__ __forceinline__ void mom_arith(const MomVals &q, const Metrics &m, const LM &lm, int k, double numol,
                                           double &tu, double &tv, double &tw) {
   const double u_c = q.u_c, u_xm = q.u_xm, u_xp = q.u_xp, u_ym = q.u_ym, u_yp = q.u_yp, u_zm = q.u_zm,
@@ -73,18 +75,18 @@ __device__ __forceinline__ void mom_arith(const MomVals &q, const Metrics &m, co
   const double dzfi_k = lm.get(6);
 
   if (ADV) {
-    const double p_c = q.p_c, p_xm = q.p_xm, p_ym = q.p_ym, p_zm = q.p_zm;
+    const double p_c = PGRAD ? q.p_c : 0., p_xm = PGRAD ? q.p_xm : 0., p_ym = PGRAD ? q.p_ym : 0., p_zm = PGRAD ? q.p_zm : 0.;
     const double dzfi5_k = lm.get(7);
     // advecu_2nd, src/modadvection.f90:178-187 and :202-207
     tu = tu - (((u_c + u_xp) * (u_c + u_xp) - (u_c + u_xm) * (u_c + u_xm)) * m.dxiq
-             + ((u_c + u_yp) * (v_yp + v_xm_yp) - (u_c + u_ym) * (v_c + v_xm)) * m.dyiq)
-            - ((p_c - p_xm) * m.dxi);
+             + ((u_c + u_yp) * (v_yp + v_xm_yp) - (u_c + u_ym) * (v_c + v_xm)) * m.dyiq);
+    if (PGRAD) tu = tu - ((p_c - p_xm) * m.dxi);
     tu = tu - ((u_zp * dzf_k + u_c * dzf_kp) * dzhi_kp * (w_zp + w_xm_zp)
              - (u_c * dzf_km + u_zm * dzf_k) * dzhi_k * (w_c + w_xm)) * 0.5 * dzfi5_k;
     // advecv_2nd, :235-245 and :260-265
     tv = tv - (((u_xp + u_xp_ym) * (v_c + v_xp) - (u_c + u_ym) * (v_c + v_xm)) * m.dxiq
-             + ((v_yp + v_c) * (v_c + v_yp) - (v_ym + v_c) * (v_c + v_ym)) * m.dyiq)
-            - ((p_c - p_ym) * m.dyi);
+             + ((v_yp + v_c) * (v_c + v_yp) - (v_ym + v_c) * (v_c + v_ym)) * m.dyiq);
+    if (PGRAD) tv = tv - ((p_c - p_ym) * m.dyi);
     tv = tv - ((w_zp + w_ym_zp) * (v_zp * dzf_k + v_c * dzf_kp) * dzhi_kp
              - (w_c + w_ym) * (v_zm * dzf_k + v_c * dzf_km) * dzhi_k) * 0.5 * dzfi5_k;
     // advecw_2nd, :295-309 (k = kb+1..ke)
@@ -94,8 +96,8 @@ __device__ __forceinline__ void mom_arith(const MomVals &q, const Metrics &m, co
                 - (w_c + w_xm) * (dzf_km * u_c + dzf_k * u_zm)) * m.dxiq * dzhi_k
                + ((w_yp + w_c) * (dzf_km * v_yp + dzf_k * v_yp_zm)
                 - (w_c + w_ym) * (dzf_km * v_c + dzf_k * v_zm)) * m.dyiq * dzhi_k
-               + ((w_c + w_zp) * (w_c + w_zp) - (w_c + w_zm) * (w_c + w_zm)) * dzhiq_k)
-              - ((p_c - p_zm) * dzhi_k);
+               + ((w_c + w_zp) * (w_c + w_zp) - (w_c + w_zm) * (w_c + w_zm)) * dzhiq_k);
+      if (PGRAD) tw = tw - ((p_c - p_zm) * dzhi_k);
     }
   }
 

@@ -61,14 +61,16 @@ __device__ __forceinline__ void halo_coords(int e, int &lx, int &ly) {
 // CPT:   cells per thread (rows ty and ty + MY/CPT of the tile).  2 halves the threads of a workgroup and gives every
 //        wave two independent stencils to interleave: measured 0.454 ms against 0.369 ms for CPT = 1 at 256^3 (181
 //        VGPRs, 2 waves/SIMD), so only CPT = 1 is instantiated.
-template <bool ADV, bool DIFF, bool LES, bool FORCES, bool FRESH, bool PUP, int CPT>
+// PGRAD = false (pressure-total form, udc_plan.h): pres0 is neither staged nor differenced.
+template <bool ADV, bool DIFF, bool LES, bool FORCES, bool FRESH, bool PUP, int CPT, bool PGRAD = true>
 __global__ __launch_bounds__(NT / CPT, CPT == 1 ? MOM_WAVES : 2) void mom_lds_kernel(Geo g, TileGrid tg, Metrics m, MomArgs a, double numol, int kc) {
   constexpr int NF = (DIFF && LES) ? 4 : 3;
   constexpr int RY = MY / CPT;        // rows of threads
   constexpr int NTH = NT / CPT;
   static_assert(LN - NT <= NTH, "one halo cell per thread");
   __shared__ double s[4][NF][LN];     // 4 rotating plane buffers: one barrier per level is enough
-  __shared__ double sp[ADV ? 3 : 1][ADV ? LN : 1];   // pres0: planes k-1, k and the one being filled (k+1)
+  constexpr bool PRS = ADV && PGRAD;                 // pres0 takes part
+  __shared__ double sp[PRS ? 3 : 1][PRS ? LN : 1];   // pres0: planes k-1, k and the one being filled (k+1)
   __shared__ double smet[2][NLEVMET + 4];            // LevelMet of levels k and k+1 (see udc_mom_arith.h)
 
   // workgroup -> (tile, k-chunk); XCD-aware like tile_decode but with chunks instead of planes
@@ -152,11 +154,11 @@ __global__ __launch_bounds__(NT / CPT, CPT == 1 ? MOM_WAVES : 2) void mom_lds_ke
   load_plane(k0 - 1, st); commit_plane(0, st);
   load_plane(k0, st);     commit_plane(1, st);
   load_plane(k0 + 1, st); commit_plane(2, st);
-  if (ADV) {
+  if (PRS) {
     load_p(k0 - 1); commit_p(0);
     load_p(k0);     commit_p(1);
   }
-  if (k0 + 1 < k1) { load_plane(k0 + 2, st); if (ADV) load_p(k0 + 1); }
+  if (k0 + 1 < k1) { load_plane(k0 + 2, st); if (PRS) load_p(k0 + 1); }
   int bm = 0, bc = 1, bp = 2, bn = 3;      // buffers holding planes k-1, k, k+1 and the one being filled (k+2)
   int qm = 0, qc = 1, qn = 2;              // pres0 buffers: planes k-1, k and the one being filled (k+1)
 
@@ -180,11 +182,11 @@ __global__ __launch_bounds__(NT / CPT, CPT == 1 ? MOM_WAVES : 2) void mom_lds_ke
     __syncthreads();
     if (k + 1 < k1) {
       commit_plane(bn, st);                                // plane k+2, read from level k+1 on
-      if (ADV) commit_p(qn);                               // pres0 plane k+1
+      if (PRS) commit_p(qn);                               // pres0 plane k+1
       if (met_thread) smet[(k + 1) & 1][tid] = mreg;       // metrics of level k+1 (visible after the next barrier)
       if (k + 2 < k1) {
         if (met_thread) mreg = mp[k + 2];
-        load_plane(k + 3, st); if (ADV) load_p(k + 2);     // in flight while this level is computed
+        load_plane(k + 3, st); if (PRS) load_p(k + 2);     // in flight while this level is computed
       }
     }
     const LevelMetLds lm{smet[k & 1]};
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(NT / CPT, CPT == 1 ? MOM_WAVES : 2) void mom_lds_ke
       qq.v_zm = vm_[o]; qq.v_zp = vp_[o]; qq.v_xm_yp = vc_[o - 1 + LX]; qq.v_yp_zm = vm_[o + LX];
       qq.w_c = wc_[o]; qq.w_xm = wc_[o - 1]; qq.w_xp = wc_[o + 1]; qq.w_ym = wc_[o - LX]; qq.w_yp = wc_[o + LX];
       qq.w_zm = wm_[o]; qq.w_zp = wp_[o]; qq.w_xm_zp = wp_[o - 1]; qq.w_ym_zp = wp_[o - LX];
-      if (ADV) { qq.p_c = sp[qc][o]; qq.p_xm = sp[qc][o - 1]; qq.p_ym = sp[qc][o - LX]; qq.p_zm = sp[qm][o]; }
+      if (PRS) { qq.p_c = sp[qc][o]; qq.p_xm = sp[qc][o - 1]; qq.p_ym = sp[qc][o - LX]; qq.p_zm = sp[qm][o]; }
       if (DIFF && LES) {
         const double *em_ = s[bm][NF - 1], *ec_ = s[bc][NF - 1], *ep_ = s[bp][NF - 1];
         qq.e_c = ec_[o]; qq.e_xm = ec_[o - 1]; qq.e_xp = ec_[o + 1]; qq.e_ym = ec_[o - LX]; qq.e_yp = ec_[o + LX];
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(NT / CPT, CPT == 1 ? MOM_WAVES : 2) void mom_lds_ke
         qq.e_ym_zm = em_[o - LX]; qq.e_ym_zp = ep_[o - LX]; qq.e_xp_ym = ec_[o + 1 - LX];
         qq.e_yp_zm = em_[o + LX]; qq.e_xp_zm = em_[o + 1];
       }
-      mom_arith<ADV, DIFF, LES, FORCES>(qq, m, lm, k, numol, tu[c], tv[c], tw[c]);
+      mom_arith<ADV, DIFF, LES, FORCES, PGRAD>(qq, m, lm, k, numol, tu[c], tv[c], tw[c]);
       if (PUP) {
         if (a.um_is_u0) { pum[c] = qq.u_c; pvm[c] = qq.v_c; pwm[c] = qq.w_c; }
         tu[c] = tu[c] + pum[c] * a.rk3coefi;
@@ -392,8 +394,9 @@ int momentum_lds_tile_height() { return MY; }
 
 // part: a piece of the sweep -- tile rows [r0, r1) (r1 <= 0: all), levels [kbeg, kend) (kend <= 0: all); `more`: not the last piece
 // of this substep (profiled under "<name>_edge", which bench.py folds into <name>)
-int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, double rk3coefi, bool um_is_u0, const MomPart *part) {
+int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, double rk3coefi, bool um_is_u0, const MomPart *part, bool pgrad) {
   const bool pup = fresh && rk3coefi != 0.;
+  if (!pgrad && !(pup && adv && diff)) { udc_set_error("k_momentum_lds: the pressure-total form is the fused substep's only"); return 1; }
   const Geo &g = h->g;
   MomArgs a{h->fields[UDC_U0], h->fields[UDC_V0], h->fields[UDC_W0], h->fields[UDC_PRES0],
             h->fields[UDC_EKM], h->fields[UDC_UP], h->fields[UDC_VP], h->fields[UDC_WP],
@@ -416,7 +419,8 @@ int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, 
 #define LAUNCH(A, D, L, F)                                                                         \
   do {                                                                                             \
     PROF(h, more ? "mom_" #A #D #L #F "_edge" : "mom_" #A #D #L #F);                               \
-    if (pup) hipLaunchKernelGGL((mom_lds_kernel<A, D, L, F, true, true, 1>), gr, b, 0, h->stream, g, tg, h->m, a, nu, kc);    \
+    if (pup && !pgrad) hipLaunchKernelGGL((mom_lds_kernel<A, D, L, F, true, true, 1, false>), gr, b, 0, h->stream, g, tg, h->m, a, nu, kc);    \
+    else if (pup) hipLaunchKernelGGL((mom_lds_kernel<A, D, L, F, true, true, 1>), gr, b, 0, h->stream, g, tg, h->m, a, nu, kc);    \
     else if (fresh) hipLaunchKernelGGL((mom_lds_kernel<A, D, L, F, true, false, 1>), gr, b, 0, h->stream, g, tg, h->m, a, nu, kc);  \
     else hipLaunchKernelGGL((mom_lds_kernel<A, D, L, F, false, false, 1>), gr, b, 0, h->stream, g, tg, h->m, a, nu, kc);            \
   } while (0)

@@ -5,7 +5,7 @@
 
 struct PlanIn {
   // switches (Switches, udc_internal.h)
-  int no_fold, no_alias, ek_always, halo_overlap, mom_pipe, div_in_fft;
+  int no_fold, no_alias, ek_always, halo_overlap, mom_pipe, div_in_fft, ptotal;
   // what the handle is
   int slab;             // distributed layout in use (more than one rank, or UDC_FORCE_SLAB)
   int comm_stream;      // the communication stream exists (slab layout set up)
@@ -15,6 +15,8 @@ struct PlanIn {
   int ibm_on, stats_any;
   int fft_fused;        // own line transforms on the slab path
   int own_fwd;          // own forward half on the single-slab path
+  int tend_plane;       // something between the sweep and the solve reads the tendencies on a single plane: masscorr's outflow-rate
+                        // branch sums up(ie, :, :) (luoutflowr), where a pressure gradient does not cancel as it does over the volume
   int between;          // something acts on the tendencies between the momentum sweep and the solve besides the floor: Coriolis,
                         // level forcings, prescribed flow rates, immersed boundary, shifted boundaries, buoyancy / radiative source
   int closure_tile_rows, mom_tile_rows, int_tile_rows;      // tile rows of the three sweeps on this slab
@@ -42,6 +44,8 @@ struct Plan {
   int vp_row;           // PlanRow: vp's ghost row
   int p_row;            // PlanRow: p's ghost row (FOLDED / BESIDE the first interior rows / INLINE)
   int integrate;        // PlanIntegrate
+  int ptotal;           // pressure-total form: the momentum sweep leaves the gradient of pres0 out, the solve returns pres0 + p, the
+                        // projection applies it as a whole and it becomes pres0 (arrays swapped): pres0 is read nowhere in the substep
 };
 
 inline bool plan_halo_overlap(const PlanIn &in, int tile_rows) { return in.slab && in.comm_stream && in.halo_overlap && tile_rows >= 3; }
@@ -82,5 +86,13 @@ inline Plan plan_substep(const PlanIn &in) {
     p.p_row = (plan_halo_overlap(in, in.int_tile_rows) && in.int_tile_rows >= 4) ? ROW_BESIDE : ROW_INLINE;
     p.integrate = plan_halo_overlap(in, in.int_tile_rows) ? INT_EDGES_FIRST : INT_ONE;
   }
+  // The reference adds -grad pres0 to the tendencies (advecu/v/w) and solves for the increment p (fillps .. tderive, pres0 += p).  The
+  // discrete operators are the same on both sides (the solver's matrix IS div grad, floor and lid rows included), so solving for
+  // pres0 + p from tendencies without the old gradient gives the same velocities and the same pres0 up to round-off -- and 24 B per
+  // cell less (pres0 read by the sweep, read and written by the projection).  Where something edits the tendencies point by point
+  // between the sweep and the solve (immersed boundary: ibmnorm zeroes them at solid points, pressure gradient included), or reads
+  // them on one plane (the outflow-rate mass correction), the two forms differ: not there.  On y-slabs p's ghost row then travels both ways (it is pres0's), and pres0 leaves the
+  // exchange of the new velocities' rows.
+  p.ptotal = in.ptotal && p.pup && !in.ibm_on && !in.tend_plane;
   return p;
 }

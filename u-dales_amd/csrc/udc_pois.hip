@@ -632,9 +632,12 @@ struct IntArgs {
 // momentum sweep does not read them).
 // PUP:  up,vp,wp hold pup = up + um/rk3coef, so u0 = rk3coef*(pup - grad p) and um is not read
 //       (algebraically the reference's um + rk3coef*(up - grad p); differs by one rounding of um).
-template <bool PROJECT, bool ZERO, bool PUP>
+// PTOT: pressure-total form of the fused substep (udc_plan.h): the momentum sweep left the gradient of pres0 out, the solve returned
+//       pres0 + p in `p`, which is projected here as a whole and IS the new pres0 (the caller swaps the two arrays): pres0 is neither read
+//       nor written -- 16 of the kernel's 72 B per cell; `pres0` then points at the same array as `p`, for its two ghost rows.
+template <bool PROJECT, bool ZERO, bool PUP, bool PTOT = false>
 __global__ __launch_bounds__(256) void integrate_kernel(Geo g, TileGrid tg, Metrics m, IntArgs a, const double *__restrict__ p,
-                                                         double *__restrict__ pres0, double rk3coef, int last,
+                                                         double *pres0, double rk3coef, int last,
                                                          int ghosts, Params pr) {
   int i, j, k;
   const bool inside_ = tile_decode(g, tg, i, j, k);
@@ -654,9 +657,13 @@ __global__ __launch_bounds__(256) void integrate_kernel(Geo g, TileGrid tg, Metr
     tu = tu - (pc - p[xm]) * m.dxi;
     tv = tv - (pc - p[ym]) * m.dyi;
     if (k >= 1) tw = tw - (pc - p[c - g.sz]) * m.dzhi[k + 1];
-    pr0 = NT_LOAD(&pres0[c]) + pc;
-    NT_STORE(pr0, &pres0[c]);
-    if (wr) pres0[c + wr] = pr0;
+    if (PTOT) {
+      if (wr) pres0[c + wr] = pc;      // (ghost rows of the array itself: read by nothing in this launch)
+    } else {
+      pr0 = NT_LOAD(&pres0[c]) + pc;
+      NT_STORE(pr0, &pres0[c]);
+      if (wr) pres0[c + wr] = pr0;
+    }
   }
   double u, v, w;
   if (PUP) { u = rk3coef * tu; v = rk3coef * tv; w = rk3coef * tw; }
@@ -1323,7 +1330,7 @@ int k_integrate(udc_handle *h, int rk3step, double dt) {
 }
 
 int k_project_integrate(udc_handle *h, int rk3step, double dt, bool zero_tend, bool pup, bool ghosts,
-                        bool write_um, bool out_to_um, int rows, int r0, int r1) {
+                        bool write_um, bool out_to_um, int rows, int r0, int r1, bool ptotal) {
   const Geo &g = h->g;
   const dim3 b(64, 4, 1);
   // rows 1 / 2: the tile rows next to the neighbouring ranks / the rows in between (the caller exchanges ghost rows in between);
@@ -1335,7 +1342,11 @@ int k_project_integrate(udc_handle *h, int rk3step, double dt, bool zero_tend, b
   const int lastf = rk3step == 3 ? (write_um ? 3 : 2) : 0;
   IntArgs ia = int_args(h);
   if (out_to_um) { ia.u0 = ia.um; ia.v0 = ia.vm; ia.w0 = ia.wm; }   // pointer rotation at RK stage 1 (um_alias)
-  if (pup)
+  if (ptotal && !pup) { udc_set_error("k_project_integrate: the pressure-total form needs the predicted-velocity form of the tendencies"); return 1; }
+  if (ptotal)      // (the caller swaps p and pres0 once every row is integrated)
+    hipLaunchKernelGGL((integrate_kernel<true, false, true, true>), gr, b, 0, h->stream, g, tg, h->m, ia,
+                       (const double *)h->fields[UDC_P], h->fields[UDC_P], rk3coef, lastf, ghosts ? 1 : 0, h->p);
+  else if (pup)
     hipLaunchKernelGGL((integrate_kernel<true, false, true>), gr, b, 0, h->stream, g, tg, h->m, ia,
                        (const double *)h->fields[UDC_P], h->fields[UDC_PRES0], rk3coef, lastf, ghosts ? 1 : 0, h->p);
   else if (zero_tend)
