@@ -65,7 +65,7 @@ def table(i):
                                             ROW_FOLDED))
     prow = np.where(fold, ROW_FOLDED, np.where(beside(i["int_tile_rows"]) & (i["int_tile_rows"] >= 4), ROW_BESIDE, ROW_INLINE))
     integ = np.where(~fold & beside(i["int_tile_rows"]), INT_EDGES_FIRST, INT_ONE)
-    ptot = b(i["ptotal"]) & pup & ~b(i["ibm_on"]) & ~b(i["tend_plane"])
+    ptot = b(i["ptotal"]) & pup & ~b(i["tend_plane"])
     return dict(lds=lds, pup=pup, fold=fold, alias_ok=alias_ok, materialise_um=mat, rotate=rotate, skip_um=skip, closure=closure,
                 need_ekh=need_ekh, mom_pipe=pipe, div_in_fft=div, vp_row=vp, p_row=prow, integrate=integ, ptotal=ptot)
 
@@ -119,10 +119,10 @@ def test_every_combination_matches_the_table_and_is_safe():
         assert ((g["rotate"] + g["materialise_um"]) == i["um_alias"]).all()
         # the divergence inside a transform needs the predicted-velocity form of the tendencies
         assert not ((g["div_in_fft"] == 1) & (g["pup"] == 0)).any()
-        # the pressure-total form: never with obstacles (ibmnorm edits the tendencies point by point) nor where the tendencies are read
-        # on one plane (outflow-rate mass correction), only over the predicted-velocity form
+        # the pressure-total form: never where the tendencies are summed over less than the periodic volume (outflow-rate mass
+        # correction, volume flow over the fluid cells of an immersed boundary), only over the predicted-velocity form
         pt = g["ptotal"] == 1
-        assert not (pt & ((i["ibm_on"] == 1) | (i["tend_plane"] == 1) | (g["pup"] == 0))).any()
+        assert not (pt & ((i["tend_plane"] == 1) | (g["pup"] == 0))).any()
         total += n
     assert total == 128 * n and n > 100000
 

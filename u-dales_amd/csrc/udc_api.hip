@@ -877,6 +877,7 @@ static int now_ibmwallfun(udc_handle *h) {
 static int now_ibmnorm(udc_handle *h) {
   if (!h->ibm_on) return 0;
   if (tend_clean(h) || um_materialise(h)) return 1;
+  h->ptotal_now = false;      // (routine by routine: the reference's form)
   return k_ibm_norm(h);
 }
 
@@ -1024,7 +1025,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   pin.slab = h->slab; pin.comm_stream = h->comm_stream != nullptr; pin.sgs = h->p.sgs; pin.lbuoycorr = h->lbuoycorr;
   pin.nslots = (int)h->slots.size(); pin.ibm_on = h->ibm_on; pin.stats_any = h->stats_on || h->xyt_on || h->yt_on;
   pin.fft_fused = h->fft_fused; pin.own_fwd = h->own_fwd;
-  pin.tend_plane = h->luvolflowr == 2;
+  pin.tend_plane = h->luvolflowr == 2 || (h->ibm_on && (h->luvolflowr || h->lvvolflowr));
   pin.between = h->coriolis_mode || !h->level_forcings.empty() || h->luvolflowr || h->lvvolflowr || h->ibm_on || h->shift_a != 0. ||
                 h->thlpcar || h->lbuoyancy;
   pin.closure_tile_rows = closure_lds_tile_rows(h->g); pin.mom_tile_rows = momentum_lds_tile_rows(h->g); pin.int_tile_rows = tile_grid(h->g).gy;
@@ -1033,6 +1034,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   pin.rk3step = rk3step; pin.um_alias = h->um_alias; pin.ibm_edits_now = (ops & (OP_IBMWALL | OP_IBMNORM)) != 0;
   const Plan plan = plan_substep(pin);
   h->last_plan = plan; h->have_plan = true;
+  h->ptotal_now = plan.ptotal != 0;
   const bool lds = true, pup = true, fold = plan.fold;      // (LDS-staged sweeps, tendencies as predicted velocity: always)
   const bool forces = (ops & OP_FORCES) != 0;
   if (plan.materialise_um) { if (um_materialise(h)) return 1; }
@@ -1173,6 +1175,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
     if (rb < gyI - 1 && k_project_integrate(h, rk3step, dt, !lds, pup, fold, !skip_um, rotate, 4, rb, gyI - 1, ptot)) return 1;
     if (k_halo_y_join(h)) return 1;
   } else if (k_project_integrate(h, rk3step, dt, !lds, pup, fold, !skip_um, rotate, 0, 0, 0, ptot)) return 1;
+  h->ptotal_now = false;
   if (ptot) std::swap(h->fields[UDC_P], h->fields[UDC_PRES0]);      // what the solve returned is pres0 now; the old pres0 array takes the next solve's output
   h->dthv_top_on = false;
   if (rk3step == 3 && k_chem(h, dt)) return 1;      // src/modtstep.f90:236-238 (before the ghosts are refreshed)

@@ -118,13 +118,22 @@ __global__ void ibm_diffc_corr_kernel(Geo g, Metrics m, int n, const int *__rest
   rhs[c] = t;
 }
 
-// solid without a mask: var = 0, rhs = 0 at the listed points (velocities)
-__global__ void ibm_solid_zero_kernel(Geo g, int n, const int *__restrict__ pt, double *__restrict__ var, double *__restrict__ rhs) {
+// solid without a mask: var = 0, rhs = 0 at the listed points (velocities).
+// comp >= 0 (pressure-total form of the fused substep, udc_plan.h): the sweep left -grad pres0 out everywhere, the reference's zero at
+// a solid point includes it -- so the tendency there becomes + the gradient's component (u, v, w: 0, 1, 2; advecu/v/w's own
+// differences, src/modadvection.f90:187,245,309), which the projection of pres0 + p then takes back out.
+__global__ void ibm_solid_zero_kernel(Geo g, int n, const int *__restrict__ pt, double *__restrict__ var, double *__restrict__ rhs,
+                                      int comp, const double *__restrict__ pres0, Metrics m) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= n) return;
-  const long c = g.idx(pt[3 * q], pt[3 * q + 1], pt[3 * q + 2]);
+  const int i = pt[3 * q], j = pt[3 * q + 1], k = pt[3 * q + 2];
+  const long c = g.idx(i, j, k);
   var[c] = 0.;
-  rhs[c] = 0.;
+  double t = 0.;
+  if (comp == 0) t = (pres0[c] - pres0[g.idx(i == 0 ? g.nx - 1 : i - 1, j, k)]) * m.dxi;
+  else if (comp == 1) t = (pres0[c] - pres0[c - g.sy]) * m.dyi;
+  else if (comp == 2 && k >= 1) t = (pres0[c] - pres0[c - g.sz]) * m.dzhi[k + 1];
+  rhs[c] = t;
 }
 
 // solid with the c mask: value and tendency become the mean over the fluid neighbours (or val / 0 without any).  A neighbour
@@ -505,7 +514,8 @@ int k_ibm_norm(udc_handle *h) {
   for (int q = 0; q < 3; ++q) {
     const udc_handle::IbmGrid &G = h->ibm[q];
     if (G.nsolid) hipLaunchKernelGGL(ibm_solid_zero_kernel, dim3(blocks(G.nsolid)), dim3(128), 0, h->stream, g, G.nsolid, G.solid,
-                                     h->fields[UDC_UM + q], h->fields[UDC_UP + q]);
+                                     h->fields[UDC_UM + q], h->fields[UDC_UP + q], h->ptotal_now ? q : -1,
+                                     (const double *)h->fields[UDC_PRES0], h->m);
   }
   const udc_handle::IbmGrid &C = h->ibm[3];
   for (int n : h->slots) {

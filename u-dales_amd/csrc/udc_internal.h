@@ -343,6 +343,7 @@ struct udc_handle {
   bool prof_focus_on = false;           // only launches whose name starts with prof_focus are timed
   std::string prof_focus;
   int prof_every = 1;                   // focus mode: the launches of every prof_every-th fused substep only (udc_profile_every)
+  bool ptotal_now = false;              // inside a fused substep in the pressure-total form (k_ibm_norm: solid tendencies = + grad pres0)
   long substep_seq = 0, prof_phase = 0; // fused substeps run so far; ... when udc_profile_every was called
   std::vector<ProfEntry> prof_events;
   std::vector<hipEvent_t> prof_pool;

@@ -15,8 +15,9 @@ struct PlanIn {
   int ibm_on, stats_any;
   int fft_fused;        // own line transforms on the slab path
   int own_fwd;          // own forward half on the single-slab path
-  int tend_plane;       // something between the sweep and the solve reads the tendencies on a single plane: masscorr's outflow-rate
-                        // branch sums up(ie, :, :) (luoutflowr), where a pressure gradient does not cancel as it does over the volume
+  int tend_plane;       // something between the sweep and the solve sums the tendencies where a pressure gradient does not cancel as it
+                        // does over the whole periodic volume: masscorr's outflow-rate branch (up(ie, :, :), luoutflowr), or masscorr's
+                        // volume flow over the fluid cells only (immersed boundary)
   int between;          // something acts on the tendencies between the momentum sweep and the solve besides the floor: Coriolis,
                         // level forcings, prescribed flow rates, immersed boundary, shifted boundaries, buoyancy / radiative source
   int closure_tile_rows, mom_tile_rows, int_tile_rows;      // tile rows of the three sweeps on this slab
@@ -89,10 +90,11 @@ inline Plan plan_substep(const PlanIn &in) {
   // The reference adds -grad pres0 to the tendencies (advecu/v/w) and solves for the increment p (fillps .. tderive, pres0 += p).  The
   // discrete operators are the same on both sides (the solver's matrix IS div grad, floor and lid rows included), so solving for
   // pres0 + p from tendencies without the old gradient gives the same velocities and the same pres0 up to round-off -- and 24 B per
-  // cell less (pres0 read by the sweep, read and written by the projection).  Where something edits the tendencies point by point
-  // between the sweep and the solve (immersed boundary: ibmnorm zeroes them at solid points, pressure gradient included), or reads
-  // them on one plane (the outflow-rate mass correction), the two forms differ: not there.  On y-slabs p's ghost row then travels both ways (it is pres0's), and pres0 leaves the
+  // cell less (pres0 read by the sweep, read and written by the projection).  ibmnorm's zero tendency at a solid point includes the
+  // old gradient: there the tendency becomes + that gradient instead (k_ibm_norm).  Where something sums the tendencies over less than
+  // the periodic volume (the outflow-rate mass correction; the volume flow over the fluid cells of an immersed boundary) the two
+  // forms differ: not there.  On y-slabs p's ghost row then travels both ways (it is pres0's), and pres0 leaves the
   // exchange of the new velocities' rows.
-  p.ptotal = in.ptotal && p.pup && !in.ibm_on && !in.tend_plane;
+  p.ptotal = in.ptotal && p.pup && !in.tend_plane;
   return p;
 }
