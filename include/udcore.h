@@ -354,7 +354,11 @@ int udc_boundary(udc_handle *h);
 int udc_tstep_maxima(udc_handle *h, double dt, double *courtot, double *diffnrtot);
 
 /* One whole RK3 substep = advection, subgrid, forces, poisson, tstep_integrate, halos,
- * boundary in the reference's order, with kernels fused across routine boundaries. */
+ * boundary in the reference's order, with kernels fused across routine boundaries.
+ * By default in the pressure-total form (UDC_PTOTAL=0: off): the momentum sweep leaves -grad pres0
+ * (src/modadvection.f90:187,245,309) out, the solve returns pres0 + p, the projection applies that and it becomes pres0 -- the same
+ * velocities and pres0 to round-off, with pres0 read nowhere.  After such a substep the array `p` (UDC_P) is scratch: it holds the
+ * previous pres0, not the increment (udc_poisson called on its own leaves the increment there as the reference does). */
 int udc_substep(udc_handle *h, int rk3step, double dt, int with_forces);
 /* n substeps with fixed dt, rk3step cycling 1,2,3 starting from rk3step0 */
 int udc_run(udc_handle *h, int nsubsteps, int rk3step0, double dt, int with_forces);
