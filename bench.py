@@ -79,6 +79,7 @@ def fold_edges(tab):
     return out
 
 
+SCALARS_INLINE = 0              # set from the executed plan: scalars whose RK3 update rode in their sweep
 PRESSURE_TOTAL = False          # set from the executed plan: the substep ran in the pressure-total form (pres0 read nowhere: the momentum
                                 # sweep 8 B less, the projection 16 B less per cell)
 
@@ -89,7 +90,9 @@ def algo_bytes(name, nscal=0, stage1_frac=0.0):
             if k == "mom":
                 return v - MOM_STAGE1_SAVING * stage1_frac - (8 if PRESSURE_TOTAL else 0)
             if k == "project_integrate":
-                return v + SCALAR_INTEGRATE_BYTES * nscal - (16 if PRESSURE_TOTAL else 0)
+                return v + SCALAR_INTEGRATE_BYTES * (nscal - SCALARS_INLINE) - (16 if PRESSURE_TOTAL else 0)
+            if k == "scalar" and SCALARS_INLINE:
+                return v + 8      # (svm read too, the new value written where the tendency would go: 56 B; the integration skips the scalar)
             if k == "closure" and nscal == 0 and os.environ.get("UDC_EK_ALWAYS", "0") in ("", "0"):
                 return v - 8 * 2.0 / 3.0
             return v + (SCALAR_INTEGRATE_BYTES * nscal if k == "project_integrate" else 0)
@@ -800,8 +803,9 @@ def main():
     poisson_ms = allmax(time_loop(core, core.poisson, 20, barrier))
     heartbeat("poisson alone")
     executed_plan = core.last_plan()
-    global PRESSURE_TOTAL
+    global PRESSURE_TOTAL, SCALARS_INLINE
     PRESSURE_TOTAL = bool(executed_plan.get("pressure_total_form"))
+    SCALARS_INLINE = int(executed_plan.get("scalars_updated_in_their_sweep", 0))
     # What the exchanges did (slab layout only).  (i) the communicator's own account of itself; (ii) six more substeps with every
     # exchange counted and timed by a pair of events on the stream it runs on: bytes per peer, and the rate one link saw during an
     # all-to-all (every peer's block travels at once, so a block's bytes / the operation's time is the per-link rate); (iii) the same

@@ -113,7 +113,8 @@ int udc_comm_dry_run(udc_handle *h, int on);
  * [2] ekh written, [3] momentum sweep pipelined with the solve's k-chunks, [4] divergence inside the x transform, [5] vp's and
  * [6] p's ghost row: 0 folded / 1 beside a sweep / 2 in line / 3 ahead of the pipelined sweep, [7] integration 0 one launch / 1 edge
  * rows first, [8] um rotated, [9] um left aliased, [10] um materialised, [11] slab layout, [12] own line transforms on the slab path,
- * [13] k-chunks of the transposes, [14] own forward half (one GPU), [15] own backward half (one GPU). */
+ * [13] k-chunks of the transposes, [14] own forward half (one GPU), [15] bit 0: pressure-total form (see udc_substep), bits 1..: how
+ * many scalars took their RK3 update inside their own sweep. */
 int udc_last_plan(udc_handle *h, int out[16]);
 #ifdef UDC_TEST_TRANSPORT
 /* Test transport, NOT part of libudcore.so: libudcore_test.so (same sources + -DUDC_TEST_TRANSPORT) adds it for the virtual-rank

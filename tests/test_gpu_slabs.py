@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     {"UDC_FORCE_SLAB": "1", "UDC_HALO_OVERLAP": "0", "UDC_MOM_PIPE": "0", "UDC_A2A_CHUNKS": "1"},      # rungs 1 and 2 of the ladder
     {"UDC_NO_FOLD": "1"},                                   # single slab: separate ghost-row kernels
     {"UDC_PTOTAL": "0"},                                    # ... pres0 and p kept apart as in the reference (default: the pressure-total form)
+    {"UDC_SV_INLINE": "0"},                                 # ... every scalar integrated by tstep_integrate's kernel (default: a plain passive kappa scalar in its own sweep)
     {"UDC_NO_ALIAS": "1"},                                  # ... um always a real copy
     {"UDC_SCALAR_PAIR": "0"},                               # ... thl and qt swept one by one
     {"UDC_THOMAS": "0"},                                    # ... the streaming tridiagonal kernel

@@ -151,6 +151,7 @@ void udc_read_switches(Switches &sw) {
   sw.own_fwd = env_int("UDC_OWN_FWD", -1);
   sw.div_in_fft = env_int("UDC_DIV_IN_FFT", 1) != 0;
   sw.ptotal = env_int("UDC_PTOTAL", 1) != 0;
+  sw.sv_inline = env_int("UDC_SV_INLINE", 1) != 0;
   sw.no_fold = env_int("UDC_NO_FOLD", 0) != 0;
   sw.no_alias = env_int("UDC_NO_ALIAS", 0) != 0;
   sw.ek_always = env_int("UDC_EK_ALWAYS", 0) != 0;
@@ -1082,6 +1083,18 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
     } else if (k_momentum_lds(h, true, true, forces, true, 1. / rk3coef, rotate, nullptr, !plan.ptotal)) return 1;
   }
   const bool piped = h->mom_pipe.active;      // (then nothing below up to the solve has anything to do: see `pipe`)
+  // a passive kappa-advected scalar whose tendency nothing else touches (no source, chemistry, obstacle, inflow / outflow, top flux) takes
+  // its RK3 update inside its sweep: the sweep writes the new value where the tendency would go, the two arrays swap after the
+  // integration, which skips it (48 + 24 -> 56 B per cell and scalar).  Single slab (the slabs' scalar rows may leave before the swap).
+  h->sv_inline_last = rk3step == 3; h->sv_inline_rk3coef = rk3coef;
+  for (int n : h->slots) {
+    bool forced = false;      // a level forcing (subsidence, nudging, sponge) acts on this scalar's tendency
+    for (const auto &f : h->level_forcings) forced = forced || f.tend == UDC_SVP + 3 * n;
+    h->sv_inline[n] = !forced && h->sw.sv_inline && lds && fold && n < h->cfg.nsv && n < 13 && !h->slot[n].tke && h->slot[n].adv == 1 && h->slot[n].top == 0 &&
+                      h->slot[n].kappa_ghosts == 0 && h->scal_bcx == 1 && !h->ibm_on && !h->svsrc[n].d && !h->lchem && h->g.nx >= 32 && h->g.ny >= 4;
+  }
+  h->last_inline_scalars = 0;
+  for (int n : h->slots) h->last_inline_scalars += h->sv_inline[n] ? 1 : 0;
   if (k_scalar_top_flux(h)) return 1;
   // thl (slot 15) and qt (13) share velocities and diffusivity: one sweep for both where their schemes agree
   bool paired = false;
@@ -1176,7 +1189,14 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
     if (k_halo_y_join(h)) return 1;
   } else if (k_project_integrate(h, rk3step, dt, !lds, pup, fold, !skip_um, rotate, 0, 0, 0, ptot)) return 1;
   h->ptotal_now = false;
-  if (ptot) std::swap(h->fields[UDC_P], h->fields[UDC_PRES0]);      // what the solve returned is pres0 now; the old pres0 array takes the next solve's output
+  if (ptot) std::swap(h->fields[UDC_P], h->fields[UDC_PRES0]);
+  for (int n : h->slots) {
+    if (!h->sv_inline[n]) continue;
+    // the array the sweep wrote is the scalar now; the planes below the floor (never written by a kernel: what the start-up put there) go along
+    HIP_OK(hipMemcpyAsync(h->fields[UDC_SVP + 3 * n], h->fields[UDC_SV0 + 3 * n], sizeof(double) * (size_t)HZ * (size_t)h->g.sz, hipMemcpyDeviceToDevice, h->stream));
+    std::swap(h->fields[UDC_SV0 + 3 * n], h->fields[UDC_SVP + 3 * n]);
+    h->sv_inline[n] = false;
+  }      // what the solve returned is pres0 now; the old pres0 array takes the next solve's output
   h->dthv_top_on = false;
   if (rk3step == 3 && k_chem(h, dt)) return 1;      // src/modtstep.f90:236-238 (before the ghosts are refreshed)
   if (rotate) {
@@ -1209,7 +1229,7 @@ extern "C" int udc_last_plan(udc_handle *h, int out[16]) {
   if (!h->have_plan) { udc_set_error("udc_last_plan: no fused substep has run on this handle"); return 1; }
   const Plan &p = h->last_plan;
   const int v[16] = {p.fold, p.closure, p.need_ekh, p.mom_pipe, p.div_in_fft, p.vp_row, p.p_row, p.integrate, p.rotate, p.skip_um,
-                     p.materialise_um, h->slab ? 1 : 0, h->fft_fused ? 1 : 0, h->nch, h->own_fwd ? 1 : 0, p.ptotal};
+                     p.materialise_um, h->slab ? 1 : 0, h->fft_fused ? 1 : 0, h->nch, h->own_fwd ? 1 : 0, p.ptotal | (h->last_inline_scalars << 1)};
   for (int q = 0; q < 16; ++q) out[q] = v[q];
   return 0;
 }

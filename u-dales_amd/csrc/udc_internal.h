@@ -148,6 +148,7 @@ struct Switches {
   int fft_fused = 1;         // UDC_FFT_FUSED=0: rocFFT + transpose kernels on the slab path
   int own_fwd = -1;          // UDC_OWN_FWD=0/1: single-slab forward half in own kernels
   int div_in_fft = 1;        // UDC_DIV_IN_FFT=0: separate divergence kernel on the slab path
+  int sv_inline = 1;         // UDC_SV_INLINE=0: no scalar takes its RK3 update inside its sweep
   int ptotal = 1;            // UDC_PTOTAL=0: the fused substep keeps pres0 and p apart like the reference (single slab: no pressure-total form)
   int no_fold = 0, no_alias = 0;      // UDC_NO_FOLD / UDC_NO_ALIAS = 1
   int ek_always = 0;         // UDC_EK_ALWAYS=1: every substep writes ekm / ekh
@@ -343,6 +344,10 @@ struct udc_handle {
   bool prof_focus_on = false;           // only launches whose name starts with prof_focus are timed
   std::string prof_focus;
   int prof_every = 1;                   // focus mode: the launches of every prof_every-th fused substep only (udc_profile_every)
+  bool sv_inline[16] = {false};         // this fused substep: the scalar's RK3 update rides in its kappa sweep (the integration skips it)
+  int last_inline_scalars = 0;          // ... how many in the last fused substep (udc_last_plan)
+  bool sv_inline_last = false;          // ... on RK stage 3 (svm takes the new value too)
+  double sv_inline_rk3coef = 0.;
   bool ptotal_now = false;              // inside a fused substep in the pressure-total form (k_ibm_norm: solid tendencies = + grad pres0)
   long substep_seq = 0, prof_phase = 0; // fused substeps run so far; ... when udc_profile_every was called
   std::vector<ProfEntry> prof_events;

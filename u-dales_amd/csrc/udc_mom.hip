@@ -65,6 +65,8 @@ struct BottomArgs {
   double *up, *vp;
   const double *sv0[16];
   double *svp[16];
+  double mult[16];      // 1, or rk3coef where svp holds the scalar's NEW value (its RK3 update rode in its sweep, udc_scalar_lds.hip)
+  double *svm_new[16];  // ... on RK stage 3: svm, which took that value too
   double flux[16];       // prescribed floor flux (0 for passive scalars, wtsurf for thl)
   int nsv, wrap_vp;
   double z0, fkar;      // fkar: von Karman constant (&WALLS fkar, src/modglobal.f90:317)
@@ -175,8 +177,9 @@ __global__ __launch_bounds__(256) void bottom_kernel(Geo g, Metrics m, BottomArg
       continue;
     }
     const double old = a.svp[n][c];
-    const double t = old + (0.5 * (m.dzf[km] * a.ekh[c] + m.dzf[k] * a.ekh[c - sz]) * (c0[c] - c0[c - sz]) * m.dzh2i[k] - a.flux[n]) * dzfi;
+    const double t = old + a.mult[n] * ((0.5 * (m.dzf[km] * a.ekh[c] + m.dzf[k] * a.ekh[c - sz]) * (c0[c] - c0[c - sz]) * m.dzh2i[k] - a.flux[n]) * dzfi);
     a.svp[n][c] = t;
+    if (a.svm_new[n]) a.svm_new[n][c] = t;
     if (a.thl_flux && n == a.thl_slot) a.thl_flux[(size_t)j * g.nx + i] = t - old;
   }
 }
@@ -272,6 +275,8 @@ int k_bottom(udc_handle *h, bool wrap_vp, int jbeg, int jend) {
     if (n == 15 && h->floor_bcbott == 2) a.thl_wf = a.nsv;
     if (n == 15) a.thl_slot = a.nsv;
     a.sv0[a.nsv] = h->fields[UDC_SV0 + 3 * n]; a.svp[a.nsv] = h->fields[UDC_SVP + 3 * n];
+    a.mult[a.nsv] = h->sv_inline[n] ? h->sv_inline_rk3coef : 1.;
+    a.svm_new[a.nsv] = (h->sv_inline[n] && h->sv_inline_last) ? h->fields[UDC_SVM + 3 * n] : nullptr;
     a.flux[a.nsv] = h->slot[n].floorflux; ++a.nsv;
   }
   PROF(h, "bottom");

@@ -1294,6 +1294,7 @@ static IntArgs int_args(udc_handle *h) {
   a.up = h->fields[UDC_UP]; a.vp = h->fields[UDC_VP]; a.wp = h->fields[UDC_WP];
   a.nsv = 0;
   for (int n : h->slots) {
+    if (h->sv_inline[n]) continue;      // (updated inside its own sweep, udc_scalar_lds.hip)
     a.sv0[a.nsv] = h->fields[UDC_SV0 + 3 * n];
     a.svm[a.nsv] = h->fields[UDC_SVM + 3 * n];
     a.svp[a.nsv] = h->fields[UDC_SVP + 3 * n];

@@ -165,7 +165,10 @@ __global__ __launch_bounds__(NT, 3) void scalar_lds_kernel(Geo g, int gx, int ti
 template <bool LES, bool FRESH>
 __global__ __launch_bounds__(NT, 4) void scalar_kappa_faces_kernel(Geo g, int gx, int tiles, Metrics m, double cekh, double dfac,
     const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ w, const double *__restrict__ ekh,
-    const double *__restrict__ c, double *__restrict__ cp, int gh, int kc) {
+    const double *__restrict__ c, double *__restrict__ cp, int gh, int kc, const double *__restrict__ svm, double *svm_out, double rk3coef) {
+  // svm != null (round 5): the RK3 update rides in the sweep -- cp receives svm + rk3coef * tendency, i.e. the NEW value of the scalar
+  // (the caller swaps the two arrays afterwards; svm_out != null on stage 3: svm takes it too), and the integration skips this scalar:
+  // 16 B per cell less (the tendency is not written and read back).  Only where nothing else touches the tendency of this scalar.
   __shared__ double sc[NCB][CN];
   __shared__ double se[LES ? NEB : 1][LES ? EN : 1];
   __shared__ double sfx[2][MY][MX + 1];
@@ -318,6 +321,7 @@ __global__ __launch_bounds__(NT, 4) void scalar_kappa_faces_kernel(Geo g, int gx
     for (int d = 0; d < 3; ++d) A.eb[d] = LES ? sef + eo[d] + own_e : nullptr;
     const double *pl = scf + co[2];
     const double t0 = (FRESH || !inside) ? 0. : cp[pb + owng];
+    const double sm = (svm && inside) ? NT_LOAD(&svm[pb + owng]) : 0.;
     double pxl = 0., pyl = 0., pzh = 0., dif = 0.;
     if (own) {
     const double c0 = pl[own_c];
@@ -356,6 +360,10 @@ __global__ __launch_bounds__(NT, 4) void scalar_kappa_faces_kernel(Geo g, int gx
       t = (t + upper) + lower;
     }
     t = t + dif;
+    if (svm) {
+      t = sm + rk3coef * t;
+      if (svm_out && inside) NT_STORE(t, &svm_out[pb + owng]);
+    }
     if (inside) NT_STORE(t, &cp[pb + owng]);      // written once, read by the integration from memory
     }
     pzl = pzh;
@@ -377,6 +385,7 @@ __global__ __launch_bounds__(NT, 4) void scalar_kappa_faces_kernel(Geo g, int gx
 // fused advection + diffusion of scalar slot n; false when this kernel does not apply (the caller falls back)
 bool k_scalar_fused_lds(udc_handle *h, int n, bool fresh, int *rc) {
   *rc = 0;
+  const bool inl = h->sv_inline[n];      // the RK3 update rides in the sweep (substep_fused decided; kappa kernel only)
   const Geo &g = h->g;
   if (g.nx < MX || g.ny < 4) return false;
   const int gx = (g.nx + MX - 1) / MX, gy = (g.ny + MY - 1) / MY, tiles = gx * gy;
@@ -401,7 +410,11 @@ bool k_scalar_fused_lds(udc_handle *h, int n, bool fresh, int *rc) {
   double *cp = h->fields[UDC_SVP + 3 * n];
   const bool les = h->p.sgs != UDC_SGS_DNS, cd2 = h->slot[n].adv == 2;
   const int gh = h->slot[n].kappa_ghosts;
-#define LF(L, F) hipLaunchKernelGGL((scalar_kappa_faces_kernel<L, F>), gr, b, 0, h->stream, g, gx, tiles, h->m, cekh, dfac, u, v, w, ekh, c, cp, gh, kc)
+  if (inl && (cd2 || !fresh)) { udc_set_error("scalar sweep: the in-sweep update is the fresh kappa sweep's only"); *rc = 1; return true; }
+  const double *svm_in = inl ? h->fields[UDC_SVM + 3 * n] : nullptr;
+  double *svm_out = (inl && h->sv_inline_last) ? h->fields[UDC_SVM + 3 * n] : nullptr;
+  const double rk = h->sv_inline_rk3coef;
+#define LF(L, F) hipLaunchKernelGGL((scalar_kappa_faces_kernel<L, F>), gr, b, 0, h->stream, g, gx, tiles, h->m, cekh, dfac, u, v, w, ekh, c, cp, gh, kc, svm_in, svm_out, rk)
 #define LS(A, L, F) hipLaunchKernelGGL((scalar_lds_kernel<A, L, F, 1>), gr, b, 0, h->stream, g, gx, tiles, h->m, cekh, dfac, u, v, w, ekh, c, cp, c, cp, gh, kc)
   {
     PROF(h, cd2 ? "scalar_lds_cd2" : "scalar_kappa_faces");

@@ -107,7 +107,7 @@ class DynCore:
                 "vp_ghost_row": row[o[5]], "p_ghost_row": row[o[6]],
                 "integration": ("one launch", "edge rows first, velocity rows beside the interior")[o[7]],
                 "slab_layout": bool(o[11]), "fused_line_transforms": bool(o[12]), "transpose_k_chunks": o[13],
-                "own_forward_half": bool(o[14]), "pressure_total_form": bool(o[15])}
+                "own_forward_half": bool(o[14]), "pressure_total_form": bool(o[15] & 1), "scalars_updated_in_their_sweep": int(o[15] >> 1)}
 
     def comm_init_local(self, group: int):
         """Attach to an in-process group of virtual ranks (udc_local_group_create); test transport."""
