@@ -797,6 +797,48 @@ def test_um_alias_and_mixed_api():
     ref.close(); mix.close()
 
 
+def test_pressure_total_form_and_in_sweep_scalar_update_are_what_runs(monkeypatch):
+    """The two byte savings of round 5 are the default of the fused substep and equal the reference's form to round-off: the
+    pressure-total form (the sweep leaves grad pres0 out, the solve's output becomes pres0) and a plain passive kappa
+    scalar's RK3 update inside its own sweep.  The executed plan says so (no silent fall-back), nine substeps agree with the same
+    library run in the reference's form (UDC_PTOTAL=0, UDC_SV_INLINE=0) at 1e-11, and the planner backs off where it must: with the
+    outflow-rate mass correction (the tendencies are summed over one plane) and with a source on the scalar."""
+    from udcore.core import DynCore
+    g = Grid.uniform(64, 32, 16)
+    st = random_state(g, 5, nsv=1)
+    st["pres0"] = np.zeros_like(st["pres0"])      # (a pres0 that no solve produced would keep an arbitrary constant in the reference's form only)
+    dt = 0.05
+
+    def run(**env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        core = DynCore(g, sgs=1, nsv=1, lbottom=True, z0=0.03)
+        core.load_state(st)
+        for isub in range(9):
+            core.substep(isub % 3 + 1, dt, True)
+        plan = core.last_plan()
+        out = {k: core.download(k)[1:-1].copy() for k in ("u0", "v0", "w0", "pres0")}
+        out["sv0"] = core.download(L.scalar_field(L.SV0, 0), halo=2)[2:-2, 2:-2, 2:-2].copy()
+        core.close()
+        for k in env:
+            monkeypatch.delenv(k)
+        return out, plan
+    new, plan = run()
+    assert plan["pressure_total_form"] and plan["scalars_updated_in_their_sweep"] == 1
+    old, plan0 = run(UDC_PTOTAL="0", UDC_SV_INLINE="0")
+    assert not plan0["pressure_total_form"] and plan0["scalars_updated_in_their_sweep"] == 0
+    for k in new:
+        a, b = (new[k], old[k]) if k == "sv0" else (nocorner(new[k]), nocorner(old[k]))
+        assert relerr(a, b) <= 1e-11, k
+    # where the forms differ the planner keeps the reference's
+    core = DynCore(g, sgs=1, nsv=1)
+    core.load_state(st)
+    core.set_masscorr_outflow(True, 1.0)
+    core.substep(1, dt, True)
+    assert not core.last_plan()["pressure_total_form"]
+    core.close()
+
+
 @pytest.mark.parametrize("shape,pmode", [((64, 32, 16), (5, 2, 1)), ((32, 48, 12), (16, 24, 0)), ((20, 12, 10), (3, 1, 7))])
 def test_poisson_returns_an_analytic_eigenmode(shape, pmode):
     """p* = cos(2 pi m x) cos(2 pi n y) cos(pi l z) is an eigenvector of the discrete operator `poisson` inverts (uniform

@@ -394,7 +394,6 @@ struct udc_handle {
   double *fft_tw = nullptr;             // twiddle tables
   int fft_L = 0, fft_C = 0;             // x rows / y columns per workgroup
   bool slab_yreg = false;               // slab path: y transforms as 16 x N2 in registers (ny = 128, 256, 512)
-  bool own_bwd = false;                 // one GPU: own backward half (reserved; rocFFT's backward plan runs today)
   bool own_fwd = false;                 // UDC_OWN_FWD=1, one GPU: divergence + x transform + y pass of udc_fft.hip instead of div_rhs + rocFFT's forward plan
   int nat_L = 0, nat_C = 0;
   bool nat_reg16 = false;               // ny = 256: the y pass as 16 x 16 in registers (UDC_NAT_REG=0: the Stockham kernel)
