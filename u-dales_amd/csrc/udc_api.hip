@@ -1036,6 +1036,8 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   const Plan plan = plan_substep(pin);
   h->last_plan = plan; h->have_plan = true;
   h->ptotal_now = plan.ptotal != 0;
+  // (whatever way this substep ends, the routine-by-routine entry points must find the reference's form again)
+  struct FormGuard { udc_handle *h; ~FormGuard() { h->ptotal_now = false; for (bool &b : h->sv_inline) b = false; } } form_guard{h};
   const bool lds = true, pup = true, fold = plan.fold;      // (LDS-staged sweeps, tendencies as predicted velocity: always)
   const bool forces = (ops & OP_FORCES) != 0;
   if (plan.materialise_um) { if (um_materialise(h)) return 1; }
@@ -1195,7 +1197,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
     // the array the sweep wrote is the scalar now; the planes below the floor (never written by a kernel: what the start-up put there) go along
     HIP_OK(hipMemcpyAsync(h->fields[UDC_SVP + 3 * n], h->fields[UDC_SV0 + 3 * n], sizeof(double) * (size_t)HZ * (size_t)h->g.sz, hipMemcpyDeviceToDevice, h->stream));
     std::swap(h->fields[UDC_SV0 + 3 * n], h->fields[UDC_SVP + 3 * n]);
-    h->sv_inline[n] = false;
+    h->sv_inline[n] = false;      // (the integration has run: from here on the scalar is like any other)
   }      // what the solve returned is pres0 now; the old pres0 array takes the next solve's output
   h->dthv_top_on = false;
   if (rk3step == 3 && k_chem(h, dt)) return 1;      // src/modtstep.f90:236-238 (before the ghosts are refreshed)
