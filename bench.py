@@ -275,12 +275,12 @@ def dropin_leg(nx, ny, nz, nsv, sgs, floor, value, nsub=450, nwarm=30):
     v, out = res
     m = re.search(r"fused_substeps=(\d+) unfused=(\d+)", out)
     dm = re.search(r"divmax=\s*([0-9.Ee+-]+)", out)
-    # ... and through the reference's OWN main program (oracle/_ref/udales_full_dropin: src/program.f90 untouched, every other file of
+    # ... and through the reference's OWN main program (u-dales_amd/bin/udales_full_dropin: src/program.f90 untouched, every other file of
     # the reference's src/ but the ten drop-in modules), timed by the reference's own clock around its loop (`TOTAL CPU time by
     # main time loop`, src/modmpi.f90:140-160) -- which, unlike the figure above, includes the first substep's upload of the state
     # and the last one's download for the restart / output code
     real = None
-    exe2 = os.path.join(ROOT, "oracle", "_ref", "udales_full_dropin")
+    exe2 = os.path.join(ROOT, "u-dales_amd", "bin", "udales_full_dropin")
     if os.path.exists(exe2):
         nstep = 400
         with tempfile.TemporaryDirectory() as tmp:
@@ -304,7 +304,7 @@ def dropin_leg(nx, ny, nz, nsv, sgs, floor, value, nsub=450, nwarm=30):
                             "steady_state": {"value": nx * ny * nz * 3 * nstep / steady, "ms_per_substep": round(steady / (3 * nstep) * 1e3, 5),
                                              "frac_of_direct": round(nx * ny * nz * 3 * nstep / steady / value, 4),
                                              "note": "the loop's time minus the one-time upload / download of the state"},
-                            "surface": "oracle/_ref/udales_full_dropin namoptions.NNN: the reference's program.f90, modstartup.f90 and every "
+                            "surface": "u-dales_amd/bin/udales_full_dropin namoptions.NNN: the reference's program.f90, modstartup.f90 and every "
                                        "other file of its src/ unmodified, minus the ten drop-in modules; its own timer around its loop "
                                        "(incl. the one-time upload / final download of the state)"}
             except subprocess.TimeoutExpired:

@@ -13,7 +13,7 @@
 ! `run` mode is pinned on the reference's executable itself: oracle/_ref/udales_full (program.f90 and all) on the same deck writes a
 ! restart file that must equal this driver's state bit for bit (tests/test_full_reference.py).
 !
-! The absent third-party layers are the stand-ins of oracle/shims (MPI, 2DECOMP&FFT, FFTW through fft_ref.c, a recording NetCDF).
+! The absent third-party layers are the stand-ins of u-dales_amd/fortran/standins (MPI, 2DECOMP, a recording NetCDF) and oracle/shims (FFTW through fft_ref.c).
 !
 ! Modes (argv[2]; argv[1] is the deck, as for the reference's executable, src/modstartup.f90:175-177):
 !   run      : nsub substeps, dump state after the substeps listed in dump_at

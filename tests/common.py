@@ -97,6 +97,7 @@ def nocorner(a, h=1):
 
 # ---- multi-rank launches: real RCCL wherever the box has a GPU per rank, the shared-memory test transport on a one-GPU box --------
 REFDIR = os.path.join(os.path.dirname(HERE), "oracle", "_ref")
+BINDIR = os.path.join(os.path.dirname(HERE), "u-dales_amd", "bin")      # the drop-in programs (u-dales_amd/fortran/Makefile)
 MPIEXEC = "/opt/conda/bin/mpiexec"
 
 
@@ -114,7 +115,7 @@ def gpu_count():
 def mpi_transport(nranks, tag):
     """-> (executable, environment, label) for `mpiexec -n nranks` of the reference's program over the drop-in modules.
 
-    A box with at least `nranks` GPUs runs the PRODUCT: oracle/_ref/udales_full_dropin_mpi over libudcore.so, one rank per GPU,
+    A box with at least `nranks` GPUs runs the PRODUCT: u-dales_amd/bin/udales_full_dropin_mpi over libudcore.so, one rank per GPU,
     ghost rows / transposes / reductions through RCCL (udc_comm_init).  A one-GPU box runs the test build
     (udales_full_dropin_mpi_test over libudcore_test.so), every rank on device 0, the same exchanges through a shared-memory
     segment (UDC_TEST_SHM) -- which validates the harness and everything but RCCL's byte mover."""
@@ -122,8 +123,8 @@ def mpi_transport(nranks, tag):
     if gpu_count() >= nranks:
         env.pop("UDC_GPUS_PER_NODE", None)
         env.pop("UDC_TEST_SHM", None)
-        return os.path.join(REFDIR, "udales_full_dropin_mpi"), env, "rccl"
+        return os.path.join(BINDIR, "udales_full_dropin_mpi"), env, "rccl"
     # (a name per launch: a run that died before its ranks had all attached leaves its segment behind under its name)
     _SHM_SERIAL[0] += 1
     env.update(UDC_GPUS_PER_NODE="1", UDC_TEST_SHM=f"/udc_{tag}_{os.getpid()}_{nranks}_{_SHM_SERIAL[0]}")
-    return os.path.join(REFDIR, "udales_full_dropin_mpi_test"), env, "shm"
+    return os.path.join(BINDIR, "udales_full_dropin_mpi_test"), env, "shm"

@@ -82,7 +82,7 @@ def write_dump(path, fields: dict):
 
 def read_ncrec(path, want=None) -> dict:
     """Reader for what the reference's output modules leave behind when they are linked against the NetCDF stand-in of the
-    oracle builds (oracle/shims/netcdf_rec_io.c): {variable name: list of (start, array)} in the order written; arrays come
+    oracle builds (u-dales_amd/fortran/standins/netcdf_rec_io.c): {variable name: list of (start, array)} in the order written; arrays come
     back [..., j, i]-ordered (the Fortran shape reversed).  `want`: only these variable names (the 3-D dumps are large)."""
     out, names = {}, {}
     with open(path, "rb") as f:

@@ -2,7 +2,7 @@
 
 oracle/_ref/udales_full is `u-dales` as the reference's CMakeLists would link it -- every file of /root/reference/src, unmodified,
 program.f90 and modstartup.f90 included (oracle/Makefile) -- over stand-ins for the third-party layers this image lacks (MPI,
-2DECOMP&FFT, FFTW, NetCDF: oracle/shims).  The fixtures tests/golden/run_*.bin.gz come from oracle/_ref/udales_ref, the same
+2DECOMP&FFT, NetCDF: u-dales_amd/fortran/standins; FFTW: oracle/shims).  The fixtures tests/golden/run_*.bin.gz come from oracle/_ref/udales_ref, the same
 objects under a second main program that can dump between routines (oracle/ref_driver.f90).  Here every run deck goes through the
 real program -- `udales_full namoptions.NNN`, nothing else on the command line -- with a run time and a restart interval that make it
 stop, and write its restart files (the reference's own writerestartfiles, real(8)), where the fixture's last dump was taken: the two

@@ -1,6 +1,6 @@
 """The drop-in boundary under the reference's REAL program.
 
-oracle/_ref/udales_full_dropin is what INTEGRATION.md section 1 prescribes, carried out: every file of the reference's src/ --
+u-dales_amd/bin/udales_full_dropin is what INTEGRATION.md section 1 prescribes, carried out: every file of the reference's src/ --
 program.f90, modstartup.f90, tests.f90, the statistics / output modules, unmodified, compiled where they lie -- except the ten
 modules u-dales_amd/fortran/ replaces, linked against libudcore (u-dales_amd/fortran/Makefile).  Same command line as the
 reference's executable: `udales_full_dropin namoptions.NNN`.  Its counterpart oracle/_ref/udales_full is the same build with the
@@ -24,14 +24,14 @@ from test_full_reference import run_full
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DROPIN = os.path.join(ROOT, "oracle", "_ref", "udales_full_dropin")
+DROPIN = os.path.join(ROOT, "u-dales_amd", "bin", "udales_full_dropin")
 
 
 @pytest.mark.parametrize("residency", [2, 0])
 @pytest.mark.parametrize("name,iexp", sorted(RUN_CASES.items()))
 def test_run_decks_through_the_reference_program(name, iexp, residency, tmp_path):
     if not os.path.exists(DROPIN):
-        pytest.skip("oracle/_ref/udales_full_dropin not built (needs the reference sources + flang)")
+        pytest.skip("u-dales_amd/bin/udales_full_dropin not built (needs the reference sources + flang)")
     if residency == 0 and name not in ("run_16x16x8", "run_ibm_wf2_16x12x10", "run_moist_16x8x12s", "run_stats_16x8x12s", "run_bcxs_16x8x12s"):
         pytest.skip("strict residency: a selection of decks")
     env = dict(os.environ, UDC_RESIDENCY=str(residency))
@@ -113,7 +113,7 @@ def test_examples_through_the_reference_program(ex, n, tmp_path):
     files of a 2 x 2 rank run: not runnable on one rank.)"""
     from udcore import restart
     if not os.path.exists(DROPIN):
-        pytest.skip("oracle/_ref/udales_full_dropin not built")
+        pytest.skip("u-dales_amd/bin/udales_full_dropin not built")
     fix = load_fixture(f"full_example_{ex}")
     cdir = os.path.join(GOLDEN, "cases", f"example_{ex}")
     for fn in os.listdir(cdir):

@@ -1,5 +1,5 @@
 """The Fortran / MPI route into the library, as far as one box allows: the reference's real program with the drop-in modules over a
-real MPI (oracle/_ref/udales_full_dropin_mpi: every file of the reference's src/ but the ten replaced ones, MPICH, the y-slab
+real MPI (u-dales_amd/bin/udales_full_dropin_mpi: every file of the reference's src/ but the ten replaced ones, MPICH, the y-slab
 decomposition stand-in), launched as a user launches the reference: `mpiexec -n 2 <exe> namoptions.NNN` with nprocx = 1, nprocy = 2.
 
 Each rank reads the deck (rank 0 reads, MPI_BCAST of every value: src/modstartup.f90:175-520), sets up its slab, creates its library
@@ -20,7 +20,7 @@ import pytest
 from common import GOLDEN, RUN_CASES, gpu_count, mpi_transport
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EXE = os.path.join(ROOT, "oracle", "_ref", "udales_full_dropin_mpi")
+EXE = os.path.join(ROOT, "u-dales_amd", "bin", "udales_full_dropin_mpi")
 MPIEXEC = "/opt/conda/bin/mpiexec"
 
 
@@ -45,7 +45,7 @@ def have_gpu():
 
 def test_two_mpi_ranks_without_a_gpu_stop_at_udc_create(tmp_path):
     if not (os.path.exists(EXE) and os.path.exists(MPIEXEC)):
-        pytest.skip("oracle/_ref/udales_full_dropin_mpi or MPICH not available")
+        pytest.skip("u-dales_amd/bin/udales_full_dropin_mpi or MPICH not available")
     if have_gpu():
         pytest.skip("this box has a GPU")
     r = launch(tmp_path, {})
@@ -58,7 +58,7 @@ def test_two_mpi_ranks_without_a_gpu_stop_at_udc_create(tmp_path):
 def test_two_mpi_ranks_on_one_gpu_reach_udc_comm_init(tmp_path):
     import torch
     if not (os.path.exists(EXE) and os.path.exists(MPIEXEC)):
-        pytest.skip("oracle/_ref/udales_full_dropin_mpi or MPICH not available")
+        pytest.skip("u-dales_amd/bin/udales_full_dropin_mpi or MPICH not available")
     if torch.cuda.device_count() >= 2:
         pytest.skip("a one-GPU behaviour (RCCL's refusal of two ranks per device); here test_mpi_ranks_run_the_deck_to_the_end runs over RCCL")
     r = launch(tmp_path, {"UDC_GPUS_PER_NODE": "1"})
@@ -71,7 +71,7 @@ def test_two_mpi_ranks_on_one_gpu_reach_udc_comm_init(tmp_path):
 
 # ---- two MPI ranks to the end, on one GPU: the test build of the same program (udales_full_dropin_mpi_test: udc_iface.f90 compiled
 # with -DUDC_TEST_TRANSPORT, linked against libudcore_test.so) exchanges through shared memory instead of RCCL (UDC_TEST_SHM)
-EXE_TEST = os.path.join(ROOT, "oracle", "_ref", "udales_full_dropin_mpi_test")
+EXE_TEST = os.path.join(ROOT, "u-dales_amd", "bin", "udales_full_dropin_mpi_test")
 
 
 def run_ranks(name, iexp, tmp_path, nranks, deck_edit=None):

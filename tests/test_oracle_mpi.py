@@ -2,7 +2,7 @@
 y-slab decomp_2d of u-dales_amd/fortran/decomp_2d.f90) must be decomposition invariant, like the
 reference's own processor_boundaries test demands of 2decomp-fft
 (tests/integration/processor_boundaries/test_processor_boundaries.py:28-34) -- and, deck by deck, give what the
-single-rank build (oracle/shims/decomp_2d_np1.f90, the one every golden fixture comes from) gives: the two stand-ins
+single-rank build (u-dales_amd/fortran/standins/decomp_2d_np1.f90, the one every golden fixture comes from) gives: the two stand-ins
 for the absent 2decomp-fft are written independently (copies vs MPI_ALLTOALL / MPI_SENDRECV), so their agreement on
 every run deck is a check of both."""
 import os

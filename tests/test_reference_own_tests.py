@@ -34,8 +34,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REFDIR = os.path.join(ROOT, "oracle", "_ref")
 FULL = os.path.join(REFDIR, "udales_full")
 FULL_MPI = os.path.join(REFDIR, "udales_full_mpi")
-DROPIN = os.path.join(REFDIR, "udales_full_dropin")
-DROPIN_MPI_TEST = os.path.join(REFDIR, "udales_full_dropin_mpi_test")
+BINDIR = os.path.join(ROOT, "u-dales_amd", "bin")
+DROPIN = os.path.join(BINDIR, "udales_full_dropin")
+DROPIN_MPI_TEST = os.path.join(BINDIR, "udales_full_dropin_mpi_test")
 MPIEXEC = "/opt/conda/bin/mpiexec"
 CASE = os.path.join(GOLDEN, "cases", "case_100")
 TOL = 1.0e-9            # ABS_TOL of test_processor_boundaries.py:28 and of src/tests.f90:389
@@ -118,7 +119,7 @@ def test_pencil_extents_of_the_decomposition_stand_in(P, tmp_path):
 @pytest.mark.gpu
 def test_operator_test_of_the_reference_over_the_dropin_modules(tmp_path):
     if not os.path.exists(DROPIN):
-        pytest.skip("oracle/_ref/udales_full_dropin not built")
+        pytest.skip("u-dales_amd/bin/udales_full_dropin not built")
     stage(tmp_path, "namoptions.1005.serial")
     r = run(tmp_path, DROPIN, env=dict(os.environ, UDC_RESIDENCY="2"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]

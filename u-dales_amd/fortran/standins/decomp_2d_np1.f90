@@ -1,4 +1,4 @@
-! TEST INFRASTRUCTURE (oracle/_ref build only) -- not part of the product.
+! Stand-in of the one-rank builds (this directory's Makefile; the test infrastructure's all-reference builds use it too).
 !
 ! Single-rank stand-in for the 2DECOMP&FFT library (uDALES fork).  The real
 ! library is an un-vendored, unpinned git submodule of the reference
@@ -8,7 +8,7 @@
 !   * pencil extents (x/y/z pencils all equal the whole domain when np=1),
 !   * alloc_{x,y,z}: allocation WITH halos, lower bound 1-h  (src/modfields.f90:469,
 !     src/modpois.f90:83-89,441-443) -- arrays are zero-filled here, which is the
-!     convention the oracle and the device library both adopt,
+!     convention the test oracle and the device library both adopt,
 !   * exchange_halo_z: no-op (with one rank 2DECOMP's periodic_bc is .false.,
 !     src/modstartup.f90:662-672, and the solver wraps periodicity itself,
 !     src/modboundary.f90:95-107),
@@ -71,7 +71,7 @@ contains
     integer, intent(in) :: nx, ny, nz, p_row, p_col
     logical, dimension(3), intent(in), optional :: periodic_bc
     if (p_row /= 1 .or. p_col /= 1) then
-      write (0, *) 'ERROR: oracle decomp_2d shim is single-rank only'
+      write (0, *) 'ERROR: the one-rank decomp_2d stand-in is single-rank only'
       stop 1
     end if
     nx_global = nx; ny_global = ny; nz_global = nz
@@ -198,7 +198,7 @@ contains
     integer, intent(in) :: level
     type(DECOMP_INFO), intent(in), optional :: opt_decomp
     logical, intent(in), optional :: opt_global
-    write (0, *) 'ERROR: update_halo not provided by the oracle shim'
+    write (0, *) 'ERROR: update_halo not provided by the one-rank stand-in'
     stop 1
   end subroutine update_halo
 
@@ -215,7 +215,7 @@ module decomp_2d_fft
   end interface
 contains
   subroutine fft_unavailable
-    write (0, *) 'ERROR: decomp_2d_fft is not provided by the oracle shim (ipoiss must be 0)'
+    write (0, *) 'ERROR: decomp_2d_fft is not provided by the one-rank stand-in (ipoiss must be 0)'
     stop 1
   end subroutine fft_unavailable
   subroutine decomp_2d_fft_init(pencil)

@@ -1,10 +1,10 @@
-"""TEST INFRASTRUCTURE.  Compile order of a Fortran source set from its `use` statements.
+"""Compile order of a Fortran source set from its `use` statements.
 
     deporder.py <reference src dir> [<drop-in dir>] [--skip name.f90 ...]
 
 prints "path path ..." (module dependencies first).  With a second directory, every file there replaces the reference file of
 the same name and the rest (udc_iface.f90, decomp_2d.f90) is added -- the source set of INTEGRATION.md section 1.  --skip leaves files
-out (the one-rank builds take their decomp_2d from oracle/shims instead of the MPI y-slab module)."""
+out (the one-rank builds take their decomp_2d from standins/ instead of the MPI y-slab module)."""
 import glob
 import os
 import re

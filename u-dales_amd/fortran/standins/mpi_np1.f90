@@ -1,11 +1,11 @@
-! TEST INFRASTRUCTURE (oracle/_ref build only) -- not part of the product.
+! Stand-in of the one-rank builds (this directory's Makefile; the test infrastructure's all-reference builds use it too).
 !
 ! Single-rank stand-in for the `mpi` module so that the reference's unmodified
 ! hot-path Fortran (src/modmpi.f90:34 `use mpi`) can be compiled in a container
 ! that has no Fortran MPI module usable by flang.  It declares only the handles
 ! and constants that the 18 hot-path modules reference; the MPI_* procedures
 ! themselves stay implicit-interface externals and are resolved by
-! oracle/shims/np1_externals.c (np=1: broadcasts are no-ops, reductions copy).
+! mpi_np1_externals.c (np=1: broadcasts are no-ops, reductions copy).
 !
 ! No arithmetic happens here: with one rank every MPI call in the hot path is
 ! an identity on the data.
@@ -15,7 +15,7 @@ module mpi
   integer, parameter :: MPI_COMM_NULL = -1
   integer, parameter :: MPI_PROC_NULL = -2
   integer, parameter :: MPI_STATUS_SIZE = 5
-  ! datatype handles: value = size in bytes * 100 + tag, decoded in np1_externals.c
+  ! datatype handles: value = size in bytes * 100 + tag, decoded in mpi_np1_externals.c
   integer, parameter :: MPI_CHARACTER        = 101
   integer, parameter :: MPI_INTEGER          = 402
   integer, parameter :: MPI_LOGICAL          = 403

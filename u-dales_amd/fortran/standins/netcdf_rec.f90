@@ -1,7 +1,7 @@
-! TEST INFRASTRUCTURE (oracle/_ref builds only) -- not part of the product.
+! Stand-in of every build of the reference's program in this image (the drop-in program and the all-reference builds).
 !
 ! Stand-in for the NetCDF Fortran-90 module, which this image does not have: the nf90_* generics that src/modstat_nc.f90 and
-! src/initfac.f90:267-270 call, over oracle/shims/netcdf_rec_io.c (tables in memory, nf90_put_var appended to the file as a flat
+! src/initfac.f90:267-270 call, over netcdf_rec_io.c (tables in memory, nf90_put_var appended to the file as a flat
 ! float64 record stream that tests/refdump.py reads).  With it the reference's WHOLE src/ tree -- program.f90, modstartup.f90,
 ! the statistics and dump modules -- compiles and runs unmodified.  Re-opening an existing file (a run continued in the
 ! directory of an earlier one, src/modstat_nc.f90:129-164) and reading view factors (lEB without lvfsparse) are not provided:

@@ -1,6 +1,6 @@
-/* TEST INFRASTRUCTURE (oracle/_ref builds only) -- not part of the product.
+/* Stand-in of every build of the reference's program in this image (the drop-in program and the all-reference builds).
  *
- * Backend of oracle/shims/netcdf_rec.f90: the NetCDF library is absent from this image, so the reference's output modules
+ * Backend of netcdf_rec.f90: the NetCDF library is absent from this image, so the reference's output modules
  * (src/modstat_nc.f90, the one nf90_open in src/initfac.f90:267) link against a stand-in that keeps the dimension / variable
  * tables of each file in memory and APPENDS what nf90_put_var is handed to the file itself as a flat record stream:
  *
