@@ -58,7 +58,7 @@ enum {
  * DNS = lles .false. (src/modglobal.f90:194) */
 enum { UDC_SGS_DNS = 0, UDC_SGS_SMAGORINSKY = 1, UDC_SGS_VREMAN = 2, UDC_SGS_ONEEQN = 3 /* set by udc_set_tke */ };
 /* BCtopm (src/modglobal.f90:150-153) */
-enum { UDC_TOP_FREESLIP = 1, UDC_TOP_NOSLIP = 2 };
+enum { UDC_TOP_FREESLIP = 1, UDC_TOP_NOSLIP = 2, UDC_TOP_PRESSURE = 3 };      /* BCtopm_*, src/modglobal.f90:140-142 */
 
 /* Everything the reference's initglobal / initsubgrid / initpois derive the kernels'
  * constants from (src/modglobal.f90:536-874, src/modsubgrid.f90:44-79, src/modpois.f90:66-220). */

@@ -535,8 +535,46 @@ void orc_forces(const orc_grid *g, const double *dpdxl, const double *dpdyl,
 
 /* ====================================================================== pressure */
 
+/* The open lid, BCtopm = 3 (BCtopm_pressure, src/modglobal.f90:142): w(ke+1) "can vary according to pressure gradient".
+ * bcpup's branch src/modboundary.f90:1234-1243: pres0ij = avexy_ibm(pres0) over the fluid c cells (src/modmpi.f90:623-664),
+ * pwp(ke+1) = wm(ke+1) rk3coefi + 2 pres0ij(ke) dzhi(ke+1), and wp(ke+1) is OVERWRITTEN with pwp(ke+1) - wm(ke+1) rk3coefi.
+ * orc_fillps needs pres0 and a writable wp for it: orc_set_lid hands them over (orc_substep does; NULL, NULL = off). */
+static const double *lid_pres0 = NULL;
+static double *lid_wp = NULL;
+void orc_set_lid(const double *pres0, double *wp) { lid_pres0 = pres0; lid_wp = wp; }
+static const double *ibm_ctx_mask(int grid);
+/* avexy_ibm's mean of level k over the fluid c cells (all cells without an immersed boundary) */
+static double lid_level_mean(const orc_grid *g, const double *f, int k) {
+  const double *mask = ibm_ctx_mask(3);
+  double s = 0., c = 0.;
+  for (int j = 1; j <= g->ny; ++j)
+    for (int i = 1; i <= g->nx; ++i) {
+      const double w = mask ? (M(mask, i, j, k) > 0.5 ? 1. : 0.) : 1.;
+      s += M(f, i, j, k) * w; c += w;
+    }
+  return c > 0. ? s / c : -999.;
+}
+void orc_bcpup_lid(const orc_grid *g, double rk3coef, const double *pres0, const double *wm, double *wp, double *pwp) {
+  const int nx = g->nx, ny = g->ny, nz = g->nz;
+  const double rk3coefi = 1. / rk3coef, dzhi = 1. / g->dzh[nz + 1];
+  const double pres0ij = lid_level_mean(g, pres0, nz);
+  for (int j = 1; j <= ny; ++j)
+    for (int i = 1; i <= nx; ++i) {
+      M(pwp, i, j, 1) = 0.;
+      M(pwp, i, j, nz + 1) = M(wm, i, j, nz + 1) * rk3coefi + 2 * pres0ij * dzhi;
+      M(wp, i, j, nz + 1) = M(pwp, i, j, nz + 1) - M(wm, i, j, nz + 1) * rk3coefi;
+    }
+}
+/* tderive's branch src/modpois.f90:1058-1069: wp(ke+1) += 2 pij(ke) dzhi(ke+1), pij = avexy_ibm(p) */
+void orc_tderive_lid(const orc_grid *g, const double *p, double *wp) {
+  const int nz = g->nz;
+  const double pij = lid_level_mean(g, p, nz), dzhi = 1. / g->dzh[nz + 1];
+  for (int i = 1; i <= g->nx; ++i)
+    for (int j = 1; j <= g->ny; ++j) M(wp, i, j, nz + 1) = M(wp, i, j, nz + 1) + 2 * pij * dzhi;
+}
+
 /* fillps src/modpois.f90:911-998 + bcpup src/modboundary.f90:1191-1341
- * (free-slip / no-slip top, periodic x and y on one rank) */
+ * (free-slip / no-slip top, or the open lid after orc_set_lid; periodic x and y on one rank) */
 void orc_fillps(const orc_grid *g, double rk3coef, const double *up, const double *vp,
                 const double *wp, const double *um, const double *vm, const double *wm,
                 double *pup, double *pvp, double *pwp, double *p) {
@@ -552,6 +590,7 @@ void orc_fillps(const orc_grid *g, double rk3coef, const double *up, const doubl
       }
   for (int j = 1; j <= ny; ++j)
     for (int i = 1; i <= nx; ++i) { M(pwp, i, j, 1) = 0.; M(pwp, i, j, nz + 1) = 0.; }
+  if (g->bctopm == 3 && lid_pres0 && lid_wp) orc_bcpup_lid(g, rk3coef, lid_pres0, wm, lid_wp, pwp);
   for (int k = 1; k <= nz; ++k)
     for (int j = 1; j <= ny; ++j) M(pup, nx + 1, j, k) = M(pup, 1, j, k);
   for (int k = 1; k <= nz; ++k)
@@ -716,6 +755,7 @@ void orc_tderive(const orc_grid *g, double *p, double *up, double *vp, double *w
         M(wp, i, j, k) = M(wp, i, j, k) - (M(p, i, j, k) - M(p, i, j, k - 1)) * (1. / g->dzh[k]);
       }
     }
+  if (g->bctopm == 3) orc_tderive_lid(g, p, wp);
   for (int k = 0; k <= nz + 1; ++k)
     for (int j = 0; j <= ny + 1; ++j)
       for (int i = 0; i <= nx + 1; ++i) M(pres0, i, j, k) = M(pres0, i, j, k) + M(p, i, j, k);
@@ -740,6 +780,9 @@ void orc_tstep_integrate(const orc_grid *g, int rk3step, double dt, double *u0, 
           C(p0, i, j, k) = C(pm, i, j, k) + rk3coef * C(pp, i, j, k);
         }
       }
+  if (g->bctopm == 3)                                             /* src/modtstep.f90:270-286 */
+    for (int j = 1; j <= g->ny; ++j)
+      for (int i = 1; i <= g->nx; ++i) M(w0, i, j, g->nz + 1) = M(wm, i, j, g->nz + 1) + rk3coef * M(wp, i, j, g->nz + 1);
   memset(up, 0, n * sizeof(double));
   memset(vp, 0, n * sizeof(double));
   memset(wp, 0, n * sizeof(double));
@@ -824,8 +867,9 @@ void orc_boundary(const orc_grid *g, double *u0, double *v0, double *w0, double 
     for (int i = 0; i <= nx + 1; ++i) { M(wm, i, j, 1) = 0.; M(w0, i, j, 1) = 0.; }
   top_row_m(g, um, g->uinf); top_row_m(g, u0, g->uinf);
   top_row_m(g, vm, g->vinf); top_row_m(g, v0, g->vinf);
-  for (int j = 0; j <= ny + 1; ++j)
-    for (int i = 0; i <= nx + 1; ++i) { M(w0, i, j, nz + 1) = 0.; M(wm, i, j, nz + 1) = 0.; }
+  if (g->bctopm != 3)                                             /* open lid: "w considered in modpois", src/modboundary.f90:191-200 */
+    for (int j = 0; j <= ny + 1; ++j)
+      for (int i = 0; i <= nx + 1; ++i) { M(w0, i, j, nz + 1) = 0.; M(wm, i, j, nz + 1) = 0.; }
   for (int s = 0; s < g->nsv; ++s) {
     double *p0 = sv0 + s * nc, *pm = svm + s * nc;
     for (int mm = 1; mm <= 2; ++mm)
@@ -1859,7 +1903,9 @@ void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
   if (ibm_ctx) orc_ibmnorm(g, ibm_ctx, s);                                             /* src/program.f90:171 */
   if (s->svsrc)                                                                          /* scalsource, src/program.f90:181 */
     for (size_t q = 0; q < (size_t)g->nsv * nc; ++q) s->svp[q] = s->svp[q] + s->svsrc[q];
+  orc_set_lid(g->bctopm == 3 ? s->pres0 : NULL, g->bctopm == 3 ? s->wp : NULL);
   orc_fillps(g, rk3coef, s->up, s->vp, s->wp, s->um, s->vm, s->wm, s->pup, s->pvp, s->pwp, s->p);
+  orc_set_lid(NULL, NULL);
   orc_poisson_solve(g, s->p);
   orc_tderive(g, s->p, s->up, s->vp, s->wp, s->pres0);
   orc_tstep_integrate(g, rk3step, dt, s->u0, s->v0, s->w0, s->um, s->vm, s->wm, s->up, s->vp, s->wp,

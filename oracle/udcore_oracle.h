@@ -36,7 +36,7 @@ typedef struct {
   double c_vreman;          /* 0.07     src/modsubgriddata.f90:61 */
   double csz;               /* Smagorinsky constant src/modsubgrid.f90:73-77 */
   int sgs;                  /* 0 = DNS (lles false), 1 = Smagorinsky, 2 = Vreman, 3 = one-equation TKE */
-  int bctopm;               /* 1 free-slip, 2 no-slip (src/modglobal.f90:150-153) */
+  int bctopm;               /* 1 free-slip, 2 no-slip, 3 open to the pressure gradient (src/modglobal.f90:140-153) */
   double uinf, vinf;        /* only for no-slip top (valuetop) */
   int nsv;                  /* passive scalars, kappa scheme (src/modglobal.f90:557-559) */
   int lbottom;              /* floor wall function (src/modibm.f90:49,2021), BCbotm = 3, BCbots = 1 */
@@ -204,6 +204,10 @@ void orc_thermodynamics(const orc_grid *g, orc_state *s);
 /* the state calthv's moist dthvdz (one-equation closure with lmoist) reads: qt0, ql0, the thermodynamics tables; NULL = dry */
 void orc_set_moist_context(const orc_state *s);
 void orc_buoyancy_moist(const orc_grid *g, const orc_state *s, double *wp);
+/* the open lid (BCtopm = 3): bcpup's and tderive's branches; orc_set_lid(pres0, wp) makes orc_fillps apply the first */
+void orc_set_lid(const double *pres0, double *wp);
+void orc_bcpup_lid(const orc_grid *g, double rk3coef, const double *pres0, const double *wm, double *wp, double *pwp);
+void orc_tderive_lid(const orc_grid *g, const double *p, double *wp);
 void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt);
 
 #ifdef __cplusplus

@@ -506,6 +506,27 @@ CASES.update({
     "run_ibm_uoutflow_16x12x10": ("run", 83, 16, 12, 10, dict(sgs="vreman", nsv=1, floor=True, randu=0.05, ibm=IBM_BLOCKS["run_ibm_edge_16x12x10"],
                                                               physics="luoutflowr = .true.\nuflowrate = 1.05", oracle="nsub = 9\ndump_at = 3, 9"), 1.04),
 })
+# the open lid, BCtopm = 3 (BCtopm_pressure): w(ke+1) is prognostic -- bcpup's row from the slab mean of pres0(ke), tderive's from the
+# mean of p(ke), tstep_integrate's plane; per-routine vectors after 4 substeps (so that pres0 and w(ke+1) are no longer zero), a run
+# with a kappa-advected scalar (its top flux now sees w(ke+1)), and a run with an immersed boundary one block of which reaches the
+# lid: avexy_ibm's mean then runs over the fluid c cells of level ke only (and, run_ibmtall, the same obstacles with a scalar under a
+# closed lid)
+IBM_BLOCKS["run_ptop_ibm_16x12x10"] = [(5, 8, 4, 7, 10), (11, 13, 8, 10, 2)]
+IBM_BLOCKS["run_ibmtall_16x12x10"] = IBM_BLOCKS["run_ptop_ibm_16x12x10"]      # the same obstacles under a closed (free-slip) lid
+CASES.update({
+    "k_ptop_12x8x6": ("kernels", 84, 12, 8, 6, dict(sgs="vreman", floor=True, bctopm=3, randu=0.05, oracle="nspin = 4"), 1.04),
+    "run_ptop_16x8x12s": ("run", 85, 16, 8, 12, dict(sgs="smag", nsv=1, floor=True, bctopm=3, randu=0.05, oracle="nsub = 9\ndump_at = 3, 9"), 1.06),
+    "run_ibmtall_16x12x10": ("run", 87, 16, 12, 10, dict(sgs="vreman", nsv=1, floor=True, bctopm=1, randu=0.05, ibm=[(5, 8, 4, 7, 10), (11, 13, 8, 10, 2)],
+                                                         oracle="nsub = 9\ndump_at = 3, 9"), 1.04),
+    # (no kappa-advected scalar in this one: advecc_kappa leaves cf w0(ke+1) dzfci(ke+1) in the out-of-domain plane svp(ke+1)
+    #  -- src/modadvection.f90:400, zero under a closed lid -- and ibmnorm's `solid` averages it into a solid cell of level ke,
+    #  src/modibm.f90:796-800: a block that touches an open lid with a kappa scalar is the one combination not reproduced)
+    #  With the temperature instead, so that the c grid's lists are read at all: src/modibm.f90:181.)
+    "run_ptop_ibm_16x12x10": ("run", 86, 16, 12, 10, dict(sgs="vreman", nsv=0, floor=True, bctopm=3, randu=0.05, ibm=IBM_BLOCKS["run_ptop_ibm_16x12x10"],
+                                                          physics="ltempeq = .true.\nlbuoyancy = .true.",
+                                                          bc="BCtopT = 1\nwttop = 0.\nBCbotT = 1\nwtsurf = 0.02\nthls = 288.0",
+                                                          oracle="nsub = 9\ndump_at = 3, 9"), 1.04),
+})
 # immersed boundary with temperature (buoyant), a kappa-advected scalar, and moisture: ibmnorm's `solid`
 # on thl with the volume-mean value, advecc2nd_corr (liberal, and conservative with lconservativeibm), diffc_corr on thl / qt,
 # the masked slab averages of thermodynamics (IIw for thvh).  Adiabatic, impermeable walls (iwalltemp = iwallmoist = 1 with
@@ -659,7 +680,7 @@ THL_CASES = {"k_tke_moist_12x8x8": dict(dthl=0.25, qt=0.0118, dqt=-8e-5, tke=0.0
              "k_qt_12x8x6": dict(dthl=0.3, qt=0.008, dqt=-4e-4), "run_qt_16x8x12s": dict(dthl=0.25, qt=0.007, dqt=-2e-4),
              "k_lsf_12x8x24": dict(dthl=0.3, ug=1.05, wtop=0.02), "run_lsf_16x8x24s": dict(dthl=0.25, ug=0.95, wtop=-0.03), "k_tke_12x8x6": dict(tke=0.05), "k_tke_thl_12x8x6": dict(tke=0.08, dthl=0.3), "k_coriol_12x8x6": dict(ug=1.1), "run_profforc_16x16x8": dict(ug=1.3), "k_thl_12x8x6": dict(dthl=0.4, dthlrad=2e-3), "run_thl_16x8x12s": dict(dthl=0.25, dthlrad=-1e-3),
              "k_buoy_12x8x6": dict(dthl=0.3), "run_buoy_16x8x12s": dict(dthl=0.2),
-             "k_ibm_thl_16x12x10": dict(dthl=0.3), "run_ibm_thl_16x12x10": dict(dthl=0.25), "run_ibm_thlcons_16x12x10": dict(dthl=0.25),
+             "k_ibm_thl_16x12x10": dict(dthl=0.3), "run_ibm_thl_16x12x10": dict(dthl=0.25), "run_ptop_ibm_16x12x10": dict(dthl=0.25), "run_ibm_thlcons_16x12x10": dict(dthl=0.25),
              "run_ibm_qt_16x12x10": dict(dthl=0.25, qt=0.007, dqt=-2e-4),
              "run_stats_16x8x12s": dict(dthl=0.25), "run_stats_ibm_16x12x10": dict(dthl=0.25), "run_ytstats_ibm_16x12x10": dict(dthl=0.25),
              "k_ibm_wf2_16x12x10": dict(dthl=0.3), "run_ibm_wf2_16x12x10": dict(dthl=0.25),
@@ -877,6 +898,17 @@ def make_reference_test_cases():
         with open(fn, "rb") as f, gzip.GzipFile(os.path.join(cdir, os.path.basename(fn) + ".gz"), "wb", mtime=0) as g:
             g.write(f.read())
     print(f"case_100: {len(files)} input files staged")
+    # tests/cases/526: the other half of the reference's processor_boundaries test -- trees (vegetation.f90) over a flat floor as an
+    # immersed boundary, temperature + moisture + buoyancy, the open lid (BCtopm = 3), treedump -- with the test driver's deck
+    # namoptions.526.serial.  (The STLs are pre-processing inputs the solver never opens.)
+    cdir = os.path.join(HERE, "cases", "case_526")
+    os.makedirs(cdir, exist_ok=True)
+    files = [os.path.join(src, "cases", "526", fn) for fn in sorted(os.listdir(os.path.join(src, "cases", "526"))) if not fn.endswith(".stl")]
+    files += [os.path.join(src, "integration", "processor_boundaries", "namoptions.526.serial")]
+    for fn in files:
+        with open(fn, "rb") as f, gzip.GzipFile(os.path.join(cdir, os.path.basename(fn) + ".gz"), "wb", mtime=0) as g:
+            g.write(f.read())
+    print(f"case_526: {len(files)} input files staged")
 
 
 def main():
@@ -920,7 +952,7 @@ def main():
         print(f"{name}: {len(keep)} records, {os.path.getsize(tmpf + '.gz') / 1024:.0f} kB")
     make_restart_cases()
     make_example_cases(only)
-    if not only or "case_100" in only:
+    if not only or "case_100" in only or "case_526" in only:
         make_reference_test_cases()
     for ex in FULL_EXAMPLES:
         if not only or f"full_example_{ex}" in only:

@@ -173,9 +173,16 @@ def test_each_routine_matches_reference(name, iexp):
     assert relerr(nocorner(pres[1:-1]), nocorner(marr(fix, "poi.pres0", nz)[1:-1]), pscale) <= KERNEL_TOL
     for k in ("up", "vp", "wp"):
         assert relerr(interior(core.download(k)), interior(marr(fix, "poi." + k, nz))) <= KERNEL_TOL, k
+    lid = int(d.get("BC", "BCtopm")) == 3
+    if lid:       # the open lid: bcpup's + tderive's row wp(ke+1) (src/modboundary.f90:1234-1243, src/modpois.f90:1058-1069)
+        ref = marr(fix, "poi.wp", nz)
+        assert relerr(core.download("wp")[nz + 1, 1:-1, 1:-1], ref[nz + 1, 1:-1, 1:-1], np.abs(ref).max()) <= KERNEL_TOL
     core.tstep_integrate()
     core.halos()
     core.boundary()
+    if lid:       # ... and tstep_integrate's plane w0(ke+1), which `boundary` leaves alone (src/modtstep.f90:270-286, src/modboundary.f90:191-200)
+        ref = marr(fix, "out.w0", nz)
+        assert relerr(nocorner(core.download("w0"))[nz + 1], nocorner(ref)[nz + 1], np.abs(ref).max()) <= KERNEL_TOL
     for k in ("u0", "v0", "w0", "um", "pres0") + (("thl0", "thlm") if thl else ()) + (("qt0", "qtm") if qt else ()):
         ref = marr(fix, "out." + k, nz)
         sc = pscale if k == "pres0" else (1.0 if k.startswith("thl") else None)
@@ -229,6 +236,11 @@ def test_substeps_match_reference(name, iexp, fused):
                 ref = marr(fix, f"{tag}.{k}", g.nz)
                 sc = 1.0 if k == "thl0" else None        # temperature differences are O(1) K on a 288 K mean
                 assert relerr(nocorner(core.download(k)[1:-1]), nocorner(ref[1:-1]), sc) <= RUN_TOL, (tag, k)
+            if int(d.get("BC", "BCtopm")) == 3:      # the open lid's prognostic plane w0(ke+1), ghost rows included
+                ref = marr(fix, f"{tag}.w0", g.nz)
+                assert relerr(nocorner(core.download("w0"))[g.nz + 1], nocorner(ref)[g.nz + 1], np.abs(ref).max()) <= RUN_TOL, (tag, "w0(ke+1)")
+                if name == "run_ptop_ibm_16x12x10":   # (a block reaches the lid: the masked slab mean of the pressure is not zero there)
+                    assert np.abs(ref[g.nz + 1]).max() > 1e-5
             for n in range(nsv):
                 got = core.download(L.scalar_field(L.SV0, n), halo=2)
                 ref = carr(fix, f"{tag}.sv0_{n + 1:02d}", g.nz)

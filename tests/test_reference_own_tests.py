@@ -38,19 +38,19 @@ BINDIR = os.path.join(ROOT, "u-dales_amd", "bin")
 DROPIN = os.path.join(BINDIR, "udales_full_dropin")
 DROPIN_MPI_TEST = os.path.join(BINDIR, "udales_full_dropin_mpi_test")
 MPIEXEC = "/opt/conda/bin/mpiexec"
-CASE = os.path.join(GOLDEN, "cases", "case_100")
 TOL = 1.0e-9            # ABS_TOL of test_processor_boundaries.py:28 and of src/tests.f90:389
 
 
-def stage(tmp, deck, nprocy=1, steps=None, nprocx=1):
-    """tests/cases/100 + one of the test drivers' decks as namoptions.100 (what run_test.sh / _copy_namelist do)."""
+def stage(tmp, deck, nprocy=1, steps=None, nprocx=1, case=100):
+    """tests/cases/100 (or 526) + one of the test drivers' decks as namoptions.100 (what run_test.sh / _copy_namelist do)."""
     os.makedirs(tmp, exist_ok=True)
-    for fn in os.listdir(CASE):
+    cdir = os.path.join(GOLDEN, "cases", f"case_{case}")
+    for fn in os.listdir(cdir):
         if fn.startswith("namoptions"):
             continue
-        with gzip.open(os.path.join(CASE, fn), "rb") as f, open(os.path.join(tmp, fn[:-3]), "wb") as o:
+        with gzip.open(os.path.join(cdir, fn), "rb") as f, open(os.path.join(tmp, fn[:-3]), "wb") as o:
             o.write(f.read())
-    with gzip.open(os.path.join(CASE, deck + ".gz"), "rt") as f:
+    with gzip.open(os.path.join(cdir, deck + ".gz"), "rt") as f:
         txt = f.read()
     txt = re.sub(r"nprocy\s*=\s*\d+", f"nprocy       = {nprocy}", txt)
     assert re.search(r"nprocx\s*=\s*1\b", txt)
@@ -61,12 +61,12 @@ def stage(tmp, deck, nprocy=1, steps=None, nprocx=1):
         # (half a step early: the dump clock is a running sum of dt, which may fall a rounding short of the product dtmax * steps)
         txt = re.sub(r"tstatsdump\s*=\s*[0-9.eE+-]+", f"tstatsdump   = {dtmax * (steps - 0.5)!r}", txt)
         txt = re.sub(r"tsample\s*=\s*[0-9.eE+-]+", f"tsample      = {dtmax!r}", txt)
-    with open(os.path.join(tmp, "namoptions.100"), "w") as f:
+    with open(os.path.join(tmp, f"namoptions.{case}"), "w") as f:
         f.write(txt)
 
 
-def run(tmp, exe, nranks=1, env=None, timeout=1500):
-    cmd = f"{exe} namoptions.100" if nranks == 1 and "mpi" not in os.path.basename(exe) else f"{MPIEXEC} -n {nranks} {exe} namoptions.100"
+def run(tmp, exe, nranks=1, env=None, timeout=1500, case=100):
+    cmd = f"{exe} namoptions.{case}" if nranks == 1 and "mpi" not in os.path.basename(exe) else f"{MPIEXEC} -n {nranks} {exe} namoptions.{case}"
     r = subprocess.run(f"ulimit -s unlimited; exec {cmd}", shell=True, cwd=tmp, env=env, capture_output=True, text=True, timeout=timeout,
                        executable="/bin/bash")
     return r
@@ -190,13 +190,13 @@ def test_masked_averages_of_the_device_pass_the_operator_test():
 
 # ---- 2. processor boundaries, case 100 ------------------------------------------------------------------------------------------
 
-def tdump_fields(tmp, nranks):
+def tdump_fields(tmp, nranks, case=100, prefix="tdump", want=("ut", "vt", "wt")):
     """ut, vt, wt of tdump.000.RRR.100.nc stitched over the ranks' rows -> {name: [k, j, i]} (the reference's _load_global_fields)."""
     parts = []
     for r in range(nranks):
-        rec = read_ncrec(os.path.join(tmp, f"tdump.000.{r:03d}.100.nc"), want=("ut", "vt", "wt"))
+        rec = read_ncrec(os.path.join(tmp, f"{prefix}.000.{r:03d}.{case}.nc"), want=want)
         parts.append({k: np.squeeze(np.asarray(v[-1][1], dtype=float)) for k, v in rec.items()})
-    return {k: np.concatenate([p[k] for p in parts], axis=1) for k in ("ut", "vt", "wt")}
+    return {k: np.concatenate([p[k] for p in parts], axis=1) for k in want}
 
 
 @pytest.mark.gpu
@@ -259,3 +259,61 @@ def test_processor_boundaries_case_100(steps, tmp_path):
     bad = {k: v for k, v in worst.items() if not v <= TOL}
     assert not bad, bad
     assert len(worst) >= 3
+
+
+# ---- 2b. processor boundaries, case 526: trees, temperature + moisture, the open lid --------------------------------------------
+DROPIN_HS = os.path.join(BINDIR, "udales_full_dropin_hoststats")
+DROPIN_HS_MPI_TEST = os.path.join(BINDIR, "udales_full_dropin_hoststats_mpi_test")
+
+
+@pytest.mark.gpu
+def test_processor_boundaries_case_526(tmp_path):
+    """The other half of test_processor_boundaries.py (:43-50, TREE_CASE_ID): tests/cases/526 -- trees (the reference's vegetation.f90,
+    untouched, on the host: the drop-ins fall back to the strict residency for it) over a floor that is an immersed boundary with
+    facet wall functions, temperature + moisture + buoyancy, the adaptive time step and BCtopm = 3, the lid open to the pressure
+    gradient (bcpup / tderive / tstep_integrate's row w(ke+1): k_lid_*, udc_pois.hip) -- one step of namoptions.526.serial; `tr_u,
+    tr_v, tr_w` of treedump (the reference's own modstatsdump linked: the device statistics do not take the tree dump over) and
+    `ut, vt, wt` of tdump, serial and split over 2 / 4 ranks in y and as 2 x 1 / 2 x 2 decks, against the ALL-REFERENCE executable:
+    <= 1e-9 everywhere (the reference's ABS_TOL on its support masks and processor-boundary bands)."""
+    if not (os.path.exists(FULL) and os.path.exists(DROPIN_HS)):
+        pytest.skip("oracle/_ref/udales_full or u-dales_amd/bin/udales_full_dropin_hoststats not built")
+    want_tr, want_t = ("tr_u", "tr_v", "tr_w"), ("ut", "vt", "wt")
+
+    def fields(d, P):
+        out = tdump_fields(d, P, 526, "treedump", want_tr)
+        out.update(tdump_fields(d, P, 526, "tdump", want_t))
+        return out
+    out = {}
+    stage(tmp_path / "ref", "namoptions.526.serial", case=526)
+    r = run(tmp_path / "ref", FULL, case=526)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    out["reference, serial"] = fields(tmp_path / "ref", 1)
+    stage(tmp_path / "dev1", "namoptions.526.serial", case=526)
+    r = run(tmp_path / "dev1", DROPIN_HS, env=dict(os.environ, UDC_RESIDENCY="2"), case=526)      # (asks for 2, gets 0: the trees)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "UDC_RESIDENCY=0" in r.stdout
+    out["device, serial"] = fields(tmp_path / "dev1", 1)
+    if os.path.exists(MPIEXEC) and os.path.exists(DROPIN_HS_MPI_TEST) and gpu_count() < 2:
+        for px, py in ((1, 2), (1, 4), (2, 1), (2, 2)):
+            P = px * py
+            _, env, how = mpi_transport(P, f"c526x{px}{py}")
+            d = tmp_path / f"dev{px}x{py}"
+            stage(d, "namoptions.526.serial", nprocy=py, nprocx=px, case=526)
+            r = run(d, DROPIN_HS_MPI_TEST, P, env=env, case=526)
+            assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+            out[f"device, deck {px} x {py} ({how})"] = fields(d, P)
+    ref = out["reference, serial"]
+    assert ref["tr_u"].shape == (64, 64, 128) and np.abs(ref["tr_u"]).max() > 0.1      # (the drag of the trees: O(0.5) m/s^2)
+    worst = {}
+    for label, cand in out.items():
+        if label == "reference, serial":
+            continue
+        for k in want_tr + want_t:
+            worst[(label, k)] = float(np.abs(cand[k] - ref[k]).max())
+    if os.environ.get("UDC_TEST_KEEP_LOGS"):
+        with open(os.path.join(os.environ["UDC_TEST_KEEP_LOGS"], "processor_boundaries_case526.txt"), "w") as f:
+            f.write("max |candidate - all-reference serial run| of treedump's tr_u, tr_v, tr_w and tdump's ut, vt, wt after one step of namoptions.526.serial (tolerance 1e-9)\n")
+            for (label, k), v in worst.items():
+                f.write(f"{label:36s} {k}: {v:.3e}\n")
+    bad = {k: v for k, v in worst.items() if not v <= TOL}
+    assert not bad, bad

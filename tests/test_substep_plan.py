@@ -17,7 +17,7 @@ LIB = os.path.join(ROOT, "u-dales_amd", "lib", "libudcplan.so")
 
 IN = ["no_fold", "no_alias", "ek_always", "halo_overlap", "mom_pipe", "div_in_fft", "ptotal",
       "slab", "comm_stream", "sgs", "lbuoycorr", "nslots", "ibm_on", "stats_any", "fft_fused", "own_fwd", "tend_plane", "between",
-      "closure_tile_rows", "mom_tile_rows", "int_tile_rows", "x_row_groups", "levels_per_chunk", "rk3step", "um_alias", "ibm_edits_now"]
+      "closure_tile_rows", "mom_tile_rows", "int_tile_rows", "x_row_groups", "levels_per_chunk", "open_lid", "rk3step", "um_alias", "ibm_edits_now"]
 OUT = ["lds", "pup", "fold", "alias_ok", "materialise_um", "rotate", "skip_um", "closure", "need_ekh", "mom_pipe", "div_in_fft",
        "vp_row", "p_row", "integrate", "ptotal"]
 FOLDED, OVERLAPPED, PLAIN = 0, 1, 2
@@ -47,7 +47,7 @@ def table(i):
     lds = np.ones_like(i["slab"], dtype=bool)
     pup = lds
     fold = lds & ~b(i["slab"]) & ~b(i["no_fold"])
-    alias_ok = pup & ~b(i["no_alias"]) & ~b(i["ibm_on"])
+    alias_ok = pup & ~b(i["no_alias"]) & ~b(i["ibm_on"]) & ~b(i["open_lid"])
     mat = b(i["um_alias"]) & ~(alias_ok & (i["rk3step"] == 1))
     rotate = b(i["um_alias"]) & ~mat
     skip = alias_ok & (i["rk3step"] == 3)
@@ -58,14 +58,14 @@ def table(i):
     closure = np.where(c_folded, FOLDED, np.where(c_over, OVERLAPPED, PLAIN))
     need_ekh = np.where(c_folded | c_over, b(i["ek_always"]) | (i["rk3step"] == 3) | (i["nslots"] > 0) | b(i["stats_any"]), True)
     pipe = (b(i["slab"]) & lds & pup & b(i["mom_pipe"]) & b(i["fft_fused"]) & b(i["div_in_fft"]) & beside(i["mom_tile_rows"])
-            & (i["nslots"] == 0) & (i["sgs"] != 3) & ~b(i["between"]) & (i["x_row_groups"] >= 2) & (i["levels_per_chunk"] >= 4))
-    div = pup & ((b(i["slab"]) & b(i["fft_fused"]) & b(i["div_in_fft"])) | (~b(i["slab"]) & b(i["own_fwd"])))
+            & (i["nslots"] == 0) & (i["sgs"] != 3) & ~b(i["between"]) & (i["x_row_groups"] >= 2) & (i["levels_per_chunk"] >= 4) & ~b(i["open_lid"]))
+    div = pup & ~b(i["open_lid"]) & ((b(i["slab"]) & b(i["fft_fused"]) & b(i["div_in_fft"])) | (~b(i["slab"]) & b(i["own_fwd"])))
     needs_row = ~fold | (b(i["ibm_on"]) & b(i["ibm_edits_now"]))
     vp = np.where(pipe, ROW_PIPED, np.where(needs_row, np.where(div & beside(np.full_like(i["sgs"], 3)) & (i["x_row_groups"] >= 2), ROW_BESIDE, ROW_INLINE),
                                             ROW_FOLDED))
     prow = np.where(fold, ROW_FOLDED, np.where(beside(i["int_tile_rows"]) & (i["int_tile_rows"] >= 4), ROW_BESIDE, ROW_INLINE))
     integ = np.where(~fold & beside(i["int_tile_rows"]), INT_EDGES_FIRST, INT_ONE)
-    ptot = b(i["ptotal"]) & pup & ~b(i["tend_plane"])
+    ptot = b(i["ptotal"]) & pup & ~b(i["tend_plane"]) & ~b(i["open_lid"])
     return dict(lds=lds, pup=pup, fold=fold, alias_ok=alias_ok, materialise_um=mat, rotate=rotate, skip_um=skip, closure=closure,
                 need_ekh=need_ekh, mom_pipe=pipe, div_in_fft=div, vp_row=vp, p_row=prow, integrate=integ, ptotal=ptot)
 
@@ -73,7 +73,7 @@ def table(i):
 def lattice():
     """every configuration / call for one setting of the eight switches"""
     axes = dict(slab=[0, 1], sgs=[0, 1, 2, 3], lbuoycorr=[0, 1], nslots=[0, 2], ibm_on=[0, 1], stats_any=[0, 1], fft_fused=[0, 1],
-                own_fwd=[0, 1], tend_plane=[0, 1], between=[0, 1], rows=[2, 3, 8], x_row_groups=[1, 4], levels_per_chunk=[2, 16], rk3step=[1, 2, 3],
+                own_fwd=[0, 1], tend_plane=[0, 1], between=[0, 1], rows=[2, 3, 8], x_row_groups=[1, 4], levels_per_chunk=[2, 16], open_lid=[0, 1], rk3step=[1, 2, 3],
                 um_alias=[0, 1], ibm_edits_now=[0, 1])
     grids = np.meshgrid(*[np.array(v, dtype=np.int32) for v in axes.values()], indexing="ij")
     cols = {k: g.ravel() for k, g in zip(axes, grids)}
@@ -123,6 +123,11 @@ def test_every_combination_matches_the_table_and_is_safe():
         # correction, volume flow over the fluid cells of an immersed boundary), only over the predicted-velocity form
         pt = g["ptotal"] == 1
         assert not (pt & ((i["tend_plane"] == 1) | (g["pup"] == 0))).any()
+        # the open lid (BCtopm = 3): its rows of bcpup / tderive / tstep_integrate are plane kernels that read and write wm(ke+1), wp(ke+1) under
+        # their own names in the reference's form, and only div_rhs_kernel reads pwp(ke+1): no aliasing, no pressure-total form, no
+        # divergence inside a transform (hence no pipelined sweep)
+        lid = i["open_lid"] == 1
+        assert not (lid & (pt | (g["div_in_fft"] == 1) | (g["mom_pipe"] == 1) | (g["skip_um"] == 1) | (g["rotate"] == 1))).any()
         total += n
     assert total == 128 * n and n > 100000
 
@@ -131,7 +136,7 @@ def test_named_configurations():
     """The rows of DESIGN.md section 7's table for the BASELINE configurations, with the library's defaults."""
     L = lib()
     dflt = dict(no_fold=0, no_alias=0, ek_always=0, halo_overlap=1, mom_pipe=1, div_in_fft=1, ptotal=1, tend_plane=0, lbuoycorr=0, stats_any=0,
-                ibm_edits_now=0, um_alias=0)
+                ibm_edits_now=0, um_alias=0, open_lid=0)
 
     def one(**kw):
         i = dict(dflt, **kw)

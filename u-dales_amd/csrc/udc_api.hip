@@ -228,6 +228,7 @@ static int create_on_device(const udc_config *cfg, udc_handle *h) {
   }
   h->zsize = 0.;
   for (int k = 1; k <= g.nz; ++k) h->zsize += dzf[k];      // zh(ke+1), src/modglobal.f90:747-750
+  h->dzhi_top = dzhi[g.nz + 1];                             // dzhi(ke+1): the open lid's rows (k_lid_*)
   double *mlen = &hm[11 * nk];
   // delta(i,k) = (dxf(i)*dy*dzf(k))**(1/3), src/modglobal.f90:793-797 (uniform x)
   for (int k = 0; k < nk; ++k) mlen[k] = cfg->csz * pow(cfg->dx * cfg->dy * dzf[k], 1. / 3.);
@@ -648,7 +649,10 @@ extern "C" int udc_set_moist_thermo(udc_handle *h, double thls, double qts, doub
   if ((int)h->fields.size() <= UDC_THL0 || !h->fields[UDC_THL0]) { udc_set_error("udc_set_moist_thermo: call udc_set_tempeq first"); return 1; }
   if (n != nz + 1) { udc_set_error("udc_set_moist_thermo: expected %d levels (zf, zh of kb..ke+kh)", nz + 1); return 1; }
   if (nz + 2 > 2000) { udc_set_error("udc_set_moist_thermo: ktot <= 1998 (diagfld keeps four level tables in LDS)"); return 1; }
-  if (!(thls > 0.) || !(ps > 0.) || qts < 0.) { udc_set_error("udc_set_moist_thermo: thls and ps must be positive, qts >= 0"); return 1; }
+  // (the reference checks nothing here and its own test deck tests/cases/526 runs with the defaults thls = qts = -1, src/modsurfdata.f90:61-64:
+  //  diagfld's exner functions and calc_halflev's floor values then follow from those numbers as they are -- so do the kernels;
+  //  refused is only what the formulas cannot take: 1 / thls, log(ps))
+  if (thls == 0. || !(ps > 0.)) { udc_set_error("udc_set_moist_thermo: thls must not be zero, ps must be positive"); return 1; }
   std::vector<double> t((size_t)udc_handle::MT_N * n2, 0.0);
   for (int k = 1; k <= nz + 1; ++k) { t[udc_handle::MT_ZF * n2 + k] = zf[k - 1]; t[udc_handle::MT_ZH * n2 + k] = zh[k - 1]; }
   if (!h->mt) HIP_OK(hipMalloc(&h->mt, sizeof(double) * t.size()));
@@ -896,11 +900,14 @@ static int now_poisson(udc_handle *h, int rk3step, double dt) {
   // (ibmnorm edits vm at the listed points after `halos` has run)
   const int fvp[2] = {UDC_VP, UDC_VM};
   if (k_halo_y(h, fvp, h->ibm_on ? 2 : 1, 1)) return 1;
+  const bool lid = h->p.bctopm == UDC_TOP_PRESSURE;
+  if (lid && k_lid_bcpup(h, rk3coef, false)) return 1;     // bcpup's open-lid rows, src/modboundary.f90:1234-1243
   if (k_divergence_rhs(h, rk3coef, false)) return 1;       // fillps
   if (k_poisson_solve(h)) return 1;
   const int fp[1] = {UDC_P};
   if (k_halo_y(h, fp, 1, 1)) return 1;              // bcp
   if (k_project(h)) return 1;                       // tderive
+  if (lid && k_lid_tderive(h)) return 1;            // src/modpois.f90:1058-1069
   const int fpr[1] = {UDC_PRES0};
   if (k_halo_y(h, fpr, 1, 1)) return 1;
   return 0;
@@ -912,6 +919,7 @@ static int now_tstep_integrate(udc_handle *h, int rk3step, double dt) {
   if (k_scalar_bcx_uout(h)) return 1;
   h->halos_fresh = h->boundary_fresh = h->thermo_fresh = false;
   h->dthv_top_on = false;      // new fields: the next dthvdz is the one of the thermodynamics call that follows `boundary`
+  if (h->p.bctopm == UDC_TOP_PRESSURE && k_lid_integrate(h, rk3step, dt, false, true, false)) return 1;   // src/modtstep.f90:270-286
   if (k_integrate(h, rk3step, dt)) return 1;
   if (rk3step == 3 && k_chem(h, dt)) return 1;      // src/modtstep.f90:236-238
   return 0;
@@ -1033,6 +1041,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   pin.x_row_groups = (h->slab && h->fft_fused) ? fft_x_row_groups(h) : 0;
   pin.levels_per_chunk = h->g.nz / (h->nch > 0 ? h->nch : 1);
   pin.rk3step = rk3step; pin.um_alias = h->um_alias; pin.ibm_edits_now = (ops & (OP_IBMWALL | OP_IBMNORM)) != 0;
+  pin.open_lid = h->p.bctopm == UDC_TOP_PRESSURE;
   const Plan plan = plan_substep(pin);
   h->last_plan = plan; h->have_plan = true;
   h->ptotal_now = plan.ptotal != 0;
@@ -1141,6 +1150,9 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
     const int fvp[1] = {UDC_VP};
     if (k_halo_y(h, fvp, 1, 1, HALO_TO_PREV)) return 1;
   }      // (ROW_PIPED: already travelling; ROW_FOLDED: written by the kernels above)
+  // open lid (BCtopm = 3): bcpup's row pwp(ke+1) from the slab mean of pres0(ke), before the divergence that reads it
+  const bool lid = pin.open_lid != 0;
+  if (lid && k_lid_bcpup(h, rk3coef, pup)) return 1;
   if (!h->div_in_fft && k_divergence_rhs(h, rk3coef, pup)) return 1;
   if (k_poisson_solve(h)) return 1;
   h->div_in_fft = false;
@@ -1159,6 +1171,9 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
     else if (k_halo_y(h, fp, 1, 1, pdirs)) return 1;
   }
   const bool skip_um = plan.skip_um;
+  // open lid: tderive's and tstep_integrate's row w(ke+1), ahead of the sweep (it reads the solve's output and the row bcpup left;
+  // the exchange of the new velocities' rows below then carries its plane like any other)
+  if (lid && (k_lid_tderive(h) || k_lid_integrate(h, rk3step, dt, pup, false, fold))) return 1;
   // y-slabs: the rows next to the neighbouring ranks first; the ghost rows of the new velocities and of pres0 travel while the rows
   // in between are integrated (the exchange names the arrays as they will be known after the pointer rotation below)
   const bool ov_int = plan.integrate == INT_EDGES_FIRST;

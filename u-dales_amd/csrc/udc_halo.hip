@@ -76,7 +76,7 @@ __global__ void top_bottom_kernel(Geo g, Params pr, BoundaryArgs a, int uv_only)
   if (uv_only) return;
   const long bot = g.idx(i, j, 0);
   a.wm[bot] = 0.; a.w0[bot] = 0.;
-  a.w0[ghost] = 0.; a.wm[ghost] = 0.;
+  if (pr.bctopm != UDC_TOP_PRESSURE) { a.w0[ghost] = 0.; a.wm[ghost] = 0.; }      // (open lid: "w considered in modpois", :191-200)
   for (int s = 0; s < a.nscal; ++s) {
     double *c = a.sv[s];
     if (a.kind[s] == 1) continue;                     // non-zero flux: top_flux_kernel (needs ekh)

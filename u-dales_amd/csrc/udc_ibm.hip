@@ -233,15 +233,15 @@ __global__ void ibm_advecc_corr_kernel(Geo g, Metrics m, int n, const int *__res
 // masked slab sums (avexy_ibm, src/modmpi.f90:623-664): the sum over the fluid cells of a level is the sum over all
 // cells minus the sum over the listed solid points.  One workgroup per (level, field); deterministic tree reduction.
 __global__ __launch_bounds__(256) void ibm_levelsum_kernel(Geo g, const int *__restrict__ pts, const int *__restrict__ off,
-                                                           const double *__restrict__ f, double *__restrict__ S) {
+                                                           const double *__restrict__ f, double *__restrict__ S, int k0) {
   __shared__ double sw[4];
-  const int k = blockIdx.x;
+  const int k = k0 + blockIdx.x;
   double v = 0.;
   for (int q = off[k] + threadIdx.x; q < off[k + 1]; q += 256) v += f[g.idx(pts[3 * q], pts[3 * q + 1], pts[3 * q + 2])];
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = v;
   __syncthreads();
-  if (threadIdx.x == 0) S[k] = S[k] - ((sw[0] + sw[1]) + (sw[2] + sw[3]));
+  if (threadIdx.x == 0) S[blockIdx.x] = S[blockIdx.x] - ((sw[0] + sw[1]) + (sw[2] + sw[3]));
 }
 // the same with a per-level weight, summed over all levels (masscorr's volume averages): one workgroup
 __global__ __launch_bounds__(1024) void ibm_flowsum_kernel(Geo g, int n, const int *__restrict__ pts, const double *__restrict__ a,
@@ -277,21 +277,27 @@ extern "C" int udc_set_ibm_points(udc_handle *h, int grid, const int *solid, int
   if (!h) { udc_set_error("null handle"); return 1; }
   if (grid < 0 || grid > 3) { udc_set_error("udc_set_ibm_points: grid 0 (u), 1 (v), 2 (w) or 3 (c)"); return 1; }
   if (nsolid < 0 || nbound < 0 || (nsolid && !solid) || (nbound && !bound)) { udc_set_error("udc_set_ibm_points: bad list"); return 1; }
+  // A point whose (i, j) lies outside the domain belongs to no rank: the reference's reader keeps the points of its own pencil and
+  // drops the rest without a word (read_sparse_ijk, src/readinput.f90:90-100 -- the lists of its own tests/cases/526 cover 256 x 128
+  // columns of a 128 x 64 domain).  Same here; a level outside kb..ke is an error (the reference would index out of bounds).
   const int ext[3] = {h->g.nx, h->jtot, h->g.nz};
+  udc_handle::IbmGrid &G = h->ibm[grid];
+  G.solid_g.clear(); G.bound_g.clear();
   for (int pass = 0; pass < 2; ++pass) {
     const int *p = pass ? bound : solid;
     const int n = pass ? nbound : nsolid;
-    for (int q = 0; q < n; ++q)
-      for (int d = 0; d < 3; ++d)
-        if (p[3 * q + d] < 1 || p[3 * q + d] > ext[d]) {
-          udc_set_error("udc_set_ibm_points: %s point %d of grid %d outside the domain (%d %d %d)", pass ? "boundary" : "solid", q + 1,
-                        grid, p[3 * q], p[3 * q + 1], p[3 * q + 2]);
-          return 1;
-        }
+    std::vector<int> &dst = pass ? G.bound_g : G.solid_g;
+    dst.reserve((size_t)3 * n);
+    for (int q = 0; q < n; ++q) {
+      if (p[3 * q + 2] < 1 || p[3 * q + 2] > ext[2]) {
+        udc_set_error("udc_set_ibm_points: %s point %d of grid %d outside the levels of the domain (%d %d %d)", pass ? "boundary" : "solid", q + 1,
+                      grid, p[3 * q], p[3 * q + 1], p[3 * q + 2]);
+        return 1;
+      }
+      if (p[3 * q] < 1 || p[3 * q] > ext[0] || p[3 * q + 1] < 1 || p[3 * q + 1] > ext[1]) continue;
+      dst.insert(dst.end(), p + 3 * q, p + 3 * q + 3);
+    }
   }
-  udc_handle::IbmGrid &G = h->ibm[grid];
-  G.solid_g.assign(solid, solid + (size_t)3 * nsolid);
-  G.bound_g.assign(bound, bound + (size_t)3 * nbound);
   G.given = true;
   h->ibm_on = false;      // until udc_ibm_commit
   return 0;
@@ -462,13 +468,13 @@ int ibm_grid_of_field(int field) {
   return 3;
 }
 
-int k_ibm_levelsum_correct(udc_handle *h, const int *fields, int nf, int n, double *S) {
+int k_ibm_levelsum_correct(udc_handle *h, const int *fields, int nf, int n, double *S, int k0) {
   if (!h->ibm_on) return 0;
   for (int q = 0; q < nf; ++q) {
     const udc_handle::IbmGrid &G = h->ibm[ibm_grid_of_field(fields[q])];
     if (!G.nsolid) continue;
     hipLaunchKernelGGL(ibm_levelsum_kernel, dim3((unsigned)n), dim3(256), 0, h->stream, h->g, G.lev_pts, G.lev_off,
-                       (const double *)h->fields[fields[q]], S + (size_t)q * n);
+                       (const double *)h->fields[fields[q]], S + (size_t)q * n, k0);
   }
   HIP_OK(hipGetLastError());
   return 0;

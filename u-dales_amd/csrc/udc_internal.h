@@ -265,6 +265,7 @@ struct udc_handle {
   double uvol_rate = 0., uout_rate = 0.;
   double *outlet_w = nullptr;             // luoutflowr: dy dzf(k) / outlet area, [nz+2] indexed by the reference's k
   double uflowrate = 0., vflowrate = 0., zsize = 0.;
+  double dzhi_top = 0.;      // dzhi(ke+1)
   bool um_alias = false;                // um,vm,wm are logically equal to u0,v0,w0 (after RK stage 3 of a fused
                                         // substep); the UM buffers are stale until stage 1 rotates the pointers
   bool no_alias = false;                // UDC_NO_ALIAS=1: always copy (A/B switch)
@@ -442,7 +443,7 @@ int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, 
 int momentum_lds_tile_rows(const Geo &g);
 int momentum_lds_tile_height();
 int k_momentum_pipe_stage(udc_handle *h, int c);      // the sweep's level range that feeds k-chunk c of the slab solve (udc_api.hip)  // rk3coefi != 0: PUP mode   // LDS-staged k-marching version (default)
-int k_level_sums_dev(udc_handle *h, int field, int n);      // udc_thermo.hip: masked, all-reduced level sums left on the device
+int k_level_sums_dev(udc_handle *h, int field, int n, int k0 = 0);      // udc_thermo.hip: masked, all-reduced sums of levels k0 .. k0 + n - 1 left on the device
 int k_scalar_adv(udc_handle *h, int n);
 int k_scalar_bcx_outlet(udc_handle *h);
 int k_scalar_bcx_uout(udc_handle *h);
@@ -458,6 +459,11 @@ int k_bottom(udc_handle *h, bool wrap_vp, int jbeg = 0, int jend = -1);      // 
 int k_divergence_rhs(udc_handle *h, double rk3coef, bool pup);
 int k_poisson_solve(udc_handle *h);
 int k_project(udc_handle *h);                       // tderive: up,vp,wp -= grad p ; pres0 += p
+// the open lid (BCtopm = 3): bcpup's, tderive's and tstep_integrate's row w(ke+1) (src/modboundary.f90:1234-1243, src/modpois.f90:1058-1069,
+// src/modtstep.f90:270-286); pup: the tendency arrays hold the predicted velocity; wrap: periodic ghost rows written here
+int k_lid_bcpup(udc_handle *h, double rk3coef, bool pup);
+int k_lid_tderive(udc_handle *h);
+int k_lid_integrate(udc_handle *h, int rk3step, double dt, bool pup, bool zero, bool wrap);
 int k_integrate(udc_handle *h, int rk3step, double dt);
 int k_project_integrate(udc_handle *h, int rk3step, double dt, bool zero_tend, bool pup, bool ghosts,
                         bool write_um = true, bool out_to_um = false, int rows = 0, int r0 = 0, int r1 = 0, bool ptotal = false);   // fused tderive + tstep_integrate
@@ -493,7 +499,7 @@ int k_ibm_wallfun(udc_handle *h);                // diffu/v/w/c_corr at the flui
 int k_ibm_norm(udc_handle *h);
 int ibm_grid_of_field(int field);                // 0 u, 1 v, 2 w, 3 c: the mask a field's slab sums use (src/modthermodynamics.f90:271-301)
 // S[q n + k] -= sum of fields[q] over the solid points of device level k (q < nf, k < n); no-op without IBM
-int k_ibm_levelsum_correct(udc_handle *h, const int *fields, int nf, int n, double *S);
+int k_ibm_levelsum_correct(udc_handle *h, const int *fields, int nf, int n, double *S, int k0 = 0);      // (levels k0 .. k0 + n - 1)
 // S[0] -= sum a w(k), S[1] -= sum b w(k) over the solid points of `grid` (b may be null)
 int k_ibm_flowsum_correct(udc_handle *h, int grid, const double *a, const double *b, const double *wlev, double *S, int only_i = -1);                   // solid: velocities zeroed, scalars to the mean of their fluid neighbours
 void ibm_destroy(udc_handle *h);

@@ -23,6 +23,8 @@ struct PlanIn {
   int closure_tile_rows, mom_tile_rows, int_tile_rows;      // tile rows of the three sweeps on this slab
   int x_row_groups;     // row groups of the x forward transform
   int levels_per_chunk; // nz / k-chunks of the transposes
+  int open_lid;         // BCtopm = 3 (BCtopm_pressure): w(ke+1) is prognostic -- bcpup, tderive and tstep_integrate have a row there,
+                        // taken by three plane kernels beside the sweeps (k_lid_*, udc_pois.hip)
   // this call
   int rk3step;
   int um_alias;         // um, vm, wm are logically u0, v0, w0 (the previous substep was an aliased stage 3)
@@ -59,7 +61,8 @@ inline Plan plan_substep(const PlanIn &in) {
   // kernels that own the neighbouring cells
   p.fold = p.lds && !in.slab && !in.no_fold;
   // um aliasing: stage 3 leaves um unwritten (== u0); stage 1 reads u0 in its place (ibmnorm edits um: not with obstacles)
-  p.alias_ok = p.pup && !in.no_alias && !in.ibm_on;
+  // (open lid: wm(ke+1) is read and written by the lid's plane kernels under its own name)
+  p.alias_ok = p.pup && !in.no_alias && !in.ibm_on && !in.open_lid;
   p.materialise_um = in.um_alias && !(p.alias_ok && in.rk3step == 1);
   p.rotate = in.um_alias && !p.materialise_um;
   p.skip_um = p.alias_ok && in.rk3step == 3;
@@ -76,8 +79,9 @@ inline Plan plan_substep(const PlanIn &in) {
     p.need_ekh = 1;
   }
   p.mom_pipe = in.slab && p.lds && p.pup && in.mom_pipe && in.fft_fused && in.div_in_fft && plan_halo_overlap(in, in.mom_tile_rows) &&
-               in.nslots == 0 && in.sgs != 3 && !in.between && in.x_row_groups >= 2 && in.levels_per_chunk >= 4;
-  p.div_in_fft = p.pup && ((in.slab && in.fft_fused && in.div_in_fft) || (!in.slab && in.own_fwd));
+               in.nslots == 0 && in.sgs != 3 && !in.between && in.x_row_groups >= 2 && in.levels_per_chunk >= 4 && !in.open_lid;
+  // (open lid: the divergence of level ke reads pwp(ke+1); only div_rhs_kernel knows that plane)
+  p.div_in_fft = p.pup && !in.open_lid && ((in.slab && in.fft_fused && in.div_in_fft) || (!in.slab && in.own_fwd));
   if (p.mom_pipe) p.vp_row = ROW_PIPED;
   else if (!p.fold || (in.ibm_on && in.ibm_edits_now))
     p.vp_row = (p.div_in_fft && plan_halo_overlap(in, 3) && in.x_row_groups >= 2) ? ROW_BESIDE : ROW_INLINE;
@@ -95,6 +99,8 @@ inline Plan plan_substep(const PlanIn &in) {
   // the periodic volume (the outflow-rate mass correction; the volume flow over the fluid cells of an immersed boundary) the two
   // forms differ: not there.  On y-slabs p's ghost row then travels both ways (it is pres0's), and pres0 leaves the
   // exchange of the new velocities' rows.
-  p.ptotal = in.ptotal && p.pup && !in.tend_plane;
+  // Open lid: the lid's row of the right-hand side carries 2 <pres0>(ke) dzhi(ke+1), which is not the matrix' (closed) lid row applied
+  // to pres0: the reference's form there.
+  p.ptotal = in.ptotal && p.pup && !in.tend_plane && !in.open_lid;
   return p;
 }

@@ -33,23 +33,24 @@ template <bool PUP>
 __global__ __launch_bounds__(256) void div_rhs_kernel(Geo g, TileGrid tg, Metrics m, double r,
     const double *__restrict__ up, const double *__restrict__ vp, const double *__restrict__ wp,
     const double *__restrict__ um, const double *__restrict__ vm, const double *__restrict__ wm,
-    double *__restrict__ p) {
+    double *__restrict__ p, int lid) {
   int i, j, k;
   const bool inside_ = tile_decode(g, tg, i, j, k);
   if (!inside_) return;
   const long r0 = g.idx(0, j, k);
   const long c = r0 + i, xp = r0 + wrapp(i, g.nx);
   double pu_c, pu_p, pv_c, pv_p, pw_c, pw_p;
+  const bool closed_top = k == g.nz - 1 && !lid;      // (open lid, BCtopm = 3: lid_bcpup_kernel has filled the plane ke+1 of wp)
   if (PUP) {   // up,vp,wp already hold pup,pvp,pwp (momentum sweep in PUP mode)
     pu_c = up[c]; pu_p = up[xp];
     pv_c = vp[c]; pv_p = vp[c + g.sy];
     pw_c = wp[c];
-    pw_p = (k == g.nz - 1) ? 0. : wp[c + g.sz];
+    pw_p = closed_top ? 0. : wp[c + g.sz];
   } else {
     pu_c = up[c] + um[c] * r; pu_p = up[xp] + um[xp] * r;
     pv_c = vp[c] + vm[c] * r; pv_p = vp[c + g.sy] + vm[c + g.sy] * r;
     pw_c = (k == 0) ? 0. : wp[c] + wm[c] * r;
-    pw_p = (k == g.nz - 1) ? 0. : wp[c + g.sz] + wm[c + g.sz] * r;
+    pw_p = closed_top ? 0. : wp[c + g.sz] + wm[c + g.sz] * r;
   }
   p[c] = (pu_p - pu_c) * m.dxi + (pv_p - pv_c) * m.dyi + (pw_p - pw_c) * m.dzfi[k + 1];
 }
@@ -682,11 +683,12 @@ __global__ __launch_bounds__(256) void integrate_kernel(Geo g, TileGrid tg, Metr
       const bool ns = pr.bctopm == UDC_TOP_NOSLIP;
       const double ut = ns ? 2 * pr.uinf - u : u, vt = ns ? 2 * pr.vinf - v : v;
       const long t = c + g.sz;
-      a.u0[t] = ut; a.v0[t] = vt; a.w0[t] = 0.;
-      if (last_m) { a.um[t] = ut; a.vm[t] = vt; a.wm[t] = 0.; }
+      const bool wtop = pr.bctopm != UDC_TOP_PRESSURE;      // (open lid: w(ke+1) is lid_integrate_kernel's, `boundary` leaves it alone)
+      a.u0[t] = ut; a.v0[t] = vt; if (wtop) a.w0[t] = 0.;
+      if (last_m) { a.um[t] = ut; a.vm[t] = vt; if (wtop) a.wm[t] = 0.; }
       if (wr) {
-        a.u0[t + wr] = ut; a.v0[t + wr] = vt; a.w0[t + wr] = 0.;
-        if (last_m) { a.um[t + wr] = ut; a.vm[t + wr] = vt; a.wm[t + wr] = 0.; }
+        a.u0[t + wr] = ut; a.v0[t + wr] = vt; if (wtop) a.w0[t + wr] = 0.;
+        if (last_m) { a.um[t + wr] = ut; a.vm[t + wr] = vt; if (wtop) a.wm[t + wr] = 0.; }
       }
     }
   }
@@ -700,6 +702,45 @@ __global__ __launch_bounds__(256) void integrate_kernel(Geo g, TileGrid tg, Metr
     if (ZERO) a.svp[s][c] = 0.;        // the fused substep's scalar sweep does not read svp either
     if (last_s) a.svm[s][c] = sv;
   }
+}
+
+// ---- the open lid, BCtopm = 3 (BCtopm_pressure, src/modglobal.f90:142: "vertical velocity can vary according to pressure gradient")
+// w(ke+1) is a prognostic plane: `boundary` leaves it alone (src/modboundary.f90:191-200), bcpup gives it the predicted velocity
+//   pwp(ke+1) = wm(ke+1) / rk3coef + 2 <pres0>(ke) dzhi(ke+1),   wp(ke+1) = pwp(ke+1) - wm(ke+1) / rk3coef   (:1234-1243),
+// fillps' divergence of level ke reads it, tderive adds 2 <p>(ke) dzhi(ke+1) (src/modpois.f90:1058-1069) and tstep_integrate steps
+// it like any other level (src/modtstep.f90:270-286).  <.> = avexy_ibm: the mean of the level over the fluid c cells of the whole
+// domain (src/modmpi.f90:623-664; -999 for a level without any).  S = that level's masked, all-reduced sum (k_level_sums_dev).
+// Planes of nx x ny cells: three small kernels beside the sweeps, which keep their closed-lid code.
+__device__ __forceinline__ double lid_mean(const double *S, double cnt) { return cnt > 0. ? S[0] / cnt : -999.; }
+// pup != 0: the tendency arrays hold the predicted velocity (the fused substep's form): wp(ke+1) takes pwp(ke+1)
+__global__ void lid_bcpup_kernel(Geo g, double r, double dzhi_top, double cnt, const double *__restrict__ S,
+                                 const double *__restrict__ wm, double *__restrict__ wp, int pup) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+  if (i >= g.nx) return;
+  const long c = g.idx(i, j, g.nz);
+  const double pres0ij = lid_mean(S, cnt);
+  const double pwp = wm[c] * r + 2 * pres0ij * dzhi_top;
+  wp[c] = pup ? pwp : pwp - wm[c] * r;
+}
+__global__ void lid_tderive_kernel(Geo g, double dzhi_top, double cnt, const double *__restrict__ S, double *__restrict__ wp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+  if (i >= g.nx) return;
+  const long c = g.idx(i, j, g.nz);
+  wp[c] = wp[c] + 2 * lid_mean(S, cnt) * dzhi_top;
+}
+// w0(ke+1) = wm(ke+1) + rk3coef wp(ke+1) (pup: rk3coef pwp(ke+1)); zero: wp(ke+1) = 0 as the reference's `wp = 0.`; last: wm = w0;
+// wrap: the slab is the whole domain in y and the periodic ghost rows are written here (`halos` folded in)
+__global__ void lid_integrate_kernel(Geo g, double rk3coef, int pup, int zero, int last, int wrap, const double *__restrict__ wm,
+                                     double *__restrict__ wp, double *__restrict__ w0, double *__restrict__ wm_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+  if (i >= g.nx) return;
+  const long c = g.idx(i, j, g.nz);
+  const double w = pup ? rk3coef * wp[c] : wm[c] + rk3coef * wp[c];
+  const long wr = !wrap ? 0 : ((j == 0) ? (long)g.sy * g.ny : ((j == g.ny - 1) ? -(long)g.sy * g.ny : 0));
+  w0[c] = w;
+  if (wr) w0[c + wr] = w;
+  if (zero) wp[c] = 0.;
+  if (last) { wm_out[c] = w; if (wr) wm_out[c + wr] = w; }
 }
 
 // ---- reductions ---------------------------------------------------------------------
@@ -1226,15 +1267,16 @@ void pois_destroy(udc_handle *h) {
 int k_divergence_rhs(udc_handle *h, double rk3coef, bool pup) {
   const Geo &g = h->g;
   dim3 b(64, 4, 1), gr = cell_grid(g, b);
+  const int lid = h->p.bctopm == UDC_TOP_PRESSURE ? 1 : 0;
   PROF(h, "div_rhs");
   if (pup)
     hipLaunchKernelGGL((div_rhs_kernel<true>), gr, b, 0, h->stream, g, tile_grid(g), h->m, 1. / rk3coef,
                        h->fields[UDC_UP], h->fields[UDC_VP], h->fields[UDC_WP], h->fields[UDC_UM],
-                       h->fields[UDC_VM], h->fields[UDC_WM], h->fields[UDC_P]);
+                       h->fields[UDC_VM], h->fields[UDC_WM], h->fields[UDC_P], lid);
   else
     hipLaunchKernelGGL((div_rhs_kernel<false>), gr, b, 0, h->stream, g, tile_grid(g), h->m, 1. / rk3coef,
                        h->fields[UDC_UP], h->fields[UDC_VP], h->fields[UDC_WP], h->fields[UDC_UM],
-                       h->fields[UDC_VM], h->fields[UDC_WM], h->fields[UDC_P]);
+                       h->fields[UDC_VM], h->fields[UDC_WM], h->fields[UDC_P], lid);
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -1283,6 +1325,40 @@ int k_project(udc_handle *h) {
   PROF(h, "project");
   hipLaunchKernelGGL(project_kernel, gr, b, 0, h->stream, g, tile_grid(g), h->m, h->fields[UDC_P], h->fields[UDC_UP],
                      h->fields[UDC_VP], h->fields[UDC_WP], h->fields[UDC_PRES0]);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// the open lid's three steps (kernels above).  cnt: the fluid c cells of level ke in the whole domain
+static double lid_count(const udc_handle *h) {
+  // (IIc is all ones where the c grid's lists were not read -- no scalar field at all, src/modibm.f90:181)
+  const bool masked = h->ibm_on && h->ibm[3].given && (int)h->ibm[3].fluid_cnt.size() > h->g.nz;
+  return masked ? h->ibm[3].fluid_cnt[h->g.nz] : (double)h->g.nx * (double)h->cfg.jtot;
+}
+int k_lid_bcpup(udc_handle *h, double rk3coef, bool pup) {
+  const Geo &g = h->g;
+  if (k_level_sums_dev(h, UDC_PRES0, 1, g.nz - 1)) return 1;
+  PROF(h, "lid");
+  hipLaunchKernelGGL(lid_bcpup_kernel, dim3((g.nx + 63) / 64, g.ny), dim3(64), 0, h->stream, g, 1. / rk3coef, h->dzhi_top, lid_count(h),
+                     (const double *)h->lev_sum16, (const double *)h->fields[UDC_WM], h->fields[UDC_WP], pup ? 1 : 0);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+int k_lid_tderive(udc_handle *h) {
+  const Geo &g = h->g;
+  if (k_level_sums_dev(h, UDC_P, 1, g.nz - 1)) return 1;
+  PROF(h, "lid");
+  hipLaunchKernelGGL(lid_tderive_kernel, dim3((g.nx + 63) / 64, g.ny), dim3(64), 0, h->stream, g, h->dzhi_top, lid_count(h),
+                     (const double *)h->lev_sum16, h->fields[UDC_WP]);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+int k_lid_integrate(udc_handle *h, int rk3step, double dt, bool pup, bool zero, bool wrap) {
+  const Geo &g = h->g;
+  PROF(h, "lid");
+  hipLaunchKernelGGL(lid_integrate_kernel, dim3((g.nx + 63) / 64, g.ny), dim3(64), 0, h->stream, g, dt / (4. - (double)rk3step), pup ? 1 : 0,
+                     zero ? 1 : 0, rk3step == 3 ? 1 : 0, wrap ? 1 : 0, (const double *)h->fields[UDC_WM], h->fields[UDC_WP], h->fields[UDC_W0],
+                     h->fields[UDC_WM]);
   HIP_OK(hipGetLastError());
   return 0;
 }

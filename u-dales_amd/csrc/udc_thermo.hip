@@ -309,13 +309,13 @@ __global__ __launch_bounds__(256) void diagfld_kernel(DiagArgs a, double *mt, co
 }
 
 // plain per-level slab sums (stage 1; levelsum_final_kernel is stage 2): levels k = 0..nlev-1 (device), i.e. 1..nlev
-__global__ __launch_bounds__(256) void levelsum_plain_kernel(Geo g, int gx, const double *__restrict__ f, double *__restrict__ part) {
+__global__ __launch_bounds__(256) void levelsum_plain_kernel(Geo g, int gx, const double *__restrict__ f, double *__restrict__ part, int k0 = 0) {
   __shared__ double sw[4];
   const int tile = blockIdx.x, k = blockIdx.y;
   const int by = tile / gx, bx = tile - by * gx;
   const int i = bx * 64 + threadIdx.x, j = by * 4 + threadIdx.y;
   double v = 0.;
-  if (i < g.nx && j < g.ny) v = f[g.idx(i, j, k)];
+  if (i < g.nx && j < g.ny) v = f[g.idx(i, j, k0 + k)];
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   if (threadIdx.x == 0) sw[threadIdx.y] = v;
   __syncthreads();
@@ -375,9 +375,9 @@ int k_slab_averages(udc_handle *h, const int *fields, int nf, double *avg_host, 
 }
 int k_slab_average(udc_handle *h, int field, double *avg_host, int n) { return k_slab_averages(h, &field, 1, avg_host, n); }
 
-// level sums of one field over levels 1..n with the immersed boundary's solid points taken out, all-reduced over the
+// level sums of one field over levels k0+1..k0+n with the immersed boundary's solid points taken out, all-reduced over the
 // slabs, left in h->lev_sum16[0..n) on the device (no host round trip: for kernels that consume them)
-int k_level_sums_dev(udc_handle *h, int field, int n) {
+int k_level_sums_dev(udc_handle *h, int field, int n, int k0) {
   const Geo &g = h->g;
   const TileGrid tg = tile_grid(g);
   const size_t need = (size_t)tg.tiles * n;
@@ -388,10 +388,10 @@ int k_level_sums_dev(udc_handle *h, int field, int n) {
   }
   if (!h->lev_sum16) HIP_OK(hipMalloc(&h->lev_sum16, sizeof(double) * 16 * (g.nz + 2)));
   hipLaunchKernelGGL(levelsum_plain_kernel, dim3((unsigned)tg.tiles, (unsigned)n), dim3(64, 4), 0, h->stream, g, tg.gx,
-                     (const double *)h->fields[field], h->lev_part);
+                     (const double *)h->fields[field], h->lev_part, k0);
   hipLaunchKernelGGL(levelsum_final_kernel, dim3((unsigned)n), dim3(256), 0, h->stream, tg.tiles, h->lev_part, h->lev_sum16);
   HIP_OK(hipGetLastError());
-  if (k_ibm_levelsum_correct(h, &field, 1, n, h->lev_sum16)) return 1;
+  if (k_ibm_levelsum_correct(h, &field, 1, n, h->lev_sum16, k0)) return 1;
   return comm_allreduce(h, h->lev_sum16, n, 1);
 }
 

@@ -24,12 +24,12 @@ contains
 
   !> sponge layer coefficients (src/modboundary.f90:38-65)
   subroutine initboundary
-    use modglobal, only: ib, kb, ke, kh, kmax, pi, zf, iplane, BCxm, BCym, BCtopm, BCtopm_pressure
+    use modglobal, only: ib, kb, ke, kh, kmax, pi, zf, iplane, BCxm, BCym
     use modinletdata, only: irecy
     real :: zspb, zspt
     integer :: k
-    if (BCxm /= 1 .or. BCym /= 1 .or. BCtopm == BCtopm_pressure) then
-      write (0, *) 'ERROR: libudcore boundary: only periodic x/y with a free-slip or no-slip top'
+    if (BCxm /= 1 .or. BCym /= 1) then
+      write (0, *) 'ERROR: libudcore boundary: only periodic x/y'
       stop 1
     end if
     allocate (tsc(kb:ke + kh))

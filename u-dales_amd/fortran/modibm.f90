@@ -260,6 +260,9 @@ contains
         nrm = facnorm(fac, :)
         if ((dalign /= 0 .and. dalign == alignment(nrm)) .or. facz0(fac) < eps1) cycle          ! :366-373
         i = lists(grid)%bnd(1, bid); j = lists(grid)%bnd(2, bid); k = lists(grid)%bnd(3, bid)
+        ! (a section of a boundary point that no rank owns acts nowhere: lfctsecsrank, src/modibm.f90:340-350; the lists of the
+        !  reference's tests/cases/526 reach beyond the domain)
+        if (i < 1 .or. i > itot .or. j < 1 .or. j > jtot) cycle
         m = m + 1
         cell(:, m) = (/i, j, k/); area(m) = a; dist(m) = dst; norm(:, m) = nrm
         z0(m) = facz0(fac); z0h(m) = facz0h(fac)

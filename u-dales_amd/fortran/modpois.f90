@@ -23,15 +23,14 @@ module modpois
 contains
 
   subroutine initpois
-    use modglobal, only: ib, ie, ih, jb, je, jh, kb, ke, kh, ipoiss, POISS_FFT2D, BCxm, BCym, BCzp, BCtopm, &
-                         BCtopm_pressure
+    use modglobal, only: ib, ie, ih, jb, je, jh, kb, ke, kh, ipoiss, POISS_FFT2D, BCxm, BCym, BCzp
     implicit none
     if (ipoiss /= POISS_FFT2D) then
       write (0, *) 'Invalid choice for Poisson solver'     ! as src/modpois.f90:897-898
       stop 1
     end if
-    if (BCxm /= 1 .or. BCym /= 1 .or. BCzp /= 1 .or. BCtopm == BCtopm_pressure) then
-      write (0, *) 'ERROR: libudcore poisson: only periodic x/y, tridiagonal z, free-slip/no-slip top'
+    if (BCxm /= 1 .or. BCym /= 1 .or. BCzp /= 1) then
+      write (0, *) 'ERROR: libudcore poisson: only periodic x/y, tridiagonal z'
       stop 1
     end if
     allocate (p(ib - ih:ie + ih, jb - jh:je + jh, kb - kh:ke + kh)); p = 0.

@@ -746,9 +746,17 @@ contains
 
   !> First tstep_update: the time loop starts.  In device mode the state goes up once and the routines start recording.
   subroutine udc_enter_loop
+    use modglobal, only: ltrees, lpurif, lheatpump
+    use modmpi, only: myid
     if (udc_in_loop) return
     call udc_ensure
     call udc_late_setup
+    ! vegetation_forcing, purifiers and heatpump are untouched host routines that edit the host's tendencies from the host's fields
+    ! inside the loop: only the strict mode carries the state to them and their terms back
+    if (udc_residency /= 0 .and. (ltrees .or. lpurif .or. lheatpump)) then
+      if (myid == 0) write (6, *) 'libudcore: trees / purifiers / heat pump run on the host inside the time loop: UDC_RESIDENCY=0'
+      udc_residency = 0
+    end if
     udc_in_loop = .true.
     if (udc_residency == 2) then
       call udc_push_state

@@ -106,6 +106,8 @@ def wall_sections(deck, g, grid, bnd_pts, facets, lnorec=False):
         if (dir_align != 0 and dir_align == alignment(norm)) or z0 < EPS1:            # :366-373
             continue
         i, j, k = (int(v) for v in bnd_pts[bid - 1])
+        if not (1 <= i <= nx and 1 <= j <= ny):      # a boundary point no rank owns: its sections act nowhere (lfctsecsrank, :340-350)
+            continue
         comprec, recpt, recids = True, np.zeros(3), np.zeros((4, 3), dtype=np.int32)
         if not (np.log(dst / z0) > 1. or lnorec):                    # :375-378: reconstruct
             comprec = False
