@@ -89,15 +89,17 @@ def test_configs2_512x512x256_kappa_smagorinsky_against_reference(path, tmp_path
     assert divmax < 1e-10
 
 
-@pytest.mark.parametrize("path", ["single slab", "slab layout"])
+@pytest.mark.parametrize("path", ["single slab", "slab layout", "slab layout, tile row 0 first"])
 def test_configs3_rank_slab_1024x64x512_against_reference(path, tmp_path, monkeypatch):
     """One rank's slab of eight of configs[3] (1024 x 512 x 512 on 8 GPUs) as a whole domain, 1024 x 64 x 512, neutral Vreman channel
     with the floor: three time steps = 9 substeps against the reference's Fortran at 1e-9.  The shapes the multi-GPU kernels work on:
     x lines of 1024 (radix-8 C2R, Stockham R2C with the divergence), columns of 512 levels (the Thomas solve with sixteen levels per
-    thread), the momentum sweep cut along four k-chunks of 128 levels.  (configs[3]'s own grid, 2.7e8 cells, does not fit the build
+    thread), the momentum sweep cut along four k-chunks of 128 levels (each handing vp's first row of its levels on; or tile row 0 first).  (configs[3]'s own grid, 2.7e8 cells, does not fit the build
     container's memory under the reference; on the device it is covered by tests/test_gpu_large.py.)"""
-    if path == "slab layout":
+    if path.startswith("slab layout"):
         monkeypatch.setenv("UDC_FORCE_SLAB", "1")
+    if path.endswith("row 0 first"):      # the pipelined sweep's earlier order (UDC_MOM_PIPE=1): vp's ghost row leaves once, ahead of the k-chunks
+        monkeypatch.setenv("UDC_MOM_PIPE", "1")
     out, divmax, _ = _run_case("c3s", tmp_path)
     _compare("c3s", out, 1e-9)
     assert divmax < 1e-10

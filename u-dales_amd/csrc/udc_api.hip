@@ -145,7 +145,7 @@ void udc_read_switches(Switches &sw) {
   sw.force_slab = env_int("UDC_FORCE_SLAB", 0) != 0;
   sw.force_comm = env_int("UDC_FORCE_COMM", 0) != 0;
   sw.halo_overlap = env_int("UDC_HALO_OVERLAP", 1) != 0;
-  sw.mom_pipe = env_int("UDC_MOM_PIPE", 1) != 0;
+  sw.mom_pipe = env_int("UDC_MOM_PIPE", 2);
   sw.a2a_chunks = env_int("UDC_A2A_CHUNKS", 0);
   sw.fft_fused = env_int("UDC_FFT_FUSED", 1) != 0;
   sw.own_fwd = env_int("UDC_OWN_FWD", -1);
@@ -1083,12 +1083,18 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
     const bool floor_on = (ops & OP_BOTTOM) && h->p.lbottom;
     const bool pipe = plan.mom_pipe;
     if (pipe) {
-      const MomPart row0{0, 1, 0, 0, true};
-      if (k_momentum_lds(h, true, true, forces, true, 1. / rk3coef, rotate, &row0, !plan.ptotal)) return 1;
-      if (floor_on && k_bottom(h, false, 0, momentum_lds_tile_height())) return 1;
-      const int fvp[1] = {UDC_VP};
-      if (k_halo_y_begin(h, fvp, 1, 1, nullptr, HALO_TO_PREV)) return 1;      // (only the divergence of the slab's last row reads a ghost row of vp)
-      h->vp_halo_pending = true;
+      // UDC_MOM_PIPE=1: tile row 0 first over all levels (its own piece: 1/8 of the work in short chunks, and the other pieces then
+      // fill 7/8 of the chip's workgroup slots at 1024 x 64 x 512).  2 (default): no such piece -- every k-chunk's piece covers all
+      // tile rows and hands vp's first row of its own levels on when it is done (k_momentum_pipe_stage)
+      h->mom_pipe.rows_all = h->sw.mom_pipe >= 2;
+      if (!h->mom_pipe.rows_all) {
+        const MomPart row0{0, 1, 0, 0, true};
+        if (k_momentum_lds(h, true, true, forces, true, 1. / rk3coef, rotate, &row0, !plan.ptotal)) return 1;
+        if (floor_on && k_bottom(h, false, 0, momentum_lds_tile_height())) return 1;
+        const int fvp[1] = {UDC_VP};
+        if (k_halo_y_begin(h, fvp, 1, 1, nullptr, HALO_TO_PREV)) return 1;      // (only the divergence of the slab's last row reads a ghost row of vp)
+        h->vp_halo_pending = true;
+      }
       h->mom_pipe.active = true; h->mom_pipe.forces = forces; h->mom_pipe.um_is_u0 = rotate; h->mom_pipe.bottom = floor_on;
       h->mom_pipe.rk3coefi = 1. / rk3coef; h->mom_pipe.pgrad = !plan.ptotal;
     } else if (k_momentum_lds(h, true, true, forces, true, 1. / rk3coef, rotate, nullptr, !plan.ptotal)) return 1;
@@ -1258,9 +1264,21 @@ int k_momentum_pipe_stage(udc_handle *h, int c) {
   if (!h->mom_pipe.active) return 0;
   const int nch = h->nch, nzc = h->g.nz / nch, gy = momentum_lds_tile_rows(h->g);
   const int kbeg = c == 0 ? 0 : c * nzc + 1, kend = c == nch - 1 ? h->g.nz : (c + 1) * nzc + 1;
-  const MomPart part{1, gy, kbeg, kend, c != nch - 1};
+  const bool all = h->mom_pipe.rows_all;
+  const MomPart part{all ? 0 : 1, gy, kbeg, kend, c != nch - 1};
   if (k_momentum_lds(h, true, true, h->mom_pipe.forces, true, h->mom_pipe.rk3coefi, h->mom_pipe.um_is_u0, &part, h->mom_pipe.pgrad)) return 1;
-  if (c == 0 && h->mom_pipe.bottom && k_bottom(h, false, momentum_lds_tile_height(), -1)) return 1;
+  if (c == 0 && h->mom_pipe.bottom && k_bottom(h, false, all ? 0 : momentum_lds_tile_height(), -1)) return 1;
+  if (all) {
+    // vp's first row of the levels this chunk's divergence reads (complete now: level c nzc is the previous piece's last) travels
+    // while the next piece is swept (k_poisson_solve_slab launches it ahead of this chunk's x transform)
+    const int fvp[1] = {UDC_VP};
+    if (k_halo_y_begin(h, fvp, 1, 1, nullptr, HALO_TO_PREV, c * nzc, nzc)) return 1;
+    if (c < 16) {
+      if (!h->ev_vp[c]) HIP_OK(hipEventCreateWithFlags(&h->ev_vp[c], hipEventDisableTiming));
+      HIP_OK(hipEventRecord(h->ev_vp[c], h->comm_stream));      // (the x transform of chunk c waits for this one, not for the last begun)
+    }
+    h->vp_halo_pending = true;
+  }
   return 0;
 }
 

@@ -712,7 +712,8 @@ static YArgs yargs(const udc_handle *h, int k0, int nzc) {
 int fft_x_row_groups(const udc_handle *h) { return h->g.ny / h->fft_L; }
 
 // g0, g1: row groups [g0, g1) of the slab (fft_x_row_groups; g1 <= 0: all)
-int fft_x_fwd_pack(udc_handle *h, int k0, int nzc, double *send, int g0, int g1) {
+int fft_x_fwd_pack(udc_handle *h, int k0, int nzc, double *send, int g0, int g1, hipStream_t st) {
+  if (!st) st = h->stream;
   XArgs q = xargs(h, k0, nzc);
   const double2 *tw = reinterpret_cast<const double2 *>(h->fft_tw);
   if (g1 <= 0) { g0 = 0; g1 = q.nyl >> q.lL; }
@@ -721,10 +722,10 @@ int fft_x_fwd_pack(udc_handle *h, int k0, int nzc, double *send, int g0, int g1)
   const size_t lds = x_lds_bytes(h, h->fft_L);
   const DivArgs dv{h->fields[UDC_UP], h->fields[UDC_VP], h->fields[UDC_WP], h->m.dzfi, h->m.dxi, h->m.dyi, h->g.nz};
   if (h->div_in_fft) {
-    FFT_DISPATCH(ilog2(q.M), hipLaunchKernelGGL((fftx_fwd_pack_kernel<LM, true>), gr, dim3(xthreads(LM)), lds, h->stream, q, (const double *)h->fields[UDC_P], dv,
+    FFT_DISPATCH(ilog2(q.M), hipLaunchKernelGGL((fftx_fwd_pack_kernel<LM, true>), gr, dim3(xthreads(LM)), lds, st, q, (const double *)h->fields[UDC_P], dv,
                                                 tw, tw + q.M, reinterpret_cast<double2 *>(send)))
   } else {
-    FFT_DISPATCH(ilog2(q.M), hipLaunchKernelGGL((fftx_fwd_pack_kernel<LM, false>), gr, dim3(xthreads(LM)), lds, h->stream, q, (const double *)h->fields[UDC_P], dv,
+    FFT_DISPATCH(ilog2(q.M), hipLaunchKernelGGL((fftx_fwd_pack_kernel<LM, false>), gr, dim3(xthreads(LM)), lds, st, q, (const double *)h->fields[UDC_P], dv,
                                                 tw, tw + q.M, reinterpret_cast<double2 *>(send)))
   }
   HIP_OK(hipGetLastError());

@@ -26,24 +26,25 @@ __global__ void halo_y_wrap_kernel(Geo g, FieldList fl, int width) {
 // multi-slab: pack `width` boundary rows of every field into a contiguous buffer
 // buf[((f*width + r)*pz + kk)*nx + i]; low = rows 0..w-1 (to previous rank), high = rows ny-w..ny-1.
 // dirs: bit 0 = the rows that go to the previous rank (and arrive from the next one), bit 1 = to the next (from the previous)
-__global__ void halo_pack_kernel(Geo g, FieldList fl, int width, double *__restrict__ to_prev, double *__restrict__ to_next, int dirs) {
+// (kk0, gridDim.z: the planes kk0 .. kk0 + gridDim.z - 1 of the padded array -- all of them, or one k-chunk's)
+__global__ void halo_pack_kernel(Geo g, FieldList fl, int width, double *__restrict__ to_prev, double *__restrict__ to_next, int dirs, int kk0) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= g.nx) return;
   const int r = blockIdx.y % width, fi = blockIdx.y / width;
-  const int kk = blockIdx.z, k = kk - HZ;
+  const int kk = kk0 + blockIdx.z, k = kk - HZ;
   const double *a = fl.f[fi];
-  const size_t o = (((size_t)fi * width + r) * g.pz + kk) * g.nx + i;
+  const size_t o = (((size_t)fi * width + r) * gridDim.z + blockIdx.z) * g.nx + i;
   if (dirs & 1) to_prev[o] = a[g.idx(i, r, k)];
   if (dirs & 2) to_next[o] = a[g.idx(i, g.ny - width + r, k)];
 }
 __global__ void halo_unpack_kernel(Geo g, FieldList fl, int width, const double *__restrict__ from_prev,
-                                   const double *__restrict__ from_next, int dirs) {
+                                   const double *__restrict__ from_next, int dirs, int kk0) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= g.nx) return;
   const int r = blockIdx.y % width, fi = blockIdx.y / width;
-  const int kk = blockIdx.z, k = kk - HZ;
+  const int kk = kk0 + blockIdx.z, k = kk - HZ;
   double *a = fl.f[fi];
-  const size_t o = (((size_t)fi * width + r) * g.pz + kk) * g.nx + i;
+  const size_t o = (((size_t)fi * width + r) * gridDim.z + blockIdx.z) * g.nx + i;
   if (dirs & 2) a[g.idx(i, -width + r, k)] = from_prev[o];
   if (dirs & 1) a[g.idx(i, g.ny + r, k)] = from_next[o];
 }
@@ -114,7 +115,7 @@ int k_halo_y(udc_handle *h, const int *fields, int nf, int width, int dirs) {
   {
     PROF(h, "halo_pack");
     hipLaunchKernelGGL(halo_pack_kernel, dim3((g.nx + 63) / 64, width * nf, g.pz), dim3(64), 0, h->stream, g, fl,
-                       width, h->halo_buf[0], h->halo_buf[1], dirs);
+                       width, h->halo_buf[0], h->halo_buf[1], dirs, 0);
     HIP_OK(hipGetLastError());
   }
   {
@@ -124,7 +125,7 @@ int k_halo_y(udc_handle *h, const int *fields, int nf, int width, int dirs) {
   {
     PROF(h, "halo_unpack");
     hipLaunchKernelGGL(halo_unpack_kernel, dim3((g.nx + 63) / 64, width * nf, g.pz), dim3(64), 0, h->stream, g, fl,
-                       width, h->halo_buf[2], h->halo_buf[3], dirs);
+                       width, h->halo_buf[2], h->halo_buf[3], dirs, 0);
     HIP_OK(hipGetLastError());
   }
   return 0;
@@ -139,20 +140,24 @@ bool halo_overlap(const udc_handle *h, int tile_rows_y) {
   return h->slab && h->comm_stream && !h->no_halo_overlap && tile_rows_y >= 3;
 }
 
-int k_halo_y_begin(udc_handle *h, const int *fields, int nf, int width, double *const *ptrs, int dirs) {
+// klev0 >= 0: only the levels klev0 .. klev0 + nlev - 1 (device levels; no ghost planes) -- a k-chunk's rows, as the pipelined momentum
+// sweep hands them on.  Exchanges begun one after the other share the pack buffers: they queue on the communication stream.
+int k_halo_y_begin(udc_handle *h, const int *fields, int nf, int width, double *const *ptrs, int dirs, int klev0, int nlev) {
   const Geo &g = h->g;
   if (width > HY || nf > 16 || !h->slab || !h->comm_stream) { udc_set_error("k_halo_y_begin: bad arguments"); return 1; }
+  if (klev0 >= 0 && (nlev < 1 || klev0 + nlev > g.nz)) { udc_set_error("k_halo_y_begin: bad level range"); return 1; }
   FieldList fl;
   for (int q = 0; q < nf; ++q) fl.f[q] = ptrs ? ptrs[q] : h->fields[fields[q]];
-  const size_t count = (size_t)nf * width * g.pz * g.nx;
+  const int kk0 = klev0 >= 0 ? klev0 + HZ : 0, nkk = klev0 >= 0 ? nlev : g.pz;
+  const size_t count = (size_t)nf * width * nkk * g.nx;
   if (count > h->halo_cap) { udc_set_error("k_halo_y_begin: pack buffer too small"); return 1; }
   hipStream_t cs = h->comm_stream;
   HIP_OK(hipEventRecord(h->ev_halo_ready, h->stream));
   HIP_OK(hipStreamWaitEvent(cs, h->ev_halo_ready, 0));
-  hipLaunchKernelGGL(halo_pack_kernel, dim3((g.nx + 63) / 64, width * nf, g.pz), dim3(64), 0, cs, g, fl, width, h->halo_buf[0], h->halo_buf[1], dirs);
+  hipLaunchKernelGGL(halo_pack_kernel, dim3((g.nx + 63) / 64, width * nf, nkk), dim3(64), 0, cs, g, fl, width, h->halo_buf[0], h->halo_buf[1], dirs, kk0);
   HIP_OK(hipGetLastError());
   if (comm_neighbours(h, h->halo_buf[0], h->halo_buf[1], h->halo_buf[2], h->halo_buf[3], count, cs, dirs)) return 1;
-  hipLaunchKernelGGL(halo_unpack_kernel, dim3((g.nx + 63) / 64, width * nf, g.pz), dim3(64), 0, cs, g, fl, width, h->halo_buf[2], h->halo_buf[3], dirs);
+  hipLaunchKernelGGL(halo_unpack_kernel, dim3((g.nx + 63) / 64, width * nf, nkk), dim3(64), 0, cs, g, fl, width, h->halo_buf[2], h->halo_buf[3], dirs, kk0);
   HIP_OK(hipGetLastError());
   HIP_OK(hipEventRecord(h->ev_halo_done, cs));
   h->halo_async_pending = true;      // (several begins in a row queue behind each other on the communication stream; one join covers them)

@@ -143,7 +143,8 @@ struct Switches {
   int force_slab = 0;        // UDC_FORCE_SLAB=1: one rank through the slab layout
   int force_comm = 0;        // UDC_FORCE_COMM=1: a real one-rank RCCL communicator under the forced slab path
   int halo_overlap = 1;      // UDC_HALO_OVERLAP=0: every ghost-row exchange in line
-  int mom_pipe = 1;          // UDC_MOM_PIPE=0: momentum sweep not cut along the solve's k-chunks
+  int mom_pipe = 2;          // UDC_MOM_PIPE=0: momentum sweep not cut along the solve's k-chunks; 1: tile row 0 first, then the k-chunks of the
+                             // other rows; 2 (default): the k-chunks of all rows, vp's ghost row travelling chunk by chunk
   int a2a_chunks = 0;        // UDC_A2A_CHUNKS: k-chunks of the transposes (0: the library's choice, pois_slab_init)
   int fft_fused = 1;         // UDC_FFT_FUSED=0: rocFFT + transpose kernels on the slab path
   int own_fwd = -1;          // UDC_OWN_FWD=0/1: single-slab forward half in own kernels
@@ -378,10 +379,13 @@ struct udc_handle {
   hipStream_t comm_stream = nullptr;    // all-to-all exchanges run here, overlapped with rocFFT on `stream`
   hipEvent_t ev_ready[16] = {}, ev_done[16] = {};
   hipEvent_t ev_halo_ready = nullptr, ev_halo_done = nullptr;      // k_halo_y_begin / _join
+  hipEvent_t ev_vp[16] = {};            // vp's ghost row of k-chunk c has arrived (pipelined momentum sweep, UDC_MOM_PIPE=2)
   bool halo_async_pending = false;      // a k_halo_y_begin has not been joined yet (k_halo_y joins it before touching the shared buffers)
   // the momentum sweep pipelined with the slab solve (substep_fused, k_momentum_pipe_stage): tile row 0 is swept first over all
   // levels, the other rows level range by level range ahead of the x forward transform of the same k-chunk
-  struct MomPipe { bool active = false, forces = false, um_is_u0 = false, bottom = false, pgrad = true; double rk3coefi = 0.; } mom_pipe;
+  // rows_all: every piece covers all tile rows and hands vp's first row of its own levels on (UDC_MOM_PIPE=2, the default); else tile
+  // row 0 was swept first over all levels and its row is already travelling (UDC_MOM_PIPE=1)
+  struct MomPipe { bool active = false, forces = false, um_is_u0 = false, bottom = false, pgrad = true, rows_all = false; double rk3coefi = 0.; } mom_pipe;
   bool no_mom_pipe = false;             // UDC_MOM_PIPE=0
   bool vp_halo_pending = false;         // vp's ghost row is travelling (k_halo_y_begin): the x forward transform joins before its last row group
   bool no_halo_overlap = false;         // UDC_HALO_OVERLAP=0: every ghost-row exchange in line on the compute stream
@@ -476,7 +480,7 @@ int k_halo_y(udc_handle *h, const int *fields, int nf, int width, int dirs = HAL
 // the same exchange beside the compute stream: _begin queues pack, exchange and unpack on the communication stream behind what
 // the compute stream holds so far; _join makes the compute stream wait for it.  `ptrs` (optional): the arrays, where the caller
 // knows better than h->fields (pointer rotation in flight)
-int k_halo_y_begin(udc_handle *h, const int *fields, int nf, int width, double *const *ptrs = nullptr, int dirs = HALO_BOTH);
+int k_halo_y_begin(udc_handle *h, const int *fields, int nf, int width, double *const *ptrs = nullptr, int dirs = HALO_BOTH, int klev0 = -1, int nlev = 0);
 int k_halo_y_join(udc_handle *h);
 bool halo_overlap(const udc_handle *h, int tile_rows_y);      // y-slabs with enough tile rows for an edge / interior split
 int k_top_bottom(udc_handle *h);
@@ -520,7 +524,7 @@ bool fft_fused_possible(const udc_handle *h);
 int fft_fused_init(udc_handle *h);
 int fft_nat_init(udc_handle *h);
 int fft_nat_forward(udc_handle *h);
-int fft_x_fwd_pack(udc_handle *h, int k0, int nzc, double *send, int g0 = 0, int g1 = 0);      // row groups [g0, g1); g1 <= 0: all
+int fft_x_fwd_pack(udc_handle *h, int k0, int nzc, double *send, int g0 = 0, int g1 = 0, hipStream_t st = nullptr);      // row groups [g0, g1); g1 <= 0: all
 int fft_x_row_groups(const udc_handle *h);
 int fft_x_bwd_unpack(udc_handle *h, int k0, int nzc, const double *recv);
 int fft_y_fwd_unpack(udc_handle *h, int k0, int nzc, const double *recv);

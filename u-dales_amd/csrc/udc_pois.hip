@@ -1154,13 +1154,30 @@ int k_poisson_solve_slab(udc_handle *h) {
     HIP_OK(hipEventRecord(h->ev_done[c], h->comm_stream));
     return 0;
   };
+  // The pipelined momentum sweep, every piece over all tile rows (UDC_MOM_PIPE=2): piece c + 1 is launched ahead of the x transform
+  // of chunk c, so that vp's ghost row of chunk c -- sent when piece c was done -- has a whole piece's time to arrive and the transform
+  // is one launch that waits for nothing:  p0 p1 x0 p2 x1 p3 x2 x3.  (Two other orders were measured at 1024 x 64 x 512 and dropped,
+  // profiles/r06/mom_pipe_orders_ab.txt: the transform split at its last row group with a join in between, 8 launches, +0.09 ms on the
+  // transforms; that last row group on the communication stream behind the row's unpack, which slows the sweep running beside it.)
+  const bool ahead = h->mom_pipe.active && h->mom_pipe.rows_all;
   {
     for (int c = 0; c < nch; ++c) {
       const int k0 = c * nzc;
-      if (k_momentum_pipe_stage(h, c)) return 1;      // (the momentum sweep's levels for this chunk, when it is pipelined with the solve)
+      // (the momentum sweep's levels for this chunk, when it is pipelined with the solve)
+      if (ahead) {
+        if (c == 0 && k_momentum_pipe_stage(h, 0)) return 1;
+        if (c + 1 < nch && k_momentum_pipe_stage(h, c + 1)) return 1;
+        if (h->ev_vp[c]) HIP_OK(hipStreamWaitEvent(h->stream, h->ev_vp[c], 0));      // vp's ghost row of this chunk's levels is in
+        if (c == nch - 1) { h->vp_halo_pending = false; h->halo_async_pending = false; }
+      } else if (k_momentum_pipe_stage(h, c)) return 1;
       PROF(h, c == nch - 1 ? "fftx_pack_fwd" : "fftx_pack_fwd_edge");      // (one table row per substep: bench.py folds *_edge)
       if (h->fft_fused) {
         const int G = fft_x_row_groups(h);
+        if (ahead) {
+          if (fft_x_fwd_pack(h, k0, nzc, h->a2a_send + chunk * c)) return 1;
+          if (exchange(c)) return 1;
+          continue;
+        }
         if (h->vp_halo_pending && G >= 2) {
           // vp's ghost row (the divergence of the slab's last row reads it) is still travelling: every row group but the last first
           if (fft_x_fwd_pack(h, k0, nzc, h->a2a_send + chunk * c, 0, G - 1)) return 1;
@@ -1258,7 +1275,7 @@ void pois_destroy(udc_handle *h) {
   if (h->comm_stream) hipStreamDestroy(h->comm_stream);
   if (h->ev_halo_ready) hipEventDestroy(h->ev_halo_ready);
   if (h->ev_halo_done) hipEventDestroy(h->ev_halo_done);
-  for (int c = 0; c < 16; ++c) { if (h->ev_ready[c]) hipEventDestroy(h->ev_ready[c]); if (h->ev_done[c]) hipEventDestroy(h->ev_done[c]); }
+  for (int c = 0; c < 16; ++c) { if (h->ev_ready[c]) hipEventDestroy(h->ev_ready[c]); if (h->ev_done[c]) hipEventDestroy(h->ev_done[c]); if (h->ev_vp[c]) hipEventDestroy(h->ev_vp[c]); }
   if (h->fft_tw) hipFree(h->fft_tw);
   double *bufs[7] = {h->specA, h->specB, h->a2a_send, h->a2a_recv, h->ev_slab, h->ztab_slab, (double *)h->fft_work_slab};
   for (auto b : bufs) if (b) hipFree(b);

@@ -16,7 +16,10 @@ inline int row_padding(int nx) { return (nx >= XPAD_MIN_NX && nx % XPAD_NX_MULTI
 // chunk minimises rounds x (kc + 3) (pick_kc).  Workgroups per CU: momentum 3 (51.7 KB of LDS), closure 4, or 5 from 1024 tiles on
 // (32.6 KB; 512 x 512 x 256 0.634 -> 0.592 ms, 256^3 0.172 against 0.19: profiles/r02), kappa sweep: its own rule in udc_scalar_lds.hip.
 constexpr int MOM_PER_CU = 3;
-inline int closure_per_cu(int tiles) { return tiles >= 1024 ? 5 : 4; }
+#ifndef UDC_CLOSURE5_MIN_TILES
+#define UDC_CLOSURE5_MIN_TILES 1024
+#endif
+inline int closure_per_cu(int tiles) { return tiles >= UDC_CLOSURE5_MIN_TILES ? 5 : 4; }
 
 // Line transforms (udc_fft.hip).  Stockham x kernels of the slab path: rows per workgroup as long as four workgroups fit a CU's LDS,
 // at least 4 (L = 4 at nx = 1024: 18.4 against 20.3 ms per substep with 8, profiles/r03/fft_threads_scan.txt); Stockham y kernels:

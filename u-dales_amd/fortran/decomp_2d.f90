@@ -7,10 +7,13 @@
 ! A deck that asks for p_row x p_col pencils (`nprocx`, `nprocy` of &RUN, src/modstartup.f90:676) is run as p_row * p_col y-slabs:
 ! the solver takes its local extents from zsize / zstart (src/modglobal.f90:622-662), decides "am I at a domain edge" from them
 ! (:640-660) and wraps a direction itself where one rank holds both edges (src/modboundary.f90:95-107), so nothing of it has to know.
-! The 19 of the reference's 28 shipped decks that say nprocx > 1 therefore run unedited (jtot must divide by the number of ranks).
+! The 19 of the reference's 28 shipped decks that say nprocx > 1 therefore run unedited (jtot must divide by the number of ranks) --
+! refused: an x-split deck with purifiers, a driver inflow or a warm start from per-pencil files (refuse_what_slabs_misplace), and the
+! per-rank output files are per slab (tdump.000.RRR...), not per pencil.
 ! Host-side data movement only; the device path (libudcore) does its own exchanges over RCCL.
-!   exchange_halo_z : whole padded rows to the two y neighbours (periodic), after wrapping the x ghosts where the DECK split x
-!                     periodically (the solver then expects them from here);
+!   exchange_halo_z : whole padded rows to the two y neighbours -- always between neighbouring slabs, from the last slab to the first
+!                     only where y is periodic (BCym of the deck; read from the deck file where the deck itself did not split y) --
+!                     after wrapping the x ghosts where the DECK split x periodically (the solver then expects them from here);
 !   transposes      : z <-> y is one MPI_ALLTOALL of equal blocks (jtot and ktot divisible by the ranks), y <-> x a copy -- used by
 !                     the reference's own modpois only (the CPU baseline of oracle/Makefile; the drop-in modpois never calls them).
 ! The all-reference MPI builds of oracle/Makefile (the CPU baseline) link this file too: the reference's own program then runs an
@@ -83,6 +86,7 @@ contains
     end if
     if (p_row > 1 .and. nrank == 0) write (*, '(A,I0,A,I0,A,I0,A)') ' decomp_2d: the deck asks for ', p_row, ' x ', p_col, &
       ' pencils; run as ', nproc, ' y-slabs (x stays whole on a rank)'
+    if (p_row > 1) call refuse_what_slabs_misplace
     nx_global = nx; ny_global = ny; nz_global = nz
     pcol = nproc
     dims = (/1, nproc/); periods = (/.true., .true./)
@@ -95,15 +99,91 @@ contains
     if (present(periodic_bc)) then
       ! (periodic_bc(d) is set by the solver only where the DECK splits direction d, src/modstartup.f90:662-672)
       wrap_x = periodic_bc(1)                    ! the deck split x: the solver expects x's periodic ghosts from the exchange
-      ! y split here but not in the deck: the solver meant to wrap y itself if periodic and cannot any more -- taken as periodic
-      ! like x (every run of the device path has periodic lateral momentum boundaries: udc_iface refuses the others)
-      periodic_y = periodic_bc(2) .or. (p_col == 1 .and. p_row > 1 .and. periodic_bc(1))
+      if (p_col > 1) then
+        periodic_y = periodic_bc(2)              ! the deck split y: this is BCym == periodic
+      else if (p_row > 1) then
+        ! y is split here but not in the deck: the solver meant to wrap y itself if it is periodic (src/modboundary.f90:95-107) and
+        ! cannot any more, and periodic_bc(2) is .false. whatever BCym says -- the deck has to be asked
+        periodic_y = deck_bcym() == 1
+      end if
+    end if
+    ! rows travel between neighbouring slabs whatever the lateral condition; only the wrap from the last slab to the first is y's
+    ! periodicity (2DECOMP's own exchange does the same on a non-periodic Cartesian communicator)
+    if (.not. periodic_y) then
+      if (mycol == 0) nbr_prev = MPI_PROC_NULL
+      if (mycol == nproc - 1) nbr_next = MPI_PROC_NULL
     end if
     call decomp_info_init(nx, ny, nz, decomp_main)
     xstart = decomp_main%xst; xend = decomp_main%xen; xsize = decomp_main%xsz
     ystart = decomp_main%yst; yend = decomp_main%yen; ysize = decomp_main%ysz
     zstart = decomp_main%zst; zend = decomp_main%zen; zsize = decomp_main%zsz
   end subroutine decomp_2d_init
+
+  !> The value of `key` (lower case) in the deck named on the command line, as text; `dflt` where the deck does not set it.  (The
+  !! solver's own variables live in modglobal, which uses this module.)  Aborts when the deck cannot be read: a guess would be a
+  !! silent wrong answer.
+  function deck_value(key, dflt) result(val)
+    character(*), intent(in) :: key, dflt
+    character(64) :: val
+    character(256) :: fname, line
+    integer :: u, ios, p, q, ierr
+    val = dflt
+    if (command_argument_count() < 1) then
+      if (nrank == 0) write (0, *) 'ERROR: decomp_2d (y-slabs): an x-split deck is run as y-slabs and needs ', key, &
+        ' from the deck, and no deck is named on the command line'
+      call MPI_ABORT(MPI_COMM_WORLD, 1, ierr)
+    end if
+    call get_command_argument(1, fname)
+    open (newunit=u, file=trim(fname), status='old', action='read', iostat=ios)
+    if (ios /= 0) then
+      if (nrank == 0) write (0, *) 'ERROR: decomp_2d (y-slabs): cannot read ', key, ' from ', trim(fname)
+      call MPI_ABORT(MPI_COMM_WORLD, 1, ierr)
+    end if
+    do
+      read (u, '(a)', iostat=ios) line
+      if (ios /= 0) exit
+      p = index(line, '!')
+      if (p > 0) line(p:) = ' '
+      do q = 1, len(line)
+        if (line(q:q) >= 'A' .and. line(q:q) <= 'Z') line(q:q) = achar(iachar(line(q:q)) + 32)
+      end do
+      line = adjustl(line)
+      if (line(1:len(key)) /= key) cycle
+      q = verify(line(len(key) + 1:), ' ')                    ! the first character after the name must be '='
+      if (q == 0) cycle
+      if (line(len(key) + q:len(key) + q) /= '=') cycle
+      val = adjustl(line(len(key) + q + 1:))
+      p = scan(val, ' ,/')
+      if (p > 0) val(p:) = ' '
+    end do
+    close (u)
+  end function deck_value
+
+  !> &BC BCym of the deck: 1 = periodic, the reference's default (src/modglobal.f90:151)
+  integer function deck_bcym()
+    integer :: ios
+    read (deck_value('bcym', '1'), *, iostat=ios) deck_bcym
+    if (ios /= 0) deck_bcym = 1
+  end function deck_bcym
+
+  !> What an x-split deck run as slabs cannot serve: reference modules that combine myidy (0 .. nproc-1 here) with the DECK's nprocy --
+  !! the purifiers' offsets (jl = purif - myidy * jtot / nprocy, src/modpurifiers.f90), the driver inflow's rank id
+  !! (mod(myidy, nprocy), src/moddriver.f90) -- and a warm start from the per-pencil restart files of a true pencil run.
+  subroutine refuse_what_slabs_misplace
+    character(64) :: v
+    integer :: ierr, n, ios
+    logical :: bad
+    bad = .false.
+    v = deck_value('lpurif', '.false.'); bad = bad .or. index(v, 't') > 0
+    v = deck_value('lwarmstart', '.false.'); bad = bad .or. index(v, 't') > 0
+    v = deck_value('idriver', '0'); read (v, *, iostat=ios) n; bad = bad .or. (ios == 0 .and. n /= 0)
+    if (bad) then
+      if (nrank == 0) write (0, *) 'ERROR: decomp_2d (y-slabs): an x-split deck with purifiers, a driver inflow or a warm start from ', &
+        'per-pencil restart files cannot be run as y-slabs (their rank arithmetic / file names are those of the pencils): ', &
+        'set nprocx = 1 in the deck'
+      call MPI_ABORT(MPI_COMM_WORLD, 1, ierr)
+    end if
+  end subroutine refuse_what_slabs_misplace
 
   subroutine decomp_2d_finalize
   end subroutine decomp_2d_finalize
@@ -261,7 +341,7 @@ contains
         var(n1 - hi + 1:n1, :, :) = var(hi + 1:2*hi, :, :)
       end if
     end if
-    if (.not. periodic_y) return
+    if (pcol == 1) return       ! (one slab: the solver wraps y itself where it is periodic, src/modboundary.f90:95-107)
     nyl = ny_global/pcol
     hj = (n2 - nyl)/2
     if (hj < 1) return
@@ -273,8 +353,8 @@ contains
                       DECOMP_2D_COMM_CART_Z, st, ierr)
     call MPI_SENDRECV(s2, cnt, MPI_DOUBLE_PRECISION, nbr_next, 2, r1, cnt, MPI_DOUBLE_PRECISION, nbr_prev, 2, &
                       DECOMP_2D_COMM_CART_Z, st, ierr)
-    var(:, 1:hj, :) = r1
-    var(:, n2 - hj + 1:n2, :) = r2
+    if (nbr_prev /= MPI_PROC_NULL) var(:, 1:hj, :) = r1             ! (a domain edge of a non-periodic y keeps what the solver put there)
+    if (nbr_next /= MPI_PROC_NULL) var(:, n2 - hj + 1:n2, :) = r2
     deallocate (s1, s2, r1, r2)
   end subroutine exchange_halo_z_real
 
