@@ -8,6 +8,7 @@ print(sys.argv[1], "ms", round(d["ms_per_step"],4), {k:round(v["avg_ms_net"],4) 
 PY
 }
 run default A=1
+run p_own_exchange UDC_P_TRANSPOSE=0
 run nooverlap UDC_HALO_OVERLAP=0
 run nopipe UDC_MOM_PIPE=0
 run pipe_row0first UDC_MOM_PIPE=1

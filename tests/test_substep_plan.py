@@ -17,11 +17,11 @@ LIB = os.path.join(ROOT, "u-dales_amd", "lib", "libudcplan.so")
 
 IN = ["no_fold", "no_alias", "ek_always", "halo_overlap", "mom_pipe", "div_in_fft", "ptotal",
       "slab", "comm_stream", "sgs", "lbuoycorr", "nslots", "ibm_on", "stats_any", "fft_fused", "own_fwd", "tend_plane", "between",
-      "closure_tile_rows", "mom_tile_rows", "int_tile_rows", "x_row_groups", "levels_per_chunk", "open_lid", "rk3step", "um_alias", "ibm_edits_now"]
+      "closure_tile_rows", "mom_tile_rows", "int_tile_rows", "x_row_groups", "levels_per_chunk", "p_transpose", "open_lid", "rk3step", "um_alias", "ibm_edits_now"]
 OUT = ["lds", "pup", "fold", "alias_ok", "materialise_um", "rotate", "skip_um", "closure", "need_ekh", "mom_pipe", "div_in_fft",
        "vp_row", "p_row", "integrate", "ptotal"]
 FOLDED, OVERLAPPED, PLAIN = 0, 1, 2
-ROW_FOLDED, ROW_BESIDE, ROW_INLINE, ROW_PIPED = 0, 1, 2, 3
+ROW_FOLDED, ROW_BESIDE, ROW_INLINE, ROW_PIPED, ROW_TRANSPOSED = 0, 1, 2, 3, 4
 INT_ONE, INT_EDGES_FIRST = 0, 1
 
 
@@ -63,7 +63,8 @@ def table(i):
     needs_row = ~fold | (b(i["ibm_on"]) & b(i["ibm_edits_now"]))
     vp = np.where(pipe, ROW_PIPED, np.where(needs_row, np.where(div & beside(np.full_like(i["sgs"], 3)) & (i["x_row_groups"] >= 2), ROW_BESIDE, ROW_INLINE),
                                             ROW_FOLDED))
-    prow = np.where(fold, ROW_FOLDED, np.where(beside(i["int_tile_rows"]) & (i["int_tile_rows"] >= 4), ROW_BESIDE, ROW_INLINE))
+    prow = np.where(fold, ROW_FOLDED, np.where(b(i["slab"]) & b(i["fft_fused"]) & b(i["p_transpose"]), ROW_TRANSPOSED,
+                                               np.where(beside(i["int_tile_rows"]) & (i["int_tile_rows"] >= 4), ROW_BESIDE, ROW_INLINE)))
     integ = np.where(~fold & beside(i["int_tile_rows"]), INT_EDGES_FIRST, INT_ONE)
     ptot = b(i["ptotal"]) & pup & ~b(i["tend_plane"]) & ~b(i["open_lid"])
     return dict(lds=lds, pup=pup, fold=fold, alias_ok=alias_ok, materialise_um=mat, rotate=rotate, skip_um=skip, closure=closure,
@@ -73,7 +74,7 @@ def table(i):
 def lattice():
     """every configuration / call for one setting of the eight switches"""
     axes = dict(slab=[0, 1], sgs=[0, 1, 2, 3], lbuoycorr=[0, 1], nslots=[0, 2], ibm_on=[0, 1], stats_any=[0, 1], fft_fused=[0, 1],
-                own_fwd=[0, 1], tend_plane=[0, 1], between=[0, 1], rows=[2, 3, 8], x_row_groups=[1, 4], levels_per_chunk=[2, 16], open_lid=[0, 1], rk3step=[1, 2, 3],
+                own_fwd=[0, 1], tend_plane=[0, 1], between=[0, 1], rows=[2, 3, 8], x_row_groups=[1, 4], levels_per_chunk=[2, 16], p_transpose=[0, 1], open_lid=[0, 1], rk3step=[1, 2, 3],
                 um_alias=[0, 1], ibm_edits_now=[0, 1])
     grids = np.meshgrid(*[np.array(v, dtype=np.int32) for v in axes.values()], indexing="ij")
     cols = {k: g.ravel() for k, g in zip(axes, grids)}
@@ -110,6 +111,8 @@ def test_every_combination_matches_the_table_and_is_safe():
         # the pipelined sweep implies its row already travelling, the divergence inside the transform, no scalar, no other term
         m = g["mom_pipe"] == 1
         assert ((g["vp_row"] == ROW_PIPED) == m).all() and (g["div_in_fft"][m] == 1).all() and (i["nslots"][m] == 0).all() and (i["between"][m] == 0).all()
+        # p's rows inside the backward transpose: only on slabs with the own line transforms (the blocks' layout is theirs)
+        assert not ((g["p_row"] == ROW_TRANSPOSED) & ((i["slab"] == 0) | (i["fft_fused"] == 0) | (i["p_transpose"] == 0))).any()
         # p's row beside the first interior rows only with the edges-first integration
         assert not ((g["p_row"] == ROW_BESIDE) & (g["integrate"] != INT_EDGES_FIRST)).any()
         # um aliasing: rotation only on stage 1 of an aliased state, the skip only on stage 3, never with obstacles; and an aliased state
@@ -136,7 +139,7 @@ def test_named_configurations():
     """The rows of DESIGN.md section 7's table for the BASELINE configurations, with the library's defaults."""
     L = lib()
     dflt = dict(no_fold=0, no_alias=0, ek_always=0, halo_overlap=1, mom_pipe=1, div_in_fft=1, ptotal=1, tend_plane=0, lbuoycorr=0, stats_any=0,
-                ibm_edits_now=0, um_alias=0, open_lid=0)
+                ibm_edits_now=0, um_alias=0, open_lid=0, p_transpose=1)
 
     def one(**kw):
         i = dict(dflt, **kw)
@@ -158,10 +161,10 @@ def test_named_configurations():
     slab = dict(slab=1, comm_stream=1, sgs=2, nslots=0, ibm_on=0, fft_fused=1, own_fwd=0, between=0, closure_tile_rows=8, mom_tile_rows=8,
                 int_tile_rows=16, x_row_groups=16, levels_per_chunk=128)
     p = one(rk3step=2, **slab)
-    assert (p["fold"], p["closure"], p["mom_pipe"], p["div_in_fft"], p["vp_row"], p["p_row"], p["integrate"]) == (0, OVERLAPPED, 1, 1, ROW_PIPED, ROW_BESIDE, INT_EDGES_FIRST)
+    assert (p["fold"], p["closure"], p["mom_pipe"], p["div_in_fft"], p["vp_row"], p["p_row"], p["integrate"]) == (0, OVERLAPPED, 1, 1, ROW_PIPED, ROW_TRANSPOSED, INT_EDGES_FIRST)
     # ... the first rung below the defaults of bench.py's ladder (UDC_HALO_OVERLAP=0 UDC_MOM_PIPE=0): every exchange in line
     p = one(rk3step=2, **dict(slab, halo_overlap=0, mom_pipe=0))
-    assert (p["closure"], p["mom_pipe"], p["vp_row"], p["p_row"], p["integrate"]) == (PLAIN, 0, ROW_INLINE, ROW_INLINE, INT_ONE)
+    assert (p["closure"], p["mom_pipe"], p["vp_row"], p["p_row"], p["integrate"]) == (PLAIN, 0, ROW_INLINE, ROW_TRANSPOSED, INT_ONE)      # (p's rows still ride in the transpose: no exchange to put in line)
     # configs[4]: the cube array on eight GPUs: obstacles act between the sweep and the solve, so the sweep is not pipelined, and um is
     # never aliased; the rest still travels beside the sweeps
     p = one(rk3step=3, **dict(slab, ibm_on=1, between=1, ibm_edits_now=1, nslots=0))

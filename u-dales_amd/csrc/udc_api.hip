@@ -151,6 +151,7 @@ void udc_read_switches(Switches &sw) {
   sw.own_fwd = env_int("UDC_OWN_FWD", -1);
   sw.div_in_fft = env_int("UDC_DIV_IN_FFT", 1) != 0;
   sw.ptotal = env_int("UDC_PTOTAL", 1) != 0;
+  sw.p_transpose = env_int("UDC_P_TRANSPOSE", 1) != 0;
   sw.sv_inline = env_int("UDC_SV_INLINE", 1) != 0;
   sw.no_fold = env_int("UDC_NO_FOLD", 0) != 0;
   sw.no_alias = env_int("UDC_NO_ALIAS", 0) != 0;
@@ -1030,7 +1031,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   // tests/test_substep_plan.py enumerates it)
   PlanIn pin{};
   pin.no_fold = h->no_fold; pin.no_alias = h->no_alias;
-  pin.ek_always = h->ek_always; pin.halo_overlap = !h->no_halo_overlap; pin.mom_pipe = !h->no_mom_pipe; pin.div_in_fft = !h->no_div_in_fft; pin.ptotal = h->sw.ptotal;
+  pin.ek_always = h->ek_always; pin.halo_overlap = !h->no_halo_overlap; pin.mom_pipe = !h->no_mom_pipe; pin.div_in_fft = !h->no_div_in_fft; pin.ptotal = h->sw.ptotal; pin.p_transpose = h->sw.p_transpose;
   pin.slab = h->slab; pin.comm_stream = h->comm_stream != nullptr; pin.sgs = h->p.sgs; pin.lbuoycorr = h->lbuoycorr;
   pin.nslots = (int)h->slots.size(); pin.ibm_on = h->ibm_on; pin.stats_any = h->stats_on || h->xyt_on || h->yt_on;
   pin.fft_fused = h->fft_fused; pin.own_fwd = h->own_fwd;
@@ -1160,7 +1161,9 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   const bool lid = pin.open_lid != 0;
   if (lid && k_lid_bcpup(h, rk3coef, pup)) return 1;
   if (!h->div_in_fft && k_divergence_rhs(h, rk3coef, pup)) return 1;
+  h->p_ghost_in_transpose = plan.p_row == ROW_TRANSPOSED;
   if (k_poisson_solve(h)) return 1;
+  h->p_ghost_in_transpose = false;
   h->div_in_fft = false;
   h->mom_pipe.active = false;
   if (h->vp_halo_pending) { if (k_halo_y_join(h)) return 1; h->vp_halo_pending = false; }      // (no path leaves it pending)
@@ -1168,7 +1171,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   // y-slabs: p's ghost row (the projection of the slab's first row reads it) travels while a first part of the interior rows is
   // integrated; those rows need neither it nor anything the edge launch writes
   const bool ov_p = plan.p_row == ROW_BESIDE;
-  if (plan.p_row != ROW_FOLDED) {
+  if (plan.p_row != ROW_FOLDED && plan.p_row != ROW_TRANSPOSED) {      // (ROW_TRANSPOSED: the backward transpose brought both rows along)
     const int fp[1] = {UDC_P};
     // (only the projection of the slab's first row reads a ghost row of p: the previous rank's last row; in the pressure-total form
     // p is the new pres0 and its other ghost row travels with it -- pres0 then leaves the exchange of the velocities' rows below)

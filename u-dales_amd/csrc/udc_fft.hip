@@ -111,6 +111,11 @@ struct XArgs {
   int lL;                   // log2 of the rows per workgroup
   int jg0;                  // first row group of this launch (fftx_fwd_pack: the last group may follow vp's ghost row)
   unsigned cxmul;           // floor(2^32 / cx) + 1: kx / cx = __umulhi(kx, cxmul) for every mode index (r8 kernels)
+  // backward blocks (fftx_bwd_r8): elements per source block; ghost != 0: behind the nzc cx nyl elements of a block's own rows sit
+  // [kc][kxl][2] -- the rows just outside this slab (j = -1 from the previous rank's last row, j = nyl from the next rank's first),
+  // which the y pass put there (p's ghost rows ride in the transpose: no exchange of their own)
+  long bstride;
+  int ghost;
 };
 
 // LDS: two line buffers [L][MP], then the twiddles of the length-M transform [M], then the rank of every mode [cx*P]
@@ -281,18 +286,22 @@ __global__ __launch_bounds__(512) void fftx_bwd_r8_kernel(XArgs q, const double2
   constexpr int M = G::M, TPL = G::TPL, LP = G::LP;
   extern __shared__ double2 lds[];
   const int tid = threadIdx.x, L = 1 << q.lL;
-  const unsigned gx = (unsigned)(q.nyl >> q.lL), nitems = gx * (unsigned)q.nzc, nwg = gridDim.x;
+  const unsigned gx = (unsigned)(q.nyl >> q.lL), nmain = gx * (unsigned)q.nzc, nitems = nmain + (q.ghost ? (unsigned)q.nzc : 0u), nwg = gridDim.x;
   // item -> (row group, level of the chunk): XCD c (workgroups b % 8 == c) walks a contiguous run of (level, row group) pairs, so
-  // that row groups sharing 128-B lines of the blocks (L = 4: runs of 64 B) meet in one L2
+  // that row groups sharing 128-B lines of the blocks (L = 4: runs of 64 B) meet in one L2.  Behind them (q.ghost) one item per level
+  // for the two rows just outside the slab: j0 = -1 marks it, lines 0 and 1 are the rows j = -1 and j = nyl (the other lines of the
+  // workgroup repeat them and store nothing).
   auto decode = [&](unsigned vb, int &j0, int &kc) {
+    if (vb >= nmain) { kc = (int)(vb - nmain); j0 = -1; return; }
     unsigned v = vb;
-    if ((nitems & 7u) == 0 && (nwg & 7u) == 0) v = (vb & 7u) * (nitems >> 3) + (vb >> 3);
+    if ((nmain & 7u) == 0 && (nwg & 7u) == 0) v = (vb & 7u) * (nmain >> 3) + (vb >> 3);
     kc = (int)(v / gx);
     j0 = (int)(v - (unsigned)kc * gx) << q.lL;
   };
   auto src = [&](int kx, int l, int j0, int kc) {
     const int s_ = (int)__umulhi((unsigned)kx, q.cxmul), kxl = kx - s_ * q.cx;
-    return recv[(((size_t)s_ * q.nzc + kc) * q.cx + kxl) * q.nyl + j0 + l];
+    const size_t b = (size_t)s_ * q.bstride, col = (size_t)kc * q.cx + kxl;
+    return j0 < 0 ? recv[b + (size_t)q.nzc * q.cx * q.nyl + col * 2 + (l & 1)] : recv[b + col * q.nyl + j0 + l];
   };
   // pairs (kx, M - kx), kx = 0 .. M/2 (kx = 0 pairs X[0] with X[M]; kx = M/2 with itself), l fastest: runs of L complex in the blocks
   constexpr int IT = (M / 2) / TPL;      // = 4 passes of all threads, then the L pairs kx = M/2
@@ -335,9 +344,12 @@ __global__ __launch_bounds__(512) void fftx_bwd_r8_kernel(XArgs q, const double2
     decode(vb, j0, kc);
     double2 x[8];
     r8_stages<true, LM>(lds + l * LP, t, tws, x);
-    double2 *row = reinterpret_cast<double2 *>(p + q.sz * (long)(q.k0 + kc + HZ) + (long)q.sy * (j0 + l + HY));
+    const int jrow = j0 < 0 ? ((l & 1) ? q.nyl : -1) : j0 + l;
+    double2 *row = reinterpret_cast<double2 *>(p + q.sz * (long)(q.k0 + kc + HZ) + (long)q.sy * (jrow + HY));
+    if (j0 >= 0 || l < 2) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) row[t + r * TPL] = x[r];
+      for (int r = 0; r < 8; ++r) row[t + r * TPL] = x[r];
+    }
     __syncthreads();                             // the last stage's reads are done before the next item is placed
   }
 }
@@ -347,7 +359,23 @@ struct YArgs {
   int nyl, lnyl, cx, P;     // local rows and their log2
   int k0, nzc;
   int C;                    // columns (kx_l) per workgroup
+  long bstride;             // backward pack: elements per destination block (nzc cx nyl, + nzc cx 2 with the ghost rows)
+  int ghost;                // backward pack: also leave every slab's edge rows in the neighbouring blocks' ghost slots
 };
+// element of the ghost slots of block e: row g (0: j = -1, 1: j = nyl) of column kxl at chunk level kc
+__device__ __forceinline__ size_t ghost_off(const YArgs &q, int e, int kc, int kxl, int g_) {
+  return (size_t)e * q.bstride + (size_t)q.nzc * q.cx * q.nyl + ((size_t)kc * q.cx + kxl) * 2 + g_;
+}
+// backward pack: where line element y of column kxl goes -- its own block, and (edge rows) a neighbour's ghost slot
+template <class F>
+__device__ __forceinline__ void bwd_store(const YArgs &q, double2 *__restrict__ send, int kc, int kxl, int y, double2 v, F) {
+  const int d_ = y >> q.lnyl, j = y & (q.nyl - 1);
+  send[(size_t)d_ * q.bstride + ((size_t)kc * q.cx + kxl) * q.nyl + j] = v;
+  if (q.ghost) {
+    if (j == q.nyl - 1) send[ghost_off(q, d_ + 1 == q.P ? 0 : d_ + 1, kc, kxl, 0)] = v;
+    if (j == 0) send[ghost_off(q, d_ == 0 ? q.P - 1 : d_ - 1, kc, kxl, 1)] = v;
+  }
+}
 
 // y forward: recv[s][kc][kxl][j] -> C2C -> specB[k][kxl][y]
 template <int LM>
@@ -392,8 +420,7 @@ __global__ __launch_bounds__(FT) void ffty_bwd_pack_kernel(YArgs q, const double
   double2 *z = fft_lines<true, LM>(a, b, tw, q.MP, ncol);
   for (int wi = tid; wi < (ncol << LM); wi += FT) {
     const int col = wi >> LM, y = wi & (M - 1);
-    const int d_ = y >> q.lnyl, j = y & (q.nyl - 1);
-    send[(((size_t)d_ * q.nzc + kc) * q.cx + c0 + col) * q.nyl + j] = z[col * q.MP + pad(y)];
+    bwd_store(q, send, kc, c0 + col, y, z[col * q.MP + pad(y)], 0);
   }
 }
 
@@ -618,7 +645,7 @@ __global__ __launch_bounds__(256) void ffty_slabreg_kernel(YArgs q, const double
 #pragma unroll
     for (int k2 = 0; k2 < N2; ++k2) {
       const int y = t + 16 * k2;
-      if (INV) out[xoff(y)] = cconj(x[regpos<N2>(k2)]);
+      if (INV) bwd_store(q, out, kc, c0 + col, y, cconj(x[regpos<N2>(k2)]), 0);
       else out[lineB + y] = x[regpos<N2>(k2)];
     }
   }
@@ -703,10 +730,10 @@ static XArgs xargs(const udc_handle *h, int k0, int nzc) {
   const Geo &g = h->g;
   const int M = g.nx / 2;
   return XArgs{g.nx, M, padded(M + 1), g.ny, g.py, g.sy, g.sz, h->nkx, h->cx, h->cfg.nranks, k0, nzc, ilog2(h->fft_L), 0,
-               (unsigned)((1ULL << 32) / (unsigned long long)h->cx + 1ULL)};
+               (unsigned)((1ULL << 32) / (unsigned long long)h->cx + 1ULL), (long)nzc * h->cx * g.ny, 0};
 }
 static YArgs yargs(const udc_handle *h, int k0, int nzc) {
-  return YArgs{h->jtot, padded(h->jtot), h->g.ny, ilog2(h->g.ny), h->cx, h->cfg.nranks, k0, nzc, h->fft_C};
+  return YArgs{h->jtot, padded(h->jtot), h->g.ny, ilog2(h->g.ny), h->cx, h->cfg.nranks, k0, nzc, h->fft_C, (long)nzc * h->cx * h->g.ny, 0};
 }
 
 int fft_x_row_groups(const udc_handle *h) { return h->g.ny / h->fft_L; }
@@ -739,13 +766,16 @@ static int r8_rows(const udc_handle *h) {
   while (L > 1 && h->g.ny % L) L >>= 1;
   return L;
 }
-int fft_x_bwd_unpack(udc_handle *h, int k0, int nzc, const double *recv) {
+// ghost: the blocks carry the two rows just outside the slab behind their own (fft_y_bwd_pack put them there): p's ghost rows are
+// transformed and stored with the others
+int fft_x_bwd_unpack(udc_handle *h, int k0, int nzc, const double *recv, bool ghost) {
   XArgs q = xargs(h, k0, nzc);
+  if (ghost) { q.ghost = 1; q.bstride = (long)nzc * h->cx * (h->g.ny + 2); }
   const double2 *tw = reinterpret_cast<const double2 *>(h->fft_tw);
   const int L = r8_rows(h), tpl = q.M / 8;
   q.lL = ilog2(L);
   const size_t lds = r8_lds_bytes(q.M, L);
-  const unsigned items = (unsigned)(q.nyl >> q.lL) * (unsigned)nzc;
+  const unsigned items = (unsigned)(q.nyl >> q.lL) * (unsigned)nzc + (ghost ? (unsigned)nzc : 0u);
   // persistent workgroups: as many as are resident at once (LDS, 2048 threads per CU)
   const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(160 * 1024 / lds, 2048 / (size_t)(L * tpl)));
   const dim3 gr(std::min(items, 256u * per_cu));
@@ -780,8 +810,9 @@ int fft_y_fwd_unpack(udc_handle *h, int k0, int nzc, const double *recv) {
   HIP_OK(hipGetLastError());
   return 0;
 }
-int fft_y_bwd_pack(udc_handle *h, int k0, int nzc, double *send) {
-  const YArgs q = yargs(h, k0, nzc);
+int fft_y_bwd_pack(udc_handle *h, int k0, int nzc, double *send, bool ghost) {
+  YArgs q = yargs(h, k0, nzc);
+  if (ghost) { q.ghost = 1; q.bstride = (long)nzc * h->cx * (h->g.ny + 2); }
   const double2 *tw = reinterpret_cast<const double2 *>(h->fft_tw) + (h->g.nx / 2) + (h->g.nx / 2 + 1);
   if (h->slab_yreg) return launch_slab_yreg<true>(h, q, reinterpret_cast<const double2 *>(h->specB), tw, reinterpret_cast<double2 *>(send));
   const dim3 gr((unsigned)((q.cx + q.C - 1) / q.C), (unsigned)nzc);

@@ -150,6 +150,7 @@ struct Switches {
   int own_fwd = -1;          // UDC_OWN_FWD=0/1: single-slab forward half in own kernels
   int div_in_fft = 1;        // UDC_DIV_IN_FFT=0: separate divergence kernel on the slab path
   int sv_inline = 1;         // UDC_SV_INLINE=0: no scalar takes its RK3 update inside its sweep
+  int p_transpose = 1;       // UDC_P_TRANSPOSE=0: p's ghost rows travel in an exchange of their own, not inside the backward transpose
   int ptotal = 1;            // UDC_PTOTAL=0: the fused substep keeps pres0 and p apart like the reference (single slab: no pressure-total form)
   int no_fold = 0, no_alias = 0;      // UDC_NO_FOLD / UDC_NO_ALIAS = 1
   int ek_always = 0;         // UDC_EK_ALWAYS=1: every substep writes ekm / ekh
@@ -387,6 +388,7 @@ struct udc_handle {
   // row 0 was swept first over all levels and its row is already travelling (UDC_MOM_PIPE=1)
   struct MomPipe { bool active = false, forces = false, um_is_u0 = false, bottom = false, pgrad = true, rows_all = false; double rk3coefi = 0.; } mom_pipe;
   bool no_mom_pipe = false;             // UDC_MOM_PIPE=0
+  bool p_ghost_in_transpose = false;    // this solve's backward blocks carry p's two ghost rows (substep_fused asked; k_poisson_solve_slab)
   bool vp_halo_pending = false;         // vp's ghost row is travelling (k_halo_y_begin): the x forward transform joins before its last row group
   bool no_halo_overlap = false;         // UDC_HALO_OVERLAP=0: every ghost-row exchange in line on the compute stream
   double *specA = nullptr, *specB = nullptr, *a2a_send = nullptr, *a2a_recv = nullptr;
@@ -526,9 +528,9 @@ int fft_nat_init(udc_handle *h);
 int fft_nat_forward(udc_handle *h);
 int fft_x_fwd_pack(udc_handle *h, int k0, int nzc, double *send, int g0 = 0, int g1 = 0, hipStream_t st = nullptr);      // row groups [g0, g1); g1 <= 0: all
 int fft_x_row_groups(const udc_handle *h);
-int fft_x_bwd_unpack(udc_handle *h, int k0, int nzc, const double *recv);
+int fft_x_bwd_unpack(udc_handle *h, int k0, int nzc, const double *recv, bool ghost = false);
 int fft_y_fwd_unpack(udc_handle *h, int k0, int nzc, const double *recv);
-int fft_y_bwd_pack(udc_handle *h, int k0, int nzc, double *send);
+int fft_y_bwd_pack(udc_handle *h, int k0, int nzc, double *send, bool ghost = false);
 // udc_comm.hip
 int comm_neighbours(udc_handle *h, const double *to_prev, const double *to_next, double *from_prev,
                     double *from_next, size_t count, hipStream_t st = nullptr, int dirs = 3);      // st: the stream it runs on (default h->stream); dirs: HALO_*

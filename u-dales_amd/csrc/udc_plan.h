@@ -23,6 +23,7 @@ struct PlanIn {
   int closure_tile_rows, mom_tile_rows, int_tile_rows;      // tile rows of the three sweeps on this slab
   int x_row_groups;     // row groups of the x forward transform
   int levels_per_chunk; // nz / k-chunks of the transposes
+  int p_transpose;      // switch UDC_P_TRANSPOSE: p's ghost rows ride in the backward transpose of the slab solve (own line transforms)
   int open_lid;         // BCtopm = 3 (BCtopm_pressure): w(ke+1) is prognostic -- bcpup, tderive and tstep_integrate have a row there,
                         // taken by three plane kernels beside the sweeps (k_lid_*, udc_pois.hip)
   // this call
@@ -32,7 +33,7 @@ struct PlanIn {
 };
 
 enum PlanClosure { CLOSURE_FOLDED = 0, CLOSURE_OVERLAPPED = 1, CLOSURE_PLAIN = 2 };
-enum PlanRow { ROW_FOLDED = 0, ROW_BESIDE = 1, ROW_INLINE = 2, ROW_PIPED = 3 };
+enum PlanRow { ROW_FOLDED = 0, ROW_BESIDE = 1, ROW_INLINE = 2, ROW_PIPED = 3, ROW_TRANSPOSED = 4 };
 enum PlanIntegrate { INT_ONE = 0, INT_EDGES_FIRST = 1 };
 
 struct Plan {
@@ -45,7 +46,7 @@ struct Plan {
   int mom_pipe;         // momentum sweep cut along the solve's k-chunks, under the forward transposes
   int div_in_fft;       // fillps' divergence inside the x forward transform
   int vp_row;           // PlanRow: vp's ghost row
-  int p_row;            // PlanRow: p's ghost row (FOLDED / BESIDE the first interior rows / INLINE)
+  int p_row;            // PlanRow: p's ghost row (FOLDED / inside the backward TRANSPOSE / BESIDE the first interior rows / INLINE)
   int integrate;        // PlanIntegrate
   int ptotal;           // pressure-total form: the momentum sweep leaves the gradient of pres0 out, the solve returns pres0 + p, the
                         // projection applies it as a whole and it becomes pres0 (arrays swapped): pres0 is read nowhere in the substep
@@ -88,7 +89,10 @@ inline Plan plan_substep(const PlanIn &in) {
   else p.vp_row = ROW_FOLDED;
   if (p.fold) { p.p_row = ROW_FOLDED; p.integrate = INT_ONE; }
   else {
-    p.p_row = (plan_halo_overlap(in, in.int_tile_rows) && in.int_tile_rows >= 4) ? ROW_BESIDE : ROW_INLINE;
+    // y-slabs with the own line transforms: the y pass leaves every slab's edge rows in the neighbours' blocks as well and the x pass
+    // transforms them with the rest (2 rows in ny_l more per transpose) -- no exchange of p's rows, no sweep to hide it behind
+    if (in.slab && in.fft_fused && in.p_transpose) p.p_row = ROW_TRANSPOSED;
+    else p.p_row = (plan_halo_overlap(in, in.int_tile_rows) && in.int_tile_rows >= 4) ? ROW_BESIDE : ROW_INLINE;
     p.integrate = plan_halo_overlap(in, in.int_tile_rows) ? INT_EDGES_FIRST : INT_ONE;
   }
   // The reference adds -grad pres0 to the tendencies (advecu/v/w) and solves for the increment p (fillps .. tderive, pres0 += p).  The

@@ -1067,8 +1067,10 @@ int pois_slab_init(udc_handle *h) {
   HIP_OK(hipMalloc(&h->specA, sizeof(double) * 2 * nkxp * rows));
   HIP_OK(hipMemsetAsync(h->specA, 0, sizeof(double) * 2 * nkxp * rows, h->stream));
   HIP_OK(hipMalloc(&h->specB, sizeof(double) * 2 * nmodes * nz));
-  HIP_OK(hipMalloc(&h->a2a_send, sizeof(double) * 2 * nmodes * nz));
-  HIP_OK(hipMalloc(&h->a2a_recv, sizeof(double) * 2 * nmodes * nz));
+  // (+ 2 rows per block: the backward blocks may carry p's ghost rows, fft_y_bwd_pack)
+  const size_t a2a_doubles = (size_t)2 * cx * ((size_t)ny + 2 * (size_t)P) * nz;
+  HIP_OK(hipMalloc(&h->a2a_send, sizeof(double) * a2a_doubles));
+  HIP_OK(hipMalloc(&h->a2a_recv, sizeof(double) * a2a_doubles));
   HIP_OK(hipMalloc(&h->ev_slab, sizeof(double) * nmodes));
   h->thomas_lds_slab = thomas_wants_lds(h, (long)nmodes, nz);
   HIP_OK(hipMalloc(&h->ztab_slab, sizeof(double) * ztab_doubles((long)nmodes, nz)));
@@ -1146,11 +1148,15 @@ int k_poisson_solve_slab(udc_handle *h) {
   // blocks are the packed ones
   const bool self = P == 1 && !h->nccl && !h->local_group;
   double *const rbuf = self ? h->a2a_send : h->a2a_recv;
-  auto exchange = [&](int c) -> int {
+  // backward blocks with p's two ghost rows behind the slab's own (substep_fused asked for them; own line transforms only)
+  const bool pg = h->p_ghost_in_transpose && h->fft_fused;
+  const size_t blockB = pg ? (size_t)2 * nzc * cx * (g.ny + 2) : block, chunkB = blockB * P;
+  auto exchange = [&](int c, bool back = false) -> int {
     if (self) return 0;
     HIP_OK(hipEventRecord(h->ev_ready[c], h->stream));
     HIP_OK(hipStreamWaitEvent(h->comm_stream, h->ev_ready[c], 0));
-    if (comm_alltoall(h, h->a2a_send + chunk * c, rbuf + chunk * c, block, h->comm_stream)) return 1;
+    const size_t ch = back ? chunkB : chunk;
+    if (comm_alltoall(h, h->a2a_send + ch * c, rbuf + ch * c, back ? blockB : block, h->comm_stream)) return 1;
     HIP_OK(hipEventRecord(h->ev_done[c], h->comm_stream));
     return 0;
   };
@@ -1226,14 +1232,14 @@ int k_poisson_solve_slab(udc_handle *h) {
     for (int c = 0; c < nch; ++c) {
       const int k0 = c * nzc;
       if (h->fft_fused) {
-        if (fft_y_bwd_pack(h, k0, nzc, h->a2a_send + chunk * c)) return 1;
+        if (fft_y_bwd_pack(h, k0, nzc, h->a2a_send + chunkB * c, pg)) return 1;
       } else {
         void *io[1] = {specB_at(k0)};
         FFT_OK(rocfft_execute(h->plan_yb, io, nullptr, h->info_x));
         hipLaunchKernelGGL(slab_pack_bwd_kernel, lin3, dim3(lb), 0, h->stream, g, cx, P, ny, k0, nzc,
                            reinterpret_cast<const double2 *>(h->specB), reinterpret_cast<double2 *>(h->a2a_send + chunk * c));
       }
-      if (exchange(c)) return 1;
+      if (exchange(c, true)) return 1;
     }
     HIP_OK(hipGetLastError());
   }
@@ -1243,7 +1249,7 @@ int k_poisson_solve_slab(udc_handle *h) {
       const int k0 = c * nzc;
       if (!self) HIP_OK(hipStreamWaitEvent(h->stream, h->ev_done[c], 0));
       if (h->fft_fused) {
-        if (fft_x_bwd_unpack(h, k0, nzc, rbuf + chunk * c)) return 1;
+        if (fft_x_bwd_unpack(h, k0, nzc, rbuf + chunkB * c, pg)) return 1;
         continue;
       }
       hipLaunchKernelGGL(slab_unpack_bwd_kernel, tg, tb, 0, h->stream, g, nkx, pitch, cx, P, k0, nzc,

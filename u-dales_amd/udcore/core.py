@@ -101,7 +101,7 @@ class DynCore:
         """The order the last fused substep ran in (udc_last_plan)."""
         o = (C.c_int * 16)()
         L._check(self.lib.udc_last_plan(self.h, o), "udc_last_plan")
-        row = ("folded", "beside a sweep", "in line", "ahead of the pipelined sweep")
+        row = ("folded", "beside a sweep", "in line", "with the pipelined sweep", "inside the backward transpose")
         return {"ghost_rows_folded": bool(o[0]), "closure": ("folded", "edge rows first, ekm rows beside the interior", "plain")[o[1]],
                 "ekh_written": bool(o[2]), "momentum_sweep_pipelined_with_solve": bool(o[3]), "divergence_in_x_transform": bool(o[4]),
                 "vp_ghost_row": row[o[5]], "p_ghost_row": row[o[6]],
