@@ -111,7 +111,7 @@ int udc_comm_dry_run(udc_handle *h, int on);
 /* The order the last fused substep ran in, as plan_substep decided it (udc_plan.h; DESIGN.md "order of a substep"): out[0] ghost rows
  * folded into the kernels (single slab), [1] closure 0 folded / 1 edge rows first, rows travel beside the interior / 2 plain,
  * [2] ekh written, [3] momentum sweep pipelined with the solve's k-chunks, [4] divergence inside the x transform, [5] vp's and
- * [6] p's ghost row: 0 folded / 1 beside a sweep / 2 in line / 3 ahead of the pipelined sweep, [7] integration 0 one launch / 1 edge
+ * [6] p's ghost row: 0 folded / 1 beside a sweep / 2 in line / 3 with the pipelined sweep / 4 inside the backward transpose, [7] integration 0 one launch / 1 edge
  * rows first, [8] um rotated, [9] um left aliased, [10] um materialised, [11] slab layout, [12] own line transforms on the slab path,
  * [13] k-chunks of the transposes, [14] own forward half (one GPU), [15] bit 0: pressure-total form (see udc_substep), bits 1..: how
  * many scalars took their RK3 update inside their own sweep. */
@@ -359,7 +359,9 @@ int udc_tstep_maxima(udc_handle *h, double dt, double *courtot, double *diffnrto
  * By default in the pressure-total form (UDC_PTOTAL=0: off): the momentum sweep leaves -grad pres0
  * (src/modadvection.f90:187,245,309) out, the solve returns pres0 + p, the projection applies that and it becomes pres0 -- the same
  * velocities and pres0 to round-off, with pres0 read nowhere.  After such a substep the array `p` (UDC_P) is scratch: it holds the
- * previous pres0, not the increment (udc_poisson called on its own leaves the increment there as the reference does). */
+ * previous pres0, not the increment (udc_poisson called on its own leaves the increment there as the reference does), and
+ * udc_field_download(UDC_P) says so instead of handing it out.  Not with an open lid (BCtopm = 3), a prescribed outflow rate, or a
+ * volume flow over an immersed boundary: the reference's form there. */
 int udc_substep(udc_handle *h, int rk3step, double dt, int with_forces);
 /* n substeps with fixed dt, rk3step cycling 1,2,3 starting from rk3step0 */
 int udc_run(udc_handle *h, int nsubsteps, int rk3step0, double dt, int with_forces);

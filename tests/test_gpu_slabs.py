@@ -323,6 +323,9 @@ def _run_virtual(P, g, deck_like, st_global, nsub, dt, sgs, nsv=0, extras=False)
                                                      ((32, 16, 12), 2, 3, False), ((32, 16, 12), 2, 1, 1),
                                                      ((32, 16, 12), 2, 2, 2),
                                                      ((128, 64, 16), 2, 2, False), ((64, 32, 8), 1, 4, 1),
+                                                     # slabs of 64 / 32 rows on 2 / 4 ranks: the momentum sweep pipelined with four k-chunks
+                                                     # (vp's ghost row handed on chunk by chunk), p's ghost rows inside the backward transpose
+                                                     ((64, 128, 16), 2, 4, False),
                                                      # rows of 512 cells carry a line of padding (Geo.sy = nx + 16): halo packs, own line
                                                      # FFTs and the exchange buffers across slabs; 272 levels: the wave-specialised Thomas
                                                      # kernel (two-workgroup occupancy) on the slabs' share of the modes

@@ -71,13 +71,15 @@ def table(i):
                 need_ekh=need_ekh, mom_pipe=pipe, div_in_fft=div, vp_row=vp, p_row=prow, integrate=integ, ptotal=ptot)
 
 
-def lattice():
-    """every configuration / call for one setting of the eight switches"""
+def lattice(p_transpose=1, open_lid=0):
+    """every configuration / call for one setting of the switches (and of the two inputs that are fixed per handle)"""
     axes = dict(slab=[0, 1], sgs=[0, 1, 2, 3], lbuoycorr=[0, 1], nslots=[0, 2], ibm_on=[0, 1], stats_any=[0, 1], fft_fused=[0, 1],
-                own_fwd=[0, 1], tend_plane=[0, 1], between=[0, 1], rows=[2, 3, 8], x_row_groups=[1, 4], levels_per_chunk=[2, 16], p_transpose=[0, 1], open_lid=[0, 1], rk3step=[1, 2, 3],
+                own_fwd=[0, 1], tend_plane=[0, 1], between=[0, 1], rows=[2, 3, 8], x_row_groups=[1, 4], levels_per_chunk=[2, 16], rk3step=[1, 2, 3],
                 um_alias=[0, 1], ibm_edits_now=[0, 1])
     grids = np.meshgrid(*[np.array(v, dtype=np.int32) for v in axes.values()], indexing="ij")
     cols = {k: g.ravel() for k, g in zip(axes, grids)}
+    cols["p_transpose"] = np.full_like(cols["slab"], p_transpose)
+    cols["open_lid"] = np.full_like(cols["slab"], open_lid)
     cols["comm_stream"] = cols["slab"].copy()      # (the communication stream exists exactly where the slab layout was set up)
     for k in ("closure_tile_rows", "mom_tile_rows", "int_tile_rows"):
         cols[k] = cols["rows"]
@@ -87,10 +89,17 @@ def lattice():
 
 def test_every_combination_matches_the_table_and_is_safe():
     L = lib()
-    base = lattice()
-    n = len(base["slab"])
     total = 0
-    for sw in itertools.product([0, 1], repeat=7):
+    # every setting of the seven order switches for the usual handle (closed lid, p's rows inside the transpose); every 8th setting
+    # for the other three kinds of handle
+    runs = [(1, 0, sw) for sw in itertools.product([0, 1], repeat=7)]
+    runs += [(pt, lid, sw) for pt, lid in ((0, 0), (1, 1), (0, 1)) for q, sw in enumerate(itertools.product([0, 1], repeat=7)) if q % 8 == 3]
+    bases = {}
+    for pt, lid, sw in runs:
+        if (pt, lid) not in bases:
+            bases[(pt, lid)] = lattice(pt, lid)
+        base = bases[(pt, lid)]
+        n = len(base["slab"])
         i = dict(base)
         for name, v in zip(IN[:7], sw):
             i[name] = np.full(n, v, dtype=np.int32)
@@ -132,7 +141,7 @@ def test_every_combination_matches_the_table_and_is_safe():
         lid = i["open_lid"] == 1
         assert not (lid & (pt | (g["div_in_fft"] == 1) | (g["mom_pipe"] == 1) | (g["skip_um"] == 1) | (g["rotate"] == 1))).any()
         total += n
-    assert total == 128 * n and n > 100000
+    assert total == len(runs) * n and len(runs) == 128 + 3 * 16 and n > 100000
 
 
 def test_named_configurations():

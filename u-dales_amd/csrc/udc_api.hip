@@ -377,6 +377,7 @@ extern "C" int udc_field_upload(udc_handle *h, int field, const double *host, co
   if (copy3d(h, field, const_cast<double *>(host), lb, ub, true)) return 1;
   if (field == UDC_EKM || field == UDC_EKH) h->ek_stale = false;
   if (field == UDC_EKH) h->ekh_stale = false;
+  if (field == UDC_P) h->p_scratch = false;
   if (h->scal_bcx == 2 && field >= UDC_SV0 && (field - UDC_SV0) % 3 == 0)      // sv0 with its east ghost columns (BCxs = 2)
     return k_scalar_bcx_capture(h, (field - UDC_SV0) / 3, host, lb, ub);
   return 0;
@@ -431,6 +432,11 @@ static int ek_current(udc_handle *h, const char *who, bool ekh_only = false) {
 extern "C" int udc_field_download(udc_handle *h, int field, double *host, const int lb[3], const int ub[3]) {
   ENTRY_FLUSH(h);
   if ((field == UDC_EKM || field == UDC_EKH) && ek_current(h, "udc_field_download", field == UDC_EKH)) return 1;
+  if (field == UDC_P && h->p_scratch) {
+    udc_set_error("udc_field_download: p is scratch after a fused substep in the pressure-total form (it holds the previous pres0, not the "
+                  "increment; udc_poisson leaves the reference's p, UDC_PTOTAL=0 keeps it in the fused substep too)");
+    return 1;
+  }
   if (copy3d(h, field, host, lb, ub, false)) return 1;
   if (h->scal_bcx == 2 && field >= UDC_SV0 && (field - UDC_SV0) % 3 == 0)      // sv0: its x ghost columns under BCxs = 2
     return k_scalar_bcx_fill_host(h, (field - UDC_SV0) / 3, host, lb, ub);
@@ -907,6 +913,7 @@ static int now_poisson(udc_handle *h, int rk3step, double dt) {
   if (k_poisson_solve(h)) return 1;
   const int fp[1] = {UDC_P};
   if (k_halo_y(h, fp, 1, 1)) return 1;              // bcp
+  h->p_scratch = false;
   if (k_project(h)) return 1;                       // tderive
   if (lid && k_lid_tderive(h)) return 1;            // src/modpois.f90:1058-1069
   const int fpr[1] = {UDC_PRES0};
@@ -1215,7 +1222,8 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
     if (k_halo_y_join(h)) return 1;
   } else if (k_project_integrate(h, rk3step, dt, !lds, pup, fold, !skip_um, rotate, 0, 0, 0, ptot)) return 1;
   h->ptotal_now = false;
-  if (ptot) std::swap(h->fields[UDC_P], h->fields[UDC_PRES0]);
+  if (ptot) { std::swap(h->fields[UDC_P], h->fields[UDC_PRES0]); h->p_scratch = true; }
+  else h->p_scratch = false;
   for (int n : h->slots) {
     if (!h->sv_inline[n]) continue;
     // the array the sweep wrote is the scalar now; the planes below the floor (never written by a kernel: what the start-up put there) go along
@@ -1252,6 +1260,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
 
 extern "C" int udc_last_plan(udc_handle *h, int out[16]) {
   if (!h || !out) { udc_set_error("udc_last_plan: null argument"); return 1; }
+  ENTRY_FLUSH(h);      // (deferred execution: the plan asked for is the one of the substep recorded last, not of an older one)
   if (!h->have_plan) { udc_set_error("udc_last_plan: no fused substep has run on this handle"); return 1; }
   const Plan &p = h->last_plan;
   const int v[16] = {p.fold, p.closure, p.need_ekh, p.mom_pipe, p.div_in_fft, p.vp_row, p.p_row, p.integrate, p.rotate, p.skip_um,

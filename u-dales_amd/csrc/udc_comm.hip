@@ -166,8 +166,11 @@ struct CommScope {
   udc_handle *h; hipStream_t st; hipEvent_t b = nullptr;
   CommScope(udc_handle *h_, hipStream_t st_, int kind) : h(h_), st(st_) {
     if (!h->comm_timing) return;
+    // (bounded: a caller that switches the timing on and never collects -- udc_comm_stats mode 1 / 2 -- stops adding pairs here)
+    if (h->ctimed.size() >= 65536) return;
     hipEvent_t a = nullptr;
-    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { b = nullptr; return; }
+    if (hipEventCreate(&a) != hipSuccess) return;
+    if (hipEventCreate(&b) != hipSuccess) { hipEventDestroy(a); b = nullptr; return; }
     hipEventRecord(a, st);
     h->ctimed.push_back({a, b, kind});
   }
@@ -193,6 +196,7 @@ extern "C" int udc_comm_info(udc_handle *h, int info[8]) {
 extern "C" int udc_comm_stats(udc_handle *h, int mode, double out[16]) {
   if (!h) { udc_set_error("udc_comm_stats: null handle"); return 1; }
   HIP_OK(hipSetDevice(h->device));
+  if (udc_flush_pending(h)) return 1;      // (deferred execution: the counters include the substeps recorded so far)
   if (mode == 1) {
     HIP_OK(hipDeviceSynchronize());
     for (auto &t : h->ctimed) { hipEventDestroy(t.a); hipEventDestroy(t.b); }

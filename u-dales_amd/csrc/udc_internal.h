@@ -388,6 +388,7 @@ struct udc_handle {
   // row 0 was swept first over all levels and its row is already travelling (UDC_MOM_PIPE=1)
   struct MomPipe { bool active = false, forces = false, um_is_u0 = false, bottom = false, pgrad = true, rows_all = false; double rk3coefi = 0.; } mom_pipe;
   bool no_mom_pipe = false;             // UDC_MOM_PIPE=0
+  bool p_scratch = false;               // the last fused substep ran in the pressure-total form: UDC_P holds the previous pres0 (download refused)
   bool p_ghost_in_transpose = false;    // this solve's backward blocks carry p's two ghost rows (substep_fused asked; k_poisson_solve_slab)
   bool vp_halo_pending = false;         // vp's ghost row is travelling (k_halo_y_begin): the x forward transform joins before its last row group
   bool no_halo_overlap = false;         // UDC_HALO_OVERLAP=0: every ghost-row exchange in line on the compute stream

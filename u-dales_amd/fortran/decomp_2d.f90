@@ -14,7 +14,8 @@
 !   exchange_halo_z : whole padded rows to the two y neighbours -- always between neighbouring slabs, from the last slab to the first
 !                     only where y is periodic (BCym of the deck; read from the deck file where the deck itself did not split y) --
 !                     after wrapping the x ghosts where the DECK split x periodically (the solver then expects them from here);
-!   transposes      : z <-> y is one MPI_ALLTOALL of equal blocks (jtot and ktot divisible by the ranks), y <-> x a copy -- used by
+!   transposes      : z <-> y is an exchange of equal blocks with every rank (pairwise MPI_SENDRECV rounds; jtot and ktot divisible by
+!                     the ranks), y <-> x a copy -- used by
 !                     the reference's own modpois only (the CPU baseline of oracle/Makefile; the drop-in modpois never calls them).
 ! The all-reference MPI builds of oracle/Makefile (the CPU baseline) link this file too: the reference's own program then runs an
 ! x-split deck as slabs as well (tests/test_oracle_mpi.py: 2 x 1 and 2 x 2 decks against the one-rank build); rank 0 says so in a line.
@@ -259,6 +260,33 @@ contains
   end subroutine unsupported_complex
 
   ! z-pencil (nx, ny/P, nz) -> y-pencil (nx, ny, nz/P): block d holds my rows, z-slab of rank d
+  !> Equal blocks to every rank.  Pairwise MPI_SENDRECV rounds by default -- in round r a rank sends to mycol + r and receives from
+  !! mycol - r, one pair of blocks in flight per rank --; UDC_DECOMP_ALLTOALL=1: one MPI_ALLTOALL (MPICH 3.3's shared-memory all-to-all
+  !! of these 0.1 - 1 MB blocks stops scaling at 16 ranks of a 128-core host: the CPU baseline of bench.py fell from 16 to 32 ranks).
+  subroutine blocks_to_all(sbuf, rbuf, blk)
+    real(mytype), intent(in) :: sbuf(:)
+    real(mytype), intent(out) :: rbuf(:)
+    integer, intent(in) :: blk
+    integer :: r, to, from, ierr, st(MPI_STATUS_SIZE), stat
+    character(8) :: env
+    logical, save :: first = .true., collective = .false.
+    if (first) then
+      call get_environment_variable('UDC_DECOMP_ALLTOALL', env, status=stat)
+      collective = stat == 0 .and. trim(env) == '1'
+      first = .false.
+    end if
+    if (collective) then
+      call MPI_ALLTOALL(sbuf, blk, MPI_DOUBLE_PRECISION, rbuf, blk, MPI_DOUBLE_PRECISION, DECOMP_2D_COMM_CART_Z, ierr)
+      return
+    end if
+    rbuf(mycol*blk + 1:(mycol + 1)*blk) = sbuf(mycol*blk + 1:(mycol + 1)*blk)
+    do r = 1, pcol - 1
+      to = mod(mycol + r, pcol); from = mod(mycol - r + pcol, pcol)
+      call MPI_SENDRECV(sbuf(to*blk + 1), blk, MPI_DOUBLE_PRECISION, to, 7, rbuf(from*blk + 1), blk, MPI_DOUBLE_PRECISION, from, 7, &
+                        DECOMP_2D_COMM_CART_Z, st, ierr)
+    end do
+  end subroutine blocks_to_all
+
   subroutine z_to_y_real(src, dst, opt_decomp)
     real(mytype), dimension(:, :, :), intent(in) :: src
     real(mytype), dimension(:, :, :), intent(out) :: dst
@@ -281,7 +309,7 @@ contains
         end do
       end do
     end do
-    call MPI_ALLTOALL(sbuf, blk, MPI_DOUBLE_PRECISION, rbuf, blk, MPI_DOUBLE_PRECISION, DECOMP_2D_COMM_CART_Z, ierr)
+    call blocks_to_all(sbuf, rbuf, blk)
     do d = 0, pcol - 1
       o = d*blk
       do k = 1, nzl
@@ -312,7 +340,7 @@ contains
         end do
       end do
     end do
-    call MPI_ALLTOALL(sbuf, blk, MPI_DOUBLE_PRECISION, rbuf, blk, MPI_DOUBLE_PRECISION, DECOMP_2D_COMM_CART_Z, ierr)
+    call blocks_to_all(sbuf, rbuf, blk)
     do d = 0, pcol - 1
       o = d*blk
       do k = 1, nzl
