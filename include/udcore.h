@@ -101,8 +101,8 @@ int udc_comm_init(udc_handle *h, const unsigned char id[128]);
  * (2decomp-fft's decomp_2d_init prints its own layout, src/modstartup.f90:676). */
 int udc_comm_info(udc_handle *h, int info[8]);
 /* Exchange bookkeeping.  mode 1: reset the counters and time every exchange from now on with a pair of events on the stream it runs
- * on; mode 0: read (waits for the device); mode 2: read and stop timing.  out[0] all-to-all operations, [1] bytes one of them sends
- * to ONE peer, [2] bytes sent to other ranks by all of them, [3] their time on the communication stream (ms, sum); [4] ghost-row
+ * on; mode 0: read (waits for the device); mode 2: read and stop timing.  out[0] all-to-all operations, [1] bytes one of them (the last: a backward transpose, with p's ghost rows
+ * when they ride along) sends to ONE peer, [2] bytes sent to other ranks by all of them, [3] their time on the communication stream (ms, sum); [4] ghost-row
  * exchanges, [5] bytes sent to the previous rank, [6] to the next, [7] their time (ms, sum); [8] all-reduces, [9] doubles reduced. */
 int udc_comm_stats(udc_handle *h, int mode, double out[16]);
 /* on != 0: every exchange returns at once without moving anything -- the substep then costs what its kernels cost (results are wrong
