@@ -1272,7 +1272,21 @@ extern "C" int udc_last_plan(udc_handle *h, int out[16]) {
 // the momentum sweep's piece that feeds k-chunk c of the slab solve: tile rows 1 .. of levels [c nzc + 1, (c + 1) nzc + 1) (the x
 // forward transform of chunk c reads pwp one level up), from level 0 for c = 0 and to the top for the last; after the first piece the
 // floor on those rows (`bottom` acts on level kb only)
-int k_momentum_pipe_stage(udc_handle *h, int c) {
+// vp's first row of the levels chunk c's divergence reads (complete once piece c is done: level c nzc is the previous piece's last)
+// starts travelling behind whatever the compute stream holds at this call
+int k_momentum_pipe_row(udc_handle *h, int c) {
+  if (!h->mom_pipe.active || !h->mom_pipe.rows_all) return 0;
+  const int nzc = h->g.nz / h->nch;
+  const int fvp[1] = {UDC_VP};
+  if (k_halo_y_begin(h, fvp, 1, 1, nullptr, HALO_TO_PREV, c * nzc, nzc)) return 1;
+  if (c < 16) {
+    if (!h->ev_vp[c]) HIP_OK(hipEventCreateWithFlags(&h->ev_vp[c], hipEventDisableTiming));
+    HIP_OK(hipEventRecord(h->ev_vp[c], h->comm_stream));      // (the x transform of chunk c waits for this one, not for the last begun)
+  }
+  h->vp_halo_pending = true;
+  return 0;
+}
+int k_momentum_pipe_stage(udc_handle *h, int c, bool row) {
   if (!h->mom_pipe.active) return 0;
   const int nch = h->nch, nzc = h->g.nz / nch, gy = momentum_lds_tile_rows(h->g);
   const int kbeg = c == 0 ? 0 : c * nzc + 1, kend = c == nch - 1 ? h->g.nz : (c + 1) * nzc + 1;
@@ -1280,17 +1294,7 @@ int k_momentum_pipe_stage(udc_handle *h, int c) {
   const MomPart part{all ? 0 : 1, gy, kbeg, kend, c != nch - 1};
   if (k_momentum_lds(h, true, true, h->mom_pipe.forces, true, h->mom_pipe.rk3coefi, h->mom_pipe.um_is_u0, &part, h->mom_pipe.pgrad)) return 1;
   if (c == 0 && h->mom_pipe.bottom && k_bottom(h, false, all ? 0 : momentum_lds_tile_height(), -1)) return 1;
-  if (all) {
-    // vp's first row of the levels this chunk's divergence reads (complete now: level c nzc is the previous piece's last) travels
-    // while the next piece is swept (k_poisson_solve_slab launches it ahead of this chunk's x transform)
-    const int fvp[1] = {UDC_VP};
-    if (k_halo_y_begin(h, fvp, 1, 1, nullptr, HALO_TO_PREV, c * nzc, nzc)) return 1;
-    if (c < 16) {
-      if (!h->ev_vp[c]) HIP_OK(hipEventCreateWithFlags(&h->ev_vp[c], hipEventDisableTiming));
-      HIP_OK(hipEventRecord(h->ev_vp[c], h->comm_stream));      // (the x transform of chunk c waits for this one, not for the last begun)
-    }
-    h->vp_halo_pending = true;
-  }
+  if (all && row) return k_momentum_pipe_row(h, c);
   return 0;
 }
 

@@ -449,7 +449,8 @@ int k_momentum_lds(udc_handle *h, bool adv, bool diff, bool forces, bool fresh, 
                    bool pgrad = true);      // pgrad false: the pressure-total form (no gradient of pres0; fused substep only)
 int momentum_lds_tile_rows(const Geo &g);
 int momentum_lds_tile_height();
-int k_momentum_pipe_stage(udc_handle *h, int c);      // the sweep's level range that feeds k-chunk c of the slab solve (udc_api.hip)  // rk3coefi != 0: PUP mode   // LDS-staged k-marching version (default)
+int k_momentum_pipe_stage(udc_handle *h, int c, bool row = true);
+int k_momentum_pipe_row(udc_handle *h, int c);      // the sweep's level range that feeds k-chunk c of the slab solve (udc_api.hip)  // rk3coefi != 0: PUP mode   // LDS-staged k-marching version (default)
 int k_level_sums_dev(udc_handle *h, int field, int n, int k0 = 0);      // udc_thermo.hip: masked, all-reduced sums of levels k0 .. k0 + n - 1 left on the device
 int k_scalar_adv(udc_handle *h, int n);
 int k_scalar_bcx_outlet(udc_handle *h);

@@ -1171,8 +1171,12 @@ int k_poisson_solve_slab(udc_handle *h) {
       const int k0 = c * nzc;
       // (the momentum sweep's levels for this chunk, when it is pipelined with the solve)
       if (ahead) {
+        // (late: the row of piece c + 1 starts travelling behind x transform c, i.e. beside piece c + 2 and not beside the transform,
+        //  which its pack / copy / unpack slowed down: 0.304 -> 0.286 ms at 1024 x 64 x 512, profiles/r06/mom_pipe_orders_ab.txt; the last
+        //  piece's row leaves at once: its transform follows the one before without a piece in between)
+        const bool late = c + 2 < nch;
         if (c == 0 && k_momentum_pipe_stage(h, 0)) return 1;
-        if (c + 1 < nch && k_momentum_pipe_stage(h, c + 1)) return 1;
+        if (c + 1 < nch && k_momentum_pipe_stage(h, c + 1, !late)) return 1;
         if (h->ev_vp[c]) HIP_OK(hipStreamWaitEvent(h->stream, h->ev_vp[c], 0));      // vp's ghost row of this chunk's levels is in
         if (c == nch - 1) { h->vp_halo_pending = false; h->halo_async_pending = false; }
       } else if (k_momentum_pipe_stage(h, c)) return 1;
@@ -1182,6 +1186,7 @@ int k_poisson_solve_slab(udc_handle *h) {
         if (ahead) {
           if (fft_x_fwd_pack(h, k0, nzc, h->a2a_send + chunk * c)) return 1;
           if (exchange(c)) return 1;
+          if (c + 2 < nch && k_momentum_pipe_row(h, c + 1)) return 1;
           continue;
         }
         if (h->vp_halo_pending && G >= 2) {
