@@ -518,11 +518,10 @@ CASES.update({
     "run_ptop_16x8x12s": ("run", 85, 16, 8, 12, dict(sgs="smag", nsv=1, floor=True, bctopm=3, randu=0.05, oracle="nsub = 9\ndump_at = 3, 9"), 1.06),
     "run_ibmtall_16x12x10": ("run", 87, 16, 12, 10, dict(sgs="vreman", nsv=1, floor=True, bctopm=1, randu=0.05, ibm=[(5, 8, 4, 7, 10), (11, 13, 8, 10, 2)],
                                                          oracle="nsub = 9\ndump_at = 3, 9"), 1.04),
-    # (no kappa-advected scalar in this one: advecc_kappa leaves cf w0(ke+1) dzfci(ke+1) in the out-of-domain plane svp(ke+1)
-    #  -- src/modadvection.f90:400, zero under a closed lid -- and ibmnorm's `solid` averages it into a solid cell of level ke,
-    #  src/modibm.f90:796-800: a block that touches an open lid with a kappa scalar is the one combination not reproduced)
-    #  With the temperature instead, so that the c grid's lists are read at all: src/modibm.f90:181.)
-    "run_ptop_ibm_16x12x10": ("run", 86, 16, 12, 10, dict(sgs="vreman", nsv=0, floor=True, bctopm=3, randu=0.05, ibm=IBM_BLOCKS["run_ptop_ibm_16x12x10"],
+    # (with a kappa-advected scalar: advecc_kappa leaves cf w0(ke+1) dzfci(ke+1) in the out-of-domain plane svp(ke+1) -- src/modadvection.f90:400,
+    #  zero under a closed lid -- and ibmnorm's `solid` averages it into a solid cell of level ke, src/modibm.f90:796-800: the device writes that
+    #  plane too, lid_kappa_plane_kernel; and with the temperature, advected by advecc_2nd, which does not)
+    "run_ptop_ibm_16x12x10": ("run", 86, 16, 12, 10, dict(sgs="vreman", nsv=1, floor=True, bctopm=3, randu=0.05, ibm=IBM_BLOCKS["run_ptop_ibm_16x12x10"],
                                                           physics="ltempeq = .true.\nlbuoyancy = .true.",
                                                           bc="BCtopT = 1\nwttop = 0.\nBCbotT = 1\nwtsurf = 0.02\nthls = 288.0",
                                                           oracle="nsub = 9\ndump_at = 3, 9"), 1.04),

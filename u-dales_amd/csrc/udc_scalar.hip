@@ -270,13 +270,38 @@ int k_scalar_bcx_fill_host(udc_handle *h, int n, double *host, const int lb[3], 
   return 0;
 }
 
-int k_scalar_adv(udc_handle *h, int n) { return launch_scalar(h, n, true, false) || k_scalar_bcx_edges(h, n, true, false); }
+// Open lid (BCtopm = 3) with an immersed boundary: advecc_kappa's loop over the faces kb+1 .. ke+1 also leaves
+// duml(ke+1) = cf w0(ke+1) dzfci(ke+1) in the out-of-domain plane svp(ke+1) (src/modadvection.f90:386-404; zero under a closed lid, where
+// w0(ke+1) = 0), and ibmnorm's `solid` averages that plane into a solid cell of level ke whose upper neighbour counts as fluid
+// (src/modibm.f90:796-800).  The sweeps stop at level ke: this plane kernel writes it (same face value as the top level's high face).
+namespace {
+__global__ void lid_kappa_plane_kernel(Geo g, Metrics m, const double *__restrict__ c, const double *__restrict__ w, double *__restrict__ cp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+  if (i >= g.nx) return;
+  const int nz = g.nz;
+  const long o = g.idx(i, j, nz);                    // the cell (i, j, ke+1)
+  const double wt = w[o];
+  // face ke+1: cells ke-1, ke | ke+1, ke+2; dzhci(ke), dzhci(ke+1), dzhci(ke+2) = dzhci(ke+1) (src/modglobal.f90:857-859); dzfc(ke+1)
+  const double f = face(wt, c[o - 2 * g.sz], c[o - g.sz], c[o], c[o + g.sz], m.dzhi[nz], m.dzhi[nz + 1], m.dzhi[nz + 1], m.dzf[nz + 1]);
+  cp[o] = f * wt * m.dzfi[nz + 1];
+}
+}  // namespace
+static int lid_kappa_plane(udc_handle *h, int n) {
+  if (h->p.bctopm != UDC_TOP_PRESSURE || !h->ibm_on || n >= h->cfg.nsv || h->slot[n].adv != 1) return 0;
+  const Geo &g = h->g;
+  hipLaunchKernelGGL(lid_kappa_plane_kernel, dim3((g.nx + 63) / 64, g.ny), dim3(64), 0, h->stream, g, h->m, (const double *)h->fields[UDC_SV0 + 3 * n],
+                     (const double *)h->fields[UDC_W0], h->fields[UDC_SVP + 3 * n]);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int k_scalar_adv(udc_handle *h, int n) { return launch_scalar(h, n, true, false) || k_scalar_bcx_edges(h, n, true, false) || lid_kappa_plane(h, n); }
 int k_scalar_diff(udc_handle *h, int n) { return launch_scalar(h, n, false, true) || k_scalar_bcx_edges(h, n, false, true); }
 bool k_scalar_fused_lds(udc_handle *h, int n, bool fresh, int *rc);      // udc_scalar_lds.hip
 int k_scalar_fused(udc_handle *h, int n, bool fresh) {
   int rc = 0;
-  if (k_scalar_fused_lds(h, n, fresh, &rc)) return rc || k_scalar_bcx_edges(h, n, true, true);
-  return launch_scalar(h, n, true, true, fresh) || k_scalar_bcx_edges(h, n, true, true);
+  if (k_scalar_fused_lds(h, n, fresh, &rc)) return rc || k_scalar_bcx_edges(h, n, true, true) || lid_kappa_plane(h, n);
+  return launch_scalar(h, n, true, true, fresh) || k_scalar_bcx_edges(h, n, true, true) || lid_kappa_plane(h, n);
 }
 
 // two slots in one sweep where that applies (udc_scalar_lds.hip, k_scalar_pair_lds): 0 done, -1 not applicable, 1 error
