@@ -267,14 +267,17 @@ DROPIN_HS_MPI_TEST = os.path.join(BINDIR, "udales_full_dropin_hoststats_mpi_test
 
 
 @pytest.mark.gpu
-def test_processor_boundaries_case_526(tmp_path):
+@pytest.mark.parametrize("steps", [None, 6])
+def test_processor_boundaries_case_526(steps, tmp_path):
     """The other half of test_processor_boundaries.py (:43-50, TREE_CASE_ID): tests/cases/526 -- trees (the reference's vegetation.f90,
     untouched, on the host: the drop-ins fall back to the strict residency for it) over a floor that is an immersed boundary with
     facet wall functions, temperature + moisture + buoyancy, the adaptive time step and BCtopm = 3, the lid open to the pressure
     gradient (bcpup / tderive / tstep_integrate's row w(ke+1): k_lid_*, udc_pois.hip) -- one step of namoptions.526.serial; `tr_u,
     tr_v, tr_w` of treedump (the reference's own modstatsdump linked: the device statistics do not take the tree dump over) and
     `ut, vt, wt` of tdump, serial and split over 2 / 4 ranks in y and as 2 x 1 / 2 x 2 decks, against the ALL-REFERENCE executable:
-    <= 1e-9 everywhere (the reference's ABS_TOL on its support masks and processor-boundary bands)."""
+    <= 1e-9 everywhere (the reference's ABS_TOL on its support masks and processor-boundary bands).
+    steps = 6 (not a test the reference holds): the same deck for six steps with a sample every step, so that the trees' drag, the wall
+    functions, the moist thermodynamics and the pressure solver have acted on each other's output; serial and one 2 x 2 deck."""
     if not (os.path.exists(FULL) and os.path.exists(DROPIN_HS)):
         pytest.skip("oracle/_ref/udales_full or u-dales_amd/bin/udales_full_dropin_hoststats not built")
     want_tr, want_t = ("tr_u", "tr_v", "tr_w"), ("ut", "vt", "wt")
@@ -284,21 +287,21 @@ def test_processor_boundaries_case_526(tmp_path):
         out.update(tdump_fields(d, P, 526, "tdump", want_t))
         return out
     out = {}
-    stage(tmp_path / "ref", "namoptions.526.serial", case=526)
+    stage(tmp_path / "ref", "namoptions.526.serial", case=526, steps=steps)
     r = run(tmp_path / "ref", FULL, case=526)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     out["reference, serial"] = fields(tmp_path / "ref", 1)
-    stage(tmp_path / "dev1", "namoptions.526.serial", case=526)
+    stage(tmp_path / "dev1", "namoptions.526.serial", case=526, steps=steps)
     r = run(tmp_path / "dev1", DROPIN_HS, env=dict(os.environ, UDC_RESIDENCY="2"), case=526)      # (asks for 2, gets 0: the trees)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     assert "UDC_RESIDENCY=0" in r.stdout
     out["device, serial"] = fields(tmp_path / "dev1", 1)
     if os.path.exists(MPIEXEC) and os.path.exists(DROPIN_HS_MPI_TEST) and gpu_count() < 2:
-        for px, py in ((1, 2), (1, 4), (2, 1), (2, 2)):
+        for px, py in (((1, 2), (1, 4), (2, 1), (2, 2)) if steps is None else ((2, 2),)):
             P = px * py
             _, env, how = mpi_transport(P, f"c526x{px}{py}")
             d = tmp_path / f"dev{px}x{py}"
-            stage(d, "namoptions.526.serial", nprocy=py, nprocx=px, case=526)
+            stage(d, "namoptions.526.serial", nprocy=py, nprocx=px, case=526, steps=steps)
             r = run(d, DROPIN_HS_MPI_TEST, P, env=env, case=526)
             assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
             out[f"device, deck {px} x {py} ({how})"] = fields(d, P)
@@ -311,8 +314,8 @@ def test_processor_boundaries_case_526(tmp_path):
         for k in want_tr + want_t:
             worst[(label, k)] = float(np.abs(cand[k] - ref[k]).max())
     if os.environ.get("UDC_TEST_KEEP_LOGS"):
-        with open(os.path.join(os.environ["UDC_TEST_KEEP_LOGS"], "processor_boundaries_case526.txt"), "w") as f:
-            f.write("max |candidate - all-reference serial run| of treedump's tr_u, tr_v, tr_w and tdump's ut, vt, wt after one step of namoptions.526.serial (tolerance 1e-9)\n")
+        with open(os.path.join(os.environ["UDC_TEST_KEEP_LOGS"], f"processor_boundaries_case526_{steps or 1}steps.txt"), "w") as f:
+            f.write(f"max |candidate - all-reference serial run| of treedump's tr_u, tr_v, tr_w and tdump's ut, vt, wt after {steps or 1} step(s) of namoptions.526.serial (tolerance 1e-9)\n")
             for (label, k), v in worst.items():
                 f.write(f"{label:36s} {k}: {v:.3e}\n")
     bad = {k: v for k, v in worst.items() if not v <= TOL}
