@@ -462,12 +462,12 @@ def single_gpu_leg(nx, ny, nz, dt, args, device, ms_n, poisson_n, poisson_sub_n,
 # slab substep's overlap features taken back one group at a time.  The line says which rung produced the number.
 LADDER = [
     ("defaults", {}),
-    ("ghost rows and sweeps in line", {"UDC_HALO_OVERLAP": "0", "UDC_MOM_PIPE": "0"}),
-    ("... and the transposes in one piece", {"UDC_HALO_OVERLAP": "0", "UDC_MOM_PIPE": "0", "UDC_A2A_CHUNKS": "1"}),
+    ("ghost rows (p's among them, in an exchange of their own) and sweeps in line", {"UDC_HALO_OVERLAP": "0", "UDC_MOM_PIPE": "0", "UDC_P_TRANSPOSE": "0"}),
+    ("... and the transposes in one piece", {"UDC_HALO_OVERLAP": "0", "UDC_MOM_PIPE": "0", "UDC_P_TRANSPOSE": "0", "UDC_A2A_CHUNKS": "1"}),
     ("... and rocFFT + transpose kernels instead of the fused line transforms",
-     {"UDC_HALO_OVERLAP": "0", "UDC_MOM_PIPE": "0", "UDC_A2A_CHUNKS": "1", "UDC_FFT_FUSED": "0"}),
+     {"UDC_HALO_OVERLAP": "0", "UDC_MOM_PIPE": "0", "UDC_P_TRANSPOSE": "0", "UDC_A2A_CHUNKS": "1", "UDC_FFT_FUSED": "0"}),
     ("... and RCCL without peer-to-peer transport (through host memory: degraded links, a number of last resort)",
-     {"UDC_HALO_OVERLAP": "0", "UDC_MOM_PIPE": "0", "UDC_A2A_CHUNKS": "1", "UDC_FFT_FUSED": "0", "NCCL_P2P_DISABLE": "1"}),
+     {"UDC_HALO_OVERLAP": "0", "UDC_MOM_PIPE": "0", "UDC_P_TRANSPOSE": "0", "UDC_A2A_CHUNKS": "1", "UDC_FFT_FUSED": "0", "NCCL_P2P_DISABLE": "1"}),
 ]
 
 
