@@ -324,6 +324,18 @@ int udc_set_ibm_wallheat(udc_handle *h, int iwalltemp);
  * udc_set_ibm_sections(3, ...) and udc_set_ibm_wallheat. */
 int udc_set_ibm_wallmoist(udc_handle *h, int iwallmoist, int n, const int *lgr, const double *qwall, const double *hurel,
                           const double *resc, const double *ress);
+/* lwritefac (&WALLS; src/modibm.f90:196-243, 1246-1282): the facet output of ibmwallfun -- per facet the wall shear stresses of the three
+ * directions (wallfunmom, :1413-1430), the pressure and its square at the boundary cells (wallfunheat, :1475-1476) and the heat transfer
+ * coefficients (:1540-1541), area-weighted over the facet's sections, divided by the facet's area and integrated in time on every RK
+ * stage 3.  udc_set_ibm_facet_output: nfcts facets with their areas (facetarea.inp), the facet of every section handed to
+ * udc_set_ibm_sections (nsec[4] = the counts given there, fac_* 1-based), and ALL sections of the c grid (cell, area, facet: the pressure is
+ * taken on the skipped ones too).  udc_ibm_facet_sample(dt): the next udc_ibmwallfun is stage 3 of a step of dt.  udc_ibm_facet_get: the
+ * integrals [7][nfcts] (tau_x, tau_y, tau_z, pres, pres2, htc, cth), reset != 0: and back to zero (fac.NNN.nc's record: the caller
+ * divides by the interval). */
+int udc_set_ibm_facet_output(udc_handle *h, int nfcts, const double *faca, const int *nsec, const int *fac_u, const int *fac_v,
+                             const int *fac_w, const int *fac_c, int npres, const int *pcell, const double *parea, const int *pfac);
+int udc_ibm_facet_sample(udc_handle *h, double dt);
+int udc_ibm_facet_get(udc_handle *h, double *out, int reset);
 int udc_set_ibm_sections(udc_handle *h, int grid, int n, const int *cell, const double *area, const double *dist, const double *norm,
                          const double *z0, const double *z0h, const double *tsurf, const int *comprec, const double *recpt,
                          const int *recids, const double *tmask);

@@ -13,6 +13,7 @@ monitor file, xytdump as handed to NetCDF."""
 import gzip
 import os
 import re
+import shutil
 import subprocess
 
 import numpy as np
@@ -174,3 +175,45 @@ def test_examples_through_the_reference_program(ex, n, tmp_path):
         assert np.abs(a[::8, ::8, ::8] - fix[f"rst.{k}.pts"].data).max() <= 1e-8 * sc, k
         assert np.abs(a.mean(axis=(1, 2)) - fix[f"rst.{k}.mean"].data).max() <= 1e-9 * sc, k
         assert np.abs(np.sqrt((a ** 2).mean(axis=(1, 2))) - fix[f"rst.{k}.rms"].data).max() <= 1e-9 * sc, k
+
+
+@pytest.mark.parametrize("name", ["run_ibm_wh2_16x12x10", "run_ibm_wf2_16x12x10"])
+@pytest.mark.parametrize("residency", ["2", "0"])
+def test_facet_output_file(name, residency, tmp_path):
+    """lwritefac (&WALLS; src/modibm.f90:196-243, 1246-1282): fac.NNN.nc -- per facet the time-averaged wall shear stresses of the three
+    directions, the pressure, its fluctuation and the two heat transfer coefficients, every dtfac seconds -- through the all-reference
+    executable and through the drop-ins (the wall-function kernels add each section to its facet on RK stage 3, the device keeps the
+    time integrals, the drop-in modibm writes the record through the reference's modstat_nc once the substep has run), device resident
+    (deferred execution) and in the strict residency; a deck with the heat wall function on the facet temperatures and one without
+    temperature wall functions.  Every record of every variable, 1e-8 of the variable's scale."""
+    from test_full_reference import FULL
+    if not (os.path.exists(DROPIN) and os.path.exists(FULL)):
+        pytest.skip("oracle/_ref/udales_full or u-dales_amd/bin/udales_full_dropin not built")
+    iexp = RUN_CASES[name]
+    out = {}
+    for tag, exe in (("ref", FULL), ("dev", DROPIN)):
+        d = tmp_path / tag
+        d.mkdir()
+        for fn in os.listdir(os.path.join(GOLDEN, "cases", name)):
+            shutil.copy(os.path.join(GOLDEN, "cases", name, fn), d)
+        deck = d / f"namoptions.{iexp:03d}"
+        txt = deck.read_text().replace("&WALLS", "&WALLS\nlwritefac = .true.\ndtfac = 0.5")
+        nfcts = int(re.findall(r"nfcts\s*=\s*(\d+)", txt)[-1])
+        txt = re.sub(r"runtime\s*=\s*[0-9.eE+-]+", "runtime = 2.2", txt)      # nine steps of dtmax = 0.25: records at 0.5, 1.0, 2.0
+        deck.write_text(txt)
+        (d / f"facetarea.inp.{iexp:03d}").write_text("# area\n" + "".join(f"{1.0 + 0.25 * n}\n" for n in range(nfcts)))
+        r = subprocess.run(f"ulimit -s unlimited; exec {exe} namoptions.{iexp:03d}", shell=True, cwd=d, capture_output=True, text=True, timeout=600,
+                           executable="/bin/bash", env=dict(os.environ, UDC_RESIDENCY=residency))
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        out[tag] = read_ncrec(str(d / f"fac.{iexp:03d}.nc"))
+    ref, dev = out["ref"], out["dev"]
+    assert list(ref) == list(dev) and {"tau_x", "tau_y", "tau_z", "pres", "htc", "cth", "pres_flc"} <= set(ref), (list(ref), list(dev))
+    checked = 0
+    for var, recs in ref.items():
+        assert len(recs) == len(dev[var]) >= 1, var
+        sc = max(max(np.abs(np.asarray(a)).max() for _, a in recs), 1e-12)
+        for (s0, a), (s1, b) in zip(recs, dev[var]):
+            assert s0 == s1 and np.asarray(a).shape == np.asarray(b).shape, var
+            assert np.abs(np.asarray(a) - np.asarray(b)).max() <= 1e-8 * sc, (var, np.abs(np.asarray(a) - np.asarray(b)).max(), sc)
+            checked += 1
+    assert checked >= 16 and np.abs(np.asarray(ref["tau_x"][-1][1])).max() > 1e-6 and np.abs(np.asarray(ref["pres"][-1][1])).max() > 1e-8

@@ -495,6 +495,7 @@ int k_ibm_wallfun(udc_handle *h) {
   PROF(h, "ibm_wallfun");
   const udc_handle::IbmGrid &U = h->ibm[0], &V = h->ibm[1], &W = h->ibm[2], &C = h->ibm[3];
   const double *ekm = h->fields[UDC_EKM], *ekh = h->fields[UDC_EKH];
+  if (k_ibm_facet_begin(h)) return 1;     // lwritefac on an RK stage 3: this substep's per-facet sums (udc_ibm_wf.hip)
   if (k_ibm_wallfunmom(h)) return 1;      // iwallmom > 1: the facet wall functions first (src/modibm.f90:1183-1194)
   if (U.nbound) hipLaunchKernelGGL(ibm_diffu_corr_kernel, dim3(blocks(U.nbound)), dim3(128), 0, h->stream, g, h->m, U.nbound, U.bound, U.bound_fl,
                                    (const double *)h->fields[UDC_U0], ekm, h->fields[UDC_UP]);
@@ -503,6 +504,7 @@ int k_ibm_wallfun(udc_handle *h) {
   if (W.nbound) hipLaunchKernelGGL(ibm_diffw_corr_kernel, dim3(blocks(W.nbound)), dim3(128), 0, h->stream, g, h->m, W.nbound, W.bound, W.bound_fl,
                                    (const double *)h->fields[UDC_W0], ekm, h->fields[UDC_WP]);
   if (k_ibm_wallfunheat(h)) return 1;     // iwalltemp = 2: the heat wall function on thlp (:1220-1231), then diffc_corr
+  if (k_ibm_facet_end(h)) return 1;
   if (C.nbound)
     for (int n : h->slots)
       hipLaunchKernelGGL(ibm_diffc_corr_kernel, dim3(blocks(C.nbound)), dim3(128), 0, h->stream, g, h->m, C.nbound, C.bound, C.bound_fl,

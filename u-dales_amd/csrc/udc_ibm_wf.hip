@@ -25,6 +25,9 @@ struct WfArgs {
   const int *lgr;
   const double *qwall, *hurel, *resc, *ress, *qt0;
   double *rhsq;
+  // lwritefac on an RK stage 3: facet of every section and this substep's sums (fa: tau of this grid's direction; fb, fc: htc, cth)
+  const int *fac;
+  double *fa, *fb, *fc;
 };
 
 __device__ __forceinline__ int wx(int i, int nx) { return i < 0 ? i + nx : (i >= nx ? i - nx : i); }
@@ -136,12 +139,14 @@ __global__ void ibm_wallfunmom_kernel(Geo g, Metrics m, WfArgs a) {
     }
     sd = copysign(fabs(sd), uv[a.grid]);                  // sign(stress_dir, dot(uvec, dir))
     t = t - sd * a.area[s] / vol;
+    if (a.fa) atomicAdd(&a.fa[a.fac[s] - 1], sd * a.area[s]);      // fac_tau_loc(fac), :1413
   }
   a.rhs[c] = t;
 }
 
 // heat_transfer_coef_flux, :1920-1986 -> flux [K m/s]; htc = flux / (|utan| dT) where that is defined, else 0 (:1975-1979)
-__device__ __forceinline__ double heat_flux(double utan, double dist, double z0, double z0h, double Tair, double Tsurf, double prt, double fkar, double &htc) {
+__device__ __forceinline__ double heat_flux(double utan, double dist, double z0, double z0h, double Tair, double Tsurf, double prt, double fkar, double &htc,
+                                            double &cth_out) {
   const double b1 = 9.4, b2 = 4.7, dm = 7.4, dh = 5.3, grav = 9.81;
   const double dT = Tair - Tsurf;
   const double Ribl0 = grav * dist * dT / (Tsurf * (utan * utan));
@@ -166,6 +171,7 @@ __device__ __forceinline__ double heat_flux(double utan, double dist, double z0,
   const double cth = fkar2 / (logdz * logdz) * Fh / prt;
   const double flux = fabs(utan) * cth * dTrough;
   htc = fabs(fabs(utan) * dT) > 0. ? flux / (fabs(utan) * dT) : 0.;
+  cth_out = cth;
   return flux;
 }
 
@@ -213,9 +219,10 @@ __global__ void ibm_wallfunheat_kernel(Geo g, Metrics m, WfArgs a) {
     const double st[3] = {sp[1] * nrm[2] - sp[2] * nrm[1], sp[2] * nrm[0] - sp[0] * nrm[2], sp[0] * nrm[1] - sp[1] * nrm[0]};
     const double utan = uv[0] * st[0] + uv[1] * st[1] + uv[2] * st[2];
     // iwalltemp = 1: the prescribed flux of the facet's direction rides in the slot of the facet temperature
-    double htc = 0.;
-    double flux = a.iwallmom == 1 ? a.tsurf[s] : heat_flux(utan, dist, z0, a.z0h[s], Tair, a.tsurf[s], a.prt, a.fkar, htc);
+    double htc = 0., cth = 0.;
+    double flux = a.iwallmom == 1 ? a.tsurf[s] : heat_flux(utan, dist, z0, a.z0h[s], Tair, a.tsurf[s], a.prt, a.fkar, htc, cth);
     t = t - flux * a.area[s] / vol;
+    if (a.fb && a.iwallmom == 2) { atomicAdd(&a.fc[a.fac[s] - 1], cth * a.area[s]); atomicAdd(&a.fb[a.fac[s] - 1], htc * a.area[s]); }      // :1540-1541
     if (moist && a.lgr[s]) {
       if (a.iwallmoist == 1) flux = a.qwall[s];
       else if (fabs(htc * fabs(utan)) > 0.) {      // (else the reference's `flux` still holds the sensible one, which is then zero)
@@ -228,6 +235,22 @@ __global__ void ibm_wallfunheat_kernel(Geo g, Metrics m, WfArgs a) {
   }
   a.rhs[c] = t;
   if (moist) a.rhsq[c] = tq;
+}
+
+// lwritefac: fac_pres_loc / fac_pres2_loc of wallfunheat (:1475-1476) -- pres0 of the boundary cell of EVERY c section, skipped ones included
+__global__ void ibm_fac_pres_kernel(Geo g, int n, int j0, const int *__restrict__ cell, const int *__restrict__ fac, const double *__restrict__ area,
+                                    const double *__restrict__ pres0, double *__restrict__ fp, double *__restrict__ fp2) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const double p = pres0[g.idx(cell[3 * q] - 1, cell[3 * q + 1] - 1 - j0, cell[3 * q + 2] - 1)];
+  atomicAdd(&fp[fac[q] - 1], p * area[q]);
+  atomicAdd(&fp2[fac[q] - 1], p * p * area[q]);
+}
+// ... / faca (:1418, 1596-1599) and the running time integrals of ibmwallfun (:1247-1254): av += dt * value
+__global__ void ibm_fac_finish_kernel(int n, double dt, const double *__restrict__ now, const double *__restrict__ faca, double *__restrict__ av) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= 7 * n) return;
+  av[q] = av[q] + dt * (now[q] / faca[q % n]);
 }
 
 template <class T>
@@ -353,6 +376,8 @@ int k_ibm_wallfunmom(udc_handle *h) {
     a.zf = h->ibm_zgrid; a.zh = h->ibm_zgrid + (g.nz + 1);
     a.rhs = h->fields[UDC_UP + q];
     a.prt = h->ibm_prt; a.fkar = h->fkar; a.iwallmoist = 0;
+    const bool smp = h->fac_sample_dt >= 0. && h->fac_now && S.fac;
+    a.fac = smp ? S.fac : nullptr; a.fa = smp ? h->fac_now + (size_t)q * h->fac_n : nullptr; a.fb = a.fc = nullptr;
     hipLaunchKernelGGL(ibm_wallfunmom_kernel, dim3((unsigned)((S.ncell + 127) / 128)), dim3(128), 0, h->stream, g, h->m, a);
   }
   HIP_OK(hipGetLastError());
@@ -418,14 +443,97 @@ int k_ibm_wallfunheat(udc_handle *h) {
   a.iwallmoist = (h->ibm_iwallmoist && S.lgr) ? h->ibm_iwallmoist : 0;
   a.lgr = S.lgr; a.qwall = S.qwall; a.hurel = S.hurel; a.resc = S.resc; a.ress = S.ress;
   a.qt0 = a.iwallmoist ? h->fields[UDC_QT0] : nullptr; a.rhsq = a.iwallmoist ? h->fields[UDC_QTP] : nullptr;
+  const bool smp = h->fac_sample_dt >= 0. && h->fac_now && S.fac;
+  a.fac = smp ? S.fac : nullptr; a.fa = nullptr;
+  a.fb = smp ? h->fac_now + (size_t)5 * h->fac_n : nullptr; a.fc = smp ? h->fac_now + (size_t)6 * h->fac_n : nullptr;
   hipLaunchKernelGGL(ibm_wallfunheat_kernel, dim3((unsigned)((S.ncell + 127) / 128)), dim3(128), 0, h->stream, g, h->m, a);
   HIP_OK(hipGetLastError());
   return 0;
 }
 
+// ---- lwritefac: facet output of ibmwallfun (src/modibm.f90:196-243, 1246-1282, 1413-1430, 1475-1476, 1540-1541, 1595-1605)
+extern "C" int udc_set_ibm_facet_output(udc_handle *h, int nfcts, const double *faca, const int *nsec, const int *fac_u, const int *fac_v,
+                                        const int *fac_w, const int *fac_c, int npres, const int *pcell, const double *parea, const int *pfac) {
+  if (!h) { udc_set_error("null handle"); return 1; }
+  HIP_OK(hipSetDevice(h->device));
+  if (udc_flush_pending(h)) return 1;
+  if (nfcts < 1 || !faca || !nsec) { udc_set_error("udc_set_ibm_facet_output: facets and their areas are needed"); return 1; }
+  const int *facs[4] = {fac_u, fac_v, fac_w, fac_c};
+  HIP_OK(hipStreamSynchronize(h->stream));
+  for (int q = 0; q < 4; ++q) {
+    udc_handle::IbmSections &S = h->ibm_sec[q];
+    if (!S.nglobal && !nsec[q]) continue;
+    if (nsec[q] != S.nglobal || (nsec[q] && !facs[q])) { udc_set_error("udc_set_ibm_facet_output: grid %d: %d facet ids, udc_set_ibm_sections was given %d sections", q, nsec[q], S.nglobal); return 1; }
+    std::vector<int> f;
+    for (int s_ : S.order) {
+      if (facs[q][s_] < 1 || facs[q][s_] > nfcts) { udc_set_error("udc_set_ibm_facet_output: facet %d of %d", facs[q][s_], nfcts); return 1; }
+      f.push_back(facs[q][s_]);
+    }
+    if (upload(&S.fac, f)) return 1;
+  }
+  // the c sections that carry the pressure: this slab's
+  const Geo &g = h->g;
+  const int j0 = h->cfg.rank * g.ny;
+  std::vector<int> pc, pf; std::vector<double> pa;
+  for (int s_ = 0; s_ < npres; ++s_) {
+    const int i = pcell[3 * s_], j = pcell[3 * s_ + 1], k = pcell[3 * s_ + 2];
+    if (i < 1 || i > g.nx || j < 1 || j > h->jtot) continue;      // (a boundary point no rank owns)
+    if (k < 1 || k > g.nz || pfac[s_] < 1 || pfac[s_] > nfcts) { udc_set_error("udc_set_ibm_facet_output: pressure section %d out of range", s_ + 1); return 1; }
+    if (j <= j0 || j > j0 + g.ny) continue;
+    pc.insert(pc.end(), pcell + 3 * s_, pcell + 3 * s_ + 3); pf.push_back(pfac[s_]); pa.push_back(parea[s_]);
+  }
+  h->fac_npres = (int)pf.size();
+  if (upload(&h->fac_pcell, pc) || upload(&h->fac_pfac, pf) || upload(&h->fac_parea, pa)) return 1;
+  std::vector<double> fa(faca, faca + nfcts), z((size_t)7 * nfcts, 0.);
+  if (upload(&h->fac_area, fa) || upload(&h->fac_now, z) || upload(&h->fac_av, z)) return 1;
+  h->fac_n = nfcts;
+  h->fac_sample_dt = -1.;
+  return 0;
+}
+// the next udc_ibmwallfun is an RK stage 3 with time step dt: it samples the facets (once)
+extern "C" int udc_ibm_facet_sample(udc_handle *h, double dt) {
+  if (!h || !h->fac_now) { udc_set_error("udc_ibm_facet_sample: udc_set_ibm_facet_output first"); return 1; }
+  h->fac_sample_dt = dt;      // (no flush: with deferred execution the recorded ibmwallfun of this substep consumes it)
+  return 0;
+}
+// the running time integrals [7][nfcts] (tau_x, tau_y, tau_z, pres, pres2, htc, cth), and back to zero if asked
+extern "C" int udc_ibm_facet_get(udc_handle *h, double *out, int reset) {
+  if (!h || !out || !h->fac_av) { udc_set_error("udc_ibm_facet_get: udc_set_ibm_facet_output first"); return 1; }
+  HIP_OK(hipSetDevice(h->device));
+  if (udc_flush_pending(h)) return 1;
+  const size_t nb = sizeof(double) * 7 * h->fac_n;
+  HIP_OK(hipMemcpyAsync(out, h->fac_av, nb, hipMemcpyDeviceToHost, h->stream));
+  if (reset) HIP_OK(hipMemsetAsync(h->fac_av, 0, nb, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+// around the wall functions of one ibmwallfun: zero this substep's sums / the pressure sections, the reduction over the slabs, the integrals
+int k_ibm_facet_begin(udc_handle *h) {
+  if (h->fac_sample_dt < 0. || !h->fac_now) return 0;
+  HIP_OK(hipMemsetAsync(h->fac_now, 0, sizeof(double) * 7 * h->fac_n, h->stream));
+  return 0;
+}
+int k_ibm_facet_end(udc_handle *h) {
+  if (h->fac_sample_dt < 0. || !h->fac_now) return 0;
+  const Geo &g = h->g;
+  if (h->fac_npres)
+    hipLaunchKernelGGL(ibm_fac_pres_kernel, dim3((unsigned)((h->fac_npres + 127) / 128)), dim3(128), 0, h->stream, g, h->fac_npres, h->cfg.rank * g.ny,
+                       (const int *)h->fac_pcell, (const int *)h->fac_pfac, (const double *)h->fac_parea, (const double *)h->fields[UDC_PRES0],
+                       h->fac_now + (size_t)3 * h->fac_n, h->fac_now + (size_t)4 * h->fac_n);
+  HIP_OK(hipGetLastError());
+  if (comm_allreduce(h, h->fac_now, 7 * h->fac_n, 1)) return 1;      // MPI_ALLREDUCE(..., MPI_SUM) over the slabs, :1419, 1601-1604
+  hipLaunchKernelGGL(ibm_fac_finish_kernel, dim3((unsigned)((7 * h->fac_n + 127) / 128)), dim3(128), 0, h->stream, h->fac_n, h->fac_sample_dt,
+                     (const double *)h->fac_now, (const double *)h->fac_area, h->fac_av);
+  HIP_OK(hipGetLastError());
+  h->fac_sample_dt = -1.;
+  return 0;
+}
+
 void ibm_wf_destroy(udc_handle *h) {
+  for (double **p : {&h->fac_now, &h->fac_av, &h->fac_area, &h->fac_parea}) if (*p) { hipFree(*p); *p = nullptr; }
+  for (int **p : {&h->fac_pcell, &h->fac_pfac}) if (*p) { hipFree(*p); *p = nullptr; }
   for (auto &S : h->ibm_sec) {
-    for (int **p : {&S.cell, &S.off, &S.comprec, &S.recids, &S.lgr}) if (*p) { hipFree(*p); *p = nullptr; }
+    for (int **p : {&S.cell, &S.off, &S.comprec, &S.recids, &S.lgr, &S.fac}) if (*p) { hipFree(*p); *p = nullptr; }
     for (double **p : {&S.area, &S.dist, &S.norm, &S.z0, &S.z0h, &S.tsurf, &S.recpt, &S.tmask, &S.qwall, &S.hurel, &S.resc, &S.ress}) if (*p) { hipFree(*p); *p = nullptr; }
     S.ncell = S.nsec = 0;
   }

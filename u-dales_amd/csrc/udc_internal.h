@@ -303,8 +303,17 @@ struct udc_handle {
     int noverride = 0;                  // sections of this slab whose reconstruction cell is out of reach (simple reconstruction instead)
     int *lgr = nullptr;                 // c grid, latent wall flux (udc_set_ibm_wallmoist): vegetated facet; saturation humidity /
     double *qwall = nullptr, *hurel = nullptr, *resc = nullptr, *ress = nullptr;      // prescribed flux, humidity, resistances
+    int *fac = nullptr;                 // facet (1-based) of every kept section (udc_set_ibm_facet_output: lwritefac)
   };
   IbmSections ibm_sec[4];               // u, v, w (wallfunmom), c (wallfunheat)
+  // lwritefac (src/modibm.f90:1246-1282): per-facet tau_x, tau_y, tau_z, pres, pres2, htc, cth -- this substep's area-weighted sums
+  // [7][nfcts] and their running time integrals; the c sections of this slab that carry the pressure (every one, skipped or not)
+  int fac_n = 0;
+  double *fac_now = nullptr, *fac_av = nullptr, *fac_area = nullptr;
+  int fac_npres = 0;
+  int *fac_pcell = nullptr, *fac_pfac = nullptr;
+  double *fac_parea = nullptr;
+  double fac_sample_dt = -1.;           // >= 0: the next ibmwallfun samples the facets (RK stage 3) with this dt, once
   int ibm_iwallmom = 1;                 // 1: no wall functions; 2: Uno et al. stability functions; 3: neutral log law
   int ibm_iwallmoist = 0;               // wallfunheat's latent part: 0 off (impermeable walls); 1 prescribed per section; 2 moist_flux
   int ibm_iwalltemp = 0;                // wallfunheat: 0 off (adiabatic walls); 1 prescribed fluxes per section; 2 from the facet temperatures
@@ -513,6 +522,8 @@ int k_ibm_flowsum_correct(udc_handle *h, int grid, const double *a, const double
 void ibm_destroy(udc_handle *h);
 void stats_destroy(udc_handle *h);
 int k_ibm_wallfunmom(udc_handle *h);
+int k_ibm_facet_begin(udc_handle *h);          // lwritefac: around the wall functions of an ibmwallfun that samples the facets
+int k_ibm_facet_end(udc_handle *h);
 int k_ibm_wallfunheat(udc_handle *h);
 void ibm_wf_destroy(udc_handle *h);
 int udc_flush_pending(udc_handle *h);

@@ -12,11 +12,12 @@
 !!   facet wall functions (iwallmom = 2, 3: wallfunmom :1286; iwalltemp = 2: wallfunheat :1436, sensible part): the section
 !!       tables of initibmwallfun (:273-644) are built here from facet_sections_*.txt and the reference's own initfac data
 !!       (readfacetfiles stays the driver's call) and handed to the device once (udc_set_ibm_sections)
-!! Not taken over (refused in initibm with the reference's error convention): prescribed non-zero wall heat fluxes, wall
-!! moisture fluxes, facet output (lwritefac).
+!!   facet output (lwritefac, :196-243, 1246-1282): the wall-function kernels add each section's stress / heat transfer coefficient /
+!!       pressure to its facet on RK stage 3 and keep the time integrals (udc_set_ibm_facet_output, udc_ibm_facet_sample); fac.NNN.nc is
+!!       written here through the reference's modstat_nc, after the substep has run (ibm_facet_output, called by the drop-in
+!!       tstep_integrate: with deferred execution the substep runs there)
 !! The tau_x / tau_y / thl_flux planes `bottom` leaves behind (src/modibm.f90:2015-2018, 2094-2097: what the floor added to the
-!! tendencies) are filled from the device whenever the host fields are refreshed (udc_iface: udc_bottom_diagnostics); the facet
-!! averages of ibmwallfun's stresses (lwritefac, :1246-1282) are not produced.
+!! tendencies) are filled from the device whenever the host fields are refreshed (udc_iface: udc_bottom_diagnostics).
 !! Without wall functions (iwallmom = 1) the fluid-boundary points of the velocity grids are not handed over: the reference never
 !! reads them then (:166-179) and diffu/v/w_corr act on no points.
 module modibm
@@ -24,7 +25,7 @@ module modibm
   use modibmdata
   implicit none
   save
-  public :: initibm, ibmnorm, ibmwallfun, bottom, lbottom, createmasks, &
+  public :: initibm, ibmnorm, ibmwallfun, bottom, lbottom, createmasks, ibm_facet_output, &
             nsolpts_u, nsolpts_v, nsolpts_w, nsolpts_c, &
             nbndpts_u, nbndpts_v, nbndpts_w, nbndpts_c, &
             nfctsecs_u, nfctsecs_v, nfctsecs_w, nfctsecs_c, &
@@ -67,6 +68,15 @@ module modibm
   logical :: ibm_pending = .false.
   ! latent part of wallfunheat: per kept c-grid section, between grid_sections(3) and udc_set_ibm_wallmoist
   logical :: latent = .false.
+  ! lwritefac: the facet of every kept section of a grid (grid_sections), the output file (names as src/modibm.f90:109-112)
+  type fac_ids
+    integer(c_int), allocatable :: fac(:)
+  end type fac_ids
+  type(fac_ids) :: secfac(0:3)
+  integer :: nstatfac = 7, ncidfac, nrecfac = 0
+  character(80), allocatable :: ncstatfac(:, :)
+  character(80) :: facname = 'fac.xxx.nc'
+  character(80), dimension(1, 4) :: tncstatfac
   integer(c_int), allocatable :: wm_lgr(:)
   real(c_double), allocatable :: wm_q(:), wm_hurel(:), wm_resc(:), wm_ress(:)
 
@@ -109,8 +119,8 @@ contains
     end if
     ! wallfunheat (src/modibm.f90:1436): sensible part prescribed (iwalltemp = 1) or from the facet temperatures (2); latent part on
     ! the vegetated facets prescribed (iwallmoist = 1) or from the facets' humidity (2, with the heat transfer coefficient of iwalltemp = 2)
-    if (lwritefac .or. (ltempeq .and. iwalltemp /= 1 .and. iwalltemp /= 2) .or. (lmoist .and. iwallmoist /= 1 .and. iwallmoist /= 2)) then
-      write (0, *) 'ERROR: libudcore modibm: not available: lwritefac; iwalltemp / iwallmoist must be 1 or 2'
+    if ((ltempeq .and. iwalltemp /= 1 .and. iwalltemp /= 2) .or. (lmoist .and. iwallmoist /= 1 .and. iwallmoist /= 2)) then
+      write (0, *) 'ERROR: libudcore modibm: iwalltemp / iwallmoist must be 1 or 2'
       stop 1
     end if
     if (lmoist .and. iwallmoist == 2 .and. .not. (ltempeq .and. iwalltemp == 2)) then
@@ -121,7 +131,7 @@ contains
       write (0, *) 'ERROR: libudcore modibm: wall moisture fluxes: wallfunheat runs with the temperature equation (ltempeq)'
       stop 1
     end if
-    need_c = nsv > 0 .or. ltempeq .or. lmoist          ! src/modibm.f90:180
+    need_c = nsv > 0 .or. ltempeq .or. lmoist .or. lwritefac          ! src/modibm.f90:181
     mask_w(:, :, kb) = 0.                     ! src/modibm.f90:154-157
     mask_u(:, :, kb - kh) = 0.; mask_v(:, :, kb - kh) = 0.; mask_w(:, :, kb - kh) = 0.; mask_c(:, :, kb - kh) = 0.
     call grid_lists(0, 'solid_u.txt', nsolpts_u, 'fluid_boundary_u.txt', nbndpts_u, mask_u, sol_u, solid_info_u, bound_info_u)
@@ -129,7 +139,60 @@ contains
     call grid_lists(2, 'solid_w.txt', nsolpts_w, 'fluid_boundary_w.txt', nbndpts_w, mask_w, sol_w, solid_info_w, bound_info_w)
     if (need_c) call grid_lists(3, 'solid_c.txt', nsolpts_c, 'fluid_boundary_c.txt', nbndpts_c, mask_c, sol_c, solid_info_c, bound_info_c)
     ibm_pending = .true.
+    if (lwritefac) call init_facet_file
   end subroutine initibm
+
+  !> fac.NNN.nc as the reference defines it (src/modibm.f90:228-246)
+  subroutine init_facet_file
+    use modglobal, only: cexpnr, nfcts
+    use modmpi, only: myid
+    use modstat_nc, only: open_nc, define_nc, ncinfo, writestat_dims_nc
+    facname(5:7) = cexpnr
+    allocate (ncstatfac(nstatfac, 4))
+    call ncinfo(tncstatfac(1, :), 't', 'Time', 's', 'time')
+    call ncinfo(ncstatfac(1, :), 'tau_x', 'tau_x', 'm^2/s^2', 'ft')
+    call ncinfo(ncstatfac(2, :), 'tau_y', 'tau_y', 'm^2/s^2', 'ft')
+    call ncinfo(ncstatfac(3, :), 'tau_z', 'tau_z', 'm^2/s^2', 'ft')
+    call ncinfo(ncstatfac(4, :), 'pres', 'pressure', 'm^2/s^2', 'ft')
+    call ncinfo(ncstatfac(5, :), 'htc', 'heat transfer coefficient', '', 'ft')
+    call ncinfo(ncstatfac(6, :), 'cth', 'heat transfer coefficient (Ivo)', '', 'ft')
+    call ncinfo(ncstatfac(7, :), 'pres_flc', 'pressure fluctuation', '', 'ft')
+    if (myid == 0) then
+      call open_nc(facname, ncidfac, nrecfac, nfcts=nfcts)
+      if (nrecfac == 0) then
+        call define_nc(ncidfac, 1, tncstatfac)
+        call writestat_dims_nc(ncidfac)
+      end if
+      call define_nc(ncidfac, nstatfac, ncstatfac)
+    end if
+  end subroutine init_facet_file
+
+  !> fac.NNN.nc's record (src/modibm.f90:1255-1280), once the substep whose ibmwallfun sampled the facets has run: called by the
+  !! drop-in tstep_integrate.  Rank 0 alone, like the reference: every rank's device holds the all-reduced integrals.
+  subroutine ibm_facet_output
+    use modglobal, only: libm, lwritefac, rk3step, timee, tnextfac, tfac, dtfac, nfcts
+    use modmpi, only: myid
+    use modstat_nc, only: writestat_nc, writestat_1D_nc
+    use udc_iface
+    real(c_double), allocatable :: acc(:, :)
+    real, allocatable :: varsfac(:, :)
+    if (.not. (libm .and. lwritefac) .or. rk3step /= 3 .or. myid /= 0) return
+    if (timee < tnextfac) return
+    allocate (acc(nfcts, 7), varsfac(nfcts, nstatfac))
+    call udc_check(udc_ibm_facet_get(udc_h, acc, 1_c_int), 'udc_ibm_facet_get')
+    tfac = timee - tfac
+    varsfac(:, 1) = acc(:, 1)/tfac
+    varsfac(:, 2) = acc(:, 2)/tfac
+    varsfac(:, 3) = acc(:, 3)/tfac
+    varsfac(:, 4) = acc(:, 4)/tfac
+    varsfac(:, 5) = acc(:, 6)/tfac
+    varsfac(:, 6) = acc(:, 7)/tfac
+    varsfac(:, 7) = acc(:, 5)/tfac - (acc(:, 4)/dtfac*acc(:, 4)/tfac)
+    call writestat_nc(ncidfac, 1, tncstatfac, (/timee/), nrecfac, .true.)
+    call writestat_1D_nc(ncidfac, nstatfac, ncstatfac, varsfac, nrecfac, nfcts)
+    tfac = timee
+    tnextfac = NINT((timee + dtfac))*1.0
+  end subroutine ibm_facet_output
 
   !> one grid: read both lists (read_sparse_ijk: this rank's points with local indices + the global list), zero the real
   !! mask at this rank's solid points, keep the global lists for the device (udc_ensure runs after all init* routines)
@@ -200,12 +263,15 @@ contains
   !> facet wall functions (wallfunmom :1286, wallfunheat :1436): level coordinates and the facet sections of each grid
   subroutine sections_to_device
     use udc_iface
-    use modglobal, only: iwallmom, iwalltemp, iwallmoist, ltempeq, lmoist, prandtlturb, zf, zh, kb, ke, kh
+    use modglobal, only: iwallmom, iwalltemp, iwallmoist, ltempeq, lmoist, prandtlturb, zf, zh, kb, ke, kh, lwritefac
     use modibmdata, only: bctfxm, bctfxp, bctfym, bctfyp, bctfz, bcqfxm, bcqfxp, bcqfym, bcqfyp, bcqfz
     logical :: heat
     latent = lmoist .and. (iwallmoist == 2 .or. (iwallmoist == 1 .and. any((/bcqfxm, bcqfxp, bcqfym, bcqfyp, bcqfz/) /= 0.)))
     heat = ltempeq .and. (iwalltemp == 2 .or. (iwalltemp == 1 .and. any((/bctfxm, bctfxp, bctfym, bctfyp, bctfz/) /= 0.)) .or. latent)
-    if (iwallmom <= 1 .and. .not. heat) return
+    if (iwallmom <= 1 .and. .not. heat) then
+      if (lwritefac) call facets_to_device
+      return
+    end if
     call udc_check(udc_set_ibm_wallfun(udc_h, int(iwallmom, c_int), real(prandtlturb, c_double), real(zf(kb:ke + kh), c_double), &
                                        real(zh(kb:ke + kh), c_double)), 'udc_set_ibm_wallfun')
     if (iwallmom > 1) then
@@ -222,7 +288,43 @@ contains
         deallocate (wm_lgr, wm_q, wm_hurel, wm_resc, wm_ress)
       end if
     end if
+    if (lwritefac) call facets_to_device
   end subroutine sections_to_device
+
+  !> lwritefac: the facet of every section the device holds (grid_sections kept them), the facets' areas (initfac's faca, read from
+  !! facetarea.inp when lwritefac) and ALL sections of the c grid for the pressure (wallfunheat adds pres0 of the boundary cell before it
+  !! looks at lskipsec, src/modibm.f90:1475-1478)
+  subroutine facets_to_device
+    use udc_iface
+    use modglobal, only: ifinput, nfcts, itot, jtot
+    use initfac, only: faca
+    integer(c_int) :: nsec(0:3), none(1)
+    integer(c_int), allocatable :: pcell(:, :), pfac(:)
+    real(c_double), allocatable :: parea(:)
+    integer :: q, n, m, fac, bid
+    real :: a, dst
+    character(80) :: chmess
+    none = 0
+    do q = 0, 3
+      if (.not. allocated(secfac(q)%fac)) allocate (secfac(q)%fac(0))
+      nsec(q) = size(secfac(q)%fac)
+    end do
+    allocate (pcell(3, max(nfctsecs_c, 1)), pfac(max(nfctsecs_c, 1)), parea(max(nfctsecs_c, 1)))
+    m = 0
+    if (nfctsecs_c > 0 .and. lists(3)%given) then
+      open (ifinput, file='facet_sections_c.txt')
+      read (ifinput, '(a80)') chmess
+      do n = 1, nfctsecs_c
+        read (ifinput, *) fac, a, bid, dst
+        if (lists(3)%bnd(1, bid) < 1 .or. lists(3)%bnd(1, bid) > itot .or. lists(3)%bnd(2, bid) < 1 .or. lists(3)%bnd(2, bid) > jtot) cycle
+        m = m + 1
+        pcell(:, m) = lists(3)%bnd(:, bid); pfac(m) = fac; parea(m) = a
+      end do
+      close (ifinput)
+    end if
+    call udc_check(udc_set_ibm_facet_output(udc_h, int(nfcts, c_int), real(faca(1:nfcts), c_double), nsec, secfac(0)%fac, secfac(1)%fac, &
+                                            secfac(2)%fac, secfac(3)%fac, int(m, c_int), pcell, parea, pfac), 'udc_set_ibm_facet_output')
+  end subroutine facets_to_device
 
   !> One grid's section table as initibmwallfun (src/modibm.f90:273-644) leaves it: which sections act (:366-373), where the
   !! velocity is taken -- the boundary cell, or a reconstruction point along the facet normal when log(dist / z0) <= 1
@@ -235,7 +337,7 @@ contains
     use decomp_2d, only: zstart, zend
     integer, intent(in) :: grid, nsec
     character(*), intent(in) :: fname
-    integer(c_int), allocatable :: cell(:, :), comprec(:), recids(:, :, :), t_lgr(:)
+    integer(c_int), allocatable :: cell(:, :), comprec(:), recids(:, :, :), t_lgr(:), t_fac(:)
     real(c_double), allocatable :: area(:), dist(:), norm(:, :), z0(:), z0h(:), ts(:), recpt(:, :), tmask(:, :), t_q(:), t_hurel(:), t_resc(:), t_ress(:)
     integer :: n, m, fac, bid, dalign, q, pos, i, j, k, di, dj, dk, li, lj
     real :: a, dst, xc, yc, zc, p0(3), p1(3), nrm(3), inter(6, 3), idist(6), planes(6, 3), pn(6, 3)
@@ -245,6 +347,7 @@ contains
     allocate (cell(3, nsec), comprec(nsec), recids(3, 4, nsec), area(nsec), dist(nsec), norm(3, nsec), z0(nsec), z0h(nsec), ts(nsec), &
               recpt(3, nsec), tmask(2, nsec))
     recids = 1; recpt = 0.; tmask = 1.
+    allocate (t_fac(nsec)); t_fac = 0
     if (grid == 3 .and. latent) then
       allocate (t_lgr(nsec), t_q(nsec), t_hurel(nsec), t_resc(nsec), t_ress(nsec))
       t_lgr = 0; t_q = 0.; t_hurel = 0.; t_resc = 0.; t_ress = 0.
@@ -264,7 +367,7 @@ contains
         !  reference's tests/cases/526 reach beyond the domain)
         if (i < 1 .or. i > itot .or. j < 1 .or. j > jtot) cycle
         m = m + 1
-        cell(:, m) = (/i, j, k/); area(m) = a; dist(m) = dst; norm(:, m) = nrm
+        cell(:, m) = (/i, j, k/); area(m) = a; dist(m) = dst; norm(:, m) = nrm; t_fac(m) = fac
         z0(m) = facz0(fac); z0h(m) = facz0h(fac)
         ts(m) = 0.
         if (allocated(facT)) ts(m) = facT(fac, 1)
@@ -352,6 +455,8 @@ contains
     end if
     call udc_check(udc_set_ibm_sections(udc_h, int(grid, c_int), int(m, c_int), cell, area, dist, norm, z0, z0h, ts, comprec, recpt, recids, &
                                         tmask), 'udc_set_ibm_sections')
+    if (allocated(secfac(grid)%fac)) deallocate (secfac(grid)%fac)
+    allocate (secfac(grid)%fac(m)); secfac(grid)%fac = t_fac(1:m)
     if (grid == 3 .and. latent) then
       allocate (wm_lgr(m), wm_q(m), wm_hurel(m), wm_resc(m), wm_ress(m))
       wm_lgr = t_lgr(1:m); wm_q = t_q(1:m); wm_hurel = t_hurel(1:m); wm_resc = t_resc(1:m); wm_ress = t_ress(1:m)
@@ -514,11 +619,13 @@ contains
 
   !> immersed boundary forcing, shear part (src/modibm.f90:1167): the diffusion corrections at the fluid-boundary points
   subroutine ibmwallfun
-    use modglobal, only: libm
+    use modglobal, only: libm, lwritefac, rk3step, dt
     use udc_iface
     if (.not. libm) return
     call ibm_to_device
     call udc_begin(.true.)
+    ! facet output: the sums of this call's sections enter the time integrals on RK stage 3 (src/modibm.f90:1246-1254, 1417, 1595)
+    if (lwritefac .and. rk3step == 3) call udc_check(udc_ibm_facet_sample(udc_h, real(dt, c_double)), 'udc_ibm_facet_sample')
     call udc_check(udc_ibmwallfun(udc_h), 'udc_ibmwallfun')
     call udc_end_tend
   end subroutine ibmwallfun

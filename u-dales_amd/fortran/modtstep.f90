@@ -88,12 +88,14 @@ contains
     use modfields, only: up, vp, wp, svp, thlp, qtp, e12p, thl0, thl0c, dpdxl, dpdyl, dgdt
     use modsubgriddata, only: loneeqn
     use modmpi, only: myid, cmyid
+    use modibm, only: ibm_facet_output
     use udc_iface
     implicit none
 
     call udc_begin(.true.)
     ! (device mode: this launches the recorded routines of the substep, fused)
     call udc_check(udc_tstep_integrate(udc_h, int(rk3step, c_int), real(dt, c_double)), 'udc_tstep_integrate')
+    call ibm_facet_output      ! lwritefac: fac.NNN.nc's record, which the reference's ibmwallfun writes (the substep has run only now)
     if (ifixuinf == 2) then      ! src/modtstep.f90:194-195: the dp/dx ODE (dgdt from fixuinf2); `forces` has used the old dpdxl
       dpdxl(:) = dpdxl(:) + dgdt*(dt/(4. - real(rk3step)))
       call udc_check(udc_set_forcing(udc_h, dpdxl(kb:ke), dpdyl(kb:ke), int(ke - kb + 1, c_int)), 'udc_set_forcing')

@@ -193,6 +193,25 @@ module udc_iface
       type(c_ptr), value :: h
       integer(c_int), value :: iwalltemp
     end function udc_set_ibm_wallheat
+    integer(c_int) function udc_set_ibm_facet_output(h, nfcts, faca, nsec, fac_u, fac_v, fac_w, fac_c, npres, pcell, parea, pfac) &
+        bind(C, name='udc_set_ibm_facet_output')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: nfcts, npres
+      real(c_double), intent(in) :: faca(*), parea(*)
+      integer(c_int), intent(in) :: nsec(4), fac_u(*), fac_v(*), fac_w(*), fac_c(*), pcell(3, *), pfac(*)
+    end function
+    integer(c_int) function udc_ibm_facet_sample(h, dt) bind(C, name='udc_ibm_facet_sample')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      real(c_double), value :: dt
+    end function
+    integer(c_int) function udc_ibm_facet_get(h, out, reset) bind(C, name='udc_ibm_facet_get')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(out) :: out(*)
+      integer(c_int), value :: reset
+    end function
     integer(c_int) function udc_set_ibm_wallmoist(h, iwallmoist, n, lgr, qwall, hurel, resc, ress) bind(C, name='udc_set_ibm_wallmoist')
       import :: c_ptr, c_int, c_double
       type(c_ptr), value :: h
