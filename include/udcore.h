@@ -354,6 +354,10 @@ int udc_set_masscorr(udc_handle *h, int luvolflowr, double uflowrate, int lvvolf
  * shape (ib:ie, kb:ke) there and overruns it. */
 int udc_set_masscorr_outflow(udc_handle *h, int luoutflowr, double uflowrate);
 int udc_masscorr(udc_handle *h, int rk3step, double dt);
+/* &BC BCzp (src/modglobal.f90:176): 1 (default) the tridiagonal solve in z (solmpj), 2 the cosine transform in z of
+ * src/modpois.f90:179-191, 559-590 (equidistant levels).  The cosine modes diagonalise the matrix solmpj solves, so 2 is served by the same
+ * solve with the singular mode's solution shifted to zero mean over the levels (what dropping its kz = 0 coefficient gives). */
+int udc_set_poisson_bczp(udc_handle *h, int bczp);
 /* poisson     src/modpois.f90:419       fillps+bcpup, FFT(x,y)+tridiagonal(z), tderive+bcp */
 int udc_poisson(udc_handle *h, int rk3step, double dt);
 /* tstep_integrate src/modtstep.f90:171  u0 = um + rk3coef*up ..., zero tendencies, m <- 0 on stage 3 */

@@ -609,6 +609,9 @@ void orc_fillps(const orc_grid *g, double rk3coef, const double *up, const doubl
  * POISS_FFT2D branch of poisson :440-712 with solmpj :1107-1166.
  * Spectral coefficients stay in real arrays with half-complex ordering
  * [Re0, Re1, Im1, ..., Re(N/2)], exactly like the reference. */
+/* &BC BCzp (src/modglobal.f90:159): 1 = tridiagonal solve in z (solmpj), 2 = cosine transform in z.  Set by orc_set_poisson_bczp. */
+static int poisson_bczp = 1;
+void orc_set_poisson_bczp(int bczp) { poisson_bczp = bczp; }
 void orc_poisson_solve(const orc_grid *g, double *p) {
   const int nx = g->nx, ny = g->ny, nz = g->nz;
   const double dxi = 1. / g->dx, dyi = 1. / g->dy;
@@ -681,6 +684,28 @@ void orc_poisson_solve(const orc_grid *g, double *p) {
       W(w, i, ny, k) = spec[2 * (ny / 2)];
       for (int j = 1; j <= ny; ++j) W(w, i, j, k) = W(w, i, j, k) * fac;
     }
+  if (poisson_bczp == 2) {
+    /* BCzp = 2, src/modpois.f90:179-191, 559-590: cosine transform in z (equidistant levels), division by the eigenvalues
+     * xyzrt = xrt + yrt + zrt with zrt(k) = -4 dzi^2 sin^2((k-1) pi / (2 ktot)); the modes with xyzrt = 0 are set to zero */
+    const double dzi = 1. / g->dzf[1];
+    double *col = (double *)malloc(sizeof(double) * 2 * (size_t)nz), *tr = col + nz;
+    const double fz = 1. / sqrt(2. * nz);
+    for (int i = 1; i <= nx; ++i)
+      for (int j = 1; j <= ny; ++j) {
+        for (int k = 1; k <= nz; ++k) col[k - 1] = W(w, i, j, k);
+        fft_ref_redft10(nz, col, tr);
+        for (int k = 1; k <= nz; ++k) {
+          double sz = sin((double)(k - 1) * M_PI * (1. / (2. * nz)));
+          double zrt = k == 1 ? 0. : -4. * dzi * dzi * (sz * sz);
+          double xyzrt = 1. * (xrt[i] + yrt[j] + zrt);
+          double v = tr[k - 1] * fz;
+          col[k - 1] = xyzrt != 0. ? v / xyzrt : 0.;
+        }
+        fft_ref_redft01(nz, col, tr);
+        for (int k = 1; k <= nz; ++k) W(w, i, j, k) = tr[k - 1] * fz;
+      }
+    free(col);
+  } else {
   /* solmpj : :1107-1166 */
   for (int j = 1; j <= ny; ++j)
     for (int i = 1; i <= nx; ++i) {
@@ -708,6 +733,7 @@ void orc_poisson_solve(const orc_grid *g, double *p) {
   for (int k = nz - 1; k >= 1; --k)
     for (int j = 1; j <= ny; ++j)
       for (int i = 1; i <= nx; ++i) W(w, i, j, k) = W(w, i, j, k) - W(d, i, j, k) * W(w, i, j, k + 1);
+  }
   /* backward y : :615-625 */
   fac = 1. / sqrt(ny * 1.);
   for (int i = 1; i <= nx; ++i)

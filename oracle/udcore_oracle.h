@@ -164,6 +164,8 @@ void orc_masscorr(const orc_grid *g, int rk3step, double dt, double *up, const d
 void orc_fillps(const orc_grid *g, double rk3coef, const double *up, const double *vp,
                 const double *wp, const double *um, const double *vm, const double *wm,
                 double *pup, double *pvp, double *pwp, double *p);
+void orc_set_poisson_bczp(int bczp);      /* 1 (default): solmpj; 2: cosine transform in z, src/modpois.f90:559-590 */
+void orc_set_poisson_bczp(int bczp);      /* 1 (default): solmpj; 2: cosine transform in z, src/modpois.f90:559-590 */
 void orc_poisson_solve(const orc_grid *g, double *p);   /* in: rhs in p interior; out: p interior */
 void orc_tderive(const orc_grid *g, double *p, double *up, double *vp, double *wp, double *pres0);
 /* ---- time stepping: src/modtstep.f90:171-340 */

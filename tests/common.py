@@ -19,6 +19,7 @@ KERNEL_CASES = {
     "k_coriol_12x8x6": 20,
     "k_tke_12x8x6": 21, "k_tke_thl_12x8x6": 28, "k_qt_12x8x6": 32, "k_moist_12x8x8": 35, "k_uno_12x8x6": 37, "k_src_12x8x8": 39, "k_thlk_12x8x6": 41, "k_svtop_8x8x8": 47, "k_tke_moist_12x8x8": 50, "k_vreman_buoycorr_12x8x10": 52, "k_floor_uno_nothl_12x8x6": 64, "k_bcxs_16x8x12": 75,
     "k_ptop_12x8x6": 84,      # the open lid (BCtopm = 3)
+    "k_bczp2_12x8x8": 88,     # BCzp = 2: cosine transform in z
 }
 # per-level forcings (lstend, nudge, grwdamp): host-level routines, checked in tests/test_level_forcings.py
 LSF_CASES = {"k_lsf_12x8x24": 29, "run_lsf_16x8x24s": 30, "k_lsfq_12x8x20": 34}
@@ -31,7 +32,7 @@ RUN_CASES = {"run_16x16x8": 21, "run_smag_scalar_16x8x12s": 22, "run_floor_scala
              "run_floor_uno_nothl_16x8x12s": 65, "run_ibm_wf2_16x12x10": 68, "run_ibm_wh2_16x12x10": 70, "run_ibm_wh1_16x12x10": 72,
              "run_ground_wf3_16x8x12": 73, "run_ground_wh2_16x8x12": 74, "run_bcxs_16x8x12s": 76, "run_bcxs_avg_16x8x12s": 77, "run_ytstats_ibm_16x12x10": 78,
              "run_ibm_moist_16x12x10": 79, "run_ibm_moistwq_16x12x10": 80, "run_uoutflow_16x16x8": 82, "run_ibm_uoutflow_16x12x10": 83,
-             "run_ptop_16x8x12s": 85, "run_ptop_ibm_16x12x10": 86, "run_ibmtall_16x12x10": 87}      # the open lid (BCtopm = 3), the second with a block that reaches it
+             "run_ptop_16x8x12s": 85, "run_ptop_ibm_16x12x10": 86, "run_ibmtall_16x12x10": 87, "run_bczp2_16x16x8": 89}      # the open lid (BCtopm = 3), the second with a block that reaches it
 # decks with the facet wall functions (iwallmom > 1): on the device path and in the reference build; not in the C oracle's
 # whole-substep driver (the numpy restatement covers the routine); the Fortran drop-in modibm builds the section tables itself
 # (also: BCxs = 2, the scalars' inflow / outflow -- pinned device against reference fixture, not restated in the C oracle)

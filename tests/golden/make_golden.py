@@ -506,6 +506,11 @@ CASES.update({
     "run_ibm_uoutflow_16x12x10": ("run", 83, 16, 12, 10, dict(sgs="vreman", nsv=1, floor=True, randu=0.05, ibm=IBM_BLOCKS["run_ibm_edge_16x12x10"],
                                                               physics="luoutflowr = .true.\nuflowrate = 1.05", oracle="nsub = 9\ndump_at = 3, 9"), 1.04),
 })
+# BCzp = 2: the Poisson solve with a cosine transform in z (equidistant levels) instead of the tridiagonal solve, src/modpois.f90:179-191, 559-590
+CASES.update({
+    "k_bczp2_12x8x8": ("kernels", 88, 12, 8, 8, dict(sgs="vreman", floor=True, randu=0.05, bc="BCzp = 2", oracle="nspin = 3"), 1.0),
+    "run_bczp2_16x16x8": ("run", 89, 16, 16, 8, dict(sgs="smag", nsv=1, floor=True, randu=0.05, bc="BCzp = 2", oracle="nsub = 9\ndump_at = 3, 9"), 1.0),
+})
 # the open lid, BCtopm = 3 (BCtopm_pressure): w(ke+1) is prognostic -- bcpup's row from the slab mean of pres0(ke), tderive's from the
 # mean of p(ke), tstep_integrate's plane; per-routine vectors after 4 substeps (so that pres0 and w(ke+1) are no longer zero), a run
 # with a kappa-advected scalar (its top flux now sees w(ke+1)), and a run with an immersed boundary one block of which reaches the

@@ -114,6 +114,7 @@ class Oracle:
                          (C.c_double * 4)(*(list(wsvtop) + [0.] * 4)[:4]), (C.c_double * 4)(*(list(sv_top) + [0.] * 4)[:4]),
                          int(bool(lchem)), k1, JNO2, int(bool(lqlnr)), iadv_thl, int(bool(lbuoycorr)), Rigc)
         self.L = lib()
+        self.L.orc_set_poisson_bczp(1)      # (a static switch of the library: every new oracle starts from the tridiagonal solve)
 
     def mshape(self):
         return (self.nz + 2, self.ny + 2, self.nx + 2)

@@ -670,6 +670,19 @@ extern "C" int udc_set_moist_thermo(udc_handle *h, double thls, double qts, doub
   return 0;
 }
 
+extern "C" int udc_set_poisson_bczp(udc_handle *h, int bczp) {
+  ENTRY_FLUSH(h);
+  if (bczp != 1 && bczp != 2) { udc_set_error("udc_set_poisson_bczp: BCzp is 1 (tridiagonal solve in z) or 2 (cosine transform in z)"); return 1; }
+  if (bczp == 2) {      // (src/modpois.f90:180: "Assumes equidistant in z")
+    std::vector<double> dzf(h->g.nz + 2);
+    HIP_OK(hipMemcpy(dzf.data(), h->m.dzf, sizeof(double) * dzf.size(), hipMemcpyDeviceToHost));
+    for (int k = 2; k <= h->g.nz; ++k)
+      if (fabs(dzf[k] - dzf[1]) > 1e-12 * fabs(dzf[1])) { udc_set_error("udc_set_poisson_bczp: BCzp = 2 (cosine transform in z) needs equidistant levels"); return 1; }
+  }
+  h->bczp = bczp;
+  return 0;
+}
+
 extern "C" int udc_set_fkar(udc_handle *h, double fkar) {
   ENTRY_FLUSH(h);
   if (!(fkar > 0.)) { udc_set_error("udc_set_fkar: the von Karman constant must be positive"); return 1; }

@@ -268,6 +268,7 @@ struct udc_handle {
   double *outlet_w = nullptr;             // luoutflowr: dy dzf(k) / outlet area, [nz+2] indexed by the reference's k
   double uflowrate = 0., vflowrate = 0., zsize = 0.;
   double dzhi_top = 0.;      // dzhi(ke+1)
+  int bczp = 1;              // &BC BCzp: 1 tridiagonal solve in z, 2 the cosine transform's solution (udc_set_poisson_bczp)
   bool um_alias = false;                // um,vm,wm are logically equal to u0,v0,w0 (after RK stage 3 of a fused
                                         // substep); the UM buffers are stale until stage 1 rotates the pointers
   bool no_alias = false;                // UDC_NO_ALIAS=1: always copy (A/B switch)

@@ -704,6 +704,23 @@ __global__ __launch_bounds__(256) void integrate_kernel(Geo g, TileGrid tg, Metr
   }
 }
 
+// ---- BCzp = 2 (src/modpois.f90:179-191, 559-590): cosine transform in z on equidistant levels instead of the tridiagonal solve.  The
+// cosine modes diagonalise exactly the matrix solmpj solves (a = c = dzi^2, Neumann rows at the floor and the lid), so every horizontal
+// mode with a non-zero eigenvalue has the same unique solution either way; the singular mode (kx = ky = 0) is closed by a Dirichlet row at
+// the lid there (:209-220) and by dropping its kz = 0 coefficient here -- two solutions of the same compatible system that differ by a
+// constant: the one with zero mean over the levels is the cosine solve's.  One small kernel behind the Thomas solve, on the rank that holds
+// kx = 0: x[k stride] -= mean_k x.
+__global__ __launch_bounds__(256) void zero_mode_mean_kernel(int nz, size_t stride, double2 *__restrict__ x) {
+  __shared__ double sr[4], si[4];
+  double ar = 0., ai = 0.;
+  for (int k = threadIdx.x; k < nz; k += 256) { const double2 v = x[(size_t)k * stride]; ar += v.x; ai += v.y; }
+  for (int o = 32; o > 0; o >>= 1) { ar += __shfl_xor(ar, o, 64); ai += __shfl_xor(ai, o, 64); }
+  if ((threadIdx.x & 63) == 0) { sr[threadIdx.x >> 6] = ar; si[threadIdx.x >> 6] = ai; }
+  __syncthreads();
+  const double mr = ((sr[0] + sr[1]) + (sr[2] + sr[3])) / nz, mi = ((si[0] + si[1]) + (si[2] + si[3])) / nz;
+  for (int k = threadIdx.x; k < nz; k += 256) { double2 v = x[(size_t)k * stride]; v.x -= mr; v.y -= mi; x[(size_t)k * stride] = v; }
+}
+
 // ---- the open lid, BCtopm = 3 (BCtopm_pressure, src/modglobal.f90:142: "vertical velocity can vary according to pressure gradient")
 // w(ke+1) is a prognostic plane: `boundary` leaves it alone (src/modboundary.f90:191-200), bcpup gives it the predicted velocity
 //   pwp(ke+1) = wm(ke+1) / rk3coef + 2 <pres0>(ke) dzhi(ke+1),   wp(ke+1) = pwp(ke+1) - wm(ke+1) / rk3coef   (:1234-1243),
@@ -1230,6 +1247,8 @@ int k_poisson_solve_slab(udc_handle *h) {
     PROF(h, "thomas");
     if (launch_thomas(h, h->thomas_lds_slab, nmodes, g.nz, 1. / ((double)g.nx * (double)ny), h->ev_slab, h->ztab_slab,
                       reinterpret_cast<double2 *>(h->specB), 0, 0, ny)) return 1;
+    if (h->bczp == 2 && h->cfg.rank == 0)      // (rank 0 holds kx = 0: specB[k][kx_l = 0][y = 0])
+      hipLaunchKernelGGL(zero_mode_mean_kernel, dim3(1), dim3(256), 0, h->stream, g.nz, nmodes, reinterpret_cast<double2 *>(h->specB));
     HIP_OK(hipGetLastError());
   }
   {
@@ -1332,6 +1351,8 @@ int k_poisson_solve(udc_handle *h) {
     const bool pairable = h->nkxp % ZB == 0 && g.ny % 2 == 0;
     if (launch_thomas(h, h->thomas_lds, nmodes, g.nz, 1. / ((double)g.nx * (double)g.ny), h->ev, h->ztab,
                       reinterpret_cast<double2 *>(h->spec), pairable ? h->nkxp / ZB : 0, pairable ? g.ny : 0)) return 1;
+    if (h->bczp == 2)      // spec[k][ky = 0][kx = 0]
+      hipLaunchKernelGGL(zero_mode_mean_kernel, dim3(1), dim3(256), 0, h->stream, g.nz, (size_t)nmodes, reinterpret_cast<double2 *>(h->spec));
     HIP_OK(hipGetLastError());
   }
   {

@@ -193,6 +193,11 @@ module udc_iface
       type(c_ptr), value :: h
       integer(c_int), value :: iwalltemp
     end function udc_set_ibm_wallheat
+    integer(c_int) function udc_set_poisson_bczp(h, bczp) bind(C, name='udc_set_poisson_bczp')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+      integer(c_int), value :: bczp
+    end function
     integer(c_int) function udc_set_ibm_facet_output(h, nfcts, faca, nsec, fac_u, fac_v, fac_w, fac_c, npres, pcell, parea, pfac) &
         bind(C, name='udc_set_ibm_facet_output')
       import :: c_int, c_ptr, c_double
@@ -533,7 +538,7 @@ contains
                          BCtopm, Uinf, Vinf, lles, ltempeq, lbuoyancy, lmoist, iadv_thl, BCtopT, BCbotT, grav, e12min, &
                          iadv_qt, BCtopq, BCbotq, zf, zh, BCbotm, prandtlturb, fkar, BCtops, lchem, k1, JNO2, &
                          lcoriol, lprofforc, om22, om23, luvolflowr, lvvolflowr, uflowrate, vflowrate, &
-                         lnudge, igrw_damp, ifixuinf, ds
+                         lnudge, igrw_damp, ifixuinf, ds, BCzp
     use modsurfdata, only: wttop, thl_top, wtsurf, thvs, wqtop, qt_top, wqsurf, thls, qts, ps, z0h, wsvtop, sv_top
     use modsubgriddata, only: lsmagorinsky, lvreman, loneeqn, ldelta, prandtli, c_vreman, csz, cm, cn, ch1, ch2, ce1, ce2, lbuoycorr, Rigc
     use modfields, only: dpdxl, dpdyl, thlpcar, ug, whls, dthldxls, dthldyls, dqtdxls, dqtdyls, dqtdtls, &
@@ -593,6 +598,7 @@ contains
     cfg%lbottom = merge(1, 0, udc_floor_on)
     cfg%z0 = udc_floor_z0
     call udc_check(udc_create(cfg, udc_h), 'udc_create')
+    if (BCzp /= 1) call udc_check(udc_set_poisson_bczp(udc_h, int(BCzp, c_int)), 'udc_set_poisson_bczp')      ! cosine transform in z
     if (nprocs > 1) then
       ! RCCL communicator over the y-slab ranks: rank 0 makes the id, MPI carries it (INTEGRATION.md section 4)
 #ifdef UDC_TEST_TRANSPORT

@@ -20,6 +20,8 @@ def from_deck(deck, device=0, rank=0, nranks=1):
                    prandtli=prandtli, c_vreman=c_vreman, csz=csz, device=device, rank=rank, nranks=nranks,
                    lbottom=lbottom, z0=float(deck.get("BC", "z0")),
                    uinf=float(deck.get("INLET", "Uinf")), vinf=float(deck.get("INLET", "Vinf")))
+    if int(deck.get("BC", "BCzp")) != 1:
+        core.set_poisson_bczp(int(deck.get("BC", "BCzp")))
     core.set_masscorr(bool(deck.get("PHYSICS", "luvolflowr")), float(deck.get("PHYSICS", "uflowrate")),
                       bool(deck.get("PHYSICS", "lvvolflowr")), float(deck.get("PHYSICS", "vflowrate")))
     if deck.get("PHYSICS", "luoutflowr"):      # masscorr's outflow-rate branch for u (src/modforces.f90:352-387)

@@ -285,6 +285,10 @@ class DynCore:
         """ltempeq off + wfuno floor: the frozen temperature of the first level (include/udcore.h)."""
         L._check(self.lib.udc_set_floor_air_temperature(self.h, C.c_double(thl_kb)), "udc_set_floor_air_temperature")
 
+    def set_poisson_bczp(self, bczp):
+        """&BC BCzp: 1 the tridiagonal solve in z, 2 the cosine transform's solution (include/udcore.h udc_set_poisson_bczp)."""
+        L._check(self.lib.udc_set_poisson_bczp(self.h, int(bczp)), "udc_set_poisson_bczp")
+
     def set_fkar(self, fkar):
         """&WALLS fkar: the von Karman constant of the floor and facet wall functions (include/udcore.h udc_set_fkar)."""
         L._check(self.lib.udc_set_fkar(self.h, C.c_double(fkar)), "udc_set_fkar")

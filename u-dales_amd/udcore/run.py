@@ -42,8 +42,8 @@ def check_supported(deck):
     #  src/modstartup.f90:811-816 -- Deck.apply_checkinitvalues)
     if int(g("BC", "BCxm")) != 1 or int(g("BC", "BCym")) != 1:
         _refuse("only periodic lateral boundaries (BCxm = BCym = 1) are on the device path")
-    if int(g("DYNAMICS", "ipoiss")) != 0 or int(g("BC", "BCzp")) != 1:
-        _refuse("only ipoiss = 0 (FFT in x, y) with BCzp = 1 is on the device path")
+    if int(g("DYNAMICS", "ipoiss")) != 0 or int(g("BC", "BCzp")) not in (1, 2):
+        _refuse("only ipoiss = 0 (FFT in x, y) with BCzp = 1 or 2 is on the device path")
     # &RUN nprocx / nprocy describe the CPU run's pencil layout; the device path splits y over however many GPUs it is
     # launched on and the fields do not depend on it.  (One thing in the reference does: the immersed boundary's point masks
     # wrap periodically only in a direction that is split over ranks -- udcore.ibm hands the deck's values to
