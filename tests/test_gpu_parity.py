@@ -10,6 +10,8 @@ Floating-point tolerances (real(8) everywhere, stated as error / max|reference f
   RUN_TOL    1e-9  : a handful of chained substeps.
 The north star's acceptance bar is 1e-6 after 100 steps (tests/test_gpu_long.py).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -849,6 +851,39 @@ def test_pressure_total_form_and_in_sweep_scalar_update_are_what_runs(monkeypatc
     core.substep(1, dt, True)
     assert not core.last_plan()["pressure_total_form"]
     core.close()
+
+
+def test_pressure_total_form_from_a_pres0_with_a_foreign_constant():
+    """A warm start whose pres0 did not come from this solver (a smooth field + 3.7): the reference's form carries the constant along,
+    the pressure-total form re-pins it with every solve (include/udcore.h, udc_substep) -- the velocities and the GRADIENT of pres0 agree
+    to round-off all the same, pres0 itself up to one constant per run; and p, scratch after a pressure-total substep, is not handed out."""
+    from udcore.core import DynCore
+    g = Grid.uniform(32, 32, 12)
+    st = random_state(g, 9)
+    k, j, i = np.meshgrid(np.arange(g.nz + 2), np.arange(g.ny + 2), np.arange(g.nx + 2), indexing="ij")
+    st["pres0"] = 3.7 + 0.02 * np.sin(2 * np.pi * (i - 0.5) / g.nx) * np.cos(2 * np.pi * (j - 0.5) / g.ny) * np.cos(np.pi * (k - 0.5) / g.nz)
+    st["pres0"][0] = 0.
+    dt = 0.05
+    out = {}
+    for form in ("1", "0"):
+        os.environ["UDC_PTOTAL"] = form
+        try:
+            core = DynCore(g, sgs=2, lbottom=True, z0=0.03)
+            core.load_state(st)
+            for isub in range(6):
+                core.substep(isub % 3 + 1, dt, True)
+            assert core.last_plan()["pressure_total_form"] == (form == "1")
+            if form == "1":
+                with pytest.raises(L.UdcError, match="scratch"):
+                    core.download("p")
+            out[form] = {q: core.download(q)[1:-1, 1:-1, 1:-1].copy() for q in ("u0", "v0", "w0", "pres0")}
+            core.close()
+        finally:
+            del os.environ["UDC_PTOTAL"]
+    for q in ("u0", "v0", "w0"):
+        assert relerr(out["1"][q], out["0"][q]) <= 1e-11, q
+    d = out["1"]["pres0"] - out["0"]["pres0"]
+    assert abs(d.mean() + 3.7) < 0.1 and np.abs(d - d.mean()).max() <= 1e-11 * max(np.abs(out["0"]["pres0"] - out["0"]["pres0"].mean()).max(), 1e-3)
 
 
 @pytest.mark.parametrize("shape,pmode", [((64, 32, 16), (5, 2, 1)), ((32, 48, 12), (16, 24, 0)), ((20, 12, 10), (3, 1, 7))])
