@@ -1,13 +1,13 @@
 """Exploratory parity fuzz (GPU box): random grid shapes / closures / scalars / lids / layouts, three to six fused substeps of the device
 against the C oracle on seeded random fields.  Prints every case that exceeds 1e-9 or raises.  Test infrastructure (uses oracle/).
-    python profiles/tools/fuzz_parity.py [ncases] [seed]"""
+    python tests/fuzz_parity.py [ncases] [seed]"""
 import os
 import sys
 import traceback
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "tests"), os.path.join(ROOT, "u-dales_amd")]
 import oracle_lib as ol  # noqa: E402
 from common import interior, nocorner, relerr  # noqa: E402

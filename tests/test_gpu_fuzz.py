@@ -1,7 +1,7 @@
 """Seeded fuzz of the fused substep against the C oracle: random grid shapes (4 .. 128 columns, 4 .. 64 rows, 3 .. 40 levels, odd and
 non-power-of-two ones among them), closures, scalars, stretched levels, floor, the three lids, one-GPU / slab layout with 1 / 2 / 4
 transpose chunks, and the order switches (UDC_PTOTAL, UDC_P_TRANSPOSE, UDC_MOM_PIPE), three or six substeps each, 1e-9.
-profiles/tools/fuzz_parity.py is the generator (1150 cases of six seeds ran clean in round 6: profiles/r06/fuzz_parity.txt); here 60
+tests/fuzz_parity.py is the generator (1150 cases of six seeds ran clean in round 6: profiles/r06/fuzz_parity.txt); here 60
 cases of a fixed seed."""
 import os
 import sys
@@ -14,7 +14,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_sixty_random_configurations_match_the_oracle():
-    sys.path.insert(0, os.path.join(ROOT, "profiles", "tools"))
     import fuzz_parity
     rng = np.random.default_rng(20260930)
     bad = [i for i in range(60) if fuzz_parity.one(rng, i)]
