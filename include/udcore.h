@@ -283,7 +283,10 @@ int udc_level_forcings(udc_handle *h, int when);
  * Both are part of udc_substep once committed.  With an immersed boundary udc_masscorr and udc_slab_average(s) average over
  * the fluid cells only (avexy_ibm, src/modmpi.f90:623-664, with IIu / IIv / IIc), and so do the moist thermodynamics' slab averages
  * (udc_thermodynamics: diagfld's thl0av, qt0av, ql0av over IIc, thvh over IIw; src/modthermodynamics.f90:76,262-279).  Wall
- * fluxes of heat and moisture: udc_set_ibm_wallheat / udc_set_ibm_wallmoist below; without them adiabatic, impermeable walls. */
+ * fluxes of heat and moisture: udc_set_ibm_wallheat / udc_set_ibm_wallmoist below; without them adiabatic, impermeable walls.
+ * A listed point whose (i, j) lies outside the domain is dropped without a word, as the reference's reader drops what no rank owns
+ * (read_sparse_ijk, src/readinput.f90:90-100; the lists of its own tests/cases/526 reach beyond the domain); a level outside kb..ke is
+ * an error. */
 enum { UDC_IBM_U = 0, UDC_IBM_V = 1, UDC_IBM_W = 2, UDC_IBM_C = 3 };
 int udc_set_ibm_points(udc_handle *h, int grid, const int *solid, int nsolid, const int *bound, int nbound);
 int udc_set_ibm_mask_wrap(udc_handle *h, int wrapx, int wrapy);
