@@ -478,6 +478,29 @@ int udc_set_scalar_bcx(udc_handle *h, int bcxs, const double *svprof, double uou
  * points.  wlev[ktot]; evaluated on the device at the start of every substep.  NULL: back to the constant of udc_set_scalar_bcx. */
 int udc_set_scalar_bcx_outflow(udc_handle *h, const double *wlev);
 
+/* Inflow and outflow in x for the flow itself (&BC BCxm = 2: the inlet's velocity from prof.inp's profile, a convective outlet;
+ * the reference opens the lid with it, src/modstartup.f90:830-849, so cfg->bctopm must be 3).  What it replaces:
+ *   xmi_profile      src/modboundary.f90:688-717     u(ib) = uprof(k); u, v, w at ib-1 mirrored about uprof, vprof, 0
+ *   xmo_convective   :908-926                         v, w (the 0 and the m fields) at ie+1 carried out with uouttot at every `boundary`
+ *   bcpup            :1257-1280                       pup(ib) = uprof / rk3coef, up(ib) = 0; pup(ie+1) = um(ie+1) / rk3coef
+ *                                                     - (u0(ie+1) - u0(ie)) dxi uouttot, at kb a copy of pup(ie)
+ *   bcp, closurebc   :1376-1394, :467-475             p, pres0, ekm, ekh at ib-1 / ie+1 = the column next to them
+ *   initpois/poisson src/modpois.f90:113-121, 492-507 cosine transform in x (REDFT10 / REDFT01) instead of the real FFT
+ *   tstep_integrate  src/modtstep.f90:262-264         u0(ie+1) = um(ie+1) + rk3coef up(ie+1)
+ * udc_create_open_x makes the handle (cfg as for udc_create, itot the deck's); uprof, vprof: [ktot+2] indexed by the reference's k
+ * (entry ktot+1 is what the reference's uprof(ke+1) holds: zero, src/modfields.f90:556).  Such a handle keeps the reference's x ghost
+ * columns ib-1 and ie+1 of every field on the device: udc_field_upload takes them from a host array that carries them (lb[0] <= 0,
+ * ub[0] >= itot+1: u0(ie+1), v0 / w0 / vm / wm(ie+1) are state), udc_field_download returns them; columns further out are left alone.
+ * One rank; no transported scalars, temperature, moisture, immersed boundary, statistics, volume-flow forcing or one-equation closure
+ * yet (those entry points refuse the handle).  DESIGN.md section 4 has the layout (udc_xopen.hip).
+ * udc_set_open_x_outflow: the outlet's speed uouttot (src/modboundary.f90:141-160) -- wlev NULL: the constant given (ubulk of a prescribed
+ * flow); wlev[ktot] = dzf(k) / (zh(ke+1) - zh(kb+1)): sum_k wlev(k) u0av(k) of the state each substep starts from, `uouttot` being
+ * the value in force until the first refresh (bcpup reads the previous `boundary`'s speed) -- and, with hold_first, through the whole
+ * first substep: the reference's start-up forms u0av before its first `boundary` puts uprof into u(ib), and the first substep's
+ * `boundary` still reads that u0av (src/modstartup.f90:1601, src/program.f90:118, 214). */
+int udc_create_open_x(const udc_config *cfg, const double *uprof, const double *vprof, udc_handle **out);
+int udc_set_open_x_outflow(udc_handle *h, const double *wlev, double uouttot, int hold_first);
+
 /* checksim's diagnostics (src/modchecksim.f90:76-203) of the state on the device: out[0] = calccourant's number -- the maximum of the
  * SIGNED sum (um dxhi + vm dyi + wm dzhi) dtmn, :111-117 --, out[1] = calcdiffnr's (:142-149), out[2], out[3] = chkdiv's divmax and
  * divtot of u0, v0, w0 (:179-196); dtmn: the mean time step since the last report (:83, :86). */

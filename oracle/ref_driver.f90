@@ -387,6 +387,7 @@ contains
       call put3(tag//'.thl0', thl0, (/ib - ih, jb - jh, kb - kh/))
       call put3(tag//'.thlm', thlm, (/ib - ih, jb - jh, kb - kh/))
     end if
+    if (BCxm /= 1) call put1(tag//'.uouttot', (/uouttot/), 1)   ! the outlet's speed as the last `boundary` left it (bcpup reads it)
     if (ifixuinf == 2) call put1(tag//'.dpdxl', dpdxl(kb:ke), kb)
     if (ladaptive) call put1(tag//'.time', (/timee, dt/), 1)
     if (lmoist) then

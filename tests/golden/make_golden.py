@@ -263,7 +263,7 @@ def write_case(d, iexpnr, text, zf, u=1.0, v=0.0, pgx=1e-4, dthl=0.0, dthlrad=0.
                     f.write(" ".join(repr(float(x)) for x in row) + "\n")
 
 
-KEEP_KERNELS = ("meta dzf dzh zf dpdxl dpdyl rk3 in.u0 in.v0 in.w0 in.um in.vm in.wm in.pres0 "
+KEEP_KERNELS = ("meta dzf dzh zf dpdxl dpdyl rk3 in.uouttot in.u0 in.v0 in.w0 in.um in.vm in.wm in.pres0 "
                 "in.ekm in.ekh adv.up adv.vp adv.wp sub.ekm sub.ekh sub.u0 sub.up sub.vp sub.wp bot.up bot.vp frc.up frc.vp "
                 "in.thl0 in.thlm adv.thlp sub.thlp sub.thl0 bot.thlp pre.thlp out.thl0 out.thlm "
                 "thm.presf thm.presh thm.exnf thm.exnh thm.thvh thm.ql0av thm.ql0 thm.thv0h "
@@ -519,6 +519,11 @@ CASES.update({
 IBM_BLOCKS["run_ptop_ibm_16x12x10"] = [(5, 8, 4, 7, 10), (11, 13, 8, 10, 2)]
 IBM_BLOCKS["run_ibmtall_16x12x10"] = IBM_BLOCKS["run_ptop_ibm_16x12x10"]      # the same obstacles under a closed (free-slip) lid
 CASES.update({
+    # inflow / outflow in x (&BC BCxm = 2: xmi_profile, xmo_convective, bcpup's and bcp's profile branches, the cosine transform in x;
+    # the reference opens the lid itself, src/modstartup.f90:845-848), prof.inp's u = 1, v = 0.1
+    "k_xopen_16x8x12": ("kernels", 90, 16, 8, 12, dict(sgs="vreman", floor=True, bctopm=3, randu=0.05, bc="BCxm = 2", oracle="nspin = 4"), 1.04),
+    "run_xopen_16x8x12s": ("run", 91, 16, 8, 12, dict(sgs="smag", floor=True, bctopm=3, randu=0.05, bc="BCxm = 2", oracle="nsub = 9\ndump_at = 3, 9"), 1.06),
+    "run_xopen_vr_24x8x10": ("run", 92, 24, 8, 10, dict(sgs="vreman", floor=True, bctopm=3, randu=0.05, bc="BCxm = 2", dx=0.4, oracle="nsub = 12\ndump_at = 6, 12"), 1.0),
     "k_ptop_12x8x6": ("kernels", 84, 12, 8, 6, dict(sgs="vreman", floor=True, bctopm=3, randu=0.05, oracle="nspin = 4"), 1.04),
     "run_ptop_16x8x12s": ("run", 85, 16, 8, 12, dict(sgs="smag", nsv=1, floor=True, bctopm=3, randu=0.05, oracle="nsub = 9\ndump_at = 3, 9"), 1.06),
     "run_ibmtall_16x12x10": ("run", 87, 16, 12, 10, dict(sgs="vreman", nsv=1, floor=True, bctopm=1, randu=0.05, ibm=[(5, 8, 4, 7, 10), (11, 13, 8, 10, 2)],
@@ -684,6 +689,7 @@ THL_CASES = {"k_tke_moist_12x8x8": dict(dthl=0.25, qt=0.0118, dqt=-8e-5, tke=0.0
              "k_qt_12x8x6": dict(dthl=0.3, qt=0.008, dqt=-4e-4), "run_qt_16x8x12s": dict(dthl=0.25, qt=0.007, dqt=-2e-4),
              "k_lsf_12x8x24": dict(dthl=0.3, ug=1.05, wtop=0.02), "run_lsf_16x8x24s": dict(dthl=0.25, ug=0.95, wtop=-0.03), "k_tke_12x8x6": dict(tke=0.05), "k_tke_thl_12x8x6": dict(tke=0.08, dthl=0.3), "k_coriol_12x8x6": dict(ug=1.1), "run_profforc_16x16x8": dict(ug=1.3), "k_thl_12x8x6": dict(dthl=0.4, dthlrad=2e-3), "run_thl_16x8x12s": dict(dthl=0.25, dthlrad=-1e-3),
              "k_buoy_12x8x6": dict(dthl=0.3), "run_buoy_16x8x12s": dict(dthl=0.2),
+             "k_xopen_16x8x12": dict(v=0.1), "run_xopen_16x8x12s": dict(v=0.1), "run_xopen_vr_24x8x10": dict(u=0.8, v=-0.05),
              "k_ibm_thl_16x12x10": dict(dthl=0.3), "run_ibm_thl_16x12x10": dict(dthl=0.25), "run_ptop_ibm_16x12x10": dict(dthl=0.25), "run_ibm_thlcons_16x12x10": dict(dthl=0.25),
              "run_ibm_qt_16x12x10": dict(dthl=0.25, qt=0.007, dqt=-2e-4),
              "run_stats_16x8x12s": dict(dthl=0.25), "run_stats_ibm_16x12x10": dict(dthl=0.25), "run_ytstats_ibm_16x12x10": dict(dthl=0.25),
@@ -946,7 +952,8 @@ def main():
         else:
             keep = {k: v for k, v in d.items()
                     if k.count(".") == 0 or k.split(".")[1] in ("u0", "v0", "w0", "pres0", "um", "thl0", "thlm", "e120", "e12m", "qt0", "qtm", "dpdxl", "time")
-                    or (k.startswith("s000.") and not k.startswith("s000.ek")) or ".sv0" in k or k.startswith(("st.", "xyt.", "yt."))}
+                    or (k.startswith("s000.") and not k.startswith("s000.ek")) or ".sv0" in k or k.startswith(("st.", "xyt.", "yt."))
+                    or ("xopen" in name and k.split(".")[1] in ("vm", "wm", "uouttot"))}
             # (s000.ekm/ekh are dumped before the first closure call: uninitialised memory, not data)
         tmpf = os.path.join(HERE, name + ".bin")
         write_dump(tmpf, keep)

@@ -1,0 +1,167 @@
+"""Inflow / outflow in x (&BC BCxm = 2; u-dales_amd/csrc/udc_xopen.hip) against vectors of the reference's own Fortran: decks with
+BCxm = 2 run through oracle/_ref/udales_ref (tests/golden/make_golden.py: k_xopen_*, run_xopen_*), fields dumped WITH their x
+ghost columns ib-1 and ie+1 -- which are state here (the inlet's mirrored values, the convective outlet's v, w and the
+prognostic u(ie+1)), so they are compared too.
+
+The oracle does not restate this branch (oracle/udcore_oracle.h: periodic x): the reference's vectors are the only check, as for
+the wall-function and scalar-outflow cases (tests/common.py WF_RUN_CASES).  Tolerances as in tests/test_gpu_parity.py.
+"""
+import numpy as np
+import pytest
+
+from common import deck_path, interior, load_fixture, marr, nocorner, relerr
+from udcore import read_deck
+
+pytestmark = pytest.mark.gpu
+
+KERNEL_TOL = 1e-11
+RUN_TOL = 1e-9
+K_CASES = {"k_xopen_16x8x12": 90}
+R_CASES = {"run_xopen_16x8x12s": 91, "run_xopen_vr_24x8x10": 92}
+
+
+def make_core(name, iexp):
+    import udcore
+    d = read_deck(deck_path(name, iexp))
+    core = udcore.from_deck(d)
+    assert core.open_x
+    return d, core
+
+
+def wlev(g):
+    return g.dzf[1:g.nz + 1] / (g.zh[g.nz + 1] - g.zh[2])      # src/modboundary.f90:146-156
+
+
+def xcols(a):
+    """The interior rows and levels of an m-array, x ghost columns included."""
+    return a[1:-1, 1:-1, :]
+
+
+@pytest.mark.parametrize("name,iexp", sorted(K_CASES.items()))
+def test_each_routine_matches_reference(name, iexp):
+    fix = load_fixture(name)
+    d, core = make_core(name, iexp)
+    g, nz = core.g, core.g.nz
+    for k in ("u0", "v0", "w0", "um", "vm", "wm", "pres0", "ekm", "ekh"):
+        core.upload(k, np.nan_to_num(marr(fix, "in." + k, nz)))
+    # what the upload took: the ghost columns come back as they went in
+    for k in ("u0", "v0", "w0", "vm", "pres0"):
+        assert np.array_equal(xcols(core.download(k)), xcols(marr(fix, "in." + k, nz))), k
+    zero = np.zeros(g.mshape())
+
+    def zero_tend():
+        for k in ("up", "vp", "wp"):
+            core.upload(k, zero)
+
+    zero_tend()
+    core.advection()
+    for k in ("up", "vp", "wp"):
+        assert relerr(interior(core.download(k)), interior(marr(fix, "adv." + k, nz))) <= KERNEL_TOL, k
+    # (the test has teeth: the same sweep on periodic x gives something else in the columns next to the ends)
+    ref = interior(marr(fix, "adv.vp", nz))
+    assert np.abs(ref[:, :, 0]).max() > 0
+    zero_tend()
+    core.subgrid()
+    assert relerr(core.download("ekm"), marr(fix, "sub.ekm", nz)) <= KERNEL_TOL          # every ghost included (closurebc)
+    assert relerr(core.download("ekh"), marr(fix, "sub.ekh", nz)) <= KERNEL_TOL
+    assert relerr(core.download("u0"), marr(fix, "sub.u0", nz)) <= KERNEL_TOL
+    for k in ("up", "vp", "wp"):
+        assert relerr(interior(core.download(k)), interior(marr(fix, "sub." + k, nz))) <= KERNEL_TOL, k
+    core.bottom()
+    for k in ("up", "vp"):
+        assert relerr(interior(core.download(k)), interior(marr(fix, "bot." + k, nz))) <= KERNEL_TOL, k
+    zero_tend()
+    core.advection(); core.subgrid(); core.bottom(); core.coriolis(); core.forces()
+    core.rk3step, core.dt = int(fix["rk3"].data[0]), float(fix["rk3"].data[1])
+    core.masscorr()
+    for k in ("up", "vp", "wp"):
+        assert relerr(interior(core.download(k)), interior(marr(fix, "pre." + k, nz))) <= KERNEL_TOL, k
+    # bcpup reads the outlet's speed as the previous substep's `boundary` left it (dumped by the driver)
+    core.set_open_x_outflow(None, float(fix["in.uouttot"].data[0]))
+    core.poisson()
+    rk3coef = core.dt / (4. - core.rk3step)
+    pnat = 1e-2 * np.abs(marr(fix, "in.um", nz)).max() * g.dx / rk3coef
+    pscale = max(np.abs(marr(fix, "poi.p", nz)).max(), np.abs(marr(fix, "poi.pres0", nz)).max(), pnat)
+    # p with bcp's columns p(ib-1) = p(ib), p(ie+1) = p(ie)
+    assert relerr(xcols(core.download("p")), xcols(marr(fix, "poi.p", nz)), pscale) <= KERNEL_TOL
+    assert relerr(nocorner(core.download("pres0")[1:-1]), nocorner(marr(fix, "poi.pres0", nz)[1:-1]), pscale) <= KERNEL_TOL
+    for k in ("vp", "wp"):
+        assert relerr(interior(core.download(k)), interior(marr(fix, "poi." + k, nz))) <= KERNEL_TOL, k
+    # up with the inlet's column (zero) and the outlet's prognostic column up(ie+1)
+    got, ref = xcols(core.download("up"))[:, :, 1:], xcols(marr(fix, "poi.up", nz))[:, :, 1:]
+    assert relerr(got, ref) <= KERNEL_TOL
+    assert np.all(got[:, :, 0] == 0.) and np.abs(ref[:, :, -1]).max() > 1e-3
+    ref = marr(fix, "poi.wp", nz)
+    assert relerr(core.download("wp")[nz + 1, 1:-1, 1:-1], ref[nz + 1, 1:-1, 1:-1], np.abs(ref).max()) <= KERNEL_TOL
+    # ... and the `boundary` that ends the substep takes it from the slab averages of the state the substep started from
+    core.set_open_x_outflow(wlev(g), 0.)
+    core.tstep_integrate()
+    core.halos()
+    core.boundary()
+    for k in ("u0", "v0", "w0", "um", "pres0"):
+        ref = marr(fix, "out." + k, nz)
+        assert relerr(nocorner(core.download(k)[1:-1]), nocorner(ref[1:-1]), pscale if k == "pres0" else None) <= KERNEL_TOL, k
+    ref = marr(fix, "out.w0", nz)
+    assert relerr(nocorner(core.download("w0"))[nz + 1], nocorner(ref)[nz + 1], np.abs(ref).max()) <= KERNEL_TOL
+    core.close()
+
+
+@pytest.mark.parametrize("fused", [True, False, "deferred"])
+@pytest.mark.parametrize("name,iexp", sorted(R_CASES.items()))
+def test_substeps_match_reference(name, iexp, fused):
+    """Chained substeps from the state the reference's start-up left (s000, x ghost columns included): the fused substep, the
+    reference's routine-by-routine order, and that order with deferred execution."""
+    fix = load_fixture(name)
+    d, core = make_core(name, iexp)
+    g = core.g
+    for k in ("u0", "v0", "w0", "um", "vm", "wm", "pres0"):
+        core.upload(k, marr(fix, "s000." + k, g.nz))
+    # (the start-up's `boundary` has run: its speed is what bcpup reads first, and what the first substep's `boundary` still uses)
+    core.set_open_x_outflow(wlev(g), float(fix["s000.uouttot"].data[0]), hold_first=True)
+    dt = float(d.get("RUN", "dtmax"))
+    dumps = sorted(int(k[1:4]) for k in fix if k.endswith(".u0") and k != "s000.u0")
+    if fused == "deferred":
+        core.set_deferred(True)
+    for isub in range(1, max(dumps) + 1):
+        if fused is True:
+            core.substep((isub - 1) % 3 + 1, dt, with_forces=True)
+        else:
+            core.tstep_update(dt)
+            core.advection(); core.subgrid(); core.bottom(); core.coriolis(); core.forces(); core.ibmwallfun(); core.masscorr()
+            core.ibmnorm(); core.scalsource(); core.poisson()
+            core.tstep_integrate(); core.halos(); core.boundary()
+        if isub in dumps:
+            tag = f"s{isub:03d}"
+            for k in ("u0", "v0", "w0", "pres0", "um", "vm", "wm"):
+                ref = marr(fix, f"{tag}.{k}", g.nz)
+                assert relerr(nocorner(core.download(k)[1:-1]), nocorner(ref[1:-1])) <= RUN_TOL, (tag, k)
+            ref = marr(fix, f"{tag}.w0", g.nz)
+            assert relerr(nocorner(core.download("w0"))[g.nz + 1], nocorner(ref)[g.nz + 1], np.abs(ref).max()) <= RUN_TOL, (tag, "w0(ke+1)")
+            if fused is True:
+                assert abs(float(fix[f"{tag}.uouttot"].data[0])) > 0.1
+    # the flow really is not periodic: what leaves differs from what enters
+    u = core.download("u0")
+    assert np.abs(u[1:-1, 1:-1, 1] - u[1:-1, 1:-1, -1]).max() > 1e-3
+    if fused == "deferred":
+        assert core.deferred_stats() == (max(dumps), 0)
+    if fused is True:
+        plan = core.last_plan()
+        assert not plan["pressure_total_form"] and not plan["slab_layout"]
+    div = core.divergence()
+    assert div[0] < 1e-12
+    core.close()
+
+
+def test_what_open_x_does_not_offer_is_refused():
+    from udcore import lib as L
+    d, core = make_core("k_xopen_16x8x12", 90)
+    with pytest.raises(L.UdcError, match="open x"):
+        core.set_tempeq()
+    with pytest.raises(L.UdcError, match="open x"):
+        core.set_masscorr(True, 1.0)
+    core.close()
+    import udcore
+    d = read_deck(deck_path("k_xopen_16x8x12", 90))
+    d.nml["BC"]["BCxm"] = 3
+    with pytest.raises(ValueError, match="BCxm"):
+        udcore.from_deck(d)

@@ -191,13 +191,62 @@ extern "C" int udc_create(const udc_config *cfg, udc_handle **out) {
   return 0;
 }
 
+// &BC BCxm = 2 (udc_xopen.hip): the handle's rows carry one ghost column at either end
+extern "C" int udc_create_open_x(const udc_config *cfg, const double *uprof, const double *vprof, udc_handle **out) {
+  if (!cfg || !out || !uprof || !vprof) { udc_set_error("udc_create_open_x: null argument"); return 1; }
+  if (cfg->nranks != 1) { udc_set_error("udc_create_open_x: one rank (the y-slab exchanges know nothing of the outlet's planes)"); return 1; }
+  if (cfg->bctopm != UDC_TOP_PRESSURE) {
+    udc_set_error("udc_create_open_x: BCtopm must be 3 (the reference opens the lid with BCxm = 2 itself, src/modstartup.f90:845-848)");
+    return 1;
+  }
+  if (cfg->nsv != 0) { udc_set_error("udc_create_open_x: no transported scalars yet (nsv = 0)"); return 1; }
+  if (cfg->sgs == UDC_SGS_ONEEQN) { udc_set_error("udc_create_open_x: the one-equation closure is not offered with open x boundaries"); return 1; }
+  if (cfg->itot < 8 || cfg->itot % 2) { udc_set_error("udc_create_open_x: itot even and >= 8"); return 1; }
+  udc_config c2 = *cfg;
+  c2.itot = cfg->itot + 2;
+  // (udc_create's own checks, then the same construction with the ghost columns switched on)
+  if (cfg->jtot < 4 || cfg->ktot < 3 || cfg->jtot % 2) { udc_set_error("udc_create_open_x: grid too small, or jtot odd"); return 1; }
+  if (cfg->jtot < 2 * HY) { udc_set_error("udc_create_open_x: slab thinner than the ghost width"); return 1; }
+  if (cfg->lbottom && !(cfg->z0 > 0.)) { udc_set_error("udc_create_open_x: lbottom needs a roughness length z0 > 0"); return 1; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { udc_set_error("udc_create_open_x: no HIP device visible -- libudcore has no CPU fallback"); return 1; }
+  const int device = cfg->device >= 0 ? cfg->device : 0;
+  if (device >= ndev) { udc_set_error("udc_create_open_x: device index beyond the visible HIP devices"); return 1; }
+  udc_handle *h = new udc_handle();
+  h->device = device;
+  h->xg = 1;
+  if (create_on_device(&c2, h) || xo_init(h, uprof, vprof)) { udc_destroy(h); return 1; }
+  if (h->slab) { udc_set_error("udc_create_open_x: not with UDC_FORCE_SLAB"); udc_destroy(h); return 1; }
+  *out = h;
+  return 0;
+}
+// the outlet's convection speed uouttot (src/modboundary.f90:141-160): a constant (a prescribed volume flow's ubulk), or -- wlev
+// [ktot] given -- sum_k wlev(k) u0av(k) of the state every substep starts from, wlev(k) = dzf(k) / (zh(ke+1) - zh(kb+1)).
+// hold_first: the first substep after this call still convects with `uouttot` -- the reference's start-up forms u0av BEFORE its
+// first `boundary` (src/modstartup.f90:1601, src/program.f90:118) and the first substep's `boundary` still reads that one
+extern "C" int udc_set_open_x_outflow(udc_handle *h, const double *wlev, double uouttot, int hold_first) {
+  ENTRY_FLUSH(h);
+  if (!h->xg) { udc_set_error("udc_set_open_x_outflow: not a handle of udc_create_open_x"); return 1; }
+  HIP_OK(hipStreamSynchronize(h->stream));
+  HIP_OK(hipMemcpy(h->bcx_uout_dev, &uouttot, sizeof(double), hipMemcpyHostToDevice));
+  h->bcx_uout = uouttot;
+  h->bcx_uout_avg = wlev != nullptr;
+  h->xo_hold = wlev != nullptr && hold_first != 0;
+  if (wlev) {
+    if (!h->bcx_wlev) HIP_OK(hipMalloc(&h->bcx_wlev, sizeof(double) * h->g.nz));
+    HIP_OK(hipMemcpy(h->bcx_wlev, wlev, sizeof(double) * h->g.nz, hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
 static int create_on_device(const udc_config *cfg, udc_handle *h) {
   udc_read_switches(h->sw);
   h->cfg = *cfg;
   HIP_OK(hipSetDevice(h->device));
-  HIP_OK(hipStreamCreate(&h->stream));
+  if (!h->stream) HIP_OK(hipStreamCreate(&h->stream));      // (a solver-only handle works on its owner's stream: udc_create_open_x)
   Geo &g = h->g;
   g.nx = cfg->itot; g.ny = cfg->jtot / cfg->nranks; g.nz = cfg->ktot;
+  g.xg = h->xg;
   h->jtot = cfg->jtot;
   h->no_fold = h->sw.no_fold;
   h->no_alias = h->sw.no_alias;
@@ -249,8 +298,10 @@ static int create_on_device(const udc_config *cfg, udc_handle *h) {
   m.dx2i = m.dxi * m.dxi; m.dy2i = m.dyi * m.dyi;
   m.dxi5 = 0.5 * m.dxi; m.dyi5 = 0.5 * m.dyi;
 
-  for (int f = UDC_U0; f <= UDC_EKH; ++f)
+  for (int f = UDC_U0; f <= UDC_EKH; ++f) {
+    if (h->poisson_only && f != UDC_P) { if ((int)h->fields.size() <= f) h->fields.resize(f + 1, nullptr); continue; }
     if (alloc_field(h, f)) return 1;
+  }
   for (int n = 0; n < cfg->nsv; ++n) {
     for (int q = 0; q < 3; ++q)
       if (alloc_field(h, UDC_SV0 + 3 * n + q)) return 1;
@@ -259,7 +310,14 @@ static int create_on_device(const udc_config *cfg, udc_handle *h) {
   h->red_cap = std::max((size_t)4096, (size_t)16 * (g.nz + 2));      // udc_slab_averages: 16 fields x (ktot + 1) levels
   HIP_OK(hipMalloc(&h->red, sizeof(double) * h->red_cap));
   HIP_OK(hipHostMalloc(&h->red_host, sizeof(double) * h->red_cap));
-  if (h->slab) { if (pois_slab_init(h)) return 1; }
+  if (h->xg) {      // open x boundaries: the solve runs on a handle of its own, twice as wide (udc_xopen.hip)
+    udc_handle *hp = new udc_handle();
+    h->xpois = hp;
+    hp->device = h->device; hp->stream = h->stream; hp->poisson_only = true;
+    udc_config c2 = *cfg;
+    c2.itot = 2 * (cfg->itot - 2 * h->xg); c2.nsv = 0;
+    if (create_on_device(&c2, hp)) return 1;
+  } else if (h->slab) { if (pois_slab_init(h)) return 1; }
   else if (pois_init(h)) return 1;
   if (h->slab) {
     h->halo_cap = (size_t)16 * HY * g.nx * g.pz;
@@ -276,6 +334,7 @@ extern "C" int udc_destroy(udc_handle *h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   prof_drain(h);
   for (hipEvent_t e : h->prof_pool) hipEventDestroy(e);
+  xo_destroy(h);
   pois_destroy(h);
   comm_destroy(h);
   ibm_destroy(h);
@@ -304,7 +363,7 @@ extern "C" int udc_destroy(udc_handle *h) {
   if (h->lev_part) hipFree(h->lev_part);
   if (h->lev_sum) hipFree(h->lev_sum);
   if (h->lev_sum16) hipFree(h->lev_sum16);
-  if (h->stream) hipStreamDestroy(h->stream);
+  if (h->stream && !h->poisson_only) hipStreamDestroy(h->stream);
   delete h;
   return 0;
 }
@@ -343,7 +402,9 @@ static int copy3d(udc_handle *h, int field, double *host, const int lb[3], const
 static int copy3d_ptr(udc_handle *h, int field, double *dev, double *host, const int lb[3], const int ub[3], bool up) {
   const Geo &g = h->g;
   const int hnx = ub[0] - lb[0] + 1, hny = ub[1] - lb[1] + 1;
-  int i0 = lb[0] > 1 ? lb[0] : 1, i1 = ub[0] < g.nx ? ub[0] : g.nx;
+  // (open x boundaries: the device row starts xg columns west of the reference's ib, udc_xopen.hip)
+  const int xg = g.xg, itot = g.nx - 2 * xg;
+  int i0 = lb[0] > 1 - xg ? lb[0] : 1 - xg, i1 = ub[0] < itot + xg ? ub[0] : itot + xg;
   int j0 = lb[1] > 1 - HY ? lb[1] : 1 - HY, j1 = ub[1] < g.ny + HY ? ub[1] : g.ny + HY;
   int k0 = lb[2] > 1 - HZ ? lb[2] : 1 - HZ, k1 = ub[2] < g.nz + HZ ? ub[2] : g.nz + HZ;
   if (i1 < i0 || j1 < j0 || k1 < k0) { udc_set_error("field %d: empty overlap with host bounds", field); return 1; }
@@ -352,13 +413,13 @@ static int copy3d_ptr(udc_handle *h, int field, double *dev, double *host, const
   hipPitchedPtr hp = make_hipPitchedPtr((void *)host, (size_t)hnx * 8, (size_t)hnx * 8, (size_t)hny);
   hipPitchedPtr dp = make_hipPitchedPtr((void *)dev, (size_t)g.sy * 8, (size_t)g.sy * 8, (size_t)g.py);
   hipPos hpos = make_hipPos((size_t)(i0 - lb[0]) * 8, (size_t)(j0 - lb[1]), (size_t)(k0 - lb[2]));
-  hipPos dpos = make_hipPos((size_t)(i0 - 1) * 8, (size_t)(j0 - 1 + HY), (size_t)(k0 - 1 + HZ));
+  hipPos dpos = make_hipPos((size_t)(i0 - 1 + xg) * 8, (size_t)(j0 - 1 + HY), (size_t)(k0 - 1 + HZ));
   p.extent = make_hipExtent((size_t)(i1 - i0 + 1) * 8, (size_t)(j1 - j0 + 1), (size_t)(k1 - k0 + 1));
   if (up) { p.srcPtr = hp; p.srcPos = hpos; p.dstPtr = dp; p.dstPos = dpos; p.kind = hipMemcpyHostToDevice; }
   else    { p.srcPtr = dp; p.srcPos = dpos; p.dstPtr = hp; p.dstPos = hpos; p.kind = hipMemcpyDeviceToHost; }
   HIP_OK(hipStreamSynchronize(h->stream));
   HIP_OK(hipMemcpy3D(&p));
-  if (!up) {
+  if (!up && !xg) {
     // the reference's x ghost columns are periodic images (src/modboundary.f90:516-529):
     // rebuild them on the host so that untouched host routines see what they expect
     const long hsy = hnx, hsz = (long)hnx * hny;
@@ -378,6 +439,7 @@ extern "C" int udc_field_upload(udc_handle *h, int field, const double *host, co
   if (field == UDC_EKM || field == UDC_EKH) h->ek_stale = false;
   if (field == UDC_EKH) h->ekh_stale = false;
   if (field == UDC_P) h->p_scratch = false;
+  if (h->xg && xo_capture_east(h, field, host, lb, ub)) return 1;      // v, w at ie+1: the convective outlet's own state
   if (h->scal_bcx == 2 && field >= UDC_SV0 && (field - UDC_SV0) % 3 == 0)      // sv0 with its east ghost columns (BCxs = 2)
     return k_scalar_bcx_capture(h, (field - UDC_SV0) / 3, host, lb, ub);
   return 0;
@@ -395,6 +457,7 @@ extern "C" int udc_set_scalar_bcx_outflow(udc_handle *h, const double *wlev) {
 }
 
 extern "C" int udc_set_scalar_bcx(udc_handle *h, int bcxs, const double *svprof, double uouttot) {
+  NO_OPEN_X(h, "udc_set_scalar_bcx");
   ENTRY_FLUSH(h);
   if (bcxs != 1 && bcxs != 2) { udc_set_error("udc_set_scalar_bcx: BCxs must be 1 (periodic) or 2 (inflow profile, convective outflow)"); return 1; }
   const Geo &g = h->g;
@@ -508,7 +571,7 @@ static int now_subgrid(udc_handle *h) {
   if (tend_clean(h) || um_materialise(h)) return 1;
   if (k_closure(h)) return 1;
   if (h->lbuoycorr && k_vreman_buoycorr(h)) return 1;
-  if (k_ek_ghosts(h)) return 1;
+  if (k_ek_ghosts(h) || k_xo_ek_ghosts(h)) return 1;
   h->ek_stale = h->ekh_stale = false;
   if (k_top_rows_after_closure(h)) return 1;
   if (k_momentum_lds(h, false, true, false, false, 0.)) return 1;
@@ -520,6 +583,7 @@ static int now_subgrid(udc_handle *h) {
 }
 
 extern "C" int udc_set_tempeq(udc_handle *h, int iadv_thl, int bctopt, double wttop, double thl_top, int bcbott, double wtsurf) {
+  NO_OPEN_X(h, "udc_set_tempeq");
   ENTRY_FLUSH(h);
   if (h->cfg.nsv > 15) { udc_set_error("udc_set_tempeq: thl uses scalar slot 15, nsv must be <= 15"); return 1; }
   if (iadv_thl != 2 && iadv_thl != 7) { udc_set_error("udc_set_tempeq: iadv_thl must be 2 (cd2, advecc_2nd) or 7 (kappa, advecc_kappa)"); return 1; }
@@ -552,6 +616,7 @@ extern "C" int udc_set_chem(udc_handle *h, int lchem, double k1, double jno2) {
 }
 
 extern "C" int udc_set_shifted_pbc(udc_handle *h, double a, const double *sinx, int nx, const double *u0av, int nz) {
+  NO_OPEN_X(h, "udc_set_shifted_pbc");
   HIP_OK(hipSetDevice(h->device));
   h->shift_a = a;
   if (a == 0.) return 0;
@@ -625,6 +690,7 @@ extern "C" int udc_set_floor_wf(udc_handle *h, int bcbotm, int bcbott, double th
 }
 
 extern "C" int udc_set_moisture(udc_handle *h, int iadv_qt, int bctopq, double wqtop, double qt_top, int bcbotq, double wqsurf) {
+  NO_OPEN_X(h, "udc_set_moisture");
   ENTRY_FLUSH(h);
   if (h->cfg.nsv > 13) { udc_set_error("udc_set_moisture: qt uses scalar slot 13, nsv must be <= 13"); return 1; }
   if (iadv_qt != 2) { udc_set_error("udc_set_moisture: only iadv_qt = 2 (cd2, advecc_2nd) exists (src/modadvection.f90:79-85)"); return 1; }
@@ -729,6 +795,7 @@ extern "C" int udc_thermo_state(udc_handle *h, double *tables, int n, int set) {
 
 extern "C" int udc_set_tke(udc_handle *h, double cm, double cn, double ch1, double ch2, double ce1, double ce2, double e12min,
                            double grav, double thvs, int ldelta) {
+  NO_OPEN_X(h, "udc_set_tke");
   ENTRY_FLUSH(h);
   if (h->cfg.nsv > 14) { udc_set_error("udc_set_tke: e12 uses scalar slot 14, nsv must be <= 14"); return 1; }
   if (!(thvs > 0.) || !(e12min > 0.)) { udc_set_error("udc_set_tke: thvs and e12min must be positive"); return 1; }
@@ -872,6 +939,7 @@ static void masscorr_effective(udc_handle *h) {
 }
 
 extern "C" int udc_set_masscorr(udc_handle *h, int luvolflowr, double uflowrate, int lvvolflowr, double vflowrate) {
+  if (luvolflowr || lvvolflowr) NO_OPEN_X(h, "udc_set_masscorr");
   ENTRY_FLUSH(h);
   // the two requests for u are kept side by side; an outflow-rate correction (udc_set_masscorr_outflow) takes precedence while it
   // is on (src/modforces.f90:352,389), whatever order the two setters are called in and however often
@@ -882,6 +950,7 @@ extern "C" int udc_set_masscorr(udc_handle *h, int luvolflowr, double uflowrate,
 }
 
 extern "C" int udc_set_masscorr_outflow(udc_handle *h, int luoutflowr, double uflowrate) {
+  NO_OPEN_X(h, "udc_set_masscorr_outflow");
   ENTRY_FLUSH(h);
   h->uout_req = luoutflowr ? 1 : 0; h->uout_rate = uflowrate;
   masscorr_effective(h);
@@ -922,6 +991,7 @@ static int now_poisson(udc_handle *h, int rk3step, double dt) {
   if (k_halo_y(h, fvp, h->ibm_on ? 2 : 1, 1)) return 1;
   const bool lid = h->p.bctopm == UDC_TOP_PRESSURE;
   if (lid && k_lid_bcpup(h, rk3coef, false)) return 1;     // bcpup's open-lid rows, src/modboundary.f90:1234-1243
+  if (k_xo_bcpup(h, rk3coef, false)) return 1;             // ... and its inflow / outflow columns, :1257-1280
   if (k_divergence_rhs(h, rk3coef, false)) return 1;       // fillps
   if (k_poisson_solve(h)) return 1;
   const int fp[1] = {UDC_P};
@@ -937,6 +1007,7 @@ static int now_poisson(udc_handle *h, int rk3step, double dt) {
 static int now_tstep_integrate(udc_handle *h, int rk3step, double dt) {
   if (tend_clean(h) || um_materialise(h)) return 1;
   h->bcx_rk3coef = dt / (4. - (double)rk3step);
+  h->xo_stage3 = rk3step == 3;
   if (k_scalar_bcx_uout(h)) return 1;
   h->halos_fresh = h->boundary_fresh = h->thermo_fresh = false;
   h->dthv_top_on = false;      // new fields: the next dthvdz is the one of the thermodynamics call that follows `boundary`
@@ -1004,6 +1075,7 @@ extern "C" int udc_boundary(udc_handle *h) {
   if (um_materialise(h)) return 1;
   if (k_top_bottom(h)) return 1;
   if (k_scalar_bcx_outlet(h)) return 1;    // BCxs = 2: xso_convective with the rk3coef of the substep just integrated
+  if (k_xo_boundary(h)) return 1;          // BCxm = 2: xmi_profile, xmo_convective
   h->boundary_fresh = h->halos_fresh;      // (boundary before halos leaves the ghost rows of the top planes stale)
   return 0;
 }
@@ -1045,8 +1117,12 @@ enum : unsigned {
 static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   const double rk3coef = dt / (4. - (double)rk3step);
   h->bcx_rk3coef = rk3coef;
+  h->xo_stage3 = rk3step == 3;
   ++h->substep_seq;
-  if (k_scalar_bcx_uout(h)) return 1;      // BCxs = 2 without a prescribed volume flow: the outlet's speed from the state the substep starts from
+  // BCxs = 2 without a prescribed volume flow: the outlet's speed from the state the substep starts from.  (BCxm = 2: bcpup still reads
+  // the speed the PREVIOUS `boundary` used -- uouttot is refreshed by `boundary` only, src/modboundary.f90:141-160 -- so there the refresh
+  // follows k_xo_bcpup below; u0 is the substep's starting state until the integration)
+  if (!h->xg && k_scalar_bcx_uout(h)) return 1;
   // what runs, in which order, is decided in one place: plan_substep (udc_plan.h; DESIGN.md section 7 has the table, the CPU test
   // tests/test_substep_plan.py enumerates it)
   PlanIn pin{};
@@ -1097,6 +1173,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
       if (k_ek_ghosts(h)) return 1;
     }
     h->ek_stale = false;
+    if (k_xo_ek_ghosts(h)) return 1;
     // y-slabs, nothing between the sweep and the solve but the floor: the sweep is pipelined with the solve's k-chunks.  Tile row 0
     // first over all levels (+ the floor on its rows): it holds the row of vp that the previous rank's divergence reads, which then
     // travels; the other rows follow level range by level range from inside k_poisson_solve_slab, each ahead of the x forward
@@ -1180,6 +1257,8 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   // open lid (BCtopm = 3): bcpup's row pwp(ke+1) from the slab mean of pres0(ke), before the divergence that reads it
   const bool lid = pin.open_lid != 0;
   if (lid && k_lid_bcpup(h, rk3coef, pup)) return 1;
+  if (k_xo_bcpup(h, rk3coef, pup)) return 1;
+  if (h->xg && k_scalar_bcx_uout(h)) return 1;
   if (!h->div_in_fft && k_divergence_rhs(h, rk3coef, pup)) return 1;
   h->p_ghost_in_transpose = plan.p_row == ROW_TRANSPOSED;
   if (k_poisson_solve(h)) return 1;
@@ -1263,6 +1342,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   if (!s.empty() && !ov_scal && k_halo_y(h, s.data(), (int)s.size(), 2)) return 1;
   if (!fold || !h->slots.empty()) { if (k_top_bottom(h)) return 1; }
   if (k_scalar_bcx_outlet(h)) return 1;
+  if (k_xo_boundary(h)) return 1;
   h->halos_fresh = h->boundary_fresh = true;
   if (h->lmoist && h->mt) {                                             // src/program.f90:214
     if (k_thermodynamics(h)) return 1;

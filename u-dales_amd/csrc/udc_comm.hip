@@ -70,6 +70,7 @@ extern "C" int udc_comm_unique_id(unsigned char id[128]) {
 // (communicator, grouped point-to-point on the library's streams, all-reduce) on a one-GPU box.
 
 extern "C" int udc_comm_init(udc_handle *h, const unsigned char id[128]) {
+  NO_OPEN_X(h, "udc_comm_init");
   if (h->cfg.nranks == 1 && !h->sw.force_comm) return 0;
   HIP_OK(hipSetDevice(h->device));
   ncclUniqueId u;
@@ -92,6 +93,7 @@ extern "C" int udc_local_group_create(int nranks) {
 }
 
 extern "C" int udc_comm_init_local(udc_handle *h, int group) {
+  NO_OPEN_X(h, "udc_comm_init_local");
   std::lock_guard<std::mutex> lk(g_groups_mu);
   if (group < 1 || group > (int)g_groups.size() || g_groups[group - 1]->P != h->cfg.nranks) {
     udc_set_error("udc_comm_init_local: bad group");

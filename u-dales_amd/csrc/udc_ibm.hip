@@ -274,6 +274,7 @@ inline unsigned blocks(int n) { return (unsigned)((n + 127) / 128); }
 
 // ------------------------------------------------------------------------------------------------ host side
 extern "C" int udc_set_ibm_points(udc_handle *h, int grid, const int *solid, int nsolid, const int *bound, int nbound) {
+  NO_OPEN_X(h, "udc_set_ibm_points");
   if (!h) { udc_set_error("null handle"); return 1; }
   if (grid < 0 || grid > 3) { udc_set_error("udc_set_ibm_points: grid 0 (u), 1 (v), 2 (w) or 3 (c)"); return 1; }
   if (nsolid < 0 || nbound < 0 || (nsolid && !solid) || (nbound && !bound)) { udc_set_error("udc_set_ibm_points: bad list"); return 1; }

@@ -57,6 +57,8 @@ struct Geo {
   int sy;              // row stride   (nx, or nx + 16 for large power-of-two rows: udc_create)
   long sz;             // plane stride (= sy*py)
   long n;              // total elements
+  int xg = 0;          // open x boundaries (udc_create_open_x): ghost columns kept at either end of a row -- the interior is
+                       // i = xg .. nx - xg - 1 (udc_xopen.hip); 0: x periodic by index wrap
   __host__ __device__ inline long idx(int i, int j, int k) const {
     return (long)i + (long)sy * (j + HY) + sz * (long)(k + HZ);
   }
@@ -268,6 +270,16 @@ struct udc_handle {
   double *outlet_w = nullptr;             // luoutflowr: dy dzf(k) / outlet area, [nz+2] indexed by the reference's k
   double uflowrate = 0., vflowrate = 0., zsize = 0.;
   double dzhi_top = 0.;      // dzhi(ke+1)
+  // inflow / outflow in x (&BC BCxm = 2, udc_create_open_x; udc_xopen.hip): the device grid is the deck's plus one ghost column at
+  // either end (g.xg = 1), swept as if periodic; the columns are set where the reference sets its x ghosts
+  int xg = 0;
+  double *xo_prof = nullptr;          // uprof, vprof: [2][nz+2], indexed by the reference's k
+  double *xo_east = nullptr;          // v0, w0, vm, wm at i = ie+1: [4][pz][py] (the convective outlet's own state)
+  bool xo_hold = false;               // the next refresh of uouttot is skipped (udc_set_open_x_outflow, hold_first)
+  bool xo_stage3 = false;             // the last integration was RK stage 3 (vm, wm took v0, w0: their outlet planes too)
+  udc_handle *xpois = nullptr;        // the pressure solve's own periodic domain: the row and its mirror image, 2 itot wide
+  bool poisson_only = false;          // (that handle: p and the solver's arrays only)
+  hipEvent_t xo_ev[2] = {nullptr, nullptr};
   int bczp = 1;              // &BC BCzp: 1 tridiagonal solve in z, 2 the cosine transform's solution (udc_set_poisson_bczp)
   bool um_alias = false;                // um,vm,wm are logically equal to u0,v0,w0 (after RK stage 3 of a fused
                                         // substep); the UM buffers are stale until stage 1 rotates the pointers
@@ -420,6 +432,12 @@ struct udc_handle {
 
 void udc_set_error(const char *fmt, ...);
 
+// entry points that are not offered on a handle with open x boundaries (udc_create_open_x): said, not silently wrong
+#define NO_OPEN_X(h, who)                                                                                              \
+  do {                                                                                                                 \
+    if ((h) && (h)->xg) { udc_set_error("%s: not offered with open x boundaries (udc_create_open_x) yet", who); return 1; } \
+  } while (0)
+
 #define HIP_OK(expr)                                                                  \
   do {                                                                                \
     hipError_t e_ = (expr);                                                           \
@@ -533,6 +551,14 @@ int k_maxima(udc_handle *h, double dt, double *cour, double *diffn, bool checksi
 int k_divergence_check(udc_handle *h, double *divmax, double *divtot);
 int k_checksim_begin(udc_handle *h, double dtmn);
 int k_checksim_end(udc_handle *h, double out[4]);
+// udc_xopen.hip: inflow / outflow in x
+int k_xo_ek_ghosts(udc_handle *h);                                  // closurebc's ekm(ib-1) = ekm(ib), ekm(ie+1) = ekm(ie)
+int k_xo_bcpup(udc_handle *h, double rk3coef, bool pup);            // bcpup's BCxm_profile branch
+int k_xo_boundary(udc_handle *h);                                   // xmi_profile, xmo_convective (+ bcp's pres0 columns)
+int k_xo_poisson(udc_handle *h);                                    // the solve on the mirrored row
+int xo_init(udc_handle *h, const double *uprof, const double *vprof);
+void xo_destroy(udc_handle *h);
+int xo_capture_east(udc_handle *h, int field, const double *host, const int lb[3], const int ub[3]);
 int pois_init(udc_handle *h);
 int pois_slab_init(udc_handle *h);
 int k_poisson_solve_slab(udc_handle *h);

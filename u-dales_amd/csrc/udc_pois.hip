@@ -804,7 +804,7 @@ __global__ __launch_bounds__(256) void maxima_kernel(Geo g, TileGrid tg, Metrics
     const double *__restrict__ vm, const double *__restrict__ wm, const double *__restrict__ ekm,
     const double *__restrict__ ekh, double *__restrict__ out) {
   int i, j, k;
-  const bool inside_ = tile_decode(g, tg, i, j, k);
+  const bool inside_ = tile_decode(g, tg, i, j, k) && i >= g.xg && i < g.nx - g.xg;      // (open x boundaries: not the ghost columns)
   double cour = 0., dif = 0.;
   if (inside_) {
     const long c = g.idx(i, j, k);
@@ -826,7 +826,7 @@ __global__ __launch_bounds__(256) void maxima_kernel(Geo g, TileGrid tg, Metrics
 __global__ __launch_bounds__(256) void divcheck_kernel(Geo g, TileGrid tg, Metrics m, const double *__restrict__ u,
     const double *__restrict__ v, const double *__restrict__ w, double *__restrict__ out) {
   int i, j, k;
-  const bool inside_ = tile_decode(g, tg, i, j, k);
+  const bool inside_ = tile_decode(g, tg, i, j, k) && i >= g.xg && i < g.nx - g.xg;
   double dmax = 0., dsum = 0.;
   if (inside_) {
     const long r0 = g.idx(0, j, k);
@@ -846,7 +846,7 @@ __global__ __launch_bounds__(256) void checksim_kernel(Geo g, TileGrid tg, Metri
     const double *__restrict__ v, const double *__restrict__ w, const double *__restrict__ ekm, const double *__restrict__ ekh,
     double *__restrict__ out) {
   int i, j, k;
-  const bool inside_ = tile_decode(g, tg, i, j, k);
+  const bool inside_ = tile_decode(g, tg, i, j, k) && i >= g.xg && i < g.nx - g.xg;
   double cour = 0., dif = 0., dmax = 0., dsum = 0.;
   if (inside_) {
     const long r0 = g.idx(0, j, k);
@@ -1329,6 +1329,7 @@ int k_divergence_rhs(udc_handle *h, double rk3coef, bool pup) {
 }
 
 int k_poisson_solve(udc_handle *h) {
+  if (h->xg) return k_xo_poisson(h);      // open x boundaries: on the mirrored row (udc_xopen.hip)
   if (h->slab) return k_poisson_solve_slab(h);
   const Geo &g = h->g;
   const long nmodes = (long)h->nkxp * g.ny;
@@ -1382,7 +1383,7 @@ int k_project(udc_handle *h) {
 static double lid_count(const udc_handle *h) {
   // (IIc is all ones where the c grid's lists were not read -- no scalar field at all, src/modibm.f90:181)
   const bool masked = h->ibm_on && h->ibm[3].given && (int)h->ibm[3].fluid_cnt.size() > h->g.nz;
-  return masked ? h->ibm[3].fluid_cnt[h->g.nz] : (double)h->g.nx * (double)h->cfg.jtot;
+  return masked ? h->ibm[3].fluid_cnt[h->g.nz] : (double)(h->g.nx - 2 * h->g.xg) * (double)h->cfg.jtot;
 }
 int k_lid_bcpup(udc_handle *h, double rk3coef, bool pup) {
   const Geo &g = h->g;

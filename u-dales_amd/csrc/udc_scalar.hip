@@ -221,12 +221,13 @@ int k_scalar_bcx_outlet(udc_handle *h) {
 
 // the outlet's speed from the state the substep starts from (= what diagfld left at the end of the previous one)
 int k_scalar_bcx_uout(udc_handle *h) {
-  if (h->scal_bcx != 2 || !h->bcx_uout_avg) return 0;
+  if ((h->scal_bcx != 2 && !h->xg) || !h->bcx_uout_avg) return 0;      // (BCxs = 2, or BCxm = 2: udc_xopen.hip)
+  if (h->xg && h->xo_hold) { h->xo_hold = false; return 0; }
   const Geo &g = h->g;
   if (k_level_sums_dev(h, UDC_U0, g.nz)) return 1;
   const double *cnt = h->ibm_on ? h->ibm[0].cnt_dev : nullptr;
   hipLaunchKernelGGL(scalar_bcx_uout_kernel, dim3(1), dim3(64), 0, h->stream, g.nz, (const double *)h->lev_sum16, cnt,
-                     (double)g.nx * (double)h->jtot, (const double *)h->bcx_wlev, h->bcx_uout_dev);
+                     (double)(g.nx - 2 * g.xg) * (double)h->jtot, (const double *)h->bcx_wlev, h->bcx_uout_dev);
   HIP_OK(hipGetLastError());
   return 0;
 }

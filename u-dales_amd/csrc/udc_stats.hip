@@ -516,6 +516,7 @@ static int stat_alloc(udc_handle *h, int id) {
 }
 
 extern "C" int udc_stats_enable(udc_handle *h, int on) {
+  NO_OPEN_X(h, "udc_stats_enable");
   if (!h) { udc_set_error("null handle"); return 1; }
   HIP_OK(hipSetDevice(h->device));
   if (udc_flush_pending(h)) return 1;
@@ -708,6 +709,7 @@ extern "C" int udc_stats_yt(udc_handle *h, double *table) {
 }
 
 extern "C" int udc_stats_set_masks(udc_handle *h, const unsigned char *bits, const int *counts) {
+  NO_OPEN_X(h, "udc_stats_set_masks");
   if (!h) { udc_set_error("null handle"); return 1; }
   HIP_OK(hipSetDevice(h->device));
   if (udc_flush_pending(h)) return 1;

@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void levelsum_plain_kernel(Geo g, int gx, cons
   const int by = tile / gx, bx = tile - by * gx;
   const int i = bx * 64 + threadIdx.x, j = by * 4 + threadIdx.y;
   double v = 0.;
-  if (i < g.nx && j < g.ny) v = f[g.idx(i, j, k0 + k)];
+  if (i >= g.xg && i < g.nx - g.xg && j < g.ny) v = f[g.idx(i, j, k0 + k)];      // (open x boundaries: the interior columns)
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   if (threadIdx.x == 0) sw[threadIdx.y] = v;
   __syncthreads();
@@ -360,7 +360,7 @@ int k_slab_averages(udc_handle *h, const int *fields, int nf, double *avg_host, 
   if (comm_allreduce(h, h->lev_sum16, n * nf, 1)) return 1;
   HIP_OK(hipMemcpyAsync(h->red_host, h->lev_sum16, sizeof(double) * n * nf, hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
-  const double cnt = (double)g.nx * (double)h->cfg.jtot;
+  const double cnt = (double)(g.nx - 2 * g.xg) * (double)h->cfg.jtot;
   for (int q = 0; q < nf; ++q) {
     const std::vector<double> *fc = h->ibm_on ? &h->ibm[ibm_grid_of_field(fields[q])].fluid_cnt : nullptr;
     for (int k = 0; k < n; ++k) {

@@ -1,0 +1,216 @@
+// Inflow / outflow in x (&BC BCxm = 2: inflow from prof.inp's profile, convective outflow; the reference then opens the lid too,
+// src/modstartup.f90:830-849).
+//
+// The device grid of such a handle (udc_create_open_x) is the deck's grid plus ONE ghost column at either end of every row:
+// device column c is the reference's i = c (ib - 1 = 0, ib = 1, ..., ie = itot, ie + 1 = itot + 1), g.nx = itot + 2, g.xg = 1.
+// Every sweep runs on it unchanged, as if those itot + 2 columns were periodic: an interior cell then finds the reference's ghost
+// values where its stencil looks for them, and what the sweeps leave IN the two ghost columns (a tendency formed across the seam, a
+// velocity integrated from it) is never read before the kernels below have put the reference's values there:
+//
+//   closurebc     src/modboundary.f90:467-475    ekm, ekh: ghost = the column next to it                  k_xo_ek_ghosts
+//   bcpup         :1257-1280                     pup(ib) = uprof / rk3coef, up(ib) = 0; pup(ie+1) convective,
+//                                                at kb a copy of pup(ie)                                   k_xo_bcpup
+//   poisson       src/modpois.f90:113-121        cosine transform in x (Neumann at both ends)             k_xo_poisson
+//   bcp           src/modboundary.f90:1376-1394  p, pres0: ghost = the column next to it                   k_xo_poisson, k_xo_boundary
+//   xmi_profile   :688-717                       u(ib) = uprof; the inlet ghosts mirrored about the profile
+//   xmo_convective :908-926                      v, w (0 and m) at ie+1 carried by uouttot                 k_xo_boundary
+//
+// u(ie+1) is prognostic in the reference (src/modtstep.f90:262-264) and here simply a cell of the extended row: bcpup gives it its
+// tendency, the projection finds p(ie+1) = p(ie) and leaves it alone, the integration advances it.  v and w at ie+1 are the outlet's
+// own state: they live in planes of their own (xo_east) and are written into the ghost column by every k_xo_boundary, whatever the
+// integration left there.  The reductions that span a level or the domain (slab sums, Courant and diffusion numbers, the divergence
+// check) leave the ghost columns out (Geo::xg).
+//
+// The pressure solve: a cosine transform in x is the Fourier transform of the row followed by its mirror image, and the Neumann
+// problem's solution is the first half of the periodic solution on that doubled row (same second-order Laplacian, same eigenvalues
+// -4 dxi^2 sin^2(pi m / (2 itot))).  So the solve runs, unchanged, on a second handle that is 2 itot wide and holds nothing but p and
+// the solver's arrays: twice the transform work of a dedicated DCT (the solve is ~40 % of a substep), no second set of line kernels.
+#include "udc_internal.h"
+
+namespace {
+
+// one thread per (row, plane) of the padded array: jj = j + HY, kk = k + HZ
+__device__ __forceinline__ bool plane_decode(const Geo &g, int &jj, int &kk) {
+  jj = blockIdx.x * blockDim.x + threadIdx.x;
+  kk = blockIdx.y;
+  return jj < g.py;
+}
+inline dim3 plane_grid(const Geo &g) { return dim3((unsigned)((g.py + 63) / 64), (unsigned)g.pz); }
+
+__global__ void xo_ek_kernel(Geo g, double *__restrict__ ekm, double *__restrict__ ekh) {
+  int jj, kk;
+  if (!plane_decode(g, jj, kk)) return;
+  const long r = (long)g.sy * jj + g.sz * kk;
+  const int e = g.nx - 1;
+  ekm[r] = ekm[r + 1]; ekm[r + e] = ekm[r + e - 1];
+  ekh[r] = ekh[r + 1]; ekh[r + e] = ekh[r + e - 1];
+}
+
+// bcpup, BCxm_profile.  PUP: the tendency array holds the predicted velocity pup = up + um / rk3coef
+template <bool PUP>
+__global__ void xo_bcpup_kernel(Geo g, double rk3coefi, double dxi, const double *__restrict__ prof, const double *__restrict__ uout,
+                                const double *__restrict__ u0, const double *__restrict__ um, double *__restrict__ up) {
+  int jj, kk;
+  if (!plane_decode(g, jj, kk)) return;
+  const int j = jj - HY, k = kk - HZ;
+  if (j < -1 || j > g.ny || k < 0 || k >= g.nz) return;
+  const long r = (long)g.sy * jj + g.sz * kk;
+  const int e = g.nx - 1;
+  up[r + 1] = PUP ? prof[k + 1] * rk3coefi : 0.;
+  const double ume = um[r + e];
+  double pe;
+  if (k > 0) pe = ume * rk3coefi - (u0[r + e] - u0[r + e - 1]) * dxi * uout[0];
+  else pe = PUP ? up[r + e - 1] : up[r + e - 1] + um[r + e - 1] * rk3coefi;      // "Neumann at bottom": pup(ie+1, kb) = pup(ie, kb)
+  up[r + e] = PUP ? pe : pe - ume * rk3coefi;
+}
+
+// xmi_profile, then xmo_convective on the outlet's planes; bcp's columns of pres0
+__global__ void xo_boundary_kernel(Geo g, const double *__restrict__ prof, double dxi, double rk3coef, const double *__restrict__ uout,
+                                   int stage3, double *__restrict__ u0, double *__restrict__ v0, double *__restrict__ w0,
+                                   double *__restrict__ um, double *__restrict__ vm, double *__restrict__ wm,
+                                   double *__restrict__ pres0, double *__restrict__ east) {
+  int jj, kk;
+  if (!plane_decode(g, jj, kk)) return;
+  const int j = jj - HY, k = kk - HZ;
+  const long r = (long)g.sy * jj + g.sz * kk;
+  const int e = g.nx - 1;
+  if (j >= -1 && j <= g.ny && k >= 0 && k <= g.nz) {      // j = jb-1 .. je+1, k = kb .. ke+1
+    const double up = prof[k + 1], vp = prof[g.nz + 2 + k + 1];
+    u0[r + 1] = up; um[r + 1] = up;
+    u0[r] = 2 * up - u0[r + 2]; um[r] = 2 * up - um[r + 2];
+    v0[r] = 2 * vp - v0[r + 1]; vm[r] = 2 * vp - vm[r + 1];
+    w0[r] = -w0[r + 1]; wm[r] = -wm[r + 1];
+  }
+  if (j >= -1 && j <= g.ny && k >= 0 && k < g.nz) { pres0[r] = pres0[r + 1]; pres0[r + e] = pres0[r + e - 1]; }
+  // the outlet: every row and plane the arrays hold
+  const long P = (long)g.py * g.pz, q = (long)kk * g.py + jj;
+  double ev0 = east[q], ew0 = east[P + q], evm = east[2 * P + q], ewm = east[3 * P + q];
+  if (stage3) { evm = ev0; ewm = ew0; }      // tstep_integrate's vm = v0, wm = w0 are whole-array copies (src/modtstep.f90:322-324)
+  const double uo = uout[0];
+  ev0 = ev0 - (ev0 - v0[r + e - 1]) * dxi * rk3coef * uo;
+  ew0 = ew0 - (ew0 - w0[r + e - 1]) * dxi * rk3coef * uo;
+  evm = evm - (evm - vm[r + e - 1]) * dxi * rk3coef * uo;
+  ewm = ewm - (ewm - wm[r + e - 1]) * dxi * rk3coef * uo;
+  east[q] = ev0; east[P + q] = ew0; east[2 * P + q] = evm; east[3 * P + q] = ewm;
+  v0[r + e] = ev0; w0[r + e] = ew0; vm[r + e] = evm; wm[r + e] = ewm;
+}
+
+// the ghost column of an uploaded v0 / w0 / vm / wm -> the outlet's plane
+__global__ void xo_capture_kernel(Geo g, const double *__restrict__ f, double *__restrict__ plane) {
+  int jj, kk;
+  if (!plane_decode(g, jj, kk)) return;
+  plane[(long)kk * g.py + jj] = f[(long)g.sy * jj + g.sz * kk + g.nx - 1];
+}
+
+// the right-hand side's interior columns and their mirror image -> the doubled row; back: the first half, and bcp's ghost columns
+__global__ __launch_bounds__(256) void xo_gather_kernel(Geo g, Geo g2, const double *__restrict__ p, double *__restrict__ p2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+  const int n = g.nx - 2;
+  if (i >= n) return;
+  const double v = p[g.idx(i + 1, j, k)];
+  p2[g2.idx(i, j, k)] = v;
+  p2[g2.idx(2 * n - 1 - i, j, k)] = v;
+}
+__global__ __launch_bounds__(256) void xo_scatter_kernel(Geo g, Geo g2, const double *__restrict__ p2, double *__restrict__ p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+  const int n = g.nx - 2;
+  if (i >= n) return;
+  const double v = p2[g2.idx(i, j, k)];
+  p[g.idx(i + 1, j, k)] = v;
+  if (i == 0) p[g.idx(0, j, k)] = v;
+  if (i == n - 1) p[g.idx(n + 1, j, k)] = v;
+}
+
+}  // namespace
+
+int xo_init(udc_handle *h, const double *uprof, const double *vprof) {
+  const Geo &g = h->g;
+  const size_t nk = (size_t)g.nz + 2, np = (size_t)g.py * g.pz;
+  HIP_OK(hipMalloc(&h->xo_prof, sizeof(double) * 2 * nk));
+  HIP_OK(hipMemcpy(h->xo_prof, uprof, sizeof(double) * nk, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(h->xo_prof + nk, vprof, sizeof(double) * nk, hipMemcpyHostToDevice));
+  HIP_OK(hipMalloc(&h->xo_east, sizeof(double) * 4 * np));
+  HIP_OK(hipMemset(h->xo_east, 0, sizeof(double) * 4 * np));
+  if (!h->bcx_uout_dev) {
+    HIP_OK(hipMalloc(&h->bcx_uout_dev, sizeof(double)));
+    HIP_OK(hipMemset(h->bcx_uout_dev, 0, sizeof(double)));
+  }
+  return 0;
+}
+
+void xo_destroy(udc_handle *h) {
+  if (h->xo_prof) { hipFree(h->xo_prof); h->xo_prof = nullptr; }
+  if (h->xo_east) { hipFree(h->xo_east); h->xo_east = nullptr; }
+  if (h->xpois) { udc_destroy(h->xpois); h->xpois = nullptr; }
+}
+
+int xo_capture_east(udc_handle *h, int field, const double *, const int lb[3], const int ub[3]) {
+  if (!h->xg) return 0;
+  int slot = -1;
+  if (field == UDC_V0) slot = 0; else if (field == UDC_W0) slot = 1; else if (field == UDC_VM) slot = 2; else if (field == UDC_WM) slot = 3;
+  if (slot < 0) return 0;
+  const int itot = h->g.nx - 2;
+  if (lb[0] > itot + 1 || ub[0] < itot + 1) return 0;      // the host array does not carry the column: the plane stays as it is
+  const Geo &g = h->g;
+  hipLaunchKernelGGL(xo_capture_kernel, plane_grid(g), dim3(64), 0, h->stream, g, (const double *)h->fields[field],
+                     h->xo_east + (size_t)slot * g.py * g.pz);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int k_xo_ek_ghosts(udc_handle *h) {
+  if (!h->xg) return 0;
+  const Geo &g = h->g;
+  PROF(h, "xo_ghosts");
+  hipLaunchKernelGGL(xo_ek_kernel, plane_grid(g), dim3(64), 0, h->stream, g, h->fields[UDC_EKM], h->fields[UDC_EKH]);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int k_xo_bcpup(udc_handle *h, double rk3coef, bool pup) {
+  if (!h->xg) return 0;
+  const Geo &g = h->g;
+  PROF(h, "xo_ghosts");
+  if (pup)
+    hipLaunchKernelGGL(xo_bcpup_kernel<true>, plane_grid(g), dim3(64), 0, h->stream, g, 1. / rk3coef, h->m.dxi, (const double *)h->xo_prof,
+                       (const double *)h->bcx_uout_dev, (const double *)h->fields[UDC_U0], (const double *)h->fields[UDC_UM], h->fields[UDC_UP]);
+  else
+    hipLaunchKernelGGL(xo_bcpup_kernel<false>, plane_grid(g), dim3(64), 0, h->stream, g, 1. / rk3coef, h->m.dxi, (const double *)h->xo_prof,
+                       (const double *)h->bcx_uout_dev, (const double *)h->fields[UDC_U0], (const double *)h->fields[UDC_UM], h->fields[UDC_UP]);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int k_xo_boundary(udc_handle *h) {
+  if (!h->xg) return 0;
+  const Geo &g = h->g;
+  PROF(h, "xo_ghosts");
+  hipLaunchKernelGGL(xo_boundary_kernel, plane_grid(g), dim3(64), 0, h->stream, g, (const double *)h->xo_prof, h->m.dxi, h->bcx_rk3coef,
+                     (const double *)h->bcx_uout_dev, h->xo_stage3 ? 1 : 0, h->fields[UDC_U0], h->fields[UDC_V0], h->fields[UDC_W0],
+                     h->fields[UDC_UM], h->fields[UDC_VM], h->fields[UDC_WM], h->fields[UDC_PRES0], h->xo_east);
+  HIP_OK(hipGetLastError());
+  h->xo_stage3 = false;      // (a second `boundary` before the next integration is the reference's second convective step)
+  return 0;
+}
+
+int k_xo_poisson(udc_handle *h) {
+  udc_handle *hp = h->xpois;
+  if (!hp) { udc_set_error("open x boundaries: the solver's handle is missing"); return 1; }
+  const Geo &g = h->g, &g2 = hp->g;
+  const int n = g.nx - 2;
+  const dim3 b(256), gr((unsigned)((n + 255) / 256), (unsigned)g.ny, (unsigned)g.nz);
+  hp->bczp = h->bczp;
+  {
+    PROF(h, "xo_mirror");
+    hipLaunchKernelGGL(xo_gather_kernel, gr, b, 0, h->stream, g, g2, (const double *)h->fields[UDC_P], hp->fields[UDC_P]);
+    HIP_OK(hipGetLastError());
+  }
+  {
+    PROF(h, "poisson_2x");      // (the doubled row's transforms and tridiagonal solves, on this handle's stream)
+    if (k_poisson_solve(hp)) return 1;
+  }
+  PROF(h, "xo_mirror");
+  hipLaunchKernelGGL(xo_scatter_kernel, gr, b, 0, h->stream, g, g2, (const double *)hp->fields[UDC_P], h->fields[UDC_P]);
+  HIP_OK(hipGetLastError());
+  return 0;
+}

@@ -16,10 +16,22 @@ def from_deck(deck, device=0, rank=0, nranks=1):
     bcbotm, bcbott = int(deck.get("BC", "BCbotm")), int(deck.get("BC", "BCbotT"))
     if lbottom and bcbotm not in (2, 3):
         raise ValueError("lbottom: BCbotm must be 2 (wfuno) or 3 (wfmneutral), src/modibm.f90:2021-2029")
-    core = DynCore(g, sgs=sgs, bctopm=int(deck.get("BC", "BCtopm")), nsv=int(deck.get("SCALARS", "nsv")),
+    import numpy as np
+    bcxm = int(deck.get("BC", "BCxm"))
+    if bcxm not in (1, 2):
+        raise ValueError("&BC BCxm: 1 (periodic) or 2 (inflow profile, convective outflow) are on the device path")
+    open_x = None
+    if bcxm == 2:      # inflow from prof.inp's u, v (xmi_profile); uprof(ke+1) = vprof(ke+1) = 0 as allocated, src/modfields.f90:556
+        open_x = (np.concatenate(([0.], np.asarray(deck.u, dtype=float)[:g.nz], [0.])),
+                  np.concatenate(([0.], np.asarray(deck.v, dtype=float)[:g.nz], [0.])))
+    core = DynCore(g, sgs=sgs, bctopm=3 if bcxm == 2 else int(deck.get("BC", "BCtopm")),      # (src/modstartup.f90:845-848: BCxm = 2 opens the lid)
+                   nsv=int(deck.get("SCALARS", "nsv")),
                    prandtli=prandtli, c_vreman=c_vreman, csz=csz, device=device, rank=rank, nranks=nranks,
                    lbottom=lbottom, z0=float(deck.get("BC", "z0")),
-                   uinf=float(deck.get("INLET", "Uinf")), vinf=float(deck.get("INLET", "Vinf")))
+                   uinf=float(deck.get("INLET", "Uinf")), vinf=float(deck.get("INLET", "Vinf")), open_x=open_x)
+    if bcxm == 2:      # the outlet's speed (src/modboundary.f90:141-160): ubulk of a prescribed flow, else the mean of u's slab averages
+        ubulk = float(np.sum(np.asarray(deck.u)[:g.nz] * g.dzf[1:g.nz + 1]) / (g.zh[g.nz + 1] - g.zh[1]))      # src/modstartup.f90:1336-1341
+        core.set_open_x_outflow(None if deck.get("PHYSICS", "luvolflowr") else g.dzf[1:g.nz + 1] / (g.zh[g.nz + 1] - g.zh[2]), ubulk)
     if int(deck.get("BC", "BCzp")) != 1:
         core.set_poisson_bczp(int(deck.get("BC", "BCzp")))
     core.set_masscorr(bool(deck.get("PHYSICS", "luvolflowr")), float(deck.get("PHYSICS", "uflowrate")),

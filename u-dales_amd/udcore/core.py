@@ -29,7 +29,8 @@ def tke_constants(cf=2.5, cn=0.76, Rigc=0.25, Prandtl=0.333, ch1=1., alpha_kolm=
 class DynCore:
     def __init__(self, g: Grid, sgs=L.SGS_VREMAN, bctopm=1, nsv=0, numol=1.5e-5, prandtlmol=0.71,
                  prandtli=1. / 0.333, c_vreman=0.07, csz=0.21658244510412, uinf=0., vinf=0.,
-                 device=0, rank=0, nranks=1, lbottom=False, z0=-1.):
+                 device=0, rank=0, nranks=1, lbottom=False, z0=-1., open_x=None):
+        # open_x = (uprof, vprof), each [ktot+2] by the reference's k: inflow / outflow in x (&BC BCxm = 2, udc_create_open_x)
         self.g = g
         self.nsv = nsv
         self.lib = L.load()
@@ -40,7 +41,15 @@ class DynCore:
                           numol, 1. / prandtlmol, prandtli, c_vreman, csz, sgs, bctopm, uinf, vinf, nsv,
                           int(bool(lbottom)), z0)
         self.h = C.c_void_p()
-        L._check(self.lib.udc_create(C.byref(cfg), C.byref(self.h)), "udc_create")
+        self.open_x = open_x is not None
+        if self.open_x:
+            up = np.ascontiguousarray(open_x[0], dtype=np.float64)
+            vp = np.ascontiguousarray(open_x[1], dtype=np.float64)
+            assert up.size == g.nz + 2 and vp.size == g.nz + 2
+            L._check(self.lib.udc_create_open_x(C.byref(cfg), up.ctypes.data_as(L.DP), vp.ctypes.data_as(L.DP), C.byref(self.h)),
+                     "udc_create_open_x")
+        else:
+            L._check(self.lib.udc_create(C.byref(cfg), C.byref(self.h)), "udc_create")
         self.nyl = g.ny // nranks
         self.rank, self.nranks = rank, nranks
         self.rk3step = 0
@@ -247,6 +256,13 @@ class DynCore:
         """&BC BCxs (include/udcore.h): svprof[nsv, ktot+2] indexed by the reference's k."""
         p = np.ascontiguousarray(svprof, dtype=np.float64)
         L._check(self.lib.udc_set_scalar_bcx(self.h, int(bcxs), p.ctypes.data_as(L.DP), C.c_double(uouttot)), "udc_set_scalar_bcx")
+
+    def set_open_x_outflow(self, wlev=None, uouttot=0., hold_first=False):
+        """The outlet's speed under BCxm = 2: a constant, or (wlev [ktot]) the weighted mean of u's slab averages."""
+        w = None if wlev is None else np.ascontiguousarray(wlev, dtype=np.float64)
+        L._check(self.lib.udc_set_open_x_outflow(self.h, None if w is None else w.ctypes.data_as(L.DP), C.c_double(uouttot),
+                                                     1 if hold_first else 0),
+                 "udc_set_open_x_outflow")
 
     def set_scalar_bcx_outflow(self, wlev):
         w = np.ascontiguousarray(wlev, dtype=np.float64)
