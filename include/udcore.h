@@ -498,8 +498,14 @@ int udc_set_scalar_bcx_outflow(udc_handle *h, const double *wlev);
  * the value in force until the first refresh (bcpup reads the previous `boundary`'s speed) -- and, with hold_first, through the whole
  * first substep: the reference's start-up forms u0av before its first `boundary` puts uprof into u(ib), and the first substep's
  * `boundary` still reads that u0av (src/modstartup.f90:1601, src/program.f90:118, 214). */
+/* The rk3coef the next udc_boundary convects the outlets with (BCxm = 2 and BCxs = 2; xmo_convective / xso_convective form it from dt
+ * and rk3step, src/modboundary.f90:914, 989).  udc_tstep_integrate and udc_substep leave their own; this one is for a `boundary` that
+ * no integration precedes: the start-up's (src/program.f90:118 -- rk3step = 0 and, on a cold start, dt = dtmax / 100,
+ * src/modstartup.f90:1099, so dtmax / 400). */
+int udc_set_boundary_rk3coef(udc_handle *h, double rk3coef);
 int udc_create_open_x(const udc_config *cfg, const double *uprof, const double *vprof, udc_handle **out);
 int udc_set_open_x_outflow(udc_handle *h, const double *wlev, double uouttot, int hold_first);
+int udc_set_open_x_profile(udc_handle *h, const double *uprof, const double *vprof);      /* the inflow profiles again */
 
 /* checksim's diagnostics (src/modchecksim.f90:76-203) of the state on the device: out[0] = calccourant's number -- the maximum of the
  * SIGNED sum (um dxhi + vm dyi + wm dzhi) dtmn, :111-117 --, out[1] = calcdiffnr's (:142-149), out[2], out[3] = chkdiv's divmax and

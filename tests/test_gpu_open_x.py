@@ -67,9 +67,14 @@ def test_each_routine_matches_reference(name, iexp):
     assert relerr(core.download("u0"), marr(fix, "sub.u0", nz)) <= KERNEL_TOL
     for k in ("up", "vp", "wp"):
         assert relerr(interior(core.download(k)), interior(marr(fix, "sub." + k, nz))) <= KERNEL_TOL, k
+    core.bottom_diagnostics(True)
     core.bottom()
     for k in ("up", "vp"):
         assert relerr(interior(core.download(k)), interior(marr(fix, "bot." + k, nz))) <= KERNEL_TOL, k
+    for nm, k in (("tau_x", "up"), ("tau_y", "vp")):      # [jtot][itot]: the deck's columns, not the device row's
+        inc = interior(marr(fix, "bot." + k, nz))[0] - interior(marr(fix, "sub." + k, nz))[0]
+        got = core.bottom_diag(nm)
+        assert got.shape == inc.shape and np.abs(got - inc).max() <= 1e-12 * np.abs(inc).max(), nm
     zero_tend()
     core.advection(); core.subgrid(); core.bottom(); core.coriolis(); core.forces()
     core.rk3step, core.dt = int(fix["rk3"].data[0]), float(fix["rk3"].data[1])
@@ -150,6 +155,50 @@ def test_substeps_match_reference(name, iexp, fused):
     div = core.divergence()
     assert div[0] < 1e-12
     core.close()
+
+
+def test_cold_start_matches_reference():
+    """From the deck alone, the way run_case.py starts: the fields as readinitfiles leaves them (the x ghost columns hold the
+    profile, no noise), the start-up's slab averages, its `boundary` (uouttot from those averages, one convective step with
+    rk3step = 0 and dt = dtmax / 100), then the loop."""
+    from udcore import cold_start
+    name, iexp = "run_xopen_16x8x12s", 91
+    fix = load_fixture(name)
+    d, core = make_core(name, iexp)
+    g = core.g
+    dt = float(d.get("RUN", "dtmax"))
+    core.load_state(cold_start(g, d, nsv=0, pre_boundary=True))
+    core.halos()
+    core.start_up(dtmax=dt)
+    for k in ("u0", "v0", "w0", "um", "vm", "wm"):
+        ref = marr(fix, "s000." + k, g.nz)
+        assert relerr(nocorner(core.download(k)[1:-1]), nocorner(ref[1:-1])) <= 1e-13, k
+    assert np.abs(marr(fix, "s000.v0", g.nz)[1:-1, 1:-1, -1] - 0.1).max() > 1e-6      # (the start-up's convective step moved the outlet)
+    for isub in range(1, 4):
+        core.substep(isub, dt, with_forces=True)
+    for k in ("u0", "v0", "w0", "pres0", "vm"):
+        ref = marr(fix, "s003." + k, g.nz)
+        assert relerr(nocorner(core.download(k)[1:-1]), nocorner(ref[1:-1])) <= RUN_TOL, k
+    core.close()
+
+
+@pytest.mark.parametrize("residency", [0, 1, 2])
+@pytest.mark.parametrize("name,iexp", sorted(R_CASES.items()))
+def test_fortran_driver_with_dropin_modules(name, iexp, residency, tmp_path):
+    """The reference's own start-up and loop over the drop-in modules (oracle/_ref/udales_dropin), every residency mode: the start-up's
+    `boundary` included (s000), x ghost columns included."""
+    from test_gpu_fortran_dropin import run_dropin
+    fix = load_fixture(name)
+    got = run_dropin(name, iexp, "run", tmp_path, residency)
+    checked = 0
+    for key, ref in fix.items():
+        if "." not in key or key.split(".")[1] not in ("u0", "v0", "w0", "pres0", "um", "vm", "wm"):
+            continue
+        a, b = got[key].data[1:-1], ref.data[1:-1]
+        assert relerr(nocorner(a), nocorner(b), None if np.abs(b).max() > 0 else 1.0) <= RUN_TOL, key
+        checked += 1
+    assert checked >= 20
+    assert abs(got["s000.uouttot"].data[0] - fix["s000.uouttot"].data[0]) <= 1e-13
 
 
 def test_what_open_x_does_not_offer_is_refused():

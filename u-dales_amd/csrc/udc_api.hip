@@ -220,6 +220,17 @@ extern "C" int udc_create_open_x(const udc_config *cfg, const double *uprof, con
   *out = h;
   return 0;
 }
+// the inflow profiles again (a driver that makes its handle before prof.inp is in)
+extern "C" int udc_set_open_x_profile(udc_handle *h, const double *uprof, const double *vprof) {
+  ENTRY_FLUSH(h);
+  if (!h->xg || !uprof || !vprof) { udc_set_error("udc_set_open_x_profile: a handle of udc_create_open_x and both profiles"); return 1; }
+  const size_t nk = (size_t)h->g.nz + 2;
+  HIP_OK(hipStreamSynchronize(h->stream));
+  HIP_OK(hipMemcpy(h->xo_prof, uprof, sizeof(double) * nk, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(h->xo_prof + nk, vprof, sizeof(double) * nk, hipMemcpyHostToDevice));
+  h->boundary_fresh = false;
+  return 0;
+}
 // the outlet's convection speed uouttot (src/modboundary.f90:141-160): a constant (a prescribed volume flow's ubulk), or -- wlev
 // [ktot] given -- sum_k wlev(k) u0av(k) of the state every substep starts from, wlev(k) = dzf(k) / (zh(ke+1) - zh(kb+1)).
 // hold_first: the first substep after this call still convects with `uouttot` -- the reference's start-up forms u0av BEFORE its
@@ -258,7 +269,8 @@ static int create_on_device(const udc_config *cfg, udc_handle *h) {
   // stencil kernels' halo lines evict each other (closure at 1024x512x512: 2.2 x its algorithmic reads, 3.2 -> 2.55 ms with
   // the padding; no effect at nx = 256).  16 doubles (one 128-B line) of padding after the nx cells of a row for
   // nx >= 512 and a multiple of 256 (udc_tuning.h); never read (x is periodic by index wrap).
-  const int xpad = tune::row_padding(g.nx);
+  // (open x boundaries: itot + 2 columns, padded to whole 128-byte lines so that rows start on one)
+  const int xpad = h->xg ? (16 - g.nx % 16) % 16 : tune::row_padding(g.nx);
   g.sy = g.nx + xpad; g.sz = (long)g.sy * g.py; g.n = g.sz * g.pz;
   h->p = Params{cfg->numol, cfg->prandtlmoli, cfg->prandtli, cfg->c_vreman, cfg->csz,
                 cfg->uinf, cfg->vinf, cfg->sgs, cfg->bctopm, cfg->lbottom ? 1 : 0, cfg->z0};
@@ -1007,12 +1019,12 @@ static int now_poisson(udc_handle *h, int rk3step, double dt) {
 static int now_tstep_integrate(udc_handle *h, int rk3step, double dt) {
   if (tend_clean(h) || um_materialise(h)) return 1;
   h->bcx_rk3coef = dt / (4. - (double)rk3step);
-  h->xo_stage3 = rk3step == 3;
   if (k_scalar_bcx_uout(h)) return 1;
   h->halos_fresh = h->boundary_fresh = h->thermo_fresh = false;
   h->dthv_top_on = false;      // new fields: the next dthvdz is the one of the thermodynamics call that follows `boundary`
   if (h->p.bctopm == UDC_TOP_PRESSURE && k_lid_integrate(h, rk3step, dt, false, true, false)) return 1;   // src/modtstep.f90:270-286
   if (k_integrate(h, rk3step, dt)) return 1;
+  if (k_xo_after_integrate(h, rk3step)) return 1;
   if (rk3step == 3 && k_chem(h, dt)) return 1;      // src/modtstep.f90:236-238
   return 0;
 }
@@ -1050,7 +1062,10 @@ extern "C" int udc_bottom_diag_get(udc_handle *h, int which, double *out) {
   if (which < 0 || which > 2 || !h->bottom_diag[which]) { udc_set_error("udc_bottom_diag_get: enable with udc_bottom_diagnostics first"); return 1; }
   HIP_OK(hipSetDevice(h->device));
   if (udc_flush_pending(h)) return 1;
-  HIP_OK(hipMemcpyAsync(out, h->bottom_diag[which], sizeof(double) * (size_t)h->g.nx * h->g.ny, hipMemcpyDeviceToHost, h->stream));
+  // (open x boundaries: the deck's itot columns, not the two ghost columns of the device row)
+  const int xg = h->g.xg, itot = h->g.nx - 2 * xg;
+  HIP_OK(hipMemcpy2DAsync(out, sizeof(double) * itot, h->bottom_diag[which] + xg, sizeof(double) * h->g.nx, sizeof(double) * itot, (size_t)h->g.ny,
+                          hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -1065,6 +1080,16 @@ extern "C" int udc_halos(udc_handle *h) {
   scalar_halo_list(h, -1, s);
   if (!s.empty() && k_halo_y(h, s.data(), (int)s.size(), 2)) return 1;
   h->halos_fresh = true;
+  h->boundary_fresh = false;
+  return 0;
+}
+
+// the rk3coef the NEXT udc_boundary convects the outlets with (xmo_convective / xso_convective form it from dt and rk3step themselves,
+// src/modboundary.f90:914): udc_tstep_integrate and udc_substep leave their own; this is for a `boundary` no integration precedes --
+// the start-up's (src/program.f90:118: rk3step = 0 and, on a cold start, dt = dtmax / 100, src/modstartup.f90:1099)
+extern "C" int udc_set_boundary_rk3coef(udc_handle *h, double rk3coef) {
+  ENTRY_FLUSH(h);
+  h->bcx_rk3coef = rk3coef;
   h->boundary_fresh = false;
   return 0;
 }
@@ -1117,7 +1142,6 @@ enum : unsigned {
 static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   const double rk3coef = dt / (4. - (double)rk3step);
   h->bcx_rk3coef = rk3coef;
-  h->xo_stage3 = rk3step == 3;
   ++h->substep_seq;
   // BCxs = 2 without a prescribed volume flow: the outlet's speed from the state the substep starts from.  (BCxm = 2: bcpup still reads
   // the speed the PREVIOUS `boundary` used -- uouttot is refreshed by `boundary` only, src/modboundary.f90:141-160 -- so there the refresh
@@ -1342,7 +1366,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   if (!s.empty() && !ov_scal && k_halo_y(h, s.data(), (int)s.size(), 2)) return 1;
   if (!fold || !h->slots.empty()) { if (k_top_bottom(h)) return 1; }
   if (k_scalar_bcx_outlet(h)) return 1;
-  if (k_xo_boundary(h)) return 1;
+  if (k_xo_after_integrate(h, rk3step) || k_xo_boundary(h)) return 1;
   h->halos_fresh = h->boundary_fresh = true;
   if (h->lmoist && h->mt) {                                             // src/program.f90:214
     if (k_thermodynamics(h)) return 1;

@@ -276,7 +276,6 @@ struct udc_handle {
   double *xo_prof = nullptr;          // uprof, vprof: [2][nz+2], indexed by the reference's k
   double *xo_east = nullptr;          // v0, w0, vm, wm at i = ie+1: [4][pz][py] (the convective outlet's own state)
   bool xo_hold = false;               // the next refresh of uouttot is skipped (udc_set_open_x_outflow, hold_first)
-  bool xo_stage3 = false;             // the last integration was RK stage 3 (vm, wm took v0, w0: their outlet planes too)
   udc_handle *xpois = nullptr;        // the pressure solve's own periodic domain: the row and its mirror image, 2 itot wide
   bool poisson_only = false;          // (that handle: p and the solver's arrays only)
   hipEvent_t xo_ev[2] = {nullptr, nullptr};
@@ -554,6 +553,7 @@ int k_checksim_end(udc_handle *h, double out[4]);
 // udc_xopen.hip: inflow / outflow in x
 int k_xo_ek_ghosts(udc_handle *h);                                  // closurebc's ekm(ib-1) = ekm(ib), ekm(ie+1) = ekm(ie)
 int k_xo_bcpup(udc_handle *h, double rk3coef, bool pup);            // bcpup's BCxm_profile branch
+int k_xo_after_integrate(udc_handle *h, int rk3step);               // v, w at ie+1 back from the outlet's planes (vm = v0 at stage 3)
 int k_xo_boundary(udc_handle *h);                                   // xmi_profile, xmo_convective (+ bcp's pres0 columns)
 int k_xo_poisson(udc_handle *h);                                    // the solve on the mirrored row
 int xo_init(udc_handle *h, const double *uprof, const double *vprof);

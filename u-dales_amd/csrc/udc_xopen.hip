@@ -14,11 +14,12 @@
 //   bcp           src/modboundary.f90:1376-1394  p, pres0: ghost = the column next to it                   k_xo_poisson, k_xo_boundary
 //   xmi_profile   :688-717                       u(ib) = uprof; the inlet ghosts mirrored about the profile
 //   xmo_convective :908-926                      v, w (0 and m) at ie+1 carried by uouttot                 k_xo_boundary
+//   tstep_integrate src/modtstep.f90:191-264, 322 v, w at ie+1 untouched; vm = v0 at stage 3 there too       k_xo_after_integrate
 //
 // u(ie+1) is prognostic in the reference (src/modtstep.f90:262-264) and here simply a cell of the extended row: bcpup gives it its
 // tendency, the projection finds p(ie+1) = p(ie) and leaves it alone, the integration advances it.  v and w at ie+1 are the outlet's
-// own state: they live in planes of their own (xo_east) and are written into the ghost column by every k_xo_boundary, whatever the
-// integration left there.  The reductions that span a level or the domain (slab sums, Courant and diffusion numbers, the divergence
+// own state: they live in planes of their own (xo_east), which every integration writes back over what it left in the ghost column
+// and every `boundary` advances.  The reductions that span a level or the domain (slab sums, Courant and diffusion numbers, the divergence
 // check) leave the ghost columns out (Geo::xg).
 //
 // The pressure solve: a cosine transform in x is the Fourier transform of the row followed by its mirror image, and the Neumann
@@ -66,7 +67,7 @@ __global__ void xo_bcpup_kernel(Geo g, double rk3coefi, double dxi, const double
 
 // xmi_profile, then xmo_convective on the outlet's planes; bcp's columns of pres0
 __global__ void xo_boundary_kernel(Geo g, const double *__restrict__ prof, double dxi, double rk3coef, const double *__restrict__ uout,
-                                   int stage3, double *__restrict__ u0, double *__restrict__ v0, double *__restrict__ w0,
+                                   double *__restrict__ u0, double *__restrict__ v0, double *__restrict__ w0,
                                    double *__restrict__ um, double *__restrict__ vm, double *__restrict__ wm,
                                    double *__restrict__ pres0, double *__restrict__ east) {
   int jj, kk;
@@ -85,7 +86,6 @@ __global__ void xo_boundary_kernel(Geo g, const double *__restrict__ prof, doubl
   // the outlet: every row and plane the arrays hold
   const long P = (long)g.py * g.pz, q = (long)kk * g.py + jj;
   double ev0 = east[q], ew0 = east[P + q], evm = east[2 * P + q], ewm = east[3 * P + q];
-  if (stage3) { evm = ev0; ewm = ew0; }      // tstep_integrate's vm = v0, wm = w0 are whole-array copies (src/modtstep.f90:322-324)
   const double uo = uout[0];
   ev0 = ev0 - (ev0 - v0[r + e - 1]) * dxi * rk3coef * uo;
   ew0 = ew0 - (ew0 - w0[r + e - 1]) * dxi * rk3coef * uo;
@@ -93,6 +93,21 @@ __global__ void xo_boundary_kernel(Geo g, const double *__restrict__ prof, doubl
   ewm = ewm - (ewm - wm[r + e - 1]) * dxi * rk3coef * uo;
   east[q] = ev0; east[P + q] = ew0; east[2 * P + q] = evm; east[3 * P + q] = ewm;
   v0[r + e] = ev0; w0[r + e] = ew0; vm[r + e] = evm; wm[r + e] = ewm;
+}
+
+// after the integration: v, w at ie+1 are not the integration's to touch (src/modtstep.f90:191-264 runs over ib:ie) -- the ghost
+// column takes the outlet's plane back; on RK stage 3 the m planes first take the 0 planes (vm = v0, wm = w0 are whole-array copies,
+// :322-324)
+__global__ void xo_restore_kernel(Geo g, int stage3, double *__restrict__ v0, double *__restrict__ w0, double *__restrict__ vm,
+                                  double *__restrict__ wm, double *__restrict__ east) {
+  int jj, kk;
+  if (!plane_decode(g, jj, kk)) return;
+  const long r = (long)g.sy * jj + g.sz * kk + g.nx - 1;
+  const long P = (long)g.py * g.pz, q = (long)kk * g.py + jj;
+  const double ev0 = east[q], ew0 = east[P + q];
+  double evm = east[2 * P + q], ewm = east[3 * P + q];
+  if (stage3) { evm = ev0; ewm = ew0; east[2 * P + q] = evm; east[3 * P + q] = ewm; }
+  v0[r] = ev0; w0[r] = ew0; vm[r] = evm; wm[r] = ewm;
 }
 
 // the ghost column of an uploaded v0 / w0 / vm / wm -> the outlet's plane
@@ -186,10 +201,19 @@ int k_xo_boundary(udc_handle *h) {
   const Geo &g = h->g;
   PROF(h, "xo_ghosts");
   hipLaunchKernelGGL(xo_boundary_kernel, plane_grid(g), dim3(64), 0, h->stream, g, (const double *)h->xo_prof, h->m.dxi, h->bcx_rk3coef,
-                     (const double *)h->bcx_uout_dev, h->xo_stage3 ? 1 : 0, h->fields[UDC_U0], h->fields[UDC_V0], h->fields[UDC_W0],
+                     (const double *)h->bcx_uout_dev, h->fields[UDC_U0], h->fields[UDC_V0], h->fields[UDC_W0],
                      h->fields[UDC_UM], h->fields[UDC_VM], h->fields[UDC_WM], h->fields[UDC_PRES0], h->xo_east);
   HIP_OK(hipGetLastError());
-  h->xo_stage3 = false;      // (a second `boundary` before the next integration is the reference's second convective step)
+  return 0;
+}
+
+int k_xo_after_integrate(udc_handle *h, int rk3step) {
+  if (!h->xg) return 0;
+  const Geo &g = h->g;
+  PROF(h, "xo_ghosts");
+  hipLaunchKernelGGL(xo_restore_kernel, plane_grid(g), dim3(64), 0, h->stream, g, rk3step == 3 ? 1 : 0, h->fields[UDC_V0], h->fields[UDC_W0],
+                     h->fields[UDC_VM], h->fields[UDC_WM], h->xo_east);
+  HIP_OK(hipGetLastError());
   return 0;
 }
 

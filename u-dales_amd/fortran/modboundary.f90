@@ -28,8 +28,8 @@ contains
     use modinletdata, only: irecy
     real :: zspb, zspt
     integer :: k
-    if (BCxm /= 1 .or. BCym /= 1) then
-      write (0, *) 'ERROR: libudcore boundary: only periodic x/y'
+    if ((BCxm /= 1 .and. BCxm /= 2) .or. BCym /= 1) then
+      write (0, *) 'ERROR: libudcore boundary: BCxm = 1 (periodic) or 2 (inflow profile, convective outflow), BCym = 1'
       stop 1
     end if
     allocate (tsc(kb:ke + kh))
@@ -96,10 +96,30 @@ contains
   !> w(kb) = 0 and the top ghost planes (src/modboundary.f90:115-247, periodic lateral subset)
   subroutine boundary
     use udc_iface
+    use modglobal, only: BCxm
     call udc_begin(.false.)
+    if (BCxm == 2 .and. .not. udc_in_loop) call open_x_startup
     call udc_check(udc_boundary(udc_h), 'udc_boundary')
     if (udc_mode() <= 1) call udc_pull_vel(.true.)
   end subroutine boundary
+
+  !> BCxm = 2, the `boundary` of the start-up (src/program.f90:118): the outlet's speed uouttot from the slab averages diagfld has
+  !! just formed (src/modboundary.f90:141-160; start-up order src/modstartup.f90:1604) -- the first substep's `boundary` still reads
+  !! those, hence hold_first -- and one convective step of the outlet with the start-up's rk3step and dt (:914).  In the loop the
+  !! library refreshes uouttot itself from the state every substep starts from.
+  subroutine open_x_startup
+    use udc_iface
+    use modglobal, only: ktot, kb, ke, dzf, zh, dt, rk3step
+    use modfields, only: uouttot
+    real(c_double) :: avg(ktot + 1), wl(ktot)
+    integer(c_int) :: fld(1)
+    fld(1) = UDC_U0
+    call udc_check(udc_slab_averages(udc_h, fld, 1_c_int, avg, int(ktot + 1, c_int)), 'udc_slab_averages')
+    wl = dzf(kb:ke)/(zh(ke + 1) - zh(kb + 1))
+    uouttot = sum(avg(1:ktot)*dzf(kb:ke))/(zh(ke + 1) - zh(kb + 1))
+    call udc_check(udc_set_open_x_outflow(udc_h, wl, real(uouttot, c_double), 1_c_int), 'udc_set_open_x_outflow')
+    call udc_check(udc_set_boundary_rk3coef(udc_h, real(dt/(4. - real(rk3step)), c_double)), 'udc_set_boundary_rk3coef')
+  end subroutine open_x_startup
 
   !> gravity-wave damping in the sponge layer (src/modboundary.f90:1447-1492): tend -= (field - ref(k)) tsc(k).
   !! Applied after masscorr together with fixuinf1's table; the constant scalar sources registered for a device-mode

@@ -498,6 +498,30 @@ module udc_iface
       import :: c_int, c_ptr
       type(c_ptr), value :: h
     end function
+    ! inflow / outflow in x (&BC BCxm = 2; include/udcore.h, udc_xopen.hip)
+    integer(c_int) function udc_create_open_x(cfg, uprof, vprof, h) bind(C, name='udc_create_open_x')
+      import :: c_int, c_ptr, c_double, udc_config
+      type(udc_config), intent(in) :: cfg
+      real(c_double), intent(in) :: uprof(*), vprof(*)
+      type(c_ptr), intent(out) :: h
+    end function
+    integer(c_int) function udc_set_open_x_profile(h, uprof, vprof) bind(C, name='udc_set_open_x_profile')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(in) :: uprof(*), vprof(*)
+    end function
+    integer(c_int) function udc_set_open_x_outflow(h, wlev, uouttot, hold_first) bind(C, name='udc_set_open_x_outflow')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(in) :: wlev(*)
+      real(c_double), value :: uouttot
+      integer(c_int), value :: hold_first
+    end function
+    integer(c_int) function udc_set_boundary_rk3coef(h, rk3coef) bind(C, name='udc_set_boundary_rk3coef')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      real(c_double), value :: rk3coef
+    end function
   end interface
 
 contains
@@ -538,7 +562,7 @@ contains
                          BCtopm, Uinf, Vinf, lles, ltempeq, lbuoyancy, lmoist, iadv_thl, BCtopT, BCbotT, grav, e12min, &
                          iadv_qt, BCtopq, BCbotq, zf, zh, BCbotm, prandtlturb, fkar, BCtops, lchem, k1, JNO2, &
                          lcoriol, lprofforc, om22, om23, luvolflowr, lvvolflowr, uflowrate, vflowrate, &
-                         lnudge, igrw_damp, ifixuinf, ds, BCzp
+                         lnudge, igrw_damp, ifixuinf, ds, BCzp, BCxm
     use modsurfdata, only: wttop, thl_top, wtsurf, thvs, wqtop, qt_top, wqsurf, thls, qts, ps, z0h, wsvtop, sv_top
     use modsubgriddata, only: lsmagorinsky, lvreman, loneeqn, ldelta, prandtli, c_vreman, csz, cm, cn, ch1, ch2, ce1, ce2, lbuoycorr, Rigc
     use modfields, only: dpdxl, dpdyl, thlpcar, ug, whls, dthldxls, dthldyls, dqtdxls, dqtdyls, dqtdtls, &
@@ -550,6 +574,7 @@ contains
     integer(c_signed_char) :: nccl_id(128)
     integer :: gpus_per_node, n
     real(c_double), allocatable, target, save :: zf_(:), zh_(:)
+    real(c_double), allocatable :: xo_u(:), xo_v(:)
     character(16) :: env
     integer :: stat
 #ifdef UDC_TEST_TRANSPORT
@@ -597,7 +622,12 @@ contains
     cfg%nsv = nsv
     cfg%lbottom = merge(1, 0, udc_floor_on)
     cfg%z0 = udc_floor_z0
-    call udc_check(udc_create(cfg, udc_h), 'udc_create')
+    if (BCxm == 2) then      ! inflow from prof.inp's profile, convective outflow: rows with the reference's ghost columns (udc_xopen.hip)
+      call open_x_profiles(xo_u, xo_v)
+      call udc_check(udc_create_open_x(cfg, xo_u, xo_v, udc_h), 'udc_create_open_x')
+    else
+      call udc_check(udc_create(cfg, udc_h), 'udc_create')
+    end if
     if (BCzp /= 1) call udc_check(udc_set_poisson_bczp(udc_h, int(BCzp, c_int)), 'udc_set_poisson_bczp')      ! cosine transform in z
     if (nprocs > 1) then
       ! RCCL communicator over the y-slab ranks: rank 0 makes the id, MPI carries it (INTEGRATION.md section 4)
@@ -662,17 +692,33 @@ contains
     call udc_push_state
   end subroutine udc_ensure
 
+  !> uprof, vprof as the library takes them: [ktot+2] indexed by the reference's k (entry 0 unused; uprof(ke+1) as allocated: zero)
+  subroutine open_x_profiles(u, v)
+    use modglobal, only: ktot, kb, ke, kh
+    use modfields, only: uprof, vprof
+    real(c_double), allocatable, intent(out) :: u(:), v(:)
+    allocate (u(0:ktot + 1), v(0:ktot + 1))
+    u = 0.; v = 0.
+    if (allocated(uprof)) u(1:ktot + 1) = uprof(kb:ke + kh)
+    if (allocated(vprof)) v(1:ktot + 1) = vprof(kb:ke + kh)
+  end subroutine open_x_profiles
+
   !> What depends on the input files readinitfiles reads (lscale.inp, scalar.inp: dpdxl, dpdyl, thlpcar, ug, whls, the
   !! large-scale gradients, sv_top).  The handle may exist before they are in (readinitfiles itself calls halos /
   !! boundary / thermodynamics), so this runs with every start-up call and a last time when the time loop starts.
   subroutine udc_late_setup
     use modglobal, only: ktot, kb, ke, nsv, ltempeq, BCtops, lcoriol, lprofforc, om22, om23, luvolflowr, lvvolflowr, luoutflowr, &
-                         uflowrate, vflowrate, lnudge, igrw_damp, ifixuinf, ds, BCxs
+                         uflowrate, vflowrate, lnudge, igrw_damp, ifixuinf, ds, BCxs, BCxm
     use modsurfdata, only: wsvtop, sv_top
     use modfields, only: dpdxl, dpdyl, thlpcar, ug, whls, dthldxls, dthldyls, dqtdxls, dqtdyls, dqtdtls, &
                          dudxls, dudyls, dvdxls, dvdyls
     integer :: n
+    real(c_double), allocatable :: xo_u(:), xo_v(:)
     call udc_check(udc_set_forcing(udc_h, dpdxl(kb:ke), dpdyl(kb:ke), int(ktot, c_int)), 'udc_set_forcing')
+    if (BCxm == 2) then      ! (the handle may be older than prof.inp's profiles)
+      call open_x_profiles(xo_u, xo_v)
+      call udc_check(udc_set_open_x_profile(udc_h, xo_u, xo_v), 'udc_set_open_x_profile')
+    end if
     if (ltempeq) then
       call udc_check(udc_set_thl_source(udc_h, thlpcar(kb:ke), int(ktot, c_int)), 'udc_set_thl_source')
     end if

@@ -335,7 +335,10 @@ class DynCore:
         """Record the top ghost planes of thl0 / qt0 as calthv would see them now (include/udcore.h udc_calthv)."""
         L._check(self.lib.udc_calthv(self.h), "udc_calthv")
 
-    def start_up(self, before_boundary=None):
+    def set_boundary_rk3coef(self, rk3coef):
+        L._check(self.lib.udc_set_boundary_rk3coef(self.h, C.c_double(rk3coef)), "udc_set_boundary_rk3coef")
+
+    def start_up(self, before_boundary=None, dtmax=None):
         """What the reference does between filling the fields and entering the loop (src/modstartup.f90:1601, src/program.f90:118):
         `thermodynamics` on the state as readinitfiles left it -- grid.cold_start(..., pre_boundary=True) --, then `boundary`.
         `before_boundary`: a callable run in between (the host's level forcings take diagfld's slab averages there)."""
@@ -345,6 +348,15 @@ class DynCore:
             self.calthv()
         if before_boundary is not None:
             before_boundary()
+        if self.open_x and dtmax is not None:
+            # BCxm = 2, cold start: diagfld has just formed u0av from the fields as readinitfiles left them; the start-up's `boundary` takes
+            # its uouttot from it (and so does the first substep's), and convects the outlet once with rk3step = 0 and dt = dtmax / 100
+            # (src/modstartup.f90:1099, src/modboundary.f90:141-160, 914)
+            g = self.g
+            wl = g.dzf[1:g.nz + 1] / (g.zh[g.nz + 1] - g.zh[2])
+            u0av = self.slab_average("u0")
+            self.set_open_x_outflow(wl, float(np.sum(np.asarray(u0av)[1:g.nz + 1] * wl)), hold_first=True)
+            self.set_boundary_rk3coef(dtmax / 100. / 4.)
         self.boundary()
 
     def thermodynamics(self):

@@ -150,9 +150,11 @@ def cold_start(g: Grid, d: Deck, j0=0, nyl=None, nsv=0, scal_a=None, scal_b=None
         out["ekm"] = ek
         out["ekh"] = ek.copy()
         out["ekh"][nz + 1] = 1.5e-5
+    open_x = int(d.get("BC", "BCxm")) == 2      # the x ghost columns keep the profile readinitfiles put there (src/modstartup.f90:1155-1177)
     for a in (um, vm, wm):
-        a[:, :, 0] = a[:, :, nx]
-        a[:, :, nx + 1] = a[:, :, 1]
+        if not open_x:
+            a[:, :, 0] = a[:, :, nx]
+            a[:, :, nx + 1] = a[:, :, 1]
         if nyl == ny:
             a[:, 0, :] = a[:, nyl, :]
             a[:, nyl + 1, :] = a[:, 1, :]

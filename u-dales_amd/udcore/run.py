@@ -40,8 +40,8 @@ def check_supported(deck):
                 _refuse(f"only periodic lateral boundaries are on the device path (&BC {n})")
     # (iwallmom = 2 without the temperature equation never reaches initibm: checkinitvalues has made it 3 by then,
     #  src/modstartup.f90:811-816 -- Deck.apply_checkinitvalues)
-    if int(g("BC", "BCxm")) != 1 or int(g("BC", "BCym")) != 1:
-        _refuse("only periodic lateral boundaries (BCxm = BCym = 1) are on the device path")
+    if int(g("BC", "BCxm")) not in (1, 2) or int(g("BC", "BCym")) != 1:
+        _refuse("lateral boundaries on the device path: BCxm = 1 (periodic) or 2 (inflow profile, convective outflow), BCym = 1")
     if int(g("DYNAMICS", "ipoiss")) != 0 or int(g("BC", "BCzp")) not in (1, 2):
         _refuse("only ipoiss = 0 (FFT in x, y) with BCzp = 1 or 2 is on the device path")
     # &RUN nprocx / nprocy describe the CPU run's pencil layout; the device path splits y over however many GPUs it is
@@ -175,7 +175,7 @@ def main(argv=None, at_end=None):
     core.dt, core.timee, core.rk3step = dt, timee, 0
     forcings = LevelForcings(core, deck)
     if warm < 0:      # the reference's order at a cold start: thermodynamics on the fields as read (src/modstartup.f90:1601), then boundary
-        core.start_up(before_boundary=forcings.capture_startup)
+        core.start_up(before_boundary=forcings.capture_startup, dtmax=float(deck.get("RUN", "dtmax")))
     tdump = None
     for sw in ("lydump", "lxydump", "ltkedump", "lkslicedump", "lislicedump", "ljslicedump"):
         if deck.is_set("OUTPUT", sw) and deck.get("OUTPUT", sw):
