@@ -61,7 +61,11 @@ def run_full(name, iexp, tmp_path, exe=FULL, env=None, deck_text=None):
     return fix, last, rs, tmp_path
 
 
-@pytest.mark.parametrize("name,iexp", sorted(RUN_CASES.items()))
+# (+ the inflow / outflow decks of tests/test_gpu_open_x.py: fixtures the oracle does not restate are pinned on the program too)
+OPEN_X_CASES = {"run_xopen_16x8x12s": 91, "run_xopen_vr_24x8x10": 92, "run_xopen_ibm_16x12x10": 93, "run_xopen_ibmwf3_16x12x10": 94}
+
+
+@pytest.mark.parametrize("name,iexp", sorted({**RUN_CASES, **OPEN_X_CASES}.items()))
 def test_fixture_equals_the_reference_executable(name, iexp, tmp_path):
     if not os.path.exists(FULL):
         pytest.skip("oracle/_ref/udales_full not built (needs the reference sources + flang)")

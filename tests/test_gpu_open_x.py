@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 KERNEL_TOL = 1e-11
 RUN_TOL = 1e-9
 K_CASES = {"k_xopen_16x8x12": 90}
-R_CASES = {"run_xopen_16x8x12s": 91, "run_xopen_vr_24x8x10": 92}
+R_CASES = {"run_xopen_16x8x12s": 91, "run_xopen_vr_24x8x10": 92, "run_xopen_ibm_16x12x10": 93, "run_xopen_ibmwf3_16x12x10": 94}
 
 
 def make_core(name, iexp):
@@ -157,12 +157,13 @@ def test_substeps_match_reference(name, iexp, fused):
     core.close()
 
 
-def test_cold_start_matches_reference():
+@pytest.mark.parametrize("name", ["run_xopen_16x8x12s", "run_xopen_ibmwf3_16x12x10"])
+def test_cold_start_matches_reference(name):
     """From the deck alone, the way run_case.py starts: the fields as readinitfiles leaves them (the x ghost columns hold the
     profile, no noise), the start-up's slab averages, its `boundary` (uouttot from those averages, one convective step with
     rk3step = 0 and dt = dtmax / 100), then the loop."""
     from udcore import cold_start
-    name, iexp = "run_xopen_16x8x12s", 91
+    iexp = R_CASES[name]
     fix = load_fixture(name)
     d, core = make_core(name, iexp)
     g = core.g
@@ -173,7 +174,8 @@ def test_cold_start_matches_reference():
     for k in ("u0", "v0", "w0", "um", "vm", "wm"):
         ref = marr(fix, "s000." + k, g.nz)
         assert relerr(nocorner(core.download(k)[1:-1]), nocorner(ref[1:-1])) <= 1e-13, k
-    assert np.abs(marr(fix, "s000.v0", g.nz)[1:-1, 1:-1, -1] - 0.1).max() > 1e-6      # (the start-up's convective step moved the outlet)
+    vin = float(d.v[0])
+    assert np.abs(marr(fix, "s000.v0", g.nz)[1:-1, 1:-1, -1] - vin).max() > 1e-6      # (the start-up's convective step moved the outlet)
     for isub in range(1, 4):
         core.substep(isub, dt, with_forces=True)
     for k in ("u0", "v0", "w0", "pres0", "vm"):
@@ -199,6 +201,25 @@ def test_fortran_driver_with_dropin_modules(name, iexp, residency, tmp_path):
         checked += 1
     assert checked >= 20
     assert abs(got["s000.uouttot"].data[0] - fix["s000.uouttot"].data[0]) <= 1e-13
+
+
+@pytest.mark.parametrize("residency", [2, 0])
+def test_through_the_reference_program(residency, tmp_path):
+    """u-dales_amd/bin/udales_full_dropin -- the reference's own program.f90, start-up, time loop and writerestartfiles over the
+    drop-in modules -- on a BCxm = 2 deck: the restart files it writes against the all-reference run's dump, x ghost columns
+    (the outlet's state) included."""
+    import os
+    from test_full_reference import run_full
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "u-dales_amd", "bin", "udales_full_dropin")
+    if not os.path.exists(exe):
+        pytest.skip("u-dales_amd/bin/udales_full_dropin not built (needs the reference sources + flang)")
+    name, iexp = "run_xopen_16x8x12s", 91
+    fix, last, rs, _ = run_full(name, iexp, tmp_path, exe=exe, env=dict(os.environ, UDC_RESIDENCY=str(residency)))
+    nz = int(fix["meta"].data[2])
+    for k in ("u0", "v0", "w0", "pres0"):
+        a, b = rs[k][1:nz + 1], fix[f"{last}.{k}"].data[1:nz + 1]
+        assert relerr(nocorner(a), nocorner(b)) <= RUN_TOL, k
+    assert np.abs(fix[f"{last}.v0"].data[1:nz + 1, 1:-1, -1] - fix[f"{last}.v0"].data[1:nz + 1, 1:-1, -2]).max() > 1e-4
 
 
 def test_what_open_x_does_not_offer_is_refused():

@@ -274,14 +274,14 @@ inline unsigned blocks(int n) { return (unsigned)((n + 127) / 128); }
 
 // ------------------------------------------------------------------------------------------------ host side
 extern "C" int udc_set_ibm_points(udc_handle *h, int grid, const int *solid, int nsolid, const int *bound, int nbound) {
-  NO_OPEN_X(h, "udc_set_ibm_points");
   if (!h) { udc_set_error("null handle"); return 1; }
   if (grid < 0 || grid > 3) { udc_set_error("udc_set_ibm_points: grid 0 (u), 1 (v), 2 (w) or 3 (c)"); return 1; }
   if (nsolid < 0 || nbound < 0 || (nsolid && !solid) || (nbound && !bound)) { udc_set_error("udc_set_ibm_points: bad list"); return 1; }
   // A point whose (i, j) lies outside the domain belongs to no rank: the reference's reader keeps the points of its own pencil and
   // drops the rest without a word (read_sparse_ijk, src/readinput.f90:90-100 -- the lists of its own tests/cases/526 cover 256 x 128
   // columns of a 128 x 64 domain).  Same here; a level outside kb..ke is an error (the reference would index out of bounds).
-  const int ext[3] = {h->g.nx, h->jtot, h->g.nz};
+  if (h->xg && grid == 3) { udc_set_error("udc_set_ibm_points: open x boundaries carry no scalar field yet: the c lists have no use"); return 1; }
+  const int ext[3] = {h->g.nx - 2 * h->g.xg, h->jtot, h->g.nz};      // (open x boundaries: the deck's itot)
   udc_handle::IbmGrid &G = h->ibm[grid];
   G.solid_g.clear(); G.bound_g.clear();
   for (int pass = 0; pass < 2; ++pass) {
@@ -339,7 +339,8 @@ extern "C" int udc_ibm_commit(udc_handle *h) {
   for (int n : h->slots)
     if (n == 14) { udc_set_error("udc_ibm_commit: the one-equation closure (e12) is not available with immersed boundaries"); return 1; }
   if (h->lmoist && h->mt && !have_c) { udc_set_error("udc_ibm_commit: the moist thermodynamics average over the fluid cells: the c point lists are needed"); return 1; }
-  const int nx = h->g.nx, ny = h->jtot, nz = h->g.nz, j0 = h->cfg.rank * h->g.ny, nyl = h->g.ny;
+  // (open x boundaries: nx is the deck's itot, the lists' i; device column = i - 1 + xg)
+  const int xg = h->g.xg, nx = h->g.nx - 2 * xg, ny = h->jtot, nz = h->g.nz, j0 = h->cfg.rank * h->g.ny, nyl = h->g.ny;
   // masks as initibm builds them (src/modibm.f90:150-186): 1 = fluid; planes k = 0 (kb-1) .. nz+1.  Beyond a lateral
   // boundary of the domain: the periodic image, or "fluid" where the reference's exchange_halo_z would not have wrapped
   // (a direction held by one rank; udc_set_ibm_mask_wrap)
@@ -369,7 +370,7 @@ extern "C" int udc_ibm_commit(udc_handle *h) {
     for (size_t q = 0; q < G.solid_g.size() / 3; ++q) {
       const int i = G.solid_g[3 * q], j = G.solid_g[3 * q + 1], k = G.solid_g[3 * q + 2];
       if (j <= j0 || j > j0 + nyl) continue;
-      sp.push_back(i - 1); sp.push_back(j - 1 - j0); sp.push_back(k - 1);
+      sp.push_back(i - 1 + xg); sp.push_back(j - 1 - j0); sp.push_back(k - 1);
       unsigned f = 0;
       if (gq == 3) {
         const int ni[6] = {i, i, i, i, i + 1, i - 1}, nj[6] = {j + 1, j - 1, j, j, j, j}, nk[6] = {k, k, k + 1, k - 1, k, k};
@@ -381,7 +382,7 @@ extern "C" int udc_ibm_commit(udc_handle *h) {
     for (size_t q = 0; q < G.bound_g.size() / 3; ++q) {
       const int i = G.bound_g[3 * q], j = G.bound_g[3 * q + 1], k = G.bound_g[3 * q + 2];
       if (j <= j0 || j > j0 + nyl) continue;
-      bp.push_back(i - 1); bp.push_back(j - 1 - j0); bp.push_back(k - 1);
+      bp.push_back(i - 1 + xg); bp.push_back(j - 1 - j0); bp.push_back(k - 1);
       unsigned f = 0;
       int ni[6], nj[6], nk[6], nb = 4;
       for (int b = 0; b < 6; ++b) { ni[b] = i; nj[b] = j; nk[b] = k; }

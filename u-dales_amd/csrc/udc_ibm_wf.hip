@@ -33,7 +33,7 @@ struct WfArgs {
 __device__ __forceinline__ int wx(int i, int nx) { return i < 0 ? i + nx : (i >= nx ? i - nx : i); }
 // field value at the reference's global (i, j, k), ghost ring included
 __device__ __forceinline__ double at(const Geo &g, const double *f, int j0, int i, int j, int k) {
-  return f[g.idx(wx(i - 1, g.nx), j - 1 - j0, k - 1)];
+  return f[g.idx(wx(i - 1 + g.xg, g.nx), j - 1 - j0, k - 1)];      // (xg: open x boundaries, the device row starts at ib - 1)
 }
 
 // coordinates of the staggered grids (equidistant x, y): xh(i) = (i-1) dx, xf(i) = (i - 1/2) dx
@@ -82,7 +82,7 @@ __global__ void ibm_wallfunmom_kernel(Geo g, Metrics m, WfArgs a) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= a.ncell) return;
   const int i = a.cell[3 * q], j = a.cell[3 * q + 1], k = a.cell[3 * q + 2], j0 = a.j0;
-  const long c = g.idx(i - 1, j - 1 - j0, k - 1);
+  const long c = g.idx(i - 1 + g.xg, j - 1 - j0, k - 1);
   const double eps1 = 1.e-10, fkar = a.fkar;
   const double vol = m.dx * m.dy * m.dzf[k];
   double t = a.rhs[c];
@@ -182,7 +182,7 @@ __global__ void ibm_wallfunheat_kernel(Geo g, Metrics m, WfArgs a) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= a.ncell) return;
   const int i = a.cell[3 * q], j = a.cell[3 * q + 1], k = a.cell[3 * q + 2], j0 = a.j0;
-  const long c = g.idx(i - 1, j - 1 - j0, k - 1);
+  const long c = g.idx(i - 1 + g.xg, j - 1 - j0, k - 1);
   const double eps1 = 1.e-10;
   const double vol = m.dx * m.dy * m.dzh[k];
   double t = a.rhs[c];
@@ -242,7 +242,7 @@ __global__ void ibm_fac_pres_kernel(Geo g, int n, int j0, const int *__restrict_
                                     const double *__restrict__ pres0, double *__restrict__ fp, double *__restrict__ fp2) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= n) return;
-  const double p = pres0[g.idx(cell[3 * q] - 1, cell[3 * q + 1] - 1 - j0, cell[3 * q + 2] - 1)];
+  const double p = pres0[g.idx(cell[3 * q] - 1 + g.xg, cell[3 * q + 1] - 1 - j0, cell[3 * q + 2] - 1)];
   atomicAdd(&fp[fac[q] - 1], p * area[q]);
   atomicAdd(&fp2[fac[q] - 1], p * p * area[q]);
 }
@@ -303,7 +303,7 @@ extern "C" int udc_set_ibm_sections(udc_handle *h, int grid, int n, const int *c
   std::vector<char> fallback(n, 0);
   for (int s = 0; s < n; ++s) {
     const int i = cell[3 * s], j = cell[3 * s + 1], k = cell[3 * s + 2];
-    if (i < 1 || i > g.nx || j < 1 || j > h->jtot || k < 1 || k > g.nz) { udc_set_error("udc_set_ibm_sections: section %d: cell (%d %d %d) outside the domain", s + 1, i, j, k); return 1; }
+    if (i < 1 || i > g.nx - 2 * g.xg || j < 1 || j > h->jtot || k < 1 || k > g.nz) { udc_set_error("udc_set_ibm_sections: section %d: cell (%d %d %d) outside the domain", s + 1, i, j, k); return 1; }
     if (!(z0[s] > 0.) || !(dist[s] > 0.)) { udc_set_error("udc_set_ibm_sections: section %d: z0 and the wall distance must be positive", s + 1); return 1; }
     const bool is_mine = j > j0 && j <= j0 + g.ny;
     if (!comprec[s] && is_mine)
@@ -315,7 +315,7 @@ extern "C" int udc_set_ibm_sections(udc_handle *h, int grid, int n, const int *c
         }
         // a reconstruction cell beyond the rows this slab can read (its own and one ghost row either side): the reference then
         // falls back to the boundary point itself -- lcomprec_loc = .true., src/modibm.f90:606-622 -- and so does this slab
-        if (r[0] < 0 || r[0] > g.nx || r[1] < j0 || r[1] > j0 + g.ny) fallback[s] = 1;
+        if (r[0] < 0 || r[0] > g.nx - 2 * g.xg || r[1] < j0 || r[1] > j0 + g.ny) fallback[s] = 1;
       }
     if (is_mine) mine.push_back(s);
   }
@@ -477,7 +477,7 @@ extern "C" int udc_set_ibm_facet_output(udc_handle *h, int nfcts, const double *
   std::vector<int> pc, pf; std::vector<double> pa;
   for (int s_ = 0; s_ < npres; ++s_) {
     const int i = pcell[3 * s_], j = pcell[3 * s_ + 1], k = pcell[3 * s_ + 2];
-    if (i < 1 || i > g.nx || j < 1 || j > h->jtot) continue;      // (a boundary point no rank owns)
+    if (i < 1 || i > g.nx - 2 * g.xg || j < 1 || j > h->jtot) continue;      // (a boundary point no rank owns)
     if (k < 1 || k > g.nz || pfac[s_] < 1 || pfac[s_] > nfcts) { udc_set_error("udc_set_ibm_facet_output: pressure section %d out of range", s_ + 1); return 1; }
     if (j <= j0 || j > j0 + g.ny) continue;
     pc.insert(pc.end(), pcell + 3 * s_, pcell + 3 * s_ + 3); pf.push_back(pfac[s_]); pa.push_back(parea[s_]);

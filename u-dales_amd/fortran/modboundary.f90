@@ -109,14 +109,15 @@ contains
   !! library refreshes uouttot itself from the state every substep starts from.
   subroutine open_x_startup
     use udc_iface
-    use modglobal, only: ktot, kb, ke, dzf, zh, dt, rk3step
-    use modfields, only: uouttot
-    real(c_double) :: avg(ktot + 1), wl(ktot)
-    integer(c_int) :: fld(1)
-    fld(1) = UDC_U0
-    call udc_check(udc_slab_averages(udc_h, fld, 1_c_int, avg, int(ktot + 1, c_int)), 'udc_slab_averages')
+    use modglobal, only: ib, ie, jb, je, kb, ke, kh, ktot, dzf, zh, dt, rk3step
+    use modfields, only: uouttot, u0, u0av, IIu, IIus
+    use modmpi, only: avexy_ibm
+    real(c_double) :: wl(ktot)
+    ! diagfld's own line (src/modthermodynamics.f90:271) on the host's start-up fields: the immersed boundary's masks are the host's
+    ! at this point (the device takes the point lists with the first ibmwallfun / ibmnorm)
+    call avexy_ibm(u0av(kb:ke + kh), u0(ib:ie, jb:je, kb:ke + kh), ib, ie, jb, je, kb, ke, kh, IIu(ib:ie, jb:je, kb:ke + kh), IIus(kb:ke + kh), .false.)
     wl = dzf(kb:ke)/(zh(ke + 1) - zh(kb + 1))
-    uouttot = sum(avg(1:ktot)*dzf(kb:ke))/(zh(ke + 1) - zh(kb + 1))
+    uouttot = sum(u0av(kb:ke)*dzf(kb:ke))/(zh(ke + 1) - zh(kb + 1))
     call udc_check(udc_set_open_x_outflow(udc_h, wl, real(uouttot, c_double), 1_c_int), 'udc_set_open_x_outflow')
     call udc_check(udc_set_boundary_rk3coef(udc_h, real(dt/(4. - real(rk3step)), c_double)), 'udc_set_boundary_rk3coef')
   end subroutine open_x_startup
