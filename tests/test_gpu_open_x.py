@@ -222,6 +222,26 @@ def test_through_the_reference_program(residency, tmp_path):
     assert np.abs(fix[f"{last}.v0"].data[1:nz + 1, 1:-1, -1] - fix[f"{last}.v0"].data[1:nz + 1, 1:-1, -2]).max() > 1e-4
 
 
+def test_cli_run_writes_the_reference_state(tmp_path):
+    """run_case.py on the BCxm = 2 deck with obstacles and wall functions: cold start, three steps, the restart file it writes."""
+    import os, shutil, subprocess, sys
+    from common import GOLDEN
+    from udcore import restart as R
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    name, iexp = "run_xopen_ibmwf3_16x12x10", 94
+    for fn in os.listdir(os.path.join(GOLDEN, "cases", name)):
+        shutil.copy(os.path.join(GOLDEN, "cases", name, fn), tmp_path)
+    r = subprocess.run([sys.executable, os.path.join(root, "run_case.py"), f"namoptions.{iexp:03d}", "--steps", "3"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    fix = load_fixture(name)
+    n = tuple(int(v) for v in fix["meta"].data[:3])
+    got = R.read_initd(os.path.join(tmp_path, R.restart_name(3, 0, iexp)), *n)
+    for k in ("u0", "v0", "w0", "pres0"):
+        ref = marr(fix, f"s009.{k}", n[2])
+        assert relerr(nocorner(got[k][1:-1]), nocorner(ref[1:-1])) <= RUN_TOL, k
+
+
 def test_what_open_x_does_not_offer_is_refused():
     from udcore import lib as L
     d, core = make_core("k_xopen_16x8x12", 90)
