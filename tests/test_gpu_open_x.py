@@ -222,6 +222,83 @@ def test_through_the_reference_program(residency, tmp_path):
     assert np.abs(fix[f"{last}.v0"].data[1:nz + 1, 1:-1, -1] - fix[f"{last}.v0"].data[1:nz + 1, 1:-1, -2]).max() > 1e-4
 
 
+def test_full_size_properties_256():
+    """BASELINE.json's 256^3 with open x boundaries: size-independent properties -- the projection leaves the interior divergence-free
+    (the outlet column included: u(ie+1) is part of the last cell's balance), the inlet column stays at the profile to the bit, the
+    outlet's planes are what the arrays hold, and the routine-by-routine order gives what the fused substep gives."""
+    from udcore.grid import Grid
+    from udcore.core import DynCore
+    from udcore import lib as L
+    n = 256
+    g = Grid.uniform(n, n, n, 2.0, 2.0, 2.0)
+    prof = np.concatenate(([0.], 1.0 + 0.2 * np.arange(n) / n, [0.]))
+    rng = np.random.default_rng(11)
+    sh = g.mshape()
+    st = {k: m + 0.05 * (rng.random(sh) - 0.5) for k, m in (("u0", 1.1), ("v0", 0.1), ("w0", 0.))}
+    st["w0"][:2] = 0.
+    out = []
+    for fused in (True, False):
+        core = DynCore(g, sgs=L.SGS_SMAGORINSKY, bctopm=3, lbottom=True, z0=0.05, open_x=(prof, 0.1 * (prof > 0)))
+        core.set_forcing(np.zeros(n), np.zeros(n))
+        core.set_open_x_outflow(g.dzf[1:n + 1] / (g.zh[n + 1] - g.zh[2]), 1.1)
+        for k, a in st.items():
+            core.upload(k, a); core.upload(k.replace("0", "m"), a)
+        core.halos(); core.boundary()
+        dt = 0.05
+        for isub in range(1, 7):
+            if fused:
+                core.substep((isub - 1) % 3 + 1, dt)
+            else:
+                core.tstep_update(dt)
+                core.advection(); core.subgrid(); core.bottom(); core.forces(); core.poisson()
+                core.tstep_integrate(); core.halos(); core.boundary()
+        u, v = core.download("u0"), core.download("v0")
+        divmax, _ = core.divergence()
+        assert divmax < 1e-12 * 1.1 / g.dx * 10
+        assert np.array_equal(u[1:n + 2, 1:-1, 1], np.broadcast_to(prof[1:n + 2, None], (n + 1, n)))      # u(ib) = uprof(k), k = kb .. ke+1
+        assert np.array_equal(u[1:n + 1, 1:-1, 0], 2 * prof[1:n + 1, None] - u[1:n + 1, 1:-1, 2])          # the inlet ghost mirrors about it
+        assert np.abs(u[1:n + 1, 1:-1, -1] - u[1:n + 1, 1:-1, -2]).max() > 1e-4                             # an outlet that carries something
+        out.append((u, v, core.download("pres0")))
+        core.close()
+    for a, b in zip(*out):
+        assert relerr(nocorner(a[1:-1]), nocorner(b[1:-1])) <= 1e-11
+
+
+def test_reductions_leave_the_ghost_columns_out():
+    """Courant / diffusion numbers (tstep_update), slab averages (diagfld) and the divergence check (chkdiv) run over ib..ie: whatever the
+    two ghost columns of the device row hold (here: something huge) does not reach them."""
+    import ctypes as C
+    d, core = make_core("k_xopen_16x8x12", 90)
+    fix = load_fixture("k_xopen_16x8x12")
+    g, nz = core.g, core.g.nz
+    st = {k: marr(fix, "in." + k, nz) for k in ("u0", "v0", "w0", "um", "vm", "wm", "ekm", "ekh")}
+    st = {k: np.nan_to_num(a) for k, a in st.items()}
+    ref_div = None
+    for poke in (False, True):
+        for k, a in st.items():
+            b = a.copy()
+            if poke and k in ("um", "vm", "wm", "ekm", "ekh", "v0", "w0"):
+                b[:, :, 0] = 1e3; b[:, :, -1] = 1e3
+            core.upload(k, b)
+        dt = 0.25
+        c, dd = C.c_double(), C.c_double()
+        assert core.lib.udc_tstep_maxima(core.h, C.c_double(dt), C.byref(c), C.byref(dd)) == 0
+        um, vm, wm, ekm, ekh = (interior(st[k]) for k in ("um", "vm", "wm", "ekm", "ekh"))
+        dzh = g.dzh[1:nz + 1][:, None, None]
+        cour = ((np.abs(um) / g.dx + np.abs(vm) / g.dy + np.abs(wm) / dzh) * dt).max()
+        f = (1. / dzh ** 2 + 1. / g.dx ** 2 + 1. / g.dy ** 2) * dt
+        dif = max(1e-5, (ekm * f).max(), (ekh * f).max())
+        assert abs(c.value - cour) <= 1e-12 * cour and abs(dd.value - dif) <= 1e-12 * dif, poke
+        av = core.slab_average("um")
+        assert np.abs(av[1:nz + 1] - um.mean(axis=(1, 2))).max() <= 1e-13
+        div = core.divergence()
+        if ref_div is None:
+            ref_div = div
+        else:
+            assert div == ref_div      # (v, w at ie+1 / ib-1 are no part of an interior cell's balance; u(ie+1) is, and was not poked)
+    core.close()
+
+
 def test_cli_run_writes_the_reference_state(tmp_path):
     """run_case.py on the BCxm = 2 deck with obstacles and wall functions: cold start, three steps, the restart file it writes."""
     import os, shutil, subprocess, sys
