@@ -360,6 +360,21 @@ void orc_closure(const orc_grid *g, const double *u0, const double *v0, const do
 
 /* src/modboundary.f90:434-505, single rank, periodic x and y.
  * (reassure_fluxtop_boundary :392-431 is applied by the caller, orc_substep.) */
+/* Inflow / outflow in x (&BC BCxm = 2, BCxm_profile): orc_set_open_x switches the x ghost columns of the m-arrays from periodic
+ * images to the reference's inflow / outflow values -- the arrays here carry the reference's ghosts, so only the routines that
+ * WRITE them change: closurebc (src/modboundary.f90:467-475), bcpup (:1257-1280), bcp (:1376-1394), the cosine transform in x of
+ * poisson (src/modpois.f90:113-121, 492-500, 689-697), tstep_integrate's u0(ie+1) (src/modtstep.f90:262-264), halos (no periodic
+ * refresh in x, src/modboundary.f90:95-100) and boundary's xmi_profile / xmo_convective (:688-717, 908-926).
+ * uprof, vprof: [nz+2] indexed by k (entry nz+1 = what the reference's uprof(ke+1) holds: zero).  uouttot is a variable of the
+ * run (the last `boundary`'s value is what bcpup reads): orc_set_open_x_uouttot / orc_open_x_uouttot; wlev[nz] (or NULL: keep the
+ * value) makes orc_boundary refresh it as the reference does, sum_k wlev(k-1) u0av(k) with the u0av handed to orc_boundary_open_x. */
+static int xo_on = 0;
+static const double *xo_uprof = NULL, *xo_vprof = NULL;
+static double xo_uouttot = 0.;
+void orc_set_open_x(int on, const double *uprof, const double *vprof) { xo_on = on; xo_uprof = uprof; xo_vprof = vprof; }
+void orc_set_open_x_uouttot(double u) { xo_uouttot = u; }
+double orc_open_x_uouttot(void) { return xo_uouttot; }
+
 void orc_closurebc(const orc_grid *g, double *ekm, double *ekh) {
   const int nx = g->nx, ny = g->ny, nz = g->nz;
   const double nm = g->numol, nh = g->numol * g->prandtlmoli;
@@ -377,6 +392,11 @@ void orc_closurebc(const orc_grid *g, double *ekm, double *ekh) {
     }
   for (int k = 0; k <= nz + 1; ++k)
     for (int j = 0; j <= ny + 1; ++j) {
+      if (xo_on) {      /* src/modboundary.f90:467-475 */
+        M(ekm, 0, j, k) = M(ekm, 1, j, k); M(ekm, nx + 1, j, k) = M(ekm, nx, j, k);
+        M(ekh, 0, j, k) = M(ekh, 1, j, k); M(ekh, nx + 1, j, k) = M(ekh, nx, j, k);
+        continue;
+      }
       M(ekm, 0, j, k) = M(ekm, nx, j, k); M(ekm, nx + 1, j, k) = M(ekm, 1, j, k);
       M(ekh, 0, j, k) = M(ekh, nx, j, k); M(ekh, nx + 1, j, k) = M(ekh, 1, j, k);
     }
@@ -575,6 +595,10 @@ void orc_tderive_lid(const orc_grid *g, const double *p, double *wp) {
 
 /* fillps src/modpois.f90:911-998 + bcpup src/modboundary.f90:1191-1341
  * (free-slip / no-slip top, or the open lid after orc_set_lid; periodic x and y on one rank) */
+/* bcpup's BCxm_profile branch reads u0 and overwrites up(ib), up(ie+1): orc_set_open_x_fields hands them to orc_fillps */
+static const double *xo_u0 = NULL;
+static double *xo_up = NULL;
+void orc_set_open_x_fields(const double *u0, double *up) { xo_u0 = u0; xo_up = up; }
 void orc_fillps(const orc_grid *g, double rk3coef, const double *up, const double *vp,
                 const double *wp, const double *um, const double *vm, const double *wm,
                 double *pup, double *pvp, double *pwp, double *p) {
@@ -591,6 +615,19 @@ void orc_fillps(const orc_grid *g, double rk3coef, const double *up, const doubl
   for (int j = 1; j <= ny; ++j)
     for (int i = 1; i <= nx; ++i) { M(pwp, i, j, 1) = 0.; M(pwp, i, j, nz + 1) = 0.; }
   if (g->bctopm == 3 && lid_pres0 && lid_wp) orc_bcpup_lid(g, rk3coef, lid_pres0, wm, lid_wp, pwp);
+  if (xo_on && xo_u0 && xo_up) {      /* src/modboundary.f90:1257-1280 */
+    for (int k = 1; k <= nz; ++k)
+      for (int j = 0; j <= ny + 1; ++j) { M(pup, 1, j, k) = xo_uprof[k] * rk3coefi; M(xo_up, 1, j, k) = 0.; }
+    for (int k = 2; k <= nz; ++k)
+      for (int j = 0; j <= ny + 1; ++j) {
+        M(pup, nx + 1, j, k) = M(um, nx + 1, j, k) * rk3coefi - (M(xo_u0, nx + 1, j, k) - M(xo_u0, nx, j, k)) * dxi * xo_uouttot;
+        M(xo_up, nx + 1, j, k) = M(pup, nx + 1, j, k) - M(um, nx + 1, j, k) * rk3coefi;
+      }
+    for (int j = 0; j <= ny + 1; ++j) {
+      M(pup, nx + 1, j, 1) = M(pup, nx, j, 1);
+      M(xo_up, nx + 1, j, 1) = M(pup, nx + 1, j, 1) - M(um, nx + 1, j, 1) * rk3coefi;
+    }
+  } else
   for (int k = 1; k <= nz; ++k)
     for (int j = 1; j <= ny; ++j) M(pup, nx + 1, j, k) = M(pup, 1, j, k);
   for (int k = 1; k <= nz; ++k)
@@ -627,6 +664,8 @@ void orc_poisson_solve(const orc_grid *g, double *p) {
     xrt[i] = xrt[i - 1];
   }
   xrt[1] = 0.; xrt[nx] = -4. * dxi * dxi;
+  if (xo_on)      /* Neumann - Neumann, src/modpois.f90:113-117 */
+    for (int i = 1; i <= nx; ++i) { double s = sin((double)(i - 1) * M_PI * (1. / (2. * nx))); xrt[i] = -4. * dxi * dxi * (s * s); }
   fac = 1. / (2. * ny);
   for (int j = 3; j <= ny; j += 2) {
     double s = sin((double)(j - 1) * M_PI * fac);
@@ -664,6 +703,15 @@ void orc_poisson_solve(const orc_grid *g, double *p) {
   double *line = (double *)malloc(sizeof(double) * (3 * (size_t)nmax + 8));
   double *spec = line + nmax;
   fac = 1. / sqrt(nx * 1.);
+  if (xo_on) {      /* REDFT10, src/modpois.f90:492-500 */
+    fac = 1. / sqrt(2. * nx);
+    for (int k = 1; k <= nz; ++k)
+      for (int j = 1; j <= ny; ++j) {
+        for (int i = 1; i <= nx; ++i) line[i - 1] = W(w, i, j, k);
+        fft_ref_redft10(nx, line, spec);
+        for (int i = 1; i <= nx; ++i) W(w, i, j, k) = spec[i - 1] * fac;
+      }
+  } else
   for (int k = 1; k <= nz; ++k)
     for (int j = 1; j <= ny; ++j) {
       for (int i = 1; i <= nx; ++i) line[i - 1] = W(w, i, j, k);
@@ -746,6 +794,15 @@ void orc_poisson_solve(const orc_grid *g, double *p) {
     }
   /* backward x : :669-679 */
   fac = 1. / sqrt(nx * 1.);
+  if (xo_on) {      /* REDFT01, src/modpois.f90:689-697 */
+    fac = 1. / sqrt(2. * nx);
+    for (int k = 1; k <= nz; ++k)
+      for (int j = 1; j <= ny; ++j) {
+        for (int i = 1; i <= nx; ++i) spec[i - 1] = W(w, i, j, k);
+        fft_ref_redft01(nx, spec, line);
+        for (int i = 1; i <= nx; ++i) W(w, i, j, k) = line[i - 1] * fac;
+      }
+  } else
   for (int k = 1; k <= nz; ++k)
     for (int j = 1; j <= ny; ++j) {
       spec[0] = W(w, 1, j, k); spec[1] = 0.;
@@ -767,6 +824,13 @@ void orc_poisson_solve(const orc_grid *g, double *p) {
 void orc_tderive(const orc_grid *g, double *p, double *up, double *vp, double *wp, double *pres0) {
   const int nx = g->nx, ny = g->ny, nz = g->nz;
   const double dxi = 1. / g->dx, dyi = 1. / g->dy;
+  if (xo_on) {      /* bcp, src/modboundary.f90:1376-1394 (p and pres0; j = jb-1 .. je+1 of the rows as they are at this point) */
+    for (int k = 1; k <= nz; ++k)
+      for (int j = 0; j <= ny + 1; ++j) {
+        M(p, 0, j, k) = M(p, 1, j, k); M(pres0, 0, j, k) = M(pres0, 1, j, k);
+        M(p, nx + 1, j, k) = M(p, nx, j, k); M(pres0, nx + 1, j, k) = M(pres0, nx, j, k);
+      }
+  } else
   for (int j = 1; j <= ny; ++j)
     for (int k = 1; k <= nz; ++k) { M(p, 0, j, k) = M(p, nx, j, k); M(p, nx + 1, j, k) = M(p, 1, j, k); }
   for (int i = 1; i <= nx; ++i)
@@ -806,6 +870,9 @@ void orc_tstep_integrate(const orc_grid *g, int rk3step, double dt, double *u0, 
           C(p0, i, j, k) = C(pm, i, j, k) + rk3coef * C(pp, i, j, k);
         }
       }
+  if (xo_on)                                                      /* src/modtstep.f90:262-264 */
+    for (int k = 1; k <= g->nz; ++k)
+      for (int j = 1; j <= g->ny; ++j) M(u0, g->nx + 1, j, k) = M(um, g->nx + 1, j, k) + rk3coef * M(up, g->nx + 1, j, k);
   if (g->bctopm == 3)                                             /* src/modtstep.f90:270-286 */
     for (int j = 1; j <= g->ny; ++j)
       for (int i = 1; i <= g->nx; ++i) M(w0, i, j, g->nz + 1) = M(wm, i, j, g->nz + 1) + rk3coef * M(wp, i, j, g->nz + 1);
@@ -826,6 +893,7 @@ void orc_tstep_integrate(const orc_grid *g, int rk3step, double dt, double *u0, 
 /* xm_periodic then ym_periodic: src/modboundary.f90:508-539, 596-627 (over ALL j / ALL i) */
 void orc_halos_m(const orc_grid *g, double *a) {
   const int nx = g->nx, ny = g->ny, nz = g->nz;
+  if (!xo_on)      /* (BCxm = 2: no periodic refresh in x, src/modboundary.f90:95-100) */
   for (int k = 0; k <= nz + 1; ++k)
     for (int j = 0; j <= ny + 1; ++j) { M(a, 0, j, k) = M(a, nx, j, k); M(a, nx + 1, j, k) = M(a, 1, j, k); }
   for (int k = 0; k <= nz + 1; ++k)
@@ -905,6 +973,53 @@ void orc_boundary(const orc_grid *g, double *u0, double *v0, double *w0, double 
           C(pm, i, j, nz + mm) = C(pm, i, j, nz) + 0.0;
         }
   }
+}
+
+/* BCxm = 2: `boundary`'s lateral part, src/modboundary.f90:250-262, 376 -- xmi_profile (:688-706) then xmo_convective (:908-919) with
+ * the substep's rk3coef (:914) and the outlet speed orc_set_open_x_uouttot / orc_set_open_x_outflow left */
+void orc_boundary_open_x(const orc_grid *g, double rk3coef, double *u0, double *v0, double *w0, double *um, double *vm, double *wm) {
+  const int nx = g->nx, ny = g->ny, nz = g->nz;
+  const double dxi = 1. / g->dx;
+  if (!xo_on) return;
+  for (int j = 0; j <= ny + 1; ++j)
+    for (int k = 1; k <= nz + 1; ++k) {
+      M(u0, 1, j, k) = xo_uprof[k];
+      M(um, 1, j, k) = xo_uprof[k];
+      M(u0, 0, j, k) = 2 * M(u0, 1, j, k) - M(u0, 2, j, k);
+      M(um, 0, j, k) = 2 * M(um, 1, j, k) - M(um, 2, j, k);
+      M(v0, 0, j, k) = 2 * xo_vprof[k] - M(v0, 1, j, k);
+      M(vm, 0, j, k) = 2 * xo_vprof[k] - M(vm, 1, j, k);
+      M(w0, 0, j, k) = -M(w0, 1, j, k);
+      M(wm, 0, j, k) = -M(wm, 1, j, k);
+    }
+  for (int k = 0; k <= nz + 1; ++k)
+    for (int j = 0; j <= ny + 1; ++j) {
+      M(v0, nx + 1, j, k) = M(v0, nx + 1, j, k) - (M(v0, nx + 1, j, k) - M(v0, nx, j, k)) * dxi * rk3coef * xo_uouttot;
+      M(w0, nx + 1, j, k) = M(w0, nx + 1, j, k) - (M(w0, nx + 1, j, k) - M(w0, nx, j, k)) * dxi * rk3coef * xo_uouttot;
+      M(vm, nx + 1, j, k) = M(vm, nx + 1, j, k) - (M(vm, nx + 1, j, k) - M(vm, nx, j, k)) * dxi * rk3coef * xo_uouttot;
+      M(wm, nx + 1, j, k) = M(wm, nx + 1, j, k) - (M(wm, nx + 1, j, k) - M(wm, nx, j, k)) * dxi * rk3coef * xo_uouttot;
+    }
+}
+/* uouttot without a prescribed volume flow (src/modboundary.f90:143-156): sum_k u0av(k) dzf(k) / (zh(ke+1) - zh(kb+1)), u0av = diagfld's
+ * slab average over the fluid u points (src/modthermodynamics.f90:271) of the state the substep starts from.  wlev[nz]: those weights
+ * (NULL: uouttot stays what orc_set_open_x_uouttot said); hold_first: the next refresh is skipped -- the first substep's `boundary` still
+ * reads the u0av the start-up formed before ITS `boundary` (src/modstartup.f90:1604, src/program.f90:118) */
+static const double *xo_wlev = NULL;
+static int xo_hold = 0;
+void orc_set_open_x_outflow(const double *wlev, double uouttot, int hold_first) { xo_wlev = wlev; xo_uouttot = uouttot; xo_hold = hold_first; }
+static double xo_outlet_speed(const orc_grid *g, const double *u0) {
+  const double *mask = ibm_ctx_mask(0);
+  double u = 0.;
+  for (int k = 1; k <= g->nz; ++k) {
+    double s = 0., c = 0.;
+    for (int j = 1; j <= g->ny; ++j)
+      for (int i = 1; i <= g->nx; ++i) {
+        const double w = mask ? (M(mask, i, j, k) > 0.5 ? 1. : 0.) : 1.;
+        s += M(u0, i, j, k) * w; c += w;
+      }
+    u = u + (c > 0. ? s / c : -999.) * xo_wlev[k - 1];
+  }
+  return u;
 }
 
 /* ====================================================================== floor wall function */
@@ -1867,6 +1982,8 @@ void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
   const size_t nc = csize(g);
   moist_ctx = (g->lmoist && s->thermo && s->ql0) ? s : NULL;
   const double rk3coef = dt / (4. - (double)rk3step);
+  double uouttot_next = xo_uouttot;      /* BCxm = 2: what this substep's `boundary` will convect the outlet with */
+  if (xo_on && xo_wlev) { if (xo_hold) xo_hold = 0; else uouttot_next = xo_outlet_speed(g, s->u0); }
   orc_advecu_2nd(g, s->u0, s->v0, s->w0, s->pres0, s->up);
   orc_advecv_2nd(g, s->u0, s->v0, s->w0, s->pres0, s->vp);
   orc_advecw_2nd(g, s->u0, s->v0, s->w0, s->pres0, s->wp);
@@ -1930,8 +2047,10 @@ void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
   if (s->svsrc)                                                                          /* scalsource, src/program.f90:181 */
     for (size_t q = 0; q < (size_t)g->nsv * nc; ++q) s->svp[q] = s->svp[q] + s->svsrc[q];
   orc_set_lid(g->bctopm == 3 ? s->pres0 : NULL, g->bctopm == 3 ? s->wp : NULL);
+  orc_set_open_x_fields(xo_on ? s->u0 : NULL, xo_on ? s->up : NULL);
   orc_fillps(g, rk3coef, s->up, s->vp, s->wp, s->um, s->vm, s->wm, s->pup, s->pvp, s->pwp, s->p);
   orc_set_lid(NULL, NULL);
+  orc_set_open_x_fields(NULL, NULL);
   orc_poisson_solve(g, s->p);
   orc_tderive(g, s->p, s->up, s->vp, s->wp, s->pres0);
   orc_tstep_integrate(g, rk3step, dt, s->u0, s->v0, s->w0, s->um, s->vm, s->wm, s->up, s->vp, s->wp,
@@ -1976,6 +2095,7 @@ void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
   orc_halos_m(g, s->um); orc_halos_m(g, s->vm); orc_halos_m(g, s->wm);
   for (int n = 0; n < g->nsv; ++n) { orc_halos_c(g, s->sv0 + n * nc); orc_halos_c(g, s->svm + n * nc); }
   orc_boundary(g, s->u0, s->v0, s->w0, s->um, s->vm, s->wm, s->sv0, s->svm);
+  if (xo_on) { xo_uouttot = uouttot_next; orc_boundary_open_x(g, rk3coef, s->u0, s->v0, s->w0, s->um, s->vm, s->wm); }
   if (g->nsv > 0 && scalar_top_active(g)) orc_scalar_tops(g, s->ekh, s->sv0, s->svm);      /* src/modboundary.f90:236-247 */
   if (g->ltempeq) { orc_thl_top(g, s->ekh, s->thlm); orc_thl_top(g, s->ekh, s->thl0); }     /* src/modboundary.f90:207-217 */
   if (g->ltempeq && g->iadv_thl == 7) orc_thl0c_from(g, s->thl0, s->thl0c);                 /* src/modtstep.f90:249 + halos + boundary */

@@ -3,7 +3,7 @@
  * Plain-C restatement of the reference's per-substep dynamical core
  * (uDALES: src/modadvection.f90, src/modsubgrid.f90, src/modpois.f90,
  * src/modtstep.f90 and the modboundary.f90 routines they call), single rank,
- * periodic x/y, used only by tests/, __graft_entry__.smoke() and bench.py's
+ * periodic x/y (+ the inflow / outflow branch in x, orc_set_open_x), used only by tests/, __graft_entry__.smoke() and bench.py's
  * cpu_baseline leg to CHECK the HIP library.  Every function cites the
  * reference lines it follows.  Pinned against per-routine and multi-substep
  * vectors produced by the reference's own unmodified Fortran (oracle/_ref,
@@ -210,6 +210,17 @@ void orc_buoyancy_moist(const orc_grid *g, const orc_state *s, double *wp);
 void orc_set_lid(const double *pres0, double *wp);
 void orc_bcpup_lid(const orc_grid *g, double rk3coef, const double *pres0, const double *wm, double *wp, double *pwp);
 void orc_tderive_lid(const orc_grid *g, const double *p, double *wp);
+/* inflow / outflow in x (&BC BCxm = 2; the reference opens the lid with it: g->bctopm = 3).  orc_set_open_x(1, uprof, vprof) -- [nz+2]
+ * by k, entry nz+1 zero like the reference's uprof(ke+1) -- switches closurebc, bcpup (inside orc_fillps; orc_substep hands it u0 and
+ * up), bcp (inside orc_tderive), the x transform of orc_poisson_solve (REDFT10 / REDFT01), u0(ie+1) in orc_tstep_integrate and
+ * orc_halos_m; orc_boundary_open_x is `boundary`'s xmi_profile + xmo_convective.  The outlet's speed uouttot is a variable of the run:
+ * _uouttot sets it; _outflow(wlev[nz], u, hold_first) makes orc_substep refresh it like the reference (udcore_oracle.c). */
+void orc_set_open_x(int on, const double *uprof, const double *vprof);
+void orc_set_open_x_uouttot(double uouttot);
+double orc_open_x_uouttot(void);
+void orc_set_open_x_fields(const double *u0, double *up);
+void orc_set_open_x_outflow(const double *wlev, double uouttot, int hold_first);
+void orc_boundary_open_x(const orc_grid *g, double rk3coef, double *u0, double *v0, double *w0, double *um, double *vm, double *wm);
 void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt);
 
 #ifdef __cplusplus

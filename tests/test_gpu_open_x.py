@@ -3,8 +3,8 @@ BCxm = 2 run through oracle/_ref/udales_ref (tests/golden/make_golden.py: k_xope
 ghost columns ib-1 and ie+1 -- which are state here (the inlet's mirrored values, the convective outlet's v, w and the
 prognostic u(ie+1)), so they are compared too.
 
-The oracle does not restate this branch (oracle/udcore_oracle.h: periodic x): the reference's vectors are the only check, as for
-the wall-function and scalar-outflow cases (tests/common.py WF_RUN_CASES).  Tolerances as in tests/test_gpu_parity.py.
+The oracle restates the branch too (oracle/udcore_oracle.c orc_set_open_x, pinned on these decks by tests/test_oracle_open_x.py) and
+checks the device on seeded fields at other sizes (test_against_oracle_seeded).  Tolerances as in tests/test_gpu_parity.py.
 """
 import numpy as np
 import pytest
@@ -220,6 +220,72 @@ def test_through_the_reference_program(residency, tmp_path):
         a, b = rs[k][1:nz + 1], fix[f"{last}.{k}"].data[1:nz + 1]
         assert relerr(nocorner(a), nocorner(b)) <= RUN_TOL, k
     assert np.abs(fix[f"{last}.v0"].data[1:nz + 1, 1:-1, -1] - fix[f"{last}.v0"].data[1:nz + 1, 1:-1, -2]).max() > 1e-4
+
+
+@pytest.mark.parametrize("shape,sgs,stretch,floor", [
+    ((20, 12, 10), 2, 1.00, False),      # 2 itot = 40: radix-5 lines in the doubled solve
+    ((64, 48, 40), 2, 1.03, True),       # Vreman, stretched z, the floor
+    ((32, 16, 24), 1, 1.05, True),       # Smagorinsky
+    ((8, 8, 6), 0, 1.00, False),         # the smallest row the library takes, DNS
+    ((126, 8, 6), 1, 1.10, False),       # itot + 2 = 128: the ghost columns end a full tile
+])
+def test_against_oracle_seeded(shape, sgs, stretch, floor):
+    """Six substeps against the CPU oracle's restatement of the branch (oracle/udcore_oracle.c orc_set_open_x; pinned on the reference by
+    tests/test_oracle_open_x.py) on seeded random fields with a sheared inflow, at sizes and line lengths the fixtures do not have;
+    x ghost columns compared."""
+    import ctypes as C
+    import oracle_lib as ol
+    from udcore.grid import Grid
+    from udcore.core import DynCore
+    nx, ny, nz = shape
+    dz = 0.5 * stretch ** np.arange(nz)
+    g = Grid.from_levels(nx, ny, nz, nx * 0.5, ny * 0.4, np.cumsum(dz) - 0.5 * dz)
+    uprof = np.ascontiguousarray(np.concatenate(([0.], 0.8 + 0.4 * np.arange(nz) / nz, [0.])))
+    vprof = np.ascontiguousarray(np.concatenate(([0.], 0.15 - 0.1 * np.arange(nz) / nz, [0.])))
+    wl = np.ascontiguousarray(g.dzf[1:nz + 1] / (g.zh[nz + 1] - g.zh[2]))
+    rng = np.random.default_rng(nx * 100 + nz)
+    st = {}
+    for k, prof in (("u0", uprof), ("v0", vprof), ("w0", 0. * uprof)):
+        a = np.zeros(g.mshape())
+        a[1:nz + 1] = prof[1:nz + 1, None, None] + 0.05 * rng.standard_normal((nz, ny + 2, nx + 2))      # (ghost columns: state)
+        a[:, 0, :] = a[:, -2, :]; a[:, -1, :] = a[:, 1, :]
+        st[k] = a
+    st["w0"][1] = 0.
+    st["u0"][nz + 1] = st["u0"][nz]; st["v0"][nz + 1] = st["v0"][nz]
+    for k, m in (("u0", "um"), ("v0", "vm"), ("w0", "wm")):
+        st[m] = st[k].copy()
+    st["pres0"] = np.zeros(g.mshape())
+    core = DynCore(g, sgs=sgs, bctopm=3, lbottom=floor, z0=0.03, open_x=(uprof, vprof))
+    o = ol.Oracle(nx, ny, nz, g.dx, g.dy, g.dzf, g.dzh, sgs=sgs, bctopm=3, csz=0.21658244510412, lbottom=floor, z0=0.03)
+    dp = np.zeros(nz + 2); dp[1:nz + 1] = -1e-3
+    dq = np.zeros(nz + 2); dq[1:nz + 1] = 2e-4
+    core.load_state(st)
+    core.set_forcing(dp[1:nz + 1], dq[1:nz + 1])
+    core.set_open_x_outflow(wl, 1.0, hold_first=True)
+    o.L.orc_set_open_x(1, ol.ptr(uprof), ol.ptr(vprof))
+    o.L.orc_set_open_x_outflow(ol.ptr(wl), C.c_double(1.0), 1)
+    try:
+        ost = {k: v.copy() for k, v in st.items()}
+        for k in ("up", "vp", "wp", "ekm", "ekh", "p", "pup", "pvp", "pwp"):
+            ost[k] = np.zeros(g.mshape())
+        ost["dpdxl"], ost["dpdyl"] = dp, dq
+        # both start with a `boundary` (the oracle's with the substep's rk3coef = 0: the inlet columns, no convection)
+        core.halos(); core.boundary()
+        o.call("orc_boundary", ost["u0"], ost["v0"], ost["w0"], ost["um"], ost["vm"], ost["wm"], None, None)
+        o.call("orc_boundary_open_x", 0., ost["u0"], ost["v0"], ost["w0"], ost["um"], ost["vm"], ost["wm"])
+        dt = 0.05
+        for isub in range(6):
+            core.substep(isub % 3 + 1, dt, with_forces=True)
+            o.substep(ost, isub % 3 + 1, dt)
+        for k in ("u0", "v0", "w0", "pres0", "um", "vm", "wm"):
+            assert relerr(nocorner(core.download(k)[1:-1]), nocorner(ost[k][1:-1])) <= RUN_TOL, k
+        ref = ost["w0"]
+        assert relerr(nocorner(core.download("w0"))[nz + 1], nocorner(ref)[nz + 1], np.abs(ref).max()) <= RUN_TOL
+        assert core.divergence()[0] < 1e-11
+    finally:
+        o.L.orc_set_open_x(0, None, None)
+        o.L.orc_set_open_x_outflow(None, C.c_double(0.), 0)
+    core.close()
 
 
 def test_full_size_properties_256():
