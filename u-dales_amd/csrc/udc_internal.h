@@ -275,6 +275,7 @@ struct udc_handle {
   int xg = 0;
   double *xo_prof = nullptr;          // uprof, vprof: [2][nz+2], indexed by the reference's k
   double *xo_east = nullptr;          // v0, w0, vm, wm at i = ie+1: [4][pz][py] (the convective outlet's own state)
+  bool xo_rhs_mirrored = false;       // the divergence kernel has written the right-hand side into the solver's doubled row itself
   bool xo_hold = false;               // the next refresh of uouttot is skipped (udc_set_open_x_outflow, hold_first)
   udc_handle *xpois = nullptr;        // the pressure solve's own periodic domain: the row and its mirror image, 2 itot wide
   bool poisson_only = false;          // (that handle: p and the solver's arrays only)

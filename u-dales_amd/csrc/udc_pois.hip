@@ -33,7 +33,7 @@ template <bool PUP>
 __global__ __launch_bounds__(256) void div_rhs_kernel(Geo g, TileGrid tg, Metrics m, double r,
     const double *__restrict__ up, const double *__restrict__ vp, const double *__restrict__ wp,
     const double *__restrict__ um, const double *__restrict__ vm, const double *__restrict__ wm,
-    double *__restrict__ p, int lid) {
+    double *__restrict__ p, int lid, double *__restrict__ p2, int sy2, long sz2) {
   int i, j, k;
   const bool inside_ = tile_decode(g, tg, i, j, k);
   if (!inside_) return;
@@ -52,7 +52,18 @@ __global__ __launch_bounds__(256) void div_rhs_kernel(Geo g, TileGrid tg, Metric
     pw_c = (k == 0) ? 0. : wp[c] + wm[c] * r;
     pw_p = closed_top ? 0. : wp[c + g.sz] + wm[c + g.sz] * r;
   }
-  p[c] = (pu_p - pu_c) * m.dxi + (pv_p - pv_c) * m.dyi + (pw_p - pw_c) * m.dzfi[k + 1];
+  const double v = (pu_p - pu_c) * m.dxi + (pv_p - pv_c) * m.dyi + (pw_p - pw_c) * m.dzfi[k + 1];
+  if (p2) {
+    // open x boundaries (udc_xopen.hip): the right-hand side goes straight to the solver's doubled row -- the interior columns and their
+    // mirror image; what the ghost columns' cells would hold is nobody's
+    const int n = g.nx - 2 * g.xg, ii = i - g.xg;
+    if (ii < 0 || ii >= n) return;
+    const long b = (long)sy2 * (j + HY) + sz2 * (long)(k + HZ);
+    p2[b + ii] = v;
+    p2[b + 2 * n - 1 - ii] = v;
+    return;
+  }
+  p[c] = v;
 }
 
 // ---- Thomas table: the pivots z(m,k) = 1/(b_k + e_m - a_k d_{k-1}) of solmpj (src/modpois.f90:1120-1139)
@@ -1315,16 +1326,21 @@ int k_divergence_rhs(udc_handle *h, double rk3coef, bool pup) {
   const Geo &g = h->g;
   dim3 b(64, 4, 1), gr = cell_grid(g, b);
   const int lid = h->p.bctopm == UDC_TOP_PRESSURE ? 1 : 0;
+  // open x boundaries: straight into the solver's doubled row (k_xo_poisson then skips its own copy)
+  double *p2 = (h->xg && h->xpois) ? h->xpois->fields[UDC_P] : nullptr;
+  const int sy2 = p2 ? h->xpois->g.sy : 0;
+  const long sz2 = p2 ? h->xpois->g.sz : 0;
   PROF(h, "div_rhs");
   if (pup)
     hipLaunchKernelGGL((div_rhs_kernel<true>), gr, b, 0, h->stream, g, tile_grid(g), h->m, 1. / rk3coef,
                        h->fields[UDC_UP], h->fields[UDC_VP], h->fields[UDC_WP], h->fields[UDC_UM],
-                       h->fields[UDC_VM], h->fields[UDC_WM], h->fields[UDC_P], lid);
+                       h->fields[UDC_VM], h->fields[UDC_WM], h->fields[UDC_P], lid, p2, sy2, sz2);
   else
     hipLaunchKernelGGL((div_rhs_kernel<false>), gr, b, 0, h->stream, g, tile_grid(g), h->m, 1. / rk3coef,
                        h->fields[UDC_UP], h->fields[UDC_VP], h->fields[UDC_WP], h->fields[UDC_UM],
-                       h->fields[UDC_VM], h->fields[UDC_WM], h->fields[UDC_P], lid);
+                       h->fields[UDC_VM], h->fields[UDC_WM], h->fields[UDC_P], lid, p2, sy2, sz2);
   HIP_OK(hipGetLastError());
+  h->xo_rhs_mirrored = p2 != nullptr;
   return 0;
 }
 

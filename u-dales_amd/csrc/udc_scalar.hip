@@ -97,14 +97,25 @@ __global__ void scalar_bcx_outlet_kernel(Geo g, double fac0, const double *__res
 // diagfld's slab averages over the fluid u points; S = level sums (solid points taken out), cnt = fluid counts or nullptr
 __global__ void scalar_bcx_uout_kernel(int nz, const double *__restrict__ S, const double *__restrict__ cnt, double ncell,
                                        const double *__restrict__ wlev, double *__restrict__ out) {
-  if (threadIdx.x || blockIdx.x) return;
+  // the terms in parallel (one wave stages them in LDS), the sum by one lane in the reference's order (a chain of nz dependent global
+  // loads cost 47 us at 256 levels: profiles/r06/open_x_kernel_stats_256.csv, first version)
+  __shared__ double term[1024];
+  if (blockIdx.x) return;
   double u = 0.;
-  for (int k = 0; k < nz; ++k) {      // (the reference's order: sum over k of u0av dzf, then the division)
-    double c = cnt ? cnt[k + 1] : ncell;
-    if (c == 0. && k == 0) c = cnt[nz];      // avexy_ibm's rule for a level without fluid cells (src/modmpi.f90:646-660)
-    u = u + (c > 0. ? S[k] / c : -999.) * wlev[k];
+  for (int k0 = 0; k0 < nz; k0 += 1024) {
+    const int n = min(1024, nz - k0);
+    for (int q = threadIdx.x; q < n; q += blockDim.x) {
+      const int k = k0 + q;
+      double c = cnt ? cnt[k + 1] : ncell;
+      if (c == 0. && k == 0) c = cnt[nz];      // avexy_ibm's rule for a level without fluid cells (src/modmpi.f90:646-660)
+      term[q] = (c > 0. ? S[k] / c : -999.) * wlev[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+      for (int q = 0; q < n; ++q) u = u + term[q];      // (the reference's order: sum over k of u0av dzf, then the division)
+    __syncthreads();
   }
-  out[0] = u;
+  if (threadIdx.x == 0) out[0] = u;
 }
 
 inline dim3 cell_grid(const Geo &g, dim3 b) {

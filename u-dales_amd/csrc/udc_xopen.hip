@@ -224,11 +224,12 @@ int k_xo_poisson(udc_handle *h) {
   const int n = g.nx - 2;
   const dim3 b(256), gr((unsigned)((n + 255) / 256), (unsigned)g.ny, (unsigned)g.nz);
   hp->bczp = h->bczp;
-  {
+  if (!h->xo_rhs_mirrored) {      // (a right-hand side that did not come from k_divergence_rhs)
     PROF(h, "xo_mirror");
     hipLaunchKernelGGL(xo_gather_kernel, gr, b, 0, h->stream, g, g2, (const double *)h->fields[UDC_P], hp->fields[UDC_P]);
     HIP_OK(hipGetLastError());
   }
+  h->xo_rhs_mirrored = false;
   {
     PROF(h, "poisson_2x");      // (the doubled row's transforms and tridiagonal solves, on this handle's stream)
     if (k_poisson_solve(hp)) return 1;
