@@ -506,6 +506,15 @@ int udc_set_boundary_rk3coef(udc_handle *h, double rk3coef);
 int udc_create_open_x(const udc_config *cfg, const double *uprof, const double *vprof, udc_handle **out);
 int udc_set_open_x_outflow(udc_handle *h, const double *wlev, double uouttot, int hold_first);
 int udc_set_open_x_profile(udc_handle *h, const double *uprof, const double *vprof);      /* the inflow profiles again */
+/* &BC BCxm = 3 (BCxm_driver): the inlet from the planes of a precursor run instead of the profile.  The reference's moddriver (host:
+ * reads the driver files, interpolates in time -- drivergen, src/moddriver.f90:174) stays what it is; after every drivergen the six
+ * planes it leaves in modinletdata go to the device: u0driver, umdriver, v0driver, vmdriver, w0driver, wmdriver, each
+ * (lb[0]:ub[0], lb[1]:ub[1]) in the reference's j, k (j fastest), covering jb-1 .. je+1, kb .. ke+1.  They are what the NEXT `boundary`
+ * applies (xmi_driver, src/modboundary.f90:720-749: u at ib and ib-1, v and w at ib-1); bcpup (:1282-1303: pup(ib) = u0driver / rk3coef,
+ * the outlet convective on every level) keeps reading the planes the LAST `boundary` applied, as the reference's does between two
+ * drivergen calls.  Everything else is the open-x handle's (udc_create_open_x; its profiles are then unused). */
+int udc_set_open_x_inlet(udc_handle *h, const double *u0driver, const double *umdriver, const double *v0driver, const double *vmdriver,
+                         const double *w0driver, const double *wmdriver, const int lb[2], const int ub[2]);
 
 /* checksim's diagnostics (src/modchecksim.f90:76-203) of the state on the device: out[0] = calccourant's number -- the maximum of the
  * SIGNED sum (um dxhi + vm dyi + wm dzhi) dtmn, :111-117 --, out[1] = calcdiffnr's (:142-149), out[2], out[3] = chkdiv's divmax and

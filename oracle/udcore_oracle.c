@@ -1676,6 +1676,7 @@ static double volflow_def(const orc_grid *g, double rk3coef, const double *tp, c
 void orc_masscorr(const orc_grid *g, int rk3step, double dt, double *up, const double *um, double *vp, const double *vm) {
   const double rk3coef = dt / (4. - (double)rk3step);
   const double rk3coefi = 1 / rk3coef;
+  if (xo_on) return;      /* every branch sits under `.not. linoutflow` (src/modforces.f90:352, 393, 424, 467) */
   if (g->luvolflowr) {
     flow_mask = ibm_ctx_mask(0);
     const double udef = volflow_def(g, rk3coef, up, um, g->uflowrate);

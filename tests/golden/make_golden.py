@@ -523,6 +523,8 @@ CASES.update({
     # the reference opens the lid itself, src/modstartup.f90:845-848), prof.inp's u = 1, v = 0.1
     "k_xopen_16x8x12": ("kernels", 90, 16, 8, 12, dict(sgs="vreman", floor=True, bctopm=3, randu=0.05, bc="BCxm = 2", oracle="nspin = 4"), 1.04),
     "run_xopen_16x8x12s": ("run", 91, 16, 8, 12, dict(sgs="smag", floor=True, bctopm=3, randu=0.05, bc="BCxm = 2", oracle="nsub = 9\ndump_at = 3, 9"), 1.06),
+    "run_xopen_volflow_16x8x12s": ("run", 99, 16, 8, 12, dict(sgs="vreman", floor=True, bctopm=3, randu=0.05, bc="BCxm = 2", physics="luvolflowr = .true.\nuflowrate = 1.05",
+                                                              oracle="nsub = 9\ndump_at = 3, 9"), 1.06),      # masscorr's volume flow; the outlet convects with ubulk
     "run_xopen_vr_24x8x10": ("run", 92, 24, 8, 10, dict(sgs="vreman", floor=True, bctopm=3, randu=0.05, bc="BCxm = 2", dx=0.4, oracle="nsub = 12\ndump_at = 6, 12"), 1.0),
     "k_ptop_12x8x6": ("kernels", 84, 12, 8, 6, dict(sgs="vreman", floor=True, bctopm=3, randu=0.05, oracle="nspin = 4"), 1.04),
     "run_ptop_16x8x12s": ("run", 85, 16, 8, 12, dict(sgs="smag", nsv=1, floor=True, bctopm=3, randu=0.05, oracle="nsub = 9\ndump_at = 3, 9"), 1.06),
@@ -699,7 +701,7 @@ THL_CASES = {"k_tke_moist_12x8x8": dict(dthl=0.25, qt=0.0118, dqt=-8e-5, tke=0.0
              "k_qt_12x8x6": dict(dthl=0.3, qt=0.008, dqt=-4e-4), "run_qt_16x8x12s": dict(dthl=0.25, qt=0.007, dqt=-2e-4),
              "k_lsf_12x8x24": dict(dthl=0.3, ug=1.05, wtop=0.02), "run_lsf_16x8x24s": dict(dthl=0.25, ug=0.95, wtop=-0.03), "k_tke_12x8x6": dict(tke=0.05), "k_tke_thl_12x8x6": dict(tke=0.08, dthl=0.3), "k_coriol_12x8x6": dict(ug=1.1), "run_profforc_16x16x8": dict(ug=1.3), "k_thl_12x8x6": dict(dthl=0.4, dthlrad=2e-3), "run_thl_16x8x12s": dict(dthl=0.25, dthlrad=-1e-3),
              "k_buoy_12x8x6": dict(dthl=0.3), "run_buoy_16x8x12s": dict(dthl=0.2),
-             "k_xopen_16x8x12": dict(v=0.1), "run_xopen_16x8x12s": dict(v=0.1), "run_xopen_vr_24x8x10": dict(u=0.8, v=-0.05), "run_xopen_ibm_16x12x10": dict(v=0.1), "run_xopen_ibmwf3_16x12x10": dict(u=0.9, v=0.15),
+             "k_xopen_16x8x12": dict(v=0.1), "run_xopen_16x8x12s": dict(v=0.1), "run_xopen_volflow_16x8x12s": dict(v=0.1), "run_xopen_vr_24x8x10": dict(u=0.8, v=-0.05), "run_xopen_ibm_16x12x10": dict(v=0.1), "run_xopen_ibmwf3_16x12x10": dict(u=0.9, v=0.15),
              "k_ibm_thl_16x12x10": dict(dthl=0.3), "run_ibm_thl_16x12x10": dict(dthl=0.25), "run_ptop_ibm_16x12x10": dict(dthl=0.25), "run_ibm_thlcons_16x12x10": dict(dthl=0.25),
              "run_ibm_qt_16x12x10": dict(dthl=0.25, qt=0.007, dqt=-2e-4),
              "run_stats_16x8x12s": dict(dthl=0.25), "run_stats_ibm_16x12x10": dict(dthl=0.25), "run_ytstats_ibm_16x12x10": dict(dthl=0.25),
@@ -931,6 +933,57 @@ def make_reference_test_cases():
     print(f"case_526: {len(files)} input files staged")
 
 
+# Inflow from a precursor run's planes (&BC BCxm = 3, idriver = 2; the class of the reference's examples/950 and tests/cases/525, whose
+# own driver files are not shipped): a periodic precursor deck (idriver = 1) writes u/v/w/tdriver_000.<nr> -- kept in the case directory as
+# data -- and the driven deck reads them.  Second case: obstacles with the neutral wall functions and a prescribed volume flow, as examples/950.
+DRIVER_CASES = {
+    # name: (iexpnr, precursor's iexpnr, nx, ny, nz, kwargs of the driven deck, stretch, prof kwargs)
+    "run_xdriver_16x8x12s": (96, 95, 16, 8, 12, dict(sgs="smag", floor=True, bctopm=3, randu=0.05, bc="BCxm = 3"), 1.06, dict(v=0.1)),
+    "run_xdriver_ibm_16x12x10": (98, 97, 16, 12, 10, dict(sgs="vreman", floor=True, bctopm=3, randu=0.05, bc="BCxm = 3", iwallmom=3,
+                                                            physics="luvolflowr = .true.\nuflowrate = 0.95"), 1.0, dict(u=0.9, v=0.15)),
+}
+IBM_BLOCKS["run_xdriver_ibm_16x12x10"] = IBM_BLOCKS["run_ibm_16x12x10"]
+WF_CASES["run_xdriver_ibm_16x12x10"] = 3
+
+
+def make_driver_cases(only):
+    nstore, nsub = 8, 9
+    for name, (iexp, ipre, nx, ny, nz, kw, stretch, prof) in DRIVER_CASES.items():
+        if only and name not in only:
+            continue
+        cdir = os.path.join(HERE, "cases", name)
+        os.makedirs(cdir, exist_ok=True)
+        zf = zlevels(nz, 0.5, stretch)
+        with tempfile.TemporaryDirectory() as tmp:
+            # the precursor: periodic channel on the same y-z grid, closed lid, one plane per time step from the start
+            pre = dict(sgs=kw["sgs"], floor=True, bctopm=1, randu=0.05,
+                       extra=f"&DRIVER\nidriver = 1\ntdriverstart = 0.\ndtdriver = 0.25\ndriverstore = {nstore}\niplane = {nx // 2 + 1}\n/",
+                       oracle=f"nsub = {3 * nstore + 3}")
+            write_case(tmp, ipre, deck(ipre, nx, ny, nz, **pre), zf, **prof)
+            subprocess.check_call([REF, f"namoptions.{ipre:03d}", "run", os.path.join(tmp, "pre.bin")], cwd=tmp, stdout=subprocess.DEVNULL)
+            for q in "uvwt":
+                shutil.copy(os.path.join(tmp, f"{q}driver_000.{ipre:03d}"), cdir)
+        ibm = IBM_BLOCKS.get(name)
+        dk = dict(kw, ibm=ibm, extra=f"&DRIVER\nidriver = 2\ndriverjobnr = {ipre}\ndriverstore = {nstore}\n/", oracle=f"nsub = {nsub}\ndump_at = 3, {nsub}")
+        write_case(cdir, iexp, deck(iexp, nx, ny, nz, **dk), zf, **prof)
+        if ibm:
+            write_ibm_files(cdir, ibm, nx, ny, nz)
+            write_facet_files(cdir, iexp, ibm, nx, ny, nz, 0.5, 0.5, 0.5, True, False)
+        with tempfile.TemporaryDirectory() as tmp:
+            for fn in os.listdir(cdir):
+                shutil.copy(os.path.join(cdir, fn), tmp)
+            out = os.path.join(tmp, "out.bin")
+            subprocess.check_call([REF, f"namoptions.{iexp:03d}", "run", out], cwd=tmp, stdout=subprocess.DEVNULL)
+            d = read_dump(out)
+        keep = {k: v for k, v in d.items() if k.count(".") == 0 or k.split(".")[1] in ("u0", "v0", "w0", "pres0", "um", "vm", "wm", "uouttot")}
+        tmpf = os.path.join(HERE, name + ".bin")
+        write_dump(tmpf, keep)
+        with open(tmpf, "rb") as f, gzip.GzipFile(tmpf + ".gz", "wb", mtime=0) as g:
+            g.write(f.read())
+        os.remove(tmpf)
+        print(f"{name}: {len(keep)} records, {os.path.getsize(tmpf + '.gz') / 1024:.0f} kB, case files {sorted(os.listdir(cdir))[:4]} ...")
+
+
 def main():
     if not os.path.exists(REF):
         sys.exit(f"{REF} missing: run `make -C oracle ref` in the build container first")
@@ -971,6 +1024,10 @@ def main():
             g.write(f.read())
         os.remove(tmpf)
         print(f"{name}: {len(keep)} records, {os.path.getsize(tmpf + '.gz') / 1024:.0f} kB")
+    if not only or any(n in DRIVER_CASES for n in only):
+        make_driver_cases(only)
+    if only and all(n in DRIVER_CASES for n in only):
+        return
     make_restart_cases()
     make_example_cases(only)
     if not only or "case_100" in only or "case_526" in only:

@@ -62,7 +62,8 @@ def run_full(name, iexp, tmp_path, exe=FULL, env=None, deck_text=None):
 
 
 # (+ the inflow / outflow decks of tests/test_gpu_open_x.py: fixtures the oracle does not restate are pinned on the program too)
-OPEN_X_CASES = {"run_xopen_16x8x12s": 91, "run_xopen_vr_24x8x10": 92, "run_xopen_ibm_16x12x10": 93, "run_xopen_ibmwf3_16x12x10": 94}
+OPEN_X_CASES = {"run_xopen_16x8x12s": 91, "run_xopen_vr_24x8x10": 92, "run_xopen_ibm_16x12x10": 93, "run_xopen_ibmwf3_16x12x10": 94,
+                "run_xopen_volflow_16x8x12s": 99, "run_xdriver_16x8x12s": 96, "run_xdriver_ibm_16x12x10": 98}
 
 
 @pytest.mark.parametrize("name,iexp", sorted({**RUN_CASES, **OPEN_X_CASES}.items()))
@@ -79,6 +80,11 @@ def test_fixture_equals_the_reference_executable(name, iexp, tmp_path):
         if key not in fix:
             continue
         a, b = fix[key].data, rs[k]
+        if name.startswith("run_xdriver"):
+            # (inflow from driver files: the program, stopped by `runtime` at the dump's time, skips the last drivergen -- "if (timee >
+            #  runtime + btime) return", src/moddriver.f90:216 -- which the fixture's driver, with its long runtime, makes: the inlet's two
+            #  columns ib-1, ib of the LAST `boundary` differ, nothing else has seen them yet)
+            a, b = a[:, :, 2:], b[:, :, 2:]
         assert np.array_equal(a[1:nz + 2], b[1:nz + 2]), key          # (the file holds kb : ke + kh, ghost columns and rows included)
         checked += 1
     for n in range(int(fix["meta"].data[12])):

@@ -228,7 +228,6 @@ extern "C" int udc_set_open_x_profile(udc_handle *h, const double *uprof, const 
   HIP_OK(hipStreamSynchronize(h->stream));
   HIP_OK(hipMemcpy(h->xo_prof, uprof, sizeof(double) * nk, hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(h->xo_prof + nk, vprof, sizeof(double) * nk, hipMemcpyHostToDevice));
-  h->boundary_fresh = false;
   return 0;
 }
 // the outlet's convection speed uouttot (src/modboundary.f90:141-160): a constant (a prescribed volume flow's ubulk), or -- wlev
@@ -951,7 +950,6 @@ static void masscorr_effective(udc_handle *h) {
 }
 
 extern "C" int udc_set_masscorr(udc_handle *h, int luvolflowr, double uflowrate, int lvvolflowr, double vflowrate) {
-  if (luvolflowr || lvvolflowr) NO_OPEN_X(h, "udc_set_masscorr");
   ENTRY_FLUSH(h);
   // the two requests for u are kept side by side; an outflow-rate correction (udc_set_masscorr_outflow) takes precedence while it
   // is on (src/modforces.f90:352,389), whatever order the two setters are called in and however often

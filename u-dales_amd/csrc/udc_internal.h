@@ -275,6 +275,11 @@ struct udc_handle {
   int xg = 0;
   double *xo_prof = nullptr;          // uprof, vprof: [2][nz+2], indexed by the reference's k
   double *xo_east = nullptr;          // v0, w0, vm, wm at i = ie+1: [4][pz][py] (the convective outlet's own state)
+  // BCxm = 3: the inlet from a precursor run's planes (udc_set_open_x_inlet) instead of the profile: u0, um, v0, vm, w0, wm at the inlet,
+  // [6][pz][py] each -- `now` is what the last `boundary` applied (bcpup reads it), `next` what the coming one will
+  int xo_driver = 0;
+  double *xo_inlet_now = nullptr, *xo_inlet_next = nullptr;
+  bool xo_inlet_fresh = false;
   bool xo_rhs_mirrored = false;       // the divergence kernel has written the right-hand side into the solver's doubled row itself
   bool xo_hold = false;               // the next refresh of uouttot is skipped (udc_set_open_x_outflow, hold_first)
   udc_handle *xpois = nullptr;        // the pressure solve's own periodic domain: the row and its mirror image, 2 itot wide

@@ -884,7 +884,7 @@ __global__ __launch_bounds__(256) void checksim_kernel(Geo g, TileGrid tg, Metri
 __global__ __launch_bounds__(256) void flowsum_kernel(Geo g, TileGrid tg, const double *__restrict__ wlev, const double *__restrict__ a,
                                                       const double *__restrict__ b, double *__restrict__ out, int only_i) {
   int i, j, k;
-  const bool inside_ = tile_decode(g, tg, i, j, k);
+  const bool inside_ = tile_decode(g, tg, i, j, k) && i >= g.xg && i < g.nx - g.xg;      // (open x boundaries: ib .. ie)
   double sa = 0., sb = 0.;
   if (inside_ && (only_i < 0 || i == only_i)) {
     const long c = g.idx(i, j, k);
@@ -1515,6 +1515,9 @@ static int ensure_partials(udc_handle *h, size_t nblocks) {
 // predicted flow rate and um is not read.  Sums are per-slab, then all-reduced (avexy_ibm's MPI_ALLREDUCE).
 int k_masscorr(udc_handle *h, double rk3coef, bool pup_mode, bool wrap_vp) {
   if (!h->luvolflowr && !h->lvvolflowr) return 0;
+  // inflow / outflow in x: every branch of the reference's masscorr sits under `.not. linoutflow` (src/modforces.f90:352, 393, 424, 467);
+  // a prescribed volume flow then only names the outlet's speed (uouttot = ubulk, src/modboundary.f90:158-160: udc_set_open_x_outflow)
+  if (h->xg) return 0;
   const Geo &g = h->g;
   // luoutflowr (h->luvolflowr == 2): the flow through the outlet plane i = ie over its fluid u points, per area of its fluid c cells
   // (uoutletarea, src/modforces.f90:499-522: sum of IIc(ie, j, k) dy dzf(k); all cells count when no c-grid lists were read)
@@ -1534,7 +1537,7 @@ int k_masscorr(udc_handle *h, double rk3coef, bool pup_mode, bool wrap_vp) {
   dim3 b(64, 4, 1), gr = cell_grid(g, b);
   if (ensure_partials(h, gr.x)) return 1;
   PROF(h, "masscorr");
-  const double vol = (double)g.nx * (double)h->cfg.jtot * h->zsize;     // IIus(k) = itot*jtot cells per level, zh(ke+1)
+  const double vol = (double)(g.nx - 2 * g.xg) * (double)h->cfg.jtot * h->zsize;     // IIus(k) = itot*jtot cells per level, zh(ke+1)
   double *S = h->red + 16;
   FlowShift fu{nullptr, S, 0., 0., 0.}, fv{nullptr, S + 2, 0., 0., 0.};
   const int mo = h->um_alias ? UDC_U0 : UDC_UM;

@@ -27,6 +27,8 @@
 // -4 dxi^2 sin^2(pi m / (2 itot))).  So the solve runs, unchanged, on a second handle that is 2 itot wide and holds nothing but p and
 // the solver's arrays: twice the transform work of a dedicated DCT (the solve is ~40 % of a substep), no second set of line kernels.
 #include "udc_internal.h"
+#include <algorithm>
+#include <vector>
 
 namespace {
 
@@ -48,8 +50,11 @@ __global__ void xo_ek_kernel(Geo g, double *__restrict__ ekm, double *__restrict
 }
 
 // bcpup, BCxm_profile.  PUP: the tendency array holds the predicted velocity pup = up + um / rk3coef
+// inlet: the profile's uprof(k), or (BCxm_driver, :1282-1303) the precursor plane u0driver(j, k) -- there the outlet is convective
+// at kb too
 template <bool PUP>
-__global__ void xo_bcpup_kernel(Geo g, double rk3coefi, double dxi, const double *__restrict__ prof, const double *__restrict__ uout,
+__global__ void xo_bcpup_kernel(Geo g, double rk3coefi, double dxi, const double *__restrict__ prof, const double *__restrict__ inlet,
+                                const double *__restrict__ uout,
                                 const double *__restrict__ u0, const double *__restrict__ um, double *__restrict__ up) {
   int jj, kk;
   if (!plane_decode(g, jj, kk)) return;
@@ -57,17 +62,18 @@ __global__ void xo_bcpup_kernel(Geo g, double rk3coefi, double dxi, const double
   if (j < -1 || j > g.ny || k < 0 || k >= g.nz) return;
   const long r = (long)g.sy * jj + g.sz * kk;
   const int e = g.nx - 1;
-  up[r + 1] = PUP ? prof[k + 1] * rk3coefi : 0.;
+  const double uin = inlet ? inlet[(long)kk * g.py + jj] : prof[k + 1];
+  up[r + 1] = PUP ? uin * rk3coefi : 0.;
   const double ume = um[r + e];
   double pe;
-  if (k > 0) pe = ume * rk3coefi - (u0[r + e] - u0[r + e - 1]) * dxi * uout[0];
+  if (k > 0 || inlet) pe = ume * rk3coefi - (u0[r + e] - u0[r + e - 1]) * dxi * uout[0];
   else pe = PUP ? up[r + e - 1] : up[r + e - 1] + um[r + e - 1] * rk3coefi;      // "Neumann at bottom": pup(ie+1, kb) = pup(ie, kb)
   up[r + e] = PUP ? pe : pe - ume * rk3coefi;
 }
 
 // xmi_profile, then xmo_convective on the outlet's planes; bcp's columns of pres0
-__global__ void xo_boundary_kernel(Geo g, const double *__restrict__ prof, double dxi, double rk3coef, const double *__restrict__ uout,
-                                   double *__restrict__ u0, double *__restrict__ v0, double *__restrict__ w0,
+__global__ void xo_boundary_kernel(Geo g, const double *__restrict__ prof, const double *__restrict__ inlet, double dxi, double rk3coef,
+                                   const double *__restrict__ uout, double *__restrict__ u0, double *__restrict__ v0, double *__restrict__ w0,
                                    double *__restrict__ um, double *__restrict__ vm, double *__restrict__ wm,
                                    double *__restrict__ pres0, double *__restrict__ east) {
   int jj, kk;
@@ -75,6 +81,17 @@ __global__ void xo_boundary_kernel(Geo g, const double *__restrict__ prof, doubl
   const int j = jj - HY, k = kk - HZ;
   const long r = (long)g.sy * jj + g.sz * kk;
   const int e = g.nx - 1;
+  const long P = (long)g.py * g.pz, q = (long)kk * g.py + jj;
+  if (inlet) {      // xmi_driver, src/modboundary.f90:720-749: u at ib and ib-1, v at ib-1 on kb .. ke; w at ib-1 on kb .. ke+1
+    if (j >= -1 && j <= g.ny && k >= 0 && k <= g.nz) {
+      if (k < g.nz) {
+        u0[r + 1] = inlet[q]; um[r + 1] = inlet[P + q];
+        u0[r] = inlet[q]; um[r] = inlet[P + q];
+        v0[r] = inlet[2 * P + q]; vm[r] = inlet[3 * P + q];
+      }
+      w0[r] = inlet[4 * P + q]; wm[r] = inlet[5 * P + q];
+    }
+  } else
   if (j >= -1 && j <= g.ny && k >= 0 && k <= g.nz) {      // j = jb-1 .. je+1, k = kb .. ke+1
     const double up = prof[k + 1], vp = prof[g.nz + 2 + k + 1];
     u0[r + 1] = up; um[r + 1] = up;
@@ -84,7 +101,6 @@ __global__ void xo_boundary_kernel(Geo g, const double *__restrict__ prof, doubl
   }
   if (j >= -1 && j <= g.ny && k >= 0 && k < g.nz) { pres0[r] = pres0[r + 1]; pres0[r + e] = pres0[r + e - 1]; }
   // the outlet: every row and plane the arrays hold
-  const long P = (long)g.py * g.pz, q = (long)kk * g.py + jj;
   double ev0 = east[q], ew0 = east[P + q], evm = east[2 * P + q], ewm = east[3 * P + q];
   const double uo = uout[0];
   ev0 = ev0 - (ev0 - v0[r + e - 1]) * dxi * rk3coef * uo;
@@ -154,9 +170,46 @@ int xo_init(udc_handle *h, const double *uprof, const double *vprof) {
 }
 
 void xo_destroy(udc_handle *h) {
+  if (h->xo_inlet_now) { hipFree(h->xo_inlet_now); h->xo_inlet_now = nullptr; }
+  if (h->xo_inlet_next) { hipFree(h->xo_inlet_next); h->xo_inlet_next = nullptr; }
   if (h->xo_prof) { hipFree(h->xo_prof); h->xo_prof = nullptr; }
   if (h->xo_east) { hipFree(h->xo_east); h->xo_east = nullptr; }
   if (h->xpois) { udc_destroy(h->xpois); h->xpois = nullptr; }
+}
+
+// BCxm = 3: the six inlet planes of the reference's drivergen (modinletdata u0driver, umdriver, v0driver, vmdriver, w0driver, wmdriver),
+// each (lb[0]:ub[0], lb[1]:ub[1]) in the reference's j, k, j fastest
+extern "C" int udc_set_open_x_inlet(udc_handle *h, const double *u0d, const double *umd, const double *v0d, const double *vmd,
+                                    const double *w0d, const double *wmd, const int lb[2], const int ub[2]) {
+  if (!h) { udc_set_error("null handle"); return 1; }
+  HIP_OK(hipSetDevice(h->device));
+  if (udc_flush_pending(h)) return 1;
+  if (!h->xg) { udc_set_error("udc_set_open_x_inlet: not a handle of udc_create_open_x"); return 1; }
+  const double *src[6] = {u0d, umd, v0d, vmd, w0d, wmd};
+  for (const double *s : src) if (!s) { udc_set_error("udc_set_open_x_inlet: six planes"); return 1; }
+  const Geo &g = h->g;
+  if (lb[0] > 0 || ub[0] < g.ny + 1 || lb[1] > 1 || ub[1] < g.nz + 1) {
+    udc_set_error("udc_set_open_x_inlet: the planes must cover j = jb-1 .. je+1, k = kb .. ke+1");
+    return 1;
+  }
+  const size_t np = (size_t)g.py * g.pz;
+  const bool first = !h->xo_inlet_next;
+  if (first) {
+    HIP_OK(hipMalloc(&h->xo_inlet_next, sizeof(double) * 6 * np));
+    HIP_OK(hipMalloc(&h->xo_inlet_now, sizeof(double) * 6 * np));
+  }
+  std::vector<double> st(6 * np, 0.);
+  const int nj = ub[0] - lb[0] + 1;
+  for (int f = 0; f < 6; ++f)
+    for (int k = std::max(lb[1], 1 - HZ); k <= std::min(ub[1], g.nz + HZ); ++k)
+      for (int j = std::max(lb[0], 1 - HY); j <= std::min(ub[0], g.ny + HY); ++j)
+        st[f * np + (size_t)(k - 1 + HZ) * g.py + (j - 1 + HY)] = src[f][(size_t)(k - lb[1]) * nj + (j - lb[0])];
+  HIP_OK(hipStreamSynchronize(h->stream));
+  HIP_OK(hipMemcpy(h->xo_inlet_next, st.data(), sizeof(double) * 6 * np, hipMemcpyHostToDevice));
+  if (first) HIP_OK(hipMemcpy(h->xo_inlet_now, st.data(), sizeof(double) * 6 * np, hipMemcpyHostToDevice));
+  h->xo_driver = 1;
+  h->xo_inlet_fresh = true;      // (takes effect with the next `boundary` that runs; it does not ask for one)
+  return 0;
 }
 
 int xo_capture_east(udc_handle *h, int field, const double *, const int lb[3], const int ub[3]) {
@@ -186,11 +239,12 @@ int k_xo_bcpup(udc_handle *h, double rk3coef, bool pup) {
   if (!h->xg) return 0;
   const Geo &g = h->g;
   PROF(h, "xo_ghosts");
+  const double *inlet = h->xo_driver ? h->xo_inlet_now : nullptr;      // (u0driver: the first of its six planes)
   if (pup)
-    hipLaunchKernelGGL(xo_bcpup_kernel<true>, plane_grid(g), dim3(64), 0, h->stream, g, 1. / rk3coef, h->m.dxi, (const double *)h->xo_prof,
+    hipLaunchKernelGGL(xo_bcpup_kernel<true>, plane_grid(g), dim3(64), 0, h->stream, g, 1. / rk3coef, h->m.dxi, (const double *)h->xo_prof, inlet,
                        (const double *)h->bcx_uout_dev, (const double *)h->fields[UDC_U0], (const double *)h->fields[UDC_UM], h->fields[UDC_UP]);
   else
-    hipLaunchKernelGGL(xo_bcpup_kernel<false>, plane_grid(g), dim3(64), 0, h->stream, g, 1. / rk3coef, h->m.dxi, (const double *)h->xo_prof,
+    hipLaunchKernelGGL(xo_bcpup_kernel<false>, plane_grid(g), dim3(64), 0, h->stream, g, 1. / rk3coef, h->m.dxi, (const double *)h->xo_prof, inlet,
                        (const double *)h->bcx_uout_dev, (const double *)h->fields[UDC_U0], (const double *)h->fields[UDC_UM], h->fields[UDC_UP]);
   HIP_OK(hipGetLastError());
   return 0;
@@ -200,7 +254,12 @@ int k_xo_boundary(udc_handle *h) {
   if (!h->xg) return 0;
   const Geo &g = h->g;
   PROF(h, "xo_ghosts");
-  hipLaunchKernelGGL(xo_boundary_kernel, plane_grid(g), dim3(64), 0, h->stream, g, (const double *)h->xo_prof, h->m.dxi, h->bcx_rk3coef,
+  if (h->xo_driver && h->xo_inlet_fresh) {      // the planes handed over since the last `boundary` are this one's (drivergen, src/modboundary.f90:262-265)
+    HIP_OK(hipMemcpyAsync(h->xo_inlet_now, h->xo_inlet_next, sizeof(double) * 6 * (size_t)g.py * g.pz, hipMemcpyDeviceToDevice, h->stream));
+    h->xo_inlet_fresh = false;
+  }
+  hipLaunchKernelGGL(xo_boundary_kernel, plane_grid(g), dim3(64), 0, h->stream, g, (const double *)h->xo_prof,
+                     (const double *)(h->xo_driver ? h->xo_inlet_now : nullptr), h->m.dxi, h->bcx_rk3coef,
                      (const double *)h->bcx_uout_dev, h->fields[UDC_U0], h->fields[UDC_V0], h->fields[UDC_W0],
                      h->fields[UDC_UM], h->fields[UDC_VM], h->fields[UDC_WM], h->fields[UDC_PRES0], h->xo_east);
   HIP_OK(hipGetLastError());

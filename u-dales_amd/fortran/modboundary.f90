@@ -13,6 +13,7 @@ module modboundary
   implicit none
   save
   private
+  public :: driver_inlet
   public :: initboundary, boundary, grwdamp, ksp, tqaver, halos, bcp, bcpup, closurebc, &
             xm_periodic, xT_periodic, xq_periodic, xs_periodic, ym_periodic, yT_periodic, yq_periodic, ys_periodic
   integer :: ksp = -1                 !< lowest level of the sponge layer (&DOMAIN ksp; -1 = default)
@@ -28,8 +29,8 @@ contains
     use modinletdata, only: irecy
     real :: zspb, zspt
     integer :: k
-    if ((BCxm /= 1 .and. BCxm /= 2) .or. BCym /= 1) then
-      write (0, *) 'ERROR: libudcore boundary: BCxm = 1 (periodic) or 2 (inflow profile, convective outflow), BCym = 1'
+    if (BCxm < 1 .or. BCxm > 3 .or. BCym /= 1) then
+      write (0, *) 'ERROR: libudcore boundary: BCxm = 1 (periodic), 2 (inflow profile) or 3 (inflow from driver files), BCym = 1'
       stop 1
     end if
     allocate (tsc(kb:ke + kh))
@@ -98,10 +99,28 @@ contains
     use udc_iface
     use modglobal, only: BCxm
     call udc_begin(.false.)
-    if (BCxm == 2 .and. .not. udc_in_loop) call open_x_startup
+    if ((BCxm == 2 .or. BCxm == 3) .and. .not. udc_in_loop) call open_x_startup
+    if (BCxm == 3) call driver_inlet
     call udc_check(udc_boundary(udc_h), 'udc_boundary')
     if (udc_mode() <= 1) call udc_pull_vel(.true.)
   end subroutine boundary
+
+  !> BCxm = 3 (src/modboundary.f90:260-266): where the reference's `boundary` calls drivergen -- RK stage 3 and the start-up -- the
+  !! reference's own moddriver interpolates the precursor's planes to the new time on the host, and the six planes go to the device,
+  !! which applies them with the next `boundary` (xmi_driver).  Device-resident runs: the fused substep contains that `boundary`, so
+  !! the drop-in tstep_integrate calls this first; the call from `boundary` that follows finds the same time and hands over the same planes.
+  subroutine driver_inlet
+    use udc_iface
+    use modglobal, only: rk3step, lchunkread, jb, je, jh, kb, ke, kh
+    use moddriver, only: drivergen, driverchunkread
+    use modinletdata, only: u0driver, umdriver, v0driver, vmdriver, w0driver, wmdriver
+    integer(c_int) :: lb(2), ub(2)
+    if (.not. (rk3step == 0 .or. rk3step == 3)) return
+    if (lchunkread) call driverchunkread
+    call drivergen
+    lb = (/jb - jh, kb - kh/); ub = (/je + jh, ke + kh/)
+    call udc_check(udc_set_open_x_inlet(udc_h, u0driver, umdriver, v0driver, vmdriver, w0driver, wmdriver, lb, ub), 'udc_set_open_x_inlet')
+  end subroutine driver_inlet
 
   !> BCxm = 2, the `boundary` of the start-up (src/program.f90:118): the outlet's speed uouttot from the slab averages diagfld has
   !! just formed (src/modboundary.f90:141-160; start-up order src/modstartup.f90:1604) -- the first substep's `boundary` still reads
@@ -109,16 +128,28 @@ contains
   !! library refreshes uouttot itself from the state every substep starts from.
   subroutine open_x_startup
     use udc_iface
-    use modglobal, only: ib, ie, jb, je, kb, ke, kh, ktot, dzf, zh, dt, rk3step
+    use iso_c_binding, only: c_loc, c_null_ptr
+    use modglobal, only: ib, ie, jb, je, kb, ke, kh, ktot, dzf, zh, dt, rk3step, luvolflowr, luoutflowr
     use modfields, only: uouttot, u0, u0av, IIu, IIus
+    use modinletdata, only: ubulk
     use modmpi, only: avexy_ibm
-    real(c_double) :: wl(ktot)
-    ! diagfld's own line (src/modthermodynamics.f90:271) on the host's start-up fields: the immersed boundary's masks are the host's
-    ! at this point (the device takes the point lists with the first ibmwallfun / ibmnorm)
-    call avexy_ibm(u0av(kb:ke + kh), u0(ib:ie, jb:je, kb:ke + kh), ib, ie, jb, je, kb, ke, kh, IIu(ib:ie, jb:je, kb:ke + kh), IIus(kb:ke + kh), .false.)
-    wl = dzf(kb:ke)/(zh(ke + 1) - zh(kb + 1))
-    uouttot = sum(u0av(kb:ke)*dzf(kb:ke))/(zh(ke + 1) - zh(kb + 1))
-    call udc_check(udc_set_open_x_outflow(udc_h, wl, real(uouttot, c_double), 1_c_int), 'udc_set_open_x_outflow')
+    real(c_double), target, save, allocatable :: wl(:)
+    if (luoutflowr) then
+      write (0, *) 'ERROR: libudcore boundary: luoutflowr with inflow / outflow in x is not on the device path'
+      stop 1
+    end if
+    if (luvolflowr) then      ! src/modboundary.f90:158-160: a prescribed volume flow convects the outlet with ubulk
+      uouttot = ubulk
+      call udc_check(udc_set_open_x_outflow(udc_h, c_null_ptr, real(uouttot, c_double), 0_c_int), 'udc_set_open_x_outflow')
+    else
+      ! diagfld's own line (src/modthermodynamics.f90:271) on the host's start-up fields: the immersed boundary's masks are the host's
+      ! at this point (the device takes the point lists with the first ibmwallfun / ibmnorm)
+      call avexy_ibm(u0av(kb:ke + kh), u0(ib:ie, jb:je, kb:ke + kh), ib, ie, jb, je, kb, ke, kh, IIu(ib:ie, jb:je, kb:ke + kh), IIus(kb:ke + kh), .false.)
+      if (.not. allocated(wl)) allocate (wl(ktot))
+      wl = dzf(kb:ke)/(zh(ke + 1) - zh(kb + 1))
+      uouttot = sum(u0av(kb:ke)*dzf(kb:ke))/(zh(ke + 1) - zh(kb + 1))
+      call udc_check(udc_set_open_x_outflow(udc_h, c_loc(wl), real(uouttot, c_double), 1_c_int), 'udc_set_open_x_outflow')
+    end if
     call udc_check(udc_set_boundary_rk3coef(udc_h, real(dt/(4. - real(rk3step)), c_double)), 'udc_set_boundary_rk3coef')
   end subroutine open_x_startup
 

@@ -29,7 +29,7 @@ contains
       write (0, *) 'Invalid choice for Poisson solver'     ! as src/modpois.f90:897-898
       stop 1
     end if
-    if ((BCxm /= 1 .and. BCxm /= 2) .or. BCym /= 1 .or. (BCzp /= 1 .and. BCzp /= 2)) then
+    if (BCxm < 1 .or. BCxm > 3 .or. BCym /= 1 .or. (BCzp /= 1 .and. BCzp /= 2)) then
       write (0, *) 'ERROR: libudcore poisson: BCxm 1 (periodic) or 2 (Neumann: cosine transform in x), periodic y; BCzp 1 (tridiagonal z) or 2 (cosine transform in z)'
       stop 1
     end if

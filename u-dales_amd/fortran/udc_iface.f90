@@ -513,9 +513,15 @@ module udc_iface
     integer(c_int) function udc_set_open_x_outflow(h, wlev, uouttot, hold_first) bind(C, name='udc_set_open_x_outflow')
       import :: c_int, c_ptr, c_double
       type(c_ptr), value :: h
-      real(c_double), intent(in) :: wlev(*)
+      type(c_ptr), value :: wlev      ! c_loc of [ktot] weights, or c_null_ptr: the constant uouttot
       real(c_double), value :: uouttot
       integer(c_int), value :: hold_first
+    end function
+    integer(c_int) function udc_set_open_x_inlet(h, u0d, umd, v0d, vmd, w0d, wmd, lb, ub) bind(C, name='udc_set_open_x_inlet')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(in) :: u0d(*), umd(*), v0d(*), vmd(*), w0d(*), wmd(*)
+      integer(c_int), intent(in) :: lb(2), ub(2)
     end function
     integer(c_int) function udc_set_boundary_rk3coef(h, rk3coef) bind(C, name='udc_set_boundary_rk3coef')
       import :: c_int, c_ptr, c_double
@@ -622,7 +628,8 @@ contains
     cfg%nsv = nsv
     cfg%lbottom = merge(1, 0, udc_floor_on)
     cfg%z0 = udc_floor_z0
-    if (BCxm == 2) then      ! inflow from prof.inp's profile, convective outflow: rows with the reference's ghost columns (udc_xopen.hip)
+    if (BCxm == 2 .or. BCxm == 3) then      ! inflow (prof.inp's profile, or a precursor run's planes: udc_set_open_x_inlet), convective
+      ! outflow: rows with the reference's ghost columns (udc_xopen.hip)
       call open_x_profiles(xo_u, xo_v)
       call udc_check(udc_create_open_x(cfg, xo_u, xo_v, udc_h), 'udc_create_open_x')
     else
@@ -715,7 +722,7 @@ contains
     integer :: n
     real(c_double), allocatable :: xo_u(:), xo_v(:)
     call udc_check(udc_set_forcing(udc_h, dpdxl(kb:ke), dpdyl(kb:ke), int(ktot, c_int)), 'udc_set_forcing')
-    if (BCxm == 2) then      ! (the handle may be older than prof.inp's profiles)
+    if (BCxm == 2 .or. BCxm == 3) then      ! (the handle may be older than prof.inp's profiles)
       call open_x_profiles(xo_u, xo_v)
       call udc_check(udc_set_open_x_profile(udc_h, xo_u, xo_v), 'udc_set_open_x_profile')
     end if

@@ -260,6 +260,7 @@ class DynCore:
     def set_open_x_outflow(self, wlev=None, uouttot=0., hold_first=False):
         """The outlet's speed under BCxm = 2: a constant, or (wlev [ktot]) the weighted mean of u's slab averages."""
         w = None if wlev is None else np.ascontiguousarray(wlev, dtype=np.float64)
+        self._open_x_avg, self._uouttot = w is not None, float(uouttot)
         L._check(self.lib.udc_set_open_x_outflow(self.h, None if w is None else w.ctypes.data_as(L.DP), C.c_double(uouttot),
                                                      1 if hold_first else 0),
                  "udc_set_open_x_outflow")
@@ -353,9 +354,10 @@ class DynCore:
             # its uouttot from it (and so does the first substep's), and convects the outlet once with rk3step = 0 and dt = dtmax / 100
             # (src/modstartup.f90:1099, src/modboundary.f90:141-160, 914)
             g = self.g
-            wl = g.dzf[1:g.nz + 1] / (g.zh[g.nz + 1] - g.zh[2])
-            u0av = self.slab_average("u0")
-            self.set_open_x_outflow(wl, float(np.sum(np.asarray(u0av)[1:g.nz + 1] * wl)), hold_first=True)
+            if getattr(self, "_open_x_avg", True):      # (a prescribed volume flow convects the outlet with ubulk instead: from_deck)
+                wl = g.dzf[1:g.nz + 1] / (g.zh[g.nz + 1] - g.zh[2])
+                u0av = self.slab_average("u0")
+                self.set_open_x_outflow(wl, float(np.sum(np.asarray(u0av)[1:g.nz + 1] * wl)), hold_first=True)
             self.set_boundary_rk3coef(dtmax / 100. / 4.)
         self.boundary()
 
