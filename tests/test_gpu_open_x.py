@@ -417,6 +417,46 @@ def test_cli_run_writes_the_reference_state(tmp_path):
         assert relerr(nocorner(got[k][1:-1]), nocorner(ref[1:-1])) <= RUN_TOL, k
 
 
+@pytest.mark.parametrize("residency", [2, 0])
+def test_statistics_with_the_reference_statsdump(residency, tmp_path):
+    """Statistics of an inflow / outflow run (the class of examples/950: driver inflow, obstacles, wall functions, tdump + xytdump): the
+    device's own accumulators are not offered on such a handle, the program variant that links the reference's modstatsdump
+    (u-dales_amd/bin/udales_full_dropin_hoststats: it samples the host arrays, which the drop-ins refresh on exactly the sampling steps)
+    is -- every record it hands to NetCDF against the all-reference program's."""
+    import os
+    from common import BINDIR, GOLDEN
+    from refdump import read_ncrec
+    from test_full_reference import FULL, run_full
+    exe = os.path.join(BINDIR, "udales_full_dropin_hoststats")
+    if not (os.path.exists(exe) and os.path.exists(FULL)):
+        pytest.skip("oracle/_ref/udales_full or u-dales_amd/bin/udales_full_dropin_hoststats not built")
+    name, iexp = "run_xdriver_ibm_16x12x10", 98
+    out = {}
+    for tag, prog in (("ref", FULL), ("dev", exe)):
+        d = tmp_path / tag
+        d.mkdir()
+        txt = open(os.path.join(GOLDEN, "cases", name, f"namoptions.{iexp:03d}")).read()
+        txt = txt.replace("&SCALARS", "&OUTPUT\nltdump = .true.\nlxytdump = .true.\ntstatsdump = 0.5\ntsample = 0.25\n/\n&SCALARS")
+        assert "ltdump" in txt
+        run_full(name, iexp, d, exe=prog, env=dict(os.environ, UDC_RESIDENCY=str(residency)), deck_text=txt)
+        out[tag] = {fn: read_ncrec(str(d / fn)) for fn in sorted(os.listdir(d)) if fn.endswith(".nc") and "dump" in fn}
+    assert set(out["ref"]) == set(out["dev"]) and len(out["ref"]) >= 2, (sorted(out["ref"]), sorted(out["dev"]))
+    checked = 0
+    for fn, ref in out["ref"].items():
+        dev = out["dev"][fn]
+        assert list(ref) == list(dev), fn
+        for var, recs in ref.items():
+            assert len(recs) == len(dev[var]) >= 1, (fn, var)
+            for (s0, a), (s1, b) in zip(recs, dev[var]):
+                assert s0 == s1 and a.shape == b.shape, (fn, var)
+                hole = a < -900.
+                assert np.array_equal(hole, b < -900.), (fn, var)
+                sc = max(np.abs(a[~hole]).max() if (~hole).any() else 0., 1e-3 if var.startswith("p") else 1e-6)
+                assert np.abs(a - b)[~hole].max(initial=0.) <= 1e-8 * sc, (fn, var)
+                checked += 1
+    assert checked >= 30
+
+
 def test_what_open_x_does_not_offer_is_refused():
     from udcore import lib as L
     d, core = make_core("k_xopen_16x8x12", 90)

@@ -275,6 +275,8 @@ struct udc_handle {
   int xg = 0;
   double *xo_prof = nullptr;          // uprof, vprof: [2][nz+2], indexed by the reference's k
   double *xo_east = nullptr;          // v0, w0, vm, wm at i = ie+1: [4][pz][py] (the convective outlet's own state)
+  double *xo_west = nullptr;          // u0, v0, w0, um, vm, wm at i = ib-1 as the last `boundary` left them: [6][pz][py] (the integration
+                                      // runs over ib:ie in the reference; here its result in that column is put back)
   // BCxm = 3: the inlet from a precursor run's planes (udc_set_open_x_inlet) instead of the profile: u0, um, v0, vm, w0, wm at the inlet,
   // [6][pz][py] each -- `now` is what the last `boundary` applied (bcpup reads it), `next` what the coming one will
   int xo_driver = 0;

@@ -75,7 +75,7 @@ __global__ void xo_bcpup_kernel(Geo g, double rk3coefi, double dxi, const double
 __global__ void xo_boundary_kernel(Geo g, const double *__restrict__ prof, const double *__restrict__ inlet, double dxi, double rk3coef,
                                    const double *__restrict__ uout, double *__restrict__ u0, double *__restrict__ v0, double *__restrict__ w0,
                                    double *__restrict__ um, double *__restrict__ vm, double *__restrict__ wm,
-                                   double *__restrict__ pres0, double *__restrict__ east) {
+                                   double *__restrict__ pres0, double *__restrict__ east, double *__restrict__ west) {
   int jj, kk;
   if (!plane_decode(g, jj, kk)) return;
   const int j = jj - HY, k = kk - HZ;
@@ -109,28 +109,36 @@ __global__ void xo_boundary_kernel(Geo g, const double *__restrict__ prof, const
   ewm = ewm - (ewm - wm[r + e - 1]) * dxi * rk3coef * uo;
   east[q] = ev0; east[P + q] = ew0; east[2 * P + q] = evm; east[3 * P + q] = ewm;
   v0[r + e] = ev0; w0[r + e] = ew0; vm[r + e] = evm; wm[r + e] = ewm;
+  // the inlet's ghost column as it stands now: what the next integration must leave there
+  west[q] = u0[r]; west[P + q] = v0[r]; west[2 * P + q] = w0[r]; west[3 * P + q] = um[r]; west[4 * P + q] = vm[r]; west[5 * P + q] = wm[r];
 }
 
 // after the integration: v, w at ie+1 are not the integration's to touch (src/modtstep.f90:191-264 runs over ib:ie) -- the ghost
 // column takes the outlet's plane back; on RK stage 3 the m planes first take the 0 planes (vm = v0, wm = w0 are whole-array copies,
 // :322-324)
-__global__ void xo_restore_kernel(Geo g, int stage3, double *__restrict__ v0, double *__restrict__ w0, double *__restrict__ vm,
-                                  double *__restrict__ wm, double *__restrict__ east) {
+__global__ void xo_restore_kernel(Geo g, int stage3, double *__restrict__ u0, double *__restrict__ v0, double *__restrict__ w0,
+                                  double *__restrict__ um, double *__restrict__ vm, double *__restrict__ wm,
+                                  double *__restrict__ east, double *__restrict__ west) {
   int jj, kk;
   if (!plane_decode(g, jj, kk)) return;
-  const long r = (long)g.sy * jj + g.sz * kk + g.nx - 1;
+  const long r0 = (long)g.sy * jj + g.sz * kk, r = r0 + g.nx - 1;
   const long P = (long)g.py * g.pz, q = (long)kk * g.py + jj;
   const double ev0 = east[q], ew0 = east[P + q];
   double evm = east[2 * P + q], ewm = east[3 * P + q];
   if (stage3) { evm = ev0; ewm = ew0; east[2 * P + q] = evm; east[3 * P + q] = ewm; }
   v0[r] = ev0; w0[r] = ew0; vm[r] = evm; wm[r] = ewm;
+  // ... and the inlet's ghost column ib-1 (what host code sees between the integration and `boundary`: statsdump, fielddump, checksim)
+  const double a0 = west[q], a1 = west[P + q], a2 = west[2 * P + q];
+  double b0 = west[3 * P + q], b1 = west[4 * P + q], b2 = west[5 * P + q];
+  if (stage3) { b0 = a0; b1 = a1; b2 = a2; west[3 * P + q] = b0; west[4 * P + q] = b1; west[5 * P + q] = b2; }
+  u0[r0] = a0; v0[r0] = a1; w0[r0] = a2; um[r0] = b0; vm[r0] = b1; wm[r0] = b2;
 }
 
 // the ghost column of an uploaded v0 / w0 / vm / wm -> the outlet's plane
-__global__ void xo_capture_kernel(Geo g, const double *__restrict__ f, double *__restrict__ plane) {
+__global__ void xo_capture_kernel(Geo g, const double *__restrict__ f, double *__restrict__ plane, int col) {
   int jj, kk;
   if (!plane_decode(g, jj, kk)) return;
-  plane[(long)kk * g.py + jj] = f[(long)g.sy * jj + g.sz * kk + g.nx - 1];
+  plane[(long)kk * g.py + jj] = f[(long)g.sy * jj + g.sz * kk + col];
 }
 
 // the right-hand side's interior columns and their mirror image -> the doubled row; back: the first half, and bcp's ghost columns
@@ -162,6 +170,8 @@ int xo_init(udc_handle *h, const double *uprof, const double *vprof) {
   HIP_OK(hipMemcpy(h->xo_prof + nk, vprof, sizeof(double) * nk, hipMemcpyHostToDevice));
   HIP_OK(hipMalloc(&h->xo_east, sizeof(double) * 4 * np));
   HIP_OK(hipMemset(h->xo_east, 0, sizeof(double) * 4 * np));
+  HIP_OK(hipMalloc(&h->xo_west, sizeof(double) * 6 * np));
+  HIP_OK(hipMemset(h->xo_west, 0, sizeof(double) * 6 * np));
   if (!h->bcx_uout_dev) {
     HIP_OK(hipMalloc(&h->bcx_uout_dev, sizeof(double)));
     HIP_OK(hipMemset(h->bcx_uout_dev, 0, sizeof(double)));
@@ -174,6 +184,7 @@ void xo_destroy(udc_handle *h) {
   if (h->xo_inlet_next) { hipFree(h->xo_inlet_next); h->xo_inlet_next = nullptr; }
   if (h->xo_prof) { hipFree(h->xo_prof); h->xo_prof = nullptr; }
   if (h->xo_east) { hipFree(h->xo_east); h->xo_east = nullptr; }
+  if (h->xo_west) { hipFree(h->xo_west); h->xo_west = nullptr; }
   if (h->xpois) { udc_destroy(h->xpois); h->xpois = nullptr; }
 }
 
@@ -214,14 +225,17 @@ extern "C" int udc_set_open_x_inlet(udc_handle *h, const double *u0d, const doub
 
 int xo_capture_east(udc_handle *h, int field, const double *, const int lb[3], const int ub[3]) {
   if (!h->xg) return 0;
+  const Geo &g = h->g;
+  const int itot = g.nx - 2;
   int slot = -1;
   if (field == UDC_V0) slot = 0; else if (field == UDC_W0) slot = 1; else if (field == UDC_VM) slot = 2; else if (field == UDC_WM) slot = 3;
-  if (slot < 0) return 0;
-  const int itot = h->g.nx - 2;
-  if (lb[0] > itot + 1 || ub[0] < itot + 1) return 0;      // the host array does not carry the column: the plane stays as it is
-  const Geo &g = h->g;
-  hipLaunchKernelGGL(xo_capture_kernel, plane_grid(g), dim3(64), 0, h->stream, g, (const double *)h->fields[field],
-                     h->xo_east + (size_t)slot * g.py * g.pz);
+  if (slot >= 0 && lb[0] <= itot + 1 && ub[0] >= itot + 1)      // (else the host array does not carry the column: the plane stays as it is)
+    hipLaunchKernelGGL(xo_capture_kernel, plane_grid(g), dim3(64), 0, h->stream, g, (const double *)h->fields[field],
+                       h->xo_east + (size_t)slot * g.py * g.pz, g.nx - 1);
+  const int wslot = (field >= UDC_U0 && field <= UDC_WM) ? field - UDC_U0 : -1;      // u0 v0 w0 um vm wm
+  if (wslot >= 0 && lb[0] <= 0 && ub[0] >= 0)
+    hipLaunchKernelGGL(xo_capture_kernel, plane_grid(g), dim3(64), 0, h->stream, g, (const double *)h->fields[field],
+                       h->xo_west + (size_t)wslot * g.py * g.pz, 0);
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -261,7 +275,7 @@ int k_xo_boundary(udc_handle *h) {
   hipLaunchKernelGGL(xo_boundary_kernel, plane_grid(g), dim3(64), 0, h->stream, g, (const double *)h->xo_prof,
                      (const double *)(h->xo_driver ? h->xo_inlet_now : nullptr), h->m.dxi, h->bcx_rk3coef,
                      (const double *)h->bcx_uout_dev, h->fields[UDC_U0], h->fields[UDC_V0], h->fields[UDC_W0],
-                     h->fields[UDC_UM], h->fields[UDC_VM], h->fields[UDC_WM], h->fields[UDC_PRES0], h->xo_east);
+                     h->fields[UDC_UM], h->fields[UDC_VM], h->fields[UDC_WM], h->fields[UDC_PRES0], h->xo_east, h->xo_west);
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -270,8 +284,8 @@ int k_xo_after_integrate(udc_handle *h, int rk3step) {
   if (!h->xg) return 0;
   const Geo &g = h->g;
   PROF(h, "xo_ghosts");
-  hipLaunchKernelGGL(xo_restore_kernel, plane_grid(g), dim3(64), 0, h->stream, g, rk3step == 3 ? 1 : 0, h->fields[UDC_V0], h->fields[UDC_W0],
-                     h->fields[UDC_VM], h->fields[UDC_WM], h->xo_east);
+  hipLaunchKernelGGL(xo_restore_kernel, plane_grid(g), dim3(64), 0, h->stream, g, rk3step == 3 ? 1 : 0, h->fields[UDC_U0], h->fields[UDC_V0],
+                     h->fields[UDC_W0], h->fields[UDC_UM], h->fields[UDC_VM], h->fields[UDC_WM], h->xo_east, h->xo_west);
   HIP_OK(hipGetLastError());
   return 0;
 }
