@@ -889,6 +889,85 @@ def make_full_example(ex="999"):
     print(f"full_example_{ex}: {len(keep)} records, {os.path.getsize(tmpf + '.gz') / 1024:.0f} kB")
 
 
+# examples/950 of the reference: inflow from a precursor run's driver files (BCxm = 3), 256 x 128 x 128, obstacles with wall functions on
+# 6612 facets, a prescribed volume flow, the adaptive time step, tdump / xytdump / fielddump switched on.  The example ships without the
+# precursor's driver data (its driver_files/ holds the time stamps only), so a precursor deck derived from the example's own -- the same
+# y-z grid, profiles and flow rate, a periodic channel 32 cells long without obstacles, one plane every 0.5 s -- is run through the
+# reference first and its four records are kept with the case as data.  Deck changes of the driven run: one rank, three steps, and
+# driverstore = 4 (the records there are).  Golden: the clock after every step and the restart file (slab means, rms, every 8th point).
+EX950_FILES = ["namoptions.950", "prof.inp.950", "lscale.inp.950", "facets.inp.950", "factypes.inp.950"] + \
+              [f"{a}_{g}.txt" for a in ("facet_sections", "fluid_boundary", "solid") for g in "uvwc"]
+
+
+def ex950_decks(txt):
+    """(driven deck, precursor deck) from the example's own"""
+    import re
+    one = re.sub(r"nprocx\s*=\s*\d+", "nprocx       = 1", re.sub(r"nprocy\s*=\s*\d+", "nprocy       = 1", txt))
+    drv = re.sub(r"runtime\s*=\s*[0-9.]+", "runtime      = 1.5\ntrestart     = 1.4", one)
+    drv = re.sub(r"driverstore\s*=\s*\d+", "driverstore  = 4", drv)
+    pre = re.sub(r"iexpnr\s*=\s*950", "iexpnr       = 949", one)
+    pre = re.sub(r"libm\s*=\s*\.true\.", "libm         = .false.", pre)
+    pre = re.sub(r"itot\s*=\s*256", "itot         = 32", re.sub(r"xlen\s*=\s*256", "xlen         = 32", pre))
+    pre = re.sub(r"BCxm\s*=\s*3", "BCxm         = 1", re.sub(r"BCtopm\s*=\s*3", "BCtopm       = 1", pre))
+    pre = re.sub(r"dtmax\s*=\s*[0-9.]+", "dtmax        = 0.5", pre).replace("ladaptive    = .true.", "ladaptive    = .false.")
+    pre = re.sub(r"runtime\s*=\s*[0-9.]+", "runtime      = 2.2", pre)
+    for grp in ("WALLS", "OUTPUT", "INPS"):
+        pre = re.sub(r"&" + grp + r"\b.*?\n/\n", "", pre, flags=re.S)
+    pre = re.sub(r"&DRIVER\b.*?\n/\n", "&DRIVER\nidriver      = 1\ntdriverstart = 0.\ndtdriver     = 0.5\ndriverstore  = 4\niplane       = 16\n/\n", pre, flags=re.S)
+    assert "idriver      = 1" in pre and "&WALLS" not in pre and "driverstore  = 4" in drv
+    return drv, pre
+
+
+def make_example_950():
+    import numpy as np
+    from refdump import Field
+    sys.path.insert(0, os.path.join(ROOT, "u-dales_amd"))
+    from udcore import restart
+    src = "/root/reference/examples/950"
+    cdir = os.path.join(HERE, "cases", "example_950")
+    os.makedirs(cdir, exist_ok=True)
+    for fn in EX950_FILES:
+        with open(os.path.join(src, fn), "rb") as f, gzip.GzipFile(os.path.join(cdir, fn + ".gz"), "wb", mtime=0) as gz:
+            gz.write(f.read())
+    with open(os.path.join(src, "namoptions.950")) as f:
+        drv, pre = ex950_decks(f.read())
+    with tempfile.TemporaryDirectory() as tmp:
+        for fn in EX950_FILES:
+            shutil.copy(os.path.join(src, fn), tmp)
+        for a in ("prof", "lscale"):
+            shutil.copy(os.path.join(src, f"{a}.inp.950"), os.path.join(tmp, f"{a}.inp.949"))
+        with open(os.path.join(tmp, "namoptions.949"), "w") as f:
+            f.write(pre)
+        subprocess.check_call(["bash", "-c", f"ulimit -s unlimited; exec {FULL} namoptions.949"], cwd=tmp, stdout=subprocess.DEVNULL)
+        for q in "uvwt":      # the precursor's planes: data of the case
+            with open(os.path.join(tmp, f"{q}driver_000.949"), "rb") as f, gzip.GzipFile(os.path.join(cdir, f"{q}driver_000.949.gz"), "wb", mtime=0) as gz:
+                gz.write(f.read())
+        for fn in os.listdir(tmp):
+            if fn.startswith(("initd", "monitor")):
+                os.remove(os.path.join(tmp, fn))
+        with open(os.path.join(tmp, "namoptions.950"), "w") as f:
+            f.write(drv)
+        subprocess.check_call(["bash", "-c", f"ulimit -s unlimited; exec {FULL} namoptions.950"], cwd=tmp, stdout=subprocess.DEVNULL)
+        keep = {"monitor": Field(np.atleast_1d(np.loadtxt(os.path.join(tmp, "monitor000.txt"))), (1,))}
+        rst = [f for f in os.listdir(tmp) if f.startswith("initd") and f.endswith(".950")]
+        assert len(rst) == 1, rst
+        nx, ny, nz = 256, 128, 128
+        r = restart.read_initd(os.path.join(tmp, rst[0]), nx, ny, nz)
+        keep["rst.time"] = Field(np.array([r["timee"], r["dt"], float(rst[0][5:13])]), (1,))
+        for k in ("u0", "v0", "w0", "pres0"):
+            a = r[k][1:nz + 1, 1:ny + 1, :]      # (x ghost columns kept: the inlet's and the outlet's state)
+            keep[f"rst.{k}.mean"] = Field(a.mean(axis=(1, 2)), (1,))
+            keep[f"rst.{k}.rms"] = Field(np.sqrt((a ** 2).mean(axis=(1, 2))), (1,))
+            keep[f"rst.{k}.pts"] = Field(np.ascontiguousarray(a[::8, ::8, ::8]), (1, 1, 1))
+            keep[f"rst.{k}.out"] = Field(np.ascontiguousarray(a[:, :, -2:]), (1, 1, 1))      # the outlet: ie, ie+1
+    tmpf = os.path.join(HERE, "full_example_950.bin")
+    write_dump(tmpf, keep)
+    with open(tmpf, "rb") as f, gzip.GzipFile(tmpf + ".gz", "wb", mtime=0) as g:
+        g.write(f.read())
+    os.remove(tmpf)
+    print(f"full_example_950: {len(keep)} records, {os.path.getsize(tmpf + '.gz') / 1024:.0f} kB; case {sum(os.path.getsize(os.path.join(cdir, f)) for f in os.listdir(cdir)) / 1e6:.1f} MB")
+
+
 def split_scal(kw):
     """scal_a / scal_b in a case's `oracle` text describe scalar.inp (they were a group of the driver once): taken out of the deck."""
     import re
@@ -1024,6 +1103,9 @@ def main():
             g.write(f.read())
         os.remove(tmpf)
         print(f"{name}: {len(keep)} records, {os.path.getsize(tmpf + '.gz') / 1024:.0f} kB")
+    if only == {"full_example_950"}:
+        make_example_950()
+        return
     if not only or any(n in DRIVER_CASES for n in only):
         make_driver_cases(only)
     if only and all(n in DRIVER_CASES for n in only):
@@ -1035,6 +1117,8 @@ def main():
     for ex in FULL_EXAMPLES:
         if not only or f"full_example_{ex}" in only:
             make_full_example(ex)
+    if not only or "full_example_950" in only:      # (~6 minutes of the reference's program)
+        make_example_950()
 
 
 if __name__ == "__main__":

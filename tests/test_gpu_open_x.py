@@ -457,6 +457,50 @@ def test_statistics_with_the_reference_statsdump(residency, tmp_path):
     assert checked >= 30
 
 
+def test_example_950_through_the_reference_program(tmp_path):
+    """examples/950 of the reference -- inflow from a precursor run's driver files (BCxm = 3), 256 x 128 x 128, 6612 facets with wall
+    functions, a prescribed volume flow, the adaptive time step, tdump / xytdump / fielddump switched on -- as a user runs it, under the
+    untouched program.f90 with the drop-in modules and the reference's own statsdump (udales_full_dropin_hoststats), device resident.
+    The example ships without its precursor's planes: tests/golden/make_golden.py (make_example_950) derives a precursor deck from the
+    example's own, runs it through the reference and keeps the four records with the case.  Deck changes: one rank, three steps,
+    driverstore = 4.  Golden: the same through the all-reference executable -- the clock after each step, the restart file (slab means,
+    rms, every 8th point, the two outlet columns)."""
+    import gzip, os, subprocess, sys
+    from common import BINDIR, GOLDEN
+    from udcore import restart
+    sys.path.insert(0, GOLDEN)
+    from make_golden import ex950_decks
+    exe = os.path.join(BINDIR, "udales_full_dropin_hoststats")
+    if not os.path.exists(exe):
+        pytest.skip("u-dales_amd/bin/udales_full_dropin_hoststats not built")
+    fix = load_fixture("full_example_950")
+    cdir = os.path.join(GOLDEN, "cases", "example_950")
+    for fn in os.listdir(cdir):
+        with gzip.open(os.path.join(cdir, fn), "rb") as f, open(tmp_path / fn[:-3], "wb") as o:
+            o.write(f.read())
+    deck = tmp_path / "namoptions.950"
+    deck.write_text(ex950_decks(deck.read_text())[0])
+    r = subprocess.run(f"ulimit -s unlimited; exec {exe} namoptions.950", shell=True, cwd=tmp_path, capture_output=True, text=True,
+                       timeout=1500, executable="/bin/bash", env=dict(os.environ, UDC_RESIDENCY="2"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    mon = np.atleast_1d(np.loadtxt(tmp_path / "monitor000.txt"))
+    ref = fix["monitor"].data
+    assert len(mon) == len(ref) == 3
+    np.testing.assert_allclose(mon, ref, rtol=2e-6)            # (the monitor file holds six digits)
+    rst = [f for f in os.listdir(tmp_path) if f.startswith("initd") and f.endswith(".950")]
+    assert len(rst) == 1 and float(rst[0][5:13]) == fix["rst.time"].data[2]
+    nx, ny, nz = 256, 128, 128
+    rs = restart.read_initd(str(tmp_path / rst[0]), nx, ny, nz)
+    np.testing.assert_allclose((rs["timee"], rs["dt"]), fix["rst.time"].data[:2], rtol=1e-9)      # the adaptive step's history
+    for k in ("u0", "v0", "w0", "pres0"):
+        a = rs[k][1:nz + 1, 1:ny + 1, :]
+        sc = np.abs(fix[f"rst.{k}.pts"].data).max()
+        assert np.abs(a[::8, ::8, ::8] - fix[f"rst.{k}.pts"].data).max() <= 1e-8 * sc, k
+        assert np.abs(a[:, :, -2:] - fix[f"rst.{k}.out"].data).max() <= 1e-8 * sc, k
+        assert np.abs(a.mean(axis=(1, 2)) - fix[f"rst.{k}.mean"].data).max() <= 1e-9 * sc, k
+        assert np.abs(np.sqrt((a ** 2).mean(axis=(1, 2))) - fix[f"rst.{k}.rms"].data).max() <= 1e-9 * sc, k
+
+
 def test_what_open_x_does_not_offer_is_refused():
     from udcore import lib as L
     d, core = make_core("k_xopen_16x8x12", 90)
