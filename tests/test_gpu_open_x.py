@@ -457,6 +457,41 @@ def test_statistics_with_the_reference_statsdump(residency, tmp_path):
     assert checked >= 30
 
 
+def test_warm_start_applies_the_start_up_boundary(tmp_path):
+    """A warm start of an inflow / outflow run (udcore.restart.load_restart): the reference's start-up runs `boundary` on the fields of the
+    restart file too (src/program.f90:118) -- the outlet's v, w take one more convective step with rk3step = 0 and the file's dt, at the speed
+    diagfld's averages of the file's u give (src/modboundary.f90:141-160, 914), the inlet's ghost column is re-derived from the profile.
+    The same expressions in numpy on the file's arrays."""
+    from udcore import cold_start, restart as R
+    name, iexp = "run_xopen_16x8x12s", 91
+    d, core = make_core(name, iexp)
+    g = core.g
+    dt = float(d.get("RUN", "dtmax"))
+    core.load_state(cold_start(g, d, nsv=0, pre_boundary=True))
+    core.halos(); core.start_up(dtmax=dt)
+    for isub in range(1, 4):
+        core.substep(isub, dt)
+    R.save_restart(core, str(tmp_path), iexp, 1, dt, dt)
+    core.close()
+    f = R.read_initd(str(tmp_path / R.restart_name(1, 0, iexp)), g.nx, g.ny, g.nz)
+    d2, warm = make_core(name, iexp)
+    R.load_restart(warm, str(tmp_path), iexp, 1)
+    wl = wlev(g)
+    uout = float(np.sum(f["u0"][1:g.nz + 1, 1:-1, 1:-1].mean(axis=(1, 2)) * wl))
+    for k in ("v0", "w0"):
+        a = f[k]
+        want = a[:, :, -1] - (a[:, :, -1] - a[:, :, -2]) / g.dx * (f["dt"] / 4.) * uout
+        got = warm.download(k)
+        lev = slice(1, g.nz + 1)
+        assert np.abs(got[lev, 1:-1, -1] - want[lev, 1:-1]).max() <= 1e-13, k
+        assert np.abs(want[lev, 1:-1] - a[lev, 1:-1, -1]).max() > 1e-6      # (the step moved the outlet)
+        assert np.array_equal(got[lev, 1:-1, 1:-1], a[lev, 1:-1, 1:-1])
+    u = warm.download("u0")
+    prof = np.asarray(d.u, dtype=float)[:g.nz]
+    assert np.array_equal(u[1:g.nz + 1, 1:-1, 1], np.broadcast_to(prof[:, None], (g.nz, g.ny)))
+    warm.close()
+
+
 def test_example_950_through_the_reference_program(tmp_path):
     """examples/950 of the reference -- inflow from a precursor run's driver files (BCxm = 3), 256 x 128 x 128, 6612 facets with wall
     functions, a prescribed volume flow, the adaptive time step, tdump / xytdump / fielddump switched on -- as a user runs it, under the

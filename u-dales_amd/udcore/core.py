@@ -350,16 +350,19 @@ class DynCore:
         if before_boundary is not None:
             before_boundary()
         if self.open_x and dtmax is not None:
-            # BCxm = 2, cold start: diagfld has just formed u0av from the fields as readinitfiles left them; the start-up's `boundary` takes
-            # its uouttot from it (and so does the first substep's), and convects the outlet once with rk3step = 0 and dt = dtmax / 100
-            # (src/modstartup.f90:1099, src/modboundary.f90:141-160, 914)
-            g = self.g
-            if getattr(self, "_open_x_avg", True):      # (a prescribed volume flow convects the outlet with ubulk instead: from_deck)
-                wl = g.dzf[1:g.nz + 1] / (g.zh[g.nz + 1] - g.zh[2])
-                u0av = self.slab_average("u0")
-                self.set_open_x_outflow(wl, float(np.sum(np.asarray(u0av)[1:g.nz + 1] * wl)), hold_first=True)
-            self.set_boundary_rk3coef(dtmax / 100. / 4.)
+            self.open_x_startup(dtmax / 100.)      # (a cold start's dt, src/modstartup.f90:1099)
         self.boundary()
+
+    def open_x_startup(self, dt):
+        """BCxm = 2, ahead of the start-up's `boundary` (src/program.f90:118): diagfld has just formed u0av from the fields as
+        readinitfiles left them (cold start) or as the restart files hold them; that `boundary` takes its uouttot from it -- and so does
+        the first substep's -- and convects the outlet once with rk3step = 0 and the start-up's dt (src/modboundary.f90:141-160, 914)."""
+        g = self.g
+        if getattr(self, "_open_x_avg", True):      # (a prescribed volume flow convects the outlet with ubulk instead: from_deck)
+            wl = g.dzf[1:g.nz + 1] / (g.zh[g.nz + 1] - g.zh[2])
+            u0av = self.slab_average("u0")
+            self.set_open_x_outflow(wl, float(np.sum(np.asarray(u0av)[1:g.nz + 1] * wl)), hold_first=True)
+        self.set_boundary_rk3coef(dt / 4.)
 
     def thermodynamics(self):
         """The reference's `thermodynamics` (src/program.f90:120 before the loop, :214 at the end of every substep)."""

@@ -219,6 +219,8 @@ def load_restart_global(core, directory, expnr, ntrun, rank=0, nranks=1, read_sc
             core.upload(L.scalar_field(L.SV0, n), c)
             core.upload(L.scalar_field(L.SVM, n), c)
     core.halos()
+    if getattr(core, "open_x", False):      # inflow / outflow in x: the start-up's `boundary` with the restart's dt (DynCore.open_x_startup)
+        core.open_x_startup(dt)
     core.boundary()
     return timee, dt
 
@@ -245,5 +247,7 @@ def load_restart(core, directory, expnr, ntrun, rank=0):
             core.upload(L.scalar_field(L.SV0, n), c)
             core.upload(L.scalar_field(L.SVM, n), c)
     core.halos()
+    if getattr(core, "open_x", False):
+        core.open_x_startup(d["dt"])
     core.boundary()
     return d["timee"], d["dt"]
