@@ -513,6 +513,12 @@ int udc_set_open_x_profile(udc_handle *h, const double *uprof, const double *vpr
  * applies (xmi_driver, src/modboundary.f90:720-749: u at ib and ib-1, v and w at ib-1); bcpup (:1282-1303: pup(ib) = u0driver / rk3coef,
  * the outlet convective on every level) keeps reading the planes the LAST `boundary` applied, as the reference's does between two
  * drivergen calls.  Everything else is the open-x handle's (udc_create_open_x; its profiles are then unused). */
+/* The temperature on such a handle (&BC BCxT = 2 with BCxm = 2 / 3; after udc_set_tempeq with the central scheme, iadv_thl = 2): the inflow
+ * profile thlprof [ktot+2] by the reference's k (entry ktot+1 as the reference's thlprof(ke+1): zero).  xTi_profile
+ * (src/modboundary.f90:766-793: thl(ib-1) = thlprof on kb .. ke+1, thl(ib) = thlprof on kb .. ke) and xTo_convective (:947-957) run with every
+ * `boundary`; thl0 / thlm at ie+1 are state like v and w there (udc_field_upload takes them from a host array that carries the column).
+ * Not with obstacles (the c-grid lists are refused on such a handle), moisture or the kappa scheme. */
+int udc_set_open_x_thl(udc_handle *h, const double *thlprof);
 int udc_set_open_x_inlet(udc_handle *h, const double *u0driver, const double *umdriver, const double *v0driver, const double *vmdriver,
                          const double *w0driver, const double *wmdriver, const int lb[2], const int ub[2]);
 

@@ -1000,6 +1000,23 @@ void orc_boundary_open_x(const orc_grid *g, double rk3coef, double *u0, double *
       M(wm, nx + 1, j, k) = M(wm, nx + 1, j, k) - (M(wm, nx + 1, j, k) - M(wm, nx, j, k)) * dxi * rk3coef * xo_uouttot;
     }
 }
+/* ... and the temperature's, BCxT = 2: xTi_profile (src/modboundary.f90:766-793), xTo_convective (:947-957); thlprof [nz+2] by k */
+static const double *xo_thlprof = NULL;
+void orc_set_open_x_thl(const double *thlprof) { xo_thlprof = thlprof; }
+void orc_boundary_open_x_thl(const orc_grid *g, double rk3coef, double *thl0, double *thlm) {
+  const int nx = g->nx, ny = g->ny, nz = g->nz;
+  const double dxi = 1. / g->dx;
+  if (!xo_on || !xo_thlprof) return;
+  for (int j = 0; j <= ny + 1; ++j)
+    for (int k = 1; k <= nz + 1; ++k) { M(thl0, 0, j, k) = xo_thlprof[k]; M(thlm, 0, j, k) = xo_thlprof[k]; }
+  for (int j = 0; j <= ny + 1; ++j)
+    for (int k = 1; k <= nz; ++k) { M(thl0, 1, j, k) = xo_thlprof[k]; M(thlm, 1, j, k) = xo_thlprof[k]; }
+  for (int k = 0; k <= nz + 1; ++k)
+    for (int j = 0; j <= ny + 1; ++j) {
+      M(thl0, nx + 1, j, k) = M(thl0, nx + 1, j, k) - (M(thl0, nx + 1, j, k) - M(thl0, nx, j, k)) * dxi * rk3coef * xo_uouttot;
+      M(thlm, nx + 1, j, k) = M(thlm, nx + 1, j, k) - (M(thlm, nx + 1, j, k) - M(thlm, nx, j, k)) * dxi * rk3coef * xo_uouttot;
+    }
+}
 /* uouttot without a prescribed volume flow (src/modboundary.f90:143-156): sum_k u0av(k) dzf(k) / (zh(ke+1) - zh(kb+1)), u0av = diagfld's
  * slab average over the fluid u points (src/modthermodynamics.f90:271) of the state the substep starts from.  wlev[nz]: those weights
  * (NULL: uouttot stays what orc_set_open_x_uouttot said); hold_first: the next refresh is skipped -- the first substep's `boundary` still
@@ -2099,6 +2116,7 @@ void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
   if (xo_on) { xo_uouttot = uouttot_next; orc_boundary_open_x(g, rk3coef, s->u0, s->v0, s->w0, s->um, s->vm, s->wm); }
   if (g->nsv > 0 && scalar_top_active(g)) orc_scalar_tops(g, s->ekh, s->sv0, s->svm);      /* src/modboundary.f90:236-247 */
   if (g->ltempeq) { orc_thl_top(g, s->ekh, s->thlm); orc_thl_top(g, s->ekh, s->thl0); }     /* src/modboundary.f90:207-217 */
+  if (g->ltempeq && xo_on) orc_boundary_open_x_thl(g, rk3coef, s->thl0, s->thlm);            /* :270-283, 377 */
   if (g->ltempeq && g->iadv_thl == 7) orc_thl0c_from(g, s->thl0, s->thl0c);                 /* src/modtstep.f90:249 + halos + boundary */
   if (g->lmoist) { orc_qt_top(g, s->ekh, s->qtm); orc_qt_top(g, s->ekh, s->qt0); }          /* src/modboundary.f90:222-231 */
   if (g->lmoist && s->thermo) orc_thermodynamics(g, s);                                     /* src/program.f90:214 */

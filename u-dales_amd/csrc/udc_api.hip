@@ -594,8 +594,12 @@ static int now_subgrid(udc_handle *h) {
 }
 
 extern "C" int udc_set_tempeq(udc_handle *h, int iadv_thl, int bctopt, double wttop, double thl_top, int bcbott, double wtsurf) {
-  NO_OPEN_X(h, "udc_set_tempeq");
   ENTRY_FLUSH(h);
+  if (h->xg && iadv_thl != 2) {
+    udc_set_error("udc_set_tempeq: with open x boundaries the temperature takes the central scheme (iadv_thl = 2; kappa reads two ghost columns)");
+    return 1;
+  }
+  if (h->xg && h->lmoist) { udc_set_error("udc_set_tempeq: no moisture with open x boundaries yet"); return 1; }
   if (h->cfg.nsv > 15) { udc_set_error("udc_set_tempeq: thl uses scalar slot 15, nsv must be <= 15"); return 1; }
   if (iadv_thl != 2 && iadv_thl != 7) { udc_set_error("udc_set_tempeq: iadv_thl must be 2 (cd2, advecc_2nd) or 7 (kappa, advecc_kappa)"); return 1; }
   if (bctopt != 1 && bctopt != 2) { udc_set_error("udc_set_tempeq: BCtopT must be 1 (flux) or 2 (value)"); return 1; }

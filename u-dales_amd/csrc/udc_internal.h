@@ -282,6 +282,9 @@ struct udc_handle {
   int xo_driver = 0;
   double *xo_inlet_now = nullptr, *xo_inlet_next = nullptr;
   bool xo_inlet_fresh = false;
+  // the temperature on such a handle (&BC BCxT = 2: xTi_profile, xTo_convective; udc_set_open_x_thl): the inflow profile [nz+2] by k,
+  // thl0 / thlm at ie+1 and at ib-1 as the last `boundary` left them ([2][pz][py] each)
+  double *xo_thl_prof = nullptr, *xo_thl_east = nullptr, *xo_thl_west = nullptr;
   bool xo_rhs_mirrored = false;       // the divergence kernel has written the right-hand side into the solver's doubled row itself
   bool xo_hold = false;               // the next refresh of uouttot is skipped (udc_set_open_x_outflow, hold_first)
   udc_handle *xpois = nullptr;        // the pressure solve's own periodic domain: the row and its mirror image, 2 itot wide

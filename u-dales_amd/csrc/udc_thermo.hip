@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void levelsum_kernel(Geo g, Metrics m, int gx,
   const int by = tile / gx, bx = tile - by * gx;
   const int i = bx * 64 + threadIdx.x, j = by * 4 + threadIdx.y;
   double v = 0.;
-  if (i < g.nx && j < g.ny && k >= 1) v = thl_half(g, m, thl, g.idx(i, j, k), k);
+  if (i >= g.xg && i < g.nx - g.xg && j < g.ny && k >= 1) v = thl_half(g, m, thl, g.idx(i, j, k), k);      // (open x boundaries: ib .. ie)
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   if (threadIdx.x == 0) sw[threadIdx.y] = v;
   __syncthreads();
@@ -525,7 +525,7 @@ int k_buoyancy(udc_handle *h) {
   }
   if (comm_allreduce(h, h->lev_sum, g.nz, 1)) return 1;       // avexy_ibm's MPI_ALLREDUCE over the slabs
   dim3 b(64, 4, 1), gr = cell_grid(g, b);
-  hipLaunchKernelGGL(buoyancy_kernel, gr, b, 0, h->stream, g, tg, h->m, thl, h->lev_sum, (double)g.nx * (double)h->cfg.jtot, cntk,
+  hipLaunchKernelGGL(buoyancy_kernel, gr, b, 0, h->stream, g, tg, h->m, thl, h->lev_sum, (double)(g.nx - 2 * g.xg) * (double)h->cfg.jtot, cntk,
                      h->grav, h->fields[UDC_WP]);
   HIP_OK(hipGetLastError());
   return 0;

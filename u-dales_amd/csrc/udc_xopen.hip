@@ -134,6 +134,43 @@ __global__ void xo_restore_kernel(Geo g, int stage3, double *__restrict__ u0, do
   u0[r0] = a0; v0[r0] = a1; w0[r0] = a2; um[r0] = b0; vm[r0] = b1; wm[r0] = b2;
 }
 
+// the temperature (m-array in scalar slot 15, central scheme): xTi_profile (src/modboundary.f90:766-793: thl(ib-1) = thlprof(k) on
+// kb .. ke+1, thl(ib) = thlprof(k) on kb .. ke), xTo_convective (:947-957) on the outlet's planes; the columns as they stand are kept
+// for the next integration to put back
+__global__ void xo_thl_boundary_kernel(Geo g, const double *__restrict__ prof, double dxi, double rk3coef, const double *__restrict__ uout,
+                                       double *__restrict__ t0, double *__restrict__ tm, double *__restrict__ east, double *__restrict__ west) {
+  int jj, kk;
+  if (!plane_decode(g, jj, kk)) return;
+  const int j = jj - HY, k = kk - HZ;
+  const long r = (long)g.sy * jj + g.sz * kk;
+  const int e = g.nx - 1;
+  if (j >= -1 && j <= g.ny && k >= 0 && k <= g.nz) {
+    const double tp = prof[k + 1];
+    t0[r] = tp; tm[r] = tp;
+    if (k < g.nz) { t0[r + 1] = tp; tm[r + 1] = tp; }
+  }
+  const long P = (long)g.py * g.pz, q = (long)kk * g.py + jj;
+  double e0 = east[q], em = east[P + q];
+  const double uo = uout[0];
+  e0 = e0 - (e0 - t0[r + e - 1]) * dxi * rk3coef * uo;
+  em = em - (em - tm[r + e - 1]) * dxi * rk3coef * uo;
+  east[q] = e0; east[P + q] = em;
+  t0[r + e] = e0; tm[r + e] = em;
+  west[q] = t0[r]; west[P + q] = tm[r];
+}
+__global__ void xo_thl_restore_kernel(Geo g, int stage3, double *__restrict__ t0, double *__restrict__ tm, double *__restrict__ east,
+                                      double *__restrict__ west) {
+  int jj, kk;
+  if (!plane_decode(g, jj, kk)) return;
+  const long r = (long)g.sy * jj + g.sz * kk;
+  const long P = (long)g.py * g.pz, q = (long)kk * g.py + jj;
+  const double e0 = east[q], w0 = west[q];
+  double em = east[P + q], wm = west[P + q];
+  if (stage3) { em = e0; wm = w0; east[P + q] = em; west[P + q] = wm; }      // thlm = thl0: a whole-array copy (src/modtstep.f90:325)
+  t0[r + g.nx - 1] = e0; tm[r + g.nx - 1] = em;
+  t0[r] = w0; tm[r] = wm;
+}
+
 // the ghost column of an uploaded v0 / w0 / vm / wm -> the outlet's plane
 __global__ void xo_capture_kernel(Geo g, const double *__restrict__ f, double *__restrict__ plane, int col) {
   int jj, kk;
@@ -183,6 +220,7 @@ void xo_destroy(udc_handle *h) {
   if (h->xo_inlet_now) { hipFree(h->xo_inlet_now); h->xo_inlet_now = nullptr; }
   if (h->xo_inlet_next) { hipFree(h->xo_inlet_next); h->xo_inlet_next = nullptr; }
   if (h->xo_prof) { hipFree(h->xo_prof); h->xo_prof = nullptr; }
+  for (double **q : {&h->xo_thl_prof, &h->xo_thl_east, &h->xo_thl_west}) if (*q) { hipFree(*q); *q = nullptr; }
   if (h->xo_east) { hipFree(h->xo_east); h->xo_east = nullptr; }
   if (h->xo_west) { hipFree(h->xo_west); h->xo_west = nullptr; }
   if (h->xpois) { udc_destroy(h->xpois); h->xpois = nullptr; }
@@ -236,6 +274,15 @@ int xo_capture_east(udc_handle *h, int field, const double *, const int lb[3], c
   if (wslot >= 0 && lb[0] <= 0 && ub[0] >= 0)
     hipLaunchKernelGGL(xo_capture_kernel, plane_grid(g), dim3(64), 0, h->stream, g, (const double *)h->fields[field],
                        h->xo_west + (size_t)wslot * g.py * g.pz, 0);
+  const int tslot = field == UDC_THL0 ? 0 : (field == UDC_THLM ? 1 : -1);
+  if (tslot >= 0 && h->xo_thl_east) {
+    if (lb[0] <= itot + 1 && ub[0] >= itot + 1)
+      hipLaunchKernelGGL(xo_capture_kernel, plane_grid(g), dim3(64), 0, h->stream, g, (const double *)h->fields[field],
+                         h->xo_thl_east + (size_t)tslot * g.py * g.pz, g.nx - 1);
+    if (lb[0] <= 0 && ub[0] >= 0)
+      hipLaunchKernelGGL(xo_capture_kernel, plane_grid(g), dim3(64), 0, h->stream, g, (const double *)h->fields[field],
+                         h->xo_thl_west + (size_t)tslot * g.py * g.pz, 0);
+  }
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -276,7 +323,32 @@ int k_xo_boundary(udc_handle *h) {
                      (const double *)(h->xo_driver ? h->xo_inlet_now : nullptr), h->m.dxi, h->bcx_rk3coef,
                      (const double *)h->bcx_uout_dev, h->fields[UDC_U0], h->fields[UDC_V0], h->fields[UDC_W0],
                      h->fields[UDC_UM], h->fields[UDC_VM], h->fields[UDC_WM], h->fields[UDC_PRES0], h->xo_east, h->xo_west);
+  if (h->xo_thl_prof)
+    hipLaunchKernelGGL(xo_thl_boundary_kernel, plane_grid(g), dim3(64), 0, h->stream, g, (const double *)h->xo_thl_prof, h->m.dxi, h->bcx_rk3coef,
+                       (const double *)h->bcx_uout_dev, h->fields[UDC_THL0], h->fields[UDC_THLM], h->xo_thl_east, h->xo_thl_west);
   HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// the temperature's inflow profile thlprof [ktot+2] by the reference's k (entry ktot+1 as the reference's thlprof(ke+1): zero);
+// after udc_set_tempeq
+extern "C" int udc_set_open_x_thl(udc_handle *h, const double *thlprof) {
+  if (!h || !thlprof) { udc_set_error("udc_set_open_x_thl: null argument"); return 1; }
+  HIP_OK(hipSetDevice(h->device));
+  if (udc_flush_pending(h)) return 1;
+  if (!h->xg) { udc_set_error("udc_set_open_x_thl: not a handle of udc_create_open_x"); return 1; }
+  if ((int)h->fields.size() <= UDC_THL0 || !h->fields[UDC_THL0]) { udc_set_error("udc_set_open_x_thl: call udc_set_tempeq first"); return 1; }
+  const Geo &g = h->g;
+  const size_t nk = (size_t)g.nz + 2, np = (size_t)g.py * g.pz;
+  HIP_OK(hipStreamSynchronize(h->stream));
+  if (!h->xo_thl_prof) {
+    HIP_OK(hipMalloc(&h->xo_thl_prof, sizeof(double) * nk));
+    HIP_OK(hipMalloc(&h->xo_thl_east, sizeof(double) * 2 * np));
+    HIP_OK(hipMalloc(&h->xo_thl_west, sizeof(double) * 2 * np));
+    HIP_OK(hipMemset(h->xo_thl_east, 0, sizeof(double) * 2 * np));
+    HIP_OK(hipMemset(h->xo_thl_west, 0, sizeof(double) * 2 * np));
+  }
+  HIP_OK(hipMemcpy(h->xo_thl_prof, thlprof, sizeof(double) * nk, hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -286,6 +358,9 @@ int k_xo_after_integrate(udc_handle *h, int rk3step) {
   PROF(h, "xo_ghosts");
   hipLaunchKernelGGL(xo_restore_kernel, plane_grid(g), dim3(64), 0, h->stream, g, rk3step == 3 ? 1 : 0, h->fields[UDC_U0], h->fields[UDC_V0],
                      h->fields[UDC_W0], h->fields[UDC_UM], h->fields[UDC_VM], h->fields[UDC_WM], h->xo_east, h->xo_west);
+  if (h->xo_thl_prof)
+    hipLaunchKernelGGL(xo_thl_restore_kernel, plane_grid(g), dim3(64), 0, h->stream, g, rk3step == 3 ? 1 : 0, h->fields[UDC_THL0],
+                       h->fields[UDC_THLM], h->xo_thl_east, h->xo_thl_west);
   HIP_OK(hipGetLastError());
   return 0;
 }

@@ -517,6 +517,11 @@ module udc_iface
       real(c_double), value :: uouttot
       integer(c_int), value :: hold_first
     end function
+    integer(c_int) function udc_set_open_x_thl(h, thlprof) bind(C, name='udc_set_open_x_thl')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(in) :: thlprof(*)
+    end function
     integer(c_int) function udc_set_open_x_inlet(h, u0d, umd, v0d, vmd, w0d, wmd, lb, ub) bind(C, name='udc_set_open_x_inlet')
       import :: c_int, c_ptr, c_double
       type(c_ptr), value :: h
@@ -715,9 +720,9 @@ contains
   !! boundary / thermodynamics), so this runs with every start-up call and a last time when the time loop starts.
   subroutine udc_late_setup
     use modglobal, only: ktot, kb, ke, nsv, ltempeq, BCtops, lcoriol, lprofforc, om22, om23, luvolflowr, lvvolflowr, luoutflowr, &
-                         uflowrate, vflowrate, lnudge, igrw_damp, ifixuinf, ds, BCxs, BCxm
+                         uflowrate, vflowrate, lnudge, igrw_damp, ifixuinf, ds, BCxs, BCxm, BCxT, kh
     use modsurfdata, only: wsvtop, sv_top
-    use modfields, only: dpdxl, dpdyl, thlpcar, ug, whls, dthldxls, dthldyls, dqtdxls, dqtdyls, dqtdtls, &
+    use modfields, only: thlprof, dpdxl, dpdyl, thlpcar, ug, whls, dthldxls, dthldyls, dqtdxls, dqtdyls, dqtdtls, &
                          dudxls, dudyls, dvdxls, dvdyls
     integer :: n
     real(c_double), allocatable :: xo_u(:), xo_v(:)
@@ -725,6 +730,15 @@ contains
     if (BCxm == 2 .or. BCxm == 3) then      ! (the handle may be older than prof.inp's profiles)
       call open_x_profiles(xo_u, xo_v)
       call udc_check(udc_set_open_x_profile(udc_h, xo_u, xo_v), 'udc_set_open_x_profile')
+      if (ltempeq) then      ! the temperature enters with its profile (xTi_profile); planes of a precursor run (BCxT = 3) are not taken yet
+        if (BCxT /= 2) then
+          write (0, *) 'ERROR: libudcore: inflow / outflow in x with the temperature equation needs BCxT = 2 (inflow profile, convective outflow)'
+          stop 1
+        end if
+        xo_u = 0.
+        if (allocated(thlprof)) xo_u(1:ktot + 1) = thlprof(kb:ke + kh)
+        call udc_check(udc_set_open_x_thl(udc_h, xo_u), 'udc_set_open_x_thl')
+      end if
     end if
     if (ltempeq) then
       call udc_check(udc_set_thl_source(udc_h, thlpcar(kb:ke), int(ktot, c_int)), 'udc_set_thl_source')

@@ -336,6 +336,12 @@ class DynCore:
         """Record the top ghost planes of thl0 / qt0 as calthv would see them now (include/udcore.h udc_calthv)."""
         L._check(self.lib.udc_calthv(self.h), "udc_calthv")
 
+    def set_open_x_thl(self, thlprof):
+        """BCxT = 2 on an open-x core: the temperature's inflow profile, [ktot+2] by the reference's k."""
+        a = np.ascontiguousarray(thlprof, dtype=np.float64)
+        assert a.size == self.g.nz + 2
+        L._check(self.lib.udc_set_open_x_thl(self.h, a.ctypes.data_as(L.DP)), "udc_set_open_x_thl")
+
     def set_boundary_rk3coef(self, rk3coef):
         L._check(self.lib.udc_set_boundary_rk3coef(self.h, C.c_double(rk3coef)), "udc_set_boundary_rk3coef")
 

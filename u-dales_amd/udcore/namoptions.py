@@ -23,7 +23,7 @@ DEFAULTS = {
     "CHEMISTRY": dict(lchem=False, k1=0., JNO2=0.),
     "INLET": dict(Uinf=0., Vinf=0., inletav=0.),
     "DYNAMICS": dict(lqlnr=False, ipoiss=0, iadv_mom=2, iadv_tke=-1, iadv_thl=-1, iadv_qt=-1),
-    "BC": dict(BCxs=1, BCxm=1, BCym=1, BCtopm=1, BCbotm=2, BCzp=1, z0=-1., z0h=-1., BCtopT=1, BCbotT=1, BCbots=1, BCtops=1,
+    "BC": dict(BCxs=1, BCxm=1, BCxT=1, BCxq=1, BCym=1, BCtopm=1, BCbotm=2, BCzp=1, z0=-1., z0h=-1., BCtopT=1, BCbotT=1, BCbots=1, BCtops=1,
                wttop=0., thl_top=-1., wtsurf=-1., thls=-1., qts=-1.,
                BCtopq=1, BCbotq=1, wqtop=0., qt_top=-1., wqsurf=-1., wsvtopdum=0., ds=0.,
                bctfxm=0., bctfxp=0., bctfym=0., bctfyp=0., bctfz=0., bcqfxm=0., bcqfxp=0., bcqfym=0., bcqfyp=0., bcqfz=0.),
