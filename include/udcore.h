@@ -519,6 +519,12 @@ int udc_set_open_x_profile(udc_handle *h, const double *uprof, const double *vpr
  * `boundary`; thl0 / thlm at ie+1 are state like v and w there (udc_field_upload takes them from a host array that carries the column).
  * Not with obstacles (the c-grid lists are refused on such a handle), moisture or the kappa scheme. */
 int udc_set_open_x_thl(udc_handle *h, const double *thlprof);
+/* Passive scalars on such a handle (&BC BCxs = 2 with BCxm = 2 / 3; cfg->nsv > 0 gives the rows two ghost columns either side, ib-2 .. ie+2:
+ * advecc_kappa reads i-2 .. i+1): the inflow profiles svprof [nsv][ktot+2] by the reference's k.  xsi_profile (src/modboundary.f90:844-861:
+ * sv(ib-1) = 2 svprof - sv(ib), sv(ib-2) = 2 svprof - sv(ib-1), rows jb .. je, levels kb .. ke+1) and xso_convective (:983-996: sv(ie+1)) run
+ * with every `boundary`; sv(ie+2) keeps what an upload put there (no routine of the reference writes it).  udc_field_upload / _download of
+ * sv0, svm carry the four ghost columns of a host c-array (lb[0] <= -1, ub[0] >= itot+2).  With obstacles: the c-grid lists as usual. */
+int udc_set_open_x_scalars(udc_handle *h, const double *svprof);
 int udc_set_open_x_inlet(udc_handle *h, const double *u0driver, const double *umdriver, const double *v0driver, const double *vmdriver,
                          const double *w0driver, const double *wmdriver, const int lb[2], const int ub[2]);
 

@@ -902,6 +902,7 @@ void orc_halos_m(const orc_grid *g, double *a) {
 /* xs_periodic, ys_periodic: :580-593, 670-685 (halo 2) */
 void orc_halos_c(const orc_grid *g, double *a) {
   const int nx = g->nx, ny = g->ny, nz = g->nz;
+  if (!xo_on)      /* (BCxs = 2 with BCxm = 2: no periodic refresh in x) */
   for (int m = 1; m <= 2; ++m)
     for (int k = -1; k <= nz + 2; ++k)
       for (int j = -1; j <= ny + 2; ++j) {
@@ -1016,6 +1017,30 @@ void orc_boundary_open_x_thl(const orc_grid *g, double rk3coef, double *thl0, do
       M(thl0, nx + 1, j, k) = M(thl0, nx + 1, j, k) - (M(thl0, nx + 1, j, k) - M(thl0, nx, j, k)) * dxi * rk3coef * xo_uouttot;
       M(thlm, nx + 1, j, k) = M(thlm, nx + 1, j, k) - (M(thlm, nx + 1, j, k) - M(thlm, nx, j, k)) * dxi * rk3coef * xo_uouttot;
     }
+}
+/* ... and the passive scalars', BCxs = 2: xsi_profile (src/modboundary.f90:844-861), xso_convective (:983-996); svprof [nsv][nz+2] by k */
+static const double *xo_svprof = NULL;
+void orc_set_open_x_scalars(const double *svprof) { xo_svprof = svprof; }
+void orc_boundary_open_x_sv(const orc_grid *g, double rk3coef, double *sv0, double *svm) {
+  const int nx = g->nx, ny = g->ny, nz = g->nz;
+  const double dxi = 1. / g->dx;
+  const size_t nc = csize(g);
+  if (!xo_on || !xo_svprof) return;
+  for (int n = 0; n < g->nsv; ++n) {
+    double *p0 = sv0 + n * nc, *pm = svm + n * nc;
+    const double *prof = xo_svprof + (size_t)n * (nz + 2);
+    for (int j = 1; j <= ny; ++j)
+      for (int k = 1; k <= nz + 1; ++k)
+        for (int m = 1; m <= 2; ++m) {
+          C(p0, 1 - m, j, k) = 2 * prof[k] - C(p0, 1 - m + 1, j, k);
+          C(pm, 1 - m, j, k) = 2 * prof[k] - C(pm, 1 - m + 1, j, k);
+        }
+    for (int k = -1; k <= nz + 2; ++k)
+      for (int j = -1; j <= ny + 2; ++j) {
+        C(p0, nx + 1, j, k) = C(p0, nx + 1, j, k) - (C(p0, nx + 1, j, k) - C(p0, nx, j, k)) * dxi * rk3coef * xo_uouttot;
+        C(pm, nx + 1, j, k) = C(pm, nx + 1, j, k) - (C(pm, nx + 1, j, k) - C(pm, nx, j, k)) * dxi * rk3coef * xo_uouttot;
+      }
+  }
 }
 /* uouttot without a prescribed volume flow (src/modboundary.f90:143-156): sum_k u0av(k) dzf(k) / (zh(ke+1) - zh(kb+1)), u0av = diagfld's
  * slab average over the fluid u points (src/modthermodynamics.f90:271) of the state the substep starts from.  wlev[nz]: those weights
@@ -2117,6 +2142,7 @@ void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
   if (g->nsv > 0 && scalar_top_active(g)) orc_scalar_tops(g, s->ekh, s->sv0, s->svm);      /* src/modboundary.f90:236-247 */
   if (g->ltempeq) { orc_thl_top(g, s->ekh, s->thlm); orc_thl_top(g, s->ekh, s->thl0); }     /* src/modboundary.f90:207-217 */
   if (g->ltempeq && xo_on) orc_boundary_open_x_thl(g, rk3coef, s->thl0, s->thlm);            /* :270-283, 377 */
+  if (g->nsv > 0 && xo_on) orc_boundary_open_x_sv(g, rk3coef, s->sv0, s->svm);                /* :300-314, 379 */
   if (g->ltempeq && g->iadv_thl == 7) orc_thl0c_from(g, s->thl0, s->thl0c);                 /* src/modtstep.f90:249 + halos + boundary */
   if (g->lmoist) { orc_qt_top(g, s->ekh, s->qtm); orc_qt_top(g, s->ekh, s->qt0); }          /* src/modboundary.f90:222-231 */
   if (g->lmoist && s->thermo) orc_thermodynamics(g, s);                                     /* src/program.f90:214 */

@@ -220,6 +220,8 @@ void orc_set_open_x_uouttot(double uouttot);
 double orc_open_x_uouttot(void);
 void orc_set_open_x_fields(const double *u0, double *up);
 void orc_set_open_x_outflow(const double *wlev, double uouttot, int hold_first);
+void orc_set_open_x_scalars(const double *svprof);      /* BCxs = 2: the scalars' inflow profiles [nsv][nz+2] by k (NULL: off) */
+void orc_boundary_open_x_sv(const orc_grid *g, double rk3coef, double *sv0, double *svm);
 void orc_set_open_x_thl(const double *thlprof);      /* BCxT = 2: the temperature's inflow profile [nz+2] by k (NULL: off) */
 void orc_boundary_open_x_thl(const orc_grid *g, double rk3coef, double *thl0, double *thlm);
 void orc_boundary_open_x(const orc_grid *g, double rk3coef, double *u0, double *v0, double *w0, double *um, double *vm, double *wm);

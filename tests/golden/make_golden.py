@@ -531,6 +531,9 @@ CASES.update({
     "run_xopen_thl_16x8x12s": ("run", 101, 16, 8, 12, dict(sgs="smag", floor=True, bctopm=3, randu=0.05, physics="ltempeq = .true.\nlbuoyancy = .true.",
                                                            bc="BCxm = 2\nBCxT = 2\nBCtopT = 2\nthl_top = 290.5\nBCbotT = 1\nwtsurf = 0.02\nthls = 288.0",
                                                            oracle="nsub = 9\ndump_at = 3, 9"), 1.06),
+    # ... with passive scalars: BCxs = 2 (xsi_profile, xso_convective), one and two scalars, the second deck with obstacles and wall functions
+    "k_xopen_sv_16x8x12": ("kernels", 102, 16, 8, 12, dict(sgs="vreman", nsv=2, floor=True, bctopm=3, randu=0.05, bc="BCxm = 2\nBCxs = 2", oracle="nspin = 4"), 1.04),
+    "run_xopen_sv_16x8x12s": ("run", 103, 16, 8, 12, dict(sgs="smag", nsv=1, floor=True, bctopm=3, randu=0.05, bc="BCxm = 2\nBCxs = 2", oracle="nsub = 9\ndump_at = 3, 9"), 1.06),
     "run_xopen_vr_24x8x10": ("run", 92, 24, 8, 10, dict(sgs="vreman", floor=True, bctopm=3, randu=0.05, bc="BCxm = 2", dx=0.4, oracle="nsub = 12\ndump_at = 6, 12"), 1.0),
     "k_ptop_12x8x6": ("kernels", 84, 12, 8, 6, dict(sgs="vreman", floor=True, bctopm=3, randu=0.05, oracle="nspin = 4"), 1.04),
     "run_ptop_16x8x12s": ("run", 85, 16, 8, 12, dict(sgs="smag", nsv=1, floor=True, bctopm=3, randu=0.05, oracle="nsub = 9\ndump_at = 3, 9"), 1.06),
@@ -665,12 +668,15 @@ for _n in ("run_ibm_moist_16x12x10", "run_ibm_moistwq_16x12x10", "k_ibm_wq2_16x1
     IBM_BLOCKS[_n] = IBM_BLOCKS["run_ibm_16x12x10"]
     WF_CASES[_n] = 2
 # inflow / outflow in x around obstacles (blocks away from the x ends): without wall functions, and with the neutral log law on the facets
-for _n in ("run_xopen_ibm_16x12x10", "run_xopen_ibmwf3_16x12x10"):
+for _n in ("run_xopen_ibm_16x12x10", "run_xopen_ibmwf3_16x12x10", "run_xopen_ibm_sv_16x12x10"):
     IBM_BLOCKS[_n] = IBM_BLOCKS["run_ibm_16x12x10"]
 WF_CASES["run_xopen_ibmwf3_16x12x10"] = 3
+WF_CASES["run_xopen_ibm_sv_16x12x10"] = 3
 CASES.update({
     "run_xopen_ibm_16x12x10": ("run", 93, 16, 12, 10, dict(sgs="vreman", floor=True, bctopm=3, randu=0.05, bc="BCxm = 2", ibm=IBM_BLOCKS["run_ibm_16x12x10"],
                                                            oracle="nsub = 9\ndump_at = 3, 9"), 1.0),
+    "run_xopen_ibm_sv_16x12x10": ("run", 104, 16, 12, 10, dict(sgs="smag", nsv=1, floor=True, bctopm=3, randu=0.05, bc="BCxm = 2\nBCxs = 2", ibm=IBM_BLOCKS["run_ibm_16x12x10"],
+                                                               iwallmom=3, oracle="nsub = 9\ndump_at = 3, 9"), 1.0),
     "run_xopen_ibmwf3_16x12x10": ("run", 94, 16, 12, 10, dict(sgs="smag", floor=True, bctopm=3, randu=0.05, bc="BCxm = 2", ibm=IBM_BLOCKS["run_ibm_16x12x10"],
                                                               iwallmom=3, oracle="nsub = 9\ndump_at = 3, 9"), 1.0),
 })
@@ -707,7 +713,7 @@ THL_CASES = {"k_tke_moist_12x8x8": dict(dthl=0.25, qt=0.0118, dqt=-8e-5, tke=0.0
              "k_qt_12x8x6": dict(dthl=0.3, qt=0.008, dqt=-4e-4), "run_qt_16x8x12s": dict(dthl=0.25, qt=0.007, dqt=-2e-4),
              "k_lsf_12x8x24": dict(dthl=0.3, ug=1.05, wtop=0.02), "run_lsf_16x8x24s": dict(dthl=0.25, ug=0.95, wtop=-0.03), "k_tke_12x8x6": dict(tke=0.05), "k_tke_thl_12x8x6": dict(tke=0.08, dthl=0.3), "k_coriol_12x8x6": dict(ug=1.1), "run_profforc_16x16x8": dict(ug=1.3), "k_thl_12x8x6": dict(dthl=0.4, dthlrad=2e-3), "run_thl_16x8x12s": dict(dthl=0.25, dthlrad=-1e-3),
              "k_buoy_12x8x6": dict(dthl=0.3), "run_buoy_16x8x12s": dict(dthl=0.2),
-             "k_xopen_16x8x12": dict(v=0.1), "run_xopen_16x8x12s": dict(v=0.1), "k_xopen_thl_16x8x12": dict(v=0.1, dthl=0.3), "run_xopen_thl_16x8x12s": dict(v=0.1, dthl=0.25), "run_xopen_volflow_16x8x12s": dict(v=0.1), "run_xopen_vr_24x8x10": dict(u=0.8, v=-0.05), "run_xopen_ibm_16x12x10": dict(v=0.1), "run_xopen_ibmwf3_16x12x10": dict(u=0.9, v=0.15),
+             "k_xopen_16x8x12": dict(v=0.1), "run_xopen_16x8x12s": dict(v=0.1), "k_xopen_sv_16x8x12": dict(v=0.1), "run_xopen_sv_16x8x12s": dict(v=0.1), "run_xopen_ibm_sv_16x12x10": dict(u=0.9, v=0.15), "k_xopen_thl_16x8x12": dict(v=0.1, dthl=0.3), "run_xopen_thl_16x8x12s": dict(v=0.1, dthl=0.25), "run_xopen_volflow_16x8x12s": dict(v=0.1), "run_xopen_vr_24x8x10": dict(u=0.8, v=-0.05), "run_xopen_ibm_16x12x10": dict(v=0.1), "run_xopen_ibmwf3_16x12x10": dict(u=0.9, v=0.15),
              "k_ibm_thl_16x12x10": dict(dthl=0.3), "run_ibm_thl_16x12x10": dict(dthl=0.25), "run_ptop_ibm_16x12x10": dict(dthl=0.25), "run_ibm_thlcons_16x12x10": dict(dthl=0.25),
              "run_ibm_qt_16x12x10": dict(dthl=0.25, qt=0.007, dqt=-2e-4),
              "run_stats_16x8x12s": dict(dthl=0.25), "run_stats_ibm_16x12x10": dict(dthl=0.25), "run_ytstats_ibm_16x12x10": dict(dthl=0.25),

@@ -9,18 +9,20 @@ checks the device on seeded fields at other sizes (test_against_oracle_seeded). 
 import numpy as np
 import pytest
 
-from common import deck_path, interior, load_fixture, marr, nocorner, relerr
+from common import carr, deck_path, interior, load_fixture, marr, nocorner, relerr
+from udcore import lib as L
 from udcore import read_deck
 
 pytestmark = pytest.mark.gpu
 
 KERNEL_TOL = 1e-11
 RUN_TOL = 1e-9
-K_CASES = {"k_xopen_16x8x12": 90, "k_xopen_thl_16x8x12": 100}
+K_CASES = {"k_xopen_16x8x12": 90, "k_xopen_thl_16x8x12": 100, "k_xopen_sv_16x8x12": 102}
 # BCxm = 3: the inlet from a precursor run's planes (the reference's moddriver stays on the host: Fortran routes only)
 D_CASES = {"run_xdriver_16x8x12s": 96, "run_xdriver_ibm_16x12x10": 98}
 R_CASES = {"run_xopen_16x8x12s": 91, "run_xopen_vr_24x8x10": 92, "run_xopen_ibm_16x12x10": 93, "run_xopen_ibmwf3_16x12x10": 94,
-           "run_xopen_volflow_16x8x12s": 99, "run_xopen_thl_16x8x12s": 101}
+           "run_xopen_volflow_16x8x12s": 99, "run_xopen_thl_16x8x12s": 101,
+           "run_xopen_sv_16x8x12s": 103, "run_xopen_ibm_sv_16x12x10": 104}
 
 
 def make_core(name, iexp):
@@ -51,11 +53,23 @@ def test_each_routine_matches_reference(name, iexp):
     # what the upload took: the ghost columns come back as they went in
     for k in ("u0", "v0", "w0", "vm", "pres0") + (("thl0", "thlm") if thl else ()):
         assert np.array_equal(xcols(core.download(k)), xcols(marr(fix, "in." + k, nz))), k
+    nsv = core.nsv      # (BCxs = 2: the scalars' c-arrays carry two ghost columns either side)
+    for n in range(nsv):
+        core.upload(L.scalar_field(L.SV0, n), carr(fix, f"in.sv0_{n + 1:02d}", nz))
+        core.upload(L.scalar_field(L.SVM, n), carr(fix, f"in.svm_{n + 1:02d}", nz))
+        assert np.array_equal(core.download(L.scalar_field(L.SV0, n), halo=2)[2:-2, 2:-2, :], carr(fix, f"in.sv0_{n + 1:02d}", nz)[2:-2, 2:-2, :])
     zero = np.zeros(g.mshape())
 
     def zero_tend():
         for k in ("up", "vp", "wp") + (("thlp",) if thl else ()):
             core.upload(k, zero)
+        for n in range(nsv):
+            core.upload(L.scalar_field(L.SVP, n), np.zeros(g.cshape()))
+
+    def svp_is(tag):
+        for n in range(nsv):
+            got = core.download(L.scalar_field(L.SVP, n), halo=2)
+            assert relerr(interior(got, 2), interior(carr(fix, f"{tag}.svp_{n + 1:02d}", nz), 2)) <= KERNEL_TOL, (tag, n)
 
     def thlp_is(tag):
         # (without the column ib: xTi_profile overwrites thl(ib, kb..ke) with the profile at every `boundary`, so its tendency is never
@@ -70,6 +84,7 @@ def test_each_routine_matches_reference(name, iexp):
     for k in ("up", "vp", "wp"):
         assert relerr(interior(core.download(k)), interior(marr(fix, "adv." + k, nz))) <= KERNEL_TOL, k
     thlp_is("adv")
+    svp_is("adv")
     # (the test has teeth: the same sweep on periodic x gives something else in the columns next to the ends)
     ref = interior(marr(fix, "adv.vp", nz))
     assert np.abs(ref[:, :, 0]).max() > 0
@@ -81,6 +96,7 @@ def test_each_routine_matches_reference(name, iexp):
     for k in ("up", "vp", "wp"):
         assert relerr(interior(core.download(k)), interior(marr(fix, "sub." + k, nz))) <= KERNEL_TOL, k
     thlp_is("sub")
+    svp_is("sub")
     core.bottom_diagnostics(True)
     core.bottom()
     for k in ("up", "vp"):
@@ -96,6 +112,7 @@ def test_each_routine_matches_reference(name, iexp):
     for k in ("up", "vp", "wp"):
         assert relerr(interior(core.download(k)), interior(marr(fix, "pre." + k, nz))) <= KERNEL_TOL, k
     thlp_is("pre")
+    svp_is("pre")
     # bcpup reads the outlet's speed as the previous substep's `boundary` left it (dumped by the driver)
     core.set_open_x_outflow(None, float(fix["in.uouttot"].data[0]))
     core.poisson()
@@ -125,6 +142,9 @@ def test_each_routine_matches_reference(name, iexp):
     assert relerr(nocorner(core.download("w0"))[nz + 1], nocorner(ref)[nz + 1], np.abs(ref).max()) <= KERNEL_TOL
     for k in ("thl0", "thlm") if thl else ():      # with the inlet's and the outlet's columns; differences are O(1) K on a 288 K mean
         assert relerr(nocorner(core.download(k)[1:-1]), nocorner(marr(fix, "out." + k, nz)[1:-1]), 1.0) <= KERNEL_TOL, k
+    for n in range(nsv):      # the interior rows and levels with ib-2, ib-1, ie+1, ie+2
+        got = core.download(L.scalar_field(L.SV0, n), halo=2)
+        assert relerr(got[2:-2, 2:-2, :], carr(fix, f"out.sv0_{n + 1:02d}", nz)[2:-2, 2:-2, :]) <= KERNEL_TOL, n
     core.close()
 
 
@@ -139,6 +159,9 @@ def test_substeps_match_reference(name, iexp, fused):
     thl = bool(d.get("PHYSICS", "ltempeq"))
     for k in ("u0", "v0", "w0", "um", "vm", "wm", "pres0") + (("thl0", "thlm") if thl else ()):
         core.upload(k, marr(fix, "s000." + k, g.nz))
+    for n in range(core.nsv):
+        core.upload(L.scalar_field(L.SV0, n), carr(fix, f"s000.sv0_{n + 1:02d}", g.nz))
+        core.upload(L.scalar_field(L.SVM, n), carr(fix, f"s000.svm_{n + 1:02d}", g.nz))
     # (the start-up's `boundary` has run: its speed is what bcpup reads first, and what the first substep's `boundary` still uses)
     if d.get("PHYSICS", "luvolflowr"):      # a prescribed volume flow names the outlet's speed, nothing else (masscorr is off with inflow / outflow)
         assert abs(core._uouttot - float(fix["s000.uouttot"].data[0])) < 1e-13      # (from_deck's ubulk)
@@ -164,6 +187,9 @@ def test_substeps_match_reference(name, iexp, fused):
             for k in ("thl0", "thlm") if thl else ():
                 ref = marr(fix, f"{tag}.{k}", g.nz)
                 assert relerr(nocorner(core.download(k)[1:-1]), nocorner(ref[1:-1]), 1.0) <= RUN_TOL, (tag, k)
+            for n in range(core.nsv):
+                got = core.download(L.scalar_field(L.SV0, n), halo=2)
+                assert relerr(got[2:-2, 2:-2, :], carr(fix, f"{tag}.sv0_{n + 1:02d}", g.nz)[2:-2, 2:-2, :]) <= RUN_TOL, (tag, n)
             ref = marr(fix, f"{tag}.w0", g.nz)
             assert relerr(nocorner(core.download("w0"))[g.nz + 1], nocorner(ref)[g.nz + 1], np.abs(ref).max()) <= RUN_TOL, (tag, "w0(ke+1)")
             if fused is True:
@@ -181,7 +207,7 @@ def test_substeps_match_reference(name, iexp, fused):
     core.close()
 
 
-@pytest.mark.parametrize("name", ["run_xopen_16x8x12s", "run_xopen_ibmwf3_16x12x10", "run_xopen_thl_16x8x12s"])
+@pytest.mark.parametrize("name", ["run_xopen_16x8x12s", "run_xopen_ibmwf3_16x12x10", "run_xopen_thl_16x8x12s", "run_xopen_ibm_sv_16x12x10"])
 def test_cold_start_matches_reference(name):
     """From the deck alone, the way run_case.py starts: the fields as readinitfiles leaves them (the x ghost columns hold the
     profile, no noise), the start-up's slab averages, its `boundary` (uouttot from those averages, one convective step with
@@ -192,12 +218,15 @@ def test_cold_start_matches_reference(name):
     d, core = make_core(name, iexp)
     g = core.g
     dt = float(d.get("RUN", "dtmax"))
-    core.load_state(cold_start(g, d, nsv=0, pre_boundary=True))
+    core.load_state(cold_start(g, d, nsv=core.nsv, pre_boundary=True))
     core.halos()
     core.start_up(dtmax=dt)
     for k in ("u0", "v0", "w0", "um", "vm", "wm"):
         ref = marr(fix, "s000." + k, g.nz)
         assert relerr(nocorner(core.download(k)[1:-1]), nocorner(ref[1:-1])) <= 1e-13, k
+    for n in range(core.nsv):
+        got = core.download(L.scalar_field(L.SV0, n), halo=2)
+        assert relerr(got[2:-2, 2:-2, :], carr(fix, f"s000.sv0_{n + 1:02d}", g.nz)[2:-2, 2:-2, :]) <= 1e-13, n
     vin = float(d.v[0])
     assert np.abs(marr(fix, "s000.v0", g.nz)[1:-1, 1:-1, -1] - vin).max() > 1e-6      # (the start-up's convective step moved the outlet)
     for isub in range(1, 4):
@@ -205,6 +234,9 @@ def test_cold_start_matches_reference(name):
     for k in ("u0", "v0", "w0", "pres0", "vm") + (("thl0",) if core.ltempeq else ()):
         ref = marr(fix, "s003." + k, g.nz)
         assert relerr(nocorner(core.download(k)[1:-1]), nocorner(ref[1:-1]), 1.0 if k == "thl0" else None) <= RUN_TOL, k
+    for n in range(core.nsv):
+        got = core.download(L.scalar_field(L.SV0, n), halo=2)
+        assert relerr(got[2:-2, 2:-2, :], carr(fix, f"s003.sv0_{n + 1:02d}", g.nz)[2:-2, 2:-2, :]) <= RUN_TOL, n
     core.close()
 
 
@@ -218,6 +250,10 @@ def test_fortran_driver_with_dropin_modules(name, iexp, residency, tmp_path):
     got = run_dropin(name, iexp, "run", tmp_path, residency)
     checked = 0
     for key, ref in fix.items():
+        if ".sv0_" in key:      # (c-arrays: two ghost cells; the interior rows and levels with their four ghost columns)
+            assert relerr(got[key].data[2:-2, 2:-2, :], ref.data[2:-2, 2:-2, :]) <= RUN_TOL, key
+            checked += 1
+            continue
         if "." not in key or key.split(".")[1] not in ("u0", "v0", "w0", "pres0", "um", "vm", "wm", "thl0", "thlm"):
             continue
         a, b = got[key].data[1:-1], ref.data[1:-1]

@@ -199,11 +199,13 @@ extern "C" int udc_create_open_x(const udc_config *cfg, const double *uprof, con
     udc_set_error("udc_create_open_x: BCtopm must be 3 (the reference opens the lid with BCxm = 2 itself, src/modstartup.f90:845-848)");
     return 1;
   }
-  if (cfg->nsv != 0) { udc_set_error("udc_create_open_x: no transported scalars yet (nsv = 0)"); return 1; }
+  if (cfg->nsv < 0 || cfg->nsv > 12) { udc_set_error("udc_create_open_x: nsv out of range (at most 12 passive scalars)"); return 1; }
   if (cfg->sgs == UDC_SGS_ONEEQN) { udc_set_error("udc_create_open_x: the one-equation closure is not offered with open x boundaries"); return 1; }
   if (cfg->itot < 8 || cfg->itot % 2) { udc_set_error("udc_create_open_x: itot even and >= 8"); return 1; }
+  // one ghost column at either end of a row; two with passive scalars (advecc_kappa reads i-2 .. i+1: ib-2, ib-1 / ie+1, ie+2)
+  const int xg = cfg->nsv > 0 ? 2 : 1;
   udc_config c2 = *cfg;
-  c2.itot = cfg->itot + 2;
+  c2.itot = cfg->itot + 2 * xg;
   // (udc_create's own checks, then the same construction with the ghost columns switched on)
   if (cfg->jtot < 4 || cfg->ktot < 3 || cfg->jtot % 2) { udc_set_error("udc_create_open_x: grid too small, or jtot odd"); return 1; }
   if (cfg->jtot < 2 * HY) { udc_set_error("udc_create_open_x: slab thinner than the ghost width"); return 1; }
@@ -214,7 +216,7 @@ extern "C" int udc_create_open_x(const udc_config *cfg, const double *uprof, con
   if (device >= ndev) { udc_set_error("udc_create_open_x: device index beyond the visible HIP devices"); return 1; }
   udc_handle *h = new udc_handle();
   h->device = device;
-  h->xg = 1;
+  h->xg = xg;
   if (create_on_device(&c2, h) || xo_init(h, uprof, vprof)) { udc_destroy(h); return 1; }
   if (h->slab) { udc_set_error("udc_create_open_x: not with UDC_FORCE_SLAB"); udc_destroy(h); return 1; }
   *out = h;
@@ -663,11 +665,11 @@ extern "C" int udc_set_scalar_source(udc_handle *h, int n, const double *src, co
   udc_handle::ScalarSource &s = h->svsrc[n];
   if (s.d) { HIP_OK(hipFree(s.d)); s.d = nullptr; }
   if (!src) return 0;
-  const int ext[3] = {h->g.nx, h->g.ny, h->g.nz};
+  const int ext[3] = {h->g.nx - 2 * h->g.xg, h->g.ny, h->g.nz};
   size_t cnt = 1;
   for (int q = 0; q < 3; ++q) {
     if (lb[q] < 1 || ub[q] > ext[q] || ub[q] < lb[q]) { udc_set_error("udc_set_scalar_source: box outside the interior (dimension %d: %d..%d of 1..%d)", q, lb[q], ub[q], ext[q]); return 1; }
-    s.lo[q] = lb[q] - 1; s.hi[q] = ub[q] - 1;
+    s.lo[q] = lb[q] - 1 + (q == 0 ? h->g.xg : 0); s.hi[q] = ub[q] - 1 + (q == 0 ? h->g.xg : 0);      // (open x boundaries: the device row starts xg columns west of ib)
     cnt *= (size_t)(ub[q] - lb[q] + 1);
   }
   HIP_OK(hipMalloc(&s.d, sizeof(double) * cnt));
@@ -1231,7 +1233,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   for (int n : h->slots) {
     bool forced = false;      // a level forcing (subsidence, nudging, sponge) acts on this scalar's tendency
     for (const auto &f : h->level_forcings) forced = forced || f.tend == UDC_SVP + 3 * n;
-    h->sv_inline[n] = !forced && h->sw.sv_inline && lds && fold && n < h->cfg.nsv && n < 13 && !h->slot[n].tke && h->slot[n].adv == 1 && h->slot[n].top == 0 &&
+    h->sv_inline[n] = !forced && !h->xg && h->sw.sv_inline && lds && fold && n < h->cfg.nsv && n < 13 && !h->slot[n].tke && h->slot[n].adv == 1 && h->slot[n].top == 0 &&
                       h->slot[n].kappa_ghosts == 0 && h->scal_bcx == 1 && !h->ibm_on && !h->svsrc[n].d && !h->lchem && h->g.nx >= 32 && h->g.ny >= 4;
   }
   h->last_inline_scalars = 0;

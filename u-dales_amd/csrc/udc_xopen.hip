@@ -2,7 +2,8 @@
 // src/modstartup.f90:830-849).
 //
 // The device grid of such a handle (udc_create_open_x) is the deck's grid plus ONE ghost column at either end of every row:
-// device column c is the reference's i = c (ib - 1 = 0, ib = 1, ..., ie = itot, ie + 1 = itot + 1), g.nx = itot + 2, g.xg = 1.
+// device column c is the reference's i = c (ib - 1 = 0, ib = 1, ..., ie = itot, ie + 1 = itot + 1), g.nx = itot + 2, g.xg = 1.  With passive
+// scalars two ghost columns (g.xg = 2, g.nx = itot + 4, column c is i = c - 1): the kappa scheme reads i-2 .. i+1.
 // Every sweep runs on it unchanged, as if those itot + 2 columns were periodic: an interior cell then finds the reference's ghost
 // values where its stencil looks for them, and what the sweeps leave IN the two ghost columns (a tendency formed across the seam, a
 // velocity integrated from it) is never read before the kernels below have put the reference's values there:
@@ -43,8 +44,8 @@ inline dim3 plane_grid(const Geo &g) { return dim3((unsigned)((g.py + 63) / 64),
 __global__ void xo_ek_kernel(Geo g, double *__restrict__ ekm, double *__restrict__ ekh) {
   int jj, kk;
   if (!plane_decode(g, jj, kk)) return;
-  const long r = (long)g.sy * jj + g.sz * kk;
-  const int e = g.nx - 1;
+  const long r = (long)g.sy * jj + g.sz * kk + (g.xg - 1);      // the ghost column ib-1 (xg = 2: one more beyond it, for the kappa scalars)
+  const int e = g.nx - 2 * g.xg + 1;                             // ... from there to ie+1
   ekm[r] = ekm[r + 1]; ekm[r + e] = ekm[r + e - 1];
   ekh[r] = ekh[r + 1]; ekh[r + e] = ekh[r + e - 1];
 }
@@ -60,8 +61,8 @@ __global__ void xo_bcpup_kernel(Geo g, double rk3coefi, double dxi, const double
   if (!plane_decode(g, jj, kk)) return;
   const int j = jj - HY, k = kk - HZ;
   if (j < -1 || j > g.ny || k < 0 || k >= g.nz) return;
-  const long r = (long)g.sy * jj + g.sz * kk;
-  const int e = g.nx - 1;
+  const long r = (long)g.sy * jj + g.sz * kk + (g.xg - 1);      // the ghost column ib-1 (xg = 2: one more beyond it, for the kappa scalars)
+  const int e = g.nx - 2 * g.xg + 1;                             // ... from there to ie+1
   const double uin = inlet ? inlet[(long)kk * g.py + jj] : prof[k + 1];
   up[r + 1] = PUP ? uin * rk3coefi : 0.;
   const double ume = um[r + e];
@@ -79,8 +80,8 @@ __global__ void xo_boundary_kernel(Geo g, const double *__restrict__ prof, const
   int jj, kk;
   if (!plane_decode(g, jj, kk)) return;
   const int j = jj - HY, k = kk - HZ;
-  const long r = (long)g.sy * jj + g.sz * kk;
-  const int e = g.nx - 1;
+  const long r = (long)g.sy * jj + g.sz * kk + (g.xg - 1);      // the ghost column ib-1 (xg = 2: one more beyond it, for the kappa scalars)
+  const int e = g.nx - 2 * g.xg + 1;                             // ... from there to ie+1
   const long P = (long)g.py * g.pz, q = (long)kk * g.py + jj;
   if (inlet) {      // xmi_driver, src/modboundary.f90:720-749: u at ib and ib-1, v at ib-1 on kb .. ke; w at ib-1 on kb .. ke+1
     if (j >= -1 && j <= g.ny && k >= 0 && k <= g.nz) {
@@ -121,7 +122,7 @@ __global__ void xo_restore_kernel(Geo g, int stage3, double *__restrict__ u0, do
                                   double *__restrict__ east, double *__restrict__ west) {
   int jj, kk;
   if (!plane_decode(g, jj, kk)) return;
-  const long r0 = (long)g.sy * jj + g.sz * kk, r = r0 + g.nx - 1;
+  const long r0 = (long)g.sy * jj + g.sz * kk + (g.xg - 1), r = r0 + g.nx - 2 * g.xg + 1;      // ib-1, ie+1
   const long P = (long)g.py * g.pz, q = (long)kk * g.py + jj;
   const double ev0 = east[q], ew0 = east[P + q];
   double evm = east[2 * P + q], ewm = east[3 * P + q];
@@ -142,8 +143,8 @@ __global__ void xo_thl_boundary_kernel(Geo g, const double *__restrict__ prof, d
   int jj, kk;
   if (!plane_decode(g, jj, kk)) return;
   const int j = jj - HY, k = kk - HZ;
-  const long r = (long)g.sy * jj + g.sz * kk;
-  const int e = g.nx - 1;
+  const long r = (long)g.sy * jj + g.sz * kk + (g.xg - 1);      // the ghost column ib-1 (xg = 2: one more beyond it, for the kappa scalars)
+  const int e = g.nx - 2 * g.xg + 1;                             // ... from there to ie+1
   if (j >= -1 && j <= g.ny && k >= 0 && k <= g.nz) {
     const double tp = prof[k + 1];
     t0[r] = tp; tm[r] = tp;
@@ -162,13 +163,60 @@ __global__ void xo_thl_restore_kernel(Geo g, int stage3, double *__restrict__ t0
                                       double *__restrict__ west) {
   int jj, kk;
   if (!plane_decode(g, jj, kk)) return;
-  const long r = (long)g.sy * jj + g.sz * kk;
+  const long r = (long)g.sy * jj + g.sz * kk + (g.xg - 1);
+  const int e = g.nx - 2 * g.xg + 1;
   const long P = (long)g.py * g.pz, q = (long)kk * g.py + jj;
   const double e0 = east[q], w0 = west[q];
   double em = east[P + q], wm = west[P + q];
   if (stage3) { em = e0; wm = w0; east[P + q] = em; west[P + q] = wm; }      // thlm = thl0: a whole-array copy (src/modtstep.f90:325)
-  t0[r + g.nx - 1] = e0; tm[r + g.nx - 1] = em;
+  t0[r + e] = e0; tm[r + e] = em;
   t0[r] = w0; tm[r] = wm;
+}
+
+// passive scalars (c-arrays, kappa scheme: two ghost columns either side).  xsi_profile (src/modboundary.f90:844-861: on jb .. je, kb .. ke+1,
+// sv(ib-1) = 2 svprof - sv(ib), sv(ib-2) = 2 svprof - sv(ib-1), sv0 and svm), xso_convective (:983-996: sv(ie+1) on every row and level; ie+2
+// stays what it is); cols [8][P]: sv0 at ib-2, ib-1, ie+1, ie+2, then svm
+__global__ void xo_sv_boundary_kernel(Geo g, const double *__restrict__ prof, double dxi, double rk3coef, const double *__restrict__ uout,
+                                      double *__restrict__ s0, double *__restrict__ sm, double *__restrict__ cols) {
+  int jj, kk;
+  if (!plane_decode(g, jj, kk)) return;
+  const int j = jj - HY, k = kk - HZ;
+  const long r = (long)g.sy * jj + g.sz * kk + (g.xg - 1);
+  const int e = g.nx - 2 * g.xg + 1;
+  const long P = (long)g.py * g.pz, q = (long)kk * g.py + jj;
+  if (j >= 0 && j < g.ny && k >= 0 && k <= g.nz) {
+    const double sp = prof[k + 1];
+    s0[r] = 2 * sp - s0[r + 1]; sm[r] = 2 * sp - sm[r + 1];
+    s0[r - 1] = 2 * sp - s0[r]; sm[r - 1] = 2 * sp - sm[r];
+  }
+  double e0 = cols[2 * P + q], em = cols[6 * P + q];
+  const double uo = uout[0];
+  e0 = e0 - (e0 - s0[r + e - 1]) * dxi * rk3coef * uo;
+  em = em - (em - sm[r + e - 1]) * dxi * rk3coef * uo;
+  s0[r + e] = e0; sm[r + e] = em;
+  s0[r + e + 1] = cols[3 * P + q]; sm[r + e + 1] = cols[7 * P + q];
+  cols[q] = s0[r - 1]; cols[P + q] = s0[r]; cols[2 * P + q] = e0;
+  cols[4 * P + q] = sm[r - 1]; cols[5 * P + q] = sm[r]; cols[6 * P + q] = em;
+}
+__global__ void xo_sv_restore_kernel(Geo g, int stage3, double *__restrict__ s0, double *__restrict__ sm, double *__restrict__ cols) {
+  int jj, kk;
+  if (!plane_decode(g, jj, kk)) return;
+  const long r = (long)g.sy * jj + g.sz * kk + (g.xg - 1);
+  const int e = g.nx - 2 * g.xg + 1;
+  const long P = (long)g.py * g.pz, q = (long)kk * g.py + jj;
+  double c[8];
+  for (int t = 0; t < 8; ++t) c[t] = cols[t * P + q];
+  if (stage3) for (int t = 0; t < 4; ++t) { c[4 + t] = c[t]; cols[(4 + t) * P + q] = c[t]; }      // svm = sv0: a whole-array copy (src/modtstep.f90:326)
+  s0[r - 1] = c[0]; s0[r] = c[1]; s0[r + e] = c[2]; s0[r + e + 1] = c[3];
+  sm[r - 1] = c[4]; sm[r] = c[5]; sm[r + e] = c[6]; sm[r + e + 1] = c[7];
+}
+__global__ void xo_sv_capture_kernel(Geo g, const double *__restrict__ f, double *__restrict__ cols4) {
+  int jj, kk;
+  if (!plane_decode(g, jj, kk)) return;
+  const long r = (long)g.sy * jj + g.sz * kk + (g.xg - 1);
+  const int e = g.nx - 2 * g.xg + 1;
+  const long P = (long)g.py * g.pz, q = (long)kk * g.py + jj;
+  cols4[q] = f[r - 1]; cols4[P + q] = f[r]; cols4[2 * P + q] = f[r + e]; cols4[3 * P + q] = f[r + e + 1];
 }
 
 // the ghost column of an uploaded v0 / w0 / vm / wm -> the outlet's plane
@@ -181,20 +229,20 @@ __global__ void xo_capture_kernel(Geo g, const double *__restrict__ f, double *_
 // the right-hand side's interior columns and their mirror image -> the doubled row; back: the first half, and bcp's ghost columns
 __global__ __launch_bounds__(256) void xo_gather_kernel(Geo g, Geo g2, const double *__restrict__ p, double *__restrict__ p2) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
-  const int n = g.nx - 2;
+  const int n = g.nx - 2 * g.xg;
   if (i >= n) return;
-  const double v = p[g.idx(i + 1, j, k)];
+  const double v = p[g.idx(i + g.xg, j, k)];
   p2[g2.idx(i, j, k)] = v;
   p2[g2.idx(2 * n - 1 - i, j, k)] = v;
 }
 __global__ __launch_bounds__(256) void xo_scatter_kernel(Geo g, Geo g2, const double *__restrict__ p2, double *__restrict__ p) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
-  const int n = g.nx - 2;
+  const int n = g.nx - 2 * g.xg;
   if (i >= n) return;
   const double v = p2[g2.idx(i, j, k)];
-  p[g.idx(i + 1, j, k)] = v;
-  if (i == 0) p[g.idx(0, j, k)] = v;
-  if (i == n - 1) p[g.idx(n + 1, j, k)] = v;
+  p[g.idx(i + g.xg, j, k)] = v;
+  if (i == 0) p[g.idx(g.xg - 1, j, k)] = v;
+  if (i == n - 1) p[g.idx(n + g.xg, j, k)] = v;
 }
 
 }  // namespace
@@ -220,7 +268,8 @@ void xo_destroy(udc_handle *h) {
   if (h->xo_inlet_now) { hipFree(h->xo_inlet_now); h->xo_inlet_now = nullptr; }
   if (h->xo_inlet_next) { hipFree(h->xo_inlet_next); h->xo_inlet_next = nullptr; }
   if (h->xo_prof) { hipFree(h->xo_prof); h->xo_prof = nullptr; }
-  for (double **q : {&h->xo_thl_prof, &h->xo_thl_east, &h->xo_thl_west}) if (*q) { hipFree(*q); *q = nullptr; }
+  for (double **q : {&h->xo_thl_prof, &h->xo_thl_east, &h->xo_thl_west, &h->xo_sv_prof}) if (*q) { hipFree(*q); *q = nullptr; }
+  for (double *&q : h->xo_sv_cols) if (q) { hipFree(q); q = nullptr; }
   if (h->xo_east) { hipFree(h->xo_east); h->xo_east = nullptr; }
   if (h->xo_west) { hipFree(h->xo_west); h->xo_west = nullptr; }
   if (h->xpois) { udc_destroy(h->xpois); h->xpois = nullptr; }
@@ -264,24 +313,28 @@ extern "C" int udc_set_open_x_inlet(udc_handle *h, const double *u0d, const doub
 int xo_capture_east(udc_handle *h, int field, const double *, const int lb[3], const int ub[3]) {
   if (!h->xg) return 0;
   const Geo &g = h->g;
-  const int itot = g.nx - 2;
+  const int itot = g.nx - 2 * g.xg;
   int slot = -1;
   if (field == UDC_V0) slot = 0; else if (field == UDC_W0) slot = 1; else if (field == UDC_VM) slot = 2; else if (field == UDC_WM) slot = 3;
   if (slot >= 0 && lb[0] <= itot + 1 && ub[0] >= itot + 1)      // (else the host array does not carry the column: the plane stays as it is)
     hipLaunchKernelGGL(xo_capture_kernel, plane_grid(g), dim3(64), 0, h->stream, g, (const double *)h->fields[field],
-                       h->xo_east + (size_t)slot * g.py * g.pz, g.nx - 1);
+                       h->xo_east + (size_t)slot * g.py * g.pz, g.nx - g.xg);
   const int wslot = (field >= UDC_U0 && field <= UDC_WM) ? field - UDC_U0 : -1;      // u0 v0 w0 um vm wm
   if (wslot >= 0 && lb[0] <= 0 && ub[0] >= 0)
     hipLaunchKernelGGL(xo_capture_kernel, plane_grid(g), dim3(64), 0, h->stream, g, (const double *)h->fields[field],
-                       h->xo_west + (size_t)wslot * g.py * g.pz, 0);
+                       h->xo_west + (size_t)wslot * g.py * g.pz, g.xg - 1);
+  if (field >= UDC_SV0 && (field - UDC_SV0) % 3 < 2 && (field - UDC_SV0) / 3 < 13 && h->xo_sv_cols[(field - UDC_SV0) / 3] &&
+      lb[0] <= -1 && ub[0] >= itot + 2)      // sv0 / svm with both ghost columns either side (the reference's c-arrays carry them)
+    hipLaunchKernelGGL(xo_sv_capture_kernel, plane_grid(g), dim3(64), 0, h->stream, g, (const double *)h->fields[field],
+                       h->xo_sv_cols[(field - UDC_SV0) / 3] + (size_t)4 * ((field - UDC_SV0) % 3) * g.py * g.pz);
   const int tslot = field == UDC_THL0 ? 0 : (field == UDC_THLM ? 1 : -1);
   if (tslot >= 0 && h->xo_thl_east) {
     if (lb[0] <= itot + 1 && ub[0] >= itot + 1)
       hipLaunchKernelGGL(xo_capture_kernel, plane_grid(g), dim3(64), 0, h->stream, g, (const double *)h->fields[field],
-                         h->xo_thl_east + (size_t)tslot * g.py * g.pz, g.nx - 1);
+                         h->xo_thl_east + (size_t)tslot * g.py * g.pz, g.nx - g.xg);
     if (lb[0] <= 0 && ub[0] >= 0)
       hipLaunchKernelGGL(xo_capture_kernel, plane_grid(g), dim3(64), 0, h->stream, g, (const double *)h->fields[field],
-                         h->xo_thl_west + (size_t)tslot * g.py * g.pz, 0);
+                         h->xo_thl_west + (size_t)tslot * g.py * g.pz, g.xg - 1);
   }
   HIP_OK(hipGetLastError());
   return 0;
@@ -326,7 +379,30 @@ int k_xo_boundary(udc_handle *h) {
   if (h->xo_thl_prof)
     hipLaunchKernelGGL(xo_thl_boundary_kernel, plane_grid(g), dim3(64), 0, h->stream, g, (const double *)h->xo_thl_prof, h->m.dxi, h->bcx_rk3coef,
                        (const double *)h->bcx_uout_dev, h->fields[UDC_THL0], h->fields[UDC_THLM], h->xo_thl_east, h->xo_thl_west);
+  for (int n = 0; n < h->cfg.nsv && n < 13; ++n)
+    if (h->xo_sv_cols[n])
+      hipLaunchKernelGGL(xo_sv_boundary_kernel, plane_grid(g), dim3(64), 0, h->stream, g, (const double *)(h->xo_sv_prof + (size_t)n * (g.nz + 2)),
+                         h->m.dxi, h->bcx_rk3coef, (const double *)h->bcx_uout_dev, h->fields[UDC_SV0 + 3 * n], h->fields[UDC_SVM + 3 * n], h->xo_sv_cols[n]);
   HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// passive scalars on such a handle (&BC BCxs = 2): the inflow profiles svprof [nsv][ktot+2] by the reference's k
+extern "C" int udc_set_open_x_scalars(udc_handle *h, const double *svprof) {
+  if (!h || !svprof) { udc_set_error("udc_set_open_x_scalars: null argument"); return 1; }
+  HIP_OK(hipSetDevice(h->device));
+  if (udc_flush_pending(h)) return 1;
+  if (!h->xg || h->cfg.nsv < 1) { udc_set_error("udc_set_open_x_scalars: a handle of udc_create_open_x with nsv > 0"); return 1; }
+  const Geo &g = h->g;
+  const size_t nk = (size_t)g.nz + 2, np = (size_t)g.py * g.pz;
+  HIP_OK(hipStreamSynchronize(h->stream));
+  if (!h->xo_sv_prof) HIP_OK(hipMalloc(&h->xo_sv_prof, sizeof(double) * nk * h->cfg.nsv));
+  HIP_OK(hipMemcpy(h->xo_sv_prof, svprof, sizeof(double) * nk * h->cfg.nsv, hipMemcpyHostToDevice));
+  for (int n = 0; n < h->cfg.nsv && n < 13; ++n)
+    if (!h->xo_sv_cols[n]) {
+      HIP_OK(hipMalloc(&h->xo_sv_cols[n], sizeof(double) * 8 * np));
+      HIP_OK(hipMemset(h->xo_sv_cols[n], 0, sizeof(double) * 8 * np));
+    }
   return 0;
 }
 
@@ -361,6 +437,10 @@ int k_xo_after_integrate(udc_handle *h, int rk3step) {
   if (h->xo_thl_prof)
     hipLaunchKernelGGL(xo_thl_restore_kernel, plane_grid(g), dim3(64), 0, h->stream, g, rk3step == 3 ? 1 : 0, h->fields[UDC_THL0],
                        h->fields[UDC_THLM], h->xo_thl_east, h->xo_thl_west);
+  for (int n = 0; n < h->cfg.nsv && n < 13; ++n)
+    if (h->xo_sv_cols[n])
+      hipLaunchKernelGGL(xo_sv_restore_kernel, plane_grid(g), dim3(64), 0, h->stream, g, rk3step == 3 ? 1 : 0, h->fields[UDC_SV0 + 3 * n],
+                         h->fields[UDC_SVM + 3 * n], h->xo_sv_cols[n]);
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -369,7 +449,7 @@ int k_xo_poisson(udc_handle *h) {
   udc_handle *hp = h->xpois;
   if (!hp) { udc_set_error("open x boundaries: the solver's handle is missing"); return 1; }
   const Geo &g = h->g, &g2 = hp->g;
-  const int n = g.nx - 2;
+  const int n = g.nx - 2 * g.xg;
   const dim3 b(256), gr((unsigned)((n + 255) / 256), (unsigned)g.ny, (unsigned)g.nz);
   hp->bczp = h->bczp;
   if (!h->xo_rhs_mirrored) {      // (a right-hand side that did not come from k_divergence_rhs)

@@ -517,6 +517,11 @@ module udc_iface
       real(c_double), value :: uouttot
       integer(c_int), value :: hold_first
     end function
+    integer(c_int) function udc_set_open_x_scalars(h, svprof) bind(C, name='udc_set_open_x_scalars')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(in) :: svprof(*)
+    end function
     integer(c_int) function udc_set_open_x_thl(h, thlprof) bind(C, name='udc_set_open_x_thl')
       import :: c_int, c_ptr, c_double
       type(c_ptr), value :: h
@@ -756,7 +761,11 @@ contains
                      'udc_set_coriolis')
     end if
     ! scalars with an inflow / outflow in x (BCxs = 2: xsi_profile, xso_convective; src/modboundary.f90:844, 983)
-    if (nsv > 0 .and. BCxs /= 1) call scalar_bcx_setup
+    if (nsv > 0 .and. (BCxm == 2 .or. BCxm == 3)) then      ! the scalars enter and leave with the flow: the rows carry their ghost columns
+      call open_x_scalars
+    else if (nsv > 0 .and. BCxs /= 1) then
+      call scalar_bcx_setup
+    end if
     ! masscorr, volume-flow branches (src/modforces.f90:389-417, 467-494)
     call udc_check(udc_set_masscorr(udc_h, merge(1_c_int, 0_c_int, luvolflowr), real(uflowrate, c_double), &
                                     merge(1_c_int, 0_c_int, lvvolflowr), real(vflowrate, c_double)), 'udc_set_masscorr')
@@ -767,6 +776,20 @@ contains
                    any(dthldxls /= 0.) .or. any(dthldyls /= 0.) .or. any(dqtdxls /= 0.) .or. any(dqtdyls /= 0.) .or. &
                    any(dqtdtls /= 0.) .or. any(dudxls /= 0.) .or. any(dudyls /= 0.) .or. any(dvdxls /= 0.) .or. any(dvdyls /= 0.)
   end subroutine udc_late_setup
+
+  subroutine open_x_scalars
+    use modglobal, only: ktot, kb, ke, nsv, BCxs
+    use modfields, only: svprof
+    real(c_double), allocatable :: t(:, :)
+    if (BCxs /= 2) then
+      write (0, *) 'ERROR: libudcore: inflow / outflow in x with passive scalars needs BCxs = 2 (inflow profile, convective outflow)'
+      stop 1
+    end if
+    allocate (t(0:ktot + 1, nsv))
+    t = 0.
+    t(1:ktot + 1, :) = svprof(kb:ke + 1, 1:nsv)
+    call udc_check(udc_set_open_x_scalars(udc_h, t), 'udc_set_open_x_scalars')
+  end subroutine open_x_scalars
 
   subroutine scalar_bcx_setup
     use modglobal, only: ktot, kb, ke, nsv, BCxs, luvolflowr, luoutflowr, dzf, zh

@@ -111,7 +111,12 @@ def from_deck(deck, device=0, rank=0, nranks=1):
     bcxs = int(deck.get("BC", "BCxs"))
     if bcxs not in (1, 2):
         raise ValueError("&BC BCxs: 1 (periodic) or 2 (inflow profile, convective outflow) are on the device path")
-    if core.nsv and bcxs == 2:      # scalars enter at the low-x side with svprof and leave at the high-x side (src/modboundary.f90:844, 983)
+    if core.nsv and bcxm == 2:      # inflow / outflow for the flow: the scalars enter and leave with it (the rows carry their ghost columns)
+        if bcxs != 2:
+            raise ValueError("&BC BCxm = 2 with passive scalars: BCxs = 2 (inflow profile, convective outflow) is what the device path has")
+        from .grid import scalar_profiles
+        core.set_open_x_scalars(np.array(scalar_profiles(g, deck, core.nsv)))
+    elif core.nsv and bcxs == 2:      # scalars enter at the low-x side with svprof and leave at the high-x side (src/modboundary.f90:844, 983)
         if deck.is_set("PHYSICS", "luoutflowr") and deck.nml["PHYSICS"][[k for k in deck.nml["PHYSICS"] if k.lower() == "luoutflowr"][0]]:
             raise ValueError("BCxs = 2 with luoutflowr is not on the device path")
         from .grid import scalar_profiles
