@@ -668,8 +668,9 @@ for _n in ("run_ibm_moist_16x12x10", "run_ibm_moistwq_16x12x10", "k_ibm_wq2_16x1
     IBM_BLOCKS[_n] = IBM_BLOCKS["run_ibm_16x12x10"]
     WF_CASES[_n] = 2
 # inflow / outflow in x around obstacles (blocks away from the x ends): without wall functions, and with the neutral log law on the facets
-for _n in ("run_xopen_ibm_16x12x10", "run_xopen_ibmwf3_16x12x10", "run_xopen_ibm_sv_16x12x10"):
+for _n in ("run_xopen_ibm_16x12x10", "run_xopen_ibmwf3_16x12x10", "run_xopen_ibm_sv_16x12x10", "run_xopen_ibm_thl_16x12x10"):
     IBM_BLOCKS[_n] = IBM_BLOCKS["run_ibm_16x12x10"]
+WF_CASES["run_xopen_ibm_thl_16x12x10"] = 2
 WF_CASES["run_xopen_ibmwf3_16x12x10"] = 3
 WF_CASES["run_xopen_ibm_sv_16x12x10"] = 3
 CASES.update({
@@ -677,6 +678,10 @@ CASES.update({
                                                            oracle="nsub = 9\ndump_at = 3, 9"), 1.0),
     "run_xopen_ibm_sv_16x12x10": ("run", 104, 16, 12, 10, dict(sgs="smag", nsv=1, floor=True, bctopm=3, randu=0.05, bc="BCxm = 2\nBCxs = 2", ibm=IBM_BLOCKS["run_ibm_16x12x10"],
                                                                iwallmom=3, oracle="nsub = 9\ndump_at = 3, 9"), 1.0),
+    # heated obstacles in an inflow / outflow: the stability wall functions for momentum and heat on the facet temperatures, buoyancy, a scalar
+    "run_xopen_ibm_thl_16x12x10": ("run", 105, 16, 12, 10, dict(sgs="vreman", nsv=1, floor=True, bctopm=3, randu=0.05, ibm=IBM_BLOCKS["run_ibm_16x12x10"], iwallmom=2,
+                                                                physics="ltempeq = .true.\nlbuoyancy = .true.", walls="iwalltemp = 2",
+                                                                bc="BCxm = 2\nBCxT = 2\nBCxs = 2\n" + _IBM_THL_BC, oracle="nsub = 9\ndump_at = 3, 9"), 1.0),
     "run_xopen_ibmwf3_16x12x10": ("run", 94, 16, 12, 10, dict(sgs="smag", floor=True, bctopm=3, randu=0.05, bc="BCxm = 2", ibm=IBM_BLOCKS["run_ibm_16x12x10"],
                                                               iwallmom=3, oracle="nsub = 9\ndump_at = 3, 9"), 1.0),
 })
@@ -713,7 +718,7 @@ THL_CASES = {"k_tke_moist_12x8x8": dict(dthl=0.25, qt=0.0118, dqt=-8e-5, tke=0.0
              "k_qt_12x8x6": dict(dthl=0.3, qt=0.008, dqt=-4e-4), "run_qt_16x8x12s": dict(dthl=0.25, qt=0.007, dqt=-2e-4),
              "k_lsf_12x8x24": dict(dthl=0.3, ug=1.05, wtop=0.02), "run_lsf_16x8x24s": dict(dthl=0.25, ug=0.95, wtop=-0.03), "k_tke_12x8x6": dict(tke=0.05), "k_tke_thl_12x8x6": dict(tke=0.08, dthl=0.3), "k_coriol_12x8x6": dict(ug=1.1), "run_profforc_16x16x8": dict(ug=1.3), "k_thl_12x8x6": dict(dthl=0.4, dthlrad=2e-3), "run_thl_16x8x12s": dict(dthl=0.25, dthlrad=-1e-3),
              "k_buoy_12x8x6": dict(dthl=0.3), "run_buoy_16x8x12s": dict(dthl=0.2),
-             "k_xopen_16x8x12": dict(v=0.1), "run_xopen_16x8x12s": dict(v=0.1), "k_xopen_sv_16x8x12": dict(v=0.1), "run_xopen_sv_16x8x12s": dict(v=0.1), "run_xopen_ibm_sv_16x12x10": dict(u=0.9, v=0.15), "k_xopen_thl_16x8x12": dict(v=0.1, dthl=0.3), "run_xopen_thl_16x8x12s": dict(v=0.1, dthl=0.25), "run_xopen_volflow_16x8x12s": dict(v=0.1), "run_xopen_vr_24x8x10": dict(u=0.8, v=-0.05), "run_xopen_ibm_16x12x10": dict(v=0.1), "run_xopen_ibmwf3_16x12x10": dict(u=0.9, v=0.15),
+             "k_xopen_16x8x12": dict(v=0.1), "run_xopen_16x8x12s": dict(v=0.1), "k_xopen_sv_16x8x12": dict(v=0.1), "run_xopen_sv_16x8x12s": dict(v=0.1), "run_xopen_ibm_sv_16x12x10": dict(u=0.9, v=0.15), "run_xopen_ibm_thl_16x12x10": dict(u=0.9, v=0.15, dthl=0.25), "k_xopen_thl_16x8x12": dict(v=0.1, dthl=0.3), "run_xopen_thl_16x8x12s": dict(v=0.1, dthl=0.25), "run_xopen_volflow_16x8x12s": dict(v=0.1), "run_xopen_vr_24x8x10": dict(u=0.8, v=-0.05), "run_xopen_ibm_16x12x10": dict(v=0.1), "run_xopen_ibmwf3_16x12x10": dict(u=0.9, v=0.15),
              "k_ibm_thl_16x12x10": dict(dthl=0.3), "run_ibm_thl_16x12x10": dict(dthl=0.25), "run_ptop_ibm_16x12x10": dict(dthl=0.25), "run_ibm_thlcons_16x12x10": dict(dthl=0.25),
              "run_ibm_qt_16x12x10": dict(dthl=0.25, qt=0.007, dqt=-2e-4),
              "run_stats_16x8x12s": dict(dthl=0.25), "run_stats_ibm_16x12x10": dict(dthl=0.25), "run_ytstats_ibm_16x12x10": dict(dthl=0.25),

@@ -22,7 +22,7 @@ K_CASES = {"k_xopen_16x8x12": 90, "k_xopen_thl_16x8x12": 100, "k_xopen_sv_16x8x1
 D_CASES = {"run_xdriver_16x8x12s": 96, "run_xdriver_ibm_16x12x10": 98}
 R_CASES = {"run_xopen_16x8x12s": 91, "run_xopen_vr_24x8x10": 92, "run_xopen_ibm_16x12x10": 93, "run_xopen_ibmwf3_16x12x10": 94,
            "run_xopen_volflow_16x8x12s": 99, "run_xopen_thl_16x8x12s": 101,
-           "run_xopen_sv_16x8x12s": 103, "run_xopen_ibm_sv_16x12x10": 104}
+           "run_xopen_sv_16x8x12s": 103, "run_xopen_ibm_sv_16x12x10": 104, "run_xopen_ibm_thl_16x12x10": 105}
 
 
 def make_core(name, iexp):

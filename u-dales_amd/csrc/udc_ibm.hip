@@ -280,7 +280,10 @@ extern "C" int udc_set_ibm_points(udc_handle *h, int grid, const int *solid, int
   // A point whose (i, j) lies outside the domain belongs to no rank: the reference's reader keeps the points of its own pencil and
   // drops the rest without a word (read_sparse_ijk, src/readinput.f90:90-100 -- the lists of its own tests/cases/526 cover 256 x 128
   // columns of a 128 x 64 domain).  Same here; a level outside kb..ke is an error (the reference would index out of bounds).
-  if (h->xg && grid == 3 && h->cfg.nsv == 0) { udc_set_error("udc_set_ibm_points: open x boundaries without a passive scalar: the c lists have no use (the temperature next to obstacles is not offered there)"); return 1; }
+  if (h->xg && grid == 3 && h->cfg.nsv == 0 && !((int)h->fields.size() > UDC_THL0 && h->fields[UDC_THL0])) {
+    udc_set_error("udc_set_ibm_points: open x boundaries without a scalar field: the c lists have no use (the reference does not read them either, src/modibm.f90:181)");
+    return 1;
+  }
   const int ext[3] = {h->g.nx - 2 * h->g.xg, h->jtot, h->g.nz};      // (open x boundaries: the deck's itot)
   udc_handle::IbmGrid &G = h->ibm[grid];
   G.solid_g.clear(); G.bound_g.clear();
