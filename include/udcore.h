@@ -493,8 +493,10 @@ int udc_set_scalar_bcx_outflow(udc_handle *h, const double *wlev);
  * ub[0] >= itot+1: u0(ie+1), v0 / w0 / vm / wm(ie+1) are state), udc_field_download returns them; columns further out are left alone.
  * With it go: the immersed boundary (point lists, facet sections: wall functions for momentum and heat), the floor, Smagorinsky / Vreman, the
  * temperature (central scheme; udc_set_open_x_thl) and up to 12 passive scalars (cfg->nsv > 0 gives the rows a second ghost column either
- * side; udc_set_open_x_scalars).  One rank; no moisture, one-equation closure or device-side statistics yet (those entry points refuse the
- * handle; udc_masscorr does nothing, as the reference's masscorr under linoutflow).  DESIGN.md sections 1 and 4 (udc_xopen.hip).
+ * side; udc_set_open_x_scalars).  A temperature without an inflow profile and the total water stay periodic in x (&BC BCxT = 1, BCxq = 1, the
+ * reference's defaults -- its tests/cases/525 runs BCxm = 3 with them): halos' xT_periodic / xq_periodic (src/modboundary.f90:543-577) refresh
+ * their ghost columns after every integration, the moist thermodynamics' slab averages run over ib .. ie.  One rank; no one-equation closure
+ * or device-side statistics yet (those entry points refuse the handle; udc_masscorr does nothing, as the reference's masscorr under linoutflow).  DESIGN.md sections 1 and 4 (udc_xopen.hip).
  * udc_set_open_x_outflow: the outlet's speed uouttot (src/modboundary.f90:141-160) -- wlev NULL: the constant given (ubulk of a prescribed
  * flow); wlev[ktot] = dzf(k) / (zh(ke+1) - zh(kb+1)): sum_k wlev(k) u0av(k) of the state each substep starts from, `uouttot` being
  * the value in force until the first refresh (bcpup reads the previous `boundary`'s speed) -- and, with hold_first, through the whole
@@ -519,7 +521,7 @@ int udc_set_open_x_profile(udc_handle *h, const double *uprof, const double *vpr
  * profile thlprof [ktot+2] by the reference's k (entry ktot+1 as the reference's thlprof(ke+1): zero).  xTi_profile
  * (src/modboundary.f90:766-793: thl(ib-1) = thlprof on kb .. ke+1, thl(ib) = thlprof on kb .. ke) and xTo_convective (:947-957) run with every
  * `boundary`; thl0 / thlm at ie+1 are state like v and w there (udc_field_upload takes them from a host array that carries the column).
- * Not with moisture or the kappa scheme. */
+ * Not with the kappa scheme.  Without this call the temperature is periodic in x (BCxT = 1). */
 int udc_set_open_x_thl(udc_handle *h, const double *thlprof);
 /* Passive scalars on such a handle (&BC BCxs = 2 with BCxm = 2 / 3; cfg->nsv > 0 gives the rows two ghost columns either side, ib-2 .. ie+2:
  * advecc_kappa reads i-2 .. i+1): the inflow profiles svprof [nsv][ktot+2] by the reference's k.  xsi_profile (src/modboundary.f90:844-861:

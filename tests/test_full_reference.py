@@ -63,7 +63,8 @@ def run_full(name, iexp, tmp_path, exe=FULL, env=None, deck_text=None):
 
 # (+ the inflow / outflow decks of tests/test_gpu_open_x.py: fixtures the oracle does not restate are pinned on the program too)
 OPEN_X_CASES = {"run_xopen_16x8x12s": 91, "run_xopen_vr_24x8x10": 92, "run_xopen_ibm_16x12x10": 93, "run_xopen_ibmwf3_16x12x10": 94,
-                "run_xopen_volflow_16x8x12s": 99, "run_xopen_thl_16x8x12s": 101, "run_xopen_sv_16x8x12s": 103, "run_xopen_ibm_sv_16x12x10": 104, "run_xopen_ibm_thl_16x12x10": 105, "run_xdriver_16x8x12s": 96, "run_xdriver_ibm_16x12x10": 98}
+                "run_xopen_volflow_16x8x12s": 99, "run_xopen_thl_16x8x12s": 101, "run_xopen_sv_16x8x12s": 103, "run_xopen_ibm_sv_16x12x10": 104, "run_xopen_ibm_thl_16x12x10": 105, "run_xdriver_16x8x12s": 96, "run_xdriver_ibm_16x12x10": 98,
+                "run_xopen_moist_16x8x12s": 107, "run_xopen_ibm_moist_16x12x10": 108, "run_xdriver_moist_16x12x10": 110}
 
 
 @pytest.mark.parametrize("name,iexp", sorted({**RUN_CASES, **OPEN_X_CASES}.items()))

@@ -17,12 +17,14 @@ pytestmark = pytest.mark.gpu
 
 KERNEL_TOL = 1e-11
 RUN_TOL = 1e-9
-K_CASES = {"k_xopen_16x8x12": 90, "k_xopen_thl_16x8x12": 100, "k_xopen_sv_16x8x12": 102}
+K_CASES = {"k_xopen_16x8x12": 90, "k_xopen_thl_16x8x12": 100, "k_xopen_sv_16x8x12": 102, "k_xopen_moist_16x8x12": 106}
 # BCxm = 3: the inlet from a precursor run's planes (the reference's moddriver stays on the host: Fortran routes only)
-D_CASES = {"run_xdriver_16x8x12s": 96, "run_xdriver_ibm_16x12x10": 98}
+D_CASES = {"run_xdriver_16x8x12s": 96, "run_xdriver_ibm_16x12x10": 98, "run_xdriver_moist_16x12x10": 110}
 R_CASES = {"run_xopen_16x8x12s": 91, "run_xopen_vr_24x8x10": 92, "run_xopen_ibm_16x12x10": 93, "run_xopen_ibmwf3_16x12x10": 94,
            "run_xopen_volflow_16x8x12s": 99, "run_xopen_thl_16x8x12s": 101,
-           "run_xopen_sv_16x8x12s": 103, "run_xopen_ibm_sv_16x12x10": 104, "run_xopen_ibm_thl_16x12x10": 105}
+           "run_xopen_sv_16x8x12s": 103, "run_xopen_ibm_sv_16x12x10": 104, "run_xopen_ibm_thl_16x12x10": 105,
+           # the temperature and the total water periodic in x (BCxT = BCxq = 1: the reference's defaults, its tests/cases/525) beside the inflow / outflow
+           "run_xopen_moist_16x8x12s": 107, "run_xopen_ibm_moist_16x12x10": 108}
 
 
 def make_core(name, iexp):
@@ -47,11 +49,15 @@ def test_each_routine_matches_reference(name, iexp):
     fix = load_fixture(name)
     d, core = make_core(name, iexp)
     g, nz = core.g, core.g.nz
-    thl = "in.thl0" in fix      # (BCxT = 2: the temperature enters with its profile and leaves convectively too)
-    for k in ("u0", "v0", "w0", "um", "vm", "wm", "pres0", "ekm", "ekh") + (("thl0", "thlm") if thl else ()):
+    thl = "in.thl0" in fix      # (BCxT = 2: the temperature enters with its profile and leaves convectively too; BCxT = 1: periodic)
+    qt = "in.qt0" in fix
+    tprof = thl and int(d.get("BC", "BCxT")) == 2
+    for k in ("u0", "v0", "w0", "um", "vm", "wm", "pres0", "ekm", "ekh") + (("thl0", "thlm") if thl else ()) + (("qt0", "qtm") if qt else ()):
         core.upload(k, np.nan_to_num(marr(fix, "in." + k, nz)))
+    if "thm.presf" in fix:      # what the reference's last thermodynamics call left behind
+        core.thermo_state({n: np.concatenate(([0.], fix["thm." + n].data)) if "thm." + n in fix else np.zeros(nz + 2) for n in core.TH_TABLES})
     # what the upload took: the ghost columns come back as they went in
-    for k in ("u0", "v0", "w0", "vm", "pres0") + (("thl0", "thlm") if thl else ()):
+    for k in ("u0", "v0", "w0", "vm", "pres0") + (("thl0", "thlm") if thl else ()) + (("qt0", "qtm") if qt else ()):
         assert np.array_equal(xcols(core.download(k)), xcols(marr(fix, "in." + k, nz))), k
     nsv = core.nsv      # (BCxs = 2: the scalars' c-arrays carry two ghost columns either side)
     for n in range(nsv):
@@ -61,7 +67,7 @@ def test_each_routine_matches_reference(name, iexp):
     zero = np.zeros(g.mshape())
 
     def zero_tend():
-        for k in ("up", "vp", "wp") + (("thlp",) if thl else ()):
+        for k in ("up", "vp", "wp") + (("thlp",) if thl else ()) + (("qtp",) if qt else ()):
             core.upload(k, zero)
         for n in range(nsv):
             core.upload(L.scalar_field(L.SVP, n), np.zeros(g.cshape()))
@@ -77,7 +83,10 @@ def test_each_routine_matches_reference(name, iexp):
         #  the reference's subgrid re-imposes it from the new one (reassure_fluxtop_boundary) between advection and diffusion, the device
         #  re-imposes a zero-flux top only where a flux is prescribed)
         if thl:
-            assert relerr(interior(core.download("thlp"))[:, :, 1:], interior(marr(fix, tag + ".thlp", nz))[:, :, 1:]) <= KERNEL_TOL, tag
+            c0 = 1 if tprof else 0      # (periodic in x: every column)
+            assert relerr(interior(core.download("thlp"))[:, :, c0:], interior(marr(fix, tag + ".thlp", nz))[:, :, c0:]) <= KERNEL_TOL, tag
+        if qt:
+            assert relerr(interior(core.download("qtp")), interior(marr(fix, tag + ".qtp", nz))) <= KERNEL_TOL, tag
 
     zero_tend()
     core.advection()
@@ -142,6 +151,8 @@ def test_each_routine_matches_reference(name, iexp):
     assert relerr(nocorner(core.download("w0"))[nz + 1], nocorner(ref)[nz + 1], np.abs(ref).max()) <= KERNEL_TOL
     for k in ("thl0", "thlm") if thl else ():      # with the inlet's and the outlet's columns; differences are O(1) K on a 288 K mean
         assert relerr(nocorner(core.download(k)[1:-1]), nocorner(marr(fix, "out." + k, nz)[1:-1]), 1.0) <= KERNEL_TOL, k
+    for k in ("qt0", "qtm") if qt else ():
+        assert relerr(nocorner(core.download(k)[1:-1]), nocorner(marr(fix, "out." + k, nz)[1:-1])) <= KERNEL_TOL, k
     for n in range(nsv):      # the interior rows and levels with ib-2, ib-1, ie+1, ie+2
         got = core.download(L.scalar_field(L.SV0, n), halo=2)
         assert relerr(got[2:-2, 2:-2, :], carr(fix, f"out.sv0_{n + 1:02d}", nz)[2:-2, 2:-2, :]) <= KERNEL_TOL, n
@@ -157,8 +168,11 @@ def test_substeps_match_reference(name, iexp, fused):
     d, core = make_core(name, iexp)
     g = core.g
     thl = bool(d.get("PHYSICS", "ltempeq"))
-    for k in ("u0", "v0", "w0", "um", "vm", "wm", "pres0") + (("thl0", "thlm") if thl else ()):
+    qt = bool(d.get("PHYSICS", "lmoist"))
+    for k in ("u0", "v0", "w0", "um", "vm", "wm", "pres0") + (("thl0", "thlm") if thl else ()) + (("qt0", "qtm") if qt else ()):
         core.upload(k, marr(fix, "s000." + k, g.nz))
+    if qt and fused is not True:
+        core.thermodynamics()      # src/program.f90:120 (the fused substep makes the call itself on its first substep)
     for n in range(core.nsv):
         core.upload(L.scalar_field(L.SV0, n), carr(fix, f"s000.sv0_{n + 1:02d}", g.nz))
         core.upload(L.scalar_field(L.SVM, n), carr(fix, f"s000.svm_{n + 1:02d}", g.nz))
@@ -179,8 +193,13 @@ def test_substeps_match_reference(name, iexp, fused):
             core.advection(); core.subgrid(); core.bottom(); core.coriolis(); core.forces(); core.ibmwallfun(); core.masscorr()
             core.ibmnorm(); core.scalsource(); core.poisson()
             core.tstep_integrate(); core.halos(); core.boundary()
+            if core.moist_thermo:
+                core.thermodynamics()
         if isub in dumps:
             tag = f"s{isub:03d}"
+            for k in ("qt0", "qtm") if qt else ():      # (x ghost columns included: xq_periodic's)
+                ref = marr(fix, f"{tag}.{k}", g.nz)
+                assert relerr(nocorner(core.download(k)[1:-1]), nocorner(ref[1:-1])) <= RUN_TOL, (tag, k)
             for k in ("u0", "v0", "w0", "pres0", "um", "vm", "wm"):
                 ref = marr(fix, f"{tag}.{k}", g.nz)
                 assert relerr(nocorner(core.download(k)[1:-1]), nocorner(ref[1:-1])) <= RUN_TOL, (tag, k)
@@ -207,7 +226,7 @@ def test_substeps_match_reference(name, iexp, fused):
     core.close()
 
 
-@pytest.mark.parametrize("name", ["run_xopen_16x8x12s", "run_xopen_ibmwf3_16x12x10", "run_xopen_thl_16x8x12s", "run_xopen_ibm_sv_16x12x10"])
+@pytest.mark.parametrize("name", ["run_xopen_16x8x12s", "run_xopen_ibmwf3_16x12x10", "run_xopen_thl_16x8x12s", "run_xopen_ibm_sv_16x12x10", "run_xopen_moist_16x8x12s"])
 def test_cold_start_matches_reference(name):
     """From the deck alone, the way run_case.py starts: the fields as readinitfiles leaves them (the x ghost columns hold the
     profile, no noise), the start-up's slab averages, its `boundary` (uouttot from those averages, one convective step with
@@ -231,7 +250,7 @@ def test_cold_start_matches_reference(name):
     assert np.abs(marr(fix, "s000.v0", g.nz)[1:-1, 1:-1, -1] - vin).max() > 1e-6      # (the start-up's convective step moved the outlet)
     for isub in range(1, 4):
         core.substep(isub, dt, with_forces=True)
-    for k in ("u0", "v0", "w0", "pres0", "vm") + (("thl0",) if core.ltempeq else ()):
+    for k in ("u0", "v0", "w0", "pres0", "vm") + (("thl0",) if core.ltempeq else ()) + (("qt0",) if core.lmoist else ()):
         ref = marr(fix, "s003." + k, g.nz)
         assert relerr(nocorner(core.download(k)[1:-1]), nocorner(ref[1:-1]), 1.0 if k == "thl0" else None) <= RUN_TOL, k
     for n in range(core.nsv):
@@ -254,7 +273,7 @@ def test_fortran_driver_with_dropin_modules(name, iexp, residency, tmp_path):
             assert relerr(got[key].data[2:-2, 2:-2, :], ref.data[2:-2, 2:-2, :]) <= RUN_TOL, key
             checked += 1
             continue
-        if "." not in key or key.split(".")[1] not in ("u0", "v0", "w0", "pres0", "um", "vm", "wm", "thl0", "thlm"):
+        if "." not in key or key.split(".")[1] not in ("u0", "v0", "w0", "pres0", "um", "vm", "wm", "thl0", "thlm", "qt0", "qtm"):
             continue
         a, b = got[key].data[1:-1], ref.data[1:-1]
         sc = 1.0 if (key.split(".")[1].startswith("thl") or np.abs(b).max() == 0) else None
@@ -264,7 +283,8 @@ def test_fortran_driver_with_dropin_modules(name, iexp, residency, tmp_path):
     assert abs(got["s000.uouttot"].data[0] - fix["s000.uouttot"].data[0]) <= 1e-13
 
 
-@pytest.mark.parametrize("name,iexp", [("run_xopen_16x8x12s", 91), ("run_xopen_thl_16x8x12s", 101), ("run_xdriver_16x8x12s", 96), ("run_xdriver_ibm_16x12x10", 98)])
+@pytest.mark.parametrize("name,iexp", [("run_xopen_16x8x12s", 91), ("run_xopen_thl_16x8x12s", 101), ("run_xdriver_16x8x12s", 96), ("run_xdriver_ibm_16x12x10", 98),
+                                       ("run_xopen_ibm_moist_16x12x10", 108), ("run_xdriver_moist_16x12x10", 110)])
 @pytest.mark.parametrize("residency", [2, 0])
 def test_through_the_reference_program(name, iexp, residency, tmp_path):
     """u-dales_amd/bin/udales_full_dropin -- the reference's own program.f90, start-up, time loop and writerestartfiles over the
@@ -278,7 +298,7 @@ def test_through_the_reference_program(name, iexp, residency, tmp_path):
     (tmp_path / "dev").mkdir()
     fix, last, rs, _ = run_full(name, iexp, tmp_path / "dev", exe=exe, env=dict(os.environ, UDC_RESIDENCY=str(residency)))
     nz = int(fix["meta"].data[2])
-    ref = {k: fix[f"{last}.{k}"].data for k in ("u0", "v0", "w0", "pres0") + (("thl0",) if f"{last}.thl0" in fix else ())}
+    ref = {k: fix[f"{last}.{k}"].data for k in ("u0", "v0", "w0", "pres0") + (("thl0",) if f"{last}.thl0" in fix else ()) + (("qt0",) if f"{last}.qt0" in fix else ())}
     if name in D_CASES:
         # (the program stopped by `runtime` skips the last step's drivergen, src/moddriver.f90:216, which the fixture's driver makes:
         #  the all-reference program run the same way is the counterpart; it travels with the snapshot)
@@ -287,7 +307,7 @@ def test_through_the_reference_program(name, iexp, residency, tmp_path):
             pytest.skip("oracle/_ref/udales_full not built")
         (tmp_path / "ref").mkdir()
         ref = run_full(name, iexp, tmp_path / "ref", exe=FULL)[2]
-    for k in [q for q in ("u0", "v0", "w0", "pres0", "thl0") if f"{last}.{q}" in fix]:
+    for k in [q for q in ("u0", "v0", "w0", "pres0", "thl0", "qt0") if f"{last}.{q}" in fix]:
         a, b = rs[k][1:nz + 1], ref[k][1:nz + 1]
         assert relerr(nocorner(a), nocorner(b), 1.0 if k == "thl0" else None) <= RUN_TOL, k
     assert np.abs(fix[f"{last}.v0"].data[1:nz + 1, 1:-1, -1] - fix[f"{last}.v0"].data[1:nz + 1, 1:-1, -2]).max() > 1e-4

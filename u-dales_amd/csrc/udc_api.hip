@@ -601,7 +601,6 @@ extern "C" int udc_set_tempeq(udc_handle *h, int iadv_thl, int bctopt, double wt
     udc_set_error("udc_set_tempeq: with open x boundaries the temperature takes the central scheme (iadv_thl = 2; kappa reads two ghost columns)");
     return 1;
   }
-  if (h->xg && h->lmoist) { udc_set_error("udc_set_tempeq: no moisture with open x boundaries yet"); return 1; }
   if (h->cfg.nsv > 15) { udc_set_error("udc_set_tempeq: thl uses scalar slot 15, nsv must be <= 15"); return 1; }
   if (iadv_thl != 2 && iadv_thl != 7) { udc_set_error("udc_set_tempeq: iadv_thl must be 2 (cd2, advecc_2nd) or 7 (kappa, advecc_kappa)"); return 1; }
   if (bctopt != 1 && bctopt != 2) { udc_set_error("udc_set_tempeq: BCtopT must be 1 (flux) or 2 (value)"); return 1; }
@@ -707,7 +706,6 @@ extern "C" int udc_set_floor_wf(udc_handle *h, int bcbotm, int bcbott, double th
 }
 
 extern "C" int udc_set_moisture(udc_handle *h, int iadv_qt, int bctopq, double wqtop, double qt_top, int bcbotq, double wqsurf) {
-  NO_OPEN_X(h, "udc_set_moisture");
   ENTRY_FLUSH(h);
   if (h->cfg.nsv > 13) { udc_set_error("udc_set_moisture: qt uses scalar slot 13, nsv must be <= 13"); return 1; }
   if (iadv_qt != 2) { udc_set_error("udc_set_moisture: only iadv_qt = 2 (cd2, advecc_2nd) exists (src/modadvection.f90:79-85)"); return 1; }

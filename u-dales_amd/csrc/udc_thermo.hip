@@ -123,10 +123,11 @@ __global__ __launch_bounds__(256) void moist_sums_kernel(Geo g, int gx, const do
     if (i < g.nx && j < g.ny) {
       const long c = g.idx(i, j, k);
       const double a = thl[c], b = qt[c];
-      v[0] += a; v[1] += b;
+      const bool in = i >= g.xg && i < g.nx - g.xg;      // (open x boundaries: the averages run over ib .. ie)
+      if (in) { v[0] += a; v[1] += b; }
       if (QL) {
         const double ql = th_cond(nr, a, b, pf, ef);
-        v[2] += ql;
+        if (in) v[2] += ql;
         if (ql0) ql0[c - g.sz] = ql;      // the reference's ql0 holds level k at k-1 (sequence association in `thermo`)
       }
     }
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256) void thv_sums_kernel(Geo g, Metrics m, int gx,
 #pragma unroll
     for (int r = 0; r < MS_ROWS; ++r) {
       const int j = (by * MS_ROWS + r) * 4 + threadIdx.y;
-      if (i < g.nx && j < g.ny) v += thv_half(g, m, thl, qt, ph, eh, g.idx(i, j, k), k, nr);
+      if (i >= g.xg && i < g.nx - g.xg && j < g.ny) v += thv_half(g, m, thl, qt, ph, eh, g.idx(i, j, k), k, nr);
     }
   }
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -430,7 +431,7 @@ int k_thermodynamics(udc_handle *h) {
   if (lev_scratch(h, (size_t)mtiles * ke1 * 3)) return 1;
   const double *thl = h->fields[UDC_THL0], *qt = h->fields[UDC_QT0];
   double *mt = h->mt, *sums = mt + udc_handle::MT_SUMS * n2;
-  const double cnt = (double)g.nx * (double)h->cfg.jtot;
+  const double cnt = (double)(g.nx - 2 * g.xg) * (double)h->cfg.jtot;
   const DiagArgs da{g.nz, cnt, h->thls, h->qts, h->ps, h->grav};
   double *ql0 = nullptr;      // kept as a field only where something reads it: the one-equation closure's moist dthvdz
   if (h->p.sgs == UDC_SGS_ONEEQN || h->lbuoycorr) {      // (and the Vreman buoyancy correction's)

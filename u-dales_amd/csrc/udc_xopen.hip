@@ -173,6 +173,18 @@ __global__ void xo_thl_restore_kernel(Geo g, int stage3, double *__restrict__ t0
   t0[r] = w0; tm[r] = wm;
 }
 
+// the temperature and the total water where they stay periodic in x while the flow enters and leaves (&BC BCxT = 1 / BCxq = 1 next to
+// BCxm = 2 / 3: the reference's defaults, its tests/cases/525): `halos` refreshes their x ghosts right after every integration
+// (xT_periodic, xq_periodic, src/modboundary.f90:543-577, called under `ibrank .and. ierank`, :95-100) -- every row and level the arrays hold
+__global__ void xo_wrap_kernel(Geo g, double *__restrict__ f0, double *__restrict__ fm) {
+  int jj, kk;
+  if (!plane_decode(g, jj, kk)) return;
+  const long r = (long)g.sy * jj + g.sz * kk + (g.xg - 1);
+  const int e = g.nx - 2 * g.xg + 1;
+  f0[r] = f0[r + e - 1]; f0[r + e] = f0[r + 1];
+  fm[r] = fm[r + e - 1]; fm[r + e] = fm[r + 1];
+}
+
 // passive scalars (c-arrays, kappa scheme: two ghost columns either side).  xsi_profile (src/modboundary.f90:844-861: on jb .. je, kb .. ke+1,
 // sv(ib-1) = 2 svprof - sv(ib), sv(ib-2) = 2 svprof - sv(ib-1), sv0 and svm), xso_convective (:983-996: sv(ie+1) on every row and level; ie+2
 // stays what it is); cols [8][P]: sv0 at ib-2, ib-1, ie+1, ie+2, then svm
@@ -437,6 +449,10 @@ int k_xo_after_integrate(udc_handle *h, int rk3step) {
   if (h->xo_thl_prof)
     hipLaunchKernelGGL(xo_thl_restore_kernel, plane_grid(g), dim3(64), 0, h->stream, g, rk3step == 3 ? 1 : 0, h->fields[UDC_THL0],
                        h->fields[UDC_THLM], h->xo_thl_east, h->xo_thl_west);
+  else if ((int)h->fields.size() > UDC_THL0 && h->fields[UDC_THL0])      // BCxT = 1: periodic (halos' xT_periodic)
+    hipLaunchKernelGGL(xo_wrap_kernel, plane_grid(g), dim3(64), 0, h->stream, g, h->fields[UDC_THL0], h->fields[UDC_THLM]);
+  if (h->lmoist && (int)h->fields.size() > UDC_QT0 && h->fields[UDC_QT0])      // BCxq = 1 (xq_periodic)
+    hipLaunchKernelGGL(xo_wrap_kernel, plane_grid(g), dim3(64), 0, h->stream, g, h->fields[UDC_QT0], h->fields[UDC_QTM]);
   for (int n = 0; n < h->cfg.nsv && n < 13; ++n)
     if (h->xo_sv_cols[n])
       hipLaunchKernelGGL(xo_sv_restore_kernel, plane_grid(g), dim3(64), 0, h->stream, g, rk3step == 3 ? 1 : 0, h->fields[UDC_SV0 + 3 * n],

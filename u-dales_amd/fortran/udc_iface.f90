@@ -725,7 +725,7 @@ contains
   !! boundary / thermodynamics), so this runs with every start-up call and a last time when the time loop starts.
   subroutine udc_late_setup
     use modglobal, only: ktot, kb, ke, nsv, ltempeq, BCtops, lcoriol, lprofforc, om22, om23, luvolflowr, lvvolflowr, luoutflowr, &
-                         uflowrate, vflowrate, lnudge, igrw_damp, ifixuinf, ds, BCxs, BCxm, BCxT, kh
+                         uflowrate, vflowrate, lnudge, igrw_damp, ifixuinf, ds, BCxs, BCxm, BCxT, BCxq, lmoist, kh
     use modsurfdata, only: wsvtop, sv_top
     use modfields, only: thlprof, dpdxl, dpdyl, thlpcar, ug, whls, dthldxls, dthldyls, dqtdxls, dqtdyls, dqtdtls, &
                          dudxls, dudyls, dvdxls, dvdyls
@@ -735,14 +735,22 @@ contains
     if (BCxm == 2 .or. BCxm == 3) then      ! (the handle may be older than prof.inp's profiles)
       call open_x_profiles(xo_u, xo_v)
       call udc_check(udc_set_open_x_profile(udc_h, xo_u, xo_v), 'udc_set_open_x_profile')
-      if (ltempeq) then      ! the temperature enters with its profile (xTi_profile); planes of a precursor run (BCxT = 3) are not taken yet
-        if (BCxT /= 2) then
-          write (0, *) 'ERROR: libudcore: inflow / outflow in x with the temperature equation needs BCxT = 2 (inflow profile, convective outflow)'
+      if (ltempeq) then      ! BCxT = 2: the temperature enters with its profile (xTi_profile); BCxT = 1 (the reference's default, its
+        ! tests/cases/525): it stays periodic in x (halos' xT_periodic) -- the library's own refresh of a handle without an inflow profile;
+        ! planes of a precursor run (BCxT = 3) are not taken yet
+        if (BCxT /= 1 .and. BCxT /= 2) then
+          write (0, *) 'ERROR: libudcore: inflow / outflow in x with the temperature equation needs BCxT = 1 (periodic) or 2 (inflow profile, convective outflow)'
           stop 1
         end if
-        xo_u = 0.
-        if (allocated(thlprof)) xo_u(1:ktot + 1) = thlprof(kb:ke + kh)
-        call udc_check(udc_set_open_x_thl(udc_h, xo_u), 'udc_set_open_x_thl')
+        if (BCxT == 2) then
+          xo_u = 0.
+          if (allocated(thlprof)) xo_u(1:ktot + 1) = thlprof(kb:ke + kh)
+          call udc_check(udc_set_open_x_thl(udc_h, xo_u), 'udc_set_open_x_thl')
+        end if
+      end if
+      if (lmoist .and. BCxq /= 1) then      ! (xqi_profile / xqi_driver are not on the device)
+        write (0, *) 'ERROR: libudcore: inflow / outflow in x with moisture needs BCxq = 1 (periodic)'
+        stop 1
       end if
     end if
     if (ltempeq) then

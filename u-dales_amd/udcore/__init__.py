@@ -44,10 +44,12 @@ def from_deck(deck, device=0, rank=0, nranks=1):
                         bctopt=int(deck.get("BC", "BCtopT")), wttop=float(deck.get("BC", "wttop")),
                         thl_top=float(deck.get("BC", "thl_top")), bcbott=int(deck.get("BC", "BCbotT")),
                         wtsurf=float(deck.get("BC", "wtsurf")), thlpcar=getattr(deck, "thlpcar", None))
-        if bcxm == 2:      # inflow / outflow: the temperature enters with prof.inp's profile too (xTi_profile), thlprof(ke+1) = 0 as allocated
-            if int(deck.get("BC", "BCxT")) != 2:
-                raise ValueError("&BC BCxm = 2 with the temperature equation: BCxT = 2 (inflow profile, convective outflow) is what the device path has")
-            core.set_open_x_thl(np.concatenate(([0.], np.asarray(deck.thl, dtype=float)[:g.nz], [0.])))
+        if bcxm == 2:      # inflow / outflow: BCxT = 2, the temperature enters with prof.inp's profile too (xTi_profile), thlprof(ke+1) = 0 as
+            # allocated; BCxT = 1 (the reference's default, its tests/cases/525): the temperature stays periodic (halos' xT_periodic)
+            if int(deck.get("BC", "BCxT")) not in (1, 2):
+                raise ValueError("&BC BCxm = 2 with the temperature equation: BCxT = 1 (periodic) or 2 (inflow profile, convective outflow) is what the device path has")
+            if int(deck.get("BC", "BCxT")) == 2:
+                core.set_open_x_thl(np.concatenate(([0.], np.asarray(deck.thl, dtype=float)[:g.nz], [0.])))
     if lbottom and bcbotm == 2 and not deck.get("PHYSICS", "ltempeq"):
         # the reference's thl0 stays at prof.inp's profile when the temperature equation is off; wfuno reads its first level
         core.set_floor_air_temperature(float(deck.thl[0]))
