@@ -1001,6 +1001,48 @@ def make_example_950():
     print(f"full_example_950: {len(keep)} records, {os.path.getsize(tmpf + '.gz') / 1024:.0f} kB; case {sum(os.path.getsize(os.path.join(cdir, f)) for f in os.listdir(cdir)) / 1e6:.1f} MB")
 
 
+# tests/cases/525 of the reference -- trees over a flat floor with BCxm = 3, the temperature and the moisture periodic -- cannot run through
+# the solver as shipped, the reference's own included: it is a pre-processing case (tests/integration/directshortwave), its deck says
+# runmode = 1005 and facet_sections_u / _v / _c.txt are not in the tree (initibmwallfun stops at src/modibm.f90:352).  Its sibling 526 is
+# complete and is the same set-up at a quarter of the resolution with periodic momentum: so the inflow / outflow of 525 is put on 526 --
+# BCxm = 3 from the planes of a precursor derived from 526's own deck (a periodic channel 16 cells long on the same y-z grid, no trees, no
+# obstacles, fixed step; iexpnr 301 = the driverjobnr both decks name), kept with the case as data.
+def c526_open_decks(txt):
+    """(driven deck, precursor deck) from namoptions.526.serial"""
+    import re
+    drv = re.sub(r"BCxm\s*=\s*1", "BCxm         = 3", txt)
+    drv = re.sub(r"idriver\s*=\s*0", "idriver      = 2", re.sub(r"driverstore\s*=\s*\d+", "driverstore  = 8", drv))
+    pre = re.sub(r"iexpnr\s*=\s*526", "iexpnr       = 301", txt)
+    pre = re.sub(r"libm\s*=\s*\.true\.", "libm         = .false.", pre)
+    pre = re.sub(r"itot\s*=\s*128", "itot         = 16", re.sub(r"xlen\s*=\s*256", "xlen         = 32", pre))
+    pre = re.sub(r"BCtopm\s*=\s*3", "BCtopm       = 1", pre).replace("ladaptive    = .true.", "ladaptive    = .false.")
+    pre = re.sub(r"runtime\s*=\s*[0-9.]+", "runtime      = 0.085", pre)
+    for grp in ("WALLS", "OUTPUT", "INPS", "TREES"):
+        pre = re.sub(r"&" + grp + r"\b.*?\n/\n", "", pre, flags=re.S)
+    pre = re.sub(r"&DRIVER\b.*?\n/\n", "&DRIVER\nidriver      = 1\ntdriverstart = 0.\ndtdriver     = 0.01\ndriverstore  = 8\niplane       = 8\n/\n", pre, flags=re.S)
+    assert "idriver      = 1" in pre and "&WALLS" not in pre and "&TREES" not in pre and "driverstore  = 8" in drv and "BCxm         = 3" in drv
+    return drv, pre
+
+
+def make_case_526_open():
+    src = "/root/reference/tests"
+    cdir = os.path.join(HERE, "cases", "case_526_open")
+    os.makedirs(cdir, exist_ok=True)
+    with open(os.path.join(src, "integration", "processor_boundaries", "namoptions.526.serial")) as f:
+        _, pre = c526_open_decks(f.read())
+    with tempfile.TemporaryDirectory() as tmp:
+        for a in ("prof", "lscale"):
+            shutil.copy(os.path.join(src, "cases", "526", f"{a}.inp.526"), os.path.join(tmp, f"{a}.inp.301"))
+        with open(os.path.join(tmp, "namoptions.301"), "w") as f:
+            f.write(pre)
+        subprocess.check_call(["bash", "-c", f"ulimit -s unlimited; exec {FULL} namoptions.301"], cwd=tmp, stdout=subprocess.DEVNULL)
+        got = sorted(fn for fn in os.listdir(tmp) if "driver_" in fn)
+        for fn in got:
+            with open(os.path.join(tmp, fn), "rb") as f, gzip.GzipFile(os.path.join(cdir, fn + ".gz"), "wb", mtime=0) as gz:
+                gz.write(f.read())
+    print(f"case_526_open: the precursor's planes {got}, {sum(os.path.getsize(os.path.join(cdir, f)) for f in os.listdir(cdir)) / 1e3:.0f} kB")
+
+
 def split_scal(kw):
     """scal_a / scal_b in a case's `oracle` text describe scalar.inp (they were a group of the driver once): taken out of the deck."""
     import re
@@ -1151,6 +1193,9 @@ def main():
     if only == {"full_example_950"}:
         make_example_950()
         return
+    if only == {"case_526_open"}:
+        make_case_526_open()
+        return
     if not only or any(n in DRIVER_CASES for n in only):
         make_driver_cases(only)
     if only and all(n in DRIVER_CASES for n in only):
@@ -1159,6 +1204,8 @@ def main():
     make_example_cases(only)
     if not only or "case_100" in only or "case_526" in only:
         make_reference_test_cases()
+    if not only or "case_526_open" in only:
+        make_case_526_open()
     for ex in FULL_EXAMPLES:
         if not only or f"full_example_{ex}" in only:
             make_full_example(ex)

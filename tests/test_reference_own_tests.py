@@ -320,3 +320,75 @@ def test_processor_boundaries_case_526(steps, tmp_path):
                 f.write(f"{label:36s} {k}: {v:.3e}\n")
     bad = {k: v for k, v in worst.items() if not v <= TOL}
     assert not bad, bad
+
+
+# ---- 2c. case 526 under the boundary conditions of case 525 ------------------------------------------------------------------------
+def stage_526_open(tmp, steps):
+    """tests/cases/526 with the inflow of tests/cases/525: BCxm = 3 from the planes of a precursor run (tests/golden/make_golden.py,
+    make_case_526_open: the reference itself on a periodic channel derived from 526's deck), temperature and moisture left periodic in x
+    as both decks have them.  525 itself cannot run through anybody's solver: the reference ships it without facet_sections_u / _v / _c.txt
+    (it is the pre-processing case of tests/integration/directshortwave; src/modibm.f90:352 stops on the missing file)."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from make_golden import c526_open_decks
+    stage(tmp, "namoptions.526.serial", case=526, steps=steps)
+    deck = os.path.join(tmp, "namoptions.526")
+    with open(deck) as f:
+        txt = c526_open_decks(f.read())[0]
+    if steps is not None:      # one restart file near the end: the state with the outlet's columns
+        dtmax = float(re.search(r"dtmax\s*=\s*([0-9.eE+-]+)", txt).group(1))
+        txt = re.sub(r"trestart\s*=\s*[0-9.eE+-]+", f"trestart     = {dtmax * (steps - 1.5)!r}", txt)
+    with open(deck, "w") as f:
+        f.write(txt)
+    cdir = os.path.join(GOLDEN, "cases", "case_526_open")
+    for fn in os.listdir(cdir):
+        with gzip.open(os.path.join(cdir, fn), "rb") as f, open(os.path.join(tmp, fn[:-3]), "wb") as o:
+            o.write(f.read())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("steps", [None, 6])
+def test_case_526_with_the_inflow_of_case_525(steps, tmp_path):
+    """Trees (the reference's vegetation.f90 on the host), a floor that is an immersed boundary with facet wall functions, temperature +
+    moisture + buoyancy, the open lid, the adaptive step -- and the flow entering from a precursor's planes and leaving through a convective
+    outlet (BCxm = 3) while thl and qt stay periodic (BCxT = BCxq = 1): what tests/cases/525 describes, on the files of 526.  Through
+    udales_full_dropin_hoststats against the all-reference executable: treedump's tr_u, tr_v, tr_w, tdump's ut, vt, wt, and the restart
+    file's u0, v0, w0, thl0, qt0 with the outlet's columns, <= 1e-9 (the reference's ABS_TOL)."""
+    if not (os.path.exists(FULL) and os.path.exists(DROPIN_HS)):
+        pytest.skip("oracle/_ref/udales_full or u-dales_amd/bin/udales_full_dropin_hoststats not built")
+    sys_path = os.path.join(ROOT, "u-dales_amd")
+    import sys
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    from udcore import restart
+    want_tr, want_t = ("tr_u", "tr_v", "tr_w"), ("ut", "vt", "wt")
+    out = {}
+    for label, exe, env in (("ref", FULL, None), ("dev", DROPIN_HS, dict(os.environ, UDC_RESIDENCY="2"))):
+        d = tmp_path / label
+        stage_526_open(d, steps)
+        r = run(d, exe, env=env, case=526)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        o = tdump_fields(d, 1, 526, "treedump", want_tr)
+        o.update(tdump_fields(d, 1, 526, "tdump", want_t))
+        out[label] = o
+        if steps is not None:      # (trestart shortened to the run's end: the restart file with the x ghost columns)
+            rst = sorted(f for f in os.listdir(d) if f.startswith("initd") and f.endswith(".526"))
+            assert rst, sorted(os.listdir(d))
+            rs = restart.read_initd(os.path.join(d, rst[-1]), 128, 64, 64)
+            o["rst.time"] = np.array([rs["timee"], rs["dt"], float(len(rst))])
+            for k in ("u0", "v0", "w0", "thl0", "qt0"):
+                o["rst." + k] = rs[k][1:65, 1:65, :]
+        if label == "dev":
+            assert "UDC_RESIDENCY=0" in r.stdout      # (asks for 2, gets 0: the trees)
+    ref, dev = out["ref"], out["dev"]
+    assert np.abs(ref["tr_u"]).max() > 0.1
+    # the flow is not periodic: what leaves differs from what enters
+    assert np.abs(ref["ut"][:, :, 0] - ref["ut"][:, :, -1]).max() > 1e-3
+    worst = {k: float(np.abs(dev[k] - ref[k]).max()) for k in ref}
+    if os.environ.get("UDC_TEST_KEEP_LOGS"):
+        with open(os.path.join(os.environ["UDC_TEST_KEEP_LOGS"], f"case526_with_inflow_of_525_{steps or 1}steps.txt"), "w") as f:
+            f.write(f"max |udales_full_dropin_hoststats - all-reference run| after {steps or 1} step(s) of tests/cases/526 with BCxm = 3 (tolerance 1e-9)\n")
+            for k, v in worst.items():
+                f.write(f"{k:10s} {v:.3e}\n")
+    bad = {k: v for k, v in worst.items() if not v <= TOL}
+    assert not bad, bad
