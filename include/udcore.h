@@ -523,6 +523,16 @@ int udc_set_open_x_profile(udc_handle *h, const double *uprof, const double *vpr
  * `boundary`; thl0 / thlm at ie+1 are state like v and w there (udc_field_upload takes them from a host array that carries the column).
  * Not with the kappa scheme.  Without this call the temperature is periodic in x (BCxT = 1). */
 int udc_set_open_x_thl(udc_handle *h, const double *thlprof);
+/* The total water's inflow profile (&BC BCxq = 2; after udc_set_moisture): qtprof [ktot+2] by the reference's k.  xqi_profile
+ * (src/modboundary.f90:811-823: qt(ib-1) = 2 qtprof - qt(ib) on jb-1 .. je+1, kb .. ke+1) and xqo_convective (:961-971 -- which starts from
+ * qt(ie), not from qt(ie+1): kept) with every `boundary`.  Without this call the total water is periodic in x (BCxq = 1). */
+int udc_set_open_x_qt(udc_handle *h, const double *qtprof);
+/* &BC BCxT = 3 / BCxq = 3 / BCxs = 3 (next to BCxm = 3): a scalar's inlet ghost columns from the planes the reference's drivergen leaves
+ * in modinletdata -- field = UDC_THL0 (thl0driver, thlmdriver -> xTi_driver, :795-808), UDC_QT0 (qt0driver, qtmdriver -> xqi_driver,
+ * :826-839), the sv0 of passive scalar n (sv0driver(:, :, n), svmdriver(:, :, n) -> xsi_driver, :883-901: both ghost columns; after
+ * udc_set_open_x_scalars) --, each (lb[0]:ub[0], lb[1]:ub[1]) in the reference's j, k (j fastest) covering jb-1 .. je+1, kb .. ke+1.  Handed
+ * over after every drivergen like the flow's planes (udc_set_open_x_inlet); the next `boundary` applies them, the outlet is convective. */
+int udc_set_open_x_inlet_scalar(udc_handle *h, int field, const double *f0driver, const double *fmdriver, const int lb[2], const int ub[2]);
 /* Passive scalars on such a handle (&BC BCxs = 2 with BCxm = 2 / 3; cfg->nsv > 0 gives the rows two ghost columns either side, ib-2 .. ie+2:
  * advecc_kappa reads i-2 .. i+1): the inflow profiles svprof [nsv][ktot+2] by the reference's k.  xsi_profile (src/modboundary.f90:844-861:
  * sv(ib-1) = 2 svprof - sv(ib), sv(ib-2) = 2 svprof - sv(ib-1), rows jb .. je, levels kb .. ke+1) and xso_convective (:983-996: sv(ie+1)) run

@@ -540,6 +540,10 @@ CASES.update({
     "run_xopen_moist_16x8x12s": ("run", 107, 16, 8, 12, dict(sgs="smag", floor=True, bctopm=3, randu=0.05, physics="lmoist = .true.\nltempeq = .true.\nlbuoyancy = .true.",
                                                              bc="BCxm = 2\nBCtopT = 2\nthl_top = 290.5\nBCbotT = 1\nwtsurf = 0.04\nthls = 288.0\nqts = 0.0105\nBCtopq = 2\nqt_top = 0.0104\nBCbotq = 1\nwqsurf = 5.e-5",
                                                              oracle="nsub = 9\ndump_at = 3, 9"), 1.06),
+    # ... and with both entering: BCxT = 2, BCxq = 2 (xqi_profile mirrors the ghost about the profile; xqo_convective)
+    "run_xopen_qt2_16x8x12s": ("run", 111, 16, 8, 12, dict(sgs="smag", floor=True, bctopm=3, randu=0.05, physics="lmoist = .true.\nltempeq = .true.\nlbuoyancy = .true.",
+                                                           bc="BCxm = 2\nBCxT = 2\nBCxq = 2\nBCtopT = 2\nthl_top = 290.5\nBCbotT = 1\nwtsurf = 0.04\nthls = 288.0\nqts = 0.0105\nBCtopq = 2\nqt_top = 0.0104\nBCbotq = 1\nwqsurf = 5.e-5",
+                                                           oracle="nsub = 9\ndump_at = 3, 9"), 1.06),
     # ... with passive scalars: BCxs = 2 (xsi_profile, xso_convective), one and two scalars, the second deck with obstacles and wall functions
     "k_xopen_sv_16x8x12": ("kernels", 102, 16, 8, 12, dict(sgs="vreman", nsv=2, floor=True, bctopm=3, randu=0.05, bc="BCxm = 2\nBCxs = 2", oracle="nspin = 4"), 1.04),
     "run_xopen_sv_16x8x12s": ("run", 103, 16, 8, 12, dict(sgs="smag", nsv=1, floor=True, bctopm=3, randu=0.05, bc="BCxm = 2\nBCxs = 2", oracle="nsub = 9\ndump_at = 3, 9"), 1.06),
@@ -732,7 +736,7 @@ THL_CASES = {"k_tke_moist_12x8x8": dict(dthl=0.25, qt=0.0118, dqt=-8e-5, tke=0.0
              "k_qt_12x8x6": dict(dthl=0.3, qt=0.008, dqt=-4e-4), "run_qt_16x8x12s": dict(dthl=0.25, qt=0.007, dqt=-2e-4),
              "k_lsf_12x8x24": dict(dthl=0.3, ug=1.05, wtop=0.02), "run_lsf_16x8x24s": dict(dthl=0.25, ug=0.95, wtop=-0.03), "k_tke_12x8x6": dict(tke=0.05), "k_tke_thl_12x8x6": dict(tke=0.08, dthl=0.3), "k_coriol_12x8x6": dict(ug=1.1), "run_profforc_16x16x8": dict(ug=1.3), "k_thl_12x8x6": dict(dthl=0.4, dthlrad=2e-3), "run_thl_16x8x12s": dict(dthl=0.25, dthlrad=-1e-3),
              "k_buoy_12x8x6": dict(dthl=0.3), "run_buoy_16x8x12s": dict(dthl=0.2),
-             "k_xopen_moist_16x8x12": dict(v=0.1, dthl=0.25, qt=0.0118, dqt=-8e-5), "run_xopen_moist_16x8x12s": dict(v=0.1, dthl=0.25, qt=0.0119, dqt=-6e-5),
+             "k_xopen_moist_16x8x12": dict(v=0.1, dthl=0.25, qt=0.0118, dqt=-8e-5), "run_xopen_moist_16x8x12s": dict(v=0.1, dthl=0.25, qt=0.0119, dqt=-6e-5), "run_xopen_qt2_16x8x12s": dict(v=0.1, dthl=0.25, qt=0.0119, dqt=-6e-5),
              "run_xopen_ibm_moist_16x12x10": dict(u=0.9, v=0.15, dthl=0.25, qt=0.0119, dqt=-6e-5),
              "k_xopen_16x8x12": dict(v=0.1), "run_xopen_16x8x12s": dict(v=0.1), "k_xopen_sv_16x8x12": dict(v=0.1), "run_xopen_sv_16x8x12s": dict(v=0.1), "run_xopen_ibm_sv_16x12x10": dict(u=0.9, v=0.15), "run_xopen_ibm_thl_16x12x10": dict(u=0.9, v=0.15, dthl=0.25), "k_xopen_thl_16x8x12": dict(v=0.1, dthl=0.3), "run_xopen_thl_16x8x12s": dict(v=0.1, dthl=0.25), "run_xopen_volflow_16x8x12s": dict(v=0.1), "run_xopen_vr_24x8x10": dict(u=0.8, v=-0.05), "run_xopen_ibm_16x12x10": dict(v=0.1), "run_xopen_ibmwf3_16x12x10": dict(u=0.9, v=0.15),
              "k_ibm_thl_16x12x10": dict(dthl=0.3), "run_ibm_thl_16x12x10": dict(dthl=0.25), "run_ptop_ibm_16x12x10": dict(dthl=0.25), "run_ibm_thlcons_16x12x10": dict(dthl=0.25),
@@ -1100,6 +1104,11 @@ DRIVER_CASES = {
     "run_xdriver_moist_16x12x10": (110, 109, 16, 12, 10, dict(_IBM_MOIST, nsv=0, bctopm=3, bc="BCxm = 3\n" + _IBM_MOIST["bc"], walls="iwalltemp = 2\niwallmoist = 2",
                                                               ENERGYBALANCE="wsoil = 300.\nwfc = 313."), 1.0, dict(u=0.9, v=0.15, dthl=0.25, qt=0.0119, dqt=-6e-5)),
 }
+# ... and the scalars entering from the precursor's planes too: BCxT = BCxq = BCxs = 3 (xTi_driver, xqi_driver, xsi_driver, the convective
+# outlets xTo / xqo / xso_convective), temperature + moisture + buoyancy + a passive scalar
+DRIVER_CASES["run_xdriver_scal_16x8x12s"] = (113, 112, 16, 8, 12, dict(sgs="smag", nsv=1, floor=True, bctopm=3, randu=0.05, physics="lmoist = .true.\nltempeq = .true.\nlbuoyancy = .true.",
+    bc="BCxm = 3\nBCxT = 3\nBCxq = 3\nBCxs = 3\nBCtopT = 2\nthl_top = 290.5\nBCbotT = 1\nwtsurf = 0.04\nthls = 288.0\nqts = 0.0105\nBCtopq = 2\nqt_top = 0.0104\nBCbotq = 1\nwqsurf = 5.e-5"),
+    1.06, dict(v=0.1, dthl=0.25, qt=0.0119, dqt=-6e-5))
 IBM_BLOCKS["run_xdriver_ibm_16x12x10"] = IBM_BLOCKS["run_ibm_16x12x10"]
 WF_CASES["run_xdriver_ibm_16x12x10"] = 3
 IBM_BLOCKS["run_xdriver_moist_16x12x10"] = IBM_BLOCKS["run_ibm_16x12x10"]
@@ -1121,17 +1130,17 @@ def make_driver_cases(only):
                        extra=f"&DRIVER\nidriver = 1\ntdriverstart = 0.\ndtdriver = 0.25\ndriverstore = {nstore}\niplane = {nx // 2 + 1}\n/",
                        oracle=f"nsub = {3 * nstore + 3}")
             if "physics" in kw and "lmoist" in kw["physics"]:      # (the precursor carries the same equations)
-                pre.update(physics=kw["physics"], bc=kw["bc"].replace("BCxm = 3\n", ""))
-            write_case(tmp, ipre, deck(ipre, nx, ny, nz, **pre), zf, **prof)
+                pre.update(physics=kw["physics"], bc="\n".join(ln for ln in kw["bc"].split("\n") if not ln.startswith("BCx")), nsv=kw.get("nsv", 0))
+            write_case(tmp, ipre, deck(ipre, nx, ny, nz, **pre), zf, nsv=pre.get("nsv", 0), **prof)
             subprocess.check_call([REF, f"namoptions.{ipre:03d}", "run", os.path.join(tmp, "pre.bin")], cwd=tmp, stdout=subprocess.DEVNULL)
-            for q in "uvwt":
+            for q in "uvwt" + ("hqs" if "BCxT = 3" in kw.get("bc", "") else ""):
                 shutil.copy(os.path.join(tmp, f"{q}driver_000.{ipre:03d}"), cdir)
         ibm = IBM_BLOCKS.get(name)
         kw = dict(kw)
         eb = kw.pop("ENERGYBALANCE", None)
         dk = dict(kw, ibm=ibm, extra=f"&DRIVER\nidriver = 2\ndriverjobnr = {ipre}\ndriverstore = {nstore}\n/" + (f"\n&ENERGYBALANCE\n{eb}\n/" if eb else ""),
                   oracle=f"nsub = {nsub}\ndump_at = 3, {nsub}")
-        write_case(cdir, iexp, deck(iexp, nx, ny, nz, **dk), zf, **prof)
+        write_case(cdir, iexp, deck(iexp, nx, ny, nz, **dk), zf, nsv=kw.get("nsv", 0), **prof)
         if ibm:
             write_ibm_files(cdir, ibm, nx, ny, nz)
             write_facet_files(cdir, iexp, ibm, nx, ny, nz, 0.5, 0.5, 0.5, True, name in GREEN_CASES)
@@ -1141,7 +1150,7 @@ def make_driver_cases(only):
             out = os.path.join(tmp, "out.bin")
             subprocess.check_call([REF, f"namoptions.{iexp:03d}", "run", out], cwd=tmp, stdout=subprocess.DEVNULL)
             d = read_dump(out)
-        keep = {k: v for k, v in d.items() if k.count(".") == 0 or k.split(".")[1] in ("u0", "v0", "w0", "pres0", "um", "vm", "wm", "uouttot", "thl0", "thlm", "qt0", "qtm")}
+        keep = {k: v for k, v in d.items() if k.count(".") == 0 or k.split(".")[1] in ("u0", "v0", "w0", "pres0", "um", "vm", "wm", "uouttot", "thl0", "thlm", "qt0", "qtm") or ".sv0" in k or ".svm" in k}
         tmpf = os.path.join(HERE, name + ".bin")
         write_dump(tmpf, keep)
         with open(tmpf, "rb") as f, gzip.GzipFile(tmpf + ".gz", "wb", mtime=0) as g:

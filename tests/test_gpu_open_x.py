@@ -19,12 +19,14 @@ KERNEL_TOL = 1e-11
 RUN_TOL = 1e-9
 K_CASES = {"k_xopen_16x8x12": 90, "k_xopen_thl_16x8x12": 100, "k_xopen_sv_16x8x12": 102, "k_xopen_moist_16x8x12": 106}
 # BCxm = 3: the inlet from a precursor run's planes (the reference's moddriver stays on the host: Fortran routes only)
-D_CASES = {"run_xdriver_16x8x12s": 96, "run_xdriver_ibm_16x12x10": 98, "run_xdriver_moist_16x12x10": 110}
+D_CASES = {"run_xdriver_16x8x12s": 96, "run_xdriver_ibm_16x12x10": 98, "run_xdriver_moist_16x12x10": 110,
+           "run_xdriver_scal_16x8x12s": 113}      # (BCxT = BCxq = BCxs = 3: the scalars' inlets from the precursor's planes too)
 R_CASES = {"run_xopen_16x8x12s": 91, "run_xopen_vr_24x8x10": 92, "run_xopen_ibm_16x12x10": 93, "run_xopen_ibmwf3_16x12x10": 94,
            "run_xopen_volflow_16x8x12s": 99, "run_xopen_thl_16x8x12s": 101,
            "run_xopen_sv_16x8x12s": 103, "run_xopen_ibm_sv_16x12x10": 104, "run_xopen_ibm_thl_16x12x10": 105,
            # the temperature and the total water periodic in x (BCxT = BCxq = 1: the reference's defaults, its tests/cases/525) beside the inflow / outflow
-           "run_xopen_moist_16x8x12s": 107, "run_xopen_ibm_moist_16x12x10": 108}
+           "run_xopen_moist_16x8x12s": 107, "run_xopen_ibm_moist_16x12x10": 108,
+           "run_xopen_qt2_16x8x12s": 111}      # (BCxT = BCxq = 2: both enter with prof.inp's profiles)
 
 
 def make_core(name, iexp):
@@ -284,7 +286,7 @@ def test_fortran_driver_with_dropin_modules(name, iexp, residency, tmp_path):
 
 
 @pytest.mark.parametrize("name,iexp", [("run_xopen_16x8x12s", 91), ("run_xopen_thl_16x8x12s", 101), ("run_xdriver_16x8x12s", 96), ("run_xdriver_ibm_16x12x10", 98),
-                                       ("run_xopen_ibm_moist_16x12x10", 108), ("run_xdriver_moist_16x12x10", 110)])
+                                       ("run_xopen_ibm_moist_16x12x10", 108), ("run_xdriver_moist_16x12x10", 110), ("run_xdriver_scal_16x8x12s", 113)])
 @pytest.mark.parametrize("residency", [2, 0])
 def test_through_the_reference_program(name, iexp, residency, tmp_path):
     """u-dales_amd/bin/udales_full_dropin -- the reference's own program.f90, start-up, time loop and writerestartfiles over the

@@ -285,6 +285,12 @@ struct udc_handle {
   // the temperature on such a handle (&BC BCxT = 2: xTi_profile, xTo_convective; udc_set_open_x_thl): the inflow profile [nz+2] by k,
   // thl0 / thlm at ie+1 and at ib-1 as the last `boundary` left them ([2][pz][py] each)
   double *xo_thl_prof = nullptr, *xo_thl_east = nullptr, *xo_thl_west = nullptr;
+  // ... the total water likewise (&BC BCxq = 2: xqi_profile mirrors the ghost about the profile, xqo_convective; udc_set_open_x_qt)
+  double *xo_qt_prof = nullptr, *xo_qt_east = nullptr, *xo_qt_west = nullptr;
+  // BCxT / BCxq / BCxs = 3: the inlet's ghost columns from the planes of a precursor run (xTi_driver, xqi_driver, xsi_driver;
+  // udc_set_open_x_inlet_scalar): f0driver, fmdriver, [2][pz][py] each; slot 0 thl, 1 qt, 2 + n scalar n; `now` / `next` as for the flow
+  double *xo_sc_in_now[15] = {nullptr}, *xo_sc_in_next[15] = {nullptr};
+  bool xo_sc_fresh[15] = {false};
   // passive scalars there (&BC BCxs = 2: xsi_profile, xso_convective; udc_set_open_x_scalars; xg = 2): the inflow profiles [nsv][nz+2], and
   // per scalar the four ghost columns ib-2, ib-1, ie+1, ie+2 of sv0 and svm as the last `boundary` left them ([8][pz][py])
   double *xo_sv_prof = nullptr, *xo_sv_cols[13] = {nullptr};

@@ -138,23 +138,34 @@ __global__ void xo_restore_kernel(Geo g, int stage3, double *__restrict__ u0, do
 // the temperature (m-array in scalar slot 15, central scheme): xTi_profile (src/modboundary.f90:766-793: thl(ib-1) = thlprof(k) on
 // kb .. ke+1, thl(ib) = thlprof(k) on kb .. ke), xTo_convective (:947-957) on the outlet's planes; the columns as they stand are kept
 // for the next integration to put back
-__global__ void xo_thl_boundary_kernel(Geo g, const double *__restrict__ prof, double dxi, double rk3coef, const double *__restrict__ uout,
+// MODE 2: the profile (thl: both columns take it; QT, xqi_profile :811-823: the ghost mirrored about it); MODE 3: the ghost column from the
+// planes f0driver, fmdriver of a precursor run (xTi_driver :795-808, xqi_driver :826-839).  QT's outlet as the reference has it
+// (xqo_convective :961-971 starts from qt(ie), not from qt(ie+1))
+template <bool QT>
+__global__ void xo_thl_boundary_kernel(Geo g, const double *__restrict__ prof, const double *__restrict__ inlet, double dxi, double rk3coef,
+                                       const double *__restrict__ uout,
                                        double *__restrict__ t0, double *__restrict__ tm, double *__restrict__ east, double *__restrict__ west) {
   int jj, kk;
   if (!plane_decode(g, jj, kk)) return;
   const int j = jj - HY, k = kk - HZ;
   const long r = (long)g.sy * jj + g.sz * kk + (g.xg - 1);      // the ghost column ib-1 (xg = 2: one more beyond it, for the kappa scalars)
   const int e = g.nx - 2 * g.xg + 1;                             // ... from there to ie+1
-  if (j >= -1 && j <= g.ny && k >= 0 && k <= g.nz) {
-    const double tp = prof[k + 1];
-    t0[r] = tp; tm[r] = tp;
-    if (k < g.nz) { t0[r + 1] = tp; tm[r + 1] = tp; }
-  }
   const long P = (long)g.py * g.pz, q = (long)kk * g.py + jj;
+  if (j >= -1 && j <= g.ny && k >= 0 && k <= g.nz) {
+    if (inlet) { t0[r] = inlet[q]; tm[r] = inlet[P + q]; }
+    else {
+      const double tp = prof[k + 1];
+      if (QT) { t0[r] = 2 * tp - t0[r + 1]; tm[r] = 2 * tp - tm[r + 1]; }
+      else {
+        t0[r] = tp; tm[r] = tp;
+        if (k < g.nz) { t0[r + 1] = tp; tm[r + 1] = tp; }
+      }
+    }
+  }
   double e0 = east[q], em = east[P + q];
   const double uo = uout[0];
-  e0 = e0 - (e0 - t0[r + e - 1]) * dxi * rk3coef * uo;
-  em = em - (em - tm[r + e - 1]) * dxi * rk3coef * uo;
+  e0 = (QT ? t0[r + e - 1] : e0) - (e0 - t0[r + e - 1]) * dxi * rk3coef * uo;
+  em = (QT ? tm[r + e - 1] : em) - (em - tm[r + e - 1]) * dxi * rk3coef * uo;
   east[q] = e0; east[P + q] = em;
   t0[r + e] = e0; tm[r + e] = em;
   west[q] = t0[r]; west[P + q] = tm[r];
@@ -188,7 +199,9 @@ __global__ void xo_wrap_kernel(Geo g, double *__restrict__ f0, double *__restric
 // passive scalars (c-arrays, kappa scheme: two ghost columns either side).  xsi_profile (src/modboundary.f90:844-861: on jb .. je, kb .. ke+1,
 // sv(ib-1) = 2 svprof - sv(ib), sv(ib-2) = 2 svprof - sv(ib-1), sv0 and svm), xso_convective (:983-996: sv(ie+1) on every row and level; ie+2
 // stays what it is); cols [8][P]: sv0 at ib-2, ib-1, ie+1, ie+2, then svm
-__global__ void xo_sv_boundary_kernel(Geo g, const double *__restrict__ prof, double dxi, double rk3coef, const double *__restrict__ uout,
+// inlet: xsi_driver (:883-901): both ghost columns take the precursor's plane, rows jb-1 .. je+1
+__global__ void xo_sv_boundary_kernel(Geo g, const double *__restrict__ prof, const double *__restrict__ inlet, double dxi, double rk3coef,
+                                      const double *__restrict__ uout,
                                       double *__restrict__ s0, double *__restrict__ sm, double *__restrict__ cols) {
   int jj, kk;
   if (!plane_decode(g, jj, kk)) return;
@@ -196,6 +209,9 @@ __global__ void xo_sv_boundary_kernel(Geo g, const double *__restrict__ prof, do
   const long r = (long)g.sy * jj + g.sz * kk + (g.xg - 1);
   const int e = g.nx - 2 * g.xg + 1;
   const long P = (long)g.py * g.pz, q = (long)kk * g.py + jj;
+  if (inlet) {
+    if (j >= -1 && j <= g.ny && k >= 0 && k <= g.nz) { s0[r] = inlet[q]; s0[r - 1] = inlet[q]; sm[r] = inlet[P + q]; sm[r - 1] = inlet[P + q]; }
+  } else
   if (j >= 0 && j < g.ny && k >= 0 && k <= g.nz) {
     const double sp = prof[k + 1];
     s0[r] = 2 * sp - s0[r + 1]; sm[r] = 2 * sp - sm[r + 1];
@@ -280,11 +296,53 @@ void xo_destroy(udc_handle *h) {
   if (h->xo_inlet_now) { hipFree(h->xo_inlet_now); h->xo_inlet_now = nullptr; }
   if (h->xo_inlet_next) { hipFree(h->xo_inlet_next); h->xo_inlet_next = nullptr; }
   if (h->xo_prof) { hipFree(h->xo_prof); h->xo_prof = nullptr; }
-  for (double **q : {&h->xo_thl_prof, &h->xo_thl_east, &h->xo_thl_west, &h->xo_sv_prof}) if (*q) { hipFree(*q); *q = nullptr; }
+  for (double **q : {&h->xo_thl_prof, &h->xo_thl_east, &h->xo_thl_west, &h->xo_sv_prof, &h->xo_qt_prof, &h->xo_qt_east, &h->xo_qt_west})
+    if (*q) { hipFree(*q); *q = nullptr; }
+  for (int t = 0; t < 15; ++t)
+    for (double **q : {&h->xo_sc_in_now[t], &h->xo_sc_in_next[t]}) if (*q) { hipFree(*q); *q = nullptr; }
   for (double *&q : h->xo_sv_cols) if (q) { hipFree(q); q = nullptr; }
   if (h->xo_east) { hipFree(h->xo_east); h->xo_east = nullptr; }
   if (h->xo_west) { hipFree(h->xo_west); h->xo_west = nullptr; }
   if (h->xpois) { udc_destroy(h->xpois); h->xpois = nullptr; }
+}
+
+// an m-scalar's outlet and inlet columns as they stand ([2][pz][py] each: the 0 and the m array), allocated on first use and filled from the
+// fields' own ghost columns (an upload that came before the call has put the host's there)
+static int xo_alloc_east_west(udc_handle *h, int f0, int fm, double **east, double **west) {
+  if (*east) return 0;
+  const Geo &g = h->g;
+  const size_t np = (size_t)g.py * g.pz;
+  HIP_OK(hipMalloc(east, sizeof(double) * 2 * np));
+  HIP_OK(hipMalloc(west, sizeof(double) * 2 * np));
+  for (int t = 0; t < 2; ++t) {
+    const double *f = h->fields[t ? fm : f0];
+    hipLaunchKernelGGL(xo_capture_kernel, plane_grid(g), dim3(64), 0, h->stream, g, f, *east + t * np, g.nx - g.xg);
+    hipLaunchKernelGGL(xo_capture_kernel, plane_grid(g), dim3(64), 0, h->stream, g, f, *west + t * np, g.xg - 1);
+  }
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// planes (lb[0]:ub[0], lb[1]:ub[1]) in the reference's j, k (j fastest) -> [n][pz][py] on the device: into `next`, and into `now` too the
+// first time (what bcpup reads before the first `boundary` has run)
+static int stage_planes(udc_handle *h, int n, const double *const *src, const int lb[2], const int ub[2], double **now, double **next) {
+  const Geo &g = h->g;
+  const size_t np = (size_t)g.py * g.pz;
+  const bool first = !*next;
+  if (first) {
+    HIP_OK(hipMalloc(next, sizeof(double) * n * np));
+    HIP_OK(hipMalloc(now, sizeof(double) * n * np));
+  }
+  std::vector<double> st(n * np, 0.);
+  const int nj = ub[0] - lb[0] + 1;
+  for (int f = 0; f < n; ++f)
+    for (int k = std::max(lb[1], 1 - HZ); k <= std::min(ub[1], g.nz + HZ); ++k)
+      for (int j = std::max(lb[0], 1 - HY); j <= std::min(ub[0], g.ny + HY); ++j)
+        st[f * np + (size_t)(k - 1 + HZ) * g.py + (j - 1 + HY)] = src[f][(size_t)(k - lb[1]) * nj + (j - lb[0])];
+  HIP_OK(hipStreamSynchronize(h->stream));
+  HIP_OK(hipMemcpy(*next, st.data(), sizeof(double) * n * np, hipMemcpyHostToDevice));
+  if (first) HIP_OK(hipMemcpy(*now, st.data(), sizeof(double) * n * np, hipMemcpyHostToDevice));
+  return 0;
 }
 
 // BCxm = 3: the six inlet planes of the reference's drivergen (modinletdata u0driver, umdriver, v0driver, vmdriver, w0driver, wmdriver),
@@ -302,23 +360,54 @@ extern "C" int udc_set_open_x_inlet(udc_handle *h, const double *u0d, const doub
     udc_set_error("udc_set_open_x_inlet: the planes must cover j = jb-1 .. je+1, k = kb .. ke+1");
     return 1;
   }
-  const size_t np = (size_t)g.py * g.pz;
-  const bool first = !h->xo_inlet_next;
-  if (first) {
-    HIP_OK(hipMalloc(&h->xo_inlet_next, sizeof(double) * 6 * np));
-    HIP_OK(hipMalloc(&h->xo_inlet_now, sizeof(double) * 6 * np));
-  }
-  std::vector<double> st(6 * np, 0.);
-  const int nj = ub[0] - lb[0] + 1;
-  for (int f = 0; f < 6; ++f)
-    for (int k = std::max(lb[1], 1 - HZ); k <= std::min(ub[1], g.nz + HZ); ++k)
-      for (int j = std::max(lb[0], 1 - HY); j <= std::min(ub[0], g.ny + HY); ++j)
-        st[f * np + (size_t)(k - 1 + HZ) * g.py + (j - 1 + HY)] = src[f][(size_t)(k - lb[1]) * nj + (j - lb[0])];
-  HIP_OK(hipStreamSynchronize(h->stream));
-  HIP_OK(hipMemcpy(h->xo_inlet_next, st.data(), sizeof(double) * 6 * np, hipMemcpyHostToDevice));
-  if (first) HIP_OK(hipMemcpy(h->xo_inlet_now, st.data(), sizeof(double) * 6 * np, hipMemcpyHostToDevice));
+  if (stage_planes(h, 6, src, lb, ub, &h->xo_inlet_now, &h->xo_inlet_next)) return 1;
   h->xo_driver = 1;
   h->xo_inlet_fresh = true;      // (takes effect with the next `boundary` that runs; it does not ask for one)
+  return 0;
+}
+
+// BCxT / BCxq / BCxs = 3 (with BCxm = 3): the temperature's, the total water's or scalar n's inlet from the planes drivergen leaves in
+// modinletdata (thl0driver / thlmdriver, qt0driver / qtmdriver: (jb-jh : je+jh, kb-kh : ke+kh); sv0driver / svmdriver(:, :, n):
+// (jb-jhc : je+jhc, kb-khc : ke+khc)), handed over after every drivergen like the flow's
+extern "C" int udc_set_open_x_inlet_scalar(udc_handle *h, int field, const double *f0d, const double *fmd, const int lb[2], const int ub[2]) {
+  if (!h) { udc_set_error("null handle"); return 1; }
+  HIP_OK(hipSetDevice(h->device));
+  if (udc_flush_pending(h)) return 1;
+  if (!h->xg || !f0d || !fmd) { udc_set_error("udc_set_open_x_inlet_scalar: a handle of udc_create_open_x and both planes"); return 1; }
+  const Geo &g = h->g;
+  if (lb[0] > 0 || ub[0] < g.ny + 1 || lb[1] > 1 || ub[1] < g.nz + 1) {
+    udc_set_error("udc_set_open_x_inlet_scalar: the planes must cover j = jb-1 .. je+1, k = kb .. ke+1");
+    return 1;
+  }
+  const size_t np = (size_t)g.py * g.pz;
+  int slot = -1;
+  if (field == UDC_THL0 || field == UDC_QT0) {
+    if ((int)h->fields.size() <= field || !h->fields[field]) { udc_set_error("udc_set_open_x_inlet_scalar: udc_set_tempeq / udc_set_moisture first"); return 1; }
+    slot = field == UDC_THL0 ? 0 : 1;
+    if (xo_alloc_east_west(h, field, field + 1, slot ? &h->xo_qt_east : &h->xo_thl_east, slot ? &h->xo_qt_west : &h->xo_thl_west)) return 1;
+  } else if (field >= UDC_SV0 && (field - UDC_SV0) % 3 == 0 && (field - UDC_SV0) / 3 < 13 && (field - UDC_SV0) / 3 < h->cfg.nsv) {
+    slot = 2 + (field - UDC_SV0) / 3;
+    if (!h->xo_sv_cols[slot - 2]) { udc_set_error("udc_set_open_x_inlet_scalar: udc_set_open_x_scalars first"); return 1; }
+  } else { udc_set_error("udc_set_open_x_inlet_scalar: UDC_THL0, UDC_QT0 or the sv0 of a passive scalar"); return 1; }
+  const double *src[2] = {f0d, fmd};
+  if (stage_planes(h, 2, src, lb, ub, &h->xo_sc_in_now[slot], &h->xo_sc_in_next[slot])) return 1;
+  h->xo_sc_fresh[slot] = true;
+  return 0;
+}
+
+// the total water's inflow profile (&BC BCxq = 2: xqi_profile, xqo_convective), qtprof [ktot+2] by the reference's k; after udc_set_moisture
+extern "C" int udc_set_open_x_qt(udc_handle *h, const double *qtprof) {
+  if (!h || !qtprof) { udc_set_error("udc_set_open_x_qt: null argument"); return 1; }
+  HIP_OK(hipSetDevice(h->device));
+  if (udc_flush_pending(h)) return 1;
+  if (!h->xg) { udc_set_error("udc_set_open_x_qt: not a handle of udc_create_open_x"); return 1; }
+  if (!h->lmoist || (int)h->fields.size() <= UDC_QT0 || !h->fields[UDC_QT0]) { udc_set_error("udc_set_open_x_qt: call udc_set_moisture first"); return 1; }
+  const Geo &g = h->g;
+  const size_t nk = (size_t)g.nz + 2, np = (size_t)g.py * g.pz;
+  HIP_OK(hipStreamSynchronize(h->stream));
+  if (!h->xo_qt_prof) HIP_OK(hipMalloc(&h->xo_qt_prof, sizeof(double) * nk));
+  if (xo_alloc_east_west(h, UDC_QT0, UDC_QTM, &h->xo_qt_east, &h->xo_qt_west)) return 1;
+  HIP_OK(hipMemcpy(h->xo_qt_prof, qtprof, sizeof(double) * nk, hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -347,6 +436,15 @@ int xo_capture_east(udc_handle *h, int field, const double *, const int lb[3], c
     if (lb[0] <= 0 && ub[0] >= 0)
       hipLaunchKernelGGL(xo_capture_kernel, plane_grid(g), dim3(64), 0, h->stream, g, (const double *)h->fields[field],
                          h->xo_thl_west + (size_t)tslot * g.py * g.pz, g.xg - 1);
+  }
+  const int qslot = field == UDC_QT0 ? 0 : (field == UDC_QTM ? 1 : -1);
+  if (qslot >= 0 && h->xo_qt_east) {
+    if (lb[0] <= itot + 1 && ub[0] >= itot + 1)
+      hipLaunchKernelGGL(xo_capture_kernel, plane_grid(g), dim3(64), 0, h->stream, g, (const double *)h->fields[field],
+                         h->xo_qt_east + (size_t)qslot * g.py * g.pz, g.nx - g.xg);
+    if (lb[0] <= 0 && ub[0] >= 0)
+      hipLaunchKernelGGL(xo_capture_kernel, plane_grid(g), dim3(64), 0, h->stream, g, (const double *)h->fields[field],
+                         h->xo_qt_west + (size_t)qslot * g.py * g.pz, g.xg - 1);
   }
   HIP_OK(hipGetLastError());
   return 0;
@@ -388,12 +486,23 @@ int k_xo_boundary(udc_handle *h) {
                      (const double *)(h->xo_driver ? h->xo_inlet_now : nullptr), h->m.dxi, h->bcx_rk3coef,
                      (const double *)h->bcx_uout_dev, h->fields[UDC_U0], h->fields[UDC_V0], h->fields[UDC_W0],
                      h->fields[UDC_UM], h->fields[UDC_VM], h->fields[UDC_WM], h->fields[UDC_PRES0], h->xo_east, h->xo_west);
-  if (h->xo_thl_prof)
-    hipLaunchKernelGGL(xo_thl_boundary_kernel, plane_grid(g), dim3(64), 0, h->stream, g, (const double *)h->xo_thl_prof, h->m.dxi, h->bcx_rk3coef,
+  for (int t = 0; t < 15; ++t)      // the scalars' planes handed over since the last `boundary`
+    if (h->xo_sc_in_next[t] && h->xo_sc_fresh[t]) {
+      HIP_OK(hipMemcpyAsync(h->xo_sc_in_now[t], h->xo_sc_in_next[t], sizeof(double) * 2 * (size_t)g.py * g.pz, hipMemcpyDeviceToDevice, h->stream));
+      h->xo_sc_fresh[t] = false;
+    }
+  if (h->xo_thl_prof || h->xo_sc_in_now[0])
+    hipLaunchKernelGGL(xo_thl_boundary_kernel<false>, plane_grid(g), dim3(64), 0, h->stream, g, (const double *)h->xo_thl_prof,
+                       (const double *)h->xo_sc_in_now[0], h->m.dxi, h->bcx_rk3coef,
                        (const double *)h->bcx_uout_dev, h->fields[UDC_THL0], h->fields[UDC_THLM], h->xo_thl_east, h->xo_thl_west);
+  if (h->xo_qt_prof || h->xo_sc_in_now[1])
+    hipLaunchKernelGGL(xo_thl_boundary_kernel<true>, plane_grid(g), dim3(64), 0, h->stream, g, (const double *)h->xo_qt_prof,
+                       (const double *)h->xo_sc_in_now[1], h->m.dxi, h->bcx_rk3coef,
+                       (const double *)h->bcx_uout_dev, h->fields[UDC_QT0], h->fields[UDC_QTM], h->xo_qt_east, h->xo_qt_west);
   for (int n = 0; n < h->cfg.nsv && n < 13; ++n)
     if (h->xo_sv_cols[n])
       hipLaunchKernelGGL(xo_sv_boundary_kernel, plane_grid(g), dim3(64), 0, h->stream, g, (const double *)(h->xo_sv_prof + (size_t)n * (g.nz + 2)),
+                         (const double *)h->xo_sc_in_now[2 + n],
                          h->m.dxi, h->bcx_rk3coef, (const double *)h->bcx_uout_dev, h->fields[UDC_SV0 + 3 * n], h->fields[UDC_SVM + 3 * n], h->xo_sv_cols[n]);
   HIP_OK(hipGetLastError());
   return 0;
@@ -429,13 +538,8 @@ extern "C" int udc_set_open_x_thl(udc_handle *h, const double *thlprof) {
   const Geo &g = h->g;
   const size_t nk = (size_t)g.nz + 2, np = (size_t)g.py * g.pz;
   HIP_OK(hipStreamSynchronize(h->stream));
-  if (!h->xo_thl_prof) {
-    HIP_OK(hipMalloc(&h->xo_thl_prof, sizeof(double) * nk));
-    HIP_OK(hipMalloc(&h->xo_thl_east, sizeof(double) * 2 * np));
-    HIP_OK(hipMalloc(&h->xo_thl_west, sizeof(double) * 2 * np));
-    HIP_OK(hipMemset(h->xo_thl_east, 0, sizeof(double) * 2 * np));
-    HIP_OK(hipMemset(h->xo_thl_west, 0, sizeof(double) * 2 * np));
-  }
+  if (!h->xo_thl_prof) HIP_OK(hipMalloc(&h->xo_thl_prof, sizeof(double) * nk));
+  if (xo_alloc_east_west(h, UDC_THL0, UDC_THLM, &h->xo_thl_east, &h->xo_thl_west)) return 1;
   HIP_OK(hipMemcpy(h->xo_thl_prof, thlprof, sizeof(double) * nk, hipMemcpyHostToDevice));
   return 0;
 }
@@ -446,12 +550,15 @@ int k_xo_after_integrate(udc_handle *h, int rk3step) {
   PROF(h, "xo_ghosts");
   hipLaunchKernelGGL(xo_restore_kernel, plane_grid(g), dim3(64), 0, h->stream, g, rk3step == 3 ? 1 : 0, h->fields[UDC_U0], h->fields[UDC_V0],
                      h->fields[UDC_W0], h->fields[UDC_UM], h->fields[UDC_VM], h->fields[UDC_WM], h->xo_east, h->xo_west);
-  if (h->xo_thl_prof)
+  if (h->xo_thl_prof || h->xo_sc_in_now[0])
     hipLaunchKernelGGL(xo_thl_restore_kernel, plane_grid(g), dim3(64), 0, h->stream, g, rk3step == 3 ? 1 : 0, h->fields[UDC_THL0],
                        h->fields[UDC_THLM], h->xo_thl_east, h->xo_thl_west);
   else if ((int)h->fields.size() > UDC_THL0 && h->fields[UDC_THL0])      // BCxT = 1: periodic (halos' xT_periodic)
     hipLaunchKernelGGL(xo_wrap_kernel, plane_grid(g), dim3(64), 0, h->stream, g, h->fields[UDC_THL0], h->fields[UDC_THLM]);
-  if (h->lmoist && (int)h->fields.size() > UDC_QT0 && h->fields[UDC_QT0])      // BCxq = 1 (xq_periodic)
+  if (h->xo_qt_prof || h->xo_sc_in_now[1])
+    hipLaunchKernelGGL(xo_thl_restore_kernel, plane_grid(g), dim3(64), 0, h->stream, g, rk3step == 3 ? 1 : 0, h->fields[UDC_QT0],
+                       h->fields[UDC_QTM], h->xo_qt_east, h->xo_qt_west);
+  else if (h->lmoist && (int)h->fields.size() > UDC_QT0 && h->fields[UDC_QT0])      // BCxq = 1 (xq_periodic)
     hipLaunchKernelGGL(xo_wrap_kernel, plane_grid(g), dim3(64), 0, h->stream, g, h->fields[UDC_QT0], h->fields[UDC_QTM]);
   for (int n = 0; n < h->cfg.nsv && n < 13; ++n)
     if (h->xo_sv_cols[n])

@@ -111,15 +111,27 @@ contains
   !! the drop-in tstep_integrate calls this first; the call from `boundary` that follows finds the same time and hands over the same planes.
   subroutine driver_inlet
     use udc_iface
-    use modglobal, only: rk3step, lchunkread, jb, je, jh, kb, ke, kh
+    use modglobal, only: rk3step, lchunkread, jb, je, jh, kb, ke, kh, jhc, khc, nsv, ltempeq, lmoist, lhdriver, lqdriver, lsdriver
     use moddriver, only: drivergen, driverchunkread
-    use modinletdata, only: u0driver, umdriver, v0driver, vmdriver, w0driver, wmdriver
+    use modinletdata, only: u0driver, umdriver, v0driver, vmdriver, w0driver, wmdriver, thl0driver, thlmdriver, qt0driver, qtmdriver, &
+                            sv0driver, svmdriver
     integer(c_int) :: lb(2), ub(2)
+    integer :: n
     if (.not. (rk3step == 0 .or. rk3step == 3)) return
     if (lchunkread) call driverchunkread
     call drivergen
     lb = (/jb - jh, kb - kh/); ub = (/je + jh, ke + kh/)
     call udc_check(udc_set_open_x_inlet(udc_h, u0driver, umdriver, v0driver, vmdriver, w0driver, wmdriver, lb, ub), 'udc_set_open_x_inlet')
+    ! BCxT / BCxq / BCxs = 3: the scalars' planes too (xTi_driver, xqi_driver, xsi_driver; src/modboundary.f90:795-901)
+    if (ltempeq .and. lhdriver) call udc_check(udc_set_open_x_inlet_scalar(udc_h, UDC_THL0, thl0driver, thlmdriver, lb, ub), 'udc_set_open_x_inlet_scalar')
+    if (lmoist .and. lqdriver) call udc_check(udc_set_open_x_inlet_scalar(udc_h, UDC_QT0, qt0driver, qtmdriver, lb, ub), 'udc_set_open_x_inlet_scalar')
+    if (nsv > 0 .and. lsdriver) then
+      lb = (/jb - jhc, kb - khc/); ub = (/je + jhc, ke + khc/)
+      do n = 1, nsv
+        call udc_check(udc_set_open_x_inlet_scalar(udc_h, UDC_SV0 + 3*(n - 1), sv0driver(:, :, n), svmdriver(:, :, n), lb, ub), &
+                       'udc_set_open_x_inlet_scalar')
+      end do
+    end if
   end subroutine driver_inlet
 
   !> BCxm = 2, the `boundary` of the start-up (src/program.f90:118): the outlet's speed uouttot from the slab averages diagfld has

@@ -527,6 +527,18 @@ module udc_iface
       type(c_ptr), value :: h
       real(c_double), intent(in) :: thlprof(*)
     end function
+    integer(c_int) function udc_set_open_x_qt(h, qtprof) bind(C, name='udc_set_open_x_qt')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(in) :: qtprof(*)
+    end function
+    integer(c_int) function udc_set_open_x_inlet_scalar(h, field, f0d, fmd, lb, ub) bind(C, name='udc_set_open_x_inlet_scalar')
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: field
+      real(c_double), intent(in) :: f0d(*), fmd(*)
+      integer(c_int), intent(in) :: lb(2), ub(2)
+    end function
     integer(c_int) function udc_set_open_x_inlet(h, u0d, umd, v0d, vmd, w0d, wmd, lb, ub) bind(C, name='udc_set_open_x_inlet')
       import :: c_int, c_ptr, c_double
       type(c_ptr), value :: h
@@ -727,7 +739,7 @@ contains
     use modglobal, only: ktot, kb, ke, nsv, ltempeq, BCtops, lcoriol, lprofforc, om22, om23, luvolflowr, lvvolflowr, luoutflowr, &
                          uflowrate, vflowrate, lnudge, igrw_damp, ifixuinf, ds, BCxs, BCxm, BCxT, BCxq, lmoist, kh
     use modsurfdata, only: wsvtop, sv_top
-    use modfields, only: thlprof, dpdxl, dpdyl, thlpcar, ug, whls, dthldxls, dthldyls, dqtdxls, dqtdyls, dqtdtls, &
+    use modfields, only: thlprof, qtprof, dpdxl, dpdyl, thlpcar, ug, whls, dthldxls, dthldyls, dqtdxls, dqtdyls, dqtdtls, &
                          dudxls, dudyls, dvdxls, dvdyls
     integer :: n
     real(c_double), allocatable :: xo_u(:), xo_v(:)
@@ -738,8 +750,8 @@ contains
       if (ltempeq) then      ! BCxT = 2: the temperature enters with its profile (xTi_profile); BCxT = 1 (the reference's default, its
         ! tests/cases/525): it stays periodic in x (halos' xT_periodic) -- the library's own refresh of a handle without an inflow profile;
         ! planes of a precursor run (BCxT = 3) are not taken yet
-        if (BCxT /= 1 .and. BCxT /= 2) then
-          write (0, *) 'ERROR: libudcore: inflow / outflow in x with the temperature equation needs BCxT = 1 (periodic) or 2 (inflow profile, convective outflow)'
+        if (BCxT /= 1 .and. BCxT /= 2 .and. .not. (BCxT == 3 .and. BCxm == 3)) then
+          write (0, *) 'ERROR: libudcore: inflow / outflow in x with the temperature equation needs BCxT = 1 (periodic), 2 (inflow profile) or, with BCxm = 3, 3 (driver planes)'
           stop 1
         end if
         if (BCxT == 2) then
@@ -748,9 +760,16 @@ contains
           call udc_check(udc_set_open_x_thl(udc_h, xo_u), 'udc_set_open_x_thl')
         end if
       end if
-      if (lmoist .and. BCxq /= 1) then      ! (xqi_profile / xqi_driver are not on the device)
-        write (0, *) 'ERROR: libudcore: inflow / outflow in x with moisture needs BCxq = 1 (periodic)'
-        stop 1
+      if (lmoist) then      ! BCxq = 1 periodic; 2 mirrored about the profile (xqi_profile); 3 planes of a precursor run (xqi_driver: driver_inlet)
+        if (BCxq /= 1 .and. BCxq /= 2 .and. .not. (BCxq == 3 .and. BCxm == 3)) then
+          write (0, *) 'ERROR: libudcore: inflow / outflow in x with moisture needs BCxq = 1 (periodic), 2 (inflow profile) or, with BCxm = 3, 3 (driver planes)'
+          stop 1
+        end if
+        if (BCxq == 2) then
+          xo_u = 0.
+          if (allocated(qtprof)) xo_u(1:ktot + 1) = qtprof(kb:ke + kh)
+          call udc_check(udc_set_open_x_qt(udc_h, xo_u), 'udc_set_open_x_qt')
+        end if
       end if
     end if
     if (ltempeq) then
@@ -786,11 +805,11 @@ contains
   end subroutine udc_late_setup
 
   subroutine open_x_scalars
-    use modglobal, only: ktot, kb, ke, nsv, BCxs
+    use modglobal, only: ktot, kb, ke, nsv, BCxs, BCxm
     use modfields, only: svprof
     real(c_double), allocatable :: t(:, :)
-    if (BCxs /= 2) then
-      write (0, *) 'ERROR: libudcore: inflow / outflow in x with passive scalars needs BCxs = 2 (inflow profile, convective outflow)'
+    if (BCxs /= 2 .and. .not. (BCxs == 3 .and. BCxm == 3)) then      ! (3: the inlet from a precursor's planes, xsi_driver: driver_inlet)
+      write (0, *) 'ERROR: libudcore: inflow / outflow in x with passive scalars needs BCxs = 2 (inflow profile) or, with BCxm = 3, 3 (driver planes)'
       stop 1
     end if
     allocate (t(0:ktot + 1, nsv))

@@ -64,6 +64,11 @@ def from_deck(deck, device=0, rank=0, nranks=1):
                           bctopq=int(deck.get("BC", "BCtopq")), wqtop=float(deck.get("BC", "wqtop")),
                           qt_top=float(deck.get("BC", "qt_top")), bcbotq=int(deck.get("BC", "BCbotq")),
                           wqsurf=float(deck.get("BC", "wqsurf")))
+        if bcxm == 2:      # inflow / outflow: BCxq = 1 periodic (xq_periodic), 2 mirrored about prof.inp's profile (xqi_profile), qtprof(ke+1) = 0 as allocated
+            if int(deck.get("BC", "BCxq")) not in (1, 2):
+                raise ValueError("&BC BCxm = 2 with moisture: BCxq = 1 (periodic) or 2 (inflow profile, convective outflow) is what the device path has")
+            if int(deck.get("BC", "BCxq")) == 2:
+                core.set_open_x_qt(np.concatenate(([0.], np.asarray(deck.qt, dtype=float)[:g.nz], [0.])))
         if deck.get("PHYSICS", "lbuoyancy") or sgs == 3:      # the moist thermodynamics feed the buoyancy and calthv's dthvdz
             if not deck.get("PHYSICS", "ltempeq"):
                 raise ValueError("lmoist with lbuoyancy or loneeqn needs ltempeq on the device path")

@@ -342,6 +342,12 @@ class DynCore:
         assert a.size == self.g.nz + 2
         L._check(self.lib.udc_set_open_x_thl(self.h, a.ctypes.data_as(L.DP)), "udc_set_open_x_thl")
 
+    def set_open_x_qt(self, qtprof):
+        """BCxq = 2 on an open-x core: the total water's inflow profile, [ktot+2] by the reference's k."""
+        a = np.ascontiguousarray(qtprof, dtype=np.float64)
+        assert a.size == self.g.nz + 2
+        L._check(self.lib.udc_set_open_x_qt(self.h, a.ctypes.data_as(L.DP)), "udc_set_open_x_qt")
+
     def set_open_x_scalars(self, svprof):
         """BCxs = 2 on an open-x core: the scalars' inflow profiles [nsv][ktot+2] by the reference's k."""
         a = np.ascontiguousarray(svprof, dtype=np.float64)

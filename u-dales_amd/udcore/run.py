@@ -36,7 +36,7 @@ def check_supported(deck):
         _refuse("&BC BCxs: only 1 (periodic) and 2 (inflow profile, convective outflow) are on the device path")
     for grp, names in (("BC", ("BCxT", "BCxq", "BCyT", "BCyq", "BCys")),):
         for n in names:
-            if n == "BCxT" and int(g("BC", "BCxm")) == 2 and int(g("BC", "BCxT")) in (1, 2):
+            if n in ("BCxT", "BCxq") and int(g("BC", "BCxm")) == 2 and int(g("BC", n)) in (1, 2):
                 continue      # (inflow / outflow for the flow and the temperature: udc_create_open_x, udc_set_open_x_thl)
             if deck.is_set(grp, n) and int(deck.nml[grp][[k for k in deck.nml[grp] if k.lower() == n.lower()][0]]) != 1:
                 _refuse(f"only periodic lateral boundaries are on the device path (&BC {n})")
