@@ -222,7 +222,7 @@ def test_substeps_match_reference(name, iexp, fused):
         assert core.deferred_stats() == (max(dumps), 0)
     if fused is True:
         plan = core.last_plan()
-        assert not plan["pressure_total_form"] and not plan["slab_layout"]
+        assert plan["pressure_total_form"] and not plan["slab_layout"]      # (under the open lid too: udc_plan.h)
     div = core.divergence()
     assert div[0] < 1e-12
     core.close()
@@ -435,8 +435,10 @@ def test_full_size_properties_256():
         assert np.abs(u[1:n + 1, 1:-1, -1] - u[1:n + 1, 1:-1, -2]).max() > 1e-4                             # an outlet that carries something
         out.append((u, v, core.download("pres0")))
         core.close()
-    for a, b in zip(*out):
-        assert relerr(nocorner(a[1:-1]), nocorner(b[1:-1])) <= 1e-11
+    # (the fused substep runs the pressure-total form, the routines the reference's: pres0 is a fresh solve on one side and a sum of six
+    #  increments on the other -- 9e-11 at this size, profiles/r06/open_lid_ptotal_ab.txt; the velocities agree to 2e-14)
+    for (a, b), tol in zip(zip(*out), (1e-12, 1e-12, 1e-9)):
+        assert relerr(nocorner(a[1:-1]), nocorner(b[1:-1])) <= tol
 
 
 def test_reductions_leave_the_ghost_columns_out():
@@ -617,7 +619,7 @@ def test_what_open_x_does_not_offer_is_refused():
     from udcore import lib as L
     d, core = make_core("k_xopen_16x8x12", 90)
     with pytest.raises(L.UdcError, match="open x"):
-        core.set_moisture()
+        L._check(core.lib.udc_stats_enable(core.h, 1), "udc_stats_enable")
     with pytest.raises(L.UdcError, match="central scheme"):
         core.set_tempeq(iadv_thl=7)
     with pytest.raises(L.UdcError, match="open x"):

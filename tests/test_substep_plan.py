@@ -17,7 +17,7 @@ LIB = os.path.join(ROOT, "u-dales_amd", "lib", "libudcplan.so")
 
 IN = ["no_fold", "no_alias", "ek_always", "halo_overlap", "mom_pipe", "div_in_fft", "ptotal",
       "slab", "comm_stream", "sgs", "lbuoycorr", "nslots", "ibm_on", "stats_any", "fft_fused", "own_fwd", "tend_plane", "between",
-      "closure_tile_rows", "mom_tile_rows", "int_tile_rows", "x_row_groups", "levels_per_chunk", "p_transpose", "open_lid", "rk3step", "um_alias", "ibm_edits_now"]
+      "closure_tile_rows", "mom_tile_rows", "int_tile_rows", "x_row_groups", "levels_per_chunk", "p_transpose", "open_lid", "lid_masked", "rk3step", "um_alias", "ibm_edits_now"]
 OUT = ["lds", "pup", "fold", "alias_ok", "materialise_um", "rotate", "skip_um", "closure", "need_ekh", "mom_pipe", "div_in_fft",
        "vp_row", "p_row", "integrate", "ptotal"]
 FOLDED, OVERLAPPED, PLAIN = 0, 1, 2
@@ -59,14 +59,14 @@ def table(i):
     need_ekh = np.where(c_folded | c_over, b(i["ek_always"]) | (i["rk3step"] == 3) | (i["nslots"] > 0) | b(i["stats_any"]), True)
     pipe = (b(i["slab"]) & lds & pup & b(i["mom_pipe"]) & b(i["fft_fused"]) & b(i["div_in_fft"]) & beside(i["mom_tile_rows"])
             & (i["nslots"] == 0) & (i["sgs"] != 3) & ~b(i["between"]) & (i["x_row_groups"] >= 2) & (i["levels_per_chunk"] >= 4) & ~b(i["open_lid"]))
-    div = pup & ~b(i["open_lid"]) & ((b(i["slab"]) & b(i["fft_fused"]) & b(i["div_in_fft"])) | (~b(i["slab"]) & b(i["own_fwd"])))
+    div = pup & ((b(i["slab"]) & b(i["fft_fused"]) & b(i["div_in_fft"])) | (~b(i["slab"]) & b(i["own_fwd"])))
     needs_row = ~fold | (b(i["ibm_on"]) & b(i["ibm_edits_now"]))
     vp = np.where(pipe, ROW_PIPED, np.where(needs_row, np.where(div & beside(np.full_like(i["sgs"], 3)) & (i["x_row_groups"] >= 2), ROW_BESIDE, ROW_INLINE),
                                             ROW_FOLDED))
     prow = np.where(fold, ROW_FOLDED, np.where(b(i["slab"]) & b(i["fft_fused"]) & b(i["p_transpose"]), ROW_TRANSPOSED,
                                                np.where(beside(i["int_tile_rows"]) & (i["int_tile_rows"] >= 4), ROW_BESIDE, ROW_INLINE)))
     integ = np.where(~fold & beside(i["int_tile_rows"]), INT_EDGES_FIRST, INT_ONE)
-    ptot = b(i["ptotal"]) & pup & ~b(i["tend_plane"]) & ~b(i["open_lid"])
+    ptot = b(i["ptotal"]) & pup & ~b(i["tend_plane"]) & ~(b(i["open_lid"]) & b(i["lid_masked"]))
     return dict(lds=lds, pup=pup, fold=fold, alias_ok=alias_ok, materialise_um=mat, rotate=rotate, skip_um=skip, closure=closure,
                 need_ekh=need_ekh, mom_pipe=pipe, div_in_fft=div, vp_row=vp, p_row=prow, integrate=integ, ptotal=ptot)
 
@@ -80,6 +80,7 @@ def lattice(p_transpose=1, open_lid=0):
     cols = {k: g.ravel() for k, g in zip(axes, grids)}
     cols["p_transpose"] = np.full_like(cols["slab"], p_transpose)
     cols["open_lid"] = np.full_like(cols["slab"], open_lid)
+    cols["lid_masked"] = cols["open_lid"] * cols["ibm_on"] * (cols["sgs"] % 2)      # (obstacles that reach the lid: some of the decks with obstacles)
     cols["comm_stream"] = cols["slab"].copy()      # (the communication stream exists exactly where the slab layout was set up)
     for k in ("closure_tile_rows", "mom_tile_rows", "int_tile_rows"):
         cols[k] = cols["rows"]
@@ -136,10 +137,11 @@ def test_every_combination_matches_the_table_and_is_safe():
         pt = g["ptotal"] == 1
         assert not (pt & ((i["tend_plane"] == 1) | (g["pup"] == 0))).any()
         # the open lid (BCtopm = 3): its rows of bcpup / tderive / tstep_integrate are plane kernels that read and write wm(ke+1), wp(ke+1) under
-        # their own names in the reference's form, and only div_rhs_kernel reads pwp(ke+1): no aliasing, no pressure-total form, no
-        # divergence inside a transform (hence no pipelined sweep)
+        # their own names: no aliasing, no pipelined sweep; the pressure-total form only where the lid's slab mean is the zero mode's
+        # (no obstacle reaches level ke)
         lid = i["open_lid"] == 1
-        assert not (lid & (pt | (g["div_in_fft"] == 1) | (g["mom_pipe"] == 1) | (g["skip_um"] == 1) | (g["rotate"] == 1))).any()
+        assert not (lid & ((g["mom_pipe"] == 1) | (g["skip_um"] == 1) | (g["rotate"] == 1))).any()
+        assert not (pt & (i["lid_masked"] == 1)).any() and (pt & lid).any() == bool(lid.any() and sw[6])
         total += n
     assert total == len(runs) * n and len(runs) == 128 + 3 * 16 and n > 100000
 
@@ -148,7 +150,7 @@ def test_named_configurations():
     """The rows of DESIGN.md section 7's table for the BASELINE configurations, with the library's defaults."""
     L = lib()
     dflt = dict(no_fold=0, no_alias=0, ek_always=0, halo_overlap=1, mom_pipe=1, div_in_fft=1, ptotal=1, tend_plane=0, lbuoycorr=0, stats_any=0,
-                ibm_edits_now=0, um_alias=0, open_lid=0, p_transpose=1)
+                ibm_edits_now=0, um_alias=0, open_lid=0, lid_masked=0, p_transpose=1)
 
     def one(**kw):
         i = dict(dflt, **kw)

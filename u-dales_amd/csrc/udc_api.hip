@@ -1156,7 +1156,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   pin.ek_always = h->ek_always; pin.halo_overlap = !h->no_halo_overlap; pin.mom_pipe = !h->no_mom_pipe; pin.div_in_fft = !h->no_div_in_fft; pin.ptotal = h->sw.ptotal; pin.p_transpose = h->sw.p_transpose;
   pin.slab = h->slab; pin.comm_stream = h->comm_stream != nullptr; pin.sgs = h->p.sgs; pin.lbuoycorr = h->lbuoycorr;
   pin.nslots = (int)h->slots.size(); pin.ibm_on = h->ibm_on; pin.stats_any = h->stats_on || h->xyt_on || h->yt_on;
-  pin.fft_fused = h->fft_fused; pin.own_fwd = h->own_fwd;
+  pin.fft_fused = h->fft_fused; pin.own_fwd = h->own_fwd && !h->xg;      // (open x boundaries: the solve's transforms run on the doubled row of h->xpois)
   pin.tend_plane = h->luvolflowr == 2 || (h->ibm_on && (h->luvolflowr || h->lvvolflowr));
   pin.between = h->coriolis_mode || !h->level_forcings.empty() || h->luvolflowr || h->lvvolflowr || h->ibm_on || h->shift_a != 0. ||
                 h->thlpcar || h->lbuoyancy;
@@ -1165,6 +1165,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   pin.levels_per_chunk = h->g.nz / (h->nch > 0 ? h->nch : 1);
   pin.rk3step = rk3step; pin.um_alias = h->um_alias; pin.ibm_edits_now = (ops & (OP_IBMWALL | OP_IBMNORM)) != 0;
   pin.open_lid = h->p.bctopm == UDC_TOP_PRESSURE;
+  pin.lid_masked = pin.open_lid && k_lid_masked(h);
   const Plan plan = plan_substep(pin);
   h->last_plan = plan; h->have_plan = true;
   h->ptotal_now = plan.ptotal != 0;
@@ -1282,8 +1283,8 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   }      // (ROW_PIPED: already travelling; ROW_FOLDED: written by the kernels above)
   // open lid (BCtopm = 3): bcpup's row pwp(ke+1) from the slab mean of pres0(ke), before the divergence that reads it
   const bool lid = pin.open_lid != 0;
-  if (lid && k_lid_bcpup(h, rk3coef, pup)) return 1;
-  if (k_xo_bcpup(h, rk3coef, pup)) return 1;
+  if (lid && k_lid_bcpup(h, rk3coef, pup, plan.ptotal != 0)) return 1;
+  if (k_xo_bcpup(h, rk3coef, pup, plan.ptotal != 0)) return 1;
   if (h->xg && k_scalar_bcx_uout(h)) return 1;
   if (!h->div_in_fft && k_divergence_rhs(h, rk3coef, pup)) return 1;
   h->p_ghost_in_transpose = plan.p_row == ROW_TRANSPOSED;

@@ -132,6 +132,7 @@ __device__ __forceinline__ void x_lds(const XArgs &q, double2 *lds, double2 *&a,
 
 // fillps folded into the x forward transform (fused substep, PUP mode): the row is not read from p but evaluated as
 // the divergence of (pup, pvp, pwp) (src/modpois.f90:968-970; pwp(ke+1) = 0 of bcpup), which then never exists in memory
+// nz: the level from which pwp(k+1) is bcpup's zero -- ktot under a closed lid, ktot + 1 (never) under the open one, whose row bcpup fills
 struct DivArgs { const double *pu, *pv, *pw; const double *dzfi; double dxi, dyi; int nz; };
 
 // x forward: rows j0..j0+L-1 of plane k0+kc -> send blocks
@@ -747,7 +748,9 @@ int fft_x_fwd_pack(udc_handle *h, int k0, int nzc, double *send, int g0, int g1,
   q.jg0 = g0;
   const dim3 gr((unsigned)(g1 - g0), (unsigned)nzc);
   const size_t lds = x_lds_bytes(h, h->fft_L);
-  const DivArgs dv{h->fields[UDC_UP], h->fields[UDC_VP], h->fields[UDC_WP], h->m.dzfi, h->m.dxi, h->m.dyi, h->g.nz};
+  // (open lid, BCtopm = 3: lid_bcpup_kernel has filled plane ke+1 of pwp -- "nz + 1 levels" makes the top cell read it instead of bcpup's zero)
+  const DivArgs dv{h->fields[UDC_UP], h->fields[UDC_VP], h->fields[UDC_WP], h->m.dzfi, h->m.dxi, h->m.dyi,
+                   h->g.nz + (h->p.bctopm == UDC_TOP_PRESSURE ? 1 : 0)};
   if (h->div_in_fft) {
     FFT_DISPATCH(ilog2(q.M), hipLaunchKernelGGL((fftx_fwd_pack_kernel<LM, true>), gr, dim3(xthreads(LM)), lds, st, q, (const double *)h->fields[UDC_P], dv,
                                                 tw, tw + q.M, reinterpret_cast<double2 *>(send)))
@@ -872,7 +875,8 @@ int fft_nat_forward(udc_handle *h) {
   const int M = g.nx / 2;
   NatArgs q{g.nx, M, padded(M + 1), g.ny, h->nkx, h->nkxp, g.sy, g.sz, ilog2(h->nat_L), h->nat_C, padded(g.ny)};
   const double2 *tw = reinterpret_cast<const double2 *>(h->fft_tw);
-  const DivArgs dv{h->fields[UDC_UP], h->fields[UDC_VP], h->fields[UDC_WP], h->m.dzfi, h->m.dxi, h->m.dyi, g.nz};
+  const DivArgs dv{h->fields[UDC_UP], h->fields[UDC_VP], h->fields[UDC_WP], h->m.dzfi, h->m.dxi, h->m.dyi,
+                   g.nz + (h->p.bctopm == UDC_TOP_PRESSURE ? 1 : 0)};      // (open lid: as in fft_x_fwd_pack)
   double2 *spec = reinterpret_cast<double2 *>(h->spec);
   {
     PROF(h, "fftx_pack_fwd");

@@ -516,7 +516,8 @@ int k_poisson_solve(udc_handle *h);
 int k_project(udc_handle *h);                       // tderive: up,vp,wp -= grad p ; pres0 += p
 // the open lid (BCtopm = 3): bcpup's, tderive's and tstep_integrate's row w(ke+1) (src/modboundary.f90:1234-1243, src/modpois.f90:1058-1069,
 // src/modtstep.f90:270-286); pup: the tendency arrays hold the predicted velocity; wrap: periodic ghost rows written here
-int k_lid_bcpup(udc_handle *h, double rk3coef, bool pup);
+int k_lid_bcpup(udc_handle *h, double rk3coef, bool pup, bool ptotal = false);
+bool k_lid_masked(const udc_handle *h);
 int k_lid_tderive(udc_handle *h);
 int k_lid_integrate(udc_handle *h, int rk3step, double dt, bool pup, bool zero, bool wrap);
 int k_integrate(udc_handle *h, int rk3step, double dt);
@@ -572,7 +573,7 @@ int k_checksim_begin(udc_handle *h, double dtmn);
 int k_checksim_end(udc_handle *h, double out[4]);
 // udc_xopen.hip: inflow / outflow in x
 int k_xo_ek_ghosts(udc_handle *h);                                  // closurebc's ekm(ib-1) = ekm(ib), ekm(ie+1) = ekm(ie)
-int k_xo_bcpup(udc_handle *h, double rk3coef, bool pup);            // bcpup's BCxm_profile branch
+int k_xo_bcpup(udc_handle *h, double rk3coef, bool pup, bool ptotal = false);            // bcpup's BCxm_profile branch
 int k_xo_after_integrate(udc_handle *h, int rk3step);               // v, w at ie+1 back from the outlet's planes (vm = v0 at stage 3)
 int k_xo_boundary(udc_handle *h);                                   // xmi_profile, xmo_convective (+ bcp's pres0 columns)
 int k_xo_poisson(udc_handle *h);                                    // the solve on the mirrored row

@@ -26,6 +26,7 @@ struct PlanIn {
   int p_transpose;      // switch UDC_P_TRANSPOSE: p's ghost rows ride in the backward transpose of the slab solve (own line transforms)
   int open_lid;         // BCtopm = 3 (BCtopm_pressure): w(ke+1) is prognostic -- bcpup, tderive and tstep_integrate have a row there,
                         // taken by three plane kernels beside the sweeps (k_lid_*, udc_pois.hip)
+  int lid_masked;       // ... and obstacles reach level ke: the lid's slab means run over the fluid c cells only (avexy_ibm)
   // this call
   int rk3step;
   int um_alias;         // um, vm, wm are logically u0, v0, w0 (the previous substep was an aliased stage 3)
@@ -81,8 +82,8 @@ inline Plan plan_substep(const PlanIn &in) {
   }
   p.mom_pipe = in.slab && p.lds && p.pup && in.mom_pipe && in.fft_fused && in.div_in_fft && plan_halo_overlap(in, in.mom_tile_rows) &&
                in.nslots == 0 && in.sgs != 3 && !in.between && in.x_row_groups >= 2 && in.levels_per_chunk >= 4 && !in.open_lid;
-  // (open lid: the divergence of level ke reads pwp(ke+1); only div_rhs_kernel knows that plane)
-  p.div_in_fft = p.pup && !in.open_lid && ((in.slab && in.fft_fused && in.div_in_fft) || (!in.slab && in.own_fwd));
+  // (open lid: the divergence of level ke reads pwp(ke+1), the plane bcpup's lid kernel fills ahead of the solve: the transform reads it too)
+  p.div_in_fft = p.pup && ((in.slab && in.fft_fused && in.div_in_fft) || (!in.slab && in.own_fwd));
   if (p.mom_pipe) p.vp_row = ROW_PIPED;
   else if (!p.fold || (in.ibm_on && in.ibm_edits_now))
     p.vp_row = (p.div_in_fft && plan_halo_overlap(in, 3) && in.x_row_groups >= 2) ? ROW_BESIDE : ROW_INLINE;
@@ -103,8 +104,13 @@ inline Plan plan_substep(const PlanIn &in) {
   // the periodic volume (the outflow-rate mass correction; the volume flow over the fluid cells of an immersed boundary) the two
   // forms differ: not there.  On y-slabs p's ghost row then travels both ways (it is pres0's), and pres0 leaves the
   // exchange of the new velocities' rows.
-  // Open lid: the lid's row of the right-hand side carries 2 <pres0>(ke) dzhi(ke+1), which is not the matrix' (closed) lid row applied
-  // to pres0: the reference's form there.
-  p.ptotal = in.ptotal && p.pup && !in.tend_plane && !in.open_lid;
+  // Open lid (last session of round 6): the matrix is the closed lid's plus, on the zero mode only, the Dirichlet row "p = 0 on the top face"
+  // (src/modpois.f90:207-217), i.e. A = L + T with (T q)(ke) = -2 <q>(ke) dzhi(ke+1) dzfi(ke).  The reference solves A p = div(pup_ref) with
+  // bcpup's lid row pwp(ke+1) = wm(ke+1) / rk3coef + 2 <pres0>(ke) dzhi(ke+1); adding A pres0 = L pres0 + T pres0 on both sides, the sum
+  // pres0 + p solves A (pres0 + p) = div(pup without grad pres0) with the lid row WITHOUT its pres0 term -- T pres0 cancels it exactly.  So
+  // the form holds with lid_bcpup_kernel leaving that term out (and, unlike under a closed lid, the constant of pres0 + p is the
+  // reference's too: the zero mode is not singular).  tderive's row 2 <p>(ke) dzhi(ke+1) then takes the mean of the sum.  Not where
+  // obstacles reach the lid: avexy_ibm's mean over the fluid cells of level ke is not the zero mode's.
+  p.ptotal = in.ptotal && p.pup && !in.tend_plane && !(in.open_lid && in.lid_masked);
   return p;
 }

@@ -741,12 +741,14 @@ __global__ __launch_bounds__(256) void zero_mode_mean_kernel(int nz, size_t stri
 // Planes of nx x ny cells: three small kernels beside the sweeps, which keep their closed-lid code.
 __device__ __forceinline__ double lid_mean(const double *S, double cnt) { return cnt > 0. ? S[0] / cnt : -999.; }
 // pup != 0: the tendency arrays hold the predicted velocity (the fused substep's form): wp(ke+1) takes pwp(ke+1)
+// S null: the pressure-total form -- the row carries no term of pres0 (planner, udc_plan.h: the solve then returns pres0 + p with the
+// Dirichlet row of the zero mode applied to the sum, and lid_tderive_kernel's 2 <pres0 + p>(ke) dzhi(ke+1) is the whole of it)
 __global__ void lid_bcpup_kernel(Geo g, double r, double dzhi_top, double cnt, const double *__restrict__ S,
                                  const double *__restrict__ wm, double *__restrict__ wp, int pup) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
   if (i >= g.nx) return;
   const long c = g.idx(i, j, g.nz);
-  const double pres0ij = lid_mean(S, cnt);
+  const double pres0ij = S ? lid_mean(S, cnt) : 0.;
   const double pwp = wm[c] * r + 2 * pres0ij * dzhi_top;
   wp[c] = pup ? pwp : pwp - wm[c] * r;
 }
@@ -1401,12 +1403,17 @@ static double lid_count(const udc_handle *h) {
   const bool masked = h->ibm_on && h->ibm[3].given && (int)h->ibm[3].fluid_cnt.size() > h->g.nz;
   return masked ? h->ibm[3].fluid_cnt[h->g.nz] : (double)(h->g.nx - 2 * h->g.xg) * (double)h->cfg.jtot;
 }
-int k_lid_bcpup(udc_handle *h, double rk3coef, bool pup) {
+// the slab mean the lid's rows take is a masked one (solid c cells in level ke: avexy_ibm's fluid-cell mean is then not the zero mode's)
+bool k_lid_masked(const udc_handle *h) {
+  return lid_count(h) != (double)(h->g.nx - 2 * h->g.xg) * (double)h->cfg.jtot;
+}
+int k_lid_bcpup(udc_handle *h, double rk3coef, bool pup, bool ptotal) {
   const Geo &g = h->g;
-  if (k_level_sums_dev(h, UDC_PRES0, 1, g.nz - 1)) return 1;
+  if (ptotal && !pup) { udc_set_error("k_lid_bcpup: the pressure-total form needs the predicted-velocity form of the tendencies"); return 1; }
+  if (!ptotal && k_level_sums_dev(h, UDC_PRES0, 1, g.nz - 1)) return 1;
   PROF(h, "lid");
   hipLaunchKernelGGL(lid_bcpup_kernel, dim3((g.nx + 63) / 64, g.ny), dim3(64), 0, h->stream, g, 1. / rk3coef, h->dzhi_top, lid_count(h),
-                     (const double *)h->lev_sum16, (const double *)h->fields[UDC_WM], h->fields[UDC_WP], pup ? 1 : 0);
+                     (const double *)(ptotal ? nullptr : h->lev_sum16), (const double *)h->fields[UDC_WM], h->fields[UDC_WP], pup ? 1 : 0);
   HIP_OK(hipGetLastError());
   return 0;
 }

@@ -56,7 +56,8 @@ __global__ void xo_ek_kernel(Geo g, double *__restrict__ ekm, double *__restrict
 template <bool PUP>
 __global__ void xo_bcpup_kernel(Geo g, double rk3coefi, double dxi, const double *__restrict__ prof, const double *__restrict__ inlet,
                                 const double *__restrict__ uout,
-                                const double *__restrict__ u0, const double *__restrict__ um, double *__restrict__ up) {
+                                const double *__restrict__ u0, const double *__restrict__ um, double *__restrict__ up,
+                                const double *__restrict__ pres0) {
   int jj, kk;
   if (!plane_decode(g, jj, kk)) return;
   const int j = jj - HY, k = kk - HZ;
@@ -68,7 +69,11 @@ __global__ void xo_bcpup_kernel(Geo g, double rk3coefi, double dxi, const double
   const double ume = um[r + e];
   double pe;
   if (k > 0 || inlet) pe = ume * rk3coefi - (u0[r + e] - u0[r + e - 1]) * dxi * uout[0];
-  else pe = PUP ? up[r + e - 1] : up[r + e - 1] + um[r + e - 1] * rk3coefi;      // "Neumann at bottom": pup(ie+1, kb) = pup(ie, kb)
+  else {
+    pe = PUP ? up[r + e - 1] : up[r + e - 1] + um[r + e - 1] * rk3coefi;      // "Neumann at bottom": pup(ie+1, kb) = pup(ie, kb)
+    // (pressure-total form: the sweep left grad pres0 out of pup(ie); the reference's copy carries it -- and nothing else at ie+1 does)
+    if (pres0) pe -= (pres0[r + e - 1] - pres0[r + e - 2]) * dxi;
+  }
   up[r + e] = PUP ? pe : pe - ume * rk3coefi;
 }
 
@@ -379,7 +384,6 @@ extern "C" int udc_set_open_x_inlet_scalar(udc_handle *h, int field, const doubl
     udc_set_error("udc_set_open_x_inlet_scalar: the planes must cover j = jb-1 .. je+1, k = kb .. ke+1");
     return 1;
   }
-  const size_t np = (size_t)g.py * g.pz;
   int slot = -1;
   if (field == UDC_THL0 || field == UDC_QT0) {
     if ((int)h->fields.size() <= field || !h->fields[field]) { udc_set_error("udc_set_open_x_inlet_scalar: udc_set_tempeq / udc_set_moisture first"); return 1; }
@@ -403,7 +407,7 @@ extern "C" int udc_set_open_x_qt(udc_handle *h, const double *qtprof) {
   if (!h->xg) { udc_set_error("udc_set_open_x_qt: not a handle of udc_create_open_x"); return 1; }
   if (!h->lmoist || (int)h->fields.size() <= UDC_QT0 || !h->fields[UDC_QT0]) { udc_set_error("udc_set_open_x_qt: call udc_set_moisture first"); return 1; }
   const Geo &g = h->g;
-  const size_t nk = (size_t)g.nz + 2, np = (size_t)g.py * g.pz;
+  const size_t nk = (size_t)g.nz + 2;
   HIP_OK(hipStreamSynchronize(h->stream));
   if (!h->xo_qt_prof) HIP_OK(hipMalloc(&h->xo_qt_prof, sizeof(double) * nk));
   if (xo_alloc_east_west(h, UDC_QT0, UDC_QTM, &h->xo_qt_east, &h->xo_qt_west)) return 1;
@@ -459,17 +463,19 @@ int k_xo_ek_ghosts(udc_handle *h) {
   return 0;
 }
 
-int k_xo_bcpup(udc_handle *h, double rk3coef, bool pup) {
+int k_xo_bcpup(udc_handle *h, double rk3coef, bool pup, bool ptotal) {
   if (!h->xg) return 0;
   const Geo &g = h->g;
   PROF(h, "xo_ghosts");
   const double *inlet = h->xo_driver ? h->xo_inlet_now : nullptr;      // (u0driver: the first of its six planes)
   if (pup)
     hipLaunchKernelGGL(xo_bcpup_kernel<true>, plane_grid(g), dim3(64), 0, h->stream, g, 1. / rk3coef, h->m.dxi, (const double *)h->xo_prof, inlet,
-                       (const double *)h->bcx_uout_dev, (const double *)h->fields[UDC_U0], (const double *)h->fields[UDC_UM], h->fields[UDC_UP]);
+                       (const double *)h->bcx_uout_dev, (const double *)h->fields[UDC_U0], (const double *)h->fields[UDC_UM], h->fields[UDC_UP],
+                       (const double *)(ptotal ? h->fields[UDC_PRES0] : nullptr));
   else
     hipLaunchKernelGGL(xo_bcpup_kernel<false>, plane_grid(g), dim3(64), 0, h->stream, g, 1. / rk3coef, h->m.dxi, (const double *)h->xo_prof, inlet,
-                       (const double *)h->bcx_uout_dev, (const double *)h->fields[UDC_U0], (const double *)h->fields[UDC_UM], h->fields[UDC_UP]);
+                       (const double *)h->bcx_uout_dev, (const double *)h->fields[UDC_U0], (const double *)h->fields[UDC_UM], h->fields[UDC_UP],
+                       (const double *)nullptr);
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -536,7 +542,7 @@ extern "C" int udc_set_open_x_thl(udc_handle *h, const double *thlprof) {
   if (!h->xg) { udc_set_error("udc_set_open_x_thl: not a handle of udc_create_open_x"); return 1; }
   if ((int)h->fields.size() <= UDC_THL0 || !h->fields[UDC_THL0]) { udc_set_error("udc_set_open_x_thl: call udc_set_tempeq first"); return 1; }
   const Geo &g = h->g;
-  const size_t nk = (size_t)g.nz + 2, np = (size_t)g.py * g.pz;
+  const size_t nk = (size_t)g.nz + 2;
   HIP_OK(hipStreamSynchronize(h->stream));
   if (!h->xo_thl_prof) HIP_OK(hipMalloc(&h->xo_thl_prof, sizeof(double) * nk));
   if (xo_alloc_east_west(h, UDC_THL0, UDC_THLM, &h->xo_thl_east, &h->xo_thl_west)) return 1;
