@@ -899,6 +899,15 @@ void orc_halos_m(const orc_grid *g, double *a) {
   for (int k = 0; k <= nz + 1; ++k)
     for (int i = 0; i <= nx + 1; ++i) { M(a, i, 0, k) = M(a, i, ny, k); M(a, i, ny + 1, k) = M(a, i, 1, k); }
 }
+/* xT_periodic / xq_periodic (:543-577) ahead of the y refresh: the temperature and the total water where they stay periodic in x beside an
+ * inflow / outflow (BCxT = BCxq = 1 with BCxm = 2 / 3, the reference's defaults: `halos` calls them under `ibrank .and. ierank`, :95-100) */
+static void halos_m_periodic_x(const orc_grid *g, double *a) {
+  const int nx = g->nx, ny = g->ny, nz = g->nz;
+  if (xo_on)
+    for (int k = 0; k <= nz + 1; ++k)
+      for (int j = 0; j <= ny + 1; ++j) { M(a, 0, j, k) = M(a, nx, j, k); M(a, nx + 1, j, k) = M(a, 1, j, k); }
+  orc_halos_m(g, a);
+}
 /* xs_periodic, ys_periodic: :580-593, 670-685 (halo 2) */
 void orc_halos_c(const orc_grid *g, double *a) {
   const int nx = g->nx, ny = g->ny, nz = g->nz;
@@ -1002,7 +1011,7 @@ void orc_boundary_open_x(const orc_grid *g, double rk3coef, double *u0, double *
     }
 }
 /* ... and the temperature's, BCxT = 2: xTi_profile (src/modboundary.f90:766-793), xTo_convective (:947-957); thlprof [nz+2] by k */
-static const double *xo_thlprof = NULL;
+static const double *xo_thlprof = NULL, *xo_qtprof = NULL;
 void orc_set_open_x_thl(const double *thlprof) { xo_thlprof = thlprof; }
 void orc_boundary_open_x_thl(const orc_grid *g, double rk3coef, double *thl0, double *thlm) {
   const int nx = g->nx, ny = g->ny, nz = g->nz;
@@ -1019,6 +1028,24 @@ void orc_boundary_open_x_thl(const orc_grid *g, double rk3coef, double *thl0, do
     }
 }
 /* ... and the passive scalars', BCxs = 2: xsi_profile (src/modboundary.f90:844-861), xso_convective (:983-996); svprof [nsv][nz+2] by k */
+/* BCxq = 2: xqi_profile (src/modboundary.f90:811-823: the ghost mirrored about qtprof) and xqo_convective (:961-971 -- which starts from
+ * qt(ie), not from qt(ie+1) like its siblings: as it is) */
+void orc_set_open_x_qt(const double *qtprof) { xo_qtprof = qtprof; }
+void orc_boundary_open_x_qt(const orc_grid *g, double rk3coef, double *qt0, double *qtm) {
+  const int nx = g->nx, ny = g->ny, nz = g->nz;
+  const double dxi = 1. / g->dx;
+  if (!xo_on || !xo_qtprof) return;
+  for (int j = 0; j <= ny + 1; ++j)
+    for (int k = 1; k <= nz + 1; ++k) {
+      M(qt0, 0, j, k) = 2 * xo_qtprof[k] - M(qt0, 1, j, k);
+      M(qtm, 0, j, k) = 2 * xo_qtprof[k] - M(qtm, 1, j, k);
+    }
+  for (int k = 0; k <= nz + 1; ++k)
+    for (int j = 0; j <= ny + 1; ++j) {
+      M(qt0, nx + 1, j, k) = M(qt0, nx, j, k) - (M(qt0, nx + 1, j, k) - M(qt0, nx, j, k)) * dxi * rk3coef * xo_uouttot;
+      M(qtm, nx + 1, j, k) = M(qtm, nx, j, k) - (M(qtm, nx + 1, j, k) - M(qtm, nx, j, k)) * dxi * rk3coef * xo_uouttot;
+    }
+}
 static const double *xo_svprof = NULL;
 void orc_set_open_x_scalars(const double *svprof) { xo_svprof = svprof; }
 void orc_boundary_open_x_sv(const orc_grid *g, double rk3coef, double *sv0, double *svm) {
@@ -2122,7 +2149,8 @@ void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
         for (int i = 1; i <= g->nx; ++i) M(s->thl0, i, j, k) = M(s->thlm, i, j, k) + rk3c * M(s->thlp, i, j, k);
     memset(s->thlp, 0, nm * sizeof(double));
     if (rk3step == 3) memcpy(s->thlm, s->thl0, nm * sizeof(double));
-    orc_halos_m(g, s->thl0); orc_halos_m(g, s->thlm);
+    if (xo_thlprof) { orc_halos_m(g, s->thl0); orc_halos_m(g, s->thlm); }
+    else { halos_m_periodic_x(g, s->thl0); halos_m_periodic_x(g, s->thlm); }      /* (BCxT = 1 beside an open flow) */
   }
   if (g->lmoist) {                                                                       /* src/modtstep.f90:256,328,337 */
     const size_t nm = msize(g);
@@ -2132,7 +2160,8 @@ void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
         for (int i = 1; i <= g->nx; ++i) M(s->qt0, i, j, k) = M(s->qtm, i, j, k) + rk3c * M(s->qtp, i, j, k);
     memset(s->qtp, 0, nm * sizeof(double));
     if (rk3step == 3) memcpy(s->qtm, s->qt0, nm * sizeof(double));
-    orc_halos_m(g, s->qt0); orc_halos_m(g, s->qtm);
+    if (xo_qtprof) { orc_halos_m(g, s->qt0); orc_halos_m(g, s->qtm); }
+    else { halos_m_periodic_x(g, s->qt0); halos_m_periodic_x(g, s->qtm); }      /* (BCxq = 1 beside an open flow) */
   }
   orc_halos_m(g, s->u0); orc_halos_m(g, s->v0); orc_halos_m(g, s->w0);
   orc_halos_m(g, s->um); orc_halos_m(g, s->vm); orc_halos_m(g, s->wm);
@@ -2145,5 +2174,6 @@ void orc_substep(const orc_grid *g, orc_state *s, int rk3step, double dt) {
   if (g->nsv > 0 && xo_on) orc_boundary_open_x_sv(g, rk3coef, s->sv0, s->svm);                /* :300-314, 379 */
   if (g->ltempeq && g->iadv_thl == 7) orc_thl0c_from(g, s->thl0, s->thl0c);                 /* src/modtstep.f90:249 + halos + boundary */
   if (g->lmoist) { orc_qt_top(g, s->ekh, s->qtm); orc_qt_top(g, s->ekh, s->qt0); }          /* src/modboundary.f90:222-231 */
+  if (g->lmoist && xo_on) orc_boundary_open_x_qt(g, rk3coef, s->qt0, s->qtm);               /* :285-297, 378 */
   if (g->lmoist && s->thermo) orc_thermodynamics(g, s);                                     /* src/program.f90:214 */
 }
