@@ -163,7 +163,7 @@ def test_each_routine_matches_reference(name, iexp):
 
 @pytest.mark.parametrize("fused", [True, False, "deferred"])
 @pytest.mark.parametrize("name,iexp", sorted(R_CASES.items()))
-def test_substeps_match_reference(name, iexp, fused):
+def test_substeps_match_reference(name, iexp, fused, want_div_in_transform=False):
     """Chained substeps from the state the reference's start-up left (s000, x ghost columns included): the fused substep, the
     reference's routine-by-routine order, and that order with deferred execution."""
     fix = load_fixture(name)
@@ -223,9 +223,19 @@ def test_substeps_match_reference(name, iexp, fused):
     if fused is True:
         plan = core.last_plan()
         assert plan["pressure_total_form"] and not plan["slab_layout"]      # (under the open lid too: udc_plan.h)
+        assert plan["divergence_in_x_transform"] == want_div_in_transform
     div = core.divergence()
     assert div[0] < 1e-12
     core.close()
+
+
+@pytest.mark.parametrize("name", ["run_xopen_16x8x12s", "run_xopen_volflow_16x8x12s", "run_xopen_moist_16x8x12s", "run_xopen_sv_16x8x12s"])
+def test_divergence_inside_the_doubled_rows_transform(name, monkeypatch):
+    """UDC_OWN_FWD=1 (the library's default from 128 rows on): the fused substep writes no right-hand side -- the x transform of the solver's
+    doubled row evaluates the divergence of the handle's tendencies itself, the interior columns and their mirror image (fftx_fwd_nat_kernel<LM,
+    true>).  Same fixtures, same tolerance; 2 itot = 32 here (the 256^3 property test runs it by default)."""
+    monkeypatch.setenv("UDC_OWN_FWD", "1")
+    test_substeps_match_reference(name, R_CASES[name], True, want_div_in_transform=True)
 
 
 @pytest.mark.parametrize("name", ["run_xopen_16x8x12s", "run_xopen_ibmwf3_16x12x10", "run_xopen_thl_16x8x12s", "run_xopen_ibm_sv_16x12x10", "run_xopen_moist_16x8x12s"])

@@ -1156,8 +1156,9 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   pin.ek_always = h->ek_always; pin.halo_overlap = !h->no_halo_overlap; pin.mom_pipe = !h->no_mom_pipe; pin.div_in_fft = !h->no_div_in_fft; pin.ptotal = h->sw.ptotal; pin.p_transpose = h->sw.p_transpose;
   pin.slab = h->slab; pin.comm_stream = h->comm_stream != nullptr; pin.sgs = h->p.sgs; pin.lbuoycorr = h->lbuoycorr;
   pin.nslots = (int)h->slots.size(); pin.ibm_on = h->ibm_on; pin.stats_any = h->stats_on || h->xyt_on || h->yt_on;
-  pin.fft_fused = h->fft_fused; pin.own_fwd = h->own_fwd && !h->xg;      // (open x boundaries: the solve's transforms run on the doubled row of h->xpois)
-  pin.tend_plane = h->luvolflowr == 2 || (h->ibm_on && (h->luvolflowr || h->lvvolflowr));
+  pin.fft_fused = h->fft_fused; pin.own_fwd = h->xg ? (h->xpois && h->xpois->own_fwd) : h->own_fwd;      // (open x boundaries: the solve's transforms run on the doubled row of h->xpois)
+  // (inflow / outflow in x: masscorr is off altogether, k_masscorr -- a prescribed flow rate only names the outlet's speed)
+  pin.tend_plane = !h->xg && (h->luvolflowr == 2 || (h->ibm_on && (h->luvolflowr || h->lvvolflowr)));
   pin.between = h->coriolis_mode || !h->level_forcings.empty() || h->luvolflowr || h->lvvolflowr || h->ibm_on || h->shift_a != 0. ||
                 h->thlpcar || h->lbuoyancy;
   pin.closure_tile_rows = closure_lds_tile_rows(h->g); pin.mom_tile_rows = momentum_lds_tile_rows(h->g); pin.int_tile_rows = tile_grid(h->g).gy;

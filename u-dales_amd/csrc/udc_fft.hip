@@ -133,7 +133,10 @@ __device__ __forceinline__ void x_lds(const XArgs &q, double2 *lds, double2 *&a,
 // fillps folded into the x forward transform (fused substep, PUP mode): the row is not read from p but evaluated as
 // the divergence of (pup, pvp, pwp) (src/modpois.f90:968-970; pwp(ke+1) = 0 of bcpup), which then never exists in memory
 // nz: the level from which pwp(k+1) is bcpup's zero -- ktot under a closed lid, ktot + 1 (never) under the open one, whose row bcpup fills
-struct DivArgs { const double *pu, *pv, *pw; const double *dzfi; double dxi, dyi; int nz; };
+// xo_n > 0 (fftx_fwd_nat_kernel<LM, true>): the arrays are those of a handle with open x boundaries (strides sy, sz; udc_xopen.hip) and the row
+// transformed is the divergence of its xo_n interior columns, from column xo_g on, followed by its mirror image -- what div_rhs_kernel wrote
+// into the solver's doubled row, 40 B per cell that now stay in LDS
+struct DivArgs { const double *pu, *pv, *pw; const double *dzfi; double dxi, dyi; int nz; int xo_n = 0, xo_g = 0, sy = 0; long sz = 0; };
 
 // x forward: rows j0..j0+L-1 of plane k0+kc -> send blocks
 template <int LM, bool DIV>
@@ -438,7 +441,7 @@ struct NatArgs {
   int C, YP;                // columns per workgroup and LDS pitch of a column (y kernel)
 };
 
-template <int LM>
+template <int LM, bool XO = false>
 __global__ __launch_bounds__(xthreads(LM)) void fftx_fwd_nat_kernel(NatArgs q, DivArgs dv, const double2 *__restrict__ twM,
                                                                     const double2 *__restrict__ twN, double2 *__restrict__ spec) {
   extern __shared__ double2 lds[];
@@ -447,6 +450,23 @@ __global__ __launch_bounds__(xthreads(LM)) void fftx_fwd_nat_kernel(NatArgs q, D
   double2 *a = lds, *b = lds + L * q.MP, *tw = b + L * q.MP;
   for (int n = tid; n < M; n += NTH) tw[n] = twM[n];
   const int j0 = blockIdx.x << q.lL, k = blockIdx.y;
+  if (XO) {
+    // M pairs per row = 2 xo_n reals: pair nn < M/2 holds the cells 2 nn, 2 nn + 1 of the interior, pair M - 1 - nn their mirror image
+    for (int wi = tid; wi < ((M / 2) << q.lL); wi += NTH) {
+      const int l = wi >> (LM - 1), nn = wi & (M / 2 - 1);
+      const long ro = dv.sz * (long)(k + HZ) + (long)dv.sy * (j0 + l + HY) + dv.xo_g + 2 * nn;
+      const double u0 = dv.pu[ro], u1 = dv.pu[ro + 1], u2 = dv.pu[ro + 2];
+      const double va = dv.pv[ro], vb = dv.pv[ro + 1], va1 = dv.pv[ro + dv.sy], vb1 = dv.pv[ro + dv.sy + 1];
+      const double wa = dv.pw[ro], wb = dv.pw[ro + 1];
+      double wa1 = 0., wb1 = 0.;
+      if (k < dv.nz - 1) { wa1 = dv.pw[ro + dv.sz]; wb1 = dv.pw[ro + dv.sz + 1]; }
+      const double dz = dv.dzfi[k + 1];
+      const double d0 = (u1 - u0) * dv.dxi + (va1 - va) * dv.dyi + (wa1 - wa) * dz;
+      const double d1 = (u2 - u1) * dv.dxi + (vb1 - vb) * dv.dyi + (wb1 - wb) * dz;
+      a[l * q.MP + pad(nn)] = make_double2(d0, d1);
+      a[l * q.MP + pad(M - 1 - nn)] = make_double2(d1, d0);
+    }
+  } else
   for (int wi = tid; wi < (M << q.lL); wi += NTH) {
     const int l = wi >> LM, n = wi & (M - 1);
     const long ro = q.sz * (long)(k + HZ) + (long)q.sy * (j0 + l + HY);
@@ -861,6 +881,7 @@ int fft_nat_init(udc_handle *h) {
   const int lmx = ilog2(M), lmy = ilog2(ny);
   if (ldsx > 65536) {
     FFT_DISPATCH(lmx, HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(fftx_fwd_nat_kernel<LM>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsx)))
+    FFT_DISPATCH(lmx, HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(fftx_fwd_nat_kernel<LM, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsx)))
   }
   if (ldsy > 65536) {
     FFT_DISPATCH(lmy, HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(ffty_nat_kernel<LM>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsy)))
@@ -875,13 +896,20 @@ int fft_nat_forward(udc_handle *h) {
   const int M = g.nx / 2;
   NatArgs q{g.nx, M, padded(M + 1), g.ny, h->nkx, h->nkxp, g.sy, g.sz, ilog2(h->nat_L), h->nat_C, padded(g.ny)};
   const double2 *tw = reinterpret_cast<const double2 *>(h->fft_tw);
-  const DivArgs dv{h->fields[UDC_UP], h->fields[UDC_VP], h->fields[UDC_WP], h->m.dzfi, h->m.dxi, h->m.dyi,
-                   g.nz + (h->p.bctopm == UDC_TOP_PRESSURE ? 1 : 0)};      // (open lid: as in fft_x_fwd_pack)
+  // (this handle is the solver's doubled row of a handle with open x boundaries: the tendencies are that handle's, k_xo_poisson)
+  const udc_handle *src = h->xo_src ? h->xo_src : h;
+  DivArgs dv{src->fields[UDC_UP], src->fields[UDC_VP], src->fields[UDC_WP], src->m.dzfi, src->m.dxi, src->m.dyi,
+             g.nz + (src->p.bctopm == UDC_TOP_PRESSURE ? 1 : 0)};      // (open lid: as in fft_x_fwd_pack)
+  if (src != h) { dv.xo_n = g.nx / 2; dv.xo_g = src->g.xg; dv.sy = src->g.sy; dv.sz = src->g.sz; }
   double2 *spec = reinterpret_cast<double2 *>(h->spec);
   {
     PROF(h, "fftx_pack_fwd");
     const dim3 gr((unsigned)(g.ny >> q.lL), (unsigned)g.nz);
-    FFT_DISPATCH(ilog2(M), hipLaunchKernelGGL(fftx_fwd_nat_kernel<LM>, gr, dim3(xthreads(LM)), nat_x_lds(M, h->nat_L), h->stream, q, dv, tw, tw + M, spec))
+    if (src != h) {
+      FFT_DISPATCH(ilog2(M), hipLaunchKernelGGL((fftx_fwd_nat_kernel<LM, true>), gr, dim3(xthreads(LM)), nat_x_lds(M, h->nat_L), h->stream, q, dv, tw, tw + M, spec))
+    } else {
+      FFT_DISPATCH(ilog2(M), hipLaunchKernelGGL(fftx_fwd_nat_kernel<LM>, gr, dim3(xthreads(LM)), nat_x_lds(M, h->nat_L), h->stream, q, dv, tw, tw + M, spec))
+    }
     HIP_OK(hipGetLastError());
   }
   {

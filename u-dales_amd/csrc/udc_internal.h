@@ -297,6 +297,7 @@ struct udc_handle {
   bool xo_rhs_mirrored = false;       // the divergence kernel has written the right-hand side into the solver's doubled row itself
   bool xo_hold = false;               // the next refresh of uouttot is skipped (udc_set_open_x_outflow, hold_first)
   udc_handle *xpois = nullptr;        // the pressure solve's own periodic domain: the row and its mirror image, 2 itot wide
+  const udc_handle *xo_src = nullptr; // (that handle, during a solve whose x transform evaluates the divergence of the owner's tendencies itself)
   bool poisson_only = false;          // (that handle: p and the solver's arrays only)
   hipEvent_t xo_ev[2] = {nullptr, nullptr};
   int bczp = 1;              // &BC BCzp: 1 tridiagonal solve in z, 2 the cosine transform's solution (udc_set_poisson_bczp)

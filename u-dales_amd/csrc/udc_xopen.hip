@@ -581,6 +581,9 @@ int k_xo_poisson(udc_handle *h) {
   const int n = g.nx - 2 * g.xg;
   const dim3 b(256), gr((unsigned)((n + 255) / 256), (unsigned)g.ny, (unsigned)g.nz);
   hp->bczp = h->bczp;
+  const bool div_in = h->div_in_fft;      // (the fused substep skipped k_divergence_rhs: the doubled row's x transform evaluates it, udc_fft.hip)
+  if (div_in) { hp->div_in_fft = true; hp->xo_src = h; }
+  else
   if (!h->xo_rhs_mirrored) {      // (a right-hand side that did not come from k_divergence_rhs)
     PROF(h, "xo_mirror");
     hipLaunchKernelGGL(xo_gather_kernel, gr, b, 0, h->stream, g, g2, (const double *)h->fields[UDC_P], hp->fields[UDC_P]);
@@ -589,7 +592,9 @@ int k_xo_poisson(udc_handle *h) {
   h->xo_rhs_mirrored = false;
   {
     PROF(h, "poisson_2x");      // (the doubled row's transforms and tridiagonal solves, on this handle's stream)
-    if (k_poisson_solve(hp)) return 1;
+    const int rc = k_poisson_solve(hp);
+    hp->div_in_fft = false; hp->xo_src = nullptr;
+    if (rc) return 1;
   }
   PROF(h, "xo_mirror");
   hipLaunchKernelGGL(xo_scatter_kernel, gr, b, 0, h->stream, g, g2, (const double *)hp->fields[UDC_P], h->fields[UDC_P]);
