@@ -1076,6 +1076,7 @@ extern "C" int udc_halos(udc_handle *h) {
   ENTRY_FLUSH(h);
   if (h->halos_fresh) return 0;       // the fused substep already exchanged them and nothing changed since
   if (um_materialise(h)) return 1;
+  if (k_xo_halos(h)) return 1;
   const int f[6] = {UDC_U0, UDC_V0, UDC_W0, UDC_UM, UDC_VM, UDC_WM};
   if (k_halo_y(h, f, 6, 1)) return 1;
   std::vector<int> s;

@@ -550,6 +550,19 @@ extern "C" int udc_set_open_x_thl(udc_handle *h, const double *thlprof) {
   return 0;
 }
 
+// `halos` on such a handle: xT_periodic / xq_periodic for a temperature / total water that stays periodic in x (src/modboundary.f90:95-100),
+// ahead of the y refresh like there
+int k_xo_halos(udc_handle *h) {
+  if (!h->xg) return 0;
+  const Geo &g = h->g;
+  if (!(h->xo_thl_prof || h->xo_sc_in_now[0]) && (int)h->fields.size() > UDC_THL0 && h->fields[UDC_THL0])
+    hipLaunchKernelGGL(xo_wrap_kernel, plane_grid(g), dim3(64), 0, h->stream, g, h->fields[UDC_THL0], h->fields[UDC_THLM]);
+  if (!(h->xo_qt_prof || h->xo_sc_in_now[1]) && h->lmoist && (int)h->fields.size() > UDC_QT0 && h->fields[UDC_QT0])
+    hipLaunchKernelGGL(xo_wrap_kernel, plane_grid(g), dim3(64), 0, h->stream, g, h->fields[UDC_QT0], h->fields[UDC_QTM]);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
 int k_xo_after_integrate(udc_handle *h, int rk3step) {
   if (!h->xg) return 0;
   const Geo &g = h->g;
