@@ -1371,7 +1371,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   if (!s.empty() && !ov_scal && k_halo_y(h, s.data(), (int)s.size(), 2)) return 1;
   if (!fold || !h->slots.empty()) { if (k_top_bottom(h)) return 1; }
   if (k_scalar_bcx_outlet(h)) return 1;
-  if (k_xo_after_integrate(h, rk3step) || k_xo_boundary(h)) return 1;
+  if (k_xo_after_integrate(h, rk3step, true) || k_xo_boundary(h, rk3step == 3 ? 1 : 0)) return 1;
   h->halos_fresh = h->boundary_fresh = true;
   if (h->lmoist && h->mt) {                                             // src/program.f90:214
     if (k_thermodynamics(h)) return 1;

@@ -575,9 +575,9 @@ int k_checksim_end(udc_handle *h, double out[4]);
 // udc_xopen.hip: inflow / outflow in x
 int k_xo_ek_ghosts(udc_handle *h);                                  // closurebc's ekm(ib-1) = ekm(ib), ekm(ie+1) = ekm(ie)
 int k_xo_bcpup(udc_handle *h, double rk3coef, bool pup, bool ptotal = false);            // bcpup's BCxm_profile branch
-int k_xo_after_integrate(udc_handle *h, int rk3step);               // v, w at ie+1 back from the outlet's planes (vm = v0 at stage 3)
+int k_xo_after_integrate(udc_handle *h, int rk3step, bool boundary_follows = false);               // v, w at ie+1 back from the outlet's planes (vm = v0 at stage 3)
 int k_xo_halos(udc_handle *h);                                      // xT_periodic / xq_periodic where those stay periodic beside the open flow
-int k_xo_boundary(udc_handle *h);                                   // xmi_profile, xmo_convective (+ bcp's pres0 columns)
+int k_xo_boundary(udc_handle *h, int merged_stage3 = -1);                                   // xmi_profile, xmo_convective (+ bcp's pres0 columns)
 int k_xo_poisson(udc_handle *h);                                    // the solve on the mirrored row
 int xo_init(udc_handle *h, const double *uprof, const double *vprof);
 void xo_destroy(udc_handle *h);

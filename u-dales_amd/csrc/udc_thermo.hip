@@ -310,13 +310,21 @@ __global__ __launch_bounds__(256) void diagfld_kernel(DiagArgs a, double *mt, co
 }
 
 // plain per-level slab sums (stage 1; levelsum_final_kernel is stage 2): levels k = 0..nlev-1 (device), i.e. 1..nlev
+// (a thread walks MS_ROWS rows of 64 cells, like the moist sums: one cell per thread left the level sums of a 256^3 field at 2 TB/s --
+//  69 us per substep of an inflow / outflow run, whose outlet speed is the mean of u's slab averages; rocprofv3 table of profiles/r06)
 __global__ __launch_bounds__(256) void levelsum_plain_kernel(Geo g, int gx, const double *__restrict__ f, double *__restrict__ part, int k0 = 0) {
   __shared__ double sw[4];
   const int tile = blockIdx.x, k = blockIdx.y;
   const int by = tile / gx, bx = tile - by * gx;
-  const int i = bx * 64 + threadIdx.x, j = by * 4 + threadIdx.y;
+  const int i = bx * 64 + threadIdx.x;
   double v = 0.;
-  if (i >= g.xg && i < g.nx - g.xg && j < g.ny) v = f[g.idx(i, j, k0 + k)];      // (open x boundaries: the interior columns)
+  if (i >= g.xg && i < g.nx - g.xg) {      // (open x boundaries: the interior columns)
+#pragma unroll
+    for (int r = 0; r < MS_ROWS; ++r) {
+      const int j = (by * MS_ROWS + r) * 4 + threadIdx.y;
+      if (j < g.ny) v += f[g.idx(i, j, k0 + k)];
+    }
+  }
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   if (threadIdx.x == 0) sw[threadIdx.y] = v;
   __syncthreads();
@@ -343,7 +351,8 @@ int k_slab_averages(udc_handle *h, const int *fields, int nf, double *avg_host, 
   if (nf < 1 || nf > 16) { udc_set_error("udc_slab_averages: at most 16 fields per call"); return 1; }
   for (int q = 0; q < nf; ++q)
     if (fields[q] < 0 || fields[q] >= (int)h->fields.size() || !h->fields[fields[q]]) { udc_set_error("udc_slab_average: unknown field %d", fields[q]); return 1; }
-  const TileGrid tg = tile_grid(g);
+  TileGrid tg = tile_grid(g);
+  tg.tiles = tg.gx * ((g.ny + 4 * MS_ROWS - 1) / (4 * MS_ROWS));      // 64 x (4 MS_ROWS) cells per workgroup of levelsum_plain_kernel
   const size_t need = (size_t)tg.tiles * n * nf;
   if (h->lev_cap < need) {
     if (h->lev_part) HIP_OK(hipFree(h->lev_part));
@@ -380,7 +389,8 @@ int k_slab_average(udc_handle *h, int field, double *avg_host, int n) { return k
 // slabs, left in h->lev_sum16[0..n) on the device (no host round trip: for kernels that consume them)
 int k_level_sums_dev(udc_handle *h, int field, int n, int k0) {
   const Geo &g = h->g;
-  const TileGrid tg = tile_grid(g);
+  TileGrid tg = tile_grid(g);
+  tg.tiles = tg.gx * ((g.ny + 4 * MS_ROWS - 1) / (4 * MS_ROWS));
   const size_t need = (size_t)tg.tiles * n;
   if (h->lev_cap < need) {
     if (h->lev_part) HIP_OK(hipFree(h->lev_part));

@@ -81,7 +81,7 @@ __global__ void xo_bcpup_kernel(Geo g, double rk3coefi, double dxi, const double
 __global__ void xo_boundary_kernel(Geo g, const double *__restrict__ prof, const double *__restrict__ inlet, double dxi, double rk3coef,
                                    const double *__restrict__ uout, double *__restrict__ u0, double *__restrict__ v0, double *__restrict__ w0,
                                    double *__restrict__ um, double *__restrict__ vm, double *__restrict__ wm,
-                                   double *__restrict__ pres0, double *__restrict__ east, double *__restrict__ west) {
+                                   double *__restrict__ pres0, double *__restrict__ east, double *__restrict__ west, int stage3) {
   int jj, kk;
   if (!plane_decode(g, jj, kk)) return;
   const int j = jj - HY, k = kk - HZ;
@@ -108,6 +108,9 @@ __global__ void xo_boundary_kernel(Geo g, const double *__restrict__ prof, const
   if (j >= -1 && j <= g.ny && k >= 0 && k < g.nz) { pres0[r] = pres0[r + 1]; pres0[r + e] = pres0[r + e - 1]; }
   // the outlet: every row and plane the arrays hold
   double ev0 = east[q], ew0 = east[P + q], evm = east[2 * P + q], ewm = east[3 * P + q];
+  // (stage3 > 0: the fused substep -- this launch stands for xo_restore_kernel too, whose every array element it overwrites: the m planes
+  //  take the 0 planes first, as tstep_integrate's vm = v0 on RK stage 3)
+  if (stage3 > 0) { evm = ev0; ewm = ew0; }
   const double uo = uout[0];
   ev0 = ev0 - (ev0 - v0[r + e - 1]) * dxi * rk3coef * uo;
   ew0 = ew0 - (ew0 - w0[r + e - 1]) * dxi * rk3coef * uo;
@@ -480,7 +483,7 @@ int k_xo_bcpup(udc_handle *h, double rk3coef, bool pup, bool ptotal) {
   return 0;
 }
 
-int k_xo_boundary(udc_handle *h) {
+int k_xo_boundary(udc_handle *h, int merged_stage3) {
   if (!h->xg) return 0;
   const Geo &g = h->g;
   PROF(h, "xo_ghosts");
@@ -491,7 +494,7 @@ int k_xo_boundary(udc_handle *h) {
   hipLaunchKernelGGL(xo_boundary_kernel, plane_grid(g), dim3(64), 0, h->stream, g, (const double *)h->xo_prof,
                      (const double *)(h->xo_driver ? h->xo_inlet_now : nullptr), h->m.dxi, h->bcx_rk3coef,
                      (const double *)h->bcx_uout_dev, h->fields[UDC_U0], h->fields[UDC_V0], h->fields[UDC_W0],
-                     h->fields[UDC_UM], h->fields[UDC_VM], h->fields[UDC_WM], h->fields[UDC_PRES0], h->xo_east, h->xo_west);
+                     h->fields[UDC_UM], h->fields[UDC_VM], h->fields[UDC_WM], h->fields[UDC_PRES0], h->xo_east, h->xo_west, merged_stage3);
   for (int t = 0; t < 15; ++t)      // the scalars' planes handed over since the last `boundary`
     if (h->xo_sc_in_next[t] && h->xo_sc_fresh[t]) {
       HIP_OK(hipMemcpyAsync(h->xo_sc_in_now[t], h->xo_sc_in_next[t], sizeof(double) * 2 * (size_t)g.py * g.pz, hipMemcpyDeviceToDevice, h->stream));
@@ -563,10 +566,12 @@ int k_xo_halos(udc_handle *h) {
   return 0;
 }
 
-int k_xo_after_integrate(udc_handle *h, int rk3step) {
+// boundary_follows: the fused substep -- k_xo_boundary(h, stage 3 or not) comes next on the stream and does the velocities' part itself
+int k_xo_after_integrate(udc_handle *h, int rk3step, bool boundary_follows) {
   if (!h->xg) return 0;
   const Geo &g = h->g;
   PROF(h, "xo_ghosts");
+  if (!boundary_follows)
   hipLaunchKernelGGL(xo_restore_kernel, plane_grid(g), dim3(64), 0, h->stream, g, rk3step == 3 ? 1 : 0, h->fields[UDC_U0], h->fields[UDC_V0],
                      h->fields[UDC_W0], h->fields[UDC_UM], h->fields[UDC_VM], h->fields[UDC_WM], h->xo_east, h->xo_west);
   if (h->xo_thl_prof || h->xo_sc_in_now[0])
