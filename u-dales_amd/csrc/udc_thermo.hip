@@ -20,14 +20,22 @@ __device__ __forceinline__ double thl_half(const Geo &g, const Metrics &m, const
   const int kf = k + 1;
   return (t[c] * m.dzf[kf - 1] + t[c - g.sz] * m.dzf[kf]) / (2 * m.dzh[kf]);
 }
-// stage 1: one workgroup per (xy tile, level) -> part[level * tiles + tile]; stage 2: one workgroup per level
+// stage 1: one workgroup per (xy tile of 64 x 4 LS_ROWS cells, level) -> part[level * tiles + tile]; stage 2: one workgroup per level
+// (LS_ROWS rows per thread: with one cell per thread the sums of a 256^3 field ran at 2 TB/s, profiles/r06/open_x_rate_256_final.txt)
+constexpr int LS_ROWS = 8;
 __global__ __launch_bounds__(256) void levelsum_kernel(Geo g, Metrics m, int gx, const double *__restrict__ thl, double *__restrict__ part) {
   __shared__ double sw[4];
   const int tile = blockIdx.x, k = blockIdx.y;
   const int by = tile / gx, bx = tile - by * gx;
-  const int i = bx * 64 + threadIdx.x, j = by * 4 + threadIdx.y;
+  const int i = bx * 64 + threadIdx.x;
   double v = 0.;
-  if (i >= g.xg && i < g.nx - g.xg && j < g.ny && k >= 1) v = thl_half(g, m, thl, g.idx(i, j, k), k);      // (open x boundaries: ib .. ie)
+  if (i >= g.xg && i < g.nx - g.xg && k >= 1) {      // (open x boundaries: ib .. ie)
+#pragma unroll
+    for (int r = 0; r < LS_ROWS; ++r) {
+      const int j = (by * LS_ROWS + r) * 4 + threadIdx.y;
+      if (j < g.ny) v += thl_half(g, m, thl, g.idx(i, j, k), k);
+    }
+  }
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   if (threadIdx.x == 0) sw[threadIdx.y] = v;
   __syncthreads();
@@ -514,6 +522,7 @@ int k_buoyancy(udc_handle *h) {
   if ((int)h->fields.size() <= UDC_THL0 || !h->fields[UDC_THL0]) { udc_set_error("buoyancy needs the temperature equation (udc_set_tempeq)"); return 1; }
   if (h->lmoist) return k_buoyancy_moist(h);
   const TileGrid tg = tile_grid(g);
+  const int ltiles = tg.gx * ((g.ny + 4 * LS_ROWS - 1) / (4 * LS_ROWS));      // levelsum_kernel's workgroups per level
   const size_t need = (size_t)tg.tiles * g.nz;
   if (h->lev_cap < need) {
     if (h->lev_part) HIP_OK(hipFree(h->lev_part));
@@ -523,8 +532,8 @@ int k_buoyancy(udc_handle *h) {
   if (!h->lev_sum) HIP_OK(hipMalloc(&h->lev_sum, sizeof(double) * (g.nz + 2)));
   PROF(h, "buoyancy");
   const double *thl = h->fields[UDC_THL0];
-  hipLaunchKernelGGL(levelsum_kernel, dim3((unsigned)tg.tiles, (unsigned)g.nz), dim3(64, 4), 0, h->stream, g, h->m, tg.gx, thl, h->lev_part);
-  hipLaunchKernelGGL(levelsum_final_kernel, dim3((unsigned)g.nz), dim3(256), 0, h->stream, tg.tiles, h->lev_part, h->lev_sum);
+  hipLaunchKernelGGL(levelsum_kernel, dim3((unsigned)ltiles, (unsigned)g.nz), dim3(64, 4), 0, h->stream, g, h->m, tg.gx, thl, h->lev_part);
+  hipLaunchKernelGGL(levelsum_final_kernel, dim3((unsigned)g.nz), dim3(256), 0, h->stream, ltiles, h->lev_part, h->lev_sum);
   HIP_OK(hipGetLastError());
   const double *cntk = nullptr;
   if (h->ibm_on) {
