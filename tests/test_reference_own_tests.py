@@ -347,7 +347,7 @@ def stage_526_open(tmp, steps):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("steps", [None, 6])
+@pytest.mark.parametrize("steps", [None, 4])
 def test_case_526_with_the_inflow_of_case_525(steps, tmp_path):
     """Trees (the reference's vegetation.f90 on the host), a floor that is an immersed boundary with facet wall functions, temperature +
     moisture + buoyancy, the open lid, the adaptive step -- and the flow entering from a precursor's planes and leaving through a convective
