@@ -506,6 +506,34 @@ def test_cli_run_writes_the_reference_state(tmp_path):
         assert relerr(nocorner(got[k][1:-1]), nocorner(ref[1:-1])) <= RUN_TOL, k
 
 
+@pytest.mark.parametrize("name,iexp", [("run_xdriver_16x8x12s", 96), ("run_xdriver_ibm_16x12x10", 98), ("run_xdriver_scal_16x8x12s", 113)])
+def test_cli_run_with_driver_inflow(name, iexp, tmp_path):
+    """run_case.py on BCxm = 3 decks: the Python runner reads the precursor's planes itself (udcore/driver.py restates readdriverfile and
+    drivergen's interpolation, src/moddriver.f90:213-376, 752-932) and hands them over where the reference's `boundary` calls drivergen;
+    cold start, three steps, the restart files against the reference's state -- with the scalars' planes too (BCxT = BCxq = BCxs = 3)."""
+    import os, shutil, subprocess, sys
+    from common import GOLDEN
+    from udcore import restart as R
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for fn in os.listdir(os.path.join(GOLDEN, "cases", name)):
+        shutil.copy(os.path.join(GOLDEN, "cases", name, fn), tmp_path)
+    r = subprocess.run([sys.executable, os.path.join(root, "run_case.py"), f"namoptions.{iexp:03d}", "--steps", "3"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    fix = load_fixture(name)
+    n = tuple(int(v) for v in fix["meta"].data[:3])
+    got = R.read_initd(os.path.join(tmp_path, R.restart_name(3, 0, iexp)), *n)
+    for k in ("u0", "v0", "w0", "pres0") + (("thl0", "qt0") if "s009.qt0" in fix else ()):
+        ref = marr(fix, f"s009.{k}", n[2])
+        assert relerr(nocorner(got[k][1:-1]), nocorner(ref[1:-1]), 1.0 if k == "thl0" else None) <= RUN_TOL, k
+    nsv = int(fix["meta"].data[12])
+    if nsv:
+        sc = R.read_inits(os.path.join(tmp_path, R.restart_name(3, 0, iexp).replace("initd", "inits")), *n, nsv)
+        for q in range(nsv):
+            ref = carr(fix, f"s009.sv0_{q + 1:02d}", n[2])[2:n[2] + 2, 2:-2, 1:-1]      # (levels kb .. ke, rows jb .. je; the file keeps one ghost column)
+            assert relerr(sc["sv0"][q][1:n[2] + 1, 1:-1, :], ref) <= RUN_TOL, q
+
+
 @pytest.mark.parametrize("residency", [2, 0])
 def test_statistics_with_the_reference_statsdump(residency, tmp_path):
     """Statistics of an inflow / outflow run (the class of examples/950: driver inflow, obstacles, wall functions, tdump + xytdump): the
@@ -637,6 +665,6 @@ def test_what_open_x_does_not_offer_is_refused():
     core.close()
     import udcore
     d = read_deck(deck_path("k_xopen_16x8x12", 90))
-    d.nml["BC"]["BCxm"] = 3
+    d.nml["BC"]["BCxm"] = 4
     with pytest.raises(ValueError, match="BCxm"):
         udcore.from_deck(d)

@@ -18,8 +18,12 @@ def from_deck(deck, device=0, rank=0, nranks=1):
         raise ValueError("lbottom: BCbotm must be 2 (wfuno) or 3 (wfmneutral), src/modibm.f90:2021-2029")
     import numpy as np
     bcxm = int(deck.get("BC", "BCxm"))
-    if bcxm not in (1, 2):
-        raise ValueError("&BC BCxm: 1 (periodic) or 2 (inflow profile, convective outflow) are on the device path")
+    if bcxm not in (1, 2, 3):
+        raise ValueError("&BC BCxm: 1 (periodic), 2 (inflow profile, convective outflow) or 3 (inflow from a precursor's planes) are on the device path")
+    driver = bcxm == 3      # (the planes come from udcore.driver.DriverInlet, handed over by the runner; everything else is BCxm = 2's)
+    bcx3 = (3,) if driver else ()
+    if driver:
+        bcxm = 2
     open_x = None
     if bcxm == 2:      # inflow from prof.inp's u, v (xmi_profile); uprof(ke+1) = vprof(ke+1) = 0 as allocated, src/modfields.f90:556
         open_x = (np.concatenate(([0.], np.asarray(deck.u, dtype=float)[:g.nz], [0.])),
@@ -32,6 +36,7 @@ def from_deck(deck, device=0, rank=0, nranks=1):
     if bcxm == 2:      # the outlet's speed (src/modboundary.f90:141-160): ubulk of a prescribed flow, else the mean of u's slab averages
         ubulk = float(np.sum(np.asarray(deck.u)[:g.nz] * g.dzf[1:g.nz + 1]) / (g.zh[g.nz + 1] - g.zh[1]))      # src/modstartup.f90:1336-1341
         core.set_open_x_outflow(None if deck.get("PHYSICS", "luvolflowr") else g.dzf[1:g.nz + 1] / (g.zh[g.nz + 1] - g.zh[2]), ubulk)
+    core.driver_inflow = driver      # (BCxm = 3: the runner hands the precursor's planes over, udcore.driver)
     if int(deck.get("BC", "BCzp")) != 1:
         core.set_poisson_bczp(int(deck.get("BC", "BCzp")))
     core.set_masscorr(bool(deck.get("PHYSICS", "luvolflowr")), float(deck.get("PHYSICS", "uflowrate")),
@@ -46,7 +51,7 @@ def from_deck(deck, device=0, rank=0, nranks=1):
                         wtsurf=float(deck.get("BC", "wtsurf")), thlpcar=getattr(deck, "thlpcar", None))
         if bcxm == 2:      # inflow / outflow: BCxT = 2, the temperature enters with prof.inp's profile too (xTi_profile), thlprof(ke+1) = 0 as
             # allocated; BCxT = 1 (the reference's default, its tests/cases/525): the temperature stays periodic (halos' xT_periodic)
-            if int(deck.get("BC", "BCxT")) not in (1, 2):
+            if int(deck.get("BC", "BCxT")) not in (1, 2) + bcx3:
                 raise ValueError("&BC BCxm = 2 with the temperature equation: BCxT = 1 (periodic) or 2 (inflow profile, convective outflow) is what the device path has")
             if int(deck.get("BC", "BCxT")) == 2:
                 core.set_open_x_thl(np.concatenate(([0.], np.asarray(deck.thl, dtype=float)[:g.nz], [0.])))
@@ -65,7 +70,7 @@ def from_deck(deck, device=0, rank=0, nranks=1):
                           qt_top=float(deck.get("BC", "qt_top")), bcbotq=int(deck.get("BC", "BCbotq")),
                           wqsurf=float(deck.get("BC", "wqsurf")))
         if bcxm == 2:      # inflow / outflow: BCxq = 1 periodic (xq_periodic), 2 mirrored about prof.inp's profile (xqi_profile), qtprof(ke+1) = 0 as allocated
-            if int(deck.get("BC", "BCxq")) not in (1, 2):
+            if int(deck.get("BC", "BCxq")) not in (1, 2) + bcx3:
                 raise ValueError("&BC BCxm = 2 with moisture: BCxq = 1 (periodic) or 2 (inflow profile, convective outflow) is what the device path has")
             if int(deck.get("BC", "BCxq")) == 2:
                 core.set_open_x_qt(np.concatenate(([0.], np.asarray(deck.qt, dtype=float)[:g.nz], [0.])))
@@ -116,11 +121,11 @@ def from_deck(deck, device=0, rank=0, nranks=1):
             for n in range(core.nsv):
                 core.set_scalar_top(n, 1, float(w[n]) if n < len(w) else 0.)
     bcxs = int(deck.get("BC", "BCxs"))
-    if bcxs not in (1, 2):
-        raise ValueError("&BC BCxs: 1 (periodic) or 2 (inflow profile, convective outflow) are on the device path")
+    if bcxs not in (1, 2) + bcx3:
+        raise ValueError("&BC BCxs: 1 (periodic), 2 (inflow profile, convective outflow) or, with BCxm = 3, 3 (the precursor's planes) are on the device path")
     if core.nsv and bcxm == 2:      # inflow / outflow for the flow: the scalars enter and leave with it (the rows carry their ghost columns)
-        if bcxs != 2:
-            raise ValueError("&BC BCxm = 2 with passive scalars: BCxs = 2 (inflow profile, convective outflow) is what the device path has")
+        if bcxs not in (2,) + bcx3:
+            raise ValueError("&BC BCxm = 2 / 3 with passive scalars: BCxs = 2 (inflow profile, convective outflow) or 3 (driver planes) is what the device path has")
         from .grid import scalar_profiles
         core.set_open_x_scalars(np.array(scalar_profiles(g, deck, core.nsv)))
     elif core.nsv and bcxs == 2:      # scalars enter at the low-x side with svprof and leave at the high-x side (src/modboundary.f90:844, 983)

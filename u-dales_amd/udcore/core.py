@@ -348,6 +348,22 @@ class DynCore:
         assert a.size == self.g.nz + 2
         L._check(self.lib.udc_set_open_x_qt(self.h, a.ctypes.data_as(L.DP)), "udc_set_open_x_qt")
 
+    def set_open_x_inlet(self, u, v, w):
+        """BCxm = 3: the inlet's planes [nz+2][ny+2] (k = kb-1 .. ke+1, j = jb-1 .. je+1) as the reference's drivergen leaves u0driver,
+        v0driver, w0driver (the m planes are the same arrays: both are refreshed on the same calls); applied by the next `boundary`."""
+        a = [np.ascontiguousarray(q, dtype=np.float64) for q in (u, u, v, v, w, w)]
+        assert all(q.shape == (self.g.nz + 2, self.nyl + 2) for q in a)
+        lb, ub = (C.c_int * 2)(0, 0), (C.c_int * 2)(self.nyl + 1, self.g.nz + 1)
+        L._check(self.lib.udc_set_open_x_inlet(self.h, *[q.ctypes.data_as(L.DP) for q in a], lb, ub), "udc_set_open_x_inlet")
+
+    def set_open_x_inlet_scalar(self, field, plane, halo=1):
+        """BCxT / BCxq / BCxs = 3: a scalar's inlet plane [nz+2 halo][ny+2 halo] (thl0driver, qt0driver, sv0driver(:, :, n))."""
+        a = np.ascontiguousarray(plane, dtype=np.float64)
+        assert a.shape == (self.g.nz + 2 * halo, self.nyl + 2 * halo)
+        lb, ub = (C.c_int * 2)(1 - halo, 1 - halo), (C.c_int * 2)(self.nyl + halo, self.g.nz + halo)
+        L._check(self.lib.udc_set_open_x_inlet_scalar(self.h, int(field), a.ctypes.data_as(L.DP), a.ctypes.data_as(L.DP), lb, ub),
+                 "udc_set_open_x_inlet_scalar")
+
     def set_open_x_scalars(self, svprof):
         """BCxs = 2 on an open-x core: the scalars' inflow profiles [nsv][ktot+2] by the reference's k."""
         a = np.ascontiguousarray(svprof, dtype=np.float64)

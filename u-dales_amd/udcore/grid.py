@@ -150,7 +150,7 @@ def cold_start(g: Grid, d: Deck, j0=0, nyl=None, nsv=0, scal_a=None, scal_b=None
         out["ekm"] = ek
         out["ekh"] = ek.copy()
         out["ekh"][nz + 1] = 1.5e-5
-    open_x = int(d.get("BC", "BCxm")) == 2      # the x ghost columns keep the profile readinitfiles put there (src/modstartup.f90:1155-1177)
+    open_x = int(d.get("BC", "BCxm")) in (2, 3)      # the x ghost columns keep the profile readinitfiles put there (src/modstartup.f90:1155-1177)
     for a in (um, vm, wm):
         if not open_x:
             a[:, :, 0] = a[:, :, nx]

@@ -22,6 +22,7 @@ DEFAULTS = {
                     ifixuinf=0, lvinf=False, tscale=0., lconservativeibm=False),
     "CHEMISTRY": dict(lchem=False, k1=0., JNO2=0.),
     "INLET": dict(Uinf=0., Vinf=0., inletav=0.),
+    "DRIVER": dict(idriver=0, tdriverstart=0., driverjobnr=0, dtdriver=0.1, driverstore=0, iplane=-1, lchunkread=False, chunkread_size=100),
     "DYNAMICS": dict(lqlnr=False, ipoiss=0, iadv_mom=2, iadv_tke=-1, iadv_thl=-1, iadv_qt=-1),
     "BC": dict(BCxs=1, BCxm=1, BCxT=1, BCxq=1, BCym=1, BCtopm=1, BCbotm=2, BCzp=1, z0=-1., z0h=-1., BCtopT=1, BCbotT=1, BCbots=1, BCtops=1,
                wttop=0., thl_top=-1., wtsurf=-1., thls=-1., qts=-1.,

@@ -28,22 +28,25 @@ def check_supported(deck):
     from .namoptions import UNSUPPORTED
     g = deck.get
     for grp, name, off in UNSUPPORTED:                       # features without a device implementation
+        if (grp, name) == ("DRIVER", "idriver") and deck.is_set(grp, name) and int(g(grp, name)) == 2 and int(g("BC", "BCxm")) == 3 \
+                and not g("DRIVER", "lchunkread"):
+            continue      # (reading a precursor's planes: udcore.driver; writing them, idriver = 1, stays with the reference)
         if deck.is_set(grp, name) and deck.nml[grp][[k for k in deck.nml[grp] if k.lower() == name.lower()][0]] != off:
             _refuse(f"&{grp} {name} is not available on the device path")
     if int(g("DYNAMICS", "iadv_mom")) != 2:
         _refuse("Unknown advection scheme: only iadv_mom = 2 (cd2) is on the device path")      # src/modadvection.f90:52
-    if deck.is_set("BC", "BCxs") and int(g("BC", "BCxs")) not in (1, 2):
-        _refuse("&BC BCxs: only 1 (periodic) and 2 (inflow profile, convective outflow) are on the device path")
+    if deck.is_set("BC", "BCxs") and int(g("BC", "BCxs")) not in ((1, 2, 3) if int(g("BC", "BCxm")) == 3 else (1, 2)):
+        _refuse("&BC BCxs: only 1 (periodic), 2 (inflow profile, convective outflow) and, with BCxm = 3, 3 (driver planes) are on the device path")
     for grp, names in (("BC", ("BCxT", "BCxq", "BCyT", "BCyq", "BCys")),):
         for n in names:
-            if n in ("BCxT", "BCxq") and int(g("BC", "BCxm")) == 2 and int(g("BC", n)) in (1, 2):
+            if n in ("BCxT", "BCxq") and int(g("BC", "BCxm")) in (2, 3) and int(g("BC", n)) in ((1, 2, 3) if int(g("BC", "BCxm")) == 3 else (1, 2)):
                 continue      # (inflow / outflow for the flow and the temperature: udc_create_open_x, udc_set_open_x_thl)
             if deck.is_set(grp, n) and int(deck.nml[grp][[k for k in deck.nml[grp] if k.lower() == n.lower()][0]]) != 1:
                 _refuse(f"only periodic lateral boundaries are on the device path (&BC {n})")
     # (iwallmom = 2 without the temperature equation never reaches initibm: checkinitvalues has made it 3 by then,
     #  src/modstartup.f90:811-816 -- Deck.apply_checkinitvalues)
-    if int(g("BC", "BCxm")) not in (1, 2) or int(g("BC", "BCym")) != 1:
-        _refuse("lateral boundaries on the device path: BCxm = 1 (periodic) or 2 (inflow profile, convective outflow), BCym = 1")
+    if int(g("BC", "BCxm")) not in (1, 2, 3) or int(g("BC", "BCym")) != 1:
+        _refuse("lateral boundaries on the device path: BCxm = 1 (periodic), 2 (inflow profile, convective outflow) or 3 (a precursor's planes), BCym = 1")
     if int(g("DYNAMICS", "ipoiss")) != 0 or int(g("BC", "BCzp")) not in (1, 2):
         _refuse("only ipoiss = 0 (FFT in x, y) with BCzp = 1 or 2 is on the device path")
     # &RUN nprocx / nprocy describe the CPU run's pencil layout; the device path splits y over however many GPUs it is
@@ -175,6 +178,15 @@ def main(argv=None, at_end=None):
         timee, ntrun = 0., 0
         dt = dtmax if not ladaptive else dtmax / 100.          # src/modstartup.f90:1099, 2038
     core.dt, core.timee, core.rk3step = dt, timee, 0
+    inlet = None
+    if getattr(core, "driver_inflow", False):      # &BC BCxm = 3: the precursor's planes (src/moddriver.f90 readdriverfile; modstartup.f90:1462-1470)
+        from .driver import DriverInlet
+        if world > 1:
+            _refuse("&BC BCxm = 3: one GPU (the handle with open x boundaries is a one-rank handle)")
+        inlet = DriverInlet(wdir, int(deck.get("DRIVER", "driverjobnr")), core.g.ny, core.g.nz, int(deck.get("DRIVER", "driverstore")),
+                            thl=core.ltempeq and int(deck.get("BC", "BCxT")) == 3, qt=core.lmoist and int(deck.get("BC", "BCxq")) == 3,
+                            nsv=core.nsv if int(deck.get("BC", "BCxs")) == 3 else 0)
+        inlet.hand_over(core, timee)      # (the start-up's `boundary` applies them: rk3step = 0, src/modboundary.f90:262-266)
     forcings = LevelForcings(core, deck)
     if warm < 0:      # the reference's order at a cold start: thermodynamics on the fields as read (src/modstartup.f90:1601), then boundary
         core.start_up(before_boundary=forcings.capture_startup, dtmax=float(deck.get("RUN", "dtmax")))
@@ -208,6 +220,8 @@ def main(argv=None, at_end=None):
         for _ in range(3):                                     # one full RK3 step
             rk, dt = core.tstep_update(dtmax, ladaptive, courant, diffnr)
             forcings.update(rk, dt)
+            if inlet is not None and rk == 3 and not core.timee > t_end:      # drivergen of stage 3's `boundary` (inside the fused substep);
+                inlet.hand_over(core, core.timee)                             # "if (timee > runtime + btime) return", src/moddriver.f90:216
             core.substep(rk, dt, with_forces=True)
             if tdump is not None and tdump.step(rk, dt, core.timee) == "dump":
                 say(f"  tdump written at timee = {core.timee:.6f} ({tdump.nsamples} samples so far)")
