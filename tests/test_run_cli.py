@@ -23,7 +23,7 @@ def test_unsupported_decks_are_refused(tmp_path):
     path = os.path.join(tmp_path, "namoptions.021")
     check_supported(read_deck(path))                       # the fixture deck itself is fine
     txt = open(path).read()
-    for bad in ("&BC\nBCzp = 3", "&BC\nBCxm = 3"):      # (BCzp = 2, the cosine transform in z, is served since round 6)
+    for bad in ("&BC\nBCzp = 3", "&BC\nBCxm = 4", "&BC\nBCym = 2"):      # (BCzp = 2, BCxm = 2 and 3 are served since round 6)
         grp = bad.split("\n")[0]
         with open(path, "w") as f:
             f.write(txt.replace(grp, bad, 1))
