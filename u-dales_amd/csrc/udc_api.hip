@@ -1105,6 +1105,7 @@ extern "C" int udc_boundary(udc_handle *h) {
   if (k_scalar_bcx_outlet(h)) return 1;    // BCxs = 2: xso_convective with the rk3coef of the substep just integrated
   if (k_xo_boundary(h)) return 1;          // BCxm = 2: xmi_profile, xmo_convective
   h->boundary_fresh = h->halos_fresh;      // (boundary before halos leaves the ghost rows of the top planes stale)
+  h->xo_boundary_owed = false;
   return 0;
 }
 
@@ -1144,6 +1145,12 @@ enum : unsigned {
 // first); masscorr sees every momentum term the reference's masscorr sees.
 static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   const double rk3coef = dt / (4. - (double)rk3step);
+  if (h->xo_boundary_owed) {      // the stage-3 substep before this one ended ahead of `boundary` (statistics sample there) and no udc_boundary came
+    if (k_top_bottom(h) || k_scalar_bcx_outlet(h) || k_xo_boundary(h)) return 1;      // (with that substep's rk3coef, still in bcx_rk3coef)
+    h->xo_boundary_owed = false;
+    h->boundary_fresh = true;
+    if (h->lmoist && h->mt && !h->thermo_fresh) { if (k_thermodynamics(h)) return 1; h->thermo_fresh = true; }
+  }
   h->bcx_rk3coef = rk3coef;
   ++h->substep_seq;
   // BCxs = 2 without a prescribed volume flow: the outlet's speed from the state the substep starts from.  (BCxm = 2: bcpup still reads
@@ -1369,6 +1376,15 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   std::vector<int> s;
   scalar_halo_list(h, rk3step, s);
   if (!s.empty() && !ov_scal && k_halo_y(h, s.data(), (int)s.size(), 2)) return 1;
+  if (h->xg && rk3step == 3 && (h->stats_on || h->xyt_on)) {
+    // Open x boundaries with the device's statistics on: the reference samples them between tstep_integrate / halos and `boundary`
+    // (src/program.f90:199-207), i.e. with the x ghost columns as the PREVIOUS `boundary` left them -- so stage 3 ends here, the ghost
+    // columns put back; udc_boundary (the host's `boundary`, or the next substep's first act) and udc_thermodynamics follow the sample
+    if (k_xo_after_integrate(h, rk3step, false)) return 1;
+    h->halos_fresh = true; h->boundary_fresh = false; h->thermo_fresh = false;
+    h->xo_boundary_owed = true;
+    return 0;
+  }
   if (!fold || !h->slots.empty()) { if (k_top_bottom(h)) return 1; }
   if (k_scalar_bcx_outlet(h)) return 1;
   if (k_xo_after_integrate(h, rk3step, true) || k_xo_boundary(h, rk3step == 3 ? 1 : 0)) return 1;

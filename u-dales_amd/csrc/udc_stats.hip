@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256) void xy_sample_kernel(Geo g, int gx, Metrics m
 // first level included -- `forced` names the masks whose first level the caller filled).
 struct XyForced { int f[7]; };
 __global__ void xy_table_kernel(int nz, const double *__restrict__ S9, const double *__restrict__ SI, const double *__restrict__ cnt, XyForced F,
-                                double *__restrict__ table) {
+                                int has_thl, double *__restrict__ table) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nz) return;
   auto a9 = [&](int p) { const double n = cnt[xs_mask[p] * nz + k]; return n > 0. ? S9[p * nz + k] / n : -999.; };
@@ -435,11 +435,12 @@ __global__ void xy_table_kernel(int nz, const double *__restrict__ S9, const dou
     const double n = (k == 0 && F.f[mk]) ? 0. : cnt[mk * nz + k];
     return n > 0. ? SI[p * nz + k] / n : -999.;
   };
-  const double uw = ai(XI_UW), vw = ai(XI_VW), wthl = ai(XI_WTHL), wxy = a9(XS_W);
+  // (without a temperature the reference never averages wthlxyk / thlxyk: they stay at the zero they were set to, :1060, 1072-1079)
+  const double uw = ai(XI_UW), vw = ai(XI_VW), wthl = has_thl ? ai(XI_WTHL) : 0., wxy = a9(XS_W);
   double *t = table + k;
   t[0 * nz] = a9(XS_U); t[1 * nz] = a9(XS_V); t[2 * nz] = wxy; t[3 * nz] = a9(XS_THL); t[4 * nz] = a9(XS_QT); t[5 * nz] = a9(XS_P);
   t[6 * nz] = uw - ai(XI_UIK) * ai(XI_WIK);
-  t[7 * nz] = wthl - wxy * ai(XI_THLK);
+  t[7 * nz] = has_thl ? wthl - wxy * ai(XI_THLK) : 0.;
   t[8 * nz] = vw - ai(XI_VJK) * ai(XI_WJK);
   t[9 * nz] = a9(XS_USGS); t[10 * nz] = a9(XS_THLSGS); t[11 * nz] = a9(XS_VSGS);
   t[12 * nz] = uw; t[13 * nz] = wthl; t[14 * nz] = vw;
@@ -515,11 +516,30 @@ static int stat_alloc(udc_handle *h, int id) {
   return 0;
 }
 
+// open x boundaries (udc_xopen.hip): the slab sums must leave the two ghost columns of the device row out -- the mask array, which is
+// indexed by the device's columns, always exists there and carries zeros in them; `bits` (or null: no obstacles) is indexed by the deck's
+// columns, [nz][ny][itot]
+static int stats_mask_upload(udc_handle *h, const unsigned char *bits) {
+  const Geo &g = h->g;
+  const size_t n = (size_t)g.nz * g.ny * g.nx;
+  if (!h->st_mask) HIP_OK(hipMalloc(&h->st_mask, n));
+  if (!g.xg) { HIP_OK(hipMemcpy(h->st_mask, bits, n, hipMemcpyHostToDevice)); return 0; }
+  std::vector<unsigned char> m(n, 0);
+  const int ni = g.nx - 2 * g.xg;
+  for (size_t r = 0; r < (size_t)g.nz * g.ny; ++r)
+    for (int i = 0; i < ni; ++i) m[r * g.nx + g.xg + i] = bits ? bits[r * ni + i] : (unsigned char)0x7f;
+  HIP_OK(hipMemcpy(h->st_mask, m.data(), n, hipMemcpyHostToDevice));
+  return 0;
+}
+
 extern "C" int udc_stats_enable(udc_handle *h, int on) {
-  NO_OPEN_X(h, "udc_stats_enable");
   if (!h) { udc_set_error("null handle"); return 1; }
   HIP_OK(hipSetDevice(h->device));
   if (udc_flush_pending(h)) return 1;
+  if (h->xg && (on & (4 | 16))) {      // (their tables are [nz][row of the device]; tdump, xytdump and xydump are offered)
+    udc_set_error("udc_stats_enable: ytdump / ydump are not offered with open x boundaries (udc_create_open_x) yet");
+    return 1;
+  }
   if (!on) {
     HIP_OK(hipStreamSynchronize(h->stream));
     stats_destroy(h);
@@ -535,8 +555,12 @@ extern "C" int udc_stats_enable(udc_handle *h, int on) {
       HIP_OK(hipMalloc(&h->st_sum, sizeof(double) * XF_N * nz));
       HIP_OK(hipMalloc(&h->st_table, sizeof(double) * UDC_XYT_N * nz));
       HIP_OK(hipMalloc(&h->st_cnt, sizeof(double) * 7 * nz));
-      std::vector<double> c((size_t)7 * nz, (double)h->g.nx * (double)h->cfg.jtot);
+      std::vector<double> c((size_t)7 * nz, (double)(h->g.nx - 2 * h->g.xg) * (double)h->cfg.jtot);
       HIP_OK(hipMemcpy(h->st_cnt, c.data(), sizeof(double) * c.size(), hipMemcpyHostToDevice));
+      if (h->xg && !h->st_mask) {
+        HIP_OK(hipStreamSynchronize(h->stream));
+        if (stats_mask_upload(h, nullptr)) return 1;
+      }
     }
     HIP_OK(hipMemsetAsync(h->st_prof, 0, sizeof(double) * XS_N * nz, h->stream));
     h->xyt_on = true;
@@ -635,7 +659,7 @@ extern "C" int udc_stats_sample(udc_handle *h, double tsamplep, double tstatsdum
       XyForced XF;
       for (int q = 0; q < 7; ++q) XF.f[q] = h->st_mask ? h->yt_forced[q] : 0;
       hipLaunchKernelGGL(xy_table_kernel, dim3((unsigned)((nz + 63) / 64)), dim3(64), 0, h->stream, nz, (const double *)h->st_sum,
-                         (const double *)h->xy_sum, (const double *)h->st_cnt, XF, h->xy_table);
+                         (const double *)h->xy_sum, (const double *)h->st_cnt, XF, thl >= 0 ? 1 : 0, h->xy_table);
       HIP_OK(hipGetLastError());
     }
   }
@@ -709,18 +733,15 @@ extern "C" int udc_stats_yt(udc_handle *h, double *table) {
 }
 
 extern "C" int udc_stats_set_masks(udc_handle *h, const unsigned char *bits, const int *counts) {
-  NO_OPEN_X(h, "udc_stats_set_masks");
   if (!h) { udc_set_error("null handle"); return 1; }
   HIP_OK(hipSetDevice(h->device));
   if (udc_flush_pending(h)) return 1;
   if (!h->xyt_on && !h->yt_on) { udc_set_error("udc_stats_set_masks: enable the xyt or yt statistics first (udc_stats_enable with bit 2 or 4)"); return 1; }
   if (!counts) { udc_set_error("udc_stats_set_masks: counts missing"); return 1; }
   const Geo &g = h->g;
-  const size_t n = (size_t)g.nz * g.ny * g.nx;
   HIP_OK(hipStreamSynchronize(h->stream));
-  if (bits) {
-    if (!h->st_mask) HIP_OK(hipMalloc(&h->st_mask, n));
-    HIP_OK(hipMemcpy(h->st_mask, bits, n, hipMemcpyHostToDevice));
+  if (bits || g.xg) {      // (bits: [nz][ny][itot] -- the deck's columns)
+    if (stats_mask_upload(h, bits)) return 1;
   } else if (h->st_mask) {
     HIP_OK(hipFree(h->st_mask));
     h->st_mask = nullptr;

@@ -270,8 +270,8 @@ contains
     integer(c_int), allocatable :: counts(:, :)
     integer(c_int) :: forced(7)
     integer :: nk, q
-    if (BCxm /= 1) then      ! (the reference samples between tstep_integrate and `boundary`, with the x ghost columns of the boundary before)
-      write (0, *) 'ERROR: libudcore statsdump: the device-side statistics are not offered with inflow / outflow in x; ', &
+    if (BCxm /= 1 .and. (lytdump .or. lydump)) then      ! (tdump, xytdump, xydump are: udc_stats_enable)
+      write (0, *) 'ERROR: libudcore statsdump: ytdump / ydump are not offered on the device with inflow / outflow in x; ', &
                    'run u-dales_amd/bin/udales_full_dropin_hoststats, which links the reference''s own modstatsdump'
       stop 1
     end if
@@ -321,7 +321,14 @@ contains
   subroutine statsdump_timed
     use modglobal, only: rk3step, timee, dt, tsample, tstatsdump, tstatstart, lxytdump, lytdump, ltdump, lmintdump, lxydump, lydump
     use udc_iface, only: udc_h, udc_check, udc_begin
+    use modglobal, only: BCxm
     if (.not. (active .or. slices)) return
+    if (active .and. BCxm /= 1 .and. .not. device_ready) then
+      ! inflow / outflow in x: a fused stage-3 substep of a handle with the statistics on ends ahead of `boundary`, where the reference samples
+      ! (src/program.f90:199-214) -- so they are switched on at the first call (RK stage 1 of the first step), not at the first sample
+      call udc_begin(.false.)
+      call device_setup
+    end if
     if (timee < tstatstart) return
     if (rk3step /= 3) return
     if (tsamplep == 0. .and. tsample <= dt) tsamplep = dt

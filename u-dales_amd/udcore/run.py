@@ -225,6 +225,12 @@ def main(argv=None, at_end=None):
             core.substep(rk, dt, with_forces=True)
             if tdump is not None and tdump.step(rk, dt, core.timee) == "dump":
                 say(f"  tdump written at timee = {core.timee:.6f} ({tdump.nsamples} samples so far)")
+            if tdump is not None and core.open_x and rk == 3:
+                # (inflow / outflow with the statistics on: stage 3 of the fused substep ends ahead of `boundary`, where the reference samples,
+                #  src/program.f90:199-214; udc_boundary and udc_thermodynamics follow the sample)
+                core.boundary()
+                if core.moist_thermo:
+                    core.thermodynamics()
         nsteps += 1
         ntrun += 1
         if fdump is not None and fdump.step(core.timee):
