@@ -405,10 +405,10 @@ int udc_deferred_stats(udc_handle *h, long *fused, long *unfused);
  * reference; the caller keeps the reference's two clocks and calls it on RK stage 3 when tsamplep >= tsample
  * (:802-811; udcore/stats.py).  udc_stats_get downloads an accumulator like udc_field_download.  The output variables
  * are means and <ab> - <a><b> of these (ut = UMT, upwpt = UWTIK - UTIK WTIK, tketc = ((UUTC - UTC^2) + ...)/2, ...).
- * On a handle of udc_create_open_x (bits 1, 2, 8; ytdump / ydump are refused): the reference samples between tstep_integrate / halos and
+ * On a handle of udc_create_open_x: the reference samples between tstep_integrate / halos and
  * `boundary` (src/program.f90:199-214), so with the statistics on a fused stage-3 udc_substep ends ahead of `boundary`; call
  * udc_stats_sample, then udc_boundary (+ udc_thermodynamics) -- the next udc_substep runs an owed boundary first if none came.  The masks of
- * udc_stats_set_masks are indexed by the deck's columns [nz][ny][itot] there as well. */
+ * udc_stats_set_masks are indexed by the deck's columns [nz][ny][itot] there as well, and so are the x-z tables of udc_stats_yt / udc_stats_y. */
 enum {
   UDC_ST_UMT = 0, UDC_ST_VMT, UDC_ST_WMT, UDC_ST_PT,          /* um, vm, wm, pres0                               */
   UDC_ST_UTC, UDC_ST_VTC, UDC_ST_WTC,                         /* velocities at the cell centre                   */

@@ -532,14 +532,19 @@ static int stats_mask_upload(udc_handle *h, const unsigned char *bits) {
   return 0;
 }
 
+// a table [rows][row of the device] to the host as [rows][itot]: the ghost columns of an open-x handle stay behind
+static int xz_table_download(udc_handle *h, const double *dev, size_t rows, double *host) {
+  const Geo &g = h->g;
+  const size_t ni = (size_t)(g.nx - 2 * g.xg);
+  HIP_OK(hipMemcpy2DAsync(host, sizeof(double) * ni, dev + g.xg, sizeof(double) * g.nx, sizeof(double) * ni, rows, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
 extern "C" int udc_stats_enable(udc_handle *h, int on) {
   if (!h) { udc_set_error("null handle"); return 1; }
   HIP_OK(hipSetDevice(h->device));
   if (udc_flush_pending(h)) return 1;
-  if (h->xg && (on & (4 | 16))) {      // (their tables are [nz][row of the device]; tdump, xytdump and xydump are offered)
-    udc_set_error("udc_stats_enable: ytdump / ydump are not offered with open x boundaries (udc_create_open_x) yet");
-    return 1;
-  }
   if (!on) {
     HIP_OK(hipStreamSynchronize(h->stream));
     stats_destroy(h);
@@ -573,6 +578,10 @@ extern "C" int udc_stats_enable(udc_handle *h, int on) {
   }
   if (on & 4) {        // ytdump: running y-averages and the column counts of the masks
     const size_t n = (size_t)h->g.nz * h->g.nx;
+    if (h->xg && !h->st_mask) {      // (open x: the ghost columns count nothing)
+      HIP_OK(hipStreamSynchronize(h->stream));
+      if (stats_mask_upload(h, nullptr)) return 1;
+    }
     if (!h->yt_prof) {
       HIP_OK(hipMalloc(&h->yt_prof, sizeof(double) * YS_N * n));
       HIP_OK(hipMalloc(&h->yt_cnt, sizeof(double) * 5 * n));
@@ -727,9 +736,7 @@ extern "C" int udc_stats_yt(udc_handle *h, double *table) {
   hipLaunchKernelGGL(yt_table_kernel, dim3((unsigned)((UDC_YT_N * n + 255) / 256)), dim3(256), 0, h->stream, (int)n, (const double *)h->yt_sum,
                      (const double *)h->yt_cnt, (const double *)h->yt_prof, h->yt_table);
   HIP_OK(hipGetLastError());
-  HIP_OK(hipMemcpyAsync(table, h->yt_table, sizeof(double) * UDC_YT_N * n, hipMemcpyDeviceToHost, h->stream));
-  HIP_OK(hipStreamSynchronize(h->stream));
-  return 0;
+  return xz_table_download(h, h->yt_table, (size_t)UDC_YT_N * g.nz, table);
 }
 
 extern "C" int udc_stats_set_masks(udc_handle *h, const unsigned char *bits, const int *counts) {
@@ -803,9 +810,7 @@ extern "C" int udc_stats_y(udc_handle *h, double *table) {
   if (udc_flush_pending(h)) return 1;
   if (!h->y_on || !h->stats_on) { udc_set_error("udc_stats_y: enable ydump's fields first (udc_stats_enable with bit 16)"); return 1; }
   if (!table) { udc_set_error("udc_stats_y: null table"); return 1; }
-  HIP_OK(hipMemcpyAsync(table, h->y_table, sizeof(double) * UDC_Y_N * (size_t)h->g.nz * h->g.nx, hipMemcpyDeviceToHost, h->stream));
-  HIP_OK(hipStreamSynchronize(h->stream));
-  return 0;
+  return xz_table_download(h, h->y_table, (size_t)UDC_Y_N * h->g.nz, table);
 }
 
 void stats_destroy(udc_handle *h) {

@@ -263,18 +263,13 @@ contains
 
   !> first call inside the loop (the handle exists by then): switch the device accumulators on and hand over createmasks' masks
   subroutine device_setup
-    use modglobal, only: ib, ie, jb, je, kb, ke, imax, jmax, lxytdump, lytdump, lxydump, lydump, libm, BCxm
+    use modglobal, only: ib, ie, jb, je, kb, ke, imax, jmax, lxytdump, lytdump, lxydump, lydump, libm
     use modfields, only: IIu, IIv, IIw, IIc, IIuw, IIvw, IIuv, IIus, IIvs, IIws, IIcs, IIuws, IIvws, IIuvs
     use udc_iface, only: udc_h, udc_check
     integer(1), allocatable :: bits(:, :, :)
     integer(c_int), allocatable :: counts(:, :)
     integer(c_int) :: forced(7)
     integer :: nk, q
-    if (BCxm /= 1 .and. (lytdump .or. lydump)) then      ! (tdump, xytdump, xydump are: udc_stats_enable)
-      write (0, *) 'ERROR: libudcore statsdump: ytdump / ydump are not offered on the device with inflow / outflow in x; ', &
-                   'run u-dales_amd/bin/udales_full_dropin_hoststats, which links the reference''s own modstatsdump'
-      stop 1
-    end if
     call udc_check(udc_stats_enable(udc_h, int(1 + merge(2, 0, lxytdump) + merge(4, 0, lytdump) + merge(8, 0, lxydump) + merge(16, 0, lydump), &
                                                c_int)), 'udc_stats_enable')
     device_ready = .true.
