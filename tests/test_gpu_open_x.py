@@ -546,11 +546,10 @@ def test_statistics_of_an_inflow_outflow_run(residency, prog_name, name, iexp, t
     ahead of `boundary` there and the drop-in boundary / thermodynamics follow the sample; the slab sums leave the device row's ghost
     columns out.  udales_full_dropin_hoststats: the reference's own modstatsdump on the host arrays, which the drop-ins refresh on exactly
     the sampling steps.
-    One line of cells is left out on a deck with BCxT = 2: xTi_profile overwrites the first interior column with the profile in `boundary`
-    (src/modboundary.f90:785-791), so what tstep_integrate left there reaches nothing but the sample -- and at its top level that value
-    depends on reassure_fluxtop_boundary (src/modboundary.f90:392-431, inside closurebc) resetting thl0(ib, j, ke+1) to the profile
-    between advection and diffusion, which the device, whose zero-flux top row is the identity everywhere else, does not restate:
-    thl's statistics in the cells (ib, :, ke) differ by ~1e-5 of thl (tdump) and the slab averages of level ke with them."""
+    On a deck with BCxT = 2 that includes the one line of cells the state never shows: xTi_profile overwrites the first interior column with
+    the profile in `boundary` (src/modboundary.f90:785-791), so what tstep_integrate left there reaches nothing but the sample -- and at its
+    top level that value depends on reassure_fluxtop_boundary (src/modboundary.f90:392-431, inside closurebc) resetting thl0(ib, j, ke+1) to
+    the profile between advection and diffusion (k_xo_thl_top)."""
     import os
     from common import BINDIR, GOLDEN
     from refdump import read_ncrec
@@ -569,7 +568,6 @@ def test_statistics_of_an_inflow_outflow_run(residency, prog_name, name, iexp, t
         out[tag] = {fn: read_ncrec(str(d / fn)) for fn in sorted(os.listdir(d)) if fn.endswith(".nc") and "dump" in fn}
     assert set(out["ref"]) == set(out["dev"]) and len(out["ref"]) >= 2, (sorted(out["ref"]), sorted(out["dev"]))
     checked, bad = 0, []
-    inlet_thl = "BCxT = 2" in txt and prog_name == "udales_full_dropin"
     import re
     m = re.search(r"^\s*nsv\s*=\s*(\d+)", txt, re.M)
     nsv = int(m.group(1)) if m else 0
@@ -585,14 +583,6 @@ def test_statistics_of_an_inflow_outflow_run(residency, prog_name, name, iexp, t
                 continue
             for (s0, a), (s1, b) in zip(recs, dev[var]):
                 assert s0 == s1 and a.shape == b.shape, (fn, var)
-                if inlet_thl and "thl" in var:      # (see the docstring: the line of cells (ib, :, ke))
-                    a, b = a.copy(), b.copy()
-                    if a.ndim == 3:
-                        b[-1, :, 0] = a[-1, :, 0]
-                    elif a.ndim == 2:      # (ytdump / ydump: [k][i])
-                        b[-1, 0] = a[-1, 0]
-                    else:
-                        b[-1] = a[-1]
                 hole = a < -900.
                 if not np.array_equal(hole, b < -900.):
                     bad.append((fn, var + " (holes)", s0, float(np.abs(a - b).max())))

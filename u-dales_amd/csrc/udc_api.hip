@@ -589,6 +589,7 @@ static int now_subgrid(udc_handle *h) {
   if (k_top_rows_after_closure(h)) return 1;
   if (k_momentum_lds(h, false, true, false, false, 0.)) return 1;
   if (k_scalar_top_flux(h)) return 1;      // reassure_fluxtop_boundary for a non-zero thl top flux (uses the new ekh)
+  if (k_xo_thl_top(h, false)) return 1;    // ... and for a zero one above the inlet's first column (BCxT = 2)
   for (int n : h->slots)
     if (k_scalar_diff(h, n)) return 1;
   if (h->p.sgs == UDC_SGS_ONEEQN && k_tke_sources(h)) return 1;
@@ -1247,6 +1248,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   h->last_inline_scalars = 0;
   for (int n : h->slots) h->last_inline_scalars += h->sv_inline[n] ? 1 : 0;
   if (k_scalar_top_flux(h)) return 1;
+  if (k_xo_thl_top(h, false)) return 1;
   // thl (slot 15) and qt (13) share velocities and diffusivity: one sweep for both where their schemes agree
   bool paired = false;
   if (lds && std::find(h->slots.begin(), h->slots.end(), 15) != h->slots.end() && std::find(h->slots.begin(), h->slots.end(), 13) != h->slots.end()) {
@@ -1258,6 +1260,7 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
     if (paired && (n == 15 || n == 13)) continue;
     if (k_scalar_fused(h, n, lds)) return 1;       // lds: the tendencies are scratch between fused substeps (tend_scratch)
   }
+  if (k_xo_thl_top(h, true)) return 1;              // (the sweep advected over the reassured row as well)
   if (h->p.sgs == UDC_SGS_ONEEQN) {
     if (k_tke_sources(h)) return 1;                // subgrid's `sources`, after the diffusion terms
     if ((ops & OP_BOTTOM) && k_tke_floor(h)) return 1;   // first lines of `bottom` (src/program.f90:152)

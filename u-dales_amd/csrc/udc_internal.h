@@ -284,7 +284,7 @@ struct udc_handle {
   bool xo_inlet_fresh = false;
   // the temperature on such a handle (&BC BCxT = 2: xTi_profile, xTo_convective; udc_set_open_x_thl): the inflow profile [nz+2] by k,
   // thl0 / thlm at ie+1 and at ib-1 as the last `boundary` left them ([2][pz][py] each)
-  double *xo_thl_prof = nullptr, *xo_thl_east = nullptr, *xo_thl_west = nullptr;
+  double *xo_thl_prof = nullptr, *xo_thl_east = nullptr, *xo_thl_west = nullptr, *xo_thl_top = nullptr;      // (top: k_xo_thl_top's row [py])
   // ... the total water likewise (&BC BCxq = 2: xqi_profile mirrors the ghost about the profile, xqo_convective; udc_set_open_x_qt)
   double *xo_qt_prof = nullptr, *xo_qt_east = nullptr, *xo_qt_west = nullptr;
   // BCxT / BCxq / BCxs = 3: the inlet's ghost columns from the planes of a precursor run (xTi_driver, xqi_driver, xsi_driver;
@@ -577,6 +577,7 @@ int k_checksim_end(udc_handle *h, double out[4]);
 // udc_xopen.hip: inflow / outflow in x
 int k_xo_ek_ghosts(udc_handle *h);                                  // closurebc's ekm(ib-1) = ekm(ib), ekm(ie+1) = ekm(ie)
 int k_xo_bcpup(udc_handle *h, double rk3coef, bool pup, bool ptotal = false);            // bcpup's BCxm_profile branch
+int k_xo_thl_top(udc_handle *h, bool fix);         // BCxT = 2: reassure_fluxtop_boundary's zero-flux row above the inlet's first column
 int k_xo_after_integrate(udc_handle *h, int rk3step, bool boundary_follows = false);               // v, w at ie+1 back from the outlet's planes (vm = v0 at stage 3)
 int k_xo_halos(udc_handle *h);                                      // xT_periodic / xq_periodic where those stay periodic beside the open flow
 int k_xo_boundary(udc_handle *h, int merged_stage3 = -1);                                   // xmi_profile, xmo_convective (+ bcp's pres0 columns)

@@ -192,6 +192,28 @@ __global__ void xo_thl_restore_kernel(Geo g, int stage3, double *__restrict__ t0
   t0[r] = w0; tm[r] = wm;
 }
 
+// BCxT = 2 and a zero-flux top (BCtopT = 1, wttop = 0): reassure_fluxtop_boundary (src/modboundary.f90:392-431, from closurebc) re-derives
+// thl(ke+1) = thl(ke) between advection and diffusion.  Everywhere that is the identity -- except in the first interior column, which
+// xTi_profile has set to the profile AFTER `boundary` formed the top row from what the integration had left there.  Nothing of this reaches
+// the state (the column is overwritten again), but statsdump samples thlm(ib, j, ke) as integrated (src/program.f90:199-214).
+// FIX = false: the row as closurebc leaves it, the value advection saw kept aside ([py]);
+// FIX = true (the fused sweep, which advects and diffuses in one pass over the reassured row): the top face's advective flux, the one
+// term that should have seen the row of `boundary` (advecc_2nd, src/modadvection.f90:146-150), corrected in the tendency
+template <bool FIX>
+__global__ void xo_thl_top_kernel(Geo g, Metrics m, double *__restrict__ t0, double *__restrict__ tm, double *__restrict__ keep,
+                                  const double *__restrict__ w0, double *__restrict__ tp) {
+  const int jj = blockIdx.x * blockDim.x + threadIdx.x;
+  if (jj >= g.py) return;
+  const long r = (long)g.sy * jj + g.sz * (long)(g.nz - 1 + HZ) + g.xg, gh = r + g.sz;      // (ib, j, ke) and the row above
+  if (!FIX) {
+    keep[jj] = t0[gh];
+    t0[gh] = t0[r]; tm[gh] = tm[r];
+  } else {
+    const int ke = g.nz;
+    tp[r] = tp[r] - (w0[gh] * ((keep[jj] - t0[gh]) * m.dzf[ke]) * m.dzhi[ke + 1]) * m.dzfi5[ke];
+  }
+}
+
 // the temperature and the total water where they stay periodic in x while the flow enters and leaves (&BC BCxT = 1 / BCxq = 1 next to
 // BCxm = 2 / 3: the reference's defaults, its tests/cases/525): `halos` refreshes their x ghosts right after every integration
 // (xT_periodic, xq_periodic, src/modboundary.f90:543-577, called under `ibrank .and. ierank`, :95-100) -- every row and level the arrays hold
@@ -304,7 +326,7 @@ void xo_destroy(udc_handle *h) {
   if (h->xo_inlet_now) { hipFree(h->xo_inlet_now); h->xo_inlet_now = nullptr; }
   if (h->xo_inlet_next) { hipFree(h->xo_inlet_next); h->xo_inlet_next = nullptr; }
   if (h->xo_prof) { hipFree(h->xo_prof); h->xo_prof = nullptr; }
-  for (double **q : {&h->xo_thl_prof, &h->xo_thl_east, &h->xo_thl_west, &h->xo_sv_prof, &h->xo_qt_prof, &h->xo_qt_east, &h->xo_qt_west})
+  for (double **q : {&h->xo_thl_top, &h->xo_thl_prof, &h->xo_thl_east, &h->xo_thl_west, &h->xo_sv_prof, &h->xo_qt_prof, &h->xo_qt_east, &h->xo_qt_west})
     if (*q) { hipFree(*q); *q = nullptr; }
   for (int t = 0; t < 15; ++t)
     for (double **q : {&h->xo_sc_in_now[t], &h->xo_sc_in_next[t]}) if (*q) { hipFree(*q); *q = nullptr; }
@@ -588,6 +610,23 @@ int k_xo_after_integrate(udc_handle *h, int rk3step, bool boundary_follows) {
     if (h->xo_sv_cols[n])
       hipLaunchKernelGGL(xo_sv_restore_kernel, plane_grid(g), dim3(64), 0, h->stream, g, rk3step == 3 ? 1 : 0, h->fields[UDC_SV0 + 3 * n],
                          h->fields[UDC_SVM + 3 * n], h->xo_sv_cols[n]);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// fix = false: before the temperature's diffusion (after closurebc); fix = true: after a sweep that advected over the reassured row too
+int k_xo_thl_top(udc_handle *h, bool fix) {
+  if (!h->xg || !h->xo_thl_prof || h->xo_sc_in_now[0] || h->slot[15].top != 0) return 0;      // (top = 1, 2: k_scalar_top_flux / a value)
+  if ((int)h->fields.size() <= UDC_THL0 || !h->fields[UDC_THL0]) return 0;
+  const Geo &g = h->g;
+  if (!h->xo_thl_top) HIP_OK(hipMalloc(&h->xo_thl_top, sizeof(double) * g.py));
+  const dim3 gr((unsigned)((g.py + 63) / 64)), b(64);
+  if (!fix)
+    hipLaunchKernelGGL(xo_thl_top_kernel<false>, gr, b, 0, h->stream, g, h->m, h->fields[UDC_THL0], h->fields[UDC_THLM], h->xo_thl_top,
+                       (const double *)nullptr, (double *)nullptr);
+  else
+    hipLaunchKernelGGL(xo_thl_top_kernel<true>, gr, b, 0, h->stream, g, h->m, h->fields[UDC_THL0], h->fields[UDC_THLM], h->xo_thl_top,
+                       (const double *)h->fields[UDC_W0], h->fields[UDC_THLP]);
   HIP_OK(hipGetLastError());
   return 0;
 }
