@@ -500,7 +500,8 @@ int udc_set_scalar_bcx_outflow(udc_handle *h, const double *wlev);
  * side; udc_set_open_x_scalars).  A temperature without an inflow profile and the total water stay periodic in x (&BC BCxT = 1, BCxq = 1, the
  * reference's defaults -- its tests/cases/525 runs BCxm = 3 with them): halos' xT_periodic / xq_periodic (src/modboundary.f90:543-577) refresh
  * their ghost columns after every integration, the moist thermodynamics' slab averages run over ib .. ie.  One rank; no one-equation closure
- * or device-side statistics yet (those entry points refuse the handle; udc_masscorr does nothing, as the reference's masscorr under linoutflow).  DESIGN.md sections 1 and 4 (udc_xopen.hip).
+ * yet (that entry point refuses the handle; udc_masscorr does nothing, as the reference's masscorr under linoutflow); the statistics
+ * (udc_stats_*) are offered.  DESIGN.md sections 1 and 4 (udc_xopen.hip).
  * udc_set_open_x_outflow: the outlet's speed uouttot (src/modboundary.f90:141-160) -- wlev NULL: the constant given (ubulk of a prescribed
  * flow); wlev[ktot] = dzf(k) / (zh(ke+1) - zh(kb+1)): sum_k wlev(k) u0av(k) of the state each substep starts from, `uouttot` being
  * the value in force until the first refresh (bcpup reads the previous `boundary`'s speed) -- and, with hold_first, through the whole
@@ -513,6 +514,13 @@ int udc_set_scalar_bcx_outflow(udc_handle *h, const double *wlev);
 int udc_set_boundary_rk3coef(udc_handle *h, double rk3coef);
 int udc_create_open_x(const udc_config *cfg, const double *uprof, const double *vprof, udc_handle **out);
 int udc_set_open_x_outflow(udc_handle *h, const double *wlev, double uouttot, int hold_first);
+/* One-shot: the next fused RK stage-3 udc_substep ends ahead of `boundary` -- interior as integrated, x ghost columns as the previous
+ * `boundary` left them -- which is the state the reference's checksim / fielddump / statsdump see (src/program.f90:199-214: they run between
+ * halos and boundary; xTi_profile, src/modboundary.f90:785-791, overwrites an interior column there).  udc_boundary (+ udc_thermodynamics)
+ * must follow; the next udc_substep runs an owed `boundary` first if none came.  With the device's own statistics on (udc_stats_enable)
+ * every stage-3 substep ends there and this call is not needed; it is for a caller that downloads the fields for host-side statistics.
+ * Does not run recorded substeps (udc_set_deferred): the one it is meant for may be among them. */
+int udc_set_open_x_sample_gap(udc_handle *h, int on);
 int udc_set_open_x_profile(udc_handle *h, const double *uprof, const double *vprof);      /* the inflow profiles again */
 /* &BC BCxm = 3 (BCxm_driver): the inlet from the planes of a precursor run instead of the profile.  The reference's moddriver (host:
  * reads the driver files, interpolates in time -- drivergen, src/moddriver.f90:174) stays what it is; after every drivergen the six

@@ -538,7 +538,8 @@ def test_cli_run_with_driver_inflow(name, iexp, tmp_path):
     (2, "udales_full_dropin", "run_xdriver_ibm_16x12x10", 98), (2, "udales_full_dropin", "run_xdriver_moist_16x12x10", 110),
     (2, "udales_full_dropin", "run_xopen_ibm_thl_16x12x10", 105), (2, "udales_full_dropin", "run_xopen_sv_16x8x12s", 103),
     (0, "udales_full_dropin", "run_xopen_ibm_thl_16x12x10", 105),
-    (2, "udales_full_dropin_hoststats", "run_xdriver_ibm_16x12x10", 98), (0, "udales_full_dropin_hoststats", "run_xdriver_ibm_16x12x10", 98)])
+    (2, "udales_full_dropin_hoststats", "run_xdriver_ibm_16x12x10", 98), (0, "udales_full_dropin_hoststats", "run_xdriver_ibm_16x12x10", 98),
+    (2, "udales_full_dropin_hoststats", "run_xopen_ibm_thl_16x12x10", 105)])
 def test_statistics_of_an_inflow_outflow_run(residency, prog_name, name, iexp, tmp_path):
     """Statistics of an inflow / outflow run (the class of examples/950: driver inflow, obstacles, wall functions, tdump + xytdump), every
     record handed to NetCDF against the all-reference program's.  udales_full_dropin: the device's own accumulators (udc_stats.hip) --
@@ -557,16 +558,20 @@ def test_statistics_of_an_inflow_outflow_run(residency, prog_name, name, iexp, t
     exe = os.path.join(BINDIR, prog_name)
     if not (os.path.exists(exe) and os.path.exists(FULL)):
         pytest.skip(f"oracle/_ref/udales_full or u-dales_amd/bin/{prog_name} not built")
-    out = {}
+    out, rst = {}, {}
     for tag, prog in (("ref", FULL), ("dev", exe)):
         d = tmp_path / tag
         d.mkdir()
         txt = open(os.path.join(GOLDEN, "cases", name, f"namoptions.{iexp:03d}")).read()
         txt = txt.replace("&SCALARS", "&OUTPUT\nltdump = .true.\nlxytdump = .true.\nlxydump = .true.\nlytdump = .true.\nlydump = .true.\ntstatsdump = 0.5\ntsample = 0.25\n/\n&SCALARS")
         assert "ltdump" in txt
-        run_full(name, iexp, d, exe=prog, env=dict(os.environ, UDC_RESIDENCY=str(residency)), deck_text=txt)
+        rst[tag] = run_full(name, iexp, d, exe=prog, env=dict(os.environ, UDC_RESIDENCY=str(residency)), deck_text=txt)[2]
         out[tag] = {fn: read_ncrec(str(d / fn)) for fn in sorted(os.listdir(d)) if fn.endswith(".nc") and "dump" in fn}
     assert set(out["ref"]) == set(out["dev"]) and len(out["ref"]) >= 2, (sorted(out["ref"]), sorted(out["dev"]))
+    # the restart file of the same run: the state AFTER the last `boundary` (the sample saw the one ahead of it), x ghost columns included
+    for k in ("u0", "v0", "w0", "pres0", "thl0", "qt0"):
+        if k in rst["ref"] and np.abs(rst["ref"][k]).max() > 0.:
+            assert relerr(nocorner(rst["dev"][k][1:-1]), nocorner(rst["ref"][k][1:-1]), 1.0 if k == "thl0" else None) <= RUN_TOL, k
     checked, bad = 0, []
     import re
     m = re.search(r"^\s*nsv\s*=\s*(\d+)", txt, re.M)

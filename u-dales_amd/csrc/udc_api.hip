@@ -1379,7 +1379,8 @@ static int substep_fused(udc_handle *h, int rk3step, double dt, unsigned ops) {
   std::vector<int> s;
   scalar_halo_list(h, rk3step, s);
   if (!s.empty() && !ov_scal && k_halo_y(h, s.data(), (int)s.size(), 2)) return 1;
-  if (h->xg && rk3step == 3 && (h->stats_on || h->xyt_on)) {
+  if (h->xg && rk3step == 3 && (h->stats_on || h->xyt_on || h->xo_sample_gap)) {
+    h->xo_sample_gap = false;
     // Open x boundaries with the device's statistics on: the reference samples them between tstep_integrate / halos and `boundary`
     // (src/program.f90:199-207), i.e. with the x ghost columns as the PREVIOUS `boundary` left them -- so stage 3 ends here, the ghost
     // columns put back; udc_boundary (the host's `boundary`, or the next substep's first act) and udc_thermodynamics follow the sample

@@ -294,6 +294,7 @@ struct udc_handle {
   // passive scalars there (&BC BCxs = 2: xsi_profile, xso_convective; udc_set_open_x_scalars; xg = 2): the inflow profiles [nsv][nz+2], and
   // per scalar the four ghost columns ib-2, ib-1, ie+1, ie+2 of sv0 and svm as the last `boundary` left them ([8][pz][py])
   double *xo_sv_prof = nullptr, *xo_sv_cols[13] = {nullptr};
+  bool xo_sample_gap = false;         // udc_set_open_x_sample_gap: the next fused stage-3 substep ends ahead of `boundary` (one-shot)
   bool xo_boundary_owed = false;      // a fused stage-3 substep ended before `boundary` (statistics on: they sample in between); the next substep
                                       // runs it first if no udc_boundary came
   bool xo_rhs_mirrored = false;       // the divergence kernel has written the right-hand side into the solver's doubled row itself

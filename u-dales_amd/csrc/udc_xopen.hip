@@ -558,6 +558,13 @@ extern "C" int udc_set_open_x_scalars(udc_handle *h, const double *svprof) {
   return 0;
 }
 
+extern "C" int udc_set_open_x_sample_gap(udc_handle *h, int on) {
+  if (!h) { udc_set_error("udc_set_open_x_sample_gap: null handle"); return 1; }
+  if (!h->xg) { udc_set_error("udc_set_open_x_sample_gap: not a handle of udc_create_open_x"); return 1; }
+  h->xo_sample_gap = on != 0;      // (no flush: the stage-3 substep it is meant for may be among the recorded ones)
+  return 0;
+}
+
 // the temperature's inflow profile thlprof [ktot+2] by the reference's k (entry ktot+1 as the reference's thlprof(ke+1): zero);
 // after udc_set_tempeq
 extern "C" int udc_set_open_x_thl(udc_handle *h, const double *thlprof) {

@@ -13,10 +13,12 @@ module modboundary
   implicit none
   save
   private
-  public :: driver_inlet
+  public :: driver_inlet, stage3_ahead
   public :: initboundary, boundary, grwdamp, ksp, tqaver, halos, bcp, bcpup, closurebc, &
             xm_periodic, xT_periodic, xq_periodic, xs_periodic, ym_periodic, yT_periodic, yq_periodic, ys_periodic
   integer :: ksp = -1                 !< lowest level of the sponge layer (&DOMAIN ksp; -1 = default)
+  logical :: due_now = .false.        !< stage3_ahead's answer for the `halos` of the same RK stage
+  logical :: pulled_ahead = .false.   !< inflow / outflow in x: halos refreshed the host arrays from a stage-3 substep that ended ahead of `boundary`
   real :: stat_clock = 0.             !< mirror of statsdump's sampling clock tsamplep (private to modstatsdump, src/modstatsdump.f90:65)
   real, allocatable :: tsc(:)         !< damping coefficients of grwdamp
   real :: rnu0 = 2.75e-3
@@ -53,10 +55,16 @@ contains
   end subroutine halos
 
   subroutine halos_timed
-    use modglobal, only: rk3step, timeleft, ntrun, timee, lfielddump, tnextfielddump
+    use modglobal, only: rk3step, timeleft, ntrun, timee, lfielddump, tnextfielddump, BCxm
     use udc_iface
-    logical :: due
+    logical :: due, ahead
     call udc_begin(.false.)
+    due = .false.
+    ahead = .false.
+    if (udc_mode() > 1 .and. rk3step == 3) then
+      due = due_now                                                 ! (stage3_ahead, called by tstep_integrate before the substep was launched)
+      ahead = BCxm /= 1 .and. (due .or. udc_stats_on_device)      ! this stage's substep has ended ahead of `boundary`
+    end if
     call udc_check(udc_halos(udc_h), 'udc_halos')
     if (udc_mode() <= 1) then
       call udc_pull_vel(.true.)
@@ -64,16 +72,30 @@ contains
       ! device mode: checksim, fielddump and statsdump come next (src/program.f90:199-205) and read the host arrays.  They are
       ! refreshed when the run ends, every UDC_PULL_EVERY steps, and -- so that the untouched statsdump samples the state it
       ! would sample in an all-host run -- on exactly the steps on which it takes a sample
-      due = .false.
-      if (.not. udc_stats_on_device) due = stats_sample_due()      ! (the drop-in statsdump samples on the device)
-      if (lfielddump .and. timee >= tnextfielddump) due = .true.      ! fielddump's own condition (src/modfielddump.f90:392-396)
       if (timeleft <= 0 .or. due) then
         call udc_pull_all
+        pulled_ahead = ahead
       else if (udc_pull_every > 0) then
-        if (mod(ntrun, udc_pull_every) == 0) call udc_pull_all
+        if (mod(ntrun, udc_pull_every) == 0) then
+          call udc_pull_all
+          pulled_ahead = ahead
+        end if
       end if
     end if
   end subroutine halos_timed
+
+  !> Device-resident runs, RK stage 3, before the fused substep is launched (the drop-in tstep_integrate calls this): are the host-side
+  !! dumps that follow `halos` due on this step?  With inflow / outflow in x the substep then ends ahead of its `boundary`, which overwrites
+  !! interior cells there (xTi_profile, src/modboundary.f90:785-791): checksim / fielddump / statsdump see the state ahead of it
+  !! (src/program.f90:199-214).
+  subroutine stage3_ahead
+    use modglobal, only: timee, lfielddump, tnextfielddump, BCxm
+    use udc_iface
+    due_now = .false.
+    if (.not. udc_stats_on_device) due_now = stats_sample_due()      ! (the drop-in statsdump samples on the device)
+    if (lfielddump .and. timee >= tnextfielddump) due_now = .true.      ! fielddump's own condition (src/modfielddump.f90:392-396)
+    if (due_now .and. BCxm /= 1) call udc_check(udc_set_open_x_sample_gap(udc_h, 1_c_int), 'udc_set_open_x_sample_gap')
+  end subroutine stage3_ahead
 
   !> statsdump's sampling clock (src/modstatsdump.f90:738-741, 797-805, 1394-1397), kept in step here because the module keeps
   !! its own private: true on the steps on which the statsdump call that follows `halos` takes a sample.  Called once per RK
@@ -103,6 +125,10 @@ contains
     if (BCxm == 3) call driver_inlet
     call udc_check(udc_boundary(udc_h), 'udc_boundary')
     if (udc_mode() <= 1) call udc_pull_vel(.true.)
+    if (pulled_ahead) then      ! the host arrays hold the state ahead of this `boundary` (the dumps' view): writerestartfiles wants the one after it
+      pulled_ahead = .false.
+      call udc_pull_all
+    end if
   end subroutine boundary
 
   !> BCxm = 3 (src/modboundary.f90:260-266): where the reference's `boundary` calls drivergen -- RK stage 3 and the start-up -- the

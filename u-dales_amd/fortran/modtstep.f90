@@ -89,7 +89,7 @@ contains
     use modsubgriddata, only: loneeqn
     use modmpi, only: myid, cmyid
     use modibm, only: ibm_facet_output
-    use modboundary, only: driver_inlet
+    use modboundary, only: driver_inlet, stage3_ahead
     use modglobal, only: BCxm
     use udc_iface
     implicit none
@@ -97,6 +97,7 @@ contains
     call udc_begin(.true.)
     ! BCxm = 3, device-resident: the substep launched below ends with the `boundary` that applies the precursor's planes of the new time
     if (BCxm == 3 .and. udc_mode() == 2) call driver_inlet
+    if (rk3step == 3 .and. udc_mode() == 2) call stage3_ahead
     ! (device mode: this launches the recorded routines of the substep, fused)
     call udc_check(udc_tstep_integrate(udc_h, int(rk3step, c_int), real(dt, c_double)), 'udc_tstep_integrate')
     call ibm_facet_output      ! lwritefac: fac.NNN.nc's record, which the reference's ibmwallfun writes (the substep has run only now)

@@ -510,6 +510,11 @@ module udc_iface
       type(c_ptr), value :: h
       real(c_double), intent(in) :: uprof(*), vprof(*)
     end function
+    integer(c_int) function udc_set_open_x_sample_gap(h, on) bind(C, name='udc_set_open_x_sample_gap')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
+      integer(c_int), value :: on
+    end function udc_set_open_x_sample_gap
     integer(c_int) function udc_set_open_x_outflow(h, wlev, uouttot, hold_first) bind(C, name='udc_set_open_x_outflow')
       import :: c_int, c_ptr, c_double
       type(c_ptr), value :: h
