@@ -749,3 +749,36 @@ def test_runner_statistics_of_an_inflow_outflow_run(tmp_path):
             assert y[var][q].shape == a.shape and np.abs(y[var][q] - a).max() <= 1e-8 * sc, (var, q)
             checked += 1
     assert checked >= 28 * nrec, checked
+
+
+def test_sample_gap_is_the_state_ahead_of_boundary():
+    """udc_set_open_x_sample_gap: the fused stage-3 substep that ends ahead of `boundary`, followed by udc_boundary, leaves what the substep
+    with its `boundary` inside leaves -- and ahead of it the inlet's first thl column is NOT yet the profile while the interior of u equals
+    the final one; one-shot: the substeps after it are whole again."""
+    name, iexp = "run_xopen_thl_16x8x12s", 101
+    out = {}
+    for gap in (False, True):
+        d, core = make_core(name, iexp)
+        g = core.g
+        dt = float(d.get("RUN", "dtmax"))
+        from udcore import cold_start
+        core.load_state(cold_start(g, d, nsv=0, pre_boundary=True))
+        core.halos(); core.start_up(dtmax=dt)
+        for step in range(2):
+            for rk in (1, 2, 3):
+                if gap and rk == 3 and step == 0:
+                    core.set_open_x_sample_gap()
+                core.substep(rk, dt)
+                if gap and rk == 3 and step == 0:
+                    ahead = {k: core.download(k) for k in ("u0", "thl0")}
+                    core.boundary()
+                    out["after"] = {k: core.download(k) for k in ("u0", "thl0")}
+        out[gap] = {k: core.download(k) for k in ("u0", "v0", "w0", "thl0", "pres0")}
+        core.close()
+    for k in out[True]:
+        assert np.array_equal(out[True][k], out[False][k]), k
+    nz = out[True]["u0"].shape[0] - 2
+    prof = np.asarray(d.thl, dtype=float)[:nz]
+    assert np.array_equal(out["after"]["thl0"][1:nz + 1, 1:-1, 1], np.broadcast_to(prof[:, None], out["after"]["thl0"][1:nz + 1, 1:-1, 1].shape))
+    assert np.abs(ahead["thl0"][1:nz + 1, 1:-1, 1] - prof[:, None]).max() > 1e-9      # (the integration's value, not the profile)
+    assert np.array_equal(ahead["u0"][1:nz + 1, 1:-1, 2:-2], out["after"]["u0"][1:nz + 1, 1:-1, 2:-2])

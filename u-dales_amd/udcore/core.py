@@ -265,6 +265,11 @@ class DynCore:
                                                      1 if hold_first else 0),
                  "udc_set_open_x_outflow")
 
+    def set_open_x_sample_gap(self, on=True):
+        """One-shot: the next fused stage-3 substep ends ahead of `boundary` (the state the reference's dumps see, src/program.f90:199-214);
+        boundary() (+ thermodynamics()) must follow the download."""
+        L._check(self.lib.udc_set_open_x_sample_gap(self.h, 1 if on else 0), "udc_set_open_x_sample_gap")
+
     def set_scalar_bcx_outflow(self, wlev):
         w = np.ascontiguousarray(wlev, dtype=np.float64)
         L._check(self.lib.udc_set_scalar_bcx_outflow(self.h, w.ctypes.data_as(L.DP)), "udc_set_scalar_bcx_outflow")

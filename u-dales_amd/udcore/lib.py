@@ -31,7 +31,7 @@ EXPORTS = ["udc_create", "udc_destroy", "udc_last_error", "udc_version", "udc_co
            "udc_advection", "udc_subgrid", "udc_bottom", "udc_forces", "udc_slab_average", "udc_slab_averages", "udc_set_level_forcing", "udc_level_forcings", "udc_set_coriolis", "udc_coriolis", "udc_set_masscorr", "udc_set_masscorr_outflow", "udc_masscorr", "udc_set_tempeq", "udc_set_thl_source", "udc_set_floor_wf", "udc_set_fkar", "udc_set_chem", "udc_set_shifted_pbc", "udc_shifted_pbcs", "udc_set_scalar_top", "udc_set_scalar_source", "udc_scalsource", "udc_set_moisture", "udc_set_moist_thermo", "udc_thermodynamics", "udc_calthv", "udc_thermo_state", "udc_set_buoyancy", "udc_set_buoycorr", "udc_set_tke", "udc_poisson", "udc_tstep_integrate",
            "udc_halos", "udc_boundary", "udc_tstep_maxima", "udc_substep", "udc_run",
            "udc_set_deferred", "udc_flush", "udc_deferred_stats",
-           "udc_stats_enable", "udc_stats_sample", "udc_stats_get", "udc_stats_set_masks", "udc_stats_xyt", "udc_stats_set_forced", "udc_stats_yt", "udc_stats_xy", "udc_stats_y", "udc_set_floor_air_temperature", "udc_set_ibm_wallfun", "udc_set_ibm_sections", "udc_set_ibm_wallheat", "udc_set_ibm_wallmoist", "udc_set_poisson_bczp", "udc_set_ibm_facet_output", "udc_ibm_facet_sample", "udc_ibm_facet_get", "udc_set_scalar_bcx", "udc_set_scalar_bcx_outflow", "udc_create_open_x", "udc_set_open_x_outflow", "udc_set_boundary_rk3coef", "udc_set_open_x_profile", "udc_set_open_x_inlet", "udc_set_open_x_thl", "udc_set_open_x_qt", "udc_set_open_x_inlet_scalar", "udc_set_open_x_scalars", "udc_set_ibm_points", "udc_ibm_commit", "udc_ibmwallfun", "udc_ibmnorm",
+           "udc_stats_enable", "udc_stats_sample", "udc_stats_get", "udc_stats_set_masks", "udc_stats_xyt", "udc_stats_set_forced", "udc_stats_yt", "udc_stats_xy", "udc_stats_y", "udc_set_floor_air_temperature", "udc_set_ibm_wallfun", "udc_set_ibm_sections", "udc_set_ibm_wallheat", "udc_set_ibm_wallmoist", "udc_set_poisson_bczp", "udc_set_ibm_facet_output", "udc_ibm_facet_sample", "udc_ibm_facet_get", "udc_set_scalar_bcx", "udc_set_scalar_bcx_outflow", "udc_create_open_x", "udc_set_open_x_outflow", "udc_set_open_x_sample_gap", "udc_set_boundary_rk3coef", "udc_set_open_x_profile", "udc_set_open_x_inlet", "udc_set_open_x_thl", "udc_set_open_x_qt", "udc_set_open_x_inlet_scalar", "udc_set_open_x_scalars", "udc_set_ibm_points", "udc_ibm_commit", "udc_ibmwallfun", "udc_ibmnorm",
            "udc_divergence", "udc_checksim", "udc_checksim_begin", "udc_checksim_end", "udc_sync", "udc_profile_enable", "udc_profile_reset",
            "udc_profile_get", "udc_profile_focus", "udc_profile_every", "udc_set_ibm_mask_wrap", "udc_bottom_diagnostics", "udc_bottom_diag_get", "udc_set_ibm_conservative"]
 
